@@ -1,0 +1,69 @@
+"""Seeded synthetic inputs for the RAM-permutation hot path.
+
+The reference gets its memory trace from the out-of-circuit VM (zk_evm, absent); the benches and parity
+tests need traces of the same shape without it. `ram_trace` produces a *valid* trace: the first touch
+of a cell is a write, later accesses are reads of the current value (70 %) or writes, timestamps are
+strictly increasing in queue order, values are uniform 256-bit, 5 % of written values are fat pointers.
+RNG: splitmix64 so that every consumer (numpy here, C in the oracle bench) can regenerate the inputs.
+"""
+import numpy as np
+
+MEM_QUERY = np.dtype(
+    [("timestamp", "<u4"), ("page", "<u4"), ("index", "<u4"), ("rw_flag", "u1"), ("value_is_pointer", "u1"),
+     ("_pad", "u1", (2,)), ("value", "<u4", (8,))], align=False)
+assert MEM_QUERY.itemsize == 48
+
+
+def splitmix64(seed: int, n: int) -> np.ndarray:
+    """n outputs of splitmix64 started at `seed` (vectorised: state_i = seed + (i+1)*gamma)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def ram_trace(n: int, seed: int = 1, pages: int = 64, indices: int = 256, first_page: int = 8,
+              read_fraction: float = 0.7, ptr_fraction: float = 0.05, ts_start: int = 1) -> np.ndarray:
+    """Valid memory trace of n queries in queue (timestamp) order."""
+    r = splitmix64(seed, 12 * n).reshape(12, n)
+    page = (r[0] % np.uint64(pages)).astype(np.uint32) + np.uint32(first_page)
+    index = (r[1] % np.uint64(indices)).astype(np.uint32)
+    want_read = (r[2] >> np.uint64(11)).astype(np.float64) / float(1 << 53) < read_fraction
+    is_ptr = (r[3] >> np.uint64(11)).astype(np.float64) / float(1 << 53) < ptr_fraction
+    rand_val = np.empty((n, 8), np.uint32)
+    for k in range(4):
+        rand_val[:, 2 * k] = (r[4 + k] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        rand_val[:, 2 * k + 1] = (r[4 + k] >> np.uint64(32)).astype(np.uint32)
+
+    cell = page.astype(np.uint64) << np.uint64(32) | index.astype(np.uint64)
+    order = np.argsort(cell, kind="stable")  # (cell, time) order
+    sc = cell[order]
+    first_touch = np.ones(n, bool)
+    first_touch[1:] = sc[1:] != sc[:-1]
+    is_write_sorted = first_touch | ~want_read[order]
+    # index (in sorted order) of the latest write at or before each position, within the cell
+    pos = np.where(is_write_sorted, np.arange(n), -1)
+    last_write = np.maximum.accumulate(pos)
+    src = order[last_write]  # original index of the write whose value is current
+    value = np.empty((n, 8), np.uint32)
+    value[order] = rand_val[src]
+    ptr = np.empty(n, bool)
+    ptr[order] = is_ptr[src]
+    rw = np.empty(n, bool)
+    rw[order] = is_write_sorted
+
+    q = np.zeros(n, MEM_QUERY)
+    q["timestamp"] = np.arange(ts_start, ts_start + n, dtype=np.uint32)
+    q["page"] = page
+    q["index"] = index
+    q["rw_flag"] = rw
+    q["value_is_pointer"] = ptr
+    q["value"] = value
+    return q
+
+
+def random_field_elements(seed: int, shape) -> np.ndarray:
+    """Uniform canonical Goldilocks elements (rejection-free: r mod p, bias 2^-32)."""
+    n = int(np.prod(shape))
+    return (splitmix64(seed, n) % np.uint64(0xFFFFFFFF00000001)).reshape(shape)

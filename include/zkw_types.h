@@ -1,0 +1,91 @@
+/* zkw_types.h — plain-data records that cross the C ABI of libzkw (MI355X witness/synthesis engine).
+ *
+ * Every record mirrors a Rust type of the reference (paths relative to the reference root):
+ *   zkw_mem_query      <- zk_evm::aux_structures::MemoryQuery as consumed by
+ *                         circuit_encodings/src/memory_query.rs:24-118 (`encoding_witness`)
+ *                         and reflected at memory_query.rs:131-144 (`reflect`).
+ *   zkw_queue_state12  <- QueueStateWitness<F, FULL_SPONGE_QUEUE_STATE_WIDTH = 12>
+ *                         built by src/witness/utils.rs:73-85 (`transform_sponge_like_queue_state`).
+ *   zkw_ram_fsm        <- RamPermutationFSMInputOutputWitness, fields as filled at
+ *                         src/witness/individual_circuits/ram_permutation.rs:385-406.
+ *   zkw_ram_instance   <- RamPermutationCircuitInstanceWitness / ClosedFormInputWitness,
+ *                         ram_permutation.rs:372-412.
+ *
+ * All field elements are Goldilocks (p = 2^64 - 2^32 + 1) stored as canonical (< p) little-endian
+ * uint64_t. No pointers inside records; bulk arrays are passed next to them.
+ */
+#ifndef ZKW_TYPES_H
+#define ZKW_TYPES_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKW_GOLDILOCKS_P 0xFFFFFFFF00000001ULL
+
+#define ZKW_MEMORY_QUERY_PACKED_WIDTH 8   /* memory_query.rs:116 */
+#define ZKW_LOG_QUERY_PACKED_WIDTH 20     /* log_query.rs:391-394 */
+#define ZKW_DECOMMIT_QUERY_PACKED_WIDTH 8 /* decommittment_request.rs:72 */
+#define ZKW_FULL_SPONGE_QUEUE_STATE_WIDTH 12
+#define ZKW_QUEUE_STATE_WIDTH 4
+#define ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS 2 /* ram_permutation.rs:85 */
+#define ZKW_RAM_SORTING_KEY_LENGTH 3               /* memory_query.rs:6-14 */
+#define ZKW_RAM_FULL_KEY_LENGTH 2                  /* memory_query.rs:16-20 */
+/* zkevm_opcode_defs::BOOTLOADER_HEAP_PAGE (used at ram_permutation.rs:315). The crate is absent from
+   the reference tree; value = heap_page_from_base(BOOTLOADER_BASE_PAGE = 8) = base + 2 in
+   zkevm_opcode_defs v1.4.1 (inferred, see DESIGN.md "inferred constants"). */
+#define ZKW_BOOTLOADER_HEAP_PAGE 10u
+
+/* One memory access. 48 bytes, 16-byte aligned so a lane moves it as three 128-bit words. */
+typedef struct zkw_mem_query {
+    uint32_t timestamp;        /* query.timestamp.0 */
+    uint32_t page;             /* query.location.page.0 */
+    uint32_t index;            /* query.location.index.0 */
+    uint8_t rw_flag;           /* 1 = write */
+    uint8_t value_is_pointer;  /* 1 = fat pointer */
+    uint8_t _pad[2];
+    uint32_t value[8];         /* U256 as 8 little-endian u32 limbs (decompose_u256_as_u32x8) */
+} zkw_mem_query;
+
+typedef struct zkw_queue_state12 {
+    uint64_t head[12];
+    uint64_t tail[12];
+    uint32_t length;
+    uint32_t _pad;
+} zkw_queue_state12;
+
+typedef struct zkw_ram_fsm {
+    uint64_t lhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];
+    uint64_t rhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];
+    zkw_queue_state12 current_unsorted_queue_state;
+    zkw_queue_state12 current_sorted_queue_state;
+    uint32_t previous_sorting_key[ZKW_RAM_SORTING_KEY_LENGTH]; /* [timestamp, index, page] */
+    uint32_t previous_full_key[ZKW_RAM_FULL_KEY_LENGTH];       /* [index, page] */
+    uint32_t previous_value[8];
+    uint32_t previous_is_ptr;
+    uint32_t num_nondeterministic_writes;
+    uint32_t _pad;
+} zkw_ram_fsm;
+
+typedef struct zkw_ram_instance {
+    uint32_t start_flag;
+    uint32_t completion_flag;
+    /* observable_input (RamPermutationInputDataWitness) */
+    zkw_queue_state12 unsorted_queue_initial_state;
+    zkw_queue_state12 sorted_queue_initial_state;
+    uint32_t non_deterministic_bootloader_memory_snapshot_length;
+    uint32_t _pad;
+    zkw_ram_fsm hidden_fsm_input;
+    zkw_ram_fsm hidden_fsm_output;
+    /* the instance's slice of the two queue witnesses: items [first_item, first_item+num_items) of
+       the block-wide unsorted / sorted arrays (queries, encodings, tails) */
+    uint64_t first_item;
+    uint64_t num_items;
+} zkw_ram_instance;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKW_TYPES_H */

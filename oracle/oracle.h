@@ -1,0 +1,85 @@
+/* oracle.h — TEST INFRASTRUCTURE. CPU restatement (plain C11, gcc) of the reference's hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product (libzkw / csrc) never includes, links or calls it.
+ *
+ * Parity status (see DESIGN.md "Oracle"): the reference is Rust and cannot be built here; the field,
+ * Poseidon2 and sponge helpers live in the absent crate era-boojum. Each function below cites the
+ * reference file:line it follows. Pinned against reference fixtures: SHA-256/Keccak/Blake2s (public
+ * KATs) and the round-constant table (Poseidon-Goldilocks KAT). The Poseidon2 permutation's linear
+ * layers are "parity unpinned" (no fixture in the reference reaches them; the Merkle-path KAT
+ * harvested from test_proofs/ is kept as tests/golden/merkle_kat_*.json and reported by
+ * tests/test_reference_fixtures.py).
+ */
+#ifndef ZKW_ORACLE_H
+#define ZKW_ORACLE_H
+#include "../include/zkw_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Goldilocks field (boojum GoldilocksField; call sites circuit_encodings/src/lib.rs:664-713) */
+uint64_t orc_gl_add(uint64_t a, uint64_t b);
+uint64_t orc_gl_sub(uint64_t a, uint64_t b);
+uint64_t orc_gl_mul(uint64_t a, uint64_t b);
+uint64_t orc_gl_pow(uint64_t a, uint64_t e);
+uint64_t orc_gl_inv(uint64_t a);
+
+/* ---- Poseidon2Goldilocks as AlgebraicRoundFunction<F, 8, 12, 4> (lib.rs:12-15) */
+void orc_poseidon2_permutation(uint64_t state[12]);
+/* Poseidon (original, Plonky2-compatible) — used only to pin the shared round-constant table */
+void orc_poseidon1_permutation(uint64_t state[12]);
+/* absorb_multiple_rounds::<AbsorptionModeOverwrite> (call sites lib.rs:198-203, 405-409):
+   for each 8-chunk: state[0..8] = chunk; permutation; record the state. `states_out` may be NULL. */
+void orc_absorb_multiple_rounds(uint64_t state[12], const uint64_t *to_absorb, size_t n_rounds,
+                                uint64_t *states_out /* n_rounds*12 */);
+/* Merkle helpers matching GoldilocksPoseidon2Sponge<AbsorptionModeOverwrite> as TreeHasher
+   (src/prover_utils.rs:43) — used by the reference-fixture KAT only. */
+void orc_poseidon2_hash_node(const uint64_t left[4], const uint64_t right[4], uint64_t out[4]);
+void orc_poseidon2_hash_leaf(const uint64_t *elems, size_t n, uint64_t out[4]);
+
+/* ---- encodings */
+/* circuit_encodings/src/memory_query.rs:24-118 */
+void orc_encode_memory_query(const zkw_mem_query *q, uint64_t out[8]);
+void orc_encode_memory_queries(const zkw_mem_query *q, size_t n, uint64_t *out /* n*8 */);
+
+/* ---- queue simulators */
+/* FullWidthQueueSimulator::push_and_output_intermediate_data, lib.rs:391-429: tails[i] = state after
+   absorbing enc[i] (rate 8, overwrite) into tails[i-1] (tail_in for i = 0). */
+void orc_queue_push_chain_full(const uint64_t *enc /* n*8 */, size_t n, const uint64_t tail_in[12],
+                               uint64_t *tails /* n*12 */);
+/* QueueSimulator::push_and_output_intermediate_data, lib.rs:179-221: new_tail = first 4 words of the
+   3-round sponge over enc(20) || old_tail(4) from the zero state. old_tails[i] is what the reference
+   stores in `witness` (lib.rs:204). */
+void orc_queue_push_chain_log(const uint64_t *enc /* n*20 */, size_t n, const uint64_t tail_in[4],
+                              uint64_t *old_tails /* n*4, may be NULL */, uint64_t *new_tails /* n*4 */);
+
+/* ---- Fiat-Shamir challenges, src/witness/utils.rs:498-550.
+   state_w = N (12 for RAM/decommit sorter, 4 for storage/events); out = 2 repetitions x n_chal. */
+void orc_fs_challenges(const uint64_t *tail_u, uint32_t len_u, const uint64_t *tail_s, uint32_t len_s,
+                       int state_w, int n_chal, uint64_t *out /* 2*n_chal */);
+
+/* ---- grand product chains, src/witness/utils.rs:554-697 (chunked by 2^16 exactly like the rayon
+   version, then folded). Returns 0, or -1 if the final lhs and rhs products differ (utils.rs:685-696). */
+int orc_grand_product_chains(const uint64_t *lhs, const uint64_t *rhs, size_t n, int width,
+                             const uint64_t *challenges /* width+1 */, uint64_t *lhs_z, uint64_t *rhs_z);
+/* multi-threaded variant (pthreads; mirrors rayon par_chunks) used by bench.py's cpu_baseline */
+int orc_grand_product_chains_mt(const uint64_t *lhs, const uint64_t *rhs, size_t n, int width,
+                                const uint64_t *challenges, uint64_t *lhs_z, uint64_t *rhs_z, int threads);
+
+/* ---- RAM permutation builder, src/witness/individual_circuits/ram_permutation.rs:26-470.
+   Inputs: the block's memory queries in queue order. Outputs (caller-allocated):
+     sorted_q[n], unsorted_enc[n*8], sorted_enc[n*8], unsorted_tails[n*12], sorted_tails[n*12],
+     challenges[2*9], lhs_z[2*n], rhs_z[2*n] (repetition-major), instances[ceil(n/capacity)].
+   Returns the number of instances, or <0 on a failed self-check. */
+int64_t orc_ram_build_instances(const zkw_mem_query *q, size_t n, uint32_t capacity,
+                                uint32_t num_non_deterministic_heap_queries, zkw_mem_query *sorted_q,
+                                uint64_t *unsorted_enc, uint64_t *sorted_enc, uint64_t *unsorted_tails,
+                                uint64_t *sorted_tails, uint64_t *challenges, uint64_t *lhs_z,
+                                uint64_t *rhs_z, zkw_ram_instance *instances);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

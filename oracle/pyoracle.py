@@ -1,0 +1,181 @@
+"""pyoracle — TEST INFRASTRUCTURE. ctypes/numpy front-end of oracle/liboracle.so (the CPU restatement
+of the reference hot path, see oracle/oracle.h). Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+P = 0xFFFFFFFF00000001
+
+# numpy mirrors of include/zkw_types.h
+MEM_QUERY = np.dtype(
+    [("timestamp", "<u4"), ("page", "<u4"), ("index", "<u4"), ("rw_flag", "u1"), ("value_is_pointer", "u1"),
+     ("_pad", "u1", (2,)), ("value", "<u4", (8,))], align=False)
+assert MEM_QUERY.itemsize == 48
+QUEUE_STATE12 = np.dtype([("head", "<u8", (12,)), ("tail", "<u8", (12,)), ("length", "<u4"), ("_pad", "<u4")])
+assert QUEUE_STATE12.itemsize == 200
+RAM_FSM = np.dtype(
+    [("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)),
+     ("current_unsorted_queue_state", QUEUE_STATE12), ("current_sorted_queue_state", QUEUE_STATE12),
+     ("previous_sorting_key", "<u4", (3,)), ("previous_full_key", "<u4", (2,)), ("previous_value", "<u4", (8,)),
+     ("previous_is_ptr", "<u4"), ("num_nondeterministic_writes", "<u4"), ("_pad", "<u4")])
+assert RAM_FSM.itemsize == 32 + 400 + 64
+RAM_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("unsorted_queue_initial_state", QUEUE_STATE12),
+     ("sorted_queue_initial_state", QUEUE_STATE12),
+     ("non_deterministic_bootloader_memory_snapshot_length", "<u4"), ("_pad", "<u4"),
+     ("hidden_fsm_input", RAM_FSM), ("hidden_fsm_output", RAM_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
+assert RAM_INSTANCE.itemsize == 8 + 400 + 8 + 2 * 496 + 16
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (building the checker is not using it)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in os.listdir(_HERE) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        u64, u64p, sz, vp = C.c_uint64, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p
+        for name in ("orc_gl_add", "orc_gl_sub", "orc_gl_mul", "orc_gl_pow"):
+            getattr(_lib, name).restype = u64
+            getattr(_lib, name).argtypes = [u64, u64]
+        _lib.orc_gl_inv.restype = u64
+        _lib.orc_gl_inv.argtypes = [u64]
+        _lib.orc_ram_build_instances.restype = C.c_int64
+        _lib.orc_grand_product_chains.restype = C.c_int
+        _lib.orc_grand_product_chains_mt.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def poseidon2(state):
+    s = _u64(state).copy()
+    assert s.shape == (12,)
+    lib().orc_poseidon2_permutation(_p(s))
+    return s
+
+
+def poseidon1(state):
+    s = _u64(state).copy()
+    lib().orc_poseidon1_permutation(_p(s))
+    return s
+
+
+def hash_node(left, right):
+    out = np.zeros(4, np.uint64)
+    lib().orc_poseidon2_hash_node(_p(_u64(left)), _p(_u64(right)), _p(out))
+    return out
+
+
+def hash_leaf(elems):
+    e = _u64(elems)
+    out = np.zeros(4, np.uint64)
+    lib().orc_poseidon2_hash_leaf(_p(e), C.c_size_t(e.size), _p(out))
+    return out
+
+
+def encode_memory_queries(q):
+    q = np.ascontiguousarray(q, dtype=MEM_QUERY)
+    out = np.zeros((q.size, 8), np.uint64)
+    lib().orc_encode_memory_queries(_p(q), C.c_size_t(q.size), _p(out))
+    return out
+
+
+def queue_push_chain_full(enc, tail_in=None):
+    enc = _u64(enc)
+    n = enc.shape[0]
+    tail_in = np.zeros(12, np.uint64) if tail_in is None else _u64(tail_in)
+    tails = np.zeros((n, 12), np.uint64)
+    lib().orc_queue_push_chain_full(_p(enc), C.c_size_t(n), _p(tail_in), _p(tails))
+    return tails
+
+
+def queue_push_chain_log(enc, tail_in=None):
+    enc = _u64(enc)
+    n = enc.shape[0]
+    tail_in = np.zeros(4, np.uint64) if tail_in is None else _u64(tail_in)
+    old_t = np.zeros((n, 4), np.uint64)
+    new_t = np.zeros((n, 4), np.uint64)
+    lib().orc_queue_push_chain_log(_p(enc), C.c_size_t(n), _p(tail_in), _p(old_t), _p(new_t))
+    return old_t, new_t
+
+
+def fs_challenges(tail_u, len_u, tail_s, len_s, state_w, n_chal):
+    out = np.zeros((2, n_chal), np.uint64)
+    lib().orc_fs_challenges(_p(_u64(tail_u)), C.c_uint32(len_u), _p(_u64(tail_s)), C.c_uint32(len_s),
+                            C.c_int(state_w), C.c_int(n_chal), _p(out))
+    return out
+
+
+def grand_product_chains(lhs, rhs, challenges, threads=1):
+    lhs, rhs, ch = _u64(lhs), _u64(rhs), _u64(challenges)
+    n, w = lhs.shape
+    assert rhs.shape == (n, w) and ch.shape == (w + 1,)
+    lz, rz = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    if threads == 1:
+        rc = lib().orc_grand_product_chains(_p(lhs), _p(rhs), C.c_size_t(n), C.c_int(w), _p(ch), _p(lz), _p(rz))
+    else:
+        rc = lib().orc_grand_product_chains_mt(_p(lhs), _p(rhs), C.c_size_t(n), C.c_int(w), _p(ch), _p(lz),
+                                               _p(rz), C.c_int(threads))
+    return rc, lz, rz
+
+
+def ram_build_instances(q, capacity, num_nondet=0):
+    q = np.ascontiguousarray(q, dtype=MEM_QUERY)
+    n = q.size
+    n_inst = (n + capacity - 1) // capacity
+    out = dict(
+        sorted_q=np.zeros(n, MEM_QUERY), unsorted_enc=np.zeros((n, 8), np.uint64),
+        sorted_enc=np.zeros((n, 8), np.uint64), unsorted_tails=np.zeros((n, 12), np.uint64),
+        sorted_tails=np.zeros((n, 12), np.uint64), challenges=np.zeros((2, 9), np.uint64),
+        lhs_z=np.zeros((2, n), np.uint64), rhs_z=np.zeros((2, n), np.uint64),
+        instances=np.zeros(n_inst, RAM_INSTANCE))
+    rc = lib().orc_ram_build_instances(
+        _p(q), C.c_size_t(n), C.c_uint32(capacity), C.c_uint32(num_nondet), _p(out["sorted_q"]),
+        _p(out["unsorted_enc"]), _p(out["sorted_enc"]), _p(out["unsorted_tails"]), _p(out["sorted_tails"]),
+        _p(out["challenges"]), _p(out["lhs_z"]), _p(out["rhs_z"]), _p(out["instances"]))
+    if rc < 0:
+        raise RuntimeError(f"orc_ram_build_instances failed: {rc}")
+    assert rc == n_inst
+    return out
+
+
+def sha256(msg: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().orc_sha256(msg, C.c_size_t(len(msg)), out)
+    return out.raw
+
+
+def keccak256(msg: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().orc_keccak256(msg, C.c_size_t(len(msg)), out)
+    return out.raw
+
+
+def blake2s256(msg: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().orc_blake2s256(msg, C.c_size_t(len(msg)), out)
+    return out.raw
