@@ -1,0 +1,119 @@
+// gl64.cuh — Goldilocks field p = 2^64 - 2^32 + 1 for gfx950 (and the host side of libzkw).
+//
+// Replaces boojum's GoldilocksField as used by the reference at circuit_encodings/src/lib.rs:664-713,
+// src/witness/utils.rs:511,578-590 (add_assign / mul_assign / from_u64_with_reduction).
+//
+// Representation: a u64 that is congruent to the element but NOT necessarily canonical ("weak" form,
+// any value in [0, 2^64)). Every operation accepts weak inputs and returns a weak output; `canon()`
+// maps to the unique representative < p and is applied once, at the point where a value is stored to
+// a buffer that crosses the C ABI (the reference compares canonical values).
+//
+// Reduction identity: 2^64 = 2^32 - 1 (=: EPS) and 2^96 = -1 (mod p).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gl {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+constexpr u64 P = 0xFFFFFFFF00000001ULL;
+constexpr u64 EPS = 0xFFFFFFFFULL;
+
+#define GL_HD __host__ __device__ __forceinline__
+
+GL_HD u64 canon(u64 x) { return x >= P ? x - P : x; }
+
+// a + b (mod p), weak in / weak out. The second fix-up only triggers for non-canonical operands.
+GL_HD u64 add(u64 a, u64 b) {
+    u64 s = a + b;
+    u64 c = s < a ? EPS : 0;
+    u64 t = s + c;
+    u64 c2 = t < s ? EPS : 0;
+    return t + c2;
+}
+
+// a - b (mod p)
+GL_HD u64 sub(u64 a, u64 b) {
+    u64 d = a - b;
+    u64 br = a < b ? EPS : 0;
+    u64 t = d - br;
+    u64 br2 = t > d ? EPS : 0;
+    return t - br2;
+}
+
+GL_HD u64 neg(u64 a) { return sub(0, a); }
+
+// (hi * 2^64 + lo) mod p
+GL_HD u64 reduce128(u64 lo, u64 hi) {
+    u64 hh = hi >> 32, hl = hi & EPS;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= EPS;  // wrapped by 2^64 = EPS: take it back out
+    u64 t1 = hl * EPS;       // (hl << 32) - hl, < 2^64
+    u64 r = t0 + t1;
+    if (r < t1) r += EPS;    // cannot overflow a second time
+    return r;
+}
+
+GL_HD u64 mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 lo = a * b;
+    u64 hi = __umul64hi(a, b);
+#else
+    unsigned __int128 w = (unsigned __int128)a * b;
+    u64 lo = (u64)w, hi = (u64)(w >> 64);
+#endif
+    return reduce128(lo, hi);
+}
+
+GL_HD u64 sqr(u64 a) { return mul(a, a); }
+
+// a*b + c
+GL_HD u64 mul_add(u64 a, u64 b, u64 c) { return add(mul(a, b), c); }
+
+// x^7 (the Poseidon2 S-box over Goldilocks)
+GL_HD u64 pow7(u64 x) {
+    u64 x2 = sqr(x);
+    u64 x3 = mul(x2, x);
+    u64 x4 = sqr(x2);
+    return mul(x3, x4);
+}
+
+// x * 2^s for 0 <= s < 32
+GL_HD u64 mul_pow2(u64 x, u32 s) {
+    u64 lo = x << s;
+    u64 hi = s ? (x >> (64 - s)) : 0;  // < 2^32
+    u64 t1 = (hi << 32) - hi;          // hi * EPS
+    u64 r = lo + t1;
+    if (r < t1) r += EPS;
+    return r;
+}
+
+// small-constant multiple, k < 2^32
+GL_HD u64 mul_small(u64 x, u32 k) {
+    u64 l = (x & EPS) * k;   // < 2^64
+    u64 h = (x >> 32) * k;   // < 2^64 ; value = l + h * 2^32
+    u64 hh = h >> 32, hl = h & EPS;  // h*2^32 = hl*2^32 + hh*2^64
+    u64 r = l + (hl << 32);
+    u64 c = r < l ? EPS : 0;
+    u64 t = hh * EPS;  // hh < 2^32
+    u64 r2 = r + c;    // r < 2^64 - ... after wrap, cannot overflow
+    u64 r3 = r2 + t;
+    if (r3 < t) r3 += EPS;
+    return r3;
+}
+
+GL_HD u64 pow(u64 a, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = mul(r, a);
+        a = sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+
+GL_HD u64 inv(u64 a) { return pow(a, P - 2); }
+
+}  // namespace gl

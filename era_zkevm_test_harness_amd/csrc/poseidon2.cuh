@@ -1,0 +1,210 @@
+// poseidon2.cuh — Poseidon2 over Goldilocks, width 12 / rate 8 / capacity 4, for gfx950.
+//
+// Replaces boojum's `Poseidon2Goldilocks` round function that the reference reaches through
+// `ZkSyncDefaultRoundFunction` (circuit_encodings/src/lib.rs:12-15) in every queue simulator
+// (lib.rs:198-203, 405-409), in produce_fs_challenges (src/witness/utils.rs:515-528) and in the
+// Poseidon2 flattened gate of every base-layer circuit (vm_main.rs:55-118, ram_permutation.rs:52-96).
+//
+// Two device formulations:
+//   * p2::permute(s[12])          one state per lane, everything in registers (row-parallel passes:
+//                                 trace materialisation, gate checks; 64 independent states per wave).
+//   * p2::Coop::permute(x)        one state per 16-lane DPP row, element g of the state in lane g
+//                                 (12 active lanes, 4 idle), 4 states per wave. Cross-lane traffic is
+//                                 DPP only (quad_perm inside the 4x4 blocks, row_ror across blocks), no
+//                                 LDS. This is the latency-oriented form for the serial queue chains.
+#pragma once
+#include "gl64.cuh"
+#include "poseidon2_constants.h"
+
+namespace p2 {
+using gl::u32;
+using gl::u64;
+
+__constant__ u64 c_rc[P2_TOTAL_ROUNDS * P2_WIDTH] = P2_ROUND_CONSTANTS_INIT;
+__constant__ u32 c_shift[P2_WIDTH] = P2_INTERNAL_DIAG_SHIFTS_INIT;
+
+__host__ __device__ __forceinline__ u64 rc_at(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return c_rc[i];
+#else
+    return P2_ROUND_CONSTANTS[i];
+#endif
+}
+__host__ __device__ __forceinline__ u32 shift_at(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return c_shift[i];
+#else
+    return P2_INTERNAL_DIAG_SHIFTS[i];
+#endif
+}
+
+// ---------------------------------------------------------------- one state per lane
+// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] by the Poseidon2 addition chain.
+GL_HD void m4(u64& x0, u64& x1, u64& x2, u64& x3) {
+    u64 t0 = gl::add(x0, x1), t1 = gl::add(x2, x3);
+    u64 t2 = gl::add(gl::add(x1, x1), t1), t3 = gl::add(gl::add(x3, x3), t0);
+    u64 t1_4 = gl::add(t1, t1); t1_4 = gl::add(t1_4, t1_4);
+    u64 t0_4 = gl::add(t0, t0); t0_4 = gl::add(t0_4, t0_4);
+    u64 t4 = gl::add(t1_4, t3), t5 = gl::add(t0_4, t2);
+    x0 = gl::add(t3, t5); x1 = t5; x2 = gl::add(t2, t4); x3 = t4;
+}
+
+// external layer circ(2*M4, M4, M4)
+GL_HD void external(u64 s[12]) {
+    m4(s[0], s[1], s[2], s[3]);
+    m4(s[4], s[5], s[6], s[7]);
+    m4(s[8], s[9], s[10], s[11]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 col = gl::add(gl::add(s[i], s[4 + i]), s[8 + i]);
+        s[i] = gl::add(s[i], col); s[4 + i] = gl::add(s[4 + i], col); s[8 + i] = gl::add(s[8 + i], col);
+    }
+}
+
+// internal layer: y_i = x_i * 2^shift_i + sum_j x_j
+GL_HD void internal(u64 s[12]) {
+    u64 sum = s[0];
+#pragma unroll
+    for (int i = 1; i < 12; i++) sum = gl::add(sum, s[i]);
+    constexpr u32 SH[12] = P2_INTERNAL_DIAG_SHIFTS_INIT;
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::add(gl::mul_pow2(s[i], SH[i]), sum);
+}
+
+GL_HD void full_round(u64 s[12], int r) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::pow7(gl::add(s[i], rc_at(12 * r + i)));
+    external(s);
+}
+
+GL_HD void partial_round(u64 s[12], int r) {
+    s[0] = gl::pow7(gl::add(s[0], rc_at(12 * r)));
+    internal(s);
+}
+
+// weak in, weak out
+GL_HD void permute(u64 s[12]) {
+    external(s);
+    int r = 0;
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) full_round(s, r);
+    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) partial_round(s, r);
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) full_round(s, r);
+}
+
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------- one state per 16-lane row
+// DPP controls (GFX9 encoding): quad_perm = sel0 | sel1<<2 | sel2<<4 | sel3<<6; row_ror:n = 0x120 + n.
+template <int CTRL>
+__device__ __forceinline__ u32 dpp32(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp((int)0, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ u64 dpp64(u64 v) {
+    u32 lo = dpp32<CTRL>((u32)v), hi = dpp32<CTRL>((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+constexpr int QP_ROT1 = 1 | (2 << 2) | (3 << 4) | (0 << 6);  // lane j reads lane j+1 (mod 4)
+constexpr int QP_ROT2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);
+constexpr int QP_ROT3 = 3 | (0 << 2) | (1 << 4) | (2 << 6);
+constexpr int QP_SWAP1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);
+constexpr int ROW_ROR4 = 0x124, ROW_ROR8 = 0x128, ROW_ROR12 = 0x12C;
+
+// value = lo + hi * 2^64, hi small
+struct Wide {
+    u64 lo;
+    u32 hi;
+};
+__device__ __forceinline__ Wide wadd(Wide a, Wide b) {
+    Wide r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ Wide wdpp(Wide a) {
+    Wide r;
+    r.lo = dpp64<CTRL>(a.lo);
+    r.hi = dpp32<CTRL>(a.hi);
+    return r;
+}
+// hi < 2^31
+__device__ __forceinline__ u64 wreduce(Wide a) {
+    u64 t = ((u64)a.hi << 32) - a.hi;  // hi * EPS
+    u64 r = a.lo + t;
+    u64 c = r < t ? gl::EPS : 0;
+    u64 r2 = r + c;
+    if (r2 < c) r2 += gl::EPS;
+    return r2;
+}
+
+struct Coop {
+    // per-lane constants, loaded once per kernel
+    u64 rc_full[2 * P2_HALF_FULL_ROUNDS];  // c_rc[12*round + g] for the 8 full rounds (0 for idle lanes)
+    u32 ka, kb, kd;                        // row of M4 seen from this lane: ka*a + kb*b + c + kd*d
+    u32 shift;                             // internal diag shift of element g
+    bool active;                           // g < 12
+    bool first;                            // g == 0
+
+    __device__ __forceinline__ void init(int g) {
+        active = g < 12;
+        first = g == 0;
+#pragma unroll
+        for (int k = 0; k < 2 * P2_HALF_FULL_ROUNDS; k++) {
+            int round = k < P2_HALF_FULL_ROUNDS ? k : k + P2_PARTIAL_ROUNDS;
+            rc_full[k] = active ? c_rc[12 * round + g] : 0;
+        }
+        bool even = (g & 1) == 0;
+        ka = even ? 5u : 6u;  // even lane j: 5 x_j + 7 x_{j+1} + x_{j+2} + 3 x_{j+3}
+        kb = even ? 7u : 1u;  // odd lane j:  6 x_j +   x_{j+1} + x_{j+2} + 4 x_{j+3}  (indices mod 4)
+        kd = even ? 3u : 4u;
+        shift = active ? c_shift[g] : 0;
+    }
+
+    // external layer on the distributed state; x weak, idle lanes must hold 0 and get 0 back
+    __device__ __forceinline__ u64 external(u64 x) const {
+        u64 a = x, b = dpp64<QP_ROT1>(x), c = dpp64<QP_ROT2>(x), d = dpp64<QP_ROT3>(x);
+        u64 L = (a & gl::EPS) * ka + (b & gl::EPS) * kb + (c & gl::EPS) + (d & gl::EPS) * kd;  // < 18 * 2^32
+        u64 H = (a >> 32) * ka + (b >> 32) * kb + (c >> 32) + (d >> 32) * kd;
+        Wide t;  // L + H * 2^32
+        t.lo = L + (H << 32);
+        t.hi = (u32)(H >> 32) + (t.lo < L ? 1u : 0u);
+        // column sums over the (up to) 4 quads of the row; the idle quad contributes 0
+        Wide col = wadd(wadd(t, wdpp<ROW_ROR4>(t)), wadd(wdpp<ROW_ROR8>(t), wdpp<ROW_ROR12>(t)));
+        u64 y = wreduce(wadd(t, col));
+        return active ? y : 0;
+    }
+
+    __device__ __forceinline__ u64 internal(u64 x) const {
+        Wide s;
+        s.lo = x;
+        s.hi = 0;
+        s = wadd(s, wdpp<ROW_ROR8>(s));
+        s = wadd(s, wdpp<ROW_ROR4>(s));
+        s = wadd(s, wdpp<QP_ROT2>(s));
+        s = wadd(s, wdpp<QP_SWAP1>(s));
+        Wide m;  // x * 2^shift
+        m.lo = x << shift;
+        m.hi = (u32)((x >> 1) >> (63 - shift));
+        u64 y = wreduce(wadd(m, s));
+        return active ? y : 0;
+    }
+
+    // weak in / weak out; x = element g of the state (0 in idle lanes)
+    __device__ __forceinline__ u64 permute(u64 x) const {
+        x = external(x);
+#pragma unroll
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) x = external(gl::pow7(gl::add(x, rc_full[k])));
+        for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
+            u64 rc = c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];  // wave-uniform -> scalar load
+            u64 sx = gl::pow7(gl::add(x, rc));
+            x = internal(first ? sx : x);
+        }
+#pragma unroll
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++)
+            x = external(gl::pow7(gl::add(x, rc_full[P2_HALF_FULL_ROUNDS + k])));
+        return x;
+    }
+};
+#endif  // __HIPCC__
+
+}  // namespace p2

@@ -1,0 +1,417 @@
+// ram_kernels.cuh — device kernels of the RAM-permutation witness path (gfx950).
+//
+// Reference functions replaced (paths relative to the reference root):
+//   k_encode_mem        MemoryQuery::encoding_witness           circuit_encodings/src/memory_query.rs:24-118
+//   k_chain_full        FullWidthQueueSimulator::push chain     circuit_encodings/src/lib.rs:391-429
+//                       (unsorted queue: src/witness/oracle.rs:894-903; sorted: W/ram_permutation.rs:61-71)
+//   k_fs_challenges     produce_fs_challenges                   src/witness/utils.rs:498-550
+//   k_gp_local/_tiles/_apply  compute_grand_product_chains      src/witness/utils.rs:554-697
+//   k_ram_sort_keys / k_gather_queries   par_sort_by            W/ram_permutation.rs:48-53
+//   k_ram_instances     per-instance FSM snapshots              W/ram_permutation.rs:239-453
+#pragma once
+#include "../../include/zkw_types.h"
+#include "poseidon2.cuh"
+
+namespace zkw {
+using gl::u32;
+using gl::u64;
+
+// ------------------------------------------------------------------------------------------------
+// K1: encode memory queries. One query per lane: 48 B in (3 x 16 B), 64 B out (4 x 16 B), both fully
+// used cache lines. AoS output [n][8] is what the queue chain and the grand product consume.
+__device__ __forceinline__ void encode_mem_query(const zkw_mem_query& q, u64 out[8]) {
+    const u32* v = q.value;
+    out[0] = q.timestamp;
+    out[1] = q.page;
+    out[2] = (u64)q.index | ((u64)(q.rw_flag ? 1 : 0) << 32) | ((u64)(q.value_is_pointer ? 1 : 0) << 33);
+    // bytes of limbs 5,6,7 ride in bits 32..55 of limbs 0..3 (memory_query.rs:53-113)
+    u64 b5 = v[5], b6 = v[6], b7 = v[7];
+    out[3] = (u64)v[0] | ((b5 & 0xFFFFFF) << 32);
+    out[4] = (u64)v[1] | ((b5 >> 24) << 32) | ((b6 & 0xFFFF) << 40);
+    out[5] = (u64)v[2] | ((b6 >> 16) << 32) | ((b7 & 0xFF) << 48);
+    out[6] = (u64)v[3] | ((b7 >> 8) << 32);
+    out[7] = v[4];
+}
+
+__global__ __launch_bounds__(256) void k_encode_mem(const zkw_mem_query* __restrict__ q, size_t n,
+                                                    u64* __restrict__ enc) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint4* src = reinterpret_cast<const uint4*>(q + i);
+        uint4 w0 = src[0], w1 = src[1], w2 = src[2];
+        zkw_mem_query m;
+        uint4* dst = reinterpret_cast<uint4*>(&m);
+        dst[0] = w0; dst[1] = w1; dst[2] = w2;
+        u64 e[8];
+        encode_mem_query(m, e);
+        ulonglong2* o = reinterpret_cast<ulonglong2*>(enc + 8 * i);
+        o[0] = make_ulonglong2(e[0], e[1]); o[1] = make_ulonglong2(e[2], e[3]);
+        o[2] = make_ulonglong2(e[4], e[5]); o[3] = make_ulonglong2(e[6], e[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: full-width queue chains. One chain per 16-lane DPP row (4 chains per wave, 1 wave per block so
+// that every chain gets its own SIMD issue slot when chains are few). tails[i] = permute(enc[i] ||
+// capacity(tails[i-1])). The absorb loads are prefetched one item ahead; stores are fire-and-forget.
+struct ChainJob {
+    const u64* enc;      // [n][8]
+    u64* tails;          // [n][12]
+    const u64* tail_in;  // [12] or nullptr (= zeros)
+    u64 n;
+};
+
+__global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ jobs, int n_jobs) {
+    const int lane = threadIdx.x & 63, g = lane & 15;
+    const int chain = blockIdx.x * 4 + (lane >> 4);
+    p2::Coop co;
+    co.init(g);
+    ChainJob job;
+    job.enc = nullptr; job.tails = nullptr; job.tail_in = nullptr; job.n = 0;
+    if (chain < n_jobs) job = jobs[chain];
+    u64 x = (co.active && job.tail_in) ? job.tail_in[g] : 0;
+    const bool absorbs = g < 8;
+    u64 e_next = (absorbs && job.n > 0) ? job.enc[g] : 0;
+    for (u64 i = 0; __any(i < job.n); i++) {
+        const bool live = i < job.n;
+        u64 e = e_next;
+        if (absorbs && i + 1 < job.n) e_next = job.enc[8 * (i + 1) + g];
+        u64 y = co.permute(absorbs ? e : x);  // AbsorptionModeOverwrite
+        if (live) {
+            x = y;
+            if (co.active) job.tails[12 * i + g] = gl::canon(y);
+        }
+    }
+}
+
+// One chain per lane (64 chains per wave): the throughput-oriented form, used when there are at least
+// `coop_threshold` chains (see Context::chain_launch).
+__global__ __launch_bounds__(64) void k_chain_full_lane(const ChainJob* __restrict__ jobs, int n_jobs) {
+    const int chain = blockIdx.x * 64 + threadIdx.x;
+    if (chain >= n_jobs) return;
+    ChainJob job = jobs[chain];
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = job.tail_in ? job.tail_in[k] : 0;
+    for (u64 i = 0; i < job.n; i++) {
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(job.enc + 8 * i);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { ulonglong2 w = src[k]; s[2 * k] = w.x; s[2 * k + 1] = w.y; }
+        p2::permute(s);
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(job.tails + 12 * i);
+#pragma unroll
+        for (int k = 0; k < 6; k++) dst[k] = make_ulonglong2(gl::canon(s[2 * k]), gl::canon(s[2 * k + 1]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: Fiat-Shamir challenges, one job per lane (a handful of permutations; latency-irrelevant).
+struct FsJob {
+    const u64* tail_u;  // [state_w]
+    const u64* tail_s;  // [state_w]
+    u32 len_u, len_s;
+    u64* out;           // [2][n_chal]
+};
+
+__global__ void k_fs_challenges(const FsJob* __restrict__ jobs, int n_jobs, int state_w, int n_chal) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_jobs) return;
+    FsJob job = jobs[j];
+    u64 fs[26];
+    int m = 0;
+    for (int i = 0; i < state_w; i++) fs[m++] = job.tail_u[i];
+    fs[m++] = job.len_u;  // < p
+    for (int i = 0; i < state_w; i++) fs[m++] = job.tail_s[i];
+    fs[m++] = job.len_s;
+    u64 s[12];
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    s[11] = (u64)m;  // specialize_for_len
+    int i = 0;
+    for (; i + 8 <= m; i += 8) {
+        for (int k = 0; k < 8; k++) s[k] = fs[i + k];
+        p2::permute(s);
+    }
+    if (i < m) {
+        for (int k = 0; k < 8; k++) s[k] = (i + k < m) ? fs[i + k] : 0;
+        p2::permute(s);
+    }
+    int can_take = 8;
+    for (int rep = 0; rep < 2; rep++) {
+        job.out[rep * n_chal] = 1;
+        for (int k = 1; k < n_chal; k++) {
+            if (can_take == 0) { p2::permute(s); can_take = 8; }
+            job.out[rep * n_chal + k] = gl::canon(s[8 - can_take]);
+            can_take--;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: grand-product chains. A "segment" is one side (lhs or rhs) of one sorter: rows[n][W] -> z[rep][n]
+// for both repetitions in ONE pass over the rows (the reference reads them once per repetition).
+// Three launches: tile-local inclusive scan (+ tile aggregates), scan of the aggregates per segment,
+// tile-prefix application. Tiles are GP_TILE rows; a block is 256 lanes = 4 waves.
+constexpr int GP_BLOCK = 256;
+constexpr int GP_SLABS = 4;
+constexpr int GP_TILE = GP_BLOCK * GP_SLABS;
+
+struct GpSeg {
+    const u64* rows;   // [n][W]
+    u64* z;            // [n_reps][n]
+    const u64* chal;   // [n_reps][W+1]
+    u64 n;
+    u32 first_tile;    // index of this segment's first tile in the launch
+    u32 n_tiles;
+};
+struct GpTile {
+    u32 seg;
+    u32 tile;  // tile index inside the segment
+};
+
+// inclusive product scan across the 64 lanes of a wave
+__device__ __forceinline__ u64 wave_scan_mul(u64 v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u64 o = __shfl_up(v, d, 64);
+        if (lane >= d) v = gl::mul(v, o);
+    }
+    return v;
+}
+
+template <int W, int REPS>
+__global__ __launch_bounds__(GP_BLOCK) void k_gp_local(const GpSeg* __restrict__ segs,
+                                                       const GpTile* __restrict__ tiles,
+                                                       u64* __restrict__ tile_aggr /* [n_tiles_total][REPS] */) {
+    __shared__ u64 sh_ch[REPS][W + 1];
+    __shared__ u64 sh_wave[REPS][GP_BLOCK / 64];
+    const GpTile t = tiles[blockIdx.x];
+    const GpSeg seg = segs[t.seg];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < REPS * (W + 1); k += GP_BLOCK) sh_ch[k / (W + 1)][k % (W + 1)] = seg.chal[k];
+    __syncthreads();
+    u64 carry[REPS];
+#pragma unroll
+    for (int r = 0; r < REPS; r++) carry[r] = 1;
+    const u64 base = (u64)t.tile * GP_TILE;
+    for (int slab = 0; slab < GP_SLABS; slab++) {
+        const u64 row = base + (u64)slab * GP_BLOCK + tid;
+        const bool live = row < seg.n;
+        u64 term[REPS];
+#pragma unroll
+        for (int r = 0; r < REPS; r++) term[r] = 1;  // neutral for rows past the end
+        if (live) {
+            u64 e[W];
+            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(seg.rows + row * W);
+#pragma unroll
+            for (int k = 0; k < W / 2; k++) { ulonglong2 w = src[k]; e[2 * k] = w.x; e[2 * k + 1] = w.y; }
+#pragma unroll
+            for (int r = 0; r < REPS; r++) {
+                u64 acc = sh_ch[r][W];
+#pragma unroll
+                for (int k = 0; k < W; k++) acc = gl::add(acc, gl::mul(e[k], sh_ch[r][k]));
+                term[r] = acc;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < REPS; r++) {
+            u64 v = wave_scan_mul(term[r], lane);
+            if (lane == 63) sh_wave[r][wave] = v;
+            __syncthreads();
+            u64 pre = carry[r];
+            for (int w = 0; w < wave; w++) pre = gl::mul(pre, sh_wave[r][w]);
+            v = gl::mul(v, pre);
+            if (live) seg.z[(u64)r * seg.n + row] = v;  // weak; canonicalised by k_gp_apply
+            u64 tot = carry[r];
+            for (int w = 0; w < GP_BLOCK / 64; w++) tot = gl::mul(tot, sh_wave[r][w]);
+            carry[r] = tot;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int r = 0; r < REPS; r++) tile_aggr[(u64)blockIdx.x * REPS + r] = carry[r];
+    }
+}
+
+// exclusive scan of the tile aggregates inside each segment: one lane per (segment, repetition)
+template <int REPS>
+__global__ void k_gp_tiles(const GpSeg* __restrict__ segs, int n_segs, u64* __restrict__ tile_aggr) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_segs * REPS) return;
+    const GpSeg seg = segs[j / REPS];
+    const int r = j % REPS;
+    u64 acc = 1;
+    for (u32 t = 0; t < seg.n_tiles; t++) {
+        u64* p = tile_aggr + (u64)(seg.first_tile + t) * REPS + r;
+        u64 v = *p;
+        *p = acc;
+        acc = gl::mul(acc, v);
+    }
+}
+
+template <int REPS>
+__global__ __launch_bounds__(GP_BLOCK) void k_gp_apply(const GpSeg* __restrict__ segs,
+                                                       const GpTile* __restrict__ tiles,
+                                                       const u64* __restrict__ tile_prefix) {
+    const GpTile t = tiles[blockIdx.x];
+    const GpSeg seg = segs[t.seg];
+    const u64 base = (u64)t.tile * GP_TILE;
+#pragma unroll
+    for (int r = 0; r < REPS; r++) {
+        const u64 pre = tile_prefix[(u64)blockIdx.x * REPS + r];
+        u64* z = seg.z + (u64)r * seg.n;
+        for (int slab = 0; slab < GP_SLABS; slab++) {
+            const u64 row = base + (u64)slab * GP_BLOCK + threadIdx.x;
+            if (row < seg.n) z[row] = gl::canon(gl::mul(z[row], pre));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 support: sort keys and the gather that applies the sorting permutation.
+// Sorting order (W/ram_permutation.rs:50-53): (page, index) then timestamp, stable.
+__global__ void k_ram_sort_keys(const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ ts,
+                                u64* __restrict__ cell, u32* __restrict__ iota, const u64* __restrict__ seg_off,
+                                int n_segs) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ts[i] = q[i].timestamp;
+    cell[i] = ((u64)q[i].page << 32) | q[i].index;
+    iota[i] = (u32)i;  // global position; segments never mix, so this is also the stable tiebreak
+    (void)seg_off; (void)n_segs;
+}
+
+__global__ void k_gather_u32_by_u32(const u32* __restrict__ src, const u32* __restrict__ idx, size_t n,
+                                    u32* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+__global__ void k_gather_u64_by_u32(const u64* __restrict__ src, const u32* __restrict__ idx, size_t n,
+                                    u64* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// sorted_q[i] = q[perm[i]] and its encoding in the same pass (the sorted side never needs the
+// un-encoded query again except for the FSM snapshots, which read sorted_q).
+__global__ __launch_bounds__(256) void k_gather_encode(const zkw_mem_query* __restrict__ q,
+                                                       const u32* __restrict__ perm, size_t n,
+                                                       zkw_mem_query* __restrict__ sorted_q,
+                                                       u64* __restrict__ sorted_enc) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* src = reinterpret_cast<const uint4*>(q + perm[i]);
+    uint4 w0 = src[0], w1 = src[1], w2 = src[2];
+    uint4* dq = reinterpret_cast<uint4*>(sorted_q + i);
+    dq[0] = w0; dq[1] = w1; dq[2] = w2;
+    zkw_mem_query m;
+    uint4* dm = reinterpret_cast<uint4*>(&m);
+    dm[0] = w0; dm[1] = w1; dm[2] = w2;
+    u64 e[8];
+    encode_mem_query(m, e);
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(sorted_enc + 8 * i);
+    o[0] = make_ulonglong2(e[0], e[1]); o[1] = make_ulonglong2(e[2], e[3]);
+    o[2] = make_ulonglong2(e[4], e[5]); o[3] = make_ulonglong2(e[6], e[7]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a10: per-instance records (W/ram_permutation.rs:239-453). One block per memory block (queue);
+// the instance loop is sequential in the reference because of the running FSM values, but every
+// field is a pure function of the block-wide arrays, so each instance is filled independently.
+struct RamBlock {
+    const zkw_mem_query* sorted_q;  // [n]
+    const u64* unsorted_tails;      // [n][12]
+    const u64* sorted_tails;        // [n][12]
+    const u64* lhs_z;               // [2][n]
+    const u64* rhs_z;               // [2][n]
+    zkw_ram_instance* instances;    // [ceil(n/capacity)]
+    u32* nondet_prefix;             // [n_instances] scratch: nondeterministic writes per chunk
+    u64 n;
+    u32 capacity;
+    u32 num_nondet_heap_queries;
+};
+
+__device__ __forceinline__ void copy12(u64* dst, const u64* src) {
+    for (int k = 0; k < 12; k++) dst[k] = src[k];
+}
+
+// pass 1: count nondeterministic writes per chunk (rw && ts == 0 && page == BOOTLOADER_HEAP_PAGE)
+__global__ __launch_bounds__(256) void k_ram_count_nondet(const RamBlock* __restrict__ blocks) {
+    const RamBlock b = blocks[blockIdx.y];
+    const u64 n_inst = (b.n + b.capacity - 1) / b.capacity;
+    __shared__ u32 sh[4];
+    for (u64 inst = blockIdx.x; inst < n_inst; inst += gridDim.x) {
+        const u64 lo = inst * b.capacity, hi = lo + b.capacity < b.n ? lo + b.capacity : b.n;
+        u32 cnt = 0;
+        for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const zkw_mem_query* q = b.sorted_q + i;
+            cnt += (q->rw_flag && q->timestamp == 0 && q->page == ZKW_BOOTLOADER_HEAP_PAGE) ? 1u : 0u;
+        }
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) b.nondet_prefix[inst] = sh[0] + sh[1] + sh[2] + sh[3];
+        __syncthreads();
+    }
+}
+
+// pass 2: one lane per instance
+__global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
+    const RamBlock b = blocks[blockIdx.y];
+    const u64 n_inst = (b.n + b.capacity - 1) / b.capacity;
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_inst) return;
+    const u64 n = b.n, lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n, last = hi - 1;
+    zkw_ram_instance w;
+    memset(&w, 0, sizeof w);
+    w.start_flag = idx == 0;
+    w.completion_flag = idx == n_inst - 1;
+    w.first_item = lo;
+    w.num_items = hi - lo;
+    const u64* u_final = b.unsorted_tails + 12 * (n - 1);
+    const u64* s_final = b.sorted_tails + 12 * (n - 1);
+    copy12(w.unsorted_queue_initial_state.tail, u_final);
+    w.unsorted_queue_initial_state.length = (u32)n;
+    copy12(w.sorted_queue_initial_state.tail, s_final);
+    w.sorted_queue_initial_state.length = (u32)n;
+    w.non_deterministic_bootloader_memory_snapshot_length = b.num_nondet_heap_queries;
+
+    u32 nondet_before = 0;
+    for (u64 k = 0; k < idx; k++) nondet_before += b.nondet_prefix[k];
+
+    // FSM output of chunk j (without the padding reset) is a function of item `end_j - 1`
+    auto fill = [&](zkw_ram_fsm& f, u64 end /* items consumed so far, > 0 */, u32 nondet) {
+        const u64 l = end - 1;
+        for (int r = 0; r < 2; r++) { f.lhs_accumulator[r] = b.lhs_z[r * n + l]; f.rhs_accumulator[r] = b.rhs_z[r * n + l]; }
+        copy12(f.current_unsorted_queue_state.head, b.unsorted_tails + 12 * l);
+        copy12(f.current_unsorted_queue_state.tail, u_final);
+        f.current_unsorted_queue_state.length = (u32)(n - end);
+        copy12(f.current_sorted_queue_state.head, b.sorted_tails + 12 * l);
+        copy12(f.current_sorted_queue_state.tail, s_final);
+        f.current_sorted_queue_state.length = (u32)(n - end);
+        const zkw_mem_query* q = b.sorted_q + l;
+        f.previous_sorting_key[0] = q->timestamp; f.previous_sorting_key[1] = q->index; f.previous_sorting_key[2] = q->page;
+        f.previous_full_key[0] = q->index; f.previous_full_key[1] = q->page;
+        for (int k = 0; k < 8; k++) f.previous_value[k] = q->value[k];
+        f.previous_is_ptr = q->value_is_pointer ? 1 : 0;
+        f.num_nondeterministic_writes = nondet;
+    };
+    if (idx == 0) {
+        for (int r = 0; r < 2; r++) { w.hidden_fsm_input.lhs_accumulator[r] = 1; w.hidden_fsm_input.rhs_accumulator[r] = 1; }
+    } else {
+        fill(w.hidden_fsm_input, lo, nondet_before);
+    }
+    fill(w.hidden_fsm_output, hi, nondet_before + b.nondet_prefix[idx]);
+    if ((hi - lo) % b.capacity != 0) {  // padding reset, W/ram_permutation.rs:414-432
+        zkw_ram_fsm& f = w.hidden_fsm_output;
+        for (int k = 0; k < 3; k++) f.previous_sorting_key[k] = 0;
+        for (int k = 0; k < 2; k++) f.previous_full_key[k] = 0;
+        for (int k = 0; k < 8; k++) f.previous_value[k] = 0;
+        f.previous_is_ptr = 0;
+    }
+    b.instances[idx] = w;
+}
+
+}  // namespace zkw

@@ -1,0 +1,671 @@
+// zkw_api.hip — host side of libzkw above the kernels and the extern "C" boundary (include/zkw.h).
+//
+// Host logic mirrors the reference's builders (Rust, compiled code => C++ here):
+//   RamBuilder::run  <->  compute_ram_circuit_snapshots, src/witness/individual_circuits/ram_permutation.rs:26-470
+// One process drives one GPU; everything is enqueued on the context's stream, scratch lives in a
+// grow-only per-context pool so that steady-state calls do no hipMalloc.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zkw.h"
+#include "ram_kernels.cuh"
+#include "sort.h"
+
+using namespace zkw;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return fail(_e == hipErrorOutOfMemory ? ZKW_ERR_OOM : ZKW_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                          \
+    } while (0)
+
+#define ZKW_TRY(expr)            \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != ZKW_OK) return _rc; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ context
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+// pinned host staging for descriptor uploads; `ev` marks the last copy that read it
+struct HostStage {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+
+struct zkw_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int ptr_mode = ZKW_PTR_HOST;
+    std::map<std::string, DevBuf> pool;  // named grow-only scratch
+    std::map<std::string, HostStage> stages;
+
+    int scratch(const char* name, size_t bytes, void** out) {
+        DevBuf& b = pool[name];
+        if (b.cap < bytes) {
+            if (b.p) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipFree(b.p));
+                b.p = nullptr;
+                b.cap = 0;
+            }
+            size_t want = bytes + bytes / 8 + 256;
+            HIP_TRY(hipMalloc(&b.p, want));
+            b.cap = want;
+        }
+        *out = b.p;
+        return ZKW_OK;
+    }
+    template <class T>
+    int scratch_t(const char* name, size_t count, T** out) {
+        void* p = nullptr;
+        ZKW_TRY(scratch(name, count * sizeof(T) + 16, &p));
+        *out = static_cast<T*>(p);
+        return ZKW_OK;
+    }
+    // descriptor upload: host vector -> named device scratch (async, pageable source is copied by the
+    // runtime before return)
+    template <class T>
+    int upload(const char* name, const std::vector<T>& h, T** out) {
+        ZKW_TRY(scratch_t<T>(name, h.size() ? h.size() : 1, out));
+        if (h.empty()) return ZKW_OK;
+        const size_t bytes = h.size() * sizeof(T);
+        HostStage& st = stages[name];
+        if (st.pending) {  // the previous upload from this staging buffer must have been consumed
+            HIP_TRY(hipEventSynchronize(st.ev));
+            st.pending = false;
+        }
+        if (st.cap < bytes) {
+            if (st.p) HIP_TRY(hipHostFree(st.p));
+            st.p = nullptr;
+            st.cap = 0;
+            HIP_TRY(hipHostMalloc(&st.p, bytes + bytes / 2 + 256, hipHostMallocDefault));
+            st.cap = bytes + bytes / 2 + 256;
+        }
+        if (!st.ev) HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+        memcpy(st.p, h.data(), bytes);
+        HIP_TRY(hipMemcpyAsync(*out, st.p, bytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(st.ev, stream));
+        st.pending = true;
+        return ZKW_OK;
+    }
+    // stage an input: returns a device pointer for `src` (copying when src is a host pointer)
+    template <class T>
+    int in(const char* name, const T* src, size_t count, const T** out) {
+        if (ptr_mode == ZKW_PTR_DEVICE || count == 0) {
+            *out = src;
+            return ZKW_OK;
+        }
+        T* d = nullptr;
+        ZKW_TRY(scratch_t<T>(name, count, &d));
+        HIP_TRY(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+        *out = d;
+        return ZKW_OK;
+    }
+    // reserve an output: device pointer to write to (dst itself in device mode)
+    template <class T>
+    int out(const char* name, T* dst, size_t count, T** dev) {
+        if (ptr_mode == ZKW_PTR_DEVICE) {
+            *dev = dst;
+            return ZKW_OK;
+        }
+        return scratch_t<T>(name, count ? count : 1, dev);
+    }
+    template <class T>
+    int finish_out(T* dst, const T* dev, size_t count) {
+        if (ptr_mode == ZKW_PTR_DEVICE || count == 0) return ZKW_OK;
+        HIP_TRY(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, stream));
+        return ZKW_OK;
+    }
+    int sync_if_host() {
+        if (ptr_mode == ZKW_PTR_HOST) HIP_TRY(hipStreamSynchronize(stream));
+        return ZKW_OK;
+    }
+};
+
+static int launch_check(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ZKW_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return ZKW_OK;
+}
+
+static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" const char* zkw_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* zkw_version(void) { return "zkw 0.1 (gfx950)"; }
+
+extern "C" zkw_ctx* zkw_create(int device_id) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        fail(ZKW_ERR_NO_DEVICE, "no HIP device available (%s); libzkw has no CPU fallback",
+             e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= count) {
+        fail(ZKW_ERR_INVALID, "device_id %d out of range [0, %d)", device_id, count);
+        return nullptr;
+    }
+    if (hipSetDevice(device_id) != hipSuccess) {
+        fail(ZKW_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            fail(ZKW_ERR_NO_DEVICE, "device %d is %s; libzkw kernels are built for gfx950 only", device_id,
+                 prop.gcnArchName);
+            return nullptr;
+        }
+    }
+    zkw_ctx* ctx = new zkw_ctx();
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        fail(ZKW_ERR_HIP, "hipStreamCreate failed");
+        delete ctx;
+        return nullptr;
+    }
+    ctx->stream = ctx->own_stream;
+    return ctx;
+}
+
+extern "C" void zkw_destroy(zkw_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->pool)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : ctx->stages) {
+        if (kv.second.p) (void)hipHostFree(kv.second.p);
+        if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int zkw_set_stream(zkw_ctx* ctx, void* s) {
+    if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = s ? static_cast<hipStream_t>(s) : ctx->own_stream;
+    return ZKW_OK;
+}
+
+extern "C" int zkw_set_pointer_mode(zkw_ctx* ctx, int mode) {
+    if (!ctx || (mode != ZKW_PTR_HOST && mode != ZKW_PTR_DEVICE)) return fail(ZKW_ERR_INVALID, "bad pointer mode");
+    ctx->ptr_mode = mode;
+    return ZKW_OK;
+}
+
+extern "C" int zkw_synchronize(zkw_ctx* ctx) {
+    if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ZKW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ device-level steps
+// (all pointers are device pointers here)
+
+static int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) {
+    if (n == 0) return ZKW_OK;
+    unsigned grid = blocks_for(n, 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(k_encode_mem, dim3(grid), dim3(256), 0, ctx->stream, q, n, enc);
+    return launch_check("k_encode_mem");
+}
+
+// Chains: the 16-lane cooperative kernel minimises latency (few chains); one-chain-per-lane maximises
+// throughput once there are enough chains to fill the SIMDs with full waves.
+static constexpr int kLaneChainThreshold = 64 * 1024;
+
+static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
+    if (jobs.empty()) return ZKW_OK;
+    ChainJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("chain_jobs", jobs, &d_jobs));
+    int n_jobs = (int)jobs.size();
+    if (n_jobs >= kLaneChainThreshold) {
+        hipLaunchKernelGGL(k_chain_full_lane, dim3((n_jobs + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, n_jobs);
+        return launch_check("k_chain_full_lane");
+    }
+    hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, ctx->stream, d_jobs, n_jobs);
+    return launch_check("k_chain_full");
+}
+
+static int dev_fs(zkw_ctx* ctx, const std::vector<FsJob>& jobs, int state_w, int n_chal) {
+    if (jobs.empty()) return ZKW_OK;
+    FsJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("fs_jobs", jobs, &d_jobs));
+    int n = (int)jobs.size();
+    hipLaunchKernelGGL(k_fs_challenges, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, n, state_w, n_chal);
+    return launch_check("k_fs_challenges");
+}
+
+template <int W, int REPS>
+static int gp_launch(zkw_ctx* ctx, const GpSeg* d_segs, int n_segs, const GpTile* d_tiles, unsigned n_tiles,
+                     u64* d_aggr) {
+    hipLaunchKernelGGL((k_gp_local<W, REPS>), dim3(n_tiles), dim3(GP_BLOCK), 0, ctx->stream, d_segs, d_tiles, d_aggr);
+    ZKW_TRY(launch_check("k_gp_local"));
+    hipLaunchKernelGGL((k_gp_tiles<REPS>), dim3((n_segs * REPS + 63) / 64), dim3(64), 0, ctx->stream, d_segs, n_segs,
+                       d_aggr);
+    ZKW_TRY(launch_check("k_gp_tiles"));
+    hipLaunchKernelGGL((k_gp_apply<REPS>), dim3(n_tiles), dim3(GP_BLOCK), 0, ctx->stream, d_segs, d_tiles, d_aggr);
+    return launch_check("k_gp_apply");
+}
+
+// segs: rows/z/chal/n filled by the caller; first_tile/n_tiles filled here
+static int dev_grand_products(zkw_ctx* ctx, std::vector<GpSeg>& segs, int width, int n_reps) {
+    std::vector<GpTile> tiles;
+    for (size_t s = 0; s < segs.size(); s++) {
+        segs[s].first_tile = (u32)tiles.size();
+        segs[s].n_tiles = (u32)((segs[s].n + GP_TILE - 1) / GP_TILE);
+        for (u32 t = 0; t < segs[s].n_tiles; t++) tiles.push_back(GpTile{(u32)s, t});
+    }
+    if (tiles.empty()) return ZKW_OK;
+    GpSeg* d_segs = nullptr;
+    GpTile* d_tiles = nullptr;
+    u64* d_aggr = nullptr;
+    ZKW_TRY(ctx->upload("gp_segs", segs, &d_segs));
+    ZKW_TRY(ctx->upload("gp_tiles", tiles, &d_tiles));
+    ZKW_TRY(ctx->scratch_t<u64>("gp_aggr", tiles.size() * 2, &d_aggr));
+    const int n_segs = (int)segs.size();
+    const unsigned n_tiles = (unsigned)tiles.size();
+    if (width == 8 && n_reps == 2) return gp_launch<8, 2>(ctx, d_segs, n_segs, d_tiles, n_tiles, d_aggr);
+    if (width == 8 && n_reps == 1) return gp_launch<8, 1>(ctx, d_segs, n_segs, d_tiles, n_tiles, d_aggr);
+    if (width == 20 && n_reps == 2) return gp_launch<20, 2>(ctx, d_segs, n_segs, d_tiles, n_tiles, d_aggr);
+    if (width == 20 && n_reps == 1) return gp_launch<20, 1>(ctx, d_segs, n_segs, d_tiles, n_tiles, d_aggr);
+    return fail(ZKW_ERR_INVALID, "grand product: unsupported width %d / repetitions %d", width, n_reps);
+}
+
+// ------------------------------------------------------------------------------------------------ L1 entry points
+extern "C" int zkw_encode_memory_queries(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, uint64_t* enc) {
+    if (!ctx || (n && (!q || !enc))) return fail(ZKW_ERR_INVALID, "zkw_encode_memory_queries: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const zkw_mem_query* d_q = nullptr;
+    u64* d_enc = nullptr;
+    ZKW_TRY(ctx->in("enc_q", q, n, &d_q));
+    ZKW_TRY(ctx->out("enc_out", enc, n * 8, &d_enc));
+    ZKW_TRY(dev_encode(ctx, d_q, n, d_enc));
+    ZKW_TRY(ctx->finish_out(enc, d_enc, n * 8));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_queue_push_chain_full_batch(zkw_ctx* ctx, const uint64_t* enc, const uint64_t* offsets,
+                                               size_t n_queues, const uint64_t* tails_in, uint64_t* tails) {
+    if (!ctx || !offsets) return fail(ZKW_ERR_INVALID, "zkw_queue_push_chain_full_batch: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (size_t k = 0; k < n_queues; k++)
+        if (offsets[k + 1] < offsets[k]) return fail(ZKW_ERR_INVALID, "offsets must be non-decreasing");
+    const size_t total = n_queues ? offsets[n_queues] - offsets[0] : 0;
+    if (total && (!enc || !tails)) return fail(ZKW_ERR_INVALID, "null enc/tails");
+    const size_t base = n_queues ? offsets[0] : 0;
+    const u64* d_enc = nullptr;
+    const u64* d_tin = nullptr;
+    u64* d_tails = nullptr;
+    ZKW_TRY(ctx->in("chain_enc", enc + base * 8, total * 8, &d_enc));
+    if (tails_in) ZKW_TRY(ctx->in("chain_tin", tails_in, n_queues * 12, &d_tin));
+    ZKW_TRY(ctx->out("chain_tails", tails + base * 12, total * 12, &d_tails));
+    std::vector<ChainJob> jobs(n_queues);
+    for (size_t k = 0; k < n_queues; k++) {
+        size_t lo = offsets[k] - base;
+        jobs[k].enc = d_enc + lo * 8;
+        jobs[k].tails = d_tails + lo * 12;
+        jobs[k].tail_in = d_tin ? d_tin + 12 * k : nullptr;
+        jobs[k].n = offsets[k + 1] - offsets[k];
+    }
+    ZKW_TRY(dev_chains(ctx, jobs));
+    ZKW_TRY(ctx->finish_out(tails + base * 12, d_tails, total * 12));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_queue_push_chain_full(zkw_ctx* ctx, const uint64_t* enc, size_t n, const uint64_t tail_in[12],
+                                         uint64_t* tails) {
+    uint64_t offsets[2] = {0, n};
+    return zkw_queue_push_chain_full_batch(ctx, enc, offsets, 1, tail_in, tails);
+}
+
+extern "C" int zkw_fs_challenges(zkw_ctx* ctx, const uint64_t* tail_u, uint32_t len_u, const uint64_t* tail_s,
+                                 uint32_t len_s, int state_w, int n_chal, uint64_t* out) {
+    if (!ctx || !tail_u || !tail_s || !out) return fail(ZKW_ERR_INVALID, "zkw_fs_challenges: null argument");
+    if ((state_w != 4 && state_w != 12) || n_chal < 1 || n_chal > 64)
+        return fail(ZKW_ERR_INVALID, "zkw_fs_challenges: state_w must be 4 or 12, 1 <= n_chal <= 64");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64 *d_u = nullptr, *d_s = nullptr;
+    u64* d_out = nullptr;
+    ZKW_TRY(ctx->in("fs_u", tail_u, (size_t)state_w, &d_u));
+    ZKW_TRY(ctx->in("fs_s", tail_s, (size_t)state_w, &d_s));
+    ZKW_TRY(ctx->out("fs_out", out, (size_t)2 * n_chal, &d_out));
+    std::vector<FsJob> jobs(1);
+    jobs[0] = FsJob{d_u, d_s, len_u, len_s, d_out};
+    ZKW_TRY(dev_fs(ctx, jobs, state_w, n_chal));
+    ZKW_TRY(ctx->finish_out(out, d_out, (size_t)2 * n_chal));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_grand_product_chains(zkw_ctx* ctx, const uint64_t* lhs, const uint64_t* rhs, size_t n, int width,
+                                        const uint64_t* challenges, int n_reps, uint64_t* lhs_z, uint64_t* rhs_z) {
+    if (!ctx || !challenges || (n && (!lhs || !rhs || !lhs_z || !rhs_z)))
+        return fail(ZKW_ERR_INVALID, "zkw_grand_product_chains: null argument");
+    if ((width != 8 && width != 20) || (n_reps != 1 && n_reps != 2))
+        return fail(ZKW_ERR_INVALID, "zkw_grand_product_chains: width must be 8 or 20, n_reps 1 or 2");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return ZKW_OK;
+    const u64 *d_l = nullptr, *d_r = nullptr, *d_c = nullptr;
+    u64 *d_lz = nullptr, *d_rz = nullptr;
+    ZKW_TRY(ctx->in("gp_lhs", lhs, n * width, &d_l));
+    ZKW_TRY(ctx->in("gp_rhs", rhs, n * width, &d_r));
+    ZKW_TRY(ctx->in("gp_chal", challenges, (size_t)n_reps * (width + 1), &d_c));
+    ZKW_TRY(ctx->out("gp_lz", lhs_z, n * n_reps, &d_lz));
+    ZKW_TRY(ctx->out("gp_rz", rhs_z, n * n_reps, &d_rz));
+    std::vector<GpSeg> segs(2);
+    segs[0] = GpSeg{d_l, d_lz, d_c, n, 0, 0};
+    segs[1] = GpSeg{d_r, d_rz, d_c, n, 0, 0};
+    ZKW_TRY(dev_grand_products(ctx, segs, width, n_reps));
+    ZKW_TRY(ctx->finish_out(lhs_z, d_lz, n * n_reps));
+    ZKW_TRY(ctx->finish_out(rhs_z, d_rz, n * n_reps));
+    ZKW_TRY(ctx->sync_if_host());
+    if (ctx->ptr_mode == ZKW_PTR_HOST)
+        for (int r = 0; r < n_reps; r++)
+            if (lhs_z[(size_t)r * n + n - 1] != rhs_z[(size_t)r * n + n - 1])
+                return fail(ZKW_ERR_CHECK_FAILED, "grand products differ in repetition %d (utils.rs:685-696)", r);
+    return ZKW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ RAM builder
+struct zkw_ram_witness {
+    zkw_ctx* ctx = nullptr;
+    std::vector<uint64_t> offsets;       // n_blocks + 1, rebased to 0
+    std::vector<uint64_t> inst_offsets;  // n_blocks + 1
+    uint32_t capacity = 0;
+    size_t total = 0, n_instances = 0;
+    // owned device arrays
+    zkw_mem_query* sorted_q = nullptr;
+    u64 *unsorted_enc = nullptr, *sorted_enc = nullptr, *unsorted_tails = nullptr, *sorted_tails = nullptr;
+    u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
+    zkw_ram_instance* instances = nullptr;
+    u32* nondet_counts = nullptr;
+
+    void release() {
+        void* ptrs[] = {sorted_q, unsorted_enc, sorted_enc, unsorted_tails, sorted_tails, challenges,
+                        lhs_z,    rhs_z,        instances,  nondet_counts};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        sorted_q = nullptr;
+        unsorted_enc = sorted_enc = unsorted_tails = sorted_tails = challenges = lhs_z = rhs_z = nullptr;
+        instances = nullptr;
+        nondet_counts = nullptr;
+    }
+};
+
+static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
+    const size_t t = w->total, ni = w->n_instances;
+    HIP_TRY(hipMalloc((void**)&w->sorted_q, (t + 1) * sizeof(zkw_mem_query)));
+    HIP_TRY(hipMalloc((void**)&w->unsorted_enc, (t + 1) * 8 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->sorted_enc, (t + 1) * 8 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->unsorted_tails, (t + 1) * 12 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->sorted_tails, (t + 1) * 12 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->challenges, (n_blocks + 1) * 18 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->lhs_z, (t + 1) * 2 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->rhs_z, (t + 1) * 2 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->instances, (ni + 1) * sizeof(zkw_ram_instance)));
+    HIP_TRY(hipMalloc((void**)&w->nondet_counts, (ni + 1) * sizeof(u32)));
+    return ZKW_OK;
+}
+
+__global__ void k_block_ids(const u64* __restrict__ offsets, int n_blocks, size_t n, u32* __restrict__ ids) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = n_blocks;  // largest b with offsets[b] <= i
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    ids[i] = (u32)lo;
+}
+
+// the sorting permutation for all blocks at once (see sort.hip)
+static int ram_sort(zkw_ctx* ctx, const zkw_mem_query* d_q, size_t total, const std::vector<uint64_t>& offsets,
+                    u32** perm_out) {
+    const size_t n_blocks = offsets.size() - 1;
+    u32 *ts = nullptr, *k32 = nullptr, *v0 = nullptr, *v1 = nullptr;
+    u64 *cell = nullptr, *k64a = nullptr, *k64b = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = radix_temp_bytes(total);
+    ZKW_TRY(ctx->scratch_t<u32>("sort_ts", total, &ts));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_k32", total, &k32));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_v0", total, &v0));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_v1", total, &v1));
+    ZKW_TRY(ctx->scratch_t<u64>("sort_cell", total, &cell));
+    ZKW_TRY(ctx->scratch_t<u64>("sort_k64a", total, &k64a));
+    ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", total, &k64b));
+    ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
+    const unsigned grid = blocks_for(total, 256);
+    hipLaunchKernelGGL(k_ram_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, total, ts, cell, v0,
+                       (const u64*)nullptr, 0);
+    ZKW_TRY(launch_check("k_ram_sort_keys"));
+    // pass 1: timestamp
+    HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, ts, k32, v0, v1, total, 32, ctx->stream));
+    // pass 2: cell of the ts-sorted items
+    hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, cell, v1, total, k64a);
+    ZKW_TRY(launch_check("k_gather_u64_by_u32"));
+    HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, v1, v0, total, 64, ctx->stream));
+    u32* perm = v0;
+    if (n_blocks > 1) {
+        // pass 3: block id, so that each block's items end up contiguous again
+        u64* d_off = nullptr;
+        ZKW_TRY(ctx->upload("sort_off", offsets, &d_off));
+        unsigned bits = 1;
+        while ((1ull << bits) < n_blocks) bits++;
+        hipLaunchKernelGGL(k_block_ids, dim3(grid), dim3(256), 0, ctx->stream, d_off, (int)n_blocks, total, ts);
+        ZKW_TRY(launch_check("k_block_ids"));
+        // ts[] now holds block ids in ORIGINAL order; gather them through the current permutation
+        hipLaunchKernelGGL(k_gather_u32_by_u32, dim3(grid), dim3(256), 0, ctx->stream, ts, v0, total, k32);
+        ZKW_TRY(launch_check("k_gather_u32_by_u32"));
+        HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, k32, ts, v0, v1, total, bits, ctx->stream));
+        perm = v1;
+    }
+    *perm_out = perm;
+    return ZKW_OK;
+}
+
+static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, const uint32_t* n_nondet) {
+    const size_t n_blocks = w->offsets.size() - 1, total = w->total;
+    // K1 (unsorted side) — src/witness/oracle.rs:894-903 encodes each query as it is pushed
+    ZKW_TRY(dev_encode(ctx, d_q, total, w->unsorted_enc));
+    // K7 + K1 (sorted side)
+    u32* perm = nullptr;
+    ZKW_TRY(ram_sort(ctx, d_q, total, w->offsets, &perm));
+    hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, d_q, perm, total,
+                       w->sorted_q, w->sorted_enc);
+    ZKW_TRY(launch_check("k_gather_encode"));
+    // K2: 2 chains per block, all in one launch
+    std::vector<ChainJob> chains;
+    chains.reserve(2 * n_blocks);
+    for (size_t b = 0; b < n_blocks; b++) {
+        const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
+        chains.push_back(ChainJob{w->unsorted_enc + 8 * lo, w->unsorted_tails + 12 * lo, nullptr, n});
+        chains.push_back(ChainJob{w->sorted_enc + 8 * lo, w->sorted_tails + 12 * lo, nullptr, n});
+    }
+    ZKW_TRY(dev_chains(ctx, chains));
+    // K5: challenges from the two final tails (W/ram_permutation.rs:80-90)
+    std::vector<FsJob> fs(n_blocks);
+    for (size_t b = 0; b < n_blocks; b++) {
+        const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
+        fs[b] = FsJob{w->unsorted_tails + 12 * (lo + n - 1), w->sorted_tails + 12 * (lo + n - 1), (u32)n, (u32)n,
+                      w->challenges + 18 * b};
+    }
+    ZKW_TRY(dev_fs(ctx, fs, 12, 9));
+    // K6: both repetitions, both sides, every block in one launch set (W/ram_permutation.rs:115-138)
+    std::vector<GpSeg> segs;
+    segs.reserve(2 * n_blocks);
+    for (size_t b = 0; b < n_blocks; b++) {
+        const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
+        segs.push_back(GpSeg{w->unsorted_enc + 8 * lo, w->lhs_z + 2 * lo, w->challenges + 18 * b, n, 0, 0});
+        segs.push_back(GpSeg{w->sorted_enc + 8 * lo, w->rhs_z + 2 * lo, w->challenges + 18 * b, n, 0, 0});
+    }
+    ZKW_TRY(dev_grand_products(ctx, segs, 8, 2));
+    // a10: per-instance records
+    std::vector<RamBlock> blocks(n_blocks);
+    size_t max_inst = 0;
+    for (size_t b = 0; b < n_blocks; b++) {
+        const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
+        const size_t n_inst = w->inst_offsets[b + 1] - w->inst_offsets[b];
+        if (n_inst > max_inst) max_inst = n_inst;
+        blocks[b] = RamBlock{w->sorted_q + lo,
+                             w->unsorted_tails + 12 * lo,
+                             w->sorted_tails + 12 * lo,
+                             w->lhs_z + 2 * lo,
+                             w->rhs_z + 2 * lo,
+                             w->instances + w->inst_offsets[b],
+                             w->nondet_counts + w->inst_offsets[b],
+                             n,
+                             w->capacity,
+                             n_nondet ? n_nondet[b] : 0u};
+    }
+    RamBlock* d_blocks = nullptr;
+    ZKW_TRY(ctx->upload("ram_blocks", blocks, &d_blocks));
+    unsigned gx = (unsigned)(max_inst < 64 ? max_inst : 64);
+    hipLaunchKernelGGL(k_ram_count_nondet, dim3(gx, (unsigned)n_blocks), dim3(256), 0, ctx->stream, d_blocks);
+    ZKW_TRY(launch_check("k_ram_count_nondet"));
+    hipLaunchKernelGGL(k_ram_instances, dim3(blocks_for(max_inst, 64), (unsigned)n_blocks), dim3(64), 0, ctx->stream,
+                       d_blocks);
+    return launch_check("k_ram_instances");
+}
+
+extern "C" int zkw_ram_build_instances_batch(zkw_ctx* ctx, const zkw_mem_query* q, const uint64_t* block_offsets,
+                                             size_t n_blocks, uint32_t capacity, const uint32_t* n_nondet,
+                                             zkw_ram_witness** out) {
+    if (!ctx || !q || !block_offsets || !out || n_blocks == 0 || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_ram_build_instances_batch: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t base = block_offsets[0];
+    std::vector<uint64_t> offs(n_blocks + 1), ioffs(n_blocks + 1, 0);
+    for (size_t b = 0; b <= n_blocks; b++) offs[b] = block_offsets[b] - base;
+    for (size_t b = 0; b < n_blocks; b++) {
+        if (block_offsets[b + 1] <= block_offsets[b])
+            return fail(ZKW_ERR_INVALID, "block %zu is empty: the VM must have made memory requests "
+                                         "(W/ram_permutation.rs:43-46)", b);
+        ioffs[b + 1] = ioffs[b] + (offs[b + 1] - offs[b] + capacity - 1) / capacity;
+    }
+    const size_t total = offs[n_blocks];
+    if (total >= (1ull << 32)) return fail(ZKW_ERR_INVALID, "more than 2^32-1 queries in one batch");
+    zkw_ram_witness* w = *out;
+    if (w && (w->ctx != ctx || w->offsets != offs || w->capacity != capacity)) {
+        w->release();
+        delete w;
+        w = nullptr;
+        *out = nullptr;
+    }
+    if (!w) {
+        w = new zkw_ram_witness();
+        w->ctx = ctx;
+        w->offsets = offs;
+        w->inst_offsets = ioffs;
+        w->capacity = capacity;
+        w->total = total;
+        w->n_instances = ioffs[n_blocks];
+        int rc = ram_alloc(w, n_blocks);
+        if (rc != ZKW_OK) {
+            w->release();
+            delete w;
+            return rc;
+        }
+    }
+    const zkw_mem_query* d_q = nullptr;
+    int rc = ctx->in("ram_q", q + base, total, &d_q);
+    if (rc == ZKW_OK) rc = ram_run(ctx, w, d_q, n_nondet);
+    if (rc == ZKW_OK) rc = ctx->sync_if_host();
+    if (rc != ZKW_OK) {
+        if (!*out) {
+            w->release();
+            delete w;
+        }
+        return rc;
+    }
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" int zkw_ram_build_instances(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, uint32_t capacity,
+                                       uint32_t num_non_deterministic_heap_queries, zkw_ram_witness** out) {
+    uint64_t offsets[2] = {0, n};
+    return zkw_ram_build_instances_batch(ctx, q, offsets, 1, capacity, &num_non_deterministic_heap_queries, out);
+}
+
+extern "C" size_t zkw_ram_witness_num_instances(const zkw_ram_witness* w) { return w ? w->n_instances : 0; }
+extern "C" size_t zkw_ram_witness_num_items(const zkw_ram_witness* w) { return w ? w->total : 0; }
+
+static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes) {
+    const size_t t = w->total, nb = w->offsets.size() - 1;
+    switch (what) {
+        case ZKW_RAM_SORTED_QUERIES: *bytes = t * sizeof(zkw_mem_query); return w->sorted_q;
+        case ZKW_RAM_UNSORTED_ENC: *bytes = t * 64; return w->unsorted_enc;
+        case ZKW_RAM_SORTED_ENC: *bytes = t * 64; return w->sorted_enc;
+        case ZKW_RAM_UNSORTED_TAILS: *bytes = t * 96; return w->unsorted_tails;
+        case ZKW_RAM_SORTED_TAILS: *bytes = t * 96; return w->sorted_tails;
+        case ZKW_RAM_CHALLENGES: *bytes = nb * 18 * 8; return w->challenges;
+        case ZKW_RAM_LHS_Z: *bytes = t * 16; return w->lhs_z;
+        case ZKW_RAM_RHS_Z: *bytes = t * 16; return w->rhs_z;
+        case ZKW_RAM_INSTANCES: *bytes = w->n_instances * sizeof(zkw_ram_instance); return w->instances;
+        default: *bytes = 0; return nullptr;
+    }
+}
+
+extern "C" size_t zkw_ram_witness_bytes(const zkw_ram_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)ram_array(w, what, &b);
+    return b;
+}
+
+extern "C" const void* zkw_ram_witness_device_ptr(const zkw_ram_witness* w, int what) {
+    size_t b = 0;
+    return w ? ram_array(w, what, &b) : nullptr;
+}
+
+extern "C" int zkw_ram_witness_get(const zkw_ram_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: null argument");
+    size_t bytes = 0;
+    const void* src = ram_array(w, what, &bytes);
+    if (!src) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: unknown array %d", what);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: need %zu bytes, got %zu", bytes, dst_bytes);
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes,
+                           ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                           ctx->stream));
+    return ctx->sync_if_host();
+}
+
+extern "C" void zkw_ram_witness_free(zkw_ram_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    delete w;
+}

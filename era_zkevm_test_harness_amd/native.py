@@ -1,0 +1,248 @@
+"""ctypes binding of libzkw.so — the C ABI declared in include/zkw.h.
+
+This is the only way Python reaches the engine; there is no Python/CPU fallback: importing works
+anywhere (so that the symbol/ABI checks can run without a GPU), but `Context()` raises when the
+library is missing or no gfx950 device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkw.so")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_CHECK_FAILED = 0, -1, -2, -3, -4, -5
+PTR_HOST, PTR_DEVICE = 0, 1
+(RAM_SORTED_QUERIES, RAM_UNSORTED_ENC, RAM_SORTED_ENC, RAM_UNSORTED_TAILS, RAM_SORTED_TAILS, RAM_CHALLENGES,
+ RAM_LHS_Z, RAM_RHS_Z, RAM_INSTANCES) = range(9)
+
+# every symbol include/zkw.h declares: (name, restype, argtypes)
+_vp, _sz, _u32, _u64p, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_int
+SYMBOLS = [
+    ("zkw_create", _vp, [_int]),
+    ("zkw_destroy", None, [_vp]),
+    ("zkw_last_error", C.c_char_p, []),
+    ("zkw_set_stream", _int, [_vp, _vp]),
+    ("zkw_set_pointer_mode", _int, [_vp, _int]),
+    ("zkw_synchronize", _int, [_vp]),
+    ("zkw_version", C.c_char_p, []),
+    ("zkw_encode_memory_queries", _int, [_vp, _vp, _sz, _u64p]),
+    ("zkw_queue_push_chain_full", _int, [_vp, _u64p, _sz, _u64p, _u64p]),
+    ("zkw_queue_push_chain_full_batch", _int, [_vp, _u64p, _u64p, _sz, _u64p, _u64p]),
+    ("zkw_fs_challenges", _int, [_vp, _u64p, _u32, _u64p, _u32, _int, _int, _u64p]),
+    ("zkw_grand_product_chains", _int, [_vp, _u64p, _u64p, _sz, _int, _u64p, _int, _u64p, _u64p]),
+    ("zkw_ram_build_instances", _int, [_vp, _vp, _sz, _u32, _u32, C.POINTER(_vp)]),
+    ("zkw_ram_build_instances_batch", _int, [_vp, _vp, _u64p, _sz, _u32, _vp, C.POINTER(_vp)]),
+    ("zkw_ram_witness_num_instances", _sz, [_vp]),
+    ("zkw_ram_witness_num_items", _sz, [_vp]),
+    ("zkw_ram_witness_bytes", _sz, [_vp, _int]),
+    ("zkw_ram_witness_device_ptr", _vp, [_vp, _int]),
+    ("zkw_ram_witness_get", _int, [_vp, _int, _vp, _sz]),
+    ("zkw_ram_witness_free", None, [_vp]),
+]
+
+_lib = None
+
+
+class ZkwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libzkw error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """dlopen libzkw.so and type every exported symbol. Fails loudly when the extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZkwError(ERR_NO_DEVICE, f"{LIB_PATH} not built: run `python -m era_zkevm_test_harness_amd.build`")
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise ZkwError(rc, load().zkw_last_error().decode())
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+from .synthetic import MEM_QUERY  # noqa: E402
+
+QUEUE_STATE12 = np.dtype([("head", "<u8", (12,)), ("tail", "<u8", (12,)), ("length", "<u4"), ("_pad", "<u4")])
+RAM_FSM = np.dtype(
+    [("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)),
+     ("current_unsorted_queue_state", QUEUE_STATE12), ("current_sorted_queue_state", QUEUE_STATE12),
+     ("previous_sorting_key", "<u4", (3,)), ("previous_full_key", "<u4", (2,)), ("previous_value", "<u4", (8,)),
+     ("previous_is_ptr", "<u4"), ("num_nondeterministic_writes", "<u4"), ("_pad", "<u4")])
+RAM_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("unsorted_queue_initial_state", QUEUE_STATE12),
+     ("sorted_queue_initial_state", QUEUE_STATE12),
+     ("non_deterministic_bootloader_memory_snapshot_length", "<u4"), ("_pad", "<u4"),
+     ("hidden_fsm_input", RAM_FSM), ("hidden_fsm_output", RAM_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
+assert QUEUE_STATE12.itemsize == 200 and RAM_FSM.itemsize == 496 and RAM_INSTANCE.itemsize == 1424
+
+
+class RamWitness:
+    """Owner of a zkw_ram_witness handle (block-wide arrays + per-instance records, all in HBM)."""
+
+    _DTYPES = {RAM_SORTED_QUERIES: MEM_QUERY, RAM_INSTANCES: RAM_INSTANCE}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = C.c_void_p(None)
+
+    @property
+    def num_instances(self):
+        return load().zkw_ram_witness_num_instances(self.handle)
+
+    @property
+    def num_items(self):
+        return load().zkw_ram_witness_num_items(self.handle)
+
+    def device_ptr(self, what):
+        return load().zkw_ram_witness_device_ptr(self.handle, what)
+
+    def nbytes(self, what):
+        return load().zkw_ram_witness_bytes(self.handle, what)
+
+    def get(self, what):
+        """Copy one array to host memory as a numpy array."""
+        lib = load()
+        nbytes = lib.zkw_ram_witness_bytes(self.handle, what)
+        dt = self._DTYPES.get(what, np.dtype("<u8"))
+        out = np.zeros(nbytes // dt.itemsize, dt)
+        mode = self.ctx.pointer_mode
+        self.ctx.set_pointer_mode(PTR_HOST)
+        try:
+            _check(lib.zkw_ram_witness_get(self.handle, what, _np_ptr(out), nbytes))
+        finally:
+            self.ctx.set_pointer_mode(mode)
+        t = self.num_items
+        shape = {RAM_UNSORTED_ENC: (t, 8), RAM_SORTED_ENC: (t, 8), RAM_UNSORTED_TAILS: (t, 12),
+                 RAM_SORTED_TAILS: (t, 12), RAM_CHALLENGES: (-1, 2, 9)}.get(what)
+        return out.reshape(shape) if shape else out
+
+    def free(self):
+        if self.handle:
+            load().zkw_ram_witness_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """zkw_ctx: one per process / GPU."""
+
+    def __init__(self, device_id=0):
+        lib = load()
+        self.handle = lib.zkw_create(device_id)
+        if not self.handle:
+            raise ZkwError(ERR_NO_DEVICE, lib.zkw_last_error().decode())
+        self.pointer_mode = PTR_HOST
+
+    def close(self):
+        if self.handle:
+            load().zkw_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_pointer_mode(self, mode):
+        _check(load().zkw_set_pointer_mode(self.handle, mode))
+        self.pointer_mode = mode
+
+    def set_stream(self, stream_handle):
+        _check(load().zkw_set_stream(self.handle, stream_handle))
+
+    def synchronize(self):
+        _check(load().zkw_synchronize(self.handle))
+
+    # ---- host-pointer conveniences (numpy in, numpy out) mirroring the reference's function names
+    def encode_memory_queries(self, q):
+        """MemoryQuery::encoding_witness over an array of queries (memory_query.rs:24-118)."""
+        q = np.ascontiguousarray(q, dtype=MEM_QUERY)
+        enc = np.zeros((q.size, 8), np.uint64)
+        _check(load().zkw_encode_memory_queries(self.handle, _np_ptr(q), q.size, _np_ptr(enc)))
+        return enc
+
+    def queue_push_chain_full(self, enc, tail_in=None):
+        """FullWidthQueueSimulator pushes (lib.rs:391-429): returns tails [n][12]."""
+        enc = _u64(enc)
+        n = enc.shape[0]
+        tails = np.zeros((n, 12), np.uint64)
+        tin = None if tail_in is None else _np_ptr(_u64(tail_in))
+        _check(load().zkw_queue_push_chain_full(self.handle, _np_ptr(enc), n, tin, _np_ptr(tails)))
+        return tails
+
+    def queue_push_chain_full_batch(self, enc, offsets, tails_in=None):
+        enc = _u64(enc)
+        offsets = _u64(offsets)
+        tails = np.zeros((enc.shape[0], 12), np.uint64)
+        tin = None if tails_in is None else _np_ptr(_u64(tails_in))
+        _check(load().zkw_queue_push_chain_full_batch(self.handle, _np_ptr(enc), _np_ptr(offsets), offsets.size - 1,
+                                                      tin, _np_ptr(tails)))
+        return tails
+
+    def produce_fs_challenges(self, tail_u, len_u, tail_s, len_s, state_w, n_chal):
+        """produce_fs_challenges (utils.rs:498-550): [2][n_chal]."""
+        out = np.zeros((2, n_chal), np.uint64)
+        tu, ts = _u64(tail_u), _u64(tail_s)
+        _check(load().zkw_fs_challenges(self.handle, _np_ptr(tu), len_u, _np_ptr(ts), len_s, state_w, n_chal,
+                                        _np_ptr(out)))
+        return out
+
+    def compute_grand_product_chains(self, lhs, rhs, challenges):
+        """compute_grand_product_chains (utils.rs:554-697). challenges: [W+1] or [n_reps][W+1]."""
+        lhs, rhs, ch = _u64(lhs), _u64(rhs), _u64(challenges)
+        n, w = lhs.shape
+        single = ch.ndim == 1
+        ch2 = ch.reshape(1, -1) if single else ch
+        reps = ch2.shape[0]
+        assert ch2.shape[1] == w + 1 and rhs.shape == (n, w)
+        lz, rz = np.zeros((reps, n), np.uint64), np.zeros((reps, n), np.uint64)
+        _check(load().zkw_grand_product_chains(self.handle, _np_ptr(lhs), _np_ptr(rhs), n, w, _np_ptr(ch2), reps,
+                                               _np_ptr(lz), _np_ptr(rz)))
+        return (lz[0], rz[0]) if single else (lz, rz)
+
+    def compute_ram_circuit_snapshots(self, queries, per_circuit_capacity, num_non_deterministic_heap_queries=0,
+                                      block_offsets=None, witness=None):
+        """compute_ram_circuit_snapshots (W/ram_permutation.rs:26-470) for one block, or for several
+        independent blocks when block_offsets is given. Returns a RamWitness."""
+        lib = load()
+        w = witness or RamWitness(self)
+        if self.pointer_mode == PTR_HOST:
+            queries = np.ascontiguousarray(queries, dtype=MEM_QUERY)
+            qptr, n = _np_ptr(queries), queries.size
+        else:
+            qptr, n = queries  # (device address, count)
+        if block_offsets is None:
+            nd = num_non_deterministic_heap_queries
+            _check(lib.zkw_ram_build_instances(self.handle, qptr, n, per_circuit_capacity, nd, C.byref(w.handle)))
+        else:
+            offs = _u64(block_offsets)
+            nb = offs.size - 1
+            nd = np.ascontiguousarray(np.broadcast_to(np.asarray(num_non_deterministic_heap_queries, np.uint32), (nb,)))
+            _check(lib.zkw_ram_build_instances_batch(self.handle, qptr, _np_ptr(offs), nb, per_circuit_capacity,
+                                                     _np_ptr(nd), C.byref(w.handle)))
+        return w

@@ -1,0 +1,114 @@
+/* zkw.h — C ABI of libzkw, the MI355X-native witness-generation / constraint-synthesis engine for the
+ * zkSync Era base-layer circuits (hot path of matter-labs/era-zkevm_test_harness).
+ *
+ * This is the drop-in boundary: a Rust host keeps `circuit_sequencer_api`, `external_calls::run` and
+ * `prover_utils` and binds these symbols with `extern "C"`. Every entry point
+ * names the reference function it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - status: 0 = ok, < 0 = error; text via zkw_last_error() (thread-local). Nothing panics or throws
+ *     across the boundary (the reference panics/asserts: src/witness/utils.rs:654-696).
+ *   - field elements: canonical (< p) little-endian uint64_t, p = 2^64 - 2^32 + 1.
+ *   - bulk pointers are HOST pointers by default; after zkw_set_pointer_mode(ctx, ZKW_PTR_DEVICE) they
+ *     are device (HBM) pointers and no staging copy is made. Small descriptor arrays documented as
+ *     "host" are always host pointers.
+ *   - all work is enqueued on the context's HIP stream (zkw_set_stream); calls that return data to
+ *     host memory synchronise that stream before returning, device-mode calls do not.
+ *   - there is no CPU fallback: every call fails with ZKW_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef ZKW_H
+#define ZKW_H
+#include "zkw_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zkw_ctx zkw_ctx;
+typedef struct zkw_ram_witness zkw_ram_witness;
+
+enum {
+    ZKW_OK = 0,
+    ZKW_ERR_INVALID = -1,
+    ZKW_ERR_NO_DEVICE = -2,
+    ZKW_ERR_HIP = -3,
+    ZKW_ERR_OOM = -4,
+    ZKW_ERR_CHECK_FAILED = -5 /* a self-check of the reference failed (e.g. lhs != rhs grand product) */
+};
+
+enum { ZKW_PTR_HOST = 0, ZKW_PTR_DEVICE = 1 };
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* device_id >= 0. Returns NULL on failure (see zkw_last_error). */
+zkw_ctx *zkw_create(int device_id);
+void zkw_destroy(zkw_ctx *ctx);
+const char *zkw_last_error(void);
+int zkw_set_stream(zkw_ctx *ctx, void *hip_stream /* hipStream_t, NULL = the context's own stream */);
+int zkw_set_pointer_mode(zkw_ctx *ctx, int mode);
+int zkw_synchronize(zkw_ctx *ctx);
+/* library/ABI version and the kernels' target ISA ("gfx950") */
+const char *zkw_version(void);
+
+/* ---- L1 primitives ------------------------------------------------------------------------------ */
+/* MemoryQuery::encoding_witness, circuit_encodings/src/memory_query.rs:24-118. enc: [n][8]. */
+int zkw_encode_memory_queries(zkw_ctx *ctx, const zkw_mem_query *q, size_t n, uint64_t *enc);
+
+/* FullWidthQueueSimulator::push_and_output_intermediate_data applied to n items in order,
+   circuit_encodings/src/lib.rs:391-429 (memory queue: src/witness/oracle.rs:894-903).
+   tails[i] = sponge state after item i; tail_in = state before item 0 (NULL = empty queue). */
+int zkw_queue_push_chain_full(zkw_ctx *ctx, const uint64_t *enc /* [n][8] */, size_t n,
+                              const uint64_t tail_in[12], uint64_t *tails /* [n][12] */);
+/* n_queues independent queues in one launch: queue k owns items [offsets[k], offsets[k+1]).
+   offsets: host, n_queues+1 entries. tails_in: [n_queues][12] or NULL. */
+int zkw_queue_push_chain_full_batch(zkw_ctx *ctx, const uint64_t *enc, const uint64_t *offsets,
+                                    size_t n_queues, const uint64_t *tails_in, uint64_t *tails);
+
+/* produce_fs_challenges, src/witness/utils.rs:498-550. state_w = 12 (RAM, decommit sorter) or 4
+   (storage / events sorters); out: [2 repetitions][n_chal], out[r][0] = 1. */
+int zkw_fs_challenges(zkw_ctx *ctx, const uint64_t *tail_u, uint32_t len_u, const uint64_t *tail_s,
+                      uint32_t len_s, int state_w, int n_chal, uint64_t *out);
+
+/* compute_grand_product_chains, src/witness/utils.rs:554-697, for n_reps (1 or 2) challenge sets in
+   one pass over the rows. lhs, rhs: [n][width] (width 8 or 20); challenges: [n_reps][width+1];
+   lhs_z, rhs_z: [n_reps][n]. Returns ZKW_ERR_CHECK_FAILED when a final lhs product differs from the
+   rhs one (utils.rs:685-696) — only checked in host pointer mode (device mode never syncs). */
+int zkw_grand_product_chains(zkw_ctx *ctx, const uint64_t *lhs, const uint64_t *rhs, size_t n, int width,
+                             const uint64_t *challenges, int n_reps, uint64_t *lhs_z, uint64_t *rhs_z);
+
+/* ---- RAM permutation witness builder ------------------------------------------------------------ */
+/* compute_ram_circuit_snapshots, src/witness/individual_circuits/ram_permutation.rs:26-470, for one
+   block's memory queue (q in queue order). *out must be NULL or a witness previously returned for the
+   same shape (its buffers are reused). */
+int zkw_ram_build_instances(zkw_ctx *ctx, const zkw_mem_query *q, size_t n, uint32_t capacity,
+                            uint32_t num_non_deterministic_heap_queries, zkw_ram_witness **out);
+/* The same for n_blocks independent memory queues (one per block being proven) in one pass:
+   block b owns q[block_offsets[b] .. block_offsets[b+1]). block_offsets / n_nondet: host arrays. */
+int zkw_ram_build_instances_batch(zkw_ctx *ctx, const zkw_mem_query *q, const uint64_t *block_offsets,
+                                  size_t n_blocks, uint32_t capacity, const uint32_t *n_nondet,
+                                  zkw_ram_witness **out);
+
+enum {
+    ZKW_RAM_SORTED_QUERIES = 0, /* zkw_mem_query[total]           */
+    ZKW_RAM_UNSORTED_ENC = 1,   /* uint64_t[total][8]             */
+    ZKW_RAM_SORTED_ENC = 2,     /* uint64_t[total][8]             */
+    ZKW_RAM_UNSORTED_TAILS = 3, /* uint64_t[total][12]            */
+    ZKW_RAM_SORTED_TAILS = 4,   /* uint64_t[total][12]            */
+    ZKW_RAM_CHALLENGES = 5,     /* uint64_t[n_blocks][2][9]       */
+    ZKW_RAM_LHS_Z = 6,          /* per block b: uint64_t[2][n_b] at element offset 2*block_offsets[b] */
+    ZKW_RAM_RHS_Z = 7,          /* idem                           */
+    ZKW_RAM_INSTANCES = 8       /* zkw_ram_instance[n_instances], blocks in order */
+};
+size_t zkw_ram_witness_num_instances(const zkw_ram_witness *w);
+size_t zkw_ram_witness_num_items(const zkw_ram_witness *w);
+/* size in bytes of one of the arrays above */
+size_t zkw_ram_witness_bytes(const zkw_ram_witness *w, int what);
+/* device (HBM) address of the array; valid until the witness is freed or rebuilt */
+const void *zkw_ram_witness_device_ptr(const zkw_ram_witness *w, int what);
+/* copy an array out (to host memory, or to a device buffer in ZKW_PTR_DEVICE mode) */
+int zkw_ram_witness_get(const zkw_ram_witness *w, int what, void *dst, size_t dst_bytes);
+void zkw_ram_witness_free(zkw_ram_witness *w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKW_H */

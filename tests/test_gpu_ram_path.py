@@ -1,0 +1,183 @@
+"""GPU parity: every entry point of the RAM-permutation path through the C ABI vs the CPU oracle,
+bit-exact (integer arithmetic mod p), on seeded inputs, including ragged / edge shapes."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from era_zkevm_test_harness_amd import native
+
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 70001])
+def test_encode(ctx, oracle, n):
+    q = synthetic.ram_trace(n, seed=n)
+    q["value"][0] = 0xFFFFFFFF
+    assert np.array_equal(ctx.encode_memory_queries(q), oracle.encode_memory_queries(q))
+
+
+def test_poseidon2_cooperative_and_lane_forms_match_oracle(ctx, oracle):
+    # chain of length 1 from the zero tail == one permutation of (enc || 0000)
+    enc = synthetic.random_field_elements(5, (7, 8))
+    enc[0] = 0
+    enc[1] = P - 1
+    offsets = np.arange(8, dtype=np.uint64)  # 7 queues of one item: exercises all 4 DPP rows + a ragged wave
+    got = ctx.queue_push_chain_full_batch(enc, offsets)
+    for k in range(7):
+        s = np.zeros(12, np.uint64)
+        s[:8] = enc[k]
+        assert np.array_equal(got[k], oracle.poseidon2(s)), k
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 500])
+def test_queue_chain(ctx, oracle, n):
+    enc = synthetic.random_field_elements(100 + n, (n, 8))
+    assert np.array_equal(ctx.queue_push_chain_full(enc), oracle.queue_push_chain_full(enc))
+    tin = synthetic.random_field_elements(7, (12,))
+    assert np.array_equal(ctx.queue_push_chain_full(enc, tin), oracle.queue_push_chain_full(enc, tin))
+
+
+def test_queue_chain_batch_ragged(ctx, oracle):
+    lens = [5, 0, 33, 1, 64, 7, 12, 3, 100]  # 9 queues: two full waves + a partial one, one empty queue
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    enc = synthetic.random_field_elements(77, (int(offsets[-1]), 8))
+    tins = synthetic.random_field_elements(78, (len(lens), 12))
+    got = ctx.queue_push_chain_full_batch(enc, offsets, tins)
+    for k, ln in enumerate(lens):
+        lo = int(offsets[k])
+        if ln:
+            assert np.array_equal(got[lo:lo + ln], oracle.queue_push_chain_full(enc[lo:lo + ln], tins[k])), k
+
+
+@pytest.mark.parametrize("state_w,n_chal", [(12, 9), (4, 21)])
+def test_fs_challenges(ctx, oracle, state_w, n_chal):
+    tu = synthetic.random_field_elements(21, (state_w,))
+    ts = synthetic.random_field_elements(22, (state_w,))
+    got = ctx.produce_fs_challenges(tu, 136714, ts, 136714, state_w, n_chal)
+    assert np.array_equal(got, oracle.fs_challenges(tu, 136714, ts, 136714, state_w, n_chal))
+
+
+@pytest.mark.parametrize("n,width", [(1, 8), (255, 8), (1024, 8), (1025, 8), (136714, 8), (46921, 20)])
+def test_grand_product(ctx, oracle, n, width):
+    lhs = synthetic.random_field_elements(31 + n, (n, width))
+    rhs = lhs[np.random.default_rng(5).permutation(n)]
+    ch = synthetic.random_field_elements(32, (2, width + 1))
+    lz, rz = ctx.compute_grand_product_chains(lhs, rhs, ch)
+    for r in range(2):
+        rc, olz, orz = oracle.grand_product_chains(lhs, rhs, ch[r])
+        assert rc == 0
+        assert np.array_equal(lz[r], olz) and np.array_equal(rz[r], orz)
+    l1, r1 = ctx.compute_grand_product_chains(lhs, rhs, ch[1])
+    assert np.array_equal(l1, lz[1]) and np.array_equal(r1, rz[1])
+
+
+def test_grand_product_detects_non_permutation(ctx):
+    from era_zkevm_test_harness_amd import native
+
+    lhs = synthetic.random_field_elements(1, (100, 8))
+    rhs = lhs.copy()
+    rhs[3, 2] = (int(rhs[3, 2]) + 1) % P
+    with pytest.raises(native.ZkwError) as ei:
+        ctx.compute_grand_product_chains(lhs, rhs, synthetic.random_field_elements(2, (9,)))
+    assert ei.value.code == native.ERR_CHECK_FAILED
+
+
+def _assert_witness_equal(w, o, native):
+    assert np.array_equal(w.get(native.RAM_SORTED_QUERIES), o["sorted_q"])
+    assert np.array_equal(w.get(native.RAM_UNSORTED_ENC), o["unsorted_enc"])
+    assert np.array_equal(w.get(native.RAM_SORTED_ENC), o["sorted_enc"])
+    assert np.array_equal(w.get(native.RAM_UNSORTED_TAILS), o["unsorted_tails"])
+    assert np.array_equal(w.get(native.RAM_SORTED_TAILS), o["sorted_tails"])
+    assert np.array_equal(w.get(native.RAM_CHALLENGES)[0], o["challenges"])
+    n = o["sorted_q"].size
+    assert np.array_equal(w.get(native.RAM_LHS_Z).reshape(2, n), o["lhs_z"])
+    assert np.array_equal(w.get(native.RAM_RHS_Z).reshape(2, n), o["rhs_z"])
+    gi, oi = w.get(native.RAM_INSTANCES), o["instances"]
+    assert gi.size == oi.size
+    assert gi.tobytes() == oi.tobytes()
+
+
+@pytest.mark.parametrize("n,capacity", [(1, 4), (64, 64), (1000, 128), (8192, 2048), (8192, 8192), (5000, 136714)])
+def test_ram_builder(ctx, oracle, n, capacity):
+    from era_zkevm_test_harness_amd import native
+
+    q = synthetic.ram_trace(n, seed=1000 + n)
+    k = min(n, 3)
+    q["page"][:k] = 10
+    q["timestamp"][:k] = 0
+    q["rw_flag"][:k] = 1
+    w = ctx.compute_ram_circuit_snapshots(q, capacity, 3)
+    o = oracle.ram_build_instances(q, capacity, 3)
+    assert w.num_instances == o["instances"].size
+    _assert_witness_equal(w, o, native)
+    w.free()
+
+
+def test_ram_builder_duplicate_keys_is_stable(ctx, oracle):
+    from era_zkevm_test_harness_amd import native
+
+    q = synthetic.ram_trace(3000, seed=4, pages=2, indices=4)
+    q["timestamp"] = q["timestamp"] // 8  # many (cell, ts) collisions: order must follow the stable sort
+    w = ctx.compute_ram_circuit_snapshots(q, 512, 0)
+    _assert_witness_equal(w, oracle.ram_build_instances(q, 512, 0), native)
+    w.free()
+
+
+def test_ram_builder_batch_of_blocks(ctx, oracle):
+    from era_zkevm_test_harness_amd import native
+
+    lens = [700, 1, 4096, 333, 2500]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    q = np.concatenate([synthetic.ram_trace(ln, seed=50 + i) for i, ln in enumerate(lens)])
+    w = ctx.compute_ram_circuit_snapshots(q, 1024, [0, 1, 2, 3, 4], block_offsets=offs)
+    sq, ue, se = w.get(native.RAM_SORTED_QUERIES), w.get(native.RAM_UNSORTED_ENC), w.get(native.RAM_SORTED_ENC)
+    ut, st = w.get(native.RAM_UNSORTED_TAILS), w.get(native.RAM_SORTED_TAILS)
+    ch, lz, rz, inst = (w.get(native.RAM_CHALLENGES), w.get(native.RAM_LHS_Z), w.get(native.RAM_RHS_Z),
+                        w.get(native.RAM_INSTANCES))
+    i0 = 0
+    for b, ln in enumerate(lens):
+        lo = int(offs[b])
+        o = oracle.ram_build_instances(q[lo:lo + ln], 1024, b)
+        assert np.array_equal(sq[lo:lo + ln], o["sorted_q"]), b
+        assert np.array_equal(ue[lo:lo + ln], o["unsorted_enc"]) and np.array_equal(se[lo:lo + ln], o["sorted_enc"])
+        assert np.array_equal(ut[lo:lo + ln], o["unsorted_tails"]) and np.array_equal(st[lo:lo + ln], o["sorted_tails"])
+        assert np.array_equal(ch[b], o["challenges"])
+        assert np.array_equal(lz[2 * lo:2 * (lo + ln)].reshape(2, ln), o["lhs_z"])
+        assert np.array_equal(rz[2 * lo:2 * (lo + ln)].reshape(2, ln), o["rhs_z"])
+        k = o["instances"].size
+        assert inst[i0:i0 + k].tobytes() == o["instances"].tobytes()
+        i0 += k
+    assert i0 == w.num_instances
+    w.free()
+
+
+def test_full_size_properties(ctx):
+    """Production capacity (136 714 queries, BASELINE config geometry): size-independent properties."""
+    from era_zkevm_test_harness_amd import native
+
+    n = 136714
+    q = synthetic.ram_trace(2 * n + 11, seed=2)
+    w = ctx.compute_ram_circuit_snapshots(q, n, 0)
+    assert w.num_instances == 3
+    inst = w.get(native.RAM_INSTANCES)
+    sq = w.get(native.RAM_SORTED_QUERIES)
+    key = (sq["page"].astype(np.uint64) << np.uint64(32)) | sq["index"]
+    assert np.all(key[1:] >= key[:-1])
+    fo = inst[-1]["hidden_fsm_output"]
+    assert np.array_equal(fo["lhs_accumulator"], fo["rhs_accumulator"])  # the permutation argument closes
+    assert np.array_equal(inst[1]["hidden_fsm_input"]["lhs_accumulator"], inst[0]["hidden_fsm_output"]["lhs_accumulator"])
+    assert not np.array_equal(inst[0]["hidden_fsm_output"]["lhs_accumulator"], inst[0]["hidden_fsm_output"]["rhs_accumulator"])
+    ut = w.get(native.RAM_UNSORTED_TAILS)
+    assert np.array_equal(inst[0]["hidden_fsm_output"]["current_unsorted_queue_state"]["head"], ut[n - 1])
+    assert int(ut.max()) < P
+    w.free()
