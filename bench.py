@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""bench.py — base-layer circuits/s for the RAM-permutation hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch: B independent blocks' memory queues (each at the
+production RAMPermutation capacity, 136 714 queries = one 2^20-row instance) go through witness
+generation (encode, sort, both Poseidon2 queue chains, Fiat-Shamir challenges, grand products, instance
+records) [+ synthesis of each instance's trace once that row of SURVEY section 8 lands]. Inputs are
+resident in HBM before the timed region. N > 1: one process per GPU, blocks sharded with no data-path
+collective; the per-instance closed-form records are gathered to rank 0 (RCCL) inside the timed region.
+
+Prints ONE JSON line (rank 0). See DESIGN.md "Measurement" for the roofline/cpu_baseline definitions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from era_zkevm_test_harness_amd import native, parallel, synthetic  # noqa: E402
+
+CAPACITY = 136714  # cycles_per_ram_permutation, circuit_sequencer_api/src/geometry_config.rs:12
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_inputs(blocks, n, rank, dev):
+    """B valid memory traces in HBM: one seeded base trace, each block's values XOR-ed with its own
+    256-bit mask (stays a valid memory: a read still returns the last written value of its cell)."""
+    base = synthetic.ram_trace(n, seed=2 + rank)
+    qb = torch.from_numpy(base.view(np.int32).reshape(n, 12).copy()).to(dev)
+    q = qb.unsqueeze(0).repeat(blocks, 1, 1)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    masks = torch.randint(-2**31, 2**31 - 1, (blocks, 1, 8), generator=g, dtype=torch.int64).to(torch.int32).to(dev)
+    q[:, :, 4:12] ^= masks
+    return base, q.contiguous()
+
+
+def cpu_baseline(base, sample_blocks):
+    """The oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded sample."""
+    from oracle import pyoracle
+
+    pyoracle.build()
+    pyoracle.ram_build_instances(base[:2048], 2048, 0)  # warm
+    t0 = time.perf_counter()
+    for _ in range(sample_blocks):
+        pyoracle.ram_build_instances(base, CAPACITY, 0)
+    dt = time.perf_counter() - t0
+    return {"value": sample_blocks / dt, "unit": "circuits/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_blocks} RAMPermutation instance(s) of {CAPACITY} queries, witness generation, "
+                      f"oracle/liboracle.so single thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=256, help="independent memory queues per GPU per step")
+    ap.add_argument("--queries", type=int, default=CAPACITY)
+    ap.add_argument("--cpu-sample", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = parallel.init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ctx = native.Context(local_rank)  # raises if libzkw / the GPU is missing: no fallback
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_pointer_mode(native.PTR_DEVICE)
+
+    B, n = args.blocks, args.queries
+    base, q = make_inputs(B, n, rank, dev)
+    offs = np.arange(B + 1, dtype=np.uint64) * n
+    w = native.RamWitness(ctx)
+    inst_bytes = native.RAM_INSTANCE.itemsize
+    n_inst_local = B * (-(-n // CAPACITY))
+    records = torch.empty((n_inst_local, inst_bytes), dtype=torch.uint8, device=dev)
+    counts = [n_inst_local] * world
+
+    def step():
+        ctx.compute_ram_circuit_snapshots((q.data_ptr(), B * n), CAPACITY, 0, block_offsets=offs, witness=w)
+        native._check(native.load().zkw_ram_witness_get(w.handle, native.RAM_INSTANCES, records.data_ptr(),
+                                                        records.numel()))
+        return parallel.gather_records(records, counts, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    prof = ctx.profile()
+    ctx.profile_enable(False)
+
+    if rank == 0:
+        assert gathered.shape[0] == n_inst_local * world
+        circuits = n_inst_local * world * args.steps
+        # dominant kernel by time, with its algorithmic HBM bytes per launch (DESIGN.md "Measurement")
+        items = B * n
+        alg_bytes = {
+            "k_chain_full": 2 * items * (64 + 96),            # per chain item: 8 words in, 12 words out
+            "k_gp_local": 2 * items * (64 + 16),              # rows read once, both repetitions written
+            "k_gp_apply": 2 * items * 32,
+            "k_encode_mem": items * (48 + 64),
+            "k_gather_encode": items * (48 + 4 + 48 + 64),
+        }
+        name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+        avg_ms = ms / max(cnt, 1)
+        ab = alg_bytes.get(name)
+        achieved = (ab / (avg_ms * 1e-3) / 1e9) if ab else None
+        chain_ms, chain_cnt = prof.get("k_chain_full", (0.0, 1))
+        out = {
+            "metric": "base-layer circuits/sec (2^20 rows)",
+            "value": circuits / dt,
+            "unit": "circuits/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 (Goldilocks, p = 2^64 - 2^32 + 1)",
+            "data": "synthetic",
+            "config": {"workload": f"RAMPermutation base circuit, capacity {CAPACITY} (2^20-row geometry), "
+                                   f"{B} independent memory queues per GPU per step, witness generation",
+                       "blocks_per_gpu": B, "queries_per_block": n, "parallelism": f"instances sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "avg_launch_ms": avg_ms,
+                         "note": "k_chain_full is a serial Poseidon2 chain per queue: latency/VALU-bound, "
+                                 "permutations/s is its meaningful rate"},
+            "poseidon2_perm_per_s": 2 * items * chain_cnt / (chain_ms * 1e-3) if chain_ms else None,
+            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(base, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    parallel.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

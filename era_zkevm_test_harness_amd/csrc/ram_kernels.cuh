@@ -85,26 +85,6 @@ __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ 
     }
 }
 
-// One chain per lane (64 chains per wave): the throughput-oriented form, used when there are at least
-// `coop_threshold` chains (see Context::chain_launch).
-__global__ __launch_bounds__(64) void k_chain_full_lane(const ChainJob* __restrict__ jobs, int n_jobs) {
-    const int chain = blockIdx.x * 64 + threadIdx.x;
-    if (chain >= n_jobs) return;
-    ChainJob job = jobs[chain];
-    u64 s[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = job.tail_in ? job.tail_in[k] : 0;
-    for (u64 i = 0; i < job.n; i++) {
-        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(job.enc + 8 * i);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { ulonglong2 w = src[k]; s[2 * k] = w.x; s[2 * k + 1] = w.y; }
-        p2::permute(s);
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(job.tails + 12 * i);
-#pragma unroll
-        for (int k = 0; k < 6; k++) dst[k] = make_ulonglong2(gl::canon(s[2 * k]), gl::canon(s[2 * k + 1]));
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K5: Fiat-Shamir challenges, one job per lane (a handful of permutations; latency-irrelevant).
 struct FsJob {
@@ -363,7 +343,7 @@ __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
     const u64 n_inst = (b.n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_inst) return;
-    const u64 n = b.n, lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n, last = hi - 1;
+    const u64 n = b.n, lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n;
     zkw_ram_instance w;
     memset(&w, 0, sizeof w);
     w.start_flag = idx == 0;

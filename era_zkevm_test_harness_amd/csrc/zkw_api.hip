@@ -67,6 +67,35 @@ struct zkw_ctx {
     int ptr_mode = ZKW_PTR_HOST;
     std::map<std::string, DevBuf> pool;  // named grow-only scratch
     std::map<std::string, HostStage> stages;
+    // optional per-kernel timing with HIP events on the context's stream (zkw_profile_*)
+    bool profiling = false;
+    struct ProfSpan { const char* name; hipEvent_t a, b; };
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> free_events;
+    std::map<std::string, std::pair<double, uint64_t>> prof_totals;  // name -> (ms, launches)
+
+    hipEvent_t prof_event() {
+        if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    int prof_collect() {
+        if (spans.empty()) return ZKW_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (auto& sp : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+                auto& t = prof_totals[sp.name];
+                t.first += ms;
+                t.second += 1;
+            }
+            free_events.push_back(sp.a);
+            free_events.push_back(sp.b);
+        }
+        spans.clear();
+        return ZKW_OK;
+    }
 
     int scratch(const char* name, size_t bytes, void** out) {
         DevBuf& b = pool[name];
@@ -151,6 +180,22 @@ struct zkw_ctx {
     }
 };
 
+// RAII span around one kernel launch (or a library sort); free when profiling is off
+struct Prof {
+    zkw_ctx* c;
+    hipEvent_t b = nullptr;
+    Prof(zkw_ctx* ctx, const char* name) : c(ctx) {
+        if (!c->profiling) return;
+        hipEvent_t a = c->prof_event();
+        b = c->prof_event();
+        (void)hipEventRecord(a, c->stream);
+        c->spans.push_back(zkw_ctx::ProfSpan{name, a, b});
+    }
+    ~Prof() {
+        if (b) (void)hipEventRecord(b, c->stream);
+    }
+};
+
 static int launch_check(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ZKW_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
@@ -203,6 +248,8 @@ extern "C" void zkw_destroy(zkw_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->pool)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     for (auto& kv : ctx->stages) {
         if (kv.second.p) (void)hipHostFree(kv.second.p);
         if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
@@ -230,6 +277,39 @@ extern "C" int zkw_synchronize(zkw_ctx* ctx) {
     return ZKW_OK;
 }
 
+extern "C" int zkw_profile_enable(zkw_ctx* ctx, int on) {
+    if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
+    ZKW_TRY(ctx->prof_collect());
+    ctx->profiling = on != 0;
+    return ZKW_OK;
+}
+
+extern "C" int zkw_profile_reset(zkw_ctx* ctx) {
+    if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
+    ZKW_TRY(ctx->prof_collect());
+    ctx->prof_totals.clear();
+    return ZKW_OK;
+}
+
+extern "C" int zkw_profile_get(zkw_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches) {
+    if (!ctx || !kernel) return fail(ZKW_ERR_INVALID, "null argument");
+    ZKW_TRY(ctx->prof_collect());
+    auto it = ctx->prof_totals.find(kernel);
+    if (total_ms) *total_ms = it == ctx->prof_totals.end() ? 0.0 : it->second.first;
+    if (launches) *launches = it == ctx->prof_totals.end() ? 0 : it->second.second;
+    return ZKW_OK;
+}
+
+extern "C" int zkw_profile_names(zkw_ctx* ctx, char* buf, size_t buf_bytes) {
+    if (!ctx || !buf || !buf_bytes) return fail(ZKW_ERR_INVALID, "null argument");
+    ZKW_TRY(ctx->prof_collect());
+    std::string all;
+    for (auto& kv : ctx->prof_totals) { if (!all.empty()) all += ","; all += kv.first; }
+    if (all.size() + 1 > buf_bytes) return fail(ZKW_ERR_INVALID, "buffer too small: need %zu bytes", all.size() + 1);
+    memcpy(buf, all.c_str(), all.size() + 1);
+    return ZKW_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ device-level steps
 // (all pointers are device pointers here)
 
@@ -237,24 +317,19 @@ static int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) 
     if (n == 0) return ZKW_OK;
     unsigned grid = blocks_for(n, 256);
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(k_encode_mem, dim3(grid), dim3(256), 0, ctx->stream, q, n, enc);
+    { Prof _p(ctx, "k_encode_mem"); hipLaunchKernelGGL(k_encode_mem, dim3(grid), dim3(256), 0, ctx->stream, q, n, enc); }
     return launch_check("k_encode_mem");
 }
 
-// Chains: the 16-lane cooperative kernel minimises latency (few chains); one-chain-per-lane maximises
-// throughput once there are enough chains to fill the SIMDs with full waves.
-static constexpr int kLaneChainThreshold = 64 * 1024;
-
+// Chains: one chain per 16-lane DPP row, 4 chains per wave, one wave per block. A single wave already
+// issues a VALU instruction every ~2 cycles (measured 3.7 us per permutation step, flat from 1 to 4096
+// concurrent chains), so throughput comes from giving each wave its own SIMD: up to 1024 waves.
 static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     if (jobs.empty()) return ZKW_OK;
     ChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("chain_jobs", jobs, &d_jobs));
     int n_jobs = (int)jobs.size();
-    if (n_jobs >= kLaneChainThreshold) {
-        hipLaunchKernelGGL(k_chain_full_lane, dim3((n_jobs + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, n_jobs);
-        return launch_check("k_chain_full_lane");
-    }
-    hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, ctx->stream, d_jobs, n_jobs);
+    { Prof _p(ctx, "k_chain_full"); hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, ctx->stream, d_jobs, n_jobs); }
     return launch_check("k_chain_full");
 }
 
@@ -263,19 +338,19 @@ static int dev_fs(zkw_ctx* ctx, const std::vector<FsJob>& jobs, int state_w, int
     FsJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("fs_jobs", jobs, &d_jobs));
     int n = (int)jobs.size();
-    hipLaunchKernelGGL(k_fs_challenges, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, n, state_w, n_chal);
+    { Prof _p(ctx, "k_fs_challenges"); hipLaunchKernelGGL(k_fs_challenges, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, n, state_w, n_chal); }
     return launch_check("k_fs_challenges");
 }
 
 template <int W, int REPS>
 static int gp_launch(zkw_ctx* ctx, const GpSeg* d_segs, int n_segs, const GpTile* d_tiles, unsigned n_tiles,
                      u64* d_aggr) {
-    hipLaunchKernelGGL((k_gp_local<W, REPS>), dim3(n_tiles), dim3(GP_BLOCK), 0, ctx->stream, d_segs, d_tiles, d_aggr);
+    { Prof _p(ctx, "k_gp_local"); hipLaunchKernelGGL((k_gp_local<W, REPS>), dim3(n_tiles), dim3(GP_BLOCK), 0, ctx->stream, d_segs, d_tiles, d_aggr); }
     ZKW_TRY(launch_check("k_gp_local"));
-    hipLaunchKernelGGL((k_gp_tiles<REPS>), dim3((n_segs * REPS + 63) / 64), dim3(64), 0, ctx->stream, d_segs, n_segs,
-                       d_aggr);
+    { Prof _p(ctx, "k_gp_tiles"); hipLaunchKernelGGL((k_gp_tiles<REPS>), dim3((n_segs * REPS + 63) / 64), dim3(64), 0, ctx->stream, d_segs, n_segs,
+                       d_aggr); }
     ZKW_TRY(launch_check("k_gp_tiles"));
-    hipLaunchKernelGGL((k_gp_apply<REPS>), dim3(n_tiles), dim3(GP_BLOCK), 0, ctx->stream, d_segs, d_tiles, d_aggr);
+    { Prof _p(ctx, "k_gp_apply"); hipLaunchKernelGGL((k_gp_apply<REPS>), dim3(n_tiles), dim3(GP_BLOCK), 0, ctx->stream, d_segs, d_tiles, d_aggr); }
     return launch_check("k_gp_apply");
 }
 
@@ -466,15 +541,15 @@ static int ram_sort(zkw_ctx* ctx, const zkw_mem_query* d_q, size_t total, const 
     ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", total, &k64b));
     ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
     const unsigned grid = blocks_for(total, 256);
-    hipLaunchKernelGGL(k_ram_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, total, ts, cell, v0,
-                       (const u64*)nullptr, 0);
+    { Prof _p(ctx, "k_ram_sort_keys"); hipLaunchKernelGGL(k_ram_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, total, ts, cell, v0,
+                       (const u64*)nullptr, 0); }
     ZKW_TRY(launch_check("k_ram_sort_keys"));
     // pass 1: timestamp
-    HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, ts, k32, v0, v1, total, 32, ctx->stream));
+    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, ts, k32, v0, v1, total, 32, ctx->stream)); }
     // pass 2: cell of the ts-sorted items
-    hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, cell, v1, total, k64a);
+    { Prof _p(ctx, "k_gather_u64_by_u32"); hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, cell, v1, total, k64a); }
     ZKW_TRY(launch_check("k_gather_u64_by_u32"));
-    HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, v1, v0, total, 64, ctx->stream));
+    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, v1, v0, total, 64, ctx->stream)); }
     u32* perm = v0;
     if (n_blocks > 1) {
         // pass 3: block id, so that each block's items end up contiguous again
@@ -482,12 +557,12 @@ static int ram_sort(zkw_ctx* ctx, const zkw_mem_query* d_q, size_t total, const 
         ZKW_TRY(ctx->upload("sort_off", offsets, &d_off));
         unsigned bits = 1;
         while ((1ull << bits) < n_blocks) bits++;
-        hipLaunchKernelGGL(k_block_ids, dim3(grid), dim3(256), 0, ctx->stream, d_off, (int)n_blocks, total, ts);
+        { Prof _p(ctx, "k_block_ids"); hipLaunchKernelGGL(k_block_ids, dim3(grid), dim3(256), 0, ctx->stream, d_off, (int)n_blocks, total, ts); }
         ZKW_TRY(launch_check("k_block_ids"));
         // ts[] now holds block ids in ORIGINAL order; gather them through the current permutation
-        hipLaunchKernelGGL(k_gather_u32_by_u32, dim3(grid), dim3(256), 0, ctx->stream, ts, v0, total, k32);
+        { Prof _p(ctx, "k_gather_u32_by_u32"); hipLaunchKernelGGL(k_gather_u32_by_u32, dim3(grid), dim3(256), 0, ctx->stream, ts, v0, total, k32); }
         ZKW_TRY(launch_check("k_gather_u32_by_u32"));
-        HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, k32, ts, v0, v1, total, bits, ctx->stream));
+        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, k32, ts, v0, v1, total, bits, ctx->stream)); }
         perm = v1;
     }
     *perm_out = perm;
@@ -501,8 +576,8 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     // K7 + K1 (sorted side)
     u32* perm = nullptr;
     ZKW_TRY(ram_sort(ctx, d_q, total, w->offsets, &perm));
-    hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, d_q, perm, total,
-                       w->sorted_q, w->sorted_enc);
+    { Prof _p(ctx, "k_gather_encode"); hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, d_q, perm, total,
+                       w->sorted_q, w->sorted_enc); }
     ZKW_TRY(launch_check("k_gather_encode"));
     // K2: 2 chains per block, all in one launch
     std::vector<ChainJob> chains;
@@ -551,10 +626,10 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     RamBlock* d_blocks = nullptr;
     ZKW_TRY(ctx->upload("ram_blocks", blocks, &d_blocks));
     unsigned gx = (unsigned)(max_inst < 64 ? max_inst : 64);
-    hipLaunchKernelGGL(k_ram_count_nondet, dim3(gx, (unsigned)n_blocks), dim3(256), 0, ctx->stream, d_blocks);
+    { Prof _p(ctx, "k_ram_count_nondet"); hipLaunchKernelGGL(k_ram_count_nondet, dim3(gx, (unsigned)n_blocks), dim3(256), 0, ctx->stream, d_blocks); }
     ZKW_TRY(launch_check("k_ram_count_nondet"));
-    hipLaunchKernelGGL(k_ram_instances, dim3(blocks_for(max_inst, 64), (unsigned)n_blocks), dim3(64), 0, ctx->stream,
-                       d_blocks);
+    { Prof _p(ctx, "k_ram_instances"); hipLaunchKernelGGL(k_ram_instances, dim3(blocks_for(max_inst, 64), (unsigned)n_blocks), dim3(64), 0, ctx->stream,
+                       d_blocks); }
     return launch_check("k_ram_instances");
 }
 

@@ -27,6 +27,10 @@ SYMBOLS = [
     ("zkw_set_pointer_mode", _int, [_vp, _int]),
     ("zkw_synchronize", _int, [_vp]),
     ("zkw_version", C.c_char_p, []),
+    ("zkw_profile_enable", _int, [_vp, _int]),
+    ("zkw_profile_reset", _int, [_vp]),
+    ("zkw_profile_get", _int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    ("zkw_profile_names", _int, [_vp, C.c_char_p, _sz]),
     ("zkw_encode_memory_queries", _int, [_vp, _vp, _sz, _u64p]),
     ("zkw_queue_push_chain_full", _int, [_vp, _u64p, _sz, _u64p, _u64p]),
     ("zkw_queue_push_chain_full_batch", _int, [_vp, _u64p, _u64p, _sz, _u64p, _u64p]),
@@ -177,6 +181,24 @@ class Context:
 
     def synchronize(self):
         _check(load().zkw_synchronize(self.handle))
+
+    def profile_enable(self, on=True):
+        _check(load().zkw_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        _check(load().zkw_profile_reset(self.handle))
+
+    def profile(self):
+        """{kernel name: (total ms, launches)} measured with HIP events on the context's stream."""
+        lib = load()
+        buf = C.create_string_buffer(4096)
+        _check(lib.zkw_profile_names(self.handle, buf, 4096))
+        out = {}
+        for name in filter(None, buf.value.decode().split(",")):
+            ms, cnt = C.c_double(0), C.c_uint64(0)
+            _check(lib.zkw_profile_get(self.handle, name.encode(), C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
 
     # ---- host-pointer conveniences (numpy in, numpy out) mirroring the reference's function names
     def encode_memory_queries(self, q):

@@ -1,0 +1,93 @@
+"""Multi-GPU plan for the base-layer hot path: one process per GPU, circuit
+instances are independent once the host-side builders have fixed their hidden FSM inputs, so they are
+sharded across ranks with NO data-path collective; the only exchange is the final gather of the
+per-instance closed-form-input records to rank 0, which replays the order-sensitive recursion-queue
+pushes (reference: src/witness/postprocessing/mod.rs:396-402, src/external_calls.rs:354-537).
+
+Everything here is backend-agnostic torch.distributed: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the
+CPU tests.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# rows used per circuit type at production geometry (setup/base_layer/finalization_hint_N.json of the
+# reference) — the LPT weight of an instance
+ROWS_USED = {1: 1033358, 2: 1021855, 3: 1045894, 4: 770857, 5: 957656, 6: 1039794, 7: 938955, 8: 1044096,
+             9: 1046318, 10: 1027359, 11: 590817, 12: 590817, 13: 1038150}
+
+
+def init_from_env(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def shard_contiguous(n_items, world):
+    """Weak-scaling shard of n_items equal units: rank r owns [bounds[r], bounds[r+1])."""
+    base, rem = divmod(n_items, world)
+    bounds = [0]
+    for r in range(world):
+        bounds.append(bounds[-1] + base + (1 if r < rem else 0))
+    return bounds
+
+
+def shard_lpt(circuit_types, world):
+    """Longest-processing-time assignment of an ordered instance list (by circuit type id) to ranks.
+    Returns owner[i] for every instance i. Deterministic: ties go to the lowest rank."""
+    order = sorted(range(len(circuit_types)), key=lambda i: (-ROWS_USED[circuit_types[i]], i))
+    load = [0] * world
+    owner = [0] * len(circuit_types)
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += ROWS_USED[circuit_types[i]]
+    return owner
+
+
+def gather_records(local: torch.Tensor, counts, dst=0):
+    """Gather per-instance records (uint8 [n_local, record_bytes]) to rank `dst` in rank order.
+    counts[r] = number of records rank r contributes (known to every rank from the shard plan).
+    Returns the concatenated [sum(counts), record_bytes] tensor on dst, None elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    rec = local.shape[1]
+    cap = max(counts)
+    padded = torch.zeros((cap, rec), dtype=torch.uint8, device=local.device)
+    padded[: local.shape[0]] = local
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][: counts[r]] for r in range(world)], dim=0)
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def records_to_numpy(t: torch.Tensor, dtype: np.dtype):
+    return t.cpu().numpy().reshape(-1).view(dtype)

@@ -49,6 +49,16 @@ int zkw_synchronize(zkw_ctx *ctx);
 /* library/ABI version and the kernels' target ISA ("gfx950") */
 const char *zkw_version(void);
 
+/* ---- per-kernel timing -------------------------------------------------------------------------- */
+/* When enabled, every kernel launch (and library sort) of this context is bracketed by HIP events
+   recorded on the context's stream; totals are keyed by kernel name ("k_chain_full", "k_gp_local",
+   "radix_sort", ...). zkw_profile_get synchronises the stream. Used by bench.py for the roofline. */
+int zkw_profile_enable(zkw_ctx *ctx, int on);
+int zkw_profile_reset(zkw_ctx *ctx);
+int zkw_profile_get(zkw_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
+/* comma-separated list of the kernel names seen so far */
+int zkw_profile_names(zkw_ctx *ctx, char *buf, size_t buf_bytes);
+
 /* ---- L1 primitives ------------------------------------------------------------------------------ */
 /* MemoryQuery::encoding_witness, circuit_encodings/src/memory_query.rs:24-118. enc: [n][8]. */
 int zkw_encode_memory_queries(zkw_ctx *ctx, const zkw_mem_query *q, size_t n, uint64_t *enc);
