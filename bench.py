@@ -70,7 +70,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctx = native.Context(local_rank)  # raises if libzkw / the GPU is missing: no fallback
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)  # one stream for torch ops, RCCL and libzkw kernels
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_pointer_mode(native.PTR_DEVICE)
 

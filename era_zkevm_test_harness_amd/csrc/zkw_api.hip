@@ -261,7 +261,7 @@ extern "C" void zkw_destroy(zkw_ctx* ctx) {
 extern "C" int zkw_set_stream(zkw_ctx* ctx, void* s) {
     if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->stream = s ? static_cast<hipStream_t>(s) : ctx->own_stream;
+    ctx->stream = (s == ZKW_STREAM_OWN) ? ctx->own_stream : static_cast<hipStream_t>(s);
     return ZKW_OK;
 }
 

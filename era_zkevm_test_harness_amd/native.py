@@ -61,6 +61,11 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ZkwError(ERR_NO_DEVICE, f"{LIB_PATH} not built: run `python -m era_zkevm_test_harness_amd.build`")
+        # torch bundles its own libamdhip64; loading it first makes libzkw bind to the SAME HIP runtime, so
+        # that device pointers and streams are interchangeable (two runtimes in one process cannot both
+        # open the device). A C/Rust host without torch simply uses the system runtime.
+        import torch  # noqa: F401
+
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
@@ -177,7 +182,10 @@ class Context:
         self.pointer_mode = mode
 
     def set_stream(self, stream_handle):
-        _check(load().zkw_set_stream(self.handle, stream_handle))
+        """stream_handle: a hipStream_t as int (0 = the null stream = torch's default stream), or None for
+        the context's own stream."""
+        h = C.c_void_p(-1) if stream_handle is None else C.c_void_p(stream_handle)
+        _check(load().zkw_set_stream(self.handle, h))
 
     def synchronize(self):
         _check(load().zkw_synchronize(self.handle))

@@ -43,7 +43,10 @@ enum { ZKW_PTR_HOST = 0, ZKW_PTR_DEVICE = 1 };
 zkw_ctx *zkw_create(int device_id);
 void zkw_destroy(zkw_ctx *ctx);
 const char *zkw_last_error(void);
-int zkw_set_stream(zkw_ctx *ctx, void *hip_stream /* hipStream_t, NULL = the context's own stream */);
+/* hip_stream: a hipStream_t (NULL = the HIP null stream, which is what torch's default stream is), or
+   ZKW_STREAM_OWN for the non-blocking stream the context created for itself (the default). */
+#define ZKW_STREAM_OWN ((void *)(intptr_t)-1)
+int zkw_set_stream(zkw_ctx *ctx, void *hip_stream);
 int zkw_set_pointer_mode(zkw_ctx *ctx, int mode);
 int zkw_synchronize(zkw_ctx *ctx);
 /* library/ABI version and the kernels' target ISA ("gfx950") */

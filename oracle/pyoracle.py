@@ -179,3 +179,42 @@ def blake2s256(msg: bytes) -> bytes:
     out = C.create_string_buffer(32)
     lib().orc_blake2s256(msg, C.c_size_t(len(msg)), out)
     return out.raw
+
+
+# ---- RAMPermutation synthesis ("zkw trace v1", include/zkw_ram_circuit_spec.h)
+RC_COLS = 149
+RC_ROWS_PER_CYCLE = 6
+
+
+def ram_synthesize(build_out, instance_index, capacity, n_rows):
+    """Fill the trace of one instance from the outputs of ram_build_instances. Returns [RC_COLS][n_rows]."""
+    o = build_out
+    n_total = o["sorted_q"].size
+    trace = np.zeros((RC_COLS, n_rows), np.uint64)
+    inst = o["instances"][instance_index:instance_index + 1]
+    f = lib().orc_ram_synthesize
+    f.restype = C.c_int
+    rc = f(_p(inst), _p(o["sorted_q"]), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["unsorted_tails"]),
+           _p(o["sorted_tails"]), _p(o["challenges"]), _p(o["lhs_z"]), _p(o["rhs_z"]), C.c_size_t(n_total),
+           C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_ram_synthesize failed: {rc}")
+    return trace
+
+
+def ram_check(trace, capacity):
+    """Satisfiability of a filled trace: (number of violated relations, code of the first one)."""
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_ram_check
+    f.restype = C.c_uint64
+    bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value
+    return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+def poseidon2_flattened(state):
+    s = _u64(state)
+    out = np.zeros(130, np.uint64)
+    lib().orc_poseidon2_flattened(_p(s), _p(out))
+    return out
