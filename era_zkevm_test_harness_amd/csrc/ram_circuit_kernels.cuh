@@ -1,0 +1,654 @@
+// ram_circuit_kernels.cuh — RAMPermutation synthesis on gfx950: materialisation of the "zkw trace v1"
+// (include/zkw_ram_circuit_spec.h) and its satisfiability check.
+//
+// Replaces, for the RAMPermutation instance type, ZkSyncBaseLayerCircuit::synthesis
+// (circuit_definitions/src/circuit_definitions/base_layer/mod.rs:286-323; wrapper
+// base_layer/ram_permutation.rs:26-135) and the `check_if_satisfied` pass of the reference's tests
+// (src/tests/mod.rs:130-259).
+//
+// Layout: column-major u64[RC_COLS][n_rows]; the trace is region-major (row of (region r, cycle i) =
+// r*capacity + i), so a wave of 64 consecutive cycles writes 512 contiguous bytes of every column it
+// touches: every store is a fully-used, coalesced line and every cell of the trace is written exactly
+// once (no memset pass): algorithmic bytes = RC_COLS * n_rows * 8.
+#pragma once
+#include "../../include/zkw_ram_circuit_spec.h"
+#include "ram_kernels.cuh"
+
+namespace zkw {
+
+struct SynthJob {
+    const zkw_ram_instance* inst;  // device
+    const zkw_mem_query* sorted_q;  // block-wide arrays (device), indexed by item
+    const u64* unsorted_enc;
+    const u64* sorted_enc;
+    const u64* unsorted_tails;
+    const u64* sorted_tails;
+    const u64* challenges;  // [2][9]
+    const u64* lhs_z;       // [2][n_block] grand-product chains of the instance's block
+    const u64* rhs_z;
+    u64 n_block;            // items in the block (stride between the two repetitions)
+    u64* trace;             // [RC_COLS][n_rows]
+    u32* hist;              // [256] lookup-value histogram of this trace (zeroed before the fills)
+    u32* nd_tiles;          // [ceil(capacity/256)] exclusive prefix of nondeterministic writes per 256-cycle tile
+};
+
+constexpr int ROW_SLOTS[RC_NUM_ROW_TYPES] = RC_ROW_NUM_SLOTS_INIT;
+constexpr int ROW_LOOKUPS[RC_NUM_ROW_TYPES] = RC_ROW_NUM_LOOKUPS_INIT;
+static_assert(ROW_SLOTS[RC_ROW_PU] == 133 && ROW_SLOTS[RC_ROW_PS] == 130, "Poseidon2 rows: 130 gate variables (+3 spare in PU)");
+static_assert(ROW_LOOKUPS[RC_ROW_PU] == 12 && ROW_LOOKUPS[RC_ROW_PS] == 12 && ROW_LOOKUPS[RC_ROW_A] == 12 &&
+              ROW_LOOKUPS[RC_ROW_B] == 12 && ROW_LOOKUPS[RC_ROW_C] == 8 && ROW_LOOKUPS[RC_ROW_D] == 0,
+              "lookup cells per cycle (56) are hard-wired in the fill kernels");
+constexpr int LOOKUPS_PER_CYCLE = 56;
+
+__device__ __forceinline__ u64 inv_or_zero(u64 x) { return gl::canon(x) ? gl::inv(x) : 0; }
+
+// effective registers at "cycle -1"
+struct RegsIn {
+    const u64* uh;  // [12]
+    const u64* sh;
+    u32 len;
+};
+__device__ __forceinline__ RegsIn regs_in(const zkw_ram_instance* in) {
+    RegsIn r;
+    const bool start = in->start_flag != 0;
+    r.uh = start ? in->unsorted_queue_initial_state.head : in->hidden_fsm_input.current_unsorted_queue_state.head;
+    r.sh = start ? in->sorted_queue_initial_state.head : in->hidden_fsm_input.current_sorted_queue_state.head;
+    r.len = start ? in->unsorted_queue_initial_state.length : in->hidden_fsm_input.current_unsorted_queue_state.length;
+    return r;
+}
+
+#define TR(col, row) trace[(size_t)(col) * n_rows + (row)]
+
+__device__ __forceinline__ void hist_bytes(u32* sh_hist, u32 x) {
+    atomicAdd(&sh_hist[x & 0xFF], 1u);
+    atomicAdd(&sh_hist[(x >> 8) & 0xFF], 1u);
+    atomicAdd(&sh_hist[(x >> 16) & 0xFF], 1u);
+    atomicAdd(&sh_hist[x >> 24], 1u);
+}
+__device__ __forceinline__ void put_bytes(u64* trace, size_t n_rows, size_t row, int col0, u32 x) {
+    TR(col0, row) = x & 0xFF;
+    TR(col0 + 1, row) = (x >> 8) & 0xFF;
+    TR(col0 + 2, row) = (x >> 16) & 0xFF;
+    TR(col0 + 3, row) = x >> 24;
+}
+__device__ __forceinline__ void hist_flush(u32* sh_hist, u32* g_hist) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 256; t += blockDim.x)
+        if (sh_hist[t]) atomicAdd(&g_hist[t], sh_hist[t]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Poseidon2 rows (regions PU and PS): one lane per cycle runs the permutation and stores all 130
+// flattened-gate variables as it goes. SIDE 0 = unsorted queue, 1 = sorted queue.
+template <int SIDE>
+__global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __restrict__ jobs, u32 capacity,
+                                                          size_t n_rows) {
+    __shared__ u32 sh_hist[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) sh_hist[t] = 0;
+    __syncthreads();
+    const SynthJob job = jobs[blockIdx.y];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < capacity) {
+        u64* trace = job.trace;
+        const zkw_ram_instance* in = job.inst;
+        const size_t first = in->first_item, m = in->num_items;
+        const bool can_pop = i < m;
+        const size_t row = (size_t)(SIDE == 0 ? RC_ROW_PU : RC_ROW_PS) * capacity + i;
+        const u64* enc = SIDE == 0 ? job.unsorted_enc : job.sorted_enc;
+        const u64* tails = SIDE == 0 ? job.unsorted_tails : job.sorted_tails;
+        u64 s[12];
+        if (can_pop) {
+            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(enc + 8 * (first + i));
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ulonglong2 w = src[k]; s[2 * k] = w.x; s[2 * k + 1] = w.y; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = 0;
+        }
+        const RegsIn ri = regs_in(in);
+        const u64* prev_head = i == 0 ? (SIDE == 0 ? ri.uh : ri.sh) : tails + 12 * (first + (i - 1 < m ? i - 1 : m - 1));
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[8 + k] = prev_head[8 + k];
+        int pos = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) TR(pos++, row) = s[k];
+        p2::external(s);
+        int r = 0;
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+            p2::full_round(s, r);
+#pragma unroll
+            for (int j = 0; j < 12; j++) TR(pos + j, row) = gl::canon(s[j]);
+            pos += 12;
+        }
+        for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
+            s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
+            TR(pos++, row) = gl::canon(s[0]);
+            p2::internal(s);
+        }
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+            p2::full_round(s, r);
+#pragma unroll
+            for (int j = 0; j < 12; j++) TR(pos + j, row) = gl::canon(s[j]);
+            pos += 12;
+        }
+        // spare general slots + lookup cells of this row type
+        zkw_mem_query q;
+        memset(&q, 0, sizeof q);
+        if (can_pop) q = job.sorted_q[first + i];
+        if (SIDE == 0) {
+            TR(RC_PU_idx, row) = q.index; TR(RC_PU_v0, row) = q.value[0]; TR(RC_PU_v1, row) = q.value[1];
+            put_bytes(trace, n_rows, row, RC_PU_idx_b0, q.index);
+            put_bytes(trace, n_rows, row, RC_PU_v0_b0, q.value[0]);
+            put_bytes(trace, n_rows, row, RC_PU_v1_b0, q.value[1]);
+            hist_bytes(sh_hist, q.index); hist_bytes(sh_hist, q.value[0]); hist_bytes(sh_hist, q.value[1]);
+        } else {
+            for (int c = 130; c < RC_G; c++) TR(c, row) = 0;
+            put_bytes(trace, n_rows, row, RC_PS_ts_b0, q.timestamp);
+            put_bytes(trace, n_rows, row, RC_PS_page_b0, q.page);
+            put_bytes(trace, n_rows, row, RC_PS_v4_b0, q.value[4]);
+            hist_bytes(sh_hist, q.timestamp); hist_bytes(sh_hist, q.page); hist_bytes(sh_hist, q.value[4]);
+        }
+        for (int c = RC_G + 12; c < RC_G + RC_L; c++) TR(c, row) = 0;
+    }
+    hist_flush(sh_hist, job.hist);
+}
+
+// ------------------------------------------------------------------------------------------------
+// General rows A..D: one lane per cycle; every value is a function of item i, item i-1 and the
+// instance record (no carried state), so all cycles are independent.
+struct CycleCtx {
+    bool can_pop;
+    zkw_mem_query q, pq;   // this item, previous item (zeros when padding / FSM-in for cycle 0)
+    u64 eu[8], es[8];
+    u64 p_val[5];          // es3..es6, v4 of the previous item
+    u32 p_ptr;
+};
+
+__device__ __forceinline__ void load_query(const zkw_mem_query* src, zkw_mem_query& dst) {
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(&dst);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
+__device__ __forceinline__ void cycle_ctx(const SynthJob& job, u32 i, CycleCtx& c, bool want_eu) {
+    const zkw_ram_instance* in = job.inst;
+    const size_t first = in->first_item, m = in->num_items;
+    c.can_pop = i < m;
+    memset(&c.q, 0, sizeof c.q);
+    memset(&c.pq, 0, sizeof c.pq);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { c.eu[k] = 0; c.es[k] = 0; }
+    if (c.can_pop) {
+        load_query(job.sorted_q + first + i, c.q);
+        encode_mem_query(c.q, c.es);
+        if (want_eu) {
+            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(job.unsorted_enc + 8 * (first + i));
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ulonglong2 w = src[k]; c.eu[2 * k] = w.x; c.eu[2 * k + 1] = w.y; }
+        }
+    }
+    if (i == 0) {
+        const zkw_ram_fsm& f = in->hidden_fsm_input;
+        c.pq.timestamp = f.previous_sorting_key[0]; c.pq.index = f.previous_sorting_key[1]; c.pq.page = f.previous_sorting_key[2];
+        for (int k = 0; k < 8; k++) c.pq.value[k] = f.previous_value[k];
+        c.pq.value_is_pointer = f.previous_is_ptr ? 1 : 0;
+    } else if (i - 1 < m) {
+        load_query(job.sorted_q + first + i - 1, c.pq);
+    }
+    u64 pe[8];
+    encode_mem_query(c.pq, pe);
+#pragma unroll
+    for (int k = 0; k < 5; k++) c.p_val[k] = pe[3 + k];
+    c.p_ptr = c.pq.value_is_pointer ? 1 : 0;
+}
+
+// accumulator entering cycle i: FSM input for i = 0, else the chain value at the last popped item
+__device__ __forceinline__ u64 acc_before(const u64* z, size_t first, size_t m, u32 i, u64 fsm_in) {
+    return i == 0 ? fsm_in : z[first + (i - 1 < m ? i - 1 : m - 1)];
+}
+
+__global__ __launch_bounds__(256) void k_ram_fill_A(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    __shared__ u32 sh_hist[256];
+    sh_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const SynthJob job = jobs[blockIdx.y];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u64* lhs_z_all = job.lhs_z;
+    const u64* rhs_z_all = job.rhs_z;
+    const size_t n_total = job.n_block;
+    if (i < capacity) {
+        u64* trace = job.trace;
+        const zkw_ram_instance* in = job.inst;
+        const size_t first = in->first_item, m = in->num_items, row = (size_t)RC_ROW_A * capacity + i;
+        CycleCtx c;
+        cycle_ctx(job, i, c, true);
+        const u64 rw = c.q.rw_flag ? 1 : 0, ptr = c.q.value_is_pointer ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { TR(RC_A_eu0 + k, row) = c.eu[k]; TR(RC_A_ts + k, row) = c.es[k]; }
+        for (int r = 0; r < 2; r++) {
+            const u64* ch = job.challenges + 9 * r;
+            u64 lc = ch[8], rc = ch[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                lc = gl::add(lc, gl::mul(c.eu[k], ch[k]));
+                rc = gl::add(rc, gl::mul(c.es[k], ch[k]));
+            }
+            const u64 pl = acc_before(lhs_z_all + (size_t)r * n_total, first, m, i, in->hidden_fsm_input.lhs_accumulator[r]);
+            const u64 pr = acc_before(rhs_z_all + (size_t)r * n_total, first, m, i, in->hidden_fsm_input.rhs_accumulator[r]);
+            const u64 nl = gl::canon(gl::mul(pl, lc)), nr = gl::canon(gl::mul(pr, rc));
+            const int o = r * (RC_A_lc1 - RC_A_lc0);
+#pragma unroll
+            for (int k = 1; k < 9; k++) TR(RC_A_G_c0_1 + (k - 1) + r * (RC_A_G_c1_1 - RC_A_G_c0_1), row) = ch[k];
+            TR(RC_A_lc0 + o, row) = gl::canon(lc); TR(RC_A_P_lhs0 + o, row) = pl; TR(RC_A_nl0 + o, row) = nl;
+            TR(RC_A_lhs0 + o, row) = c.can_pop ? nl : pl;
+            TR(RC_A_rc0 + o, row) = gl::canon(rc); TR(RC_A_P_rhs0 + o, row) = pr; TR(RC_A_nr0 + o, row) = nr;
+            TR(RC_A_rhs0 + o, row) = c.can_pop ? nr : pr;
+        }
+        TR(RC_A_rw, row) = rw; TR(RC_A_ptr, row) = ptr; TR(RC_A_idx, row) = c.q.index;
+        TR(RC_A_v2, row) = c.q.value[2]; TR(RC_A_v3, row) = c.q.value[3]; TR(RC_A_v0, row) = c.q.value[0];
+        TR(RC_A_v5_b3c, row) = c.q.value[5] >> 24; TR(RC_A_can_pop, row) = c.can_pop ? 1 : 0;
+        put_bytes(trace, n_rows, row, RC_A_v2_b0, c.q.value[2]);
+        put_bytes(trace, n_rows, row, RC_A_v3_b0, c.q.value[3]);
+        put_bytes(trace, n_rows, row, RC_A_v5_b0, c.q.value[5]);
+        hist_bytes(sh_hist, c.q.value[2]); hist_bytes(sh_hist, c.q.value[3]); hist_bytes(sh_hist, c.q.value[5]);
+        constexpr int NA = ROW_SLOTS[RC_ROW_A];  // general slots used by row type A
+        for (int col = NA; col < RC_G; col++) TR(col, row) = 0;
+        for (int col = RC_G + 12; col < RC_G + RC_L; col++) TR(col, row) = 0;
+    }
+    hist_flush(sh_hist, job.hist);
+}
+
+__global__ __launch_bounds__(256) void k_ram_fill_B(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    __shared__ u32 sh_hist[256];
+    sh_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const SynthJob job = jobs[blockIdx.y];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < capacity) {
+        u64* trace = job.trace;
+        const size_t row = (size_t)RC_ROW_B * capacity + i;
+        CycleCtx c;
+        cycle_ctx(job, i, c, false);
+        put_bytes(trace, n_rows, row, RC_B_v6_b0, c.q.value[6]);
+        put_bytes(trace, n_rows, row, RC_B_v7_b0, c.q.value[7]);
+        TR(RC_B_es4, row) = c.es[4]; TR(RC_B_v1, row) = c.q.value[1]; TR(RC_B_v5_b3c, row) = c.q.value[5] >> 24;
+        TR(RC_B_es5, row) = c.es[5]; TR(RC_B_v2, row) = c.q.value[2];
+        TR(RC_B_es6, row) = c.es[6]; TR(RC_B_v3, row) = c.q.value[3];
+        const u32 d0 = c.q.timestamp - c.pq.timestamp;
+        TR(RC_B_d0, row) = d0; put_bytes(trace, n_rows, row, RC_B_d0_b0, d0);
+        TR(RC_B_bw0, row) = c.q.timestamp < c.pq.timestamp ? 1 : 0;
+        TR(RC_B_ts, row) = c.q.timestamp; TR(RC_B_P_ts, row) = c.pq.timestamp;
+        hist_bytes(sh_hist, c.q.value[6]); hist_bytes(sh_hist, c.q.value[7]); hist_bytes(sh_hist, d0);
+        constexpr int NB = ROW_SLOTS[RC_ROW_B];
+        for (int col = NB; col < RC_G; col++) TR(col, row) = 0;
+        for (int col = RC_G + 12; col < RC_G + RC_L; col++) TR(col, row) = 0;
+    }
+    hist_flush(sh_hist, job.hist);
+}
+
+// nondeterministic-write flag of a cycle (circuit definition: popped & ts == 0 & heap page & write & !ptr)
+__device__ __forceinline__ bool nd_flag(bool can_pop, const zkw_mem_query& q) {
+    return can_pop && q.timestamp == 0 && q.page == RC_HEAP_PAGE && q.rw_flag && !q.value_is_pointer;
+}
+
+// per 256-cycle tile: number of nondeterministic writes; then an exclusive scan per instance
+__global__ __launch_bounds__(256) void k_ram_nd_tiles(const SynthJob* __restrict__ jobs, u32 capacity) {
+    __shared__ u32 sh[4];
+    const SynthJob job = jobs[blockIdx.y];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const zkw_ram_instance* in = job.inst;
+    bool f = false;
+    if (i < capacity && i < in->num_items) {
+        zkw_mem_query q;
+        load_query(job.sorted_q + in->first_item + i, q);
+        f = nd_flag(true, q);
+    }
+    u32 cnt = __popcll(__ballot(f));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) job.nd_tiles[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void k_ram_nd_scan(const SynthJob* __restrict__ jobs, int n_jobs, u32 n_tiles) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_jobs) return;
+    u32* t = jobs[j].nd_tiles;
+    u32 acc = 0;
+    for (u32 k = 0; k < n_tiles; k++) { u32 v = t[k]; t[k] = acc; acc += v; }
+}
+
+__global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    __shared__ u32 sh_hist[256];
+    __shared__ u32 sh_wave[4];
+    sh_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const SynthJob job = jobs[blockIdx.y];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < capacity;
+    CycleCtx c;
+    c.can_pop = false;
+    bool nd = false;
+    if (live) {
+        cycle_ctx(job, i, c, false);
+        nd = nd_flag(c.can_pop, c.q);
+    }
+    // exclusive count of nd flags before this lane inside the block (tile)
+    const unsigned long long bal = __ballot(nd);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh_wave[wave] = __popcll(bal);
+    __syncthreads();
+    u32 before = __popcll(bal & ((1ull << lane) - 1));
+    for (int w = 0; w < wave; w++) before += sh_wave[w];
+    if (live) {
+        u64* trace = job.trace;
+        const zkw_ram_instance* in = job.inst;
+        const size_t row = (size_t)RC_ROW_C * capacity + i;
+        const u64 rw = c.q.rw_flag ? 1 : 0, ptr = c.q.value_is_pointer ? 1 : 0;
+        const u64 bw0 = c.q.timestamp < c.pq.timestamp ? 1 : 0;
+        const u64 t1 = (u64)c.pq.index + bw0, bw1 = (u64)c.q.index < t1 ? 1 : 0;
+        const u32 d1 = (u32)((u64)c.q.index - t1);
+        const u64 t2 = (u64)c.pq.page + bw1, bw2 = (u64)c.q.page < t2 ? 1 : 0;
+        const u32 d2 = (u32)((u64)c.q.page - t2);
+        TR(RC_C_d1, row) = d1; put_bytes(trace, n_rows, row, RC_C_d1_b0, d1);
+        TR(RC_C_d2, row) = d2; put_bytes(trace, n_rows, row, RC_C_d2_b0, d2);
+        hist_bytes(sh_hist, d1); hist_bytes(sh_hist, d2);
+        TR(RC_C_bw1, row) = bw1; TR(RC_C_bw2, row) = bw2; TR(RC_C_bw0, row) = bw0;
+        TR(RC_C_idx, row) = c.q.index; TR(RC_C_P_idx, row) = c.pq.index;
+        TR(RC_C_page, row) = c.q.page; TR(RC_C_P_page, row) = c.pq.page;
+        TR(RC_C_can_pop, row) = c.can_pop ? 1 : 0;
+        // 14 "inverse or zero" witnesses with one field inversion (Montgomery batch trick)
+        u64 x[14];
+        x[0] = gl::canon(gl::sub(c.q.index, c.pq.index));
+        x[1] = gl::canon(gl::sub(c.q.page, c.pq.page));
+        const u64 val[5] = {c.es[3], c.es[4], c.es[5], c.es[6], c.es[7]};
+#pragma unroll
+        for (int k = 0; k < 5; k++) { x[2 + k] = gl::canon(gl::sub(val[k], c.p_val[k])); x[7 + k] = val[k]; }
+        x[12] = c.q.timestamp;
+        x[13] = gl::canon(gl::sub(c.q.page, RC_HEAP_PAGE));
+        u64 pre[14], acc = 1;
+#pragma unroll
+        for (int k = 0; k < 14; k++) { pre[k] = acc; acc = gl::mul(acc, x[k] ? x[k] : 1); }
+        u64 inv = gl::inv(acc), w[14];
+#pragma unroll
+        for (int k = 13; k >= 0; k--) {
+            w[k] = x[k] ? gl::canon(gl::mul(inv, pre[k])) : 0;
+            inv = gl::mul(inv, x[k] ? x[k] : 1);
+        }
+        const u64 z_idx = x[0] == 0, z_page = x[1] == 0, same = z_idx & z_page;
+        TR(RC_C_w_idx, row) = w[0]; TR(RC_C_z_idx, row) = z_idx;
+        TR(RC_C_w_page, row) = w[1]; TR(RC_C_z_page, row) = z_page; TR(RC_C_same, row) = same;
+        const int C_VAL[5] = {RC_C_es3, RC_C_es4, RC_C_es5, RC_C_es6, RC_C_v4};
+        const int C_PVAL[5] = {RC_C_P_es3, RC_C_P_es4, RC_C_P_es5, RC_C_P_es6, RC_C_P_v4};
+        const int C_WEQ[5] = {RC_C_w_eq0, RC_C_w_eq1, RC_C_w_eq2, RC_C_w_eq3, RC_C_w_eq4};
+        const int C_ZEQ[5] = {RC_C_z_eq0, RC_C_z_eq1, RC_C_z_eq2, RC_C_z_eq3, RC_C_z_eq4};
+        const int C_WZ[5] = {RC_C_w_z0, RC_C_w_z1, RC_C_w_z2, RC_C_w_z3, RC_C_w_z4};
+        const int C_ZZ[5] = {RC_C_z_z0, RC_C_z_z1, RC_C_z_z2, RC_C_z_z3, RC_C_z_z4};
+        u64 zeq[5], zz[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            zeq[k] = x[2 + k] == 0; zz[k] = x[7 + k] == 0;
+            TR(C_VAL[k], row) = val[k]; TR(C_PVAL[k], row) = c.p_val[k];
+            TR(C_WEQ[k], row) = w[2 + k]; TR(C_ZEQ[k], row) = zeq[k];
+            TR(C_WZ[k], row) = w[7 + k]; TR(C_ZZ[k], row) = zz[k];
+        }
+        const u64 peq = ptr == c.p_ptr, eq_a = zeq[0] & zeq[1] & zeq[2], value_equal = eq_a & zeq[3] & zeq[4] & peq;
+        const u64 zz_a = zz[0] & zz[1] & zz[2], all_zero = zz_a & zz[3] & zz[4] & (1 - ptr);
+        TR(RC_C_ptr, row) = ptr; TR(RC_C_P_ptr, row) = c.p_ptr; TR(RC_C_peq, row) = peq;
+        TR(RC_C_eq_a, row) = eq_a; TR(RC_C_value_equal, row) = value_equal;
+        TR(RC_C_zz_a, row) = zz_a; TR(RC_C_all_zero, row) = all_zero; TR(RC_C_rw, row) = rw;
+        TR(RC_C_ts, row) = c.q.timestamp; TR(RC_C_w_ts, row) = w[12]; TR(RC_C_z_ts, row) = x[12] == 0;
+        TR(RC_C_w_heap, row) = w[13]; TR(RC_C_z_heap, row) = x[13] == 0; TR(RC_C_nd, row) = nd ? 1 : 0;
+        const u64 p_cnt = (u64)in->hidden_fsm_input.num_nondeterministic_writes + job.nd_tiles[blockIdx.x] + before;
+        TR(RC_C_P_cnt, row) = p_cnt; TR(RC_C_cnt, row) = p_cnt + (nd ? 1 : 0);
+        constexpr int NC = ROW_SLOTS[RC_ROW_C];
+        for (int col = NC; col < RC_G; col++) TR(col, row) = 0;
+        for (int col = RC_G + 8; col < RC_G + RC_L; col++) TR(col, row) = 0;
+    }
+    hist_flush(sh_hist, job.hist);
+}
+
+__global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const SynthJob job = jobs[blockIdx.y];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    u64* trace = job.trace;
+    const zkw_ram_instance* in = job.inst;
+    const size_t first = in->first_item, m = in->num_items, row = (size_t)RC_ROW_D * capacity + i;
+    const size_t rPU = (size_t)RC_ROW_PU * capacity + i, rPS = (size_t)RC_ROW_PS * capacity + i;
+    const RegsIn ri = regs_in(in);
+    const bool can_pop = i < m;
+    const u64 p_len = (u64)ri.len - (i < m ? i : m);
+    const u64 w_len = inv_or_zero(p_len), z_len = p_len == 0;
+    TR(RC_D_P_len_u, row) = p_len; TR(RC_D_w_lu, row) = w_len; TR(RC_D_z_lu, row) = z_len;
+    TR(RC_D_P_len_s, row) = p_len; TR(RC_D_w_ls, row) = w_len; TR(RC_D_z_ls, row) = z_len;
+    TR(RC_D_can_pop, row) = can_pop ? 1 : 0;
+    TR(RC_D_len_u, row) = p_len - (can_pop ? 1 : 0); TR(RC_D_len_s, row) = p_len - (can_pop ? 1 : 0);
+    const u64* puh = i == 0 ? ri.uh : job.unsorted_tails + 12 * (first + (i - 1 < m ? i - 1 : m - 1));
+    const u64* psh = i == 0 ? ri.sh : job.sorted_tails + 12 * (first + (i - 1 < m ? i - 1 : m - 1));
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        // the Poseidon2 rows of this cycle were written by an earlier kernel on the same stream
+        const u64 uo = TR(RC_PU_uo0 + k, rPU), so = TR(RC_PS_so0 + k, rPS);
+        const u64 a = puh[k], b = psh[k];
+        const int o = 3 * k;
+        TR(RC_D_uo0 + o, row) = uo; TR(RC_D_P_uh0 + o, row) = a; TR(RC_D_uh0 + o, row) = can_pop ? uo : a;
+        TR(RC_D_so0 + o, row) = so; TR(RC_D_P_sh0 + o, row) = b; TR(RC_D_sh0 + o, row) = can_pop ? so : b;
+    }
+    constexpr int ND = ROW_SLOTS[RC_ROW_D];
+    for (int col = ND; col < RC_G + RC_L; col++) TR(col, row) = 0;
+}
+
+// boundary rows, the zero padding below them and the multiplicity column: one block column per job
+__global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const SynthJob job = jobs[blockIdx.y];
+    u64* trace = job.trace;
+    const size_t bnd = (size_t)RC_ROWS_PER_CYCLE * capacity;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    // zero everything from the first boundary row down, all general + lookup columns
+    const size_t n_pad = n_rows - bnd;
+    for (size_t k = tid; k < n_pad * (RC_G + RC_L); k += stride) {
+        const size_t col = k / n_pad, r = bnd + k % n_pad;
+        TR(col, r) = 0;
+    }
+    // multiplicities: histogram of the used lookup cells + every unused lookup cell counts as value 0
+    for (size_t r = tid; r < n_rows; r += stride) {
+        u64 v = 0;
+        if (r < 256) {
+            v = job.hist[r];
+            if (r == 0) v += (u64)RC_L * n_rows - (u64)LOOKUPS_PER_CYCLE * capacity;
+        }
+        TR(RC_MULT_COL, r) = v;
+    }
+}
+
+// runs after k_ram_fill_tail (same stream): the three boundary rows
+__global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const SynthJob job = jobs[blockIdx.x];
+    if (threadIdx.x != 0) return;
+    const u64* lhs_z_all = job.lhs_z;
+    const u64* rhs_z_all = job.rhs_z;
+    const size_t n_total = job.n_block;
+    u64* trace = job.trace;
+    const zkw_ram_instance* in = job.inst;
+    const zkw_ram_fsm& fi = in->hidden_fsm_input;
+    const size_t first = in->first_item, m = in->num_items;
+    const size_t bin = (size_t)RC_ROWS_PER_CYCLE * capacity + RC_ROWOFF_BND_IN, bout = bin - RC_ROWOFF_BND_IN + RC_ROWOFF_BND_OUT;
+    const RegsIn ri = regs_in(in);
+    for (int k = 0; k < 12; k++) { TR(RC_BND_IN_uh0 + k, bin) = ri.uh[k]; TR(RC_BND_IN_sh0 + k, bin) = ri.sh[k]; }
+    TR(RC_BND_IN_len_u, bin) = ri.len; TR(RC_BND_IN_len_s, bin) = ri.len;
+    for (int r = 0; r < 2; r++) { TR(RC_BND_IN_lhs0 + r, bin) = fi.lhs_accumulator[r]; TR(RC_BND_IN_rhs0 + r, bin) = fi.rhs_accumulator[r]; }
+    zkw_mem_query pq;
+    memset(&pq, 0, sizeof pq);
+    for (int k = 0; k < 8; k++) pq.value[k] = fi.previous_value[k];
+    u64 pe[8];
+    encode_mem_query(pq, pe);
+    TR(RC_BND_IN_ts, bin) = fi.previous_sorting_key[0]; TR(RC_BND_IN_idx, bin) = fi.previous_sorting_key[1];
+    TR(RC_BND_IN_page, bin) = fi.previous_sorting_key[2];
+    TR(RC_BND_IN_es3, bin) = pe[3]; TR(RC_BND_IN_es4, bin) = pe[4]; TR(RC_BND_IN_es5, bin) = pe[5];
+    TR(RC_BND_IN_es6, bin) = pe[6]; TR(RC_BND_IN_v4, bin) = pe[7];
+    TR(RC_BND_IN_ptr, bin) = fi.previous_is_ptr ? 1 : 0; TR(RC_BND_IN_cnt, bin) = fi.num_nondeterministic_writes;
+    for (int r = 0; r < 2; r++)
+        for (int k = 1; k < 9; k++) TR(RC_BND_IN_G_c0_1 + 8 * r + (k - 1), bin) = job.challenges[9 * r + k];
+    // BND_OUT = registers after the last cycle
+    const size_t last = first + m - 1;
+    const bool padded = m < capacity;
+    const u64 len_out = (u64)ri.len - m;
+    for (int k = 0; k < 12; k++) {
+        TR(RC_BND_OUT_uh0 + k, bout) = job.unsorted_tails[12 * last + k];
+        TR(RC_BND_OUT_sh0 + k, bout) = job.sorted_tails[12 * last + k];
+        TR(RC_BND_OUT_tail_u0 + k, bout) = in->unsorted_queue_initial_state.tail[k];
+        TR(RC_BND_OUT_tail_s0 + k, bout) = in->sorted_queue_initial_state.tail[k];
+    }
+    TR(RC_BND_OUT_len_u, bout) = len_out; TR(RC_BND_OUT_len_s, bout) = len_out;
+    for (int r = 0; r < 2; r++) {
+        TR(RC_BND_OUT_lhs0 + r, bout) = lhs_z_all[(size_t)r * n_total + last];
+        TR(RC_BND_OUT_rhs0 + r, bout) = rhs_z_all[(size_t)r * n_total + last];
+    }
+    zkw_mem_query lq;
+    memset(&lq, 0, sizeof lq);
+    if (!padded) lq = job.sorted_q[last];  // padding cycles reset the "previous" registers to zero
+    u64 le[8];
+    encode_mem_query(lq, le);
+    TR(RC_BND_OUT_ts, bout) = lq.timestamp; TR(RC_BND_OUT_idx, bout) = lq.index; TR(RC_BND_OUT_page, bout) = lq.page;
+    TR(RC_BND_OUT_es3, bout) = le[3]; TR(RC_BND_OUT_es4, bout) = le[4]; TR(RC_BND_OUT_es5, bout) = le[5];
+    TR(RC_BND_OUT_es6, bout) = le[6]; TR(RC_BND_OUT_v4, bout) = le[7];
+    TR(RC_BND_OUT_ptr, bout) = lq.value_is_pointer ? 1 : 0;
+    // cnt after the last cycle = cnt of the last cycle's row C
+    TR(RC_BND_OUT_cnt, bout) = TR(RC_C_cnt, (size_t)RC_ROW_C * capacity + capacity - 1);
+    TR(RC_BND_OUT_completion, bout) = in->completion_flag ? 1 : 0;
+    TR(RC_BND_OUT_w_end, bout) = inv_or_zero(len_out); TR(RC_BND_OUT_z_end, bout) = len_out == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Satisfiability check. Spec tables live in constant memory; a block stages 64 consecutive rows of one
+// region (all 148 general + lookup columns) in LDS, then each lane interprets its row's constraints.
+__constant__ rc_term c_terms[RC_NUM_TERMS] = RC_TERMS_INIT;
+__constant__ rc_constraint c_cons[RC_NUM_CONSTRAINTS] = RC_CONSTRAINTS_INIT;
+__constant__ uint16_t c_row_first[RC_NUM_ROW_TYPES + 1] = RC_ROW_FIRST_CONSTRAINT_INIT;
+__constant__ rc_link c_links[RC_NUM_LINKS] = RC_LINKS_INIT;
+
+struct CheckResult {
+    unsigned long long violations;
+    unsigned long long first_bad;  // (kind << 56) | (index << 32) | row ; smallest code wins
+};
+
+__device__ __forceinline__ void flag_bad(CheckResult* res, u64 kind, u64 idx, u64 row) {
+    atomicAdd(&res->violations, 1ull);
+    atomicMin(&res->first_bad, (kind << 56) | (idx << 32) | row);
+}
+
+constexpr int CHK_ROWS = 64;
+constexpr int CHK_COLS = RC_G + RC_L;
+
+__global__ __launch_bounds__(64) void k_ram_check_rows(const u64* __restrict__ trace, u32 capacity, size_t n_rows,
+                                                       CheckResult* res) {
+    extern __shared__ __attribute__((aligned(16))) u64 tile[];  // [CHK_COLS][CHK_ROWS]
+    const int rt = blockIdx.y;  // row type; boundary row types are handled by block x == 0 only
+    const bool per_cycle = rt < RC_ROWS_PER_CYCLE;
+    const u32 n_in_region = per_cycle ? capacity : 1;
+    const u32 i = blockIdx.x * CHK_ROWS + threadIdx.x;
+    if (blockIdx.x * CHK_ROWS >= n_in_region) return;
+    const bool live = i < n_in_region;
+    const size_t row = per_cycle ? (size_t)rt * capacity + i : (size_t)RC_ROWS_PER_CYCLE * capacity + (rt - RC_ROWS_PER_CYCLE);
+    for (int c = 0; c < CHK_COLS; c++) {
+        u64 v = live ? TR(c, row) : 0;
+        tile[c * CHK_ROWS + threadIdx.x] = v;
+        if (live && (v >= gl::P || (c >= RC_G && v > 255))) flag_bad(res, 3, c, row);
+    }
+    __syncthreads();
+    if (!live) return;
+#define CELLV(c) tile[(c) * CHK_ROWS + threadIdx.x]
+    for (int k = c_row_first[rt]; k < c_row_first[rt + 1]; k++) {
+        const rc_constraint cn = c_cons[k];
+        u64 acc = 0;
+        for (int t = 0; t < cn.n_terms; t++) {
+            const rc_term tm = c_terms[cn.first_term + t];
+            u64 v = tm.coef;
+            for (int f = 0; f < tm.nf; f++) v = gl::mul(v, CELLV(tm.f[f]));
+            acc = gl::add(acc, v);
+        }
+        if (gl::canon(acc) != 0) flag_bad(res, 1, k, row);
+    }
+    if (rt == RC_ROW_PU || rt == RC_ROW_PS) {
+        u64 s[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) s[k] = CELLV(k);
+        int pos = 12, r = 0;
+        bool ok = true;
+        p2::external(s);
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+            p2::full_round(s, r);
+#pragma unroll
+            for (int j = 0; j < 12; j++) ok &= gl::canon(s[j]) == CELLV(pos + j);
+            pos += 12;
+        }
+        for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
+            s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
+            ok &= gl::canon(s[0]) == CELLV(pos);
+            pos++;
+            p2::internal(s);
+        }
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+            p2::full_round(s, r);
+#pragma unroll
+            for (int j = 0; j < 12; j++) ok &= gl::canon(s[j]) == CELLV(pos + j);
+            pos += 12;
+        }
+        if (!ok) flag_bad(res, 2, 0, row);
+    }
+#undef CELLV
+}
+
+// copy links: one lane per cycle walks the link table (both cells are read coalesced across lanes)
+__global__ __launch_bounds__(256) void k_ram_check_links(const u64* __restrict__ trace, u32 capacity, size_t n_rows,
+                                                         CheckResult* res) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    const size_t bnd = (size_t)RC_ROWS_PER_CYCLE * capacity;
+    for (int l = 0; l < RC_NUM_LINKS; l++) {
+        const rc_link k = c_links[l];
+        if (k.kind == 3) {
+            if (i == capacity - 1 && TR(k.col_a, bnd + RC_ROWOFF_BND_OUT) != TR(k.col_b, (size_t)k.row_b * capacity + i))
+                flag_bad(res, 4, l, bnd + RC_ROWOFF_BND_OUT);
+            continue;
+        }
+        const size_t ra = (size_t)k.row_a * capacity + i;
+        const u64 a = TR(k.col_a, ra);
+        u64 b;
+        if (k.kind == 0) b = TR(k.col_b, (size_t)k.row_b * capacity + i);
+        else if (k.kind == 1) b = i ? TR(k.col_b, (size_t)k.row_b * capacity + i - 1) : TR(k.bin_col, bnd + RC_ROWOFF_BND_IN);
+        else b = TR(k.col_b, bnd + RC_ROWOFF_BND_IN);
+        if (a != b) flag_bad(res, 4, l, ra);
+    }
+}
+
+// lookup columns: histogram of every cell (all n_rows), padding rows must be zero in every column
+__global__ __launch_bounds__(256) void k_ram_check_lookups(const u64* __restrict__ trace, u32 capacity, size_t n_rows,
+                                                           u32* __restrict__ hist, CheckResult* res) {
+    __shared__ u32 sh_hist[256];
+    sh_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t pad0 = (size_t)RC_ROWS_PER_CYCLE * capacity + (RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        for (int c = RC_G; c < RC_G + RC_L; c++) {
+            const u64 v = TR(c, r);
+            if (v > 255) flag_bad(res, 3, c, r); else atomicAdd(&sh_hist[v], 1u);
+        }
+        if (r >= pad0)
+            for (int c = 0; c < RC_G; c++)
+                if (TR(c, r) != 0) { flag_bad(res, 6, c, r); break; }
+    }
+    __syncthreads();
+    if (sh_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh_hist[threadIdx.x]);
+}
+__global__ void k_ram_check_mult(const u64* __restrict__ trace, size_t n_rows, const u32* __restrict__ hist,
+                                 CheckResult* res) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        const u64 want = r < 256 ? hist[r] : 0;
+        if (TR(RC_MULT_COL, r) != want) flag_bad(res, 5, 0, r);
+    }
+}
+
+#undef TR
+}  // namespace zkw

@@ -15,6 +15,7 @@
 
 #include "../../include/zkw.h"
 #include "ram_kernels.cuh"
+#include "ram_circuit_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -743,4 +744,152 @@ extern "C" void zkw_ram_witness_free(zkw_ram_witness* w) {
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
     delete w;
+}
+
+// ------------------------------------------------------------------------------------------------ traces / synthesis
+struct zkw_trace {
+    zkw_ctx* ctx = nullptr;
+    size_t n_rows = 0, n_slots = 0;
+    u64* data = nullptr;
+    size_t slot_elems() const { return (size_t)RC_COLS * n_rows; }
+};
+
+extern "C" int zkw_trace_create(zkw_ctx* ctx, size_t n_rows, size_t n_slots, zkw_trace** out) {
+    if (!ctx || !out || n_rows < 256 || n_slots == 0) return fail(ZKW_ERR_INVALID, "zkw_trace_create: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    zkw_trace* t = new zkw_trace();
+    t->ctx = ctx;
+    t->n_rows = n_rows;
+    t->n_slots = n_slots;
+    hipError_t e = hipMalloc((void**)&t->data, t->slot_elems() * n_slots * sizeof(u64));
+    if (e != hipSuccess) {
+        delete t;
+        return fail(ZKW_ERR_OOM, "zkw_trace_create: hipMalloc of %zu bytes failed: %s",
+                    (size_t)RC_COLS * n_rows * n_slots * 8, hipGetErrorString(e));
+    }
+    *out = t;
+    return ZKW_OK;
+}
+
+extern "C" void zkw_trace_free(zkw_trace* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    if (t->data) (void)hipFree(t->data);
+    delete t;
+}
+
+extern "C" size_t zkw_trace_num_rows(const zkw_trace* t) { return t ? t->n_rows : 0; }
+extern "C" size_t zkw_trace_num_cols(const zkw_trace* t) { return t ? RC_COLS : 0; }
+extern "C" size_t zkw_trace_num_slots(const zkw_trace* t) { return t ? t->n_slots : 0; }
+extern "C" const uint64_t* zkw_trace_device_ptr(const zkw_trace* t, size_t slot) {
+    return (t && slot < t->n_slots) ? t->data + slot * t->slot_elems() : nullptr;
+}
+
+extern "C" int zkw_trace_get(const zkw_trace* t, size_t slot, uint32_t first_col, uint32_t n_cols, uint64_t* dst) {
+    if (!t || !dst || slot >= t->n_slots || first_col + n_cols > RC_COLS) return fail(ZKW_ERR_INVALID, "zkw_trace_get: bad argument");
+    zkw_ctx* ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64* src = t->data + slot * t->slot_elems() + (size_t)first_col * t->n_rows;
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n_cols * t->n_rows * sizeof(u64),
+                           ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t first_instance, size_t n_instances,
+                                  zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_ram_synthesize: bad argument");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    const u32 capacity = w->capacity;
+    const size_t n_rows = t->n_rows;
+    if (RC_MIN_ROWS(capacity) > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity,
+                    (unsigned long long)RC_MIN_ROWS(capacity), n_rows);
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u32 n_tiles = (capacity + 255) / 256;
+    u32 *d_hist = nullptr, *d_nd = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("synth_hist", n_instances * 256, &d_hist));
+    ZKW_TRY(ctx->scratch_t<u32>("synth_nd", n_instances * n_tiles, &d_nd));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    std::vector<SynthJob> jobs(n_instances);
+    const size_t n_blocks = w->offsets.size() - 1;
+    size_t b = 0;
+    for (size_t k = 0; k < n_instances; k++) {
+        const size_t idx = first_instance + k;
+        while (b + 1 < n_blocks && w->inst_offsets[b + 1] <= idx) b++;
+        const size_t lo = w->offsets[b], nb = w->offsets[b + 1] - lo;
+        SynthJob& j = jobs[k];
+        j.inst = w->instances + idx;
+        j.sorted_q = w->sorted_q + lo;
+        j.unsorted_enc = w->unsorted_enc + 8 * lo;
+        j.sorted_enc = w->sorted_enc + 8 * lo;
+        j.unsorted_tails = w->unsorted_tails + 12 * lo;
+        j.sorted_tails = w->sorted_tails + 12 * lo;
+        j.challenges = w->challenges + 18 * b;
+        j.lhs_z = w->lhs_z + 2 * lo;
+        j.rhs_z = w->rhs_z + 2 * lo;
+        j.n_block = nb;
+        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.hist = d_hist + 256 * k;
+        j.nd_tiles = d_nd + (size_t)n_tiles * k;
+    }
+    SynthJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("synth_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)n_instances;
+    const dim3 g64((capacity + 63) / 64, nj), g256(n_tiles, nj);
+    { Prof _p(ctx, "k_ram_nd_tiles"); hipLaunchKernelGGL(k_ram_nd_tiles, g256, dim3(256), 0, ctx->stream, d_jobs, capacity); }
+    ZKW_TRY(launch_check("k_ram_nd_tiles"));
+    { Prof _p(ctx, "k_ram_nd_scan"); hipLaunchKernelGGL(k_ram_nd_scan, dim3((nj + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, (int)nj, n_tiles); }
+    ZKW_TRY(launch_check("k_ram_nd_scan"));
+    { Prof _p(ctx, "k_ram_fill_poseidon"); hipLaunchKernelGGL((k_ram_fill_poseidon<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ram_fill_poseidon<0>"));
+    { Prof _p(ctx, "k_ram_fill_poseidon"); hipLaunchKernelGGL((k_ram_fill_poseidon<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ram_fill_poseidon<1>"));
+    { Prof _p(ctx, "k_ram_fill_A"); hipLaunchKernelGGL(k_ram_fill_A, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ram_fill_A"));
+    { Prof _p(ctx, "k_ram_fill_B"); hipLaunchKernelGGL(k_ram_fill_B, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ram_fill_B"));
+    { Prof _p(ctx, "k_ram_fill_C"); hipLaunchKernelGGL(k_ram_fill_C, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ram_fill_C"));
+    { Prof _p(ctx, "k_ram_fill_D"); hipLaunchKernelGGL(k_ram_fill_D, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ram_fill_D"));
+    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(256, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ram_fill_tail"));
+    { Prof _p(ctx, "k_ram_fill_boundary"); hipLaunchKernelGGL(k_ram_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ram_fill_boundary"));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_ram_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
+                                       uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+        return fail(ZKW_ERR_INVALID, "zkw_ram_check_satisfied: bad argument");
+    if (RC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64* trace = t->data + slot * t->slot_elems();
+    const size_t n_rows = t->n_rows;
+    CheckResult* d_res = nullptr;
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
+    ZKW_TRY(ctx->scratch_t<u32>("check_hist", 256, &d_hist));
+    CheckResult init{0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), ctx->stream));
+    const size_t lds = (size_t)CHK_COLS * CHK_ROWS * sizeof(u64);
+    { Prof _p(ctx, "k_ram_check_rows"); hipLaunchKernelGGL(k_ram_check_rows, dim3((capacity + CHK_ROWS - 1) / CHK_ROWS, RC_NUM_ROW_TYPES), dim3(CHK_ROWS), lds, ctx->stream, trace, capacity, n_rows, d_res); }
+    ZKW_TRY(launch_check("k_ram_check_rows"));
+    { Prof _p(ctx, "k_ram_check_links"); hipLaunchKernelGGL(k_ram_check_links, dim3((capacity + 255) / 256), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_res); }
+    ZKW_TRY(launch_check("k_ram_check_links"));
+    { Prof _p(ctx, "k_ram_check_lookups"); hipLaunchKernelGGL(k_ram_check_lookups, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_ram_check_lookups"));
+    { Prof _p(ctx, "k_ram_check_mult"); hipLaunchKernelGGL(k_ram_check_mult, dim3(256), dim3(256), 0, ctx->stream, trace, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_ram_check_mult"));
+    CheckResult res;
+    HIP_TRY(hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *n_violations = res.violations;
+    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
+    return ZKW_OK;
 }

@@ -44,6 +44,15 @@ SYMBOLS = [
     ("zkw_ram_witness_device_ptr", _vp, [_vp, _int]),
     ("zkw_ram_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_ram_witness_free", None, [_vp]),
+    ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
+    ("zkw_trace_free", None, [_vp]),
+    ("zkw_trace_num_rows", _sz, [_vp]),
+    ("zkw_trace_num_cols", _sz, [_vp]),
+    ("zkw_trace_num_slots", _sz, [_vp]),
+    ("zkw_trace_device_ptr", _vp, [_vp, _sz]),
+    ("zkw_trace_get", _int, [_vp, _sz, _u32, _u32, _vp]),
+    ("zkw_ram_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_ram_check_satisfied", _int, [_vp, _vp, _sz, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 ]
 
 _lib = None
@@ -147,6 +156,42 @@ class RamWitness:
     def free(self):
         if self.handle:
             load().zkw_ram_witness_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Trace:
+    """zkw_trace: a ring of filled-trace buffers in HBM, each column-major u64[n_cols][n_rows]."""
+
+    def __init__(self, ctx, n_rows, n_slots=1):
+        self.ctx = ctx
+        self.handle = C.c_void_p(None)
+        _check(load().zkw_trace_create(ctx.handle, n_rows, n_slots, C.byref(self.handle)))
+        self.n_rows, self.n_slots = n_rows, n_slots
+        self.n_cols = load().zkw_trace_num_cols(self.handle)
+
+    def device_ptr(self, slot=0):
+        return load().zkw_trace_device_ptr(self.handle, slot)
+
+    def get(self, slot=0, first_col=0, n_cols=None):
+        n_cols = self.n_cols - first_col if n_cols is None else n_cols
+        out = np.zeros((n_cols, self.n_rows), np.uint64)
+        mode = self.ctx.pointer_mode
+        self.ctx.set_pointer_mode(PTR_HOST)
+        try:
+            _check(load().zkw_trace_get(self.handle, slot, first_col, n_cols, _np_ptr(out)))
+        finally:
+            self.ctx.set_pointer_mode(mode)
+        return out
+
+    def free(self):
+        if self.handle:
+            load().zkw_trace_free(self.handle)
             self.handle = C.c_void_p(None)
 
     def __del__(self):
@@ -276,3 +321,16 @@ class Context:
             _check(lib.zkw_ram_build_instances_batch(self.handle, qptr, _np_ptr(offs), nb, per_circuit_capacity,
                                                      _np_ptr(nd), C.byref(w.handle)))
         return w
+
+    def synthesize_ram(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+        """ZkSyncBaseLayerCircuit::synthesis for RAMPermutation instances (base_layer/mod.rs:286-323):
+        fills trace slots (first_slot + k) % n_slots with instances first_instance + k."""
+        n = witness.num_instances - first_instance if n_instances is None else n_instances
+        _check(load().zkw_ram_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+    def check_if_satisfied_ram(self, trace, slot, capacity):
+        """check_if_satisfied (src/tests/mod.rs:130-259): (violations, (kind, index, row) of the first)."""
+        bad, first = C.c_uint64(0), C.c_uint64(0)
+        _check(load().zkw_ram_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+        v = first.value
+        return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)

@@ -26,6 +26,7 @@ extern "C" {
 
 typedef struct zkw_ctx zkw_ctx;
 typedef struct zkw_ram_witness zkw_ram_witness;
+typedef struct zkw_trace zkw_trace;
 
 enum {
     ZKW_OK = 0,
@@ -120,6 +121,36 @@ const void *zkw_ram_witness_device_ptr(const zkw_ram_witness *w, int what);
 /* copy an array out (to host memory, or to a device buffer in ZKW_PTR_DEVICE mode) */
 int zkw_ram_witness_get(const zkw_ram_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_ram_witness_free(zkw_ram_witness *w);
+
+/* ---- synthesis: filled traces ------------------------------------------------------------------- */
+/* A zkw_trace owns n_slots trace buffers in HBM, each column-major uint64_t[n_cols][n_rows] (n_rows =
+   2^20 at production geometry = TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17). It plays the role of
+   the reference's CSReferenceAssembly (output of `synthesis`, base_layer/mod.rs:315-323): variable
+   columns, lookup columns and the lookup-multiplicity column, every cell written. Slots are a ring: a
+   prover consumes a slot while later instances are synthesised into the others. */
+int zkw_trace_create(zkw_ctx *ctx, size_t n_rows, size_t n_slots, zkw_trace **out);
+void zkw_trace_free(zkw_trace *t);
+size_t zkw_trace_num_rows(const zkw_trace *t);
+size_t zkw_trace_num_cols(const zkw_trace *t); /* 149 = 133 copy-permutation + 15 lookup + 1 multiplicity */
+size_t zkw_trace_num_slots(const zkw_trace *t);
+/* device address of slot's column 0; column c starts at + c * n_rows */
+const uint64_t *zkw_trace_device_ptr(const zkw_trace *t, size_t slot);
+/* copy columns [first_col, first_col + n_cols) of a slot out (host, or device in ZKW_PTR_DEVICE mode) */
+int zkw_trace_get(const zkw_trace *t, size_t slot, uint32_t first_col, uint32_t n_cols, uint64_t *dst);
+
+/* ZkSyncBaseLayerCircuit::synthesis for RAMPermutation instances (base_layer/mod.rs:286-323 with
+   base_layer/ram_permutation.rs:26-135): instances [first_instance, first_instance + n_instances) of a
+   witness are materialised into slots (first_slot + k) % n_slots. Layout: include/zkw_ram_circuit_spec.h.
+   Requires RC_MIN_ROWS(capacity) <= n_rows. */
+int zkw_ram_synthesize(zkw_ctx *ctx, const zkw_ram_witness *w, size_t first_instance, size_t n_instances,
+                       zkw_trace *t, size_t first_slot);
+/* check_if_satisfied (src/tests/mod.rs:130-259) for one RAMPermutation trace: every row constraint, the
+   Poseidon2 rows, copy links, lookup ranges and multiplicities, zero padding, canonical cells.
+   n_violations = number of failed relations; first_bad = (kind << 56) | (index << 32) | row of the
+   smallest failing code (kind 1 constraint, 2 poseidon row, 3 cell range, 4 copy link, 5 multiplicity,
+   6 padding). Synchronises the stream. */
+int zkw_ram_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
+                            uint64_t *n_violations, uint64_t *first_bad);
 
 #ifdef __cplusplus
 }
