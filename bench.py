@@ -4,7 +4,8 @@
 One "step" = one pass of the hot path over one batch: B independent blocks' memory queues (each at the
 production RAMPermutation capacity, 136 714 queries = one 2^20-row instance) go through witness
 generation (encode, sort, both Poseidon2 queue chains, Fiat-Shamir challenges, grand products, instance
-records) [+ synthesis of each instance's trace once that row of SURVEY section 8 lands]. Inputs are
+records) and synthesis (every instance materialised into a full 149-column x 2^20-row trace, written
+into a ring of trace buffers). Inputs are
 resident in HBM before the timed region. N > 1: one process per GPU, blocks sharded with no data-path
 collective; the per-instance closed-form records are gathered to rank 0 (RCCL) inside the timed region.
 
@@ -47,11 +48,12 @@ def cpu_baseline(base, sample_blocks):
     pyoracle.ram_build_instances(base[:2048], 2048, 0)  # warm
     t0 = time.perf_counter()
     for _ in range(sample_blocks):
-        pyoracle.ram_build_instances(base, CAPACITY, 0)
+        o = pyoracle.ram_build_instances(base, CAPACITY, 0)
+        pyoracle.ram_synthesize(o, 0, CAPACITY, 1 << 20)
     dt = time.perf_counter() - t0
     return {"value": sample_blocks / dt, "unit": "circuits/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_blocks} RAMPermutation instance(s) of {CAPACITY} queries, witness generation, "
-                      f"oracle/liboracle.so single thread, {dt:.1f} s"}
+            "sample": f"{sample_blocks} RAMPermutation instance(s) of {CAPACITY} queries, witness generation + "
+                      f"synthesis of the 2^20-row trace, oracle/liboracle.so single thread, {dt:.1f} s"}
 
 
 def main():
@@ -61,7 +63,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=256, help="independent memory queues per GPU per step")
     ap.add_argument("--queries", type=int, default=CAPACITY)
-    ap.add_argument("--cpu-sample", type=int, default=6)
+    ap.add_argument("--ring", type=int, default=16, help="trace buffers (1.25 GB each) in the output ring")
+    ap.add_argument("--cpu-sample", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -76,6 +79,8 @@ def main():
     ctx.set_pointer_mode(native.PTR_DEVICE)
 
     B, n = args.blocks, args.queries
+    n_rows = 1 << 20  # TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17
+    ring = native.Trace(ctx, n_rows, args.ring)  # trace buffers a prover would consume and hand back
     base, q = make_inputs(B, n, rank, dev)
     offs = np.arange(B + 1, dtype=np.uint64) * n
     w = native.RamWitness(ctx)
@@ -86,6 +91,8 @@ def main():
 
     def step():
         ctx.compute_ram_circuit_snapshots((q.data_ptr(), B * n), CAPACITY, 0, block_offsets=offs, witness=w)
+        for first in range(0, n_inst_local, args.ring):  # synthesis: every instance -> a full 2^20-row trace
+            ctx.synthesize_ram(w, ring, first, min(args.ring, n_inst_local - first), 0)
         native._check(native.load().zkw_ram_witness_get(w.handle, native.RAM_INSTANCES, records.data_ptr(),
                                                         records.numel()))
         return parallel.gather_records(records, counts, dst=0)
@@ -110,17 +117,35 @@ def main():
         circuits = n_inst_local * world * args.steps
         # dominant kernel by time, with its algorithmic HBM bytes per launch (DESIGN.md "Measurement")
         items = B * n
+        # algorithmic HBM bytes PER LAUNCH of each kernel (DESIGN.md "Measurement"): cells written once +
+        # the instance's witness read once. A synthesis launch covers `args.ring` instances.
+        per_launch_inst = min(args.ring, n_inst_local)
+        cell = 8 * CAPACITY * per_launch_inst          # one column of one region, all instances of a launch
+        wit = per_launch_inst * n                      # witness items read by a launch
         alg_bytes = {
             "k_chain_full": 2 * items * (64 + 96),            # per chain item: 8 words in, 12 words out
             "k_gp_local": 2 * items * (64 + 16),              # rows read once, both repetitions written
             "k_gp_apply": 2 * items * 32,
             "k_encode_mem": items * (48 + 64),
             "k_gather_encode": items * (48 + 4 + 48 + 64),
+            "k_ram_fill_poseidon": 148 * cell + wit * (64 + 48 + 32),   # one Poseidon2 region per launch
+            "k_ram_fill_A": 148 * cell + wit * (64 + 48 + 32),
+            "k_ram_fill_B": 148 * cell + wit * 96,
+            "k_ram_fill_C": 148 * cell + wit * 96,
+            "k_ram_fill_D": 148 * cell + wit * 192 + 24 * cell,
+            "k_ram_fill_tail": per_launch_inst * 8 * (148 * (n_rows - 6 * CAPACITY) + n_rows),
         }
         name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / max(cnt, 1)
         ab = alg_bytes.get(name)
         achieved = (ab / (avg_ms * 1e-3) / 1e9) if ab else None
+        hbm_kernels = {}
+        for k, (kms, kcnt) in prof.items():
+            if k.startswith("k_ram_fill") and k in alg_bytes and kcnt:
+                gbs = alg_bytes[k] / (kms / kcnt * 1e-3) / 1e9
+                hbm_kernels[k] = {"achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": kms / kcnt}
+        synth_ms = sum(v[0] for k, v in prof.items() if k.startswith("k_ram_fill") or k.startswith("k_ram_nd"))
+        synth_gbs = (149 * n_rows * 8 * n_inst_local * args.steps) / (synth_ms * 1e-3) / 1e9 if synth_ms else None
         chain_ms, chain_cnt = prof.get("k_chain_full", (0.0, 1))
         out = {
             "metric": "base-layer circuits/sec (2^20 rows)",
@@ -136,13 +161,17 @@ def main():
             "dtype": "u64 (Goldilocks, p = 2^64 - 2^32 + 1)",
             "data": "synthetic",
             "config": {"workload": f"RAMPermutation base circuit, capacity {CAPACITY} (2^20-row geometry), "
-                                   f"{B} independent memory queues per GPU per step, witness generation",
+                                   f"{B} independent memory queues per GPU per step, witness generation + synthesis "
+                                   f"of every instance into a 149-column x 2^20-row trace",
                        "blocks_per_gpu": B, "queries_per_block": n, "parallelism": f"instances sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "avg_launch_ms": avg_ms,
                          "note": "k_chain_full is a serial Poseidon2 chain per queue: latency/VALU-bound, "
                                  "permutations/s is its meaningful rate"},
+            "synthesis": {"trace_bytes_per_circuit": 149 * n_rows * 8, "kernels_ms_per_step": synth_ms / args.steps,
+                          "achieved_GBps": synth_gbs, "frac_of_hbm_peak": synth_gbs / HBM_PEAK_GBS if synth_gbs else None,
+                          "per_kernel": hbm_kernels},
             "poseidon2_perm_per_s": 2 * items * chain_cnt / (chain_ms * 1e-3) if chain_ms else None,
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
         }
