@@ -1,0 +1,40 @@
+"""Pins against the reference's own committed artifacts (tests/golden, data harvested from
+/root/reference/test_proofs — see tests/golden/README.md)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+P = 0xFFFFFFFF00000001
+
+
+def _load_kat():
+    toks = open(os.path.join(GOLD, "merkle_kat_ram.txt")).read().split()
+    n = int(toks[0])
+    vals = np.array([int(x) for x in toks[1:]], dtype=np.uint64)
+    return vals[: 4 * n].reshape(n, 4), vals[4 * n:].reshape(16, 4)
+
+
+def test_fixture_shapes_and_canonical_values():
+    nodes, cap = _load_kat()
+    assert nodes.shape[0] >= 30 and cap.shape == (16, 4)
+    assert int(nodes.max()) < P and int(cap.max()) < P
+    pis = json.load(open(os.path.join(GOLD, "reference_public_inputs.json")))
+    assert len(pis) == 18 and pis["8_0"]["circuit"] == "RAMPermutation"
+    assert pis["8_0"]["public_inputs"] == [109708311973601377, 8419656762706556756, 7577600993993766672, 4894740677854192130]
+
+
+@pytest.mark.xfail(reason="Poseidon2 linear layers are restated from memory of the absent era-boojum crate and do not "
+                          "reproduce the reference's Merkle nodes yet: 'parity unpinned' (DESIGN.md section 4)", strict=True)
+def test_poseidon2_merkle_node_kat(oracle):
+    """Among the level-16 digests of one proof, sibling pairs must hash to a cap digest."""
+    nodes, cap = _load_kat()
+    capset = {tuple(int(x) for x in c) for c in cap}
+    hits = 0
+    for a in nodes:
+        for b in nodes:
+            if a is not b and tuple(int(x) for x in oracle.hash_node(a, b)) in capset:
+                hits += 1
+    assert hits >= 15
