@@ -77,6 +77,8 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_pointer_mode(native.PTR_DEVICE)
+    if os.environ.get("ZKW_CHAIN_FORM"):
+        ctx.set_chain_form(int(os.environ["ZKW_CHAIN_FORM"]))
 
     B, n = args.blocks, args.queries
     n_rows = 1 << 20  # TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17
@@ -124,6 +126,7 @@ def main():
         wit = per_launch_inst * n                      # witness items read by a launch
         alg_bytes = {
             "k_chain_full": 2 * items * (64 + 96),            # per chain item: 8 words in, 12 words out
+            "k_chain_full_q4": 2 * items * (64 + 96),
             "k_gp_local": 2 * items * (64 + 16),              # rows read once, both repetitions written
             "k_gp_apply": 2 * items * 32,
             "k_encode_mem": items * (48 + 64),
@@ -146,7 +149,7 @@ def main():
                 hbm_kernels[k] = {"achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": kms / kcnt}
         synth_ms = sum(v[0] for k, v in prof.items() if k.startswith("k_ram_fill") or k.startswith("k_ram_nd"))
         synth_gbs = (149 * n_rows * 8 * n_inst_local * args.steps) / (synth_ms * 1e-3) / 1e9 if synth_ms else None
-        chain_ms, chain_cnt = prof.get("k_chain_full", (0.0, 1))
+        chain_ms, chain_cnt = prof.get("k_chain_full", prof.get("k_chain_full_q4", (0.0, 1)))
         out = {
             "metric": "base-layer circuits/sec (2^20 rows)",
             "value": circuits / dt,

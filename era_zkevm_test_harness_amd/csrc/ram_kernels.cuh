@@ -85,6 +85,36 @@ __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ 
     }
 }
 
+// Quad form: 16 chains per wave (p2::Coop4). Lane j of a quad loads enc[j], enc[4+j] and stores tails[j],
+// tails[4+j], tails[8+j]: 32 contiguous bytes per quad per access.
+__global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict__ jobs, int n_jobs) {
+    const int lane = threadIdx.x & 63, j = lane & 3;
+    const int chain = blockIdx.x * 16 + (lane >> 2);
+    p2::Coop4 co;
+    co.init(j);
+    ChainJob job;
+    job.enc = nullptr; job.tails = nullptr; job.tail_in = nullptr; job.n = 0;
+    if (chain < n_jobs) job = jobs[chain];
+    u64 x[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) x[c] = job.tail_in ? job.tail_in[4 * c + j] : 0;
+    u64 e0 = 0, e1 = 0;
+    if (job.n > 0) { e0 = job.enc[j]; e1 = job.enc[4 + j]; }
+    for (u64 i = 0; __any(i < job.n); i++) {
+        const bool live = i < job.n;
+        u64 y[3] = {e0, e1, x[2]};  // AbsorptionModeOverwrite: rate part replaced, capacity kept
+        if (i + 1 < job.n) { e0 = job.enc[8 * (i + 1) + j]; e1 = job.enc[8 * (i + 1) + 4 + j]; }
+        co.permute(y);
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                x[c] = y[c];
+                job.tails[12 * i + 4 * c + j] = gl::canon(y[c]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5: Fiat-Shamir challenges, one job per lane (a handful of permutations; latency-irrelevant).
 struct FsJob {

@@ -66,6 +66,7 @@ struct zkw_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int ptr_mode = ZKW_PTR_HOST;
+    int chain_form = 0;  // lanes per Poseidon2 state in the queue-chain kernel: 4 (quad), 16 (row), 0 = auto
     std::map<std::string, DevBuf> pool;  // named grow-only scratch
     std::map<std::string, HostStage> stages;
     // optional per-kernel timing with HIP events on the context's stream (zkw_profile_*)
@@ -272,6 +273,13 @@ extern "C" int zkw_set_pointer_mode(zkw_ctx* ctx, int mode) {
     return ZKW_OK;
 }
 
+extern "C" int zkw_set_chain_form(zkw_ctx* ctx, int lanes_per_state) {
+    if (!ctx || (lanes_per_state != 0 && lanes_per_state != 4 && lanes_per_state != 16))
+        return fail(ZKW_ERR_INVALID, "chain form must be 0 (auto), 4 or 16");
+    ctx->chain_form = lanes_per_state;
+    return ZKW_OK;
+}
+
 extern "C" int zkw_synchronize(zkw_ctx* ctx) {
     if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -330,8 +338,15 @@ static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     ChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("chain_jobs", jobs, &d_jobs));
     int n_jobs = (int)jobs.size();
-    { Prof _p(ctx, "k_chain_full"); hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, ctx->stream, d_jobs, n_jobs); }
-    return launch_check("k_chain_full");
+    // auto: the row form has the lower latency (11.2 vs 16.3 us per step) and wins while every wave can have
+    // a SIMD to itself (<= 4096 chains); beyond that the quad form's 16 chains per wave win on throughput
+    const int form = ctx->chain_form ? ctx->chain_form : (n_jobs >= 4096 ? 4 : 16);
+    if (form == 16) {
+        { Prof _p(ctx, "k_chain_full"); hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, ctx->stream, d_jobs, n_jobs); }
+        return launch_check("k_chain_full");
+    }
+    { Prof _p(ctx, "k_chain_full_q4"); hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, ctx->stream, d_jobs, n_jobs); }
+    return launch_check("k_chain_full_q4");
 }
 
 static int dev_fs(zkw_ctx* ctx, const std::vector<FsJob>& jobs, int state_w, int n_chal) {

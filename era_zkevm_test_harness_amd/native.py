@@ -26,6 +26,7 @@ SYMBOLS = [
     ("zkw_set_stream", _int, [_vp, _vp]),
     ("zkw_set_pointer_mode", _int, [_vp, _int]),
     ("zkw_synchronize", _int, [_vp]),
+    ("zkw_set_chain_form", _int, [_vp, _int]),
     ("zkw_version", C.c_char_p, []),
     ("zkw_profile_enable", _int, [_vp, _int]),
     ("zkw_profile_reset", _int, [_vp]),
@@ -231,6 +232,9 @@ class Context:
         the context's own stream."""
         h = C.c_void_p(-1) if stream_handle is None else C.c_void_p(stream_handle)
         _check(load().zkw_set_stream(self.handle, h))
+
+    def set_chain_form(self, lanes_per_state):
+        _check(load().zkw_set_chain_form(self.handle, lanes_per_state))
 
     def synchronize(self):
         _check(load().zkw_synchronize(self.handle))

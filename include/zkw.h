@@ -50,6 +50,10 @@ const char *zkw_last_error(void);
 int zkw_set_stream(zkw_ctx *ctx, void *hip_stream);
 int zkw_set_pointer_mode(zkw_ctx *ctx, int mode);
 int zkw_synchronize(zkw_ctx *ctx);
+/* tuning knob: lanes that cooperate on one Poseidon2 state in the queue-chain kernel: 16 (4 chains per wave,
+   row DPP, lowest latency), 4 (16 chains per wave, quad DPP, highest throughput) or 0 = choose by the
+   number of chains in the launch (default). Results are identical. */
+int zkw_set_chain_form(zkw_ctx *ctx, int lanes_per_state);
 /* library/ABI version and the kernels' target ISA ("gfx950") */
 const char *zkw_version(void);
 

@@ -39,6 +39,24 @@ def test_poseidon2_cooperative_and_lane_forms_match_oracle(ctx, oracle):
         assert np.array_equal(got[k], oracle.poseidon2(s)), k
 
 
+@pytest.mark.parametrize("form", [4, 16])
+def test_queue_chain_forms_agree(ctx, oracle, form):
+    """both cooperative layouts of the chain kernel (quad / row of 16) against the oracle, ragged batch"""
+    lens = [3, 0, 40, 1, 9, 17, 2, 5, 33, 8, 1, 1, 64, 7, 12, 3, 100, 6, 2]  # 19 queues: > one wave in quad form
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    enc = synthetic.random_field_elements(177, (int(offsets[-1]), 8))
+    tins = synthetic.random_field_elements(178, (len(lens), 12))
+    ctx.set_chain_form(form)
+    try:
+        got = ctx.queue_push_chain_full_batch(enc, offsets, tins)
+    finally:
+        ctx.set_chain_form(0)
+    for k, ln in enumerate(lens):
+        lo = int(offsets[k])
+        if ln:
+            assert np.array_equal(got[lo:lo + ln], oracle.queue_push_chain_full(enc[lo:lo + ln], tins[k])), k
+
+
 @pytest.mark.parametrize("n", [1, 2, 17, 500])
 def test_queue_chain(ctx, oracle, n):
     enc = synthetic.random_field_elements(100 + n, (n, 8))
