@@ -16,6 +16,7 @@
 #include "../../include/zkw.h"
 #include "ram_kernels.cuh"
 #include "ram_circuit_kernels.cuh"
+#include "log_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -486,6 +487,85 @@ extern "C" int zkw_grand_product_chains(zkw_ctx* ctx, const uint64_t* lhs, const
             if (lhs_z[(size_t)r * n + n - 1] != rhs_z[(size_t)r * n + n - 1])
                 return fail(ZKW_ERR_CHECK_FAILED, "grand products differ in repetition %d (utils.rs:685-696)", r);
     return ZKW_OK;
+}
+
+extern "C" int zkw_encode_log_queries(zkw_ctx* ctx, const zkw_log_query* q, size_t n, const uint32_t* ext_ts,
+                                      uint64_t* enc) {
+    if (!ctx || (n && (!q || !enc))) return fail(ZKW_ERR_INVALID, "zkw_encode_log_queries: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return ZKW_OK;
+    const zkw_log_query* d_q = nullptr;
+    const u32* d_e = nullptr;
+    u64* d_enc = nullptr;
+    ZKW_TRY(ctx->in("lenc_q", q, n, &d_q));
+    if (ext_ts) ZKW_TRY(ctx->in("lenc_ts", ext_ts, n, &d_e));
+    ZKW_TRY(ctx->out("lenc_out", enc, n * 20, &d_enc));
+    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, n, d_e, d_enc); }
+    ZKW_TRY(launch_check("k_encode_log"));
+    ZKW_TRY(ctx->finish_out(enc, d_enc, n * 20));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_encode_decommit_queries(zkw_ctx* ctx, const zkw_decommit_query* q, size_t n, uint64_t* enc) {
+    if (!ctx || (n && (!q || !enc))) return fail(ZKW_ERR_INVALID, "zkw_encode_decommit_queries: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return ZKW_OK;
+    const zkw_decommit_query* d_q = nullptr;
+    u64* d_enc = nullptr;
+    ZKW_TRY(ctx->in("denc_q", q, n, &d_q));
+    ZKW_TRY(ctx->out("denc_out", enc, n * 8, &d_enc));
+    { Prof _p(ctx, "k_encode_decommit"); hipLaunchKernelGGL(k_encode_decommit, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, n, d_enc); }
+    ZKW_TRY(launch_check("k_encode_decommit"));
+    ZKW_TRY(ctx->finish_out(enc, d_enc, n * 8));
+    return ctx->sync_if_host();
+}
+
+// device-level: rounds 1-2 of every item in parallel, then one serial permutation per item and queue
+static int dev_log_chains(zkw_ctx* ctx, const u64* d_enc, size_t total, std::vector<LogChainJob>& jobs) {
+    if (total == 0 || jobs.empty()) return ZKW_OK;
+    u64* d_pre = nullptr;
+    ZKW_TRY(ctx->scratch_t<u64>("log_pre", total * 4, &d_pre));
+    { Prof _p(ctx, "k_log_prehash"); hipLaunchKernelGGL(k_log_prehash, dim3(blocks_for(total, 128)), dim3(128), 0, ctx->stream, d_enc, total, d_pre); }
+    ZKW_TRY(launch_check("k_log_prehash"));
+    for (auto& j : jobs) j.pre = d_pre + (j.enc - d_enc) / 20 * 4;
+    LogChainJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("log_chain_jobs", jobs, &d_jobs));
+    const int n_jobs = (int)jobs.size();
+    { Prof _p(ctx, "k_chain_log"); hipLaunchKernelGGL(k_chain_log, dim3((n_jobs + 3) / 4), dim3(64), 0, ctx->stream, d_jobs, n_jobs); }
+    return launch_check("k_chain_log");
+}
+
+extern "C" int zkw_queue_push_chain_log_batch(zkw_ctx* ctx, const uint64_t* enc, const uint64_t* offsets,
+                                              size_t n_queues, const uint64_t* tails_in, uint64_t* old_tails,
+                                              uint64_t* new_tails) {
+    if (!ctx || !offsets) return fail(ZKW_ERR_INVALID, "zkw_queue_push_chain_log_batch: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (size_t k = 0; k < n_queues; k++)
+        if (offsets[k + 1] < offsets[k]) return fail(ZKW_ERR_INVALID, "offsets must be non-decreasing");
+    const size_t base = n_queues ? offsets[0] : 0, total = n_queues ? offsets[n_queues] - base : 0;
+    if (total && (!enc || !new_tails)) return fail(ZKW_ERR_INVALID, "null enc/new_tails");
+    const u64 *d_enc = nullptr, *d_tin = nullptr;
+    u64 *d_old = nullptr, *d_new = nullptr;
+    ZKW_TRY(ctx->in("lchain_enc", enc + base * 20, total * 20, &d_enc));
+    if (tails_in) ZKW_TRY(ctx->in("lchain_tin", tails_in, n_queues * 4, &d_tin));
+    if (old_tails) ZKW_TRY(ctx->out("lchain_old", old_tails + base * 4, total * 4, &d_old));
+    ZKW_TRY(ctx->out("lchain_new", new_tails + base * 4, total * 4, &d_new));
+    std::vector<LogChainJob> jobs(n_queues);
+    for (size_t k = 0; k < n_queues; k++) {
+        const size_t lo = offsets[k] - base;
+        jobs[k] = LogChainJob{d_enc + lo * 20, nullptr, d_old ? d_old + lo * 4 : nullptr, d_new + lo * 4,
+                              d_tin ? d_tin + 4 * k : nullptr, offsets[k + 1] - offsets[k]};
+    }
+    ZKW_TRY(dev_log_chains(ctx, d_enc, total, jobs));
+    if (old_tails) ZKW_TRY(ctx->finish_out(old_tails + base * 4, d_old, total * 4));
+    ZKW_TRY(ctx->finish_out(new_tails + base * 4, d_new, total * 4));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_queue_push_chain_log(zkw_ctx* ctx, const uint64_t* enc, size_t n, const uint64_t tail_in[4],
+                                        uint64_t* old_tails, uint64_t* new_tails) {
+    uint64_t offsets[2] = {0, n};
+    return zkw_queue_push_chain_log_batch(ctx, enc, offsets, 1, tail_in, old_tails, new_tails);
 }
 
 // ------------------------------------------------------------------------------------------------ RAM builder

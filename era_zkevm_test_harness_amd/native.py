@@ -35,6 +35,10 @@ SYMBOLS = [
     ("zkw_encode_memory_queries", _int, [_vp, _vp, _sz, _u64p]),
     ("zkw_queue_push_chain_full", _int, [_vp, _u64p, _sz, _u64p, _u64p]),
     ("zkw_queue_push_chain_full_batch", _int, [_vp, _u64p, _u64p, _sz, _u64p, _u64p]),
+    ("zkw_encode_log_queries", _int, [_vp, _vp, _sz, _vp, _u64p]),
+    ("zkw_encode_decommit_queries", _int, [_vp, _vp, _sz, _u64p]),
+    ("zkw_queue_push_chain_log_batch", _int, [_vp, _u64p, _u64p, _sz, _u64p, _u64p, _u64p]),
+    ("zkw_queue_push_chain_log", _int, [_vp, _u64p, _sz, _u64p, _u64p, _u64p]),
     ("zkw_fs_challenges", _int, [_vp, _u64p, _u32, _u64p, _u32, _int, _int, _u64p]),
     ("zkw_grand_product_chains", _int, [_vp, _u64p, _u64p, _sz, _int, _u64p, _int, _u64p, _u64p]),
     ("zkw_ram_build_instances", _int, [_vp, _vp, _sz, _u32, _u32, C.POINTER(_vp)]),
@@ -100,6 +104,13 @@ def _u64(a):
 
 from .synthetic import MEM_QUERY  # noqa: E402
 
+LOG_QUERY = np.dtype(
+    [("timestamp", "<u4"), ("tx_number_in_block", "<u2"), ("aux_byte", "u1"), ("shard_id", "u1"),
+     ("address", "<u4", (5,)), ("key", "<u4", (8,)), ("read_value", "<u4", (8,)), ("written_value", "<u4", (8,)),
+     ("rw_flag", "u1"), ("rollback", "u1"), ("is_service", "u1"), ("_pad", "u1")])
+DECOMMIT_QUERY = np.dtype([("hash", "<u4", (8,)), ("timestamp", "<u4"), ("memory_page", "<u4"),
+                           ("decommitted_length", "<u2"), ("is_fresh", "u1"), ("_pad", "u1", (5,))])
+assert LOG_QUERY.itemsize == 128 and DECOMMIT_QUERY.itemsize == 48
 QUEUE_STATE12 = np.dtype([("head", "<u8", (12,)), ("tail", "<u8", (12,)), ("length", "<u4"), ("_pad", "<u4")])
 RAM_FSM = np.dtype(
     [("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)),
@@ -282,6 +293,32 @@ class Context:
         _check(load().zkw_queue_push_chain_full_batch(self.handle, _np_ptr(enc), _np_ptr(offsets), offsets.size - 1,
                                                       tin, _np_ptr(tails)))
         return tails
+
+    def encode_log_queries(self, q, ext_ts=None):
+        """LogQuery::encoding_witness (log_query.rs:102-396); ext_ts -> the extended-enumeration variant."""
+        q = np.ascontiguousarray(q, dtype=LOG_QUERY)
+        enc = np.zeros((q.size, 20), np.uint64)
+        e = None if ext_ts is None else np.ascontiguousarray(ext_ts, dtype=np.uint32)
+        _check(load().zkw_encode_log_queries(self.handle, _np_ptr(q), q.size, None if e is None else _np_ptr(e),
+                                             _np_ptr(enc)))
+        return enc
+
+    def encode_decommit_queries(self, q):
+        q = np.ascontiguousarray(q, dtype=DECOMMIT_QUERY)
+        enc = np.zeros((q.size, 8), np.uint64)
+        _check(load().zkw_encode_decommit_queries(self.handle, _np_ptr(q), q.size, _np_ptr(enc)))
+        return enc
+
+    def queue_push_chain_log(self, enc, offsets=None, tails_in=None):
+        """QueueSimulator pushes (lib.rs:179-221): returns (old_tails, new_tails), each [n][4]."""
+        enc = _u64(enc)
+        n = enc.shape[0]
+        offsets = np.array([0, n], np.uint64) if offsets is None else _u64(offsets)
+        old_t, new_t = np.zeros((n, 4), np.uint64), np.zeros((n, 4), np.uint64)
+        tin = None if tails_in is None else _np_ptr(_u64(tails_in))
+        _check(load().zkw_queue_push_chain_log_batch(self.handle, _np_ptr(enc), _np_ptr(offsets), offsets.size - 1,
+                                                     tin, _np_ptr(old_t), _np_ptr(new_t)))
+        return old_t, new_t
 
     def produce_fs_challenges(self, tail_u, len_u, tail_s, len_s, state_w, n_chal):
         """produce_fs_challenges (utils.rs:498-550): [2][n_chal]."""

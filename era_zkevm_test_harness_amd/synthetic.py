@@ -67,3 +67,43 @@ def random_field_elements(seed: int, shape) -> np.ndarray:
     """Uniform canonical Goldilocks elements (rejection-free: r mod p, bias 2^-32)."""
     n = int(np.prod(shape))
     return (splitmix64(seed, n) % np.uint64(0xFFFFFFFF00000001)).reshape(shape)
+
+
+LOG_QUERY = np.dtype(
+    [("timestamp", "<u4"), ("tx_number_in_block", "<u2"), ("aux_byte", "u1"), ("shard_id", "u1"),
+     ("address", "<u4", (5,)), ("key", "<u4", (8,)), ("read_value", "<u4", (8,)), ("written_value", "<u4", (8,)),
+     ("rw_flag", "u1"), ("rollback", "u1"), ("is_service", "u1"), ("_pad", "u1")])
+DECOMMIT_QUERY = np.dtype([("hash", "<u4", (8,)), ("timestamp", "<u4"), ("memory_page", "<u4"),
+                           ("decommitted_length", "<u2"), ("is_fresh", "u1"), ("_pad", "u1", (5,))])
+
+
+def random_log_queries(n: int, seed: int = 1) -> np.ndarray:
+    """n uniformly random log records (every field exercised; no semantic validity)."""
+    r = splitmix64(seed, 16 * n).reshape(16, n)
+    q = np.zeros(n, LOG_QUERY)
+    q["timestamp"] = (r[0] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    q["tx_number_in_block"] = (r[0] >> np.uint64(32)).astype(np.uint16)
+    q["aux_byte"] = (r[0] >> np.uint64(48)).astype(np.uint8)
+    q["shard_id"] = (r[0] >> np.uint64(56)).astype(np.uint8)
+    w = np.empty((n, 30), np.uint32)
+    for k in range(15):
+        w[:, 2 * k] = (r[1 + k] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        w[:, 2 * k + 1] = (r[1 + k] >> np.uint64(32)).astype(np.uint32)
+    q["address"], q["key"], q["read_value"], q["written_value"] = w[:, 0:5], w[:, 5:13], w[:, 13:21], w[:, 21:29]
+    q["rw_flag"] = (w[:, 29] & 1).astype(np.uint8)
+    q["rollback"] = ((w[:, 29] >> 1) & 1).astype(np.uint8)
+    q["is_service"] = ((w[:, 29] >> 2) & 1).astype(np.uint8)
+    return q
+
+
+def random_decommit_queries(n: int, seed: int = 1) -> np.ndarray:
+    r = splitmix64(seed, 6 * n).reshape(6, n)
+    q = np.zeros(n, DECOMMIT_QUERY)
+    for k in range(4):
+        q["hash"][:, 2 * k] = (r[k] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        q["hash"][:, 2 * k + 1] = (r[k] >> np.uint64(32)).astype(np.uint32)
+    q["timestamp"] = (r[4] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    q["memory_page"] = (r[4] >> np.uint64(32)).astype(np.uint32)
+    q["decommitted_length"] = (r[5] & np.uint64(0xFFFF)).astype(np.uint16)
+    q["is_fresh"] = ((r[5] >> np.uint64(16)) & np.uint64(1)).astype(np.uint8)
+    return q

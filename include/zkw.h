@@ -81,6 +81,23 @@ int zkw_queue_push_chain_full(zkw_ctx *ctx, const uint64_t *enc /* [n][8] */, si
 int zkw_queue_push_chain_full_batch(zkw_ctx *ctx, const uint64_t *enc, const uint64_t *offsets,
                                     size_t n_queues, const uint64_t *tails_in, uint64_t *tails);
 
+/* LogQuery::encoding_witness, circuit_encodings/src/log_query.rs:102-396; with ext_ts != NULL the
+   LogQueryWithExtendedEnumeration variant (log_query.rs:400-427). enc: [n][20]. */
+int zkw_encode_log_queries(zkw_ctx *ctx, const zkw_log_query *q, size_t n, const uint32_t *ext_ts, uint64_t *enc);
+/* DecommittmentQuery::encoding_witness, circuit_encodings/src/decommittment_request.rs:9-74. enc: [n][8]
+   (feeds zkw_queue_push_chain_full: the decommit queue is a full-width queue). */
+int zkw_encode_decommit_queries(zkw_ctx *ctx, const zkw_decommit_query *q, size_t n, uint64_t *enc);
+
+/* QueueSimulator::push_and_output_intermediate_data applied to the items of n_queues independent
+   4-wide queues, circuit_encodings/src/lib.rs:179-221 (LogQueueSimulator: storage, events, L1 messages,
+   precompile requests). enc: [total][20]; offsets: host, n_queues+1; tails_in: [n_queues][4] or NULL;
+   old_tails: [total][4] or NULL (the tail BEFORE each push, what the reference keeps as queue witness,
+   lib.rs:204); new_tails: [total][4]. */
+int zkw_queue_push_chain_log_batch(zkw_ctx *ctx, const uint64_t *enc, const uint64_t *offsets, size_t n_queues,
+                                   const uint64_t *tails_in, uint64_t *old_tails, uint64_t *new_tails);
+int zkw_queue_push_chain_log(zkw_ctx *ctx, const uint64_t *enc, size_t n, const uint64_t tail_in[4],
+                             uint64_t *old_tails, uint64_t *new_tails);
+
 /* produce_fs_challenges, src/witness/utils.rs:498-550. state_w = 12 (RAM, decommit sorter) or 4
    (storage / events sorters); out: [2 repetitions][n_chal], out[r][0] = 1. */
 int zkw_fs_challenges(zkw_ctx *ctx, const uint64_t *tail_u, uint32_t len_u, const uint64_t *tail_s,

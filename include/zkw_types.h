@@ -49,6 +49,48 @@ typedef struct zkw_mem_query {
     uint32_t value[8];         /* U256 as 8 little-endian u32 limbs (decompose_u256_as_u32x8) */
 } zkw_mem_query;
 
+/* One storage / event / L1-message / precompile log (zk_evm::aux_structures::LogQuery as consumed by
+   circuit_encodings/src/log_query.rs:102-396). 128 bytes. 256-bit and 160-bit fields are little-endian
+   u32 limbs (decompose_u256_as_u32x8 / decompose_address_as_u32x5). */
+typedef struct zkw_log_query {
+    uint32_t timestamp;
+    uint16_t tx_number_in_block; /* u16 out of circuit, u32 in circuit (log_query.rs:367) */
+    uint8_t aux_byte;
+    uint8_t shard_id;
+    uint32_t address[5];
+    uint32_t key[8];
+    uint32_t read_value[8];
+    uint32_t written_value[8];
+    uint8_t rw_flag;
+    uint8_t rollback;
+    uint8_t is_service;
+    uint8_t _pad;
+} zkw_log_query;
+
+/* zk_evm::aux_structures::DecommittmentQuery as consumed by
+   circuit_encodings/src/decommittment_request.rs:9-74. 48 bytes. */
+typedef struct zkw_decommit_query {
+    uint32_t hash[8]; /* U256, little-endian limbs */
+    uint32_t timestamp;
+    uint32_t memory_page;
+    uint16_t decommitted_length;
+    uint8_t is_fresh;
+    uint8_t _pad[5];
+} zkw_decommit_query;
+
+/* QueueStateWitness<F, QUEUE_STATE_WIDTH = 4> (src/witness/utils.rs:59-71) */
+typedef struct zkw_queue_state4 {
+    uint64_t head[4];
+    uint64_t tail[4];
+    uint32_t length;
+    uint32_t _pad;
+} zkw_queue_state4;
+
+/* zkevm_circuits::storage_validity_by_grand_product::EXTENDED_TIMESTAMP_ENCODING_{ELEMENT,OFFSET}
+   (log_query.rs:400-427); the crate is absent, values inferred (DESIGN.md "inferred constants") */
+#define ZKW_EXTENDED_TIMESTAMP_ENCODING_ELEMENT 19
+#define ZKW_EXTENDED_TIMESTAMP_ENCODING_OFFSET 8
+
 typedef struct zkw_queue_state12 {
     uint64_t head[12];
     uint64_t tail[12];

@@ -156,6 +156,62 @@ void orc_encode_memory_queries(const zkw_mem_query *q, size_t n, uint64_t *out) 
     for (size_t i = 0; i < n; i++) orc_encode_memory_query(q + i, out + 8 * i);
 }
 
+/* log_query.rs:102-396 */
+static void encode_log_query(const zkw_log_query *q, uint32_t ext_ts, int has_ext, uint64_t out[20]) {
+    uint8_t key_bytes[32], address_bytes[20];
+    for (int i = 0; i < 32; i++) key_bytes[i] = (uint8_t)(q->key[i / 4] >> (8 * (i % 4)));       /* to_little_endian */
+    for (int i = 0; i < 20; i++) address_bytes[i] = (uint8_t)(q->address[i / 4] >> (8 * (i % 4))); /* H160 bytes reversed */
+    const uint64_t S32 = 1ULL << 32, S40 = 1ULL << 40, S48 = 1ULL << 48;
+    uint8_t tail_bytes[60]; /* the 3-byte riders of v0..v16 in order: key[0..32] then address[0..19] */
+    memcpy(tail_bytes, key_bytes, 32);
+    memcpy(tail_bytes + 32, address_bytes, 20);
+    for (int k = 0; k < 17; k++) {
+        uint64_t base = k < 8 ? q->read_value[k] : (k < 16 ? q->written_value[k - 8] : q->timestamp);
+        uint64_t v = base;
+        v = orc_gl_add(v, orc_gl_mul(tail_bytes[3 * k], S32));
+        v = orc_gl_add(v, orc_gl_mul(tail_bytes[3 * k + 1], S40));
+        v = orc_gl_add(v, orc_gl_mul(tail_bytes[3 * k + 2], S48));
+        out[k] = v;
+    }
+    /* v17 = tx_number + address_bytes[19]<<32 + aux_byte<<40 + shard_id<<48 */
+    uint64_t v17 = q->tx_number_in_block;
+    v17 = orc_gl_add(v17, orc_gl_mul(address_bytes[19], S32));
+    v17 = orc_gl_add(v17, orc_gl_mul(q->aux_byte, S40));
+    v17 = orc_gl_add(v17, orc_gl_mul(q->shard_id, S48));
+    out[17] = v17;
+    out[18] = (uint64_t)(q->rw_flag ? 1 : 0) + 2 * (uint64_t)(q->is_service ? 1 : 0);
+    out[19] = q->rollback ? 1 : 0;
+    if (has_ext) /* scale_and_accumulate, log_query.rs:414-421 */
+        out[ZKW_EXTENDED_TIMESTAMP_ENCODING_ELEMENT] =
+            orc_gl_add(out[ZKW_EXTENDED_TIMESTAMP_ENCODING_ELEMENT],
+                       orc_gl_mul(ext_ts, 1ULL << ZKW_EXTENDED_TIMESTAMP_ENCODING_OFFSET));
+}
+
+void orc_encode_log_queries(const zkw_log_query *q, size_t n, const uint32_t *ext_ts, uint64_t *out) {
+    for (size_t i = 0; i < n; i++) encode_log_query(q + i, ext_ts ? ext_ts[i] : 0, ext_ts != NULL, out + 20 * i);
+}
+
+/* decommittment_request.rs:9-74 */
+void orc_encode_decommit_queries(const zkw_decommit_query *q, size_t n, uint64_t *out) {
+    const uint64_t S32 = 1ULL << 32, S40 = 1ULL << 40, S48 = 1ULL << 48;
+    for (size_t i = 0; i < n; i++) {
+        const zkw_decommit_query *d = q + i;
+        uint8_t pb[4], tb[4];
+        for (int k = 0; k < 4; k++) { pb[k] = (uint8_t)(d->memory_page >> (8 * k)); tb[k] = (uint8_t)(d->timestamp >> (8 * k)); }
+        uint64_t *o = out + 8 * i;
+        o[0] = orc_gl_add(orc_gl_add(orc_gl_add(d->hash[0], orc_gl_mul(pb[0], S32)), orc_gl_mul(pb[1], S40)), orc_gl_mul(pb[2], S48));
+        o[1] = orc_gl_add(orc_gl_add(orc_gl_add(d->hash[1], orc_gl_mul(pb[3], S32)), orc_gl_mul(tb[0], S40)), orc_gl_mul(tb[1], S48));
+        o[2] = orc_gl_add(orc_gl_add(orc_gl_add(d->hash[2], orc_gl_mul(tb[2], S32)), orc_gl_mul(tb[3], S40)), orc_gl_mul(d->is_fresh ? 1 : 0, S48));
+        for (int k = 3; k < 8; k++) o[k] = d->hash[k];
+    }
+}
+
+void orc_encode_recursion_request(uint64_t circuit_type, const uint64_t pi[4], uint64_t out[8]) {
+    out[0] = circuit_type % P;
+    for (int k = 0; k < 4; k++) out[1 + k] = pi[k] % P;
+    out[5] = out[6] = out[7] = 0;
+}
+
 /* ------------------------------------------------------------------ queues */
 void orc_queue_push_chain_full(const uint64_t *enc, size_t n, const uint64_t tail_in[12], uint64_t *tails) {
     uint64_t state[12];

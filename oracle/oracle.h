@@ -44,6 +44,14 @@ void orc_poseidon2_hash_leaf(const uint64_t *elems, size_t n, uint64_t out[4]);
 void orc_encode_memory_query(const zkw_mem_query *q, uint64_t out[8]);
 void orc_encode_memory_queries(const zkw_mem_query *q, size_t n, uint64_t *out /* n*8 */);
 
+/* circuit_encodings/src/log_query.rs:102-396; ext_ts != NULL adds the extended timestamp
+   (LogQueryWithExtendedEnumeration, log_query.rs:400-427). out: n*20 */
+void orc_encode_log_queries(const zkw_log_query *q, size_t n, const uint32_t *ext_ts, uint64_t *out);
+/* circuit_encodings/src/decommittment_request.rs:9-74. out: n*8 */
+void orc_encode_decommit_queries(const zkw_decommit_query *q, size_t n, uint64_t *out);
+/* circuit_encodings/src/recursion_request.rs:13-28: [circuit_type, pi0..pi3, 0, 0, 0] */
+void orc_encode_recursion_request(uint64_t circuit_type, const uint64_t pi[4], uint64_t out[8]);
+
 /* ---- queue simulators */
 /* FullWidthQueueSimulator::push_and_output_intermediate_data, lib.rs:391-429: tails[i] = state after
    absorbing enc[i] (rate 8, overwrite) into tails[i-1] (tail_in for i = 0). */

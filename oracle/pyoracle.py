@@ -34,6 +34,16 @@ RAM_INSTANCE = np.dtype(
 assert RAM_INSTANCE.itemsize == 8 + 400 + 8 + 2 * 496 + 16
 
 
+LOG_QUERY = np.dtype(
+    [("timestamp", "<u4"), ("tx_number_in_block", "<u2"), ("aux_byte", "u1"), ("shard_id", "u1"),
+     ("address", "<u4", (5,)), ("key", "<u4", (8,)), ("read_value", "<u4", (8,)), ("written_value", "<u4", (8,)),
+     ("rw_flag", "u1"), ("rollback", "u1"), ("is_service", "u1"), ("_pad", "u1")])
+assert LOG_QUERY.itemsize == 128
+DECOMMIT_QUERY = np.dtype([("hash", "<u4", (8,)), ("timestamp", "<u4"), ("memory_page", "<u4"),
+                           ("decommitted_length", "<u2"), ("is_fresh", "u1"), ("_pad", "u1", (5,))])
+assert DECOMMIT_QUERY.itemsize == 48
+
+
 def build(force=False):
     """Compile liboracle.so with gcc (building the checker is not using it)."""
     if force or not os.path.exists(_LIB_PATH) or any(
@@ -101,6 +111,21 @@ def encode_memory_queries(q):
     q = np.ascontiguousarray(q, dtype=MEM_QUERY)
     out = np.zeros((q.size, 8), np.uint64)
     lib().orc_encode_memory_queries(_p(q), C.c_size_t(q.size), _p(out))
+    return out
+
+
+def encode_log_queries(q, ext_ts=None):
+    q = np.ascontiguousarray(q, dtype=LOG_QUERY)
+    out = np.zeros((q.size, 20), np.uint64)
+    e = None if ext_ts is None else np.ascontiguousarray(ext_ts, dtype=np.uint32)
+    lib().orc_encode_log_queries(_p(q), C.c_size_t(q.size), None if e is None else _p(e), _p(out))
+    return out
+
+
+def encode_decommit_queries(q):
+    q = np.ascontiguousarray(q, dtype=DECOMMIT_QUERY)
+    out = np.zeros((q.size, 8), np.uint64)
+    lib().orc_encode_decommit_queries(_p(q), C.c_size_t(q.size), _p(out))
     return out
 
 

@@ -199,3 +199,31 @@ def test_full_size_properties(ctx):
     assert np.array_equal(inst[0]["hidden_fsm_output"]["current_unsorted_queue_state"]["head"], ut[n - 1])
     assert int(ut.max()) < P
     w.free()
+
+
+@pytest.mark.parametrize("n", [1, 255, 3000])
+def test_log_and_decommit_encodings(ctx, oracle, n):
+    q = synthetic.random_log_queries(n, seed=n)
+    q["key"][0] = 0xFFFFFFFF
+    q["address"][0] = 0xFFFFFFFF
+    assert np.array_equal(ctx.encode_log_queries(q), oracle.encode_log_queries(q))
+    ext = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761)) | np.uint32(0x80000000)
+    assert np.array_equal(ctx.encode_log_queries(q, ext), oracle.encode_log_queries(q, ext))
+    d = synthetic.random_decommit_queries(n, seed=n + 1)
+    assert np.array_equal(ctx.encode_decommit_queries(d), oracle.encode_decommit_queries(d))
+
+
+def test_log_queue_chain_batch(ctx, oracle):
+    lens = [5, 0, 33, 1, 64, 7, 130]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    enc = oracle.encode_log_queries(synthetic.random_log_queries(int(offsets[-1]), seed=9))
+    tins = synthetic.random_field_elements(78, (len(lens), 4))
+    old_t, new_t = ctx.queue_push_chain_log(enc, offsets, tins)
+    for k, ln in enumerate(lens):
+        lo = int(offsets[k])
+        if ln:
+            o_old, o_new = oracle.queue_push_chain_log(enc[lo:lo + ln], tins[k])
+            assert np.array_equal(old_t[lo:lo + ln], o_old) and np.array_equal(new_t[lo:lo + ln], o_new), k
+    o2, n2 = ctx.queue_push_chain_log(enc[:40])
+    e_old, e_new = oracle.queue_push_chain_log(enc[:40])
+    assert np.array_equal(o2, e_old) and np.array_equal(n2, e_new)

@@ -150,3 +150,34 @@ def test_ram_builder_invariants(oracle, n, capacity):
         assert not np.any(fo_last["previous_sorting_key"]) and not np.any(fo_last["previous_value"])
     assert np.all(inst["unsorted_queue_initial_state"]["length"] == n)
     assert np.array_equal(inst[0]["unsorted_queue_initial_state"]["tail"], out["unsorted_tails"][-1])
+
+
+def test_log_and_decommit_encodings_vs_python(oracle):
+    q = synthetic.random_log_queries(50, seed=4)
+    enc = oracle.encode_log_queries(q)
+    ext = np.arange(50, dtype=np.uint32) + np.uint32(7)
+    enc_x = oracle.encode_log_queries(q, ext)
+    for i in range(50):
+        r = q[i]
+        kb = b"".join(int(x).to_bytes(4, "little") for x in r["key"])
+        ab = b"".join(int(x).to_bytes(4, "little") for x in r["address"])
+        riders = kb + ab
+        exp = []
+        for k in range(17):
+            base = int(r["read_value"][k]) if k < 8 else (int(r["written_value"][k - 8]) if k < 16 else int(r["timestamp"]))
+            exp.append(base + (riders[3 * k] << 32) + (riders[3 * k + 1] << 40) + (riders[3 * k + 2] << 48))
+        exp.append(int(r["tx_number_in_block"]) + (ab[19] << 32) + (int(r["aux_byte"]) << 40) + (int(r["shard_id"]) << 48))
+        exp.append(int(r["rw_flag"]) + 2 * int(r["is_service"]))
+        exp.append(int(r["rollback"]))
+        assert [int(x) for x in enc[i]] == exp
+        exp[19] += int(ext[i]) << 8
+        assert [int(x) for x in enc_x[i]] == exp
+    d = synthetic.random_decommit_queries(20, seed=5)
+    e = oracle.encode_decommit_queries(d)
+    for i in range(20):
+        r = d[i]
+        pb, tb = int(r["memory_page"]).to_bytes(4, "little"), int(r["timestamp"]).to_bytes(4, "little")
+        h = [int(x) for x in r["hash"]]
+        exp = [h[0] + (pb[0] << 32) + (pb[1] << 40) + (pb[2] << 48), h[1] + (pb[3] << 32) + (tb[0] << 40) + (tb[1] << 48),
+               h[2] + (tb[2] << 32) + (tb[3] << 40) + (int(r["is_fresh"]) << 48)] + h[3:]
+        assert [int(x) for x in e[i]] == exp
