@@ -17,6 +17,7 @@
 #include "ram_kernels.cuh"
 #include "ram_circuit_kernels.cuh"
 #include "log_kernels.cuh"
+#include "decommit_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -987,4 +988,191 @@ extern "C" int zkw_ram_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t 
     *n_violations = res.violations;
     if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
     return ZKW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decommit sorter
+struct zkw_decommit_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n = 0, n_instances = 0, n_dedup = 0;
+    uint32_t capacity = 0;
+    zkw_decommit_query *sorted_q = nullptr, *dedup_q = nullptr;
+    u64 *unsorted_enc = nullptr, *sorted_enc = nullptr, *unsorted_tails = nullptr, *sorted_tails = nullptr;
+    u64 *dedup_enc = nullptr, *dedup_tails = nullptr, *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
+    zkw_decommit_sorter_instance* instances = nullptr;
+    void release() {
+        void* ptrs[] = {sorted_q, dedup_q, unsorted_enc, sorted_enc, unsorted_tails, sorted_tails, dedup_enc,
+                        dedup_tails, challenges, lhs_z, rhs_z, instances};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+};
+
+static int decommit_run(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_decommit_query* d_q,
+                        const zkw_queue_state12& dedup_in) {
+    const size_t n = w->n;
+    const unsigned grid = blocks_for(n, 256);
+    // unsorted side
+    { Prof _p(ctx, "k_encode_decommit"); hipLaunchKernelGGL(k_encode_decommit, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, w->unsorted_enc); }
+    ZKW_TRY(launch_check("k_encode_decommit"));
+    // sort: timestamp, then the hash from its least to its most significant 64 bits (stable LSD)
+    u32 *ts = nullptr, *k32 = nullptr, *v0 = nullptr, *v1 = nullptr;
+    u64 *hk[4] = {nullptr, nullptr, nullptr, nullptr}, *k64a = nullptr, *k64b = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = radix_temp_bytes(n);
+    ZKW_TRY(ctx->scratch_t<u32>("sort_ts", n, &ts));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_k32", n, &k32));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_v0", n, &v0));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_v1", n, &v1));
+    const char* hn[4] = {"dsort_h0", "dsort_h1", "dsort_h2", "dsort_h3"};
+    for (int k = 0; k < 4; k++) ZKW_TRY(ctx->scratch_t<u64>(hn[k], n, &hk[k]));
+    ZKW_TRY(ctx->scratch_t<u64>("sort_k64a", n, &k64a));
+    ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", n, &k64b));
+    ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
+    { Prof _p(ctx, "k_decommit_sort_keys"); hipLaunchKernelGGL(k_decommit_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, ts, hk[0], hk[1], hk[2], hk[3], v0); }
+    ZKW_TRY(launch_check("k_decommit_sort_keys"));
+    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, ts, k32, v0, v1, n, 32, ctx->stream)); }
+    u32 *cur = v1, *nxt = v0;
+    for (int k = 0; k < 4; k++) {
+        { Prof _p(ctx, "k_gather_u64_by_u32"); hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, hk[k], cur, n, k64a); }
+        ZKW_TRY(launch_check("k_gather_u64_by_u32"));
+        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, cur, nxt, n, 64, ctx->stream)); }
+        u32* t = cur; cur = nxt; nxt = t;
+    }
+    { Prof _p(ctx, "k_decommit_gather_encode"); hipLaunchKernelGGL(k_decommit_gather_encode, dim3(grid), dim3(256), 0, ctx->stream, d_q, cur, n, w->sorted_q, w->sorted_enc); }
+    ZKW_TRY(launch_check("k_decommit_gather_encode"));
+    // deduplicated queue = the fresh requests in sorted order
+    u32 *fresh_count = nullptr, *last_fresh = nullptr, *totals = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("dec_fresh", n, &fresh_count));
+    ZKW_TRY(ctx->scratch_t<u32>("dec_lastf", n, &last_fresh));
+    ZKW_TRY(ctx->scratch_t<u32>("dec_totals", 2, &totals));
+    { Prof _p(ctx, "k_decommit_dedup"); hipLaunchKernelGGL(k_decommit_dedup, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, w->sorted_enc, n, fresh_count, last_fresh, w->dedup_q, w->dedup_enc, totals); }
+    ZKW_TRY(launch_check("k_decommit_dedup"));
+    u32 h_totals[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_totals, totals, sizeof h_totals, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the dedup chain length is data-dependent
+    if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "decommit requests with the same hash disagree on page or are not "
+                                                       "timestamp-ordered (sort_decommit_requests.rs:99-114)");
+    w->n_dedup = h_totals[0];
+    // three chains in one launch
+    zkw_queue_state12* d_dedup_in = nullptr;
+    std::vector<zkw_queue_state12> din(1, dedup_in);
+    ZKW_TRY(ctx->upload("dec_dedup_in", din, &d_dedup_in));
+    std::vector<ChainJob> chains;
+    chains.push_back(ChainJob{w->unsorted_enc, w->unsorted_tails, nullptr, n});
+    chains.push_back(ChainJob{w->sorted_enc, w->sorted_tails, nullptr, n});
+    chains.push_back(ChainJob{w->dedup_enc, w->dedup_tails, d_dedup_in->tail, w->n_dedup});
+    ZKW_TRY(dev_chains(ctx, chains));
+    std::vector<FsJob> fs(1);
+    fs[0] = FsJob{w->unsorted_tails + 12 * (n - 1), w->sorted_tails + 12 * (n - 1), (u32)n, (u32)n, w->challenges};
+    ZKW_TRY(dev_fs(ctx, fs, 12, 9));
+    std::vector<GpSeg> segs;
+    segs.push_back(GpSeg{w->unsorted_enc, w->lhs_z, w->challenges, n, 0, 0});
+    segs.push_back(GpSeg{w->sorted_enc, w->rhs_z, w->challenges, n, 0, 0});
+    ZKW_TRY(dev_grand_products(ctx, segs, 8, 2));
+    std::vector<DecommitBlock> blk(1);
+    blk[0] = DecommitBlock{w->sorted_q, w->unsorted_tails, w->sorted_tails, w->dedup_tails, w->lhs_z, w->rhs_z,
+                           fresh_count, last_fresh, w->instances, dedup_in, n, w->capacity};
+    DecommitBlock* d_blk = nullptr;
+    ZKW_TRY(ctx->upload("dec_block", blk, &d_blk));
+    { Prof _p(ctx, "k_decommit_instances"); hipLaunchKernelGGL(k_decommit_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    return launch_check("k_decommit_instances");
+}
+
+extern "C" int zkw_decommit_sorter_build(zkw_ctx* ctx, const zkw_decommit_query* q, size_t n, uint32_t capacity,
+                                         const zkw_queue_state12* dedup_in, zkw_decommit_witness** out) {
+    if (!ctx || !q || !out || capacity == 0) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_build: bad argument");
+    if (n == 0) return fail(ZKW_ERR_INVALID, "VM should have made some code decommits (sort_decommit_requests.rs:38-41)");
+    if (n >= (1ull << 32)) return fail(ZKW_ERR_INVALID, "too many requests");
+    HIP_TRY(hipSetDevice(ctx->device));
+    zkw_decommit_witness* w = new zkw_decommit_witness();
+    w->ctx = ctx;
+    w->n = n;
+    w->capacity = capacity;
+    w->n_instances = (n + capacity - 1) / capacity;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    alloc((void**)&w->sorted_q, n * sizeof(zkw_decommit_query));
+    alloc((void**)&w->dedup_q, n * sizeof(zkw_decommit_query));
+    alloc((void**)&w->unsorted_enc, n * 64); alloc((void**)&w->sorted_enc, n * 64); alloc((void**)&w->dedup_enc, n * 64);
+    alloc((void**)&w->unsorted_tails, n * 96); alloc((void**)&w->sorted_tails, n * 96); alloc((void**)&w->dedup_tails, n * 96);
+    alloc((void**)&w->challenges, 18 * 8); alloc((void**)&w->lhs_z, n * 16); alloc((void**)&w->rhs_z, n * 16);
+    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_decommit_sorter_instance));
+    if (e != hipSuccess) {
+        w->release();
+        delete w;
+        return fail(ZKW_ERR_OOM, "zkw_decommit_sorter_build: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    zkw_queue_state12 din;
+    memset(&din, 0, sizeof din);
+    if (dedup_in) din = *dedup_in;
+    const zkw_decommit_query* d_q = nullptr;
+    int rc = ctx->in("dec_q", q, n, &d_q);
+    if (rc == ZKW_OK) rc = decommit_run(ctx, w, d_q, din);
+    if (rc == ZKW_OK) rc = ctx->sync_if_host();
+    if (rc == ZKW_OK && ctx->ptr_mode == ZKW_PTR_HOST) {  // lhs == rhs at the end (utils.rs:685-696)
+        u64 ends[4];
+        for (int r = 0; r < 2 && rc == ZKW_OK; r++) {
+            if (hipMemcpy(&ends[2 * r], w->lhs_z + (size_t)r * n + n - 1, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(&ends[2 * r + 1], w->rhs_z + (size_t)r * n + n - 1, 8, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail(ZKW_ERR_HIP, "readback failed");
+            else if (ends[2 * r] != ends[2 * r + 1])
+                rc = fail(ZKW_ERR_CHECK_FAILED, "grand products differ in repetition %d", r);
+        }
+    }
+    if (rc != ZKW_OK) {
+        w->release();
+        delete w;
+        return rc;
+    }
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" size_t zkw_decommit_witness_num_instances(const zkw_decommit_witness* w) { return w ? w->n_instances : 0; }
+extern "C" size_t zkw_decommit_witness_num_dedup(const zkw_decommit_witness* w) { return w ? w->n_dedup : 0; }
+
+static const void* dec_array(const zkw_decommit_witness* w, int what, size_t* bytes) {
+    const size_t n = w->n, nd = w->n_dedup;
+    switch (what) {
+        case ZKW_DEC_SORTED_QUERIES: *bytes = n * sizeof(zkw_decommit_query); return w->sorted_q;
+        case ZKW_DEC_UNSORTED_ENC: *bytes = n * 64; return w->unsorted_enc;
+        case ZKW_DEC_SORTED_ENC: *bytes = n * 64; return w->sorted_enc;
+        case ZKW_DEC_UNSORTED_TAILS: *bytes = n * 96; return w->unsorted_tails;
+        case ZKW_DEC_SORTED_TAILS: *bytes = n * 96; return w->sorted_tails;
+        case ZKW_DEC_DEDUP_QUERIES: *bytes = nd * sizeof(zkw_decommit_query); return w->dedup_q;
+        case ZKW_DEC_DEDUP_TAILS: *bytes = nd * 96; return w->dedup_tails;
+        case ZKW_DEC_CHALLENGES: *bytes = 18 * 8; return w->challenges;
+        case ZKW_DEC_LHS_Z: *bytes = n * 16; return w->lhs_z;
+        case ZKW_DEC_RHS_Z: *bytes = n * 16; return w->rhs_z;
+        case ZKW_DEC_INSTANCES: *bytes = w->n_instances * sizeof(zkw_decommit_sorter_instance); return w->instances;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_decommit_witness_bytes(const zkw_decommit_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)dec_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_decommit_witness_device_ptr(const zkw_decommit_witness* w, int what) {
+    size_t b = 0;
+    return w ? dec_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_decommit_witness_get(const zkw_decommit_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_decommit_witness_get: null argument");
+    size_t bytes = 0;
+    const void* src = dec_array(w, what, &bytes);
+    if (!src && bytes == 0 && what > ZKW_DEC_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_decommit_witness_free(zkw_decommit_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    delete w;
 }

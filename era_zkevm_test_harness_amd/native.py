@@ -49,6 +49,13 @@ SYMBOLS = [
     ("zkw_ram_witness_device_ptr", _vp, [_vp, _int]),
     ("zkw_ram_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_ram_witness_free", None, [_vp]),
+    ("zkw_decommit_sorter_build", _int, [_vp, _vp, _sz, _u32, _vp, C.POINTER(_vp)]),
+    ("zkw_decommit_witness_num_instances", _sz, [_vp]),
+    ("zkw_decommit_witness_num_dedup", _sz, [_vp]),
+    ("zkw_decommit_witness_bytes", _sz, [_vp, _int]),
+    ("zkw_decommit_witness_device_ptr", _vp, [_vp, _int]),
+    ("zkw_decommit_witness_get", _int, [_vp, _int, _vp, _sz]),
+    ("zkw_decommit_witness_free", None, [_vp]),
     ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
     ("zkw_trace_free", None, [_vp]),
     ("zkw_trace_num_rows", _sz, [_vp]),
@@ -123,6 +130,59 @@ RAM_INSTANCE = np.dtype(
      ("non_deterministic_bootloader_memory_snapshot_length", "<u4"), ("_pad", "<u4"),
      ("hidden_fsm_input", RAM_FSM), ("hidden_fsm_output", RAM_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
 assert QUEUE_STATE12.itemsize == 200 and RAM_FSM.itemsize == 496 and RAM_INSTANCE.itemsize == 1424
+
+
+DECOMMIT_FSM = np.dtype(
+    [("initial_queue_state", QUEUE_STATE12), ("sorted_queue_state", QUEUE_STATE12), ("final_queue_state", QUEUE_STATE12),
+     ("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)), ("previous_packed_key", "<u4", (9,)),
+     ("first_encountered_timestamp", "<u4"), ("_pad", "<u4", (2,)), ("previous_record", DECOMMIT_QUERY)])
+DECOMMIT_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_queue_state", QUEUE_STATE12),
+     ("sorted_queue_initial_state", QUEUE_STATE12), ("final_queue_state", QUEUE_STATE12),
+     ("hidden_fsm_input", DECOMMIT_FSM), ("hidden_fsm_output", DECOMMIT_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
+(DEC_SORTED_QUERIES, DEC_UNSORTED_ENC, DEC_SORTED_ENC, DEC_UNSORTED_TAILS, DEC_SORTED_TAILS, DEC_DEDUP_QUERIES,
+ DEC_DEDUP_TAILS, DEC_CHALLENGES, DEC_LHS_Z, DEC_RHS_Z, DEC_INSTANCES) = range(11)
+
+
+class DecommitWitness:
+    """Owner of a zkw_decommit_witness handle."""
+
+    _DTYPES = {DEC_SORTED_QUERIES: DECOMMIT_QUERY, DEC_DEDUP_QUERIES: DECOMMIT_QUERY, DEC_INSTANCES: DECOMMIT_INSTANCE}
+    _SHAPES = {DEC_UNSORTED_ENC: (-1, 8), DEC_SORTED_ENC: (-1, 8), DEC_UNSORTED_TAILS: (-1, 12), DEC_SORTED_TAILS: (-1, 12),
+               DEC_DEDUP_TAILS: (-1, 12), DEC_CHALLENGES: (2, 9), DEC_LHS_Z: (2, -1), DEC_RHS_Z: (2, -1)}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = C.c_void_p(None)
+
+    @property
+    def num_instances(self):
+        return load().zkw_decommit_witness_num_instances(self.handle)
+
+    @property
+    def num_dedup(self):
+        return load().zkw_decommit_witness_num_dedup(self.handle)
+
+    def get(self, what):
+        lib = load()
+        nbytes = lib.zkw_decommit_witness_bytes(self.handle, what)
+        dt = self._DTYPES.get(what, np.dtype("<u8"))
+        out = np.zeros(nbytes // dt.itemsize, dt)
+        if nbytes:
+            _check(lib.zkw_decommit_witness_get(self.handle, what, _np_ptr(out), nbytes))
+        shape = self._SHAPES.get(what)
+        return out.reshape(shape) if shape else out
+
+    def free(self):
+        if self.handle:
+            load().zkw_decommit_witness_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class RamWitness:
@@ -375,3 +435,12 @@ class Context:
         _check(load().zkw_ram_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
         v = first.value
         return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+    def compute_decommitts_sorter_circuit_snapshots(self, queries, deduplicator_circuit_capacity, dedup_in=None):
+        """compute_decommitts_sorter_circuit_snapshots (sort_decommit_requests.rs:20-420) -> DecommitWitness."""
+        q = np.ascontiguousarray(queries, dtype=DECOMMIT_QUERY)
+        w = DecommitWitness(self)
+        din = None if dedup_in is None else _np_ptr(np.ascontiguousarray(dedup_in, dtype=QUEUE_STATE12))
+        _check(load().zkw_decommit_sorter_build(self.handle, _np_ptr(q), q.size, deduplicator_circuit_capacity, din,
+                                                C.byref(w.handle)))
+        return w

@@ -107,3 +107,30 @@ def random_decommit_queries(n: int, seed: int = 1) -> np.ndarray:
     q["decommitted_length"] = (r[5] & np.uint64(0xFFFF)).astype(np.uint16)
     q["is_fresh"] = ((r[5] >> np.uint64(16)) & np.uint64(1)).astype(np.uint8)
     return q
+
+
+def decommit_trace(n: int, n_hashes: int, seed: int = 1) -> np.ndarray:
+    """Valid decommit-request queue: n requests over n_hashes distinct bytecode hashes, timestamps strictly
+    increasing in queue order, one memory page per hash, is_fresh on the first request of each hash."""
+    r = splitmix64(seed, 5 * n_hashes + n).reshape(-1)
+    hashes = np.zeros((n_hashes, 8), np.uint32)
+    for k in range(4):
+        hashes[:, 2 * k] = (r[k * n_hashes:(k + 1) * n_hashes] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hashes[:, 2 * k + 1] = (r[k * n_hashes:(k + 1) * n_hashes] >> np.uint64(32)).astype(np.uint32)
+    hashes[:, 7] &= 0x0000FFFF  # the top bytes of a versioned hash are small
+    hashes[: min(4, n_hashes), 1:] = hashes[0, 1:]  # a few hashes that differ only in the lowest limb
+    pages = (8 + 8 * np.arange(n_hashes)).astype(np.uint32)
+    pick = (r[5 * n_hashes:] % np.uint64(n_hashes)).astype(np.int64)
+    q = np.zeros(n, DECOMMIT_QUERY)
+    q["hash"] = hashes[pick]
+    q["memory_page"] = pages[pick]
+    q["timestamp"] = 1 + 3 * np.arange(n, dtype=np.uint32)
+    q["decommitted_length"] = (1 + 2 * (pick % 100)).astype(np.uint16)
+    seen = np.zeros(n_hashes, bool)
+    fresh = np.zeros(n, np.uint8)
+    for i, h in enumerate(pick):
+        if not seen[h]:
+            seen[h] = True
+            fresh[i] = 1
+    q["is_fresh"] = fresh
+    return q

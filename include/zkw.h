@@ -143,6 +143,35 @@ const void *zkw_ram_witness_device_ptr(const zkw_ram_witness *w, int what);
 int zkw_ram_witness_get(const zkw_ram_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_ram_witness_free(zkw_ram_witness *w);
 
+/* ---- CodeDecommittmentsSorter witness builder --------------------------------------------------- */
+typedef struct zkw_decommit_witness zkw_decommit_witness;
+/* compute_decommitts_sorter_circuit_snapshots, src/witness/individual_circuits/sort_decommit_requests.rs:20-420.
+   q: the block's decommit requests in queue order (n > 0); dedup_in (host, may be NULL = empty) is the
+   state of the deduplicated queue the results are appended to (the reference passes the simulator in).
+   Returns ZKW_ERR_CHECK_FAILED when the reference's ordering self-check (:99-114) or the grand-product
+   check fails. */
+int zkw_decommit_sorter_build(zkw_ctx *ctx, const zkw_decommit_query *q, size_t n, uint32_t capacity,
+                              const zkw_queue_state12 *dedup_in, zkw_decommit_witness **out);
+enum {
+    ZKW_DEC_SORTED_QUERIES = 0, /* zkw_decommit_query[n]  */
+    ZKW_DEC_UNSORTED_ENC = 1,   /* uint64_t[n][8]         */
+    ZKW_DEC_SORTED_ENC = 2,
+    ZKW_DEC_UNSORTED_TAILS = 3, /* uint64_t[n][12]        */
+    ZKW_DEC_SORTED_TAILS = 4,
+    ZKW_DEC_DEDUP_QUERIES = 5,  /* zkw_decommit_query[n_dedup] : deduplicated_decommit_requests */
+    ZKW_DEC_DEDUP_TAILS = 6,    /* uint64_t[n_dedup][12]   : deduplicated_decommittment_queue_states */
+    ZKW_DEC_CHALLENGES = 7,     /* uint64_t[2][9]          */
+    ZKW_DEC_LHS_Z = 8,          /* uint64_t[2][n]          */
+    ZKW_DEC_RHS_Z = 9,
+    ZKW_DEC_INSTANCES = 10      /* zkw_decommit_sorter_instance[ceil(n/capacity)] */
+};
+size_t zkw_decommit_witness_num_instances(const zkw_decommit_witness *w);
+size_t zkw_decommit_witness_num_dedup(const zkw_decommit_witness *w);
+size_t zkw_decommit_witness_bytes(const zkw_decommit_witness *w, int what);
+const void *zkw_decommit_witness_device_ptr(const zkw_decommit_witness *w, int what);
+int zkw_decommit_witness_get(const zkw_decommit_witness *w, int what, void *dst, size_t dst_bytes);
+void zkw_decommit_witness_free(zkw_decommit_witness *w);
+
 /* ---- synthesis: filled traces ------------------------------------------------------------------- */
 /* A zkw_trace owns n_slots trace buffers in HBM, each column-major uint64_t[n_cols][n_rows] (n_rows =
    2^20 at production geometry = TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17). It plays the role of

@@ -127,6 +127,36 @@ typedef struct zkw_ram_instance {
     uint64_t num_items;
 } zkw_ram_instance;
 
+/* ---- CodeDecommittmentsSorter (sort_decommit_requests.rs) ---------------------------------------- */
+#define ZKW_DECOMMIT_PACKED_KEY_LENGTH 9 /* [timestamp, hash limbs 0..7], sort_decommit_requests.rs:422-435 */
+
+/* CodeDecommittmentsDeduplicatorFSMInputOutputWitness, fields as filled at
+   src/witness/individual_circuits/sort_decommit_requests.rs:402-414 */
+typedef struct zkw_decommit_sorter_fsm {
+    zkw_queue_state12 initial_queue_state; /* unsorted queue, remaining part */
+    zkw_queue_state12 sorted_queue_state;
+    zkw_queue_state12 final_queue_state;   /* deduplicated (output) queue */
+    uint64_t lhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];
+    uint64_t rhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];
+    uint32_t previous_packed_key[ZKW_DECOMMIT_PACKED_KEY_LENGTH];
+    uint32_t first_encountered_timestamp;
+    uint32_t _pad[2];
+    zkw_decommit_query previous_record; /* DecommitQueryWitness{code_hash, page, is_first, timestamp} */
+} zkw_decommit_sorter_fsm;
+
+/* CodeDecommittmentsDeduplicatorInstanceWitness, sort_decommit_requests.rs:345-420 */
+typedef struct zkw_decommit_sorter_instance {
+    uint32_t start_flag;
+    uint32_t completion_flag;
+    zkw_queue_state12 initial_queue_state;        /* observable_input */
+    zkw_queue_state12 sorted_queue_initial_state; /* observable_input */
+    zkw_queue_state12 final_queue_state;          /* observable_output (placeholder except on the last) */
+    zkw_decommit_sorter_fsm hidden_fsm_input;
+    zkw_decommit_sorter_fsm hidden_fsm_output;
+    uint64_t first_item;
+    uint64_t num_items;
+} zkw_decommit_sorter_instance;
+
 #ifdef __cplusplus
 }
 #endif

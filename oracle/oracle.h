@@ -87,6 +87,19 @@ int64_t orc_ram_build_instances(const zkw_mem_query *q, size_t n, uint32_t capac
                                 uint64_t *sorted_tails, uint64_t *challenges, uint64_t *lhs_z,
                                 uint64_t *rhs_z, zkw_ram_instance *instances);
 
+/* ---- decommit sorter builder, src/witness/individual_circuits/sort_decommit_requests.rs:20-420.
+   q: the block's decommit requests in queue order (n > 0). dedup_in: state of the deduplicated queue
+   before the call (NULL = empty). Outputs (caller-allocated): sorted_q[n], unsorted/sorted enc [n*8] and
+   tails [n*12], dedup_q/dedup_enc/dedup_tails sized for n (first *n_dedup used), challenges [2*9],
+   lhs_z/rhs_z [2*n], instances [ceil(n/capacity)]. Returns the number of instances or <0 when one of the
+   reference's asserts fails. */
+int64_t orc_decommit_sorter_build(const zkw_decommit_query *q, size_t n, uint32_t capacity,
+                                  const zkw_queue_state12 *dedup_in, zkw_decommit_query *sorted_q,
+                                  uint64_t *unsorted_enc, uint64_t *sorted_enc, uint64_t *unsorted_tails,
+                                  uint64_t *sorted_tails, zkw_decommit_query *dedup_q, uint64_t *dedup_enc,
+                                  uint64_t *dedup_tails, uint64_t *n_dedup, uint64_t *challenges,
+                                  uint64_t *lhs_z, uint64_t *rhs_z, zkw_decommit_sorter_instance *instances);
+
 #ifdef __cplusplus
 }
 #endif

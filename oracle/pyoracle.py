@@ -44,6 +44,16 @@ DECOMMIT_QUERY = np.dtype([("hash", "<u4", (8,)), ("timestamp", "<u4"), ("memory
 assert DECOMMIT_QUERY.itemsize == 48
 
 
+DECOMMIT_FSM = np.dtype(
+    [("initial_queue_state", QUEUE_STATE12), ("sorted_queue_state", QUEUE_STATE12), ("final_queue_state", QUEUE_STATE12),
+     ("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)), ("previous_packed_key", "<u4", (9,)),
+     ("first_encountered_timestamp", "<u4"), ("_pad", "<u4", (2,)), ("previous_record", DECOMMIT_QUERY)])
+DECOMMIT_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_queue_state", QUEUE_STATE12),
+     ("sorted_queue_initial_state", QUEUE_STATE12), ("final_queue_state", QUEUE_STATE12),
+     ("hidden_fsm_input", DECOMMIT_FSM), ("hidden_fsm_output", DECOMMIT_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
+
+
 def build(force=False):
     """Compile liboracle.so with gcc (building the checker is not using it)."""
     if force or not os.path.exists(_LIB_PATH) or any(
@@ -243,3 +253,27 @@ def poseidon2_flattened(state):
     out = np.zeros(130, np.uint64)
     lib().orc_poseidon2_flattened(_p(s), _p(out))
     return out
+
+
+def decommit_sorter_build(q, capacity, dedup_in=None):
+    q = np.ascontiguousarray(q, dtype=DECOMMIT_QUERY)
+    n = q.size
+    n_inst = (n + capacity - 1) // capacity
+    o = dict(sorted_q=np.zeros(n, DECOMMIT_QUERY), unsorted_enc=np.zeros((n, 8), np.uint64),
+             sorted_enc=np.zeros((n, 8), np.uint64), unsorted_tails=np.zeros((n, 12), np.uint64),
+             sorted_tails=np.zeros((n, 12), np.uint64), dedup_q=np.zeros(n, DECOMMIT_QUERY),
+             dedup_enc=np.zeros((n, 8), np.uint64), dedup_tails=np.zeros((n, 12), np.uint64),
+             challenges=np.zeros((2, 9), np.uint64), lhs_z=np.zeros((2, n), np.uint64), rhs_z=np.zeros((2, n), np.uint64),
+             instances=np.zeros(n_inst, DECOMMIT_INSTANCE))
+    nd = C.c_uint64(0)
+    din = None if dedup_in is None else _p(np.ascontiguousarray(dedup_in, dtype=QUEUE_STATE12))
+    f = lib().orc_decommit_sorter_build
+    f.restype = C.c_int64
+    rc = f(_p(q), C.c_size_t(n), C.c_uint32(capacity), din, _p(o["sorted_q"]), _p(o["unsorted_enc"]), _p(o["sorted_enc"]),
+           _p(o["unsorted_tails"]), _p(o["sorted_tails"]), _p(o["dedup_q"]), _p(o["dedup_enc"]), _p(o["dedup_tails"]),
+           C.byref(nd), _p(o["challenges"]), _p(o["lhs_z"]), _p(o["rhs_z"]), _p(o["instances"]))
+    if rc < 0:
+        raise RuntimeError(f"orc_decommit_sorter_build failed: {rc}")
+    k = nd.value
+    o["dedup_q"], o["dedup_enc"], o["dedup_tails"] = o["dedup_q"][:k], o["dedup_enc"][:k], o["dedup_tails"][:k]
+    return o

@@ -227,3 +227,41 @@ def test_log_queue_chain_batch(ctx, oracle):
     o2, n2 = ctx.queue_push_chain_log(enc[:40])
     e_old, e_new = oracle.queue_push_chain_log(enc[:40])
     assert np.array_equal(o2, e_old) and np.array_equal(n2, e_new)
+
+
+@pytest.mark.parametrize("n,hashes,capacity", [(1, 1, 4), (64, 5, 16), (100, 30, 16), (3000, 700, 256), (5000, 40, 117500),
+                                               (2048, 2048, 1024)])
+def test_decommit_sorter(ctx, oracle, n, hashes, capacity):
+    from era_zkevm_test_harness_amd import native as nv
+
+    q = synthetic.decommit_trace(n, hashes, seed=n + hashes)
+    din = np.zeros(1, oracle.QUEUE_STATE12)
+    din["tail"] = synthetic.random_field_elements(3, (12,))
+    din["head"] = synthetic.random_field_elements(4, (12,))
+    din["length"] = 9
+    for dedup_in in (None, din):
+        w = ctx.compute_decommitts_sorter_circuit_snapshots(q, capacity, dedup_in)
+        o = oracle.decommit_sorter_build(q, capacity, dedup_in)
+        assert w.num_dedup == o["dedup_q"].size
+        for what, key in ((nv.DEC_SORTED_QUERIES, "sorted_q"), (nv.DEC_UNSORTED_ENC, "unsorted_enc"),
+                          (nv.DEC_SORTED_ENC, "sorted_enc"), (nv.DEC_UNSORTED_TAILS, "unsorted_tails"),
+                          (nv.DEC_SORTED_TAILS, "sorted_tails"), (nv.DEC_DEDUP_QUERIES, "dedup_q"),
+                          (nv.DEC_DEDUP_TAILS, "dedup_tails"), (nv.DEC_CHALLENGES, "challenges"),
+                          (nv.DEC_LHS_Z, "lhs_z"), (nv.DEC_RHS_Z, "rhs_z")):
+            assert np.array_equal(w.get(what), o[key]), key
+        gi = w.get(nv.DEC_INSTANCES)
+        assert gi.size == o["instances"].size
+        for a, b in zip(gi, o["instances"]):
+            for f in a.dtype.names:
+                assert a[f].tobytes() == b[f].tobytes(), f
+        w.free()
+
+
+def test_decommit_sorter_self_check(ctx):
+    from era_zkevm_test_harness_amd import native as nv
+
+    q = synthetic.decommit_trace(40, 3, seed=2)
+    q["memory_page"][-1] += 1
+    with pytest.raises(nv.ZkwError) as ei:
+        ctx.compute_decommitts_sorter_circuit_snapshots(q, 16)
+    assert ei.value.code == nv.ERR_CHECK_FAILED

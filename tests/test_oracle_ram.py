@@ -181,3 +181,42 @@ def test_log_and_decommit_encodings_vs_python(oracle):
         exp = [h[0] + (pb[0] << 32) + (pb[1] << 40) + (pb[2] << 48), h[1] + (pb[3] << 32) + (tb[0] << 40) + (tb[1] << 48),
                h[2] + (tb[2] << 32) + (tb[3] << 40) + (int(r["is_fresh"]) << 48)] + h[3:]
         assert [int(x) for x in e[i]] == exp
+
+
+@pytest.mark.parametrize("n,hashes,capacity", [(1, 1, 4), (64, 5, 16), (100, 30, 16), (300, 300, 64), (50, 7, 1000)])
+def test_decommit_sorter_oracle_invariants(oracle, n, hashes, capacity):
+    q = synthetic.decommit_trace(n, hashes, seed=n)
+    o = oracle.decommit_sorter_build(q, capacity)
+    sq = o["sorted_q"]
+    keys = [tuple(int(x) for x in r["hash"][::-1]) + (int(r["timestamp"]),) for r in sq]
+    assert keys == sorted(keys)
+    assert o["dedup_q"].size == int(q["is_fresh"].sum()) == len({tuple(r["hash"]) for r in q})
+    assert np.array_equal(o["dedup_q"], sq[sq["is_fresh"] == 1])
+    inst = o["instances"]
+    k = inst.size
+    assert k == -(-n // capacity) and inst[0]["start_flag"] == 1 and inst[-1]["completion_flag"] == 1
+    assert not inst[0]["hidden_fsm_input"].tobytes().strip(b"\0")  # placeholder
+    for i in range(k - 1):
+        assert inst[i + 1]["hidden_fsm_input"].tobytes() == inst[i]["hidden_fsm_output"].tobytes()
+    fo = inst[-1]["hidden_fsm_output"]
+    assert np.array_equal(fo["lhs_accumulator"], fo["rhs_accumulator"])
+    assert fo["initial_queue_state"]["length"] == 0 and fo["sorted_queue_state"]["length"] == 0
+    assert np.array_equal(fo["final_queue_state"]["tail"], o["dedup_tails"][-1])
+    assert int(fo["final_queue_state"]["length"]) == o["dedup_q"].size
+    assert inst[-1]["final_queue_state"].tobytes() == fo["final_queue_state"].tobytes()
+    if n % capacity:
+        assert not fo["previous_packed_key"].any() and fo["first_encountered_timestamp"] == 0
+    # appending to a non-empty deduplicated queue continues its chain
+    din = np.zeros(1, oracle.QUEUE_STATE12)
+    din["tail"] = synthetic.random_field_elements(3, (12,))
+    din["length"] = 5
+    o2 = oracle.decommit_sorter_build(q, capacity, din)
+    assert np.array_equal(o2["dedup_tails"][0], oracle.queue_push_chain_full(o2["dedup_enc"][:1], din["tail"][0])[0])
+    assert int(o2["instances"][-1]["final_queue_state"]["length"]) == 5 + o["dedup_q"].size
+
+
+def test_decommit_sorter_rejects_inconsistent_pages(oracle):
+    q = synthetic.decommit_trace(40, 3, seed=2)
+    q["memory_page"][-1] += 1
+    with pytest.raises(RuntimeError):
+        oracle.decommit_sorter_build(q, 16)
