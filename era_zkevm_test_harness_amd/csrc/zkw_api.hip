@@ -18,6 +18,7 @@
 #include "ram_circuit_kernels.cuh"
 #include "log_kernels.cuh"
 #include "decommit_kernels.cuh"
+#include "events_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -1170,6 +1171,185 @@ extern "C" int zkw_decommit_witness_get(const zkw_decommit_witness* w, int what,
     return ctx->sync_if_host();
 }
 extern "C" void zkw_decommit_witness_free(zkw_decommit_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    delete w;
+}
+
+// ------------------------------------------------------------------------------------------------ events sorter
+struct zkw_events_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n = 0, n_instances = 0, n_result = 0;
+    uint32_t capacity = 0;
+    zkw_log_query *sorted_q = nullptr, *result_q = nullptr;
+    u64* enc_all = nullptr;    // [3n][20]: unsorted | sorted | result (one array so that one prehash covers all)
+    u64* tails_all = nullptr;  // [5n][4]: unsorted old | unsorted new | sorted old | sorted new | result new
+    u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
+    zkw_events_sorter_instance* instances = nullptr;
+    void release() {
+        void* ptrs[] = {sorted_q, result_q, enc_all, tails_all, challenges, lhs_z, rhs_z, instances};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+};
+
+static int events_run(zkw_ctx* ctx, zkw_events_witness* w, const zkw_log_query* d_q, const zkw_queue_state4& result_in) {
+    const size_t n = w->n;
+    const unsigned grid = blocks_for(n, 256);
+    u64 *u_enc = w->enc_all, *s_enc = w->enc_all + 20 * n, *r_enc = w->enc_all + 40 * n;
+    u64 *u_old = w->tails_all, *u_new = u_old + 4 * n, *s_old = u_new + 4 * n, *s_new = s_old + 4 * n, *r_new = s_new + 4 * n;
+    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, u_enc); }
+    ZKW_TRY(launch_check("k_encode_log"));
+    // stable sort by (timestamp, rollback): 33-bit key
+    u64 *key = nullptr, *key_out = nullptr;
+    u32 *v0 = nullptr, *v1 = nullptr, *kept = nullptr, *totals = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = radix_temp_bytes(n);
+    ZKW_TRY(ctx->scratch_t<u64>("sort_k64a", n, &key));
+    ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", n, &key_out));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_v0", n, &v0));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_v1", n, &v1));
+    ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
+    { Prof _p(ctx, "k_events_sort_keys"); hipLaunchKernelGGL(k_events_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, key, v0); }
+    ZKW_TRY(launch_check("k_events_sort_keys"));
+    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, key, key_out, v0, v1, n, 33, ctx->stream)); }
+    { Prof _p(ctx, "k_log_gather_encode"); hipLaunchKernelGGL(k_log_gather_encode, dim3(grid), dim3(256), 0, ctx->stream, d_q, v1, n, w->sorted_q, s_enc); }
+    ZKW_TRY(launch_check("k_log_gather_encode"));
+    ZKW_TRY(ctx->scratch_t<u32>("evt_kept", n, &kept));
+    ZKW_TRY(ctx->scratch_t<u32>("evt_totals", 2, &totals));
+    { Prof _p(ctx, "k_events_dedup"); hipLaunchKernelGGL(k_events_dedup, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, kept, w->result_q, r_enc, totals); }
+    ZKW_TRY(launch_check("k_events_dedup"));
+    u32 h_totals[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_totals, totals, sizeof h_totals, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "event queue is not a sequence of forward events each optionally followed by "
+                                                       "its own rollback (events_sort_dedup.rs:344-356, 512-533): %u violations", h_totals[1]);
+    w->n_result = h_totals[0];
+    zkw_queue_state4* d_rin = nullptr;
+    std::vector<zkw_queue_state4> rin(1, result_in);
+    ZKW_TRY(ctx->upload("evt_result_in", rin, &d_rin));
+    std::vector<LogChainJob> chains;
+    chains.push_back(LogChainJob{u_enc, nullptr, u_old, u_new, nullptr, n});
+    chains.push_back(LogChainJob{s_enc, nullptr, s_old, s_new, nullptr, n});
+    chains.push_back(LogChainJob{r_enc, nullptr, nullptr, r_new, d_rin->tail, w->n_result});
+    ZKW_TRY(dev_log_chains(ctx, w->enc_all, 3 * n, chains));
+    std::vector<FsJob> fs(1);
+    fs[0] = FsJob{u_new + 4 * (n - 1), s_new + 4 * (n - 1), (u32)n, (u32)n, w->challenges};
+    ZKW_TRY(dev_fs(ctx, fs, 4, 21));
+    std::vector<GpSeg> segs;
+    segs.push_back(GpSeg{u_enc, w->lhs_z, w->challenges, n, 0, 0});
+    segs.push_back(GpSeg{s_enc, w->rhs_z, w->challenges, n, 0, 0});
+    ZKW_TRY(dev_grand_products(ctx, segs, 20, 2));
+    std::vector<EventsBlock> blk(1);
+    blk[0] = EventsBlock{w->sorted_q, u_new, s_new, r_new, w->lhs_z, w->rhs_z, kept, w->instances, result_in, n, w->capacity};
+    EventsBlock* d_blk = nullptr;
+    ZKW_TRY(ctx->upload("evt_block", blk, &d_blk));
+    { Prof _p(ctx, "k_events_instances"); hipLaunchKernelGGL(k_events_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    return launch_check("k_events_instances");
+}
+
+extern "C" int zkw_events_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, size_t n, uint32_t capacity,
+                                       const zkw_queue_state4* result_in, zkw_events_witness** out) {
+    if (!ctx || !out || capacity == 0 || (n && !q)) return fail(ZKW_ERR_INVALID, "zkw_events_sorter_build: bad argument");
+    if (n >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many log queries");
+    HIP_TRY(hipSetDevice(ctx->device));
+    zkw_events_witness* w = new zkw_events_witness();
+    w->ctx = ctx;
+    w->n = n;
+    w->capacity = capacity;
+    w->n_instances = n ? (n + capacity - 1) / capacity : 1;
+    const size_t m = n ? n : 1;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    alloc((void**)&w->sorted_q, m * sizeof(zkw_log_query));
+    alloc((void**)&w->result_q, m * sizeof(zkw_log_query));
+    alloc((void**)&w->enc_all, 3 * m * 160);
+    alloc((void**)&w->tails_all, 5 * m * 32);
+    alloc((void**)&w->challenges, 42 * 8);
+    alloc((void**)&w->lhs_z, m * 16);
+    alloc((void**)&w->rhs_z, m * 16);
+    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_events_sorter_instance));
+    if (e != hipSuccess) {
+        w->release();
+        delete w;
+        return fail(ZKW_ERR_OOM, "zkw_events_sorter_build: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    zkw_queue_state4 rin;
+    memset(&rin, 0, sizeof rin);
+    if (result_in) rin = *result_in;
+    int rc = ZKW_OK;
+    if (n == 0) {  // events_sort_dedup.rs:27-76: one dummy instance, accumulators forced to ONE
+        zkw_events_sorter_instance inst;
+        memset(&inst, 0, sizeof inst);
+        inst.start_flag = inst.completion_flag = 1;
+        for (int r = 0; r < 2; r++) {
+            inst.hidden_fsm_input.lhs_accumulator[r] = inst.hidden_fsm_input.rhs_accumulator[r] = 1;
+            inst.hidden_fsm_output.lhs_accumulator[r] = inst.hidden_fsm_output.rhs_accumulator[r] = 1;
+        }
+        if (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(w->challenges, 0, 42 * 8) != hipSuccess)
+            rc = fail(ZKW_ERR_HIP, "copy failed");
+    } else {
+        const zkw_log_query* d_q = nullptr;
+        rc = ctx->in("evt_q", q, n, &d_q);
+        if (rc == ZKW_OK) rc = events_run(ctx, w, d_q, rin);
+        if (rc == ZKW_OK) rc = ctx->sync_if_host();
+    }
+    if (rc != ZKW_OK) {
+        w->release();
+        delete w;
+        return rc;
+    }
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" size_t zkw_events_witness_num_instances(const zkw_events_witness* w) { return w ? w->n_instances : 0; }
+extern "C" size_t zkw_events_witness_num_results(const zkw_events_witness* w) { return w ? w->n_result : 0; }
+
+static const void* evt_array(const zkw_events_witness* w, int what, size_t* bytes) {
+    const size_t n = w->n, nr = w->n_result;
+    switch (what) {
+        case ZKW_EVT_SORTED_QUERIES: *bytes = n * sizeof(zkw_log_query); return w->sorted_q;
+        case ZKW_EVT_UNSORTED_ENC: *bytes = n * 160; return w->enc_all;
+        case ZKW_EVT_SORTED_ENC: *bytes = n * 160; return w->enc_all + 20 * n;
+        case ZKW_EVT_UNSORTED_OLD_TAILS: *bytes = n * 32; return w->tails_all;
+        case ZKW_EVT_UNSORTED_NEW_TAILS: *bytes = n * 32; return w->tails_all + 4 * n;
+        case ZKW_EVT_SORTED_OLD_TAILS: *bytes = n * 32; return w->tails_all + 8 * n;
+        case ZKW_EVT_SORTED_NEW_TAILS: *bytes = n * 32; return w->tails_all + 12 * n;
+        case ZKW_EVT_RESULT_QUERIES: *bytes = nr * sizeof(zkw_log_query); return w->result_q;
+        case ZKW_EVT_RESULT_NEW_TAILS: *bytes = nr * 32; return w->tails_all + 16 * n;
+        case ZKW_EVT_CHALLENGES: *bytes = 42 * 8; return w->challenges;
+        case ZKW_EVT_LHS_Z: *bytes = n * 16; return w->lhs_z;
+        case ZKW_EVT_RHS_Z: *bytes = n * 16; return w->rhs_z;
+        case ZKW_EVT_INSTANCES: *bytes = w->n_instances * sizeof(zkw_events_sorter_instance); return w->instances;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_events_witness_bytes(const zkw_events_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)evt_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_events_witness_device_ptr(const zkw_events_witness* w, int what) {
+    size_t b = 0;
+    return w ? evt_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_events_witness_get(const zkw_events_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_events_witness_get: null argument");
+    if (what < 0 || what > ZKW_EVT_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    size_t bytes = 0;
+    const void* src = evt_array(w, what, &bytes);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_events_witness_free(zkw_events_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);

@@ -56,6 +56,13 @@ SYMBOLS = [
     ("zkw_decommit_witness_device_ptr", _vp, [_vp, _int]),
     ("zkw_decommit_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_decommit_witness_free", None, [_vp]),
+    ("zkw_events_sorter_build", _int, [_vp, _vp, _sz, _u32, _vp, C.POINTER(_vp)]),
+    ("zkw_events_witness_num_instances", _sz, [_vp]),
+    ("zkw_events_witness_num_results", _sz, [_vp]),
+    ("zkw_events_witness_bytes", _sz, [_vp, _int]),
+    ("zkw_events_witness_device_ptr", _vp, [_vp, _int]),
+    ("zkw_events_witness_get", _int, [_vp, _int, _vp, _sz]),
+    ("zkw_events_witness_free", None, [_vp]),
     ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
     ("zkw_trace_free", None, [_vp]),
     ("zkw_trace_num_rows", _sz, [_vp]),
@@ -142,6 +149,61 @@ DECOMMIT_INSTANCE = np.dtype(
      ("hidden_fsm_input", DECOMMIT_FSM), ("hidden_fsm_output", DECOMMIT_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
 (DEC_SORTED_QUERIES, DEC_UNSORTED_ENC, DEC_SORTED_ENC, DEC_UNSORTED_TAILS, DEC_SORTED_TAILS, DEC_DEDUP_QUERIES,
  DEC_DEDUP_TAILS, DEC_CHALLENGES, DEC_LHS_Z, DEC_RHS_Z, DEC_INSTANCES) = range(11)
+
+
+QUEUE_STATE4 = np.dtype([("head", "<u8", (4,)), ("tail", "<u8", (4,)), ("length", "<u4"), ("_pad", "<u4")])
+EVENTS_FSM = np.dtype(
+    [("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)), ("initial_unsorted_queue_state", QUEUE_STATE4),
+     ("intermediate_sorted_queue_state", QUEUE_STATE4), ("final_result_queue_state", QUEUE_STATE4),
+     ("previous_key", "<u4"), ("_pad", "<u4"), ("previous_item", LOG_QUERY)])
+EVENTS_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_log_queue_state", QUEUE_STATE4),
+     ("intermediate_sorted_queue_state", QUEUE_STATE4), ("final_queue_state", QUEUE_STATE4),
+     ("hidden_fsm_input", EVENTS_FSM), ("hidden_fsm_output", EVENTS_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
+(EVT_SORTED_QUERIES, EVT_UNSORTED_ENC, EVT_SORTED_ENC, EVT_UNSORTED_OLD_TAILS, EVT_UNSORTED_NEW_TAILS, EVT_SORTED_OLD_TAILS,
+ EVT_SORTED_NEW_TAILS, EVT_RESULT_QUERIES, EVT_RESULT_NEW_TAILS, EVT_CHALLENGES, EVT_LHS_Z, EVT_RHS_Z, EVT_INSTANCES) = range(13)
+
+
+class EventsWitness:
+    """Owner of a zkw_events_witness handle."""
+
+    _DTYPES = {EVT_SORTED_QUERIES: LOG_QUERY, EVT_RESULT_QUERIES: LOG_QUERY, EVT_INSTANCES: EVENTS_INSTANCE}
+    _SHAPES = {EVT_UNSORTED_ENC: (-1, 20), EVT_SORTED_ENC: (-1, 20), EVT_UNSORTED_OLD_TAILS: (-1, 4),
+               EVT_UNSORTED_NEW_TAILS: (-1, 4), EVT_SORTED_OLD_TAILS: (-1, 4), EVT_SORTED_NEW_TAILS: (-1, 4),
+               EVT_RESULT_NEW_TAILS: (-1, 4), EVT_CHALLENGES: (2, 21), EVT_LHS_Z: (2, -1), EVT_RHS_Z: (2, -1)}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = C.c_void_p(None)
+
+    @property
+    def num_instances(self):
+        return load().zkw_events_witness_num_instances(self.handle)
+
+    @property
+    def num_results(self):
+        return load().zkw_events_witness_num_results(self.handle)
+
+    def get(self, what):
+        lib = load()
+        nbytes = lib.zkw_events_witness_bytes(self.handle, what)
+        dt = self._DTYPES.get(what, np.dtype("<u8"))
+        out = np.zeros(nbytes // dt.itemsize, dt)
+        if nbytes:
+            _check(lib.zkw_events_witness_get(self.handle, what, _np_ptr(out), nbytes))
+        shape = self._SHAPES.get(what)
+        return out.reshape(shape) if shape else out
+
+    def free(self):
+        if self.handle:
+            load().zkw_events_witness_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DecommitWitness:
@@ -443,4 +505,13 @@ class Context:
         din = None if dedup_in is None else _np_ptr(np.ascontiguousarray(dedup_in, dtype=QUEUE_STATE12))
         _check(load().zkw_decommit_sorter_build(self.handle, _np_ptr(q), q.size, deduplicator_circuit_capacity, din,
                                                 C.byref(w.handle)))
+        return w
+
+    def compute_events_dedup_and_sort(self, unsorted_queries, per_circuit_capacity, result_in=None):
+        """compute_events_dedup_and_sort (events_sort_dedup.rs:16-506) -> EventsWitness."""
+        q = np.ascontiguousarray(unsorted_queries, dtype=LOG_QUERY)
+        w = EventsWitness(self)
+        rin = None if result_in is None else _np_ptr(np.ascontiguousarray(result_in, dtype=QUEUE_STATE4))
+        _check(load().zkw_events_sorter_build(self.handle, _np_ptr(q) if q.size else None, q.size, per_circuit_capacity, rin,
+                                              C.byref(w.handle)))
         return w

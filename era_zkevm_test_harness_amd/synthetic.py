@@ -134,3 +134,25 @@ def decommit_trace(n: int, n_hashes: int, seed: int = 1) -> np.ndarray:
             fresh[i] = 1
     q["is_fresh"] = fresh
     return q
+
+
+def events_trace(n_forward: int, rollback_fraction: float = 0.3, seed: int = 1) -> np.ndarray:
+    """Valid event queue: n_forward events with strictly increasing timestamps (rw_flag set, shard 0); a
+    fraction of them is later rolled back by a twin record (same timestamp and payload, rollback = 1) that
+    sits somewhere AFTER its forward in queue order."""
+    fw = random_log_queries(n_forward, seed)
+    fw["timestamp"] = 10 + 2 * np.arange(n_forward, dtype=np.uint32)
+    fw["shard_id"] = 0
+    fw["rw_flag"] = 1
+    fw["rollback"] = 0
+    fw["aux_byte"] = 2
+    r = splitmix64(seed + 77, 2 * n_forward)
+    rolled = (r[:n_forward] >> np.uint64(11)).astype(np.float64) / float(1 << 53) < rollback_fraction
+    items = [(2 * i, fw[i]) for i in range(n_forward)]
+    for i in np.flatnonzero(rolled):
+        tw = fw[i].copy()
+        tw["rollback"] = 1
+        pos = 2 * (i + int(r[n_forward + i] % np.uint64(max(1, n_forward - i)))) + 1  # after its forward
+        items.append((pos, tw))
+    items.sort(key=lambda t: t[0])
+    return np.array([t[1] for t in items], dtype=LOG_QUERY)

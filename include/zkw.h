@@ -172,6 +172,37 @@ const void *zkw_decommit_witness_device_ptr(const zkw_decommit_witness *w, int w
 int zkw_decommit_witness_get(const zkw_decommit_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_decommit_witness_free(zkw_decommit_witness *w);
 
+/* ---- Events / L1-messages sorter witness builder ------------------------------------------------ */
+typedef struct zkw_events_witness zkw_events_witness;
+/* compute_events_dedup_and_sort (+ sort_and_dedup_events_log), src/witness/individual_circuits/
+   events_sort_dedup.rs:16-580 — used twice by the reference (events and L2->L1 messages, oracle.rs:1069-1088).
+   q: the demuxed log queue in queue order (n == 0 yields the reference's single dummy instance);
+   result_in (host, NULL = empty): state of the result queue the net events are appended to.
+   ZKW_ERR_CHECK_FAILED when one of the reference's asserts on the queue's shape fails. */
+int zkw_events_sorter_build(zkw_ctx *ctx, const zkw_log_query *q, size_t n, uint32_t capacity,
+                            const zkw_queue_state4 *result_in, zkw_events_witness **out);
+enum {
+    ZKW_EVT_SORTED_QUERIES = 0,     /* zkw_log_query[n]  */
+    ZKW_EVT_UNSORTED_ENC = 1,       /* uint64_t[n][20]   */
+    ZKW_EVT_SORTED_ENC = 2,
+    ZKW_EVT_UNSORTED_OLD_TAILS = 3, /* uint64_t[n][4]: tail before each push = queue witness (lib.rs:204) */
+    ZKW_EVT_UNSORTED_NEW_TAILS = 4,
+    ZKW_EVT_SORTED_OLD_TAILS = 5,
+    ZKW_EVT_SORTED_NEW_TAILS = 6,
+    ZKW_EVT_RESULT_QUERIES = 7,     /* zkw_log_query[n_result]: sort_and_dedup_events_log output */
+    ZKW_EVT_RESULT_NEW_TAILS = 8,   /* uint64_t[n_result][4] */
+    ZKW_EVT_CHALLENGES = 9,         /* uint64_t[2][21]   */
+    ZKW_EVT_LHS_Z = 10,             /* uint64_t[2][n]    */
+    ZKW_EVT_RHS_Z = 11,
+    ZKW_EVT_INSTANCES = 12          /* zkw_events_sorter_instance[max(1, ceil(n/capacity))] */
+};
+size_t zkw_events_witness_num_instances(const zkw_events_witness *w);
+size_t zkw_events_witness_num_results(const zkw_events_witness *w);
+size_t zkw_events_witness_bytes(const zkw_events_witness *w, int what);
+const void *zkw_events_witness_device_ptr(const zkw_events_witness *w, int what);
+int zkw_events_witness_get(const zkw_events_witness *w, int what, void *dst, size_t dst_bytes);
+void zkw_events_witness_free(zkw_events_witness *w);
+
 /* ---- synthesis: filled traces ------------------------------------------------------------------- */
 /* A zkw_trace owns n_slots trace buffers in HBM, each column-major uint64_t[n_cols][n_rows] (n_rows =
    2^20 at production geometry = TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17). It plays the role of

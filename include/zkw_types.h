@@ -157,6 +157,32 @@ typedef struct zkw_decommit_sorter_instance {
     uint64_t num_items;
 } zkw_decommit_sorter_instance;
 
+/* ---- Events / L1-messages sorter (events_sort_dedup.rs) ----------------------------------------- */
+/* EventsDeduplicatorFSMInputOutputWitness, src/witness/individual_circuits/events_sort_dedup.rs:438-455 */
+typedef struct zkw_events_sorter_fsm {
+    uint64_t lhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];
+    uint64_t rhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];
+    zkw_queue_state4 initial_unsorted_queue_state;
+    zkw_queue_state4 intermediate_sorted_queue_state;
+    zkw_queue_state4 final_result_queue_state;
+    uint32_t previous_key; /* timestamp */
+    uint32_t _pad;
+    zkw_log_query previous_item;
+} zkw_events_sorter_fsm;
+
+/* EventsDeduplicatorInstanceWitness, events_sort_dedup.rs:426-461 */
+typedef struct zkw_events_sorter_instance {
+    uint32_t start_flag;
+    uint32_t completion_flag;
+    zkw_queue_state4 initial_log_queue_state;         /* observable_input */
+    zkw_queue_state4 intermediate_sorted_queue_state; /* observable_input */
+    zkw_queue_state4 final_queue_state;               /* observable_output (placeholder except on the last) */
+    zkw_events_sorter_fsm hidden_fsm_input;
+    zkw_events_sorter_fsm hidden_fsm_output;
+    uint64_t first_item;
+    uint64_t num_items;
+} zkw_events_sorter_instance;
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,18 @@ int64_t orc_decommit_sorter_build(const zkw_decommit_query *q, size_t n, uint32_
                                   uint64_t *dedup_tails, uint64_t *n_dedup, uint64_t *challenges,
                                   uint64_t *lhs_z, uint64_t *rhs_z, zkw_decommit_sorter_instance *instances);
 
+/* ---- events / L1-messages sorter builder, src/witness/individual_circuits/events_sort_dedup.rs:16-580.
+   q: the demuxed event (or L1 message) log queue in queue order; result_in: state of the result queue
+   before the call (NULL = empty). Outputs sized for n (n_result entries used in result_*). For n == 0 one
+   dummy instance is produced (events_sort_dedup.rs:27-76). Returns the number of instances or <0. */
+int64_t orc_events_sorter_build(const zkw_log_query *q, size_t n, uint32_t capacity, const zkw_queue_state4 *result_in,
+                                zkw_log_query *sorted_q, uint64_t *unsorted_enc, uint64_t *sorted_enc,
+                                uint64_t *unsorted_old_tails, uint64_t *unsorted_new_tails,
+                                uint64_t *sorted_old_tails, uint64_t *sorted_new_tails, zkw_log_query *result_q,
+                                uint64_t *result_enc, uint64_t *result_new_tails, uint64_t *n_result,
+                                uint64_t *challenges /* [2][21] */, uint64_t *lhs_z, uint64_t *rhs_z,
+                                zkw_events_sorter_instance *instances);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,17 @@ DECOMMIT_INSTANCE = np.dtype(
      ("hidden_fsm_input", DECOMMIT_FSM), ("hidden_fsm_output", DECOMMIT_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
 
 
+QUEUE_STATE4 = np.dtype([("head", "<u8", (4,)), ("tail", "<u8", (4,)), ("length", "<u4"), ("_pad", "<u4")])
+EVENTS_FSM = np.dtype(
+    [("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)), ("initial_unsorted_queue_state", QUEUE_STATE4),
+     ("intermediate_sorted_queue_state", QUEUE_STATE4), ("final_result_queue_state", QUEUE_STATE4),
+     ("previous_key", "<u4"), ("_pad", "<u4"), ("previous_item", LOG_QUERY)])
+EVENTS_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_log_queue_state", QUEUE_STATE4),
+     ("intermediate_sorted_queue_state", QUEUE_STATE4), ("final_queue_state", QUEUE_STATE4),
+     ("hidden_fsm_input", EVENTS_FSM), ("hidden_fsm_output", EVENTS_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
+
+
 def build(force=False):
     """Compile liboracle.so with gcc (building the checker is not using it)."""
     if force or not os.path.exists(_LIB_PATH) or any(
@@ -276,4 +287,34 @@ def decommit_sorter_build(q, capacity, dedup_in=None):
         raise RuntimeError(f"orc_decommit_sorter_build failed: {rc}")
     k = nd.value
     o["dedup_q"], o["dedup_enc"], o["dedup_tails"] = o["dedup_q"][:k], o["dedup_enc"][:k], o["dedup_tails"][:k]
+    return o
+
+
+def events_sorter_build(q, capacity, result_in=None):
+    q = np.ascontiguousarray(q, dtype=LOG_QUERY)
+    n = q.size
+    m = max(n, 1)
+    n_inst = max(1, (n + capacity - 1) // capacity)
+    o = dict(sorted_q=np.zeros(m, LOG_QUERY), unsorted_enc=np.zeros((m, 20), np.uint64), sorted_enc=np.zeros((m, 20), np.uint64),
+             unsorted_old_tails=np.zeros((m, 4), np.uint64), unsorted_new_tails=np.zeros((m, 4), np.uint64),
+             sorted_old_tails=np.zeros((m, 4), np.uint64), sorted_new_tails=np.zeros((m, 4), np.uint64),
+             result_q=np.zeros(m, LOG_QUERY), result_enc=np.zeros((m, 20), np.uint64),
+             result_new_tails=np.zeros((m, 4), np.uint64), challenges=np.zeros((2, 21), np.uint64),
+             lhs_z=np.zeros((2, n), np.uint64), rhs_z=np.zeros((2, n), np.uint64), instances=np.zeros(n_inst, EVENTS_INSTANCE))
+    nr = C.c_uint64(0)
+    rin = None if result_in is None else _p(np.ascontiguousarray(result_in, dtype=QUEUE_STATE4))
+    f = lib().orc_events_sorter_build
+    f.restype = C.c_int64
+    rc = f(_p(q), C.c_size_t(n), C.c_uint32(capacity), rin, _p(o["sorted_q"]), _p(o["unsorted_enc"]), _p(o["sorted_enc"]),
+           _p(o["unsorted_old_tails"]), _p(o["unsorted_new_tails"]), _p(o["sorted_old_tails"]), _p(o["sorted_new_tails"]),
+           _p(o["result_q"]), _p(o["result_enc"]), _p(o["result_new_tails"]), C.byref(nr), _p(o["challenges"]),
+           _p(o["lhs_z"]), _p(o["rhs_z"]), _p(o["instances"]))
+    if rc < 0:
+        raise RuntimeError(f"orc_events_sorter_build failed: {rc}")
+    k = nr.value
+    for key in ("sorted_q", "unsorted_enc", "sorted_enc", "unsorted_old_tails", "unsorted_new_tails", "sorted_old_tails",
+                "sorted_new_tails"):
+        o[key] = o[key][:n]
+    for key in ("result_q", "result_enc", "result_new_tails"):
+        o[key] = o[key][:k]
     return o

@@ -265,3 +265,45 @@ def test_decommit_sorter_self_check(ctx):
     with pytest.raises(nv.ZkwError) as ei:
         ctx.compute_decommitts_sorter_circuit_snapshots(q, 16)
     assert ei.value.code == nv.ERR_CHECK_FAILED
+
+
+@pytest.mark.parametrize("nf,frac,capacity", [(1, 0.0, 4), (1, 1.0, 4), (40, 0.3, 16), (2000, 0.5, 256), (64, 0.0, 16),
+                                              (30, 1.0, 7), (5000, 0.2, 31287)])
+def test_events_sorter(ctx, oracle, nf, frac, capacity):
+    from era_zkevm_test_harness_amd import native as nv
+
+    q = synthetic.events_trace(nf, frac, seed=nf + 1)
+    rin = np.zeros(1, oracle.QUEUE_STATE4)
+    rin["tail"] = synthetic.random_field_elements(3, (4,))
+    rin["head"] = synthetic.random_field_elements(4, (4,))
+    rin["length"] = 3
+    for result_in in (None, rin):
+        w = ctx.compute_events_dedup_and_sort(q, capacity, result_in)
+        o = oracle.events_sorter_build(q, capacity, result_in)
+        assert w.num_results == o["result_q"].size
+        for what, key in ((nv.EVT_SORTED_QUERIES, "sorted_q"), (nv.EVT_UNSORTED_ENC, "unsorted_enc"), (nv.EVT_SORTED_ENC, "sorted_enc"),
+                          (nv.EVT_UNSORTED_OLD_TAILS, "unsorted_old_tails"), (nv.EVT_UNSORTED_NEW_TAILS, "unsorted_new_tails"),
+                          (nv.EVT_SORTED_OLD_TAILS, "sorted_old_tails"), (nv.EVT_SORTED_NEW_TAILS, "sorted_new_tails"),
+                          (nv.EVT_RESULT_QUERIES, "result_q"), (nv.EVT_RESULT_NEW_TAILS, "result_new_tails"),
+                          (nv.EVT_CHALLENGES, "challenges"), (nv.EVT_LHS_Z, "lhs_z"), (nv.EVT_RHS_Z, "rhs_z")):
+            assert np.array_equal(w.get(what), o[key]), key
+        gi = w.get(nv.EVT_INSTANCES)
+        assert gi.size == o["instances"].size
+        for a, b in zip(gi, o["instances"]):
+            for f in a.dtype.names:
+                assert a[f].tobytes() == b[f].tobytes(), f
+        w.free()
+
+
+def test_events_sorter_empty_and_malformed(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    w = ctx.compute_events_dedup_and_sort(np.zeros(0, nv.LOG_QUERY), 16)
+    o = oracle.events_sorter_build(np.zeros(0, oracle.LOG_QUERY), 16)
+    assert w.get(nv.EVT_INSTANCES).tobytes() == o["instances"].tobytes()
+    w.free()
+    q = synthetic.events_trace(10, 0.0, seed=3)
+    q["rollback"][4] = 1
+    with pytest.raises(nv.ZkwError) as ei:
+        ctx.compute_events_dedup_and_sort(q, 16)
+    assert ei.value.code == nv.ERR_CHECK_FAILED

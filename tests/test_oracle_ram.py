@@ -220,3 +220,42 @@ def test_decommit_sorter_rejects_inconsistent_pages(oracle):
     q["memory_page"][-1] += 1
     with pytest.raises(RuntimeError):
         oracle.decommit_sorter_build(q, 16)
+
+
+@pytest.mark.parametrize("nf,frac,capacity", [(1, 0.0, 4), (1, 1.0, 4), (40, 0.3, 16), (200, 0.5, 64), (64, 0.0, 16), (30, 1.0, 7)])
+def test_events_sorter_oracle_invariants(oracle, nf, frac, capacity):
+    q = synthetic.events_trace(nf, frac, seed=nf)
+    n = q.size
+    o = oracle.events_sorter_build(q, capacity)
+    sq = o["sorted_q"]
+    assert np.all(np.diff(sq["timestamp"].astype(np.int64)) >= 0)
+    n_rb = int(q["rollback"].sum())
+    assert o["result_q"].size == nf - n_rb
+    # net events are exactly the forwards that were never rolled back, normalised
+    rolled_ts = set(int(x) for x in q["timestamp"][q["rollback"] == 1])
+    keep = [r for r in q if not r["rollback"] and int(r["timestamp"]) not in rolled_ts]
+    assert len(keep) == o["result_q"].size
+    for a, b in zip(o["result_q"], keep):
+        assert a["timestamp"] == 0 and a["rw_flag"] == 0 and a["aux_byte"] == 0 and not a["read_value"].any()
+        assert np.array_equal(a["key"], b["key"]) and np.array_equal(a["written_value"], b["written_value"])
+    inst = o["instances"]
+    fo = inst[-1]["hidden_fsm_output"]
+    assert np.array_equal(fo["lhs_accumulator"], fo["rhs_accumulator"])
+    assert int(fo["final_result_queue_state"]["length"]) == o["result_q"].size
+    assert inst[-1]["final_queue_state"].tobytes() == fo["final_result_queue_state"].tobytes()
+    for i in range(inst.size - 1):
+        a, b = inst[i]["hidden_fsm_output"], inst[i + 1]["hidden_fsm_input"]
+        for f in ("lhs_accumulator", "rhs_accumulator", "initial_unsorted_queue_state", "intermediate_sorted_queue_state",
+                  "final_result_queue_state", "previous_key", "previous_item"):
+            assert a[f].tobytes() == b[f].tobytes(), f
+    assert np.array_equal(o["unsorted_old_tails"][1:], o["unsorted_new_tails"][:-1])
+
+
+def test_events_sorter_empty_and_malformed(oracle):
+    o = oracle.events_sorter_build(np.zeros(0, oracle.LOG_QUERY), 16)
+    assert o["instances"].size == 1 and o["instances"][0]["start_flag"] == 1 and o["instances"][0]["completion_flag"] == 1
+    assert np.all(o["instances"][0]["hidden_fsm_output"]["lhs_accumulator"] == 1)
+    q = synthetic.events_trace(10, 0.0, seed=3)
+    q["rollback"][4] = 1  # a rollback without a forward twin
+    with pytest.raises(RuntimeError):
+        oracle.events_sorter_build(q, 16)
