@@ -1,0 +1,144 @@
+// demux_kernels.cuh — LogDemuxer witness builder on gfx950.
+// Reference: compute_logs_demux, src/witness/individual_circuits/log_demux.rs:20-388.
+// The reference pushes each log into one of six queues while walking the input; here the route of an item
+// is a local predicate, the six queues are stable compactions (prefix counts per route) and their hash
+// chains run concurrently with the input queue's chain in one launch.
+#pragma once
+#include "events_kernels.cuh"
+
+namespace zkw {
+
+__device__ __forceinline__ int demux_route(const zkw_log_query& q, const zkw_demux_params& p) {
+    if (q.aux_byte == p.storage_aux_byte) return q.shard_id == 0 ? ZKW_DEMUX_STORAGE : -2;
+    if (q.aux_byte == p.l1_message_aux_byte) return ZKW_DEMUX_L1_MESSAGES;
+    if (q.aux_byte == p.event_aux_byte) return ZKW_DEMUX_EVENTS;
+    if (q.aux_byte == p.precompile_aux_byte) {
+        if (q.rollback) return -2;
+        const bool high_zero = (q.address[1] | q.address[2] | q.address[3] | q.address[4]) == 0;
+        if (high_zero && q.address[0] == p.keccak256_address) return ZKW_DEMUX_KECCAK256;
+        if (high_zero && q.address[0] == p.sha256_address) return ZKW_DEMUX_SHA256;
+        if (high_zero && q.address[0] == p.ecrecover_address) return ZKW_DEMUX_ECRECOVER;
+        return -1;
+    }
+    return -2;
+}
+
+// one workgroup, two sweeps: (1) totals per route -> queue offsets; (2) inclusive prefix counts per route,
+// scatter of the routed items and their encodings
+__global__ __launch_bounds__(1024) void k_demux_route(const zkw_log_query* __restrict__ q, const u64* __restrict__ in_enc,
+                                                      size_t n, zkw_demux_params params,
+                                                      u32* __restrict__ route_count /* [6][n] inclusive */,
+                                                      zkw_log_query* __restrict__ out_q, u64* __restrict__ out_enc,
+                                                      u64* __restrict__ totals /* [8]: offsets[7], violations */) {
+    __shared__ u32 sh_cnt[6][16];
+    __shared__ u32 carry[6], base[7], viol;
+    if (threadIdx.x < 6) carry[threadIdx.x] = 0;
+    if (threadIdx.x == 0) viol = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int sweep = 0; sweep < 2; sweep++) {
+        for (size_t b0 = 0; b0 < n; b0 += 1024) {
+            const size_t i = b0 + threadIdx.x;
+            const bool live = i < n;
+            int r = -1;
+            if (live) {
+                zkw_log_query m;
+                m.aux_byte = q[i].aux_byte; m.shard_id = q[i].shard_id; m.rollback = q[i].rollback;
+                for (int k = 0; k < 5; k++) m.address[k] = q[i].address[k];
+                r = demux_route(m, params);
+                if (r == -2 && sweep == 0) atomicAdd(&viol, 1u);
+            }
+            u32 mine = 0, below[6];  // inclusive counts inside the wave, per route
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const unsigned long long bal = __ballot(r == c);
+                below[c] = __popcll(bal & ((2ull << lane) - 1));
+                if (lane == 63) sh_cnt[c][wave] = below[c];
+                if (r == c) mine = below[c];
+            }
+            __syncthreads();
+            u32 cnt[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                u32 v = carry[c];
+                for (int w = 0; w < wave; w++) v += sh_cnt[c][w];
+                cnt[c] = v;  // exclusive of this wave
+            }
+            u32 tile_tot[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                u32 v = 0;
+                for (int w = 0; w < 16; w++) v += sh_cnt[c][w];
+                tile_tot[c] = v;
+            }
+            if (sweep == 1 && live) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) route_count[(size_t)c * n + i] = cnt[c] + below[c];
+            }
+            if (sweep == 1 && live && r >= 0) {
+                const size_t dst = base[r] + cnt[r] + mine - 1;
+                zkw_log_query m;
+                load_log(q + i, m);
+                store_log(out_q + dst, m);
+                const ulonglong2* se = reinterpret_cast<const ulonglong2*>(in_enc + 20 * i);
+                ulonglong2* de = reinterpret_cast<ulonglong2*>(out_enc + 20 * dst);
+#pragma unroll
+                for (int k = 0; k < 10; k++) de[k] = se[k];
+            }
+            __syncthreads();
+            if (threadIdx.x < 6) carry[threadIdx.x] += tile_tot[threadIdx.x];
+            __syncthreads();
+        }
+        if (sweep == 0) {
+            if (threadIdx.x == 0) {
+                base[0] = 0;
+                for (int c = 0; c < 6; c++) base[c + 1] = base[c] + carry[c];
+                for (int c = 0; c < 7; c++) totals[c] = base[c];
+                totals[7] = viol;
+            }
+            __syncthreads();
+            if (threadIdx.x < 6) carry[threadIdx.x] = 0;
+            __syncthreads();
+        }
+    }
+}
+
+struct DemuxBlock {
+    const u64* in_new_tails;   // [n][4]
+    const u64* out_new_tails;  // [routed][4], queues back to back
+    const u32* route_count;    // [6][n] inclusive
+    zkw_log_demux_instance* instances;
+    u64 offsets[7];
+    u64 n;
+    u32 capacity;
+};
+
+__global__ void k_demux_instances(const DemuxBlock* __restrict__ blk) {
+    const DemuxBlock b = *blk;
+    const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_inst) return;
+    zkw_log_demux_instance w;
+    memset(&w, 0, sizeof w);
+    const u64 lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n;
+    w.start_flag = idx == 0;
+    w.completion_flag = idx == n_inst - 1;
+    w.first_item = lo;
+    w.num_items = hi - lo;
+    const u64* full_tail = b.in_new_tails + 4 * (n - 1);
+    qs4(w.initial_log_queue_state, nullptr, full_tail, (u32)n);
+    auto fill = [&](zkw_log_demux_fsm& f, u64 end /* > 0 */) {
+        qs4(f.initial_log_queue_state, b.in_new_tails + 4 * (end - 1), full_tail, (u32)(n - end));
+        for (int c = 0; c < 6; c++) {
+            const u32 cnt = b.route_count[(size_t)c * n + end - 1];
+            qs4(f.queue_state[c], nullptr, cnt ? b.out_new_tails + 4 * (b.offsets[c] + cnt - 1) : nullptr, cnt);
+        }
+    };
+    if (idx > 0) fill(w.hidden_fsm_input, lo);
+    fill(w.hidden_fsm_output, hi);
+    if (idx == n_inst - 1)
+        for (int c = 0; c < 6; c++) w.output_queue_state[c] = w.hidden_fsm_output.queue_state[c];
+    b.instances[idx] = w;
+}
+
+}  // namespace zkw

@@ -19,6 +19,7 @@
 #include "log_kernels.cuh"
 #include "decommit_kernels.cuh"
 #include "events_kernels.cuh"
+#include "demux_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -1350,6 +1351,155 @@ extern "C" int zkw_events_witness_get(const zkw_events_witness* w, int what, voi
     return ctx->sync_if_host();
 }
 extern "C" void zkw_events_witness_free(zkw_events_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    delete w;
+}
+
+// ------------------------------------------------------------------------------------------------ log demuxer
+struct zkw_demux_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n = 0, n_instances = 0, routed = 0;
+    uint32_t capacity = 0;
+    uint64_t offsets[7] = {0, 0, 0, 0, 0, 0, 0};
+    zkw_log_query* out_q = nullptr;
+    u64* enc_all = nullptr;    // [2n][20]: input | routed
+    u64* tails_all = nullptr;  // [4n][4]: in old | in new | out old | out new
+    u64* d_offsets = nullptr;  // [8]
+    zkw_log_demux_instance* instances = nullptr;
+    void release() {
+        void* ptrs[] = {out_q, enc_all, tails_all, d_offsets, instances};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+};
+
+static int demux_run(zkw_ctx* ctx, zkw_demux_witness* w, const zkw_log_query* d_q, const zkw_demux_params& params) {
+    const size_t n = w->n;
+    u64 *in_enc = w->enc_all, *out_enc = w->enc_all + 20 * n;
+    u64 *in_old = w->tails_all, *in_new = in_old + 4 * n, *out_old = in_new + 4 * n, *out_new = out_old + 4 * n;
+    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, in_enc); }
+    ZKW_TRY(launch_check("k_encode_log"));
+    u32* route_count = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("dmx_route_count", 6 * n, &route_count));
+    { Prof _p(ctx, "k_demux_route"); hipLaunchKernelGGL(k_demux_route, dim3(1), dim3(1024), 0, ctx->stream, d_q, in_enc, n, params, route_count, w->out_q, out_enc, w->d_offsets); }
+    ZKW_TRY(launch_check("k_demux_route"));
+    u64 h_tot[8];
+    HIP_TRY(hipMemcpyAsync(h_tot, w->d_offsets, sizeof h_tot, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (h_tot[7]) return fail(ZKW_ERR_CHECK_FAILED, "%llu log queries have an aux byte / shard / rollback combination the "
+                                                    "reference treats as unreachable (log_demux.rs:174-249)", (unsigned long long)h_tot[7]);
+    for (int k = 0; k < 7; k++) w->offsets[k] = h_tot[k];
+    w->routed = h_tot[6];
+    std::vector<LogChainJob> chains;
+    chains.push_back(LogChainJob{in_enc, nullptr, in_old, in_new, nullptr, n});
+    for (int k = 0; k < 6; k++) {
+        const size_t lo = w->offsets[k], cnt = w->offsets[k + 1] - lo;
+        chains.push_back(LogChainJob{out_enc + 20 * lo, nullptr, out_old + 4 * lo, out_new + 4 * lo, nullptr, cnt});
+    }
+    ZKW_TRY(dev_log_chains(ctx, w->enc_all, n + w->routed, chains));
+    std::vector<DemuxBlock> blk(1);
+    blk[0].in_new_tails = in_new;
+    blk[0].out_new_tails = out_new;
+    blk[0].route_count = route_count;
+    blk[0].instances = w->instances;
+    for (int k = 0; k < 7; k++) blk[0].offsets[k] = w->offsets[k];
+    blk[0].n = n;
+    blk[0].capacity = w->capacity;
+    DemuxBlock* d_blk = nullptr;
+    ZKW_TRY(ctx->upload("dmx_block", blk, &d_blk));
+    { Prof _p(ctx, "k_demux_instances"); hipLaunchKernelGGL(k_demux_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    return launch_check("k_demux_instances");
+}
+
+extern "C" int zkw_log_demux_build(zkw_ctx* ctx, const zkw_log_query* q, size_t n, uint32_t capacity,
+                                   const zkw_demux_params* params, zkw_demux_witness** out) {
+    if (!ctx || !out || capacity == 0 || (n && !q)) return fail(ZKW_ERR_INVALID, "zkw_log_demux_build: bad argument");
+    if (n >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many log queries");
+    HIP_TRY(hipSetDevice(ctx->device));
+    zkw_demux_witness* w = new zkw_demux_witness();
+    w->ctx = ctx;
+    w->n = n;
+    w->capacity = capacity;
+    w->n_instances = n ? (n + capacity - 1) / capacity : 1;
+    const size_t m = n ? n : 1;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    alloc((void**)&w->out_q, m * sizeof(zkw_log_query));
+    alloc((void**)&w->enc_all, 2 * m * 160);
+    alloc((void**)&w->tails_all, 4 * m * 32);
+    alloc((void**)&w->d_offsets, 8 * 8);
+    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_log_demux_instance));
+    if (e != hipSuccess) {
+        w->release();
+        delete w;
+        return fail(ZKW_ERR_OOM, "zkw_log_demux_build: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    zkw_demux_params p = ZKW_DEMUX_PARAMS_DEFAULT;
+    if (params) p = *params;
+    int rc = ZKW_OK;
+    if (n == 0) {  // log_demux.rs:51-107
+        zkw_log_demux_instance inst;
+        memset(&inst, 0, sizeof inst);
+        inst.start_flag = inst.completion_flag = 1;
+        if (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(w->d_offsets, 0, 64) != hipSuccess)
+            rc = fail(ZKW_ERR_HIP, "copy failed");
+    } else {
+        const zkw_log_query* d_q = nullptr;
+        rc = ctx->in("dmx_q", q, n, &d_q);
+        if (rc == ZKW_OK) rc = demux_run(ctx, w, d_q, p);
+        if (rc == ZKW_OK) rc = ctx->sync_if_host();
+    }
+    if (rc != ZKW_OK) {
+        w->release();
+        delete w;
+        return rc;
+    }
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" size_t zkw_demux_witness_num_instances(const zkw_demux_witness* w) { return w ? w->n_instances : 0; }
+static const void* dmx_array(const zkw_demux_witness* w, int what, size_t* bytes) {
+    const size_t n = w->n, r = w->routed;
+    switch (what) {
+        case ZKW_DMX_IN_ENC: *bytes = n * 160; return w->enc_all;
+        case ZKW_DMX_IN_OLD_TAILS: *bytes = n * 32; return w->tails_all;
+        case ZKW_DMX_IN_NEW_TAILS: *bytes = n * 32; return w->tails_all + 4 * n;
+        case ZKW_DMX_OUT_QUERIES: *bytes = r * sizeof(zkw_log_query); return w->out_q;
+        case ZKW_DMX_OUT_ENC: *bytes = r * 160; return w->enc_all + 20 * n;
+        case ZKW_DMX_OUT_OLD_TAILS: *bytes = r * 32; return w->tails_all + 8 * n;
+        case ZKW_DMX_OUT_NEW_TAILS: *bytes = r * 32; return w->tails_all + 12 * n;
+        case ZKW_DMX_OUT_OFFSETS: *bytes = 7 * 8; return w->d_offsets;
+        case ZKW_DMX_INSTANCES: *bytes = w->n_instances * sizeof(zkw_log_demux_instance); return w->instances;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_demux_witness_bytes(const zkw_demux_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)dmx_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_demux_witness_device_ptr(const zkw_demux_witness* w, int what) {
+    size_t b = 0;
+    return w ? dmx_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_demux_witness_get(const zkw_demux_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_demux_witness_get: null argument");
+    if (what < 0 || what > ZKW_DMX_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    size_t bytes = 0;
+    const void* src = dmx_array(w, what, &bytes);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_demux_witness_free(zkw_demux_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);

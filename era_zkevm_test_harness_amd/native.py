@@ -63,6 +63,12 @@ SYMBOLS = [
     ("zkw_events_witness_device_ptr", _vp, [_vp, _int]),
     ("zkw_events_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_events_witness_free", None, [_vp]),
+    ("zkw_log_demux_build", _int, [_vp, _vp, _sz, _u32, _vp, C.POINTER(_vp)]),
+    ("zkw_demux_witness_num_instances", _sz, [_vp]),
+    ("zkw_demux_witness_bytes", _sz, [_vp, _int]),
+    ("zkw_demux_witness_device_ptr", _vp, [_vp, _int]),
+    ("zkw_demux_witness_get", _int, [_vp, _int, _vp, _sz]),
+    ("zkw_demux_witness_free", None, [_vp]),
     ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
     ("zkw_trace_free", None, [_vp]),
     ("zkw_trace_num_rows", _sz, [_vp]),
@@ -197,6 +203,52 @@ class EventsWitness:
     def free(self):
         if self.handle:
             load().zkw_events_witness_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+DEMUX_FSM = np.dtype([("initial_log_queue_state", QUEUE_STATE4), ("queue_state", QUEUE_STATE4, (6,))])
+DEMUX_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_log_queue_state", QUEUE_STATE4),
+     ("output_queue_state", QUEUE_STATE4, (6,)), ("hidden_fsm_input", DEMUX_FSM), ("hidden_fsm_output", DEMUX_FSM),
+     ("first_item", "<u8"), ("num_items", "<u8")])
+(DMX_IN_ENC, DMX_IN_OLD_TAILS, DMX_IN_NEW_TAILS, DMX_OUT_QUERIES, DMX_OUT_ENC, DMX_OUT_OLD_TAILS, DMX_OUT_NEW_TAILS,
+ DMX_OUT_OFFSETS, DMX_INSTANCES) = range(9)
+
+
+class DemuxWitness:
+    """Owner of a zkw_demux_witness handle."""
+
+    _DTYPES = {DMX_OUT_QUERIES: LOG_QUERY, DMX_INSTANCES: DEMUX_INSTANCE}
+    _SHAPES = {DMX_IN_ENC: (-1, 20), DMX_OUT_ENC: (-1, 20), DMX_IN_OLD_TAILS: (-1, 4), DMX_IN_NEW_TAILS: (-1, 4),
+               DMX_OUT_OLD_TAILS: (-1, 4), DMX_OUT_NEW_TAILS: (-1, 4)}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = C.c_void_p(None)
+
+    @property
+    def num_instances(self):
+        return load().zkw_demux_witness_num_instances(self.handle)
+
+    def get(self, what):
+        lib = load()
+        nbytes = lib.zkw_demux_witness_bytes(self.handle, what)
+        dt = self._DTYPES.get(what, np.dtype("<u8"))
+        out = np.zeros(nbytes // dt.itemsize, dt)
+        if nbytes:
+            _check(lib.zkw_demux_witness_get(self.handle, what, _np_ptr(out), nbytes))
+        shape = self._SHAPES.get(what)
+        return out.reshape(shape) if shape else out
+
+    def free(self):
+        if self.handle:
+            load().zkw_demux_witness_free(self.handle)
             self.handle = C.c_void_p(None)
 
     def __del__(self):
@@ -514,4 +566,12 @@ class Context:
         rin = None if result_in is None else _np_ptr(np.ascontiguousarray(result_in, dtype=QUEUE_STATE4))
         _check(load().zkw_events_sorter_build(self.handle, _np_ptr(q) if q.size else None, q.size, per_circuit_capacity, rin,
                                               C.byref(w.handle)))
+        return w
+
+    def compute_logs_demux(self, log_queries, per_circuit_capacity):
+        """compute_logs_demux (log_demux.rs:20-388) -> DemuxWitness (six demuxed queues + per-instance records)."""
+        q = np.ascontiguousarray(log_queries, dtype=LOG_QUERY)
+        w = DemuxWitness(self)
+        _check(load().zkw_log_demux_build(self.handle, _np_ptr(q) if q.size else None, q.size, per_circuit_capacity, None,
+                                          C.byref(w.handle)))
         return w

@@ -156,3 +156,22 @@ def events_trace(n_forward: int, rollback_fraction: float = 0.3, seed: int = 1) 
         items.append((pos, tw))
     items.sort(key=lambda t: t[0])
     return np.array([t[1] for t in items], dtype=LOG_QUERY)
+
+
+def mixed_log_queue(n: int, seed: int = 1) -> np.ndarray:
+    """A forward-applied log queue as the VM would leave it: storage (aux 0, shard 0), events (aux 1),
+    L1 messages (aux 2) and precompile calls (aux 3: keccak 0x8010, sha256 0x02, ecrecover 0x01 and a few other
+    addresses that the demuxer drops), increasing timestamps."""
+    q = random_log_queries(n, seed)
+    r = splitmix64(seed + 5, n)
+    kind = (r % np.uint64(10)).astype(np.int64)
+    q["timestamp"] = 100 + np.arange(n, dtype=np.uint32)
+    q["shard_id"] = 0
+    q["aux_byte"] = np.select([kind < 4, kind < 6, kind < 7], [0, 1, 2], 3)
+    pre = q["aux_byte"] == 3
+    q["rollback"][pre] = 0
+    addr_pick = ((r >> np.uint64(8)) % np.uint64(4)).astype(np.int64)
+    low = np.array([0x8010, 0x02, 0x01, 0x77], np.uint32)[addr_pick]
+    q["address"][pre] = 0
+    q["address"][pre, 0] = low[pre]
+    return q

@@ -203,6 +203,32 @@ const void *zkw_events_witness_device_ptr(const zkw_events_witness *w, int what)
 int zkw_events_witness_get(const zkw_events_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_events_witness_free(zkw_events_witness *w);
 
+/* ---- LogDemuxer witness builder ------------------------------------------------------------------- */
+typedef struct zkw_demux_witness zkw_demux_witness;
+/* compute_logs_demux, src/witness/individual_circuits/log_demux.rs:20-388. q: the original log queue in order
+   (n == 0 yields the reference's single placeholder instance); params: routing constants (NULL = defaults).
+   The six demuxed queues (queries, encodings, old/new tails = LogQueue.simulator.witness / .states) are what
+   the storage / events / L1-message sorters and the precompile circuits consume next.
+   ZKW_ERR_CHECK_FAILED on an input the reference treats as unreachable!(). */
+int zkw_log_demux_build(zkw_ctx *ctx, const zkw_log_query *q, size_t n, uint32_t capacity,
+                        const zkw_demux_params *params, zkw_demux_witness **out);
+enum {
+    ZKW_DMX_IN_ENC = 0,        /* uint64_t[n][20]  */
+    ZKW_DMX_IN_OLD_TAILS = 1,  /* uint64_t[n][4]   */
+    ZKW_DMX_IN_NEW_TAILS = 2,
+    ZKW_DMX_OUT_QUERIES = 3,   /* zkw_log_query[routed]: the six queues back to back, route order */
+    ZKW_DMX_OUT_ENC = 4,       /* uint64_t[routed][20] */
+    ZKW_DMX_OUT_OLD_TAILS = 5, /* uint64_t[routed][4]  */
+    ZKW_DMX_OUT_NEW_TAILS = 6,
+    ZKW_DMX_OUT_OFFSETS = 7,   /* uint64_t[7]: queue k = [offsets[k], offsets[k+1]) */
+    ZKW_DMX_INSTANCES = 8      /* zkw_log_demux_instance[max(1, ceil(n/capacity))] */
+};
+size_t zkw_demux_witness_num_instances(const zkw_demux_witness *w);
+size_t zkw_demux_witness_bytes(const zkw_demux_witness *w, int what);
+const void *zkw_demux_witness_device_ptr(const zkw_demux_witness *w, int what);
+int zkw_demux_witness_get(const zkw_demux_witness *w, int what, void *dst, size_t dst_bytes);
+void zkw_demux_witness_free(zkw_demux_witness *w);
+
 /* ---- synthesis: filled traces ------------------------------------------------------------------- */
 /* A zkw_trace owns n_slots trace buffers in HBM, each column-major uint64_t[n_cols][n_rows] (n_rows =
    2^20 at production geometry = TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17). It plays the role of

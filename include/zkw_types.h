@@ -183,6 +183,41 @@ typedef struct zkw_events_sorter_instance {
     uint64_t num_items;
 } zkw_events_sorter_instance;
 
+/* ---- LogDemuxer (log_demux.rs) --------------------------------------------------------------------- */
+#define ZKW_DEMUX_NUM_QUEUES 6
+enum { ZKW_DEMUX_STORAGE = 0, ZKW_DEMUX_EVENTS = 1, ZKW_DEMUX_L1_MESSAGES = 2, ZKW_DEMUX_KECCAK256 = 3,
+       ZKW_DEMUX_SHA256 = 4, ZKW_DEMUX_ECRECOVER = 5 };
+/* Routing constants of zkevm_opcode_defs::system_params used at src/witness/individual_circuits/
+   log_demux.rs:154-161 (crate absent: values inferred, DESIGN.md "inferred constants"). */
+typedef struct zkw_demux_params {
+    uint8_t storage_aux_byte;     /* STORAGE_AUX_BYTE = 0 */
+    uint8_t event_aux_byte;       /* EVENT_AUX_BYTE = 1 */
+    uint8_t l1_message_aux_byte;  /* L1_MESSAGE_AUX_BYTE = 2 */
+    uint8_t precompile_aux_byte;  /* PRECOMPILE_AUX_BYTE = 3 */
+    uint32_t keccak256_address;   /* KECCAK256_ROUND_FUNCTION_PRECOMPILE_ADDRESS = 0x8010 (as the low limb of H160) */
+    uint32_t sha256_address;      /* SHA256_ROUND_FUNCTION_PRECOMPILE_ADDRESS = 0x02 */
+    uint32_t ecrecover_address;   /* ECRECOVER_INNER_FUNCTION_PRECOMPILE_ADDRESS = 0x01 */
+} zkw_demux_params;
+#define ZKW_DEMUX_PARAMS_DEFAULT {0, 1, 2, 3, 0x8010u, 0x02u, 0x01u}
+
+/* LogDemuxerFSMInputOutput, log_demux.rs:283-301 */
+typedef struct zkw_log_demux_fsm {
+    zkw_queue_state4 initial_log_queue_state;
+    zkw_queue_state4 queue_state[ZKW_DEMUX_NUM_QUEUES]; /* storage, events, l1messages, keccak256, sha256, ecrecover */
+} zkw_log_demux_fsm;
+
+/* LogDemuxerCircuitInstanceWitness, log_demux.rs:303-375 */
+typedef struct zkw_log_demux_instance {
+    uint32_t start_flag;
+    uint32_t completion_flag;
+    zkw_queue_state4 initial_log_queue_state;                 /* observable_input */
+    zkw_queue_state4 output_queue_state[ZKW_DEMUX_NUM_QUEUES]; /* observable_output (placeholder except on the last) */
+    zkw_log_demux_fsm hidden_fsm_input;
+    zkw_log_demux_fsm hidden_fsm_output;
+    uint64_t first_item;
+    uint64_t num_items;
+} zkw_log_demux_instance;
+
 #ifdef __cplusplus
 }
 #endif

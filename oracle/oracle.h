@@ -112,6 +112,16 @@ int64_t orc_events_sorter_build(const zkw_log_query *q, size_t n, uint32_t capac
                                 uint64_t *challenges /* [2][21] */, uint64_t *lhs_z, uint64_t *rhs_z,
                                 zkw_events_sorter_instance *instances);
 
+/* ---- log demuxer builder, src/witness/individual_circuits/log_demux.rs:20-388.
+   q: the original (forward-applied) log queue in order. Outputs: in_enc [n][20], in_old/new tails [n][4];
+   the six demuxed queues back to back in route order 0..5: out_q / out_enc / out_old_tails / out_new_tails
+   sized for n, queue k occupying [out_offsets[k], out_offsets[k+1]) (out_offsets: 7 entries);
+   instances [max(1, ceil(n/capacity))]. Returns the number of instances or <0. */
+int64_t orc_log_demux_build(const zkw_log_query *q, size_t n, uint32_t capacity, const zkw_demux_params *params,
+                            uint64_t *in_enc, uint64_t *in_old_tails, uint64_t *in_new_tails, zkw_log_query *out_q,
+                            uint64_t *out_enc, uint64_t *out_old_tails, uint64_t *out_new_tails, uint64_t *out_offsets,
+                            zkw_log_demux_instance *instances);
+
 #ifdef __cplusplus
 }
 #endif

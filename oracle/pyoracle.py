@@ -65,6 +65,13 @@ EVENTS_INSTANCE = np.dtype(
      ("hidden_fsm_input", EVENTS_FSM), ("hidden_fsm_output", EVENTS_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
 
 
+DEMUX_FSM = np.dtype([("initial_log_queue_state", QUEUE_STATE4), ("queue_state", QUEUE_STATE4, (6,))])
+DEMUX_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_log_queue_state", QUEUE_STATE4),
+     ("output_queue_state", QUEUE_STATE4, (6,)), ("hidden_fsm_input", DEMUX_FSM), ("hidden_fsm_output", DEMUX_FSM),
+     ("first_item", "<u8"), ("num_items", "<u8")])
+
+
 def build(force=False):
     """Compile liboracle.so with gcc (building the checker is not using it)."""
     if force or not os.path.exists(_LIB_PATH) or any(
@@ -317,4 +324,30 @@ def events_sorter_build(q, capacity, result_in=None):
         o[key] = o[key][:n]
     for key in ("result_q", "result_enc", "result_new_tails"):
         o[key] = o[key][:k]
+    return o
+
+
+def log_demux_build(q, capacity):
+    q = np.ascontiguousarray(q, dtype=LOG_QUERY)
+    n = q.size
+    m = max(n, 1)
+    n_inst = max(1, (n + capacity - 1) // capacity)
+    o = dict(in_enc=np.zeros((m, 20), np.uint64), in_old_tails=np.zeros((m, 4), np.uint64), in_new_tails=np.zeros((m, 4), np.uint64),
+             out_q=np.zeros(m, LOG_QUERY), out_enc=np.zeros((m, 20), np.uint64), out_old_tails=np.zeros((m, 4), np.uint64),
+             out_new_tails=np.zeros((m, 4), np.uint64), out_offsets=np.zeros(7, np.uint64), instances=np.zeros(n_inst, DEMUX_INSTANCE))
+    params = (C.c_uint8 * 4)(0, 1, 2, 3)
+    pbuf = np.zeros(1, np.dtype([("b", "u1", (4,)), ("k", "<u4"), ("s", "<u4"), ("e", "<u4")]))
+    pbuf["b"] = [0, 1, 2, 3]
+    pbuf["k"], pbuf["s"], pbuf["e"] = 0x8010, 2, 1
+    f = lib().orc_log_demux_build
+    f.restype = C.c_int64
+    rc = f(_p(q), C.c_size_t(n), C.c_uint32(capacity), _p(pbuf), _p(o["in_enc"]), _p(o["in_old_tails"]), _p(o["in_new_tails"]),
+           _p(o["out_q"]), _p(o["out_enc"]), _p(o["out_old_tails"]), _p(o["out_new_tails"]), _p(o["out_offsets"]), _p(o["instances"]))
+    if rc < 0:
+        raise RuntimeError(f"orc_log_demux_build failed: {rc}")
+    r = int(o["out_offsets"][6])
+    for key in ("in_enc", "in_old_tails", "in_new_tails"):
+        o[key] = o[key][:n]
+    for key in ("out_q", "out_enc", "out_old_tails", "out_new_tails"):
+        o[key] = o[key][:r]
     return o

@@ -307,3 +307,35 @@ def test_events_sorter_empty_and_malformed(ctx, oracle):
     with pytest.raises(nv.ZkwError) as ei:
         ctx.compute_events_dedup_and_sort(q, 16)
     assert ei.value.code == nv.ERR_CHECK_FAILED
+
+
+@pytest.mark.parametrize("n,capacity", [(1, 4), (100, 16), (3000, 128), (77, 1000), (5000, 58750), (2048, 1024)])
+def test_log_demux(ctx, oracle, n, capacity):
+    from era_zkevm_test_harness_amd import native as nv
+
+    q = synthetic.mixed_log_queue(n, seed=n + 3)
+    w = ctx.compute_logs_demux(q, capacity)
+    o = oracle.log_demux_build(q, capacity)
+    for what, key in ((nv.DMX_IN_ENC, "in_enc"), (nv.DMX_IN_OLD_TAILS, "in_old_tails"), (nv.DMX_IN_NEW_TAILS, "in_new_tails"),
+                      (nv.DMX_OUT_QUERIES, "out_q"), (nv.DMX_OUT_ENC, "out_enc"), (nv.DMX_OUT_OLD_TAILS, "out_old_tails"),
+                      (nv.DMX_OUT_NEW_TAILS, "out_new_tails"), (nv.DMX_OUT_OFFSETS, "out_offsets")):
+        assert np.array_equal(w.get(what), o[key]), key
+    gi = w.get(nv.DMX_INSTANCES)
+    assert gi.size == o["instances"].size
+    for a, b in zip(gi, o["instances"]):
+        for f in a.dtype.names:
+            assert a[f].tobytes() == b[f].tobytes(), f
+    w.free()
+
+
+def test_log_demux_empty_and_unreachable(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    w = ctx.compute_logs_demux(np.zeros(0, nv.LOG_QUERY), 16)
+    assert w.get(nv.DMX_INSTANCES).tobytes() == oracle.log_demux_build(np.zeros(0, oracle.LOG_QUERY), 16)["instances"].tobytes()
+    w.free()
+    q = synthetic.mixed_log_queue(50, seed=1)
+    q["aux_byte"][7] = 9
+    with pytest.raises(nv.ZkwError) as ei:
+        ctx.compute_logs_demux(q, 16)
+    assert ei.value.code == nv.ERR_CHECK_FAILED

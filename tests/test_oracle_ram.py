@@ -259,3 +259,28 @@ def test_events_sorter_empty_and_malformed(oracle):
     q["rollback"][4] = 1  # a rollback without a forward twin
     with pytest.raises(RuntimeError):
         oracle.events_sorter_build(q, 16)
+
+
+@pytest.mark.parametrize("n,capacity", [(1, 4), (100, 16), (1000, 128), (77, 1000)])
+def test_log_demux_oracle(oracle, n, capacity):
+    q = synthetic.mixed_log_queue(n, seed=n)
+    o = oracle.log_demux_build(q, capacity)
+    offs = [int(x) for x in o["out_offsets"]]
+    pre = q["aux_byte"] == 3
+    exp = [q[(q["aux_byte"] == 0)], q[(q["aux_byte"] == 1)], q[(q["aux_byte"] == 2)],
+           q[pre & (q["address"][:, 0] == 0x8010)], q[pre & (q["address"][:, 0] == 2)], q[pre & (q["address"][:, 0] == 1)]]
+    for k in range(6):
+        assert np.array_equal(o["out_q"][offs[k]:offs[k + 1]], exp[k]), k
+        if offs[k + 1] > offs[k]:
+            old_t, new_t = oracle.queue_push_chain_log(oracle.encode_log_queries(exp[k]))
+            assert np.array_equal(o["out_new_tails"][offs[k]:offs[k + 1]], new_t)
+            assert np.array_equal(o["out_old_tails"][offs[k]:offs[k + 1]], old_t)
+    inst = o["instances"]
+    assert inst.size == -(-n // capacity)
+    for i in range(inst.size - 1):
+        assert inst[i + 1]["hidden_fsm_input"].tobytes() == inst[i]["hidden_fsm_output"].tobytes()
+    fo = inst[-1]["hidden_fsm_output"]
+    assert fo["initial_log_queue_state"]["length"] == 0
+    assert [int(x) for x in fo["queue_state"]["length"]] == [offs[k + 1] - offs[k] for k in range(6)]
+    assert inst[-1]["output_queue_state"].tobytes() == fo["queue_state"].tobytes()
+    assert oracle.log_demux_build(np.zeros(0, oracle.LOG_QUERY), 8)["instances"].size == 1
