@@ -20,6 +20,7 @@
 #include "decommit_kernels.cuh"
 #include "events_kernels.cuh"
 #include "demux_kernels.cuh"
+#include "storage_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -1500,6 +1501,209 @@ extern "C" int zkw_demux_witness_get(const zkw_demux_witness* w, int what, void*
     return ctx->sync_if_host();
 }
 extern "C" void zkw_demux_witness_free(zkw_demux_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    delete w;
+}
+
+// ------------------------------------------------------------------------------------------------ storage sorter
+struct zkw_storage_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n = 0, n_instances = 0, n_result = 0;
+    uint32_t capacity = 0;
+    zkw_log_query *sorted_q = nullptr, *result_q = nullptr;
+    u32* sorted_ext = nullptr;
+    u64* enc_all = nullptr;    // [3n][20]: unsorted plain | sorted (ext) | result : the three hashed queues
+    u64* lhs_enc = nullptr;    // [n][20]: unsorted with extended timestamp (permutation argument only)
+    u64* tails_all = nullptr;  // [5n][4]
+    u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
+    zkw_storage_sorter_instance* instances = nullptr;
+    void release() {
+        void* ptrs[] = {sorted_q, result_q, sorted_ext, enc_all, lhs_enc, tails_all, challenges, lhs_z, rhs_z, instances};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+};
+
+static int storage_run(zkw_ctx* ctx, zkw_storage_witness* w, const zkw_log_query* d_q) {
+    const size_t n = w->n;
+    const unsigned grid = blocks_for(n, 256);
+    u64 *u_enc = w->enc_all, *s_enc = w->enc_all + 20 * n, *r_enc = w->enc_all + 40 * n;
+    u64 *u_old = w->tails_all, *u_new = u_old + 4 * n, *s_old = u_new + 4 * n, *s_new = s_old + 4 * n, *r_new = s_new + 4 * n;
+    // sort keys; the initial order IS the extended timestamp, so 7 stable passes (key low..high, address low..high)
+    u64 *kk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *k64a = nullptr, *k64b = nullptr;
+    u32 *a2 = nullptr, *k32a = nullptr, *k32b = nullptr, *v0 = nullptr, *v1 = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = radix_temp_bytes(n);
+    const char* kn[6] = {"ssort_k0", "ssort_k1", "ssort_k2", "ssort_k3", "ssort_a0", "ssort_a1"};
+    for (int k = 0; k < 6; k++) ZKW_TRY(ctx->scratch_t<u64>(kn[k], n, &kk[k]));
+    ZKW_TRY(ctx->scratch_t<u32>("ssort_a2", n, &a2));
+    ZKW_TRY(ctx->scratch_t<u64>("sort_k64a", n, &k64a));
+    ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", n, &k64b));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_ts", n, &k32a));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_k32", n, &k32b));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_v0", n, &v0));
+    ZKW_TRY(ctx->scratch_t<u32>("sort_v1", n, &v1));
+    ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
+    u32* iota = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("ssort_iota", n, &iota));
+    { Prof _p(ctx, "k_storage_sort_keys"); hipLaunchKernelGGL(k_storage_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], a2, iota); }
+    ZKW_TRY(launch_check("k_storage_sort_keys"));
+    // plain and extended encodings of the unsorted side
+    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, u_enc); }
+    ZKW_TRY(launch_check("k_encode_log"));
+    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, (const u32*)iota, w->lhs_enc); }
+    ZKW_TRY(launch_check("k_encode_log"));
+    HIP_TRY(hipMemcpyAsync(v0, iota, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    u32 *cur = v0, *nxt = v1;
+    for (int k = 0; k < 6; k++) {
+        { Prof _p(ctx, "k_gather_u64_by_u32"); hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, kk[k], cur, n, k64a); }
+        ZKW_TRY(launch_check("k_gather_u64_by_u32"));
+        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, cur, nxt, n, 64, ctx->stream)); }
+        u32* t = cur; cur = nxt; nxt = t;
+    }
+    { Prof _p(ctx, "k_gather_u32_by_u32"); hipLaunchKernelGGL(k_gather_u32_by_u32, dim3(grid), dim3(256), 0, ctx->stream, a2, cur, n, k32a); }
+    ZKW_TRY(launch_check("k_gather_u32_by_u32"));
+    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, k32a, k32b, cur, nxt, n, 32, ctx->stream)); }
+    { u32* t = cur; cur = nxt; nxt = t; }
+    { Prof _p(ctx, "k_storage_gather_encode"); hipLaunchKernelGGL(k_storage_gather_encode, dim3(grid), dim3(256), 0, ctx->stream, d_q, cur, n, w->sorted_q, w->sorted_ext, s_enc); }
+    ZKW_TRY(launch_check("k_storage_gather_encode"));
+    // per-cell registers and the deduplicated queue
+    StorageScan sc;
+    u32* totals = nullptr;
+    ZKW_TRY(ctx->scratch_t<int>("sto_D", n, &sc.D));
+    ZKW_TRY(ctx->scratch_t<u32>("sto_S", n, &sc.S));
+    ZKW_TRY(ctx->scratch_t<u32>("sto_R", n, &sc.R));
+    ZKW_TRY(ctx->scratch_t<u32>("sto_E", n, &sc.E));
+    ZKW_TRY(ctx->scratch_t<u32>("sto_totals", 2, &totals));
+    { Prof _p(ctx, "k_storage_cells"); hipLaunchKernelGGL(k_storage_cells, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, sc, w->result_q, r_enc, totals); }
+    ZKW_TRY(launch_check("k_storage_cells"));
+    u32 h_totals[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_totals, totals, sizeof h_totals, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "storage log is not a consistent history (%u violations of the asserts at "
+                                                       "sort_storage_access.rs:64-203)", h_totals[1]);
+    w->n_result = h_totals[0];
+    std::vector<LogChainJob> chains;
+    chains.push_back(LogChainJob{u_enc, nullptr, u_old, u_new, nullptr, n});
+    chains.push_back(LogChainJob{s_enc, nullptr, s_old, s_new, nullptr, n});
+    chains.push_back(LogChainJob{r_enc, nullptr, nullptr, r_new, nullptr, w->n_result});
+    ZKW_TRY(dev_log_chains(ctx, w->enc_all, 3 * n, chains));
+    std::vector<FsJob> fs(1);
+    fs[0] = FsJob{u_new + 4 * (n - 1), s_new + 4 * (n - 1), (u32)n, (u32)n, w->challenges};
+    ZKW_TRY(dev_fs(ctx, fs, 4, 21));
+    std::vector<GpSeg> segs;
+    segs.push_back(GpSeg{w->lhs_enc, w->lhs_z, w->challenges, n, 0, 0});
+    segs.push_back(GpSeg{s_enc, w->rhs_z, w->challenges, n, 0, 0});
+    ZKW_TRY(dev_grand_products(ctx, segs, 20, 2));
+    std::vector<StorageBlock> blk(1);
+    blk[0] = StorageBlock{w->sorted_q, w->sorted_ext, u_new, s_new, r_new, w->lhs_z, w->rhs_z, sc, w->instances, n, w->capacity};
+    StorageBlock* d_blk = nullptr;
+    ZKW_TRY(ctx->upload("sto_block", blk, &d_blk));
+    { Prof _p(ctx, "k_storage_instances"); hipLaunchKernelGGL(k_storage_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    return launch_check("k_storage_instances");
+}
+
+extern "C" int zkw_storage_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, size_t n, uint32_t capacity,
+                                        zkw_storage_witness** out) {
+    if (!ctx || !out || capacity == 0 || (n && !q)) return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_build: bad argument");
+    if (n >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many log queries");
+    HIP_TRY(hipSetDevice(ctx->device));
+    zkw_storage_witness* w = new zkw_storage_witness();
+    w->ctx = ctx;
+    w->n = n;
+    w->capacity = capacity;
+    w->n_instances = n ? (n + capacity - 1) / capacity : 1;
+    const size_t m = n ? n : 1;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    alloc((void**)&w->sorted_q, m * sizeof(zkw_log_query));
+    alloc((void**)&w->result_q, m * sizeof(zkw_log_query));
+    alloc((void**)&w->sorted_ext, m * 4);
+    alloc((void**)&w->enc_all, 3 * m * 160);
+    alloc((void**)&w->lhs_enc, m * 160);
+    alloc((void**)&w->tails_all, 5 * m * 32);
+    alloc((void**)&w->challenges, 42 * 8);
+    alloc((void**)&w->lhs_z, m * 16);
+    alloc((void**)&w->rhs_z, m * 16);
+    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_storage_sorter_instance));
+    if (e != hipSuccess) {
+        w->release();
+        delete w;
+        return fail(ZKW_ERR_OOM, "zkw_storage_sorter_build: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    int rc = ZKW_OK;
+    if (n == 0) {  // storage_sort_dedup.rs:23-70
+        zkw_storage_sorter_instance inst;
+        memset(&inst, 0, sizeof inst);
+        inst.start_flag = inst.completion_flag = 1;
+        for (int r = 0; r < 2; r++) inst.hidden_fsm_output.lhs_accumulator[r] = inst.hidden_fsm_output.rhs_accumulator[r] = 1;
+        inst.hidden_fsm_output.cycle_idx = 4;
+        if (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(w->challenges, 0, 42 * 8) != hipSuccess)
+            rc = fail(ZKW_ERR_HIP, "copy failed");
+    } else {
+        const zkw_log_query* d_q = nullptr;
+        rc = ctx->in("sto_q", q, n, &d_q);
+        if (rc == ZKW_OK) rc = storage_run(ctx, w, d_q);
+        if (rc == ZKW_OK) rc = ctx->sync_if_host();
+    }
+    if (rc != ZKW_OK) {
+        w->release();
+        delete w;
+        return rc;
+    }
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" size_t zkw_storage_witness_num_instances(const zkw_storage_witness* w) { return w ? w->n_instances : 0; }
+extern "C" size_t zkw_storage_witness_num_results(const zkw_storage_witness* w) { return w ? w->n_result : 0; }
+static const void* sto_array(const zkw_storage_witness* w, int what, size_t* bytes) {
+    const size_t n = w->n, nr = w->n_result;
+    switch (what) {
+        case ZKW_STO_SORTED_QUERIES: *bytes = n * sizeof(zkw_log_query); return w->sorted_q;
+        case ZKW_STO_SORTED_EXT_TS: *bytes = n * 4; return w->sorted_ext;
+        case ZKW_STO_UNSORTED_ENC: *bytes = n * 160; return w->enc_all;
+        case ZKW_STO_LHS_ENC: *bytes = n * 160; return w->lhs_enc;
+        case ZKW_STO_SORTED_ENC: *bytes = n * 160; return w->enc_all + 20 * n;
+        case ZKW_STO_UNSORTED_OLD_TAILS: *bytes = n * 32; return w->tails_all;
+        case ZKW_STO_UNSORTED_NEW_TAILS: *bytes = n * 32; return w->tails_all + 4 * n;
+        case ZKW_STO_SORTED_OLD_TAILS: *bytes = n * 32; return w->tails_all + 8 * n;
+        case ZKW_STO_SORTED_NEW_TAILS: *bytes = n * 32; return w->tails_all + 12 * n;
+        case ZKW_STO_RESULT_QUERIES: *bytes = nr * sizeof(zkw_log_query); return w->result_q;
+        case ZKW_STO_RESULT_NEW_TAILS: *bytes = nr * 32; return w->tails_all + 16 * n;
+        case ZKW_STO_CHALLENGES: *bytes = 42 * 8; return w->challenges;
+        case ZKW_STO_LHS_Z: *bytes = n * 16; return w->lhs_z;
+        case ZKW_STO_RHS_Z: *bytes = n * 16; return w->rhs_z;
+        case ZKW_STO_INSTANCES: *bytes = w->n_instances * sizeof(zkw_storage_sorter_instance); return w->instances;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_storage_witness_bytes(const zkw_storage_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)sto_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_storage_witness_device_ptr(const zkw_storage_witness* w, int what) {
+    size_t b = 0;
+    return w ? sto_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_storage_witness_get(const zkw_storage_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_storage_witness_get: null argument");
+    if (what < 0 || what > ZKW_STO_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    size_t bytes = 0;
+    const void* src = sto_array(w, what, &bytes);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_storage_witness_free(zkw_storage_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);

@@ -69,6 +69,13 @@ SYMBOLS = [
     ("zkw_demux_witness_device_ptr", _vp, [_vp, _int]),
     ("zkw_demux_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_demux_witness_free", None, [_vp]),
+    ("zkw_storage_sorter_build", _int, [_vp, _vp, _sz, _u32, C.POINTER(_vp)]),
+    ("zkw_storage_witness_num_instances", _sz, [_vp]),
+    ("zkw_storage_witness_num_results", _sz, [_vp]),
+    ("zkw_storage_witness_bytes", _sz, [_vp, _int]),
+    ("zkw_storage_witness_device_ptr", _vp, [_vp, _int]),
+    ("zkw_storage_witness_get", _int, [_vp, _int, _vp, _sz]),
+    ("zkw_storage_witness_free", None, [_vp]),
     ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
     ("zkw_trace_free", None, [_vp]),
     ("zkw_trace_num_rows", _sz, [_vp]),
@@ -249,6 +256,66 @@ class DemuxWitness:
     def free(self):
         if self.handle:
             load().zkw_demux_witness_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+STORAGE_FSM = np.dtype(
+    [("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)), ("current_unsorted_queue_state", QUEUE_STATE4),
+     ("current_intermediate_sorted_queue_state", QUEUE_STATE4), ("current_final_sorted_queue_state", QUEUE_STATE4),
+     ("cycle_idx", "<u4"), ("previous_packed_key", "<u4", (13,)), ("previous_key", "<u4", (8,)), ("previous_address", "<u4", (5,)),
+     ("previous_timestamp", "<u4"), ("this_cell_has_explicit_read_and_rollback_depth_zero", "<u4"),
+     ("this_cell_base_value", "<u4", (8,)), ("this_cell_current_value", "<u4", (8,)), ("this_cell_current_depth", "<u4"),
+     ("_pad", "<u4", (2,))])
+STORAGE_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("shard_id_to_process", "<u4"), ("_pad", "<u4"),
+     ("unsorted_log_queue_state", QUEUE_STATE4), ("intermediate_sorted_queue_state", QUEUE_STATE4),
+     ("final_sorted_queue_state", QUEUE_STATE4), ("hidden_fsm_input", STORAGE_FSM), ("hidden_fsm_output", STORAGE_FSM),
+     ("first_item", "<u8"), ("num_items", "<u8")])
+(STO_SORTED_QUERIES, STO_SORTED_EXT_TS, STO_UNSORTED_ENC, STO_LHS_ENC, STO_SORTED_ENC, STO_UNSORTED_OLD_TAILS,
+ STO_UNSORTED_NEW_TAILS, STO_SORTED_OLD_TAILS, STO_SORTED_NEW_TAILS, STO_RESULT_QUERIES, STO_RESULT_NEW_TAILS, STO_CHALLENGES,
+ STO_LHS_Z, STO_RHS_Z, STO_INSTANCES) = range(15)
+
+
+class StorageWitness:
+    """Owner of a zkw_storage_witness handle."""
+
+    _DTYPES = {STO_SORTED_QUERIES: LOG_QUERY, STO_RESULT_QUERIES: LOG_QUERY, STO_INSTANCES: STORAGE_INSTANCE,
+               STO_SORTED_EXT_TS: np.dtype("<u4")}
+    _SHAPES = {STO_UNSORTED_ENC: (-1, 20), STO_LHS_ENC: (-1, 20), STO_SORTED_ENC: (-1, 20), STO_UNSORTED_OLD_TAILS: (-1, 4),
+               STO_UNSORTED_NEW_TAILS: (-1, 4), STO_SORTED_OLD_TAILS: (-1, 4), STO_SORTED_NEW_TAILS: (-1, 4),
+               STO_RESULT_NEW_TAILS: (-1, 4), STO_CHALLENGES: (2, 21), STO_LHS_Z: (2, -1), STO_RHS_Z: (2, -1)}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = C.c_void_p(None)
+
+    @property
+    def num_instances(self):
+        return load().zkw_storage_witness_num_instances(self.handle)
+
+    @property
+    def num_results(self):
+        return load().zkw_storage_witness_num_results(self.handle)
+
+    def get(self, what):
+        lib = load()
+        nbytes = lib.zkw_storage_witness_bytes(self.handle, what)
+        dt = self._DTYPES.get(what, np.dtype("<u8"))
+        out = np.zeros(nbytes // dt.itemsize, dt)
+        if nbytes:
+            _check(lib.zkw_storage_witness_get(self.handle, what, _np_ptr(out), nbytes))
+        shape = self._SHAPES.get(what)
+        return out.reshape(shape) if shape else out
+
+    def free(self):
+        if self.handle:
+            load().zkw_storage_witness_free(self.handle)
             self.handle = C.c_void_p(None)
 
     def __del__(self):
@@ -574,4 +641,12 @@ class Context:
         w = DemuxWitness(self)
         _check(load().zkw_log_demux_build(self.handle, _np_ptr(q) if q.size else None, q.size, per_circuit_capacity, None,
                                           C.byref(w.handle)))
+        return w
+
+    def compute_storage_dedup_and_sort(self, demuxed_rollup_storage_queries, per_circuit_capacity):
+        """sort_storage_access_queries + compute_storage_dedup_and_sort (storage_sort_dedup.rs:12-703) -> StorageWitness."""
+        q = np.ascontiguousarray(demuxed_rollup_storage_queries, dtype=LOG_QUERY)
+        w = StorageWitness(self)
+        _check(load().zkw_storage_sorter_build(self.handle, _np_ptr(q) if q.size else None, q.size, per_circuit_capacity,
+                                               C.byref(w.handle)))
         return w

@@ -175,3 +175,47 @@ def mixed_log_queue(n: int, seed: int = 1) -> np.ndarray:
     q["address"][pre] = 0
     q["address"][pre, 0] = low[pre]
     return q
+
+
+def storage_trace(n: int, n_cells: int, seed: int = 1, p_read: float = 0.35, p_rollback: float = 0.2) -> np.ndarray:
+    """Valid rollup-storage log of n records over n_cells (address, key) cells: reads return the current
+    value, writes record (previous, new), a rollback undoes the most recent pending write of its cell and
+    repeats that write's (read_value, written_value). Timestamps increase; aux_byte 0, shard 0."""
+    r = splitmix64(seed, 4 * n + 13 * n_cells)
+    cells_w = np.zeros((n_cells, 13), np.uint32)
+    for k in range(13):
+        cells_w[:, k] = (r[4 * n + k * n_cells: 4 * n + (k + 1) * n_cells] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    if n_cells > 2:
+        cells_w[1, 5:] = cells_w[0, 5:]   # same key, different address
+        cells_w[2, :5] = cells_w[0, :5]   # same address, different key
+    pick = (r[:n] % np.uint64(n_cells)).astype(np.int64)
+    u = (r[n:2 * n] >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    newv = np.zeros((n, 8), np.uint32)
+    newv[:, 0] = (r[2 * n:3 * n] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    newv[:, 7] = (r[2 * n:3 * n] >> np.uint64(32)).astype(np.uint32)
+    newv[:, 3] = (r[3 * n:4 * n] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    q = np.zeros(n, LOG_QUERY)
+    cur = {}      # cell -> current value
+    stack = {}    # cell -> list of (read_value, written_value)
+    for i in range(n):
+        c = int(pick[i])
+        q["address"][i] = cells_w[c, :5]
+        q["key"][i] = cells_w[c, 5:]
+        q["timestamp"][i] = 1000 + i
+        q["tx_number_in_block"][i] = i % 7
+        val = cur.get(c, np.zeros(8, np.uint32))
+        st = stack.setdefault(c, [])
+        if u[i] < p_read:
+            q["read_value"][i] = val
+            q["written_value"][i] = 0
+        elif u[i] < p_read + p_rollback and st:
+            rv, wv = st.pop()
+            q["rw_flag"][i], q["rollback"][i] = 1, 1
+            q["read_value"][i], q["written_value"][i] = rv, wv
+            cur[c] = rv
+        else:
+            q["rw_flag"][i] = 1
+            q["read_value"][i], q["written_value"][i] = val, newv[i]
+            st.append((val.copy(), newv[i].copy()))
+            cur[c] = newv[i].copy()
+    return q

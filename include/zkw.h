@@ -229,6 +229,39 @@ const void *zkw_demux_witness_device_ptr(const zkw_demux_witness *w, int what);
 int zkw_demux_witness_get(const zkw_demux_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_demux_witness_free(zkw_demux_witness *w);
 
+/* ---- StorageSorter witness builder ---------------------------------------------------------------- */
+typedef struct zkw_storage_witness zkw_storage_witness;
+/* sort_storage_access_queries (circuit_sequencer_api/src/sort_storage_access.rs:19-260) +
+   compute_storage_dedup_and_sort (src/witness/individual_circuits/storage_sort_dedup.rs:12-703).
+   q: the demuxed rollup-storage queue in order (n == 0 yields the reference's dummy instance with its
+   cycle_idx = 4 convention). ZKW_ERR_CHECK_FAILED when the log is not a consistent storage history
+   (rollback without a pending write, first access of a cell being a rollback, ...). */
+int zkw_storage_sorter_build(zkw_ctx *ctx, const zkw_log_query *q, size_t n, uint32_t capacity,
+                             zkw_storage_witness **out);
+enum {
+    ZKW_STO_SORTED_QUERIES = 0,     /* zkw_log_query[n] */
+    ZKW_STO_SORTED_EXT_TS = 1,      /* uint32_t[n]: extended timestamp = position in the unsorted queue */
+    ZKW_STO_UNSORTED_ENC = 2,       /* uint64_t[n][20]: plain encodings hashed into the unsorted queue */
+    ZKW_STO_LHS_ENC = 3,            /* uint64_t[n][20]: with extended timestamp (storage_sort_dedup.rs:128-143) */
+    ZKW_STO_SORTED_ENC = 4,         /* uint64_t[n][20]: with extended timestamp */
+    ZKW_STO_UNSORTED_OLD_TAILS = 5, /* uint64_t[n][4] */
+    ZKW_STO_UNSORTED_NEW_TAILS = 6,
+    ZKW_STO_SORTED_OLD_TAILS = 7,
+    ZKW_STO_SORTED_NEW_TAILS = 8,
+    ZKW_STO_RESULT_QUERIES = 9,     /* zkw_log_query[n_result]: deduplicated_rollup_storage_queries */
+    ZKW_STO_RESULT_NEW_TAILS = 10,  /* uint64_t[n_result][4] */
+    ZKW_STO_CHALLENGES = 11,        /* uint64_t[2][21] */
+    ZKW_STO_LHS_Z = 12,             /* uint64_t[2][n] */
+    ZKW_STO_RHS_Z = 13,
+    ZKW_STO_INSTANCES = 14          /* zkw_storage_sorter_instance[max(1, ceil(n/capacity))] */
+};
+size_t zkw_storage_witness_num_instances(const zkw_storage_witness *w);
+size_t zkw_storage_witness_num_results(const zkw_storage_witness *w);
+size_t zkw_storage_witness_bytes(const zkw_storage_witness *w, int what);
+const void *zkw_storage_witness_device_ptr(const zkw_storage_witness *w, int what);
+int zkw_storage_witness_get(const zkw_storage_witness *w, int what, void *dst, size_t dst_bytes);
+void zkw_storage_witness_free(zkw_storage_witness *w);
+
 /* ---- synthesis: filled traces ------------------------------------------------------------------- */
 /* A zkw_trace owns n_slots trace buffers in HBM, each column-major uint64_t[n_cols][n_rows] (n_rows =
    2^20 at production geometry = TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17). It plays the role of

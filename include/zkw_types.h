@@ -218,6 +218,43 @@ typedef struct zkw_log_demux_instance {
     uint64_t num_items;
 } zkw_log_demux_instance;
 
+/* ---- StorageSorter (storage_sort_dedup.rs + sort_storage_access.rs) -------------------------------- */
+#define ZKW_STORAGE_PACKED_KEY_LENGTH 13 /* key limbs 0..7 then address limbs 0..4, log_query.rs:82-92 */
+
+/* StorageDeduplicatorFSMInputOutputWitness, src/witness/individual_circuits/storage_sort_dedup.rs:563-596 */
+typedef struct zkw_storage_sorter_fsm {
+    uint64_t lhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];
+    uint64_t rhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];
+    zkw_queue_state4 current_unsorted_queue_state;
+    zkw_queue_state4 current_intermediate_sorted_queue_state;
+    zkw_queue_state4 current_final_sorted_queue_state;
+    uint32_t cycle_idx;
+    uint32_t previous_packed_key[ZKW_STORAGE_PACKED_KEY_LENGTH];
+    uint32_t previous_key[8];
+    uint32_t previous_address[5];
+    uint32_t previous_timestamp;
+    uint32_t this_cell_has_explicit_read_and_rollback_depth_zero;
+    uint32_t this_cell_base_value[8];
+    uint32_t this_cell_current_value[8];
+    uint32_t this_cell_current_depth;
+    uint32_t _pad[2];
+} zkw_storage_sorter_fsm;
+
+/* StorageDeduplicatorInstanceWitness, storage_sort_dedup.rs:552-603 */
+typedef struct zkw_storage_sorter_instance {
+    uint32_t start_flag;
+    uint32_t completion_flag;
+    uint32_t shard_id_to_process;                    /* observable_input */
+    uint32_t _pad;
+    zkw_queue_state4 unsorted_log_queue_state;        /* observable_input */
+    zkw_queue_state4 intermediate_sorted_queue_state; /* observable_input */
+    zkw_queue_state4 final_sorted_queue_state;        /* observable_output (placeholder except on the last) */
+    zkw_storage_sorter_fsm hidden_fsm_input;
+    zkw_storage_sorter_fsm hidden_fsm_output;
+    uint64_t first_item;
+    uint64_t num_items;
+} zkw_storage_sorter_instance;
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,20 @@ int64_t orc_log_demux_build(const zkw_log_query *q, size_t n, uint32_t capacity,
                             uint64_t *out_enc, uint64_t *out_old_tails, uint64_t *out_new_tails, uint64_t *out_offsets,
                             zkw_log_demux_instance *instances);
 
+/* ---- storage sorter builder: sort_storage_access_queries (circuit_sequencer_api/src/sort_storage_access.rs:19-260)
+   + compute_storage_dedup_and_sort (src/witness/individual_circuits/storage_sort_dedup.rs:12-703).
+   q: the demuxed rollup storage queue in order. Outputs sized for n: sorted_q / sorted_ext_ts (= position in
+   the unsorted queue), unsorted_enc (plain, what the queue hashes), lhs_enc (with extended timestamp, the
+   permutation-argument side), sorted_enc (with extended timestamp), old/new tails of both queues, the
+   deduplicated queries + encodings + new tails (n_result used), challenges [2][21], chains, instances
+   [max(1, ceil(n/capacity))]. Returns the number of instances or <0 when an assert of the reference fails. */
+int64_t orc_storage_sorter_build(const zkw_log_query *q, size_t n, uint32_t capacity, zkw_log_query *sorted_q,
+                                 uint32_t *sorted_ext_ts, uint64_t *unsorted_enc, uint64_t *lhs_enc, uint64_t *sorted_enc,
+                                 uint64_t *unsorted_old_tails, uint64_t *unsorted_new_tails, uint64_t *sorted_old_tails,
+                                 uint64_t *sorted_new_tails, zkw_log_query *result_q, uint64_t *result_enc,
+                                 uint64_t *result_new_tails, uint64_t *n_result, uint64_t *challenges, uint64_t *lhs_z,
+                                 uint64_t *rhs_z, zkw_storage_sorter_instance *instances);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,20 @@ DEMUX_INSTANCE = np.dtype(
      ("first_item", "<u8"), ("num_items", "<u8")])
 
 
+STORAGE_FSM = np.dtype(
+    [("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)), ("current_unsorted_queue_state", QUEUE_STATE4),
+     ("current_intermediate_sorted_queue_state", QUEUE_STATE4), ("current_final_sorted_queue_state", QUEUE_STATE4),
+     ("cycle_idx", "<u4"), ("previous_packed_key", "<u4", (13,)), ("previous_key", "<u4", (8,)), ("previous_address", "<u4", (5,)),
+     ("previous_timestamp", "<u4"), ("this_cell_has_explicit_read_and_rollback_depth_zero", "<u4"),
+     ("this_cell_base_value", "<u4", (8,)), ("this_cell_current_value", "<u4", (8,)), ("this_cell_current_depth", "<u4"),
+     ("_pad", "<u4", (2,))])
+STORAGE_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("shard_id_to_process", "<u4"), ("_pad", "<u4"),
+     ("unsorted_log_queue_state", QUEUE_STATE4), ("intermediate_sorted_queue_state", QUEUE_STATE4),
+     ("final_sorted_queue_state", QUEUE_STATE4), ("hidden_fsm_input", STORAGE_FSM), ("hidden_fsm_output", STORAGE_FSM),
+     ("first_item", "<u8"), ("num_items", "<u8")])
+
+
 def build(force=False):
     """Compile liboracle.so with gcc (building the checker is not using it)."""
     if force or not os.path.exists(_LIB_PATH) or any(
@@ -350,4 +364,34 @@ def log_demux_build(q, capacity):
         o[key] = o[key][:n]
     for key in ("out_q", "out_enc", "out_old_tails", "out_new_tails"):
         o[key] = o[key][:r]
+    return o
+
+
+def storage_sorter_build(q, capacity):
+    q = np.ascontiguousarray(q, dtype=LOG_QUERY)
+    n = q.size
+    m = max(n, 1)
+    n_inst = max(1, (n + capacity - 1) // capacity)
+    o = dict(sorted_q=np.zeros(m, LOG_QUERY), sorted_ext_ts=np.zeros(m, np.uint32), unsorted_enc=np.zeros((m, 20), np.uint64),
+             lhs_enc=np.zeros((m, 20), np.uint64), sorted_enc=np.zeros((m, 20), np.uint64),
+             unsorted_old_tails=np.zeros((m, 4), np.uint64), unsorted_new_tails=np.zeros((m, 4), np.uint64),
+             sorted_old_tails=np.zeros((m, 4), np.uint64), sorted_new_tails=np.zeros((m, 4), np.uint64),
+             result_q=np.zeros(m, LOG_QUERY), result_enc=np.zeros((m, 20), np.uint64), result_new_tails=np.zeros((m, 4), np.uint64),
+             challenges=np.zeros((2, 21), np.uint64), lhs_z=np.zeros((2, n), np.uint64), rhs_z=np.zeros((2, n), np.uint64),
+             instances=np.zeros(n_inst, STORAGE_INSTANCE))
+    nr = C.c_uint64(0)
+    f = lib().orc_storage_sorter_build
+    f.restype = C.c_int64
+    rc = f(_p(q), C.c_size_t(n), C.c_uint32(capacity), _p(o["sorted_q"]), _p(o["sorted_ext_ts"]), _p(o["unsorted_enc"]),
+           _p(o["lhs_enc"]), _p(o["sorted_enc"]), _p(o["unsorted_old_tails"]), _p(o["unsorted_new_tails"]),
+           _p(o["sorted_old_tails"]), _p(o["sorted_new_tails"]), _p(o["result_q"]), _p(o["result_enc"]),
+           _p(o["result_new_tails"]), C.byref(nr), _p(o["challenges"]), _p(o["lhs_z"]), _p(o["rhs_z"]), _p(o["instances"]))
+    if rc < 0:
+        raise RuntimeError(f"orc_storage_sorter_build failed: {rc}")
+    k = nr.value
+    for key in ("sorted_q", "sorted_ext_ts", "unsorted_enc", "lhs_enc", "sorted_enc", "unsorted_old_tails", "unsorted_new_tails",
+                "sorted_old_tails", "sorted_new_tails"):
+        o[key] = o[key][:n]
+    for key in ("result_q", "result_enc", "result_new_tails"):
+        o[key] = o[key][:k]
     return o

@@ -339,3 +339,44 @@ def test_log_demux_empty_and_unreachable(ctx, oracle):
     with pytest.raises(nv.ZkwError) as ei:
         ctx.compute_logs_demux(q, 16)
     assert ei.value.code == nv.ERR_CHECK_FAILED
+
+
+@pytest.mark.parametrize("n,cells,capacity", [(1, 1, 4), (60, 4, 16), (3000, 300, 256), (300, 300, 64), (128, 9, 32),
+                                              (5000, 50, 46921), (2048, 700, 1024)])
+def test_storage_sorter(ctx, oracle, n, cells, capacity):
+    from era_zkevm_test_harness_amd import native as nv
+
+    q = synthetic.storage_trace(n, cells, seed=n + cells + 1)
+    w = ctx.compute_storage_dedup_and_sort(q, capacity)
+    o = oracle.storage_sorter_build(q, capacity)
+    assert w.num_results == o["result_q"].size
+    for what, key in ((nv.STO_SORTED_QUERIES, "sorted_q"), (nv.STO_SORTED_EXT_TS, "sorted_ext_ts"), (nv.STO_UNSORTED_ENC, "unsorted_enc"),
+                      (nv.STO_LHS_ENC, "lhs_enc"), (nv.STO_SORTED_ENC, "sorted_enc"), (nv.STO_UNSORTED_OLD_TAILS, "unsorted_old_tails"),
+                      (nv.STO_UNSORTED_NEW_TAILS, "unsorted_new_tails"), (nv.STO_SORTED_OLD_TAILS, "sorted_old_tails"),
+                      (nv.STO_SORTED_NEW_TAILS, "sorted_new_tails"), (nv.STO_RESULT_QUERIES, "result_q"),
+                      (nv.STO_RESULT_NEW_TAILS, "result_new_tails"), (nv.STO_CHALLENGES, "challenges"), (nv.STO_LHS_Z, "lhs_z"),
+                      (nv.STO_RHS_Z, "rhs_z")):
+        assert np.array_equal(w.get(what), o[key]), key
+    gi = w.get(nv.STO_INSTANCES)
+    assert gi.size == o["instances"].size
+    for a, b in zip(gi, o["instances"]):
+        for f in a.dtype.names:
+            if a[f].dtype.names:
+                for g in a[f].dtype.names:
+                    assert a[f][g].tobytes() == b[f][g].tobytes(), (f, g)
+            else:
+                assert a[f].tobytes() == b[f].tobytes(), f
+    w.free()
+
+
+def test_storage_sorter_empty_and_inconsistent(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    w = ctx.compute_storage_dedup_and_sort(np.zeros(0, nv.LOG_QUERY), 16)
+    assert w.get(nv.STO_INSTANCES).tobytes() == oracle.storage_sorter_build(np.zeros(0, oracle.LOG_QUERY), 16)["instances"].tobytes()
+    w.free()
+    q = synthetic.storage_trace(40, 3, seed=9, p_rollback=0.0)
+    q["rw_flag"][0], q["rollback"][0] = 1, 1  # a rollback with nothing to roll back
+    with pytest.raises(nv.ZkwError) as ei:
+        ctx.compute_storage_dedup_and_sort(q, 16)
+    assert ei.value.code == nv.ERR_CHECK_FAILED

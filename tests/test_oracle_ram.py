@@ -284,3 +284,45 @@ def test_log_demux_oracle(oracle, n, capacity):
     assert [int(x) for x in fo["queue_state"]["length"]] == [offs[k + 1] - offs[k] for k in range(6)]
     assert inst[-1]["output_queue_state"].tobytes() == fo["queue_state"].tobytes()
     assert oracle.log_demux_build(np.zeros(0, oracle.LOG_QUERY), 8)["instances"].size == 1
+
+
+@pytest.mark.parametrize("n,cells,capacity", [(1, 1, 4), (60, 4, 16), (400, 40, 64), (300, 300, 64), (128, 9, 32), (50, 3, 1000)])
+def test_storage_sorter_oracle(oracle, n, cells, capacity):
+    q = synthetic.storage_trace(n, cells, seed=n + cells)
+    o = oracle.storage_sorter_build(q, capacity)
+    sq, ext = o["sorted_q"], o["sorted_ext_ts"]
+    assert sorted(int(x) for x in ext) == list(range(n))
+    keyf = lambda r, e: tuple(int(x) for x in r["address"][::-1]) + tuple(int(x) for x in r["key"][::-1]) + (int(e),)
+    ks = [keyf(sq[i], ext[i]) for i in range(n)]
+    assert ks == sorted(ks)
+    # replay the memory model: net effect per cell
+    hist = {}
+    for r in q:
+        cell = (r["address"].tobytes(), r["key"].tobytes())
+        h = hist.setdefault(cell, dict(initial=r["read_value"].copy(), cur=r["read_value"].copy(), depth=0, read0=False))
+        if not r["rw_flag"]:
+            h["read0"] |= h["depth"] == 0
+        elif not r["rollback"]:
+            h["depth"] += 1; h["cur"] = r["written_value"].copy()
+        else:
+            h["depth"] -= 1; h["cur"] = r["read_value"].copy()
+    exp = []
+    for cell in sorted(hist, key=lambda c: (c[0][::-1], c[1][::-1])):
+        h = hist[cell]
+        if h["depth"] > 0 or h["read0"]:
+            exp.append((cell, h["initial"], h["cur"], not np.array_equal(h["initial"], h["cur"])))
+    assert o["result_q"].size == len(exp)
+    for rq, (cell, ini, cur, rw) in zip(o["result_q"], exp):
+        assert rq["address"].tobytes() == cell[0] and rq["key"].tobytes() == cell[1]
+        assert np.array_equal(rq["read_value"], ini) and np.array_equal(rq["written_value"], cur) and bool(rq["rw_flag"]) == rw
+    inst = o["instances"]
+    fo = inst[-1]["hidden_fsm_output"]
+    assert np.array_equal(fo["lhs_accumulator"], fo["rhs_accumulator"])
+    assert int(fo["current_final_sorted_queue_state"]["length"]) == len(exp)
+    assert int(fo["cycle_idx"]) == inst.size * capacity
+    for i in range(inst.size - 1):
+        a, b = inst[i]["hidden_fsm_output"], inst[i + 1]["hidden_fsm_input"]
+        for f in a.dtype.names:
+            assert a[f].tobytes() == b[f].tobytes(), f
+    dummy = oracle.storage_sorter_build(np.zeros(0, oracle.LOG_QUERY), 8)["instances"]
+    assert dummy.size == 1 and dummy[0]["hidden_fsm_output"]["cycle_idx"] == 4
