@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=256, help="independent memory queues per GPU per step")
+    ap.add_argument("--blocks", type=int, default=0,
+                    help="independent memory queues per GPU per step (0 = size the batch to the free HBM)")
     ap.add_argument("--queries", type=int, default=CAPACITY)
     ap.add_argument("--ring", type=int, default=16, help="trace buffers (1.25 GB each) in the output ring")
     ap.add_argument("--cpu-sample", type=int, default=4)
@@ -80,7 +81,14 @@ def main():
     if os.environ.get("ZKW_CHAIN_FORM"):
         ctx.set_chain_form(int(os.environ["ZKW_CHAIN_FORM"]))
 
-    B, n = args.blocks, args.queries
+    n = args.queries
+    B = args.blocks
+    if B <= 0:
+        # one block of n queries keeps ~74 B/query... measured 69 MB per 136 714-query block (inputs 6.6 + witness
+        # 54.7 + sort scratch 5.5 + chain/descriptor scratch); the chains want as many concurrent queues as fit
+        free, _total = torch.cuda.mem_get_info(dev)
+        per_block = int(n * 520)
+        B = int(max(16, min(3072, (0.82 * free - args.ring * 1.25e9) // per_block)))
     n_rows = 1 << 20  # TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17
     ring = native.Trace(ctx, n_rows, args.ring)  # trace buffers a prover would consume and hand back
     base, q = make_inputs(B, n, rank, dev)
@@ -150,6 +158,7 @@ def main():
         synth_ms = sum(v[0] for k, v in prof.items() if k.startswith("k_ram_fill") or k.startswith("k_ram_nd"))
         synth_gbs = (149 * n_rows * 8 * n_inst_local * args.steps) / (synth_ms * 1e-3) / 1e9 if synth_ms else None
         chain_ms, chain_cnt = prof.get("k_chain_full", prof.get("k_chain_full_q4", (0.0, 1)))
+        free_after, total_mem = torch.cuda.mem_get_info(dev)
         out = {
             "metric": "base-layer circuits/sec (2^20 rows)",
             "value": circuits / dt,
@@ -175,6 +184,7 @@ def main():
             "synthesis": {"trace_bytes_per_circuit": 149 * n_rows * 8, "kernels_ms_per_step": synth_ms / args.steps,
                           "achieved_GBps": synth_gbs, "frac_of_hbm_peak": synth_gbs / HBM_PEAK_GBS if synth_gbs else None,
                           "per_kernel": hbm_kernels},
+            "hbm_used_GB": (total_mem - free_after) / 1e9,
             "poseidon2_perm_per_s": 2 * items * chain_cnt / (chain_ms * 1e-3) if chain_ms else None,
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
         }

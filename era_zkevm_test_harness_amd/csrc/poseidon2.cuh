@@ -38,37 +38,63 @@ __host__ __device__ __forceinline__ u32 shift_at(int i) {
 #endif
 }
 
-// ---------------------------------------------------------------- one state per lane
-// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] by the Poseidon2 addition chain.
-GL_HD void m4(u64& x0, u64& x1, u64& x2, u64& x3) {
-    u64 t0 = gl::add(x0, x1), t1 = gl::add(x2, x3);
-    u64 t2 = gl::add(gl::add(x1, x1), t1), t3 = gl::add(gl::add(x3, x3), t0);
-    u64 t1_4 = gl::add(t1, t1); t1_4 = gl::add(t1_4, t1_4);
-    u64 t0_4 = gl::add(t0, t0); t0_4 = gl::add(t0_4, t0_4);
-    u64 t4 = gl::add(t1_4, t3), t5 = gl::add(t0_4, t2);
-    x0 = gl::add(t3, t5); x1 = t5; x2 = gl::add(t2, t4); x3 = t4;
+// ---------------------------------------------------------------- lazy-reduction helpers
+// value = lo + hi * 2^64 with a small hi: sums of a few dozen field elements are accumulated without
+// reducing and brought back with one `lo + hi * (2^32 - 1)` at the end (2^64 = 2^32 - 1 mod p).
+struct Wide {
+    u64 lo;
+    u32 hi;
+};
+GL_HD Wide wide(u64 x) { Wide r; r.lo = x; r.hi = 0; return r; }
+GL_HD Wide wadd(Wide a, Wide b) {
+    Wide r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
+    return r;
+}
+// a * 2^s for 1 <= s <= 31
+GL_HD Wide wshl(Wide a, u32 s) {
+    Wide r;
+    r.lo = a.lo << s;
+    r.hi = (a.hi << s) | (u32)(a.lo >> (64 - s));
+    return r;
+}
+// hi < 2^31
+GL_HD u64 wreduce(Wide a) {
+    u64 t = ((u64)a.hi << 32) - a.hi;  // hi * EPS
+    u64 r = a.lo + t;
+    u64 c = r < t ? gl::EPS : 0;
+    return r + c;  // cannot wrap again: after a wrap r < t < 2^63
 }
 
-// external layer circ(2*M4, M4, M4)
+// ---------------------------------------------------------------- one state per lane
+// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] by the Poseidon2 addition chain, on unreduced sums
+GL_HD void m4w(const u64 x[4], Wide t[4]) {
+    Wide t0 = wadd(wide(x[0]), wide(x[1])), t1 = wadd(wide(x[2]), wide(x[3]));
+    Wide t2 = wadd(wshl(wide(x[1]), 1), t1), t3 = wadd(wshl(wide(x[3]), 1), t0);
+    Wide t4 = wadd(wshl(t1, 2), t3), t5 = wadd(wshl(t0, 2), t2);
+    t[0] = wadd(t3, t5); t[1] = t5; t[2] = wadd(t2, t4); t[3] = t4;
+}
+
+// external layer circ(2*M4, M4, M4): every output is < 64 * 2^64 before its single reduction
 GL_HD void external(u64 s[12]) {
-    m4(s[0], s[1], s[2], s[3]);
-    m4(s[4], s[5], s[6], s[7]);
-    m4(s[8], s[9], s[10], s[11]);
+    Wide t[12];
+    m4w(s, t); m4w(s + 4, t + 4); m4w(s + 8, t + 8);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        u64 col = gl::add(gl::add(s[i], s[4 + i]), s[8 + i]);
-        s[i] = gl::add(s[i], col); s[4 + i] = gl::add(s[4 + i], col); s[8 + i] = gl::add(s[8 + i], col);
+        Wide col = wadd(wadd(t[i], t[4 + i]), t[8 + i]);
+        s[i] = wreduce(wadd(t[i], col)); s[4 + i] = wreduce(wadd(t[4 + i], col)); s[8 + i] = wreduce(wadd(t[8 + i], col));
     }
 }
 
 // internal layer: y_i = x_i * 2^shift_i + sum_j x_j
 GL_HD void internal(u64 s[12]) {
-    u64 sum = s[0];
+    Wide sum = wide(s[0]);
 #pragma unroll
-    for (int i = 1; i < 12; i++) sum = gl::add(sum, s[i]);
+    for (int i = 1; i < 12; i++) sum = wadd(sum, wide(s[i]));
     constexpr u32 SH[12] = P2_INTERNAL_DIAG_SHIFTS_INIT;
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl::add(gl::mul_pow2(s[i], SH[i]), sum);
+    for (int i = 0; i < 12; i++) s[i] = wreduce(wadd(SH[i] ? wshl(wide(s[i]), SH[i]) : wide(s[i]), sum));
 }
 
 GL_HD void full_round(u64 s[12], int r) {
@@ -109,17 +135,6 @@ constexpr int QP_ROT3 = 3 | (0 << 2) | (1 << 4) | (2 << 6);
 constexpr int QP_SWAP1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);
 constexpr int ROW_ROR4 = 0x124, ROW_ROR8 = 0x128, ROW_ROR12 = 0x12C;
 
-// value = lo + hi * 2^64, hi small
-struct Wide {
-    u64 lo;
-    u32 hi;
-};
-__device__ __forceinline__ Wide wadd(Wide a, Wide b) {
-    Wide r;
-    r.lo = a.lo + b.lo;
-    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
-    return r;
-}
 template <int CTRL>
 __device__ __forceinline__ Wide wdpp(Wide a) {
     Wide r;
@@ -127,16 +142,6 @@ __device__ __forceinline__ Wide wdpp(Wide a) {
     r.hi = dpp32<CTRL>(a.hi);
     return r;
 }
-// hi < 2^31
-__device__ __forceinline__ u64 wreduce(Wide a) {
-    u64 t = ((u64)a.hi << 32) - a.hi;  // hi * EPS
-    u64 r = a.lo + t;
-    u64 c = r < t ? gl::EPS : 0;
-    u64 r2 = r + c;
-    if (r2 < c) r2 += gl::EPS;
-    return r2;
-}
-
 struct Coop {
     // per-lane constants, loaded once per kernel
     u64 rc_full[2 * P2_HALF_FULL_ROUNDS];  // c_rc[12*round + g] for the 8 full rounds (0 for idle lanes)

@@ -426,8 +426,10 @@ __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__
     const u64* psh = i == 0 ? ri.sh : job.sorted_tails + 12 * (first + (i - 1 < m ? i - 1 : m - 1));
 #pragma unroll
     for (int k = 0; k < 12; k++) {
-        // the Poseidon2 rows of this cycle were written by an earlier kernel on the same stream
-        const u64 uo = TR(RC_PU_uo0 + k, rPU), so = TR(RC_PS_so0 + k, rPS);
+        // popped cycle: the Poseidon2 row's output IS the queue tail after this item (verified by the checker's
+        // copy links); padding cycle: read what k_ram_fill_poseidon wrote earlier on this stream
+        const u64 uo = can_pop ? job.unsorted_tails[12 * (first + i) + k] : TR(RC_PU_uo0 + k, rPU);
+        const u64 so = can_pop ? job.sorted_tails[12 * (first + i) + k] : TR(RC_PS_so0 + k, rPS);
         const u64 a = puh[k], b = psh[k];
         const int o = 3 * k;
         TR(RC_D_uo0 + o, row) = uo; TR(RC_D_P_uh0 + o, row) = a; TR(RC_D_uh0 + o, row) = can_pop ? uo : a;
@@ -437,26 +439,32 @@ __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__
     for (int col = ND; col < RC_G + RC_L; col++) TR(col, row) = 0;
 }
 
-// boundary rows, the zero padding below them and the multiplicity column: one block column per job
+// the zero padding from the first boundary row down (all general + lookup columns) and the multiplicity
+// column. grid.x tiles the rows (2 rows per lane, 16-byte stores where the pair is aligned), grid.y = job.
 __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SynthJob job = jobs[blockIdx.y];
     u64* trace = job.trace;
     const size_t bnd = (size_t)RC_ROWS_PER_CYCLE * capacity;
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-    // zero everything from the first boundary row down, all general + lookup columns
-    const size_t n_pad = n_rows - bnd;
-    for (size_t k = tid; k < n_pad * (RC_G + RC_L); k += stride) {
-        const size_t col = k / n_pad, r = bnd + k % n_pad;
-        TR(col, r) = 0;
+    const size_t first_even = (bnd + 1) & ~(size_t)1;  // pairs start on even rows: (col*n_rows + row)*8 is 16-B aligned
+    const size_t n_pairs = (n_rows - first_even) / 2;  // n_rows is even (power of two)
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const ulonglong2 z = make_ulonglong2(0, 0);
+    for (int col = 0; col < RC_G + RC_L; col++) {
+        u64* c = trace + (size_t)col * n_rows;
+        if (tid == 0 && first_even != bnd) c[bnd] = 0;
+        ulonglong2* c2 = reinterpret_cast<ulonglong2*>(c + first_even);
+        for (size_t k = tid; k < n_pairs; k += stride) c2[k] = z;
     }
     // multiplicities: histogram of the used lookup cells + every unused lookup cell counts as value 0
+    u64* m = trace + (size_t)RC_MULT_COL * n_rows;
     for (size_t r = tid; r < n_rows; r += stride) {
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];
             if (r == 0) v += (u64)RC_L * n_rows - (u64)LOOKUPS_PER_CYCLE * capacity;
         }
-        TR(RC_MULT_COL, r) = v;
+        m[r] = v;
     }
 }
 

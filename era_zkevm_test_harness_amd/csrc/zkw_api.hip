@@ -905,6 +905,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     if (RC_MIN_ROWS(capacity) > n_rows)
         return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity,
                     (unsigned long long)RC_MIN_ROWS(capacity), n_rows);
+    if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const u32 n_tiles = (capacity + 255) / 256;
@@ -954,7 +955,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     ZKW_TRY(launch_check("k_ram_fill_C"));
     { Prof _p(ctx, "k_ram_fill_D"); hipLaunchKernelGGL(k_ram_fill_D, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_D"));
-    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(256, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(128, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_tail"));
     { Prof _p(ctx, "k_ram_fill_boundary"); hipLaunchKernelGGL(k_ram_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_boundary"));
