@@ -21,6 +21,7 @@
 #include "events_kernels.cuh"
 #include "demux_kernels.cuh"
 #include "storage_kernels.cuh"
+#include "decommitter_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -1705,6 +1706,134 @@ extern "C" int zkw_storage_witness_get(const zkw_storage_witness* w, int what, v
     return ctx->sync_if_host();
 }
 extern "C" void zkw_storage_witness_free(zkw_storage_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    delete w;
+}
+
+// ------------------------------------------------------------------------------------------------ code decommitter
+struct zkw_decommitter_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n_requests = 0, total_words = 0, total_rounds = 0, n_instances = 0;
+    zkw_mem_query* mem_q = nullptr;
+    u64 *mem_enc = nullptr, *mem_tails = nullptr;
+    u32* round_states = nullptr;
+    zkw_decommitter_instance* instances = nullptr;
+    void release() {
+        void* ptrs[] = {mem_q, mem_enc, mem_tails, round_states, instances};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+};
+
+extern "C" int zkw_decommitter_build(zkw_ctx* ctx, const zkw_decommit_query* requests, const uint64_t* dedup_tails,
+                                     size_t n_requests, const uint32_t* words, const uint64_t* word_offsets,
+                                     uint32_t capacity, const zkw_queue_state12* mem_in, zkw_decommitter_witness** out) {
+    if (!ctx || !requests || !dedup_tails || !words || !word_offsets || !mem_in || !out || capacity == 0 || n_requests == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_decommitter_build: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint64_t> woff(n_requests + 1), roff(n_requests + 1, 0);
+    for (size_t k = 0; k <= n_requests; k++) woff[k] = word_offsets[k] - word_offsets[0];
+    for (size_t k = 0; k < n_requests; k++) {
+        if (word_offsets[k + 1] <= word_offsets[k]) return fail(ZKW_ERR_INVALID, "request %zu has no bytecode (decommit_code.rs:236)", k);
+        roff[k + 1] = roff[k] + (woff[k + 1] - woff[k] + 1) / 2;
+    }
+    zkw_decommitter_witness* w = new zkw_decommitter_witness();
+    w->ctx = ctx;
+    w->n_requests = n_requests;
+    w->total_words = woff[n_requests];
+    w->total_rounds = roff[n_requests];
+    w->n_instances = (w->total_rounds + capacity - 1) / capacity;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    alloc((void**)&w->mem_q, w->total_words * sizeof(zkw_mem_query));
+    alloc((void**)&w->mem_enc, w->total_words * 64);
+    alloc((void**)&w->mem_tails, w->total_words * 96);
+    alloc((void**)&w->round_states, w->total_rounds * 32);
+    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_decommitter_instance));
+    auto bail = [&](int rc) { w->release(); delete w; return rc; };
+    if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_decommitter_build: hipMalloc failed: %s", hipGetErrorString(e)));
+    const zkw_decommit_query* d_req = nullptr;
+    const u64* d_dt = nullptr;
+    const u32* d_words = nullptr;
+    u64 *d_woff = nullptr, *d_roff = nullptr;
+    u32* d_viol = nullptr;
+    int rc = ctx->in("dcm_req", requests, n_requests, &d_req);
+    if (rc == ZKW_OK) rc = ctx->in("dcm_dt", dedup_tails, n_requests * 12, &d_dt);
+    if (rc == ZKW_OK) rc = ctx->in("dcm_words", words + 8 * word_offsets[0], w->total_words * 8, &d_words);
+    if (rc == ZKW_OK) rc = ctx->upload("dcm_woff", woff, &d_woff);
+    if (rc == ZKW_OK) rc = ctx->upload("dcm_roff", roff, &d_roff);
+    if (rc == ZKW_OK) rc = ctx->scratch_t<u32>("dcm_viol", 1, &d_viol);
+    if (rc != ZKW_OK) return bail(rc);
+    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
+    DecommitterJob job{d_req, d_words, d_woff, d_roff, w->round_states, w->mem_q, w->mem_enc, d_viol, n_requests};
+    { Prof _p(ctx, "k_decommitter_sha"); hipLaunchKernelGGL(k_decommitter_sha, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
+    if ((rc = launch_check("k_decommitter_sha")) != ZKW_OK) return bail(rc);
+    { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(w->total_words, 256)), dim3(256), 0, ctx->stream, job, (u64)w->total_words); }
+    if ((rc = launch_check("k_decommitter_mem_queries")) != ZKW_OK) return bail(rc);
+    zkw_queue_state12* d_min = nullptr;
+    std::vector<zkw_queue_state12> minv(1, *mem_in);
+    if ((rc = ctx->upload("dcm_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
+    std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, w->total_words});
+    if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
+    std::vector<DecommitterBlock> blk(1);
+    blk[0].job = job;
+    blk[0].dedup_tails = d_dt;
+    blk[0].mem_tails = w->mem_tails;
+    blk[0].instances = w->instances;
+    blk[0].mem_in = *mem_in;
+    blk[0].total_rounds = w->total_rounds;
+    blk[0].total_words = w->total_words;
+    blk[0].capacity = capacity;
+    DecommitterBlock* d_blk = nullptr;
+    if ((rc = ctx->upload("dcm_block", blk, &d_blk)) != ZKW_OK) return bail(rc);
+    { Prof _p(ctx, "k_decommitter_instances"); hipLaunchKernelGGL(k_decommitter_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    if ((rc = launch_check("k_decommitter_instances")) != ZKW_OK) return bail(rc);
+    u32 viol = 0;
+    if (hipMemcpyAsync(&viol, d_viol, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return bail(fail(ZKW_ERR_HIP, "readback failed"));
+    if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u bytecodes do not match their decommit request (length parity, word count or "
+                                                     "SHA-256 digest, decommit_code.rs:241-244, 323-337)", viol));
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" size_t zkw_decommitter_witness_num_instances(const zkw_decommitter_witness* w) { return w ? w->n_instances : 0; }
+static const void* dcm_array(const zkw_decommitter_witness* w, int what, size_t* bytes) {
+    switch (what) {
+        case ZKW_DCM_MEM_QUERIES: *bytes = w->total_words * sizeof(zkw_mem_query); return w->mem_q;
+        case ZKW_DCM_MEM_ENC: *bytes = w->total_words * 64; return w->mem_enc;
+        case ZKW_DCM_MEM_TAILS: *bytes = w->total_words * 96; return w->mem_tails;
+        case ZKW_DCM_ROUND_STATES: *bytes = w->total_rounds * 32; return w->round_states;
+        case ZKW_DCM_INSTANCES: *bytes = w->n_instances * sizeof(zkw_decommitter_instance); return w->instances;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_decommitter_witness_bytes(const zkw_decommitter_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)dcm_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness* w, int what) {
+    size_t b = 0;
+    return w ? dcm_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_decommitter_witness_get(const zkw_decommitter_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_decommitter_witness_get: null argument");
+    if (what < 0 || what > ZKW_DCM_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    size_t bytes = 0;
+    const void* src = dcm_array(w, what, &bytes);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_decommitter_witness_free(zkw_decommitter_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);

@@ -76,6 +76,12 @@ SYMBOLS = [
     ("zkw_storage_witness_device_ptr", _vp, [_vp, _int]),
     ("zkw_storage_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_storage_witness_free", None, [_vp]),
+    ("zkw_decommitter_build", _int, [_vp, _vp, _u64p, _sz, _vp, _u64p, _u32, _vp, C.POINTER(_vp)]),
+    ("zkw_decommitter_witness_num_instances", _sz, [_vp]),
+    ("zkw_decommitter_witness_bytes", _sz, [_vp, _int]),
+    ("zkw_decommitter_witness_device_ptr", _vp, [_vp, _int]),
+    ("zkw_decommitter_witness_get", _int, [_vp, _int, _vp, _sz]),
+    ("zkw_decommitter_witness_free", None, [_vp]),
     ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
     ("zkw_trace_free", None, [_vp]),
     ("zkw_trace_num_rows", _sz, [_vp]),
@@ -316,6 +322,55 @@ class StorageWitness:
     def free(self):
         if self.handle:
             load().zkw_storage_witness_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+DECOMMITTER_FSM = np.dtype(
+    [("decommittment_requests_queue_state", QUEUE_STATE12), ("memory_queue_state", QUEUE_STATE12),
+     ("sha256_inner_state", "<u4", (8,)), ("hash_to_compare_against", "<u4", (8,)), ("current_index", "<u4"),
+     ("current_page", "<u4"), ("timestamp", "<u4"), ("num_rounds_left", "<u4"), ("length_in_bits", "<u4"),
+     ("state_get_from_queue", "u1"), ("state_decommit", "u1"), ("finished", "u1"), ("_pad", "u1")])
+DECOMMITTER_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("sorted_requests_queue_initial_state", QUEUE_STATE12),
+     ("memory_queue_initial_state", QUEUE_STATE12), ("memory_queue_final_state", QUEUE_STATE12),
+     ("hidden_fsm_input", DECOMMITTER_FSM), ("hidden_fsm_output", DECOMMITTER_FSM), ("first_round", "<u8"),
+     ("num_rounds", "<u8"), ("first_request", "<u8"), ("num_requests", "<u8"), ("first_word", "<u8"), ("num_words", "<u8")])
+DCM_MEM_QUERIES, DCM_MEM_ENC, DCM_MEM_TAILS, DCM_ROUND_STATES, DCM_INSTANCES = range(5)
+
+
+class DecommitterWitness:
+    """Owner of a zkw_decommitter_witness handle."""
+
+    _DTYPES = {DCM_MEM_QUERIES: MEM_QUERY, DCM_INSTANCES: DECOMMITTER_INSTANCE, DCM_ROUND_STATES: np.dtype("<u4")}
+    _SHAPES = {DCM_MEM_ENC: (-1, 8), DCM_MEM_TAILS: (-1, 12), DCM_ROUND_STATES: (-1, 8)}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = C.c_void_p(None)
+
+    @property
+    def num_instances(self):
+        return load().zkw_decommitter_witness_num_instances(self.handle)
+
+    def get(self, what):
+        lib = load()
+        nbytes = lib.zkw_decommitter_witness_bytes(self.handle, what)
+        dt = self._DTYPES.get(what, np.dtype("<u8"))
+        out = np.zeros(nbytes // dt.itemsize, dt)
+        if nbytes:
+            _check(lib.zkw_decommitter_witness_get(self.handle, what, _np_ptr(out), nbytes))
+        shape = self._SHAPES.get(what)
+        return out.reshape(shape) if shape else out
+
+    def free(self):
+        if self.handle:
+            load().zkw_decommitter_witness_free(self.handle)
             self.handle = C.c_void_p(None)
 
     def __del__(self):
@@ -649,4 +704,17 @@ class Context:
         w = StorageWitness(self)
         _check(load().zkw_storage_sorter_build(self.handle, _np_ptr(q) if q.size else None, q.size, per_circuit_capacity,
                                                C.byref(w.handle)))
+        return w
+
+    def compute_decommitter_circuit_snapshots(self, requests, dedup_tails, words, word_offsets, decommiter_circuit_capacity,
+                                              mem_in):
+        """compute_decommitter_circuit_snapshots (decommit_code.rs:20-439) -> DecommitterWitness."""
+        req = np.ascontiguousarray(requests, dtype=DECOMMIT_QUERY)
+        dt = _u64(dedup_tails)
+        wd = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 8)
+        woff = _u64(word_offsets)
+        mi = np.ascontiguousarray(mem_in, dtype=QUEUE_STATE12)
+        w = DecommitterWitness(self)
+        _check(load().zkw_decommitter_build(self.handle, _np_ptr(req), _np_ptr(dt), req.size, _np_ptr(wd), _np_ptr(woff),
+                                            decommiter_circuit_capacity, _np_ptr(mi), C.byref(w.handle)))
         return w

@@ -262,6 +262,32 @@ const void *zkw_storage_witness_device_ptr(const zkw_storage_witness *w, int wha
 int zkw_storage_witness_get(const zkw_storage_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_storage_witness_free(zkw_storage_witness *w);
 
+/* ---- CodeDecommitter witness builder --------------------------------------------------------------- */
+typedef struct zkw_decommitter_witness zkw_decommitter_witness;
+/* compute_decommitter_circuit_snapshots, src/witness/individual_circuits/decommit_code.rs:20-439.
+   requests / dedup_tails: the deduplicated decommit requests and the deduplicated queue's states (outputs
+   ZKW_DEC_DEDUP_QUERIES / ZKW_DEC_DEDUP_TAILS of zkw_decommit_sorter_build started from an empty queue);
+   words: the bytecodes back to back, 8 little-endian u32 limbs per 32-byte word, request k owning words
+   [word_offsets[k], word_offsets[k+1]) (word_offsets: host, n_requests + 1); capacity = SHA-256 rounds per
+   instance; mem_in (host): state of the global memory queue before the call. The code words become memory
+   writes appended to that queue (ZKW_DCM_MEM_*), which the RAM permutation consumes later.
+   ZKW_ERR_CHECK_FAILED when a bytecode does not hash to its request (decommit_code.rs:323-337). */
+int zkw_decommitter_build(zkw_ctx *ctx, const zkw_decommit_query *requests, const uint64_t *dedup_tails,
+                          size_t n_requests, const uint32_t *words, const uint64_t *word_offsets, uint32_t capacity,
+                          const zkw_queue_state12 *mem_in, zkw_decommitter_witness **out);
+enum {
+    ZKW_DCM_MEM_QUERIES = 0,  /* zkw_mem_query[total_words]     */
+    ZKW_DCM_MEM_ENC = 1,      /* uint64_t[total_words][8]       */
+    ZKW_DCM_MEM_TAILS = 2,    /* uint64_t[total_words][12]      */
+    ZKW_DCM_ROUND_STATES = 3, /* uint32_t[total_rounds][8]: SHA-256 state after every round */
+    ZKW_DCM_INSTANCES = 4     /* zkw_decommitter_instance[ceil(total_rounds/capacity)] */
+};
+size_t zkw_decommitter_witness_num_instances(const zkw_decommitter_witness *w);
+size_t zkw_decommitter_witness_bytes(const zkw_decommitter_witness *w, int what);
+const void *zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness *w, int what);
+int zkw_decommitter_witness_get(const zkw_decommitter_witness *w, int what, void *dst, size_t dst_bytes);
+void zkw_decommitter_witness_free(zkw_decommitter_witness *w);
+
 /* ---- synthesis: filled traces ------------------------------------------------------------------- */
 /* A zkw_trace owns n_slots trace buffers in HBM, each column-major uint64_t[n_cols][n_rows] (n_rows =
    2^20 at production geometry = TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17). It plays the role of

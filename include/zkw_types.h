@@ -255,6 +255,39 @@ typedef struct zkw_storage_sorter_instance {
     uint64_t num_items;
 } zkw_storage_sorter_instance;
 
+/* ---- CodeDecommitter (decommit_code.rs) ------------------------------------------------------------- */
+/* CodeDecommitterFSMInputOutput incl. CodeDecommittmentFSM, src/witness/individual_circuits/decommit_code.rs:
+   172-199 (input), 363-401 (output), internal fields set at :262-277 */
+typedef struct zkw_decommitter_fsm {
+    zkw_queue_state12 decommittment_requests_queue_state;
+    zkw_queue_state12 memory_queue_state;
+    uint32_t sha256_inner_state[8];
+    uint32_t hash_to_compare_against[8]; /* U256 LE limbs; the 4 most significant bytes zeroed */
+    uint32_t current_index;
+    uint32_t current_page;
+    uint32_t timestamp;
+    uint32_t num_rounds_left; /* u16 in the reference */
+    uint32_t length_in_bits;
+    uint8_t state_get_from_queue;
+    uint8_t state_decommit;
+    uint8_t finished;
+    uint8_t _pad;
+} zkw_decommitter_fsm;
+
+/* CodeDecommitterCircuitInstanceWitness, decommit_code.rs:139-420 */
+typedef struct zkw_decommitter_instance {
+    uint32_t start_flag;
+    uint32_t completion_flag;
+    zkw_queue_state12 sorted_requests_queue_initial_state; /* observable_input (first instance only) */
+    zkw_queue_state12 memory_queue_initial_state;          /* observable_input (first instance only) */
+    zkw_queue_state12 memory_queue_final_state;            /* observable_output (last instance only) */
+    zkw_decommitter_fsm hidden_fsm_input;
+    zkw_decommitter_fsm hidden_fsm_output;
+    uint64_t first_round, num_rounds;     /* SHA-256 rounds (cycles) of this instance in the flattened sequence */
+    uint64_t first_request, num_requests; /* requests popped in this instance = sorted_requests_queue_witness */
+    uint64_t first_word, num_words;       /* code words consumed = code_words (flattened) */
+} zkw_decommitter_instance;
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,22 @@ int64_t orc_storage_sorter_build(const zkw_log_query *q, size_t n, uint32_t capa
                                  uint64_t *result_new_tails, uint64_t *n_result, uint64_t *challenges, uint64_t *lhs_z,
                                  uint64_t *rhs_z, zkw_storage_sorter_instance *instances);
 
+/* ---- code decommitter builder, src/witness/individual_circuits/decommit_code.rs:20-439.
+   requests: the deduplicated (fresh) decommit requests in queue order with their deduplicated-queue tails
+   (dedup_tails[k] = queue state after request k, as produced by the decommit sorter from an EMPTY queue);
+   words: all bytecode words back to back (8 LE u32 limbs each), request k owning [word_offsets[k],
+   word_offsets[k+1]); mem_in: state of the global memory queue before the call. Outputs: mem_q / mem_enc /
+   mem_tails (one memory query per word, appended to the memory queue), round_states [total_rounds][8],
+   instances [ceil(total_rounds/capacity)]. Returns the number of instances or <0 (e.g. -5 = a bytecode does
+   not hash to its request, decommit_code.rs:323-337). */
+int64_t orc_decommitter_build(const zkw_decommit_query *requests, const uint64_t *dedup_tails, size_t n_requests,
+                              const uint32_t *words, const uint64_t *word_offsets, uint32_t capacity,
+                              const zkw_queue_state12 *mem_in, zkw_mem_query *mem_q, uint64_t *mem_enc,
+                              uint64_t *mem_tails, uint32_t *round_states, zkw_decommitter_instance *instances);
+/* helper for tests/benches: SHA-256 based versioned hash of a bytecode the way the decommitter checks it:
+   digest of the words (each big-endian) with the 4 most significant bytes replaced by `top4` */
+void orc_bytecode_hash(const uint32_t *words, size_t n_words, uint32_t top_limb, uint32_t hash_out[8]);
+
 #ifdef __cplusplus
 }
 #endif

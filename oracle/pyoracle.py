@@ -86,6 +86,18 @@ STORAGE_INSTANCE = np.dtype(
      ("first_item", "<u8"), ("num_items", "<u8")])
 
 
+DECOMMITTER_FSM = np.dtype(
+    [("decommittment_requests_queue_state", QUEUE_STATE12), ("memory_queue_state", QUEUE_STATE12),
+     ("sha256_inner_state", "<u4", (8,)), ("hash_to_compare_against", "<u4", (8,)), ("current_index", "<u4"),
+     ("current_page", "<u4"), ("timestamp", "<u4"), ("num_rounds_left", "<u4"), ("length_in_bits", "<u4"),
+     ("state_get_from_queue", "u1"), ("state_decommit", "u1"), ("finished", "u1"), ("_pad", "u1")])
+DECOMMITTER_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("sorted_requests_queue_initial_state", QUEUE_STATE12),
+     ("memory_queue_initial_state", QUEUE_STATE12), ("memory_queue_final_state", QUEUE_STATE12),
+     ("hidden_fsm_input", DECOMMITTER_FSM), ("hidden_fsm_output", DECOMMITTER_FSM), ("first_round", "<u8"),
+     ("num_rounds", "<u8"), ("first_request", "<u8"), ("num_requests", "<u8"), ("first_word", "<u8"), ("num_words", "<u8")])
+
+
 def build(force=False):
     """Compile liboracle.so with gcc (building the checker is not using it)."""
     if force or not os.path.exists(_LIB_PATH) or any(
@@ -394,4 +406,34 @@ def storage_sorter_build(q, capacity):
         o[key] = o[key][:n]
     for key in ("result_q", "result_enc", "result_new_tails"):
         o[key] = o[key][:k]
+    return o
+
+
+def bytecode_hash(words):
+    """versioned bytecode hash the decommitter checks: SHA-256 of the big-endian words, top limb = 0x0100<<16 | n_words"""
+    w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 8)
+    out = np.zeros(8, np.uint32)
+    lib().orc_bytecode_hash(_p(w), C.c_size_t(w.shape[0]), C.c_uint32(0x01000000 | w.shape[0]), _p(out))
+    return out
+
+
+def decommitter_build(requests, dedup_tails, words, word_offsets, capacity, mem_in):
+    requests = np.ascontiguousarray(requests, dtype=DECOMMIT_QUERY)
+    dedup_tails = _u64(dedup_tails)
+    words = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 8)
+    woff = _u64(word_offsets)
+    mem_in = np.ascontiguousarray(mem_in, dtype=QUEUE_STATE12)
+    total_words = int(woff[-1] - woff[0])
+    total_rounds = int(sum((int(woff[k + 1] - woff[k]) + 1) // 2 for k in range(requests.size)))
+    n_inst = -(-total_rounds // capacity)
+    o = dict(mem_q=np.zeros(total_words, MEM_QUERY), mem_enc=np.zeros((total_words, 8), np.uint64),
+             mem_tails=np.zeros((total_words, 12), np.uint64), round_states=np.zeros((total_rounds, 8), np.uint32),
+             instances=np.zeros(n_inst, DECOMMITTER_INSTANCE))
+    f = lib().orc_decommitter_build
+    f.restype = C.c_int64
+    rc = f(_p(requests), _p(dedup_tails), C.c_size_t(requests.size), _p(words), _p(woff), C.c_uint32(capacity), _p(mem_in),
+           _p(o["mem_q"]), _p(o["mem_enc"]), _p(o["mem_tails"]), _p(o["round_states"]), _p(o["instances"]))
+    if rc < 0:
+        raise RuntimeError(f"orc_decommitter_build failed: {rc}")
+    o["instances"] = o["instances"][:rc]
     return o

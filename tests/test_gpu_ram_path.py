@@ -380,3 +380,34 @@ def test_storage_sorter_empty_and_inconsistent(ctx, oracle):
     with pytest.raises(nv.ZkwError) as ei:
         ctx.compute_storage_dedup_and_sort(q, 16)
     assert ei.value.code == nv.ERR_CHECK_FAILED
+
+
+@pytest.mark.parametrize("n_req,capacity", [(1, 4), (5, 7), (40, 16), (3, 2845), (9, 1), (300, 64)])
+def test_decommitter(ctx, oracle, n_req, capacity):
+    from era_zkevm_test_harness_amd import native as nv
+    from tests.test_oracle_ram import _bytecodes
+
+    req, tails, words, woff = _bytecodes(oracle, n_req, seed=n_req + 5)
+    mem_in = np.zeros(1, oracle.QUEUE_STATE12)
+    mem_in["tail"] = synthetic.random_field_elements(9, (12,))
+    mem_in["length"] = 77
+    w = ctx.compute_decommitter_circuit_snapshots(req, tails, words, woff, capacity, mem_in)
+    o = oracle.decommitter_build(req, tails, words, woff, capacity, mem_in)
+    for what, key in ((nv.DCM_MEM_QUERIES, "mem_q"), (nv.DCM_MEM_ENC, "mem_enc"), (nv.DCM_MEM_TAILS, "mem_tails"),
+                      (nv.DCM_ROUND_STATES, "round_states")):
+        assert np.array_equal(w.get(what), o[key]), key
+    gi = w.get(nv.DCM_INSTANCES)
+    assert gi.size == o["instances"].size
+    for a, b in zip(gi, o["instances"]):
+        for f in a.dtype.names:
+            if a[f].dtype.names:
+                for g in a[f].dtype.names:
+                    assert a[f][g].tobytes() == b[f][g].tobytes(), (f, g)
+            else:
+                assert a[f].tobytes() == b[f].tobytes(), f
+    w.free()
+    bad = words.copy()
+    bad[-1, 3] ^= 0x10
+    with pytest.raises(nv.ZkwError) as ei:
+        ctx.compute_decommitter_circuit_snapshots(req, tails, bad, woff, capacity, mem_in)
+    assert ei.value.code == nv.ERR_CHECK_FAILED

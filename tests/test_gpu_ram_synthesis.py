@@ -147,3 +147,19 @@ def test_production_geometry(ctx):
         assert np.array_equal(bout[30:33].astype(np.uint32), fo["previous_sorting_key"])
     t.free()
     w.free()
+
+
+def test_baseline_config0_ram_2pow16(ctx, oracle):
+    """BASELINE.json configs[0] on the GPU: 2^16-row RAMPermutation trace bit-exact vs the CPU-only run."""
+    from era_zkevm_test_harness_amd import native
+
+    capacity, n_rows = 8192, 1 << 16
+    q = synthetic.ram_trace(capacity, seed=1)
+    w = ctx.compute_ram_circuit_snapshots(q, capacity, 0)
+    o = oracle.ram_build_instances(q, capacity, 0)
+    t = native.Trace(ctx, n_rows, 1)
+    ctx.synthesize_ram(w, t)
+    assert np.array_equal(t.get(0), oracle.ram_synthesize(o, 0, capacity, n_rows))
+    assert ctx.check_if_satisfied_ram(t, 0, capacity)[0] == 0
+    t.free()
+    w.free()

@@ -326,3 +326,59 @@ def test_storage_sorter_oracle(oracle, n, cells, capacity):
             assert a[f].tobytes() == b[f].tobytes(), f
     dummy = oracle.storage_sorter_build(np.zeros(0, oracle.LOG_QUERY), 8)["instances"]
     assert dummy.size == 1 and dummy[0]["hidden_fsm_output"]["cycle_idx"] == 4
+
+
+def _bytecodes(oracle, n_req, seed, max_words=41):
+    """n_req fresh decommit requests with random bytecodes of odd length, hashes computed the decommitter's way,
+    and the deduplicated queue's tails (queue started empty)."""
+    r = synthetic.splitmix64(seed, n_req)
+    lens = [1 + 2 * int(x % np.uint64((max_words + 1) // 2)) for x in r]
+    woff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    words = (synthetic.splitmix64(seed + 1, 4 * int(woff[-1])).view(np.uint32)).reshape(-1, 8).copy()
+    req = np.zeros(n_req, oracle.DECOMMIT_QUERY)
+    for k in range(n_req):
+        req["hash"][k] = oracle.bytecode_hash(words[int(woff[k]):int(woff[k + 1])])
+    req["timestamp"] = 5 + 2 * np.arange(n_req)
+    req["memory_page"] = 16 + 8 * np.arange(n_req)
+    req["is_fresh"] = 1
+    req["decommitted_length"] = np.array(lens, np.uint16)
+    tails = oracle.queue_push_chain_full(oracle.encode_decommit_queries(req))
+    return req, tails, words, woff
+
+
+@pytest.mark.parametrize("n_req,capacity", [(1, 4), (5, 7), (12, 16), (3, 1000), (9, 1)])
+def test_decommitter_oracle(oracle, n_req, capacity):
+    import hashlib
+
+    req, tails, words, woff = _bytecodes(oracle, n_req, seed=n_req)
+    # the versioned hash really is SHA-256 of the big-endian words (public algorithm check)
+    k = n_req - 1
+    code = b"".join(int(x).to_bytes(4, "big") for w in words[int(woff[k]):int(woff[k + 1])] for x in w[::-1])
+    dig = hashlib.sha256(code).digest()
+    assert b"".join(int(x).to_bytes(4, "big") for x in req["hash"][k][::-1])[4:] == dig[4:]
+    mem_in = np.zeros(1, oracle.QUEUE_STATE12)
+    mem_in["tail"] = synthetic.random_field_elements(9, (12,))
+    mem_in["length"] = 1234
+    o = oracle.decommitter_build(req, tails, words, woff, capacity, mem_in)
+    total_rounds = sum((int(woff[i + 1] - woff[i]) + 1) // 2 for i in range(n_req))
+    inst = o["instances"]
+    assert inst.size == -(-total_rounds // capacity)
+    assert inst[0]["start_flag"] == 1 and inst[-1]["completion_flag"] == 1 and inst["completion_flag"].sum() == 1
+    assert int(inst["num_rounds"].sum()) == total_rounds and int(inst["num_words"].sum()) == int(woff[-1])
+    assert int(inst["num_requests"].sum()) == n_req
+    fo = inst[-1]["hidden_fsm_output"]
+    assert fo["finished"] == 1 and fo["num_rounds_left"] == 0
+    assert int(fo["memory_queue_state"]["length"]) == 1234 + int(woff[-1])
+    assert np.array_equal(fo["memory_queue_state"]["tail"], o["mem_tails"][-1])
+    assert inst[-1]["memory_queue_final_state"].tobytes() == fo["memory_queue_state"].tobytes()
+    assert fo["decommittment_requests_queue_state"]["length"] == 0
+    assert np.array_equal(fo["decommittment_requests_queue_state"]["head"], fo["decommittment_requests_queue_state"]["tail"])
+    for i in range(inst.size - 1):
+        a, b = inst[i]["hidden_fsm_output"], inst[i + 1]["hidden_fsm_input"]
+        assert a.tobytes() == b.tobytes()
+    assert np.array_equal(o["mem_q"]["page"][: int(woff[1])], np.full(int(woff[1]), 16))
+    assert np.array_equal(o["mem_q"]["index"][: int(woff[1])], np.arange(int(woff[1])))
+    bad = words.copy()
+    bad[0, 0] ^= 1
+    with pytest.raises(RuntimeError):
+        oracle.decommitter_build(req, tails, bad, woff, capacity, mem_in)

@@ -92,3 +92,18 @@ def test_invalid_memory_is_rejected(oracle):
     o = oracle.ram_build_instances(q, capacity, 0)
     with pytest.raises(RuntimeError):
         oracle.ram_synthesize(o, 0, capacity, 512)
+
+
+def test_baseline_config0_ram_2pow16_cpu_only(oracle):
+    """BASELINE.json configs[0]: RAMPermutation base circuit, 2^16 rows, CPU-only synthesize. Capacity 8 192
+    (SURVEY section 8d), seeded trace; witness + synthesis + satisfiability on the oracle alone."""
+    capacity, n_rows = 8192, 1 << 16
+    q = synthetic.ram_trace(capacity, seed=1)
+    o = oracle.ram_build_instances(q, capacity, 0)
+    assert o["instances"].size == 1
+    t = oracle.ram_synthesize(o, 0, capacity, n_rows)
+    bad, first = oracle.ram_check(t, capacity)
+    assert bad == 0, first
+    assert t.shape == (149, n_rows) and int(t[148].sum()) == 15 * n_rows
+    fo = o["instances"][0]["hidden_fsm_output"]
+    assert np.array_equal(fo["lhs_accumulator"], fo["rhs_accumulator"])
