@@ -181,4 +181,75 @@ __global__ void k_decommitter_instances(const DecommitterBlock* __restrict__ blk
     b.instances[idx] = w;
 }
 
+// ------------------------------------------------------------------------------------------------
+// L1 messages hasher (compute_linear_keccak256, data_hasher_and_merklizer.rs:8-67): one Keccak-256 sponge
+// over n * 88 bytes. The sponge is serial; one wave runs it with lane x+5y holding lane (x, y) of the state
+// (theta / rho-pi / chi through ds_bpermute-free LDS-less shuffles), the message bytes are produced on the fly.
+__constant__ u64 c_keccak_rc[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+    0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+    0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+__constant__ int c_keccak_rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+
+__device__ __forceinline__ u64 rol64(u64 x, int r) { return r ? (x << r) | (x >> (64 - r)) : x; }
+
+// byte `pos` of the concatenated serialisations (log_query.rs:503-534)
+__device__ __forceinline__ u32 l1_message_byte(const zkw_log_query* q, size_t pos) {
+    const zkw_log_query* m = q + pos / 88;
+    const int o = (int)(pos % 88);
+    if (o == 0) return m->shard_id;
+    if (o == 1) return m->is_service ? 1 : 0;
+    if (o == 2) return m->tx_number_in_block >> 8;
+    if (o == 3) return m->tx_number_in_block & 0xFF;
+    if (o < 24) { const int b = 19 - (o - 4); return (m->address[b >> 2] >> (8 * (b & 3))) & 0xFF; }       // big-endian
+    if (o < 56) { const int b = 31 - (o - 24); return (m->key[b >> 2] >> (8 * (b & 3))) & 0xFF; }
+    const int b = 31 - (o - 56);
+    return (m->written_value[b >> 2] >> (8 * (b & 3))) & 0xFF;
+}
+
+__global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_query* __restrict__ q, size_t n, uint8_t* __restrict__ out) {
+    __shared__ u64 A[25], Bm[25], Cc[5];
+    const int t = threadIdx.x;
+    const size_t len = n * 88;
+    if (t < 25) A[t] = 0;
+    __syncthreads();
+    for (size_t off = 0;; off += 136) {
+        const bool last = len - off < 136;  // the final (padded) block; len % 136 == 0 gives a pure padding block
+        if (t < 17) {
+            u64 lane = 0;
+            for (int b = 0; b < 8; b++) {
+                const size_t pos = off + 8 * t + b;
+                u32 byte = pos < len ? l1_message_byte(q, pos) : 0;
+                if (last && pos == len) byte ^= 0x01;
+                if (last && 8 * t + b == 135) byte ^= 0x80;
+                lane |= (u64)byte << (8 * b);
+            }
+            A[t] ^= lane;
+        }
+        __syncthreads();
+        for (int round = 0; round < 24; round++) {
+            if (t < 5) Cc[t] = A[t] ^ A[t + 5] ^ A[t + 10] ^ A[t + 15] ^ A[t + 20];
+            __syncthreads();
+            if (t < 25) {
+                const int x = t % 5, y = t / 5;
+                const u64 d = Cc[(x + 4) % 5] ^ rol64(Cc[(x + 1) % 5], 1);
+                Bm[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(A[t] ^ d, c_keccak_rot[t]);
+            }
+            __syncthreads();
+            if (t < 25) {
+                const int x = t % 5, y = t / 5;
+                u64 v = Bm[t] ^ (~Bm[(x + 1) % 5 + 5 * y] & Bm[(x + 2) % 5 + 5 * y]);
+                if (t == 0) v ^= c_keccak_rc[round];
+                A[t] = v;
+            }
+            __syncthreads();
+        }
+        if (last) break;
+    }
+    if (t < 32) out[t] = (uint8_t)(A[t >> 3] >> (8 * (t & 7)));
+}
+
 }  // namespace zkw

@@ -1840,3 +1840,17 @@ extern "C" void zkw_decommitter_witness_free(zkw_decommitter_witness* w) {
     w->release();
     delete w;
 }
+
+// ------------------------------------------------------------------------------------------------ L1 messages hasher
+extern "C" int zkw_linear_keccak256(zkw_ctx* ctx, const zkw_log_query* messages, size_t n, uint8_t* hash_out) {
+    if (!ctx || !hash_out || (n && !messages)) return fail(ZKW_ERR_INVALID, "zkw_linear_keccak256: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const zkw_log_query* d_q = nullptr;
+    uint8_t* d_out = nullptr;
+    ZKW_TRY(ctx->in("lk_q", messages, n, &d_q));
+    ZKW_TRY(ctx->out("lk_out", hash_out, 32, &d_out));
+    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out); }
+    ZKW_TRY(launch_check("k_linear_keccak256"));
+    ZKW_TRY(ctx->finish_out(hash_out, d_out, 32));
+    return ctx->sync_if_host();
+}

@@ -82,6 +82,7 @@ SYMBOLS = [
     ("zkw_decommitter_witness_device_ptr", _vp, [_vp, _int]),
     ("zkw_decommitter_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_decommitter_witness_free", None, [_vp]),
+    ("zkw_linear_keccak256", _int, [_vp, _vp, _sz, _vp]),
     ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
     ("zkw_trace_free", None, [_vp]),
     ("zkw_trace_num_rows", _sz, [_vp]),
@@ -718,3 +719,10 @@ class Context:
         _check(load().zkw_decommitter_build(self.handle, _np_ptr(req), _np_ptr(dt), req.size, _np_ptr(wd), _np_ptr(woff),
                                             decommiter_circuit_capacity, _np_ptr(mi), C.byref(w.handle)))
         return w
+
+    def compute_linear_keccak256(self, messages) -> bytes:
+        """compute_linear_keccak256 (data_hasher_and_merklizer.rs:8-67): the pubdata hash of the L2->L1 messages."""
+        q = np.ascontiguousarray(messages, dtype=LOG_QUERY)
+        out = np.zeros(32, np.uint8)
+        _check(load().zkw_linear_keccak256(self.handle, _np_ptr(q) if q.size else None, q.size, _np_ptr(out)))
+        return out.tobytes()

@@ -288,6 +288,13 @@ const void *zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness *w,
 int zkw_decommitter_witness_get(const zkw_decommitter_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_decommitter_witness_free(zkw_decommitter_witness *w);
 
+/* ---- L1 messages hasher ------------------------------------------------------------------------------ */
+/* compute_linear_keccak256, src/witness/individual_circuits/data_hasher_and_merklizer.rs:8-67: Keccak-256 of
+   the concatenated 88-byte serialisations (circuit_encodings/src/log_query.rs:503-534) of the net L2->L1
+   messages (ZKW_EVT_RESULT_QUERIES of the L1-messages sorter). hash_out: 32 bytes (host, or device in
+   ZKW_PTR_DEVICE mode). The instance's queue witness/state is the sorter's result queue itself. */
+int zkw_linear_keccak256(zkw_ctx *ctx, const zkw_log_query *messages, size_t n, uint8_t *hash_out);
+
 /* ---- synthesis: filled traces ------------------------------------------------------------------- */
 /* A zkw_trace owns n_slots trace buffers in HBM, each column-major uint64_t[n_cols][n_rows] (n_rows =
    2^20 at production geometry = TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17). It plays the role of

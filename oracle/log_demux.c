@@ -87,3 +87,24 @@ int64_t orc_log_demux_build(const zkw_log_query *q, size_t n, uint32_t capacity,
         if (filled[k] != cnt[k]) return -4;
     return (int64_t)num_chunks;
 }
+
+/* ---- linear hasher (data_hasher_and_merklizer.rs:8-67) */
+void orc_keccak256(const uint8_t *msg, size_t len, uint8_t out[32]);
+
+void orc_serialize_l1_message(const zkw_log_query *q, uint8_t out[88]) {
+    int o = 0;
+    out[o++] = q->shard_id;
+    out[o++] = q->is_service ? 1 : 0;
+    out[o++] = (uint8_t)(q->tx_number_in_block >> 8);
+    out[o++] = (uint8_t)q->tx_number_in_block;
+    for (int k = 4; k >= 0; k--) { uint32_t l = q->address[k]; out[o++] = (uint8_t)(l >> 24); out[o++] = (uint8_t)(l >> 16); out[o++] = (uint8_t)(l >> 8); out[o++] = (uint8_t)l; }
+    for (int k = 7; k >= 0; k--) { uint32_t l = q->key[k]; out[o++] = (uint8_t)(l >> 24); out[o++] = (uint8_t)(l >> 16); out[o++] = (uint8_t)(l >> 8); out[o++] = (uint8_t)l; }
+    for (int k = 7; k >= 0; k--) { uint32_t l = q->written_value[k]; out[o++] = (uint8_t)(l >> 24); out[o++] = (uint8_t)(l >> 16); out[o++] = (uint8_t)(l >> 8); out[o++] = (uint8_t)l; }
+}
+
+void orc_linear_keccak256(const zkw_log_query *q, size_t n, uint8_t hash_out[32]) {
+    uint8_t *buf = (uint8_t *)malloc(n * 88 + 1);
+    for (size_t i = 0; i < n; i++) orc_serialize_l1_message(q + i, buf + 88 * i);
+    orc_keccak256(buf, n * 88, hash_out);
+    free(buf);
+}

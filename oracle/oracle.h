@@ -152,6 +152,12 @@ int64_t orc_decommitter_build(const zkw_decommit_query *requests, const uint64_t
    digest of the words (each big-endian) with the 4 most significant bytes replaced by `top4` */
 void orc_bytecode_hash(const uint32_t *words, size_t n_words, uint32_t top_limb, uint32_t hash_out[8]);
 
+/* ---- L1 messages hasher, src/witness/individual_circuits/data_hasher_and_merklizer.rs:8-67:
+   Keccak256 over the concatenated 88-byte serialisations (circuit_encodings/src/log_query.rs:503-534:
+   shard | is_service | tx_number BE u16 | address 20 BE | key 32 BE | written_value 32 BE) */
+void orc_serialize_l1_message(const zkw_log_query *q, uint8_t out[88]);
+void orc_linear_keccak256(const zkw_log_query *q, size_t n, uint8_t hash_out[32]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -437,3 +437,17 @@ def decommitter_build(requests, dedup_tails, words, word_offsets, capacity, mem_
         raise RuntimeError(f"orc_decommitter_build failed: {rc}")
     o["instances"] = o["instances"][:rc]
     return o
+
+
+def linear_keccak256(q) -> bytes:
+    q = np.ascontiguousarray(q, dtype=LOG_QUERY)
+    out = C.create_string_buffer(32)
+    lib().orc_linear_keccak256(_p(q), C.c_size_t(q.size), out)
+    return out.raw
+
+
+def serialize_l1_message(q) -> bytes:
+    q = np.ascontiguousarray(q, dtype=LOG_QUERY).reshape(1)
+    out = C.create_string_buffer(88)
+    lib().orc_serialize_l1_message(_p(q), out)
+    return out.raw

@@ -411,3 +411,10 @@ def test_decommitter(ctx, oracle, n_req, capacity):
     with pytest.raises(nv.ZkwError) as ei:
         ctx.compute_decommitter_circuit_snapshots(req, tails, bad, woff, capacity, mem_in)
     assert ei.value.code == nv.ERR_CHECK_FAILED
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 17, 31, 774])
+def test_linear_hasher(ctx, oracle, n):
+    # n = 17: 17 * 88 = 1496 = 11 * 136 bytes -> a pure padding block; n = 774: production capacity
+    q = synthetic.random_log_queries(max(n, 1), seed=n + 2)[:n]
+    assert ctx.compute_linear_keccak256(q) == oracle.linear_keccak256(q)

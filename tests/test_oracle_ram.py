@@ -382,3 +382,17 @@ def test_decommitter_oracle(oracle, n_req, capacity):
     bad[0, 0] ^= 1
     with pytest.raises(RuntimeError):
         oracle.decommitter_build(req, tails, bad, woff, capacity, mem_in)
+
+
+def test_linear_hasher_oracle(oracle):
+    q = synthetic.random_log_queries(5, seed=2)
+    ser = oracle.serialize_l1_message(q[0])
+    r = q[0]
+    exp = bytes([int(r["shard_id"]), int(r["is_service"])]) + int(r["tx_number_in_block"]).to_bytes(2, "big")
+    exp += b"".join(int(x).to_bytes(4, "big") for x in r["address"][::-1])
+    exp += b"".join(int(x).to_bytes(4, "big") for x in r["key"][::-1])
+    exp += b"".join(int(x).to_bytes(4, "big") for x in r["written_value"][::-1])
+    assert ser == exp and len(ser) == 88
+    full = b"".join(oracle.serialize_l1_message(x) for x in q)
+    assert oracle.linear_keccak256(q) == oracle.keccak256(full)
+    assert oracle.linear_keccak256(q[:0]) == oracle.keccak256(b"")
