@@ -1,0 +1,111 @@
+// public_input_kernels.cuh — closed-form input commitments and the recursion queue.
+//
+// Reference functions replaced:
+//   k_commit_encodings   commit_variable_length_encodable_item, as driven by
+//                        simulate_public_input_value_from_witness         src/witness/utils.rs:269-306
+//   k_ram_commitments    ClosedFormInputCompactForm::from_full_form for RamPermutationInputOutput
+//                        (+ the shared observable input)                  src/witness/postprocessing/mod.rs:353-369
+//   k_encode_recursion   RecursionRequest::encoding_witness               circuit_encodings/src/recursion_request.rs:13-28
+//
+// Every commitment is a short serial sponge (<= 9 permutations), so the parallel axis is (instance, part):
+// one lane each, the three non-trivial parts of an instance in adjacent lanes.
+#pragma once
+#include "../../include/zkw_types.h"
+#include "poseidon2.cuh"
+
+namespace zkw {
+using gl::u32;
+using gl::u64;
+
+constexpr int RAM_INPUT_ENC_LEN = 51;
+constexpr int RAM_FSM_ENC_LEN = 69;
+constexpr int COMPACT_FORM_LEN = 18;
+
+// sponge in overwrite mode from the zero state, length in the last capacity word, last chunk zero padded
+__device__ inline void commit_var_length(const u64* enc, int n, u64 out[4]) {
+    u64 s[12];
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    s[11] = (u64)n;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        for (int k = 0; k < 8; k++) s[k] = enc[i + k];
+        p2::permute(s);
+    }
+    if (i < n) {
+        for (int k = 0; k < 8; k++) s[k] = (i + k < n) ? enc[i + k] : 0;
+        p2::permute(s);
+    }
+    for (int k = 0; k < 4; k++) out[k] = gl::canon(s[k]);
+}
+
+__global__ __launch_bounds__(64) void k_commit_encodings(const u64* __restrict__ enc, size_t n_items, u32 item_len,
+                                                         u64* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    u64 c[4];
+    commit_var_length(enc + (size_t)item_len * i, (int)item_len, c);
+    for (int k = 0; k < 4; k++) out[4 * i + k] = c[k];
+}
+
+__device__ inline int put_queue12(const zkw_queue_state12& q, u64* o) {
+    for (int k = 0; k < 12; k++) { o[k] = q.head[k]; o[12 + k] = q.tail[k]; }
+    o[24] = q.length;
+    return 25;
+}
+
+__device__ inline int ram_encode_fsm(const zkw_ram_fsm& f, u64* o) {
+    int m = 0;
+    for (int r = 0; r < 2; r++) o[m++] = f.lhs_accumulator[r];
+    for (int r = 0; r < 2; r++) o[m++] = f.rhs_accumulator[r];
+    m += put_queue12(f.current_unsorted_queue_state, o + m);
+    m += put_queue12(f.current_sorted_queue_state, o + m);
+    for (int k = 0; k < 3; k++) o[m++] = f.previous_sorting_key[k];
+    for (int k = 0; k < 2; k++) o[m++] = f.previous_full_key[k];
+    for (int k = 0; k < 8; k++) o[m++] = f.previous_value[k];
+    o[m++] = f.previous_is_ptr ? 1 : 0;
+    o[m++] = f.num_nondeterministic_writes;
+    return m;
+}
+
+// lane = 4 * instance + part; part 0: observable input of the block's FIRST instance, 1: flags + empty output,
+// 2: hidden FSM input, 3: hidden FSM output
+__global__ __launch_bounds__(64) void k_ram_commitments(const zkw_ram_instance* __restrict__ inst, size_t n,
+                                                        u64* __restrict__ compact) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = t >> 2;
+    const int part = (int)(t & 3);
+    if (i >= n) return;
+    u64* cf = compact + COMPACT_FORM_LEN * i;
+    u64 buf[RAM_FSM_ENC_LEN];
+    u64 c[4];
+    if (part == 1) {
+        cf[0] = inst[i].start_flag ? 1 : 0;
+        cf[1] = inst[i].completion_flag ? 1 : 0;
+        for (int k = 0; k < 4; k++) cf[6 + k] = 0;  // observable output is (): nothing absorbed
+        return;
+    }
+    int m;
+    if (part == 0) {
+        size_t j = i;
+        while (j > 0 && !inst[j].start_flag) j--;
+        m = put_queue12(inst[j].unsorted_queue_initial_state, buf);
+        m += put_queue12(inst[j].sorted_queue_initial_state, buf + m);
+        buf[m++] = inst[j].non_deterministic_bootloader_memory_snapshot_length;
+    } else {
+        m = ram_encode_fsm(part == 2 ? inst[i].hidden_fsm_input : inst[i].hidden_fsm_output, buf);
+    }
+    commit_var_length(buf, m, c);
+    const int at = part == 0 ? 2 : (part == 2 ? 10 : 14);
+    for (int k = 0; k < 4; k++) cf[at + k] = c[k];
+}
+
+__global__ __launch_bounds__(64) void k_encode_recursion(u64 circuit_type, const u64* __restrict__ pi, size_t n,
+                                                         u64* __restrict__ enc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    enc[8 * i] = circuit_type;
+    for (int k = 0; k < 4; k++) enc[8 * i + 1 + k] = pi[4 * i + k];
+    for (int k = 5; k < 8; k++) enc[8 * i + k] = 0;
+}
+
+}  // namespace zkw

@@ -30,6 +30,7 @@ struct SynthJob {
     u64* trace;             // [RC_COLS][n_rows]
     u32* hist;              // [256] lookup-value histogram of this trace (zeroed before the fills)
     u32* nd_tiles;          // [ceil(capacity/256)] exclusive prefix of nondeterministic writes per 256-cycle tile
+    const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ram_commitments)
 };
 
 constexpr int ROW_SLOTS[RC_NUM_ROW_TYPES] = RC_ROW_NUM_SLOTS_INIT;
@@ -524,6 +525,7 @@ __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __rest
     TR(RC_BND_OUT_cnt, bout) = TR(RC_C_cnt, (size_t)RC_ROW_C * capacity + capacity - 1);
     TR(RC_BND_OUT_completion, bout) = in->completion_flag ? 1 : 0;
     TR(RC_BND_OUT_w_end, bout) = inv_or_zero(len_out); TR(RC_BND_OUT_z_end, bout) = len_out == 0;
+    for (int k = 0; k < 4; k++) TR(RC_PI_pi0 + k, bin - RC_ROWOFF_BND_IN + RC_ROWOFF_PI) = job.public_input[k];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -22,6 +22,7 @@
 #include "demux_kernels.cuh"
 #include "storage_kernels.cuh"
 #include "decommitter_kernels.cuh"
+#include "public_input_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -586,16 +587,18 @@ struct zkw_ram_witness {
     u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
     zkw_ram_instance* instances = nullptr;
     u32* nondet_counts = nullptr;
+    u64 *compact_forms = nullptr, *public_inputs = nullptr;  // [n_instances][18], [n_instances][4]
 
     void release() {
         void* ptrs[] = {sorted_q, unsorted_enc, sorted_enc, unsorted_tails, sorted_tails, challenges,
-                        lhs_z,    rhs_z,        instances,  nondet_counts};
+                        lhs_z,    rhs_z,        instances,  nondet_counts, compact_forms, public_inputs};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         sorted_q = nullptr;
         unsorted_enc = sorted_enc = unsorted_tails = sorted_tails = challenges = lhs_z = rhs_z = nullptr;
         instances = nullptr;
         nondet_counts = nullptr;
+        compact_forms = public_inputs = nullptr;
     }
 };
 
@@ -611,6 +614,8 @@ static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
     HIP_TRY(hipMalloc((void**)&w->rhs_z, (t + 1) * 2 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->instances, (ni + 1) * sizeof(zkw_ram_instance)));
     HIP_TRY(hipMalloc((void**)&w->nondet_counts, (ni + 1) * sizeof(u32)));
+    HIP_TRY(hipMalloc((void**)&w->compact_forms, (ni + 1) * COMPACT_FORM_LEN * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->public_inputs, (ni + 1) * 4 * sizeof(u64)));
     return ZKW_OK;
 }
 
@@ -731,7 +736,13 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     ZKW_TRY(launch_check("k_ram_count_nondet"));
     { Prof _p(ctx, "k_ram_instances"); hipLaunchKernelGGL(k_ram_instances, dim3(blocks_for(max_inst, 64), (unsigned)n_blocks), dim3(64), 0, ctx->stream,
                        d_blocks); }
-    return launch_check("k_ram_instances");
+    ZKW_TRY(launch_check("k_ram_instances"));
+    // a20: compact forms and public inputs of every instance (postprocessing/mod.rs:353-369)
+    const size_t ni = w->n_instances;
+    { Prof _p(ctx, "k_ram_commitments"); hipLaunchKernelGGL(k_ram_commitments, dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, w->instances, ni, w->compact_forms); }
+    ZKW_TRY(launch_check("k_ram_commitments"));
+    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, w->compact_forms, ni, (u32)COMPACT_FORM_LEN, w->public_inputs); }
+    return launch_check("k_commit_encodings");
 }
 
 extern "C" int zkw_ram_build_instances_batch(zkw_ctx* ctx, const zkw_mem_query* q, const uint64_t* block_offsets,
@@ -809,6 +820,8 @@ static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes) 
         case ZKW_RAM_LHS_Z: *bytes = t * 16; return w->lhs_z;
         case ZKW_RAM_RHS_Z: *bytes = t * 16; return w->rhs_z;
         case ZKW_RAM_INSTANCES: *bytes = w->n_instances * sizeof(zkw_ram_instance); return w->instances;
+        case ZKW_RAM_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->compact_forms;
+        case ZKW_RAM_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->public_inputs;
         default: *bytes = 0; return nullptr;
     }
 }
@@ -935,6 +948,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + 256 * k;
         j.nd_tiles = d_nd + (size_t)n_tiles * k;
+        j.public_input = w->public_inputs + 4 * idx;
     }
     SynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("synth_jobs", jobs, &d_jobs));
@@ -1852,5 +1866,35 @@ extern "C" int zkw_linear_keccak256(zkw_ctx* ctx, const zkw_log_query* messages,
     { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out); }
     ZKW_TRY(launch_check("k_linear_keccak256"));
     ZKW_TRY(ctx->finish_out(hash_out, d_out, 32));
+    return ctx->sync_if_host();
+}
+
+// ------------------------------------------------------------------------------------------------ public inputs (a20)
+extern "C" int zkw_commit_encodings(zkw_ctx* ctx, const uint64_t* enc, size_t n_items, uint32_t item_len, uint64_t* out) {
+    if (!ctx || !out || (n_items && item_len && !enc)) return fail(ZKW_ERR_INVALID, "zkw_commit_encodings: null argument");
+    if (n_items == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64* d_enc = nullptr;
+    u64* d_out = nullptr;
+    ZKW_TRY(ctx->in("ce_enc", enc, n_items * item_len + 1, &d_enc));
+    ZKW_TRY(ctx->out("ce_out", out, n_items * 4, &d_out));
+    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, d_enc, n_items, item_len, d_out); }
+    ZKW_TRY(launch_check("k_commit_encodings"));
+    ZKW_TRY(ctx->finish_out(out, d_out, n_items * 4));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_encode_recursion_requests(zkw_ctx* ctx, uint64_t circuit_type, const uint64_t* public_inputs, size_t n,
+                                             uint64_t* enc) {
+    if (!ctx || !enc || !public_inputs) return fail(ZKW_ERR_INVALID, "zkw_encode_recursion_requests: null argument");
+    if (n == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64* d_pi = nullptr;
+    u64* d_enc = nullptr;
+    ZKW_TRY(ctx->in("rr_pi", public_inputs, n * 4, &d_pi));
+    ZKW_TRY(ctx->out("rr_enc", enc, n * 8, &d_enc));
+    { Prof _p(ctx, "k_encode_recursion"); hipLaunchKernelGGL(k_encode_recursion, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, circuit_type, d_pi, n, d_enc); }
+    ZKW_TRY(launch_check("k_encode_recursion"));
+    ZKW_TRY(ctx->finish_out(enc, d_enc, n * 8));
     return ctx->sync_if_host();
 }

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libzkw.so")
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_CHECK_FAILED = 0, -1, -2, -3, -4, -5
 PTR_HOST, PTR_DEVICE = 0, 1
 (RAM_SORTED_QUERIES, RAM_UNSORTED_ENC, RAM_SORTED_ENC, RAM_UNSORTED_TAILS, RAM_SORTED_TAILS, RAM_CHALLENGES,
- RAM_LHS_Z, RAM_RHS_Z, RAM_INSTANCES) = range(9)
+ RAM_LHS_Z, RAM_RHS_Z, RAM_INSTANCES, RAM_COMPACT_FORMS, RAM_PUBLIC_INPUTS) = range(11)
 
 # every symbol include/zkw.h declares: (name, restype, argtypes)
 _vp, _sz, _u32, _u64p, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_int
@@ -83,6 +83,8 @@ SYMBOLS = [
     ("zkw_decommitter_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_decommitter_witness_free", None, [_vp]),
     ("zkw_linear_keccak256", _int, [_vp, _vp, _sz, _vp]),
+    ("zkw_commit_encodings", _int, [_vp, _vp, _sz, C.c_uint32, _vp]),
+    ("zkw_encode_recursion_requests", _int, [_vp, C.c_uint64, _vp, _sz, _vp]),
     ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
     ("zkw_trace_free", None, [_vp]),
     ("zkw_trace_num_rows", _sz, [_vp]),
@@ -459,7 +461,8 @@ class RamWitness:
             self.ctx.set_pointer_mode(mode)
         t = self.num_items
         shape = {RAM_UNSORTED_ENC: (t, 8), RAM_SORTED_ENC: (t, 8), RAM_UNSORTED_TAILS: (t, 12),
-                 RAM_SORTED_TAILS: (t, 12), RAM_CHALLENGES: (-1, 2, 9)}.get(what)
+                 RAM_SORTED_TAILS: (t, 12), RAM_CHALLENGES: (-1, 2, 9), RAM_COMPACT_FORMS: (-1, 18),
+                 RAM_PUBLIC_INPUTS: (-1, 4)}.get(what)
         return out.reshape(shape) if shape else out
 
     def free(self):
@@ -726,3 +729,22 @@ class Context:
         out = np.zeros(32, np.uint8)
         _check(load().zkw_linear_keccak256(self.handle, _np_ptr(q) if q.size else None, q.size, _np_ptr(out)))
         return out.tobytes()
+
+    def commit_variable_length_encodable_items(self, enc) -> np.ndarray:
+        """commit_variable_length_encodable_item for a batch of equal-length flat encodings [n][len] -> [n][4]
+        (the step simulate_public_input_value_from_witness applies four times + once, utils.rs:269-306)."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint64)
+        assert enc.ndim == 2
+        out = np.zeros((enc.shape[0], 4), np.uint64)
+        # one spare element keeps the pointer valid for zero-length items
+        buf = np.concatenate([enc.reshape(-1), np.zeros(1, np.uint64)])
+        _check(load().zkw_commit_encodings(self.handle, _np_ptr(buf), enc.shape[0], enc.shape[1], _np_ptr(out)))
+        return out
+
+    def recursion_queue_push(self, circuit_type, public_inputs, tail_in=None):
+        """RecursionQueueSimulator::push for every instance of one circuit type (postprocessing/mod.rs:393-400):
+        returns (encodings [n][8], queue states [n][12])."""
+        pi = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(-1, 4)
+        enc = np.zeros((pi.shape[0], 8), np.uint64)
+        _check(load().zkw_encode_recursion_requests(self.handle, circuit_type, _np_ptr(pi), pi.shape[0], _np_ptr(enc)))
+        return enc, self.queue_push_chain_full(enc, tail_in)

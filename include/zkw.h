@@ -131,7 +131,13 @@ enum {
     ZKW_RAM_CHALLENGES = 5,     /* uint64_t[n_blocks][2][9]       */
     ZKW_RAM_LHS_Z = 6,          /* per block b: uint64_t[2][n_b] at element offset 2*block_offsets[b] */
     ZKW_RAM_RHS_Z = 7,          /* idem                           */
-    ZKW_RAM_INSTANCES = 8       /* zkw_ram_instance[n_instances], blocks in order */
+    ZKW_RAM_INSTANCES = 8,      /* zkw_ram_instance[n_instances], blocks in order */
+    /* a20, CircuitMaker::process src/witness/postprocessing/mod.rs:353-405 (every instance of a block shares
+       the first one's observable input): ClosedFormInputCompactForm = [start, completion, C(observable_input),
+       C(observable_output), C(hidden_fsm_input), C(hidden_fsm_output)], and the public input C(compact form)
+       that simulate_public_input_value_from_witness (src/witness/utils.rs:269-306) returns. */
+    ZKW_RAM_COMPACT_FORMS = 9,  /* uint64_t[n_instances][18]      */
+    ZKW_RAM_PUBLIC_INPUTS = 10  /* uint64_t[n_instances][4]       */
 };
 size_t zkw_ram_witness_num_instances(const zkw_ram_witness *w);
 size_t zkw_ram_witness_num_items(const zkw_ram_witness *w);
@@ -287,6 +293,16 @@ size_t zkw_decommitter_witness_bytes(const zkw_decommitter_witness *w, int what)
 const void *zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness *w, int what);
 int zkw_decommitter_witness_get(const zkw_decommitter_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_decommitter_witness_free(zkw_decommitter_witness *w);
+
+/* ---- public inputs and the recursion queue (a20) ---------------------------------------------------- */
+/* commit_variable_length_encodable_item as driven by simulate_public_input_value_from_witness
+   (src/witness/utils.rs:269-306): n_items flat encodings of item_len elements each -> out[n_items][4]. */
+int zkw_commit_encodings(zkw_ctx *ctx, const uint64_t *enc, size_t n_items, uint32_t item_len, uint64_t *out);
+/* RecursionRequest::encoding_witness, circuit_encodings/src/recursion_request.rs:13-28: enc[i] =
+   [circuit_type, pi[i][0..4], 0, 0, 0]; feed the result to zkw_queue_push_chain_full to obtain the
+   RecursionQueueSimulator states CircuitMaker::process produces (postprocessing/mod.rs:393-400). */
+int zkw_encode_recursion_requests(zkw_ctx *ctx, uint64_t circuit_type, const uint64_t *public_inputs, size_t n,
+                                  uint64_t *enc /* n*8 */);
 
 /* ---- L1 messages hasher ------------------------------------------------------------------------------ */
 /* compute_linear_keccak256, src/witness/individual_circuits/data_hasher_and_merklizer.rs:8-67: Keccak-256 of

@@ -152,6 +152,20 @@ int64_t orc_decommitter_build(const zkw_decommit_query *requests, const uint64_t
    digest of the words (each big-endian) with the 4 most significant bytes replaced by `top4` */
 void orc_bytecode_hash(const uint32_t *words, size_t n_words, uint32_t top_limb, uint32_t hash_out[8]);
 
+/* ---- public-input commitment (a20), see public_input.c */
+#define ORC_RAM_INPUT_ENC_LEN 51
+#define ORC_RAM_FSM_ENC_LEN 69
+void orc_commit_var_length(const uint64_t *enc, size_t n, uint64_t out[4]);
+size_t orc_ram_encode_observable_input(const zkw_ram_instance *in, uint64_t out[ORC_RAM_INPUT_ENC_LEN]);
+size_t orc_ram_encode_fsm(const zkw_ram_fsm *f, uint64_t out[ORC_RAM_FSM_ENC_LEN]);
+void orc_ram_public_input(const zkw_ram_instance *first, const zkw_ram_instance *in, uint64_t compact[18],
+                          uint64_t pi[4]);
+void orc_ram_public_inputs(const zkw_ram_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
+void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_instance *in, uint32_t capacity,
+                               size_t n_rows, uint64_t *trace);
+void orc_recursion_queue(uint64_t circuit_type, const uint64_t *pi, size_t n, const uint64_t tail_in[12],
+                         uint64_t *enc, uint64_t *tails);
+
 /* ---- L1 messages hasher, src/witness/individual_circuits/data_hasher_and_merklizer.rs:8-67:
    Keccak256 over the concatenated 88-byte serialisations (circuit_encodings/src/log_query.rs:503-534:
    shard | is_service | tx_number BE u16 | address 20 BE | key 32 BE | written_value 32 BE) */

@@ -1,0 +1,110 @@
+/* TEST INFRASTRUCTURE — CPU restatement, never linked into the product (see oracle.h).
+ *
+ * Public-input commitment of a closed-form input:
+ *   simulate_public_input_value_from_witness   src/witness/utils.rs:269-306
+ *   CircuitMaker::process                      src/witness/postprocessing/mod.rs:353-405
+ *   RecursionRequest::encoding_witness         circuit_encodings/src/recursion_request.rs:13-28
+ *
+ * `commit_variable_length_encodable_item` / `ClosedFormInputCompactForm::from_full_form` live in the absent
+ * zkevm_circuits crate (v1.4.1, fsm_input_output/mod.rs). Restated from its published algorithm: the flat
+ * encoding is hashed by a Poseidon2 sponge in overwrite mode from the zero state with the length written into
+ * the last capacity element (the same length specialisation produce_fs_challenges uses, utils.rs:511-517), the
+ * last chunk zero padded, commitment = the first 4 state words; an empty encoding commits to zero. The field
+ * order of the encodings follows the struct declarations as mirrored by the reference's own struct literals
+ * (W/ram_permutation.rs:373-409). PARITY UNPINNED: no reference fixture carries a closed-form witness next to
+ * its public input (tests/golden/reference_public_inputs.json holds only the outputs).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+#include "../include/zkw_ram_circuit_spec.h"
+
+void orc_commit_var_length(const uint64_t *enc, size_t n, uint64_t out[4]) {
+    uint64_t s[12];
+    memset(s, 0, sizeof s);
+    s[11] = (uint64_t)n; /* apply_length_specialization */
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        memcpy(s, enc + i, 64);
+        orc_poseidon2_permutation(s);
+    }
+    if (i < n) {
+        for (int k = 0; k < 8; k++) s[k] = i + k < n ? enc[i + k] : 0;
+        orc_poseidon2_permutation(s);
+    }
+    memcpy(out, s, 32);
+}
+
+static size_t put_queue12(const zkw_queue_state12 *q, uint64_t *o) {
+    memcpy(o, q->head, 96);
+    memcpy(o + 12, q->tail, 96);
+    o[24] = q->length;
+    return 25;
+}
+
+/* RamPermutationInputData: unsorted_queue_initial_state, sorted_queue_initial_state, snapshot length */
+size_t orc_ram_encode_observable_input(const zkw_ram_instance *in, uint64_t out[ORC_RAM_INPUT_ENC_LEN]) {
+    size_t m = 0;
+    m += put_queue12(&in->unsorted_queue_initial_state, out + m);
+    m += put_queue12(&in->sorted_queue_initial_state, out + m);
+    out[m++] = in->non_deterministic_bootloader_memory_snapshot_length;
+    return m;
+}
+
+/* RamPermutationFSMInputOutput, fields in the order of W/ram_permutation.rs:385-406 */
+size_t orc_ram_encode_fsm(const zkw_ram_fsm *f, uint64_t out[ORC_RAM_FSM_ENC_LEN]) {
+    size_t m = 0;
+    for (int r = 0; r < 2; r++) out[m++] = f->lhs_accumulator[r];
+    for (int r = 0; r < 2; r++) out[m++] = f->rhs_accumulator[r];
+    m += put_queue12(&f->current_unsorted_queue_state, out + m);
+    m += put_queue12(&f->current_sorted_queue_state, out + m);
+    for (int k = 0; k < 3; k++) out[m++] = f->previous_sorting_key[k];
+    for (int k = 0; k < 2; k++) out[m++] = f->previous_full_key[k];
+    for (int k = 0; k < 8; k++) out[m++] = f->previous_value[k];
+    out[m++] = f->previous_is_ptr ? 1 : 0;
+    out[m++] = f->num_nondeterministic_writes;
+    return m;
+}
+
+/* compact form = [start, completion, C(observable_input), C(observable_output), C(fsm_in), C(fsm_out)] (18);
+   public input = C(compact form). `first` = the first instance of the same block: CircuitMaker::process
+   overwrites every instance's observable input with the first one's (postprocessing/mod.rs:358-364). */
+void orc_ram_public_input(const zkw_ram_instance *first, const zkw_ram_instance *in, uint64_t compact[18],
+                          uint64_t pi[4]) {
+    uint64_t buf[ORC_RAM_FSM_ENC_LEN];
+    compact[0] = in->start_flag ? 1 : 0;
+    compact[1] = in->completion_flag ? 1 : 0;
+    size_t m = orc_ram_encode_observable_input(first, buf);
+    orc_commit_var_length(buf, m, compact + 2);
+    orc_commit_var_length(buf, 0, compact + 6); /* observable output = () */
+    m = orc_ram_encode_fsm(&in->hidden_fsm_input, buf);
+    orc_commit_var_length(buf, m, compact + 10);
+    m = orc_ram_encode_fsm(&in->hidden_fsm_output, buf);
+    orc_commit_var_length(buf, m, compact + 14);
+    orc_commit_var_length(compact, 18, pi);
+}
+
+void orc_ram_public_inputs(const zkw_ram_instance *inst, size_t n, uint64_t *compact, uint64_t *pi) {
+    const zkw_ram_instance *first = inst;
+    for (size_t i = 0; i < n; i++) {
+        if (inst[i].start_flag) first = inst + i;
+        orc_ram_public_input(first, inst + i, compact + 18 * i, pi + 4 * i);
+    }
+}
+
+/* the recursion queue CircuitMaker::process feeds (postprocessing/mod.rs:393-400): tails[i] = full-width queue
+   state after pushing RecursionRequest{circuit_type, pi[i]} */
+void orc_recursion_queue(uint64_t circuit_type, const uint64_t *pi, size_t n, const uint64_t tail_in[12],
+                         uint64_t *enc /* n*8 */, uint64_t *tails /* n*12 */) {
+    for (size_t i = 0; i < n; i++) orc_encode_recursion_request(circuit_type, pi + 4 * i, enc + 8 * i);
+    orc_queue_push_chain_full(enc, n, tail_in, tails);
+}
+
+/* the PI row of a synthesized RAM trace ("zkw trace v1", include/zkw_ram_circuit_spec.h) */
+void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_instance *in, uint32_t capacity,
+                               size_t n_rows, uint64_t *trace) {
+    uint64_t compact[18], pi[4];
+    orc_ram_public_input(first, in, compact, pi);
+    const size_t row = (size_t)RC_ROWS_PER_CYCLE * capacity + RC_ROWOFF_PI;
+    for (int k = 0; k < 4; k++) trace[(size_t)(RC_PI_pi0 + k) * n_rows + row] = pi[k];
+}

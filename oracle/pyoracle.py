@@ -278,6 +278,8 @@ def ram_synthesize(build_out, instance_index, capacity, n_rows):
            C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_ram_synthesize failed: {rc}")
+    first = o["instances"][0:1]  # build_out is one block: its first instance carries the shared observable input
+    lib().orc_ram_fill_public_input(_p(first), _p(inst), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     return trace
 
 
@@ -451,3 +453,38 @@ def serialize_l1_message(q) -> bytes:
     out = C.create_string_buffer(88)
     lib().orc_serialize_l1_message(_p(q), out)
     return out.raw
+
+
+def commit_var_length(enc) -> np.ndarray:
+    enc = np.ascontiguousarray(enc, dtype=np.uint64)
+    out = np.zeros(4, np.uint64)
+    lib().orc_commit_var_length(_p(enc), C.c_size_t(enc.size), _p(out))
+    return out
+
+
+def ram_public_inputs(instances):
+    """(compact forms [n][18], public inputs [n][4]) of consecutive RAM instances (blocks delimited by start_flag)."""
+    inst = np.ascontiguousarray(instances, dtype=RAM_INSTANCE)
+    compact = np.zeros((inst.size, 18), np.uint64)
+    pi = np.zeros((inst.size, 4), np.uint64)
+    lib().orc_ram_public_inputs(_p(inst), C.c_size_t(inst.size), _p(compact), _p(pi))
+    return compact, pi
+
+
+def ram_encode_fsm(fsm) -> np.ndarray:
+    fsm = np.ascontiguousarray(fsm, dtype=RAM_FSM).reshape(1)
+    out = np.zeros(69, np.uint64)
+    f = lib().orc_ram_encode_fsm
+    f.restype = C.c_size_t
+    m = f(_p(fsm), _p(out))
+    return out[:m]
+
+
+def recursion_queue(circuit_type, pi, tail_in=None):
+    pi = np.ascontiguousarray(pi, dtype=np.uint64).reshape(-1, 4)
+    n = pi.shape[0]
+    tin = np.zeros(12, np.uint64) if tail_in is None else np.ascontiguousarray(tail_in, dtype=np.uint64)
+    enc = np.zeros((n, 8), np.uint64)
+    tails = np.zeros((n, 12), np.uint64)
+    lib().orc_recursion_queue(C.c_uint64(circuit_type), _p(pi), C.c_size_t(n), _p(tin), _p(enc), _p(tails))
+    return enc, tails

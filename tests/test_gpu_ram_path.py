@@ -123,6 +123,11 @@ def _assert_witness_equal(w, o, native):
     gi, oi = w.get(native.RAM_INSTANCES), o["instances"]
     assert gi.size == oi.size
     assert gi.tobytes() == oi.tobytes()
+    from oracle import pyoracle
+
+    compact, pi = pyoracle.ram_public_inputs(oi)
+    assert np.array_equal(w.get(native.RAM_COMPACT_FORMS), compact)
+    assert np.array_equal(w.get(native.RAM_PUBLIC_INPUTS), pi)
 
 
 @pytest.mark.parametrize("n,capacity", [(1, 4), (64, 64), (1000, 128), (8192, 2048), (8192, 8192), (5000, 136714)])
@@ -418,3 +423,20 @@ def test_linear_hasher(ctx, oracle, n):
     # n = 17: 17 * 88 = 1496 = 11 * 136 bytes -> a pure padding block; n = 774: production capacity
     q = synthetic.random_log_queries(max(n, 1), seed=n + 2)[:n]
     assert ctx.compute_linear_keccak256(q) == oracle.linear_keccak256(q)
+
+
+@pytest.mark.parametrize("item_len", [0, 1, 7, 8, 9, 18, 51, 69])
+def test_commit_encodings(ctx, oracle, item_len):
+    enc = synthetic.random_field_elements(item_len + 5, (37, item_len))
+    got = ctx.commit_variable_length_encodable_items(enc)
+    for i in range(enc.shape[0]):
+        assert np.array_equal(got[i], oracle.commit_var_length(enc[i]))
+
+
+def test_recursion_queue(ctx, oracle):
+    pi = synthetic.random_field_elements(77, (29, 4))
+    tail_in = synthetic.random_field_elements(78, (12,))
+    for tin in (None, tail_in):
+        enc, tails = ctx.recursion_queue_push(8, pi, tin)
+        oenc, otails = oracle.recursion_queue(8, pi, tin)
+        assert np.array_equal(enc, oenc) and np.array_equal(tails, otails)

@@ -396,3 +396,35 @@ def test_linear_hasher_oracle(oracle):
     full = b"".join(oracle.serialize_l1_message(x) for x in q)
     assert oracle.linear_keccak256(q) == oracle.keccak256(full)
     assert oracle.linear_keccak256(q[:0]) == oracle.keccak256(b"")
+
+
+def test_public_input_commitment_oracle(oracle):
+    """a20: structure of the compact form and the sponge (length specialisation, zero padding, empty item)."""
+    q = synthetic.ram_trace(300, seed=5)
+    o = oracle.ram_build_instances(q, 128, 0)
+    inst = o["instances"]
+    compact, pi = oracle.ram_public_inputs(inst)
+    assert compact.shape == (3, 18) and pi.shape == (3, 4)
+    assert list(compact[:, 0]) == [1, 0, 0] and list(compact[:, 1]) == [0, 0, 1]
+    # the observable input is shared by every instance of the block; the observable output is () -> zero
+    assert (compact[:, 2:6] == compact[0, 2:6]).all() and (compact[:, 6:10] == 0).all()
+    # FSM chaining: output commitment of instance i == input commitment of instance i + 1
+    assert np.array_equal(compact[:-1, 14:18], compact[1:, 10:14])
+    for i in range(3):
+        assert np.array_equal(pi[i], oracle.commit_var_length(compact[i]))
+        assert np.array_equal(compact[i, 14:18], oracle.commit_var_length(oracle.ram_encode_fsm(inst[i]["hidden_fsm_output"])))
+    # the sponge: length in state[11], overwrite absorption, zero padded tail chunk
+    enc = synthetic.random_field_elements(9, (11,))
+    s = np.zeros(12, np.uint64)
+    s[11] = 11
+    s[:8] = enc[:8]
+    s = oracle.poseidon2(s)
+    s[:8] = 0
+    s[:3] = enc[8:]
+    s = oracle.poseidon2(s)
+    assert np.array_equal(oracle.commit_var_length(enc), s[:4])
+    assert not oracle.commit_var_length(enc[:0]).any()
+    # recursion request layout
+    enc8, tails = oracle.recursion_queue(8, pi)
+    assert list(enc8[1]) == [8, *pi[1], 0, 0, 0]
+    assert np.array_equal(tails, oracle.queue_push_chain_full(enc8))
