@@ -23,6 +23,7 @@
 #include "storage_kernels.cuh"
 #include "decommitter_kernels.cuh"
 #include "public_input_kernels.cuh"
+#include "callstack_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -1896,5 +1897,88 @@ extern "C" int zkw_encode_recursion_requests(zkw_ctx* ctx, uint64_t circuit_type
     { Prof _p(ctx, "k_encode_recursion"); hipLaunchKernelGGL(k_encode_recursion, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, circuit_type, d_pi, n, d_enc); }
     ZKW_TRY(launch_check("k_encode_recursion"));
     ZKW_TRY(ctx->finish_out(enc, d_enc, n * 8));
+    return ctx->sync_if_host();
+}
+
+// ------------------------------------------------------------------------------------------------ callstack (a3, a6)
+extern "C" int zkw_encode_callstack_entries(zkw_ctx* ctx, const zkw_callstack_entry* entries, size_t n, uint64_t* enc) {
+    if (!ctx || !enc || !entries) return fail(ZKW_ERR_INVALID, "zkw_encode_callstack_entries: null argument");
+    if (n == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const zkw_callstack_entry* d_e = nullptr;
+    u64* d_enc = nullptr;
+    ZKW_TRY(ctx->in("cs_e", entries, n, &d_e));
+    ZKW_TRY(ctx->out("cs_enc", enc, n * 32, &d_enc));
+    { Prof _p(ctx, "k_encode_callstack"); hipLaunchKernelGGL(k_encode_callstack, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, d_e, n, d_enc); }
+    ZKW_TRY(launch_check("k_encode_callstack"));
+    ZKW_TRY(ctx->finish_out(enc, d_enc, n * 32));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_callstack_simulate(zkw_ctx* ctx, const uint8_t* is_push, size_t n_ops, const zkw_callstack_entry* pushed,
+                                      size_t n_pushed, uint64_t* previous_state, uint64_t* new_state, uint32_t* depth,
+                                      uint64_t* round_states, uint32_t* entry_index) {
+    if (!ctx || !is_push || !previous_state || !new_state || !depth || !round_states || !entry_index || (n_pushed && !pushed))
+        return fail(ZKW_ERR_INVALID, "zkw_callstack_simulate: null argument");
+    if (n_ops == 0) return ZKW_OK;
+    if (n_ops >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many stack operations");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint8_t* d_ops = nullptr;
+    const zkw_callstack_entry* d_e = nullptr;
+    ZKW_TRY(ctx->in("st_ops", is_push, n_ops, &d_ops));
+    if (n_pushed) ZKW_TRY(ctx->in("st_e", pushed, n_pushed, &d_e));
+    u32 *d_depth = nullptr, *d_rank = nullptr, *d_meta = nullptr, *d_pd = nullptr, *d_pid = nullptr, *d_sd = nullptr, *d_sid = nullptr,
+        *d_parent = nullptr, *d_node = nullptr;
+    u64* d_rounds = nullptr;
+    void* tmp = nullptr;
+    const size_t tmp_bytes = radix_temp_bytes(n_ops);
+    ZKW_TRY(ctx->scratch_t<u32>("st_depth", n_ops, &d_depth));
+    ZKW_TRY(ctx->scratch_t<u32>("st_rank", n_ops, &d_rank));
+    ZKW_TRY(ctx->scratch_t<u32>("st_meta", 4, &d_meta));
+    ZKW_TRY(ctx->scratch_t<u32>("st_pd", n_ops, &d_pd));
+    ZKW_TRY(ctx->scratch_t<u32>("st_pid", n_ops, &d_pid));
+    ZKW_TRY(ctx->scratch_t<u32>("st_sd", n_ops, &d_sd));
+    ZKW_TRY(ctx->scratch_t<u32>("st_sid", n_ops, &d_sid));
+    ZKW_TRY(ctx->scratch_t<u32>("st_parent", n_ops, &d_parent));
+    ZKW_TRY(ctx->scratch_t<u32>("st_node", n_ops, &d_node));
+    ZKW_TRY(ctx->scratch_t<u64>("st_rounds", n_ops * 48, &d_rounds));
+    ZKW_TRY(ctx->scratch("st_tmp", tmp_bytes + 256, &tmp));
+    { Prof _p(ctx, "k_stack_depth"); hipLaunchKernelGGL(k_stack_depth, dim3(1), dim3(1024), 0, ctx->stream, d_ops, n_ops, d_depth, d_rank, d_meta); }
+    ZKW_TRY(launch_check("k_stack_depth"));
+    u32 meta[3];
+    HIP_TRY(hipMemcpyAsync(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (meta[2]) return fail(ZKW_ERR_INVALID, "pop from the empty callstack (circuit_encodings/src/lib.rs:619)");
+    const u32 n_push = meta[0], max_depth = meta[1];
+    if (n_push > n_pushed) return fail(ZKW_ERR_INVALID, "%u pushes but only %zu entries", n_push, n_pushed);
+    const unsigned grid = blocks_for(n_ops, 256);
+    if (n_push) {
+        { Prof _p(ctx, "k_stack_push_keys"); hipLaunchKernelGGL(k_stack_push_keys, dim3(grid), dim3(256), 0, ctx->stream, d_ops, n_ops, d_depth, d_rank, d_pd, d_pid); }
+        ZKW_TRY(launch_check("k_stack_push_keys"));
+        unsigned bits = 1;
+        while ((1ull << bits) <= max_depth) bits++;
+        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, d_pd, d_sd, d_pid, d_sid, n_push, bits, ctx->stream)); }
+    }
+    { Prof _p(ctx, "k_stack_links"); hipLaunchKernelGGL(k_stack_links, dim3(grid), dim3(256), 0, ctx->stream, d_ops, n_ops, d_depth, d_rank, d_sd, d_sid, d_meta, d_parent, d_node); }
+    ZKW_TRY(launch_check("k_stack_links"));
+    for (u32 d = 1; d <= max_depth; d++) {
+        Prof _p(ctx, "k_stack_level");
+        hipLaunchKernelGGL(k_stack_level, dim3(blocks_for(n_push, 64)), dim3(64), 0, ctx->stream, d_e, d_pd, d_parent, d_meta, d, d_rounds);
+    }
+    ZKW_TRY(launch_check("k_stack_level"));
+    u64 *d_prev = nullptr, *d_new = nullptr, *d_rs = nullptr;
+    u32 *d_dep = nullptr, *d_idx = nullptr;
+    ZKW_TRY(ctx->out("st_o_prev", previous_state, n_ops * 12, &d_prev));
+    ZKW_TRY(ctx->out("st_o_new", new_state, n_ops * 12, &d_new));
+    ZKW_TRY(ctx->out("st_o_rs", round_states, n_ops * 48, &d_rs));
+    ZKW_TRY(ctx->out("st_o_dep", depth, n_ops, &d_dep));
+    ZKW_TRY(ctx->out("st_o_idx", entry_index, n_ops, &d_idx));
+    { Prof _p(ctx, "k_stack_emit"); hipLaunchKernelGGL(k_stack_emit, dim3(grid), dim3(256), 0, ctx->stream, d_ops, n_ops, d_depth, d_parent, d_node, d_rounds, d_meta, d_prev, d_new, d_dep, d_rs, d_idx); }
+    ZKW_TRY(launch_check("k_stack_emit"));
+    ZKW_TRY(ctx->finish_out(previous_state, d_prev, n_ops * 12));
+    ZKW_TRY(ctx->finish_out(new_state, d_new, n_ops * 12));
+    ZKW_TRY(ctx->finish_out(round_states, d_rs, n_ops * 48));
+    ZKW_TRY(ctx->finish_out(depth, d_dep, n_ops));
+    ZKW_TRY(ctx->finish_out(entry_index, d_idx, n_ops));
     return ctx->sync_if_host();
 }

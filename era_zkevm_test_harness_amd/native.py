@@ -83,6 +83,8 @@ SYMBOLS = [
     ("zkw_decommitter_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_decommitter_witness_free", None, [_vp]),
     ("zkw_linear_keccak256", _int, [_vp, _vp, _sz, _vp]),
+    ("zkw_encode_callstack_entries", _int, [_vp, _vp, _sz, _vp]),
+    ("zkw_callstack_simulate", _int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("zkw_commit_encodings", _int, [_vp, _vp, _sz, C.c_uint32, _vp]),
     ("zkw_encode_recursion_requests", _int, [_vp, C.c_uint64, _vp, _sz, _vp]),
     ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
@@ -147,6 +149,14 @@ LOG_QUERY = np.dtype(
 DECOMMIT_QUERY = np.dtype([("hash", "<u4", (8,)), ("timestamp", "<u4"), ("memory_page", "<u4"),
                            ("decommitted_length", "<u2"), ("is_fresh", "u1"), ("_pad", "u1", (5,))])
 assert LOG_QUERY.itemsize == 128 and DECOMMIT_QUERY.itemsize == 48
+CALLSTACK_ENTRY = np.dtype(
+    [("rollback_queue_head", "<u8", (4,)), ("rollback_queue_tail", "<u8", (4,)), ("rollback_queue_segment_length", "<u4"),
+     ("code_address", "<u4", (5,)), ("this_address", "<u4", (5,)), ("msg_sender", "<u4", (5,)),
+     ("context_u128_value", "<u4", (4,)), ("code_page", "<u4"), ("base_memory_page", "<u4"), ("ergs_remaining", "<u4"),
+     ("heap_bound", "<u4"), ("aux_heap_bound", "<u4"), ("pc", "<u2"), ("sp", "<u2"), ("exception_handler_location", "<u2"),
+     ("this_shard_id", "u1"), ("caller_shard_id", "u1"), ("code_shard_id", "u1"), ("is_static", "u1"),
+     ("is_local_frame", "u1"), ("_pad", "u1", (1,))])
+assert CALLSTACK_ENTRY.itemsize == 176
 QUEUE_STATE12 = np.dtype([("head", "<u8", (12,)), ("tail", "<u8", (12,)), ("length", "<u4"), ("_pad", "<u4")])
 RAM_FSM = np.dtype(
     [("lhs_accumulator", "<u8", (2,)), ("rhs_accumulator", "<u8", (2,)),
@@ -748,3 +758,23 @@ class Context:
         enc = np.zeros((pi.shape[0], 8), np.uint64)
         _check(load().zkw_encode_recursion_requests(self.handle, circuit_type, _np_ptr(pi), pi.shape[0], _np_ptr(enc)))
         return enc, self.queue_push_chain_full(enc, tail_in)
+
+    def encode_callstack_entries(self, entries) -> np.ndarray:
+        """ExtendedCallstackEntry::encoding_witness (callstack_entry.rs:36-179): [n][32]."""
+        e = np.ascontiguousarray(entries, dtype=CALLSTACK_ENTRY)
+        enc = np.zeros((e.size, 32), np.uint64)
+        _check(load().zkw_encode_callstack_entries(self.handle, _np_ptr(e), e.size, _np_ptr(enc)))
+        return enc
+
+    def callstack_simulate(self, is_push, pushed):
+        """CallstackSimulator pushes / pops replayed on an empty stack (lib.rs:558-644)."""
+        ops = np.ascontiguousarray(is_push, dtype=np.uint8)
+        e = np.ascontiguousarray(pushed, dtype=CALLSTACK_ENTRY)
+        n = ops.size
+        o = {"previous_state": np.zeros((n, 12), np.uint64), "new_state": np.zeros((n, 12), np.uint64),
+             "depth": np.zeros(n, np.uint32), "round_states": np.zeros((n, 4, 12), np.uint64),
+             "entry_index": np.zeros(n, np.uint32)}
+        _check(load().zkw_callstack_simulate(self.handle, _np_ptr(ops), n, _np_ptr(e) if e.size else None, e.size,
+                                             _np_ptr(o["previous_state"]), _np_ptr(o["new_state"]), _np_ptr(o["depth"]),
+                                             _np_ptr(o["round_states"]), _np_ptr(o["entry_index"])))
+        return o

@@ -219,3 +219,31 @@ def storage_trace(n: int, n_cells: int, seed: int = 1, p_read: float = 0.35, p_r
             st.append((val.copy(), newv[i].copy()))
             cur[c] = newv[i].copy()
     return q
+
+
+def callstack_trace(n_ops, seed=0, max_depth=40, final_unwind=True):
+    """A random but valid sequence of call-stack pushes (1) / pops (0) with the pushed ExtendedCallstackEntry records."""
+    from .native import CALLSTACK_ENTRY
+
+    rng = np.random.default_rng(seed)
+    ops, depth = [], 0
+    for _ in range(n_ops):
+        push = depth == 0 or (depth < max_depth and rng.random() < 0.55)
+        ops.append(1 if push else 0)
+        depth += 1 if push else -1
+    if final_unwind:
+        ops += [0] * depth
+    ops = np.array(ops, np.uint8)
+    n_push = int(ops.sum())
+    e = np.zeros(n_push, CALLSTACK_ENTRY)
+    raw = rng.integers(0, 256, (n_push, CALLSTACK_ENTRY.itemsize), dtype=np.uint8)
+    e[:] = raw.view(CALLSTACK_ENTRY).reshape(n_push)
+    e["rollback_queue_head"] = random_field_elements(seed + 1, (n_push, 4))
+    e["rollback_queue_tail"] = random_field_elements(seed + 2, (n_push, 4))
+    e["is_static"] &= 1
+    e["is_local_frame"] &= 1
+    e["_pad"] = 0
+    kernel = rng.random(n_push) < 0.5  # half of the frames run in kernel space (address < 2^16)
+    e["this_address"][kernel, 1:] = 0
+    e["this_address"][kernel, 0] &= 0xFFFF
+    return ops, e

@@ -294,6 +294,21 @@ const void *zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness *w,
 int zkw_decommitter_witness_get(const zkw_decommitter_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_decommitter_witness_free(zkw_decommitter_witness *w);
 
+/* ---- callstack (a3 / a6) ------------------------------------------------------------------------------ */
+/* ExtendedCallstackEntry::encoding_witness, circuit_encodings/src/callstack_entry.rs:36-179. enc: n*32 */
+int zkw_encode_callstack_entries(zkw_ctx *ctx, const zkw_callstack_entry *entries, size_t n, uint64_t *enc);
+/* FullWidthStackSimulator::{push,pop}_and_output_intermediate_data (circuit_encodings/src/lib.rs:558-644) for a
+   whole sequence of operations on an initially empty CallstackSimulator: is_push[i] != 0 pushes the next entry
+   of `pushed` (in order), 0 pops the top. Outputs per operation i (FullWidthStackIntermediateStates,
+   lib.rs:511-521): previous_state[i][12], new_state[i][12], depth[i] (= num_items after the operation),
+   round_states[i][4][12] (the outputs of round_function_execution_pairs; their inputs are the previous output
+   with the rate replaced by the encoding chunk), entry_index[i] = index in `pushed` of the element pushed /
+   returned by the pop. ZKW_ERR_INVALID on a pop from the empty stack (the reference's unwrap at lib.rs:619)
+   or when pushes outnumber n_pushed. */
+int zkw_callstack_simulate(zkw_ctx *ctx, const uint8_t *is_push, size_t n_ops, const zkw_callstack_entry *pushed,
+                           size_t n_pushed, uint64_t *previous_state, uint64_t *new_state, uint32_t *depth,
+                           uint64_t *round_states, uint32_t *entry_index);
+
 /* ---- public inputs and the recursion queue (a20) ---------------------------------------------------- */
 /* commit_variable_length_encodable_item as driven by simulate_public_input_value_from_witness
    (src/witness/utils.rs:269-306): n_items flat encodings of item_len elements each -> out[n_items][4]. */

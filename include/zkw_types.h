@@ -127,6 +127,38 @@ typedef struct zkw_ram_instance {
     uint64_t num_items;
 } zkw_ram_instance;
 
+/* ---- callstack (a3 / a6) -------------------------------------------------------------------------- */
+#define ZKW_EXECUTION_CONTEXT_RECORD_ENCODING_WIDTH 32 /* callstack_entry.rs:33-36,179 */
+
+/* ExtendedCallstackEntry (circuit_encodings/src/callstack_entry.rs:16-24) around zk_evm's CallStackEntry,
+   only the fields encoding_witness (:36-179) reads. Addresses are u32x5 little-endian limbs
+   (decompose_address_as_u32x5), context_u128_value is u32x4 (u128_as_u32_le, :6-13). is_kernel_mode is
+   derived by the reference from this_address (CallStackEntry::is_kernel_mode in the absent zk_evm crate:
+   the upper 18 bytes of the address are zero); the library derives it the same way. 176 bytes. */
+typedef struct zkw_callstack_entry {
+    uint64_t rollback_queue_head[4];
+    uint64_t rollback_queue_tail[4];
+    uint32_t rollback_queue_segment_length;
+    uint32_t code_address[5];
+    uint32_t this_address[5];
+    uint32_t msg_sender[5];
+    uint32_t context_u128_value[4];
+    uint32_t code_page;
+    uint32_t base_memory_page;
+    uint32_t ergs_remaining;
+    uint32_t heap_bound;
+    uint32_t aux_heap_bound;
+    uint16_t pc;
+    uint16_t sp;
+    uint16_t exception_handler_location;
+    uint8_t this_shard_id;
+    uint8_t caller_shard_id;
+    uint8_t code_shard_id;
+    uint8_t is_static;
+    uint8_t is_local_frame;
+    uint8_t _pad[1];
+} zkw_callstack_entry;
+
 /* ---- CodeDecommittmentsSorter (sort_decommit_requests.rs) ---------------------------------------- */
 #define ZKW_DECOMMIT_PACKED_KEY_LENGTH 9 /* [timestamp, hash limbs 0..7], sort_decommit_requests.rs:422-435 */
 

@@ -152,6 +152,13 @@ int64_t orc_decommitter_build(const zkw_decommit_query *requests, const uint64_t
    digest of the words (each big-endian) with the 4 most significant bytes replaced by `top4` */
 void orc_bytecode_hash(const uint32_t *words, size_t n_words, uint32_t top_limb, uint32_t hash_out[8]);
 
+/* ---- callstack (a3 / a6), see callstack.c */
+void orc_encode_callstack_entry(const zkw_callstack_entry *e, uint64_t out[32]);
+void orc_encode_callstack_entries(const zkw_callstack_entry *e, size_t n, uint64_t *out /* n*32 */);
+int orc_callstack_simulate(const uint8_t *is_push, size_t n_ops, const zkw_callstack_entry *pushed, size_t n_pushed,
+                           uint64_t *previous_state, uint64_t *new_state, uint32_t *depth, uint64_t *round_states,
+                           uint32_t *entry_index);
+
 /* ---- public-input commitment (a20), see public_input.c */
 #define ORC_RAM_INPUT_ENC_LEN 51
 #define ORC_RAM_FSM_ENC_LEN 69

@@ -42,6 +42,14 @@ assert LOG_QUERY.itemsize == 128
 DECOMMIT_QUERY = np.dtype([("hash", "<u4", (8,)), ("timestamp", "<u4"), ("memory_page", "<u4"),
                            ("decommitted_length", "<u2"), ("is_fresh", "u1"), ("_pad", "u1", (5,))])
 assert DECOMMIT_QUERY.itemsize == 48
+CALLSTACK_ENTRY = np.dtype(
+    [("rollback_queue_head", "<u8", (4,)), ("rollback_queue_tail", "<u8", (4,)), ("rollback_queue_segment_length", "<u4"),
+     ("code_address", "<u4", (5,)), ("this_address", "<u4", (5,)), ("msg_sender", "<u4", (5,)),
+     ("context_u128_value", "<u4", (4,)), ("code_page", "<u4"), ("base_memory_page", "<u4"), ("ergs_remaining", "<u4"),
+     ("heap_bound", "<u4"), ("aux_heap_bound", "<u4"), ("pc", "<u2"), ("sp", "<u2"), ("exception_handler_location", "<u2"),
+     ("this_shard_id", "u1"), ("caller_shard_id", "u1"), ("code_shard_id", "u1"), ("is_static", "u1"),
+     ("is_local_frame", "u1"), ("_pad", "u1", (1,))])
+assert CALLSTACK_ENTRY.itemsize == 176
 
 
 DECOMMIT_FSM = np.dtype(
@@ -488,3 +496,26 @@ def recursion_queue(circuit_type, pi, tail_in=None):
     tails = np.zeros((n, 12), np.uint64)
     lib().orc_recursion_queue(C.c_uint64(circuit_type), _p(pi), C.c_size_t(n), _p(tin), _p(enc), _p(tails))
     return enc, tails
+
+
+def encode_callstack_entries(e) -> np.ndarray:
+    e = np.ascontiguousarray(e, dtype=CALLSTACK_ENTRY)
+    out = np.zeros((e.size, 32), np.uint64)
+    lib().orc_encode_callstack_entries(_p(e), C.c_size_t(e.size), _p(out))
+    return out
+
+
+def callstack_simulate(is_push, pushed):
+    ops = np.ascontiguousarray(is_push, dtype=np.uint8)
+    e = np.ascontiguousarray(pushed, dtype=CALLSTACK_ENTRY)
+    n = ops.size
+    o = {"previous_state": np.zeros((n, 12), np.uint64), "new_state": np.zeros((n, 12), np.uint64),
+         "depth": np.zeros(n, np.uint32), "round_states": np.zeros((n, 4, 12), np.uint64),
+         "entry_index": np.zeros(n, np.uint32)}
+    f = lib().orc_callstack_simulate
+    f.restype = C.c_int
+    rc = f(_p(ops), C.c_size_t(n), _p(e), C.c_size_t(e.size), _p(o["previous_state"]), _p(o["new_state"]),
+           _p(o["depth"]), _p(o["round_states"]), _p(o["entry_index"]))
+    if rc != 0:
+        raise RuntimeError(f"orc_callstack_simulate failed: {rc}")
+    return o

@@ -58,6 +58,7 @@ def test_record_layouts_match_header():
     #include "zkw_types.h"
     int main(void){
       printf("%zu %zu %zu %zu\n", sizeof(zkw_mem_query), sizeof(zkw_queue_state12), sizeof(zkw_ram_fsm), sizeof(zkw_ram_instance));
+      printf("%zu %zu %zu %zu\n", sizeof(zkw_callstack_entry), offsetof(zkw_callstack_entry, pc), sizeof(zkw_log_query), sizeof(zkw_decommit_query));
       printf("%zu %zu %zu %zu\n", offsetof(zkw_mem_query, value), offsetof(zkw_ram_fsm, previous_sorting_key),
              offsetof(zkw_ram_instance, hidden_fsm_input), offsetof(zkw_ram_instance, first_item));
       return 0; }
@@ -72,10 +73,12 @@ def test_record_layouts_match_header():
     sizes = [int(x) for x in out]
     for mod in (native, pyoracle):
         assert sizes[:4] == [mod.MEM_QUERY.itemsize, mod.QUEUE_STATE12.itemsize, mod.RAM_FSM.itemsize, mod.RAM_INSTANCE.itemsize]
-        assert sizes[4] == mod.MEM_QUERY.fields["value"][1]
-        assert sizes[5] == mod.RAM_FSM.fields["previous_sorting_key"][1]
-        assert sizes[6] == mod.RAM_INSTANCE.fields["hidden_fsm_input"][1]
-        assert sizes[7] == mod.RAM_INSTANCE.fields["first_item"][1]
+        assert sizes[4:8] == [mod.CALLSTACK_ENTRY.itemsize, mod.CALLSTACK_ENTRY.fields["pc"][1], mod.LOG_QUERY.itemsize,
+                              mod.DECOMMIT_QUERY.itemsize]
+        assert sizes[8] == mod.MEM_QUERY.fields["value"][1]
+        assert sizes[9] == mod.RAM_FSM.fields["previous_sorting_key"][1]
+        assert sizes[10] == mod.RAM_INSTANCE.fields["hidden_fsm_input"][1]
+        assert sizes[11] == mod.RAM_INSTANCE.fields["first_item"][1]
 
 
 def test_synthetic_trace_is_valid_memory():

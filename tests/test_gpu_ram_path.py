@@ -440,3 +440,22 @@ def test_recursion_queue(ctx, oracle):
         enc, tails = ctx.recursion_queue_push(8, pi, tin)
         oenc, otails = oracle.recursion_queue(8, pi, tin)
         assert np.array_equal(enc, oenc) and np.array_equal(tails, otails)
+
+
+@pytest.mark.parametrize("n_ops,max_depth", [(1, 4), (50, 3), (3000, 40), (20000, 200)])
+def test_callstack_simulator(ctx, oracle, n_ops, max_depth):
+    ops, e = synthetic.callstack_trace(n_ops, seed=n_ops, max_depth=max_depth, final_unwind=n_ops != 50)
+    assert np.array_equal(ctx.encode_callstack_entries(e), oracle.encode_callstack_entries(e))
+    g, o = ctx.callstack_simulate(ops, e), oracle.callstack_simulate(ops, e)
+    for k in o:
+        assert np.array_equal(g[k], o[k]), k
+
+
+def test_callstack_pop_from_empty(ctx):
+    from era_zkevm_test_harness_amd import native
+
+    ops, e = synthetic.callstack_trace(10, seed=1)
+    bad = np.concatenate([ops, np.array([0], np.uint8)])
+    with pytest.raises(native.ZkwError) as ei:
+        ctx.callstack_simulate(bad, e)
+    assert ei.value.code == native.ERR_INVALID

@@ -428,3 +428,28 @@ def test_public_input_commitment_oracle(oracle):
     enc8, tails = oracle.recursion_queue(8, pi)
     assert list(enc8[1]) == [8, *pi[1], 0, 0, 0]
     assert np.array_equal(tails, oracle.queue_push_chain_full(enc8))
+
+
+def test_callstack_oracle(oracle):
+    ops, e = synthetic.callstack_trace(200, seed=3)
+    enc = oracle.encode_callstack_entries(e)
+    r = e[0]
+    assert int(enc[0, 27]) == int(r["code_page"]) | int(r["pc"]) << 32 | int(r["this_shard_id"]) << 48 | int(r["is_static"]) << 56
+    kernel = int(not r["this_address"][1:].any() and r["this_address"][0] < 65536)
+    assert int(enc[0, 28]) >> 56 == kernel
+    ln = int(r["rollback_queue_segment_length"])
+    assert int(enc[0, 30]) == int(r["heap_bound"]) | (ln & 0xFFFF) << 32
+    assert int(enc[0, 31]) == int(r["aux_heap_bound"]) | (ln >> 16) << 32
+    o = oracle.callstack_simulate(ops, e)
+    # first operation pushes onto the empty stack: 4 overwrite rounds from the zero state
+    s = np.zeros(12, np.uint64)
+    for rnd in range(4):
+        s[:8] = enc[0, 8 * rnd:8 * rnd + 8]
+        s = oracle.poseidon2(s)
+        assert np.array_equal(o["round_states"][0, rnd], s)
+    assert np.array_equal(o["new_state"][0], s) and not o["previous_state"][0].any() and o["depth"][0] == 1
+    # every pop restores the state its push saw, and the walk ends on the empty stack
+    assert o["depth"][-1] == 0 and not o["new_state"][-1].any()
+    assert np.array_equal(o["previous_state"][1:], o["new_state"][:-1])
+    with pytest.raises(RuntimeError):
+        oracle.callstack_simulate(np.array([1, 0, 0], np.uint8), e[:1])
