@@ -1,0 +1,350 @@
+// precompile_kernels.cuh — keccak256 / sha256 / ecrecover round-function witness builders.
+//
+// Reference functions replaced:
+//   keccak256_decompose_into_per_circuit_witness  src/witness/individual_circuits/keccak256_round_function.rs:23-528
+//   sha256_decompose_into_per_circuit_witness     src/witness/individual_circuits/sha256_round_function.rs:23-406
+//   ecrecover_decompose_into_per_circuit_witness  src/witness/individual_circuits/ecrecover.rs:12-262
+//
+// The reference walks the rounds of all requests one after another, cutting an instance every `capacity` rounds.
+// Requests are independent: rounds and memory queries per request follow from its ABI, so a prefix sum places
+// every request in the global round / query sequence (k_precompile_counts), one lane per request then replays
+// its own rounds and leaves a snapshot of the FSM at each instance boundary it crosses (k_precompile_walk), the
+// memory queue is one Poseidon2 chain over the given queries (k_chain_full), and one lane per instance joins
+// snapshots and queue states into the instance record (k_precompile_instances).
+#pragma once
+#include "decommitter_kernels.cuh"
+
+namespace zkw {
+
+struct PrecompileAbi {  // PrecompileCallABI::from_u256(query.key), zkevm_opcode_defs (absent crate, see zkw_types.h)
+    u32 input_memory_offset, input_memory_length, output_memory_offset, output_memory_length;
+    u32 memory_page_to_read, memory_page_to_write;
+    u64 precompile_interpreted_data;
+};
+__device__ __forceinline__ PrecompileAbi precompile_abi_in_log(const zkw_log_query& q) {
+    PrecompileAbi a;
+    a.input_memory_offset = q.key[0]; a.input_memory_length = q.key[1];
+    a.output_memory_offset = q.key[2]; a.output_memory_length = q.key[3];
+    a.memory_page_to_read = q.key[4]; a.memory_page_to_write = q.key[5];
+    a.precompile_interpreted_data = (u64)q.key[6] | ((u64)q.key[7] << 32);
+    return a;
+}
+
+// rounds / memory queries / reads one request contributes
+__device__ __forceinline__ void precompile_request_shape(int kind, const zkw_log_query& q, u64& rounds, u64& queries, u64& reads) {
+    const PrecompileAbi a = precompile_abi_in_log(q);
+    if (kind == ZKW_PRECOMPILE_SHA256) {
+        rounds = a.precompile_interpreted_data; reads = 2 * rounds; queries = reads + 1;
+    } else if (kind == ZKW_PRECOMPILE_ECRECOVER) {
+        rounds = 1; reads = 4; queries = 6;
+    } else {
+        const u64 off = a.input_memory_offset, len = a.input_memory_length;
+        rounds = (len + 135) / 136 + (len % 136 == 0 ? 1 : 0);
+        reads = len ? (off + len - 1) / 32 - off / 32 + 1 : 0;  // every touched word is read exactly once
+        queries = reads + 1;
+    }
+}
+
+// offsets[0..3][n+1]: exclusive prefix sums of rounds, queries, reads. meta[0..3] = totals, meta[3] = error
+// (a request without rounds). One workgroup walks the requests in tiles of 1024.
+__global__ __launch_bounds__(1024) void k_precompile_counts(int kind, const zkw_log_query* __restrict__ requests, size_t n,
+                                                            u64* __restrict__ round_off, u64* __restrict__ query_off,
+                                                            u64* __restrict__ read_off, u64* __restrict__ meta) {
+    __shared__ u64 s[3][1024];
+    __shared__ u64 carry[3];
+    __shared__ u32 err;
+    const int t = threadIdx.x;
+    if (t == 0) { carry[0] = carry[1] = carry[2] = 0; err = 0; }
+    __syncthreads();
+    for (size_t base = 0; base < n; base += 1024) {
+        const size_t i = base + t;
+        u64 v[3] = {0, 0, 0};
+        if (i < n) {
+            precompile_request_shape(kind, requests[i], v[0], v[1], v[2]);
+            if (v[0] == 0 || v[0] > (1ull << 32)) atomicOr(&err, 1u);
+        }
+        for (int c = 0; c < 3; c++) s[c][t] = v[c];
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            u64 a[3];
+            for (int c = 0; c < 3; c++) a[c] = t >= off ? s[c][t - off] : 0;
+            __syncthreads();
+            for (int c = 0; c < 3; c++) s[c][t] += a[c];
+            __syncthreads();
+        }
+        if (i < n) {
+            round_off[i] = carry[0] + s[0][t] - v[0];
+            query_off[i] = carry[1] + s[1][t] - v[1];
+            read_off[i] = carry[2] + s[2][t] - v[2];
+        }
+        __syncthreads();
+        if (t == 0) for (int c = 0; c < 3; c++) carry[c] += s[c][1023];
+        __syncthreads();
+    }
+    if (t == 0) {
+        round_off[n] = carry[0]; query_off[n] = carry[1]; read_off[n] = carry[2];
+        meta[0] = carry[0]; meta[1] = carry[1]; meta[2] = carry[2]; meta[3] = err;
+    }
+}
+
+__device__ inline void keccak_f1600(u64 a[25]) {
+    for (int round = 0; round < 24; round++) {
+        u64 c[5], b[25];
+#pragma unroll
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            const u64 d = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
+#pragma unroll
+            for (int y = 0; y < 5; y++) a[x + 5 * y] ^= d;
+        }
+#pragma unroll
+        for (int x = 0; x < 5; x++)
+#pragma unroll
+            for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(a[x + 5 * y], c_keccak_rot[x + 5 * y]);
+#pragma unroll
+        for (int y = 0; y < 5; y++)
+#pragma unroll
+            for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= c_keccak_rc[round];
+    }
+}
+
+// the internal part of the FSM at an instance boundary + how far the global sequences have advanced
+struct PrecompileSnap {
+    zkw_precompile_fsm fsm;  // queue states are filled in by k_precompile_instances
+    u64 popped, queries_done, reads_done;
+};
+
+struct PrecompileJob {
+    int kind;
+    const zkw_log_query* requests;
+    const zkw_mem_query* mem_q;
+    const u64 *round_off, *query_off, *read_off;
+    PrecompileSnap* snaps;  // [n_instances]
+    u32* violations;
+    u64 n_requests, total_rounds;
+    u32 capacity;
+};
+
+__device__ __forceinline__ void word_be_bytes(const u32* limbs, uint8_t out[32]) {  // U256::to_big_endian
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const u32 l = limbs[7 - k];
+        out[4 * k] = (uint8_t)(l >> 24); out[4 * k + 1] = (uint8_t)(l >> 16); out[4 * k + 2] = (uint8_t)(l >> 8); out[4 * k + 3] = (uint8_t)l;
+    }
+}
+
+// one lane per request
+__global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= job.n_requests) return;
+    const zkw_log_query request = job.requests[r];
+    PrecompileAbi abi = precompile_abi_in_log(request);
+    const u64 g0 = job.round_off[r], num_rounds = job.round_off[r + 1] - g0;
+    u64 qpos = job.query_off[r], reads = job.read_off[r];
+    const u64 qend = job.query_off[r + 1];
+    const bool is_last_request = r + 1 == job.n_requests;
+    const int kind = job.kind;
+    u32 sha[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    u64 kst[25];
+    for (int i = 0; i < 25; i++) kst[i] = 0;
+    uint8_t buf[ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE];
+    for (int i = 0; i < ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE; i++) buf[i] = 0;
+    u32 filled = 0;
+    const u32 padding_space = abi.input_memory_length % 136;
+    const bool needs_extra_padding_round = kind == ZKW_PRECOMPILE_KECCAK256 && padding_space == 0;
+    u64 rounds_left = num_rounds;
+    int state = 1;  // 0 GetRequestFromQueue, 1 RunRoundFunction, 2 RunPaddingRound, 3 Finished
+    if (kind == ZKW_PRECOMPILE_KECCAK256 && abi.input_memory_length == 0 && num_rounds == 1) state = 2;
+    u32 bad = 0;
+    for (u64 round = 0; round < num_rounds; round++) {
+        const bool is_last_round = round + 1 == num_rounds;
+        if (kind == ZKW_PRECOMPILE_SHA256) {
+            u32 w[16];
+            for (int k = 0; k < 2; k++) {
+                const zkw_mem_query* q = job.mem_q + qpos;
+                bad |= q->rw_flag;
+#pragma unroll
+                for (int j = 0; j < 8; j++) w[8 * k + j] = q->value[7 - j];
+                qpos++; reads++;
+                abi.input_memory_offset += 1;
+            }
+            sha256_compress(sha, w);
+            rounds_left--;
+        } else if (kind == ZKW_PRECOMPILE_ECRECOVER) {
+            for (int k = 0; k < 4; k++) bad |= job.mem_q[qpos + k].rw_flag;
+            for (int k = 4; k < 6; k++) bad |= !job.mem_q[qpos + k].rw_flag;
+            qpos += 6; reads += 4;
+        } else {
+            const bool paddings_round = needs_extra_padding_round && is_last_round;
+            for (int slot = 0; slot < ZKW_KECCAK_MEMORY_READS_PER_CYCLE; slot++) {
+                const u32 memory_index = abi.input_memory_offset / 32, unalignment = abi.input_memory_offset % 32;
+                const u32 at_most = 32 - unalignment;
+                const u32 meaningful = abi.input_memory_length >= at_most ? at_most : abi.input_memory_length;
+                const bool should_read = meaningful != 0 && filled + meaningful <= ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE;
+                if (!should_read) continue;
+                if (paddings_round || qpos + 1 >= qend) { bad = 1; break; }  // the last query of a request is its write
+                const zkw_mem_query* q = job.mem_q + qpos;
+                bad |= q->rw_flag | (q->index != memory_index);
+                abi.input_memory_offset += meaningful;
+                abi.input_memory_length -= meaningful;
+                uint8_t be[32];
+                word_be_bytes(q->value, be);
+                qpos++; reads++;
+                for (u32 j = 0; j < meaningful; j++) buf[filled + j] = be[unalignment + j];
+                filled += meaningful;
+            }
+            // consume::<136>, padding applied to the copy
+            u64 lanes[17];
+            for (int k = 0; k < 17; k++) {
+                u64 l = 0;
+                for (int b = 0; b < 8; b++) l |= (u64)buf[8 * k + b] << (8 * b);
+                lanes[k] = l;
+            }
+            filled = filled < 136 ? 0 : filled - 136;
+            for (int i = 0; i < ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE; i++)
+                buf[i] = i + 136 < ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE ? buf[i + 136] : 0;
+            if (is_last_round) {
+                const u32 at = needs_extra_padding_round ? 0 : padding_space;
+                // block[at] = 0x01 (or 0x81 when at == 135), block[135] = 0x80: the bytes being replaced are zero
+                // because the buffer is zero beyond `filled`
+                lanes[at >> 3] |= (u64)0x01 << (8 * (at & 7));
+                lanes[16] |= (u64)0x80 << 56;
+            }
+            for (int k = 0; k < 17; k++) kst[k] ^= lanes[k];
+            keccak_f1600(kst);
+            if (state == 1 && needs_extra_padding_round && round + 2 == num_rounds) state = 2;
+        }
+        if (is_last_round) {
+            if (kind != ZKW_PRECOMPILE_ECRECOVER) { bad |= !job.mem_q[qpos].rw_flag; qpos++; }
+            state = is_last_request ? 3 : 0;
+        }
+        const u64 g = g0 + round;
+        const bool cut = (g + 1) % job.capacity == 0 || g + 1 == job.total_rounds;
+        if (!cut) continue;
+        const bool early_termination = (g + 1) % job.capacity != 0;
+        PrecompileSnap* sn = job.snaps + g / job.capacity;
+        zkw_precompile_fsm f;
+        memset(&f, 0, sizeof f);
+        if (kind != ZKW_PRECOMPILE_ECRECOVER) {
+            f.completed = state == 3; f.read_words_for_round = state == 1; f.read_precompile_call = state == 0;
+            f.padding_round = state == 2;
+            f.timestamp_to_use_for_read = request.timestamp;
+            f.timestamp_to_use_for_write = request.timestamp + 1;
+            f.input_page = abi.memory_page_to_read; f.input_offset = abi.input_memory_offset;
+            f.output_page = abi.memory_page_to_write; f.output_offset = abi.output_memory_offset;
+            if (kind == ZKW_PRECOMPILE_SHA256) {
+                f.num_rounds = (u32)rounds_left;
+                if (early_termination) {  // Sha256 over one zero block, sha256_round_function.rs:283-296
+                    u32 e[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+                    u32 z[16];
+                    for (int j = 0; j < 16; j++) z[j] = 0;
+                    sha256_compress(e, z);
+                    for (int j = 0; j < 8; j++) f.sha256_inner_state[j] = e[j];
+                } else {
+                    for (int j = 0; j < 8; j++) f.sha256_inner_state[j] = sha[j];
+                }
+            } else {
+                f.input_length = abi.input_memory_length;
+                f.needs_full_padding_round = needs_extra_padding_round;
+                f.buffer_filled = filled;
+                u64 e[25];
+                if (early_termination) {  // keccak256_round_function.rs:376-394
+                    for (int i = 0; i < 25; i++) e[i] = 0;
+                    keccak_f1600(e);
+                } else {
+                    for (int i = 0; i < 25; i++) e[i] = kst[i];
+                    for (int i = 0; i < ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE; i++) f.buffer_bytes[i] = buf[i];
+                }
+                for (int idx = 0; idx < 25; idx++) {  // encode_kecca256_inner_state :530-541
+                    const int i = idx % 5, j = idx / 5;
+                    for (int b = 0; b < 8; b++) f.keccak_internal_state[(i * 5 + j) * 8 + b] = (uint8_t)(e[idx] >> (8 * b));
+                }
+            }
+        }
+        sn->fsm = f;
+        sn->popped = r + 1;
+        sn->queries_done = qpos;
+        sn->reads_done = reads;
+    }
+    if (bad || qpos != qend) atomicAdd(job.violations, 1u);
+}
+
+struct PrecompileBlock {
+    int kind;
+    const PrecompileSnap* snaps;
+    const u64* req_tails;  // [n_requests][4]
+    const u64* mem_tails;  // [n_queries][12]
+    zkw_precompile_instance* instances;
+    zkw_queue_state12 mem_in;
+    u64 n_requests, total_rounds, n_instances;
+    u32 capacity;
+};
+
+__global__ void k_precompile_instances(const PrecompileBlock* __restrict__ blk) {
+    const PrecompileBlock b = *blk;
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= b.n_instances) return;
+    const u64* req_final = b.n_requests ? b.req_tails + 4 * (b.n_requests - 1) : nullptr;
+    auto queues = [&](zkw_precompile_fsm& f, u64 popped, u64 queries_done) {
+        qs4(f.log_queue_state, popped ? b.req_tails + 4 * (popped - 1) : nullptr, req_final, (u32)(b.n_requests - popped));
+        qs12(f.memory_queue_state, b.mem_in.head, queries_done ? b.mem_tails + 12 * (queries_done - 1) : b.mem_in.tail,
+             b.mem_in.length + (u32)queries_done);
+    };
+    zkw_precompile_instance w;
+    memset(&w, 0, sizeof w);
+    if (b.n_requests == 0) {  // the dummy instance (keccak :88-157, sha256 :82-150, ecrecover :60-103)
+        w.start_flag = w.completion_flag = 1;
+        w.initial_memory_queue_state = b.mem_in;
+        w.final_memory_state = b.mem_in;
+        queues(w.hidden_fsm_input, 0, 0);
+        queues(w.hidden_fsm_output, 0, 0);
+        if (b.kind != ZKW_PRECOMPILE_ECRECOVER) {
+            w.hidden_fsm_input.read_precompile_call = 1;
+            w.hidden_fsm_output.completed = 1;
+            if (b.kind == ZKW_PRECOMPILE_SHA256) {
+                u32 e[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+                u32 z[16];
+                for (int j = 0; j < 16; j++) z[j] = 0;
+                sha256_compress(e, z);
+                for (int j = 0; j < 8; j++) w.hidden_fsm_output.sha256_inner_state[j] = e[j];
+            } else {
+                u64 e[25];
+                for (int i = 0; i < 25; i++) e[i] = 0;
+                keccak_f1600(e);
+                for (int id = 0; id < 25; id++)
+                    for (int by = 0; by < 8; by++)
+                        w.hidden_fsm_output.keccak_internal_state[((id % 5) * 5 + id / 5) * 8 + by] = (uint8_t)(e[id] >> (8 * by));
+            }
+        }
+        b.instances[0] = w;
+        return;
+    }
+    const PrecompileSnap out = b.snaps[idx];
+    u64 p0 = 0, q0 = 0, r0 = 0;
+    w.start_flag = idx == 0;
+    if (idx == 0) {
+        if (b.kind != ZKW_PRECOMPILE_ECRECOVER) w.hidden_fsm_input.read_precompile_call = 1;
+        qs4(w.initial_log_queue_state, nullptr, req_final, (u32)b.n_requests);
+        w.initial_memory_queue_state = b.mem_in;
+    } else {
+        const PrecompileSnap in = b.snaps[idx - 1];
+        w.hidden_fsm_input = in.fsm;
+        p0 = in.popped; q0 = in.queries_done; r0 = in.reads_done;
+    }
+    queues(w.hidden_fsm_input, p0, q0);
+    w.hidden_fsm_output = out.fsm;
+    queues(w.hidden_fsm_output, out.popped, out.queries_done);
+    w.first_request = p0; w.num_requests = out.popped - p0;
+    w.first_read = r0; w.num_reads = out.reads_done - r0;
+    w.first_round = idx * b.capacity;
+    w.num_rounds = (idx + 1 == b.n_instances ? b.total_rounds : (idx + 1) * b.capacity) - w.first_round;
+    if (idx + 1 == b.n_instances) {
+        w.completion_flag = 1;
+        w.final_memory_state = w.hidden_fsm_output.memory_queue_state;
+    }
+    b.instances[idx] = w;
+}
+
+}  // namespace zkw

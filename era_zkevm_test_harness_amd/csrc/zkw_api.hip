@@ -24,6 +24,7 @@
 #include "decommitter_kernels.cuh"
 #include "public_input_kernels.cuh"
 #include "callstack_kernels.cuh"
+#include "precompile_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -1981,4 +1982,143 @@ extern "C" int zkw_callstack_simulate(zkw_ctx* ctx, const uint8_t* is_push, size
     ZKW_TRY(ctx->finish_out(depth, d_dep, n_ops));
     ZKW_TRY(ctx->finish_out(entry_index, d_idx, n_ops));
     return ctx->sync_if_host();
+}
+
+// ------------------------------------------------------------------------------------------------ precompile round functions (a16)
+struct zkw_precompile_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n_requests = 0, n_queries = 0, total_rounds = 0, total_reads = 0, n_instances = 0;
+    u64 *mem_enc = nullptr, *mem_tails = nullptr;
+    zkw_precompile_instance* instances = nullptr;
+    void release() {
+        void* ptrs[] = {mem_enc, mem_tails, instances};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+};
+
+extern "C" int zkw_precompile_build(zkw_ctx* ctx, int kind, const zkw_log_query* requests, const uint64_t* request_tails,
+                                    size_t n_requests, const zkw_mem_query* mem_queries, size_t n_queries, uint32_t capacity,
+                                    const zkw_queue_state12* mem_in, zkw_precompile_witness** out) {
+    if (!ctx || !mem_in || !out || capacity == 0 || kind < ZKW_PRECOMPILE_KECCAK256 || kind > ZKW_PRECOMPILE_ECRECOVER ||
+        (n_requests && (!requests || !request_tails)) || (n_queries && !mem_queries))
+        return fail(ZKW_ERR_INVALID, "zkw_precompile_build: bad argument");
+    if (n_requests == 0 && n_queries) return fail(ZKW_ERR_INVALID, "memory queries without a precompile request");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const zkw_log_query* d_req = nullptr;
+    const u64* d_rt = nullptr;
+    const zkw_mem_query* d_mq = nullptr;
+    u64 *d_roff = nullptr, *d_qoff = nullptr, *d_rdoff = nullptr, *d_meta = nullptr;
+    u64 meta[4] = {0, 0, 0, 0};
+    if (n_requests) {
+        ZKW_TRY(ctx->in("pc_req", requests, n_requests, &d_req));
+        ZKW_TRY(ctx->in("pc_rt", request_tails, n_requests * 4, &d_rt));
+        if (n_queries) ZKW_TRY(ctx->in("pc_mq", mem_queries, n_queries, &d_mq));
+        ZKW_TRY(ctx->scratch_t<u64>("pc_roff", n_requests + 1, &d_roff));
+        ZKW_TRY(ctx->scratch_t<u64>("pc_qoff", n_requests + 1, &d_qoff));
+        ZKW_TRY(ctx->scratch_t<u64>("pc_rdoff", n_requests + 1, &d_rdoff));
+        ZKW_TRY(ctx->scratch_t<u64>("pc_meta", 4, &d_meta));
+        { Prof _p(ctx, "k_precompile_counts"); hipLaunchKernelGGL(k_precompile_counts, dim3(1), dim3(1024), 0, ctx->stream, kind, d_req, n_requests, d_roff, d_qoff, d_rdoff, d_meta); }
+        ZKW_TRY(launch_check("k_precompile_counts"));
+        HIP_TRY(hipMemcpyAsync(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (meta[3]) return fail(ZKW_ERR_INVALID, "a precompile request without rounds (the first round carries `new_request`)");
+        if (meta[1] != n_queries)
+            return fail(ZKW_ERR_INVALID, "the requests need %llu memory queries, %zu given", (unsigned long long)meta[1], n_queries);
+    }
+    zkw_precompile_witness* w = new zkw_precompile_witness();
+    w->ctx = ctx;
+    w->n_requests = n_requests;
+    w->n_queries = n_queries;
+    w->total_rounds = meta[0];
+    w->total_reads = meta[2];
+    w->n_instances = n_requests ? (w->total_rounds + capacity - 1) / capacity : 1;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    alloc((void**)&w->mem_enc, n_queries * 64);
+    alloc((void**)&w->mem_tails, n_queries * 96);
+    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_precompile_instance));
+    auto bail = [&](int rc) { w->release(); delete w; return rc; };
+    if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_precompile_build: hipMalloc failed: %s", hipGetErrorString(e)));
+    int rc = ZKW_OK;
+    PrecompileSnap* d_snaps = nullptr;
+    u32* d_viol = nullptr;
+    if ((rc = ctx->scratch_t<u32>("pc_viol", 1, &d_viol)) != ZKW_OK) return bail(rc);
+    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
+    if (n_requests) {
+        if ((rc = ctx->scratch_t<PrecompileSnap>("pc_snaps", w->n_instances, &d_snaps)) != ZKW_OK) return bail(rc);
+        if (n_queries) {
+            if ((rc = dev_encode(ctx, d_mq, n_queries, w->mem_enc)) != ZKW_OK) return bail(rc);
+            zkw_queue_state12* d_min = nullptr;
+            std::vector<zkw_queue_state12> minv(1, *mem_in);
+            if ((rc = ctx->upload("pc_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
+            std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, n_queries});
+            if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
+        }
+        PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity};
+        { Prof _p(ctx, "k_precompile_walk"); hipLaunchKernelGGL(k_precompile_walk, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
+        if ((rc = launch_check("k_precompile_walk")) != ZKW_OK) return bail(rc);
+    }
+    std::vector<PrecompileBlock> blk(1);
+    blk[0].kind = kind;
+    blk[0].snaps = d_snaps;
+    blk[0].req_tails = d_rt;
+    blk[0].mem_tails = w->mem_tails;
+    blk[0].instances = w->instances;
+    blk[0].mem_in = *mem_in;
+    blk[0].n_requests = n_requests;
+    blk[0].total_rounds = w->total_rounds;
+    blk[0].n_instances = w->n_instances;
+    blk[0].capacity = capacity;
+    PrecompileBlock* d_blk = nullptr;
+    if ((rc = ctx->upload("pc_block", blk, &d_blk)) != ZKW_OK) return bail(rc);
+    { Prof _p(ctx, "k_precompile_instances"); hipLaunchKernelGGL(k_precompile_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    if ((rc = launch_check("k_precompile_instances")) != ZKW_OK) return bail(rc);
+    u32 viol = 0;
+    if (hipMemcpyAsync(&viol, d_viol, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return bail(fail(ZKW_ERR_HIP, "readback failed"));
+    if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u requests whose memory queries do not fit their ABI (read/write flags, word "
+                                                     "index or count: the asserts of the round walks)", viol));
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" size_t zkw_precompile_witness_num_instances(const zkw_precompile_witness* w) { return w ? w->n_instances : 0; }
+extern "C" size_t zkw_precompile_witness_num_rounds(const zkw_precompile_witness* w) { return w ? w->total_rounds : 0; }
+static const void* pc_array(const zkw_precompile_witness* w, int what, size_t* bytes) {
+    switch (what) {
+        case ZKW_PRC_MEM_ENC: *bytes = w->n_queries * 64; return w->mem_enc;
+        case ZKW_PRC_MEM_TAILS: *bytes = w->n_queries * 96; return w->mem_tails;
+        case ZKW_PRC_INSTANCES: *bytes = w->n_instances * sizeof(zkw_precompile_instance); return w->instances;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_precompile_witness_bytes(const zkw_precompile_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)pc_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_precompile_witness_device_ptr(const zkw_precompile_witness* w, int what) {
+    size_t b = 0;
+    return w ? pc_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_precompile_witness_get(const zkw_precompile_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_precompile_witness_get: null argument");
+    if (what < 0 || what > ZKW_PRC_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    size_t bytes = 0;
+    const void* src = pc_array(w, what, &bytes);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_precompile_witness_free(zkw_precompile_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    delete w;
 }

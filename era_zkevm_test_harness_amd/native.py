@@ -83,6 +83,13 @@ SYMBOLS = [
     ("zkw_decommitter_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_decommitter_witness_free", None, [_vp]),
     ("zkw_linear_keccak256", _int, [_vp, _vp, _sz, _vp]),
+    ("zkw_precompile_build", _int, [_vp, _int, _vp, _vp, _sz, _vp, _sz, C.c_uint32, _vp, _vp]),
+    ("zkw_precompile_witness_num_instances", _sz, [_vp]),
+    ("zkw_precompile_witness_num_rounds", _sz, [_vp]),
+    ("zkw_precompile_witness_bytes", _sz, [_vp, _int]),
+    ("zkw_precompile_witness_device_ptr", _vp, [_vp, _int]),
+    ("zkw_precompile_witness_get", _int, [_vp, _int, _vp, _sz]),
+    ("zkw_precompile_witness_free", None, [_vp]),
     ("zkw_encode_callstack_entries", _int, [_vp, _vp, _sz, _vp]),
     ("zkw_callstack_simulate", _int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("zkw_commit_encodings", _int, [_vp, _vp, _sz, C.c_uint32, _vp]),
@@ -355,6 +362,62 @@ DECOMMITTER_INSTANCE = np.dtype(
      ("hidden_fsm_input", DECOMMITTER_FSM), ("hidden_fsm_output", DECOMMITTER_FSM), ("first_round", "<u8"),
      ("num_rounds", "<u8"), ("first_request", "<u8"), ("num_requests", "<u8"), ("first_word", "<u8"), ("num_words", "<u8")])
 DCM_MEM_QUERIES, DCM_MEM_ENC, DCM_MEM_TAILS, DCM_ROUND_STATES, DCM_INSTANCES = range(5)
+PRECOMPILE_KECCAK256, PRECOMPILE_SHA256, PRECOMPILE_ECRECOVER = range(3)
+PRECOMPILE_FSM = np.dtype(
+    [("log_queue_state", QUEUE_STATE4), ("memory_queue_state", QUEUE_STATE12), ("read_precompile_call", "u1"),
+     ("read_words_for_round", "u1"), ("padding_round", "u1"), ("completed", "u1"), ("timestamp_to_use_for_read", "<u4"),
+     ("timestamp_to_use_for_write", "<u4"), ("input_page", "<u4"), ("input_offset", "<u4"), ("input_length", "<u4"),
+     ("output_page", "<u4"), ("output_offset", "<u4"), ("num_rounds", "<u4"), ("needs_full_padding_round", "<u4"),
+     ("buffer_filled", "<u4"), ("sha256_inner_state", "<u4", (8,)), ("keccak_internal_state", "u1", (200,)),
+     ("buffer_bytes", "u1", (192,)), ("_pad", "<u4")])
+PRECOMPILE_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_log_queue_state", QUEUE_STATE4),
+     ("initial_memory_queue_state", QUEUE_STATE12), ("final_memory_state", QUEUE_STATE12),
+     ("hidden_fsm_input", PRECOMPILE_FSM), ("hidden_fsm_output", PRECOMPILE_FSM), ("first_request", "<u8"),
+     ("num_requests", "<u8"), ("first_read", "<u8"), ("num_reads", "<u8"), ("first_round", "<u8"), ("num_rounds", "<u8")])
+assert PRECOMPILE_FSM.itemsize == 744 and PRECOMPILE_INSTANCE.itemsize == 2016
+PRC_MEM_ENC, PRC_MEM_TAILS, PRC_INSTANCES = range(3)
+
+
+class PrecompileWitness:
+    """Owner of a zkw_precompile_witness handle (keccak256 / sha256 / ecrecover round-function instances)."""
+
+    _DTYPES = {PRC_INSTANCES: PRECOMPILE_INSTANCE}
+    _SHAPES = {PRC_MEM_ENC: (-1, 8), PRC_MEM_TAILS: (-1, 12)}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = C.c_void_p(None)
+
+    @property
+    def num_instances(self):
+        return load().zkw_precompile_witness_num_instances(self.handle)
+
+    @property
+    def num_rounds(self):
+        return load().zkw_precompile_witness_num_rounds(self.handle)
+
+    def get(self, what):
+        lib = load()
+        nbytes = lib.zkw_precompile_witness_bytes(self.handle, what)
+        dt = self._DTYPES.get(what, np.dtype("<u8"))
+        out = np.zeros(nbytes // dt.itemsize, dt)
+        if nbytes:
+            _check(lib.zkw_precompile_witness_get(self.handle, what, _np_ptr(out), nbytes))
+        shape = self._SHAPES.get(what)
+        return out.reshape(shape) if shape else out
+
+    def free(self):
+        if self.handle:
+            load().zkw_precompile_witness_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
 
 
 class DecommitterWitness:
@@ -778,3 +841,26 @@ class Context:
                                              _np_ptr(o["previous_state"]), _np_ptr(o["new_state"]), _np_ptr(o["depth"]),
                                              _np_ptr(o["round_states"]), _np_ptr(o["entry_index"])))
         return o
+
+    def _precompile(self, kind, requests, request_tails, mem_queries, num_rounds_per_circuit, mem_in):
+        req = np.ascontiguousarray(requests, dtype=LOG_QUERY)
+        rt = _u64(request_tails)
+        mq = np.ascontiguousarray(mem_queries, dtype=MEM_QUERY)
+        mi = np.ascontiguousarray(mem_in, dtype=QUEUE_STATE12)
+        w = PrecompileWitness(self)
+        _check(load().zkw_precompile_build(self.handle, kind, _np_ptr(req) if req.size else None,
+                                           _np_ptr(rt) if req.size else None, req.size, _np_ptr(mq) if mq.size else None,
+                                           mq.size, num_rounds_per_circuit, _np_ptr(mi), C.byref(w.handle)))
+        return w
+
+    def keccak256_decompose_into_per_circuit_witness(self, requests, request_tails, mem_queries, num_rounds_per_circuit, mem_in):
+        """keccak256_round_function.rs:23-528 -> PrecompileWitness."""
+        return self._precompile(PRECOMPILE_KECCAK256, requests, request_tails, mem_queries, num_rounds_per_circuit, mem_in)
+
+    def sha256_decompose_into_per_circuit_witness(self, requests, request_tails, mem_queries, num_rounds_per_circuit, mem_in):
+        """sha256_round_function.rs:23-406 -> PrecompileWitness."""
+        return self._precompile(PRECOMPILE_SHA256, requests, request_tails, mem_queries, num_rounds_per_circuit, mem_in)
+
+    def ecrecover_decompose_into_per_circuit_witness(self, requests, request_tails, mem_queries, num_rounds_per_circuit, mem_in):
+        """ecrecover.rs:12-262 -> PrecompileWitness."""
+        return self._precompile(PRECOMPILE_ECRECOVER, requests, request_tails, mem_queries, num_rounds_per_circuit, mem_in)

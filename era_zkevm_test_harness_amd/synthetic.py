@@ -247,3 +247,56 @@ def callstack_trace(n_ops, seed=0, max_depth=40, final_unwind=True):
     e["this_address"][kernel, 1:] = 0
     e["this_address"][kernel, 0] &= 0xFFFF
     return ops, e
+
+
+def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
+    """Requests of one precompile (0 keccak256, 1 sha256, 2 ecrecover) with the memory queries the VM would have
+    made for them, in the order the reference flattens them (reads round by round, then the write(s))."""
+    from .native import LOG_QUERY, MEM_QUERY
+
+    rng = np.random.default_rng(seed)
+    req = random_log_queries(max(n_requests, 1), seed=seed + 1)[:n_requests]
+    req["timestamp"] = np.sort(rng.integers(1, 1 << 30, n_requests).astype(np.uint32) * 2)
+    qs = []
+
+    def query(ts, page, index, rw):
+        m = np.zeros(1, MEM_QUERY)
+        m["timestamp"], m["page"], m["index"], m["rw_flag"] = ts, page, index, rw
+        m["value"] = rng.integers(0, 1 << 32, 8, dtype=np.uint64).astype(np.uint32)
+        return m
+
+    for k in range(n_requests):
+        ts = int(req["timestamp"][k])
+        page_r, page_w = int(rng.integers(8, 1 << 20)), int(rng.integers(8, 1 << 20))
+        out_off = int(rng.integers(0, 1 << 16))
+        key = np.zeros(8, np.uint32)
+        key[2], key[3], key[4], key[5] = out_off, 1, page_r, page_w
+        if kind == 1:
+            rounds = int(rng.integers(1, max_rounds + 1))
+            in_off = int(rng.integers(0, 1 << 16))
+            key[0], key[1], key[6] = in_off, 2 * rounds, rounds
+            for r in range(2 * rounds):
+                qs.append(query(ts, page_r, in_off + r, 0))
+            qs.append(query(ts + 1, page_w, out_off, 1))
+        elif kind == 2:
+            in_off = int(rng.integers(0, 1 << 16))
+            key[0], key[1], key[3] = in_off, 4, 2
+            for r in range(4):
+                qs.append(query(ts, page_r, in_off + r, 0))
+            for r in range(2):
+                qs.append(query(ts + 1, page_w, out_off + r, 1))
+        else:
+            # lengths around the interesting edges: empty, one byte short of / exactly / one past whole blocks
+            choices = [0, 1, 31, 32, 33, 135, 136, 137, 271, 272, 273, 136 * max_rounds]
+            length = int(rng.choice(choices)) if rng.random() < 0.6 else int(rng.integers(0, 136 * max_rounds + 1))
+            in_off = int(rng.integers(0, 1 << 12))
+            if rng.random() < 0.3:
+                in_off = in_off // 32 * 32 + int(rng.choice([0, 31]))
+            key[0], key[1] = in_off, length
+            if length:
+                for wi in range(in_off // 32, (in_off + length - 1) // 32 + 1):
+                    qs.append(query(ts, page_r, wi, 0))
+            qs.append(query(ts + 1, page_w, out_off, 1))
+        req["key"][k] = key
+    mq = np.concatenate(qs) if qs else np.zeros(0, MEM_QUERY)
+    return req, mq

@@ -294,6 +294,34 @@ const void *zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness *w,
 int zkw_decommitter_witness_get(const zkw_decommitter_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_decommitter_witness_free(zkw_decommitter_witness *w);
 
+/* ---- keccak256 / sha256 / ecrecover round-function witness builders (a16) ---------------------------- */
+typedef struct zkw_precompile_witness zkw_precompile_witness;
+/* kind = ZKW_PRECOMPILE_KECCAK256: keccak256_decompose_into_per_circuit_witness,
+                                    src/witness/individual_circuits/keccak256_round_function.rs:23-528
+          ZKW_PRECOMPILE_SHA256:    sha256_decompose_into_per_circuit_witness, .../sha256_round_function.rs:23-406
+          ZKW_PRECOMPILE_ECRECOVER: ecrecover_decompose_into_per_circuit_witness, .../ecrecover.rs:12-262
+   requests / request_tails: the demuxed precompile queue and its states (ZKW_DMX_OUT_QUERIES / _NEW_TAILS of
+   that queue, pushed from the empty queue). mem_queries: the memory accesses of all requests back to back in
+   the order the reference flattens the VM's round witnesses (keccak :44-65, sha256 :45-59, ecrecover :31-41):
+   per request its reads round by round, then its write(s); n_queries must equal what the requests' ABIs imply.
+   capacity = rounds per instance; mem_in (host): state of the global memory queue before the call. The queries
+   are appended to that queue (ZKW_PRC_MEM_*). With n_requests == 0 one dummy instance is produced.
+   ZKW_ERR_CHECK_FAILED when a query contradicts its request (read/write flag, keccak word index). */
+int zkw_precompile_build(zkw_ctx *ctx, int kind, const zkw_log_query *requests, const uint64_t *request_tails,
+                         size_t n_requests, const zkw_mem_query *mem_queries, size_t n_queries, uint32_t capacity,
+                         const zkw_queue_state12 *mem_in, zkw_precompile_witness **out);
+enum {
+    ZKW_PRC_MEM_ENC = 0,   /* uint64_t[n_queries][8]  */
+    ZKW_PRC_MEM_TAILS = 1, /* uint64_t[n_queries][12] */
+    ZKW_PRC_INSTANCES = 2  /* zkw_precompile_instance[max(1, ceil(total_rounds/capacity))] */
+};
+size_t zkw_precompile_witness_num_instances(const zkw_precompile_witness *w);
+size_t zkw_precompile_witness_num_rounds(const zkw_precompile_witness *w);
+size_t zkw_precompile_witness_bytes(const zkw_precompile_witness *w, int what);
+const void *zkw_precompile_witness_device_ptr(const zkw_precompile_witness *w, int what);
+int zkw_precompile_witness_get(const zkw_precompile_witness *w, int what, void *dst, size_t dst_bytes);
+void zkw_precompile_witness_free(zkw_precompile_witness *w);
+
 /* ---- callstack (a3 / a6) ------------------------------------------------------------------------------ */
 /* ExtendedCallstackEntry::encoding_witness, circuit_encodings/src/callstack_entry.rs:36-179. enc: n*32 */
 int zkw_encode_callstack_entries(zkw_ctx *ctx, const zkw_callstack_entry *entries, size_t n, uint64_t *enc);

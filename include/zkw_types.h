@@ -320,6 +320,59 @@ typedef struct zkw_decommitter_instance {
     uint64_t first_word, num_words;       /* code words consumed = code_words (flattened) */
 } zkw_decommitter_instance;
 
+/* ---- precompile round-function circuits: keccak256 / sha256 / ecrecover (a16) ------------------------ */
+/* zk_evm_abstractions::precompiles::keccak256::{KECCAK_RATE_BYTES, MEMORY_READS_PER_CYCLE,
+   KECCAK_PRECOMPILE_BUFFER_SIZE} (used at src/witness/individual_circuits/keccak256_round_function.rs:214-221).
+   The crate is absent from the reference tree; values as in zk_evm_abstractions v1.4.1 (inferred: a round must
+   find 136 bytes after at most MEMORY_READS_PER_CYCLE unaligned 32-byte reads, which needs 6 reads; the buffer
+   holds MEMORY_READS_PER_CYCLE words). */
+#define ZKW_KECCAK_RATE_BYTES 136
+#define ZKW_KECCAK_MEMORY_READS_PER_CYCLE 6
+#define ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE 192
+
+enum { ZKW_PRECOMPILE_KECCAK256 = 0, ZKW_PRECOMPILE_SHA256 = 1, ZKW_PRECOMPILE_ECRECOVER = 2 };
+
+/* {Keccak256,Sha256}RoundFunctionFSMInputOutputWitness / EcrecoverCircuitFSMInputOutputWitness: the two queue
+   states + the internal FSM (keccak256_round_function.rs:420-441, sha256_round_function.rs:302-316; ecrecover
+   has no internal part, ecrecover.rs:226-233). Fields a circuit does not have stay zero. */
+typedef struct zkw_precompile_fsm {
+    zkw_queue_state4 log_queue_state;
+    zkw_queue_state12 memory_queue_state;
+    uint8_t read_precompile_call;
+    uint8_t read_words_for_round; /* keccak: read_unaligned_words_for_round */
+    uint8_t padding_round;        /* keccak only */
+    uint8_t completed;
+    uint32_t timestamp_to_use_for_read;
+    uint32_t timestamp_to_use_for_write;
+    /* precompile_call_params */
+    uint32_t input_page;
+    uint32_t input_offset;  /* sha256: word index of the next read; keccak: input_memory_byte_offset */
+    uint32_t input_length;  /* keccak: input_memory_byte_length (bytes left) */
+    uint32_t output_page;
+    uint32_t output_offset;
+    uint32_t num_rounds;    /* sha256: rounds left */
+    uint32_t needs_full_padding_round; /* keccak only */
+    uint32_t buffer_filled;            /* keccak only */
+    uint32_t sha256_inner_state[8];
+    uint8_t keccak_internal_state[200]; /* [5][5][8]: [x][y] = lane (x, y) little-endian, keccak256_round_function.rs:530-541 */
+    uint8_t buffer_bytes[ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE];
+    uint32_t _pad;
+} zkw_precompile_fsm;
+
+/* {Keccak256RoundFunction,Sha256RoundFunction,Ecrecover}CircuitInstanceWitness */
+typedef struct zkw_precompile_instance {
+    uint32_t start_flag;
+    uint32_t completion_flag;
+    zkw_queue_state4 initial_log_queue_state;     /* observable_input, first instance only (else placeholder) */
+    zkw_queue_state12 initial_memory_queue_state; /* observable_input, first instance only */
+    zkw_queue_state12 final_memory_state;         /* observable_output, last instance only */
+    zkw_precompile_fsm hidden_fsm_input;
+    zkw_precompile_fsm hidden_fsm_output;
+    uint64_t first_request, num_requests; /* requests_queue_witness: items of the demuxed request queue */
+    uint64_t first_read, num_reads;       /* memory_reads_witness: values of the READ queries, in queue order */
+    uint64_t first_round, num_rounds;
+} zkw_precompile_instance;
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,6 +152,11 @@ int64_t orc_decommitter_build(const zkw_decommit_query *requests, const uint64_t
    digest of the words (each big-endian) with the 4 most significant bytes replaced by `top4` */
 void orc_bytecode_hash(const uint32_t *words, size_t n_words, uint32_t top_limb, uint32_t hash_out[8]);
 
+/* ---- keccak256 / sha256 / ecrecover round-function builders (a16), see precompiles.c */
+int64_t orc_precompile_build(int kind, const zkw_log_query *requests, const uint64_t *req_tails, size_t n_req,
+                             const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,
+                             uint64_t *mem_enc, uint64_t *mem_tails, zkw_precompile_instance *instances);
+
 /* ---- callstack (a3 / a6), see callstack.c */
 void orc_encode_callstack_entry(const zkw_callstack_entry *e, uint64_t out[32]);
 void orc_encode_callstack_entries(const zkw_callstack_entry *e, size_t n, uint64_t *out /* n*32 */);

@@ -135,6 +135,22 @@ def lib():
     return _lib
 
 
+PRECOMPILE_KECCAK256, PRECOMPILE_SHA256, PRECOMPILE_ECRECOVER = range(3)
+PRECOMPILE_FSM = np.dtype(
+    [("log_queue_state", QUEUE_STATE4), ("memory_queue_state", QUEUE_STATE12), ("read_precompile_call", "u1"),
+     ("read_words_for_round", "u1"), ("padding_round", "u1"), ("completed", "u1"), ("timestamp_to_use_for_read", "<u4"),
+     ("timestamp_to_use_for_write", "<u4"), ("input_page", "<u4"), ("input_offset", "<u4"), ("input_length", "<u4"),
+     ("output_page", "<u4"), ("output_offset", "<u4"), ("num_rounds", "<u4"), ("needs_full_padding_round", "<u4"),
+     ("buffer_filled", "<u4"), ("sha256_inner_state", "<u4", (8,)), ("keccak_internal_state", "u1", (200,)),
+     ("buffer_bytes", "u1", (192,)), ("_pad", "<u4")])
+PRECOMPILE_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_log_queue_state", QUEUE_STATE4),
+     ("initial_memory_queue_state", QUEUE_STATE12), ("final_memory_state", QUEUE_STATE12),
+     ("hidden_fsm_input", PRECOMPILE_FSM), ("hidden_fsm_output", PRECOMPILE_FSM), ("first_request", "<u8"),
+     ("num_requests", "<u8"), ("first_read", "<u8"), ("num_reads", "<u8"), ("first_round", "<u8"), ("num_rounds", "<u8")])
+assert PRECOMPILE_FSM.itemsize == 744 and PRECOMPILE_INSTANCE.itemsize == 2016
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -519,3 +535,30 @@ def callstack_simulate(is_push, pushed):
     if rc != 0:
         raise RuntimeError(f"orc_callstack_simulate failed: {rc}")
     return o
+
+
+def precompile_build(kind, requests, request_tails, mem_queries, capacity, mem_in, max_instances=None):
+    req = np.ascontiguousarray(requests, dtype=LOG_QUERY)
+    rt = _u64(request_tails)
+    mq = np.ascontiguousarray(mem_queries, dtype=MEM_QUERY)
+    mem_in = np.ascontiguousarray(mem_in, dtype=QUEUE_STATE12)
+    n_inst = max_instances if max_instances is not None else mq.size + req.size + 1  # upper bound on rounds
+    o = dict(mem_enc=np.zeros((mq.size, 8), np.uint64), mem_tails=np.zeros((mq.size, 12), np.uint64),
+             instances=np.zeros(n_inst, PRECOMPILE_INSTANCE))
+    f = lib().orc_precompile_build
+    f.restype = C.c_int64
+    rc = f(C.c_int(kind), _p(req), _p(rt), C.c_size_t(req.size), _p(mq), C.c_size_t(mq.size), C.c_uint32(capacity),
+           _p(mem_in), _p(o["mem_enc"]), _p(o["mem_tails"]), _p(o["instances"]))
+    if rc < 0:
+        raise RuntimeError(f"orc_precompile_build failed: {rc}")
+    o["instances"] = o["instances"][:rc]
+    return o
+
+
+def sha256_compress_chain(data: bytes) -> np.ndarray:
+    """SHA-256 state after compressing the 64-byte blocks of `data` (no padding)."""
+    st = (C.c_uint32 * 8).in_dll(lib(), "ORC_SHA256_IV")
+    state = np.array(list(st), np.uint32)
+    for i in range(0, len(data), 64):
+        lib().orc_sha256_compress(_p(state), C.c_char_p(data[i:i + 64]))
+    return state

@@ -59,6 +59,7 @@ def test_record_layouts_match_header():
     int main(void){
       printf("%zu %zu %zu %zu\n", sizeof(zkw_mem_query), sizeof(zkw_queue_state12), sizeof(zkw_ram_fsm), sizeof(zkw_ram_instance));
       printf("%zu %zu %zu %zu\n", sizeof(zkw_callstack_entry), offsetof(zkw_callstack_entry, pc), sizeof(zkw_log_query), sizeof(zkw_decommit_query));
+      printf("%zu %zu %zu %zu\n", sizeof(zkw_precompile_fsm), sizeof(zkw_precompile_instance), offsetof(zkw_precompile_fsm, buffer_bytes), offsetof(zkw_precompile_instance, first_request));
       printf("%zu %zu %zu %zu\n", offsetof(zkw_mem_query, value), offsetof(zkw_ram_fsm, previous_sorting_key),
              offsetof(zkw_ram_instance, hidden_fsm_input), offsetof(zkw_ram_instance, first_item));
       return 0; }
@@ -75,10 +76,12 @@ def test_record_layouts_match_header():
         assert sizes[:4] == [mod.MEM_QUERY.itemsize, mod.QUEUE_STATE12.itemsize, mod.RAM_FSM.itemsize, mod.RAM_INSTANCE.itemsize]
         assert sizes[4:8] == [mod.CALLSTACK_ENTRY.itemsize, mod.CALLSTACK_ENTRY.fields["pc"][1], mod.LOG_QUERY.itemsize,
                               mod.DECOMMIT_QUERY.itemsize]
-        assert sizes[8] == mod.MEM_QUERY.fields["value"][1]
-        assert sizes[9] == mod.RAM_FSM.fields["previous_sorting_key"][1]
-        assert sizes[10] == mod.RAM_INSTANCE.fields["hidden_fsm_input"][1]
-        assert sizes[11] == mod.RAM_INSTANCE.fields["first_item"][1]
+        assert sizes[8:12] == [mod.PRECOMPILE_FSM.itemsize, mod.PRECOMPILE_INSTANCE.itemsize,
+                               mod.PRECOMPILE_FSM.fields["buffer_bytes"][1], mod.PRECOMPILE_INSTANCE.fields["first_request"][1]]
+        assert sizes[12] == mod.MEM_QUERY.fields["value"][1]
+        assert sizes[13] == mod.RAM_FSM.fields["previous_sorting_key"][1]
+        assert sizes[14] == mod.RAM_INSTANCE.fields["hidden_fsm_input"][1]
+        assert sizes[15] == mod.RAM_INSTANCE.fields["first_item"][1]
 
 
 def test_synthetic_trace_is_valid_memory():

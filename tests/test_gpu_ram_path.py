@@ -459,3 +459,39 @@ def test_callstack_pop_from_empty(ctx):
     with pytest.raises(native.ZkwError) as ei:
         ctx.callstack_simulate(bad, e)
     assert ei.value.code == native.ERR_INVALID
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("n_req,capacity", [(0, 5), (1, 1), (40, 3), (40, 7), (300, 293), (300, 100000)])
+def test_precompile_builders(ctx, oracle, kind, n_req, capacity):
+    from era_zkevm_test_harness_amd import native
+
+    req, mq = synthetic.precompile_trace(kind, n_req, seed=7 * n_req + kind, max_rounds=6)
+    new = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1] if n_req else np.zeros((0, 4), np.uint64)
+    mem_in = np.zeros(1, native.QUEUE_STATE12)
+    mem_in["tail"] = synthetic.random_field_elements(n_req + 3, (12,))
+    mem_in["length"] = 12345
+    o = oracle.precompile_build(kind, req, new, mq, capacity, mem_in)
+    w = ctx._precompile(kind, req, new, mq, capacity, mem_in)
+    assert w.num_instances == o["instances"].size
+    assert np.array_equal(w.get(native.PRC_MEM_ENC), o["mem_enc"])
+    assert np.array_equal(w.get(native.PRC_MEM_TAILS), o["mem_tails"])
+    gi = w.get(native.PRC_INSTANCES)
+    for name in gi.dtype.names:
+        assert gi[name].tobytes() == o["instances"][name].tobytes(), name
+
+
+def test_precompile_builder_rejects_inconsistent_queries(ctx, oracle):
+    from era_zkevm_test_harness_amd import native
+
+    req, mq = synthetic.precompile_trace(0, 10, seed=5)
+    new = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    mem_in = np.zeros(1, native.QUEUE_STATE12)
+    with pytest.raises(native.ZkwError) as ei:
+        ctx._precompile(0, req, new, mq[:-1], 3, mem_in)
+    assert ei.value.code == native.ERR_INVALID
+    bad = mq.copy()
+    bad["rw_flag"][-1] = 0
+    with pytest.raises(native.ZkwError) as ei:
+        ctx._precompile(0, req, new, bad, 3, mem_in)
+    assert ei.value.code == native.ERR_CHECK_FAILED

@@ -453,3 +453,60 @@ def test_callstack_oracle(oracle):
     assert np.array_equal(o["previous_state"][1:], o["new_state"][:-1])
     with pytest.raises(RuntimeError):
         oracle.callstack_simulate(np.array([1, 0, 0], np.uint8), e[:1])
+
+
+def _word_be(value):
+    return b"".join(int(x).to_bytes(4, "big") for x in value[::-1])
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_precompile_builders_oracle(oracle, kind):
+    req, mq = synthetic.precompile_trace(kind, 25, seed=40 + kind)
+    _, new = oracle.queue_push_chain_log(oracle.encode_log_queries(req))
+    mem_in = np.zeros(1, oracle.QUEUE_STATE12)
+    mem_in["tail"] = synthetic.random_field_elements(5, (12,))
+    mem_in["length"] = 1000
+    one = oracle.precompile_build(kind, req, new, mq, 1, mem_in)["instances"]  # an instance per round
+    for cap in (3, 1000):
+        inst = oracle.precompile_build(kind, req, new, mq, cap, mem_in)["instances"]
+        assert inst["num_rounds"].sum() == one.size and inst["num_requests"].sum() == req.size
+        assert inst["num_reads"].sum() == int((mq["rw_flag"] == 0).sum())
+        assert inst[0]["start_flag"] == 1 and inst[-1]["completion_flag"] == 1 and inst["start_flag"].sum() == 1
+        # FSM chaining
+        assert inst["hidden_fsm_output"][:-1].tobytes() == inst["hidden_fsm_input"][1:].tobytes()
+        last = inst[-1]["hidden_fsm_output"]
+        assert last["memory_queue_state"]["length"] == 1000 + mq.size and last["log_queue_state"]["length"] == 0
+        if kind != 2:
+            assert last["completed"] == 1
+    if kind == 0:
+        # the sponge state after a request's last round is Keccak-256 of its input: pins the buffer / padding walk
+        # against the public hash
+        qpos, g = 0, 0
+        for k in range(req.size):
+            off, length = int(req["key"][k][0]), int(req["key"][k][1])
+            n_words = (off + length - 1) // 32 - off // 32 + 1 if length else 0
+            data = b"".join(_word_be(mq["value"][qpos + i]) for i in range(n_words))[off % 32:off % 32 + length]
+            qpos += n_words + 1
+            g += (length + 135) // 136 + (1 if length % 136 == 0 else 0)
+            st = one[g - 1]["hidden_fsm_output"]["keccak_internal_state"].reshape(5, 5, 8)
+            if k + 1 < req.size:  # the very last instance shows the state over an empty block instead (early termination n/a: cap 1)
+                digest = b"".join(st[x, 0].tobytes() for x in range(4))
+                assert digest == oracle.keccak256(data), k
+    if kind == 1:
+        qpos, g = 0, 0
+        for k in range(req.size):
+            rounds = int(req["key"][k][6])
+            data = b"".join(_word_be(mq["value"][qpos + i]) for i in range(2 * rounds))
+            qpos += 2 * rounds + 1
+            g += rounds
+            st = one[g - 1]["hidden_fsm_output"]["sha256_inner_state"]
+            assert np.array_equal(st, oracle.sha256_compress_chain(data)), k
+    # no requests: one dummy instance
+    d = oracle.precompile_build(kind, req[:0], new[:0], mq[:0], 7, mem_in)["instances"]
+    assert d.size == 1 and d[0]["start_flag"] == 1 and d[0]["completion_flag"] == 1
+    assert d[0]["final_memory_state"].tobytes() == mem_in[0].tobytes()
+    # a read where a write is expected
+    bad = mq.copy()
+    bad["rw_flag"][-1] = 0
+    with pytest.raises(RuntimeError):
+        oracle.precompile_build(kind, req, new, bad, 3, mem_in)
