@@ -25,6 +25,7 @@
 #include "public_input_kernels.cuh"
 #include "callstack_kernels.cuh"
 #include "precompile_kernels.cuh"
+#include "storage_application_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -2116,6 +2117,172 @@ extern "C" int zkw_precompile_witness_get(const zkw_precompile_witness* w, int w
     return ctx->sync_if_host();
 }
 extern "C" void zkw_precompile_witness_free(zkw_precompile_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    delete w;
+}
+
+// ------------------------------------------------------------------------------------------------ storage application (a17)
+struct zkw_storage_application_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n = 0, n_instances = 0;
+    u32 *keys = nullptr, *paths = nullptr, *roots = nullptr;
+    u64* leaf_indexes = nullptr;
+    zkw_storage_application_instance* instances = nullptr;
+    void release() {
+        void* ptrs[] = {keys, paths, roots, leaf_indexes, instances};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+};
+
+extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* queries, const uint64_t* query_tails, size_t n,
+                                             const uint64_t* init_leaf_indexes, const uint8_t* init_merkle_paths,
+                                             const uint8_t initial_root[32], uint64_t initial_next_enumeration_index,
+                                             uint32_t capacity, zkw_storage_application_witness** out) {
+    if (!ctx || !out || !initial_root || capacity < 2 || (n && (!queries || !query_tails || !init_leaf_indexes || !init_merkle_paths)))
+        return fail(ZKW_ERR_INVALID, "zkw_storage_application_build: bad argument");
+    if (n >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many storage queries");
+    HIP_TRY(hipSetDevice(ctx->device));
+    zkw_storage_application_witness* w = new zkw_storage_application_witness();
+    w->ctx = ctx;
+    w->n = n;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    alloc((void**)&w->keys, n * 32);
+    alloc((void**)&w->paths, n * 256 * 32);
+    alloc((void**)&w->roots, n * 32);
+    alloc((void**)&w->leaf_indexes, n * 8);
+    auto bail = [&](int rc) { w->release(); delete w; return rc; };
+    if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed: %s", hipGetErrorString(e)));
+    int rc = ZKW_OK;
+    SapJob job;
+    memset(&job, 0, sizeof job);
+    const u64* d_qt = nullptr;
+    const uint8_t* d_ip = nullptr;
+    u64 *d_snap = nullptr, *d_meta = nullptr;
+    uint8_t* d_hash = nullptr;
+    u32* d_viol = nullptr;
+    auto TRY = [&](int r) { if (rc == ZKW_OK) rc = r; };
+    if (n) {
+        TRY(ctx->in("sap_q", queries, n, &job.queries));
+        TRY(ctx->in("sap_qt", query_tails, n * 4, &d_qt));
+        TRY(ctx->in("sap_ii", init_leaf_indexes, n, &job.init_index));
+        TRY(ctx->in("sap_ip", init_merkle_paths, n * 256 * 32, &d_ip));
+    }
+    job.init_paths = reinterpret_cast<const u32*>(d_ip);
+    job.keys = w->keys; job.paths = w->paths; job.roots = w->roots;
+    TRY(ctx->scratch_t<u64>("sap_newidx", n + 1, &job.new_index));
+    TRY(ctx->scratch_t<u32>("sap_prevw", n + 1, &job.prev_write));
+    TRY(ctx->scratch_t<u32>("sap_chunk", n + 1, &job.chunk_of));
+    TRY(ctx->scratch_t<u32>("sap_fwu", n + 1, &job.first_writes_upto));
+    TRY(ctx->scratch_t<u64>("sap_cend", n + 2, &job.chunk_end));
+    TRY(ctx->scratch_t<u32>("sap_jstar", (n + 1) * 256, &job.jstar));
+    TRY(ctx->scratch_t<u32>("sap_A0", (n + 1) * 8, &job.A0));
+    TRY(ctx->scratch_t<u32>("sap_A1", (n + 1) * 8, &job.A1));
+    TRY(ctx->scratch_t<u32>("sap_C0", (n + 1) * 8, &job.C0));
+    TRY(ctx->scratch_t<u32>("sap_C1", (n + 1) * 8, &job.C1));
+    TRY(ctx->scratch_t<u32>("sap_viol", 1, &d_viol));
+    TRY(ctx->scratch_t<u64>("sap_meta", 2, &d_meta));
+    TRY(ctx->scratch_t<u64>("sap_snap", (n + 1) * 25, &d_snap));
+    TRY(ctx->scratch_t<uint8_t>("sap_hash", 32, &d_hash));
+    if (rc != ZKW_OK) return bail(rc);
+    job.violations = d_viol;
+    job.meta = d_meta;
+    job.n = n;
+    job.next_enumeration_index = initial_next_enumeration_index;
+    memcpy(job.initial_root, initial_root, 32);
+    job.capacity = capacity;
+    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
+    u64 meta[2] = {1, initial_next_enumeration_index};
+    if (n) {
+        const unsigned g64 = blocks_for(n, 64);
+        { Prof _p(ctx, "k_sap_keys"); hipLaunchKernelGGL(k_sap_keys, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_keys"));
+        { Prof _p(ctx, "k_sap_scan"); hipLaunchKernelGGL(k_sap_scan, dim3(1), dim3(1024), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_scan"));
+        { Prof _p(ctx, "k_sap_pairs"); hipLaunchKernelGGL(k_sap_pairs, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_pairs"));
+        { Prof _p(ctx, "k_sap_leaves"); hipLaunchKernelGGL(k_sap_leaves, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_leaves"));
+        for (int L = 0; L < ZKW_STORAGE_TREE_DEPTH && rc == ZKW_OK; L++) {
+            Prof _p(ctx, "k_sap_level");
+            hipLaunchKernelGGL(k_sap_level, dim3(g64), dim3(64), 0, ctx->stream, job, L);
+        }
+        TRY(launch_check("k_sap_level"));
+        { Prof _p(ctx, "k_sap_roots"); hipLaunchKernelGGL(k_sap_roots, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_roots"));
+        if (rc != ZKW_OK) return bail(rc);
+        if (hipMemcpyAsync(w->leaf_indexes, job.init_index, n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return bail(fail(ZKW_ERR_HIP, "readback failed"));
+    }
+    w->n_instances = n ? (size_t)meta[0] : 1;
+    if (hipMalloc((void**)&w->instances, w->n_instances * sizeof(zkw_storage_application_instance) + 64) != hipSuccess)
+        return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed"));
+    SapKeccakOut ko{d_snap, d_hash};
+    { Prof _p(ctx, "k_sap_keccak"); hipLaunchKernelGGL(k_sap_keccak, dim3(1), dim3(64), 0, ctx->stream, job, ko); }
+    TRY(launch_check("k_sap_keccak"));
+    std::vector<SapBlock> blk(1);
+    blk[0].job = job;
+    blk[0].query_tails = d_qt;
+    blk[0].snapshots = d_snap;
+    blk[0].final_hash = d_hash;
+    blk[0].instances = w->instances;
+    blk[0].n_instances = w->n_instances;
+    SapBlock* d_blk = nullptr;
+    TRY(ctx->upload("sap_block", blk, &d_blk));
+    if (rc != ZKW_OK) return bail(rc);
+    { Prof _p(ctx, "k_sap_instances"); hipLaunchKernelGGL(k_sap_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    TRY(launch_check("k_sap_instances"));
+    if (rc != ZKW_OK) return bail(rc);
+    u32 viol = 0;
+    if (hipMemcpyAsync(&viol, d_viol, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return bail(fail(ZKW_ERR_HIP, "readback failed"));
+    if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u storage queries contradict the tree: the pre-state proof does not lead to the "
+                                                     "initial root, the read value is not the leaf's (storage_application.rs:221,276), "
+                                                     "or a slot occurs twice", viol));
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" size_t zkw_storage_application_witness_num_instances(const zkw_storage_application_witness* w) { return w ? w->n_instances : 0; }
+static const void* sap_array(const zkw_storage_application_witness* w, int what, size_t* bytes) {
+    switch (what) {
+        case ZKW_SAP_DERIVED_KEYS: *bytes = w->n * 32; return w->keys;
+        case ZKW_SAP_MERKLE_PATHS: *bytes = w->n * 256 * 32; return w->paths;
+        case ZKW_SAP_LEAF_INDEXES: *bytes = w->n * 8; return w->leaf_indexes;
+        case ZKW_SAP_ROOTS: *bytes = w->n * 32; return w->roots;
+        case ZKW_SAP_INSTANCES: *bytes = w->n_instances * sizeof(zkw_storage_application_instance); return w->instances;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_storage_application_witness_bytes(const zkw_storage_application_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)sap_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_storage_application_witness_device_ptr(const zkw_storage_application_witness* w, int what) {
+    size_t b = 0;
+    return w ? sap_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_storage_application_witness_get(const zkw_storage_application_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_storage_application_witness_get: null argument");
+    if (what < 0 || what > ZKW_SAP_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    size_t bytes = 0;
+    const void* src = sap_array(w, what, &bytes);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_storage_application_witness_free(zkw_storage_application_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);

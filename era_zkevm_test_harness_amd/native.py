@@ -83,6 +83,12 @@ SYMBOLS = [
     ("zkw_decommitter_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_decommitter_witness_free", None, [_vp]),
     ("zkw_linear_keccak256", _int, [_vp, _vp, _sz, _vp]),
+    ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
+    ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
+    ("zkw_storage_application_witness_bytes", _sz, [_vp, _int]),
+    ("zkw_storage_application_witness_device_ptr", _vp, [_vp, _int]),
+    ("zkw_storage_application_witness_get", _int, [_vp, _int, _vp, _sz]),
+    ("zkw_storage_application_witness_free", None, [_vp]),
     ("zkw_precompile_build", _int, [_vp, _int, _vp, _vp, _sz, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_precompile_witness_num_instances", _sz, [_vp]),
     ("zkw_precompile_witness_num_rounds", _sz, [_vp]),
@@ -376,7 +382,56 @@ PRECOMPILE_INSTANCE = np.dtype(
      ("hidden_fsm_input", PRECOMPILE_FSM), ("hidden_fsm_output", PRECOMPILE_FSM), ("first_request", "<u8"),
      ("num_requests", "<u8"), ("first_read", "<u8"), ("num_reads", "<u8"), ("first_round", "<u8"), ("num_rounds", "<u8")])
 assert PRECOMPILE_FSM.itemsize == 744 and PRECOMPILE_INSTANCE.itemsize == 2016
+STORAGE_APPLICATION_FSM = np.dtype(
+    [("next_enumeration_counter", "<u4", (2,)), ("current_root_hash", "u1", (32,)),
+     ("current_storage_application_log_state", QUEUE_STATE4), ("current_diffs_keccak_accumulator_state", "u1", (200,))])
+STORAGE_APPLICATION_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_next_enumeration_counter", "<u4", (2,)),
+     ("initial_root_hash", "u1", (32,)), ("shard", "<u4"), ("_pad0", "<u4"), ("storage_application_log_state", QUEUE_STATE4),
+     ("new_next_enumeration_counter", "<u4", (2,)), ("new_root_hash", "u1", (32,)), ("state_diffs_keccak256_hash", "u1", (32,)),
+     ("hidden_fsm_input", STORAGE_APPLICATION_FSM), ("hidden_fsm_output", STORAGE_APPLICATION_FSM), ("first_item", "<u8"),
+     ("num_items", "<u8")])
+assert STORAGE_APPLICATION_FSM.itemsize == 312 and STORAGE_APPLICATION_INSTANCE.itemsize == 840
 PRC_MEM_ENC, PRC_MEM_TAILS, PRC_INSTANCES = range(3)
+SAP_DERIVED_KEYS, SAP_MERKLE_PATHS, SAP_LEAF_INDEXES, SAP_ROOTS, SAP_INSTANCES = range(5)
+
+
+class StorageApplicationWitness:
+    """Owner of a zkw_storage_application_witness handle."""
+
+    _DTYPES = {SAP_DERIVED_KEYS: np.dtype("u1"), SAP_MERKLE_PATHS: np.dtype("u1"), SAP_ROOTS: np.dtype("u1"),
+               SAP_INSTANCES: STORAGE_APPLICATION_INSTANCE}
+    _SHAPES = {SAP_DERIVED_KEYS: (-1, 32), SAP_MERKLE_PATHS: (-1, 256, 32), SAP_ROOTS: (-1, 32)}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = C.c_void_p(None)
+
+    @property
+    def num_instances(self):
+        return load().zkw_storage_application_witness_num_instances(self.handle)
+
+    def get(self, what):
+        lib = load()
+        nbytes = lib.zkw_storage_application_witness_bytes(self.handle, what)
+        dt = self._DTYPES.get(what, np.dtype("<u8"))
+        out = np.zeros(nbytes // dt.itemsize, dt)
+        if nbytes:
+            _check(lib.zkw_storage_application_witness_get(self.handle, what, _np_ptr(out), nbytes))
+        shape = self._SHAPES.get(what)
+        return out.reshape(shape) if shape else out
+
+    def free(self):
+        if self.handle:
+            load().zkw_storage_application_witness_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
 
 
 class PrecompileWitness:
@@ -864,3 +919,20 @@ class Context:
     def ecrecover_decompose_into_per_circuit_witness(self, requests, request_tails, mem_queries, num_rounds_per_circuit, mem_in):
         """ecrecover.rs:12-262 -> PrecompileWitness."""
         return self._precompile(PRECOMPILE_ECRECOVER, requests, request_tails, mem_queries, num_rounds_per_circuit, mem_in)
+
+    def decompose_into_storage_application_witnesses(self, queries, query_tails, init_leaf_indexes, init_merkle_paths,
+                                                     initial_root, initial_next_enumeration_index, num_rounds_per_circuit):
+        """storage_application.rs:31-361 over the pre-block answers of the storage tree -> StorageApplicationWitness."""
+        q = np.ascontiguousarray(queries, dtype=LOG_QUERY)
+        qt = _u64(query_tails)
+        ii = _u64(init_leaf_indexes)
+        ip = np.ascontiguousarray(init_merkle_paths, dtype=np.uint8)
+        root = np.frombuffer(bytes(initial_root), np.uint8).copy()
+        assert root.size == 32 and ip.size == q.size * 256 * 32
+        w = StorageApplicationWitness(self)
+        some = q.size > 0
+        _check(load().zkw_storage_application_build(self.handle, _np_ptr(q) if some else None, _np_ptr(qt) if some else None,
+                                                    q.size, _np_ptr(ii) if some else None, _np_ptr(ip) if some else None,
+                                                    _np_ptr(root), initial_next_enumeration_index, num_rounds_per_circuit,
+                                                    C.byref(w.handle)))
+        return w

@@ -300,3 +300,23 @@ def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
         req["key"][k] = key
     mq = np.concatenate(qs) if qs else np.zeros(0, MEM_QUERY)
     return req, mq
+
+
+def storage_application_trace(n, seed=0, existing_fraction=0.5, write_fraction=0.6):
+    """Deduplicated rollup storage queries (distinct slots, shard 0) for the StorageApplication circuit.
+    Returns (queries, existing): `existing[i]` says slot i must already hold read_value in the tree before the block;
+    the other slots are empty (read_value = 0)."""
+    rng = np.random.default_rng(seed)
+    q = random_log_queries(max(n, 1), seed=seed + 1)[:n]
+    q["shard_id"] = 0
+    q["aux_byte"] = 0
+    q["rollback"] = 0
+    q["is_service"] = 0
+    for i in range(n):  # distinct (address, key)
+        q["key"][i][0] = i
+    q["rw_flag"] = (rng.random(n) < write_fraction).astype(np.uint8)
+    existing = rng.random(n) < existing_fraction
+    q["read_value"][~existing] = 0
+    ro = q["rw_flag"] == 0
+    q["written_value"][ro] = q["read_value"][ro]
+    return q, existing

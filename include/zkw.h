@@ -294,6 +294,36 @@ const void *zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness *w,
 int zkw_decommitter_witness_get(const zkw_decommitter_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_decommitter_witness_free(zkw_decommitter_witness *w);
 
+/* ---- StorageApplication witness builder (a17) --------------------------------------------------------- */
+typedef struct zkw_storage_application_witness zkw_storage_application_witness;
+/* decompose_into_storage_application_witnesses, src/witness/individual_circuits/storage_application.rs:31-361.
+   queries / query_tails: the deduplicated rollup storage queries and their queue states (ZKW_STO_RESULT_QUERIES /
+   ZKW_STO_RESULT_NEW_TAILS of the storage sorter, pushed from the empty queue); every slot occurs once.
+   The reference walks a `BinarySparseStorageTree` (src/witness/tree/mod.rs:41-98) query by query. This entry
+   takes what that tree answers for the state BEFORE the block, per query i: init_leaf_indexes[i] = get_leaf(slot)
+   .leaf.current_index() (0 = empty leaf), init_merkle_paths[i][256][32] = its merkle_path (level 0 = the leaf's
+   sibling), plus root() and next_enumeration_index(); paths, roots and enumeration indices as the sequential
+   walk sees them are rebuilt on the device. capacity = cycles_per_storage_application. With n == 0 one dummy
+   instance is produced. The caller applies the writes to its own tree (new root: last instance's output).
+   ZKW_ERR_CHECK_FAILED when a pre-state proof does not lead to initial_root, a read value differs from the leaf
+   (storage_application.rs:221, 276) or a slot repeats. */
+int zkw_storage_application_build(zkw_ctx *ctx, const zkw_log_query *queries, const uint64_t *query_tails, size_t n,
+                                  const uint64_t *init_leaf_indexes, const uint8_t *init_merkle_paths,
+                                  const uint8_t initial_root[32], uint64_t initial_next_enumeration_index,
+                                  uint32_t capacity, zkw_storage_application_witness **out);
+enum {
+    ZKW_SAP_DERIVED_KEYS = 0, /* uint8_t[n][32]: LogQuery::derive_final_address */
+    ZKW_SAP_MERKLE_PATHS = 1, /* uint8_t[n][256][32]: merkle_paths as seen when query i is applied */
+    ZKW_SAP_LEAF_INDEXES = 2, /* uint64_t[n]: leaf_indexes_for_reads (the index BEFORE a write) */
+    ZKW_SAP_ROOTS = 3,        /* uint8_t[n][32]: tree root after query i */
+    ZKW_SAP_INSTANCES = 4     /* zkw_storage_application_instance[n_instances] */
+};
+size_t zkw_storage_application_witness_num_instances(const zkw_storage_application_witness *w);
+size_t zkw_storage_application_witness_bytes(const zkw_storage_application_witness *w, int what);
+const void *zkw_storage_application_witness_device_ptr(const zkw_storage_application_witness *w, int what);
+int zkw_storage_application_witness_get(const zkw_storage_application_witness *w, int what, void *dst, size_t dst_bytes);
+void zkw_storage_application_witness_free(zkw_storage_application_witness *w);
+
 /* ---- keccak256 / sha256 / ecrecover round-function witness builders (a16) ---------------------------- */
 typedef struct zkw_precompile_witness zkw_precompile_witness;
 /* kind = ZKW_PRECOMPILE_KECCAK256: keccak256_decompose_into_per_circuit_witness,

@@ -373,6 +373,42 @@ typedef struct zkw_precompile_instance {
     uint64_t first_round, num_rounds;
 } zkw_precompile_instance;
 
+/* ---- StorageApplication (a17) ------------------------------------------------------------------------ */
+#define ZKW_STORAGE_TREE_DEPTH 256 /* BinarySparseStorageTree<256, 32, 32, 8, 32, Blake2s256, ZkSyncStorageLeaf>, storage_application.rs:41 */
+#define ZKW_STATE_DIFF_RECORD_BYTE_ENCODING_LEN 156 /* state_diff_record.rs:21-53: 20 + 32 + 32 + 8 + 32 + 32 */
+/* zkevm_circuits::base_structures::state_diff_record::NUM_KECCAK256_ROUNDS_PER_RECORD_ACCUMULATION (absent crate;
+   156 bytes need two 136-byte keccak blocks, storage_application.rs:253-260) */
+#define ZKW_NUM_KECCAK256_ROUNDS_PER_RECORD_ACCUMULATION 2
+
+/* StorageApplicationFSMInputOutput, fields as filled at storage_application.rs:293-299 */
+typedef struct zkw_storage_application_fsm {
+    uint32_t next_enumeration_counter[2]; /* u64_as_u32_le */
+    uint8_t current_root_hash[32];
+    zkw_queue_state4 current_storage_application_log_state;
+    uint8_t current_diffs_keccak_accumulator_state[200]; /* [5][5][8], keccak256_round_function.rs:530-541 */
+} zkw_storage_application_fsm;
+
+/* StorageApplicationCircuitInstanceWitness, storage_application.rs:322-336 */
+typedef struct zkw_storage_application_instance {
+    uint32_t start_flag;
+    uint32_t completion_flag;
+    /* observable_input (StorageApplicationInputData), first instance only */
+    uint32_t initial_next_enumeration_counter[2];
+    uint8_t initial_root_hash[32];
+    uint32_t shard;
+    uint32_t _pad0;
+    zkw_queue_state4 storage_application_log_state;
+    /* observable_output (StorageApplicationOutputData), last instance only */
+    uint32_t new_next_enumeration_counter[2];
+    uint8_t new_root_hash[32];
+    uint8_t state_diffs_keccak256_hash[32];
+    zkw_storage_application_fsm hidden_fsm_input;
+    zkw_storage_application_fsm hidden_fsm_output;
+    /* the instance's slice of storage_queue_witness / merkle_paths / leaf_indexes_for_reads */
+    uint64_t first_item;
+    uint64_t num_items;
+} zkw_storage_application_instance;
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,6 +152,22 @@ int64_t orc_decommitter_build(const zkw_decommit_query *requests, const uint64_t
    digest of the words (each big-endian) with the 4 most significant bytes replaced by `top4` */
 void orc_bytecode_hash(const uint32_t *words, size_t n_words, uint32_t top_limb, uint32_t hash_out[8]);
 
+/* ---- sparse storage tree + StorageApplication builder (a17), see storage_application.c */
+typedef struct orc_tree orc_tree;
+orc_tree *orc_tree_new(void);
+void orc_tree_free(orc_tree *t);
+void orc_tree_root(const orc_tree *t, uint8_t out[32]);
+uint64_t orc_tree_next_enumeration_index(const orc_tree *t);
+void orc_tree_get_leaf(orc_tree *t, const uint8_t key[32], uint64_t *leaf_index, uint8_t value[32], uint8_t *path);
+uint64_t orc_tree_insert_leaf(orc_tree *t, const uint8_t key[32], const uint8_t value[32], uint8_t *path);
+int orc_tree_verify_inclusion(const uint8_t root[32], const uint8_t key[32], uint64_t leaf_index, const uint8_t value[32],
+                              const uint8_t *path);
+void orc_derive_final_address(const zkw_log_query *q, uint8_t out[32]);
+void orc_state_diff_encode(const zkw_log_query *q, const uint8_t derived_key[32], uint64_t enumeration_index, uint8_t out[156]);
+int64_t orc_storage_application_build(orc_tree *tree, const zkw_log_query *queries, const uint64_t *query_tails, size_t n,
+                                      uint32_t capacity, uint8_t *derived_keys, uint8_t *merkle_paths, uint64_t *leaf_indexes,
+                                      uint8_t *roots, zkw_storage_application_instance *instances);
+
 /* ---- keccak256 / sha256 / ecrecover round-function builders (a16), see precompiles.c */
 int64_t orc_precompile_build(int kind, const zkw_log_query *requests, const uint64_t *req_tails, size_t n_req,
                              const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,

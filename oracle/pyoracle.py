@@ -151,6 +151,18 @@ PRECOMPILE_INSTANCE = np.dtype(
 assert PRECOMPILE_FSM.itemsize == 744 and PRECOMPILE_INSTANCE.itemsize == 2016
 
 
+STORAGE_APPLICATION_FSM = np.dtype(
+    [("next_enumeration_counter", "<u4", (2,)), ("current_root_hash", "u1", (32,)),
+     ("current_storage_application_log_state", QUEUE_STATE4), ("current_diffs_keccak_accumulator_state", "u1", (200,))])
+STORAGE_APPLICATION_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_next_enumeration_counter", "<u4", (2,)),
+     ("initial_root_hash", "u1", (32,)), ("shard", "<u4"), ("_pad0", "<u4"), ("storage_application_log_state", QUEUE_STATE4),
+     ("new_next_enumeration_counter", "<u4", (2,)), ("new_root_hash", "u1", (32,)), ("state_diffs_keccak256_hash", "u1", (32,)),
+     ("hidden_fsm_input", STORAGE_APPLICATION_FSM), ("hidden_fsm_output", STORAGE_APPLICATION_FSM), ("first_item", "<u8"),
+     ("num_items", "<u8")])
+assert STORAGE_APPLICATION_FSM.itemsize == 312 and STORAGE_APPLICATION_INSTANCE.itemsize == 840
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -562,3 +574,78 @@ def sha256_compress_chain(data: bytes) -> np.ndarray:
     for i in range(0, len(data), 64):
         lib().orc_sha256_compress(_p(state), C.c_char_p(data[i:i + 64]))
     return state
+
+
+class Tree:
+    """InMemoryStorageTree<256, 32, 8, Blake2s256, ZkSyncStorageLeaf> (src/witness/tree/mod.rs:113-384)."""
+
+    def __init__(self):
+        f = lib().orc_tree_new
+        f.restype = C.c_void_p
+        self.handle = C.c_void_p(f())
+
+    def __del__(self):
+        try:
+            lib().orc_tree_free(self.handle)
+        except Exception:
+            pass
+
+    @property
+    def root(self) -> bytes:
+        out = C.create_string_buffer(32)
+        lib().orc_tree_root(self.handle, out)
+        return out.raw
+
+    @property
+    def next_enumeration_index(self) -> int:
+        f = lib().orc_tree_next_enumeration_index
+        f.restype = C.c_uint64
+        return f(self.handle)
+
+    def get_leaf(self, key: bytes):
+        idx = C.c_uint64(0)
+        value = C.create_string_buffer(32)
+        path = np.zeros((256, 32), np.uint8)
+        lib().orc_tree_get_leaf(self.handle, C.c_char_p(key), C.byref(idx), value, _p(path))
+        return idx.value, value.raw, path
+
+    def insert_leaf(self, key: bytes, value: bytes) -> int:
+        f = lib().orc_tree_insert_leaf
+        f.restype = C.c_uint64
+        return f(self.handle, C.c_char_p(key), C.c_char_p(value), None)
+
+    def verify_inclusion(self, root: bytes, key: bytes, index: int, value: bytes, path) -> bool:
+        path = np.ascontiguousarray(path, dtype=np.uint8)
+        return bool(lib().orc_tree_verify_inclusion(C.c_char_p(root), C.c_char_p(key), C.c_uint64(index), C.c_char_p(value), _p(path)))
+
+
+def derive_final_address(q) -> bytes:
+    q = np.ascontiguousarray(q, dtype=LOG_QUERY).reshape(1)
+    out = C.create_string_buffer(32)
+    lib().orc_derive_final_address(_p(q), out)
+    return out.raw
+
+
+def state_diff_encode(q, derived_key: bytes, enumeration_index: int) -> bytes:
+    q = np.ascontiguousarray(q, dtype=LOG_QUERY).reshape(1)
+    out = C.create_string_buffer(156)
+    lib().orc_state_diff_encode(_p(q), C.c_char_p(derived_key), C.c_uint64(enumeration_index), out)
+    return out.raw
+
+
+def storage_application_build(tree, queries, query_tails, capacity):
+    """decompose_into_storage_application_witnesses on `tree` (mutated)."""
+    q = np.ascontiguousarray(queries, dtype=LOG_QUERY)
+    qt = _u64(query_tails)
+    n = q.size
+    o = dict(derived_keys=np.zeros((n, 32), np.uint8), merkle_paths=np.zeros((n, 256, 32), np.uint8),
+             leaf_indexes=np.zeros(n, np.uint64), roots=np.zeros((n, 32), np.uint8),
+             instances=np.zeros(n + 1, STORAGE_APPLICATION_INSTANCE))
+    f = lib().orc_storage_application_build
+    f.restype = C.c_int64
+    rc = f(tree.handle, _p(q), _p(qt), C.c_size_t(n), C.c_uint32(capacity), _p(o["derived_keys"]), _p(o["merkle_paths"]),
+           _p(o["leaf_indexes"]), _p(o["roots"]), _p(o["instances"]))
+    if rc < 0:
+        raise RuntimeError(f"orc_storage_application_build failed: {rc}")
+    o["instances"] = o["instances"][:rc]
+    return o

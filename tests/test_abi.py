@@ -60,6 +60,7 @@ def test_record_layouts_match_header():
       printf("%zu %zu %zu %zu\n", sizeof(zkw_mem_query), sizeof(zkw_queue_state12), sizeof(zkw_ram_fsm), sizeof(zkw_ram_instance));
       printf("%zu %zu %zu %zu\n", sizeof(zkw_callstack_entry), offsetof(zkw_callstack_entry, pc), sizeof(zkw_log_query), sizeof(zkw_decommit_query));
       printf("%zu %zu %zu %zu\n", sizeof(zkw_precompile_fsm), sizeof(zkw_precompile_instance), offsetof(zkw_precompile_fsm, buffer_bytes), offsetof(zkw_precompile_instance, first_request));
+      printf("%zu %zu %zu %zu\n", sizeof(zkw_storage_application_fsm), sizeof(zkw_storage_application_instance), offsetof(zkw_storage_application_instance, hidden_fsm_input), offsetof(zkw_storage_application_instance, first_item));
       printf("%zu %zu %zu %zu\n", offsetof(zkw_mem_query, value), offsetof(zkw_ram_fsm, previous_sorting_key),
              offsetof(zkw_ram_instance, hidden_fsm_input), offsetof(zkw_ram_instance, first_item));
       return 0; }
@@ -78,10 +79,13 @@ def test_record_layouts_match_header():
                               mod.DECOMMIT_QUERY.itemsize]
         assert sizes[8:12] == [mod.PRECOMPILE_FSM.itemsize, mod.PRECOMPILE_INSTANCE.itemsize,
                                mod.PRECOMPILE_FSM.fields["buffer_bytes"][1], mod.PRECOMPILE_INSTANCE.fields["first_request"][1]]
-        assert sizes[12] == mod.MEM_QUERY.fields["value"][1]
-        assert sizes[13] == mod.RAM_FSM.fields["previous_sorting_key"][1]
-        assert sizes[14] == mod.RAM_INSTANCE.fields["hidden_fsm_input"][1]
-        assert sizes[15] == mod.RAM_INSTANCE.fields["first_item"][1]
+        assert sizes[12:16] == [mod.STORAGE_APPLICATION_FSM.itemsize, mod.STORAGE_APPLICATION_INSTANCE.itemsize,
+                                mod.STORAGE_APPLICATION_INSTANCE.fields["hidden_fsm_input"][1],
+                                mod.STORAGE_APPLICATION_INSTANCE.fields["first_item"][1]]
+        assert sizes[16] == mod.MEM_QUERY.fields["value"][1]
+        assert sizes[17] == mod.RAM_FSM.fields["previous_sorting_key"][1]
+        assert sizes[18] == mod.RAM_INSTANCE.fields["hidden_fsm_input"][1]
+        assert sizes[19] == mod.RAM_INSTANCE.fields["first_item"][1]
 
 
 def test_synthetic_trace_is_valid_memory():

@@ -495,3 +495,59 @@ def test_precompile_builder_rejects_inconsistent_queries(ctx, oracle):
     with pytest.raises(native.ZkwError) as ei:
         ctx._precompile(0, req, new, bad, 3, mem_in)
     assert ei.value.code == native.ERR_CHECK_FAILED
+
+
+def _be32(limbs):
+    return b"".join(int(x).to_bytes(4, "big") for x in limbs[::-1])
+
+
+def _storage_application_case(oracle, n, seed):
+    q, existing = synthetic.storage_application_trace(n, seed=seed)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(q))[1] if n else np.zeros((0, 4), np.uint64)
+    tree = oracle.Tree()
+    rng = np.random.default_rng(seed)
+    for _ in range(30):
+        tree.insert_leaf(rng.bytes(32), rng.bytes(32))
+    keys = [oracle.derive_final_address(q[i]) for i in range(n)]
+    for i in np.nonzero(existing)[0]:
+        tree.insert_leaf(keys[i], _be32(q["read_value"][i]))
+    # what the tree answers before the block
+    idx = np.zeros(n, np.uint64)
+    paths = np.zeros((n, 256, 32), np.uint8)
+    for i in range(n):
+        idx[i], _, paths[i] = tree.get_leaf(keys[i])
+    return q, tails, tree, idx, paths
+
+
+@pytest.mark.parametrize("n,capacity", [(0, 33), (1, 33), (40, 5), (300, 33), (1500, 33)])
+def test_storage_application(ctx, oracle, n, capacity):
+    from era_zkevm_test_harness_amd import native
+
+    q, tails, tree, idx, paths = _storage_application_case(oracle, n, seed=n + 11)
+    root0, next0 = tree.root, tree.next_enumeration_index
+    w = ctx.decompose_into_storage_application_witnesses(q, tails, idx, paths, root0, next0, capacity)
+    o = oracle.storage_application_build(tree, q, tails, capacity)  # mutates the tree
+    assert np.array_equal(w.get(native.SAP_DERIVED_KEYS), o["derived_keys"])
+    assert np.array_equal(w.get(native.SAP_LEAF_INDEXES), o["leaf_indexes"])
+    assert np.array_equal(w.get(native.SAP_ROOTS), o["roots"])
+    assert np.array_equal(w.get(native.SAP_MERKLE_PATHS), o["merkle_paths"])
+    gi = w.get(native.SAP_INSTANCES)
+    assert gi.size == o["instances"].size
+    for name in gi.dtype.names:
+        assert gi[name].tobytes() == o["instances"][name].tobytes(), name
+
+
+def test_storage_application_rejects_bad_proofs(ctx, oracle):
+    from era_zkevm_test_harness_amd import native
+
+    q, tails, tree, idx, paths = _storage_application_case(oracle, 50, seed=3)
+    bad = paths.copy()
+    bad[7, 100, 5] ^= 1
+    with pytest.raises(native.ZkwError) as ei:
+        ctx.decompose_into_storage_application_witnesses(q, tails, idx, bad, tree.root, tree.next_enumeration_index, 33)
+    assert ei.value.code == native.ERR_CHECK_FAILED
+    badq = q.copy()
+    badq["read_value"][9][0] ^= 1
+    with pytest.raises(native.ZkwError) as ei:
+        ctx.decompose_into_storage_application_witnesses(badq, tails, idx, paths, tree.root, tree.next_enumeration_index, 33)
+    assert ei.value.code == native.ERR_CHECK_FAILED

@@ -510,3 +510,79 @@ def test_precompile_builders_oracle(oracle, kind):
     bad["rw_flag"][-1] = 0
     with pytest.raises(RuntimeError):
         oracle.precompile_build(kind, req, new, bad, 3, mem_in)
+
+
+def _be32(limbs):
+    return b"".join(int(x).to_bytes(4, "big") for x in limbs[::-1])
+
+
+def _populated_tree(oracle, q, existing, extra=20, seed=1):
+    import hashlib
+
+    tree = oracle.Tree()
+    rng = np.random.default_rng(seed)
+    for _ in range(extra):  # unrelated leaves
+        tree.insert_leaf(rng.bytes(32), rng.bytes(32))
+    for i in np.nonzero(existing)[0]:
+        tree.insert_leaf(oracle.derive_final_address(q[i]), _be32(q["read_value"][i]))
+    return tree
+
+
+def test_storage_application_oracle(oracle):
+    import hashlib
+
+    # the tree against hashlib: empty root and one insertion
+    t0 = oracle.Tree()
+    h = hashlib.blake2s(bytes(40)).digest()
+    for _ in range(256):
+        h = hashlib.blake2s(h + h).digest()
+    assert t0.root == h and t0.next_enumeration_index == 1
+    key, val = bytes(range(32)), bytes(range(100, 132))
+    assert t0.insert_leaf(key, val) == 1 and t0.next_enumeration_index == 2
+    idx, value, path = t0.get_leaf(key)
+    assert (idx, value) == (1, val)
+    cur = hashlib.blake2s((1).to_bytes(8, "big") + val).digest()
+    for level in range(256):
+        right = (key[level // 8] >> (level % 8)) & 1
+        sib = path[level].tobytes()
+        cur = hashlib.blake2s(sib + cur if right else cur + sib).digest()
+    assert cur == t0.root and t0.verify_inclusion(t0.root, key, 1, val, path)
+
+    q, existing = synthetic.storage_application_trace(60, seed=4)
+    a, k = q[0]["address"], q[0]["key"]
+    msg = bytes(12) + b"".join(int(x).to_bytes(4, "big") for x in a[::-1]) + _be32(k)
+    assert oracle.derive_final_address(q[0]) == hashlib.blake2s(msg).digest()
+    enc = oracle.state_diff_encode(q[0], b"\x07" * 32, 0x0102030405060708)
+    assert enc == msg[12:32] + msg[32:] + b"\x07" * 32 + bytes([1, 2, 3, 4, 5, 6, 7, 8]) + _be32(q[0]["read_value"]) + _be32(q[0]["written_value"])
+
+    _, tails = oracle.queue_push_chain_log(oracle.encode_log_queries(q))
+    tree = _populated_tree(oracle, q, existing)
+    root0, next0 = tree.root, tree.next_enumeration_index
+    o = oracle.storage_application_build(tree, q, tails, 33)
+    inst = o["instances"]
+    # chunking: at most capacity - 1 tree operations (+1 for a trailing write) per instance
+    ops = np.where(q["rw_flag"] == 1, 2, 1)
+    for w in inst:
+        s = ops[int(w["first_item"]):int(w["first_item"] + w["num_items"])].sum()
+        assert 32 <= s <= 33 or w["completion_flag"]
+    assert inst["num_items"].sum() == 60 and inst[0]["initial_root_hash"].tobytes() == root0
+    assert int(inst[0]["initial_next_enumeration_counter"][0]) == next0
+    first_writes = int(((q["rw_flag"] == 1) & ~existing).sum())
+    assert int(inst[-1]["new_next_enumeration_counter"][0]) == next0 + first_writes == tree.next_enumeration_index
+    assert inst[-1]["new_root_hash"].tobytes() == tree.root == o["roots"][-1].tobytes()
+    assert inst["hidden_fsm_output"][:-1].tobytes() == inst["hidden_fsm_input"][1:].tobytes()
+    # the pubdata hash is Keccak-256 over the zero-extended state diffs of the writes, in order
+    data = b""
+    for i in range(60):
+        if q["rw_flag"][i]:
+            data += oracle.state_diff_encode(q[i], o["derived_keys"][i].tobytes(), int(o["leaf_indexes"][i])).ljust(272, b"\0")
+    assert inst[-1]["state_diffs_keccak256_hash"].tobytes() == oracle.keccak256(data)
+    # a read of a value the tree does not hold is rejected
+    bad = q.copy()
+    bad["read_value"][5][0] ^= 1
+    with pytest.raises(RuntimeError):
+        oracle.storage_application_build(_populated_tree(oracle, q, existing), bad, tails, 33)
+    # no queries: one dummy instance carrying the tree's state and the hash of nothing
+    d = oracle.storage_application_build(tree, q[:0], tails[:0], 33)["instances"]
+    assert d.size == 1 and d[0]["new_root_hash"].tobytes() == tree.root
+    assert d[0]["state_diffs_keccak256_hash"].tobytes() == oracle.keccak256(b"")
