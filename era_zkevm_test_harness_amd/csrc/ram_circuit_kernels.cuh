@@ -60,6 +60,11 @@ __device__ __forceinline__ RegsIn regs_in(const zkw_ram_instance* in) {
 
 #define TR(col, row) trace[(size_t)(col) * n_rows + (row)]
 
+// rows [capacity, RC_REGION_STRIDE(capacity)) of a region: the alignment gap, all general + lookup columns zero
+__device__ __forceinline__ void zero_gap_row(u64* trace, size_t n_rows, size_t row) {
+    for (int col = 0; col < RC_G + RC_L; col++) TR(col, row) = 0;
+}
+
 __device__ __forceinline__ void hist_bytes(u32* sh_hist, u32 x) {
     atomicAdd(&sh_hist[x & 0xFF], 1u);
     atomicAdd(&sh_hist[(x >> 8) & 0xFF], 1u);
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __rest
         const zkw_ram_instance* in = job.inst;
         const size_t first = in->first_item, m = in->num_items;
         const bool can_pop = i < m;
-        const size_t row = (size_t)(SIDE == 0 ? RC_ROW_PU : RC_ROW_PS) * capacity + i;
+        const size_t row = (size_t)(SIDE == 0 ? RC_ROW_PU : RC_ROW_PS) * RC_REGION_STRIDE(capacity) + i;
         const u64* enc = SIDE == 0 ? job.unsorted_enc : job.sorted_enc;
         const u64* tails = SIDE == 0 ? job.unsorted_tails : job.sorted_tails;
         u64 s[12];
@@ -150,6 +155,8 @@ __global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __rest
             hist_bytes(sh_hist, q.timestamp); hist_bytes(sh_hist, q.page); hist_bytes(sh_hist, q.value[4]);
         }
         for (int c = RC_G + 12; c < RC_G + RC_L; c++) TR(c, row) = 0;
+    } else if (i < RC_REGION_STRIDE(capacity)) {
+        zero_gap_row(job.trace, n_rows, (size_t)(SIDE == 0 ? RC_ROW_PU : RC_ROW_PS) * RC_REGION_STRIDE(capacity) + i);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256) void k_ram_fill_A(const SynthJob* __restrict__
     if (i < capacity) {
         u64* trace = job.trace;
         const zkw_ram_instance* in = job.inst;
-        const size_t first = in->first_item, m = in->num_items, row = (size_t)RC_ROW_A * capacity + i;
+        const size_t first = in->first_item, m = in->num_items, row = (size_t)RC_ROW_A * RC_REGION_STRIDE(capacity) + i;
         CycleCtx c;
         cycle_ctx(job, i, c, true);
         const u64 rw = c.q.rw_flag ? 1 : 0, ptr = c.q.value_is_pointer ? 1 : 0;
@@ -255,6 +262,8 @@ __global__ __launch_bounds__(256) void k_ram_fill_A(const SynthJob* __restrict__
         constexpr int NA = ROW_SLOTS[RC_ROW_A];  // general slots used by row type A
         for (int col = NA; col < RC_G; col++) TR(col, row) = 0;
         for (int col = RC_G + 12; col < RC_G + RC_L; col++) TR(col, row) = 0;
+    } else if (i < RC_REGION_STRIDE(capacity)) {
+        zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_A * RC_REGION_STRIDE(capacity) + i);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256) void k_ram_fill_B(const SynthJob* __restrict__
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < capacity) {
         u64* trace = job.trace;
-        const size_t row = (size_t)RC_ROW_B * capacity + i;
+        const size_t row = (size_t)RC_ROW_B * RC_REGION_STRIDE(capacity) + i;
         CycleCtx c;
         cycle_ctx(job, i, c, false);
         put_bytes(trace, n_rows, row, RC_B_v6_b0, c.q.value[6]);
@@ -283,6 +292,8 @@ __global__ __launch_bounds__(256) void k_ram_fill_B(const SynthJob* __restrict__
         constexpr int NB = ROW_SLOTS[RC_ROW_B];
         for (int col = NB; col < RC_G; col++) TR(col, row) = 0;
         for (int col = RC_G + 12; col < RC_G + RC_L; col++) TR(col, row) = 0;
+    } else if (i < RC_REGION_STRIDE(capacity)) {
+        zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_B * RC_REGION_STRIDE(capacity) + i);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -309,12 +320,22 @@ __global__ __launch_bounds__(256) void k_ram_nd_tiles(const SynthJob* __restrict
     __syncthreads();
     if (threadIdx.x == 0) job.nd_tiles[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ void k_ram_nd_scan(const SynthJob* __restrict__ jobs, int n_jobs, u32 n_tiles) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_jobs) return;
-    u32* t = jobs[j].nd_tiles;
+__global__ __launch_bounds__(64) void k_ram_nd_scan(const SynthJob* __restrict__ jobs, int n_jobs, u32 n_tiles) {
+    // one wave per job: exclusive prefix over the tile counts, 64 tiles at a time
+    u32* t = jobs[blockIdx.x].nd_tiles;
+    const int lane = threadIdx.x;
     u32 acc = 0;
-    for (u32 k = 0; k < n_tiles; k++) { u32 v = t[k]; t[k] = acc; acc += v; }
+    for (u32 base = 0; base < n_tiles; base += 64) {
+        const u32 k = base + lane;
+        const u32 v = k < n_tiles ? t[k] : 0;
+        u32 incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (k < n_tiles) t[k] = acc + incl - v;
+        acc += __shfl(incl, 63);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __restrict__
     if (live) {
         u64* trace = job.trace;
         const zkw_ram_instance* in = job.inst;
-        const size_t row = (size_t)RC_ROW_C * capacity + i;
+        const size_t row = (size_t)RC_ROW_C * RC_REGION_STRIDE(capacity) + i;
         const u64 rw = c.q.rw_flag ? 1 : 0, ptr = c.q.value_is_pointer ? 1 : 0;
         const u64 bw0 = c.q.timestamp < c.pq.timestamp ? 1 : 0;
         const u64 t1 = (u64)c.pq.index + bw0, bw1 = (u64)c.q.index < t1 ? 1 : 0;
@@ -403,6 +424,8 @@ __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __restrict__
         constexpr int NC = ROW_SLOTS[RC_ROW_C];
         for (int col = NC; col < RC_G; col++) TR(col, row) = 0;
         for (int col = RC_G + 8; col < RC_G + RC_L; col++) TR(col, row) = 0;
+    } else if (i < RC_REGION_STRIDE(capacity)) {
+        zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_C * RC_REGION_STRIDE(capacity) + i);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -410,11 +433,15 @@ __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __restrict__
 __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SynthJob job = jobs[blockIdx.y];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= capacity) return;
+    const size_t rs = RC_REGION_STRIDE(capacity);
+    if (i >= capacity) {
+        if (i < rs) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_D * rs + i);
+        return;
+    }
     u64* trace = job.trace;
     const zkw_ram_instance* in = job.inst;
-    const size_t first = in->first_item, m = in->num_items, row = (size_t)RC_ROW_D * capacity + i;
-    const size_t rPU = (size_t)RC_ROW_PU * capacity + i, rPS = (size_t)RC_ROW_PS * capacity + i;
+    const size_t first = in->first_item, m = in->num_items, row = (size_t)RC_ROW_D * rs + i;
+    const size_t rPU = (size_t)RC_ROW_PU * rs + i, rPS = (size_t)RC_ROW_PS * rs + i;
     const RegsIn ri = regs_in(in);
     const bool can_pop = i < m;
     const u64 p_len = (u64)ri.len - (i < m ? i : m);
@@ -440,26 +467,29 @@ __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__
     for (int col = ND; col < RC_G + RC_L; col++) TR(col, row) = 0;
 }
 
-// the zero padding from the first boundary row down (all general + lookup columns) and the multiplicity
-// column. grid.x tiles the rows (2 rows per lane, 16-byte stores where the pair is aligned), grid.y = job.
+// the zero padding from the first boundary row down (all general + lookup columns) and the multiplicity column.
+// blockIdx.x = (column, chunk): every block streams one contiguous chunk of one column with 16-byte stores, so
+// at any time the blocks in flight write ~all columns at once (a sweep of all blocks over one column at a time
+// runs at 3.9 TB/s, this at 5.6, tools/ubench_fill.hip). The last TAIL_CHUNKS blocks of a job do the multiplicity
+// column. grid.y = job.
+constexpr int TAIL_CHUNKS = 8;
 __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SynthJob job = jobs[blockIdx.y];
     u64* trace = job.trace;
-    const size_t bnd = (size_t)RC_ROWS_PER_CYCLE * capacity;
-    const size_t first_even = (bnd + 1) & ~(size_t)1;  // pairs start on even rows: (col*n_rows + row)*8 is 16-B aligned
-    const size_t n_pairs = (n_rows - first_even) / 2;  // n_rows is even (power of two)
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const ulonglong2 z = make_ulonglong2(0, 0);
-    for (int col = 0; col < RC_G + RC_L; col++) {
-        u64* c = trace + (size_t)col * n_rows;
-        if (tid == 0 && first_even != bnd) c[bnd] = 0;
-        ulonglong2* c2 = reinterpret_cast<ulonglong2*>(c + first_even);
-        for (size_t k = tid; k < n_pairs; k += stride) c2[k] = z;
+    const int col = blockIdx.x / TAIL_CHUNKS, ch = blockIdx.x % TAIL_CHUNKS;
+    if (col < RC_G + RC_L) {
+        const size_t bnd = (size_t)RC_BOUNDARY_ROW(capacity);  // a multiple of 64 rows: 16-byte aligned
+        const size_t n_pairs = (n_rows - bnd) / 2;             // n_rows is even (power of two)
+        const size_t per = (n_pairs + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_pairs ? lo + per : n_pairs;
+        ulonglong2* c2 = reinterpret_cast<ulonglong2*>(trace + (size_t)col * n_rows + bnd);
+        const ulonglong2 z = make_ulonglong2(0, 0);
+        for (size_t k = lo + threadIdx.x; k < hi; k += 256) c2[k] = z;
+        return;
     }
     // multiplicities: histogram of the used lookup cells + every unused lookup cell counts as value 0
     u64* m = trace + (size_t)RC_MULT_COL * n_rows;
-    for (size_t r = tid; r < n_rows; r += stride) {
+    const size_t per = (n_rows + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_rows ? lo + per : n_rows;
+    for (size_t r = lo + threadIdx.x; r < hi; r += 256) {
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];
@@ -480,7 +510,7 @@ __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __rest
     const zkw_ram_instance* in = job.inst;
     const zkw_ram_fsm& fi = in->hidden_fsm_input;
     const size_t first = in->first_item, m = in->num_items;
-    const size_t bin = (size_t)RC_ROWS_PER_CYCLE * capacity + RC_ROWOFF_BND_IN, bout = bin - RC_ROWOFF_BND_IN + RC_ROWOFF_BND_OUT;
+    const size_t bin = (size_t)RC_BOUNDARY_ROW(capacity) + RC_ROWOFF_BND_IN, bout = bin - RC_ROWOFF_BND_IN + RC_ROWOFF_BND_OUT;
     const RegsIn ri = regs_in(in);
     for (int k = 0; k < 12; k++) { TR(RC_BND_IN_uh0 + k, bin) = ri.uh[k]; TR(RC_BND_IN_sh0 + k, bin) = ri.sh[k]; }
     TR(RC_BND_IN_len_u, bin) = ri.len; TR(RC_BND_IN_len_s, bin) = ri.len;
@@ -522,7 +552,7 @@ __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __rest
     TR(RC_BND_OUT_es6, bout) = le[6]; TR(RC_BND_OUT_v4, bout) = le[7];
     TR(RC_BND_OUT_ptr, bout) = lq.value_is_pointer ? 1 : 0;
     // cnt after the last cycle = cnt of the last cycle's row C
-    TR(RC_BND_OUT_cnt, bout) = TR(RC_C_cnt, (size_t)RC_ROW_C * capacity + capacity - 1);
+    TR(RC_BND_OUT_cnt, bout) = TR(RC_C_cnt, (size_t)RC_ROW_C * RC_REGION_STRIDE(capacity) + capacity - 1);
     TR(RC_BND_OUT_completion, bout) = in->completion_flag ? 1 : 0;
     TR(RC_BND_OUT_w_end, bout) = inv_or_zero(len_out); TR(RC_BND_OUT_z_end, bout) = len_out == 0;
     for (int k = 0; k < 4; k++) TR(RC_PI_pi0 + k, bin - RC_ROWOFF_BND_IN + RC_ROWOFF_PI) = job.public_input[k];
@@ -558,7 +588,7 @@ __global__ __launch_bounds__(64) void k_ram_check_rows(const u64* __restrict__ t
     const u32 i = blockIdx.x * CHK_ROWS + threadIdx.x;
     if (blockIdx.x * CHK_ROWS >= n_in_region) return;
     const bool live = i < n_in_region;
-    const size_t row = per_cycle ? (size_t)rt * capacity + i : (size_t)RC_ROWS_PER_CYCLE * capacity + (rt - RC_ROWS_PER_CYCLE);
+    const size_t row = per_cycle ? (size_t)rt * RC_REGION_STRIDE(capacity) + i : (size_t)RC_BOUNDARY_ROW(capacity) + (rt - RC_ROWS_PER_CYCLE);
     for (int c = 0; c < CHK_COLS; c++) {
         u64 v = live ? TR(c, row) : 0;
         tile[c * CHK_ROWS + threadIdx.x] = v;
@@ -613,19 +643,19 @@ __global__ __launch_bounds__(256) void k_ram_check_links(const u64* __restrict__
                                                          CheckResult* res) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
-    const size_t bnd = (size_t)RC_ROWS_PER_CYCLE * capacity;
+    const size_t bnd = (size_t)RC_BOUNDARY_ROW(capacity), rs = RC_REGION_STRIDE(capacity);
     for (int l = 0; l < RC_NUM_LINKS; l++) {
         const rc_link k = c_links[l];
         if (k.kind == 3) {
-            if (i == capacity - 1 && TR(k.col_a, bnd + RC_ROWOFF_BND_OUT) != TR(k.col_b, (size_t)k.row_b * capacity + i))
+            if (i == capacity - 1 && TR(k.col_a, bnd + RC_ROWOFF_BND_OUT) != TR(k.col_b, (size_t)k.row_b * rs + i))
                 flag_bad(res, 4, l, bnd + RC_ROWOFF_BND_OUT);
             continue;
         }
-        const size_t ra = (size_t)k.row_a * capacity + i;
+        const size_t ra = (size_t)k.row_a * rs + i;
         const u64 a = TR(k.col_a, ra);
         u64 b;
-        if (k.kind == 0) b = TR(k.col_b, (size_t)k.row_b * capacity + i);
-        else if (k.kind == 1) b = i ? TR(k.col_b, (size_t)k.row_b * capacity + i - 1) : TR(k.bin_col, bnd + RC_ROWOFF_BND_IN);
+        if (k.kind == 0) b = TR(k.col_b, (size_t)k.row_b * rs + i);
+        else if (k.kind == 1) b = i ? TR(k.col_b, (size_t)k.row_b * rs + i - 1) : TR(k.bin_col, bnd + RC_ROWOFF_BND_IN);
         else b = TR(k.col_b, bnd + RC_ROWOFF_BND_IN);
         if (a != b) flag_bad(res, 4, l, ra);
     }
@@ -637,14 +667,14 @@ __global__ __launch_bounds__(256) void k_ram_check_lookups(const u64* __restrict
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
-    const size_t pad0 = (size_t)RC_ROWS_PER_CYCLE * capacity + (RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE);
+    const size_t rs = RC_REGION_STRIDE(capacity), pad0 = (size_t)RC_BOUNDARY_ROW(capacity) + (RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
         for (int c = RC_G; c < RC_G + RC_L; c++) {
             const u64 v = TR(c, r);
             if (v > 255) flag_bad(res, 3, c, r); else atomicAdd(&sh_hist[v], 1u);
         }
-        if (r >= pad0)
+        if (r >= pad0 || (r < (size_t)RC_ROWS_PER_CYCLE * rs && r % rs >= capacity))  // tail padding and the region gaps
             for (int c = 0; c < RC_G; c++)
                 if (TR(c, r) != 0) { flag_bad(res, 6, c, r); break; }
     }

@@ -925,7 +925,8 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    const u32 n_tiles = (capacity + 255) / 256;
+    const u32 rstride = (u32)RC_REGION_STRIDE(capacity);  // rows per region incl. the alignment gap
+    const u32 n_tiles = (rstride + 255) / 256;
     u32 *d_hist = nullptr, *d_nd = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("synth_hist", n_instances * 256, &d_hist));
     ZKW_TRY(ctx->scratch_t<u32>("synth_nd", n_instances * n_tiles, &d_nd));
@@ -956,10 +957,10 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     SynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("synth_jobs", jobs, &d_jobs));
     const unsigned nj = (unsigned)n_instances;
-    const dim3 g64((capacity + 63) / 64, nj), g256(n_tiles, nj);
+    const dim3 g64((rstride + 63) / 64, nj), g256(n_tiles, nj);
     { Prof _p(ctx, "k_ram_nd_tiles"); hipLaunchKernelGGL(k_ram_nd_tiles, g256, dim3(256), 0, ctx->stream, d_jobs, capacity); }
     ZKW_TRY(launch_check("k_ram_nd_tiles"));
-    { Prof _p(ctx, "k_ram_nd_scan"); hipLaunchKernelGGL(k_ram_nd_scan, dim3((nj + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, (int)nj, n_tiles); }
+    { Prof _p(ctx, "k_ram_nd_scan"); hipLaunchKernelGGL(k_ram_nd_scan, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, (int)nj, n_tiles); }
     ZKW_TRY(launch_check("k_ram_nd_scan"));
     { Prof _p(ctx, "k_ram_fill_poseidon"); hipLaunchKernelGGL((k_ram_fill_poseidon<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_poseidon<0>"));
@@ -973,7 +974,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     ZKW_TRY(launch_check("k_ram_fill_C"));
     { Prof _p(ctx, "k_ram_fill_D"); hipLaunchKernelGGL(k_ram_fill_D, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_D"));
-    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(128, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3((RC_G + RC_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_tail"));
     { Prof _p(ctx, "k_ram_fill_boundary"); hipLaunchKernelGGL(k_ram_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_boundary"));

@@ -1,4 +1,4 @@
-"""Host-side helpers for RAMPermutation synthesis (zkw trace v1, include/zkw_ram_circuit_spec.h)."""
+"""Host-side helpers for RAMPermutation synthesis (zkw trace v2, include/zkw_ram_circuit_spec.h)."""
 import numpy as np
 
 ROWS_PER_CYCLE = 6
@@ -6,9 +6,22 @@ N_COLS = 149
 N_BOUNDARY_ROWS = 3
 
 
+REGION_ALIGN = 64
+
+
+def region_stride(capacity: int) -> int:
+    """RC_REGION_STRIDE: rows per region; every region starts on a 64-row boundary."""
+    return (capacity + REGION_ALIGN - 1) // REGION_ALIGN * REGION_ALIGN
+
+
+def boundary_row(capacity: int) -> int:
+    """RC_BOUNDARY_ROW: first of the three boundary rows (BND_IN, BND_OUT, PI)."""
+    return ROWS_PER_CYCLE * region_stride(capacity)
+
+
 def min_rows(capacity: int) -> int:
     """RC_MIN_ROWS: rows a trace needs for a given per-circuit capacity."""
-    return ROWS_PER_CYCLE * capacity + N_BOUNDARY_ROWS
+    return boundary_row(capacity) + N_BOUNDARY_ROWS
 
 
 def smoke(ctx, witness, oracle_out, pyoracle):

@@ -105,6 +105,6 @@ void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_inst
                                size_t n_rows, uint64_t *trace) {
     uint64_t compact[18], pi[4];
     orc_ram_public_input(first, in, compact, pi);
-    const size_t row = (size_t)RC_ROWS_PER_CYCLE * capacity + RC_ROWOFF_PI;
+    const size_t row = (size_t)RC_BOUNDARY_ROW(capacity) + RC_ROWOFF_PI;
     for (int k = 0; k < 4; k++) trace[(size_t)(RC_PI_pi0 + k) * n_rows + row] = pi[k];
 }

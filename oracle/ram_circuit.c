@@ -72,7 +72,7 @@ void orc_poseidon2_flattened(const uint64_t in[12], uint64_t slots[130]) {
 
 /* column-major trace: cell(col, row) = t[col * n_rows + row] */
 #define CELL(col, row) trace[(size_t)(col) * n_rows + (row)]
-#define ROWOF(region, cyc) ((size_t)(region) * capacity + (cyc))
+#define ROWOF(region, cyc) ((size_t)(region) * RC_REGION_STRIDE(capacity) + (cyc))
 
 static uint64_t inv_or_zero(uint64_t x) { return x % P ? orc_gl_inv(x) : 0; }
 
@@ -317,7 +317,7 @@ uint64_t orc_ram_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, 
         if (!bad && first_bad) *first_bad = ((uint64_t)(kind) << 56) | ((uint64_t)(idx) << 32) | (uint64_t)(row); \
         bad++;                                                                                      \
     } while (0)
-    const size_t bnd = (size_t)RC_ROWS_PER_CYCLE * capacity;
+    const size_t bnd = (size_t)RC_BOUNDARY_ROW(capacity);
     for (size_t i = 0; i < capacity; i++) {
         for (int rt = 0; rt < RC_ROWS_PER_CYCLE; rt++) {
             const size_t row = ROWOF(rt, i);
@@ -368,6 +368,10 @@ uint64_t orc_ram_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, 
     for (size_t r = bnd + (RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE); r < n_rows; r++)
         for (int c = 0; c < RC_G + RC_L; c++)
             if (CELL(c, r)) { FLAG(6, c, r); break; }
+    for (int rt = 0; rt < RC_ROWS_PER_CYCLE; rt++) /* the alignment gap at the end of every region */
+        for (size_t r = ROWOF(rt, capacity); r < ROWOF(rt + 1, 0); r++)
+            for (int c = 0; c < RC_G + RC_L; c++)
+                if (CELL(c, r)) { FLAG(6, c, r); break; }
     /* canonical form everywhere */
     for (int c = 0; c < RC_COLS; c++)
         for (size_t r = 0; r < n_rows; r++)

@@ -4,6 +4,8 @@ and rejects tampered traces; production geometry (2^20 rows, capacity 136 714) v
 import ctypes as C
 
 import numpy as np
+
+from era_zkevm_test_harness_amd.ram_circuit import boundary_row
 import pytest
 
 from era_zkevm_test_harness_amd import synthetic
@@ -41,7 +43,7 @@ def _trace(n, seed, pages=3, indices=16, heap_writes=2):
     return q
 
 
-@pytest.mark.parametrize("n,capacity,n_rows", [(1, 8, 256), (100, 128, 1024), (256, 128, 1024), (700, 256, 2048),
+@pytest.mark.parametrize("n,capacity,n_rows", [(1, 8, 512), (100, 128, 1024), (256, 128, 1024), (700, 256, 2048),
                                                (5000, 2048, 1 << 14)])
 def test_trace_matches_oracle(ctx, oracle, n, capacity, n_rows):
     from era_zkevm_test_harness_amd import native
@@ -79,7 +81,7 @@ def test_gpu_checker_rejects_tampering(ctx, oracle):
     assert ctx.check_if_satisfied_ram(t, 0, capacity)[0] == 0
     host = t.get(0)
     rng = np.random.default_rng(2)
-    used = np.argwhere(host[:148, :6 * capacity + 2] != 0)
+    used = np.argwhere(host[:148, :boundary_row(capacity) + 2] != 0)
     kinds = set()
     base = native.load().zkw_trace_device_ptr(t.handle, 0)
     for _ in range(25):
@@ -140,7 +142,7 @@ def test_production_geometry(ctx):
         assert bad == 0, (idx, first)
         mult = t.get(idx, 148, 1)[0]
         assert int(mult.sum()) == 15 * n_rows and not mult[256:].any()
-        bout = t.get(idx, 0, 40)[:, 6 * capacity + 1]
+        bout = t.get(idx, 0, 40)[:, boundary_row(capacity) + 1]
         fo = inst[idx]["hidden_fsm_output"]
         assert np.array_equal(bout[0:12], fo["current_unsorted_queue_state"]["head"])
         assert np.array_equal(bout[26:28], fo["lhs_accumulator"]) and np.array_equal(bout[28:30], fo["rhs_accumulator"])

@@ -2,6 +2,8 @@
 constraint / copy link / lookup of the spec, and tampering is detected (the reference's tests run
 `check_if_satisfied` on every emitted circuit, src/tests/mod.rs:130-259)."""
 import numpy as np
+
+from era_zkevm_test_harness_amd.ram_circuit import boundary_row
 import pytest
 
 from era_zkevm_test_harness_amd import synthetic
@@ -37,7 +39,7 @@ def test_flattened_poseidon_matches_permutation(oracle):
     assert np.array_equal(slots[118:], oracle.poseidon2(s))
 
 
-@pytest.mark.parametrize("n,capacity,n_rows", [(100, 128, 1024), (256, 128, 1024), (300, 128, 1 << 12), (1, 8, 256)])
+@pytest.mark.parametrize("n,capacity,n_rows", [(100, 128, 1024), (256, 128, 1024), (300, 128, 1 << 12), (1, 8, 512)])
 def test_oracle_trace_is_satisfied(oracle, n, capacity, n_rows):
     o = _build(oracle, n, capacity)
     for idx in range(o["instances"].size):
@@ -49,7 +51,7 @@ def test_oracle_trace_is_satisfied(oracle, n, capacity, n_rows):
         assert int(t[148].sum()) == 15 * n_rows
         # the boundary-out registers are the instance's hidden_fsm_output
         fo = o["instances"][idx]["hidden_fsm_output"]
-        bout = 6 * capacity + 1
+        bout = boundary_row(capacity) + 1
         assert np.array_equal(t[0:12, bout], fo["current_unsorted_queue_state"]["head"])
         assert np.array_equal(t[24:26, bout].astype(np.uint32),
                               [fo["current_unsorted_queue_state"]["length"], fo["current_sorted_queue_state"]["length"]])
@@ -66,7 +68,7 @@ def test_tampering_is_detected(oracle):
     assert oracle.ram_check(t, capacity)[0] == 0
     rng = np.random.default_rng(1)
     kinds = set()
-    used = [(c, r) for c in range(148) for r in range(6 * capacity + 2) if t[c, r] != 0]
+    used = [(c, r) for c in range(148) for r in range(boundary_row(capacity) + 2) if t[c, r] != 0]
     for _ in range(60):
         c, r = used[rng.integers(len(used))]
         t2 = t.copy()
@@ -75,7 +77,7 @@ def test_tampering_is_detected(oracle):
         assert bad > 0, (c, r)
         kinds.add(first[0])
     assert {1, 2} <= kinds  # constraint and poseidon violations both occur
-    t2 = t.copy(); t2[39, 6 * capacity + 1] += 1  # BND_OUT.cnt is held by a copy link only
+    t2 = t.copy(); t2[39, boundary_row(capacity) + 1] += 1  # BND_OUT.cnt is held by a copy link only
     assert oracle.ram_check(t2, capacity)[1][0] == 4
     # a wrong multiplicity and a dirty padding row
     t2 = t.copy(); t2[148, 0] -= 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates include/zkw_ram_circuit_spec.h — the declarative layout of the RAMPermutation trace that
-libzkw emits ("zkw trace v1"): row types, named slots, lookup cells, polynomial constraints per row
+libzkw emits ("zkw trace v2"): row types, named slots, lookup cells, polynomial constraints per row
 type and the copy links between slots. The fill kernels (csrc), the oracle's fill (oracle/) and both
 checkers are written against this one table, so the table IS the contract of `zkw_ram_synthesize`.
 
@@ -254,7 +254,7 @@ def emit(rows, links, path):
     out = []
     w = out.append
     w("/* GENERATED by tools/gen_ram_circuit.py — do not edit. Layout contract of the RAMPermutation trace")
-    w(" * emitted by zkw_ram_synthesize (\"zkw trace v1\"). See the generator's docstring and DESIGN.md. */")
+    w(" * emitted by zkw_ram_synthesize (\"zkw trace v2\"). See the generator's docstring and DESIGN.md. */")
     w("#ifndef ZKW_RAM_CIRCUIT_SPEC_H\n#define ZKW_RAM_CIRCUIT_SPEC_H\n#include <stdint.h>")
     w(f"#define RC_G {G}            /* general-purpose (copy-permutation) columns 0..{G - 1} */")
     w(f"#define RC_L {L}             /* lookup columns {G}..{G + L - 1}: every cell is in [0, 256) */")
@@ -262,15 +262,21 @@ def emit(rows, links, path):
     w(f"#define RC_COLS {G + L + 1}")
     w(f"#define RC_HEAP_PAGE {HEAP_PAGE}")
     n_cyc = sum(1 for r in rows if r.per_cycle)
-    w(f"#define RC_ROWS_PER_CYCLE {n_cyc}  /* region-major: row of (region r, cycle i) = r*capacity + i */")
+    w(f"#define RC_ROWS_PER_CYCLE {n_cyc}  /* region-major: row of (region r, cycle i) = r*RC_REGION_STRIDE(capacity) + i */")
+    w("/* every region starts on a 64-row (512-byte) boundary so that a wave's 64 x 8-byte store of one column is one")
+    w("   aligned 512-byte burst (misaligned regions cap the fills at 3.5 TB/s instead of 5.6, tools/ubench_fill.hip);")
+    w("   rows [capacity, stride) of a region are zero */")
+    w("#define RC_REGION_ALIGN 64")
+    w("#define RC_REGION_STRIDE(capacity) ((((uint64_t)(capacity)) + RC_REGION_ALIGN - 1) & ~(uint64_t)(RC_REGION_ALIGN - 1))")
+    w("#define RC_BOUNDARY_ROW(capacity) ((uint64_t)RC_ROWS_PER_CYCLE * RC_REGION_STRIDE(capacity))")
     w(f"#define RC_NUM_ROW_TYPES {len(rows)}")
     w("/* boundary rows sit right after the per-cycle regions */")
     for i, r in enumerate(rows):
         w(f"#define RC_ROW_{r.name} {i}")
     for i, r in enumerate(rows):
         if not r.per_cycle:
-            w(f"#define RC_ROWOFF_{r.name} {i - n_cyc}  /* row = RC_ROWS_PER_CYCLE*capacity + this */")
-    w(f"#define RC_MIN_ROWS(capacity) ((uint64_t)RC_ROWS_PER_CYCLE * (capacity) + {len(rows) - n_cyc})")
+            w(f"#define RC_ROWOFF_{r.name} {i - n_cyc}  /* row = RC_BOUNDARY_ROW(capacity) + this */")
+    w(f"#define RC_MIN_ROWS(capacity) (RC_BOUNDARY_ROW(capacity) + {len(rows) - n_cyc})")
     w("/* named slots: RC_<row>_<var> = column of that variable in rows of that type */")
     for r in rows:
         for v in r.slots + r.lookups:
