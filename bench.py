@@ -87,8 +87,13 @@ def main():
         # one block of n queries keeps ~74 B/query... measured 69 MB per 136 714-query block (inputs 6.6 + witness
         # 54.7 + sort scratch 5.5 + chain/descriptor scratch); the chains want as many concurrent queues as fit
         free, _total = torch.cuda.mem_get_info(dev)
-        per_block = int(n * 520)
-        B = int(max(16, min(3072, (0.82 * free - args.ring * 1.25e9) // per_block)))
+        # resident per query: input 48 + sorted copy 48 + two encodings 2 x 64 + capacity words of the tails 2 x 32 +
+        # grand products 2 x 16 = 320 bytes (sort scratch aliases arrays that are filled later). Cap: 4096 blocks =
+        # 8192 queue chains. Inside the builder the chain kernel runs at 14.7 us per step up to ~8 400 chains and
+        # at 22.3 us beyond (measured cliff), so more blocks per step only pay above ~6 000 blocks,
+        # which do not fit the HBM.
+        per_block = int(n * 330)
+        B = int(max(16, min(4096, (0.90 * free - args.ring * 1.25e9) // per_block)))
     n_rows = 1 << 20  # TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17
     ring = native.Trace(ctx, n_rows, args.ring)  # trace buffers a prover would consume and hand back
     base, q = make_inputs(B, n, rank, dev)

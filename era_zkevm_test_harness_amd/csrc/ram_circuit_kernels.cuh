@@ -21,8 +21,10 @@ struct SynthJob {
     const zkw_mem_query* sorted_q;  // block-wide arrays (device), indexed by item
     const u64* unsorted_enc;
     const u64* sorted_enc;
-    const u64* unsorted_tails;
-    const u64* sorted_tails;
+    const u64* unsorted_caps;  // [n_block][4] capacity words of the unsorted queue tail after every item
+    const u64* sorted_caps;
+    const u64* u_mark;         // [12] full unsorted / sorted queue tail after this instance's last item
+    const u64* s_mark;
     const u64* challenges;  // [2][9]
     const u64* lhs_z;       // [2][n_block] grand-product chains of the instance's block
     const u64* rhs_z;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __rest
         const bool can_pop = i < m;
         const size_t row = (size_t)(SIDE == 0 ? RC_ROW_PU : RC_ROW_PS) * RC_REGION_STRIDE(capacity) + i;
         const u64* enc = SIDE == 0 ? job.unsorted_enc : job.sorted_enc;
-        const u64* tails = SIDE == 0 ? job.unsorted_tails : job.sorted_tails;
+        const u64* caps = SIDE == 0 ? job.unsorted_caps : job.sorted_caps;
         u64 s[12];
         if (can_pop) {
             const ulonglong2* src = reinterpret_cast<const ulonglong2*>(enc + 8 * (first + i));
@@ -112,9 +114,10 @@ __global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __rest
             for (int k = 0; k < 8; k++) s[k] = 0;
         }
         const RegsIn ri = regs_in(in);
-        const u64* prev_head = i == 0 ? (SIDE == 0 ? ri.uh : ri.sh) : tails + 12 * (first + (i - 1 < m ? i - 1 : m - 1));
+        // capacity part of the queue head entering this cycle
+        const u64* prev_cap = i == 0 ? (SIDE == 0 ? ri.uh : ri.sh) + 8 : caps + 4 * (first + (i - 1 < m ? i - 1 : m - 1));
 #pragma unroll
-        for (int k = 0; k < 4; k++) s[8 + k] = prev_head[8 + k];
+        for (int k = 0; k < 4; k++) s[8 + k] = prev_cap[k];
         int pos = 0;
 #pragma unroll
         for (int k = 0; k < 12; k++) TR(pos++, row) = s[k];
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__
     }
     u64* trace = job.trace;
     const zkw_ram_instance* in = job.inst;
-    const size_t first = in->first_item, m = in->num_items, row = (size_t)RC_ROW_D * rs + i;
+    const size_t m = in->num_items, row = (size_t)RC_ROW_D * rs + i;
     const size_t rPU = (size_t)RC_ROW_PU * rs + i, rPS = (size_t)RC_ROW_PS * rs + i;
     const RegsIn ri = regs_in(in);
     const bool can_pop = i < m;
@@ -450,15 +453,15 @@ __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__
     TR(RC_D_P_len_s, row) = p_len; TR(RC_D_w_ls, row) = w_len; TR(RC_D_z_ls, row) = z_len;
     TR(RC_D_can_pop, row) = can_pop ? 1 : 0;
     TR(RC_D_len_u, row) = p_len - (can_pop ? 1 : 0); TR(RC_D_len_s, row) = p_len - (can_pop ? 1 : 0);
-    const u64* puh = i == 0 ? ri.uh : job.unsorted_tails + 12 * (first + (i - 1 < m ? i - 1 : m - 1));
-    const u64* psh = i == 0 ? ri.sh : job.sorted_tails + 12 * (first + (i - 1 < m ? i - 1 : m - 1));
+    // The Poseidon2 rows (written earlier on this stream by k_ram_fill_poseidon) hold the queue tails: the output of
+    // a popped cycle IS the tail after that item. The head entering cycle i is the output of the last popped cycle
+    // before it (the FSM input for i = 0).
+    const size_t p = i - 1 < m ? i - 1 : m - 1, rPUp = (size_t)RC_ROW_PU * rs + p, rPSp = (size_t)RC_ROW_PS * rs + p;
 #pragma unroll
     for (int k = 0; k < 12; k++) {
-        // popped cycle: the Poseidon2 row's output IS the queue tail after this item (verified by the checker's
-        // copy links); padding cycle: read what k_ram_fill_poseidon wrote earlier on this stream
-        const u64 uo = can_pop ? job.unsorted_tails[12 * (first + i) + k] : TR(RC_PU_uo0 + k, rPU);
-        const u64 so = can_pop ? job.sorted_tails[12 * (first + i) + k] : TR(RC_PS_so0 + k, rPS);
-        const u64 a = puh[k], b = psh[k];
+        const u64 uo = TR(RC_PU_uo0 + k, rPU);
+        const u64 so = TR(RC_PS_so0 + k, rPS);
+        const u64 a = i == 0 ? ri.uh[k] : TR(RC_PU_uo0 + k, rPUp), b = i == 0 ? ri.sh[k] : TR(RC_PS_so0 + k, rPSp);
         const int o = 3 * k;
         TR(RC_D_uo0 + o, row) = uo; TR(RC_D_P_uh0 + o, row) = a; TR(RC_D_uh0 + o, row) = can_pop ? uo : a;
         TR(RC_D_so0 + o, row) = so; TR(RC_D_P_sh0 + o, row) = b; TR(RC_D_sh0 + o, row) = can_pop ? so : b;
@@ -532,8 +535,8 @@ __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __rest
     const bool padded = m < capacity;
     const u64 len_out = (u64)ri.len - m;
     for (int k = 0; k < 12; k++) {
-        TR(RC_BND_OUT_uh0 + k, bout) = job.unsorted_tails[12 * last + k];
-        TR(RC_BND_OUT_sh0 + k, bout) = job.sorted_tails[12 * last + k];
+        TR(RC_BND_OUT_uh0 + k, bout) = job.u_mark[k];
+        TR(RC_BND_OUT_sh0 + k, bout) = job.s_mark[k];
         TR(RC_BND_OUT_tail_u0 + k, bout) = in->unsorted_queue_initial_state.tail[k];
         TR(RC_BND_OUT_tail_s0 + k, bout) = in->sorted_queue_initial_state.tail[k];
     }

@@ -57,9 +57,24 @@ __global__ __launch_bounds__(256) void k_encode_mem(const zkw_mem_query* __restr
 // capacity(tails[i-1])). The absorb loads are prefetched one item ahead; stores are fire-and-forget.
 struct ChainJob {
     const u64* enc;      // [n][8]
-    u64* tails;          // [n][12]
+    u64* tails;          // [n][12], or nullptr when only the compact outputs below are wanted
     const u64* tail_in;  // [12] or nullptr (= zeros)
     u64 n;
+    // compact outputs (RAM builder): the next absorption only needs the capacity words of a tail, and any full tail
+    // is one permutation away from (enc[i], caps[i-1]); full tails are kept at the instance boundaries only
+    u64* caps;           // [n][4] elements 8..11 of every tail, or nullptr
+    u64* marks;          // [ceil(n / period)][12] full tails at items period-1, 2*period-1, ... and n-1, or nullptr
+    u64 period;
+};
+
+// The stores of item i are issued at the top of iteration i + 1, before the prefetch of item i + 2: gfx9 counts
+// loads and stores in one in-order vmcnt, so consuming the prefetched encoding waits for every earlier store too.
+// Stored late, those stores are a whole permutation (>= 10 us) old by then; stored right after the permutation their
+// write latency was exposed once per step (15 -> 22.5 us per step beyond ~8.5 k concurrent chains).
+struct ChainOut {
+    u64* tails;
+    u64* caps;
+    u64* marks;
 };
 
 __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ jobs, int n_jobs) {
@@ -68,21 +83,40 @@ __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ 
     p2::Coop co;
     co.init(g);
     ChainJob job;
-    job.enc = nullptr; job.tails = nullptr; job.tail_in = nullptr; job.n = 0;
+    memset(&job, 0, sizeof job);
     if (chain < n_jobs) job = jobs[chain];
     u64 x = (co.active && job.tail_in) ? job.tail_in[g] : 0;
     const bool absorbs = g < 8;
     u64 e_next = (absorbs && job.n > 0) ? job.enc[g] : 0;
+    u64 next_mark = job.marks ? job.period : ~0ull, mark_idx = 0;  // item count at which the next full tail is kept
+    u64 pend = 0, pend_i = 0;  // canonical tail of the previous item, not stored yet
+    bool have_pend = false, pend_mark = false;
+    auto flush = [&]() {
+        if (!have_pend) return;
+        if (co.active && job.tails) job.tails[12 * pend_i + g] = pend;
+        if (g >= 8 && g < 12 && job.caps) job.caps[4 * pend_i + (g - 8)] = pend;
+        if (pend_mark) {
+            if (co.active) job.marks[12 * mark_idx + g] = pend;
+            mark_idx++;
+        }
+        have_pend = false;
+    };
     for (u64 i = 0; __any(i < job.n); i++) {
         const bool live = i < job.n;
         u64 e = e_next;
+        flush();
         if (absorbs && i + 1 < job.n) e_next = job.enc[8 * (i + 1) + g];
         u64 y = co.permute(absorbs ? e : x);  // AbsorptionModeOverwrite
         if (live) {
             x = y;
-            if (co.active) job.tails[12 * i + g] = gl::canon(y);
+            pend = gl::canon(y);
+            pend_i = i;
+            have_pend = true;
+            pend_mark = job.marks && (i + 1 == next_mark || i + 1 == job.n);
+            if (pend_mark) next_mark += job.period;
         }
     }
+    flush();
 }
 
 // Quad form: 16 chains per wave (p2::Coop4). Lane j of a quad loads enc[j], enc[4+j] and stores tails[j],
@@ -93,26 +127,46 @@ __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict
     p2::Coop4 co;
     co.init(j);
     ChainJob job;
-    job.enc = nullptr; job.tails = nullptr; job.tail_in = nullptr; job.n = 0;
+    memset(&job, 0, sizeof job);
     if (chain < n_jobs) job = jobs[chain];
     u64 x[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) x[c] = job.tail_in ? job.tail_in[4 * c + j] : 0;
     u64 e0 = 0, e1 = 0;
     if (job.n > 0) { e0 = job.enc[j]; e1 = job.enc[4 + j]; }
+    u64 next_mark = job.marks ? job.period : ~0ull, mark_idx = 0;
+    u64 pend[3] = {0, 0, 0}, pend_i = 0;
+    bool have_pend = false, pend_mark = false;
+    auto flush = [&]() {
+        if (!have_pend) return;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (job.tails) job.tails[12 * pend_i + 4 * c + j] = pend[c];
+            if (c == 2 && job.caps) job.caps[4 * pend_i + j] = pend[c];
+            if (pend_mark) job.marks[12 * mark_idx + 4 * c + j] = pend[c];
+        }
+        if (pend_mark) mark_idx++;
+        have_pend = false;
+    };
     for (u64 i = 0; __any(i < job.n); i++) {
         const bool live = i < job.n;
         u64 y[3] = {e0, e1, x[2]};  // AbsorptionModeOverwrite: rate part replaced, capacity kept
+        flush();
         if (i + 1 < job.n) { e0 = job.enc[8 * (i + 1) + j]; e1 = job.enc[8 * (i + 1) + 4 + j]; }
         co.permute(y);
         if (live) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 x[c] = y[c];
-                job.tails[12 * i + 4 * c + j] = gl::canon(y[c]);
+                pend[c] = gl::canon(y[c]);
             }
+            pend_i = i;
+            have_pend = true;
+            pend_mark = job.marks && (i + 1 == next_mark || i + 1 == job.n);
+            if (pend_mark) next_mark += job.period;
         }
     }
+    flush();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -332,8 +386,8 @@ __global__ __launch_bounds__(256) void k_gather_encode(const zkw_mem_query* __re
 // field is a pure function of the block-wide arrays, so each instance is filled independently.
 struct RamBlock {
     const zkw_mem_query* sorted_q;  // [n]
-    const u64* unsorted_tails;      // [n][12]
-    const u64* sorted_tails;        // [n][12]
+    const u64* u_marks;             // [n_instances][12] unsorted queue tail after the last item of each instance
+    const u64* s_marks;             // [n_instances][12] the same for the sorted queue
     const u64* lhs_z;               // [2][n]
     const u64* rhs_z;               // [2][n]
     zkw_ram_instance* instances;    // [ceil(n/capacity)]
@@ -380,8 +434,8 @@ __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
     w.completion_flag = idx == n_inst - 1;
     w.first_item = lo;
     w.num_items = hi - lo;
-    const u64* u_final = b.unsorted_tails + 12 * (n - 1);
-    const u64* s_final = b.sorted_tails + 12 * (n - 1);
+    const u64* u_final = b.u_marks + 12 * (n_inst - 1);
+    const u64* s_final = b.s_marks + 12 * (n_inst - 1);
     copy12(w.unsorted_queue_initial_state.tail, u_final);
     w.unsorted_queue_initial_state.length = (u32)n;
     copy12(w.sorted_queue_initial_state.tail, s_final);
@@ -395,10 +449,10 @@ __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
     auto fill = [&](zkw_ram_fsm& f, u64 end /* items consumed so far, > 0 */, u32 nondet) {
         const u64 l = end - 1;
         for (int r = 0; r < 2; r++) { f.lhs_accumulator[r] = b.lhs_z[r * n + l]; f.rhs_accumulator[r] = b.rhs_z[r * n + l]; }
-        copy12(f.current_unsorted_queue_state.head, b.unsorted_tails + 12 * l);
+        copy12(f.current_unsorted_queue_state.head, b.u_marks + 12 * (l / b.capacity));
         copy12(f.current_unsorted_queue_state.tail, u_final);
         f.current_unsorted_queue_state.length = (u32)(n - end);
-        copy12(f.current_sorted_queue_state.head, b.sorted_tails + 12 * l);
+        copy12(f.current_sorted_queue_state.head, b.s_marks + 12 * (l / b.capacity));
         copy12(f.current_sorted_queue_state.tail, s_final);
         f.current_sorted_queue_state.length = (u32)(n - end);
         const zkw_mem_query* q = b.sorted_q + l;
@@ -422,6 +476,31 @@ __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
         f.previous_is_ptr = 0;
     }
     b.instances[idx] = w;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Full tails on demand: tails[i] = permute(enc[i] || caps[i-1]) (zero capacity at the first item of a queue).
+// One item per lane; offsets[] are the queue boundaries inside the batch.
+__global__ __launch_bounds__(64) void k_tails_expand(const u64* __restrict__ enc, const u64* __restrict__ caps,
+                                                     const u64* __restrict__ offsets, int n_queues, size_t n,
+                                                     u64* __restrict__ tails) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = n_queues;  // largest b with offsets[b] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = enc[8 * i + k];
+    const bool first = offsets[lo] == i;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[8 + k] = first ? 0 : caps[4 * (i - 1) + k];
+    p2::permute(s);
+#pragma unroll
+    for (int k = 0; k < 12; k++) tails[12 * i + k] = gl::canon(s[k]);
 }
 
 }  // namespace zkw

@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -586,19 +587,27 @@ struct zkw_ram_witness {
     size_t total = 0, n_instances = 0;
     // owned device arrays
     zkw_mem_query* sorted_q = nullptr;
-    u64 *unsorted_enc = nullptr, *sorted_enc = nullptr, *unsorted_tails = nullptr, *sorted_tails = nullptr;
+    u64 *unsorted_enc = nullptr, *sorted_enc = nullptr;
+    // queue tails, compact: capacity words of every tail [total][4] + full tails at instance ends [n_instances][12];
+    // the full [total][12] arrays of the C ABI are expanded on first access (ram_full_tails)
+    u64 *unsorted_caps = nullptr, *sorted_caps = nullptr, *unsorted_marks = nullptr, *sorted_marks = nullptr;
+    u64 *unsorted_tails = nullptr, *sorted_tails = nullptr;
+    bool tails_valid = false;
     u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
     zkw_ram_instance* instances = nullptr;
     u32* nondet_counts = nullptr;
     u64 *compact_forms = nullptr, *public_inputs = nullptr;  // [n_instances][18], [n_instances][4]
 
     void release() {
-        void* ptrs[] = {sorted_q, unsorted_enc, sorted_enc, unsorted_tails, sorted_tails, challenges,
+        void* ptrs[] = {sorted_q, unsorted_enc, sorted_enc, unsorted_caps, sorted_caps, unsorted_marks, sorted_marks,
+                        unsorted_tails, sorted_tails, challenges,
                         lhs_z,    rhs_z,        instances,  nondet_counts, compact_forms, public_inputs};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         sorted_q = nullptr;
         unsorted_enc = sorted_enc = unsorted_tails = sorted_tails = challenges = lhs_z = rhs_z = nullptr;
+        unsorted_caps = sorted_caps = unsorted_marks = sorted_marks = nullptr;
+        tails_valid = false;
         instances = nullptr;
         nondet_counts = nullptr;
         compact_forms = public_inputs = nullptr;
@@ -610,8 +619,10 @@ static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
     HIP_TRY(hipMalloc((void**)&w->sorted_q, (t + 1) * sizeof(zkw_mem_query)));
     HIP_TRY(hipMalloc((void**)&w->unsorted_enc, (t + 1) * 8 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->sorted_enc, (t + 1) * 8 * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->unsorted_tails, (t + 1) * 12 * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->sorted_tails, (t + 1) * 12 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->unsorted_caps, (t + 1) * 4 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->sorted_caps, (t + 1) * 4 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->unsorted_marks, (ni + 1) * 12 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void**)&w->sorted_marks, (ni + 1) * 12 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->challenges, (n_blocks + 1) * 18 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->lhs_z, (t + 1) * 2 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->rhs_z, (t + 1) * 2 * sizeof(u64)));
@@ -634,21 +645,24 @@ __global__ void k_block_ids(const u64* __restrict__ offsets, int n_blocks, size_
 }
 
 // the sorting permutation for all blocks at once (see sort.hip)
+// `work_a` / `work_b`: two device areas of 32 bytes per query that nothing else uses until the sort is over (the
+// builder passes the capacity-word arrays, which the chains fill afterwards); the radix temporary falls back to
+// the context scratch when it does not fit (tiny batches: its histograms dominate).
 static int ram_sort(zkw_ctx* ctx, const zkw_mem_query* d_q, size_t total, const std::vector<uint64_t>& offsets,
-                    u32** perm_out) {
+                    void* work_a, void* work_b, u32** perm_out) {
     const size_t n_blocks = offsets.size() - 1;
-    u32 *ts = nullptr, *k32 = nullptr, *v0 = nullptr, *v1 = nullptr;
-    u64 *cell = nullptr, *k64a = nullptr, *k64b = nullptr;
-    void* tmp = nullptr;
     size_t tmp_bytes = radix_temp_bytes(total);
-    ZKW_TRY(ctx->scratch_t<u32>("sort_ts", total, &ts));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_k32", total, &k32));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_v0", total, &v0));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_v1", total, &v1));
-    ZKW_TRY(ctx->scratch_t<u64>("sort_cell", total, &cell));
-    ZKW_TRY(ctx->scratch_t<u64>("sort_k64a", total, &k64a));
-    ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", total, &k64b));
-    ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
+    // work_a: ts | k32 | v0 | v1 (4 x u32) | cell | k64a (2 x u64) = 32 bytes per query
+    u32* ts = static_cast<u32*>(work_a);
+    u32 *k32 = ts + total, *v0 = k32 + total, *v1 = v0 + total;
+    u64* cell = reinterpret_cast<u64*>(v1 + total);
+    u64* k64a = cell + total;
+    // work_b: k64b | radix temporary
+    u64* k64b = static_cast<u64*>(work_b);
+    void* tmp = nullptr;
+    const size_t tmp_off = (total * 8 + 255) & ~(size_t)255;
+    if (tmp_off + tmp_bytes <= total * 32) tmp = static_cast<char*>(work_b) + tmp_off;
+    else ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
     const unsigned grid = blocks_for(total, 256);
     { Prof _p(ctx, "k_ram_sort_keys"); hipLaunchKernelGGL(k_ram_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, total, ts, cell, v0,
                        (const u64*)nullptr, 0); }
@@ -684,7 +698,8 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     ZKW_TRY(dev_encode(ctx, d_q, total, w->unsorted_enc));
     // K7 + K1 (sorted side)
     u32* perm = nullptr;
-    ZKW_TRY(ram_sort(ctx, d_q, total, w->offsets, &perm));
+    ZKW_TRY(ram_sort(ctx, d_q, total, w->offsets, w->unsorted_caps, w->sorted_caps, &perm));
+    w->tails_valid = false;
     { Prof _p(ctx, "k_gather_encode"); hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, d_q, perm, total,
                        w->sorted_q, w->sorted_enc); }
     ZKW_TRY(launch_check("k_gather_encode"));
@@ -693,15 +708,17 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     chains.reserve(2 * n_blocks);
     for (size_t b = 0; b < n_blocks; b++) {
         const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
-        chains.push_back(ChainJob{w->unsorted_enc + 8 * lo, w->unsorted_tails + 12 * lo, nullptr, n});
-        chains.push_back(ChainJob{w->sorted_enc + 8 * lo, w->sorted_tails + 12 * lo, nullptr, n});
+        const size_t io = w->inst_offsets[b];
+        chains.push_back(ChainJob{w->unsorted_enc + 8 * lo, nullptr, nullptr, n, w->unsorted_caps + 4 * lo, w->unsorted_marks + 12 * io, w->capacity});
+        chains.push_back(ChainJob{w->sorted_enc + 8 * lo, nullptr, nullptr, n, w->sorted_caps + 4 * lo, w->sorted_marks + 12 * io, w->capacity});
     }
     ZKW_TRY(dev_chains(ctx, chains));
     // K5: challenges from the two final tails (W/ram_permutation.rs:80-90)
     std::vector<FsJob> fs(n_blocks);
     for (size_t b = 0; b < n_blocks; b++) {
         const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
-        fs[b] = FsJob{w->unsorted_tails + 12 * (lo + n - 1), w->sorted_tails + 12 * (lo + n - 1), (u32)n, (u32)n,
+        const size_t last_inst = w->inst_offsets[b + 1] - 1;  // the block's last instance ends on its last item
+        fs[b] = FsJob{w->unsorted_marks + 12 * last_inst, w->sorted_marks + 12 * last_inst, (u32)n, (u32)n,
                       w->challenges + 18 * b};
     }
     ZKW_TRY(dev_fs(ctx, fs, 12, 9));
@@ -722,8 +739,8 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
         const size_t n_inst = w->inst_offsets[b + 1] - w->inst_offsets[b];
         if (n_inst > max_inst) max_inst = n_inst;
         blocks[b] = RamBlock{w->sorted_q + lo,
-                             w->unsorted_tails + 12 * lo,
-                             w->sorted_tails + 12 * lo,
+                             w->unsorted_marks + 12 * w->inst_offsets[b],
+                             w->sorted_marks + 12 * w->inst_offsets[b],
                              w->lhs_z + 2 * lo,
                              w->rhs_z + 2 * lo,
                              w->instances + w->inst_offsets[b],
@@ -811,14 +828,37 @@ extern "C" int zkw_ram_build_instances(zkw_ctx* ctx, const zkw_mem_query* q, siz
 extern "C" size_t zkw_ram_witness_num_instances(const zkw_ram_witness* w) { return w ? w->n_instances : 0; }
 extern "C" size_t zkw_ram_witness_num_items(const zkw_ram_witness* w) { return w ? w->total : 0; }
 
-static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes) {
+// The [total][12] tail arrays of the ABI. The builder keeps tails compact (capacity words + instance ends); the full
+// arrays are expanded on first access: one independent permutation per item from (enc[i], caps[i-1]).
+static int ram_full_tails(const zkw_ram_witness* cw) {
+    zkw_ram_witness* w = const_cast<zkw_ram_witness*>(cw);
+    if (w->tails_valid) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t t = w->total;
+    if (!w->unsorted_tails) {
+        if (hipMalloc((void**)&w->unsorted_tails, (t + 1) * 96) != hipSuccess || hipMalloc((void**)&w->sorted_tails, (t + 1) * 96) != hipSuccess)
+            return fail(ZKW_ERR_OOM, "no room for the expanded queue tails (%zu bytes): read ZKW_RAM_*_TAILS from a smaller batch", 2 * t * 96);
+    }
+    u64* d_off = nullptr;
+    ZKW_TRY(ctx->upload("tails_off", w->offsets, &d_off));
+    const int nq = (int)(w->offsets.size() - 1);
+    { Prof _p(ctx, "k_tails_expand"); hipLaunchKernelGGL(k_tails_expand, dim3(blocks_for(t, 64)), dim3(64), 0, ctx->stream, w->unsorted_enc, w->unsorted_caps, d_off, nq, t, w->unsorted_tails); }
+    ZKW_TRY(launch_check("k_tails_expand"));
+    { Prof _p(ctx, "k_tails_expand"); hipLaunchKernelGGL(k_tails_expand, dim3(blocks_for(t, 64)), dim3(64), 0, ctx->stream, w->sorted_enc, w->sorted_caps, d_off, nq, t, w->sorted_tails); }
+    ZKW_TRY(launch_check("k_tails_expand"));
+    w->tails_valid = true;
+    return ZKW_OK;
+}
+
+static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes, bool materialize = true) {
     const size_t t = w->total, nb = w->offsets.size() - 1;
     switch (what) {
         case ZKW_RAM_SORTED_QUERIES: *bytes = t * sizeof(zkw_mem_query); return w->sorted_q;
         case ZKW_RAM_UNSORTED_ENC: *bytes = t * 64; return w->unsorted_enc;
         case ZKW_RAM_SORTED_ENC: *bytes = t * 64; return w->sorted_enc;
-        case ZKW_RAM_UNSORTED_TAILS: *bytes = t * 96; return w->unsorted_tails;
-        case ZKW_RAM_SORTED_TAILS: *bytes = t * 96; return w->sorted_tails;
+        case ZKW_RAM_UNSORTED_TAILS: *bytes = t * 96; return materialize && ram_full_tails(w) == ZKW_OK ? w->unsorted_tails : nullptr;
+        case ZKW_RAM_SORTED_TAILS: *bytes = t * 96; return materialize && ram_full_tails(w) == ZKW_OK ? w->sorted_tails : nullptr;
         case ZKW_RAM_CHALLENGES: *bytes = nb * 18 * 8; return w->challenges;
         case ZKW_RAM_LHS_Z: *bytes = t * 16; return w->lhs_z;
         case ZKW_RAM_RHS_Z: *bytes = t * 16; return w->rhs_z;
@@ -831,7 +871,7 @@ static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes) 
 
 extern "C" size_t zkw_ram_witness_bytes(const zkw_ram_witness* w, int what) {
     size_t b = 0;
-    if (w) (void)ram_array(w, what, &b);
+    if (w) (void)ram_array(w, what, &b, false);
     return b;
 }
 
@@ -844,6 +884,7 @@ extern "C" int zkw_ram_witness_get(const zkw_ram_witness* w, int what, void* dst
     if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: null argument");
     size_t bytes = 0;
     const void* src = ram_array(w, what, &bytes);
+    if (!src && (what == ZKW_RAM_UNSORTED_TAILS || what == ZKW_RAM_SORTED_TAILS)) return ZKW_ERR_OOM;  // message set by ram_full_tails
     if (!src) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: unknown array %d", what);
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: need %zu bytes, got %zu", bytes, dst_bytes);
     zkw_ctx* ctx = w->ctx;
@@ -943,8 +984,10 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
         j.sorted_q = w->sorted_q + lo;
         j.unsorted_enc = w->unsorted_enc + 8 * lo;
         j.sorted_enc = w->sorted_enc + 8 * lo;
-        j.unsorted_tails = w->unsorted_tails + 12 * lo;
-        j.sorted_tails = w->sorted_tails + 12 * lo;
+        j.unsorted_caps = w->unsorted_caps + 4 * lo;
+        j.sorted_caps = w->sorted_caps + 4 * lo;
+        j.u_mark = w->unsorted_marks + 12 * idx;
+        j.s_mark = w->sorted_marks + 12 * idx;
         j.challenges = w->challenges + 18 * b;
         j.lhs_z = w->lhs_z + 2 * lo;
         j.rhs_z = w->rhs_z + 2 * lo;

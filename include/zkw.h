@@ -126,8 +126,8 @@ enum {
     ZKW_RAM_SORTED_QUERIES = 0, /* zkw_mem_query[total]           */
     ZKW_RAM_UNSORTED_ENC = 1,   /* uint64_t[total][8]             */
     ZKW_RAM_SORTED_ENC = 2,     /* uint64_t[total][8]             */
-    ZKW_RAM_UNSORTED_TAILS = 3, /* uint64_t[total][12]            */
-    ZKW_RAM_SORTED_TAILS = 4,   /* uint64_t[total][12]            */
+    ZKW_RAM_UNSORTED_TAILS = 3, /* uint64_t[total][12]: expanded on first access (the builder keeps only the   */
+    ZKW_RAM_SORTED_TAILS = 4,   /* capacity words + the tails at instance ends: 64 instead of 192 bytes per query) */
     ZKW_RAM_CHALLENGES = 5,     /* uint64_t[n_blocks][2][9]       */
     ZKW_RAM_LHS_Z = 6,          /* per block b: uint64_t[2][n_b] at element offset 2*block_offsets[b] */
     ZKW_RAM_RHS_Z = 7,          /* idem                           */

@@ -15,6 +15,6 @@ def run(form, nc, L):
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
     dt = min(ts)
     print(f"form {form:2d}: {nc:5d} chains x {L}: {dt*1e3:8.2f} ms  {dt*1e6/L:6.2f} us/step  {nc*L/dt/1e6:8.1f} Mperm/s", flush=True)
-for nc, L in ((16, 20000), (512, 20000), (4096, 5000), (8192, 2500), (16384, 2000)):
+for nc, L in ((16, 20000), (4096, 5000), (6144, 4000), (8192, 2500), (11416, 2500), (16384, 2000), (11416, 20000)):
     for form in (16, 4):
         run(form, nc, L)
