@@ -135,11 +135,12 @@ def main():
         # algorithmic HBM bytes PER LAUNCH of each kernel (DESIGN.md "Measurement"): cells written once +
         # the instance's witness read once. A synthesis launch covers `args.ring` instances.
         per_launch_inst = min(args.ring, n_inst_local)
-        cell = 8 * CAPACITY * per_launch_inst          # one column of one region, all instances of a launch
+        stride = (CAPACITY + 63) // 64 * 64            # rows per region incl. the alignment gap (zkw trace v2)
+        cell = 8 * stride * per_launch_inst            # one column of one region, all instances of a launch
         wit = per_launch_inst * n                      # witness items read by a launch
         alg_bytes = {
-            "k_chain_full": 2 * items * (64 + 96),            # per chain item: 8 words in, 12 words out
-            "k_chain_full_q4": 2 * items * (64 + 96),
+            "k_chain_full": 2 * items * (64 + 32),            # per chain item: 8 words in, 4 capacity words out
+            "k_chain_full_q4": 2 * items * (64 + 32),
             "k_gp_local": 2 * items * (64 + 16),              # rows read once, both repetitions written
             "k_gp_apply": 2 * items * 32,
             "k_encode_mem": items * (48 + 64),
@@ -148,8 +149,8 @@ def main():
             "k_ram_fill_A": 148 * cell + wit * (64 + 48 + 32),
             "k_ram_fill_B": 148 * cell + wit * 96,
             "k_ram_fill_C": 148 * cell + wit * 96,
-            "k_ram_fill_D": 148 * cell + wit * 192 + 24 * cell,
-            "k_ram_fill_tail": per_launch_inst * 8 * (148 * (n_rows - 6 * CAPACITY) + n_rows),
+            "k_ram_fill_D": 148 * cell + 48 * cell,           # reads the queue tails back from the Poseidon2 rows
+            "k_ram_fill_tail": per_launch_inst * 8 * (148 * (n_rows - 6 * stride) + n_rows),
         }
         name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / max(cnt, 1)
