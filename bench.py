@@ -94,6 +94,7 @@ def main():
         # which do not fit the HBM.
         per_block = int(n * 330)
         B = int(max(16, min(4096, (0.90 * free - args.ring * 1.25e9) // per_block)))
+        B = parallel.min_over_ranks(B, dev)  # every rank runs the same batch (weak scaling, equal record counts)
     n_rows = 1 << 20  # TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17
     ring = native.Trace(ctx, n_rows, args.ring)  # trace buffers a prover would consume and hand back
     base, q = make_inputs(B, n, rank, dev)

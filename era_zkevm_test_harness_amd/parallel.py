@@ -84,6 +84,15 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def min_over_ranks(value: int, device) -> int:
+    """Agree on a common integer (the smallest proposal), e.g. the batch size every rank can hold."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

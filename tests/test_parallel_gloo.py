@@ -36,6 +36,7 @@ def _worker(rank, world, port, n_blocks, q_out):
     t = torch.from_numpy(local.view(np.uint8).reshape(local.size, -1).copy())
     parallel.barrier()
     out = parallel.gather_records(t, counts, dst=0)
+    assert parallel.min_over_ranks(100 + rank, "cpu") == 100  # the batch size every rank agrees on
     m = parallel.max_over_ranks(float(rank + 1), "cpu")
     assert m == float(world)
     if rank == 0:
