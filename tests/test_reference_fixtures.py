@@ -38,3 +38,18 @@ def test_poseidon2_merkle_node_kat(oracle):
             if a is not b and tuple(int(x) for x in oracle.hash_node(a, b)) in capset:
                 hits += 1
     assert hits >= 15
+
+
+@pytest.mark.xfail(reason="same cause as the Merkle-node KAT: the Poseidon2 restatement is not pinned yet", strict=True)
+def test_poseidon2_fri_leaf_kat(oracle):
+    """The last FRI oracle of a proof has 16 leaves of 8 elements and a 16-entry cap, so hash_into_leaf(leaf) — one
+    permutation of (leaf || 0000), first four words — must itself be a cap entry."""
+    kat = json.load(open(os.path.join(GOLD, "fri_leaf_kat_ram.json")))
+    capset = {tuple(c) for c in kat["cap"]}
+    hits = 0
+    for leaf in kat["leaves"]:
+        s = np.zeros(12, np.uint64)
+        s[:8] = np.array(leaf, dtype=np.uint64)
+        if tuple(int(x) for x in oracle.poseidon2(s)[:4]) in capset:
+            hits += 1
+    assert hits == len(kat["leaves"])
