@@ -48,12 +48,24 @@ GL_HD u64 neg(u64 a) { return sub(0, a); }
 // (hi * 2^64 + lo) mod p
 GL_HD u64 reduce128(u64 lo, u64 hi) {
     u64 hh = hi >> 32, hl = hi & EPS;
-    u64 t0 = lo - hh;
-    if (lo < hh) t0 -= EPS;  // wrapped by 2^64 = EPS: take it back out
-    u64 t1 = hl * EPS;       // (hl << 32) - hl, < 2^64
-    u64 r = t0 + t1;
-    if (r < t1) r += EPS;    // cannot overflow a second time
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the overflow builtins keep the borrow / carry of the 64-bit subtract / add instead of re-deriving them with a
+    // second 64-bit compare: 86 instead of 94 VALU instructions per S-box (tools note in DESIGN.md 3.2)
+    unsigned long long t0, r;
+    const bool borrow = __builtin_usubll_overflow(lo, hh, &t0);
+    t0 -= borrow ? EPS : 0;  // wrapped by 2^64 = EPS: take it back out
+    const u64 t1 = (hl << 32) - hl;  // hl * EPS < 2^64
+    const bool carry = __builtin_uaddll_overflow(t0, t1, &r);
+    r += carry ? EPS : 0;    // cannot overflow a second time
     return r;
+#else
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= EPS;
+    u64 t1 = hl * EPS;
+    u64 r = t0 + t1;
+    if (r < t1) r += EPS;
+    return r;
+#endif
 }
 
 GL_HD u64 mul(u64 a, u64 b) {
