@@ -220,6 +220,41 @@ static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n 
 extern "C" const char* zkw_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* zkw_version(void) { return "zkw 0.1 (gfx950)"; }
 
+extern "C" int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometry* out) {
+    // {copy columns, lookup width, repetitions, max degree, capacity, big size hint}: vm_main.rs:29-44,
+    // sort_code_decommits.rs:28-39, code_decommitter.rs:28-39, log_demux.rs:36-47, keccak256_round_function.rs:28-39,
+    // sha256_round_function.rs:28-39, ecrecover.rs:30-41, ram_permutation.rs:26-41,117-122, storage_sort_dedup.rs:29-40,
+    // storage_apply.rs:28-39, events_sort_dedup.rs:28-39 (x2), linear_hasher.rs:28-39; geometry_config.rs:5-20
+    static const struct { u32 c, lw, lr, deg, cap; bool big; } T[14] = {
+        {0, 0, 0, 0, 0, false},
+        {130, 3, 8, 8, 5585, false},    // 1 MainVM
+        {130, 1, 18, 8, 117500, true},  // 2 CodeDecommittmentsSorter
+        {108, 4, 11, 8, 2845, false},   // 3 CodeDecommitter
+        {136, 1, 14, 8, 58750, true},   // 4 LogDemuxer
+        {86, 3, 14, 8, 293, false},     // 5 KeccakRoundFunction
+        {116, 4, 9, 8, 2206, false},    // 6 Sha256RoundFunction
+        {80, 3, 16, 8, 7, false},       // 7 ECRecover
+        {133, 1, 15, 8, 136714, true},  // 8 RAMPermutation
+        {132, 1, 16, 8, 46921, true},   // 9 StorageSorter
+        {60, 3, 26, 8, 33, false},      // 10 StorageApplication
+        {130, 1, 8, 18, 31287, true},   // 11 EventsSorter
+        {130, 1, 8, 18, 31287, true},   // 12 L1MessagesSorter
+        {66, 3, 26, 8, 774, false},     // 13 L1MessagesHasher
+    };
+    if (!out || circuit_type < 1 || circuit_type > 13) return fail(ZKW_ERR_INVALID, "unknown base-layer circuit type %u", circuit_type);
+    const auto& g = T[circuit_type];
+    out->num_columns_under_copy_permutation = g.c;
+    out->num_witness_columns = 0;
+    out->num_constant_columns = 4;
+    out->max_allowed_constraint_degree = g.deg;
+    out->lookup_width = g.lw;
+    out->lookup_repetitions = g.lr;
+    out->capacity = g.cap;
+    out->trace_len_log2 = 20;
+    out->size_hint_variables = g.big ? (1ull << 26) + (1ull << 25) : (1ull << 26);
+    return ZKW_OK;
+}
+
 extern "C" zkw_ctx* zkw_create(int device_id) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);

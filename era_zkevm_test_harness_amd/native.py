@@ -28,6 +28,7 @@ SYMBOLS = [
     ("zkw_synchronize", _int, [_vp]),
     ("zkw_set_chain_form", _int, [_vp, _int]),
     ("zkw_version", C.c_char_p, []),
+    ("zkw_circuit_geometry_of", _int, [C.c_uint8, _vp]),
     ("zkw_profile_enable", _int, [_vp, _int]),
     ("zkw_profile_reset", _int, [_vp]),
     ("zkw_profile_get", _int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -936,3 +937,16 @@ class Context:
                                                     _np_ptr(root), initial_next_enumeration_index, num_rounds_per_circuit,
                                                     C.byref(w.handle)))
         return w
+
+
+CIRCUIT_GEOMETRY = np.dtype(
+    [("num_columns_under_copy_permutation", "<u4"), ("num_witness_columns", "<u4"), ("num_constant_columns", "<u4"),
+     ("max_allowed_constraint_degree", "<u4"), ("lookup_width", "<u4"), ("lookup_repetitions", "<u4"), ("capacity", "<u4"),
+     ("trace_len_log2", "<u4"), ("size_hint_variables", "<u8")])
+
+
+def circuit_geometry(circuit_type: int):
+    """ZkSyncBaseLayerCircuit::geometry / size_hint + the GeometryConfig capacity of one circuit type (no GPU needed)."""
+    g = np.zeros(1, CIRCUIT_GEOMETRY)
+    _check(load().zkw_circuit_geometry_of(circuit_type, _np_ptr(g)))
+    return g[0]

@@ -57,6 +57,23 @@ int zkw_set_chain_form(zkw_ctx *ctx, int lanes_per_state);
 /* library/ABI version and the kernels' target ISA ("gfx950") */
 const char *zkw_version(void);
 
+/* ZkSyncBaseLayerCircuit::{numeric_circuit_type, geometry, size_hint} + the per-type capacity of GeometryConfig
+   (circuit_definitions/src/circuit_definitions/base_layer/mod.rs:268-394, 442-476; wrappers under base_layer/;
+   circuit_sequencer_api/src/geometry_config.rs:5-20). circuit_type = BaseLayerCircuitType as u8 (1 = MainVM ...
+   13 = L1MessagesHasher). trace_len_log2 = 20 for every type. Returns ZKW_ERR_INVALID for an unknown type. */
+typedef struct zkw_circuit_geometry {
+    uint32_t num_columns_under_copy_permutation;
+    uint32_t num_witness_columns;
+    uint32_t num_constant_columns;
+    uint32_t max_allowed_constraint_degree;
+    uint32_t lookup_width;          /* LookupParameters: width x num_repetitions, table id as constant */
+    uint32_t lookup_repetitions;
+    uint32_t capacity;              /* cycles / items per instance (geometry_config.rs) */
+    uint32_t trace_len_log2;
+    uint64_t size_hint_variables;   /* size_hint().1: 2^26, or 2^26 + 2^25 for RAM / sorters / demuxer */
+} zkw_circuit_geometry;
+int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometry *out);
+
 /* ---- per-kernel timing -------------------------------------------------------------------------- */
 /* When enabled, every kernel launch (and library sort) of this context is bracketed by HIP events
    recorded on the context's stream; totals are keyed by kernel name ("k_chain_full", "k_gp_local",

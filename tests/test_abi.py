@@ -102,3 +102,17 @@ def test_synthetic_trace_is_valid_memory():
         else:
             assert key in mem and mem[key] == val
     assert 0.5 < 1 - q["rw_flag"].mean() < 0.75
+
+
+def test_circuit_geometry_table():
+    """No GPU needed: the per-type geometry is a table. Witness bytes = (columns + 1 multiplicity) * 2^20 * 8."""
+    from era_zkevm_test_harness_amd import native
+
+    ram = native.circuit_geometry(8)
+    assert (int(ram["num_columns_under_copy_permutation"]), int(ram["lookup_width"]), int(ram["lookup_repetitions"])) == (133, 1, 15)
+    assert int(ram["capacity"]) == 136714 and int(ram["size_hint_variables"]) == (1 << 26) + (1 << 25)
+    cols = lambda g: int(g["num_columns_under_copy_permutation"]) + int(g["lookup_width"]) * int(g["lookup_repetitions"])
+    assert [cols(native.circuit_geometry(t)) for t in range(1, 14)] == [154, 148, 152, 150, 128, 152, 128, 148, 148, 138, 138, 138, 144]
+    assert int(native.circuit_geometry(11)["max_allowed_constraint_degree"]) == 18
+    with pytest.raises(native.ZkwError):
+        native.circuit_geometry(14)
