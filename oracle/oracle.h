@@ -152,6 +152,16 @@ int64_t orc_decommitter_build(const zkw_decommit_query *requests, const uint64_t
    digest of the words (each big-endian) with the 4 most significant bytes replaced by `top4` */
 void orc_bytecode_hash(const uint32_t *words, size_t n_words, uint32_t top_limb, uint32_t hash_out[8]);
 
+/* ---- CodeDecommittmentsSorter synthesis + check (a21, second circuit type), see decommit_sorter_circuit.c */
+/* sorted_q / *_enc: the block-wide arrays of orc_decommit_sorter_build; the fill carries every register itself, so
+   the trace's BND_OUT row is an independent re-derivation of the instance's hidden_fsm_output */
+void orc_poseidon2_flattened(const uint64_t in[12], uint64_t slots[130]);
+int orc_decommit_sorter_synthesize(const zkw_decommit_sorter_instance *inst, const zkw_decommit_query *sorted_q,
+                                   const uint64_t *unsorted_enc, const uint64_t *sorted_enc, const uint64_t *challenges,
+                                   const uint64_t *rq_tail_in, uint32_t rq_len_in, uint32_t capacity, size_t n_rows,
+                                   uint64_t *trace);
+uint64_t orc_decommit_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+
 /* ---- sparse storage tree + StorageApplication builder (a17), see storage_application.c */
 typedef struct orc_tree orc_tree;
 orc_tree *orc_tree_new(void);

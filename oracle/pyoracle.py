@@ -649,3 +649,30 @@ def storage_application_build(tree, queries, query_tails, capacity):
         raise RuntimeError(f"orc_storage_application_build failed: {rc}")
     o["instances"] = o["instances"][:rc]
     return o
+
+
+DS_COLS = 149
+
+
+def decommit_sorter_synthesize(build_out, instance_index, capacity, n_rows):
+    """Fill the CodeDecommittmentsSorter trace of one instance from the outputs of decommit_sorter_build."""
+    o = build_out
+    trace = np.zeros((DS_COLS, n_rows), np.uint64)
+    inst = o["instances"][instance_index:instance_index + 1]
+    f = lib().orc_decommit_sorter_synthesize
+    f.restype = C.c_int
+    rc = f(_p(inst), _p(o["sorted_q"]), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), None, C.c_uint32(0),
+           C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_decommit_sorter_synthesize failed: {rc}")
+    return trace
+
+
+def decommit_sorter_check(trace, capacity):
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_decommit_sorter_check
+    f.restype = C.c_uint64
+    bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value
+    return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)

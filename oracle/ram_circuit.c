@@ -17,10 +17,7 @@
 #define P ZKW_GOLDILOCKS_P
 typedef unsigned __int128 u128;
 
-static const rc_term TERMS[] = RC_TERMS_INIT;
-static const rc_constraint CONS[] = RC_CONSTRAINTS_INIT;
-static const uint16_t ROW_FIRST[] = RC_ROW_FIRST_CONSTRAINT_INIT;
-static const rc_link LINKS[] = RC_LINKS_INIT;
+/* (the satisfiability check lives in circuit_check.c) */
 
 /* ---- Poseidon2 with every flattened-gate variable written out: 12 inputs, the state after each of
    the first 4 full rounds, the S-box output of element 0 in each partial round, the state after each of
@@ -293,89 +290,4 @@ int orc_ram_synthesize(const zkw_ram_instance *inst, const zkw_mem_query *sorted
             CELL(RC_MULT_COL, v) += 1;
         }
     return 0;
-}
-
-/* ---- checker (generic over the spec tables) */
-static uint64_t eval_constraint(const rc_constraint *c, const uint64_t *trace, size_t n_rows, size_t row) {
-    uint64_t acc = 0;
-    for (int t = 0; t < c->n_terms; t++) {
-        const rc_term *tm = &TERMS[c->first_term + t];
-        uint64_t v = tm->coef;
-        for (int f = 0; f < tm->nf; f++) v = orc_gl_mul(v, CELL(tm->f[f], row));
-        acc = orc_gl_add(acc, v);
-    }
-    return acc % P;
-}
-
-/* Returns the number of violated relations (0 = satisfied); `first_bad` receives a description code:
-   (kind << 56) | (index << 32) | row  with kind 1 constraint, 2 poseidon, 3 lookup range, 4 copy link,
-   5 multiplicity, 6 non-zero padding. */
-uint64_t orc_ram_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
-    uint64_t bad = 0;
-#define FLAG(kind, idx, row)                                                                        \
-    do {                                                                                            \
-        if (!bad && first_bad) *first_bad = ((uint64_t)(kind) << 56) | ((uint64_t)(idx) << 32) | (uint64_t)(row); \
-        bad++;                                                                                      \
-    } while (0)
-    const size_t bnd = (size_t)RC_BOUNDARY_ROW(capacity);
-    for (size_t i = 0; i < capacity; i++) {
-        for (int rt = 0; rt < RC_ROWS_PER_CYCLE; rt++) {
-            const size_t row = ROWOF(rt, i);
-            for (int c = ROW_FIRST[rt]; c < ROW_FIRST[rt + 1]; c++)
-                if (eval_constraint(&CONS[c], trace, n_rows, row)) FLAG(1, c, row);
-            if (rt == RC_ROW_PU || rt == RC_ROW_PS) {
-                uint64_t in[12], slots[130];
-                for (int k = 0; k < 12; k++) in[k] = CELL(k, row);
-                orc_poseidon2_flattened(in, slots);
-                for (int k = 0; k < 130; k++)
-                    if (slots[k] != CELL(k, row)) { FLAG(2, k, row); break; }
-            }
-        }
-    }
-    for (int rt = RC_ROWS_PER_CYCLE; rt < RC_NUM_ROW_TYPES; rt++) {
-        const size_t row = bnd + (size_t)(rt - RC_ROWS_PER_CYCLE);
-        for (int c = ROW_FIRST[rt]; c < ROW_FIRST[rt + 1]; c++)
-            if (eval_constraint(&CONS[c], trace, n_rows, row)) FLAG(1, c, row);
-    }
-    /* copy links */
-    for (int l = 0; l < RC_NUM_LINKS; l++) {
-        const rc_link *k = &LINKS[l];
-        if (k->kind == 3) {
-            if (CELL(k->col_a, bnd + RC_ROWOFF_BND_OUT) != CELL(k->col_b, ROWOF(k->row_b, capacity - 1))) FLAG(4, l, bnd + 1);
-            continue;
-        }
-        for (size_t i = 0; i < capacity; i++) {
-            const uint64_t a = CELL(k->col_a, ROWOF(k->row_a, i));
-            uint64_t b;
-            if (k->kind == 0) b = CELL(k->col_b, ROWOF(k->row_b, i));
-            else if (k->kind == 1) b = i ? CELL(k->col_b, ROWOF(k->row_b, i - 1)) : CELL(k->bin_col, bnd + RC_ROWOFF_BND_IN);
-            else b = CELL(k->col_b, bnd + RC_ROWOFF_BND_IN);
-            if (a != b) FLAG(4, l, ROWOF(k->row_a, i));
-        }
-    }
-    /* lookups, multiplicities, padding */
-    uint64_t *hist = (uint64_t *)calloc(256, 8);
-    for (int c = RC_G; c < RC_G + RC_L; c++)
-        for (size_t r = 0; r < n_rows; r++) {
-            uint64_t v = CELL(c, r);
-            if (v > 255) FLAG(3, c, r); else hist[v]++;
-        }
-    for (size_t r = 0; r < n_rows; r++) {
-        uint64_t want = r < 256 ? hist[r] : 0;
-        if (CELL(RC_MULT_COL, r) != want) FLAG(5, 0, r);
-    }
-    free(hist);
-    for (size_t r = bnd + (RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE); r < n_rows; r++)
-        for (int c = 0; c < RC_G + RC_L; c++)
-            if (CELL(c, r)) { FLAG(6, c, r); break; }
-    for (int rt = 0; rt < RC_ROWS_PER_CYCLE; rt++) /* the alignment gap at the end of every region */
-        for (size_t r = ROWOF(rt, capacity); r < ROWOF(rt + 1, 0); r++)
-            for (int c = 0; c < RC_G + RC_L; c++)
-                if (CELL(c, r)) { FLAG(6, c, r); break; }
-    /* canonical form everywhere */
-    for (int c = 0; c < RC_COLS; c++)
-        for (size_t r = 0; r < n_rows; r++)
-            if (CELL(c, r) >= P) FLAG(6, c, r);
-    return bad;
-#undef FLAG
 }

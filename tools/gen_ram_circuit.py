@@ -250,17 +250,26 @@ def build():
     return rows, links, regs
 
 
-def emit(rows, links, path):
+def emit(rows, links, path, prefix="RC", guard="ZKW_RAM_CIRCUIT_SPEC_H",
+         title=("/* GENERATED by tools/gen_ram_circuit.py — do not edit. Layout contract of the RAMPermutation trace",
+                " * emitted by zkw_ram_synthesize (\"zkw trace v2\"). See the generator's docstring and DESIGN.md. */"),
+         poseidon_rows=("PU", "PS"), shared_types=False):
+    """Writes the spec header. `prefix` replaces RC in every macro so that several circuits can coexist; the
+    rc_term / rc_constraint / rc_link types are declared by the RAM header only (shared_types=True skips them)."""
     out = []
-    w = out.append
-    w("/* GENERATED by tools/gen_ram_circuit.py — do not edit. Layout contract of the RAMPermutation trace")
-    w(" * emitted by zkw_ram_synthesize (\"zkw trace v2\"). See the generator's docstring and DESIGN.md. */")
-    w("#ifndef ZKW_RAM_CIRCUIT_SPEC_H\n#define ZKW_RAM_CIRCUIT_SPEC_H\n#include <stdint.h>")
+
+    def w(line):
+        out.append(line if prefix == "RC" else line.replace("RC_", prefix + "_"))
+
+    for t in title:
+        out.append(t)
+    out.append(f"#ifndef {guard}\n#define {guard}\n#include <stdint.h>")
     w(f"#define RC_G {G}            /* general-purpose (copy-permutation) columns 0..{G - 1} */")
     w(f"#define RC_L {L}             /* lookup columns {G}..{G + L - 1}: every cell is in [0, 256) */")
     w(f"#define RC_MULT_COL {G + L}     /* multiplicity column of the 8-bit range-check table */")
     w(f"#define RC_COLS {G + L + 1}")
-    w(f"#define RC_HEAP_PAGE {HEAP_PAGE}")
+    if prefix == "RC":
+        w(f"#define RC_HEAP_PAGE {HEAP_PAGE}")
     n_cyc = sum(1 for r in rows if r.per_cycle)
     w(f"#define RC_ROWS_PER_CYCLE {n_cyc}  /* region-major: row of (region r, cycle i) = r*RC_REGION_STRIDE(capacity) + i */")
     w("/* every region starts on a 64-row (512-byte) boundary so that a wave's 64 x 8-byte store of one column is one")
@@ -280,10 +289,11 @@ def emit(rows, links, path):
     w("/* named slots: RC_<row>_<var> = column of that variable in rows of that type */")
     for r in rows:
         for v in r.slots + r.lookups:
-            name = v.replace("p.", "P_").replace("g.", "G_")
+            name = v.replace("p.", "P_").replace("g.", "G_").replace("x.", "X_")
             w(f"#define RC_{r.name}_{name} {r.slot(v)}")
-    w("typedef struct { uint64_t coef; uint8_t nf; uint8_t f[6]; } rc_term;")
-    w("typedef struct { uint16_t first_term; uint16_t n_terms; } rc_constraint;")
+    if not shared_types:
+        out.append("typedef struct { uint64_t coef; uint8_t nf; uint8_t f[6]; } rc_term;")
+        out.append("typedef struct { uint16_t first_term; uint16_t n_terms; } rc_constraint;")
     terms, cons, row_first = [], [], []
     for r in rows:
         row_first.append(len(cons))
@@ -305,10 +315,13 @@ def emit(rows, links, path):
     w(f"#define RC_ROW_FIRST_CONSTRAINT_INIT {{{', '.join(map(str, row_first))}}}")
     w(f"#define RC_ROW_NUM_SLOTS_INIT {{{', '.join(str(len(r.slots)) for r in rows)}}}")
     w(f"#define RC_ROW_NUM_LOOKUPS_INIT {{{', '.join(str(len(r.lookups)) for r in rows)}}}")
+    w("/* rows whose first 130 slots are one flattened Poseidon2 permutation (checked by recomputation) */")
+    w(f"#define RC_ROW_IS_POSEIDON_INIT {{{', '.join('1' if r.name in poseidon_rows else '0' for r in rows)}}}")
     w("/* copy links: cell (row_a, col_a) must equal cell (row_b, col_b):")
     w("   kind 0: both at the same cycle; kind 1: b at the previous cycle (for cycle 0: BND_IN column bin_col);")
     w("   kind 2: b = BND_IN (one row per instance); kind 3: a = BND_OUT, b at the LAST cycle */")
-    w("typedef struct { uint8_t kind, row_a, col_a, row_b, col_b, bin_col; } rc_link;")
+    if not shared_types:
+        out.append("typedef struct { uint8_t kind, row_a, col_a, row_b, col_b, bin_col; } rc_link;")
     w(f"#define RC_NUM_LINKS {len(links)}")
     w("#define RC_LINKS_INIT { \\")
     for k in links:
