@@ -12,6 +12,7 @@
 // once (no memset pass): algorithmic bytes = RC_COLS * n_rows * 8.
 #pragma once
 #include "../../include/zkw_ram_circuit_spec.h"
+#include "../../include/zkw_decommit_sorter_circuit_spec.h"
 #include "ram_kernels.cuh"
 
 namespace zkw {
@@ -85,6 +86,34 @@ __device__ __forceinline__ void hist_flush(u32* sh_hist, u32* g_hist) {
         if (sh_hist[t]) atomicAdd(&g_hist[t], sh_hist[t]);
 }
 
+// One flattened Poseidon2 gate: columns 0..129 of `row` = the 12 inputs, the state after each of the first 4 full
+// rounds, the S-box output of element 0 in each of the 22 partial rounds, the state after each of the last 4 full
+// rounds. s holds the (weak) output state on return.
+__device__ __forceinline__ void fill_flattened_poseidon(u64* trace, size_t n_rows, size_t row, u64 s[12]) {
+    int pos = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) TR(pos++, row) = gl::canon(s[k]);
+    p2::external(s);
+    int r = 0;
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+        p2::full_round(s, r);
+#pragma unroll
+        for (int j = 0; j < 12; j++) TR(pos + j, row) = gl::canon(s[j]);
+        pos += 12;
+    }
+    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
+        s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
+        TR(pos++, row) = gl::canon(s[0]);
+        p2::internal(s);
+    }
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+        p2::full_round(s, r);
+#pragma unroll
+        for (int j = 0; j < 12; j++) TR(pos + j, row) = gl::canon(s[j]);
+        pos += 12;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Poseidon2 rows (regions PU and PS): one lane per cycle runs the permutation and stores all 130
 // flattened-gate variables as it goes. SIDE 0 = unsorted queue, 1 = sorted queue.
@@ -118,28 +147,7 @@ __global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __rest
         const u64* prev_cap = i == 0 ? (SIDE == 0 ? ri.uh : ri.sh) + 8 : caps + 4 * (first + (i - 1 < m ? i - 1 : m - 1));
 #pragma unroll
         for (int k = 0; k < 4; k++) s[8 + k] = prev_cap[k];
-        int pos = 0;
-#pragma unroll
-        for (int k = 0; k < 12; k++) TR(pos++, row) = s[k];
-        p2::external(s);
-        int r = 0;
-        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
-            p2::full_round(s, r);
-#pragma unroll
-            for (int j = 0; j < 12; j++) TR(pos + j, row) = gl::canon(s[j]);
-            pos += 12;
-        }
-        for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
-            s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
-            TR(pos++, row) = gl::canon(s[0]);
-            p2::internal(s);
-        }
-        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
-            p2::full_round(s, r);
-#pragma unroll
-            for (int j = 0; j < 12; j++) TR(pos + j, row) = gl::canon(s[j]);
-            pos += 12;
-        }
+        fill_flattened_poseidon(trace, n_rows, row, s);
         // spare general slots + lookup cells of this row type
         zkw_mem_query q;
         memset(&q, 0, sizeof q);
@@ -562,12 +570,39 @@ __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// Satisfiability check. Spec tables live in constant memory; a block stages 64 consecutive rows of one
-// region (all 148 general + lookup columns) in LDS, then each lane interprets its row's constraints.
+// Satisfiability check, generic over a spec (include/zkw_*_circuit_spec.h): the tables live in constant memory; a
+// block stages 64 consecutive rows of one region (all 148 general + lookup columns) in LDS, then each lane
+// interprets its row's constraints; Poseidon2 rows are recomputed from their 12 inputs.
 __constant__ rc_term c_terms[RC_NUM_TERMS] = RC_TERMS_INIT;
 __constant__ rc_constraint c_cons[RC_NUM_CONSTRAINTS] = RC_CONSTRAINTS_INIT;
 __constant__ uint16_t c_row_first[RC_NUM_ROW_TYPES + 1] = RC_ROW_FIRST_CONSTRAINT_INIT;
+__constant__ uint8_t c_is_poseidon[RC_NUM_ROW_TYPES] = RC_ROW_IS_POSEIDON_INIT;
 __constant__ rc_link c_links[RC_NUM_LINKS] = RC_LINKS_INIT;
+__constant__ rc_term c_ds_terms[DS_NUM_TERMS] = DS_TERMS_INIT;
+__constant__ rc_constraint c_ds_cons[DS_NUM_CONSTRAINTS] = DS_CONSTRAINTS_INIT;
+__constant__ uint16_t c_ds_row_first[DS_NUM_ROW_TYPES + 1] = DS_ROW_FIRST_CONSTRAINT_INIT;
+__constant__ uint8_t c_ds_is_poseidon[DS_NUM_ROW_TYPES] = DS_ROW_IS_POSEIDON_INIT;
+__constant__ rc_link c_ds_links[DS_NUM_LINKS] = DS_LINKS_INIT;
+
+struct SpecRam {  // RAMPermutation, circuit type 8
+    static constexpr int G = RC_G, L = RC_L, ROWS_PER_CYCLE = RC_ROWS_PER_CYCLE, NUM_ROW_TYPES = RC_NUM_ROW_TYPES, NUM_LINKS = RC_NUM_LINKS;
+    static constexpr int OFF_BIN = RC_ROWOFF_BND_IN, OFF_BOUT = RC_ROWOFF_BND_OUT;
+    __device__ static const rc_term* terms() { return c_terms; }
+    __device__ static const rc_constraint* cons() { return c_cons; }
+    __device__ static const uint16_t* row_first() { return c_row_first; }
+    __device__ static const uint8_t* is_poseidon() { return c_is_poseidon; }
+    __device__ static const rc_link* links() { return c_links; }
+};
+struct SpecDecommitSorter {  // CodeDecommittmentsSorter, circuit type 2
+    static constexpr int G = DS_G, L = DS_L, ROWS_PER_CYCLE = DS_ROWS_PER_CYCLE, NUM_ROW_TYPES = DS_NUM_ROW_TYPES, NUM_LINKS = DS_NUM_LINKS;
+    static constexpr int OFF_BIN = DS_ROWOFF_BND_IN, OFF_BOUT = DS_ROWOFF_BND_OUT;
+    __device__ static const rc_term* terms() { return c_ds_terms; }
+    __device__ static const rc_constraint* cons() { return c_ds_cons; }
+    __device__ static const uint16_t* row_first() { return c_ds_row_first; }
+    __device__ static const uint8_t* is_poseidon() { return c_ds_is_poseidon; }
+    __device__ static const rc_link* links() { return c_ds_links; }
+};
+static_assert(RC_G + RC_L == DS_G + DS_L, "both layouts have 148 general + lookup columns and the multiplicities in column 148");
 
 struct CheckResult {
     unsigned long long violations;
@@ -582,36 +617,42 @@ __device__ __forceinline__ void flag_bad(CheckResult* res, u64 kind, u64 idx, u6
 constexpr int CHK_ROWS = 64;
 constexpr int CHK_COLS = RC_G + RC_L;
 
-__global__ __launch_bounds__(64) void k_ram_check_rows(const u64* __restrict__ trace, u32 capacity, size_t n_rows,
-                                                       CheckResult* res) {
+template <class S>
+__device__ __forceinline__ size_t spec_row(int rt, u32 capacity, u32 i) {
+    const size_t rs = RC_REGION_STRIDE(capacity);
+    return rt < S::ROWS_PER_CYCLE ? (size_t)rt * rs + i : (size_t)S::ROWS_PER_CYCLE * rs + (rt - S::ROWS_PER_CYCLE);
+}
+
+template <class S>
+__global__ __launch_bounds__(64) void k_check_rows(const u64* __restrict__ trace, u32 capacity, size_t n_rows, CheckResult* res) {
     extern __shared__ __attribute__((aligned(16))) u64 tile[];  // [CHK_COLS][CHK_ROWS]
     const int rt = blockIdx.y;  // row type; boundary row types are handled by block x == 0 only
-    const bool per_cycle = rt < RC_ROWS_PER_CYCLE;
+    const bool per_cycle = rt < S::ROWS_PER_CYCLE;
     const u32 n_in_region = per_cycle ? capacity : 1;
     const u32 i = blockIdx.x * CHK_ROWS + threadIdx.x;
     if (blockIdx.x * CHK_ROWS >= n_in_region) return;
     const bool live = i < n_in_region;
-    const size_t row = per_cycle ? (size_t)rt * RC_REGION_STRIDE(capacity) + i : (size_t)RC_BOUNDARY_ROW(capacity) + (rt - RC_ROWS_PER_CYCLE);
+    const size_t row = spec_row<S>(rt, capacity, per_cycle ? i : 0);
     for (int c = 0; c < CHK_COLS; c++) {
         u64 v = live ? TR(c, row) : 0;
         tile[c * CHK_ROWS + threadIdx.x] = v;
-        if (live && (v >= gl::P || (c >= RC_G && v > 255))) flag_bad(res, 3, c, row);
+        if (live && (v >= gl::P || (c >= S::G && v > 255))) flag_bad(res, 3, c, row);
     }
     __syncthreads();
     if (!live) return;
 #define CELLV(c) tile[(c) * CHK_ROWS + threadIdx.x]
-    for (int k = c_row_first[rt]; k < c_row_first[rt + 1]; k++) {
-        const rc_constraint cn = c_cons[k];
+    for (int k = S::row_first()[rt]; k < S::row_first()[rt + 1]; k++) {
+        const rc_constraint cn = S::cons()[k];
         u64 acc = 0;
         for (int t = 0; t < cn.n_terms; t++) {
-            const rc_term tm = c_terms[cn.first_term + t];
+            const rc_term tm = S::terms()[cn.first_term + t];
             u64 v = tm.coef;
             for (int f = 0; f < tm.nf; f++) v = gl::mul(v, CELLV(tm.f[f]));
             acc = gl::add(acc, v);
         }
         if (gl::canon(acc) != 0) flag_bad(res, 1, k, row);
     }
-    if (rt == RC_ROW_PU || rt == RC_ROW_PS) {
+    if (S::is_poseidon()[rt]) {
         u64 s[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) s[k] = CELLV(k);
@@ -642,50 +683,55 @@ __global__ __launch_bounds__(64) void k_ram_check_rows(const u64* __restrict__ t
 }
 
 // copy links: one lane per cycle walks the link table (both cells are read coalesced across lanes)
-__global__ __launch_bounds__(256) void k_ram_check_links(const u64* __restrict__ trace, u32 capacity, size_t n_rows,
-                                                         CheckResult* res) {
+template <class S>
+__global__ __launch_bounds__(256) void k_check_links(const u64* __restrict__ trace, u32 capacity, size_t n_rows, CheckResult* res) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
-    const size_t bnd = (size_t)RC_BOUNDARY_ROW(capacity), rs = RC_REGION_STRIDE(capacity);
-    for (int l = 0; l < RC_NUM_LINKS; l++) {
-        const rc_link k = c_links[l];
+    const size_t rs = RC_REGION_STRIDE(capacity), bnd = (size_t)S::ROWS_PER_CYCLE * rs;
+    for (int l = 0; l < S::NUM_LINKS; l++) {
+        const rc_link k = S::links()[l];
         if (k.kind == 3) {
-            if (i == capacity - 1 && TR(k.col_a, bnd + RC_ROWOFF_BND_OUT) != TR(k.col_b, (size_t)k.row_b * rs + i))
-                flag_bad(res, 4, l, bnd + RC_ROWOFF_BND_OUT);
+            if (i == capacity - 1 && TR(k.col_a, bnd + S::OFF_BOUT) != TR(k.col_b, (size_t)k.row_b * rs + i))
+                flag_bad(res, 4, l, bnd + S::OFF_BOUT);
+            continue;
+        }
+        if (k.kind == 4) {  // a boundary row's cell equals a BND_OUT cell
+            if (i == 0 && TR(k.col_a, spec_row<S>(k.row_a, capacity, 0)) != TR(k.col_b, bnd + S::OFF_BOUT))
+                flag_bad(res, 4, l, spec_row<S>(k.row_a, capacity, 0));
             continue;
         }
         const size_t ra = (size_t)k.row_a * rs + i;
         const u64 a = TR(k.col_a, ra);
         u64 b;
         if (k.kind == 0) b = TR(k.col_b, (size_t)k.row_b * rs + i);
-        else if (k.kind == 1) b = i ? TR(k.col_b, (size_t)k.row_b * rs + i - 1) : TR(k.bin_col, bnd + RC_ROWOFF_BND_IN);
-        else b = TR(k.col_b, bnd + RC_ROWOFF_BND_IN);
+        else if (k.kind == 1) b = i ? TR(k.col_b, (size_t)k.row_b * rs + i - 1) : TR(k.bin_col, bnd + S::OFF_BIN);
+        else b = TR(k.col_b, bnd + S::OFF_BIN);
         if (a != b) flag_bad(res, 4, l, ra);
     }
 }
 
 // lookup columns: histogram of every cell (all n_rows), padding rows must be zero in every column
-__global__ __launch_bounds__(256) void k_ram_check_lookups(const u64* __restrict__ trace, u32 capacity, size_t n_rows,
-                                                           u32* __restrict__ hist, CheckResult* res) {
+template <class S>
+__global__ __launch_bounds__(256) void k_check_lookups(const u64* __restrict__ trace, u32 capacity, size_t n_rows,
+                                                       u32* __restrict__ hist, CheckResult* res) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
-    const size_t rs = RC_REGION_STRIDE(capacity), pad0 = (size_t)RC_BOUNDARY_ROW(capacity) + (RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE);
+    const size_t rs = RC_REGION_STRIDE(capacity), pad0 = (size_t)S::ROWS_PER_CYCLE * rs + (S::NUM_ROW_TYPES - S::ROWS_PER_CYCLE);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
-        for (int c = RC_G; c < RC_G + RC_L; c++) {
+        for (int c = S::G; c < S::G + S::L; c++) {
             const u64 v = TR(c, r);
             if (v > 255) flag_bad(res, 3, c, r); else atomicAdd(&sh_hist[v], 1u);
         }
-        if (r >= pad0 || (r < (size_t)RC_ROWS_PER_CYCLE * rs && r % rs >= capacity))  // tail padding and the region gaps
-            for (int c = 0; c < RC_G; c++)
+        if (r >= pad0 || (r < (size_t)S::ROWS_PER_CYCLE * rs && r % rs >= capacity))  // tail padding and the region gaps
+            for (int c = 0; c < S::G; c++)
                 if (TR(c, r) != 0) { flag_bad(res, 6, c, r); break; }
     }
     __syncthreads();
     if (sh_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh_hist[threadIdx.x]);
 }
-__global__ void k_ram_check_mult(const u64* __restrict__ trace, size_t n_rows, const u32* __restrict__ hist,
-                                 CheckResult* res) {
+__global__ void k_check_mult(const u64* __restrict__ trace, size_t n_rows, const u32* __restrict__ hist, CheckResult* res) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
         const u64 want = r < 256 ? hist[r] : 0;

@@ -27,6 +27,7 @@
 #include "callstack_kernels.cuh"
 #include "precompile_kernels.cuh"
 #include "storage_application_kernels.cuh"
+#include "decommit_sorter_circuit_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -1059,11 +1060,8 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     return ctx->sync_if_host();
 }
 
-extern "C" int zkw_ram_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
-                                       uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
-        return fail(ZKW_ERR_INVALID, "zkw_ram_check_satisfied: bad argument");
-    if (RC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+template <class S>
+static int check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     HIP_TRY(hipSetDevice(ctx->device));
     const u64* trace = t->data + slot * t->slot_elems();
     const size_t n_rows = t->n_rows;
@@ -1075,20 +1073,36 @@ extern "C" int zkw_ram_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t 
     HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), ctx->stream));
     const size_t lds = (size_t)CHK_COLS * CHK_ROWS * sizeof(u64);
-    { Prof _p(ctx, "k_ram_check_rows"); hipLaunchKernelGGL(k_ram_check_rows, dim3((capacity + CHK_ROWS - 1) / CHK_ROWS, RC_NUM_ROW_TYPES), dim3(CHK_ROWS), lds, ctx->stream, trace, capacity, n_rows, d_res); }
-    ZKW_TRY(launch_check("k_ram_check_rows"));
-    { Prof _p(ctx, "k_ram_check_links"); hipLaunchKernelGGL(k_ram_check_links, dim3((capacity + 255) / 256), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_res); }
-    ZKW_TRY(launch_check("k_ram_check_links"));
-    { Prof _p(ctx, "k_ram_check_lookups"); hipLaunchKernelGGL(k_ram_check_lookups, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_ram_check_lookups"));
-    { Prof _p(ctx, "k_ram_check_mult"); hipLaunchKernelGGL(k_ram_check_mult, dim3(256), dim3(256), 0, ctx->stream, trace, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_ram_check_mult"));
+    { Prof _p(ctx, "k_check_rows"); hipLaunchKernelGGL((k_check_rows<S>), dim3((capacity + CHK_ROWS - 1) / CHK_ROWS, S::NUM_ROW_TYPES), dim3(CHK_ROWS), lds, ctx->stream, trace, capacity, n_rows, d_res); }
+    ZKW_TRY(launch_check("k_check_rows"));
+    { Prof _p(ctx, "k_check_links"); hipLaunchKernelGGL((k_check_links<S>), dim3((capacity + 255) / 256), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_res); }
+    ZKW_TRY(launch_check("k_check_links"));
+    { Prof _p(ctx, "k_check_lookups"); hipLaunchKernelGGL((k_check_lookups<S>), dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_check_lookups"));
+    { Prof _p(ctx, "k_check_mult"); hipLaunchKernelGGL(k_check_mult, dim3(256), dim3(256), 0, ctx->stream, trace, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_check_mult"));
     CheckResult res;
     HIP_TRY(hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *n_violations = res.violations;
     if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
     return ZKW_OK;
+}
+
+extern "C" int zkw_ram_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
+                                       uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+        return fail(ZKW_ERR_INVALID, "zkw_ram_check_satisfied: bad argument");
+    if (RC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    return check_satisfied<SpecRam>(ctx, t, slot, capacity, n_violations, first_bad);
+}
+
+extern "C" int zkw_decommit_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
+                                                   uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+        return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_check_satisfied: bad argument");
+    if (DS_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    return check_satisfied<SpecDecommitSorter>(ctx, t, slot, capacity, n_violations, first_bad);
 }
 
 // ------------------------------------------------------------------------------------------------ decommit sorter
@@ -1100,9 +1114,11 @@ struct zkw_decommit_witness {
     u64 *unsorted_enc = nullptr, *sorted_enc = nullptr, *unsorted_tails = nullptr, *sorted_tails = nullptr;
     u64 *dedup_enc = nullptr, *dedup_tails = nullptr, *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
     zkw_decommit_sorter_instance* instances = nullptr;
+    zkw_queue_state12 dedup_in;   // state of the deduplicated queue before the block (host copy)
+    u32* fresh_prefix = nullptr;  // [n + 1], computed by the first synthesis call
     void release() {
         void* ptrs[] = {sorted_q, dedup_q, unsorted_enc, sorted_enc, unsorted_tails, sorted_tails, dedup_enc,
-                        dedup_tails, challenges, lhs_z, rhs_z, instances};
+                        dedup_tails, challenges, lhs_z, rhs_z, instances, fresh_prefix};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -1206,6 +1222,7 @@ extern "C" int zkw_decommit_sorter_build(zkw_ctx* ctx, const zkw_decommit_query*
     zkw_queue_state12 din;
     memset(&din, 0, sizeof din);
     if (dedup_in) din = *dedup_in;
+    w->dedup_in = din;
     const zkw_decommit_query* d_q = nullptr;
     int rc = ctx->in("dec_q", q, n, &d_q);
     if (rc == ZKW_OK) rc = decommit_run(ctx, w, d_q, din);
@@ -2367,4 +2384,69 @@ extern "C" void zkw_storage_application_witness_free(zkw_storage_application_wit
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
     delete w;
+}
+
+// ------------------------------------------------------------------------------------------------ decommit sorter synthesis (a21, type 2)
+extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_witness* cw, size_t first_instance, size_t n_instances,
+                                              zkw_trace* t, size_t first_slot) {
+    zkw_decommit_witness* w = const_cast<zkw_decommit_witness*>(cw);
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_synthesize: bad argument");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    const u32 capacity = w->capacity;
+    const size_t n_rows = t->n_rows;
+    if (DS_MIN_ROWS(capacity) > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)DS_MIN_ROWS(capacity), n_rows);
+    if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!w->fresh_prefix) {
+        HIP_TRY(hipMalloc((void**)&w->fresh_prefix, (w->n + 2) * sizeof(u32)));
+        { Prof _p(ctx, "k_ds_fresh_prefix"); hipLaunchKernelGGL(k_ds_fresh_prefix, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, w->n, w->fresh_prefix); }
+        ZKW_TRY(launch_check("k_ds_fresh_prefix"));
+    }
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("ds_hist", n_instances * 256, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    std::vector<DsSynthJob> jobs(n_instances);
+    for (size_t k = 0; k < n_instances; k++) {
+        DsSynthJob& j = jobs[k];
+        j.inst = w->instances + first_instance + k;
+        j.sorted_q = w->sorted_q;
+        j.unsorted_enc = w->unsorted_enc; j.sorted_enc = w->sorted_enc;
+        j.unsorted_tails = w->unsorted_tails; j.sorted_tails = w->sorted_tails;
+        j.dedup_enc = w->dedup_enc; j.dedup_tails = w->dedup_tails;
+        j.fresh_prefix = w->fresh_prefix;
+        j.challenges = w->challenges;
+        j.lhs_z = w->lhs_z; j.rhs_z = w->rhs_z;
+        j.n_block = w->n;
+        memcpy(j.rq_tail_in, w->dedup_in.tail, 96);
+        j.rq_len_in = w->dedup_in.length;
+        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.hist = d_hist + 256 * k;
+    }
+    DsSynthJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("ds_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)n_instances;
+    const u32 rstride = (u32)DS_REGION_STRIDE(capacity);
+    const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
+    { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ds_fill_poseidon<0>"));
+    { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ds_fill_poseidon<1>"));
+    { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ds_fill_poseidon<2>"));
+    { Prof _p(ctx, "k_ds_fill_row"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_A>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ds_fill_row<A>"));
+    { Prof _p(ctx, "k_ds_fill_row"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_B>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ds_fill_row<B>"));
+    { Prof _p(ctx, "k_ds_fill_row"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_C>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ds_fill_row<C>"));
+    { Prof _p(ctx, "k_ds_fill_row"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_D>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ds_fill_row<D>"));
+    { Prof _p(ctx, "k_ds_fill_tail"); hipLaunchKernelGGL(k_ds_fill_tail, dim3((DS_G + DS_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ds_fill_tail"));
+    { Prof _p(ctx, "k_ds_fill_boundary"); hipLaunchKernelGGL(k_ds_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ds_fill_boundary"));
+    return ctx->sync_if_host();
 }

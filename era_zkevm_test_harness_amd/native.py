@@ -84,6 +84,8 @@ SYMBOLS = [
     ("zkw_decommitter_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_decommitter_witness_free", None, [_vp]),
     ("zkw_linear_keccak256", _int, [_vp, _vp, _sz, _vp]),
+    ("zkw_decommit_sorter_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_decommit_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
     ("zkw_storage_application_witness_bytes", _sz, [_vp, _int]),
@@ -950,3 +952,20 @@ def circuit_geometry(circuit_type: int):
     g = np.zeros(1, CIRCUIT_GEOMETRY)
     _check(load().zkw_circuit_geometry_of(circuit_type, _np_ptr(g)))
     return g[0]
+
+
+def _ctx_synthesize_decommit_sorter(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+    """ZkSyncBaseLayerCircuit::CodeDecommittmentsSorter synthesis for instances of a DecommitWitness."""
+    n = witness.num_instances - first_instance if n_instances is None else n_instances
+    _check(load().zkw_decommit_sorter_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+
+def _ctx_check_if_satisfied_decommit_sorter(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_decommit_sorter_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.synthesize_decommit_sorter = _ctx_synthesize_decommit_sorter
+Context.check_if_satisfied_decommit_sorter = _ctx_check_if_satisfied_decommit_sorter

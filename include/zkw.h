@@ -311,6 +311,17 @@ const void *zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness *w,
 int zkw_decommitter_witness_get(const zkw_decommitter_witness *w, int what, void *dst, size_t dst_bytes);
 void zkw_decommitter_witness_free(zkw_decommitter_witness *w);
 
+/* ---- CodeDecommittmentsSorter synthesis (a21, circuit type 2) ------------------------------------------ */
+/* Counterpart of ZkSyncBaseLayerCircuit::CodeDecommittmentsSorter(..).synthesis (base_layer/mod.rs:286-323, wrapper
+   base_layer/sort_code_decommits.rs:28-39): fills the traces of instances [first_instance, first_instance + n) of a
+   zkw_decommit_witness into consecutive slots of `t` (geometry 130 + 18 + 1 = 149 columns, layout
+   include/zkw_decommit_sorter_circuit_spec.h, "zkw trace v2"; production capacity 117 500 needs n_rows = 2^20).
+   Requires DS_MIN_ROWS(capacity) <= n_rows. The public-input row is left zero for this type. */
+int zkw_decommit_sorter_synthesize(zkw_ctx *ctx, const zkw_decommit_witness *w, size_t first_instance, size_t n_instances,
+                                   zkw_trace *t, size_t first_slot);
+int zkw_decommit_sorter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
+                                        uint64_t *n_violations, uint64_t *first_bad);
+
 /* ---- StorageApplication witness builder (a17) --------------------------------------------------------- */
 typedef struct zkw_storage_application_witness zkw_storage_application_witness;
 /* decompose_into_storage_application_witnesses, src/witness/individual_circuits/storage_application.rs:31-361.

@@ -1,0 +1,87 @@
+"""GPU parity: CodeDecommittmentsSorter synthesis through the C ABI vs the oracle's trace, cell by cell, and the GPU
+satisfiability checker vs the oracle's on clean and tampered traces."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from era_zkevm_test_harness_amd import native
+
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n,n_hashes,capacity,n_rows", [(5, 5, 8, 512), (100, 7, 128, 1024), (256, 40, 128, 1024), (300, 3, 128, 1024),
+                                                        (64, 1, 64, 512), (3000, 400, 1024, 8192)])
+def test_trace_matches_oracle(ctx, oracle, n, n_hashes, capacity, n_rows):
+    from era_zkevm_test_harness_amd import native
+
+    q = synthetic.decommit_trace(n, n_hashes, seed=n)
+    o = oracle.decommit_sorter_build(q, capacity)
+    w = ctx.compute_decommitts_sorter_circuit_snapshots(q, capacity)
+    n_inst = o["instances"].size
+    t = native.Trace(ctx, n_rows, n_inst)
+    ctx.synthesize_decommit_sorter(w, t)
+    for idx in range(n_inst):
+        got = t.get(idx)
+        exp = oracle.decommit_sorter_synthesize(o, idx, capacity, n_rows)
+        if not np.array_equal(got, exp):
+            bad = np.argwhere(got != exp)
+            raise AssertionError(f"instance {idx}: {len(bad)} cells differ, first (col, row) = {bad[:8].tolist()}")
+        assert ctx.check_if_satisfied_decommit_sorter(t, idx, capacity)[0] == 0
+    t.free()
+
+
+def test_production_geometry(ctx, oracle):
+    """capacity 117 500 in a 2^20-row trace: one full instance and a ragged last one."""
+    from era_zkevm_test_harness_amd import native
+
+    capacity, n_rows = 117500, 1 << 20
+    q = synthetic.decommit_trace(capacity + 5000, 3000, seed=9)
+    w = ctx.compute_decommitts_sorter_circuit_snapshots(q, capacity)
+    t = native.Trace(ctx, n_rows, 2)
+    ctx.synthesize_decommit_sorter(w, t)
+    for idx in range(2):
+        bad, first = ctx.check_if_satisfied_decommit_sorter(t, idx, capacity)
+        assert bad == 0, (idx, first)
+        mult = t.get(idx, 148, 1)[0]
+        assert int(mult.sum()) == 18 * n_rows and not mult[256:].any()
+    t.free()
+
+
+def test_gpu_checker_flags_tampering(ctx, oracle):
+    import torch
+
+    from era_zkevm_test_harness_amd import native
+
+    capacity, n_rows = 128, 1024
+    q = synthetic.decommit_trace(200, 11, seed=3)
+    w = ctx.compute_decommitts_sorter_circuit_snapshots(q, capacity)
+    t = native.Trace(ctx, n_rows, 1)
+    ctx.synthesize_decommit_sorter(w, t, 0, 1)
+    assert ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)[0] == 0
+    host = t.get(0)
+    rng = np.random.default_rng(2)
+    used = np.argwhere(host[:148, :7 * 128 + 3] != 0)
+    base = native.load().zkw_trace_device_ptr(t.handle, 0)
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    for _ in range(25):
+        c, r = used[rng.integers(len(used))]
+        addr = base + (int(c) * n_rows + int(r)) * 8
+        old = np.array([host[c, r]], np.uint64)
+        new = np.array([(int(host[c, r]) + 1) % P], np.uint64)
+        torch.cuda.synchronize()
+        hip.hipMemcpy(C.c_void_p(addr), new.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
+        assert ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)[0] > 0, (c, r)
+        hip.hipMemcpy(C.c_void_p(addr), old.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
+    assert ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)[0] == 0
+    t.free()

@@ -239,6 +239,10 @@ if __name__ == "__main__":
              "   previous cycle, XG(col, v) per-instance global, XX(col, v) value in BND_OUT (the flush permutation). */",
              "#define DS_VARS(X) " + " ".join(f"X({n})" for n in names)]
     for r in rows:
+        lines.append(f"#define DS_NSLOTS_{r.name} {len(r.slots)}")
+        lines.append(f"#define DS_NLOOK_{r.name} {len(r.lookups)}")
+    lines.append(f"#define DS_LOOKUPS_PER_CYCLE {sum(len(r.lookups) for r in rows if r.per_cycle)}")
+    for r in rows:
         ent = []
         for v in r.slots + r.lookups:
             kind = {"p.": "XP", "g.": "XG", "x.": "XX"}.get(v[:2], "XC")
