@@ -52,11 +52,34 @@ struct DsVars {
     dst.pfx##_b2 = (_x >> 16) & 0xFF; dst.pfx##_b3 = _x >> 24; } while (0)
 #define DS_ISZ(dst, w, z, a, b) do { const u64 _d = gl::canon(gl::sub((a), (b))); dst.z = _d == 0; dst.w = _d ? gl::inv(_d) : 0; } while (0)
 
-__device__ __forceinline__ void ds_encode(const zkw_decommit_query& q, u64 e[8]) {  // decommittment_request.rs:9-74
+template <class Q>
+__device__ __forceinline__ void ds_encode(const Q& q, u64 e[8]) {  // decommittment_request.rs:9-74
     e[0] = (u64)q.hash[0] | ((u64)(q.memory_page & 0xFFFFFF) << 32);
     e[1] = (u64)q.hash[1] | ((u64)(q.memory_page >> 24) << 32) | ((u64)(q.timestamp & 0xFFFF) << 40);
     e[2] = (u64)q.hash[2] | ((u64)(q.timestamp >> 16) << 32) | ((u64)(q.is_fresh ? 1 : 0) << 48);
+#pragma unroll
     for (int k = 3; k < 8; k++) e[k] = q.hash[k];
+}
+
+// the fields of a request the circuit looks at (kept in registers; zkw_decommit_query itself carries padding)
+struct DsReq {
+    u32 hash[8];
+    u32 timestamp, memory_page, is_fresh;
+};
+__device__ __forceinline__ DsReq ds_req_zero() {
+    DsReq r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.hash[k] = 0;
+    r.timestamp = 0; r.memory_page = 0; r.is_fresh = 0;
+    return r;
+}
+__device__ __forceinline__ DsReq ds_req_load(const zkw_decommit_query* q) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(q);
+    const uint4 a = s4[0], b = s4[1], c = s4[2];
+    DsReq r;
+    r.hash[0] = a.x; r.hash[1] = a.y; r.hash[2] = a.z; r.hash[3] = a.w; r.hash[4] = b.x; r.hash[5] = b.y; r.hash[6] = b.z; r.hash[7] = b.w;
+    r.timestamp = c.x; r.memory_page = c.y; r.is_fresh = (c.z >> 16) & 0xFF;  // decommitted_length u16, is_fresh u8
+    return r;
 }
 
 // the registers entering cycle 0 of an instance = its hidden FSM input (or the observable input on the first one)
@@ -64,7 +87,7 @@ struct DsRegsIn {
     const u64 *uh, *sh;  // [12]
     u64 rh[12], ge[8], lhs[2], rhs[2];
     u32 len, len_r, gvalid;
-    zkw_decommit_query pq;  // previous request's key fields (zeros on the first instance)
+    DsReq pq;  // previous request's key fields (zeros on the first instance)
 };
 __device__ __forceinline__ void ds_regs_in(const DsSynthJob& job, DsRegsIn& r) {
     const zkw_decommit_sorter_instance* in = job.inst;
@@ -73,17 +96,21 @@ __device__ __forceinline__ void ds_regs_in(const DsSynthJob& job, DsRegsIn& r) {
     r.uh = start ? in->initial_queue_state.head : f.initial_queue_state.head;
     r.sh = start ? in->sorted_queue_initial_state.head : f.sorted_queue_state.head;
     r.len = start ? in->initial_queue_state.length : f.initial_queue_state.length;
+#pragma unroll
     for (int k = 0; k < 12; k++) r.rh[k] = start ? job.rq_tail_in[k] : f.final_queue_state.tail[k];
     r.len_r = start ? job.rq_len_in : f.final_queue_state.length;
+#pragma unroll
     for (int k = 0; k < 2; k++) { r.lhs[k] = start ? 1 : f.lhs_accumulator[k]; r.rhs[k] = start ? 1 : f.rhs_accumulator[k]; }
     r.gvalid = start ? 0 : 1;
-    memset(&r.pq, 0, sizeof r.pq);
+    r.pq = ds_req_zero();
     r.pq.timestamp = f.previous_packed_key[0];
+#pragma unroll
     for (int k = 0; k < 8; k++) r.pq.hash[k] = f.previous_packed_key[1 + k];
     r.pq.memory_page = f.previous_record.memory_page;
+#pragma unroll
     for (int k = 0; k < 8; k++) r.ge[k] = 0;
     if (!start) {  // the open group's first request: (hash, page, first_encountered_timestamp, fresh)
-        zkw_decommit_query g = f.previous_record;
+        DsReq g = r.pq;  // hash and page of the previous record
         g.timestamp = f.first_encountered_timestamp;
         g.is_fresh = 1;
         ds_encode(g, r.ge);
@@ -93,7 +120,7 @@ __device__ __forceinline__ void ds_regs_in(const DsSynthJob& job, DsRegsIn& r) {
 // what a cycle needs from its neighbourhood: this request, the previous one, group / queue positions
 struct DsCycle {
     bool can_pop;
-    zkw_decommit_query q, pq;
+    DsReq q, pq;
     u32 p_gvalid, fresh_before;  // fresh requests among sorted[0, idx)
     u64 pushes_before;           // pushes into the deduplicated queue before this cycle (from the block's start)
     size_t last_popped;          // index of the last item popped before this cycle (valid when i > 0)
@@ -102,11 +129,11 @@ __device__ __forceinline__ void ds_cycle(const DsSynthJob& job, const DsRegsIn& 
     const zkw_decommit_sorter_instance* in = job.inst;
     const size_t first = in->first_item, m = in->num_items;
     c.can_pop = i < m;
-    memset(&c.q, 0, sizeof c.q);
-    memset(&c.pq, 0, sizeof c.pq);
-    if (c.can_pop) c.q = job.sorted_q[first + i];
+    c.q = ds_req_zero();
+    c.pq = ds_req_zero();
+    if (c.can_pop) c.q = ds_req_load(job.sorted_q + first + i);
     if (i == 0) c.pq = ri.pq;
-    else if (i - 1 < m) c.pq = job.sorted_q[first + i - 1];
+    else if (i - 1 < m) c.pq = ds_req_load(job.sorted_q + first + i - 1);
     c.p_gvalid = i == 0 ? ri.gvalid : 1;
     c.fresh_before = job.fresh_prefix[first + (i < m ? i : m)];
     c.pushes_before = c.fresh_before ? c.fresh_before - 1 : 0;
@@ -143,17 +170,22 @@ __global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob* __res
         if (WHICH == 2) {
             u64 rh[12], ge[8];
             ds_prev_result_queue(job, ri, c, rh, ge);
+#pragma unroll
             for (int k = 0; k < 8; k++) s[k] = ge[k];
+#pragma unroll
             for (int k = 0; k < 4; k++) s[8 + k] = rh[8 + k];
         } else {
             const u64* enc = WHICH == 0 ? job.unsorted_enc : job.sorted_enc;
             const u64* tails = WHICH == 0 ? job.unsorted_tails : job.sorted_tails;
+#pragma unroll
             for (int k = 0; k < 8; k++) s[k] = c.can_pop ? enc[8 * (first + i) + k] : 0;
             const u64* ph = i == 0 ? (WHICH == 0 ? ri.uh : ri.sh) : tails + 12 * c.last_popped;
+#pragma unroll
             for (int k = 0; k < 4; k++) s[8 + k] = ph[8 + k];
         }
         fill_flattened_poseidon(trace, n_rows, row, s);
         if (WHICH == 1) {  // the range checks of hash limbs 3..6 ride here
+#pragma unroll
             for (int k = 3; k < 7; k++) {
                 put_bytes(trace, n_rows, row, DS_PS_h3_b0 + 4 * (k - 3), c.q.hash[k]);
                 hist_bytes(sh_hist, c.q.hash[k]);
@@ -194,12 +226,13 @@ __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __restric
         const u64 can_pop = c.can_pop ? 1 : 0;
         cur.can_pop = can_pop;
         u64 eu[8], es[8];
+#pragma unroll
         for (int k = 0; k < 8; k++) { eu[k] = c.can_pop ? job.unsorted_enc[8 * idx + k] : 0; es[k] = c.can_pop ? job.sorted_enc[8 * idx + k] : 0; }
         DS_SET8(cur, eu, eu);
         DS_SET8(cur, es, es);
         // this request and the previous one
-        const zkw_decommit_query& q = c.q;
-        const zkw_decommit_query& pq = c.pq;
+        const DsReq& q = c.q;
+        const DsReq& pq = c.pq;
         cur.h0 = q.hash[0]; cur.h1 = q.hash[1]; cur.h2 = q.hash[2]; cur.page = q.memory_page; cur.ts = q.timestamp;
         cur.fresh = q.is_fresh ? 1 : 0;
         prev.h0 = pq.hash[0]; prev.h1 = pq.hash[1]; prev.h2 = pq.hash[2]; prev.es3 = pq.hash[3]; prev.es4 = pq.hash[4];
@@ -228,14 +261,24 @@ __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __restric
         }
         // hash equality with the previous request and the group logic
         bool same = true;
+#pragma unroll
         for (int k = 0; k < 8; k++) same &= q.hash[k] == pq.hash[k];
         const bool new_group = c.can_pop && !(same && c.p_gvalid), push = new_group && c.p_gvalid;
         cur.new_group = new_group; cur.push = push;
         if (ROW == DS_ROW_C) {
-            DS_ISZ(cur, w_e0, z_e0, (u64)q.hash[0], (u64)pq.hash[0]); DS_ISZ(cur, w_e1, z_e1, (u64)q.hash[1], (u64)pq.hash[1]);
-            DS_ISZ(cur, w_e2, z_e2, (u64)q.hash[2], (u64)pq.hash[2]); DS_ISZ(cur, w_e3, z_e3, (u64)q.hash[3], (u64)pq.hash[3]);
-            DS_ISZ(cur, w_e4, z_e4, (u64)q.hash[4], (u64)pq.hash[4]); DS_ISZ(cur, w_e5, z_e5, (u64)q.hash[5], (u64)pq.hash[5]);
-            DS_ISZ(cur, w_e6, z_e6, (u64)q.hash[6], (u64)pq.hash[6]); DS_ISZ(cur, w_e7, z_e7, (u64)q.hash[7], (u64)pq.hash[7]);
+            // eight "inverse or zero" witnesses from ONE field inversion (Montgomery's trick; zeros are replaced by 1)
+            u64 dlt[8], pre[8], inv[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) dlt[k] = gl::canon(gl::sub((u64)q.hash[k], (u64)pq.hash[k]));
+            u64 acc = 1;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { pre[k] = acc; acc = gl::mul(acc, dlt[k] ? dlt[k] : 1); }
+            u64 ia = gl::inv(acc);
+#pragma unroll
+            for (int k = 7; k >= 0; k--) { inv[k] = dlt[k] ? gl::canon(gl::mul(ia, pre[k])) : 0; ia = gl::mul(ia, dlt[k] ? dlt[k] : 1); }
+            cur.w_e0 = inv[0]; cur.w_e1 = inv[1]; cur.w_e2 = inv[2]; cur.w_e3 = inv[3]; cur.w_e4 = inv[4]; cur.w_e5 = inv[5]; cur.w_e6 = inv[6]; cur.w_e7 = inv[7];
+            cur.z_e0 = dlt[0] == 0; cur.z_e1 = dlt[1] == 0; cur.z_e2 = dlt[2] == 0; cur.z_e3 = dlt[3] == 0; cur.z_e4 = dlt[4] == 0;
+            cur.z_e5 = dlt[5] == 0; cur.z_e6 = dlt[6] == 0; cur.z_e7 = dlt[7] == 0;
             cur.same_a = cur.z_e0 & cur.z_e1 & cur.z_e2 & cur.z_e3;
             cur.same_hash = same;
             // deduplicated queue: the PR row (written earlier on this stream) holds the pushed state
@@ -243,6 +286,7 @@ __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __restric
             ds_prev_result_queue(job, ri, c, rh, ge);
             const size_t rPR = (size_t)DS_ROW_PR * rs + i;
             constexpr int RO[12] = DS_COLS12(PR, ro);
+#pragma unroll
             for (int k = 0; k < 12; k++) { ro[k] = TR(RO[k], rPR); o[k] = push ? ro[k] : rh[k]; }
             DS_SET12(cur, ro, ro); DS_SET12(prev, rh, rh); DS_SET12(cur, rh, o);
         }
@@ -251,6 +295,7 @@ __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __restric
             glob.c0_5 = job.challenges[5]; glob.c0_6 = job.challenges[6]; glob.c0_7 = job.challenges[7]; glob.c0_8 = job.challenges[8];
             glob.c1_1 = job.challenges[10]; glob.c1_2 = job.challenges[11]; glob.c1_3 = job.challenges[12]; glob.c1_4 = job.challenges[13];
             glob.c1_5 = job.challenges[14]; glob.c1_6 = job.challenges[15]; glob.c1_7 = job.challenges[16]; glob.c1_8 = job.challenges[17];
+#pragma unroll
             for (int r = 0; r < 2; r++) {
                 const u64* ch = job.challenges + 9 * r;
                 u64 lc = gl::add(ch[8], eu[0]), rc = gl::add(ch[8], es[0]);
@@ -273,12 +318,14 @@ __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __restric
             cur.len_r = prev.len_r + (push ? 1 : 0);
             u64 rh[12], ge[8], o8[8];
             ds_prev_result_queue(job, ri, c, rh, ge);
+#pragma unroll
             for (int k = 0; k < 8; k++) o8[k] = new_group ? es[k] : ge[k];
             DS_SET8(prev, ge, ge); DS_SET8(cur, ge, o8);
             // queue heads: the Poseidon2 rows hold the popped states
             const size_t rPU = (size_t)DS_ROW_PU * rs + i, rPS = (size_t)DS_ROW_PS * rs + i;
             u64 uo[12], so[12], pu[12], ps[12], ou[12], os[12];
             constexpr int UO[12] = DS_COLS12(PU, uo), SO[12] = DS_COLS12(PS, so);
+#pragma unroll
             for (int k = 0; k < 12; k++) {
                 uo[k] = TR(UO[k], rPU); so[k] = TR(SO[k], rPS);
                 pu[k] = i == 0 ? ri.uh[k] : job.unsorted_tails[12 * c.last_popped + k];
@@ -361,11 +408,14 @@ __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __res
         const size_t rPS = (size_t)DS_ROW_PS * rs + lc;
         u64 t12[12], t8[8];
         constexpr int UH[12] = DS_COLS12(D, uh), SH[12] = DS_COLS12(D, sh), RH[12] = DS_COLS12(C, rh), GE[8] = DS_COLS8(D, ge);
+#pragma unroll
         for (int k = 0; k < 12; k++) t12[k] = TR(UH[k], rD);
         DS_SET12(cur, uh, t12);
+#pragma unroll
         for (int k = 0; k < 12; k++) t12[k] = TR(SH[k], rD);
         DS_SET12(cur, sh, t12);
         u64 rh[12];
+#pragma unroll
         for (int k = 0; k < 12; k++) rh[k] = TR(RH[k], rC);
         DS_SET12(cur, rh, rh);
         cur.len_u = TR(DS_D_len_u, rD); cur.len_s = TR(DS_D_len_s, rD); cur.len_r = TR(DS_D_len_r, rD);
@@ -374,6 +424,7 @@ __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __res
         cur.es3 = TR(DS_PS_es3, rPS); cur.es4 = TR(DS_PS_es4, rPS); cur.es5 = TR(DS_PS_es5, rPS); cur.es6 = TR(DS_PS_es6, rPS);
         cur.es7 = TR(DS_PS_es7, rPS);
         cur.gvalid = TR(DS_C_gvalid, rC);
+#pragma unroll
         for (int k = 0; k < 8; k++) t8[k] = TR(GE[k], rD);
         DS_SET8(cur, ge, t8);
         DS_SET12(cur, tail_u, in->initial_queue_state.tail);
@@ -382,12 +433,15 @@ __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __res
         cur.w_end = gl::canon(cur.len_u) ? gl::inv(cur.len_u) : 0; cur.z_end = cur.len_u == 0;
         cur.flush = cur.completion & cur.gvalid;
         u64 s[12];
+#pragma unroll
         for (int k = 0; k < 8; k++) s[k] = t8[k];
+#pragma unroll
         for (int k = 0; k < 4; k++) s[8 + k] = rh[8 + k];
         const size_t rPF = bnd + DS_ROWOFF_PF;
         fill_flattened_poseidon(trace, n_rows, rPF, s);
         for (int col = DS_G; col < DS_G + DS_L; col++) TR(col, rPF) = 0;
         u64 fo[12], fr[12];
+#pragma unroll
         for (int k = 0; k < 12; k++) { fo[k] = gl::canon(s[k]); fr[k] = cur.flush ? fo[k] : rh[k]; }
         DS_SET12(cur, fo, fo); DS_SET12(cur, final_rh, fr);
         cur.final_len_r = cur.len_r + cur.flush;

@@ -2436,13 +2436,13 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
     ZKW_TRY(launch_check("k_ds_fill_poseidon<1>"));
     { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_poseidon<2>"));
-    { Prof _p(ctx, "k_ds_fill_row"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_A>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_row_A"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_A>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_row<A>"));
-    { Prof _p(ctx, "k_ds_fill_row"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_B>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_row_B"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_B>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_row<B>"));
-    { Prof _p(ctx, "k_ds_fill_row"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_C>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_row_C"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_C>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_row<C>"));
-    { Prof _p(ctx, "k_ds_fill_row"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_D>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_row_D"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_D>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_row<D>"));
     { Prof _p(ctx, "k_ds_fill_tail"); hipLaunchKernelGGL(k_ds_fill_tail, dim3((DS_G + DS_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_tail"));
