@@ -31,6 +31,7 @@ struct DsSynthJob {
     u32 rq_len_in;
     u64* trace;
     u32* hist;  // [256]
+    const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ds_commitments)
 };
 
 struct DsVars {
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __res
         for (int col = DS_NSLOTS_BND_OUT; col < DS_G + DS_L; col++) TR(col, row) = 0;
     }
     const size_t rPI = bnd + DS_ROWOFF_PI;
-    for (int col = 0; col < DS_G + DS_L; col++) TR(col, rPI) = 0;  // the public input is not derived for this type yet
+    for (int col = 0; col < DS_G + DS_L; col++) TR(col, rPI) = col < 4 ? job.public_input[col] : 0;
 }
 
 // fresh_prefix[k] = fresh requests among sorted[0, k), k = 0..n. One workgroup, tiles of 1024.

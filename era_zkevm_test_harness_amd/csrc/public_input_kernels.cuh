@@ -99,6 +99,49 @@ __global__ __launch_bounds__(64) void k_ram_commitments(const zkw_ram_instance* 
     for (int k = 0; k < 4; k++) cf[at + k] = c[k];
 }
 
+// CodeDecommittmentsSorter (type 2): same lane plan; part 1 commits the observable output (the final queue state)
+constexpr int DS_FSM_ENC_LEN = 100;
+__device__ inline int ds_encode_fsm(const zkw_decommit_sorter_fsm& f, u64* o) {
+    int m = put_queue12(f.initial_queue_state, o);
+    m += put_queue12(f.sorted_queue_state, o + m);
+    m += put_queue12(f.final_queue_state, o + m);
+    for (int r = 0; r < 2; r++) o[m++] = f.lhs_accumulator[r];
+    for (int r = 0; r < 2; r++) o[m++] = f.rhs_accumulator[r];
+    for (int k = 0; k < 9; k++) o[m++] = f.previous_packed_key[k];
+    for (int k = 0; k < 8; k++) o[m++] = f.previous_record.hash[k];
+    o[m++] = f.previous_record.memory_page;
+    o[m++] = f.previous_record.is_fresh ? 1 : 0;
+    o[m++] = f.previous_record.timestamp;
+    o[m++] = f.first_encountered_timestamp;
+    return m;
+}
+__global__ __launch_bounds__(64) void k_ds_commitments(const zkw_decommit_sorter_instance* __restrict__ inst, size_t n,
+                                                       u64* __restrict__ compact) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = t >> 2;
+    const int part = (int)(t & 3);
+    if (i >= n) return;
+    u64* cf = compact + COMPACT_FORM_LEN * i;
+    u64 buf[DS_FSM_ENC_LEN];
+    u64 c[4];
+    int m;
+    if (part == 0) {
+        size_t j = i;
+        while (j > 0 && !inst[j].start_flag) j--;
+        m = put_queue12(inst[j].initial_queue_state, buf);
+        m += put_queue12(inst[j].sorted_queue_initial_state, buf + m);
+    } else if (part == 1) {
+        cf[0] = inst[i].start_flag ? 1 : 0;
+        cf[1] = inst[i].completion_flag ? 1 : 0;
+        m = put_queue12(inst[i].final_queue_state, buf);
+    } else {
+        m = ds_encode_fsm(part == 2 ? inst[i].hidden_fsm_input : inst[i].hidden_fsm_output, buf);
+    }
+    commit_var_length(buf, m, c);
+    const int at = part == 0 ? 2 : (part == 1 ? 6 : (part == 2 ? 10 : 14));
+    for (int k = 0; k < 4; k++) cf[at + k] = c[k];
+}
+
 __global__ __launch_bounds__(64) void k_encode_recursion(u64 circuit_type, const u64* __restrict__ pi, size_t n,
                                                          u64* __restrict__ enc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1116,9 +1116,10 @@ struct zkw_decommit_witness {
     zkw_decommit_sorter_instance* instances = nullptr;
     zkw_queue_state12 dedup_in;   // state of the deduplicated queue before the block (host copy)
     u32* fresh_prefix = nullptr;  // [n + 1], computed by the first synthesis call
+    u64 *compact_forms = nullptr, *public_inputs = nullptr;  // [n_instances][18], [n_instances][4]
     void release() {
         void* ptrs[] = {sorted_q, dedup_q, unsorted_enc, sorted_enc, unsorted_tails, sorted_tails, dedup_enc,
-                        dedup_tails, challenges, lhs_z, rhs_z, instances, fresh_prefix};
+                        dedup_tails, challenges, lhs_z, rhs_z, instances, fresh_prefix, compact_forms, public_inputs};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -1214,6 +1215,8 @@ extern "C" int zkw_decommit_sorter_build(zkw_ctx* ctx, const zkw_decommit_query*
     alloc((void**)&w->unsorted_tails, n * 96); alloc((void**)&w->sorted_tails, n * 96); alloc((void**)&w->dedup_tails, n * 96);
     alloc((void**)&w->challenges, 18 * 8); alloc((void**)&w->lhs_z, n * 16); alloc((void**)&w->rhs_z, n * 16);
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_decommit_sorter_instance));
+    alloc((void**)&w->compact_forms, w->n_instances * COMPACT_FORM_LEN * 8);
+    alloc((void**)&w->public_inputs, w->n_instances * 32);
     if (e != hipSuccess) {
         w->release();
         delete w;
@@ -1226,6 +1229,15 @@ extern "C" int zkw_decommit_sorter_build(zkw_ctx* ctx, const zkw_decommit_query*
     const zkw_decommit_query* d_q = nullptr;
     int rc = ctx->in("dec_q", q, n, &d_q);
     if (rc == ZKW_OK) rc = decommit_run(ctx, w, d_q, din);
+    if (rc == ZKW_OK) {  // a20: compact forms and public inputs (postprocessing/mod.rs:353-369)
+        const size_t ni = w->n_instances;
+        { Prof _p(ctx, "k_ds_commitments"); hipLaunchKernelGGL(k_ds_commitments, dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, w->instances, ni, w->compact_forms); }
+        rc = launch_check("k_ds_commitments");
+        if (rc == ZKW_OK) {
+            { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, w->compact_forms, ni, (u32)COMPACT_FORM_LEN, w->public_inputs); }
+            rc = launch_check("k_commit_encodings");
+        }
+    }
     if (rc == ZKW_OK) rc = ctx->sync_if_host();
     if (rc == ZKW_OK && ctx->ptr_mode == ZKW_PTR_HOST) {  // lhs == rhs at the end (utils.rs:685-696)
         u64 ends[4];
@@ -1263,6 +1275,8 @@ static const void* dec_array(const zkw_decommit_witness* w, int what, size_t* by
         case ZKW_DEC_LHS_Z: *bytes = n * 16; return w->lhs_z;
         case ZKW_DEC_RHS_Z: *bytes = n * 16; return w->rhs_z;
         case ZKW_DEC_INSTANCES: *bytes = w->n_instances * sizeof(zkw_decommit_sorter_instance); return w->instances;
+        case ZKW_DEC_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->compact_forms;
+        case ZKW_DEC_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->public_inputs;
         default: *bytes = 0; return nullptr;
     }
 }
@@ -1279,7 +1293,7 @@ extern "C" int zkw_decommit_witness_get(const zkw_decommit_witness* w, int what,
     if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_decommit_witness_get: null argument");
     size_t bytes = 0;
     const void* src = dec_array(w, what, &bytes);
-    if (!src && bytes == 0 && what > ZKW_DEC_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    if (!src && bytes == 0 && what > ZKW_DEC_PUBLIC_INPUTS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
     if (bytes == 0) return ZKW_OK;
     zkw_ctx* ctx = w->ctx;
@@ -2424,6 +2438,7 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
         j.rq_len_in = w->dedup_in.length;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + 256 * k;
+        j.public_input = w->public_inputs + 4 * (first_instance + k);
     }
     DsSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("ds_jobs", jobs, &d_jobs));

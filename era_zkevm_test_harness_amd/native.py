@@ -196,7 +196,7 @@ DECOMMIT_INSTANCE = np.dtype(
      ("sorted_queue_initial_state", QUEUE_STATE12), ("final_queue_state", QUEUE_STATE12),
      ("hidden_fsm_input", DECOMMIT_FSM), ("hidden_fsm_output", DECOMMIT_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
 (DEC_SORTED_QUERIES, DEC_UNSORTED_ENC, DEC_SORTED_ENC, DEC_UNSORTED_TAILS, DEC_SORTED_TAILS, DEC_DEDUP_QUERIES,
- DEC_DEDUP_TAILS, DEC_CHALLENGES, DEC_LHS_Z, DEC_RHS_Z, DEC_INSTANCES) = range(11)
+ DEC_DEDUP_TAILS, DEC_CHALLENGES, DEC_LHS_Z, DEC_RHS_Z, DEC_INSTANCES, DEC_COMPACT_FORMS, DEC_PUBLIC_INPUTS) = range(13)
 
 
 QUEUE_STATE4 = np.dtype([("head", "<u8", (4,)), ("tail", "<u8", (4,)), ("length", "<u4"), ("_pad", "<u4")])
@@ -519,7 +519,8 @@ class DecommitWitness:
 
     _DTYPES = {DEC_SORTED_QUERIES: DECOMMIT_QUERY, DEC_DEDUP_QUERIES: DECOMMIT_QUERY, DEC_INSTANCES: DECOMMIT_INSTANCE}
     _SHAPES = {DEC_UNSORTED_ENC: (-1, 8), DEC_SORTED_ENC: (-1, 8), DEC_UNSORTED_TAILS: (-1, 12), DEC_SORTED_TAILS: (-1, 12),
-               DEC_DEDUP_TAILS: (-1, 12), DEC_CHALLENGES: (2, 9), DEC_LHS_Z: (2, -1), DEC_RHS_Z: (2, -1)}
+               DEC_DEDUP_TAILS: (-1, 12), DEC_CHALLENGES: (2, 9), DEC_LHS_Z: (2, -1), DEC_RHS_Z: (2, -1),
+               DEC_COMPACT_FORMS: (-1, 18), DEC_PUBLIC_INPUTS: (-1, 4)}
 
     def __init__(self, ctx):
         self.ctx = ctx

@@ -186,7 +186,9 @@ enum {
     ZKW_DEC_CHALLENGES = 7,     /* uint64_t[2][9]          */
     ZKW_DEC_LHS_Z = 8,          /* uint64_t[2][n]          */
     ZKW_DEC_RHS_Z = 9,
-    ZKW_DEC_INSTANCES = 10      /* zkw_decommit_sorter_instance[ceil(n/capacity)] */
+    ZKW_DEC_INSTANCES = 10,     /* zkw_decommit_sorter_instance[ceil(n/capacity)] */
+    ZKW_DEC_COMPACT_FORMS = 11, /* uint64_t[n_instances][18]: see ZKW_RAM_COMPACT_FORMS */
+    ZKW_DEC_PUBLIC_INPUTS = 12  /* uint64_t[n_instances][4] */
 };
 size_t zkw_decommit_witness_num_instances(const zkw_decommit_witness *w);
 size_t zkw_decommit_witness_num_dedup(const zkw_decommit_witness *w);
@@ -316,7 +318,7 @@ void zkw_decommitter_witness_free(zkw_decommitter_witness *w);
    base_layer/sort_code_decommits.rs:28-39): fills the traces of instances [first_instance, first_instance + n) of a
    zkw_decommit_witness into consecutive slots of `t` (geometry 130 + 18 + 1 = 149 columns, layout
    include/zkw_decommit_sorter_circuit_spec.h, "zkw trace v2"; production capacity 117 500 needs n_rows = 2^20).
-   Requires DS_MIN_ROWS(capacity) <= n_rows. The public-input row is left zero for this type. */
+   Requires DS_MIN_ROWS(capacity) <= n_rows. */
 int zkw_decommit_sorter_synthesize(zkw_ctx *ctx, const zkw_decommit_witness *w, size_t first_instance, size_t n_instances,
                                    zkw_trace *t, size_t first_slot);
 int zkw_decommit_sorter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,

@@ -45,7 +45,8 @@ static void poseidon_cells(uint64_t *trace, size_t n_rows, size_t row, const uin
 int orc_decommit_sorter_synthesize(const zkw_decommit_sorter_instance *inst, const zkw_decommit_query *sorted_q,
                                    const uint64_t *unsorted_enc, const uint64_t *sorted_enc,
                                    const uint64_t *challenges /* [2][9] */, const uint64_t *rq_tail_in, uint32_t rq_len_in,
-                                   uint32_t capacity, size_t n_rows, uint64_t *trace) {
+                                   const uint64_t *public_input /* [4] or NULL */, uint32_t capacity, size_t n_rows,
+                                   uint64_t *trace) {
     if (DS_MIN_ROWS(capacity) > n_rows) return -1;
     const size_t first = inst->first_item, m = inst->num_items;
     if (m == 0 || m > capacity) return -2;
@@ -216,6 +217,9 @@ int orc_decommit_sorter_synthesize(const zkw_decommit_sorter_instance *inst, con
         DS_FILL_BND_OUT(XC, XP, XG, XX)
         if (cur.completion && !cur.z_end) return -6;
     }
+
+    if (public_input) /* the commitment of the closed-form input (orc_ds_public_inputs), placed like in the RAM trace */
+        for (int k = 0; k < 4; k++) CELL(DS_PI_pi0 + k, bnd + DS_ROWOFF_PI) = public_input[k];
 
     /* multiplicities of the 8-bit range-check table: every cell of the lookup columns, padding included */
     for (int t = 0; t < 256; t++) CELL(DS_MULT_COL, t) = 0;

@@ -158,8 +158,8 @@ void orc_bytecode_hash(const uint32_t *words, size_t n_words, uint32_t top_limb,
 void orc_poseidon2_flattened(const uint64_t in[12], uint64_t slots[130]);
 int orc_decommit_sorter_synthesize(const zkw_decommit_sorter_instance *inst, const zkw_decommit_query *sorted_q,
                                    const uint64_t *unsorted_enc, const uint64_t *sorted_enc, const uint64_t *challenges,
-                                   const uint64_t *rq_tail_in, uint32_t rq_len_in, uint32_t capacity, size_t n_rows,
-                                   uint64_t *trace);
+                                   const uint64_t *rq_tail_in, uint32_t rq_len_in, const uint64_t *public_input,
+                                   uint32_t capacity, size_t n_rows, uint64_t *trace);
 uint64_t orc_decommit_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 
 /* ---- sparse storage tree + StorageApplication builder (a17), see storage_application.c */
@@ -201,6 +201,9 @@ void orc_ram_public_input(const zkw_ram_instance *first, const zkw_ram_instance 
 void orc_ram_public_inputs(const zkw_ram_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
 void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_instance *in, uint32_t capacity,
                                size_t n_rows, uint64_t *trace);
+#define ORC_DS_FSM_ENC_LEN 100
+size_t orc_ds_encode_fsm(const zkw_decommit_sorter_fsm *f, uint64_t out[ORC_DS_FSM_ENC_LEN]);
+void orc_ds_public_inputs(const zkw_decommit_sorter_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
 void orc_recursion_queue(uint64_t circuit_type, const uint64_t *pi, size_t n, const uint64_t tail_in[12],
                          uint64_t *enc, uint64_t *tails);
 

@@ -108,3 +108,42 @@ void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_inst
     const size_t row = (size_t)RC_BOUNDARY_ROW(capacity) + RC_ROWOFF_PI;
     for (int k = 0; k < 4; k++) trace[(size_t)(RC_PI_pi0 + k) * n_rows + row] = pi[k];
 }
+
+/* ---- CodeDecommittmentsSorter (type 2): encodings in the order of the reference's struct literals
+   (sort_decommit_requests.rs:402-414; DecommitQuery = {code_hash, page, is_first, timestamp}) */
+size_t orc_ds_encode_fsm(const zkw_decommit_sorter_fsm *f, uint64_t out[ORC_DS_FSM_ENC_LEN]) {
+    size_t m = 0;
+    m += put_queue12(&f->initial_queue_state, out + m);
+    m += put_queue12(&f->sorted_queue_state, out + m);
+    m += put_queue12(&f->final_queue_state, out + m);
+    for (int r = 0; r < 2; r++) out[m++] = f->lhs_accumulator[r];
+    for (int r = 0; r < 2; r++) out[m++] = f->rhs_accumulator[r];
+    for (int k = 0; k < 9; k++) out[m++] = f->previous_packed_key[k];
+    for (int k = 0; k < 8; k++) out[m++] = f->previous_record.hash[k];
+    out[m++] = f->previous_record.memory_page;
+    out[m++] = f->previous_record.is_fresh ? 1 : 0;
+    out[m++] = f->previous_record.timestamp;
+    out[m++] = f->first_encountered_timestamp;
+    return m;
+}
+
+void orc_ds_public_inputs(const zkw_decommit_sorter_instance *inst, size_t n, uint64_t *compact, uint64_t *pi) {
+    const zkw_decommit_sorter_instance *first = inst;
+    uint64_t buf[ORC_DS_FSM_ENC_LEN];
+    for (size_t i = 0; i < n; i++) {
+        if (inst[i].start_flag) first = inst + i;
+        uint64_t *cf = compact + 18 * i;
+        cf[0] = inst[i].start_flag ? 1 : 0;
+        cf[1] = inst[i].completion_flag ? 1 : 0;
+        size_t m = put_queue12(&first->initial_queue_state, buf);
+        m += put_queue12(&first->sorted_queue_initial_state, buf + m);
+        orc_commit_var_length(buf, m, cf + 2);
+        m = put_queue12(&inst[i].final_queue_state, buf);
+        orc_commit_var_length(buf, m, cf + 6);
+        m = orc_ds_encode_fsm(&inst[i].hidden_fsm_input, buf);
+        orc_commit_var_length(buf, m, cf + 10);
+        m = orc_ds_encode_fsm(&inst[i].hidden_fsm_output, buf);
+        orc_commit_var_length(buf, m, cf + 14);
+        orc_commit_var_length(cf, 18, pi + 4 * i);
+    }
+}

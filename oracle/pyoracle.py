@@ -661,8 +661,10 @@ def decommit_sorter_synthesize(build_out, instance_index, capacity, n_rows):
     inst = o["instances"][instance_index:instance_index + 1]
     f = lib().orc_decommit_sorter_synthesize
     f.restype = C.c_int
+    _, pis = decommit_sorter_public_inputs(o["instances"])
+    pi = np.ascontiguousarray(pis[instance_index])
     rc = f(_p(inst), _p(o["sorted_q"]), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), None, C.c_uint32(0),
-           C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+           _p(pi), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_decommit_sorter_synthesize failed: {rc}")
     return trace
@@ -676,3 +678,12 @@ def decommit_sorter_check(trace, capacity):
     bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
     v = first_bad.value
     return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+def decommit_sorter_public_inputs(instances):
+    """(compact forms [n][18], public inputs [n][4]) of the instances of one decommit-sorter block."""
+    inst = np.ascontiguousarray(instances, dtype=DECOMMIT_INSTANCE)
+    compact = np.zeros((inst.size, 18), np.uint64)
+    pi = np.zeros((inst.size, 4), np.uint64)
+    lib().orc_ds_public_inputs(_p(inst), C.c_size_t(inst.size), _p(compact), _p(pi))
+    return compact, pi

@@ -27,6 +27,8 @@ def test_trace_matches_oracle(ctx, oracle, n, n_hashes, capacity, n_rows):
     o = oracle.decommit_sorter_build(q, capacity)
     w = ctx.compute_decommitts_sorter_circuit_snapshots(q, capacity)
     n_inst = o["instances"].size
+    compact, pis = oracle.decommit_sorter_public_inputs(o["instances"])
+    assert np.array_equal(w.get(native.DEC_COMPACT_FORMS), compact) and np.array_equal(w.get(native.DEC_PUBLIC_INPUTS), pis)
     t = native.Trace(ctx, n_rows, n_inst)
     ctx.synthesize_decommit_sorter(w, t)
     for idx in range(n_inst):

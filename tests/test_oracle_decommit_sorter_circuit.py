@@ -73,3 +73,17 @@ def test_unsorted_or_mislabelled_input_is_rejected(oracle):
     bad["sorted_q"]["is_fresh"][1] ^= 1  # freshness no longer marks the first request of a hash
     with pytest.raises(RuntimeError):
         oracle.decommit_sorter_synthesize(bad, 0, 64, 512)
+
+
+def test_public_inputs_oracle(oracle):
+    q = synthetic.decommit_trace(300, 20, seed=8)
+    o = oracle.decommit_sorter_build(q, 128)
+    compact, pi = oracle.decommit_sorter_public_inputs(o["instances"])
+    assert compact.shape == (3, 18) and list(compact[:, 0]) == [1, 0, 0] and list(compact[:, 1]) == [0, 0, 1]
+    assert (compact[:, 2:6] == compact[0, 2:6]).all()  # shared observable input
+    assert np.array_equal(compact[:-1, 14:18], compact[1:, 10:14])  # FSM chaining
+    assert np.array_equal(compact[0, 6:10], compact[1, 6:10]) and not np.array_equal(compact[1, 6:10], compact[2, 6:10])
+    for i in range(3):
+        assert np.array_equal(pi[i], oracle.commit_var_length(compact[i]))
+    t = oracle.decommit_sorter_synthesize(o, 1, 128, 1024)
+    assert np.array_equal(t[0:4, 7 * 128 + 3], pi[1])
