@@ -4,6 +4,7 @@
 #include "oracle.h"
 #include "../include/zkw_ram_circuit_spec.h"
 #include "../include/zkw_decommit_sorter_circuit_spec.h"
+#include "../include/zkw_events_sorter_circuit_spec.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -26,6 +27,14 @@ static const uint8_t DS_IS_POSEIDON[] = DS_ROW_IS_POSEIDON_INIT;
 static const rc_link DS_LINKS[] = DS_LINKS_INIT;
 static const orc_spec SPEC_DS = {DS_G, DS_L, DS_ROWS_PER_CYCLE, DS_NUM_ROW_TYPES, DS_NUM_LINKS, DS_ROWOFF_BND_IN, DS_ROWOFF_BND_OUT,
                                  DS_TERMS, DS_CONS, DS_ROW_FIRST, DS_IS_POSEIDON, DS_LINKS};
+
+static const rc_term ES_TERMS[] = ES_TERMS_INIT;
+static const rc_constraint ES_CONS[] = ES_CONSTRAINTS_INIT;
+static const uint16_t ES_ROW_FIRST[] = ES_ROW_FIRST_CONSTRAINT_INIT;
+static const uint8_t ES_IS_POSEIDON[] = ES_ROW_IS_POSEIDON_INIT;
+static const rc_link ES_LINKS[] = ES_LINKS_INIT;
+static const orc_spec SPEC_ES = {ES_G, ES_L, ES_ROWS_PER_CYCLE, ES_NUM_ROW_TYPES, ES_NUM_LINKS, ES_ROWOFF_BND_IN, ES_ROWOFF_BND_OUT,
+                                 ES_TERMS, ES_CONS, ES_ROW_FIRST, ES_IS_POSEIDON, ES_LINKS};
 
 static const rc_term RC_TERMS[] = RC_TERMS_INIT;
 static const rc_constraint RC_CONS[] = RC_CONSTRAINTS_INIT;
@@ -84,6 +93,10 @@ static uint64_t check(const orc_spec *sp, const uint64_t *trace, uint32_t capaci
             if (CELL(k->col_a, ROWOF(k->row_a, 0)) != CELL(k->col_b, bnd + sp->off_bout)) FLAG(4, l, ROWOF(k->row_a, 0));
             continue;
         }
+        if (k->kind == 5) { /* a boundary row's cell equals a cell of another boundary row */
+            if (CELL(k->col_a, ROWOF(k->row_a, 0)) != CELL(k->col_b, ROWOF(k->row_b, 0))) FLAG(4, l, ROWOF(k->row_a, 0));
+            continue;
+        }
         for (size_t i = 0; i < capacity; i++) {
             const uint64_t a = CELL(k->col_a, ROWOF(k->row_a, i));
             uint64_t b;
@@ -124,4 +137,7 @@ uint64_t orc_ram_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, 
 }
 uint64_t orc_decommit_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
     return check(&SPEC_DS, trace, capacity, n_rows, first_bad);
+}
+uint64_t orc_events_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
+    return check(&SPEC_ES, trace, capacity, n_rows, first_bad);
 }

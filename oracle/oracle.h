@@ -162,6 +162,12 @@ int orc_decommit_sorter_synthesize(const zkw_decommit_sorter_instance *inst, con
                                    uint32_t capacity, size_t n_rows, uint64_t *trace);
 uint64_t orc_decommit_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 
+/* ---- EventsSorter / L1MessagesSorter synthesis + check (a21, circuit types 11 and 12), see events_sorter_circuit.c */
+int orc_events_sorter_synthesize(const zkw_events_sorter_instance *inst, const zkw_log_query *sorted_q, const uint64_t *unsorted_enc,
+                                 const uint64_t *sorted_enc, const uint64_t *challenges, const uint64_t *rq_tail_in,
+                                 uint32_t rq_len_in, uint32_t capacity, size_t n_rows, uint64_t *trace);
+uint64_t orc_events_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+
 /* ---- sparse storage tree + StorageApplication builder (a17), see storage_application.c */
 typedef struct orc_tree orc_tree;
 orc_tree *orc_tree_new(void);

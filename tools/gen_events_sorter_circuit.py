@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generates include/zkw_events_sorter_circuit_spec.h — the declarative layout of the EventsSorter / L1MessagesSorter
+trace that libzkw emits ("zkw trace v2", circuit types 11 and 12), in the DSL of tools/gen_ram_circuit.py.
+
+Geometry of the reference wrapper (circuit_definitions/.../base_layer/events_sort_dedup.rs:28-39): 130 copy columns,
+1x8 width-1 range-check lookups, Poseidon2 flattened gate, 2^20 rows, capacity 31 287; witness semantics
+src/witness/individual_circuits/events_sort_dedup.rs:16-580. The circuit body lives in the absent crate
+era-zkevm_circuits, so gate placement is OUR design ("parity unpinned" at the trace-layout level).
+
+Statement, per cycle (21 rows, region-major): pop the unsorted and the sorted log queue in lock step — a 4-wide queue
+hashes enc(20) || tail(4) in three permutations (circuit_encodings/src/lib.rs:179-221): rows U1-U3, S1-S3 —, multiply
+both grand-product accumulators (A, W = 20), split the sorted record's encoding far enough to (i) read timestamp and
+rollback flag and (ii) rebuild the encoding of its *normalised* form — read value, timestamp, aux byte, rw and
+rollback flags cleared (events_sort_dedup.rs:541-553) — (N0-N7, T, V), compare timestamps with the previous record
+and apply the dedup rule (W): equal timestamps = a forward record and its rollback, both dropped; a forward record is
+pushed into the result queue when the NEXT record proves it was not rolled back (R1-R3 hash the previous record's
+normalised encoding); Q does the queue bookkeeping. The last record is flushed by three more permutations outside
+the cycles (F1-F3) when the instance completes.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_ram_circuit as dsl  # noqa: E402
+
+dsl.G, dsl.L = 130, 8
+Row = dsl.Row
+
+
+def poseidon(row, ins, out):
+    assert len(ins) == 12
+    for v in ins:
+        row.slot(v)
+    for r in range(4):
+        for k in range(12):
+            row.slot(f"{row.name}_f{r}_{k}")
+    for r in range(22):
+        row.slot(f"{row.name}_p{r}")
+    for r in range(3):
+        for k in range(12):
+            row.slot(f"{row.name}_f{4 + r}_{k}")
+    for k in range(12):
+        row.slot(out[k] if isinstance(out, list) else f"{out}{k}")
+    assert len(row.slots) == 130, (row.name, len(row.slots))
+
+
+def queue_rows(rows3, enc, old, tag, zero_tag):
+    """three permutations of one 4-wide queue operation: enc[0..8] | 0000, enc[8..16] | cap, enc[16..20] old[0..4] | cap"""
+    r1, r2, r3 = rows3
+    zeros = [f"{zero_tag}{k}" for k in range(4)]
+    poseidon(r1, enc[0:8] + zeros, f"{tag}1o")
+    for z in zeros:
+        r1.c([(1, [z])], f"{z} = 0: the sponge starts from the zero state")
+    poseidon(r2, enc[8:16] + [f"{tag}1o{8 + k}" for k in range(4)], f"{tag}2o")
+    poseidon(r3, enc[16:20] + old + [f"{tag}2o{8 + k}" for k in range(4)], f"{tag}3o")
+
+
+def build():
+    U = [Row("U1"), Row("U2"), Row("U3")]
+    S = [Row("S1"), Row("S2"), Row("S3")]
+    R = [Row("R1"), Row("R2"), Row("R3")]
+    A = Row("A")
+    N = [Row(f"N{k}") for k in range(8)]
+    T, V, W, Q = Row("T"), Row("V"), Row("W"), Row("Q")
+    BIN, BOUT, PI = Row("BND_IN", False), Row("BND_OUT", False), Row("PI", False)
+    F = [Row("F1", False), Row("F2", False), Row("F3", False)]
+
+    eu = [f"eu{k}" for k in range(20)]
+    es = [f"es{k}" for k in range(20)]
+    ne = [f"ne{k}" for k in range(20)]   # normalised encoding of the latest popped record (register)
+    cn = [f"cn{k}" for k in range(20)]   # normalised encoding of THIS cycle's record
+    queue_rows(U, eu, [f"p.uh{k}" for k in range(4)], "u", "uz")
+    queue_rows(S, es, [f"p.sh{k}" for k in range(4)], "s", "sz")
+    queue_rows(R, [f"p.ne{k}" for k in range(20)], [f"p.rh{k}" for k in range(4)], "r", "rz")
+
+    # ---------------- row A: grand products, W = 20 (utils.rs:554-697, challenge 0 is the constant ONE, 20 is additive)
+    for v in eu + es:
+        A.slot(v)
+    for r in range(2):
+        for k in range(1, 21):
+            A.slot(f"g.c{r}_{k}")
+    for r in range(2):
+        for v in (f"lc{r}", f"p.lhs{r}", f"nl{r}", f"lhs{r}", f"rc{r}", f"p.rhs{r}", f"nr{r}", f"rhs{r}"):
+            A.slot(v)
+    for r in range(2):
+        ch = [None] + [f"g.c{r}_{k}" for k in range(1, 21)]
+        for side, enc, acc in (("l", eu, "lhs"), ("r", es, "rhs")):
+            lc = f"{side}c{r}"
+            A.c([(-1, [lc]), (1, [ch[20]]), (1, [enc[0]])] + [(1, [enc[k], ch[k]]) for k in range(1, 20)],
+                f"{lc} = c20 + sum enc_k c_k")
+            A.c([(1, [f"p.{acc}{r}", lc]), (-1, [f"n{side}{r}"])], f"n{side}{r} = acc*contribution")
+            A.select("can_pop", f"n{side}{r}", f"p.{acc}{r}", f"{acc}{r}")
+
+    # ---------------- rows N0..N7: es_k = read_value limb k + three key bytes << 32/40/48 (log_query.rs:118-196)
+    for k in range(8):
+        row = N[k]
+        lo = [f"rv{k}_b{j}" for j in range(4)]
+        hi = [f"kb{k}_b{j}" for j in range(3)]
+        for b in lo + hi:
+            row.lookup(b)
+        row.c([(1, [f"rv{k}"])] + [(-(1 << (8 * j)), [lo[j]]) for j in range(4)], f"rv{k} = sum bytes")
+        row.c([(1, [es[k]]), (-1, [f"rv{k}"])] + [(-(1 << (32 + 8 * j)), [hi[j]]) for j in range(3)], f"es{k} = rv{k} + key bytes")
+        row.c([(1, [cn[k]]), (-1, [es[k]]), (1, [f"rv{k}"])], f"cn{k} = es{k} without the read value")
+
+    # ---------------- row T: es16 = timestamp + three address bytes
+    tb = [f"ts_b{j}" for j in range(4)]
+    ab = [f"a16_b{j}" for j in range(3)]
+    for b in tb + ab:
+        T.lookup(b)
+    T.c([(1, ["ts"])] + [(-(1 << (8 * j)), [tb[j]]) for j in range(4)], "ts = sum bytes")
+    T.c([(1, [es[16]]), (-1, ["ts"])] + [(-(1 << (32 + 8 * j)), [ab[j]]) for j in range(3)], "es16 = ts + address bytes")
+    T.c([(1, [cn[16]]), (-1, [es[16]]), (1, ["ts"])], "cn16 = es16 without the timestamp")
+    for k in range(8, 16):
+        T.c([(1, [cn[k]]), (-1, [es[k]])], f"cn{k} = es{k}")
+
+    # ---------------- row V: es17 = tx number + address byte 19 << 32 + aux byte << 40 + shard << 48; flags
+    xb = [f"tx_b{j}" for j in range(4)]
+    for b in xb + ["a19", "aux", "shard"]:
+        V.lookup(b)
+    V.c([(1, ["tx"])] + [(-(1 << (8 * j)), [xb[j]]) for j in range(4)], "tx = sum bytes")
+    V.c([(1, [es[17]]), (-1, ["tx"]), (-(1 << 32), ["a19"]), (-(1 << 40), ["aux"]), (-(1 << 48), ["shard"])], "es17")
+    V.c([(1, [cn[17]]), (-1, [es[17]]), (1 << 40, ["aux"])], "cn17 = es17 without the aux byte")
+    V.boolean("rw")
+    V.boolean("sv")
+    V.boolean("rb")
+    V.c([(1, [es[18]]), (-1, ["rw"]), (-2, ["sv"])], "es18 = rw + 2 is_service")
+    V.c([(1, [cn[18]]), (-2, ["sv"])], "cn18 = 2 is_service")
+    V.c([(1, [es[19]]), (-1, ["rb"])], "es19 = rollback")
+    V.c([(1, [cn[19]])], "cn19 = 0")
+
+    # ---------------- row W: timestamp order and the dedup rule (events_sort_dedup.rs:292-331)
+    W.bytes_of("dts", "dts")
+    W.boolean("bw")
+    W.c([(1, ["dts"]), (-1, ["ts"]), (1, ["p.kts"]), (-(1 << 32), ["bw"])], "dts = ts - previous ts + 2^32 bw")
+    W.c([(1, ["can_pop", "p.valid", "bw"])], "sorted by timestamp")
+    W.is_zero([(1, "ts"), (-1, "p.kts")], "w_ts", "same_ts", "ts == previous ts")
+    W.c([(1, ["can_pop", "p.valid", "same_ts"]), (-1, ["can_pop", "p.valid", "same_ts", "rb"])], "same timestamp => this record is a rollback")
+    W.c([(1, ["can_pop", "p.valid", "same_ts", "p.krb"])], "... of a forward record")
+    W.c([(1, ["can_pop", "p.valid", "rb"]), (-1, ["can_pop", "p.valid", "same_ts", "rb"])], "a new timestamp starts with a forward record")
+    W.c([(1, ["can_pop", "rb"]), (-1, ["can_pop", "p.valid", "rb"])], "the very first record is a forward record")
+    W.c([(1, ["can_pop", "p.valid"]), (-1, ["can_pop", "p.valid", "same_ts"]), (-1, ["can_pop", "p.valid", "p.krb"]),
+         (1, ["can_pop", "p.valid", "same_ts", "p.krb"]), (-1, ["push"])],
+        "push = can_pop & valid & new timestamp & previous record is forward")
+    W.c([(1, ["valid"]), (-1, ["p.valid"]), (-1, ["can_pop"]), (1, ["can_pop", "p.valid"])], "valid = p.valid | can_pop")
+    W.select("can_pop", "ts", "p.kts", "kts")
+    W.select("can_pop", "rb", "p.krb", "krb")
+    for k in range(4):
+        W.select("push", f"r3o{k}", f"p.rh{k}", f"rh{k}")
+    W.c([(1, ["len_r"]), (-1, ["p.len_r"]), (-1, ["push"])], "len_r = p.len_r + push")
+
+    # ---------------- row Q: queue bookkeeping, heads, the normalised-encoding registers
+    Q.is_zero([(1, "p.len_u")], "w_lu", "z_lu", "len_u == 0")
+    Q.is_zero([(1, "p.len_s")], "w_ls", "z_ls", "len_s == 0")
+    Q.c([(1, ["z_lu"]), (-1, ["z_ls"])], "both queues empty together")
+    Q.c([(1, ["can_pop"]), (1, ["z_lu"]), (-1, [])], "can_pop = 1 - empty")
+    Q.c([(1, ["len_u"]), (-1, ["p.len_u"]), (1, ["can_pop"])], "len_u = p.len_u - can_pop")
+    Q.c([(1, ["len_s"]), (-1, ["p.len_s"]), (1, ["can_pop"])], "len_s = p.len_s - can_pop")
+    for q, o in (("uh", "u3o"), ("sh", "s3o")):
+        for k in range(4):
+            Q.select("can_pop", f"{o}{k}", f"p.{q}{k}", f"{q}{k}")
+    for k in range(20):
+        Q.select("can_pop", cn[k], f"p.ne{k}", ne[k])
+
+    # ---------------- boundary rows
+    regs = ([f"uh{k}" for k in range(4)] + [f"sh{k}" for k in range(4)] + [f"rh{k}" for k in range(4)] +
+            ["len_u", "len_s", "len_r", "lhs0", "lhs1", "rhs0", "rhs1", "kts", "krb", "valid"] + ne)
+    for v in regs:
+        BIN.slot(v)
+    for r in range(2):
+        for k in range(1, 21):
+            BIN.slot(f"g.c{r}_{k}")
+    for v in regs:
+        BOUT.slot(v)
+    for q in ("u", "s"):
+        for k in range(4):
+            BOUT.slot(f"tail_{q}{k}")
+    BOUT.boolean("completion")
+    BOUT.is_zero([(1, "len_u")], "w_end", "z_end", "queue exhausted")
+    for q, h in (("u", "uh"), ("s", "sh")):
+        for k in range(4):
+            BOUT.c([(1, ["z_end", f"{h}{k}"]), (-1, ["z_end", f"tail_{q}{k}"])], f"empty queue: head == tail ({q}{k})")
+    BOUT.c([(1, ["completion"]), (-1, ["completion", "z_end"])], "completion => queues exhausted")
+    for r in range(2):
+        BOUT.c([(1, ["completion", f"lhs{r}"]), (-1, ["completion", f"rhs{r}"])], f"completion => lhs{r} == rhs{r}")
+    BOUT.c([(1, ["completion", "valid"]), (-1, ["completion", "valid", "krb"]), (-1, ["flush"])],
+           "flush = completion & the last record is a forward record")
+    for k in range(4):
+        BOUT.slot(f"f3o{k}")
+    for k in range(4):
+        BOUT.select("flush", f"f3o{k}", f"rh{k}", f"final_rh{k}")
+    BOUT.c([(1, ["final_len_r"]), (-1, ["len_r"]), (-1, ["flush"])], "final_len_r = len_r + flush")
+    # the flush: three permutations over the registers in BND_OUT
+    zeros = [f"fz{k}" for k in range(4)]
+    poseidon(F[0], [f"x.ne{k}" for k in range(8)] + zeros, "f1o")
+    for z in zeros:
+        F[0].c([(1, [z])], f"{z} = 0")
+    poseidon(F[1], [f"x.ne{k}" for k in range(8, 16)] + [f"y.f1o{8 + k}" for k in range(4)], "f2o")
+    poseidon(F[2], [f"x.ne{k}" for k in range(16, 20)] + [f"x.rh{k}" for k in range(4)] + [f"y.f2o{8 + k}" for k in range(4)],
+             [f"x.f3o{k}" for k in range(4)] + [f"f3w{k}" for k in range(4, 12)])
+    for k in range(4):
+        PI.slot(f"pi{k}")
+
+    rows = U + S + R + [A] + N + [T, V, W, Q, BIN, BOUT] + F + [PI]
+    return rows, regs
+
+
+def links_of(rows, regs):
+    """As in gen_decommit_sorter_circuit, plus y.v in a boundary row -> v in the boundary row that holds it (kind 5:
+    row_b = that row)."""
+    BIN = next(r for r in rows if r.name == "BND_IN")
+    BOUT = next(r for r in rows if r.name == "BND_OUT")
+    home = {}
+    for ri, r in enumerate(rows):
+        if not r.per_cycle:
+            continue
+        for v in r.slots + r.lookups:
+            if not v.startswith(("p.", "g.")) and v not in home:
+                home[v] = (ri, r.slot(v))
+    bhome = {}
+    for ri, r in enumerate(rows):
+        if r.per_cycle or r in (BIN, BOUT):
+            continue
+        for v in r.slots:
+            if not v.startswith(("x.", "y.")) and v not in bhome:
+                bhome[v] = (ri, r.slot(v))
+    links = []
+    for ri, r in enumerate(rows):
+        for v in r.slots + r.lookups:
+            col = r.slot(v)
+            if r.per_cycle:
+                if v.startswith("p."):
+                    hv = v[2:]
+                    assert hv in home, v
+                    assert hv in BIN.slots, f"{v}: register missing from BND_IN"
+                    links.append((1, ri, col, home[hv][0], home[hv][1], BIN.slot(hv)))
+                elif v.startswith("g."):
+                    links.append((2, ri, col, rows.index(BIN), BIN.slot(v), 0))
+                elif home[v] != (ri, col):
+                    links.append((0, ri, col, home[v][0], home[v][1], 0))
+            elif r is BOUT and v in regs:
+                links.append((3, ri, col, home[v][0], home[v][1], 0))
+            elif v.startswith("x."):
+                links.append((4, ri, col, rows.index(BOUT), BOUT.slot(v[2:]), 0))
+            elif v.startswith("y."):
+                links.append((5, ri, col, bhome[v[2:]][0], bhome[v[2:]][1], 0))
+    return links
+
+
+def emit_scatter(rows, path, prefix):
+    names = []
+    for r in rows:
+        for v in r.slots + r.lookups:
+            base = v.split(".", 1)[1] if v[:2] in ("p.", "g.", "x.", "y.") else v
+            if base not in names:
+                names.append(base)
+    lines = ["", f"/* ---- scatter lists: {prefix}_VARS(X) lists every distinct variable once; {prefix}_FILL_<row>(XC, XP, XG, XX) lists the",
+             "   cells of a row: XC(col, v) current value, XP previous cycle, XG per-instance global, XX a boundary row's value */",
+             f"#define {prefix}_VARS(X) " + " ".join(f"X({n})" for n in names)]
+    for r in rows:
+        lines.append(f"#define {prefix}_NSLOTS_{r.name} {len(r.slots)}")
+        lines.append(f"#define {prefix}_NLOOK_{r.name} {len(r.lookups)}")
+    lines.append(f"#define {prefix}_LOOKUPS_PER_CYCLE {sum(len(r.lookups) for r in rows if r.per_cycle)}")
+    for r in rows:
+        ent = []
+        for v in r.slots + r.lookups:
+            kind = {"p.": "XP", "g.": "XG", "x.": "XX", "y.": "XX"}.get(v[:2], "XC")
+            base = v.split(".", 1)[1] if kind != "XC" else v
+            ent.append(f"{kind}({r.slot(v)}, {base})")
+        lines.append(f"#define {prefix}_FILL_{r.name}(XC, XP, XG, XX) " + " ".join(ent))
+    txt = open(path).read()
+    txt = txt.replace("\n#endif\n", "\n" + "\n".join(lines) + "\n#endif\n")
+    open(path, "w").write(txt)
+
+
+if __name__ == "__main__":
+    rows, regs = build()
+    links = links_of(rows, regs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "include", "zkw_events_sorter_circuit_spec.h")
+    nt, nc = dsl.emit(rows, links, path, prefix="ES", guard="ZKW_EVENTS_SORTER_CIRCUIT_SPEC_H",
+                      title=("/* GENERATED by tools/gen_events_sorter_circuit.py — do not edit. Layout contract of the EventsSorter /",
+                             " * L1MessagesSorter trace emitted by zkw_events_sorter_synthesize (\"zkw trace v2\"). */",
+                             "#include \"zkw_ram_circuit_spec.h\" /* rc_term, rc_constraint, rc_link */"),
+                      poseidon_rows=("U1", "U2", "U3", "S1", "S2", "S3", "R1", "R2", "R3", "F1", "F2", "F3"), shared_types=True)
+    emit_scatter(rows, path, "ES")
+    for r in rows:
+        print(f"{r.name:8s} slots {len(r.slots):3d} lookups {len(r.lookups):2d} constraints {len(r.constraints)}")
+    print(f"{nt} terms, {nc} constraints, {len(links)} links -> {path}")

@@ -289,7 +289,7 @@ def emit(rows, links, path, prefix="RC", guard="ZKW_RAM_CIRCUIT_SPEC_H",
     w("/* named slots: RC_<row>_<var> = column of that variable in rows of that type */")
     for r in rows:
         for v in r.slots + r.lookups:
-            name = v.replace("p.", "P_").replace("g.", "G_").replace("x.", "X_")
+            name = v.replace("p.", "P_").replace("g.", "G_").replace("x.", "X_").replace("y.", "Y_")
             w(f"#define RC_{r.name}_{name} {r.slot(v)}")
     if not shared_types:
         out.append("typedef struct { uint64_t coef; uint8_t nf; uint8_t f[6]; } rc_term;")
