@@ -13,6 +13,7 @@
 #pragma once
 #include "../../include/zkw_ram_circuit_spec.h"
 #include "../../include/zkw_decommit_sorter_circuit_spec.h"
+#include "../../include/zkw_events_sorter_circuit_spec.h"
 #include "ram_kernels.cuh"
 
 namespace zkw {
@@ -66,6 +67,9 @@ __device__ __forceinline__ RegsIn regs_in(const zkw_ram_instance* in) {
 // rows [capacity, RC_REGION_STRIDE(capacity)) of a region: the alignment gap, all general + lookup columns zero
 __device__ __forceinline__ void zero_gap_row(u64* trace, size_t n_rows, size_t row) {
     for (int col = 0; col < RC_G + RC_L; col++) TR(col, row) = 0;
+}
+__device__ __forceinline__ void zero_gap_row_n(u64* trace, size_t n_rows, size_t row, int n_cols) {
+    for (int col = 0; col < n_cols; col++) TR(col, row) = 0;
 }
 
 __device__ __forceinline__ void hist_bytes(u32* sh_hist, u32 x) {
@@ -602,7 +606,20 @@ struct SpecDecommitSorter {  // CodeDecommittmentsSorter, circuit type 2
     __device__ static const uint8_t* is_poseidon() { return c_ds_is_poseidon; }
     __device__ static const rc_link* links() { return c_ds_links; }
 };
-static_assert(RC_G + RC_L == DS_G + DS_L, "both layouts have 148 general + lookup columns and the multiplicities in column 148");
+__constant__ rc_term c_es_terms[ES_NUM_TERMS] = ES_TERMS_INIT;
+__constant__ rc_constraint c_es_cons[ES_NUM_CONSTRAINTS] = ES_CONSTRAINTS_INIT;
+__constant__ uint16_t c_es_row_first[ES_NUM_ROW_TYPES + 1] = ES_ROW_FIRST_CONSTRAINT_INIT;
+__constant__ uint8_t c_es_is_poseidon[ES_NUM_ROW_TYPES] = ES_ROW_IS_POSEIDON_INIT;
+__constant__ rc_link c_es_links[ES_NUM_LINKS] = ES_LINKS_INIT;
+struct SpecEventsSorter {  // EventsSorter / L1MessagesSorter, circuit types 11 and 12
+    static constexpr int G = ES_G, L = ES_L, ROWS_PER_CYCLE = ES_ROWS_PER_CYCLE, NUM_ROW_TYPES = ES_NUM_ROW_TYPES, NUM_LINKS = ES_NUM_LINKS;
+    static constexpr int OFF_BIN = ES_ROWOFF_BND_IN, OFF_BOUT = ES_ROWOFF_BND_OUT;
+    __device__ static const rc_term* terms() { return c_es_terms; }
+    __device__ static const rc_constraint* cons() { return c_es_cons; }
+    __device__ static const uint16_t* row_first() { return c_es_row_first; }
+    __device__ static const uint8_t* is_poseidon() { return c_es_is_poseidon; }
+    __device__ static const rc_link* links() { return c_es_links; }
+};
 
 struct CheckResult {
     unsigned long long violations;
@@ -615,7 +632,6 @@ __device__ __forceinline__ void flag_bad(CheckResult* res, u64 kind, u64 idx, u6
 }
 
 constexpr int CHK_ROWS = 64;
-constexpr int CHK_COLS = RC_G + RC_L;
 
 template <class S>
 __device__ __forceinline__ size_t spec_row(int rt, u32 capacity, u32 i) {
@@ -625,7 +641,8 @@ __device__ __forceinline__ size_t spec_row(int rt, u32 capacity, u32 i) {
 
 template <class S>
 __global__ __launch_bounds__(64) void k_check_rows(const u64* __restrict__ trace, u32 capacity, size_t n_rows, CheckResult* res) {
-    extern __shared__ __attribute__((aligned(16))) u64 tile[];  // [CHK_COLS][CHK_ROWS]
+    extern __shared__ __attribute__((aligned(16))) u64 tile[];  // [G + L][CHK_ROWS]
+    constexpr int CHK_COLS = S::G + S::L;
     const int rt = blockIdx.y;  // row type; boundary row types are handled by block x == 0 only
     const bool per_cycle = rt < S::ROWS_PER_CYCLE;
     const u32 n_in_region = per_cycle ? capacity : 1;
@@ -700,6 +717,11 @@ __global__ __launch_bounds__(256) void k_check_links(const u64* __restrict__ tra
                 flag_bad(res, 4, l, spec_row<S>(k.row_a, capacity, 0));
             continue;
         }
+        if (k.kind == 5) {  // a boundary row's cell equals a cell of another boundary row
+            if (i == 0 && TR(k.col_a, spec_row<S>(k.row_a, capacity, 0)) != TR(k.col_b, spec_row<S>(k.row_b, capacity, 0)))
+                flag_bad(res, 4, l, spec_row<S>(k.row_a, capacity, 0));
+            continue;
+        }
         const size_t ra = (size_t)k.row_a * rs + i;
         const u64 a = TR(k.col_a, ra);
         u64 b;
@@ -731,11 +753,11 @@ __global__ __launch_bounds__(256) void k_check_lookups(const u64* __restrict__ t
     __syncthreads();
     if (sh_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh_hist[threadIdx.x]);
 }
-__global__ void k_check_mult(const u64* __restrict__ trace, size_t n_rows, const u32* __restrict__ hist, CheckResult* res) {
+__global__ void k_check_mult(const u64* __restrict__ trace, size_t n_rows, int mult_col, const u32* __restrict__ hist, CheckResult* res) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
         const u64 want = r < 256 ? hist[r] : 0;
-        if (TR(RC_MULT_COL, r) != want) flag_bad(res, 5, 0, r);
+        if (TR(mult_col, r) != want) flag_bad(res, 5, 0, r);
     }
 }
 

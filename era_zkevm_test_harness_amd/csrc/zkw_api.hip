@@ -28,6 +28,7 @@
 #include "precompile_kernels.cuh"
 #include "storage_application_kernels.cuh"
 #include "decommit_sorter_circuit_kernels.cuh"
+#include "events_sorter_circuit_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -1072,14 +1073,14 @@ static int check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32
     CheckResult init{0ull, ~0ull};
     HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), ctx->stream));
-    const size_t lds = (size_t)CHK_COLS * CHK_ROWS * sizeof(u64);
+    const size_t lds = (size_t)(S::G + S::L) * CHK_ROWS * sizeof(u64);
     { Prof _p(ctx, "k_check_rows"); hipLaunchKernelGGL((k_check_rows<S>), dim3((capacity + CHK_ROWS - 1) / CHK_ROWS, S::NUM_ROW_TYPES), dim3(CHK_ROWS), lds, ctx->stream, trace, capacity, n_rows, d_res); }
     ZKW_TRY(launch_check("k_check_rows"));
     { Prof _p(ctx, "k_check_links"); hipLaunchKernelGGL((k_check_links<S>), dim3((capacity + 255) / 256), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_res); }
     ZKW_TRY(launch_check("k_check_links"));
     { Prof _p(ctx, "k_check_lookups"); hipLaunchKernelGGL((k_check_lookups<S>), dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
     ZKW_TRY(launch_check("k_check_lookups"));
-    { Prof _p(ctx, "k_check_mult"); hipLaunchKernelGGL(k_check_mult, dim3(256), dim3(256), 0, ctx->stream, trace, n_rows, d_hist, d_res); }
+    { Prof _p(ctx, "k_check_mult"); hipLaunchKernelGGL(k_check_mult, dim3(256), dim3(256), 0, ctx->stream, trace, n_rows, S::G + S::L, d_hist, d_res); }
     ZKW_TRY(launch_check("k_check_mult"));
     CheckResult res;
     HIP_TRY(hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
@@ -1319,8 +1320,10 @@ struct zkw_events_witness {
     u64* tails_all = nullptr;  // [5n][4]: unsorted old | unsorted new | sorted old | sorted new | result new
     u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
     zkw_events_sorter_instance* instances = nullptr;
+    zkw_queue_state4 result_in;  // state of the result queue before the block (host copy)
+    u32* kept_prefix = nullptr;  // [n + 1], computed by the first synthesis call
     void release() {
-        void* ptrs[] = {sorted_q, result_q, enc_all, tails_all, challenges, lhs_z, rhs_z, instances};
+        void* ptrs[] = {sorted_q, result_q, enc_all, tails_all, challenges, lhs_z, rhs_z, instances, kept_prefix};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -1410,6 +1413,7 @@ extern "C" int zkw_events_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, siz
     zkw_queue_state4 rin;
     memset(&rin, 0, sizeof rin);
     if (result_in) rin = *result_in;
+    w->result_in = rin;
     int rc = ZKW_OK;
     if (n == 0) {  // events_sort_dedup.rs:27-76: one dummy instance, accumulators forced to ONE
         zkw_events_sorter_instance inst;
@@ -2464,4 +2468,76 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
     { Prof _p(ctx, "k_ds_fill_boundary"); hipLaunchKernelGGL(k_ds_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_boundary"));
     return ctx->sync_if_host();
+}
+
+// ------------------------------------------------------------------------------------------------ events / L1 messages sorter synthesis (a21, types 11 / 12)
+extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witness* cw, size_t first_instance, size_t n_instances,
+                                            zkw_trace* t, size_t first_slot) {
+    zkw_events_witness* w = const_cast<zkw_events_witness*>(cw);
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_events_sorter_synthesize: bad argument");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    const u32 capacity = w->capacity;
+    const size_t n_rows = t->n_rows, n = w->n;
+    if (ES_MIN_ROWS(capacity) > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)ES_MIN_ROWS(capacity), n_rows);
+    if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!w->kept_prefix) {
+        HIP_TRY(hipMalloc((void**)&w->kept_prefix, (n + 2) * sizeof(u32)));
+        { Prof _p(ctx, "k_es_kept_prefix"); hipLaunchKernelGGL(k_es_kept_prefix, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, w->kept_prefix); }
+        ZKW_TRY(launch_check("k_es_kept_prefix"));
+    }
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("es_hist", n_instances * 256, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    const size_t m = n ? n : 1;
+    u64 *u_enc = w->enc_all, *s_enc = w->enc_all + 20 * m;
+    u64 *u_new = w->tails_all + 4 * m, *s_new = w->tails_all + 12 * m, *r_new = w->tails_all + 16 * m;
+    std::vector<EsSynthJob> jobs(n_instances);
+    for (size_t k = 0; k < n_instances; k++) {
+        EsSynthJob& j = jobs[k];
+        j.inst = w->instances + first_instance + k;
+        j.sorted_q = w->sorted_q;
+        j.unsorted_enc = u_enc; j.sorted_enc = s_enc;
+        j.unsorted_new_tails = u_new; j.sorted_new_tails = s_new; j.result_new_tails = r_new;
+        j.kept_prefix = w->kept_prefix;
+        j.challenges = w->challenges;
+        j.lhs_z = w->lhs_z; j.rhs_z = w->rhs_z;
+        j.n_block = n;
+        memcpy(j.rq_tail_in, w->result_in.tail, 32);
+        j.rq_len_in = w->result_in.length;
+        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.hist = d_hist + 256 * k;
+    }
+    EsSynthJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("es_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)n_instances;
+    const u32 rstride = (u32)ES_REGION_STRIDE(capacity);
+    const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
+    { Prof _p(ctx, "k_es_fill_queue"); hipLaunchKernelGGL((k_es_fill_queue<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_es_fill_queue<0>"));
+    { Prof _p(ctx, "k_es_fill_queue"); hipLaunchKernelGGL((k_es_fill_queue<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_es_fill_queue<1>"));
+    { Prof _p(ctx, "k_es_fill_queue"); hipLaunchKernelGGL((k_es_fill_queue<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_es_fill_queue<2>"));
+#define ES_LAUNCH_ROW(R) { Prof _p(ctx, "k_es_fill_row"); hipLaunchKernelGGL((k_es_fill_row<ES_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
+    ZKW_TRY(launch_check("k_es_fill_row<" #R ">"));
+    ES_LAUNCH_ROW(A) ES_LAUNCH_ROW(N0) ES_LAUNCH_ROW(N1) ES_LAUNCH_ROW(N2) ES_LAUNCH_ROW(N3) ES_LAUNCH_ROW(N4) ES_LAUNCH_ROW(N5)
+    ES_LAUNCH_ROW(N6) ES_LAUNCH_ROW(N7) ES_LAUNCH_ROW(T) ES_LAUNCH_ROW(V) ES_LAUNCH_ROW(W) ES_LAUNCH_ROW(Q)
+#undef ES_LAUNCH_ROW
+    { Prof _p(ctx, "k_es_fill_tail"); hipLaunchKernelGGL(k_es_fill_tail, dim3((ES_G + ES_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_es_fill_tail"));
+    { Prof _p(ctx, "k_es_fill_boundary"); hipLaunchKernelGGL(k_es_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_es_fill_boundary"));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_events_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
+                                                 uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+        return fail(ZKW_ERR_INVALID, "zkw_events_sorter_check_satisfied: bad argument");
+    if (ES_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    return check_satisfied<SpecEventsSorter>(ctx, t, slot, capacity, n_violations, first_bad);
 }

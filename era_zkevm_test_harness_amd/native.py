@@ -86,6 +86,8 @@ SYMBOLS = [
     ("zkw_linear_keccak256", _int, [_vp, _vp, _sz, _vp]),
     ("zkw_decommit_sorter_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_decommit_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
+    ("zkw_events_sorter_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_events_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
     ("zkw_storage_application_witness_bytes", _sz, [_vp, _int]),
@@ -970,3 +972,20 @@ def _ctx_check_if_satisfied_decommit_sorter(self, trace, slot, capacity):
 
 Context.synthesize_decommit_sorter = _ctx_synthesize_decommit_sorter
 Context.check_if_satisfied_decommit_sorter = _ctx_check_if_satisfied_decommit_sorter
+
+
+def _ctx_synthesize_events_sorter(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+    """ZkSyncBaseLayerCircuit::{EventsSorter, L1MessagesSorter} synthesis for instances of an EventsWitness."""
+    n = witness.num_instances - first_instance if n_instances is None else n_instances
+    _check(load().zkw_events_sorter_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+
+def _ctx_check_if_satisfied_events_sorter(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_events_sorter_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.synthesize_events_sorter = _ctx_synthesize_events_sorter
+Context.check_if_satisfied_events_sorter = _ctx_check_if_satisfied_events_sorter

@@ -324,6 +324,16 @@ int zkw_decommit_sorter_synthesize(zkw_ctx *ctx, const zkw_decommit_witness *w, 
 int zkw_decommit_sorter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                                         uint64_t *n_violations, uint64_t *first_bad);
 
+/* ---- EventsSorter / L1MessagesSorter synthesis (a21, circuit types 11 and 12) --------------------------- */
+/* Counterpart of ZkSyncBaseLayerCircuit::{EventsSorter, L1MessagesSorter}(..).synthesis (base_layer/mod.rs:286-323,
+   wrapper base_layer/events_sort_dedup.rs:28-39) on a zkw_events_witness: geometry 130 + 8 + 1 = 139 columns (the
+   first 139 of a trace slot), layout include/zkw_events_sorter_circuit_spec.h ("zkw trace v2", 22 rows per cycle;
+   production capacity 31 287 needs n_rows = 2^20). Requires ES_MIN_ROWS(capacity) <= n_rows. */
+int zkw_events_sorter_synthesize(zkw_ctx *ctx, const zkw_events_witness *w, size_t first_instance, size_t n_instances,
+                                 zkw_trace *t, size_t first_slot);
+int zkw_events_sorter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
+                                      uint64_t *n_violations, uint64_t *first_bad);
+
 /* ---- StorageApplication witness builder (a17) --------------------------------------------------------- */
 typedef struct zkw_storage_application_witness zkw_storage_application_witness;
 /* decompose_into_storage_application_witnesses, src/witness/individual_circuits/storage_application.rs:31-361.
