@@ -29,6 +29,7 @@
 #include "storage_application_kernels.cuh"
 #include "decommit_sorter_circuit_kernels.cuh"
 #include "events_sorter_circuit_kernels.cuh"
+#include "log_demux_circuit_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -943,26 +944,32 @@ extern "C" void zkw_ram_witness_free(zkw_ram_witness* w) {
 // ------------------------------------------------------------------------------------------------ traces / synthesis
 struct zkw_trace {
     zkw_ctx* ctx = nullptr;
-    size_t n_rows = 0, n_slots = 0;
+    size_t n_rows = 0, n_cols = RC_COLS, n_slots = 0;
     u64* data = nullptr;
-    size_t slot_elems() const { return (size_t)RC_COLS * n_rows; }
+    size_t slot_elems() const { return n_cols * n_rows; }
 };
 
-extern "C" int zkw_trace_create(zkw_ctx* ctx, size_t n_rows, size_t n_slots, zkw_trace** out) {
-    if (!ctx || !out || n_rows < 256 || n_slots == 0) return fail(ZKW_ERR_INVALID, "zkw_trace_create: bad argument");
+extern "C" int zkw_trace_create_with_columns(zkw_ctx* ctx, size_t n_rows, size_t n_cols, size_t n_slots, zkw_trace** out) {
+    if (!ctx || !out || n_rows < 256 || n_slots == 0 || n_cols == 0 || n_cols > 4096)
+        return fail(ZKW_ERR_INVALID, "zkw_trace_create: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     zkw_trace* t = new zkw_trace();
     t->ctx = ctx;
     t->n_rows = n_rows;
+    t->n_cols = n_cols;
     t->n_slots = n_slots;
     hipError_t e = hipMalloc((void**)&t->data, t->slot_elems() * n_slots * sizeof(u64));
     if (e != hipSuccess) {
         delete t;
         return fail(ZKW_ERR_OOM, "zkw_trace_create: hipMalloc of %zu bytes failed: %s",
-                    (size_t)RC_COLS * n_rows * n_slots * 8, hipGetErrorString(e));
+                    n_cols * n_rows * n_slots * 8, hipGetErrorString(e));
     }
     *out = t;
     return ZKW_OK;
+}
+
+extern "C" int zkw_trace_create(zkw_ctx* ctx, size_t n_rows, size_t n_slots, zkw_trace** out) {
+    return zkw_trace_create_with_columns(ctx, n_rows, RC_COLS, n_slots, out);
 }
 
 extern "C" void zkw_trace_free(zkw_trace* t) {
@@ -974,14 +981,14 @@ extern "C" void zkw_trace_free(zkw_trace* t) {
 }
 
 extern "C" size_t zkw_trace_num_rows(const zkw_trace* t) { return t ? t->n_rows : 0; }
-extern "C" size_t zkw_trace_num_cols(const zkw_trace* t) { return t ? RC_COLS : 0; }
+extern "C" size_t zkw_trace_num_cols(const zkw_trace* t) { return t ? t->n_cols : 0; }
 extern "C" size_t zkw_trace_num_slots(const zkw_trace* t) { return t ? t->n_slots : 0; }
 extern "C" const uint64_t* zkw_trace_device_ptr(const zkw_trace* t, size_t slot) {
     return (t && slot < t->n_slots) ? t->data + slot * t->slot_elems() : nullptr;
 }
 
 extern "C" int zkw_trace_get(const zkw_trace* t, size_t slot, uint32_t first_col, uint32_t n_cols, uint64_t* dst) {
-    if (!t || !dst || slot >= t->n_slots || first_col + n_cols > RC_COLS) return fail(ZKW_ERR_INVALID, "zkw_trace_get: bad argument");
+    if (!t || !dst || slot >= t->n_slots || (size_t)first_col + n_cols > t->n_cols) return fail(ZKW_ERR_INVALID, "zkw_trace_get: bad argument");
     zkw_ctx* ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const u64* src = t->data + slot * t->slot_elems() + (size_t)first_col * t->n_rows;
@@ -1064,6 +1071,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
 template <class S>
 static int check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     HIP_TRY(hipSetDevice(ctx->device));
+    if (t->n_cols < (size_t)(S::G + S::L + 1)) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %d", t->n_cols, S::G + S::L + 1);
     const u64* trace = t->data + slot * t->slot_elems();
     const size_t n_rows = t->n_rows;
     CheckResult* d_res = nullptr;
@@ -1502,9 +1510,11 @@ struct zkw_demux_witness {
     u64* enc_all = nullptr;    // [2n][20]: input | routed
     u64* tails_all = nullptr;  // [4n][4]: in old | in new | out old | out new
     u64* d_offsets = nullptr;  // [8]
+    u32* route_count = nullptr;  // [6][n] inclusive prefix counts per route (kept for synthesis)
+    bool default_params = true;
     zkw_log_demux_instance* instances = nullptr;
     void release() {
-        void* ptrs[] = {out_q, enc_all, tails_all, d_offsets, instances};
+        void* ptrs[] = {out_q, enc_all, tails_all, d_offsets, route_count, instances};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -1516,8 +1526,7 @@ static int demux_run(zkw_ctx* ctx, zkw_demux_witness* w, const zkw_log_query* d_
     u64 *in_old = w->tails_all, *in_new = in_old + 4 * n, *out_old = in_new + 4 * n, *out_new = out_old + 4 * n;
     { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, in_enc); }
     ZKW_TRY(launch_check("k_encode_log"));
-    u32* route_count = nullptr;
-    ZKW_TRY(ctx->scratch_t<u32>("dmx_route_count", 6 * n, &route_count));
+    u32* route_count = w->route_count;
     { Prof _p(ctx, "k_demux_route"); hipLaunchKernelGGL(k_demux_route, dim3(1), dim3(1024), 0, ctx->stream, d_q, in_enc, n, params, route_count, w->out_q, out_enc, w->d_offsets); }
     ZKW_TRY(launch_check("k_demux_route"));
     u64 h_tot[8];
@@ -1565,6 +1574,7 @@ extern "C" int zkw_log_demux_build(zkw_ctx* ctx, const zkw_log_query* q, size_t 
     alloc((void**)&w->enc_all, 2 * m * 160);
     alloc((void**)&w->tails_all, 4 * m * 32);
     alloc((void**)&w->d_offsets, 8 * 8);
+    alloc((void**)&w->route_count, 6 * m * sizeof(u32));
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_log_demux_instance));
     if (e != hipSuccess) {
         w->release();
@@ -1573,6 +1583,10 @@ extern "C" int zkw_log_demux_build(zkw_ctx* ctx, const zkw_log_query* q, size_t 
     }
     zkw_demux_params p = ZKW_DEMUX_PARAMS_DEFAULT;
     if (params) p = *params;
+    {
+        const zkw_demux_params d = ZKW_DEMUX_PARAMS_DEFAULT;
+        w->default_params = memcmp(&p, &d, sizeof d) == 0;
+    }
     int rc = ZKW_OK;
     if (n == 0) {  // log_demux.rs:51-107
         zkw_log_demux_instance inst;
@@ -2540,4 +2554,64 @@ extern "C" int zkw_events_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* 
         return fail(ZKW_ERR_INVALID, "zkw_events_sorter_check_satisfied: bad argument");
     if (ES_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecEventsSorter>(ctx, t, slot, capacity, n_violations, first_bad);
+}
+
+// ------------------------------------------------------------------------------------------------ LogDemuxer synthesis
+extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w, size_t first_instance, size_t n_instances,
+                                        zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_log_demux_synthesize: bad argument");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (!w->default_params)
+        return fail(ZKW_ERR_INVALID, "the LogDemuxer circuit hard-wires ZKW_DEMUX_PARAMS_DEFAULT; this witness was built with other routing constants");
+    if (t->n_cols < LD_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the LogDemuxer needs %d (zkw_trace_create_with_columns)", t->n_cols, LD_COLS);
+    const u32 capacity = w->capacity;
+    const size_t n_rows = t->n_rows, n = w->n;
+    if (LD_MIN_ROWS(capacity) > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)LD_MIN_ROWS(capacity), n_rows);
+    if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("ld_hist", n_instances * 256, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    std::vector<LdSynthJob> jobs(n_instances);
+    for (size_t k = 0; k < n_instances; k++) {
+        LdSynthJob& j = jobs[k];
+        j.inst = w->instances + first_instance + k;
+        j.in_enc = w->enc_all;
+        j.in_new_tails = w->tails_all + 4 * n;
+        j.out_new_tails = w->tails_all + 12 * n;
+        j.route_count = w->route_count;
+        for (int c = 0; c < 7; c++) j.offsets[c] = w->offsets[c];
+        j.n_block = n;
+        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.hist = d_hist + 256 * k;
+    }
+    LdSynthJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("ld_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)n_instances;
+    const u32 rstride = (u32)LD_REGION_STRIDE(capacity);
+    const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
+    { Prof _p(ctx, "k_ld_fill_queue"); hipLaunchKernelGGL((k_ld_fill_queue<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ld_fill_queue<0>"));
+    { Prof _p(ctx, "k_ld_fill_queue"); hipLaunchKernelGGL((k_ld_fill_queue<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ld_fill_queue<1>"));
+#define LD_LAUNCH_ROW(R) { Prof _p(ctx, "k_ld_fill_row"); hipLaunchKernelGGL((k_ld_fill_row<LD_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
+    ZKW_TRY(launch_check("k_ld_fill_row<" #R ">"));
+    LD_LAUNCH_ROW(X0) LD_LAUNCH_ROW(X1) LD_LAUNCH_ROW(X2) LD_LAUNCH_ROW(X3) LD_LAUNCH_ROW(R) LD_LAUNCH_ROW(Q)
+#undef LD_LAUNCH_ROW
+    { Prof _p(ctx, "k_ld_fill_tail"); hipLaunchKernelGGL(k_ld_fill_tail, dim3((LD_G + LD_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ld_fill_tail"));
+    { Prof _p(ctx, "k_ld_fill_boundary"); hipLaunchKernelGGL(k_ld_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ld_fill_boundary"));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_log_demux_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
+                                             uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+        return fail(ZKW_ERR_INVALID, "zkw_log_demux_check_satisfied: bad argument");
+    if (LD_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    return check_satisfied<SpecLogDemux>(ctx, t, slot, capacity, n_violations, first_bad);
 }

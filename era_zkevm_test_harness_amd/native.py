@@ -88,6 +88,8 @@ SYMBOLS = [
     ("zkw_decommit_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_events_sorter_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_events_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
+    ("zkw_log_demux_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_log_demux_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
     ("zkw_storage_application_witness_bytes", _sz, [_vp, _int]),
@@ -106,6 +108,7 @@ SYMBOLS = [
     ("zkw_commit_encodings", _int, [_vp, _vp, _sz, C.c_uint32, _vp]),
     ("zkw_encode_recursion_requests", _int, [_vp, C.c_uint64, _vp, _sz, _vp]),
     ("zkw_trace_create", _int, [_vp, _sz, _sz, C.POINTER(_vp)]),
+    ("zkw_trace_create_with_columns", _int, [_vp, _sz, _sz, _sz, C.POINTER(_vp)]),
     ("zkw_trace_free", None, [_vp]),
     ("zkw_trace_num_rows", _sz, [_vp]),
     ("zkw_trace_num_cols", _sz, [_vp]),
@@ -614,10 +617,13 @@ class RamWitness:
 class Trace:
     """zkw_trace: a ring of filled-trace buffers in HBM, each column-major u64[n_cols][n_rows]."""
 
-    def __init__(self, ctx, n_rows, n_slots=1):
+    def __init__(self, ctx, n_rows, n_slots=1, n_cols=None):
         self.ctx = ctx
         self.handle = C.c_void_p(None)
-        _check(load().zkw_trace_create(ctx.handle, n_rows, n_slots, C.byref(self.handle)))
+        if n_cols is None:  # the RAMPermutation geometry, 149 columns
+            _check(load().zkw_trace_create(ctx.handle, n_rows, n_slots, C.byref(self.handle)))
+        else:
+            _check(load().zkw_trace_create_with_columns(ctx.handle, n_rows, n_cols, n_slots, C.byref(self.handle)))
         self.n_rows, self.n_slots = n_rows, n_slots
         self.n_cols = load().zkw_trace_num_cols(self.handle)
 
@@ -988,4 +994,21 @@ def _ctx_check_if_satisfied_events_sorter(self, trace, slot, capacity):
 
 
 Context.synthesize_events_sorter = _ctx_synthesize_events_sorter
+
+
+def _ctx_synthesize_log_demux(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+    """ZkSyncBaseLayerCircuit::LogDemuxer synthesis for instances of a DemuxWitness (the trace needs 151 columns)."""
+    n = witness.num_instances - first_instance if n_instances is None else n_instances
+    _check(load().zkw_log_demux_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+
+def _ctx_check_if_satisfied_log_demux(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_log_demux_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.synthesize_log_demux = _ctx_synthesize_log_demux
+Context.check_if_satisfied_log_demux = _ctx_check_if_satisfied_log_demux
 Context.check_if_satisfied_events_sorter = _ctx_check_if_satisfied_events_sorter

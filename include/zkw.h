@@ -334,6 +334,17 @@ int zkw_events_sorter_synthesize(zkw_ctx *ctx, const zkw_events_witness *w, size
 int zkw_events_sorter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                                       uint64_t *n_violations, uint64_t *first_bad);
 
+/* ---- LogDemuxer synthesis (a21, circuit type 4) ----------------------------------------------------------- */
+/* Counterpart of ZkSyncBaseLayerCircuit::LogDemuxer(..).synthesis (base_layer/mod.rs:286-323, wrapper
+   base_layer/log_demux.rs:27-38) on a zkw_demux_witness: geometry 136 + 14 + 1 = 151 columns (create the trace with
+   zkw_trace_create_with_columns(.., 151, ..)), layout include/zkw_log_demux_circuit_spec.h ("zkw trace v2", 12 rows
+   per cycle; production capacity 58 750 needs n_rows = 2^20). Requires LD_MIN_ROWS(capacity) <= n_rows and a witness
+   built with ZKW_DEMUX_PARAMS_DEFAULT (the routing constants are constants of the circuit). */
+int zkw_log_demux_synthesize(zkw_ctx *ctx, const zkw_demux_witness *w, size_t first_instance, size_t n_instances,
+                             zkw_trace *t, size_t first_slot);
+int zkw_log_demux_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
+                                  uint64_t *n_violations, uint64_t *first_bad);
+
 /* ---- StorageApplication witness builder (a17) --------------------------------------------------------- */
 typedef struct zkw_storage_application_witness zkw_storage_application_witness;
 /* decompose_into_storage_application_witnesses, src/witness/individual_circuits/storage_application.rs:31-361.
@@ -431,9 +442,12 @@ int zkw_linear_keccak256(zkw_ctx *ctx, const zkw_log_query *messages, size_t n, 
    columns, lookup columns and the lookup-multiplicity column, every cell written. Slots are a ring: a
    prover consumes a slot while later instances are synthesised into the others. */
 int zkw_trace_create(zkw_ctx *ctx, size_t n_rows, size_t n_slots, zkw_trace **out);
+/* same with an explicit column count (zkw_trace_create = 149, the RAMPermutation geometry): a circuit type whose
+   geometry is wider — the LogDemuxer's 136 + 14 + 1 = 151 — needs its own trace */
+int zkw_trace_create_with_columns(zkw_ctx *ctx, size_t n_rows, size_t n_cols, size_t n_slots, zkw_trace **out);
 void zkw_trace_free(zkw_trace *t);
 size_t zkw_trace_num_rows(const zkw_trace *t);
-size_t zkw_trace_num_cols(const zkw_trace *t); /* 149 = 133 copy-permutation + 15 lookup + 1 multiplicity */
+size_t zkw_trace_num_cols(const zkw_trace *t); /* default 149 = 133 copy-permutation + 15 lookup + 1 multiplicity */
 size_t zkw_trace_num_slots(const zkw_trace *t);
 /* device address of slot's column 0; column c starts at + c * n_rows */
 const uint64_t *zkw_trace_device_ptr(const zkw_trace *t, size_t slot);

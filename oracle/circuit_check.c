@@ -5,6 +5,7 @@
 #include "../include/zkw_ram_circuit_spec.h"
 #include "../include/zkw_decommit_sorter_circuit_spec.h"
 #include "../include/zkw_events_sorter_circuit_spec.h"
+#include "../include/zkw_log_demux_circuit_spec.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -35,6 +36,14 @@ static const uint8_t ES_IS_POSEIDON[] = ES_ROW_IS_POSEIDON_INIT;
 static const rc_link ES_LINKS[] = ES_LINKS_INIT;
 static const orc_spec SPEC_ES = {ES_G, ES_L, ES_ROWS_PER_CYCLE, ES_NUM_ROW_TYPES, ES_NUM_LINKS, ES_ROWOFF_BND_IN, ES_ROWOFF_BND_OUT,
                                  ES_TERMS, ES_CONS, ES_ROW_FIRST, ES_IS_POSEIDON, ES_LINKS};
+
+static const rc_term LD_TERMS[] = LD_TERMS_INIT;
+static const rc_constraint LD_CONS[] = LD_CONSTRAINTS_INIT;
+static const uint16_t LD_ROW_FIRST[] = LD_ROW_FIRST_CONSTRAINT_INIT;
+static const uint8_t LD_IS_POSEIDON[] = LD_ROW_IS_POSEIDON_INIT;
+static const rc_link LD_LINKS[] = LD_LINKS_INIT;
+static const orc_spec SPEC_LD = {LD_G, LD_L, LD_ROWS_PER_CYCLE, LD_NUM_ROW_TYPES, LD_NUM_LINKS, LD_ROWOFF_BND_IN, LD_ROWOFF_BND_OUT,
+                                 LD_TERMS, LD_CONS, LD_ROW_FIRST, LD_IS_POSEIDON, LD_LINKS};
 
 static const rc_term RC_TERMS[] = RC_TERMS_INIT;
 static const rc_constraint RC_CONS[] = RC_CONSTRAINTS_INIT;
@@ -140,4 +149,7 @@ uint64_t orc_decommit_sorter_check(const uint64_t *trace, uint32_t capacity, siz
 }
 uint64_t orc_events_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
     return check(&SPEC_ES, trace, capacity, n_rows, first_bad);
+}
+uint64_t orc_log_demux_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
+    return check(&SPEC_LD, trace, capacity, n_rows, first_bad);
 }

@@ -167,6 +167,10 @@ int orc_events_sorter_synthesize(const zkw_events_sorter_instance *inst, const z
                                  const uint64_t *sorted_enc, const uint64_t *challenges, const uint64_t *rq_tail_in,
                                  uint32_t rq_len_in, uint32_t capacity, size_t n_rows, uint64_t *trace);
 uint64_t orc_events_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+/* log_demux_circuit.c: LogDemuxer synthesis (circuit type 4) */
+int orc_log_demux_synthesize(const zkw_log_demux_instance *inst, const uint64_t *in_enc, uint32_t capacity, size_t n_rows,
+                             uint64_t *trace);
+uint64_t orc_log_demux_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 
 /* ---- sparse storage tree + StorageApplication builder (a17), see storage_application.c */
 typedef struct orc_tree orc_tree;

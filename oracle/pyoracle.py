@@ -716,3 +716,30 @@ def events_sorter_check(trace, capacity):
     bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
     v = first_bad.value
     return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+LD_COLS = 151
+
+
+def log_demux_synthesize(build_out, instance_index, capacity, n_rows):
+    """Fill the LogDemuxer trace of one instance from the outputs of log_demux_build."""
+    o = build_out
+    trace = np.zeros((LD_COLS, n_rows), np.uint64)
+    inst = o["instances"][instance_index:instance_index + 1]
+    enc = o["in_enc"] if o["in_enc"].size else np.zeros((1, 20), np.uint64)
+    f = lib().orc_log_demux_synthesize
+    f.restype = C.c_int
+    rc = f(_p(inst), _p(enc), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_log_demux_synthesize failed: {rc}")
+    return trace
+
+
+def log_demux_check(trace, capacity):
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_log_demux_check
+    f.restype = C.c_uint64
+    bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value
+    return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
