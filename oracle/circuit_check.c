@@ -6,6 +6,7 @@
 #include "../include/zkw_decommit_sorter_circuit_spec.h"
 #include "../include/zkw_events_sorter_circuit_spec.h"
 #include "../include/zkw_log_demux_circuit_spec.h"
+#include "../include/zkw_storage_sorter_circuit_spec.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -44,6 +45,14 @@ static const uint8_t LD_IS_POSEIDON[] = LD_ROW_IS_POSEIDON_INIT;
 static const rc_link LD_LINKS[] = LD_LINKS_INIT;
 static const orc_spec SPEC_LD = {LD_G, LD_L, LD_ROWS_PER_CYCLE, LD_NUM_ROW_TYPES, LD_NUM_LINKS, LD_ROWOFF_BND_IN, LD_ROWOFF_BND_OUT,
                                  LD_TERMS, LD_CONS, LD_ROW_FIRST, LD_IS_POSEIDON, LD_LINKS};
+
+static const rc_term SS_TERMS[] = SS_TERMS_INIT;
+static const rc_constraint SS_CONS[] = SS_CONSTRAINTS_INIT;
+static const uint16_t SS_ROW_FIRST[] = SS_ROW_FIRST_CONSTRAINT_INIT;
+static const uint8_t SS_IS_POSEIDON[] = SS_ROW_IS_POSEIDON_INIT;
+static const rc_link SS_LINKS[] = SS_LINKS_INIT;
+static const orc_spec SPEC_SS = {SS_G, SS_L, SS_ROWS_PER_CYCLE, SS_NUM_ROW_TYPES, SS_NUM_LINKS, SS_ROWOFF_BND_IN, SS_ROWOFF_BND_OUT,
+                                 SS_TERMS, SS_CONS, SS_ROW_FIRST, SS_IS_POSEIDON, SS_LINKS};
 
 static const rc_term RC_TERMS[] = RC_TERMS_INIT;
 static const rc_constraint RC_CONS[] = RC_CONSTRAINTS_INIT;
@@ -152,4 +161,7 @@ uint64_t orc_events_sorter_check(const uint64_t *trace, uint32_t capacity, size_
 }
 uint64_t orc_log_demux_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
     return check(&SPEC_LD, trace, capacity, n_rows, first_bad);
+}
+uint64_t orc_storage_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
+    return check(&SPEC_SS, trace, capacity, n_rows, first_bad);
 }

@@ -171,6 +171,10 @@ uint64_t orc_events_sorter_check(const uint64_t *trace, uint32_t capacity, size_
 int orc_log_demux_synthesize(const zkw_log_demux_instance *inst, const uint64_t *in_enc, uint32_t capacity, size_t n_rows,
                              uint64_t *trace);
 uint64_t orc_log_demux_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+/* storage_sorter_circuit.c: StorageSorter synthesis (circuit type 9) */
+int orc_storage_sorter_synthesize(const zkw_storage_sorter_instance *inst, const uint64_t *unsorted_enc, const uint64_t *sorted_enc,
+                                  const uint64_t *challenges, uint32_t capacity, size_t n_rows, uint64_t *trace);
+uint64_t orc_storage_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 
 /* ---- sparse storage tree + StorageApplication builder (a17), see storage_application.c */
 typedef struct orc_tree orc_tree;

@@ -743,3 +743,29 @@ def log_demux_check(trace, capacity):
     bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
     v = first_bad.value
     return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+SS_COLS = 149
+
+
+def storage_sorter_synthesize(build_out, instance_index, capacity, n_rows):
+    """Fill the StorageSorter trace of one instance from the outputs of storage_sorter_build."""
+    o = build_out
+    trace = np.zeros((SS_COLS, n_rows), np.uint64)
+    inst = o["instances"][instance_index:instance_index + 1]
+    f = lib().orc_storage_sorter_synthesize
+    f.restype = C.c_int
+    rc = f(_p(inst), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_storage_sorter_synthesize failed: {rc}")
+    return trace
+
+
+def storage_sorter_check(trace, capacity):
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_storage_sorter_check
+    f.restype = C.c_uint64
+    bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value
+    return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
