@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __restric
             for (int k = 0; k < 20; k++) eu[k] = c.can_pop ? job.unsorted_enc[20 * c.idx + k] : 0;
             ES_SET20(cur, eu, eu);
             u64* g = &glob.c0_1;  // c0_1..c0_20, c1_1..c1_20 are consecutive fields
+#pragma unroll
             for (int r = 0; r < 2; r++) {
                 const u64* ch = job.challenges + 21 * r;
 #pragma unroll

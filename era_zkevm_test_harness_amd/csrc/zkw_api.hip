@@ -30,6 +30,7 @@
 #include "decommit_sorter_circuit_kernels.cuh"
 #include "events_sorter_circuit_kernels.cuh"
 #include "log_demux_circuit_kernels.cuh"
+#include "storage_sorter_circuit_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -1666,9 +1667,10 @@ struct zkw_storage_witness {
     u64* lhs_enc = nullptr;    // [n][20]: unsorted with extended timestamp (permutation argument only)
     u64* tails_all = nullptr;  // [5n][4]
     u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
+    u32* scans = nullptr;  // [4][n]: D, S, R, E of k_storage_cells (kept for synthesis)
     zkw_storage_sorter_instance* instances = nullptr;
     void release() {
-        void* ptrs[] = {sorted_q, result_q, sorted_ext, enc_all, lhs_enc, tails_all, challenges, lhs_z, rhs_z, instances};
+        void* ptrs[] = {sorted_q, result_q, sorted_ext, enc_all, lhs_enc, tails_all, challenges, lhs_z, rhs_z, scans, instances};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -1720,10 +1722,10 @@ static int storage_run(zkw_ctx* ctx, zkw_storage_witness* w, const zkw_log_query
     // per-cell registers and the deduplicated queue
     StorageScan sc;
     u32* totals = nullptr;
-    ZKW_TRY(ctx->scratch_t<int>("sto_D", n, &sc.D));
-    ZKW_TRY(ctx->scratch_t<u32>("sto_S", n, &sc.S));
-    ZKW_TRY(ctx->scratch_t<u32>("sto_R", n, &sc.R));
-    ZKW_TRY(ctx->scratch_t<u32>("sto_E", n, &sc.E));
+    sc.D = reinterpret_cast<int*>(w->scans);
+    sc.S = w->scans + n;
+    sc.R = w->scans + 2 * n;
+    sc.E = w->scans + 3 * n;
     ZKW_TRY(ctx->scratch_t<u32>("sto_totals", 2, &totals));
     { Prof _p(ctx, "k_storage_cells"); hipLaunchKernelGGL(k_storage_cells, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, sc, w->result_q, r_enc, totals); }
     ZKW_TRY(launch_check("k_storage_cells"));
@@ -1775,6 +1777,7 @@ extern "C" int zkw_storage_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, si
     alloc((void**)&w->challenges, 42 * 8);
     alloc((void**)&w->lhs_z, m * 16);
     alloc((void**)&w->rhs_z, m * 16);
+    alloc((void**)&w->scans, 4 * m * sizeof(u32));
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_storage_sorter_instance));
     if (e != hipSuccess) {
         w->release();
@@ -2614,4 +2617,65 @@ extern "C" int zkw_log_demux_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, s
         return fail(ZKW_ERR_INVALID, "zkw_log_demux_check_satisfied: bad argument");
     if (LD_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecLogDemux>(ctx, t, slot, capacity, n_violations, first_bad);
+}
+
+// ------------------------------------------------------------------------------------------------ StorageSorter synthesis
+extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_witness* w, size_t first_instance, size_t n_instances,
+                                             zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_synthesize: bad argument");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (t->n_cols < SS_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the StorageSorter needs %d", t->n_cols, SS_COLS);
+    const u32 capacity = w->capacity;
+    const size_t n_rows = t->n_rows, n = w->n;
+    if (SS_MIN_ROWS(capacity) > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)SS_MIN_ROWS(capacity), n_rows);
+    if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("ss_hist", n_instances * 256, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    std::vector<SsSynthJob> jobs(n_instances);
+    for (size_t k = 0; k < n_instances; k++) {
+        SsSynthJob& j = jobs[k];
+        j.inst = w->instances + first_instance + k;
+        j.unsorted_enc = w->enc_all; j.sorted_enc = w->enc_all + 20 * n;
+        j.unsorted_new_tails = w->tails_all + 4 * n; j.sorted_new_tails = w->tails_all + 12 * n; j.result_new_tails = w->tails_all + 16 * n;
+        j.challenges = w->challenges;
+        j.lhs_z = w->lhs_z; j.rhs_z = w->rhs_z;
+        j.sc.D = reinterpret_cast<int*>(w->scans); j.sc.S = w->scans + n; j.sc.R = w->scans + 2 * n; j.sc.E = w->scans + 3 * n;
+        j.n_block = n;
+        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.hist = d_hist + 256 * k;
+    }
+    SsSynthJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("ss_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)n_instances;
+    const u32 rstride = (u32)SS_REGION_STRIDE(capacity);
+    const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
+    { Prof _p(ctx, "k_ss_fill_queue"); hipLaunchKernelGGL((k_ss_fill_queue<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ss_fill_queue<0>"));
+    { Prof _p(ctx, "k_ss_fill_queue"); hipLaunchKernelGGL((k_ss_fill_queue<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ss_fill_queue<1>"));
+    { Prof _p(ctx, "k_ss_fill_queue"); hipLaunchKernelGGL((k_ss_fill_queue<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ss_fill_queue<2>"));
+#define SS_LAUNCH_ROW(R) { Prof _p(ctx, "k_ss_fill_row"); hipLaunchKernelGGL((k_ss_fill_row<SS_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
+    ZKW_TRY(launch_check("k_ss_fill_row<" #R ">"));
+    SS_LAUNCH_ROW(A) SS_LAUNCH_ROW(X0) SS_LAUNCH_ROW(X1) SS_LAUNCH_ROW(X2) SS_LAUNCH_ROW(X3) SS_LAUNCH_ROW(X4) SS_LAUNCH_ROW(X5)
+    SS_LAUNCH_ROW(X6) SS_LAUNCH_ROW(X7) SS_LAUNCH_ROW(K) SS_LAUNCH_ROW(C1) SS_LAUNCH_ROW(C2) SS_LAUNCH_ROW(Q)
+#undef SS_LAUNCH_ROW
+    { Prof _p(ctx, "k_ss_fill_tail"); hipLaunchKernelGGL(k_ss_fill_tail, dim3((SS_G + SS_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ss_fill_tail"));
+    { Prof _p(ctx, "k_ss_fill_boundary"); hipLaunchKernelGGL(k_ss_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_ss_fill_boundary"));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_storage_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
+                                                  uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+        return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_check_satisfied: bad argument");
+    if (SS_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    return check_satisfied<SpecStorageSorter>(ctx, t, slot, capacity, n_violations, first_bad);
 }

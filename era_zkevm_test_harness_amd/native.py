@@ -89,6 +89,8 @@ SYMBOLS = [
     ("zkw_events_sorter_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_events_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_log_demux_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_storage_sorter_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_storage_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_log_demux_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
@@ -1010,5 +1012,22 @@ def _ctx_check_if_satisfied_log_demux(self, trace, slot, capacity):
 
 
 Context.synthesize_log_demux = _ctx_synthesize_log_demux
+
+
+def _ctx_synthesize_storage_sorter(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+    """ZkSyncBaseLayerCircuit::StorageSorter synthesis for instances of a StorageWitness."""
+    n = witness.num_instances - first_instance if n_instances is None else n_instances
+    _check(load().zkw_storage_sorter_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+
+def _ctx_check_if_satisfied_storage_sorter(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_storage_sorter_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.synthesize_storage_sorter = _ctx_synthesize_storage_sorter
+Context.check_if_satisfied_storage_sorter = _ctx_check_if_satisfied_storage_sorter
 Context.check_if_satisfied_log_demux = _ctx_check_if_satisfied_log_demux
 Context.check_if_satisfied_events_sorter = _ctx_check_if_satisfied_events_sorter

@@ -345,6 +345,16 @@ int zkw_log_demux_synthesize(zkw_ctx *ctx, const zkw_demux_witness *w, size_t fi
 int zkw_log_demux_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                                   uint64_t *n_violations, uint64_t *first_bad);
 
+/* ---- StorageSorter synthesis (a21, circuit type 9) -------------------------------------------------------- */
+/* Counterpart of ZkSyncBaseLayerCircuit::StorageSorter(..).synthesis (base_layer/mod.rs:286-323, wrapper
+   base_layer/storage_sort_dedup.rs:29-40) on a zkw_storage_witness: geometry 132 + 16 + 1 = 149 columns, layout
+   include/zkw_storage_sorter_circuit_spec.h ("zkw trace v2", 22 rows per cycle; production capacity 46 921 needs
+   n_rows = 2^20). Requires SS_MIN_ROWS(capacity) <= n_rows. */
+int zkw_storage_sorter_synthesize(zkw_ctx *ctx, const zkw_storage_witness *w, size_t first_instance, size_t n_instances,
+                                  zkw_trace *t, size_t first_slot);
+int zkw_storage_sorter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
+                                       uint64_t *n_violations, uint64_t *first_bad);
+
 /* ---- StorageApplication witness builder (a17) --------------------------------------------------------- */
 typedef struct zkw_storage_application_witness zkw_storage_application_witness;
 /* decompose_into_storage_application_witnesses, src/witness/individual_circuits/storage_application.rs:31-361.

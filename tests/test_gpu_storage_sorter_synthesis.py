@@ -1,0 +1,87 @@
+"""GPU parity: StorageSorter synthesis through the C ABI vs the oracle's trace, cell by cell, and the GPU satisfiability
+checker on clean and tampered traces."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from era_zkevm_test_harness_amd import native
+
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n,cells,capacity,n_rows", [(7, 2, 8, 2048), (100, 12, 64, 2048), (64, 5, 64, 2048), (128, 40, 64, 2048),
+                                                     (150, 150, 50, 2048), (90, 1, 32, 2048), (3000, 400, 700, 16384)])
+def test_trace_matches_oracle(ctx, oracle, n, cells, capacity, n_rows):
+    from era_zkevm_test_harness_amd import native
+
+    q = synthetic.storage_trace(n, cells, seed=n)
+    o = oracle.storage_sorter_build(q, capacity)
+    w = ctx.compute_storage_dedup_and_sort(q, capacity)
+    n_inst = o["instances"].size
+    t = native.Trace(ctx, n_rows, n_inst)
+    ctx.synthesize_storage_sorter(w, t)
+    for idx in range(n_inst):
+        got = t.get(idx)
+        exp = oracle.storage_sorter_synthesize(o, idx, capacity, n_rows)
+        if not np.array_equal(got, exp):
+            bad = np.argwhere(got != exp)
+            raise AssertionError(f"instance {idx}: {len(bad)} cells differ, first (col, row) = {bad[:8].tolist()}")
+        assert ctx.check_if_satisfied_storage_sorter(t, idx, capacity)[0] == 0
+    t.free()
+
+
+def test_production_geometry(ctx, oracle):
+    """capacity 46 921 in a 2^20-row trace (all 22 x 46 976 + 6 rows of it): one full instance and a ragged last one."""
+    from era_zkevm_test_harness_amd import native
+
+    capacity, n_rows = 46921, 1 << 20
+    q = synthetic.storage_trace(60000, 9000, seed=9)
+    w = ctx.compute_storage_dedup_and_sort(q, capacity)
+    t = native.Trace(ctx, n_rows, 2)
+    ctx.synthesize_storage_sorter(w, t)
+    for idx in range(2):
+        bad, first = ctx.check_if_satisfied_storage_sorter(t, idx, capacity)
+        assert bad == 0, (idx, first)
+        mult = t.get(idx, 148, 1)[0]
+        assert int(mult.sum()) == 16 * n_rows and not mult[256:].any()
+    t.free()
+
+
+def test_gpu_checker_flags_tampering(ctx, oracle):
+    import torch
+
+    from era_zkevm_test_harness_amd import native
+
+    capacity, n_rows = 64, 2048
+    q = synthetic.storage_trace(50, 8, seed=3)
+    w = ctx.compute_storage_dedup_and_sort(q, capacity)
+    t = native.Trace(ctx, n_rows, 1)
+    ctx.synthesize_storage_sorter(w, t, 0, 1)
+    assert ctx.check_if_satisfied_storage_sorter(t, 0, capacity)[0] == 0
+    host = t.get(0)
+    rng = np.random.default_rng(2)
+    used = np.argwhere(host[:148, :22 * 64 + 6] != 0)
+    base = native.load().zkw_trace_device_ptr(t.handle, 0)
+    hip = C.CDLL("libamdhip64.so")
+    for _ in range(25):
+        c, r = used[rng.integers(len(used))]
+        addr = base + (int(c) * n_rows + int(r)) * 8
+        old = np.array([host[c, r]], np.uint64)
+        new = np.array([(int(host[c, r]) + 1) % P], np.uint64)
+        torch.cuda.synchronize()
+        hip.hipMemcpy(C.c_void_p(addr), new.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
+        assert ctx.check_if_satisfied_storage_sorter(t, 0, capacity)[0] > 0, (c, r)
+        hip.hipMemcpy(C.c_void_p(addr), old.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
+    assert ctx.check_if_satisfied_storage_sorter(t, 0, capacity)[0] == 0
+    t.free()
