@@ -80,7 +80,13 @@ def main():
     ap.add_argument("--blocks", type=int, default=0,
                     help="independent memory queues per GPU per step (0 = size the batch to the free HBM)")
     ap.add_argument("--queries", type=int, default=CAPACITY)
-    ap.add_argument("--ring", type=int, default=16, help="trace buffers (1.25 GB each) in the output ring")
+    ap.add_argument("--ring", type=int, default=16, help="trace buffers (1.25 GB each) in the output ring, all pipelines together")
+    ap.add_argument("--pipelines", type=int, default=int(os.environ.get("ZKW_PIPELINES", "1")),
+                    help="experiment (DESIGN.md 3.2): split the step into P sub-batches that run as independent pipelines "
+                         "(own context, HIP stream, host thread), started 1/P of a period apart so that one pipeline's "
+                         "synthesis overlaps the others' queue chains. Measured slower than P = 1 on MI355X: the synthesis "
+                         "waves land on the SIMDs the chain waves need, and fewer chains per launch do not run faster")
+    ap.add_argument("--stagger-ms", type=float, default=-1.0, help="start offset between pipelines (default: measured in warm-up)")
     ap.add_argument("--cpu-sample", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -89,76 +95,138 @@ def main():
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    ctx = native.Context(local_rank)  # raises if libzkw / the GPU is missing: no fallback
-    stream = torch.cuda.Stream(device=dev)  # one stream for torch ops, RCCL and libzkw kernels
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.set_pointer_mode(native.PTR_DEVICE)
-    if os.environ.get("ZKW_CHAIN_FORM"):
-        ctx.set_chain_form(int(os.environ["ZKW_CHAIN_FORM"]))
+    P = max(1, args.pipelines)
+    ctxs, streams = [], []
+    for _p in range(P):  # raises if libzkw / the GPU is missing: no fallback
+        c = native.Context(local_rank)
+        st = torch.cuda.Stream(device=dev)  # one stream per pipeline for torch ops and libzkw kernels
+        c.set_stream(st.cuda_stream)
+        c.set_pointer_mode(native.PTR_DEVICE)
+        if os.environ.get("ZKW_CHAIN_FORM"):
+            c.set_chain_form(int(os.environ["ZKW_CHAIN_FORM"]))
+        ctxs.append(c)
+        streams.append(st)
+    ctx = ctxs[0]
+    torch.cuda.set_stream(streams[0])
 
     n = args.queries
     B = args.blocks
+    ring_p = max(2, args.ring // P)
     if B <= 0:
-        # one block of n queries keeps ~74 B/query... measured 69 MB per 136 714-query block (inputs 6.6 + witness
-        # 54.7 + sort scratch 5.5 + chain/descriptor scratch); the chains want as many concurrent queues as fit
         free, _total = torch.cuda.mem_get_info(dev)
         # resident per query: input 48 + sorted copy 48 + two encodings 2 x 64 + capacity words of the tails 2 x 32 +
         # grand products 2 x 16 = 320 bytes (sort scratch aliases arrays that are filled later). Cap: 4096 blocks =
-        # 8192 queue chains. Inside the builder the chain kernel runs at 14.7 us per step up to ~8 400 chains and
-        # at 22.3 us beyond (measured cliff), so more blocks per step only pay above ~6 000 blocks,
-        # which do not fit the HBM.
+        # 8192 queue chains in flight. The chain kernel is serial per queue (14.7 us per item whatever the number of
+        # chains, up to ~8 400 of them), so a step wants as many concurrent queues as fit the HBM.
         per_block = int(n * 330)
-        B = int(max(16, min(4096, (0.90 * free - args.ring * 1.25e9) // per_block)))
+        B = int(max(16, min(4096, (0.90 * free - P * ring_p * 1.25e9) // per_block)))
         B = parallel.min_over_ranks(B, dev)  # every rank runs the same batch (weak scaling, equal record counts)
+    B = max(P, B // P * P)
+    Bp = B // P
     n_rows = 1 << 20  # TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17
-    ring = native.Trace(ctx, n_rows, args.ring)  # trace buffers a prover would consume and hand back
+    rings = [native.Trace(ctxs[p], n_rows, ring_p) for p in range(P)]  # trace buffers a prover would consume and hand back
     base, q = make_inputs(B, n, rank, dev)
-    offs = np.arange(B + 1, dtype=np.uint64) * n
-    w = native.RamWitness(ctx)
+    offs = np.arange(Bp + 1, dtype=np.uint64) * n
+    ws = [native.RamWitness(ctxs[p]) for p in range(P)]
     # what rank 0 needs from every instance to replay the recursion queue and build the scheduler witness
     # (SURVEY 8(e)): compact closed-form input (2 flags + 4 commitments = 18 words) + public input (4 words) = 176 B
     inst_bytes = (18 + 4) * 8
-    n_inst_local = B * (-(-n // CAPACITY))
+    inst_per_block = -(-n // CAPACITY)
+    n_inst_p = Bp * inst_per_block
+    n_inst_local = B * inst_per_block
     records = torch.empty((n_inst_local, inst_bytes), dtype=torch.uint8, device=dev)
     compact = torch.empty((n_inst_local, 18), dtype=torch.int64, device=dev)
     pis = torch.empty((n_inst_local, 4), dtype=torch.int64, device=dev)
     counts = [n_inst_local] * world
+    lib = native.load()
+    q_item = q.element_size() * q.shape[2]  # 48 bytes per query
 
-    def step():
-        ctx.compute_ram_circuit_snapshots((q.data_ptr(), B * n), CAPACITY, 0, block_offsets=offs, witness=w)
-        for first in range(0, n_inst_local, args.ring):  # synthesis: every instance -> a full 2^20-row trace
-            ctx.synthesize_ram(w, ring, first, min(args.ring, n_inst_local - first), 0)
-        lib = native.load()
-        native._check(lib.zkw_ram_witness_get(w.handle, native.RAM_COMPACT_FORMS, compact.data_ptr(), compact.numel() * 8))
-        native._check(lib.zkw_ram_witness_get(w.handle, native.RAM_PUBLIC_INPUTS, pis.data_ptr(), pis.numel() * 8))
-        records.view(torch.int64).view(n_inst_local, 22)[:, :18] = compact
-        records.view(torch.int64).view(n_inst_local, 22)[:, 18:] = pis
-        return parallel.gather_records(records, counts, dst=0)
+    def pipeline_pass(p):
+        """witness generation + synthesis of sub-batch p (blocks p*Bp .. (p+1)*Bp) on pipeline p's stream"""
+        c, w, ring = ctxs[p], ws[p], rings[p]
+        with torch.cuda.stream(streams[p]):
+            c.compute_ram_circuit_snapshots((q.data_ptr() + p * Bp * n * q_item, Bp * n), CAPACITY, 0, block_offsets=offs, witness=w)
+            for first in range(0, n_inst_p, ring_p):  # synthesis: every instance -> a full 2^20-row trace
+                c.synthesize_ram(w, ring, first, min(ring_p, n_inst_p - first), 0)
+            lo, hi = p * n_inst_p, (p + 1) * n_inst_p
+            cp, pp = compact[lo:hi], pis[lo:hi]
+            native._check(lib.zkw_ram_witness_get(w.handle, native.RAM_COMPACT_FORMS, cp.data_ptr(), cp.numel() * 8))
+            native._check(lib.zkw_ram_witness_get(w.handle, native.RAM_PUBLIC_INPUTS, pp.data_ptr(), pp.numel() * 8))
+            rec = records.view(torch.int64).view(n_inst_local, 22)
+            rec[lo:hi, :18] = cp
+            rec[lo:hi, 18:] = pp
+            streams[p].synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.profile_enable(True)
-    ctx.profile_reset()
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(P)
+
+    def pipeline_run(p, passes, delay_s):
+        torch.cuda.set_device(local_rank)
+        if delay_s > 0:
+            time.sleep(delay_s)
+        for _ in range(passes):
+            pipeline_pass(p)
+
+    def run_steps(passes, stagger_s):
+        """`passes` steps; after each step the closed-form records go to rank 0. P == 1: pass, gather, pass, gather ...
+        P > 1: every pipeline makes `passes` passes over its sub-batch back to back (= `passes` passes over all B
+        blocks), pipeline p starting p * stagger_s after pipeline 0, and the `passes` gathers follow."""
+        out = None
+        if P == 1:
+            for _ in range(passes):
+                pipeline_pass(0)
+                out = parallel.gather_records(records, counts, dst=0)
+            return out
+        futs = [pool.submit(pipeline_run, p, passes, p * stagger_s) for p in range(P)]
+        for f in futs:
+            f.result()
+        for _ in range(passes):
+            out = parallel.gather_records(records, counts, dst=0)
+        return out
+
+    # Start offset between pipelines. A pipeline's pass = its queue chains (VALU-bound, serial per queue: T_chain whatever
+    # the sub-batch size) followed by everything else (T_rest, HBM-bound). With the starts spread over one period
+    # (T_chain + T_rest / P) every pipeline's HBM-bound phase falls inside the other pipelines' chains. T_chain and T_rest
+    # come from the HIP-event kernel times of pipeline 0 in the last warm-up step (all pipelines in lockstep there, so
+    # T_rest is the contended time of all P synthesis phases together).
+    stagger_s = (n * 12e-6) / P if P > 1 else 0.0
+    for k in range(args.warmup):
+        ctxs[0].profile_enable(True)
+        ctxs[0].profile_reset()
+        run_steps(1, 0.0)
+        pr0 = ctxs[0].profile()
+        ctxs[0].profile_enable(False)
+        t_chain = sum(ms for name, (ms, _c) in pr0.items() if name.startswith("k_chain_full")) * 1e-3
+        t_rest = sum(ms for name, (ms, _c) in pr0.items() if name.startswith(("k_ram_fill", "k_ram_nd", "k_gp_", "k_encode", "k_gather_encode"))) * 1e-3
+        if P > 1 and t_chain > 0:
+            stagger_s = (t_chain + t_rest / P) / P
+    if args.stagger_ms >= 0:
+        stagger_s = args.stagger_ms * 1e-3
+    for c in ctxs:
+        c.profile_enable(True)
+        c.profile_reset()
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gathered = step()
+    gathered = run_steps(args.steps, stagger_s)
     torch.cuda.synchronize()
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-    prof = ctx.profile()
-    ctx.profile_enable(False)
+    prof = {}
+    for c in ctxs:  # kernel time per name, summed over the pipelines (HIP events on each pipeline's own stream)
+        for k, (ms, cnt) in c.profile().items():
+            a = prof.get(k, (0.0, 0))
+            prof[k] = (a[0] + ms, a[1] + cnt)
+        c.profile_enable(False)
 
     if rank == 0:
         assert gathered.shape[0] == n_inst_local * world
         circuits = n_inst_local * world * args.steps
         # dominant kernel by time, with its algorithmic HBM bytes per launch (DESIGN.md "Measurement")
-        items = B * n
+        items = Bp * n  # queue items per builder launch (one sub-batch)
         # algorithmic HBM bytes PER LAUNCH of each kernel (DESIGN.md "Measurement"): cells written once +
         # the instance's witness read once. A synthesis launch covers `args.ring` instances.
-        per_launch_inst = min(args.ring, n_inst_local)
+        per_launch_inst = min(ring_p, n_inst_p)
         stride = (CAPACITY + 63) // 64 * 64            # rows per region incl. the alignment gap (zkw trace v2)
         cell = 8 * stride * per_launch_inst            # one column of one region, all instances of a launch
         wit = per_launch_inst * n                      # witness items read by a launch
@@ -205,17 +273,19 @@ def main():
             "config": {"workload": f"RAMPermutation base circuit, capacity {CAPACITY} (2^20-row geometry), "
                                    f"{B} independent memory queues per GPU per step, witness generation + synthesis "
                                    f"of every instance into a 149-column x 2^20-row trace",
-                       "blocks_per_gpu": B, "queries_per_block": n, "parallelism": f"instances sharded x{world}"},
+                       "blocks_per_gpu": B, "queries_per_block": n, "parallelism": f"instances sharded x{world}",
+                       "pipelines_per_gpu": P, "pipeline_stagger_ms": stagger_s * 1e3},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "avg_launch_ms": avg_ms,
-                         "note": "k_chain_full is a serial Poseidon2 chain per queue: latency/VALU-bound, "
-                                 "permutations/s is its meaningful rate"},
+                         "note": "k_chain_full is a serial Poseidon2 chain per queue: latency/VALU-bound, permutations/s is "
+                                 "its meaningful rate; with P pipelines its launches overlap the other pipelines' synthesis, "
+                                 "so per-kernel times sum to more than the wall time"},
             "synthesis": {"trace_bytes_per_circuit": 149 * n_rows * 8, "kernels_ms_per_step": synth_ms / args.steps,
                           "achieved_GBps": synth_gbs, "frac_of_hbm_peak": synth_gbs / HBM_PEAK_GBS if synth_gbs else None,
                           "per_kernel": hbm_kernels},
             "hbm_used_GB": (total_mem - free_after) / 1e9,
-            "poseidon2_perm_per_s": 2 * items * chain_cnt / (chain_ms * 1e-3) if chain_ms else None,
+            "poseidon2_perm_per_s": 2 * B * n * args.steps / dt,
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
         }
         if not args.no_cpu_baseline:
