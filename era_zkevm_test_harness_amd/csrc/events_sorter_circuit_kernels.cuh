@@ -29,6 +29,7 @@ struct EsSynthJob {
     u64 n_block;
     u64 rq_tail_in[4];                         // result queue before the block
     u32 rq_len_in;
+    const u64* public_input;  // [4]: commitment of the compact closed-form input
     u64* trace;
     u32* hist;
 };
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(64) void k_es_fill_boundary(const EsSynthJob* __res
         for (int col = ES_NSLOTS_BND_OUT; col < ES_G + ES_L; col++) TR(col, row) = 0;
     }
     const size_t rPI = bnd + ES_ROWOFF_PI;
-    for (int col = 0; col < ES_G + ES_L; col++) TR(col, rPI) = 0;  // the public input is not derived for these types yet
+    for (int col = 0; col < ES_G + ES_L; col++) TR(col, rPI) = col < 4 ? job.public_input[col] : 0;
 }
 
 // kept_prefix[k] = #{ j < k : record j is a forward record whose successor has another timestamp }, k = 0..n

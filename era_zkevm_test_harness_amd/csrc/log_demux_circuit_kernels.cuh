@@ -40,6 +40,7 @@ struct LdSynthJob {
     const u32* route_count;    // [6][n] inclusive prefix counts per route
     u64 offsets[7];
     u64 n_block;
+    const u64* public_input;  // [4]: commitment of the compact closed-form input
     u64* trace;
     u32* hist;
 };
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64) void k_ld_fill_boundary(const LdSynthJob* __res
         for (int col = LD_NSLOTS_BND_OUT; col < LD_G + LD_L; col++) TR(col, row) = 0;
     }
     const size_t rPI = bnd + LD_ROWOFF_PI;
-    for (int col = 0; col < LD_G + LD_L; col++) TR(col, rPI) = 0;  // the public input is not derived for this type yet
+    for (int col = 0; col < LD_G + LD_L; col++) TR(col, rPI) = col < 4 ? job.public_input[col] : 0;
 }
 
 #undef TR

@@ -142,6 +142,126 @@ __global__ __launch_bounds__(64) void k_ds_commitments(const zkw_decommit_sorter
     for (int k = 0; k < 4; k++) cf[at + k] = c[k];
 }
 
+// ---- the 4-wide log-queue circuits (LogDemuxer 4, StorageSorter 9, EventsSorter / L1MessagesSorter 11 / 12): one
+// templated kernel over a per-type encoder; same lane plan as above. Field order = the struct declarations as
+// mirrored by include/zkw_types.h (the reference's struct literals: log_demux.rs:283-301, storage_sort_dedup.rs:
+// 577-612, events_sort_dedup.rs:426-455); LogQuery in the declaration order of the in-circuit struct.
+__device__ inline int put_queue4(const zkw_queue_state4& q, u64* o) {
+    for (int k = 0; k < 4; k++) { o[k] = q.head[k]; o[4 + k] = q.tail[k]; }
+    o[8] = q.length;
+    return 9;
+}
+__device__ inline int put_log_query(const zkw_log_query& q, u64* o) {
+    int m = 0;
+    for (int k = 0; k < 5; k++) o[m++] = q.address[k];
+    for (int k = 0; k < 8; k++) o[m++] = q.key[k];
+    for (int k = 0; k < 8; k++) o[m++] = q.read_value[k];
+    for (int k = 0; k < 8; k++) o[m++] = q.written_value[k];
+    o[m++] = q.rw_flag ? 1 : 0;
+    o[m++] = q.aux_byte;
+    o[m++] = q.rollback ? 1 : 0;
+    o[m++] = q.is_service ? 1 : 0;
+    o[m++] = q.shard_id;
+    o[m++] = q.tx_number_in_block;
+    o[m++] = q.timestamp;
+    return m;
+}
+struct CfLogDemux {
+    using Inst = zkw_log_demux_instance;
+    static constexpr int MAXLEN = 63;
+    __device__ static int input(const Inst& w, u64* o) { return put_queue4(w.initial_log_queue_state, o); }
+    __device__ static int output(const Inst& w, u64* o) {
+        int m = 0;
+        for (int c = 0; c < ZKW_DEMUX_NUM_QUEUES; c++) m += put_queue4(w.output_queue_state[c], o + m);
+        return m;
+    }
+    __device__ static int fsm(const zkw_log_demux_fsm& f, u64* o) {
+        int m = put_queue4(f.initial_log_queue_state, o);
+        for (int c = 0; c < ZKW_DEMUX_NUM_QUEUES; c++) m += put_queue4(f.queue_state[c], o + m);
+        return m;
+    }
+    __device__ static const zkw_log_demux_fsm& fsm_in(const Inst& w) { return w.hidden_fsm_input; }
+    __device__ static const zkw_log_demux_fsm& fsm_out(const Inst& w) { return w.hidden_fsm_output; }
+};
+struct CfEventsSorter {
+    using Inst = zkw_events_sorter_instance;
+    static constexpr int MAXLEN = 68;
+    __device__ static int input(const Inst& w, u64* o) {
+        int m = put_queue4(w.initial_log_queue_state, o);
+        return m + put_queue4(w.intermediate_sorted_queue_state, o + m);
+    }
+    __device__ static int output(const Inst& w, u64* o) { return put_queue4(w.final_queue_state, o); }
+    __device__ static int fsm(const zkw_events_sorter_fsm& f, u64* o) {
+        int m = 0;
+        for (int r = 0; r < 2; r++) o[m++] = f.lhs_accumulator[r];
+        for (int r = 0; r < 2; r++) o[m++] = f.rhs_accumulator[r];
+        m += put_queue4(f.initial_unsorted_queue_state, o + m);
+        m += put_queue4(f.intermediate_sorted_queue_state, o + m);
+        m += put_queue4(f.final_result_queue_state, o + m);
+        o[m++] = f.previous_key;
+        return m + put_log_query(f.previous_item, o + m);
+    }
+    __device__ static const zkw_events_sorter_fsm& fsm_in(const Inst& w) { return w.hidden_fsm_input; }
+    __device__ static const zkw_events_sorter_fsm& fsm_out(const Inst& w) { return w.hidden_fsm_output; }
+};
+struct CfStorageSorter {
+    using Inst = zkw_storage_sorter_instance;
+    static constexpr int MAXLEN = 77;
+    __device__ static int input(const Inst& w, u64* o) {
+        o[0] = w.shard_id_to_process;
+        int m = 1 + put_queue4(w.unsorted_log_queue_state, o + 1);
+        return m + put_queue4(w.intermediate_sorted_queue_state, o + m);
+    }
+    __device__ static int output(const Inst& w, u64* o) { return put_queue4(w.final_sorted_queue_state, o); }
+    __device__ static int fsm(const zkw_storage_sorter_fsm& f, u64* o) {
+        int m = 0;
+        for (int r = 0; r < 2; r++) o[m++] = f.lhs_accumulator[r];
+        for (int r = 0; r < 2; r++) o[m++] = f.rhs_accumulator[r];
+        m += put_queue4(f.current_unsorted_queue_state, o + m);
+        m += put_queue4(f.current_intermediate_sorted_queue_state, o + m);
+        m += put_queue4(f.current_final_sorted_queue_state, o + m);
+        o[m++] = f.cycle_idx;
+        for (int k = 0; k < ZKW_STORAGE_PACKED_KEY_LENGTH; k++) o[m++] = f.previous_packed_key[k];
+        for (int k = 0; k < 8; k++) o[m++] = f.previous_key[k];
+        for (int k = 0; k < 5; k++) o[m++] = f.previous_address[k];
+        o[m++] = f.previous_timestamp;
+        o[m++] = f.this_cell_has_explicit_read_and_rollback_depth_zero ? 1 : 0;
+        for (int k = 0; k < 8; k++) o[m++] = f.this_cell_base_value[k];
+        for (int k = 0; k < 8; k++) o[m++] = f.this_cell_current_value[k];
+        o[m++] = f.this_cell_current_depth;
+        return m;
+    }
+    __device__ static const zkw_storage_sorter_fsm& fsm_in(const Inst& w) { return w.hidden_fsm_input; }
+    __device__ static const zkw_storage_sorter_fsm& fsm_out(const Inst& w) { return w.hidden_fsm_output; }
+};
+
+template <class T>
+__global__ __launch_bounds__(64) void k_closed_form_commitments(const typename T::Inst* __restrict__ inst, size_t n,
+                                                                u64* __restrict__ compact) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = t >> 2;
+    const int part = (int)(t & 3);
+    if (i >= n) return;
+    u64* cf = compact + COMPACT_FORM_LEN * i;
+    u64 buf[T::MAXLEN];
+    u64 c[4];
+    int m;
+    if (part == 0) {  // the observable input is the one of the block's first instance (postprocessing/mod.rs:358-364)
+        size_t j = i;
+        while (j > 0 && !inst[j].start_flag) j--;
+        m = T::input(inst[j], buf);
+    } else if (part == 1) {
+        cf[0] = inst[i].start_flag ? 1 : 0;
+        cf[1] = inst[i].completion_flag ? 1 : 0;
+        m = T::output(inst[i], buf);
+    } else {
+        m = T::fsm(part == 2 ? T::fsm_in(inst[i]) : T::fsm_out(inst[i]), buf);
+    }
+    commit_var_length(buf, m, c);
+    const int at = part == 0 ? 2 : (part == 1 ? 6 : (part == 2 ? 10 : 14));
+    for (int k = 0; k < 4; k++) cf[at + k] = c[k];
+}
+
 __global__ __launch_bounds__(64) void k_encode_recursion(u64 circuit_type, const u64* __restrict__ pi, size_t n,
                                                          u64* __restrict__ enc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -42,6 +42,7 @@ struct SsSynthJob {
     const u64 *lhs_z, *rhs_z;                          // [2][n]
     StorageScan sc;                                    // D, S, R, E over the sorted records
     u64 n_block;
+    const u64* public_input;  // [4]: commitment of the compact closed-form input
     u64* trace;
     u32* hist;
 };
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(64) void k_ss_fill_boundary(const SsSynthJob* __res
         for (int col = SS_NSLOTS_BND_OUT; col < SS_G + SS_L; col++) TR(col, row) = 0;
     }
     const size_t rPI = bnd + SS_ROWOFF_PI;
-    for (int col = 0; col < SS_G + SS_L; col++) TR(col, rPI) = 0;  // the public input is not derived for this type yet
+    for (int col = 0; col < SS_G + SS_L; col++) TR(col, rPI) = col < 4 ? job.public_input[col] : 0;
 }
 
 #undef TR

@@ -1320,6 +1320,18 @@ extern "C" void zkw_decommit_witness_free(zkw_decommit_witness* w) {
 }
 
 // ------------------------------------------------------------------------------------------------ events sorter
+// a20 for the 4-wide log-queue circuits: compact closed-form inputs [ni][18] followed by the public inputs [ni][4]
+// in one allocation (ClosedFormInputCompactForm::from_full_form + commit, postprocessing/mod.rs:353-369)
+template <class T>
+static int closed_form_public_inputs(zkw_ctx* ctx, const typename T::Inst* d_inst, size_t ni, u64** cf_pi) {
+    if (!*cf_pi) HIP_TRY(hipMalloc((void**)cf_pi, ni * (COMPACT_FORM_LEN + 4) * sizeof(u64)));
+    u64 *compact = *cf_pi, *pis = *cf_pi + COMPACT_FORM_LEN * ni;
+    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, d_inst, ni, compact); }
+    ZKW_TRY(launch_check("k_closed_form_commitments"));
+    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, compact, ni, (u32)COMPACT_FORM_LEN, pis); }
+    return launch_check("k_commit_encodings");
+}
+
 struct zkw_events_witness {
     zkw_ctx* ctx = nullptr;
     size_t n = 0, n_instances = 0, n_result = 0;
@@ -1331,8 +1343,9 @@ struct zkw_events_witness {
     zkw_events_sorter_instance* instances = nullptr;
     zkw_queue_state4 result_in;  // state of the result queue before the block (host copy)
     u32* kept_prefix = nullptr;  // [n + 1], computed by the first synthesis call
+    u64* cf_pi = nullptr;        // compact forms [ni][18] | public inputs [ni][4]
     void release() {
-        void* ptrs[] = {sorted_q, result_q, enc_all, tails_all, challenges, lhs_z, rhs_z, instances, kept_prefix};
+        void* ptrs[] = {sorted_q, result_q, enc_all, tails_all, challenges, lhs_z, rhs_z, instances, kept_prefix, cf_pi};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -1439,8 +1452,9 @@ extern "C" int zkw_events_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, siz
         const zkw_log_query* d_q = nullptr;
         rc = ctx->in("evt_q", q, n, &d_q);
         if (rc == ZKW_OK) rc = events_run(ctx, w, d_q, rin);
-        if (rc == ZKW_OK) rc = ctx->sync_if_host();
     }
+    if (rc == ZKW_OK) rc = closed_form_public_inputs<CfEventsSorter>(ctx, w->instances, w->n_instances, &w->cf_pi);
+    if (rc == ZKW_OK) rc = ctx->sync_if_host();
     if (rc != ZKW_OK) {
         w->release();
         delete w;
@@ -1469,6 +1483,8 @@ static const void* evt_array(const zkw_events_witness* w, int what, size_t* byte
         case ZKW_EVT_LHS_Z: *bytes = n * 16; return w->lhs_z;
         case ZKW_EVT_RHS_Z: *bytes = n * 16; return w->rhs_z;
         case ZKW_EVT_INSTANCES: *bytes = w->n_instances * sizeof(zkw_events_sorter_instance); return w->instances;
+        case ZKW_EVT_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->cf_pi;
+        case ZKW_EVT_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->cf_pi + COMPACT_FORM_LEN * w->n_instances;
         default: *bytes = 0; return nullptr;
     }
 }
@@ -1483,7 +1499,7 @@ extern "C" const void* zkw_events_witness_device_ptr(const zkw_events_witness* w
 }
 extern "C" int zkw_events_witness_get(const zkw_events_witness* w, int what, void* dst, size_t dst_bytes) {
     if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_events_witness_get: null argument");
-    if (what < 0 || what > ZKW_EVT_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    if (what < 0 || what > ZKW_EVT_PUBLIC_INPUTS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
     size_t bytes = 0;
     const void* src = evt_array(w, what, &bytes);
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
@@ -1514,8 +1530,9 @@ struct zkw_demux_witness {
     u32* route_count = nullptr;  // [6][n] inclusive prefix counts per route (kept for synthesis)
     bool default_params = true;
     zkw_log_demux_instance* instances = nullptr;
+    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4]
     void release() {
-        void* ptrs[] = {out_q, enc_all, tails_all, d_offsets, route_count, instances};
+        void* ptrs[] = {out_q, enc_all, tails_all, d_offsets, route_count, instances, cf_pi};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -1600,8 +1617,9 @@ extern "C" int zkw_log_demux_build(zkw_ctx* ctx, const zkw_log_query* q, size_t 
         const zkw_log_query* d_q = nullptr;
         rc = ctx->in("dmx_q", q, n, &d_q);
         if (rc == ZKW_OK) rc = demux_run(ctx, w, d_q, p);
-        if (rc == ZKW_OK) rc = ctx->sync_if_host();
     }
+    if (rc == ZKW_OK) rc = closed_form_public_inputs<CfLogDemux>(ctx, w->instances, w->n_instances, &w->cf_pi);
+    if (rc == ZKW_OK) rc = ctx->sync_if_host();
     if (rc != ZKW_OK) {
         w->release();
         delete w;
@@ -1624,6 +1642,8 @@ static const void* dmx_array(const zkw_demux_witness* w, int what, size_t* bytes
         case ZKW_DMX_OUT_NEW_TAILS: *bytes = r * 32; return w->tails_all + 12 * n;
         case ZKW_DMX_OUT_OFFSETS: *bytes = 7 * 8; return w->d_offsets;
         case ZKW_DMX_INSTANCES: *bytes = w->n_instances * sizeof(zkw_log_demux_instance); return w->instances;
+        case ZKW_DMX_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->cf_pi;
+        case ZKW_DMX_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->cf_pi + COMPACT_FORM_LEN * w->n_instances;
         default: *bytes = 0; return nullptr;
     }
 }
@@ -1638,7 +1658,7 @@ extern "C" const void* zkw_demux_witness_device_ptr(const zkw_demux_witness* w, 
 }
 extern "C" int zkw_demux_witness_get(const zkw_demux_witness* w, int what, void* dst, size_t dst_bytes) {
     if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_demux_witness_get: null argument");
-    if (what < 0 || what > ZKW_DMX_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    if (what < 0 || what > ZKW_DMX_PUBLIC_INPUTS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
     size_t bytes = 0;
     const void* src = dmx_array(w, what, &bytes);
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
@@ -1669,8 +1689,9 @@ struct zkw_storage_witness {
     u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
     u32* scans = nullptr;  // [4][n]: D, S, R, E of k_storage_cells (kept for synthesis)
     zkw_storage_sorter_instance* instances = nullptr;
+    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4]
     void release() {
-        void* ptrs[] = {sorted_q, result_q, sorted_ext, enc_all, lhs_enc, tails_all, challenges, lhs_z, rhs_z, scans, instances};
+        void* ptrs[] = {sorted_q, result_q, sorted_ext, enc_all, lhs_enc, tails_all, challenges, lhs_z, rhs_z, scans, instances, cf_pi};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -1798,8 +1819,9 @@ extern "C" int zkw_storage_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, si
         const zkw_log_query* d_q = nullptr;
         rc = ctx->in("sto_q", q, n, &d_q);
         if (rc == ZKW_OK) rc = storage_run(ctx, w, d_q);
-        if (rc == ZKW_OK) rc = ctx->sync_if_host();
     }
+    if (rc == ZKW_OK) rc = closed_form_public_inputs<CfStorageSorter>(ctx, w->instances, w->n_instances, &w->cf_pi);
+    if (rc == ZKW_OK) rc = ctx->sync_if_host();
     if (rc != ZKW_OK) {
         w->release();
         delete w;
@@ -1829,6 +1851,8 @@ static const void* sto_array(const zkw_storage_witness* w, int what, size_t* byt
         case ZKW_STO_LHS_Z: *bytes = n * 16; return w->lhs_z;
         case ZKW_STO_RHS_Z: *bytes = n * 16; return w->rhs_z;
         case ZKW_STO_INSTANCES: *bytes = w->n_instances * sizeof(zkw_storage_sorter_instance); return w->instances;
+        case ZKW_STO_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->cf_pi;
+        case ZKW_STO_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->cf_pi + COMPACT_FORM_LEN * w->n_instances;
         default: *bytes = 0; return nullptr;
     }
 }
@@ -1843,7 +1867,7 @@ extern "C" const void* zkw_storage_witness_device_ptr(const zkw_storage_witness*
 }
 extern "C" int zkw_storage_witness_get(const zkw_storage_witness* w, int what, void* dst, size_t dst_bytes) {
     if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_storage_witness_get: null argument");
-    if (what < 0 || what > ZKW_STO_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    if (what < 0 || what > ZKW_STO_PUBLIC_INPUTS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
     size_t bytes = 0;
     const void* src = sto_array(w, what, &bytes);
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
@@ -2525,6 +2549,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
         j.n_block = n;
         memcpy(j.rq_tail_in, w->result_in.tail, 32);
         j.rq_len_in = w->result_in.length;
+        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + 256 * k;
     }
@@ -2588,6 +2613,7 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
         j.route_count = w->route_count;
         for (int c = 0; c < 7; c++) j.offsets[c] = w->offsets[c];
         j.n_block = n;
+        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + 256 * k;
     }
@@ -2646,6 +2672,7 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
         j.lhs_z = w->lhs_z; j.rhs_z = w->rhs_z;
         j.sc.D = reinterpret_cast<int*>(w->scans); j.sc.S = w->scans + n; j.sc.R = w->scans + 2 * n; j.sc.E = w->scans + 3 * n;
         j.n_block = n;
+        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + 256 * k;
     }

@@ -216,7 +216,8 @@ EVENTS_INSTANCE = np.dtype(
      ("intermediate_sorted_queue_state", QUEUE_STATE4), ("final_queue_state", QUEUE_STATE4),
      ("hidden_fsm_input", EVENTS_FSM), ("hidden_fsm_output", EVENTS_FSM), ("first_item", "<u8"), ("num_items", "<u8")])
 (EVT_SORTED_QUERIES, EVT_UNSORTED_ENC, EVT_SORTED_ENC, EVT_UNSORTED_OLD_TAILS, EVT_UNSORTED_NEW_TAILS, EVT_SORTED_OLD_TAILS,
- EVT_SORTED_NEW_TAILS, EVT_RESULT_QUERIES, EVT_RESULT_NEW_TAILS, EVT_CHALLENGES, EVT_LHS_Z, EVT_RHS_Z, EVT_INSTANCES) = range(13)
+ EVT_SORTED_NEW_TAILS, EVT_RESULT_QUERIES, EVT_RESULT_NEW_TAILS, EVT_CHALLENGES, EVT_LHS_Z, EVT_RHS_Z, EVT_INSTANCES,
+ EVT_COMPACT_FORMS, EVT_PUBLIC_INPUTS) = range(15)
 
 
 class EventsWitness:
@@ -225,7 +226,8 @@ class EventsWitness:
     _DTYPES = {EVT_SORTED_QUERIES: LOG_QUERY, EVT_RESULT_QUERIES: LOG_QUERY, EVT_INSTANCES: EVENTS_INSTANCE}
     _SHAPES = {EVT_UNSORTED_ENC: (-1, 20), EVT_SORTED_ENC: (-1, 20), EVT_UNSORTED_OLD_TAILS: (-1, 4),
                EVT_UNSORTED_NEW_TAILS: (-1, 4), EVT_SORTED_OLD_TAILS: (-1, 4), EVT_SORTED_NEW_TAILS: (-1, 4),
-               EVT_RESULT_NEW_TAILS: (-1, 4), EVT_CHALLENGES: (2, 21), EVT_LHS_Z: (2, -1), EVT_RHS_Z: (2, -1)}
+               EVT_RESULT_NEW_TAILS: (-1, 4), EVT_CHALLENGES: (2, 21), EVT_LHS_Z: (2, -1), EVT_RHS_Z: (2, -1),
+               EVT_COMPACT_FORMS: (-1, 18), EVT_PUBLIC_INPUTS: (-1, 4)}
 
     def __init__(self, ctx):
         self.ctx = ctx
@@ -267,7 +269,7 @@ DEMUX_INSTANCE = np.dtype(
      ("output_queue_state", QUEUE_STATE4, (6,)), ("hidden_fsm_input", DEMUX_FSM), ("hidden_fsm_output", DEMUX_FSM),
      ("first_item", "<u8"), ("num_items", "<u8")])
 (DMX_IN_ENC, DMX_IN_OLD_TAILS, DMX_IN_NEW_TAILS, DMX_OUT_QUERIES, DMX_OUT_ENC, DMX_OUT_OLD_TAILS, DMX_OUT_NEW_TAILS,
- DMX_OUT_OFFSETS, DMX_INSTANCES) = range(9)
+ DMX_OUT_OFFSETS, DMX_INSTANCES, DMX_COMPACT_FORMS, DMX_PUBLIC_INPUTS) = range(11)
 
 
 class DemuxWitness:
@@ -275,7 +277,7 @@ class DemuxWitness:
 
     _DTYPES = {DMX_OUT_QUERIES: LOG_QUERY, DMX_INSTANCES: DEMUX_INSTANCE}
     _SHAPES = {DMX_IN_ENC: (-1, 20), DMX_OUT_ENC: (-1, 20), DMX_IN_OLD_TAILS: (-1, 4), DMX_IN_NEW_TAILS: (-1, 4),
-               DMX_OUT_OLD_TAILS: (-1, 4), DMX_OUT_NEW_TAILS: (-1, 4)}
+               DMX_OUT_OLD_TAILS: (-1, 4), DMX_OUT_NEW_TAILS: (-1, 4), DMX_COMPACT_FORMS: (-1, 18), DMX_PUBLIC_INPUTS: (-1, 4)}
 
     def __init__(self, ctx):
         self.ctx = ctx
@@ -321,7 +323,7 @@ STORAGE_INSTANCE = np.dtype(
      ("first_item", "<u8"), ("num_items", "<u8")])
 (STO_SORTED_QUERIES, STO_SORTED_EXT_TS, STO_UNSORTED_ENC, STO_LHS_ENC, STO_SORTED_ENC, STO_UNSORTED_OLD_TAILS,
  STO_UNSORTED_NEW_TAILS, STO_SORTED_OLD_TAILS, STO_SORTED_NEW_TAILS, STO_RESULT_QUERIES, STO_RESULT_NEW_TAILS, STO_CHALLENGES,
- STO_LHS_Z, STO_RHS_Z, STO_INSTANCES) = range(15)
+ STO_LHS_Z, STO_RHS_Z, STO_INSTANCES, STO_COMPACT_FORMS, STO_PUBLIC_INPUTS) = range(17)
 
 
 class StorageWitness:
@@ -331,7 +333,8 @@ class StorageWitness:
                STO_SORTED_EXT_TS: np.dtype("<u4")}
     _SHAPES = {STO_UNSORTED_ENC: (-1, 20), STO_LHS_ENC: (-1, 20), STO_SORTED_ENC: (-1, 20), STO_UNSORTED_OLD_TAILS: (-1, 4),
                STO_UNSORTED_NEW_TAILS: (-1, 4), STO_SORTED_OLD_TAILS: (-1, 4), STO_SORTED_NEW_TAILS: (-1, 4),
-               STO_RESULT_NEW_TAILS: (-1, 4), STO_CHALLENGES: (2, 21), STO_LHS_Z: (2, -1), STO_RHS_Z: (2, -1)}
+               STO_RESULT_NEW_TAILS: (-1, 4), STO_CHALLENGES: (2, 21), STO_LHS_Z: (2, -1), STO_RHS_Z: (2, -1),
+               STO_COMPACT_FORMS: (-1, 18), STO_PUBLIC_INPUTS: (-1, 4)}
 
     def __init__(self, ctx):
         self.ctx = ctx

@@ -219,7 +219,9 @@ enum {
     ZKW_EVT_CHALLENGES = 9,         /* uint64_t[2][21]   */
     ZKW_EVT_LHS_Z = 10,             /* uint64_t[2][n]    */
     ZKW_EVT_RHS_Z = 11,
-    ZKW_EVT_INSTANCES = 12          /* zkw_events_sorter_instance[max(1, ceil(n/capacity))] */
+    ZKW_EVT_INSTANCES = 12,         /* zkw_events_sorter_instance[max(1, ceil(n/capacity))] */
+    ZKW_EVT_COMPACT_FORMS = 13,     /* uint64_t[n_instances][18]: see ZKW_RAM_COMPACT_FORMS */
+    ZKW_EVT_PUBLIC_INPUTS = 14      /* uint64_t[n_instances][4] */
 };
 size_t zkw_events_witness_num_instances(const zkw_events_witness *w);
 size_t zkw_events_witness_num_results(const zkw_events_witness *w);
@@ -246,7 +248,9 @@ enum {
     ZKW_DMX_OUT_OLD_TAILS = 5, /* uint64_t[routed][4]  */
     ZKW_DMX_OUT_NEW_TAILS = 6,
     ZKW_DMX_OUT_OFFSETS = 7,   /* uint64_t[7]: queue k = [offsets[k], offsets[k+1]) */
-    ZKW_DMX_INSTANCES = 8      /* zkw_log_demux_instance[max(1, ceil(n/capacity))] */
+    ZKW_DMX_INSTANCES = 8,     /* zkw_log_demux_instance[max(1, ceil(n/capacity))] */
+    ZKW_DMX_COMPACT_FORMS = 9, /* uint64_t[n_instances][18]: see ZKW_RAM_COMPACT_FORMS */
+    ZKW_DMX_PUBLIC_INPUTS = 10 /* uint64_t[n_instances][4] */
 };
 size_t zkw_demux_witness_num_instances(const zkw_demux_witness *w);
 size_t zkw_demux_witness_bytes(const zkw_demux_witness *w, int what);
@@ -278,7 +282,9 @@ enum {
     ZKW_STO_CHALLENGES = 11,        /* uint64_t[2][21] */
     ZKW_STO_LHS_Z = 12,             /* uint64_t[2][n] */
     ZKW_STO_RHS_Z = 13,
-    ZKW_STO_INSTANCES = 14          /* zkw_storage_sorter_instance[max(1, ceil(n/capacity))] */
+    ZKW_STO_INSTANCES = 14,         /* zkw_storage_sorter_instance[max(1, ceil(n/capacity))] */
+    ZKW_STO_COMPACT_FORMS = 15,     /* uint64_t[n_instances][18]: see ZKW_RAM_COMPACT_FORMS */
+    ZKW_STO_PUBLIC_INPUTS = 16      /* uint64_t[n_instances][4] */
 };
 size_t zkw_storage_witness_num_instances(const zkw_storage_witness *w);
 size_t zkw_storage_witness_num_results(const zkw_storage_witness *w);

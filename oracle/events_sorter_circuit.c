@@ -66,7 +66,7 @@ static zkw_log_query normalized(const zkw_log_query *p) { /* events_sort_dedup.r
 /* rq_tail_in / rq_len_in: state of the result queue before the block (NULL / 0 = empty), read for the first instance */
 int orc_events_sorter_synthesize(const zkw_events_sorter_instance *inst, const zkw_log_query *sorted_q, const uint64_t *unsorted_enc,
                                  const uint64_t *sorted_enc, const uint64_t *challenges /* [2][21] */, const uint64_t *rq_tail_in,
-                                 uint32_t rq_len_in, uint32_t capacity, size_t n_rows, uint64_t *trace) {
+                                 uint32_t rq_len_in, const uint64_t *public_input /* [4] or NULL */, uint32_t capacity, size_t n_rows, uint64_t *trace) {
     if (ES_MIN_ROWS(capacity) > n_rows) return -1;
     const size_t first = inst->first_item, m = inst->num_items;
     if (m > capacity) return -2;
@@ -243,6 +243,8 @@ int orc_events_sorter_synthesize(const zkw_events_sorter_instance *inst, const z
         if (cur.completion && !cur.z_end) return -7;
     }
 
+    if (public_input)
+        for (int k = 0; k < 4; k++) CELL(ES_PI_pi0 + k, bnd + ES_ROWOFF_PI) = public_input[k];
     for (int t = 0; t < 256; t++) CELL(ES_MULT_COL, t) = 0;
     for (int c = ES_G; c < ES_G + ES_L; c++)
         for (size_t r = 0; r < n_rows; r++) {

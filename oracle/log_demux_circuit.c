@@ -43,8 +43,8 @@ static void queue_op(uint64_t *trace, size_t n_rows, size_t r1, size_t r2, size_
     memcpy(out4, slots + 118, 32);
 }
 
-int orc_log_demux_synthesize(const zkw_log_demux_instance *inst, const uint64_t *in_enc, uint32_t capacity, size_t n_rows,
-                             uint64_t *trace) {
+int orc_log_demux_synthesize(const zkw_log_demux_instance *inst, const uint64_t *in_enc, const uint64_t *public_input /* [4] or NULL */, uint32_t capacity,
+        size_t n_rows, uint64_t *trace) {
     if (LD_MIN_ROWS(capacity) > n_rows) return -1;
     const size_t first = inst->first_item, m = inst->num_items;
     if (m > capacity) return -2;
@@ -160,6 +160,8 @@ int orc_log_demux_synthesize(const zkw_log_demux_instance *inst, const uint64_t 
         if (cur.completion && !cur.z_end) return -7;
     }
 
+    if (public_input)
+        for (int k = 0; k < 4; k++) CELL(LD_PI_pi0 + k, bnd + LD_ROWOFF_PI) = public_input[k];
     for (int t = 0; t < 256; t++) CELL(LD_MULT_COL, t) = 0;
     for (int c = LD_G; c < LD_G + LD_L; c++)
         for (size_t r = 0; r < n_rows; r++) {

@@ -165,15 +165,19 @@ uint64_t orc_decommit_sorter_check(const uint64_t *trace, uint32_t capacity, siz
 /* ---- EventsSorter / L1MessagesSorter synthesis + check (a21, circuit types 11 and 12), see events_sorter_circuit.c */
 int orc_events_sorter_synthesize(const zkw_events_sorter_instance *inst, const zkw_log_query *sorted_q, const uint64_t *unsorted_enc,
                                  const uint64_t *sorted_enc, const uint64_t *challenges, const uint64_t *rq_tail_in,
-                                 uint32_t rq_len_in, uint32_t capacity, size_t n_rows, uint64_t *trace);
+                                 uint32_t rq_len_in, const uint64_t *public_input, uint32_t capacity, size_t n_rows, uint64_t *trace);
 uint64_t orc_events_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 /* log_demux_circuit.c: LogDemuxer synthesis (circuit type 4) */
-int orc_log_demux_synthesize(const zkw_log_demux_instance *inst, const uint64_t *in_enc, uint32_t capacity, size_t n_rows,
-                             uint64_t *trace);
+int orc_log_demux_synthesize(const zkw_log_demux_instance *inst, const uint64_t *in_enc, const uint64_t *public_input,
+                             uint32_t capacity, size_t n_rows, uint64_t *trace);
+void orc_log_demux_public_inputs(const zkw_log_demux_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
+void orc_events_sorter_public_inputs(const zkw_events_sorter_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
+void orc_storage_sorter_public_inputs(const zkw_storage_sorter_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
 uint64_t orc_log_demux_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 /* storage_sorter_circuit.c: StorageSorter synthesis (circuit type 9) */
 int orc_storage_sorter_synthesize(const zkw_storage_sorter_instance *inst, const uint64_t *unsorted_enc, const uint64_t *sorted_enc,
-                                  const uint64_t *challenges, uint32_t capacity, size_t n_rows, uint64_t *trace);
+                                  const uint64_t *challenges, const uint64_t *public_input, uint32_t capacity, size_t n_rows,
+                                  uint64_t *trace);
 uint64_t orc_storage_sorter_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 
 /* ---- sparse storage tree + StorageApplication builder (a17), see storage_application.c */

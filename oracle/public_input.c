@@ -147,3 +147,112 @@ void orc_ds_public_inputs(const zkw_decommit_sorter_instance *inst, size_t n, ui
         orc_commit_var_length(cf, 18, pi + 4 * i);
     }
 }
+
+/* ---- the 4-wide log-queue circuits (LogDemuxer 4, StorageSorter 9, EventsSorter / L1MessagesSorter 11 / 12). Field
+   order = the struct declarations as mirrored by include/zkw_types.h (the reference's struct literals: log_demux.rs:
+   283-301, storage_sort_dedup.rs:577-612, events_sort_dedup.rs:426-455); LogQuery in the declaration order of the
+   in-circuit struct (absent crate). PARITY UNPINNED like the types above. */
+static size_t put_queue4(const zkw_queue_state4 *q, uint64_t *o) {
+    memcpy(o, q->head, 32);
+    memcpy(o + 4, q->tail, 32);
+    o[8] = q->length;
+    return 9;
+}
+static size_t put_log_query(const zkw_log_query *q, uint64_t *o) {
+    size_t m = 0;
+    for (int k = 0; k < 5; k++) o[m++] = q->address[k];
+    for (int k = 0; k < 8; k++) o[m++] = q->key[k];
+    for (int k = 0; k < 8; k++) o[m++] = q->read_value[k];
+    for (int k = 0; k < 8; k++) o[m++] = q->written_value[k];
+    o[m++] = q->rw_flag ? 1 : 0;
+    o[m++] = q->aux_byte;
+    o[m++] = q->rollback ? 1 : 0;
+    o[m++] = q->is_service ? 1 : 0;
+    o[m++] = q->shard_id;
+    o[m++] = q->tx_number_in_block;
+    o[m++] = q->timestamp;
+    return m;
+}
+static void compact_and_pi(int start, int completion, const uint64_t *in, size_t n_in, const uint64_t *out, size_t n_out,
+                           const uint64_t *fi, size_t n_fi, const uint64_t *fo, size_t n_fo, uint64_t cf[18], uint64_t pi[4]) {
+    cf[0] = start ? 1 : 0;
+    cf[1] = completion ? 1 : 0;
+    orc_commit_var_length(in, n_in, cf + 2);
+    orc_commit_var_length(out, n_out, cf + 6);
+    orc_commit_var_length(fi, n_fi, cf + 10);
+    orc_commit_var_length(fo, n_fo, cf + 14);
+    orc_commit_var_length(cf, 18, pi);
+}
+
+static size_t ld_fsm(const zkw_log_demux_fsm *f, uint64_t *o) {
+    size_t m = put_queue4(&f->initial_log_queue_state, o);
+    for (int c = 0; c < ZKW_DEMUX_NUM_QUEUES; c++) m += put_queue4(&f->queue_state[c], o + m);
+    return m;
+}
+void orc_log_demux_public_inputs(const zkw_log_demux_instance *inst, size_t n, uint64_t *compact, uint64_t *pi) {
+    const zkw_log_demux_instance *first = inst;
+    uint64_t in[16], out[64], fi[64], fo[64];
+    for (size_t i = 0; i < n; i++) {
+        if (inst[i].start_flag) first = inst + i;
+        const size_t n_in = put_queue4(&first->initial_log_queue_state, in);
+        size_t n_out = 0;
+        for (int c = 0; c < ZKW_DEMUX_NUM_QUEUES; c++) n_out += put_queue4(&inst[i].output_queue_state[c], out + n_out);
+        const size_t n_fi = ld_fsm(&inst[i].hidden_fsm_input, fi), n_fo = ld_fsm(&inst[i].hidden_fsm_output, fo);
+        compact_and_pi(inst[i].start_flag, inst[i].completion_flag, in, n_in, out, n_out, fi, n_fi, fo, n_fo, compact + 18 * i, pi + 4 * i);
+    }
+}
+
+static size_t es_fsm(const zkw_events_sorter_fsm *f, uint64_t *o) {
+    size_t m = 0;
+    for (int r = 0; r < 2; r++) o[m++] = f->lhs_accumulator[r];
+    for (int r = 0; r < 2; r++) o[m++] = f->rhs_accumulator[r];
+    m += put_queue4(&f->initial_unsorted_queue_state, o + m);
+    m += put_queue4(&f->intermediate_sorted_queue_state, o + m);
+    m += put_queue4(&f->final_result_queue_state, o + m);
+    o[m++] = f->previous_key;
+    return m + put_log_query(&f->previous_item, o + m);
+}
+void orc_events_sorter_public_inputs(const zkw_events_sorter_instance *inst, size_t n, uint64_t *compact, uint64_t *pi) {
+    const zkw_events_sorter_instance *first = inst;
+    uint64_t in[32], out[16], fi[80], fo[80];
+    for (size_t i = 0; i < n; i++) {
+        if (inst[i].start_flag) first = inst + i;
+        size_t n_in = put_queue4(&first->initial_log_queue_state, in);
+        n_in += put_queue4(&first->intermediate_sorted_queue_state, in + n_in);
+        const size_t n_out = put_queue4(&inst[i].final_queue_state, out);
+        const size_t n_fi = es_fsm(&inst[i].hidden_fsm_input, fi), n_fo = es_fsm(&inst[i].hidden_fsm_output, fo);
+        compact_and_pi(inst[i].start_flag, inst[i].completion_flag, in, n_in, out, n_out, fi, n_fi, fo, n_fo, compact + 18 * i, pi + 4 * i);
+    }
+}
+
+static size_t ss_fsm(const zkw_storage_sorter_fsm *f, uint64_t *o) {
+    size_t m = 0;
+    for (int r = 0; r < 2; r++) o[m++] = f->lhs_accumulator[r];
+    for (int r = 0; r < 2; r++) o[m++] = f->rhs_accumulator[r];
+    m += put_queue4(&f->current_unsorted_queue_state, o + m);
+    m += put_queue4(&f->current_intermediate_sorted_queue_state, o + m);
+    m += put_queue4(&f->current_final_sorted_queue_state, o + m);
+    o[m++] = f->cycle_idx;
+    for (int k = 0; k < ZKW_STORAGE_PACKED_KEY_LENGTH; k++) o[m++] = f->previous_packed_key[k];
+    for (int k = 0; k < 8; k++) o[m++] = f->previous_key[k];
+    for (int k = 0; k < 5; k++) o[m++] = f->previous_address[k];
+    o[m++] = f->previous_timestamp;
+    o[m++] = f->this_cell_has_explicit_read_and_rollback_depth_zero ? 1 : 0;
+    for (int k = 0; k < 8; k++) o[m++] = f->this_cell_base_value[k];
+    for (int k = 0; k < 8; k++) o[m++] = f->this_cell_current_value[k];
+    o[m++] = f->this_cell_current_depth;
+    return m;
+}
+void orc_storage_sorter_public_inputs(const zkw_storage_sorter_instance *inst, size_t n, uint64_t *compact, uint64_t *pi) {
+    const zkw_storage_sorter_instance *first = inst;
+    uint64_t in[32], out[16], fi[80], fo[80];
+    for (size_t i = 0; i < n; i++) {
+        if (inst[i].start_flag) first = inst + i;
+        in[0] = first->shard_id_to_process;
+        size_t n_in = 1 + put_queue4(&first->unsorted_log_queue_state, in + 1);
+        n_in += put_queue4(&first->intermediate_sorted_queue_state, in + n_in);
+        const size_t n_out = put_queue4(&inst[i].final_sorted_queue_state, out);
+        const size_t n_fi = ss_fsm(&inst[i].hidden_fsm_input, fi), n_fo = ss_fsm(&inst[i].hidden_fsm_output, fo);
+        compact_and_pi(inst[i].start_flag, inst[i].completion_flag, in, n_in, out, n_out, fi, n_fi, fo, n_fo, compact + 18 * i, pi + 4 * i);
+    }
+}

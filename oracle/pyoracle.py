@@ -701,8 +701,9 @@ def events_sorter_synthesize(build_out, instance_index, capacity, n_rows):
     inst = o["instances"][instance_index:instance_index + 1]
     f = lib().orc_events_sorter_synthesize
     f.restype = C.c_int
+    pi = events_sorter_public_inputs(o["instances"])[1][instance_index:instance_index + 1].copy()
     rc = f(_p(inst), _p(o["sorted_q"]), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), None, C.c_uint32(0),
-           C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+           _p(pi), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_events_sorter_synthesize failed: {rc}")
     return trace
@@ -729,7 +730,8 @@ def log_demux_synthesize(build_out, instance_index, capacity, n_rows):
     enc = o["in_enc"] if o["in_enc"].size else np.zeros((1, 20), np.uint64)
     f = lib().orc_log_demux_synthesize
     f.restype = C.c_int
-    rc = f(_p(inst), _p(enc), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+    pi = log_demux_public_inputs(o["instances"])[1][instance_index:instance_index + 1].copy()
+    rc = f(_p(inst), _p(enc), _p(pi), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_log_demux_synthesize failed: {rc}")
     return trace
@@ -755,7 +757,9 @@ def storage_sorter_synthesize(build_out, instance_index, capacity, n_rows):
     inst = o["instances"][instance_index:instance_index + 1]
     f = lib().orc_storage_sorter_synthesize
     f.restype = C.c_int
-    rc = f(_p(inst), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+    pi = storage_sorter_public_inputs(o["instances"])[1][instance_index:instance_index + 1].copy()
+    rc = f(_p(inst), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), _p(pi), C.c_uint32(capacity), C.c_size_t(n_rows),
+           _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_storage_sorter_synthesize failed: {rc}")
     return trace
@@ -769,3 +773,24 @@ def storage_sorter_check(trace, capacity):
     bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
     v = first_bad.value
     return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+def _public_inputs(fn, instances):
+    instances = np.ascontiguousarray(instances)
+    n = instances.size
+    compact, pi = np.zeros((n, 18), np.uint64), np.zeros((n, 4), np.uint64)
+    getattr(lib(), fn)(_p(instances), C.c_size_t(n), _p(compact), _p(pi))
+    return compact, pi
+
+
+def log_demux_public_inputs(instances):
+    """(compact closed-form inputs [n][18], public inputs [n][4]) of a block's LogDemuxer instances"""
+    return _public_inputs("orc_log_demux_public_inputs", instances)
+
+
+def events_sorter_public_inputs(instances):
+    return _public_inputs("orc_events_sorter_public_inputs", instances)
+
+
+def storage_sorter_public_inputs(instances):
+    return _public_inputs("orc_storage_sorter_public_inputs", instances)

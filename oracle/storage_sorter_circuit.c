@@ -98,7 +98,7 @@ static void emit_record(const ss_regs *r, ss_emit *e) {
     v.W##14 = (e).w[14]; v.W##15 = (e).w[15]; v.W##16 = (e).w[16]; v.W##17 = (e).w[17]; v.W##18 = (e).w[18]; v.W##19 = (e).w[19]; } while (0)
 
 int orc_storage_sorter_synthesize(const zkw_storage_sorter_instance *inst, const uint64_t *unsorted_enc, const uint64_t *sorted_enc,
-                                  const uint64_t *challenges /* [2][21] */, uint32_t capacity, size_t n_rows, uint64_t *trace) {
+                                  const uint64_t *challenges /* [2][21] */, const uint64_t *public_input /* [4] or NULL */, uint32_t capacity, size_t n_rows, uint64_t *trace) {
     if (SS_MIN_ROWS(capacity) > n_rows) return -1;
     const size_t first = inst->first_item, m = inst->num_items;
     if (m > capacity) return -2;
@@ -300,6 +300,8 @@ int orc_storage_sorter_synthesize(const zkw_storage_sorter_instance *inst, const
         if (cur.completion && (pr.lhs[0] != pr.rhs[0] || pr.lhs[1] != pr.rhs[1])) return -11;
     }
 
+    if (public_input)
+        for (int k = 0; k < 4; k++) CELL(SS_PI_pi0 + k, bnd + SS_ROWOFF_PI) = public_input[k];
     for (int t = 0; t < 256; t++) CELL(SS_MULT_COL, t) = 0;
     for (int c = SS_G; c < SS_G + SS_L; c++)
         for (size_t r = 0; r < n_rows; r++) {

@@ -86,3 +86,16 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
         hip.hipMemcpy(C.c_void_p(addr), old.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
     assert ctx.check_if_satisfied_events_sorter(t, 0, capacity)[0] == 0
     t.free()
+
+
+def test_compact_forms_and_public_inputs(ctx, oracle):
+    """a20: compact closed-form inputs and public-input commitments of every instance, GPU vs oracle"""
+    from era_zkevm_test_harness_amd import native as nv
+
+    q = synthetic.events_trace(80, 0.3, seed=11)
+    o = oracle.events_sorter_build(q, 32)
+    w = ctx.compute_events_dedup_and_sort(q, 32)
+    compact, pi = oracle.events_sorter_public_inputs(o["instances"])
+    assert o["instances"].size >= 3
+    assert np.array_equal(w.get(nv.EVT_COMPACT_FORMS), compact)
+    assert np.array_equal(w.get(nv.EVT_PUBLIC_INPUTS), pi)

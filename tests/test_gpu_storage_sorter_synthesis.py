@@ -71,7 +71,7 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
     assert ctx.check_if_satisfied_storage_sorter(t, 0, capacity)[0] == 0
     host = t.get(0)
     rng = np.random.default_rng(2)
-    used = np.argwhere(host[:148, :22 * 64 + 6] != 0)
+    used = np.argwhere(host[:148, :22 * 64 + 5] != 0)  # not the (unconstrained) PI row
     base = native.load().zkw_trace_device_ptr(t.handle, 0)
     hip = C.CDLL("libamdhip64.so")
     for _ in range(25):
@@ -85,3 +85,16 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
         hip.hipMemcpy(C.c_void_p(addr), old.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
     assert ctx.check_if_satisfied_storage_sorter(t, 0, capacity)[0] == 0
     t.free()
+
+
+def test_compact_forms_and_public_inputs(ctx, oracle):
+    """a20: compact closed-form inputs and public-input commitments of every instance, GPU vs oracle"""
+    from era_zkevm_test_harness_amd import native as nv
+
+    q = synthetic.storage_trace(100, 20, seed=11)
+    o = oracle.storage_sorter_build(q, 32)
+    w = ctx.compute_storage_dedup_and_sort(q, 32)
+    compact, pi = oracle.storage_sorter_public_inputs(o["instances"])
+    assert o["instances"].size >= 3
+    assert np.array_equal(w.get(nv.STO_COMPACT_FORMS), compact)
+    assert np.array_equal(w.get(nv.STO_PUBLIC_INPUTS), pi)

@@ -63,7 +63,7 @@ def test_checker_notices_tampering(oracle):
     t = oracle.log_demux_synthesize(o, 0, capacity, n_rows)
     assert oracle.log_demux_check(t, capacity)[0] == 0
     rng = np.random.default_rng(1)
-    used = [(c, r) for c in range(150) for r in range(_bnd(capacity) + 3) if t[c, r] != 0]
+    used = [(c, r) for c in range(150) for r in range(_bnd(capacity) + 2) if t[c, r] != 0]  # the PI row is unconstrained
     for _ in range(40):
         c, r = used[rng.integers(len(used))]
         t2 = t.copy()
@@ -85,3 +85,19 @@ def test_misrouted_record_is_rejected(oracle):
     t[col["r_ev"], row_r + i] = 0
     t[col["r_l1"], row_r + i] = 1
     assert oracle.log_demux_check(t, capacity)[0] > 0
+
+
+def test_public_input_row_and_compact_forms(oracle):
+    """the PI row carries the commitment of the compact closed-form input; flags and the shared observable input
+    behave as CircuitMaker::process prescribes (postprocessing/mod.rs:353-369)"""
+    capacity, n_rows = 32, 1024
+    q = synthetic.mixed_log_queue(80, seed=7)
+    o = oracle.log_demux_build(q, capacity)
+    compact, pi = oracle.log_demux_public_inputs(o["instances"])
+    n_inst = o["instances"].size
+    assert n_inst == 3 and compact[0, 0] == 1 and compact[-1, 1] == 1 and compact[1, 0] == 0 and compact[0, 1] == 0
+    assert all((compact[i, 2:6] == compact[0, 2:6]).all() for i in range(n_inst))  # one observable input per block
+    assert all((compact[i, 10:14] == compact[i - 1, 14:18]).all() for i in range(1, n_inst))  # fsm_in = previous fsm_out
+    assert len({tuple(p) for p in pi.tolist()}) == n_inst
+    t = oracle.log_demux_synthesize(o, 1, capacity, n_rows)
+    assert t[:4, _bnd(capacity) + 2].tolist() == pi[1].tolist()
