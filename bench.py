@@ -285,7 +285,7 @@ def main():
                           "achieved_GBps": synth_gbs, "frac_of_hbm_peak": synth_gbs / HBM_PEAK_GBS if synth_gbs else None,
                           "per_kernel": hbm_kernels},
             "hbm_used_GB": (total_mem - free_after) / 1e9,
-            "poseidon2_perm_per_s": 2 * B * n * args.steps / dt,
+            "poseidon2_perm_per_s": 2 * items * chain_cnt / (chain_ms * 1e-3) if chain_ms else None,  # inside the chain launches
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
         }
         if not args.no_cpu_baseline:
