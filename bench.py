@@ -114,12 +114,12 @@ def main():
     ring_p = max(2, args.ring // P)
     if B <= 0:
         free, _total = torch.cuda.mem_get_info(dev)
-        # resident per query: input 48 + sorted copy 48 + two encodings 2 x 64 + capacity words of the tails 2 x 32 +
-        # grand products 2 x 16 = 320 bytes (sort scratch aliases arrays that are filled later). Cap: 4096 blocks =
-        # 8192 queue chains in flight. The chain kernel is serial per queue (14.7 us per item whatever the number of
-        # chains, up to ~8 400 of them), so a step wants as many concurrent queues as fit the HBM.
-        per_block = int(n * 330)
-        B = int(max(16, min(4096, (0.90 * free - P * ring_p * 1.25e9) // per_block)))
+        # resident per query: input 48 + sorted copy 48 + capacity words of the tails 2 x 32 + grand products 2 x 16 =
+        # 192 bytes (no encodings are kept: every kernel re-encodes the 48-byte query; sort scratch aliases arrays that
+        # are filled later). The chain kernel is serial per queue, so a step wants as many concurrent queues as fit.
+        per_block = int(n * 200)
+        cap = int(os.environ.get("ZKW_MAX_BLOCKS", "16384"))
+        B = int(max(16, min(cap, (0.90 * free - P * ring_p * 1.25e9) // per_block)))
         B = parallel.min_over_ranks(B, dev)  # every rank runs the same batch (weak scaling, equal record counts)
     B = max(P, B // P * P)
     Bp = B // P
@@ -231,14 +231,14 @@ def main():
         cell = 8 * stride * per_launch_inst            # one column of one region, all instances of a launch
         wit = per_launch_inst * n                      # witness items read by a launch
         alg_bytes = {
-            "k_chain_full": 2 * items * (64 + 32),            # per chain item: 8 words in, 4 capacity words out
-            "k_chain_full_q4": 2 * items * (64 + 32),
-            "k_gp_local": 2 * items * (64 + 16),              # rows read once, both repetitions written
+            "k_chain_full": 2 * items * (48 + 32),            # per chain item: the 48-byte query in, 4 capacity words out
+            "k_chain_full_q4": 2 * items * (48 + 32),
+            "k_gp_local": 2 * items * (48 + 16),              # queries read once, both repetitions written
             "k_gp_apply": 2 * items * 32,
             "k_encode_mem": items * (48 + 64),
-            "k_gather_encode": items * (48 + 4 + 48 + 64),
-            "k_ram_fill_poseidon": 148 * cell + wit * (64 + 48 + 32),   # one Poseidon2 region per launch
-            "k_ram_fill_A": 148 * cell + wit * (64 + 48 + 32),
+            "k_gather_encode": items * (48 + 4 + 48),
+            "k_ram_fill_poseidon": 148 * cell + wit * (48 + 32),        # one Poseidon2 region per launch
+            "k_ram_fill_A": 148 * cell + wit * (48 + 48 + 32),
             "k_ram_fill_B": 148 * cell + wit * 96,
             "k_ram_fill_C": 148 * cell + wit * 96,
             "k_ram_fill_D": 148 * cell + 48 * cell,           # reads the queue tails back from the Poseidon2 rows

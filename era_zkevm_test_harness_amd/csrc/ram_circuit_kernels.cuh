@@ -21,8 +21,7 @@ namespace zkw {
 struct SynthJob {
     const zkw_ram_instance* inst;  // device
     const zkw_mem_query* sorted_q;  // block-wide arrays (device), indexed by item
-    const u64* unsorted_enc;
-    const u64* sorted_enc;
+    const zkw_mem_query* unsorted_q;  // the block's queue in its original order; encodings are computed on the fly
     const u64* unsorted_caps;  // [n_block][4] capacity words of the unsorted queue tail after every item
     const u64* sorted_caps;
     const u64* u_mark;         // [12] full unsorted / sorted queue tail after this instance's last item
@@ -135,13 +134,11 @@ __global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __rest
         const size_t first = in->first_item, m = in->num_items;
         const bool can_pop = i < m;
         const size_t row = (size_t)(SIDE == 0 ? RC_ROW_PU : RC_ROW_PS) * RC_REGION_STRIDE(capacity) + i;
-        const u64* enc = SIDE == 0 ? job.unsorted_enc : job.sorted_enc;
+        const zkw_mem_query* qs = SIDE == 0 ? job.unsorted_q : job.sorted_q;
         const u64* caps = SIDE == 0 ? job.unsorted_caps : job.sorted_caps;
         u64 s[12];
         if (can_pop) {
-            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(enc + 8 * (first + i));
-#pragma unroll
-            for (int k = 0; k < 4; k++) { ulonglong2 w = src[k]; s[2 * k] = w.x; s[2 * k + 1] = w.y; }
+            encode_raw_query(load_raw_query(qs + first + i), s);
         } else {
 #pragma unroll
             for (int k = 0; k < 8; k++) s[k] = 0;
@@ -204,11 +201,7 @@ __device__ __forceinline__ void cycle_ctx(const SynthJob& job, u32 i, CycleCtx& 
     if (c.can_pop) {
         load_query(job.sorted_q + first + i, c.q);
         encode_mem_query(c.q, c.es);
-        if (want_eu) {
-            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(job.unsorted_enc + 8 * (first + i));
-#pragma unroll
-            for (int k = 0; k < 4; k++) { ulonglong2 w = src[k]; c.eu[2 * k] = w.x; c.eu[2 * k + 1] = w.y; }
-        }
+        if (want_eu) encode_raw_query(load_raw_query(job.unsorted_q + first + i), c.eu);
     }
     if (i == 0) {
         const zkw_ram_fsm& f = in->hidden_fsm_input;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_encode_mem(const zkw_mem_query* __restr
 // that every chain gets its own SIMD issue slot when chains are few). tails[i] = permute(enc[i] ||
 // capacity(tails[i-1])). The absorb loads are prefetched one item ahead; stores are fire-and-forget.
 struct ChainJob {
-    const u64* enc;      // [n][8]
+    const u64* enc;      // [n][8], or nullptr: the items are memory queries, encoded on the fly from `q`
     u64* tails;          // [n][12], or nullptr when only the compact outputs below are wanted
     const u64* tail_in;  // [12] or nullptr (= zeros)
     u64 n;
@@ -65,7 +65,29 @@ struct ChainJob {
     u64* caps;           // [n][4] elements 8..11 of every tail, or nullptr
     u64* marks;          // [ceil(n / period)][12] full tails at items period-1, 2*period-1, ... and n-1, or nullptr
     u64 period;
+    const zkw_mem_query* q;  // [n] when enc == nullptr (the RAM builder keeps no encodings: 48 B per item instead of 64)
 };
+
+// a memory query as three 16-byte words, and word g (0..7) of its encoding (memory_query.rs:24-118)
+struct RawQuery { uint4 a, b, c; };
+__device__ __forceinline__ RawQuery load_raw_query(const zkw_mem_query* q) {
+    const uint4* src = reinterpret_cast<const uint4*>(q);
+    RawQuery r;
+    r.a = src[0]; r.b = src[1]; r.c = src[2];
+    return r;
+}
+__device__ __forceinline__ void encode_raw_query(const RawQuery& r, u64 e[8]) {
+    zkw_mem_query m;
+    uint4* dm = reinterpret_cast<uint4*>(&m);
+    dm[0] = r.a; dm[1] = r.b; dm[2] = r.c;
+    encode_mem_query(m, e);
+}
+__device__ __forceinline__ u64 pick8(const u64 e[8], int g) {
+    u64 v = e[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) v = g == k ? e[k] : v;
+    return v;
+}
 
 // The stores of item i are issued at the top of iteration i + 1, before the prefetch of item i + 2: gfx9 counts
 // loads and stores in one in-order vmcnt, so consuming the prefetched encoding waits for every earlier store too.
@@ -87,7 +109,13 @@ __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ 
     if (chain < n_jobs) job = jobs[chain];
     u64 x = (co.active && job.tail_in) ? job.tail_in[g] : 0;
     const bool absorbs = g < 8;
-    u64 e_next = (absorbs && job.n > 0) ? job.enc[g] : 0;
+    const bool from_q = job.enc == nullptr;
+    RawQuery rq_next;
+    rq_next.a = rq_next.b = rq_next.c = make_uint4(0, 0, 0, 0);
+    u64 e_next = 0;
+    if (absorbs && job.n > 0) {
+        if (from_q) rq_next = load_raw_query(job.q); else e_next = job.enc[g];
+    }
     u64 next_mark = job.marks ? job.period : ~0ull, mark_idx = 0;  // item count at which the next full tail is kept
     u64 pend = 0, pend_i = 0;  // canonical tail of the previous item, not stored yet
     bool have_pend = false, pend_mark = false;
@@ -104,8 +132,15 @@ __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ 
     for (u64 i = 0; __any(i < job.n); i++) {
         const bool live = i < job.n;
         u64 e = e_next;
+        if (from_q) {
+            u64 ew[8];
+            encode_raw_query(rq_next, ew);
+            e = pick8(ew, g);
+        }
         flush();
-        if (absorbs && i + 1 < job.n) e_next = job.enc[8 * (i + 1) + g];
+        if (absorbs && i + 1 < job.n) {
+            if (from_q) rq_next = load_raw_query(job.q + i + 1); else e_next = job.enc[8 * (i + 1) + g];
+        }
         u64 y = co.permute(absorbs ? e : x);  // AbsorptionModeOverwrite
         if (live) {
             x = y;
@@ -133,7 +168,12 @@ __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict
 #pragma unroll
     for (int c = 0; c < 3; c++) x[c] = job.tail_in ? job.tail_in[4 * c + j] : 0;
     u64 e0 = 0, e1 = 0;
-    if (job.n > 0) { e0 = job.enc[j]; e1 = job.enc[4 + j]; }
+    const bool from_q = job.enc == nullptr;
+    RawQuery rq_next;
+    rq_next.a = rq_next.b = rq_next.c = make_uint4(0, 0, 0, 0);
+    if (job.n > 0) {
+        if (from_q) rq_next = load_raw_query(job.q); else { e0 = job.enc[j]; e1 = job.enc[4 + j]; }
+    }
     u64 next_mark = job.marks ? job.period : ~0ull, mark_idx = 0;
     u64 pend[3] = {0, 0, 0}, pend_i = 0;
     bool have_pend = false, pend_mark = false;
@@ -150,9 +190,17 @@ __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict
     };
     for (u64 i = 0; __any(i < job.n); i++) {
         const bool live = i < job.n;
+        if (from_q) {
+            u64 ew[8];
+            encode_raw_query(rq_next, ew);
+            e0 = pick8(ew, j);
+            e1 = pick8(ew, 4 + j);
+        }
         u64 y[3] = {e0, e1, x[2]};  // AbsorptionModeOverwrite: rate part replaced, capacity kept
         flush();
-        if (i + 1 < job.n) { e0 = job.enc[8 * (i + 1) + j]; e1 = job.enc[8 * (i + 1) + 4 + j]; }
+        if (i + 1 < job.n) {
+            if (from_q) rq_next = load_raw_query(job.q + i + 1); else { e0 = job.enc[8 * (i + 1) + j]; e1 = job.enc[8 * (i + 1) + 4 + j]; }
+        }
         co.permute(y);
         if (live) {
 #pragma unroll
@@ -221,12 +269,13 @@ constexpr int GP_SLABS = 4;
 constexpr int GP_TILE = GP_BLOCK * GP_SLABS;
 
 struct GpSeg {
-    const u64* rows;   // [n][W]
+    const u64* rows;   // [n][W], or nullptr: W = 8 and the rows are the encodings of the memory queries `mem_q`
     u64* z;            // [n_reps][n]
     const u64* chal;   // [n_reps][W+1]
     u64 n;
     u32 first_tile;    // index of this segment's first tile in the launch
     u32 n_tiles;
+    const zkw_mem_query* mem_q;  // [n] when rows == nullptr
 };
 struct GpTile {
     u32 seg;
@@ -266,9 +315,16 @@ __global__ __launch_bounds__(GP_BLOCK) void k_gp_local(const GpSeg* __restrict__
         for (int r = 0; r < REPS; r++) term[r] = 1;  // neutral for rows past the end
         if (live) {
             u64 e[W];
-            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(seg.rows + row * W);
+            if (W == 8 && seg.rows == nullptr) {
+                u64 e8[8];
+                encode_raw_query(load_raw_query(seg.mem_q + row), e8);
 #pragma unroll
-            for (int k = 0; k < W / 2; k++) { ulonglong2 w = src[k]; e[2 * k] = w.x; e[2 * k + 1] = w.y; }
+                for (int k = 0; k < (W < 8 ? W : 8); k++) e[k] = e8[k];
+            } else {
+                const ulonglong2* src = reinterpret_cast<const ulonglong2*>(seg.rows + row * W);
+#pragma unroll
+                for (int k = 0; k < W / 2; k++) { ulonglong2 w = src[k]; e[2 * k] = w.x; e[2 * k + 1] = w.y; }
+            }
 #pragma unroll
             for (int r = 0; r < REPS; r++) {
                 u64 acc = sh_ch[r][W];
@@ -373,6 +429,7 @@ __global__ __launch_bounds__(256) void k_gather_encode(const zkw_mem_query* __re
     zkw_mem_query m;
     uint4* dm = reinterpret_cast<uint4*>(&m);
     dm[0] = w0; dm[1] = w1; dm[2] = w2;
+    if (!sorted_enc) return;
     u64 e[8];
     encode_mem_query(m, e);
     ulonglong2* o = reinterpret_cast<ulonglong2*>(sorted_enc + 8 * i);

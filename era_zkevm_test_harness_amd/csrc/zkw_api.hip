@@ -626,7 +626,14 @@ struct zkw_ram_witness {
     size_t total = 0, n_instances = 0;
     // owned device arrays
     zkw_mem_query* sorted_q = nullptr;
+    // The queue in its original order. Device-pointer mode: the CALLER's array (it must stay valid and unchanged
+    // while the witness is synthesized or read); host-pointer mode: a copy owned by the witness. The builder keeps no
+    // encodings (64 B per item and side): the chain, grand-product and fill kernels encode the 48-byte queries on the
+    // fly; the [total][8] arrays of the C ABI are materialised on first access (ram_encodings).
+    const zkw_mem_query* unsorted_q = nullptr;
+    zkw_mem_query* owned_q = nullptr;
     u64 *unsorted_enc = nullptr, *sorted_enc = nullptr;
+    bool enc_valid = false;
     // queue tails, compact: capacity words of every tail [total][4] + full tails at instance ends [n_instances][12];
     // the full [total][12] arrays of the C ABI are expanded on first access (ram_full_tails)
     u64 *unsorted_caps = nullptr, *sorted_caps = nullptr, *unsorted_marks = nullptr, *sorted_marks = nullptr;
@@ -638,12 +645,15 @@ struct zkw_ram_witness {
     u64 *compact_forms = nullptr, *public_inputs = nullptr;  // [n_instances][18], [n_instances][4]
 
     void release() {
-        void* ptrs[] = {sorted_q, unsorted_enc, sorted_enc, unsorted_caps, sorted_caps, unsorted_marks, sorted_marks,
+        void* ptrs[] = {sorted_q, owned_q, unsorted_enc, sorted_enc, unsorted_caps, sorted_caps, unsorted_marks, sorted_marks,
                         unsorted_tails, sorted_tails, challenges,
                         lhs_z,    rhs_z,        instances,  nondet_counts, compact_forms, public_inputs};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         sorted_q = nullptr;
+        owned_q = nullptr;
+        unsorted_q = nullptr;
+        enc_valid = false;
         unsorted_enc = sorted_enc = unsorted_tails = sorted_tails = challenges = lhs_z = rhs_z = nullptr;
         unsorted_caps = sorted_caps = unsorted_marks = sorted_marks = nullptr;
         tails_valid = false;
@@ -656,8 +666,6 @@ struct zkw_ram_witness {
 static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
     const size_t t = w->total, ni = w->n_instances;
     HIP_TRY(hipMalloc((void**)&w->sorted_q, (t + 1) * sizeof(zkw_mem_query)));
-    HIP_TRY(hipMalloc((void**)&w->unsorted_enc, (t + 1) * 8 * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->sorted_enc, (t + 1) * 8 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->unsorted_caps, (t + 1) * 4 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->sorted_caps, (t + 1) * 4 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->unsorted_marks, (ni + 1) * 12 * sizeof(u64)));
@@ -733,14 +741,21 @@ static int ram_sort(zkw_ctx* ctx, const zkw_mem_query* d_q, size_t total, const 
 
 static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, const uint32_t* n_nondet) {
     const size_t n_blocks = w->offsets.size() - 1, total = w->total;
-    // K1 (unsorted side) — src/witness/oracle.rs:894-903 encodes each query as it is pushed
-    ZKW_TRY(dev_encode(ctx, d_q, total, w->unsorted_enc));
-    // K7 + K1 (sorted side)
+    // K1 — src/witness/oracle.rs:894-903 encodes each query as it is pushed; here every consumer encodes on the fly
+    if (ctx->ptr_mode == ZKW_PTR_DEVICE) {
+        w->unsorted_q = d_q;
+    } else {  // d_q is the context's staging copy, which the next call overwrites
+        if (!w->owned_q) HIP_TRY(hipMalloc((void**)&w->owned_q, (total + 1) * sizeof(zkw_mem_query)));
+        HIP_TRY(hipMemcpyAsync(w->owned_q, d_q, total * sizeof(zkw_mem_query), hipMemcpyDeviceToDevice, ctx->stream));
+        w->unsorted_q = w->owned_q;
+    }
+    // K7 (sorted side)
     u32* perm = nullptr;
     ZKW_TRY(ram_sort(ctx, d_q, total, w->offsets, w->unsorted_caps, w->sorted_caps, &perm));
     w->tails_valid = false;
+    w->enc_valid = false;
     { Prof _p(ctx, "k_gather_encode"); hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, d_q, perm, total,
-                       w->sorted_q, w->sorted_enc); }
+                       w->sorted_q, (u64*)nullptr); }
     ZKW_TRY(launch_check("k_gather_encode"));
     // K2: 2 chains per block, all in one launch
     std::vector<ChainJob> chains;
@@ -748,8 +763,8 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     for (size_t b = 0; b < n_blocks; b++) {
         const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
         const size_t io = w->inst_offsets[b];
-        chains.push_back(ChainJob{w->unsorted_enc + 8 * lo, nullptr, nullptr, n, w->unsorted_caps + 4 * lo, w->unsorted_marks + 12 * io, w->capacity});
-        chains.push_back(ChainJob{w->sorted_enc + 8 * lo, nullptr, nullptr, n, w->sorted_caps + 4 * lo, w->sorted_marks + 12 * io, w->capacity});
+        chains.push_back(ChainJob{nullptr, nullptr, nullptr, n, w->unsorted_caps + 4 * lo, w->unsorted_marks + 12 * io, w->capacity, w->unsorted_q + lo});
+        chains.push_back(ChainJob{nullptr, nullptr, nullptr, n, w->sorted_caps + 4 * lo, w->sorted_marks + 12 * io, w->capacity, w->sorted_q + lo});
     }
     ZKW_TRY(dev_chains(ctx, chains));
     // K5: challenges from the two final tails (W/ram_permutation.rs:80-90)
@@ -766,8 +781,8 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     segs.reserve(2 * n_blocks);
     for (size_t b = 0; b < n_blocks; b++) {
         const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
-        segs.push_back(GpSeg{w->unsorted_enc + 8 * lo, w->lhs_z + 2 * lo, w->challenges + 18 * b, n, 0, 0});
-        segs.push_back(GpSeg{w->sorted_enc + 8 * lo, w->rhs_z + 2 * lo, w->challenges + 18 * b, n, 0, 0});
+        segs.push_back(GpSeg{nullptr, w->lhs_z + 2 * lo, w->challenges + 18 * b, n, 0, 0, w->unsorted_q + lo});
+        segs.push_back(GpSeg{nullptr, w->rhs_z + 2 * lo, w->challenges + 18 * b, n, 0, 0, w->sorted_q + lo});
     }
     ZKW_TRY(dev_grand_products(ctx, segs, 8, 2));
     // a10: per-instance records
@@ -867,11 +882,29 @@ extern "C" int zkw_ram_build_instances(zkw_ctx* ctx, const zkw_mem_query* q, siz
 extern "C" size_t zkw_ram_witness_num_instances(const zkw_ram_witness* w) { return w ? w->n_instances : 0; }
 extern "C" size_t zkw_ram_witness_num_items(const zkw_ram_witness* w) { return w ? w->total : 0; }
 
+// The [total][8] encoding arrays of the ABI: materialised on first access from the queries.
+static int ram_encodings(const zkw_ram_witness* cw) {
+    zkw_ram_witness* w = const_cast<zkw_ram_witness*>(cw);
+    if (w->enc_valid) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t t = w->total;
+    if (!w->unsorted_enc) {
+        if (hipMalloc((void**)&w->unsorted_enc, (t + 1) * 64) != hipSuccess || hipMalloc((void**)&w->sorted_enc, (t + 1) * 64) != hipSuccess)
+            return fail(ZKW_ERR_OOM, "no room for the materialised encodings (%zu bytes): read ZKW_RAM_*_ENC from a smaller batch", 2 * t * 64);
+    }
+    ZKW_TRY(dev_encode(ctx, w->unsorted_q, t, w->unsorted_enc));
+    ZKW_TRY(dev_encode(ctx, w->sorted_q, t, w->sorted_enc));
+    w->enc_valid = true;
+    return ZKW_OK;
+}
+
 // The [total][12] tail arrays of the ABI. The builder keeps tails compact (capacity words + instance ends); the full
 // arrays are expanded on first access: one independent permutation per item from (enc[i], caps[i-1]).
 static int ram_full_tails(const zkw_ram_witness* cw) {
     zkw_ram_witness* w = const_cast<zkw_ram_witness*>(cw);
     if (w->tails_valid) return ZKW_OK;
+    ZKW_TRY(ram_encodings(cw));
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t t = w->total;
@@ -894,8 +927,8 @@ static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes, 
     const size_t t = w->total, nb = w->offsets.size() - 1;
     switch (what) {
         case ZKW_RAM_SORTED_QUERIES: *bytes = t * sizeof(zkw_mem_query); return w->sorted_q;
-        case ZKW_RAM_UNSORTED_ENC: *bytes = t * 64; return w->unsorted_enc;
-        case ZKW_RAM_SORTED_ENC: *bytes = t * 64; return w->sorted_enc;
+        case ZKW_RAM_UNSORTED_ENC: *bytes = t * 64; return materialize && ram_encodings(w) == ZKW_OK ? w->unsorted_enc : nullptr;
+        case ZKW_RAM_SORTED_ENC: *bytes = t * 64; return materialize && ram_encodings(w) == ZKW_OK ? w->sorted_enc : nullptr;
         case ZKW_RAM_UNSORTED_TAILS: *bytes = t * 96; return materialize && ram_full_tails(w) == ZKW_OK ? w->unsorted_tails : nullptr;
         case ZKW_RAM_SORTED_TAILS: *bytes = t * 96; return materialize && ram_full_tails(w) == ZKW_OK ? w->sorted_tails : nullptr;
         case ZKW_RAM_CHALLENGES: *bytes = nb * 18 * 8; return w->challenges;
@@ -1027,8 +1060,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
         SynthJob& j = jobs[k];
         j.inst = w->instances + idx;
         j.sorted_q = w->sorted_q + lo;
-        j.unsorted_enc = w->unsorted_enc + 8 * lo;
-        j.sorted_enc = w->sorted_enc + 8 * lo;
+        j.unsorted_q = w->unsorted_q + lo;
         j.unsorted_caps = w->unsorted_caps + 4 * lo;
         j.sorted_caps = w->sorted_caps + 4 * lo;
         j.u_mark = w->unsorted_marks + 12 * idx;

@@ -130,7 +130,9 @@ int zkw_grand_product_chains(zkw_ctx *ctx, const uint64_t *lhs, const uint64_t *
 /* ---- RAM permutation witness builder ------------------------------------------------------------ */
 /* compute_ram_circuit_snapshots, src/witness/individual_circuits/ram_permutation.rs:26-470, for one
    block's memory queue (q in queue order). *out must be NULL or a witness previously returned for the
-   same shape (its buffers are reused). */
+   same shape (its buffers are reused). In device-pointer mode the witness keeps a reference to q (the kernels
+   re-encode the queries instead of storing their encodings): q must stay valid and unchanged until the witness
+   has been synthesized / read or is freed. In host-pointer mode the witness owns a device copy. */
 int zkw_ram_build_instances(zkw_ctx *ctx, const zkw_mem_query *q, size_t n, uint32_t capacity,
                             uint32_t num_non_deterministic_heap_queries, zkw_ram_witness **out);
 /* The same for n_blocks independent memory queues (one per block being proven) in one pass:
@@ -141,8 +143,8 @@ int zkw_ram_build_instances_batch(zkw_ctx *ctx, const zkw_mem_query *q, const ui
 
 enum {
     ZKW_RAM_SORTED_QUERIES = 0, /* zkw_mem_query[total]           */
-    ZKW_RAM_UNSORTED_ENC = 1,   /* uint64_t[total][8]             */
-    ZKW_RAM_SORTED_ENC = 2,     /* uint64_t[total][8]             */
+    ZKW_RAM_UNSORTED_ENC = 1,   /* uint64_t[total][8]: materialised on first access (the builder encodes the 48-byte */
+    ZKW_RAM_SORTED_ENC = 2,     /* queries on the fly in every kernel instead of keeping 2 x 64 bytes per query)     */
     ZKW_RAM_UNSORTED_TAILS = 3, /* uint64_t[total][12]: expanded on first access (the builder keeps only the   */
     ZKW_RAM_SORTED_TAILS = 4,   /* capacity words + the tails at instance ends: 64 instead of 192 bytes per query) */
     ZKW_RAM_CHALLENGES = 5,     /* uint64_t[n_blocks][2][9]       */
