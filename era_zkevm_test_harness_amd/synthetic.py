@@ -320,3 +320,81 @@ def storage_application_trace(n, seed=0, existing_fraction=0.5, write_fraction=0
     ro = q["rw_flag"] == 0
     q["written_value"][ro] = q["read_value"][ro]
     return q, existing
+
+
+def bytecode_hash(words: np.ndarray) -> np.ndarray:
+    """versioned bytecode hash of an odd number of 32-byte words (decommit_code.rs:47-78, 136-401): SHA-256 over the
+    big-endian words, the four most significant bytes replaced by version 1 and the length in words."""
+    import hashlib
+
+    w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 8)
+    assert w.shape[0] % 2 == 1
+    code = b"".join(int(x).to_bytes(4, "big") for row in w for x in row[::-1])
+    dig = hashlib.sha256(code).digest()
+    out = np.zeros(8, np.uint32)
+    for j in range(1, 8):
+        out[7 - j] = int.from_bytes(dig[4 * j:4 * j + 4], "big")
+    out[7] = 0x01000000 | w.shape[0]
+    return out
+
+
+def block_after_vm(seed=1, n_vm_memory=3000, n_bytecodes=5, n_decommits=12, n_storage=150, n_storage_cells=25,
+                   n_events=60, n_l1_messages=25, n_precompile_calls=(5, 4, 3)):
+    """What the VM run of one block hands to the witness builders (src/witness/oracle.rs:185-927), synthesised
+    consistently: the VM's memory queue incl. the writes every precompile input needs, the decommit-request queue with
+    the bytecodes behind its hashes, the forward-applied log queue (storage, events, L1 messages, precompile calls,
+    interleaved) and the memory queries of the three precompiles."""
+    from .native import DECOMMIT_QUERY, MEM_QUERY
+
+    rng = np.random.default_rng(seed)
+    # bytecodes and the decommit queue over them
+    lens = [1 + 2 * int(rng.integers(0, 12)) for _ in range(n_bytecodes)]
+    codes = [rng.integers(0, 1 << 32, (n, 8), dtype=np.uint64).astype(np.uint32) for n in lens]
+    hashes = np.stack([bytecode_hash(c) for c in codes])
+    pick = np.concatenate([np.arange(n_bytecodes), rng.integers(0, n_bytecodes, max(0, n_decommits - n_bytecodes))])
+    rng.shuffle(pick)
+    dq = np.zeros(pick.size, DECOMMIT_QUERY)
+    dq["hash"] = hashes[pick]
+    dq["memory_page"] = (100000 + 8 * pick).astype(np.uint32)
+    dq["timestamp"] = 3 + 4 * np.arange(pick.size, dtype=np.uint32)
+    dq["decommitted_length"] = np.array(lens, np.uint16)[pick]
+    seen = set()
+    for i, h in enumerate(pick):
+        dq["is_fresh"][i] = 0 if int(h) in seen else 1
+        seen.add(int(h))
+    # precompile calls: (requests, memory queries) per kind; every input word is written by the VM one tick earlier
+    pre_addr = (0x8010, 0x02, 0x01)
+    pre_req, pre_mem, vm_extra = [], [], []
+    used_pages = set(range(8, 8 + 64)) | {int(p) for p in dq["memory_page"]}
+    for kind, n_calls in enumerate(n_precompile_calls):
+        for attempt in range(50):
+            req, mq = precompile_trace(kind, n_calls, seed=seed * 100 + 10 * kind + attempt)
+            pages = {int(p) for p in mq["page"]}
+            if not (pages & used_pages):
+                break
+        used_pages |= pages
+        req["aux_byte"], req["shard_id"], req["rollback"] = 3, 0, 0
+        req["address"] = 0
+        req["address"][:, 0] = pre_addr[kind]
+        pre_req.append(req)
+        pre_mem.append(mq)
+        rd = mq[mq["rw_flag"] == 0].copy()
+        rd["rw_flag"] = 1
+        rd["timestamp"] -= 1
+        vm_extra.append(rd)
+    vm_mem = np.concatenate([ram_trace(n_vm_memory, seed=seed + 3)] + vm_extra).astype(MEM_QUERY)
+    # the log queue: sub-queues merged at random, each keeping its own order
+    ev = events_trace(n_events, 0.3, seed=seed + 5)
+    ev["aux_byte"] = 1
+    l1 = events_trace(n_l1_messages, 0.2, seed=seed + 6)
+    l1["aux_byte"] = 2
+    subs = [storage_trace(n_storage, n_storage_cells, seed=seed + 4), ev, l1] + pre_req
+    tags = np.concatenate([np.full(s.size, k) for k, s in enumerate(subs)])
+    rng.shuffle(tags)
+    cursor = [0] * len(subs)
+    logs = np.zeros(tags.size, subs[0].dtype)
+    for i, t in enumerate(tags):
+        logs[i] = subs[t][cursor[t]]
+        cursor[t] += 1
+    return {"vm_memory_queries": vm_mem, "decommit_queries": dq, "bytecodes": {h.tobytes(): c for h, c in zip(hashes, codes)},
+            "log_queries": logs, "precompile_memory_queries": pre_mem}
