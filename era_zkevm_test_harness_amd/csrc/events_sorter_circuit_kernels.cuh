@@ -80,14 +80,14 @@ __device__ __forceinline__ void es_regs_in(const EsSynthJob& job, EsRegsIn& r) {
     for (int k = 0; k < 4; k++) r.rh[k] = start ? job.rq_tail_in[k] : f.final_result_queue_state.tail[k];
     r.len_r = start ? job.rq_len_in : f.final_result_queue_state.length;
 #pragma unroll
-    for (int k = 0; k < 2; k++) { r.lhs[k] = f.lhs_accumulator[k]; r.rhs[k] = f.rhs_accumulator[k]; }
+    for (int k = 0; k < 2; k++) { r.lhs[k] = start ? 1 : f.lhs_accumulator[k]; r.rhs[k] = start ? 1 : f.rhs_accumulator[k]; }  // ONE at the start
     r.valid = start ? 0 : 1;
     r.kts = f.previous_key;
     r.krb = f.previous_item.rollback ? 1 : 0;
 }
 
 struct EsCycle {
-    bool can_pop;
+    bool can_pop, fresh;
     size_t idx, last_popped;  // last_popped: item popped last before this cycle (valid when i > 0)
     u32 p_valid, p_kts, p_krb;
     u64 pushes_before;
@@ -97,8 +97,9 @@ __device__ __forceinline__ void es_cycle(const EsSynthJob& job, const EsRegsIn& 
     c.can_pop = i < m;
     c.idx = first + i;
     c.last_popped = first + (i - 1 < m ? i - 1 : m - 1);
-    c.p_valid = i == 0 ? ri.valid : 1;
-    if (i == 0) { c.p_kts = ri.kts; c.p_krb = ri.krb; }
+    c.fresh = i == 0 || m == 0;  // nothing popped in this instance yet (an empty instance never pops): registers = FSM input
+    c.p_valid = c.fresh ? ri.valid : 1;
+    if (c.fresh) { c.p_kts = ri.kts; c.p_krb = ri.krb; }
     else { const zkw_log_query* pq = job.sorted_q + c.last_popped; c.p_kts = pq->timestamp; c.p_krb = pq->rollback ? 1 : 0; }
     const size_t tt = first + (i < m ? i : m);
     c.pushes_before = tt ? job.kept_prefix[tt - 1] : 0;
@@ -106,7 +107,7 @@ __device__ __forceinline__ void es_cycle(const EsSynthJob& job, const EsRegsIn& 
 // the normalised encoding of the latest popped record before this cycle (zeros before the very first record)
 __device__ __forceinline__ void es_prev_ne(const EsSynthJob& job, const EsCycle& c, u32 i, u64 ne[20]) {
     u64 e[20];
-    if (i == 0) {
+    if (c.fresh) {
         if (job.inst->start_flag) {
 #pragma unroll
             for (int k = 0; k < 20; k++) ne[k] = 0;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64) void k_es_fill_queue(const EsSynthJob* __restri
             const u64* tails = WHICH == 0 ? job.unsorted_new_tails : job.sorted_new_tails;
 #pragma unroll
             for (int k = 0; k < 20; k++) enc[k] = c.can_pop ? src[20 * c.idx + k] : 0;
-            const u64* ph = i == 0 ? (WHICH == 0 ? ri.uh : ri.sh) : tails + 4 * c.last_popped;
+            const u64* ph = c.fresh ? (WHICH == 0 ? ri.uh : ri.sh) : tails + 4 * c.last_popped;
 #pragma unroll
             for (int k = 0; k < 4; k++) old[k] = ph[k];
         }
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __restric
                 u64 lc = gl::add(ch[20], eu[0]), rc = gl::add(ch[20], es[0]);
 #pragma unroll
                 for (int k = 1; k < 20; k++) { lc = gl::add(lc, gl::mul(eu[k], ch[k])); rc = gl::add(rc, gl::mul(es[k], ch[k])); }
-                const u64 pl = i == 0 ? ri.lhs[r] : job.lhs_z[(size_t)r * n + c.last_popped];
-                const u64 pr = i == 0 ? ri.rhs[r] : job.rhs_z[(size_t)r * n + c.last_popped];
+                const u64 pl = c.fresh ? ri.lhs[r] : job.lhs_z[(size_t)r * n + c.last_popped];
+                const u64 pr = c.fresh ? ri.rhs[r] : job.rhs_z[(size_t)r * n + c.last_popped];
                 const u64 nl = gl::canon(gl::mul(pl, lc)), nr = gl::canon(gl::mul(pr, rc));
                 lc = gl::canon(lc); rc = gl::canon(rc);
                 if (r == 0) { cur.lc0 = lc; cur.rc0 = rc; cur.nl0 = nl; cur.nr0 = nr; prev.lhs0 = pl; prev.rhs0 = pr; cur.lhs0 = can_pop ? nl : pl; cur.rhs0 = can_pop ? nr : pr; }
@@ -283,8 +284,8 @@ __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __restric
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 uo[k] = TR(U3O[k], rU3); so[k] = TR(S3O[k], rS3);
-                pu[k] = i == 0 ? ri.uh[k] : job.unsorted_new_tails[4 * c.last_popped + k];
-                ps[k] = i == 0 ? ri.sh[k] : job.sorted_new_tails[4 * c.last_popped + k];
+                pu[k] = c.fresh ? ri.uh[k] : job.unsorted_new_tails[4 * c.last_popped + k];
+                ps[k] = c.fresh ? ri.sh[k] : job.sorted_new_tails[4 * c.last_popped + k];
                 ou[k] = c.can_pop ? uo[k] : pu[k]; os[k] = c.can_pop ? so[k] : ps[k];
             }
             ES_SET4(cur, u3o, uo); ES_SET4(cur, s3o, so); ES_SET4(prev, uh, pu); ES_SET4(prev, sh, ps); ES_SET4(cur, uh, ou); ES_SET4(cur, sh, os);

@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __restric
 #pragma unroll
                 for (int k = 1; k < 20; k++) { lc = gl::add(lc, gl::mul(eu[k], ch[k])); rc = gl::add(rc, gl::mul(es[k], ch[k])); }
                 if (c.can_pop) lc = gl::add(lc, gl::mul(256 * c.cidx, ch[19]));  // extended timestamp = queue position
-                const u64 pl = c.pos ? job.lhs_z[(size_t)r * n + c.pos - 1] : job.inst->hidden_fsm_input.lhs_accumulator[r];
-                const u64 pr = c.pos ? job.rhs_z[(size_t)r * n + c.pos - 1] : job.inst->hidden_fsm_input.rhs_accumulator[r];
+                const u64 pl = c.pos ? job.lhs_z[(size_t)r * n + c.pos - 1] : (u64)1;  // pos == 0 only in the first instance: ONE at the start
+                const u64 pr = c.pos ? job.rhs_z[(size_t)r * n + c.pos - 1] : (u64)1;
                 const u64 nl = gl::canon(gl::mul(pl, lc)), nr = gl::canon(gl::mul(pr, rc));
                 lc = gl::canon(lc); rc = gl::canon(rc);
                 if (r == 0) { cur.lc0 = lc; cur.rc0 = rc; cur.nl0 = nl; cur.nr0 = nr; prev.lhs0 = pl; prev.rhs0 = pr; cur.lhs0 = can_pop ? nl : pl; cur.rhs0 = can_pop ? nr : pr; }
@@ -456,10 +456,10 @@ __global__ __launch_bounds__(64) void k_ss_fill_boundary(const SsSynthJob* __res
         SS_I4(M)
 #undef M
         cur.len_u = c.p_len; cur.len_s = c.p_len; cur.len_r = c.pushes;
-        cur.lhs0 = c.pos ? job.lhs_z[c.pos - 1] : in->hidden_fsm_input.lhs_accumulator[0];
-        cur.lhs1 = c.pos ? job.lhs_z[n + c.pos - 1] : in->hidden_fsm_input.lhs_accumulator[1];
-        cur.rhs0 = c.pos ? job.rhs_z[c.pos - 1] : in->hidden_fsm_input.rhs_accumulator[0];
-        cur.rhs1 = c.pos ? job.rhs_z[n + c.pos - 1] : in->hidden_fsm_input.rhs_accumulator[1];
+        cur.lhs0 = c.pos ? job.lhs_z[c.pos - 1] : (u64)1;
+        cur.lhs1 = c.pos ? job.lhs_z[n + c.pos - 1] : (u64)1;
+        cur.rhs0 = c.pos ? job.rhs_z[c.pos - 1] : (u64)1;
+        cur.rhs1 = c.pos ? job.rhs_z[n + c.pos - 1] : (u64)1;
         SS_KEYS_TO(cur, pk);
         SS_CELL_TO(cur, cell);
         cur.cidx = c.cidx; cur.valid = c.pos ? 1 : 0;

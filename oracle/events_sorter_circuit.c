@@ -84,8 +84,10 @@ int orc_events_sorter_synthesize(const zkw_events_sorter_instance *inst, const z
     prev.len_s = start ? inst->intermediate_sorted_queue_state.length : fi->intermediate_sorted_queue_state.length;
     SET4(prev, rh, start ? (rq_tail_in ? rq_tail_in : zero4) : fi->final_result_queue_state.tail);
     prev.len_r = start ? rq_len_in : fi->final_result_queue_state.length;
-    prev.lhs0 = fi->lhs_accumulator[0]; prev.lhs1 = fi->lhs_accumulator[1];
-    prev.rhs0 = fi->rhs_accumulator[0]; prev.rhs1 = fi->rhs_accumulator[1];
+    /* the first instance starts its accumulators at ONE whatever the (placeholder) FSM input says: the empty-queue
+       dummy instance has a zero FSM input and ONE in its output (events_sort_dedup.rs:27-76) */
+    prev.lhs0 = start ? 1 : fi->lhs_accumulator[0]; prev.lhs1 = start ? 1 : fi->lhs_accumulator[1];
+    prev.rhs0 = start ? 1 : fi->rhs_accumulator[0]; prev.rhs1 = start ? 1 : fi->rhs_accumulator[1];
     prev.kts = fi->previous_key;
     prev.krb = fi->previous_item.rollback ? 1 : 0;
     prev.valid = start ? 0 : 1;

@@ -129,7 +129,9 @@ int orc_storage_sorter_synthesize(const zkw_storage_sorter_instance *inst, const
         for (int k = 0; k < 8; k++) { pr.base[k] = fi->this_cell_base_value[k]; pr.cur[k] = fi->this_cell_current_value[k]; }
     }
     pr.cidx = fi->cycle_idx;
-    for (int r = 0; r < 2; r++) { pr.lhs[r] = fi->lhs_accumulator[r]; pr.rhs[r] = fi->rhs_accumulator[r]; }
+    /* the first instance starts its accumulators at ONE whatever the (placeholder) FSM input says: the empty-queue
+       dummy instance has a zero FSM input and ONE in its output (storage_sort_dedup.rs:23-70) */
+    for (int r = 0; r < 2; r++) { pr.lhs[r] = start ? 1 : fi->lhs_accumulator[r]; pr.rhs[r] = start ? 1 : fi->rhs_accumulator[r]; }
     {
         uint64_t *g = &glob.c0_1; /* c0_1..c0_20, c1_1..c1_20 are consecutive fields (generated in that order) */
         for (int r = 0; r < 2; r++)

@@ -98,3 +98,18 @@ def test_compact_forms_and_public_inputs(ctx, oracle):
     assert o["instances"].size >= 3
     assert np.array_equal(w.get(nv.STO_COMPACT_FORMS), compact)
     assert np.array_equal(w.get(nv.STO_PUBLIC_INPUTS), pi)
+
+
+def test_empty_queue_dummy_instance(ctx, oracle):
+    """no records: the one dummy instance of the reference, synthesized and satisfied, bit-exact vs the oracle"""
+    from era_zkevm_test_harness_amd import native
+
+    q = np.zeros(0, oracle.LOG_QUERY)
+    o = oracle.storage_sorter_build(q, 16)
+    w = ctx.compute_storage_dedup_and_sort(q, 16)
+    assert w.num_instances == 1
+    t = native.Trace(ctx, 2048, 1)
+    ctx.synthesize_storage_sorter(w, t)
+    assert np.array_equal(t.get(0)[:149], oracle.storage_sorter_synthesize(o, 0, 16, 2048))
+    assert ctx.check_if_satisfied_storage_sorter(t, 0, 16)[0] == 0
+    t.free()

@@ -59,3 +59,15 @@ def test_checker_notices_tampering(oracle):
         t2 = t.copy()
         t2[c, r] = (int(t2[c, r]) + 1) % P
         assert oracle.events_sorter_check(t2, capacity)[0] > 0, (c, r)
+
+
+def test_empty_queue_dummy_instance(oracle):
+    """no events: one dummy instance, placeholder FSM input, ONE in the output accumulators (events_sort_dedup.rs:27-76)"""
+    o = oracle.events_sorter_build(np.zeros(0, oracle.LOG_QUERY), 16)
+    assert o["instances"].size == 1
+    t = oracle.events_sorter_synthesize(o, 0, 16, 2048)
+    assert oracle.events_sorter_check(t, 16)[0] == 0
+    names = _slots()["BND_OUT"]
+    bout = t[:, _bnd(16) + 1]
+    fo = o["instances"][0]["hidden_fsm_output"]
+    assert [int(bout[names[k]]) for k in ("lhs0", "lhs1", "rhs0", "rhs1")] == [1, 1, 1, 1] == [int(x) for x in fo["lhs_accumulator"]] + [int(x) for x in fo["rhs_accumulator"]]

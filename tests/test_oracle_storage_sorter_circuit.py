@@ -90,3 +90,16 @@ def test_unsorted_queue_is_rejected(oracle):
     o["sorted_enc"][[i - 1, i]] = o["sorted_enc"][[i, i - 1]]
     with pytest.raises(RuntimeError):
         oracle.storage_sorter_synthesize(o, 0, capacity, n_rows)
+
+
+def test_empty_queue_dummy_instance(oracle):
+    """no storage logs: the reference emits one dummy instance with a placeholder FSM input and ONE in the output
+    accumulators (storage_sort_dedup.rs:23-70); the trace starts its accumulators at ONE and is satisfied"""
+    o = oracle.storage_sorter_build(np.zeros(0, oracle.LOG_QUERY), 16)
+    assert o["instances"].size == 1
+    t = oracle.storage_sorter_synthesize(o, 0, 16, 2048)
+    assert oracle.storage_sorter_check(t, 16)[0] == 0
+    names = _slots()["BND_OUT"]
+    bout = t[:, _bnd(16) + 1]
+    fo = o["instances"][0]["hidden_fsm_output"]
+    assert [int(bout[names[k]]) for k in ("lhs0", "lhs1", "rhs0", "rhs1")] == [1, 1, 1, 1] == [int(x) for x in fo["lhs_accumulator"]] + [int(x) for x in fo["rhs_accumulator"]]
