@@ -384,11 +384,14 @@ def block_after_vm(seed=1, n_vm_memory=3000, n_bytecodes=5, n_decommits=12, n_st
         vm_extra.append(rd)
     vm_mem = np.concatenate([ram_trace(n_vm_memory, seed=seed + 3)] + vm_extra).astype(MEM_QUERY)
     # the log queue: sub-queues merged at random, each keeping its own order
-    ev = events_trace(n_events, 0.3, seed=seed + 5)
+    from .native import LOG_QUERY
+
+    ev = events_trace(n_events, 0.3, seed=seed + 5) if n_events else np.zeros(0, LOG_QUERY)
     ev["aux_byte"] = 1
-    l1 = events_trace(n_l1_messages, 0.2, seed=seed + 6)
+    l1 = events_trace(n_l1_messages, 0.2, seed=seed + 6) if n_l1_messages else np.zeros(0, LOG_QUERY)
     l1["aux_byte"] = 2
-    subs = [storage_trace(n_storage, n_storage_cells, seed=seed + 4), ev, l1] + pre_req
+    sto = storage_trace(n_storage, n_storage_cells, seed=seed + 4) if n_storage else np.zeros(0, LOG_QUERY)
+    subs = [sto, ev, l1] + pre_req
     tags = np.concatenate([np.full(s.size, k) for k, s in enumerate(subs)])
     rng.shuffle(tags)
     cursor = [0] * len(subs)

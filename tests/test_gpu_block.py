@@ -61,3 +61,23 @@ def test_block_after_vm(ctx, oracle, seed):
         assert np.array_equal(states, oracle.queue_push_chain_full(enc))
     for wit in w.values():
         wit.free()
+
+
+def test_block_with_empty_queues(ctx, oracle):
+    """a block without events, L1 messages, keccak and ecrecover calls: the builders of the empty queues emit their
+    dummy instances (events_sort_dedup.rs:27-76), everything else composes as before"""
+    from era_zkevm_test_harness_amd import block as blk, native as nv
+
+    b = synthetic.block_after_vm(seed=3, n_events=0, n_l1_messages=0, n_precompile_calls=(0, 3, 0), n_storage=60)
+    caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+    a = blk.create_artifacts_after_vm(ctx, b, caps)
+    w = a["witnesses"]
+    assert w["events_sorter"].num_instances == 1 and w["l1_messages_sorter"].num_instances == 1
+    assert a["l1_messages_pubdata_hash"] == oracle.linear_keccak256(np.zeros(0, oracle.LOG_QUERY))
+    ram_inst = w["ram_permutation"].get(nv.RAM_INSTANCES)
+    assert np.array_equal(ram_inst[0]["unsorted_queue_initial_state"]["tail"], a["memory_queue_state"]["tail"][0])
+    done = blk.synthesize_and_check(ctx, a, 1 << 15)
+    assert done[blk.EVENTS_SORTER] == 1 and done[blk.L1_MESSAGES_SORTER] == 1 and done[blk.STORAGE_SORTER] >= 2
+    for wit in w.values():
+        wit.free()
