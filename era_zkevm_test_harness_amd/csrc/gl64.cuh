@@ -27,20 +27,35 @@ GL_HD u64 canon(u64 x) { return x >= P ? x - P : x; }
 
 // a + b (mod p), weak in / weak out. The second fix-up only triggers for non-canonical operands.
 GL_HD u64 add(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the carry-out of the 64-bit add (v_add_co / v_addc_co) instead of a second 64-bit compare
+    unsigned long long s, t;
+    const bool c = __builtin_uaddll_overflow(a, b, &s);
+    const bool c2 = __builtin_uaddll_overflow(s, c ? EPS : 0, &t);
+    return t + (c2 ? EPS : 0);
+#else
     u64 s = a + b;
     u64 c = s < a ? EPS : 0;
     u64 t = s + c;
     u64 c2 = t < s ? EPS : 0;
     return t + c2;
+#endif
 }
 
 // a - b (mod p)
 GL_HD u64 sub(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long d, t;
+    const bool br = __builtin_usubll_overflow(a, b, &d);
+    const bool br2 = __builtin_usubll_overflow(d, br ? EPS : 0, &t);
+    return t - (br2 ? EPS : 0);
+#else
     u64 d = a - b;
     u64 br = a < b ? EPS : 0;
     u64 t = d - br;
     u64 br2 = t > d ? EPS : 0;
     return t - br2;
+#endif
 }
 
 GL_HD u64 neg(u64 a) { return sub(0, a); }
