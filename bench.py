@@ -75,17 +75,17 @@ def cpu_baseline(base, sample_blocks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=0,
                     help="independent memory queues per GPU per step (0 = size the batch to the free HBM)")
     ap.add_argument("--queries", type=int, default=CAPACITY)
     ap.add_argument("--ring", type=int, default=16, help="trace buffers (1.25 GB each) in the output ring, all pipelines together")
-    ap.add_argument("--pipelines", type=int, default=int(os.environ.get("ZKW_PIPELINES", "1")),
-                    help="experiment (DESIGN.md 3.2): split the step into P sub-batches that run as independent pipelines "
-                         "(own context, HIP stream, host thread), started 1/P of a period apart so that one pipeline's "
-                         "synthesis overlaps the others' queue chains. Measured slower than P = 1 on MI355X: the synthesis "
-                         "waves land on the SIMDs the chain waves need, and fewer chains per launch do not run faster")
+    ap.add_argument("--pipelines", type=int, default=int(os.environ.get("ZKW_PIPELINES", "2")),
+                    help="the step's blocks are split into P sub-batches that run as independent pipelines (own context, HIP "
+                         "stream, host thread), started a fraction of a chain pass apart so that one pipeline's synthesis "
+                         "overlaps the other's queue chains (DESIGN.md 3.2: +10..14 %% at P = 2 on the HBM-sized batch; "
+                         "P = 1 is the plain sequential step)")
     ap.add_argument("--stagger-ms", type=float, default=-1.0, help="start offset between pipelines (default: measured in warm-up)")
     ap.add_argument("--cpu-sample", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,22 +184,16 @@ def main():
             out = parallel.gather_records(records, counts, dst=0)
         return out
 
-    # Start offset between pipelines. A pipeline's pass = its queue chains (VALU-bound, serial per queue: T_chain whatever
-    # the sub-batch size) followed by everything else (T_rest, HBM-bound). With the starts spread over one period
-    # (T_chain + T_rest / P) every pipeline's HBM-bound phase falls inside the other pipelines' chains. T_chain and T_rest
-    # come from the HIP-event kernel times of pipeline 0 in the last warm-up step (all pipelines in lockstep there, so
-    # T_rest is the contended time of all P synthesis phases together).
-    stagger_s = (n * 12e-6) / P if P > 1 else 0.0
+    # Start offset between pipelines. A pipeline's pass = its queue chains (one wave per SIMD at most, latency-bound: T_chain
+    # whatever the sub-batch size between ~9 k and ~19 k chains) followed by everything else (HBM / VALU-bound). Started
+    # apart, one pipeline's synthesis runs inside the other's chain pass, whose waves leave issue slots free in the
+    # throttled regime of DESIGN.md 3.2.
+    # Offset = 0.72 x the chain pass of one sub-batch (2.1 s at P = 2: best of 2.1 / 2.4 / 2.8 s measured), from the
+    # per-item latency of the regime the sub-batch is in rather than from a noisy warm-up measurement.
+    per_item_s = 21.5e-6 if 2 * Bp > 8400 else 14.4e-6
+    stagger_s = 0.72 * n * per_item_s * 2 / P if P > 1 else 0.0
     for k in range(args.warmup):
-        ctxs[0].profile_enable(True)
-        ctxs[0].profile_reset()
         run_steps(1, 0.0)
-        pr0 = ctxs[0].profile()
-        ctxs[0].profile_enable(False)
-        t_chain = sum(ms for name, (ms, _c) in pr0.items() if name.startswith("k_chain_full")) * 1e-3
-        t_rest = sum(ms for name, (ms, _c) in pr0.items() if name.startswith(("k_ram_fill", "k_ram_nd", "k_gp_", "k_encode", "k_gather_encode"))) * 1e-3
-        if P > 1 and t_chain > 0:
-            stagger_s = (t_chain + t_rest / P) / P
     if args.stagger_ms >= 0:
         stagger_s = args.stagger_ms * 1e-3
     for c in ctxs:

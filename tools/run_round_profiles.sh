@@ -10,6 +10,7 @@ OUT=$(cd "$OUT" && pwd)
 export TMPDIR=/tmp
 # 1. the default bench, without a profiler
 timeout -s KILL 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+timeout -s KILL 900 python bench.py --pipelines 1 --no-cpu-baseline > "$OUT/bench_sequential.json" 2> "$OUT/bench_sequential.err"
 # 2. the same command under rocprofv3 --kernel-trace --stats
 cd /tmp && rm -rf /tmp/prof_stats && timeout -s KILL 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- \
     python "$ROOT/bench.py" > "$OUT/bench_default_under_rocprofv3.json" 2> "$OUT/rocprof_stats.err"
