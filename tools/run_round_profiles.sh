@@ -18,7 +18,7 @@ cp "$(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1)" "$OUT/bench_default_ker
 # 3. HBM counters, one pass each (never combined with other trace domains)
 for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/prof_pmc && timeout -s KILL 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_pmc -- \
-        python "$ROOT/bench.py" --blocks 32 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/rocprof_pmc_$C.err"
+        python "$ROOT/bench.py" --pipelines 1 --blocks 32 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/rocprof_pmc_$C.err"
     cp "$(ls /tmp/prof_pmc/*/*counter_collection.csv | head -1)" "$OUT/bench_b32_pmc_$C.csv"
 done
 cd "$ROOT"
