@@ -639,7 +639,13 @@ struct zkw_ram_witness {
     u64 *unsorted_caps = nullptr, *sorted_caps = nullptr, *unsorted_marks = nullptr, *sorted_marks = nullptr;
     u64 *unsorted_tails = nullptr, *sorted_tails = nullptr;
     bool tails_valid = false;
+    // grand-product chains: the builder only needs them at instance boundaries and the fills only inside the block
+    // being filled, so they live in a window (zbuf_*, zcap items) that is recomputed per group of blocks / per synthesis
+    // call (16 B per query and side instead of 32 B resident); the [total] arrays of the C ABI are computed on first access
     u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
+    bool z_valid = false;
+    u64 *zbuf_l = nullptr, *zbuf_r = nullptr;
+    size_t zcap = 0;
     zkw_ram_instance* instances = nullptr;
     u32* nondet_counts = nullptr;
     u64 *compact_forms = nullptr, *public_inputs = nullptr;  // [n_instances][18], [n_instances][4]
@@ -647,7 +653,7 @@ struct zkw_ram_witness {
     void release() {
         void* ptrs[] = {sorted_q, owned_q, unsorted_enc, sorted_enc, unsorted_caps, sorted_caps, unsorted_marks, sorted_marks,
                         unsorted_tails, sorted_tails, challenges,
-                        lhs_z,    rhs_z,        instances,  nondet_counts, compact_forms, public_inputs};
+                        lhs_z,    rhs_z,        instances,  nondet_counts, compact_forms, public_inputs, zbuf_l, zbuf_r};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         sorted_q = nullptr;
@@ -657,6 +663,9 @@ struct zkw_ram_witness {
         unsorted_enc = sorted_enc = unsorted_tails = sorted_tails = challenges = lhs_z = rhs_z = nullptr;
         unsorted_caps = sorted_caps = unsorted_marks = sorted_marks = nullptr;
         tails_valid = false;
+        z_valid = false;
+        zbuf_l = zbuf_r = nullptr;
+        zcap = 0;
         instances = nullptr;
         nondet_counts = nullptr;
         compact_forms = public_inputs = nullptr;
@@ -671,8 +680,15 @@ static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
     HIP_TRY(hipMalloc((void**)&w->unsorted_marks, (ni + 1) * 12 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->sorted_marks, (ni + 1) * 12 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->challenges, (n_blocks + 1) * 18 * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->lhs_z, (t + 1) * 2 * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->rhs_z, (t + 1) * 2 * sizeof(u64)));
+    {   // window of the grand-product chains: whole blocks, about 1 GB per side, at least the largest block
+        size_t max_block = 0;
+        for (size_t b = 0; b + 1 < w->offsets.size(); b++) max_block = std::max(max_block, (size_t)(w->offsets[b + 1] - w->offsets[b]));
+        size_t window = (size_t)1 << 26;
+        if (const char* e = getenv("ZKW_Z_WINDOW_ITEMS")) window = (size_t)strtoull(e, nullptr, 10);  // tests: force small groups
+        w->zcap = std::max(max_block, std::min(t, window));
+        HIP_TRY(hipMalloc((void**)&w->zbuf_l, (w->zcap + 1) * 2 * sizeof(u64)));
+        HIP_TRY(hipMalloc((void**)&w->zbuf_r, (w->zcap + 1) * 2 * sizeof(u64)));
+    }
     HIP_TRY(hipMalloc((void**)&w->instances, (ni + 1) * sizeof(zkw_ram_instance)));
     HIP_TRY(hipMalloc((void**)&w->nondet_counts, (ni + 1) * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&w->compact_forms, (ni + 1) * COMPACT_FORM_LEN * sizeof(u64)));
@@ -739,6 +755,19 @@ static int ram_sort(zkw_ctx* ctx, const zkw_mem_query* d_q, size_t total, const 
     return ZKW_OK;
 }
 
+// grand-product chains of blocks [b0, b1): block b's [2][n_b] chains at dst + 2 * (offsets[b] - offsets[b0])
+static int ram_gp_blocks(zkw_ctx* ctx, const zkw_ram_witness* w, size_t b0, size_t b1, u64* dst_l, u64* dst_r) {
+    std::vector<GpSeg> segs;
+    segs.reserve(2 * (b1 - b0));
+    const size_t base = w->offsets[b0];
+    for (size_t b = b0; b < b1; b++) {
+        const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
+        segs.push_back(GpSeg{nullptr, dst_l + 2 * (lo - base), w->challenges + 18 * b, n, 0, 0, w->unsorted_q + lo});
+        segs.push_back(GpSeg{nullptr, dst_r + 2 * (lo - base), w->challenges + 18 * b, n, 0, 0, w->sorted_q + lo});
+    }
+    return dev_grand_products(ctx, segs, 8, 2);
+}
+
 static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, const uint32_t* n_nondet) {
     const size_t n_blocks = w->offsets.size() - 1, total = w->total;
     // K1 — src/witness/oracle.rs:894-903 encodes each query as it is pushed; here every consumer encodes on the fly
@@ -776,41 +805,40 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
                       w->challenges + 18 * b};
     }
     ZKW_TRY(dev_fs(ctx, fs, 12, 9));
-    // K6: both repetitions, both sides, every block in one launch set (W/ram_permutation.rs:115-138)
-    std::vector<GpSeg> segs;
-    segs.reserve(2 * n_blocks);
-    for (size_t b = 0; b < n_blocks; b++) {
-        const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
-        segs.push_back(GpSeg{nullptr, w->lhs_z + 2 * lo, w->challenges + 18 * b, n, 0, 0, w->unsorted_q + lo});
-        segs.push_back(GpSeg{nullptr, w->rhs_z + 2 * lo, w->challenges + 18 * b, n, 0, 0, w->sorted_q + lo});
+    // K6 + a10 in groups of whole blocks that fit the chain window: both repetitions and both sides of a group in one
+    // launch set (W/ram_permutation.rs:115-138), then the per-instance records that read the chains at instance ends
+    w->z_valid = false;
+    for (size_t b0 = 0; b0 < n_blocks;) {
+        size_t b1 = b0 + 1;
+        while (b1 < n_blocks && w->offsets[b1 + 1] - w->offsets[b0] <= w->zcap) b1++;
+        ZKW_TRY(ram_gp_blocks(ctx, w, b0, b1, w->zbuf_l, w->zbuf_r));
+        const size_t base = w->offsets[b0];
+        std::vector<RamBlock> blocks(b1 - b0);
+        size_t max_inst = 0;
+        for (size_t b = b0; b < b1; b++) {
+            const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
+            const size_t n_inst = w->inst_offsets[b + 1] - w->inst_offsets[b];
+            if (n_inst > max_inst) max_inst = n_inst;
+            blocks[b - b0] = RamBlock{w->sorted_q + lo,
+                                      w->unsorted_marks + 12 * w->inst_offsets[b],
+                                      w->sorted_marks + 12 * w->inst_offsets[b],
+                                      w->zbuf_l + 2 * (lo - base),
+                                      w->zbuf_r + 2 * (lo - base),
+                                      w->instances + w->inst_offsets[b],
+                                      w->nondet_counts + w->inst_offsets[b],
+                                      n,
+                                      w->capacity,
+                                      n_nondet ? n_nondet[b] : 0u};
+        }
+        RamBlock* d_blocks = nullptr;
+        ZKW_TRY(ctx->upload("ram_blocks", blocks, &d_blocks));
+        const unsigned gx = (unsigned)(max_inst < 64 ? max_inst : 64), gy = (unsigned)(b1 - b0);
+        { Prof _p(ctx, "k_ram_count_nondet"); hipLaunchKernelGGL(k_ram_count_nondet, dim3(gx, gy), dim3(256), 0, ctx->stream, d_blocks); }
+        ZKW_TRY(launch_check("k_ram_count_nondet"));
+        { Prof _p(ctx, "k_ram_instances"); hipLaunchKernelGGL(k_ram_instances, dim3(blocks_for(max_inst, 64), gy), dim3(64), 0, ctx->stream, d_blocks); }
+        ZKW_TRY(launch_check("k_ram_instances"));
+        b0 = b1;
     }
-    ZKW_TRY(dev_grand_products(ctx, segs, 8, 2));
-    // a10: per-instance records
-    std::vector<RamBlock> blocks(n_blocks);
-    size_t max_inst = 0;
-    for (size_t b = 0; b < n_blocks; b++) {
-        const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
-        const size_t n_inst = w->inst_offsets[b + 1] - w->inst_offsets[b];
-        if (n_inst > max_inst) max_inst = n_inst;
-        blocks[b] = RamBlock{w->sorted_q + lo,
-                             w->unsorted_marks + 12 * w->inst_offsets[b],
-                             w->sorted_marks + 12 * w->inst_offsets[b],
-                             w->lhs_z + 2 * lo,
-                             w->rhs_z + 2 * lo,
-                             w->instances + w->inst_offsets[b],
-                             w->nondet_counts + w->inst_offsets[b],
-                             n,
-                             w->capacity,
-                             n_nondet ? n_nondet[b] : 0u};
-    }
-    RamBlock* d_blocks = nullptr;
-    ZKW_TRY(ctx->upload("ram_blocks", blocks, &d_blocks));
-    unsigned gx = (unsigned)(max_inst < 64 ? max_inst : 64);
-    { Prof _p(ctx, "k_ram_count_nondet"); hipLaunchKernelGGL(k_ram_count_nondet, dim3(gx, (unsigned)n_blocks), dim3(256), 0, ctx->stream, d_blocks); }
-    ZKW_TRY(launch_check("k_ram_count_nondet"));
-    { Prof _p(ctx, "k_ram_instances"); hipLaunchKernelGGL(k_ram_instances, dim3(blocks_for(max_inst, 64), (unsigned)n_blocks), dim3(64), 0, ctx->stream,
-                       d_blocks); }
-    ZKW_TRY(launch_check("k_ram_instances"));
     // a20: compact forms and public inputs of every instance (postprocessing/mod.rs:353-369)
     const size_t ni = w->n_instances;
     { Prof _p(ctx, "k_ram_commitments"); hipLaunchKernelGGL(k_ram_commitments, dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, w->instances, ni, w->compact_forms); }
@@ -882,6 +910,22 @@ extern "C" int zkw_ram_build_instances(zkw_ctx* ctx, const zkw_mem_query* q, siz
 extern "C" size_t zkw_ram_witness_num_instances(const zkw_ram_witness* w) { return w ? w->n_instances : 0; }
 extern "C" size_t zkw_ram_witness_num_items(const zkw_ram_witness* w) { return w ? w->total : 0; }
 
+// The grand-product chains of the ABI ([2][n_b] per block at element offset 2 * block_offsets[b]): on first access.
+static int ram_full_chains(const zkw_ram_witness* cw) {
+    zkw_ram_witness* w = const_cast<zkw_ram_witness*>(cw);
+    if (w->z_valid) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t t = w->total;
+    if (!w->lhs_z) {
+        if (hipMalloc((void**)&w->lhs_z, (t + 1) * 16) != hipSuccess || hipMalloc((void**)&w->rhs_z, (t + 1) * 16) != hipSuccess)
+            return fail(ZKW_ERR_OOM, "no room for the grand-product chains (%zu bytes): read ZKW_RAM_*_Z from a smaller batch", 2 * t * 16);
+    }
+    ZKW_TRY(ram_gp_blocks(ctx, w, 0, w->offsets.size() - 1, w->lhs_z, w->rhs_z));
+    w->z_valid = true;
+    return ZKW_OK;
+}
+
 // The [total][8] encoding arrays of the ABI: materialised on first access from the queries.
 static int ram_encodings(const zkw_ram_witness* cw) {
     zkw_ram_witness* w = const_cast<zkw_ram_witness*>(cw);
@@ -932,8 +976,8 @@ static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes, 
         case ZKW_RAM_UNSORTED_TAILS: *bytes = t * 96; return materialize && ram_full_tails(w) == ZKW_OK ? w->unsorted_tails : nullptr;
         case ZKW_RAM_SORTED_TAILS: *bytes = t * 96; return materialize && ram_full_tails(w) == ZKW_OK ? w->sorted_tails : nullptr;
         case ZKW_RAM_CHALLENGES: *bytes = nb * 18 * 8; return w->challenges;
-        case ZKW_RAM_LHS_Z: *bytes = t * 16; return w->lhs_z;
-        case ZKW_RAM_RHS_Z: *bytes = t * 16; return w->rhs_z;
+        case ZKW_RAM_LHS_Z: *bytes = t * 16; return materialize && ram_full_chains(w) == ZKW_OK ? w->lhs_z : nullptr;
+        case ZKW_RAM_RHS_Z: *bytes = t * 16; return materialize && ram_full_chains(w) == ZKW_OK ? w->rhs_z : nullptr;
         case ZKW_RAM_INSTANCES: *bytes = w->n_instances * sizeof(zkw_ram_instance); return w->instances;
         case ZKW_RAM_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->compact_forms;
         case ZKW_RAM_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->public_inputs;
@@ -1044,6 +1088,21 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
+    // the grand-product chains of the blocks these instances belong to, recomputed into the witness's window
+    const size_t n_blocks = w->offsets.size() - 1;
+    size_t b_first = 0;
+    while (b_first + 1 < n_blocks && w->inst_offsets[b_first + 1] <= first_instance) b_first++;
+    size_t b_end = b_first + 1;  // one past the last block touched
+    while (b_end < n_blocks && w->inst_offsets[b_end] < first_instance + n_instances) b_end++;
+    if (w->offsets[b_end] - w->offsets[b_first] > w->zcap) {  // too many blocks for one window: split at a block boundary
+        size_t b_mid = b_first + 1;
+        while (b_mid + 1 < b_end && w->offsets[b_mid + 1] - w->offsets[b_first] <= w->zcap) b_mid++;
+        const size_t n_head = w->inst_offsets[b_mid] - first_instance;
+        ZKW_TRY(zkw_ram_synthesize(ctx, w, first_instance, n_head, t, first_slot));
+        return zkw_ram_synthesize(ctx, w, first_instance + n_head, n_instances - n_head, t, first_slot + n_head);
+    }
+    ZKW_TRY(ram_gp_blocks(ctx, w, b_first, b_end, w->zbuf_l, w->zbuf_r));
+    const size_t z_base = w->offsets[b_first];
     const u32 rstride = (u32)RC_REGION_STRIDE(capacity);  // rows per region incl. the alignment gap
     const u32 n_tiles = (rstride + 255) / 256;
     u32 *d_hist = nullptr, *d_nd = nullptr;
@@ -1051,8 +1110,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     ZKW_TRY(ctx->scratch_t<u32>("synth_nd", n_instances * n_tiles, &d_nd));
     HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
     std::vector<SynthJob> jobs(n_instances);
-    const size_t n_blocks = w->offsets.size() - 1;
-    size_t b = 0;
+    size_t b = b_first;
     for (size_t k = 0; k < n_instances; k++) {
         const size_t idx = first_instance + k;
         while (b + 1 < n_blocks && w->inst_offsets[b + 1] <= idx) b++;
@@ -1066,8 +1124,8 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
         j.u_mark = w->unsorted_marks + 12 * idx;
         j.s_mark = w->sorted_marks + 12 * idx;
         j.challenges = w->challenges + 18 * b;
-        j.lhs_z = w->lhs_z + 2 * lo;
-        j.rhs_z = w->rhs_z + 2 * lo;
+        j.lhs_z = w->zbuf_l + 2 * (lo - z_base);
+        j.rhs_z = w->zbuf_r + 2 * (lo - z_base);
         j.n_block = nb;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + 256 * k;

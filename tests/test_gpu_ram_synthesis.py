@@ -165,3 +165,36 @@ def test_baseline_config0_ram_2pow16(ctx, oracle):
     assert ctx.check_if_satisfied_ram(t, 0, capacity)[0] == 0
     t.free()
     w.free()
+
+
+def test_chain_window_smaller_than_the_batch(oracle, monkeypatch):
+    """the grand-product chains are recomputed per group of blocks (builder) and per synthesis call: with a window of
+    one block the batch of 5 blocks goes through 5 groups, and a synthesis call that spans blocks is split"""
+    from era_zkevm_test_harness_amd import native
+
+    monkeypatch.setenv("ZKW_Z_WINDOW_ITEMS", "1")
+    ctx = native.Context(0)
+    capacity, n_rows = 300, 1 << 12
+    sizes = [700, 300, 1000, 50, 620]
+    qs = [synthetic.ram_trace(n, seed=30 + k) for k, n in enumerate(sizes)]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    w = ctx.compute_ram_circuit_snapshots(np.concatenate(qs), capacity, 0, block_offsets=offs)
+    os_ = [oracle.ram_build_instances(q, capacity, 0) for q in qs]
+    exp_inst = np.concatenate([o["instances"] for o in os_])
+    assert w.get(native.RAM_INSTANCES).tobytes() == exp_inst.tobytes()
+    n_inst = exp_inst.size
+    t = native.Trace(ctx, n_rows, n_inst)
+    ctx.synthesize_ram(w, t)  # one call over all 5 blocks
+    k = 0
+    for o in os_:
+        for i in range(o["instances"].size):
+            assert np.array_equal(t.get(k), oracle.ram_synthesize(o, i, capacity, n_rows)), k
+            k += 1
+    # the ABI arrays are still whole
+    lz = w.get(native.RAM_LHS_Z)
+    for b, o in enumerate(os_):
+        lo, n = int(offs[b]), sizes[b]
+        assert np.array_equal(lz.reshape(-1)[2 * lo:2 * (lo + n)].reshape(2, n), o["lhs_z"])
+    t.free()
+    w.free()
+    ctx.close()
