@@ -114,13 +114,14 @@ def main():
     ring_p = max(2, args.ring // P)
     if B <= 0:
         free, _total = torch.cuda.mem_get_info(dev)
-        # resident per query: input 48 + sorted copy 48 + capacity words of the tails 2 x 32 = 160 bytes (no encodings are
-        # kept: every kernel re-encodes the 48-byte query; the grand-product chains live in a 2 GB window per context that
-        # is recomputed per synthesis launch; sort scratch aliases arrays that are filled later). The chain kernel is
+        # resident per query: input 48 + sorting permutation 4 + capacity words of the tails 2 x 32 = 116 bytes (no encodings
+        # and no sorted copy are kept: every kernel re-encodes the 48-byte query, the sorted side through the permutation;
+        # the grand-product chains and the sorted queries of the blocks being synthesized live in 2.3 GB of windows per context, recomputed per synthesis launch; sort scratch
+        # aliases arrays that are filled later). The chain kernel is
         # serial per queue, so a step wants as many concurrent queues as fit.
-        per_block = int(n * 168)
+        per_block = int(n * 128)
         cap = int(os.environ.get("ZKW_MAX_BLOCKS", "16384"))
-        B = int(max(16, min(cap, (0.90 * free - P * ring_p * 1.25e9 - P * 2.3e9) // per_block)))
+        B = int(max(16, min(cap, (0.90 * free - P * ring_p * 1.25e9 - P * 2.5e9) // per_block)))
         B = parallel.min_over_ranks(B, dev)  # every rank runs the same batch (weak scaling, equal record counts)
     B = max(P, B // P * P)
     Bp = B // P

@@ -66,6 +66,8 @@ struct ChainJob {
     u64* marks;          // [ceil(n / period)][12] full tails at items period-1, 2*period-1, ... and n-1, or nullptr
     u64 period;
     const zkw_mem_query* q;  // [n] when enc == nullptr (the RAM builder keeps no encodings: 48 B per item instead of 64)
+    const u32* perm;         // [n] or nullptr: item i is q[perm[i]] (the sorted queue as a permutation of the batch: q is
+                             // then the batch's base pointer; no sorted copy of the queries is kept)
 };
 
 // a memory query as three 16-byte words, and word g (0..7) of its encoding (memory_query.rs:24-118)
@@ -113,9 +115,11 @@ __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ 
     RawQuery rq_next;
     rq_next.a = rq_next.b = rq_next.c = make_uint4(0, 0, 0, 0);
     u64 e_next = 0;
+    u64 at_next = 0;  // index (into q) of item i + 2, fetched one iteration before its query
     if (absorbs && job.n > 0) {
-        if (from_q) rq_next = load_raw_query(job.q); else e_next = job.enc[g];
+        if (from_q) rq_next = load_raw_query(job.q + (job.perm ? job.perm[0] : 0)); else e_next = job.enc[g];
     }
+    if (absorbs && from_q && job.n > 1) at_next = job.perm ? job.perm[1] : 1;
     u64 next_mark = job.marks ? job.period : ~0ull, mark_idx = 0;  // item count at which the next full tail is kept
     u64 pend = 0, pend_i = 0;  // canonical tail of the previous item, not stored yet
     bool have_pend = false, pend_mark = false;
@@ -139,7 +143,12 @@ __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ 
         }
         flush();
         if (absorbs && i + 1 < job.n) {
-            if (from_q) rq_next = load_raw_query(job.q + i + 1); else e_next = job.enc[8 * (i + 1) + g];
+            if (from_q) {
+                rq_next = load_raw_query(job.q + at_next);
+                if (i + 2 < job.n) at_next = job.perm ? job.perm[i + 2] : i + 2;
+            } else {
+                e_next = job.enc[8 * (i + 1) + g];
+            }
         }
         u64 y = co.permute(absorbs ? e : x);  // AbsorptionModeOverwrite
         if (live) {
@@ -171,9 +180,11 @@ __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict
     const bool from_q = job.enc == nullptr;
     RawQuery rq_next;
     rq_next.a = rq_next.b = rq_next.c = make_uint4(0, 0, 0, 0);
+    u64 at_next = 0;  // index (into q) of item i + 2, fetched one iteration before its query
     if (job.n > 0) {
-        if (from_q) rq_next = load_raw_query(job.q); else { e0 = job.enc[j]; e1 = job.enc[4 + j]; }
+        if (from_q) rq_next = load_raw_query(job.q + (job.perm ? job.perm[0] : 0)); else { e0 = job.enc[j]; e1 = job.enc[4 + j]; }
     }
+    if (from_q && job.n > 1) at_next = job.perm ? job.perm[1] : 1;
     u64 next_mark = job.marks ? job.period : ~0ull, mark_idx = 0;
     u64 pend[3] = {0, 0, 0}, pend_i = 0;
     bool have_pend = false, pend_mark = false;
@@ -199,7 +210,12 @@ __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict
         u64 y[3] = {e0, e1, x[2]};  // AbsorptionModeOverwrite: rate part replaced, capacity kept
         flush();
         if (i + 1 < job.n) {
-            if (from_q) rq_next = load_raw_query(job.q + i + 1); else { e0 = job.enc[8 * (i + 1) + j]; e1 = job.enc[8 * (i + 1) + 4 + j]; }
+            if (from_q) {
+                rq_next = load_raw_query(job.q + at_next);
+                if (i + 2 < job.n) at_next = job.perm ? job.perm[i + 2] : i + 2;
+            } else {
+                e0 = job.enc[8 * (i + 1) + j]; e1 = job.enc[8 * (i + 1) + 4 + j];
+            }
         }
         co.permute(y);
         if (live) {
@@ -276,6 +292,7 @@ struct GpSeg {
     u32 first_tile;    // index of this segment's first tile in the launch
     u32 n_tiles;
     const zkw_mem_query* mem_q;  // [n] when rows == nullptr
+    const u32* perm;             // [n] or nullptr: row i is the encoding of mem_q[perm[i]]
 };
 struct GpTile {
     u32 seg;
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(GP_BLOCK) void k_gp_local(const GpSeg* __restrict__
             u64 e[W];
             if (W == 8 && seg.rows == nullptr) {
                 u64 e8[8];
-                encode_raw_query(load_raw_query(seg.mem_q + row), e8);
+                encode_raw_query(load_raw_query(seg.mem_q + (seg.perm ? seg.perm[row] : row)), e8);
 #pragma unroll
                 for (int k = 0; k < (W < 8 ? W : 8); k++) e[k] = e8[k];
             } else {
@@ -442,7 +459,8 @@ __global__ __launch_bounds__(256) void k_gather_encode(const zkw_mem_query* __re
 // the instance loop is sequential in the reference because of the running FSM values, but every
 // field is a pure function of the block-wide arrays, so each instance is filled independently.
 struct RamBlock {
-    const zkw_mem_query* sorted_q;  // [n]
+    const zkw_mem_query* sorted_q;  // the BATCH's queries; sorted item i of this block is sorted_q[sorted_perm[i]]
+    const u32* sorted_perm;         // [n]
     const u64* u_marks;             // [n_instances][12] unsorted queue tail after the last item of each instance
     const u64* s_marks;             // [n_instances][12] the same for the sorted queue
     const u64* lhs_z;               // [2][n]
@@ -467,7 +485,7 @@ __global__ __launch_bounds__(256) void k_ram_count_nondet(const RamBlock* __rest
         const u64 lo = inst * b.capacity, hi = lo + b.capacity < b.n ? lo + b.capacity : b.n;
         u32 cnt = 0;
         for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-            const zkw_mem_query* q = b.sorted_q + i;
+            const zkw_mem_query* q = b.sorted_q + b.sorted_perm[i];
             cnt += (q->rw_flag && q->timestamp == 0 && q->page == ZKW_BOOTLOADER_HEAP_PAGE) ? 1u : 0u;
         }
         for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
@@ -512,7 +530,7 @@ __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
         copy12(f.current_sorted_queue_state.head, b.s_marks + 12 * (l / b.capacity));
         copy12(f.current_sorted_queue_state.tail, s_final);
         f.current_sorted_queue_state.length = (u32)(n - end);
-        const zkw_mem_query* q = b.sorted_q + l;
+        const zkw_mem_query* q = b.sorted_q + b.sorted_perm[l];
         f.previous_sorting_key[0] = q->timestamp; f.previous_sorting_key[1] = q->index; f.previous_sorting_key[2] = q->page;
         f.previous_full_key[0] = q->index; f.previous_full_key[1] = q->page;
         for (int k = 0; k < 8; k++) f.previous_value[k] = q->value[k];

@@ -625,7 +625,11 @@ struct zkw_ram_witness {
     uint32_t capacity = 0;
     size_t total = 0, n_instances = 0;
     // owned device arrays
+    // The sorted queue is kept as the sorting permutation (4 B per query instead of a 48 B copy): sorted item i =
+    // unsorted_q[perm[i]], perm indexes the whole batch. ZKW_RAM_SORTED_QUERIES is gathered on first access.
     zkw_mem_query* sorted_q = nullptr;
+    bool sorted_valid = false;
+    u32* perm = nullptr;
     // The queue in its original order. Device-pointer mode: the CALLER's array (it must stay valid and unchanged
     // while the witness is synthesized or read); host-pointer mode: a copy owned by the witness. The builder keeps no
     // encodings (64 B per item and side): the chain, grand-product and fill kernels encode the 48-byte queries on the
@@ -645,18 +649,21 @@ struct zkw_ram_witness {
     u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
     bool z_valid = false;
     u64 *zbuf_l = nullptr, *zbuf_r = nullptr;
-    size_t zcap = 0;
+    zkw_mem_query* sq_win = nullptr;  // the sorted queries of the blocks being synthesized, gathered per synthesis call
+    size_t zcap = 0, sqcap = 0;       // capacity of the chain windows / of the sorted window, in queue items
     zkw_ram_instance* instances = nullptr;
     u32* nondet_counts = nullptr;
     u64 *compact_forms = nullptr, *public_inputs = nullptr;  // [n_instances][18], [n_instances][4]
 
     void release() {
-        void* ptrs[] = {sorted_q, owned_q, unsorted_enc, sorted_enc, unsorted_caps, sorted_caps, unsorted_marks, sorted_marks,
+        void* ptrs[] = {sorted_q, perm, owned_q, unsorted_enc, sorted_enc, unsorted_caps, sorted_caps, unsorted_marks, sorted_marks,
                         unsorted_tails, sorted_tails, challenges,
-                        lhs_z,    rhs_z,        instances,  nondet_counts, compact_forms, public_inputs, zbuf_l, zbuf_r};
+                        lhs_z,    rhs_z,        instances,  nondet_counts, compact_forms, public_inputs, zbuf_l, zbuf_r, sq_win};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         sorted_q = nullptr;
+        sorted_valid = false;
+        perm = nullptr;
         owned_q = nullptr;
         unsorted_q = nullptr;
         enc_valid = false;
@@ -665,7 +672,8 @@ struct zkw_ram_witness {
         tails_valid = false;
         z_valid = false;
         zbuf_l = zbuf_r = nullptr;
-        zcap = 0;
+        sq_win = nullptr;
+        zcap = sqcap = 0;
         instances = nullptr;
         nondet_counts = nullptr;
         compact_forms = public_inputs = nullptr;
@@ -674,7 +682,7 @@ struct zkw_ram_witness {
 
 static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
     const size_t t = w->total, ni = w->n_instances;
-    HIP_TRY(hipMalloc((void**)&w->sorted_q, (t + 1) * sizeof(zkw_mem_query)));
+    HIP_TRY(hipMalloc((void**)&w->perm, (t + 1) * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&w->unsorted_caps, (t + 1) * 4 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->sorted_caps, (t + 1) * 4 * sizeof(u64)));
     HIP_TRY(hipMalloc((void**)&w->unsorted_marks, (ni + 1) * 12 * sizeof(u64)));
@@ -683,11 +691,13 @@ static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
     {   // window of the grand-product chains: whole blocks, about 1 GB per side, at least the largest block
         size_t max_block = 0;
         for (size_t b = 0; b + 1 < w->offsets.size(); b++) max_block = std::max(max_block, (size_t)(w->offsets[b + 1] - w->offsets[b]));
-        size_t window = (size_t)1 << 26;
-        if (const char* e = getenv("ZKW_Z_WINDOW_ITEMS")) window = (size_t)strtoull(e, nullptr, 10);  // tests: force small groups
+        size_t window = (size_t)1 << 26, sq_window = (size_t)1 << 22;  // 2 x 1 GB of chains (few builder groups), 192 MB of sorted queries
+        if (const char* e = getenv("ZKW_Z_WINDOW_ITEMS")) window = sq_window = (size_t)strtoull(e, nullptr, 10);  // tests: force small groups
         w->zcap = std::max(max_block, std::min(t, window));
+        w->sqcap = std::max(max_block, std::min(t, sq_window));
         HIP_TRY(hipMalloc((void**)&w->zbuf_l, (w->zcap + 1) * 2 * sizeof(u64)));
         HIP_TRY(hipMalloc((void**)&w->zbuf_r, (w->zcap + 1) * 2 * sizeof(u64)));
+        HIP_TRY(hipMalloc((void**)&w->sq_win, (w->sqcap + 1) * sizeof(zkw_mem_query)));
     }
     HIP_TRY(hipMalloc((void**)&w->instances, (ni + 1) * sizeof(zkw_ram_instance)));
     HIP_TRY(hipMalloc((void**)&w->nondet_counts, (ni + 1) * sizeof(u32)));
@@ -763,7 +773,7 @@ static int ram_gp_blocks(zkw_ctx* ctx, const zkw_ram_witness* w, size_t b0, size
     for (size_t b = b0; b < b1; b++) {
         const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
         segs.push_back(GpSeg{nullptr, dst_l + 2 * (lo - base), w->challenges + 18 * b, n, 0, 0, w->unsorted_q + lo});
-        segs.push_back(GpSeg{nullptr, dst_r + 2 * (lo - base), w->challenges + 18 * b, n, 0, 0, w->sorted_q + lo});
+        segs.push_back(GpSeg{nullptr, dst_r + 2 * (lo - base), w->challenges + 18 * b, n, 0, 0, w->unsorted_q, w->perm + lo});
     }
     return dev_grand_products(ctx, segs, 8, 2);
 }
@@ -783,9 +793,9 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     ZKW_TRY(ram_sort(ctx, d_q, total, w->offsets, w->unsorted_caps, w->sorted_caps, &perm));
     w->tails_valid = false;
     w->enc_valid = false;
-    { Prof _p(ctx, "k_gather_encode"); hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, d_q, perm, total,
-                       w->sorted_q, (u64*)nullptr); }
-    ZKW_TRY(launch_check("k_gather_encode"));
+    w->sorted_valid = false;
+    // the permutation lives in the sort's scratch (the capacity-word arrays the chains are about to fill): keep a copy
+    HIP_TRY(hipMemcpyAsync(w->perm, perm, total * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
     // K2: 2 chains per block, all in one launch
     std::vector<ChainJob> chains;
     chains.reserve(2 * n_blocks);
@@ -793,7 +803,7 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
         const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
         const size_t io = w->inst_offsets[b];
         chains.push_back(ChainJob{nullptr, nullptr, nullptr, n, w->unsorted_caps + 4 * lo, w->unsorted_marks + 12 * io, w->capacity, w->unsorted_q + lo});
-        chains.push_back(ChainJob{nullptr, nullptr, nullptr, n, w->sorted_caps + 4 * lo, w->sorted_marks + 12 * io, w->capacity, w->sorted_q + lo});
+        chains.push_back(ChainJob{nullptr, nullptr, nullptr, n, w->sorted_caps + 4 * lo, w->sorted_marks + 12 * io, w->capacity, w->unsorted_q, w->perm + lo});
     }
     ZKW_TRY(dev_chains(ctx, chains));
     // K5: challenges from the two final tails (W/ram_permutation.rs:80-90)
@@ -819,7 +829,8 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
             const size_t lo = w->offsets[b], n = w->offsets[b + 1] - lo;
             const size_t n_inst = w->inst_offsets[b + 1] - w->inst_offsets[b];
             if (n_inst > max_inst) max_inst = n_inst;
-            blocks[b - b0] = RamBlock{w->sorted_q + lo,
+            blocks[b - b0] = RamBlock{w->unsorted_q,
+                                      w->perm + lo,
                                       w->unsorted_marks + 12 * w->inst_offsets[b],
                                       w->sorted_marks + 12 * w->inst_offsets[b],
                                       w->zbuf_l + 2 * (lo - base),
@@ -910,6 +921,21 @@ extern "C" int zkw_ram_build_instances(zkw_ctx* ctx, const zkw_mem_query* q, siz
 extern "C" size_t zkw_ram_witness_num_instances(const zkw_ram_witness* w) { return w ? w->n_instances : 0; }
 extern "C" size_t zkw_ram_witness_num_items(const zkw_ram_witness* w) { return w ? w->total : 0; }
 
+// The sorted queries of the ABI: gathered on first access.
+static int ram_sorted_queries(const zkw_ram_witness* cw) {
+    zkw_ram_witness* w = const_cast<zkw_ram_witness*>(cw);
+    if (w->sorted_valid) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t t = w->total;
+    if (!w->sorted_q && hipMalloc((void**)&w->sorted_q, (t + 1) * sizeof(zkw_mem_query)) != hipSuccess)
+        return fail(ZKW_ERR_OOM, "no room for the sorted queries (%zu bytes): read ZKW_RAM_SORTED_QUERIES from a smaller batch", t * sizeof(zkw_mem_query));
+    { Prof _p(ctx, "k_gather_encode"); hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(t, 256)), dim3(256), 0, ctx->stream, w->unsorted_q, w->perm, t, w->sorted_q, (u64*)nullptr); }
+    ZKW_TRY(launch_check("k_gather_encode"));
+    w->sorted_valid = true;
+    return ZKW_OK;
+}
+
 // The grand-product chains of the ABI ([2][n_b] per block at element offset 2 * block_offsets[b]): on first access.
 static int ram_full_chains(const zkw_ram_witness* cw) {
     zkw_ram_witness* w = const_cast<zkw_ram_witness*>(cw);
@@ -937,6 +963,7 @@ static int ram_encodings(const zkw_ram_witness* cw) {
         if (hipMalloc((void**)&w->unsorted_enc, (t + 1) * 64) != hipSuccess || hipMalloc((void**)&w->sorted_enc, (t + 1) * 64) != hipSuccess)
             return fail(ZKW_ERR_OOM, "no room for the materialised encodings (%zu bytes): read ZKW_RAM_*_ENC from a smaller batch", 2 * t * 64);
     }
+    ZKW_TRY(ram_sorted_queries(cw));
     ZKW_TRY(dev_encode(ctx, w->unsorted_q, t, w->unsorted_enc));
     ZKW_TRY(dev_encode(ctx, w->sorted_q, t, w->sorted_enc));
     w->enc_valid = true;
@@ -970,7 +997,7 @@ static int ram_full_tails(const zkw_ram_witness* cw) {
 static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes, bool materialize = true) {
     const size_t t = w->total, nb = w->offsets.size() - 1;
     switch (what) {
-        case ZKW_RAM_SORTED_QUERIES: *bytes = t * sizeof(zkw_mem_query); return w->sorted_q;
+        case ZKW_RAM_SORTED_QUERIES: *bytes = t * sizeof(zkw_mem_query); return materialize && ram_sorted_queries(w) == ZKW_OK ? w->sorted_q : nullptr;
         case ZKW_RAM_UNSORTED_ENC: *bytes = t * 64; return materialize && ram_encodings(w) == ZKW_OK ? w->unsorted_enc : nullptr;
         case ZKW_RAM_SORTED_ENC: *bytes = t * 64; return materialize && ram_encodings(w) == ZKW_OK ? w->sorted_enc : nullptr;
         case ZKW_RAM_UNSORTED_TAILS: *bytes = t * 96; return materialize && ram_full_tails(w) == ZKW_OK ? w->unsorted_tails : nullptr;
@@ -1094,15 +1121,22 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     while (b_first + 1 < n_blocks && w->inst_offsets[b_first + 1] <= first_instance) b_first++;
     size_t b_end = b_first + 1;  // one past the last block touched
     while (b_end < n_blocks && w->inst_offsets[b_end] < first_instance + n_instances) b_end++;
-    if (w->offsets[b_end] - w->offsets[b_first] > w->zcap) {  // too many blocks for one window: split at a block boundary
+    const size_t win = std::min(w->zcap, w->sqcap);
+    if (w->offsets[b_end] - w->offsets[b_first] > win) {  // too many blocks for one window: split at a block boundary
         size_t b_mid = b_first + 1;
-        while (b_mid + 1 < b_end && w->offsets[b_mid + 1] - w->offsets[b_first] <= w->zcap) b_mid++;
+        while (b_mid + 1 < b_end && w->offsets[b_mid + 1] - w->offsets[b_first] <= win) b_mid++;
         const size_t n_head = w->inst_offsets[b_mid] - first_instance;
         ZKW_TRY(zkw_ram_synthesize(ctx, w, first_instance, n_head, t, first_slot));
         return zkw_ram_synthesize(ctx, w, first_instance + n_head, n_instances - n_head, t, first_slot + n_head);
     }
     ZKW_TRY(ram_gp_blocks(ctx, w, b_first, b_end, w->zbuf_l, w->zbuf_r));
     const size_t z_base = w->offsets[b_first];
+    {   // the fills read the sorted queue contiguously: gather the touched blocks once per call
+        const size_t cnt = w->offsets[b_end] - z_base;
+        Prof _p(ctx, "k_gather_encode");
+        hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, w->unsorted_q, w->perm + z_base, cnt, w->sq_win, (u64*)nullptr);
+    }
+    ZKW_TRY(launch_check("k_gather_encode"));
     const u32 rstride = (u32)RC_REGION_STRIDE(capacity);  // rows per region incl. the alignment gap
     const u32 n_tiles = (rstride + 255) / 256;
     u32 *d_hist = nullptr, *d_nd = nullptr;
@@ -1117,7 +1151,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
         const size_t lo = w->offsets[b], nb = w->offsets[b + 1] - lo;
         SynthJob& j = jobs[k];
         j.inst = w->instances + idx;
-        j.sorted_q = w->sorted_q + lo;
+        j.sorted_q = w->sq_win + (lo - z_base);
         j.unsorted_q = w->unsorted_q + lo;
         j.unsorted_caps = w->unsorted_caps + 4 * lo;
         j.sorted_caps = w->sorted_caps + 4 * lo;
