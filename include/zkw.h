@@ -142,13 +142,14 @@ int zkw_ram_build_instances_batch(zkw_ctx *ctx, const zkw_mem_query *q, const ui
                                   zkw_ram_witness **out);
 
 enum {
-    ZKW_RAM_SORTED_QUERIES = 0, /* zkw_mem_query[total]           */
+    ZKW_RAM_SORTED_QUERIES = 0, /* zkw_mem_query[total]: gathered on first access (the builder keeps the permutation) */
     ZKW_RAM_UNSORTED_ENC = 1,   /* uint64_t[total][8]: materialised on first access (the builder encodes the 48-byte */
     ZKW_RAM_SORTED_ENC = 2,     /* queries on the fly in every kernel instead of keeping 2 x 64 bytes per query)     */
     ZKW_RAM_UNSORTED_TAILS = 3, /* uint64_t[total][12]: expanded on first access (the builder keeps only the   */
     ZKW_RAM_SORTED_TAILS = 4,   /* capacity words + the tails at instance ends: 64 instead of 192 bytes per query) */
     ZKW_RAM_CHALLENGES = 5,     /* uint64_t[n_blocks][2][9]       */
-    ZKW_RAM_LHS_Z = 6,          /* per block b: uint64_t[2][n_b] at element offset 2*block_offsets[b] */
+    ZKW_RAM_LHS_Z = 6,          /* per block b: uint64_t[2][n_b] at element offset 2*block_offsets[b]; computed on first
+                                   access (builder and synthesis recompute the chains in a window) */
     ZKW_RAM_RHS_Z = 7,          /* idem                           */
     ZKW_RAM_INSTANCES = 8,      /* zkw_ram_instance[n_instances], blocks in order */
     /* a20, CircuitMaker::process src/witness/postprocessing/mod.rs:353-405 (every instance of a block shares
