@@ -198,3 +198,23 @@ def test_chain_window_smaller_than_the_batch(oracle, monkeypatch):
     t.free()
     w.free()
     ctx.close()
+
+
+def test_witness_outlives_later_builds_in_host_pointer_mode(ctx, oracle):
+    """host-pointer mode: the witness owns a device copy of its queries (the kernels re-encode them at synthesis time),
+    so a later build on the same context — which reuses the context's staging buffers — does not disturb it"""
+    from era_zkevm_test_harness_amd import native
+
+    capacity, n_rows = 400, 1 << 12
+    q1, q2 = synthetic.ram_trace(1000, seed=71), synthetic.ram_trace(1000, seed=72)
+    w1 = ctx.compute_ram_circuit_snapshots(q1, capacity, 0)
+    w2 = ctx.compute_ram_circuit_snapshots(q2, capacity, 0)  # overwrites the staging copy of q1
+    o1 = oracle.ram_build_instances(q1, capacity, 0)
+    t = native.Trace(ctx, n_rows, w1.num_instances)
+    ctx.synthesize_ram(w1, t)
+    for i in range(w1.num_instances):
+        assert np.array_equal(t.get(i), oracle.ram_synthesize(o1, i, capacity, n_rows)), i
+    assert np.array_equal(w1.get(native.RAM_SORTED_QUERIES), o1["sorted_q"])
+    assert np.array_equal(w1.get(native.RAM_UNSORTED_ENC), o1["unsorted_enc"])
+    assert np.array_equal(w1.get(native.RAM_RHS_Z).reshape(2, -1), o1["rhs_z"])
+    t.free(); w1.free(); w2.free()
