@@ -95,7 +95,25 @@ def main():
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    n = args.queries
+    B = args.blocks
     P = max(1, args.pipelines)
+    if B <= 0:
+        free, _total = torch.cuda.mem_get_info(dev)
+        # resident per query: input 48 + sorting permutation 4 + capacity words of the tails 2 x 32 = 116 bytes (no
+        # encodings and no sorted copy are kept: every kernel re-encodes the 48-byte query, the sorted side through the
+        # permutation; the grand-product chains and the sorted queries of the blocks being synthesized live in 2.3 GB of
+        # windows per context, recomputed per synthesis launch; sort scratch aliases arrays that are filled later). The
+        # chain kernel is serial per queue, so a step wants as many concurrent queues as fit.
+        per_block = int(n * 128)
+        cap = int(os.environ.get("ZKW_MAX_BLOCKS", "16384"))
+        B = int(max(16, min(cap, (0.90 * free - max(2, args.ring // P) * P * 1.25e9 - P * 2.5e9) // per_block)))
+        B = parallel.min_over_ranks(B, dev)  # every rank runs the same batch (weak scaling, equal record counts)
+    if P > 1 and 2 * (B // P) <= 8400 and "--pipelines" not in sys.argv and "ZKW_PIPELINES" not in os.environ:
+        P = 1  # small batches keep their chains below the cliff of DESIGN.md 3.2, where overlapping pipelines lose
+    ring_p = max(2, args.ring // P)
+    B = max(P, B // P * P)
+    Bp = B // P
     ctxs, streams = [], []
     for _p in range(P):  # raises if libzkw / the GPU is missing: no fallback
         c = native.Context(local_rank)
@@ -108,23 +126,6 @@ def main():
         streams.append(st)
     ctx = ctxs[0]
     torch.cuda.set_stream(streams[0])
-
-    n = args.queries
-    B = args.blocks
-    ring_p = max(2, args.ring // P)
-    if B <= 0:
-        free, _total = torch.cuda.mem_get_info(dev)
-        # resident per query: input 48 + sorting permutation 4 + capacity words of the tails 2 x 32 = 116 bytes (no encodings
-        # and no sorted copy are kept: every kernel re-encodes the 48-byte query, the sorted side through the permutation;
-        # the grand-product chains and the sorted queries of the blocks being synthesized live in 2.3 GB of windows per context, recomputed per synthesis launch; sort scratch
-        # aliases arrays that are filled later). The chain kernel is
-        # serial per queue, so a step wants as many concurrent queues as fit.
-        per_block = int(n * 128)
-        cap = int(os.environ.get("ZKW_MAX_BLOCKS", "16384"))
-        B = int(max(16, min(cap, (0.90 * free - P * ring_p * 1.25e9 - P * 2.5e9) // per_block)))
-        B = parallel.min_over_ranks(B, dev)  # every rank runs the same batch (weak scaling, equal record counts)
-    B = max(P, B // P * P)
-    Bp = B // P
     n_rows = 1 << 20  # TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17
     rings = [native.Trace(ctxs[p], n_rows, ring_p) for p in range(P)]  # trace buffers a prover would consume and hand back
     base, q = make_inputs(B, n, rank, dev)
