@@ -117,8 +117,22 @@ def main():
     ctxs, streams = [], []
     for _p in range(P):  # raises if libzkw / the GPU is missing: no fallback
         c = native.Context(local_rank)
-        st = torch.cuda.Stream(device=dev)  # one stream per pipeline for torch ops and libzkw kernels
-        c.set_stream(st.cuda_stream)
+        cu_split = os.environ.get("ZKW_CU_SPLIT")  # experiment: "x/y" hex words, e.g. 55555555/aaaaaaaa
+        if cu_split:
+            import ctypes as C
+            hip = C.CDLL("libamdhip64.so")
+            mx, my = (int(v, 16) for v in cu_split.split("/"))
+            def masked(word):
+                h = C.c_void_p()
+                arr = (C.c_uint32 * 8)(*([word] * 8))
+                assert hip.hipExtStreamCreateWithCUMask(C.byref(h), 8, arr) == 0
+                return h.value
+            st = torch.cuda.ExternalStream(masked(my), device=dev)   # everything but the chains
+            c.set_stream(st.cuda_stream)
+            c.set_chain_stream(masked(mx))
+        else:
+            st = torch.cuda.Stream(device=dev)  # one stream per pipeline for torch ops and libzkw kernels
+            c.set_stream(st.cuda_stream)
         c.set_pointer_mode(native.PTR_DEVICE)
         if os.environ.get("ZKW_CHAIN_FORM"):
             c.set_chain_form(int(os.environ["ZKW_CHAIN_FORM"]))

@@ -81,6 +81,8 @@ struct zkw_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int ptr_mode = ZKW_PTR_HOST;
+    hipStream_t chain_stream = nullptr;  // optional second stream for the queue-chain kernels (zkw_set_chain_stream)
+    hipEvent_t chain_ev_a = nullptr, chain_ev_b = nullptr;
     int chain_form = 0;  // lanes per Poseidon2 state in the queue-chain kernel: 4 (quad), 16 (row), 0 = auto
     std::map<std::string, DevBuf> pool;  // named grow-only scratch
     std::map<std::string, HostStage> stages;
@@ -317,6 +319,17 @@ extern "C" int zkw_set_stream(zkw_ctx* ctx, void* s) {
     return ZKW_OK;
 }
 
+extern "C" int zkw_set_chain_stream(zkw_ctx* ctx, void* s) {
+    if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->chain_stream = static_cast<hipStream_t>(s);
+    if (s && !ctx->chain_ev_a) {
+        HIP_TRY(hipEventCreateWithFlags(&ctx->chain_ev_a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->chain_ev_b, hipEventDisableTiming));
+    }
+    return ZKW_OK;
+}
+
 extern "C" int zkw_set_pointer_mode(zkw_ctx* ctx, int mode) {
     if (!ctx || (mode != ZKW_PTR_HOST && mode != ZKW_PTR_DEVICE)) return fail(ZKW_ERR_INVALID, "bad pointer mode");
     ctx->ptr_mode = mode;
@@ -391,12 +404,25 @@ static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     // auto: the row form has the lower latency (11.2 vs 16.3 us per step) and wins while every wave can have
     // a SIMD to itself (<= 4096 chains); beyond that the quad form's 16 chains per wave win on throughput
     const int form = ctx->chain_form ? ctx->chain_form : (n_jobs >= 4096 ? 4 : 16);
-    if (form == 16) {
-        { Prof _p(ctx, "k_chain_full"); hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, ctx->stream, d_jobs, n_jobs); }
-        return launch_check("k_chain_full");
+    // the chain kernel may run on its own stream (e.g. one created with a CU mask): ordered after everything queued on
+    // the context's stream so far, and the context's stream continues after it
+    hipStream_t st = ctx->stream;
+    if (ctx->chain_stream) {
+        HIP_TRY(hipEventRecord(ctx->chain_ev_a, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->chain_stream, ctx->chain_ev_a, 0));
+        st = ctx->chain_stream;
     }
-    { Prof _p(ctx, "k_chain_full_q4"); hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, ctx->stream, d_jobs, n_jobs); }
-    return launch_check("k_chain_full_q4");
+    const char* name = form == 16 ? "k_chain_full" : "k_chain_full_q4";
+    {
+        Prof _p(ctx, name);
+        if (form == 16) hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
+        else hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
+        if (ctx->chain_stream) {  // the profiling events live on the context's stream: bring the kernel's end onto it first
+            (void)hipEventRecord(ctx->chain_ev_b, ctx->chain_stream);
+            (void)hipStreamWaitEvent(ctx->stream, ctx->chain_ev_b, 0);
+        }
+    }
+    return launch_check(name);
 }
 
 static int dev_fs(zkw_ctx* ctx, const std::vector<FsJob>& jobs, int state_w, int n_chal) {

@@ -24,6 +24,7 @@ SYMBOLS = [
     ("zkw_destroy", None, [_vp]),
     ("zkw_last_error", C.c_char_p, []),
     ("zkw_set_stream", _int, [_vp, _vp]),
+    ("zkw_set_chain_stream", _int, [_vp, _vp]),
     ("zkw_set_pointer_mode", _int, [_vp, _int]),
     ("zkw_synchronize", _int, [_vp]),
     ("zkw_set_chain_form", _int, [_vp, _int]),
@@ -678,6 +679,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_chain_stream(self, hip_stream):
+        _check(load().zkw_set_chain_stream(self.handle, C.c_void_p(hip_stream)))
 
     def set_pointer_mode(self, mode):
         _check(load().zkw_set_pointer_mode(self.handle, mode))

@@ -48,6 +48,9 @@ const char *zkw_last_error(void);
    ZKW_STREAM_OWN for the non-blocking stream the context created for itself (the default). */
 #define ZKW_STREAM_OWN ((void *)(intptr_t)-1)
 int zkw_set_stream(zkw_ctx *ctx, void *hip_stream);
+/* optional: run the queue-chain kernels on this HIP stream (ordered against the context's stream by events); lets the
+   host give the latency-bound chains their own CUs with a stream created by hipExtStreamCreateWithCUMask. NULL = off. */
+int zkw_set_chain_stream(zkw_ctx *ctx, void *hip_stream);
 int zkw_set_pointer_mode(zkw_ctx *ctx, int mode);
 int zkw_synchronize(zkw_ctx *ctx);
 /* tuning knob: lanes that cooperate on one Poseidon2 state in the queue-chain kernel: 16 (4 chains per wave,

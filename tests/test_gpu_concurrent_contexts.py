@@ -51,3 +51,33 @@ def test_two_contexts_in_parallel(oracle):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_chain_kernels_on_their_own_stream(oracle):
+    """zkw_set_chain_stream: the queue chains run on a second stream (here a CU-masked one), ordered against the context's
+    stream by events; results are unchanged"""
+    import ctypes as C
+
+    import torch
+
+    from era_zkevm_test_harness_amd import native
+
+    hip = C.CDLL("libamdhip64.so")
+    h = C.c_void_p()
+    mask = (C.c_uint32 * 8)(*([0x55555555] * 8))
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(h), 8, mask) == 0
+    ctx = native.Context(0)
+    st = torch.cuda.Stream()
+    ctx.set_stream(st.cuda_stream)
+    ctx.set_chain_stream(h.value)
+    q = synthetic.ram_trace(3000, seed=5)
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            w = ctx.compute_ram_circuit_snapshots(q, 700, 0)
+            o = oracle.ram_build_instances(q, 700, 0)
+            assert w.get(native.RAM_INSTANCES).tobytes() == o["instances"].tobytes()
+            assert np.array_equal(w.get(native.RAM_UNSORTED_TAILS), o["unsorted_tails"])
+            w.free()
+    ctx.set_chain_stream(None)
+    ctx.close()
+    assert hip.hipStreamDestroy(h) == 0
