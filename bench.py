@@ -163,8 +163,19 @@ def main():
         c, w, ring = ctxs[p], ws[p], rings[p]
         with torch.cuda.stream(streams[p]):
             c.compute_ram_circuit_snapshots((q.data_ptr() + p * Bp * n * q_item, Bp * n), CAPACITY, 0, block_offsets=offs, witness=w)
-            for first in range(0, n_inst_p, ring_p):  # synthesis: every instance -> a full 2^20-row trace
-                c.synthesize_ram(w, ring, first, min(ring_p, n_inst_p - first), 0)
+            if P > 1 and synth_turns:
+                # synthesis phases take turns: a pipeline fills at full speed while the others are in their chain pass,
+                # instead of two synthesis phases slowing each other down
+                streams[p].synchronize()
+                synth_lock.acquire()
+            try:
+                for first in range(0, n_inst_p, ring_p):  # synthesis: every instance -> a full 2^20-row trace
+                    c.synthesize_ram(w, ring, first, min(ring_p, n_inst_p - first), 0)
+                if P > 1 and synth_turns:
+                    streams[p].synchronize()
+            finally:
+                if P > 1 and synth_turns:
+                    synth_lock.release()
             lo, hi = p * n_inst_p, (p + 1) * n_inst_p
             cp, pp = compact[lo:hi], pis[lo:hi]
             native._check(lib.zkw_ram_witness_get(w.handle, native.RAM_COMPACT_FORMS, cp.data_ptr(), cp.numel() * 8))
@@ -175,7 +186,10 @@ def main():
             streams[p].synchronize()
 
     from concurrent.futures import ThreadPoolExecutor
+    import threading
     pool = ThreadPoolExecutor(P)
+    synth_lock = threading.Lock()
+    synth_turns = os.environ.get("ZKW_SYNTH_TURNS", "1") != "0"
 
     def pipeline_run(p, passes, delay_s):
         torch.cuda.set_device(local_rank)
@@ -209,6 +223,8 @@ def main():
     # per-item latency of the regime the sub-batch is in rather than from a noisy warm-up measurement.
     per_item_s = 21.5e-6 if 2 * Bp > 8400 else 14.4e-6
     stagger_s = 0.72 * n * per_item_s * 2 / P if P > 1 else 0.0
+    if P > 1 and os.environ.get("ZKW_SYNTH_TURNS", "1") != "0":
+        stagger_s = 0.5  # with the synthesis phases taking turns the pipelines order themselves; a short offset starts that
     for k in range(args.warmup):
         run_steps(1, 0.0)
     if args.stagger_ms >= 0:
