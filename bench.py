@@ -6,7 +6,9 @@ production RAMPermutation capacity, 136 714 queries = one 2^20-row instance) go 
 generation (encode, sort, both Poseidon2 queue chains, Fiat-Shamir challenges, grand products, instance
 records) and synthesis (every instance materialised into a full 149-column x 2^20-row trace, written
 into a ring of trace buffers). Inputs are
-resident in HBM before the timed region. N > 1: one process per GPU, blocks sharded with no data-path
+resident in HBM before the timed region. By default the B blocks run as two pipelines (two contexts, HIP streams and host
+threads over one half of the blocks each) whose synthesis phases take turns, so that one half's synthesis overlaps the
+other half's queue chains; every timed step is still one pass of every block through the whole path. N > 1: one process per GPU, blocks sharded with no data-path
 collective; the per-instance closed-form records are gathered to rank 0 (RCCL) inside the timed region.
 
 Prints ONE JSON line (rank 0). See DESIGN.md "Measurement" for the roofline/cpu_baseline definitions.
@@ -86,7 +88,7 @@ def main():
                          "stream, host thread), started a fraction of a chain pass apart so that one pipeline's synthesis "
                          "overlaps the other's queue chains (DESIGN.md 3.2: +10..14 %% at P = 2 on the HBM-sized batch; "
                          "P = 1 is the plain sequential step)")
-    ap.add_argument("--stagger-ms", type=float, default=-1.0, help="start offset between pipelines (default: measured in warm-up)")
+    ap.add_argument("--stagger-ms", type=float, default=-1.0, help="start offset between pipelines (default 500 ms)")
     ap.add_argument("--cpu-sample", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
