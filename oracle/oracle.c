@@ -1,5 +1,6 @@
 /* oracle.c — TEST INFRASTRUCTURE: CPU restatement of the reference hot path (see oracle.h).
- * Written for obviousness, not speed: field ops reduce through unsigned __int128 `% p`.
+ * Written for obviousness; the field ops use the 2^64 = 2^32 - 1 reduction (checked against one-`%` reference forms
+ * in the tests) so that the cpu_baseline leg of bench.py times a competent scalar CPU path.
  */
 #include "oracle.h"
 #include "poseidon2_constants.h"
@@ -11,9 +12,26 @@ typedef unsigned __int128 u128;
 #define P ZKW_GOLDILOCKS_P
 
 /* ------------------------------------------------------------------ field */
-uint64_t orc_gl_add(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a + b) % P); }
-uint64_t orc_gl_sub(uint64_t a, uint64_t b) { return (uint64_t)(((u128)(a % P) + P - (b % P)) % P); }
-uint64_t orc_gl_mul(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % P); }
+/* Reference forms (one `%` on unsigned __int128 each): what the fast forms below are checked against in
+ * tests/test_oracle_field_hash.py. */
+uint64_t orc_gl_add_ref(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a + b) % P); }
+uint64_t orc_gl_sub_ref(uint64_t a, uint64_t b) { return (uint64_t)(((u128)(a % P) + P - (b % P)) % P); }
+uint64_t orc_gl_mul_ref(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % P); }
+
+/* Fast forms (boojum's GoldilocksField does the same: 2^64 = 2^32 - 1 and 2^96 = -1 mod p). Any u64 in, canonical out.
+ * Defined inline in oracle.h; these are the exported symbols (ctypes, tests). */
+#undef orc_gl_reduce128
+#undef orc_gl_add
+#undef orc_gl_sub
+#undef orc_gl_mul
+uint64_t orc_gl_reduce128(u128 w) { return orc_gl_reduce128_inl(w); }
+uint64_t orc_gl_add(uint64_t a, uint64_t b) { return orc_gl_add_inl(a, b); }
+uint64_t orc_gl_sub(uint64_t a, uint64_t b) { return orc_gl_sub_inl(a, b); }
+uint64_t orc_gl_mul(uint64_t a, uint64_t b) { return orc_gl_mul_inl(a, b); }
+#define orc_gl_reduce128 orc_gl_reduce128_inl
+#define orc_gl_add orc_gl_add_inl
+#define orc_gl_sub orc_gl_sub_inl
+#define orc_gl_mul orc_gl_mul_inl
 uint64_t orc_gl_pow(uint64_t a, uint64_t e) {
     uint64_t r = 1, b = a % P;
     while (e) {
@@ -39,7 +57,7 @@ static void p2_external(uint64_t s[12]) {
         for (int i = 0; i < 4; i++) {
             u128 acc = 0;
             for (int j = 0; j < 4; j++) acc += (u128)M4[i][j] * s[4 * c + j];
-            t[4 * c + i] = (uint64_t)(acc % P);
+            t[4 * c + i] = orc_gl_reduce128(acc);
         }
     for (int i = 0; i < 4; i++) {
         uint64_t col = orc_gl_add(orc_gl_add(t[i], t[4 + i]), t[8 + i]);
@@ -55,7 +73,8 @@ static void p2_internal(uint64_t s[12]) {
         s[i] = orc_gl_add(orc_gl_mul(s[i], 1ULL << P2_INTERNAL_DIAG_SHIFTS[i]), sum);
 }
 
-void orc_poseidon2_permutation(uint64_t s[12]) {
+/* the obvious form: what the fast form below is tested against (tests/test_oracle_field_hash.py) */
+void orc_poseidon2_permutation_ref(uint64_t s[12]) {
     int r = 0;
     p2_external(s);
     for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
@@ -72,6 +91,66 @@ void orc_poseidon2_permutation(uint64_t s[12]) {
     }
 }
 
+/* The same permutation written the way a competent scalar CPU implementation does it (boojum's generic
+ * `State`: unreduced u128 sums in the linear layers, one reduction per output, branch-free reductions, values kept
+ * in "weak" form = any u64 congruent to the element, canonicalised once at the end). This is what every oracle
+ * routine calls and what bench.py's cpu_baseline leg times. */
+static inline uint64_t w_red(u128 w) { /* weak result */
+    const uint64_t lo = (uint64_t)w, hi = (uint64_t)(w >> 64), hh = hi >> 32, hl = hi & ORC_GL_EPS;
+    uint64_t t0, r;
+    const uint64_t bo = __builtin_sub_overflow(lo, hh, &t0);
+    t0 -= (0 - bo) & ORC_GL_EPS;
+    const uint64_t t1 = (hl << 32) - hl;
+    const uint64_t ca = __builtin_add_overflow(t0, t1, &r);
+    return r + ((0 - ca) & ORC_GL_EPS);
+}
+static inline uint64_t w_mul(uint64_t a, uint64_t b) { return w_red((u128)a * b); }
+static inline uint64_t w_sbox(uint64_t x) {
+    const uint64_t x2 = w_mul(x, x), x3 = w_mul(x2, x), x4 = w_mul(x2, x2);
+    return w_mul(x3, x4);
+}
+static inline void w_external(uint64_t s[12]) {
+    u128 t[12];
+    for (int c = 0; c < 3; c++) { /* the Poseidon2 addition chain for M4, on unreduced sums (< 2^68) */
+        const u128 x0 = s[4 * c], x1 = s[4 * c + 1], x2 = s[4 * c + 2], x3 = s[4 * c + 3];
+        const u128 t0 = x0 + x1, t1 = x2 + x3, t2 = 2 * x1 + t1, t3 = 2 * x3 + t0, t4 = 4 * t1 + t3, t5 = 4 * t0 + t2;
+        t[4 * c] = t3 + t5; t[4 * c + 1] = t5; t[4 * c + 2] = t2 + t4; t[4 * c + 3] = t4;
+    }
+    for (int i = 0; i < 4; i++) {
+        const u128 col = t[i] + t[4 + i] + t[8 + i];
+        for (int c = 0; c < 3; c++) s[4 * c + i] = w_red(t[4 * c + i] + col);
+    }
+}
+static inline void w_internal(uint64_t s[12]) {
+    u128 sum = 0;
+    for (int i = 0; i < 12; i++) sum += s[i];
+    for (int i = 0; i < 12; i++) s[i] = w_red(((u128)s[i] << P2_INTERNAL_DIAG_SHIFTS[i]) + sum);
+}
+static inline uint64_t w_add(uint64_t a, uint64_t b) { /* weak + canonical constant */
+    uint64_t r;
+    const uint64_t ca = __builtin_add_overflow(a, b, &r);
+    uint64_t r2;
+    const uint64_t cb = __builtin_add_overflow(r, (0 - ca) & ORC_GL_EPS, &r2);
+    return r2 + ((0 - cb) & ORC_GL_EPS);
+}
+void orc_poseidon2_permutation(uint64_t s[12]) {
+    int r = 0;
+    w_external(s);
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+        for (int i = 0; i < 12; i++) s[i] = w_sbox(w_add(s[i], P2_ROUND_CONSTANTS[12 * r + i]));
+        w_external(s);
+    }
+    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
+        s[0] = w_sbox(w_add(s[0], P2_ROUND_CONSTANTS[12 * r]));
+        w_internal(s);
+    }
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+        for (int i = 0; i < 12; i++) s[i] = w_sbox(w_add(s[i], P2_ROUND_CONSTANTS[12 * r + i]));
+        w_external(s);
+    }
+    for (int i = 0; i < 12; i++) s[i] = s[i] >= P ? s[i] - P : s[i];
+}
+
 /* Plonky2-compatible Poseidon over the same constant table (naive form): pins the table. */
 void orc_poseidon1_permutation(uint64_t s[12]) {
     static const uint64_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
@@ -86,7 +165,7 @@ void orc_poseidon1_permutation(uint64_t s[12]) {
             u128 acc = 0;
             for (int i = 0; i < 12; i++) acc += (u128)CIRC[i] * s[(i + row) % 12];
             if (row == 0) acc += (u128)8 * s[0];
-            t[row] = (uint64_t)(acc % P);
+            t[row] = orc_gl_reduce128(acc);
         }
         memcpy(s, t, sizeof t);
     }

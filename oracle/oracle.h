@@ -20,14 +20,48 @@ extern "C" {
 #endif
 
 /* ---- Goldilocks field (boojum GoldilocksField; call sites circuit_encodings/src/lib.rs:664-713) */
+/* field ops: any u64 in, canonical out. The *_ref forms are the one-`%` definitions the fast forms are tested against. */
+uint64_t orc_gl_reduce128(unsigned __int128 w);
+uint64_t orc_gl_add_ref(uint64_t a, uint64_t b);
+uint64_t orc_gl_sub_ref(uint64_t a, uint64_t b);
+uint64_t orc_gl_mul_ref(uint64_t a, uint64_t b);
 uint64_t orc_gl_add(uint64_t a, uint64_t b);
 uint64_t orc_gl_sub(uint64_t a, uint64_t b);
 uint64_t orc_gl_mul(uint64_t a, uint64_t b);
 uint64_t orc_gl_pow(uint64_t a, uint64_t e);
 uint64_t orc_gl_inv(uint64_t a);
+/* The same three ops as static inline functions: inside the oracle's own translation units calls to orc_gl_add / _sub /
+ * _mul resolve to these (a call through the PLT per field operation costs more than the operation). */
+#define ORC_GL_P 0xFFFFFFFF00000001ULL
+#define ORC_GL_EPS 0xFFFFFFFFULL
+static inline uint64_t orc_gl_reduce128_inl(unsigned __int128 w) {
+    const uint64_t lo = (uint64_t)w, hi = (uint64_t)(w >> 64), hh = hi >> 32, hl = hi & ORC_GL_EPS;
+    uint64_t t0 = lo - hh;
+    if (lo < hh) t0 -= ORC_GL_EPS; /* wrapped by 2^64 = EPS */
+    const uint64_t t1 = hl * ORC_GL_EPS;
+    uint64_t r = t0 + t1;
+    if (r < t1) r += ORC_GL_EPS;
+    return r >= ORC_GL_P ? r - ORC_GL_P : r;
+}
+static inline uint64_t orc_gl_add_inl(uint64_t a, uint64_t b) { return orc_gl_reduce128_inl((unsigned __int128)a + b); }
+static inline uint64_t orc_gl_sub_inl(uint64_t a, uint64_t b) {
+    if (a >= ORC_GL_P) a -= ORC_GL_P;
+    if (b >= ORC_GL_P) b -= ORC_GL_P;
+    return a >= b ? a - b : a + (ORC_GL_P - b);
+}
+static inline uint64_t orc_gl_mul_inl(uint64_t a, uint64_t b) { return orc_gl_reduce128_inl((unsigned __int128)a * b); }
+#ifndef ORC_FIELD_EXPORTS
+#define orc_gl_reduce128 orc_gl_reduce128_inl
+#define orc_gl_add orc_gl_add_inl
+#define orc_gl_sub orc_gl_sub_inl
+#define orc_gl_mul orc_gl_mul_inl
+#endif
+
 
 /* ---- Poseidon2Goldilocks as AlgebraicRoundFunction<F, 8, 12, 4> (lib.rs:12-15) */
 void orc_poseidon2_permutation(uint64_t state[12]);
+/* the same permutation in its obvious form (one reduction per field operation): cross-check of the fast form */
+void orc_poseidon2_permutation_ref(uint64_t state[12]);
 /* Poseidon (original, Plonky2-compatible) — used only to pin the shared round-constant table */
 void orc_poseidon1_permutation(uint64_t state[12]);
 /* absorb_multiple_rounds::<AbsorptionModeOverwrite> (call sites lib.rs:198-203, 405-409):

@@ -126,7 +126,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         u64, u64p, sz, vp = C.c_uint64, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p
-        for name in ("orc_gl_add", "orc_gl_sub", "orc_gl_mul", "orc_gl_pow"):
+        for name in ("orc_gl_add", "orc_gl_sub", "orc_gl_mul", "orc_gl_pow", "orc_gl_add_ref", "orc_gl_sub_ref", "orc_gl_mul_ref"):
             getattr(_lib, name).restype = u64
             getattr(_lib, name).argtypes = [u64, u64]
         _lib.orc_gl_inv.restype = u64
@@ -177,6 +177,13 @@ def poseidon2(state):
     s = _u64(state).copy()
     assert s.shape == (12,)
     lib().orc_poseidon2_permutation(_p(s))
+    return s
+
+
+def poseidon2_ref(state):
+    s = _u64(state).copy()
+    assert s.shape == (12,)
+    lib().orc_poseidon2_permutation_ref(_p(s))
     return s
 
 

@@ -33,7 +33,7 @@ static void ext_layer(uint64_t s[12]) {
         for (int i = 0; i < 4; i++) {
             u128 acc = 0;
             for (int j = 0; j < 4; j++) acc += (u128)M4[i][j] * s[4 * c + j];
-            t[4 * c + i] = (uint64_t)(acc % P);
+            t[4 * c + i] = orc_gl_reduce128(acc);
         }
     for (int i = 0; i < 4; i++) {
         uint64_t col = orc_gl_add(orc_gl_add(t[i], t[4 + i]), t[8 + i]);

@@ -19,7 +19,8 @@ def test_field_ops_match_bigint(oracle):
         for b in vals:
             assert lib.orc_gl_add(a, b) == (a + b) % P
             assert lib.orc_gl_sub(a, b) == (a - b) % P
-            assert lib.orc_gl_mul(a, b) == (a * b) % P
+            assert lib.orc_gl_mul(a, b) == (a * b) % P == lib.orc_gl_mul_ref(a, b)
+            assert lib.orc_gl_add_ref(a, b) == (a + b) % P and lib.orc_gl_sub_ref(a, b) == (a - b) % P
     for a in vals[1:30]:
         if a % P:
             assert lib.orc_gl_mul(a, lib.orc_gl_inv(a)) == 1
@@ -33,6 +34,17 @@ def test_round_constant_table_pinned_by_poseidon_kat(oracle):
            0xD7709673896996DC, 0x46A84E87642F44ED, 0xD032648251EE0B3C, 0x1C687363B207DF62,
            0xDF8565563E8045FE, 0x40F5B37FF4254DAE, 0xD070F637B431067C, 0x1792B1C4342109D7]
     assert [int(x) for x in out] == exp
+
+
+def test_fast_permutation_matches_obvious_form(oracle):
+    """orc_poseidon2_permutation (lazy reductions, weak representatives) against the one-reduction-per-operation form,
+    incl. non-canonical and extreme inputs"""
+    cases = [np.zeros(12, np.uint64), np.full(12, 2**64 - 1, np.uint64), np.full(12, P - 1, np.uint64),
+             np.array([P, P + 1, 2**64 - 1, 0, 1, 2**32 - 1, 2**32, 2**63, P - 1, 5, 7, 2**64 - 2**32], np.uint64)]
+    cases += [RNG.integers(0, 2**64, 12, dtype=np.uint64) for _ in range(200)]
+    for c in cases:
+        a, b = oracle.poseidon2(c), oracle.poseidon2_ref(c)
+        assert np.array_equal(a, b) and int(a.max()) < P
 
 
 def _py_poseidon2(s, RC, SH):
