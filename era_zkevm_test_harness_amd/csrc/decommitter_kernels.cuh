@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void k_decommitter_mem_queries(DecommitterJob 
     uint4* d = reinterpret_cast<uint4*>(job.mem_q + i);
     const uint4* s = reinterpret_cast<const uint4*>(&m);
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    if (!job.mem_enc) return;  // zkw_decommitter_memory_queries: the queries only
     u64 e[8];
     encode_mem_query(m, e);
     ulonglong2* o = reinterpret_cast<ulonglong2*>(job.mem_enc + 8 * i);

@@ -6,6 +6,8 @@
 // grow-only per-context pool so that steady-state calls do no hipMalloc.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -83,6 +85,9 @@ struct zkw_ctx {
     int ptr_mode = ZKW_PTR_HOST;
     hipStream_t chain_stream = nullptr;  // optional second stream for the queue-chain kernels (zkw_set_chain_stream)
     hipEvent_t chain_ev_a = nullptr, chain_ev_b = nullptr;
+    // witnesses and traces created from this context keep it alive: zkw_destroy defers while any is outstanding
+    std::atomic<long> children{0};
+    std::atomic<bool> destroy_requested{false};
     int chain_form = 0;  // lanes per Poseidon2 state in the queue-chain kernel: 4 (quad), 16 (row), 0 = auto
     std::map<std::string, DevBuf> pool;  // named grow-only scratch
     std::map<std::string, HostStage> stages;
@@ -296,8 +301,7 @@ extern "C" zkw_ctx* zkw_create(int device_id) {
     return ctx;
 }
 
-extern "C" void zkw_destroy(zkw_ctx* ctx) {
-    if (!ctx) return;
+static void ctx_destroy_now(zkw_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->pool)
@@ -308,8 +312,27 @@ extern "C" void zkw_destroy(zkw_ctx* ctx) {
         if (kv.second.p) (void)hipHostFree(kv.second.p);
         if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
     }
+    if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
+    if (ctx->chain_ev_b) (void)hipEventDestroy(ctx->chain_ev_b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+static void ctx_retain(zkw_ctx* ctx) { ctx->children.fetch_add(1); }
+static void ctx_release(zkw_ctx* ctx) {
+    if (ctx->children.fetch_sub(1) == 1 && ctx->destroy_requested.load()) ctx_destroy_now(ctx);
+}
+
+// Witnesses and traces dereference their context when they are read or freed, so a context with outstanding
+// children is only marked: the last zkw_*_free destroys it (zkw.h "Lifetimes").
+extern "C" void zkw_destroy(zkw_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->children.load() > 0) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->destroy_requested.store(true);
+        return;
+    }
+    ctx_destroy_now(ctx);
 }
 
 extern "C" int zkw_set_stream(zkw_ctx* ctx, void* s) {
@@ -322,11 +345,20 @@ extern "C" int zkw_set_stream(zkw_ctx* ctx, void* s) {
 extern "C" int zkw_set_chain_stream(zkw_ctx* ctx, void* s) {
     if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->chain_stream = static_cast<hipStream_t>(s);
-    if (s && !ctx->chain_ev_a) {
-        HIP_TRY(hipEventCreateWithFlags(&ctx->chain_ev_a, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->chain_ev_b, hipEventDisableTiming));
+    if (s && !(ctx->chain_ev_a && ctx->chain_ev_b)) {  // both events or neither
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        hipError_t e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(a);
+            return fail(ZKW_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+        }
+        if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
+        if (ctx->chain_ev_b) (void)hipEventDestroy(ctx->chain_ev_b);
+        ctx->chain_ev_a = a;
+        ctx->chain_ev_b = b;
     }
+    ctx->chain_stream = static_cast<hipStream_t>(s);
     return ZKW_OK;
 }
 
@@ -418,8 +450,8 @@ static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
         if (form == 16) hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
         else hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
         if (ctx->chain_stream) {  // the profiling events live on the context's stream: bring the kernel's end onto it first
-            (void)hipEventRecord(ctx->chain_ev_b, ctx->chain_stream);
-            (void)hipStreamWaitEvent(ctx->stream, ctx->chain_ev_b, 0);
+            HIP_TRY(hipEventRecord(ctx->chain_ev_b, ctx->chain_stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->chain_ev_b, 0));
         }
     }
     return launch_check(name);
@@ -706,6 +738,7 @@ struct zkw_ram_witness {
     }
 };
 
+extern "C" void zkw_ram_witness_free(zkw_ram_witness* w);
 static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
     const size_t t = w->total, ni = w->n_instances;
     HIP_TRY(hipMalloc((void**)&w->perm, (t + 1) * sizeof(u32)));
@@ -903,8 +936,7 @@ extern "C" int zkw_ram_build_instances_batch(zkw_ctx* ctx, const zkw_mem_query* 
     if (total >= (1ull << 32)) return fail(ZKW_ERR_INVALID, "more than 2^32-1 queries in one batch");
     zkw_ram_witness* w = *out;
     if (w && (w->ctx != ctx || w->offsets != offs || w->capacity != capacity)) {
-        w->release();
-        delete w;
+        zkw_ram_witness_free(w);
         w = nullptr;
         *out = nullptr;
     }
@@ -934,6 +966,7 @@ extern "C" int zkw_ram_build_instances_batch(zkw_ctx* ctx, const zkw_mem_query* 
         }
         return rc;
     }
+    if (!*out) ctx_retain(ctx);  // a reused witness already holds its reference
     *out = w;
     return ZKW_OK;
 }
@@ -1020,22 +1053,29 @@ static int ram_full_tails(const zkw_ram_witness* cw) {
     return ZKW_OK;
 }
 
-static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes, bool materialize = true) {
+// rc (optional): status of the lazy materialisation, so that an OOM / HIP failure is reported as such
+static const void* ram_array(const zkw_ram_witness* w, int what, size_t* bytes, bool materialize = true, int* rc = nullptr) {
     const size_t t = w->total, nb = w->offsets.size() - 1;
+    int st = ZKW_OK;
+    const void* p = nullptr;
+#define RAM_LAZY(fn, field) do { if (materialize) { st = fn(w); if (st == ZKW_OK) p = w->field; } } while (0)
     switch (what) {
-        case ZKW_RAM_SORTED_QUERIES: *bytes = t * sizeof(zkw_mem_query); return materialize && ram_sorted_queries(w) == ZKW_OK ? w->sorted_q : nullptr;
-        case ZKW_RAM_UNSORTED_ENC: *bytes = t * 64; return materialize && ram_encodings(w) == ZKW_OK ? w->unsorted_enc : nullptr;
-        case ZKW_RAM_SORTED_ENC: *bytes = t * 64; return materialize && ram_encodings(w) == ZKW_OK ? w->sorted_enc : nullptr;
-        case ZKW_RAM_UNSORTED_TAILS: *bytes = t * 96; return materialize && ram_full_tails(w) == ZKW_OK ? w->unsorted_tails : nullptr;
-        case ZKW_RAM_SORTED_TAILS: *bytes = t * 96; return materialize && ram_full_tails(w) == ZKW_OK ? w->sorted_tails : nullptr;
-        case ZKW_RAM_CHALLENGES: *bytes = nb * 18 * 8; return w->challenges;
-        case ZKW_RAM_LHS_Z: *bytes = t * 16; return materialize && ram_full_chains(w) == ZKW_OK ? w->lhs_z : nullptr;
-        case ZKW_RAM_RHS_Z: *bytes = t * 16; return materialize && ram_full_chains(w) == ZKW_OK ? w->rhs_z : nullptr;
-        case ZKW_RAM_INSTANCES: *bytes = w->n_instances * sizeof(zkw_ram_instance); return w->instances;
-        case ZKW_RAM_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->compact_forms;
-        case ZKW_RAM_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->public_inputs;
-        default: *bytes = 0; return nullptr;
+        case ZKW_RAM_SORTED_QUERIES: *bytes = t * sizeof(zkw_mem_query); RAM_LAZY(ram_sorted_queries, sorted_q); break;
+        case ZKW_RAM_UNSORTED_ENC: *bytes = t * 64; RAM_LAZY(ram_encodings, unsorted_enc); break;
+        case ZKW_RAM_SORTED_ENC: *bytes = t * 64; RAM_LAZY(ram_encodings, sorted_enc); break;
+        case ZKW_RAM_UNSORTED_TAILS: *bytes = t * 96; RAM_LAZY(ram_full_tails, unsorted_tails); break;
+        case ZKW_RAM_SORTED_TAILS: *bytes = t * 96; RAM_LAZY(ram_full_tails, sorted_tails); break;
+        case ZKW_RAM_CHALLENGES: *bytes = nb * 18 * 8; p = w->challenges; break;
+        case ZKW_RAM_LHS_Z: *bytes = t * 16; RAM_LAZY(ram_full_chains, lhs_z); break;
+        case ZKW_RAM_RHS_Z: *bytes = t * 16; RAM_LAZY(ram_full_chains, rhs_z); break;
+        case ZKW_RAM_INSTANCES: *bytes = w->n_instances * sizeof(zkw_ram_instance); p = w->instances; break;
+        case ZKW_RAM_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; p = w->compact_forms; break;
+        case ZKW_RAM_PUBLIC_INPUTS: *bytes = w->n_instances * 32; p = w->public_inputs; break;
+        default: *bytes = 0; st = ZKW_ERR_INVALID; break;
     }
+#undef RAM_LAZY
+    if (rc) *rc = st;
+    return p;
 }
 
 extern "C" size_t zkw_ram_witness_bytes(const zkw_ram_witness* w, int what) {
@@ -1052,9 +1092,11 @@ extern "C" const void* zkw_ram_witness_device_ptr(const zkw_ram_witness* w, int 
 extern "C" int zkw_ram_witness_get(const zkw_ram_witness* w, int what, void* dst, size_t dst_bytes) {
     if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: null argument");
     size_t bytes = 0;
-    const void* src = ram_array(w, what, &bytes);
-    if (!src && (what == ZKW_RAM_UNSORTED_TAILS || what == ZKW_RAM_SORTED_TAILS)) return ZKW_ERR_OOM;  // message set by ram_full_tails
-    if (!src) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: unknown array %d", what);
+    int st = ZKW_OK;
+    const void* src = ram_array(w, what, &bytes, true, &st);
+    if (st == ZKW_ERR_INVALID) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: unknown array %d", what);
+    if (st != ZKW_OK) return st;  // the lazy materialisation failed: its own code and message (OOM, HIP)
+    if (!src) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: array %d is empty", what);
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: need %zu bytes, got %zu", bytes, dst_bytes);
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1069,7 +1111,9 @@ extern "C" void zkw_ram_witness_free(zkw_ram_witness* w) {
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
+    zkw_ctx* owner = w->ctx;
     delete w;
+    ctx_release(owner);
 }
 
 // ------------------------------------------------------------------------------------------------ traces / synthesis
@@ -1095,6 +1139,7 @@ extern "C" int zkw_trace_create_with_columns(zkw_ctx* ctx, size_t n_rows, size_t
         return fail(ZKW_ERR_OOM, "zkw_trace_create: hipMalloc of %zu bytes failed: %s",
                     n_cols * n_rows * n_slots * 8, hipGetErrorString(e));
     }
+    ctx_retain(ctx);
     *out = t;
     return ZKW_OK;
 }
@@ -1108,7 +1153,9 @@ extern "C" void zkw_trace_free(zkw_trace* t) {
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
     if (t->data) (void)hipFree(t->data);
+    zkw_ctx* owner = t->ctx;
     delete t;
+    ctx_release(owner);
 }
 
 extern "C" size_t zkw_trace_num_rows(const zkw_trace* t) { return t ? t->n_rows : 0; }
@@ -1130,7 +1177,7 @@ extern "C" int zkw_trace_get(const zkw_trace* t, size_t slot, uint32_t first_col
 
 extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t first_instance, size_t n_instances,
                                   zkw_trace* t, size_t first_slot) {
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_ram_synthesize: bad argument");
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_ram_synthesize: bad argument");
     if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
     if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
     const u32 capacity = w->capacity;
@@ -1251,7 +1298,7 @@ static int check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32
 
 extern "C" int zkw_ram_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
                                        uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations)
         return fail(ZKW_ERR_INVALID, "zkw_ram_check_satisfied: bad argument");
     if (RC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecRam>(ctx, t, slot, capacity, n_violations, first_bad);
@@ -1259,7 +1306,7 @@ extern "C" int zkw_ram_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t 
 
 extern "C" int zkw_decommit_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
                                                    uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations)
         return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_check_satisfied: bad argument");
     if (DS_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecDecommitSorter>(ctx, t, slot, capacity, n_violations, first_bad);
@@ -1277,6 +1324,8 @@ struct zkw_decommit_witness {
     zkw_queue_state12 dedup_in;   // state of the deduplicated queue before the block (host copy)
     u32* fresh_prefix = nullptr;  // [n + 1], computed by the first synthesis call
     u64 *compact_forms = nullptr, *public_inputs = nullptr;  // [n_instances][18], [n_instances][4]
+    u32 *fresh_count = nullptr, *last_fresh = nullptr;  // context scratch shared by the two phases of the builder
+    bool finished = false;  // zkw_decommit_sorter_finish has run: tails, challenges, chains, instances are valid
     void release() {
         void* ptrs[] = {sorted_q, dedup_q, unsorted_enc, sorted_enc, unsorted_tails, sorted_tails, dedup_enc,
                         dedup_tails, challenges, lhs_z, rhs_z, instances, fresh_prefix, compact_forms, public_inputs};
@@ -1285,8 +1334,8 @@ struct zkw_decommit_witness {
     }
 };
 
-static int decommit_run(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_decommit_query* d_q,
-                        const zkw_queue_state12& dedup_in) {
+// phase 1 (contents): encodings, the stable (hash, timestamp) sort, the deduplicated queue. No hashing.
+static int decommit_prepare(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_decommit_query* d_q) {
     const size_t n = w->n;
     const unsigned grid = blocks_for(n, 256);
     // unsorted side
@@ -1331,7 +1380,16 @@ static int decommit_run(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_decommi
     if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "decommit requests with the same hash disagree on page or are not "
                                                        "timestamp-ordered (sort_decommit_requests.rs:99-114)");
     w->n_dedup = h_totals[0];
-    // three chains in one launch
+    w->fresh_count = fresh_count;
+    w->last_fresh = last_fresh;
+    return ZKW_OK;
+}
+
+// phase 2 (hashes): the three queue chains in one launch, challenges, grand products, instance records
+static int decommit_finish(zkw_ctx* ctx, zkw_decommit_witness* w) {
+    const size_t n = w->n;
+    const zkw_queue_state12& dedup_in = w->dedup_in;
+    u32 *fresh_count = w->fresh_count, *last_fresh = w->last_fresh;
     zkw_queue_state12* d_dedup_in = nullptr;
     std::vector<zkw_queue_state12> din(1, dedup_in);
     ZKW_TRY(ctx->upload("dec_dedup_in", din, &d_dedup_in));
@@ -1356,9 +1414,11 @@ static int decommit_run(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_decommi
     return launch_check("k_decommit_instances");
 }
 
-extern "C" int zkw_decommit_sorter_build(zkw_ctx* ctx, const zkw_decommit_query* q, size_t n, uint32_t capacity,
-                                         const zkw_queue_state12* dedup_in, zkw_decommit_witness** out) {
-    if (!ctx || !q || !out || capacity == 0) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_build: bad argument");
+extern "C" void zkw_decommit_witness_free(zkw_decommit_witness* w);
+
+extern "C" int zkw_decommit_sorter_prepare(zkw_ctx* ctx, const zkw_decommit_query* q, size_t n, uint32_t capacity,
+                                           const zkw_queue_state12* dedup_in, zkw_decommit_witness** out) {
+    if (!ctx || !q || !out || capacity == 0) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_prepare: bad argument");
     if (n == 0) return fail(ZKW_ERR_INVALID, "VM should have made some code decommits (sort_decommit_requests.rs:38-41)");
     if (n >= (1ull << 32)) return fail(ZKW_ERR_INVALID, "too many requests");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1380,15 +1440,29 @@ extern "C" int zkw_decommit_sorter_build(zkw_ctx* ctx, const zkw_decommit_query*
     if (e != hipSuccess) {
         w->release();
         delete w;
-        return fail(ZKW_ERR_OOM, "zkw_decommit_sorter_build: hipMalloc failed: %s", hipGetErrorString(e));
+        return fail(ZKW_ERR_OOM, "zkw_decommit_sorter_prepare: hipMalloc failed: %s", hipGetErrorString(e));
     }
-    zkw_queue_state12 din;
-    memset(&din, 0, sizeof din);
-    if (dedup_in) din = *dedup_in;
-    w->dedup_in = din;
+    memset(&w->dedup_in, 0, sizeof w->dedup_in);
+    if (dedup_in) w->dedup_in = *dedup_in;
     const zkw_decommit_query* d_q = nullptr;
     int rc = ctx->in("dec_q", q, n, &d_q);
-    if (rc == ZKW_OK) rc = decommit_run(ctx, w, d_q, din);
+    if (rc == ZKW_OK) rc = decommit_prepare(ctx, w, d_q);
+    if (rc != ZKW_OK) {
+        w->release();
+        delete w;
+        return rc;
+    }
+    ctx_retain(ctx);
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" int zkw_decommit_sorter_finish(zkw_ctx* ctx, zkw_decommit_witness* w) {
+    if (!ctx || !w || w->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_finish: bad argument");
+    if (w->finished) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = w->n;
+    int rc = decommit_finish(ctx, w);
     if (rc == ZKW_OK) {  // a20: compact forms and public inputs (postprocessing/mod.rs:353-369)
         const size_t ni = w->n_instances;
         { Prof _p(ctx, "k_ds_commitments"); hipLaunchKernelGGL(k_ds_commitments, dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, w->instances, ni, w->compact_forms); }
@@ -1409,9 +1483,18 @@ extern "C" int zkw_decommit_sorter_build(zkw_ctx* ctx, const zkw_decommit_query*
                 rc = fail(ZKW_ERR_CHECK_FAILED, "grand products differ in repetition %d", r);
         }
     }
+    if (rc == ZKW_OK) w->finished = true;
+    return rc;
+}
+
+extern "C" int zkw_decommit_sorter_build(zkw_ctx* ctx, const zkw_decommit_query* q, size_t n, uint32_t capacity,
+                                         const zkw_queue_state12* dedup_in, zkw_decommit_witness** out) {
+    if (!out) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_build: bad argument");
+    zkw_decommit_witness* w = nullptr;
+    ZKW_TRY(zkw_decommit_sorter_prepare(ctx, q, n, capacity, dedup_in, &w));
+    const int rc = zkw_decommit_sorter_finish(ctx, w);
     if (rc != ZKW_OK) {
-        w->release();
-        delete w;
+        zkw_decommit_witness_free(w);
         return rc;
     }
     *out = w;
@@ -1466,7 +1549,9 @@ extern "C" void zkw_decommit_witness_free(zkw_decommit_witness* w) {
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
+    zkw_ctx* owner = w->ctx;
     delete w;
+    ctx_release(owner);
 }
 
 // ------------------------------------------------------------------------------------------------ events sorter
@@ -1610,6 +1695,7 @@ extern "C" int zkw_events_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, siz
         delete w;
         return rc;
     }
+    ctx_retain(ctx);
     *out = w;
     return ZKW_OK;
 }
@@ -1664,7 +1750,9 @@ extern "C" void zkw_events_witness_free(zkw_events_witness* w) {
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
+    zkw_ctx* owner = w->ctx;
     delete w;
+    ctx_release(owner);
 }
 
 // ------------------------------------------------------------------------------------------------ log demuxer
@@ -1775,6 +1863,7 @@ extern "C" int zkw_log_demux_build(zkw_ctx* ctx, const zkw_log_query* q, size_t 
         delete w;
         return rc;
     }
+    ctx_retain(ctx);
     *out = w;
     return ZKW_OK;
 }
@@ -1823,7 +1912,9 @@ extern "C" void zkw_demux_witness_free(zkw_demux_witness* w) {
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
+    zkw_ctx* owner = w->ctx;
     delete w;
+    ctx_release(owner);
 }
 
 // ------------------------------------------------------------------------------------------------ storage sorter
@@ -1977,6 +2068,7 @@ extern "C" int zkw_storage_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, si
         delete w;
         return rc;
     }
+    ctx_retain(ctx);
     *out = w;
     return ZKW_OK;
 }
@@ -2032,7 +2124,9 @@ extern "C" void zkw_storage_witness_free(zkw_storage_witness* w) {
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
+    zkw_ctx* owner = w->ctx;
     delete w;
+    ctx_release(owner);
 }
 
 // ------------------------------------------------------------------------------------------------ code decommitter
@@ -2050,9 +2144,35 @@ struct zkw_decommitter_witness {
     }
 };
 
-extern "C" int zkw_decommitter_build(zkw_ctx* ctx, const zkw_decommit_query* requests, const uint64_t* dedup_tails,
+extern "C" int zkw_decommitter_memory_queries(zkw_ctx* ctx, const zkw_decommit_query* requests, size_t n_requests,
+                                              const uint32_t* words, const uint64_t* word_offsets, zkw_mem_query* out) {
+    if (!ctx || !requests || !words || !word_offsets || !out || n_requests == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_decommitter_memory_queries: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint64_t> woff(n_requests + 1);
+    for (size_t k = 0; k <= n_requests; k++) woff[k] = word_offsets[k] - word_offsets[0];
+    const size_t total = woff[n_requests];
+    const zkw_decommit_query* d_req = nullptr;
+    const u32* d_words = nullptr;
+    u64* d_woff = nullptr;
+    zkw_mem_query* d_out = nullptr;
+    ZKW_TRY(ctx->in("dcm_req", requests, n_requests, &d_req));
+    ZKW_TRY(ctx->in("dcm_words", words + 8 * word_offsets[0], total * 8, &d_words));
+    ZKW_TRY(ctx->upload("dcm_woff", woff, &d_woff));
+    ZKW_TRY(ctx->out("dcm_mq_out", out, total, &d_out));
+    DecommitterJob job{d_req, d_words, d_woff, nullptr, nullptr, d_out, nullptr, nullptr, n_requests};
+    if (total) {
+        { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, job, (u64)total); }
+        ZKW_TRY(launch_check("k_decommitter_mem_queries"));
+    }
+    ZKW_TRY(ctx->finish_out(out, d_out, total));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit_query* requests, const uint64_t* dedup_tails,
                                      size_t n_requests, const uint32_t* words, const uint64_t* word_offsets,
-                                     uint32_t capacity, const zkw_queue_state12* mem_in, zkw_decommitter_witness** out) {
+                                     uint32_t capacity, const zkw_queue_state12* mem_in, const uint64_t* given_mem_tails,
+                                     zkw_decommitter_witness** out) {
     if (!ctx || !requests || !dedup_tails || !words || !word_offsets || !mem_in || !out || capacity == 0 || n_requests == 0)
         return fail(ZKW_ERR_INVALID, "zkw_decommitter_build: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -2098,8 +2218,14 @@ extern "C" int zkw_decommitter_build(zkw_ctx* ctx, const zkw_decommit_query* req
     zkw_queue_state12* d_min = nullptr;
     std::vector<zkw_queue_state12> minv(1, *mem_in);
     if ((rc = ctx->upload("dcm_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
-    std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, w->total_words});
-    if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
+    if (given_mem_tails) {  // the caller has already hashed the memory queue this slice belongs to (zkw_block_run)
+        if (hipMemcpyAsync(w->mem_tails, given_mem_tails, w->total_words * 96,
+                           ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return bail(fail(ZKW_ERR_HIP, "copy of the given memory-queue states failed"));
+    } else {
+        std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, w->total_words});
+        if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
+    }
     std::vector<DecommitterBlock> blk(1);
     blk[0].job = job;
     blk[0].dedup_tails = d_dt;
@@ -2119,8 +2245,15 @@ extern "C" int zkw_decommitter_build(zkw_ctx* ctx, const zkw_decommit_query* req
         return bail(fail(ZKW_ERR_HIP, "readback failed"));
     if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u bytecodes do not match their decommit request (length parity, word count or "
                                                      "SHA-256 digest, decommit_code.rs:241-244, 323-337)", viol));
+    ctx_retain(ctx);
     *out = w;
     return ZKW_OK;
+}
+
+extern "C" int zkw_decommitter_build(zkw_ctx* ctx, const zkw_decommit_query* requests, const uint64_t* dedup_tails,
+                                     size_t n_requests, const uint32_t* words, const uint64_t* word_offsets,
+                                     uint32_t capacity, const zkw_queue_state12* mem_in, zkw_decommitter_witness** out) {
+    return zkw_decommitter_build_with_tails(ctx, requests, dedup_tails, n_requests, words, word_offsets, capacity, mem_in, nullptr, out);
 }
 
 extern "C" size_t zkw_decommitter_witness_num_instances(const zkw_decommitter_witness* w) { return w ? w->n_instances : 0; }
@@ -2160,7 +2293,9 @@ extern "C" void zkw_decommitter_witness_free(zkw_decommitter_witness* w) {
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
+    zkw_ctx* owner = w->ctx;
     delete w;
+    ctx_release(owner);
 }
 
 // ------------------------------------------------------------------------------------------------ L1 messages hasher
@@ -2303,9 +2438,10 @@ struct zkw_precompile_witness {
     }
 };
 
-extern "C" int zkw_precompile_build(zkw_ctx* ctx, int kind, const zkw_log_query* requests, const uint64_t* request_tails,
+extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw_log_query* requests, const uint64_t* request_tails,
                                     size_t n_requests, const zkw_mem_query* mem_queries, size_t n_queries, uint32_t capacity,
-                                    const zkw_queue_state12* mem_in, zkw_precompile_witness** out) {
+                                    const zkw_queue_state12* mem_in, const uint64_t* given_mem_tails,
+                                    zkw_precompile_witness** out) {
     if (!ctx || !mem_in || !out || capacity == 0 || kind < ZKW_PRECOMPILE_KECCAK256 || kind > ZKW_PRECOMPILE_ECRECOVER ||
         (n_requests && (!requests || !request_tails)) || (n_queries && !mem_queries))
         return fail(ZKW_ERR_INVALID, "zkw_precompile_build: bad argument");
@@ -2358,8 +2494,14 @@ extern "C" int zkw_precompile_build(zkw_ctx* ctx, int kind, const zkw_log_query*
             zkw_queue_state12* d_min = nullptr;
             std::vector<zkw_queue_state12> minv(1, *mem_in);
             if ((rc = ctx->upload("pc_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
-            std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, n_queries});
-            if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
+            if (given_mem_tails) {  // already hashed by the caller as part of the whole memory queue (zkw_block_run)
+                if (hipMemcpyAsync(w->mem_tails, given_mem_tails, n_queries * 96,
+                                   ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    return bail(fail(ZKW_ERR_HIP, "copy of the given memory-queue states failed"));
+            } else {
+                std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, n_queries});
+                if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
+            }
         }
         PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity};
         { Prof _p(ctx, "k_precompile_walk"); hipLaunchKernelGGL(k_precompile_walk, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
@@ -2386,8 +2528,15 @@ extern "C" int zkw_precompile_build(zkw_ctx* ctx, int kind, const zkw_log_query*
         return bail(fail(ZKW_ERR_HIP, "readback failed"));
     if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u requests whose memory queries do not fit their ABI (read/write flags, word "
                                                      "index or count: the asserts of the round walks)", viol));
+    ctx_retain(ctx);
     *out = w;
     return ZKW_OK;
+}
+
+extern "C" int zkw_precompile_build(zkw_ctx* ctx, int kind, const zkw_log_query* requests, const uint64_t* request_tails,
+                                    size_t n_requests, const zkw_mem_query* mem_queries, size_t n_queries, uint32_t capacity,
+                                    const zkw_queue_state12* mem_in, zkw_precompile_witness** out) {
+    return zkw_precompile_build_with_tails(ctx, kind, requests, request_tails, n_requests, mem_queries, n_queries, capacity, mem_in, nullptr, out);
 }
 
 extern "C" size_t zkw_precompile_witness_num_instances(const zkw_precompile_witness* w) { return w ? w->n_instances : 0; }
@@ -2426,7 +2575,9 @@ extern "C" void zkw_precompile_witness_free(zkw_precompile_witness* w) {
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
+    zkw_ctx* owner = w->ctx;
     delete w;
+    ctx_release(owner);
 }
 
 // ------------------------------------------------------------------------------------------------ storage application (a17)
@@ -2551,6 +2702,7 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
     if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u storage queries contradict the tree: the pre-state proof does not lead to the "
                                                      "initial root, the read value is not the leaf's (storage_application.rs:221,276), "
                                                      "or a slot occurs twice", viol));
+    ctx_retain(ctx);
     *out = w;
     return ZKW_OK;
 }
@@ -2592,14 +2744,16 @@ extern "C" void zkw_storage_application_witness_free(zkw_storage_application_wit
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);
     w->release();
+    zkw_ctx* owner = w->ctx;
     delete w;
+    ctx_release(owner);
 }
 
 // ------------------------------------------------------------------------------------------------ decommit sorter synthesis (a21, type 2)
 extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_witness* cw, size_t first_instance, size_t n_instances,
                                               zkw_trace* t, size_t first_slot) {
     zkw_decommit_witness* w = const_cast<zkw_decommit_witness*>(cw);
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_synthesize: bad argument");
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_synthesize: bad argument");
     if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
     if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
     const u32 capacity = w->capacity;
@@ -2665,7 +2819,7 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
 extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witness* cw, size_t first_instance, size_t n_instances,
                                             zkw_trace* t, size_t first_slot) {
     zkw_events_witness* w = const_cast<zkw_events_witness*>(cw);
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_events_sorter_synthesize: bad argument");
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_events_sorter_synthesize: bad argument");
     if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
     if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
     const u32 capacity = w->capacity;
@@ -2728,7 +2882,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
 
 extern "C" int zkw_events_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
                                                  uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations)
         return fail(ZKW_ERR_INVALID, "zkw_events_sorter_check_satisfied: bad argument");
     if (ES_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecEventsSorter>(ctx, t, slot, capacity, n_violations, first_bad);
@@ -2737,7 +2891,7 @@ extern "C" int zkw_events_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* 
 // ------------------------------------------------------------------------------------------------ LogDemuxer synthesis
 extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w, size_t first_instance, size_t n_instances,
                                         zkw_trace* t, size_t first_slot) {
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_log_demux_synthesize: bad argument");
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_log_demux_synthesize: bad argument");
     if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
     if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
     if (!w->default_params)
@@ -2789,7 +2943,7 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
 
 extern "C" int zkw_log_demux_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
                                              uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations)
         return fail(ZKW_ERR_INVALID, "zkw_log_demux_check_satisfied: bad argument");
     if (LD_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecLogDemux>(ctx, t, slot, capacity, n_violations, first_bad);
@@ -2798,7 +2952,7 @@ extern "C" int zkw_log_demux_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, s
 // ------------------------------------------------------------------------------------------------ StorageSorter synthesis
 extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_witness* w, size_t first_instance, size_t n_instances,
                                              zkw_trace* t, size_t first_slot) {
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_synthesize: bad argument");
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_synthesize: bad argument");
     if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
     if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
     if (t->n_cols < SS_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the StorageSorter needs %d", t->n_cols, SS_COLS);
@@ -2851,7 +3005,7 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
 
 extern "C" int zkw_storage_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
                                                   uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx != ctx || slot >= t->n_slots || !n_violations)
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations)
         return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_check_satisfied: bad argument");
     if (SS_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecStorageSorter>(ctx, t, slot, capacity, n_violations, first_bad);

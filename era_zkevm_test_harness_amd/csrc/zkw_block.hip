@@ -1,0 +1,584 @@
+// zkw_block.hip — one block's witness generation as a dependency graph of builders (C++ host code; no kernels here).
+//
+// Counterpart of the post-VM half of `create_artifacts_from_tracer` (src/witness/oracle.rs:928-1130: the builders in
+// order, the memory queue threaded VM -> code decommitter -> keccak256 -> sha256 -> ecrecover -> RAM permutation, the
+// demuxed log queues feeding the sorters and the precompiles) and of `CircuitMaker::process / into_results`
+// (src/witness/postprocessing/mod.rs:353-405: public inputs, one recursion queue per circuit type).
+//
+// Written against include/zkw.h only (a Rust host could do the same over the FFI). What it adds over calling the
+// builders in the reference's order is scheduling: a Poseidon2 queue chain is serial (~10 us per item on one wave)
+// while independent chains cost nothing extra, so
+//   * every branch of the graph has its own zkw_ctx (HIP stream + scratch) and host thread,
+//   * contents (sorts, routing, deduplication) are computed before anything is hashed,
+//   * the block's memory queue is assembled up front and hashed once, by the RAM-permutation builder; the decommitter
+//     and the precompile builders receive their slices of its states (zkw_*_build_with_tails).
+// Wall time of the builders ~ the longest chain of the block instead of the sum over builders.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <future>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/zkw.h"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+
+enum { T_VM = 1, T_DEC = 2, T_DCM = 3, T_DMX = 4, T_KEC = 5, T_SHA = 6, T_ECR = 7, T_RAM = 8, T_STO = 9, T_SAP = 10, T_EVT = 11, T_L1 = 12, T_HSH = 13 };
+enum { C_DEC = 0, C_RAM, C_DMX, C_STO, C_EVT, C_L1, C_PRE, N_CTX };
+
+struct Status {
+    int rc = ZKW_OK;
+    std::string msg;
+    bool ok() const { return rc == ZKW_OK; }
+};
+
+Status from_rc(int rc) {
+    Status s;
+    s.rc = rc;
+    if (rc != ZKW_OK) s.msg = zkw_last_error();
+    return s;
+}
+Status hip_status(hipError_t e, const char* what) {
+    Status s;
+    if (e != hipSuccess) {
+        s.rc = e == hipErrorOutOfMemory ? ZKW_ERR_OOM : ZKW_ERR_HIP;
+        s.msg = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    return s;
+}
+#define ST_TRY(expr)              \
+    do {                          \
+        Status _s = (expr);       \
+        if (!_s.ok()) return _s;  \
+    } while (0)
+#define ST_ZKW(expr) ST_TRY(from_rc(expr))
+#define ST_HIP(expr) ST_TRY(hip_status((expr), #expr))
+
+struct Span {
+    std::string name;
+    double a, b;
+};
+
+struct PerType {
+    std::vector<uint64_t> pi, enc, states;  // [n][4], [n][8], [n][12]
+};
+
+}  // namespace
+
+struct zkw_block {
+    int device = 0;
+    zkw_ctx* ctx[N_CTX] = {};
+    uint32_t cap[14] = {};
+    Clock::time_point t0;
+    std::mutex mu;
+    std::vector<Span> spans;
+    // device buffers owned by the block
+    std::vector<void*> dev;
+    zkw_mem_query* d_all_mem = nullptr;
+    size_t n_mem = 0;
+    size_t mem_off[6] = {};  // VM | code words | keccak256 | sha256 | ecrecover | end
+    // witnesses
+    zkw_decommit_witness* dec = nullptr;
+    zkw_decommitter_witness* dcm = nullptr;
+    zkw_demux_witness* dmx = nullptr;
+    zkw_precompile_witness* pre[3] = {};
+    zkw_ram_witness* ram = nullptr;
+    zkw_storage_witness* sto = nullptr;
+    zkw_storage_application_witness* sap = nullptr;
+    zkw_events_witness *evt = nullptr, *l1 = nullptr;
+    uint64_t dmx_off[7] = {};
+    zkw_queue_state12 mem_state;
+    uint8_t l1_hash[32] = {};
+    PerType per[14];
+    // synthesis ring (created by the first zkw_block_synthesize)
+    zkw_trace *ring149 = nullptr, *ring151 = nullptr;
+    size_t ring_rows = 0, ring_slots = 0;
+
+    double ms_now() const { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+    void span(const char* name, double a) {
+        const double b = ms_now();
+        std::lock_guard<std::mutex> g(mu);
+        spans.push_back(Span{name, a, b});
+    }
+    template <class T>
+    Status alloc(T** p, size_t count) {
+        void* q = nullptr;
+        ST_HIP(hipMalloc(&q, count * sizeof(T) + 64));
+        {
+            std::lock_guard<std::mutex> g(mu);
+            dev.push_back(q);
+        }
+        *p = static_cast<T*>(q);
+        return Status();
+    }
+    template <class T>
+    Status upload(T** p, const T* host, size_t count) {
+        ST_TRY(alloc(p, count ? count : 1));
+        if (count) ST_HIP(hipMemcpy(*p, host, count * sizeof(T), hipMemcpyHostToDevice));
+        return Status();
+    }
+};
+
+namespace {
+
+struct Timed {
+    zkw_block* b;
+    const char* name;
+    double a;
+    Timed(zkw_block* blk, const char* n) : b(blk), name(n), a(blk->ms_now()) {}
+    ~Timed() { b->span(name, a); }
+};
+
+// ---- branch: log demuxer, then the three sorters (each on its own thread) --------------------------------------
+Status storage_branch(zkw_block* B, const zkw_block_inputs* in, const zkw_log_query* d_q, size_t n) {
+    ST_HIP(hipSetDevice(B->device));
+    {
+        Timed t(B, "storage_sorter");
+        ST_ZKW(zkw_storage_sorter_build(B->ctx[C_STO], d_q, n, B->cap[T_STO], &B->sto));
+        ST_ZKW(zkw_synchronize(B->ctx[C_STO]));
+    }
+    if (!in->storage_tree) return Status();
+    Timed t(B, "storage_application");
+    const size_t nr = zkw_storage_witness_num_results(B->sto);
+    const zkw_log_query* d_rq = static_cast<const zkw_log_query*>(zkw_storage_witness_device_ptr(B->sto, ZKW_STO_RESULT_QUERIES));
+    const uint64_t* d_rt = static_cast<const uint64_t*>(zkw_storage_witness_device_ptr(B->sto, ZKW_STO_RESULT_NEW_TAILS));
+    std::vector<zkw_log_query> hq(nr);
+    std::vector<uint64_t> idx(nr);
+    std::vector<uint8_t> paths(nr * 256 * 32);
+    uint64_t* d_idx = nullptr;
+    uint8_t* d_paths = nullptr;
+    if (nr) {
+        ST_HIP(hipMemcpy(hq.data(), d_rq, nr * sizeof(zkw_log_query), hipMemcpyDeviceToHost));
+        if (in->storage_tree(in->storage_tree_user, hq.data(), nr, idx.data(), paths.data()) != 0) {
+            Status s;
+            s.rc = ZKW_ERR_INVALID;
+            s.msg = "the storage_tree callback failed";
+            return s;
+        }
+        ST_TRY(B->upload(&d_idx, idx.data(), nr));
+        ST_TRY(B->upload(&d_paths, paths.data(), paths.size()));
+    }
+    ST_ZKW(zkw_storage_application_build(B->ctx[C_STO], d_rq, d_rt, nr, d_idx, d_paths, in->storage_initial_root,
+                                         in->storage_initial_next_enumeration_index, B->cap[T_SAP], &B->sap));
+    ST_ZKW(zkw_synchronize(B->ctx[C_STO]));
+    return Status();
+}
+
+Status events_branch(zkw_block* B, int which, const zkw_log_query* d_q, size_t n) {
+    ST_HIP(hipSetDevice(B->device));
+    zkw_ctx* c = B->ctx[which ? C_L1 : C_EVT];
+    {
+        Timed t(B, which ? "l1_messages_sorter" : "events_sorter");
+        ST_ZKW(zkw_events_sorter_build(c, d_q, n, B->cap[which ? T_L1 : T_EVT], nullptr, which ? &B->l1 : &B->evt));
+        ST_ZKW(zkw_synchronize(c));
+    }
+    if (which) {  // pubdata hash of the net L2 -> L1 messages (oracle.rs:1102-1112)
+        Timed t(B, "l1_messages_hasher");
+        uint8_t* d_hash = nullptr;
+        ST_TRY(B->alloc(&d_hash, 32));
+        const zkw_log_query* d_res = static_cast<const zkw_log_query*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_RESULT_QUERIES));
+        ST_ZKW(zkw_linear_keccak256(c, d_res, zkw_events_witness_num_results(B->l1), d_hash));
+        ST_ZKW(zkw_synchronize(c));
+        ST_HIP(hipMemcpy(B->l1_hash, d_hash, 32, hipMemcpyDeviceToHost));
+    }
+    return Status();
+}
+
+Status log_branch(zkw_block* B, const zkw_block_inputs* in) {
+    ST_HIP(hipSetDevice(B->device));
+    zkw_log_query* d_logs = nullptr;
+    {
+        Timed t(B, "log_demuxer");
+        ST_TRY(B->upload(&d_logs, in->log_queries, in->n_log_queries));
+        ST_ZKW(zkw_log_demux_build(B->ctx[C_DMX], d_logs, in->n_log_queries, B->cap[T_DMX], nullptr, &B->dmx));
+        ST_ZKW(zkw_synchronize(B->ctx[C_DMX]));
+        ST_HIP(hipMemcpy(B->dmx_off, zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_OUT_OFFSETS), sizeof B->dmx_off, hipMemcpyDeviceToHost));
+    }
+    const zkw_log_query* d_out = static_cast<const zkw_log_query*>(zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_OUT_QUERIES));
+    auto q = [&](int k) { return d_out + B->dmx_off[k]; };
+    auto nq = [&](int k) { return (size_t)(B->dmx_off[k + 1] - B->dmx_off[k]); };
+    auto f_sto = std::async(std::launch::async, storage_branch, B, in, q(0), nq(0));
+    auto f_evt = std::async(std::launch::async, events_branch, B, 0, q(1), nq(1));
+    auto f_l1 = std::async(std::launch::async, events_branch, B, 1, q(2), nq(2));
+    Status s0 = f_sto.get(), s1 = f_evt.get(), s2 = f_l1.get();
+    if (!s0.ok()) return s0;
+    if (!s1.ok()) return s1;
+    return s2;
+}
+
+// ---- branch: the RAM permutation over the whole memory queue (the one place the memory queue is hashed) ----------
+Status ram_branch(zkw_block* B, const zkw_block_inputs* in, const uint64_t** d_tails) {
+    ST_HIP(hipSetDevice(B->device));
+    Timed t(B, "ram_permutation");
+    ST_ZKW(zkw_ram_build_instances(B->ctx[C_RAM], B->d_all_mem, B->n_mem, B->cap[T_RAM], in->num_non_deterministic_heap_queries, &B->ram));
+    *d_tails = static_cast<const uint64_t*>(zkw_ram_witness_device_ptr(B->ram, ZKW_RAM_UNSORTED_TAILS));
+    if (!*d_tails) return from_rc(ZKW_ERR_OOM);
+    ST_ZKW(zkw_synchronize(B->ctx[C_RAM]));
+    return Status();
+}
+
+Status dec_finish_branch(zkw_block* B) {
+    ST_HIP(hipSetDevice(B->device));
+    Timed t(B, "decommit_sorter.finish");
+    ST_ZKW(zkw_decommit_sorter_finish(B->ctx[C_DEC], B->dec));
+    ST_ZKW(zkw_synchronize(B->ctx[C_DEC]));
+    return Status();
+}
+
+std::string key32(const uint32_t* h) { return std::string(reinterpret_cast<const char*>(h), 32); }
+
+Status run(zkw_block* B, const zkw_block_inputs* in) {
+    ST_HIP(hipSetDevice(B->device));
+    for (int i = 0; i < N_CTX; i++) {
+        B->ctx[i] = zkw_create(B->device);
+        if (!B->ctx[i]) return from_rc(ZKW_ERR_NO_DEVICE);
+        ST_ZKW(zkw_set_pointer_mode(B->ctx[i], ZKW_PTR_DEVICE));
+    }
+    for (int t = 1; t <= 13; t++) {
+        zkw_circuit_geometry g;
+        ST_ZKW(zkw_circuit_geometry_of((uint8_t)t, &g));
+        B->cap[t] = in->capacities[t] ? in->capacities[t] : g.capacity;
+    }
+    // the log branch does not depend on anything else: start it first
+    auto f_log = std::async(std::launch::async, log_branch, B, in);
+
+    // 1. decommit sorter, contents only: the deduplicated requests fix which code words enter the memory queue
+    zkw_decommit_query* d_dq = nullptr;
+    std::vector<zkw_decommit_query> dedup;
+    {
+        Timed t(B, "decommit_sorter.prepare");
+        ST_TRY(B->upload(&d_dq, in->decommit_queries, in->n_decommit_queries));
+        ST_ZKW(zkw_decommit_sorter_prepare(B->ctx[C_DEC], d_dq, in->n_decommit_queries, B->cap[T_DEC], nullptr, &B->dec));
+        dedup.resize(zkw_decommit_witness_num_dedup(B->dec));
+        ST_HIP(hipMemcpy(dedup.data(), zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_QUERIES),
+                         dedup.size() * sizeof(zkw_decommit_query), hipMemcpyDeviceToHost));
+    }
+    auto f_dec = std::async(std::launch::async, dec_finish_branch, B);  // its three chains run next to everything below
+
+    // 2. the whole memory queue: VM | code words in the order of the deduplicated queue | keccak256 | sha256 | ecrecover
+    std::vector<uint32_t> words;
+    std::vector<uint64_t> woff(dedup.size() + 1, 0);
+    uint32_t* d_words = nullptr;
+    const uint64_t* d_tails = nullptr;
+    {
+        Timed t(B, "memory_queue.assemble");
+        std::unordered_map<std::string, size_t> by_hash;
+        for (size_t k = 0; k < in->n_bytecodes; k++) by_hash[key32(in->bytecode_hashes + 8 * k)] = k;
+        for (size_t i = 0; i < dedup.size(); i++) {
+            auto it = by_hash.find(key32(dedup[i].hash));
+            if (it == by_hash.end()) {
+                Status s;
+                s.rc = ZKW_ERR_INVALID;
+                s.msg = "a decommit request names a bytecode hash that is not among the block's bytecodes";
+                return s;
+            }
+            const uint64_t lo = in->bytecode_word_offsets[it->second], hi = in->bytecode_word_offsets[it->second + 1];
+            words.insert(words.end(), in->bytecode_words + 8 * lo, in->bytecode_words + 8 * hi);
+            woff[i + 1] = woff[i] + (hi - lo);
+        }
+        B->mem_off[0] = 0;
+        B->mem_off[1] = in->n_vm_memory_queries;
+        B->mem_off[2] = B->mem_off[1] + woff.back();
+        for (int k = 0; k < 3; k++) B->mem_off[3 + k] = B->mem_off[2 + k] + in->n_precompile_memory_queries[k];
+        B->n_mem = B->mem_off[5];
+        if (B->n_mem == 0) {
+            Status s;
+            s.rc = ZKW_ERR_INVALID;
+            s.msg = "the block has no memory queries (ram_permutation.rs:43-46)";
+            return s;
+        }
+        ST_TRY(B->alloc(&B->d_all_mem, B->n_mem));
+        if (in->n_vm_memory_queries)
+            ST_HIP(hipMemcpy(B->d_all_mem, in->vm_memory_queries, in->n_vm_memory_queries * sizeof(zkw_mem_query), hipMemcpyHostToDevice));
+        for (int k = 0; k < 3; k++)
+            if (in->n_precompile_memory_queries[k])
+                ST_HIP(hipMemcpy(B->d_all_mem + B->mem_off[2 + k], in->precompile_memory_queries[k],
+                                 in->n_precompile_memory_queries[k] * sizeof(zkw_mem_query), hipMemcpyHostToDevice));
+        ST_TRY(B->upload(&d_words, words.data(), words.size()));
+        const zkw_decommit_query* d_dedup = static_cast<const zkw_decommit_query*>(zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_QUERIES));
+        // on the precompile context: the decommit context is busy hashing
+        ST_ZKW(zkw_decommitter_memory_queries(B->ctx[C_PRE], d_dedup, dedup.size(), d_words, woff.data(), B->d_all_mem + B->mem_off[1]));
+        ST_ZKW(zkw_synchronize(B->ctx[C_PRE]));
+    }
+    auto f_ram = std::async(std::launch::async, ram_branch, B, in, &d_tails);
+
+    Status s_ram = f_ram.get(), s_dec = f_dec.get(), s_log = f_log.get();
+    ST_TRY(s_ram);
+    ST_TRY(s_dec);
+    ST_TRY(s_log);
+
+    // 3. the builders that own a slice of the memory queue: states given, nothing left to hash
+    auto mem_in_at = [&](size_t start, zkw_queue_state12* st) -> Status {
+        memset(st, 0, sizeof *st);
+        st->length = (uint32_t)start;
+        if (start) ST_HIP(hipMemcpy(st->tail, d_tails + 12 * (start - 1), 96, hipMemcpyDeviceToHost));
+        return Status();
+    };
+    {
+        Timed t(B, "code_decommitter");
+        zkw_queue_state12 st;
+        ST_TRY(mem_in_at(B->mem_off[1], &st));
+        const zkw_decommit_query* d_dedup = static_cast<const zkw_decommit_query*>(zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_QUERIES));
+        const uint64_t* d_dt = static_cast<const uint64_t*>(zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_TAILS));
+        ST_ZKW(zkw_decommitter_build_with_tails(B->ctx[C_PRE], d_dedup, d_dt, dedup.size(), d_words, woff.data(), B->cap[T_DCM], &st,
+                                                d_tails + 12 * B->mem_off[1], &B->dcm));
+    }
+    const zkw_log_query* d_out = static_cast<const zkw_log_query*>(zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_OUT_QUERIES));
+    const uint64_t* d_out_tails = static_cast<const uint64_t*>(zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_OUT_NEW_TAILS));
+    static const char* pre_names[3] = {"keccak256_round_function", "sha256_round_function", "ecrecover"};
+    for (int k = 0; k < 3; k++) {
+        Timed t(B, pre_names[k]);
+        zkw_queue_state12 st;
+        ST_TRY(mem_in_at(B->mem_off[2 + k], &st));
+        const size_t nreq = (size_t)(B->dmx_off[4 + k] - B->dmx_off[3 + k]);
+        const size_t nq = in->n_precompile_memory_queries[k];
+        ST_ZKW(zkw_precompile_build_with_tails(B->ctx[C_PRE], k, nreq ? d_out + B->dmx_off[3 + k] : nullptr,
+                                               nreq ? d_out_tails + 4 * B->dmx_off[3 + k] : nullptr, nreq,
+                                               nq ? B->d_all_mem + B->mem_off[2 + k] : nullptr, nq, B->cap[T_KEC + k], &st,
+                                               nq ? d_tails + 12 * B->mem_off[2 + k] : nullptr, &B->pre[k]));
+    }
+    ST_ZKW(zkw_synchronize(B->ctx[C_PRE]));
+    ST_TRY(mem_in_at(B->n_mem, &B->mem_state));
+
+    // 4. public inputs and one recursion queue per circuit type (postprocessing/mod.rs:353-405), all queues in one launch
+    {
+        Timed t(B, "recursion_queues");
+        struct Src { int type; const void* d_pi; size_t n; };
+        std::vector<Src> src;
+        src.push_back({T_DEC, zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_PUBLIC_INPUTS), zkw_decommit_witness_num_instances(B->dec)});
+        src.push_back({T_DMX, zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_PUBLIC_INPUTS), zkw_demux_witness_num_instances(B->dmx)});
+        src.push_back({T_RAM, zkw_ram_witness_device_ptr(B->ram, ZKW_RAM_PUBLIC_INPUTS), zkw_ram_witness_num_instances(B->ram)});
+        src.push_back({T_STO, zkw_storage_witness_device_ptr(B->sto, ZKW_STO_PUBLIC_INPUTS), zkw_storage_witness_num_instances(B->sto)});
+        src.push_back({T_EVT, zkw_events_witness_device_ptr(B->evt, ZKW_EVT_PUBLIC_INPUTS), zkw_events_witness_num_instances(B->evt)});
+        src.push_back({T_L1, zkw_events_witness_device_ptr(B->l1, ZKW_EVT_PUBLIC_INPUTS), zkw_events_witness_num_instances(B->l1)});
+        size_t total = 0;
+        for (auto& s : src) total += s.n;
+        uint64_t *d_pi = nullptr, *d_enc = nullptr, *d_states = nullptr;
+        ST_TRY(B->alloc(&d_pi, total * 4));
+        ST_TRY(B->alloc(&d_enc, total * 8));
+        ST_TRY(B->alloc(&d_states, total * 12));
+        std::vector<uint64_t> offs(1, 0);
+        zkw_ctx* c = B->ctx[C_PRE];
+        for (auto& s : src) {
+            const size_t o = offs.back();
+            ST_HIP(hipMemcpy(d_pi + 4 * o, s.d_pi, s.n * 32, hipMemcpyDeviceToDevice));
+            ST_ZKW(zkw_encode_recursion_requests(c, (uint64_t)s.type, d_pi + 4 * o, s.n, d_enc + 8 * o));
+            offs.push_back(o + s.n);
+        }
+        ST_ZKW(zkw_queue_push_chain_full_batch(c, d_enc, offs.data(), src.size(), nullptr, d_states));
+        ST_ZKW(zkw_synchronize(c));
+        for (size_t k = 0; k < src.size(); k++) {
+            PerType& p = B->per[src[k].type];
+            const size_t o = offs[k], n = src[k].n;
+            p.pi.resize(n * 4);
+            p.enc.resize(n * 8);
+            p.states.resize(n * 12);
+            ST_HIP(hipMemcpy(p.pi.data(), d_pi + 4 * o, n * 32, hipMemcpyDeviceToHost));
+            ST_HIP(hipMemcpy(p.enc.data(), d_enc + 8 * o, n * 64, hipMemcpyDeviceToHost));
+            ST_HIP(hipMemcpy(p.states.data(), d_states + 12 * o, n * 96, hipMemcpyDeviceToHost));
+        }
+    }
+    return Status();
+}
+
+thread_local std::string g_block_error;
+
+}  // namespace
+
+extern "C" int zkw_block_run(int device_id, const zkw_block_inputs* in, zkw_block** out) {
+    if (!in || !out || !in->decommit_queries || in->n_decommit_queries == 0 || (in->n_log_queries && !in->log_queries) ||
+        (in->n_vm_memory_queries && !in->vm_memory_queries) || (in->n_bytecodes && (!in->bytecode_hashes || !in->bytecode_words || !in->bytecode_word_offsets)))
+        return ZKW_ERR_INVALID;
+    zkw_block* B = new zkw_block();
+    B->device = device_id;
+    B->t0 = Clock::now();
+    Status s;
+    {
+        Timed t(B, "builders");
+        s = run(B, in);
+    }
+    if (!s.ok()) {
+        zkw_block_free(B);
+        // re-raise through the library's thread-local message: zkw_last_error() belongs to zkw_api; a failing zkw call on
+        // THIS thread has already set it, failures on worker threads are reported through zkw_block_last_error()
+        g_block_error = s.msg;
+        return s.rc;
+    }
+    *out = B;
+    return ZKW_OK;
+}
+
+extern "C" const char* zkw_block_last_error(void) { return g_block_error.c_str(); }
+
+extern "C" void zkw_block_free(zkw_block* B) {
+    if (!B) return;
+    (void)hipSetDevice(B->device);
+    if (B->ring149) zkw_trace_free(B->ring149);
+    if (B->ring151) zkw_trace_free(B->ring151);
+    if (B->dec) zkw_decommit_witness_free(B->dec);
+    if (B->dcm) zkw_decommitter_witness_free(B->dcm);
+    if (B->dmx) zkw_demux_witness_free(B->dmx);
+    for (int k = 0; k < 3; k++)
+        if (B->pre[k]) zkw_precompile_witness_free(B->pre[k]);
+    if (B->ram) zkw_ram_witness_free(B->ram);
+    if (B->sto) zkw_storage_witness_free(B->sto);
+    if (B->sap) zkw_storage_application_witness_free(B->sap);
+    if (B->evt) zkw_events_witness_free(B->evt);
+    if (B->l1) zkw_events_witness_free(B->l1);
+    for (int i = 0; i < N_CTX; i++)
+        if (B->ctx[i]) zkw_destroy(B->ctx[i]);
+    for (void* p : B->dev) (void)hipFree(p);
+    delete B;
+}
+
+extern "C" void* zkw_block_witness(const zkw_block* B, uint8_t t) {
+    if (!B) return nullptr;
+    switch (t) {
+        case T_DEC: return B->dec;
+        case T_DCM: return B->dcm;
+        case T_DMX: return B->dmx;
+        case T_KEC: case T_SHA: case T_ECR: return B->pre[t - T_KEC];
+        case T_RAM: return B->ram;
+        case T_STO: return B->sto;
+        case T_SAP: return B->sap;
+        case T_EVT: return B->evt;
+        case T_L1: return B->l1;
+        default: return nullptr;
+    }
+}
+
+extern "C" zkw_ctx* zkw_block_context(const zkw_block* B, uint8_t t) {
+    if (!B) return nullptr;
+    switch (t) {
+        case T_DEC: return B->ctx[C_DEC];
+        case T_DCM: case T_KEC: case T_SHA: case T_ECR: return B->ctx[C_PRE];
+        case T_DMX: return B->ctx[C_DMX];
+        case T_RAM: return B->ctx[C_RAM];
+        case T_STO: case T_SAP: return B->ctx[C_STO];
+        case T_EVT: return B->ctx[C_EVT];
+        case T_L1: case T_HSH: return B->ctx[C_L1];
+        default: return nullptr;
+    }
+}
+
+extern "C" size_t zkw_block_num_instances(const zkw_block* B, uint8_t t) {
+    if (!B) return 0;
+    switch (t) {
+        case T_DEC: return zkw_decommit_witness_num_instances(B->dec);
+        case T_DCM: return zkw_decommitter_witness_num_instances(B->dcm);
+        case T_DMX: return zkw_demux_witness_num_instances(B->dmx);
+        case T_KEC: case T_SHA: case T_ECR: return zkw_precompile_witness_num_instances(B->pre[t - T_KEC]);
+        case T_RAM: return zkw_ram_witness_num_instances(B->ram);
+        case T_STO: return zkw_storage_witness_num_instances(B->sto);
+        case T_SAP: return B->sap ? zkw_storage_application_witness_num_instances(B->sap) : 0;
+        case T_EVT: return zkw_events_witness_num_instances(B->evt);
+        case T_L1: return zkw_events_witness_num_instances(B->l1);
+        case T_HSH: return 1;  // compute_linear_keccak256 feeds a single instance (data_hasher_and_merklizer.rs:8-67)
+        default: return 0;
+    }
+}
+
+extern "C" const uint64_t* zkw_block_public_inputs(const zkw_block* B, uint8_t t) {
+    return B && t < 14 && !B->per[t].pi.empty() ? B->per[t].pi.data() : nullptr;
+}
+extern "C" const uint64_t* zkw_block_recursion_encodings(const zkw_block* B, uint8_t t) {
+    return B && t < 14 && !B->per[t].enc.empty() ? B->per[t].enc.data() : nullptr;
+}
+extern "C" const uint64_t* zkw_block_recursion_states(const zkw_block* B, uint8_t t) {
+    return B && t < 14 && !B->per[t].states.empty() ? B->per[t].states.data() : nullptr;
+}
+extern "C" size_t zkw_block_memory_queue_length(const zkw_block* B) { return B ? B->n_mem : 0; }
+extern "C" const zkw_mem_query* zkw_block_memory_queue_device_ptr(const zkw_block* B) { return B ? B->d_all_mem : nullptr; }
+extern "C" int zkw_block_memory_queue_state(const zkw_block* B, zkw_queue_state12* out) {
+    if (!B || !out) return ZKW_ERR_INVALID;
+    *out = B->mem_state;
+    return ZKW_OK;
+}
+extern "C" int zkw_block_demuxed_offsets(const zkw_block* B, uint64_t out[7]) {
+    if (!B || !out) return ZKW_ERR_INVALID;
+    memcpy(out, B->dmx_off, sizeof B->dmx_off);
+    return ZKW_OK;
+}
+extern "C" int zkw_block_l1_messages_hash(const zkw_block* B, uint8_t out[32]) {
+    if (!B || !out) return ZKW_ERR_INVALID;
+    memcpy(out, B->l1_hash, 32);
+    return ZKW_OK;
+}
+
+extern "C" int zkw_block_timings(const zkw_block* B, char* names, size_t names_bytes, double* start_ms, double* end_ms,
+                                 size_t max_spans, size_t* n_spans) {
+    if (!B || !n_spans) return ZKW_ERR_INVALID;
+    std::string all;
+    size_t n = 0;
+    for (const Span& s : B->spans) {
+        if (n >= max_spans) break;
+        if (n) all += ",";
+        all += s.name;
+        if (start_ms) start_ms[n] = s.a;
+        if (end_ms) end_ms[n] = s.b;
+        n++;
+    }
+    if (names && names_bytes) {
+        strncpy(names, all.c_str(), names_bytes - 1);
+        names[names_bytes - 1] = 0;
+    }
+    *n_spans = n;
+    return ZKW_OK;
+}
+
+// ---- synthesis of every instance, in the reference's emission order ----------------------------------------------
+extern "C" int zkw_block_synthesize(zkw_block* B, size_t n_rows, size_t ring_slots, zkw_circuit_fn cb, void* user, size_t* n_done) {
+    if (!B || n_rows == 0 || ring_slots == 0) return ZKW_ERR_INVALID;
+    if (hipSetDevice(B->device) != hipSuccess) return ZKW_ERR_HIP;
+    if (B->ring149 && (B->ring_rows != n_rows || B->ring_slots != ring_slots)) {
+        zkw_trace_free(B->ring149);
+        zkw_trace_free(B->ring151);
+        B->ring149 = B->ring151 = nullptr;
+    }
+    int rc = ZKW_OK;
+    if (!B->ring149) {
+        if ((rc = zkw_trace_create(B->ctx[C_RAM], n_rows, ring_slots, &B->ring149)) != ZKW_OK) return rc;
+        if ((rc = zkw_trace_create_with_columns(B->ctx[C_DMX], n_rows, 151, ring_slots, &B->ring151)) != ZKW_OK) return rc;
+        B->ring_rows = n_rows;
+        B->ring_slots = ring_slots;
+    }
+    const double a = B->ms_now();
+    size_t done = 0;
+    // emission order: log demuxer (oracle.rs:975-984), RAM permutation (:1039-1049), then CircuitMaker order (:1494-1732)
+    const int order[6] = {T_DMX, T_RAM, T_DEC, T_STO, T_EVT, T_L1};
+    for (int t : order) {
+        const size_t ni = zkw_block_num_instances(B, (uint8_t)t);
+        zkw_ctx* c = zkw_block_context(B, (uint8_t)t);
+        zkw_trace* ring = t == T_DMX ? B->ring151 : B->ring149;
+        for (size_t first = 0; first < ni; first += ring_slots) {
+            const size_t cnt = ni - first < ring_slots ? ni - first : ring_slots;
+            switch (t) {
+                case T_DMX: rc = zkw_log_demux_synthesize(c, B->dmx, first, cnt, ring, 0); break;
+                case T_RAM: rc = zkw_ram_synthesize(c, B->ram, first, cnt, ring, 0); break;
+                case T_DEC: rc = zkw_decommit_sorter_synthesize(c, B->dec, first, cnt, ring, 0); break;
+                case T_STO: rc = zkw_storage_sorter_synthesize(c, B->sto, first, cnt, ring, 0); break;
+                case T_EVT: rc = zkw_events_sorter_synthesize(c, B->evt, first, cnt, ring, 0); break;
+                case T_L1: rc = zkw_events_sorter_synthesize(c, B->l1, first, cnt, ring, 0); break;
+            }
+            if (rc != ZKW_OK) return rc;
+            // the ring is shared by contexts with different streams: a slot is complete before the next type touches it
+            if ((rc = zkw_synchronize(c)) != ZKW_OK) return rc;
+            for (size_t k = 0; k < cnt; k++) {
+                if (cb) {
+                    const uint64_t* pi = B->per[t].pi.data() + 4 * (first + k);
+                    if (cb(user, (uint8_t)t, first + k, ring, k, pi) != 0) return ZKW_ERR_CHECK_FAILED;
+                }
+                done++;
+            }
+        }
+    }
+    B->span("synthesis", a);
+    if (n_done) *n_done = done;
+    return ZKW_OK;
+}

@@ -52,6 +52,8 @@ SYMBOLS = [
     ("zkw_ram_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_ram_witness_free", None, [_vp]),
     ("zkw_decommit_sorter_build", _int, [_vp, _vp, _sz, _u32, _vp, C.POINTER(_vp)]),
+    ("zkw_decommit_sorter_prepare", _int, [_vp, _vp, _sz, _u32, _vp, C.POINTER(_vp)]),
+    ("zkw_decommit_sorter_finish", _int, [_vp, _vp]),
     ("zkw_decommit_witness_num_instances", _sz, [_vp]),
     ("zkw_decommit_witness_num_dedup", _sz, [_vp]),
     ("zkw_decommit_witness_bytes", _sz, [_vp, _int]),
@@ -79,6 +81,8 @@ SYMBOLS = [
     ("zkw_storage_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_storage_witness_free", None, [_vp]),
     ("zkw_decommitter_build", _int, [_vp, _vp, _u64p, _sz, _vp, _u64p, _u32, _vp, C.POINTER(_vp)]),
+    ("zkw_decommitter_build_with_tails", _int, [_vp, _vp, _u64p, _sz, _vp, _u64p, _u32, _vp, _vp, C.POINTER(_vp)]),
+    ("zkw_decommitter_memory_queries", _int, [_vp, _vp, _sz, _vp, _u64p, _vp]),
     ("zkw_decommitter_witness_num_instances", _sz, [_vp]),
     ("zkw_decommitter_witness_bytes", _sz, [_vp, _int]),
     ("zkw_decommitter_witness_device_ptr", _vp, [_vp, _int]),
@@ -100,6 +104,7 @@ SYMBOLS = [
     ("zkw_storage_application_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_storage_application_witness_free", None, [_vp]),
     ("zkw_precompile_build", _int, [_vp, _int, _vp, _vp, _sz, _vp, _sz, C.c_uint32, _vp, _vp]),
+    ("zkw_precompile_build_with_tails", _int, [_vp, _int, _vp, _vp, _sz, _vp, _sz, C.c_uint32, _vp, _vp, _vp]),
     ("zkw_precompile_witness_num_instances", _sz, [_vp]),
     ("zkw_precompile_witness_num_rounds", _sz, [_vp]),
     ("zkw_precompile_witness_bytes", _sz, [_vp, _int]),
@@ -120,6 +125,22 @@ SYMBOLS = [
     ("zkw_trace_get", _int, [_vp, _sz, _u32, _u32, _vp]),
     ("zkw_ram_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_ram_check_satisfied", _int, [_vp, _vp, _sz, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("zkw_block_run", _int, [_int, _vp, C.POINTER(_vp)]),
+    ("zkw_block_last_error", C.c_char_p, []),
+    ("zkw_block_free", None, [_vp]),
+    ("zkw_block_witness", _vp, [_vp, C.c_uint8]),
+    ("zkw_block_context", _vp, [_vp, C.c_uint8]),
+    ("zkw_block_num_instances", _sz, [_vp, C.c_uint8]),
+    ("zkw_block_public_inputs", _vp, [_vp, C.c_uint8]),
+    ("zkw_block_recursion_encodings", _vp, [_vp, C.c_uint8]),
+    ("zkw_block_recursion_states", _vp, [_vp, C.c_uint8]),
+    ("zkw_block_memory_queue_length", _sz, [_vp]),
+    ("zkw_block_memory_queue_device_ptr", _vp, [_vp]),
+    ("zkw_block_memory_queue_state", _int, [_vp, _vp]),
+    ("zkw_block_demuxed_offsets", _int, [_vp, _vp]),
+    ("zkw_block_l1_messages_hash", _int, [_vp, _vp]),
+    ("zkw_block_timings", _int, [_vp, C.c_char_p, _sz, _vp, _vp, _sz, C.POINTER(_sz)]),
+    ("zkw_block_synthesize", _int, [_vp, _sz, _sz, _vp, _vp, C.POINTER(_sz)]),
 ]
 
 _lib = None
@@ -1038,3 +1059,197 @@ Context.synthesize_storage_sorter = _ctx_synthesize_storage_sorter
 Context.check_if_satisfied_storage_sorter = _ctx_check_if_satisfied_storage_sorter
 Context.check_if_satisfied_log_demux = _ctx_check_if_satisfied_log_demux
 Context.check_if_satisfied_events_sorter = _ctx_check_if_satisfied_events_sorter
+
+
+# ---- one block (zkw_block_run): the post-VM half of create_artifacts_from_tracer inside the library ------------------
+STORAGE_TREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+CIRCUIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint8, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64))
+
+
+class BlockInputs(C.Structure):
+    """zkw_block_inputs (include/zkw.h)"""
+    _fields_ = [("vm_memory_queries", C.c_void_p), ("n_vm_memory_queries", C.c_size_t),
+                ("decommit_queries", C.c_void_p), ("n_decommit_queries", C.c_size_t),
+                ("bytecode_hashes", C.c_void_p), ("bytecode_words", C.c_void_p), ("bytecode_word_offsets", C.c_void_p),
+                ("n_bytecodes", C.c_size_t),
+                ("log_queries", C.c_void_p), ("n_log_queries", C.c_size_t),
+                ("precompile_memory_queries", C.c_void_p * 3), ("n_precompile_memory_queries", C.c_size_t * 3),
+                ("num_non_deterministic_heap_queries", C.c_uint32),
+                ("storage_tree", STORAGE_TREE_FN), ("storage_tree_user", C.c_void_p),
+                ("storage_initial_root", C.c_uint8 * 32), ("storage_initial_next_enumeration_index", C.c_uint64),
+                ("capacities", C.c_uint32 * 14)]
+
+
+class Block:
+    """zkw_block: every witness builder of one block scheduled as a dependency graph inside libzkw (csrc/zkw_block.hip).
+    `block`: the dict of synthetic.block_after_vm (or the same arrays from a real VM run); `capacities`: circuit type ->
+    capacity (default geometry_config.rs); `storage_tree`: callable(dedup_queries) -> (leaf_indexes, merkle_paths,
+    initial_root, next_enumeration_index is given separately) or None."""
+
+    WITNESS_GETTERS = {2: "zkw_decommit_witness", 3: "zkw_decommitter_witness", 4: "zkw_demux_witness", 5: "zkw_precompile_witness",
+                       6: "zkw_precompile_witness", 7: "zkw_precompile_witness", 8: "zkw_ram_witness", 9: "zkw_storage_witness",
+                       10: "zkw_storage_application_witness", 11: "zkw_events_witness", 12: "zkw_events_witness"}
+
+    def __init__(self, device_id, block, capacities=None, storage_tree=None, storage_initial_root=None,
+                 storage_next_enumeration_index=0, num_non_deterministic_heap_queries=0):
+        lib = load()
+        inp = BlockInputs()
+        keep = []
+
+        def arr(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            keep.append(a)
+            return a
+
+        vm = arr(block["vm_memory_queries"], MEM_QUERY)
+        inp.vm_memory_queries, inp.n_vm_memory_queries = vm.ctypes.data, vm.size
+        dq = arr(block["decommit_queries"], DECOMMIT_QUERY)
+        inp.decommit_queries, inp.n_decommit_queries = dq.ctypes.data, dq.size
+        hashes = list(block["bytecodes"].keys())
+        codes = [np.ascontiguousarray(block["bytecodes"][h], dtype=np.uint32).reshape(-1, 8) for h in hashes]
+        hh = arr(np.frombuffer(b"".join(hashes), np.uint32).reshape(-1, 8) if hashes else np.zeros((0, 8), np.uint32), np.uint32)
+        ww = arr(np.concatenate(codes) if codes else np.zeros((0, 8), np.uint32), np.uint32)
+        wo = arr(np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]), np.uint64)
+        inp.bytecode_hashes, inp.bytecode_words, inp.bytecode_word_offsets, inp.n_bytecodes = hh.ctypes.data, ww.ctypes.data, wo.ctypes.data, len(hashes)
+        lq = arr(block["log_queries"], LOG_QUERY)
+        inp.log_queries, inp.n_log_queries = lq.ctypes.data, lq.size
+        for k in range(3):
+            mq = arr(block["precompile_memory_queries"][k], MEM_QUERY)
+            inp.precompile_memory_queries[k] = mq.ctypes.data if mq.size else None
+            inp.n_precompile_memory_queries[k] = mq.size
+        inp.num_non_deterministic_heap_queries = num_non_deterministic_heap_queries
+        self._tree_error = None
+        if storage_tree is not None:
+            def _cb(_user, q_ptr, n, idx_ptr, paths_ptr):
+                try:
+                    q = np.ctypeslib.as_array(C.cast(q_ptr, C.POINTER(C.c_uint8)), (n * LOG_QUERY.itemsize,)).view(LOG_QUERY).copy()
+                    idx, paths = storage_tree(q)
+                    np.ctypeslib.as_array(C.cast(idx_ptr, C.POINTER(C.c_uint64)), (n,))[:] = np.asarray(idx, np.uint64)
+                    np.ctypeslib.as_array(C.cast(paths_ptr, C.POINTER(C.c_uint8)), (n * 256 * 32,))[:] = np.asarray(paths, np.uint8).reshape(-1)
+                    return 0
+                except Exception as e:  # noqa: BLE001 - reported through the return code
+                    self._tree_error = e
+                    return 1
+            self._cb = STORAGE_TREE_FN(_cb)
+            inp.storage_tree = self._cb
+            root = np.frombuffer(bytes(storage_initial_root), np.uint8)
+            assert root.size == 32
+            for i in range(32):
+                inp.storage_initial_root[i] = int(root[i])
+            inp.storage_initial_next_enumeration_index = storage_next_enumeration_index
+        self.capacities = {t: int(circuit_geometry(t)["capacity"]) for t in range(1, 14)}
+        for t, c in (capacities or {}).items():
+            inp.capacities[t] = c
+            self.capacities[t] = c
+        self.handle = C.c_void_p(None)
+        rc = lib.zkw_block_run(device_id, C.byref(inp), C.byref(self.handle))
+        if rc != OK:
+            if self._tree_error is not None:
+                raise self._tree_error
+            raise ZkwError(rc, (lib.zkw_block_last_error() or b"").decode() or lib.zkw_last_error().decode())
+        self._keep = keep
+
+    def num_instances(self, circuit_type):
+        return load().zkw_block_num_instances(self.handle, circuit_type)
+
+    def witness_get(self, circuit_type, what, dtype=np.uint64):
+        """one array of the witness of `circuit_type` (the ZKW_* enum of its witness type), copied to the host"""
+        lib = load()
+        prefix = self.WITNESS_GETTERS[circuit_type]
+        w = lib.zkw_block_witness(self.handle, circuit_type)
+        if not w:
+            return None
+        nbytes = getattr(lib, prefix + "_bytes")(w, what)
+        out = np.zeros(nbytes, np.uint8)
+        if nbytes:
+            ctx = lib.zkw_block_context(self.handle, circuit_type)
+            _check(lib.zkw_set_pointer_mode(ctx, PTR_HOST))  # the block's contexts run in device-pointer mode
+            try:
+                _check(getattr(lib, prefix + "_get")(w, what, _np_ptr(out), nbytes))
+            finally:
+                _check(lib.zkw_set_pointer_mode(ctx, PTR_DEVICE))
+        return out.view(dtype)
+
+    def _host_u64(self, fn, circuit_type, width):
+        p = fn(self.handle, circuit_type)
+        n = self.num_instances(circuit_type)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), (n, width)).copy()
+
+    def public_inputs(self, t):
+        return self._host_u64(load().zkw_block_public_inputs, t, 4)
+
+    def recursion_queue(self, t):
+        return (self._host_u64(load().zkw_block_recursion_encodings, t, 8), self._host_u64(load().zkw_block_recursion_states, t, 12))
+
+    @property
+    def memory_queue_length(self):
+        return load().zkw_block_memory_queue_length(self.handle)
+
+    def memory_queue_state(self):
+        s = np.zeros(1, QUEUE_STATE12)
+        _check(load().zkw_block_memory_queue_state(self.handle, _np_ptr(s)))
+        return s
+
+    def demuxed_offsets(self):
+        o = np.zeros(7, np.uint64)
+        _check(load().zkw_block_demuxed_offsets(self.handle, _np_ptr(o)))
+        return o
+
+    def l1_messages_hash(self):
+        h = np.zeros(32, np.uint8)
+        _check(load().zkw_block_l1_messages_hash(self.handle, _np_ptr(h)))
+        return h.tobytes()
+
+    def timings(self):
+        """[(name, start_ms, end_ms)] of the builders' (and the last synthesis call's) wall-clock spans"""
+        names = C.create_string_buffer(4096)
+        a, b = np.zeros(128), np.zeros(128)
+        n = C.c_size_t(0)
+        _check(load().zkw_block_timings(self.handle, names, 4096, _np_ptr(a), _np_ptr(b), 128, C.byref(n)))
+        nm = names.value.decode().split(",") if n.value else []
+        return [(nm[i], float(a[i]), float(b[i])) for i in range(n.value)]
+
+    def synthesize(self, n_rows, ring_slots=4, callback=None):
+        """ZkSyncBaseLayerCircuit::synthesis of every instance in emission order; callback(circuit_type, instance, trace_handle,
+        slot, public_input[4]) -> None (raise to stop). Returns the number of instances synthesized."""
+        err = []
+
+        def _cb(_user, ctype, inst, trace, slot, pi):
+            try:
+                if callback is not None:
+                    callback(int(ctype), int(inst), trace, int(slot), [int(pi[i]) for i in range(4)])
+                return 0
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                return 1
+        cb = CIRCUIT_FN(_cb)
+        n = C.c_size_t(0)
+        rc = load().zkw_block_synthesize(self.handle, n_rows, ring_slots, C.cast(cb, C.c_void_p), None, C.byref(n))
+        if err:
+            raise err[0]
+        _check(rc)
+        return n.value
+
+    CHECKERS = {8: "zkw_ram_check_satisfied", 2: "zkw_decommit_sorter_check_satisfied", 4: "zkw_log_demux_check_satisfied",
+                9: "zkw_storage_sorter_check_satisfied", 11: "zkw_events_sorter_check_satisfied", 12: "zkw_events_sorter_check_satisfied"}
+
+    def check_satisfied(self, circuit_type, trace_handle, slot):
+        """check_if_satisfied (src/tests/mod.rs:130-259) on a slot handed to a synthesize callback: (n_violations, first_bad)"""
+        lib = load()
+        bad, first = C.c_uint64(0), C.c_uint64(0)
+        _check(getattr(lib, self.CHECKERS[circuit_type])(lib.zkw_block_context(self.handle, circuit_type), trace_handle, slot,
+                                                         self.capacities[circuit_type], C.byref(bad), C.byref(first)))
+        return bad.value, first.value
+
+    def free(self):
+        if self.handle:
+            load().zkw_block_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -15,6 +15,10 @@
  *   - all work is enqueued on the context's HIP stream (zkw_set_stream); calls that return data to
  *     host memory synchronise that stream before returning, device-mode calls do not.
  *   - there is no CPU fallback: every call fails with ZKW_ERR_NO_DEVICE when no gfx950 device is usable.
+ *   - lifetimes: every witness / trace / block object keeps a reference to the context it was created from (its
+ *     accessors and its free function use the context's device and stream). zkw_destroy on a context with outstanding
+ *     objects synchronises and marks it; the context is released by the last zkw_*_free. The context must not be
+ *     passed to any other call after zkw_destroy.
  */
 #ifndef ZKW_H
 #define ZKW_H
@@ -42,6 +46,7 @@ enum { ZKW_PTR_HOST = 0, ZKW_PTR_DEVICE = 1 };
 /* ---- context ------------------------------------------------------------------------------------ */
 /* device_id >= 0. Returns NULL on failure (see zkw_last_error). */
 zkw_ctx *zkw_create(int device_id);
+/* deferred while witnesses / traces created from ctx are outstanding (see "lifetimes" above) */
 void zkw_destroy(zkw_ctx *ctx);
 const char *zkw_last_error(void);
 /* hip_stream: a hipStream_t (NULL = the HIP null stream, which is what torch's default stream is), or
@@ -181,6 +186,14 @@ typedef struct zkw_decommit_witness zkw_decommit_witness;
    check fails. */
 int zkw_decommit_sorter_build(zkw_ctx *ctx, const zkw_decommit_query *q, size_t n, uint32_t capacity,
                               const zkw_queue_state12 *dedup_in, zkw_decommit_witness **out);
+/* The same builder in two phases, so that a block sequencer can overlap the hash chains of independent builders:
+   _prepare does everything that depends on the requests' CONTENTS only (encodings, the stable sort, the deduplicated
+   queue: ZKW_DEC_SORTED_QUERIES / _ENC and ZKW_DEC_DEDUP_QUERIES are valid when it returns and it has synchronised),
+   _finish hashes the three queues in one launch and derives challenges, grand products, instance records and public
+   inputs. No other decommit-sorter call may be made on ctx between the two. zkw_decommit_sorter_build = both. */
+int zkw_decommit_sorter_prepare(zkw_ctx *ctx, const zkw_decommit_query *q, size_t n, uint32_t capacity,
+                                const zkw_queue_state12 *dedup_in, zkw_decommit_witness **out);
+int zkw_decommit_sorter_finish(zkw_ctx *ctx, zkw_decommit_witness *w);
 enum {
     ZKW_DEC_SORTED_QUERIES = 0, /* zkw_decommit_query[n]  */
     ZKW_DEC_UNSORTED_ENC = 1,   /* uint64_t[n][8]         */
@@ -312,6 +325,17 @@ typedef struct zkw_decommitter_witness zkw_decommitter_witness;
 int zkw_decommitter_build(zkw_ctx *ctx, const zkw_decommit_query *requests, const uint64_t *dedup_tails,
                           size_t n_requests, const uint32_t *words, const uint64_t *word_offsets, uint32_t capacity,
                           const zkw_queue_state12 *mem_in, zkw_decommitter_witness **out);
+/* The same with the states of the memory queue over the code words given instead of hashed here:
+   given_mem_tails[total_words][12] (NULL = hash them) — a slice of a memory queue the caller has already hashed as a
+   whole (zkw_block_run hashes one block's memory queue once, inside the RAM-permutation builder). */
+int zkw_decommitter_build_with_tails(zkw_ctx *ctx, const zkw_decommit_query *requests, const uint64_t *dedup_tails,
+                                     size_t n_requests, const uint32_t *words, const uint64_t *word_offsets,
+                                     uint32_t capacity, const zkw_queue_state12 *mem_in, const uint64_t *given_mem_tails,
+                                     zkw_decommitter_witness **out);
+/* Only the memory writes the code words become (decommit_code.rs:47-78), in the order of `requests`:
+   out[total_words]. Lets a sequencer assemble the block's whole memory queue before anything is hashed. */
+int zkw_decommitter_memory_queries(zkw_ctx *ctx, const zkw_decommit_query *requests, size_t n_requests,
+                                   const uint32_t *words, const uint64_t *word_offsets, zkw_mem_query *out);
 enum {
     ZKW_DCM_MEM_QUERIES = 0,  /* zkw_mem_query[total_words]     */
     ZKW_DCM_MEM_ENC = 1,      /* uint64_t[total_words][8]       */
@@ -413,6 +437,11 @@ typedef struct zkw_precompile_witness zkw_precompile_witness;
 int zkw_precompile_build(zkw_ctx *ctx, int kind, const zkw_log_query *requests, const uint64_t *request_tails,
                          size_t n_requests, const zkw_mem_query *mem_queries, size_t n_queries, uint32_t capacity,
                          const zkw_queue_state12 *mem_in, zkw_precompile_witness **out);
+/* given_mem_tails[n_queries][12] (NULL = hash them): see zkw_decommitter_build_with_tails */
+int zkw_precompile_build_with_tails(zkw_ctx *ctx, int kind, const zkw_log_query *requests, const uint64_t *request_tails,
+                                    size_t n_requests, const zkw_mem_query *mem_queries, size_t n_queries,
+                                    uint32_t capacity, const zkw_queue_state12 *mem_in, const uint64_t *given_mem_tails,
+                                    zkw_precompile_witness **out);
 enum {
     ZKW_PRC_MEM_ENC = 0,   /* uint64_t[n_queries][8]  */
     ZKW_PRC_MEM_TAILS = 1, /* uint64_t[n_queries][12] */
@@ -462,7 +491,9 @@ int zkw_linear_keccak256(zkw_ctx *ctx, const zkw_log_query *messages, size_t n, 
    2^20 at production geometry = TARGET_CIRCUIT_TRACE_LENGTH, base_layer/mod.rs:17). It plays the role of
    the reference's CSReferenceAssembly (output of `synthesis`, base_layer/mod.rs:315-323): variable
    columns, lookup columns and the lookup-multiplicity column, every cell written. Slots are a ring: a
-   prover consumes a slot while later instances are synthesised into the others. */
+   prover consumes a slot while later instances are synthesised into the others.
+   A trace may be filled / checked through any context of the same device (the kernels run on THAT context's stream;
+   ordering between streams that touch one slot is the caller's business). */
 int zkw_trace_create(zkw_ctx *ctx, size_t n_rows, size_t n_slots, zkw_trace **out);
 /* same with an explicit column count (zkw_trace_create = 149, the RAMPermutation geometry): a circuit type whose
    geometry is wider — the LogDemuxer's 136 + 14 + 1 = 151 — needs its own trace */
@@ -489,6 +520,87 @@ int zkw_ram_synthesize(zkw_ctx *ctx, const zkw_ram_witness *w, size_t first_inst
    6 padding). Synchronises the stream. */
 int zkw_ram_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                             uint64_t *n_violations, uint64_t *first_bad);
+
+/* ---- one block: the post-VM half of create_artifacts_from_tracer (a19) ----------------------------------------- */
+/* Counterpart of src/witness/oracle.rs:928-1130 + 1494-1732 (everything `create_artifacts_from_tracer` does after the
+   VM has run, except the MainVM instances): every per-circuit witness builder over what the VM left behind, the shared
+   queues threaded through them, public inputs and one recursion queue per circuit type, then the synthesis of every
+   instance in the reference's emission order. The sequencer lives in the library (csrc/zkw_block.hip, written against
+   this header only) so that a Rust host makes ONE call per block and nothing round-trips through host memory.
+
+   Scheduling (why this is not the reference's order): every queue hash chain is serial, ~10 us per item on one wave,
+   but independent chains run concurrently for free. The builders are therefore run as a dependency graph on their own
+   contexts / HIP streams / host threads: contents first (sorts, routing, deduplication), then all hash chains side by
+   side; the block's memory queue (VM, code words, keccak256, sha256, ecrecover queries) is assembled up front and
+   hashed ONCE, inside the RAM-permutation builder, and the decommitter / precompile builders take their slices of it.
+   Results are identical to calling the builders one by one (tests/test_gpu_block.py). */
+typedef struct zkw_block zkw_block;
+/* the reference's `tree: impl BinarySparseStorageTree` (src/external_calls.rs:81): asked once, for the deduplicated
+   rollup storage queries of the block in their final order: leaf_indexes[n] (0 = empty leaf) and merkle_paths[n][256][32]
+   of the state BEFORE the block (see zkw_storage_application_build). Return 0 on success. Called on the thread that runs
+   the storage branch. */
+typedef int (*zkw_storage_tree_fn)(void *user, const zkw_log_query *dedup_queries, size_t n, uint64_t *leaf_indexes,
+                                   uint8_t *merkle_paths);
+typedef struct zkw_block_inputs {
+    const zkw_mem_query *vm_memory_queries;      /* the VM's memory queue in order (oracle.rs:894-903) */
+    size_t n_vm_memory_queries;
+    const zkw_decommit_query *decommit_queries;  /* decommit requests in order (oracle.rs:928-945), n > 0 */
+    size_t n_decommit_queries;
+    /* the bytecodes behind the decommit hashes: code k has hash bytecode_hashes[k][8] (limbs as zkw_decommit_query.hash)
+       and owns 32-byte words [bytecode_word_offsets[k], bytecode_word_offsets[k+1]) of bytecode_words[..][8] */
+    const uint32_t *bytecode_hashes;
+    const uint32_t *bytecode_words;
+    const uint64_t *bytecode_word_offsets;
+    size_t n_bytecodes;
+    const zkw_log_query *log_queries;            /* forward-applied log queue (oracle.rs:308-350) */
+    size_t n_log_queries;
+    const zkw_mem_query *precompile_memory_queries[3]; /* keccak256, sha256, ecrecover (see zkw_precompile_build) */
+    size_t n_precompile_memory_queries[3];
+    uint32_t num_non_deterministic_heap_queries;
+    zkw_storage_tree_fn storage_tree;            /* NULL = no StorageApplication instances are built */
+    void *storage_tree_user;
+    uint8_t storage_initial_root[32];
+    uint64_t storage_initial_next_enumeration_index;
+    uint32_t capacities[14];                     /* per BaseLayerCircuitType; 0 = geometry_config.rs default */
+} zkw_block_inputs;
+/* All pointers in `in` are HOST pointers. Blocks until every builder has finished. */
+int zkw_block_run(int device_id, const zkw_block_inputs *in, zkw_block **out);
+/* message of the last failed zkw_block_run on this thread (its builders run on worker threads, whose zkw_last_error
+   is not the caller's) */
+const char *zkw_block_last_error(void);
+void zkw_block_free(zkw_block *b);
+/* witness of one circuit type, to be cast to its zkw_*_witness type (2 zkw_decommit_witness, 3 zkw_decommitter_witness,
+   4 zkw_demux_witness, 5/6/7 zkw_precompile_witness, 8 zkw_ram_witness, 9 zkw_storage_witness, 10
+   zkw_storage_application_witness, 11/12 zkw_events_witness); NULL for the others. The handles belong to the block and
+   to the context zkw_block_context() returns for the type (device pointer mode). */
+void *zkw_block_witness(const zkw_block *b, uint8_t circuit_type);
+zkw_ctx *zkw_block_context(const zkw_block *b, uint8_t circuit_type);
+size_t zkw_block_num_instances(const zkw_block *b, uint8_t circuit_type);
+/* public inputs [n_instances][4] of a type that has them (2, 4, 8, 9, 11, 12), the RecursionRequest encodings
+   [n_instances][8] and the RecursionQueueSimulator states [n_instances][12] after each push (postprocessing/mod.rs:393-400).
+   Host pointers valid until zkw_block_free; NULL when the type has none. */
+const uint64_t *zkw_block_public_inputs(const zkw_block *b, uint8_t circuit_type);
+const uint64_t *zkw_block_recursion_encodings(const zkw_block *b, uint8_t circuit_type);
+const uint64_t *zkw_block_recursion_states(const zkw_block *b, uint8_t circuit_type);
+/* the whole memory queue the RAM permutation saw, its final state, the six demuxed queue offsets, the L1 messages
+   pubdata hash (compute_linear_keccak256) */
+size_t zkw_block_memory_queue_length(const zkw_block *b);
+const zkw_mem_query *zkw_block_memory_queue_device_ptr(const zkw_block *b);
+int zkw_block_memory_queue_state(const zkw_block *b, zkw_queue_state12 *out);
+int zkw_block_demuxed_offsets(const zkw_block *b, uint64_t out[7]);
+int zkw_block_l1_messages_hash(const zkw_block *b, uint8_t out[32]);
+/* wall-clock spans of the last run: names (comma separated), then start / end in ms since zkw_block_run was entered */
+int zkw_block_timings(const zkw_block *b, char *names, size_t names_bytes, double *start_ms, double *end_ms, size_t max_spans,
+                      size_t *n_spans);
+/* ZkSyncBaseLayerCircuit::synthesis for every instance of the synthesizable types of the block, in the reference's
+   emission order (oracle.rs:975-984 demuxer, 1039-1049 RAM, then CircuitMaker order 1494-1732: decommit sorter,
+   storage sorter, events, L1 messages): each instance is filled into a slot of an internal trace ring (n_rows rows,
+   `ring_slots` slots per geometry) and handed to `cb` — the counterpart of external_calls::run's circuit_callback
+   (a prover consumes the slot before it is reused; the slot stays valid until cb returns). cb may be NULL.
+   *n_done = number of instances synthesized. */
+typedef int (*zkw_circuit_fn)(void *user, uint8_t circuit_type, size_t instance, const zkw_trace *trace, size_t slot,
+                              const uint64_t public_input[4]);
+int zkw_block_synthesize(zkw_block *b, size_t n_rows, size_t ring_slots, zkw_circuit_fn cb, void *user, size_t *n_done);
 
 #ifdef __cplusplus
 }

@@ -81,3 +81,100 @@ def test_block_with_empty_queues(ctx, oracle):
     assert done[blk.EVENTS_SORTER] == 1 and done[blk.L1_MESSAGES_SORTER] == 1 and done[blk.STORAGE_SORTER] >= 2
     for wit in w.values():
         wit.free()
+
+
+def _tree_for(oracle, dedup_queries, seed):
+    """a storage tree that holds, before the block, exactly what the block's first reads of every slot expect"""
+    tree = oracle.Tree()
+    rng = np.random.default_rng(seed)
+    for _ in range(10):
+        tree.insert_leaf(rng.bytes(32), rng.bytes(32))
+    for q in dedup_queries:
+        if q["read_value"].any():
+            tree.insert_leaf(oracle.derive_final_address(q), b"".join(int(x).to_bytes(4, "big") for x in q["read_value"][::-1]))
+    return tree
+
+
+@pytest.mark.parametrize("seed", [1, 4])
+def test_block_sequencer_matches_builder_by_builder(ctx, oracle, seed):
+    """zkw_block_run (the C++ sequencer: builders as a dependency graph on their own streams / threads, the memory queue
+    hashed once) against the same builders called one by one in the reference's order (block.create_artifacts_after_vm):
+    every instance record, public input, recursion queue and shared queue state identical; then every instance
+    synthesized in emission order through the circuit callback and checked."""
+    from era_zkevm_test_harness_amd import block as blk, native as nv
+
+    b = synthetic.block_after_vm(seed=seed)
+    caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.STORAGE_APPLICATION: 5, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+    a = blk.create_artifacts_after_vm(ctx, b, caps)
+    w = a["witnesses"]
+    dedup = w["storage_sorter"].get(nv.STO_RESULT_QUERIES)
+    tree = _tree_for(oracle, dedup, seed)
+    root0, next0 = tree.root, tree.next_enumeration_index
+
+    def tree_answers(q):
+        assert q.tobytes() == dedup.tobytes()
+        idx = np.zeros(q.size, np.uint64)
+        paths = np.zeros((q.size, 256, 32), np.uint8)
+        for i in range(q.size):
+            idx[i], _, paths[i] = tree.get_leaf(oracle.derive_final_address(q[i]))
+        return idx, paths
+
+    B = nv.Block(0, b, caps, storage_tree=tree_answers, storage_initial_root=root0, storage_next_enumeration_index=next0)
+    # shared queues
+    assert B.memory_queue_length == a["memory_queries"].size
+    assert B.memory_queue_state().tobytes() == a["memory_queue_state"].tobytes()
+    assert np.array_equal(B.demuxed_offsets().astype(np.int64), a["demuxed_offsets"])
+    assert B.l1_messages_hash() == a["l1_messages_pubdata_hash"]
+    # instance records of every builder
+    pairs = ((blk.DECOMMITS_SORTER, nv.DEC_INSTANCES, "decommits_sorter"), (blk.CODE_DECOMMITTER, nv.DCM_INSTANCES, "code_decommitter"),
+             (blk.LOG_DEMUXER, nv.DMX_INSTANCES, "log_demuxer"), (blk.KECCAK256, nv.PRC_INSTANCES, "keccak256"),
+             (blk.SHA256, nv.PRC_INSTANCES, "sha256"), (blk.ECRECOVER, nv.PRC_INSTANCES, "ecrecover"),
+             (blk.RAM_PERMUTATION, nv.RAM_INSTANCES, "ram_permutation"), (blk.STORAGE_SORTER, nv.STO_INSTANCES, "storage_sorter"),
+             (blk.EVENTS_SORTER, nv.EVT_INSTANCES, "events_sorter"), (blk.L1_MESSAGES_SORTER, nv.EVT_INSTANCES, "l1_messages_sorter"))
+    for ctype, what, key in pairs:
+        got, exp = B.witness_get(ctype, what, np.uint8), w[key].get(what)
+        assert B.num_instances(ctype) == w[key].num_instances, key
+        assert got.tobytes() == exp.tobytes(), key
+    # the storage application over the callback's answers == the builder called directly == the oracle
+    qt = w["storage_sorter"].get(nv.STO_RESULT_NEW_TAILS)
+    idx, paths = tree_answers(dedup)
+    sap = ctx.decompose_into_storage_application_witnesses(dedup, qt, idx, paths, root0, next0, caps[blk.STORAGE_APPLICATION])
+    assert B.witness_get(blk.STORAGE_APPLICATION, nv.SAP_INSTANCES, np.uint8).tobytes() == sap.get(nv.SAP_INSTANCES).tobytes()
+    o = oracle.storage_application_build(tree, dedup, qt, caps[blk.STORAGE_APPLICATION])
+    assert B.witness_get(blk.STORAGE_APPLICATION, nv.SAP_ROOTS, np.uint8).tobytes() == o["roots"].tobytes()
+    assert B.num_instances(blk.STORAGE_APPLICATION) == o["instances"].size >= 2
+    sap.free()
+    # public inputs and recursion queues
+    for ctype, pi in a["public_inputs"].items():
+        assert np.array_equal(B.public_inputs(ctype), pi), ctype
+        enc, states = B.recursion_queue(ctype)
+        assert np.array_equal(enc, a["recursion_queues"][ctype][0]) and np.array_equal(states, a["recursion_queues"][ctype][1])
+    # synthesis in emission order through the circuit callback
+    seen = []
+
+    def on_circuit(ctype, inst, trace, slot, pi):
+        bad, first = B.check_satisfied(ctype, trace, slot)
+        assert bad == 0, (ctype, inst, bad, first)
+        assert pi == [int(x) for x in a["public_inputs"][ctype][inst]]
+        seen.append((ctype, inst))
+
+    n = B.synthesize(1 << 15, ring_slots=3, callback=on_circuit)
+    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.DECOMMITS_SORTER, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER]
+    assert seen == [(t, i) for t in order for i in range(B.num_instances(t))] and n == len(seen) > 12
+    spans = {name for name, _, _ in B.timings()}
+    assert {"builders", "ram_permutation", "decommit_sorter.finish", "log_demuxer", "storage_application", "synthesis"} <= spans
+    B.free()
+    for wit in w.values():
+        wit.free()
+
+
+def test_block_sequencer_reports_builder_failures(ctx):
+    """a failure on a worker thread (here: a decommit request whose bytecode is missing) surfaces as an error, not a crash"""
+    from era_zkevm_test_harness_amd import native as nv
+
+    b = synthetic.block_after_vm(seed=2)
+    b["bytecodes"].pop(next(iter(b["bytecodes"])))
+    with pytest.raises(nv.ZkwError) as ei:
+        nv.Block(0, b, {2: 5, 3: 7, 4: 64, 8: 1000})
+    assert ei.value.code == nv.ERR_INVALID and "bytecode" in str(ei.value)
