@@ -125,8 +125,7 @@ struct zkw_ctx {
         DevBuf& b = pool[name];
         if (b.cap < bytes) {
             if (b.p) {
-                HIP_TRY(hipStreamSynchronize(stream));
-                HIP_TRY(hipFree(b.p));
+                retired_dev.push_back(b.p);
                 b.p = nullptr;
                 b.cap = 0;
             }
@@ -157,7 +156,7 @@ struct zkw_ctx {
             st.pending = false;
         }
         if (st.cap < bytes) {
-            if (st.p) HIP_TRY(hipHostFree(st.p));
+            if (st.p) retired_host.push_back(st.p);
             st.p = nullptr;
             st.cap = 0;
             HIP_TRY(hipHostMalloc(&st.p, bytes + bytes / 2 + 256, hipHostMallocDefault));
@@ -202,6 +201,28 @@ struct zkw_ctx {
         if (ptr_mode == ZKW_PTR_HOST) HIP_TRY(hipStreamSynchronize(stream));
         return ZKW_OK;
     }
+    // Small device -> host readback (counts, violation flags) THROUGH PINNED MEMORY, then a sync of this stream only.
+    // A hipMemcpyAsync into pageable memory waits for every stream of the device (measured: 0.9 s behind another
+    // context's queue chain), which serialises the builders that zkw_block_run runs side by side.
+    void* pinned_rb = nullptr;
+    size_t pinned_rb_cap = 0;
+    int read_small(void* dst, const void* src, size_t bytes) {
+        if (pinned_rb_cap < bytes) {
+            if (pinned_rb) retired_host.push_back(pinned_rb);
+            pinned_rb = nullptr;
+            pinned_rb_cap = 0;
+            const size_t want = bytes < 4096 ? 4096 : bytes;
+            HIP_TRY(hipHostMalloc(&pinned_rb, want, hipHostMallocDefault));
+            pinned_rb_cap = want;
+        }
+        HIP_TRY(hipMemcpyAsync(pinned_rb, src, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        memcpy(dst, pinned_rb, bytes);
+        return ZKW_OK;
+    }
+    // buffers replaced by a bigger one: hipFree / hipHostFree wait for the whole device, so they are kept until the
+    // context is destroyed (growth is geometric: bounded waste)
+    std::vector<void*> retired_dev, retired_host;
 };
 
 // RAII span around one kernel launch (or a library sort); free when profiling is off
@@ -312,6 +333,9 @@ static void ctx_destroy_now(zkw_ctx* ctx) {
         if (kv.second.p) (void)hipHostFree(kv.second.p);
         if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
     }
+    for (void* q : ctx->retired_dev) (void)hipFree(q);
+    for (void* q : ctx->retired_host) (void)hipHostFree(q);
+    if (ctx->pinned_rb) (void)hipHostFree(ctx->pinned_rb);
     if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
     if (ctx->chain_ev_b) (void)hipEventDestroy(ctx->chain_ev_b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -353,7 +377,10 @@ extern "C" int zkw_set_chain_stream(zkw_ctx* ctx, void* s) {
             (void)hipEventDestroy(a);
             return fail(ZKW_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
         }
-        if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
+        for (void* q : ctx->retired_dev) (void)hipFree(q);
+    for (void* q : ctx->retired_host) (void)hipHostFree(q);
+    if (ctx->pinned_rb) (void)hipHostFree(ctx->pinned_rb);
+    if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
         if (ctx->chain_ev_b) (void)hipEventDestroy(ctx->chain_ev_b);
         ctx->chain_ev_a = a;
         ctx->chain_ev_b = b;
@@ -1289,8 +1316,7 @@ static int check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32
     { Prof _p(ctx, "k_check_mult"); hipLaunchKernelGGL(k_check_mult, dim3(256), dim3(256), 0, ctx->stream, trace, n_rows, S::G + S::L, d_hist, d_res); }
     ZKW_TRY(launch_check("k_check_mult"));
     CheckResult res;
-    HIP_TRY(hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
     *n_violations = res.violations;
     if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
     return ZKW_OK;
@@ -1375,8 +1401,7 @@ static int decommit_prepare(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_dec
     { Prof _p(ctx, "k_decommit_dedup"); hipLaunchKernelGGL(k_decommit_dedup, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, w->sorted_enc, n, fresh_count, last_fresh, w->dedup_q, w->dedup_enc, totals); }
     ZKW_TRY(launch_check("k_decommit_dedup"));
     u32 h_totals[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h_totals, totals, sizeof h_totals, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the dedup chain length is data-dependent
+    ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
     if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "decommit requests with the same hash disagree on page or are not "
                                                        "timestamp-ordered (sort_decommit_requests.rs:99-114)");
     w->n_dedup = h_totals[0];
@@ -1613,8 +1638,7 @@ static int events_run(zkw_ctx* ctx, zkw_events_witness* w, const zkw_log_query* 
     { Prof _p(ctx, "k_events_dedup"); hipLaunchKernelGGL(k_events_dedup, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, kept, w->result_q, r_enc, totals); }
     ZKW_TRY(launch_check("k_events_dedup"));
     u32 h_totals[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h_totals, totals, sizeof h_totals, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
     if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "event queue is not a sequence of forward events each optionally followed by "
                                                        "its own rollback (events_sort_dedup.rs:344-356, 512-533): %u violations", h_totals[1]);
     w->n_result = h_totals[0];
@@ -1786,8 +1810,7 @@ static int demux_run(zkw_ctx* ctx, zkw_demux_witness* w, const zkw_log_query* d_
     { Prof _p(ctx, "k_demux_route"); hipLaunchKernelGGL(k_demux_route, dim3(1), dim3(1024), 0, ctx->stream, d_q, in_enc, n, params, route_count, w->out_q, out_enc, w->d_offsets); }
     ZKW_TRY(launch_check("k_demux_route"));
     u64 h_tot[8];
-    HIP_TRY(hipMemcpyAsync(h_tot, w->d_offsets, sizeof h_tot, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZKW_TRY(ctx->read_small(h_tot, w->d_offsets, sizeof h_tot));
     if (h_tot[7]) return fail(ZKW_ERR_CHECK_FAILED, "%llu log queries have an aux byte / shard / rollback combination the "
                                                     "reference treats as unreachable (log_demux.rs:174-249)", (unsigned long long)h_tot[7]);
     for (int k = 0; k < 7; k++) w->offsets[k] = h_tot[k];
@@ -1992,8 +2015,7 @@ static int storage_run(zkw_ctx* ctx, zkw_storage_witness* w, const zkw_log_query
     { Prof _p(ctx, "k_storage_cells"); hipLaunchKernelGGL(k_storage_cells, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, sc, w->result_q, r_enc, totals); }
     ZKW_TRY(launch_check("k_storage_cells"));
     u32 h_totals[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h_totals, totals, sizeof h_totals, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
     if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "storage log is not a consistent history (%u violations of the asserts at "
                                                        "sort_storage_access.rs:64-203)", h_totals[1]);
     w->n_result = h_totals[0];
@@ -2240,8 +2262,7 @@ extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit
     { Prof _p(ctx, "k_decommitter_instances"); hipLaunchKernelGGL(k_decommitter_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
     if ((rc = launch_check("k_decommitter_instances")) != ZKW_OK) return bail(rc);
     u32 viol = 0;
-    if (hipMemcpyAsync(&viol, d_viol, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess)
+    if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
         return bail(fail(ZKW_ERR_HIP, "readback failed"));
     if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u bytecodes do not match their decommit request (length parity, word count or "
                                                      "SHA-256 digest, decommit_code.rs:241-244, 323-337)", viol));
@@ -2388,8 +2409,7 @@ extern "C" int zkw_callstack_simulate(zkw_ctx* ctx, const uint8_t* is_push, size
     { Prof _p(ctx, "k_stack_depth"); hipLaunchKernelGGL(k_stack_depth, dim3(1), dim3(1024), 0, ctx->stream, d_ops, n_ops, d_depth, d_rank, d_meta); }
     ZKW_TRY(launch_check("k_stack_depth"));
     u32 meta[3];
-    HIP_TRY(hipMemcpyAsync(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZKW_TRY(ctx->read_small(meta, d_meta, sizeof meta));
     if (meta[2]) return fail(ZKW_ERR_INVALID, "pop from the empty callstack (circuit_encodings/src/lib.rs:619)");
     const u32 n_push = meta[0], max_depth = meta[1];
     if (n_push > n_pushed) return fail(ZKW_ERR_INVALID, "%u pushes but only %zu entries", n_push, n_pushed);
@@ -2462,8 +2482,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
         ZKW_TRY(ctx->scratch_t<u64>("pc_meta", 4, &d_meta));
         { Prof _p(ctx, "k_precompile_counts"); hipLaunchKernelGGL(k_precompile_counts, dim3(1), dim3(1024), 0, ctx->stream, kind, d_req, n_requests, d_roff, d_qoff, d_rdoff, d_meta); }
         ZKW_TRY(launch_check("k_precompile_counts"));
-        HIP_TRY(hipMemcpyAsync(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ZKW_TRY(ctx->read_small(meta, d_meta, sizeof meta));
         if (meta[3]) return fail(ZKW_ERR_INVALID, "a precompile request without rounds (the first round carries `new_request`)");
         if (meta[1] != n_queries)
             return fail(ZKW_ERR_INVALID, "the requests need %llu memory queries, %zu given", (unsigned long long)meta[1], n_queries);
@@ -2523,8 +2542,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
     { Prof _p(ctx, "k_precompile_instances"); hipLaunchKernelGGL(k_precompile_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
     if ((rc = launch_check("k_precompile_instances")) != ZKW_OK) return bail(rc);
     u32 viol = 0;
-    if (hipMemcpyAsync(&viol, d_viol, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess)
+    if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
         return bail(fail(ZKW_ERR_HIP, "readback failed"));
     if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u requests whose memory queries do not fit their ABI (read/write flags, word "
                                                      "index or count: the asserts of the round walks)", viol));
@@ -2672,8 +2690,7 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
         TRY(launch_check("k_sap_roots"));
         if (rc != ZKW_OK) return bail(rc);
         if (hipMemcpyAsync(w->leaf_indexes, job.init_index, n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            ctx->read_small(meta, d_meta, sizeof meta) != ZKW_OK)
             return bail(fail(ZKW_ERR_HIP, "readback failed"));
     }
     w->n_instances = n ? (size_t)meta[0] : 1;
@@ -2696,8 +2713,7 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
     TRY(launch_check("k_sap_instances"));
     if (rc != ZKW_OK) return bail(rc);
     u32 viol = 0;
-    if (hipMemcpyAsync(&viol, d_viol, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess)
+    if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
         return bail(fail(ZKW_ERR_HIP, "readback failed"));
     if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u storage queries contradict the tree: the pre-state proof does not lead to the "
                                                      "initial root, the read value is not the leaf's (storage_application.rs:221,276), "

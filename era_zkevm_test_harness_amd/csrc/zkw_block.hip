@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <mutex>
@@ -69,11 +71,55 @@ struct PerType {
     std::vector<uint64_t> pi, enc, states;  // [n][4], [n][8], [n][12]
 };
 
+// One transfer lane per host thread of the graph: a private non-blocking stream + a grow-only pinned staging buffer,
+// created before anything long runs. Copies through pageable memory (hipMemcpy, hipMemcpyAsync with a pageable side) and
+// hipHostFree / hipStreamDestroy wait for EVERY stream of the device, i.e. for the other branches' queue chains
+// (measured: +0.9 s per builder), so nothing of the kind happens while the graph runs.
+enum { X_MAIN = 0, X_LOG, X_STO, X_EVT, X_L1, X_RAM, X_DEC, N_XFER };
+struct Xfer {
+    hipStream_t st = nullptr;
+    void* pin = nullptr;
+    size_t cap = 0;
+    std::vector<void*> retired;
+    Status reserve(size_t bytes) {
+        if (cap >= bytes) return Status();
+        if (pin) retired.push_back(pin);
+        pin = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        ST_HIP(hipHostMalloc(&pin, want, hipHostMallocDefault));
+        cap = want;
+        return Status();
+    }
+    Status d2h(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return Status();
+        ST_TRY(reserve(bytes));
+        ST_HIP(hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, st));
+        ST_HIP(hipStreamSynchronize(st));
+        memcpy(dst, pin, bytes);
+        return Status();
+    }
+    Status h2d(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return Status();
+        ST_TRY(reserve(bytes));
+        memcpy(pin, src, bytes);
+        ST_HIP(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, st));
+        ST_HIP(hipStreamSynchronize(st));
+        return Status();
+    }
+    void destroy() {
+        if (st) (void)hipStreamDestroy(st);
+        if (pin) (void)hipHostFree(pin);
+        for (void* q : retired) (void)hipHostFree(q);
+    }
+};
+
 }  // namespace
 
 struct zkw_block {
     int device = 0;
     zkw_ctx* ctx[N_CTX] = {};
+    Xfer xf[N_XFER];
     uint32_t cap[14] = {};
     Clock::time_point t0;
     std::mutex mu;
@@ -118,9 +164,9 @@ struct zkw_block {
         return Status();
     }
     template <class T>
-    Status upload(T** p, const T* host, size_t count) {
+    Status upload(int lane, T** p, const T* host, size_t count) {
         ST_TRY(alloc(p, count ? count : 1));
-        if (count) ST_HIP(hipMemcpy(*p, host, count * sizeof(T), hipMemcpyHostToDevice));
+        if (count) ST_TRY(xf[lane].h2d(*p, host, count * sizeof(T)));
         return Status();
     }
 };
@@ -154,15 +200,15 @@ Status storage_branch(zkw_block* B, const zkw_block_inputs* in, const zkw_log_qu
     uint64_t* d_idx = nullptr;
     uint8_t* d_paths = nullptr;
     if (nr) {
-        ST_HIP(hipMemcpy(hq.data(), d_rq, nr * sizeof(zkw_log_query), hipMemcpyDeviceToHost));
+        ST_TRY(B->xf[X_STO].d2h(hq.data(), d_rq, nr * sizeof(zkw_log_query)));
         if (in->storage_tree(in->storage_tree_user, hq.data(), nr, idx.data(), paths.data()) != 0) {
             Status s;
             s.rc = ZKW_ERR_INVALID;
             s.msg = "the storage_tree callback failed";
             return s;
         }
-        ST_TRY(B->upload(&d_idx, idx.data(), nr));
-        ST_TRY(B->upload(&d_paths, paths.data(), paths.size()));
+        ST_TRY(B->upload(X_STO, &d_idx, idx.data(), nr));
+        ST_TRY(B->upload(X_STO, &d_paths, paths.data(), paths.size()));
     }
     ST_ZKW(zkw_storage_application_build(B->ctx[C_STO], d_rq, d_rt, nr, d_idx, d_paths, in->storage_initial_root,
                                          in->storage_initial_next_enumeration_index, B->cap[T_SAP], &B->sap));
@@ -185,7 +231,7 @@ Status events_branch(zkw_block* B, int which, const zkw_log_query* d_q, size_t n
         const zkw_log_query* d_res = static_cast<const zkw_log_query*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_RESULT_QUERIES));
         ST_ZKW(zkw_linear_keccak256(c, d_res, zkw_events_witness_num_results(B->l1), d_hash));
         ST_ZKW(zkw_synchronize(c));
-        ST_HIP(hipMemcpy(B->l1_hash, d_hash, 32, hipMemcpyDeviceToHost));
+        ST_TRY(B->xf[X_L1].d2h(B->l1_hash, d_hash, 32));
     }
     return Status();
 }
@@ -195,10 +241,10 @@ Status log_branch(zkw_block* B, const zkw_block_inputs* in) {
     zkw_log_query* d_logs = nullptr;
     {
         Timed t(B, "log_demuxer");
-        ST_TRY(B->upload(&d_logs, in->log_queries, in->n_log_queries));
+        ST_TRY(B->upload(X_LOG, &d_logs, in->log_queries, in->n_log_queries));
         ST_ZKW(zkw_log_demux_build(B->ctx[C_DMX], d_logs, in->n_log_queries, B->cap[T_DMX], nullptr, &B->dmx));
         ST_ZKW(zkw_synchronize(B->ctx[C_DMX]));
-        ST_HIP(hipMemcpy(B->dmx_off, zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_OUT_OFFSETS), sizeof B->dmx_off, hipMemcpyDeviceToHost));
+        ST_TRY(B->xf[X_LOG].d2h(B->dmx_off, zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_OUT_OFFSETS), sizeof B->dmx_off));
     }
     const zkw_log_query* d_out = static_cast<const zkw_log_query*>(zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_OUT_QUERIES));
     auto q = [&](int k) { return d_out + B->dmx_off[k]; };
@@ -235,10 +281,15 @@ std::string key32(const uint32_t* h) { return std::string(reinterpret_cast<const
 
 Status run(zkw_block* B, const zkw_block_inputs* in) {
     ST_HIP(hipSetDevice(B->device));
+    for (int i = 0; i < N_XFER; i++) {
+        ST_HIP(hipStreamCreateWithFlags(&B->xf[i].st, hipStreamNonBlocking));
+        ST_TRY(B->xf[i].reserve(i == X_MAIN || i == X_LOG ? (size_t)8 << 20 : (size_t)1 << 20));
+    }
     for (int i = 0; i < N_CTX; i++) {
         B->ctx[i] = zkw_create(B->device);
         if (!B->ctx[i]) return from_rc(ZKW_ERR_NO_DEVICE);
         ST_ZKW(zkw_set_pointer_mode(B->ctx[i], ZKW_PTR_DEVICE));
+        if (getenv("ZKW_BLOCK_PROFILE")) ST_ZKW(zkw_profile_enable(B->ctx[i], 1));
     }
     for (int t = 1; t <= 13; t++) {
         zkw_circuit_geometry g;
@@ -253,11 +304,11 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
     std::vector<zkw_decommit_query> dedup;
     {
         Timed t(B, "decommit_sorter.prepare");
-        ST_TRY(B->upload(&d_dq, in->decommit_queries, in->n_decommit_queries));
+        ST_TRY(B->upload(X_MAIN, &d_dq, in->decommit_queries, in->n_decommit_queries));
         ST_ZKW(zkw_decommit_sorter_prepare(B->ctx[C_DEC], d_dq, in->n_decommit_queries, B->cap[T_DEC], nullptr, &B->dec));
         dedup.resize(zkw_decommit_witness_num_dedup(B->dec));
-        ST_HIP(hipMemcpy(dedup.data(), zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_QUERIES),
-                         dedup.size() * sizeof(zkw_decommit_query), hipMemcpyDeviceToHost));
+        ST_TRY(B->xf[X_MAIN].d2h(dedup.data(), zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_QUERIES),
+                         dedup.size() * sizeof(zkw_decommit_query)));
     }
     auto f_dec = std::async(std::launch::async, dec_finish_branch, B);  // its three chains run next to everything below
 
@@ -295,12 +346,12 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
         }
         ST_TRY(B->alloc(&B->d_all_mem, B->n_mem));
         if (in->n_vm_memory_queries)
-            ST_HIP(hipMemcpy(B->d_all_mem, in->vm_memory_queries, in->n_vm_memory_queries * sizeof(zkw_mem_query), hipMemcpyHostToDevice));
+            ST_TRY(B->xf[X_MAIN].h2d(B->d_all_mem, in->vm_memory_queries, in->n_vm_memory_queries * sizeof(zkw_mem_query)));
         for (int k = 0; k < 3; k++)
             if (in->n_precompile_memory_queries[k])
-                ST_HIP(hipMemcpy(B->d_all_mem + B->mem_off[2 + k], in->precompile_memory_queries[k],
-                                 in->n_precompile_memory_queries[k] * sizeof(zkw_mem_query), hipMemcpyHostToDevice));
-        ST_TRY(B->upload(&d_words, words.data(), words.size()));
+                ST_TRY(B->xf[X_MAIN].h2d(B->d_all_mem + B->mem_off[2 + k], in->precompile_memory_queries[k],
+                                 in->n_precompile_memory_queries[k] * sizeof(zkw_mem_query)));
+        ST_TRY(B->upload(X_MAIN, &d_words, words.data(), words.size()));
         const zkw_decommit_query* d_dedup = static_cast<const zkw_decommit_query*>(zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_QUERIES));
         // on the precompile context: the decommit context is busy hashing
         ST_ZKW(zkw_decommitter_memory_queries(B->ctx[C_PRE], d_dedup, dedup.size(), d_words, woff.data(), B->d_all_mem + B->mem_off[1]));
@@ -317,7 +368,7 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
     auto mem_in_at = [&](size_t start, zkw_queue_state12* st) -> Status {
         memset(st, 0, sizeof *st);
         st->length = (uint32_t)start;
-        if (start) ST_HIP(hipMemcpy(st->tail, d_tails + 12 * (start - 1), 96, hipMemcpyDeviceToHost));
+        if (start) ST_TRY(B->xf[X_MAIN].d2h(st->tail, d_tails + 12 * (start - 1), 96));
         return Status();
     };
     {
@@ -367,7 +418,7 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
         zkw_ctx* c = B->ctx[C_PRE];
         for (auto& s : src) {
             const size_t o = offs.back();
-            ST_HIP(hipMemcpy(d_pi + 4 * o, s.d_pi, s.n * 32, hipMemcpyDeviceToDevice));
+            ST_HIP(hipMemcpy(d_pi + 4 * o, s.d_pi, s.n * 32, hipMemcpyDeviceToDevice));  // every branch has joined: nothing else runs
             ST_ZKW(zkw_encode_recursion_requests(c, (uint64_t)s.type, d_pi + 4 * o, s.n, d_enc + 8 * o));
             offs.push_back(o + s.n);
         }
@@ -379,15 +430,24 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
             p.pi.resize(n * 4);
             p.enc.resize(n * 8);
             p.states.resize(n * 12);
-            ST_HIP(hipMemcpy(p.pi.data(), d_pi + 4 * o, n * 32, hipMemcpyDeviceToHost));
-            ST_HIP(hipMemcpy(p.enc.data(), d_enc + 8 * o, n * 64, hipMemcpyDeviceToHost));
-            ST_HIP(hipMemcpy(p.states.data(), d_states + 12 * o, n * 96, hipMemcpyDeviceToHost));
+            ST_TRY(B->xf[X_MAIN].d2h(p.pi.data(), d_pi + 4 * o, n * 32));
+            ST_TRY(B->xf[X_MAIN].d2h(p.enc.data(), d_enc + 8 * o, n * 64));
+            ST_TRY(B->xf[X_MAIN].d2h(p.states.data(), d_states + 12 * o, n * 96));
         }
     }
     return Status();
 }
 
 thread_local std::string g_block_error;
+
+// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and work on one hardware queue runs in
+// order: with the default, a 50 us kernel of one branch can sit behind another branch's 1.4 s queue chain (measured:
+// builders 2.6 s instead of 1.43 s). The variable is read when the HIP runtime initialises the device, so it is set when
+// the library is loaded, unless the host has chosen a value itself; a host that initialises HIP before loading libzkw
+// must export GPU_MAX_HW_QUEUES >= 16 itself.
+struct HwQueuesDefault {
+    HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} g_hw_queues_default;
 
 }  // namespace
 
@@ -402,6 +462,19 @@ extern "C" int zkw_block_run(int device_id, const zkw_block_inputs* in, zkw_bloc
     {
         Timed t(B, "builders");
         s = run(B, in);
+    }
+    if (getenv("ZKW_BLOCK_PROFILE") && s.ok()) {  // per-kernel HIP-event times of every branch's context (debugging aid)
+        static const char* cn[N_CTX] = {"dec", "ram", "dmx", "sto", "evt", "l1", "pre"};
+        for (int i = 0; i < N_CTX; i++) {
+            char names[4096];
+            if (zkw_profile_names(B->ctx[i], names, sizeof names) != ZKW_OK) continue;
+            char* save = nullptr;
+            for (char* k = strtok_r(names, ",", &save); k; k = strtok_r(nullptr, ",", &save)) {
+                double ms = 0;
+                uint64_t cnt = 0;
+                if (zkw_profile_get(B->ctx[i], k, &ms, &cnt) == ZKW_OK) fprintf(stderr, "[zkw_block] %-4s %-28s %10.3f ms %6llu launches\n", cn[i], k, ms, (unsigned long long)cnt);
+            }
+        }
     }
     if (!s.ok()) {
         zkw_block_free(B);
@@ -434,6 +507,7 @@ extern "C" void zkw_block_free(zkw_block* B) {
     for (int i = 0; i < N_CTX; i++)
         if (B->ctx[i]) zkw_destroy(B->ctx[i]);
     for (void* p : B->dev) (void)hipFree(p);
+    for (int i = 0; i < N_XFER; i++) B->xf[i].destroy();
     delete B;
 }
 

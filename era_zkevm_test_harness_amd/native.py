@@ -7,7 +7,11 @@ library is missing or no gfx950 device is usable.
 import ctypes as C
 import os
 
-import numpy as np
+# zkw_block_run overlaps the builders of a block on ~14 HIP streams; HIP's default of 4 hardware queues would serialise
+# them (csrc/zkw_block.hip). Read by the HIP runtime at device initialisation, i.e. before the first torch.cuda call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+import numpy as np  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkw.so")

@@ -339,7 +339,8 @@ def bytecode_hash(words: np.ndarray) -> np.ndarray:
 
 
 def block_after_vm(seed=1, n_vm_memory=3000, n_bytecodes=5, n_decommits=12, n_storage=150, n_storage_cells=25,
-                   n_events=60, n_l1_messages=25, n_precompile_calls=(5, 4, 3)):
+                   n_events=60, n_l1_messages=25, n_precompile_calls=(5, 4, 3), total_memory=None, max_code_words=23,
+                   precompile_max_rounds=5):
     """What the VM run of one block hands to the witness builders (src/witness/oracle.rs:185-927), synthesised
     consistently: the VM's memory queue incl. the writes every precompile input needs, the decommit-request queue with
     the bytecodes behind its hashes, the forward-applied log queue (storage, events, L1 messages, precompile calls,
@@ -348,7 +349,7 @@ def block_after_vm(seed=1, n_vm_memory=3000, n_bytecodes=5, n_decommits=12, n_st
 
     rng = np.random.default_rng(seed)
     # bytecodes and the decommit queue over them
-    lens = [1 + 2 * int(rng.integers(0, 12)) for _ in range(n_bytecodes)]
+    lens = [1 + 2 * int(rng.integers(0, (max_code_words + 1) // 2)) for _ in range(n_bytecodes)]
     codes = [rng.integers(0, 1 << 32, (n, 8), dtype=np.uint64).astype(np.uint32) for n in lens]
     hashes = np.stack([bytecode_hash(c) for c in codes])
     pick = np.concatenate([np.arange(n_bytecodes), rng.integers(0, n_bytecodes, max(0, n_decommits - n_bytecodes))])
@@ -368,7 +369,7 @@ def block_after_vm(seed=1, n_vm_memory=3000, n_bytecodes=5, n_decommits=12, n_st
     used_pages = set(range(8, 8 + 64)) | {int(p) for p in dq["memory_page"]}
     for kind, n_calls in enumerate(n_precompile_calls):
         for attempt in range(50):
-            req, mq = precompile_trace(kind, n_calls, seed=seed * 100 + 10 * kind + attempt)
+            req, mq = precompile_trace(kind, n_calls, seed=seed * 100 + 10 * kind + attempt, max_rounds=precompile_max_rounds)
             pages = {int(p) for p in mq["page"]}
             if not (pages & used_pages):
                 break
@@ -382,6 +383,9 @@ def block_after_vm(seed=1, n_vm_memory=3000, n_bytecodes=5, n_decommits=12, n_st
         rd["rw_flag"] = 1
         rd["timestamp"] -= 1
         vm_extra.append(rd)
+    if total_memory is not None:  # size the VM's part so that the whole memory queue has exactly `total_memory` items
+        n_vm_memory = total_memory - sum(lens) - sum(m.size for m in pre_mem) - sum(m.size for m in vm_extra)
+        assert n_vm_memory > 0
     vm_mem = np.concatenate([ram_trace(n_vm_memory, seed=seed + 3)] + vm_extra).astype(MEM_QUERY)
     # the log queue: sub-queues merged at random, each keeping its own order
     from .native import LOG_QUERY
@@ -394,10 +398,18 @@ def block_after_vm(seed=1, n_vm_memory=3000, n_bytecodes=5, n_decommits=12, n_st
     subs = [sto, ev, l1] + pre_req
     tags = np.concatenate([np.full(s.size, k) for k, s in enumerate(subs)])
     rng.shuffle(tags)
-    cursor = [0] * len(subs)
     logs = np.zeros(tags.size, subs[0].dtype)
-    for i, t in enumerate(tags):
-        logs[i] = subs[t][cursor[t]]
-        cursor[t] += 1
+    for k, sub in enumerate(subs):  # sub-queue k fills, in its own order, the positions tagged k
+        logs[np.nonzero(tags == k)[0]] = sub
     return {"vm_memory_queries": vm_mem, "decommit_queries": dq, "bytecodes": {h.tobytes(): c for h, c in zip(hashes, codes)},
             "log_queries": logs, "precompile_memory_queries": pre_mem}
+
+
+def block_production(seed=1):
+    """One block with the instance multiset of the reference's `basic_test` (file list of test_proofs/base_layer/: one
+    instance of every type, two of ECRecover and StorageApplication; the three MainVM instances need the VM) with every
+    builder at its PRODUCTION capacity (circuit_sequencer_api/src/geometry_config.rs:5-20): a memory queue of exactly
+    136 714 queries, 117 500 decommit requests over ~2 800 SHA-256 rounds of bytecode, a log queue of ~58 000 records
+    (storage over 60 slots, events, L1 messages, keccak256 / sha256 / ecrecover calls)."""
+    return block_after_vm(seed=seed, total_memory=136714, n_bytecodes=400, n_decommits=117500, n_storage=35000,
+                          n_storage_cells=60, n_events=11000, n_l1_messages=700, n_precompile_calls=(60, 700, 14))
