@@ -413,3 +413,88 @@ def block_production(seed=1):
     (storage over 60 slots, events, L1 messages, keccak256 / sha256 / ecrecover calls)."""
     return block_after_vm(seed=seed, total_memory=136714, n_bytecodes=400, n_decommits=117500, n_storage=35000,
                           n_storage_cells=60, n_events=11000, n_l1_messages=700, n_precompile_calls=(60, 700, 14))
+
+
+class StorageTree:
+    """Host-side storage tree, the input provider of the StorageApplication builder: the counterpart of the reference's
+    `ZKSyncTestingTree` / `InMemoryStorageTree<256, 32, 8, Blake2s256, ZkSyncStorageLeaf>` (src/witness/tree/mod.rs:
+    113-384, handed to `run()` as `tree: impl BinarySparseStorageTree`, src/external_calls.rs:81). Depth 256, Blake2s-256;
+    leaf hash = H(index as 8 big-endian bytes || value), node hash = H(left || right); bit `level` of the little-endian
+    key picks the side; enumeration indices start at 1. Answers the pre-block questions zkw_block_run's storage_tree
+    callback asks (get_leaf) — sequential CPU code by nature, a few hundred slots per block."""
+    DEPTH = 256
+
+    def __init__(self):
+        import hashlib
+
+        self._h = lambda b: hashlib.blake2s(b, digest_size=32).digest()
+        self.next_enumeration_index = 1
+        self.leaves = {}   # key int -> (index, value bytes)
+        self.nodes = {}    # (level, masked key int) -> hash
+        cur = self._leaf_hash(0, bytes(32))
+        self.empty = []
+        for _level in range(self.DEPTH):
+            self.empty.append(cur)
+            cur = self._h(cur + cur)
+        self.root = cur
+
+    def _leaf_hash(self, index, value):
+        return self._h(int(index).to_bytes(8, "big") + value)
+
+    def _sibling(self, k, level):
+        masked = ((k ^ (1 << level)) >> level) << level
+        return self.nodes.get((level, masked), self.empty[level])
+
+    def get_leaf(self, key: bytes):
+        """(enumeration index or 0, value, merkle path [256][32] with level 0 = the leaf's sibling)"""
+        k = int.from_bytes(key, "little")
+        index, value = self.leaves.get(k, (0, bytes(32)))
+        path = np.frombuffer(b"".join(self._sibling(k, level) for level in range(self.DEPTH)), np.uint8).reshape(self.DEPTH, 32)
+        return index, value, path
+
+    def insert_leaf(self, key: bytes, value: bytes) -> int:
+        k = int.from_bytes(key, "little")
+        if k in self.leaves:
+            index = self.leaves[k][0]
+        else:
+            index = self.next_enumeration_index
+            self.next_enumeration_index += 1
+        self.leaves[k] = (index, value)
+        cur = self._leaf_hash(index, value)
+        for level in range(self.DEPTH):
+            self.nodes[(level, (k >> level) << level)] = cur
+            sib = self._sibling(k, level)
+            cur = self._h(sib + cur) if (k >> level) & 1 else self._h(cur + sib)
+        self.root = cur
+        return index
+
+
+def derive_final_address(q) -> bytes:
+    """LogQuery::derive_final_address (zk_evm v1.4.1): Blake2s-256 of the 32-byte left-padded address followed by the
+    32-byte big-endian key — the storage tree's leaf key of a log query."""
+    import hashlib
+
+    addr = b"".join(int(x).to_bytes(4, "big") for x in q["address"][::-1])
+    key = b"".join(int(x).to_bytes(4, "big") for x in q["key"][::-1])
+    return hashlib.blake2s(bytes(12) + addr + key, digest_size=32).digest()
+
+
+def storage_tree_for(dedup_queries, seed=0, extra_leaves=10):
+    """A tree that holds, before the block, what the block's first access of every slot expects (read_value) plus a few
+    unrelated leaves; returns (tree, answers) with answers(q) -> (leaf_indexes, merkle_paths) for the callback."""
+    tree = StorageTree()
+    rng = np.random.default_rng(seed)
+    for _ in range(extra_leaves):
+        tree.insert_leaf(rng.bytes(32), rng.bytes(32))
+    for q in dedup_queries:
+        if q["read_value"].any():
+            tree.insert_leaf(derive_final_address(q), b"".join(int(x).to_bytes(4, "big") for x in q["read_value"][::-1]))
+
+    def answers(q):
+        idx = np.zeros(q.size, np.uint64)
+        paths = np.zeros((q.size, 256, 32), np.uint8)
+        for i in range(q.size):
+            idx[i], _, paths[i] = tree.get_leaf(derive_final_address(q[i]))
+        return idx, paths
+
+    return tree, answers
