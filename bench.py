@@ -74,7 +74,39 @@ def cpu_baseline(base, sample_blocks):
                       f"thread ({dt1:.1f} s): witness generation + synthesis of the 2^20-row trace, oracle/liboracle.so"}
 
 
-def full_block_gpu(local_rank, reps=3):
+def make_comm(ctx, rank, world):
+    """zkw_comm over RCCL for the C-ABI gather (include/zkw.h); the 128-byte id travels over torch.distributed, the way a
+    Rust host would use its own control channel. Returns None (every rank alike) when RCCL cannot be set up inside libzkw:
+    the gather then goes through torch.distributed (the same RCCL, torch's copy)."""
+    if world == 1:
+        return native.Comm(ctx, 0, 1)
+    import torch.distributed as dist
+
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = native.Comm.unique_id()
+        except native.ZkwError as e:
+            print(f"[bench] zkw_comm_unique_id failed ({e}); gathering through torch.distributed", file=sys.stderr)
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        return None
+    ok = torch.ones(1, dtype=torch.int32, device=f"cuda:{torch.cuda.current_device()}")
+    comm = None
+    try:
+        comm = native.Comm(ctx, rank, world, box[0])
+    except native.ZkwError as e:
+        print(f"[bench] rank {rank}: zkw_comm_init failed ({e})", file=sys.stderr)
+        ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if comm is not None:
+            comm.destroy()
+        return None
+    return comm
+
+
+def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     """BASELINE.json's second figure: wall time of ONE block — the instance multiset of the reference's basic_test with
     every builder at production capacity (synthetic.block_production) — through zkw_block_run (all witness builders as a
     dependency graph inside libzkw) + zkw_block_synthesize (every instance of the synthesizable types into a 2^20-row
@@ -93,19 +125,25 @@ def full_block_gpu(local_rank, reps=3):
         t0 = time.perf_counter()
         B = native.Block(local_rank, blk, storage_tree=answers, storage_initial_root=root0, storage_next_enumeration_index=next0)
         t1 = time.perf_counter()
-        n_synth = B.synthesize(1 << 20, ring_slots=2)
+        n_synth = B.synthesize(1 << 20, ring_slots=2, rank=rank, world=world)  # this rank's LPT share of the instances
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        rep = {"wall_ms": (t2 - t0) * 1e3, "builders_ms": (t1 - t0) * 1e3, "synthesis_ms": (t2 - t1) * 1e3,
-               "instances_synthesized": n_synth, "instances": {str(t): B.num_instances(t) for t in range(2, 14)},
+        if comm is not None:  # the one collective: closed-form records to rank 0
+            B.gather_closed_form_inputs(comm, rank, world, 0)
+        t3 = time.perf_counter()
+        wall = parallel.max_over_ranks(t3 - t0, torch.device("cuda", local_rank))
+        rep = {"wall_ms": wall * 1e3, "builders_ms": (t1 - t0) * 1e3, "synthesis_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3,
+               "instances_synthesized": n_synth, "n_gpus": world, "instances": {str(t): B.num_instances(t) for t in range(2, 14)},
                "spans_ms": {name: round(e - s_, 2) for name, s_, e in B.timings() if name != "builders"},
                "memory_queue_items": B.memory_queue_length}
         B.free()
         if best is None or rep["wall_ms"] < best["wall_ms"]:
             best = rep
-    best["note"] = ("one block, 1 GPU: builders = zkw_block_run (every builder of the post-VM half of create_artifacts_from_tracer, "
-                    "incl. the first ring allocation of synthesis), bounded by the block's longest serial Poseidon2 queue chain "
-                    "(memory queue: %d items x ~10.3 us); synthesis = 6 instances x 1.25 GB" % best["memory_queue_items"])
+    best["note"] = ("one block on %d GPU(s): builders = zkw_block_run (every builder of the post-VM half of "
+                    "create_artifacts_from_tracer; replicated on every rank: they are bounded by the block's longest serial "
+                    "Poseidon2 queue chain, memory queue = %d items x ~10.3 us, which more GPUs cannot shorten); synthesis = this "
+                    "rank's LPT share of the 6 synthesizable instances x 1.25 GB; gather = the closed-form records to rank 0"
+                    % (world, best["memory_queue_items"]))
     return best, blk
 
 
@@ -167,8 +205,12 @@ def main():
     B = args.blocks
     P = max(1, args.pipelines)
     full_block = blk_inputs = None
-    if not args.no_full_block and rank == 0:  # before the batch takes the HBM; its buffers are released again
-        full_block, blk_inputs = full_block_gpu(local_rank)
+    comm_ctx = native.Context(local_rank)
+    comm = make_comm(comm_ctx, rank, world)
+    gather_backend = "libzkw zkw_gather_closed_form_inputs (RCCL)" if comm is not None else "torch.distributed (RCCL)"
+    if not args.no_full_block:  # before the batch takes the HBM; its buffers are released again. N > 1: every rank runs the
+        # (deterministic, chain-bound) builders, synthesizes its LPT share of the block's instances, one gather to rank 0
+        full_block, blk_inputs = full_block_gpu(local_rank, rank=rank, world=world, comm=comm)
         torch.cuda.empty_cache()
     if B <= 0:
         free, _total = torch.cuda.mem_get_info(dev)
@@ -270,6 +312,17 @@ def main():
         for _ in range(passes):
             pipeline_pass(p)
 
+    recv_all = torch.empty((n_inst_local * world, inst_bytes), dtype=torch.uint8, device=dev) if rank == 0 else None
+
+    def gather_step():
+        """the closed-form records of this step to rank 0: through the C ABI (RCCL inside libzkw) when available"""
+        if comm is None:
+            return parallel.gather_records(records, counts, dst=0)
+        torch.cuda.synchronize()  # the records were written on the pipelines' streams; the gather runs on the comm context's
+        comm.gather(records.data_ptr(), counts, inst_bytes, 0, recv_all.data_ptr() if rank == 0 else 0)
+        comm_ctx.synchronize()
+        return recv_all
+
     def run_steps(passes, stagger_s):
         """`passes` steps; after each step the closed-form records go to rank 0. P == 1: pass, gather, pass, gather ...
         P > 1: every pipeline makes `passes` passes over its sub-batch back to back (= `passes` passes over all B
@@ -278,13 +331,13 @@ def main():
         if P == 1:
             for _ in range(passes):
                 pipeline_pass(0)
-                out = parallel.gather_records(records, counts, dst=0)
+                out = gather_step()
             return out
         futs = [pool.submit(pipeline_run, p, passes, p * stagger_s) for p in range(P)]
         for f in futs:
             f.result()
         for _ in range(passes):
-            out = parallel.gather_records(records, counts, dst=0)
+            out = gather_step()
         return out
 
     # Start offset between pipelines. A pipeline's pass = its queue chains (one wave per SIMD at most, latency-bound: T_chain
@@ -375,7 +428,7 @@ def main():
                        "trace_layout": "zkw trace v2 (own gate placement, same geometry as the reference wrapper; not interoperable "
                                        "with the reference's vk_8 / finalization_hint_8: DESIGN.md section 4)",
                        "blocks_per_gpu": B, "queries_per_block": n, "parallelism": f"instances sharded x{world}",
-                       "pipelines_per_gpu": P, "pipeline_stagger_ms": stagger_s * 1e3},
+                       "pipelines_per_gpu": P, "pipeline_stagger_ms": stagger_s * 1e3, "gather": gather_backend},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "avg_launch_ms": avg_ms,

@@ -6,7 +6,9 @@
 // grow-only per-context pool so that steady-state calls do no hipMalloc.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <mutex>
 
 #include <cstdarg>
 #include <cstdio>
@@ -3025,4 +3027,166 @@ extern "C" int zkw_storage_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace*
         return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_check_satisfied: bad argument");
     if (SS_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecStorageSorter>(ctx, t, slot, capacity, n_violations, first_bad);
+}
+
+// ------------------------------------------------------------------------------------------------ multi-GPU: the one collective (8e)
+// circuit instances are independent once the builders have fixed their hidden FSM inputs, so they are
+// sharded across the GPUs of a node with no data-path collective; the only exchange is the gather of the per-instance
+// closed-form records to rank 0, which replays the order-sensitive RecursionQueueSimulator pushes
+// (src/witness/postprocessing/mod.rs:396-402) and assembles the scheduler witness (src/external_calls.rs:354-537).
+// RCCL is resolved with dlopen when a communicator is created: libzkw itself does not link against it, a single-GPU
+// host never loads it, and a failure to find it is an error code, not a load failure.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+    bool load() {
+        if (handle) return true;
+        // a process that already holds an RCCL (torch's) keeps using that copy: one runtime per process
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (handle) break;
+        }
+        for (const char* n : names) {
+            if (handle) break;
+            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!handle) { error = std::string("librccl.so not found: ") + dlerror(); return false; }
+        auto sym = [&](const char* s) { void* p = dlsym(handle, s); if (!p) error = std::string("RCCL symbol missing: ") + s; return p; };
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !Send || !Recv || !GroupStart || !GroupEnd || !GetErrorString) {
+            handle = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+}  // namespace
+
+struct zkw_comm {
+    zkw_ctx* ctx = nullptr;
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+};
+
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t _r = (expr);                                                                        \
+        if (_r != ncclSuccess) return fail(ZKW_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+extern "C" int zkw_comm_unique_id(uint8_t id[ZKW_COMM_ID_BYTES]) {
+    if (!id) return fail(ZKW_ERR_INVALID, "zkw_comm_unique_id: null argument");
+    std::lock_guard<std::mutex> g(g_rccl_mu);
+    if (!g_rccl.load()) return fail(ZKW_ERR_NO_DEVICE, "%s", g_rccl.error.c_str());
+    static_assert(ZKW_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, ZKW_COMM_ID_BYTES);
+    return ZKW_OK;
+}
+
+extern "C" int zkw_comm_init(zkw_ctx* ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, zkw_comm** out) {
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return fail(ZKW_ERR_INVALID, "zkw_comm_init: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    zkw_comm* c = new zkw_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    if (world > 1) {  // a single rank needs no transport at all
+        std::lock_guard<std::mutex> g(g_rccl_mu);
+        if (!g_rccl.load()) { delete c; return fail(ZKW_ERR_NO_DEVICE, "%s", g_rccl.error.c_str()); }
+        ncclUniqueId u;
+        memcpy(u.internal, id, ZKW_COMM_ID_BYTES);
+        ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+        if (r != ncclSuccess) { delete c; return fail(ZKW_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+    }
+    ctx_retain(ctx);
+    *out = c;
+    return ZKW_OK;
+}
+
+extern "C" void zkw_comm_destroy(zkw_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    zkw_ctx* owner = c->ctx;
+    delete c;
+    ctx_release(owner);
+}
+
+// counts[r] records of record_bytes each from rank r, concatenated in rank order into recv on root. Device pointers.
+extern "C" int zkw_gather_closed_form_inputs(zkw_comm* c, const void* records, const uint64_t* counts, size_t record_bytes,
+                                             int root, void* recv) {
+    if (!c || !counts || record_bytes == 0 || root < 0 || root >= c->world) return fail(ZKW_ERR_INVALID, "zkw_gather_closed_form_inputs: bad argument");
+    zkw_ctx* ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t mine = (size_t)counts[c->rank] * record_bytes;
+    if (mine && !records) return fail(ZKW_ERR_INVALID, "zkw_gather_closed_form_inputs: no records given");
+    if (c->rank == root && !recv) return fail(ZKW_ERR_INVALID, "zkw_gather_closed_form_inputs: the root needs a receive buffer");
+    if (c->world == 1) {
+        if (mine) HIP_TRY(hipMemcpyAsync(recv, records, mine, hipMemcpyDeviceToDevice, ctx->stream));
+        return ZKW_OK;
+    }
+    NCCL_TRY(g_rccl.GroupStart());
+    if (c->rank == root) {
+        size_t off = 0;
+        for (int r = 0; r < c->world; r++) {
+            const size_t bytes = (size_t)counts[r] * record_bytes;
+            if (bytes) {
+                if (r == root) HIP_TRY(hipMemcpyAsync(static_cast<char*>(recv) + off, records, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                else NCCL_TRY(g_rccl.Recv(static_cast<char*>(recv) + off, bytes, ncclUint8, r, c->comm, ctx->stream));
+            }
+            off += bytes;
+        }
+    } else if (mine) {
+        NCCL_TRY(g_rccl.Send(records, mine, ncclUint8, root, c->comm, ctx->stream));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return ZKW_OK;
+}
+
+// Longest-processing-time assignment of an ordered instance list to ranks, weight = rows the reference's synthesis of
+// that circuit type uses (setup/base_layer/finalization_hint_N.json): the shard plan of SURVEY 8(e).
+// Deterministic (ties: lower instance index first, lowest rank first), so every rank computes the same plan. No GPU needed.
+extern "C" int zkw_shard_lpt(const uint8_t* circuit_types, size_t n, int world, uint32_t* owner) {
+    static const uint32_t ROWS_USED[14] = {0, 1033358, 1021855, 1045894, 770857, 957656, 1039794, 938955, 1044096, 1046318, 1027359, 590817, 590817, 1038150};
+    if ((n && (!circuit_types || !owner)) || world < 1) return fail(ZKW_ERR_INVALID, "zkw_shard_lpt: bad argument");
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) {
+        if (circuit_types[i] < 1 || circuit_types[i] > 13) return fail(ZKW_ERR_INVALID, "zkw_shard_lpt: circuit type %u", circuit_types[i]);
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return ROWS_USED[circuit_types[a]] > ROWS_USED[circuit_types[b]]; });
+    std::vector<uint64_t> load((size_t)world, 0);
+    for (size_t i : order) {
+        int best = 0;
+        for (int r = 1; r < world; r++)
+            if (load[r] < load[best]) best = r;
+        owner[i] = (uint32_t)best;
+        load[best] += ROWS_USED[circuit_types[i]];
+    }
+    return ZKW_OK;
 }

@@ -68,7 +68,7 @@ struct Span {
 };
 
 struct PerType {
-    std::vector<uint64_t> pi, enc, states;  // [n][4], [n][8], [n][12]
+    std::vector<uint64_t> pi, enc, states, compact;  // [n][4], [n][8], [n][12], [n][18]
 };
 
 // One transfer lane per host thread of the graph: a private non-blocking stream + a grow-only pinned staging buffer,
@@ -400,14 +400,14 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
     // 4. public inputs and one recursion queue per circuit type (postprocessing/mod.rs:353-405), all queues in one launch
     {
         Timed t(B, "recursion_queues");
-        struct Src { int type; const void* d_pi; size_t n; };
+        struct Src { int type; const void* d_pi; const void* d_cf; size_t n; };
         std::vector<Src> src;
-        src.push_back({T_DEC, zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_PUBLIC_INPUTS), zkw_decommit_witness_num_instances(B->dec)});
-        src.push_back({T_DMX, zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_PUBLIC_INPUTS), zkw_demux_witness_num_instances(B->dmx)});
-        src.push_back({T_RAM, zkw_ram_witness_device_ptr(B->ram, ZKW_RAM_PUBLIC_INPUTS), zkw_ram_witness_num_instances(B->ram)});
-        src.push_back({T_STO, zkw_storage_witness_device_ptr(B->sto, ZKW_STO_PUBLIC_INPUTS), zkw_storage_witness_num_instances(B->sto)});
-        src.push_back({T_EVT, zkw_events_witness_device_ptr(B->evt, ZKW_EVT_PUBLIC_INPUTS), zkw_events_witness_num_instances(B->evt)});
-        src.push_back({T_L1, zkw_events_witness_device_ptr(B->l1, ZKW_EVT_PUBLIC_INPUTS), zkw_events_witness_num_instances(B->l1)});
+        src.push_back({T_DEC, zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_PUBLIC_INPUTS), zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_COMPACT_FORMS), zkw_decommit_witness_num_instances(B->dec)});
+        src.push_back({T_DMX, zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_PUBLIC_INPUTS), zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_COMPACT_FORMS), zkw_demux_witness_num_instances(B->dmx)});
+        src.push_back({T_RAM, zkw_ram_witness_device_ptr(B->ram, ZKW_RAM_PUBLIC_INPUTS), zkw_ram_witness_device_ptr(B->ram, ZKW_RAM_COMPACT_FORMS), zkw_ram_witness_num_instances(B->ram)});
+        src.push_back({T_STO, zkw_storage_witness_device_ptr(B->sto, ZKW_STO_PUBLIC_INPUTS), zkw_storage_witness_device_ptr(B->sto, ZKW_STO_COMPACT_FORMS), zkw_storage_witness_num_instances(B->sto)});
+        src.push_back({T_EVT, zkw_events_witness_device_ptr(B->evt, ZKW_EVT_PUBLIC_INPUTS), zkw_events_witness_device_ptr(B->evt, ZKW_EVT_COMPACT_FORMS), zkw_events_witness_num_instances(B->evt)});
+        src.push_back({T_L1, zkw_events_witness_device_ptr(B->l1, ZKW_EVT_PUBLIC_INPUTS), zkw_events_witness_device_ptr(B->l1, ZKW_EVT_COMPACT_FORMS), zkw_events_witness_num_instances(B->l1)});
         size_t total = 0;
         for (auto& s : src) total += s.n;
         uint64_t *d_pi = nullptr, *d_enc = nullptr, *d_states = nullptr;
@@ -433,6 +433,8 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
             ST_TRY(B->xf[X_MAIN].d2h(p.pi.data(), d_pi + 4 * o, n * 32));
             ST_TRY(B->xf[X_MAIN].d2h(p.enc.data(), d_enc + 8 * o, n * 64));
             ST_TRY(B->xf[X_MAIN].d2h(p.states.data(), d_states + 12 * o, n * 96));
+            p.compact.resize(n * 18);
+            ST_TRY(B->xf[X_MAIN].d2h(p.compact.data(), src[k].d_cf, n * 18 * 8));
         }
     }
     return Status();
@@ -607,8 +609,38 @@ extern "C" int zkw_block_timings(const zkw_block* B, char* names, size_t names_b
 }
 
 // ---- synthesis of every instance, in the reference's emission order ----------------------------------------------
+namespace {
+const int kOrder[6] = {T_DMX, T_RAM, T_DEC, T_STO, T_EVT, T_L1};
+// the block's synthesizable instances in emission order and their LPT owners
+int shard_plan(const zkw_block* B, int world, std::vector<uint8_t>* types, std::vector<uint32_t>* index, std::vector<uint32_t>* owner) {
+    for (int t : kOrder)
+        for (size_t i = 0; i < zkw_block_num_instances(B, (uint8_t)t); i++) {
+            types->push_back((uint8_t)t);
+            index->push_back((uint32_t)i);
+        }
+    owner->assign(types->size(), 0);
+    return zkw_shard_lpt(types->data(), types->size(), world, owner->data());
+}
+}  // namespace
+
 extern "C" int zkw_block_synthesize(zkw_block* B, size_t n_rows, size_t ring_slots, zkw_circuit_fn cb, void* user, size_t* n_done) {
-    if (!B || n_rows == 0 || ring_slots == 0) return ZKW_ERR_INVALID;
+    return zkw_block_synthesize_sharded(B, n_rows, ring_slots, 0, 1, cb, user, n_done);
+}
+
+extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb,
+                                            void* user, size_t* n_done) {
+    if (!B || n_rows == 0 || ring_slots == 0 || world < 1 || rank < 0 || rank >= world) return ZKW_ERR_INVALID;
+    std::vector<uint8_t> plan_types;
+    std::vector<uint32_t> plan_index, plan_owner;
+    {
+        const int prc = shard_plan(B, world, &plan_types, &plan_index, &plan_owner);
+        if (prc != ZKW_OK) return prc;
+    }
+    auto owned = [&](int t, size_t inst) {
+        for (size_t k = 0; k < plan_types.size(); k++)
+            if (plan_types[k] == t && plan_index[k] == inst) return (int)plan_owner[k] == rank;
+        return false;
+    };
     if (hipSetDevice(B->device) != hipSuccess) return ZKW_ERR_HIP;
     if (B->ring149 && (B->ring_rows != n_rows || B->ring_slots != ring_slots)) {
         zkw_trace_free(B->ring149);
@@ -625,13 +657,15 @@ extern "C" int zkw_block_synthesize(zkw_block* B, size_t n_rows, size_t ring_slo
     const double a = B->ms_now();
     size_t done = 0;
     // emission order: log demuxer (oracle.rs:975-984), RAM permutation (:1039-1049), then CircuitMaker order (:1494-1732)
-    const int order[6] = {T_DMX, T_RAM, T_DEC, T_STO, T_EVT, T_L1};
-    for (int t : order) {
+    for (int t : kOrder) {
         const size_t ni = zkw_block_num_instances(B, (uint8_t)t);
         zkw_ctx* c = zkw_block_context(B, (uint8_t)t);
         zkw_trace* ring = t == T_DMX ? B->ring151 : B->ring149;
-        for (size_t first = 0; first < ni; first += ring_slots) {
-            const size_t cnt = ni - first < ring_slots ? ni - first : ring_slots;
+        for (size_t first = 0; first < ni;) {
+            // a maximal run of consecutive instances this rank owns (world == 1: all of them), at most one ring
+            if (!owned(t, first)) { first++; continue; }
+            size_t cnt = 1;
+            while (cnt < ring_slots && first + cnt < ni && owned(t, first + cnt)) cnt++;
             switch (t) {
                 case T_DMX: rc = zkw_log_demux_synthesize(c, B->dmx, first, cnt, ring, 0); break;
                 case T_RAM: rc = zkw_ram_synthesize(c, B->ram, first, cnt, ring, 0); break;
@@ -650,9 +684,58 @@ extern "C" int zkw_block_synthesize(zkw_block* B, size_t n_rows, size_t ring_slo
                 }
                 done++;
             }
+            first += cnt;
         }
     }
     B->span("synthesis", a);
     if (n_done) *n_done = done;
+    return ZKW_OK;
+}
+
+// ---- multi-GPU: every rank has run the builders (they are deterministic and bounded by one serial chain, so replicating
+// them costs nothing on the critical path), synthesizes the instances the LPT plan gives it, and the per-instance
+// closed-form records travel to the root in ONE gather: record = [circuit_type, instance, compact form (18), public
+// input (4)] = 24 words = 192 bytes. The root receives them in emission order, ready for the recursion-queue replay.
+extern "C" int zkw_block_gather_closed_form_inputs(zkw_block* B, zkw_comm* comm, int rank, int world, int root, uint64_t* out,
+                                                   size_t max_records, size_t* n_records) {
+    if (!B || !comm || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return ZKW_ERR_INVALID;
+    if (hipSetDevice(B->device) != hipSuccess) return ZKW_ERR_HIP;
+    std::vector<uint8_t> types;
+    std::vector<uint32_t> index, owner;
+    int rc = shard_plan(B, world, &types, &index, &owner);
+    if (rc != ZKW_OK) return rc;
+    const size_t n = types.size();
+    std::vector<uint64_t> counts((size_t)world, 0), mine;
+    for (size_t k = 0; k < n; k++) {
+        counts[owner[k]]++;
+        if ((int)owner[k] != rank) continue;
+        const PerType& p = B->per[types[k]];
+        mine.push_back(types[k]);
+        mine.push_back(index[k]);
+        mine.insert(mine.end(), p.compact.begin() + 18 * index[k], p.compact.begin() + 18 * (index[k] + 1));
+        mine.insert(mine.end(), p.pi.begin() + 4 * index[k], p.pi.begin() + 4 * (index[k] + 1));
+    }
+    uint64_t *d_send = nullptr, *d_recv = nullptr;
+    Status s = B->upload(X_MAIN, &d_send, mine.data(), mine.size());
+    if (s.ok() && rank == root) s = B->alloc(&d_recv, n * 24 + 1);
+    if (!s.ok()) return s.rc;
+    zkw_ctx* c = B->ctx[C_PRE];  // the communicator's context decides the stream; records are ready (host-synchronous upload)
+    (void)c;
+    if ((rc = zkw_gather_closed_form_inputs(comm, d_send, counts.data(), 24 * 8, root, d_recv)) != ZKW_OK) return rc;
+    if (n_records) *n_records = n;
+    if (rank != root) return ZKW_OK;
+    if (!out || max_records < n) return ZKW_ERR_INVALID;
+    // the gather is enqueued on the communicator's stream: the caller's zkw_comm context; synchronise the device-side copy
+    if (hipDeviceSynchronize() != hipSuccess) return ZKW_ERR_HIP;
+    std::vector<uint64_t> got(n * 24);
+    s = B->xf[X_MAIN].d2h(got.data(), d_recv, got.size() * 8);
+    if (!s.ok()) return s.rc;
+    // rank order -> emission order
+    std::vector<size_t> next((size_t)world, 0), base((size_t)world, 0);
+    for (int r = 1; r < world; r++) base[r] = base[r - 1] + counts[r - 1];
+    for (size_t k = 0; k < n; k++) {
+        const size_t from = base[owner[k]] + next[owner[k]]++;
+        memcpy(out + 24 * k, got.data() + 24 * from, 24 * 8);
+    }
     return ZKW_OK;
 }

@@ -129,6 +129,11 @@ SYMBOLS = [
     ("zkw_trace_get", _int, [_vp, _sz, _u32, _u32, _vp]),
     ("zkw_ram_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_ram_check_satisfied", _int, [_vp, _vp, _sz, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("zkw_shard_lpt", _int, [_vp, _sz, _int, _vp]),
+    ("zkw_comm_unique_id", _int, [_vp]),
+    ("zkw_comm_init", _int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
+    ("zkw_comm_destroy", None, [_vp]),
+    ("zkw_gather_closed_form_inputs", _int, [_vp, _vp, _vp, _sz, _int, _vp]),
     ("zkw_block_run", _int, [_int, _vp, C.POINTER(_vp)]),
     ("zkw_block_last_error", C.c_char_p, []),
     ("zkw_block_free", None, [_vp]),
@@ -145,6 +150,8 @@ SYMBOLS = [
     ("zkw_block_l1_messages_hash", _int, [_vp, _vp]),
     ("zkw_block_timings", _int, [_vp, C.c_char_p, _sz, _vp, _vp, _sz, C.POINTER(_sz)]),
     ("zkw_block_synthesize", _int, [_vp, _sz, _sz, _vp, _vp, C.POINTER(_sz)]),
+    ("zkw_block_synthesize_sharded", _int, [_vp, _sz, _sz, _int, _int, _vp, _vp, C.POINTER(_sz)]),
+    ("zkw_block_gather_closed_form_inputs", _int, [_vp, _vp, _int, _int, _int, _vp, _sz, C.POINTER(_sz)]),
 ]
 
 _lib = None
@@ -1215,9 +1222,10 @@ class Block:
         nm = names.value.decode().split(",") if n.value else []
         return [(nm[i], float(a[i]), float(b[i])) for i in range(n.value)]
 
-    def synthesize(self, n_rows, ring_slots=4, callback=None):
-        """ZkSyncBaseLayerCircuit::synthesis of every instance in emission order; callback(circuit_type, instance, trace_handle,
-        slot, public_input[4]) -> None (raise to stop). Returns the number of instances synthesized."""
+    def synthesize(self, n_rows, ring_slots=4, callback=None, rank=0, world=1):
+        """ZkSyncBaseLayerCircuit::synthesis of every instance (of this rank's LPT share when world > 1) in emission order;
+        callback(circuit_type, instance, trace_handle, slot, public_input[4]) -> None (raise to stop). Returns the number of
+        instances synthesized."""
         err = []
 
         def _cb(_user, ctype, inst, trace, slot, pi):
@@ -1230,11 +1238,21 @@ class Block:
                 return 1
         cb = CIRCUIT_FN(_cb)
         n = C.c_size_t(0)
-        rc = load().zkw_block_synthesize(self.handle, n_rows, ring_slots, C.cast(cb, C.c_void_p), None, C.byref(n))
+        rc = load().zkw_block_synthesize_sharded(self.handle, n_rows, ring_slots, rank, world, C.cast(cb, C.c_void_p), None, C.byref(n))
         if err:
             raise err[0]
         _check(rc)
         return n.value
+
+    def gather_closed_form_inputs(self, comm, rank=0, world=1, root=0):
+        """the multi-GPU path's one collective: records [n][24] = [circuit type, instance, compact form (18), public input (4)]
+        in emission order on the root, None elsewhere"""
+        total = sum(self.num_instances(t) for t in (4, 8, 2, 9, 11, 12))
+        out = np.zeros((total, 24), np.uint64)
+        n = C.c_size_t(0)
+        _check(load().zkw_block_gather_closed_form_inputs(self.handle, comm.handle, rank, world, root, _np_ptr(out), total, C.byref(n)))
+        assert n.value == total
+        return out if rank == root else None
 
     CHECKERS = {8: "zkw_ram_check_satisfied", 2: "zkw_decommit_sorter_check_satisfied", 4: "zkw_log_demux_check_satisfied",
                 9: "zkw_storage_sorter_check_satisfied", 11: "zkw_events_sorter_check_satisfied", 12: "zkw_events_sorter_check_satisfied"}
@@ -1255,5 +1273,46 @@ class Block:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+def shard_lpt(circuit_types, world):
+    """zkw_shard_lpt: owner rank of every instance of an ordered instance list (no GPU needed)"""
+    t = np.ascontiguousarray(circuit_types, dtype=np.uint8)
+    owner = np.zeros(t.size, np.uint32)
+    _check(load().zkw_shard_lpt(_np_ptr(t), t.size, world, _np_ptr(owner)))
+    return [int(x) for x in owner]
+
+
+class Comm:
+    """zkw_comm: the RCCL communicator behind zkw_gather_closed_form_inputs. `unique_id`: bytes from Comm.unique_id() on
+    rank 0, handed to the other ranks by the host (here: torch.distributed broadcast); world == 1 needs none."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = np.zeros(128, np.uint8)
+        _check(load().zkw_comm_unique_id(_np_ptr(buf)))
+        return buf.tobytes()
+
+    def __init__(self, ctx, rank=0, world=1, unique_id=None):
+        self.handle = C.c_void_p(None)
+        idbuf = np.frombuffer(unique_id, np.uint8).copy() if unique_id is not None else None
+        _check(load().zkw_comm_init(ctx.handle, _np_ptr(idbuf) if idbuf is not None else None, rank, world, C.byref(self.handle)))
+        self.ctx, self.rank, self.world = ctx, rank, world
+
+    def gather(self, records_dev_ptr, counts, record_bytes, root, recv_dev_ptr):
+        cnt = np.ascontiguousarray(counts, dtype=np.uint64)
+        _check(load().zkw_gather_closed_form_inputs(self.handle, C.c_void_p(records_dev_ptr), _np_ptr(cnt), record_bytes, root,
+                                                    C.c_void_p(recv_dev_ptr) if recv_dev_ptr else None))
+
+    def destroy(self):
+        if self.handle:
+            load().zkw_comm_destroy(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.destroy()
         except Exception:
             pass

@@ -521,6 +521,27 @@ int zkw_ram_synthesize(zkw_ctx *ctx, const zkw_ram_witness *w, size_t first_inst
 int zkw_ram_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                             uint64_t *n_violations, uint64_t *first_bad);
 
+/* ---- multi-GPU (8e): shard plan and the one collective ------------------------------------------------------- */
+/* One process per GPU. Instances are independent once the builders have fixed their hidden FSM inputs, so they are
+   sharded with no data-path collective; the only exchange is the gather of the per-instance closed-form records to the
+   root, which replays the order-sensitive recursion-queue pushes (src/witness/postprocessing/mod.rs:396-402,
+   src/external_calls.rs:354-537). The transport is RCCL (xGMI inside a node), loaded with dlopen when a communicator
+   of more than one rank is created. */
+/* owner[i] = rank of instance i: longest-processing-time over the rows the reference's synthesis of each circuit type
+   uses (setup/base_layer/finalization_hint_N.json). Deterministic; needs no GPU. circuit_types: 1..13. */
+int zkw_shard_lpt(const uint8_t *circuit_types, size_t n, int world, uint32_t *owner);
+typedef struct zkw_comm zkw_comm;
+#define ZKW_COMM_ID_BYTES 128
+/* rank 0 creates the id (ncclGetUniqueId) and hands it to the other ranks over the host's own channel */
+int zkw_comm_unique_id(uint8_t id[ZKW_COMM_ID_BYTES]);
+/* collective over all ranks (ncclCommInitRank); world == 1 needs no id and no RCCL. Work runs on ctx's stream. */
+int zkw_comm_init(zkw_ctx *ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, zkw_comm **out);
+void zkw_comm_destroy(zkw_comm *c);
+/* counts[r] (host, every rank passes the same array) records of record_bytes each from rank r, concatenated in rank
+   order into recv on `root` (NULL elsewhere). records / recv: DEVICE pointers. Enqueued on the stream; not synchronised. */
+int zkw_gather_closed_form_inputs(zkw_comm *c, const void *records, const uint64_t *counts, size_t record_bytes, int root,
+                                  void *recv);
+
 /* ---- one block: the post-VM half of create_artifacts_from_tracer (a19) ----------------------------------------- */
 /* Counterpart of src/witness/oracle.rs:928-1130 + 1494-1732 (everything `create_artifacts_from_tracer` does after the
    VM has run, except the MainVM instances): every per-circuit witness builder over what the VM left behind, the shared
@@ -601,6 +622,16 @@ int zkw_block_timings(const zkw_block *b, char *names, size_t names_bytes, doubl
 typedef int (*zkw_circuit_fn)(void *user, uint8_t circuit_type, size_t instance, const zkw_trace *trace, size_t slot,
                               const uint64_t public_input[4]);
 int zkw_block_synthesize(zkw_block *b, size_t n_rows, size_t ring_slots, zkw_circuit_fn cb, void *user, size_t *n_done);
+/* The same on one rank of a multi-GPU job: every rank has run zkw_block_run on the same inputs (the builders are
+   deterministic and bounded by one serial hash chain: replicating them keeps every GPU's witnesses local) and synthesizes
+   only the instances zkw_shard_lpt gives it (the plan covers the block's synthesizable instances in emission order). */
+int zkw_block_synthesize_sharded(zkw_block *b, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb,
+                                 void *user, size_t *n_done);
+/* The one collective of the multi-GPU path: per owned instance the record [circuit_type, instance, compact closed-form
+   input (18), public input (4)] (24 words) is gathered to `root` over `comm` (RCCL), which receives them in emission
+   order in out[n_records][24] (host) for the recursion-queue replay (postprocessing/mod.rs:396-402). Collective. */
+int zkw_block_gather_closed_form_inputs(zkw_block *b, zkw_comm *comm, int rank, int world, int root, uint64_t *out,
+                                        size_t max_records, size_t *n_records);
 
 #ifdef __cplusplus
 }

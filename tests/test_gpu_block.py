@@ -178,3 +178,39 @@ def test_block_sequencer_reports_builder_failures(ctx):
     with pytest.raises(nv.ZkwError) as ei:
         nv.Block(0, b, {2: 5, 3: 7, 4: 64, 8: 1000})
     assert ei.value.code == nv.ERR_INVALID and "bytecode" in str(ei.value)
+
+
+def test_block_sharded_synthesis_and_gather(ctx):
+    """the multi-GPU path on one GPU: the LPT plan splits the block's instances over `world` ranks (each rank's share
+    synthesized here in turn, disjoint and complete), and the C-ABI gather (world 1: no transport) returns the records
+    [type, instance, compact form, public input] in emission order."""
+    from era_zkevm_test_harness_amd import block as blk, native as nv
+
+    b = synthetic.block_after_vm(seed=5)
+    caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+    B = nv.Block(0, b, caps)
+    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.DECOMMITS_SORTER, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER]
+    full = [(t, i) for t in order for i in range(B.num_instances(t))]
+    owner = nv.shard_lpt([t for t, _ in full], 3)
+    got = []
+    for rank in range(3):
+        seen = []
+        n = B.synthesize(1 << 15, ring_slots=2, callback=lambda t, i, tr, s, pi: seen.append((t, i)), rank=rank, world=3)
+        assert n == len(seen) and seen == [x for x, o in zip(full, owner) if o == rank]
+        got += seen
+    assert sorted(got) == sorted(full) and len(set(got)) == len(full)
+    comm = nv.Comm(ctx, 0, 1)
+    rec = B.gather_closed_form_inputs(comm)
+    assert rec.shape == (len(full), 24)
+    assert [(int(r[0]), int(r[1])) for r in rec] == full
+    for r in rec:
+        t, i = int(r[0]), int(r[1])
+        assert np.array_equal(r[20:], B.public_inputs(t)[i])
+    what = {blk.RAM_PERMUTATION: nv.RAM_COMPACT_FORMS, blk.LOG_DEMUXER: nv.DMX_COMPACT_FORMS}
+    for t, w in what.items():
+        cf = B.witness_get(t, w).reshape(-1, 18)
+        for r in rec[rec[:, 0] == t]:
+            assert np.array_equal(r[2:20], cf[int(r[1])])
+    comm.destroy()
+    B.free()
