@@ -228,7 +228,7 @@ def main():
     ring_p = max(2, args.ring // P)
     B = max(P, B // P * P)
     Bp = B // P
-    ctxs, streams = [], []
+    ctxs, streams, chain_streams = [], [], []
     for _p in range(P):  # raises if libzkw / the GPU is missing: no fallback
         c = native.Context(local_rank)
         cu_split = os.environ.get("ZKW_CU_SPLIT")  # experiment: "x/y" hex words, e.g. 55555555/aaaaaaaa
@@ -247,6 +247,12 @@ def main():
         else:
             st = torch.cuda.Stream(device=dev)  # one stream per pipeline for torch ops and libzkw kernels
             c.set_stream(st.cuda_stream)
+            if os.environ.get("ZKW_CHAIN_PRIO", "0") != "0":
+                # the latency-bound queue chains on a HIGH-PRIORITY stream of their own: their waves issue first whenever
+                # they are ready, the other pipeline's fills take the slots (and the HBM) they leave
+                cst = torch.cuda.Stream(device=dev, priority=-1)
+                chain_streams.append(cst)
+                c.set_chain_stream(cst.cuda_stream)
         c.set_pointer_mode(native.PTR_DEVICE)
         if os.environ.get("ZKW_CHAIN_FORM"):
             c.set_chain_form(int(os.environ["ZKW_CHAIN_FORM"]))

@@ -102,6 +102,7 @@ struct ChainOut {
 };
 
 __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ jobs, int n_jobs) {
+    __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
     const int lane = threadIdx.x & 63, g = lane & 15;
     const int chain = blockIdx.x * 4 + (lane >> 4);
     p2::Coop co;
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ 
 // Quad form: 16 chains per wave (p2::Coop4). Lane j of a quad loads enc[j], enc[4+j] and stores tails[j],
 // tails[4+j], tails[8+j]: 32 contiguous bytes per quad per access.
 __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict__ jobs, int n_jobs) {
+    __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
     const int lane = threadIdx.x & 63, j = lane & 3;
     const int chain = blockIdx.x * 16 + (lane >> 2);
     p2::Coop4 co;
@@ -224,6 +226,95 @@ __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict
                 x[c] = y[c];
                 pend[c] = gl::canon(y[c]);
             }
+            pend_i = i;
+            have_pend = true;
+            pend_mark = job.marks && (i + 1 == next_mark || i + 1 == job.n);
+            if (pend_mark) next_mark += job.period;
+        }
+    }
+    flush();
+}
+
+// Lane form: ONE CHAIN PER LANE, 64 chains per wave (p2::permute, the whole state in the lane's registers). The
+// cooperative forms above buy latency with idle lanes (during the 22 partial rounds only one S-box per state is live:
+// 506 wave-instructions per permutation in the quad form); per lane a permutation costs ~210. With tens of thousands
+// of queues in one launch (bench.py: 2 x 14 440) latency per step is irrelevant and VALU issue slots are what the
+// chains take away from the trace fills they overlap: 29 k chains are 451 waves, fewer than half the SIMDs, instead of
+// 1 805 waves on every SIMD twice. Accesses are per-lane (48 B in, 32 B out per step, each lane on its own stream): a few
+// hundred bytes per wave every ~25 us.
+__global__ __launch_bounds__(64) void k_chain_full_lane(const ChainJob* __restrict__ jobs, int n_jobs) {
+    __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
+    const int chain = blockIdx.x * 64 + (threadIdx.x & 63);
+    ChainJob job;
+    memset(&job, 0, sizeof job);
+    if (chain < n_jobs) job = jobs[chain];
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = job.tail_in ? job.tail_in[k] : 0;
+    const bool from_q = job.enc == nullptr;
+    RawQuery rq_next;
+    rq_next.a = rq_next.b = rq_next.c = make_uint4(0, 0, 0, 0);
+    u64 e_next[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 at_next = 0;
+    if (job.n > 0) {
+        if (from_q) rq_next = load_raw_query(job.q + (job.perm ? job.perm[0] : 0));
+        else {
+            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(job.enc);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const ulonglong2 v = src[k]; e_next[2 * k] = v.x; e_next[2 * k + 1] = v.y; }
+        }
+    }
+    if (from_q && job.n > 1) at_next = job.perm ? job.perm[1] : 1;
+    u64 next_mark = job.marks ? job.period : ~0ull, mark_idx = 0;
+    u64 pend[12], pend_i = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) pend[k] = 0;
+    bool have_pend = false, pend_mark = false;
+    auto flush = [&]() {  // the stores of item i go out at the top of iteration i + 1 (see k_chain_full)
+        if (!have_pend) return;
+        if (job.tails) {
+            ulonglong2* d = reinterpret_cast<ulonglong2*>(job.tails + 12 * pend_i);
+#pragma unroll
+            for (int k = 0; k < 6; k++) d[k] = make_ulonglong2(pend[2 * k], pend[2 * k + 1]);
+        }
+        if (job.caps) {
+            ulonglong2* d = reinterpret_cast<ulonglong2*>(job.caps + 4 * pend_i);
+            d[0] = make_ulonglong2(pend[8], pend[9]);
+            d[1] = make_ulonglong2(pend[10], pend[11]);
+        }
+        if (pend_mark) {
+            ulonglong2* d = reinterpret_cast<ulonglong2*>(job.marks + 12 * mark_idx);
+#pragma unroll
+            for (int k = 0; k < 6; k++) d[k] = make_ulonglong2(pend[2 * k], pend[2 * k + 1]);
+            mark_idx++;
+        }
+        have_pend = false;
+    };
+    for (u64 i = 0; __any(i < job.n); i++) {
+        const bool live = i < job.n;
+        u64 e[8];
+        if (from_q) encode_raw_query(rq_next, e);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[k] = e_next[k];
+        }
+        flush();
+        if (i + 1 < job.n) {
+            if (from_q) {
+                rq_next = load_raw_query(job.q + at_next);
+                if (i + 2 < job.n) at_next = job.perm ? job.perm[i + 2] : i + 2;
+            } else {
+                const ulonglong2* src = reinterpret_cast<const ulonglong2*>(job.enc + 8 * (i + 1));
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const ulonglong2 v = src[k]; e_next[2 * k] = v.x; e_next[2 * k + 1] = v.y; }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = e[k];  // AbsorptionModeOverwrite
+            p2::permute(s);
+#pragma unroll
+            for (int k = 0; k < 12; k++) pend[k] = gl::canon(s[k]);
             pend_i = i;
             have_pend = true;
             pend_mark = job.marks && (i + 1 == next_mark || i + 1 == job.n);

@@ -35,6 +35,7 @@
 #include "events_sorter_circuit_kernels.cuh"
 #include "log_demux_circuit_kernels.cuh"
 #include "storage_sorter_circuit_kernels.cuh"
+#include "vm_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -398,8 +399,8 @@ extern "C" int zkw_set_pointer_mode(zkw_ctx* ctx, int mode) {
 }
 
 extern "C" int zkw_set_chain_form(zkw_ctx* ctx, int lanes_per_state) {
-    if (!ctx || (lanes_per_state != 0 && lanes_per_state != 4 && lanes_per_state != 16))
-        return fail(ZKW_ERR_INVALID, "chain form must be 0 (auto), 4 or 16");
+    if (!ctx || (lanes_per_state != 0 && lanes_per_state != 1 && lanes_per_state != 4 && lanes_per_state != 16))
+        return fail(ZKW_ERR_INVALID, "chain form must be 0 (auto), 1, 4 or 16");
     ctx->chain_form = lanes_per_state;
     return ZKW_OK;
 }
@@ -462,9 +463,11 @@ static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     ChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("chain_jobs", jobs, &d_jobs));
     int n_jobs = (int)jobs.size();
-    // auto: the row form has the lower latency (11.2 vs 16.3 us per step) and wins while every wave can have
-    // a SIMD to itself (<= 4096 chains); beyond that the quad form's 16 chains per wave win on throughput
-    const int form = ctx->chain_form ? ctx->chain_form : (n_jobs >= 4096 ? 4 : 16);
+    // auto: the row form has the lowest latency (10.4 us per step) and wins while every wave can have a SIMD to itself
+    // (<= 4096 chains); the quad form packs 16 chains per wave (14.3 us); from 16 384 chains on nothing but throughput
+    // counts and the lane form (64 chains per wave, ~2.4x fewer VALU instructions per permutation) leaves more than half of
+    // the SIMDs to whatever runs next to the chains
+    const int form = ctx->chain_form ? ctx->chain_form : (n_jobs >= 16384 ? 1 : n_jobs >= 4096 ? 4 : 16);
     // the chain kernel may run on its own stream (e.g. one created with a CU mask): ordered after everything queued on
     // the context's stream so far, and the context's stream continues after it
     hipStream_t st = ctx->stream;
@@ -473,11 +476,12 @@ static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
         HIP_TRY(hipStreamWaitEvent(ctx->chain_stream, ctx->chain_ev_a, 0));
         st = ctx->chain_stream;
     }
-    const char* name = form == 16 ? "k_chain_full" : "k_chain_full_q4";
+    const char* name = form == 16 ? "k_chain_full" : form == 4 ? "k_chain_full_q4" : "k_chain_full_lane";
     {
         Prof _p(ctx, name);
         if (form == 16) hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
-        else hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
+        else if (form == 4) hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
+        else hipLaunchKernelGGL(k_chain_full_lane, dim3((n_jobs + 63) / 64), dim3(64), 0, st, d_jobs, n_jobs);
         if (ctx->chain_stream) {  // the profiling events live on the context's stream: bring the kernel's end onto it first
             HIP_TRY(hipEventRecord(ctx->chain_ev_b, ctx->chain_stream));
             HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->chain_ev_b, 0));
@@ -3027,6 +3031,69 @@ extern "C" int zkw_storage_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace*
         return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_check_satisfied: bad argument");
     if (SS_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecStorageSorter>(ctx, t, slot, capacity, n_violations, first_bad);
+}
+
+// ------------------------------------------------------------------------------------------------ MainVM instance slicing (a19)
+extern "C" int zkw_vm_slice_instances(zkw_ctx* ctx, const zkw_vm_tracer_streams* in, zkw_vm_instance* instances,
+                                      uint32_t* memory_read_index, uint32_t* memory_write_index, uint64_t* n_reads, uint64_t* n_writes) {
+    if (!ctx || !in || !instances || !in->snapshot_cycles || in->n_snapshots < 2 || ((memory_read_index == nullptr) != (memory_write_index == nullptr)))
+        return fail(ZKW_ERR_INVALID, "zkw_vm_slice_instances: bad argument");
+    for (int k = 0; k < ZKW_VM_NUM_STREAMS; k++)
+        if (in->stream_len[k] && !in->stream_cycles[k]) return fail(ZKW_ERR_INVALID, "zkw_vm_slice_instances: stream %d has no cycle stamps", k);
+    const size_t n_mem = in->stream_len[ZKW_VMS_MEMORY];
+    if (n_mem >= (1ull << 32)) return fail(ZKW_ERR_INVALID, "too many memory queries");
+    if ((n_mem && (!in->vm_memory_queries || !in->memory_queue_tails)) || (in->n_decommit_states && (!in->decommit_state_cycles || !in->decommit_queue_tails)) ||
+        (in->n_callstack_sponges && (!in->callstack_sponge_cycles || !in->callstack_sponge_states)) ||
+        (in->n_storage_log_states && (!in->storage_log_state_cycles || !in->storage_log_states)))
+        return fail(ZKW_ERR_INVALID, "zkw_vm_slice_instances: a stream's payload is missing");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n_inst = in->n_snapshots - 1;
+    VmSliceJob job;
+    job.s = *in;
+    ZKW_TRY(ctx->in("vm_snap", in->snapshot_cycles, in->n_snapshots, &job.s.snapshot_cycles));
+    static const char* names[ZKW_VM_NUM_STREAMS] = {"vm_c0", "vm_c1", "vm_c2", "vm_c3", "vm_c4", "vm_c5", "vm_c6", "vm_c7"};
+    for (int k = 0; k < ZKW_VM_NUM_STREAMS; k++) ZKW_TRY(ctx->in(names[k], in->stream_cycles[k], in->stream_len[k], &job.s.stream_cycles[k]));
+    ZKW_TRY(ctx->in("vm_memq", in->vm_memory_queries, n_mem, &job.s.vm_memory_queries));
+    ZKW_TRY(ctx->in("vm_memt", in->memory_queue_tails, n_mem * 12, &job.s.memory_queue_tails));
+    ZKW_TRY(ctx->in("vm_decc", in->decommit_state_cycles, in->n_decommit_states, &job.s.decommit_state_cycles));
+    ZKW_TRY(ctx->in("vm_dect", in->decommit_queue_tails, in->n_decommit_states * 12, &job.s.decommit_queue_tails));
+    ZKW_TRY(ctx->in("vm_csc", in->callstack_sponge_cycles, in->n_callstack_sponges, &job.s.callstack_sponge_cycles));
+    ZKW_TRY(ctx->in("vm_css", in->callstack_sponge_states, in->n_callstack_sponges * 12, &job.s.callstack_sponge_states));
+    ZKW_TRY(ctx->in("vm_slc", in->storage_log_state_cycles, in->n_storage_log_states, &job.s.storage_log_state_cycles));
+    ZKW_TRY(ctx->in("vm_sls", in->storage_log_states, in->n_storage_log_states, &job.s.storage_log_states));
+    // the read / write split of the memory stream: one stable partition for all instances
+    u32 *d_tiles = nullptr, *d_prefix = nullptr, *d_ri = nullptr, *d_wi = nullptr;
+    u64* d_total = nullptr;
+    const u32 n_tiles = (u32)((n_mem + VM_TILE) / VM_TILE);  // covers index n_mem itself (the total)
+    ZKW_TRY(ctx->scratch_t<u32>("vm_tiles", n_tiles, &d_tiles));
+    ZKW_TRY(ctx->scratch_t<u32>("vm_prefix", n_mem + 1, &d_prefix));
+    ZKW_TRY(ctx->scratch_t<u64>("vm_total", 1, &d_total));
+    if (memory_read_index) {
+        ZKW_TRY(ctx->out("vm_ri", memory_read_index, n_mem, &d_ri));
+        ZKW_TRY(ctx->out("vm_wi", memory_write_index, n_mem, &d_wi));
+    }
+    { Prof _p(ctx, "k_vm_rw_tile_counts"); hipLaunchKernelGGL(k_vm_rw_tile_counts, dim3(n_tiles), dim3(256), 0, ctx->stream, job.s.vm_memory_queries, (u64)n_mem, d_tiles); }
+    ZKW_TRY(launch_check("k_vm_rw_tile_counts"));
+    { Prof _p(ctx, "k_vm_rw_scan_tiles"); hipLaunchKernelGGL(k_vm_rw_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, d_tiles, n_tiles, d_total); }
+    ZKW_TRY(launch_check("k_vm_rw_scan_tiles"));
+    { Prof _p(ctx, "k_vm_rw_scatter"); hipLaunchKernelGGL(k_vm_rw_scatter, dim3(n_tiles), dim3(256), 0, ctx->stream, job.s.vm_memory_queries, (u64)n_mem, d_tiles, d_prefix, d_ri, d_wi); }
+    ZKW_TRY(launch_check("k_vm_rw_scatter"));
+    job.read_prefix = d_prefix;
+    ZKW_TRY(ctx->out("vm_inst", instances, n_inst, &job.out));
+    { Prof _p(ctx, "k_vm_slice"); hipLaunchKernelGGL(k_vm_slice, dim3(blocks_for(n_inst, 64)), dim3(64), 0, ctx->stream, job); }
+    ZKW_TRY(launch_check("k_vm_slice"));
+    ZKW_TRY(ctx->finish_out(instances, job.out, n_inst));
+    if (memory_read_index) {
+        ZKW_TRY(ctx->finish_out(memory_read_index, d_ri, n_mem));
+        ZKW_TRY(ctx->finish_out(memory_write_index, d_wi, n_mem));
+    }
+    if (n_reads || n_writes) {
+        u64 total = 0;
+        ZKW_TRY(ctx->read_small(&total, d_total, 8));
+        if (n_reads) *n_reads = total;
+        if (n_writes) *n_writes = n_mem - total;
+    }
+    return ctx->sync_if_host();
 }
 
 // ------------------------------------------------------------------------------------------------ multi-GPU: the one collective (8e)

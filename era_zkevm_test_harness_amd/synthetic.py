@@ -498,3 +498,36 @@ def storage_tree_for(dedup_queries, seed=0, extra_leaves=10):
         return idx, paths
 
     return tree, answers
+
+
+def vm_tracer_streams(n_cycles=3000, cycles_per_snapshot=400, seed=0, n_memory=2500, sparse=200, first_snapshot_cycle=0):
+    """Cycle-stamped streams of the kind WitnessTracer leaves for the MainVM slicing (src/witness/tracer.rs:221-407 records,
+    oracle.rs:1229-1469 consumes): the memory stream (several queries per cycle, reads and writes), seven sparser FIFOs,
+    the entry-state histories (decommit queue states, callstack sponge states, storage-log states with strictly ascending
+    cycles) and the snapshot cycles. Hash-like payloads are random field elements: the slicing only moves them."""
+    rng = np.random.default_rng(seed)
+    p = 0xFFFFFFFF00000001
+
+    def cycles(n, strict=False):
+        c = np.sort(rng.integers(0, n_cycles, n)).astype(np.uint32)
+        return np.unique(c) if strict else c
+
+    def felts(shape):
+        return (rng.integers(0, 2**63, shape, dtype=np.uint64) * 2 + rng.integers(0, 2, shape, dtype=np.uint64)) % np.uint64(p)
+
+    mem_cycles = cycles(n_memory)
+    mem = ram_trace(max(n_memory, 1), seed=seed + 1)[:n_memory]
+    streams = [mem_cycles] + [cycles(int(rng.integers(0, sparse))) for _ in range(7)]
+    dec_c, cs_c, sl_c = cycles(int(rng.integers(0, sparse))), cycles(int(rng.integers(0, sparse))), cycles(int(rng.integers(1, sparse)), strict=True)
+    from .native import STORAGE_LOG_DETAILED_STATE
+
+    sl = np.zeros(sl_c.size, STORAGE_LOG_DETAILED_STATE)
+    for f in ("forward_tail", "rollback_head", "rollback_tail"):
+        sl[f] = felts((sl_c.size, 4))
+    sl["forward_length"] = rng.integers(0, 1000, sl_c.size)
+    sl["rollback_length"] = rng.integers(0, 1000, sl_c.size)
+    snaps = np.arange(first_snapshot_cycle, n_cycles + cycles_per_snapshot, cycles_per_snapshot, dtype=np.uint32)
+    return {"snapshot_cycles": snaps, "stream_cycles": streams, "vm_memory_queries": mem, "memory_queue_tails": felts((n_memory, 12)),
+            "decommit_state_cycles": dec_c, "decommit_queue_tails": felts((dec_c.size, 12)), "callstack_sponge_cycles": cs_c,
+            "callstack_sponge_states": felts((cs_c.size, 12)), "storage_log_state_cycles": sl_c, "storage_log_states": sl,
+            "global_end_of_storage_log": felts(4)}

@@ -59,8 +59,9 @@ int zkw_set_chain_stream(zkw_ctx *ctx, void *hip_stream);
 int zkw_set_pointer_mode(zkw_ctx *ctx, int mode);
 int zkw_synchronize(zkw_ctx *ctx);
 /* tuning knob: lanes that cooperate on one Poseidon2 state in the queue-chain kernel: 16 (4 chains per wave,
-   row DPP, lowest latency), 4 (16 chains per wave, quad DPP, highest throughput) or 0 = choose by the
-   number of chains in the launch (default). Results are identical. */
+   row DPP, lowest latency), 4 (16 chains per wave, quad DPP), 1 (64 chains per wave, the whole state in one lane:
+   fewest instructions per permutation, for launches of tens of thousands of queues) or 0 = choose by the number of
+   chains in the launch (default). Results are identical. */
 int zkw_set_chain_form(zkw_ctx *ctx, int lanes_per_state);
 /* library/ABI version and the kernels' target ISA ("gfx950") */
 const char *zkw_version(void);
@@ -520,6 +521,20 @@ int zkw_ram_synthesize(zkw_ctx *ctx, const zkw_ram_witness *w, size_t first_inst
    6 padding). Synchronises the stream. */
 int zkw_ram_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                             uint64_t *n_violations, uint64_t *first_bad);
+
+/* ---- MainVM instance slicing (a19) ------------------------------------------------------------------------------ */
+/* The loop of src/witness/oracle.rs:1229-1469 (`vm_snapshots.windows(2)`): every window [at_cycle_k, at_cycle_{k+1}) of
+   the VM's snapshots becomes one MainVM instance whose VmWitnessOracle FIFOs are the elements of eight cycle-stamped
+   streams that fall into the window, whose entry states are "the last state with cycle < from" of the memory queue,
+   the decommit queue, the callstack sponge and the storage-log history (:1245-1273, :1359-1375), and whose
+   auxilary_final_parameters are the next instance's initial ones (the global final states on the last one, :1414-1468);
+   plus the flags and observable input / output of vm_instance_witness_to_circuit_formal_input (src/witness/utils.rs:
+   428-496). One lane per (instance, stream) does the binary searches the reference does with take_while / partition_point.
+   instances: [n_snapshots - 1]; memory_read_index / memory_write_index: [stream_len[ZKW_VMS_MEMORY]] capacity each (the
+   memory stream's reads / writes in order; n_reads / n_writes receive the totals; may be NULL together). The VM and its
+   tracer themselves (which produce the streams) are out of scope. */
+int zkw_vm_slice_instances(zkw_ctx *ctx, const zkw_vm_tracer_streams *streams, zkw_vm_instance *instances,
+                           uint32_t *memory_read_index, uint32_t *memory_write_index, uint64_t *n_reads, uint64_t *n_writes);
 
 /* ---- multi-GPU (8e): shard plan and the one collective ------------------------------------------------------- */
 /* One process per GPU. Instances are independent once the builders have fixed their hidden FSM inputs, so they are

@@ -409,6 +409,93 @@ typedef struct zkw_storage_application_instance {
     uint64_t num_items;
 } zkw_storage_application_instance;
 
+/* ---- MainVM instance slicing (a19): src/witness/oracle.rs:1229-1469, src/witness/utils.rs:428-496 -------------------- */
+/* The eight cycle-stamped FIFOs the reference cuts into per-instance `VmWitnessOracle`s
+   (circuit_definitions/src/aux_definitions/witness_oracle.rs:25-36): element k of stream s happened at VM cycle
+   stream_cycles[s][k] (ascending). An instance covering cycles [from, to) owns the elements with from <= cycle < to. */
+enum {
+    ZKW_VMS_MEMORY = 0,                        /* memory_read_witness + memory_write_witness (split by rw_flag) */
+    ZKW_VMS_STORAGE_QUERIES = 1,               /* storage_queries */
+    ZKW_VMS_REFUNDS = 2,                       /* storage_refund_queries */
+    ZKW_VMS_DECOMMIT_REQUESTS = 3,             /* decommittment_requests_witness */
+    ZKW_VMS_ROLLBACK_TAILS_FOR_NEW_FRAMES = 4, /* rollback_queue_initial_tails_for_new_frames */
+    ZKW_VMS_CALLSTACK_VALUES = 5,              /* callstack_values_witnesses */
+    ZKW_VMS_ROLLBACK_HEAD_SEGMENTS = 6,        /* rollback_queue_head_segments */
+    ZKW_VMS_NEW_FRAMES = 7,                    /* callstack_new_frames_witnesses (flat_new_frames_history) */
+    ZKW_VM_NUM_STREAMS = 8
+};
+
+/* StorageLogDetailedState, src/witness/oracle.rs:87-94 (frame_idx is not consumed by the slicing) */
+typedef struct zkw_storage_log_detailed_state {
+    uint64_t forward_tail[4];
+    uint64_t rollback_head[4];
+    uint64_t rollback_tail[4];
+    uint32_t forward_length;
+    uint32_t rollback_length;
+} zkw_storage_log_detailed_state;
+
+/* VmInCircuitAuxilaryParameters, src/witness/oracle.rs:98-108 (the CallStackEntry of callstack_state travels with the
+   VmLocalState snapshot the instance points at) */
+typedef struct zkw_vm_aux_parameters {
+    uint64_t callstack_state[12];
+    zkw_queue_state12 decommittment_queue_state;
+    zkw_queue_state12 memory_queue_state;
+    zkw_queue_state4 storage_log_queue_state;
+    uint64_t current_frame_rollback_queue_tail[4];
+    uint64_t current_frame_rollback_queue_head[4];
+    uint32_t current_frame_rollback_queue_segment_length;
+    uint32_t _pad;
+} zkw_vm_aux_parameters;
+
+/* VmInstanceWitness + the closed-form flags / observable parts vm_instance_witness_to_circuit_formal_input derives
+   (src/witness/utils.rs:428-496). The VmWitnessOracle FIFOs are [lo, hi) ranges of the block-wide streams. */
+typedef struct zkw_vm_instance {
+    uint32_t start_flag;      /* is_first */
+    uint32_t completion_flag; /* is_last */
+    uint32_t cycle_from;      /* cycles_range */
+    uint32_t cycle_to;
+    uint32_t snapshot_initial; /* initial_state = vm_snapshots[snapshot_initial].local_state */
+    uint32_t snapshot_final;   /* final_state   = vm_snapshots[snapshot_final].local_state */
+    uint64_t range[ZKW_VM_NUM_STREAMS][2];
+    /* the memory stream's elements of the instance split by rw_flag, order kept: entries [first, first + num) of the
+       block-wide index arrays zkw_vm_slice_instances returns (indices into the memory stream) */
+    uint64_t first_memory_read, num_memory_reads;
+    uint64_t first_memory_write, num_memory_writes;
+    zkw_vm_aux_parameters auxilary_initial_parameters;
+    zkw_vm_aux_parameters auxilary_final_parameters; /* = the next instance's initial ones; global final states on the last */
+    /* observable_input (first instance; zero elsewhere): VmInputData without per_block_context */
+    uint64_t rollback_queue_tail_for_block[4];
+    uint64_t memory_queue_initial_tail[12];
+    uint32_t memory_queue_initial_length;
+    uint32_t decommitment_queue_initial_length;
+    uint64_t decommitment_queue_initial_tail[12];
+    /* observable_output (last instance; zero elsewhere): VmOutputData */
+    zkw_queue_state12 memory_queue_final_state;
+    zkw_queue_state12 decommitment_queue_final_state;
+    zkw_queue_state4 log_queue_final_state;
+} zkw_vm_instance;
+
+/* What the tracer leaves for the slicing (all arrays HOST or DEVICE per the context's pointer mode). */
+typedef struct zkw_vm_tracer_streams {
+    const uint32_t *snapshot_cycles;  /* vm_snapshots[k].at_cycle, ascending, n_snapshots >= 2 */
+    size_t n_snapshots;
+    const uint32_t *stream_cycles[ZKW_VM_NUM_STREAMS];
+    size_t stream_len[ZKW_VM_NUM_STREAMS];
+    const zkw_mem_query *vm_memory_queries; /* [stream_len[ZKW_VMS_MEMORY]]: the rw_flag splits reads from writes */
+    const uint64_t *memory_queue_tails;     /* [stream_len[ZKW_VMS_MEMORY]][12]: all_memory_queue_states (tail after item k;
+                                               its head is the tail after item k-1, num_items = k+1) */
+    const uint32_t *decommit_state_cycles;  /* all_decommittment_queue_states: (cycle, state after push k) */
+    const uint64_t *decommit_queue_tails;   /* [n_decommit_states][12] */
+    size_t n_decommit_states;
+    const uint32_t *callstack_sponge_cycles; /* callstack_sponge_encoding_ranges: (cycle, sponge state) */
+    const uint64_t *callstack_sponge_states; /* [n_callstack_sponges][12] */
+    size_t n_callstack_sponges;
+    const uint32_t *storage_log_state_cycles; /* history_of_storage_log_states (BTreeMap: strictly ascending cycles) */
+    const zkw_storage_log_detailed_state *storage_log_states;
+    size_t n_storage_log_states;
+    uint64_t global_end_of_storage_log[4];
+} zkw_vm_tracer_streams;
+
 #ifdef __cplusplus
 }
 #endif

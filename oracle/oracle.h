@@ -268,4 +268,8 @@ void orc_linear_keccak256(const zkw_log_query *q, size_t n, uint8_t hash_out[32]
 #ifdef __cplusplus
 }
 #endif
+/* MainVM instance slicing (src/witness/oracle.rs:1229-1469, src/witness/utils.rs:428-496); host pointers */
+int orc_vm_slice_instances(const zkw_vm_tracer_streams *s, zkw_vm_instance *out, uint32_t *read_index, uint32_t *write_index,
+                           uint64_t *n_reads, uint64_t *n_writes);
+
 #endif

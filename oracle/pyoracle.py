@@ -801,3 +801,73 @@ def events_sorter_public_inputs(instances):
 
 def storage_sorter_public_inputs(instances):
     return _public_inputs("orc_storage_sorter_public_inputs", instances)
+
+# ---- MainVM instance slicing (include/zkw_types.h: zkw_vm_instance & co) ------------------------------------------------
+VM_NUM_STREAMS = 8
+(VMS_MEMORY, VMS_STORAGE_QUERIES, VMS_REFUNDS, VMS_DECOMMIT_REQUESTS, VMS_ROLLBACK_TAILS_FOR_NEW_FRAMES, VMS_CALLSTACK_VALUES,
+ VMS_ROLLBACK_HEAD_SEGMENTS, VMS_NEW_FRAMES) = range(8)
+STORAGE_LOG_DETAILED_STATE = np.dtype([("forward_tail", "<u8", (4,)), ("rollback_head", "<u8", (4,)), ("rollback_tail", "<u8", (4,)),
+                                       ("forward_length", "<u4"), ("rollback_length", "<u4")])
+VM_AUX_PARAMETERS = np.dtype(
+    [("callstack_state", "<u8", (12,)), ("decommittment_queue_state", QUEUE_STATE12), ("memory_queue_state", QUEUE_STATE12),
+     ("storage_log_queue_state", QUEUE_STATE4), ("current_frame_rollback_queue_tail", "<u8", (4,)),
+     ("current_frame_rollback_queue_head", "<u8", (4,)), ("current_frame_rollback_queue_segment_length", "<u4"), ("_pad", "<u4")])
+VM_INSTANCE = np.dtype(
+    [("start_flag", "<u4"), ("completion_flag", "<u4"), ("cycle_from", "<u4"), ("cycle_to", "<u4"), ("snapshot_initial", "<u4"),
+     ("snapshot_final", "<u4"), ("range", "<u8", (8, 2)), ("first_memory_read", "<u8"), ("num_memory_reads", "<u8"),
+     ("first_memory_write", "<u8"), ("num_memory_writes", "<u8"), ("auxilary_initial_parameters", VM_AUX_PARAMETERS),
+     ("auxilary_final_parameters", VM_AUX_PARAMETERS), ("rollback_queue_tail_for_block", "<u8", (4,)),
+     ("memory_queue_initial_tail", "<u8", (12,)), ("memory_queue_initial_length", "<u4"), ("decommitment_queue_initial_length", "<u4"),
+     ("decommitment_queue_initial_tail", "<u8", (12,)), ("memory_queue_final_state", QUEUE_STATE12),
+     ("decommitment_queue_final_state", QUEUE_STATE12), ("log_queue_final_state", QUEUE_STATE4)])
+
+
+class VmTracerStreams(C.Structure):
+    """zkw_vm_tracer_streams"""
+    _fields_ = [("snapshot_cycles", C.c_void_p), ("n_snapshots", C.c_size_t), ("stream_cycles", C.c_void_p * 8), ("stream_len", C.c_size_t * 8),
+                ("vm_memory_queries", C.c_void_p), ("memory_queue_tails", C.c_void_p), ("decommit_state_cycles", C.c_void_p),
+                ("decommit_queue_tails", C.c_void_p), ("n_decommit_states", C.c_size_t), ("callstack_sponge_cycles", C.c_void_p),
+                ("callstack_sponge_states", C.c_void_p), ("n_callstack_sponges", C.c_size_t), ("storage_log_state_cycles", C.c_void_p),
+                ("storage_log_states", C.c_void_p), ("n_storage_log_states", C.c_size_t), ("global_end_of_storage_log", C.c_uint64 * 4)]
+
+
+def _vm_streams_struct(t, keep):
+    """t: dict with snapshot_cycles, stream_cycles (list of 8 arrays), vm_memory_queries, memory_queue_tails, decommit_state_cycles,
+    decommit_queue_tails, callstack_sponge_cycles, callstack_sponge_states, storage_log_state_cycles, storage_log_states,
+    global_end_of_storage_log"""
+    def arr(a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        keep.append(a)
+        return a
+    s = VmTracerStreams()
+    sc = arr(t["snapshot_cycles"], np.uint32)
+    s.snapshot_cycles, s.n_snapshots = sc.ctypes.data, sc.size
+    for k in range(8):
+        c = arr(t["stream_cycles"][k], np.uint32)
+        s.stream_cycles[k] = c.ctypes.data if c.size else None
+        s.stream_len[k] = c.size
+    for name, dtype, cnt in (("vm_memory_queries", MEM_QUERY, None), ("memory_queue_tails", np.uint64, None),
+                             ("decommit_state_cycles", np.uint32, "n_decommit_states"), ("decommit_queue_tails", np.uint64, None),
+                             ("callstack_sponge_cycles", np.uint32, "n_callstack_sponges"), ("callstack_sponge_states", np.uint64, None),
+                             ("storage_log_state_cycles", np.uint32, "n_storage_log_states"), ("storage_log_states", STORAGE_LOG_DETAILED_STATE, None)):
+        a = arr(t[name], dtype)
+        setattr(s, name, a.ctypes.data if a.size else None)
+        if cnt:
+            setattr(s, cnt, a.size)
+    for j in range(4):
+        s.global_end_of_storage_log[j] = int(t["global_end_of_storage_log"][j])
+    return s
+
+
+def vm_slice_instances(tracer):
+    """orc_vm_slice_instances: (instances, memory read indices, memory write indices)"""
+    keep = []
+    st = _vm_streams_struct(tracer, keep)
+    n_inst, n_mem = st.n_snapshots - 1, st.stream_len[0]
+    inst = np.zeros(n_inst, VM_INSTANCE)
+    ri, wi = np.zeros(max(n_mem, 1), np.uint32), np.zeros(max(n_mem, 1), np.uint32)
+    nr, nw = C.c_uint64(0), C.c_uint64(0)
+    rc = lib().orc_vm_slice_instances(C.byref(st), _p(inst), _p(ri), _p(wi), C.byref(nr), C.byref(nw))
+    if rc != 0:
+        raise RuntimeError(f"orc_vm_slice_instances failed: {rc}")
+    return inst, ri[:nr.value], wi[:nw.value]

@@ -63,6 +63,9 @@ def test_record_layouts_match_header():
       printf("%zu %zu %zu %zu\n", sizeof(zkw_storage_application_fsm), sizeof(zkw_storage_application_instance), offsetof(zkw_storage_application_instance, hidden_fsm_input), offsetof(zkw_storage_application_instance, first_item));
       printf("%zu %zu %zu %zu\n", offsetof(zkw_mem_query, value), offsetof(zkw_ram_fsm, previous_sorting_key),
              offsetof(zkw_ram_instance, hidden_fsm_input), offsetof(zkw_ram_instance, first_item));
+      printf("%zu %zu %zu %zu\n", sizeof(zkw_vm_instance), sizeof(zkw_vm_aux_parameters), sizeof(zkw_storage_log_detailed_state), sizeof(zkw_vm_tracer_streams));
+      printf("%zu %zu %zu %zu\n", offsetof(zkw_vm_instance, auxilary_final_parameters), offsetof(zkw_vm_instance, memory_queue_final_state),
+             offsetof(zkw_vm_tracer_streams, vm_memory_queries), offsetof(zkw_vm_tracer_streams, global_end_of_storage_log));
       return 0; }
     """
     import subprocess
@@ -86,6 +89,10 @@ def test_record_layouts_match_header():
         assert sizes[17] == mod.RAM_FSM.fields["previous_sorting_key"][1]
         assert sizes[18] == mod.RAM_INSTANCE.fields["hidden_fsm_input"][1]
         assert sizes[19] == mod.RAM_INSTANCE.fields["first_item"][1]
+        assert sizes[20:24] == [mod.VM_INSTANCE.itemsize, mod.VM_AUX_PARAMETERS.itemsize, mod.STORAGE_LOG_DETAILED_STATE.itemsize,
+                                ctypes.sizeof(mod.VmTracerStreams)]
+        assert sizes[24:28] == [mod.VM_INSTANCE.fields["auxilary_final_parameters"][1], mod.VM_INSTANCE.fields["memory_queue_final_state"][1],
+                                mod.VmTracerStreams.vm_memory_queries.offset, mod.VmTracerStreams.global_end_of_storage_log.offset]
 
 
 def test_synthetic_trace_is_valid_memory():

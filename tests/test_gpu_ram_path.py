@@ -39,10 +39,10 @@ def test_poseidon2_cooperative_and_lane_forms_match_oracle(ctx, oracle):
         assert np.array_equal(got[k], oracle.poseidon2(s)), k
 
 
-@pytest.mark.parametrize("form", [4, 16])
+@pytest.mark.parametrize("form", [1, 4, 16])
 def test_queue_chain_forms_agree(ctx, oracle, form):
-    """both cooperative layouts of the chain kernel (quad / row of 16) against the oracle, ragged batch"""
-    lens = [3, 0, 40, 1, 9, 17, 2, 5, 33, 8, 1, 1, 64, 7, 12, 3, 100, 6, 2]  # 19 queues: > one wave in quad form
+    """the three layouts of the chain kernel (one lane / quad / row of 16 per state) against the oracle, ragged batch"""
+    lens = [3, 0, 40, 1, 9, 17, 2, 5, 33, 8, 1, 1, 64, 7, 12, 3, 100, 6, 2] + [4, 9, 1] * 20  # 79 queues: > one wave in every form
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     enc = synthetic.random_field_elements(177, (int(offsets[-1]), 8))
     tins = synthetic.random_field_elements(178, (len(lens), 12))
@@ -55,6 +55,32 @@ def test_queue_chain_forms_agree(ctx, oracle, form):
         lo = int(offsets[k])
         if ln:
             assert np.array_equal(got[lo:lo + ln], oracle.queue_push_chain_full(enc[lo:lo + ln], tins[k])), k
+
+
+@pytest.mark.parametrize("form", [1, 4])
+def test_ram_builder_chain_forms(ctx, oracle, form):
+    """the RAM builder's chain path (queries encoded on the fly, the sorted side through the permutation, capacity words +
+    instance-end tails as outputs) in the lane and quad forms: a ragged batch of blocks against the oracle"""
+    from era_zkevm_test_harness_amd import native
+
+    sizes = [2500, 700, 1301, 64, 999]
+    qs = [synthetic.ram_trace(n, seed=300 + k) for k, n in enumerate(sizes)]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    ctx.set_chain_form(form)
+    try:
+        w = ctx.compute_ram_circuit_snapshots(np.concatenate(qs), 512, 0, block_offsets=offs)
+    finally:
+        ctx.set_chain_form(0)
+    ut, st, inst = w.get(native.RAM_UNSORTED_TAILS), w.get(native.RAM_SORTED_TAILS), w.get(native.RAM_INSTANCES)
+    i0 = 0
+    for k, q in enumerate(qs):
+        o = oracle.ram_build_instances(q, 512, 0)
+        lo, hi = int(offs[k]), int(offs[k + 1])
+        assert np.array_equal(ut[lo:hi], o["unsorted_tails"]) and np.array_equal(st[lo:hi], o["sorted_tails"]), k
+        ni = o["instances"].size
+        assert inst[i0:i0 + ni].tobytes() == o["instances"].tobytes(), k
+        i0 += ni
+    w.free()
 
 
 @pytest.mark.parametrize("n", [1, 2, 17, 500])

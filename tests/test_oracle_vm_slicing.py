@@ -1,0 +1,77 @@
+"""CPU: the oracle's MainVM instance slicing (oracle/vm_slicing.c) against a direct Python restatement of the reference's
+iterator chains (src/witness/oracle.rs:1229-1469: take_while / skip_while / partition_point, "next instance's initial
+parameters are this one's final ones", the special pass for the last instance)."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import synthetic
+
+
+def _py_slicing(t):
+    snaps = [int(c) for c in t["snapshot_cycles"]]
+    out = []
+    mem_c = [int(c) for c in t["stream_cycles"][0]]
+    for i in range(len(snaps) - 1):
+        frm, to = snaps[i], snaps[i + 1]
+        d = {"from": frm, "to": to, "ranges": []}
+        for k in range(8):
+            cs = [int(c) for c in t["stream_cycles"][k]]
+            kept = [j for j, c in enumerate(cs) if frm <= c < to]
+            lo = sum(1 for c in cs if c < frm)
+            d["ranges"].append((lo, lo + len(kept)))
+        lo, hi = d["ranges"][0]
+        d["reads"] = [j for j in range(lo, hi) if not t["vm_memory_queries"][j]["rw_flag"]]
+        d["writes"] = [j for j in range(lo, hi) if t["vm_memory_queries"][j]["rw_flag"]]
+        d["mem_entry"] = sum(1 for c in mem_c if c < frm)
+        d["dec_entry"] = sum(1 for c in t["decommit_state_cycles"] if int(c) < frm)
+        d["cs_entry"] = sum(1 for c in t["callstack_sponge_cycles"] if int(c) < frm)
+        d["sl_entry"] = sum(1 for c in t["storage_log_state_cycles"] if int(c) < frm)
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("seed,first", [(1, 0), (2, 0), (3, 700)])
+def test_vm_slicing_matches_iterator_restatement(oracle, seed, first):
+    t = synthetic.vm_tracer_streams(seed=seed, first_snapshot_cycle=first)
+    inst, ri, wi = oracle.vm_slice_instances(t)
+    ref = _py_slicing(t)
+    assert inst.size == len(ref) >= 6
+    tails = t["memory_queue_tails"]
+    for i, (v, d) in enumerate(zip(inst, ref)):
+        assert (int(v["cycle_from"]), int(v["cycle_to"])) == (d["from"], d["to"])
+        assert bool(v["start_flag"]) == (i == 0) and bool(v["completion_flag"]) == (i == len(ref) - 1)
+        assert [tuple(int(x) for x in r) for r in v["range"]] == d["ranges"]
+        r0, rn, w0, wn = (int(v[k]) for k in ("first_memory_read", "num_memory_reads", "first_memory_write", "num_memory_writes"))
+        assert ri[r0:r0 + rn].tolist() == d["reads"] and wi[w0:w0 + wn].tolist() == d["writes"]
+        a = v["auxilary_initial_parameters"]
+        m = d["mem_entry"]
+        assert int(a["memory_queue_state"]["length"]) == m
+        assert np.array_equal(a["memory_queue_state"]["tail"], tails[m - 1] if m else np.zeros(12, np.uint64))
+        assert np.array_equal(a["memory_queue_state"]["head"], tails[m - 2] if m >= 2 else np.zeros(12, np.uint64))
+        dq = d["dec_entry"]
+        assert int(a["decommittment_queue_state"]["length"]) == dq
+        assert np.array_equal(a["decommittment_queue_state"]["tail"], t["decommit_queue_tails"][dq - 1] if dq else np.zeros(12, np.uint64))
+        cs = d["cs_entry"]
+        assert np.array_equal(a["callstack_state"], t["callstack_sponge_states"][cs - 1] if cs else np.zeros(12, np.uint64))
+        sl = d["sl_entry"]
+        if sl:
+            st = t["storage_log_states"][sl - 1]
+            assert np.array_equal(a["storage_log_queue_state"]["tail"], st["forward_tail"]) and int(a["storage_log_queue_state"]["length"]) == int(st["forward_length"])
+            assert np.array_equal(a["current_frame_rollback_queue_head"], st["rollback_head"])
+        else:
+            assert np.array_equal(a["current_frame_rollback_queue_tail"], t["global_end_of_storage_log"]) and not a["storage_log_queue_state"]["tail"].any()
+        if i:
+            assert inst[i - 1]["auxilary_final_parameters"].tobytes() == a.tobytes()
+    last = inst[-1]["auxilary_final_parameters"]
+    assert not last["callstack_state"].any() and int(last["memory_queue_state"]["length"]) == tails.shape[0]
+    assert np.array_equal(last["memory_queue_state"]["tail"], tails[-1])
+    assert inst[-1]["memory_queue_final_state"].tobytes() == last["memory_queue_state"].tobytes()
+    assert np.array_equal(inst[0]["memory_queue_initial_tail"], inst[0]["auxilary_initial_parameters"]["memory_queue_state"]["tail"])
+    assert not inst[1]["memory_queue_initial_tail"].any() and not inst[0]["memory_queue_final_state"]["tail"].any()
+
+
+def test_vm_slicing_empty_streams(oracle):
+    t = synthetic.vm_tracer_streams(seed=5, n_memory=0, sparse=2)
+    inst, ri, wi = oracle.vm_slice_instances(t)
+    assert ri.size == 0 and wi.size == 0 and not inst["num_memory_reads"].any()
+    assert int(inst[-1]["auxilary_final_parameters"]["memory_queue_state"]["length"]) == 0
