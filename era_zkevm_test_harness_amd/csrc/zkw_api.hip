@@ -290,6 +290,37 @@ extern "C" int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometr
     return ZKW_OK;
 }
 
+// Where this library's own trace layout ("zkw trace v2") of a circuit type puts things: what the reference keeps in
+// FinalizationHintsForProver / VerificationKey.fixed_parameters for ITS layout (setup/base_layer/finalization_hint_N.json:
+// `public_inputs` = (column, row) of the four PI cells, `nop_gates_to_add`, `final_trace_len`). No GPU needed.
+extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_layout* out) {
+    if (!out) return fail(ZKW_ERR_INVALID, "zkw_circuit_layout_of: null argument");
+    zkw_circuit_geometry g;
+    ZKW_TRY(zkw_circuit_geometry_of(circuit_type, &g));
+    memset(out, 0, sizeof *out);
+    if (capacity == 0) capacity = g.capacity;
+    out->capacity = capacity;
+    out->trace_len = 1ull << g.trace_len_log2;
+    uint64_t boundary = 0, min_rows = 0, pi_off = 0;
+    switch (circuit_type) {
+        case 8: out->num_columns = RC_COLS; out->rows_per_cycle = RC_ROWS_PER_CYCLE; out->region_stride = RC_REGION_STRIDE(capacity); boundary = RC_BOUNDARY_ROW(capacity); min_rows = RC_MIN_ROWS(capacity); pi_off = RC_ROWOFF_PI; break;
+        case 2: out->num_columns = DS_COLS; out->rows_per_cycle = DS_ROWS_PER_CYCLE; out->region_stride = DS_REGION_STRIDE(capacity); boundary = DS_BOUNDARY_ROW(capacity); min_rows = DS_MIN_ROWS(capacity); pi_off = DS_ROWOFF_PI; break;
+        case 4: out->num_columns = LD_COLS; out->rows_per_cycle = LD_ROWS_PER_CYCLE; out->region_stride = LD_REGION_STRIDE(capacity); boundary = LD_BOUNDARY_ROW(capacity); min_rows = LD_MIN_ROWS(capacity); pi_off = LD_ROWOFF_PI; break;
+        case 9: out->num_columns = SS_COLS; out->rows_per_cycle = SS_ROWS_PER_CYCLE; out->region_stride = SS_REGION_STRIDE(capacity); boundary = SS_BOUNDARY_ROW(capacity); min_rows = SS_MIN_ROWS(capacity); pi_off = SS_ROWOFF_PI; break;
+        case 11: case 12: out->num_columns = ES_COLS; out->rows_per_cycle = ES_ROWS_PER_CYCLE; out->region_stride = ES_REGION_STRIDE(capacity); boundary = ES_BOUNDARY_ROW(capacity); min_rows = ES_MIN_ROWS(capacity); pi_off = ES_ROWOFF_PI; break;
+        default: return ZKW_OK;  // a known circuit type this library does not synthesize yet: synthesizable = 0
+    }
+    out->synthesizable = 1;
+    out->rows_used = min_rows;
+    out->fits = min_rows <= out->trace_len;
+    out->nop_rows = out->fits ? out->trace_len - min_rows : 0;
+    for (int k = 0; k < 4; k++) {
+        out->public_input_column[k] = (uint32_t)k;
+        out->public_input_row[k] = boundary + pi_off;
+    }
+    return ZKW_OK;
+}
+
 extern "C" zkw_ctx* zkw_create(int device_id) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);

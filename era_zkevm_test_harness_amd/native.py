@@ -34,6 +34,7 @@ SYMBOLS = [
     ("zkw_set_chain_form", _int, [_vp, _int]),
     ("zkw_version", C.c_char_p, []),
     ("zkw_circuit_geometry_of", _int, [C.c_uint8, _vp]),
+    ("zkw_circuit_layout_of", _int, [C.c_uint8, _u32, _vp]),
     ("zkw_profile_enable", _int, [_vp, _int]),
     ("zkw_profile_reset", _int, [_vp]),
     ("zkw_profile_get", _int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -996,6 +997,19 @@ CIRCUIT_GEOMETRY = np.dtype(
     [("num_columns_under_copy_permutation", "<u4"), ("num_witness_columns", "<u4"), ("num_constant_columns", "<u4"),
      ("max_allowed_constraint_degree", "<u4"), ("lookup_width", "<u4"), ("lookup_repetitions", "<u4"), ("capacity", "<u4"),
      ("trace_len_log2", "<u4"), ("size_hint_variables", "<u8")])
+
+
+CIRCUIT_LAYOUT = np.dtype(
+    [("synthesizable", "<u4"), ("fits", "<u4"), ("capacity", "<u4"), ("num_columns", "<u4"), ("rows_per_cycle", "<u4"), ("_pad", "<u4"),
+     ("region_stride", "<u8"), ("rows_used", "<u8"), ("nop_rows", "<u8"), ("trace_len", "<u8"), ("public_input_column", "<u4", (4,)),
+     ("public_input_row", "<u8", (4,))])
+
+
+def circuit_layout(circuit_type: int, capacity: int = 0):
+    """zkw_circuit_layout_of: rows used, padding and public-input cells of this library's trace layout (no GPU needed)"""
+    g = np.zeros(1, CIRCUIT_LAYOUT)
+    _check(load().zkw_circuit_layout_of(circuit_type, capacity, _np_ptr(g)))
+    return g[0]
 
 
 def circuit_geometry(circuit_type: int):

@@ -83,6 +83,29 @@ typedef struct zkw_circuit_geometry {
 } zkw_circuit_geometry;
 int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometry *out);
 
+/* Where this library's own trace layout of a circuit type puts things — the counterpart, for the "zkw trace v2" layouts,
+   of what the reference stores per circuit in FinalizationHintsForProver (setup/base_layer/finalization_hint_N.json:
+   `public_inputs` locations, `nop_gates_to_add`, `final_trace_len`; src/prover_utils.rs:48-197 produces it,
+   base_layer/mod.rs:302-312 consumes it). capacity = 0: geometry_config.rs default. synthesizable = 0 for the circuit
+   types without a layout yet (the other fields are then 0 except capacity / trace_len). No GPU needed.
+   These layouts are NOT the reference's gate placement: rows_used differs from its hints and the traces do not pair with
+   its vk_N.json. */
+typedef struct zkw_circuit_layout {
+    uint32_t synthesizable;
+    uint32_t fits;              /* rows_used <= trace_len */
+    uint32_t capacity;
+    uint32_t num_columns;       /* copy-permutation + lookup + multiplicity columns of a trace slot */
+    uint32_t rows_per_cycle;    /* row types repeated once per cycle, region-major */
+    uint32_t _pad;
+    uint64_t region_stride;     /* rows between two regions (capacity rounded up to 64) */
+    uint64_t rows_used;         /* cycle regions + boundary rows */
+    uint64_t nop_rows;          /* trace_len - rows_used: zero padding, the reference's nop_gates_to_add */
+    uint64_t trace_len;         /* 2^20 */
+    uint32_t public_input_column[4];
+    uint64_t public_input_row[4];
+} zkw_circuit_layout;
+int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_layout *out);
+
 /* ---- per-kernel timing -------------------------------------------------------------------------- */
 /* When enabled, every kernel launch (and library sort) of this context is bracketed by HIP events
    recorded on the context's stream; totals are keyed by kernel name ("k_chain_full", "k_gp_local",

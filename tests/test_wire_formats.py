@@ -1,0 +1,53 @@
+"""CPU: the disk formats around the hot path (wire.py) reproduce the reference's committed artifacts byte for byte, and the
+layout descriptions of this library (zkw_circuit_layout_of) are consistent with the geometry and comparable with the
+reference's finalization hints."""
+import json
+import os
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("fname,ctype", [("finalization_hint_8.json", 8), ("finalization_hint_11.json", 11), ("vk_8.json", 8)])
+def test_reference_artifacts_round_trip_byte_exact(fname, ctype):
+    from era_zkevm_test_harness_amd import wire
+
+    raw = open(os.path.join(GOLD, "reference_setup", fname)).read()
+    t, payload = wire.loads(raw)
+    assert t == ctype
+    assert wire.dumps(t, payload) == raw
+    if fname.startswith("vk"):
+        fp = payload["fixed_parameters"]
+        assert fp["domain_size"] == 1 << 20 and fp["parameters"]["num_columns_under_copy_permutation"] == 133
+        assert len(payload["setup_merkle_tree_cap"]) == 16 and all(len(d) == 4 for d in payload["setup_merkle_tree_cap"])
+
+
+def test_layouts_against_reference_hints(tmp_path):
+    from era_zkevm_test_harness_amd import native, wire
+
+    ref = {int(k): v for k, v in json.load(open(os.path.join(GOLD, "reference_finalization_hints.json"))).items()}
+    assert {t: ref[t]["name"] for t in ref} == wire.CIRCUIT_NAMES
+    table = wire.rows_used_table(ref)
+    synth = {t for t, (_, _, ours) in table.items() if ours is not None}
+    assert synth == {2, 4, 8, 9, 11, 12}
+    for t in sorted(synth):
+        name, ref_rows, ours = table[t]
+        lay = native.circuit_layout(t)
+        geo = native.circuit_geometry(t)
+        assert lay["fits"] and int(lay["capacity"]) == int(geo["capacity"]) and int(lay["trace_len"]) == 1 << 20
+        assert int(lay["rows_used"]) + int(lay["nop_rows"]) == 1 << 20 == ref[t]["final_trace_len"]
+        assert int(lay["rows_used"]) == int(lay["rows_per_cycle"]) * int(lay["region_stride"]) + (ours - int(lay["rows_per_cycle"]) * int(lay["region_stride"]))
+        assert int(lay["num_columns"]) == int(geo["num_columns_under_copy_permutation"]) + int(geo["lookup_width"]) * int(geo["lookup_repetitions"]) + 1
+        # the reference's own rows: PI row + 1 + nop == 2^20
+        assert ref_rows + ref[t]["nop_gates_to_add"] == 1 << 20
+        # same file shape as the reference's hint, for this library's layout; and it reads back
+        hint = wire.finalization_hint_of_layout(t)
+        assert set(hint) == {"row_finalization_hints", "column_finalization_hints", "nop_gates_to_add", "final_trace_len", "public_inputs"}
+        assert [c for c, _ in hint["public_inputs"]] == [0, 1, 2, 3] and len({r for _, r in hint["public_inputs"]}) == 1
+        path = os.path.join(tmp_path, os.path.basename(wire.base_layer_paths(str(tmp_path), t)[1]))
+        wire.dump(path, t, hint)
+        assert wire.load(path) == (t, hint)
+    assert not native.circuit_layout(1)["synthesizable"] and not native.circuit_layout(5)["synthesizable"]
+    with pytest.raises(native.ZkwError):
+        native.circuit_layout(14)
