@@ -147,6 +147,7 @@ struct Coop {
     u64 rc_full[2 * P2_HALF_FULL_ROUNDS];  // c_rc[12*round + g] for the 8 full rounds (0 for idle lanes)
     u32 ka, kb, kd;                        // row of M4 seen from this lane: ka*a + kb*b + c + kd*d
     u32 shift;                             // internal diag shift of element g
+    u32 rsh, hi_mask;                      // 32 - shift (mod 32) and all-ones unless shift == 0: the word x * 2^shift spills
     bool active;                           // g < 12
     bool first;                            // g == 0
 
@@ -163,6 +164,8 @@ struct Coop {
         kb = even ? 7u : 1u;  // odd lane j:  6 x_j +   x_{j+1} + x_{j+2} + 4 x_{j+3}  (indices mod 4)
         kd = even ? 3u : 4u;
         shift = active ? c_shift[g] : 0;
+        rsh = (32u - shift) & 31u;
+        hi_mask = shift ? 0xffffffffu : 0u;
     }
 
     // external layer on the distributed state; x weak, idle lanes must hold 0 and get 0 back
@@ -179,18 +182,55 @@ struct Coop {
         return active ? y : 0;
     }
 
+    // Internal layer y_g = x_g * 2^shift_g + sum over the row, hand-scheduled: the compiler's form of the same arithmetic is
+    // ~75 instructions per call (a v_mov_b32_dpp per 32-bit word and butterfly step, 64-bit compares to recover carries,
+    // zero-extension moves); here every butterfly step is three adds-with-carry that take their DPP operand directly
+    // (12 instructions for the 96-bit row sum), the reduction keeps its carries in VCC (7), ~30 in all. 22 calls per
+    // permutation, and a lone chain wave pays ~4 cycles per instruction whatever it is.
     __device__ __forceinline__ u64 internal(u64 x) const {
-        Wide s;
-        s.lo = x;
-        s.hi = 0;
-        s = wadd(s, wdpp<ROW_ROR8>(s));
-        s = wadd(s, wdpp<ROW_ROR4>(s));
-        s = wadd(s, wdpp<QP_ROT2>(s));
-        s = wadd(s, wdpp<QP_SWAP1>(s));
-        Wide m;  // x * 2^shift
-        m.lo = x << shift;
-        m.hi = (u32)((x >> 1) >> (63 - shift));
-        u64 y = wreduce(wadd(m, s));
+        const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+        u32 s0, s1, s2;
+        const u32 zero = 0;
+        // s = sum of x over the 16 lanes of the row as a 96-bit number (idle lanes hold 0). A DPP read needs two wait
+        // states after the VALU write of its source: s_nop before the first step; inside, three instructions separate a
+        // register's write from its next DPP read.
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_co_u32_dpp %0, vcc, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32_dpp %1, vcc, %4, %4, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32 %2, vcc, 0, %5, vcc\n\t"
+            "v_add_co_u32_dpp %0, vcc, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_co_u32_dpp %0, vcc, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_co_u32_dpp %0, vcc, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+            : "=&v"(s0), "=&v"(s1), "=&v"(s2)
+            : "v"(x0), "v"(x1), "v"(zero)
+            : "vcc");
+        // m = x * 2^shift as 96 bits; rsh / hi_mask are per-lane constants (shift 0: no high word)
+        const u64 mlo = x << shift;
+        const u32 m2 = (x1 >> rsh) & hi_mask;
+        u32 r0, r1;
+        u32 t0, t1, t2, t3;
+        asm volatile(
+            "v_add_co_u32 %0, vcc, %6, %9\n\t"            // y = m + s (96 bits): y0
+            "v_addc_co_u32 %1, vcc, %7, %10, vcc\n\t"     // y1
+            "v_addc_co_u32 %2, vcc, %8, %11, vcc\n\t"     // y2 < 2^32: the part above 2^64, worth y2 * (2^32 - 1)
+            "v_sub_co_u32 %3, vcc, 0, %2\n\t"             // y2 * EPS = (y2 << 32) - y2: low word
+            "v_subbrev_co_u32 %4, vcc, 0, %2, vcc\n\t"    //                              high word
+            "v_add_co_u32 %0, vcc, %0, %3\n\t"
+            "v_addc_co_u32 %1, vcc, %1, %4, vcc\n\t"
+            "v_cndmask_b32 %5, 0, -1, vcc\n\t"            // wrapped past 2^64 (= EPS): add it back; cannot wrap twice
+            "v_add_co_u32 %0, vcc, %0, %5\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"((u32)mlo), "v"((u32)(mlo >> 32)), "v"(m2), "v"(s0), "v"(s1), "v"(s2)
+            : "vcc");
+        const u64 y = ((u64)r1 << 32) | r0;
         return active ? y : 0;
     }
 

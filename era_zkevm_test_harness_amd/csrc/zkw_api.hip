@@ -494,11 +494,12 @@ static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     ChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("chain_jobs", jobs, &d_jobs));
     int n_jobs = (int)jobs.size();
-    // auto: the row form has the lowest latency (10.4 us per step) and wins while every wave can have a SIMD to itself
-    // (<= 4096 chains); the quad form packs 16 chains per wave (14.3 us); from 16 384 chains on nothing but throughput
-    // counts and the lane form (64 chains per wave, ~2.4x fewer VALU instructions per permutation) leaves more than half of
-    // the SIMDs to whatever runs next to the chains
-    const int form = ctx->chain_form ? ctx->chain_form : (n_jobs >= 16384 ? 1 : n_jobs >= 4096 ? 4 : 16);
+    // auto: the row form has the lowest latency (10 us per step) and wins while every wave can have a SIMD to itself
+    // (<= 4096 chains); the quad form packs 16 chains per wave (14.3 us up to 16 384 chains = one wave per SIMD, 21.3 us
+    // with two waves per SIMD). The lane form (64 chains per wave, ~2.4x fewer VALU instructions per permutation, 36 us
+    // per step) is never chosen automatically: measured on the bench's batch it loses to the quad form both alone
+    // (1 418 vs 1 493 circuits/s) and next to another pipeline's fills (1 240 vs 1 790), DESIGN.md 3.2
+    const int form = ctx->chain_form ? ctx->chain_form : (n_jobs >= 4096 ? 4 : 16);
     // the chain kernel may run on its own stream (e.g. one created with a CU mask): ordered after everything queued on
     // the context's stream so far, and the context's stream continues after it
     hipStream_t st = ctx->stream;

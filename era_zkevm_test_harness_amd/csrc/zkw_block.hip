@@ -410,16 +410,15 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
         src.push_back({T_L1, zkw_events_witness_device_ptr(B->l1, ZKW_EVT_PUBLIC_INPUTS), zkw_events_witness_device_ptr(B->l1, ZKW_EVT_COMPACT_FORMS), zkw_events_witness_num_instances(B->l1)});
         size_t total = 0;
         for (auto& s : src) total += s.n;
-        uint64_t *d_pi = nullptr, *d_enc = nullptr, *d_states = nullptr;
-        ST_TRY(B->alloc(&d_pi, total * 4));
+        uint64_t *d_enc = nullptr, *d_states = nullptr;
         ST_TRY(B->alloc(&d_enc, total * 8));
         ST_TRY(B->alloc(&d_states, total * 12));
         std::vector<uint64_t> offs(1, 0);
         zkw_ctx* c = B->ctx[C_PRE];
         for (auto& s : src) {
             const size_t o = offs.back();
-            ST_HIP(hipMemcpy(d_pi + 4 * o, s.d_pi, s.n * 32, hipMemcpyDeviceToDevice));  // every branch has joined: nothing else runs
-            ST_ZKW(zkw_encode_recursion_requests(c, (uint64_t)s.type, d_pi + 4 * o, s.n, d_enc + 8 * o));
+            // straight from the witness (its branch has synchronised its stream before joining)
+            ST_ZKW(zkw_encode_recursion_requests(c, (uint64_t)s.type, static_cast<const uint64_t*>(s.d_pi), s.n, d_enc + 8 * o));
             offs.push_back(o + s.n);
         }
         ST_ZKW(zkw_queue_push_chain_full_batch(c, d_enc, offs.data(), src.size(), nullptr, d_states));
@@ -430,7 +429,7 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
             p.pi.resize(n * 4);
             p.enc.resize(n * 8);
             p.states.resize(n * 12);
-            ST_TRY(B->xf[X_MAIN].d2h(p.pi.data(), d_pi + 4 * o, n * 32));
+            ST_TRY(B->xf[X_MAIN].d2h(p.pi.data(), src[k].d_pi, n * 32));
             ST_TRY(B->xf[X_MAIN].d2h(p.enc.data(), d_enc + 8 * o, n * 64));
             ST_TRY(B->xf[X_MAIN].d2h(p.states.data(), d_states + 12 * o, n * 96));
             p.compact.resize(n * 18);

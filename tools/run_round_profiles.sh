@@ -1,30 +1,46 @@
 #!/bin/bash
 # Reproduces the artefacts under profiles/rNN/ on a GPU box (run from the repo root):
-#   bash tools/run_round_profiles.sh gpurun_out/r01
-# then copy the directory's contents into profiles/r01/ and run `python tools/make_profile_readme.py`.
+#   bash tools/run_round_profiles.sh gpurun_out/r02
+# then copy the directory's contents into profiles/r02/ and run `python tools/make_profile_readme.py r02`.
 set -u
 OUT=${1:-gpurun_out/profiles}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 OUT=$(cd "$OUT" && pwd)
 export TMPDIR=/tmp
-# 1. the default bench, without a profiler
-timeout -s KILL 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-timeout -s KILL 900 python bench.py --pipelines 1 --no-cpu-baseline > "$OUT/bench_sequential.json" 2> "$OUT/bench_sequential.err"
+# 1. the default bench (throughput leg + full-block leg + CPU legs), without a profiler
+timeout -s KILL 1200 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+timeout -s KILL 900 python bench.py --pipelines 1 --no-cpu-baseline --no-full-block > "$OUT/bench_sequential.json" 2> "$OUT/bench_sequential.err"
 # 2. the same command under rocprofv3 --kernel-trace --stats
-cd /tmp && rm -rf /tmp/prof_stats && timeout -s KILL 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- \
-    python "$ROOT/bench.py" > "$OUT/bench_default_under_rocprofv3.json" 2> "$OUT/rocprof_stats.err"
+cd /tmp && rm -rf /tmp/prof_stats && timeout -s KILL 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- \
+    python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_default_under_rocprofv3.json" 2> "$OUT/rocprof_stats.err"
 cp "$(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1)" "$OUT/bench_default_kernel_stats.csv"
-# 3. HBM counters, one pass each (never combined with other trace domains)
+# 3. HBM counters AT THE BENCHMARKED BATCH, one pass each (never combined with other trace domains): one timed step of the
+#    sequential form (counter collection serialises the dispatches anyway)
 for C in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/prof_pmc && timeout -s KILL 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_pmc -- \
-        python "$ROOT/bench.py" --pipelines 1 --blocks 32 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/rocprof_pmc_$C.err"
-    cp "$(ls /tmp/prof_pmc/*/*counter_collection.csv | head -1)" "$OUT/bench_b32_pmc_$C.csv"
+    rm -rf /tmp/prof_pmc && timeout -s KILL 1500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_pmc -- \
+        python "$ROOT/bench.py" --pipelines 1 --steps 1 --warmup 0 --no-cpu-baseline --no-full-block > "$OUT/bench_pmc_$C.json" 2> "$OUT/rocprof_pmc_$C.err"
+    python3 - "$(ls /tmp/prof_pmc/*/*counter_collection.csv | head -1)" "$OUT/bench_pmc_$C.summary.csv" <<'PY'
+import collections, csv, sys
+tot, disp = collections.defaultdict(float), collections.defaultdict(set)
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    tot[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+with open(sys.argv[2], "w") as f:
+    f.write("kernel,dispatches,counter_total,counter_per_dispatch\n")
+    for k in sorted(tot, key=lambda k: -tot[k]):
+        f.write(f"\"{k}\",{len(disp[k])},{tot[k]:.0f},{tot[k]/len(disp[k]):.1f}\n")
+PY
 done
 cd "$ROOT"
-# 4. synthesis throughput of the other circuit types at production geometry
+# 4. one production-capacity block: spans of zkw_block_run, per-kernel times of every branch, bit-exactness vs the oracle
+ZKW_BLOCK_PROFILE=1 timeout -s KILL 600 python tools/probe_block.py 2>&1 | grep -v amdgpu.ids > "$OUT/full_block_probe.txt"
+# 5. synthesis throughput of the other circuit types at production geometry
 for P in ds es ld ss; do
     echo "== tools/probe_${P}_synth.py" >> "$OUT/synthesis_probes.txt"
     timeout -s KILL 300 python tools/probe_${P}_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
 done
+# 6. the hardware probes behind DESIGN.md 3.2
+(cd tools && for b in probe_wave_placement probe_clock_regime ubench_perm; do [ -x ./$b ] && { echo "== $b"; timeout -s KILL 300 ./$b; }; done) > "$OUT/hardware_probes.txt" 2>&1
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/gpu_tests_tail.txt"
 ls -la "$OUT"
