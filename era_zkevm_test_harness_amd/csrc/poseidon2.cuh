@@ -142,6 +142,63 @@ __device__ __forceinline__ Wide wdpp(Wide a) {
     r.hi = dpp32<CTRL>(a.hi);
     return r;
 }
+// a * b mod p for the latency-bound cooperative forms, hand-scheduled: four independent 32 x 32 products (the compiler's
+// chain feeds each product's high half into the next one's addend through a v_mov and multiplies by 2^32 - 1 with a fifth
+// v_mad_u64_u32), three adds-with-carry to line the partial products up and a 12-instruction reduction whose borrow and
+// carries stay in VCC: 20 instructions against ~23 + s_nops. Weak in, weak out.
+__device__ __forceinline__ u64 mul_sched(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u32 zero = 0;
+    u64 p, q, h;
+    u32 cm;
+    asm("v_mad_u64_u32 %0, s[100:101], %4, %6, 0\n\t"      // p = a0 * b0
+        "v_mad_u64_u32 %1, s[100:101], %4, %7, 0\n\t"      // q = a0 * b1
+        "v_mad_u64_u32 %2, s[100:101], %5, %7, 0\n\t"      // h = a1 * b1
+        "v_mad_u64_u32 %1, vcc, %5, %6, %1\n\t"            // q += a1 * b0, carry out of 64 bits
+        "v_addc_co_u32 %3, vcc, 0, %8, vcc"                   // cm = that carry (worth 2^96)
+        : "=&v"(p), "=&v"(q), "=&v"(h), "=&v"(cm)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(zero)
+        : "vcc", "s100", "s101");
+    const u32 p0 = (u32)p, p1 = (u32)(p >> 32), q0 = (u32)q, q1 = (u32)(q >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
+    u32 r0, r1, w1, g0, g1, m, t0, t1;
+    asm("v_add_co_u32 %2, vcc, %8, %10\n\t"                // product = p + (q << 32) + (h << 64) + (cm << 96): word 1
+        "v_addc_co_u32 %3, vcc, %12, %11, vcc\n\t"         // word 2 = hl
+        "v_addc_co_u32 %4, vcc, %13, %14, vcc\n\t"         // word 3 = hh
+        "v_sub_co_u32 %0, vcc, %9, %4\n\t"                 // lo - hh            (2^96 = -1)
+        "v_subbrev_co_u32 %1, vcc, 0, %2, vcc\n\t"
+        "v_cndmask_b32 %5, 0, -1, vcc\n\t"                 // borrowed: the wrap added 2^64 = EPS, take it out again
+        "v_sub_co_u32 %0, vcc, %0, %5\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_sub_co_u32 %6, vcc, 0, %3\n\t"                  // hl * EPS = (hl << 32) - hl
+        "v_subbrev_co_u32 %7, vcc, 0, %3, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %6\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %7, vcc\n\t"
+        "v_cndmask_b32 %5, 0, -1, vcc\n\t"                 // carried: add EPS; cannot carry twice
+        "v_add_co_u32 %0, vcc, %0, %5\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(w1), "=&v"(g0), "=&v"(g1), "=&v"(m), "=&v"(t0), "=&v"(t1)
+        : "v"(p1), "v"(p0), "v"(q0), "v"(q1), "v"(h0), "v"(h1), "v"(cm)
+        : "vcc");
+    return ((u64)r1 << 32) | r0;
+}
+// x + c for a CANONICAL c (round constant): one wrap at most, so one conditional "+ EPS" (gl::add handles weak + weak)
+__device__ __forceinline__ u64 add_rc_sched(u64 x, u64 c) {
+    u32 r0, r1, m;
+    asm("v_add_co_u32 %0, vcc, %3, %5\n\t"
+        "v_addc_co_u32 %1, vcc, %4, %6, vcc\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(m)
+        : "v"((u32)x), "v"((u32)(x >> 32)), "v"((u32)c), "v"((u32)(c >> 32))
+        : "vcc");
+    return ((u64)r1 << 32) | r0;
+}
+__device__ __forceinline__ u64 pow7_sched(u64 x) {
+    const u64 x2 = mul_sched(x, x), x3 = mul_sched(x2, x), x4 = mul_sched(x2, x2);
+    return mul_sched(x3, x4);
+}
+
 struct Coop {
     // per-lane constants, loaded once per kernel
     u64 rc_full[2 * P2_HALF_FULL_ROUNDS];  // c_rc[12*round + g] for the 8 full rounds (0 for idle lanes)
@@ -173,12 +230,33 @@ struct Coop {
         u64 a = x, b = dpp64<QP_ROT1>(x), c = dpp64<QP_ROT2>(x), d = dpp64<QP_ROT3>(x);
         u64 L = (a & gl::EPS) * ka + (b & gl::EPS) * kb + (c & gl::EPS) + (d & gl::EPS) * kd;  // < 18 * 2^32
         u64 H = (a >> 32) * ka + (b >> 32) * kb + (c >> 32) + (d >> 32) * kd;
-        Wide t;  // L + H * 2^32
-        t.lo = L + (H << 32);
-        t.hi = (u32)(H >> 32) + (t.lo < L ? 1u : 0u);
-        // column sums over the (up to) 4 quads of the row; the idle quad contributes 0
-        Wide col = wadd(wadd(t, wdpp<ROW_ROR4>(t)), wadd(wdpp<ROW_ROR8>(t), wdpp<ROW_ROR12>(t)));
-        u64 y = wreduce(wadd(t, col));
+        // t = L + H * 2^32 (the M4 row of this lane, 96 bits); col = t summed over the row's four quads (the idle quad holds
+        // 0); y = t + col reduced. Hand-scheduled like `internal`: DPP operands taken by the adds themselves, carries in VCC.
+        u32 r0, r1, t0, t1, t2, u0, u1, u2, e0, e1, e2;
+        asm volatile(
+            "v_add_co_u32 %3, vcc, %11, %13\n\t"          // t1 = L.hi + H.lo
+            "v_addc_co_u32 %4, vcc, 0, %14, vcc\n\t"      // t2 = H.hi + carry        (t0 = L.lo = %12)
+            "s_nop 0\n\t"
+            "v_add_co_u32_dpp %5, vcc, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"   // u = t + ror8(t)
+            "v_addc_co_u32_dpp %6, vcc, %3, %3, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32_dpp %7, vcc, %4, %4, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_co_u32_dpp %5, vcc, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"      // col = u + ror4(u)
+            "v_addc_co_u32_dpp %6, vcc, %6, %6, vcc row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_addc_co_u32_dpp %7, vcc, %7, %7, vcc row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_co_u32 %0, vcc, %12, %5\n\t"           // y = t + col
+            "v_addc_co_u32 %1, vcc, %3, %6, vcc\n\t"
+            "v_addc_co_u32 %2, vcc, %4, %7, vcc\n\t"      // y2 < 2^32, worth y2 * (2^32 - 1)
+            "v_sub_co_u32 %8, vcc, 0, %2\n\t"
+            "v_subbrev_co_u32 %9, vcc, 0, %2, vcc\n\t"
+            "v_add_co_u32 %0, vcc, %0, %8\n\t"
+            "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+            "v_cndmask_b32 %10, 0, -1, vcc\n\t"
+            "v_add_co_u32 %0, vcc, %0, %10\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(e0), "=&v"(e1), "=&v"(e2)
+            : "v"((u32)(L >> 32)), "v"((u32)L), "v"((u32)H), "v"((u32)(H >> 32))
+            : "vcc");
+        const u64 y = ((u64)r1 << 32) | r0;
         return active ? y : 0;
     }
 
@@ -238,15 +316,15 @@ struct Coop {
     __device__ __forceinline__ u64 permute(u64 x) const {
         x = external(x);
 #pragma unroll
-        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) x = external(gl::pow7(gl::add(x, rc_full[k])));
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) x = external(pow7_sched(add_rc_sched(x, rc_full[k])));
         for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
             u64 rc = c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];  // wave-uniform -> scalar load
-            u64 sx = gl::pow7(gl::add(x, rc));
+            u64 sx = pow7_sched(add_rc_sched(x, rc));
             x = internal(first ? sx : x);
         }
 #pragma unroll
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++)
-            x = external(gl::pow7(gl::add(x, rc_full[P2_HALF_FULL_ROUNDS + k])));
+            x = external(pow7_sched(add_rc_sched(x, rc_full[P2_HALF_FULL_ROUNDS + k])));
         return x;
     }
 };
