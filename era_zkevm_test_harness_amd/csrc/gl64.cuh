@@ -83,7 +83,60 @@ GL_HD u64 reduce128(u64 lo, u64 hi) {
 #endif
 }
 
+#if defined(__HIPCC__)
+// a * b mod p, hand-scheduled for gfx950: four independent 32 x 32 products (the compiler's chain feeds each product's
+// high half into the next one's addend through a v_mov and multiplies by 2^32 - 1 with a fifth v_mad_u64_u32), three
+// adds-with-carry to line the partial products up and a 12-instruction reduction whose borrow and carries stay in VCC:
+// 20 instructions against ~23 + s_nops. Weak in, weak out.
+__device__ __forceinline__ u64 mul_sched(u64 a, u64 b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return 0;  // device-only (the host pass of hipcc only needs the declaration)
+#else
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u32 zero = 0;
+    u64 p, q, h;
+    u32 cm;
+    asm("v_mad_u64_u32 %0, s[100:101], %4, %6, 0\n\t"      // p = a0 * b0
+        "v_mad_u64_u32 %1, s[100:101], %4, %7, 0\n\t"      // q = a0 * b1
+        "v_mad_u64_u32 %2, s[100:101], %5, %7, 0\n\t"      // h = a1 * b1
+        "v_mad_u64_u32 %1, vcc, %5, %6, %1\n\t"            // q += a1 * b0, carry out of 64 bits
+        "v_addc_co_u32 %3, vcc, 0, %8, vcc"                   // cm = that carry (worth 2^96)
+        : "=&v"(p), "=&v"(q), "=&v"(h), "=&v"(cm)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(zero)
+        : "vcc", "s100", "s101");
+    const u32 p0 = (u32)p, p1 = (u32)(p >> 32), q0 = (u32)q, q1 = (u32)(q >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
+    u32 r0, r1, w1, g0, g1, m, t0, t1;
+    asm("v_add_co_u32 %2, vcc, %8, %10\n\t"                // product = p + (q << 32) + (h << 64) + (cm << 96): word 1
+        "v_addc_co_u32 %3, vcc, %12, %11, vcc\n\t"         // word 2 = hl
+        "v_addc_co_u32 %4, vcc, %13, %14, vcc\n\t"         // word 3 = hh
+        "v_sub_co_u32 %0, vcc, %9, %4\n\t"                 // lo - hh            (2^96 = -1)
+        "v_subbrev_co_u32 %1, vcc, 0, %2, vcc\n\t"
+        "v_cndmask_b32 %5, 0, -1, vcc\n\t"                 // borrowed: the wrap added 2^64 = EPS, take it out again
+        "v_sub_co_u32 %0, vcc, %0, %5\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_sub_co_u32 %6, vcc, 0, %3\n\t"                  // hl * EPS = (hl << 32) - hl
+        "v_subbrev_co_u32 %7, vcc, 0, %3, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %6\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %7, vcc\n\t"
+        "v_cndmask_b32 %5, 0, -1, vcc\n\t"                 // carried: add EPS; cannot carry twice
+        "v_add_co_u32 %0, vcc, %0, %5\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(w1), "=&v"(g0), "=&v"(g1), "=&v"(m), "=&v"(t0), "=&v"(t1)
+        : "v"(p1), "v"(p0), "v"(q0), "v"(q1), "v"(h0), "v"(h1), "v"(cm)
+        : "vcc");
+    return ((u64)r1 << 32) | r0;
+#endif
+}
+#endif
+
 GL_HD u64 mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_MUL_SCHEDULED_EVERYWHERE)
+    // measured (bench.py): the hand-scheduled form only pays where a wave runs ONE dependent S-box chain (the row-form
+    // queue chains, p2::Coop: 9.99 -> 7.44 us per permutation with the other hand-scheduled pieces). Kernels with several
+    // independent multiplications per lane (quad-form chains, the per-lane permutation of the trace fills) lose 3-4 %:
+    // the compiler interleaves independent multiplications instruction by instruction, opaque asm blocks it cannot.
+    return mul_sched(a, b);
+#else
 #if defined(__HIP_DEVICE_COMPILE__)
     // four chained v_mad_u64_u32 give both halves of the 128-bit product; computing `a * b` and
     // `__umul64hi(a, b)` separately costs 5 mads + 2 v_mul_lo_u32 (+16 % instructions per S-box, measured)
@@ -98,6 +151,7 @@ GL_HD u64 mul(u64 a, u64 b) {
     u64 lo = (u64)w, hi = (u64)(w >> 64);
 #endif
     return reduce128(lo, hi);
+#endif
 }
 
 GL_HD u64 sqr(u64 a) { return mul(a, a); }

@@ -142,45 +142,6 @@ __device__ __forceinline__ Wide wdpp(Wide a) {
     r.hi = dpp32<CTRL>(a.hi);
     return r;
 }
-// a * b mod p for the latency-bound cooperative forms, hand-scheduled: four independent 32 x 32 products (the compiler's
-// chain feeds each product's high half into the next one's addend through a v_mov and multiplies by 2^32 - 1 with a fifth
-// v_mad_u64_u32), three adds-with-carry to line the partial products up and a 12-instruction reduction whose borrow and
-// carries stay in VCC: 20 instructions against ~23 + s_nops. Weak in, weak out.
-__device__ __forceinline__ u64 mul_sched(u64 a, u64 b) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u32 zero = 0;
-    u64 p, q, h;
-    u32 cm;
-    asm("v_mad_u64_u32 %0, s[100:101], %4, %6, 0\n\t"      // p = a0 * b0
-        "v_mad_u64_u32 %1, s[100:101], %4, %7, 0\n\t"      // q = a0 * b1
-        "v_mad_u64_u32 %2, s[100:101], %5, %7, 0\n\t"      // h = a1 * b1
-        "v_mad_u64_u32 %1, vcc, %5, %6, %1\n\t"            // q += a1 * b0, carry out of 64 bits
-        "v_addc_co_u32 %3, vcc, 0, %8, vcc"                   // cm = that carry (worth 2^96)
-        : "=&v"(p), "=&v"(q), "=&v"(h), "=&v"(cm)
-        : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(zero)
-        : "vcc", "s100", "s101");
-    const u32 p0 = (u32)p, p1 = (u32)(p >> 32), q0 = (u32)q, q1 = (u32)(q >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
-    u32 r0, r1, w1, g0, g1, m, t0, t1;
-    asm("v_add_co_u32 %2, vcc, %8, %10\n\t"                // product = p + (q << 32) + (h << 64) + (cm << 96): word 1
-        "v_addc_co_u32 %3, vcc, %12, %11, vcc\n\t"         // word 2 = hl
-        "v_addc_co_u32 %4, vcc, %13, %14, vcc\n\t"         // word 3 = hh
-        "v_sub_co_u32 %0, vcc, %9, %4\n\t"                 // lo - hh            (2^96 = -1)
-        "v_subbrev_co_u32 %1, vcc, 0, %2, vcc\n\t"
-        "v_cndmask_b32 %5, 0, -1, vcc\n\t"                 // borrowed: the wrap added 2^64 = EPS, take it out again
-        "v_sub_co_u32 %0, vcc, %0, %5\n\t"
-        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
-        "v_sub_co_u32 %6, vcc, 0, %3\n\t"                  // hl * EPS = (hl << 32) - hl
-        "v_subbrev_co_u32 %7, vcc, 0, %3, vcc\n\t"
-        "v_add_co_u32 %0, vcc, %0, %6\n\t"
-        "v_addc_co_u32 %1, vcc, %1, %7, vcc\n\t"
-        "v_cndmask_b32 %5, 0, -1, vcc\n\t"                 // carried: add EPS; cannot carry twice
-        "v_add_co_u32 %0, vcc, %0, %5\n\t"
-        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
-        : "=&v"(r0), "=&v"(r1), "=&v"(w1), "=&v"(g0), "=&v"(g1), "=&v"(m), "=&v"(t0), "=&v"(t1)
-        : "v"(p1), "v"(p0), "v"(q0), "v"(q1), "v"(h0), "v"(h1), "v"(cm)
-        : "vcc");
-    return ((u64)r1 << 32) | r0;
-}
 // x + c for a CANONICAL c (round constant): one wrap at most, so one conditional "+ EPS" (gl::add handles weak + weak)
 __device__ __forceinline__ u64 add_rc_sched(u64 x, u64 c) {
     u32 r0, r1, m;
@@ -194,9 +155,9 @@ __device__ __forceinline__ u64 add_rc_sched(u64 x, u64 c) {
         : "vcc");
     return ((u64)r1 << 32) | r0;
 }
-__device__ __forceinline__ u64 pow7_sched(u64 x) {
-    const u64 x2 = mul_sched(x, x), x3 = mul_sched(x2, x), x4 = mul_sched(x2, x2);
-    return mul_sched(x3, x4);
+__device__ __forceinline__ u64 pow7_sched(u64 x) {  // one dependent chain per wave: the hand-scheduled multiplication (gl64.cuh)
+    const u64 x2 = gl::mul_sched(x, x), x3 = gl::mul_sched(x2, x), x4 = gl::mul_sched(x2, x2);
+    return gl::mul_sched(x3, x4);
 }
 
 struct Coop {
