@@ -402,6 +402,21 @@ def main():
             "k_ram_fill_D": 148 * cell + 48 * cell,           # reads the queue tails back from the Poseidon2 rows
             "k_ram_fill_tail": per_launch_inst * 8 * (148 * (n_rows - 6 * stride) + n_rows),
         }
+        def pmc_traffic(kernel, launches_items):
+            """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate
+            runs at the benchmarked batch, gfx950 FETCH correction applied: profiles/r02/traffic.json; counters cannot be read
+            inside this process). Scaled by items per launch when this run's launch differs from the profiled one."""
+            path = os.path.join(ROOT, "profiles", "r02", "traffic.json")
+            if not os.path.exists(path):
+                return None
+            t = json.load(open(path))
+            k = t["kernels"].get("zkw::" + kernel)
+            if not k:
+                return None
+            profiled_items = 2 * t["blocks"] * n if kernel.startswith("k_chain") else None
+            scale = (launches_items / profiled_items) if profiled_items else 1.0
+            return k["traffic_bytes_per_launch"] * scale
+
         name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / max(cnt, 1)
         ab = alg_bytes.get(name)
@@ -436,7 +451,8 @@ def main():
                        "blocks_per_gpu": B, "queries_per_block": n, "parallelism": f"instances sharded x{world}",
                        "pipelines_per_gpu": P, "pipeline_stagger_ms": stagger_s * 1e3, "gather": gather_backend},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(name, 2 * items),
+                         "traffic_unit": "bytes per launch (PMC, profiles/r02/traffic.json)", "algorithmic_bytes_per_launch": ab,
                          "avg_launch_ms": avg_ms,
                          "note": "k_chain_full is a serial Poseidon2 chain per queue: latency/VALU-bound, permutations/s is "
                                  "its meaningful rate; with P pipelines its launches overlap the other pipelines' synthesis, "
