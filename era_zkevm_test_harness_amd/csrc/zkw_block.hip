@@ -142,6 +142,7 @@ struct zkw_block {
     zkw_queue_state12 mem_state;
     uint8_t l1_hash[32] = {};
     PerType per[14];
+    std::vector<zkw_vm_instance> vm_instances;
     // synthesis ring (created by the first zkw_block_synthesize)
     zkw_trace *ring149 = nullptr, *ring151 = nullptr;
     size_t ring_rows = 0, ring_slots = 0;
@@ -397,6 +398,41 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
     ST_ZKW(zkw_synchronize(B->ctx[C_PRE]));
     ST_TRY(mem_in_at(B->n_mem, &B->mem_state));
 
+    // 3b. MainVM instances (oracle.rs:1229-1469): the tracer's vectors cut at the snapshots, entry states from the queues
+    //     hashed above (memory queue: the VM's prefix of the RAM permutation's unsorted states; decommit queue: the
+    //     decommit sorter's unsorted states)
+    if (in->vm_tracer) {
+        Timed t(B, "main_vm.slicing");
+        const zkw_vm_tracer_streams& v = *in->vm_tracer;
+        if (v.stream_len[ZKW_VMS_MEMORY] != in->n_vm_memory_queries || v.n_decommit_states != in->n_decommit_queries || v.n_snapshots < 2) {
+            Status s;
+            s.rc = ZKW_ERR_INVALID;
+            s.msg = "vm_tracer: the memory stream / decommit states must be as long as the block's VM memory queue / decommit queue";
+            return s;
+        }
+        zkw_vm_tracer_streams d = v;
+        uint32_t* p32 = nullptr;
+        ST_TRY(B->upload(X_MAIN, &p32, v.snapshot_cycles, v.n_snapshots)); d.snapshot_cycles = p32;
+        for (int k = 0; k < ZKW_VM_NUM_STREAMS; k++) { ST_TRY(B->upload(X_MAIN, &p32, v.stream_cycles[k], v.stream_len[k])); d.stream_cycles[k] = p32; }
+        ST_TRY(B->upload(X_MAIN, &p32, v.decommit_state_cycles, v.n_decommit_states)); d.decommit_state_cycles = p32;
+        ST_TRY(B->upload(X_MAIN, &p32, v.callstack_sponge_cycles, v.n_callstack_sponges)); d.callstack_sponge_cycles = p32;
+        ST_TRY(B->upload(X_MAIN, &p32, v.storage_log_state_cycles, v.n_storage_log_states)); d.storage_log_state_cycles = p32;
+        uint64_t* p64 = nullptr;
+        ST_TRY(B->upload(X_MAIN, &p64, v.callstack_sponge_states, v.n_callstack_sponges * 12)); d.callstack_sponge_states = p64;
+        zkw_storage_log_detailed_state* psl = nullptr;
+        ST_TRY(B->upload(X_MAIN, &psl, v.storage_log_states, v.n_storage_log_states)); d.storage_log_states = psl;
+        d.vm_memory_queries = B->d_all_mem;   // the VM's queries are the first n_vm of the memory queue
+        d.memory_queue_tails = d_tails;
+        d.decommit_queue_tails = static_cast<const uint64_t*>(zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_UNSORTED_TAILS));
+        const size_t ni = v.n_snapshots - 1;
+        zkw_vm_instance* d_inst = nullptr;
+        ST_TRY(B->alloc(&d_inst, ni));
+        ST_ZKW(zkw_vm_slice_instances(B->ctx[C_PRE], &d, d_inst, nullptr, nullptr, nullptr, nullptr));
+        ST_ZKW(zkw_synchronize(B->ctx[C_PRE]));
+        B->vm_instances.resize(ni);
+        ST_TRY(B->xf[X_MAIN].d2h(B->vm_instances.data(), d_inst, ni * sizeof(zkw_vm_instance)));
+    }
+
     // 4. public inputs and one recursion queue per circuit type (postprocessing/mod.rs:353-405), all queues in one launch
     {
         Timed t(B, "recursion_queues");
@@ -545,6 +581,7 @@ extern "C" zkw_ctx* zkw_block_context(const zkw_block* B, uint8_t t) {
 extern "C" size_t zkw_block_num_instances(const zkw_block* B, uint8_t t) {
     if (!B) return 0;
     switch (t) {
+        case T_VM: return B->vm_instances.size();
         case T_DEC: return zkw_decommit_witness_num_instances(B->dec);
         case T_DCM: return zkw_decommitter_witness_num_instances(B->dcm);
         case T_DMX: return zkw_demux_witness_num_instances(B->dmx);
@@ -567,6 +604,9 @@ extern "C" const uint64_t* zkw_block_recursion_encodings(const zkw_block* B, uin
 }
 extern "C" const uint64_t* zkw_block_recursion_states(const zkw_block* B, uint8_t t) {
     return B && t < 14 && !B->per[t].states.empty() ? B->per[t].states.data() : nullptr;
+}
+extern "C" const zkw_vm_instance* zkw_block_vm_instances(const zkw_block* B) {
+    return B && !B->vm_instances.empty() ? B->vm_instances.data() : nullptr;
 }
 extern "C" size_t zkw_block_memory_queue_length(const zkw_block* B) { return B ? B->n_mem : 0; }
 extern "C" const zkw_mem_query* zkw_block_memory_queue_device_ptr(const zkw_block* B) { return B ? B->d_all_mem : nullptr; }

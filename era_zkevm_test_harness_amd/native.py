@@ -145,6 +145,7 @@ SYMBOLS = [
     ("zkw_block_public_inputs", _vp, [_vp, C.c_uint8]),
     ("zkw_block_recursion_encodings", _vp, [_vp, C.c_uint8]),
     ("zkw_block_recursion_states", _vp, [_vp, C.c_uint8]),
+    ("zkw_block_vm_instances", _vp, [_vp]),
     ("zkw_block_memory_queue_length", _sz, [_vp]),
     ("zkw_block_memory_queue_device_ptr", _vp, [_vp]),
     ("zkw_block_memory_queue_state", _int, [_vp, _vp]),
@@ -1172,7 +1173,7 @@ class BlockInputs(C.Structure):
                 ("num_non_deterministic_heap_queries", C.c_uint32),
                 ("storage_tree", STORAGE_TREE_FN), ("storage_tree_user", C.c_void_p),
                 ("storage_initial_root", C.c_uint8 * 32), ("storage_initial_next_enumeration_index", C.c_uint64),
-                ("capacities", C.c_uint32 * 14)]
+                ("capacities", C.c_uint32 * 14), ("vm_tracer", C.c_void_p)]
 
 
 class Block:
@@ -1186,7 +1187,7 @@ class Block:
                        10: "zkw_storage_application_witness", 11: "zkw_events_witness", 12: "zkw_events_witness"}
 
     def __init__(self, device_id, block, capacities=None, storage_tree=None, storage_initial_root=None,
-                 storage_next_enumeration_index=0, num_non_deterministic_heap_queries=0):
+                 storage_next_enumeration_index=0, num_non_deterministic_heap_queries=0, vm_tracer=None):
         lib = load()
         inp = BlockInputs()
         keep = []
@@ -1232,6 +1233,13 @@ class Block:
             for i in range(32):
                 inp.storage_initial_root[i] = int(root[i])
             inp.storage_initial_next_enumeration_index = storage_next_enumeration_index
+        if vm_tracer is not None:  # the tracer's cycle-stamped vectors: MainVM instance records come back with the block
+            t = dict(vm_tracer)
+            t.setdefault("vm_memory_queries", vm)              # ignored by the block (it uses its own memory queue / states)
+            t.setdefault("memory_queue_tails", np.zeros((vm.size, 12), np.uint64))
+            t.setdefault("decommit_queue_tails", np.zeros((dq.size, 12), np.uint64))
+            self._vm_struct = _vm_streams_struct(t, keep)
+            inp.vm_tracer = C.addressof(self._vm_struct)
         self.capacities = {t: int(circuit_geometry(t)["capacity"]) for t in range(1, 14)}
         for t, c in (capacities or {}).items():
             inp.capacities[t] = c
@@ -1271,6 +1279,14 @@ class Block:
         if not p:
             return None
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), (n, width)).copy()
+
+    def vm_instances(self):
+        """MainVM instance records (VM_INSTANCE) when the block was given the tracer's vectors, else None"""
+        p = load().zkw_block_vm_instances(self.handle)
+        n = self.num_instances(1)
+        if not p or not n:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n * VM_INSTANCE.itemsize,)).view(VM_INSTANCE).copy()
 
     def public_inputs(self, t):
         return self._host_u64(load().zkw_block_public_inputs, t, 4)

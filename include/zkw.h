@@ -621,6 +621,11 @@ typedef struct zkw_block_inputs {
     uint8_t storage_initial_root[32];
     uint64_t storage_initial_next_enumeration_index;
     uint32_t capacities[14];                     /* per BaseLayerCircuitType; 0 = geometry_config.rs default */
+    /* optional (NULL = no MainVM records): the tracer's cycle-stamped vectors for the MainVM instance slicing
+       (zkw_vm_slice_instances). HOST pointers. stream_len[ZKW_VMS_MEMORY] must equal n_vm_memory_queries and
+       n_decommit_states must equal n_decommit_queries: the block supplies vm_memory_queries, memory_queue_tails and
+       decommit_queue_tails itself, from the states it has just hashed (the fields of the same name are ignored). */
+    const zkw_vm_tracer_streams *vm_tracer;
 } zkw_block_inputs;
 /* All pointers in `in` are HOST pointers. Blocks until every builder has finished. */
 int zkw_block_run(int device_id, const zkw_block_inputs *in, zkw_block **out);
@@ -641,6 +646,8 @@ size_t zkw_block_num_instances(const zkw_block *b, uint8_t circuit_type);
 const uint64_t *zkw_block_public_inputs(const zkw_block *b, uint8_t circuit_type);
 const uint64_t *zkw_block_recursion_encodings(const zkw_block *b, uint8_t circuit_type);
 const uint64_t *zkw_block_recursion_states(const zkw_block *b, uint8_t circuit_type);
+/* MainVM instance records (zkw_vm_instance[zkw_block_num_instances(b, 1)], host) when vm_tracer was given, else NULL */
+const zkw_vm_instance *zkw_block_vm_instances(const zkw_block *b);
 /* the whole memory queue the RAM permutation saw, its final state, the six demuxed queue offsets, the L1 messages
    pubdata hash (compute_linear_keccak256) */
 size_t zkw_block_memory_queue_length(const zkw_block *b);

@@ -214,3 +214,32 @@ def test_block_sharded_synthesis_and_gather(ctx):
             assert np.array_equal(r[2:20], cf[int(r[1])])
     comm.destroy()
     B.free()
+
+
+def test_block_with_main_vm_slicing(ctx, oracle):
+    """zkw_block_run given the tracer's cycle-stamped vectors also returns the MainVM instance records: the entry states come
+    from the queues the block itself hashed (VM prefix of the memory queue, unsorted decommit queue); compared with the
+    oracle's slicing over the builder-by-builder path's states"""
+    from era_zkevm_test_harness_amd import block as blk, native as nv
+
+    b = synthetic.block_after_vm(seed=7)
+    caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+    n_vm, n_dec = b["vm_memory_queries"].size, b["decommit_queries"].size
+    t = synthetic.vm_tracer_streams(n_cycles=2000, cycles_per_snapshot=250, seed=11, n_memory=n_vm, sparse=60)
+    rng = np.random.default_rng(12)
+    t["decommit_state_cycles"] = np.sort(rng.integers(0, 2000, n_dec)).astype(np.uint32)
+    B = nv.Block(0, b, caps, vm_tracer=t)
+    got = B.vm_instances()
+    assert got is not None and got.size == t["snapshot_cycles"].size - 1 == B.num_instances(blk.MAIN_VM)
+    a = blk.create_artifacts_after_vm(ctx, b, caps)
+    t_ref = dict(t)
+    t_ref["vm_memory_queries"] = b["vm_memory_queries"]
+    t_ref["memory_queue_tails"] = a["witnesses"]["ram_permutation"].get(nv.RAM_UNSORTED_TAILS)[:n_vm]
+    t_ref["decommit_queue_tails"] = a["witnesses"]["decommits_sorter"].get(nv.DEC_UNSORTED_TAILS)
+    exp, _, _ = oracle.vm_slice_instances(t_ref)
+    assert got.tobytes() == exp.tobytes()
+    assert int(got[-1]["memory_queue_final_state"]["length"]) == n_vm and int(got[-1]["decommitment_queue_final_state"]["length"]) == n_dec
+    B.free()
+    for wit in a["witnesses"].values():
+        wit.free()
