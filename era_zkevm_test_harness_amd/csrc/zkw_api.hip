@@ -8,7 +8,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 #include <cstdarg>
 #include <cstdio>
@@ -91,6 +95,7 @@ struct zkw_ctx {
     // witnesses and traces created from this context keep it alive: zkw_destroy defers while any is outstanding
     std::atomic<long> children{0};
     std::atomic<bool> destroy_requested{false};
+    bool chain_service = false;  // queue chains go to the device's chain service (batched with other contexts' chains)
     int chain_form = 0;  // lanes per Poseidon2 state in the queue-chain kernel: 4 (quad), 16 (row), 0 = auto
     std::map<std::string, DevBuf> pool;  // named grow-only scratch
     std::map<std::string, HostStage> stages;
@@ -475,6 +480,170 @@ extern "C" int zkw_profile_names(zkw_ctx* ctx, char* buf, size_t buf_bytes) {
     return ZKW_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ chain service
+// Many contexts, few launches. A queue chain is serial — microseconds per item on ONE wave — and a launch of n chains costs
+// what its longest chain costs as long as every wave has a SIMD to itself (4 096 chains in the row form). When many blocks
+// are in flight (zkw_blocks_run: K blocks x ~6 builder threads, each with its own context and stream), their chain jobs
+// would be K x 6 long-running one-wave kernels on as many streams: HIP multiplexes streams onto a handful of hardware
+// queues, a queue runs in order, and the launches serialise (measured: 8 concurrent blocks = 1.8 blocks/s, hardly more than
+// one). The service turns them into one launch: a context that opted in (zkw_set_chain_service) synchronises its stream,
+// hands its jobs over and waits; a worker collects whatever arrives within a short window from ALL contexts of the device
+// and launches it as one kernel on a HIGH-PRIORITY stream (HIP gives priority levels their own hardware queues — measured
+// with tools/probe_hw_queues — so the long kernel never sits in front of anybody's short ones). Results are identical:
+// the jobs are the same, only the launch they travel in differs.
+struct ChainService {
+    struct Batch {
+        std::vector<ChainJob> full;
+        std::vector<LogChainJob> log;
+        int waiters = 0;
+        bool done[2] = {false, false};  // [0] full-width chains, [1] log-queue chains
+        int rc = ZKW_OK;
+        std::string err;
+    };
+    int device = 0;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::shared_ptr<Batch> open;   // the batch that still accepts jobs
+    std::chrono::steady_clock::time_point open_since, last_arrival;
+    std::vector<std::thread> workers;
+    bool stop = false;
+
+    explicit ChainService(int dev) : device(dev) {
+        for (int i = 0; i < 4; i++) workers.emplace_back([this] { run(); });
+    }
+    ~ChainService() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    int submit(const std::vector<ChainJob>* full, const std::vector<LogChainJob>* log, std::string* err) {
+        std::shared_ptr<Batch> b;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (!open) { open = std::make_shared<Batch>(); open_since = std::chrono::steady_clock::now(); }
+            b = open;
+            if (full) b->full.insert(b->full.end(), full->begin(), full->end());
+            if (log) b->log.insert(b->log.end(), log->begin(), log->end());
+            b->waiters++;
+            last_arrival = std::chrono::steady_clock::now();
+            cv_work.notify_one();
+            const int kind = full ? 0 : 1;
+            cv_done.wait(lk, [&] { return b->done[kind]; });
+        }
+        if (b->rc != ZKW_OK && err) *err = b->err;
+        return b->rc;
+    }
+    void run() {
+        (void)hipSetDevice(device);
+        hipStream_t st = nullptr, st_log = nullptr;  // the two kinds of chains of a batch run side by side, not one after the other
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) st = nullptr;
+        if (hipStreamCreateWithPriority(&st_log, hipStreamNonBlocking, hi) != hipSuccess) st_log = nullptr;
+        void* pin = nullptr;
+        void* dev = nullptr;
+        size_t cap = 0;
+        for (;;) {
+            std::shared_ptr<Batch> b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || open; });
+                if (stop) break;
+                // batching window: launch when nothing has arrived for 400 us, or 4 ms after the first job
+                for (;;) {
+                    const auto now = std::chrono::steady_clock::now();
+                    if (!open) break;  // another worker took it
+                    if (now - last_arrival >= std::chrono::microseconds(400) || now - open_since >= std::chrono::milliseconds(4)) break;
+                    cv_work.wait_for(lk, std::chrono::microseconds(200));
+                    if (stop) break;
+                }
+                if (stop) break;
+                if (!open) continue;
+                b = open;
+                open.reset();
+            }
+            int rc = ZKW_OK;
+            std::string err;
+            auto fail_hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == ZKW_OK) { rc = ZKW_ERR_HIP; err = std::string(what) + ": " + hipGetErrorString(e); } };
+            const size_t bytes = b->full.size() * sizeof(ChainJob) + b->log.size() * sizeof(LogChainJob) + 256;
+            if (!st || !st_log) { rc = ZKW_ERR_HIP; err = "chain service: no stream"; }
+            if (rc == ZKW_OK && cap < bytes) {  // grow-only; freed with the service (hipFree would stall the device)
+                const size_t want = bytes * 2;
+                void *np = nullptr, *nd = nullptr;
+                fail_hip(hipHostMalloc(&np, want, hipHostMallocDefault), "hipHostMalloc");
+                if (rc == ZKW_OK) fail_hip(hipMalloc(&nd, want), "hipMalloc");
+                if (rc == ZKW_OK) { pin = np; dev = nd; cap = want; }
+            }
+            if (rc == ZKW_OK) {
+                char* hp = static_cast<char*>(pin);
+                char* dp = static_cast<char*>(dev);
+                const size_t off_log = (b->full.size() * sizeof(ChainJob) + 127) & ~(size_t)127;
+                if (!b->full.empty()) memcpy(hp, b->full.data(), b->full.size() * sizeof(ChainJob));
+                if (!b->log.empty()) memcpy(hp + off_log, b->log.data(), b->log.size() * sizeof(LogChainJob));
+                fail_hip(hipMemcpyAsync(dp, hp, off_log + b->log.size() * sizeof(LogChainJob), hipMemcpyHostToDevice, st), "job upload");
+                fail_hip(hipStreamSynchronize(st), "job upload");
+                const int nf = (int)b->full.size(), nl = (int)b->log.size();
+                if (rc == ZKW_OK && nl) hipLaunchKernelGGL(k_chain_log, dim3((nl + 3) / 4), dim3(64), 0, st_log, reinterpret_cast<const LogChainJob*>(dp + off_log), nl);
+                if (rc == ZKW_OK && nf) {
+                    if (nf >= 4096) hipLaunchKernelGGL(k_chain_full_q4, dim3((nf + 15) / 16), dim3(64), 0, st, reinterpret_cast<const ChainJob*>(dp), nf);
+                    else hipLaunchKernelGGL(k_chain_full, dim3((nf + 3) / 4), dim3(64), 0, st, reinterpret_cast<const ChainJob*>(dp), nf);
+                }
+                fail_hip(hipGetLastError(), "chain launch");
+                fail_hip(hipStreamSynchronize(st_log), "chain batch (log queues)");
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    if (rc != ZKW_OK) { b->rc = rc; b->err = err; }
+                    b->done[1] = true;
+                }
+                cv_done.notify_all();
+                fail_hip(hipStreamSynchronize(st), "chain batch");
+            }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (rc != ZKW_OK) { b->rc = rc; b->err = err; }
+                b->done[0] = b->done[1] = true;
+            }
+            cv_done.notify_all();
+        }
+        if (st) (void)hipStreamDestroy(st);
+        if (st_log) (void)hipStreamDestroy(st_log);
+    }
+};
+static std::mutex g_chain_services_mu;
+static std::map<int, std::unique_ptr<ChainService>> g_chain_services;
+// One service per device. A batch carries both kinds of chains (full-width queues, log queues) as two kernels on two streams
+// and completes per kind: a short log-queue chain does not wait for a long memory-queue chain that arrived in the same
+// window. Keeping the kinds in ONE batch (rather than one service per kind) matters: fewer concurrent one-wave kernels,
+// fewer chances that the dispatcher parks two of them on the same SIMD (each then runs 1.4x slower; measured).
+static ChainService* chain_service_of(int device) {
+    std::lock_guard<std::mutex> g(g_chain_services_mu);
+    auto& p = g_chain_services[device];
+    if (!p) p.reset(new ChainService(device));
+    return p.get();
+}
+
+extern "C" int zkw_set_chain_service(zkw_ctx* ctx, int on) {
+    if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
+    ctx->chain_service = on != 0;
+    if (on) (void)chain_service_of(ctx->device);
+    return ZKW_OK;
+}
+
+// hand the chains of one builder call over to the service and wait for them
+static int chain_service_run(zkw_ctx* ctx, const std::vector<ChainJob>* full, const std::vector<LogChainJob>* log, const char* name) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the jobs' inputs are produced on this context's stream
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string err;
+    const int rc = chain_service_of(ctx->device)->submit(full, log, &err);
+    if (ctx->profiling) {  // wall time spent waiting for the shared launch (no HIP events: it runs on the service's stream)
+        auto& t = ctx->prof_totals[std::string(name) + "(service)"];
+        t.first += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        t.second += 1;
+    }
+    if (rc != ZKW_OK) return fail(rc, "chain service: %s", err.c_str());
+    return ZKW_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ device-level steps
 // (all pointers are device pointers here)
 
@@ -491,6 +660,7 @@ static int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) 
 // concurrent chains), so throughput comes from giving each wave its own SIMD: up to 1024 waves.
 static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     if (jobs.empty()) return ZKW_OK;
+    if (ctx->chain_service) return chain_service_run(ctx, &jobs, nullptr, "k_chain_full");
     ChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("chain_jobs", jobs, &d_jobs));
     int n_jobs = (int)jobs.size();
@@ -700,6 +870,7 @@ static int dev_log_chains(zkw_ctx* ctx, const u64* d_enc, size_t total, std::vec
     { Prof _p(ctx, "k_log_prehash"); hipLaunchKernelGGL(k_log_prehash, dim3(blocks_for(total, 128)), dim3(128), 0, ctx->stream, d_enc, total, d_pre); }
     ZKW_TRY(launch_check("k_log_prehash"));
     for (auto& j : jobs) j.pre = d_pre + (j.enc - d_enc) / 20 * 4;
+    if (ctx->chain_service) return chain_service_run(ctx, nullptr, &jobs, "k_chain_log");
     LogChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("log_chain_jobs", jobs, &d_jobs));
     const int n_jobs = (int)jobs.size();

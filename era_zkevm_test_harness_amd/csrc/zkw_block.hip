@@ -121,6 +121,7 @@ struct zkw_block {
     zkw_ctx* ctx[N_CTX] = {};
     Xfer xf[N_XFER];
     uint32_t cap[14] = {};
+    bool use_chain_service = false;  // zkw_blocks_run: this block's chains travel in launches shared with the other blocks
     Clock::time_point t0;
     std::mutex mu;
     std::vector<Span> spans;
@@ -290,6 +291,7 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
         B->ctx[i] = zkw_create(B->device);
         if (!B->ctx[i]) return from_rc(ZKW_ERR_NO_DEVICE);
         ST_ZKW(zkw_set_pointer_mode(B->ctx[i], ZKW_PTR_DEVICE));
+        if (B->use_chain_service) ST_ZKW(zkw_set_chain_service(B->ctx[i], 1));
         if (getenv("ZKW_BLOCK_PROFILE")) ST_ZKW(zkw_profile_enable(B->ctx[i], 1));
     }
     for (int t = 1; t <= 13; t++) {
@@ -525,6 +527,46 @@ extern "C" int zkw_block_run(int device_id, const zkw_block_inputs* in, zkw_bloc
 }
 
 extern "C" const char* zkw_block_last_error(void) { return g_block_error.c_str(); }
+
+// K blocks at once: one host thread per block runs the same dependency graph, every context opted into the device's chain
+// service, so that the blocks' queue chains — the only long-running work — share a few launches (csrc/zkw_api.hip, "chain
+// service") instead of queueing behind each other on HIP's hardware queues. Throughput of whole blocks, not latency of one.
+extern "C" int zkw_blocks_run(int device_id, const zkw_block_inputs* const* inputs, size_t n_blocks, zkw_block** out) {
+    if (!inputs || !out || n_blocks == 0) return ZKW_ERR_INVALID;
+    for (size_t k = 0; k < n_blocks; k++) {
+        const zkw_block_inputs* in = inputs[k];
+        if (!in || !in->decommit_queries || in->n_decommit_queries == 0 || (in->n_log_queries && !in->log_queries) ||
+            (in->n_vm_memory_queries && !in->vm_memory_queries) || (in->n_bytecodes && (!in->bytecode_hashes || !in->bytecode_words || !in->bytecode_word_offsets)))
+            return ZKW_ERR_INVALID;
+        out[k] = nullptr;
+    }
+    std::vector<zkw_block*> blocks(n_blocks, nullptr);
+    std::vector<std::future<Status>> futs;
+    const Clock::time_point t0 = Clock::now();
+    for (size_t k = 0; k < n_blocks; k++) {
+        zkw_block* B = new zkw_block();
+        B->device = device_id;
+        B->t0 = t0;
+        B->use_chain_service = true;
+        blocks[k] = B;
+        futs.push_back(std::async(std::launch::async, [B, in = inputs[k]] {
+            Timed t(B, "builders");
+            return run(B, in);
+        }));
+    }
+    Status first;
+    for (auto& f : futs) {
+        Status s = f.get();
+        if (!s.ok() && first.ok()) first = s;
+    }
+    if (!first.ok()) {
+        for (zkw_block* B : blocks) zkw_block_free(B);
+        g_block_error = first.msg;
+        return first.rc;
+    }
+    for (size_t k = 0; k < n_blocks; k++) out[k] = blocks[k];
+    return ZKW_OK;
+}
 
 extern "C" void zkw_block_free(zkw_block* B) {
     if (!B) return;

@@ -32,6 +32,7 @@ SYMBOLS = [
     ("zkw_set_pointer_mode", _int, [_vp, _int]),
     ("zkw_synchronize", _int, [_vp]),
     ("zkw_set_chain_form", _int, [_vp, _int]),
+    ("zkw_set_chain_service", _int, [_vp, _int]),
     ("zkw_version", C.c_char_p, []),
     ("zkw_circuit_geometry_of", _int, [C.c_uint8, _vp]),
     ("zkw_circuit_layout_of", _int, [C.c_uint8, _u32, _vp]),
@@ -137,6 +138,7 @@ SYMBOLS = [
     ("zkw_comm_destroy", None, [_vp]),
     ("zkw_gather_closed_form_inputs", _int, [_vp, _vp, _vp, _sz, _int, _vp]),
     ("zkw_block_run", _int, [_int, _vp, C.POINTER(_vp)]),
+    ("zkw_blocks_run", _int, [_int, _vp, _sz, _vp]),
     ("zkw_block_last_error", C.c_char_p, []),
     ("zkw_block_free", None, [_vp]),
     ("zkw_block_witness", _vp, [_vp, C.c_uint8]),
@@ -1187,10 +1189,11 @@ class Block:
                        10: "zkw_storage_application_witness", 11: "zkw_events_witness", 12: "zkw_events_witness"}
 
     def __init__(self, device_id, block, capacities=None, storage_tree=None, storage_initial_root=None,
-                 storage_next_enumeration_index=0, num_non_deterministic_heap_queries=0, vm_tracer=None):
+                 storage_next_enumeration_index=0, num_non_deterministic_heap_queries=0, vm_tracer=None, _run=True):
         lib = load()
         inp = BlockInputs()
         keep = []
+        self._inp = inp
 
         def arr(a, dtype):
             a = np.ascontiguousarray(a, dtype=dtype)
@@ -1245,12 +1248,29 @@ class Block:
             inp.capacities[t] = c
             self.capacities[t] = c
         self.handle = C.c_void_p(None)
+        self._keep = keep
+        if not _run:
+            return
         rc = lib.zkw_block_run(device_id, C.byref(inp), C.byref(self.handle))
         if rc != OK:
             if self._tree_error is not None:
                 raise self._tree_error
             raise ZkwError(rc, (lib.zkw_block_last_error() or b"").decode() or lib.zkw_last_error().decode())
-        self._keep = keep
+
+    @staticmethod
+    def run_many(device_id, blocks, capacities=None):
+        """zkw_blocks_run: the given blocks (dicts as for Block) in flight together, their queue chains merged into shared
+        launches by the chain service. Returns the list of Block objects."""
+        lib = load()
+        objs = [Block(device_id, b, capacities, _run=False) for b in blocks]
+        ptrs = (C.c_void_p * len(objs))(*[C.addressof(o._inp) for o in objs])
+        outs = (C.c_void_p * len(objs))()
+        rc = lib.zkw_blocks_run(device_id, ptrs, len(objs), outs)
+        if rc != OK:
+            raise ZkwError(rc, (lib.zkw_block_last_error() or b"").decode() or lib.zkw_last_error().decode())
+        for o, h in zip(objs, outs):
+            o.handle = C.c_void_p(h)
+        return objs
 
     def num_instances(self, circuit_type):
         return load().zkw_block_num_instances(self.handle, circuit_type)

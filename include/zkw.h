@@ -63,6 +63,11 @@ int zkw_synchronize(zkw_ctx *ctx);
    fewest instructions per permutation, for launches of tens of thousands of queues) or 0 = choose by the number of
    chains in the launch (default). Results are identical. */
 int zkw_set_chain_form(zkw_ctx *ctx, int lanes_per_state);
+/* Opt this context into the device's chain service: its queue-chain jobs are no longer launched on its own stream but
+   handed to a per-device worker that merges the jobs of ALL opted-in contexts arriving within a short window (0.4 - 4 ms)
+   into ONE launch on a high-priority stream, and the call waits for that launch. For hosts that keep many contexts busy
+   at once (zkw_blocks_run): K concurrent builders cost one chain pass instead of K serialised ones. Results are identical. */
+int zkw_set_chain_service(zkw_ctx *ctx, int on);
 /* library/ABI version and the kernels' target ISA ("gfx950") */
 const char *zkw_version(void);
 
@@ -629,6 +634,11 @@ typedef struct zkw_block_inputs {
 } zkw_block_inputs;
 /* All pointers in `in` are HOST pointers. Blocks until every builder has finished. */
 int zkw_block_run(int device_id, const zkw_block_inputs *in, zkw_block **out);
+/* n_blocks independent blocks at once (a witness-generation service's batch): the same graph per block, one host thread
+   each, all queue chains of all blocks merged into a few launches by the device's chain service (zkw_set_chain_service):
+   K blocks cost about one block's chain pass while SIMDs and memory last. out[k] receives block k; on failure every block
+   is released and out[] is all NULL. */
+int zkw_blocks_run(int device_id, const zkw_block_inputs *const *inputs, size_t n_blocks, zkw_block **out);
 /* message of the last failed zkw_block_run on this thread (its builders run on worker threads, whose zkw_last_error
    is not the caller's) */
 const char *zkw_block_last_error(void);

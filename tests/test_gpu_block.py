@@ -243,3 +243,36 @@ def test_block_with_main_vm_slicing(ctx, oracle):
     B.free()
     for wit in a["witnesses"].values():
         wit.free()
+
+
+def test_blocks_run_many_at_once(ctx, oracle):
+    """zkw_blocks_run: several different blocks in flight together, every context on the chain service (their queue chains
+    travel in shared launches): each block's records equal what zkw_block_run gives for it alone"""
+    from era_zkevm_test_harness_amd import block as blk, native as nv
+
+    caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+    bs = [synthetic.block_after_vm(seed=20 + k, n_vm_memory=1500 + 400 * k, n_storage=60 + 30 * k) for k in range(5)]
+    many = nv.Block.run_many(0, bs, caps)
+    whats = ((blk.RAM_PERMUTATION, nv.RAM_INSTANCES), (blk.DECOMMITS_SORTER, nv.DEC_INSTANCES), (blk.LOG_DEMUXER, nv.DMX_INSTANCES),
+             (blk.STORAGE_SORTER, nv.STO_INSTANCES), (blk.EVENTS_SORTER, nv.EVT_INSTANCES), (blk.CODE_DECOMMITTER, nv.DCM_INSTANCES),
+             (blk.SHA256, nv.PRC_INSTANCES))
+    for b, m in zip(bs, many):
+        one = nv.Block(0, b, caps)
+        assert m.memory_queue_state().tobytes() == one.memory_queue_state().tobytes()
+        for t, w in whats:
+            assert m.witness_get(t, w, np.uint8).tobytes() == one.witness_get(t, w, np.uint8).tobytes(), t
+        for t in (2, 4, 8, 9, 11, 12):
+            assert np.array_equal(m.public_inputs(t), one.public_inputs(t))
+            assert np.array_equal(m.recursion_queue(t)[1], one.recursion_queue(t)[1])
+        bad = []
+        n = m.synthesize(1 << 15, ring_slots=2, callback=lambda t, i, tr, s, pi: bad.append(m.check_satisfied(t, tr, s)[0]))
+        assert n == len(bad) > 10 and not any(bad)
+        one.free()
+    # the oracle agrees with one of them end to end (public inputs of the RAM permutation)
+    a = blk.create_artifacts_after_vm(ctx, bs[2], caps)
+    assert np.array_equal(many[2].public_inputs(blk.RAM_PERMUTATION), a["public_inputs"][blk.RAM_PERMUTATION])
+    for wit in a["witnesses"].values():
+        wit.free()
+    for m in many:
+        m.free()
