@@ -21,8 +21,11 @@ using gl::u64;
 constexpr u32 STACK_NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void encode_callstack_entry(const zkw_callstack_entry& e, u64 o[32]) {
+#pragma unroll
     for (int k = 0; k < 4; k++) { o[k] = e.rollback_queue_head[k]; o[4 + k] = e.rollback_queue_tail[k]; }
+#pragma unroll
     for (int k = 0; k < 5; k++) { o[8 + k] = e.code_address[k]; o[13 + k] = e.this_address[k]; o[18 + k] = e.msg_sender[k]; }
+#pragma unroll
     for (int k = 0; k < 4; k++) o[23 + k] = e.context_u128_value[k];
     const u32* a = e.this_address;
     const u64 kernel = (a[4] | a[3] | a[2] | a[1]) == 0 && a[0] < (1u << 16);
@@ -131,13 +134,18 @@ __global__ __launch_bounds__(64) void k_stack_level(const zkw_callstack_entry* _
                                                     u64* __restrict__ rounds) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= meta[0] || push_depth[k] != d) return;
-    u64 enc[32], s[12];
+    __shared__ u64 sh_enc[64 * 32];  // a slice of LDS per lane instead of a per-lane array in scratch memory
+    u64* enc = sh_enc + 32 * threadIdx.x;
+    u64 s[12];
     encode_callstack_entry(pushed[k], enc);
     const u32 par = parent[k];
+#pragma unroll
     for (int j = 0; j < 12; j++) s[j] = par == STACK_NONE ? 0 : rounds[(size_t)48 * par + 36 + j];
     for (int r = 0; r < 4; r++) {
+#pragma unroll
         for (int j = 0; j < 8; j++) s[j] = enc[8 * r + j];
         p2::permute(s);
+#pragma unroll
         for (int j = 0; j < 12; j++) { s[j] = gl::canon(s[j]); rounds[(size_t)48 * k + 12 * r + j] = s[j]; }
     }
 }

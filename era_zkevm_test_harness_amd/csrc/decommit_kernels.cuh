@@ -133,11 +133,11 @@ __device__ __forceinline__ void dedup_state_at(const DecommitBlock& b, u32 cnt, 
 }
 
 __global__ void k_decommit_instances(const DecommitBlock* __restrict__ blk) {
-    const DecommitBlock b = *blk;
+    const DecommitBlock& b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_inst) return;
-    zkw_decommit_sorter_instance w;
+    zkw_decommit_sorter_instance& w = b.instances[idx];  // filled in place: a local copy would live in scratch memory
     memset(&w, 0, sizeof w);
     const u64 lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n;
     w.start_flag = idx == 0;
@@ -171,7 +171,6 @@ __global__ void k_decommit_instances(const DecommitBlock* __restrict__ blk) {
     };
     if (idx > 0) fill(w.hidden_fsm_input, lo);
     fill(w.hidden_fsm_output, hi);
-    b.instances[idx] = w;
 }
 
 }  // namespace zkw

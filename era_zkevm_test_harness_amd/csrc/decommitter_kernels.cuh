@@ -126,7 +126,7 @@ struct DecommitterBlock {
 };
 
 __global__ void k_decommitter_instances(const DecommitterBlock* __restrict__ blk) {
-    const DecommitterBlock b = *blk;
+    const DecommitterBlock& b = *blk;
     const u64 n_inst = (b.total_rounds + b.capacity - 1) / b.capacity, nreq = b.job.n_requests;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_inst) return;
@@ -159,7 +159,7 @@ __global__ void k_decommitter_instances(const DecommitterBlock* __restrict__ blk
         f.finished = all_done ? 1 : 0;
         f._pad = 0;
     };
-    zkw_decommitter_instance w;
+    zkw_decommitter_instance& w = b.instances[idx];  // filled in place: a local copy would live in scratch memory
     memset(&w, 0, sizeof w);
     const u64 lo = idx * b.capacity, hi = lo + b.capacity < b.total_rounds ? lo + b.capacity : b.total_rounds;
     u64 p0 = 0, w0 = 0, p1 = 0, w1 = 0;
@@ -179,7 +179,6 @@ __global__ void k_decommitter_instances(const DecommitterBlock* __restrict__ blk
         w.completion_flag = 1;
         w.memory_queue_final_state = w.hidden_fsm_output.memory_queue_state;
     }
-    b.instances[idx] = w;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -118,7 +118,7 @@ __global__ void k_demux_instances(const DemuxBlock* __restrict__ blk) {
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_inst) return;
-    zkw_log_demux_instance w;
+    zkw_log_demux_instance& w = b.instances[idx];  // filled in place: a local copy would live in scratch memory
     memset(&w, 0, sizeof w);
     const u64 lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n;
     w.start_flag = idx == 0;
@@ -138,7 +138,6 @@ __global__ void k_demux_instances(const DemuxBlock* __restrict__ blk) {
     fill(w.hidden_fsm_output, hi);
     if (idx == n_inst - 1)
         for (int c = 0; c < 6; c++) w.output_queue_state[c] = w.hidden_fsm_output.queue_state[c];
-    b.instances[idx] = w;
 }
 
 }  // namespace zkw

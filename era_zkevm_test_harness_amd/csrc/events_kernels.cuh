@@ -140,11 +140,11 @@ __device__ __forceinline__ void qs4(zkw_queue_state4& s, const u64* head, const 
 }
 
 __global__ void k_events_instances(const EventsBlock* __restrict__ blk) {
-    const EventsBlock b = *blk;
+    const EventsBlock& b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_inst) return;
-    zkw_events_sorter_instance w;
+    zkw_events_sorter_instance& w = b.instances[idx];  // filled in place: a local copy would live in scratch memory
     memset(&w, 0, sizeof w);
     const u64 lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n;
     w.start_flag = idx == 0;
@@ -182,7 +182,6 @@ __global__ void k_events_instances(const EventsBlock* __restrict__ blk) {
         memset(&w.hidden_fsm_output.previous_item, 0, sizeof(zkw_log_query));
     }
     if (idx == n_inst - 1) result_at(n, w.final_queue_state);
-    b.instances[idx] = w;
 }
 
 }  // namespace zkw

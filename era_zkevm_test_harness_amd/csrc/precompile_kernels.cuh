@@ -149,7 +149,11 @@ __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
     u32 sha[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     u64 kst[25];
     for (int i = 0; i < 25; i++) kst[i] = 0;
-    uint8_t buf[ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE];
+    // Per-lane arrays with run-time indices would live in scratch memory, which every HSA queue that ran the kernel then
+    // holds for every wave slot of the chip: the byte buffer is a slice of LDS, the FSM snapshot is
+    // written in place, bytes of a memory word are picked out of its limbs.
+    __shared__ uint8_t sh_buf[64][ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE];
+    uint8_t* buf = sh_buf[threadIdx.x];
     for (int i = 0; i < ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE; i++) buf[i] = 0;
     u32 filled = 0;
     const u32 padding_space = abi.input_memory_length % 136;
@@ -189,14 +193,16 @@ __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
                 bad |= q->rw_flag | (q->index != memory_index);
                 abi.input_memory_offset += meaningful;
                 abi.input_memory_length -= meaningful;
-                uint8_t be[32];
-                word_be_bytes(q->value, be);
                 qpos++; reads++;
-                for (u32 j = 0; j < meaningful; j++) buf[filled + j] = be[unalignment + j];
+                for (u32 j = 0; j < meaningful; j++) {  // byte x of U256::to_big_endian
+                    const u32 x = unalignment + j;
+                    buf[filled + j] = (uint8_t)(q->value[7 - (x >> 2)] >> (8 * (3 - (x & 3))));
+                }
                 filled += meaningful;
             }
             // consume::<136>, padding applied to the copy
             u64 lanes[17];
+#pragma unroll
             for (int k = 0; k < 17; k++) {
                 u64 l = 0;
                 for (int b = 0; b < 8; b++) l |= (u64)buf[8 * k + b] << (8 * b);
@@ -209,9 +215,11 @@ __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
                 const u32 at = needs_extra_padding_round ? 0 : padding_space;
                 // block[at] = 0x01 (or 0x81 when at == 135), block[135] = 0x80: the bytes being replaced are zero
                 // because the buffer is zero beyond `filled`
-                lanes[at >> 3] |= (u64)0x01 << (8 * (at & 7));
+#pragma unroll
+                for (int k = 0; k < 17; k++) lanes[k] |= k == (int)(at >> 3) ? (u64)0x01 << (8 * (at & 7)) : 0;
                 lanes[16] |= (u64)0x80 << 56;
             }
+#pragma unroll
             for (int k = 0; k < 17; k++) kst[k] ^= lanes[k];
             keccak_f1600(kst);
             if (state == 1 && needs_extra_padding_round && round + 2 == num_rounds) state = 2;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
         if (!cut) continue;
         const bool early_termination = (g + 1) % job.capacity != 0;
         PrecompileSnap* sn = job.snaps + g / job.capacity;
-        zkw_precompile_fsm f;
+        zkw_precompile_fsm& f = sn->fsm;
         memset(&f, 0, sizeof f);
         if (kind != ZKW_PRECOMPILE_ECRECOVER) {
             f.completed = state == 3; f.read_words_for_round = state == 1; f.read_precompile_call = state == 0;
@@ -263,7 +271,6 @@ __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
                 }
             }
         }
-        sn->fsm = f;
         sn->popped = r + 1;
         sn->queries_done = qpos;
         sn->reads_done = reads;
@@ -283,7 +290,7 @@ struct PrecompileBlock {
 };
 
 __global__ void k_precompile_instances(const PrecompileBlock* __restrict__ blk) {
-    const PrecompileBlock b = *blk;
+    const PrecompileBlock& b = *blk;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= b.n_instances) return;
     const u64* req_final = b.n_requests ? b.req_tails + 4 * (b.n_requests - 1) : nullptr;
@@ -292,7 +299,7 @@ __global__ void k_precompile_instances(const PrecompileBlock* __restrict__ blk) 
         qs12(f.memory_queue_state, b.mem_in.head, queries_done ? b.mem_tails + 12 * (queries_done - 1) : b.mem_in.tail,
              b.mem_in.length + (u32)queries_done);
     };
-    zkw_precompile_instance w;
+    zkw_precompile_instance& w = b.instances[idx];  // filled in place: a local copy would live in scratch memory
     memset(&w, 0, sizeof w);
     if (b.n_requests == 0) {  // the dummy instance (keccak :88-157, sha256 :82-150, ecrecover :60-103)
         w.start_flag = w.completion_flag = 1;
@@ -318,10 +325,9 @@ __global__ void k_precompile_instances(const PrecompileBlock* __restrict__ blk) 
                         w.hidden_fsm_output.keccak_internal_state[((id % 5) * 5 + id / 5) * 8 + by] = (uint8_t)(e[id] >> (8 * by));
             }
         }
-        b.instances[0] = w;
         return;
     }
-    const PrecompileSnap out = b.snaps[idx];
+    const PrecompileSnap& out = b.snaps[idx];
     u64 p0 = 0, q0 = 0, r0 = 0;
     w.start_flag = idx == 0;
     if (idx == 0) {
@@ -329,7 +335,7 @@ __global__ void k_precompile_instances(const PrecompileBlock* __restrict__ blk) 
         qs4(w.initial_log_queue_state, nullptr, req_final, (u32)b.n_requests);
         w.initial_memory_queue_state = b.mem_in;
     } else {
-        const PrecompileSnap in = b.snaps[idx - 1];
+        const PrecompileSnap& in = b.snaps[idx - 1];
         w.hidden_fsm_input = in.fsm;
         p0 = in.popped; q0 = in.queries_done; r0 = in.reads_done;
     }
@@ -344,7 +350,6 @@ __global__ void k_precompile_instances(const PrecompileBlock* __restrict__ blk) 
         w.completion_flag = 1;
         w.final_memory_state = w.hidden_fsm_output.memory_queue_state;
     }
-    b.instances[idx] = w;
 }
 
 }  // namespace zkw

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(64) void k_ram_commitments(const zkw_ram_instance* 
     const int part = (int)(t & 3);
     if (i >= n) return;
     u64* cf = compact + COMPACT_FORM_LEN * i;
-    u64 buf[RAM_FSM_ENC_LEN];
+    __shared__ u64 sh_buf[64 * RAM_FSM_ENC_LEN];  // in LDS, one slice per lane: a run-time-indexed per-lane array would live in scratch memory
+    u64* buf = sh_buf + threadIdx.x * RAM_FSM_ENC_LEN;
     u64 c[4];
     if (part == 1) {
         cf[0] = inst[i].start_flag ? 1 : 0;
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(64) void k_ds_commitments(const zkw_decommit_sorter
     const int part = (int)(t & 3);
     if (i >= n) return;
     u64* cf = compact + COMPACT_FORM_LEN * i;
-    u64 buf[DS_FSM_ENC_LEN];
+    __shared__ u64 sh_buf[64 * DS_FSM_ENC_LEN];  // in LDS, one slice per lane: a run-time-indexed per-lane array would live in scratch memory
+    u64* buf = sh_buf + threadIdx.x * DS_FSM_ENC_LEN;
     u64 c[4];
     int m;
     if (part == 0) {
@@ -243,7 +245,8 @@ __global__ __launch_bounds__(64) void k_closed_form_commitments(const typename T
     const int part = (int)(t & 3);
     if (i >= n) return;
     u64* cf = compact + COMPACT_FORM_LEN * i;
-    u64 buf[T::MAXLEN];
+    __shared__ u64 sh_buf[64 * T::MAXLEN];  // in LDS, one slice per lane: a run-time-indexed per-lane array would live in scratch memory
+    u64* buf = sh_buf + threadIdx.x * T::MAXLEN;
     u64 c[4];
     int m;
     if (part == 0) {  // the observable input is the one of the block's first instance (postprocessing/mod.rs:358-364)

@@ -655,9 +655,9 @@ __global__ __launch_bounds__(64) void k_check_rows(const u64* __restrict__ trace
         const rc_constraint cn = S::cons()[k];
         u64 acc = 0;
         for (int t = 0; t < cn.n_terms; t++) {
-            const rc_term tm = S::terms()[cn.first_term + t];
-            u64 v = tm.coef;
-            for (int f = 0; f < tm.nf; f++) v = gl::mul(v, CELLV(tm.f[f]));
+            const rc_term* tm = &S::terms()[cn.first_term + t];  // read in place: a local copy indexed by f would live in scratch
+            u64 v = tm->coef;
+            for (int f = 0; f < tm->nf; f++) v = gl::mul(v, CELLV(tm->f[f]));
             acc = gl::add(acc, v);
         }
         if (gl::canon(acc) != 0) flag_bad(res, 1, k, row);

@@ -333,26 +333,29 @@ struct FsJob {
     u64* out;           // [2][n_chal]
 };
 
+// No per-lane arrays with run-time indices: they would live in scratch memory, and every HSA queue that ever ran the
+// kernel keeps scratch-per-lane x every wave slot of the chip (117 MB for 224 B per lane) out of the runtime's 4 GB
+// scratch aperture; with 32 hardware queues in use that exhausted it (HSA_STATUS_ERROR_OUT_OF_RESOURCES).
 __global__ void k_fs_challenges(const FsJob* __restrict__ jobs, int n_jobs, int state_w, int n_chal) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_jobs) return;
-    FsJob job = jobs[j];
-    u64 fs[26];
-    int m = 0;
-    for (int i = 0; i < state_w; i++) fs[m++] = job.tail_u[i];
-    fs[m++] = job.len_u;  // < p
-    for (int i = 0; i < state_w; i++) fs[m++] = job.tail_s[i];
-    fs[m++] = job.len_s;
+    const FsJob job = jobs[j];
+    const int m = 2 * state_w + 2;
+    // element e of the transcript: tail_u, len_u, tail_s, len_s
+    auto elem = [&](int e) -> u64 {
+        if (e >= m) return 0;
+        if (e < state_w) return job.tail_u[e];
+        if (e == state_w) return job.len_u;  // < p
+        if (e < 2 * state_w + 1) return job.tail_s[e - state_w - 1];
+        return job.len_s;
+    };
     u64 s[12];
+#pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
     s[11] = (u64)m;  // specialize_for_len
-    int i = 0;
-    for (; i + 8 <= m; i += 8) {
-        for (int k = 0; k < 8; k++) s[k] = fs[i + k];
-        p2::permute(s);
-    }
-    if (i < m) {
-        for (int k = 0; k < 8; k++) s[k] = (i + k < m) ? fs[i + k] : 0;
+    for (int i = 0; i < m; i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = elem(i + k);
         p2::permute(s);
     }
     int can_take = 8;
@@ -360,7 +363,10 @@ __global__ void k_fs_challenges(const FsJob* __restrict__ jobs, int n_jobs, int 
         job.out[rep * n_chal] = 1;
         for (int k = 1; k < n_chal; k++) {
             if (can_take == 0) { p2::permute(s); can_take = 8; }
-            job.out[rep * n_chal + k] = gl::canon(s[8 - can_take]);
+            u64 v = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) v = (q == 8 - can_take) ? s[q] : v;
+            job.out[rep * n_chal + k] = gl::canon(v);
             can_take--;
         }
     }
@@ -594,7 +600,7 @@ __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_inst) return;
     const u64 n = b.n, lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n;
-    zkw_ram_instance w;
+    zkw_ram_instance& w = b.instances[idx];  // filled in place: a local copy would live in scratch memory
     memset(&w, 0, sizeof w);
     w.start_flag = idx == 0;
     w.completion_flag = idx == n_inst - 1;
@@ -641,7 +647,6 @@ __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
         for (int k = 0; k < 8; k++) f.previous_value[k] = 0;
         f.previous_is_ptr = 0;
     }
-    b.instances[idx] = w;
 }
 
 

@@ -353,7 +353,7 @@ __global__ void k_sap_instances(const SapBlock* __restrict__ blk) {
         for (int id = 0; id < 25; id++)
             for (int by = 0; by < 8; by++) dst[((id % 5) * 5 + id / 5) * 8 + by] = st ? (uint8_t)(st[id] >> (8 * by)) : 0;
     };
-    zkw_storage_application_instance w;
+    zkw_storage_application_instance& w = b.instances[c];  // filled in place: a local copy would live in scratch memory
     memset(&w, 0, sizeof w);
     const u64 ne0 = b.job.next_enumeration_index;
     if (n == 0) {  // the dummy instance, :69-132
@@ -365,7 +365,6 @@ __global__ void k_sap_instances(const SapBlock* __restrict__ blk) {
         w.new_next_enumeration_counter[0] = (u32)ne0; w.new_next_enumeration_counter[1] = (u32)(ne0 >> 32);
         sap_bytes32(w.new_root_hash, b.job.initial_root);
         for (int k = 0; k < 32; k++) w.state_diffs_keccak256_hash[k] = b.final_hash[k];
-        b.instances[0] = w;
         return;
     }
     const u64 lo = c ? b.job.chunk_end[c - 1] : 0, hi = b.job.chunk_end[c];
@@ -388,7 +387,6 @@ __global__ void k_sap_instances(const SapBlock* __restrict__ blk) {
     }
     w.first_item = lo;
     w.num_items = hi - lo;
-    b.instances[c] = w;
 }
 
 }  // namespace zkw

@@ -196,7 +196,7 @@ __global__ void k_storage_instances(const StorageBlock* __restrict__ blk) {
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_inst) return;
-    zkw_storage_sorter_instance w;
+    zkw_storage_sorter_instance& w = b.instances[idx];  // filled in place: a local copy would live in scratch memory
     memset(&w, 0, sizeof w);
     const u64 lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n;
     const bool is_last = idx == n_inst - 1;
@@ -248,7 +248,6 @@ __global__ void k_storage_instances(const StorageBlock* __restrict__ blk) {
         fo.this_cell_has_explicit_read_and_rollback_depth_zero = 0;
     }
     if (is_last) result_at(n, w.final_sorted_queue_state);
-    b.instances[idx] = w;
 }
 
 }  // namespace zkw

@@ -126,7 +126,7 @@ __device__ void vm_aux_at(const zkw_vm_tracer_streams& s, u32 at_cycle, bool fin
     }
     const u64 l = final_of_block ? s.n_storage_log_states : vm_lower_bound(s.storage_log_state_cycles, s.n_storage_log_states, at_cycle);
     if (l) {
-        const zkw_storage_log_detailed_state st = s.storage_log_states[l - 1];
+        const zkw_storage_log_detailed_state& st = s.storage_log_states[l - 1];
         for (int j = 0; j < 4; j++) {
             a->storage_log_queue_state.tail[j] = st.forward_tail[j];
             a->current_frame_rollback_queue_tail[j] = st.rollback_tail[j];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64) void k_vm_slice(VmSliceJob job) {
     const u64 n_inst = s.n_snapshots - 1;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_inst) return;
-    zkw_vm_instance v;
+    zkw_vm_instance& v = job.out[i];  // filled in place: a local copy would live in scratch memory
     memset(&v, 0, sizeof v);
     const u32 from = s.snapshot_cycles[i], to = s.snapshot_cycles[i + 1];
     v.start_flag = i == 0;
@@ -184,7 +184,6 @@ __global__ __launch_bounds__(64) void k_vm_slice(VmSliceJob job) {
         v.decommitment_queue_final_state = v.auxilary_final_parameters.decommittment_queue_state;
         v.log_queue_final_state = v.auxilary_final_parameters.storage_log_queue_state;
     }
-    job.out[i] = v;
 }
 
 }  // namespace zkw

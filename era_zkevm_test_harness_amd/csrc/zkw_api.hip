@@ -57,6 +57,143 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// ------------------------------------------------------------------------------------------------ allocation cache
+// hipFree / hipHostFree wait for EVERY stream of the device and hipMalloc takes the runtime's global lock: with many
+// blocks in flight (zkw_blocks_run) the ~300 buffers of each block cost more than its kernels (measured: 65 ms of
+// frees per block, and a 1.25 GB trace ring costs up to 20 ms to map). Freed buffers therefore go to
+// a per-device list of size classes and are handed out again: 8 classes per octave up to SMALL_MAX bytes (at most
+// 12.5 % slack), the exact size rounded to 2 MiB above it (the traces and the benchmark-sized witness arrays recur with
+// the same sizes step after step; no slack where HBM is tight). Nothing here zeroes memory: as with hipMalloc, the
+// contents of a new buffer are unspecified. An allocation failure empties the cache and retries once;
+// zkw_trim_caches() empties it on request; ZKW_ALLOC_CACHE=0 turns it off.
+struct AllocCache {
+    static constexpr size_t SMALL_MAX = size_t(256) << 20;
+    static constexpr int MAX_DEV = 16;
+    std::mutex mu;
+    std::map<const void*, std::pair<int, size_t>> live[2];  // [pinned host?] pointer -> (device, class bytes)
+    std::map<size_t, std::vector<void*>> idle[2][MAX_DEV];
+    const bool enabled = [] { const char* e = getenv("ZKW_ALLOC_CACHE"); return !(e && e[0] == '0'); }();
+
+    static size_t size_class(size_t b) {
+        if (b <= 4096) return 4096;
+        if (b > SMALL_MAX) return (b + ((size_t(2) << 20) - 1)) & ~((size_t(2) << 20) - 1);
+        int top = 63 - __builtin_clzll(b);
+        const size_t step = size_t(1) << (top - 3);
+        return (b + step - 1) & ~(step - 1);
+    }
+    static hipError_t raw_alloc(int host, void** p, size_t bytes) {
+        return host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+    }
+    hipError_t alloc(int host, void** p, size_t bytes) {
+        int dev = 0;
+        if (!enabled || hipGetDevice(&dev) != hipSuccess || dev >= MAX_DEV) return raw_alloc(host, p, bytes);
+        const size_t cls = size_class(bytes);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = idle[host][dev].find(cls);
+            if (it != idle[host][dev].end() && !it->second.empty()) {
+                *p = it->second.back();
+                it->second.pop_back();
+                live[host][*p] = {dev, cls};
+                return hipSuccess;
+            }
+        }
+        hipError_t e = raw_alloc(host, p, cls);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            trim();
+            e = raw_alloc(host, p, cls);
+        }
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> g(mu);
+            live[host][*p] = {dev, cls};
+        }
+        return e;
+    }
+    // the caller has synchronised whatever used the buffer (every zkw_*_free / context destruction does)
+    void release(int host, void* p) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = live[host].find(p);
+            if (it != live[host].end()) {
+                idle[host][it->second.first][it->second.second].push_back(p);
+                live[host].erase(it);
+                return;
+            }
+        }
+        if (host) (void)hipHostFree(p); else (void)hipFree(p);
+    }
+    void trim() {
+        std::vector<void*> d, h;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (int dev = 0; dev < MAX_DEV; ++dev) {
+                for (auto& kv : idle[0][dev]) { d.insert(d.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+                for (auto& kv : idle[1][dev]) { h.insert(h.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+            }
+        }
+        for (void* q : d) (void)hipFree(q);
+        for (void* q : h) (void)hipHostFree(q);
+    }
+};
+static AllocCache& alloc_cache() {
+    static AllocCache* c = new AllocCache();  // never destroyed: the HIP runtime may be gone by static destruction time
+    return *c;
+}
+static inline hipError_t dev_malloc(void** p, size_t bytes) { return alloc_cache().alloc(0, p, bytes); }
+template <class T> static inline hipError_t dev_malloc(T** p, size_t bytes) { return alloc_cache().alloc(0, (void**)p, bytes); }
+static inline void dev_free(void* p) { alloc_cache().release(0, p); }
+static inline hipError_t pin_malloc(void** p, size_t bytes) { return alloc_cache().alloc(1, p, bytes); }
+static inline void pin_free(void* p) { alloc_cache().release(1, p); }
+
+
+// Streams are pooled for the same reason: hipStreamDestroy waits for the whole device. A released stream has been
+// synchronised by its owner; it keeps its hardware queue.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> idle[AllocCache::MAX_DEV];
+    hipError_t acquire(hipStream_t* s) {
+        int dev = 0;
+        if (alloc_cache().enabled && hipGetDevice(&dev) == hipSuccess && dev < AllocCache::MAX_DEV) {
+            std::lock_guard<std::mutex> g(mu);
+            if (!idle[dev].empty()) {
+                *s = idle[dev].back();
+                idle[dev].pop_back();
+                return hipSuccess;
+            }
+        }
+        return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    }
+    void release(hipStream_t s) {
+        if (!s) return;
+        int dev = 0;
+        if (alloc_cache().enabled && hipGetDevice(&dev) == hipSuccess && dev < AllocCache::MAX_DEV) {
+            std::lock_guard<std::mutex> g(mu);
+            idle[dev].push_back(s);
+            return;
+        }
+        (void)hipStreamDestroy(s);
+    }
+    void trim() {
+        std::vector<hipStream_t> all;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (auto& v : idle) { all.insert(all.end(), v.begin(), v.end()); v.clear(); }
+        }
+        for (hipStream_t s : all) (void)hipStreamDestroy(s);
+    }
+};
+static StreamPool& stream_pool() {
+    static StreamPool* p = new StreamPool();
+    return *p;
+}
+
+extern "C" void zkw_trim_caches(void) {
+    alloc_cache().trim();
+    stream_pool().trim();
+}
+
 #define HIP_TRY(expr)                                                                               \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \
@@ -138,7 +275,7 @@ struct zkw_ctx {
                 b.cap = 0;
             }
             size_t want = bytes + bytes / 8 + 256;
-            HIP_TRY(hipMalloc(&b.p, want));
+            HIP_TRY(dev_malloc(&b.p, want));
             b.cap = want;
         }
         *out = b.p;
@@ -167,7 +304,7 @@ struct zkw_ctx {
             if (st.p) retired_host.push_back(st.p);
             st.p = nullptr;
             st.cap = 0;
-            HIP_TRY(hipHostMalloc(&st.p, bytes + bytes / 2 + 256, hipHostMallocDefault));
+            HIP_TRY(pin_malloc(&st.p, bytes + bytes / 2 + 256));
             st.cap = bytes + bytes / 2 + 256;
         }
         if (!st.ev) HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
@@ -220,7 +357,7 @@ struct zkw_ctx {
             pinned_rb = nullptr;
             pinned_rb_cap = 0;
             const size_t want = bytes < 4096 ? 4096 : bytes;
-            HIP_TRY(hipHostMalloc(&pinned_rb, want, hipHostMallocDefault));
+            HIP_TRY(pin_malloc(&pinned_rb, want));
             pinned_rb_cap = want;
         }
         HIP_TRY(hipMemcpyAsync(pinned_rb, src, bytes, hipMemcpyDeviceToHost, stream));
@@ -352,7 +489,7 @@ extern "C" zkw_ctx* zkw_create(int device_id) {
     }
     zkw_ctx* ctx = new zkw_ctx();
     ctx->device = device_id;
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (stream_pool().acquire(&ctx->own_stream) != hipSuccess) {
         fail(ZKW_ERR_HIP, "hipStreamCreate failed");
         delete ctx;
         return nullptr;
@@ -365,19 +502,22 @@ static void ctx_destroy_now(zkw_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->pool)
-        if (kv.second.p) (void)hipFree(kv.second.p);
+        if (kv.second.p) dev_free(kv.second.p);
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     for (auto& kv : ctx->stages) {
-        if (kv.second.p) (void)hipHostFree(kv.second.p);
+        if (kv.second.p) pin_free(kv.second.p);
         if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
     }
-    for (void* q : ctx->retired_dev) (void)hipFree(q);
-    for (void* q : ctx->retired_host) (void)hipHostFree(q);
-    if (ctx->pinned_rb) (void)hipHostFree(ctx->pinned_rb);
+    for (void* q : ctx->retired_dev) dev_free(q);
+    for (void* q : ctx->retired_host) pin_free(q);
+    if (ctx->pinned_rb) pin_free(ctx->pinned_rb);
     if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
     if (ctx->chain_ev_b) (void)hipEventDestroy(ctx->chain_ev_b);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->own_stream) {
+        (void)hipStreamSynchronize(ctx->own_stream);
+        stream_pool().release(ctx->own_stream);
+    }
     delete ctx;
 }
 static void ctx_retain(zkw_ctx* ctx) { ctx->children.fetch_add(1); }
@@ -405,6 +545,35 @@ extern "C" int zkw_set_stream(zkw_ctx* ctx, void* s) {
     return ZKW_OK;
 }
 
+extern "C" int zkw_buffer_alloc(zkw_ctx* ctx, int pinned_host, size_t bytes, void** out) {
+    if (!ctx || !out) return fail(ZKW_ERR_INVALID, "zkw_buffer_alloc: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    *out = nullptr;
+    hipError_t e = pinned_host ? pin_malloc(out, bytes ? bytes : 1) : dev_malloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ZKW_ERR_OOM, "zkw_buffer_alloc: %zu bytes of %s memory: %s", bytes, pinned_host ? "pinned host" : "device", hipGetErrorString(e));
+    }
+    return ZKW_OK;
+}
+extern "C" void zkw_buffer_free(int pinned_host, void* p) {
+    if (pinned_host) pin_free(p); else dev_free(p);
+}
+extern "C" int zkw_stream_acquire(zkw_ctx* ctx, void** stream) {
+    if (!ctx || !stream) return fail(ZKW_ERR_INVALID, "zkw_stream_acquire: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    HIP_TRY(stream_pool().acquire(&s));
+    *stream = s;
+    return ZKW_OK;
+}
+extern "C" void zkw_stream_release(zkw_ctx* ctx, void* stream) {
+    if (!ctx || !stream) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    stream_pool().release(static_cast<hipStream_t>(stream));
+}
+
 extern "C" int zkw_set_chain_stream(zkw_ctx* ctx, void* s) {
     if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -416,10 +585,7 @@ extern "C" int zkw_set_chain_stream(zkw_ctx* ctx, void* s) {
             (void)hipEventDestroy(a);
             return fail(ZKW_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
         }
-        for (void* q : ctx->retired_dev) (void)hipFree(q);
-    for (void* q : ctx->retired_host) (void)hipHostFree(q);
-    if (ctx->pinned_rb) (void)hipHostFree(ctx->pinned_rb);
-    if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
+        if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
         if (ctx->chain_ev_b) (void)hipEventDestroy(ctx->chain_ev_b);
         ctx->chain_ev_a = a;
         ctx->chain_ev_b = b;
@@ -570,8 +736,8 @@ struct ChainService {
             if (rc == ZKW_OK && cap < bytes) {  // grow-only; freed with the service (hipFree would stall the device)
                 const size_t want = bytes * 2;
                 void *np = nullptr, *nd = nullptr;
-                fail_hip(hipHostMalloc(&np, want, hipHostMallocDefault), "hipHostMalloc");
-                if (rc == ZKW_OK) fail_hip(hipMalloc(&nd, want), "hipMalloc");
+                fail_hip(pin_malloc(&np, want), "hipHostMalloc");
+                if (rc == ZKW_OK) fail_hip(dev_malloc(&nd, want), "hipMalloc");
                 if (rc == ZKW_OK) { pin = np; dev = nd; cap = want; }
             }
             if (rc == ZKW_OK) {
@@ -954,7 +1120,7 @@ struct zkw_ram_witness {
                         unsorted_tails, sorted_tails, challenges,
                         lhs_z,    rhs_z,        instances,  nondet_counts, compact_forms, public_inputs, zbuf_l, zbuf_r, sq_win};
         for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) dev_free(p);
         sorted_q = nullptr;
         sorted_valid = false;
         perm = nullptr;
@@ -977,12 +1143,12 @@ struct zkw_ram_witness {
 extern "C" void zkw_ram_witness_free(zkw_ram_witness* w);
 static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
     const size_t t = w->total, ni = w->n_instances;
-    HIP_TRY(hipMalloc((void**)&w->perm, (t + 1) * sizeof(u32)));
-    HIP_TRY(hipMalloc((void**)&w->unsorted_caps, (t + 1) * 4 * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->sorted_caps, (t + 1) * 4 * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->unsorted_marks, (ni + 1) * 12 * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->sorted_marks, (ni + 1) * 12 * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->challenges, (n_blocks + 1) * 18 * sizeof(u64)));
+    HIP_TRY(dev_malloc((void**)&w->perm, (t + 1) * sizeof(u32)));
+    HIP_TRY(dev_malloc((void**)&w->unsorted_caps, (t + 1) * 4 * sizeof(u64)));
+    HIP_TRY(dev_malloc((void**)&w->sorted_caps, (t + 1) * 4 * sizeof(u64)));
+    HIP_TRY(dev_malloc((void**)&w->unsorted_marks, (ni + 1) * 12 * sizeof(u64)));
+    HIP_TRY(dev_malloc((void**)&w->sorted_marks, (ni + 1) * 12 * sizeof(u64)));
+    HIP_TRY(dev_malloc((void**)&w->challenges, (n_blocks + 1) * 18 * sizeof(u64)));
     {   // window of the grand-product chains: whole blocks, about 1 GB per side, at least the largest block
         size_t max_block = 0;
         for (size_t b = 0; b + 1 < w->offsets.size(); b++) max_block = std::max(max_block, (size_t)(w->offsets[b + 1] - w->offsets[b]));
@@ -990,14 +1156,14 @@ static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
         if (const char* e = getenv("ZKW_Z_WINDOW_ITEMS")) window = sq_window = (size_t)strtoull(e, nullptr, 10);  // tests: force small groups
         w->zcap = std::max(max_block, std::min(t, window));
         w->sqcap = std::max(max_block, std::min(t, sq_window));
-        HIP_TRY(hipMalloc((void**)&w->zbuf_l, (w->zcap + 1) * 2 * sizeof(u64)));
-        HIP_TRY(hipMalloc((void**)&w->zbuf_r, (w->zcap + 1) * 2 * sizeof(u64)));
-        HIP_TRY(hipMalloc((void**)&w->sq_win, (w->sqcap + 1) * sizeof(zkw_mem_query)));
+        HIP_TRY(dev_malloc((void**)&w->zbuf_l, (w->zcap + 1) * 2 * sizeof(u64)));
+        HIP_TRY(dev_malloc((void**)&w->zbuf_r, (w->zcap + 1) * 2 * sizeof(u64)));
+        HIP_TRY(dev_malloc((void**)&w->sq_win, (w->sqcap + 1) * sizeof(zkw_mem_query)));
     }
-    HIP_TRY(hipMalloc((void**)&w->instances, (ni + 1) * sizeof(zkw_ram_instance)));
-    HIP_TRY(hipMalloc((void**)&w->nondet_counts, (ni + 1) * sizeof(u32)));
-    HIP_TRY(hipMalloc((void**)&w->compact_forms, (ni + 1) * COMPACT_FORM_LEN * sizeof(u64)));
-    HIP_TRY(hipMalloc((void**)&w->public_inputs, (ni + 1) * 4 * sizeof(u64)));
+    HIP_TRY(dev_malloc((void**)&w->instances, (ni + 1) * sizeof(zkw_ram_instance)));
+    HIP_TRY(dev_malloc((void**)&w->nondet_counts, (ni + 1) * sizeof(u32)));
+    HIP_TRY(dev_malloc((void**)&w->compact_forms, (ni + 1) * COMPACT_FORM_LEN * sizeof(u64)));
+    HIP_TRY(dev_malloc((void**)&w->public_inputs, (ni + 1) * 4 * sizeof(u64)));
     return ZKW_OK;
 }
 
@@ -1079,7 +1245,7 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     if (ctx->ptr_mode == ZKW_PTR_DEVICE) {
         w->unsorted_q = d_q;
     } else {  // d_q is the context's staging copy, which the next call overwrites
-        if (!w->owned_q) HIP_TRY(hipMalloc((void**)&w->owned_q, (total + 1) * sizeof(zkw_mem_query)));
+        if (!w->owned_q) HIP_TRY(dev_malloc((void**)&w->owned_q, (total + 1) * sizeof(zkw_mem_query)));
         HIP_TRY(hipMemcpyAsync(w->owned_q, d_q, total * sizeof(zkw_mem_query), hipMemcpyDeviceToDevice, ctx->stream));
         w->unsorted_q = w->owned_q;
     }
@@ -1223,7 +1389,7 @@ static int ram_sorted_queries(const zkw_ram_witness* cw) {
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t t = w->total;
-    if (!w->sorted_q && hipMalloc((void**)&w->sorted_q, (t + 1) * sizeof(zkw_mem_query)) != hipSuccess)
+    if (!w->sorted_q && dev_malloc((void**)&w->sorted_q, (t + 1) * sizeof(zkw_mem_query)) != hipSuccess)
         return fail(ZKW_ERR_OOM, "no room for the sorted queries (%zu bytes): read ZKW_RAM_SORTED_QUERIES from a smaller batch", t * sizeof(zkw_mem_query));
     { Prof _p(ctx, "k_gather_encode"); hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(t, 256)), dim3(256), 0, ctx->stream, w->unsorted_q, w->perm, t, w->sorted_q, (u64*)nullptr); }
     ZKW_TRY(launch_check("k_gather_encode"));
@@ -1239,7 +1405,7 @@ static int ram_full_chains(const zkw_ram_witness* cw) {
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t t = w->total;
     if (!w->lhs_z) {
-        if (hipMalloc((void**)&w->lhs_z, (t + 1) * 16) != hipSuccess || hipMalloc((void**)&w->rhs_z, (t + 1) * 16) != hipSuccess)
+        if (dev_malloc((void**)&w->lhs_z, (t + 1) * 16) != hipSuccess || dev_malloc((void**)&w->rhs_z, (t + 1) * 16) != hipSuccess)
             return fail(ZKW_ERR_OOM, "no room for the grand-product chains (%zu bytes): read ZKW_RAM_*_Z from a smaller batch", 2 * t * 16);
     }
     ZKW_TRY(ram_gp_blocks(ctx, w, 0, w->offsets.size() - 1, w->lhs_z, w->rhs_z));
@@ -1255,7 +1421,7 @@ static int ram_encodings(const zkw_ram_witness* cw) {
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t t = w->total;
     if (!w->unsorted_enc) {
-        if (hipMalloc((void**)&w->unsorted_enc, (t + 1) * 64) != hipSuccess || hipMalloc((void**)&w->sorted_enc, (t + 1) * 64) != hipSuccess)
+        if (dev_malloc((void**)&w->unsorted_enc, (t + 1) * 64) != hipSuccess || dev_malloc((void**)&w->sorted_enc, (t + 1) * 64) != hipSuccess)
             return fail(ZKW_ERR_OOM, "no room for the materialised encodings (%zu bytes): read ZKW_RAM_*_ENC from a smaller batch", 2 * t * 64);
     }
     ZKW_TRY(ram_sorted_queries(cw));
@@ -1275,7 +1441,7 @@ static int ram_full_tails(const zkw_ram_witness* cw) {
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t t = w->total;
     if (!w->unsorted_tails) {
-        if (hipMalloc((void**)&w->unsorted_tails, (t + 1) * 96) != hipSuccess || hipMalloc((void**)&w->sorted_tails, (t + 1) * 96) != hipSuccess)
+        if (dev_malloc((void**)&w->unsorted_tails, (t + 1) * 96) != hipSuccess || dev_malloc((void**)&w->sorted_tails, (t + 1) * 96) != hipSuccess)
             return fail(ZKW_ERR_OOM, "no room for the expanded queue tails (%zu bytes): read ZKW_RAM_*_TAILS from a smaller batch", 2 * t * 96);
     }
     u64* d_off = nullptr;
@@ -1369,7 +1535,7 @@ extern "C" int zkw_trace_create_with_columns(zkw_ctx* ctx, size_t n_rows, size_t
     t->n_rows = n_rows;
     t->n_cols = n_cols;
     t->n_slots = n_slots;
-    hipError_t e = hipMalloc((void**)&t->data, t->slot_elems() * n_slots * sizeof(u64));
+    hipError_t e = dev_malloc((void**)&t->data, t->slot_elems() * n_slots * sizeof(u64));
     if (e != hipSuccess) {
         delete t;
         return fail(ZKW_ERR_OOM, "zkw_trace_create: hipMalloc of %zu bytes failed: %s",
@@ -1388,7 +1554,7 @@ extern "C" void zkw_trace_free(zkw_trace* t) {
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
-    if (t->data) (void)hipFree(t->data);
+    if (t->data) dev_free(t->data);
     zkw_ctx* owner = t->ctx;
     delete t;
     ctx_release(owner);
@@ -1565,7 +1731,7 @@ struct zkw_decommit_witness {
         void* ptrs[] = {sorted_q, dedup_q, unsorted_enc, sorted_enc, unsorted_tails, sorted_tails, dedup_enc,
                         dedup_tails, challenges, lhs_z, rhs_z, instances, fresh_prefix, compact_forms, public_inputs};
         for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) dev_free(p);
     }
 };
 
@@ -1662,7 +1828,7 @@ extern "C" int zkw_decommit_sorter_prepare(zkw_ctx* ctx, const zkw_decommit_quer
     w->capacity = capacity;
     w->n_instances = (n + capacity - 1) / capacity;
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
     alloc((void**)&w->sorted_q, n * sizeof(zkw_decommit_query));
     alloc((void**)&w->dedup_q, n * sizeof(zkw_decommit_query));
     alloc((void**)&w->unsorted_enc, n * 64); alloc((void**)&w->sorted_enc, n * 64); alloc((void**)&w->dedup_enc, n * 64);
@@ -1793,7 +1959,7 @@ extern "C" void zkw_decommit_witness_free(zkw_decommit_witness* w) {
 // in one allocation (ClosedFormInputCompactForm::from_full_form + commit, postprocessing/mod.rs:353-369)
 template <class T>
 static int closed_form_public_inputs(zkw_ctx* ctx, const typename T::Inst* d_inst, size_t ni, u64** cf_pi) {
-    if (!*cf_pi) HIP_TRY(hipMalloc((void**)cf_pi, ni * (COMPACT_FORM_LEN + 4) * sizeof(u64)));
+    if (!*cf_pi) HIP_TRY(dev_malloc((void**)cf_pi, ni * (COMPACT_FORM_LEN + 4) * sizeof(u64)));
     u64 *compact = *cf_pi, *pis = *cf_pi + COMPACT_FORM_LEN * ni;
     { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, d_inst, ni, compact); }
     ZKW_TRY(launch_check("k_closed_form_commitments"));
@@ -1816,7 +1982,7 @@ struct zkw_events_witness {
     void release() {
         void* ptrs[] = {sorted_q, result_q, enc_all, tails_all, challenges, lhs_z, rhs_z, instances, kept_prefix, cf_pi};
         for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) dev_free(p);
     }
 };
 
@@ -1886,7 +2052,7 @@ extern "C" int zkw_events_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, siz
     w->n_instances = n ? (n + capacity - 1) / capacity : 1;
     const size_t m = n ? n : 1;
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
     alloc((void**)&w->sorted_q, m * sizeof(zkw_log_query));
     alloc((void**)&w->result_q, m * sizeof(zkw_log_query));
     alloc((void**)&w->enc_all, 3 * m * 160);
@@ -2005,7 +2171,7 @@ struct zkw_demux_witness {
     void release() {
         void* ptrs[] = {out_q, enc_all, tails_all, d_offsets, route_count, instances, cf_pi};
         for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) dev_free(p);
     }
 };
 
@@ -2057,7 +2223,7 @@ extern "C" int zkw_log_demux_build(zkw_ctx* ctx, const zkw_log_query* q, size_t 
     w->n_instances = n ? (n + capacity - 1) / capacity : 1;
     const size_t m = n ? n : 1;
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
     alloc((void**)&w->out_q, m * sizeof(zkw_log_query));
     alloc((void**)&w->enc_all, 2 * m * 160);
     alloc((void**)&w->tails_all, 4 * m * 32);
@@ -2166,7 +2332,7 @@ struct zkw_storage_witness {
     void release() {
         void* ptrs[] = {sorted_q, result_q, sorted_ext, enc_all, lhs_enc, tails_all, challenges, lhs_z, rhs_z, scans, instances, cf_pi};
         for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) dev_free(p);
     }
 };
 
@@ -2260,7 +2426,7 @@ extern "C" int zkw_storage_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, si
     w->n_instances = n ? (n + capacity - 1) / capacity : 1;
     const size_t m = n ? n : 1;
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
     alloc((void**)&w->sorted_q, m * sizeof(zkw_log_query));
     alloc((void**)&w->result_q, m * sizeof(zkw_log_query));
     alloc((void**)&w->sorted_ext, m * 4);
@@ -2371,7 +2537,7 @@ struct zkw_decommitter_witness {
     void release() {
         void* ptrs[] = {mem_q, mem_enc, mem_tails, round_states, instances};
         for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) dev_free(p);
     }
 };
 
@@ -2420,7 +2586,7 @@ extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit
     w->total_rounds = roff[n_requests];
     w->n_instances = (w->total_rounds + capacity - 1) / capacity;
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
     alloc((void**)&w->mem_q, w->total_words * sizeof(zkw_mem_query));
     alloc((void**)&w->mem_enc, w->total_words * 64);
     alloc((void**)&w->mem_tails, w->total_words * 96);
@@ -2663,7 +2829,7 @@ struct zkw_precompile_witness {
     void release() {
         void* ptrs[] = {mem_enc, mem_tails, instances};
         for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) dev_free(p);
     }
 };
 
@@ -2704,7 +2870,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
     w->total_reads = meta[2];
     w->n_instances = n_requests ? (w->total_rounds + capacity - 1) / capacity : 1;
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
     alloc((void**)&w->mem_enc, n_queries * 64);
     alloc((void**)&w->mem_tails, n_queries * 96);
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_precompile_instance));
@@ -2817,7 +2983,7 @@ struct zkw_storage_application_witness {
     void release() {
         void* ptrs[] = {keys, paths, roots, leaf_indexes, instances};
         for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) dev_free(p);
     }
 };
 
@@ -2833,7 +2999,7 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
     w->ctx = ctx;
     w->n = n;
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes + 64); };
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
     alloc((void**)&w->keys, n * 32);
     alloc((void**)&w->paths, n * 256 * 32);
     alloc((void**)&w->roots, n * 32);
@@ -2903,7 +3069,7 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
             return bail(fail(ZKW_ERR_HIP, "readback failed"));
     }
     w->n_instances = n ? (size_t)meta[0] : 1;
-    if (hipMalloc((void**)&w->instances, w->n_instances * sizeof(zkw_storage_application_instance) + 64) != hipSuccess)
+    if (dev_malloc((void**)&w->instances, w->n_instances * sizeof(zkw_storage_application_instance) + 64) != hipSuccess)
         return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed"));
     SapKeccakOut ko{d_snap, d_hash};
     { Prof _p(ctx, "k_sap_keccak"); hipLaunchKernelGGL(k_sap_keccak, dim3(1), dim3(64), 0, ctx->stream, job, ko); }
@@ -2989,7 +3155,7 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!w->fresh_prefix) {
-        HIP_TRY(hipMalloc((void**)&w->fresh_prefix, (w->n + 2) * sizeof(u32)));
+        HIP_TRY(dev_malloc((void**)&w->fresh_prefix, (w->n + 2) * sizeof(u32)));
         { Prof _p(ctx, "k_ds_fresh_prefix"); hipLaunchKernelGGL(k_ds_fresh_prefix, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, w->n, w->fresh_prefix); }
         ZKW_TRY(launch_check("k_ds_fresh_prefix"));
     }
@@ -3055,7 +3221,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!w->kept_prefix) {
-        HIP_TRY(hipMalloc((void**)&w->kept_prefix, (n + 2) * sizeof(u32)));
+        HIP_TRY(dev_malloc((void**)&w->kept_prefix, (n + 2) * sizeof(u32)));
         { Prof _p(ctx, "k_es_kept_prefix"); hipLaunchKernelGGL(k_es_kept_prefix, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, w->kept_prefix); }
         ZKW_TRY(launch_check("k_es_kept_prefix"));
     }

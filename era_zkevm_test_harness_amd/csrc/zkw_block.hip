@@ -77,6 +77,7 @@ struct PerType {
 // (measured: +0.9 s per builder), so nothing of the kind happens while the graph runs.
 enum { X_MAIN = 0, X_LOG, X_STO, X_EVT, X_L1, X_RAM, X_DEC, N_XFER };
 struct Xfer {
+    zkw_ctx* c = nullptr;  // any context of the block: names the device for the library's buffer / stream caches
     hipStream_t st = nullptr;
     void* pin = nullptr;
     size_t cap = 0;
@@ -87,7 +88,7 @@ struct Xfer {
         pin = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 4 + 4096;
-        ST_HIP(hipHostMalloc(&pin, want, hipHostMallocDefault));
+        ST_ZKW(zkw_buffer_alloc(c, 1, want, &pin));
         cap = want;
         return Status();
     }
@@ -108,9 +109,9 @@ struct Xfer {
         return Status();
     }
     void destroy() {
-        if (st) (void)hipStreamDestroy(st);
-        if (pin) (void)hipHostFree(pin);
-        for (void* q : retired) (void)hipHostFree(q);
+        if (st) zkw_stream_release(c, st);
+        if (pin) zkw_buffer_free(1, pin);
+        for (void* q : retired) zkw_buffer_free(1, q);
     }
 };
 
@@ -157,7 +158,7 @@ struct zkw_block {
     template <class T>
     Status alloc(T** p, size_t count) {
         void* q = nullptr;
-        ST_HIP(hipMalloc(&q, count * sizeof(T) + 64));
+        ST_ZKW(zkw_buffer_alloc(ctx[0], 0, count * sizeof(T) + 64, &q));
         {
             std::lock_guard<std::mutex> g(mu);
             dev.push_back(q);
@@ -283,16 +284,19 @@ std::string key32(const uint32_t* h) { return std::string(reinterpret_cast<const
 
 Status run(zkw_block* B, const zkw_block_inputs* in) {
     ST_HIP(hipSetDevice(B->device));
-    for (int i = 0; i < N_XFER; i++) {
-        ST_HIP(hipStreamCreateWithFlags(&B->xf[i].st, hipStreamNonBlocking));
-        ST_TRY(B->xf[i].reserve(i == X_MAIN || i == X_LOG ? (size_t)8 << 20 : (size_t)1 << 20));
-    }
     for (int i = 0; i < N_CTX; i++) {
         B->ctx[i] = zkw_create(B->device);
         if (!B->ctx[i]) return from_rc(ZKW_ERR_NO_DEVICE);
         ST_ZKW(zkw_set_pointer_mode(B->ctx[i], ZKW_PTR_DEVICE));
         if (B->use_chain_service) ST_ZKW(zkw_set_chain_service(B->ctx[i], 1));
         if (getenv("ZKW_BLOCK_PROFILE")) ST_ZKW(zkw_profile_enable(B->ctx[i], 1));
+    }
+    for (int i = 0; i < N_XFER; i++) {
+        void* st = nullptr;
+        B->xf[i].c = B->ctx[0];
+        ST_ZKW(zkw_stream_acquire(B->ctx[0], &st));
+        B->xf[i].st = static_cast<hipStream_t>(st);
+        ST_TRY(B->xf[i].reserve(i == X_MAIN || i == X_LOG ? (size_t)8 << 20 : (size_t)1 << 20));
     }
     for (int t = 1; t <= 13; t++) {
         zkw_circuit_geometry g;
@@ -479,13 +483,17 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
 
 thread_local std::string g_block_error;
 
-// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and work on one hardware queue runs in
-// order: with the default, a 50 us kernel of one branch can sit behind another branch's 1.4 s queue chain (measured:
-// builders 2.6 s instead of 1.43 s). The variable is read when the HIP runtime initialises the device, so it is set when
-// the library is loaded, unless the host has chosen a value itself; a host that initialises HIP before loading libzkw
-// must export GPU_MAX_HW_QUEUES >= 16 itself.
+// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues PER PRIORITY CLASS (default 4) and work on one hardware
+// queue runs in order: with the default, a 50 us kernel of one branch can sit behind another branch's 1.4 s queue chain
+// (measured: builders 2.6 s instead of 1.43 s). More is not better: the chip maps about 24 user queues at once, and a
+// process that has touched more (16 normal + 16 high-priority + the host framework's) is time-sliced by the hardware
+// scheduler from then on, idle queues included (measured: every HBM-bound kernel 40 % slower, 1390 instead of 1870
+// circuits/s in bench.py). 8 per class keeps the total below that with the chain service's 8 high-priority streams on
+// queues of their own. The variable is read when the HIP runtime initialises the device, so it is set when the library
+// is loaded, unless the host has chosen a value itself; a host that initialises HIP before loading libzkw must export
+// GPU_MAX_HW_QUEUES=8 itself.
 struct HwQueuesDefault {
-    HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+    HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 } g_hw_queues_default;
 
 }  // namespace
@@ -571,6 +579,10 @@ extern "C" int zkw_blocks_run(int device_id, const zkw_block_inputs* const* inpu
 extern "C" void zkw_block_free(zkw_block* B) {
     if (!B) return;
     (void)hipSetDevice(B->device);
+    // buffers go back to the library's caches, not to hipFree (which used to wait for the whole device): nothing of this
+    // block may still be in flight on any of its contexts
+    for (int i = 0; i < N_CTX; i++)
+        if (B->ctx[i]) (void)zkw_synchronize(B->ctx[i]);
     if (B->ring149) zkw_trace_free(B->ring149);
     if (B->ring151) zkw_trace_free(B->ring151);
     if (B->dec) zkw_decommit_witness_free(B->dec);
@@ -583,10 +595,10 @@ extern "C" void zkw_block_free(zkw_block* B) {
     if (B->sap) zkw_storage_application_witness_free(B->sap);
     if (B->evt) zkw_events_witness_free(B->evt);
     if (B->l1) zkw_events_witness_free(B->l1);
+    for (void* p : B->dev) zkw_buffer_free(0, p);
+    for (int i = 0; i < N_XFER; i++) B->xf[i].destroy();  // before the contexts: the lanes name one of them
     for (int i = 0; i < N_CTX; i++)
         if (B->ctx[i]) zkw_destroy(B->ctx[i]);
-    for (void* p : B->dev) (void)hipFree(p);
-    for (int i = 0; i < N_XFER; i++) B->xf[i].destroy();
     delete B;
 }
 

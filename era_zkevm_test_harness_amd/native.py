@@ -7,9 +7,10 @@ library is missing or no gfx950 device is usable.
 import ctypes as C
 import os
 
-# zkw_block_run overlaps the builders of a block on ~14 HIP streams; HIP's default of 4 hardware queues would serialise
-# them (csrc/zkw_block.hip). Read by the HIP runtime at device initialisation, i.e. before the first torch.cuda call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# zkw_block_run overlaps the builders of a block on ~14 HIP streams; HIP's default of 4 hardware queues per priority class
+# would serialise them, more than 8 oversubscribes the chip's queue slots (csrc/zkw_block.hip). Read by the HIP runtime
+# at device initialisation, i.e. before the first torch.cuda call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -33,6 +34,11 @@ SYMBOLS = [
     ("zkw_synchronize", _int, [_vp]),
     ("zkw_set_chain_form", _int, [_vp, _int]),
     ("zkw_set_chain_service", _int, [_vp, _int]),
+    ("zkw_buffer_alloc", _int, [_vp, _int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("zkw_buffer_free", None, [_int, _vp]),
+    ("zkw_stream_acquire", _int, [_vp, C.POINTER(C.c_void_p)]),
+    ("zkw_stream_release", None, [_vp, _vp]),
+    ("zkw_trim_caches", None, []),
     ("zkw_version", C.c_char_p, []),
     ("zkw_circuit_geometry_of", _int, [C.c_uint8, _vp]),
     ("zkw_circuit_layout_of", _int, [C.c_uint8, _u32, _vp]),
@@ -1395,6 +1401,11 @@ class Block:
             self.free()
         except Exception:
             pass
+
+
+def trim_caches():
+    """zkw_trim_caches: hand every idle buffer / stream of the library's caches back to the HIP runtime"""
+    load().zkw_trim_caches()
 
 
 def shard_lpt(circuit_types, world):

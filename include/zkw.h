@@ -18,7 +18,12 @@
  *   - lifetimes: every witness / trace / block object keeps a reference to the context it was created from (its
  *     accessors and its free function use the context's device and stream). zkw_destroy on a context with outstanding
  *     objects synchronises and marks it; the context is released by the last zkw_*_free. The context must not be
- *     passed to any other call after zkw_destroy.
+ *     passed to any other call after zkw_destroy. A zkw_*_free synchronises its OWN context's stream; work that another
+ *     context (or the host's own streams) still has in flight on the object must be synchronised by the caller first.
+ *   - memory: device and pinned buffers and the library's streams are recycled through per-device
+ *     caches instead of going back to the HIP runtime (hipFree / hipHostFree / hipStreamDestroy wait for the whole
+ *     device, which stalls every other context); zkw_trim_caches() hands everything idle back, an allocation failure
+ *     does so by itself and retries, ZKW_ALLOC_CACHE=0 in the environment turns the caches off.
  */
 #ifndef ZKW_H
 #define ZKW_H
@@ -68,6 +73,14 @@ int zkw_set_chain_form(zkw_ctx *ctx, int lanes_per_state);
    into ONE launch on a high-priority stream, and the call waits for that launch. For hosts that keep many contexts busy
    at once (zkw_blocks_run): K concurrent builders cost one chain pass instead of K serialised ones. Results are identical. */
 int zkw_set_chain_service(zkw_ctx *ctx, int on);
+/* Buffers and streams from the library's caches (see "memory" above), for hosts that build graphs of contexts the way
+   zkw_block_run does. pinned_host = 0: device memory on ctx's device, 1: pinned host memory. Contents are unspecified.
+   zkw_stream_release synchronises the stream. */
+int zkw_buffer_alloc(zkw_ctx *ctx, int pinned_host, size_t bytes, void **out);
+void zkw_buffer_free(int pinned_host, void *p);
+int zkw_stream_acquire(zkw_ctx *ctx, void **hip_stream);
+void zkw_stream_release(zkw_ctx *ctx, void *hip_stream);
+void zkw_trim_caches(void);
 /* library/ABI version and the kernels' target ISA ("gfx950") */
 const char *zkw_version(void);
 
