@@ -50,6 +50,7 @@ def create_artifacts_after_vm(ctx, block, capacities=None):
     woff = np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]).astype(np.uint64)
     dcm = ctx.compute_decommitter_circuit_snapshots(dedup_q, dedup_tails, np.concatenate(codes), woff, cap[CODE_DECOMMITTER], mem_state)
     art["code_decommitter"] = dcm
+    pis[CODE_DECOMMITTER] = ctx.closed_form_public_inputs(CODE_DECOMMITTER, dcm.get(nv.DCM_INSTANCES))[1]
     q = dcm.get(nv.DCM_MEM_QUERIES)
     memory.append(q)
     mem_state = _queue_state12(dcm.get(nv.DCM_MEM_TAILS)[-1], int(mem_state["length"][0]) + q.size)
@@ -70,6 +71,7 @@ def create_artifacts_after_vm(ctx, block, capacities=None):
         mq = np.ascontiguousarray(block["precompile_memory_queries"][k], dtype=nv.MEM_QUERY)
         w = fn(req, req_tails, mq, cap[ctype], mem_state)
         art[name] = w
+        pis[ctype] = ctx.closed_form_public_inputs(ctype, w.get(nv.PRC_INSTANCES))[1]
         if mq.size:
             memory.append(mq)
             mem_state = _queue_state12(w.get(nv.PRC_MEM_TAILS)[-1], int(mem_state["length"][0]) + mq.size)
@@ -91,11 +93,18 @@ def create_artifacts_after_vm(ctx, block, capacities=None):
     art["l1_messages_sorter"] = l1s
     pis[L1_MESSAGES_SORTER] = l1s.get(nv.EVT_PUBLIC_INPUTS)
     pubdata_hash = ctx.compute_linear_keccak256(l1s.get(nv.EVT_RESULT_QUERIES))
+    hasher = np.zeros(1, nv.LINEAR_HASHER_INSTANCE)  # the LinearHasher instance, data_hasher_and_merklizer.rs:34-60
+    hasher["start_flag"] = hasher["completion_flag"] = 1
+    hasher["queue_state"] = l1s.get(nv.EVT_INSTANCES)["final_queue_state"][-1]
+    hasher["keccak256_hash"] = np.frombuffer(pubdata_hash, np.uint8)
+    art_hasher = hasher
+    pis[L1_MESSAGES_HASHER] = ctx.closed_form_public_inputs(L1_MESSAGES_HASHER, hasher)[1]
 
     # 7. one recursion queue per circuit type (postprocessing/mod.rs:393-400)
     recursion = {t: ctx.recursion_queue_push(t, p) for t, p in pis.items()}
     return {"witnesses": art, "memory_queries": all_mem, "memory_queue_state": mem_state, "demuxed_offsets": off,
-            "public_inputs": pis, "recursion_queues": recursion, "l1_messages_pubdata_hash": pubdata_hash, "capacities": cap}
+            "public_inputs": pis, "recursion_queues": recursion, "l1_messages_pubdata_hash": pubdata_hash,
+            "linear_hasher_instance": art_hasher, "capacities": cap}
 
 
 def synthesize_and_check(ctx, artifacts, n_rows):

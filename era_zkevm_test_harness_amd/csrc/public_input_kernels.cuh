@@ -237,15 +237,140 @@ struct CfStorageSorter {
     __device__ static const zkw_storage_sorter_fsm& fsm_out(const Inst& w) { return w.hidden_fsm_output; }
 };
 
+// ---- the remaining non-VM circuits: CodeDecommitter 3, Keccak256 / Sha256 / ECRecover round functions 5 / 6 / 7,
+// StorageApplication 10, LinearHasher 13. Struct declarations of the absent zkevm_circuits crate (v1.4.1, */input.rs),
+// field sets as the reference's builders fill them (decommit_code.rs:172-199,363-401; keccak256_round_function.rs:
+// 420-441; sha256_round_function.rs:302-316; ecrecover.rs:215-233; storage_application.rs:286-336;
+// data_hasher_and_merklizer.rs:34-60). One field element per Boolean / UInt8 / UInt16 / UInt32.
+__device__ inline int put_bytes(const uint8_t* b, int n, u64* o) {
+    for (int k = 0; k < n; k++) o[k] = b[k];
+    return n;
+}
+__device__ inline int put_u32s(const u32* w, int n, u64* o) {
+    for (int k = 0; k < n; k++) o[k] = w[k];
+    return n;
+}
+struct CfDecommitter {
+    using Inst = zkw_decommitter_instance;
+    static constexpr int MAXLEN = 80, LANES = 64;  // FSM: 8 + 8 + 5 + 3 + 25 + 25 = 74
+    __device__ static int input(const Inst& w, u64* o) {
+        int m = put_queue12(w.memory_queue_initial_state, o);
+        return m + put_queue12(w.sorted_requests_queue_initial_state, o + m);
+    }
+    __device__ static int output(const Inst& w, u64* o) { return put_queue12(w.memory_queue_final_state, o); }
+    __device__ static int fsm(const zkw_decommitter_fsm& f, u64* o) {
+        int m = put_u32s(f.sha256_inner_state, 8, o);
+        m += put_u32s(f.hash_to_compare_against, 8, o + m);
+        o[m++] = f.current_index;
+        o[m++] = f.current_page;
+        o[m++] = f.timestamp;
+        o[m++] = f.num_rounds_left;
+        o[m++] = f.length_in_bits;
+        o[m++] = f.state_get_from_queue ? 1 : 0;
+        o[m++] = f.state_decommit ? 1 : 0;
+        o[m++] = f.finished ? 1 : 0;
+        m += put_queue12(f.decommittment_requests_queue_state, o + m);
+        return m + put_queue12(f.memory_queue_state, o + m);
+    }
+    __device__ static const zkw_decommitter_fsm& fsm_in(const Inst& w) { return w.hidden_fsm_input; }
+    __device__ static const zkw_decommitter_fsm& fsm_out(const Inst& w) { return w.hidden_fsm_output; }
+};
+template <int KIND>
+struct CfPrecompile {
+    using Inst = zkw_precompile_instance;
+    // keccak: 4 flags + 200 + 2 timestamps + 6 parameters + 192 + 1 buffer + 9 + 25 queue words
+    static constexpr int MAXLEN = KIND == ZKW_PRECOMPILE_KECCAK256 ? 440 : 56, LANES = KIND == ZKW_PRECOMPILE_KECCAK256 ? 16 : 64;
+    __device__ static int input(const Inst& w, u64* o) {
+        int m = put_queue4(w.initial_log_queue_state, o);
+        return m + put_queue12(w.initial_memory_queue_state, o + m);
+    }
+    __device__ static int output(const Inst& w, u64* o) { return put_queue12(w.final_memory_state, o); }
+    __device__ static int fsm(const zkw_precompile_fsm& f, u64* o) {
+        int m = 0;
+        if (KIND == ZKW_PRECOMPILE_KECCAK256) {
+            o[m++] = f.read_precompile_call ? 1 : 0;
+            o[m++] = f.read_words_for_round ? 1 : 0;
+            o[m++] = f.completed ? 1 : 0;
+            o[m++] = f.padding_round ? 1 : 0;
+            m += put_bytes(f.keccak_internal_state, 200, o + m);
+            o[m++] = f.timestamp_to_use_for_read;
+            o[m++] = f.timestamp_to_use_for_write;
+            o[m++] = f.input_page;
+            o[m++] = f.input_offset;
+            o[m++] = f.input_length;
+            o[m++] = f.output_page;
+            o[m++] = f.output_offset;
+            o[m++] = f.needs_full_padding_round ? 1 : 0;
+            m += put_bytes(f.buffer_bytes, ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE, o + m);
+            o[m++] = f.buffer_filled;
+        } else if (KIND == ZKW_PRECOMPILE_SHA256) {
+            o[m++] = f.read_precompile_call ? 1 : 0;
+            o[m++] = f.read_words_for_round ? 1 : 0;
+            o[m++] = f.completed ? 1 : 0;
+            m += put_u32s(f.sha256_inner_state, 8, o + m);
+            o[m++] = f.timestamp_to_use_for_read;
+            o[m++] = f.timestamp_to_use_for_write;
+            o[m++] = f.input_page;
+            o[m++] = f.input_offset;
+            o[m++] = f.output_page;
+            o[m++] = f.output_offset;
+            o[m++] = f.num_rounds;
+        }
+        m += put_queue4(f.log_queue_state, o + m);
+        return m + put_queue12(f.memory_queue_state, o + m);
+    }
+    __device__ static const zkw_precompile_fsm& fsm_in(const Inst& w) { return w.hidden_fsm_input; }
+    __device__ static const zkw_precompile_fsm& fsm_out(const Inst& w) { return w.hidden_fsm_output; }
+};
+struct CfStorageApplication {
+    using Inst = zkw_storage_application_instance;
+    static constexpr int MAXLEN = 244, LANES = 32;
+    __device__ static int input(const Inst& w, u64* o) {
+        o[0] = w.shard;
+        int m = 1 + put_bytes(w.initial_root_hash, 32, o + 1);
+        m += put_u32s(w.initial_next_enumeration_counter, 2, o + m);
+        return m + put_queue4(w.storage_application_log_state, o + m);
+    }
+    __device__ static int output(const Inst& w, u64* o) {
+        int m = put_bytes(w.new_root_hash, 32, o);
+        m += put_u32s(w.new_next_enumeration_counter, 2, o + m);
+        return m + put_bytes(w.state_diffs_keccak256_hash, 32, o + m);
+    }
+    __device__ static int fsm(const zkw_storage_application_fsm& f, u64* o) {
+        int m = put_bytes(f.current_root_hash, 32, o);
+        m += put_u32s(f.next_enumeration_counter, 2, o + m);
+        m += put_queue4(f.current_storage_application_log_state, o + m);
+        return m + put_bytes(f.current_diffs_keccak_accumulator_state, 200, o + m);
+    }
+    __device__ static const zkw_storage_application_fsm& fsm_in(const Inst& w) { return w.hidden_fsm_input; }
+    __device__ static const zkw_storage_application_fsm& fsm_out(const Inst& w) { return w.hidden_fsm_output; }
+};
+struct CfLinearHasher {
+    using Inst = zkw_linear_hasher_instance;
+    struct NoFsm {};
+    static constexpr int MAXLEN = 32, LANES = 64;
+    __device__ static int input(const Inst& w, u64* o) { return put_queue4(w.queue_state, o); }
+    __device__ static int output(const Inst& w, u64* o) { return put_bytes(w.keccak256_hash, 32, o); }
+    __device__ static int fsm(const NoFsm&, u64*) { return 0; }  // hidden FSM = (): nothing absorbed
+    __device__ static NoFsm fsm_in(const Inst&) { return NoFsm{}; }
+    __device__ static NoFsm fsm_out(const Inst&) { return NoFsm{}; }
+};
+
+// lanes per workgroup: the encoding buffers are slices of LDS (64 KB per workgroup), so the long encodings run narrower
+template <class T> struct CfLanes { static constexpr int value = 64; };
+template <> struct CfLanes<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>> { static constexpr int value = 16; };
+template <> struct CfLanes<CfStorageApplication> { static constexpr int value = 32; };
+
 template <class T>
-__global__ __launch_bounds__(64) void k_closed_form_commitments(const typename T::Inst* __restrict__ inst, size_t n,
-                                                                u64* __restrict__ compact) {
+__global__ __launch_bounds__(CfLanes<T>::value) void k_closed_form_commitments(const typename T::Inst* __restrict__ inst, size_t n,
+                                                                               u64* __restrict__ compact) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t i = t >> 2;
     const int part = (int)(t & 3);
     if (i >= n) return;
     u64* cf = compact + COMPACT_FORM_LEN * i;
-    __shared__ u64 sh_buf[64 * T::MAXLEN];  // in LDS, one slice per lane: a run-time-indexed per-lane array would live in scratch memory
+    // in LDS, one slice per lane: a run-time-indexed per-lane array would live in scratch memory
+    __shared__ u64 sh_buf[CfLanes<T>::value * T::MAXLEN];
     u64* buf = sh_buf + threadIdx.x * T::MAXLEN;
     u64 c[4];
     int m;
@@ -260,6 +385,7 @@ __global__ __launch_bounds__(64) void k_closed_form_commitments(const typename T
     } else {
         m = T::fsm(part == 2 ? T::fsm_in(inst[i]) : T::fsm_out(inst[i]), buf);
     }
+    if (m > T::MAXLEN) __builtin_trap();  // an encoder outgrew its slice: fail loudly instead of hashing a neighbour's words
     commit_var_length(buf, m, c);
     const int at = part == 0 ? 2 : (part == 1 ? 6 : (part == 2 ? 10 : 14));
     for (int k = 0; k < 4; k++) cf[at + k] = c[k];

@@ -1961,10 +1961,46 @@ template <class T>
 static int closed_form_public_inputs(zkw_ctx* ctx, const typename T::Inst* d_inst, size_t ni, u64** cf_pi) {
     if (!*cf_pi) HIP_TRY(dev_malloc((void**)cf_pi, ni * (COMPACT_FORM_LEN + 4) * sizeof(u64)));
     u64 *compact = *cf_pi, *pis = *cf_pi + COMPACT_FORM_LEN * ni;
-    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, d_inst, ni, compact); }
+    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3(blocks_for(4 * ni, CfLanes<T>::value)), dim3(CfLanes<T>::value), 0, ctx->stream, d_inst, ni, compact); }
     ZKW_TRY(launch_check("k_closed_form_commitments"));
     { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, compact, ni, (u32)COMPACT_FORM_LEN, pis); }
     return launch_check("k_commit_encodings");
+}
+
+// a20 for the circuits whose builders keep no compact forms themselves (3, 5, 6, 7, 10, 13): commitments straight from
+// the instance records
+template <class T>
+static int closed_form_from_records(zkw_ctx* ctx, const void* instances, size_t n, uint64_t* compact, uint64_t* public_inputs) {
+    const typename T::Inst* d_inst = nullptr;
+    ZKW_TRY(ctx->in("cf_records", static_cast<const typename T::Inst*>(instances), n, &d_inst));
+    u64 *d_cf = nullptr, *d_pi = nullptr;
+    ZKW_TRY(ctx->out("cf_compact", reinterpret_cast<u64*>(compact), n * COMPACT_FORM_LEN, &d_cf));
+    ZKW_TRY(ctx->out("cf_pi", reinterpret_cast<u64*>(public_inputs), n * 4, &d_pi));
+    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3(blocks_for(4 * n, CfLanes<T>::value)), dim3(CfLanes<T>::value), 0, ctx->stream, d_inst, n, d_cf); }
+    ZKW_TRY(launch_check("k_closed_form_commitments"));
+    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, d_cf, n, (u32)COMPACT_FORM_LEN, d_pi); }
+    ZKW_TRY(launch_check("k_commit_encodings"));
+    ZKW_TRY(ctx->finish_out(reinterpret_cast<u64*>(compact), d_cf, n * COMPACT_FORM_LEN));
+    ZKW_TRY(ctx->finish_out(reinterpret_cast<u64*>(public_inputs), d_pi, n * 4));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_closed_form_public_inputs(zkw_ctx* ctx, uint8_t circuit_type, const void* instances, size_t n, uint64_t* compact,
+                                             uint64_t* public_inputs) {
+    if (!ctx || !compact || !public_inputs || (n && !instances)) return fail(ZKW_ERR_INVALID, "zkw_closed_form_public_inputs: null argument");
+    if (n == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    switch (circuit_type) {
+        case 3: return closed_form_from_records<CfDecommitter>(ctx, instances, n, compact, public_inputs);
+        case 5: return closed_form_from_records<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>>(ctx, instances, n, compact, public_inputs);
+        case 6: return closed_form_from_records<CfPrecompile<ZKW_PRECOMPILE_SHA256>>(ctx, instances, n, compact, public_inputs);
+        case 7: return closed_form_from_records<CfPrecompile<ZKW_PRECOMPILE_ECRECOVER>>(ctx, instances, n, compact, public_inputs);
+        case 10: return closed_form_from_records<CfStorageApplication>(ctx, instances, n, compact, public_inputs);
+        case 13: return closed_form_from_records<CfLinearHasher>(ctx, instances, n, compact, public_inputs);
+        default: break;
+    }
+    return fail(ZKW_ERR_INVALID, "zkw_closed_form_public_inputs: circuit type %u keeps its compact forms in its witness (2, 4, 8, 9, 11, 12) "
+                                 "or is not a base-layer circuit with a closed form here", (unsigned)circuit_type);
 }
 
 struct zkw_events_witness {

@@ -143,6 +143,7 @@ struct zkw_block {
     uint64_t dmx_off[7] = {};
     zkw_queue_state12 mem_state;
     uint8_t l1_hash[32] = {};
+    zkw_linear_hasher_instance linear_hasher = {};
     PerType per[14];
     std::vector<zkw_vm_instance> vm_instances;
     // synthesis ring (created by the first zkw_block_synthesize)
@@ -450,6 +451,39 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
         src.push_back({T_STO, zkw_storage_witness_device_ptr(B->sto, ZKW_STO_PUBLIC_INPUTS), zkw_storage_witness_device_ptr(B->sto, ZKW_STO_COMPACT_FORMS), zkw_storage_witness_num_instances(B->sto)});
         src.push_back({T_EVT, zkw_events_witness_device_ptr(B->evt, ZKW_EVT_PUBLIC_INPUTS), zkw_events_witness_device_ptr(B->evt, ZKW_EVT_COMPACT_FORMS), zkw_events_witness_num_instances(B->evt)});
         src.push_back({T_L1, zkw_events_witness_device_ptr(B->l1, ZKW_EVT_PUBLIC_INPUTS), zkw_events_witness_device_ptr(B->l1, ZKW_EVT_COMPACT_FORMS), zkw_events_witness_num_instances(B->l1)});
+        // the circuits whose builders return instance records without compact forms (3, 5, 6, 7, 10, 13): commitments from
+        // the records (zkw_closed_form_public_inputs); the MainVM closed form needs the VM's local state and is the host's
+        zkw_ctx* cfc = B->ctx[C_PRE];
+        auto closed_form = [&](int type, const void* d_inst, size_t n) -> Status {
+            uint64_t *d_cf = nullptr, *d_pi = nullptr;
+            ST_TRY(B->alloc(&d_cf, n * 18));
+            ST_TRY(B->alloc(&d_pi, n * 4));
+            ST_ZKW(zkw_closed_form_public_inputs(cfc, (uint8_t)type, d_inst, n, d_cf, d_pi));
+            src.push_back({type, d_pi, d_cf, n});
+            return Status();
+        };
+        ST_TRY(closed_form(T_DCM, zkw_decommitter_witness_device_ptr(B->dcm, ZKW_DCM_INSTANCES), zkw_decommitter_witness_num_instances(B->dcm)));
+        for (int k = 0; k < 3; k++)
+            ST_TRY(closed_form(T_KEC + k, zkw_precompile_witness_device_ptr(B->pre[k], ZKW_PRC_INSTANCES), zkw_precompile_witness_num_instances(B->pre[k])));
+        if (B->sap)
+            ST_TRY(closed_form(T_SAP, zkw_storage_application_witness_device_ptr(B->sap, ZKW_SAP_INSTANCES),
+                               zkw_storage_application_witness_num_instances(B->sap)));
+        {   // LinearHasher: one instance over the net L2 -> L1 messages queue (data_hasher_and_merklizer.rs:34-60)
+            zkw_linear_hasher_instance h;
+            memset(&h, 0, sizeof h);
+            h.start_flag = h.completion_flag = 1;
+            const size_t nl = zkw_events_witness_num_instances(B->l1);
+            zkw_events_sorter_instance last;
+            ST_TRY(B->xf[X_MAIN].d2h(&last, static_cast<const zkw_events_sorter_instance*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_INSTANCES)) + (nl - 1),
+                                     sizeof last));
+            h.queue_state = last.final_queue_state;  // take_queue_state_from_simulator of the deduplicated queue
+            memcpy(h.keccak256_hash, B->l1_hash, 32);
+            B->linear_hasher = h;
+            zkw_linear_hasher_instance* d_h = nullptr;
+            ST_TRY(B->upload(X_MAIN, &d_h, &h, 1));
+            ST_TRY(closed_form(T_HSH, d_h, 1));
+        }
+        ST_ZKW(zkw_synchronize(cfc));
         size_t total = 0;
         for (auto& s : src) total += s.n;
         uint64_t *d_enc = nullptr, *d_states = nullptr;
@@ -672,6 +706,11 @@ extern "C" int zkw_block_memory_queue_state(const zkw_block* B, zkw_queue_state1
 extern "C" int zkw_block_demuxed_offsets(const zkw_block* B, uint64_t out[7]) {
     if (!B || !out) return ZKW_ERR_INVALID;
     memcpy(out, B->dmx_off, sizeof B->dmx_off);
+    return ZKW_OK;
+}
+extern "C" int zkw_block_linear_hasher_instance(const zkw_block* B, zkw_linear_hasher_instance* out) {
+    if (!B || !out) return ZKW_ERR_INVALID;
+    *out = B->linear_hasher;
     return ZKW_OK;
 }
 extern "C" int zkw_block_l1_messages_hash(const zkw_block* B, uint8_t out[32]) {

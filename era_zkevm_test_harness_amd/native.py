@@ -39,6 +39,8 @@ SYMBOLS = [
     ("zkw_stream_acquire", _int, [_vp, C.POINTER(C.c_void_p)]),
     ("zkw_stream_release", None, [_vp, _vp]),
     ("zkw_trim_caches", None, []),
+    ("zkw_block_linear_hasher_instance", _int, [_vp, _vp]),
+    ("zkw_closed_form_public_inputs", _int, [_vp, C.c_uint8, _vp, C.c_size_t, _vp, _vp]),
     ("zkw_version", C.c_char_p, []),
     ("zkw_circuit_geometry_of", _int, [C.c_uint8, _vp]),
     ("zkw_circuit_layout_of", _int, [C.c_uint8, _u32, _vp]),
@@ -449,6 +451,12 @@ STORAGE_APPLICATION_INSTANCE = np.dtype(
      ("hidden_fsm_input", STORAGE_APPLICATION_FSM), ("hidden_fsm_output", STORAGE_APPLICATION_FSM), ("first_item", "<u8"),
      ("num_items", "<u8")])
 assert STORAGE_APPLICATION_FSM.itemsize == 312 and STORAGE_APPLICATION_INSTANCE.itemsize == 840
+LINEAR_HASHER_INSTANCE = np.dtype([("start_flag", "<u4"), ("completion_flag", "<u4"), ("queue_state", QUEUE_STATE4),
+                                   ("keccak256_hash", "u1", (32,))])
+assert LINEAR_HASHER_INSTANCE.itemsize == 112
+# instance record of the circuits zkw_closed_form_public_inputs serves, by numeric circuit type
+CLOSED_FORM_RECORD = {3: DECOMMITTER_INSTANCE, 5: PRECOMPILE_INSTANCE, 6: PRECOMPILE_INSTANCE, 7: PRECOMPILE_INSTANCE,
+                      10: STORAGE_APPLICATION_INSTANCE, 13: LINEAR_HASHER_INSTANCE}
 PRC_MEM_ENC, PRC_MEM_TAILS, PRC_INSTANCES = range(3)
 SAP_DERIVED_KEYS, SAP_MERKLE_PATHS, SAP_LEAF_INDEXES, SAP_ROOTS, SAP_INSTANCES = range(5)
 
@@ -933,6 +941,16 @@ class Context:
         _check(load().zkw_commit_encodings(self.handle, _np_ptr(buf), enc.shape[0], enc.shape[1], _np_ptr(out)))
         return out
 
+    def closed_form_public_inputs(self, circuit_type, instances):
+        """zkw_closed_form_public_inputs: compact closed-form inputs [n][18] and public inputs [n][4] of the instance
+        records of circuit type 3, 5, 6, 7, 10 or 13 (postprocessing/mod.rs:353-369)."""
+        inst = np.ascontiguousarray(instances, dtype=CLOSED_FORM_RECORD[circuit_type])
+        compact = np.zeros((inst.size, 18), np.uint64)
+        pi = np.zeros((inst.size, 4), np.uint64)
+        _check(load().zkw_closed_form_public_inputs(self.handle, circuit_type, _np_ptr(inst) if inst.size else None, inst.size,
+                                                    _np_ptr(compact), _np_ptr(pi)))
+        return compact, pi
+
     def recursion_queue_push(self, circuit_type, public_inputs, tail_in=None):
         """RecursionQueueSimulator::push for every instance of one circuit type (postprocessing/mod.rs:393-400):
         returns (encodings [n][8], queue states [n][12])."""
@@ -1333,6 +1351,11 @@ class Block:
         o = np.zeros(7, np.uint64)
         _check(load().zkw_block_demuxed_offsets(self.handle, _np_ptr(o)))
         return o
+
+    def linear_hasher_instance(self):
+        rec = np.zeros(1, LINEAR_HASHER_INSTANCE)
+        _check(load().zkw_block_linear_hasher_instance(self.handle, _np_ptr(rec)))
+        return rec
 
     def l1_messages_hash(self):
         h = np.zeros(32, np.uint8)

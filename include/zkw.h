@@ -521,6 +521,16 @@ int zkw_commit_encodings(zkw_ctx *ctx, const uint64_t *enc, size_t n_items, uint
 int zkw_encode_recursion_requests(zkw_ctx *ctx, uint64_t circuit_type, const uint64_t *public_inputs, size_t n,
                                   uint64_t *enc /* n*8 */);
 
+/* ClosedFormInputCompactForm::from_full_form + the public input (postprocessing/mod.rs:353-369) for the circuits whose
+   builders return instance records without compact forms: circuit_type 3 (zkw_decommitter_instance), 5 / 6 / 7
+   (zkw_precompile_instance of that kind), 10 (zkw_storage_application_instance), 13 (zkw_linear_hasher_instance). The
+   observable input of instance i is the one of the latest instance <= i with start_flag set, as in the reference.
+   compact: [n][18] = start, completion, 4 x 4 commitment words; public_inputs: [n][4]. Types 2, 4, 8, 9, 11, 12 carry
+   theirs in the witness (ZKW_*_COMPACT_FORMS / ZKW_*_PUBLIC_INPUTS); the MainVM closed form needs the VM's local state,
+   which this library does not see. */
+int zkw_closed_form_public_inputs(zkw_ctx *ctx, uint8_t circuit_type, const void *instances, size_t n, uint64_t *compact,
+                                  uint64_t *public_inputs);
+
 /* ---- L1 messages hasher ------------------------------------------------------------------------------ */
 /* compute_linear_keccak256, src/witness/individual_circuits/data_hasher_and_merklizer.rs:8-67: Keccak-256 of
    the concatenated 88-byte serialisations (circuit_encodings/src/log_query.rs:503-534) of the net L2->L1
@@ -663,7 +673,8 @@ void zkw_block_free(zkw_block *b);
 void *zkw_block_witness(const zkw_block *b, uint8_t circuit_type);
 zkw_ctx *zkw_block_context(const zkw_block *b, uint8_t circuit_type);
 size_t zkw_block_num_instances(const zkw_block *b, uint8_t circuit_type);
-/* public inputs [n_instances][4] of a type that has them (2, 4, 8, 9, 11, 12), the RecursionRequest encodings
+/* public inputs [n_instances][4] of every type but MainVM (1; its closed form needs the VM's local state; 10 only when the
+   storage tree answers were given), the RecursionRequest encodings
    [n_instances][8] and the RecursionQueueSimulator states [n_instances][12] after each push (postprocessing/mod.rs:393-400).
    Host pointers valid until zkw_block_free; NULL when the type has none. */
 const uint64_t *zkw_block_public_inputs(const zkw_block *b, uint8_t circuit_type);
@@ -678,6 +689,8 @@ const zkw_mem_query *zkw_block_memory_queue_device_ptr(const zkw_block *b);
 int zkw_block_memory_queue_state(const zkw_block *b, zkw_queue_state12 *out);
 int zkw_block_demuxed_offsets(const zkw_block *b, uint64_t out[7]);
 int zkw_block_l1_messages_hash(const zkw_block *b, uint8_t out[32]);
+/* the LinearHasher instance (type 13) over the net L2 -> L1 messages queue: its closed form is among zkw_block_public_inputs */
+int zkw_block_linear_hasher_instance(const zkw_block *b, zkw_linear_hasher_instance *out);
 /* wall-clock spans of the last run: names (comma separated), then start / end in ms since zkw_block_run was entered */
 int zkw_block_timings(const zkw_block *b, char *names, size_t names_bytes, double *start_ms, double *end_ms, size_t max_spans,
                       size_t *n_spans);

@@ -409,6 +409,15 @@ typedef struct zkw_storage_application_instance {
     uint64_t num_items;
 } zkw_storage_application_instance;
 
+/* ---- LinearHasher (type 13): LinearHasherCircuitInstanceWitness, src/witness/individual_circuits/
+   data_hasher_and_merklizer.rs:34-60: one instance per block, no FSM (start = completion = 1) ------------------------- */
+typedef struct zkw_linear_hasher_instance {
+    uint32_t start_flag;
+    uint32_t completion_flag;
+    zkw_queue_state4 queue_state; /* observable_input: the L1-messages result queue (:34-37) */
+    uint8_t keccak256_hash[32];   /* observable_output (:38-49) */
+} zkw_linear_hasher_instance;
+
 /* ---- MainVM instance slicing (a19): src/witness/oracle.rs:1229-1469, src/witness/utils.rs:428-496 -------------------- */
 /* The eight cycle-stamped FIFOs the reference cuts into per-instance `VmWitnessOracle`s
    (circuit_definitions/src/aux_definitions/witness_oracle.rs:25-36): element k of stream s happened at VM cycle

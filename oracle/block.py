@@ -55,6 +55,7 @@ def create_artifacts_after_vm(block, capacities=None, storage_tree=None, timings
     dcm = timed("code_decommitter", o.decommitter_build, dec["dedup_q"], dec["dedup_tails"], np.concatenate(codes), woff,
                 cap[CODE_DECOMMITTER], mem_state)
     art["code_decommitter"] = dcm
+    pis[CODE_DECOMMITTER] = o.closed_form_public_inputs(CODE_DECOMMITTER, dcm["instances"])[1]
     memory.append(dcm["mem_q"])
     mem_state = _state12(dcm["mem_tails"][-1], int(mem_state["length"][0]) + dcm["mem_q"].size)
     dmx = timed("log_demuxer", o.log_demux_build, block["log_queries"], cap[LOG_DEMUXER])
@@ -67,6 +68,7 @@ def create_artifacts_after_vm(block, capacities=None, storage_tree=None, timings
         mq = np.ascontiguousarray(block["precompile_memory_queries"][k], dtype=o.MEM_QUERY)
         w = timed(name, o.precompile_build, k, req, req_tails, mq, cap[ctype], mem_state)
         art[name] = w
+        pis[ctype] = o.closed_form_public_inputs(ctype, w["instances"])[1]
         if mq.size:
             memory.append(mq)
             mem_state = _state12(w["mem_tails"][-1], int(mem_state["length"][0]) + mq.size)
@@ -84,9 +86,17 @@ def create_artifacts_after_vm(block, capacities=None, storage_tree=None, timings
     art["l1_messages_sorter"] = l1s
     pis[L1_MESSAGES_SORTER] = o.events_sorter_public_inputs(l1s["instances"])[1]
     pubdata_hash = timed("l1_messages_hasher", o.linear_keccak256, l1s["result_q"])
+    hasher = np.zeros(1, o.LINEAR_HASHER_INSTANCE)  # data_hasher_and_merklizer.rs:34-60
+    hasher["start_flag"] = hasher["completion_flag"] = 1
+    hasher["queue_state"] = l1s["instances"]["final_queue_state"][-1]
+    hasher["keccak256_hash"] = np.frombuffer(pubdata_hash, np.uint8)
+    art["l1_messages_hasher"] = {"instances": hasher}
+    pis[L1_MESSAGES_HASHER] = o.closed_form_public_inputs(L1_MESSAGES_HASHER, hasher)[1]
     if storage_tree is not None:
-        art["storage_application"] = timed("storage_application", o.storage_application_build, storage_tree, sto["result_q"],
-                                           sto["result_new_tails"], cap[STORAGE_APPLICATION])
+        sap = timed("storage_application", o.storage_application_build, storage_tree, sto["result_q"],
+                    sto["result_new_tails"], cap[STORAGE_APPLICATION])
+        art["storage_application"] = sap
+        pis[STORAGE_APPLICATION] = o.closed_form_public_inputs(STORAGE_APPLICATION, sap["instances"])[1]
     recursion = {t: o.recursion_queue(t, p) for t, p in pis.items()}
     return {"witnesses": art, "memory_queries": all_mem, "memory_queue_state": mem_state, "demuxed_offsets": off,
             "public_inputs": pis, "recursion_queues": recursion, "l1_messages_pubdata_hash": pubdata_hash, "capacities": cap}

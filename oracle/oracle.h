@@ -207,6 +207,9 @@ int orc_log_demux_synthesize(const zkw_log_demux_instance *inst, const uint64_t 
 void orc_log_demux_public_inputs(const zkw_log_demux_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
 void orc_events_sorter_public_inputs(const zkw_events_sorter_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
 void orc_storage_sorter_public_inputs(const zkw_storage_sorter_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
+/* closed-form commitments of the circuits 3, 5, 6, 7, 10, 13 (instances: the type's zkw_*_instance records); -1 = unknown type */
+#define ORC_CF_MAX_FSM_LEN 448
+int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_t n, uint64_t *compact, uint64_t *pi);
 uint64_t orc_log_demux_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 /* storage_sorter_circuit.c: StorageSorter synthesis (circuit type 9) */
 int orc_storage_sorter_synthesize(const zkw_storage_sorter_instance *inst, const uint64_t *unsorted_enc, const uint64_t *sorted_enc,

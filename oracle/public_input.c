@@ -256,3 +256,149 @@ void orc_storage_sorter_public_inputs(const zkw_storage_sorter_instance *inst, s
         compact_and_pi(inst[i].start_flag, inst[i].completion_flag, in, n_in, out, n_out, fi, n_fi, fo, n_fo, compact + 18 * i, pi + 4 * i);
     }
 }
+
+/* ---- the remaining non-VM circuits: CodeDecommitter 3, Keccak256 / Sha256 / ECRecover round functions 5 / 6 / 7,
+   StorageApplication 10, LinearHasher 13. The closed-form structs live in the absent zkevm_circuits crate (v1.4.1:
+   code_unpacker_sha256/input.rs, keccak256_round_function/input.rs, sha256_round_function/input.rs, ecrecover/input.rs,
+   storage_application/input.rs, linear_hasher/input.rs); field order restated from their published declarations, the
+   field SETS are the ones the reference's builders fill (decommit_code.rs:172-199,363-401; keccak256_round_function.rs:
+   420-441; sha256_round_function.rs:302-316; ecrecover.rs:215-233; storage_application.rs:286-336;
+   data_hasher_and_merklizer.rs:34-60). One field element per Boolean / UInt8 / UInt16 / UInt32, eight per UInt256
+   (u32 limbs, least significant first). PARITY UNPINNED like the types above. */
+static size_t put_bytes(const uint8_t *b, size_t n, uint64_t *o) {
+    for (size_t k = 0; k < n; k++) o[k] = b[k];
+    return n;
+}
+static size_t put_u32s(const uint32_t *w, size_t n, uint64_t *o) {
+    for (size_t k = 0; k < n; k++) o[k] = w[k];
+    return n;
+}
+/* CodeDecommitterFSMInputOutput { internal_fsm: CodeDecommittmentFSM, decommittment_requests_queue_state, memory_queue_state } */
+static size_t dcm_fsm(const zkw_decommitter_fsm *f, uint64_t *o) {
+    size_t m = put_u32s(f->sha256_inner_state, 8, o);
+    m += put_u32s(f->hash_to_compare_against, 8, o + m);
+    o[m++] = f->current_index;
+    o[m++] = f->current_page;
+    o[m++] = f->timestamp;
+    o[m++] = f->num_rounds_left;
+    o[m++] = f->length_in_bits;
+    o[m++] = f->state_get_from_queue ? 1 : 0;
+    o[m++] = f->state_decommit ? 1 : 0;
+    o[m++] = f->finished ? 1 : 0;
+    m += put_queue12(&f->decommittment_requests_queue_state, o + m);
+    m += put_queue12(&f->memory_queue_state, o + m);
+    return m;
+}
+/* {Keccak256,Sha256}RoundFunctionFSMInputOutput { internal_fsm, log_queue_state, memory_queue_state };
+   EcrecoverCircuitFSMInputOutput { log_queue_state, memory_queue_state } */
+static size_t pre_fsm(int kind, const zkw_precompile_fsm *f, uint64_t *o) {
+    size_t m = 0;
+    if (kind == ZKW_PRECOMPILE_KECCAK256) {
+        o[m++] = f->read_precompile_call ? 1 : 0;
+        o[m++] = f->read_words_for_round ? 1 : 0;
+        o[m++] = f->completed ? 1 : 0;
+        o[m++] = f->padding_round ? 1 : 0;
+        m += put_bytes(f->keccak_internal_state, 200, o + m);
+        o[m++] = f->timestamp_to_use_for_read;
+        o[m++] = f->timestamp_to_use_for_write;
+        o[m++] = f->input_page;   /* Keccak256PrecompileCallParams */
+        o[m++] = f->input_offset;
+        o[m++] = f->input_length;
+        o[m++] = f->output_page;
+        o[m++] = f->output_offset;
+        o[m++] = f->needs_full_padding_round ? 1 : 0;
+        m += put_bytes(f->buffer_bytes, ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE, o + m); /* ByteBuffer { bytes, filled } */
+        o[m++] = f->buffer_filled;
+    } else if (kind == ZKW_PRECOMPILE_SHA256) {
+        o[m++] = f->read_precompile_call ? 1 : 0;
+        o[m++] = f->read_words_for_round ? 1 : 0;
+        o[m++] = f->completed ? 1 : 0;
+        m += put_u32s(f->sha256_inner_state, 8, o + m);
+        o[m++] = f->timestamp_to_use_for_read;
+        o[m++] = f->timestamp_to_use_for_write;
+        o[m++] = f->input_page;   /* Sha256PrecompileCallParams */
+        o[m++] = f->input_offset;
+        o[m++] = f->output_page;
+        o[m++] = f->output_offset;
+        o[m++] = f->num_rounds;
+    }
+    m += put_queue4(&f->log_queue_state, o + m);
+    m += put_queue12(&f->memory_queue_state, o + m);
+    return m;
+}
+/* StorageApplicationFSMInputOutput { current_root_hash, next_enumeration_counter, current_storage_application_log_state,
+   current_diffs_keccak_accumulator_state } */
+static size_t sap_fsm(const zkw_storage_application_fsm *f, uint64_t *o) {
+    size_t m = put_bytes(f->current_root_hash, 32, o);
+    m += put_u32s(f->next_enumeration_counter, 2, o + m);
+    m += put_queue4(&f->current_storage_application_log_state, o + m);
+    m += put_bytes(f->current_diffs_keccak_accumulator_state, 200, o + m);
+    return m;
+}
+
+int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_t n, uint64_t *compact, uint64_t *pi) {
+    uint64_t in[64], out[80];
+    uint64_t *fi = malloc(2 * ORC_CF_MAX_FSM_LEN * sizeof(uint64_t)), *fo = fi + ORC_CF_MAX_FSM_LEN;
+    int rc = 0;
+    size_t first = 0;
+    for (size_t i = 0; i < n && rc == 0; i++) {
+        size_t n_in = 0, n_out = 0, n_fi = 0, n_fo = 0;
+        int start = 0, completion = 0;
+        switch (circuit_type) {
+            case 3: {
+                const zkw_decommitter_instance *w = (const zkw_decommitter_instance *)instances;
+                if (w[i].start_flag) first = i;
+                start = w[i].start_flag; completion = w[i].completion_flag;
+                /* CodeDecommitterInputData { memory_queue_initial_state, sorted_requests_queue_initial_state } */
+                n_in = put_queue12(&w[first].memory_queue_initial_state, in);
+                n_in += put_queue12(&w[first].sorted_requests_queue_initial_state, in + n_in);
+                n_out = put_queue12(&w[i].memory_queue_final_state, out);
+                n_fi = dcm_fsm(&w[i].hidden_fsm_input, fi);
+                n_fo = dcm_fsm(&w[i].hidden_fsm_output, fo);
+                break;
+            }
+            case 5: case 6: case 7: {
+                const zkw_precompile_instance *w = (const zkw_precompile_instance *)instances;
+                const int kind = circuit_type - 5; /* ZKW_PRECOMPILE_KECCAK256 .. ZKW_PRECOMPILE_ECRECOVER */
+                if (w[i].start_flag) first = i;
+                start = w[i].start_flag; completion = w[i].completion_flag;
+                /* PrecompileFunctionInputData { initial_log_queue_state, initial_memory_queue_state } */
+                n_in = put_queue4(&w[first].initial_log_queue_state, in);
+                n_in += put_queue12(&w[first].initial_memory_queue_state, in + n_in);
+                n_out = put_queue12(&w[i].final_memory_state, out);
+                n_fi = pre_fsm(kind, &w[i].hidden_fsm_input, fi);
+                n_fo = pre_fsm(kind, &w[i].hidden_fsm_output, fo);
+                break;
+            }
+            case 10: {
+                const zkw_storage_application_instance *w = (const zkw_storage_application_instance *)instances;
+                if (w[i].start_flag) first = i;
+                start = w[i].start_flag; completion = w[i].completion_flag;
+                /* StorageApplicationInputData { shard, initial_root_hash, initial_next_enumeration_counter,
+                   storage_application_log_state } */
+                in[0] = w[first].shard;
+                n_in = 1 + put_bytes(w[first].initial_root_hash, 32, in + 1);
+                n_in += put_u32s(w[first].initial_next_enumeration_counter, 2, in + n_in);
+                n_in += put_queue4(&w[first].storage_application_log_state, in + n_in);
+                /* StorageApplicationOutputData { new_root_hash, new_next_enumeration_counter, state_diffs_keccak256_hash } */
+                n_out = put_bytes(w[i].new_root_hash, 32, out);
+                n_out += put_u32s(w[i].new_next_enumeration_counter, 2, out + n_out);
+                n_out += put_bytes(w[i].state_diffs_keccak256_hash, 32, out + n_out);
+                n_fi = sap_fsm(&w[i].hidden_fsm_input, fi);
+                n_fo = sap_fsm(&w[i].hidden_fsm_output, fo);
+                break;
+            }
+            case 13: {
+                const zkw_linear_hasher_instance *w = (const zkw_linear_hasher_instance *)instances;
+                start = w[i].start_flag; completion = w[i].completion_flag;
+                n_in = put_queue4(&w[i].queue_state, in);      /* LinearHasherInputData { queue_state } */
+                n_out = put_bytes(w[i].keccak256_hash, 32, out); /* LinearHasherOutputData { keccak256_hash } */
+                break;                                          /* hidden FSM = (): nothing absorbed */
+            }
+            default: rc = -1; break;
+        }
+        if (rc == 0) compact_and_pi(start, completion, in, n_in, out, n_out, fi, n_fi, fo, n_fo, compact + 18 * i, pi + 4 * i);
+    }
+    free(fi);
+    return rc;
+}

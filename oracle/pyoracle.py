@@ -802,6 +802,27 @@ def events_sorter_public_inputs(instances):
 def storage_sorter_public_inputs(instances):
     return _public_inputs("orc_storage_sorter_public_inputs", instances)
 
+
+LINEAR_HASHER_INSTANCE = np.dtype([("start_flag", "<u4"), ("completion_flag", "<u4"), ("queue_state", QUEUE_STATE4),
+                                   ("keccak256_hash", "u1", (32,))])
+CLOSED_FORM_RECORD = {3: DECOMMITTER_INSTANCE, 5: PRECOMPILE_INSTANCE, 6: PRECOMPILE_INSTANCE, 7: PRECOMPILE_INSTANCE,
+                      10: STORAGE_APPLICATION_INSTANCE, 13: LINEAR_HASHER_INSTANCE}
+
+
+def closed_form_public_inputs(circuit_type, instances):
+    """orc_closed_form_public_inputs: (compact [n][18], public inputs [n][4]) of the instance records of circuit type
+    3, 5, 6, 7, 10 or 13"""
+    instances = np.ascontiguousarray(instances, dtype=CLOSED_FORM_RECORD[circuit_type])
+    n = instances.size
+    compact, pi = np.zeros((n, 18), np.uint64), np.zeros((n, 4), np.uint64)
+    f = lib().orc_closed_form_public_inputs
+    f.restype = C.c_int
+    rc = f(C.c_int(circuit_type), _p(instances), C.c_size_t(n), _p(compact), _p(pi))
+    if rc != 0:
+        raise ValueError(f"orc_closed_form_public_inputs: unknown circuit type {circuit_type}")
+    return compact, pi
+
+
 # ---- MainVM instance slicing (include/zkw_types.h: zkw_vm_instance & co) ------------------------------------------------
 VM_NUM_STREAMS = 8
 (VMS_MEMORY, VMS_STORAGE_QUERIES, VMS_REFUNDS, VMS_DECOMMIT_REQUESTS, VMS_ROLLBACK_TAILS_FOR_NEW_FRAMES, VMS_CALLSTACK_VALUES,

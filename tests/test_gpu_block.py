@@ -144,6 +144,16 @@ def test_block_sequencer_matches_builder_by_builder(ctx, oracle, seed):
     o = oracle.storage_application_build(tree, dedup, qt, caps[blk.STORAGE_APPLICATION])
     assert B.witness_get(blk.STORAGE_APPLICATION, nv.SAP_ROOTS, np.uint8).tobytes() == o["roots"].tobytes()
     assert B.num_instances(blk.STORAGE_APPLICATION) == o["instances"].size >= 2
+    # closed forms of every non-VM type: the builder-by-builder path, the oracle on the same records, the sequencer
+    assert B.linear_hasher_instance().tobytes() == a["linear_hasher_instance"].tobytes()
+    a["public_inputs"][blk.STORAGE_APPLICATION] = ctx.closed_form_public_inputs(blk.STORAGE_APPLICATION, sap.get(nv.SAP_INSTANCES))[1]
+    a["recursion_queues"][blk.STORAGE_APPLICATION] = ctx.recursion_queue_push(blk.STORAGE_APPLICATION, a["public_inputs"][blk.STORAGE_APPLICATION])
+    assert set(a["public_inputs"]) == set(range(2, 14))
+    for ctype, what, key in pairs:
+        if ctype in nv.CLOSED_FORM_RECORD:
+            assert np.array_equal(oracle.closed_form_public_inputs(ctype, w[key].get(what))[1], a["public_inputs"][ctype]), key
+    assert np.array_equal(oracle.closed_form_public_inputs(blk.STORAGE_APPLICATION, o["instances"])[1], a["public_inputs"][blk.STORAGE_APPLICATION])
+    assert np.array_equal(oracle.closed_form_public_inputs(13, a["linear_hasher_instance"])[1], a["public_inputs"][13])
     sap.free()
     # public inputs and recursion queues
     for ctype, pi in a["public_inputs"].items():

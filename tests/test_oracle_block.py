@@ -34,3 +34,42 @@ def test_oracle_block_threads_queues_and_satisfies_circuits(oracle):
     assert n == len(seen) > 12 and seen == sorted(seen, key=ob.EMISSION_ORDER.index)
     for ctype, (enc, states) in a["recursion_queues"].items():
         assert np.array_equal(enc[:, 1:5], a["public_inputs"][ctype]) and (enc[:, 0] == ctype).all()
+
+
+def test_oracle_closed_forms_of_the_record_only_circuits(oracle):
+    """ClosedFormInputCompactForm for the circuits whose builders return records without compact forms (3, 5, 6, 7, 10,
+    13): flags copied, the observable input of every instance is the block's first one, the four commitments are the
+    variable-length commitment of the flat encoding (spot-checked by re-encoding the smallest struct by hand), the public
+    input commits to the compact form."""
+    from oracle import block as ob
+
+    b = synthetic.block_after_vm(seed=2)
+    caps = {ob.DECOMMITS_SORTER: 5, ob.CODE_DECOMMITTER: 7, ob.LOG_DEMUXER: 64, ob.KECCAK256: 3, ob.SHA256: 4, ob.ECRECOVER: 2,
+            ob.RAM_PERMUTATION: 1000, ob.STORAGE_SORTER: 40, ob.STORAGE_APPLICATION: 5, ob.EVENTS_SORTER: 16, ob.L1_MESSAGES_SORTER: 9}
+    tree = oracle.Tree()
+    a = ob.create_artifacts_after_vm(b, caps)
+    w = a["witnesses"]
+    assert set(a["public_inputs"]) == set(range(2, 14)) - {ob.STORAGE_APPLICATION}  # 10 needs the tree
+    keys = {ob.CODE_DECOMMITTER: "code_decommitter", ob.KECCAK256: "keccak256", ob.SHA256: "sha256", ob.ECRECOVER: "ecrecover",
+            ob.L1_MESSAGES_HASHER: "l1_messages_hasher"}
+    for ctype, key in keys.items():
+        inst = w[key]["instances"]
+        compact, pi = oracle.closed_form_public_inputs(ctype, inst)
+        assert np.array_equal(pi, a["public_inputs"][ctype]) and compact.shape == (inst.size, 18)
+        assert np.array_equal(compact[:, 0], inst["start_flag"]) and np.array_equal(compact[:, 1], inst["completion_flag"])
+        assert (compact[:, 2:6] == compact[0, 2:6]).all(), "one observable input per block"
+        assert np.array_equal(pi, np.array([oracle.commit_var_length(c) for c in compact]))
+        if inst.size > 1:
+            assert not np.array_equal(compact[0, 14:18], compact[1, 14:18])     # FSM outputs differ between instances
+            assert np.array_equal(compact[0, 14:18], compact[1, 10:14])         # and chain: out of i == in of i + 1
+    # ECRecover: FSM = { log_queue_state (9 words), memory_queue_state (25 words) }
+    e = w["ecrecover"]["instances"][0]["hidden_fsm_output"]
+    flat = np.concatenate([e["log_queue_state"]["head"], e["log_queue_state"]["tail"], [e["log_queue_state"]["length"]],
+                           e["memory_queue_state"]["head"], e["memory_queue_state"]["tail"], [e["memory_queue_state"]["length"]]]).astype(np.uint64)
+    assert np.array_equal(oracle.commit_var_length(flat), oracle.closed_form_public_inputs(7, w["ecrecover"]["instances"])[0][0, 14:18])
+    # LinearHasher: input = the queue state (9 words), output = 32 hash bytes, no FSM (commitment of nothing = 0)
+    h = w["l1_messages_hasher"]["instances"]
+    c = oracle.closed_form_public_inputs(13, h)[0][0]
+    assert c[0] == c[1] == 1 and not c[10:18].any()
+    assert np.array_equal(c[6:10], oracle.commit_var_length(np.frombuffer(a["l1_messages_pubdata_hash"], np.uint8).astype(np.uint64)))
+    del tree
