@@ -125,6 +125,7 @@ struct PrecompileJob {
     u32* violations;
     u64 n_requests, total_rounds;
     u32 capacity;
+    zkw_keccak_round_record* keccak_rounds;  // keccak256 only, may be null: one record per round in the global round order
 };
 
 __device__ __forceinline__ void word_be_bytes(const u32* limbs, uint8_t out[32]) {  // U256::to_big_endian
@@ -222,6 +223,16 @@ __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
 #pragma unroll
             for (int k = 0; k < 17; k++) kst[k] ^= lanes[k];
             keccak_f1600(kst);
+            if (job.keccak_rounds) {  // the cycle of the Keccak256RoundFunction circuit: padded block, reset, state after
+                zkw_keccak_round_record* rec = job.keccak_rounds + g0 + round;
+                u64* blk64 = reinterpret_cast<u64*>(rec->block);  // records are 344 = 8 * 43 bytes: 8-byte aligned
+#pragma unroll
+                for (int k = 0; k < 17; k++) blk64[k] = lanes[k];
+                blk64[17] = round == 0 ? 1 : 0;                    // reset + 7 bytes of padding
+                u64* st64 = reinterpret_cast<u64*>(rec->state_after);
+#pragma unroll
+                for (int k = 0; k < 25; k++) st64[k] = kst[k];
+            }
             if (state == 1 && needs_extra_padding_round && round + 2 == num_rounds) state = 2;
         }
         if (is_last_round) {

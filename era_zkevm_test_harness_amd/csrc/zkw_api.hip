@@ -40,6 +40,7 @@
 #include "log_demux_circuit_kernels.cuh"
 #include "storage_sorter_circuit_kernels.cuh"
 #include "vm_kernels.cuh"
+#include "keccak_circuit_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -2862,8 +2863,12 @@ struct zkw_precompile_witness {
     size_t n_requests = 0, n_queries = 0, total_rounds = 0, total_reads = 0, n_instances = 0;
     u64 *mem_enc = nullptr, *mem_tails = nullptr;
     zkw_precompile_instance* instances = nullptr;
+    zkw_keccak_round_record* keccak_rounds = nullptr;  // keccak256 only: [total_rounds], the cycles of the circuit
+    int kind = 0;
+    u32 capacity = 0;
+    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
     void release() {
-        void* ptrs[] = {mem_enc, mem_tails, instances};
+        void* ptrs[] = {mem_enc, mem_tails, instances, keccak_rounds, cf_pi};
         for (void* p : ptrs)
             if (p) dev_free(p);
     }
@@ -2905,11 +2910,14 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
     w->total_rounds = meta[0];
     w->total_reads = meta[2];
     w->n_instances = n_requests ? (w->total_rounds + capacity - 1) / capacity : 1;
+    w->kind = kind;
+    w->capacity = capacity;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
     alloc((void**)&w->mem_enc, n_queries * 64);
     alloc((void**)&w->mem_tails, n_queries * 96);
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_precompile_instance));
+    if (kind == ZKW_PRECOMPILE_KECCAK256) alloc((void**)&w->keccak_rounds, w->total_rounds * sizeof(zkw_keccak_round_record));
     auto bail = [&](int rc) { w->release(); delete w; return rc; };
     if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_precompile_build: hipMalloc failed: %s", hipGetErrorString(e)));
     int rc = ZKW_OK;
@@ -2933,7 +2941,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
                 if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
             }
         }
-        PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity};
+        PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity, w->keccak_rounds};
         { Prof _p(ctx, "k_precompile_walk"); hipLaunchKernelGGL(k_precompile_walk, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
         if ((rc = launch_check("k_precompile_walk")) != ZKW_OK) return bail(rc);
     }
@@ -2975,6 +2983,7 @@ static const void* pc_array(const zkw_precompile_witness* w, int what, size_t* b
         case ZKW_PRC_MEM_ENC: *bytes = w->n_queries * 64; return w->mem_enc;
         case ZKW_PRC_MEM_TAILS: *bytes = w->n_queries * 96; return w->mem_tails;
         case ZKW_PRC_INSTANCES: *bytes = w->n_instances * sizeof(zkw_precompile_instance); return w->instances;
+        case ZKW_PRC_KECCAK_ROUNDS: *bytes = w->keccak_rounds ? w->total_rounds * sizeof(zkw_keccak_round_record) : 0; return w->keccak_rounds;
         default: *bytes = 0; return nullptr;
     }
 }
@@ -2989,7 +2998,7 @@ extern "C" const void* zkw_precompile_witness_device_ptr(const zkw_precompile_wi
 }
 extern "C" int zkw_precompile_witness_get(const zkw_precompile_witness* w, int what, void* dst, size_t dst_bytes) {
     if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_precompile_witness_get: null argument");
-    if (what < 0 || what > ZKW_PRC_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    if (what < 0 || what > ZKW_PRC_KECCAK_ROUNDS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
     size_t bytes = 0;
     const void* src = pc_array(w, what, &bytes);
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
@@ -3374,6 +3383,78 @@ extern "C" int zkw_log_demux_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, s
         return fail(ZKW_ERR_INVALID, "zkw_log_demux_check_satisfied: bad argument");
     if (LD_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     return check_satisfied<SpecLogDemux>(ctx, t, slot, capacity, n_violations, first_bad);
+}
+
+// ------------------------------------------------------------------------------------------------ Keccak256RoundFunction synthesis
+// ZkSyncBaseLayerCircuit::synthesis for Keccak256RoundFunction (type 5) in "zkw trace v3" (keccak_circuit_kernels.cuh)
+extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances,
+                                           zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_keccak_round_synthesize: bad argument");
+    if (w->kind != ZKW_PRECOMPILE_KECCAK256) return fail(ZKW_ERR_INVALID, "zkw_keccak_round_synthesize: not a keccak256 witness");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (t->n_cols < KC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the Keccak256RoundFunction circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, KC_COLS);
+    const u32 capacity = w->capacity;
+    const size_t n_rows = t->n_rows;
+    if (KC_MIN_ROWS(capacity) > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)KC_MIN_ROWS(capacity), n_rows);
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!w->cf_pi) {  // public inputs of the block's instances (a20), once
+        ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>>(ctx, w->instances, w->n_instances, &w->cf_pi));
+    }
+    u32* d_hist = nullptr;
+    const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
+    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", n_instances * hist_elems, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_elems * sizeof(u32), ctx->stream));
+    std::vector<KcSynthJob> jobs(n_instances);
+    for (size_t k = 0; k < n_instances; k++) {
+        const size_t i = first_instance + k;
+        KcSynthJob& j = jobs[k];
+        j.rounds = w->keccak_rounds;
+        // instance i covers the rounds [i * capacity, min((i + 1) * capacity, total)) of the block (none for the dummy instance)
+        j.first_round = (u64)i * capacity;
+        j.n_active = w->n_requests ? (u32)std::min<u64>(capacity, w->total_rounds - j.first_round) : 0;
+        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
+        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.hist = d_hist + k * hist_elems;
+        HIP_TRY(hipMemsetAsync(j.trace, 0, (size_t)KC_COLS * n_rows * sizeof(u64), ctx->stream));
+    }
+    KcSynthJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("kc_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)n_instances;
+    { Prof _p(ctx, "k_kc_fill"); hipLaunchKernelGGL(k_kc_fill, dim3(capacity, nj), dim3(KC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_kc_fill"));
+    { Prof _p(ctx, "k_kc_finish"); hipLaunchKernelGGL(k_kc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    return launch_check("k_kc_finish");
+}
+
+extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
+                                                uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_keccak_round_check_satisfied: bad argument");
+    if (t->n_cols < KC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %d", t->n_cols, KC_COLS);
+    if (KC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64* trace = t->data + slot * t->slot_elems();
+    const size_t n_rows = t->n_rows, hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
+    CheckResult* d_res = nullptr;
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
+    ZKW_TRY(ctx->scratch_t<u32>("kc_check_hist", hist_elems, &d_hist));
+    CheckResult init{0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, hist_elems * sizeof(u32), ctx->stream));
+    const size_t cyc_rows = KC_BOUNDARY_ROW(capacity);
+    { Prof _p(ctx, "k_kc_check_rows"); hipLaunchKernelGGL(k_kc_check_rows, dim3((unsigned)((cyc_rows + 255) / 256)), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_kc_check_rows"));
+    { Prof _p(ctx, "k_kc_check_tail"); hipLaunchKernelGGL(k_kc_check_tail, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_kc_check_tail"));
+    CheckResult res;
+    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
+    *n_violations = res.violations;
+    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
+    return ZKW_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ StorageSorter synthesis

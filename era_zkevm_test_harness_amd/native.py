@@ -111,6 +111,8 @@ SYMBOLS = [
     ("zkw_storage_sorter_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_storage_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_log_demux_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
+    ("zkw_keccak_round_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
     ("zkw_storage_application_witness_bytes", _sz, [_vp, _int]),
@@ -457,7 +459,9 @@ assert LINEAR_HASHER_INSTANCE.itemsize == 112
 # instance record of the circuits zkw_closed_form_public_inputs serves, by numeric circuit type
 CLOSED_FORM_RECORD = {3: DECOMMITTER_INSTANCE, 5: PRECOMPILE_INSTANCE, 6: PRECOMPILE_INSTANCE, 7: PRECOMPILE_INSTANCE,
                       10: STORAGE_APPLICATION_INSTANCE, 13: LINEAR_HASHER_INSTANCE}
-PRC_MEM_ENC, PRC_MEM_TAILS, PRC_INSTANCES = range(3)
+PRC_MEM_ENC, PRC_MEM_TAILS, PRC_INSTANCES, PRC_KECCAK_ROUNDS = range(4)
+KECCAK_ROUND_RECORD = np.dtype([("block", "u1", (136,)), ("reset", "u1"), ("_pad", "u1", (7,)), ("state_after", "u1", (200,))])
+assert KECCAK_ROUND_RECORD.itemsize == 344
 SAP_DERIVED_KEYS, SAP_MERKLE_PATHS, SAP_LEAF_INDEXES, SAP_ROOTS, SAP_INSTANCES = range(5)
 
 
@@ -502,7 +506,7 @@ class StorageApplicationWitness:
 class PrecompileWitness:
     """Owner of a zkw_precompile_witness handle (keccak256 / sha256 / ecrecover round-function instances)."""
 
-    _DTYPES = {PRC_INSTANCES: PRECOMPILE_INSTANCE}
+    _DTYPES = {PRC_INSTANCES: PRECOMPILE_INSTANCE, PRC_KECCAK_ROUNDS: KECCAK_ROUND_RECORD}
     _SHAPES = {PRC_MEM_ENC: (-1, 8), PRC_MEM_TAILS: (-1, 12)}
 
     def __init__(self, ctx):
@@ -1093,6 +1097,27 @@ def _ctx_check_if_satisfied_log_demux(self, trace, slot, capacity):
 
 
 Context.synthesize_log_demux = _ctx_synthesize_log_demux
+
+
+KC_COLS = 137  # include/zkw_keccak_circuit_spec.h
+
+
+def _ctx_synthesize_keccak_round_function(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+    """ZkSyncBaseLayerCircuit::Keccak256RoundFunction synthesis ("zkw trace v3") for instances of a keccak256
+    PrecompileWitness (the trace needs KC_COLS = 137 columns and at least 65 536 rows)."""
+    n = witness.num_instances - first_instance if n_instances is None else n_instances
+    _check(load().zkw_keccak_round_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+
+def _ctx_check_if_satisfied_keccak_round_function(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_keccak_round_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.synthesize_keccak_round_function = _ctx_synthesize_keccak_round_function
+Context.check_if_satisfied_keccak_round_function = _ctx_check_if_satisfied_keccak_round_function
 
 
 def _ctx_synthesize_storage_sorter(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):

@@ -487,7 +487,8 @@ int zkw_precompile_build_with_tails(zkw_ctx *ctx, int kind, const zkw_log_query 
 enum {
     ZKW_PRC_MEM_ENC = 0,   /* uint64_t[n_queries][8]  */
     ZKW_PRC_MEM_TAILS = 1, /* uint64_t[n_queries][12] */
-    ZKW_PRC_INSTANCES = 2  /* zkw_precompile_instance[max(1, ceil(total_rounds/capacity))] */
+    ZKW_PRC_INSTANCES = 2, /* zkw_precompile_instance[max(1, ceil(total_rounds/capacity))] */
+    ZKW_PRC_KECCAK_ROUNDS = 3 /* keccak256 only: zkw_keccak_round_record[total_rounds], the cycles of the type-5 circuit */
 };
 size_t zkw_precompile_witness_num_instances(const zkw_precompile_witness *w);
 size_t zkw_precompile_witness_num_rounds(const zkw_precompile_witness *w);
@@ -510,6 +511,20 @@ int zkw_encode_callstack_entries(zkw_ctx *ctx, const zkw_callstack_entry *entrie
 int zkw_callstack_simulate(zkw_ctx *ctx, const uint8_t *is_push, size_t n_ops, const zkw_callstack_entry *pushed,
                            size_t n_pushed, uint64_t *previous_state, uint64_t *new_state, uint32_t *depth,
                            uint64_t *round_states, uint32_t *entry_index);
+
+/* ---- Keccak256RoundFunction circuit (type 5) ----------------------------------------------------------------
+   ZkSyncBaseLayerCircuit::synthesis for the keccak256 round function (wrapper geometry: circuit_definitions/src/
+   circuit_definitions/base_layer/keccak256_round_function.rs:28-39,52-142: 86 copy columns, width-3 lookups x 14 per row
+   with one table id per row, 2^20 rows, capacity 293). Trace "zkw trace v3", include/zkw_keccak_circuit_spec.h: 137 columns
+   (zkw_trace_create_with_columns(.., 137, ..)), a netlist of byte lookups (XOR8, ANDN8, ROT<1..7>) stating, per cycle,
+   out = idle ? prev : Keccak-f[1600]((reset ? 0 : prev) ^ block); cycles = the instance's rounds (ZKW_PRC_KECCAK_ROUNDS),
+   idle up to the capacity the witness was built with. n_rows >= 65 536 (one multiplicity column per 2^16-row table).
+   The check re-derives every relation from the cells: table membership, copy constraints, headers, boundary rows,
+   multiplicities. w must be a keccak256 witness (zkw_precompile_build(ctx, ZKW_PRECOMPILE_KECCAK256, ..)). */
+int zkw_keccak_round_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t first_instance, size_t n_instances,
+                                zkw_trace *t, size_t first_slot);
+int zkw_keccak_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
+                                     uint64_t *n_violations, uint64_t *first_bad);
 
 /* ---- public inputs and the recursion queue (a20) ---------------------------------------------------- */
 /* commit_variable_length_encodable_item as driven by simulate_public_input_value_from_witness

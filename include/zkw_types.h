@@ -359,6 +359,17 @@ typedef struct zkw_precompile_fsm {
     uint32_t _pad;
 } zkw_precompile_fsm;
 
+/* One Keccak-f[1600] call of the keccak256 precompile (= one cycle of the Keccak256RoundFunction circuit, type 5), in the
+   global round order of the block: the padded 136-byte block absorbed by the call, whether it starts a new request (the
+   sponge state is reset to zero first) and the sponge state after the call ([x + 5y] lanes, little-endian bytes).
+   ZKW_PRC_KECCAK_ROUNDS of the keccak256 witness; consumed by zkw_keccak_round_synthesize. */
+typedef struct zkw_keccak_round_record {
+    uint8_t block[136];
+    uint8_t reset;
+    uint8_t _pad[7];
+    uint8_t state_after[200];
+} zkw_keccak_round_record;
+
 /* {Keccak256RoundFunction,Sha256RoundFunction,Ecrecover}CircuitInstanceWitness */
 typedef struct zkw_precompile_instance {
     uint32_t start_flag;

@@ -237,6 +237,14 @@ int64_t orc_storage_application_build(orc_tree *tree, const zkw_log_query *queri
 int64_t orc_precompile_build(int kind, const zkw_log_query *requests, const uint64_t *req_tails, size_t n_req,
                              const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,
                              uint64_t *mem_enc, uint64_t *mem_tails, zkw_precompile_instance *instances);
+int64_t orc_precompile_build_ex(int kind, const zkw_log_query *requests, const uint64_t *req_tails, size_t n_req,
+                                const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,
+                                uint64_t *mem_enc, uint64_t *mem_tails, zkw_precompile_instance *instances,
+                                zkw_keccak_round_record *keccak_rounds);
+/* ---- Keccak256RoundFunction circuit ("zkw trace v3", include/zkw_keccak_circuit_spec.h), keccak_circuit.c */
+int orc_keccak_round_synthesize(const uint8_t state_in[200], const zkw_keccak_round_record *rounds, uint32_t n_active,
+                                uint32_t capacity, const uint64_t pi[4], size_t n_rows, uint64_t *trace);
+uint64_t orc_keccak_round_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 
 /* ---- callstack (a3 / a6), see callstack.c */
 void orc_encode_callstack_entry(const zkw_callstack_entry *e, uint64_t out[32]);

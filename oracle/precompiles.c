@@ -82,9 +82,21 @@ static void mem_state(const walk_t *w, zkw_queue_state12 *s) { /* take_sponge_li
 
 /* Outputs: mem_enc [n_q*8], mem_tails [n_q*12] (the given queries appended to the memory queue), instances.
    Returns the number of instances, or <0 when one of the reference's asserts fails. */
+int64_t orc_precompile_build_ex(int kind, const zkw_log_query *requests, const uint64_t *req_tails, size_t n_req,
+                                const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,
+                                uint64_t *mem_enc, uint64_t *mem_tails, zkw_precompile_instance *instances,
+                                zkw_keccak_round_record *keccak_rounds);
 int64_t orc_precompile_build(int kind, const zkw_log_query *requests, const uint64_t *req_tails, size_t n_req,
                              const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,
                              uint64_t *mem_enc, uint64_t *mem_tails, zkw_precompile_instance *instances) {
+    return orc_precompile_build_ex(kind, requests, req_tails, n_req, mem_q, n_q, capacity, mem_in, mem_enc, mem_tails, instances, NULL);
+}
+/* keccak_rounds (keccak256 only, may be NULL): one record per Keccak-f call in the global round order, at most
+   n_q + n_req of them — the witness of the Keccak256RoundFunction circuit's cycles (keccak_circuit.c) */
+int64_t orc_precompile_build_ex(int kind, const zkw_log_query *requests, const uint64_t *req_tails, size_t n_req,
+                                const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,
+                                uint64_t *mem_enc, uint64_t *mem_tails, zkw_precompile_instance *instances,
+                                zkw_keccak_round_record *keccak_rounds) {
     if (capacity == 0) return -2;
     orc_encode_memory_queries(mem_q, n_q, mem_enc);
     orc_queue_push_chain_full(mem_enc, n_q, mem_in->tail, mem_tails);
@@ -207,6 +219,14 @@ int64_t orc_precompile_build(int kind, const zkw_log_query *requests, const uint
                     else { block[padding_space] = 0x01; block[135] = 0x80; }
                 }
                 keccak_absorb_block(kst, block);
+                if (keccak_rounds) {
+                    zkw_keccak_round_record *rec = keccak_rounds + total_rounds;
+                    memset(rec, 0, sizeof *rec);
+                    memcpy(rec->block, block, 136);
+                    rec->reset = round == 0;
+                    for (int l = 0; l < 25; l++)
+                        for (int by = 0; by < 8; by++) rec->state_after[8 * l + by] = (uint8_t)(kst[l] >> (8 * by));
+                }
                 const int next_round_is_padding = needs_extra_padding_round && round + 2 == num_rounds;
                 if (state == 1 && next_round_is_padding) state = 2;
             }

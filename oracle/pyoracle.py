@@ -145,6 +145,8 @@ PRECOMPILE_FSM = np.dtype(
      ("output_page", "<u4"), ("output_offset", "<u4"), ("num_rounds", "<u4"), ("needs_full_padding_round", "<u4"),
      ("buffer_filled", "<u4"), ("sha256_inner_state", "<u4", (8,)), ("keccak_internal_state", "u1", (200,)),
      ("buffer_bytes", "u1", (192,)), ("_pad", "<u4")])
+KECCAK_ROUND_RECORD = np.dtype([("block", "u1", (136,)), ("reset", "u1"), ("_pad", "u1", (7,)), ("state_after", "u1", (200,))])
+assert KECCAK_ROUND_RECORD.itemsize == 344
 PRECOMPILE_INSTANCE = np.dtype(
     [("start_flag", "<u4"), ("completion_flag", "<u4"), ("initial_log_queue_state", QUEUE_STATE4),
      ("initial_memory_queue_state", QUEUE_STATE12), ("final_memory_state", QUEUE_STATE12),
@@ -566,14 +568,48 @@ def precompile_build(kind, requests, request_tails, mem_queries, capacity, mem_i
     n_inst = max_instances if max_instances is not None else mq.size + req.size + 1  # upper bound on rounds
     o = dict(mem_enc=np.zeros((mq.size, 8), np.uint64), mem_tails=np.zeros((mq.size, 12), np.uint64),
              instances=np.zeros(n_inst, PRECOMPILE_INSTANCE))
-    f = lib().orc_precompile_build
+    rounds = np.zeros(mq.size + req.size + 1, KECCAK_ROUND_RECORD) if kind == 0 else None
+    f = lib().orc_precompile_build_ex
     f.restype = C.c_int64
     rc = f(C.c_int(kind), _p(req), _p(rt), C.c_size_t(req.size), _p(mq), C.c_size_t(mq.size), C.c_uint32(capacity),
-           _p(mem_in), _p(o["mem_enc"]), _p(o["mem_tails"]), _p(o["instances"]))
+           _p(mem_in), _p(o["mem_enc"]), _p(o["mem_tails"]), _p(o["instances"]), _p(rounds) if rounds is not None else None)
     if rc < 0:
         raise RuntimeError(f"orc_precompile_build failed: {rc}")
     o["instances"] = o["instances"][:rc]
+    if rounds is not None:  # one record per Keccak-f call, in the global round order
+        o["keccak_rounds"] = rounds[:int(o["instances"]["num_rounds"].sum()) if req.size else 0]
     return o
+
+
+KC_COLS, KC_G, KC_ROWS_PER_CYCLE = 137, 86, 1919
+
+
+def keccak_round_synthesize(build_out, instance_index, capacity, n_rows, public_input=None):
+    """Fill the Keccak256RoundFunction trace ("zkw trace v3") of one instance from the outputs of precompile_build(0, ...):
+    cycles = the instance's Keccak-f calls, then idle cycles up to `capacity`."""
+    inst = build_out["instances"][instance_index]
+    first, n = int(inst["first_round"]), int(inst["num_rounds"])
+    recs = np.ascontiguousarray(build_out["keccak_rounds"][first:first + n])
+    state_in = np.ascontiguousarray(build_out["keccak_rounds"][first - 1]["state_after"]) if first else np.zeros(200, np.uint8)
+    pi = np.ascontiguousarray(public_input if public_input is not None else
+                              closed_form_public_inputs(5, build_out["instances"])[1][instance_index], dtype=np.uint64)
+    trace = np.zeros((KC_COLS, n_rows), np.uint64)
+    f = lib().orc_keccak_round_synthesize
+    f.restype = C.c_int
+    rc = f(_p(state_in), _p(recs) if n else None, C.c_uint32(n), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_keccak_round_synthesize failed: {rc}")
+    return trace
+
+
+def keccak_round_check(trace, capacity):
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_keccak_round_check
+    f.restype = C.c_uint64
+    bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value
+    return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
 def sha256_compress_chain(data: bytes) -> np.ndarray:

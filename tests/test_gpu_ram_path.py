@@ -505,6 +505,8 @@ def test_precompile_builders(ctx, oracle, kind, n_req, capacity):
     gi = w.get(native.PRC_INSTANCES)
     for name in gi.dtype.names:
         assert gi[name].tobytes() == o["instances"][name].tobytes(), name
+    if kind == 0:  # the cycles of the Keccak256RoundFunction circuit: padded block, reset flag, sponge state after the call
+        assert w.get(native.PRC_KECCAK_ROUNDS).tobytes() == o["keccak_rounds"].tobytes()
 
 
 def test_precompile_builder_rejects_inconsistent_queries(ctx, oracle):

@@ -1,0 +1,79 @@
+"""CPU: the oracle's Keccak256RoundFunction circuit ("zkw trace v3", oracle/keccak_circuit.c over
+include/zkw_keccak_circuit_spec.h): the netlist computes Keccak-f[1600] (final sponge states = Keccak-256 digests), the
+filled trace satisfies the checker, every kind of tampering is caught with the right violation kind."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import synthetic
+
+N_ROWS = 1 << 16
+CAP = 6
+
+
+@pytest.fixture(scope="module")
+def built(oracle):
+    req, mq = synthetic.precompile_trace(0, 9, seed=3, max_rounds=4)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    mem_in = np.zeros(1, oracle.QUEUE_STATE12)
+    w = oracle.precompile_build(0, req, tails, mq, CAP, mem_in)
+    return req, mq, w
+
+
+def test_round_records_are_the_sponge(oracle, built):
+    """block bytes = the pad10*1-padded message blocks, state after the last round of a request = keccak256 of its input
+    (oracle.keccak256 is pinned to the Keccak-256 known answers in tests/test_oracle_field_hash.py)"""
+    req, mq, w = built
+    recs = w["keccak_rounds"]
+    assert recs.size == int(w["instances"]["num_rounds"].sum()) and recs["reset"].sum() == req.size
+    starts = np.flatnonzero(recs["reset"])
+    ends = np.append(starts[1:], recs.size)
+    for a, b in zip(starts, ends):
+        raw = recs["block"][a:b].reshape(-1).copy()
+        assert raw[-1] & 0x80
+        raw[-1] ^= 0x80
+        last = int(np.flatnonzero(raw)[-1])  # the 0x01 that starts the padding
+        assert raw[last] == 0x01
+        assert recs["state_after"][b - 1][:32].tobytes() == oracle.keccak256(raw[:last].tobytes())
+
+
+def test_trace_satisfies_and_tampering_is_caught(oracle, built):
+    _, _, w = built
+    ni = w["instances"].size
+    assert ni >= 3
+    for i in (0, ni - 1):
+        t = oracle.keccak_round_synthesize(w, i, CAP, N_ROWS)
+        assert oracle.keccak_round_check(t, CAP) == (0, (0, 0, 0))
+        n = int(w["instances"]["num_rounds"][i])
+        hdr = t[:5, np.arange(CAP) * oracle.KC_ROWS_PER_CYCLE]
+        assert hdr[1].tolist() == [0] * n + [1] * (CAP - n)                       # idle bits
+        first = int(w["instances"]["first_round"][i])
+        assert hdr[0][:n].tolist() == w["keccak_rounds"]["reset"][first:first + n].tolist()
+        bnd = CAP * oracle.KC_ROWS_PER_CYCLE
+        out = np.concatenate([t[:86, bnd + 3], t[:86, bnd + 4], t[:28, bnd + 5]])
+        assert out.astype(np.uint8).tobytes() == w["keccak_rounds"]["state_after"][first + n - 1].tobytes()
+    t = oracle.keccak_round_synthesize(w, 1, CAP, N_ROWS)
+    base = oracle.KC_ROWS_PER_CYCLE  # cycle 1
+    cases = [
+        ((86 + 2, base + 30), 1, "an operation's output"),                 # c cell of a lookup: relation broken
+        ((86 + 0, base + 40), 1, "an operand out of range", 300),
+        ((0, base), 3, "the reset bit is not boolean", 2),
+        ((2, base), 2, "mask_r (header violation 3 and 200 copy violations 2: the smallest code is reported)"),
+        ((10, base + 7), 6, "a general-purpose cell of a lookup row"),
+        ((86, 0), 6, "a lookup cell of a header row"),
+        ((128, 5), 5, "a multiplicity"),
+        ((3, CAP * oracle.KC_ROWS_PER_CYCLE + 3), 4, "a byte of BND_OUT"),
+        ((50, CAP * oracle.KC_ROWS_PER_CYCLE + 9), 6, "a cell below the boundary rows"),
+    ]
+    for (col, row), kind, what, *val in cases:
+        bad = t.copy()
+        bad[col, row] = val[0] if val else bad[col, row] + 1
+        n, first = oracle.keccak_round_check(bad, CAP)
+        assert n > 0 and first[0] == kind, (what, n, first)
+    # a consistent forgery of ONE lookup (c = table(a, b) with a changed operand) breaks the copy constraint instead
+    bad = t.copy()
+    row = base + 1 + 15 + 10 + 3  # a round row of XOR lookups
+    a, b = int(bad[86, row]), int(bad[87, row])
+    bad[86, row] = a ^ 1
+    bad[88, row] = (a ^ 1) ^ b
+    n, first = oracle.keccak_round_check(bad, CAP)
+    assert n > 0 and first[0] == 2
