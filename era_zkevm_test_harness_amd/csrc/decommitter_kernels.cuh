@@ -210,7 +210,9 @@ __device__ __forceinline__ u32 l1_message_byte(const zkw_log_query* q, size_t po
     return (m->written_value[b >> 2] >> (8 * (b & 3))) & 0xFF;
 }
 
-__global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_query* __restrict__ q, size_t n, uint8_t* __restrict__ out) {
+// rounds (may be null): one zkw_keccak_round_record per absorbed block — the cycles of the LinearHasher circuit (type 13)
+__global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_query* __restrict__ q, size_t n, uint8_t* __restrict__ out,
+                                                         zkw_keccak_round_record* __restrict__ rounds) {
     __shared__ u64 A[25], Bm[25], Cc[5];
     const int t = threadIdx.x;
     const size_t len = n * 88;
@@ -228,7 +230,9 @@ __global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_query* __
                 lane |= (u64)byte << (8 * b);
             }
             A[t] ^= lane;
+            if (rounds) reinterpret_cast<u64*>(rounds[off / 136].block)[t] = lane;  // records are 8-byte aligned (344 = 8 * 43)
         }
+        if (rounds && t == 17) reinterpret_cast<u64*>(rounds[off / 136].block)[17] = off == 0 ? 1 : 0;  // reset + padding
         __syncthreads();
         for (int round = 0; round < 24; round++) {
             if (t < 5) Cc[t] = A[t] ^ A[t + 5] ^ A[t + 10] ^ A[t + 15] ^ A[t + 20];
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_query* __
             }
             __syncthreads();
         }
+        if (rounds && t < 25) reinterpret_cast<u64*>(rounds[off / 136].state_after)[t] = A[t];
         if (last) break;
     }
     if (t < 32) out[t] = (uint8_t)(A[t >> 3] >> (8 * (t & 7)));

@@ -2739,7 +2739,7 @@ extern "C" int zkw_linear_keccak256(zkw_ctx* ctx, const zkw_log_query* messages,
     uint8_t* d_out = nullptr;
     ZKW_TRY(ctx->in("lk_q", messages, n, &d_q));
     ZKW_TRY(ctx->out("lk_out", hash_out, 32, &d_out));
-    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out); }
+    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out, (zkw_keccak_round_record*)nullptr); }
     ZKW_TRY(launch_check("k_linear_keccak256"));
     ZKW_TRY(ctx->finish_out(hash_out, d_out, 32));
     return ctx->sync_if_host();
@@ -3427,6 +3427,66 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     ZKW_TRY(launch_check("k_kc_fill"));
     { Prof _p(ctx, "k_kc_finish"); hipLaunchKernelGGL(k_kc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     return launch_check("k_kc_finish");
+}
+
+// LinearHasher (type 13): the Keccak-f netlist over the sponge of the serialized L2 -> L1 messages (compute_linear_keccak256,
+// data_hasher_and_merklizer.rs:8-67; wrapper base_layer/linear_hasher.rs:28-138). One instance per block.
+extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* messages, size_t n, const zkw_queue_state4* queue_state,
+                                            uint32_t capacity, zkw_trace* t, size_t slot, zkw_linear_hasher_instance* record_out,
+                                            uint64_t* public_input_out) {
+    if (!ctx || !t || !queue_state || !record_out || t->ctx->device != ctx->device || slot >= t->n_slots || capacity == 0 || (n && !messages))
+        return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize: bad argument");
+    if (n > capacity) return fail(ZKW_ERR_INVALID, "%zu messages, the circuit hashes at most %u", n, capacity);
+    if (t->n_cols < KC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the LinearHasher circuit needs %d", t->n_cols, KC_COLS);
+    const u32 cycles = ZKW_LINEAR_HASHER_CYCLES(capacity);
+    const size_t n_rows = t->n_rows, n_rounds = n * 88 / 136 + 1;
+    if (KC_MIN_ROWS(cycles) > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u = %u cycles needs %llu rows, trace has %zu", capacity, cycles, (unsigned long long)KC_MIN_ROWS(cycles), n_rows);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const zkw_log_query* d_q = nullptr;
+    ZKW_TRY(ctx->in("lh_q", messages, n, &d_q));
+    zkw_keccak_round_record* d_rounds = nullptr;
+    uint8_t* d_hash = nullptr;
+    ZKW_TRY(ctx->scratch_t<zkw_keccak_round_record>("lh_rounds", n_rounds, &d_rounds));
+    ZKW_TRY(ctx->scratch_t<uint8_t>("lh_hash", 32, &d_hash));
+    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_hash, d_rounds); }
+    ZKW_TRY(launch_check("k_linear_keccak256"));
+    zkw_linear_hasher_instance rec;
+    memset(&rec, 0, sizeof rec);
+    rec.start_flag = rec.completion_flag = 1;
+    rec.queue_state = *queue_state;
+    ZKW_TRY(ctx->read_small(rec.keccak256_hash, d_hash, 32));
+    std::vector<zkw_linear_hasher_instance> recv(1, rec);
+    zkw_linear_hasher_instance* d_rec = nullptr;
+    ZKW_TRY(ctx->upload("lh_record", recv, &d_rec));
+    u64 *d_cf = nullptr, *d_pi = nullptr;
+    ZKW_TRY(ctx->scratch_t<u64>("lh_cf", COMPACT_FORM_LEN, &d_cf));
+    ZKW_TRY(ctx->scratch_t<u64>("lh_pi", 4, &d_pi));
+    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<CfLinearHasher>), dim3(1), dim3(CfLanes<CfLinearHasher>::value), 0, ctx->stream, d_rec, (size_t)1, d_cf); }
+    ZKW_TRY(launch_check("k_closed_form_commitments"));
+    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(1), dim3(64), 0, ctx->stream, d_cf, (size_t)1, (u32)COMPACT_FORM_LEN, d_pi); }
+    ZKW_TRY(launch_check("k_commit_encodings"));
+    u32* d_hist = nullptr;
+    const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
+    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", hist_elems, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, hist_elems * sizeof(u32), ctx->stream));
+    std::vector<KcSynthJob> jobs(1);
+    jobs[0].rounds = d_rounds;
+    jobs[0].first_round = 0;
+    jobs[0].n_active = (u32)n_rounds;
+    jobs[0].public_input = d_pi;
+    jobs[0].trace = t->data + slot * t->slot_elems();
+    jobs[0].hist = d_hist;
+    HIP_TRY(hipMemsetAsync(jobs[0].trace, 0, (size_t)KC_COLS * n_rows * sizeof(u64), ctx->stream));
+    KcSynthJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("kc_jobs", jobs, &d_jobs));
+    { Prof _p(ctx, "k_kc_fill"); hipLaunchKernelGGL(k_kc_fill, dim3(cycles, 1), dim3(KC_FILL_THREADS), 0, ctx->stream, d_jobs, cycles, n_rows); }
+    ZKW_TRY(launch_check("k_kc_fill"));
+    { Prof _p(ctx, "k_kc_finish"); hipLaunchKernelGGL(k_kc_finish, dim3((unsigned)((hist_elems + 255) / 256), 1), dim3(256), 0, ctx->stream, d_jobs, cycles, n_rows); }
+    ZKW_TRY(launch_check("k_kc_finish"));
+    *record_out = rec;
+    if (public_input_out) ZKW_TRY(ctx->read_small(public_input_out, d_pi, 32));
+    return ZKW_OK;
 }
 
 extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,

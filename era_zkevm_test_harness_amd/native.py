@@ -112,6 +112,7 @@ SYMBOLS = [
     ("zkw_storage_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_log_demux_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_keccak_round_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_linear_hasher_synthesize", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
     ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
@@ -1116,6 +1117,24 @@ def _ctx_check_if_satisfied_keccak_round_function(self, trace, slot, capacity):
     return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
+def linear_hasher_cycles(capacity):
+    return capacity * 88 // 136 + 1  # ZKW_LINEAR_HASHER_CYCLES
+
+
+def _ctx_synthesize_linear_hasher(self, messages, queue_state, capacity, trace, slot=0):
+    """ZkSyncBaseLayerCircuit::LinearHasher synthesis (type 13) over the net L2 -> L1 messages of a block: returns the
+    instance record and its public input. Check with check_if_satisfied_keccak_round_function(trace, slot,
+    linear_hasher_cycles(capacity))."""
+    q = np.ascontiguousarray(messages, dtype=LOG_QUERY)
+    qs = np.ascontiguousarray(queue_state, dtype=QUEUE_STATE4).reshape(1)
+    rec = np.zeros(1, LINEAR_HASHER_INSTANCE)
+    pi = np.zeros(4, np.uint64)
+    _check(load().zkw_linear_hasher_synthesize(self.handle, _np_ptr(q) if q.size else None, q.size, _np_ptr(qs), capacity, trace.handle,
+                                               slot, _np_ptr(rec), _np_ptr(pi)))
+    return rec, pi
+
+
+Context.synthesize_linear_hasher = _ctx_synthesize_linear_hasher
 Context.synthesize_keccak_round_function = _ctx_synthesize_keccak_round_function
 Context.check_if_satisfied_keccak_round_function = _ctx_check_if_satisfied_keccak_round_function
 

@@ -526,6 +526,18 @@ int zkw_keccak_round_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t 
 int zkw_keccak_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                                      uint64_t *n_violations, uint64_t *first_bad);
 
+/* ---- LinearHasher circuit (type 13) ---------------------------------------------------------------------
+   ZkSyncBaseLayerCircuit::synthesis for the L1-messages hasher (wrapper base_layer/linear_hasher.rs:28-138, witness
+   compute_linear_keccak256 data_hasher_and_merklizer.rs:8-67): the Keccak-f netlist of the type-5 trace over the sponge that
+   hashes the n <= capacity serialized messages (host or device pointer per the pointer mode); cycles =
+   ZKW_LINEAR_HASHER_CYCLES(capacity), idle beyond the message's rounds; BND_OUT's first 32 bytes are the pubdata hash.
+   queue_state (host): the state of the deduplicated L1-messages queue = the closed form's observable input. record_out /
+   public_input_out (host): the instance record and its public input [4] (may be NULL). Check with
+   zkw_keccak_round_check_satisfied(ctx, t, slot, ZKW_LINEAR_HASHER_CYCLES(capacity), ..). */
+int zkw_linear_hasher_synthesize(zkw_ctx *ctx, const zkw_log_query *messages, size_t n, const zkw_queue_state4 *queue_state,
+                                 uint32_t capacity, zkw_trace *t, size_t slot, zkw_linear_hasher_instance *record_out,
+                                 uint64_t *public_input_out);
+
 /* ---- public inputs and the recursion queue (a20) ---------------------------------------------------- */
 /* commit_variable_length_encodable_item as driven by simulate_public_input_value_from_witness
    (src/witness/utils.rs:269-306): n_items flat encodings of item_len elements each -> out[n_items][4]. */

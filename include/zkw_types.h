@@ -428,6 +428,9 @@ typedef struct zkw_linear_hasher_instance {
     zkw_queue_state4 queue_state; /* observable_input: the L1-messages result queue (:34-37) */
     uint8_t keccak256_hash[32];   /* observable_output (:38-49) */
 } zkw_linear_hasher_instance;
+/* cycles (Keccak-f calls) of the LinearHasher circuit for `capacity` messages of 88 bytes (L2_TO_L1_MESSAGE_BYTE_LENGTH,
+   data_hasher_and_merklizer.rs:23): ceil of the padded length over the 136-byte rate; 774 messages -> 501 cycles */
+#define ZKW_LINEAR_HASHER_CYCLES(capacity) ((uint32_t)((uint64_t)(capacity) * 88 / 136 + 1))
 
 /* ---- MainVM instance slicing (a19): src/witness/oracle.rs:1229-1469, src/witness/utils.rs:428-496 -------------------- */
 /* The eight cycle-stamped FIFOs the reference cuts into per-instance `VmWitnessOracle`s

@@ -245,6 +245,7 @@ int64_t orc_precompile_build_ex(int kind, const zkw_log_query *requests, const u
 int orc_keccak_round_synthesize(const uint8_t state_in[200], const zkw_keccak_round_record *rounds, uint32_t n_active,
                                 uint32_t capacity, const uint64_t pi[4], size_t n_rows, uint64_t *trace);
 uint64_t orc_keccak_round_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+size_t orc_linear_hasher_rounds(const zkw_log_query *q, size_t n, zkw_keccak_round_record *records);
 
 /* ---- callstack (a3 / a6), see callstack.c */
 void orc_encode_callstack_entry(const zkw_callstack_entry *e, uint64_t out[32]);

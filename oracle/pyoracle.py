@@ -602,6 +602,35 @@ def keccak_round_synthesize(build_out, instance_index, capacity, n_rows, public_
     return trace
 
 
+def linear_hasher_cycles(capacity):
+    """cycles (Keccak-f calls) of the LinearHasher circuit for `capacity` 88-byte messages: ZKW_LINEAR_HASHER_CYCLES"""
+    return capacity * 88 // 136 + 1
+
+
+def linear_hasher_synthesize(messages, queue_state, capacity, n_rows):
+    """LinearHasher (type 13): (trace, instance record, public input) for the net L2 -> L1 messages of a block"""
+    q = np.ascontiguousarray(messages, dtype=LOG_QUERY)
+    assert q.size <= capacity
+    recs = np.zeros(q.size * 88 // 136 + 1, KECCAK_ROUND_RECORD)
+    f = lib().orc_linear_hasher_rounds
+    f.restype = C.c_size_t
+    n = f(_p(q), C.c_size_t(q.size), _p(recs))
+    assert n == recs.size
+    inst = np.zeros(1, LINEAR_HASHER_INSTANCE)
+    inst["start_flag"] = inst["completion_flag"] = 1
+    inst["queue_state"] = queue_state
+    inst["keccak256_hash"] = recs["state_after"][-1][:32]
+    pi = closed_form_public_inputs(13, inst)[1][0]
+    cycles = linear_hasher_cycles(capacity)
+    trace = np.zeros((KC_COLS, n_rows), np.uint64)
+    g = lib().orc_keccak_round_synthesize
+    g.restype = C.c_int
+    rc = g(_p(np.zeros(200, np.uint8)), _p(recs), C.c_uint32(n), C.c_uint32(cycles), _p(pi), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_keccak_round_synthesize failed: {rc}")
+    return trace, inst, pi
+
+
 def keccak_round_check(trace, capacity):
     trace = np.ascontiguousarray(trace, dtype=np.uint64)
     first_bad = C.c_uint64(0)

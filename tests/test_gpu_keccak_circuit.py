@@ -113,3 +113,38 @@ def test_production_geometry(ctx, oracle):
     assert out.tobytes() == o["keccak_rounds"]["state_after"][first + n - 1].tobytes()
     t.free()
     w.free()
+
+
+@pytest.mark.parametrize("n_msg,capacity,n_rows", [(0, 4, 1 << 16), (7, 20, 1 << 16), (20, 20, 1 << 16), (774, 774, 1 << 20), (301, 774, 1 << 20)])
+def test_linear_hasher_circuit(ctx, oracle, n_msg, capacity, n_rows):
+    """type 13 (LinearHasher): cell-exact against the oracle, satisfied, the record and the public input identical; the
+    reference's capacity (774 messages = 501 cycles in 2^20 rows) included"""
+    from era_zkevm_test_harness_amd import native
+
+    q = synthetic.mixed_log_queue(4 * n_msg + 8, seed=n_msg + 1)[:n_msg]
+    qs = np.zeros(1, native.QUEUE_STATE4)
+    qs["tail"] = synthetic.random_field_elements(n_msg + 2, (4,))
+    qs["length"] = n_msg
+    t = native.Trace(ctx, n_rows, 1, n_cols=native.KC_COLS)
+    rec, pi = ctx.synthesize_linear_hasher(q, qs, capacity, t, 0)
+    cycles = native.linear_hasher_cycles(capacity)
+    assert ctx.check_if_satisfied_keccak_round_function(t, 0, cycles) == (0, (0, 0, 0))
+    exp, orec, opi = oracle.linear_hasher_synthesize(q, qs, capacity, n_rows)
+    assert rec.tobytes() == orec.tobytes() and pi.tolist() == opi.tolist()
+    assert rec["keccak256_hash"][0].tobytes() == ctx.compute_linear_keccak256(q)
+    got = t.get(0)
+    if not np.array_equal(got, exp):
+        c, r = np.argwhere(got != exp)[0]
+        raise AssertionError(f"first difference at column {c} row {r}: {got[c, r]} != {exp[c, r]}")
+    t.free()
+
+
+def test_linear_hasher_rejects_too_many_messages(ctx):
+    from era_zkevm_test_harness_amd import native
+
+    q = synthetic.mixed_log_queue(64, seed=2)[:9]
+    t = native.Trace(ctx, 1 << 16, 1, n_cols=native.KC_COLS)
+    with pytest.raises(native.ZkwError) as ei:
+        ctx.synthesize_linear_hasher(q, np.zeros(1, native.QUEUE_STATE4), 8, t, 0)
+    assert ei.value.code == native.ERR_INVALID
+    t.free()

@@ -77,3 +77,21 @@ def test_trace_satisfies_and_tampering_is_caught(oracle, built):
     bad[88, row] = (a ^ 1) ^ b
     n, first = oracle.keccak_round_check(bad, CAP)
     assert n > 0 and first[0] == 2
+
+
+@pytest.mark.parametrize("n_msg,capacity", [(0, 4), (7, 20), (20, 20), (17, 17)])
+def test_linear_hasher_circuit(oracle, n_msg, capacity):
+    """type 13: the same netlist over the sponge of the serialized L2 -> L1 messages; BND_OUT starts with the pubdata hash"""
+    q = synthetic.mixed_log_queue(4 * n_msg + 8, seed=n_msg + 1)[:n_msg]
+    qs = np.zeros(1, oracle.QUEUE_STATE4)
+    qs["tail"] = synthetic.random_field_elements(n_msg + 2, (4,))
+    qs["length"] = n_msg
+    trace, inst, pi = oracle.linear_hasher_synthesize(q, qs, capacity, N_ROWS)
+    cycles = oracle.linear_hasher_cycles(capacity)
+    assert cycles == capacity * 88 // 136 + 1
+    assert oracle.keccak_round_check(trace, cycles) == (0, (0, 0, 0))
+    bnd = cycles * oracle.KC_ROWS_PER_CYCLE
+    assert trace[:32, bnd + 3].astype(np.uint8).tobytes() == oracle.linear_keccak256(q) == inst["keccak256_hash"][0].tobytes()
+    assert trace[:4, bnd + 6].tolist() == pi.tolist()
+    idle = trace[1, np.arange(cycles) * oracle.KC_ROWS_PER_CYCLE]
+    assert int((idle == 0).sum()) == n_msg * 88 // 136 + 1
