@@ -143,7 +143,7 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     best["note"] = ("one block on %d GPU(s): builders = zkw_block_run (every builder of the post-VM half of "
                     "create_artifacts_from_tracer; replicated on every rank: they are bounded by the block's longest serial "
                     "Poseidon2 queue chain, memory queue = %d items x ~10.3 us, which more GPUs cannot shorten); synthesis = this "
-                    "rank's LPT share of the 6 synthesizable instances x 1.25 GB; gather = the closed-form records to rank 0"
+                    "rank's LPT share of the synthesizable instances (six queue circuits x 1.25 GB, keccak256 round function and L1-messages hasher x 1.15 GB); gather = the closed-form records to rank 0"
                     % (world, best["memory_queue_items"]))
     return best, blk
 

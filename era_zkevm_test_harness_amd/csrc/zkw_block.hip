@@ -147,7 +147,7 @@ struct zkw_block {
     PerType per[14];
     std::vector<zkw_vm_instance> vm_instances;
     // synthesis ring (created by the first zkw_block_synthesize)
-    zkw_trace *ring149 = nullptr, *ring151 = nullptr;
+    zkw_trace* ring = nullptr;  // 151 columns: the widest of the synthesized types (a type with fewer uses the first of them)
     size_t ring_rows = 0, ring_slots = 0;
 
     double ms_now() const { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
@@ -617,8 +617,7 @@ extern "C" void zkw_block_free(zkw_block* B) {
     // block may still be in flight on any of its contexts
     for (int i = 0; i < N_CTX; i++)
         if (B->ctx[i]) (void)zkw_synchronize(B->ctx[i]);
-    if (B->ring149) zkw_trace_free(B->ring149);
-    if (B->ring151) zkw_trace_free(B->ring151);
+    if (B->ring) zkw_trace_free(B->ring);
     if (B->dec) zkw_decommit_witness_free(B->dec);
     if (B->dcm) zkw_decommitter_witness_free(B->dcm);
     if (B->dmx) zkw_demux_witness_free(B->dmx);
@@ -742,7 +741,10 @@ extern "C" int zkw_block_timings(const zkw_block* B, char* names, size_t names_b
 
 // ---- synthesis of every instance, in the reference's emission order ----------------------------------------------
 namespace {
-const int kOrder[6] = {T_DMX, T_RAM, T_DEC, T_STO, T_EVT, T_L1};
+// emission order of the synthesized types: log demuxer (oracle.rs:975-984), RAM permutation (:1039-1049), then CircuitMaker
+// order (:1494-1732: decommits sorter, [code decommitter], keccak, [sha256, ecrecover], storage sorter, events sorter,
+// L1-messages sorter, L1-messages hasher)
+const int kOrder[8] = {T_DMX, T_RAM, T_DEC, T_KEC, T_STO, T_EVT, T_L1, T_HSH};
 // the block's synthesizable instances in emission order and their LPT owners
 int shard_plan(const zkw_block* B, int world, std::vector<uint8_t>* types, std::vector<uint32_t>* index, std::vector<uint32_t>* owner) {
     for (int t : kOrder)
@@ -774,25 +776,23 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
         return false;
     };
     if (hipSetDevice(B->device) != hipSuccess) return ZKW_ERR_HIP;
-    if (B->ring149 && (B->ring_rows != n_rows || B->ring_slots != ring_slots)) {
-        zkw_trace_free(B->ring149);
-        zkw_trace_free(B->ring151);
-        B->ring149 = B->ring151 = nullptr;
+    if (B->ring && (B->ring_rows != n_rows || B->ring_slots != ring_slots)) {
+        zkw_trace_free(B->ring);
+        B->ring = nullptr;
     }
     int rc = ZKW_OK;
-    if (!B->ring149) {
-        if ((rc = zkw_trace_create(B->ctx[C_RAM], n_rows, ring_slots, &B->ring149)) != ZKW_OK) return rc;
-        if ((rc = zkw_trace_create_with_columns(B->ctx[C_DMX], n_rows, 151, ring_slots, &B->ring151)) != ZKW_OK) return rc;
+    if (!B->ring) {
+        if ((rc = zkw_trace_create_with_columns(B->ctx[C_RAM], n_rows, 151, ring_slots, &B->ring)) != ZKW_OK) return rc;
         B->ring_rows = n_rows;
         B->ring_slots = ring_slots;
     }
     const double a = B->ms_now();
     size_t done = 0;
-    // emission order: log demuxer (oracle.rs:975-984), RAM permutation (:1039-1049), then CircuitMaker order (:1494-1732)
     for (int t : kOrder) {
         const size_t ni = zkw_block_num_instances(B, (uint8_t)t);
         zkw_ctx* c = zkw_block_context(B, (uint8_t)t);
-        zkw_trace* ring = t == T_DMX ? B->ring151 : B->ring149;
+        zkw_trace* ring = B->ring;
+
         for (size_t first = 0; first < ni;) {
             // a maximal run of consecutive instances this rank owns (world == 1: all of them), at most one ring
             if (!owned(t, first)) { first++; continue; }
@@ -805,6 +805,13 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
                 case T_STO: rc = zkw_storage_sorter_synthesize(c, B->sto, first, cnt, ring, 0); break;
                 case T_EVT: rc = zkw_events_sorter_synthesize(c, B->evt, first, cnt, ring, 0); break;
                 case T_L1: rc = zkw_events_sorter_synthesize(c, B->l1, first, cnt, ring, 0); break;
+                case T_KEC: rc = zkw_keccak_round_synthesize(c, B->pre[0], first, cnt, ring, 0); break;
+                case T_HSH: {  // one instance over the net L2 -> L1 messages (the L1 sorter's result queue)
+                    zkw_linear_hasher_instance rec;
+                    rc = zkw_linear_hasher_synthesize(c, static_cast<const zkw_log_query*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_RESULT_QUERIES)),
+                                                      zkw_events_witness_num_results(B->l1), &B->linear_hasher.queue_state, B->cap[T_HSH], ring, 0, &rec, nullptr);
+                    break;
+                }
             }
             if (rc != ZKW_OK) return rc;
             // the ring is shared by contexts with different streams: a slot is complete before the next type touches it

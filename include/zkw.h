@@ -722,10 +722,12 @@ int zkw_block_linear_hasher_instance(const zkw_block *b, zkw_linear_hasher_insta
 int zkw_block_timings(const zkw_block *b, char *names, size_t names_bytes, double *start_ms, double *end_ms, size_t max_spans,
                       size_t *n_spans);
 /* ZkSyncBaseLayerCircuit::synthesis for every instance of the synthesizable types of the block, in the reference's
-   emission order (oracle.rs:975-984 demuxer, 1039-1049 RAM, then CircuitMaker order 1494-1732: decommit sorter,
-   storage sorter, events, L1 messages): each instance is filled into a slot of an internal trace ring (n_rows rows,
-   `ring_slots` slots per geometry) and handed to `cb` — the counterpart of external_calls::run's circuit_callback
+   emission order (oracle.rs:975-984 demuxer, 1039-1049 RAM, then CircuitMaker order 1494-1732: decommit sorter, keccak256
+   round function, storage sorter, events, L1 messages, L1-messages hasher): each instance is filled into a slot of an
+   internal trace ring (n_rows rows, 151 columns — a type with fewer columns uses the first of them, the rest of the slot
+   is unspecified; `ring_slots` slots) and handed to `cb` — the counterpart of external_calls::run's circuit_callback
    (a prover consumes the slot before it is reused; the slot stays valid until cb returns). cb may be NULL.
+   n_rows must hold every type at the block's capacities (the keccak netlist circuits need at least 65 536 rows).
    *n_done = number of instances synthesized. */
 typedef int (*zkw_circuit_fn)(void *user, uint8_t circuit_type, size_t instance, const zkw_trace *trace, size_t slot,
                               const uint64_t public_input[4]);

@@ -90,7 +90,7 @@ def create_artifacts_after_vm(block, capacities=None, storage_tree=None, timings
     hasher["start_flag"] = hasher["completion_flag"] = 1
     hasher["queue_state"] = l1s["instances"]["final_queue_state"][-1]
     hasher["keccak256_hash"] = np.frombuffer(pubdata_hash, np.uint8)
-    art["l1_messages_hasher"] = {"instances": hasher}
+    art["l1_messages_hasher"] = {"instances": hasher, "messages": l1s["result_q"]}
     pis[L1_MESSAGES_HASHER] = o.closed_form_public_inputs(L1_MESSAGES_HASHER, hasher)[1]
     if storage_tree is not None:
         sap = timed("storage_application", o.storage_application_build, storage_tree, sto["result_q"],
@@ -102,14 +102,21 @@ def create_artifacts_after_vm(block, capacities=None, storage_tree=None, timings
             "public_inputs": pis, "recursion_queues": recursion, "l1_messages_pubdata_hash": pubdata_hash, "capacities": cap}
 
 
+def _linear_hasher_synthesize(w, i, capacity, n_rows):
+    return o.linear_hasher_synthesize(w["messages"], w["instances"]["queue_state"][0], capacity, n_rows)[0]
+
+
 SYNTH = {LOG_DEMUXER: ("log_demuxer", o.log_demux_synthesize), RAM_PERMUTATION: ("ram_permutation", o.ram_synthesize),
          DECOMMITS_SORTER: ("decommits_sorter", o.decommit_sorter_synthesize), STORAGE_SORTER: ("storage_sorter", o.storage_sorter_synthesize),
-         EVENTS_SORTER: ("events_sorter", o.events_sorter_synthesize), L1_MESSAGES_SORTER: ("l1_messages_sorter", o.events_sorter_synthesize)}
-EMISSION_ORDER = (LOG_DEMUXER, RAM_PERMUTATION, DECOMMITS_SORTER, STORAGE_SORTER, EVENTS_SORTER, L1_MESSAGES_SORTER)
+         EVENTS_SORTER: ("events_sorter", o.events_sorter_synthesize), L1_MESSAGES_SORTER: ("l1_messages_sorter", o.events_sorter_synthesize),
+         KECCAK256: ("keccak256", o.keccak_round_synthesize), L1_MESSAGES_HASHER: ("l1_messages_hasher", _linear_hasher_synthesize)}
+# oracle.rs:975-984 demuxer, :1039-1049 RAM, then CircuitMaker order :1494-1732 (the types that have a synthesis here)
+EMISSION_ORDER = (LOG_DEMUXER, RAM_PERMUTATION, DECOMMITS_SORTER, KECCAK256, STORAGE_SORTER, EVENTS_SORTER, L1_MESSAGES_SORTER,
+                  L1_MESSAGES_HASHER)
 
 
 def synthesize_all(artifacts, n_rows, on_trace=None):
-    """ZkSyncBaseLayerCircuit::synthesis of every instance of the six synthesized types in emission order; returns the
+    """ZkSyncBaseLayerCircuit::synthesis of every instance of the eight synthesized types in emission order; returns the
     number of instances. on_trace(circuit_type, instance, trace) is called with each filled trace."""
     done = 0
     for ctype in EMISSION_ORDER:

@@ -24,7 +24,7 @@ def test_block_after_vm(ctx, oracle, seed):
 
     b = synthetic.block_after_vm(seed=seed)
     caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
-            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
     a = blk.create_artifacts_after_vm(ctx, b, caps)
     w = a["witnesses"]
     # the memory queue: VM, then code words, then keccak / sha256 / ecrecover queries; RAM sees exactly that queue
@@ -70,7 +70,7 @@ def test_block_with_empty_queues(ctx, oracle):
 
     b = synthetic.block_after_vm(seed=3, n_events=0, n_l1_messages=0, n_precompile_calls=(0, 3, 0), n_storage=60)
     caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
-            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
     a = blk.create_artifacts_after_vm(ctx, b, caps)
     w = a["witnesses"]
     assert w["events_sorter"].num_instances == 1 and w["l1_messages_sorter"].num_instances == 1
@@ -105,7 +105,7 @@ def test_block_sequencer_matches_builder_by_builder(ctx, oracle, seed):
 
     b = synthetic.block_after_vm(seed=seed)
     caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
-            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.STORAGE_APPLICATION: 5, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.STORAGE_APPLICATION: 5, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
     a = blk.create_artifacts_after_vm(ctx, b, caps)
     w = a["witnesses"]
     dedup = w["storage_sorter"].get(nv.STO_RESULT_QUERIES)
@@ -169,8 +169,9 @@ def test_block_sequencer_matches_builder_by_builder(ctx, oracle, seed):
         assert pi == [int(x) for x in a["public_inputs"][ctype][inst]]
         seen.append((ctype, inst))
 
-    n = B.synthesize(1 << 15, ring_slots=3, callback=on_circuit)
-    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.DECOMMITS_SORTER, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER]
+    n = B.synthesize(1 << 16, ring_slots=3, callback=on_circuit)
+    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.DECOMMITS_SORTER, blk.KECCAK256, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER,
+             blk.L1_MESSAGES_HASHER]
     assert seen == [(t, i) for t in order for i in range(B.num_instances(t))] and n == len(seen) > 12
     spans = {name for name, _, _ in B.timings()}
     assert {"builders", "ram_permutation", "decommit_sorter.finish", "log_demuxer", "storage_application", "synthesis"} <= spans
@@ -198,15 +199,16 @@ def test_block_sharded_synthesis_and_gather(ctx):
 
     b = synthetic.block_after_vm(seed=5)
     caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
-            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
     B = nv.Block(0, b, caps)
-    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.DECOMMITS_SORTER, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER]
+    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.DECOMMITS_SORTER, blk.KECCAK256, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER,
+             blk.L1_MESSAGES_HASHER]
     full = [(t, i) for t in order for i in range(B.num_instances(t))]
     owner = nv.shard_lpt([t for t, _ in full], 3)
     got = []
     for rank in range(3):
         seen = []
-        n = B.synthesize(1 << 15, ring_slots=2, callback=lambda t, i, tr, s, pi: seen.append((t, i)), rank=rank, world=3)
+        n = B.synthesize(1 << 16, ring_slots=2, callback=lambda t, i, tr, s, pi: seen.append((t, i)), rank=rank, world=3)
         assert n == len(seen) and seen == [x for x, o in zip(full, owner) if o == rank]
         got += seen
     assert sorted(got) == sorted(full) and len(set(got)) == len(full)
@@ -234,7 +236,7 @@ def test_block_with_main_vm_slicing(ctx, oracle):
 
     b = synthetic.block_after_vm(seed=7)
     caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
-            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
     n_vm, n_dec = b["vm_memory_queries"].size, b["decommit_queries"].size
     t = synthetic.vm_tracer_streams(n_cycles=2000, cycles_per_snapshot=250, seed=11, n_memory=n_vm, sparse=60)
     rng = np.random.default_rng(12)
@@ -261,7 +263,7 @@ def test_blocks_run_many_at_once(ctx, oracle):
     from era_zkevm_test_harness_amd import block as blk, native as nv
 
     caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
-            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9}
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
     bs = [synthetic.block_after_vm(seed=20 + k, n_vm_memory=1500 + 400 * k, n_storage=60 + 30 * k) for k in range(5)]
     many = nv.Block.run_many(0, bs, caps)
     whats = ((blk.RAM_PERMUTATION, nv.RAM_INSTANCES), (blk.DECOMMITS_SORTER, nv.DEC_INSTANCES), (blk.LOG_DEMUXER, nv.DMX_INSTANCES),
@@ -276,7 +278,7 @@ def test_blocks_run_many_at_once(ctx, oracle):
             assert np.array_equal(m.public_inputs(t), one.public_inputs(t))
             assert np.array_equal(m.recursion_queue(t)[1], one.recursion_queue(t)[1])
         bad = []
-        n = m.synthesize(1 << 15, ring_slots=2, callback=lambda t, i, tr, s, pi: bad.append(m.check_satisfied(t, tr, s)[0]))
+        n = m.synthesize(1 << 16, ring_slots=2, callback=lambda t, i, tr, s, pi: bad.append(m.check_satisfied(t, tr, s)[0]))
         assert n == len(bad) > 10 and not any(bad)
         one.free()
     # the oracle agrees with one of them end to end (public inputs of the RAM permutation)

@@ -10,7 +10,8 @@ def test_oracle_block_threads_queues_and_satisfies_circuits(oracle):
 
     b = synthetic.block_after_vm(seed=1)
     caps = {ob.DECOMMITS_SORTER: 5, ob.CODE_DECOMMITTER: 7, ob.LOG_DEMUXER: 64, ob.KECCAK256: 3, ob.SHA256: 4, ob.ECRECOVER: 2,
-            ob.RAM_PERMUTATION: 1000, ob.STORAGE_SORTER: 40, ob.STORAGE_APPLICATION: 5, ob.EVENTS_SORTER: 16, ob.L1_MESSAGES_SORTER: 9}
+            ob.RAM_PERMUTATION: 1000, ob.STORAGE_SORTER: 40, ob.STORAGE_APPLICATION: 5, ob.EVENTS_SORTER: 16, ob.L1_MESSAGES_SORTER: 9,
+            ob.L1_MESSAGES_HASHER: 48}
     timings = {}
     a = ob.create_artifacts_after_vm(b, caps, timings=timings)
     w = a["witnesses"]
@@ -22,7 +23,8 @@ def test_oracle_block_threads_queues_and_satisfies_circuits(oracle):
     assert {"ram_permutation", "decommit_sorter", "log_demuxer", "storage_sorter"} <= set(timings)
     checks = {ob.LOG_DEMUXER: oracle.log_demux_check, ob.RAM_PERMUTATION: oracle.ram_check, ob.DECOMMITS_SORTER: oracle.decommit_sorter_check,
               ob.STORAGE_SORTER: oracle.storage_sorter_check, ob.EVENTS_SORTER: oracle.events_sorter_check,
-              ob.L1_MESSAGES_SORTER: oracle.events_sorter_check}
+              ob.L1_MESSAGES_SORTER: oracle.events_sorter_check, ob.KECCAK256: oracle.keccak_round_check,
+              ob.L1_MESSAGES_HASHER: lambda t, cap: oracle.keccak_round_check(t, oracle.linear_hasher_cycles(cap))}
     seen = []
 
     def on_trace(ctype, i, t):
@@ -30,7 +32,7 @@ def test_oracle_block_threads_queues_and_satisfies_circuits(oracle):
         assert bad == 0, (ctype, i, first)
         seen.append(ctype)
 
-    n = ob.synthesize_all(a, 1 << 15, on_trace)
+    n = ob.synthesize_all(a, 1 << 16, on_trace)
     assert n == len(seen) > 12 and seen == sorted(seen, key=ob.EMISSION_ORDER.index)
     for ctype, (enc, states) in a["recursion_queues"].items():
         assert np.array_equal(enc[:, 1:5], a["public_inputs"][ctype]) and (enc[:, 0] == ctype).all()
