@@ -87,29 +87,6 @@ __global__ __launch_bounds__(1024) void k_precompile_counts(int kind, const zkw_
     }
 }
 
-__device__ inline void keccak_f1600(u64 a[25]) {
-    for (int round = 0; round < 24; round++) {
-        u64 c[5], b[25];
-#pragma unroll
-        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
-#pragma unroll
-        for (int x = 0; x < 5; x++) {
-            const u64 d = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
-#pragma unroll
-            for (int y = 0; y < 5; y++) a[x + 5 * y] ^= d;
-        }
-#pragma unroll
-        for (int x = 0; x < 5; x++)
-#pragma unroll
-            for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(a[x + 5 * y], c_keccak_rot[x + 5 * y]);
-#pragma unroll
-        for (int y = 0; y < 5; y++)
-#pragma unroll
-            for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-        a[0] ^= c_keccak_rc[round];
-    }
-}
-
 // the internal part of the FSM at an instance boundary + how far the global sequences have advanced
 struct PrecompileSnap {
     zkw_precompile_fsm fsm;  // queue states are filled in by k_precompile_instances

@@ -3385,6 +3385,20 @@ extern "C" int zkw_log_demux_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, s
     return check_satisfied<SpecLogDemux>(ctx, t, slot, capacity, n_violations, first_bad);
 }
 
+// compact closed-form inputs and public inputs of a precompile witness's instances, computed once and kept with the witness
+extern "C" int zkw_precompile_closed_forms(zkw_ctx* ctx, zkw_precompile_witness* w, const uint64_t** compact, const uint64_t** public_inputs) {
+    if (!ctx || !w || w->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_precompile_closed_forms: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!w->cf_pi) {
+        if (w->kind == ZKW_PRECOMPILE_KECCAK256) ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>>(ctx, w->instances, w->n_instances, &w->cf_pi));
+        else if (w->kind == ZKW_PRECOMPILE_SHA256) ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_SHA256>>(ctx, w->instances, w->n_instances, &w->cf_pi));
+        else ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_ECRECOVER>>(ctx, w->instances, w->n_instances, &w->cf_pi));
+    }
+    if (compact) *compact = w->cf_pi;
+    if (public_inputs) *public_inputs = w->cf_pi + COMPACT_FORM_LEN * w->n_instances;
+    return ZKW_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ Keccak256RoundFunction synthesis
 // ZkSyncBaseLayerCircuit::synthesis for Keccak256RoundFunction (type 5) in "zkw trace v3" (keccak_circuit_kernels.cuh)
 extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances,
@@ -3400,9 +3414,7 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
         return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)KC_MIN_ROWS(capacity), n_rows);
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (!w->cf_pi) {  // public inputs of the block's instances (a20), once
-        ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>>(ctx, w->instances, w->n_instances, &w->cf_pi));
-    }
+    ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));  // public inputs of the block's instances (a20), once
     u32* d_hist = nullptr;
     const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
     ZKW_TRY(ctx->scratch_t<u32>("kc_hist", n_instances * hist_elems, &d_hist));

@@ -122,7 +122,11 @@ struct zkw_block {
     zkw_ctx* ctx[N_CTX] = {};
     Xfer xf[N_XFER];
     uint32_t cap[14] = {};
-    bool use_chain_service = false;  // zkw_blocks_run: this block's chains travel in launches shared with the other blocks
+    // The block's chains go through the device's chain service (zkw_set_chain_service): with zkw_blocks_run they travel in
+    // launches shared with the other blocks; for a single block the point is that the service's high-priority streams have
+    // hardware queues of their own — on the contexts' own streams a branch's chain can land on the hardware queue of another
+    // branch (8 queues, ~14 streams) and the two 1 s chains of the critical path then run one after the other (seen: 2.08 s).
+    bool use_chain_service = true;
     Clock::time_point t0;
     std::mutex mu;
     std::vector<Span> spans;
@@ -463,8 +467,11 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
             return Status();
         };
         ST_TRY(closed_form(T_DCM, zkw_decommitter_witness_device_ptr(B->dcm, ZKW_DCM_INSTANCES), zkw_decommitter_witness_num_instances(B->dcm)));
-        for (int k = 0; k < 3; k++)
-            ST_TRY(closed_form(T_KEC + k, zkw_precompile_witness_device_ptr(B->pre[k], ZKW_PRC_INSTANCES), zkw_precompile_witness_num_instances(B->pre[k])));
+        for (int k = 0; k < 3; k++) {  // kept with the witness: the type-5 synthesis needs them again
+            const uint64_t *d_cf = nullptr, *d_pi = nullptr;
+            ST_ZKW(zkw_precompile_closed_forms(cfc, B->pre[k], &d_cf, &d_pi));
+            src.push_back({T_KEC + k, d_pi, d_cf, zkw_precompile_witness_num_instances(B->pre[k])});
+        }
         if (B->sap)
             ST_TRY(closed_form(T_SAP, zkw_storage_application_witness_device_ptr(B->sap, ZKW_SAP_INSTANCES),
                                zkw_storage_application_witness_num_instances(B->sap)));

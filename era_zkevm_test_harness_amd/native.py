@@ -111,6 +111,7 @@ SYMBOLS = [
     ("zkw_storage_sorter_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_storage_sorter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_log_demux_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
+    ("zkw_precompile_closed_forms", _int, [_vp, _vp, _vp, _vp]),
     ("zkw_keccak_round_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_linear_hasher_synthesize", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
     ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),

@@ -521,6 +521,10 @@ int zkw_callstack_simulate(zkw_ctx *ctx, const uint8_t *is_push, size_t n_ops, c
    idle up to the capacity the witness was built with. n_rows >= 65 536 (one multiplicity column per 2^16-row table).
    The check re-derives every relation from the cells: table membership, copy constraints, headers, boundary rows,
    multiplicities. w must be a keccak256 witness (zkw_precompile_build(ctx, ZKW_PRECOMPILE_KECCAK256, ..)). */
+/* compact closed-form inputs [n_instances][18] and public inputs [n_instances][4] of a precompile witness (any kind), DEVICE
+   pointers valid until the witness is freed; computed on ctx's stream at the first call and kept with the witness (the
+   type-5 synthesis writes them into the PI rows). Either out pointer may be NULL. */
+int zkw_precompile_closed_forms(zkw_ctx *ctx, zkw_precompile_witness *w, const uint64_t **compact, const uint64_t **public_inputs);
 int zkw_keccak_round_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t first_instance, size_t n_instances,
                                 zkw_trace *t, size_t first_slot);
 int zkw_keccak_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
