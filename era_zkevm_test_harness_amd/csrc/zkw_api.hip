@@ -2745,6 +2745,27 @@ extern "C" int zkw_linear_keccak256(zkw_ctx* ctx, const zkw_log_query* messages,
     return ctx->sync_if_host();
 }
 
+// RecursionQueueSimulator::split_by(RECURSION_ARITY) as create_leaf_witnesses uses it (src/witness/recursive_aggregation.rs:
+// 98-117, circuit_encodings/src/lib.rs:472-506): leaf k covers the requests [k * arity, min((k + 1) * arity, n)); its queue
+// starts at the state the previous leaf ended with (head = tail before its first request), ends at the state after its last
+// request. Pure host arithmetic over the states zkw_queue_push_chain_full returned: no device work.
+extern "C" int zkw_recursion_queue_split(const uint64_t* states, size_t n, uint32_t arity, zkw_queue_state12* leaf_states,
+                                         size_t max_leaves, size_t* n_leaves) {
+    if (!n_leaves || arity == 0 || (n && !states)) return fail(ZKW_ERR_INVALID, "zkw_recursion_queue_split: bad argument");
+    const size_t leaves = (n + arity - 1) / arity;  // an empty queue has no leaves (split_by returns an empty vector)
+    *n_leaves = leaves;
+    if (leaves > max_leaves || (leaves && !leaf_states)) return fail(ZKW_ERR_INVALID, "zkw_recursion_queue_split: %zu leaves, room for %zu", leaves, max_leaves);
+    for (size_t k = 0; k < leaves; k++) {
+        const size_t first = k * arity, end = std::min(n, first + arity);
+        zkw_queue_state12& q = leaf_states[k];
+        memset(&q, 0, sizeof q);
+        if (first) memcpy(q.head, states + 12 * (first - 1), 96);
+        memcpy(q.tail, states + 12 * (end - 1), 96);
+        q.length = (uint32_t)(end - first);
+    }
+    return ZKW_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ public inputs (a20)
 extern "C" int zkw_commit_encodings(zkw_ctx* ctx, const uint64_t* enc, size_t n_items, uint32_t item_len, uint64_t* out) {
     if (!ctx || !out || (n_items && item_len && !enc)) return fail(ZKW_ERR_INVALID, "zkw_commit_encodings: null argument");

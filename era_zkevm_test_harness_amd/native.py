@@ -40,6 +40,7 @@ SYMBOLS = [
     ("zkw_stream_release", None, [_vp, _vp]),
     ("zkw_trim_caches", None, []),
     ("zkw_block_linear_hasher_instance", _int, [_vp, _vp]),
+    ("zkw_recursion_queue_split", _int, [_vp, _sz, C.c_uint32, _vp, _sz, _vp]),
     ("zkw_closed_form_public_inputs", _int, [_vp, C.c_uint8, _vp, C.c_size_t, _vp, _vp]),
     ("zkw_version", C.c_char_p, []),
     ("zkw_circuit_geometry_of", _int, [C.c_uint8, _vp]),
@@ -1473,6 +1474,17 @@ class Block:
             self.free()
         except Exception:
             pass
+
+
+def recursion_queue_split(states, arity=32):
+    """zkw_recursion_queue_split: the RecursionLeafInput queue state of every leaf (split_by(RECURSION_ARITY)); no GPU needed"""
+    st = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 12)
+    n_leaves = (st.shape[0] + arity - 1) // arity
+    out = np.zeros(n_leaves, QUEUE_STATE12)
+    n = C.c_size_t(0)
+    _check(load().zkw_recursion_queue_split(_np_ptr(st) if st.size else None, st.shape[0], arity, _np_ptr(out) if n_leaves else None, n_leaves, C.byref(n)))
+    assert n.value == n_leaves
+    return out
 
 
 def trim_caches():

@@ -562,6 +562,15 @@ int zkw_encode_recursion_requests(zkw_ctx *ctx, uint64_t circuit_type, const uin
 int zkw_closed_form_public_inputs(zkw_ctx *ctx, uint8_t circuit_type, const void *instances, size_t n, uint64_t *compact,
                                   uint64_t *public_inputs);
 
+/* The leaf layer's view of a recursion queue: RecursionQueueSimulator::split_by(RECURSION_ARITY = 32) as create_leaf_witnesses
+   uses it (src/witness/recursive_aggregation.rs:98-117): states = the [n][12] queue states after each request (host; from
+   zkw_queue_push_chain_full or zkw_block_recursion_states), leaf_states[k] = RecursionLeafInputWitness::queue_state of leaf k
+   (head = the state before its first request, tail = the state after its last, length = its requests); the leaf's
+   queue_witness elements are the requests' encodings with old_tail = the state before each. Host arithmetic only. */
+#define ZKW_RECURSION_ARITY 32
+int zkw_recursion_queue_split(const uint64_t *states, size_t n, uint32_t arity, zkw_queue_state12 *leaf_states, size_t max_leaves,
+                              size_t *n_leaves);
+
 /* ---- L1 messages hasher ------------------------------------------------------------------------------ */
 /* compute_linear_keccak256, src/witness/individual_circuits/data_hasher_and_merklizer.rs:8-67: Keccak-256 of
    the concatenated 88-byte serialisations (circuit_encodings/src/log_query.rs:503-534) of the net L2->L1
