@@ -103,6 +103,7 @@ struct PrecompileJob {
     u64 n_requests, total_rounds;
     u32 capacity;
     zkw_keccak_round_record* keccak_rounds;  // keccak256 only, may be null: one record per round in the global round order
+    zkw_sha256_round_record* sha256_rounds;  // sha256 only, may be null
 };
 
 __device__ __forceinline__ void word_be_bytes(const u32* limbs, uint8_t out[32]) {  // U256::to_big_endian
@@ -152,7 +153,20 @@ __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
                 qpos++; reads++;
                 abi.input_memory_offset += 1;
             }
-            sha256_compress(sha, w);
+            // the cycle of the Sha256RoundFunction circuit: block as hashed (big-endian words), reset, state after
+            u64* rec = job.sha256_rounds ? reinterpret_cast<u64*>(job.sha256_rounds + g0 + round) : nullptr;  // 104 = 8 * 13 bytes
+            if (rec) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) rec[m] = (u64)__builtin_bswap32(w[2 * m]) | ((u64)__builtin_bswap32(w[2 * m + 1]) << 32);
+            }
+            sha256_compress(sha, w);  // expands the schedule in place
+            if (rec) {
+                rec[8] = (u64)(round == 0 ? 1u : 0u) | ((u64)sha[0] << 32);
+                rec[9] = (u64)sha[1] | ((u64)sha[2] << 32);
+                rec[10] = (u64)sha[3] | ((u64)sha[4] << 32);
+                rec[11] = (u64)sha[5] | ((u64)sha[6] << 32);
+                rec[12] = (u64)sha[7];
+            }
             rounds_left--;
         } else if (kind == ZKW_PRECOMPILE_ECRECOVER) {
             for (int k = 0; k < 4; k++) bad |= job.mem_q[qpos + k].rw_flag;

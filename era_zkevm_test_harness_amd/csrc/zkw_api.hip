@@ -41,6 +41,7 @@
 #include "storage_sorter_circuit_kernels.cuh"
 #include "vm_kernels.cuh"
 #include "keccak_circuit_kernels.cuh"
+#include "sha256_circuit_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -2885,11 +2886,12 @@ struct zkw_precompile_witness {
     u64 *mem_enc = nullptr, *mem_tails = nullptr;
     zkw_precompile_instance* instances = nullptr;
     zkw_keccak_round_record* keccak_rounds = nullptr;  // keccak256 only: [total_rounds], the cycles of the circuit
+    zkw_sha256_round_record* sha256_rounds = nullptr;  // sha256 only
     int kind = 0;
     u32 capacity = 0;
     u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
     void release() {
-        void* ptrs[] = {mem_enc, mem_tails, instances, keccak_rounds, cf_pi};
+        void* ptrs[] = {mem_enc, mem_tails, instances, keccak_rounds, sha256_rounds, cf_pi};
         for (void* p : ptrs)
             if (p) dev_free(p);
     }
@@ -2939,6 +2941,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
     alloc((void**)&w->mem_tails, n_queries * 96);
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_precompile_instance));
     if (kind == ZKW_PRECOMPILE_KECCAK256) alloc((void**)&w->keccak_rounds, w->total_rounds * sizeof(zkw_keccak_round_record));
+    if (kind == ZKW_PRECOMPILE_SHA256) alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
     auto bail = [&](int rc) { w->release(); delete w; return rc; };
     if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_precompile_build: hipMalloc failed: %s", hipGetErrorString(e)));
     int rc = ZKW_OK;
@@ -2962,7 +2965,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
                 if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
             }
         }
-        PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity, w->keccak_rounds};
+        PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity, w->keccak_rounds, w->sha256_rounds};
         { Prof _p(ctx, "k_precompile_walk"); hipLaunchKernelGGL(k_precompile_walk, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
         if ((rc = launch_check("k_precompile_walk")) != ZKW_OK) return bail(rc);
     }
@@ -3005,6 +3008,7 @@ static const void* pc_array(const zkw_precompile_witness* w, int what, size_t* b
         case ZKW_PRC_MEM_TAILS: *bytes = w->n_queries * 96; return w->mem_tails;
         case ZKW_PRC_INSTANCES: *bytes = w->n_instances * sizeof(zkw_precompile_instance); return w->instances;
         case ZKW_PRC_KECCAK_ROUNDS: *bytes = w->keccak_rounds ? w->total_rounds * sizeof(zkw_keccak_round_record) : 0; return w->keccak_rounds;
+        case ZKW_PRC_SHA256_ROUNDS: *bytes = w->sha256_rounds ? w->total_rounds * sizeof(zkw_sha256_round_record) : 0; return w->sha256_rounds;
         default: *bytes = 0; return nullptr;
     }
 }
@@ -3019,7 +3023,7 @@ extern "C" const void* zkw_precompile_witness_device_ptr(const zkw_precompile_wi
 }
 extern "C" int zkw_precompile_witness_get(const zkw_precompile_witness* w, int what, void* dst, size_t dst_bytes) {
     if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_precompile_witness_get: null argument");
-    if (what < 0 || what > ZKW_PRC_KECCAK_ROUNDS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    if (what < 0 || what > ZKW_PRC_SHA256_ROUNDS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
     size_t bytes = 0;
     const void* src = pc_array(w, what, &bytes);
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
@@ -3460,6 +3464,75 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     ZKW_TRY(launch_check("k_kc_fill"));
     { Prof _p(ctx, "k_kc_finish"); hipLaunchKernelGGL(k_kc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     return launch_check("k_kc_finish");
+}
+
+// ------------------------------------------------------------------------------------------------ Sha256RoundFunction synthesis
+// ZkSyncBaseLayerCircuit::synthesis for Sha256RoundFunction (type 6) in "zkw trace v3" (sha256_circuit_kernels.cuh)
+extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances,
+                                           zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_sha256_round_synthesize: bad argument");
+    if (w->kind != ZKW_PRECOMPILE_SHA256) return fail(ZKW_ERR_INVALID, "zkw_sha256_round_synthesize: not a sha256 witness");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (t->n_cols < SC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the Sha256RoundFunction circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, SC_COLS);
+    const u32 capacity = w->capacity;
+    const size_t n_rows = t->n_rows;
+    if (SC_MIN_ROWS(capacity) > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)SC_MIN_ROWS(capacity), n_rows);
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
+    u32* d_hist = nullptr;
+    const size_t hist_elems = (size_t)SC_NUM_TABLES * SC_TABLE_ROWS;
+    ZKW_TRY(ctx->scratch_t<u32>("sc_hist", n_instances * hist_elems, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_elems * sizeof(u32), ctx->stream));
+    std::vector<ScSynthJob> jobs(n_instances);
+    for (size_t k = 0; k < n_instances; k++) {
+        const size_t i = first_instance + k;
+        ScSynthJob& j = jobs[k];
+        j.rounds = w->sha256_rounds;
+        j.first_round = (u64)i * capacity;
+        j.n_active = w->n_requests ? (u32)std::min<u64>(capacity, w->total_rounds - j.first_round) : 0;
+        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
+        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.hist = d_hist + k * hist_elems;
+        HIP_TRY(hipMemsetAsync(j.trace, 0, (size_t)SC_COLS * n_rows * sizeof(u64), ctx->stream));
+    }
+    ScSynthJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("sc_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)n_instances;
+    { Prof _p(ctx, "k_sc_fill"); hipLaunchKernelGGL(k_sc_fill, dim3(std::min<unsigned>(capacity, SC_FILL_BLOCKS), nj), dim3(SC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_sc_fill"));
+    { Prof _p(ctx, "k_sc_finish"); hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    return launch_check("k_sc_finish");
+}
+
+extern "C" int zkw_sha256_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
+                                                uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_sha256_round_check_satisfied: bad argument");
+    if (t->n_cols < SC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %d", t->n_cols, SC_COLS);
+    if (SC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64* trace = t->data + slot * t->slot_elems();
+    const size_t n_rows = t->n_rows, hist_elems = (size_t)SC_NUM_TABLES * SC_TABLE_ROWS;
+    CheckResult* d_res = nullptr;
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
+    ZKW_TRY(ctx->scratch_t<u32>("sc_check_hist", hist_elems, &d_hist));
+    CheckResult init{0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, hist_elems * sizeof(u32), ctx->stream));
+    const unsigned items = SC_NUM_OPS + SC_NUM_GATES + SC_ROWS_PER_CYCLE;
+    { Prof _p(ctx, "k_sc_check_cycle"); hipLaunchKernelGGL(k_sc_check_cycle, dim3((items + 255) / 256, capacity), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_sc_check_cycle"));
+    { Prof _p(ctx, "k_sc_check_tail"); hipLaunchKernelGGL(k_sc_check_tail, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_sc_check_tail"));
+    CheckResult res;
+    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
+    *n_violations = res.violations;
+    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
+    return ZKW_OK;
 }
 
 // LinearHasher (type 13): the Keccak-f netlist over the sponge of the serialized L2 -> L1 messages (compute_linear_keccak256,

@@ -114,6 +114,8 @@ SYMBOLS = [
     ("zkw_log_demux_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_precompile_closed_forms", _int, [_vp, _vp, _vp, _vp]),
     ("zkw_keccak_round_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_sha256_round_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_sha256_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_linear_hasher_synthesize", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
     ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
@@ -462,7 +464,9 @@ assert LINEAR_HASHER_INSTANCE.itemsize == 112
 # instance record of the circuits zkw_closed_form_public_inputs serves, by numeric circuit type
 CLOSED_FORM_RECORD = {3: DECOMMITTER_INSTANCE, 5: PRECOMPILE_INSTANCE, 6: PRECOMPILE_INSTANCE, 7: PRECOMPILE_INSTANCE,
                       10: STORAGE_APPLICATION_INSTANCE, 13: LINEAR_HASHER_INSTANCE}
-PRC_MEM_ENC, PRC_MEM_TAILS, PRC_INSTANCES, PRC_KECCAK_ROUNDS = range(4)
+PRC_MEM_ENC, PRC_MEM_TAILS, PRC_INSTANCES, PRC_KECCAK_ROUNDS, PRC_SHA256_ROUNDS = range(5)
+SHA256_ROUND_RECORD = np.dtype([("block", "u1", (64,)), ("reset", "<u4"), ("state_after", "<u4", (8,)), ("_pad", "<u4")])
+assert SHA256_ROUND_RECORD.itemsize == 104
 KECCAK_ROUND_RECORD = np.dtype([("block", "u1", (136,)), ("reset", "u1"), ("_pad", "u1", (7,)), ("state_after", "u1", (200,))])
 assert KECCAK_ROUND_RECORD.itemsize == 344
 SAP_DERIVED_KEYS, SAP_MERKLE_PATHS, SAP_LEAF_INDEXES, SAP_ROOTS, SAP_INSTANCES = range(5)
@@ -509,7 +513,7 @@ class StorageApplicationWitness:
 class PrecompileWitness:
     """Owner of a zkw_precompile_witness handle (keccak256 / sha256 / ecrecover round-function instances)."""
 
-    _DTYPES = {PRC_INSTANCES: PRECOMPILE_INSTANCE, PRC_KECCAK_ROUNDS: KECCAK_ROUND_RECORD}
+    _DTYPES = {PRC_INSTANCES: PRECOMPILE_INSTANCE, PRC_KECCAK_ROUNDS: KECCAK_ROUND_RECORD, PRC_SHA256_ROUNDS: SHA256_ROUND_RECORD}
     _SHAPES = {PRC_MEM_ENC: (-1, 8), PRC_MEM_TAILS: (-1, 12)}
 
     def __init__(self, ctx):
@@ -1136,6 +1140,25 @@ def _ctx_synthesize_linear_hasher(self, messages, queue_state, capacity, trace, 
     return rec, pi
 
 
+SC_COLS = 138  # include/zkw_sha256_circuit_spec.h
+
+
+def _ctx_synthesize_sha256_round_function(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+    """ZkSyncBaseLayerCircuit::Sha256RoundFunction synthesis ("zkw trace v3") for instances of a sha256 PrecompileWitness
+    (the trace needs SC_COLS = 138 columns and at least 65 536 rows)."""
+    n = witness.num_instances - first_instance if n_instances is None else n_instances
+    _check(load().zkw_sha256_round_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+
+def _ctx_check_if_satisfied_sha256_round_function(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_sha256_round_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.synthesize_sha256_round_function = _ctx_synthesize_sha256_round_function
+Context.check_if_satisfied_sha256_round_function = _ctx_check_if_satisfied_sha256_round_function
 Context.synthesize_linear_hasher = _ctx_synthesize_linear_hasher
 Context.synthesize_keccak_round_function = _ctx_synthesize_keccak_round_function
 Context.check_if_satisfied_keccak_round_function = _ctx_check_if_satisfied_keccak_round_function

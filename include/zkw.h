@@ -488,7 +488,8 @@ enum {
     ZKW_PRC_MEM_ENC = 0,   /* uint64_t[n_queries][8]  */
     ZKW_PRC_MEM_TAILS = 1, /* uint64_t[n_queries][12] */
     ZKW_PRC_INSTANCES = 2, /* zkw_precompile_instance[max(1, ceil(total_rounds/capacity))] */
-    ZKW_PRC_KECCAK_ROUNDS = 3 /* keccak256 only: zkw_keccak_round_record[total_rounds], the cycles of the type-5 circuit */
+    ZKW_PRC_KECCAK_ROUNDS = 3, /* keccak256 only: zkw_keccak_round_record[total_rounds], the cycles of the type-5 circuit */
+    ZKW_PRC_SHA256_ROUNDS = 4  /* sha256 only: zkw_sha256_round_record[total_rounds], the cycles of the type-6 circuit */
 };
 size_t zkw_precompile_witness_num_instances(const zkw_precompile_witness *w);
 size_t zkw_precompile_witness_num_rounds(const zkw_precompile_witness *w);
@@ -528,6 +529,18 @@ int zkw_precompile_closed_forms(zkw_ctx *ctx, zkw_precompile_witness *w, const u
 int zkw_keccak_round_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t first_instance, size_t n_instances,
                                 zkw_trace *t, size_t first_slot);
 int zkw_keccak_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
+                                     uint64_t *n_violations, uint64_t *first_bad);
+
+/* ---- Sha256RoundFunction circuit (type 6) ------------------------------------------------------------------
+   ZkSyncBaseLayerCircuit::synthesis for the sha256 round function (wrapper geometry: circuit_definitions/src/
+   circuit_definitions/base_layer/sha256_round_function.rs:28-39,52-134; 2^20 rows, capacity 2206). Trace "zkw trace v3",
+   include/zkw_sha256_circuit_spec.h: 138 columns, one netlist per cycle of 6552 byte lookups (XOR8, ANDN8, AND8, ROT<1..7>)
+   and 184 32-bit ADD gates in the general-purpose columns of the same rows, stating out = idle ? prev :
+   sha256_compress(reset ? IV : prev, block); 469 rows per cycle (up to 2235 cycles in 2^20 rows). Cycles = the instance's
+   rounds (ZKW_PRC_SHA256_ROUNDS), idle up to the witness's capacity; n_rows >= 65 536. w must be a sha256 witness. */
+int zkw_sha256_round_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t first_instance, size_t n_instances,
+                                zkw_trace *t, size_t first_slot);
+int zkw_sha256_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                                      uint64_t *n_violations, uint64_t *first_bad);
 
 /* ---- LinearHasher circuit (type 13) ---------------------------------------------------------------------

@@ -370,6 +370,17 @@ typedef struct zkw_keccak_round_record {
     uint8_t state_after[200];
 } zkw_keccak_round_record;
 
+/* One SHA-256 compression of the sha256 precompile (= one cycle of the Sha256RoundFunction circuit, type 6), in the global
+   round order of the block: the 64-byte message block (two memory words, big-endian as hashed), whether it starts a new
+   request (the chaining state is reset to the IV first) and the chaining state after the compression.
+   ZKW_PRC_SHA256_ROUNDS of the sha256 witness; consumed by zkw_sha256_round_synthesize. */
+typedef struct zkw_sha256_round_record {
+    uint8_t block[64];
+    uint32_t reset;
+    uint32_t state_after[8];
+    uint32_t _pad;
+} zkw_sha256_round_record;
+
 /* {Keccak256RoundFunction,Sha256RoundFunction,Ecrecover}CircuitInstanceWitness */
 typedef struct zkw_precompile_instance {
     uint32_t start_flag;

@@ -86,6 +86,9 @@ int64_t orc_precompile_build_ex(int kind, const zkw_log_query *requests, const u
                                 const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,
                                 uint64_t *mem_enc, uint64_t *mem_tails, zkw_precompile_instance *instances,
                                 zkw_keccak_round_record *keccak_rounds);
+/* sha256 only, may be NULL (set before orc_precompile_build_ex; test infrastructure, single-threaded use) */
+static zkw_sha256_round_record *g_sha_rounds = NULL;
+void orc_precompile_set_sha256_rounds(zkw_sha256_round_record *r) { g_sha_rounds = r; }
 int64_t orc_precompile_build(int kind, const zkw_log_query *requests, const uint64_t *req_tails, size_t n_req,
                              const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,
                              uint64_t *mem_enc, uint64_t *mem_tails, zkw_precompile_instance *instances) {
@@ -178,6 +181,13 @@ int64_t orc_precompile_build_ex(int kind, const zkw_log_query *requests, const u
                     abi.input_memory_offset += 1;
                 }
                 orc_sha256_compress(sha, block);
+                if (g_sha_rounds) {
+                    zkw_sha256_round_record *rec = g_sha_rounds + total_rounds;
+                    memset(rec, 0, sizeof *rec);
+                    memcpy(rec->block, block, 64);
+                    rec->reset = round == 0;
+                    memcpy(rec->state_after, sha, 32);
+                }
                 rounds_left--;
             } else if (kind == ZKW_PRECOMPILE_ECRECOVER) {
                 for (int k = 0; k < 4; k++) {

@@ -145,6 +145,8 @@ PRECOMPILE_FSM = np.dtype(
      ("output_page", "<u4"), ("output_offset", "<u4"), ("num_rounds", "<u4"), ("needs_full_padding_round", "<u4"),
      ("buffer_filled", "<u4"), ("sha256_inner_state", "<u4", (8,)), ("keccak_internal_state", "u1", (200,)),
      ("buffer_bytes", "u1", (192,)), ("_pad", "<u4")])
+SHA256_ROUND_RECORD = np.dtype([("block", "u1", (64,)), ("reset", "<u4"), ("state_after", "<u4", (8,)), ("_pad", "<u4")])
+assert SHA256_ROUND_RECORD.itemsize == 104
 KECCAK_ROUND_RECORD = np.dtype([("block", "u1", (136,)), ("reset", "u1"), ("_pad", "u1", (7,)), ("state_after", "u1", (200,))])
 assert KECCAK_ROUND_RECORD.itemsize == 344
 PRECOMPILE_INSTANCE = np.dtype(
@@ -569,13 +571,18 @@ def precompile_build(kind, requests, request_tails, mem_queries, capacity, mem_i
     o = dict(mem_enc=np.zeros((mq.size, 8), np.uint64), mem_tails=np.zeros((mq.size, 12), np.uint64),
              instances=np.zeros(n_inst, PRECOMPILE_INSTANCE))
     rounds = np.zeros(mq.size + req.size + 1, KECCAK_ROUND_RECORD) if kind == 0 else None
+    sha_rounds = np.zeros(mq.size + req.size + 1, SHA256_ROUND_RECORD) if kind == 1 else None
+    lib().orc_precompile_set_sha256_rounds(_p(sha_rounds) if sha_rounds is not None else None)
     f = lib().orc_precompile_build_ex
     f.restype = C.c_int64
     rc = f(C.c_int(kind), _p(req), _p(rt), C.c_size_t(req.size), _p(mq), C.c_size_t(mq.size), C.c_uint32(capacity),
            _p(mem_in), _p(o["mem_enc"]), _p(o["mem_tails"]), _p(o["instances"]), _p(rounds) if rounds is not None else None)
+    lib().orc_precompile_set_sha256_rounds(None)
     if rc < 0:
         raise RuntimeError(f"orc_precompile_build failed: {rc}")
     o["instances"] = o["instances"][:rc]
+    if sha_rounds is not None:
+        o["sha256_rounds"] = sha_rounds[:int(o["instances"]["num_rounds"].sum()) if req.size else 0]
     if rounds is not None:  # one record per Keccak-f call, in the global round order
         o["keccak_rounds"] = rounds[:int(o["instances"]["num_rounds"].sum()) if req.size else 0]
     return o
@@ -600,6 +607,44 @@ def keccak_round_synthesize(build_out, instance_index, capacity, n_rows, public_
     if rc != 0:
         raise RuntimeError(f"orc_keccak_round_synthesize failed: {rc}")
     return trace
+
+
+SC_COLS, SC_ROWS_PER_CYCLE = 138, 469
+
+
+def sha256_round_synthesize_raw(state_in, records, capacity, n_rows, public_input):
+    """orc_sha256_round_synthesize: cycles = the given records, then idle cycles up to `capacity`; raises when the netlist's
+    chaining state differs from a record's state_after"""
+    recs = np.ascontiguousarray(records, dtype=SHA256_ROUND_RECORD)
+    st = np.ascontiguousarray(state_in, dtype=np.uint8)
+    pi = np.ascontiguousarray(public_input, dtype=np.uint64)
+    trace = np.zeros((SC_COLS, n_rows), np.uint64)
+    f = lib().orc_sha256_round_synthesize
+    f.restype = C.c_int
+    rc = f(_p(st), _p(recs) if recs.size else None, C.c_uint32(recs.size), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_sha256_round_synthesize failed: {rc}")
+    return trace
+
+
+def sha256_round_synthesize(build_out, instance_index, capacity, n_rows, public_input=None):
+    """Fill the Sha256RoundFunction trace of one instance from the outputs of precompile_build(1, ...)"""
+    inst = build_out["instances"][instance_index]
+    first, n = int(inst["first_round"]), int(inst["num_rounds"])
+    state_in = (np.ascontiguousarray(build_out["sha256_rounds"][first - 1]["state_after"]).view(np.uint8) if first
+                else np.zeros(32, np.uint8))
+    pi = (public_input if public_input is not None else closed_form_public_inputs(6, build_out["instances"])[1][instance_index])
+    return sha256_round_synthesize_raw(state_in, build_out["sha256_rounds"][first:first + n], capacity, n_rows, pi)
+
+
+def sha256_round_check(trace, capacity):
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_sha256_round_check
+    f.restype = C.c_uint64
+    bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value
+    return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
 def linear_hasher_cycles(capacity):
