@@ -3441,9 +3441,9 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));  // public inputs of the block's instances (a20), once
     u32* d_hist = nullptr;
-    const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
-    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", n_instances * hist_elems, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_elems * sizeof(u32), ctx->stream));
+    const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS, hist_all = ZKW_NUM_XCD * hist_elems;  // one copy per XCD
+    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", n_instances * hist_all, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_all * sizeof(u32), ctx->stream));
     std::vector<KcSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         const size_t i = first_instance + k;
@@ -3454,7 +3454,7 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
         j.n_active = w->n_requests ? (u32)std::min<u64>(capacity, w->total_rounds - j.first_round) : 0;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
-        j.hist = d_hist + k * hist_elems;
+        j.hist = d_hist + k * hist_all;
         HIP_TRY(hipMemsetAsync(j.trace, 0, (size_t)KC_COLS * n_rows * sizeof(u64), ctx->stream));
     }
     KcSynthJob* d_jobs = nullptr;
@@ -3483,9 +3483,9 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
     u32* d_hist = nullptr;
-    const size_t hist_elems = (size_t)SC_NUM_TABLES * SC_TABLE_ROWS;
-    ZKW_TRY(ctx->scratch_t<u32>("sc_hist", n_instances * hist_elems, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_elems * sizeof(u32), ctx->stream));
+    const size_t hist_elems = (size_t)SC_NUM_TABLES * SC_TABLE_ROWS, hist_all = ZKW_NUM_XCD * hist_elems;  // one copy per XCD
+    ZKW_TRY(ctx->scratch_t<u32>("sc_hist", n_instances * hist_all, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_all * sizeof(u32), ctx->stream));
     std::vector<ScSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         const size_t i = first_instance + k;
@@ -3495,7 +3495,7 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
         j.n_active = w->n_requests ? (u32)std::min<u64>(capacity, w->total_rounds - j.first_round) : 0;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
-        j.hist = d_hist + k * hist_elems;
+        j.hist = d_hist + k * hist_all;
         HIP_TRY(hipMemsetAsync(j.trace, 0, (size_t)SC_COLS * n_rows * sizeof(u64), ctx->stream));
     }
     ScSynthJob* d_jobs = nullptr;
@@ -3574,8 +3574,8 @@ extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* m
     ZKW_TRY(launch_check("k_commit_encodings"));
     u32* d_hist = nullptr;
     const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
-    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", hist_elems, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, hist_elems * sizeof(u32), ctx->stream));
+    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", ZKW_NUM_XCD * hist_elems, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, ZKW_NUM_XCD * hist_elems * sizeof(u32), ctx->stream));
     std::vector<KcSynthJob> jobs(1);
     jobs[0].rounds = d_rounds;
     jobs[0].first_round = 0;
