@@ -1,0 +1,27 @@
+"""The committed layout contracts include/zkw_*_circuit_spec.h are exactly what their generators emit (nobody edits a
+generated header by hand, nobody changes a generator without regenerating): every generator is run against a scratch copy
+of the tree and its output compared byte for byte. The netlist generators also re-check their netlists against plain
+Keccak-f[1600] / hashlib.sha256 on the way."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GENERATORS = {"gen_ram_circuit.py": "zkw_ram_circuit_spec.h", "gen_decommit_sorter_circuit.py": "zkw_decommit_sorter_circuit_spec.h",
+              "gen_events_sorter_circuit.py": "zkw_events_sorter_circuit_spec.h", "gen_log_demux_circuit.py": "zkw_log_demux_circuit_spec.h",
+              "gen_storage_sorter_circuit.py": "zkw_storage_sorter_circuit_spec.h", "gen_keccak_circuit.py": "zkw_keccak_circuit_spec.h",
+              "gen_sha256_circuit.py": "zkw_sha256_circuit_spec.h"}
+
+
+@pytest.mark.parametrize("gen,header", sorted(GENERATORS.items()))
+def test_generated_header_is_current(gen, header, tmp_path):
+    tools = tmp_path / "tools"
+    (tmp_path / "include").mkdir()
+    shutil.copytree(os.path.join(ROOT, "tools"), tools, ignore=shutil.ignore_patterns("__pycache__", "probe_*", "p2_*", "ubench_*", "*.hip"))
+    r = subprocess.run([sys.executable, str(tools / gen)], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-1500:]
+    got = (tmp_path / "include" / header).read_bytes()
+    assert got == open(os.path.join(ROOT, "include", header), "rb").read(), f"{header} is stale: run python tools/{gen}"
