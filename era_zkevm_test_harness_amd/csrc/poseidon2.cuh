@@ -364,6 +364,9 @@ struct Coop4 {
         }
         for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
             u64 rc = c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];
+            // (the hand-scheduled multiplication of the row form was tried here, where a lane has ONE dependent S-box: the
+            // chain kernel got 4 % slower, 891 against 932 M permutations/s — with ~2 waves per SIMD the other wave fills
+            // the gaps the compiler's schedule leaves, and the opaque asm blocks only cost)
             u64 sx = gl::pow7(gl::add(x[0], rc));
             x[0] = first ? sx : x[0];
             internal(x);

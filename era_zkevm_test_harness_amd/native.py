@@ -15,7 +15,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkw.so")
+LIB_PATH = os.environ.get("ZKW_LIB", os.path.join(_HERE, "libzkw.so"))  # ZKW_LIB: an alternative build (A/B measurements)
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_CHECK_FAILED = 0, -1, -2, -3, -4, -5
 PTR_HOST, PTR_DEVICE = 0, 1
