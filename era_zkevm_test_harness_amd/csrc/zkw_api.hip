@@ -3501,7 +3501,7 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     ScSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("sc_jobs", jobs, &d_jobs));
     const unsigned nj = (unsigned)n_instances;
-    { Prof _p(ctx, "k_sc_fill"); hipLaunchKernelGGL(k_sc_fill, dim3(std::min<unsigned>(capacity, SC_FILL_BLOCKS), nj), dim3(SC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_sc_fill"); hipLaunchKernelGGL(k_sc_fill, dim3(std::min<unsigned>((capacity + SC_FILL_WAVES - 1) / SC_FILL_WAVES, SC_FILL_BLOCKS), nj), dim3(SC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_sc_fill"));
     { Prof _p(ctx, "k_sc_finish"); hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     return launch_check("k_sc_finish");
