@@ -49,6 +49,7 @@ struct DecommitterJob {
     u64* mem_enc;                        // [total_words][8]
     u32* violations;
     u64 n_requests;
+    zkw_sha256_round_record* sha256_rounds;  // may be null: [total_rounds], the cycles of the CodeDecommitter circuit (type 3)
 };
 
 // one lane per request: SHA-256 over its bytecode (two big-endian words per block, padding in the last
@@ -76,7 +77,20 @@ __global__ __launch_bounds__(64) void k_decommitter_sha(DecommitterJob job) {
             for (int j = 9; j < 15; j++) w[j] = 0;
             w[15] = num_words * 32 * 8;  // length_in_bits, 32-bit big-endian at bytes 60..64
         }
-        sha256_compress(st, w);
+        // the cycle of the CodeDecommitter circuit: block as hashed (big-endian words, padding included), reset, state after
+        u64* rec = job.sha256_rounds ? reinterpret_cast<u64*>(job.sha256_rounds + r0 + r) : nullptr;  // 104 = 8 * 13 bytes
+        if (rec) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) rec[m] = (u64)__builtin_bswap32(w[2 * m]) | ((u64)__builtin_bswap32(w[2 * m + 1]) << 32);
+        }
+        sha256_compress(st, w);  // expands the schedule in place
+        if (rec) {
+            rec[8] = (u64)(r == 0 ? 1u : 0u) | ((u64)st[0] << 32);
+            rec[9] = (u64)st[1] | ((u64)st[2] << 32);
+            rec[10] = (u64)st[3] | ((u64)st[4] << 32);
+            rec[11] = (u64)st[5] | ((u64)st[6] << 32);
+            rec[12] = (u64)st[7];
+        }
         u32* o = job.round_states + 8 * (r0 + r);
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = st[j];

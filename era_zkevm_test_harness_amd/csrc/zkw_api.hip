@@ -42,6 +42,7 @@
 #include "vm_kernels.cuh"
 #include "keccak_circuit_kernels.cuh"
 #include "sha256_circuit_kernels.cuh"
+#include "code_decommitter_circuit_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -2572,8 +2573,11 @@ struct zkw_decommitter_witness {
     u64 *mem_enc = nullptr, *mem_tails = nullptr;
     u32* round_states = nullptr;
     zkw_decommitter_instance* instances = nullptr;
+    zkw_sha256_round_record* sha256_rounds = nullptr;  // [total_rounds]: the cycles of the circuit
+    u32 capacity = 0;
+    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
     void release() {
-        void* ptrs[] = {mem_q, mem_enc, mem_tails, round_states, instances};
+        void* ptrs[] = {mem_q, mem_enc, mem_tails, round_states, instances, sha256_rounds, cf_pi};
         for (void* p : ptrs)
             if (p) dev_free(p);
     }
@@ -2595,7 +2599,7 @@ extern "C" int zkw_decommitter_memory_queries(zkw_ctx* ctx, const zkw_decommit_q
     ZKW_TRY(ctx->in("dcm_words", words + 8 * word_offsets[0], total * 8, &d_words));
     ZKW_TRY(ctx->upload("dcm_woff", woff, &d_woff));
     ZKW_TRY(ctx->out("dcm_mq_out", out, total, &d_out));
-    DecommitterJob job{d_req, d_words, d_woff, nullptr, nullptr, d_out, nullptr, nullptr, n_requests};
+    DecommitterJob job{d_req, d_words, d_woff, nullptr, nullptr, d_out, nullptr, nullptr, n_requests, nullptr};
     if (total) {
         { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, job, (u64)total); }
         ZKW_TRY(launch_check("k_decommitter_mem_queries"));
@@ -2629,6 +2633,8 @@ extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit
     alloc((void**)&w->mem_enc, w->total_words * 64);
     alloc((void**)&w->mem_tails, w->total_words * 96);
     alloc((void**)&w->round_states, w->total_rounds * 32);
+    alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
+    w->capacity = capacity;
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_decommitter_instance));
     auto bail = [&](int rc) { w->release(); delete w; return rc; };
     if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_decommitter_build: hipMalloc failed: %s", hipGetErrorString(e)));
@@ -2645,7 +2651,7 @@ extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit
     if (rc == ZKW_OK) rc = ctx->scratch_t<u32>("dcm_viol", 1, &d_viol);
     if (rc != ZKW_OK) return bail(rc);
     if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
-    DecommitterJob job{d_req, d_words, d_woff, d_roff, w->round_states, w->mem_q, w->mem_enc, d_viol, n_requests};
+    DecommitterJob job{d_req, d_words, d_woff, d_roff, w->round_states, w->mem_q, w->mem_enc, d_viol, n_requests, w->sha256_rounds};
     { Prof _p(ctx, "k_decommitter_sha"); hipLaunchKernelGGL(k_decommitter_sha, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
     if ((rc = launch_check("k_decommitter_sha")) != ZKW_OK) return bail(rc);
     { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(w->total_words, 256)), dim3(256), 0, ctx->stream, job, (u64)w->total_words); }
@@ -2698,6 +2704,7 @@ static const void* dcm_array(const zkw_decommitter_witness* w, int what, size_t*
         case ZKW_DCM_MEM_TAILS: *bytes = w->total_words * 96; return w->mem_tails;
         case ZKW_DCM_ROUND_STATES: *bytes = w->total_rounds * 32; return w->round_states;
         case ZKW_DCM_INSTANCES: *bytes = w->n_instances * sizeof(zkw_decommitter_instance); return w->instances;
+        case ZKW_DCM_SHA256_ROUNDS: *bytes = w->total_rounds * sizeof(zkw_sha256_round_record); return w->sha256_rounds;
         default: *bytes = 0; return nullptr;
     }
 }
@@ -2712,7 +2719,7 @@ extern "C" const void* zkw_decommitter_witness_device_ptr(const zkw_decommitter_
 }
 extern "C" int zkw_decommitter_witness_get(const zkw_decommitter_witness* w, int what, void* dst, size_t dst_bytes) {
     if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_decommitter_witness_get: null argument");
-    if (what < 0 || what > ZKW_DCM_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    if (what < 0 || what > ZKW_DCM_SHA256_ROUNDS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
     size_t bytes = 0;
     const void* src = dcm_array(w, what, &bytes);
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
@@ -3528,6 +3535,75 @@ extern "C" int zkw_sha256_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t
     ZKW_TRY(launch_check("k_sc_check_cycle"));
     { Prof _p(ctx, "k_sc_check_tail"); hipLaunchKernelGGL(k_sc_check_tail, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
     ZKW_TRY(launch_check("k_sc_check_tail"));
+    CheckResult res;
+    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
+    *n_violations = res.violations;
+    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
+    return ZKW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ CodeDecommitter synthesis
+// ZkSyncBaseLayerCircuit::synthesis for CodeDecommitter (type 3): the SHA-256 netlist at 18 lookups per row
+// (code_decommitter_circuit_kernels.cuh, generated from sha256_circuit_kernels.cuh), one cycle per round of the unpacked bytecodes
+extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_witness* w, size_t first_instance, size_t n_instances,
+                                               zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_code_decommitter_synthesize: bad argument");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (t->n_cols < DC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the CodeDecommitter circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, DC_COLS);
+    const u32 capacity = w->capacity;
+    const size_t n_rows = t->n_rows;
+    if (DC_MIN_ROWS(capacity) > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)DC_MIN_ROWS(capacity), n_rows);
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!w->cf_pi) ZKW_TRY(closed_form_public_inputs<CfDecommitter>(ctx, w->instances, w->n_instances, &w->cf_pi));
+    u32* d_hist = nullptr;
+    const size_t hist_elems = (size_t)DC_NUM_TABLES * DC_TABLE_ROWS, hist_all = ZKW_NUM_XCD * hist_elems;  // one copy per XCD
+    ZKW_TRY(ctx->scratch_t<u32>("dc_hist", n_instances * hist_all, &d_hist));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_all * sizeof(u32), ctx->stream));
+    std::vector<DcSynthJob> jobs(n_instances);
+    for (size_t k = 0; k < n_instances; k++) {
+        const size_t i = first_instance + k;
+        DcSynthJob& j = jobs[k];
+        j.rounds = w->sha256_rounds;
+        j.first_round = (u64)i * capacity;  // a cycle is one round (BeginNew shares the cycle of a bytecode's first round)
+        j.n_active = (u32)std::min<u64>(capacity, w->total_rounds - j.first_round);
+        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
+        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.hist = d_hist + k * hist_all;
+        HIP_TRY(hipMemsetAsync(j.trace, 0, (size_t)DC_COLS * n_rows * sizeof(u64), ctx->stream));
+    }
+    DcSynthJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("dc_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)n_instances;
+    { Prof _p(ctx, "k_dc_fill"); hipLaunchKernelGGL(k_dc_fill, dim3(std::min<unsigned>((capacity + DC_FILL_WAVES - 1) / DC_FILL_WAVES, DC_FILL_BLOCKS), nj), dim3(DC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_dc_fill"));
+    { Prof _p(ctx, "k_dc_finish"); hipLaunchKernelGGL(k_dc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    return launch_check("k_dc_finish");
+}
+
+extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
+                                                    uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_code_decommitter_check_satisfied: bad argument");
+    if (t->n_cols < DC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %d", t->n_cols, DC_COLS);
+    if (DC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64* trace = t->data + slot * t->slot_elems();
+    const size_t n_rows = t->n_rows, hist_elems = (size_t)DC_NUM_TABLES * DC_TABLE_ROWS;
+    CheckResult* d_res = nullptr;
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
+    ZKW_TRY(ctx->scratch_t<u32>("dc_check_hist", hist_elems, &d_hist));
+    CheckResult init{0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, hist_elems * sizeof(u32), ctx->stream));
+    const unsigned items = DC_NUM_OPS + DC_NUM_GATES + DC_ROWS_PER_CYCLE;
+    { Prof _p(ctx, "k_dc_check_cycle"); hipLaunchKernelGGL(k_dc_check_cycle, dim3((items + 255) / 256, capacity), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_dc_check_cycle"));
+    { Prof _p(ctx, "k_dc_check_tail"); hipLaunchKernelGGL(k_dc_check_tail, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_dc_check_tail"));
     CheckResult res;
     ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
     *n_violations = res.violations;

@@ -115,6 +115,8 @@ SYMBOLS = [
     ("zkw_precompile_closed_forms", _int, [_vp, _vp, _vp, _vp]),
     ("zkw_keccak_round_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_sha256_round_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_code_decommitter_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_code_decommitter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_sha256_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_linear_hasher_synthesize", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
     ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
@@ -433,7 +435,7 @@ DECOMMITTER_INSTANCE = np.dtype(
      ("memory_queue_initial_state", QUEUE_STATE12), ("memory_queue_final_state", QUEUE_STATE12),
      ("hidden_fsm_input", DECOMMITTER_FSM), ("hidden_fsm_output", DECOMMITTER_FSM), ("first_round", "<u8"),
      ("num_rounds", "<u8"), ("first_request", "<u8"), ("num_requests", "<u8"), ("first_word", "<u8"), ("num_words", "<u8")])
-DCM_MEM_QUERIES, DCM_MEM_ENC, DCM_MEM_TAILS, DCM_ROUND_STATES, DCM_INSTANCES = range(5)
+DCM_MEM_QUERIES, DCM_MEM_ENC, DCM_MEM_TAILS, DCM_ROUND_STATES, DCM_INSTANCES, DCM_SHA256_ROUNDS = range(6)
 PRECOMPILE_KECCAK256, PRECOMPILE_SHA256, PRECOMPILE_ECRECOVER = range(3)
 PRECOMPILE_FSM = np.dtype(
     [("log_queue_state", QUEUE_STATE4), ("memory_queue_state", QUEUE_STATE12), ("read_precompile_call", "u1"),
@@ -554,7 +556,8 @@ class PrecompileWitness:
 class DecommitterWitness:
     """Owner of a zkw_decommitter_witness handle."""
 
-    _DTYPES = {DCM_MEM_QUERIES: MEM_QUERY, DCM_INSTANCES: DECOMMITTER_INSTANCE, DCM_ROUND_STATES: np.dtype("<u4")}
+    _DTYPES = {DCM_MEM_QUERIES: MEM_QUERY, DCM_INSTANCES: DECOMMITTER_INSTANCE, DCM_ROUND_STATES: np.dtype("<u4"),
+               DCM_SHA256_ROUNDS: SHA256_ROUND_RECORD}
     _SHAPES = {DCM_MEM_ENC: (-1, 8), DCM_MEM_TAILS: (-1, 12), DCM_ROUND_STATES: (-1, 8)}
 
     def __init__(self, ctx):
@@ -1157,6 +1160,25 @@ def _ctx_check_if_satisfied_sha256_round_function(self, trace, slot, capacity):
     return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
+DC_COLS = 150  # include/zkw_code_decommitter_circuit_spec.h
+
+
+def _ctx_synthesize_code_decommitter(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+    """ZkSyncBaseLayerCircuit::CodeDecommitter synthesis ("zkw trace v3": the SHA-256 netlist at 18 lookups per row) for
+    instances of a DecommitterWitness (the trace needs DC_COLS = 150 columns and at least 65 536 rows)."""
+    n = witness.num_instances - first_instance if n_instances is None else n_instances
+    _check(load().zkw_code_decommitter_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+
+def _ctx_check_if_satisfied_code_decommitter(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_code_decommitter_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.synthesize_code_decommitter = _ctx_synthesize_code_decommitter
+Context.check_if_satisfied_code_decommitter = _ctx_check_if_satisfied_code_decommitter
 Context.synthesize_sha256_round_function = _ctx_synthesize_sha256_round_function
 Context.check_if_satisfied_sha256_round_function = _ctx_check_if_satisfied_sha256_round_function
 Context.synthesize_linear_hasher = _ctx_synthesize_linear_hasher

@@ -383,7 +383,8 @@ enum {
     ZKW_DCM_MEM_ENC = 1,      /* uint64_t[total_words][8]       */
     ZKW_DCM_MEM_TAILS = 2,    /* uint64_t[total_words][12]      */
     ZKW_DCM_ROUND_STATES = 3, /* uint32_t[total_rounds][8]: SHA-256 state after every round */
-    ZKW_DCM_INSTANCES = 4     /* zkw_decommitter_instance[ceil(total_rounds/capacity)] */
+    ZKW_DCM_INSTANCES = 4,    /* zkw_decommitter_instance[ceil(total_rounds/capacity)] */
+    ZKW_DCM_SHA256_ROUNDS = 5 /* zkw_sha256_round_record[total_rounds]: the cycles of the type-3 circuit */
 };
 size_t zkw_decommitter_witness_num_instances(const zkw_decommitter_witness *w);
 size_t zkw_decommitter_witness_bytes(const zkw_decommitter_witness *w, int what);
@@ -542,6 +543,18 @@ int zkw_sha256_round_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t 
                                 zkw_trace *t, size_t first_slot);
 int zkw_sha256_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                                      uint64_t *n_violations, uint64_t *first_bad);
+
+/* ---- CodeDecommitter circuit (type 3) ----------------------------------------------------------------------
+   ZkSyncBaseLayerCircuit::synthesis for the code decommitter (wrapper geometry: circuit_definitions/src/circuit_definitions/
+   base_layer/code_decommitter.rs:28-39: 2^20 rows, capacity 2845 SHA-256 rounds). Trace "zkw trace v3",
+   include/zkw_code_decommitter_circuit_spec.h: the SHA-256 netlist of the type-6 trace at 18 lookups per row (150 columns,
+   366 rows per cycle: up to 2864 cycles in 2^20 rows); one cycle per round of the unpacked bytecodes (ZKW_DCM_SHA256_ROUNDS:
+   block as hashed incl. the final padding, reset at a bytecode's first round, state after), idle beyond the instance's
+   rounds. w: the witness of zkw_decommitter_build. n_rows >= 65 536. */
+int zkw_code_decommitter_synthesize(zkw_ctx *ctx, zkw_decommitter_witness *w, size_t first_instance, size_t n_instances,
+                                    zkw_trace *t, size_t first_slot);
+int zkw_code_decommitter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
+                                         uint64_t *n_violations, uint64_t *first_bad);
 
 /* ---- LinearHasher circuit (type 13) ---------------------------------------------------------------------
    ZkSyncBaseLayerCircuit::synthesis for the L1-messages hasher (wrapper base_layer/linear_hasher.rs:28-138, witness

@@ -41,6 +41,9 @@ static void qs12(zkw_queue_state12 *s, const uint64_t *head, const uint64_t *tai
     s->length = len;
 }
 
+/* may be NULL (set before orc_decommitter_build; test infrastructure, single-threaded use): one record per SHA-256 round */
+static zkw_sha256_round_record *g_dcm_sha_rounds = NULL;
+void orc_decommitter_set_sha256_rounds(zkw_sha256_round_record *r) { g_dcm_sha_rounds = r; }
 int64_t orc_decommitter_build(const zkw_decommit_query *requests, const uint64_t *dedup_tails, size_t n_requests,
                               const uint32_t *words, const uint64_t *word_offsets, uint32_t capacity,
                               const zkw_queue_state12 *mem_in, zkw_mem_query *mem_q, uint64_t *mem_enc,
@@ -125,6 +128,13 @@ int64_t orc_decommitter_build(const zkw_decommit_query *requests, const uint64_t
             }
             orc_sha256_compress(sha, block);
             memcpy(round_states + 8 * round_g, sha, 32);
+            if (g_dcm_sha_rounds) { /* the cycle of the CodeDecommitter circuit */
+                zkw_sha256_round_record *rec = g_dcm_sha_rounds + round_g;
+                memset(rec, 0, sizeof *rec);
+                memcpy(rec->block, block, 64);
+                rec->reset = (size_t)fsm.num_rounds_left + 1 == ((size_t)(requests[req].hash[7] & 0xFFFF) + 1) / 2;
+                memcpy(rec->state_after, sha, 32);
+            }
             round_g++;
             if (rounds_left == 0) {
                 for (int j = 1; j < 8; j++)

@@ -250,6 +250,11 @@ void orc_precompile_set_sha256_rounds(zkw_sha256_round_record *r);
 int orc_sha256_round_synthesize(const uint8_t state_in[32], const zkw_sha256_round_record *rounds, uint32_t n_active,
                                 uint32_t capacity, const uint64_t pi[4], size_t n_rows, uint64_t *trace);
 uint64_t orc_sha256_round_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+/* ---- CodeDecommitter circuit (include/zkw_code_decommitter_circuit_spec.h), code_decommitter_circuit.c (generated) */
+void orc_decommitter_set_sha256_rounds(zkw_sha256_round_record *r);
+int orc_code_decommitter_round_synthesize(const uint8_t state_in[32], const zkw_sha256_round_record *rounds, uint32_t n_active,
+                                          uint32_t capacity, const uint64_t pi[4], size_t n_rows, uint64_t *trace);
+uint64_t orc_code_decommitter_round_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 size_t orc_linear_hasher_rounds(const zkw_log_query *q, size_t n, zkw_keccak_round_record *records);
 
 /* ---- callstack (a3 / a6), see callstack.c */

@@ -480,10 +480,13 @@ def decommitter_build(requests, dedup_tails, words, word_offsets, capacity, mem_
     o = dict(mem_q=np.zeros(total_words, MEM_QUERY), mem_enc=np.zeros((total_words, 8), np.uint64),
              mem_tails=np.zeros((total_words, 12), np.uint64), round_states=np.zeros((total_rounds, 8), np.uint32),
              instances=np.zeros(n_inst, DECOMMITTER_INSTANCE))
+    o["sha256_rounds"] = np.zeros(total_rounds, SHA256_ROUND_RECORD)  # the cycles of the CodeDecommitter circuit
+    lib().orc_decommitter_set_sha256_rounds(_p(o["sha256_rounds"]))
     f = lib().orc_decommitter_build
     f.restype = C.c_int64
     rc = f(_p(requests), _p(dedup_tails), C.c_size_t(requests.size), _p(words), _p(woff), C.c_uint32(capacity), _p(mem_in),
            _p(o["mem_q"]), _p(o["mem_enc"]), _p(o["mem_tails"]), _p(o["round_states"]), _p(o["instances"]))
+    lib().orc_decommitter_set_sha256_rounds(None)
     if rc < 0:
         raise RuntimeError(f"orc_decommitter_build failed: {rc}")
     o["instances"] = o["instances"][:rc]
@@ -635,6 +638,37 @@ def sha256_round_synthesize(build_out, instance_index, capacity, n_rows, public_
                 else np.zeros(32, np.uint8))
     pi = (public_input if public_input is not None else closed_form_public_inputs(6, build_out["instances"])[1][instance_index])
     return sha256_round_synthesize_raw(state_in, build_out["sha256_rounds"][first:first + n], capacity, n_rows, pi)
+
+
+DC_COLS, DC_ROWS_PER_CYCLE = 150, 366
+
+
+def code_decommitter_synthesize(build_out, instance_index, capacity, n_rows, public_input=None):
+    """Fill the CodeDecommitter trace (the SHA-256 netlist at 18 lookups per row) of one instance of decommitter_build(...)"""
+    inst = build_out["instances"][instance_index]
+    first, n = int(inst["first_round"]), int(inst["num_rounds"])
+    recs = np.ascontiguousarray(build_out["sha256_rounds"][first:first + n])
+    state_in = (np.ascontiguousarray(build_out["sha256_rounds"][first - 1]["state_after"]).view(np.uint8) if first
+                else np.zeros(32, np.uint8))
+    pi = np.ascontiguousarray(public_input if public_input is not None else
+                              closed_form_public_inputs(3, build_out["instances"])[1][instance_index], dtype=np.uint64)
+    trace = np.zeros((DC_COLS, n_rows), np.uint64)
+    f = lib().orc_code_decommitter_round_synthesize
+    f.restype = C.c_int
+    rc = f(_p(np.ascontiguousarray(state_in)), _p(recs) if n else None, C.c_uint32(n), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_code_decommitter_round_synthesize failed: {rc}")
+    return trace
+
+
+def code_decommitter_check(trace, capacity):
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_code_decommitter_round_check
+    f.restype = C.c_uint64
+    bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value
+    return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
 def sha256_round_check(trace, capacity):

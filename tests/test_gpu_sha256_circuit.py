@@ -110,3 +110,36 @@ def test_production_geometry(ctx, oracle):
     assert out.tobytes() == o["sha256_rounds"]["state_after"][first + n - 1].astype("<u4").tobytes()
     t.free()
     w.free()
+
+
+@pytest.mark.parametrize("capacity,n_rows", [(7, 1 << 16), (2845, 1 << 20)])
+def test_code_decommitter_circuit(ctx, oracle, capacity, n_rows):
+    """type 3 (CodeDecommitter): round records and traces cell-exact against the oracle, satisfied; the reference's capacity
+    (2845 rounds in 2^20 rows) included"""
+    from era_zkevm_test_harness_amd import block as blk, native
+
+    big = capacity > 100
+    b = synthetic.block_production(seed=3) if big else synthetic.block_after_vm(seed=2)
+    dec = ctx.compute_decommitts_sorter_circuit_snapshots(b["decommit_queries"], 117500 if big else 5)
+    dq, dt = dec.get(native.DEC_DEDUP_QUERIES), dec.get(native.DEC_DEDUP_TAILS)
+    codes = [b["bytecodes"][h.tobytes()] for h in dq["hash"]]
+    woff = np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]).astype(np.uint64)
+    words = np.concatenate(codes)
+    mem_in = np.zeros(1, native.QUEUE_STATE12)
+    w = ctx.compute_decommitter_circuit_snapshots(dq, dt, words, woff, capacity, mem_in)
+    o = oracle.decommitter_build(dq, dt, words, woff, capacity, mem_in)
+    assert w.get(native.DCM_SHA256_ROUNDS).tobytes() == o["sha256_rounds"].tobytes()
+    ni = w.num_instances
+    assert ni == o["instances"].size and (ni >= 3 or big)
+    t = native.Trace(ctx, n_rows, 1, n_cols=native.DC_COLS)
+    for i in sorted({0, ni - 1}):
+        ctx.synthesize_code_decommitter(w, t, i, 1, 0)
+        assert ctx.check_if_satisfied_code_decommitter(t, 0, capacity) == (0, (0, 0, 0)), i
+        exp = oracle.code_decommitter_synthesize(o, i, capacity, n_rows)
+        got = t.get(0)
+        if not np.array_equal(got, exp):
+            c, r = np.argwhere(got != exp)[0]
+            raise AssertionError(f"instance {i}: first difference at column {c} row {r}: {got[c, r]} != {exp[c, r]}")
+    t.free()
+    w.free()
+    dec.free()

@@ -75,3 +75,34 @@ def test_trace_satisfies_and_tampering_is_caught(oracle, built):
         bad[col, row] = val[0] if val else bad[col, row] + 1
         n, first = oracle.sha256_round_check(bad, CAP)
         assert n > 0 and first[0] == kind, (what, n, first)
+
+
+def test_code_decommitter_circuit(oracle):
+    """type 3: the same netlist at 18 lookups per row over the rounds of the unpacked bytecodes (padding block included):
+    satisfied, the last round of every bytecode ends in its SHA-256 digest, tampering is caught"""
+    from oracle import block as ob
+
+    b = synthetic.block_after_vm(seed=2)
+    cap = 7
+    a = ob.create_artifacts_after_vm(b, {ob.CODE_DECOMMITTER: cap})
+    w = a["witnesses"]["code_decommitter"]
+    recs = w["sha256_rounds"]
+    starts = np.flatnonzero(recs["reset"])
+    assert starts.size == a["witnesses"]["decommits_sorter"]["dedup_q"].size
+    for s, e in zip(starts, np.append(starts[1:], recs.size)):
+        blocks = recs["block"][s:e].tobytes()  # bytecode words big-endian, then 0x80 .. length: a padded SHA-256 message
+        bits = int.from_bytes(blocks[-4:], "big")
+        msg = blocks[:bits // 8]
+        assert recs["state_after"][e - 1].astype(">u4").tobytes() == hashlib.sha256(msg).digest()
+    ni = w["instances"].size
+    assert ni >= 3
+    for i in (0, ni - 1):
+        t = oracle.code_decommitter_synthesize(w, i, cap, N_ROWS)
+        assert t.shape[0] == oracle.DC_COLS and oracle.code_decommitter_check(t, cap) == (0, (0, 0, 0))
+    t = oracle.code_decommitter_synthesize(w, 1, cap, N_ROWS)
+    base = oracle.DC_ROWS_PER_CYCLE
+    for (col, row), kind in (((86 + 2, base + 30), 1), ((28, base + 5), 7), ((0, base), 3), ((140, 5), 5)):
+        bad = t.copy()
+        bad[col, row] += 2
+        n, first = oracle.code_decommitter_check(bad, cap)
+        assert n > 0 and first[0] == kind, ((col, row), n, first)

@@ -14,6 +14,7 @@ GENERATORS = {"gen_ram_circuit.py": "zkw_ram_circuit_spec.h", "gen_decommit_sort
               "gen_events_sorter_circuit.py": "zkw_events_sorter_circuit_spec.h", "gen_log_demux_circuit.py": "zkw_log_demux_circuit_spec.h",
               "gen_storage_sorter_circuit.py": "zkw_storage_sorter_circuit_spec.h", "gen_keccak_circuit.py": "zkw_keccak_circuit_spec.h",
               "gen_sha256_circuit.py": "zkw_sha256_circuit_spec.h"}
+DERIVED = ("oracle/code_decommitter_circuit.c", "era_zkevm_test_harness_amd/csrc/code_decommitter_circuit_kernels.cuh")
 
 
 @pytest.mark.parametrize("gen,header", sorted(GENERATORS.items()))
@@ -25,3 +26,19 @@ def test_generated_header_is_current(gen, header, tmp_path):
     assert r.returncode == 0, r.stderr[-1500:]
     got = (tmp_path / "include" / header).read_bytes()
     assert got == open(os.path.join(ROOT, "include", header), "rb").read(), f"{header} is stale: run python tools/{gen}"
+
+
+def test_code_decommitter_headers_and_derived_sources_are_current(tmp_path):
+    """gen_sha256_circuit.py also emits the 18-lookups-per-row spec of the CodeDecommitter; its oracle and kernels are
+    renamed copies of the SHA-256 ones (tools/gen_code_decommitter_sources.py)"""
+    tools = tmp_path / "tools"
+    (tmp_path / "include").mkdir()
+    shutil.copytree(os.path.join(ROOT, "tools"), tools, ignore=shutil.ignore_patterns("__pycache__", "probe_*", "p2_*", "ubench_*", "*.hip"))
+    for rel in ("oracle/sha256_circuit.c", "era_zkevm_test_harness_amd/csrc/sha256_circuit_kernels.cuh"):
+        os.makedirs(tmp_path / os.path.dirname(rel), exist_ok=True)
+        shutil.copy(os.path.join(ROOT, rel), tmp_path / rel)
+    for script in ("gen_sha256_circuit.py", "gen_code_decommitter_sources.py"):
+        r = subprocess.run([sys.executable, str(tools / script)], capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-1500:]
+    for rel in ("include/zkw_code_decommitter_circuit_spec.h",) + DERIVED:
+        assert (tmp_path / rel).read_bytes() == open(os.path.join(ROOT, rel), "rb").read(), f"{rel} is stale"

@@ -154,7 +154,7 @@ def build_cycle():
 
 
 def finalize(nl, out):
-    """group the lookups by table, pad to rows of 14, encode references"""
+    """group the lookups by table, pad to rows of LOOKUPS_PER_ROW, encode references"""
     order = sorted(range(len(nl.ops)), key=lambda j: nl.ops[j][0])
     new_index, placed = {}, []
     for j in order:
@@ -271,7 +271,9 @@ def sha_compress(state, block):
     return [(x + y) & 0xFFFFFFFF for x, y in zip(state, [a, b, c, d, e, f, g, h])]
 
 
-def main():
+def emit(prefix, lookups_per_row, header, title):
+    global LOOKUPS_PER_ROW
+    LOOKUPS_PER_ROW = lookups_per_row
     nl, out = build_cycle()
     ops, gates, out = finalize(nl, out)
     order, starts, n_levels = topo_order(ops, gates)
@@ -294,14 +296,18 @@ def main():
     rows_per_cycle = 1 + max(lookup_rows, gate_rows)
     max_operands = max(len(o) for o, _ in gates)
     o = []
-    w = o.append
-    w("/* GENERATED by tools/gen_sha256_circuit.py — do not edit. Layout contract of the Sha256RoundFunction trace emitted by")
-    w(" * zkw_sha256_round_synthesize (\"zkw trace v3\": one netlist per cycle, byte lookups + 32-bit ADD gates). See the generator. */")
-    w("#ifndef ZKW_SHA256_CIRCUIT_SPEC_H\n#define ZKW_SHA256_CIRCUIT_SPEC_H\n#include <stdint.h>")
+
+    def w(line):
+        o.append(line.replace("SC_", prefix + "_").replace("sc_op", prefix.lower() + "_op").replace("sc_gate", prefix.lower() + "_gate"))
+
+    for t in title:
+        o.append(t)
+    guard = f"ZKW_{header.upper().replace('.', '_').replace('ZKW_', '')}"
+    o.append(f"#ifndef {guard}\n#define {guard}\n#include <stdint.h>")
     w(f"#define SC_G {G}\n#define SC_LOOKUPS_PER_ROW {LOOKUPS_PER_ROW}\n#define SC_LOOKUP_COL0 {G}\n#define SC_NUM_TABLES {N_TABLES}")
     w(f"#define SC_MULT_COL0 {G + 3 * LOOKUPS_PER_ROW}\n#define SC_COLS {G + 3 * LOOKUPS_PER_ROW + N_TABLES}\n#define SC_TABLE_ROWS 65536")
     w("#define SC_T_XOR 1\n#define SC_T_ANDN 2\n#define SC_T_ROT(s) (2 + (s))\n#define SC_T_AND 10")
-    w(f"#define SC_NUM_OPS {len(ops)}      /* lookups of a cycle, grouped by table, padded to rows; lookup j: row 1 + j / 14, slot j % 14 */")
+    w(f"#define SC_NUM_OPS {len(ops)}      /* lookups of a cycle, grouped by table, padded to rows; lookup j: row 1 + j / {LOOKUPS_PER_ROW}, slot j % {LOOKUPS_PER_ROW} */")
     w(f"#define SC_NUM_GATES {len(gates)}   /* ADD gates; gate g: row 1 + g / 2, columns (g % 2) * SC_GATE_COLS .. */")
     w(f"#define SC_GATE_COLS {GATE_COLS}   /* operand o byte b at 4 * o + b, out byte b at SC_GATE_OUT + b, carry at SC_GATE_CARRY */")
     w(f"#define SC_GATE_MAX_OPERANDS {max_operands}\n#define SC_GATE_OUT {4 * max_operands}\n#define SC_GATE_CARRY {4 * max_operands + 4}")
@@ -316,25 +322,36 @@ def main():
     w("typedef struct { uint32_t n_operands, constant; uint16_t in[SC_GATE_MAX_OPERANDS][4]; } sc_gate;")
     w("#define SC_OPS_INIT { \\")
     for t, a, b in ops:
-        w(f"  {{{t}, {a}, {b}}}, \\")
-    w("}")
+        o.append(f"  {{{t}, {a}, {b}}}, \\")
+    o.append("}")
     w("#define SC_GATES_INIT { \\")
     for operands, k in gates:
         rows = [("{" + ", ".join(str(r) for r in wd) + "}") for wd in operands] + ["{0, 0, 0, 0}"] * (max_operands - len(operands))
-        w(f"  {{{len(operands)}, 0x{k:08X}u, {{{', '.join(rows)}}}}}, \\")
-    w("}")
+        o.append(f"  {{{len(operands)}, 0x{k:08X}u, {{{', '.join(rows)}}}}}, \\")
+    o.append("}")
     w("/* byte k of the cycle's output state = this reference (a lookup output) */")
     w("#define SC_OUT_INIT {" + ", ".join(str(r) for r in out) + "}")
     w(f"#define SC_NUM_LEVELS {n_levels}")
     w("/* items (lookup j, or SC_REF_GATE + g) in dependency order; level l = [SC_LEVEL_START[l], SC_LEVEL_START[l + 1]) */")
     w("#define SC_EVAL_ORDER_INIT {" + ", ".join(str(it) for it in order) + "}")
     w("#define SC_LEVEL_START_INIT {" + ", ".join(str(v) for v in starts) + "}")
-    w("#endif")
+    o.append("#endif")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "include", "zkw_sha256_circuit_spec.h")
+    path = os.path.join(root, "include", header)
     open(path, "w").write("\n".join(o) + "\n")
-    print(f"{len(ops)} lookups ({lookup_rows} rows), {len(gates)} gates ({gate_rows} rows), {n_levels} levels, {rows_per_cycle} rows per cycle -> "
-          f"capacity up to {((1 << 20) - 3) // rows_per_cycle} in 2^20 rows; {path}")
+    print(f"{prefix}: {len(ops)} lookups ({lookup_rows} rows of {LOOKUPS_PER_ROW}), {len(gates)} gates ({gate_rows} rows), {n_levels} levels, "
+          f"{rows_per_cycle} rows per cycle -> capacity up to {((1 << 20) - 3) // rows_per_cycle} in 2^20 rows; {path}")
+
+
+def main():
+    emit("SC", 14, "zkw_sha256_circuit_spec.h",
+         ("/* GENERATED by tools/gen_sha256_circuit.py — do not edit. Layout contract of the Sha256RoundFunction trace emitted by",
+          " * zkw_sha256_round_synthesize (\"zkw trace v3\": one netlist per cycle, byte lookups + 32-bit ADD gates). See the generator. */"))
+    # CodeDecommitter (type 3): the same compression at 2845 cycles per trace (geometry_config.rs) = 368 rows per cycle: 18
+    # lookups per row (54 lookup columns; the reference wrapper has 44, base_layer/code_decommitter.rs:28-39) -> 365 rows
+    emit("DC", 18, "zkw_code_decommitter_circuit_spec.h",
+         ("/* GENERATED by tools/gen_sha256_circuit.py — do not edit. Layout contract of the CodeDecommitter trace emitted by",
+          " * zkw_code_decommitter_synthesize (\"zkw trace v3\": the SHA-256 netlist of zkw_sha256_circuit_spec.h at 18 lookups per row). */"))
 
 
 if __name__ == "__main__":
