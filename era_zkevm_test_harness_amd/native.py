@@ -1487,7 +1487,7 @@ class Block:
     def gather_closed_form_inputs(self, comm, rank=0, world=1, root=0):
         """the multi-GPU path's one collective: records [n][24] = [circuit type, instance, compact form (18), public input (4)]
         in emission order on the root, None elsewhere"""
-        total = sum(self.num_instances(t) for t in (4, 8, 2, 5, 6, 9, 11, 12, 13))  # the synthesized types, zkw_block.hip kOrder
+        total = sum(self.num_instances(t) for t in (4, 8, 2, 3, 5, 6, 9, 11, 12, 13))  # the synthesized types, zkw_block.hip kOrder
         out = np.zeros((total, 24), np.uint64)
         n = C.c_size_t(0)
         _check(load().zkw_block_gather_closed_form_inputs(self.handle, comm.handle, rank, world, root, _np_ptr(out), total, C.byref(n)))
@@ -1496,7 +1496,8 @@ class Block:
 
     CHECKERS = {8: "zkw_ram_check_satisfied", 2: "zkw_decommit_sorter_check_satisfied", 4: "zkw_log_demux_check_satisfied",
                 9: "zkw_storage_sorter_check_satisfied", 11: "zkw_events_sorter_check_satisfied", 12: "zkw_events_sorter_check_satisfied",
-                5: "zkw_keccak_round_check_satisfied", 13: "zkw_keccak_round_check_satisfied", 6: "zkw_sha256_round_check_satisfied"}
+                5: "zkw_keccak_round_check_satisfied", 13: "zkw_keccak_round_check_satisfied", 6: "zkw_sha256_round_check_satisfied",
+                3: "zkw_code_decommitter_check_satisfied"}
 
     def check_satisfied(self, circuit_type, trace_handle, slot):
         """check_if_satisfied (src/tests/mod.rs:130-259) on a slot handed to a synthesize callback: (n_violations, first_bad)"""
