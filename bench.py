@@ -174,6 +174,58 @@ def full_blocks_batched(local_rank, blk, K=48, rounds=3):
     return best
 
 
+def hash_circuits_gpu(local_rank, blk):
+    """Synthesis rates of the netlist circuits at the reference's geometry — 2^20 rows, capacities of
+    geometry_config.rs — on synthetic precompile calls / the block's bytecodes: instances per second of 8 (4, 1) traces per
+    call, memset of the slots included. Not part of `value`."""
+    ctx = native.Context(local_rank)
+    n_rows = 1 << 20
+    out = {}
+
+    def timed(n, fn, reps=3):
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return {"circuits_per_s": n / best, "ms_per_call": best * 1e3, "instances_per_call": n}
+
+    mem_in = np.zeros(1, native.QUEUE_STATE12)
+    for name, kind, n_req, cap, cols, synth in (("keccak256_round_function", 0, 1400, 293, native.KC_COLS, ctx.synthesize_keccak_round_function),
+                                                ("sha256_round_function", 1, 6000, 2206, native.SC_COLS, ctx.synthesize_sha256_round_function)):
+        req, mq = synthetic.precompile_trace(kind, n_req, seed=5, max_rounds=6)
+        tails = ctx.queue_push_chain_log(ctx.encode_log_queries(req))[1]
+        w = ctx._precompile(kind, req, tails, mq, cap, mem_in)
+        n = min(8, w.num_instances)
+        t = native.Trace(ctx, n_rows, n, n_cols=cols)
+        out[name] = dict(timed(n, lambda: synth(w, t, 0, n, 0)), capacity=cap, columns=cols, trace_bytes=cols * n_rows * 8)
+        t.free()
+        w.free()
+    dec = ctx.compute_decommitts_sorter_circuit_snapshots(blk["decommit_queries"], 117500)
+    dq, dt_ = dec.get(native.DEC_DEDUP_QUERIES), dec.get(native.DEC_DEDUP_TAILS)
+    codes = [blk["bytecodes"][h.tobytes()] for h in dq["hash"]]
+    woff = np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]).astype(np.uint64)
+    w = ctx.compute_decommitter_circuit_snapshots(dq, dt_, np.concatenate(codes), woff, 2845, mem_in)
+    n = min(4, w.num_instances)
+    t = native.Trace(ctx, n_rows, n, n_cols=native.DC_COLS)
+    out["code_decommitter"] = dict(timed(n, lambda: ctx.synthesize_code_decommitter(w, t, 0, n, 0)), capacity=2845, columns=native.DC_COLS,
+                                   trace_bytes=native.DC_COLS * n_rows * 8)
+    t.free()
+    w.free()
+    dec.free()
+    q = synthetic.mixed_log_queue(4000, seed=3)[:700]
+    t = native.Trace(ctx, n_rows, 1, n_cols=native.KC_COLS)
+    out["linear_hasher"] = dict(timed(1, lambda: ctx.synthesize_linear_hasher(q, np.zeros(1, native.QUEUE_STATE4), 774, t, 0)), capacity=774,
+                                columns=native.KC_COLS, trace_bytes=native.KC_COLS * n_rows * 8,
+                                note="one instance per block; 3.6 ms of it is the serial sponge over the messages")
+    t.free()
+    ctx.close()
+    return out
+
+
 def full_block_cpu(blk, threads):
     """The oracle (oracle/block.py: the builders one after the other in the reference's order on one thread, the way
     create_artifacts_from_tracer runs them, then every instance synthesized on up to `threads` threads — synthesis of
@@ -221,6 +273,7 @@ def main():
     ap.add_argument("--stagger-ms", type=float, default=-1.0, help="start offset between pipelines (default 500 ms)")
     ap.add_argument("--cpu-sample", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hash-circuits", action="store_true", help="skip the synthesis-rate leg of the netlist circuits")
     ap.add_argument("--no-full-block", action="store_true", help="skip the full-block wall-time leg")
     args = ap.parse_args()
 
@@ -231,7 +284,7 @@ def main():
     n = args.queries
     B = args.blocks
     P = max(1, args.pipelines)
-    full_block = blk_inputs = None
+    full_block = blk_inputs = hash_circuits = None
     comm_ctx = native.Context(local_rank)
     comm = make_comm(comm_ctx, rank, world)
     gather_backend = "libzkw zkw_gather_closed_form_inputs (RCCL)" if comm is not None else "torch.distributed (RCCL)"
@@ -498,6 +551,17 @@ def main():
         }
         if full_block is not None:
             out["full_block"] = full_block
+            if not args.no_hash_circuits:
+                # AFTER the timed region and with the batch released: run before it, this leg costs the throughput leg 11 %
+                # (1604 against 1800 circuits/s, four runs each; what it leaves behind is not understood)
+                for w_ in ws:
+                    w_.free()
+                for r_ in rings:
+                    r_.free()
+                del q, records, compact, pis
+                torch.cuda.empty_cache()
+                native.trim_caches()
+                out["hash_circuits"] = hash_circuits_gpu(local_rank, blk_inputs)
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(base, args.cpu_sample)
             if full_block is not None:
