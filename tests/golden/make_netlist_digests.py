@@ -1,0 +1,57 @@
+"""Regenerates tests/golden/netlist_trace_digests.json: SHA-256 digests of small oracle-synthesized traces of the netlist
+circuits (types 5, 13, 6, 3) on fixed seeds. The traces do not depend on Poseidon2 except for the four public-input cells,
+which are zeroed here — so these digests pin the netlists, the layouts and the fills independently of the unpinned
+permutation. Run from the repository root:  python tests/golden/make_netlist_digests.py"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from era_zkevm_test_harness_amd import synthetic  # noqa: E402
+from oracle import pyoracle as o  # noqa: E402
+
+N_ROWS = 1 << 16
+ZERO_PI = np.zeros(4, np.uint64)
+
+
+def digest(trace):
+    return hashlib.sha256(np.ascontiguousarray(trace).tobytes()).hexdigest()
+
+
+def cases():
+    out = {}
+    for kind, name, cap, synth in ((0, "keccak256_round_function", 6, o.keccak_round_synthesize), (1, "sha256_round_function", 7, o.sha256_round_synthesize)):
+        req, mq = synthetic.precompile_trace(kind, 9, seed=3, max_rounds=4)
+        tails = o.queue_push_chain_log(o.encode_log_queries(req))[1]
+        w = o.precompile_build(kind, req, tails, mq, cap, np.zeros(1, o.QUEUE_STATE12))
+        for i in range(w["instances"].size):
+            out[f"{name}/capacity{cap}/instance{i}"] = digest(synth(w, i, cap, N_ROWS, public_input=ZERO_PI))
+    from oracle import block as ob
+    b = synthetic.block_after_vm(seed=2)
+    a = ob.create_artifacts_after_vm(b, {ob.CODE_DECOMMITTER: 7})
+    w = a["witnesses"]["code_decommitter"]
+    for i in range(w["instances"].size):
+        out[f"code_decommitter/capacity7/instance{i}"] = digest(o.code_decommitter_synthesize(w, i, 7, N_ROWS, public_input=ZERO_PI))
+    q = synthetic.mixed_log_queue(36, seed=8)[:7]
+    recs = np.zeros(q.size * 88 // 136 + 1, o.KECCAK_ROUND_RECORD)
+    f = o.lib().orc_linear_hasher_rounds
+    import ctypes as C
+    f.restype = C.c_size_t
+    n = f(o._p(q), C.c_size_t(q.size), o._p(recs))
+    tr = np.zeros((o.KC_COLS, N_ROWS), np.uint64)
+    g = o.lib().orc_keccak_round_synthesize
+    g.restype = C.c_int
+    assert g(o._p(np.zeros(200, np.uint8)), o._p(recs), C.c_uint32(n), C.c_uint32(o.linear_hasher_cycles(20)), o._p(ZERO_PI), C.c_size_t(N_ROWS), o._p(tr)) == 0
+    out["linear_hasher/capacity20/7messages"] = digest(tr)
+    return out
+
+
+if __name__ == "__main__":
+    o.build()
+    path = os.path.join(ROOT, "tests", "golden", "netlist_trace_digests.json")
+    json.dump(cases(), open(path, "w"), indent=1, sort_keys=True)
+    print(open(path).read())
