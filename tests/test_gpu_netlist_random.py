@@ -1,0 +1,81 @@
+"""GPU: randomized parity of the netlist circuits (types 5, 6, 3) against the oracle — request counts, round counts and
+capacities drawn so that instance boundaries fall on request boundaries, inside requests and on the last round, incl.
+capacity 1 and capacities larger than the whole block. Every instance: round records, trace cell for cell, both checkers."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+N_ROWS = 1 << 16
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from era_zkevm_test_harness_amd import native
+
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def _compare(ctx, native, t, i, got_fn, exp, check_gpu, check_orc, capacity):
+    got = t.get(0)
+    if not np.array_equal(got, exp):
+        c, r = np.argwhere(got != exp)[0]
+        raise AssertionError(f"instance {i}: first difference at column {c} row {r}: {got[c, r]} != {exp[c, r]}")
+    assert check_gpu(t, 0, capacity) == (0, (0, 0, 0)) and check_orc(exp, capacity)[0] == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_precompile_circuits_random(ctx, oracle, seed):
+    from era_zkevm_test_harness_amd import native
+
+    rng = np.random.default_rng(100 + seed)
+    for kind, cols, rounds_key, synth, check, osynth, ocheck, max_cap in (
+            (0, native.KC_COLS, "keccak_rounds", ctx.synthesize_keccak_round_function, ctx.check_if_satisfied_keccak_round_function,
+             oracle.keccak_round_synthesize, oracle.keccak_round_check, 30),
+            (1, native.SC_COLS, "sha256_rounds", ctx.synthesize_sha256_round_function, ctx.check_if_satisfied_sha256_round_function,
+             oracle.sha256_round_synthesize, oracle.sha256_round_check, 120)):
+        n_req = int(rng.integers(1, 9))
+        req, mq = synthetic.precompile_trace(kind, n_req, seed=int(rng.integers(1 << 30)), max_rounds=int(rng.integers(1, 7)))
+        tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+        mem_in = np.zeros(1, native.QUEUE_STATE12)
+        total = int(oracle.precompile_build(kind, req, tails, mq, 1 << 20, mem_in)["instances"]["num_rounds"].sum())
+        capacity = int(rng.choice([1, max(1, total // 2), total, total + 3, int(rng.integers(1, max_cap))]))
+        o = oracle.precompile_build(kind, req, tails, mq, capacity, mem_in)
+        w = ctx._precompile(kind, req, tails, mq, capacity, mem_in)
+        assert w.get(native.PRC_KECCAK_ROUNDS if kind == 0 else native.PRC_SHA256_ROUNDS).tobytes() == o[rounds_key].tobytes()
+        t = native.Trace(ctx, N_ROWS, 1, n_cols=cols)
+        for i in sorted({0, w.num_instances // 2, w.num_instances - 1}):
+            synth(w, t, i, 1, 0)
+            _compare(ctx, native, t, i, None, osynth(o, i, capacity, N_ROWS), check, ocheck, capacity)
+        t.free()
+        w.free()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_code_decommitter_random(ctx, oracle, seed):
+    from era_zkevm_test_harness_amd import native
+
+    rng = np.random.default_rng(200 + seed)
+    b = synthetic.block_after_vm(seed=30 + seed, max_code_words=int(rng.integers(3, 40)))
+    dec = ctx.compute_decommitts_sorter_circuit_snapshots(b["decommit_queries"], 5)
+    dq, dt = dec.get(native.DEC_DEDUP_QUERIES), dec.get(native.DEC_DEDUP_TAILS)
+    codes = [b["bytecodes"][h.tobytes()] for h in dq["hash"]]
+    woff = np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]).astype(np.uint64)
+    words = np.concatenate(codes)
+    total = sum((c.shape[0] + 1) // 2 for c in codes)
+    capacity = int(rng.choice([1, total // 3 + 1, total, total + 2]))
+    mem_in = np.zeros(1, native.QUEUE_STATE12)
+    w = ctx.compute_decommitter_circuit_snapshots(dq, dt, words, woff, capacity, mem_in)
+    o = oracle.decommitter_build(dq, dt, words, woff, capacity, mem_in)
+    assert w.get(native.DCM_SHA256_ROUNDS).tobytes() == o["sha256_rounds"].tobytes()
+    t = native.Trace(ctx, N_ROWS, 1, n_cols=native.DC_COLS)
+    for i in sorted({0, w.num_instances // 2, w.num_instances - 1}):
+        ctx.synthesize_code_decommitter(w, t, i, 1, 0)
+        _compare(ctx, native, t, i, None, oracle.code_decommitter_synthesize(o, i, capacity, N_ROWS), ctx.check_if_satisfied_code_decommitter,
+                 oracle.code_decommitter_check, capacity)
+    t.free()
+    w.free()
+    dec.free()
