@@ -453,6 +453,15 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
         case 4: out->num_columns = LD_COLS; out->rows_per_cycle = LD_ROWS_PER_CYCLE; out->region_stride = LD_REGION_STRIDE(capacity); boundary = LD_BOUNDARY_ROW(capacity); min_rows = LD_MIN_ROWS(capacity); pi_off = LD_ROWOFF_PI; break;
         case 9: out->num_columns = SS_COLS; out->rows_per_cycle = SS_ROWS_PER_CYCLE; out->region_stride = SS_REGION_STRIDE(capacity); boundary = SS_BOUNDARY_ROW(capacity); min_rows = SS_MIN_ROWS(capacity); pi_off = SS_ROWOFF_PI; break;
         case 11: case 12: out->num_columns = ES_COLS; out->rows_per_cycle = ES_ROWS_PER_CYCLE; out->region_stride = ES_REGION_STRIDE(capacity); boundary = ES_BOUNDARY_ROW(capacity); min_rows = ES_MIN_ROWS(capacity); pi_off = ES_ROWOFF_PI; break;
+        // the netlist circuits ("zkw trace v3") are cycle-major: region_stride = 0, cycle i starts at row i * rows_per_cycle
+        case 5: case 13: {
+            const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(capacity) : capacity;
+            out->num_columns = KC_COLS; out->rows_per_cycle = KC_ROWS_PER_CYCLE; boundary = KC_BOUNDARY_ROW(cycles);
+            min_rows = boundary + 2 * KC_BND_ROWS_PER_STATE + 1; pi_off = 2 * KC_BND_ROWS_PER_STATE;
+            break;
+        }
+        case 6: out->num_columns = SC_COLS; out->rows_per_cycle = SC_ROWS_PER_CYCLE; boundary = SC_BOUNDARY_ROW(capacity); min_rows = boundary + 3; pi_off = 2; break;
+        case 3: out->num_columns = DC_COLS; out->rows_per_cycle = DC_ROWS_PER_CYCLE; boundary = DC_BOUNDARY_ROW(capacity); min_rows = boundary + 3; pi_off = 2; break;
         default: return ZKW_OK;  // a known circuit type this library does not synthesize yet: synthesizable = 0
     }
     out->synthesizable = 1;

@@ -115,7 +115,7 @@ typedef struct zkw_circuit_layout {
     uint32_t num_columns;       /* copy-permutation + lookup + multiplicity columns of a trace slot */
     uint32_t rows_per_cycle;    /* row types repeated once per cycle, region-major */
     uint32_t _pad;
-    uint64_t region_stride;     /* rows between two regions (capacity rounded up to 64) */
+    uint64_t region_stride;     /* rows between two regions (capacity rounded up to 64); 0: cycle-major (the netlist circuits 3, 5, 6, 13) */
     uint64_t rows_used;         /* cycle regions + boundary rows */
     uint64_t nop_rows;          /* trace_len - rows_used: zero padding, the reference's nop_gates_to_add */
     uint64_t trace_len;         /* 2^20 */
