@@ -44,6 +44,10 @@ echo "== tools/probe_kc_synth.py (Keccak256RoundFunction, 2^20 rows, capacity 29
 timeout -s KILL 300 python tools/probe_kc_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
 echo "== tools/probe_sc_synth.py (Sha256RoundFunction, 2^20 rows, capacity 2206)" >> "$OUT/synthesis_probes.txt"
 timeout -s KILL 300 python tools/probe_sc_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
+for P in kc sc; do
+    rm -rf /tmp/pk_$P && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk_$P -- python tools/probe_${P}_synth.py > /dev/null 2>&1
+    cp "$(ls /tmp/pk_$P/*/*kernel_stats.csv | head -1)" "$OUT/netlist_${P}_kernel_stats.csv"
+done
 # 6. the hardware probes behind DESIGN.md 3.2
 (cd tools && for b in probe_wave_placement probe_clock_regime ubench_perm; do [ -x ./$b ] && { echo "== $b"; timeout -s KILL 300 ./$b; }; done) > "$OUT/hardware_probes.txt" 2>&1
 (cd tools && for b in probe_hw_queues2; do [ -x ./$b ] && { echo "== $b (default environment)"; timeout -s KILL 120 ./$b; echo "== $b (GPU_MAX_HW_QUEUES=8)"; GPU_MAX_HW_QUEUES=8 timeout -s KILL 120 ./$b; }; done) > "$OUT/hw_queue_probes.txt" 2>&1
