@@ -149,6 +149,8 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
 
 
 def full_blocks_batched(local_rank, blk, K=48, rounds=3):
+    from concurrent.futures import ThreadPoolExecutor
+
     """Throughput of WHOLE blocks: K production-capacity blocks in flight at once through zkw_blocks_run (one host thread
     per block; the chain service merges every block's Poseidon2 queue chains into a few shared launches, so K blocks cost
     about two chain passes instead of K), then every synthesizable instance of every block into its trace, then the blocks
@@ -161,7 +163,8 @@ def full_blocks_batched(local_rank, blk, K=48, rounds=3):
         t0 = time.perf_counter()
         bs = native.Block.run_many(local_rank, blocks)
         t1 = time.perf_counter()
-        n = sum(b.synthesize(1 << 20, ring_slots=1) for b in bs)
+        with ThreadPoolExecutor(8) as ex:  # the blocks' synthesis calls side by side (they are short kernels and host waits)
+            n = sum(ex.map(lambda b: b.synthesize(1 << 20, ring_slots=1), bs))
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         for b in bs:

@@ -1,6 +1,7 @@
 """K production-capacity blocks in flight at once through zkw_blocks_run (one host thread per block, every queue chain of
 every block merged into a few launches by the chain service): throughput of whole blocks. Usage: probe_block_concurrency.py K [reps]"""
 import sys, time
+from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 sys.path.insert(0, '.')
 from era_zkevm_test_harness_amd import native as nv, synthetic
@@ -14,7 +15,8 @@ for r in range(reps):
     t0 = time.perf_counter()
     bs = nv.Block.run_many(0, blocks)
     t1 = time.perf_counter()
-    n = sum(b.synthesize(1 << 20, ring_slots=1) for b in bs)
+    with ThreadPoolExecutor(8) as ex:
+        n = sum(ex.map(lambda b: b.synthesize(1 << 20, ring_slots=1), bs))
     t2 = time.perf_counter()
     spans = {}
     for name, s, e in bs[0].timings():
