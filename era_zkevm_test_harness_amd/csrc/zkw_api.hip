@@ -475,6 +475,54 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
     return ZKW_OK;
 }
 
+// Setup side, selectors: which gate set applies to each row of a trace of this library's layout — what the
+// reference's setup keeps in its constant columns (gate selectors, the lookup table id of a row). Host arithmetic over the specs.
+//   queue circuits (2, 4, 8, 9, 11, 12; "zkw trace v2", region-major): selector = row type of the spec (0 .. NUM_ROW_TYPES - 1:
+//     the per-cycle row types, then the boundary rows), ZKW_ROW_PADDING elsewhere (gaps of a region, rows after the boundary)
+//   netlist circuits (3, 5, 6, 13; "zkw trace v3", cycle-major): selector = lookup table id of the row (0: none) |
+//     ZKW_ROW_HAS_GATES when ADD gates sit in its general-purpose columns | ZKW_ROW_HEADER for a cycle's first row;
+//     boundary rows ZKW_ROW_BOUNDARY + k; ZKW_ROW_PADDING elsewhere
+static const sc_op h_sc_ops[SC_NUM_OPS] = SC_OPS_INIT;
+static const dc_op h_dc_ops[DC_NUM_OPS] = DC_OPS_INIT;
+static const kc_op h_kc_ops[KC_OPS_PER_ROUND] = KC_ROUND_OPS_INIT;
+extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint8_t* out) {
+    if (!out || n_rows == 0) return fail(ZKW_ERR_INVALID, "zkw_setup_row_selectors: null argument");
+    zkw_circuit_layout lay;
+    ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
+    if (!lay.synthesizable) return fail(ZKW_ERR_INVALID, "circuit type %u has no layout in this library", (unsigned)circuit_type);
+    if (lay.rows_used > n_rows) return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, %zu given", lay.capacity, (unsigned long long)lay.rows_used, n_rows);
+    memset(out, ZKW_ROW_PADDING, n_rows);
+    const uint32_t cap = lay.capacity;
+    if (lay.region_stride) {  // region-major
+        const uint64_t stride = lay.region_stride, rpc = lay.rows_per_cycle;
+        for (uint64_t r = 0; r < rpc; r++) memset(out + r * stride, (int)r, cap);
+        const uint64_t bnd = rpc * stride;
+        for (uint64_t k = 0; bnd + k < lay.rows_used; k++) out[bnd + k] = (uint8_t)(rpc + k);
+        return ZKW_OK;
+    }
+    const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
+    const uint64_t rpc = lay.rows_per_cycle;
+    for (uint32_t c = 0; c < cycles; c++) {
+        uint8_t* row = out + (uint64_t)c * rpc;
+        row[0] = ZKW_ROW_HEADER;
+        for (uint64_t r = 1; r < rpc; r++) {
+            if (circuit_type == 5 || circuit_type == 13) {
+                row[r] = r < KC_ROW_ABSORB0 ? KC_T_ANDN : r < KC_ROW_ROUND0 ? KC_T_XOR
+                       : r < KC_ROW_SEL_T0 ? (uint8_t)h_kc_ops[((r - KC_ROW_ROUND0) % KC_ROWS_PER_ROUND) * KC_LOOKUPS_PER_ROW].table
+                       : r < KC_ROW_SEL_O0 ? KC_T_ANDN : KC_T_XOR;
+            } else if (circuit_type == 6) {
+                row[r] = (uint8_t)((r - 1 < SC_NUM_OPS / SC_LOOKUPS_PER_ROW ? h_sc_ops[(r - 1) * SC_LOOKUPS_PER_ROW].table : 0) |
+                                   (r - 1 < (SC_NUM_GATES + 1) / 2 ? ZKW_ROW_HAS_GATES : 0));
+            } else {
+                row[r] = (uint8_t)((r - 1 < DC_NUM_OPS / DC_LOOKUPS_PER_ROW ? h_dc_ops[(r - 1) * DC_LOOKUPS_PER_ROW].table : 0) |
+                                   (r - 1 < (DC_NUM_GATES + 1) / 2 ? ZKW_ROW_HAS_GATES : 0));
+            }
+        }
+    }
+    for (uint64_t k = 0; (uint64_t)cycles * rpc + k < lay.rows_used; k++) out[(uint64_t)cycles * rpc + k] = (uint8_t)(ZKW_ROW_BOUNDARY + k);
+    return ZKW_OK;
+}
+
 extern "C" zkw_ctx* zkw_create(int device_id) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);

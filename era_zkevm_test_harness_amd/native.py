@@ -40,6 +40,7 @@ SYMBOLS = [
     ("zkw_stream_release", None, [_vp, _vp]),
     ("zkw_trim_caches", None, []),
     ("zkw_block_linear_hasher_instance", _int, [_vp, _vp]),
+    ("zkw_setup_row_selectors", _int, [C.c_uint8, C.c_uint32, _sz, _vp]),
     ("zkw_recursion_queue_split", _int, [_vp, _sz, C.c_uint32, _vp, _sz, _vp]),
     ("zkw_closed_form_public_inputs", _int, [_vp, C.c_uint8, _vp, C.c_size_t, _vp, _vp]),
     ("zkw_version", C.c_char_p, []),
@@ -1520,6 +1521,16 @@ class Block:
             self.free()
         except Exception:
             pass
+
+
+ROW_HAS_GATES, ROW_HEADER, ROW_BOUNDARY, ROW_PADDING = 0x40, 0x80, 0xC0, 0xFF
+
+
+def setup_row_selectors(circuit_type, capacity=0, n_rows=1 << 20):
+    """zkw_setup_row_selectors: the selector (row type / lookup table id) of every row of this library's layout; no GPU needed"""
+    out = np.zeros(n_rows, np.uint8)
+    _check(load().zkw_setup_row_selectors(circuit_type, capacity, n_rows, _np_ptr(out)))
+    return out
 
 
 def recursion_queue_split(states, arity=32):

@@ -123,6 +123,18 @@ typedef struct zkw_circuit_layout {
     uint64_t public_input_row[4];
 } zkw_circuit_layout;
 int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_layout *out);
+/* Setup side, selectors: out[r] (host, n_rows bytes) says which gate set applies to row r of a trace of this library's
+   layout — what the reference's setup keeps in its constant columns (gate selectors / the lookup table id of a row).
+   Queue circuits (2, 4, 8, 9, 11, 12): the row type of the type's spec header (0 .. NUM_ROW_TYPES - 1: the per-cycle row types
+   in region order, then the boundary rows). Netlist circuits (3, 5, 6, 13): the lookup table id of the row (0: none), |
+   ZKW_ROW_HAS_GATES where ADD gates sit in the general-purpose columns, ZKW_ROW_HEADER for a cycle's first row, boundary rows
+   ZKW_ROW_BOUNDARY + k. ZKW_ROW_PADDING: the row holds nothing (all cells zero). capacity 0 = the type's default.
+   No GPU needed. Copy-permutation (sigma) columns are not produced yet. */
+#define ZKW_ROW_HAS_GATES 0x40
+#define ZKW_ROW_HEADER 0x80
+#define ZKW_ROW_BOUNDARY 0xC0
+#define ZKW_ROW_PADDING 0xFF
+int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint8_t *out);
 
 /* ---- per-kernel timing -------------------------------------------------------------------------- */
 /* When enabled, every kernel launch (and library sort) of this context is bracketed by HIP events

@@ -1,0 +1,76 @@
+"""CPU (host arithmetic of libzkw): zkw_setup_row_selectors against oracle-synthesized traces — rows marked as padding hold
+nothing, the number of other rows is the layout's rows_used, and on the netlist circuits every row's lookups satisfy the
+table its selector names (the tables recomputed here in numpy)."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import native as nv, synthetic
+
+N_ROWS = 1 << 16
+
+
+def _table(t, a, b):
+    if t == 1:
+        return a ^ b
+    if t == 2:
+        return ~a & 0xFF & b
+    if t == 10:
+        return a & b
+    s = t - 2
+    return ((a << s) & 0xFF) | (b >> (8 - s))
+
+
+def _netlist_cases(oracle):
+    out = []
+    for kind, ctype, cap, synth, cols0, lpr in ((0, 5, 6, oracle.keccak_round_synthesize, 86, 14), (1, 6, 7, oracle.sha256_round_synthesize, 86, 14)):
+        req, mq = synthetic.precompile_trace(kind, 9, seed=3, max_rounds=4)
+        tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+        w = oracle.precompile_build(kind, req, tails, mq, cap, np.zeros(1, oracle.QUEUE_STATE12))
+        out.append((ctype, cap, synth(w, 1, cap, N_ROWS), cols0, lpr))
+    from oracle import block as ob
+    a = ob.create_artifacts_after_vm(synthetic.block_after_vm(seed=2), {ob.CODE_DECOMMITTER: 7})
+    out.append((3, 7, oracle.code_decommitter_synthesize(a["witnesses"]["code_decommitter"], 1, 7, N_ROWS), 86, 18))
+    q = synthetic.mixed_log_queue(36, seed=8)[:7]
+    out.append((13, 20, oracle.linear_hasher_synthesize(q, np.zeros(1, oracle.QUEUE_STATE4), 20, N_ROWS)[0], 86, 14))
+    return out
+
+
+def test_netlist_selectors_name_the_tables_of_their_rows(oracle):
+    for ctype, cap, trace, col0, lpr in _netlist_cases(oracle):
+        sel = nv.setup_row_selectors(ctype, cap, N_ROWS)
+        lay = nv.circuit_layout(ctype, cap)
+        assert int((sel != nv.ROW_PADDING).sum()) == int(lay["rows_used"])
+        body = trace[:col0 + 3 * lpr]
+        assert not body[:, sel == nv.ROW_PADDING].any(), ctype
+        hdr = sel == nv.ROW_HEADER
+        assert int(hdr.sum()) == (nv.linear_hasher_cycles(cap) if ctype == 13 else cap)
+        assert not body[col0:, hdr].any()
+        lookups = (sel < nv.ROW_HEADER) & ((sel & 0x3F) != 0)
+        for t in np.unique(sel[lookups] & 0x3F):
+            rows = np.flatnonzero(lookups & ((sel & 0x3F) == t))
+            a, b, c = (body[col0 + k::3][:lpr][:, rows].astype(np.int64) for k in range(3))
+            assert (a < 256).all() and (b < 256).all() and np.array_equal(c, _table(int(t), a, b)), (ctype, int(t))
+        gates = (sel < nv.ROW_HEADER) & ((sel & nv.ROW_HAS_GATES) != 0)
+        assert not body[:col0, (sel < nv.ROW_HEADER) & ~gates].any()          # no general-purpose cells where no gate sits
+        assert bool(gates.any()) == (ctype in (3, 6))
+
+
+def test_queue_circuit_selectors(oracle):
+    """RAMPermutation: region r of the trace is row type r for `capacity` rows, padding in the gap up to the 64-row stride"""
+    cap = 1000
+    sel = nv.setup_row_selectors(8, cap, 1 << 15)
+    lay = nv.circuit_layout(8, cap)
+    stride = int(lay["region_stride"])
+    assert stride == 1024 and int((sel != nv.ROW_PADDING).sum()) == 6 * cap + 3
+    for r in range(6):
+        assert (sel[r * stride:r * stride + cap] == r).all() and (sel[r * stride + cap:(r + 1) * stride] == nv.ROW_PADDING).all()
+    assert sel[6 * stride:6 * stride + 3].tolist() == [6, 7, 8]
+    q = synthetic.random_memory_queries(3 * cap, seed=5) if hasattr(synthetic, "random_memory_queries") else None
+    if q is not None:
+        w = oracle.ram_build_instances(q, cap, 0)
+        t = oracle.ram_synthesize(w, 1, cap, 1 << 15)
+        assert not t[:148, sel == nv.ROW_PADDING].any()
+    with pytest.raises(nv.ZkwError):
+        nv.setup_row_selectors(7)       # ECRecover: no layout
+    with pytest.raises(nv.ZkwError):
+        nv.setup_row_selectors(8, 136714, 1 << 19)  # does not fit
