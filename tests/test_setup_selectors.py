@@ -65,11 +65,10 @@ def test_queue_circuit_selectors(oracle):
     for r in range(6):
         assert (sel[r * stride:r * stride + cap] == r).all() and (sel[r * stride + cap:(r + 1) * stride] == nv.ROW_PADDING).all()
     assert sel[6 * stride:6 * stride + 3].tolist() == [6, 7, 8]
-    q = synthetic.random_memory_queries(3 * cap, seed=5) if hasattr(synthetic, "random_memory_queries") else None
-    if q is not None:
-        w = oracle.ram_build_instances(q, cap, 0)
-        t = oracle.ram_synthesize(w, 1, cap, 1 << 15)
-        assert not t[:148, sel == nv.ROW_PADDING].any()
+    w = oracle.ram_build_instances(synthetic.ram_trace(3 * cap - 17, seed=5), cap, 0)
+    for i in (0, 2):  # a full instance and the ragged last one
+        t = oracle.ram_synthesize(w, i, cap, 1 << 15)
+        assert not t[:148, sel == nv.ROW_PADDING].any() and t[:148, sel == 0].any()
     with pytest.raises(nv.ZkwError):
         nv.setup_row_selectors(7)       # ECRecover: no layout
     with pytest.raises(nv.ZkwError):
