@@ -523,6 +523,82 @@ extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, 
     return ZKW_OK;
 }
 
+// Setup side, copy permutation of the queue circuits: sigma[c][r] = the cell (c' * n_rows + r') that follows
+// cell (c, r) in its copy cycle; a cell under no copy constraint maps to itself. Built on the host from the spec's link table
+// (the same table the satisfiability checker walks, ram_circuit_kernels.cuh k_check_links) with a union-find over the
+// general-purpose cells; cycles run through their cells in increasing cell order. Seconds at production size (1.1 GB of output).
+namespace {
+struct LinkSpec { int G /* general-purpose + lookup columns: links reach both */, rows_per_cycle, num_links, off_bin, off_bout; const rc_link* links; };
+static const rc_link h_rc_links[RC_NUM_LINKS] = RC_LINKS_INIT;
+static const rc_link h_ds_links[DS_NUM_LINKS] = DS_LINKS_INIT;
+static const rc_link h_es_links[ES_NUM_LINKS] = ES_LINKS_INIT;
+static const rc_link h_ld_links[LD_NUM_LINKS] = LD_LINKS_INIT;
+static const rc_link h_ss_links[SS_NUM_LINKS] = SS_LINKS_INIT;
+bool link_spec_of(uint8_t t, LinkSpec* o) {
+    switch (t) {
+        case 8: *o = {RC_G + RC_L, RC_ROWS_PER_CYCLE, RC_NUM_LINKS, RC_ROWOFF_BND_IN, RC_ROWOFF_BND_OUT, h_rc_links}; return true;
+        case 2: *o = {DS_G + DS_L, DS_ROWS_PER_CYCLE, DS_NUM_LINKS, DS_ROWOFF_BND_IN, DS_ROWOFF_BND_OUT, h_ds_links}; return true;
+        case 11: case 12: *o = {ES_G + ES_L, ES_ROWS_PER_CYCLE, ES_NUM_LINKS, ES_ROWOFF_BND_IN, ES_ROWOFF_BND_OUT, h_es_links}; return true;
+        case 4: *o = {LD_G + LD_L, LD_ROWS_PER_CYCLE, LD_NUM_LINKS, LD_ROWOFF_BND_IN, LD_ROWOFF_BND_OUT, h_ld_links}; return true;
+        case 9: *o = {SS_G + SS_L, SS_ROWS_PER_CYCLE, SS_NUM_LINKS, SS_ROWOFF_BND_IN, SS_ROWOFF_BND_OUT, h_ss_links}; return true;
+        default: return false;
+    }
+}
+}  // namespace
+
+extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t* sigma, uint32_t* n_columns) {
+    LinkSpec sp;
+    if (!link_spec_of(circuit_type, &sp))
+        return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: circuit type %u (the netlist circuits' copy constraints are their operand references: "
+                                     "not produced as sigma columns yet)", (unsigned)circuit_type);
+    zkw_circuit_layout lay;
+    ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
+    if (n_columns) *n_columns = (uint32_t)sp.G;
+    if (!sigma) return ZKW_OK;  // size query
+    if (lay.rows_used > n_rows || n_rows >= (1ull << 32) / (size_t)sp.G)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, %zu given", lay.capacity, (unsigned long long)lay.rows_used, n_rows);
+    const uint32_t cap = lay.capacity;
+    const uint64_t rs = lay.region_stride, bnd = (uint64_t)sp.rows_per_cycle * rs;
+    const size_t n_cells = (size_t)sp.G * n_rows;
+    std::vector<uint32_t> parent(n_cells);
+    for (size_t i = 0; i < n_cells; i++) parent[i] = (uint32_t)i;
+    auto find = [&](uint32_t x) {
+        while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+        return x;
+    };
+    bool out_of_range = false;
+    auto unite = [&](uint64_t col_a, uint64_t row_a, uint64_t col_b, uint64_t row_b) {
+        if (col_a >= (uint64_t)sp.G || col_b >= (uint64_t)sp.G || row_a >= n_rows || row_b >= n_rows) { out_of_range = true; return; }
+        uint32_t a = find((uint32_t)(col_a * n_rows + row_a)), b = find((uint32_t)(col_b * n_rows + row_b));
+        if (a != b) parent[a > b ? a : b] = a > b ? b : a;  // the smallest cell of a class is its root
+    };
+    auto brow = [&](int rt) { return bnd + (uint64_t)(rt - sp.rows_per_cycle); };  // a boundary row type
+    for (int l = 0; l < sp.num_links; l++) {
+        const rc_link k = sp.links[l];
+        if (k.kind == 3) { unite(k.col_a, bnd + sp.off_bout, k.col_b, (uint64_t)k.row_b * rs + cap - 1); continue; }
+        if (k.kind == 4) { unite(k.col_a, brow(k.row_a), k.col_b, bnd + sp.off_bout); continue; }
+        if (k.kind == 5) { unite(k.col_a, brow(k.row_a), k.col_b, brow(k.row_b)); continue; }
+        for (uint32_t i = 0; i < cap; i++) {
+            const uint64_t ra = (uint64_t)k.row_a * rs + i;
+            if (k.kind == 0) unite(k.col_a, ra, k.col_b, (uint64_t)k.row_b * rs + i);
+            else if (k.kind == 1) { if (i) unite(k.col_a, ra, k.col_b, (uint64_t)k.row_b * rs + i - 1); else unite(k.col_a, ra, k.bin_col, bnd + sp.off_bin); }
+            else unite(k.col_a, ra, k.col_b, bnd + sp.off_bin);
+        }
+    }
+    if (out_of_range) return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: a link of the spec leaves the copy-permutation columns");
+    // cycles: the cells of a class in increasing order, the last one back to the root
+    std::vector<uint32_t> last(n_cells);
+    for (size_t i = 0; i < n_cells; i++) { sigma[i] = i; last[i] = (uint32_t)i; }
+    for (size_t i = 0; i < n_cells; i++) {
+        const uint32_t r = find((uint32_t)i);
+        if (r == i) continue;
+        sigma[last[r]] = i;  // i > last[r]: cells are visited in increasing order
+        last[r] = (uint32_t)i;
+        sigma[i] = r;
+    }
+    return ZKW_OK;
+}
+
 extern "C" zkw_ctx* zkw_create(int device_id) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -3661,6 +3737,36 @@ extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trac
     ZKW_TRY(launch_check("k_dc_check_cycle"));
     { Prof _p(ctx, "k_dc_check_tail"); hipLaunchKernelGGL(k_dc_check_tail, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
     ZKW_TRY(launch_check("k_dc_check_tail"));
+    CheckResult res;
+    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
+    *n_violations = res.violations;
+    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
+    return ZKW_OK;
+}
+
+// copy-permutation check through sigma columns (zkw_setup_copy_permutation): trace[cell] == trace[sigma[cell]] for every cell
+__global__ __launch_bounds__(256) void k_check_sigma(const u64* __restrict__ trace, const u64* __restrict__ sigma, size_t n_cells, CheckResult* res,
+                                                     size_t n_rows) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += stride) {
+        const u64 j = sigma[i];
+        if (j >= n_cells || trace[i] != trace[j]) flag_bad(res, 4, i / n_rows, i % n_rows);
+    }
+}
+extern "C" int zkw_check_copy_permutation(zkw_ctx* ctx, const zkw_trace* t, size_t slot, const uint64_t* sigma, uint32_t n_columns,
+                                          uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || !sigma || !n_violations || t->ctx->device != ctx->device || slot >= t->n_slots || n_columns == 0 || n_columns > t->n_cols)
+        return fail(ZKW_ERR_INVALID, "zkw_check_copy_permutation: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n_cells = (size_t)n_columns * t->n_rows;
+    const u64* d_sigma = nullptr;
+    ZKW_TRY(ctx->in("sigma", sigma, n_cells, &d_sigma));
+    CheckResult* d_res = nullptr;
+    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
+    CheckResult init{0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    { Prof _p(ctx, "k_check_sigma"); hipLaunchKernelGGL(k_check_sigma, dim3(2048), dim3(256), 0, ctx->stream, t->data + slot * t->slot_elems(), d_sigma, n_cells, d_res, t->n_rows); }
+    ZKW_TRY(launch_check("k_check_sigma"));
     CheckResult res;
     ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
     *n_violations = res.violations;

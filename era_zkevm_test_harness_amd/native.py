@@ -40,6 +40,8 @@ SYMBOLS = [
     ("zkw_stream_release", None, [_vp, _vp]),
     ("zkw_trim_caches", None, []),
     ("zkw_block_linear_hasher_instance", _int, [_vp, _vp]),
+    ("zkw_setup_copy_permutation", _int, [C.c_uint8, C.c_uint32, _sz, _vp, _vp]),
+    ("zkw_check_copy_permutation", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _vp]),
     ("zkw_setup_row_selectors", _int, [C.c_uint8, C.c_uint32, _sz, _vp]),
     ("zkw_recursion_queue_split", _int, [_vp, _sz, C.c_uint32, _vp, _sz, _vp]),
     ("zkw_closed_form_public_inputs", _int, [_vp, C.c_uint8, _vp, C.c_size_t, _vp, _vp]),
@@ -1182,6 +1184,16 @@ Context.synthesize_code_decommitter = _ctx_synthesize_code_decommitter
 Context.check_if_satisfied_code_decommitter = _ctx_check_if_satisfied_code_decommitter
 Context.synthesize_sha256_round_function = _ctx_synthesize_sha256_round_function
 Context.check_if_satisfied_sha256_round_function = _ctx_check_if_satisfied_sha256_round_function
+def _ctx_check_copy_permutation(self, trace, slot, sigma):
+    """zkw_check_copy_permutation: (violations, (kind, column, row)) of trace[cell] == trace[sigma[cell]]"""
+    sg = np.ascontiguousarray(sigma, dtype=np.uint64)
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_check_copy_permutation(self.handle, trace.handle, slot, _np_ptr(sg), sg.shape[0], C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.check_copy_permutation = _ctx_check_copy_permutation
 Context.synthesize_linear_hasher = _ctx_synthesize_linear_hasher
 Context.synthesize_keccak_round_function = _ctx_synthesize_keccak_round_function
 Context.check_if_satisfied_keccak_round_function = _ctx_check_if_satisfied_keccak_round_function
@@ -1531,6 +1543,15 @@ def setup_row_selectors(circuit_type, capacity=0, n_rows=1 << 20):
     out = np.zeros(n_rows, np.uint8)
     _check(load().zkw_setup_row_selectors(circuit_type, capacity, n_rows, _np_ptr(out)))
     return out
+
+
+def setup_copy_permutation(circuit_type, capacity, n_rows):
+    """zkw_setup_copy_permutation: sigma [n_columns][n_rows] (cell ids) of a queue circuit's layout; no GPU needed"""
+    ncol = C.c_uint32(0)
+    _check(load().zkw_setup_copy_permutation(circuit_type, capacity, n_rows, None, C.byref(ncol)))
+    sigma = np.zeros((ncol.value, n_rows), np.uint64)
+    _check(load().zkw_setup_copy_permutation(circuit_type, capacity, n_rows, _np_ptr(sigma), C.byref(ncol)))
+    return sigma
 
 
 def recursion_queue_split(states, arity=32):

@@ -1,0 +1,60 @@
+"""CPU (host arithmetic of libzkw): zkw_setup_copy_permutation of the queue circuits — sigma is a permutation, every
+oracle-synthesized trace satisfies trace[cell] == trace[sigma[cell]], and sigma's classes are the link classes of the
+spec-driven checker: bumping a cell that sigma moves is a copy violation (kind 4) for the oracle's checker too, bumping a
+cell sigma fixes is never one."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import native as nv, synthetic
+
+N_ROWS = 1 << 15
+
+
+def _cases(oracle):
+    w = oracle.ram_build_instances(synthetic.ram_trace(2983, seed=5), 1000, 0)
+    yield 8, 1000, [oracle.ram_synthesize(w, i, 1000, N_ROWS) for i in (0, 2)], oracle.ram_check
+    d = oracle.decommit_sorter_build(synthetic.decommit_trace(700, 60, seed=3), 300)
+    yield 2, 300, [oracle.decommit_sorter_synthesize(d, i, 300, N_ROWS) for i in (0, d["instances"].size - 1)], oracle.decommit_sorter_check
+    lq = synthetic.mixed_log_queue(900, seed=4)
+    m = oracle.log_demux_build(lq, 400)
+    yield 4, 400, [oracle.log_demux_synthesize(m, i, 400, N_ROWS) for i in (0, m["instances"].size - 1)], oracle.log_demux_check
+    e = oracle.events_sorter_build(synthetic.events_trace(500, 0.3, seed=6), 300)
+    yield 11, 300, [oracle.events_sorter_synthesize(e, i, 300, N_ROWS) for i in (0, e["instances"].size - 1)], oracle.events_sorter_check
+
+
+def test_sigma_is_the_link_structure(oracle):
+    rng = np.random.default_rng(1)
+    for ctype, cap, traces, check in _cases(oracle):
+        sigma = nv.setup_copy_permutation(ctype, cap, N_ROWS)
+        flat = sigma.reshape(-1)
+        ident = np.arange(flat.size, dtype=np.uint64)
+        assert np.array_equal(np.sort(flat), ident), ctype                       # a permutation
+        moved = np.flatnonzero(flat != ident)
+        assert moved.size > 100 * cap // 10
+        for t in traces:
+            body = t[:sigma.shape[0]].reshape(-1)
+            assert np.array_equal(body, body[flat]), ctype                       # satisfied traces satisfy sigma
+        t = traces[0]
+        G = sigma.shape[0]
+        for cell in rng.choice(moved, 6, replace=False):                         # a cell in a copy cycle
+            bad = t.copy()
+            bad[int(cell) // N_ROWS, int(cell) % N_ROWS] += 1
+            body = bad[:G].reshape(-1)
+            assert not np.array_equal(body, body[flat])
+            n, first = check(bad, cap)
+            assert n > 0
+        used_fixed = np.flatnonzero((flat == ident) & (t[:G].reshape(-1) != 0))
+        for cell in rng.choice(used_fixed, 4, replace=False):                    # a used cell outside every copy cycle
+            bad = t.copy()
+            bad[int(cell) // N_ROWS, int(cell) % N_ROWS] += 1
+            body = bad[:G].reshape(-1)
+            assert np.array_equal(body, body[flat])                              # sigma does not see it ...
+            n, first = check(bad, cap)
+            assert n == 0 or first[0] != 4, (ctype, int(cell), first)            # ... and neither do the checker's links
+
+
+def test_sigma_rejects_what_it_cannot_describe():
+    with pytest.raises(nv.ZkwError):
+        nv.setup_copy_permutation(6, 0, 1 << 20)   # a netlist circuit
+    with pytest.raises(nv.ZkwError):
+        nv.setup_copy_permutation(8, 136714, 1 << 19)
