@@ -548,9 +548,10 @@ bool link_spec_of(uint8_t t, LinkSpec* o) {
 
 extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t* sigma, uint32_t* n_columns) {
     LinkSpec sp;
-    if (!link_spec_of(circuit_type, &sp))
-        return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: circuit type %u (the netlist circuits' copy constraints are their operand references: "
-                                     "not produced as sigma columns yet)", (unsigned)circuit_type);
+    const bool netlist = circuit_type == 3 || circuit_type == 5 || circuit_type == 6 || circuit_type == 13;
+    if (netlist) sp = {circuit_type == 3 ? DC_MULT_COL0 : circuit_type == 6 ? SC_MULT_COL0 : KC_MULT_COL0, 0, 0, 0, 0, nullptr};  // all but the multiplicity columns
+    else if (!link_spec_of(circuit_type, &sp))
+        return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: circuit type %u has no layout in this library", (unsigned)circuit_type);
     zkw_circuit_layout lay;
     ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
     if (n_columns) *n_columns = (uint32_t)sp.G;
@@ -573,6 +574,89 @@ extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacit
         if (a != b) parent[a > b ? a : b] = a > b ? b : a;  // the smallest cell of a class is its root
     };
     auto brow = [&](int rt) { return bnd + (uint64_t)(rt - sp.rows_per_cycle); };  // a boundary row type
+    if (netlist) {
+        // the netlist circuits: every operand cell of a lookup / gate is a copy of the cell that produced it (the references of
+        // the spec, resolved exactly as the checkers do: k_kc_check_rows, k_sc_check_cycle); constants and free witness bytes
+        // are under no copy constraint
+        const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
+        if (circuit_type == 5 || circuit_type == 13) {
+            static const uint16_t kc_out[200] = KC_ROUND_OUT_INIT;
+            const uint64_t kb = KC_BOUNDARY_ROW(cycles);
+            auto ccol = [](int k) { return (uint64_t)(KC_LOOKUP_COL0 + 3 * (k % KC_LOOKUPS_PER_ROW) + 2); };
+            auto crow = [](uint64_t row0, int k) { return row0 + (uint64_t)(k / KC_LOOKUPS_PER_ROW); };
+            for (uint32_t c = 0; c < cycles; c++) {
+                const uint64_t base = (uint64_t)c * KC_ROWS_PER_CYCLE;
+                auto block = [&](uint64_t row0, int k, int part, uint64_t hcol, uint64_t hrow) {  // operand `part` of lookup k of a 200-lookup block
+                    unite((uint64_t)(KC_LOOKUP_COL0 + 3 * (k % KC_LOOKUPS_PER_ROW) + part), crow(row0, k), hcol, hrow);
+                };
+                for (int k = 0; k < 200; k++) {
+                    const uint64_t pcol = c ? ccol(k) : (uint64_t)(k % KC_G), prow = c ? crow(base - KC_ROWS_PER_CYCLE + KC_ROW_SEL_O0, k) : kb + k / KC_G;
+                    block(base + KC_ROW_MASK0, k, 0, KC_HDR_MASK_R, base);
+                    block(base + KC_ROW_MASK0, k, 1, pcol, prow);
+                    if (k < 136) block(base + KC_ROW_ABSORB0, k, 0, ccol(k), crow(base + KC_ROW_MASK0, k));
+                    block(base + KC_ROW_SEL_T0, k, 0, KC_HDR_MASK_I, base);
+                    block(base + KC_ROW_SEL_T0, k, 1, ccol(kc_out[k] - KC_REF_OP0), crow(base + KC_ROW_ROUND0 + 23 * (uint64_t)KC_ROWS_PER_ROUND, kc_out[k] - KC_REF_OP0));
+                    block(base + KC_ROW_SEL_U0, k, 0, KC_HDR_MASK_A, base);
+                    block(base + KC_ROW_SEL_U0, k, 1, pcol, prow);
+                    block(base + KC_ROW_SEL_O0, k, 0, ccol(k), crow(base + KC_ROW_SEL_T0, k));
+                    block(base + KC_ROW_SEL_O0, k, 1, ccol(k), crow(base + KC_ROW_SEL_U0, k));
+                }
+                for (int rnd = 0; rnd < 24; rnd++) {
+                    const uint64_t row0 = base + KC_ROW_ROUND0 + (uint64_t)rnd * KC_ROWS_PER_ROUND;
+                    for (int j = 0; j < KC_OPS_PER_ROUND; j++)
+                        for (int side = 0; side < 2; side++) {
+                            const uint16_t ref = side ? h_kc_ops[j].b : h_kc_ops[j].a;
+                            if (ref >= KC_REF_RC0) continue;  // round constant / zero
+                            uint64_t hc, hr;
+                            if (ref >= KC_REF_OP0) { hc = ccol(ref - KC_REF_OP0); hr = crow(row0, ref - KC_REF_OP0); }
+                            else if (rnd) { hc = ccol(kc_out[ref] - KC_REF_OP0); hr = crow(row0 - KC_ROWS_PER_ROUND, kc_out[ref] - KC_REF_OP0); }
+                            else { hc = ccol(ref); hr = crow(base + (ref < 136 ? KC_ROW_ABSORB0 : KC_ROW_MASK0), ref); }
+                            unite((uint64_t)(KC_LOOKUP_COL0 + 3 * (j % KC_LOOKUPS_PER_ROW) + side), crow(row0, j), hc, hr);
+                        }
+                }
+            }
+            for (int k = 0; k < 200; k++)
+                unite((uint64_t)(k % KC_G), kb + KC_BND_ROWS_PER_STATE + k / KC_G, ccol(k), crow(kb - KC_ROWS_PER_CYCLE + KC_ROW_SEL_O0, k));
+        } else {
+            // Sha256RoundFunction (SC_) and CodeDecommitter (DC_): the same netlist shape, different constants
+            const bool dc = circuit_type == 3;
+            const int lpr = dc ? DC_LOOKUPS_PER_ROW : SC_LOOKUPS_PER_ROW, n_ops = dc ? DC_NUM_OPS : SC_NUM_OPS, n_gates = dc ? DC_NUM_GATES : SC_NUM_GATES;
+            const uint64_t rpc = dc ? DC_ROWS_PER_CYCLE : SC_ROWS_PER_CYCLE, nb = (uint64_t)cycles * rpc;
+            static const sc_gate sc_gates[SC_NUM_GATES] = SC_GATES_INIT;
+            static const dc_gate dc_gates[DC_NUM_GATES] = DC_GATES_INIT;
+            static const uint16_t sc_out[32] = SC_OUT_INIT, dc_out[32] = DC_OUT_INIT;
+            const uint16_t* outr = dc ? dc_out : sc_out;
+            auto ocol = [&](int j, int part) { return (uint64_t)(SC_LOOKUP_COL0 + 3 * (j % lpr) + part); };
+            auto orow = [&](uint64_t base, int j) { return base + 1 + (uint64_t)(j / lpr); };
+            for (uint32_t c = 0; c < cycles; c++) {
+                const uint64_t base = (uint64_t)c * rpc;
+                auto home = [&](uint16_t ref, uint64_t* hc, uint64_t* hr) {  // false: no copy constraint
+                    if (ref < SC_REF_GATE) { *hc = ocol(ref, 2); *hr = orow(base, ref); return true; }
+                    if (ref < SC_REF_HDR) { const int g = (ref - SC_REF_GATE) >> 2; *hc = (uint64_t)((g % 2) * SC_GATE_COLS + SC_GATE_OUT + ((ref - SC_REF_GATE) & 3)); *hr = base + 1 + g / 2; return true; }
+                    if (ref < SC_REF_PREV) { *hc = ref - SC_REF_HDR; *hr = base; return true; }
+                    if (ref < SC_REF_FREE) {
+                        const int k = ref - SC_REF_PREV;
+                        if (c) { *hc = ocol(outr[k], 2); *hr = orow(base - rpc, outr[k]); } else { *hc = (uint64_t)k; *hr = nb; }
+                        return true;
+                    }
+                    return false;
+                };
+                uint64_t hc, hr;
+                for (int j = 0; j < n_ops; j++) {
+                    const uint16_t ra = dc ? h_dc_ops[j].a : h_sc_ops[j].a, rb = dc ? h_dc_ops[j].b : h_sc_ops[j].b;
+                    if (home(ra, &hc, &hr)) unite(ocol(j, 0), orow(base, j), hc, hr);
+                    if (home(rb, &hc, &hr)) unite(ocol(j, 1), orow(base, j), hc, hr);
+                }
+                for (int g = 0; g < n_gates; g++) {
+                    const uint32_t n = dc ? dc_gates[g].n_operands : sc_gates[g].n_operands;
+                    for (uint32_t k = 0; k < 4 * n; k++)
+                        if (home(dc ? dc_gates[g].in[k >> 2][k & 3] : sc_gates[g].in[k >> 2][k & 3], &hc, &hr))
+                            unite((uint64_t)((g % 2) * SC_GATE_COLS + k), base + 1 + g / 2, hc, hr);
+                }
+            }
+            for (int k = 0; k < 32; k++) unite((uint64_t)k, nb + 1, ocol(outr[k], 2), orow(nb - rpc, outr[k]));
+        }
+    }
     for (int l = 0; l < sp.num_links; l++) {
         const rc_link k = sp.links[l];
         if (k.kind == 3) { unite(k.col_a, bnd + sp.off_bout, k.col_b, (uint64_t)k.row_b * rs + cap - 1); continue; }

@@ -135,13 +135,13 @@ int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_l
 #define ZKW_ROW_BOUNDARY 0xC0
 #define ZKW_ROW_PADDING 0xFF
 int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint8_t *out);
-/* Setup side, copy permutation of the queue circuits (2, 4, 8, 9, 11, 12): sigma[c * n_rows + r] (host, *n_columns x n_rows
-   words; *n_columns = the type's general-purpose + lookup columns, i.e. all but the multiplicity column) = the cell c' * n_rows + r' that follows cell (c, r) in its copy
-   cycle, itself when the cell is under no copy constraint. Built from the spec's link table by a host union-find (seconds and
-   1.1 GB at production size; sigma = NULL only reports *n_columns). The netlist circuits' copy constraints are their operand
-   references and are not produced as sigma columns yet. zkw_check_copy_permutation: trace[cell] == trace[sigma[cell]] on the
-   GPU for every cell of the first n_columns columns of a slot (sigma: host or device pointer per the context's pointer mode);
-   violations are reported as kind 4 with (column, row). */
+/* Setup side, copy permutation of the ten synthesized types: sigma[c * n_rows + r] (host, *n_columns x n_rows words;
+   *n_columns = every column but the multiplicity column(s)) = the cell c' * n_rows + r' that follows cell (c, r) in its copy
+   cycle, itself when the cell is under no copy constraint. Built by a host union-find — from the spec's link table for the
+   queue circuits, from the netlist's operand references for the netlist circuits (seconds and ~1.1 GB at production size;
+   sigma = NULL only reports *n_columns). zkw_check_copy_permutation: trace[cell] == trace[sigma[cell]] on the GPU for every
+   cell of the first n_columns columns of a slot (sigma: host or device pointer per the context's pointer mode); violations
+   are reported as kind 4 with (column, row). */
 int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t *sigma, uint32_t *n_columns);
 int zkw_check_copy_permutation(zkw_ctx *ctx, const zkw_trace *t, size_t slot, const uint64_t *sigma, uint32_t n_columns,
                                uint64_t *n_violations, uint64_t *first_bad);

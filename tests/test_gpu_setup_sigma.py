@@ -53,3 +53,21 @@ def test_gpu_traces_satisfy_sigma(ctx):
     assert ctx.check_copy_permutation(t, 0, native.setup_copy_permutation(4, 400, n_rows)) == (0, (0, 0, 0))
     t.free()
     d.free()
+
+
+def test_gpu_netlist_traces_satisfy_sigma(ctx, oracle):
+    from era_zkevm_test_harness_amd import native
+
+    n_rows = 1 << 16
+    for kind, ctype, cap, cols, synth in ((0, 5, 6, native.KC_COLS, ctx.synthesize_keccak_round_function),
+                                          (1, 6, 7, native.SC_COLS, ctx.synthesize_sha256_round_function)):
+        req, mq = synthetic.precompile_trace(kind, 9, seed=3, max_rounds=4)
+        tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+        w = ctx._precompile(kind, req, tails, mq, cap, np.zeros(1, native.QUEUE_STATE12))
+        t = native.Trace(ctx, n_rows, w.num_instances, n_cols=cols)
+        synth(w, t)
+        sigma = native.setup_copy_permutation(ctype, cap, n_rows)
+        for slot in range(w.num_instances):
+            assert ctx.check_copy_permutation(t, slot, sigma) == (0, (0, 0, 0)), (ctype, slot)
+        t.free()
+        w.free()

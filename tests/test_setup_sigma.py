@@ -53,8 +53,38 @@ def test_sigma_is_the_link_structure(oracle):
             assert n == 0 or first[0] != 4, (ctype, int(cell), first)            # ... and neither do the checker's links
 
 
+def test_sigma_of_the_netlist_circuits(oracle):
+    """types 5, 13, 6, 3: the classes come from the netlists' operand references — traces satisfy sigma, a bumped cell of a
+    cycle is a copy violation (kind 2) or a broken relation (kind 1 / 7) for the oracle's checker, a free witness byte is in
+    no cycle"""
+    from tests.test_setup_selectors import _netlist_cases
+
+    rng = np.random.default_rng(2)
+    checks = {5: oracle.keccak_round_check, 13: lambda t, c: oracle.keccak_round_check(t, oracle.linear_hasher_cycles(c)),
+              6: oracle.sha256_round_check, 3: oracle.code_decommitter_check}
+    n_rows = 1 << 16
+    for ctype, cap, trace, col0, lpr in _netlist_cases(oracle):
+        sigma = nv.setup_copy_permutation(ctype, cap, n_rows)
+        G = sigma.shape[0]
+        assert G == col0 + 3 * lpr
+        flat = sigma.reshape(-1)
+        ident = np.arange(flat.size, dtype=np.uint64)
+        assert np.array_equal(np.sort(flat), ident), ctype
+        body = trace[:G].reshape(-1)
+        assert np.array_equal(body, body[flat]), ctype
+        moved = np.flatnonzero(flat != ident)
+        assert moved.size > 10000
+        for cell in rng.choice(moved, 5, replace=False):
+            bad = trace.copy()
+            bad[int(cell) // n_rows, int(cell) % n_rows] += 1
+            b = bad[:G].reshape(-1)
+            assert not np.array_equal(b, b[flat])
+            n, first = checks[ctype](bad, cap)
+            assert n > 0 and first[0] in (1, 2, 7), (ctype, int(cell), first)
+
+
 def test_sigma_rejects_what_it_cannot_describe():
     with pytest.raises(nv.ZkwError):
-        nv.setup_copy_permutation(6, 0, 1 << 20)   # a netlist circuit
+        nv.setup_copy_permutation(7, 0, 1 << 20)   # ECRecover: no layout
     with pytest.raises(nv.ZkwError):
         nv.setup_copy_permutation(8, 136714, 1 << 19)
