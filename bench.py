@@ -148,7 +148,7 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     return best, blk
 
 
-def full_blocks_batched(local_rank, blk, K=48, rounds=3):
+def full_blocks_batched(local_rank, blk, K=96, rounds=3):
     from concurrent.futures import ThreadPoolExecutor
 
     """Throughput of WHOLE blocks: K production-capacity blocks in flight at once through zkw_blocks_run (one host thread
