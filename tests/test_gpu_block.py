@@ -1,6 +1,6 @@
 """GPU, end to end: the post-VM half of create_artifacts_from_tracer (src/witness/oracle.rs:928-1130) over one synthetic
 block — every witness builder in the reference's order with the shared queues threaded through them, every instance of
-the six synthesized circuit types filled and checked, one recursion queue per circuit type."""
+the synthesized circuit types filled and checked, one recursion queue per circuit type."""
 import numpy as np
 import pytest
 
@@ -50,7 +50,7 @@ def test_block_after_vm(ctx, oracle, seed):
         what = {blk.LOG_DEMUXER: nv.DMX_INSTANCES, blk.STORAGE_SORTER: nv.STO_INSTANCES, blk.EVENTS_SORTER: nv.EVT_INSTANCES}[ctype]
         assert np.array_equal(fn(w[key].get(what))[1], a["public_inputs"][ctype])
     assert a["l1_messages_pubdata_hash"] == oracle.linear_keccak256(w["l1_messages_sorter"].get(nv.EVT_RESULT_QUERIES))
-    # every instance of the six synthesized circuit types: filled, satisfied, PI row = the instance's public input
+    # every instance of the six queue circuit types (block.synthesize_and_check): filled, satisfied, PI row = the instance's public input
     done = blk.synthesize_and_check(ctx, a, 1 << 15)
     assert done[blk.RAM_PERMUTATION] == ram_inst.size and done[blk.STORAGE_SORTER] == sto_inst.size >= 3
     assert done[blk.LOG_DEMUXER] >= 4 and done[blk.DECOMMITS_SORTER] >= 2 and done[blk.EVENTS_SORTER] >= 2 and done[blk.L1_MESSAGES_SORTER] >= 2
