@@ -398,7 +398,7 @@ static int launch_check(const char* what) {
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 extern "C" const char* zkw_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char* zkw_version(void) { return "zkw 0.1 (gfx950)"; }
+extern "C" const char* zkw_version(void) { return "zkw 0.2 (gfx950)"; }
 
 extern "C" int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometry* out) {
     // {copy columns, lookup width, repetitions, max degree, capacity, big size hint}: vm_main.rs:29-44,
