@@ -148,13 +148,16 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     return best, blk
 
 
-def full_blocks_batched(local_rank, blk, K=96, rounds=3):
+def full_blocks_batched(local_rank, blk, K=48, rounds=3):
     from concurrent.futures import ThreadPoolExecutor
 
     """Throughput of WHOLE blocks: K production-capacity blocks in flight at once through zkw_blocks_run (one host thread
     per block; the chain service merges every block's Poseidon2 queue chains into a few shared launches, so K blocks cost
     about two chain passes instead of K), then every synthesizable instance of every block into its trace, then the blocks
     released. The first round fills the library's buffer caches (untimed); the best of the others is reported."""
+    # K = 48: with 96 blocks in flight (27 blocks/s, tools/probe_block_concurrency.py) rocprofv3's own interception crashes in
+    # hipMemcpyAsync under ~500 host threads; the bench must stay profilable
+    K = int(os.environ.get("ZKW_BATCHED_BLOCKS", K))
     blocks = [blk] + [synthetic.block_production(seed=2 + k) for k in range(3)]
     blocks = [blocks[k % len(blocks)] for k in range(K)]
     best = None
