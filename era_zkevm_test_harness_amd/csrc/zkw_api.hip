@@ -3707,9 +3707,8 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
     u32* d_hist = nullptr;
-    const size_t hist_elems = (size_t)SC_NUM_TABLES * SC_TABLE_ROWS, hist_all = ZKW_NUM_XCD * hist_elems;  // one copy per XCD
+    const size_t hist_elems = (size_t)SC_NUM_TABLES * SC_TABLE_ROWS, hist_all = (size_t)SC_HIST_SLICES * SC_TABLE_ROWS;  // k_sc_hist stores every bin
     ZKW_TRY(ctx->scratch_t<u32>("sc_hist", n_instances * hist_all, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_all * sizeof(u32), ctx->stream));
     std::vector<ScSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         const size_t i = first_instance + k;
@@ -3727,6 +3726,8 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     const unsigned nj = (unsigned)n_instances;
     { Prof _p(ctx, "k_sc_fill"); hipLaunchKernelGGL(k_sc_fill, dim3(std::min<unsigned>((capacity + SC_FILL_WAVES - 1) / SC_FILL_WAVES, SC_FILL_BLOCKS), nj), dim3(SC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_sc_fill"));
+    { Prof _p(ctx, "k_sc_hist"); hipLaunchKernelGGL(k_sc_hist, dim3(SC_HIST_SLICES, 2, nj), dim3(SC_HIST_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_sc_hist"));
     { Prof _p(ctx, "k_sc_finish"); hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     return launch_check("k_sc_finish");
 }
@@ -3776,9 +3777,8 @@ extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_wit
     HIP_TRY(hipSetDevice(ctx->device));
     if (!w->cf_pi) ZKW_TRY(closed_form_public_inputs<CfDecommitter>(ctx, w->instances, w->n_instances, &w->cf_pi));
     u32* d_hist = nullptr;
-    const size_t hist_elems = (size_t)DC_NUM_TABLES * DC_TABLE_ROWS, hist_all = ZKW_NUM_XCD * hist_elems;  // one copy per XCD
+    const size_t hist_elems = (size_t)DC_NUM_TABLES * DC_TABLE_ROWS, hist_all = (size_t)DC_HIST_SLICES * DC_TABLE_ROWS;  // k_dc_hist stores every bin
     ZKW_TRY(ctx->scratch_t<u32>("dc_hist", n_instances * hist_all, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_all * sizeof(u32), ctx->stream));
     std::vector<DcSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         const size_t i = first_instance + k;
@@ -3796,6 +3796,8 @@ extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_wit
     const unsigned nj = (unsigned)n_instances;
     { Prof _p(ctx, "k_dc_fill"); hipLaunchKernelGGL(k_dc_fill, dim3(std::min<unsigned>((capacity + DC_FILL_WAVES - 1) / DC_FILL_WAVES, DC_FILL_BLOCKS), nj), dim3(DC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_dc_fill"));
+    { Prof _p(ctx, "k_dc_hist"); hipLaunchKernelGGL(k_dc_hist, dim3(DC_HIST_SLICES, 2, nj), dim3(DC_HIST_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_dc_hist"));
     { Prof _p(ctx, "k_dc_finish"); hipLaunchKernelGGL(k_dc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     return launch_check("k_dc_finish");
 }

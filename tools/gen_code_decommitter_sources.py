@@ -10,7 +10,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RENAMES = [(r"\bSC_", "DC_"), (r"\bsc_op\b", "dc_op"), (r"\bsc_gate\b", "dc_gate"), (r"\bg_sc_", "g_dc_"), (r"\bk_sc_", "k_dc_"),
-           (r"\bScSynthJob\b", "DcSynthJob"), (r"\bsc_table\b", "dc_table"), (r"\bsc_prev_byte\b", "dc_prev_byte"),
+           (r"\bScSynthJob\b", "DcSynthJob"), (r"\bScHistPlan\b", "DcHistPlan"), (r"\bsc_hist_plan\b", "dc_hist_plan"), (r"\bc_sc_", "c_dc_"), (r"\bsc_table\b", "dc_table"), (r"\bsc_prev_byte\b", "dc_prev_byte"),
            (r"\bsc_pads_per_cycle\b", "dc_pads_per_cycle"), (r"orc_sha256_round_", "orc_code_decommitter_round_"),
            (r"zkw_sha256_circuit_spec\.h", "zkw_code_decommitter_circuit_spec.h")]
 
