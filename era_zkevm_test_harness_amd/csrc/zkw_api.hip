@@ -3665,9 +3665,8 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));  // public inputs of the block's instances (a20), once
     u32* d_hist = nullptr;
-    const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS, hist_all = ZKW_NUM_XCD * hist_elems;  // one copy per XCD
+    const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS, hist_all = (size_t)KC_HIST_SLICES * KC_TABLE_ROWS;  // k_kc_hist stores every bin
     ZKW_TRY(ctx->scratch_t<u32>("kc_hist", n_instances * hist_all, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * hist_all * sizeof(u32), ctx->stream));
     std::vector<KcSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         const size_t i = first_instance + k;
@@ -3686,6 +3685,8 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     const unsigned nj = (unsigned)n_instances;
     { Prof _p(ctx, "k_kc_fill"); hipLaunchKernelGGL(k_kc_fill, dim3(capacity, nj), dim3(KC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_kc_fill"));
+    { Prof _p(ctx, "k_kc_hist"); hipLaunchKernelGGL(k_kc_hist, dim3(KC_HIST_SLICES, 2, nj), dim3(KC_HIST_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_kc_hist"));
     { Prof _p(ctx, "k_kc_finish"); hipLaunchKernelGGL(k_kc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     return launch_check("k_kc_finish");
 }
@@ -3899,8 +3900,7 @@ extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* m
     ZKW_TRY(launch_check("k_commit_encodings"));
     u32* d_hist = nullptr;
     const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
-    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", ZKW_NUM_XCD * hist_elems, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, ZKW_NUM_XCD * hist_elems * sizeof(u32), ctx->stream));
+    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", (size_t)KC_HIST_SLICES * KC_TABLE_ROWS, &d_hist));
     std::vector<KcSynthJob> jobs(1);
     jobs[0].rounds = d_rounds;
     jobs[0].first_round = 0;
@@ -3913,6 +3913,8 @@ extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* m
     ZKW_TRY(ctx->upload("kc_jobs", jobs, &d_jobs));
     { Prof _p(ctx, "k_kc_fill"); hipLaunchKernelGGL(k_kc_fill, dim3(cycles, 1), dim3(KC_FILL_THREADS), 0, ctx->stream, d_jobs, cycles, n_rows); }
     ZKW_TRY(launch_check("k_kc_fill"));
+    { Prof _p(ctx, "k_kc_hist"); hipLaunchKernelGGL(k_kc_hist, dim3(KC_HIST_SLICES, 2, 1), dim3(KC_HIST_THREADS), 0, ctx->stream, d_jobs, cycles, n_rows); }
+    ZKW_TRY(launch_check("k_kc_hist"));
     { Prof _p(ctx, "k_kc_finish"); hipLaunchKernelGGL(k_kc_finish, dim3((unsigned)((hist_elems + 255) / 256), 1), dim3(256), 0, ctx->stream, d_jobs, cycles, n_rows); }
     ZKW_TRY(launch_check("k_kc_finish"));
     *record_out = rec;
