@@ -42,3 +42,22 @@ def test_code_decommitter_headers_and_derived_sources_are_current(tmp_path):
         assert r.returncode == 0, r.stderr[-1500:]
     for rel in ("include/zkw_code_decommitter_circuit_spec.h",) + DERIVED:
         assert (tmp_path / rel).read_bytes() == open(os.path.join(ROOT, rel), "rb").read(), f"{rel} is stale"
+
+
+@pytest.mark.parametrize("header,prefix", [("zkw_sha256_circuit_spec.h", "SC"), ("zkw_code_decommitter_circuit_spec.h", "DC")])
+def test_netlist_lookups_are_grouped_by_table_with_padding_last(header, prefix):
+    """k_sc_hist / k_dc_hist count multiplicities by reading a table's rows as one run per cycle and skip the padding by
+    position (sha256_circuit_kernels.cuh, sc_hist_plan): the committed specs must keep that shape"""
+    import re
+    text = open(os.path.join(ROOT, "include", header)).read()
+    per_row = int(re.search(rf"#define {prefix}_LOOKUPS_PER_ROW (\d+)", text).group(1))
+    const0 = int(re.search(rf"#define {prefix}_REF_CONST (0x[0-9A-Fa-f]+)", text).group(1), 16)
+    body = text[text.index(f"#define {prefix}_OPS_INIT"):text.index(f"#define {prefix}_GATES_INIT")]
+    ops = [tuple(int(x) for x in m) for m in re.findall(r"\{(\d+), (\d+), (\d+)\}", body)]
+    assert len(ops) == int(re.search(rf"#define {prefix}_NUM_OPS (\d+)", text).group(1)) and len(ops) % per_row == 0
+    for j in range(1, len(ops)):
+        assert ops[j][0] >= ops[j - 1][0]
+        if ops[j][0] != ops[j - 1][0]:
+            assert j % per_row == 0
+        elif ops[j - 1][1:] == (const0, const0):
+            assert ops[j][1:] == (const0, const0)

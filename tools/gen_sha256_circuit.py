@@ -182,6 +182,14 @@ def finalize(nl, out):
         return R_CONST + r[1]
 
     ops = [(t, enc(a), enc(b)) for t, a, b in placed]
+    # k_sc_hist (multiplicities) reads a table's lookups as ONE run of rows per cycle and skips the padding by position:
+    # tables ascending, every table starts a row, padding (0, 0) only after a table's last real lookup
+    for j in range(1, len(ops)):
+        assert ops[j][0] >= ops[j - 1][0]
+        if ops[j][0] != ops[j - 1][0]:
+            assert j % LOOKUPS_PER_ROW == 0
+        elif (ops[j - 1][1], ops[j - 1][2]) == (R_CONST, R_CONST):
+            assert (ops[j][1], ops[j][2]) == (R_CONST, R_CONST), "a real lookup after padding"
     gates = [([[enc(r) for r in w] for w in operands], k) for operands, k in nl.gates]
     return ops, gates, [enc(r) for r in out]
 
