@@ -395,6 +395,26 @@ static int launch_check(const char* what) {
     return ZKW_OK;
 }
 
+// rows [0, width) of blockIdx.y's column of a column-major strip
+__global__ __launch_bounds__(256) void k_zero_strip(u64* __restrict__ base, size_t pitch, size_t width) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < width) base[(size_t)blockIdx.y * pitch + i] = 0;
+}
+// Zeroes what the fill of a "zkw trace v3" netlist circuit does NOT write itself: the general-purpose columns [0, g) (the
+// fill then overwrites its header / gate cells), the lookup columns [g, g + lookup_cols) below the last cycle only (the fill
+// writes every lookup cell of the cycles' rows, padding and header rows included), and the multiplicity columns. Zeroing
+// the whole slot first wrote the lookup columns twice: a third of the memset.
+static int zero_netlist_slot(zkw_ctx* ctx, u64* trace, size_t n_rows, size_t g, size_t lookup_cols, size_t n_cols, size_t used_rows) {
+    HIP_TRY(hipMemsetAsync(trace, 0, g * n_rows * sizeof(u64), ctx->stream));
+    if (used_rows < n_rows) {  // (hipMemset2DAsync took 0.2 ms per slot for this strip of 42 x 802 cells)
+        hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - used_rows + 255) / 256), (unsigned)lookup_cols), dim3(256), 0, ctx->stream,
+                           trace + g * n_rows + used_rows, n_rows, n_rows - used_rows);
+        ZKW_TRY(launch_check("k_zero_strip"));
+    }
+    HIP_TRY(hipMemsetAsync(trace + (g + lookup_cols) * n_rows, 0, (n_cols - g - lookup_cols) * n_rows * sizeof(u64), ctx->stream));
+    return ZKW_OK;
+}
+
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 extern "C" const char* zkw_last_error(void) { return g_last_error.c_str(); }
@@ -3678,7 +3698,7 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + k * hist_all;
-        HIP_TRY(hipMemsetAsync(j.trace, 0, (size_t)KC_COLS * n_rows * sizeof(u64), ctx->stream));
+        ZKW_TRY(zero_netlist_slot(ctx, j.trace, n_rows, KC_G, 3 * KC_LOOKUPS_PER_ROW, KC_COLS, (size_t)capacity * KC_ROWS_PER_CYCLE));
     }
     KcSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("kc_jobs", jobs, &d_jobs));
@@ -3720,7 +3740,7 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + k * hist_all;
-        HIP_TRY(hipMemsetAsync(j.trace, 0, (size_t)SC_COLS * n_rows * sizeof(u64), ctx->stream));
+        ZKW_TRY(zero_netlist_slot(ctx, j.trace, n_rows, SC_G, 3 * SC_LOOKUPS_PER_ROW, SC_COLS, (size_t)capacity * SC_ROWS_PER_CYCLE));
     }
     ScSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("sc_jobs", jobs, &d_jobs));
@@ -3790,7 +3810,7 @@ extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_wit
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + k * hist_all;
-        HIP_TRY(hipMemsetAsync(j.trace, 0, (size_t)DC_COLS * n_rows * sizeof(u64), ctx->stream));
+        ZKW_TRY(zero_netlist_slot(ctx, j.trace, n_rows, DC_G, 3 * DC_LOOKUPS_PER_ROW, DC_COLS, (size_t)capacity * DC_ROWS_PER_CYCLE));
     }
     DcSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("dc_jobs", jobs, &d_jobs));
@@ -3908,7 +3928,7 @@ extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* m
     jobs[0].public_input = d_pi;
     jobs[0].trace = t->data + slot * t->slot_elems();
     jobs[0].hist = d_hist;
-    HIP_TRY(hipMemsetAsync(jobs[0].trace, 0, (size_t)KC_COLS * n_rows * sizeof(u64), ctx->stream));
+    ZKW_TRY(zero_netlist_slot(ctx, jobs[0].trace, n_rows, KC_G, 3 * KC_LOOKUPS_PER_ROW, KC_COLS, (size_t)cycles * KC_ROWS_PER_CYCLE));
     KcSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("kc_jobs", jobs, &d_jobs));
     { Prof _p(ctx, "k_kc_fill"); hipLaunchKernelGGL(k_kc_fill, dim3(cycles, 1), dim3(KC_FILL_THREADS), 0, ctx->stream, d_jobs, cycles, n_rows); }

@@ -19,6 +19,18 @@ def ctx():
     c.close()
 
 
+def _dirty(ctx, t, n_cols):
+    """garbage in the whole slot: the synthesis must leave no cell of a previous tenant behind (it zeroes only what its fill
+    does not write: zero_netlist_slot, zkw_api.hip)"""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    ctx.synchronize()
+    assert hip.hipMemset(t.device_ptr(0), 0xA5, n_cols * N_ROWS * 8) == 0
+    assert hip.hipDeviceSynchronize() == 0
+
+
 def _compare(ctx, native, t, i, got_fn, exp, check_gpu, check_orc, capacity):
     got = t.get(0)
     if not np.array_equal(got, exp):
@@ -48,6 +60,7 @@ def test_precompile_circuits_random(ctx, oracle, seed):
         assert w.get(native.PRC_KECCAK_ROUNDS if kind == 0 else native.PRC_SHA256_ROUNDS).tobytes() == o[rounds_key].tobytes()
         t = native.Trace(ctx, N_ROWS, 1, n_cols=cols)
         for i in sorted({0, w.num_instances // 2, w.num_instances - 1}):
+            _dirty(ctx, t, cols)
             synth(w, t, i, 1, 0)
             _compare(ctx, native, t, i, None, osynth(o, i, capacity, N_ROWS), check, ocheck, capacity)
         t.free()
@@ -73,6 +86,7 @@ def test_code_decommitter_random(ctx, oracle, seed):
     assert w.get(native.DCM_SHA256_ROUNDS).tobytes() == o["sha256_rounds"].tobytes()
     t = native.Trace(ctx, N_ROWS, 1, n_cols=native.DC_COLS)
     for i in sorted({0, w.num_instances // 2, w.num_instances - 1}):
+        _dirty(ctx, t, native.DC_COLS)
         ctx.synthesize_code_decommitter(w, t, i, 1, 0)
         _compare(ctx, native, t, i, None, oracle.code_decommitter_synthesize(o, i, capacity, N_ROWS), ctx.check_if_satisfied_code_decommitter,
                  oracle.code_decommitter_check, capacity)
