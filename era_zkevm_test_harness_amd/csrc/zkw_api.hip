@@ -3687,6 +3687,9 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     u32* d_hist = nullptr;
     const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS, hist_all = (size_t)KC_HIST_SLICES * KC_TABLE_ROWS;  // k_kc_hist stores every bin
     ZKW_TRY(ctx->scratch_t<u32>("kc_hist", n_instances * hist_all, &d_hist));
+    uint16_t* d_keys = nullptr;
+    const size_t keys_per_slot = (size_t)capacity * (size_t)KC_LOOKUPS_PER_ROW * (KC_ROWS_PER_CYCLE - 1);
+    ZKW_TRY(ctx->scratch_t<uint16_t>("kc_keys", n_instances * keys_per_slot, &d_keys));
     std::vector<KcSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         const size_t i = first_instance + k;
@@ -3698,6 +3701,7 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + k * hist_all;
+        j.keys = d_keys + k * keys_per_slot;
         ZKW_TRY(zero_netlist_slot(ctx, j.trace, n_rows, KC_G, 3 * KC_LOOKUPS_PER_ROW, KC_COLS, (size_t)capacity * KC_ROWS_PER_CYCLE));
     }
     KcSynthJob* d_jobs = nullptr;
@@ -3730,6 +3734,9 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     u32* d_hist = nullptr;
     const size_t hist_elems = (size_t)SC_NUM_TABLES * SC_TABLE_ROWS, hist_all = (size_t)SC_HIST_SLICES * SC_TABLE_ROWS;  // k_sc_hist stores every bin
     ZKW_TRY(ctx->scratch_t<u32>("sc_hist", n_instances * hist_all, &d_hist));
+    uint16_t* d_keys = nullptr;
+    const size_t keys_per_slot = (size_t)capacity * SC_NUM_OPS;
+    ZKW_TRY(ctx->scratch_t<uint16_t>("sc_keys", n_instances * keys_per_slot, &d_keys));
     std::vector<ScSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         const size_t i = first_instance + k;
@@ -3740,6 +3747,7 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + k * hist_all;
+        j.keys = d_keys + k * keys_per_slot;
         ZKW_TRY(zero_netlist_slot(ctx, j.trace, n_rows, SC_G, 3 * SC_LOOKUPS_PER_ROW, SC_COLS, (size_t)capacity * SC_ROWS_PER_CYCLE));
     }
     ScSynthJob* d_jobs = nullptr;
@@ -3800,6 +3808,9 @@ extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_wit
     u32* d_hist = nullptr;
     const size_t hist_elems = (size_t)DC_NUM_TABLES * DC_TABLE_ROWS, hist_all = (size_t)DC_HIST_SLICES * DC_TABLE_ROWS;  // k_dc_hist stores every bin
     ZKW_TRY(ctx->scratch_t<u32>("dc_hist", n_instances * hist_all, &d_hist));
+    uint16_t* d_keys = nullptr;
+    const size_t keys_per_slot = (size_t)capacity * DC_NUM_OPS;
+    ZKW_TRY(ctx->scratch_t<uint16_t>("dc_keys", n_instances * keys_per_slot, &d_keys));
     std::vector<DcSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         const size_t i = first_instance + k;
@@ -3810,6 +3821,7 @@ extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_wit
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
         j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
         j.hist = d_hist + k * hist_all;
+        j.keys = d_keys + k * keys_per_slot;
         ZKW_TRY(zero_netlist_slot(ctx, j.trace, n_rows, DC_G, 3 * DC_LOOKUPS_PER_ROW, DC_COLS, (size_t)capacity * DC_ROWS_PER_CYCLE));
     }
     DcSynthJob* d_jobs = nullptr;
@@ -3921,6 +3933,8 @@ extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* m
     u32* d_hist = nullptr;
     const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
     ZKW_TRY(ctx->scratch_t<u32>("kc_hist", (size_t)KC_HIST_SLICES * KC_TABLE_ROWS, &d_hist));
+    uint16_t* d_keys = nullptr;
+    ZKW_TRY(ctx->scratch_t<uint16_t>("kc_keys", (size_t)cycles * KC_LOOKUPS_PER_ROW * (KC_ROWS_PER_CYCLE - 1), &d_keys));
     std::vector<KcSynthJob> jobs(1);
     jobs[0].rounds = d_rounds;
     jobs[0].first_round = 0;
@@ -3928,6 +3942,7 @@ extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* m
     jobs[0].public_input = d_pi;
     jobs[0].trace = t->data + slot * t->slot_elems();
     jobs[0].hist = d_hist;
+    jobs[0].keys = d_keys;
     ZKW_TRY(zero_netlist_slot(ctx, jobs[0].trace, n_rows, KC_G, 3 * KC_LOOKUPS_PER_ROW, KC_COLS, (size_t)cycles * KC_ROWS_PER_CYCLE));
     KcSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("kc_jobs", jobs, &d_jobs));
