@@ -3753,7 +3753,7 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     ScSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("sc_jobs", jobs, &d_jobs));
     const unsigned nj = (unsigned)n_instances;
-    { Prof _p(ctx, "k_sc_fill"); hipLaunchKernelGGL(k_sc_fill, dim3(std::min<unsigned>((capacity + SC_FILL_WAVES - 1) / SC_FILL_WAVES, SC_FILL_BLOCKS), nj), dim3(SC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_sc_fill"); hipLaunchKernelGGL(k_sc_fill, dim3(std::min<unsigned>((capacity + SC_FILL_WAVES - 1) / SC_FILL_WAVES, std::max<unsigned>(1, SC_FILL_BLOCKS / nj)), nj), dim3(SC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_sc_fill"));
     { Prof _p(ctx, "k_sc_hist"); hipLaunchKernelGGL(k_sc_hist, dim3(SC_HIST_SLICES, 2, nj), dim3(SC_HIST_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_sc_hist"));
@@ -3827,7 +3827,7 @@ extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_wit
     DcSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("dc_jobs", jobs, &d_jobs));
     const unsigned nj = (unsigned)n_instances;
-    { Prof _p(ctx, "k_dc_fill"); hipLaunchKernelGGL(k_dc_fill, dim3(std::min<unsigned>((capacity + DC_FILL_WAVES - 1) / DC_FILL_WAVES, DC_FILL_BLOCKS), nj), dim3(DC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_dc_fill"); hipLaunchKernelGGL(k_dc_fill, dim3(std::min<unsigned>((capacity + DC_FILL_WAVES - 1) / DC_FILL_WAVES, std::max<unsigned>(1, DC_FILL_BLOCKS / nj)), nj), dim3(DC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_dc_fill"));
     { Prof _p(ctx, "k_dc_hist"); hipLaunchKernelGGL(k_dc_hist, dim3(DC_HIST_SLICES, 2, nj), dim3(DC_HIST_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_dc_hist"));
