@@ -560,7 +560,9 @@ int zkw_keccak_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t sl
    include/zkw_sha256_circuit_spec.h: 138 columns, one netlist per cycle of 6552 byte lookups (XOR8, ANDN8, AND8, ROT<1..7>)
    and 184 32-bit ADD gates in the general-purpose columns of the same rows, stating out = idle ? prev :
    sha256_compress(reset ? IV : prev, block); 469 rows per cycle (up to 2235 cycles in 2^20 rows). Cycles = the instance's
-   rounds (ZKW_PRC_SHA256_ROUNDS), idle up to the witness's capacity; n_rows >= 65 536. w must be a sha256 witness. */
+   rounds (ZKW_PRC_SHA256_ROUNDS), idle up to the witness's capacity; n_rows >= 65 536. w must be a sha256 witness.
+   Context scratch per instance of the call (kept by the context for the next call): 21 MB of multiplicity histogram slices
+   and 2 bytes per lookup of keys (29 MB at capacity 2206); the same holds for the type-5 / 13 / 3 calls. */
 int zkw_sha256_round_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t first_instance, size_t n_instances,
                                 zkw_trace *t, size_t first_slot);
 int zkw_sha256_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
