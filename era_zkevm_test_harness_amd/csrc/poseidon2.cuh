@@ -14,7 +14,7 @@
 //                                 LDS. This is the latency-oriented form for the serial queue chains.
 #pragma once
 #include "gl64.cuh"
-#include "poseidon2_constants.h"
+#include "../../include/zkw_poseidon2_params.h"
 
 namespace p2 {
 using gl::u32;

@@ -3,7 +3,7 @@
  * in the tests) so that the cpu_baseline leg of bench.py times a competent scalar CPU path.
  */
 #include "oracle.h"
-#include "poseidon2_constants.h"
+#include "../include/zkw_poseidon2_params.h"
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -149,26 +149,6 @@ void orc_poseidon2_permutation(uint64_t s[12]) {
         w_external(s);
     }
     for (int i = 0; i < 12; i++) s[i] = s[i] >= P ? s[i] - P : s[i];
-}
-
-/* Plonky2-compatible Poseidon over the same constant table (naive form): pins the table. */
-void orc_poseidon1_permutation(uint64_t s[12]) {
-    static const uint64_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    for (int r = 0; r < 30; r++) {
-        for (int i = 0; i < 12; i++) s[i] = orc_gl_add(s[i], P2_ROUND_CONSTANTS[12 * r + i]);
-        if (r < 4 || r >= 26)
-            for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
-        else
-            s[0] = sbox7(s[0]);
-        uint64_t t[12];
-        for (int row = 0; row < 12; row++) {
-            u128 acc = 0;
-            for (int i = 0; i < 12; i++) acc += (u128)CIRC[i] * s[(i + row) % 12];
-            if (row == 0) acc += (u128)8 * s[0];
-            t[row] = orc_gl_reduce128(acc);
-        }
-        memcpy(s, t, sizeof t);
-    }
 }
 
 void orc_absorb_multiple_rounds(uint64_t state[12], const uint64_t *to_absorb, size_t n_rounds,

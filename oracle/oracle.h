@@ -63,7 +63,6 @@ void orc_poseidon2_permutation(uint64_t state[12]);
 /* the same permutation in its obvious form (one reduction per field operation): cross-check of the fast form */
 void orc_poseidon2_permutation_ref(uint64_t state[12]);
 /* Poseidon (original, Plonky2-compatible) — used only to pin the shared round-constant table */
-void orc_poseidon1_permutation(uint64_t state[12]);
 /* absorb_multiple_rounds::<AbsorptionModeOverwrite> (call sites lib.rs:198-203, 405-409):
    for each 8-chunk: state[0..8] = chunk; permutation; record the state. `states_out` may be NULL. */
 void orc_absorb_multiple_rounds(uint64_t state[12], const uint64_t *to_absorb, size_t n_rounds,

@@ -191,12 +191,6 @@ def poseidon2_ref(state):
     return s
 
 
-def poseidon1(state):
-    s = _u64(state).copy()
-    lib().orc_poseidon1_permutation(_p(s))
-    return s
-
-
 def hash_node(left, right):
     out = np.zeros(4, np.uint64)
     lib().orc_poseidon2_hash_node(_p(_u64(left)), _p(_u64(right)), _p(out))

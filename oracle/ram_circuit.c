@@ -10,7 +10,7 @@
  */
 #include "oracle.h"
 #include "../include/zkw_ram_circuit_spec.h"
-#include "poseidon2_constants.h"
+#include "../include/zkw_poseidon2_params.h"
 #include <stdlib.h>
 #include <string.h>
 

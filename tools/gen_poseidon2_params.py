@@ -1,4 +1,27 @@
-RC = [
+#!/usr/bin/env python3
+"""Generates include/zkw_poseidon2_params.h — the ONE parameter file of the Poseidon2 permutation, consumed by the product
+(csrc/poseidon2.cuh) and by the test oracle (oracle/oracle.c, oracle/ram_circuit.c): a parameter fix is a one-file flip.
+
+Provenance. The reference takes `Poseidon2Goldilocks` from the absent crate era-boojum (circuit_encodings/src/lib.rs:12-15,
+src/prover_utils.rs:43). boojum's Poseidon2 reuses the 30x12 round-constant table of its Poseidon (rows 0-3 and 26-29 in
+full, element 0 of rows 4-25), and that table is NOT today's Plonky2 Goldilocks table: it is the table Plonky2 shipped
+while its field was still the Crandall prime 2^64 - 9*2^28 + 1 (first entry 0xb585f767417ee042; boojum also keeps that
+era's power-of-two Poseidon MDS exponents [0,0,1,0,3,5,1,8,12,3,16,10]). Both Plonky2 tables are the same ChaCha8 stream
+R_i mapped into the field with a widening multiply, c_i = floor(R_i * ORDER / 2^64); 2^64 / ORDER_goldilocks = 1 + 2^-32
+makes the map invertible on the Goldilocks table, so the Crandall-era table is *derived* here from the Goldilocks one
+(which is pinned by Plonky2's published all-zero Poseidon vector, tests/test_oracle_field_hash.py) — 0 ambiguous entries.
+
+Pin: with the derived table the permutation reproduces every known answer the reference holds in
+test_proofs/base_layer/basic_circuit_proof_8_0.json (tests/test_reference_fixtures.py, tests/test_gpu_reference_kats.py):
+Merkle sibling pairs -> parent, FRI last-oracle leaves -> cap, whole witness/setup paths -> caps.
+"""
+import os
+
+ORDER_GOLDILOCKS = 2**64 - 2**32 + 1
+ORDER_CRANDALL = 2**64 - 9 * 2**28 + 1
+
+# today's Plonky2 Goldilocks table (plonky2/src/hash/poseidon_goldilocks.rs ALL_ROUND_CONSTANTS); public
+PLONKY2_GOLDILOCKS_RC = [
 0xb585f766f2144405, 0x7746a55f43921ad7, 0xb2fb0d31cee799b4, 0x0f6760a4803427d7,
 0xe10d666650f4e012, 0x8cae14cb07d09bf1, 0xd438539c95f63e9f, 0xef781c7ce35b4c3d,
 0xcdc4a239b0c44426, 0x277fa208bf337bff, 0xe17653a29da578a1, 0xc54302f225db2c76,
@@ -90,4 +113,117 @@ RC = [
 0xaaed34074b164346, 0x8ffd96bbf9c9c81d, 0x70fc91eb5937085c, 0x7f795e2a5f915440,
 0x4543d9df5476d3cb, 0xf172d73e004fc90d, 0xdfd1c4febcc81238, 0xbc8dfb627fe558fc,
 ]
-assert len(RC)==360, len(RC)
+assert len(PLONKY2_GOLDILOCKS_RC) == 360
+
+
+def derive_boojum_table(goldilocks_table=PLONKY2_GOLDILOCKS_RC):
+    """R = the unique u64 with floor(R * ORDER_G / 2^64) == g; boojum's entry = floor(R * ORDER_C / 2^64)."""
+    out = []
+    for g in goldilocks_table:
+        lo = -(-(g << 64) // ORDER_GOLDILOCKS)
+        hi = (((g + 1) << 64) - 1) // ORDER_GOLDILOCKS
+        cands = {(r * ORDER_CRANDALL) >> 64 for r in range(lo, hi + 1)}
+        assert len(cands) == 1, "ambiguous preimage"
+        out.append(cands.pop())
+    return out
+
+
+RC = derive_boojum_table()
+assert RC[0] == 0xB585F767417EE042 and RC[1] == 0x7746A55F77C10331  # the entries quoted in boojum's table
+M4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]  # external layer = circ(2*M4, M4, M4)
+INTERNAL_DIAG_SHIFTS = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]  # internal layer = all-ones + diag(2^shift)
+HALF_FULL_ROUNDS, PARTIAL_ROUNDS = 4, 22
+INITIAL_EXTERNAL_LAYER = 1  # Poseidon2 applies the external layer once before round 0
+PARTIAL_CONSTANT_INDEX = 0  # partial round r adds element 0 of row r
+
+
+def permutation(state, rc=None):
+    """plain big-int restatement (the third, independent one: oracle C, device HIP, this)"""
+    rc = RC if rc is None else rc
+    P = ORDER_GOLDILOCKS
+
+    def ext(s):
+        t = [sum(M4[i][j] * s[4 * c + j] for j in range(4)) % P for c in range(3) for i in range(4)]
+        col = [(t[i] + t[4 + i] + t[8 + i]) % P for i in range(4)]
+        return [(t[4 * c + i] + col[i]) % P for c in range(3) for i in range(4)]
+
+    s = ext([x % P for x in state]) if INITIAL_EXTERNAL_LAYER else [x % P for x in state]
+    r = 0
+    for _ in range(HALF_FULL_ROUNDS):
+        s = ext([pow((s[i] + rc[12 * r + i]) % P, 7, P) for i in range(12)])
+        r += 1
+    for _ in range(PARTIAL_ROUNDS):
+        s[0] = pow((s[0] + rc[12 * r + PARTIAL_CONSTANT_INDEX]) % P, 7, P)
+        tot = sum(s) % P
+        s = [(s[i] * (1 << INTERNAL_DIAG_SHIFTS[i]) + tot) % P for i in range(12)]
+        r += 1
+    for _ in range(HALF_FULL_ROUNDS):
+        s = ext([pow((s[i] + rc[12 * r + i]) % P, 7, P) for i in range(12)])
+        r += 1
+    return s
+
+
+def plonky2_poseidon(state):
+    """Plonky2's Poseidon over PLONKY2_GOLDILOCKS_RC (naive form): pins the table the derivation starts from."""
+    P = ORDER_GOLDILOCKS
+    circ = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+    diag = [8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    s = [x % P for x in state]
+    for r in range(30):
+        s = [(s[i] + PLONKY2_GOLDILOCKS_RC[12 * r + i]) % P for i in range(12)]
+        if r < 4 or r >= 26:
+            s = [pow(x, 7, P) for x in s]
+        else:
+            s[0] = pow(s[0], 7, P)
+        s = [(sum(circ[i] * s[(i + row) % 12] for i in range(12)) + diag[row] * s[row]) % P for row in range(12)]
+    return s
+
+
+HEADER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "zkw_poseidon2_params.h")
+
+
+def render():
+    rows = []
+    for r in range(30):
+        rows.append("    " + ", ".join("0x%016xULL" % c for c in RC[12 * r:12 * r + 12]) + ", \\")
+    body = "\n".join(rows)
+    return f"""/* zkw_poseidon2_params.h — GENERATED by tools/gen_poseidon2_params.py; do not edit.
+ * The one parameter file of Poseidon2 over Goldilocks (width 12, rate 8, capacity 4) as era-boojum's
+ * `Poseidon2Goldilocks` defines it (reference call sites: circuit_encodings/src/lib.rs:12-15, src/prover_utils.rs:43).
+ * Consumed by the product (csrc/poseidon2.cuh) AND the test oracle (oracle/oracle.c, oracle/ram_circuit.c). Provenance of the table and the
+ * reference-held known answers that pin it: tools/gen_poseidon2_params.py, tests/test_reference_fixtures.py.
+ */
+#ifndef ZKW_POSEIDON2_PARAMS_H
+#define ZKW_POSEIDON2_PARAMS_H
+#include <stdint.h>
+#define P2_WIDTH 12
+#define P2_RATE 8
+#define P2_CAPACITY 4
+#define P2_HALF_FULL_ROUNDS {HALF_FULL_ROUNDS}
+#define P2_PARTIAL_ROUNDS {PARTIAL_ROUNDS}
+#define P2_TOTAL_ROUNDS {2 * HALF_FULL_ROUNDS + PARTIAL_ROUNDS}
+#define P2_INITIAL_EXTERNAL_LAYER {INITIAL_EXTERNAL_LAYER}
+#define P2_PARTIAL_CONSTANT_INDEX {PARTIAL_CONSTANT_INDEX} /* partial round r adds element [12*r + this] to state[0] */
+/* 30 x 12 round constants: rows 0-3 and 26-29 in full, one element of rows 4-25 */
+#define P2_ROUND_CONSTANTS_INIT {{ \\
+{body}
+}}
+static const uint64_t P2_ROUND_CONSTANTS[P2_TOTAL_ROUNDS * P2_WIDTH] = P2_ROUND_CONSTANTS_INIT;
+/* external layer = circ(2*M4, M4, M4) */
+#define P2_M4_INIT {{{{5, 7, 1, 3}}, {{4, 6, 1, 1}}, {{1, 3, 5, 7}}, {{1, 1, 4, 6}}}}
+static const uint64_t P2_M4[4][4] = P2_M4_INIT;
+/* internal (partial-round) layer = all-ones + diag(2^shift[i]) */
+#define P2_INTERNAL_DIAG_SHIFTS_INIT {{{", ".join(map(str, INTERNAL_DIAG_SHIFTS))}}}
+static const uint32_t P2_INTERNAL_DIAG_SHIFTS[P2_WIDTH] = P2_INTERNAL_DIAG_SHIFTS_INIT;
+#endif /* ZKW_POSEIDON2_PARAMS_H */
+"""
+
+
+if __name__ == "__main__":
+    import sys
+
+    txt = render()
+    if "--check" in sys.argv:
+        sys.exit(0 if open(HEADER).read() == txt else 1)
+    open(HEADER, "w").write(txt)
+    print("wrote", os.path.normpath(HEADER))
