@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/zkw.h"
+#include "zkw_internal.h"
 #include "ram_kernels.cuh"
 #include "ram_circuit_kernels.cuh"
 #include "log_kernels.cuh"
@@ -51,6 +52,15 @@ using namespace zkw;
 static thread_local std::string g_last_error;
 
 static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+int zkw_fail(int code, const char* fmt, ...) {  // the same for the library's other translation units (zkw_internal.h)
     char buf[512];
     va_list ap;
     va_start(ap, fmt);

@@ -44,6 +44,11 @@ SYMBOLS = [
     ("zkw_check_copy_permutation", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _vp]),
     ("zkw_setup_row_selectors", _int, [C.c_uint8, C.c_uint32, _sz, _vp]),
     ("zkw_recursion_queue_split", _int, [_vp, _sz, C.c_uint32, _vp, _sz, _vp]),
+    ("zkw_vk_commitment", _int, [_vp, _vp, _sz, _vp]),
+    ("zkw_compute_leaf_params", _int, [_vp, C.c_uint8, _vp, _vp, _sz, _vp]),
+    ("zkw_leaf_vks_and_params_commitment", _int, [_vp, _vp, _vp]),
+    ("zkw_create_leaf_witnesses", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    ("zkw_create_node_witnesses", _int, [_vp, C.c_uint8, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp]),
     ("zkw_closed_form_public_inputs", _int, [_vp, C.c_uint8, _vp, C.c_size_t, _vp, _vp]),
     ("zkw_version", C.c_char_p, []),
     ("zkw_circuit_geometry_of", _int, [C.c_uint8, _vp]),
@@ -1563,6 +1568,66 @@ def recursion_queue_split(states, arity=32):
     _check(load().zkw_recursion_queue_split(_np_ptr(st) if st.size else None, st.shape[0], arity, _np_ptr(out) if n_leaves else None, n_leaves, C.byref(n)))
     assert n.value == n_leaves
     return out
+
+
+LEAF_PARAMS = np.dtype([("circuit_type", "<u8"), ("basic_circuit_vk_commitment", "<u8", 4), ("leaf_layer_vk_commitment", "<u8", 4)])
+QUEUE_TAIL12 = np.dtype([("tail", "<u8", 12), ("length", "<u4"), ("_pad", "<u4")])
+
+
+def vk_commitment(ctx, cap):
+    """zkw_vk_commitment: commitment of a verification key = of its setup_merkle_tree_cap [cap_size][4]"""
+    cap = np.ascontiguousarray(cap, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(4, np.uint64)
+    _check(load().zkw_vk_commitment(ctx.handle, _np_ptr(cap), cap.shape[0], _np_ptr(out)))
+    return out
+
+
+def compute_leaf_params(ctx, circuit_type, base_layer_cap, leaf_layer_cap):
+    """compute_leaf_params (recursive_aggregation.rs:163-216)"""
+    b = np.ascontiguousarray(base_layer_cap, dtype=np.uint64).reshape(-1, 4)
+    l = np.ascontiguousarray(leaf_layer_cap, dtype=np.uint64).reshape(-1, 4)
+    assert b.shape == l.shape
+    out = np.zeros(1, LEAF_PARAMS)
+    _check(load().zkw_compute_leaf_params(ctx.handle, circuit_type, _np_ptr(b), _np_ptr(l), b.shape[0], _np_ptr(out)))
+    return out
+
+
+def leaf_vks_and_params_commitment(ctx, leaf_params):
+    p = np.ascontiguousarray(leaf_params, dtype=LEAF_PARAMS).reshape(13)
+    out = np.zeros(4, np.uint64)
+    _check(load().zkw_leaf_vks_and_params_commitment(ctx.handle, _np_ptr(p), _np_ptr(out)))
+    return out
+
+
+def create_leaf_witnesses(ctx, params, public_inputs, queue_tail_in=None):
+    """create_leaf_witnesses (recursive_aggregation.rs:71-161) -> dict(enc, states, leaf_states, leaf_public_inputs)"""
+    p = np.ascontiguousarray(params, dtype=LEAF_PARAMS).reshape(1)
+    pi = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(-1, 4)
+    n = pi.shape[0]
+    n_leaves = (n + 31) // 32
+    enc, states = np.zeros((n, 8), np.uint64), np.zeros((n, 12), np.uint64)
+    leaf_states, leaf_pi = np.zeros(n_leaves, QUEUE_STATE12), np.zeros((n_leaves, 4), np.uint64)
+    tin = None if queue_tail_in is None else _np_ptr(_u64(queue_tail_in))
+    got = C.c_size_t(0)
+    opt = lambda a: _np_ptr(a) if a.size else None
+    _check(load().zkw_create_leaf_witnesses(ctx.handle, _np_ptr(p), opt(pi), n, tin, opt(enc), opt(states), opt(leaf_states), opt(leaf_pi),
+                                            n_leaves, C.byref(got)))
+    assert got.value == n_leaves
+    return {"enc": enc, "states": states, "leaf_states": leaf_states, "leaf_public_inputs": leaf_pi}
+
+
+def create_node_witnesses(ctx, branch_circuit_type, leaf_layer_params, node_layer_vk_commitment, chunks):
+    """create_node_witnesses (recursive_aggregation.rs:270-421) -> dict(node_states, split_points [n][31], node_public_inputs)"""
+    p = np.ascontiguousarray(leaf_layer_params, dtype=LEAF_PARAMS).reshape(13)
+    ch = np.ascontiguousarray(chunks, dtype=QUEUE_STATE12)
+    nvk = np.ascontiguousarray(node_layer_vk_commitment, dtype=np.uint64).reshape(4)
+    n_nodes = (ch.size + 31) // 32
+    st, sp, pi = np.zeros(n_nodes, QUEUE_STATE12), np.zeros((n_nodes, 31), QUEUE_TAIL12), np.zeros((n_nodes, 4), np.uint64)
+    got = C.c_size_t(0)
+    _check(load().zkw_create_node_witnesses(ctx.handle, branch_circuit_type, _np_ptr(p), _np_ptr(nvk), _np_ptr(ch) if ch.size else None, ch.size,
+                                            _np_ptr(st) if n_nodes else None, _np_ptr(sp) if n_nodes else None, _np_ptr(pi) if n_nodes else None,
+                                            n_nodes, C.byref(got)))
+    return {"node_states": st, "split_points": sp, "node_public_inputs": pi}
 
 
 def trim_caches():

@@ -621,6 +621,36 @@ int zkw_closed_form_public_inputs(zkw_ctx *ctx, uint8_t circuit_type, const void
 int zkw_recursion_queue_split(const uint64_t *states, size_t n, uint32_t arity, zkw_queue_state12 *leaf_states, size_t max_leaves,
                               size_t *n_leaves);
 
+/* ---- recursion layer witnesses (src/witness/recursive_aggregation.rs; BASELINE config #5, witness side) --------------
+   All arrays are HOST arrays (a few hundred bytes per leaf): call these on a context in ZKW_PTR_HOST mode. The hashing runs
+   in the library's kernels. The encodings are pinned by three committed leaf proofs of the reference
+   (tests/golden/leaf_layer_kat.json). */
+/* records: zkw_leaf_params, zkw_queue_tail12 (include/zkw_types.h) */
+/* commitment of a verification key = compute_encodable_item_from_witness::<AllocatedVerificationKey> (:45-68; used at
+   :184-206 and by compute_node_vk_commitment :242-268): setup_merkle_tree_cap[cap_size][4] of a vk_N.json -> out[4] */
+int zkw_vk_commitment(zkw_ctx *ctx, const uint64_t *setup_merkle_tree_cap, size_t cap_size, uint64_t out[4]);
+/* compute_leaf_params (:163-216): circuit_type = the base-layer type, its VK's cap and the cap of the leaf-layer VK that
+   aggregates it (recursion type = base type + 2) */
+int zkw_compute_leaf_params(zkw_ctx *ctx, uint8_t circuit_type, const uint64_t *base_layer_cap, const uint64_t *leaf_layer_cap,
+                            size_t cap_size, zkw_leaf_params *out);
+/* compute_leaf_vks_and_params_commitment (:218-240): leaf_params[13] in base circuit type order -> out[4] */
+int zkw_leaf_vks_and_params_commitment(zkw_ctx *ctx, const zkw_leaf_params *leaf_params, uint64_t out[4]);
+/* create_leaf_witnesses (:71-161) for one circuit type: public_inputs[n][4] of its base-layer instances in emission order
+   -> the recursion queue (enc[n][8], states[n][12]: FullStateCircuitQueueRawWitness element i = (request i, old tail =
+   states[i - 1] or queue_tail_in/zero)), split_by(32) into leaf_states[*n_leaves] and, if leaf_public_inputs != NULL, each
+   leaf circuit's public input = commit(RecursionLeafInput{params, queue_state}) [*n_leaves][4]. queue_tail_in: NULL = empty. */
+int zkw_create_leaf_witnesses(zkw_ctx *ctx, const zkw_leaf_params *params, const uint64_t *public_inputs, size_t n,
+                              const uint64_t *queue_tail_in, uint64_t *enc, uint64_t *states, zkw_queue_state12 *leaf_states,
+                              uint64_t *leaf_public_inputs, size_t max_leaves, size_t *n_leaves);
+/* create_node_witnesses (:270-421) for one circuit type: chunks[n_chunks] = the queue states of the leaves (or nodes) below,
+   in order; every 32 are merged into node_states[k] (heads and tails must chain), split_points[k][31] (tails of the first 31
+   chunks, padded with (merged tail, 0)) and, if node_public_inputs != NULL, the node circuit's public input =
+   commit(RecursionNodeInput{branch_circuit_type, leaf_layer_parameters[13], node_layer_vk_commitment, queue_state}). */
+int zkw_create_node_witnesses(zkw_ctx *ctx, uint8_t branch_circuit_type, const zkw_leaf_params *leaf_layer_params,
+                              const uint64_t node_layer_vk_commitment[4], const zkw_queue_state12 *chunks, size_t n_chunks,
+                              zkw_queue_state12 *node_states, zkw_queue_tail12 *split_points, uint64_t *node_public_inputs,
+                              size_t max_nodes, size_t *n_nodes);
+
 /* ---- L1 messages hasher ------------------------------------------------------------------------------ */
 /* compute_linear_keccak256, src/witness/individual_circuits/data_hasher_and_merklizer.rs:8-67: Keccak-256 of
    the concatenated 88-byte serialisations (circuit_encodings/src/log_query.rs:503-534) of the net L2->L1

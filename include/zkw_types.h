@@ -98,6 +98,21 @@ typedef struct zkw_queue_state12 {
     uint32_t _pad;
 } zkw_queue_state12;
 
+/* ---- recursion layer (src/witness/recursive_aggregation.rs) */
+#define ZKW_NUM_BASE_LAYER_CIRCUITS 13
+/* RecursionLeafParametersWitness (recursive_aggregation.rs:208-213) */
+typedef struct zkw_leaf_params {
+    uint64_t circuit_type;
+    uint64_t basic_circuit_vk_commitment[4];
+    uint64_t leaf_layer_vk_commitment[4];
+} zkw_leaf_params;
+/* QueueTailStateWitness: a node's split point (recursive_aggregation.rs:352-367) */
+typedef struct zkw_queue_tail12 {
+    uint64_t tail[12];
+    uint32_t length;
+    uint32_t _pad;
+} zkw_queue_tail12;
+
 typedef struct zkw_ram_fsm {
     uint64_t lhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];
     uint64_t rhs_accumulator[ZKW_NUM_PERMUTATION_ARGUMENT_REPETITIONS];

@@ -267,6 +267,14 @@ int orc_callstack_simulate(const uint8_t *is_push, size_t n_ops, const zkw_calls
 #define ORC_RAM_INPUT_ENC_LEN 51
 #define ORC_RAM_FSM_ENC_LEN 69
 void orc_commit_var_length(const uint64_t *enc, size_t n, uint64_t out[4]);
+/* ---- recursion layer witnesses, recursion.c (src/witness/recursive_aggregation.rs) */
+void orc_vk_commitment(const uint64_t *cap, size_t cap_size, uint64_t out[4]);
+void orc_leaf_params(uint8_t circuit_type, const uint64_t *base_cap, const uint64_t *leaf_cap, size_t cap_size, zkw_leaf_params *out);
+void orc_leaf_vks_and_params_commitment(const zkw_leaf_params *p, uint64_t out[4]);
+void orc_leaf_public_input(const zkw_leaf_params *params, const zkw_queue_state12 *queue_state, uint64_t out[4]);
+int orc_node_witness(uint8_t branch_circuit_type, const zkw_leaf_params *leaf_layer_params, const uint64_t node_vk_commitment[4],
+                     const zkw_queue_state12 *chunks, size_t n_chunks, zkw_queue_state12 *node_state, zkw_queue_tail12 *split_points,
+                     uint64_t public_input[4]);
 size_t orc_ram_encode_observable_input(const zkw_ram_instance *in, uint64_t out[ORC_RAM_INPUT_ENC_LEN]);
 size_t orc_ram_encode_fsm(const zkw_ram_fsm *f, uint64_t out[ORC_RAM_FSM_ENC_LEN]);
 void orc_ram_public_input(const zkw_ram_instance *first, const zkw_ram_instance *in, uint64_t compact[18],

@@ -536,6 +536,53 @@ def recursion_queue(circuit_type, pi, tail_in=None):
     return enc, tails
 
 
+LEAF_PARAMS = np.dtype([("circuit_type", "<u8"), ("basic_circuit_vk_commitment", "<u8", 4), ("leaf_layer_vk_commitment", "<u8", 4)])
+QUEUE_TAIL12 = np.dtype([("tail", "<u8", 12), ("length", "<u4"), ("_pad", "<u4")])
+
+
+def vk_commitment(cap):
+    cap = np.ascontiguousarray(cap, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(4, np.uint64)
+    lib().orc_vk_commitment(_p(cap), C.c_size_t(cap.shape[0]), _p(out))
+    return out
+
+
+def leaf_params(circuit_type, base_cap, leaf_cap):
+    b = np.ascontiguousarray(base_cap, dtype=np.uint64).reshape(-1, 4)
+    l = np.ascontiguousarray(leaf_cap, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(1, LEAF_PARAMS)
+    lib().orc_leaf_params(C.c_uint8(circuit_type), _p(b), _p(l), C.c_size_t(b.shape[0]), _p(out))
+    return out
+
+
+def leaf_vks_and_params_commitment(params):
+    p = np.ascontiguousarray(params, dtype=LEAF_PARAMS).reshape(13)
+    out = np.zeros(4, np.uint64)
+    lib().orc_leaf_vks_and_params_commitment(_p(p), _p(out))
+    return out
+
+
+def leaf_public_input(params, queue_state):
+    p = np.ascontiguousarray(params, dtype=LEAF_PARAMS).reshape(1)
+    q = np.ascontiguousarray(queue_state, dtype=QUEUE_STATE12).reshape(1)
+    out = np.zeros(4, np.uint64)
+    lib().orc_leaf_public_input(_p(p), _p(q), _p(out))
+    return out
+
+
+def node_witness(branch_circuit_type, leaf_layer_params, node_vk_commitment, chunks):
+    p = np.ascontiguousarray(leaf_layer_params, dtype=LEAF_PARAMS).reshape(13)
+    ch = np.ascontiguousarray(chunks, dtype=QUEUE_STATE12)
+    nvk = np.ascontiguousarray(node_vk_commitment, dtype=np.uint64).reshape(4)
+    st, sp, pi = np.zeros(1, QUEUE_STATE12), np.zeros(31, QUEUE_TAIL12), np.zeros(4, np.uint64)
+    f = lib().orc_node_witness
+    f.restype = C.c_int
+    rc = f(C.c_uint8(branch_circuit_type), _p(p), _p(nvk), _p(ch), C.c_size_t(ch.size), _p(st), _p(sp), _p(pi))
+    if rc != 0:
+        raise ValueError("orc_node_witness: empty or non-chaining chunks")
+    return st[0], sp, pi
+
+
 def encode_callstack_entries(e) -> np.ndarray:
     e = np.ascontiguousarray(e, dtype=CALLSTACK_ENTRY)
     out = np.zeros((e.size, 32), np.uint64)

@@ -101,7 +101,30 @@ def pair_kat():
             "pairs": pairs, "parents": sorted(list(k) for k in g), "cap": d["quotient_oracle_cap"]}
 
 
+def leaf_layer_kat():
+    """what the leaf-layer public inputs are computed from, for the three circuit types whose committed VKs are the
+    ones their proofs were made with (setup paths of base AND leaf proof end in the committed caps)"""
+    import glob
+    out = []
+    for base_t in (4, 8, 13):
+        leaf_t = base_t + 2
+        cap = lambda f: (lambda v: v[list(v)[0]]["setup_merkle_tree_cap"])(json.load(open(os.path.join(REF, f))))
+        pis = []
+        for f in sorted(glob.glob(os.path.join(REF, f"test_proofs/base_layer/basic_circuit_proof_{base_t}_*.json"))):
+            d = json.load(open(f))
+            pis.append(d[list(d)[0]]["public_inputs"])
+        lp = json.load(open(os.path.join(REF, f"test_proofs/recursion_layer/leaf_layer_proof_{leaf_t}_0.json")))
+        out.append({"base_circuit_type": base_t, "leaf_circuit_type": leaf_t,
+                    "base_vk_cap": cap(f"setup/base_layer/vk_{base_t}.json"), "leaf_vk_cap": cap(f"setup/recursion_layer/vk_{leaf_t}.json"),
+                    "base_public_inputs": pis, "leaf_public_input": lp[list(lp)[0]]["public_inputs"]})
+    return {"source": "setup/base_layer/vk_N.json, setup/recursion_layer/vk_{N+2}.json, test_proofs/base_layer/basic_circuit_proof_N_*.json, "
+                      "test_proofs/recursion_layer/leaf_layer_proof_{N+2}_0.json for N = 4, 8, 13",
+            "statement": "leaf_public_input = commit(RecursionLeafInput{params = compute_leaf_params(N, base vk, leaf vk), queue_state = "
+                         "the recursion queue over base_public_inputs})", "cases": out}
+
+
 if __name__ == "__main__":
+    json.dump(leaf_layer_kat(), open(os.path.join(HERE, "leaf_layer_kat.json"), "w"))
     json.dump(pair_kat(), open(os.path.join(HERE, "merkle_pair_kat_ram.json"), "w"))
     out = [paths_of("test_proofs/base_layer/basic_circuit_proof_8_0.json", "setup/base_layer/vk_8.json", [0, 57]),
            paths_of("test_proofs/base_layer/basic_circuit_proof_4_0.json", "setup/base_layer/vk_4.json", [3]),
