@@ -101,10 +101,12 @@ __device__ __forceinline__ u64 vm_lower_bound(const u32* a, u64 n, u32 c) {  // 
 }
 
 // the state of a full-width queue after its item k (FullWidthQueueIntermediateStates -> QueueStateWitness,
-// transform_sponge_like_queue_state src/witness/utils.rs:73-85): head = tail before the item, tail, length = k + 1
+// transform_sponge_like_queue_state src/witness/utils.rs:73-85): head = the SIMULATOR's head (push_and_output_intermediate_data
+// records `head: self.head`, circuit_encodings/src/lib.rs:419-421) = zero for the push-only memory / decommitment queues, tail =
+// the state after the item, length = k + 1
 __device__ __forceinline__ void vm_full_queue_state(const u64* tails, u64 k_plus_one, zkw_queue_state12* st) {
     for (int j = 0; j < 12; j++) {
-        st->head[j] = k_plus_one >= 2 ? tails[12 * (k_plus_one - 2) + j] : 0;
+        st->head[j] = 0;
         st->tail[j] = k_plus_one >= 1 ? tails[12 * (k_plus_one - 1) + j] : 0;
     }
     st->length = (u32)k_plus_one;

@@ -245,6 +245,7 @@ struct zkw_ctx {
     // witnesses and traces created from this context keep it alive: zkw_destroy defers while any is outstanding
     std::atomic<long> children{0};
     std::atomic<bool> destroy_requested{false};
+    std::atomic<bool> destroying{false};
     bool chain_service = false;  // queue chains go to the device's chain service (batched with other contexts' chains)
     int chain_form = 0;  // lanes per Poseidon2 state in the queue-chain kernel: 4 (quad), 16 (row), 0 = auto
     std::map<std::string, DevBuf> pool;  // named grow-only scratch
@@ -771,8 +772,19 @@ static void ctx_destroy_now(zkw_ctx* ctx) {
     delete ctx;
 }
 static void ctx_retain(zkw_ctx* ctx) { ctx->children.fetch_add(1); }
+static void ctx_release(zkw_ctx* ctx);
+// the context's internals the library's other translation units need (zkw_internal.h)
+int zkw_ctx_device(const zkw_ctx* ctx) { return ctx->device; }
+void* zkw_ctx_stream(const zkw_ctx* ctx) { return ctx->stream; }
+void zkw_ctx_retain(zkw_ctx* ctx) { ctx_retain(ctx); }
+void zkw_ctx_release(zkw_ctx* ctx) { ctx_release(ctx); }
+// zkw_destroy and the last child's release may race: whoever flips `destroying` first destroys, exactly once
+static void ctx_try_destroy(zkw_ctx* ctx) {
+    bool expected = false;
+    if (ctx->destroying.compare_exchange_strong(expected, true)) ctx_destroy_now(ctx);
+}
 static void ctx_release(zkw_ctx* ctx) {
-    if (ctx->children.fetch_sub(1) == 1 && ctx->destroy_requested.load()) ctx_destroy_now(ctx);
+    if (ctx->children.fetch_sub(1) == 1 && ctx->destroy_requested.load()) ctx_try_destroy(ctx);
 }
 
 // Witnesses and traces dereference their context when they are read or freed, so a context with outstanding
@@ -782,10 +794,11 @@ extern "C" void zkw_destroy(zkw_ctx* ctx) {
     if (ctx->children.load() > 0) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
-        ctx->destroy_requested.store(true);
-        return;
     }
-    ctx_destroy_now(ctx);
+    // request first, THEN look at the children: a release that drops the last child after this store sees the request; one
+    // that dropped it before is seen by the load below. Either way exactly one side wins ctx_try_destroy.
+    ctx->destroy_requested.store(true);
+    if (ctx->children.load() == 0) ctx_try_destroy(ctx);
 }
 
 extern "C" int zkw_set_stream(zkw_ctx* ctx, void* s) {
@@ -983,12 +996,18 @@ struct ChainService {
             auto fail_hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == ZKW_OK) { rc = ZKW_ERR_HIP; err = std::string(what) + ": " + hipGetErrorString(e); } };
             const size_t bytes = b->full.size() * sizeof(ChainJob) + b->log.size() * sizeof(LogChainJob) + 256;
             if (!st || !st_log) { rc = ZKW_ERR_HIP; err = "chain service: no stream"; }
-            if (rc == ZKW_OK && cap < bytes) {  // grow-only; freed with the service (hipFree would stall the device)
+            if (rc == ZKW_OK && cap < bytes) {  // grow-only; the outgrown pair goes back to the allocation cache (no hipFree stall)
                 const size_t want = bytes * 2;
                 void *np = nullptr, *nd = nullptr;
                 fail_hip(pin_malloc(&np, want), "hipHostMalloc");
                 if (rc == ZKW_OK) fail_hip(dev_malloc(&nd, want), "hipMalloc");
-                if (rc == ZKW_OK) { pin = np; dev = nd; cap = want; }
+                if (rc == ZKW_OK) {
+                    if (pin) pin_free(pin);
+                    if (dev) dev_free(dev);
+                    pin = np; dev = nd; cap = want;
+                } else if (np) {
+                    pin_free(np);
+                }
             }
             if (rc == ZKW_OK) {
                 char* hp = static_cast<char*>(pin);
@@ -1021,21 +1040,25 @@ struct ChainService {
             }
             cv_done.notify_all();
         }
+        if (pin) pin_free(pin);
+        if (dev) dev_free(dev);
         if (st) (void)hipStreamDestroy(st);
         if (st_log) (void)hipStreamDestroy(st_log);
     }
 };
 static std::mutex g_chain_services_mu;
-static std::map<int, std::unique_ptr<ChainService>> g_chain_services;
+// leaked on purpose, like the allocation cache: a static destructor would join the workers and destroy HIP streams while the
+// HIP runtime itself is being torn down at process exit
+static std::map<int, ChainService*>& g_chain_services = *new std::map<int, ChainService*>();
 // One service per device. A batch carries both kinds of chains (full-width queues, log queues) as two kernels on two streams
 // and completes per kind: a short log-queue chain does not wait for a long memory-queue chain that arrived in the same
 // window. Keeping the kinds in ONE batch (rather than one service per kind) matters: fewer concurrent one-wave kernels,
 // fewer chances that the dispatcher parks two of them on the same SIMD (each then runs 1.4x slower; measured).
 static ChainService* chain_service_of(int device) {
     std::lock_guard<std::mutex> g(g_chain_services_mu);
-    auto& p = g_chain_services[device];
-    if (!p) p.reset(new ChainService(device));
-    return p.get();
+    ChainService*& p = g_chain_services[device];
+    if (!p) p = new ChainService(device);
+    return p;
 }
 
 extern "C" int zkw_set_chain_service(zkw_ctx* ctx, int on) {
@@ -4120,164 +4143,3 @@ extern "C" int zkw_vm_slice_instances(zkw_ctx* ctx, const zkw_vm_tracer_streams*
     return ctx->sync_if_host();
 }
 
-// ------------------------------------------------------------------------------------------------ multi-GPU: the one collective (8e)
-// circuit instances are independent once the builders have fixed their hidden FSM inputs, so they are
-// sharded across the GPUs of a node with no data-path collective; the only exchange is the gather of the per-instance
-// closed-form records to rank 0, which replays the order-sensitive RecursionQueueSimulator pushes
-// (src/witness/postprocessing/mod.rs:396-402) and assembles the scheduler witness (src/external_calls.rs:354-537).
-// RCCL is resolved with dlopen when a communicator is created: libzkw itself does not link against it, a single-GPU
-// host never loads it, and a failure to find it is an error code, not a load failure.
-#include <dlfcn.h>
-#include <rccl/rccl.h>
-
-namespace {
-struct Rccl {
-    void* handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    std::string error;
-    bool load() {
-        if (handle) return true;
-        // a process that already holds an RCCL (torch's) keeps using that copy: one runtime per process
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
-            handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-            if (handle) break;
-        }
-        for (const char* n : names) {
-            if (handle) break;
-            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        }
-        if (!handle) { error = std::string("librccl.so not found: ") + dlerror(); return false; }
-        auto sym = [&](const char* s) { void* p = dlsym(handle, s); if (!p) error = std::string("RCCL symbol missing: ") + s; return p; };
-        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
-        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
-        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
-        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
-        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
-        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
-        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
-        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
-        if (!GetUniqueId || !CommInitRank || !CommDestroy || !Send || !Recv || !GroupStart || !GroupEnd || !GetErrorString) {
-            handle = nullptr;
-            return false;
-        }
-        return true;
-    }
-};
-Rccl g_rccl;
-std::mutex g_rccl_mu;
-}  // namespace
-
-struct zkw_comm {
-    zkw_ctx* ctx = nullptr;
-    int rank = 0, world = 1;
-    ncclComm_t comm = nullptr;
-};
-
-#define NCCL_TRY(expr)                                                                                   \
-    do {                                                                                                 \
-        ncclResult_t _r = (expr);                                                                        \
-        if (_r != ncclSuccess) return fail(ZKW_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(_r)); \
-    } while (0)
-
-extern "C" int zkw_comm_unique_id(uint8_t id[ZKW_COMM_ID_BYTES]) {
-    if (!id) return fail(ZKW_ERR_INVALID, "zkw_comm_unique_id: null argument");
-    std::lock_guard<std::mutex> g(g_rccl_mu);
-    if (!g_rccl.load()) return fail(ZKW_ERR_NO_DEVICE, "%s", g_rccl.error.c_str());
-    static_assert(ZKW_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
-    ncclUniqueId u;
-    NCCL_TRY(g_rccl.GetUniqueId(&u));
-    memcpy(id, u.internal, ZKW_COMM_ID_BYTES);
-    return ZKW_OK;
-}
-
-extern "C" int zkw_comm_init(zkw_ctx* ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, zkw_comm** out) {
-    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return fail(ZKW_ERR_INVALID, "zkw_comm_init: bad argument");
-    HIP_TRY(hipSetDevice(ctx->device));
-    zkw_comm* c = new zkw_comm();
-    c->ctx = ctx;
-    c->rank = rank;
-    c->world = world;
-    if (world > 1) {  // a single rank needs no transport at all
-        std::lock_guard<std::mutex> g(g_rccl_mu);
-        if (!g_rccl.load()) { delete c; return fail(ZKW_ERR_NO_DEVICE, "%s", g_rccl.error.c_str()); }
-        ncclUniqueId u;
-        memcpy(u.internal, id, ZKW_COMM_ID_BYTES);
-        ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
-        if (r != ncclSuccess) { delete c; return fail(ZKW_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
-    }
-    ctx_retain(ctx);
-    *out = c;
-    return ZKW_OK;
-}
-
-extern "C" void zkw_comm_destroy(zkw_comm* c) {
-    if (!c) return;
-    (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
-    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-    zkw_ctx* owner = c->ctx;
-    delete c;
-    ctx_release(owner);
-}
-
-// counts[r] records of record_bytes each from rank r, concatenated in rank order into recv on root. Device pointers.
-extern "C" int zkw_gather_closed_form_inputs(zkw_comm* c, const void* records, const uint64_t* counts, size_t record_bytes,
-                                             int root, void* recv) {
-    if (!c || !counts || record_bytes == 0 || root < 0 || root >= c->world) return fail(ZKW_ERR_INVALID, "zkw_gather_closed_form_inputs: bad argument");
-    zkw_ctx* ctx = c->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    const size_t mine = (size_t)counts[c->rank] * record_bytes;
-    if (mine && !records) return fail(ZKW_ERR_INVALID, "zkw_gather_closed_form_inputs: no records given");
-    if (c->rank == root && !recv) return fail(ZKW_ERR_INVALID, "zkw_gather_closed_form_inputs: the root needs a receive buffer");
-    if (c->world == 1) {
-        if (mine) HIP_TRY(hipMemcpyAsync(recv, records, mine, hipMemcpyDeviceToDevice, ctx->stream));
-        return ZKW_OK;
-    }
-    NCCL_TRY(g_rccl.GroupStart());
-    if (c->rank == root) {
-        size_t off = 0;
-        for (int r = 0; r < c->world; r++) {
-            const size_t bytes = (size_t)counts[r] * record_bytes;
-            if (bytes) {
-                if (r == root) HIP_TRY(hipMemcpyAsync(static_cast<char*>(recv) + off, records, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-                else NCCL_TRY(g_rccl.Recv(static_cast<char*>(recv) + off, bytes, ncclUint8, r, c->comm, ctx->stream));
-            }
-            off += bytes;
-        }
-    } else if (mine) {
-        NCCL_TRY(g_rccl.Send(records, mine, ncclUint8, root, c->comm, ctx->stream));
-    }
-    NCCL_TRY(g_rccl.GroupEnd());
-    return ZKW_OK;
-}
-
-// Longest-processing-time assignment of an ordered instance list to ranks, weight = rows the reference's synthesis of
-// that circuit type uses (setup/base_layer/finalization_hint_N.json): the shard plan of SURVEY 8(e).
-// Deterministic (ties: lower instance index first, lowest rank first), so every rank computes the same plan. No GPU needed.
-extern "C" int zkw_shard_lpt(const uint8_t* circuit_types, size_t n, int world, uint32_t* owner) {
-    static const uint32_t ROWS_USED[14] = {0, 1033358, 1021855, 1045894, 770857, 957656, 1039794, 938955, 1044096, 1046318, 1027359, 590817, 590817, 1038150};
-    if ((n && (!circuit_types || !owner)) || world < 1) return fail(ZKW_ERR_INVALID, "zkw_shard_lpt: bad argument");
-    std::vector<size_t> order(n);
-    for (size_t i = 0; i < n; i++) {
-        if (circuit_types[i] < 1 || circuit_types[i] > 13) return fail(ZKW_ERR_INVALID, "zkw_shard_lpt: circuit type %u", circuit_types[i]);
-        order[i] = i;
-    }
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return ROWS_USED[circuit_types[a]] > ROWS_USED[circuit_types[b]]; });
-    std::vector<uint64_t> load((size_t)world, 0);
-    for (size_t i : order) {
-        int best = 0;
-        for (int r = 1; r < world; r++)
-            if (load[r] < load[best]) best = r;
-        owner[i] = (uint32_t)best;
-        load[best] += ROWS_USED[circuit_types[i]];
-    }
-    return ZKW_OK;
-}

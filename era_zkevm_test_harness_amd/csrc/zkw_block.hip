@@ -480,6 +480,7 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
             memset(&h, 0, sizeof h);
             h.start_flag = h.completion_flag = 1;
             const size_t nl = zkw_events_witness_num_instances(B->l1);
+            if (nl == 0) return Status{ZKW_ERR_CHECK_FAILED, "L1-messages sorter produced no instance (an empty queue still yields one)"};
             zkw_events_sorter_instance last;
             ST_TRY(B->xf[X_MAIN].d2h(&last, static_cast<const zkw_events_sorter_instance*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_INSTANCES)) + (nl - 1),
                                      sizeof last));
@@ -530,19 +531,28 @@ thread_local std::string g_block_error;
 // process that has touched more (16 normal + 16 high-priority + the host framework's) is time-sliced by the hardware
 // scheduler from then on, idle queues included (measured: every HBM-bound kernel 40 % slower, 1390 instead of 1870
 // circuits/s in bench.py). 8 per class keeps the total below that with the chain service's 8 high-priority streams on
-// queues of their own. The variable is read when the HIP runtime initialises the device, so it is set when the library
-// is loaded, unless the host has chosen a value itself; a host that initialises HIP before loading libzkw must export
-// GPU_MAX_HW_QUEUES=8 itself.
-struct HwQueuesDefault {
-    HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-} g_hw_queues_default;
+// queues of their own. The variable is read when the HIP runtime initialises the device, so the host calls
+// zkw_process_init() before its first HIP call (an explicit call, not a load-time side effect), unless it has chosen a
+// value itself.
 
 }  // namespace
 
-extern "C" int zkw_block_run(int device_id, const zkw_block_inputs* in, zkw_block** out) {
-    if (!in || !out || !in->decommit_queries || in->n_decommit_queries == 0 || (in->n_log_queries && !in->log_queries) ||
+extern "C" int zkw_process_init(void) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);  // 0: a value the host exported wins
+    return ZKW_OK;
+}
+
+static bool inputs_valid(const zkw_block_inputs* in) {
+    if (!in || !in->decommit_queries || in->n_decommit_queries == 0 || (in->n_log_queries && !in->log_queries) ||
         (in->n_vm_memory_queries && !in->vm_memory_queries) || (in->n_bytecodes && (!in->bytecode_hashes || !in->bytecode_words || !in->bytecode_word_offsets)))
-        return ZKW_ERR_INVALID;
+        return false;
+    for (int k = 0; k < 3; k++)
+        if (in->n_precompile_memory_queries[k] && !in->precompile_memory_queries[k]) return false;
+    return true;
+}
+
+extern "C" int zkw_block_run(int device_id, const zkw_block_inputs* in, zkw_block** out) {
+    if (!out || !inputs_valid(in)) return ZKW_ERR_INVALID;
     zkw_block* B = new zkw_block();
     B->device = device_id;
     B->t0 = Clock::now();
@@ -584,9 +594,7 @@ extern "C" int zkw_blocks_run(int device_id, const zkw_block_inputs* const* inpu
     if (!inputs || !out || n_blocks == 0) return ZKW_ERR_INVALID;
     for (size_t k = 0; k < n_blocks; k++) {
         const zkw_block_inputs* in = inputs[k];
-        if (!in || !in->decommit_queries || in->n_decommit_queries == 0 || (in->n_log_queries && !in->log_queries) ||
-            (in->n_vm_memory_queries && !in->vm_memory_queries) || (in->n_bytecodes && (!in->bytecode_hashes || !in->bytecode_words || !in->bytecode_word_offsets)))
-            return ZKW_ERR_INVALID;
+        if (!inputs_valid(in)) return ZKW_ERR_INVALID;
         out[k] = nullptr;
     }
     std::vector<zkw_block*> blocks(n_blocks, nullptr);
@@ -777,11 +785,14 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
         const int prc = shard_plan(B, world, &plan_types, &plan_index, &plan_owner);
         if (prc != ZKW_OK) return prc;
     }
-    auto owned = [&](int t, size_t inst) {
-        for (size_t k = 0; k < plan_types.size(); k++)
-            if (plan_types[k] == t && plan_index[k] == inst) return (int)plan_owner[k] == rank;
-        return false;
-    };
+    // owner of (type, instance) in O(1): one table per type, filled from the plan once
+    std::vector<std::vector<int>> owner_of(14);
+    for (size_t k = 0; k < plan_types.size(); k++) {
+        std::vector<int>& o = owner_of[plan_types[k]];
+        if (o.size() <= plan_index[k]) o.resize(plan_index[k] + 1, -1);
+        o[plan_index[k]] = (int)plan_owner[k];
+    }
+    auto owned = [&](int t, size_t inst) { return inst < owner_of[t].size() && owner_of[t][inst] == rank; };
     if (hipSetDevice(B->device) != hipSuccess) return ZKW_ERR_HIP;
     if (B->ring && (B->ring_rows != n_rows || B->ring_slots != ring_slots)) {
         zkw_trace_free(B->ring);
@@ -853,9 +864,8 @@ extern "C" int zkw_block_gather_closed_form_inputs(zkw_block* B, zkw_comm* comm,
     int rc = shard_plan(B, world, &types, &index, &owner);
     if (rc != ZKW_OK) return rc;
     const size_t n = types.size();
-    std::vector<uint64_t> counts((size_t)world, 0), mine;
+    std::vector<uint64_t> mine;
     for (size_t k = 0; k < n; k++) {
-        counts[owner[k]]++;
         if ((int)owner[k] != rank) continue;
         const PerType& p = B->per[types[k]];
         mine.push_back(types[k]);
@@ -863,27 +873,10 @@ extern "C" int zkw_block_gather_closed_form_inputs(zkw_block* B, zkw_comm* comm,
         mine.insert(mine.end(), p.compact.begin() + 18 * index[k], p.compact.begin() + 18 * (index[k] + 1));
         mine.insert(mine.end(), p.pi.begin() + 4 * index[k], p.pi.begin() + 4 * (index[k] + 1));
     }
-    uint64_t *d_send = nullptr, *d_recv = nullptr;
-    Status s = B->upload(X_MAIN, &d_send, mine.data(), mine.size());
-    if (s.ok() && rank == root) s = B->alloc(&d_recv, n * 24 + 1);
-    if (!s.ok()) return s.rc;
-    zkw_ctx* c = B->ctx[C_PRE];  // the communicator's context decides the stream; records are ready (host-synchronous upload)
-    (void)c;
-    if ((rc = zkw_gather_closed_form_inputs(comm, d_send, counts.data(), 24 * 8, root, d_recv)) != ZKW_OK) return rc;
+    // host records in, host records out: the communicator stages them through its own (reused) device buffers, synchronises
+    // on every rank, and hands the root the records in emission order
+    if (rank == root && n && (!out || max_records < n)) return ZKW_ERR_INVALID;
+    if ((rc = zkw_gather_records(comm, owner.data(), n, mine.data(), 24 * 8, root, out)) != ZKW_OK) return rc;
     if (n_records) *n_records = n;
-    if (rank != root) return ZKW_OK;
-    if (!out || max_records < n) return ZKW_ERR_INVALID;
-    // the gather is enqueued on the communicator's stream: the caller's zkw_comm context; synchronise the device-side copy
-    if (hipDeviceSynchronize() != hipSuccess) return ZKW_ERR_HIP;
-    std::vector<uint64_t> got(n * 24);
-    s = B->xf[X_MAIN].d2h(got.data(), d_recv, got.size() * 8);
-    if (!s.ok()) return s.rc;
-    // rank order -> emission order
-    std::vector<size_t> next((size_t)world, 0), base((size_t)world, 0);
-    for (int r = 1; r < world; r++) base[r] = base[r - 1] + counts[r - 1];
-    for (size_t k = 0; k < n; k++) {
-        const size_t from = base[owner[k]] + next[owner[k]]++;
-        memcpy(out + 24 * k, got.data() + 24 * from, 24 * 8);
-    }
     return ZKW_OK;
 }

@@ -2,3 +2,9 @@
 #pragma once
 // sets the calling thread's zkw_last_error() text and returns `code` (defined in zkw_api.hip)
 int zkw_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// a context's device / HIP stream, and the reference count its witnesses, traces and communicators hold on it
+struct zkw_ctx;
+int zkw_ctx_device(const zkw_ctx* ctx);
+void* zkw_ctx_stream(const zkw_ctx* ctx);
+void zkw_ctx_retain(zkw_ctx* ctx);
+void zkw_ctx_release(zkw_ctx* ctx);

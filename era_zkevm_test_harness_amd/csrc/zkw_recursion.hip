@@ -70,8 +70,8 @@ extern "C" int zkw_create_leaf_witnesses(zkw_ctx* ctx, const zkw_leaf_params* pa
                                          const uint64_t* queue_tail_in, uint64_t* enc, uint64_t* states, zkw_queue_state12* leaf_states,
                                          uint64_t* leaf_public_inputs, size_t max_leaves, size_t* n_leaves) {
     if (!ctx || !params || !n_leaves || (n && (!public_inputs || !enc || !states))) return zkw_fail(ZKW_ERR_INVALID, "zkw_create_leaf_witnesses: null argument");
-    int rc = zkw_encode_recursion_requests(ctx, params->circuit_type, public_inputs, n, enc);
-    if (rc != ZKW_OK) return rc;
+    int rc = ZKW_OK;
+    if (n && (rc = zkw_encode_recursion_requests(ctx, params->circuit_type, public_inputs, n, enc)) != ZKW_OK) return rc;
     if (n && (rc = zkw_queue_push_chain_full(ctx, enc, n, queue_tail_in, states)) != ZKW_OK) return rc;
     if ((rc = zkw_recursion_queue_split(states, n, ZKW_RECURSION_ARITY, leaf_states, max_leaves, n_leaves)) != ZKW_OK) return rc;
     const size_t leaves = *n_leaves;

@@ -25,6 +25,7 @@ PTR_HOST, PTR_DEVICE = 0, 1
 # every symbol include/zkw.h declares: (name, restype, argtypes)
 _vp, _sz, _u32, _u64p, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_int
 SYMBOLS = [
+    ("zkw_process_init", _int, []),
     ("zkw_create", _vp, [_int]),
     ("zkw_destroy", None, [_vp]),
     ("zkw_last_error", C.c_char_p, []),
@@ -160,7 +161,10 @@ SYMBOLS = [
     ("zkw_shard_lpt", _int, [_vp, _sz, _int, _vp]),
     ("zkw_comm_unique_id", _int, [_vp]),
     ("zkw_comm_init", _int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
+    ("zkw_comm_init_tcp", _int, [_vp, C.c_char_p, _int, _int, _int, _int, C.POINTER(_vp)]),
     ("zkw_comm_destroy", None, [_vp]),
+    ("zkw_comm_synchronize", _int, [_vp]),
+    ("zkw_gather_records", _int, [_vp, _vp, _sz, _vp, _sz, _int, _vp]),
     ("zkw_gather_closed_form_inputs", _int, [_vp, _vp, _vp, _sz, _int, _vp]),
     ("zkw_block_run", _int, [_int, _vp, C.POINTER(_vp)]),
     ("zkw_blocks_run", _int, [_int, _vp, _sz, _vp]),
@@ -1658,6 +1662,29 @@ class Comm:
         idbuf = np.frombuffer(unique_id, np.uint8).copy() if unique_id is not None else None
         _check(load().zkw_comm_init(ctx.handle, _np_ptr(idbuf) if idbuf is not None else None, rank, world, C.byref(self.handle)))
         self.ctx, self.rank, self.world = ctx, rank, world
+
+    @classmethod
+    def tcp(cls, ctx, address, port, rank, world, timeout_ms=30000):
+        """zkw_comm_init_tcp: the same collective over sockets; ctx=None -> host-memory communicator (needs no GPU)"""
+        self = cls.__new__(cls)
+        self.handle = C.c_void_p(None)
+        _check(load().zkw_comm_init_tcp(ctx.handle if ctx is not None else None, address.encode(), port, rank, world, timeout_ms, C.byref(self.handle)))
+        self.ctx, self.rank, self.world = ctx, rank, world
+        return self
+
+    def synchronize(self):
+        _check(load().zkw_comm_synchronize(self.handle))
+
+    def gather_records(self, owner, mine, root=0):
+        """zkw_gather_records: owner[n] (zkw_shard_lpt), mine = this rank's records [k][w] u64 in list order (host);
+        returns the n records in list order on the root, None elsewhere"""
+        owner = np.ascontiguousarray(owner, dtype=np.uint32)
+        mine = np.ascontiguousarray(mine, dtype=np.uint64)
+        assert mine.ndim == 2 and mine.shape[0] == int((owner == self.rank).sum())
+        out = np.zeros((owner.size, mine.shape[1]), np.uint64) if self.rank == root else None
+        _check(load().zkw_gather_records(self.handle, _np_ptr(owner) if owner.size else None, owner.size, _np_ptr(mine) if mine.size else None,
+                                         mine.shape[1] * 8, root, _np_ptr(out) if out is not None and out.size else None))
+        return out
 
     def gather(self, records_dev_ptr, counts, record_bytes, root, recv_dev_ptr):
         cnt = np.ascontiguousarray(counts, dtype=np.uint64)

@@ -49,6 +49,10 @@ enum {
 enum { ZKW_PTR_HOST = 0, ZKW_PTR_DEVICE = 1 };
 
 /* ---- context ------------------------------------------------------------------------------------ */
+/* Optional, once per process, BEFORE the process's first HIP call: process-wide settings the block sequencer's scheduling
+   relies on (today: GPU_MAX_HW_QUEUES=8 unless the host exported a value; csrc/zkw_block.hip explains the number). The
+   library changes nothing in the process environment unless this is called. */
+int zkw_process_init(void);
 /* device_id >= 0. Returns NULL on failure (see zkw_last_error). */
 zkw_ctx *zkw_create(int device_id);
 /* deferred while witnesses / traces created from ctx are outstanding (see "lifetimes" above) */
@@ -712,7 +716,8 @@ int zkw_vm_slice_instances(zkw_ctx *ctx, const zkw_vm_tracer_streams *streams, z
    sharded with no data-path collective; the only exchange is the gather of the per-instance closed-form records to the
    root, which replays the order-sensitive recursion-queue pushes (src/witness/postprocessing/mod.rs:396-402,
    src/external_calls.rs:354-537). The transport is RCCL (xGMI inside a node), loaded with dlopen when a communicator
-   of more than one rank is created. */
+   of more than one rank is created; a TCP transport (zkw_comm_init_tcp) runs the same collective between processes that
+   have no GPU (tests) or where RCCL cannot start. */
 /* owner[i] = rank of instance i: longest-processing-time over the rows the reference's synthesis of each circuit type
    uses (setup/base_layer/finalization_hint_N.json). Deterministic; needs no GPU. circuit_types: 1..13. */
 int zkw_shard_lpt(const uint8_t *circuit_types, size_t n, int world, uint32_t *owner);
@@ -722,11 +727,23 @@ typedef struct zkw_comm zkw_comm;
 int zkw_comm_unique_id(uint8_t id[ZKW_COMM_ID_BYTES]);
 /* collective over all ranks (ncclCommInitRank); world == 1 needs no id and no RCCL. Work runs on ctx's stream. */
 int zkw_comm_init(zkw_ctx *ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, zkw_comm **out);
+/* the same communicator over a full mesh of TCP sockets: rank j connects to every rank i < j at address:(port + i).
+   ctx == NULL: a host-memory communicator (records / recv of zkw_gather_closed_form_inputs are HOST pointers; needs no GPU);
+   ctx != NULL: device pointers, staged through host memory. timeout_ms <= 0: 30 s. Collective over all ranks. */
+int zkw_comm_init_tcp(zkw_ctx *ctx, const char *address, int port, int rank, int world, int timeout_ms, zkw_comm **out);
 void zkw_comm_destroy(zkw_comm *c);
+/* everything this communicator has enqueued so far has completed (its context's stream, for the device transports) */
+int zkw_comm_synchronize(zkw_comm *c);
 /* counts[r] (host, every rank passes the same array) records of record_bytes each from rank r, concatenated in rank
-   order into recv on `root` (NULL elsewhere). records / recv: DEVICE pointers. Enqueued on the stream; not synchronised. */
+   order into recv on `root` (NULL elsewhere). records / recv: DEVICE pointers (HOST pointers on a context-less TCP
+   communicator). Enqueued on the stream; not synchronised (zkw_comm_synchronize). */
 int zkw_gather_closed_form_inputs(zkw_comm *c, const void *records, const uint64_t *counts, size_t record_bytes, int root,
                                   void *recv);
+
+/* The gather as a sequencer uses it. Every rank passes the same owner[n] (zkw_shard_lpt over the ordered instance list) and
+   `mine` = the records of ITS instances in list order (HOST memory, record_bytes each); the root receives all n records in
+   list (= emission) order in out (HOST, n * record_bytes; NULL elsewhere). Synchronous on every rank. */
+int zkw_gather_records(zkw_comm *c, const uint32_t *owner, size_t n, const void *mine, size_t record_bytes, int root, void *out);
 
 /* ---- one block: the post-VM half of create_artifacts_from_tracer (a19) ----------------------------------------- */
 /* Counterpart of src/witness/oracle.rs:928-1130 + 1494-1732 (everything `create_artifacts_from_tracer` does after the

@@ -5,9 +5,10 @@
 #include <string.h>
 
 static void full_queue_state(const uint64_t *tails, size_t k_plus_one, zkw_queue_state12 *st) {
-    /* transform_sponge_like_queue_state(all_*_queue_states[k]) (src/witness/utils.rs:73-85): head = the tail before item k */
+    /* transform_sponge_like_queue_state(all_*_queue_states[k]) (src/witness/utils.rs:73-85) copies the intermediate state's
+       `head`, which push_and_output_intermediate_data fills with the simulator's own head (circuit_encodings/src/lib.rs:419-421):
+       the memory and decommitment simulators only ever push, so it stays the initial all-zero head */
     memset(st, 0, sizeof *st);
-    if (k_plus_one >= 2) memcpy(st->head, tails + 12 * (k_plus_one - 2), 96);
     if (k_plus_one >= 1) memcpy(st->tail, tails + 12 * (k_plus_one - 1), 96);
     st->length = (uint32_t)k_plus_one;
 }

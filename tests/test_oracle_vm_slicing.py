@@ -47,7 +47,8 @@ def test_vm_slicing_matches_iterator_restatement(oracle, seed, first):
         m = d["mem_entry"]
         assert int(a["memory_queue_state"]["length"]) == m
         assert np.array_equal(a["memory_queue_state"]["tail"], tails[m - 1] if m else np.zeros(12, np.uint64))
-        assert np.array_equal(a["memory_queue_state"]["head"], tails[m - 2] if m >= 2 else np.zeros(12, np.uint64))
+        # head = the push-only simulator's head (lib.rs:419-421 `head: self.head`), never a previous tail
+        assert not a["memory_queue_state"]["head"].any() and not a["decommittment_queue_state"]["head"].any()
         dq = d["dec_entry"]
         assert int(a["decommittment_queue_state"]["length"]) == dq
         assert np.array_equal(a["decommittment_queue_state"]["tail"], t["decommit_queue_tails"][dq - 1] if dq else np.zeros(12, np.uint64))
