@@ -44,6 +44,13 @@ SYMBOLS = [
     ("zkw_setup_copy_permutation", _int, [C.c_uint8, C.c_uint32, _sz, _vp, _vp]),
     ("zkw_check_copy_permutation", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _vp]),
     ("zkw_setup_row_selectors", _int, [C.c_uint8, C.c_uint32, _sz, _vp]),
+    ("zkw_vm_trace_build", _int, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(_vp)]),
+    ("zkw_vm_trace_count", _sz, [_vp, _int]),
+    ("zkw_vm_trace_ptr", _vp, [_vp, _int]),
+    ("zkw_vm_trace_get", _int, [_vp, _int, _vp, _sz]),
+    ("zkw_vm_trace_info", _int, [_vp, _vp]),
+    ("zkw_vm_trace_streams", _int, [_vp, _vp]),
+    ("zkw_vm_trace_free", None, [_vp]),
     ("zkw_recursion_queue_split", _int, [_vp, _sz, C.c_uint32, _vp, _sz, _vp]),
     ("zkw_vk_commitment", _int, [_vp, _vp, _sz, _vp]),
     ("zkw_compute_leaf_params", _int, [_vp, C.c_uint8, _vp, _vp, _sz, _vp]),
@@ -1295,6 +1302,75 @@ def vm_slice_instances(ctx, tracer):
     nr, nw = C.c_uint64(0), C.c_uint64(0)
     _check(load().zkw_vm_slice_instances(ctx.handle, C.byref(st), _np_ptr(inst), _np_ptr(ri), _np_ptr(wi), C.byref(nr), C.byref(nw)))
     return inst, ri[:nr.value], wi[:nw.value]
+
+VM_EVENT = np.dtype([("kind", "<u4"), ("cycle", "<u4"), ("panicked", "<u4"), ("index", "<u4")])
+VM_TRACE_SUMMARY = np.dtype([("n_flat", "<u8"), ("original_log_queue_length", "<u8"), ("n_frames", "<u8"),
+                             ("global_end_of_storage_log", "<u8", 4), ("original_log_queue_tail", "<u8", 4)])
+_VMT = {"flat_queries": (0, None), "flat_cycles": (1, np.uint32), "flat_frames": (2, np.uint32), "flat_old_tails": (3, (np.uint64, 4)),
+        "flat_new_tails": (4, (np.uint64, 4)), "new_frame_tail_cycles": (5, np.uint32), "new_frame_tails": (6, (np.uint64, 4)),
+        "head_segment_cycles": (7, np.uint32), "head_segments": (8, (np.uint64, 4)), "storage_log_state_cycles": (9, np.uint32),
+        "storage_log_state_frames": (10, np.uint32), "storage_log_states": (11, None), "callstack_witness_cycles": (12, np.uint32),
+        "callstack_witness_is_push": (13, np.uint8), "callstack_witness_entries": (14, None),
+        "callstack_witness_previous_states": (15, (np.uint64, 12)), "callstack_witness_new_states": (16, (np.uint64, 12)),
+        "callstack_witness_depths": (17, np.uint32), "callstack_witness_round_states": (18, (np.uint64, 48)),
+        "callstack_sponge_cycles": (19, np.uint32), "callstack_sponge_states": (20, (np.uint64, 12)), "new_frame_cycles": (21, np.uint32),
+        "new_frame_entries": (22, None)}
+
+
+class VmTrace:
+    """zkw_vm_trace: the pre-builder half of create_artifacts_from_tracer (callstack_handler.rs:174-460, oracle.rs:233-843)
+    over the tracer's raw record (synthetic.vm_events shapes)."""
+
+    def __init__(self, ctx, events, log_queries, entries):
+        ev = np.ascontiguousarray(events, dtype=VM_EVENT)
+        q = np.ascontiguousarray(log_queries, dtype=LOG_QUERY)
+        e = np.ascontiguousarray(entries, dtype=CALLSTACK_ENTRY)
+        self.handle = C.c_void_p(None)
+        _check(load().zkw_vm_trace_build(ctx.handle, _np_ptr(ev) if ev.size else None, ev.size, _np_ptr(q) if q.size else None, q.size,
+                                         _np_ptr(e) if e.size else None, e.size, C.byref(self.handle)))
+
+    def get(self, name):
+        what, kind = _VMT[name]
+        n = load().zkw_vm_trace_count(self.handle, what)
+        if kind is None:
+            dt = {0: LOG_QUERY, 11: STORAGE_LOG_DETAILED_STATE, 14: CALLSTACK_ENTRY, 22: CALLSTACK_ENTRY}[what]
+            out = np.zeros(n, dt)
+        elif isinstance(kind, tuple):
+            out = np.zeros((n, kind[1]), kind[0])
+        else:
+            out = np.zeros(n, kind)
+        _check(load().zkw_vm_trace_get(self.handle, what, _np_ptr(out) if out.size else None, out.nbytes))
+        return out
+
+    def info(self):
+        out = np.zeros(1, VM_TRACE_SUMMARY)
+        _check(load().zkw_vm_trace_info(self.handle, _np_ptr(out)))
+        return out[0]
+
+    def tracer_streams(self, vm_streams):
+        """the dict zkw_vm_slice_instances takes: `vm_streams` (the VM's own streams, synthetic.vm_tracer_streams keys) with the
+        four FIFOs and the histories this trace produced put in"""
+        t = dict(vm_streams)
+        sc = list(t["stream_cycles"])
+        sc[4], sc[5], sc[6], sc[7] = (self.get("new_frame_tail_cycles"), self.get("callstack_witness_cycles"), self.get("head_segment_cycles"),
+                                      self.get("new_frame_cycles"))
+        t["stream_cycles"] = sc
+        t["callstack_sponge_cycles"], t["callstack_sponge_states"] = self.get("callstack_sponge_cycles"), self.get("callstack_sponge_states")
+        t["storage_log_state_cycles"], t["storage_log_states"] = self.get("storage_log_state_cycles"), self.get("storage_log_states")
+        t["global_end_of_storage_log"] = self.info()["global_end_of_storage_log"].copy()
+        return t
+
+    def free(self):
+        if self.handle:
+            load().zkw_vm_trace_free(self.handle)
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
 
 # ---- one block (zkw_block_run): the post-VM half of create_artifacts_from_tracer inside the library ------------------
 STORAGE_TREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)

@@ -531,3 +531,65 @@ def vm_tracer_streams(n_cycles=3000, cycles_per_snapshot=400, seed=0, n_memory=2
             "decommit_state_cycles": dec_c, "decommit_queue_tails": felts((dec_c.size, 12)), "callstack_sponge_cycles": cs_c,
             "callstack_sponge_states": felts((cs_c.size, 12)), "storage_log_state_cycles": sl_c, "storage_log_states": sl,
             "global_end_of_storage_log": felts(4)}
+
+
+VM_EVENT = np.dtype([("kind", "<u4"), ("cycle", "<u4"), ("panicked", "<u4"), ("index", "<u4")])
+
+
+def vm_events(n_events=400, seed=0, max_depth=12, p_panic=0.3, p_log=0.6, first_cycle=1024):
+    """What WitnessTracer hands CallstackWithAuxData over one block (src/witness/tracer.rs:221-407 ->
+    callstack_handler.rs:174-460), as plain arrays: events in time order (kind 0 = log query, 1 = far/near call pushing a
+    frame, 2 = ret / panic popping one), one event per VM cycle; log_queries[index] for kind 0 (storage reads / writes on
+    shard 0, events, L2->L1 messages, precompile calls; unique increasing timestamps, rollback = 0); entries[2 * index] =
+    the caller's frame as saved, entries[2 * index + 1] = the new frame, for kind 1. The trace starts with the bootloader
+    frame's push (from_initial_callstack) and unwinds every frame at the end, some of them by panics, so that nested
+    reverts of reverted frames occur."""
+    from .native import CALLSTACK_ENTRY, LOG_QUERY
+
+    rng = np.random.default_rng(seed)
+    ev, depth, cycle = [], 0, first_cycle
+    n_log = n_push = 0
+
+    def emit(kind, panicked=0, index=0):
+        nonlocal cycle
+        ev.append((kind, cycle, panicked, index))
+        cycle += int(rng.integers(1, 4))
+
+    emit(1, 0, 0)
+    n_push, depth = 1, 1
+    for _ in range(n_events):
+        r = rng.random()
+        if r < p_log:
+            emit(0, 0, n_log)
+            n_log += 1
+        elif depth < max_depth and (depth == 1 or rng.random() < 0.55):
+            emit(1, 0, n_push)
+            n_push += 1
+            depth += 1
+        elif depth > 1:
+            emit(2, int(rng.random() < p_panic), 0)
+            depth -= 1
+    while depth:
+        emit(2, int(depth > 1 and rng.random() < p_panic), 0)
+        depth -= 1
+    events = np.array(ev, VM_EVENT)
+    q = random_log_queries(max(n_log, 1), seed=seed + 7)[:n_log]
+    kind = rng.integers(0, 10, n_log)
+    q["rollback"] = 0
+    q["timestamp"] = 1024 + 4 * np.arange(n_log, dtype=np.uint32)
+    q["shard_id"] = 0
+    q["aux_byte"] = np.select([kind < 5, kind < 7, kind < 9], [0, 1, 2], 3).astype(np.uint8)  # storage, event, L1 message, precompile
+    q["rw_flag"] = np.where(q["aux_byte"] == 0, rng.integers(0, 2, n_log), np.where(q["aux_byte"] == 3, 0, 1)).astype(np.uint8)
+    pre = q["aux_byte"] == 3
+    q["address"][pre] = 0
+    q["address"][pre, 0] = np.array([0x8010, 0x02, 0x01, 0x7777], np.uint32)[rng.integers(0, 4, int(pre.sum()))]  # keccak, sha256, ecrecover, other
+    e = np.zeros(2 * n_push, CALLSTACK_ENTRY)
+    raw = rng.integers(0, 256, (2 * n_push, CALLSTACK_ENTRY.itemsize), dtype=np.uint8)
+    e[:] = raw.view(CALLSTACK_ENTRY).reshape(2 * n_push)
+    e["rollback_queue_head"] = 0  # filled by the replay (ExtendedCallstackEntry, oracle.rs:648-653)
+    e["rollback_queue_tail"] = 0
+    e["rollback_queue_segment_length"] = 0
+    e["is_static"] &= 1
+    e["is_local_frame"] &= 1
+    e["_pad"] = 0
+    return events, q, e

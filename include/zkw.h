@@ -711,6 +711,51 @@ int zkw_ram_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint3
 int zkw_vm_slice_instances(zkw_ctx *ctx, const zkw_vm_tracer_streams *streams, zkw_vm_instance *instances,
                            uint32_t *memory_read_index, uint32_t *memory_write_index, uint64_t *n_reads, uint64_t *n_writes);
 
+/* ---- a19, pre-builder half: the tracer's raw record -> log queue with rollbacks, callstack replay ----------------------
+   Counterpart of src/witness/callstack_handler.rs:174-460 (forward / rollback queues per frame, glued on `ret`, the rollback
+   queue appended in reverse to the parent's forward queue on a panic) and src/witness/oracle.rs:233-843 (the flat queue
+   hashed through one LogQueueSimulator, marker positions, rollback tails of new frames, rollback head segments, the
+   storage-log state per cycle, the callstack entries with their rollback segments pushed / popped through the
+   CallstackSimulator). events: time order, events[0] = the bootloader frame's push (from_initial_callstack), every frame
+   popped at the end. HOST arrays; ctx in ZKW_PTR_HOST mode. The reference's panics are ZKW_ERR_CHECK_FAILED. */
+typedef struct zkw_vm_trace zkw_vm_trace;
+int zkw_vm_trace_build(zkw_ctx *ctx, const zkw_vm_event *events, size_t n_events, const zkw_log_query *log_queries, size_t n_logs,
+                       const zkw_callstack_entry *entries, size_t n_entries, zkw_vm_trace **out);
+enum {
+    ZKW_VMT_FLAT_QUERIES = 0,           /* zkw_log_query[n_flat]: the flat queue, rollback twins with rollback = 1; the first
+                                           original_log_queue_length items are the block's log queue (the demuxer's input) */
+    ZKW_VMT_FLAT_CYCLES = 1,            /* uint32_t[n_flat] */
+    ZKW_VMT_FLAT_FRAMES = 2,            /* uint32_t[n_flat]: the frame that issued the query */
+    ZKW_VMT_FLAT_OLD_TAILS = 3,         /* uint64_t[n_flat][4]: chain_of_states previous_tail */
+    ZKW_VMT_FLAT_NEW_TAILS = 4,         /* uint64_t[n_flat][4]: chain_of_states tail */
+    ZKW_VMT_NEW_FRAME_TAIL_CYCLES = 5,  /* rollback_queue_initial_tails_for_new_frames: uint32_t[n_frames] ...          */
+    ZKW_VMT_NEW_FRAME_TAILS = 6,        /* ... uint64_t[n_frames][4]                                                   */
+    ZKW_VMT_HEAD_SEGMENT_CYCLES = 7,    /* rollback_queue_head_segments: ascending cycles ... */
+    ZKW_VMT_HEAD_SEGMENTS = 8,          /* ... uint64_t[][4] */
+    ZKW_VMT_STORAGE_LOG_STATE_CYCLES = 9,   /* history_of_storage_log_states: strictly ascending cycles ... */
+    ZKW_VMT_STORAGE_LOG_STATE_FRAMES = 10,  /* ... frame_idx ... */
+    ZKW_VMT_STORAGE_LOG_STATES = 11,        /* ... zkw_storage_log_detailed_state[] */
+    ZKW_VMT_CALLSTACK_WITNESS_CYCLES = 12,  /* callstack_values_witnesses: one per push and per pop ... */
+    ZKW_VMT_CALLSTACK_WITNESS_IS_PUSH = 13, /* uint8_t[] */
+    ZKW_VMT_CALLSTACK_WITNESS_ENTRIES = 14, /* zkw_callstack_entry[] (ExtendedCallstackEntry: with the rollback segment) */
+    ZKW_VMT_CALLSTACK_WITNESS_PREVIOUS_STATES = 15, /* uint64_t[][12] */
+    ZKW_VMT_CALLSTACK_WITNESS_NEW_STATES = 16,      /* uint64_t[][12] */
+    ZKW_VMT_CALLSTACK_WITNESS_DEPTHS = 17,          /* uint32_t[] */
+    ZKW_VMT_CALLSTACK_WITNESS_ROUND_STATES = 18,    /* uint64_t[][4][12] */
+    ZKW_VMT_CALLSTACK_SPONGE_CYCLES = 19,   /* callstack_sponge_encoding_ranges: (0, zero) first ... */
+    ZKW_VMT_CALLSTACK_SPONGE_STATES = 20,   /* ... uint64_t[][12] */
+    ZKW_VMT_NEW_FRAME_CYCLES = 21,          /* flat_new_frames_history ... */
+    ZKW_VMT_NEW_FRAME_ENTRIES = 22          /* ... zkw_callstack_entry[] */
+};
+size_t zkw_vm_trace_count(const zkw_vm_trace *t, int what);
+const void *zkw_vm_trace_ptr(const zkw_vm_trace *t, int what); /* host memory, valid until zkw_vm_trace_free */
+int zkw_vm_trace_get(const zkw_vm_trace *t, int what, void *dst, size_t dst_bytes);
+int zkw_vm_trace_info(const zkw_vm_trace *t, zkw_vm_trace_summary *out);
+/* points the four FIFOs (streams 4-7) and the callstack-sponge / storage-log-state histories of `s` at this trace's arrays
+   (host): with the VM's own streams added, `s` is the input of zkw_vm_slice_instances — the VmWitnessOracle FIFOs end to end */
+int zkw_vm_trace_streams(const zkw_vm_trace *t, zkw_vm_tracer_streams *s);
+void zkw_vm_trace_free(zkw_vm_trace *t);
+
 /* ---- multi-GPU (8e): shard plan and the one collective ------------------------------------------------------- */
 /* One process per GPU. Instances are independent once the builders have fixed their hidden FSM inputs, so they are
    sharded with no data-path collective; the only exchange is the gather of the per-instance closed-form records to the

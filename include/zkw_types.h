@@ -483,6 +483,27 @@ typedef struct zkw_storage_log_detailed_state {
     uint32_t rollback_length;
 } zkw_storage_log_detailed_state;
 
+/* ---- the tracer's raw record of one block (a19, pre-builder half): what WitnessTracer feeds CallstackWithAuxData
+   (src/witness/tracer.rs:221-407 -> src/witness/callstack_handler.rs:174-460), in time order --------------------------- */
+enum {
+    ZKW_VME_LOG = 0,  /* add_log_query(cycle, log_queries[index])                                   callstack_handler.rs:348 */
+    ZKW_VME_PUSH = 1, /* push_entry(cycle, entries[2 * index] = the caller as saved, entries[2 * index + 1] = the new frame) :174 */
+    ZKW_VME_POP = 2   /* pop_entry(cycle, panicked)                                                                        :224 */
+};
+typedef struct zkw_vm_event {
+    uint32_t kind;
+    uint32_t cycle; /* monotonic_cycle_counter */
+    uint32_t panicked;
+    uint32_t index;
+} zkw_vm_event;
+typedef struct zkw_vm_trace_summary {
+    uint64_t n_flat;                    /* forward ++ reverse(rollback) of the root frame */
+    uint64_t original_log_queue_length; /* its applied prefix = original_log_queue_simulator (oracle.rs:322-330): what the demuxer gets */
+    uint64_t n_frames;                  /* monotonic_frame_counter */
+    uint64_t global_end_of_storage_log[4];
+    uint64_t original_log_queue_tail[4];
+} zkw_vm_trace_summary;
+
 /* VmInCircuitAuxilaryParameters, src/witness/oracle.rs:98-108 (the CallStackEntry of callstack_state travels with the
    VmLocalState snapshot the instance points at) */
 typedef struct zkw_vm_aux_parameters {
