@@ -27,6 +27,51 @@ def _state12(tail, length):
     return s
 
 
+def create_artifacts_after_vm_concurrent(block, capacities=None, threads=8):
+    """The same builders as create_artifacts_after_vm on concurrent host threads, the way a CPU implementation with a thread
+    pool would run them (the C oracle releases the GIL): decommit sorter || the VM's memory-queue chain || log demuxer first;
+    the code decommitter and the precompile builders then extend the memory queue one after the other (its hash chain is
+    serial); the RAM permutation, the storage / events / L1 sorters and the hasher run beside them as soon as their inputs
+    exist. Used by bench.py's full-block leg so that the GPU's dependency-graph sequencer is compared with a CPU side that
+    is also concurrent, not with a sequential one. Returns (artifacts-lite dict, wall seconds)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    cap = dict(DEFAULT_CAPACITY)
+    cap.update(capacities or {})
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        f_dec = ex.submit(o.decommit_sorter_build, block["decommit_queries"], cap[DECOMMITS_SORTER])
+        vm_mem = np.ascontiguousarray(block["vm_memory_queries"], dtype=o.MEM_QUERY)
+        f_vm = ex.submit(lambda: o.queue_push_chain_full(o.encode_memory_queries(vm_mem)))
+        f_dmx = ex.submit(o.log_demux_build, block["log_queries"], cap[LOG_DEMUXER])
+        dec = f_dec.result()
+        codes = [np.ascontiguousarray(block["bytecodes"][h.tobytes()], dtype=np.uint32).reshape(-1, 8) for h in dec["dedup_q"]["hash"]]
+        woff = np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]).astype(np.uint64)
+        dmx = f_dmx.result()
+        off = dmx["out_offsets"].astype(np.int64)
+        queue = lambda k: (dmx["out_q"][off[k]:off[k + 1]], dmx["out_new_tails"][off[k]:off[k + 1]])  # noqa: E731
+        f_sto = ex.submit(o.storage_sorter_build, queue(0)[0], cap[STORAGE_SORTER])
+        f_evs = ex.submit(o.events_sorter_build, queue(1)[0], cap[EVENTS_SORTER])
+        f_l1 = ex.submit(lambda: (lambda l1s: (l1s, o.linear_keccak256(l1s["result_q"])))(o.events_sorter_build(queue(2)[0], cap[L1_MESSAGES_SORTER])))
+        vm_tails = f_vm.result()
+        mem_state = _state12(vm_tails[-1] if vm_mem.size else None, vm_mem.size)
+        dcm = o.decommitter_build(dec["dedup_q"], dec["dedup_tails"], np.concatenate(codes), woff, cap[CODE_DECOMMITTER], mem_state)
+        memory = [vm_mem, dcm["mem_q"]] + [np.ascontiguousarray(m, dtype=o.MEM_QUERY) for m in block["precompile_memory_queries"]]
+        f_ram = ex.submit(o.ram_build_instances, np.concatenate(memory), cap[RAM_PERMUTATION], 0)  # contents only: no hash of the chain above is needed
+        mem_state = _state12(dcm["mem_tails"][-1], int(mem_state["length"][0]) + dcm["mem_q"].size)
+        pre = []
+        for k, ctype in enumerate((KECCAK256, SHA256, ECRECOVER)):
+            req, req_tails = queue(3 + k)
+            mq = np.ascontiguousarray(block["precompile_memory_queries"][k], dtype=o.MEM_QUERY)
+            w = o.precompile_build(k, req, req_tails, mq, cap[ctype], mem_state)
+            pre.append(w)
+            if mq.size:
+                mem_state = _state12(w["mem_tails"][-1], int(mem_state["length"][0]) + mq.size)
+        out = {"decommits_sorter": dec, "code_decommitter": dcm, "log_demuxer": dmx, "precompiles": pre, "ram_permutation": f_ram.result(),
+               "storage_sorter": f_sto.result(), "events_sorter": f_evs.result(), "l1": f_l1.result()}
+    return out, time.perf_counter() - t0
+
+
 def create_artifacts_after_vm(block, capacities=None, storage_tree=None, timings=None):
     """Returns a dict of the builders' outputs, public inputs per circuit type (for the types that have an encoder) and
     one recursion queue per type. `storage_tree`: an oracle.Tree holding the pre-block state (mutated), or None.
