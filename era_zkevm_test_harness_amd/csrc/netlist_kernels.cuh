@@ -1,0 +1,511 @@
+// netlist_kernels.cuh — synthesis and satisfiability check of the netlist circuits in "zkw trace v4" (include/zkw_netlist.h,
+// tools/netlist.py): Sha256RoundFunction (6), CodeDecommitter (3), Keccak256RoundFunction (5), L1MessagesHasher (13) on the
+// REFERENCE's geometry and lookup-table sets (wrappers circuit_definitions/src/circuit_definitions/base_layer/
+// {sha256_round_function,code_decommitter,keccak256_round_function,linear_hasher}.rs:28-39 + add_tables), ONE multiplicity
+// column. One set of kernels for the four circuits, driven by the generated specs (include/zkw_*_circuit_spec.h); the
+// circuit bodies are in the absent era-zkevm_circuits crate, so the placement is this library's own.
+//
+// Fill (k_nl_fill): a WAVE owns a cycle. The workgroup stages the netlists of all step types in LDS once (lanes index them
+// with different values); a wave then walks its cycle's steps: the items of a step level by level with no workgroup barrier
+// (a wave's LDS operations execute in order), every value a reference can name in ONE byte array per wave, and streams the
+// step's rows out lane <-> row — all general-purpose and lookup cells of the rows, so nothing above the boundary needs a
+// memset. Multiplicities are a pass of their own over 16-bit keys the fill leaves behind (k_nl_hist: a table's bins in LDS).
+#pragma once
+#include "../../include/zkw_netlist.h"
+#include "../../include/zkw_sha256_circuit_spec.h"
+#include "../../include/zkw_code_decommitter_circuit_spec.h"
+#include "../../include/zkw_keccak_circuit_spec.h"
+#include "../../include/zkw_linear_hasher_circuit_spec.h"
+#include "../../include/zkw_types.h"
+#include "ram_circuit_kernels.cuh"  // CheckResult, flag_bad
+
+namespace zkw {
+
+__device__ __forceinline__ void store_streaming(u64* cell, u64 v) { __builtin_nontemporal_store(v, cell); }
+
+// host copies of the four specs (launch sizing, setup side) ...
+NL_DEFINE_SPEC(h_sc, SC);
+NL_DEFINE_SPEC(h_dc, DC);
+NL_DEFINE_SPEC(h_kc, KC);
+NL_DEFINE_SPEC(h_lh, LH);
+static inline const nl_spec* nl_host_spec(int circuit_type) {
+    switch (circuit_type) {
+        case 6: return &h_sc_spec;
+        case 3: return &h_dc_spec;
+        case 5: return &h_kc_spec;
+        case 13: return &h_lh_spec;
+        default: return nullptr;
+    }
+}
+
+// ---- what the kernels get: the spec with DEVICE pointers plus tables derived from it on the host
+struct NlHistEntry { u32 step, r0, r1, key0, lookup_rows; };  // rows [r0, r1) of the lookup rows of cycle step `step` hold this table
+struct NlDev {
+    nl_spec s;                   // pointers are device pointers
+    const uint16_t* cellmap;     // [step type: cell0 + col * rows + row] dense reference of the general-purpose cell, 0xFFFF = empty
+    const u32* cell0;            // [step type]
+    const u32* step_key0;        // [cycle step]: offset of the step's keys inside a cycle's keys
+    u32 keys_per_cycle;
+    const NlHistEntry* hist_entries;
+    const u32* hist_first;       // [n_tables + 1]: table t's entries
+    const u32* hist_slice0;      // [n_tables + 1]: table t owns histogram slices [slice0[t], slice0[t + 1])
+    u32 n_hist_slices;
+    u32 max_items;               // max over step types of n_ops + n_gates + rows (the checker's grid)
+    u32 vsize;                   // bytes of a wave's value array
+    u32 lds_bytes;               // dynamic LDS of k_nl_fill
+};
+struct NlJob {
+    const uint8_t* hdr_bits;      // [capacity]: bit 0 reset, bit 1 idle
+    const uint8_t* free_elems;    // [capacity][free_per_cycle]
+    const uint8_t* state_before;  // [capacity + 1][state]
+    const u64* public_input;      // [4]
+    u64* trace;                   // [cols][n_rows]
+    uint16_t* keys;               // [capacity][keys_per_cycle]
+};
+
+constexpr int NL_FILL_WAVES = 4;
+constexpr int NL_FILL_THREADS = 64 * NL_FILL_WAVES;
+
+// layout of a wave's value array: [values | header 4 | prev state | cycle state | free | rc 8 | constants 256]
+struct NlV {
+    u32 hdr, prev, cyc, fre, rc, con, size;
+    __host__ __device__ NlV(const nl_spec& s) {
+        hdr = s.max_values;
+        prev = hdr + 4;
+        cyc = prev + s.state;
+        fre = cyc + s.state;
+        rc = fre + s.max_free;
+        con = rc + 8;
+        size = (con + 256 + 15) & ~15u;
+    }
+    __host__ __device__ uint16_t dense(u32 ref) const {
+        return (uint16_t)(ref < NL_REF_HDR ? ref : ref < NL_REF_PREV ? hdr + (ref - NL_REF_HDR) : ref < NL_REF_CYC ? prev + (ref - NL_REF_PREV)
+                          : ref < NL_REF_FREE ? cyc + (ref - NL_REF_CYC) : ref < NL_REF_RC ? fre + (ref - NL_REF_FREE)
+                          : ref < NL_REF_CONST ? rc + (ref - NL_REF_RC) : con + (ref - NL_REF_CONST));
+    }
+};
+
+struct NlLdsGate { uint16_t first_term, row, col; uint8_t n_known, n_new; u32 constant; };
+// LDS carve of k_nl_fill, the same arithmetic on the host (lds_bytes) and in the kernel
+struct NlLds {
+    u32 tab, types, cyc, op_table, op_in, op_out, gates, term_ref, term_code, hints, order, level, out, waves, total;
+    __host__ __device__ NlLds(const nl_spec& s, u32 vsize) {
+        u32 at = 0;
+        auto take = [&](u32 bytes) { u32 r = at; at = (at + bytes + 15) & ~15u; return r; };
+        tab = take(s.n_tables * sizeof(nl_table));
+        types = take(s.n_step_types * sizeof(nl_step_type));
+        cyc = take(s.steps_per_cycle * sizeof(nl_cycle_step));
+        op_table = take(s.n_ops);
+        op_in = take(s.n_ops * 6);
+        op_out = take(s.n_ops * 2);
+        gates = take(s.n_gates * sizeof(NlLdsGate));
+        term_ref = take(s.n_terms * 2);
+        term_code = take(s.n_terms);
+        hints = take((s.n_hints ? s.n_hints : 1) * sizeof(nl_hint));
+        order = take(s.n_order * 2);
+        level = take(s.n_level_starts * 2);
+        out = take(s.n_step_types * s.state * 2);
+        waves = take(NL_FILL_WAVES * vsize);
+        total = at;
+    }
+};
+
+#define NL_TR(col, row) job.trace[(size_t)(col) * n_rows + (size_t)(row)]
+#define NL_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+__device__ __forceinline__ void nl_eval_sel(u32 fn, u32 k, u32 a0, u32 a1, u32 a2, u32& o0, u32& o1, u32& o2) {
+    // selects, not branches: the lanes of a level hold lookups of several tables
+    const u32 lo = a0 & ((1u << k) - 1), hi = a0 >> k;
+    u32 r0 = a0 ^ a1;                                       // XOR8
+    r0 = fn == NL_FN_AND8 ? (a0 & a1) : r0;
+    r0 = fn == NL_FN_TRIXOR4 ? (a0 ^ a1 ^ a2) : r0;
+    r0 = fn == NL_FN_CH4 ? ((a0 & a1) ^ (~a0 & a2 & 15u)) : r0;
+    r0 = fn == NL_FN_MAJ4 ? ((a0 & a1) ^ (a0 & a2) ^ (a1 & a2)) : r0;
+    const bool split = fn == NL_FN_BYTESPLIT || fn == NL_FN_SPLIT4;
+    o0 = split ? lo : r0;
+    o1 = split ? hi : 0;
+    o2 = fn == NL_FN_SPLIT4 ? ((lo << (4 - k)) | hi) : 0;
+}
+
+template <int W, int R>
+__global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const NlDev& D = *devp;
+    const nl_spec& S = D.s;
+    const NlJob job = jobs[blockIdx.y];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const NlV V(S);
+    const NlLds L(S, V.size);
+    nl_table* const s_tab = reinterpret_cast<nl_table*>(lds + L.tab);
+    nl_step_type* const s_types = reinterpret_cast<nl_step_type*>(lds + L.types);
+    nl_cycle_step* const s_cyc = reinterpret_cast<nl_cycle_step*>(lds + L.cyc);
+    uint8_t* const s_op_table = lds + L.op_table;
+    uint16_t* const s_op_in = reinterpret_cast<uint16_t*>(lds + L.op_in);  // [3][n_ops]
+    uint16_t* const s_op_out = reinterpret_cast<uint16_t*>(lds + L.op_out);
+    NlLdsGate* const s_gates = reinterpret_cast<NlLdsGate*>(lds + L.gates);
+    uint16_t* const s_term_ref = reinterpret_cast<uint16_t*>(lds + L.term_ref);
+    uint8_t* const s_term_code = lds + L.term_code;
+    nl_hint* const s_hints = reinterpret_cast<nl_hint*>(lds + L.hints);
+    uint16_t* const s_order = reinterpret_cast<uint16_t*>(lds + L.order);
+    uint16_t* const s_level = reinterpret_cast<uint16_t*>(lds + L.level);
+    uint16_t* const s_out = reinterpret_cast<uint16_t*>(lds + L.out);
+    uint8_t* const val = lds + L.waves + wv * V.size;
+    // ---- stage the netlists (references made dense: one LDS read resolves any of them)
+    for (u32 i = t; i < S.n_tables; i += NL_FILL_THREADS) s_tab[i] = S.tables[i];
+    for (u32 i = t; i < S.n_step_types; i += NL_FILL_THREADS) s_types[i] = S.step_types[i];
+    for (u32 i = t; i < S.steps_per_cycle; i += NL_FILL_THREADS) s_cyc[i] = S.cycle[i];
+    for (u32 i = t; i < S.n_ops; i += NL_FILL_THREADS) {
+        const nl_op op = S.ops[i];
+        s_op_table[i] = (uint8_t)op.table;
+        for (int k = 0; k < 3; k++) s_op_in[k * S.n_ops + i] = V.dense(op.in[k]);
+        s_op_out[i] = op.out;
+    }
+    for (u32 i = t; i < S.n_gates; i += NL_FILL_THREADS) {
+        const nl_gate g = S.gates[i];
+        NlLdsGate lg;
+        lg.first_term = (uint16_t)g.first_term; lg.row = g.row; lg.col = g.col;
+        lg.n_known = (uint8_t)g.n_known; lg.n_new = (uint8_t)g.n_new; lg.constant = g.constant;
+        s_gates[i] = lg;
+    }
+    for (u32 i = t; i < S.n_terms; i += NL_FILL_THREADS) { s_term_ref[i] = V.dense(S.terms[i].ref); s_term_code[i] = (uint8_t)S.terms[i].code; }
+    for (u32 i = t; i < S.n_hints; i += NL_FILL_THREADS) {
+        nl_hint h = S.hints[i];
+        h.ref_a = V.dense(h.ref_a); h.ref_b = V.dense(h.ref_b);
+        s_hints[i] = h;
+    }
+    for (u32 i = t; i < S.n_order; i += NL_FILL_THREADS) s_order[i] = S.order[i];
+    for (u32 i = t; i < S.n_level_starts; i += NL_FILL_THREADS) s_level[i] = S.level_start[i];
+    for (u32 i = t; i < S.n_step_types * S.state; i += NL_FILL_THREADS) s_out[i] = V.dense(S.out[i]);
+    for (u32 i = t; i < NL_FILL_WAVES * 256; i += NL_FILL_THREADS) lds[L.waves + (i >> 8) * V.size + V.con + (i & 255)] = (uint8_t)i;
+    __syncthreads();  // the only workgroup barrier: from here on every wave is on its own
+    const u32 m_n_ops = S.n_ops;
+    for (u32 c = blockIdx.x * NL_FILL_WAVES + wv; c < capacity; c += gridDim.x * NL_FILL_WAVES) {
+        NL_WAVE_SYNC();  // the previous cycle's write phase has read everything it needs
+        const u32 bits = job.hdr_bits[c], reset = bits & 1, idle = (bits >> 1) & 1;
+        if (lane == 0) {
+            val[V.hdr + 0] = (uint8_t)reset; val[V.hdr + 1] = (uint8_t)idle;
+            val[V.hdr + 2] = (uint8_t)(S.masks[0] + S.masks[1] * (int)reset);
+            val[V.hdr + 3] = (uint8_t)(S.masks[2] + S.masks[3] * (int)idle);
+        }
+        for (u32 k = lane; k < S.state; k += 64) {
+            const uint8_t x = job.state_before[(size_t)c * S.state + k];
+            val[V.cyc + k] = x;
+            val[V.prev + k] = x;
+        }
+        u32 free_at = 0;
+        for (u32 s = 0; s < S.steps_per_cycle; s++) {
+            const nl_cycle_step cs = s_cyc[s];
+            const nl_step_type T = s_types[cs.type];
+            const size_t base = (size_t)c * S.rows_per_cycle + cs.row0;
+            for (u32 k = lane; k < T.n_free; k += 64) val[V.fre + k] = job.free_elems[(size_t)c * S.free_per_cycle + free_at + k];
+            if (lane < 8) val[V.rc + lane] = s_cyc[s].rc[lane];  // (indexing the register copy `cs` by lane would put it in scratch memory)
+            free_at += T.n_free;
+            NL_WAVE_SYNC();
+            const uint16_t* const lvl = s_level + T.level0;
+            for (u32 l = 0; l < T.n_levels; l++) {
+                for (u32 e = lvl[l] + lane; e < lvl[l + 1]; e += 64) {
+                    const u32 it = s_order[T.order0 + e];
+                    if (it < NL_ORDER_GATE) {
+                        const u32 j = T.op0 + it;
+                        const nl_table tb = s_tab[s_op_table[j] - 1];
+                        const u32 out = s_op_out[j];
+                        u32 o0, o1, o2;
+                        nl_eval_sel(tb.fn, tb.param, val[s_op_in[j]], val[s_op_in[m_n_ops + j]], val[s_op_in[2 * m_n_ops + j]], o0, o1, o2);
+                        if (out != 0xFFFF) {
+                            val[out] = (uint8_t)o0;
+                            if (tb.n_out > 1) val[out + 1] = (uint8_t)o1;
+                            if (tb.n_out > 2) val[out + 2] = (uint8_t)o2;
+                        }
+                    } else if (it < NL_ORDER_HINT) {
+                        const NlLdsGate g = s_gates[T.gate0 + (it - NL_ORDER_GATE)];
+                        const u32 t0 = T.term0 + g.first_term;
+                        long long sum = g.constant;
+                        for (u32 i = 0; i < g.n_known; i++) {
+                            const u32 code = s_term_code[t0 + i];
+                            const long long x = (long long)val[s_term_ref[t0 + i]] << (code & 0x7F);
+                            sum += (code & 0x80) ? -x : x;
+                        }
+                        for (u32 i = 0; i < g.n_new; i++) {
+                            const u32 sh = s_term_code[t0 + g.n_known + i] & 0x7F;
+                            u64 x = (u64)sum >> sh;
+                            if (i + 1 < g.n_new) x &= (1ull << ((s_term_code[t0 + g.n_known + i + 1] & 0x7F) - sh)) - 1;
+                            val[s_term_ref[t0 + g.n_known + i]] = (uint8_t)x;
+                        }
+                    } else {
+                        const nl_hint h = s_hints[T.hint0 + (it - NL_ORDER_HINT)];
+                        const u32 a = val[h.ref_a], b = val[h.ref_b];
+                        val[h.value] = (uint8_t)(((a >> h.lo_a) & ((1u << h.n_a) - 1)) | (((b >> h.lo_b) & ((1u << h.n_b) - 1)) << h.n_a));
+                    }
+                }
+                NL_WAVE_SYNC();
+            }
+            // ---- stream the step's rows out, lane <-> row: every general-purpose and lookup cell
+            const uint16_t* const cmap = D.cellmap + D.cell0[cs.type];
+            uint16_t* const keys = job.keys + (size_t)c * D.keys_per_cycle + D.step_key0[s];
+            for (u32 r = lane; r < T.rows; r += 64) {
+                const size_t row = base + r;
+                for (u32 col = 0; col < S.g; col++) {
+                    const uint16_t ref = cmap[(size_t)col * T.rows + r];
+                    store_streaming(&NL_TR(col, row), ref == 0xFFFF ? 0 : (u64)val[ref]);
+                }
+                if (r == 0 || r > T.lookup_rows) {
+                    for (int k = 0; k < W * R; k++) store_streaming(&NL_TR(S.g + k, row), 0);
+                    continue;
+                }
+#pragma unroll 1
+                for (int sl = 0; sl < R; sl++) {
+                    const u32 j = T.op0 + (r - 1) * R + sl;
+                    const nl_table tb = s_tab[s_op_table[j] - 1];
+                    const u32 a0 = val[s_op_in[j]], a1 = val[s_op_in[m_n_ops + j]], a2 = val[s_op_in[2 * m_n_ops + j]];
+                    u32 o0, o1, o2;
+                    nl_eval_sel(tb.fn, tb.param, a0, a1, a2, o0, o1, o2);
+                    // cell k of the slot: input k, or output k - n_in, or zero padding — selects only (a local array indexed by a
+                    // runtime value would live in scratch memory)
+#pragma unroll
+                    for (int k = 0; k < W; k++) {
+                        const int j = k - (int)tb.n_in;
+                        const u32 vin = k == 0 ? a0 : k == 1 ? a1 : a2;
+                        const u32 vout = j == 0 ? o0 : j == 1 ? o1 : o2;
+                        const u64 v = j < 0 ? vin : (j < (int)tb.n_out ? vout : 0u);
+                        store_streaming(&NL_TR(S.g + W * sl + k, row), v);
+                    }
+                    const u32 key = a0 | (tb.n_in > 1 ? a1 << tb.in_bits : 0u) | (tb.n_in > 2 ? a2 << (2 * tb.in_bits) : 0u);
+                    keys[(size_t)sl * T.lookup_rows + (r - 1)] = (uint16_t)key;  // lanes <-> rows: contiguous runs per slot
+                }
+            }
+            // the state this step leaves becomes the next step's PREV bank (through registers: the banks overlap in time)
+            const uint16_t* const so = s_out + cs.type * S.state;
+            uint8_t nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0;  // state <= 256 elements: four per lane
+            if (lane < S.state) nx0 = val[so[lane]];
+            if (lane + 64 < S.state) nx1 = val[so[lane + 64]];
+            if (lane + 128 < S.state) nx2 = val[so[lane + 128]];
+            if (lane + 192 < S.state) nx3 = val[so[lane + 192]];
+            NL_WAVE_SYNC();
+            if (lane < S.state) val[V.prev + lane] = nx0;
+            if (lane + 64 < S.state) val[V.prev + lane + 64] = nx1;
+            if (lane + 128 < S.state) val[V.prev + lane + 128] = nx2;
+            if (lane + 192 < S.state) val[V.prev + lane + 192] = nx3;
+        }
+    }
+}
+
+// ---- multiplicities: grid (histogram slices, 2 halves of a table's rows, instances). A workgroup counts the keys of ITS table in
+// its share of the cycles, the half's bins (at most 32768) in LDS, and adds the non-zero bins to the ONE multiplicity column.
+constexpr int NL_HIST_THREADS = 1024;
+constexpr int NL_HIST_HALF = 32768;
+template <int R>
+__global__ __launch_bounds__(NL_HIST_THREADS) void k_nl_hist(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const NlDev& D = *devp;
+    const nl_spec& S = D.s;
+    const NlJob job = jobs[blockIdx.z];
+    const u32 half = blockIdx.y, t = threadIdx.x;
+    u32 tb = 0;
+    while (D.hist_slice0[tb + 1] <= blockIdx.x) tb++;
+    const nl_table T = S.tables[tb];
+    if (half * NL_HIST_HALF >= T.rows) return;
+    const u32 split = blockIdx.x - D.hist_slice0[tb], n_splits = D.hist_slice0[tb + 1] - D.hist_slice0[tb];
+    __shared__ u32 s_bins[NL_HIST_HALF];
+    const u32 nbins = T.rows < NL_HIST_HALF ? T.rows : NL_HIST_HALF;
+    for (u32 i = t; i < nbins; i += NL_HIST_THREADS) s_bins[i] = 0;
+    __syncthreads();
+    for (u32 c = split; c < capacity; c += n_splits) {
+        const uint16_t* const kc = job.keys + (size_t)c * D.keys_per_cycle;
+        for (u32 e = D.hist_first[tb]; e < D.hist_first[tb + 1]; e++) {
+            const NlHistEntry he = D.hist_entries[e];
+            const u32 nr = he.r1 - he.r0, total = nr * R;
+            for (u32 i = t; i < total; i += NL_HIST_THREADS) {
+                const u32 sl = i / nr, r = he.r0 + (i - sl * nr);
+                const u32 key = kc[he.key0 + (size_t)sl * he.lookup_rows + r];
+                if (key / NL_HIST_HALF == half) atomicAdd(&s_bins[key % NL_HIST_HALF], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long* const col = reinterpret_cast<unsigned long long*>(job.trace + (size_t)S.mult_col * n_rows + T.offset + (size_t)half * NL_HIST_HALF);
+    for (u32 i = t; i < nbins; i += NL_HIST_THREADS)
+        if (s_bins[i]) atomicAdd(&col[i], (unsigned long long)s_bins[i]);
+}
+
+// boundary rows (BND_IN, BND_OUT) and the public input row
+__global__ __launch_bounds__(256) void k_nl_finish(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const nl_spec& S = devp->s;
+    const NlJob job = jobs[blockIdx.y];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t bnd = NL_BOUNDARY_ROW(&S, capacity), brows = NL_BND_ROWS(&S);
+    if (i < S.state) {
+        NL_TR(i % S.g, bnd + i / S.g) = job.state_before[i];
+        NL_TR(i % S.g, bnd + brows + i / S.g) = job.state_before[(size_t)capacity * S.state + i];
+    }
+    if (i < 4) NL_TR(i, bnd + 2 * brows) = job.public_input[i];
+}
+#undef NL_TR
+
+// ---- round records -> the engine's inputs. SHA-like: 64-byte blocks, state 8 words as 64 nibbles; Keccak-like: 136 / 200 bytes
+struct NlPrepJob { const void* rounds; u64 first_round; u32 n_active; uint8_t* hdr_bits; uint8_t* free_elems; uint8_t* state_before; };
+__global__ __launch_bounds__(128) void k_nl_prepare_sha(const NlPrepJob* __restrict__ jobs, u32 capacity) {
+    const NlPrepJob j = jobs[blockIdx.y];
+    const zkw_sha256_round_record* rounds = static_cast<const zkw_sha256_round_record*>(j.rounds);
+    const u32 c = blockIdx.x, t = threadIdx.x;  // c in [0, capacity]: the state BEFORE cycle c
+    const u64 idx = j.first_round + (c < j.n_active ? c : j.n_active);  // records before the cycle
+    if (t < 64) j.state_before[(size_t)c * 64 + t] = idx ? (uint8_t)((rounds[idx - 1].state_after[t >> 3] >> (4 * (t & 7))) & 15) : 0;
+    if (c == capacity) return;
+    const bool active = c < j.n_active;
+    const uint8_t b = active ? rounds[j.first_round + c].block[t >> 1] : 0;
+    j.free_elems[(size_t)c * 128 + t] = (uint8_t)((t & 1) ? b >> 4 : b & 15);
+    if (t == 0) j.hdr_bits[c] = active ? (rounds[j.first_round + c].reset ? 1 : 0) : 2;
+}
+__global__ __launch_bounds__(256) void k_nl_prepare_keccak(const NlPrepJob* __restrict__ jobs, u32 capacity) {
+    const NlPrepJob j = jobs[blockIdx.y];
+    const zkw_keccak_round_record* rounds = static_cast<const zkw_keccak_round_record*>(j.rounds);
+    const u32 c = blockIdx.x, t = threadIdx.x;
+    const u64 idx = j.first_round + (c < j.n_active ? c : j.n_active);
+    if (t < 200) j.state_before[(size_t)c * 200 + t] = idx ? rounds[idx - 1].state_after[t] : 0;
+    if (c == capacity) return;
+    const bool active = c < j.n_active;
+    if (t < 136) j.free_elems[(size_t)c * 136 + t] = active ? rounds[j.first_round + c].block[t] : 0;
+    if (t == 0) j.hdr_bits[c] = active ? (rounds[j.first_round + c].reset ? 1 : 0) : 2;
+}
+
+// ------------------------------------------------------------------------------------------------ checker
+// violation kinds: 1 lookup relation / range, 2 copy constraint, 3 header, 4 boundary, 5 multiplicity, 6 non-zero unused cell,
+// 7 gate arithmetic (the codes of oracle/netlist_circuit.c)
+#define NL_TR(col, row) trace[(size_t)(col) * n_rows + (size_t)(row)]
+__device__ u64 nl_home_cell(const nl_spec& S, const u64* __restrict__ trace, size_t n_rows, u32 capacity, u32 c, u32 s, u32 ref) {
+    for (;;) {
+        const nl_cycle_step& cs = S.cycle[s];
+        const nl_step_type& T = S.step_types[cs.type];
+        const size_t base = (size_t)c * S.rows_per_cycle + cs.row0;
+        if (ref < NL_REF_HDR) {
+            const nl_home h = S.homes[T.home0 + ref];
+            if (h.kind == 1) {
+                const nl_gate& g = S.gates[T.gate0 + h.item];
+                return NL_TR(g.col + h.cell, base + g.row);
+            }
+            return NL_TR(S.g + S.w * (h.item % S.r) + h.cell, base + 1 + h.item / S.r);
+        }
+        if (ref < NL_REF_PREV) return NL_TR(ref - NL_REF_HDR, base);
+        if (ref >= NL_REF_CONST) return ref - NL_REF_CONST;
+        if (ref >= NL_REF_RC) return cs.rc[ref - NL_REF_RC];
+        if (ref >= NL_REF_FREE) return 0;
+        u32 k;
+        if (ref >= NL_REF_CYC || s == 0) {
+            k = ref >= NL_REF_CYC ? ref - NL_REF_CYC : ref - NL_REF_PREV;
+            if (c == 0) {
+                const size_t bnd = NL_BOUNDARY_ROW(&S, capacity);
+                return NL_TR(k % S.g, bnd + k / S.g);
+            }
+            c--;
+            s = S.steps_per_cycle - 1;
+        } else {
+            k = ref - NL_REF_PREV;
+            s--;
+        }
+        ref = S.out[(size_t)S.cycle[s].type * S.state + k];
+    }
+}
+
+// grid (chunks of items, capacity * steps_per_cycle): one lane per lookup / gate / row of a step instance
+__global__ __launch_bounds__(256) void k_nl_check_steps(const NlDev* __restrict__ devp, const u64* __restrict__ trace, u32 capacity, size_t n_rows,
+                                                        u32* __restrict__ hist, CheckResult* res) {
+    const nl_spec& S = devp->s;
+    const u32 c = blockIdx.y / S.steps_per_cycle, s = blockIdx.y % S.steps_per_cycle;
+    const nl_cycle_step& cs = S.cycle[s];
+    const nl_step_type& T = S.step_types[cs.type];
+    const size_t base = (size_t)c * S.rows_per_cycle + cs.row0;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T.n_ops) {
+        const u32 j = i;
+        const nl_op& op = S.ops[T.op0 + j];
+        const nl_table& t = S.tables[op.table - 1];
+        const size_t row = base + 1 + j / S.r;
+        const u32 slot = j % S.r, col = S.g + S.w * slot;
+        u32 a[3] = {0, 0, 0}, o[3];
+        bool ok = true;
+        for (u32 k = 0; k < t.n_in; k++) {
+            const u64 x = NL_TR(col + k, row);
+            if (x >> t.in_bits) ok = false;
+            a[k] = (u32)x;
+        }
+        if (ok) {
+            nl_table_eval(t.fn, t.param, a, o);
+            for (u32 k = 0; k < t.n_out; k++) ok &= NL_TR(col + t.n_in + k, row) == o[k];
+            for (u32 k = t.n_in + t.n_out; k < S.w; k++) ok &= NL_TR(col + k, row) == 0;
+        }
+        if (!ok) { flag_bad(res, 1, slot, row); return; }
+        bool copies = true;
+        for (u32 k = 0; k < t.n_in; k++) {
+            const u32 ref = op.in[k];
+            if (ref >= NL_REF_FREE && ref < NL_REF_RC) continue;
+            if (ref < NL_REF_HDR) {
+                const nl_home h = S.homes[T.home0 + ref];
+                if (h.kind == 2 && h.item == j && h.cell == k) continue;  // the hint's own cell
+            }
+            if (a[k] != nl_home_cell(S, trace, n_rows, capacity, c, s, ref)) copies = false;
+        }
+        if (!copies) flag_bad(res, 2, slot, row);
+        atomicAdd(&hist[nl_table_key(&t, a)], 1u);  // padding lookups hit entry 0 of their table like any other
+    } else if (i < T.n_ops + T.n_gates) {
+        const u32 gi = i - T.n_ops;
+        const nl_gate& g = S.gates[T.gate0 + gi];
+        const nl_term* tm = S.terms + T.term0 + g.first_term;
+        const size_t row = base + g.row;
+        u64 acc = gl::canon(g.constant);
+        bool copies = true;
+        for (u32 k = 0; k < (u32)g.n_known + g.n_new; k++) {
+            const u64 x = NL_TR(g.col + k, row);
+            if (k < g.n_known && !(tm[k].ref >= NL_REF_FREE && tm[k].ref < NL_REF_RC) && x != nl_home_cell(S, trace, n_rows, capacity, c, s, tm[k].ref)) copies = false;
+            const u64 term = gl::canon(gl::mul(x, 1ull << (tm[k].code & 0x7F)));
+            acc = gl::canon((tm[k].code & 0x80) ? gl::sub(acc, term) : gl::add(acc, term));
+        }
+        if (!copies) flag_bad(res, 2, 0x10000 + gi, row);
+        if (acc != 0) flag_bad(res, 7, gi, row);
+    } else if (i < T.n_ops + T.n_gates + T.rows) {
+        const u32 r = i - T.n_ops - T.n_gates;
+        const size_t row = base + r;
+        if (r == 0) {
+            if (s == 0) {
+                const u64 reset = NL_TR(NL_HDR_RESET, base), idle = NL_TR(NL_HDR_IDLE, base);
+                if (reset > 1 || idle > 1) flag_bad(res, 3, 0, base);
+                else if (NL_TR(NL_HDR_M0, base) != (u64)(S.masks[0] + S.masks[1] * (long long)reset) ||
+                         NL_TR(NL_HDR_M1, base) != (u64)(S.masks[2] + S.masks[3] * (long long)idle)) flag_bad(res, 3, 1, base);
+            } else {
+                const size_t b0 = (size_t)c * S.rows_per_cycle;
+                for (int f = 0; f < NL_HDR_FIELDS; f++)
+                    if (NL_TR(f, base) != NL_TR(f, b0)) { flag_bad(res, 3, 2, base); break; }
+            }
+        }
+        for (u32 col = S.gate_row_end[T.rowend0 + r]; col < S.g; col++)
+            if (NL_TR(col, row)) { flag_bad(res, 6, col, row); break; }
+        if (r == 0 || r > T.lookup_rows)
+            for (u32 col = S.g; col < S.mult_col; col++)
+                if (NL_TR(col, row)) { flag_bad(res, 6, col, row); break; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nl_check_tail(const NlDev* __restrict__ devp, const u64* __restrict__ trace, u32 capacity, size_t n_rows,
+                                                       const u32* __restrict__ hist, CheckResult* res) {
+    const nl_spec& S = devp->s;
+    const size_t bnd = NL_BOUNDARY_ROW(&S, capacity), brows = NL_BND_ROWS(&S);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += stride) {
+        if (NL_TR(S.mult_col, row) != (row < S.total_table_rows ? (u64)hist[row] : 0)) flag_bad(res, 5, 0, row);
+        if (row < bnd) continue;
+        const size_t off = row - bnd;
+        for (u32 col = 0; col < S.mult_col; col++) {
+            bool allowed = false;
+            if (off < 2 * brows) allowed = col < S.g && (off % brows) * S.g + col < S.state;
+            else if (off == 2 * brows) allowed = col < 4;
+            const u64 x = NL_TR(col, row);
+            if (!allowed && x) { flag_bad(res, 6, col, row); break; }
+            if (allowed && off < brows && x > 255) { flag_bad(res, 4, col, row); break; }
+        }
+        if (off >= brows && off < 2 * brows && capacity)
+            for (u32 col = 0; col < S.g; col++) {
+                const u32 k = (u32)(off - brows) * S.g + col;
+                if (k < S.state && NL_TR(col, row) != nl_home_cell(S, trace, n_rows, capacity, capacity, 0, NL_REF_CYC + k)) flag_bad(res, 4, k, row);
+            }
+    }
+}
+#undef NL_TR
+
+}  // namespace zkw

@@ -41,9 +41,7 @@
 #include "log_demux_circuit_kernels.cuh"
 #include "storage_sorter_circuit_kernels.cuh"
 #include "vm_kernels.cuh"
-#include "keccak_circuit_kernels.cuh"
-#include "sha256_circuit_kernels.cuh"
-#include "code_decommitter_circuit_kernels.cuh"
+#include "netlist_kernels.cuh"
 #include "sort.h"
 
 using namespace zkw;
@@ -484,18 +482,19 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
         case 4: out->num_columns = LD_COLS; out->rows_per_cycle = LD_ROWS_PER_CYCLE; out->region_stride = LD_REGION_STRIDE(capacity); boundary = LD_BOUNDARY_ROW(capacity); min_rows = LD_MIN_ROWS(capacity); pi_off = LD_ROWOFF_PI; break;
         case 9: out->num_columns = SS_COLS; out->rows_per_cycle = SS_ROWS_PER_CYCLE; out->region_stride = SS_REGION_STRIDE(capacity); boundary = SS_BOUNDARY_ROW(capacity); min_rows = SS_MIN_ROWS(capacity); pi_off = SS_ROWOFF_PI; break;
         case 11: case 12: out->num_columns = ES_COLS; out->rows_per_cycle = ES_ROWS_PER_CYCLE; out->region_stride = ES_REGION_STRIDE(capacity); boundary = ES_BOUNDARY_ROW(capacity); min_rows = ES_MIN_ROWS(capacity); pi_off = ES_ROWOFF_PI; break;
-        // the netlist circuits ("zkw trace v3") are cycle-major: region_stride = 0, cycle i starts at row i * rows_per_cycle
-        case 5: case 13: {
+        // the netlist circuits ("zkw trace v4") are cycle-major: region_stride = 0, cycle i starts at row i * rows_per_cycle
+        case 3: case 5: case 6: case 13: {
+            const nl_spec* sp = nl_host_spec(circuit_type);
             const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(capacity) : capacity;
-            out->num_columns = KC_COLS; out->rows_per_cycle = KC_ROWS_PER_CYCLE; boundary = KC_BOUNDARY_ROW(cycles);
-            min_rows = boundary + 2 * KC_BND_ROWS_PER_STATE + 1; pi_off = 2 * KC_BND_ROWS_PER_STATE;
+            out->num_columns = sp->cols; out->rows_per_cycle = sp->rows_per_cycle; boundary = NL_BOUNDARY_ROW(sp, cycles);
+            min_rows = NL_USED_ROWS(sp, cycles); pi_off = 2 * NL_BND_ROWS(sp);
+            out->total_table_rows = sp->total_table_rows;
             break;
         }
-        case 6: out->num_columns = SC_COLS; out->rows_per_cycle = SC_ROWS_PER_CYCLE; boundary = SC_BOUNDARY_ROW(capacity); min_rows = boundary + 3; pi_off = 2; break;
-        case 3: out->num_columns = DC_COLS; out->rows_per_cycle = DC_ROWS_PER_CYCLE; boundary = DC_BOUNDARY_ROW(capacity); min_rows = boundary + 3; pi_off = 2; break;
         default: return ZKW_OK;  // a known circuit type this library does not synthesize yet: synthesizable = 0
     }
     out->synthesizable = 1;
+    if (out->region_stride) out->total_table_rows = 256;  // the queue circuits' one table: RangeCheckTable<8>
     out->rows_used = min_rows;
     out->fits = min_rows <= out->trace_len;
     out->nop_rows = out->fits ? out->trace_len - min_rows : 0;
@@ -513,9 +512,6 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
 //   netlist circuits (3, 5, 6, 13; "zkw trace v3", cycle-major): selector = lookup table id of the row (0: none) |
 //     ZKW_ROW_HAS_GATES when ADD gates sit in its general-purpose columns | ZKW_ROW_HEADER for a cycle's first row;
 //     boundary rows ZKW_ROW_BOUNDARY + k; ZKW_ROW_PADDING elsewhere
-static const sc_op h_sc_ops[SC_NUM_OPS] = SC_OPS_INIT;
-static const dc_op h_dc_ops[DC_NUM_OPS] = DC_OPS_INIT;
-static const kc_op h_kc_ops[KC_OPS_PER_ROUND] = KC_ROUND_OPS_INIT;
 extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint8_t* out) {
     if (!out || n_rows == 0) return fail(ZKW_ERR_INVALID, "zkw_setup_row_selectors: null argument");
     zkw_circuit_layout lay;
@@ -533,23 +529,16 @@ extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, 
     }
     const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
     const uint64_t rpc = lay.rows_per_cycle;
-    for (uint32_t c = 0; c < cycles; c++) {
-        uint8_t* row = out + (uint64_t)c * rpc;
+    const nl_spec* sp = nl_host_spec(circuit_type);
+    std::vector<uint8_t> one(rpc);  // every cycle has the same selectors
+    for (uint32_t st = 0; st < sp->steps_per_cycle; st++) {
+        const nl_step_type& T = sp->step_types[sp->cycle[st].type];
+        uint8_t* row = one.data() + sp->cycle[st].row0;
         row[0] = ZKW_ROW_HEADER;
-        for (uint64_t r = 1; r < rpc; r++) {
-            if (circuit_type == 5 || circuit_type == 13) {
-                row[r] = r < KC_ROW_ABSORB0 ? KC_T_ANDN : r < KC_ROW_ROUND0 ? KC_T_XOR
-                       : r < KC_ROW_SEL_T0 ? (uint8_t)h_kc_ops[((r - KC_ROW_ROUND0) % KC_ROWS_PER_ROUND) * KC_LOOKUPS_PER_ROW].table
-                       : r < KC_ROW_SEL_O0 ? KC_T_ANDN : KC_T_XOR;
-            } else if (circuit_type == 6) {
-                row[r] = (uint8_t)((r - 1 < SC_NUM_OPS / SC_LOOKUPS_PER_ROW ? h_sc_ops[(r - 1) * SC_LOOKUPS_PER_ROW].table : 0) |
-                                   (r - 1 < (SC_NUM_GATES + 1) / 2 ? ZKW_ROW_HAS_GATES : 0));
-            } else {
-                row[r] = (uint8_t)((r - 1 < DC_NUM_OPS / DC_LOOKUPS_PER_ROW ? h_dc_ops[(r - 1) * DC_LOOKUPS_PER_ROW].table : 0) |
-                                   (r - 1 < (DC_NUM_GATES + 1) / 2 ? ZKW_ROW_HAS_GATES : 0));
-            }
-        }
+        for (uint32_t r = 1; r < T.rows; r++)
+            row[r] = (uint8_t)((r <= T.lookup_rows ? sp->ops[T.op0 + (r - 1) * sp->r].table : 0) | (sp->gate_row_end[T.rowend0 + r] ? ZKW_ROW_HAS_GATES : 0));
     }
+    for (uint32_t c = 0; c < cycles; c++) memcpy(out + (uint64_t)c * rpc, one.data(), rpc);
     for (uint64_t k = 0; (uint64_t)cycles * rpc + k < lay.rows_used; k++) out[(uint64_t)cycles * rpc + k] = (uint8_t)(ZKW_ROW_BOUNDARY + k);
     return ZKW_OK;
 }
@@ -580,7 +569,7 @@ bool link_spec_of(uint8_t t, LinkSpec* o) {
 extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t* sigma, uint32_t* n_columns) {
     LinkSpec sp;
     const bool netlist = circuit_type == 3 || circuit_type == 5 || circuit_type == 6 || circuit_type == 13;
-    if (netlist) sp = {circuit_type == 3 ? DC_MULT_COL0 : circuit_type == 6 ? SC_MULT_COL0 : KC_MULT_COL0, 0, 0, 0, 0, nullptr};  // all but the multiplicity columns
+    if (netlist) sp = {(int)nl_host_spec(circuit_type)->mult_col, 0, 0, 0, 0, nullptr};  // all but the multiplicity column
     else if (!link_spec_of(circuit_type, &sp))
         return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: circuit type %u has no layout in this library", (unsigned)circuit_type);
     zkw_circuit_layout lay;
@@ -610,83 +599,64 @@ extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacit
         // the spec, resolved exactly as the checkers do: k_kc_check_rows, k_sc_check_cycle); constants and free witness bytes
         // are under no copy constraint
         const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
-        if (circuit_type == 5 || circuit_type == 13) {
-            static const uint16_t kc_out[200] = KC_ROUND_OUT_INIT;
-            const uint64_t kb = KC_BOUNDARY_ROW(cycles);
-            auto ccol = [](int k) { return (uint64_t)(KC_LOOKUP_COL0 + 3 * (k % KC_LOOKUPS_PER_ROW) + 2); };
-            auto crow = [](uint64_t row0, int k) { return row0 + (uint64_t)(k / KC_LOOKUPS_PER_ROW); };
-            for (uint32_t c = 0; c < cycles; c++) {
-                const uint64_t base = (uint64_t)c * KC_ROWS_PER_CYCLE;
-                auto block = [&](uint64_t row0, int k, int part, uint64_t hcol, uint64_t hrow) {  // operand `part` of lookup k of a 200-lookup block
-                    unite((uint64_t)(KC_LOOKUP_COL0 + 3 * (k % KC_LOOKUPS_PER_ROW) + part), crow(row0, k), hcol, hrow);
-                };
-                for (int k = 0; k < 200; k++) {
-                    const uint64_t pcol = c ? ccol(k) : (uint64_t)(k % KC_G), prow = c ? crow(base - KC_ROWS_PER_CYCLE + KC_ROW_SEL_O0, k) : kb + k / KC_G;
-                    block(base + KC_ROW_MASK0, k, 0, KC_HDR_MASK_R, base);
-                    block(base + KC_ROW_MASK0, k, 1, pcol, prow);
-                    if (k < 136) block(base + KC_ROW_ABSORB0, k, 0, ccol(k), crow(base + KC_ROW_MASK0, k));
-                    block(base + KC_ROW_SEL_T0, k, 0, KC_HDR_MASK_I, base);
-                    block(base + KC_ROW_SEL_T0, k, 1, ccol(kc_out[k] - KC_REF_OP0), crow(base + KC_ROW_ROUND0 + 23 * (uint64_t)KC_ROWS_PER_ROUND, kc_out[k] - KC_REF_OP0));
-                    block(base + KC_ROW_SEL_U0, k, 0, KC_HDR_MASK_A, base);
-                    block(base + KC_ROW_SEL_U0, k, 1, pcol, prow);
-                    block(base + KC_ROW_SEL_O0, k, 0, ccol(k), crow(base + KC_ROW_SEL_T0, k));
-                    block(base + KC_ROW_SEL_O0, k, 1, ccol(k), crow(base + KC_ROW_SEL_U0, k));
+        const nl_spec* ns = nl_host_spec(circuit_type);
+        const uint64_t nb = NL_BOUNDARY_ROW(ns, cycles), brows = NL_BND_ROWS(ns);
+        // the cell a reference names, seen from step st of cycle c (nl_home of netlist_kernels.cuh as coordinates); false: a constant
+        auto home = [&](uint32_t c, uint32_t st, uint32_t ref, uint64_t* hc, uint64_t* hr) {
+            for (;;) {
+                const nl_cycle_step& cs = ns->cycle[st];
+                const nl_step_type& T = ns->step_types[cs.type];
+                const uint64_t base = (uint64_t)c * ns->rows_per_cycle + cs.row0;
+                if (ref < NL_REF_HDR) {
+                    const nl_home h = ns->homes[T.home0 + ref];
+                    if (h.kind == 1) { const nl_gate& g = ns->gates[T.gate0 + h.item]; *hc = g.col + h.cell; *hr = base + g.row; }
+                    else { *hc = ns->g + ns->w * (h.item % ns->r) + h.cell; *hr = base + 1 + h.item / ns->r; }
+                    return true;
                 }
-                for (int rnd = 0; rnd < 24; rnd++) {
-                    const uint64_t row0 = base + KC_ROW_ROUND0 + (uint64_t)rnd * KC_ROWS_PER_ROUND;
-                    for (int j = 0; j < KC_OPS_PER_ROUND; j++)
-                        for (int side = 0; side < 2; side++) {
-                            const uint16_t ref = side ? h_kc_ops[j].b : h_kc_ops[j].a;
-                            if (ref >= KC_REF_RC0) continue;  // round constant / zero
-                            uint64_t hc, hr;
-                            if (ref >= KC_REF_OP0) { hc = ccol(ref - KC_REF_OP0); hr = crow(row0, ref - KC_REF_OP0); }
-                            else if (rnd) { hc = ccol(kc_out[ref] - KC_REF_OP0); hr = crow(row0 - KC_ROWS_PER_ROUND, kc_out[ref] - KC_REF_OP0); }
-                            else { hc = ccol(ref); hr = crow(base + (ref < 136 ? KC_ROW_ABSORB0 : KC_ROW_MASK0), ref); }
-                            unite((uint64_t)(KC_LOOKUP_COL0 + 3 * (j % KC_LOOKUPS_PER_ROW) + side), crow(row0, j), hc, hr);
+                if (ref < NL_REF_PREV) { *hc = ref - NL_REF_HDR; *hr = base; return true; }
+                if (ref >= NL_REF_FREE && ref < NL_REF_RC) return false;
+                if (ref >= NL_REF_RC) return false;
+                uint32_t k;
+                if (ref >= NL_REF_CYC || st == 0) {
+                    k = ref >= NL_REF_CYC ? ref - NL_REF_CYC : ref - NL_REF_PREV;
+                    if (c == 0) { *hc = k % ns->g; *hr = nb + k / ns->g; return true; }
+                    c--;
+                    st = ns->steps_per_cycle - 1;
+                } else {
+                    k = ref - NL_REF_PREV;
+                    st--;
+                }
+                ref = ns->out[(size_t)ns->cycle[st].type * ns->state + k];
+            }
+        };
+        uint64_t hc, hr;
+        for (uint32_t c = 0; c < cycles; c++)
+            for (uint32_t st = 0; st < ns->steps_per_cycle; st++) {
+                const nl_cycle_step& cs = ns->cycle[st];
+                const nl_step_type& T = ns->step_types[cs.type];
+                const uint64_t base = (uint64_t)c * ns->rows_per_cycle + cs.row0;
+                if (st)  // a step's header is a copy of the cycle's
+                    for (int f = 0; f < NL_HDR_FIELDS; f++) unite((uint64_t)f, base, (uint64_t)f, (uint64_t)c * ns->rows_per_cycle);
+                for (uint32_t j = 0; j < T.n_ops; j++) {
+                    const nl_op& op = ns->ops[T.op0 + j];
+                    const nl_table& tb = ns->tables[op.table - 1];
+                    for (uint32_t i = 0; i < tb.n_in; i++) {
+                        if (op.in[i] < NL_REF_HDR) {
+                            const nl_home h = ns->homes[T.home0 + op.in[i]];
+                            if (h.kind == 2 && h.item == j && h.cell == i) continue;  // a hint's own cell
                         }
-                }
-            }
-            for (int k = 0; k < 200; k++)
-                unite((uint64_t)(k % KC_G), kb + KC_BND_ROWS_PER_STATE + k / KC_G, ccol(k), crow(kb - KC_ROWS_PER_CYCLE + KC_ROW_SEL_O0, k));
-        } else {
-            // Sha256RoundFunction (SC_) and CodeDecommitter (DC_): the same netlist shape, different constants
-            const bool dc = circuit_type == 3;
-            const int lpr = dc ? DC_LOOKUPS_PER_ROW : SC_LOOKUPS_PER_ROW, n_ops = dc ? DC_NUM_OPS : SC_NUM_OPS, n_gates = dc ? DC_NUM_GATES : SC_NUM_GATES;
-            const uint64_t rpc = dc ? DC_ROWS_PER_CYCLE : SC_ROWS_PER_CYCLE, nb = (uint64_t)cycles * rpc;
-            static const sc_gate sc_gates[SC_NUM_GATES] = SC_GATES_INIT;
-            static const dc_gate dc_gates[DC_NUM_GATES] = DC_GATES_INIT;
-            static const uint16_t sc_out[32] = SC_OUT_INIT, dc_out[32] = DC_OUT_INIT;
-            const uint16_t* outr = dc ? dc_out : sc_out;
-            auto ocol = [&](int j, int part) { return (uint64_t)(SC_LOOKUP_COL0 + 3 * (j % lpr) + part); };
-            auto orow = [&](uint64_t base, int j) { return base + 1 + (uint64_t)(j / lpr); };
-            for (uint32_t c = 0; c < cycles; c++) {
-                const uint64_t base = (uint64_t)c * rpc;
-                auto home = [&](uint16_t ref, uint64_t* hc, uint64_t* hr) {  // false: no copy constraint
-                    if (ref < SC_REF_GATE) { *hc = ocol(ref, 2); *hr = orow(base, ref); return true; }
-                    if (ref < SC_REF_HDR) { const int g = (ref - SC_REF_GATE) >> 2; *hc = (uint64_t)((g % 2) * SC_GATE_COLS + SC_GATE_OUT + ((ref - SC_REF_GATE) & 3)); *hr = base + 1 + g / 2; return true; }
-                    if (ref < SC_REF_PREV) { *hc = ref - SC_REF_HDR; *hr = base; return true; }
-                    if (ref < SC_REF_FREE) {
-                        const int k = ref - SC_REF_PREV;
-                        if (c) { *hc = ocol(outr[k], 2); *hr = orow(base - rpc, outr[k]); } else { *hc = (uint64_t)k; *hr = nb; }
-                        return true;
+                        if (home(c, st, op.in[i], &hc, &hr)) unite((uint64_t)(ns->g + ns->w * (j % ns->r) + i), base + 1 + j / ns->r, hc, hr);
                     }
-                    return false;
-                };
-                uint64_t hc, hr;
-                for (int j = 0; j < n_ops; j++) {
-                    const uint16_t ra = dc ? h_dc_ops[j].a : h_sc_ops[j].a, rb = dc ? h_dc_ops[j].b : h_sc_ops[j].b;
-                    if (home(ra, &hc, &hr)) unite(ocol(j, 0), orow(base, j), hc, hr);
-                    if (home(rb, &hc, &hr)) unite(ocol(j, 1), orow(base, j), hc, hr);
                 }
-                for (int g = 0; g < n_gates; g++) {
-                    const uint32_t n = dc ? dc_gates[g].n_operands : sc_gates[g].n_operands;
-                    for (uint32_t k = 0; k < 4 * n; k++)
-                        if (home(dc ? dc_gates[g].in[k >> 2][k & 3] : sc_gates[g].in[k >> 2][k & 3], &hc, &hr))
-                            unite((uint64_t)((g % 2) * SC_GATE_COLS + k), base + 1 + g / 2, hc, hr);
+                for (uint32_t gi = 0; gi < T.n_gates; gi++) {
+                    const nl_gate& g = ns->gates[T.gate0 + gi];
+                    for (uint32_t i = 0; i < g.n_known; i++)
+                        if (home(c, st, ns->terms[T.term0 + g.first_term + i].ref, &hc, &hr)) unite((uint64_t)(g.col + i), base + g.row, hc, hr);
                 }
             }
-            for (int k = 0; k < 32; k++) unite((uint64_t)k, nb + 1, ocol(outr[k], 2), orow(nb - rpc, outr[k]));
-        }
+        if (cycles)
+            for (uint32_t k = 0; k < ns->state; k++)
+                if (home(cycles, 0, NL_REF_CYC + k, &hc, &hr)) unite((uint64_t)(k % ns->g), nb + brows + k / ns->g, hc, hr);
     }
     for (int l = 0; l < sp.num_links; l++) {
         const rc_link k = sp.links[l];
@@ -3701,8 +3671,223 @@ extern "C" int zkw_precompile_closed_forms(zkw_ctx* ctx, zkw_precompile_witness*
     return ZKW_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ Keccak256RoundFunction synthesis
-// ZkSyncBaseLayerCircuit::synthesis for Keccak256RoundFunction (type 5) in "zkw trace v3" (keccak_circuit_kernels.cuh)
+// ------------------------------------------------------------------------------------------------ netlist circuits ("zkw trace v4")
+// Sha256RoundFunction (6), CodeDecommitter (3), Keccak256RoundFunction (5), L1MessagesHasher (13): one engine (netlist_kernels.cuh),
+// four generated specs on the reference's geometry and table sets. The device copy of a spec (its arrays, the general-purpose cell
+// map, the key layout and the histogram plan) is built once per device and circuit and never freed.
+namespace {
+struct NlCached { NlDev host; NlDev* dev = nullptr; };
+std::mutex g_nl_mu;
+std::map<std::pair<int, int>, NlCached>& nl_cache() { static auto* m = new std::map<std::pair<int, int>, NlCached>(); return *m; }
+
+template <class T>
+int nl_to_device(const T* src, size_t n, const T** out) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return fail(ZKW_ERR_OOM, "netlist spec: hipMalloc failed");
+    if (n && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return fail(ZKW_ERR_HIP, "netlist spec: upload failed");
+    *out = static_cast<const T*>(p);
+    return ZKW_OK;
+}
+
+int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
+    const nl_spec* hs = nl_host_spec(circuit_type);
+    if (!hs) return fail(ZKW_ERR_INVALID, "circuit type %d is not a netlist circuit", circuit_type);
+    std::lock_guard<std::mutex> g(g_nl_mu);
+    NlCached& c = nl_cache()[{ctx->device, circuit_type}];
+    if (c.dev) { *out = &c; return ZKW_OK; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    NlDev d;
+    memset(&d, 0, sizeof d);
+    d.s = *hs;
+    ZKW_TRY(nl_to_device(hs->tables, hs->n_tables, &d.s.tables));
+    ZKW_TRY(nl_to_device(hs->step_types, hs->n_step_types, &d.s.step_types));
+    ZKW_TRY(nl_to_device(hs->ops, hs->n_ops, &d.s.ops));
+    ZKW_TRY(nl_to_device(hs->gates, hs->n_gates, &d.s.gates));
+    ZKW_TRY(nl_to_device(hs->terms, hs->n_terms, &d.s.terms));
+    ZKW_TRY(nl_to_device(hs->hints, hs->n_hints ? hs->n_hints : 1, &d.s.hints));
+    ZKW_TRY(nl_to_device(hs->out, (size_t)hs->n_step_types * hs->state, &d.s.out));
+    ZKW_TRY(nl_to_device(hs->order, hs->n_order, &d.s.order));
+    ZKW_TRY(nl_to_device(hs->level_start, hs->n_level_starts, &d.s.level_start));
+    ZKW_TRY(nl_to_device(hs->homes, hs->n_values, &d.s.homes));
+    ZKW_TRY(nl_to_device(hs->cycle, hs->steps_per_cycle, &d.s.cycle));
+    size_t n_rowend = 0;
+    for (u32 k = 0; k < hs->n_step_types; k++) n_rowend += hs->step_types[k].rows;
+    ZKW_TRY(nl_to_device(hs->gate_row_end, n_rowend, &d.s.gate_row_end));
+    const NlV V(*hs);
+    // general-purpose cell map: [type: cell0 + col * rows + row] = dense reference of the cell
+    std::vector<u32> cell0(hs->n_step_types);
+    std::vector<uint16_t> cmap;
+    u32 max_items = 0;
+    for (u32 k = 0; k < hs->n_step_types; k++) {
+        const nl_step_type& T = hs->step_types[k];
+        cell0[k] = (u32)cmap.size();
+        cmap.resize(cmap.size() + (size_t)hs->g * T.rows, 0xFFFF);
+        uint16_t* m = cmap.data() + cell0[k];
+        for (int f = 0; f < NL_HDR_FIELDS; f++) m[(size_t)f * T.rows] = (uint16_t)(V.hdr + f);
+        for (u32 gi = 0; gi < T.n_gates; gi++) {
+            const nl_gate& gt = hs->gates[T.gate0 + gi];
+            for (u32 i = 0; i < (u32)gt.n_known + gt.n_new; i++)
+                m[(size_t)(gt.col + i) * T.rows + gt.row] = V.dense(hs->terms[T.term0 + gt.first_term + i].ref);
+        }
+        max_items = std::max(max_items, T.n_ops + T.n_gates + T.rows);
+    }
+    ZKW_TRY(nl_to_device(cmap.data(), cmap.size(), &d.cellmap));
+    ZKW_TRY(nl_to_device(cell0.data(), cell0.size(), &d.cell0));
+    // keys of a cycle: step after step, [slot][lookup row] inside a step
+    std::vector<u32> key0(hs->steps_per_cycle);
+    u32 keys = 0;
+    for (u32 s = 0; s < hs->steps_per_cycle; s++) {
+        key0[s] = keys;
+        keys += hs->r * hs->step_types[hs->cycle[s].type].lookup_rows;
+    }
+    d.keys_per_cycle = keys;
+    ZKW_TRY(nl_to_device(key0.data(), key0.size(), &d.step_key0));
+    // histogram plan: the row runs of every table in every step of a cycle; slices in proportion to the lookups
+    std::vector<NlHistEntry> entries;
+    std::vector<u32> first(hs->n_tables + 1, 0), slice0(hs->n_tables + 1, 0);
+    std::vector<unsigned long long> weight(hs->n_tables, 0);
+    for (u32 tb = 0; tb < hs->n_tables; tb++) {
+        first[tb] = (u32)entries.size();
+        for (u32 s = 0; s < hs->steps_per_cycle; s++) {
+            const nl_step_type& T = hs->step_types[hs->cycle[s].type];
+            u32 r0 = ~0u, r1 = 0;
+            for (u32 r = 0; r < T.lookup_rows; r++)
+                if (hs->ops[T.op0 + r * hs->r].table == tb + 1) { r0 = std::min(r0, r); r1 = r + 1; }
+            if (r1) { entries.push_back(NlHistEntry{s, r0, r1, key0[s], T.lookup_rows}); weight[tb] += (r1 - r0) * hs->r; }
+        }
+    }
+    first[hs->n_tables] = (u32)entries.size();
+    std::vector<u32> slices(hs->n_tables, 1);
+    for (int left = 64 - (int)hs->n_tables; left > 0; left--) {  // the next slice goes to the table with the most lookups per slice
+        u32 best = 0;
+        for (u32 tb = 1; tb < hs->n_tables; tb++)
+            if (weight[tb] * slices[best] > weight[best] * slices[tb]) best = tb;
+        slices[best]++;
+    }
+    for (u32 tb = 0; tb < hs->n_tables; tb++) slice0[tb + 1] = slice0[tb] + slices[tb];
+    d.n_hist_slices = slice0[hs->n_tables];
+    ZKW_TRY(nl_to_device(entries.data(), entries.size(), &d.hist_entries));
+    ZKW_TRY(nl_to_device(first.data(), first.size(), &d.hist_first));
+    ZKW_TRY(nl_to_device(slice0.data(), slice0.size(), &d.hist_slice0));
+    d.max_items = max_items;
+    d.vsize = V.size;
+    d.lds_bytes = NlLds(*hs, V.size).total;
+    const NlDev* dd = nullptr;
+    ZKW_TRY(nl_to_device(&d, 1, &dd));
+    c.host = d;
+    c.dev = const_cast<NlDev*>(dd);
+    *out = &c;
+    return ZKW_OK;
+}
+
+struct NlInstance { u64 first_round; u32 n_active; const u64* public_input; u64* trace; };
+
+template <int W, int R>
+int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
+    static bool attr_set[16] = {};
+    if (!attr_set[ctx->device & 15]) {  // more than the default 64 KB of dynamic LDS
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[ctx->device & 15] = true;
+    }
+    const unsigned blocks = std::min<unsigned>((capacity + NL_FILL_WAVES - 1) / NL_FILL_WAVES, std::max<unsigned>(1, 256 / nj));
+    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R>), dim3(blocks, nj), dim3(NL_FILL_THREADS), nc->host.lds_bytes, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+    ZKW_TRY(launch_check("k_nl_fill"));
+    { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+    return launch_check("k_nl_hist");
+}
+
+// synthesis of instances of one netlist circuit from the block's round records (`sha_like`: zkw_sha256_round_record, else keccak)
+int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_rounds, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
+    const NlCached* nc = nullptr;
+    ZKW_TRY(nl_get(ctx, circuit_type, &nc));
+    const nl_spec& S = nc->host.s;
+    if (nc->host.lds_bytes > 160 * 1024) return fail(ZKW_ERR_INVALID, "netlist of circuit %d needs %u bytes of LDS", circuit_type, nc->host.lds_bytes);
+    const size_t used = NL_USED_ROWS(&S, capacity);
+    if (used > n_rows || S.total_table_rows > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %zu rows (tables: %u), trace has %zu", capacity, used, S.total_table_rows, n_rows);
+    const size_t ni = inst.size();
+    if (ni == 0) return ZKW_OK;
+    uint8_t *d_hdr = nullptr, *d_free = nullptr, *d_state = nullptr;
+    uint16_t* d_keys = nullptr;
+    const size_t hdr_n = capacity, free_n = (size_t)capacity * S.free_per_cycle, state_n = (size_t)(capacity + 1) * S.state, keys_n = (size_t)capacity * nc->host.keys_per_cycle;
+    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_hdr", ni * hdr_n, &d_hdr));
+    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_free", ni * free_n + 1, &d_free));
+    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_state", ni * state_n, &d_state));
+    ZKW_TRY(ctx->scratch_t<uint16_t>("nl_keys", ni * keys_n, &d_keys));
+    std::vector<NlPrepJob> prep(ni);
+    std::vector<NlJob> jobs(ni);
+    const size_t bnd = NL_BOUNDARY_ROW(&S, capacity);
+    for (size_t k = 0; k < ni; k++) {
+        prep[k] = NlPrepJob{d_rounds, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n};
+        jobs[k] = NlJob{prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before, inst[k].public_input, inst[k].trace, d_keys + k * keys_n};
+        // the fill writes every general-purpose and lookup cell above the boundary: zero the rows from the boundary down, and the
+        // multiplicity column (k_nl_hist adds to it)
+        u64* tr = inst[k].trace;
+        hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - bnd + 255) / 256), S.mult_col), dim3(256), 0, ctx->stream, tr + bnd, n_rows, n_rows - bnd);
+        ZKW_TRY(launch_check("k_zero_strip"));
+        HIP_TRY(hipMemsetAsync(tr + (size_t)S.mult_col * n_rows, 0, n_rows * sizeof(u64), ctx->stream));
+    }
+    NlPrepJob* d_prep = nullptr;
+    NlJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("nl_prep", prep, &d_prep));
+    ZKW_TRY(ctx->upload("nl_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)ni;
+    if (sha_like) { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_sha, dim3(capacity + 1, nj), dim3(128), 0, ctx->stream, d_prep, capacity); }
+    else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
+    ZKW_TRY(launch_check("k_nl_prepare"));
+    switch (circuit_type) {
+        case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+    }
+    { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((S.state + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+    return launch_check("k_nl_finish");
+}
+
+int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u32 capacity, uint64_t* n_violations, uint64_t* first_bad) {
+    const NlCached* nc = nullptr;
+    ZKW_TRY(nl_get(ctx, circuit_type, &nc));
+    const nl_spec& S = nc->host.s;
+    if (t->n_cols < S.cols) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %u", t->n_cols, S.cols);
+    if (NL_USED_ROWS(&S, capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64* trace = t->data + slot * t->slot_elems();
+    const size_t n_rows = t->n_rows;
+    CheckResult* d_res = nullptr;
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
+    ZKW_TRY(ctx->scratch_t<u32>("nl_check_hist", S.total_table_rows, &d_hist));
+    CheckResult init{0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, S.total_table_rows * sizeof(u32), ctx->stream));
+    { Prof _p(ctx, "k_nl_check_steps"); hipLaunchKernelGGL(k_nl_check_steps, dim3((nc->host.max_items + 255) / 256, capacity * S.steps_per_cycle), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_nl_check_steps"));
+    { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_nl_check_tail"));
+    CheckResult res;
+    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
+    *n_violations = res.violations;
+    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
+    return ZKW_OK;
+}
+
+// instance i of a precompile-style witness covers the rounds [i * capacity, min((i + 1) * capacity, total)) (none for the dummy instance)
+std::vector<NlInstance> nl_instances(size_t first_instance, size_t n_instances, u32 capacity, bool any, u64 total_rounds, const u64* cf_pi, size_t n_all,
+                                     zkw_trace* t, size_t first_slot) {
+    std::vector<NlInstance> v(n_instances);
+    for (size_t k = 0; k < n_instances; k++) {
+        const size_t i = first_instance + k;
+        v[k].first_round = (u64)i * capacity;
+        v[k].n_active = any ? (u32)std::min<u64>(capacity, total_rounds - v[k].first_round) : 0;
+        v[k].public_input = cf_pi + COMPACT_FORM_LEN * n_all + 4 * i;
+        v[k].trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+    }
+    return v;
+}
+}  // namespace
+
+// ZkSyncBaseLayerCircuit::synthesis for Keccak256RoundFunction (type 5): 86 + 3 x 14 columns, Xor8 / And8 / ByteSplit<1..4>
 extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances,
                                            zkw_trace* t, size_t first_slot) {
     if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_keccak_round_synthesize: bad argument");
@@ -3710,46 +3895,19 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
     if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
     if (t->n_cols < KC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the Keccak256RoundFunction circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, KC_COLS);
-    const u32 capacity = w->capacity;
-    const size_t n_rows = t->n_rows;
-    if (KC_MIN_ROWS(capacity) > n_rows)
-        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)KC_MIN_ROWS(capacity), n_rows);
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));  // public inputs of the block's instances (a20), once
-    u32* d_hist = nullptr;
-    const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS, hist_all = (size_t)KC_HIST_SLICES * KC_TABLE_ROWS;  // k_kc_hist stores every bin
-    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", n_instances * hist_all, &d_hist));
-    uint16_t* d_keys = nullptr;
-    const size_t keys_per_slot = (size_t)capacity * (size_t)KC_LOOKUPS_PER_ROW * (KC_ROWS_PER_CYCLE - 1);
-    ZKW_TRY(ctx->scratch_t<uint16_t>("kc_keys", n_instances * keys_per_slot, &d_keys));
-    std::vector<KcSynthJob> jobs(n_instances);
-    for (size_t k = 0; k < n_instances; k++) {
-        const size_t i = first_instance + k;
-        KcSynthJob& j = jobs[k];
-        j.rounds = w->keccak_rounds;
-        // instance i covers the rounds [i * capacity, min((i + 1) * capacity, total)) of the block (none for the dummy instance)
-        j.first_round = (u64)i * capacity;
-        j.n_active = w->n_requests ? (u32)std::min<u64>(capacity, w->total_rounds - j.first_round) : 0;
-        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
-        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
-        j.hist = d_hist + k * hist_all;
-        j.keys = d_keys + k * keys_per_slot;
-        ZKW_TRY(zero_netlist_slot(ctx, j.trace, n_rows, KC_G, 3 * KC_LOOKUPS_PER_ROW, KC_COLS, (size_t)capacity * KC_ROWS_PER_CYCLE));
-    }
-    KcSynthJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("kc_jobs", jobs, &d_jobs));
-    const unsigned nj = (unsigned)n_instances;
-    { Prof _p(ctx, "k_kc_fill"); hipLaunchKernelGGL(k_kc_fill, dim3(capacity, nj), dim3(KC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_kc_fill"));
-    { Prof _p(ctx, "k_kc_hist"); hipLaunchKernelGGL(k_kc_hist, dim3(KC_HIST_SLICES, 2, nj), dim3(KC_HIST_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_kc_hist"));
-    { Prof _p(ctx, "k_kc_finish"); hipLaunchKernelGGL(k_kc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    return launch_check("k_kc_finish");
+    return nl_synthesize(ctx, 5, false, w->keccak_rounds, nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
+                         w->capacity, t->n_rows);
+}
+extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_keccak_round_check_satisfied: bad argument");
+    return nl_check(ctx, 5, t, slot, capacity, n_violations, first_bad);
 }
 
-// ------------------------------------------------------------------------------------------------ Sha256RoundFunction synthesis
-// ZkSyncBaseLayerCircuit::synthesis for Sha256RoundFunction (type 6) in "zkw trace v3" (sha256_circuit_kernels.cuh)
+// ZkSyncBaseLayerCircuit::synthesis for Sha256RoundFunction (type 6): 116 + 4 x 9 columns, TriXor4 / Ch4 / Maj4 / Split4BitChunk<1, 2>
 extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances,
                                            zkw_trace* t, size_t first_slot) {
     if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_sha256_round_synthesize: bad argument");
@@ -3757,143 +3915,37 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
     if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
     if (t->n_cols < SC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the Sha256RoundFunction circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, SC_COLS);
-    const u32 capacity = w->capacity;
-    const size_t n_rows = t->n_rows;
-    if (SC_MIN_ROWS(capacity) > n_rows)
-        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)SC_MIN_ROWS(capacity), n_rows);
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
-    u32* d_hist = nullptr;
-    const size_t hist_elems = (size_t)SC_NUM_TABLES * SC_TABLE_ROWS, hist_all = (size_t)SC_HIST_SLICES * SC_TABLE_ROWS;  // k_sc_hist stores every bin
-    ZKW_TRY(ctx->scratch_t<u32>("sc_hist", n_instances * hist_all, &d_hist));
-    uint16_t* d_keys = nullptr;
-    const size_t keys_per_slot = (size_t)capacity * SC_NUM_OPS;
-    ZKW_TRY(ctx->scratch_t<uint16_t>("sc_keys", n_instances * keys_per_slot, &d_keys));
-    std::vector<ScSynthJob> jobs(n_instances);
-    for (size_t k = 0; k < n_instances; k++) {
-        const size_t i = first_instance + k;
-        ScSynthJob& j = jobs[k];
-        j.rounds = w->sha256_rounds;
-        j.first_round = (u64)i * capacity;
-        j.n_active = w->n_requests ? (u32)std::min<u64>(capacity, w->total_rounds - j.first_round) : 0;
-        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
-        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
-        j.hist = d_hist + k * hist_all;
-        j.keys = d_keys + k * keys_per_slot;
-        ZKW_TRY(zero_netlist_slot(ctx, j.trace, n_rows, SC_G, 3 * SC_LOOKUPS_PER_ROW, SC_COLS, (size_t)capacity * SC_ROWS_PER_CYCLE));
-    }
-    ScSynthJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("sc_jobs", jobs, &d_jobs));
-    const unsigned nj = (unsigned)n_instances;
-    { Prof _p(ctx, "k_sc_fill"); hipLaunchKernelGGL(k_sc_fill, dim3(std::min<unsigned>((capacity + SC_FILL_WAVES - 1) / SC_FILL_WAVES, std::max<unsigned>(1, SC_FILL_BLOCKS / nj)), nj), dim3(SC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_sc_fill"));
-    { Prof _p(ctx, "k_sc_hist"); hipLaunchKernelGGL(k_sc_hist, dim3(SC_HIST_SLICES, 2, nj), dim3(SC_HIST_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_sc_hist"));
-    { Prof _p(ctx, "k_sc_finish"); hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    return launch_check("k_sc_finish");
+    return nl_synthesize(ctx, 6, true, w->sha256_rounds, nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
+                         w->capacity, t->n_rows);
 }
-
-extern "C" int zkw_sha256_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
-                                                uint64_t* n_violations, uint64_t* first_bad) {
+extern "C" int zkw_sha256_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
         return fail(ZKW_ERR_INVALID, "zkw_sha256_round_check_satisfied: bad argument");
-    if (t->n_cols < SC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %d", t->n_cols, SC_COLS);
-    if (SC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
-    HIP_TRY(hipSetDevice(ctx->device));
-    const u64* trace = t->data + slot * t->slot_elems();
-    const size_t n_rows = t->n_rows, hist_elems = (size_t)SC_NUM_TABLES * SC_TABLE_ROWS;
-    CheckResult* d_res = nullptr;
-    u32* d_hist = nullptr;
-    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
-    ZKW_TRY(ctx->scratch_t<u32>("sc_check_hist", hist_elems, &d_hist));
-    CheckResult init{0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, hist_elems * sizeof(u32), ctx->stream));
-    const unsigned items = SC_NUM_OPS + SC_NUM_GATES + SC_ROWS_PER_CYCLE;
-    { Prof _p(ctx, "k_sc_check_cycle"); hipLaunchKernelGGL(k_sc_check_cycle, dim3((items + 255) / 256, capacity), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_sc_check_cycle"));
-    { Prof _p(ctx, "k_sc_check_tail"); hipLaunchKernelGGL(k_sc_check_tail, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_sc_check_tail"));
-    CheckResult res;
-    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
-    *n_violations = res.violations;
-    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
-    return ZKW_OK;
+    return nl_check(ctx, 6, t, slot, capacity, n_violations, first_bad);
 }
 
 // ------------------------------------------------------------------------------------------------ CodeDecommitter synthesis
-// ZkSyncBaseLayerCircuit::synthesis for CodeDecommitter (type 3): the SHA-256 netlist at 18 lookups per row
-// (code_decommitter_circuit_kernels.cuh, generated from sha256_circuit_kernels.cuh), one cycle per round of the unpacked bytecodes
+// ZkSyncBaseLayerCircuit::synthesis for CodeDecommitter (type 3): the SHA-256 netlist on 108 + 4 x 11 columns, one cycle per round
+// of the unpacked bytecodes (a cycle is one round: BeginNew shares the cycle of a bytecode's first round)
 extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_witness* w, size_t first_instance, size_t n_instances,
                                                zkw_trace* t, size_t first_slot) {
     if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_code_decommitter_synthesize: bad argument");
     if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
     if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
     if (t->n_cols < DC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the CodeDecommitter circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, DC_COLS);
-    const u32 capacity = w->capacity;
-    const size_t n_rows = t->n_rows;
-    if (DC_MIN_ROWS(capacity) > n_rows)
-        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)DC_MIN_ROWS(capacity), n_rows);
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!w->cf_pi) ZKW_TRY(closed_form_public_inputs<CfDecommitter>(ctx, w->instances, w->n_instances, &w->cf_pi));
-    u32* d_hist = nullptr;
-    const size_t hist_elems = (size_t)DC_NUM_TABLES * DC_TABLE_ROWS, hist_all = (size_t)DC_HIST_SLICES * DC_TABLE_ROWS;  // k_dc_hist stores every bin
-    ZKW_TRY(ctx->scratch_t<u32>("dc_hist", n_instances * hist_all, &d_hist));
-    uint16_t* d_keys = nullptr;
-    const size_t keys_per_slot = (size_t)capacity * DC_NUM_OPS;
-    ZKW_TRY(ctx->scratch_t<uint16_t>("dc_keys", n_instances * keys_per_slot, &d_keys));
-    std::vector<DcSynthJob> jobs(n_instances);
-    for (size_t k = 0; k < n_instances; k++) {
-        const size_t i = first_instance + k;
-        DcSynthJob& j = jobs[k];
-        j.rounds = w->sha256_rounds;
-        j.first_round = (u64)i * capacity;  // a cycle is one round (BeginNew shares the cycle of a bytecode's first round)
-        j.n_active = (u32)std::min<u64>(capacity, w->total_rounds - j.first_round);
-        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * i;
-        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
-        j.hist = d_hist + k * hist_all;
-        j.keys = d_keys + k * keys_per_slot;
-        ZKW_TRY(zero_netlist_slot(ctx, j.trace, n_rows, DC_G, 3 * DC_LOOKUPS_PER_ROW, DC_COLS, (size_t)capacity * DC_ROWS_PER_CYCLE));
-    }
-    DcSynthJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("dc_jobs", jobs, &d_jobs));
-    const unsigned nj = (unsigned)n_instances;
-    { Prof _p(ctx, "k_dc_fill"); hipLaunchKernelGGL(k_dc_fill, dim3(std::min<unsigned>((capacity + DC_FILL_WAVES - 1) / DC_FILL_WAVES, std::max<unsigned>(1, DC_FILL_BLOCKS / nj)), nj), dim3(DC_FILL_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_dc_fill"));
-    { Prof _p(ctx, "k_dc_hist"); hipLaunchKernelGGL(k_dc_hist, dim3(DC_HIST_SLICES, 2, nj), dim3(DC_HIST_THREADS), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_dc_hist"));
-    { Prof _p(ctx, "k_dc_finish"); hipLaunchKernelGGL(k_dc_finish, dim3((unsigned)((hist_elems + 255) / 256), nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    return launch_check("k_dc_finish");
+    return nl_synthesize(ctx, 3, true, w->sha256_rounds, nl_instances(first_instance, n_instances, w->capacity, true, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
+                         w->capacity, t->n_rows);
 }
-
-extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
-                                                    uint64_t* n_violations, uint64_t* first_bad) {
+extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
         return fail(ZKW_ERR_INVALID, "zkw_code_decommitter_check_satisfied: bad argument");
-    if (t->n_cols < DC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %d", t->n_cols, DC_COLS);
-    if (DC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
-    HIP_TRY(hipSetDevice(ctx->device));
-    const u64* trace = t->data + slot * t->slot_elems();
-    const size_t n_rows = t->n_rows, hist_elems = (size_t)DC_NUM_TABLES * DC_TABLE_ROWS;
-    CheckResult* d_res = nullptr;
-    u32* d_hist = nullptr;
-    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
-    ZKW_TRY(ctx->scratch_t<u32>("dc_check_hist", hist_elems, &d_hist));
-    CheckResult init{0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, hist_elems * sizeof(u32), ctx->stream));
-    const unsigned items = DC_NUM_OPS + DC_NUM_GATES + DC_ROWS_PER_CYCLE;
-    { Prof _p(ctx, "k_dc_check_cycle"); hipLaunchKernelGGL(k_dc_check_cycle, dim3((items + 255) / 256, capacity), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_dc_check_cycle"));
-    { Prof _p(ctx, "k_dc_check_tail"); hipLaunchKernelGGL(k_dc_check_tail, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_dc_check_tail"));
-    CheckResult res;
-    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
-    *n_violations = res.violations;
-    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
-    return ZKW_OK;
+    return nl_check(ctx, 3, t, slot, capacity, n_violations, first_bad);
 }
 
 // copy-permutation check through sigma columns (zkw_setup_copy_permutation): trace[cell] == trace[sigma[cell]] for every cell
@@ -3934,11 +3986,9 @@ extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* m
     if (!ctx || !t || !queue_state || !record_out || t->ctx->device != ctx->device || slot >= t->n_slots || capacity == 0 || (n && !messages))
         return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize: bad argument");
     if (n > capacity) return fail(ZKW_ERR_INVALID, "%zu messages, the circuit hashes at most %u", n, capacity);
-    if (t->n_cols < KC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the LinearHasher circuit needs %d", t->n_cols, KC_COLS);
+    if (t->n_cols < LH_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the LinearHasher circuit needs %d", t->n_cols, LH_COLS);
     const u32 cycles = ZKW_LINEAR_HASHER_CYCLES(capacity);
     const size_t n_rows = t->n_rows, n_rounds = n * 88 / 136 + 1;
-    if (KC_MIN_ROWS(cycles) > n_rows)
-        return fail(ZKW_ERR_INVALID, "capacity %u = %u cycles needs %llu rows, trace has %zu", capacity, cycles, (unsigned long long)KC_MIN_ROWS(cycles), n_rows);
     HIP_TRY(hipSetDevice(ctx->device));
     const zkw_log_query* d_q = nullptr;
     ZKW_TRY(ctx->in("lh_q", messages, n, &d_q));
@@ -3963,59 +4013,18 @@ extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* m
     ZKW_TRY(launch_check("k_closed_form_commitments"));
     { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(1), dim3(64), 0, ctx->stream, d_cf, (size_t)1, (u32)COMPACT_FORM_LEN, d_pi); }
     ZKW_TRY(launch_check("k_commit_encodings"));
-    u32* d_hist = nullptr;
-    const size_t hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
-    ZKW_TRY(ctx->scratch_t<u32>("kc_hist", (size_t)KC_HIST_SLICES * KC_TABLE_ROWS, &d_hist));
-    uint16_t* d_keys = nullptr;
-    ZKW_TRY(ctx->scratch_t<uint16_t>("kc_keys", (size_t)cycles * KC_LOOKUPS_PER_ROW * (KC_ROWS_PER_CYCLE - 1), &d_keys));
-    std::vector<KcSynthJob> jobs(1);
-    jobs[0].rounds = d_rounds;
-    jobs[0].first_round = 0;
-    jobs[0].n_active = (u32)n_rounds;
-    jobs[0].public_input = d_pi;
-    jobs[0].trace = t->data + slot * t->slot_elems();
-    jobs[0].hist = d_hist;
-    jobs[0].keys = d_keys;
-    ZKW_TRY(zero_netlist_slot(ctx, jobs[0].trace, n_rows, KC_G, 3 * KC_LOOKUPS_PER_ROW, KC_COLS, (size_t)cycles * KC_ROWS_PER_CYCLE));
-    KcSynthJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("kc_jobs", jobs, &d_jobs));
-    { Prof _p(ctx, "k_kc_fill"); hipLaunchKernelGGL(k_kc_fill, dim3(cycles, 1), dim3(KC_FILL_THREADS), 0, ctx->stream, d_jobs, cycles, n_rows); }
-    ZKW_TRY(launch_check("k_kc_fill"));
-    { Prof _p(ctx, "k_kc_hist"); hipLaunchKernelGGL(k_kc_hist, dim3(KC_HIST_SLICES, 2, 1), dim3(KC_HIST_THREADS), 0, ctx->stream, d_jobs, cycles, n_rows); }
-    ZKW_TRY(launch_check("k_kc_hist"));
-    { Prof _p(ctx, "k_kc_finish"); hipLaunchKernelGGL(k_kc_finish, dim3((unsigned)((hist_elems + 255) / 256), 1), dim3(256), 0, ctx->stream, d_jobs, cycles, n_rows); }
-    ZKW_TRY(launch_check("k_kc_finish"));
+    std::vector<NlInstance> inst(1);
+    inst[0] = NlInstance{0, (u32)n_rounds, d_pi, t->data + slot * t->slot_elems()};
+    ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows));
     *record_out = rec;
     if (public_input_out) ZKW_TRY(ctx->read_small(public_input_out, d_pi, 32));
     return ZKW_OK;
 }
 
-extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
-                                                uint64_t* n_violations, uint64_t* first_bad) {
+extern "C" int zkw_linear_hasher_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
-        return fail(ZKW_ERR_INVALID, "zkw_keccak_round_check_satisfied: bad argument");
-    if (t->n_cols < KC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %d", t->n_cols, KC_COLS);
-    if (KC_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
-    HIP_TRY(hipSetDevice(ctx->device));
-    const u64* trace = t->data + slot * t->slot_elems();
-    const size_t n_rows = t->n_rows, hist_elems = (size_t)KC_NUM_TABLES * KC_TABLE_ROWS;
-    CheckResult* d_res = nullptr;
-    u32* d_hist = nullptr;
-    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
-    ZKW_TRY(ctx->scratch_t<u32>("kc_check_hist", hist_elems, &d_hist));
-    CheckResult init{0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, hist_elems * sizeof(u32), ctx->stream));
-    const size_t cyc_rows = KC_BOUNDARY_ROW(capacity);
-    { Prof _p(ctx, "k_kc_check_rows"); hipLaunchKernelGGL(k_kc_check_rows, dim3((unsigned)((cyc_rows + 255) / 256)), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_kc_check_rows"));
-    { Prof _p(ctx, "k_kc_check_tail"); hipLaunchKernelGGL(k_kc_check_tail, dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_kc_check_tail"));
-    CheckResult res;
-    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
-    *n_violations = res.violations;
-    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
-    return ZKW_OK;
+        return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_check_satisfied: bad argument");
+    return nl_check(ctx, 13, t, slot, ZKW_LINEAR_HASHER_CYCLES(capacity), n_violations, first_bad);
 }
 
 // ------------------------------------------------------------------------------------------------ StorageSorter synthesis

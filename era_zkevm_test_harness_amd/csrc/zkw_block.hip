@@ -151,7 +151,7 @@ struct zkw_block {
     PerType per[14];
     std::vector<zkw_vm_instance> vm_instances;
     // synthesis ring (created by the first zkw_block_synthesize)
-    zkw_trace* ring = nullptr;  // 151 columns: the widest of the synthesized types (a type with fewer uses the first of them)
+    zkw_trace* ring = nullptr;  // 153 columns: the widest of the synthesized types (a type with fewer uses the first of them)
     size_t ring_rows = 0, ring_slots = 0;
 
     double ms_now() const { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
@@ -800,7 +800,7 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
     }
     int rc = ZKW_OK;
     if (!B->ring) {
-        if ((rc = zkw_trace_create_with_columns(B->ctx[C_RAM], n_rows, 151, ring_slots, &B->ring)) != ZKW_OK) return rc;
+        if ((rc = zkw_trace_create_with_columns(B->ctx[C_RAM], n_rows, 153, ring_slots, &B->ring)) != ZKW_OK) return rc;
         B->ring_rows = n_rows;
         B->ring_slots = ring_slots;
     }

@@ -135,6 +135,7 @@ SYMBOLS = [
     ("zkw_code_decommitter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_sha256_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_linear_hasher_synthesize", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
+    ("zkw_linear_hasher_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
@@ -1060,7 +1061,7 @@ CIRCUIT_GEOMETRY = np.dtype(
 
 
 CIRCUIT_LAYOUT = np.dtype(
-    [("synthesizable", "<u4"), ("fits", "<u4"), ("capacity", "<u4"), ("num_columns", "<u4"), ("rows_per_cycle", "<u4"), ("_pad", "<u4"),
+    [("synthesizable", "<u4"), ("fits", "<u4"), ("capacity", "<u4"), ("num_columns", "<u4"), ("rows_per_cycle", "<u4"), ("total_table_rows", "<u4"),
      ("region_stride", "<u8"), ("rows_used", "<u8"), ("nop_rows", "<u8"), ("trace_len", "<u8"), ("public_input_column", "<u4", (4,)),
      ("public_input_row", "<u8", (4,))])
 
@@ -1128,12 +1129,12 @@ def _ctx_check_if_satisfied_log_demux(self, trace, slot, capacity):
 Context.synthesize_log_demux = _ctx_synthesize_log_demux
 
 
-KC_COLS = 137  # include/zkw_keccak_circuit_spec.h
+KC_COLS, LH_COLS = 129, 145  # 86 + 3 x 14 + 1, 66 + 3 x 26 + 1 (include/zkw_keccak_circuit_spec.h, zkw_linear_hasher_circuit_spec.h)
 
 
 def _ctx_synthesize_keccak_round_function(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
-    """ZkSyncBaseLayerCircuit::Keccak256RoundFunction synthesis ("zkw trace v3") for instances of a keccak256
-    PrecompileWitness (the trace needs KC_COLS = 137 columns and at least 65 536 rows)."""
+    """ZkSyncBaseLayerCircuit::Keccak256RoundFunction synthesis ("zkw trace v4") for instances of a keccak256
+    PrecompileWitness (the trace needs KC_COLS columns and at least 132 096 rows: the stacked tables)."""
     n = witness.num_instances - first_instance if n_instances is None else n_instances
     _check(load().zkw_keccak_round_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
 
@@ -1151,8 +1152,8 @@ def linear_hasher_cycles(capacity):
 
 def _ctx_synthesize_linear_hasher(self, messages, queue_state, capacity, trace, slot=0):
     """ZkSyncBaseLayerCircuit::LinearHasher synthesis (type 13) over the net L2 -> L1 messages of a block: returns the
-    instance record and its public input. Check with check_if_satisfied_keccak_round_function(trace, slot,
-    linear_hasher_cycles(capacity))."""
+    instance record and its public input (the trace needs LH_COLS columns). Check with check_if_satisfied_linear_hasher(trace,
+    slot, capacity)."""
     q = np.ascontiguousarray(messages, dtype=LOG_QUERY)
     qs = np.ascontiguousarray(queue_state, dtype=QUEUE_STATE4).reshape(1)
     rec = np.zeros(1, LINEAR_HASHER_INSTANCE)
@@ -1162,12 +1163,12 @@ def _ctx_synthesize_linear_hasher(self, messages, queue_state, capacity, trace, 
     return rec, pi
 
 
-SC_COLS = 138  # include/zkw_sha256_circuit_spec.h
+SC_COLS = 153  # 116 + 4 x 9 + 1 (include/zkw_sha256_circuit_spec.h)
 
 
 def _ctx_synthesize_sha256_round_function(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
-    """ZkSyncBaseLayerCircuit::Sha256RoundFunction synthesis ("zkw trace v3") for instances of a sha256 PrecompileWitness
-    (the trace needs SC_COLS = 138 columns and at least 65 536 rows)."""
+    """ZkSyncBaseLayerCircuit::Sha256RoundFunction synthesis ("zkw trace v4") for instances of a sha256 PrecompileWitness
+    (the trace needs SC_COLS columns)."""
     n = witness.num_instances - first_instance if n_instances is None else n_instances
     _check(load().zkw_sha256_round_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
 
@@ -1179,12 +1180,12 @@ def _ctx_check_if_satisfied_sha256_round_function(self, trace, slot, capacity):
     return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
-DC_COLS = 150  # include/zkw_code_decommitter_circuit_spec.h
+DC_COLS = 153  # 108 + 4 x 11 + 1 (include/zkw_code_decommitter_circuit_spec.h)
 
 
 def _ctx_synthesize_code_decommitter(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
-    """ZkSyncBaseLayerCircuit::CodeDecommitter synthesis ("zkw trace v3": the SHA-256 netlist at 18 lookups per row) for
-    instances of a DecommitterWitness (the trace needs DC_COLS = 150 columns and at least 65 536 rows)."""
+    """ZkSyncBaseLayerCircuit::CodeDecommitter synthesis ("zkw trace v4": the SHA-256 netlist on 108 + 4 x 11 columns) for
+    instances of a DecommitterWitness (the trace needs DC_COLS columns)."""
     n = witness.num_instances - first_instance if n_instances is None else n_instances
     _check(load().zkw_code_decommitter_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
 
@@ -1209,6 +1210,14 @@ def _ctx_check_copy_permutation(self, trace, slot, sigma):
     return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
+def _ctx_check_if_satisfied_linear_hasher(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_linear_hasher_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.check_if_satisfied_linear_hasher = _ctx_check_if_satisfied_linear_hasher
 Context.check_copy_permutation = _ctx_check_copy_permutation
 Context.synthesize_linear_hasher = _ctx_synthesize_linear_hasher
 Context.synthesize_keccak_round_function = _ctx_synthesize_keccak_round_function
@@ -1594,7 +1603,7 @@ class Block:
 
     CHECKERS = {8: "zkw_ram_check_satisfied", 2: "zkw_decommit_sorter_check_satisfied", 4: "zkw_log_demux_check_satisfied",
                 9: "zkw_storage_sorter_check_satisfied", 11: "zkw_events_sorter_check_satisfied", 12: "zkw_events_sorter_check_satisfied",
-                5: "zkw_keccak_round_check_satisfied", 13: "zkw_keccak_round_check_satisfied", 6: "zkw_sha256_round_check_satisfied",
+                5: "zkw_keccak_round_check_satisfied", 13: "zkw_linear_hasher_check_satisfied", 6: "zkw_sha256_round_check_satisfied",
                 3: "zkw_code_decommitter_check_satisfied"}
 
     def check_satisfied(self, circuit_type, trace_handle, slot):
@@ -1602,8 +1611,6 @@ class Block:
         lib = load()
         bad, first = C.c_uint64(0), C.c_uint64(0)
         cap = self.capacities[circuit_type]
-        if circuit_type == 13:  # the LinearHasher trace is the keccak netlist over ZKW_LINEAR_HASHER_CYCLES(capacity) cycles
-            cap = linear_hasher_cycles(cap)
         _check(getattr(lib, self.CHECKERS[circuit_type])(lib.zkw_block_context(self.handle, circuit_type), trace_handle, slot,
                                                          cap, C.byref(bad), C.byref(first)))
         return bad.value, first.value

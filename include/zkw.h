@@ -118,7 +118,7 @@ typedef struct zkw_circuit_layout {
     uint32_t capacity;
     uint32_t num_columns;       /* copy-permutation + lookup + multiplicity columns of a trace slot */
     uint32_t rows_per_cycle;    /* row types repeated once per cycle, region-major */
-    uint32_t _pad;
+    uint32_t total_table_rows;  /* rows of the stacked lookup tables = the reference's `total_tables_len` (vk_N.json) */
     uint64_t region_stride;     /* rows between two regions (capacity rounded up to 64); 0: cycle-major (the netlist circuits 3, 5, 6, 13) */
     uint64_t rows_used;         /* cycle regions + boundary rows */
     uint64_t nop_rows;          /* trace_len - rows_used: zero padding, the reference's nop_gates_to_add */
@@ -590,8 +590,8 @@ int zkw_code_decommitter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_
    hashes the n <= capacity serialized messages (host or device pointer per the pointer mode); cycles =
    ZKW_LINEAR_HASHER_CYCLES(capacity), idle beyond the message's rounds; BND_OUT's first 32 bytes are the pubdata hash.
    queue_state (host): the state of the deduplicated L1-messages queue = the closed form's observable input. record_out /
-   public_input_out (host): the instance record and its public input [4] (may be NULL). Check with
-   zkw_keccak_round_check_satisfied(ctx, t, slot, ZKW_LINEAR_HASHER_CYCLES(capacity), ..). */
+   public_input_out (host): the instance record and its public input [4] (may be NULL). Its own geometry (66 + 3 x 26 + 1
+   columns: zkw_circuit_layout_of(13)); check with zkw_linear_hasher_check_satisfied(ctx, t, slot, capacity, ..). */
 int zkw_linear_hasher_synthesize(zkw_ctx *ctx, const zkw_log_query *messages, size_t n, const zkw_queue_state4 *queue_state,
                                  uint32_t capacity, zkw_trace *t, size_t slot, zkw_linear_hasher_instance *record_out,
                                  uint64_t *public_input_out);
@@ -655,6 +655,8 @@ int zkw_create_node_witnesses(zkw_ctx *ctx, uint8_t branch_circuit_type, const z
                               zkw_queue_state12 *node_states, zkw_queue_tail12 *split_points, uint64_t *node_public_inputs,
                               size_t max_nodes, size_t *n_nodes);
 
+int zkw_linear_hasher_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity, uint64_t *n_violations,
+                                     uint64_t *first_bad);
 /* ---- L1 messages hasher ------------------------------------------------------------------------------ */
 /* compute_linear_keccak256, src/witness/individual_circuits/data_hasher_and_merklizer.rs:8-67: Keccak-256 of
    the concatenated 88-byte serialisations (circuit_encodings/src/log_query.rs:503-534) of the net L2->L1

@@ -240,7 +240,17 @@ int64_t orc_precompile_build_ex(int kind, const zkw_log_query *requests, const u
                                 const zkw_mem_query *mem_q, size_t n_q, uint32_t capacity, const zkw_queue_state12 *mem_in,
                                 uint64_t *mem_enc, uint64_t *mem_tails, zkw_precompile_instance *instances,
                                 zkw_keccak_round_record *keccak_rounds);
-/* ---- Keccak256RoundFunction circuit ("zkw trace v3", include/zkw_keccak_circuit_spec.h), keccak_circuit.c */
+/* ---- the netlist circuits ("zkw trace v4", include/zkw_netlist.h), netlist_circuit.c: one fill, one checker, four specs */
+#include "../include/zkw_netlist.h"
+const nl_spec *orc_nl_spec(int circuit_type); /* 6, 3, 5, 13 */
+int orc_nl_synthesize(const nl_spec *sp, uint32_t capacity, const uint8_t *hdr_bits, const uint8_t *free_elems, const uint8_t *state_before,
+                      const uint64_t pi[4], size_t n_rows, uint64_t *trace);
+uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+void orc_nl_geometry(int circuit_type, uint32_t out[6]);
+void orc_nl_slots_per_cycle(int circuit_type, uint32_t *out);
+int orc_linear_hasher_round_synthesize(const uint8_t state_in[200], const zkw_keccak_round_record *rounds, uint32_t n_active,
+                                       uint32_t capacity, const uint64_t pi[4], size_t n_rows, uint64_t *trace);
+uint64_t orc_linear_hasher_round_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 int orc_keccak_round_synthesize(const uint8_t state_in[200], const zkw_keccak_round_record *rounds, uint32_t n_active,
                                 uint32_t capacity, const uint64_t pi[4], size_t n_rows, uint64_t *trace);
 uint64_t orc_keccak_round_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);

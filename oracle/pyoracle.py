@@ -3,6 +3,7 @@ of the reference hot path, see oracle/oracle.h). Only tests/, __graft_entry__.sm
 cpu_baseline leg may import this module; the product package never does.
 """
 import ctypes as C
+import re
 import os
 import subprocess
 
@@ -632,7 +633,6 @@ def precompile_build(kind, requests, request_tails, mem_queries, capacity, mem_i
     return o
 
 
-KC_COLS, KC_G, KC_ROWS_PER_CYCLE = 137, 86, 1919
 
 
 def keccak_round_synthesize(build_out, instance_index, capacity, n_rows, public_input=None):
@@ -644,7 +644,7 @@ def keccak_round_synthesize(build_out, instance_index, capacity, n_rows, public_
     state_in = np.ascontiguousarray(build_out["keccak_rounds"][first - 1]["state_after"]) if first else np.zeros(200, np.uint8)
     pi = np.ascontiguousarray(public_input if public_input is not None else
                               closed_form_public_inputs(5, build_out["instances"])[1][instance_index], dtype=np.uint64)
-    trace = np.zeros((KC_COLS, n_rows), np.uint64)
+    trace = np.zeros((nl_geometry(5)["cols"], n_rows), np.uint64)
     f = lib().orc_keccak_round_synthesize
     f.restype = C.c_int
     rc = f(_p(state_in), _p(recs) if n else None, C.c_uint32(n), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
@@ -653,7 +653,31 @@ def keccak_round_synthesize(build_out, instance_index, capacity, n_rows, public_
     return trace
 
 
-SC_COLS, SC_ROWS_PER_CYCLE = 138, 469
+def nl_geometry(circuit_type):
+    """{cols, general, lookup width, lookups per row, total table rows, rows per cycle} of a netlist circuit's layout (3, 5, 6, 13)"""
+    out = np.zeros(6, np.uint32)
+    lib().orc_nl_geometry(C.c_int(circuit_type), _p(out))
+    return dict(zip(("cols", "general", "width", "lookups_per_row", "table_rows", "rows_per_cycle"), (int(x) for x in out)))
+
+
+def nl_spec_state(circuit_type):
+    """elements of the chaining / sponge state of a netlist circuit (64 nibbles, 200 bytes)"""
+    return 64 if circuit_type in (3, 6) else 200
+
+
+def nl_slots_per_cycle(circuit_type):
+    """lookup slots of one cycle (padding included: every slot is counted by the multiplicity column)"""
+    out = np.zeros(1, np.uint32)
+    lib().orc_nl_slots_per_cycle(C.c_int(circuit_type), _p(out))
+    return int(out[0])
+
+
+def __getattr__(name):  # SC_COLS, KC_ROWS_PER_CYCLE, ...: read from the compiled specs, not restated here
+    m = re.fullmatch(r"(SC|DC|KC|LH)_(COLS|ROWS_PER_CYCLE)", name)
+    if not m:
+        raise AttributeError(name)
+    g = nl_geometry({"SC": 6, "DC": 3, "KC": 5, "LH": 13}[m.group(1)])
+    return g["cols"] if m.group(2) == "COLS" else g["rows_per_cycle"]
 
 
 def sha256_round_synthesize_raw(state_in, records, capacity, n_rows, public_input):
@@ -662,7 +686,7 @@ def sha256_round_synthesize_raw(state_in, records, capacity, n_rows, public_inpu
     recs = np.ascontiguousarray(records, dtype=SHA256_ROUND_RECORD)
     st = np.ascontiguousarray(state_in, dtype=np.uint8)
     pi = np.ascontiguousarray(public_input, dtype=np.uint64)
-    trace = np.zeros((SC_COLS, n_rows), np.uint64)
+    trace = np.zeros((nl_geometry(6)["cols"], n_rows), np.uint64)
     f = lib().orc_sha256_round_synthesize
     f.restype = C.c_int
     rc = f(_p(st), _p(recs) if recs.size else None, C.c_uint32(recs.size), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
@@ -681,7 +705,6 @@ def sha256_round_synthesize(build_out, instance_index, capacity, n_rows, public_
     return sha256_round_synthesize_raw(state_in, build_out["sha256_rounds"][first:first + n], capacity, n_rows, pi)
 
 
-DC_COLS, DC_ROWS_PER_CYCLE = 150, 366
 
 
 def code_decommitter_synthesize(build_out, instance_index, capacity, n_rows, public_input=None):
@@ -693,7 +716,7 @@ def code_decommitter_synthesize(build_out, instance_index, capacity, n_rows, pub
                 else np.zeros(32, np.uint8))
     pi = np.ascontiguousarray(public_input if public_input is not None else
                               closed_form_public_inputs(3, build_out["instances"])[1][instance_index], dtype=np.uint64)
-    trace = np.zeros((DC_COLS, n_rows), np.uint64)
+    trace = np.zeros((nl_geometry(3)["cols"], n_rows), np.uint64)
     f = lib().orc_code_decommitter_round_synthesize
     f.restype = C.c_int
     rc = f(_p(np.ascontiguousarray(state_in)), _p(recs) if n else None, C.c_uint32(n), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
@@ -742,13 +765,23 @@ def linear_hasher_synthesize(messages, queue_state, capacity, n_rows):
     inst["keccak256_hash"] = recs["state_after"][-1][:32]
     pi = closed_form_public_inputs(13, inst)[1][0]
     cycles = linear_hasher_cycles(capacity)
-    trace = np.zeros((KC_COLS, n_rows), np.uint64)
-    g = lib().orc_keccak_round_synthesize
+    trace = np.zeros((nl_geometry(13)["cols"], n_rows), np.uint64)
+    g = lib().orc_linear_hasher_round_synthesize
     g.restype = C.c_int
     rc = g(_p(np.zeros(200, np.uint8)), _p(recs), C.c_uint32(n), C.c_uint32(cycles), _p(pi), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
-        raise RuntimeError(f"orc_keccak_round_synthesize failed: {rc}")
+        raise RuntimeError(f"orc_linear_hasher_round_synthesize failed: {rc}")
     return trace, inst, pi
+
+
+def linear_hasher_check(trace, cycles):
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_linear_hasher_round_check
+    f.restype = C.c_uint64
+    bad = f(_p(trace), C.c_uint32(cycles), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value
+    return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
 def keccak_round_check(trace, capacity):

@@ -1,6 +1,6 @@
 """Regenerates tests/golden/netlist_trace_digests.json: SHA-256 digests of small oracle-synthesized traces of the netlist
-circuits (types 5, 13, 6, 3) on fixed seeds. The traces do not depend on Poseidon2 except for the four public-input cells,
-which are zeroed here — so these digests pin the netlists, the layouts and the fills independently of the unpinned
+circuits (types 5, 13, 6, 3; "zkw trace v4") on fixed seeds. The traces do not depend on Poseidon2 except for the four public-input cells,
+which are zeroed here — so these digests pin the netlists, the layouts and the fills independently of the
 permutation. Run from the repository root:  python tests/golden/make_netlist_digests.py"""
 import hashlib
 import json
@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from era_zkevm_test_harness_amd import synthetic  # noqa: E402
 from oracle import pyoracle as o  # noqa: E402
 
-N_ROWS = 1 << 16
+N_ROWS = 1 << 18  # the stacked Keccak tables alone are 132 096 rows
 ZERO_PI = np.zeros(4, np.uint64)
 
 
@@ -37,15 +37,9 @@ def cases():
     for i in range(w["instances"].size):
         out[f"code_decommitter/capacity7/instance{i}"] = digest(o.code_decommitter_synthesize(w, i, 7, N_ROWS, public_input=ZERO_PI))
     q = synthetic.mixed_log_queue(36, seed=8)[:7]
-    recs = np.zeros(q.size * 88 // 136 + 1, o.KECCAK_ROUND_RECORD)
-    f = o.lib().orc_linear_hasher_rounds
-    import ctypes as C
-    f.restype = C.c_size_t
-    n = f(o._p(q), C.c_size_t(q.size), o._p(recs))
-    tr = np.zeros((o.KC_COLS, N_ROWS), np.uint64)
-    g = o.lib().orc_keccak_round_synthesize
-    g.restype = C.c_int
-    assert g(o._p(np.zeros(200, np.uint8)), o._p(recs), C.c_uint32(n), C.c_uint32(o.linear_hasher_cycles(20)), o._p(ZERO_PI), C.c_size_t(N_ROWS), o._p(tr)) == 0
+    tr, inst, pi = o.linear_hasher_synthesize(q, np.zeros(1, o.QUEUE_STATE4), 20, N_ROWS)
+    g = o.nl_geometry(13)
+    tr[:4, o.linear_hasher_cycles(20) * g["rows_per_cycle"] + 2 * -(-200 // g["general"])] = 0  # the Poseidon2-dependent public input
     out["linear_hasher/capacity20/7messages"] = digest(tr)
     return out
 

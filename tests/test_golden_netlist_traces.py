@@ -1,7 +1,7 @@
 """CPU: the oracle's netlist traces (types 5, 13, 6, 3) on fixed seeds hash to the committed digests
 (tests/golden/netlist_trace_digests.json, made by tests/golden/make_netlist_digests.py with the four Poseidon2-dependent
 public-input cells zeroed): a silent change of a generator, a layout or a fill shows up here even when GPU and oracle
-change together. The GPU is tied to the same traces cell for cell by tests/test_gpu_{keccak,sha256}_circuit.py."""
+change together. The GPU is tied to the same traces cell for cell by tests/test_gpu_netlist_circuits.py."""
 import importlib.util
 import json
 import os

@@ -169,7 +169,7 @@ def test_block_sequencer_matches_builder_by_builder(ctx, oracle, seed):
         assert pi == [int(x) for x in a["public_inputs"][ctype][inst]]
         seen.append((ctype, inst))
 
-    n = B.synthesize(1 << 16, ring_slots=3, callback=on_circuit)
+    n = B.synthesize(1 << 18, ring_slots=3, callback=on_circuit)
     order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.DECOMMITS_SORTER, blk.CODE_DECOMMITTER, blk.KECCAK256, blk.SHA256, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER,
              blk.L1_MESSAGES_HASHER]
     assert seen == [(t, i) for t in order for i in range(B.num_instances(t))] and n == len(seen) > 12
@@ -208,7 +208,7 @@ def test_block_sharded_synthesis_and_gather(ctx):
     got = []
     for rank in range(3):
         seen = []
-        n = B.synthesize(1 << 16, ring_slots=2, callback=lambda t, i, tr, s, pi: seen.append((t, i)), rank=rank, world=3)
+        n = B.synthesize(1 << 18, ring_slots=2, callback=lambda t, i, tr, s, pi: seen.append((t, i)), rank=rank, world=3)
         assert n == len(seen) and seen == [x for x, o in zip(full, owner) if o == rank]
         got += seen
     assert sorted(got) == sorted(full) and len(set(got)) == len(full)
@@ -278,7 +278,7 @@ def test_blocks_run_many_at_once(ctx, oracle):
             assert np.array_equal(m.public_inputs(t), one.public_inputs(t))
             assert np.array_equal(m.recursion_queue(t)[1], one.recursion_queue(t)[1])
         bad = []
-        n = m.synthesize(1 << 16, ring_slots=2, callback=lambda t, i, tr, s, pi: bad.append(m.check_satisfied(t, tr, s)[0]))
+        n = m.synthesize(1 << 18, ring_slots=2, callback=lambda t, i, tr, s, pi: bad.append(m.check_satisfied(t, tr, s)[0]))
         assert n == len(bad) > 10 and not any(bad)
         one.free()
     # the oracle agrees with one of them end to end (public inputs of the RAM permutation)

@@ -1,0 +1,160 @@
+"""GPU: the four netlist circuits in "zkw trace v4" (csrc/netlist_kernels.cuh) through the C ABI against the oracle
+(oracle/netlist_circuit.c): Keccak256RoundFunction (5), Sha256RoundFunction (6), CodeDecommitter (3), L1MessagesHasher (13) on the
+reference's geometry and table sets. Traces cell for cell; the two checkers violation for violation on tampered cells of every
+region (header, lookup inputs / outputs, gate cells, multiplicities, boundary rows, padding); production geometry (2^20 rows at
+the reference's capacities) through the GPU checker."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+N_ROWS = 1 << 18
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from era_zkevm_test_harness_amd import native
+
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def _precompile(ctx, oracle, kind, n_req, cap, seed=3, max_rounds=4):
+    from era_zkevm_test_harness_amd import native
+
+    req, mq = synthetic.precompile_trace(kind, n_req, seed=seed, max_rounds=max_rounds)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    mem_in = np.zeros(1, native.QUEUE_STATE12)
+    return ctx._precompile(kind, req, tails, mq, cap, mem_in), oracle.precompile_build(kind, req, tails, mq, cap, mem_in)
+
+
+CIRCUITS = {5: (0, "KC_COLS", "synthesize_keccak_round_function", "check_if_satisfied_keccak_round_function", "keccak_round_synthesize", "keccak_round_check", 6),
+            6: (1, "SC_COLS", "synthesize_sha256_round_function", "check_if_satisfied_sha256_round_function", "sha256_round_synthesize", "sha256_round_check", 7)}
+
+
+@pytest.mark.parametrize("ct", [5, 6])
+def test_traces_match_oracle_and_tamper_parity(ctx, oracle, ct):
+    from era_zkevm_test_harness_amd import native
+
+    kind, cols, synth, check, osynth, ocheck, cap = CIRCUITS[ct]
+    cols = getattr(native, cols)
+    w, o = _precompile(ctx, oracle, kind, 9, cap)
+    ni = w.num_instances
+    assert ni >= 3 and ni == o["instances"].size
+    lay = native.circuit_layout(ct, cap)
+    assert int(lay["num_columns"]) == cols and int(lay["total_table_rows"]) == oracle.nl_geometry(ct)["table_rows"]
+    t = native.Trace(ctx, N_ROWS, ni, n_cols=cols)
+    getattr(ctx, synth)(w, t, 0, ni, 0)
+    for i in range(ni):
+        exp = getattr(oracle, osynth)(o, i, cap, N_ROWS)
+        got = t.get(i)
+        assert np.array_equal(got, exp), np.argwhere(got != exp)[:4]
+        assert getattr(ctx, check)(t, i, cap) == (0, (0, 0, 0))
+        assert got[:4, int(lay["public_input_row"][0])].tolist() == oracle.closed_form_public_inputs(ct, o["instances"])[1][i].tolist()
+    # tamper parity on instance 1: random cells of every region + the structured ones; upload the tampered slot and compare verdicts
+    base = getattr(oracle, osynth)(o, 1, cap, N_ROWS)
+    g = oracle.nl_geometry(ct)
+    rpc, G = g["rows_per_cycle"], g["general"]
+    rng = np.random.default_rng(ct)
+    used = cap * rpc
+    cells = [(int(rng.integers(0, G)), int(rng.integers(0, used))) for _ in range(14)]                      # general-purpose cells: gates, headers, empties
+    cells += [(int(rng.integers(G, cols - 1)), int(rng.integers(0, used))) for _ in range(14)]               # lookup cells
+    cells += [(cols - 1, int(rng.integers(0, g["table_rows"]))) for _ in range(4)] + [(cols - 1, g["table_rows"] + 5)]  # multiplicities
+    cells += [(int(rng.integers(0, G)), used + k) for k in range(0, 2 * -(-oracle.nl_spec_state(ct) // G) + 3)]          # boundary rows, PI, below
+    cells += [(0, rpc), (1, rpc), (2, rpc), (3, 2 * rpc)]                                                   # reset / idle / masks
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    n_flagged = 0
+    for col, row in cells:
+        bad = base.copy()
+        bad[col, row] = bad[col, row] + 1 if rng.random() < 0.7 else 300
+        ctx.synchronize()
+        assert hip.hipMemcpy(t.device_ptr(0), bad.ctypes.data, bad.nbytes, 1) == 0
+        got = getattr(ctx, check)(t, 0, cap)
+        want = getattr(oracle, ocheck)(bad, cap)
+        assert got == want, ((col, row), got, want)
+        n_flagged += got[0] > 0
+    assert n_flagged >= len(cells) - 2  # (a PI cell is free; everything else is constrained)
+    t.free()
+    w.free()
+
+
+def test_linear_hasher_matches_oracle(ctx, oracle):
+    from era_zkevm_test_harness_amd import native
+
+    for n, cap in ((0, 4), (7, 20), (20, 20)):
+        q = synthetic.random_log_queries(max(n, 1), seed=n + 1)[:n]
+        qs = np.zeros(1, native.QUEUE_STATE4)
+        t = native.Trace(ctx, N_ROWS, 1, n_cols=native.LH_COLS)
+        rec, pi = ctx.synthesize_linear_hasher(q, qs, cap, t, 0)
+        exp, orec, opi = oracle.linear_hasher_synthesize(q, qs, cap, N_ROWS)
+        assert np.array_equal(t.get(0), exp) and rec.tobytes() == orec.tobytes() and np.array_equal(pi, opi)
+        assert rec["keccak256_hash"][0].tobytes() == oracle.linear_keccak256(q)
+        assert ctx.check_if_satisfied_linear_hasher(t, 0, cap) == (0, (0, 0, 0))
+        t.free()
+
+
+def test_dummy_instances_of_empty_queues(ctx, oracle):
+    """no request at all: one instance of idle cycles, satisfied, equal to the oracle's"""
+    from era_zkevm_test_harness_amd import native
+
+    for ct in (5, 6):
+        kind, cols, synth, check, osynth, ocheck, cap = CIRCUITS[ct]
+        w, o = _precompile(ctx, oracle, kind, 0, cap)
+        assert w.num_instances == 1
+        t = native.Trace(ctx, N_ROWS, 1, n_cols=getattr(native, cols))
+        getattr(ctx, synth)(w, t, 0, 1, 0)
+        assert np.array_equal(t.get(0), getattr(oracle, osynth)(o, 0, cap, N_ROWS)) and getattr(ctx, check)(t, 0, cap)[0] == 0
+        t.free()
+        w.free()
+
+
+@pytest.mark.parametrize("ct,n_req,max_rounds", [(5, 700, 2), (6, 3000, 3)])
+def test_production_geometry(ctx, oracle, ct, n_req, max_rounds):
+    """2^20 rows at the reference's capacity (293 / 2206 cycles): two full instances synthesized in one call and checked on the GPU;
+    the multiplicity column counts every lookup slot once"""
+    from era_zkevm_test_harness_amd import native
+
+    kind, cols, synth, check, osynth, ocheck, _ = CIRCUITS[ct]
+    cap = int(native.circuit_geometry(ct)["capacity"])
+    w, _o = _precompile(ctx, oracle, kind, n_req, cap, seed=11, max_rounds=max_rounds)
+    assert w.num_instances >= 2
+    n_rows = 1 << 20
+    lay = native.circuit_layout(ct)
+    assert int(lay["fits"]) == 1 and int(lay["rows_used"]) <= n_rows
+    t = native.Trace(ctx, n_rows, 2, n_cols=getattr(native, cols))
+    getattr(ctx, synth)(w, t, 0, 2, 0)
+    g = oracle.nl_geometry(ct)
+    for i in range(2):
+        assert getattr(ctx, check)(t, i, cap) == (0, (0, 0, 0))
+        mult = t.get(i, getattr(native, cols) - 1, 1)[0]
+        assert int(mult.sum()) == cap * oracle.nl_slots_per_cycle(ct) and not mult[g["table_rows"]:].any()
+    t.free()
+    w.free()
+
+
+def test_code_decommitter_over_a_block(ctx, oracle):
+    from era_zkevm_test_harness_amd import native
+
+    b = synthetic.block_after_vm(seed=2)
+    cap = 7
+    dec = ctx.compute_decommitts_sorter_circuit_snapshots(b["decommit_queries"], 5)
+    dq, dt = dec.get(native.DEC_DEDUP_QUERIES), dec.get(native.DEC_DEDUP_TAILS)
+    codes = [b["bytecodes"][h.tobytes()] for h in dq["hash"]]
+    woff = np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]).astype(np.uint64)
+    mem_in = np.zeros(1, native.QUEUE_STATE12)
+    w = ctx.compute_decommitter_circuit_snapshots(dq, dt, np.concatenate(codes), woff, cap, mem_in)
+    o = oracle.decommitter_build(dq, dt, np.concatenate(codes), woff, cap, mem_in)
+    ni = w.num_instances
+    t = native.Trace(ctx, N_ROWS, ni, n_cols=native.DC_COLS)
+    ctx.synthesize_code_decommitter(w, t, 0, ni, 0)
+    for i in range(ni):
+        assert np.array_equal(t.get(i), oracle.code_decommitter_synthesize(o, i, cap, N_ROWS))
+        assert ctx.check_if_satisfied_code_decommitter(t, i, cap) == (0, (0, 0, 0))
+    t.free()
+    w.free()
+    dec.free()

@@ -7,7 +7,7 @@ import pytest
 from era_zkevm_test_harness_amd import synthetic
 
 pytestmark = pytest.mark.gpu
-N_ROWS = 1 << 16
+N_ROWS = 1 << 18  # the stacked Keccak tables alone are 132 096 rows
 
 
 @pytest.fixture(scope="module")

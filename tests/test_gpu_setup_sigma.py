@@ -58,7 +58,7 @@ def test_gpu_traces_satisfy_sigma(ctx):
 def test_gpu_netlist_traces_satisfy_sigma(ctx, oracle):
     from era_zkevm_test_harness_amd import native
 
-    n_rows = 1 << 16
+    n_rows = 1 << 18
     for kind, ctype, cap, cols, synth in ((0, 5, 6, native.KC_COLS, ctx.synthesize_keccak_round_function),
                                           (1, 6, 7, native.SC_COLS, ctx.synthesize_sha256_round_function)):
         req, mq = synthetic.precompile_trace(kind, 9, seed=3, max_rounds=4)

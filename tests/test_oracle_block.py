@@ -25,7 +25,7 @@ def test_oracle_block_threads_queues_and_satisfies_circuits(oracle):
               ob.STORAGE_SORTER: oracle.storage_sorter_check, ob.EVENTS_SORTER: oracle.events_sorter_check,
               ob.L1_MESSAGES_SORTER: oracle.events_sorter_check, ob.KECCAK256: oracle.keccak_round_check, ob.SHA256: oracle.sha256_round_check,
               ob.CODE_DECOMMITTER: oracle.code_decommitter_check,
-              ob.L1_MESSAGES_HASHER: lambda t, cap: oracle.keccak_round_check(t, oracle.linear_hasher_cycles(cap))}
+              ob.L1_MESSAGES_HASHER: lambda t, cap: oracle.linear_hasher_check(t, oracle.linear_hasher_cycles(cap))}
     seen = []
 
     def on_trace(ctype, i, t):
@@ -33,7 +33,7 @@ def test_oracle_block_threads_queues_and_satisfies_circuits(oracle):
         assert bad == 0, (ctype, i, first)
         seen.append(ctype)
 
-    n = ob.synthesize_all(a, 1 << 16, on_trace)
+    n = ob.synthesize_all(a, 1 << 18, on_trace)
     assert n == len(seen) > 12 and seen == sorted(seen, key=ob.EMISSION_ORDER.index)
     for ctype, (enc, states) in a["recursion_queues"].items():
         assert np.array_equal(enc[:, 1:5], a["public_inputs"][ctype]) and (enc[:, 0] == ctype).all()

@@ -6,53 +6,61 @@ import pytest
 
 from era_zkevm_test_harness_amd import native as nv, synthetic
 
-N_ROWS = 1 << 16
+N_ROWS = 1 << 18  # the stacked Keccak tables alone are 132 096 rows
 
 
-def _table(t, a, b):
-    if t == 1:
-        return a ^ b
-    if t == 2:
-        return ~a & 0xFF & b
-    if t == 10:
-        return a & b
-    s = t - 2
-    return ((a << s) & 0xFF) | (b >> (8 - s))
+def _tables(ctype):
+    """table id -> (inputs, function of the input columns -> output columns), restated in numpy from the reference's table set"""
+    if ctype in (3, 6):  # TriXor4, Ch4, Maj4, Split4BitChunk<1>, <2>
+        sp = lambda k: (1, lambda a: [a & ((1 << k) - 1), a >> k, ((a & ((1 << k) - 1)) << (4 - k)) | (a >> k)])  # noqa: E731
+        return {1: (3, lambda a, b, c: [a ^ b ^ c]), 2: (3, lambda e, f, g: [(e & f) ^ (~e & g & 15)]),
+                3: (3, lambda a, b, c: [(a & b) ^ (a & c) ^ (b & c)]), 4: sp(1), 5: sp(2)}
+    bs = lambda k: (1, lambda a: [a & ((1 << k) - 1), a >> k])  # noqa: E731
+    return {1: (2, lambda a, b: [a ^ b]), 2: (2, lambda a, b: [a & b]), 3: bs(1), 4: bs(2), 5: bs(3), 6: bs(4)}  # Xor8, And8, ByteSplit<1..4>
 
 
 def _netlist_cases(oracle):
     out = []
-    for kind, ctype, cap, synth, cols0, lpr in ((0, 5, 6, oracle.keccak_round_synthesize, 86, 14), (1, 6, 7, oracle.sha256_round_synthesize, 86, 14)):
+    geo = lambda ct: (oracle.nl_geometry(ct)["general"], oracle.nl_geometry(ct)["width"], oracle.nl_geometry(ct)["lookups_per_row"])  # noqa: E731
+    for kind, ctype, cap, synth in ((0, 5, 6, oracle.keccak_round_synthesize), (1, 6, 7, oracle.sha256_round_synthesize)):
         req, mq = synthetic.precompile_trace(kind, 9, seed=3, max_rounds=4)
         tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
         w = oracle.precompile_build(kind, req, tails, mq, cap, np.zeros(1, oracle.QUEUE_STATE12))
-        out.append((ctype, cap, synth(w, 1, cap, N_ROWS), cols0, lpr))
+        out.append((ctype, cap, synth(w, 1, cap, N_ROWS)) + geo(ctype))
     from oracle import block as ob
     a = ob.create_artifacts_after_vm(synthetic.block_after_vm(seed=2), {ob.CODE_DECOMMITTER: 7})
-    out.append((3, 7, oracle.code_decommitter_synthesize(a["witnesses"]["code_decommitter"], 1, 7, N_ROWS), 86, 18))
+    out.append((3, 7, oracle.code_decommitter_synthesize(a["witnesses"]["code_decommitter"], 1, 7, N_ROWS)) + geo(3))
     q = synthetic.mixed_log_queue(36, seed=8)[:7]
-    out.append((13, 20, oracle.linear_hasher_synthesize(q, np.zeros(1, oracle.QUEUE_STATE4), 20, N_ROWS)[0], 86, 14))
+    out.append((13, 20, oracle.linear_hasher_synthesize(q, np.zeros(1, oracle.QUEUE_STATE4), 20, N_ROWS)[0]) + geo(13))
     return out
 
 
 def test_netlist_selectors_name_the_tables_of_their_rows(oracle):
-    for ctype, cap, trace, col0, lpr in _netlist_cases(oracle):
+    for ctype, cap, trace, col0, width, lpr in _netlist_cases(oracle):
         sel = nv.setup_row_selectors(ctype, cap, N_ROWS)
         lay = nv.circuit_layout(ctype, cap)
         assert int((sel != nv.ROW_PADDING).sum()) == int(lay["rows_used"])
-        body = trace[:col0 + 3 * lpr]
+        body = trace[:col0 + width * lpr]
         assert not body[:, sel == nv.ROW_PADDING].any(), ctype
         hdr = sel == nv.ROW_HEADER
-        assert int(hdr.sum()) == (nv.linear_hasher_cycles(cap) if ctype == 13 else cap)
+        cycles = nv.linear_hasher_cycles(cap) if ctype == 13 else cap
+        steps = {3: 1, 6: 1, 5: 26, 13: 26}[ctype]  # every step of a cycle starts with a header row
+        assert int(hdr.sum()) == cycles * steps
         assert not body[col0:, hdr].any()
         lookups = (sel < nv.ROW_HEADER) & ((sel & 0x3F) != 0)
+        tables = _tables(ctype)
         for t in np.unique(sel[lookups] & 0x3F):
             rows = np.flatnonzero(lookups & ((sel & 0x3F) == t))
-            a, b, c = (body[col0 + k::3][:lpr][:, rows].astype(np.int64) for k in range(3))
-            assert (a < 256).all() and (b < 256).all() and np.array_equal(c, _table(int(t), a, b)), (ctype, int(t))
+            n_in, fn = tables[int(t)]
+            cells = [body[col0 + k::width][:lpr][:, rows].astype(np.int64) for k in range(width)]
+            outs = fn(*cells[:n_in])
+            for k, o in enumerate(outs):
+                assert np.array_equal(cells[n_in + k], o), (ctype, int(t), k)
+            for k in range(n_in + len(outs), width):
+                assert not cells[k].any()
         gates = (sel < nv.ROW_HEADER) & ((sel & nv.ROW_HAS_GATES) != 0)
         assert not body[:col0, (sel < nv.ROW_HEADER) & ~gates].any()          # no general-purpose cells where no gate sits
-        assert bool(gates.any()) == (ctype in (3, 6))
+        assert gates.any()  # additions / re-chunkings (SHA-256), recompositions of rotated bytes (Keccak)
 
 
 def test_queue_circuit_selectors(oracle):

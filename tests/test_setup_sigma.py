@@ -60,13 +60,13 @@ def test_sigma_of_the_netlist_circuits(oracle):
     from tests.test_setup_selectors import _netlist_cases
 
     rng = np.random.default_rng(2)
-    checks = {5: oracle.keccak_round_check, 13: lambda t, c: oracle.keccak_round_check(t, oracle.linear_hasher_cycles(c)),
+    checks = {5: oracle.keccak_round_check, 13: lambda t, c: oracle.linear_hasher_check(t, oracle.linear_hasher_cycles(c)),
               6: oracle.sha256_round_check, 3: oracle.code_decommitter_check}
-    n_rows = 1 << 16
-    for ctype, cap, trace, col0, lpr in _netlist_cases(oracle):
+    n_rows = 1 << 18
+    for ctype, cap, trace, col0, width, lpr in _netlist_cases(oracle):
         sigma = nv.setup_copy_permutation(ctype, cap, n_rows)
         G = sigma.shape[0]
-        assert G == col0 + 3 * lpr
+        assert G == col0 + width * lpr
         flat = sigma.reshape(-1)
         ident = np.arange(flat.size, dtype=np.uint64)
         assert np.array_equal(np.sort(flat), ident), ctype

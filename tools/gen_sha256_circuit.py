@@ -1,41 +1,31 @@
 #!/usr/bin/env python3
-"""Generates include/zkw_sha256_circuit_spec.h — the layout of the Sha256RoundFunction trace that libzkw emits ("zkw trace
-v3", circuit type 6): ONE netlist per cycle (= one SHA-256 compression), two kinds of operations.
+"""Generates include/zkw_sha256_circuit_spec.h (Sha256RoundFunction, type 6) and include/zkw_code_decommitter_circuit_spec.h
+(CodeDecommitter, type 3): ONE netlist — a SHA-256 compression on 4-bit chunks — on the reference's two geometries
+(sha256_round_function.rs:28-39,121-134: 116 + 4 x 9; code_decommitter.rs:28-39,121-134: 108 + 4 x 11) and its table set
+TriXor4 / Ch4 / Maj4 / Split4BitChunk<1> / <2> (12 320 rows = `total_tables_len` of vk_6.json / vk_3.json). Format: tools/netlist.py.
 
-Geometry of the reference wrapper (circuit_definitions/.../base_layer/sha256_round_function.rs:28-39,52-134): 2^20 rows,
-capacity 2206 cycles (geometry_config.rs), lookups next to general-purpose gates (UIntXAddGate<32> among them). The circuit
-body lives in the absent crate era-zkevm_circuits: placement and tables are OUR design.
-
-Operations of a cycle:
-  * LOOKUP {table, a, b} -> c: width-3 byte lookups, 14 per row, one table per row. Tables (2^16 rows, row a * 256 + b):
-    1 XOR8, 2 ANDN8 (~a & b), 3..9 ROT<s> (((a << s) & 0xff) | (b >> (8 - s)), s = 1..7), 10 AND8.
-    A 32-bit word is four bytes, least significant first; rotr by n = rotl by 32 - n = 8q + s: byte k of the result is
-    ROT<s>(byte k - q, byte k - q - 1) (indices mod 4); shr is the same with zero above the top byte.
-  * ADD gates in the general-purpose columns of the same rows (two gates of 43 columns per row): up to seven byte-wise
-    operands + a 32-bit constant = out (4 bytes) + 2^32 * carry. One gate per SHA-256 addition chain:
-      e' = d + h + S1 + ch + K[i] + W[i],  a' = h + S1 + ch + K[i] + W[i] + S0 + maj,  W[i] = W[i-16] + s0 + W[i-7] + s1,
-      H'[j] = H[j] + v[j].
-    Output bytes are range-checked by the lookups that consume them; the generator adds XOR(x, 0) lookups for the ones no
-    lookup consumes.
-References (uint16): 0x0000.. output of lookup j; 0x8000 + 4g + b: byte b of gate g; 0x9000 + f: header field f;
-0xA000 + k: byte k of the chaining state after the previous cycle (BND_IN for cycle 0); 0xB000 + i: free witness byte i
-(the 64 message bytes of the block); 0xC000 + v: the constant v.
-Statement per cycle: in = reset ? IV : prev; H' = compress(in, block); out = idle ? prev : H' (masks as in the type-5 trace).
-The generator checks the netlist against hashlib.sha256 before writing the header.
-"""
+A 32-bit word is 8 nibbles, least significant first (state: 8 words x 8 nibbles = 64 elements).
+  * rotr / shr by n = 4q + m, m != 0: the word is re-chunked at phase m — low piece (m bits), seven nibbles at bits m + 4t, high
+    piece (4 - m bits) — by ONE gate (the word's nibbles in, the seven middle nibbles NEW, the two boundary pieces taken from a
+    lookup) and ONE Split4BitChunk lookup whose key packs the boundary pieces: its outputs are the pieces (range-checked) and the
+    nibble with the halves swapped = the rotated word's wrap-around nibble. Nibble i of the rotated word is middle piece (i + q) mod 8
+    (or the wrap nibble); shr drops what falls off. Key: low | high << m for m = 1, 2 (Split<m>), high | low << 1 for m = 3 (Split<1>).
+  * s0 / s1 / S0 / S1: TriXor4 on the three re-chunked words; ch: Ch4; maj: Maj4.
+  * additions: one gate per chain, operands as nibbles, out = 8 NEW nibbles + a carry nibble:
+      e' = d + h + S1 + ch + K + W,  a' = h + S1 + ch + K + W + S0 + maj,  W[i] = W[i-16] + s0 + W[i-7] + s1,  H' = H + v.
+    Out nibbles are range-checked by the lookups that consume them (Ch4 / Maj4, or a re-chunking that bounds the word), carries
+    and otherwise unconsumed nibbles by TriXor4(x, y, z) range lookups (three per lookup).
+  * in = reset ? IV : prev and out = idle ? prev : H' are Ch4 selects with the header's masks 15 * reset / 15 * idle.
+The 128 message nibbles are FREE elements (block byte j = nibbles 2j (low), 2j + 1 (high); word i = bytes 4i .. 4i + 3 big-endian)."""
 import hashlib
 import os
 import random
 import struct
+import sys
 
-LOOKUPS_PER_ROW = 14
-G = 86
-GATE_COLS = 43
-T_XOR, T_ANDN, T_AND = 1, 2, 10
-T_ROT = lambda s: 2 + s  # noqa: E731
-N_TABLES = 10
-R_GATE, R_HDR, R_PREV, R_FREE, R_CONST = 0x8000, 0x9000, 0xA000, 0xB000, 0xC000
-HDR_RESET, HDR_IDLE, HDR_MASK_R, HDR_MASK_NR, HDR_MASK_I, HDR_MASK_A = range(6)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import netlist as nl  # noqa: E402
+
 K = [0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
      0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
      0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
@@ -44,220 +34,111 @@ K = [0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x9
      0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
      0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
 IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+HDR_RESET, HDR_IDLE, HDR_M0, HDR_M1 = range(4)
+ZERO = nl.const(0)
 
 
-def table_fn(t, a, b):
-    if t == T_XOR:
-        return a ^ b
-    if t == T_ANDN:
-        return (~a & 0xFF) & b
-    if t == T_AND:
-        return a & b
-    s = t - 2
-    return ((a << s) & 0xFF) | (b >> (8 - s))
-
-
-class Netlist:
+class Sha(nl.StepType):
     def __init__(self):
-        self.ops = []    # (table, a, b)
-        self.gates = []  # (operands: list of 4-byte ref lists, constant)
+        super().__init__("compress", nl.sha_tables())
+        self.phase_cache = {}
+        self.to_range_check = []
 
-    def op(self, t, a, b):
-        self.ops.append((t, a, b))
-        return ("op", len(self.ops) - 1)
+    def rechunk(self, word, m):
+        """word: 8 nibble refs. Returns (mids[7], high piece, wrap nibble)."""
+        key = (id(word[0]), tuple(id(x) for x in word), m)
+        if key in self.phase_cache:
+            return self.phase_cache[key]
+        lo_src, hi_src = word[0], word[7]  # low piece = bits [0, m) of nibble 0, high piece = bits [m, 4) of nibble 7
+        if m in (1, 2):
+            k = self.hint((lo_src, 0, m), (hi_src, m, 4 - m))          # low | high << m
+            low, high, wrap = self.lookup(f"SPLIT4_{m}", k)            # wrap = low << (4 - m) | high
+        else:
+            k = self.hint((hi_src, 3, 1), (lo_src, 0, 3))              # high | low << 1: the wrap nibble itself
+            high, low, _ = self.lookup("SPLIT4_1", k)
+            wrap = k
+        known = [(word[i], 4 * i, +1) for i in range(8)] + [(low, 0, -1), (high, m + 28, -1)]
+        mids = self.gate(known, [m + 4 * t for t in range(7)])
+        res = (mids, high, wrap)
+        self.phase_cache[key] = res
+        return res
 
-    def xor(self, x, y):
-        return [self.op(T_XOR, x[k], y[k]) for k in range(4)]
-
-    def word_op(self, t, x, y):
-        return [self.op(t, x[k], y[k]) for k in range(4)]
-
-    def rotr(self, x, n, shift=False):
-        """rotate (or shift) right by n: bytes least significant first"""
-        q, s = divmod((32 - n) % 32, 8)
+    def rot(self, word, n, shift=False):
+        q, m = divmod(n, 4)
+        if m == 0:
+            return [word[(i + q) % 8] if not shift or i + q < 8 else ZERO for i in range(8)]
+        mids, high, wrap = self.rechunk(word, m)
         out = []
-        for k in range(4):
-            hi_i, lo_i = k - q, k - q - 1  # byte that supplies the upper part (shifted left by s), the one below it
-            if shift:
-                # shr n: result byte k = bits of x >> n; as a left rotation by 32 - n with the wrapped-around bytes zeroed:
-                # a source byte index that wrapped (index + 4 used) carries no bits
-                hi = x[hi_i] if 0 <= hi_i < 4 and False else None
+        for i in range(8):
+            t = i + q
             if not shift:
-                a, b = x[hi_i % 4], x[lo_i % 4]
-                out.append(a if s == 0 else self.op(T_ROT(s), a, b))
+                t %= 8
+                out.append(mids[t] if t < 7 else wrap)
             else:
-                # shr by n = 8 * qn + sn: byte k = (x[k + qn] >> sn) | (x[k + qn + 1] << (8 - sn)), zero beyond byte 3
-                qn, sn = divmod(n, 8)
-                lo = x[k + qn] if k + qn < 4 else ("const", 0)
-                hi = x[k + qn + 1] if k + qn + 1 < 4 else ("const", 0)
-                if sn == 0:
-                    out.append(lo)
-                elif lo == ("const", 0) and hi == ("const", 0):
-                    out.append(("const", 0))
-                else:
-                    out.append(self.op(T_ROT(8 - sn), hi, lo))  # ((hi << (8 - sn)) & 0xff) | (lo >> sn)
+                out.append(mids[t] if t < 7 else high if t == 7 else ZERO)
+        if shift:  # the middle nibbles that fall off still have to be range-checked (if nothing else consumes them)
+            self.to_range_check += [mids[t] for t in range(min(q, 7))]
         return out
 
-    def add(self, operands, constant=0):
-        self.gates.append((operands, constant))
-        g = len(self.gates) - 1
-        return [("gate", g, b) for b in range(4)]
+    def xor3(self, x, y, z):
+        return [self.lookup("TRIXOR4", x[i], y[i], z[i]) for i in range(8)]
+
+    def add(self, words, constant=0):
+        known = [(w[i], 4 * i, +1) for w in words for i in range(8)]
+        cells = self.gate(known, [4 * i for i in range(9)], constant)
+        self.to_range_check.append(cells[8])  # the carry
+        return cells[:8]
 
 
-def build_cycle():
-    nl = Netlist()
-    hdr = lambda f: ("hdr", f)  # noqa: E731
-    # chaining state: in = reset ? IV : prev
-    inb = []
-    for k in range(32):
-        p = nl.op(T_ANDN, hdr(HDR_MASK_R), ("prev", k))
-        q = nl.op(T_ANDN, hdr(HDR_MASK_NR), ("const", (IV[k // 4] >> (8 * (k % 4))) & 0xFF))
-        inb.append(nl.op(T_XOR, p, q))
-    H = [inb[4 * j:4 * j + 4] for j in range(8)]
-    # message words: block byte 4i + 3 - b is byte b (least significant first) of W[i]; loaded through XOR(x, 0) (range check + home)
-    load = [nl.op(T_XOR, ("free", i), ("const", 0)) for i in range(64)]
-    W = [[load[4 * i + 3 - b] for b in range(4)] for i in range(16)]
+def build():
+    s = Sha()
+    # chaining state: in = reset ? IV : prev (Ch4(mask, x, y) = mask ? x : y bitwise)
+    H = [[s.lookup("CH4", nl.hdr(HDR_M0), nl.const((IV[j] >> (4 * i)) & 15), nl.prev(8 * j + i)) for i in range(8)] for j in range(8)]
+    # message words from the FREE nibbles: a load gate gives every nibble a home cell
+    W = []
+    for i in range(16):
+        src = []  # nibble t of word i: byte 4i + 3 - t // 2, low nibble for even t
+        for t in range(8):
+            byte = 4 * i + 3 - t // 2
+            src.append(nl.free(2 * byte + (t & 1)))
+        W.append(s.gate([(src[t], 4 * t, +1) for t in range(8)], [4 * t for t in range(8)]))
+        s.to_range_check += W[-1]
     for i in range(16, 64):
         x, y = W[i - 15], W[i - 2]
-        s0 = nl.xor(nl.xor(nl.rotr(x, 7), nl.rotr(x, 18)), nl.rotr(x, 3, shift=True))
-        s1 = nl.xor(nl.xor(nl.rotr(y, 17), nl.rotr(y, 19)), nl.rotr(y, 10, shift=True))
-        W.append(nl.add([W[i - 16], s0, W[i - 7], s1]))
+        s0 = s.xor3(s.rot(x, 7), s.rot(x, 18), s.rot(x, 3, shift=True))
+        s1 = s.xor3(s.rot(y, 17), s.rot(y, 19), s.rot(y, 10, shift=True))
+        W.append(s.add([W[i - 16], s0, W[i - 7], s1]))
     a, b, c, d, e, f, g, h = H
     for i in range(64):
-        S1 = nl.xor(nl.xor(nl.rotr(e, 6), nl.rotr(e, 11)), nl.rotr(e, 25))
-        ch = nl.xor(g, nl.word_op(T_AND, e, nl.xor(f, g)))              # g ^ (e & (f ^ g))
-        S0 = nl.xor(nl.xor(nl.rotr(a, 2), nl.rotr(a, 13)), nl.rotr(a, 22))
-        maj = nl.xor(nl.word_op(T_AND, a, nl.xor(b, c)), nl.word_op(T_AND, b, c))  # (a & (b ^ c)) ^ (b & c)
-        new_e = nl.add([d, h, S1, ch, W[i]], K[i])
-        new_a = nl.add([h, S1, ch, W[i], S0, maj], K[i])
+        S1 = s.xor3(s.rot(e, 6), s.rot(e, 11), s.rot(e, 25))
+        ch = [s.lookup("CH4", e[t], f[t], g[t]) for t in range(8)]
+        S0 = s.xor3(s.rot(a, 2), s.rot(a, 13), s.rot(a, 22))
+        maj = [s.lookup("MAJ4", a[t], b[t], c[t]) for t in range(8)]
+        new_e = s.add([d, h, S1, ch, W[i]], K[i])
+        new_a = s.add([h, S1, ch, W[i], S0, maj], K[i])
         a, b, c, d, e, f, g, h = new_a, a, b, c, new_e, e, f, g
     v = [a, b, c, d, e, f, g, h]
-    Hn = [nl.add([H[j], v[j]]) for j in range(8)]
-    hn = [Hn[k // 4][k % 4] for k in range(32)]
+    Hn = [s.add([H[j], v[j]]) for j in range(8)]
     # out = idle ? prev : H'
-    out = []
-    for k in range(32):
-        t = nl.op(T_ANDN, hdr(HDR_MASK_I), hn[k])
-        u = nl.op(T_ANDN, hdr(HDR_MASK_A), ("prev", k))
-        out.append(nl.op(T_XOR, t, u))
-    # range checks for gate outputs no lookup consumes
-    used = set()
-    for t, x, y in nl.ops:
-        for r in (x, y):
-            if r[0] == "gate":
-                used.add((r[1], r[2]))
-    for gi in range(len(nl.gates)):
-        for bb in range(4):
-            if (gi, bb) not in used:
-                nl.op(T_XOR, ("gate", gi, bb), ("const", 0))
-    return nl, out
-
-
-def finalize(nl, out):
-    """group the lookups by table, pad to rows of LOOKUPS_PER_ROW, encode references"""
-    order = sorted(range(len(nl.ops)), key=lambda j: nl.ops[j][0])
-    new_index, placed = {}, []
-    for j in order:
-        t = nl.ops[j][0]
-        if placed and placed[-1][0] != t:
-            while len(placed) % LOOKUPS_PER_ROW:
-                placed.append((placed[-1][0], ("const", 0), ("const", 0)))
-        new_index[j] = len(placed)
-        placed.append(nl.ops[j])
-    while len(placed) % LOOKUPS_PER_ROW:
-        placed.append((placed[-1][0], ("const", 0), ("const", 0)))
-
-    def enc(r):
-        kind = r[0]
-        if kind == "op":
-            return new_index[r[1]]
-        if kind == "gate":
-            return R_GATE + 4 * r[1] + r[2]
-        if kind == "hdr":
-            return R_HDR + r[1]
-        if kind == "prev":
-            return R_PREV + r[1]
-        if kind == "free":
-            return R_FREE + r[1]
-        return R_CONST + r[1]
-
-    ops = [(t, enc(a), enc(b)) for t, a, b in placed]
-    # k_sc_hist (multiplicities) reads a table's lookups as ONE run of rows per cycle and skips the padding by position:
-    # tables ascending, every table starts a row, padding (0, 0) only after a table's last real lookup
-    for j in range(1, len(ops)):
-        assert ops[j][0] >= ops[j - 1][0]
-        if ops[j][0] != ops[j - 1][0]:
-            assert j % LOOKUPS_PER_ROW == 0
-        elif (ops[j - 1][1], ops[j - 1][2]) == (R_CONST, R_CONST):
-            assert (ops[j][1], ops[j][2]) == (R_CONST, R_CONST), "a real lookup after padding"
-    gates = [([[enc(r) for r in w] for w in operands], k) for operands, k in nl.gates]
-    return ops, gates, [enc(r) for r in out]
-
-
-def evaluate(ops, gates, out, order, prev, block, reset, idle):
-    hdrv = {HDR_RESET: reset, HDR_IDLE: idle, HDR_MASK_R: 255 * reset, HDR_MASK_NR: 255 - 255 * reset, HDR_MASK_I: 255 * idle,
-            HDR_MASK_A: 255 - 255 * idle}
-    ov, gv = [None] * len(ops), [None] * len(gates)
-
-    def get(r):
-        if r < R_GATE:
-            return ov[r]
-        if r < R_HDR:
-            return gv[(r - R_GATE) // 4][(r - R_GATE) % 4]
-        if r < R_PREV:
-            return hdrv[r - R_HDR]
-        if r < R_FREE:
-            return prev[r - R_PREV]
-        if r < R_CONST:
-            return block[r - R_FREE]
-        return r - R_CONST
-
-    for it in order:
-        if it < R_GATE:
-            t, a, b = ops[it]
-            ov[it] = table_fn(t, get(a), get(b))
-        else:
-            operands, k = gates[it - R_GATE]
-            total = k + sum(sum(get(w[b]) << (8 * b) for b in range(4)) for w in operands)
-            gv[it - R_GATE] = [(total >> (8 * b)) & 0xFF for b in range(4)] + [total >> 32]
-            assert total >> 32 <= len(operands)
-    return [get(r) for r in out]
-
-
-def topo_order(ops, gates):
-    """evaluation order: items (lookup j or R_GATE + g) by dependency level; returns (order, level starts)"""
-    lvl_op, lvl_g = [None] * len(ops), [None] * len(gates)
-
-    def ref_level(r):
-        if r < R_GATE:
-            return level_op(r)
-        if r < R_HDR:
-            return level_gate((r - R_GATE) // 4)
-        return 0
-
-    def level_op(j):
-        if lvl_op[j] is None:
-            lvl_op[j] = 1 + max(ref_level(ops[j][1]), ref_level(ops[j][2]))
-        return lvl_op[j]
-
-    def level_gate(g):
-        if lvl_g[g] is None:
-            lvl_g[g] = 1 + max(ref_level(r) for w in gates[g][0] for r in w)
-        return lvl_g[g]
-
-    import sys
-    sys.setrecursionlimit(100000)
-    items = [(level_op(j), j) for j in range(len(ops))] + [(level_gate(g), R_GATE + g) for g in range(len(gates))]
-    items.sort()
-    order = [it for _, it in items]
-    n_levels = items[-1][0]
-    starts, cur = [], 0
-    for idx, (lv, _) in enumerate(items):
-        while cur < lv:
-            starts.append(idx)
-            cur += 1
-    starts.append(len(items))
-    return order, starts[0:1] * 0 + starts, n_levels
+    s.out = [s.lookup("CH4", nl.hdr(HDR_M1), nl.prev(8 * j + i), Hn[j][i]) for j in range(8) for i in range(8)]
+    # Range lookups (three nibbles per TriXor4) for what no other lookup consumes and no re-chunking bounds: the carries, the
+    # middle nibbles a shift drops, the nibbles of message words that are never re-chunked. (Out nibbles of an addition that only
+    # feed further additions need none: with its carry bounded, the word is right modulo 2^32 wherever it is used.)
+    consumed = {id(r) for t, ins, *_ in s.ops for r in ins if isinstance(r, nl.Val)}
+    rechunked = {k[1] for k in s.phase_cache}
+    for wd in W[:16]:
+        if tuple(id(x) for x in wd) in rechunked:
+            for x in wd:
+                consumed.add(id(x))
+    pending = []
+    for v_ in s.to_range_check:
+        if id(v_) not in consumed:
+            pending.append(v_)
+            consumed.add(id(v_))
+    for i in range(0, len(pending), 3):
+        grp = pending[i:i + 3] + [ZERO, ZERO]
+        s.lookup("TRIXOR4", grp[0], grp[1], grp[2])
+    return s
 
 
 def sha_compress(state, block):
@@ -274,92 +155,64 @@ def sha_compress(state, block):
         t1 = (h + S1 + ch + K[i] + w[i]) & 0xFFFFFFFF
         S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)
         maj = (a & b) ^ (a & c) ^ (b & c)
-        t2 = (S0 + maj) & 0xFFFFFFFF
-        a, b, c, d, e, f, g, h = (t1 + t2) & 0xFFFFFFFF, a, b, c, (d + t1) & 0xFFFFFFFF, e, f, g
+        a, b, c, d, e, f, g, h = (t1 + S0 + maj) & 0xFFFFFFFF, a, b, c, (d + t1) & 0xFFFFFFFF, e, f, g
     return [(x + y) & 0xFFFFFFFF for x, y in zip(state, [a, b, c, d, e, f, g, h])]
 
 
-def emit(prefix, lookups_per_row, header, title):
-    global LOOKUPS_PER_ROW
-    LOOKUPS_PER_ROW = lookups_per_row
-    nl, out = build_cycle()
-    ops, gates, out = finalize(nl, out)
-    order, starts, n_levels = topo_order(ops, gates)
-    to_bytes = lambda ws: [(w >> (8 * b)) & 0xFF for w in ws for b in range(4)]  # noqa: E731
+def nibbles_of_words(ws):
+    return [(w >> (4 * i)) & 15 for w in ws for i in range(8)]
+
+
+def nibbles_of_block(block):
+    return [(b >> (4 * k)) & 15 for b in block for k in range(2)]
+
+
+def make_spec(prefix, general_cols, lookups_per_row):
+    tables = nl.sha_tables()
+    spec = nl.Spec(prefix, general_cols, 4, lookups_per_row, tables, 64, (0, 15, 0, 15))
+    s = build()
+    s.tables = {t.name: t for t in tables}
+    for op in s.ops:  # the step was built against its own table objects: rebind to the spec's (ids / offsets)
+        op[0] = s.tables[op[0].name]
+    spec.cycle = [(spec.add_step_type(s), [])]
+    return spec
+
+
+def self_check(spec):
     rng = random.Random(1)
-    # one compression against the plain function, then a two-block message against hashlib
     st = [rng.getrandbits(32) for _ in range(8)]
     blk = [rng.randrange(256) for _ in range(64)]
-    assert evaluate(ops, gates, out, order, to_bytes(st), blk, 0, 0) == to_bytes(sha_compress(st, blk))
-    assert evaluate(ops, gates, out, order, to_bytes(st), blk, 0, 1) == to_bytes(st)            # idle carries the state
+    assert spec.evaluate_cycle(nibbles_of_words(st), [nibbles_of_block(blk)], 0, 0) == nibbles_of_words(sha_compress(st, blk))
+    assert spec.evaluate_cycle(nibbles_of_words(st), [nibbles_of_block(blk)], 0, 1) == nibbles_of_words(st)  # idle carries the state
+    for blk2 in ([0] * 64, [255] * 64):
+        for st2 in ([0] * 8, [0xFFFFFFFF] * 8):
+            assert spec.evaluate_cycle(nibbles_of_words(st2), [nibbles_of_block(blk2)], 0, 0) == nibbles_of_words(sha_compress(st2, blk2))
     msg = bytes(rng.randrange(256) for _ in range(100))
     padded = msg + b"\x80" + bytes((55 - len(msg)) % 64) + struct.pack(">Q", 8 * len(msg))
-    state = to_bytes([0] * 8)
+    state = nibbles_of_words([0] * 8)
     for i in range(0, len(padded), 64):
-        state = evaluate(ops, gates, out, order, state, list(padded[i:i + 64]), 1 if i == 0 else 0, 0)
-    digest = b"".join(struct.pack(">I", sum(state[4 * j + b] << (8 * b) for b in range(4))) for j in range(8))
-    assert digest == hashlib.sha256(msg).digest(), "netlist != SHA-256"
-    lookup_rows = len(ops) // LOOKUPS_PER_ROW
-    gate_rows = -(-len(gates) // 2)
-    rows_per_cycle = 1 + max(lookup_rows, gate_rows)
-    max_operands = max(len(o) for o, _ in gates)
-    o = []
+        state = spec.evaluate_cycle(state, [nibbles_of_block(padded[i:i + 64])], 1 if i == 0 else 0, 0)
+    words = [sum(state[8 * j + t] << (4 * t) for t in range(8)) for j in range(8)]
+    assert b"".join(struct.pack(">I", w) for w in words) == hashlib.sha256(msg).digest(), "netlist != SHA-256"
 
-    def w(line):
-        o.append(line.replace("SC_", prefix + "_").replace("sc_op", prefix.lower() + "_op").replace("sc_gate", prefix.lower() + "_gate"))
 
-    for t in title:
-        o.append(t)
-    guard = f"ZKW_{header.upper().replace('.', '_').replace('ZKW_', '')}"
-    o.append(f"#ifndef {guard}\n#define {guard}\n#include <stdint.h>")
-    w(f"#define SC_G {G}\n#define SC_LOOKUPS_PER_ROW {LOOKUPS_PER_ROW}\n#define SC_LOOKUP_COL0 {G}\n#define SC_NUM_TABLES {N_TABLES}")
-    w(f"#define SC_MULT_COL0 {G + 3 * LOOKUPS_PER_ROW}\n#define SC_COLS {G + 3 * LOOKUPS_PER_ROW + N_TABLES}\n#define SC_TABLE_ROWS 65536")
-    w("#define SC_T_XOR 1\n#define SC_T_ANDN 2\n#define SC_T_ROT(s) (2 + (s))\n#define SC_T_AND 10")
-    w(f"#define SC_NUM_OPS {len(ops)}      /* lookups of a cycle, grouped by table, padded to rows; lookup j: row 1 + j / {LOOKUPS_PER_ROW}, slot j % {LOOKUPS_PER_ROW} */")
-    w(f"#define SC_NUM_GATES {len(gates)}   /* ADD gates; gate g: row 1 + g / 2, columns (g % 2) * SC_GATE_COLS .. */")
-    w(f"#define SC_GATE_COLS {GATE_COLS}   /* operand o byte b at 4 * o + b, out byte b at SC_GATE_OUT + b, carry at SC_GATE_CARRY */")
-    w(f"#define SC_GATE_MAX_OPERANDS {max_operands}\n#define SC_GATE_OUT {4 * max_operands}\n#define SC_GATE_CARRY {4 * max_operands + 4}")
-    w(f"#define SC_ROWS_PER_CYCLE {rows_per_cycle}  /* header row + max(lookup rows {lookup_rows}, gate rows {gate_rows}); cycle-major */")
-    w("#define SC_HDR_RESET 0\n#define SC_HDR_IDLE 1\n#define SC_HDR_MASK_R 2\n#define SC_HDR_MASK_NR 3\n#define SC_HDR_MASK_I 4\n#define SC_HDR_MASK_A 5\n#define SC_HDR_FIELDS 6")
-    w("/* boundary rows after the last cycle: BND_IN (columns 0..31: the chaining state before cycle 0, byte k = byte k % 4 of")
-    w("   word k / 4, least significant first), BND_OUT (after the last cycle), PI (columns 0..3) */")
-    w("#define SC_BOUNDARY_ROW(capacity) ((uint64_t)(capacity) * SC_ROWS_PER_CYCLE)")
-    w("#define SC_MIN_ROWS(capacity) (SC_BOUNDARY_ROW(capacity) + 3 > SC_TABLE_ROWS ? SC_BOUNDARY_ROW(capacity) + 3 : SC_TABLE_ROWS)")
-    w(f"#define SC_REF_GATE 0x{R_GATE:X}\n#define SC_REF_HDR 0x{R_HDR:X}\n#define SC_REF_PREV 0x{R_PREV:X}\n#define SC_REF_FREE 0x{R_FREE:X}\n#define SC_REF_CONST 0x{R_CONST:X}")
-    w("typedef struct { uint16_t table, a, b; } sc_op;")
-    w("typedef struct { uint32_t n_operands, constant; uint16_t in[SC_GATE_MAX_OPERANDS][4]; } sc_gate;")
-    w("#define SC_OPS_INIT { \\")
-    for t, a, b in ops:
-        o.append(f"  {{{t}, {a}, {b}}}, \\")
-    o.append("}")
-    w("#define SC_GATES_INIT { \\")
-    for operands, k in gates:
-        rows = [("{" + ", ".join(str(r) for r in wd) + "}") for wd in operands] + ["{0, 0, 0, 0}"] * (max_operands - len(operands))
-        o.append(f"  {{{len(operands)}, 0x{k:08X}u, {{{', '.join(rows)}}}}}, \\")
-    o.append("}")
-    w("/* byte k of the cycle's output state = this reference (a lookup output) */")
-    w("#define SC_OUT_INIT {" + ", ".join(str(r) for r in out) + "}")
-    w(f"#define SC_NUM_LEVELS {n_levels}")
-    w("/* items (lookup j, or SC_REF_GATE + g) in dependency order; level l = [SC_LEVEL_START[l], SC_LEVEL_START[l + 1]) */")
-    w("#define SC_EVAL_ORDER_INIT {" + ", ".join(str(it) for it in order) + "}")
-    w("#define SC_LEVEL_START_INIT {" + ", ".join(str(v) for v in starts) + "}")
-    o.append("#endif")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "include", header)
-    open(path, "w").write("\n".join(o) + "\n")
-    print(f"{prefix}: {len(ops)} lookups ({lookup_rows} rows of {LOOKUPS_PER_ROW}), {len(gates)} gates ({gate_rows} rows), {n_levels} levels, "
-          f"{rows_per_cycle} rows per cycle -> capacity up to {((1 << 20) - 3) // rows_per_cycle} in 2^20 rows; {path}")
+CIRCUITS = {"SC": (116, 9, "zkw_sha256_circuit_spec.h", "Sha256RoundFunction: 116 + 4 x 9 columns"),
+            "DC": (108, 11, "zkw_code_decommitter_circuit_spec.h", "CodeDecommitter: the same compression on 108 + 4 x 11 columns")}
+
+
+def emit(prefix, path=None):
+    g, r, header, circuit = CIRCUITS[prefix]
+    spec = make_spec(prefix, g, r)
+    self_check(spec)
+    path = path or os.path.join(nl.root(), "include", header)
+    spec.emit(path, f"tools/gen_sha256_circuit.py ({circuit})")
+    return spec, path
 
 
 def main():
-    emit("SC", 14, "zkw_sha256_circuit_spec.h",
-         ("/* GENERATED by tools/gen_sha256_circuit.py — do not edit. Layout contract of the Sha256RoundFunction trace emitted by",
-          " * zkw_sha256_round_synthesize (\"zkw trace v3\": one netlist per cycle, byte lookups + 32-bit ADD gates). See the generator. */"))
-    # CodeDecommitter (type 3): the same compression at 2845 cycles per trace (geometry_config.rs) = 368 rows per cycle: 18
-    # lookups per row (54 lookup columns; the reference wrapper has 44, base_layer/code_decommitter.rs:28-39) -> 365 rows
-    emit("DC", 18, "zkw_code_decommitter_circuit_spec.h",
-         ("/* GENERATED by tools/gen_sha256_circuit.py — do not edit. Layout contract of the CodeDecommitter trace emitted by",
-          " * zkw_code_decommitter_synthesize (\"zkw trace v3\": the SHA-256 netlist of zkw_sha256_circuit_spec.h at 18 lookups per row). */"))
+    for prefix in CIRCUITS:
+        spec, path = emit(prefix)
+        print(spec.stats(), path)
 
 
 if __name__ == "__main__":
