@@ -223,9 +223,9 @@ def hash_circuits_gpu(local_rank, blk):
     w.free()
     dec.free()
     q = synthetic.mixed_log_queue(4000, seed=3)[:700]
-    t = native.Trace(ctx, n_rows, 1, n_cols=native.KC_COLS)
+    t = native.Trace(ctx, n_rows, 1, n_cols=native.LH_COLS)
     out["linear_hasher"] = dict(timed(1, lambda: ctx.synthesize_linear_hasher(q, np.zeros(1, native.QUEUE_STATE4), 774, t, 0)), capacity=774,
-                                columns=native.KC_COLS, trace_bytes=native.KC_COLS * n_rows * 8,
+                                columns=native.LH_COLS, trace_bytes=native.LH_COLS * n_rows * 8,
                                 note="one instance per block; 3.6 ms of it is the serial sponge over the messages")
     t.free()
     ctx.close()

@@ -235,7 +235,7 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
                     if (a[i] != home(&v, c, s, ref)) copies = 0;
                 }
                 if (!copies) flag(&res, 2, slot, row);
-                if (op->out != 0xFFFF) hist[nl_table_key(t, a)]++;
+                hist[nl_table_key(t, a)]++; /* padding lookups hit entry 0 of their table like any other */
             }
             /* gates */
             for (uint32_t gi = 0; gi < T->n_gates; gi++) {
@@ -262,11 +262,6 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
                         if (TR(col, base + r)) { flag(&res, 6, col, base + r); break; }
             }
         }
-    for (uint32_t s = 0; s < sp->steps_per_cycle; s++) {
-        const nl_step_type *T = &sp->step_types[sp->cycle[s].type];
-        for (uint32_t j = 0; j < T->n_ops; j++)
-            if (sp->ops[T->op0 + j].out == 0xFFFF) hist[sp->tables[sp->ops[T->op0 + j].table - 1].offset] += capacity;
-    }
     const size_t bnd = NL_BOUNDARY_ROW(sp, capacity), brows = NL_BND_ROWS(sp);
     for (size_t row = 0; row < n_rows; row++) {
         if (TR(sp->mult_col, row) != (row < sp->total_table_rows ? hist[row] : 0)) flag(&res, 5, 0, row);

@@ -21,7 +21,7 @@ out = {}
 for rep in range(2):
     B = nv.Block(0, synthetic.block_after_vm(seed=4), caps)
     bad = []
-    n = B.synthesize(1 << 16, ring_slots=2, callback=lambda t, i, tr, s, pi: bad.append(B.check_satisfied(t, tr, s)[0]))
+    n = B.synthesize(1 << 18, ring_slots=2, callback=lambda t, i, tr, s, pi: bad.append(B.check_satisfied(t, tr, s)[0]))
     out = {"n": n, "bad": int(sum(bad)), "pi": {str(t): B.public_inputs(t).tolist() for t in (2, 3, 5, 6, 8, 13)}}
     B.free()
     nv.trim_caches()
