@@ -50,6 +50,12 @@ struct NlDev {
     const u32* hist_first;       // [n_tables + 1]: table t's entries
     const u32* hist_slice0;      // [n_tables + 1]: table t owns histogram slices [slice0[t], slice0[t + 1])
     u32 n_hist_slices;
+    // the gates' KNOWN cells run-length packed for the fill (a word = 8 consecutive values at shifts 4 apart is ONE entry):
+    // {dense first reference, count - 1, shift of the first | 0x80 if negative, shift step}; per gate: [pk_first[g], pk_first[g + 1])
+    const uint32_t* pk_terms;    // ref | (count - 1) << 16 | code << 20 | step << 28
+    const uint16_t* pk_first;    // [n_gates + 1] (indices relative to the step type's pk0)
+    const u32* pk0;              // [step type]
+    u32 n_pk_terms;
     u32 max_items;               // max over step types of n_ops + n_gates + rows (the checker's grid)
     u32 vsize;                   // bytes of a wave's value array
     u32 lds_bytes;               // dynamic LDS of k_nl_fill
@@ -61,9 +67,10 @@ struct NlJob {
     const u64* public_input;      // [4]
     u64* trace;                   // [cols][n_rows]
     uint16_t* keys;               // [capacity][keys_per_cycle]
+    u32* hist;                    // [n_hist_slices][2 halves][NL_HIST_HALF]: k_nl_hist's bins (every bin stored), summed by k_nl_finish
 };
 
-constexpr int NL_FILL_WAVES = 4;
+constexpr int NL_FILL_WAVES = 8;
 constexpr int NL_FILL_THREADS = 64 * NL_FILL_WAVES;
 
 // layout of a wave's value array: [values | header 4 | prev state | cycle state | free | rc 8 | constants 256]
@@ -85,11 +92,11 @@ struct NlV {
     }
 };
 
-struct NlLdsGate { uint16_t first_term, row, col; uint8_t n_known, n_new; u32 constant; };
+struct NlLdsGate { u32 constant; uint16_t new_ref; uint8_t n_new, new_sh0, new_step, _pad[3]; };  // NEW cells: consecutive values at shifts sh0 + i * step
 // LDS carve of k_nl_fill, the same arithmetic on the host (lds_bytes) and in the kernel
 struct NlLds {
-    u32 tab, types, cyc, op_table, op_in, op_out, gates, term_ref, term_code, hints, order, level, out, waves, total;
-    __host__ __device__ NlLds(const nl_spec& s, u32 vsize) {
+    u32 tab, types, cyc, op_table, op_in, op_out, gates, term_ref, term_code, pk, pk_first, hints, order, level, out, waves, total;
+    __host__ __device__ NlLds(const nl_spec& s, u32 vsize, u32 n_pk) {
         u32 at = 0;
         auto take = [&](u32 bytes) { u32 r = at; at = (at + bytes + 15) & ~15u; return r; };
         tab = take(s.n_tables * sizeof(nl_table));
@@ -99,8 +106,9 @@ struct NlLds {
         op_in = take(s.n_ops * 6);
         op_out = take(s.n_ops * 2);
         gates = take(s.n_gates * sizeof(NlLdsGate));
-        term_ref = take(s.n_terms * 2);
-        term_code = take(s.n_terms);
+        term_ref = term_code = at;  // (the NEW cells of a gate are described by its record)
+        pk = take(n_pk * 4);
+        pk_first = take((s.n_gates + s.n_step_types) * 2);
         hints = take((s.n_hints ? s.n_hints : 1) * sizeof(nl_hint));
         order = take(s.n_order * 2);
         level = take(s.n_level_starts * 2);
@@ -128,14 +136,14 @@ __device__ __forceinline__ void nl_eval_sel(u32 fn, u32 k, u32 a0, u32 a1, u32 a
 }
 
 template <int W, int R>
-__global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+__global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
     const NlJob job = jobs[blockIdx.y];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const NlV V(S);
-    const NlLds L(S, V.size);
+    const NlLds L(S, V.size, D.n_pk_terms);
     nl_table* const s_tab = reinterpret_cast<nl_table*>(lds + L.tab);
     nl_step_type* const s_types = reinterpret_cast<nl_step_type*>(lds + L.types);
     nl_cycle_step* const s_cyc = reinterpret_cast<nl_cycle_step*>(lds + L.cyc);
@@ -143,8 +151,8 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
     uint16_t* const s_op_in = reinterpret_cast<uint16_t*>(lds + L.op_in);  // [3][n_ops]
     uint16_t* const s_op_out = reinterpret_cast<uint16_t*>(lds + L.op_out);
     NlLdsGate* const s_gates = reinterpret_cast<NlLdsGate*>(lds + L.gates);
-    uint16_t* const s_term_ref = reinterpret_cast<uint16_t*>(lds + L.term_ref);
-    uint8_t* const s_term_code = lds + L.term_code;
+    u32* const s_pk = reinterpret_cast<u32*>(lds + L.pk);
+    uint16_t* const s_pk_first = reinterpret_cast<uint16_t*>(lds + L.pk_first);   // [step type: gate0 + type index + gate .. + n_gates]
     nl_hint* const s_hints = reinterpret_cast<nl_hint*>(lds + L.hints);
     uint16_t* const s_order = reinterpret_cast<uint16_t*>(lds + L.order);
     uint16_t* const s_level = reinterpret_cast<uint16_t*>(lds + L.level);
@@ -162,12 +170,20 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
     }
     for (u32 i = t; i < S.n_gates; i += NL_FILL_THREADS) {
         const nl_gate g = S.gates[i];
+        u32 ty = 0;
+        while (ty + 1 < S.n_step_types && S.step_types[ty + 1].gate0 <= i) ty++;
+        const nl_term* tm = S.terms + S.step_types[ty].term0 + g.first_term + g.n_known;
         NlLdsGate lg;
-        lg.first_term = (uint16_t)g.first_term; lg.row = g.row; lg.col = g.col;
-        lg.n_known = (uint8_t)g.n_known; lg.n_new = (uint8_t)g.n_new; lg.constant = g.constant;
+        lg.constant = g.constant;
+        lg.n_new = (uint8_t)g.n_new;
+        lg.new_ref = g.n_new ? V.dense(tm[0].ref) : 0;
+        lg.new_sh0 = g.n_new ? (uint8_t)(tm[0].code & 0x7F) : 0;
+        lg.new_step = g.n_new > 1 ? (uint8_t)((tm[1].code & 0x7F) - (tm[0].code & 0x7F)) : 0;  // (nl_get checked that the NEW cells are evenly spaced)
+        lg._pad[0] = lg._pad[1] = lg._pad[2] = 0;
         s_gates[i] = lg;
     }
-    for (u32 i = t; i < S.n_terms; i += NL_FILL_THREADS) { s_term_ref[i] = V.dense(S.terms[i].ref); s_term_code[i] = (uint8_t)S.terms[i].code; }
+    for (u32 i = t; i < D.n_pk_terms; i += NL_FILL_THREADS) s_pk[i] = D.pk_terms[i];
+    for (u32 i = t; i < S.n_gates + S.n_step_types; i += NL_FILL_THREADS) s_pk_first[i] = D.pk_first[i];
     for (u32 i = t; i < S.n_hints; i += NL_FILL_THREADS) {
         nl_hint h = S.hints[i];
         h.ref_a = V.dense(h.ref_a); h.ref_b = V.dense(h.ref_b);
@@ -178,32 +194,42 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
     for (u32 i = t; i < S.n_step_types * S.state; i += NL_FILL_THREADS) s_out[i] = V.dense(S.out[i]);
     for (u32 i = t; i < NL_FILL_WAVES * 256; i += NL_FILL_THREADS) lds[L.waves + (i >> 8) * V.size + V.con + (i & 255)] = (uint8_t)i;
     __syncthreads();  // the only workgroup barrier: from here on every wave is on its own
-    const u32 m_n_ops = S.n_ops;
+    // everything the cycle loop needs from the spec, in registers: the trace stores below go through a pointer the compiler cannot
+    // prove distinct from *devp, so every `S.field` inside the loops would be re-read from global memory after each store
+    const u32 m_n_ops = S.n_ops, G = S.g, STATE = S.state, STEPS = S.steps_per_cycle, RPC = S.rows_per_cycle, FPC = S.free_per_cycle;
+    const int m0a = S.masks[0], m0b = S.masks[1], m1a = S.masks[2], m1b = S.masks[3];
+    const uint16_t* const g_cellmap = D.cellmap;
+    const u32* const g_cell0 = D.cell0;
+    const u32* const g_key0 = D.step_key0;
+    const u32* const g_pk0 = D.pk0;
+    const u32 keys_per_cycle = D.keys_per_cycle;
     for (u32 c = blockIdx.x * NL_FILL_WAVES + wv; c < capacity; c += gridDim.x * NL_FILL_WAVES) {
         NL_WAVE_SYNC();  // the previous cycle's write phase has read everything it needs
         const u32 bits = job.hdr_bits[c], reset = bits & 1, idle = (bits >> 1) & 1;
         if (lane == 0) {
             val[V.hdr + 0] = (uint8_t)reset; val[V.hdr + 1] = (uint8_t)idle;
-            val[V.hdr + 2] = (uint8_t)(S.masks[0] + S.masks[1] * (int)reset);
-            val[V.hdr + 3] = (uint8_t)(S.masks[2] + S.masks[3] * (int)idle);
+            val[V.hdr + 2] = (uint8_t)(m0a + m0b * (int)reset);
+            val[V.hdr + 3] = (uint8_t)(m1a + m1b * (int)idle);
         }
-        for (u32 k = lane; k < S.state; k += 64) {
-            const uint8_t x = job.state_before[(size_t)c * S.state + k];
+        for (u32 k = lane; k < STATE; k += 64) {
+            const uint8_t x = job.state_before[(size_t)c * STATE + k];
             val[V.cyc + k] = x;
             val[V.prev + k] = x;
         }
         u32 free_at = 0;
-        for (u32 s = 0; s < S.steps_per_cycle; s++) {
-            const nl_cycle_step cs = s_cyc[s];
-            const nl_step_type T = s_types[cs.type];
-            const size_t base = (size_t)c * S.rows_per_cycle + cs.row0;
-            for (u32 k = lane; k < T.n_free; k += 64) val[V.fre + k] = job.free_elems[(size_t)c * S.free_per_cycle + free_at + k];
-            if (lane < 8) val[V.rc + lane] = s_cyc[s].rc[lane];  // (indexing the register copy `cs` by lane would put it in scratch memory)
+        for (u32 s = 0; s < STEPS; s++) {
+            const u32 type = s_cyc[s].type, row0 = s_cyc[s].row0;
+            const nl_step_type T = s_types[type];
+            const size_t base = (size_t)c * RPC + row0;
+            for (u32 k = lane; k < T.n_free; k += 64) val[V.fre + k] = job.free_elems[(size_t)c * FPC + free_at + k];
+            if (lane < 8) val[V.rc + lane] = s_cyc[s].rc[lane];  // (indexing a register copy by lane would put it in scratch memory)
             free_at += T.n_free;
             NL_WAVE_SYNC();
             const uint16_t* const lvl = s_level + T.level0;
-            for (u32 l = 0; l < T.n_levels; l++) {
-                for (u32 e = lvl[l] + lane; e < lvl[l + 1]; e += 64) {
+            u32 lv0 = lvl[0];
+            for (u32 l = 0; l < ((probe & 1) ? 0u : T.n_levels); l++) {  // probe bit 0: skip the level walk (measurement only)
+                const u32 lv1 = lvl[l + 1];
+                for (u32 e = lv0 + lane; e < lv1; e += 64) {
                     const u32 it = s_order[T.order0 + e];
                     if (it < NL_ORDER_GATE) {
                         const u32 j = T.op0 + it;
@@ -217,19 +243,26 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
                             if (tb.n_out > 2) val[out + 2] = (uint8_t)o2;
                         }
                     } else if (it < NL_ORDER_HINT) {
-                        const NlLdsGate g = s_gates[T.gate0 + (it - NL_ORDER_GATE)];
-                        const u32 t0 = T.term0 + g.first_term;
+                        const u32 gi = T.gate0 + (it - NL_ORDER_GATE);
+                        const NlLdsGate g = s_gates[gi];
+                        const uint16_t* const pf = s_pk_first + gi + type;  // (one extra entry per step type closes its last gate)
+                        const u32 p0 = g_pk0[type] + pf[0], p1 = g_pk0[type] + pf[1];
                         long long sum = g.constant;
-                        for (u32 i = 0; i < g.n_known; i++) {
-                            const u32 code = s_term_code[t0 + i];
-                            const long long x = (long long)val[s_term_ref[t0 + i]] << (code & 0x7F);
-                            sum += (code & 0x80) ? -x : x;
+                        // the known cells, run-length packed: a word operand (8 nibbles) is one entry and eight independent byte reads
+                        // (four entries at a time with all reads issued up front was slower: 5.2 against 4.5 ms per 8 SHA-256 instances)
+                        for (u32 p = p0; p < p1; p++) {
+                            const u32 w = s_pk[p], ref = w & 0xFFFF, cnt = (w >> 16) & 15, code = (w >> 20) & 0xFF, step = w >> 28;
+                            u64 part = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; k++)
+                                if ((u32)k <= cnt) part |= (u64)val[ref + k] << (k * step);  // cells of a run are < 2^step (or the run is one cell)
+                            const long long v = (long long)(part << (code & 0x7F));
+                            sum += (code & 0x80) ? -v : v;
                         }
                         for (u32 i = 0; i < g.n_new; i++) {
-                            const u32 sh = s_term_code[t0 + g.n_known + i] & 0x7F;
-                            u64 x = (u64)sum >> sh;
-                            if (i + 1 < g.n_new) x &= (1ull << ((s_term_code[t0 + g.n_known + i + 1] & 0x7F) - sh)) - 1;
-                            val[s_term_ref[t0 + g.n_known + i]] = (uint8_t)x;
+                            u64 x = (u64)sum >> (g.new_sh0 + i * g.new_step);
+                            if (i + 1 < g.n_new) x &= (1ull << g.new_step) - 1;
+                            val[g.new_ref + i] = (uint8_t)x;
                         }
                     } else {
                         const nl_hint h = s_hints[T.hint0 + (it - NL_ORDER_HINT)];
@@ -237,19 +270,28 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
                         val[h.value] = (uint8_t)(((a >> h.lo_a) & ((1u << h.n_a) - 1)) | (((b >> h.lo_b) & ((1u << h.n_b) - 1)) << h.n_a));
                     }
                 }
+                lv0 = lv1;
                 NL_WAVE_SYNC();
             }
             // ---- stream the step's rows out, lane <-> row: every general-purpose and lookup cell
-            const uint16_t* const cmap = D.cellmap + D.cell0[cs.type];
-            uint16_t* const keys = job.keys + (size_t)c * D.keys_per_cycle + D.step_key0[s];
-            for (u32 r = lane; r < T.rows; r += 64) {
+            const uint16_t* const cmap = g_cellmap + g_cell0[type];
+            uint16_t* const keys = job.keys + (size_t)c * keys_per_cycle + g_key0[s];
+            for (u32 r = lane; r < ((probe & 2) ? 0u : T.rows); r += 64) {  // probe bit 1: skip the streaming (measurement only)
                 const size_t row = base + r;
-                for (u32 col = 0; col < S.g; col++) {
-                    const uint16_t ref = cmap[(size_t)col * T.rows + r];
-                    store_streaming(&NL_TR(col, row), ref == 0xFFFF ? 0 : (u64)val[ref]);
+                if (r <= T.gate_rows && !(probe & 4)) {  // rows below the gate rows hold no general-purpose cell: zero already (nl_synthesize)
+                    // the cell map is read in batches of independent loads
+                    for (u32 col0 = 0; col0 < G; col0 += 8) {
+                        uint16_t ref[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) ref[k] = col0 + k < G ? cmap[(size_t)(col0 + k) * T.rows + r] : (uint16_t)0xFFFF;
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (col0 + k < G) store_streaming(&NL_TR(col0 + k, row), ref[k] == 0xFFFF ? 0 : (u64)val[ref[k]]);
+                    }
                 }
+                if (probe & 8) continue;
                 if (r == 0 || r > T.lookup_rows) {
-                    for (int k = 0; k < W * R; k++) store_streaming(&NL_TR(S.g + k, row), 0);
+                    for (int k = 0; k < W * R; k++) store_streaming(&NL_TR(G + k, row), 0);
                     continue;
                 }
 #pragma unroll 1
@@ -263,34 +305,35 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
                     // runtime value would live in scratch memory)
 #pragma unroll
                     for (int k = 0; k < W; k++) {
-                        const int j = k - (int)tb.n_in;
+                        const int jj = k - (int)tb.n_in;
                         const u32 vin = k == 0 ? a0 : k == 1 ? a1 : a2;
-                        const u32 vout = j == 0 ? o0 : j == 1 ? o1 : o2;
-                        const u64 v = j < 0 ? vin : (j < (int)tb.n_out ? vout : 0u);
-                        store_streaming(&NL_TR(S.g + W * sl + k, row), v);
+                        const u32 vout = jj == 0 ? o0 : jj == 1 ? o1 : o2;
+                        const u64 v = jj < 0 ? vin : (jj < (int)tb.n_out ? vout : 0u);
+                        store_streaming(&NL_TR(G + W * sl + k, row), v);
                     }
                     const u32 key = a0 | (tb.n_in > 1 ? a1 << tb.in_bits : 0u) | (tb.n_in > 2 ? a2 << (2 * tb.in_bits) : 0u);
                     keys[(size_t)sl * T.lookup_rows + (r - 1)] = (uint16_t)key;  // lanes <-> rows: contiguous runs per slot
                 }
             }
             // the state this step leaves becomes the next step's PREV bank (through registers: the banks overlap in time)
-            const uint16_t* const so = s_out + cs.type * S.state;
+            const uint16_t* const so = s_out + type * STATE;
             uint8_t nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0;  // state <= 256 elements: four per lane
-            if (lane < S.state) nx0 = val[so[lane]];
-            if (lane + 64 < S.state) nx1 = val[so[lane + 64]];
-            if (lane + 128 < S.state) nx2 = val[so[lane + 128]];
-            if (lane + 192 < S.state) nx3 = val[so[lane + 192]];
+            if (lane < STATE) nx0 = val[so[lane]];
+            if (lane + 64 < STATE) nx1 = val[so[lane + 64]];
+            if (lane + 128 < STATE) nx2 = val[so[lane + 128]];
+            if (lane + 192 < STATE) nx3 = val[so[lane + 192]];
             NL_WAVE_SYNC();
-            if (lane < S.state) val[V.prev + lane] = nx0;
-            if (lane + 64 < S.state) val[V.prev + lane + 64] = nx1;
-            if (lane + 128 < S.state) val[V.prev + lane + 128] = nx2;
-            if (lane + 192 < S.state) val[V.prev + lane + 192] = nx3;
+            if (lane < STATE) val[V.prev + lane] = nx0;
+            if (lane + 64 < STATE) val[V.prev + lane + 64] = nx1;
+            if (lane + 128 < STATE) val[V.prev + lane + 128] = nx2;
+            if (lane + 192 < STATE) val[V.prev + lane + 192] = nx3;
         }
     }
 }
 
 // ---- multiplicities: grid (histogram slices, 2 halves of a table's rows, instances). A workgroup counts the keys of ITS table in
-// its share of the cycles, the half's bins (at most 32768) in LDS, and adds the non-zero bins to the ONE multiplicity column.
+// its share of the cycles, the half's bins (at most 32768) in LDS, and stores them to its slice; k_nl_finish adds a table's slices
+// up into the ONE multiplicity column (33 M global atomics per call, the first version, cost more than the counting).
 constexpr int NL_HIST_THREADS = 1024;
 constexpr int NL_HIST_HALF = 32768;
 template <int R>
@@ -308,29 +351,50 @@ __global__ __launch_bounds__(NL_HIST_THREADS) void k_nl_hist(const NlDev* __rest
     const u32 nbins = T.rows < NL_HIST_HALF ? T.rows : NL_HIST_HALF;
     for (u32 i = t; i < nbins; i += NL_HIST_THREADS) s_bins[i] = 0;
     __syncthreads();
-    for (u32 c = split; c < capacity; c += n_splits) {
-        const uint16_t* const kc = job.keys + (size_t)c * D.keys_per_cycle;
-        for (u32 e = D.hist_first[tb]; e < D.hist_first[tb + 1]; e++) {
-            const NlHistEntry he = D.hist_entries[e];
-            const u32 nr = he.r1 - he.r0, total = nr * R;
-            for (u32 i = t; i < total; i += NL_HIST_THREADS) {
-                const u32 sl = i / nr, r = he.r0 + (i - sl * nr);
-                const u32 key = kc[he.key0 + (size_t)sl * he.lookup_rows + r];
-                if (key / NL_HIST_HALF == half) atomicAdd(&s_bins[key % NL_HIST_HALF], 1u);
-            }
-        }
+    // the table's row runs of a cycle, cached with their running key counts: item i of a cycle -> (run, slot, row)
+    constexpr int MAX_RUNS = 64;
+    __shared__ NlHistEntry s_run[MAX_RUNS];
+    __shared__ u32 s_run_first[MAX_RUNS + 1];
+    const u32 e0 = D.hist_first[tb], n_runs = min(D.hist_first[tb + 1] - e0, (u32)MAX_RUNS);
+    if (t < n_runs) s_run[t] = D.hist_entries[e0 + t];
+    __syncthreads();
+    if (t == 0) {
+        u32 acc = 0;
+        for (u32 e = 0; e < n_runs; e++) { s_run_first[e] = acc; acc += (s_run[e].r1 - s_run[e].r0) * R; }
+        s_run_first[n_runs] = acc;
     }
     __syncthreads();
-    unsigned long long* const col = reinterpret_cast<unsigned long long*>(job.trace + (size_t)S.mult_col * n_rows + T.offset + (size_t)half * NL_HIST_HALF);
-    for (u32 i = t; i < nbins; i += NL_HIST_THREADS)
-        if (s_bins[i]) atomicAdd(&col[i], (unsigned long long)s_bins[i]);
+    const u32 per_cycle = s_run_first[n_runs], keys_per_cycle = D.keys_per_cycle;
+    const u32 ncyc = capacity > split ? (capacity - split + n_splits - 1) / n_splits : 0;
+    const u64 total = (u64)ncyc * per_cycle;
+    for (u64 i = t; i < total; i += NL_HIST_THREADS) {
+        const u32 ci = (u32)(i / per_cycle), k = (u32)(i - (u64)ci * per_cycle);
+        u32 e = 0;
+        while (s_run_first[e + 1] <= k) e++;
+        const NlHistEntry he = s_run[e];
+        const u32 q = k - s_run_first[e], nr = he.r1 - he.r0, sl = q / nr, r = he.r0 + (q - sl * nr);
+        const u32 key = job.keys[(size_t)(split + ci * n_splits) * keys_per_cycle + he.key0 + (size_t)sl * he.lookup_rows + r];
+        if (key / NL_HIST_HALF == half) atomicAdd(&s_bins[key % NL_HIST_HALF], 1u);
+    }
+    __syncthreads();
+    u32* const out = job.hist + ((size_t)blockIdx.x * 2 + half) * NL_HIST_HALF;
+    for (u32 i = t; i < nbins; i += NL_HIST_THREADS) out[i] = s_bins[i];
 }
 
-// boundary rows (BND_IN, BND_OUT) and the public input row
+// the multiplicity column (sum of a table's slices), boundary rows (BND_IN, BND_OUT) and the public input row
 __global__ __launch_bounds__(256) void k_nl_finish(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const nl_spec& S = devp->s;
+    const NlDev& D = *devp;
+    const nl_spec& S = D.s;
     const NlJob job = jobs[blockIdx.y];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S.total_table_rows) {
+        u32 tb = 0;
+        while (tb + 1 < S.n_tables && S.tables[tb + 1].offset <= i) tb++;
+        const u32 e = i - S.tables[tb].offset, half = e / NL_HIST_HALF, bin = e % NL_HIST_HALF;
+        u64 n = 0;
+        for (u32 x = D.hist_slice0[tb]; x < D.hist_slice0[tb + 1]; x++) n += job.hist[((size_t)x * 2 + half) * NL_HIST_HALF + bin];
+        NL_TR(S.mult_col, i) = n;
+    }
     const size_t bnd = NL_BOUNDARY_ROW(&S, capacity), brows = NL_BND_ROWS(&S);
     if (i < S.state) {
         NL_TR(i % S.g, bnd + i / S.g) = job.state_before[i];

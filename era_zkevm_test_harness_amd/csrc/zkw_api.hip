@@ -1767,6 +1767,15 @@ struct zkw_trace {
     size_t n_rows = 0, n_cols = RC_COLS, n_slots = 0;
     u64* data = nullptr;
     size_t slot_elems() const { return n_cols * n_rows; }
+    // What a slot held last, for the netlist circuits (which then only rewrite the cells their fill writes: everything else is
+    // still zero from the same layout's previous tenant). 0 = unknown; every other writer and zkw_trace_device_ptr reset it.
+    mutable std::vector<uint64_t> slot_tag;
+    u64* slot_for_write(size_t slot, uint64_t tag) const {
+        if (slot_tag.size() != n_slots) slot_tag.assign(n_slots, 0);
+        slot_tag[slot] = tag;
+        return data + slot * slot_elems();
+    }
+    uint64_t tag_of(size_t slot) const { return slot_tag.size() == n_slots ? slot_tag[slot] : 0; }
 };
 
 extern "C" int zkw_trace_create_with_columns(zkw_ctx* ctx, size_t n_rows, size_t n_cols, size_t n_slots, zkw_trace** out) {
@@ -1807,7 +1816,8 @@ extern "C" size_t zkw_trace_num_rows(const zkw_trace* t) { return t ? t->n_rows 
 extern "C" size_t zkw_trace_num_cols(const zkw_trace* t) { return t ? t->n_cols : 0; }
 extern "C" size_t zkw_trace_num_slots(const zkw_trace* t) { return t ? t->n_slots : 0; }
 extern "C" const uint64_t* zkw_trace_device_ptr(const zkw_trace* t, size_t slot) {
-    return (t && slot < t->n_slots) ? t->data + slot * t->slot_elems() : nullptr;
+    if (!t || slot >= t->n_slots) return nullptr;
+    return t->slot_for_write(slot, 0);  // the caller may write through it: the slot's contents are unknown from here on
 }
 
 extern "C" int zkw_trace_get(const zkw_trace* t, size_t slot, uint32_t first_col, uint32_t n_cols, uint64_t* dst) {
@@ -1879,7 +1889,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
         j.lhs_z = w->zbuf_l + 2 * (lo - z_base);
         j.rhs_z = w->zbuf_r + 2 * (lo - z_base);
         j.n_block = nb;
-        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
         j.hist = d_hist + 256 * k;
         j.nd_tiles = d_nd + (size_t)n_tiles * k;
         j.public_input = w->public_inputs + 4 * idx;
@@ -3493,7 +3503,7 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
         j.n_block = w->n;
         memcpy(j.rq_tail_in, w->dedup_in.tail, 96);
         j.rq_len_in = w->dedup_in.length;
-        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
         j.hist = d_hist + 256 * k;
         j.public_input = w->public_inputs + 4 * (first_instance + k);
     }
@@ -3562,7 +3572,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
         memcpy(j.rq_tail_in, w->result_in.tail, 32);
         j.rq_len_in = w->result_in.length;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
-        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
         j.hist = d_hist + 256 * k;
     }
     EsSynthJob* d_jobs = nullptr;
@@ -3626,7 +3636,7 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
         for (int c = 0; c < 7; c++) j.offsets[c] = w->offsets[c];
         j.n_block = n;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
-        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
         j.hist = d_hist + 256 * k;
     }
     LdSynthJob* d_jobs = nullptr;
@@ -3769,9 +3779,50 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
     ZKW_TRY(nl_to_device(entries.data(), entries.size(), &d.hist_entries));
     ZKW_TRY(nl_to_device(first.data(), first.size(), &d.hist_first));
     ZKW_TRY(nl_to_device(slice0.data(), slice0.size(), &d.hist_slice0));
+    // the gates' known cells, run-length packed (netlist_kernels.cuh NlDev): consecutive cells whose dense references step by 1 and whose
+    // shifts step by `step` with one sign fold into one entry, provided every cell of the run is < 2^step (nibbles at step 4, bytes at
+    // step 8: true for this format's values, which are nibbles or bytes by construction of the generators)
+    std::vector<uint32_t> pk;
+    std::vector<uint16_t> pk_first;
+    std::vector<u32> pk0(hs->n_step_types);
+    for (u32 k = 0; k < hs->n_step_types; k++) {
+        const nl_step_type& T = hs->step_types[k];
+        pk0[k] = (u32)pk.size();
+        for (u32 gi = 0; gi < T.n_gates; gi++) {
+            const nl_gate& gt = hs->gates[T.gate0 + gi];
+            const nl_term* tm = hs->terms + T.term0 + gt.first_term;
+            pk_first.push_back((uint16_t)(pk.size() - pk0[k]));
+            for (u32 i = 1; i < gt.n_new; i++) {  // the fill describes a gate's NEW cells as (first value, count, first shift, step)
+                const nl_term *a = tm + gt.n_known + i - 1, *b = a + 1;
+                if (b->ref != a->ref + 1 || (i > 1 && (b->code & 0x7F) - (a->code & 0x7F) != (a->code & 0x7F) - (a[-1].code & 0x7F)))
+                    return fail(ZKW_ERR_INVALID, "netlist circuit %d: the NEW cells of gate %u are not consecutive values at evenly spaced shifts", circuit_type, gi);
+            }
+            for (u32 i = 0; i < gt.n_known;) {
+                const u32 ref = V.dense(tm[i].ref), code = tm[i].code;
+                u32 cnt = 1, step = 0;
+                if (i + 1 < gt.n_known && V.dense(tm[i + 1].ref) == ref + 1 && (tm[i + 1].code & 0x80) == (code & 0x80) && (tm[i + 1].code & 0x7F) > (code & 0x7F)) {
+                    step = (tm[i + 1].code & 0x7F) - (code & 0x7F);
+                    const bool nibble_run = hs->w == 4 && step == 4, byte_run = hs->w == 3 && step == 8;  // values < 2^step
+                    if (nibble_run || byte_run)
+                        while (cnt < 8 && i + cnt < gt.n_known && V.dense(tm[i + cnt].ref) == ref + cnt && tm[i + cnt].code == code + cnt * step) cnt++;
+                    else step = 0;
+                }
+                if (cnt == 1) step = 0;
+                pk.push_back(ref | (cnt - 1) << 16 | code << 20 | step << 28);
+                i += cnt;
+            }
+        }
+        pk_first.push_back((uint16_t)(pk.size() - pk0[k]));  // closes the step type's last gate
+    }
+    if (pk.empty()) pk.push_back(0);
+    d.n_pk_terms = (u32)pk.size();
+    ZKW_TRY(nl_to_device(pk.data(), pk.size(), &d.pk_terms));
+    ZKW_TRY(nl_to_device(pk_first.data(), pk_first.size(), &d.pk_first));
+    ZKW_TRY(nl_to_device(pk0.data(), pk0.size(), &d.pk0));
     d.max_items = max_items;
     d.vsize = V.size;
-    d.lds_bytes = NlLds(*hs, V.size).total;
+    d.lds_bytes = NlLds(*hs, V.size, d.n_pk_terms).total;
+    if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d: %u terms packed into %u, LDS %u bytes for %d waves\n", circuit_type, hs->n_terms, d.n_pk_terms, d.lds_bytes, NL_FILL_WAVES);
     const NlDev* dd = nullptr;
     ZKW_TRY(nl_to_device(&d, 1, &dd));
     c.host = d;
@@ -3780,7 +3831,7 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
     return ZKW_OK;
 }
 
-struct NlInstance { u64 first_round; u32 n_active; const u64* public_input; u64* trace; };
+struct NlInstance { u64 first_round; u32 n_active; const u64* public_input; const zkw_trace* t; size_t slot; };
 
 template <int W, int R>
 int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
@@ -3789,8 +3840,9 @@ int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsign
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ctx->device & 15] = true;
     }
+    static const u32 probe = [] { const char* e = getenv("ZKW_NL_PROBE"); return e ? (u32)atoi(e) : 0u; }();  // measurement only: 1 = no level walk, 2 = no streaming
     const unsigned blocks = std::min<unsigned>((capacity + NL_FILL_WAVES - 1) / NL_FILL_WAVES, std::max<unsigned>(1, 256 / nj));
-    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R>), dim3(blocks, nj), dim3(NL_FILL_THREADS), nc->host.lds_bytes, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R>), dim3(blocks, nj), dim3(NL_FILL_THREADS), nc->host.lds_bytes, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
     ZKW_TRY(launch_check("k_nl_fill"));
     { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
     return launch_check("k_nl_hist");
@@ -3814,18 +3866,27 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
     ZKW_TRY(ctx->scratch_t<uint8_t>("nl_free", ni * free_n + 1, &d_free));
     ZKW_TRY(ctx->scratch_t<uint8_t>("nl_state", ni * state_n, &d_state));
     ZKW_TRY(ctx->scratch_t<uint16_t>("nl_keys", ni * keys_n, &d_keys));
+    u32* d_hist = nullptr;
+    const size_t hist_n = (size_t)nc->host.n_hist_slices * 2 * NL_HIST_HALF;
+    ZKW_TRY(ctx->scratch_t<u32>("nl_hist", ni * hist_n, &d_hist));
     std::vector<NlPrepJob> prep(ni);
     std::vector<NlJob> jobs(ni);
     const size_t bnd = NL_BOUNDARY_ROW(&S, capacity);
     for (size_t k = 0; k < ni; k++) {
         prep[k] = NlPrepJob{d_rounds, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n};
-        jobs[k] = NlJob{prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before, inst[k].public_input, inst[k].trace, d_keys + k * keys_n};
-        // the fill writes every general-purpose and lookup cell above the boundary: zero the rows from the boundary down, and the
-        // multiplicity column (k_nl_hist adds to it)
-        u64* tr = inst[k].trace;
-        hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - bnd + 255) / 256), S.mult_col), dim3(256), 0, ctx->stream, tr + bnd, n_rows, n_rows - bnd);
-        ZKW_TRY(launch_check("k_zero_strip"));
-        HIP_TRY(hipMemsetAsync(tr + (size_t)S.mult_col * n_rows, 0, n_rows * sizeof(u64), ctx->stream));
+        // The fill writes the lookup cells of every row above the boundary and the general-purpose cells of the header / gate rows;
+        // everything else is zero. A slot whose previous tenant was the same layout (circuit, capacity, rows) already has those
+        // zeros: nothing to clear (the multiplicity column is rewritten over the tables' rows). Otherwise: clear it.
+        const uint64_t tag = ((uint64_t)circuit_type << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
+        const bool clean = inst[k].t->tag_of(inst[k].slot) == tag;
+        u64* tr = inst[k].t->slot_for_write(inst[k].slot, tag);
+        jobs[k] = NlJob{prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before, inst[k].public_input, tr, d_keys + k * keys_n, d_hist + k * hist_n};
+        if (!clean) {
+            HIP_TRY(hipMemsetAsync(tr, 0, (size_t)S.g * n_rows * sizeof(u64), ctx->stream));  // general-purpose columns
+            hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - bnd + 255) / 256), S.mult_col - S.g), dim3(256), 0, ctx->stream, tr + (size_t)S.g * n_rows + bnd, n_rows, n_rows - bnd);
+            ZKW_TRY(launch_check("k_zero_strip"));
+            HIP_TRY(hipMemsetAsync(tr + (size_t)S.mult_col * n_rows, 0, n_rows * sizeof(u64), ctx->stream));
+        }
     }
     NlPrepJob* d_prep = nullptr;
     NlJob* d_jobs = nullptr;
@@ -3841,7 +3902,7 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
         case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
         default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
     }
-    { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((S.state + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
     return launch_check("k_nl_finish");
 }
 
@@ -3881,7 +3942,8 @@ std::vector<NlInstance> nl_instances(size_t first_instance, size_t n_instances, 
         v[k].first_round = (u64)i * capacity;
         v[k].n_active = any ? (u32)std::min<u64>(capacity, total_rounds - v[k].first_round) : 0;
         v[k].public_input = cf_pi + COMPACT_FORM_LEN * n_all + 4 * i;
-        v[k].trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        v[k].t = t;
+        v[k].slot = (first_slot + k) % t->n_slots;
     }
     return v;
 }
@@ -4014,7 +4076,7 @@ extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* m
     { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(1), dim3(64), 0, ctx->stream, d_cf, (size_t)1, (u32)COMPACT_FORM_LEN, d_pi); }
     ZKW_TRY(launch_check("k_commit_encodings"));
     std::vector<NlInstance> inst(1);
-    inst[0] = NlInstance{0, (u32)n_rounds, d_pi, t->data + slot * t->slot_elems()};
+    inst[0] = NlInstance{0, (u32)n_rounds, d_pi, t, slot};
     ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows));
     *record_out = rec;
     if (public_input_out) ZKW_TRY(ctx->read_small(public_input_out, d_pi, 32));
@@ -4055,7 +4117,7 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
         j.sc.D = reinterpret_cast<int*>(w->scans); j.sc.S = w->scans + n; j.sc.R = w->scans + 2 * n; j.sc.E = w->scans + 3 * n;
         j.n_block = n;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
-        j.trace = t->data + ((first_slot + k) % t->n_slots) * t->slot_elems();
+        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
         j.hist = d_hist + 256 * k;
     }
     SsSynthJob* d_jobs = nullptr;

@@ -1,0 +1,30 @@
+"""per-kernel times of the netlist circuits' synthesis at production geometry (2^20 rows, reference capacities)"""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
+from era_zkevm_test_harness_amd import native, synthetic
+ctx = native.Context(0)
+n_rows = 1 << 20
+mem_in = np.zeros(1, native.QUEUE_STATE12)
+for name, kind, n_req, cap, cols, synth in (("keccak", 0, 1400, 293, native.KC_COLS, ctx.synthesize_keccak_round_function),
+                                            ("sha256", 1, 6000, 2206, native.SC_COLS, ctx.synthesize_sha256_round_function)):
+    req, mq = synthetic.precompile_trace(kind, n_req, seed=5, max_rounds=6)
+    tails = ctx.queue_push_chain_log(ctx.encode_log_queries(req))[1]
+    w = ctx._precompile(kind, req, tails, mq, cap, mem_in)
+    n = min(8, w.num_instances)
+    t = native.Trace(ctx, n_rows, n, n_cols=cols)
+    synth(w, t, 0, n, 0); ctx.synchronize()
+    ctx.profile_enable(True); ctx.profile_reset()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); synth(w, t, 0, n, 0); ctx.synchronize(); best = min(best, time.perf_counter() - t0)
+    prof = ctx.profile()
+    print(name, f"{n} instances {best*1e3:.2f} ms = {n/best:.0f} circuits/s", {k: round(v[0] / 3, 3) for k, v in prof.items()})
+    ctx.profile_enable(False)
+    t.free(); w.free()
+q = synthetic.mixed_log_queue(4000, seed=3)[:700]
+t = native.Trace(ctx, n_rows, 1, n_cols=native.LH_COLS)
+ctx.synthesize_linear_hasher(q, np.zeros(1, native.QUEUE_STATE4), 774, t, 0); ctx.synchronize()
+ctx.profile_enable(True); ctx.profile_reset()
+t0 = time.perf_counter(); ctx.synthesize_linear_hasher(q, np.zeros(1, native.QUEUE_STATE4), 774, t, 0); ctx.synchronize(); dt = time.perf_counter() - t0
+print("linear hasher", f"{dt*1e3:.2f} ms", {k: round(v[0], 3) for k, v in ctx.profile().items()})
