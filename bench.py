@@ -139,7 +139,7 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
         B.free()
         if best is None or rep["wall_ms"] < best["wall_ms"]:
             best = rep
-    best["batched"] = full_blocks_batched(local_rank, blk) if world == 1 else None
+    best["batched"] = full_blocks_batched(local_rank, blk, rank=rank, world=world, comm=comm)
     best["note"] = ("one block on %d GPU(s): builders = zkw_block_run (every builder of the post-VM half of "
                     "create_artifacts_from_tracer; replicated on every rank: they are bounded by the block's longest serial "
                     "Poseidon2 queue chain, memory queue = %d items x ~10.3 us, which more GPUs cannot shorten); synthesis = this "
@@ -148,33 +148,50 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     return best, blk
 
 
-def full_blocks_batched(local_rank, blk, K=48, rounds=3):
+def full_blocks_batched(local_rank, blk, K=48, rounds=3, rank=0, world=1, comm=None):
+    """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once (one host thread per block; the chain
+    service merges every block's Poseidon2 queue chains into a few shared launches, so K blocks cost about two chain passes
+    instead of K), then every synthesizable instance of every block into its trace, then the blocks released. With N GPUs the
+    K x N blocks are sharded over the ranks by zkw_blocks_run_sharded (round-robin, nothing replicated) and every block's
+    closed-form records are gathered to rank 0 (zkw_blocks_gather_closed_form_inputs): the mode that scales. The first round
+    fills the library's buffer caches (untimed); the best of the others is reported."""
     from concurrent.futures import ThreadPoolExecutor
 
-    """Throughput of WHOLE blocks: K production-capacity blocks in flight at once through zkw_blocks_run (one host thread
-    per block; the chain service merges every block's Poseidon2 queue chains into a few shared launches, so K blocks cost
-    about two chain passes instead of K), then every synthesizable instance of every block into its trace, then the blocks
-    released. The first round fills the library's buffer caches (untimed); the best of the others is reported."""
     # K = 48: with 96 blocks in flight (27 blocks/s, tools/probe_block_concurrency.py) rocprofv3's own interception crashes in
     # hipMemcpyAsync under ~500 host threads; the bench must stay profilable
     K = int(os.environ.get("ZKW_BATCHED_BLOCKS", K))
-    blocks = [blk] + [synthetic.block_production(seed=2 + k) for k in range(3)]
-    blocks = [blocks[k % len(blocks)] for k in range(K)]
+    distinct = [blk] + [synthetic.block_production(seed=2 + k) for k in range(3)]
+    blocks = [distinct[(k // world) % len(distinct)] for k in range(K * world)]
+    dev = torch.device("cuda", local_rank)
     best = None
     for r in range(rounds):
+        parallel.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        bs = native.Block.run_many(local_rank, blocks)
+        if world == 1:
+            bs = native.Block.run_many(local_rank, blocks)
+        else:
+            bs = native.Block.run_sharded(local_rank, blocks, rank, world)
+        mine = [b for b in bs if b is not None]
         t1 = time.perf_counter()
         with ThreadPoolExecutor(8) as ex:  # the blocks' synthesis calls side by side (they are short kernels and host waits)
-            n = sum(ex.map(lambda b: b.synthesize(1 << 20, ring_slots=1), bs))
+            n = sum(ex.map(lambda b: b.synthesize(1 << 20, ring_slots=1), mine))
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        for b in bs:
-            b.free()
+        n_records = None
+        if world > 1 and comm is not None:
+            got = native.Block.gather_sharded(bs, comm, rank, world, root=0)
+            n_records = sum(len(g) for g in got) if got is not None else None
         t3 = time.perf_counter()
-        rep = {"blocks": K, "blocks_per_s": K / (t3 - t0), "synthesized_circuits_per_s": n / (t3 - t0), "wall_ms": (t3 - t0) * 1e3,
-               "builders_ms": (t1 - t0) * 1e3, "synthesis_ms": (t2 - t1) * 1e3, "release_ms": (t3 - t2) * 1e3, "instances_synthesized": n}
+        for b in mine:
+            b.free()
+        t4 = time.perf_counter()
+        wall = parallel.max_over_ranks(t4 - t0, dev)
+        n_all = int(parallel.sum_over_ranks(n, dev)) if world > 1 else n
+        rep = {"blocks": K * world, "blocks_per_gpu": K, "n_gpus": world, "blocks_per_s": K * world / wall, "blocks_per_s_this_rank": len(mine) / (t4 - t0),
+               "synthesized_circuits_per_s": n_all / wall, "wall_ms": wall * 1e3, "builders_ms": (t1 - t0) * 1e3, "synthesis_ms": (t2 - t1) * 1e3,
+               "gather_ms": (t3 - t2) * 1e3, "release_ms": (t4 - t3) * 1e3, "instances_synthesized": n_all, "records_gathered": n_records,
+               "sharding": "one GPU" if world == 1 else "zkw_blocks_run_sharded (round-robin over ranks) + zkw_blocks_gather_closed_form_inputs"}
         if r and (best is None or rep["wall_ms"] < best["wall_ms"]):
             best = rep
     return best
@@ -222,11 +239,14 @@ def hash_circuits_gpu(local_rank, blk):
     t.free()
     w.free()
     dec.free()
-    q = synthetic.mixed_log_queue(4000, seed=3)[:700]
-    t = native.Trace(ctx, n_rows, 1, n_cols=native.LH_COLS)
-    out["linear_hasher"] = dict(timed(1, lambda: ctx.synthesize_linear_hasher(q, np.zeros(1, native.QUEUE_STATE4), 774, t, 0)), capacity=774,
+    queues = [synthetic.mixed_log_queue(4000, seed=3 + k)[:700] for k in range(8)]
+    t = native.Trace(ctx, n_rows, 8, n_cols=native.LH_COLS)
+    states = np.zeros(8, native.QUEUE_STATE4)
+    out["linear_hasher"] = dict(timed(8, lambda: ctx.synthesize_linear_hasher_batch(queues, states, 774, t, 0)), capacity=774,
                                 columns=native.LH_COLS, trace_bytes=native.LH_COLS * n_rows * 8,
-                                note="one instance per block; 3.6 ms of it is the serial sponge over the messages")
+                                note="the L1-messages queues of 8 blocks per call (zkw_linear_hasher_synthesize_batch); the sponge of a "
+                                     "queue is serial, ~4.5 ms whatever the batch",
+                                single_queue_ms_per_call=timed(1, lambda: ctx.synthesize_linear_hasher(queues[0], states[:1], 774, t, 0))["ms_per_call"])
     t.free()
     ctx.close()
     return out

@@ -251,10 +251,21 @@ __device__ __forceinline__ u32 l1_message_byte(const zkw_log_query* q, size_t po
 // rounds (may be null): one zkw_keccak_round_record per absorbed block — the cycles of the LinearHasher circuit (type 13).
 // The sponge is serial: 25 lanes of one wave hold the state in LDS (7.7 us per call; lane 0 alone running the unrolled
 // register form of keccak_f1600 was measured at 17 us)
+// Batch form: workgroup b hashes the messages [msg_off[b], msg_off[b + 1]) into out + 32 b, its round records start at
+// rounds + round_off[b] (msg_off == nullptr: one queue of n messages). The queues of a batch run side by side — the chain of
+// one queue stays serial.
 __global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_query* __restrict__ q, size_t n, uint8_t* __restrict__ out,
-                                                         zkw_keccak_round_record* __restrict__ rounds) {
+                                                         zkw_keccak_round_record* __restrict__ rounds,
+                                                         const u64* __restrict__ msg_off, const u64* __restrict__ round_off) {
     __shared__ u64 A[25], Bm[25], Cc[5];
     const int t = threadIdx.x;
+    if (msg_off) {
+        const u64 m0 = msg_off[blockIdx.x];
+        q += m0;
+        n = msg_off[blockIdx.x + 1] - m0;
+        out += 32 * (size_t)blockIdx.x;
+        if (rounds) rounds += round_off[blockIdx.x];
+    }
     const size_t len = n * 88;
     if (t < 25) A[t] = 0;
     __syncthreads();

@@ -208,9 +208,8 @@ __global__ __launch_bounds__(64) void k_sap_leaves(SapJob job) {
     for (int k = 0; k < 8; k++) { job.A0[8 * i + k] = a[k]; job.C0[8 * i + k] = c[k]; }
 }
 
-__global__ __launch_bounds__(64) void k_sap_level(SapJob job, int L) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= job.n) return;
+// one level of every path: A(i, L + 1), C(i, L + 1) from level L (see the header comment)
+__device__ __forceinline__ void sap_level_step(const SapJob& job, int L, u64 i) {
     const u32 *Ac = (L & 1) ? job.A1 : job.A0, *Cc = (L & 1) ? job.C1 : job.C0;
     u32 *An = (L & 1) ? job.A0 : job.A1, *Cn = (L & 1) ? job.C0 : job.C1;
     const u32 js = job.jstar[(u64)L * job.n + i];
@@ -233,6 +232,26 @@ __global__ __launch_bounds__(64) void k_sap_level(SapJob job, int L) {
     if (right) sap_node_hash(init_sib, c, o); else sap_node_hash(c, init_sib, o);
 #pragma unroll
     for (int k = 0; k < 8; k++) Cn[8 * i + k] = o[k];
+}
+
+// Level-synchronous launches: for blocks with more storage queries than one workgroup walks (n > SAP_PERSISTENT_MAX)
+__global__ __launch_bounds__(64) void k_sap_level(SapJob job, int L) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < job.n) sap_level_step(job, L, i);
+}
+
+// All 256 levels in ONE launch: a single workgroup walks every path upwards, a workgroup barrier (and a device-scope fence:
+// the level's hashes travel through global memory) between levels instead of a kernel boundary. A block's storage
+// application sees tens to a few hundred distinct slots (production: 33 per instance), so one CU holds all of them; the walk
+// is a chain of 256 dependent Blake2s pairs either way.
+constexpr int SAP_PERSISTENT_THREADS = 256;
+constexpr u64 SAP_PERSISTENT_MAX = 4 * SAP_PERSISTENT_THREADS;
+__global__ __launch_bounds__(SAP_PERSISTENT_THREADS) void k_sap_levels(SapJob job) {
+    for (int L = 0; L < 256; L++) {
+        for (u64 i = threadIdx.x; i < job.n; i += SAP_PERSISTENT_THREADS) sap_level_step(job, L, i);
+        __threadfence();
+        __syncthreads();
+    }
 }
 
 // after level 255 (A0 / C0 hold the roots): root after every query + the reference's inclusion asserts

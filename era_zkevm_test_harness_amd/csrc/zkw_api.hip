@@ -2997,7 +2997,7 @@ extern "C" int zkw_linear_keccak256(zkw_ctx* ctx, const zkw_log_query* messages,
     uint8_t* d_out = nullptr;
     ZKW_TRY(ctx->in("lk_q", messages, n, &d_q));
     ZKW_TRY(ctx->out("lk_out", hash_out, 32, &d_out));
-    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out, (zkw_keccak_round_record*)nullptr); }
+    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out, (zkw_keccak_round_record*)nullptr, (const u64*)nullptr, (const u64*)nullptr); }
     ZKW_TRY(launch_check("k_linear_keccak256"));
     ZKW_TRY(ctx->finish_out(hash_out, d_out, 32));
     return ctx->sync_if_host();
@@ -3383,9 +3383,15 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
         TRY(launch_check("k_sap_pairs"));
         { Prof _p(ctx, "k_sap_leaves"); hipLaunchKernelGGL(k_sap_leaves, dim3(g64), dim3(64), 0, ctx->stream, job); }
         TRY(launch_check("k_sap_leaves"));
-        for (int L = 0; L < ZKW_STORAGE_TREE_DEPTH && rc == ZKW_OK; L++) {
-            Prof _p(ctx, "k_sap_level");
-            hipLaunchKernelGGL(k_sap_level, dim3(g64), dim3(64), 0, ctx->stream, job, L);
+        static_assert(ZKW_STORAGE_TREE_DEPTH == 256, "k_sap_levels walks 256 levels");
+        if (n <= SAP_PERSISTENT_MAX) {
+            Prof _p(ctx, "k_sap_levels");
+            hipLaunchKernelGGL(k_sap_levels, dim3(1), dim3(SAP_PERSISTENT_THREADS), 0, ctx->stream, job);
+        } else {
+            for (int L = 0; L < ZKW_STORAGE_TREE_DEPTH && rc == ZKW_OK; L++) {
+                Prof _p(ctx, "k_sap_level");
+                hipLaunchKernelGGL(k_sap_level, dim3(g64), dim3(64), 0, ctx->stream, job, L);
+            }
         }
         TRY(launch_check("k_sap_level"));
         { Prof _p(ctx, "k_sap_roots"); hipLaunchKernelGGL(k_sap_roots, dim3(g64), dim3(64), 0, ctx->stream, job); }
@@ -4042,45 +4048,73 @@ extern "C" int zkw_check_copy_permutation(zkw_ctx* ctx, const zkw_trace* t, size
 
 // LinearHasher (type 13): the Keccak-f netlist over the sponge of the serialized L2 -> L1 messages (compute_linear_keccak256,
 // data_hasher_and_merklizer.rs:8-67; wrapper base_layer/linear_hasher.rs:28-138). One instance per block.
-extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* messages, size_t n, const zkw_queue_state4* queue_state,
-                                            uint32_t capacity, zkw_trace* t, size_t slot, zkw_linear_hasher_instance* record_out,
-                                            uint64_t* public_input_out) {
-    if (!ctx || !t || !queue_state || !record_out || t->ctx->device != ctx->device || slot >= t->n_slots || capacity == 0 || (n && !messages))
-        return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize: bad argument");
-    if (n > capacity) return fail(ZKW_ERR_INVALID, "%zu messages, the circuit hashes at most %u", n, capacity);
+extern "C" int zkw_linear_hasher_synthesize_batch(zkw_ctx* ctx, const zkw_log_query* messages, const uint64_t* message_offsets, size_t n_queues,
+                                                  const zkw_queue_state4* queue_states, uint32_t capacity, zkw_trace* t, size_t first_slot,
+                                                  zkw_linear_hasher_instance* records_out, uint64_t* public_inputs_out) {
+    if (!ctx || !t || !message_offsets || !queue_states || !records_out || t->ctx->device != ctx->device || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: bad argument");
+    if (n_queues == 0) return ZKW_OK;
+    if (first_slot + n_queues > t->n_slots) return fail(ZKW_ERR_INVALID, "slots [%zu, %zu) of a trace with %zu", first_slot, first_slot + n_queues, t->n_slots);
     if (t->n_cols < LH_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the LinearHasher circuit needs %d", t->n_cols, LH_COLS);
+    const size_t total = message_offsets[n_queues];
+    if (message_offsets[0] != 0 || (total && !messages)) return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: offsets must start at 0");
+    std::vector<u64> moff(message_offsets, message_offsets + n_queues + 1), roff(n_queues + 1, 0);
+    for (size_t b = 0; b < n_queues; b++) {
+        if (moff[b + 1] < moff[b]) return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: offsets decrease at %zu", b);
+        const size_t n = moff[b + 1] - moff[b];
+        if (n > capacity) return fail(ZKW_ERR_INVALID, "queue %zu: %zu messages, the circuit hashes at most %u", b, n, capacity);
+        roff[b + 1] = roff[b] + n * 88 / 136 + 1;
+    }
     const u32 cycles = ZKW_LINEAR_HASHER_CYCLES(capacity);
-    const size_t n_rows = t->n_rows, n_rounds = n * 88 / 136 + 1;
+    const size_t n_rows = t->n_rows;
     HIP_TRY(hipSetDevice(ctx->device));
     const zkw_log_query* d_q = nullptr;
-    ZKW_TRY(ctx->in("lh_q", messages, n, &d_q));
+    ZKW_TRY(ctx->in("lh_q", messages, total, &d_q));
     zkw_keccak_round_record* d_rounds = nullptr;
     uint8_t* d_hash = nullptr;
-    ZKW_TRY(ctx->scratch_t<zkw_keccak_round_record>("lh_rounds", n_rounds, &d_rounds));
-    ZKW_TRY(ctx->scratch_t<uint8_t>("lh_hash", 32, &d_hash));
-    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_hash, d_rounds); }
+    u64 *d_moff = nullptr, *d_roff = nullptr;
+    ZKW_TRY(ctx->scratch_t<zkw_keccak_round_record>("lh_rounds", roff[n_queues], &d_rounds));
+    ZKW_TRY(ctx->scratch_t<uint8_t>("lh_hash", 32 * n_queues, &d_hash));
+    ZKW_TRY(ctx->upload("lh_moff", moff, &d_moff));
+    ZKW_TRY(ctx->upload("lh_roff", roff, &d_roff));
+    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3((unsigned)n_queues), dim3(64), 0, ctx->stream, d_q, (size_t)0, d_hash, d_rounds, d_moff, d_roff); }
     ZKW_TRY(launch_check("k_linear_keccak256"));
-    zkw_linear_hasher_instance rec;
-    memset(&rec, 0, sizeof rec);
-    rec.start_flag = rec.completion_flag = 1;
-    rec.queue_state = *queue_state;
-    ZKW_TRY(ctx->read_small(rec.keccak256_hash, d_hash, 32));
-    std::vector<zkw_linear_hasher_instance> recv(1, rec);
+    std::vector<zkw_linear_hasher_instance> recv(n_queues);
+    std::vector<uint8_t> hashes(32 * n_queues);
+    ZKW_TRY(ctx->read_small(hashes.data(), d_hash, hashes.size()));
+    for (size_t b = 0; b < n_queues; b++) {
+        memset(&recv[b], 0, sizeof recv[b]);
+        recv[b].start_flag = recv[b].completion_flag = 1;
+        recv[b].queue_state = queue_states[b];
+        memcpy(recv[b].keccak256_hash, &hashes[32 * b], 32);
+    }
     zkw_linear_hasher_instance* d_rec = nullptr;
     ZKW_TRY(ctx->upload("lh_record", recv, &d_rec));
     u64 *d_cf = nullptr, *d_pi = nullptr;
-    ZKW_TRY(ctx->scratch_t<u64>("lh_cf", COMPACT_FORM_LEN, &d_cf));
-    ZKW_TRY(ctx->scratch_t<u64>("lh_pi", 4, &d_pi));
-    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<CfLinearHasher>), dim3(1), dim3(CfLanes<CfLinearHasher>::value), 0, ctx->stream, d_rec, (size_t)1, d_cf); }
+    ZKW_TRY(ctx->scratch_t<u64>("lh_cf", COMPACT_FORM_LEN * n_queues, &d_cf));
+    ZKW_TRY(ctx->scratch_t<u64>("lh_pi", 4 * n_queues, &d_pi));
+    {
+        constexpr int lanes = CfLanes<CfLinearHasher>::value;
+        Prof _p(ctx, "k_closed_form_commitments");
+        hipLaunchKernelGGL((k_closed_form_commitments<CfLinearHasher>), dim3(blocks_for(4 * n_queues, lanes)), dim3(lanes), 0, ctx->stream, d_rec, n_queues, d_cf);
+    }
     ZKW_TRY(launch_check("k_closed_form_commitments"));
-    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(1), dim3(64), 0, ctx->stream, d_cf, (size_t)1, (u32)COMPACT_FORM_LEN, d_pi); }
+    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n_queues, 64)), dim3(64), 0, ctx->stream, d_cf, n_queues, (u32)COMPACT_FORM_LEN, d_pi); }
     ZKW_TRY(launch_check("k_commit_encodings"));
-    std::vector<NlInstance> inst(1);
-    inst[0] = NlInstance{0, (u32)n_rounds, d_pi, t, slot};
+    std::vector<NlInstance> inst(n_queues);
+    for (size_t b = 0; b < n_queues; b++) inst[b] = NlInstance{roff[b], (u32)(roff[b + 1] - roff[b]), d_pi + 4 * b, t, first_slot + b};
     ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows));
-    *record_out = rec;
-    if (public_input_out) ZKW_TRY(ctx->read_small(public_input_out, d_pi, 32));
+    memcpy(records_out, recv.data(), n_queues * sizeof recv[0]);
+    if (public_inputs_out) ZKW_TRY(ctx->read_small(public_inputs_out, d_pi, 32 * n_queues));
     return ZKW_OK;
+}
+
+extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* messages, size_t n, const zkw_queue_state4* queue_state,
+                                            uint32_t capacity, zkw_trace* t, size_t slot, zkw_linear_hasher_instance* record_out,
+                                            uint64_t* public_input_out) {
+    if (!queue_state || !record_out) return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize: bad argument");
+    const uint64_t offsets[2] = {0, n};
+    return zkw_linear_hasher_synthesize_batch(ctx, messages, offsets, 1, queue_state, capacity, t, slot, record_out, public_input_out);
 }
 
 extern "C" int zkw_linear_hasher_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {

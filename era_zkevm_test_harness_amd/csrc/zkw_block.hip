@@ -625,6 +625,28 @@ extern "C" int zkw_blocks_run(int device_id, const zkw_block_inputs* const* inpu
     return ZKW_OK;
 }
 
+// Blocks sharded over the ranks of a multi-GPU job: the mode that scales (a block's builders are bound by one serial chain, so
+// splitting ONE block over GPUs only divides its synthesis; whole blocks divide everything). Round-robin: a stream of blocks of
+// uneven size spreads evenly, and every rank computes the same assignment without talking.
+extern "C" int zkw_blocks_owner(size_t block, int world) { return world > 0 ? (int)(block % (size_t)world) : -1; }
+
+extern "C" int zkw_blocks_run_sharded(int device_id, const zkw_block_inputs* const* inputs, size_t n_blocks, int rank, int world, zkw_block** out) {
+    if (!inputs || !out || world < 1 || rank < 0 || rank >= world) return ZKW_ERR_INVALID;
+    std::vector<const zkw_block_inputs*> mine;
+    std::vector<size_t> where;
+    for (size_t k = 0; k < n_blocks; k++) {
+        out[k] = nullptr;
+        if (!inputs_valid(inputs[k])) return ZKW_ERR_INVALID;  // every rank checks every block: all ranks fail or none
+        if (zkw_blocks_owner(k, world) == rank) { mine.push_back(inputs[k]); where.push_back(k); }
+    }
+    if (mine.empty()) return ZKW_OK;
+    std::vector<zkw_block*> got(mine.size(), nullptr);
+    const int rc = zkw_blocks_run(device_id, mine.data(), mine.size(), got.data());
+    if (rc != ZKW_OK) return rc;
+    for (size_t i = 0; i < mine.size(); i++) out[where[i]] = got[i];
+    return ZKW_OK;
+}
+
 extern "C" void zkw_block_free(zkw_block* B) {
     if (!B) return;
     (void)hipSetDevice(B->device);
@@ -879,4 +901,39 @@ extern "C" int zkw_block_gather_closed_form_inputs(zkw_block* B, zkw_comm* comm,
     if ((rc = zkw_gather_records(comm, owner.data(), n, mine.data(), 24 * 8, root, out)) != ZKW_OK) return rc;
     if (n_records) *n_records = n;
     return ZKW_OK;
+}
+
+// The gather of the sharded-blocks mode: block k's records [n_instances, then per instance (circuit_type, instance, compact form
+// (18), public input (4))] travel from the block's owner to the root as ONE fixed-size record of 1 + 24 * max_per_block words,
+// so that no rank needs another rank's instance counts to take part. out[n_blocks][1 + 24 * max_per_block] (host, root only).
+extern "C" int zkw_blocks_gather_closed_form_inputs(zkw_block* const* blocks, size_t n_blocks, zkw_comm* comm, int rank, int world, int root,
+                                                    size_t max_per_block, uint64_t* out) {
+    if (!comm || (n_blocks && !blocks) || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || max_per_block == 0) return ZKW_ERR_INVALID;
+    const size_t words = 1 + 24 * max_per_block;
+    std::vector<uint32_t> owner(n_blocks);
+    std::vector<uint64_t> mine;
+    for (size_t k = 0; k < n_blocks; k++) {
+        owner[k] = (uint32_t)zkw_blocks_owner(k, world);
+        if ((int)owner[k] != rank) continue;
+        zkw_block* B = blocks[k];
+        if (!B) return ZKW_ERR_INVALID;
+        std::vector<uint8_t> types;
+        std::vector<uint32_t> index, one;
+        int rc = shard_plan(B, 1, &types, &index, &one);
+        if (rc != ZKW_OK) return rc;
+        if (types.size() > max_per_block) { g_block_error = "zkw_blocks_gather_closed_form_inputs: block has more instances than max_per_block"; return ZKW_ERR_INVALID; }
+        const size_t base = mine.size();
+        mine.resize(base + words, 0);
+        mine[base] = types.size();
+        for (size_t i = 0; i < types.size(); i++) {
+            const PerType& p = B->per[types[i]];
+            uint64_t* r = &mine[base + 1 + 24 * i];
+            r[0] = types[i];
+            r[1] = index[i];
+            std::copy(p.compact.begin() + 18 * index[i], p.compact.begin() + 18 * (index[i] + 1), r + 2);
+            std::copy(p.pi.begin() + 4 * index[i], p.pi.begin() + 4 * (index[i] + 1), r + 20);
+        }
+    }
+    if (rank == root && n_blocks && !out) return ZKW_ERR_INVALID;
+    return zkw_gather_records(comm, owner.data(), n_blocks, mine.data(), words * 8, root, out);
 }

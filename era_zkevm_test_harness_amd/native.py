@@ -135,6 +135,7 @@ SYMBOLS = [
     ("zkw_code_decommitter_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_sha256_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_linear_hasher_synthesize", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
+    ("zkw_linear_hasher_synthesize_batch", _int, [_vp, _vp, _vp, _sz, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
     ("zkw_linear_hasher_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
@@ -176,6 +177,9 @@ SYMBOLS = [
     ("zkw_gather_closed_form_inputs", _int, [_vp, _vp, _vp, _sz, _int, _vp]),
     ("zkw_block_run", _int, [_int, _vp, C.POINTER(_vp)]),
     ("zkw_blocks_run", _int, [_int, _vp, _sz, _vp]),
+    ("zkw_blocks_owner", _int, [_sz, _int]),
+    ("zkw_blocks_run_sharded", _int, [_int, _vp, _sz, _int, _int, _vp]),
+    ("zkw_blocks_gather_closed_form_inputs", _int, [_vp, _sz, _vp, _int, _int, _int, _sz, _vp]),
     ("zkw_block_last_error", C.c_char_p, []),
     ("zkw_block_free", None, [_vp]),
     ("zkw_block_witness", _vp, [_vp, C.c_uint8]),
@@ -1163,6 +1167,21 @@ def _ctx_synthesize_linear_hasher(self, messages, queue_state, capacity, trace, 
     return rec, pi
 
 
+def _ctx_synthesize_linear_hasher_batch(self, queues, queue_states, capacity, trace, first_slot=0):
+    """zkw_linear_hasher_synthesize_batch: the L1-messages queues of several blocks in one call (queue b -> slot first_slot + b).
+    Returns (records, public inputs [n, 4])."""
+    qs = [np.ascontiguousarray(q, dtype=LOG_QUERY) for q in queues]
+    off = np.zeros(len(qs) + 1, np.uint64)
+    off[1:] = np.cumsum([q.size for q in qs])
+    flat = np.concatenate(qs) if qs else np.zeros(0, LOG_QUERY)
+    st = np.ascontiguousarray(queue_states, dtype=QUEUE_STATE4).reshape(len(qs))
+    rec = np.zeros(len(qs), LINEAR_HASHER_INSTANCE)
+    pi = np.zeros((len(qs), 4), np.uint64)
+    _check(load().zkw_linear_hasher_synthesize_batch(self.handle, _np_ptr(flat) if flat.size else None, _np_ptr(off), len(qs), _np_ptr(st),
+                                                     capacity, trace.handle, first_slot, _np_ptr(rec), _np_ptr(pi)))
+    return rec, pi
+
+
 SC_COLS = 153  # 116 + 4 x 9 + 1 (include/zkw_sha256_circuit_spec.h)
 
 
@@ -1220,6 +1239,7 @@ def _ctx_check_if_satisfied_linear_hasher(self, trace, slot, capacity):
 Context.check_if_satisfied_linear_hasher = _ctx_check_if_satisfied_linear_hasher
 Context.check_copy_permutation = _ctx_check_copy_permutation
 Context.synthesize_linear_hasher = _ctx_synthesize_linear_hasher
+Context.synthesize_linear_hasher_batch = _ctx_synthesize_linear_hasher_batch
 Context.synthesize_keccak_round_function = _ctx_synthesize_keccak_round_function
 Context.check_if_satisfied_keccak_round_function = _ctx_check_if_satisfied_keccak_round_function
 
@@ -1493,6 +1513,42 @@ class Block:
         for o, h in zip(objs, outs):
             o.handle = C.c_void_p(h)
         return objs
+
+    @staticmethod
+    def run_sharded(device_id, blocks, rank, world, capacities=None):
+        """zkw_blocks_run_sharded: every rank passes the same list of blocks; rank r builds the blocks k with k % world == r.
+        Returns a list with a Block for every owned index and None elsewhere."""
+        lib = load()
+        objs = [Block(device_id, b, capacities, _run=False) for b in blocks]
+        ptrs = (C.c_void_p * len(objs))(*[C.addressof(o._inp) for o in objs])
+        outs = (C.c_void_p * len(objs))()
+        rc = lib.zkw_blocks_run_sharded(device_id, ptrs, len(objs), rank, world, outs)
+        if rc != OK:
+            raise ZkwError(rc, (lib.zkw_block_last_error() or b"").decode() or lib.zkw_last_error().decode())
+        res = []
+        for k, (o, h) in enumerate(zip(objs, outs)):
+            assert (h is not None) == (lib.zkw_blocks_owner(k, world) == rank)
+            if h is None:
+                res.append(None)
+            else:
+                o.handle = C.c_void_p(h)
+                res.append(o)
+        return res
+
+    @staticmethod
+    def gather_sharded(blocks, comm, rank, world, root=0, max_per_block=32):
+        """zkw_blocks_gather_closed_form_inputs (collective): on the root a list, per block, of its records [n, 24] (type,
+        instance, compact form, public input) in emission order; None on the other ranks."""
+        n = len(blocks)
+        handles = (C.c_void_p * max(n, 1))(*[b.handle if b is not None else None for b in blocks])
+        words = 1 + 24 * max_per_block
+        out = np.zeros((n, words), np.uint64)
+        rc = load().zkw_blocks_gather_closed_form_inputs(handles, n, comm.handle, rank, world, root, max_per_block, _np_ptr(out))
+        if rc != OK:
+            raise ZkwError(rc, (load().zkw_block_last_error() or b"").decode() or load().zkw_last_error().decode())
+        if rank != root:
+            return None
+        return [out[k, 1:1 + 24 * int(out[k, 0])].reshape(-1, 24).copy() for k in range(n)]
 
     def num_instances(self, circuit_type):
         return load().zkw_block_num_instances(self.handle, circuit_type)

@@ -93,6 +93,14 @@ def min_over_ranks(value: int, device) -> int:
     return int(t.item())
 
 
+def sum_over_ranks(value: int, device) -> int:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

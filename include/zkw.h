@@ -595,6 +595,13 @@ int zkw_code_decommitter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_
 int zkw_linear_hasher_synthesize(zkw_ctx *ctx, const zkw_log_query *messages, size_t n, const zkw_queue_state4 *queue_state,
                                  uint32_t capacity, zkw_trace *t, size_t slot, zkw_linear_hasher_instance *record_out,
                                  uint64_t *public_input_out);
+/* The same for n_queues independent message queues in ONE call (the L1-messages queues of several blocks): queue b = messages
+   [message_offsets[b], message_offsets[b + 1]) -> slot first_slot + b, records_out[b], public_inputs_out[4 b ..]. The sponge of
+   a queue is serial (one Keccak-f per 136 bytes); a batch runs the queues' sponges side by side and fills all traces with one
+   launch. */
+int zkw_linear_hasher_synthesize_batch(zkw_ctx *ctx, const zkw_log_query *messages, const uint64_t *message_offsets, size_t n_queues,
+                                       const zkw_queue_state4 *queue_states, uint32_t capacity, zkw_trace *t, size_t first_slot,
+                                       zkw_linear_hasher_instance *records_out, uint64_t *public_inputs_out);
 
 /* ---- public inputs and the recursion queue (a20) ---------------------------------------------------- */
 /* commit_variable_length_encodable_item as driven by simulate_public_input_value_from_witness
@@ -846,6 +853,17 @@ int zkw_block_run(int device_id, const zkw_block_inputs *in, zkw_block **out);
    K blocks cost about one block's chain pass while SIMDs and memory last. out[k] receives block k; on failure every block
    is released and out[] is all NULL. */
 int zkw_blocks_run(int device_id, const zkw_block_inputs *const *inputs, size_t n_blocks, zkw_block **out);
+/* The same on one rank of a multi-GPU job, the BLOCKS sharded (the mode that scales: nothing is replicated): rank r builds the
+   blocks k with zkw_blocks_owner(k, world) == r (round-robin) and leaves out[k] = NULL for the others. Every rank passes the same
+   inputs array (pointers of blocks it does not own are only validated). No communication. */
+int zkw_blocks_owner(size_t block, int world);
+int zkw_blocks_run_sharded(int device_id, const zkw_block_inputs *const *inputs, size_t n_blocks, int rank, int world, zkw_block **out);
+/* Collective over `comm` after zkw_blocks_run_sharded: the closed-form records of every block reach `root` in block order —
+   out[n_blocks][1 + 24 * max_per_block] (host, root only): word 0 = the block's instance count n, then n records
+   [circuit_type, instance, compact form (18), public input (4)] in emission order, zero padded — for the recursion-queue
+   replay of each block (postprocessing/mod.rs:396-402). blocks[k] is read only for the blocks this rank owns. */
+int zkw_blocks_gather_closed_form_inputs(zkw_block *const *blocks, size_t n_blocks, zkw_comm *comm, int rank, int world, int root,
+                                         size_t max_per_block, uint64_t *out);
 /* message of the last failed zkw_block_run on this thread (its builders run on worker threads, whose zkw_last_error
    is not the caller's) */
 const char *zkw_block_last_error(void);

@@ -288,3 +288,50 @@ def test_blocks_run_many_at_once(ctx, oracle):
         wit.free()
     for m in many:
         m.free()
+
+
+def test_blocks_run_sharded_and_gather_two_ranks_over_tcp(ctx):
+    """zkw_blocks_run_sharded + zkw_blocks_gather_closed_form_inputs with world = 2 on one GPU: two host threads are the two
+    ranks (the socket transport of zkw_comm between them), each builds only its round-robin share of five blocks, and the root
+    receives every block's records in block order — equal to what each block gives alone."""
+    import socket
+    import threading
+
+    from era_zkevm_test_harness_amd import block as blk, native as nv
+
+    caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
+    bs = [synthetic.block_after_vm(seed=50 + k, n_vm_memory=1200 + 500 * k, n_storage=40 + 25 * k) for k in range(5)]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    res, err = {}, []
+
+    def rank_main(rank):
+        try:
+            c = nv.Context(0)
+            comm = nv.Comm.tcp(c, "127.0.0.1", port, rank, 2)
+            mine = nv.Block.run_sharded(0, bs, rank, 2, caps)
+            assert [m is not None for m in mine] == [k % 2 == rank for k in range(5)]
+            res[rank] = nv.Block.gather_sharded(mine, comm, rank, 2, root=1, max_per_block=256)
+            comm.destroy()
+            for m in mine:
+                if m is not None:
+                    m.free()
+            c.close()
+        except Exception as e:  # noqa: BLE001 — reported by the main thread
+            err.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not err, err
+    assert res[0] is None and len(res[1]) == 5
+    comm1 = nv.Comm(ctx, 0, 1)
+    for b, got in zip(bs, res[1]):
+        one = nv.Block(0, b, caps)
+        assert np.array_equal(got, one.gather_closed_form_inputs(comm1))
+        one.free()
+    comm1.destroy()

@@ -98,6 +98,26 @@ def test_linear_hasher_matches_oracle(ctx, oracle):
         t.free()
 
 
+def test_linear_hasher_batch_equals_single_calls(ctx, oracle):
+    """zkw_linear_hasher_synthesize_batch: ragged queues (incl. an empty one and a full one) in one call == the oracle per queue"""
+    from era_zkevm_test_harness_amd import native
+
+    cap, sizes = 20, (7, 0, 20, 1, 13)
+    queues = [synthetic.random_log_queries(max(n, 1), seed=40 + k)[:n] for k, n in enumerate(sizes)]
+    states = np.zeros(len(sizes), native.QUEUE_STATE4)
+    states["length"] = np.arange(len(sizes))  # distinguishable records
+    t = native.Trace(ctx, N_ROWS, len(sizes) + 1, n_cols=native.LH_COLS)
+    rec, pi = ctx.synthesize_linear_hasher_batch(queues, states, cap, t, 1)
+    for k, q in enumerate(queues):
+        exp, orec, opi = oracle.linear_hasher_synthesize(q, states[k:k + 1], cap, N_ROWS)
+        assert np.array_equal(t.get(1 + k), exp), k
+        assert rec[k:k + 1].tobytes() == orec.tobytes() and np.array_equal(pi[k], opi)
+        assert ctx.check_if_satisfied_linear_hasher(t, 1 + k, cap) == (0, (0, 0, 0))
+    with pytest.raises(native.ZkwError):
+        ctx.synthesize_linear_hasher_batch(queues, states, cap, t, 2)  # one slot short
+    t.free()
+
+
 def test_dummy_instances_of_empty_queues(ctx, oracle):
     """no request at all: one instance of idle cycles, satisfied, equal to the oracle's"""
     from era_zkevm_test_harness_amd import native

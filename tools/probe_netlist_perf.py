@@ -28,3 +28,10 @@ ctx.synthesize_linear_hasher(q, np.zeros(1, native.QUEUE_STATE4), 774, t, 0); ct
 ctx.profile_enable(True); ctx.profile_reset()
 t0 = time.perf_counter(); ctx.synthesize_linear_hasher(q, np.zeros(1, native.QUEUE_STATE4), 774, t, 0); ctx.synchronize(); dt = time.perf_counter() - t0
 print("linear hasher", f"{dt*1e3:.2f} ms", {k: round(v[0], 3) for k, v in ctx.profile().items()})
+queues = [synthetic.mixed_log_queue(4000, seed=3 + k)[:700] for k in range(8)]
+t8 = native.Trace(ctx, n_rows, 8, n_cols=native.LH_COLS)
+st = np.zeros(8, native.QUEUE_STATE4)
+ctx.synthesize_linear_hasher_batch(queues, st, 774, t8, 0); ctx.synchronize()
+ctx.profile_reset()
+t0 = time.perf_counter(); ctx.synthesize_linear_hasher_batch(queues, st, 774, t8, 0); ctx.synchronize(); dt = time.perf_counter() - t0
+print("linear hasher, 8 queues per call", f"{dt*1e3:.2f} ms = {8/dt:.0f} circuits/s", {k: round(v[0], 3) for k, v in ctx.profile().items()})

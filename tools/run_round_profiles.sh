@@ -40,30 +40,26 @@ for P in ds es ld ss; do
     echo "== tools/probe_${P}_synth.py" >> "$OUT/synthesis_probes.txt"
     timeout -s KILL 300 python tools/probe_${P}_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
 done
-echo "== tools/probe_kc_synth.py (Keccak256RoundFunction, 2^20 rows, capacity 293)" >> "$OUT/synthesis_probes.txt"
-timeout -s KILL 300 python tools/probe_kc_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
-echo "== tools/probe_sc_synth.py (Sha256RoundFunction, 2^20 rows, capacity 2206)" >> "$OUT/synthesis_probes.txt"
-timeout -s KILL 300 python tools/probe_sc_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
-for P in kc sc; do
-    rm -rf /tmp/pk_$P && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk_$P -- python tools/probe_${P}_synth.py > /dev/null 2>&1
-    cp "$(ls /tmp/pk_$P/*/*kernel_stats.csv | head -1)" "$OUT/netlist_${P}_kernel_stats.csv"
-done
-# 5b. HBM counters of the netlist probes (separate passes per counter): bytes per dispatch of 8 instances
+echo "== tools/probe_netlist_perf.py (Keccak256RoundFunction 293 / Sha256RoundFunction 2206 cycles, 2^20 rows, 8 instances; L1MessagesHasher)" >> "$OUT/synthesis_probes.txt"
+timeout -s KILL 300 python tools/probe_netlist_perf.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
+rm -rf /tmp/pk_nl && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk_nl -- python tools/probe_netlist_perf.py > /dev/null 2>&1
+cp "$(ls /tmp/pk_nl/*/*kernel_stats.csv | head -1)" "$OUT/netlist_kernel_stats.csv"
+# 5b. HBM counters of the netlist probe (separate passes per counter): bytes per dispatch of 8 instances
 : > "$OUT/netlist_pmc.txt"
-for P in sc kc; do for C in WRITE_SIZE FETCH_SIZE; do
-    rm -rf /tmp/pn && timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pn -- python tools/probe_${P}_synth.py > /dev/null 2>&1
-    python3 - "$(ls /tmp/pn/*/*counter_collection.csv | head -1)" $P $C >> "$OUT/netlist_pmc.txt" <<'PY'
+for C in WRITE_SIZE FETCH_SIZE; do
+    rm -rf /tmp/pn && timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pn -- python tools/probe_netlist_perf.py > /dev/null 2>&1
+    python3 - "$(ls /tmp/pn/*/*counter_collection.csv | head -1)" $C >> "$OUT/netlist_pmc.txt" <<'PY'
 import collections, csv, sys
 tot, disp = collections.defaultdict(float), collections.defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")
     tot[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
 # the counters are in KiB; FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section: the same corrections as traffic.json)
-scale = 1024 * (2 if sys.argv[3] == "FETCH_SIZE" else 1)
-for k in sorted(tot, key=lambda k: -tot[k])[:5]:
-    print(f"{sys.argv[2]} {sys.argv[3]}{' x2' if scale > 1024 else ''} {k} {len(disp[k])} dispatches {tot[k] / len(disp[k]) * scale / 1e9:.3g} GB per dispatch")
+scale = 1024 * (2 if sys.argv[2] == "FETCH_SIZE" else 1)
+for k in sorted(tot, key=lambda k: -tot[k])[:8]:
+    print(f"{sys.argv[2]}{' x2' if scale > 1024 else ''} {k} {len(disp[k])} dispatches {tot[k] / len(disp[k]) * scale / 1e9:.3g} GB per dispatch")
 PY
-done; done
+done
 # 6. the hardware probes behind DESIGN.md 3.2
 (cd tools && for b in probe_wave_placement probe_clock_regime ubench_perm; do [ -x ./$b ] && { echo "== $b"; timeout -s KILL 300 ./$b; }; done) > "$OUT/hardware_probes.txt" 2>&1
 (cd tools && for b in probe_hw_queues2; do [ -x ./$b ] && { echo "== $b (default environment)"; timeout -s KILL 120 ./$b; echo "== $b (GPU_MAX_HW_QUEUES=8)"; GPU_MAX_HW_QUEUES=8 timeout -s KILL 120 ./$b; }; done) > "$OUT/hw_queue_probes.txt" 2>&1
