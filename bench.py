@@ -323,6 +323,11 @@ def main():
         full_block, blk_inputs = full_block_gpu(local_rank, rank=rank, world=world, comm=comm)
         native.trim_caches()  # the batch below is sized by the free HBM
         torch.cuda.empty_cache()
+    if os.environ.get("ZKW_HASH_CIRCUITS_FIRST") and blk_inputs is not None:
+        # experiment: the hash-circuit leg BEFORE the timed region, to see what it leaves behind
+        hash_circuits = hash_circuits_gpu(local_rank, blk_inputs)
+        native.trim_caches()
+        torch.cuda.empty_cache()
     if B <= 0:
         free, _total = torch.cuda.mem_get_info(dev)
         # resident per query: input 48 + sorting permutation 4 + capacity words of the tails 2 x 32 = 116 bytes (no
@@ -581,7 +586,9 @@ def main():
         }
         if full_block is not None:
             out["full_block"] = full_block
-            if not args.no_hash_circuits:
+            if hash_circuits is not None:
+                out["hash_circuits"] = hash_circuits
+            elif not args.no_hash_circuits:
                 # AFTER the timed region and with the batch released: run before it, this leg costs the throughput leg 11 %
                 # (1604 against 1800 circuits/s, four runs each; what it leaves behind is not understood)
                 for w_ in ws:

@@ -114,7 +114,7 @@ struct NlLds {
         level = take(s.n_level_starts * 2);
         out = take(s.n_step_types * s.state * 2);
         waves = take(NL_FILL_WAVES * vsize);
-        total = at;
+        total = at + 16;  // (gate operands are read 8 bytes at a time: the last wave's last cells have something behind them)
     }
 };
 
@@ -135,13 +135,21 @@ __device__ __forceinline__ void nl_eval_sel(u32 fn, u32 k, u32 a0, u32 a1, u32 a
     o2 = fn == NL_FN_SPLIT4 ? ((lo << (4 - k)) | hi) : 0;
 }
 
-template <int W, int R>
-__global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
+// CPW = cycles per wave: 1 (a wave owns a cycle: 8 waves per workgroup) or 2 (each half of a wave owns a cycle: 4 waves per
+// workgroup, the same 8 cycles in LDS). A level of the SHA-256 netlist holds 15 items on average — three quarters of a wave's
+// lanes idle through the walk — so two cycles per wave halve the instructions the walk issues. Measured: SHA-256 3.35 ms per 8
+// instances with CPW = 1, 4.19 ms with CPW = 2 — the walk is bound by the latency of its dependent LDS reads, which two waves
+// per SIMD hide from each other and one wave per SIMD does not. Every circuit runs CPW = 1; 2 stays selectable.
+template <int W, int R, int CPW>
+__global__ __launch_bounds__(NL_FILL_THREADS / CPW) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int NL_FILL_THREADS_ = NL_FILL_THREADS / CPW;  // threads of this instantiation
+    constexpr u32 LW = 64 / CPW;                             // lanes that share a cycle
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
     const NlJob job = jobs[blockIdx.y];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, wv = t >> 6;
+    const u32 lane = (u32)(t & 63) % LW, sub = (u32)(t & 63) / LW;
     const NlV V(S);
     const NlLds L(S, V.size, D.n_pk_terms);
     nl_table* const s_tab = reinterpret_cast<nl_table*>(lds + L.tab);
@@ -157,18 +165,18 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
     uint16_t* const s_order = reinterpret_cast<uint16_t*>(lds + L.order);
     uint16_t* const s_level = reinterpret_cast<uint16_t*>(lds + L.level);
     uint16_t* const s_out = reinterpret_cast<uint16_t*>(lds + L.out);
-    uint8_t* const val = lds + L.waves + wv * V.size;
+    uint8_t* const val = lds + L.waves + (wv * CPW + sub) * V.size;
     // ---- stage the netlists (references made dense: one LDS read resolves any of them)
-    for (u32 i = t; i < S.n_tables; i += NL_FILL_THREADS) s_tab[i] = S.tables[i];
-    for (u32 i = t; i < S.n_step_types; i += NL_FILL_THREADS) s_types[i] = S.step_types[i];
-    for (u32 i = t; i < S.steps_per_cycle; i += NL_FILL_THREADS) s_cyc[i] = S.cycle[i];
-    for (u32 i = t; i < S.n_ops; i += NL_FILL_THREADS) {
+    for (u32 i = t; i < S.n_tables; i += NL_FILL_THREADS_) s_tab[i] = S.tables[i];
+    for (u32 i = t; i < S.n_step_types; i += NL_FILL_THREADS_) s_types[i] = S.step_types[i];
+    for (u32 i = t; i < S.steps_per_cycle; i += NL_FILL_THREADS_) s_cyc[i] = S.cycle[i];
+    for (u32 i = t; i < S.n_ops; i += NL_FILL_THREADS_) {
         const nl_op op = S.ops[i];
         s_op_table[i] = (uint8_t)op.table;
         for (int k = 0; k < 3; k++) s_op_in[k * S.n_ops + i] = V.dense(op.in[k]);
         s_op_out[i] = op.out;
     }
-    for (u32 i = t; i < S.n_gates; i += NL_FILL_THREADS) {
+    for (u32 i = t; i < S.n_gates; i += NL_FILL_THREADS_) {
         const nl_gate g = S.gates[i];
         u32 ty = 0;
         while (ty + 1 < S.n_step_types && S.step_types[ty + 1].gate0 <= i) ty++;
@@ -182,17 +190,17 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
         lg._pad[0] = lg._pad[1] = lg._pad[2] = 0;
         s_gates[i] = lg;
     }
-    for (u32 i = t; i < D.n_pk_terms; i += NL_FILL_THREADS) s_pk[i] = D.pk_terms[i];
-    for (u32 i = t; i < S.n_gates + S.n_step_types; i += NL_FILL_THREADS) s_pk_first[i] = D.pk_first[i];
-    for (u32 i = t; i < S.n_hints; i += NL_FILL_THREADS) {
+    for (u32 i = t; i < D.n_pk_terms; i += NL_FILL_THREADS_) s_pk[i] = D.pk_terms[i];
+    for (u32 i = t; i < S.n_gates + S.n_step_types; i += NL_FILL_THREADS_) s_pk_first[i] = D.pk_first[i];
+    for (u32 i = t; i < S.n_hints; i += NL_FILL_THREADS_) {
         nl_hint h = S.hints[i];
         h.ref_a = V.dense(h.ref_a); h.ref_b = V.dense(h.ref_b);
         s_hints[i] = h;
     }
-    for (u32 i = t; i < S.n_order; i += NL_FILL_THREADS) s_order[i] = S.order[i];
-    for (u32 i = t; i < S.n_level_starts; i += NL_FILL_THREADS) s_level[i] = S.level_start[i];
-    for (u32 i = t; i < S.n_step_types * S.state; i += NL_FILL_THREADS) s_out[i] = V.dense(S.out[i]);
-    for (u32 i = t; i < NL_FILL_WAVES * 256; i += NL_FILL_THREADS) lds[L.waves + (i >> 8) * V.size + V.con + (i & 255)] = (uint8_t)i;
+    for (u32 i = t; i < S.n_order; i += NL_FILL_THREADS_) s_order[i] = S.order[i];
+    for (u32 i = t; i < S.n_level_starts; i += NL_FILL_THREADS_) s_level[i] = S.level_start[i];
+    for (u32 i = t; i < S.n_step_types * S.state; i += NL_FILL_THREADS_) s_out[i] = V.dense(S.out[i]);
+    for (u32 i = t; i < NL_FILL_WAVES * 256; i += NL_FILL_THREADS_) lds[L.waves + (i >> 8) * V.size + V.con + (i & 255)] = (uint8_t)i;
     __syncthreads();  // the only workgroup barrier: from here on every wave is on its own
     // everything the cycle loop needs from the spec, in registers: the trace stores below go through a pointer the compiler cannot
     // prove distinct from *devp, so every `S.field` inside the loops would be re-read from global memory after each store
@@ -203,15 +211,17 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
     const u32* const g_key0 = D.step_key0;
     const u32* const g_pk0 = D.pk0;
     const u32 keys_per_cycle = D.keys_per_cycle;
-    for (u32 c = blockIdx.x * NL_FILL_WAVES + wv; c < capacity; c += gridDim.x * NL_FILL_WAVES) {
+    for (u32 c0 = (blockIdx.x * (NL_FILL_WAVES / CPW) + wv) * CPW; c0 < capacity; c0 += gridDim.x * NL_FILL_WAVES) {
         NL_WAVE_SYNC();  // the previous cycle's write phase has read everything it needs
+        const bool live = c0 + sub < capacity;         // (the last pair of a trace may have one cycle only: its half walks along, stores nothing)
+        const u32 c = live ? c0 + sub : c0;
         const u32 bits = job.hdr_bits[c], reset = bits & 1, idle = (bits >> 1) & 1;
         if (lane == 0) {
             val[V.hdr + 0] = (uint8_t)reset; val[V.hdr + 1] = (uint8_t)idle;
             val[V.hdr + 2] = (uint8_t)(m0a + m0b * (int)reset);
             val[V.hdr + 3] = (uint8_t)(m1a + m1b * (int)idle);
         }
-        for (u32 k = lane; k < STATE; k += 64) {
+        for (u32 k = lane; k < STATE; k += LW) {
             const uint8_t x = job.state_before[(size_t)c * STATE + k];
             val[V.cyc + k] = x;
             val[V.prev + k] = x;
@@ -221,7 +231,8 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
             const u32 type = s_cyc[s].type, row0 = s_cyc[s].row0;
             const nl_step_type T = s_types[type];
             const size_t base = (size_t)c * RPC + row0;
-            for (u32 k = lane; k < T.n_free; k += 64) val[V.fre + k] = job.free_elems[(size_t)c * FPC + free_at + k];
+            const u32 pk0_t = g_pk0[type];  // (a global read: once per step, not once per gate)
+            for (u32 k = lane; k < T.n_free; k += LW) val[V.fre + k] = job.free_elems[(size_t)c * FPC + free_at + k];
             if (lane < 8) val[V.rc + lane] = s_cyc[s].rc[lane];  // (indexing a register copy by lane would put it in scratch memory)
             free_at += T.n_free;
             NL_WAVE_SYNC();
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
             u32 lv0 = lvl[0];
             for (u32 l = 0; l < ((probe & 1) ? 0u : T.n_levels); l++) {  // probe bit 0: skip the level walk (measurement only)
                 const u32 lv1 = lvl[l + 1];
-                for (u32 e = lv0 + lane; e < lv1; e += 64) {
+                for (u32 e = lv0 + lane; e < lv1; e += LW) {
                     const u32 it = s_order[T.order0 + e];
                     if (it < NL_ORDER_GATE) {
                         const u32 j = T.op0 + it;
@@ -246,23 +257,55 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
                         const u32 gi = T.gate0 + (it - NL_ORDER_GATE);
                         const NlLdsGate g = s_gates[gi];
                         const uint16_t* const pf = s_pk_first + gi + type;  // (one extra entry per step type closes its last gate)
-                        const u32 p0 = g_pk0[type] + pf[0], p1 = g_pk0[type] + pf[1];
+                        const u32 p0 = pk0_t + pf[0], p1 = pk0_t + pf[1];
                         long long sum = g.constant;
-                        // the known cells, run-length packed: a word operand (8 nibbles) is one entry and eight independent byte reads
-                        // (four entries at a time with all reads issued up front was slower: 5.2 against 4.5 ms per 8 SHA-256 instances)
+                        // the known cells, run-length packed: a word operand (8 nibbles) is one entry
                         for (u32 p = p0; p < p1; p++) {
                             const u32 w = s_pk[p], ref = w & 0xFFFF, cnt = (w >> 16) & 15, code = (w >> 20) & 0xFF, step = w >> 28;
-                            u64 part = 0;
-#pragma unroll
-                            for (int k = 0; k < 8; k++)
-                                if ((u32)k <= cnt) part |= (u64)val[ref + k] << (k * step);  // cells of a run are < 2^step (or the run is one cell)
+                            // the run's cells in ONE 8-byte LDS read (any alignment), then packed: nibble runs (step 4) by three
+                            // shift-or-mask stages, byte runs as they are (cells of a run are < 2^step, or the run is one cell)
+                            u64 raw;
+                            __builtin_memcpy(&raw, val + ref, 8);
+                            raw = cnt >= 7 ? raw : raw & ((1ull << (8 * (cnt + 1))) - 1);
+                            u64 x4 = (raw | (raw >> 4)) & 0x00FF00FF00FF00FFull;
+                            x4 = (x4 | (x4 >> 8)) & 0x0000FFFF0000FFFFull;
+                            x4 = (x4 | (x4 >> 16)) & 0xFFFFFFFFull;
+                            u64 part = step == 4 ? x4 : raw;
+                            if (step != 4 && step != 8 && cnt != 0) {  // (no circuit has such runs today)
+                                part = 0;
+                                for (u32 k = 0; k <= cnt; k++) part |= ((raw >> (8 * k)) & 0xFF) << (k * step);
+                            }
                             const long long v = (long long)(part << (code & 0x7F));
                             sum += (code & 0x80) ? -v : v;
                         }
-                        for (u32 i = 0; i < g.n_new; i++) {
-                            u64 x = (u64)sum >> (g.new_sh0 + i * g.new_step);
-                            if (i + 1 < g.n_new) x &= (1ull << g.new_step) - 1;
-                            val[g.new_ref + i] = (uint8_t)x;
+                        if (g.new_step == 4 && g.n_new >= 7 && g.n_new <= 9) {
+                            // the NEW cells of a word: 7 - 9 consecutive values, nibble digits and a last digit that takes what is left
+                            const u64 v = (u64)sum >> g.new_sh0;
+                            u64 x = v & 0xFFFFFFFFull;
+                            x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+                            x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+                            x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+                            const u32 last = (u32)(uint8_t)(v >> (4 * (g.n_new - 1)));
+                            if (g.n_new == 9) {
+                                __builtin_memcpy(val + g.new_ref, &x, 8);
+                                val[g.new_ref + 8] = (uint8_t)last;
+                            } else if (g.n_new == 8) {
+                                x = (x & 0x00FFFFFFFFFFFFFFull) | ((u64)last << 56);
+                                __builtin_memcpy(val + g.new_ref, &x, 8);
+                            } else {
+                                x = (x & 0x0000FFFFFFFFFFFFull) | ((u64)last << 48);
+                                const u32 lo = (u32)x;
+                                const uint16_t mid = (uint16_t)(x >> 32);
+                                __builtin_memcpy(val + g.new_ref, &lo, 4);
+                                __builtin_memcpy(val + g.new_ref + 4, &mid, 2);
+                                val[g.new_ref + 6] = (uint8_t)(x >> 48);
+                            }
+                        } else {
+                            for (u32 i = 0; i < g.n_new; i++) {
+                                u64 x = (u64)sum >> (g.new_sh0 + i * g.new_step);
+                                if (i + 1 < g.n_new) x &= (1ull << g.new_step) - 1;
+                                val[g.new_ref + i] = (uint8_t)x;
+                            }
                         }
                     } else {
                         const nl_hint h = s_hints[T.hint0 + (it - NL_ORDER_HINT)];
@@ -276,7 +319,7 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
             // ---- stream the step's rows out, lane <-> row: every general-purpose and lookup cell
             const uint16_t* const cmap = g_cellmap + g_cell0[type];
             uint16_t* const keys = job.keys + (size_t)c * keys_per_cycle + g_key0[s];
-            for (u32 r = lane; r < ((probe & 2) ? 0u : T.rows); r += 64) {  // probe bit 1: skip the streaming (measurement only)
+            for (u32 r = lane; r < ((probe & 2) || !live ? 0u : T.rows); r += LW) {  // probe bit 1: skip the streaming (measurement only)
                 const size_t row = base + r;
                 if (r <= T.gate_rows && !(probe & 4)) {  // rows below the gate rows hold no general-purpose cell: zero already (nl_synthesize)
                     // the cell map is read in batches of independent loads
@@ -317,16 +360,13 @@ __global__ __launch_bounds__(NL_FILL_THREADS) void k_nl_fill(const NlDev* __rest
             }
             // the state this step leaves becomes the next step's PREV bank (through registers: the banks overlap in time)
             const uint16_t* const so = s_out + type * STATE;
-            uint8_t nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0;  // state <= 256 elements: four per lane
-            if (lane < STATE) nx0 = val[so[lane]];
-            if (lane + 64 < STATE) nx1 = val[so[lane + 64]];
-            if (lane + 128 < STATE) nx2 = val[so[lane + 128]];
-            if (lane + 192 < STATE) nx3 = val[so[lane + 192]];
+            uint8_t nx[256 / LW];  // state <= 256 elements (constant indices after unrolling: registers)
+#pragma unroll
+            for (u32 k = 0; k < 256 / LW; k++) nx[k] = lane + k * LW < STATE ? val[so[lane + k * LW]] : (uint8_t)0;
             NL_WAVE_SYNC();
-            if (lane < STATE) val[V.prev + lane] = nx0;
-            if (lane + 64 < STATE) val[V.prev + lane + 64] = nx1;
-            if (lane + 128 < STATE) val[V.prev + lane + 128] = nx2;
-            if (lane + 192 < STATE) val[V.prev + lane + 192] = nx3;
+#pragma unroll
+            for (u32 k = 0; k < 256 / LW; k++)
+                if (lane + k * LW < STATE) val[V.prev + lane + k * LW] = nx[k];
         }
     }
 }
@@ -366,15 +406,40 @@ __global__ __launch_bounds__(NL_HIST_THREADS) void k_nl_hist(const NlDev* __rest
     __syncthreads();
     const u32 per_cycle = s_run_first[n_runs], keys_per_cycle = D.keys_per_cycle;
     const u32 ncyc = capacity > split ? (capacity - split + n_splits - 1) / n_splits : 0;
-    const u64 total = (u64)ncyc * per_cycle;
-    for (u64 i = t; i < total; i += NL_HIST_THREADS) {
-        const u32 ci = (u32)(i / per_cycle), k = (u32)(i - (u64)ci * per_cycle);
-        u32 e = 0;
-        while (s_run_first[e + 1] <= k) e++;
-        const NlHistEntry he = s_run[e];
-        const u32 q = k - s_run_first[e], nr = he.r1 - he.r0, sl = q / nr, r = he.r0 + (q - sl * nr);
-        const u32 key = job.keys[(size_t)(split + ci * n_splits) * keys_per_cycle + he.key0 + (size_t)sl * he.lookup_rows + r];
-        if (key / NL_HIST_HALF == half) atomicAdd(&s_bins[key % NL_HIST_HALF], 1u);
+    // flat item index over the workgroup's cycles -> (cycle, run, slot, row) without a hardware division: cycle and slot are
+    // multiplications by reciprocals, the runs' first items are cached and a thread's run pointer only advances within a cycle.
+    // The first version decomposed a 64-bit index with two divisions (~300 instructions per key: the kernel was bound by them,
+    // not by the LDS atomics); four independent 2-byte loads are in flight before their counts.
+    __shared__ u32 s_run_inv[MAX_RUNS];
+    if (t < n_runs) s_run_inv[t] = (u32)(0xFFFFFFFFull / (s_run[t].r1 - s_run[t].r0)) + 1;  // ceil(2^32 / rows of the run) (1 row: wraps to 0, handled below)
+    __syncthreads();
+    const uint16_t* const keys = job.keys;
+    const u32 total = ncyc * per_cycle;  // < 2^32: at most 2^20 rows x 26 lookups
+    const u32 inv_pc = per_cycle > 1 ? (u32)(0xFFFFFFFFull / per_cycle) + 1 : 0;
+    u32 e = 0, k_prev = 0;
+    for (u32 i0 = t; i0 < total; i0 += 4 * NL_HIST_THREADS) {
+        u32 key[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const u32 i = i0 + b * NL_HIST_THREADS;
+            key[b] = 0xFFFFFFFFu;
+            if (i < total) {
+                u32 ci = per_cycle > 1 ? (u32)(((u64)i * inv_pc) >> 32) : i;
+                if (ci * per_cycle > i) ci--;              // (a reciprocal rounded up gives at most one too many)
+                const u32 k = i - ci * per_cycle;
+                if (k < k_prev) e = 0;
+                k_prev = k;
+                while (s_run_first[e + 1] <= k) e++;
+                const NlHistEntry he = s_run[e];
+                const u32 q = k - s_run_first[e], nr = he.r1 - he.r0;
+                u32 sl = nr == 1 ? q : (u32)(((u64)q * s_run_inv[e]) >> 32);
+                if (sl * nr > q) sl--;
+                key[b] = keys[(size_t)(split + ci * n_splits) * keys_per_cycle + he.key0 + (size_t)sl * he.lookup_rows + he.r0 + (q - sl * nr)];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (key[b] != 0xFFFFFFFFu && key[b] / NL_HIST_HALF == half) atomicAdd(&s_bins[key[b] % NL_HIST_HALF], 1u);
     }
     __syncthreads();
     u32* const out = job.hist + ((size_t)blockIdx.x * 2 + half) * NL_HIST_HALF;

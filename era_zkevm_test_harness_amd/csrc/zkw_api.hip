@@ -3837,18 +3837,18 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
     return ZKW_OK;
 }
 
-struct NlInstance { u64 first_round; u32 n_active; const u64* public_input; const zkw_trace* t; size_t slot; };
+struct NlInstance { u64 first_round; u32 n_active; const u64* public_input; const zkw_trace* t; size_t slot; bool fresh = false; /* the hash state before the instance is zero, not what round first_round - 1 left (independent queues in one call) */ };
 
-template <int W, int R>
+template <int W, int R, int CPW>
 int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
     static bool attr_set[16] = {};
     if (!attr_set[ctx->device & 15]) {  // more than the default 64 KB of dynamic LDS
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ctx->device & 15] = true;
     }
     static const u32 probe = [] { const char* e = getenv("ZKW_NL_PROBE"); return e ? (u32)atoi(e) : 0u; }();  // measurement only: 1 = no level walk, 2 = no streaming
     const unsigned blocks = std::min<unsigned>((capacity + NL_FILL_WAVES - 1) / NL_FILL_WAVES, std::max<unsigned>(1, 256 / nj));
-    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R>), dim3(blocks, nj), dim3(NL_FILL_THREADS), nc->host.lds_bytes, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
+    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R, CPW>), dim3(blocks, nj), dim3(NL_FILL_THREADS / CPW), nc->host.lds_bytes, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
     ZKW_TRY(launch_check("k_nl_fill"));
     { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
     return launch_check("k_nl_hist");
@@ -3879,7 +3879,9 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
     std::vector<NlJob> jobs(ni);
     const size_t bnd = NL_BOUNDARY_ROW(&S, capacity);
     for (size_t k = 0; k < ni; k++) {
-        prep[k] = NlPrepJob{d_rounds, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n};
+        const size_t rec_bytes = sha_like ? sizeof(zkw_sha256_round_record) : sizeof(zkw_keccak_round_record);
+        prep[k] = inst[k].fresh ? NlPrepJob{static_cast<const char*>(d_rounds) + inst[k].first_round * rec_bytes, 0, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n}
+                                : NlPrepJob{d_rounds, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n};
         // The fill writes the lookup cells of every row above the boundary and the general-purpose cells of the header / gate rows;
         // everything else is zero. A slot whose previous tenant was the same layout (circuit, capacity, rows) already has those
         // zeros: nothing to clear (the multiplicity column is rewritten over the tables' rows). Otherwise: clear it.
@@ -3903,10 +3905,10 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
     else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
     ZKW_TRY(launch_check("k_nl_prepare"));
     switch (circuit_type) {
-        case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R, 1>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R, 1>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R, 1>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R, 1>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
     }
     { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
     return launch_check("k_nl_finish");
@@ -4102,7 +4104,7 @@ extern "C" int zkw_linear_hasher_synthesize_batch(zkw_ctx* ctx, const zkw_log_qu
     { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n_queues, 64)), dim3(64), 0, ctx->stream, d_cf, n_queues, (u32)COMPACT_FORM_LEN, d_pi); }
     ZKW_TRY(launch_check("k_commit_encodings"));
     std::vector<NlInstance> inst(n_queues);
-    for (size_t b = 0; b < n_queues; b++) inst[b] = NlInstance{roff[b], (u32)(roff[b + 1] - roff[b]), d_pi + 4 * b, t, first_slot + b};
+    for (size_t b = 0; b < n_queues; b++) inst[b] = NlInstance{roff[b], (u32)(roff[b + 1] - roff[b]), d_pi + 4 * b, t, first_slot + b, true};
     ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows));
     memcpy(records_out, recv.data(), n_queues * sizeof recv[0]);
     if (public_inputs_out) ZKW_TRY(ctx->read_small(public_inputs_out, d_pi, 32 * n_queues));
