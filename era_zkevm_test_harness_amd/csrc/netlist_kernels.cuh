@@ -92,7 +92,7 @@ struct NlV {
     }
 };
 
-struct NlLdsGate { u32 constant; uint16_t new_ref; uint8_t n_new, new_sh0, new_step, _pad[3]; };  // NEW cells: consecutive values at shifts sh0 + i * step
+struct NlLdsGate { u32 constant; uint16_t new_ref; uint8_t n_new, new_sh0, new_step, mask_last, _pad[2]; };  // NEW cells: consecutive values at shifts sh0 + i * step; mask_last: the gate has late cells, its last NEW cell is a digit like the others
 // LDS carve of k_nl_fill, the same arithmetic on the host (lds_bytes) and in the kernel
 struct NlLds {
     u32 tab, types, cyc, op_table, op_in, op_out, gates, term_ref, term_code, pk, pk_first, hints, order, level, out, waves, total;
@@ -187,7 +187,9 @@ __global__ __launch_bounds__(NL_FILL_THREADS / CPW) void k_nl_fill(const NlDev* 
         lg.new_ref = g.n_new ? V.dense(tm[0].ref) : 0;
         lg.new_sh0 = g.n_new ? (uint8_t)(tm[0].code & 0x7F) : 0;
         lg.new_step = g.n_new > 1 ? (uint8_t)((tm[1].code & 0x7F) - (tm[0].code & 0x7F)) : 0;  // (nl_get checked that the NEW cells are evenly spaced)
-        lg._pad[0] = lg._pad[1] = lg._pad[2] = 0;
+        lg.mask_last = 0;
+        for (u32 k = 0; k < g.n_known; k++) lg.mask_last |= (tm[(int)k - (int)g.n_known].code & NL_TERM_LATE) ? 1 : 0;
+        lg._pad[0] = lg._pad[1] = 0;
         s_gates[i] = lg;
     }
     for (u32 i = t; i < D.n_pk_terms; i += NL_FILL_THREADS_) s_pk[i] = D.pk_terms[i];
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(NL_FILL_THREADS / CPW) void k_nl_fill(const NlDev* 
                             x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
                             x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
                             x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-                            const u32 last = (u32)(uint8_t)(v >> (4 * (g.n_new - 1)));
+                            const u32 last = (u32)(uint8_t)(v >> (4 * (g.n_new - 1))) & (g.mask_last ? 15u : 255u);
                             if (g.n_new == 9) {
                                 __builtin_memcpy(val + g.new_ref, &x, 8);
                                 val[g.new_ref + 8] = (uint8_t)last;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(NL_FILL_THREADS / CPW) void k_nl_fill(const NlDev* 
                         } else {
                             for (u32 i = 0; i < g.n_new; i++) {
                                 u64 x = (u64)sum >> (g.new_sh0 + i * g.new_step);
-                                if (i + 1 < g.n_new) x &= (1ull << g.new_step) - 1;
+                                if (i + 1 < g.n_new || g.mask_last) x &= (1ull << g.new_step) - 1;
                                 val[g.new_ref + i] = (uint8_t)x;
                             }
                         }

@@ -3804,9 +3804,10 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
                     return fail(ZKW_ERR_INVALID, "netlist circuit %d: the NEW cells of gate %u are not consecutive values at evenly spaced shifts", circuit_type, gi);
             }
             for (u32 i = 0; i < gt.n_known;) {
-                const u32 ref = V.dense(tm[i].ref), code = tm[i].code;
+                if (tm[i].code & NL_TERM_LATE) { i++; continue; }  // in the constraint, not in the fill's evaluation
+                const u32 ref = V.dense(tm[i].ref), code = tm[i].code & 0xFF;
                 u32 cnt = 1, step = 0;
-                if (i + 1 < gt.n_known && V.dense(tm[i + 1].ref) == ref + 1 && (tm[i + 1].code & 0x80) == (code & 0x80) && (tm[i + 1].code & 0x7F) > (code & 0x7F)) {
+                if (i + 1 < gt.n_known && !(tm[i + 1].code & NL_TERM_LATE) && V.dense(tm[i + 1].ref) == ref + 1 && (tm[i + 1].code & 0x80) == (code & 0x80) && (tm[i + 1].code & 0x7F) > (code & 0x7F)) {
                     step = (tm[i + 1].code & 0x7F) - (code & 0x7F);
                     const bool nibble_run = hs->w == 4 && step == 4, byte_run = hs->w == 3 && step == 8;  // values < 2^step
                     if (nibble_run || byte_run)

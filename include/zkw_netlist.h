@@ -35,7 +35,8 @@ enum { NL_FN_XOR8 = 1, NL_FN_AND8 = 2, NL_FN_BYTESPLIT = 3, NL_FN_TRIXOR4 = 4, N
 typedef struct nl_table { uint8_t fn, param, n_in, in_bits, n_out; uint32_t rows, offset; } nl_table;
 typedef struct nl_op { uint16_t table, in[3], out; } nl_op;
 typedef struct nl_gate { uint32_t first_term; uint16_t n_known, n_new; uint32_t constant; uint16_t row, col; } nl_gate;
-typedef struct nl_term { uint16_t ref; uint16_t code; /* shift | 0x80: negative coefficient */ } nl_term;
+#define NL_TERM_LATE 0x100 /* a known cell that is part of the constraint but not of the evaluation of the gate's NEW cells */
+typedef struct nl_term { uint16_t ref; uint16_t code; /* shift | 0x80: negative coefficient | NL_TERM_LATE */ } nl_term;
 typedef struct nl_hint { uint16_t value, ref_a; uint8_t lo_a, n_a; uint16_t ref_b; uint8_t lo_b, n_b; } nl_hint;
 typedef struct nl_home { uint16_t kind, item, cell; } nl_home;
 typedef struct nl_step_type {

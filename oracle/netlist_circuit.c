@@ -128,15 +128,19 @@ int orc_nl_synthesize(const nl_spec *sp, uint32_t capacity, const uint8_t *hdr_b
                     const nl_term *tm = &sp->terms[T->term0 + g->first_term];
                     int64_t S = g->constant;
                     for (uint32_t i = 0; i < g->n_known; i++) {
+                        if (tm[i].code & NL_TERM_LATE) continue; /* in the constraint, not in the evaluation: written below */
                         const int64_t x = REF(tm[i].ref);
                         TR(g->col + i, base + g->row) = (uint64_t)x;
                         S += (tm[i].code & 0x80) ? -(x << (tm[i].code & 0x7F)) : (x << (tm[i].code & 0x7F));
                     }
                     if (S < 0) rc = -2;
+                    int has_late = 0;
+                    for (uint32_t i = 0; i < g->n_known; i++) has_late |= (tm[i].code & NL_TERM_LATE) != 0;
                     for (uint32_t i = 0; i < g->n_new && rc == 0; i++) {
                         const uint32_t sh = tm[g->n_known + i].code & 0x7F;
                         uint64_t x = (uint64_t)S >> sh;
                         if (i + 1 < g->n_new) x &= (1ull << ((tm[g->n_known + i + 1].code & 0x7F) - sh)) - 1;
+                        else if (has_late && i > 0) x &= (1ull << (sh - (tm[g->n_known + i - 1].code & 0x7F))) - 1; /* a digit like the others */
                         if (x > 255) rc = -3;
                         val[tm[g->n_known + i].ref] = (uint8_t)x;
                         TR(g->col + g->n_known + i, base + g->row) = x;
@@ -147,6 +151,12 @@ int orc_nl_synthesize(const nl_spec *sp, uint32_t capacity, const uint8_t *hdr_b
                     const uint32_t a = REF(h->ref_a), b = REF(h->ref_b);
                     val[h->value] = (uint8_t)(((a >> h->lo_a) & ((1u << h->n_a) - 1)) | (((b >> h->lo_b) & ((1u << h->n_b) - 1)) << h->n_a));
                 }
+            }
+            for (uint32_t gi = 0; gi < T->n_gates; gi++) { /* the late cells of the gates: their producers have run by now */
+                const nl_gate *g = &sp->gates[T->gate0 + gi];
+                const nl_term *tm = &sp->terms[T->term0 + g->first_term];
+                for (uint32_t i = 0; i < g->n_known; i++)
+                    if (tm[i].code & NL_TERM_LATE) TR(g->col + i, base + g->row) = (uint64_t)REF(tm[i].ref);
             }
             const uint16_t *out = sp->out + (size_t)cs->type * sp->state;
             for (uint32_t k = 0; k < sp->state; k++) next[k] = REF(out[k]);

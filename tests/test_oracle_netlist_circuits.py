@@ -167,7 +167,7 @@ def test_trace_satisfies_and_tampering_is_caught(oracle, specs, ct):
     # a NEW gate cell that nothing else copies: only the gate's own sum catches it (kind 7) — the carry of an addition / a recomposed byte
     gates = [(k, st) for k, st in enumerate(spec.step_types) if st.gates]
     k, stg = gates[0]
-    consumed = {id(r) for _, ins, *_ in stg.ops for r in ins} | {id(r) for g_ in stg.gates for r, _, _ in g_[0]} | {id(r) for r in stg.out}
+    consumed = {id(r) for _, ins, *_ in stg.ops for r in ins} | {id(r) for g_ in stg.gates for r, *_ in g_[0]} | {id(r) for r in stg.out}
     for gi, (known, shifts, news, const) in enumerate(stg.gates):
         lonely = [n_ for n_ in news if id(n_) not in consumed]
         if lonely:

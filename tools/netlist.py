@@ -131,11 +131,15 @@ class StepType:
         return v
 
     def gate(self, known, new_shifts, constant=0):
-        """known: [(ref, shift, sign)]; NEW cells at new_shifts (ascending): digits of S = sum(sign * ref << shift) + constant.
-        Constraint: S - sum(new_i << shift_i) == 0. No NEW cell: a pure assertion. Returns the NEW cells."""
+        """known: [(ref, shift, sign)] or [(ref, shift, sign, late)]; NEW cells at new_shifts (ascending): digits of
+        S = sum(sign * ref << shift) + constant. Constraint: S - sum(new_i << shift_i) == 0. No NEW cell: a pure assertion.
+        A `late` known cell is part of the constraint but not of the evaluation: the generator asserts that the digits at the
+        NEW cells' positions are the same without it (a piece that only cancels bits outside them) — the fill then computes
+        the gate before the late cell's producer, which shortens the dependency chain; in such a gate the last NEW cell is a digit
+        of the common width like the others (without late cells it takes everything that is left). Returns the NEW cells."""
         assert list(new_shifts) == sorted(new_shifts)
         news = [Val("gate", len(self.gates), k) for k in range(len(new_shifts))]
-        self.gates.append([[(r, s, sg) for r, s, sg in known], list(new_shifts), news, constant])
+        self.gates.append([[(t[0], t[1], t[2], bool(t[3]) if len(t) > 3 else False) for t in known], list(new_shifts), news, constant])
         return news
 
     # ---- finishing: group lookups by table, pad to rows, number the values, place the gates, levels
@@ -184,7 +188,7 @@ class StepType:
             self.values.append((2, users[h][0][0], users[h][0][1]))  # home: the first lookup cell that takes it
         assert len(self.values) < MAX_VALUES
         frees = [r[1] for t, ins, *_ in self.ops for r in ins if not isinstance(r, Val) and r[0] == "free"] + \
-                [r[1] for g in self.gates for r, _, _ in g[0] if not isinstance(r, Val) and r[0] == "free"]
+                [r[1] for g in self.gates for r, *_ in g[0] if not isinstance(r, Val) and r[0] == "free"]
         assert len(frees) == len(set(frees)), "a FREE element is used twice (it has no home cell to copy from)"
         self.n_free = max(frees) + 1 if frees else 0
         self.lookup_rows = len(self.slots) // lookups_per_row
@@ -215,7 +219,7 @@ class StepType:
                     j = self.slots[i][0]
                     refs = self.ops[j][1] if j is not None else []
                 elif kind == 1:
-                    refs = [r for r, _, _ in self.gates[i][0]]
+                    refs = [r for r, _, _, late in self.gates[i][0] if not late]
                 else:
                     refs = [self.hints[i][1][0], self.hints[i][2][0]]
                 lvl[it] = 1 + max([ref_level(r) for r in refs] + [0])
@@ -236,6 +240,7 @@ class StepType:
     # ---- evaluation (the Python reference semantics of a step)
     def evaluate(self, hdrv, prevv, cycv, freev, rcv):
         vals = [None] * len(self.values)
+        self.late_checks = []
 
         def get(r):
             if isinstance(r, Val):
@@ -255,21 +260,32 @@ class StepType:
                     vals[v.index] = x
             elif kind == 1:
                 known, shifts, news, k = self.gates[i]
-                S = k + sum(sg * (get(r) << s) for r, s, sg in known)
+                S = k + sum(sg * (get(r) << s) for r, s, sg, late in known if not late)
                 assert S >= 0, (self.name, "gate", i, S)
                 if not news:
                     assert S == 0, (self.name, "assertion gate", i, S)
                     continue
-                assert S & ((1 << shifts[0]) - 1) == 0
+                if any(late for *_, late in known):
+                    self.late_checks.append((i, S))  # the full constraint is checked once every value exists
+                else:
+                    assert S & ((1 << shifts[0]) - 1) == 0
+                has_late = any(late for *_, late in known)
                 for n, v in enumerate(news):
                     x = S >> shifts[n]
                     if n + 1 < len(shifts):
                         x &= (1 << (shifts[n + 1] - shifts[n])) - 1
+                    elif has_late:  # nothing above the last digit cancels in the evaluation: it has the width of the others
+                        assert len(shifts) > 1
+                        x &= (1 << (shifts[n] - shifts[n - 1])) - 1
                     assert x < 256, (self.name, "gate", i, "cell", n, x)
                     vals[v.index] = x
             else:
                 v, (ra, la, na), (rb, lb, nb) = self.hints[i]
                 vals[v.index] = ((get(ra) >> la) & ((1 << na) - 1)) | (((get(rb) >> lb) & ((1 << nb) - 1)) << na)
+        for i, _ in self.late_checks:  # gates with late cells: the constraint over ALL cells holds
+            known, shifts, news, k = self.gates[i]
+            full = k + sum(sg * (get(r) << s) for r, s, sg, _ in known)
+            assert full == sum(vals[v.index] << sh for v, sh in zip(news, shifts)), (self.name, "gate with late cells", i)
         return vals, [get(r) for r in self.out]
 
 
@@ -337,8 +353,8 @@ class Spec:
             for g, (known, shifts, news, k) in enumerate(st.gates):
                 row, col = st.gate_pos[g]
                 gates.append((len(terms) - b["term0"], len(known), len(news), k, row, col))
-                for r, s, sg in known:
-                    terms.append((st.enc(r), s | (0x80 if sg < 0 else 0)))
+                for r, s, sg, late in known:
+                    terms.append((st.enc(r), s | (0x80 if sg < 0 else 0) | (0x100 if late else 0)))
                 for v, s in zip(news, shifts):
                     terms.append((v.index, s | 0x80))  # NEW cells enter the constraint with coefficient -2^s
             for v, (ra, la, na), (rb, lb, nb) in st.hints:
@@ -373,7 +389,7 @@ class Spec:
         for g in gates:
             o.append("  {" + ", ".join(str(x) for x in g) + "}, \\")
         o.append("}")
-        w("/* gate cells {reference, shift | 0x80 if the coefficient is negative}: a gate's known cells, then its NEW cells */")
+        w("/* gate cells {reference, shift | 0x80 if the coefficient is negative | 0x100 if the cell is LATE (in the constraint, not in the evaluation of the NEW cells)}: a gate's known cells, then its NEW cells */")
         w(f"#define {P}_TERMS_INIT {{" + ", ".join(f"{{{r}, {c}}}" for r, c in terms) + "}")
         w("/* hints {value, ref A, lo A, bits A, ref B, lo B, bits B} */")
         w(f"#define {P}_HINTS_INIT {{" + (", ".join("{" + ", ".join(str(x) for x in h) + "}" for h in hints) or "{0, 0, 0, 0, 0, 0, 0}") + "}")
