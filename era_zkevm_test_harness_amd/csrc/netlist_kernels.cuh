@@ -245,11 +245,20 @@ __global__ __launch_bounds__(NL_FILL_THREADS / CPW) void k_nl_fill(const NlDev* 
                 for (u32 e = lv0 + lane; e < lv1; e += LW) {
                     const u32 it = s_order[T.order0 + e];
                     if (it < NL_ORDER_GATE) {
-                        const u32 j = T.op0 + it;
+                        u32 j = T.op0 + it, a0;
+                        if (it >= NL_ORDER_FUSED) {  // a hint and the lookup it keys: one item, one level
+                            const nl_hint h = s_hints[T.hint0 + (it - NL_ORDER_FUSED)];
+                            const u32 a = val[h.ref_a], b = val[h.ref_b];
+                            a0 = ((a >> h.lo_a) & ((1u << h.n_a) - 1)) | (((b >> h.lo_b) & ((1u << h.n_b) - 1)) << h.n_a);
+                            val[h.value] = (uint8_t)a0;
+                            j = T.op0 + h.fused_slot;
+                        } else {
+                            a0 = val[s_op_in[j]];
+                        }
                         const nl_table tb = s_tab[s_op_table[j] - 1];
                         const u32 out = s_op_out[j];
                         u32 o0, o1, o2;
-                        nl_eval_sel(tb.fn, tb.param, val[s_op_in[j]], val[s_op_in[m_n_ops + j]], val[s_op_in[2 * m_n_ops + j]], o0, o1, o2);
+                        nl_eval_sel(tb.fn, tb.param, a0, val[s_op_in[m_n_ops + j]], val[s_op_in[2 * m_n_ops + j]], o0, o1, o2);
                         if (out != 0xFFFF) {
                             val[out] = (uint8_t)o0;
                             if (tb.n_out > 1) val[out + 1] = (uint8_t)o1;

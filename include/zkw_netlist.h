@@ -22,6 +22,7 @@
 #define NL_REF_FREE 0xC300u
 #define NL_REF_RC 0xC400u
 #define NL_REF_CONST 0xC500u
+#define NL_ORDER_FUSED 0x4000u /* + hint index: the hint and, in the same item, the lookup it keys (nl_hint.fused_slot) */
 #define NL_ORDER_GATE 0x8000u
 #define NL_ORDER_HINT 0xC000u
 #define NL_HDR_RESET 0
@@ -37,7 +38,7 @@ typedef struct nl_op { uint16_t table, in[3], out; } nl_op;
 typedef struct nl_gate { uint32_t first_term; uint16_t n_known, n_new; uint32_t constant; uint16_t row, col; } nl_gate;
 #define NL_TERM_LATE 0x100 /* a known cell that is part of the constraint but not of the evaluation of the gate's NEW cells */
 typedef struct nl_term { uint16_t ref; uint16_t code; /* shift | 0x80: negative coefficient | NL_TERM_LATE */ } nl_term;
-typedef struct nl_hint { uint16_t value, ref_a; uint8_t lo_a, n_a; uint16_t ref_b; uint8_t lo_b, n_b; } nl_hint;
+typedef struct nl_hint { uint16_t value, ref_a; uint8_t lo_a, n_a; uint16_t ref_b; uint8_t lo_b, n_b; uint16_t fused_slot; /* 0xFFFF: evaluated on its own */ } nl_hint;
 typedef struct nl_home { uint16_t kind, item, cell; } nl_home;
 typedef struct nl_step_type {
     uint32_t op0, n_ops, gate0, n_gates, term0, n_terms, hint0, n_hints, order0, level0, n_levels, home0, n_values, rows, lookup_rows,

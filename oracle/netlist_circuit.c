@@ -107,8 +107,15 @@ int orc_nl_synthesize(const nl_spec *sp, uint32_t capacity, const uint8_t *hdr_b
 #define REF(x) ((x) < NL_REF_HDR ? val[x] : (x) < NL_REF_PREV ? hdr[(x) - NL_REF_HDR] : (x) < NL_REF_CYC ? prev[(x) - NL_REF_PREV] \
                 : (x) < NL_REF_FREE ? cyc[(x) - NL_REF_CYC] : (x) < NL_REF_RC ? fr[(x) - NL_REF_FREE] : (x) < NL_REF_CONST ? cs->rc[(x) - NL_REF_RC] : (uint8_t)((x) - NL_REF_CONST))
             for (int f = 0; f < NL_HDR_FIELDS; f++) TR(f, base) = hdr[f];
-            for (uint32_t e = 0; e < T->n_ops + T->n_gates + T->n_hints; e++) {
-                const uint32_t it = sp->order[T->order0 + e];
+            const uint32_t n_items = sp->level_start[T->level0 + T->n_levels]; /* (a fused hint + lookup is one item) */
+            for (uint32_t e = 0; e < n_items; e++) {
+                uint32_t it = sp->order[T->order0 + e];
+                if (it >= NL_ORDER_FUSED && it < NL_ORDER_GATE) { /* the hint first, then the lookup it keys */
+                    const nl_hint *h = &sp->hints[T->hint0 + (it - NL_ORDER_FUSED)];
+                    const uint32_t a = REF(h->ref_a), b = REF(h->ref_b);
+                    val[h->value] = (uint8_t)(((a >> h->lo_a) & ((1u << h->n_a) - 1)) | (((b >> h->lo_b) & ((1u << h->n_b) - 1)) << h->n_a));
+                    it = h->fused_slot;
+                }
                 if (it < NL_ORDER_GATE) {
                     const nl_op *op = &sp->ops[T->op0 + it];
                     const nl_table *t = &sp->tables[op->table - 1];

@@ -206,6 +206,15 @@ class StepType:
     def _levels(self):
         sys.setrecursionlimit(1000000)
         lvl = {}
+        # a hint that is the key (only input) of a lookup is evaluated WITH that lookup, as one item: a dependency level less
+        # wherever a lookup is keyed by packed bit fields. fused_slot[h] = slot position of that lookup
+        self.fused_slot = {}
+        for p, (j, _t) in enumerate(self.slots):
+            if j is not None and len(self.ops[j][1]) == 1 and isinstance(self.ops[j][1][0], Val) and self.ops[j][1][0].kind == "hint":
+                h = self.ops[j][1][0].item
+                if h not in self.fused_slot:
+                    self.fused_slot[h] = p
+        fused_of_slot = {p: h for h, p in self.fused_slot.items()}
 
         def ref_level(r):
             if not isinstance(r, Val):
@@ -215,6 +224,8 @@ class StepType:
         def item_level(it):
             if it not in lvl:
                 kind, i = it
+                if kind == 0 and i in fused_of_slot:
+                    return item_level((2, fused_of_slot[i]))
                 if kind == 0:
                     j = self.slots[i][0]
                     refs = self.ops[j][1] if j is not None else []
@@ -225,8 +236,9 @@ class StepType:
                 lvl[it] = 1 + max([ref_level(r) for r in refs] + [0])
             return lvl[it]
 
-        items = [(item_level((0, p)), 0, p) for p in range(len(self.slots))] + [(item_level((1, g)), 1, g) for g in range(len(self.gates))] + \
-                [(item_level((2, h)), 2, h) for h in range(len(self.hints))]
+        items = [(item_level((0, p)), 0, p) for p in range(len(self.slots)) if p not in fused_of_slot] + \
+                [(item_level((1, g)), 1, g) for g in range(len(self.gates))] + \
+                [(item_level((2, h)), 3 if h in self.fused_slot else 2, h) for h in range(len(self.hints))]
         items.sort()
         self.order = [(k, i) for _, k, i in items]
         self.n_levels = items[-1][0] if items else 0
@@ -282,6 +294,11 @@ class StepType:
             else:
                 v, (ra, la, na), (rb, lb, nb) = self.hints[i]
                 vals[v.index] = ((get(ra) >> la) & ((1 << na) - 1)) | (((get(rb) >> lb) & ((1 << nb) - 1)) << na)
+                if kind == 3:  # the lookup this hint keys, in the same item
+                    t, ins, outs, _ = self.ops[self.slots[self.fused_slot[i]][0]]
+                    assert 0 <= vals[v.index] < (1 << t.in_bits)
+                    for o, x in zip(outs, t.eval([vals[v.index]])):
+                        vals[o.index] = x
         for i, _ in self.late_checks:  # gates with late cells: the constraint over ALL cells holds
             known, shifts, news, k = self.gates[i]
             full = k + sum(sg * (get(r) << s) for r, s, sg, _ in known)
@@ -358,9 +375,9 @@ class Spec:
                 for v, s in zip(news, shifts):
                     terms.append((v.index, s | 0x80))  # NEW cells enter the constraint with coefficient -2^s
             for v, (ra, la, na), (rb, lb, nb) in st.hints:
-                hints.append((v.index, st.enc(ra), la, na, st.enc(rb), lb, nb))
+                hints.append((v.index, st.enc(ra), la, na, st.enc(rb), lb, nb, st.fused_slot.get(len(hints) - b["hint0"], 0xFFFF)))
             for kind, i in st.order:
-                order.append(i if kind == 0 else 0x8000 + i if kind == 1 else 0xC000 + i)
+                order.append(i if kind == 0 else 0x8000 + i if kind == 1 else 0xC000 + i if kind == 2 else 0x4000 + i)
             levels.extend(st.level_start)
             homes.extend(st.values)
             outs.extend(st.enc(r) for r in st.out)
@@ -391,10 +408,10 @@ class Spec:
         o.append("}")
         w("/* gate cells {reference, shift | 0x80 if the coefficient is negative | 0x100 if the cell is LATE (in the constraint, not in the evaluation of the NEW cells)}: a gate's known cells, then its NEW cells */")
         w(f"#define {P}_TERMS_INIT {{" + ", ".join(f"{{{r}, {c}}}" for r, c in terms) + "}")
-        w("/* hints {value, ref A, lo A, bits A, ref B, lo B, bits B} */")
-        w(f"#define {P}_HINTS_INIT {{" + (", ".join("{" + ", ".join(str(x) for x in h) + "}" for h in hints) or "{0, 0, 0, 0, 0, 0, 0}") + "}")
+        w("/* hints {value, ref A, lo A, bits A, ref B, lo B, bits B, slot of the lookup evaluated with the hint or 0xFFFF} */")
+        w(f"#define {P}_HINTS_INIT {{" + (", ".join("{" + ", ".join(str(x) for x in h) + "}" for h in hints) or "{0, 0, 0, 0, 0, 0, 0, 65535}") + "}")
         w(f"#define {P}_OUT_INIT {{" + ", ".join(str(x) for x in outs) + "}")
-        w("/* evaluation order per step type: lookup slot j, 0x8000 + gate, 0xC000 + hint; level l of a type = [level_start[level0 + l], level_start[level0 + l + 1]) */")
+        w("/* evaluation order per step type: lookup slot j, 0x4000 + hint evaluated together with the lookup it keys (hint field 8: that slot), 0x8000 + gate, 0xC000 + hint; level l of a type = [level_start[level0 + l], level_start[level0 + l + 1]) */")
         w(f"#define {P}_ORDER_INIT {{" + ", ".join(str(x) for x in order) + "}")
         w(f"#define {P}_LEVEL_START_INIT {{" + ", ".join(str(x) for x in levels) + "}")
         w("/* where value v has its own cell: {0: lookup slot, cell of the slot | 1: gate, cell of the gate | 2: lookup slot, input cell (a hint)} */")
