@@ -58,7 +58,8 @@ struct NlDev {
     u32 n_pk_terms;
     u32 max_items;               // max over step types of n_ops + n_gates + rows (the checker's grid)
     u32 vsize;                   // bytes of a wave's value array
-    u32 lds_bytes;               // dynamic LDS of k_nl_fill
+    u32 fill_waves;              // waves per workgroup of k_nl_fill (8 or 16)
+    u32 lds_bytes, lds_bytes16;  // dynamic LDS of k_nl_fill with 8 / 16 waves per workgroup
 };
 struct NlJob {
     const uint8_t* hdr_bits;      // [capacity]: bit 0 reset, bit 1 idle
@@ -70,8 +71,7 @@ struct NlJob {
     u32* hist;                    // [n_hist_slices][2 halves][NL_HIST_HALF]: k_nl_hist's bins (every bin stored), summed by k_nl_finish
 };
 
-constexpr int NL_FILL_WAVES = 8;
-constexpr int NL_FILL_THREADS = 64 * NL_FILL_WAVES;
+constexpr int NL_FILL_WAVES_MAX = 16;  // waves (= cycles in flight) per workgroup: 16 where two such workgroups fit a CU's LDS, else 8 (nl_get)
 
 // layout of a wave's value array: [values | header 4 | prev state | cycle state | free | rc 8 | constants 256]
 struct NlV {
@@ -96,7 +96,7 @@ struct NlLdsGate { u32 constant; uint16_t new_ref; uint8_t n_new, new_sh0, new_s
 // LDS carve of k_nl_fill, the same arithmetic on the host (lds_bytes) and in the kernel
 struct NlLds {
     u32 tab, types, cyc, op_table, op_in, op_out, gates, term_ref, term_code, pk, pk_first, hints, order, level, out, waves, total;
-    __host__ __device__ NlLds(const nl_spec& s, u32 vsize, u32 n_pk) {
+    __host__ __device__ NlLds(const nl_spec& s, u32 vsize, u32 n_pk, u32 n_waves) {
         u32 at = 0;
         auto take = [&](u32 bytes) { u32 r = at; at = (at + bytes + 15) & ~15u; return r; };
         tab = take(s.n_tables * sizeof(nl_table));
@@ -113,7 +113,7 @@ struct NlLds {
         order = take(s.n_order * 2);
         level = take(s.n_level_starts * 2);
         out = take(s.n_step_types * s.state * 2);
-        waves = take(NL_FILL_WAVES * vsize);
+        waves = take(n_waves * vsize);
         total = at + 16;  // (gate operands are read 8 bytes at a time: the last wave's last cells have something behind them)
     }
 };
@@ -135,15 +135,14 @@ __device__ __forceinline__ void nl_eval_sel(u32 fn, u32 k, u32 a0, u32 a1, u32 a
     o2 = fn == NL_FN_SPLIT4 ? ((lo << (4 - k)) | hi) : 0;
 }
 
-// CPW = cycles per wave: 1 (a wave owns a cycle: 8 waves per workgroup) or 2 (each half of a wave owns a cycle: 4 waves per
-// workgroup, the same 8 cycles in LDS). A level of the SHA-256 netlist holds 15 items on average — three quarters of a wave's
-// lanes idle through the walk — so two cycles per wave halve the instructions the walk issues. Measured: SHA-256 3.35 ms per 8
-// instances with CPW = 1, 4.19 ms with CPW = 2 — the walk is bound by the latency of its dependent LDS reads, which two waves
-// per SIMD hide from each other and one wave per SIMD does not. Every circuit runs CPW = 1; 2 stays selectable.
-template <int W, int R, int CPW>
-__global__ __launch_bounds__(NL_FILL_THREADS / CPW) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
+// WAVES = waves per workgroup, a wave owns a cycle. (Two cycles per wave — each half of a wave walking its own cycle, since a
+// level of the SHA-256 netlist holds 15 items on average and most lanes idle through the walk — was measured: 4.19 ms against
+// 3.35 ms per 8 SHA-256 instances. The walk is bound by the latency of its dependent LDS reads, which two waves per SIMD hide
+// from each other and one wave per SIMD does not; CPW below is what is left of that experiment.)
+template <int W, int R, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
+    constexpr int CPW = 1, NL_FILL_WAVES = WAVES, NL_FILL_THREADS = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int NL_FILL_THREADS_ = NL_FILL_THREADS / CPW;  // threads of this instantiation
     constexpr u32 LW = 64 / CPW;                             // lanes that share a cycle
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(NL_FILL_THREADS / CPW) void k_nl_fill(const NlDev* 
     const int t = threadIdx.x, wv = t >> 6;
     const u32 lane = (u32)(t & 63) % LW, sub = (u32)(t & 63) / LW;
     const NlV V(S);
-    const NlLds L(S, V.size, D.n_pk_terms);
+    const NlLds L(S, V.size, D.n_pk_terms, WAVES);
     nl_table* const s_tab = reinterpret_cast<nl_table*>(lds + L.tab);
     nl_step_type* const s_types = reinterpret_cast<nl_step_type*>(lds + L.types);
     nl_cycle_step* const s_cyc = reinterpret_cast<nl_cycle_step*>(lds + L.cyc);
@@ -167,16 +166,16 @@ __global__ __launch_bounds__(NL_FILL_THREADS / CPW) void k_nl_fill(const NlDev* 
     uint16_t* const s_out = reinterpret_cast<uint16_t*>(lds + L.out);
     uint8_t* const val = lds + L.waves + (wv * CPW + sub) * V.size;
     // ---- stage the netlists (references made dense: one LDS read resolves any of them)
-    for (u32 i = t; i < S.n_tables; i += NL_FILL_THREADS_) s_tab[i] = S.tables[i];
-    for (u32 i = t; i < S.n_step_types; i += NL_FILL_THREADS_) s_types[i] = S.step_types[i];
-    for (u32 i = t; i < S.steps_per_cycle; i += NL_FILL_THREADS_) s_cyc[i] = S.cycle[i];
-    for (u32 i = t; i < S.n_ops; i += NL_FILL_THREADS_) {
+    for (u32 i = t; i < S.n_tables; i += NL_FILL_THREADS) s_tab[i] = S.tables[i];
+    for (u32 i = t; i < S.n_step_types; i += NL_FILL_THREADS) s_types[i] = S.step_types[i];
+    for (u32 i = t; i < S.steps_per_cycle; i += NL_FILL_THREADS) s_cyc[i] = S.cycle[i];
+    for (u32 i = t; i < S.n_ops; i += NL_FILL_THREADS) {
         const nl_op op = S.ops[i];
         s_op_table[i] = (uint8_t)op.table;
         for (int k = 0; k < 3; k++) s_op_in[k * S.n_ops + i] = V.dense(op.in[k]);
         s_op_out[i] = op.out;
     }
-    for (u32 i = t; i < S.n_gates; i += NL_FILL_THREADS_) {
+    for (u32 i = t; i < S.n_gates; i += NL_FILL_THREADS) {
         const nl_gate g = S.gates[i];
         u32 ty = 0;
         while (ty + 1 < S.n_step_types && S.step_types[ty + 1].gate0 <= i) ty++;
@@ -192,17 +191,17 @@ __global__ __launch_bounds__(NL_FILL_THREADS / CPW) void k_nl_fill(const NlDev* 
         lg._pad[0] = lg._pad[1] = 0;
         s_gates[i] = lg;
     }
-    for (u32 i = t; i < D.n_pk_terms; i += NL_FILL_THREADS_) s_pk[i] = D.pk_terms[i];
-    for (u32 i = t; i < S.n_gates + S.n_step_types; i += NL_FILL_THREADS_) s_pk_first[i] = D.pk_first[i];
-    for (u32 i = t; i < S.n_hints; i += NL_FILL_THREADS_) {
+    for (u32 i = t; i < D.n_pk_terms; i += NL_FILL_THREADS) s_pk[i] = D.pk_terms[i];
+    for (u32 i = t; i < S.n_gates + S.n_step_types; i += NL_FILL_THREADS) s_pk_first[i] = D.pk_first[i];
+    for (u32 i = t; i < S.n_hints; i += NL_FILL_THREADS) {
         nl_hint h = S.hints[i];
         h.ref_a = V.dense(h.ref_a); h.ref_b = V.dense(h.ref_b);
         s_hints[i] = h;
     }
-    for (u32 i = t; i < S.n_order; i += NL_FILL_THREADS_) s_order[i] = S.order[i];
-    for (u32 i = t; i < S.n_level_starts; i += NL_FILL_THREADS_) s_level[i] = S.level_start[i];
-    for (u32 i = t; i < S.n_step_types * S.state; i += NL_FILL_THREADS_) s_out[i] = V.dense(S.out[i]);
-    for (u32 i = t; i < NL_FILL_WAVES * 256; i += NL_FILL_THREADS_) lds[L.waves + (i >> 8) * V.size + V.con + (i & 255)] = (uint8_t)i;
+    for (u32 i = t; i < S.n_order; i += NL_FILL_THREADS) s_order[i] = S.order[i];
+    for (u32 i = t; i < S.n_level_starts; i += NL_FILL_THREADS) s_level[i] = S.level_start[i];
+    for (u32 i = t; i < S.n_step_types * S.state; i += NL_FILL_THREADS) s_out[i] = V.dense(S.out[i]);
+    for (u32 i = t; i < NL_FILL_WAVES * 256; i += NL_FILL_THREADS) lds[L.waves + (i >> 8) * V.size + V.con + (i & 255)] = (uint8_t)i;
     __syncthreads();  // the only workgroup barrier: from here on every wave is on its own
     // everything the cycle loop needs from the spec, in registers: the trace stores below go through a pointer the compiler cannot
     // prove distinct from *devp, so every `S.field` inside the loops would be re-read from global memory after each store

@@ -3828,8 +3828,11 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
     ZKW_TRY(nl_to_device(pk0.data(), pk0.size(), &d.pk0));
     d.max_items = max_items;
     d.vsize = V.size;
-    d.lds_bytes = NlLds(*hs, V.size, d.n_pk_terms).total;
-    if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d: %u terms packed into %u, LDS %u bytes for %d waves\n", circuit_type, hs->n_terms, d.n_pk_terms, d.lds_bytes, NL_FILL_WAVES);
+    // 16 waves per workgroup where two such workgroups still fit a CU (the Keccak family: 32 cycles in flight per CU), else 8
+    d.lds_bytes = NlLds(*hs, V.size, d.n_pk_terms, 8).total;
+    d.lds_bytes16 = NlLds(*hs, V.size, d.n_pk_terms, 16).total;
+    d.fill_waves = d.lds_bytes16 <= 80 * 1024 ? 16 : 8;
+    if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d: %u terms packed into %u, LDS %u bytes for %u waves\n", circuit_type, hs->n_terms, d.n_pk_terms, d.fill_waves == 16 ? d.lds_bytes16 : d.lds_bytes, d.fill_waves);
     const NlDev* dd = nullptr;
     ZKW_TRY(nl_to_device(&d, 1, &dd));
     c.host = d;
@@ -3840,17 +3843,26 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
 
 struct NlInstance { u64 first_round; u32 n_active; const u64* public_input; const zkw_trace* t; size_t slot; bool fresh = false; /* the hash state before the instance is zero, not what round first_round - 1 left (independent queues in one call) */ };
 
-template <int W, int R, int CPW>
-int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
+template <int W, int R, int WAVES>
+int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
     static bool attr_set[16] = {};
     if (!attr_set[ctx->device & 15]) {  // more than the default 64 KB of dynamic LDS
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ctx->device & 15] = true;
     }
     static const u32 probe = [] { const char* e = getenv("ZKW_NL_PROBE"); return e ? (u32)atoi(e) : 0u; }();  // measurement only: 1 = no level walk, 2 = no streaming
-    const unsigned blocks = std::min<unsigned>((capacity + NL_FILL_WAVES - 1) / NL_FILL_WAVES, std::max<unsigned>(1, 256 / nj));
-    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R, CPW>), dim3(blocks, nj), dim3(NL_FILL_THREADS / CPW), nc->host.lds_bytes, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
-    ZKW_TRY(launch_check("k_nl_fill"));
+    // as many workgroups as the LDS lets a CU hold: the write phase is a stream of stores and wants waves in flight
+    const unsigned lds = WAVES == 16 ? nc->host.lds_bytes16 : nc->host.lds_bytes;
+    const unsigned per_cu = std::max<unsigned>(1, std::min<unsigned>(4, (160u * 1024u) / std::max<unsigned>(1, lds)));
+    const unsigned blocks = std::min<unsigned>((capacity + WAVES - 1) / WAVES, std::max<unsigned>(1, 256 * per_cu / nj));
+    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R, WAVES>), dim3(blocks, nj), dim3(64 * WAVES), lds, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
+    return launch_check("k_nl_fill");
+}
+template <int W, int R>
+int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
+    // (a call with few cycles keeps 8 waves per workgroup: twice the workgroups, so that every CU has one)
+    if (nc->host.fill_waves == 16 && (size_t)((capacity + 15) / 16) * nj >= 128) ZKW_TRY((nl_launch_fill_w<W, R, 16>(ctx, nc, d_jobs, nj, capacity, n_rows)));
+    else ZKW_TRY((nl_launch_fill_w<W, R, 8>(ctx, nc, d_jobs, nj, capacity, n_rows)));
     { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
     return launch_check("k_nl_hist");
 }
@@ -3906,10 +3918,10 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
     else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
     ZKW_TRY(launch_check("k_nl_prepare"));
     switch (circuit_type) {
-        case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R, 1>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R, 1>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R, 1>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R, 1>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
     }
     { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
     return launch_check("k_nl_finish");
