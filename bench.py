@@ -589,8 +589,11 @@ def main():
             if hash_circuits is not None:
                 out["hash_circuits"] = hash_circuits
             elif not args.no_hash_circuits:
-                # AFTER the timed region and with the batch released: run before it, this leg costs the throughput leg 11 %
-                # (1604 against 1800 circuits/s, four runs each; what it leaves behind is not understood)
+                # AFTER the timed region and with the batch released. Round 2 measured an 11 % loss of the throughput leg when this
+                # leg ran first (1604 against 1800 circuits/s): the leg's context and streams shifted the round-robin assignment of
+                # the pipelines' streams to hardware queues, and two pipelines on one queue do not overlap — the mechanism fixed at
+                # the pipelines' stream creation above (alternating priorities). With that fix the order no longer matters:
+                # ZKW_HASH_CIRCUITS_FIRST=1 gives 1761 against 1797 circuits/s (3-step runs, round 3, gpurun_out/r03l)
                 for w_ in ws:
                     w_.free()
                 for r_ in rings:
