@@ -379,6 +379,92 @@ struct Coop4 {
         }
     }
 };
+
+// ---------------------------------------------------------------- one state per PAIR of lanes: 32 states per wave
+// Lane j (0 / 1) of a pair holds elements 4c + 2j, 4c + 2j + 1 of the three 4-blocks (x[2c], x[2c + 1]). M4 is symmetric under
+// exchanging the halves of a block — with own = (o0, o1), partner = (p0, p1):  B = 4 (o0 + o1) + 2 o1 + (p0 + p1),
+// A = B + 2 p1 + (o0 + o1) are rows (0, 1) of the block for lane 0 and rows (2, 3) for lane 1 — so both lanes run the same code
+// on one exchanged sum and one exchanged element per block. Against the quad form: a partial round's single S-box idles one
+// lane of two instead of three of four and a lane's six S-boxes per full round interleave: ~270 wave-instructions per
+// permutation against ~506 (the lane form: ~190), at about the latency the quad form has with two waves per SIMD.
+struct Coop2 {
+    u64 rc_full[2 * P2_HALF_FULL_ROUNDS][6];
+    u32 shift[6];
+    bool first;  // lane 0 of the pair: owns element 0
+
+    __device__ __forceinline__ void init(int j) {
+        first = j == 0;
+#pragma unroll
+        for (int k = 0; k < 2 * P2_HALF_FULL_ROUNDS; k++) {
+            const int round = k < P2_HALF_FULL_ROUNDS ? k : k + P2_PARTIAL_ROUNDS;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                rc_full[k][2 * c] = c_rc[12 * round + 4 * c + 2 * j];
+                rc_full[k][2 * c + 1] = c_rc[12 * round + 4 * c + 2 * j + 1];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            shift[2 * c] = c_shift[4 * c + 2 * j];
+            shift[2 * c + 1] = c_shift[4 * c + 2 * j + 1];
+        }
+    }
+
+    __device__ __forceinline__ void external(u64 x[6]) const {
+        Wide A[3], B[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const Wide own = wadd(wide(x[2 * c]), wide(x[2 * c + 1]));
+            const Wide oth = wdpp<QP_SWAP1>(own);
+            const u64 p1 = dpp64<QP_SWAP1>(x[2 * c + 1]);
+            B[c] = wadd(wadd(wshl(own, 2), wshl(wide(x[2 * c + 1]), 1)), oth);
+            A[c] = wadd(wadd(B[c], wshl(wide(p1), 1)), own);
+        }
+        const Wide colA = wadd(wadd(A[0], A[1]), A[2]), colB = wadd(wadd(B[0], B[1]), B[2]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            x[2 * c] = wreduce(wadd(A[c], colA));
+            x[2 * c + 1] = wreduce(wadd(B[c], colB));
+        }
+    }
+
+    __device__ __forceinline__ void internal(u64 x[6]) const {
+        Wide s = wide(x[0]);
+#pragma unroll
+        for (int i = 1; i < 6; i++) s = wadd(s, wide(x[i]));
+        s = wadd(s, wdpp<QP_SWAP1>(s));
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            Wide m;
+            m.lo = x[i] << shift[i];
+            m.hi = (u32)((x[i] >> 1) >> (63 - shift[i]));
+            x[i] = wreduce(wadd(m, s));
+        }
+    }
+
+    // weak in / weak out
+    __device__ __forceinline__ void permute(u64 x[6]) const {
+        external(x);
+#pragma unroll
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) x[i] = gl::pow7(gl::add(x[i], rc_full[k][i]));
+            external(x);
+        }
+        for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
+            const u64 rc = c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];
+            const u64 sx = gl::pow7(gl::add(x[0], rc));
+            x[0] = first ? sx : x[0];
+            internal(x);
+        }
+#pragma unroll
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) x[i] = gl::pow7(gl::add(x[i], rc_full[P2_HALF_FULL_ROUNDS + k][i]));
+            external(x);
+        }
+    }
+};
 #endif  // __HIPCC__
 
 }  // namespace p2

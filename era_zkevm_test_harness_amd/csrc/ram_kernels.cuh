@@ -235,6 +235,88 @@ __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict
     flush();
 }
 
+// Pair form: 32 chains per wave (p2::Coop2). Lane j of a pair holds elements 4c + 2j, 4c + 2j + 1: it loads / stores 16
+// contiguous bytes per block of four. Half the waves of the quad form for the same queues and ~half its wave-instructions per
+// permutation: what a launch of tens of thousands of queues takes away from the trace fills it overlaps.
+__global__ __launch_bounds__(64) void k_chain_full_p2(const ChainJob* __restrict__ jobs, int n_jobs) {
+    __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
+    const int lane = threadIdx.x & 63, j = lane & 1;
+    const int chain = blockIdx.x * 32 + (lane >> 1);
+    p2::Coop2 co;
+    co.init(j);
+    ChainJob job;
+    memset(&job, 0, sizeof job);
+    if (chain < n_jobs) job = jobs[chain];
+    u64 x[6];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        x[2 * c] = job.tail_in ? job.tail_in[4 * c + 2 * j] : 0;
+        x[2 * c + 1] = job.tail_in ? job.tail_in[4 * c + 2 * j + 1] : 0;
+    }
+    u64 e[4] = {0, 0, 0, 0};  // rate elements 2j, 2j + 1, 4 + 2j, 5 + 2j of the next item
+    const bool from_q = job.enc == nullptr;
+    RawQuery rq_next;
+    rq_next.a = rq_next.b = rq_next.c = make_uint4(0, 0, 0, 0);
+    u64 at_next = 0;  // index (into q) of item i + 2, fetched one iteration before its query
+    auto load_enc = [&](u64 i) {
+        const ulonglong2 lo = *reinterpret_cast<const ulonglong2*>(job.enc + 8 * i + 2 * j), hi = *reinterpret_cast<const ulonglong2*>(job.enc + 8 * i + 4 + 2 * j);
+        e[0] = lo.x; e[1] = lo.y; e[2] = hi.x; e[3] = hi.y;
+    };
+    if (job.n > 0) {
+        if (from_q) rq_next = load_raw_query(job.q + (job.perm ? job.perm[0] : 0)); else load_enc(0);
+    }
+    if (from_q && job.n > 1) at_next = job.perm ? job.perm[1] : 1;
+    u64 next_mark = job.marks ? job.period : ~0ull, mark_idx = 0;
+    u64 pend[6] = {0, 0, 0, 0, 0, 0}, pend_i = 0;
+    bool have_pend = false, pend_mark = false;
+    auto flush = [&]() {  // the stores of item i go out at the top of iteration i + 1 (see k_chain_full)
+        if (!have_pend) return;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const ulonglong2 v = make_ulonglong2(pend[2 * c], pend[2 * c + 1]);
+            if (job.tails) *reinterpret_cast<ulonglong2*>(job.tails + 12 * pend_i + 4 * c + 2 * j) = v;
+            if (c == 2 && job.caps) *reinterpret_cast<ulonglong2*>(job.caps + 4 * pend_i + 2 * j) = v;
+            if (pend_mark) *reinterpret_cast<ulonglong2*>(job.marks + 12 * mark_idx + 4 * c + 2 * j) = v;
+        }
+        if (pend_mark) mark_idx++;
+        have_pend = false;
+    };
+    for (u64 i = 0; __any(i < job.n); i++) {
+        const bool live = i < job.n;
+        if (from_q) {
+            u64 ew[8];
+            encode_raw_query(rq_next, ew);
+            e[0] = j ? ew[2] : ew[0];
+            e[1] = j ? ew[3] : ew[1];
+            e[2] = j ? ew[6] : ew[4];
+            e[3] = j ? ew[7] : ew[5];
+        }
+        u64 y[6] = {e[0], e[1], e[2], e[3], x[4], x[5]};  // AbsorptionModeOverwrite: rate part replaced, capacity kept
+        flush();
+        if (i + 1 < job.n) {
+            if (from_q) {
+                rq_next = load_raw_query(job.q + at_next);
+                if (i + 2 < job.n) at_next = job.perm ? job.perm[i + 2] : i + 2;
+            } else {
+                load_enc(i + 1);
+            }
+        }
+        co.permute(y);
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                x[c] = y[c];
+                pend[c] = gl::canon(y[c]);
+            }
+            pend_i = i;
+            have_pend = true;
+            pend_mark = job.marks && (i + 1 == next_mark || i + 1 == job.n);
+            if (pend_mark) next_mark += job.period;
+        }
+    }
+    flush();
+}
+
 // Lane form: ONE CHAIN PER LANE, 64 chains per wave (p2::permute, the whole state in the lane's registers). The
 // cooperative forms above buy latency with idle lanes (during the 22 partial rounds only one S-box per state is live:
 // 506 wave-instructions per permutation in the quad form); per lane a permutation costs ~210. With tens of thousands

@@ -834,8 +834,8 @@ extern "C" int zkw_set_pointer_mode(zkw_ctx* ctx, int mode) {
 }
 
 extern "C" int zkw_set_chain_form(zkw_ctx* ctx, int lanes_per_state) {
-    if (!ctx || (lanes_per_state != 0 && lanes_per_state != 1 && lanes_per_state != 4 && lanes_per_state != 16))
-        return fail(ZKW_ERR_INVALID, "chain form must be 0 (auto), 1, 4 or 16");
+    if (!ctx || (lanes_per_state != 0 && lanes_per_state != 1 && lanes_per_state != 2 && lanes_per_state != 4 && lanes_per_state != 16))
+        return fail(ZKW_ERR_INVALID, "chain form must be 0 (auto), 1, 2, 4 or 16");
     ctx->chain_form = lanes_per_state;
     return ZKW_OK;
 }
@@ -1077,7 +1077,10 @@ static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     // (<= 4096 chains); the quad form packs 16 chains per wave (14.3 us up to 16 384 chains = one wave per SIMD, 21.3 us
     // with two waves per SIMD). The lane form (64 chains per wave, ~2.4x fewer VALU instructions per permutation, 36 us
     // per step) is never chosen automatically: measured on the bench's batch it loses to the quad form both alone
-    // (1 418 vs 1 493 circuits/s) and next to another pipeline's fills (1 240 vs 1 790), DESIGN.md 3.2
+    // (1 418 vs 1 493 circuits/s) and next to another pipeline's fills (1 240 vs 1 790), DESIGN.md 3.2. The pair form (32 chains
+    // per wave, round 3) is in between and not chosen either: 31 us per step on the bench's batch with half the quad form's waves
+    // — the same pass time alone (1 506 vs 1 481 circuits/s), and next to the fills its longer pass costs more than the issue
+    // slots it frees (1 738 vs 1 812)
     const int form = ctx->chain_form ? ctx->chain_form : (n_jobs >= 4096 ? 4 : 16);
     // the chain kernel may run on its own stream (e.g. one created with a CU mask): ordered after everything queued on
     // the context's stream so far, and the context's stream continues after it
@@ -1087,11 +1090,12 @@ static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
         HIP_TRY(hipStreamWaitEvent(ctx->chain_stream, ctx->chain_ev_a, 0));
         st = ctx->chain_stream;
     }
-    const char* name = form == 16 ? "k_chain_full" : form == 4 ? "k_chain_full_q4" : "k_chain_full_lane";
+    const char* name = form == 16 ? "k_chain_full" : form == 4 ? "k_chain_full_q4" : form == 2 ? "k_chain_full_p2" : "k_chain_full_lane";
     {
         Prof _p(ctx, name);
         if (form == 16) hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
         else if (form == 4) hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
+        else if (form == 2) hipLaunchKernelGGL(k_chain_full_p2, dim3((n_jobs + 31) / 32), dim3(64), 0, st, d_jobs, n_jobs);
         else hipLaunchKernelGGL(k_chain_full_lane, dim3((n_jobs + 63) / 64), dim3(64), 0, st, d_jobs, n_jobs);
         if (ctx->chain_stream) {  // the profiling events live on the context's stream: bring the kernel's end onto it first
             HIP_TRY(hipEventRecord(ctx->chain_ev_b, ctx->chain_stream));

@@ -68,7 +68,7 @@ int zkw_set_chain_stream(zkw_ctx *ctx, void *hip_stream);
 int zkw_set_pointer_mode(zkw_ctx *ctx, int mode);
 int zkw_synchronize(zkw_ctx *ctx);
 /* tuning knob: lanes that cooperate on one Poseidon2 state in the queue-chain kernel: 16 (4 chains per wave,
-   row DPP, lowest latency), 4 (16 chains per wave, quad DPP), 1 (64 chains per wave, the whole state in one lane:
+   row DPP, lowest latency), 4 (16 chains per wave, quad DPP), 2 (32 chains per wave, a pair of lanes per state), 1 (64 chains per wave, the whole state in one lane:
    fewest instructions per permutation, for launches of tens of thousands of queues) or 0 = choose by the number of
    chains in the launch (default). Results are identical. */
 int zkw_set_chain_form(zkw_ctx *ctx, int lanes_per_state);

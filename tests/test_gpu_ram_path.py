@@ -39,7 +39,7 @@ def test_poseidon2_cooperative_and_lane_forms_match_oracle(ctx, oracle):
         assert np.array_equal(got[k], oracle.poseidon2(s)), k
 
 
-@pytest.mark.parametrize("form", [1, 4, 16])
+@pytest.mark.parametrize("form", [1, 2, 4, 16])
 def test_queue_chain_forms_agree(ctx, oracle, form):
     """the three layouts of the chain kernel (one lane / quad / row of 16 per state) against the oracle, ragged batch"""
     lens = [3, 0, 40, 1, 9, 17, 2, 5, 33, 8, 1, 1, 64, 7, 12, 3, 100, 6, 2] + [4, 9, 1] * 20  # 79 queues: > one wave in every form
@@ -57,7 +57,7 @@ def test_queue_chain_forms_agree(ctx, oracle, form):
             assert np.array_equal(got[lo:lo + ln], oracle.queue_push_chain_full(enc[lo:lo + ln], tins[k])), k
 
 
-@pytest.mark.parametrize("form", [1, 4])
+@pytest.mark.parametrize("form", [1, 2, 4])
 def test_ram_builder_chain_forms(ctx, oracle, form):
     """the RAM builder's chain path (queries encoded on the fly, the sorted side through the permutation, capacity words +
     instance-end tails as outputs) in the lane and quad forms: a ragged batch of blocks against the oracle"""

@@ -16,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-FORMS = [16, 4, 1]
+FORMS = [16, 4, 2, 1]
 
 
 @pytest.fixture(scope="module")
