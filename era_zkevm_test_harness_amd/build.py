@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libzkw.so")
-SOURCES = ["zkw_api.hip", "zkw_block.hip", "zkw_recursion.hip", "zkw_comm.hip", "zkw_vm_trace.hip", "sort.hip"]
+SOURCES = ["zkw_api.hip", "zkw_sorters.hip", "zkw_precompiles.hip", "zkw_setup.hip", "zkw_block.hip", "zkw_recursion.hip", "zkw_comm.hip", "zkw_vm_trace.hip",
+           "sort.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

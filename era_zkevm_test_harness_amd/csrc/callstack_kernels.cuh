@@ -38,7 +38,7 @@ __device__ __forceinline__ void encode_callstack_entry(const zkw_callstack_entry
     o[31] = (u64)e.aux_heap_bound | ((u64)((len >> 16) & 0xFF) << 32) | ((u64)(len >> 24) << 40);
 }
 
-__global__ __launch_bounds__(64) void k_encode_callstack(const zkw_callstack_entry* __restrict__ e, size_t n, u64* __restrict__ enc) {
+static __global__ __launch_bounds__(64) void k_encode_callstack(const zkw_callstack_entry* __restrict__ e, size_t n, u64* __restrict__ enc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 o[32];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64) void k_encode_callstack(const zkw_callstack_ent
 
 // meta[0] = number of pushes, meta[1] = maximum depth, meta[2] = error (1: pop from the empty stack)
 // One workgroup of 1024 lanes walks the operations in tiles, carrying (depth, push count) across tiles.
-__global__ __launch_bounds__(1024) void k_stack_depth(const uint8_t* __restrict__ is_push, size_t n, u32* __restrict__ depth_after,
+static __global__ __launch_bounds__(1024) void k_stack_depth(const uint8_t* __restrict__ is_push, size_t n, u32* __restrict__ depth_after,
                                                       u32* __restrict__ push_rank, u32* __restrict__ meta) {
     __shared__ int s_d[1024];
     __shared__ u32 s_p[1024];
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(1024) void k_stack_depth(const uint8_t* __restrict_
     if (t == 0) { meta[0] = carry_p; meta[1] = max_d; meta[2] = err; }
 }
 
-__global__ __launch_bounds__(256) void k_stack_push_keys(const uint8_t* __restrict__ is_push, size_t n, const u32* __restrict__ depth_after,
+static __global__ __launch_bounds__(256) void k_stack_push_keys(const uint8_t* __restrict__ is_push, size_t n, const u32* __restrict__ depth_after,
                                                          const u32* __restrict__ push_rank, u32* __restrict__ push_depth,
                                                          u32* __restrict__ push_id) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,7 +113,7 @@ __device__ __forceinline__ u32 stack_find(const u32* sorted_depth, const u32* so
 }
 
 // per operation: for a push its parent node, for a pop the node it removes
-__global__ __launch_bounds__(256) void k_stack_links(const uint8_t* __restrict__ is_push, size_t n, const u32* __restrict__ depth_after,
+static __global__ __launch_bounds__(256) void k_stack_links(const uint8_t* __restrict__ is_push, size_t n, const u32* __restrict__ depth_after,
                                                      const u32* __restrict__ push_rank, const u32* __restrict__ sorted_depth,
                                                      const u32* __restrict__ sorted_id, const u32* __restrict__ meta,
                                                      u32* __restrict__ parent, u32* __restrict__ op_node) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_stack_links(const uint8_t* __restrict__
 }
 
 // all nodes of depth d: rounds[k] = the 4 sponge states of absorbing enc(entry k) into the parent's state
-__global__ __launch_bounds__(64) void k_stack_level(const zkw_callstack_entry* __restrict__ pushed, const u32* __restrict__ push_depth,
+static __global__ __launch_bounds__(64) void k_stack_level(const zkw_callstack_entry* __restrict__ pushed, const u32* __restrict__ push_depth,
                                                     const u32* __restrict__ parent, const u32* __restrict__ meta, u32 d,
                                                     u64* __restrict__ rounds) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void k_stack_level(const zkw_callstack_entry* _
     }
 }
 
-__global__ __launch_bounds__(256) void k_stack_emit(const uint8_t* __restrict__ is_push, size_t n, const u32* __restrict__ depth_after,
+static __global__ __launch_bounds__(256) void k_stack_emit(const uint8_t* __restrict__ is_push, size_t n, const u32* __restrict__ depth_after,
                                                     const u32* __restrict__ parent, const u32* __restrict__ op_node,
                                                     const u64* __restrict__ rounds, const u32* __restrict__ meta,
                                                     u64* __restrict__ previous_state, u64* __restrict__ new_state,

@@ -9,7 +9,7 @@
 namespace zkw {
 
 // sort keys: timestamp and the four 64-bit halves of the hash (least significant first)
-__global__ void k_decommit_sort_keys(const zkw_decommit_query* __restrict__ q, size_t n, u32* __restrict__ ts,
+static __global__ void k_decommit_sort_keys(const zkw_decommit_query* __restrict__ q, size_t n, u32* __restrict__ ts,
                                      u64* __restrict__ h0, u64* __restrict__ h1, u64* __restrict__ h2,
                                      u64* __restrict__ h3, u32* __restrict__ iota) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -23,7 +23,7 @@ __global__ void k_decommit_sort_keys(const zkw_decommit_query* __restrict__ q, s
     iota[i] = (u32)i;
 }
 
-__global__ __launch_bounds__(256) void k_decommit_gather_encode(const zkw_decommit_query* __restrict__ q,
+static __global__ __launch_bounds__(256) void k_decommit_gather_encode(const zkw_decommit_query* __restrict__ q,
                                                                 const u32* __restrict__ perm, size_t n,
                                                                 zkw_decommit_query* __restrict__ sorted_q,
                                                                 u64* __restrict__ sorted_enc) {
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_decommit_gather_encode(const zkw_decomm
 // one workgroup: inclusive prefix count of is_fresh over the sorted requests, index of the latest fresh
 // request at or before each position, the reference's ordering self-check (:99-114), and the compaction
 // of the fresh requests (= the deduplicated queue, :121-140)
-__global__ __launch_bounds__(1024) void k_decommit_dedup(const zkw_decommit_query* __restrict__ sorted_q,
+static __global__ __launch_bounds__(1024) void k_decommit_dedup(const zkw_decommit_query* __restrict__ sorted_q,
                                                          const u64* __restrict__ sorted_enc, size_t n,
                                                          u32* __restrict__ fresh_count /* [n] inclusive */,
                                                          u32* __restrict__ last_fresh /* [n] */,
@@ -132,7 +132,7 @@ __device__ __forceinline__ void dedup_state_at(const DecommitBlock& b, u32 cnt, 
     qs12(s, b.dedup_in.head, cnt ? b.dedup_tails + 12 * (size_t)(cnt - 1) : b.dedup_in.tail, b.dedup_in.length + cnt);
 }
 
-__global__ void k_decommit_instances(const DecommitBlock* __restrict__ blk) {
+static __global__ void k_decommit_instances(const DecommitBlock* __restrict__ blk) {
     const DecommitBlock& b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;

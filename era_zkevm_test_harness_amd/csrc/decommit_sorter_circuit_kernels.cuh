@@ -151,7 +151,7 @@ __device__ __forceinline__ void ds_prev_result_queue(const DsSynthJob& job, cons
 // ------------------------------------------------------------------------------------------------
 // Poseidon2 rows: WHICH 0 = PU (pop unsorted), 1 = PS (pop sorted), 2 = PR (push into the deduplicated queue)
 template <int WHICH>
-__global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     for (int t = threadIdx.x; t < 256; t += blockDim.x) sh_hist[t] = 0;
     __syncthreads();
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob* __res
 #define DS_XG(col, v) TR(col, row) = glob.v;
 
 template <int ROW>
-__global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __restric
 }
 
 // the zero padding below the boundary rows and the multiplicity column (see k_ram_fill_tail)
-__global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const DsSynthJob& job = jobs[blockIdx.y];
     u64* trace = job.trace;
     const int col = blockIdx.x / TAIL_CHUNKS, ch = blockIdx.x % TAIL_CHUNKS;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* __restri
 }
 
 // runs after everything else (same stream): BND_IN, BND_OUT, the flush permutation PF, PI
-__global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const DsSynthJob& job = jobs[blockIdx.x];
     if (threadIdx.x != 0) return;
     u64* trace = job.trace;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __res
 }
 
 // fresh_prefix[k] = fresh requests among sorted[0, k), k = 0..n. One workgroup, tiles of 1024.
-__global__ __launch_bounds__(1024) void k_ds_fresh_prefix(const zkw_decommit_query* __restrict__ sorted_q, size_t n, u32* __restrict__ prefix) {
+static __global__ __launch_bounds__(1024) void k_ds_fresh_prefix(const zkw_decommit_query* __restrict__ sorted_q, size_t n, u32* __restrict__ prefix) {
     __shared__ u32 s[1024];
     __shared__ u32 carry;
     const int t = threadIdx.x;

@@ -5,10 +5,11 @@
 // global round e is located by binary search in the prefix sums of rounds per request.
 #pragma once
 #include "storage_kernels.cuh"
+#include "decommit_kernels.cuh"  // qs12
 
 namespace zkw {
 
-__constant__ u32 c_sha_k[64] = {
+static __constant__ u32 c_sha_k[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
     0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
     0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
@@ -54,7 +55,7 @@ struct DecommitterJob {
 
 // one lane per request: SHA-256 over its bytecode (two big-endian words per block, padding in the last
 // block, decommit_code.rs:286-320), every round's state kept; digest compared with the request's hash
-__global__ __launch_bounds__(64) void k_decommitter_sha(DecommitterJob job) {
+static __global__ __launch_bounds__(64) void k_decommitter_sha(DecommitterJob job) {
     const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= job.n_requests) return;
     const zkw_decommit_query q = job.requests[k];
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(64) void k_decommitter_sha(DecommitterJob job) {
 }
 
 // one lane per code word: the memory write it becomes (decommit_code.rs:47-78) and its encoding
-__global__ __launch_bounds__(256) void k_decommitter_mem_queries(DecommitterJob job, u64 total_words) {
+static __global__ __launch_bounds__(256) void k_decommitter_mem_queries(DecommitterJob job, u64 total_words) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total_words) return;
     u64 lo = 0, hi = job.n_requests;  // largest k with word_offsets[k] <= i
@@ -139,7 +140,7 @@ struct DecommitterBlock {
     u32 capacity;
 };
 
-__global__ void k_decommitter_instances(const DecommitterBlock* __restrict__ blk) {
+static __global__ void k_decommitter_instances(const DecommitterBlock* __restrict__ blk) {
     const DecommitterBlock& b = *blk;
     const u64 n_inst = (b.total_rounds + b.capacity - 1) / b.capacity, nreq = b.job.n_requests;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,14 +200,14 @@ __global__ void k_decommitter_instances(const DecommitterBlock* __restrict__ blk
 // L1 messages hasher (compute_linear_keccak256, data_hasher_and_merklizer.rs:8-67): one Keccak-256 sponge
 // over n * 88 bytes. The sponge is serial; one wave runs it with lane x+5y holding lane (x, y) of the state
 // (theta / rho-pi / chi through ds_bpermute-free LDS-less shuffles), the message bytes are produced on the fly.
-__constant__ u64 c_keccak_rc[24] = {
+static __constant__ u64 c_keccak_rc[24] = {
     0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
     0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
     0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
     0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
     0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
     0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-__constant__ int c_keccak_rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+static __constant__ int c_keccak_rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
 
 __device__ __forceinline__ u64 rol64(u64 x, int r) { return r ? (x << r) | (x >> (64 - r)) : x; }
 
@@ -254,7 +255,7 @@ __device__ __forceinline__ u32 l1_message_byte(const zkw_log_query* q, size_t po
 // Batch form: workgroup b hashes the messages [msg_off[b], msg_off[b + 1]) into out + 32 b, its round records start at
 // rounds + round_off[b] (msg_off == nullptr: one queue of n messages). The queues of a batch run side by side — the chain of
 // one queue stays serial.
-__global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_query* __restrict__ q, size_t n, uint8_t* __restrict__ out,
+static __global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_query* __restrict__ q, size_t n, uint8_t* __restrict__ out,
                                                          zkw_keccak_round_record* __restrict__ rounds,
                                                          const u64* __restrict__ msg_off, const u64* __restrict__ round_off) {
     __shared__ u64 A[25], Bm[25], Cc[5];

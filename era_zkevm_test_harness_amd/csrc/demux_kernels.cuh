@@ -25,7 +25,7 @@ __device__ __forceinline__ int demux_route(const zkw_log_query& q, const zkw_dem
 
 // one workgroup, two sweeps: (1) totals per route -> queue offsets; (2) inclusive prefix counts per route,
 // scatter of the routed items and their encodings
-__global__ __launch_bounds__(1024) void k_demux_route(const zkw_log_query* __restrict__ q, const u64* __restrict__ in_enc,
+static __global__ __launch_bounds__(1024) void k_demux_route(const zkw_log_query* __restrict__ q, const u64* __restrict__ in_enc,
                                                       size_t n, zkw_demux_params params,
                                                       u32* __restrict__ route_count /* [6][n] inclusive */,
                                                       zkw_log_query* __restrict__ out_q, u64* __restrict__ out_enc,
@@ -113,7 +113,7 @@ struct DemuxBlock {
     u32 capacity;
 };
 
-__global__ void k_demux_instances(const DemuxBlock* __restrict__ blk) {
+static __global__ void k_demux_instances(const DemuxBlock* __restrict__ blk) {
     const DemuxBlock b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -9,7 +9,7 @@
 
 namespace zkw {
 
-__global__ void k_events_sort_keys(const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ key,
+static __global__ void k_events_sort_keys(const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ key,
                                    u32* __restrict__ iota) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -35,7 +35,7 @@ __device__ __forceinline__ void store_enc20(u64* dst, const u64 e[20]) {
     for (int k = 0; k < 10; k++) o[k] = make_ulonglong2(e[2 * k], e[2 * k + 1]);
 }
 
-__global__ __launch_bounds__(256) void k_log_gather_encode(const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
+static __global__ __launch_bounds__(256) void k_log_gather_encode(const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
                                                            size_t n, zkw_log_query* __restrict__ sorted_q,
                                                            u64* __restrict__ sorted_enc) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,7 +56,7 @@ __device__ __forceinline__ bool same_words(const u32* a, const u32* b, int n) {
 
 // one workgroup: kept flags + inclusive prefix count, the reference's asserts (:344-356, :512-533), and the
 // compaction of the kept items into normalised result records (:541-553) with their encodings
-__global__ __launch_bounds__(1024) void k_events_dedup(const zkw_log_query* __restrict__ sorted_q, size_t n,
+static __global__ __launch_bounds__(1024) void k_events_dedup(const zkw_log_query* __restrict__ sorted_q, size_t n,
                                                        u32* __restrict__ kept_count /* [n] inclusive */,
                                                        zkw_log_query* __restrict__ result_q, u64* __restrict__ result_enc,
                                                        u32* __restrict__ totals /* [2]: n_result, violations */) {
@@ -139,7 +139,7 @@ __device__ __forceinline__ void qs4(zkw_queue_state4& s, const u64* head, const 
     s._pad = 0;
 }
 
-__global__ void k_events_instances(const EventsBlock* __restrict__ blk) {
+static __global__ void k_events_instances(const EventsBlock* __restrict__ blk) {
     const EventsBlock& b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;

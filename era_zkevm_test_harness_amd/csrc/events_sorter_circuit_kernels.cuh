@@ -146,7 +146,7 @@ __device__ __forceinline__ void es_queue_op(u64* trace, size_t n_rows, size_t r1
 
 // WHICH 0 = unsorted pop (U1..U3), 1 = sorted pop (S1..S3), 2 = result push (R1..R3)
 template <int WHICH>
-__global__ __launch_bounds__(64) void k_es_fill_queue(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(64) void k_es_fill_queue(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const EsSynthJob& job = jobs[blockIdx.y];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t rs = ES_REGION_STRIDE(capacity);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64) void k_es_fill_queue(const EsSynthJob* __restri
 #define ES_XG(col, v) TR(col, row) = glob.v;
 
 template <int ROW>
-__global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __restric
     hist_flush(sh_hist, job.hist);
 }
 
-__global__ __launch_bounds__(256) void k_es_fill_tail(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_es_fill_tail(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const EsSynthJob& job = jobs[blockIdx.y];
     u64* trace = job.trace;
     const int col = blockIdx.x / TAIL_CHUNKS, ch = blockIdx.x % TAIL_CHUNKS;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_es_fill_tail(const EsSynthJob* __restri
 }
 
 // BND_IN, BND_OUT, the flush permutations F1..F3, PI (runs last on the stream: reads the last cycle's rows)
-__global__ __launch_bounds__(64) void k_es_fill_boundary(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(64) void k_es_fill_boundary(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const EsSynthJob& job = jobs[blockIdx.x];
     if (threadIdx.x != 0) return;
     u64* trace = job.trace;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64) void k_es_fill_boundary(const EsSynthJob* __res
 
 // kept_prefix[k] = #{ j < k : record j is a forward record whose successor has another timestamp }, k = 0..n
 // (a record without a successor is never counted: it is flushed at the very end). One workgroup, tiles of 1024.
-__global__ __launch_bounds__(1024) void k_es_kept_prefix(const zkw_log_query* __restrict__ sorted_q, size_t n, u32* __restrict__ prefix) {
+static __global__ __launch_bounds__(1024) void k_es_kept_prefix(const zkw_log_query* __restrict__ sorted_q, size_t n, u32* __restrict__ prefix) {
     __shared__ u32 s[1024];
     __shared__ u32 carry;
     const int t = threadIdx.x;

@@ -17,11 +17,11 @@
 
 namespace zkw {
 
-__constant__ rc_term c_ld_terms[LD_NUM_TERMS] = LD_TERMS_INIT;
-__constant__ rc_constraint c_ld_cons[LD_NUM_CONSTRAINTS] = LD_CONSTRAINTS_INIT;
-__constant__ uint16_t c_ld_row_first[LD_NUM_ROW_TYPES + 1] = LD_ROW_FIRST_CONSTRAINT_INIT;
-__constant__ uint8_t c_ld_is_poseidon[LD_NUM_ROW_TYPES] = LD_ROW_IS_POSEIDON_INIT;
-__constant__ rc_link c_ld_links[LD_NUM_LINKS] = LD_LINKS_INIT;
+static __constant__ rc_term c_ld_terms[LD_NUM_TERMS] = LD_TERMS_INIT;
+static __constant__ rc_constraint c_ld_cons[LD_NUM_CONSTRAINTS] = LD_CONSTRAINTS_INIT;
+static __constant__ uint16_t c_ld_row_first[LD_NUM_ROW_TYPES + 1] = LD_ROW_FIRST_CONSTRAINT_INIT;
+static __constant__ uint8_t c_ld_is_poseidon[LD_NUM_ROW_TYPES] = LD_ROW_IS_POSEIDON_INIT;
+static __constant__ rc_link c_ld_links[LD_NUM_LINKS] = LD_LINKS_INIT;
 struct SpecLogDemux {  // LogDemuxer, circuit type 4
     static constexpr int G = LD_G, L = LD_L, ROWS_PER_CYCLE = LD_ROWS_PER_CYCLE, NUM_ROW_TYPES = LD_NUM_ROW_TYPES, NUM_LINKS = LD_NUM_LINKS;
     static constexpr int OFF_BIN = LD_ROWOFF_BND_IN, OFF_BOUT = LD_ROWOFF_BND_OUT;
@@ -94,7 +94,7 @@ __device__ __forceinline__ int ld_route(const LdSynthJob& job, const LdCycle& c)
 
 // WHICH 0 = pop of the input queue (I1..I3), 1 = the conditional push (P1..P3)
 template <int WHICH>
-__global__ __launch_bounds__(64) void k_ld_fill_queue(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(64) void k_ld_fill_queue(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const LdSynthJob& job = jobs[blockIdx.y];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t rs = LD_REGION_STRIDE(capacity);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void k_ld_fill_queue(const LdSynthJob* __restri
 #define LD_QUEUES(M) M(st, 0) M(ev, 1) M(l1, 2) M(kc, 3) M(sh, 4) M(ec, 5)
 
 template <int ROW>
-__global__ __launch_bounds__(256) void k_ld_fill_row(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ld_fill_row(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_ld_fill_row(const LdSynthJob* __restric
     hist_flush(sh_hist, job.hist);
 }
 
-__global__ __launch_bounds__(256) void k_ld_fill_tail(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ld_fill_tail(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const LdSynthJob& job = jobs[blockIdx.y];
     u64* trace = job.trace;
     const int col = blockIdx.x / TAIL_CHUNKS, ch = blockIdx.x % TAIL_CHUNKS;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_ld_fill_tail(const LdSynthJob* __restri
 }
 
 // BND_IN, BND_OUT, PI (runs last on the stream: reads the last cycle's row Q)
-__global__ __launch_bounds__(64) void k_ld_fill_boundary(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(64) void k_ld_fill_boundary(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const LdSynthJob& job = jobs[blockIdx.x];
     if (threadIdx.x != 0) return;
     u64* trace = job.trace;

@@ -140,7 +140,7 @@ __device__ __forceinline__ void nl_eval_sel(u32 fn, u32 k, u32 a0, u32 a1, u32 a
 // 3.35 ms per 8 SHA-256 instances. The walk is bound by the latency of its dependent LDS reads, which two waves per SIMD hide
 // from each other and one wave per SIMD does not; CPW below is what is left of that experiment.)
 template <int W, int R, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
+static __global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
     constexpr int CPW = 1, NL_FILL_WAVES = WAVES, NL_FILL_THREADS = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr u32 LW = 64 / CPW;                             // lanes that share a cycle
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __restrict_
 constexpr int NL_HIST_THREADS = 1024;
 constexpr int NL_HIST_HALF = 32768;
 template <int R>
-__global__ __launch_bounds__(NL_HIST_THREADS) void k_nl_hist(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(NL_HIST_THREADS) void k_nl_hist(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
     const NlJob job = jobs[blockIdx.z];
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(NL_HIST_THREADS) void k_nl_hist(const NlDev* __rest
 }
 
 // the multiplicity column (sum of a table's slices), boundary rows (BND_IN, BND_OUT) and the public input row
-__global__ __launch_bounds__(256) void k_nl_finish(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_nl_finish(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
     const NlJob job = jobs[blockIdx.y];
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void k_nl_finish(const NlDev* __restrict__ dev
 
 // ---- round records -> the engine's inputs. SHA-like: 64-byte blocks, state 8 words as 64 nibbles; Keccak-like: 136 / 200 bytes
 struct NlPrepJob { const void* rounds; u64 first_round; u32 n_active; uint8_t* hdr_bits; uint8_t* free_elems; uint8_t* state_before; };
-__global__ __launch_bounds__(128) void k_nl_prepare_sha(const NlPrepJob* __restrict__ jobs, u32 capacity) {
+static __global__ __launch_bounds__(128) void k_nl_prepare_sha(const NlPrepJob* __restrict__ jobs, u32 capacity) {
     const NlPrepJob j = jobs[blockIdx.y];
     const zkw_sha256_round_record* rounds = static_cast<const zkw_sha256_round_record*>(j.rounds);
     const u32 c = blockIdx.x, t = threadIdx.x;  // c in [0, capacity]: the state BEFORE cycle c
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(128) void k_nl_prepare_sha(const NlPrepJob* __restr
     j.free_elems[(size_t)c * 128 + t] = (uint8_t)((t & 1) ? b >> 4 : b & 15);
     if (t == 0) j.hdr_bits[c] = active ? (rounds[j.first_round + c].reset ? 1 : 0) : 2;
 }
-__global__ __launch_bounds__(256) void k_nl_prepare_keccak(const NlPrepJob* __restrict__ jobs, u32 capacity) {
+static __global__ __launch_bounds__(256) void k_nl_prepare_keccak(const NlPrepJob* __restrict__ jobs, u32 capacity) {
     const NlPrepJob j = jobs[blockIdx.y];
     const zkw_keccak_round_record* rounds = static_cast<const zkw_keccak_round_record*>(j.rounds);
     const u32 c = blockIdx.x, t = threadIdx.x;
@@ -544,7 +544,7 @@ __device__ u64 nl_home_cell(const nl_spec& S, const u64* __restrict__ trace, siz
 }
 
 // grid (chunks of items, capacity * steps_per_cycle): one lane per lookup / gate / row of a step instance
-__global__ __launch_bounds__(256) void k_nl_check_steps(const NlDev* __restrict__ devp, const u64* __restrict__ trace, u32 capacity, size_t n_rows,
+static __global__ __launch_bounds__(256) void k_nl_check_steps(const NlDev* __restrict__ devp, const u64* __restrict__ trace, u32 capacity, size_t n_rows,
                                                         u32* __restrict__ hist, CheckResult* res) {
     const nl_spec& S = devp->s;
     const u32 c = blockIdx.y / S.steps_per_cycle, s = blockIdx.y % S.steps_per_cycle;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void k_nl_check_steps(const NlDev* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_nl_check_tail(const NlDev* __restrict__ devp, const u64* __restrict__ trace, u32 capacity, size_t n_rows,
+static __global__ __launch_bounds__(256) void k_nl_check_tail(const NlDev* __restrict__ devp, const u64* __restrict__ trace, u32 capacity, size_t n_rows,
                                                        const u32* __restrict__ hist, CheckResult* res) {
     const nl_spec& S = devp->s;
     const size_t bnd = NL_BOUNDARY_ROW(&S, capacity), brows = NL_BND_ROWS(&S);

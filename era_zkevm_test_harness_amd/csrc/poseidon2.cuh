@@ -20,8 +20,8 @@ namespace p2 {
 using gl::u32;
 using gl::u64;
 
-__constant__ u64 c_rc[P2_TOTAL_ROUNDS * P2_WIDTH] = P2_ROUND_CONSTANTS_INIT;
-__constant__ u32 c_shift[P2_WIDTH] = P2_INTERNAL_DIAG_SHIFTS_INIT;
+static __constant__ u64 c_rc[P2_TOTAL_ROUNDS * P2_WIDTH] = P2_ROUND_CONSTANTS_INIT;
+static __constant__ u32 c_shift[P2_WIDTH] = P2_INTERNAL_DIAG_SHIFTS_INIT;
 
 __host__ __device__ __forceinline__ u64 rc_at(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)

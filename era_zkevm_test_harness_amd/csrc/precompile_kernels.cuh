@@ -47,7 +47,7 @@ __device__ __forceinline__ void precompile_request_shape(int kind, const zkw_log
 
 // offsets[0..3][n+1]: exclusive prefix sums of rounds, queries, reads. meta[0..3] = totals, meta[3] = error
 // (a request without rounds). One workgroup walks the requests in tiles of 1024.
-__global__ __launch_bounds__(1024) void k_precompile_counts(int kind, const zkw_log_query* __restrict__ requests, size_t n,
+static __global__ __launch_bounds__(1024) void k_precompile_counts(int kind, const zkw_log_query* __restrict__ requests, size_t n,
                                                             u64* __restrict__ round_off, u64* __restrict__ query_off,
                                                             u64* __restrict__ read_off, u64* __restrict__ meta) {
     __shared__ u64 s[3][1024];
@@ -115,7 +115,7 @@ __device__ __forceinline__ void word_be_bytes(const u32* limbs, uint8_t out[32])
 }
 
 // one lane per request
-__global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
+static __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= job.n_requests) return;
     const zkw_log_query request = job.requests[r];
@@ -291,7 +291,7 @@ struct PrecompileBlock {
     u32 capacity;
 };
 
-__global__ void k_precompile_instances(const PrecompileBlock* __restrict__ blk) {
+static __global__ void k_precompile_instances(const PrecompileBlock* __restrict__ blk) {
     const PrecompileBlock& b = *blk;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= b.n_instances) return;

@@ -38,7 +38,7 @@ __device__ inline void commit_var_length(const u64* enc, int n, u64 out[4]) {
     for (int k = 0; k < 4; k++) out[k] = gl::canon(s[k]);
 }
 
-__global__ __launch_bounds__(64) void k_commit_encodings(const u64* __restrict__ enc, size_t n_items, u32 item_len,
+static __global__ __launch_bounds__(64) void k_commit_encodings(const u64* __restrict__ enc, size_t n_items, u32 item_len,
                                                          u64* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
@@ -69,7 +69,7 @@ __device__ inline int ram_encode_fsm(const zkw_ram_fsm& f, u64* o) {
 
 // lane = 4 * instance + part; part 0: observable input of the block's FIRST instance, 1: flags + empty output,
 // 2: hidden FSM input, 3: hidden FSM output
-__global__ __launch_bounds__(64) void k_ram_commitments(const zkw_ram_instance* __restrict__ inst, size_t n,
+static __global__ __launch_bounds__(64) void k_ram_commitments(const zkw_ram_instance* __restrict__ inst, size_t n,
                                                         u64* __restrict__ compact) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t i = t >> 2;
@@ -116,7 +116,7 @@ __device__ inline int ds_encode_fsm(const zkw_decommit_sorter_fsm& f, u64* o) {
     o[m++] = f.first_encountered_timestamp;
     return m;
 }
-__global__ __launch_bounds__(64) void k_ds_commitments(const zkw_decommit_sorter_instance* __restrict__ inst, size_t n,
+static __global__ __launch_bounds__(64) void k_ds_commitments(const zkw_decommit_sorter_instance* __restrict__ inst, size_t n,
                                                        u64* __restrict__ compact) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t i = t >> 2;
@@ -362,7 +362,7 @@ template <> struct CfLanes<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>> { static cons
 template <> struct CfLanes<CfStorageApplication> { static constexpr int value = 32; };
 
 template <class T>
-__global__ __launch_bounds__(CfLanes<T>::value) void k_closed_form_commitments(const typename T::Inst* __restrict__ inst, size_t n,
+static __global__ __launch_bounds__(CfLanes<T>::value) void k_closed_form_commitments(const typename T::Inst* __restrict__ inst, size_t n,
                                                                                u64* __restrict__ compact) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t i = t >> 2;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(CfLanes<T>::value) void k_closed_form_commitments(c
     for (int k = 0; k < 4; k++) cf[at + k] = c[k];
 }
 
-__global__ __launch_bounds__(64) void k_encode_recursion(u64 circuit_type, const u64* __restrict__ pi, size_t n,
+static __global__ __launch_bounds__(64) void k_encode_recursion(u64 circuit_type, const u64* __restrict__ pi, size_t n,
                                                          u64* __restrict__ enc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

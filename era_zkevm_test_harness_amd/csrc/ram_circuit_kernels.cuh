@@ -121,7 +121,7 @@ __device__ __forceinline__ void fill_flattened_poseidon(u64* trace, size_t n_row
 // Poseidon2 rows (regions PU and PS): one lane per cycle runs the permutation and stores all 130
 // flattened-gate variables as it goes. SIDE 0 = unsorted queue, 1 = sorted queue.
 template <int SIDE>
-__global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __restrict__ jobs, u32 capacity,
+static __global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __restrict__ jobs, u32 capacity,
                                                           size_t n_rows) {
     __shared__ u32 sh_hist[256];
     for (int t = threadIdx.x; t < 256; t += blockDim.x) sh_hist[t] = 0;
@@ -223,7 +223,7 @@ __device__ __forceinline__ u64 acc_before(const u64* z, size_t first, size_t m, 
     return i == 0 ? fsm_in : z[first + (i - 1 < m ? i - 1 : m - 1)];
 }
 
-__global__ __launch_bounds__(256) void k_ram_fill_A(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ram_fill_A(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_ram_fill_A(const SynthJob* __restrict__
     hist_flush(sh_hist, job.hist);
 }
 
-__global__ __launch_bounds__(256) void k_ram_fill_B(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ram_fill_B(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -312,7 +312,7 @@ __device__ __forceinline__ bool nd_flag(bool can_pop, const zkw_mem_query& q) {
 }
 
 // per 256-cycle tile: number of nondeterministic writes; then an exclusive scan per instance
-__global__ __launch_bounds__(256) void k_ram_nd_tiles(const SynthJob* __restrict__ jobs, u32 capacity) {
+static __global__ __launch_bounds__(256) void k_ram_nd_tiles(const SynthJob* __restrict__ jobs, u32 capacity) {
     __shared__ u32 sh[4];
     const SynthJob job = jobs[blockIdx.y];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_ram_nd_tiles(const SynthJob* __restrict
     __syncthreads();
     if (threadIdx.x == 0) job.nd_tiles[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ __launch_bounds__(64) void k_ram_nd_scan(const SynthJob* __restrict__ jobs, int n_jobs, u32 n_tiles) {
+static __global__ __launch_bounds__(64) void k_ram_nd_scan(const SynthJob* __restrict__ jobs, int n_jobs, u32 n_tiles) {
     // one wave per job: exclusive prefix over the tile counts, 64 tiles at a time
     u32* t = jobs[blockIdx.x].nd_tiles;
     const int lane = threadIdx.x;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64) void k_ram_nd_scan(const SynthJob* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     __shared__ u32 sh_wave[4];
     sh_hist[threadIdx.x] = 0;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __restrict__
     hist_flush(sh_hist, job.hist);
 }
 
-__global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SynthJob job = jobs[blockIdx.y];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t rs = RC_REGION_STRIDE(capacity);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__
 // runs at 3.9 TB/s, this at 5.6, tools/ubench_fill.hip). The last TAIL_CHUNKS blocks of a job do the multiplicity
 // column. grid.y = job.
 constexpr int TAIL_CHUNKS = 8;
-__global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SynthJob job = jobs[blockIdx.y];
     u64* trace = job.trace;
     const int col = blockIdx.x / TAIL_CHUNKS, ch = blockIdx.x % TAIL_CHUNKS;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restric
 }
 
 // runs after k_ram_fill_tail (same stream): the three boundary rows
-__global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SynthJob job = jobs[blockIdx.x];
     if (threadIdx.x != 0) return;
     const u64* lhs_z_all = job.lhs_z;
@@ -570,16 +570,16 @@ __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __rest
 // Satisfiability check, generic over a spec (include/zkw_*_circuit_spec.h): the tables live in constant memory; a
 // block stages 64 consecutive rows of one region (all 148 general + lookup columns) in LDS, then each lane
 // interprets its row's constraints; Poseidon2 rows are recomputed from their 12 inputs.
-__constant__ rc_term c_terms[RC_NUM_TERMS] = RC_TERMS_INIT;
-__constant__ rc_constraint c_cons[RC_NUM_CONSTRAINTS] = RC_CONSTRAINTS_INIT;
-__constant__ uint16_t c_row_first[RC_NUM_ROW_TYPES + 1] = RC_ROW_FIRST_CONSTRAINT_INIT;
-__constant__ uint8_t c_is_poseidon[RC_NUM_ROW_TYPES] = RC_ROW_IS_POSEIDON_INIT;
-__constant__ rc_link c_links[RC_NUM_LINKS] = RC_LINKS_INIT;
-__constant__ rc_term c_ds_terms[DS_NUM_TERMS] = DS_TERMS_INIT;
-__constant__ rc_constraint c_ds_cons[DS_NUM_CONSTRAINTS] = DS_CONSTRAINTS_INIT;
-__constant__ uint16_t c_ds_row_first[DS_NUM_ROW_TYPES + 1] = DS_ROW_FIRST_CONSTRAINT_INIT;
-__constant__ uint8_t c_ds_is_poseidon[DS_NUM_ROW_TYPES] = DS_ROW_IS_POSEIDON_INIT;
-__constant__ rc_link c_ds_links[DS_NUM_LINKS] = DS_LINKS_INIT;
+static __constant__ rc_term c_terms[RC_NUM_TERMS] = RC_TERMS_INIT;
+static __constant__ rc_constraint c_cons[RC_NUM_CONSTRAINTS] = RC_CONSTRAINTS_INIT;
+static __constant__ uint16_t c_row_first[RC_NUM_ROW_TYPES + 1] = RC_ROW_FIRST_CONSTRAINT_INIT;
+static __constant__ uint8_t c_is_poseidon[RC_NUM_ROW_TYPES] = RC_ROW_IS_POSEIDON_INIT;
+static __constant__ rc_link c_links[RC_NUM_LINKS] = RC_LINKS_INIT;
+static __constant__ rc_term c_ds_terms[DS_NUM_TERMS] = DS_TERMS_INIT;
+static __constant__ rc_constraint c_ds_cons[DS_NUM_CONSTRAINTS] = DS_CONSTRAINTS_INIT;
+static __constant__ uint16_t c_ds_row_first[DS_NUM_ROW_TYPES + 1] = DS_ROW_FIRST_CONSTRAINT_INIT;
+static __constant__ uint8_t c_ds_is_poseidon[DS_NUM_ROW_TYPES] = DS_ROW_IS_POSEIDON_INIT;
+static __constant__ rc_link c_ds_links[DS_NUM_LINKS] = DS_LINKS_INIT;
 
 struct SpecRam {  // RAMPermutation, circuit type 8
     static constexpr int G = RC_G, L = RC_L, ROWS_PER_CYCLE = RC_ROWS_PER_CYCLE, NUM_ROW_TYPES = RC_NUM_ROW_TYPES, NUM_LINKS = RC_NUM_LINKS;
@@ -599,11 +599,11 @@ struct SpecDecommitSorter {  // CodeDecommittmentsSorter, circuit type 2
     __device__ static const uint8_t* is_poseidon() { return c_ds_is_poseidon; }
     __device__ static const rc_link* links() { return c_ds_links; }
 };
-__constant__ rc_term c_es_terms[ES_NUM_TERMS] = ES_TERMS_INIT;
-__constant__ rc_constraint c_es_cons[ES_NUM_CONSTRAINTS] = ES_CONSTRAINTS_INIT;
-__constant__ uint16_t c_es_row_first[ES_NUM_ROW_TYPES + 1] = ES_ROW_FIRST_CONSTRAINT_INIT;
-__constant__ uint8_t c_es_is_poseidon[ES_NUM_ROW_TYPES] = ES_ROW_IS_POSEIDON_INIT;
-__constant__ rc_link c_es_links[ES_NUM_LINKS] = ES_LINKS_INIT;
+static __constant__ rc_term c_es_terms[ES_NUM_TERMS] = ES_TERMS_INIT;
+static __constant__ rc_constraint c_es_cons[ES_NUM_CONSTRAINTS] = ES_CONSTRAINTS_INIT;
+static __constant__ uint16_t c_es_row_first[ES_NUM_ROW_TYPES + 1] = ES_ROW_FIRST_CONSTRAINT_INIT;
+static __constant__ uint8_t c_es_is_poseidon[ES_NUM_ROW_TYPES] = ES_ROW_IS_POSEIDON_INIT;
+static __constant__ rc_link c_es_links[ES_NUM_LINKS] = ES_LINKS_INIT;
 struct SpecEventsSorter {  // EventsSorter / L1MessagesSorter, circuit types 11 and 12
     static constexpr int G = ES_G, L = ES_L, ROWS_PER_CYCLE = ES_ROWS_PER_CYCLE, NUM_ROW_TYPES = ES_NUM_ROW_TYPES, NUM_LINKS = ES_NUM_LINKS;
     static constexpr int OFF_BIN = ES_ROWOFF_BND_IN, OFF_BOUT = ES_ROWOFF_BND_OUT;
@@ -633,7 +633,7 @@ __device__ __forceinline__ size_t spec_row(int rt, u32 capacity, u32 i) {
 }
 
 template <class S>
-__global__ __launch_bounds__(64) void k_check_rows(const u64* __restrict__ trace, u32 capacity, size_t n_rows, CheckResult* res) {
+static __global__ __launch_bounds__(64) void k_check_rows(const u64* __restrict__ trace, u32 capacity, size_t n_rows, CheckResult* res) {
     extern __shared__ __attribute__((aligned(16))) u64 tile[];  // [G + L][CHK_ROWS]
     constexpr int CHK_COLS = S::G + S::L;
     const int rt = blockIdx.y;  // row type; boundary row types are handled by block x == 0 only
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(64) void k_check_rows(const u64* __restrict__ trace
 
 // copy links: one lane per cycle walks the link table (both cells are read coalesced across lanes)
 template <class S>
-__global__ __launch_bounds__(256) void k_check_links(const u64* __restrict__ trace, u32 capacity, size_t n_rows, CheckResult* res) {
+static __global__ __launch_bounds__(256) void k_check_links(const u64* __restrict__ trace, u32 capacity, size_t n_rows, CheckResult* res) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
     const size_t rs = RC_REGION_STRIDE(capacity), bnd = (size_t)S::ROWS_PER_CYCLE * rs;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void k_check_links(const u64* __restrict__ tra
 
 // lookup columns: histogram of every cell (all n_rows), padding rows must be zero in every column
 template <class S>
-__global__ __launch_bounds__(256) void k_check_lookups(const u64* __restrict__ trace, u32 capacity, size_t n_rows,
+static __global__ __launch_bounds__(256) void k_check_lookups(const u64* __restrict__ trace, u32 capacity, size_t n_rows,
                                                        u32* __restrict__ hist, CheckResult* res) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256) void k_check_lookups(const u64* __restrict__ t
     __syncthreads();
     if (sh_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh_hist[threadIdx.x]);
 }
-__global__ void k_check_mult(const u64* __restrict__ trace, size_t n_rows, int mult_col, const u32* __restrict__ hist, CheckResult* res) {
+static __global__ void k_check_mult(const u64* __restrict__ trace, size_t n_rows, int mult_col, const u32* __restrict__ hist, CheckResult* res) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
         const u64 want = r < 256 ? hist[r] : 0;

@@ -33,7 +33,7 @@ __device__ __forceinline__ void encode_mem_query(const zkw_mem_query& q, u64 out
     out[7] = v[4];
 }
 
-__global__ __launch_bounds__(256) void k_encode_mem(const zkw_mem_query* __restrict__ q, size_t n,
+static __global__ __launch_bounds__(256) void k_encode_mem(const zkw_mem_query* __restrict__ q, size_t n,
                                                     u64* __restrict__ enc) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -101,7 +101,7 @@ struct ChainOut {
     u64* marks;
 };
 
-__global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ jobs, int n_jobs) {
+static __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ jobs, int n_jobs) {
     __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
     const int lane = threadIdx.x & 63, g = lane & 15;
     const int chain = blockIdx.x * 4 + (lane >> 4);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ 
 
 // Quad form: 16 chains per wave (p2::Coop4). Lane j of a quad loads enc[j], enc[4+j] and stores tails[j],
 // tails[4+j], tails[8+j]: 32 contiguous bytes per quad per access.
-__global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict__ jobs, int n_jobs) {
+static __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict__ jobs, int n_jobs) {
     __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
     const int lane = threadIdx.x & 63, j = lane & 3;
     const int chain = blockIdx.x * 16 + (lane >> 2);
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict
 // Pair form: 32 chains per wave (p2::Coop2). Lane j of a pair holds elements 4c + 2j, 4c + 2j + 1: it loads / stores 16
 // contiguous bytes per block of four. Half the waves of the quad form for the same queues and ~half its wave-instructions per
 // permutation: what a launch of tens of thousands of queues takes away from the trace fills it overlaps.
-__global__ __launch_bounds__(64) void k_chain_full_p2(const ChainJob* __restrict__ jobs, int n_jobs) {
+static __global__ __launch_bounds__(64) void k_chain_full_p2(const ChainJob* __restrict__ jobs, int n_jobs) {
     __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
     const int lane = threadIdx.x & 63, j = lane & 1;
     const int chain = blockIdx.x * 32 + (lane >> 1);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64) void k_chain_full_p2(const ChainJob* __restrict
 // chains take away from the trace fills they overlap: 29 k chains are 451 waves, fewer than half the SIMDs, instead of
 // 1 805 waves on every SIMD twice. Accesses are per-lane (48 B in, 32 B out per step, each lane on its own stream): a few
 // hundred bytes per wave every ~25 us.
-__global__ __launch_bounds__(64) void k_chain_full_lane(const ChainJob* __restrict__ jobs, int n_jobs) {
+static __global__ __launch_bounds__(64) void k_chain_full_lane(const ChainJob* __restrict__ jobs, int n_jobs) {
     __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
     const int chain = blockIdx.x * 64 + (threadIdx.x & 63);
     ChainJob job;
@@ -418,7 +418,7 @@ struct FsJob {
 // No per-lane arrays with run-time indices: they would live in scratch memory, and every HSA queue that ever ran the
 // kernel keeps scratch-per-lane x every wave slot of the chip (117 MB for 224 B per lane) out of the runtime's 4 GB
 // scratch aperture; with 32 hardware queues in use that exhausted it (HSA_STATUS_ERROR_OUT_OF_RESOURCES).
-__global__ void k_fs_challenges(const FsJob* __restrict__ jobs, int n_jobs, int state_w, int n_chal) {
+static __global__ void k_fs_challenges(const FsJob* __restrict__ jobs, int n_jobs, int state_w, int n_chal) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_jobs) return;
     const FsJob job = jobs[j];
@@ -489,7 +489,7 @@ __device__ __forceinline__ u64 wave_scan_mul(u64 v, int lane) {
 }
 
 template <int W, int REPS>
-__global__ __launch_bounds__(GP_BLOCK) void k_gp_local(const GpSeg* __restrict__ segs,
+static __global__ __launch_bounds__(GP_BLOCK) void k_gp_local(const GpSeg* __restrict__ segs,
                                                        const GpTile* __restrict__ tiles,
                                                        u64* __restrict__ tile_aggr /* [n_tiles_total][REPS] */) {
     __shared__ u64 sh_ch[REPS][W + 1];
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(GP_BLOCK) void k_gp_local(const GpSeg* __restrict__
 
 // exclusive scan of the tile aggregates inside each segment: one lane per (segment, repetition)
 template <int REPS>
-__global__ void k_gp_tiles(const GpSeg* __restrict__ segs, int n_segs, u64* __restrict__ tile_aggr) {
+static __global__ void k_gp_tiles(const GpSeg* __restrict__ segs, int n_segs, u64* __restrict__ tile_aggr) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_segs * REPS) return;
     const GpSeg seg = segs[j / REPS];
@@ -567,7 +567,7 @@ __global__ void k_gp_tiles(const GpSeg* __restrict__ segs, int n_segs, u64* __re
 }
 
 template <int REPS>
-__global__ __launch_bounds__(GP_BLOCK) void k_gp_apply(const GpSeg* __restrict__ segs,
+static __global__ __launch_bounds__(GP_BLOCK) void k_gp_apply(const GpSeg* __restrict__ segs,
                                                        const GpTile* __restrict__ tiles,
                                                        const u64* __restrict__ tile_prefix) {
     const GpTile t = tiles[blockIdx.x];
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(GP_BLOCK) void k_gp_apply(const GpSeg* __restrict__
 // ------------------------------------------------------------------------------------------------
 // K7 support: sort keys and the gather that applies the sorting permutation.
 // Sorting order (W/ram_permutation.rs:50-53): (page, index) then timestamp, stable.
-__global__ void k_ram_sort_keys(const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ ts,
+static __global__ void k_ram_sort_keys(const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ ts,
                                 u64* __restrict__ cell, u32* __restrict__ iota, const u64* __restrict__ seg_off,
                                 int n_segs) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -598,13 +598,13 @@ __global__ void k_ram_sort_keys(const zkw_mem_query* __restrict__ q, size_t n, u
     (void)seg_off; (void)n_segs;
 }
 
-__global__ void k_gather_u32_by_u32(const u32* __restrict__ src, const u32* __restrict__ idx, size_t n,
+static __global__ void k_gather_u32_by_u32(const u32* __restrict__ src, const u32* __restrict__ idx, size_t n,
                                     u32* __restrict__ dst) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
 }
 
-__global__ void k_gather_u64_by_u32(const u64* __restrict__ src, const u32* __restrict__ idx, size_t n,
+static __global__ void k_gather_u64_by_u32(const u64* __restrict__ src, const u32* __restrict__ idx, size_t n,
                                     u64* __restrict__ dst) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
@@ -612,7 +612,7 @@ __global__ void k_gather_u64_by_u32(const u64* __restrict__ src, const u32* __re
 
 // sorted_q[i] = q[perm[i]] and its encoding in the same pass (the sorted side never needs the
 // un-encoded query again except for the FSM snapshots, which read sorted_q).
-__global__ __launch_bounds__(256) void k_gather_encode(const zkw_mem_query* __restrict__ q,
+static __global__ __launch_bounds__(256) void k_gather_encode(const zkw_mem_query* __restrict__ q,
                                                        const u32* __restrict__ perm, size_t n,
                                                        zkw_mem_query* __restrict__ sorted_q,
                                                        u64* __restrict__ sorted_enc) {
@@ -656,7 +656,7 @@ __device__ __forceinline__ void copy12(u64* dst, const u64* src) {
 }
 
 // pass 1: count nondeterministic writes per chunk (rw && ts == 0 && page == BOOTLOADER_HEAP_PAGE)
-__global__ __launch_bounds__(256) void k_ram_count_nondet(const RamBlock* __restrict__ blocks) {
+static __global__ __launch_bounds__(256) void k_ram_count_nondet(const RamBlock* __restrict__ blocks) {
     const RamBlock b = blocks[blockIdx.y];
     const u64 n_inst = (b.n + b.capacity - 1) / b.capacity;
     __shared__ u32 sh[4];
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void k_ram_count_nondet(const RamBlock* __rest
 }
 
 // pass 2: one lane per instance
-__global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
+static __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
     const RamBlock b = blocks[blockIdx.y];
     const u64 n_inst = (b.n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -735,7 +735,7 @@ __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
 // ------------------------------------------------------------------------------------------------
 // Full tails on demand: tails[i] = permute(enc[i] || caps[i-1]) (zero capacity at the first item of a queue).
 // One item per lane; offsets[] are the queue boundaries inside the batch.
-__global__ __launch_bounds__(64) void k_tails_expand(const u64* __restrict__ enc, const u64* __restrict__ caps,
+static __global__ __launch_bounds__(64) void k_tails_expand(const u64* __restrict__ enc, const u64* __restrict__ caps,
                                                      const u64* __restrict__ offsets, int n_queues, size_t n,
                                                      u64* __restrict__ tails) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -20,8 +20,8 @@
 
 namespace zkw {
 
-__constant__ u32 c_b2s_iv[8] = {0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19};
-__constant__ uint8_t c_b2s_sigma[10][16] = {
+static __constant__ u32 c_b2s_iv[8] = {0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19};
+static __constant__ uint8_t c_b2s_sigma[10][16] = {
     {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
     {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
     {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
@@ -100,7 +100,7 @@ struct SapJob {
 };
 
 // derive_final_address: Blake2s-256(0^12 || address BE (20) || key BE (32))
-__global__ __launch_bounds__(64) void k_sap_keys(SapJob job) {
+static __global__ __launch_bounds__(64) void k_sap_keys(SapJob job) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     const zkw_log_query* q = job.queries + i;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) void k_sap_keys(SapJob job) {
 
 // One workgroup. Flags are staged in LDS tile by tile; lane 0 runs the two sequential rules (instance cuts,
 // storage_application.rs:143-165; enumeration of first writes, tree/mod.rs:305-313), all lanes write the results.
-__global__ __launch_bounds__(1024) void k_sap_scan(SapJob job) {
+static __global__ __launch_bounds__(1024) void k_sap_scan(SapJob job) {
     __shared__ uint8_t s_rw[1024], s_first[1024];
     __shared__ u32 s_chunk[1024], s_prev[1024], s_enum[1024];
     __shared__ u32 total, chunk, first_writes, prev;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(1024) void k_sap_scan(SapJob job) {
 // j*(i, L): the latest write j < i whose key first differs from key_i (from the top) at bit L. One wave per block,
 // lane = i; j is uniform across the wave so key_j is a broadcast load. The per-lane level table lives in LDS as
 // [level][lane] (bank = lane, conflict free).
-__global__ __launch_bounds__(64) void k_sap_pairs(SapJob job) {
+static __global__ __launch_bounds__(64) void k_sap_pairs(SapJob job) {
     __shared__ u32 tab[256 * 64];
     const int lane = threadIdx.x;
     const u64 i = (u64)blockIdx.x * 64 + lane;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void k_sap_pairs(SapJob job) {
 }
 
 // level 0: the leaf after the query (current tree) and the leaf before the block (pre-state check)
-__global__ __launch_bounds__(64) void k_sap_leaves(SapJob job) {
+static __global__ __launch_bounds__(64) void k_sap_leaves(SapJob job) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     const zkw_log_query* q = job.queries + i;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void sap_level_step(const SapJob& job, int L, u64 i) 
 }
 
 // Level-synchronous launches: for blocks with more storage queries than one workgroup walks (n > SAP_PERSISTENT_MAX)
-__global__ __launch_bounds__(64) void k_sap_level(SapJob job, int L) {
+static __global__ __launch_bounds__(64) void k_sap_level(SapJob job, int L) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < job.n) sap_level_step(job, L, i);
 }
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64) void k_sap_level(SapJob job, int L) {
 // is a chain of 256 dependent Blake2s pairs either way.
 constexpr int SAP_PERSISTENT_THREADS = 256;
 constexpr u64 SAP_PERSISTENT_MAX = 4 * SAP_PERSISTENT_THREADS;
-__global__ __launch_bounds__(SAP_PERSISTENT_THREADS) void k_sap_levels(SapJob job) {
+static __global__ __launch_bounds__(SAP_PERSISTENT_THREADS) void k_sap_levels(SapJob job) {
     for (int L = 0; L < 256; L++) {
         for (u64 i = threadIdx.x; i < job.n; i += SAP_PERSISTENT_THREADS) sap_level_step(job, L, i);
         __threadfence();
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(SAP_PERSISTENT_THREADS) void k_sap_levels(SapJob jo
 }
 
 // after level 255 (A0 / C0 hold the roots): root after every query + the reference's inclusion asserts
-__global__ __launch_bounds__(64) void k_sap_roots(SapJob job) {
+static __global__ __launch_bounds__(64) void k_sap_roots(SapJob job) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     bool bad = false;
@@ -290,7 +290,7 @@ __device__ __forceinline__ u32 sap_diff_byte(const SapJob& job, u64 i, int pos) 
 }
 
 // one wave: the running Keccak-256 over the writes' state diffs (two rate blocks each, :253-260)
-__global__ __launch_bounds__(64) void k_sap_keccak(SapJob job, SapKeccakOut out) {
+static __global__ __launch_bounds__(64) void k_sap_keccak(SapJob job, SapKeccakOut out) {
     __shared__ u64 A[25], Bm[25], Cc[5];
     const int t = threadIdx.x;
     if (t < 25) A[t] = 0;
@@ -355,7 +355,7 @@ __device__ __forceinline__ void sap_bytes32(uint8_t* dst, const u32* words) {
         for (int b = 0; b < 4; b++) dst[4 * k + b] = (uint8_t)(words[k] >> (8 * b));
 }
 
-__global__ void k_sap_instances(const SapBlock* __restrict__ blk) {
+static __global__ void k_sap_instances(const SapBlock* __restrict__ blk) {
     const SapBlock b = *blk;
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= b.n_instances) return;

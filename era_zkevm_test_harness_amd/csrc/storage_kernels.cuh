@@ -12,7 +12,7 @@
 
 namespace zkw {
 
-__global__ void k_storage_sort_keys(const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ k0, u64* __restrict__ k1,
+static __global__ void k_storage_sort_keys(const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ k0, u64* __restrict__ k1,
                                     u64* __restrict__ k2, u64* __restrict__ k3, u64* __restrict__ a0, u64* __restrict__ a1,
                                     u32* __restrict__ a2, u32* __restrict__ iota) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -29,7 +29,7 @@ __global__ void k_storage_sort_keys(const zkw_log_query* __restrict__ q, size_t 
 }
 
 // sorted_q[i] = q[perm[i]], encoded with extended_timestamp = perm[i] (its position in the unsorted queue)
-__global__ __launch_bounds__(256) void k_storage_gather_encode(const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
+static __global__ __launch_bounds__(256) void k_storage_gather_encode(const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
                                                                size_t n, zkw_log_query* __restrict__ sorted_q,
                                                                u32* __restrict__ sorted_ext, u64* __restrict__ sorted_enc) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void cell_current_value(const zkw_log_query& m, u32 o
     for (int k = 0; k < 8; k++) out[k] = fwd_write ? m.written_value[k] : m.read_value[k];
 }
 
-__global__ __launch_bounds__(1024) void k_storage_cells(const zkw_log_query* __restrict__ sorted_q, size_t n, StorageScan sc,
+static __global__ __launch_bounds__(1024) void k_storage_cells(const zkw_log_query* __restrict__ sorted_q, size_t n, StorageScan sc,
                                                         zkw_log_query* __restrict__ result_q, u64* __restrict__ result_enc,
                                                         u32* __restrict__ totals /* [2]: n_result, violations */) {
     __shared__ int sh_i[16];
@@ -191,7 +191,7 @@ struct StorageBlock {
     u32 capacity;
 };
 
-__global__ void k_storage_instances(const StorageBlock* __restrict__ blk) {
+static __global__ void k_storage_instances(const StorageBlock* __restrict__ blk) {
     const StorageBlock b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;

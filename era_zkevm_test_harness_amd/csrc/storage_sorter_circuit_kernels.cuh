@@ -18,11 +18,11 @@
 
 namespace zkw {
 
-__constant__ rc_term c_ss_terms[SS_NUM_TERMS] = SS_TERMS_INIT;
-__constant__ rc_constraint c_ss_cons[SS_NUM_CONSTRAINTS] = SS_CONSTRAINTS_INIT;
-__constant__ uint16_t c_ss_row_first[SS_NUM_ROW_TYPES + 1] = SS_ROW_FIRST_CONSTRAINT_INIT;
-__constant__ uint8_t c_ss_is_poseidon[SS_NUM_ROW_TYPES] = SS_ROW_IS_POSEIDON_INIT;
-__constant__ rc_link c_ss_links[SS_NUM_LINKS] = SS_LINKS_INIT;
+static __constant__ rc_term c_ss_terms[SS_NUM_TERMS] = SS_TERMS_INIT;
+static __constant__ rc_constraint c_ss_cons[SS_NUM_CONSTRAINTS] = SS_CONSTRAINTS_INIT;
+static __constant__ uint16_t c_ss_row_first[SS_NUM_ROW_TYPES + 1] = SS_ROW_FIRST_CONSTRAINT_INIT;
+static __constant__ uint8_t c_ss_is_poseidon[SS_NUM_ROW_TYPES] = SS_ROW_IS_POSEIDON_INIT;
+static __constant__ rc_link c_ss_links[SS_NUM_LINKS] = SS_LINKS_INIT;
 struct SpecStorageSorter {  // StorageSorter, circuit type 9
     static constexpr int G = SS_G, L = SS_L, ROWS_PER_CYCLE = SS_ROWS_PER_CYCLE, NUM_ROW_TYPES = SS_NUM_ROW_TYPES, NUM_LINKS = SS_NUM_LINKS;
     static constexpr int OFF_BIN = SS_ROWOFF_BND_IN, OFF_BOUT = SS_ROWOFF_BND_OUT;
@@ -160,7 +160,7 @@ __device__ __forceinline__ bool ss_same_key(const u64 cv[18], const SsKeys& p) {
 
 // WHICH 0 = unsorted pop (U1..U3), 1 = sorted pop (S1..S3), 2 = result push (R1..R3)
 template <int WHICH>
-__global__ __launch_bounds__(64) void k_ss_fill_queue(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(64) void k_ss_fill_queue(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SsSynthJob& job = jobs[blockIdx.y];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t rs = SS_REGION_STRIDE(capacity);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void k_ss_fill_queue(const SsSynthJob* __restri
     v.wq0 = _w[0]; v.wq1 = _w[1]; v.wq2 = _w[2]; v.wq3 = _w[3]; v.wq4 = _w[4]; v.wq5 = _w[5]; v.wq6 = _w[6]; v.wq7 = _w[7]; v.w_d = _w[8]; } while (0)
 
 template <int ROW>
-__global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __restric
     hist_flush(sh_hist, job.hist);
 }
 
-__global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SsSynthJob& job = jobs[blockIdx.y];
     u64* trace = job.trace;
     const int col = blockIdx.x / TAIL_CHUNKS, ch = blockIdx.x % TAIL_CHUNKS;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* __restri
 }
 
 // BND_IN, BND_OUT, the flush permutations F1..F3, PI (runs last on the stream: reads the last cycle's rows)
-__global__ __launch_bounds__(64) void k_ss_fill_boundary(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __global__ __launch_bounds__(64) void k_ss_fill_boundary(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SsSynthJob& job = jobs[blockIdx.x];
     if (threadIdx.x != 0) return;
     u64* trace = job.trace;

@@ -4,60 +4,17 @@
 //   RamBuilder::run  <->  compute_ram_circuit_snapshots, src/witness/individual_circuits/ram_permutation.rs:26-470
 // One process drives one GPU; everything is enqueued on the context's stream, scratch lives in a
 // grow-only per-context pool so that steady-state calls do no hipMalloc.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <memory>
-#include <mutex>
-#include <thread>
-
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/zkw.h"
-#include "zkw_internal.h"
-#include "ram_kernels.cuh"
-#include "ram_circuit_kernels.cuh"
-#include "log_kernels.cuh"
-#include "decommit_kernels.cuh"
-#include "events_kernels.cuh"
-#include "demux_kernels.cuh"
-#include "storage_kernels.cuh"
-#include "decommitter_kernels.cuh"
-#include "public_input_kernels.cuh"
+#include "zkw_ctx.h"
+#include "circuit_check_host.h"
+#include "closed_forms_host.h"
 #include "callstack_kernels.cuh"
-#include "precompile_kernels.cuh"
-#include "storage_application_kernels.cuh"
-#include "decommit_sorter_circuit_kernels.cuh"
-#include "events_sorter_circuit_kernels.cuh"
-#include "log_demux_circuit_kernels.cuh"
-#include "storage_sorter_circuit_kernels.cuh"
 #include "vm_kernels.cuh"
-#include "netlist_kernels.cuh"
 #include "sort.h"
-
-using namespace zkw;
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string g_last_error;
 
-static int fail(int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_last_error = buf;
-    return code;
-}
+#undef fail
 int zkw_fail(int code, const char* fmt, ...) {  // the same for the library's other translation units (zkw_internal.h)
     char buf[512];
     va_list ap;
@@ -67,6 +24,8 @@ int zkw_fail(int code, const char* fmt, ...) {  // the same for the library's ot
     g_last_error = buf;
     return code;
 }
+
+#define fail zkw_fail
 
 // ------------------------------------------------------------------------------------------------ allocation cache
 // hipFree / hipHostFree wait for EVERY stream of the device and hipMalloc takes the runtime's global lock: with many
@@ -152,11 +111,8 @@ static AllocCache& alloc_cache() {
     static AllocCache* c = new AllocCache();  // never destroyed: the HIP runtime may be gone by static destruction time
     return *c;
 }
-static inline hipError_t dev_malloc(void** p, size_t bytes) { return alloc_cache().alloc(0, p, bytes); }
-template <class T> static inline hipError_t dev_malloc(T** p, size_t bytes) { return alloc_cache().alloc(0, (void**)p, bytes); }
-static inline void dev_free(void* p) { alloc_cache().release(0, p); }
-static inline hipError_t pin_malloc(void** p, size_t bytes) { return alloc_cache().alloc(1, p, bytes); }
-static inline void pin_free(void* p) { alloc_cache().release(1, p); }
+hipError_t zkw_cache_alloc(int pinned_host, void** p, size_t bytes) { return alloc_cache().alloc(pinned_host ? 1 : 0, p, bytes); }
+void zkw_cache_release(int pinned_host, void* p) { alloc_cache().release(pinned_host ? 1 : 0, p); }
 
 
 // Streams are pooled for the same reason: hipStreamDestroy waits for the whole device. A released stream has been
@@ -205,484 +161,8 @@ extern "C" void zkw_trim_caches(void) {
     stream_pool().trim();
 }
 
-#define HIP_TRY(expr)                                                                               \
-    do {                                                                                            \
-        hipError_t _e = (expr);                                                                     \
-        if (_e != hipSuccess)                                                                       \
-            return fail(_e == hipErrorOutOfMemory ? ZKW_ERR_OOM : ZKW_ERR_HIP, "%s failed: %s (%s:%d)", \
-                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                          \
-    } while (0)
-
-#define ZKW_TRY(expr)            \
-    do {                         \
-        int _rc = (expr);        \
-        if (_rc != ZKW_OK) return _rc; \
-    } while (0)
-
-// ------------------------------------------------------------------------------------------------ context
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-};
-
-// pinned host staging for descriptor uploads; `ev` marks the last copy that read it
-struct HostStage {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipEvent_t ev = nullptr;
-    bool pending = false;
-};
-
-struct zkw_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    int ptr_mode = ZKW_PTR_HOST;
-    hipStream_t chain_stream = nullptr;  // optional second stream for the queue-chain kernels (zkw_set_chain_stream)
-    hipEvent_t chain_ev_a = nullptr, chain_ev_b = nullptr;
-    // witnesses and traces created from this context keep it alive: zkw_destroy defers while any is outstanding
-    std::atomic<long> children{0};
-    std::atomic<bool> destroy_requested{false};
-    std::atomic<bool> destroying{false};
-    bool chain_service = false;  // queue chains go to the device's chain service (batched with other contexts' chains)
-    int chain_form = 0;  // lanes per Poseidon2 state in the queue-chain kernel: 4 (quad), 16 (row), 0 = auto
-    std::map<std::string, DevBuf> pool;  // named grow-only scratch
-    std::map<std::string, HostStage> stages;
-    // optional per-kernel timing with HIP events on the context's stream (zkw_profile_*)
-    bool profiling = false;
-    struct ProfSpan { const char* name; hipEvent_t a, b; };
-    std::vector<ProfSpan> spans;
-    std::vector<hipEvent_t> free_events;
-    std::map<std::string, std::pair<double, uint64_t>> prof_totals;  // name -> (ms, launches)
-
-    hipEvent_t prof_event() {
-        if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
-        hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
-        return e;
-    }
-    int prof_collect() {
-        if (spans.empty()) return ZKW_OK;
-        HIP_TRY(hipStreamSynchronize(stream));
-        for (auto& sp : spans) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-                auto& t = prof_totals[sp.name];
-                t.first += ms;
-                t.second += 1;
-            }
-            free_events.push_back(sp.a);
-            free_events.push_back(sp.b);
-        }
-        spans.clear();
-        return ZKW_OK;
-    }
-
-    int scratch(const char* name, size_t bytes, void** out) {
-        DevBuf& b = pool[name];
-        if (b.cap < bytes) {
-            if (b.p) {
-                retired_dev.push_back(b.p);
-                b.p = nullptr;
-                b.cap = 0;
-            }
-            size_t want = bytes + bytes / 8 + 256;
-            HIP_TRY(dev_malloc(&b.p, want));
-            b.cap = want;
-        }
-        *out = b.p;
-        return ZKW_OK;
-    }
-    template <class T>
-    int scratch_t(const char* name, size_t count, T** out) {
-        void* p = nullptr;
-        ZKW_TRY(scratch(name, count * sizeof(T) + 16, &p));
-        *out = static_cast<T*>(p);
-        return ZKW_OK;
-    }
-    // descriptor upload: host vector -> named device scratch (async, pageable source is copied by the
-    // runtime before return)
-    template <class T>
-    int upload(const char* name, const std::vector<T>& h, T** out) {
-        ZKW_TRY(scratch_t<T>(name, h.size() ? h.size() : 1, out));
-        if (h.empty()) return ZKW_OK;
-        const size_t bytes = h.size() * sizeof(T);
-        HostStage& st = stages[name];
-        if (st.pending) {  // the previous upload from this staging buffer must have been consumed
-            HIP_TRY(hipEventSynchronize(st.ev));
-            st.pending = false;
-        }
-        if (st.cap < bytes) {
-            if (st.p) retired_host.push_back(st.p);
-            st.p = nullptr;
-            st.cap = 0;
-            HIP_TRY(pin_malloc(&st.p, bytes + bytes / 2 + 256));
-            st.cap = bytes + bytes / 2 + 256;
-        }
-        if (!st.ev) HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
-        memcpy(st.p, h.data(), bytes);
-        HIP_TRY(hipMemcpyAsync(*out, st.p, bytes, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipEventRecord(st.ev, stream));
-        st.pending = true;
-        return ZKW_OK;
-    }
-    // stage an input: returns a device pointer for `src` (copying when src is a host pointer)
-    template <class T>
-    int in(const char* name, const T* src, size_t count, const T** out) {
-        if (ptr_mode == ZKW_PTR_DEVICE || count == 0) {
-            *out = src;
-            return ZKW_OK;
-        }
-        T* d = nullptr;
-        ZKW_TRY(scratch_t<T>(name, count, &d));
-        HIP_TRY(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
-        *out = d;
-        return ZKW_OK;
-    }
-    // reserve an output: device pointer to write to (dst itself in device mode)
-    template <class T>
-    int out(const char* name, T* dst, size_t count, T** dev) {
-        if (ptr_mode == ZKW_PTR_DEVICE) {
-            *dev = dst;
-            return ZKW_OK;
-        }
-        return scratch_t<T>(name, count ? count : 1, dev);
-    }
-    template <class T>
-    int finish_out(T* dst, const T* dev, size_t count) {
-        if (ptr_mode == ZKW_PTR_DEVICE || count == 0) return ZKW_OK;
-        HIP_TRY(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, stream));
-        return ZKW_OK;
-    }
-    int sync_if_host() {
-        if (ptr_mode == ZKW_PTR_HOST) HIP_TRY(hipStreamSynchronize(stream));
-        return ZKW_OK;
-    }
-    // Small device -> host readback (counts, violation flags) THROUGH PINNED MEMORY, then a sync of this stream only.
-    // A hipMemcpyAsync into pageable memory waits for every stream of the device (measured: 0.9 s behind another
-    // context's queue chain), which serialises the builders that zkw_block_run runs side by side.
-    void* pinned_rb = nullptr;
-    size_t pinned_rb_cap = 0;
-    int read_small(void* dst, const void* src, size_t bytes) {
-        if (pinned_rb_cap < bytes) {
-            if (pinned_rb) retired_host.push_back(pinned_rb);
-            pinned_rb = nullptr;
-            pinned_rb_cap = 0;
-            const size_t want = bytes < 4096 ? 4096 : bytes;
-            HIP_TRY(pin_malloc(&pinned_rb, want));
-            pinned_rb_cap = want;
-        }
-        HIP_TRY(hipMemcpyAsync(pinned_rb, src, bytes, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        memcpy(dst, pinned_rb, bytes);
-        return ZKW_OK;
-    }
-    // buffers replaced by a bigger one: hipFree / hipHostFree wait for the whole device, so they are kept until the
-    // context is destroyed (growth is geometric: bounded waste)
-    std::vector<void*> retired_dev, retired_host;
-};
-
-// RAII span around one kernel launch (or a library sort); free when profiling is off
-struct Prof {
-    zkw_ctx* c;
-    hipEvent_t b = nullptr;
-    Prof(zkw_ctx* ctx, const char* name) : c(ctx) {
-        if (!c->profiling) return;
-        hipEvent_t a = c->prof_event();
-        b = c->prof_event();
-        (void)hipEventRecord(a, c->stream);
-        c->spans.push_back(zkw_ctx::ProfSpan{name, a, b});
-    }
-    ~Prof() {
-        if (b) (void)hipEventRecord(b, c->stream);
-    }
-};
-
-static int launch_check(const char* what) {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(ZKW_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
-    return ZKW_OK;
-}
-
-// rows [0, width) of blockIdx.y's column of a column-major strip
-__global__ __launch_bounds__(256) void k_zero_strip(u64* __restrict__ base, size_t pitch, size_t width) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < width) base[(size_t)blockIdx.y * pitch + i] = 0;
-}
-// Zeroes what the fill of a "zkw trace v3" netlist circuit does NOT write itself: the general-purpose columns [0, g) (the
-// fill then overwrites its header / gate cells), the lookup columns [g, g + lookup_cols) below the last cycle only (the fill
-// writes every lookup cell of the cycles' rows, padding and header rows included), and the multiplicity columns. Zeroing
-// the whole slot first wrote the lookup columns twice: a third of the memset.
-static int zero_netlist_slot(zkw_ctx* ctx, u64* trace, size_t n_rows, size_t g, size_t lookup_cols, size_t n_cols, size_t used_rows) {
-    HIP_TRY(hipMemsetAsync(trace, 0, g * n_rows * sizeof(u64), ctx->stream));
-    if (used_rows < n_rows) {  // (hipMemset2DAsync ran this strip at 0.8 TB/s: 0.2 ms per Keccak slot)
-        hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - used_rows + 255) / 256), (unsigned)lookup_cols), dim3(256), 0, ctx->stream,
-                           trace + g * n_rows + used_rows, n_rows, n_rows - used_rows);
-        ZKW_TRY(launch_check("k_zero_strip"));
-    }
-    HIP_TRY(hipMemsetAsync(trace + (g + lookup_cols) * n_rows, 0, (n_cols - g - lookup_cols) * n_rows * sizeof(u64), ctx->stream));
-    return ZKW_OK;
-}
-
-static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
-
 extern "C" const char* zkw_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* zkw_version(void) { return "zkw 0.2 (gfx950)"; }
-
-extern "C" int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometry* out) {
-    // {copy columns, lookup width, repetitions, max degree, capacity, big size hint}: vm_main.rs:29-44,
-    // sort_code_decommits.rs:28-39, code_decommitter.rs:28-39, log_demux.rs:36-47, keccak256_round_function.rs:28-39,
-    // sha256_round_function.rs:28-39, ecrecover.rs:30-41, ram_permutation.rs:26-41,117-122, storage_sort_dedup.rs:29-40,
-    // storage_apply.rs:28-39, events_sort_dedup.rs:28-39 (x2), linear_hasher.rs:28-39; geometry_config.rs:5-20
-    static const struct { u32 c, lw, lr, deg, cap; bool big; } T[14] = {
-        {0, 0, 0, 0, 0, false},
-        {130, 3, 8, 8, 5585, false},    // 1 MainVM
-        {130, 1, 18, 8, 117500, true},  // 2 CodeDecommittmentsSorter
-        {108, 4, 11, 8, 2845, false},   // 3 CodeDecommitter
-        {136, 1, 14, 8, 58750, true},   // 4 LogDemuxer
-        {86, 3, 14, 8, 293, false},     // 5 KeccakRoundFunction
-        {116, 4, 9, 8, 2206, false},    // 6 Sha256RoundFunction
-        {80, 3, 16, 8, 7, false},       // 7 ECRecover
-        {133, 1, 15, 8, 136714, true},  // 8 RAMPermutation
-        {132, 1, 16, 8, 46921, true},   // 9 StorageSorter
-        {60, 3, 26, 8, 33, false},      // 10 StorageApplication
-        {130, 1, 8, 18, 31287, true},   // 11 EventsSorter
-        {130, 1, 8, 18, 31287, true},   // 12 L1MessagesSorter
-        {66, 3, 26, 8, 774, false},     // 13 L1MessagesHasher
-    };
-    if (!out || circuit_type < 1 || circuit_type > 13) return fail(ZKW_ERR_INVALID, "unknown base-layer circuit type %u", circuit_type);
-    const auto& g = T[circuit_type];
-    out->num_columns_under_copy_permutation = g.c;
-    out->num_witness_columns = 0;
-    out->num_constant_columns = 4;
-    out->max_allowed_constraint_degree = g.deg;
-    out->lookup_width = g.lw;
-    out->lookup_repetitions = g.lr;
-    out->capacity = g.cap;
-    out->trace_len_log2 = 20;
-    out->size_hint_variables = g.big ? (1ull << 26) + (1ull << 25) : (1ull << 26);
-    return ZKW_OK;
-}
-
-// Where this library's own trace layout ("zkw trace v2") of a circuit type puts things: what the reference keeps in
-// FinalizationHintsForProver / VerificationKey.fixed_parameters for ITS layout (setup/base_layer/finalization_hint_N.json:
-// `public_inputs` = (column, row) of the four PI cells, `nop_gates_to_add`, `final_trace_len`). No GPU needed.
-extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_layout* out) {
-    if (!out) return fail(ZKW_ERR_INVALID, "zkw_circuit_layout_of: null argument");
-    zkw_circuit_geometry g;
-    ZKW_TRY(zkw_circuit_geometry_of(circuit_type, &g));
-    memset(out, 0, sizeof *out);
-    if (capacity == 0) capacity = g.capacity;
-    out->capacity = capacity;
-    out->trace_len = 1ull << g.trace_len_log2;
-    uint64_t boundary = 0, min_rows = 0, pi_off = 0;
-    switch (circuit_type) {
-        case 8: out->num_columns = RC_COLS; out->rows_per_cycle = RC_ROWS_PER_CYCLE; out->region_stride = RC_REGION_STRIDE(capacity); boundary = RC_BOUNDARY_ROW(capacity); min_rows = RC_MIN_ROWS(capacity); pi_off = RC_ROWOFF_PI; break;
-        case 2: out->num_columns = DS_COLS; out->rows_per_cycle = DS_ROWS_PER_CYCLE; out->region_stride = DS_REGION_STRIDE(capacity); boundary = DS_BOUNDARY_ROW(capacity); min_rows = DS_MIN_ROWS(capacity); pi_off = DS_ROWOFF_PI; break;
-        case 4: out->num_columns = LD_COLS; out->rows_per_cycle = LD_ROWS_PER_CYCLE; out->region_stride = LD_REGION_STRIDE(capacity); boundary = LD_BOUNDARY_ROW(capacity); min_rows = LD_MIN_ROWS(capacity); pi_off = LD_ROWOFF_PI; break;
-        case 9: out->num_columns = SS_COLS; out->rows_per_cycle = SS_ROWS_PER_CYCLE; out->region_stride = SS_REGION_STRIDE(capacity); boundary = SS_BOUNDARY_ROW(capacity); min_rows = SS_MIN_ROWS(capacity); pi_off = SS_ROWOFF_PI; break;
-        case 11: case 12: out->num_columns = ES_COLS; out->rows_per_cycle = ES_ROWS_PER_CYCLE; out->region_stride = ES_REGION_STRIDE(capacity); boundary = ES_BOUNDARY_ROW(capacity); min_rows = ES_MIN_ROWS(capacity); pi_off = ES_ROWOFF_PI; break;
-        // the netlist circuits ("zkw trace v4") are cycle-major: region_stride = 0, cycle i starts at row i * rows_per_cycle
-        case 3: case 5: case 6: case 13: {
-            const nl_spec* sp = nl_host_spec(circuit_type);
-            const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(capacity) : capacity;
-            out->num_columns = sp->cols; out->rows_per_cycle = sp->rows_per_cycle; boundary = NL_BOUNDARY_ROW(sp, cycles);
-            min_rows = NL_USED_ROWS(sp, cycles); pi_off = 2 * NL_BND_ROWS(sp);
-            out->total_table_rows = sp->total_table_rows;
-            break;
-        }
-        default: return ZKW_OK;  // a known circuit type this library does not synthesize yet: synthesizable = 0
-    }
-    out->synthesizable = 1;
-    if (out->region_stride) out->total_table_rows = 256;  // the queue circuits' one table: RangeCheckTable<8>
-    out->rows_used = min_rows;
-    out->fits = min_rows <= out->trace_len;
-    out->nop_rows = out->fits ? out->trace_len - min_rows : 0;
-    for (int k = 0; k < 4; k++) {
-        out->public_input_column[k] = (uint32_t)k;
-        out->public_input_row[k] = boundary + pi_off;
-    }
-    return ZKW_OK;
-}
-
-// Setup side, selectors: which gate set applies to each row of a trace of this library's layout — what the
-// reference's setup keeps in its constant columns (gate selectors, the lookup table id of a row). Host arithmetic over the specs.
-//   queue circuits (2, 4, 8, 9, 11, 12; "zkw trace v2", region-major): selector = row type of the spec (0 .. NUM_ROW_TYPES - 1:
-//     the per-cycle row types, then the boundary rows), ZKW_ROW_PADDING elsewhere (gaps of a region, rows after the boundary)
-//   netlist circuits (3, 5, 6, 13; "zkw trace v3", cycle-major): selector = lookup table id of the row (0: none) |
-//     ZKW_ROW_HAS_GATES when ADD gates sit in its general-purpose columns | ZKW_ROW_HEADER for a cycle's first row;
-//     boundary rows ZKW_ROW_BOUNDARY + k; ZKW_ROW_PADDING elsewhere
-extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint8_t* out) {
-    if (!out || n_rows == 0) return fail(ZKW_ERR_INVALID, "zkw_setup_row_selectors: null argument");
-    zkw_circuit_layout lay;
-    ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
-    if (!lay.synthesizable) return fail(ZKW_ERR_INVALID, "circuit type %u has no layout in this library", (unsigned)circuit_type);
-    if (lay.rows_used > n_rows) return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, %zu given", lay.capacity, (unsigned long long)lay.rows_used, n_rows);
-    memset(out, ZKW_ROW_PADDING, n_rows);
-    const uint32_t cap = lay.capacity;
-    if (lay.region_stride) {  // region-major
-        const uint64_t stride = lay.region_stride, rpc = lay.rows_per_cycle;
-        for (uint64_t r = 0; r < rpc; r++) memset(out + r * stride, (int)r, cap);
-        const uint64_t bnd = rpc * stride;
-        for (uint64_t k = 0; bnd + k < lay.rows_used; k++) out[bnd + k] = (uint8_t)(rpc + k);
-        return ZKW_OK;
-    }
-    const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
-    const uint64_t rpc = lay.rows_per_cycle;
-    const nl_spec* sp = nl_host_spec(circuit_type);
-    std::vector<uint8_t> one(rpc);  // every cycle has the same selectors
-    for (uint32_t st = 0; st < sp->steps_per_cycle; st++) {
-        const nl_step_type& T = sp->step_types[sp->cycle[st].type];
-        uint8_t* row = one.data() + sp->cycle[st].row0;
-        row[0] = ZKW_ROW_HEADER;
-        for (uint32_t r = 1; r < T.rows; r++)
-            row[r] = (uint8_t)((r <= T.lookup_rows ? sp->ops[T.op0 + (r - 1) * sp->r].table : 0) | (sp->gate_row_end[T.rowend0 + r] ? ZKW_ROW_HAS_GATES : 0));
-    }
-    for (uint32_t c = 0; c < cycles; c++) memcpy(out + (uint64_t)c * rpc, one.data(), rpc);
-    for (uint64_t k = 0; (uint64_t)cycles * rpc + k < lay.rows_used; k++) out[(uint64_t)cycles * rpc + k] = (uint8_t)(ZKW_ROW_BOUNDARY + k);
-    return ZKW_OK;
-}
-
-// Setup side, copy permutation of the queue circuits: sigma[c][r] = the cell (c' * n_rows + r') that follows
-// cell (c, r) in its copy cycle; a cell under no copy constraint maps to itself. Built on the host from the spec's link table
-// (the same table the satisfiability checker walks, ram_circuit_kernels.cuh k_check_links) with a union-find over the
-// general-purpose cells; cycles run through their cells in increasing cell order. Seconds at production size (1.1 GB of output).
-namespace {
-struct LinkSpec { int G /* general-purpose + lookup columns: links reach both */, rows_per_cycle, num_links, off_bin, off_bout; const rc_link* links; };
-static const rc_link h_rc_links[RC_NUM_LINKS] = RC_LINKS_INIT;
-static const rc_link h_ds_links[DS_NUM_LINKS] = DS_LINKS_INIT;
-static const rc_link h_es_links[ES_NUM_LINKS] = ES_LINKS_INIT;
-static const rc_link h_ld_links[LD_NUM_LINKS] = LD_LINKS_INIT;
-static const rc_link h_ss_links[SS_NUM_LINKS] = SS_LINKS_INIT;
-bool link_spec_of(uint8_t t, LinkSpec* o) {
-    switch (t) {
-        case 8: *o = {RC_G + RC_L, RC_ROWS_PER_CYCLE, RC_NUM_LINKS, RC_ROWOFF_BND_IN, RC_ROWOFF_BND_OUT, h_rc_links}; return true;
-        case 2: *o = {DS_G + DS_L, DS_ROWS_PER_CYCLE, DS_NUM_LINKS, DS_ROWOFF_BND_IN, DS_ROWOFF_BND_OUT, h_ds_links}; return true;
-        case 11: case 12: *o = {ES_G + ES_L, ES_ROWS_PER_CYCLE, ES_NUM_LINKS, ES_ROWOFF_BND_IN, ES_ROWOFF_BND_OUT, h_es_links}; return true;
-        case 4: *o = {LD_G + LD_L, LD_ROWS_PER_CYCLE, LD_NUM_LINKS, LD_ROWOFF_BND_IN, LD_ROWOFF_BND_OUT, h_ld_links}; return true;
-        case 9: *o = {SS_G + SS_L, SS_ROWS_PER_CYCLE, SS_NUM_LINKS, SS_ROWOFF_BND_IN, SS_ROWOFF_BND_OUT, h_ss_links}; return true;
-        default: return false;
-    }
-}
-}  // namespace
-
-extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t* sigma, uint32_t* n_columns) {
-    LinkSpec sp;
-    const bool netlist = circuit_type == 3 || circuit_type == 5 || circuit_type == 6 || circuit_type == 13;
-    if (netlist) sp = {(int)nl_host_spec(circuit_type)->mult_col, 0, 0, 0, 0, nullptr};  // all but the multiplicity column
-    else if (!link_spec_of(circuit_type, &sp))
-        return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: circuit type %u has no layout in this library", (unsigned)circuit_type);
-    zkw_circuit_layout lay;
-    ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
-    if (n_columns) *n_columns = (uint32_t)sp.G;
-    if (!sigma) return ZKW_OK;  // size query
-    if (lay.rows_used > n_rows || n_rows >= (1ull << 32) / (size_t)sp.G)
-        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, %zu given", lay.capacity, (unsigned long long)lay.rows_used, n_rows);
-    const uint32_t cap = lay.capacity;
-    const uint64_t rs = lay.region_stride, bnd = (uint64_t)sp.rows_per_cycle * rs;
-    const size_t n_cells = (size_t)sp.G * n_rows;
-    std::vector<uint32_t> parent(n_cells);
-    for (size_t i = 0; i < n_cells; i++) parent[i] = (uint32_t)i;
-    auto find = [&](uint32_t x) {
-        while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
-        return x;
-    };
-    bool out_of_range = false;
-    auto unite = [&](uint64_t col_a, uint64_t row_a, uint64_t col_b, uint64_t row_b) {
-        if (col_a >= (uint64_t)sp.G || col_b >= (uint64_t)sp.G || row_a >= n_rows || row_b >= n_rows) { out_of_range = true; return; }
-        uint32_t a = find((uint32_t)(col_a * n_rows + row_a)), b = find((uint32_t)(col_b * n_rows + row_b));
-        if (a != b) parent[a > b ? a : b] = a > b ? b : a;  // the smallest cell of a class is its root
-    };
-    auto brow = [&](int rt) { return bnd + (uint64_t)(rt - sp.rows_per_cycle); };  // a boundary row type
-    if (netlist) {
-        // the netlist circuits: every operand cell of a lookup / gate is a copy of the cell that produced it (the references of
-        // the spec, resolved exactly as the checkers do: k_kc_check_rows, k_sc_check_cycle); constants and free witness bytes
-        // are under no copy constraint
-        const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
-        const nl_spec* ns = nl_host_spec(circuit_type);
-        const uint64_t nb = NL_BOUNDARY_ROW(ns, cycles), brows = NL_BND_ROWS(ns);
-        // the cell a reference names, seen from step st of cycle c (nl_home of netlist_kernels.cuh as coordinates); false: a constant
-        auto home = [&](uint32_t c, uint32_t st, uint32_t ref, uint64_t* hc, uint64_t* hr) {
-            for (;;) {
-                const nl_cycle_step& cs = ns->cycle[st];
-                const nl_step_type& T = ns->step_types[cs.type];
-                const uint64_t base = (uint64_t)c * ns->rows_per_cycle + cs.row0;
-                if (ref < NL_REF_HDR) {
-                    const nl_home h = ns->homes[T.home0 + ref];
-                    if (h.kind == 1) { const nl_gate& g = ns->gates[T.gate0 + h.item]; *hc = g.col + h.cell; *hr = base + g.row; }
-                    else { *hc = ns->g + ns->w * (h.item % ns->r) + h.cell; *hr = base + 1 + h.item / ns->r; }
-                    return true;
-                }
-                if (ref < NL_REF_PREV) { *hc = ref - NL_REF_HDR; *hr = base; return true; }
-                if (ref >= NL_REF_FREE && ref < NL_REF_RC) return false;
-                if (ref >= NL_REF_RC) return false;
-                uint32_t k;
-                if (ref >= NL_REF_CYC || st == 0) {
-                    k = ref >= NL_REF_CYC ? ref - NL_REF_CYC : ref - NL_REF_PREV;
-                    if (c == 0) { *hc = k % ns->g; *hr = nb + k / ns->g; return true; }
-                    c--;
-                    st = ns->steps_per_cycle - 1;
-                } else {
-                    k = ref - NL_REF_PREV;
-                    st--;
-                }
-                ref = ns->out[(size_t)ns->cycle[st].type * ns->state + k];
-            }
-        };
-        uint64_t hc, hr;
-        for (uint32_t c = 0; c < cycles; c++)
-            for (uint32_t st = 0; st < ns->steps_per_cycle; st++) {
-                const nl_cycle_step& cs = ns->cycle[st];
-                const nl_step_type& T = ns->step_types[cs.type];
-                const uint64_t base = (uint64_t)c * ns->rows_per_cycle + cs.row0;
-                if (st)  // a step's header is a copy of the cycle's
-                    for (int f = 0; f < NL_HDR_FIELDS; f++) unite((uint64_t)f, base, (uint64_t)f, (uint64_t)c * ns->rows_per_cycle);
-                for (uint32_t j = 0; j < T.n_ops; j++) {
-                    const nl_op& op = ns->ops[T.op0 + j];
-                    const nl_table& tb = ns->tables[op.table - 1];
-                    for (uint32_t i = 0; i < tb.n_in; i++) {
-                        if (op.in[i] < NL_REF_HDR) {
-                            const nl_home h = ns->homes[T.home0 + op.in[i]];
-                            if (h.kind == 2 && h.item == j && h.cell == i) continue;  // a hint's own cell
-                        }
-                        if (home(c, st, op.in[i], &hc, &hr)) unite((uint64_t)(ns->g + ns->w * (j % ns->r) + i), base + 1 + j / ns->r, hc, hr);
-                    }
-                }
-                for (uint32_t gi = 0; gi < T.n_gates; gi++) {
-                    const nl_gate& g = ns->gates[T.gate0 + gi];
-                    for (uint32_t i = 0; i < g.n_known; i++)
-                        if (home(c, st, ns->terms[T.term0 + g.first_term + i].ref, &hc, &hr)) unite((uint64_t)(g.col + i), base + g.row, hc, hr);
-                }
-            }
-        if (cycles)
-            for (uint32_t k = 0; k < ns->state; k++)
-                if (home(cycles, 0, NL_REF_CYC + k, &hc, &hr)) unite((uint64_t)(k % ns->g), nb + brows + k / ns->g, hc, hr);
-    }
-    for (int l = 0; l < sp.num_links; l++) {
-        const rc_link k = sp.links[l];
-        if (k.kind == 3) { unite(k.col_a, bnd + sp.off_bout, k.col_b, (uint64_t)k.row_b * rs + cap - 1); continue; }
-        if (k.kind == 4) { unite(k.col_a, brow(k.row_a), k.col_b, bnd + sp.off_bout); continue; }
-        if (k.kind == 5) { unite(k.col_a, brow(k.row_a), k.col_b, brow(k.row_b)); continue; }
-        for (uint32_t i = 0; i < cap; i++) {
-            const uint64_t ra = (uint64_t)k.row_a * rs + i;
-            if (k.kind == 0) unite(k.col_a, ra, k.col_b, (uint64_t)k.row_b * rs + i);
-            else if (k.kind == 1) { if (i) unite(k.col_a, ra, k.col_b, (uint64_t)k.row_b * rs + i - 1); else unite(k.col_a, ra, k.bin_col, bnd + sp.off_bin); }
-            else unite(k.col_a, ra, k.col_b, bnd + sp.off_bin);
-        }
-    }
-    if (out_of_range) return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: a link of the spec leaves the copy-permutation columns");
-    // cycles: the cells of a class in increasing order, the last one back to the root
-    std::vector<uint32_t> last(n_cells);
-    for (size_t i = 0; i < n_cells; i++) { sigma[i] = i; last[i] = (uint32_t)i; }
-    for (size_t i = 0; i < n_cells; i++) {
-        const uint32_t r = find((uint32_t)i);
-        if (r == i) continue;
-        sigma[last[r]] = i;  // i > last[r]: cells are visited in increasing order
-        last[r] = (uint32_t)i;
-        sigma[i] = r;
-    }
-    return ZKW_OK;
-}
 
 extern "C" zkw_ctx* zkw_create(int device_id) {
     int count = 0;
@@ -741,8 +221,7 @@ static void ctx_destroy_now(zkw_ctx* ctx) {
     }
     delete ctx;
 }
-static void ctx_retain(zkw_ctx* ctx) { ctx->children.fetch_add(1); }
-static void ctx_release(zkw_ctx* ctx);
+void ctx_retain(zkw_ctx* ctx) { ctx->children.fetch_add(1); }
 // the context's internals the library's other translation units need (zkw_internal.h)
 int zkw_ctx_device(const zkw_ctx* ctx) { return ctx->device; }
 void* zkw_ctx_stream(const zkw_ctx* ctx) { return ctx->stream; }
@@ -753,7 +232,7 @@ static void ctx_try_destroy(zkw_ctx* ctx) {
     bool expected = false;
     if (ctx->destroying.compare_exchange_strong(expected, true)) ctx_destroy_now(ctx);
 }
-static void ctx_release(zkw_ctx* ctx) {
+void ctx_release(zkw_ctx* ctx) {
     if (ctx->children.fetch_sub(1) == 1 && ctx->destroy_requested.load()) ctx_try_destroy(ctx);
 }
 
@@ -1056,7 +535,7 @@ static int chain_service_run(zkw_ctx* ctx, const std::vector<ChainJob>* full, co
 // ------------------------------------------------------------------------------------------------ device-level steps
 // (all pointers are device pointers here)
 
-static int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) {
+int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) {
     if (n == 0) return ZKW_OK;
     unsigned grid = blocks_for(n, 256);
     if (grid > 256 * 16) grid = 256 * 16;
@@ -1067,7 +546,7 @@ static int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) 
 // Chains: one chain per 16-lane DPP row, 4 chains per wave, one wave per block. A single wave already
 // issues a VALU instruction every ~2 cycles (measured 3.7 us per permutation step, flat from 1 to 4096
 // concurrent chains), so throughput comes from giving each wave its own SIMD: up to 1024 waves.
-static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
+int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     if (jobs.empty()) return ZKW_OK;
     if (ctx->chain_service) return chain_service_run(ctx, &jobs, nullptr, "k_chain_full");
     ChainJob* d_jobs = nullptr;
@@ -1105,7 +584,7 @@ static int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     return launch_check(name);
 }
 
-static int dev_fs(zkw_ctx* ctx, const std::vector<FsJob>& jobs, int state_w, int n_chal) {
+int dev_fs(zkw_ctx* ctx, const std::vector<FsJob>& jobs, int state_w, int n_chal) {
     if (jobs.empty()) return ZKW_OK;
     FsJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("fs_jobs", jobs, &d_jobs));
@@ -1127,7 +606,7 @@ static int gp_launch(zkw_ctx* ctx, const GpSeg* d_segs, int n_segs, const GpTile
 }
 
 // segs: rows/z/chal/n filled by the caller; first_tile/n_tiles filled here
-static int dev_grand_products(zkw_ctx* ctx, std::vector<GpSeg>& segs, int width, int n_reps) {
+int dev_grand_products(zkw_ctx* ctx, std::vector<GpSeg>& segs, int width, int n_reps) {
     std::vector<GpTile> tiles;
     for (size_t s = 0; s < segs.size(); s++) {
         segs[s].first_tile = (u32)tiles.size();
@@ -1276,7 +755,7 @@ extern "C" int zkw_encode_decommit_queries(zkw_ctx* ctx, const zkw_decommit_quer
 }
 
 // device-level: rounds 1-2 of every item in parallel, then one serial permutation per item and queue
-static int dev_log_chains(zkw_ctx* ctx, const u64* d_enc, size_t total, std::vector<LogChainJob>& jobs) {
+int dev_log_chains(zkw_ctx* ctx, const u64* d_enc, size_t total, std::vector<LogChainJob>& jobs) {
     if (total == 0 || jobs.empty()) return ZKW_OK;
     u64* d_pre = nullptr;
     ZKW_TRY(ctx->scratch_t<u64>("log_pre", total * 4, &d_pre));
@@ -1766,21 +1245,6 @@ extern "C" void zkw_ram_witness_free(zkw_ram_witness* w) {
 }
 
 // ------------------------------------------------------------------------------------------------ traces / synthesis
-struct zkw_trace {
-    zkw_ctx* ctx = nullptr;
-    size_t n_rows = 0, n_cols = RC_COLS, n_slots = 0;
-    u64* data = nullptr;
-    size_t slot_elems() const { return n_cols * n_rows; }
-    // What a slot held last, for the netlist circuits (which then only rewrite the cells their fill writes: everything else is
-    // still zero from the same layout's previous tenant). 0 = unknown; every other writer and zkw_trace_device_ptr reset it.
-    mutable std::vector<uint64_t> slot_tag;
-    u64* slot_for_write(size_t slot, uint64_t tag) const {
-        if (slot_tag.size() != n_slots) slot_tag.assign(n_slots, 0);
-        slot_tag[slot] = tag;
-        return data + slot * slot_elems();
-    }
-    uint64_t tag_of(size_t slot) const { return slot_tag.size() == n_slots ? slot_tag[slot] : 0; }
-};
 
 extern "C" int zkw_trace_create_with_columns(zkw_ctx* ctx, size_t n_rows, size_t n_cols, size_t n_slots, zkw_trace** out) {
     if (!ctx || !out || n_rows < 256 || n_slots == 0 || n_cols == 0 || n_cols > 4096)
@@ -1925,34 +1389,6 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     return ctx->sync_if_host();
 }
 
-template <class S>
-static int check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (t->n_cols < (size_t)(S::G + S::L + 1)) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %d", t->n_cols, S::G + S::L + 1);
-    const u64* trace = t->data + slot * t->slot_elems();
-    const size_t n_rows = t->n_rows;
-    CheckResult* d_res = nullptr;
-    u32* d_hist = nullptr;
-    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
-    ZKW_TRY(ctx->scratch_t<u32>("check_hist", 256, &d_hist));
-    CheckResult init{0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), ctx->stream));
-    const size_t lds = (size_t)(S::G + S::L) * CHK_ROWS * sizeof(u64);
-    { Prof _p(ctx, "k_check_rows"); hipLaunchKernelGGL((k_check_rows<S>), dim3((capacity + CHK_ROWS - 1) / CHK_ROWS, S::NUM_ROW_TYPES), dim3(CHK_ROWS), lds, ctx->stream, trace, capacity, n_rows, d_res); }
-    ZKW_TRY(launch_check("k_check_rows"));
-    { Prof _p(ctx, "k_check_links"); hipLaunchKernelGGL((k_check_links<S>), dim3((capacity + 255) / 256), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_res); }
-    ZKW_TRY(launch_check("k_check_links"));
-    { Prof _p(ctx, "k_check_lookups"); hipLaunchKernelGGL((k_check_lookups<S>), dim3(1024), dim3(256), 0, ctx->stream, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_check_lookups"));
-    { Prof _p(ctx, "k_check_mult"); hipLaunchKernelGGL(k_check_mult, dim3(256), dim3(256), 0, ctx->stream, trace, n_rows, S::G + S::L, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_check_mult"));
-    CheckResult res;
-    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
-    *n_violations = res.violations;
-    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
-    return ZKW_OK;
-}
 
 extern "C" int zkw_ram_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
                                        uint64_t* n_violations, uint64_t* first_bad) {
@@ -1970,278 +1406,7 @@ extern "C" int zkw_decommit_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace
     return check_satisfied<SpecDecommitSorter>(ctx, t, slot, capacity, n_violations, first_bad);
 }
 
-// ------------------------------------------------------------------------------------------------ decommit sorter
-struct zkw_decommit_witness {
-    zkw_ctx* ctx = nullptr;
-    size_t n = 0, n_instances = 0, n_dedup = 0;
-    uint32_t capacity = 0;
-    zkw_decommit_query *sorted_q = nullptr, *dedup_q = nullptr;
-    u64 *unsorted_enc = nullptr, *sorted_enc = nullptr, *unsorted_tails = nullptr, *sorted_tails = nullptr;
-    u64 *dedup_enc = nullptr, *dedup_tails = nullptr, *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
-    zkw_decommit_sorter_instance* instances = nullptr;
-    zkw_queue_state12 dedup_in;   // state of the deduplicated queue before the block (host copy)
-    u32* fresh_prefix = nullptr;  // [n + 1], computed by the first synthesis call
-    u64 *compact_forms = nullptr, *public_inputs = nullptr;  // [n_instances][18], [n_instances][4]
-    u32 *fresh_count = nullptr, *last_fresh = nullptr;  // context scratch shared by the two phases of the builder
-    bool finished = false;  // zkw_decommit_sorter_finish has run: tails, challenges, chains, instances are valid
-    void release() {
-        void* ptrs[] = {sorted_q, dedup_q, unsorted_enc, sorted_enc, unsorted_tails, sorted_tails, dedup_enc,
-                        dedup_tails, challenges, lhs_z, rhs_z, instances, fresh_prefix, compact_forms, public_inputs};
-        for (void* p : ptrs)
-            if (p) dev_free(p);
-    }
-};
-
-// phase 1 (contents): encodings, the stable (hash, timestamp) sort, the deduplicated queue. No hashing.
-static int decommit_prepare(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_decommit_query* d_q) {
-    const size_t n = w->n;
-    const unsigned grid = blocks_for(n, 256);
-    // unsorted side
-    { Prof _p(ctx, "k_encode_decommit"); hipLaunchKernelGGL(k_encode_decommit, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, w->unsorted_enc); }
-    ZKW_TRY(launch_check("k_encode_decommit"));
-    // sort: timestamp, then the hash from its least to its most significant 64 bits (stable LSD)
-    u32 *ts = nullptr, *k32 = nullptr, *v0 = nullptr, *v1 = nullptr;
-    u64 *hk[4] = {nullptr, nullptr, nullptr, nullptr}, *k64a = nullptr, *k64b = nullptr;
-    void* tmp = nullptr;
-    size_t tmp_bytes = radix_temp_bytes(n);
-    ZKW_TRY(ctx->scratch_t<u32>("sort_ts", n, &ts));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_k32", n, &k32));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_v0", n, &v0));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_v1", n, &v1));
-    const char* hn[4] = {"dsort_h0", "dsort_h1", "dsort_h2", "dsort_h3"};
-    for (int k = 0; k < 4; k++) ZKW_TRY(ctx->scratch_t<u64>(hn[k], n, &hk[k]));
-    ZKW_TRY(ctx->scratch_t<u64>("sort_k64a", n, &k64a));
-    ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", n, &k64b));
-    ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
-    { Prof _p(ctx, "k_decommit_sort_keys"); hipLaunchKernelGGL(k_decommit_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, ts, hk[0], hk[1], hk[2], hk[3], v0); }
-    ZKW_TRY(launch_check("k_decommit_sort_keys"));
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, ts, k32, v0, v1, n, 32, ctx->stream)); }
-    u32 *cur = v1, *nxt = v0;
-    for (int k = 0; k < 4; k++) {
-        { Prof _p(ctx, "k_gather_u64_by_u32"); hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, hk[k], cur, n, k64a); }
-        ZKW_TRY(launch_check("k_gather_u64_by_u32"));
-        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, cur, nxt, n, 64, ctx->stream)); }
-        u32* t = cur; cur = nxt; nxt = t;
-    }
-    { Prof _p(ctx, "k_decommit_gather_encode"); hipLaunchKernelGGL(k_decommit_gather_encode, dim3(grid), dim3(256), 0, ctx->stream, d_q, cur, n, w->sorted_q, w->sorted_enc); }
-    ZKW_TRY(launch_check("k_decommit_gather_encode"));
-    // deduplicated queue = the fresh requests in sorted order
-    u32 *fresh_count = nullptr, *last_fresh = nullptr, *totals = nullptr;
-    ZKW_TRY(ctx->scratch_t<u32>("dec_fresh", n, &fresh_count));
-    ZKW_TRY(ctx->scratch_t<u32>("dec_lastf", n, &last_fresh));
-    ZKW_TRY(ctx->scratch_t<u32>("dec_totals", 2, &totals));
-    { Prof _p(ctx, "k_decommit_dedup"); hipLaunchKernelGGL(k_decommit_dedup, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, w->sorted_enc, n, fresh_count, last_fresh, w->dedup_q, w->dedup_enc, totals); }
-    ZKW_TRY(launch_check("k_decommit_dedup"));
-    u32 h_totals[2] = {0, 0};
-    ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
-    if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "decommit requests with the same hash disagree on page or are not "
-                                                       "timestamp-ordered (sort_decommit_requests.rs:99-114)");
-    w->n_dedup = h_totals[0];
-    w->fresh_count = fresh_count;
-    w->last_fresh = last_fresh;
-    return ZKW_OK;
-}
-
-// phase 2 (hashes): the three queue chains in one launch, challenges, grand products, instance records
-static int decommit_finish(zkw_ctx* ctx, zkw_decommit_witness* w) {
-    const size_t n = w->n;
-    const zkw_queue_state12& dedup_in = w->dedup_in;
-    u32 *fresh_count = w->fresh_count, *last_fresh = w->last_fresh;
-    zkw_queue_state12* d_dedup_in = nullptr;
-    std::vector<zkw_queue_state12> din(1, dedup_in);
-    ZKW_TRY(ctx->upload("dec_dedup_in", din, &d_dedup_in));
-    std::vector<ChainJob> chains;
-    chains.push_back(ChainJob{w->unsorted_enc, w->unsorted_tails, nullptr, n});
-    chains.push_back(ChainJob{w->sorted_enc, w->sorted_tails, nullptr, n});
-    chains.push_back(ChainJob{w->dedup_enc, w->dedup_tails, d_dedup_in->tail, w->n_dedup});
-    ZKW_TRY(dev_chains(ctx, chains));
-    std::vector<FsJob> fs(1);
-    fs[0] = FsJob{w->unsorted_tails + 12 * (n - 1), w->sorted_tails + 12 * (n - 1), (u32)n, (u32)n, w->challenges};
-    ZKW_TRY(dev_fs(ctx, fs, 12, 9));
-    std::vector<GpSeg> segs;
-    segs.push_back(GpSeg{w->unsorted_enc, w->lhs_z, w->challenges, n, 0, 0});
-    segs.push_back(GpSeg{w->sorted_enc, w->rhs_z, w->challenges, n, 0, 0});
-    ZKW_TRY(dev_grand_products(ctx, segs, 8, 2));
-    std::vector<DecommitBlock> blk(1);
-    blk[0] = DecommitBlock{w->sorted_q, w->unsorted_tails, w->sorted_tails, w->dedup_tails, w->lhs_z, w->rhs_z,
-                           fresh_count, last_fresh, w->instances, dedup_in, n, w->capacity};
-    DecommitBlock* d_blk = nullptr;
-    ZKW_TRY(ctx->upload("dec_block", blk, &d_blk));
-    { Prof _p(ctx, "k_decommit_instances"); hipLaunchKernelGGL(k_decommit_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
-    return launch_check("k_decommit_instances");
-}
-
-extern "C" void zkw_decommit_witness_free(zkw_decommit_witness* w);
-
-extern "C" int zkw_decommit_sorter_prepare(zkw_ctx* ctx, const zkw_decommit_query* q, size_t n, uint32_t capacity,
-                                           const zkw_queue_state12* dedup_in, zkw_decommit_witness** out) {
-    if (!ctx || !q || !out || capacity == 0) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_prepare: bad argument");
-    if (n == 0) return fail(ZKW_ERR_INVALID, "VM should have made some code decommits (sort_decommit_requests.rs:38-41)");
-    if (n >= (1ull << 32)) return fail(ZKW_ERR_INVALID, "too many requests");
-    HIP_TRY(hipSetDevice(ctx->device));
-    zkw_decommit_witness* w = new zkw_decommit_witness();
-    w->ctx = ctx;
-    w->n = n;
-    w->capacity = capacity;
-    w->n_instances = (n + capacity - 1) / capacity;
-    hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
-    alloc((void**)&w->sorted_q, n * sizeof(zkw_decommit_query));
-    alloc((void**)&w->dedup_q, n * sizeof(zkw_decommit_query));
-    alloc((void**)&w->unsorted_enc, n * 64); alloc((void**)&w->sorted_enc, n * 64); alloc((void**)&w->dedup_enc, n * 64);
-    alloc((void**)&w->unsorted_tails, n * 96); alloc((void**)&w->sorted_tails, n * 96); alloc((void**)&w->dedup_tails, n * 96);
-    alloc((void**)&w->challenges, 18 * 8); alloc((void**)&w->lhs_z, n * 16); alloc((void**)&w->rhs_z, n * 16);
-    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_decommit_sorter_instance));
-    alloc((void**)&w->compact_forms, w->n_instances * COMPACT_FORM_LEN * 8);
-    alloc((void**)&w->public_inputs, w->n_instances * 32);
-    if (e != hipSuccess) {
-        w->release();
-        delete w;
-        return fail(ZKW_ERR_OOM, "zkw_decommit_sorter_prepare: hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    memset(&w->dedup_in, 0, sizeof w->dedup_in);
-    if (dedup_in) w->dedup_in = *dedup_in;
-    const zkw_decommit_query* d_q = nullptr;
-    int rc = ctx->in("dec_q", q, n, &d_q);
-    if (rc == ZKW_OK) rc = decommit_prepare(ctx, w, d_q);
-    if (rc != ZKW_OK) {
-        w->release();
-        delete w;
-        return rc;
-    }
-    ctx_retain(ctx);
-    *out = w;
-    return ZKW_OK;
-}
-
-extern "C" int zkw_decommit_sorter_finish(zkw_ctx* ctx, zkw_decommit_witness* w) {
-    if (!ctx || !w || w->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_finish: bad argument");
-    if (w->finished) return ZKW_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    const size_t n = w->n;
-    int rc = decommit_finish(ctx, w);
-    if (rc == ZKW_OK) {  // a20: compact forms and public inputs (postprocessing/mod.rs:353-369)
-        const size_t ni = w->n_instances;
-        { Prof _p(ctx, "k_ds_commitments"); hipLaunchKernelGGL(k_ds_commitments, dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, w->instances, ni, w->compact_forms); }
-        rc = launch_check("k_ds_commitments");
-        if (rc == ZKW_OK) {
-            { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, w->compact_forms, ni, (u32)COMPACT_FORM_LEN, w->public_inputs); }
-            rc = launch_check("k_commit_encodings");
-        }
-    }
-    if (rc == ZKW_OK) rc = ctx->sync_if_host();
-    if (rc == ZKW_OK && ctx->ptr_mode == ZKW_PTR_HOST) {  // lhs == rhs at the end (utils.rs:685-696)
-        u64 ends[4];
-        for (int r = 0; r < 2 && rc == ZKW_OK; r++) {
-            if (hipMemcpy(&ends[2 * r], w->lhs_z + (size_t)r * n + n - 1, 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                hipMemcpy(&ends[2 * r + 1], w->rhs_z + (size_t)r * n + n - 1, 8, hipMemcpyDeviceToHost) != hipSuccess)
-                rc = fail(ZKW_ERR_HIP, "readback failed");
-            else if (ends[2 * r] != ends[2 * r + 1])
-                rc = fail(ZKW_ERR_CHECK_FAILED, "grand products differ in repetition %d", r);
-        }
-    }
-    if (rc == ZKW_OK) w->finished = true;
-    return rc;
-}
-
-extern "C" int zkw_decommit_sorter_build(zkw_ctx* ctx, const zkw_decommit_query* q, size_t n, uint32_t capacity,
-                                         const zkw_queue_state12* dedup_in, zkw_decommit_witness** out) {
-    if (!out) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_build: bad argument");
-    zkw_decommit_witness* w = nullptr;
-    ZKW_TRY(zkw_decommit_sorter_prepare(ctx, q, n, capacity, dedup_in, &w));
-    const int rc = zkw_decommit_sorter_finish(ctx, w);
-    if (rc != ZKW_OK) {
-        zkw_decommit_witness_free(w);
-        return rc;
-    }
-    *out = w;
-    return ZKW_OK;
-}
-
-extern "C" size_t zkw_decommit_witness_num_instances(const zkw_decommit_witness* w) { return w ? w->n_instances : 0; }
-extern "C" size_t zkw_decommit_witness_num_dedup(const zkw_decommit_witness* w) { return w ? w->n_dedup : 0; }
-
-static const void* dec_array(const zkw_decommit_witness* w, int what, size_t* bytes) {
-    const size_t n = w->n, nd = w->n_dedup;
-    switch (what) {
-        case ZKW_DEC_SORTED_QUERIES: *bytes = n * sizeof(zkw_decommit_query); return w->sorted_q;
-        case ZKW_DEC_UNSORTED_ENC: *bytes = n * 64; return w->unsorted_enc;
-        case ZKW_DEC_SORTED_ENC: *bytes = n * 64; return w->sorted_enc;
-        case ZKW_DEC_UNSORTED_TAILS: *bytes = n * 96; return w->unsorted_tails;
-        case ZKW_DEC_SORTED_TAILS: *bytes = n * 96; return w->sorted_tails;
-        case ZKW_DEC_DEDUP_QUERIES: *bytes = nd * sizeof(zkw_decommit_query); return w->dedup_q;
-        case ZKW_DEC_DEDUP_TAILS: *bytes = nd * 96; return w->dedup_tails;
-        case ZKW_DEC_CHALLENGES: *bytes = 18 * 8; return w->challenges;
-        case ZKW_DEC_LHS_Z: *bytes = n * 16; return w->lhs_z;
-        case ZKW_DEC_RHS_Z: *bytes = n * 16; return w->rhs_z;
-        case ZKW_DEC_INSTANCES: *bytes = w->n_instances * sizeof(zkw_decommit_sorter_instance); return w->instances;
-        case ZKW_DEC_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->compact_forms;
-        case ZKW_DEC_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->public_inputs;
-        default: *bytes = 0; return nullptr;
-    }
-}
-extern "C" size_t zkw_decommit_witness_bytes(const zkw_decommit_witness* w, int what) {
-    size_t b = 0;
-    if (w) (void)dec_array(w, what, &b);
-    return b;
-}
-extern "C" const void* zkw_decommit_witness_device_ptr(const zkw_decommit_witness* w, int what) {
-    size_t b = 0;
-    return w ? dec_array(w, what, &b) : nullptr;
-}
-extern "C" int zkw_decommit_witness_get(const zkw_decommit_witness* w, int what, void* dst, size_t dst_bytes) {
-    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_decommit_witness_get: null argument");
-    size_t bytes = 0;
-    const void* src = dec_array(w, what, &bytes);
-    if (!src && bytes == 0 && what > ZKW_DEC_PUBLIC_INPUTS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
-    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
-    if (bytes == 0) return ZKW_OK;
-    zkw_ctx* ctx = w->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-    return ctx->sync_if_host();
-}
-extern "C" void zkw_decommit_witness_free(zkw_decommit_witness* w) {
-    if (!w) return;
-    (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
-    w->release();
-    zkw_ctx* owner = w->ctx;
-    delete w;
-    ctx_release(owner);
-}
-
-// ------------------------------------------------------------------------------------------------ events sorter
-// a20 for the 4-wide log-queue circuits: compact closed-form inputs [ni][18] followed by the public inputs [ni][4]
-// in one allocation (ClosedFormInputCompactForm::from_full_form + commit, postprocessing/mod.rs:353-369)
-template <class T>
-static int closed_form_public_inputs(zkw_ctx* ctx, const typename T::Inst* d_inst, size_t ni, u64** cf_pi) {
-    if (!*cf_pi) HIP_TRY(dev_malloc((void**)cf_pi, ni * (COMPACT_FORM_LEN + 4) * sizeof(u64)));
-    u64 *compact = *cf_pi, *pis = *cf_pi + COMPACT_FORM_LEN * ni;
-    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3(blocks_for(4 * ni, CfLanes<T>::value)), dim3(CfLanes<T>::value), 0, ctx->stream, d_inst, ni, compact); }
-    ZKW_TRY(launch_check("k_closed_form_commitments"));
-    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, compact, ni, (u32)COMPACT_FORM_LEN, pis); }
-    return launch_check("k_commit_encodings");
-}
-
-// a20 for the circuits whose builders keep no compact forms themselves (3, 5, 6, 7, 10, 13): commitments straight from
-// the instance records
-template <class T>
-static int closed_form_from_records(zkw_ctx* ctx, const void* instances, size_t n, uint64_t* compact, uint64_t* public_inputs) {
-    const typename T::Inst* d_inst = nullptr;
-    ZKW_TRY(ctx->in("cf_records", static_cast<const typename T::Inst*>(instances), n, &d_inst));
-    u64 *d_cf = nullptr, *d_pi = nullptr;
-    ZKW_TRY(ctx->out("cf_compact", reinterpret_cast<u64*>(compact), n * COMPACT_FORM_LEN, &d_cf));
-    ZKW_TRY(ctx->out("cf_pi", reinterpret_cast<u64*>(public_inputs), n * 4, &d_pi));
-    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3(blocks_for(4 * n, CfLanes<T>::value)), dim3(CfLanes<T>::value), 0, ctx->stream, d_inst, n, d_cf); }
-    ZKW_TRY(launch_check("k_closed_form_commitments"));
-    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, d_cf, n, (u32)COMPACT_FORM_LEN, d_pi); }
-    ZKW_TRY(launch_check("k_commit_encodings"));
-    ZKW_TRY(ctx->finish_out(reinterpret_cast<u64*>(compact), d_cf, n * COMPACT_FORM_LEN));
-    ZKW_TRY(ctx->finish_out(reinterpret_cast<u64*>(public_inputs), d_pi, n * 4));
-    return ctx->sync_if_host();
-}
-
+// ------------------------------------------------------------------------------------------------ closed forms from records (a20)
 extern "C" int zkw_closed_form_public_inputs(zkw_ctx* ctx, uint8_t circuit_type, const void* instances, size_t n, uint64_t* compact,
                                              uint64_t* public_inputs) {
     if (!ctx || !compact || !public_inputs || (n && !instances)) return fail(ZKW_ERR_INVALID, "zkw_closed_form_public_inputs: null argument");
@@ -2258,774 +1423,6 @@ extern "C" int zkw_closed_form_public_inputs(zkw_ctx* ctx, uint8_t circuit_type,
     }
     return fail(ZKW_ERR_INVALID, "zkw_closed_form_public_inputs: circuit type %u keeps its compact forms in its witness (2, 4, 8, 9, 11, 12) "
                                  "or is not a base-layer circuit with a closed form here", (unsigned)circuit_type);
-}
-
-struct zkw_events_witness {
-    zkw_ctx* ctx = nullptr;
-    size_t n = 0, n_instances = 0, n_result = 0;
-    uint32_t capacity = 0;
-    zkw_log_query *sorted_q = nullptr, *result_q = nullptr;
-    u64* enc_all = nullptr;    // [3n][20]: unsorted | sorted | result (one array so that one prehash covers all)
-    u64* tails_all = nullptr;  // [5n][4]: unsorted old | unsorted new | sorted old | sorted new | result new
-    u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
-    zkw_events_sorter_instance* instances = nullptr;
-    zkw_queue_state4 result_in;  // state of the result queue before the block (host copy)
-    u32* kept_prefix = nullptr;  // [n + 1], computed by the first synthesis call
-    u64* cf_pi = nullptr;        // compact forms [ni][18] | public inputs [ni][4]
-    void release() {
-        void* ptrs[] = {sorted_q, result_q, enc_all, tails_all, challenges, lhs_z, rhs_z, instances, kept_prefix, cf_pi};
-        for (void* p : ptrs)
-            if (p) dev_free(p);
-    }
-};
-
-static int events_run(zkw_ctx* ctx, zkw_events_witness* w, const zkw_log_query* d_q, const zkw_queue_state4& result_in) {
-    const size_t n = w->n;
-    const unsigned grid = blocks_for(n, 256);
-    u64 *u_enc = w->enc_all, *s_enc = w->enc_all + 20 * n, *r_enc = w->enc_all + 40 * n;
-    u64 *u_old = w->tails_all, *u_new = u_old + 4 * n, *s_old = u_new + 4 * n, *s_new = s_old + 4 * n, *r_new = s_new + 4 * n;
-    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, u_enc); }
-    ZKW_TRY(launch_check("k_encode_log"));
-    // stable sort by (timestamp, rollback): 33-bit key
-    u64 *key = nullptr, *key_out = nullptr;
-    u32 *v0 = nullptr, *v1 = nullptr, *kept = nullptr, *totals = nullptr;
-    void* tmp = nullptr;
-    size_t tmp_bytes = radix_temp_bytes(n);
-    ZKW_TRY(ctx->scratch_t<u64>("sort_k64a", n, &key));
-    ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", n, &key_out));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_v0", n, &v0));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_v1", n, &v1));
-    ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
-    { Prof _p(ctx, "k_events_sort_keys"); hipLaunchKernelGGL(k_events_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, key, v0); }
-    ZKW_TRY(launch_check("k_events_sort_keys"));
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, key, key_out, v0, v1, n, 33, ctx->stream)); }
-    { Prof _p(ctx, "k_log_gather_encode"); hipLaunchKernelGGL(k_log_gather_encode, dim3(grid), dim3(256), 0, ctx->stream, d_q, v1, n, w->sorted_q, s_enc); }
-    ZKW_TRY(launch_check("k_log_gather_encode"));
-    ZKW_TRY(ctx->scratch_t<u32>("evt_kept", n, &kept));
-    ZKW_TRY(ctx->scratch_t<u32>("evt_totals", 2, &totals));
-    { Prof _p(ctx, "k_events_dedup"); hipLaunchKernelGGL(k_events_dedup, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, kept, w->result_q, r_enc, totals); }
-    ZKW_TRY(launch_check("k_events_dedup"));
-    u32 h_totals[2] = {0, 0};
-    ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
-    if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "event queue is not a sequence of forward events each optionally followed by "
-                                                       "its own rollback (events_sort_dedup.rs:344-356, 512-533): %u violations", h_totals[1]);
-    w->n_result = h_totals[0];
-    zkw_queue_state4* d_rin = nullptr;
-    std::vector<zkw_queue_state4> rin(1, result_in);
-    ZKW_TRY(ctx->upload("evt_result_in", rin, &d_rin));
-    std::vector<LogChainJob> chains;
-    chains.push_back(LogChainJob{u_enc, nullptr, u_old, u_new, nullptr, n});
-    chains.push_back(LogChainJob{s_enc, nullptr, s_old, s_new, nullptr, n});
-    chains.push_back(LogChainJob{r_enc, nullptr, nullptr, r_new, d_rin->tail, w->n_result});
-    ZKW_TRY(dev_log_chains(ctx, w->enc_all, 3 * n, chains));
-    std::vector<FsJob> fs(1);
-    fs[0] = FsJob{u_new + 4 * (n - 1), s_new + 4 * (n - 1), (u32)n, (u32)n, w->challenges};
-    ZKW_TRY(dev_fs(ctx, fs, 4, 21));
-    std::vector<GpSeg> segs;
-    segs.push_back(GpSeg{u_enc, w->lhs_z, w->challenges, n, 0, 0});
-    segs.push_back(GpSeg{s_enc, w->rhs_z, w->challenges, n, 0, 0});
-    ZKW_TRY(dev_grand_products(ctx, segs, 20, 2));
-    std::vector<EventsBlock> blk(1);
-    blk[0] = EventsBlock{w->sorted_q, u_new, s_new, r_new, w->lhs_z, w->rhs_z, kept, w->instances, result_in, n, w->capacity};
-    EventsBlock* d_blk = nullptr;
-    ZKW_TRY(ctx->upload("evt_block", blk, &d_blk));
-    { Prof _p(ctx, "k_events_instances"); hipLaunchKernelGGL(k_events_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
-    return launch_check("k_events_instances");
-}
-
-extern "C" int zkw_events_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, size_t n, uint32_t capacity,
-                                       const zkw_queue_state4* result_in, zkw_events_witness** out) {
-    if (!ctx || !out || capacity == 0 || (n && !q)) return fail(ZKW_ERR_INVALID, "zkw_events_sorter_build: bad argument");
-    if (n >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many log queries");
-    HIP_TRY(hipSetDevice(ctx->device));
-    zkw_events_witness* w = new zkw_events_witness();
-    w->ctx = ctx;
-    w->n = n;
-    w->capacity = capacity;
-    w->n_instances = n ? (n + capacity - 1) / capacity : 1;
-    const size_t m = n ? n : 1;
-    hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
-    alloc((void**)&w->sorted_q, m * sizeof(zkw_log_query));
-    alloc((void**)&w->result_q, m * sizeof(zkw_log_query));
-    alloc((void**)&w->enc_all, 3 * m * 160);
-    alloc((void**)&w->tails_all, 5 * m * 32);
-    alloc((void**)&w->challenges, 42 * 8);
-    alloc((void**)&w->lhs_z, m * 16);
-    alloc((void**)&w->rhs_z, m * 16);
-    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_events_sorter_instance));
-    if (e != hipSuccess) {
-        w->release();
-        delete w;
-        return fail(ZKW_ERR_OOM, "zkw_events_sorter_build: hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    zkw_queue_state4 rin;
-    memset(&rin, 0, sizeof rin);
-    if (result_in) rin = *result_in;
-    w->result_in = rin;
-    int rc = ZKW_OK;
-    if (n == 0) {  // events_sort_dedup.rs:27-76: one dummy instance, accumulators forced to ONE
-        zkw_events_sorter_instance inst;
-        memset(&inst, 0, sizeof inst);
-        inst.start_flag = inst.completion_flag = 1;
-        for (int r = 0; r < 2; r++) {
-            inst.hidden_fsm_input.lhs_accumulator[r] = inst.hidden_fsm_input.rhs_accumulator[r] = 1;
-            inst.hidden_fsm_output.lhs_accumulator[r] = inst.hidden_fsm_output.rhs_accumulator[r] = 1;
-        }
-        if (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemset(w->challenges, 0, 42 * 8) != hipSuccess)
-            rc = fail(ZKW_ERR_HIP, "copy failed");
-    } else {
-        const zkw_log_query* d_q = nullptr;
-        rc = ctx->in("evt_q", q, n, &d_q);
-        if (rc == ZKW_OK) rc = events_run(ctx, w, d_q, rin);
-    }
-    if (rc == ZKW_OK) rc = closed_form_public_inputs<CfEventsSorter>(ctx, w->instances, w->n_instances, &w->cf_pi);
-    if (rc == ZKW_OK) rc = ctx->sync_if_host();
-    if (rc != ZKW_OK) {
-        w->release();
-        delete w;
-        return rc;
-    }
-    ctx_retain(ctx);
-    *out = w;
-    return ZKW_OK;
-}
-
-extern "C" size_t zkw_events_witness_num_instances(const zkw_events_witness* w) { return w ? w->n_instances : 0; }
-extern "C" size_t zkw_events_witness_num_results(const zkw_events_witness* w) { return w ? w->n_result : 0; }
-
-static const void* evt_array(const zkw_events_witness* w, int what, size_t* bytes) {
-    const size_t n = w->n, nr = w->n_result;
-    switch (what) {
-        case ZKW_EVT_SORTED_QUERIES: *bytes = n * sizeof(zkw_log_query); return w->sorted_q;
-        case ZKW_EVT_UNSORTED_ENC: *bytes = n * 160; return w->enc_all;
-        case ZKW_EVT_SORTED_ENC: *bytes = n * 160; return w->enc_all + 20 * n;
-        case ZKW_EVT_UNSORTED_OLD_TAILS: *bytes = n * 32; return w->tails_all;
-        case ZKW_EVT_UNSORTED_NEW_TAILS: *bytes = n * 32; return w->tails_all + 4 * n;
-        case ZKW_EVT_SORTED_OLD_TAILS: *bytes = n * 32; return w->tails_all + 8 * n;
-        case ZKW_EVT_SORTED_NEW_TAILS: *bytes = n * 32; return w->tails_all + 12 * n;
-        case ZKW_EVT_RESULT_QUERIES: *bytes = nr * sizeof(zkw_log_query); return w->result_q;
-        case ZKW_EVT_RESULT_NEW_TAILS: *bytes = nr * 32; return w->tails_all + 16 * n;
-        case ZKW_EVT_CHALLENGES: *bytes = 42 * 8; return w->challenges;
-        case ZKW_EVT_LHS_Z: *bytes = n * 16; return w->lhs_z;
-        case ZKW_EVT_RHS_Z: *bytes = n * 16; return w->rhs_z;
-        case ZKW_EVT_INSTANCES: *bytes = w->n_instances * sizeof(zkw_events_sorter_instance); return w->instances;
-        case ZKW_EVT_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->cf_pi;
-        case ZKW_EVT_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->cf_pi + COMPACT_FORM_LEN * w->n_instances;
-        default: *bytes = 0; return nullptr;
-    }
-}
-extern "C" size_t zkw_events_witness_bytes(const zkw_events_witness* w, int what) {
-    size_t b = 0;
-    if (w) (void)evt_array(w, what, &b);
-    return b;
-}
-extern "C" const void* zkw_events_witness_device_ptr(const zkw_events_witness* w, int what) {
-    size_t b = 0;
-    return w ? evt_array(w, what, &b) : nullptr;
-}
-extern "C" int zkw_events_witness_get(const zkw_events_witness* w, int what, void* dst, size_t dst_bytes) {
-    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_events_witness_get: null argument");
-    if (what < 0 || what > ZKW_EVT_PUBLIC_INPUTS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
-    size_t bytes = 0;
-    const void* src = evt_array(w, what, &bytes);
-    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
-    if (bytes == 0) return ZKW_OK;
-    zkw_ctx* ctx = w->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-    return ctx->sync_if_host();
-}
-extern "C" void zkw_events_witness_free(zkw_events_witness* w) {
-    if (!w) return;
-    (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
-    w->release();
-    zkw_ctx* owner = w->ctx;
-    delete w;
-    ctx_release(owner);
-}
-
-// ------------------------------------------------------------------------------------------------ log demuxer
-struct zkw_demux_witness {
-    zkw_ctx* ctx = nullptr;
-    size_t n = 0, n_instances = 0, routed = 0;
-    uint32_t capacity = 0;
-    uint64_t offsets[7] = {0, 0, 0, 0, 0, 0, 0};
-    zkw_log_query* out_q = nullptr;
-    u64* enc_all = nullptr;    // [2n][20]: input | routed
-    u64* tails_all = nullptr;  // [4n][4]: in old | in new | out old | out new
-    u64* d_offsets = nullptr;  // [8]
-    u32* route_count = nullptr;  // [6][n] inclusive prefix counts per route (kept for synthesis)
-    bool default_params = true;
-    zkw_log_demux_instance* instances = nullptr;
-    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4]
-    void release() {
-        void* ptrs[] = {out_q, enc_all, tails_all, d_offsets, route_count, instances, cf_pi};
-        for (void* p : ptrs)
-            if (p) dev_free(p);
-    }
-};
-
-static int demux_run(zkw_ctx* ctx, zkw_demux_witness* w, const zkw_log_query* d_q, const zkw_demux_params& params) {
-    const size_t n = w->n;
-    u64 *in_enc = w->enc_all, *out_enc = w->enc_all + 20 * n;
-    u64 *in_old = w->tails_all, *in_new = in_old + 4 * n, *out_old = in_new + 4 * n, *out_new = out_old + 4 * n;
-    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, in_enc); }
-    ZKW_TRY(launch_check("k_encode_log"));
-    u32* route_count = w->route_count;
-    { Prof _p(ctx, "k_demux_route"); hipLaunchKernelGGL(k_demux_route, dim3(1), dim3(1024), 0, ctx->stream, d_q, in_enc, n, params, route_count, w->out_q, out_enc, w->d_offsets); }
-    ZKW_TRY(launch_check("k_demux_route"));
-    u64 h_tot[8];
-    ZKW_TRY(ctx->read_small(h_tot, w->d_offsets, sizeof h_tot));
-    if (h_tot[7]) return fail(ZKW_ERR_CHECK_FAILED, "%llu log queries have an aux byte / shard / rollback combination the "
-                                                    "reference treats as unreachable (log_demux.rs:174-249)", (unsigned long long)h_tot[7]);
-    for (int k = 0; k < 7; k++) w->offsets[k] = h_tot[k];
-    w->routed = h_tot[6];
-    std::vector<LogChainJob> chains;
-    chains.push_back(LogChainJob{in_enc, nullptr, in_old, in_new, nullptr, n});
-    for (int k = 0; k < 6; k++) {
-        const size_t lo = w->offsets[k], cnt = w->offsets[k + 1] - lo;
-        chains.push_back(LogChainJob{out_enc + 20 * lo, nullptr, out_old + 4 * lo, out_new + 4 * lo, nullptr, cnt});
-    }
-    ZKW_TRY(dev_log_chains(ctx, w->enc_all, n + w->routed, chains));
-    std::vector<DemuxBlock> blk(1);
-    blk[0].in_new_tails = in_new;
-    blk[0].out_new_tails = out_new;
-    blk[0].route_count = route_count;
-    blk[0].instances = w->instances;
-    for (int k = 0; k < 7; k++) blk[0].offsets[k] = w->offsets[k];
-    blk[0].n = n;
-    blk[0].capacity = w->capacity;
-    DemuxBlock* d_blk = nullptr;
-    ZKW_TRY(ctx->upload("dmx_block", blk, &d_blk));
-    { Prof _p(ctx, "k_demux_instances"); hipLaunchKernelGGL(k_demux_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
-    return launch_check("k_demux_instances");
-}
-
-extern "C" int zkw_log_demux_build(zkw_ctx* ctx, const zkw_log_query* q, size_t n, uint32_t capacity,
-                                   const zkw_demux_params* params, zkw_demux_witness** out) {
-    if (!ctx || !out || capacity == 0 || (n && !q)) return fail(ZKW_ERR_INVALID, "zkw_log_demux_build: bad argument");
-    if (n >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many log queries");
-    HIP_TRY(hipSetDevice(ctx->device));
-    zkw_demux_witness* w = new zkw_demux_witness();
-    w->ctx = ctx;
-    w->n = n;
-    w->capacity = capacity;
-    w->n_instances = n ? (n + capacity - 1) / capacity : 1;
-    const size_t m = n ? n : 1;
-    hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
-    alloc((void**)&w->out_q, m * sizeof(zkw_log_query));
-    alloc((void**)&w->enc_all, 2 * m * 160);
-    alloc((void**)&w->tails_all, 4 * m * 32);
-    alloc((void**)&w->d_offsets, 8 * 8);
-    alloc((void**)&w->route_count, 6 * m * sizeof(u32));
-    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_log_demux_instance));
-    if (e != hipSuccess) {
-        w->release();
-        delete w;
-        return fail(ZKW_ERR_OOM, "zkw_log_demux_build: hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    zkw_demux_params p = ZKW_DEMUX_PARAMS_DEFAULT;
-    if (params) p = *params;
-    {
-        const zkw_demux_params d = ZKW_DEMUX_PARAMS_DEFAULT;
-        w->default_params = memcmp(&p, &d, sizeof d) == 0;
-    }
-    int rc = ZKW_OK;
-    if (n == 0) {  // log_demux.rs:51-107
-        zkw_log_demux_instance inst;
-        memset(&inst, 0, sizeof inst);
-        inst.start_flag = inst.completion_flag = 1;
-        if (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemset(w->d_offsets, 0, 64) != hipSuccess)
-            rc = fail(ZKW_ERR_HIP, "copy failed");
-    } else {
-        const zkw_log_query* d_q = nullptr;
-        rc = ctx->in("dmx_q", q, n, &d_q);
-        if (rc == ZKW_OK) rc = demux_run(ctx, w, d_q, p);
-    }
-    if (rc == ZKW_OK) rc = closed_form_public_inputs<CfLogDemux>(ctx, w->instances, w->n_instances, &w->cf_pi);
-    if (rc == ZKW_OK) rc = ctx->sync_if_host();
-    if (rc != ZKW_OK) {
-        w->release();
-        delete w;
-        return rc;
-    }
-    ctx_retain(ctx);
-    *out = w;
-    return ZKW_OK;
-}
-
-extern "C" size_t zkw_demux_witness_num_instances(const zkw_demux_witness* w) { return w ? w->n_instances : 0; }
-static const void* dmx_array(const zkw_demux_witness* w, int what, size_t* bytes) {
-    const size_t n = w->n, r = w->routed;
-    switch (what) {
-        case ZKW_DMX_IN_ENC: *bytes = n * 160; return w->enc_all;
-        case ZKW_DMX_IN_OLD_TAILS: *bytes = n * 32; return w->tails_all;
-        case ZKW_DMX_IN_NEW_TAILS: *bytes = n * 32; return w->tails_all + 4 * n;
-        case ZKW_DMX_OUT_QUERIES: *bytes = r * sizeof(zkw_log_query); return w->out_q;
-        case ZKW_DMX_OUT_ENC: *bytes = r * 160; return w->enc_all + 20 * n;
-        case ZKW_DMX_OUT_OLD_TAILS: *bytes = r * 32; return w->tails_all + 8 * n;
-        case ZKW_DMX_OUT_NEW_TAILS: *bytes = r * 32; return w->tails_all + 12 * n;
-        case ZKW_DMX_OUT_OFFSETS: *bytes = 7 * 8; return w->d_offsets;
-        case ZKW_DMX_INSTANCES: *bytes = w->n_instances * sizeof(zkw_log_demux_instance); return w->instances;
-        case ZKW_DMX_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->cf_pi;
-        case ZKW_DMX_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->cf_pi + COMPACT_FORM_LEN * w->n_instances;
-        default: *bytes = 0; return nullptr;
-    }
-}
-extern "C" size_t zkw_demux_witness_bytes(const zkw_demux_witness* w, int what) {
-    size_t b = 0;
-    if (w) (void)dmx_array(w, what, &b);
-    return b;
-}
-extern "C" const void* zkw_demux_witness_device_ptr(const zkw_demux_witness* w, int what) {
-    size_t b = 0;
-    return w ? dmx_array(w, what, &b) : nullptr;
-}
-extern "C" int zkw_demux_witness_get(const zkw_demux_witness* w, int what, void* dst, size_t dst_bytes) {
-    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_demux_witness_get: null argument");
-    if (what < 0 || what > ZKW_DMX_PUBLIC_INPUTS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
-    size_t bytes = 0;
-    const void* src = dmx_array(w, what, &bytes);
-    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
-    if (bytes == 0) return ZKW_OK;
-    zkw_ctx* ctx = w->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-    return ctx->sync_if_host();
-}
-extern "C" void zkw_demux_witness_free(zkw_demux_witness* w) {
-    if (!w) return;
-    (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
-    w->release();
-    zkw_ctx* owner = w->ctx;
-    delete w;
-    ctx_release(owner);
-}
-
-// ------------------------------------------------------------------------------------------------ storage sorter
-struct zkw_storage_witness {
-    zkw_ctx* ctx = nullptr;
-    size_t n = 0, n_instances = 0, n_result = 0;
-    uint32_t capacity = 0;
-    zkw_log_query *sorted_q = nullptr, *result_q = nullptr;
-    u32* sorted_ext = nullptr;
-    u64* enc_all = nullptr;    // [3n][20]: unsorted plain | sorted (ext) | result : the three hashed queues
-    u64* lhs_enc = nullptr;    // [n][20]: unsorted with extended timestamp (permutation argument only)
-    u64* tails_all = nullptr;  // [5n][4]
-    u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
-    u32* scans = nullptr;  // [4][n]: D, S, R, E of k_storage_cells (kept for synthesis)
-    zkw_storage_sorter_instance* instances = nullptr;
-    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4]
-    void release() {
-        void* ptrs[] = {sorted_q, result_q, sorted_ext, enc_all, lhs_enc, tails_all, challenges, lhs_z, rhs_z, scans, instances, cf_pi};
-        for (void* p : ptrs)
-            if (p) dev_free(p);
-    }
-};
-
-static int storage_run(zkw_ctx* ctx, zkw_storage_witness* w, const zkw_log_query* d_q) {
-    const size_t n = w->n;
-    const unsigned grid = blocks_for(n, 256);
-    u64 *u_enc = w->enc_all, *s_enc = w->enc_all + 20 * n, *r_enc = w->enc_all + 40 * n;
-    u64 *u_old = w->tails_all, *u_new = u_old + 4 * n, *s_old = u_new + 4 * n, *s_new = s_old + 4 * n, *r_new = s_new + 4 * n;
-    // sort keys; the initial order IS the extended timestamp, so 7 stable passes (key low..high, address low..high)
-    u64 *kk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *k64a = nullptr, *k64b = nullptr;
-    u32 *a2 = nullptr, *k32a = nullptr, *k32b = nullptr, *v0 = nullptr, *v1 = nullptr;
-    void* tmp = nullptr;
-    size_t tmp_bytes = radix_temp_bytes(n);
-    const char* kn[6] = {"ssort_k0", "ssort_k1", "ssort_k2", "ssort_k3", "ssort_a0", "ssort_a1"};
-    for (int k = 0; k < 6; k++) ZKW_TRY(ctx->scratch_t<u64>(kn[k], n, &kk[k]));
-    ZKW_TRY(ctx->scratch_t<u32>("ssort_a2", n, &a2));
-    ZKW_TRY(ctx->scratch_t<u64>("sort_k64a", n, &k64a));
-    ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", n, &k64b));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_ts", n, &k32a));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_k32", n, &k32b));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_v0", n, &v0));
-    ZKW_TRY(ctx->scratch_t<u32>("sort_v1", n, &v1));
-    ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
-    u32* iota = nullptr;
-    ZKW_TRY(ctx->scratch_t<u32>("ssort_iota", n, &iota));
-    { Prof _p(ctx, "k_storage_sort_keys"); hipLaunchKernelGGL(k_storage_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], a2, iota); }
-    ZKW_TRY(launch_check("k_storage_sort_keys"));
-    // plain and extended encodings of the unsorted side
-    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, u_enc); }
-    ZKW_TRY(launch_check("k_encode_log"));
-    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, (const u32*)iota, w->lhs_enc); }
-    ZKW_TRY(launch_check("k_encode_log"));
-    HIP_TRY(hipMemcpyAsync(v0, iota, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
-    u32 *cur = v0, *nxt = v1;
-    for (int k = 0; k < 6; k++) {
-        { Prof _p(ctx, "k_gather_u64_by_u32"); hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, kk[k], cur, n, k64a); }
-        ZKW_TRY(launch_check("k_gather_u64_by_u32"));
-        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, cur, nxt, n, 64, ctx->stream)); }
-        u32* t = cur; cur = nxt; nxt = t;
-    }
-    { Prof _p(ctx, "k_gather_u32_by_u32"); hipLaunchKernelGGL(k_gather_u32_by_u32, dim3(grid), dim3(256), 0, ctx->stream, a2, cur, n, k32a); }
-    ZKW_TRY(launch_check("k_gather_u32_by_u32"));
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, k32a, k32b, cur, nxt, n, 32, ctx->stream)); }
-    { u32* t = cur; cur = nxt; nxt = t; }
-    { Prof _p(ctx, "k_storage_gather_encode"); hipLaunchKernelGGL(k_storage_gather_encode, dim3(grid), dim3(256), 0, ctx->stream, d_q, cur, n, w->sorted_q, w->sorted_ext, s_enc); }
-    ZKW_TRY(launch_check("k_storage_gather_encode"));
-    // per-cell registers and the deduplicated queue
-    StorageScan sc;
-    u32* totals = nullptr;
-    sc.D = reinterpret_cast<int*>(w->scans);
-    sc.S = w->scans + n;
-    sc.R = w->scans + 2 * n;
-    sc.E = w->scans + 3 * n;
-    ZKW_TRY(ctx->scratch_t<u32>("sto_totals", 2, &totals));
-    { Prof _p(ctx, "k_storage_cells"); hipLaunchKernelGGL(k_storage_cells, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, sc, w->result_q, r_enc, totals); }
-    ZKW_TRY(launch_check("k_storage_cells"));
-    u32 h_totals[2] = {0, 0};
-    ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
-    if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "storage log is not a consistent history (%u violations of the asserts at "
-                                                       "sort_storage_access.rs:64-203)", h_totals[1]);
-    w->n_result = h_totals[0];
-    std::vector<LogChainJob> chains;
-    chains.push_back(LogChainJob{u_enc, nullptr, u_old, u_new, nullptr, n});
-    chains.push_back(LogChainJob{s_enc, nullptr, s_old, s_new, nullptr, n});
-    chains.push_back(LogChainJob{r_enc, nullptr, nullptr, r_new, nullptr, w->n_result});
-    ZKW_TRY(dev_log_chains(ctx, w->enc_all, 3 * n, chains));
-    std::vector<FsJob> fs(1);
-    fs[0] = FsJob{u_new + 4 * (n - 1), s_new + 4 * (n - 1), (u32)n, (u32)n, w->challenges};
-    ZKW_TRY(dev_fs(ctx, fs, 4, 21));
-    std::vector<GpSeg> segs;
-    segs.push_back(GpSeg{w->lhs_enc, w->lhs_z, w->challenges, n, 0, 0});
-    segs.push_back(GpSeg{s_enc, w->rhs_z, w->challenges, n, 0, 0});
-    ZKW_TRY(dev_grand_products(ctx, segs, 20, 2));
-    std::vector<StorageBlock> blk(1);
-    blk[0] = StorageBlock{w->sorted_q, w->sorted_ext, u_new, s_new, r_new, w->lhs_z, w->rhs_z, sc, w->instances, n, w->capacity};
-    StorageBlock* d_blk = nullptr;
-    ZKW_TRY(ctx->upload("sto_block", blk, &d_blk));
-    { Prof _p(ctx, "k_storage_instances"); hipLaunchKernelGGL(k_storage_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
-    return launch_check("k_storage_instances");
-}
-
-extern "C" int zkw_storage_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, size_t n, uint32_t capacity,
-                                        zkw_storage_witness** out) {
-    if (!ctx || !out || capacity == 0 || (n && !q)) return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_build: bad argument");
-    if (n >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many log queries");
-    HIP_TRY(hipSetDevice(ctx->device));
-    zkw_storage_witness* w = new zkw_storage_witness();
-    w->ctx = ctx;
-    w->n = n;
-    w->capacity = capacity;
-    w->n_instances = n ? (n + capacity - 1) / capacity : 1;
-    const size_t m = n ? n : 1;
-    hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
-    alloc((void**)&w->sorted_q, m * sizeof(zkw_log_query));
-    alloc((void**)&w->result_q, m * sizeof(zkw_log_query));
-    alloc((void**)&w->sorted_ext, m * 4);
-    alloc((void**)&w->enc_all, 3 * m * 160);
-    alloc((void**)&w->lhs_enc, m * 160);
-    alloc((void**)&w->tails_all, 5 * m * 32);
-    alloc((void**)&w->challenges, 42 * 8);
-    alloc((void**)&w->lhs_z, m * 16);
-    alloc((void**)&w->rhs_z, m * 16);
-    alloc((void**)&w->scans, 4 * m * sizeof(u32));
-    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_storage_sorter_instance));
-    if (e != hipSuccess) {
-        w->release();
-        delete w;
-        return fail(ZKW_ERR_OOM, "zkw_storage_sorter_build: hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    int rc = ZKW_OK;
-    if (n == 0) {  // storage_sort_dedup.rs:23-70
-        zkw_storage_sorter_instance inst;
-        memset(&inst, 0, sizeof inst);
-        inst.start_flag = inst.completion_flag = 1;
-        for (int r = 0; r < 2; r++) inst.hidden_fsm_output.lhs_accumulator[r] = inst.hidden_fsm_output.rhs_accumulator[r] = 1;
-        inst.hidden_fsm_output.cycle_idx = 4;
-        if (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemset(w->challenges, 0, 42 * 8) != hipSuccess)
-            rc = fail(ZKW_ERR_HIP, "copy failed");
-    } else {
-        const zkw_log_query* d_q = nullptr;
-        rc = ctx->in("sto_q", q, n, &d_q);
-        if (rc == ZKW_OK) rc = storage_run(ctx, w, d_q);
-    }
-    if (rc == ZKW_OK) rc = closed_form_public_inputs<CfStorageSorter>(ctx, w->instances, w->n_instances, &w->cf_pi);
-    if (rc == ZKW_OK) rc = ctx->sync_if_host();
-    if (rc != ZKW_OK) {
-        w->release();
-        delete w;
-        return rc;
-    }
-    ctx_retain(ctx);
-    *out = w;
-    return ZKW_OK;
-}
-
-extern "C" size_t zkw_storage_witness_num_instances(const zkw_storage_witness* w) { return w ? w->n_instances : 0; }
-extern "C" size_t zkw_storage_witness_num_results(const zkw_storage_witness* w) { return w ? w->n_result : 0; }
-static const void* sto_array(const zkw_storage_witness* w, int what, size_t* bytes) {
-    const size_t n = w->n, nr = w->n_result;
-    switch (what) {
-        case ZKW_STO_SORTED_QUERIES: *bytes = n * sizeof(zkw_log_query); return w->sorted_q;
-        case ZKW_STO_SORTED_EXT_TS: *bytes = n * 4; return w->sorted_ext;
-        case ZKW_STO_UNSORTED_ENC: *bytes = n * 160; return w->enc_all;
-        case ZKW_STO_LHS_ENC: *bytes = n * 160; return w->lhs_enc;
-        case ZKW_STO_SORTED_ENC: *bytes = n * 160; return w->enc_all + 20 * n;
-        case ZKW_STO_UNSORTED_OLD_TAILS: *bytes = n * 32; return w->tails_all;
-        case ZKW_STO_UNSORTED_NEW_TAILS: *bytes = n * 32; return w->tails_all + 4 * n;
-        case ZKW_STO_SORTED_OLD_TAILS: *bytes = n * 32; return w->tails_all + 8 * n;
-        case ZKW_STO_SORTED_NEW_TAILS: *bytes = n * 32; return w->tails_all + 12 * n;
-        case ZKW_STO_RESULT_QUERIES: *bytes = nr * sizeof(zkw_log_query); return w->result_q;
-        case ZKW_STO_RESULT_NEW_TAILS: *bytes = nr * 32; return w->tails_all + 16 * n;
-        case ZKW_STO_CHALLENGES: *bytes = 42 * 8; return w->challenges;
-        case ZKW_STO_LHS_Z: *bytes = n * 16; return w->lhs_z;
-        case ZKW_STO_RHS_Z: *bytes = n * 16; return w->rhs_z;
-        case ZKW_STO_INSTANCES: *bytes = w->n_instances * sizeof(zkw_storage_sorter_instance); return w->instances;
-        case ZKW_STO_COMPACT_FORMS: *bytes = w->n_instances * COMPACT_FORM_LEN * 8; return w->cf_pi;
-        case ZKW_STO_PUBLIC_INPUTS: *bytes = w->n_instances * 32; return w->cf_pi + COMPACT_FORM_LEN * w->n_instances;
-        default: *bytes = 0; return nullptr;
-    }
-}
-extern "C" size_t zkw_storage_witness_bytes(const zkw_storage_witness* w, int what) {
-    size_t b = 0;
-    if (w) (void)sto_array(w, what, &b);
-    return b;
-}
-extern "C" const void* zkw_storage_witness_device_ptr(const zkw_storage_witness* w, int what) {
-    size_t b = 0;
-    return w ? sto_array(w, what, &b) : nullptr;
-}
-extern "C" int zkw_storage_witness_get(const zkw_storage_witness* w, int what, void* dst, size_t dst_bytes) {
-    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_storage_witness_get: null argument");
-    if (what < 0 || what > ZKW_STO_PUBLIC_INPUTS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
-    size_t bytes = 0;
-    const void* src = sto_array(w, what, &bytes);
-    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
-    if (bytes == 0) return ZKW_OK;
-    zkw_ctx* ctx = w->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-    return ctx->sync_if_host();
-}
-extern "C" void zkw_storage_witness_free(zkw_storage_witness* w) {
-    if (!w) return;
-    (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
-    w->release();
-    zkw_ctx* owner = w->ctx;
-    delete w;
-    ctx_release(owner);
-}
-
-// ------------------------------------------------------------------------------------------------ code decommitter
-struct zkw_decommitter_witness {
-    zkw_ctx* ctx = nullptr;
-    size_t n_requests = 0, total_words = 0, total_rounds = 0, n_instances = 0;
-    zkw_mem_query* mem_q = nullptr;
-    u64 *mem_enc = nullptr, *mem_tails = nullptr;
-    u32* round_states = nullptr;
-    zkw_decommitter_instance* instances = nullptr;
-    zkw_sha256_round_record* sha256_rounds = nullptr;  // [total_rounds]: the cycles of the circuit
-    u32 capacity = 0;
-    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
-    void release() {
-        void* ptrs[] = {mem_q, mem_enc, mem_tails, round_states, instances, sha256_rounds, cf_pi};
-        for (void* p : ptrs)
-            if (p) dev_free(p);
-    }
-};
-
-extern "C" int zkw_decommitter_memory_queries(zkw_ctx* ctx, const zkw_decommit_query* requests, size_t n_requests,
-                                              const uint32_t* words, const uint64_t* word_offsets, zkw_mem_query* out) {
-    if (!ctx || !requests || !words || !word_offsets || !out || n_requests == 0)
-        return fail(ZKW_ERR_INVALID, "zkw_decommitter_memory_queries: bad argument");
-    HIP_TRY(hipSetDevice(ctx->device));
-    std::vector<uint64_t> woff(n_requests + 1);
-    for (size_t k = 0; k <= n_requests; k++) woff[k] = word_offsets[k] - word_offsets[0];
-    const size_t total = woff[n_requests];
-    const zkw_decommit_query* d_req = nullptr;
-    const u32* d_words = nullptr;
-    u64* d_woff = nullptr;
-    zkw_mem_query* d_out = nullptr;
-    ZKW_TRY(ctx->in("dcm_req", requests, n_requests, &d_req));
-    ZKW_TRY(ctx->in("dcm_words", words + 8 * word_offsets[0], total * 8, &d_words));
-    ZKW_TRY(ctx->upload("dcm_woff", woff, &d_woff));
-    ZKW_TRY(ctx->out("dcm_mq_out", out, total, &d_out));
-    DecommitterJob job{d_req, d_words, d_woff, nullptr, nullptr, d_out, nullptr, nullptr, n_requests, nullptr};
-    if (total) {
-        { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, job, (u64)total); }
-        ZKW_TRY(launch_check("k_decommitter_mem_queries"));
-    }
-    ZKW_TRY(ctx->finish_out(out, d_out, total));
-    return ctx->sync_if_host();
-}
-
-extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit_query* requests, const uint64_t* dedup_tails,
-                                     size_t n_requests, const uint32_t* words, const uint64_t* word_offsets,
-                                     uint32_t capacity, const zkw_queue_state12* mem_in, const uint64_t* given_mem_tails,
-                                     zkw_decommitter_witness** out) {
-    if (!ctx || !requests || !dedup_tails || !words || !word_offsets || !mem_in || !out || capacity == 0 || n_requests == 0)
-        return fail(ZKW_ERR_INVALID, "zkw_decommitter_build: bad argument");
-    HIP_TRY(hipSetDevice(ctx->device));
-    std::vector<uint64_t> woff(n_requests + 1), roff(n_requests + 1, 0);
-    for (size_t k = 0; k <= n_requests; k++) woff[k] = word_offsets[k] - word_offsets[0];
-    for (size_t k = 0; k < n_requests; k++) {
-        if (word_offsets[k + 1] <= word_offsets[k]) return fail(ZKW_ERR_INVALID, "request %zu has no bytecode (decommit_code.rs:236)", k);
-        roff[k + 1] = roff[k] + (woff[k + 1] - woff[k] + 1) / 2;
-    }
-    zkw_decommitter_witness* w = new zkw_decommitter_witness();
-    w->ctx = ctx;
-    w->n_requests = n_requests;
-    w->total_words = woff[n_requests];
-    w->total_rounds = roff[n_requests];
-    w->n_instances = (w->total_rounds + capacity - 1) / capacity;
-    hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
-    alloc((void**)&w->mem_q, w->total_words * sizeof(zkw_mem_query));
-    alloc((void**)&w->mem_enc, w->total_words * 64);
-    alloc((void**)&w->mem_tails, w->total_words * 96);
-    alloc((void**)&w->round_states, w->total_rounds * 32);
-    alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
-    w->capacity = capacity;
-    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_decommitter_instance));
-    auto bail = [&](int rc) { w->release(); delete w; return rc; };
-    if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_decommitter_build: hipMalloc failed: %s", hipGetErrorString(e)));
-    const zkw_decommit_query* d_req = nullptr;
-    const u64* d_dt = nullptr;
-    const u32* d_words = nullptr;
-    u64 *d_woff = nullptr, *d_roff = nullptr;
-    u32* d_viol = nullptr;
-    int rc = ctx->in("dcm_req", requests, n_requests, &d_req);
-    if (rc == ZKW_OK) rc = ctx->in("dcm_dt", dedup_tails, n_requests * 12, &d_dt);
-    if (rc == ZKW_OK) rc = ctx->in("dcm_words", words + 8 * word_offsets[0], w->total_words * 8, &d_words);
-    if (rc == ZKW_OK) rc = ctx->upload("dcm_woff", woff, &d_woff);
-    if (rc == ZKW_OK) rc = ctx->upload("dcm_roff", roff, &d_roff);
-    if (rc == ZKW_OK) rc = ctx->scratch_t<u32>("dcm_viol", 1, &d_viol);
-    if (rc != ZKW_OK) return bail(rc);
-    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
-    DecommitterJob job{d_req, d_words, d_woff, d_roff, w->round_states, w->mem_q, w->mem_enc, d_viol, n_requests, w->sha256_rounds};
-    { Prof _p(ctx, "k_decommitter_sha"); hipLaunchKernelGGL(k_decommitter_sha, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
-    if ((rc = launch_check("k_decommitter_sha")) != ZKW_OK) return bail(rc);
-    { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(w->total_words, 256)), dim3(256), 0, ctx->stream, job, (u64)w->total_words); }
-    if ((rc = launch_check("k_decommitter_mem_queries")) != ZKW_OK) return bail(rc);
-    zkw_queue_state12* d_min = nullptr;
-    std::vector<zkw_queue_state12> minv(1, *mem_in);
-    if ((rc = ctx->upload("dcm_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
-    if (given_mem_tails) {  // the caller has already hashed the memory queue this slice belongs to (zkw_block_run)
-        if (hipMemcpyAsync(w->mem_tails, given_mem_tails, w->total_words * 96,
-                           ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-            return bail(fail(ZKW_ERR_HIP, "copy of the given memory-queue states failed"));
-    } else {
-        std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, w->total_words});
-        if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
-    }
-    std::vector<DecommitterBlock> blk(1);
-    blk[0].job = job;
-    blk[0].dedup_tails = d_dt;
-    blk[0].mem_tails = w->mem_tails;
-    blk[0].instances = w->instances;
-    blk[0].mem_in = *mem_in;
-    blk[0].total_rounds = w->total_rounds;
-    blk[0].total_words = w->total_words;
-    blk[0].capacity = capacity;
-    DecommitterBlock* d_blk = nullptr;
-    if ((rc = ctx->upload("dcm_block", blk, &d_blk)) != ZKW_OK) return bail(rc);
-    { Prof _p(ctx, "k_decommitter_instances"); hipLaunchKernelGGL(k_decommitter_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
-    if ((rc = launch_check("k_decommitter_instances")) != ZKW_OK) return bail(rc);
-    u32 viol = 0;
-    if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
-        return bail(fail(ZKW_ERR_HIP, "readback failed"));
-    if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u bytecodes do not match their decommit request (length parity, word count or "
-                                                     "SHA-256 digest, decommit_code.rs:241-244, 323-337)", viol));
-    ctx_retain(ctx);
-    *out = w;
-    return ZKW_OK;
-}
-
-extern "C" int zkw_decommitter_build(zkw_ctx* ctx, const zkw_decommit_query* requests, const uint64_t* dedup_tails,
-                                     size_t n_requests, const uint32_t* words, const uint64_t* word_offsets,
-                                     uint32_t capacity, const zkw_queue_state12* mem_in, zkw_decommitter_witness** out) {
-    return zkw_decommitter_build_with_tails(ctx, requests, dedup_tails, n_requests, words, word_offsets, capacity, mem_in, nullptr, out);
-}
-
-extern "C" size_t zkw_decommitter_witness_num_instances(const zkw_decommitter_witness* w) { return w ? w->n_instances : 0; }
-static const void* dcm_array(const zkw_decommitter_witness* w, int what, size_t* bytes) {
-    switch (what) {
-        case ZKW_DCM_MEM_QUERIES: *bytes = w->total_words * sizeof(zkw_mem_query); return w->mem_q;
-        case ZKW_DCM_MEM_ENC: *bytes = w->total_words * 64; return w->mem_enc;
-        case ZKW_DCM_MEM_TAILS: *bytes = w->total_words * 96; return w->mem_tails;
-        case ZKW_DCM_ROUND_STATES: *bytes = w->total_rounds * 32; return w->round_states;
-        case ZKW_DCM_INSTANCES: *bytes = w->n_instances * sizeof(zkw_decommitter_instance); return w->instances;
-        case ZKW_DCM_SHA256_ROUNDS: *bytes = w->total_rounds * sizeof(zkw_sha256_round_record); return w->sha256_rounds;
-        default: *bytes = 0; return nullptr;
-    }
-}
-extern "C" size_t zkw_decommitter_witness_bytes(const zkw_decommitter_witness* w, int what) {
-    size_t b = 0;
-    if (w) (void)dcm_array(w, what, &b);
-    return b;
-}
-extern "C" const void* zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness* w, int what) {
-    size_t b = 0;
-    return w ? dcm_array(w, what, &b) : nullptr;
-}
-extern "C" int zkw_decommitter_witness_get(const zkw_decommitter_witness* w, int what, void* dst, size_t dst_bytes) {
-    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_decommitter_witness_get: null argument");
-    if (what < 0 || what > ZKW_DCM_SHA256_ROUNDS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
-    size_t bytes = 0;
-    const void* src = dcm_array(w, what, &bytes);
-    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
-    if (bytes == 0) return ZKW_OK;
-    zkw_ctx* ctx = w->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-    return ctx->sync_if_host();
-}
-extern "C" void zkw_decommitter_witness_free(zkw_decommitter_witness* w) {
-    if (!w) return;
-    (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
-    w->release();
-    zkw_ctx* owner = w->ctx;
-    delete w;
-    ctx_release(owner);
-}
-
-// ------------------------------------------------------------------------------------------------ L1 messages hasher
-extern "C" int zkw_linear_keccak256(zkw_ctx* ctx, const zkw_log_query* messages, size_t n, uint8_t* hash_out) {
-    if (!ctx || !hash_out || (n && !messages)) return fail(ZKW_ERR_INVALID, "zkw_linear_keccak256: null argument");
-    HIP_TRY(hipSetDevice(ctx->device));
-    const zkw_log_query* d_q = nullptr;
-    uint8_t* d_out = nullptr;
-    ZKW_TRY(ctx->in("lk_q", messages, n, &d_q));
-    ZKW_TRY(ctx->out("lk_out", hash_out, 32, &d_out));
-    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out, (zkw_keccak_round_record*)nullptr, (const u64*)nullptr, (const u64*)nullptr); }
-    ZKW_TRY(launch_check("k_linear_keccak256"));
-    ZKW_TRY(ctx->finish_out(hash_out, d_out, 32));
-    return ctx->sync_if_host();
-}
-
-// RecursionQueueSimulator::split_by(RECURSION_ARITY) as create_leaf_witnesses uses it (src/witness/recursive_aggregation.rs:
-// 98-117, circuit_encodings/src/lib.rs:472-506): leaf k covers the requests [k * arity, min((k + 1) * arity, n)); its queue
-// starts at the state the previous leaf ended with (head = tail before its first request), ends at the state after its last
-// request. Pure host arithmetic over the states zkw_queue_push_chain_full returned: no device work.
-extern "C" int zkw_recursion_queue_split(const uint64_t* states, size_t n, uint32_t arity, zkw_queue_state12* leaf_states,
-                                         size_t max_leaves, size_t* n_leaves) {
-    if (!n_leaves || arity == 0 || (n && !states)) return fail(ZKW_ERR_INVALID, "zkw_recursion_queue_split: bad argument");
-    const size_t leaves = (n + arity - 1) / arity;  // an empty queue has no leaves (split_by returns an empty vector)
-    *n_leaves = leaves;
-    if (leaves > max_leaves || (leaves && !leaf_states)) return fail(ZKW_ERR_INVALID, "zkw_recursion_queue_split: %zu leaves, room for %zu", leaves, max_leaves);
-    for (size_t k = 0; k < leaves; k++) {
-        const size_t first = k * arity, end = std::min(n, first + arity);
-        zkw_queue_state12& q = leaf_states[k];
-        memset(&q, 0, sizeof q);
-        if (first) memcpy(q.head, states + 12 * (first - 1), 96);
-        memcpy(q.tail, states + 12 * (end - 1), 96);
-        q.length = (uint32_t)(end - first);
-    }
-    return ZKW_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ public inputs (a20)
@@ -3140,1070 +1537,6 @@ extern "C" int zkw_callstack_simulate(zkw_ctx* ctx, const uint8_t* is_push, size
     return ctx->sync_if_host();
 }
 
-// ------------------------------------------------------------------------------------------------ precompile round functions (a16)
-struct zkw_precompile_witness {
-    zkw_ctx* ctx = nullptr;
-    size_t n_requests = 0, n_queries = 0, total_rounds = 0, total_reads = 0, n_instances = 0;
-    u64 *mem_enc = nullptr, *mem_tails = nullptr;
-    zkw_precompile_instance* instances = nullptr;
-    zkw_keccak_round_record* keccak_rounds = nullptr;  // keccak256 only: [total_rounds], the cycles of the circuit
-    zkw_sha256_round_record* sha256_rounds = nullptr;  // sha256 only
-    int kind = 0;
-    u32 capacity = 0;
-    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
-    void release() {
-        void* ptrs[] = {mem_enc, mem_tails, instances, keccak_rounds, sha256_rounds, cf_pi};
-        for (void* p : ptrs)
-            if (p) dev_free(p);
-    }
-};
-
-extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw_log_query* requests, const uint64_t* request_tails,
-                                    size_t n_requests, const zkw_mem_query* mem_queries, size_t n_queries, uint32_t capacity,
-                                    const zkw_queue_state12* mem_in, const uint64_t* given_mem_tails,
-                                    zkw_precompile_witness** out) {
-    if (!ctx || !mem_in || !out || capacity == 0 || kind < ZKW_PRECOMPILE_KECCAK256 || kind > ZKW_PRECOMPILE_ECRECOVER ||
-        (n_requests && (!requests || !request_tails)) || (n_queries && !mem_queries))
-        return fail(ZKW_ERR_INVALID, "zkw_precompile_build: bad argument");
-    if (n_requests == 0 && n_queries) return fail(ZKW_ERR_INVALID, "memory queries without a precompile request");
-    HIP_TRY(hipSetDevice(ctx->device));
-    const zkw_log_query* d_req = nullptr;
-    const u64* d_rt = nullptr;
-    const zkw_mem_query* d_mq = nullptr;
-    u64 *d_roff = nullptr, *d_qoff = nullptr, *d_rdoff = nullptr, *d_meta = nullptr;
-    u64 meta[4] = {0, 0, 0, 0};
-    if (n_requests) {
-        ZKW_TRY(ctx->in("pc_req", requests, n_requests, &d_req));
-        ZKW_TRY(ctx->in("pc_rt", request_tails, n_requests * 4, &d_rt));
-        if (n_queries) ZKW_TRY(ctx->in("pc_mq", mem_queries, n_queries, &d_mq));
-        ZKW_TRY(ctx->scratch_t<u64>("pc_roff", n_requests + 1, &d_roff));
-        ZKW_TRY(ctx->scratch_t<u64>("pc_qoff", n_requests + 1, &d_qoff));
-        ZKW_TRY(ctx->scratch_t<u64>("pc_rdoff", n_requests + 1, &d_rdoff));
-        ZKW_TRY(ctx->scratch_t<u64>("pc_meta", 4, &d_meta));
-        { Prof _p(ctx, "k_precompile_counts"); hipLaunchKernelGGL(k_precompile_counts, dim3(1), dim3(1024), 0, ctx->stream, kind, d_req, n_requests, d_roff, d_qoff, d_rdoff, d_meta); }
-        ZKW_TRY(launch_check("k_precompile_counts"));
-        ZKW_TRY(ctx->read_small(meta, d_meta, sizeof meta));
-        if (meta[3]) return fail(ZKW_ERR_INVALID, "a precompile request without rounds (the first round carries `new_request`)");
-        if (meta[1] != n_queries)
-            return fail(ZKW_ERR_INVALID, "the requests need %llu memory queries, %zu given", (unsigned long long)meta[1], n_queries);
-    }
-    zkw_precompile_witness* w = new zkw_precompile_witness();
-    w->ctx = ctx;
-    w->n_requests = n_requests;
-    w->n_queries = n_queries;
-    w->total_rounds = meta[0];
-    w->total_reads = meta[2];
-    w->n_instances = n_requests ? (w->total_rounds + capacity - 1) / capacity : 1;
-    w->kind = kind;
-    w->capacity = capacity;
-    hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
-    alloc((void**)&w->mem_enc, n_queries * 64);
-    alloc((void**)&w->mem_tails, n_queries * 96);
-    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_precompile_instance));
-    if (kind == ZKW_PRECOMPILE_KECCAK256) alloc((void**)&w->keccak_rounds, w->total_rounds * sizeof(zkw_keccak_round_record));
-    if (kind == ZKW_PRECOMPILE_SHA256) alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
-    auto bail = [&](int rc) { w->release(); delete w; return rc; };
-    if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_precompile_build: hipMalloc failed: %s", hipGetErrorString(e)));
-    int rc = ZKW_OK;
-    PrecompileSnap* d_snaps = nullptr;
-    u32* d_viol = nullptr;
-    if ((rc = ctx->scratch_t<u32>("pc_viol", 1, &d_viol)) != ZKW_OK) return bail(rc);
-    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
-    if (n_requests) {
-        if ((rc = ctx->scratch_t<PrecompileSnap>("pc_snaps", w->n_instances, &d_snaps)) != ZKW_OK) return bail(rc);
-        if (n_queries) {
-            if ((rc = dev_encode(ctx, d_mq, n_queries, w->mem_enc)) != ZKW_OK) return bail(rc);
-            zkw_queue_state12* d_min = nullptr;
-            std::vector<zkw_queue_state12> minv(1, *mem_in);
-            if ((rc = ctx->upload("pc_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
-            if (given_mem_tails) {  // already hashed by the caller as part of the whole memory queue (zkw_block_run)
-                if (hipMemcpyAsync(w->mem_tails, given_mem_tails, n_queries * 96,
-                                   ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-                    return bail(fail(ZKW_ERR_HIP, "copy of the given memory-queue states failed"));
-            } else {
-                std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, n_queries});
-                if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
-            }
-        }
-        PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity, w->keccak_rounds, w->sha256_rounds};
-        { Prof _p(ctx, "k_precompile_walk"); hipLaunchKernelGGL(k_precompile_walk, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
-        if ((rc = launch_check("k_precompile_walk")) != ZKW_OK) return bail(rc);
-    }
-    std::vector<PrecompileBlock> blk(1);
-    blk[0].kind = kind;
-    blk[0].snaps = d_snaps;
-    blk[0].req_tails = d_rt;
-    blk[0].mem_tails = w->mem_tails;
-    blk[0].instances = w->instances;
-    blk[0].mem_in = *mem_in;
-    blk[0].n_requests = n_requests;
-    blk[0].total_rounds = w->total_rounds;
-    blk[0].n_instances = w->n_instances;
-    blk[0].capacity = capacity;
-    PrecompileBlock* d_blk = nullptr;
-    if ((rc = ctx->upload("pc_block", blk, &d_blk)) != ZKW_OK) return bail(rc);
-    { Prof _p(ctx, "k_precompile_instances"); hipLaunchKernelGGL(k_precompile_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
-    if ((rc = launch_check("k_precompile_instances")) != ZKW_OK) return bail(rc);
-    u32 viol = 0;
-    if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
-        return bail(fail(ZKW_ERR_HIP, "readback failed"));
-    if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u requests whose memory queries do not fit their ABI (read/write flags, word "
-                                                     "index or count: the asserts of the round walks)", viol));
-    ctx_retain(ctx);
-    *out = w;
-    return ZKW_OK;
-}
-
-extern "C" int zkw_precompile_build(zkw_ctx* ctx, int kind, const zkw_log_query* requests, const uint64_t* request_tails,
-                                    size_t n_requests, const zkw_mem_query* mem_queries, size_t n_queries, uint32_t capacity,
-                                    const zkw_queue_state12* mem_in, zkw_precompile_witness** out) {
-    return zkw_precompile_build_with_tails(ctx, kind, requests, request_tails, n_requests, mem_queries, n_queries, capacity, mem_in, nullptr, out);
-}
-
-extern "C" size_t zkw_precompile_witness_num_instances(const zkw_precompile_witness* w) { return w ? w->n_instances : 0; }
-extern "C" size_t zkw_precompile_witness_num_rounds(const zkw_precompile_witness* w) { return w ? w->total_rounds : 0; }
-static const void* pc_array(const zkw_precompile_witness* w, int what, size_t* bytes) {
-    switch (what) {
-        case ZKW_PRC_MEM_ENC: *bytes = w->n_queries * 64; return w->mem_enc;
-        case ZKW_PRC_MEM_TAILS: *bytes = w->n_queries * 96; return w->mem_tails;
-        case ZKW_PRC_INSTANCES: *bytes = w->n_instances * sizeof(zkw_precompile_instance); return w->instances;
-        case ZKW_PRC_KECCAK_ROUNDS: *bytes = w->keccak_rounds ? w->total_rounds * sizeof(zkw_keccak_round_record) : 0; return w->keccak_rounds;
-        case ZKW_PRC_SHA256_ROUNDS: *bytes = w->sha256_rounds ? w->total_rounds * sizeof(zkw_sha256_round_record) : 0; return w->sha256_rounds;
-        default: *bytes = 0; return nullptr;
-    }
-}
-extern "C" size_t zkw_precompile_witness_bytes(const zkw_precompile_witness* w, int what) {
-    size_t b = 0;
-    if (w) (void)pc_array(w, what, &b);
-    return b;
-}
-extern "C" const void* zkw_precompile_witness_device_ptr(const zkw_precompile_witness* w, int what) {
-    size_t b = 0;
-    return w ? pc_array(w, what, &b) : nullptr;
-}
-extern "C" int zkw_precompile_witness_get(const zkw_precompile_witness* w, int what, void* dst, size_t dst_bytes) {
-    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_precompile_witness_get: null argument");
-    if (what < 0 || what > ZKW_PRC_SHA256_ROUNDS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
-    size_t bytes = 0;
-    const void* src = pc_array(w, what, &bytes);
-    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
-    if (bytes == 0) return ZKW_OK;
-    zkw_ctx* ctx = w->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-    return ctx->sync_if_host();
-}
-extern "C" void zkw_precompile_witness_free(zkw_precompile_witness* w) {
-    if (!w) return;
-    (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
-    w->release();
-    zkw_ctx* owner = w->ctx;
-    delete w;
-    ctx_release(owner);
-}
-
-// ------------------------------------------------------------------------------------------------ storage application (a17)
-struct zkw_storage_application_witness {
-    zkw_ctx* ctx = nullptr;
-    size_t n = 0, n_instances = 0;
-    u32 *keys = nullptr, *paths = nullptr, *roots = nullptr;
-    u64* leaf_indexes = nullptr;
-    zkw_storage_application_instance* instances = nullptr;
-    void release() {
-        void* ptrs[] = {keys, paths, roots, leaf_indexes, instances};
-        for (void* p : ptrs)
-            if (p) dev_free(p);
-    }
-};
-
-extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* queries, const uint64_t* query_tails, size_t n,
-                                             const uint64_t* init_leaf_indexes, const uint8_t* init_merkle_paths,
-                                             const uint8_t initial_root[32], uint64_t initial_next_enumeration_index,
-                                             uint32_t capacity, zkw_storage_application_witness** out) {
-    if (!ctx || !out || !initial_root || capacity < 2 || (n && (!queries || !query_tails || !init_leaf_indexes || !init_merkle_paths)))
-        return fail(ZKW_ERR_INVALID, "zkw_storage_application_build: bad argument");
-    if (n >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many storage queries");
-    HIP_TRY(hipSetDevice(ctx->device));
-    zkw_storage_application_witness* w = new zkw_storage_application_witness();
-    w->ctx = ctx;
-    w->n = n;
-    hipError_t e = hipSuccess;
-    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
-    alloc((void**)&w->keys, n * 32);
-    alloc((void**)&w->paths, n * 256 * 32);
-    alloc((void**)&w->roots, n * 32);
-    alloc((void**)&w->leaf_indexes, n * 8);
-    auto bail = [&](int rc) { w->release(); delete w; return rc; };
-    if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed: %s", hipGetErrorString(e)));
-    int rc = ZKW_OK;
-    SapJob job;
-    memset(&job, 0, sizeof job);
-    const u64* d_qt = nullptr;
-    const uint8_t* d_ip = nullptr;
-    u64 *d_snap = nullptr, *d_meta = nullptr;
-    uint8_t* d_hash = nullptr;
-    u32* d_viol = nullptr;
-    auto TRY = [&](int r) { if (rc == ZKW_OK) rc = r; };
-    if (n) {
-        TRY(ctx->in("sap_q", queries, n, &job.queries));
-        TRY(ctx->in("sap_qt", query_tails, n * 4, &d_qt));
-        TRY(ctx->in("sap_ii", init_leaf_indexes, n, &job.init_index));
-        TRY(ctx->in("sap_ip", init_merkle_paths, n * 256 * 32, &d_ip));
-    }
-    job.init_paths = reinterpret_cast<const u32*>(d_ip);
-    job.keys = w->keys; job.paths = w->paths; job.roots = w->roots;
-    TRY(ctx->scratch_t<u64>("sap_newidx", n + 1, &job.new_index));
-    TRY(ctx->scratch_t<u32>("sap_prevw", n + 1, &job.prev_write));
-    TRY(ctx->scratch_t<u32>("sap_chunk", n + 1, &job.chunk_of));
-    TRY(ctx->scratch_t<u32>("sap_fwu", n + 1, &job.first_writes_upto));
-    TRY(ctx->scratch_t<u64>("sap_cend", n + 2, &job.chunk_end));
-    TRY(ctx->scratch_t<u32>("sap_jstar", (n + 1) * 256, &job.jstar));
-    TRY(ctx->scratch_t<u32>("sap_A0", (n + 1) * 8, &job.A0));
-    TRY(ctx->scratch_t<u32>("sap_A1", (n + 1) * 8, &job.A1));
-    TRY(ctx->scratch_t<u32>("sap_C0", (n + 1) * 8, &job.C0));
-    TRY(ctx->scratch_t<u32>("sap_C1", (n + 1) * 8, &job.C1));
-    TRY(ctx->scratch_t<u32>("sap_viol", 1, &d_viol));
-    TRY(ctx->scratch_t<u64>("sap_meta", 2, &d_meta));
-    TRY(ctx->scratch_t<u64>("sap_snap", (n + 1) * 25, &d_snap));
-    TRY(ctx->scratch_t<uint8_t>("sap_hash", 32, &d_hash));
-    if (rc != ZKW_OK) return bail(rc);
-    job.violations = d_viol;
-    job.meta = d_meta;
-    job.n = n;
-    job.next_enumeration_index = initial_next_enumeration_index;
-    memcpy(job.initial_root, initial_root, 32);
-    job.capacity = capacity;
-    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
-    u64 meta[2] = {1, initial_next_enumeration_index};
-    if (n) {
-        const unsigned g64 = blocks_for(n, 64);
-        { Prof _p(ctx, "k_sap_keys"); hipLaunchKernelGGL(k_sap_keys, dim3(g64), dim3(64), 0, ctx->stream, job); }
-        TRY(launch_check("k_sap_keys"));
-        { Prof _p(ctx, "k_sap_scan"); hipLaunchKernelGGL(k_sap_scan, dim3(1), dim3(1024), 0, ctx->stream, job); }
-        TRY(launch_check("k_sap_scan"));
-        { Prof _p(ctx, "k_sap_pairs"); hipLaunchKernelGGL(k_sap_pairs, dim3(g64), dim3(64), 0, ctx->stream, job); }
-        TRY(launch_check("k_sap_pairs"));
-        { Prof _p(ctx, "k_sap_leaves"); hipLaunchKernelGGL(k_sap_leaves, dim3(g64), dim3(64), 0, ctx->stream, job); }
-        TRY(launch_check("k_sap_leaves"));
-        static_assert(ZKW_STORAGE_TREE_DEPTH == 256, "k_sap_levels walks 256 levels");
-        if (n <= SAP_PERSISTENT_MAX) {
-            Prof _p(ctx, "k_sap_levels");
-            hipLaunchKernelGGL(k_sap_levels, dim3(1), dim3(SAP_PERSISTENT_THREADS), 0, ctx->stream, job);
-        } else {
-            for (int L = 0; L < ZKW_STORAGE_TREE_DEPTH && rc == ZKW_OK; L++) {
-                Prof _p(ctx, "k_sap_level");
-                hipLaunchKernelGGL(k_sap_level, dim3(g64), dim3(64), 0, ctx->stream, job, L);
-            }
-        }
-        TRY(launch_check("k_sap_level"));
-        { Prof _p(ctx, "k_sap_roots"); hipLaunchKernelGGL(k_sap_roots, dim3(g64), dim3(64), 0, ctx->stream, job); }
-        TRY(launch_check("k_sap_roots"));
-        if (rc != ZKW_OK) return bail(rc);
-        if (hipMemcpyAsync(w->leaf_indexes, job.init_index, n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-            ctx->read_small(meta, d_meta, sizeof meta) != ZKW_OK)
-            return bail(fail(ZKW_ERR_HIP, "readback failed"));
-    }
-    w->n_instances = n ? (size_t)meta[0] : 1;
-    if (dev_malloc((void**)&w->instances, w->n_instances * sizeof(zkw_storage_application_instance) + 64) != hipSuccess)
-        return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed"));
-    SapKeccakOut ko{d_snap, d_hash};
-    { Prof _p(ctx, "k_sap_keccak"); hipLaunchKernelGGL(k_sap_keccak, dim3(1), dim3(64), 0, ctx->stream, job, ko); }
-    TRY(launch_check("k_sap_keccak"));
-    std::vector<SapBlock> blk(1);
-    blk[0].job = job;
-    blk[0].query_tails = d_qt;
-    blk[0].snapshots = d_snap;
-    blk[0].final_hash = d_hash;
-    blk[0].instances = w->instances;
-    blk[0].n_instances = w->n_instances;
-    SapBlock* d_blk = nullptr;
-    TRY(ctx->upload("sap_block", blk, &d_blk));
-    if (rc != ZKW_OK) return bail(rc);
-    { Prof _p(ctx, "k_sap_instances"); hipLaunchKernelGGL(k_sap_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
-    TRY(launch_check("k_sap_instances"));
-    if (rc != ZKW_OK) return bail(rc);
-    u32 viol = 0;
-    if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
-        return bail(fail(ZKW_ERR_HIP, "readback failed"));
-    if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u storage queries contradict the tree: the pre-state proof does not lead to the "
-                                                     "initial root, the read value is not the leaf's (storage_application.rs:221,276), "
-                                                     "or a slot occurs twice", viol));
-    ctx_retain(ctx);
-    *out = w;
-    return ZKW_OK;
-}
-
-extern "C" size_t zkw_storage_application_witness_num_instances(const zkw_storage_application_witness* w) { return w ? w->n_instances : 0; }
-static const void* sap_array(const zkw_storage_application_witness* w, int what, size_t* bytes) {
-    switch (what) {
-        case ZKW_SAP_DERIVED_KEYS: *bytes = w->n * 32; return w->keys;
-        case ZKW_SAP_MERKLE_PATHS: *bytes = w->n * 256 * 32; return w->paths;
-        case ZKW_SAP_LEAF_INDEXES: *bytes = w->n * 8; return w->leaf_indexes;
-        case ZKW_SAP_ROOTS: *bytes = w->n * 32; return w->roots;
-        case ZKW_SAP_INSTANCES: *bytes = w->n_instances * sizeof(zkw_storage_application_instance); return w->instances;
-        default: *bytes = 0; return nullptr;
-    }
-}
-extern "C" size_t zkw_storage_application_witness_bytes(const zkw_storage_application_witness* w, int what) {
-    size_t b = 0;
-    if (w) (void)sap_array(w, what, &b);
-    return b;
-}
-extern "C" const void* zkw_storage_application_witness_device_ptr(const zkw_storage_application_witness* w, int what) {
-    size_t b = 0;
-    return w ? sap_array(w, what, &b) : nullptr;
-}
-extern "C" int zkw_storage_application_witness_get(const zkw_storage_application_witness* w, int what, void* dst, size_t dst_bytes) {
-    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_storage_application_witness_get: null argument");
-    if (what < 0 || what > ZKW_SAP_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
-    size_t bytes = 0;
-    const void* src = sap_array(w, what, &bytes);
-    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
-    if (bytes == 0) return ZKW_OK;
-    zkw_ctx* ctx = w->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-    return ctx->sync_if_host();
-}
-extern "C" void zkw_storage_application_witness_free(zkw_storage_application_witness* w) {
-    if (!w) return;
-    (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
-    w->release();
-    zkw_ctx* owner = w->ctx;
-    delete w;
-    ctx_release(owner);
-}
-
-// ------------------------------------------------------------------------------------------------ decommit sorter synthesis (a21, type 2)
-extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_witness* cw, size_t first_instance, size_t n_instances,
-                                              zkw_trace* t, size_t first_slot) {
-    zkw_decommit_witness* w = const_cast<zkw_decommit_witness*>(cw);
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_decommit_sorter_synthesize: bad argument");
-    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
-    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
-    const u32 capacity = w->capacity;
-    const size_t n_rows = t->n_rows;
-    if (DS_MIN_ROWS(capacity) > n_rows)
-        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)DS_MIN_ROWS(capacity), n_rows);
-    if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
-    if (n_instances == 0) return ZKW_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (!w->fresh_prefix) {
-        HIP_TRY(dev_malloc((void**)&w->fresh_prefix, (w->n + 2) * sizeof(u32)));
-        { Prof _p(ctx, "k_ds_fresh_prefix"); hipLaunchKernelGGL(k_ds_fresh_prefix, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, w->n, w->fresh_prefix); }
-        ZKW_TRY(launch_check("k_ds_fresh_prefix"));
-    }
-    u32* d_hist = nullptr;
-    ZKW_TRY(ctx->scratch_t<u32>("ds_hist", n_instances * 256, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
-    std::vector<DsSynthJob> jobs(n_instances);
-    for (size_t k = 0; k < n_instances; k++) {
-        DsSynthJob& j = jobs[k];
-        j.inst = w->instances + first_instance + k;
-        j.sorted_q = w->sorted_q;
-        j.unsorted_enc = w->unsorted_enc; j.sorted_enc = w->sorted_enc;
-        j.unsorted_tails = w->unsorted_tails; j.sorted_tails = w->sorted_tails;
-        j.dedup_enc = w->dedup_enc; j.dedup_tails = w->dedup_tails;
-        j.fresh_prefix = w->fresh_prefix;
-        j.challenges = w->challenges;
-        j.lhs_z = w->lhs_z; j.rhs_z = w->rhs_z;
-        j.n_block = w->n;
-        memcpy(j.rq_tail_in, w->dedup_in.tail, 96);
-        j.rq_len_in = w->dedup_in.length;
-        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
-        j.hist = d_hist + 256 * k;
-        j.public_input = w->public_inputs + 4 * (first_instance + k);
-    }
-    DsSynthJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("ds_jobs", jobs, &d_jobs));
-    const unsigned nj = (unsigned)n_instances;
-    const u32 rstride = (u32)DS_REGION_STRIDE(capacity);
-    const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
-    { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_poseidon<0>"));
-    { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_poseidon<1>"));
-    { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_poseidon<2>"));
-    { Prof _p(ctx, "k_ds_fill_row_A"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_A>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_row<A>"));
-    { Prof _p(ctx, "k_ds_fill_row_B"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_B>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_row<B>"));
-    { Prof _p(ctx, "k_ds_fill_row_C"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_C>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_row<C>"));
-    { Prof _p(ctx, "k_ds_fill_row_D"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_D>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_row<D>"));
-    { Prof _p(ctx, "k_ds_fill_tail"); hipLaunchKernelGGL(k_ds_fill_tail, dim3((DS_G + DS_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_tail"));
-    { Prof _p(ctx, "k_ds_fill_boundary"); hipLaunchKernelGGL(k_ds_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_boundary"));
-    return ctx->sync_if_host();
-}
-
-// ------------------------------------------------------------------------------------------------ events / L1 messages sorter synthesis (a21, types 11 / 12)
-extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witness* cw, size_t first_instance, size_t n_instances,
-                                            zkw_trace* t, size_t first_slot) {
-    zkw_events_witness* w = const_cast<zkw_events_witness*>(cw);
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_events_sorter_synthesize: bad argument");
-    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
-    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
-    const u32 capacity = w->capacity;
-    const size_t n_rows = t->n_rows, n = w->n;
-    if (ES_MIN_ROWS(capacity) > n_rows)
-        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)ES_MIN_ROWS(capacity), n_rows);
-    if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
-    if (n_instances == 0) return ZKW_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (!w->kept_prefix) {
-        HIP_TRY(dev_malloc((void**)&w->kept_prefix, (n + 2) * sizeof(u32)));
-        { Prof _p(ctx, "k_es_kept_prefix"); hipLaunchKernelGGL(k_es_kept_prefix, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, w->kept_prefix); }
-        ZKW_TRY(launch_check("k_es_kept_prefix"));
-    }
-    u32* d_hist = nullptr;
-    ZKW_TRY(ctx->scratch_t<u32>("es_hist", n_instances * 256, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
-    const size_t m = n ? n : 1;
-    u64 *u_enc = w->enc_all, *s_enc = w->enc_all + 20 * m;
-    u64 *u_new = w->tails_all + 4 * m, *s_new = w->tails_all + 12 * m, *r_new = w->tails_all + 16 * m;
-    std::vector<EsSynthJob> jobs(n_instances);
-    for (size_t k = 0; k < n_instances; k++) {
-        EsSynthJob& j = jobs[k];
-        j.inst = w->instances + first_instance + k;
-        j.sorted_q = w->sorted_q;
-        j.unsorted_enc = u_enc; j.sorted_enc = s_enc;
-        j.unsorted_new_tails = u_new; j.sorted_new_tails = s_new; j.result_new_tails = r_new;
-        j.kept_prefix = w->kept_prefix;
-        j.challenges = w->challenges;
-        j.lhs_z = w->lhs_z; j.rhs_z = w->rhs_z;
-        j.n_block = n;
-        memcpy(j.rq_tail_in, w->result_in.tail, 32);
-        j.rq_len_in = w->result_in.length;
-        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
-        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
-        j.hist = d_hist + 256 * k;
-    }
-    EsSynthJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("es_jobs", jobs, &d_jobs));
-    const unsigned nj = (unsigned)n_instances;
-    const u32 rstride = (u32)ES_REGION_STRIDE(capacity);
-    const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
-    { Prof _p(ctx, "k_es_fill_queue"); hipLaunchKernelGGL((k_es_fill_queue<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_es_fill_queue<0>"));
-    { Prof _p(ctx, "k_es_fill_queue"); hipLaunchKernelGGL((k_es_fill_queue<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_es_fill_queue<1>"));
-    { Prof _p(ctx, "k_es_fill_queue"); hipLaunchKernelGGL((k_es_fill_queue<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_es_fill_queue<2>"));
-#define ES_LAUNCH_ROW(R) { Prof _p(ctx, "k_es_fill_row"); hipLaunchKernelGGL((k_es_fill_row<ES_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
-    ZKW_TRY(launch_check("k_es_fill_row<" #R ">"));
-    ES_LAUNCH_ROW(A) ES_LAUNCH_ROW(N0) ES_LAUNCH_ROW(N1) ES_LAUNCH_ROW(N2) ES_LAUNCH_ROW(N3) ES_LAUNCH_ROW(N4) ES_LAUNCH_ROW(N5)
-    ES_LAUNCH_ROW(N6) ES_LAUNCH_ROW(N7) ES_LAUNCH_ROW(T) ES_LAUNCH_ROW(V) ES_LAUNCH_ROW(W) ES_LAUNCH_ROW(Q)
-#undef ES_LAUNCH_ROW
-    { Prof _p(ctx, "k_es_fill_tail"); hipLaunchKernelGGL(k_es_fill_tail, dim3((ES_G + ES_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_es_fill_tail"));
-    { Prof _p(ctx, "k_es_fill_boundary"); hipLaunchKernelGGL(k_es_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_es_fill_boundary"));
-    return ctx->sync_if_host();
-}
-
-extern "C" int zkw_events_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
-                                                 uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations)
-        return fail(ZKW_ERR_INVALID, "zkw_events_sorter_check_satisfied: bad argument");
-    if (ES_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
-    return check_satisfied<SpecEventsSorter>(ctx, t, slot, capacity, n_violations, first_bad);
-}
-
-// ------------------------------------------------------------------------------------------------ LogDemuxer synthesis
-extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w, size_t first_instance, size_t n_instances,
-                                        zkw_trace* t, size_t first_slot) {
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_log_demux_synthesize: bad argument");
-    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
-    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
-    if (!w->default_params)
-        return fail(ZKW_ERR_INVALID, "the LogDemuxer circuit hard-wires ZKW_DEMUX_PARAMS_DEFAULT; this witness was built with other routing constants");
-    if (t->n_cols < LD_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the LogDemuxer needs %d (zkw_trace_create_with_columns)", t->n_cols, LD_COLS);
-    const u32 capacity = w->capacity;
-    const size_t n_rows = t->n_rows, n = w->n;
-    if (LD_MIN_ROWS(capacity) > n_rows)
-        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)LD_MIN_ROWS(capacity), n_rows);
-    if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
-    if (n_instances == 0) return ZKW_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    u32* d_hist = nullptr;
-    ZKW_TRY(ctx->scratch_t<u32>("ld_hist", n_instances * 256, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
-    std::vector<LdSynthJob> jobs(n_instances);
-    for (size_t k = 0; k < n_instances; k++) {
-        LdSynthJob& j = jobs[k];
-        j.inst = w->instances + first_instance + k;
-        j.in_enc = w->enc_all;
-        j.in_new_tails = w->tails_all + 4 * n;
-        j.out_new_tails = w->tails_all + 12 * n;
-        j.route_count = w->route_count;
-        for (int c = 0; c < 7; c++) j.offsets[c] = w->offsets[c];
-        j.n_block = n;
-        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
-        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
-        j.hist = d_hist + 256 * k;
-    }
-    LdSynthJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("ld_jobs", jobs, &d_jobs));
-    const unsigned nj = (unsigned)n_instances;
-    const u32 rstride = (u32)LD_REGION_STRIDE(capacity);
-    const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
-    { Prof _p(ctx, "k_ld_fill_queue"); hipLaunchKernelGGL((k_ld_fill_queue<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ld_fill_queue<0>"));
-    { Prof _p(ctx, "k_ld_fill_queue"); hipLaunchKernelGGL((k_ld_fill_queue<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ld_fill_queue<1>"));
-#define LD_LAUNCH_ROW(R) { Prof _p(ctx, "k_ld_fill_row"); hipLaunchKernelGGL((k_ld_fill_row<LD_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
-    ZKW_TRY(launch_check("k_ld_fill_row<" #R ">"));
-    LD_LAUNCH_ROW(X0) LD_LAUNCH_ROW(X1) LD_LAUNCH_ROW(X2) LD_LAUNCH_ROW(X3) LD_LAUNCH_ROW(R) LD_LAUNCH_ROW(Q)
-#undef LD_LAUNCH_ROW
-    { Prof _p(ctx, "k_ld_fill_tail"); hipLaunchKernelGGL(k_ld_fill_tail, dim3((LD_G + LD_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ld_fill_tail"));
-    { Prof _p(ctx, "k_ld_fill_boundary"); hipLaunchKernelGGL(k_ld_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ld_fill_boundary"));
-    return ctx->sync_if_host();
-}
-
-extern "C" int zkw_log_demux_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
-                                             uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations)
-        return fail(ZKW_ERR_INVALID, "zkw_log_demux_check_satisfied: bad argument");
-    if (LD_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
-    return check_satisfied<SpecLogDemux>(ctx, t, slot, capacity, n_violations, first_bad);
-}
-
-// compact closed-form inputs and public inputs of a precompile witness's instances, computed once and kept with the witness
-extern "C" int zkw_precompile_closed_forms(zkw_ctx* ctx, zkw_precompile_witness* w, const uint64_t** compact, const uint64_t** public_inputs) {
-    if (!ctx || !w || w->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_precompile_closed_forms: bad argument");
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (!w->cf_pi) {
-        if (w->kind == ZKW_PRECOMPILE_KECCAK256) ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>>(ctx, w->instances, w->n_instances, &w->cf_pi));
-        else if (w->kind == ZKW_PRECOMPILE_SHA256) ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_SHA256>>(ctx, w->instances, w->n_instances, &w->cf_pi));
-        else ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_ECRECOVER>>(ctx, w->instances, w->n_instances, &w->cf_pi));
-    }
-    if (compact) *compact = w->cf_pi;
-    if (public_inputs) *public_inputs = w->cf_pi + COMPACT_FORM_LEN * w->n_instances;
-    return ZKW_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ netlist circuits ("zkw trace v4")
-// Sha256RoundFunction (6), CodeDecommitter (3), Keccak256RoundFunction (5), L1MessagesHasher (13): one engine (netlist_kernels.cuh),
-// four generated specs on the reference's geometry and table sets. The device copy of a spec (its arrays, the general-purpose cell
-// map, the key layout and the histogram plan) is built once per device and circuit and never freed.
-namespace {
-struct NlCached { NlDev host; NlDev* dev = nullptr; };
-std::mutex g_nl_mu;
-std::map<std::pair<int, int>, NlCached>& nl_cache() { static auto* m = new std::map<std::pair<int, int>, NlCached>(); return *m; }
-
-template <class T>
-int nl_to_device(const T* src, size_t n, const T** out) {
-    void* p = nullptr;
-    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return fail(ZKW_ERR_OOM, "netlist spec: hipMalloc failed");
-    if (n && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return fail(ZKW_ERR_HIP, "netlist spec: upload failed");
-    *out = static_cast<const T*>(p);
-    return ZKW_OK;
-}
-
-int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
-    const nl_spec* hs = nl_host_spec(circuit_type);
-    if (!hs) return fail(ZKW_ERR_INVALID, "circuit type %d is not a netlist circuit", circuit_type);
-    std::lock_guard<std::mutex> g(g_nl_mu);
-    NlCached& c = nl_cache()[{ctx->device, circuit_type}];
-    if (c.dev) { *out = &c; return ZKW_OK; }
-    HIP_TRY(hipSetDevice(ctx->device));
-    NlDev d;
-    memset(&d, 0, sizeof d);
-    d.s = *hs;
-    ZKW_TRY(nl_to_device(hs->tables, hs->n_tables, &d.s.tables));
-    ZKW_TRY(nl_to_device(hs->step_types, hs->n_step_types, &d.s.step_types));
-    ZKW_TRY(nl_to_device(hs->ops, hs->n_ops, &d.s.ops));
-    ZKW_TRY(nl_to_device(hs->gates, hs->n_gates, &d.s.gates));
-    ZKW_TRY(nl_to_device(hs->terms, hs->n_terms, &d.s.terms));
-    ZKW_TRY(nl_to_device(hs->hints, hs->n_hints ? hs->n_hints : 1, &d.s.hints));
-    ZKW_TRY(nl_to_device(hs->out, (size_t)hs->n_step_types * hs->state, &d.s.out));
-    ZKW_TRY(nl_to_device(hs->order, hs->n_order, &d.s.order));
-    ZKW_TRY(nl_to_device(hs->level_start, hs->n_level_starts, &d.s.level_start));
-    ZKW_TRY(nl_to_device(hs->homes, hs->n_values, &d.s.homes));
-    ZKW_TRY(nl_to_device(hs->cycle, hs->steps_per_cycle, &d.s.cycle));
-    size_t n_rowend = 0;
-    for (u32 k = 0; k < hs->n_step_types; k++) n_rowend += hs->step_types[k].rows;
-    ZKW_TRY(nl_to_device(hs->gate_row_end, n_rowend, &d.s.gate_row_end));
-    const NlV V(*hs);
-    // general-purpose cell map: [type: cell0 + col * rows + row] = dense reference of the cell
-    std::vector<u32> cell0(hs->n_step_types);
-    std::vector<uint16_t> cmap;
-    u32 max_items = 0;
-    for (u32 k = 0; k < hs->n_step_types; k++) {
-        const nl_step_type& T = hs->step_types[k];
-        cell0[k] = (u32)cmap.size();
-        cmap.resize(cmap.size() + (size_t)hs->g * T.rows, 0xFFFF);
-        uint16_t* m = cmap.data() + cell0[k];
-        for (int f = 0; f < NL_HDR_FIELDS; f++) m[(size_t)f * T.rows] = (uint16_t)(V.hdr + f);
-        for (u32 gi = 0; gi < T.n_gates; gi++) {
-            const nl_gate& gt = hs->gates[T.gate0 + gi];
-            for (u32 i = 0; i < (u32)gt.n_known + gt.n_new; i++)
-                m[(size_t)(gt.col + i) * T.rows + gt.row] = V.dense(hs->terms[T.term0 + gt.first_term + i].ref);
-        }
-        max_items = std::max(max_items, T.n_ops + T.n_gates + T.rows);
-    }
-    ZKW_TRY(nl_to_device(cmap.data(), cmap.size(), &d.cellmap));
-    ZKW_TRY(nl_to_device(cell0.data(), cell0.size(), &d.cell0));
-    // keys of a cycle: step after step, [slot][lookup row] inside a step
-    std::vector<u32> key0(hs->steps_per_cycle);
-    u32 keys = 0;
-    for (u32 s = 0; s < hs->steps_per_cycle; s++) {
-        key0[s] = keys;
-        keys += hs->r * hs->step_types[hs->cycle[s].type].lookup_rows;
-    }
-    d.keys_per_cycle = keys;
-    ZKW_TRY(nl_to_device(key0.data(), key0.size(), &d.step_key0));
-    // histogram plan: the row runs of every table in every step of a cycle; slices in proportion to the lookups
-    std::vector<NlHistEntry> entries;
-    std::vector<u32> first(hs->n_tables + 1, 0), slice0(hs->n_tables + 1, 0);
-    std::vector<unsigned long long> weight(hs->n_tables, 0);
-    for (u32 tb = 0; tb < hs->n_tables; tb++) {
-        first[tb] = (u32)entries.size();
-        for (u32 s = 0; s < hs->steps_per_cycle; s++) {
-            const nl_step_type& T = hs->step_types[hs->cycle[s].type];
-            u32 r0 = ~0u, r1 = 0;
-            for (u32 r = 0; r < T.lookup_rows; r++)
-                if (hs->ops[T.op0 + r * hs->r].table == tb + 1) { r0 = std::min(r0, r); r1 = r + 1; }
-            if (r1) { entries.push_back(NlHistEntry{s, r0, r1, key0[s], T.lookup_rows}); weight[tb] += (r1 - r0) * hs->r; }
-        }
-    }
-    first[hs->n_tables] = (u32)entries.size();
-    std::vector<u32> slices(hs->n_tables, 1);
-    for (int left = 64 - (int)hs->n_tables; left > 0; left--) {  // the next slice goes to the table with the most lookups per slice
-        u32 best = 0;
-        for (u32 tb = 1; tb < hs->n_tables; tb++)
-            if (weight[tb] * slices[best] > weight[best] * slices[tb]) best = tb;
-        slices[best]++;
-    }
-    for (u32 tb = 0; tb < hs->n_tables; tb++) slice0[tb + 1] = slice0[tb] + slices[tb];
-    d.n_hist_slices = slice0[hs->n_tables];
-    ZKW_TRY(nl_to_device(entries.data(), entries.size(), &d.hist_entries));
-    ZKW_TRY(nl_to_device(first.data(), first.size(), &d.hist_first));
-    ZKW_TRY(nl_to_device(slice0.data(), slice0.size(), &d.hist_slice0));
-    // the gates' known cells, run-length packed (netlist_kernels.cuh NlDev): consecutive cells whose dense references step by 1 and whose
-    // shifts step by `step` with one sign fold into one entry, provided every cell of the run is < 2^step (nibbles at step 4, bytes at
-    // step 8: true for this format's values, which are nibbles or bytes by construction of the generators)
-    std::vector<uint32_t> pk;
-    std::vector<uint16_t> pk_first;
-    std::vector<u32> pk0(hs->n_step_types);
-    for (u32 k = 0; k < hs->n_step_types; k++) {
-        const nl_step_type& T = hs->step_types[k];
-        pk0[k] = (u32)pk.size();
-        for (u32 gi = 0; gi < T.n_gates; gi++) {
-            const nl_gate& gt = hs->gates[T.gate0 + gi];
-            const nl_term* tm = hs->terms + T.term0 + gt.first_term;
-            pk_first.push_back((uint16_t)(pk.size() - pk0[k]));
-            for (u32 i = 1; i < gt.n_new; i++) {  // the fill describes a gate's NEW cells as (first value, count, first shift, step)
-                const nl_term *a = tm + gt.n_known + i - 1, *b = a + 1;
-                if (b->ref != a->ref + 1 || (i > 1 && (b->code & 0x7F) - (a->code & 0x7F) != (a->code & 0x7F) - (a[-1].code & 0x7F)))
-                    return fail(ZKW_ERR_INVALID, "netlist circuit %d: the NEW cells of gate %u are not consecutive values at evenly spaced shifts", circuit_type, gi);
-            }
-            for (u32 i = 0; i < gt.n_known;) {
-                if (tm[i].code & NL_TERM_LATE) { i++; continue; }  // in the constraint, not in the fill's evaluation
-                const u32 ref = V.dense(tm[i].ref), code = tm[i].code & 0xFF;
-                u32 cnt = 1, step = 0;
-                if (i + 1 < gt.n_known && !(tm[i + 1].code & NL_TERM_LATE) && V.dense(tm[i + 1].ref) == ref + 1 && (tm[i + 1].code & 0x80) == (code & 0x80) && (tm[i + 1].code & 0x7F) > (code & 0x7F)) {
-                    step = (tm[i + 1].code & 0x7F) - (code & 0x7F);
-                    const bool nibble_run = hs->w == 4 && step == 4, byte_run = hs->w == 3 && step == 8;  // values < 2^step
-                    if (nibble_run || byte_run)
-                        while (cnt < 8 && i + cnt < gt.n_known && V.dense(tm[i + cnt].ref) == ref + cnt && tm[i + cnt].code == code + cnt * step) cnt++;
-                    else step = 0;
-                }
-                if (cnt == 1) step = 0;
-                pk.push_back(ref | (cnt - 1) << 16 | code << 20 | step << 28);
-                i += cnt;
-            }
-        }
-        pk_first.push_back((uint16_t)(pk.size() - pk0[k]));  // closes the step type's last gate
-    }
-    if (pk.empty()) pk.push_back(0);
-    d.n_pk_terms = (u32)pk.size();
-    ZKW_TRY(nl_to_device(pk.data(), pk.size(), &d.pk_terms));
-    ZKW_TRY(nl_to_device(pk_first.data(), pk_first.size(), &d.pk_first));
-    ZKW_TRY(nl_to_device(pk0.data(), pk0.size(), &d.pk0));
-    d.max_items = max_items;
-    d.vsize = V.size;
-    // 16 waves per workgroup where two such workgroups still fit a CU (the Keccak family: 32 cycles in flight per CU), else 8
-    d.lds_bytes = NlLds(*hs, V.size, d.n_pk_terms, 8).total;
-    d.lds_bytes16 = NlLds(*hs, V.size, d.n_pk_terms, 16).total;
-    d.fill_waves = d.lds_bytes16 <= 80 * 1024 ? 16 : 8;
-    if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d: %u terms packed into %u, LDS %u bytes for %u waves\n", circuit_type, hs->n_terms, d.n_pk_terms, d.fill_waves == 16 ? d.lds_bytes16 : d.lds_bytes, d.fill_waves);
-    const NlDev* dd = nullptr;
-    ZKW_TRY(nl_to_device(&d, 1, &dd));
-    c.host = d;
-    c.dev = const_cast<NlDev*>(dd);
-    *out = &c;
-    return ZKW_OK;
-}
-
-struct NlInstance { u64 first_round; u32 n_active; const u64* public_input; const zkw_trace* t; size_t slot; bool fresh = false; /* the hash state before the instance is zero, not what round first_round - 1 left (independent queues in one call) */ };
-
-template <int W, int R, int WAVES>
-int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
-    static bool attr_set[16] = {};
-    if (!attr_set[ctx->device & 15]) {  // more than the default 64 KB of dynamic LDS
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[ctx->device & 15] = true;
-    }
-    static const u32 probe = [] { const char* e = getenv("ZKW_NL_PROBE"); return e ? (u32)atoi(e) : 0u; }();  // measurement only: 1 = no level walk, 2 = no streaming
-    // as many workgroups as the LDS lets a CU hold: the write phase is a stream of stores and wants waves in flight
-    const unsigned lds = WAVES == 16 ? nc->host.lds_bytes16 : nc->host.lds_bytes;
-    const unsigned per_cu = std::max<unsigned>(1, std::min<unsigned>(4, (160u * 1024u) / std::max<unsigned>(1, lds)));
-    const unsigned blocks = std::min<unsigned>((capacity + WAVES - 1) / WAVES, std::max<unsigned>(1, 256 * per_cu / nj));
-    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R, WAVES>), dim3(blocks, nj), dim3(64 * WAVES), lds, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
-    return launch_check("k_nl_fill");
-}
-template <int W, int R>
-int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
-    // (a call with few cycles keeps 8 waves per workgroup: twice the workgroups, so that every CU has one)
-    if (nc->host.fill_waves == 16 && (size_t)((capacity + 15) / 16) * nj >= 128) ZKW_TRY((nl_launch_fill_w<W, R, 16>(ctx, nc, d_jobs, nj, capacity, n_rows)));
-    else ZKW_TRY((nl_launch_fill_w<W, R, 8>(ctx, nc, d_jobs, nj, capacity, n_rows)));
-    { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
-    return launch_check("k_nl_hist");
-}
-
-// synthesis of instances of one netlist circuit from the block's round records (`sha_like`: zkw_sha256_round_record, else keccak)
-int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_rounds, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
-    const NlCached* nc = nullptr;
-    ZKW_TRY(nl_get(ctx, circuit_type, &nc));
-    const nl_spec& S = nc->host.s;
-    if (nc->host.lds_bytes > 160 * 1024) return fail(ZKW_ERR_INVALID, "netlist of circuit %d needs %u bytes of LDS", circuit_type, nc->host.lds_bytes);
-    const size_t used = NL_USED_ROWS(&S, capacity);
-    if (used > n_rows || S.total_table_rows > n_rows)
-        return fail(ZKW_ERR_INVALID, "capacity %u needs %zu rows (tables: %u), trace has %zu", capacity, used, S.total_table_rows, n_rows);
-    const size_t ni = inst.size();
-    if (ni == 0) return ZKW_OK;
-    uint8_t *d_hdr = nullptr, *d_free = nullptr, *d_state = nullptr;
-    uint16_t* d_keys = nullptr;
-    const size_t hdr_n = capacity, free_n = (size_t)capacity * S.free_per_cycle, state_n = (size_t)(capacity + 1) * S.state, keys_n = (size_t)capacity * nc->host.keys_per_cycle;
-    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_hdr", ni * hdr_n, &d_hdr));
-    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_free", ni * free_n + 1, &d_free));
-    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_state", ni * state_n, &d_state));
-    ZKW_TRY(ctx->scratch_t<uint16_t>("nl_keys", ni * keys_n, &d_keys));
-    u32* d_hist = nullptr;
-    const size_t hist_n = (size_t)nc->host.n_hist_slices * 2 * NL_HIST_HALF;
-    ZKW_TRY(ctx->scratch_t<u32>("nl_hist", ni * hist_n, &d_hist));
-    std::vector<NlPrepJob> prep(ni);
-    std::vector<NlJob> jobs(ni);
-    const size_t bnd = NL_BOUNDARY_ROW(&S, capacity);
-    for (size_t k = 0; k < ni; k++) {
-        const size_t rec_bytes = sha_like ? sizeof(zkw_sha256_round_record) : sizeof(zkw_keccak_round_record);
-        prep[k] = inst[k].fresh ? NlPrepJob{static_cast<const char*>(d_rounds) + inst[k].first_round * rec_bytes, 0, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n}
-                                : NlPrepJob{d_rounds, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n};
-        // The fill writes the lookup cells of every row above the boundary and the general-purpose cells of the header / gate rows;
-        // everything else is zero. A slot whose previous tenant was the same layout (circuit, capacity, rows) already has those
-        // zeros: nothing to clear (the multiplicity column is rewritten over the tables' rows). Otherwise: clear it.
-        const uint64_t tag = ((uint64_t)circuit_type << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
-        const bool clean = inst[k].t->tag_of(inst[k].slot) == tag;
-        u64* tr = inst[k].t->slot_for_write(inst[k].slot, tag);
-        jobs[k] = NlJob{prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before, inst[k].public_input, tr, d_keys + k * keys_n, d_hist + k * hist_n};
-        if (!clean) {
-            HIP_TRY(hipMemsetAsync(tr, 0, (size_t)S.g * n_rows * sizeof(u64), ctx->stream));  // general-purpose columns
-            hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - bnd + 255) / 256), S.mult_col - S.g), dim3(256), 0, ctx->stream, tr + (size_t)S.g * n_rows + bnd, n_rows, n_rows - bnd);
-            ZKW_TRY(launch_check("k_zero_strip"));
-            HIP_TRY(hipMemsetAsync(tr + (size_t)S.mult_col * n_rows, 0, n_rows * sizeof(u64), ctx->stream));
-        }
-    }
-    NlPrepJob* d_prep = nullptr;
-    NlJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("nl_prep", prep, &d_prep));
-    ZKW_TRY(ctx->upload("nl_jobs", jobs, &d_jobs));
-    const unsigned nj = (unsigned)ni;
-    if (sha_like) { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_sha, dim3(capacity + 1, nj), dim3(128), 0, ctx->stream, d_prep, capacity); }
-    else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
-    ZKW_TRY(launch_check("k_nl_prepare"));
-    switch (circuit_type) {
-        case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-    }
-    { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
-    return launch_check("k_nl_finish");
-}
-
-int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u32 capacity, uint64_t* n_violations, uint64_t* first_bad) {
-    const NlCached* nc = nullptr;
-    ZKW_TRY(nl_get(ctx, circuit_type, &nc));
-    const nl_spec& S = nc->host.s;
-    if (t->n_cols < S.cols) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %u", t->n_cols, S.cols);
-    if (NL_USED_ROWS(&S, capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
-    HIP_TRY(hipSetDevice(ctx->device));
-    const u64* trace = t->data + slot * t->slot_elems();
-    const size_t n_rows = t->n_rows;
-    CheckResult* d_res = nullptr;
-    u32* d_hist = nullptr;
-    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
-    ZKW_TRY(ctx->scratch_t<u32>("nl_check_hist", S.total_table_rows, &d_hist));
-    CheckResult init{0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, S.total_table_rows * sizeof(u32), ctx->stream));
-    { Prof _p(ctx, "k_nl_check_steps"); hipLaunchKernelGGL(k_nl_check_steps, dim3((nc->host.max_items + 255) / 256, capacity * S.steps_per_cycle), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_nl_check_steps"));
-    { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
-    ZKW_TRY(launch_check("k_nl_check_tail"));
-    CheckResult res;
-    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
-    *n_violations = res.violations;
-    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
-    return ZKW_OK;
-}
-
-// instance i of a precompile-style witness covers the rounds [i * capacity, min((i + 1) * capacity, total)) (none for the dummy instance)
-std::vector<NlInstance> nl_instances(size_t first_instance, size_t n_instances, u32 capacity, bool any, u64 total_rounds, const u64* cf_pi, size_t n_all,
-                                     zkw_trace* t, size_t first_slot) {
-    std::vector<NlInstance> v(n_instances);
-    for (size_t k = 0; k < n_instances; k++) {
-        const size_t i = first_instance + k;
-        v[k].first_round = (u64)i * capacity;
-        v[k].n_active = any ? (u32)std::min<u64>(capacity, total_rounds - v[k].first_round) : 0;
-        v[k].public_input = cf_pi + COMPACT_FORM_LEN * n_all + 4 * i;
-        v[k].t = t;
-        v[k].slot = (first_slot + k) % t->n_slots;
-    }
-    return v;
-}
-}  // namespace
-
-// ZkSyncBaseLayerCircuit::synthesis for Keccak256RoundFunction (type 5): 86 + 3 x 14 columns, Xor8 / And8 / ByteSplit<1..4>
-extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances,
-                                           zkw_trace* t, size_t first_slot) {
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_keccak_round_synthesize: bad argument");
-    if (w->kind != ZKW_PRECOMPILE_KECCAK256) return fail(ZKW_ERR_INVALID, "zkw_keccak_round_synthesize: not a keccak256 witness");
-    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
-    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
-    if (t->n_cols < KC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the Keccak256RoundFunction circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, KC_COLS);
-    if (n_instances == 0) return ZKW_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));  // public inputs of the block's instances (a20), once
-    return nl_synthesize(ctx, 5, false, w->keccak_rounds, nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
-                         w->capacity, t->n_rows);
-}
-extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
-        return fail(ZKW_ERR_INVALID, "zkw_keccak_round_check_satisfied: bad argument");
-    return nl_check(ctx, 5, t, slot, capacity, n_violations, first_bad);
-}
-
-// ZkSyncBaseLayerCircuit::synthesis for Sha256RoundFunction (type 6): 116 + 4 x 9 columns, TriXor4 / Ch4 / Maj4 / Split4BitChunk<1, 2>
-extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances,
-                                           zkw_trace* t, size_t first_slot) {
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_sha256_round_synthesize: bad argument");
-    if (w->kind != ZKW_PRECOMPILE_SHA256) return fail(ZKW_ERR_INVALID, "zkw_sha256_round_synthesize: not a sha256 witness");
-    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
-    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
-    if (t->n_cols < SC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the Sha256RoundFunction circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, SC_COLS);
-    if (n_instances == 0) return ZKW_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
-    return nl_synthesize(ctx, 6, true, w->sha256_rounds, nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
-                         w->capacity, t->n_rows);
-}
-extern "C" int zkw_sha256_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
-        return fail(ZKW_ERR_INVALID, "zkw_sha256_round_check_satisfied: bad argument");
-    return nl_check(ctx, 6, t, slot, capacity, n_violations, first_bad);
-}
-
-// ------------------------------------------------------------------------------------------------ CodeDecommitter synthesis
-// ZkSyncBaseLayerCircuit::synthesis for CodeDecommitter (type 3): the SHA-256 netlist on 108 + 4 x 11 columns, one cycle per round
-// of the unpacked bytecodes (a cycle is one round: BeginNew shares the cycle of a bytecode's first round)
-extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_witness* w, size_t first_instance, size_t n_instances,
-                                               zkw_trace* t, size_t first_slot) {
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_code_decommitter_synthesize: bad argument");
-    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
-    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
-    if (t->n_cols < DC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the CodeDecommitter circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, DC_COLS);
-    if (n_instances == 0) return ZKW_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (!w->cf_pi) ZKW_TRY(closed_form_public_inputs<CfDecommitter>(ctx, w->instances, w->n_instances, &w->cf_pi));
-    return nl_synthesize(ctx, 3, true, w->sha256_rounds, nl_instances(first_instance, n_instances, w->capacity, true, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
-                         w->capacity, t->n_rows);
-}
-extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
-        return fail(ZKW_ERR_INVALID, "zkw_code_decommitter_check_satisfied: bad argument");
-    return nl_check(ctx, 3, t, slot, capacity, n_violations, first_bad);
-}
-
-// copy-permutation check through sigma columns (zkw_setup_copy_permutation): trace[cell] == trace[sigma[cell]] for every cell
-__global__ __launch_bounds__(256) void k_check_sigma(const u64* __restrict__ trace, const u64* __restrict__ sigma, size_t n_cells, CheckResult* res,
-                                                     size_t n_rows) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += stride) {
-        const u64 j = sigma[i];
-        if (j >= n_cells || trace[i] != trace[j]) flag_bad(res, 4, i / n_rows, i % n_rows);
-    }
-}
-extern "C" int zkw_check_copy_permutation(zkw_ctx* ctx, const zkw_trace* t, size_t slot, const uint64_t* sigma, uint32_t n_columns,
-                                          uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || !sigma || !n_violations || t->ctx->device != ctx->device || slot >= t->n_slots || n_columns == 0 || n_columns > t->n_cols)
-        return fail(ZKW_ERR_INVALID, "zkw_check_copy_permutation: bad argument");
-    HIP_TRY(hipSetDevice(ctx->device));
-    const size_t n_cells = (size_t)n_columns * t->n_rows;
-    const u64* d_sigma = nullptr;
-    ZKW_TRY(ctx->in("sigma", sigma, n_cells, &d_sigma));
-    CheckResult* d_res = nullptr;
-    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
-    CheckResult init{0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    { Prof _p(ctx, "k_check_sigma"); hipLaunchKernelGGL(k_check_sigma, dim3(2048), dim3(256), 0, ctx->stream, t->data + slot * t->slot_elems(), d_sigma, n_cells, d_res, t->n_rows); }
-    ZKW_TRY(launch_check("k_check_sigma"));
-    CheckResult res;
-    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
-    *n_violations = res.violations;
-    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
-    return ZKW_OK;
-}
-
-// LinearHasher (type 13): the Keccak-f netlist over the sponge of the serialized L2 -> L1 messages (compute_linear_keccak256,
-// data_hasher_and_merklizer.rs:8-67; wrapper base_layer/linear_hasher.rs:28-138). One instance per block.
-extern "C" int zkw_linear_hasher_synthesize_batch(zkw_ctx* ctx, const zkw_log_query* messages, const uint64_t* message_offsets, size_t n_queues,
-                                                  const zkw_queue_state4* queue_states, uint32_t capacity, zkw_trace* t, size_t first_slot,
-                                                  zkw_linear_hasher_instance* records_out, uint64_t* public_inputs_out) {
-    if (!ctx || !t || !message_offsets || !queue_states || !records_out || t->ctx->device != ctx->device || capacity == 0)
-        return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: bad argument");
-    if (n_queues == 0) return ZKW_OK;
-    if (first_slot + n_queues > t->n_slots) return fail(ZKW_ERR_INVALID, "slots [%zu, %zu) of a trace with %zu", first_slot, first_slot + n_queues, t->n_slots);
-    if (t->n_cols < LH_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the LinearHasher circuit needs %d", t->n_cols, LH_COLS);
-    const size_t total = message_offsets[n_queues];
-    if (message_offsets[0] != 0 || (total && !messages)) return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: offsets must start at 0");
-    std::vector<u64> moff(message_offsets, message_offsets + n_queues + 1), roff(n_queues + 1, 0);
-    for (size_t b = 0; b < n_queues; b++) {
-        if (moff[b + 1] < moff[b]) return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: offsets decrease at %zu", b);
-        const size_t n = moff[b + 1] - moff[b];
-        if (n > capacity) return fail(ZKW_ERR_INVALID, "queue %zu: %zu messages, the circuit hashes at most %u", b, n, capacity);
-        roff[b + 1] = roff[b] + n * 88 / 136 + 1;
-    }
-    const u32 cycles = ZKW_LINEAR_HASHER_CYCLES(capacity);
-    const size_t n_rows = t->n_rows;
-    HIP_TRY(hipSetDevice(ctx->device));
-    const zkw_log_query* d_q = nullptr;
-    ZKW_TRY(ctx->in("lh_q", messages, total, &d_q));
-    zkw_keccak_round_record* d_rounds = nullptr;
-    uint8_t* d_hash = nullptr;
-    u64 *d_moff = nullptr, *d_roff = nullptr;
-    ZKW_TRY(ctx->scratch_t<zkw_keccak_round_record>("lh_rounds", roff[n_queues], &d_rounds));
-    ZKW_TRY(ctx->scratch_t<uint8_t>("lh_hash", 32 * n_queues, &d_hash));
-    ZKW_TRY(ctx->upload("lh_moff", moff, &d_moff));
-    ZKW_TRY(ctx->upload("lh_roff", roff, &d_roff));
-    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3((unsigned)n_queues), dim3(64), 0, ctx->stream, d_q, (size_t)0, d_hash, d_rounds, d_moff, d_roff); }
-    ZKW_TRY(launch_check("k_linear_keccak256"));
-    std::vector<zkw_linear_hasher_instance> recv(n_queues);
-    std::vector<uint8_t> hashes(32 * n_queues);
-    ZKW_TRY(ctx->read_small(hashes.data(), d_hash, hashes.size()));
-    for (size_t b = 0; b < n_queues; b++) {
-        memset(&recv[b], 0, sizeof recv[b]);
-        recv[b].start_flag = recv[b].completion_flag = 1;
-        recv[b].queue_state = queue_states[b];
-        memcpy(recv[b].keccak256_hash, &hashes[32 * b], 32);
-    }
-    zkw_linear_hasher_instance* d_rec = nullptr;
-    ZKW_TRY(ctx->upload("lh_record", recv, &d_rec));
-    u64 *d_cf = nullptr, *d_pi = nullptr;
-    ZKW_TRY(ctx->scratch_t<u64>("lh_cf", COMPACT_FORM_LEN * n_queues, &d_cf));
-    ZKW_TRY(ctx->scratch_t<u64>("lh_pi", 4 * n_queues, &d_pi));
-    {
-        constexpr int lanes = CfLanes<CfLinearHasher>::value;
-        Prof _p(ctx, "k_closed_form_commitments");
-        hipLaunchKernelGGL((k_closed_form_commitments<CfLinearHasher>), dim3(blocks_for(4 * n_queues, lanes)), dim3(lanes), 0, ctx->stream, d_rec, n_queues, d_cf);
-    }
-    ZKW_TRY(launch_check("k_closed_form_commitments"));
-    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n_queues, 64)), dim3(64), 0, ctx->stream, d_cf, n_queues, (u32)COMPACT_FORM_LEN, d_pi); }
-    ZKW_TRY(launch_check("k_commit_encodings"));
-    std::vector<NlInstance> inst(n_queues);
-    for (size_t b = 0; b < n_queues; b++) inst[b] = NlInstance{roff[b], (u32)(roff[b + 1] - roff[b]), d_pi + 4 * b, t, first_slot + b, true};
-    ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows));
-    memcpy(records_out, recv.data(), n_queues * sizeof recv[0]);
-    if (public_inputs_out) ZKW_TRY(ctx->read_small(public_inputs_out, d_pi, 32 * n_queues));
-    return ZKW_OK;
-}
-
-extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* messages, size_t n, const zkw_queue_state4* queue_state,
-                                            uint32_t capacity, zkw_trace* t, size_t slot, zkw_linear_hasher_instance* record_out,
-                                            uint64_t* public_input_out) {
-    if (!queue_state || !record_out) return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize: bad argument");
-    const uint64_t offsets[2] = {0, n};
-    return zkw_linear_hasher_synthesize_batch(ctx, messages, offsets, 1, queue_state, capacity, t, slot, record_out, public_input_out);
-}
-
-extern "C" int zkw_linear_hasher_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
-        return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_check_satisfied: bad argument");
-    return nl_check(ctx, 13, t, slot, ZKW_LINEAR_HASHER_CYCLES(capacity), n_violations, first_bad);
-}
-
-// ------------------------------------------------------------------------------------------------ StorageSorter synthesis
-extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_witness* w, size_t first_instance, size_t n_instances,
-                                             zkw_trace* t, size_t first_slot) {
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_synthesize: bad argument");
-    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
-    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
-    if (t->n_cols < SS_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the StorageSorter needs %d", t->n_cols, SS_COLS);
-    const u32 capacity = w->capacity;
-    const size_t n_rows = t->n_rows, n = w->n;
-    if (SS_MIN_ROWS(capacity) > n_rows)
-        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, trace has %zu", capacity, (unsigned long long)SS_MIN_ROWS(capacity), n_rows);
-    if (n_rows & 1) return fail(ZKW_ERR_INVALID, "trace length must be even (it is a power of two in every circuit)");
-    if (n_instances == 0) return ZKW_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    u32* d_hist = nullptr;
-    ZKW_TRY(ctx->scratch_t<u32>("ss_hist", n_instances * 256, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
-    std::vector<SsSynthJob> jobs(n_instances);
-    for (size_t k = 0; k < n_instances; k++) {
-        SsSynthJob& j = jobs[k];
-        j.inst = w->instances + first_instance + k;
-        j.unsorted_enc = w->enc_all; j.sorted_enc = w->enc_all + 20 * n;
-        j.unsorted_new_tails = w->tails_all + 4 * n; j.sorted_new_tails = w->tails_all + 12 * n; j.result_new_tails = w->tails_all + 16 * n;
-        j.challenges = w->challenges;
-        j.lhs_z = w->lhs_z; j.rhs_z = w->rhs_z;
-        j.sc.D = reinterpret_cast<int*>(w->scans); j.sc.S = w->scans + n; j.sc.R = w->scans + 2 * n; j.sc.E = w->scans + 3 * n;
-        j.n_block = n;
-        j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
-        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
-        j.hist = d_hist + 256 * k;
-    }
-    SsSynthJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("ss_jobs", jobs, &d_jobs));
-    const unsigned nj = (unsigned)n_instances;
-    const u32 rstride = (u32)SS_REGION_STRIDE(capacity);
-    const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
-    { Prof _p(ctx, "k_ss_fill_queue"); hipLaunchKernelGGL((k_ss_fill_queue<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ss_fill_queue<0>"));
-    { Prof _p(ctx, "k_ss_fill_queue"); hipLaunchKernelGGL((k_ss_fill_queue<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ss_fill_queue<1>"));
-    { Prof _p(ctx, "k_ss_fill_queue"); hipLaunchKernelGGL((k_ss_fill_queue<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ss_fill_queue<2>"));
-#define SS_LAUNCH_ROW(R) { Prof _p(ctx, "k_ss_fill_row"); hipLaunchKernelGGL((k_ss_fill_row<SS_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
-    ZKW_TRY(launch_check("k_ss_fill_row<" #R ">"));
-    SS_LAUNCH_ROW(A) SS_LAUNCH_ROW(X0) SS_LAUNCH_ROW(X1) SS_LAUNCH_ROW(X2) SS_LAUNCH_ROW(X3) SS_LAUNCH_ROW(X4) SS_LAUNCH_ROW(X5)
-    SS_LAUNCH_ROW(X6) SS_LAUNCH_ROW(X7) SS_LAUNCH_ROW(K) SS_LAUNCH_ROW(C1) SS_LAUNCH_ROW(C2) SS_LAUNCH_ROW(Q)
-#undef SS_LAUNCH_ROW
-    { Prof _p(ctx, "k_ss_fill_tail"); hipLaunchKernelGGL(k_ss_fill_tail, dim3((SS_G + SS_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ss_fill_tail"));
-    { Prof _p(ctx, "k_ss_fill_boundary"); hipLaunchKernelGGL(k_ss_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ss_fill_boundary"));
-    return ctx->sync_if_host();
-}
-
-extern "C" int zkw_storage_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
-                                                  uint64_t* n_violations, uint64_t* first_bad) {
-    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations)
-        return fail(ZKW_ERR_INVALID, "zkw_storage_sorter_check_satisfied: bad argument");
-    if (SS_MIN_ROWS(capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
-    return check_satisfied<SpecStorageSorter>(ctx, t, slot, capacity, n_violations, first_bad);
-}
-
 // ------------------------------------------------------------------------------------------------ MainVM instance slicing (a19)
 extern "C" int zkw_vm_slice_instances(zkw_ctx* ctx, const zkw_vm_tracer_streams* in, zkw_vm_instance* instances,
                                       uint32_t* memory_read_index, uint32_t* memory_write_index, uint64_t* n_reads, uint64_t* n_writes) {
@@ -4266,4 +1599,5 @@ extern "C" int zkw_vm_slice_instances(zkw_ctx* ctx, const zkw_vm_tracer_streams*
     }
     return ctx->sync_if_host();
 }
+
 

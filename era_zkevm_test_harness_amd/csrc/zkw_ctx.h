@@ -1,0 +1,289 @@
+// zkw_ctx.h — the context, its buffer helpers and the device-level steps shared by the library's translation units that
+// launch kernels (zkw_api.hip: core + RAM path; zkw_sorters.hip: the four sorter / demuxer circuits; zkw_precompiles.hip: code
+// decommitter, precompiles, storage application and the netlist circuits; zkw_setup.hip: layouts, selectors, sigma). The other
+// units (zkw_block.hip, zkw_comm.hip, zkw_recursion.hip, zkw_vm_trace.hip) are written against include/zkw.h and zkw_internal.h.
+// Kernels live in the *.cuh headers with internal linkage: a unit includes the ones it launches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zkw.h"
+#include "zkw_internal.h"
+#include "ram_kernels.cuh"
+#include "log_kernels.cuh"
+#include "../../include/zkw_ram_circuit_spec.h"  // RC_COLS: the default width of a trace
+
+using namespace zkw;
+
+#define fail zkw_fail  // sets the calling thread's zkw_last_error() text and returns the code
+
+// the library's allocation caches (zkw_api.hip): device / pinned host buffers by size class, never hipFree'd while cached
+hipError_t zkw_cache_alloc(int pinned_host, void** p, size_t bytes);
+void zkw_cache_release(int pinned_host, void* p);
+static inline hipError_t dev_malloc(void** p, size_t bytes) { return zkw_cache_alloc(0, p, bytes); }
+template <class T> static inline hipError_t dev_malloc(T** p, size_t bytes) { return zkw_cache_alloc(0, (void**)p, bytes); }
+static inline void dev_free(void* p) { zkw_cache_release(0, p); }
+static inline hipError_t pin_malloc(void** p, size_t bytes) { return zkw_cache_alloc(1, p, bytes); }
+static inline void pin_free(void* p) { zkw_cache_release(1, p); }
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return fail(_e == hipErrorOutOfMemory ? ZKW_ERR_OOM : ZKW_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                          \
+    } while (0)
+
+#define ZKW_TRY(expr)            \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != ZKW_OK) return _rc; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ context
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+// pinned host staging for descriptor uploads; `ev` marks the last copy that read it
+struct HostStage {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+
+struct zkw_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int ptr_mode = ZKW_PTR_HOST;
+    hipStream_t chain_stream = nullptr;  // optional second stream for the queue-chain kernels (zkw_set_chain_stream)
+    hipEvent_t chain_ev_a = nullptr, chain_ev_b = nullptr;
+    // witnesses and traces created from this context keep it alive: zkw_destroy defers while any is outstanding
+    std::atomic<long> children{0};
+    std::atomic<bool> destroy_requested{false};
+    std::atomic<bool> destroying{false};
+    bool chain_service = false;  // queue chains go to the device's chain service (batched with other contexts' chains)
+    int chain_form = 0;  // lanes per Poseidon2 state in the queue-chain kernel: 4 (quad), 16 (row), 0 = auto
+    std::map<std::string, DevBuf> pool;  // named grow-only scratch
+    std::map<std::string, HostStage> stages;
+    // optional per-kernel timing with HIP events on the context's stream (zkw_profile_*)
+    bool profiling = false;
+    struct ProfSpan { const char* name; hipEvent_t a, b; };
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> free_events;
+    std::map<std::string, std::pair<double, uint64_t>> prof_totals;  // name -> (ms, launches)
+
+    hipEvent_t prof_event() {
+        if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    int prof_collect() {
+        if (spans.empty()) return ZKW_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (auto& sp : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+                auto& t = prof_totals[sp.name];
+                t.first += ms;
+                t.second += 1;
+            }
+            free_events.push_back(sp.a);
+            free_events.push_back(sp.b);
+        }
+        spans.clear();
+        return ZKW_OK;
+    }
+
+    int scratch(const char* name, size_t bytes, void** out) {
+        DevBuf& b = pool[name];
+        if (b.cap < bytes) {
+            if (b.p) {
+                retired_dev.push_back(b.p);
+                b.p = nullptr;
+                b.cap = 0;
+            }
+            size_t want = bytes + bytes / 8 + 256;
+            HIP_TRY(dev_malloc(&b.p, want));
+            b.cap = want;
+        }
+        *out = b.p;
+        return ZKW_OK;
+    }
+    template <class T>
+    int scratch_t(const char* name, size_t count, T** out) {
+        void* p = nullptr;
+        ZKW_TRY(scratch(name, count * sizeof(T) + 16, &p));
+        *out = static_cast<T*>(p);
+        return ZKW_OK;
+    }
+    // descriptor upload: host vector -> named device scratch (async, pageable source is copied by the
+    // runtime before return)
+    template <class T>
+    int upload(const char* name, const std::vector<T>& h, T** out) {
+        ZKW_TRY(scratch_t<T>(name, h.size() ? h.size() : 1, out));
+        if (h.empty()) return ZKW_OK;
+        const size_t bytes = h.size() * sizeof(T);
+        HostStage& st = stages[name];
+        if (st.pending) {  // the previous upload from this staging buffer must have been consumed
+            HIP_TRY(hipEventSynchronize(st.ev));
+            st.pending = false;
+        }
+        if (st.cap < bytes) {
+            if (st.p) retired_host.push_back(st.p);
+            st.p = nullptr;
+            st.cap = 0;
+            HIP_TRY(pin_malloc(&st.p, bytes + bytes / 2 + 256));
+            st.cap = bytes + bytes / 2 + 256;
+        }
+        if (!st.ev) HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+        memcpy(st.p, h.data(), bytes);
+        HIP_TRY(hipMemcpyAsync(*out, st.p, bytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(st.ev, stream));
+        st.pending = true;
+        return ZKW_OK;
+    }
+    // stage an input: returns a device pointer for `src` (copying when src is a host pointer)
+    template <class T>
+    int in(const char* name, const T* src, size_t count, const T** out) {
+        if (ptr_mode == ZKW_PTR_DEVICE || count == 0) {
+            *out = src;
+            return ZKW_OK;
+        }
+        T* d = nullptr;
+        ZKW_TRY(scratch_t<T>(name, count, &d));
+        HIP_TRY(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+        *out = d;
+        return ZKW_OK;
+    }
+    // reserve an output: device pointer to write to (dst itself in device mode)
+    template <class T>
+    int out(const char* name, T* dst, size_t count, T** dev) {
+        if (ptr_mode == ZKW_PTR_DEVICE) {
+            *dev = dst;
+            return ZKW_OK;
+        }
+        return scratch_t<T>(name, count ? count : 1, dev);
+    }
+    template <class T>
+    int finish_out(T* dst, const T* dev, size_t count) {
+        if (ptr_mode == ZKW_PTR_DEVICE || count == 0) return ZKW_OK;
+        HIP_TRY(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, stream));
+        return ZKW_OK;
+    }
+    int sync_if_host() {
+        if (ptr_mode == ZKW_PTR_HOST) HIP_TRY(hipStreamSynchronize(stream));
+        return ZKW_OK;
+    }
+    // Small device -> host readback (counts, violation flags) THROUGH PINNED MEMORY, then a sync of this stream only.
+    // A hipMemcpyAsync into pageable memory waits for every stream of the device (measured: 0.9 s behind another
+    // context's queue chain), which serialises the builders that zkw_block_run runs side by side.
+    void* pinned_rb = nullptr;
+    size_t pinned_rb_cap = 0;
+    int read_small(void* dst, const void* src, size_t bytes) {
+        if (pinned_rb_cap < bytes) {
+            if (pinned_rb) retired_host.push_back(pinned_rb);
+            pinned_rb = nullptr;
+            pinned_rb_cap = 0;
+            const size_t want = bytes < 4096 ? 4096 : bytes;
+            HIP_TRY(pin_malloc(&pinned_rb, want));
+            pinned_rb_cap = want;
+        }
+        HIP_TRY(hipMemcpyAsync(pinned_rb, src, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        memcpy(dst, pinned_rb, bytes);
+        return ZKW_OK;
+    }
+    // buffers replaced by a bigger one: hipFree / hipHostFree wait for the whole device, so they are kept until the
+    // context is destroyed (growth is geometric: bounded waste)
+    std::vector<void*> retired_dev, retired_host;
+};
+
+// RAII span around one kernel launch (or a library sort); free when profiling is off
+struct Prof {
+    zkw_ctx* c;
+    hipEvent_t b = nullptr;
+    Prof(zkw_ctx* ctx, const char* name) : c(ctx) {
+        if (!c->profiling) return;
+        hipEvent_t a = c->prof_event();
+        b = c->prof_event();
+        (void)hipEventRecord(a, c->stream);
+        c->spans.push_back(zkw_ctx::ProfSpan{name, a, b});
+    }
+    ~Prof() {
+        if (b) (void)hipEventRecord(b, c->stream);
+    }
+};
+
+static inline int launch_check(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ZKW_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return ZKW_OK;
+}
+
+// rows [0, width) of blockIdx.y's column of a column-major strip
+static __global__ __launch_bounds__(256) void k_zero_strip(u64* __restrict__ base, size_t pitch, size_t width) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < width) base[(size_t)blockIdx.y * pitch + i] = 0;
+}
+// Zeroes what the fill of a "zkw trace v3" netlist circuit does NOT write itself: the general-purpose columns [0, g) (the
+// fill then overwrites its header / gate cells), the lookup columns [g, g + lookup_cols) below the last cycle only (the fill
+// writes every lookup cell of the cycles' rows, padding and header rows included), and the multiplicity columns. Zeroing
+// the whole slot first wrote the lookup columns twice: a third of the memset.
+static inline int zero_netlist_slot(zkw_ctx* ctx, u64* trace, size_t n_rows, size_t g, size_t lookup_cols, size_t n_cols, size_t used_rows) {
+    HIP_TRY(hipMemsetAsync(trace, 0, g * n_rows * sizeof(u64), ctx->stream));
+    if (used_rows < n_rows) {  // (hipMemset2DAsync ran this strip at 0.8 TB/s: 0.2 ms per Keccak slot)
+        hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - used_rows + 255) / 256), (unsigned)lookup_cols), dim3(256), 0, ctx->stream,
+                           trace + g * n_rows + used_rows, n_rows, n_rows - used_rows);
+        ZKW_TRY(launch_check("k_zero_strip"));
+    }
+    HIP_TRY(hipMemsetAsync(trace + (g + lookup_cols) * n_rows, 0, (n_cols - g - lookup_cols) * n_rows * sizeof(u64), ctx->stream));
+    return ZKW_OK;
+}
+
+static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+void ctx_retain(zkw_ctx* ctx);
+void ctx_release(zkw_ctx* ctx);
+
+struct zkw_trace {
+    zkw_ctx* ctx = nullptr;
+    size_t n_rows = 0, n_cols = RC_COLS, n_slots = 0;
+    u64* data = nullptr;
+    size_t slot_elems() const { return n_cols * n_rows; }
+    // What a slot held last, for the netlist circuits (which then only rewrite the cells their fill writes: everything else is
+    // still zero from the same layout's previous tenant). 0 = unknown; every other writer and zkw_trace_device_ptr reset it.
+    mutable std::vector<uint64_t> slot_tag;
+    u64* slot_for_write(size_t slot, uint64_t tag) const {
+        if (slot_tag.size() != n_slots) slot_tag.assign(n_slots, 0);
+        slot_tag[slot] = tag;
+        return data + slot * slot_elems();
+    }
+    uint64_t tag_of(size_t slot) const { return slot_tag.size() == n_slots ? slot_tag[slot] : 0; }
+};
+
+// device-level steps (zkw_api.hip): every builder's queue chains, challenges and grand products go through these
+int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc);
+int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs);
+int dev_fs(zkw_ctx* ctx, const std::vector<FsJob>& jobs, int state_w, int n_chal);
+int dev_grand_products(zkw_ctx* ctx, std::vector<GpSeg>& segs, int width, int n_reps);
+int dev_log_chains(zkw_ctx* ctx, const u64* d_enc, size_t total, std::vector<LogChainJob>& jobs);

@@ -1,0 +1,991 @@
+// zkw_precompiles.hip — the hash-circuit side of include/zkw.h: CodeDecommitter (3), the keccak256 / sha256 / ecrecover
+// round functions (5, 6, 7), StorageApplication (10), L1MessagesHasher (13): witness builders, and the netlist engine that
+// synthesizes and checks types 3, 5, 6, 13 ("zkw trace v4").
+#include "zkw_ctx.h"
+#include "closed_forms_host.h"
+#include "decommitter_kernels.cuh"
+#include "precompile_kernels.cuh"
+#include "storage_application_kernels.cuh"
+#include "netlist_kernels.cuh"
+#include "sort.h"
+
+// ------------------------------------------------------------------------------------------------ code decommitter
+struct zkw_decommitter_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n_requests = 0, total_words = 0, total_rounds = 0, n_instances = 0;
+    zkw_mem_query* mem_q = nullptr;
+    u64 *mem_enc = nullptr, *mem_tails = nullptr;
+    u32* round_states = nullptr;
+    zkw_decommitter_instance* instances = nullptr;
+    zkw_sha256_round_record* sha256_rounds = nullptr;  // [total_rounds]: the cycles of the circuit
+    u32 capacity = 0;
+    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
+    void release() {
+        void* ptrs[] = {mem_q, mem_enc, mem_tails, round_states, instances, sha256_rounds, cf_pi};
+        for (void* p : ptrs)
+            if (p) dev_free(p);
+    }
+};
+
+extern "C" int zkw_decommitter_memory_queries(zkw_ctx* ctx, const zkw_decommit_query* requests, size_t n_requests,
+                                              const uint32_t* words, const uint64_t* word_offsets, zkw_mem_query* out) {
+    if (!ctx || !requests || !words || !word_offsets || !out || n_requests == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_decommitter_memory_queries: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint64_t> woff(n_requests + 1);
+    for (size_t k = 0; k <= n_requests; k++) woff[k] = word_offsets[k] - word_offsets[0];
+    const size_t total = woff[n_requests];
+    const zkw_decommit_query* d_req = nullptr;
+    const u32* d_words = nullptr;
+    u64* d_woff = nullptr;
+    zkw_mem_query* d_out = nullptr;
+    ZKW_TRY(ctx->in("dcm_req", requests, n_requests, &d_req));
+    ZKW_TRY(ctx->in("dcm_words", words + 8 * word_offsets[0], total * 8, &d_words));
+    ZKW_TRY(ctx->upload("dcm_woff", woff, &d_woff));
+    ZKW_TRY(ctx->out("dcm_mq_out", out, total, &d_out));
+    DecommitterJob job{d_req, d_words, d_woff, nullptr, nullptr, d_out, nullptr, nullptr, n_requests, nullptr};
+    if (total) {
+        { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, job, (u64)total); }
+        ZKW_TRY(launch_check("k_decommitter_mem_queries"));
+    }
+    ZKW_TRY(ctx->finish_out(out, d_out, total));
+    return ctx->sync_if_host();
+}
+
+extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit_query* requests, const uint64_t* dedup_tails,
+                                     size_t n_requests, const uint32_t* words, const uint64_t* word_offsets,
+                                     uint32_t capacity, const zkw_queue_state12* mem_in, const uint64_t* given_mem_tails,
+                                     zkw_decommitter_witness** out) {
+    if (!ctx || !requests || !dedup_tails || !words || !word_offsets || !mem_in || !out || capacity == 0 || n_requests == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_decommitter_build: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint64_t> woff(n_requests + 1), roff(n_requests + 1, 0);
+    for (size_t k = 0; k <= n_requests; k++) woff[k] = word_offsets[k] - word_offsets[0];
+    for (size_t k = 0; k < n_requests; k++) {
+        if (word_offsets[k + 1] <= word_offsets[k]) return fail(ZKW_ERR_INVALID, "request %zu has no bytecode (decommit_code.rs:236)", k);
+        roff[k + 1] = roff[k] + (woff[k + 1] - woff[k] + 1) / 2;
+    }
+    zkw_decommitter_witness* w = new zkw_decommitter_witness();
+    w->ctx = ctx;
+    w->n_requests = n_requests;
+    w->total_words = woff[n_requests];
+    w->total_rounds = roff[n_requests];
+    w->n_instances = (w->total_rounds + capacity - 1) / capacity;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
+    alloc((void**)&w->mem_q, w->total_words * sizeof(zkw_mem_query));
+    alloc((void**)&w->mem_enc, w->total_words * 64);
+    alloc((void**)&w->mem_tails, w->total_words * 96);
+    alloc((void**)&w->round_states, w->total_rounds * 32);
+    alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
+    w->capacity = capacity;
+    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_decommitter_instance));
+    auto bail = [&](int rc) { w->release(); delete w; return rc; };
+    if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_decommitter_build: hipMalloc failed: %s", hipGetErrorString(e)));
+    const zkw_decommit_query* d_req = nullptr;
+    const u64* d_dt = nullptr;
+    const u32* d_words = nullptr;
+    u64 *d_woff = nullptr, *d_roff = nullptr;
+    u32* d_viol = nullptr;
+    int rc = ctx->in("dcm_req", requests, n_requests, &d_req);
+    if (rc == ZKW_OK) rc = ctx->in("dcm_dt", dedup_tails, n_requests * 12, &d_dt);
+    if (rc == ZKW_OK) rc = ctx->in("dcm_words", words + 8 * word_offsets[0], w->total_words * 8, &d_words);
+    if (rc == ZKW_OK) rc = ctx->upload("dcm_woff", woff, &d_woff);
+    if (rc == ZKW_OK) rc = ctx->upload("dcm_roff", roff, &d_roff);
+    if (rc == ZKW_OK) rc = ctx->scratch_t<u32>("dcm_viol", 1, &d_viol);
+    if (rc != ZKW_OK) return bail(rc);
+    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
+    DecommitterJob job{d_req, d_words, d_woff, d_roff, w->round_states, w->mem_q, w->mem_enc, d_viol, n_requests, w->sha256_rounds};
+    { Prof _p(ctx, "k_decommitter_sha"); hipLaunchKernelGGL(k_decommitter_sha, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
+    if ((rc = launch_check("k_decommitter_sha")) != ZKW_OK) return bail(rc);
+    { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(w->total_words, 256)), dim3(256), 0, ctx->stream, job, (u64)w->total_words); }
+    if ((rc = launch_check("k_decommitter_mem_queries")) != ZKW_OK) return bail(rc);
+    zkw_queue_state12* d_min = nullptr;
+    std::vector<zkw_queue_state12> minv(1, *mem_in);
+    if ((rc = ctx->upload("dcm_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
+    if (given_mem_tails) {  // the caller has already hashed the memory queue this slice belongs to (zkw_block_run)
+        if (hipMemcpyAsync(w->mem_tails, given_mem_tails, w->total_words * 96,
+                           ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return bail(fail(ZKW_ERR_HIP, "copy of the given memory-queue states failed"));
+    } else {
+        std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, w->total_words});
+        if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
+    }
+    std::vector<DecommitterBlock> blk(1);
+    blk[0].job = job;
+    blk[0].dedup_tails = d_dt;
+    blk[0].mem_tails = w->mem_tails;
+    blk[0].instances = w->instances;
+    blk[0].mem_in = *mem_in;
+    blk[0].total_rounds = w->total_rounds;
+    blk[0].total_words = w->total_words;
+    blk[0].capacity = capacity;
+    DecommitterBlock* d_blk = nullptr;
+    if ((rc = ctx->upload("dcm_block", blk, &d_blk)) != ZKW_OK) return bail(rc);
+    { Prof _p(ctx, "k_decommitter_instances"); hipLaunchKernelGGL(k_decommitter_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    if ((rc = launch_check("k_decommitter_instances")) != ZKW_OK) return bail(rc);
+    u32 viol = 0;
+    if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
+        return bail(fail(ZKW_ERR_HIP, "readback failed"));
+    if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u bytecodes do not match their decommit request (length parity, word count or "
+                                                     "SHA-256 digest, decommit_code.rs:241-244, 323-337)", viol));
+    ctx_retain(ctx);
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" int zkw_decommitter_build(zkw_ctx* ctx, const zkw_decommit_query* requests, const uint64_t* dedup_tails,
+                                     size_t n_requests, const uint32_t* words, const uint64_t* word_offsets,
+                                     uint32_t capacity, const zkw_queue_state12* mem_in, zkw_decommitter_witness** out) {
+    return zkw_decommitter_build_with_tails(ctx, requests, dedup_tails, n_requests, words, word_offsets, capacity, mem_in, nullptr, out);
+}
+
+extern "C" size_t zkw_decommitter_witness_num_instances(const zkw_decommitter_witness* w) { return w ? w->n_instances : 0; }
+static const void* dcm_array(const zkw_decommitter_witness* w, int what, size_t* bytes) {
+    switch (what) {
+        case ZKW_DCM_MEM_QUERIES: *bytes = w->total_words * sizeof(zkw_mem_query); return w->mem_q;
+        case ZKW_DCM_MEM_ENC: *bytes = w->total_words * 64; return w->mem_enc;
+        case ZKW_DCM_MEM_TAILS: *bytes = w->total_words * 96; return w->mem_tails;
+        case ZKW_DCM_ROUND_STATES: *bytes = w->total_rounds * 32; return w->round_states;
+        case ZKW_DCM_INSTANCES: *bytes = w->n_instances * sizeof(zkw_decommitter_instance); return w->instances;
+        case ZKW_DCM_SHA256_ROUNDS: *bytes = w->total_rounds * sizeof(zkw_sha256_round_record); return w->sha256_rounds;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_decommitter_witness_bytes(const zkw_decommitter_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)dcm_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_decommitter_witness_device_ptr(const zkw_decommitter_witness* w, int what) {
+    size_t b = 0;
+    return w ? dcm_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_decommitter_witness_get(const zkw_decommitter_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_decommitter_witness_get: null argument");
+    if (what < 0 || what > ZKW_DCM_SHA256_ROUNDS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    size_t bytes = 0;
+    const void* src = dcm_array(w, what, &bytes);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_decommitter_witness_free(zkw_decommitter_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    zkw_ctx* owner = w->ctx;
+    delete w;
+    ctx_release(owner);
+}
+
+// ------------------------------------------------------------------------------------------------ L1 messages hasher
+extern "C" int zkw_linear_keccak256(zkw_ctx* ctx, const zkw_log_query* messages, size_t n, uint8_t* hash_out) {
+    if (!ctx || !hash_out || (n && !messages)) return fail(ZKW_ERR_INVALID, "zkw_linear_keccak256: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const zkw_log_query* d_q = nullptr;
+    uint8_t* d_out = nullptr;
+    ZKW_TRY(ctx->in("lk_q", messages, n, &d_q));
+    ZKW_TRY(ctx->out("lk_out", hash_out, 32, &d_out));
+    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out, (zkw_keccak_round_record*)nullptr, (const u64*)nullptr, (const u64*)nullptr); }
+    ZKW_TRY(launch_check("k_linear_keccak256"));
+    ZKW_TRY(ctx->finish_out(hash_out, d_out, 32));
+    return ctx->sync_if_host();
+}
+
+// RecursionQueueSimulator::split_by(RECURSION_ARITY) as create_leaf_witnesses uses it (src/witness/recursive_aggregation.rs:
+// 98-117, circuit_encodings/src/lib.rs:472-506): leaf k covers the requests [k * arity, min((k + 1) * arity, n)); its queue
+// starts at the state the previous leaf ended with (head = tail before its first request), ends at the state after its last
+// request. Pure host arithmetic over the states zkw_queue_push_chain_full returned: no device work.
+extern "C" int zkw_recursion_queue_split(const uint64_t* states, size_t n, uint32_t arity, zkw_queue_state12* leaf_states,
+                                         size_t max_leaves, size_t* n_leaves) {
+    if (!n_leaves || arity == 0 || (n && !states)) return fail(ZKW_ERR_INVALID, "zkw_recursion_queue_split: bad argument");
+    const size_t leaves = (n + arity - 1) / arity;  // an empty queue has no leaves (split_by returns an empty vector)
+    *n_leaves = leaves;
+    if (leaves > max_leaves || (leaves && !leaf_states)) return fail(ZKW_ERR_INVALID, "zkw_recursion_queue_split: %zu leaves, room for %zu", leaves, max_leaves);
+    for (size_t k = 0; k < leaves; k++) {
+        const size_t first = k * arity, end = std::min(n, first + arity);
+        zkw_queue_state12& q = leaf_states[k];
+        memset(&q, 0, sizeof q);
+        if (first) memcpy(q.head, states + 12 * (first - 1), 96);
+        memcpy(q.tail, states + 12 * (end - 1), 96);
+        q.length = (uint32_t)(end - first);
+    }
+    return ZKW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ precompile round functions (a16)
+struct zkw_precompile_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n_requests = 0, n_queries = 0, total_rounds = 0, total_reads = 0, n_instances = 0;
+    u64 *mem_enc = nullptr, *mem_tails = nullptr;
+    zkw_precompile_instance* instances = nullptr;
+    zkw_keccak_round_record* keccak_rounds = nullptr;  // keccak256 only: [total_rounds], the cycles of the circuit
+    zkw_sha256_round_record* sha256_rounds = nullptr;  // sha256 only
+    int kind = 0;
+    u32 capacity = 0;
+    u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
+    void release() {
+        void* ptrs[] = {mem_enc, mem_tails, instances, keccak_rounds, sha256_rounds, cf_pi};
+        for (void* p : ptrs)
+            if (p) dev_free(p);
+    }
+};
+
+extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw_log_query* requests, const uint64_t* request_tails,
+                                    size_t n_requests, const zkw_mem_query* mem_queries, size_t n_queries, uint32_t capacity,
+                                    const zkw_queue_state12* mem_in, const uint64_t* given_mem_tails,
+                                    zkw_precompile_witness** out) {
+    if (!ctx || !mem_in || !out || capacity == 0 || kind < ZKW_PRECOMPILE_KECCAK256 || kind > ZKW_PRECOMPILE_ECRECOVER ||
+        (n_requests && (!requests || !request_tails)) || (n_queries && !mem_queries))
+        return fail(ZKW_ERR_INVALID, "zkw_precompile_build: bad argument");
+    if (n_requests == 0 && n_queries) return fail(ZKW_ERR_INVALID, "memory queries without a precompile request");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const zkw_log_query* d_req = nullptr;
+    const u64* d_rt = nullptr;
+    const zkw_mem_query* d_mq = nullptr;
+    u64 *d_roff = nullptr, *d_qoff = nullptr, *d_rdoff = nullptr, *d_meta = nullptr;
+    u64 meta[4] = {0, 0, 0, 0};
+    if (n_requests) {
+        ZKW_TRY(ctx->in("pc_req", requests, n_requests, &d_req));
+        ZKW_TRY(ctx->in("pc_rt", request_tails, n_requests * 4, &d_rt));
+        if (n_queries) ZKW_TRY(ctx->in("pc_mq", mem_queries, n_queries, &d_mq));
+        ZKW_TRY(ctx->scratch_t<u64>("pc_roff", n_requests + 1, &d_roff));
+        ZKW_TRY(ctx->scratch_t<u64>("pc_qoff", n_requests + 1, &d_qoff));
+        ZKW_TRY(ctx->scratch_t<u64>("pc_rdoff", n_requests + 1, &d_rdoff));
+        ZKW_TRY(ctx->scratch_t<u64>("pc_meta", 4, &d_meta));
+        { Prof _p(ctx, "k_precompile_counts"); hipLaunchKernelGGL(k_precompile_counts, dim3(1), dim3(1024), 0, ctx->stream, kind, d_req, n_requests, d_roff, d_qoff, d_rdoff, d_meta); }
+        ZKW_TRY(launch_check("k_precompile_counts"));
+        ZKW_TRY(ctx->read_small(meta, d_meta, sizeof meta));
+        if (meta[3]) return fail(ZKW_ERR_INVALID, "a precompile request without rounds (the first round carries `new_request`)");
+        if (meta[1] != n_queries)
+            return fail(ZKW_ERR_INVALID, "the requests need %llu memory queries, %zu given", (unsigned long long)meta[1], n_queries);
+    }
+    zkw_precompile_witness* w = new zkw_precompile_witness();
+    w->ctx = ctx;
+    w->n_requests = n_requests;
+    w->n_queries = n_queries;
+    w->total_rounds = meta[0];
+    w->total_reads = meta[2];
+    w->n_instances = n_requests ? (w->total_rounds + capacity - 1) / capacity : 1;
+    w->kind = kind;
+    w->capacity = capacity;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
+    alloc((void**)&w->mem_enc, n_queries * 64);
+    alloc((void**)&w->mem_tails, n_queries * 96);
+    alloc((void**)&w->instances, w->n_instances * sizeof(zkw_precompile_instance));
+    if (kind == ZKW_PRECOMPILE_KECCAK256) alloc((void**)&w->keccak_rounds, w->total_rounds * sizeof(zkw_keccak_round_record));
+    if (kind == ZKW_PRECOMPILE_SHA256) alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
+    auto bail = [&](int rc) { w->release(); delete w; return rc; };
+    if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_precompile_build: hipMalloc failed: %s", hipGetErrorString(e)));
+    int rc = ZKW_OK;
+    PrecompileSnap* d_snaps = nullptr;
+    u32* d_viol = nullptr;
+    if ((rc = ctx->scratch_t<u32>("pc_viol", 1, &d_viol)) != ZKW_OK) return bail(rc);
+    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
+    if (n_requests) {
+        if ((rc = ctx->scratch_t<PrecompileSnap>("pc_snaps", w->n_instances, &d_snaps)) != ZKW_OK) return bail(rc);
+        if (n_queries) {
+            if ((rc = dev_encode(ctx, d_mq, n_queries, w->mem_enc)) != ZKW_OK) return bail(rc);
+            zkw_queue_state12* d_min = nullptr;
+            std::vector<zkw_queue_state12> minv(1, *mem_in);
+            if ((rc = ctx->upload("pc_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
+            if (given_mem_tails) {  // already hashed by the caller as part of the whole memory queue (zkw_block_run)
+                if (hipMemcpyAsync(w->mem_tails, given_mem_tails, n_queries * 96,
+                                   ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    return bail(fail(ZKW_ERR_HIP, "copy of the given memory-queue states failed"));
+            } else {
+                std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, n_queries});
+                if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
+            }
+        }
+        PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity, w->keccak_rounds, w->sha256_rounds};
+        { Prof _p(ctx, "k_precompile_walk"); hipLaunchKernelGGL(k_precompile_walk, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
+        if ((rc = launch_check("k_precompile_walk")) != ZKW_OK) return bail(rc);
+    }
+    std::vector<PrecompileBlock> blk(1);
+    blk[0].kind = kind;
+    blk[0].snaps = d_snaps;
+    blk[0].req_tails = d_rt;
+    blk[0].mem_tails = w->mem_tails;
+    blk[0].instances = w->instances;
+    blk[0].mem_in = *mem_in;
+    blk[0].n_requests = n_requests;
+    blk[0].total_rounds = w->total_rounds;
+    blk[0].n_instances = w->n_instances;
+    blk[0].capacity = capacity;
+    PrecompileBlock* d_blk = nullptr;
+    if ((rc = ctx->upload("pc_block", blk, &d_blk)) != ZKW_OK) return bail(rc);
+    { Prof _p(ctx, "k_precompile_instances"); hipLaunchKernelGGL(k_precompile_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    if ((rc = launch_check("k_precompile_instances")) != ZKW_OK) return bail(rc);
+    u32 viol = 0;
+    if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
+        return bail(fail(ZKW_ERR_HIP, "readback failed"));
+    if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u requests whose memory queries do not fit their ABI (read/write flags, word "
+                                                     "index or count: the asserts of the round walks)", viol));
+    ctx_retain(ctx);
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" int zkw_precompile_build(zkw_ctx* ctx, int kind, const zkw_log_query* requests, const uint64_t* request_tails,
+                                    size_t n_requests, const zkw_mem_query* mem_queries, size_t n_queries, uint32_t capacity,
+                                    const zkw_queue_state12* mem_in, zkw_precompile_witness** out) {
+    return zkw_precompile_build_with_tails(ctx, kind, requests, request_tails, n_requests, mem_queries, n_queries, capacity, mem_in, nullptr, out);
+}
+
+extern "C" size_t zkw_precompile_witness_num_instances(const zkw_precompile_witness* w) { return w ? w->n_instances : 0; }
+extern "C" size_t zkw_precompile_witness_num_rounds(const zkw_precompile_witness* w) { return w ? w->total_rounds : 0; }
+static const void* pc_array(const zkw_precompile_witness* w, int what, size_t* bytes) {
+    switch (what) {
+        case ZKW_PRC_MEM_ENC: *bytes = w->n_queries * 64; return w->mem_enc;
+        case ZKW_PRC_MEM_TAILS: *bytes = w->n_queries * 96; return w->mem_tails;
+        case ZKW_PRC_INSTANCES: *bytes = w->n_instances * sizeof(zkw_precompile_instance); return w->instances;
+        case ZKW_PRC_KECCAK_ROUNDS: *bytes = w->keccak_rounds ? w->total_rounds * sizeof(zkw_keccak_round_record) : 0; return w->keccak_rounds;
+        case ZKW_PRC_SHA256_ROUNDS: *bytes = w->sha256_rounds ? w->total_rounds * sizeof(zkw_sha256_round_record) : 0; return w->sha256_rounds;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_precompile_witness_bytes(const zkw_precompile_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)pc_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_precompile_witness_device_ptr(const zkw_precompile_witness* w, int what) {
+    size_t b = 0;
+    return w ? pc_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_precompile_witness_get(const zkw_precompile_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_precompile_witness_get: null argument");
+    if (what < 0 || what > ZKW_PRC_SHA256_ROUNDS) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    size_t bytes = 0;
+    const void* src = pc_array(w, what, &bytes);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_precompile_witness_free(zkw_precompile_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    zkw_ctx* owner = w->ctx;
+    delete w;
+    ctx_release(owner);
+}
+
+// ------------------------------------------------------------------------------------------------ storage application (a17)
+struct zkw_storage_application_witness {
+    zkw_ctx* ctx = nullptr;
+    size_t n = 0, n_instances = 0;
+    u32 *keys = nullptr, *paths = nullptr, *roots = nullptr;
+    u64* leaf_indexes = nullptr;
+    zkw_storage_application_instance* instances = nullptr;
+    void release() {
+        void* ptrs[] = {keys, paths, roots, leaf_indexes, instances};
+        for (void* p : ptrs)
+            if (p) dev_free(p);
+    }
+};
+
+extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* queries, const uint64_t* query_tails, size_t n,
+                                             const uint64_t* init_leaf_indexes, const uint8_t* init_merkle_paths,
+                                             const uint8_t initial_root[32], uint64_t initial_next_enumeration_index,
+                                             uint32_t capacity, zkw_storage_application_witness** out) {
+    if (!ctx || !out || !initial_root || capacity < 2 || (n && (!queries || !query_tails || !init_leaf_indexes || !init_merkle_paths)))
+        return fail(ZKW_ERR_INVALID, "zkw_storage_application_build: bad argument");
+    if (n >= (1ull << 31)) return fail(ZKW_ERR_INVALID, "too many storage queries");
+    HIP_TRY(hipSetDevice(ctx->device));
+    zkw_storage_application_witness* w = new zkw_storage_application_witness();
+    w->ctx = ctx;
+    w->n = n;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = dev_malloc(p, bytes + 64); };
+    alloc((void**)&w->keys, n * 32);
+    alloc((void**)&w->paths, n * 256 * 32);
+    alloc((void**)&w->roots, n * 32);
+    alloc((void**)&w->leaf_indexes, n * 8);
+    auto bail = [&](int rc) { w->release(); delete w; return rc; };
+    if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed: %s", hipGetErrorString(e)));
+    int rc = ZKW_OK;
+    SapJob job;
+    memset(&job, 0, sizeof job);
+    const u64* d_qt = nullptr;
+    const uint8_t* d_ip = nullptr;
+    u64 *d_snap = nullptr, *d_meta = nullptr;
+    uint8_t* d_hash = nullptr;
+    u32* d_viol = nullptr;
+    auto TRY = [&](int r) { if (rc == ZKW_OK) rc = r; };
+    if (n) {
+        TRY(ctx->in("sap_q", queries, n, &job.queries));
+        TRY(ctx->in("sap_qt", query_tails, n * 4, &d_qt));
+        TRY(ctx->in("sap_ii", init_leaf_indexes, n, &job.init_index));
+        TRY(ctx->in("sap_ip", init_merkle_paths, n * 256 * 32, &d_ip));
+    }
+    job.init_paths = reinterpret_cast<const u32*>(d_ip);
+    job.keys = w->keys; job.paths = w->paths; job.roots = w->roots;
+    TRY(ctx->scratch_t<u64>("sap_newidx", n + 1, &job.new_index));
+    TRY(ctx->scratch_t<u32>("sap_prevw", n + 1, &job.prev_write));
+    TRY(ctx->scratch_t<u32>("sap_chunk", n + 1, &job.chunk_of));
+    TRY(ctx->scratch_t<u32>("sap_fwu", n + 1, &job.first_writes_upto));
+    TRY(ctx->scratch_t<u64>("sap_cend", n + 2, &job.chunk_end));
+    TRY(ctx->scratch_t<u32>("sap_jstar", (n + 1) * 256, &job.jstar));
+    TRY(ctx->scratch_t<u32>("sap_A0", (n + 1) * 8, &job.A0));
+    TRY(ctx->scratch_t<u32>("sap_A1", (n + 1) * 8, &job.A1));
+    TRY(ctx->scratch_t<u32>("sap_C0", (n + 1) * 8, &job.C0));
+    TRY(ctx->scratch_t<u32>("sap_C1", (n + 1) * 8, &job.C1));
+    TRY(ctx->scratch_t<u32>("sap_viol", 1, &d_viol));
+    TRY(ctx->scratch_t<u64>("sap_meta", 2, &d_meta));
+    TRY(ctx->scratch_t<u64>("sap_snap", (n + 1) * 25, &d_snap));
+    TRY(ctx->scratch_t<uint8_t>("sap_hash", 32, &d_hash));
+    if (rc != ZKW_OK) return bail(rc);
+    job.violations = d_viol;
+    job.meta = d_meta;
+    job.n = n;
+    job.next_enumeration_index = initial_next_enumeration_index;
+    memcpy(job.initial_root, initial_root, 32);
+    job.capacity = capacity;
+    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
+    u64 meta[2] = {1, initial_next_enumeration_index};
+    if (n) {
+        const unsigned g64 = blocks_for(n, 64);
+        { Prof _p(ctx, "k_sap_keys"); hipLaunchKernelGGL(k_sap_keys, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_keys"));
+        { Prof _p(ctx, "k_sap_scan"); hipLaunchKernelGGL(k_sap_scan, dim3(1), dim3(1024), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_scan"));
+        { Prof _p(ctx, "k_sap_pairs"); hipLaunchKernelGGL(k_sap_pairs, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_pairs"));
+        { Prof _p(ctx, "k_sap_leaves"); hipLaunchKernelGGL(k_sap_leaves, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_leaves"));
+        static_assert(ZKW_STORAGE_TREE_DEPTH == 256, "k_sap_levels walks 256 levels");
+        if (n <= SAP_PERSISTENT_MAX) {
+            Prof _p(ctx, "k_sap_levels");
+            hipLaunchKernelGGL(k_sap_levels, dim3(1), dim3(SAP_PERSISTENT_THREADS), 0, ctx->stream, job);
+        } else {
+            for (int L = 0; L < ZKW_STORAGE_TREE_DEPTH && rc == ZKW_OK; L++) {
+                Prof _p(ctx, "k_sap_level");
+                hipLaunchKernelGGL(k_sap_level, dim3(g64), dim3(64), 0, ctx->stream, job, L);
+            }
+        }
+        TRY(launch_check("k_sap_level"));
+        { Prof _p(ctx, "k_sap_roots"); hipLaunchKernelGGL(k_sap_roots, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        TRY(launch_check("k_sap_roots"));
+        if (rc != ZKW_OK) return bail(rc);
+        if (hipMemcpyAsync(w->leaf_indexes, job.init_index, n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            ctx->read_small(meta, d_meta, sizeof meta) != ZKW_OK)
+            return bail(fail(ZKW_ERR_HIP, "readback failed"));
+    }
+    w->n_instances = n ? (size_t)meta[0] : 1;
+    if (dev_malloc((void**)&w->instances, w->n_instances * sizeof(zkw_storage_application_instance) + 64) != hipSuccess)
+        return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed"));
+    SapKeccakOut ko{d_snap, d_hash};
+    { Prof _p(ctx, "k_sap_keccak"); hipLaunchKernelGGL(k_sap_keccak, dim3(1), dim3(64), 0, ctx->stream, job, ko); }
+    TRY(launch_check("k_sap_keccak"));
+    std::vector<SapBlock> blk(1);
+    blk[0].job = job;
+    blk[0].query_tails = d_qt;
+    blk[0].snapshots = d_snap;
+    blk[0].final_hash = d_hash;
+    blk[0].instances = w->instances;
+    blk[0].n_instances = w->n_instances;
+    SapBlock* d_blk = nullptr;
+    TRY(ctx->upload("sap_block", blk, &d_blk));
+    if (rc != ZKW_OK) return bail(rc);
+    { Prof _p(ctx, "k_sap_instances"); hipLaunchKernelGGL(k_sap_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    TRY(launch_check("k_sap_instances"));
+    if (rc != ZKW_OK) return bail(rc);
+    u32 viol = 0;
+    if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
+        return bail(fail(ZKW_ERR_HIP, "readback failed"));
+    if (viol) return bail(fail(ZKW_ERR_CHECK_FAILED, "%u storage queries contradict the tree: the pre-state proof does not lead to the "
+                                                     "initial root, the read value is not the leaf's (storage_application.rs:221,276), "
+                                                     "or a slot occurs twice", viol));
+    ctx_retain(ctx);
+    *out = w;
+    return ZKW_OK;
+}
+
+extern "C" size_t zkw_storage_application_witness_num_instances(const zkw_storage_application_witness* w) { return w ? w->n_instances : 0; }
+static const void* sap_array(const zkw_storage_application_witness* w, int what, size_t* bytes) {
+    switch (what) {
+        case ZKW_SAP_DERIVED_KEYS: *bytes = w->n * 32; return w->keys;
+        case ZKW_SAP_MERKLE_PATHS: *bytes = w->n * 256 * 32; return w->paths;
+        case ZKW_SAP_LEAF_INDEXES: *bytes = w->n * 8; return w->leaf_indexes;
+        case ZKW_SAP_ROOTS: *bytes = w->n * 32; return w->roots;
+        case ZKW_SAP_INSTANCES: *bytes = w->n_instances * sizeof(zkw_storage_application_instance); return w->instances;
+        default: *bytes = 0; return nullptr;
+    }
+}
+extern "C" size_t zkw_storage_application_witness_bytes(const zkw_storage_application_witness* w, int what) {
+    size_t b = 0;
+    if (w) (void)sap_array(w, what, &b);
+    return b;
+}
+extern "C" const void* zkw_storage_application_witness_device_ptr(const zkw_storage_application_witness* w, int what) {
+    size_t b = 0;
+    return w ? sap_array(w, what, &b) : nullptr;
+}
+extern "C" int zkw_storage_application_witness_get(const zkw_storage_application_witness* w, int what, void* dst, size_t dst_bytes) {
+    if (!w || !dst) return fail(ZKW_ERR_INVALID, "zkw_storage_application_witness_get: null argument");
+    if (what < 0 || what > ZKW_SAP_INSTANCES) return fail(ZKW_ERR_INVALID, "unknown array %d", what);
+    size_t bytes = 0;
+    const void* src = sap_array(w, what, &bytes);
+    if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "need %zu bytes, got %zu", bytes, dst_bytes);
+    if (bytes == 0) return ZKW_OK;
+    zkw_ctx* ctx = w->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return ctx->sync_if_host();
+}
+extern "C" void zkw_storage_application_witness_free(zkw_storage_application_witness* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->ctx->device);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    w->release();
+    zkw_ctx* owner = w->ctx;
+    delete w;
+    ctx_release(owner);
+}
+
+extern "C" int zkw_precompile_closed_forms(zkw_ctx* ctx, zkw_precompile_witness* w, const uint64_t** compact, const uint64_t** public_inputs) {
+    if (!ctx || !w || w->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_precompile_closed_forms: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!w->cf_pi) {
+        if (w->kind == ZKW_PRECOMPILE_KECCAK256) ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>>(ctx, w->instances, w->n_instances, &w->cf_pi));
+        else if (w->kind == ZKW_PRECOMPILE_SHA256) ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_SHA256>>(ctx, w->instances, w->n_instances, &w->cf_pi));
+        else ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_ECRECOVER>>(ctx, w->instances, w->n_instances, &w->cf_pi));
+    }
+    if (compact) *compact = w->cf_pi;
+    if (public_inputs) *public_inputs = w->cf_pi + COMPACT_FORM_LEN * w->n_instances;
+    return ZKW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ netlist circuits ("zkw trace v4")
+// Sha256RoundFunction (6), CodeDecommitter (3), Keccak256RoundFunction (5), L1MessagesHasher (13): one engine (netlist_kernels.cuh),
+// four generated specs on the reference's geometry and table sets. The device copy of a spec (its arrays, the general-purpose cell
+// map, the key layout and the histogram plan) is built once per device and circuit and never freed.
+namespace {
+struct NlCached { NlDev host; NlDev* dev = nullptr; };
+std::mutex g_nl_mu;
+std::map<std::pair<int, int>, NlCached>& nl_cache() { static auto* m = new std::map<std::pair<int, int>, NlCached>(); return *m; }
+
+template <class T>
+int nl_to_device(const T* src, size_t n, const T** out) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return fail(ZKW_ERR_OOM, "netlist spec: hipMalloc failed");
+    if (n && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return fail(ZKW_ERR_HIP, "netlist spec: upload failed");
+    *out = static_cast<const T*>(p);
+    return ZKW_OK;
+}
+
+int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
+    const nl_spec* hs = nl_host_spec(circuit_type);
+    if (!hs) return fail(ZKW_ERR_INVALID, "circuit type %d is not a netlist circuit", circuit_type);
+    std::lock_guard<std::mutex> g(g_nl_mu);
+    NlCached& c = nl_cache()[{ctx->device, circuit_type}];
+    if (c.dev) { *out = &c; return ZKW_OK; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    NlDev d;
+    memset(&d, 0, sizeof d);
+    d.s = *hs;
+    ZKW_TRY(nl_to_device(hs->tables, hs->n_tables, &d.s.tables));
+    ZKW_TRY(nl_to_device(hs->step_types, hs->n_step_types, &d.s.step_types));
+    ZKW_TRY(nl_to_device(hs->ops, hs->n_ops, &d.s.ops));
+    ZKW_TRY(nl_to_device(hs->gates, hs->n_gates, &d.s.gates));
+    ZKW_TRY(nl_to_device(hs->terms, hs->n_terms, &d.s.terms));
+    ZKW_TRY(nl_to_device(hs->hints, hs->n_hints ? hs->n_hints : 1, &d.s.hints));
+    ZKW_TRY(nl_to_device(hs->out, (size_t)hs->n_step_types * hs->state, &d.s.out));
+    ZKW_TRY(nl_to_device(hs->order, hs->n_order, &d.s.order));
+    ZKW_TRY(nl_to_device(hs->level_start, hs->n_level_starts, &d.s.level_start));
+    ZKW_TRY(nl_to_device(hs->homes, hs->n_values, &d.s.homes));
+    ZKW_TRY(nl_to_device(hs->cycle, hs->steps_per_cycle, &d.s.cycle));
+    size_t n_rowend = 0;
+    for (u32 k = 0; k < hs->n_step_types; k++) n_rowend += hs->step_types[k].rows;
+    ZKW_TRY(nl_to_device(hs->gate_row_end, n_rowend, &d.s.gate_row_end));
+    const NlV V(*hs);
+    // general-purpose cell map: [type: cell0 + col * rows + row] = dense reference of the cell
+    std::vector<u32> cell0(hs->n_step_types);
+    std::vector<uint16_t> cmap;
+    u32 max_items = 0;
+    for (u32 k = 0; k < hs->n_step_types; k++) {
+        const nl_step_type& T = hs->step_types[k];
+        cell0[k] = (u32)cmap.size();
+        cmap.resize(cmap.size() + (size_t)hs->g * T.rows, 0xFFFF);
+        uint16_t* m = cmap.data() + cell0[k];
+        for (int f = 0; f < NL_HDR_FIELDS; f++) m[(size_t)f * T.rows] = (uint16_t)(V.hdr + f);
+        for (u32 gi = 0; gi < T.n_gates; gi++) {
+            const nl_gate& gt = hs->gates[T.gate0 + gi];
+            for (u32 i = 0; i < (u32)gt.n_known + gt.n_new; i++)
+                m[(size_t)(gt.col + i) * T.rows + gt.row] = V.dense(hs->terms[T.term0 + gt.first_term + i].ref);
+        }
+        max_items = std::max(max_items, T.n_ops + T.n_gates + T.rows);
+    }
+    ZKW_TRY(nl_to_device(cmap.data(), cmap.size(), &d.cellmap));
+    ZKW_TRY(nl_to_device(cell0.data(), cell0.size(), &d.cell0));
+    // keys of a cycle: step after step, [slot][lookup row] inside a step
+    std::vector<u32> key0(hs->steps_per_cycle);
+    u32 keys = 0;
+    for (u32 s = 0; s < hs->steps_per_cycle; s++) {
+        key0[s] = keys;
+        keys += hs->r * hs->step_types[hs->cycle[s].type].lookup_rows;
+    }
+    d.keys_per_cycle = keys;
+    ZKW_TRY(nl_to_device(key0.data(), key0.size(), &d.step_key0));
+    // histogram plan: the row runs of every table in every step of a cycle; slices in proportion to the lookups
+    std::vector<NlHistEntry> entries;
+    std::vector<u32> first(hs->n_tables + 1, 0), slice0(hs->n_tables + 1, 0);
+    std::vector<unsigned long long> weight(hs->n_tables, 0);
+    for (u32 tb = 0; tb < hs->n_tables; tb++) {
+        first[tb] = (u32)entries.size();
+        for (u32 s = 0; s < hs->steps_per_cycle; s++) {
+            const nl_step_type& T = hs->step_types[hs->cycle[s].type];
+            u32 r0 = ~0u, r1 = 0;
+            for (u32 r = 0; r < T.lookup_rows; r++)
+                if (hs->ops[T.op0 + r * hs->r].table == tb + 1) { r0 = std::min(r0, r); r1 = r + 1; }
+            if (r1) { entries.push_back(NlHistEntry{s, r0, r1, key0[s], T.lookup_rows}); weight[tb] += (r1 - r0) * hs->r; }
+        }
+    }
+    first[hs->n_tables] = (u32)entries.size();
+    std::vector<u32> slices(hs->n_tables, 1);
+    for (int left = 64 - (int)hs->n_tables; left > 0; left--) {  // the next slice goes to the table with the most lookups per slice
+        u32 best = 0;
+        for (u32 tb = 1; tb < hs->n_tables; tb++)
+            if (weight[tb] * slices[best] > weight[best] * slices[tb]) best = tb;
+        slices[best]++;
+    }
+    for (u32 tb = 0; tb < hs->n_tables; tb++) slice0[tb + 1] = slice0[tb] + slices[tb];
+    d.n_hist_slices = slice0[hs->n_tables];
+    ZKW_TRY(nl_to_device(entries.data(), entries.size(), &d.hist_entries));
+    ZKW_TRY(nl_to_device(first.data(), first.size(), &d.hist_first));
+    ZKW_TRY(nl_to_device(slice0.data(), slice0.size(), &d.hist_slice0));
+    // the gates' known cells, run-length packed (netlist_kernels.cuh NlDev): consecutive cells whose dense references step by 1 and whose
+    // shifts step by `step` with one sign fold into one entry, provided every cell of the run is < 2^step (nibbles at step 4, bytes at
+    // step 8: true for this format's values, which are nibbles or bytes by construction of the generators)
+    std::vector<uint32_t> pk;
+    std::vector<uint16_t> pk_first;
+    std::vector<u32> pk0(hs->n_step_types);
+    for (u32 k = 0; k < hs->n_step_types; k++) {
+        const nl_step_type& T = hs->step_types[k];
+        pk0[k] = (u32)pk.size();
+        for (u32 gi = 0; gi < T.n_gates; gi++) {
+            const nl_gate& gt = hs->gates[T.gate0 + gi];
+            const nl_term* tm = hs->terms + T.term0 + gt.first_term;
+            pk_first.push_back((uint16_t)(pk.size() - pk0[k]));
+            for (u32 i = 1; i < gt.n_new; i++) {  // the fill describes a gate's NEW cells as (first value, count, first shift, step)
+                const nl_term *a = tm + gt.n_known + i - 1, *b = a + 1;
+                if (b->ref != a->ref + 1 || (i > 1 && (b->code & 0x7F) - (a->code & 0x7F) != (a->code & 0x7F) - (a[-1].code & 0x7F)))
+                    return fail(ZKW_ERR_INVALID, "netlist circuit %d: the NEW cells of gate %u are not consecutive values at evenly spaced shifts", circuit_type, gi);
+            }
+            for (u32 i = 0; i < gt.n_known;) {
+                if (tm[i].code & NL_TERM_LATE) { i++; continue; }  // in the constraint, not in the fill's evaluation
+                const u32 ref = V.dense(tm[i].ref), code = tm[i].code & 0xFF;
+                u32 cnt = 1, step = 0;
+                if (i + 1 < gt.n_known && !(tm[i + 1].code & NL_TERM_LATE) && V.dense(tm[i + 1].ref) == ref + 1 && (tm[i + 1].code & 0x80) == (code & 0x80) && (tm[i + 1].code & 0x7F) > (code & 0x7F)) {
+                    step = (tm[i + 1].code & 0x7F) - (code & 0x7F);
+                    const bool nibble_run = hs->w == 4 && step == 4, byte_run = hs->w == 3 && step == 8;  // values < 2^step
+                    if (nibble_run || byte_run)
+                        while (cnt < 8 && i + cnt < gt.n_known && V.dense(tm[i + cnt].ref) == ref + cnt && tm[i + cnt].code == code + cnt * step) cnt++;
+                    else step = 0;
+                }
+                if (cnt == 1) step = 0;
+                pk.push_back(ref | (cnt - 1) << 16 | code << 20 | step << 28);
+                i += cnt;
+            }
+        }
+        pk_first.push_back((uint16_t)(pk.size() - pk0[k]));  // closes the step type's last gate
+    }
+    if (pk.empty()) pk.push_back(0);
+    d.n_pk_terms = (u32)pk.size();
+    ZKW_TRY(nl_to_device(pk.data(), pk.size(), &d.pk_terms));
+    ZKW_TRY(nl_to_device(pk_first.data(), pk_first.size(), &d.pk_first));
+    ZKW_TRY(nl_to_device(pk0.data(), pk0.size(), &d.pk0));
+    d.max_items = max_items;
+    d.vsize = V.size;
+    // 16 waves per workgroup where two such workgroups still fit a CU (the Keccak family: 32 cycles in flight per CU), else 8
+    d.lds_bytes = NlLds(*hs, V.size, d.n_pk_terms, 8).total;
+    d.lds_bytes16 = NlLds(*hs, V.size, d.n_pk_terms, 16).total;
+    d.fill_waves = d.lds_bytes16 <= 80 * 1024 ? 16 : 8;
+    if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d: %u terms packed into %u, LDS %u bytes for %u waves\n", circuit_type, hs->n_terms, d.n_pk_terms, d.fill_waves == 16 ? d.lds_bytes16 : d.lds_bytes, d.fill_waves);
+    const NlDev* dd = nullptr;
+    ZKW_TRY(nl_to_device(&d, 1, &dd));
+    c.host = d;
+    c.dev = const_cast<NlDev*>(dd);
+    *out = &c;
+    return ZKW_OK;
+}
+
+struct NlInstance { u64 first_round; u32 n_active; const u64* public_input; const zkw_trace* t; size_t slot; bool fresh = false; /* the hash state before the instance is zero, not what round first_round - 1 left (independent queues in one call) */ };
+
+template <int W, int R, int WAVES>
+int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
+    static bool attr_set[16] = {};
+    if (!attr_set[ctx->device & 15]) {  // more than the default 64 KB of dynamic LDS
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[ctx->device & 15] = true;
+    }
+    static const u32 probe = [] { const char* e = getenv("ZKW_NL_PROBE"); return e ? (u32)atoi(e) : 0u; }();  // measurement only: 1 = no level walk, 2 = no streaming
+    // as many workgroups as the LDS lets a CU hold: the write phase is a stream of stores and wants waves in flight
+    const unsigned lds = WAVES == 16 ? nc->host.lds_bytes16 : nc->host.lds_bytes;
+    const unsigned per_cu = std::max<unsigned>(1, std::min<unsigned>(4, (160u * 1024u) / std::max<unsigned>(1, lds)));
+    const unsigned blocks = std::min<unsigned>((capacity + WAVES - 1) / WAVES, std::max<unsigned>(1, 256 * per_cu / nj));
+    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R, WAVES>), dim3(blocks, nj), dim3(64 * WAVES), lds, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
+    return launch_check("k_nl_fill");
+}
+template <int W, int R>
+int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
+    // (a call with few cycles keeps 8 waves per workgroup: twice the workgroups, so that every CU has one)
+    if (nc->host.fill_waves == 16 && (size_t)((capacity + 15) / 16) * nj >= 128) ZKW_TRY((nl_launch_fill_w<W, R, 16>(ctx, nc, d_jobs, nj, capacity, n_rows)));
+    else ZKW_TRY((nl_launch_fill_w<W, R, 8>(ctx, nc, d_jobs, nj, capacity, n_rows)));
+    { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+    return launch_check("k_nl_hist");
+}
+
+// synthesis of instances of one netlist circuit from the block's round records (`sha_like`: zkw_sha256_round_record, else keccak)
+int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_rounds, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
+    const NlCached* nc = nullptr;
+    ZKW_TRY(nl_get(ctx, circuit_type, &nc));
+    const nl_spec& S = nc->host.s;
+    if (nc->host.lds_bytes > 160 * 1024) return fail(ZKW_ERR_INVALID, "netlist of circuit %d needs %u bytes of LDS", circuit_type, nc->host.lds_bytes);
+    const size_t used = NL_USED_ROWS(&S, capacity);
+    if (used > n_rows || S.total_table_rows > n_rows)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %zu rows (tables: %u), trace has %zu", capacity, used, S.total_table_rows, n_rows);
+    const size_t ni = inst.size();
+    if (ni == 0) return ZKW_OK;
+    uint8_t *d_hdr = nullptr, *d_free = nullptr, *d_state = nullptr;
+    uint16_t* d_keys = nullptr;
+    const size_t hdr_n = capacity, free_n = (size_t)capacity * S.free_per_cycle, state_n = (size_t)(capacity + 1) * S.state, keys_n = (size_t)capacity * nc->host.keys_per_cycle;
+    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_hdr", ni * hdr_n, &d_hdr));
+    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_free", ni * free_n + 1, &d_free));
+    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_state", ni * state_n, &d_state));
+    ZKW_TRY(ctx->scratch_t<uint16_t>("nl_keys", ni * keys_n, &d_keys));
+    u32* d_hist = nullptr;
+    const size_t hist_n = (size_t)nc->host.n_hist_slices * 2 * NL_HIST_HALF;
+    ZKW_TRY(ctx->scratch_t<u32>("nl_hist", ni * hist_n, &d_hist));
+    std::vector<NlPrepJob> prep(ni);
+    std::vector<NlJob> jobs(ni);
+    const size_t bnd = NL_BOUNDARY_ROW(&S, capacity);
+    for (size_t k = 0; k < ni; k++) {
+        const size_t rec_bytes = sha_like ? sizeof(zkw_sha256_round_record) : sizeof(zkw_keccak_round_record);
+        prep[k] = inst[k].fresh ? NlPrepJob{static_cast<const char*>(d_rounds) + inst[k].first_round * rec_bytes, 0, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n}
+                                : NlPrepJob{d_rounds, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n};
+        // The fill writes the lookup cells of every row above the boundary and the general-purpose cells of the header / gate rows;
+        // everything else is zero. A slot whose previous tenant was the same layout (circuit, capacity, rows) already has those
+        // zeros: nothing to clear (the multiplicity column is rewritten over the tables' rows). Otherwise: clear it.
+        const uint64_t tag = ((uint64_t)circuit_type << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
+        const bool clean = inst[k].t->tag_of(inst[k].slot) == tag;
+        u64* tr = inst[k].t->slot_for_write(inst[k].slot, tag);
+        jobs[k] = NlJob{prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before, inst[k].public_input, tr, d_keys + k * keys_n, d_hist + k * hist_n};
+        if (!clean) {
+            HIP_TRY(hipMemsetAsync(tr, 0, (size_t)S.g * n_rows * sizeof(u64), ctx->stream));  // general-purpose columns
+            hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - bnd + 255) / 256), S.mult_col - S.g), dim3(256), 0, ctx->stream, tr + (size_t)S.g * n_rows + bnd, n_rows, n_rows - bnd);
+            ZKW_TRY(launch_check("k_zero_strip"));
+            HIP_TRY(hipMemsetAsync(tr + (size_t)S.mult_col * n_rows, 0, n_rows * sizeof(u64), ctx->stream));
+        }
+    }
+    NlPrepJob* d_prep = nullptr;
+    NlJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("nl_prep", prep, &d_prep));
+    ZKW_TRY(ctx->upload("nl_jobs", jobs, &d_jobs));
+    const unsigned nj = (unsigned)ni;
+    if (sha_like) { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_sha, dim3(capacity + 1, nj), dim3(128), 0, ctx->stream, d_prep, capacity); }
+    else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
+    ZKW_TRY(launch_check("k_nl_prepare"));
+    switch (circuit_type) {
+        case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+    }
+    { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+    return launch_check("k_nl_finish");
+}
+
+int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u32 capacity, uint64_t* n_violations, uint64_t* first_bad) {
+    const NlCached* nc = nullptr;
+    ZKW_TRY(nl_get(ctx, circuit_type, &nc));
+    const nl_spec& S = nc->host.s;
+    if (t->n_cols < S.cols) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %u", t->n_cols, S.cols);
+    if (NL_USED_ROWS(&S, capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u64* trace = t->data + slot * t->slot_elems();
+    const size_t n_rows = t->n_rows;
+    CheckResult* d_res = nullptr;
+    u32* d_hist = nullptr;
+    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
+    ZKW_TRY(ctx->scratch_t<u32>("nl_check_hist", S.total_table_rows, &d_hist));
+    CheckResult init{0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, S.total_table_rows * sizeof(u32), ctx->stream));
+    { Prof _p(ctx, "k_nl_check_steps"); hipLaunchKernelGGL(k_nl_check_steps, dim3((nc->host.max_items + 255) / 256, capacity * S.steps_per_cycle), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_nl_check_steps"));
+    { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
+    ZKW_TRY(launch_check("k_nl_check_tail"));
+    CheckResult res;
+    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
+    *n_violations = res.violations;
+    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
+    return ZKW_OK;
+}
+
+// instance i of a precompile-style witness covers the rounds [i * capacity, min((i + 1) * capacity, total)) (none for the dummy instance)
+std::vector<NlInstance> nl_instances(size_t first_instance, size_t n_instances, u32 capacity, bool any, u64 total_rounds, const u64* cf_pi, size_t n_all,
+                                     zkw_trace* t, size_t first_slot) {
+    std::vector<NlInstance> v(n_instances);
+    for (size_t k = 0; k < n_instances; k++) {
+        const size_t i = first_instance + k;
+        v[k].first_round = (u64)i * capacity;
+        v[k].n_active = any ? (u32)std::min<u64>(capacity, total_rounds - v[k].first_round) : 0;
+        v[k].public_input = cf_pi + COMPACT_FORM_LEN * n_all + 4 * i;
+        v[k].t = t;
+        v[k].slot = (first_slot + k) % t->n_slots;
+    }
+    return v;
+}
+}  // namespace
+
+// ZkSyncBaseLayerCircuit::synthesis for Keccak256RoundFunction (type 5): 86 + 3 x 14 columns, Xor8 / And8 / ByteSplit<1..4>
+extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances,
+                                           zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_keccak_round_synthesize: bad argument");
+    if (w->kind != ZKW_PRECOMPILE_KECCAK256) return fail(ZKW_ERR_INVALID, "zkw_keccak_round_synthesize: not a keccak256 witness");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (t->n_cols < KC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the Keccak256RoundFunction circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, KC_COLS);
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));  // public inputs of the block's instances (a20), once
+    return nl_synthesize(ctx, 5, false, w->keccak_rounds, nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
+                         w->capacity, t->n_rows);
+}
+extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_keccak_round_check_satisfied: bad argument");
+    return nl_check(ctx, 5, t, slot, capacity, n_violations, first_bad);
+}
+
+// ZkSyncBaseLayerCircuit::synthesis for Sha256RoundFunction (type 6): 116 + 4 x 9 columns, TriXor4 / Ch4 / Maj4 / Split4BitChunk<1, 2>
+extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances,
+                                           zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_sha256_round_synthesize: bad argument");
+    if (w->kind != ZKW_PRECOMPILE_SHA256) return fail(ZKW_ERR_INVALID, "zkw_sha256_round_synthesize: not a sha256 witness");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (t->n_cols < SC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the Sha256RoundFunction circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, SC_COLS);
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
+    return nl_synthesize(ctx, 6, true, w->sha256_rounds, nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
+                         w->capacity, t->n_rows);
+}
+extern "C" int zkw_sha256_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_sha256_round_check_satisfied: bad argument");
+    return nl_check(ctx, 6, t, slot, capacity, n_violations, first_bad);
+}
+
+// ------------------------------------------------------------------------------------------------ CodeDecommitter synthesis
+// ZkSyncBaseLayerCircuit::synthesis for CodeDecommitter (type 3): the SHA-256 netlist on 108 + 4 x 11 columns, one cycle per round
+// of the unpacked bytecodes (a cycle is one round: BeginNew shares the cycle of a bytecode's first round)
+extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_witness* w, size_t first_instance, size_t n_instances,
+                                               zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_code_decommitter_synthesize: bad argument");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (t->n_cols < DC_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the CodeDecommitter circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, DC_COLS);
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!w->cf_pi) ZKW_TRY(closed_form_public_inputs<CfDecommitter>(ctx, w->instances, w->n_instances, &w->cf_pi));
+    return nl_synthesize(ctx, 3, true, w->sha256_rounds, nl_instances(first_instance, n_instances, w->capacity, true, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
+                         w->capacity, t->n_rows);
+}
+extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_code_decommitter_check_satisfied: bad argument");
+    return nl_check(ctx, 3, t, slot, capacity, n_violations, first_bad);
+}
+
+// LinearHasher (type 13): the Keccak-f netlist over the sponge of the serialized L2 -> L1 messages (compute_linear_keccak256,
+// data_hasher_and_merklizer.rs:8-67; wrapper base_layer/linear_hasher.rs:28-138). One instance per block.
+extern "C" int zkw_linear_hasher_synthesize_batch(zkw_ctx* ctx, const zkw_log_query* messages, const uint64_t* message_offsets, size_t n_queues,
+                                                  const zkw_queue_state4* queue_states, uint32_t capacity, zkw_trace* t, size_t first_slot,
+                                                  zkw_linear_hasher_instance* records_out, uint64_t* public_inputs_out) {
+    if (!ctx || !t || !message_offsets || !queue_states || !records_out || t->ctx->device != ctx->device || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: bad argument");
+    if (n_queues == 0) return ZKW_OK;
+    if (first_slot + n_queues > t->n_slots) return fail(ZKW_ERR_INVALID, "slots [%zu, %zu) of a trace with %zu", first_slot, first_slot + n_queues, t->n_slots);
+    if (t->n_cols < LH_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the LinearHasher circuit needs %d", t->n_cols, LH_COLS);
+    const size_t total = message_offsets[n_queues];
+    if (message_offsets[0] != 0 || (total && !messages)) return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: offsets must start at 0");
+    std::vector<u64> moff(message_offsets, message_offsets + n_queues + 1), roff(n_queues + 1, 0);
+    for (size_t b = 0; b < n_queues; b++) {
+        if (moff[b + 1] < moff[b]) return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: offsets decrease at %zu", b);
+        const size_t n = moff[b + 1] - moff[b];
+        if (n > capacity) return fail(ZKW_ERR_INVALID, "queue %zu: %zu messages, the circuit hashes at most %u", b, n, capacity);
+        roff[b + 1] = roff[b] + n * 88 / 136 + 1;
+    }
+    const u32 cycles = ZKW_LINEAR_HASHER_CYCLES(capacity);
+    const size_t n_rows = t->n_rows;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const zkw_log_query* d_q = nullptr;
+    ZKW_TRY(ctx->in("lh_q", messages, total, &d_q));
+    zkw_keccak_round_record* d_rounds = nullptr;
+    uint8_t* d_hash = nullptr;
+    u64 *d_moff = nullptr, *d_roff = nullptr;
+    ZKW_TRY(ctx->scratch_t<zkw_keccak_round_record>("lh_rounds", roff[n_queues], &d_rounds));
+    ZKW_TRY(ctx->scratch_t<uint8_t>("lh_hash", 32 * n_queues, &d_hash));
+    ZKW_TRY(ctx->upload("lh_moff", moff, &d_moff));
+    ZKW_TRY(ctx->upload("lh_roff", roff, &d_roff));
+    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3((unsigned)n_queues), dim3(64), 0, ctx->stream, d_q, (size_t)0, d_hash, d_rounds, d_moff, d_roff); }
+    ZKW_TRY(launch_check("k_linear_keccak256"));
+    std::vector<zkw_linear_hasher_instance> recv(n_queues);
+    std::vector<uint8_t> hashes(32 * n_queues);
+    ZKW_TRY(ctx->read_small(hashes.data(), d_hash, hashes.size()));
+    for (size_t b = 0; b < n_queues; b++) {
+        memset(&recv[b], 0, sizeof recv[b]);
+        recv[b].start_flag = recv[b].completion_flag = 1;
+        recv[b].queue_state = queue_states[b];
+        memcpy(recv[b].keccak256_hash, &hashes[32 * b], 32);
+    }
+    zkw_linear_hasher_instance* d_rec = nullptr;
+    ZKW_TRY(ctx->upload("lh_record", recv, &d_rec));
+    u64 *d_cf = nullptr, *d_pi = nullptr;
+    ZKW_TRY(ctx->scratch_t<u64>("lh_cf", COMPACT_FORM_LEN * n_queues, &d_cf));
+    ZKW_TRY(ctx->scratch_t<u64>("lh_pi", 4 * n_queues, &d_pi));
+    {
+        constexpr int lanes = CfLanes<CfLinearHasher>::value;
+        Prof _p(ctx, "k_closed_form_commitments");
+        hipLaunchKernelGGL((k_closed_form_commitments<CfLinearHasher>), dim3(blocks_for(4 * n_queues, lanes)), dim3(lanes), 0, ctx->stream, d_rec, n_queues, d_cf);
+    }
+    ZKW_TRY(launch_check("k_closed_form_commitments"));
+    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n_queues, 64)), dim3(64), 0, ctx->stream, d_cf, n_queues, (u32)COMPACT_FORM_LEN, d_pi); }
+    ZKW_TRY(launch_check("k_commit_encodings"));
+    std::vector<NlInstance> inst(n_queues);
+    for (size_t b = 0; b < n_queues; b++) inst[b] = NlInstance{roff[b], (u32)(roff[b + 1] - roff[b]), d_pi + 4 * b, t, first_slot + b, true};
+    ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows));
+    memcpy(records_out, recv.data(), n_queues * sizeof recv[0]);
+    if (public_inputs_out) ZKW_TRY(ctx->read_small(public_inputs_out, d_pi, 32 * n_queues));
+    return ZKW_OK;
+}
+
+extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* messages, size_t n, const zkw_queue_state4* queue_state,
+                                            uint32_t capacity, zkw_trace* t, size_t slot, zkw_linear_hasher_instance* record_out,
+                                            uint64_t* public_input_out) {
+    if (!queue_state || !record_out) return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize: bad argument");
+    const uint64_t offsets[2] = {0, n};
+    return zkw_linear_hasher_synthesize_batch(ctx, messages, offsets, 1, queue_state, capacity, t, slot, record_out, public_input_out);
+}
+
+extern "C" int zkw_linear_hasher_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_check_satisfied: bad argument");
+    return nl_check(ctx, 13, t, slot, ZKW_LINEAR_HASHER_CYCLES(capacity), n_violations, first_bad);
+}
+

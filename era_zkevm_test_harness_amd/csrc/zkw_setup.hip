@@ -1,0 +1,295 @@
+// zkw_setup.hip — what a setup needs to know about this library's trace layouts: geometry, layout description (finalization
+// hint fields), row selectors, the copy permutation (sigma) and its check on a trace.
+#include "zkw_ctx.h"
+#include "ram_circuit_kernels.cuh"
+#include "decommit_sorter_circuit_kernels.cuh"
+#include "events_sorter_circuit_kernels.cuh"
+#include "log_demux_circuit_kernels.cuh"
+#include "storage_sorter_circuit_kernels.cuh"
+#include "netlist_kernels.cuh"
+
+extern "C" int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometry* out) {
+    // {copy columns, lookup width, repetitions, max degree, capacity, big size hint}: vm_main.rs:29-44,
+    // sort_code_decommits.rs:28-39, code_decommitter.rs:28-39, log_demux.rs:36-47, keccak256_round_function.rs:28-39,
+    // sha256_round_function.rs:28-39, ecrecover.rs:30-41, ram_permutation.rs:26-41,117-122, storage_sort_dedup.rs:29-40,
+    // storage_apply.rs:28-39, events_sort_dedup.rs:28-39 (x2), linear_hasher.rs:28-39; geometry_config.rs:5-20
+    static const struct { u32 c, lw, lr, deg, cap; bool big; } T[14] = {
+        {0, 0, 0, 0, 0, false},
+        {130, 3, 8, 8, 5585, false},    // 1 MainVM
+        {130, 1, 18, 8, 117500, true},  // 2 CodeDecommittmentsSorter
+        {108, 4, 11, 8, 2845, false},   // 3 CodeDecommitter
+        {136, 1, 14, 8, 58750, true},   // 4 LogDemuxer
+        {86, 3, 14, 8, 293, false},     // 5 KeccakRoundFunction
+        {116, 4, 9, 8, 2206, false},    // 6 Sha256RoundFunction
+        {80, 3, 16, 8, 7, false},       // 7 ECRecover
+        {133, 1, 15, 8, 136714, true},  // 8 RAMPermutation
+        {132, 1, 16, 8, 46921, true},   // 9 StorageSorter
+        {60, 3, 26, 8, 33, false},      // 10 StorageApplication
+        {130, 1, 8, 18, 31287, true},   // 11 EventsSorter
+        {130, 1, 8, 18, 31287, true},   // 12 L1MessagesSorter
+        {66, 3, 26, 8, 774, false},     // 13 L1MessagesHasher
+    };
+    if (!out || circuit_type < 1 || circuit_type > 13) return fail(ZKW_ERR_INVALID, "unknown base-layer circuit type %u", circuit_type);
+    const auto& g = T[circuit_type];
+    out->num_columns_under_copy_permutation = g.c;
+    out->num_witness_columns = 0;
+    out->num_constant_columns = 4;
+    out->max_allowed_constraint_degree = g.deg;
+    out->lookup_width = g.lw;
+    out->lookup_repetitions = g.lr;
+    out->capacity = g.cap;
+    out->trace_len_log2 = 20;
+    out->size_hint_variables = g.big ? (1ull << 26) + (1ull << 25) : (1ull << 26);
+    return ZKW_OK;
+}
+
+// Where this library's own trace layout ("zkw trace v2") of a circuit type puts things: what the reference keeps in
+// FinalizationHintsForProver / VerificationKey.fixed_parameters for ITS layout (setup/base_layer/finalization_hint_N.json:
+// `public_inputs` = (column, row) of the four PI cells, `nop_gates_to_add`, `final_trace_len`). No GPU needed.
+extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_layout* out) {
+    if (!out) return fail(ZKW_ERR_INVALID, "zkw_circuit_layout_of: null argument");
+    zkw_circuit_geometry g;
+    ZKW_TRY(zkw_circuit_geometry_of(circuit_type, &g));
+    memset(out, 0, sizeof *out);
+    if (capacity == 0) capacity = g.capacity;
+    out->capacity = capacity;
+    out->trace_len = 1ull << g.trace_len_log2;
+    uint64_t boundary = 0, min_rows = 0, pi_off = 0;
+    switch (circuit_type) {
+        case 8: out->num_columns = RC_COLS; out->rows_per_cycle = RC_ROWS_PER_CYCLE; out->region_stride = RC_REGION_STRIDE(capacity); boundary = RC_BOUNDARY_ROW(capacity); min_rows = RC_MIN_ROWS(capacity); pi_off = RC_ROWOFF_PI; break;
+        case 2: out->num_columns = DS_COLS; out->rows_per_cycle = DS_ROWS_PER_CYCLE; out->region_stride = DS_REGION_STRIDE(capacity); boundary = DS_BOUNDARY_ROW(capacity); min_rows = DS_MIN_ROWS(capacity); pi_off = DS_ROWOFF_PI; break;
+        case 4: out->num_columns = LD_COLS; out->rows_per_cycle = LD_ROWS_PER_CYCLE; out->region_stride = LD_REGION_STRIDE(capacity); boundary = LD_BOUNDARY_ROW(capacity); min_rows = LD_MIN_ROWS(capacity); pi_off = LD_ROWOFF_PI; break;
+        case 9: out->num_columns = SS_COLS; out->rows_per_cycle = SS_ROWS_PER_CYCLE; out->region_stride = SS_REGION_STRIDE(capacity); boundary = SS_BOUNDARY_ROW(capacity); min_rows = SS_MIN_ROWS(capacity); pi_off = SS_ROWOFF_PI; break;
+        case 11: case 12: out->num_columns = ES_COLS; out->rows_per_cycle = ES_ROWS_PER_CYCLE; out->region_stride = ES_REGION_STRIDE(capacity); boundary = ES_BOUNDARY_ROW(capacity); min_rows = ES_MIN_ROWS(capacity); pi_off = ES_ROWOFF_PI; break;
+        // the netlist circuits ("zkw trace v4") are cycle-major: region_stride = 0, cycle i starts at row i * rows_per_cycle
+        case 3: case 5: case 6: case 13: {
+            const nl_spec* sp = nl_host_spec(circuit_type);
+            const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(capacity) : capacity;
+            out->num_columns = sp->cols; out->rows_per_cycle = sp->rows_per_cycle; boundary = NL_BOUNDARY_ROW(sp, cycles);
+            min_rows = NL_USED_ROWS(sp, cycles); pi_off = 2 * NL_BND_ROWS(sp);
+            out->total_table_rows = sp->total_table_rows;
+            break;
+        }
+        default: return ZKW_OK;  // a known circuit type this library does not synthesize yet: synthesizable = 0
+    }
+    out->synthesizable = 1;
+    if (out->region_stride) out->total_table_rows = 256;  // the queue circuits' one table: RangeCheckTable<8>
+    out->rows_used = min_rows;
+    out->fits = min_rows <= out->trace_len;
+    out->nop_rows = out->fits ? out->trace_len - min_rows : 0;
+    for (int k = 0; k < 4; k++) {
+        out->public_input_column[k] = (uint32_t)k;
+        out->public_input_row[k] = boundary + pi_off;
+    }
+    return ZKW_OK;
+}
+
+// Setup side, selectors: which gate set applies to each row of a trace of this library's layout — what the
+// reference's setup keeps in its constant columns (gate selectors, the lookup table id of a row). Host arithmetic over the specs.
+//   queue circuits (2, 4, 8, 9, 11, 12; "zkw trace v2", region-major): selector = row type of the spec (0 .. NUM_ROW_TYPES - 1:
+//     the per-cycle row types, then the boundary rows), ZKW_ROW_PADDING elsewhere (gaps of a region, rows after the boundary)
+//   netlist circuits (3, 5, 6, 13; "zkw trace v3", cycle-major): selector = lookup table id of the row (0: none) |
+//     ZKW_ROW_HAS_GATES when ADD gates sit in its general-purpose columns | ZKW_ROW_HEADER for a cycle's first row;
+//     boundary rows ZKW_ROW_BOUNDARY + k; ZKW_ROW_PADDING elsewhere
+extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint8_t* out) {
+    if (!out || n_rows == 0) return fail(ZKW_ERR_INVALID, "zkw_setup_row_selectors: null argument");
+    zkw_circuit_layout lay;
+    ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
+    if (!lay.synthesizable) return fail(ZKW_ERR_INVALID, "circuit type %u has no layout in this library", (unsigned)circuit_type);
+    if (lay.rows_used > n_rows) return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, %zu given", lay.capacity, (unsigned long long)lay.rows_used, n_rows);
+    memset(out, ZKW_ROW_PADDING, n_rows);
+    const uint32_t cap = lay.capacity;
+    if (lay.region_stride) {  // region-major
+        const uint64_t stride = lay.region_stride, rpc = lay.rows_per_cycle;
+        for (uint64_t r = 0; r < rpc; r++) memset(out + r * stride, (int)r, cap);
+        const uint64_t bnd = rpc * stride;
+        for (uint64_t k = 0; bnd + k < lay.rows_used; k++) out[bnd + k] = (uint8_t)(rpc + k);
+        return ZKW_OK;
+    }
+    const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
+    const uint64_t rpc = lay.rows_per_cycle;
+    const nl_spec* sp = nl_host_spec(circuit_type);
+    std::vector<uint8_t> one(rpc);  // every cycle has the same selectors
+    for (uint32_t st = 0; st < sp->steps_per_cycle; st++) {
+        const nl_step_type& T = sp->step_types[sp->cycle[st].type];
+        uint8_t* row = one.data() + sp->cycle[st].row0;
+        row[0] = ZKW_ROW_HEADER;
+        for (uint32_t r = 1; r < T.rows; r++)
+            row[r] = (uint8_t)((r <= T.lookup_rows ? sp->ops[T.op0 + (r - 1) * sp->r].table : 0) | (sp->gate_row_end[T.rowend0 + r] ? ZKW_ROW_HAS_GATES : 0));
+    }
+    for (uint32_t c = 0; c < cycles; c++) memcpy(out + (uint64_t)c * rpc, one.data(), rpc);
+    for (uint64_t k = 0; (uint64_t)cycles * rpc + k < lay.rows_used; k++) out[(uint64_t)cycles * rpc + k] = (uint8_t)(ZKW_ROW_BOUNDARY + k);
+    return ZKW_OK;
+}
+
+// Setup side, copy permutation of the queue circuits: sigma[c][r] = the cell (c' * n_rows + r') that follows
+// cell (c, r) in its copy cycle; a cell under no copy constraint maps to itself. Built on the host from the spec's link table
+// (the same table the satisfiability checker walks, ram_circuit_kernels.cuh k_check_links) with a union-find over the
+// general-purpose cells; cycles run through their cells in increasing cell order. Seconds at production size (1.1 GB of output).
+namespace {
+struct LinkSpec { int G /* general-purpose + lookup columns: links reach both */, rows_per_cycle, num_links, off_bin, off_bout; const rc_link* links; };
+static const rc_link h_rc_links[RC_NUM_LINKS] = RC_LINKS_INIT;
+static const rc_link h_ds_links[DS_NUM_LINKS] = DS_LINKS_INIT;
+static const rc_link h_es_links[ES_NUM_LINKS] = ES_LINKS_INIT;
+static const rc_link h_ld_links[LD_NUM_LINKS] = LD_LINKS_INIT;
+static const rc_link h_ss_links[SS_NUM_LINKS] = SS_LINKS_INIT;
+bool link_spec_of(uint8_t t, LinkSpec* o) {
+    switch (t) {
+        case 8: *o = {RC_G + RC_L, RC_ROWS_PER_CYCLE, RC_NUM_LINKS, RC_ROWOFF_BND_IN, RC_ROWOFF_BND_OUT, h_rc_links}; return true;
+        case 2: *o = {DS_G + DS_L, DS_ROWS_PER_CYCLE, DS_NUM_LINKS, DS_ROWOFF_BND_IN, DS_ROWOFF_BND_OUT, h_ds_links}; return true;
+        case 11: case 12: *o = {ES_G + ES_L, ES_ROWS_PER_CYCLE, ES_NUM_LINKS, ES_ROWOFF_BND_IN, ES_ROWOFF_BND_OUT, h_es_links}; return true;
+        case 4: *o = {LD_G + LD_L, LD_ROWS_PER_CYCLE, LD_NUM_LINKS, LD_ROWOFF_BND_IN, LD_ROWOFF_BND_OUT, h_ld_links}; return true;
+        case 9: *o = {SS_G + SS_L, SS_ROWS_PER_CYCLE, SS_NUM_LINKS, SS_ROWOFF_BND_IN, SS_ROWOFF_BND_OUT, h_ss_links}; return true;
+        default: return false;
+    }
+}
+}  // namespace
+
+extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t* sigma, uint32_t* n_columns) {
+    LinkSpec sp;
+    const bool netlist = circuit_type == 3 || circuit_type == 5 || circuit_type == 6 || circuit_type == 13;
+    if (netlist) sp = {(int)nl_host_spec(circuit_type)->mult_col, 0, 0, 0, 0, nullptr};  // all but the multiplicity column
+    else if (!link_spec_of(circuit_type, &sp))
+        return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: circuit type %u has no layout in this library", (unsigned)circuit_type);
+    zkw_circuit_layout lay;
+    ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
+    if (n_columns) *n_columns = (uint32_t)sp.G;
+    if (!sigma) return ZKW_OK;  // size query
+    if (lay.rows_used > n_rows || n_rows >= (1ull << 32) / (size_t)sp.G)
+        return fail(ZKW_ERR_INVALID, "capacity %u needs %llu rows, %zu given", lay.capacity, (unsigned long long)lay.rows_used, n_rows);
+    const uint32_t cap = lay.capacity;
+    const uint64_t rs = lay.region_stride, bnd = (uint64_t)sp.rows_per_cycle * rs;
+    const size_t n_cells = (size_t)sp.G * n_rows;
+    std::vector<uint32_t> parent(n_cells);
+    for (size_t i = 0; i < n_cells; i++) parent[i] = (uint32_t)i;
+    auto find = [&](uint32_t x) {
+        while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+        return x;
+    };
+    bool out_of_range = false;
+    auto unite = [&](uint64_t col_a, uint64_t row_a, uint64_t col_b, uint64_t row_b) {
+        if (col_a >= (uint64_t)sp.G || col_b >= (uint64_t)sp.G || row_a >= n_rows || row_b >= n_rows) { out_of_range = true; return; }
+        uint32_t a = find((uint32_t)(col_a * n_rows + row_a)), b = find((uint32_t)(col_b * n_rows + row_b));
+        if (a != b) parent[a > b ? a : b] = a > b ? b : a;  // the smallest cell of a class is its root
+    };
+    auto brow = [&](int rt) { return bnd + (uint64_t)(rt - sp.rows_per_cycle); };  // a boundary row type
+    if (netlist) {
+        // the netlist circuits: every operand cell of a lookup / gate is a copy of the cell that produced it (the references of
+        // the spec, resolved exactly as the checkers do: k_kc_check_rows, k_sc_check_cycle); constants and free witness bytes
+        // are under no copy constraint
+        const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
+        const nl_spec* ns = nl_host_spec(circuit_type);
+        const uint64_t nb = NL_BOUNDARY_ROW(ns, cycles), brows = NL_BND_ROWS(ns);
+        // the cell a reference names, seen from step st of cycle c (nl_home of netlist_kernels.cuh as coordinates); false: a constant
+        auto home = [&](uint32_t c, uint32_t st, uint32_t ref, uint64_t* hc, uint64_t* hr) {
+            for (;;) {
+                const nl_cycle_step& cs = ns->cycle[st];
+                const nl_step_type& T = ns->step_types[cs.type];
+                const uint64_t base = (uint64_t)c * ns->rows_per_cycle + cs.row0;
+                if (ref < NL_REF_HDR) {
+                    const nl_home h = ns->homes[T.home0 + ref];
+                    if (h.kind == 1) { const nl_gate& g = ns->gates[T.gate0 + h.item]; *hc = g.col + h.cell; *hr = base + g.row; }
+                    else { *hc = ns->g + ns->w * (h.item % ns->r) + h.cell; *hr = base + 1 + h.item / ns->r; }
+                    return true;
+                }
+                if (ref < NL_REF_PREV) { *hc = ref - NL_REF_HDR; *hr = base; return true; }
+                if (ref >= NL_REF_FREE && ref < NL_REF_RC) return false;
+                if (ref >= NL_REF_RC) return false;
+                uint32_t k;
+                if (ref >= NL_REF_CYC || st == 0) {
+                    k = ref >= NL_REF_CYC ? ref - NL_REF_CYC : ref - NL_REF_PREV;
+                    if (c == 0) { *hc = k % ns->g; *hr = nb + k / ns->g; return true; }
+                    c--;
+                    st = ns->steps_per_cycle - 1;
+                } else {
+                    k = ref - NL_REF_PREV;
+                    st--;
+                }
+                ref = ns->out[(size_t)ns->cycle[st].type * ns->state + k];
+            }
+        };
+        uint64_t hc, hr;
+        for (uint32_t c = 0; c < cycles; c++)
+            for (uint32_t st = 0; st < ns->steps_per_cycle; st++) {
+                const nl_cycle_step& cs = ns->cycle[st];
+                const nl_step_type& T = ns->step_types[cs.type];
+                const uint64_t base = (uint64_t)c * ns->rows_per_cycle + cs.row0;
+                if (st)  // a step's header is a copy of the cycle's
+                    for (int f = 0; f < NL_HDR_FIELDS; f++) unite((uint64_t)f, base, (uint64_t)f, (uint64_t)c * ns->rows_per_cycle);
+                for (uint32_t j = 0; j < T.n_ops; j++) {
+                    const nl_op& op = ns->ops[T.op0 + j];
+                    const nl_table& tb = ns->tables[op.table - 1];
+                    for (uint32_t i = 0; i < tb.n_in; i++) {
+                        if (op.in[i] < NL_REF_HDR) {
+                            const nl_home h = ns->homes[T.home0 + op.in[i]];
+                            if (h.kind == 2 && h.item == j && h.cell == i) continue;  // a hint's own cell
+                        }
+                        if (home(c, st, op.in[i], &hc, &hr)) unite((uint64_t)(ns->g + ns->w * (j % ns->r) + i), base + 1 + j / ns->r, hc, hr);
+                    }
+                }
+                for (uint32_t gi = 0; gi < T.n_gates; gi++) {
+                    const nl_gate& g = ns->gates[T.gate0 + gi];
+                    for (uint32_t i = 0; i < g.n_known; i++)
+                        if (home(c, st, ns->terms[T.term0 + g.first_term + i].ref, &hc, &hr)) unite((uint64_t)(g.col + i), base + g.row, hc, hr);
+                }
+            }
+        if (cycles)
+            for (uint32_t k = 0; k < ns->state; k++)
+                if (home(cycles, 0, NL_REF_CYC + k, &hc, &hr)) unite((uint64_t)(k % ns->g), nb + brows + k / ns->g, hc, hr);
+    }
+    for (int l = 0; l < sp.num_links; l++) {
+        const rc_link k = sp.links[l];
+        if (k.kind == 3) { unite(k.col_a, bnd + sp.off_bout, k.col_b, (uint64_t)k.row_b * rs + cap - 1); continue; }
+        if (k.kind == 4) { unite(k.col_a, brow(k.row_a), k.col_b, bnd + sp.off_bout); continue; }
+        if (k.kind == 5) { unite(k.col_a, brow(k.row_a), k.col_b, brow(k.row_b)); continue; }
+        for (uint32_t i = 0; i < cap; i++) {
+            const uint64_t ra = (uint64_t)k.row_a * rs + i;
+            if (k.kind == 0) unite(k.col_a, ra, k.col_b, (uint64_t)k.row_b * rs + i);
+            else if (k.kind == 1) { if (i) unite(k.col_a, ra, k.col_b, (uint64_t)k.row_b * rs + i - 1); else unite(k.col_a, ra, k.bin_col, bnd + sp.off_bin); }
+            else unite(k.col_a, ra, k.col_b, bnd + sp.off_bin);
+        }
+    }
+    if (out_of_range) return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: a link of the spec leaves the copy-permutation columns");
+    // cycles: the cells of a class in increasing order, the last one back to the root
+    std::vector<uint32_t> last(n_cells);
+    for (size_t i = 0; i < n_cells; i++) { sigma[i] = i; last[i] = (uint32_t)i; }
+    for (size_t i = 0; i < n_cells; i++) {
+        const uint32_t r = find((uint32_t)i);
+        if (r == i) continue;
+        sigma[last[r]] = i;  // i > last[r]: cells are visited in increasing order
+        last[r] = (uint32_t)i;
+        sigma[i] = r;
+    }
+    return ZKW_OK;
+}
+
+// copy-permutation check through sigma columns (zkw_setup_copy_permutation): trace[cell] == trace[sigma[cell]] for every cell
+__global__ __launch_bounds__(256) void k_check_sigma(const u64* __restrict__ trace, const u64* __restrict__ sigma, size_t n_cells, CheckResult* res,
+                                                     size_t n_rows) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += stride) {
+        const u64 j = sigma[i];
+        if (j >= n_cells || trace[i] != trace[j]) flag_bad(res, 4, i / n_rows, i % n_rows);
+    }
+}
+extern "C" int zkw_check_copy_permutation(zkw_ctx* ctx, const zkw_trace* t, size_t slot, const uint64_t* sigma, uint32_t n_columns,
+                                          uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || !sigma || !n_violations || t->ctx->device != ctx->device || slot >= t->n_slots || n_columns == 0 || n_columns > t->n_cols)
+        return fail(ZKW_ERR_INVALID, "zkw_check_copy_permutation: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n_cells = (size_t)n_columns * t->n_rows;
+    const u64* d_sigma = nullptr;
+    ZKW_TRY(ctx->in("sigma", sigma, n_cells, &d_sigma));
+    CheckResult* d_res = nullptr;
+    ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
+    CheckResult init{0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    { Prof _p(ctx, "k_check_sigma"); hipLaunchKernelGGL(k_check_sigma, dim3(2048), dim3(256), 0, ctx->stream, t->data + slot * t->slot_elems(), d_sigma, n_cells, d_res, t->n_rows); }
+    ZKW_TRY(launch_check("k_check_sigma"));
+    CheckResult res;
+    ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
+    *n_violations = res.violations;
+    if (first_bad) *first_bad = res.violations ? res.first_bad : 0;
+    return ZKW_OK;
+}
+

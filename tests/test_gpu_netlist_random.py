@@ -21,7 +21,7 @@ def ctx():
 
 def _dirty(ctx, t, n_cols):
     """garbage in the whole slot: the synthesis must leave no cell of a previous tenant behind (it zeroes only what its fill
-    does not write: zero_netlist_slot, zkw_api.hip)"""
+    does not write: nl_synthesize, zkw_precompiles.hip)"""
     import ctypes
 
     hip = ctypes.CDLL("libamdhip64.so")

@@ -14,7 +14,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src", ["zkw_api.hip", "zkw_block.hip"])
+@pytest.mark.parametrize("src", ["zkw_api.hip", "zkw_sorters.hip", "zkw_precompiles.hip", "zkw_setup.hip", "zkw_block.hip"])
 def test_no_kernel_uses_scratch(src, tmp_path):
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o",
                         str(tmp_path / "x.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
@@ -22,7 +22,7 @@ def test_no_kernel_uses_scratch(src, tmp_path):
     names = re.findall(r"Function Name: (\S+)", r.stderr)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
     assert len(names) == len(scratch)
-    if src == "zkw_api.hip":
-        assert len(names) > 100
+    if src in ("zkw_api.hip", "zkw_sorters.hip", "zkw_precompiles.hip"):
+        assert len(names) > 25, names  # (the report is really the kernels': each of these units launches dozens)
     bad = {n: s for n, s in zip(names, scratch) if s}
     assert not bad, f"kernels with scratch memory: {bad}"
