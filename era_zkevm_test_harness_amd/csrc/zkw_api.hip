@@ -407,9 +407,12 @@ struct ChainService {
             cv_work.notify_one();
             const int kind = full ? 0 : 1;
             cv_done.wait(lk, [&] { return b->done[kind]; });
+            // read under the lock: a log-queue waiter is released before the batch's full-width chains have finished, and the
+            // worker may still record their failure
+            const int rc = b->rc;
+            if (rc != ZKW_OK && err) *err = b->err;
+            return rc;
         }
-        if (b->rc != ZKW_OK && err) *err = b->err;
-        return b->rc;
     }
     void run() {
         (void)hipSetDevice(device);

@@ -1536,7 +1536,7 @@ class Block:
         return res
 
     @staticmethod
-    def gather_sharded(blocks, comm, rank, world, root=0, max_per_block=32):
+    def gather_sharded(blocks, comm, rank, world, root=0, max_per_block=64):
         """zkw_blocks_gather_closed_form_inputs (collective): on the root a list, per block, of its records [n, 24] (type,
         instance, compact form, public input) in emission order; None on the other ranks."""
         n = len(blocks)
