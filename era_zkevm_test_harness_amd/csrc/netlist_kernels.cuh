@@ -21,7 +21,7 @@
 
 namespace zkw {
 
-__device__ __forceinline__ void store_streaming(u64* cell, u64 v) { __builtin_nontemporal_store(v, cell); }
+__device__ __forceinline__ void store_streaming(u64* cell, u64 v) { *cell = v; }
 
 // host copies of the four specs (launch sizing, setup side) ...
 NL_DEFINE_SPEC(h_sc, SC);
@@ -480,13 +480,14 @@ static __global__ __launch_bounds__(256) void k_nl_finish(const NlDev* __restric
 #undef NL_TR
 
 // ---- round records -> the engine's inputs. SHA-like: 64-byte blocks, state 8 words as 64 nibbles; Keccak-like: 136 / 200 bytes
-struct NlPrepJob { const void* rounds; u64 first_round; u32 n_active; uint8_t* hdr_bits; uint8_t* free_elems; uint8_t* state_before; };
+struct NlPrepJob { const void* rounds; u64 first_round; u32 n_active; uint8_t* hdr_bits; uint8_t* free_elems; uint8_t* state_before; u32 state; /* elements of a cycle state (SHA-256: 64 nibbles of the chaining value, then zeros) */ };
 static __global__ __launch_bounds__(128) void k_nl_prepare_sha(const NlPrepJob* __restrict__ jobs, u32 capacity) {
     const NlPrepJob j = jobs[blockIdx.y];
     const zkw_sha256_round_record* rounds = static_cast<const zkw_sha256_round_record*>(j.rounds);
     const u32 c = blockIdx.x, t = threadIdx.x;  // c in [0, capacity]: the state BEFORE cycle c
     const u64 idx = j.first_round + (c < j.n_active ? c : j.n_active);  // records before the cycle
-    if (t < 64) j.state_before[(size_t)c * 64 + t] = idx ? (uint8_t)((rounds[idx - 1].state_after[t >> 3] >> (4 * (t & 7))) & 15) : 0;
+    for (u32 k = t; k < j.state; k += 128)
+        j.state_before[(size_t)c * j.state + k] = (idx && k < 64) ? (uint8_t)((rounds[idx - 1].state_after[k >> 3] >> (4 * (k & 7))) & 15) : 0;
     if (c == capacity) return;
     const bool active = c < j.n_active;
     const uint8_t b = active ? rounds[j.first_round + c].block[t >> 1] : 0;

@@ -709,10 +709,11 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
     ZKW_TRY(nl_to_device(pk0.data(), pk0.size(), &d.pk0));
     d.max_items = max_items;
     d.vsize = V.size;
-    // 16 waves per workgroup where two such workgroups still fit a CU (the Keccak family: 32 cycles in flight per CU), else 8
+    // 16 waves per workgroup (= cycles in flight) wherever the LDS holds them: the Keccak family fits two such workgroups per CU,
+    // the SHA-256 family (a compression in three steps, so that a cycle's values are a third) one
     d.lds_bytes = NlLds(*hs, V.size, d.n_pk_terms, 8).total;
     d.lds_bytes16 = NlLds(*hs, V.size, d.n_pk_terms, 16).total;
-    d.fill_waves = d.lds_bytes16 <= 80 * 1024 ? 16 : 8;
+    d.fill_waves = d.lds_bytes16 <= 160 * 1024 ? 16 : 8;
     if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d: %u terms packed into %u, LDS %u bytes for %u waves\n", circuit_type, hs->n_terms, d.n_pk_terms, d.fill_waves == 16 ? d.lds_bytes16 : d.lds_bytes, d.fill_waves);
     const NlDev* dd = nullptr;
     ZKW_TRY(nl_to_device(&d, 1, &dd));
@@ -753,7 +754,7 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
     const NlCached* nc = nullptr;
     ZKW_TRY(nl_get(ctx, circuit_type, &nc));
     const nl_spec& S = nc->host.s;
-    if (nc->host.lds_bytes > 160 * 1024) return fail(ZKW_ERR_INVALID, "netlist of circuit %d needs %u bytes of LDS", circuit_type, nc->host.lds_bytes);
+    if ((nc->host.fill_waves == 16 ? nc->host.lds_bytes16 : nc->host.lds_bytes) > 160 * 1024) return fail(ZKW_ERR_INVALID, "netlist of circuit %d needs %u bytes of LDS", circuit_type, nc->host.lds_bytes);
     const size_t used = NL_USED_ROWS(&S, capacity);
     if (used > n_rows || S.total_table_rows > n_rows)
         return fail(ZKW_ERR_INVALID, "capacity %u needs %zu rows (tables: %u), trace has %zu", capacity, used, S.total_table_rows, n_rows);
@@ -774,8 +775,8 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
     const size_t bnd = NL_BOUNDARY_ROW(&S, capacity);
     for (size_t k = 0; k < ni; k++) {
         const size_t rec_bytes = sha_like ? sizeof(zkw_sha256_round_record) : sizeof(zkw_keccak_round_record);
-        prep[k] = inst[k].fresh ? NlPrepJob{static_cast<const char*>(d_rounds) + inst[k].first_round * rec_bytes, 0, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n}
-                                : NlPrepJob{d_rounds, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n};
+        prep[k] = inst[k].fresh ? NlPrepJob{static_cast<const char*>(d_rounds) + inst[k].first_round * rec_bytes, 0, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n, S.state}
+                                : NlPrepJob{d_rounds, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n, S.state};
         // The fill writes the lookup cells of every row above the boundary and the general-purpose cells of the header / gate rows;
         // everything else is zero. A slot whose previous tenant was the same layout (circuit, capacity, rows) already has those
         // zeros: nothing to clear (the multiplicity column is rewritten over the tables' rows). Otherwise: clear it.

@@ -307,10 +307,11 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
 static int sha_like(const nl_spec *sp, const uint8_t state_in[32], const zkw_sha256_round_record *rounds, uint32_t n_active, uint32_t capacity,
                     const uint64_t pi[4], size_t n_rows, uint64_t *trace) {
     if (n_active > capacity) return -1;
-    uint8_t *hdr = calloc(capacity ? capacity : 1, 1), *fr = calloc((size_t)capacity * 128 + 1, 1), *st = calloc((size_t)(capacity + 1) * 64, 1);
+    const size_t ST = sp->state; /* the chaining value's 64 nibbles, then zeros (the steps of a compression pass more between them) */
+    uint8_t *hdr = calloc(capacity ? capacity : 1, 1), *fr = calloc((size_t)capacity * 128 + 1, 1), *st = calloc((size_t)(capacity + 1) * ST, 1);
     for (int k = 0; k < 64; k++) st[k] = (state_in[k / 2] >> (4 * (k & 1))) & 15; /* nibble i of word j = byte 4j + i/2 of the LE bytes */
     for (uint32_t c = 0; c < capacity; c++) {
-        uint8_t *nx = st + (size_t)(c + 1) * 64;
+        uint8_t *nx = st + (size_t)(c + 1) * ST;
         if (c < n_active) {
             hdr[c] = rounds[c].reset ? 1 : 0;
             for (int b = 0; b < 64; b++) {
@@ -320,7 +321,7 @@ static int sha_like(const nl_spec *sp, const uint8_t state_in[32], const zkw_sha
             for (int k = 0; k < 64; k++) nx[k] = (rounds[c].state_after[k / 8] >> (4 * (k % 8))) & 15;
         } else {
             hdr[c] = 2;
-            memcpy(nx, nx - 64, 64);
+            memcpy(nx, nx - ST, ST);
         }
     }
     const int rc = orc_nl_synthesize(sp, capacity, hdr, fr, st, pi, n_rows, trace);
@@ -370,6 +371,7 @@ int orc_linear_hasher_round_synthesize(const uint8_t state_in[200], const zkw_ke
 uint64_t orc_linear_hasher_round_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) { return orc_nl_check(&lh_spec, trace, capacity, n_rows, first_bad); }
 
 /* geometry of the four layouts, for the tests: {cols, general, lookup width, lookups per row, total table rows, rows per cycle} */
+uint32_t orc_nl_state(int circuit_type) { const nl_spec *sp = orc_nl_spec(circuit_type); return sp ? sp->state : 0; }
 void orc_nl_geometry(int circuit_type, uint32_t out[6]) {
     const nl_spec *sp = orc_nl_spec(circuit_type);
     memset(out, 0, 6 * sizeof(uint32_t));

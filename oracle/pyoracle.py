@@ -661,8 +661,11 @@ def nl_geometry(circuit_type):
 
 
 def nl_spec_state(circuit_type):
-    """elements of the chaining / sponge state of a netlist circuit (64 nibbles, 200 bytes)"""
-    return 64 if circuit_type in (3, 6) else 200
+    """elements of a netlist circuit's cycle state (what the boundary rows hold): 256 for the SHA-256 circuits (the chaining value's 64
+    nibbles, then zeros: the steps of a compression pass more between them), 200 bytes for the Keccak circuits"""
+    f = lib().orc_nl_state
+    f.restype = C.c_uint32
+    return int(f(C.c_int(circuit_type)))
 
 
 def nl_slots_per_cycle(circuit_type):

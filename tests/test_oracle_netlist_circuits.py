@@ -89,7 +89,9 @@ def test_sha256_netlist_ends_in_hashlib_digests(oracle):
     assert oracle.sha256_round_check(t, cap) == (0, (0, 0, 0))
     g = oracle.nl_geometry(6)
     bnd = cap * g["rows_per_cycle"]
-    out = t[:64, bnd + 1].astype(np.uint64)  # BND_OUT: 64 nibbles, word j = nibbles 8j.. least significant first
+    brows = -(-oracle.nl_spec_state(6) // g["general"])  # rows of BND_IN (the cycle state: 64 nibbles of the chaining value, then zeros)
+    out = t[:64, bnd + brows].astype(np.uint64)  # BND_OUT: 64 nibbles, word j = nibbles 8j.. least significant first
+    assert not t[64:g["general"], bnd + brows].any() and not t[:g["general"], bnd + brows + 1:bnd + 2 * brows].any()
     words = [sum(int(out[8 * j + i]) << (4 * i) for i in range(8)) for j in range(8)]
     assert b"".join(struct.pack(">I", w) for w in words) == hashlib.sha256(msgs[-1]).digest()
     bad = recs.copy()

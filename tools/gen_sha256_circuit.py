@@ -92,26 +92,42 @@ class Sha(nl.StepType):
         return cells[:8]
 
 
-def build():
+# A compression is cut into steps of consecutive rounds: a step's values are what a wave of the fill keeps in LDS, so three steps
+# put twice as many cycles in flight per CU as one. State between the steps (256 elements, also the engine's
+# cycle state — elements 64.. are zero between cycles): a..h (64 nibbles), the 16 most recent message-schedule words (128), the
+# chaining value H the compression started from (64, for the final addition).
+SEGMENTS = [(0, 24), (24, 44), (44, 64)]
+STATE = 256
+
+
+def build_step(r0, r1):
     s = Sha()
-    # chaining state: in = reset ? IV : prev (Ch4(mask, x, y) = mask ? x : y bitwise)
-    H = [[s.lookup("CH4", nl.hdr(HDR_M0), nl.const((IV[j] >> (4 * i)) & 15), nl.prev(8 * j + i)) for i in range(8)] for j in range(8)]
-    # message words from the FREE nibbles: a load gate gives every nibble a home cell
-    W = []
-    for i in range(16):
-        src = []  # nibble t of word i: byte 4i + 3 - t // 2, low nibble for even t
-        for t in range(8):
-            byte = 4 * i + 3 - t // 2
-            src.append(nl.free(2 * byte + (t & 1)))
-        W.append(s.gate([(src[t], 4 * t, +1) for t in range(8)], [4 * t for t in range(8)]))
-        s.to_range_check += W[-1]
-    for i in range(16, 64):
+    s.name = f"rounds{r0}_{r1}"
+    first, last = r0 == 0, r1 == 64
+    W = {}
+    if first:
+        # chaining state: in = reset ? IV : prev (Ch4(mask, x, y) = mask ? x : y bitwise)
+        H = [[s.lookup("CH4", nl.hdr(HDR_M0), nl.const((IV[j] >> (4 * i)) & 15), nl.prev(8 * j + i)) for i in range(8)] for j in range(8)]
+        v = list(H)
+        for i in range(16):  # message words from the FREE nibbles: a load gate gives every nibble a home cell
+            src = []  # nibble t of word i: byte 4i + 3 - t // 2, low nibble for even t
+            for t in range(8):
+                byte = 4 * i + 3 - t // 2
+                src.append(nl.free(2 * byte + (t & 1)))
+            W[i] = s.gate([(src[t], 4 * t, +1) for t in range(8)], [4 * t for t in range(8)])
+            s.to_range_check += W[i]
+    else:
+        v = [[nl.prev(8 * j + i) for i in range(8)] for j in range(8)]
+        for t in range(16):
+            W[r0 - 16 + t] = [nl.prev(64 + 8 * t + i) for i in range(8)]
+        H = [[nl.prev(192 + 8 * j + i) for i in range(8)] for j in range(8)]
+    for i in range(max(16, r0), r1):
         x, y = W[i - 15], W[i - 2]
         s0 = s.xor3(s.rot(x, 7), s.rot(x, 18), s.rot(x, 3, shift=True))
         s1 = s.xor3(s.rot(y, 17), s.rot(y, 19), s.rot(y, 10, shift=True))
-        W.append(s.add([W[i - 16], s0, W[i - 7], s1]))
-    a, b, c, d, e, f, g, h = H
-    for i in range(64):
+        W[i] = s.add([W[i - 16], s0, W[i - 7], s1])
+    a, b, c, d, e, f, g, h = v
+    for i in range(r0, r1):
         S1 = s.xor3(s.rot(e, 6), s.rot(e, 11), s.rot(e, 25))
         ch = [s.lookup("CH4", e[t], f[t], g[t]) for t in range(8)]
         S0 = s.xor3(s.rot(a, 2), s.rot(a, 13), s.rot(a, 22))
@@ -120,15 +136,19 @@ def build():
         new_a = s.add([h, S1, ch, W[i], S0, maj], K[i])
         a, b, c, d, e, f, g, h = new_a, a, b, c, new_e, e, f, g
     v = [a, b, c, d, e, f, g, h]
-    Hn = [s.add([H[j], v[j]]) for j in range(8)]
-    # out = idle ? prev : H'
-    s.out = [s.lookup("CH4", nl.hdr(HDR_M1), nl.prev(8 * j + i), Hn[j][i]) for j in range(8) for i in range(8)]
+    if last:
+        Hn = [s.add([H[j], v[j]]) for j in range(8)]
+        # out = idle ? the state before the cycle : H'
+        s.out = [s.lookup("CH4", nl.hdr(HDR_M1), nl.cyc(8 * j + i), Hn[j][i]) for j in range(8) for i in range(8)] + [ZERO] * (STATE - 64)
+    else:
+        s.out = [x for wd in v for x in wd] + [x for t in range(r1 - 16, r1) for x in W[t]] + [x for wd in H for x in wd]
+    assert len(s.out) == STATE
     # Range lookups (three nibbles per TriXor4) for what no other lookup consumes and no re-chunking bounds: the carries, the
     # middle nibbles a shift drops, the nibbles of message words that are never re-chunked. (Out nibbles of an addition that only
     # feed further additions need none: with its carry bounded, the word is right modulo 2^32 wherever it is used.)
     consumed = {id(r) for t, ins, *_ in s.ops for r in ins if isinstance(r, nl.Val)}
     rechunked = {k[1] for k in s.phase_cache}
-    for wd in W[:16]:
+    for wd in (W[i] for i in range(16) if first):
         if tuple(id(x) for x in wd) in rechunked:
             for x in wd:
                 consumed.add(id(x))
@@ -171,29 +191,37 @@ def nibbles_of_block(block):
 
 def make_spec(prefix, general_cols, lookups_per_row):
     tables = nl.sha_tables()
-    spec = nl.Spec(prefix, general_cols, 4, lookups_per_row, tables, 64, (0, 15, 0, 15))
-    s = build()
-    s.tables = {t.name: t for t in tables}
-    for op in s.ops:  # the step was built against its own table objects: rebind to the spec's (ids / offsets)
-        op[0] = s.tables[op[0].name]
-    spec.cycle = [(spec.add_step_type(s), [])]
+    spec = nl.Spec(prefix, general_cols, 4, lookups_per_row, tables, STATE, (0, 15, 0, 15))
+    by_name = {t.name: t for t in tables}
+    for r0, r1 in SEGMENTS:
+        s = build_step(r0, r1)
+        s.tables = by_name
+        for op in s.ops:  # the step was built against its own table objects: rebind to the spec's (ids / offsets)
+            op[0] = by_name[op[0].name]
+        spec.cycle.append((spec.add_step_type(s), []))
     return spec
+
+
+def cycle_state(words):
+    """the engine's cycle state of 8 chaining words: their nibbles, then zeros"""
+    return nibbles_of_words(words) + [0] * (STATE - 64)
 
 
 def self_check(spec):
     rng = random.Random(1)
     st = [rng.getrandbits(32) for _ in range(8)]
     blk = [rng.randrange(256) for _ in range(64)]
-    assert spec.evaluate_cycle(nibbles_of_words(st), [nibbles_of_block(blk)], 0, 0) == nibbles_of_words(sha_compress(st, blk))
-    assert spec.evaluate_cycle(nibbles_of_words(st), [nibbles_of_block(blk)], 0, 1) == nibbles_of_words(st)  # idle carries the state
+    frees = lambda b: [nibbles_of_block(b)] + [[]] * (len(SEGMENTS) - 1)  # noqa: E731
+    assert spec.evaluate_cycle(cycle_state(st), frees(blk), 0, 0) == cycle_state(sha_compress(st, blk))
+    assert spec.evaluate_cycle(cycle_state(st), frees(blk), 0, 1) == cycle_state(st)  # idle carries the state
     for blk2 in ([0] * 64, [255] * 64):
         for st2 in ([0] * 8, [0xFFFFFFFF] * 8):
-            assert spec.evaluate_cycle(nibbles_of_words(st2), [nibbles_of_block(blk2)], 0, 0) == nibbles_of_words(sha_compress(st2, blk2))
+            assert spec.evaluate_cycle(cycle_state(st2), frees(blk2), 0, 0) == cycle_state(sha_compress(st2, blk2))
     msg = bytes(rng.randrange(256) for _ in range(100))
     padded = msg + b"\x80" + bytes((55 - len(msg)) % 64) + struct.pack(">Q", 8 * len(msg))
-    state = nibbles_of_words([0] * 8)
+    state = cycle_state([0] * 8)
     for i in range(0, len(padded), 64):
-        state = spec.evaluate_cycle(state, [nibbles_of_block(padded[i:i + 64])], 1 if i == 0 else 0, 0)
+        state = spec.evaluate_cycle(state, frees(padded[i:i + 64]), 1 if i == 0 else 0, 0)
     words = [sum(state[8 * j + t] << (4 * t) for t in range(8)) for j in range(8)]
     assert b"".join(struct.pack(">I", w) for w in words) == hashlib.sha256(msg).digest(), "netlist != SHA-256"
 
