@@ -249,16 +249,46 @@ __device__ __forceinline__ u32 l1_message_byte(const zkw_log_query* q, size_t po
     return (m->written_value[b >> 2] >> (8 * (b & 3))) & 0xFF;
 }
 
+// lane t (< 17) of the 136-byte block at byte offset `off` of a queue of `len` message bytes, pad10*1 included
+__device__ __forceinline__ u64 l1_block_lane(const zkw_log_query* q, size_t len, size_t off, int t) {
+    const bool last = len - off < 136;
+    u64 lane = 0;
+    for (int b = 0; b < 8; b++) {
+        const size_t pos = off + 8 * t + b;
+        u32 byte = pos < len ? l1_message_byte(q, pos) : 0;
+        if (last && pos == len) byte ^= 0x01;
+        if (last && 8 * t + b == 135) byte ^= 0x80;
+        lane |= (u64)byte << (8 * b);
+    }
+    return lane;
+}
+
+// The absorbed blocks of all queues of a batch, in parallel: thread = (block, word w < 18) -> rounds[block].block words (w = 17:
+// the reset flag). The serial sponge then only loads them — building a block's bytes from the 88-byte serialisations inside the
+// sponge loop (eight dependent message loads and a division per byte) took more of its time than the permutation.
+static __global__ __launch_bounds__(256) void k_linear_blocks(const zkw_log_query* __restrict__ q, const u64* __restrict__ msg_off,
+                                                               const u64* __restrict__ round_off, u32 n_queues, zkw_keccak_round_record* __restrict__ rounds) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x, total = round_off[n_queues] * 18;
+    if (i >= total) return;
+    const u64 blk = i / 18;
+    const int w = (int)(i % 18);
+    u32 b = 0;
+    while (round_off[b + 1] <= blk) b++;
+    const u64 local = blk - round_off[b];
+    const size_t len = (size_t)(msg_off[b + 1] - msg_off[b]) * 88;
+    u64* dst = reinterpret_cast<u64*>(rounds[blk].block);
+    dst[w] = w < 17 ? l1_block_lane(q + msg_off[b], len, (size_t)local * 136, w) : (local == 0 ? 1 : 0);
+}
+
 // rounds (may be null): one zkw_keccak_round_record per absorbed block — the cycles of the LinearHasher circuit (type 13).
-// The sponge is serial: 25 lanes of one wave hold the state in LDS (7.7 us per call; lane 0 alone running the unrolled
-// register form of keccak_f1600 was measured at 17 us)
+// The sponge is serial: 25 lanes of one wave hold the state, one 64-bit lane each (with the state in LDS and three barriers per
+// round a Keccak-f took 9.7 us; lane 0 alone running the unrolled register form of keccak_f1600 was measured at 17 us)
 // Batch form: workgroup b hashes the messages [msg_off[b], msg_off[b + 1]) into out + 32 b, its round records start at
 // rounds + round_off[b] (msg_off == nullptr: one queue of n messages). The queues of a batch run side by side — the chain of
 // one queue stays serial.
 static __global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_query* __restrict__ q, size_t n, uint8_t* __restrict__ out,
                                                          zkw_keccak_round_record* __restrict__ rounds,
-                                                         const u64* __restrict__ msg_off, const u64* __restrict__ round_off) {
-    __shared__ u64 A[25], Bm[25], Cc[5];
+                                                         const u64* __restrict__ msg_off, const u64* __restrict__ round_off, bool blocks_ready) {
     const int t = threadIdx.x;
     if (msg_off) {
         const u64 m0 = msg_off[blockIdx.x];
@@ -268,45 +298,46 @@ static __global__ __launch_bounds__(64) void k_linear_keccak256(const zkw_log_qu
         if (rounds) rounds += round_off[blockIdx.x];
     }
     const size_t len = n * 88;
-    if (t < 25) A[t] = 0;
-    __syncthreads();
+    // lane t = x + 5 y < 25 holds lane (x, y) of the state in a register; a round is four exchanges through the wave's shuffle
+    // network (column parities, their neighbours, rho-pi, chi's row neighbours) with no LDS round trip and no barrier: 4.4 ms
+    // per queue of 700 messages with the state in LDS and three barriers per round, ~half with this form
+    const int x = t % 5, y = t / 5;
+    const int src_pi = (x + 3 * y) % 5 + 5 * x;                // B[x + 5y] = rol(A'[x' + 5y'], rot[x' + 5y']) with x = y', y = (2x' + 3y') % 5
+    const int rot_pi = t < 25 ? c_keccak_rot[src_pi] : 0;
+    u64 a = 0, lane_next = 0;
+    if (blocks_ready && t < 17) lane_next = reinterpret_cast<const u64*>(rounds[0].block)[t];
     for (size_t off = 0;; off += 136) {
         const bool last = len - off < 136;  // the final (padded) block; len % 136 == 0 gives a pure padding block
         if (t < 17) {
-            u64 lane = 0;
-            for (int b = 0; b < 8; b++) {
-                const size_t pos = off + 8 * t + b;
-                u32 byte = pos < len ? l1_message_byte(q, pos) : 0;
-                if (last && pos == len) byte ^= 0x01;
-                if (last && 8 * t + b == 135) byte ^= 0x80;
-                lane |= (u64)byte << (8 * b);
+            u64 lane;
+            if (blocks_ready) {  // (k_linear_blocks has written every block: one load, the next block's issued before this block's rounds)
+                lane = lane_next;
+                if (!last) lane_next = reinterpret_cast<const u64*>(rounds[off / 136 + 1].block)[t];
+            } else {
+                lane = l1_block_lane(q, len, off, t);
+                if (rounds) reinterpret_cast<u64*>(rounds[off / 136].block)[t] = lane;  // records are 8-byte aligned (344 = 8 * 43)
             }
-            A[t] ^= lane;
-            if (rounds) reinterpret_cast<u64*>(rounds[off / 136].block)[t] = lane;  // records are 8-byte aligned (344 = 8 * 43)
+            a ^= lane;
         }
-        if (rounds && t == 17) reinterpret_cast<u64*>(rounds[off / 136].block)[17] = off == 0 ? 1 : 0;  // reset + padding
-        __syncthreads();
+        if (rounds && !blocks_ready && t == 17) reinterpret_cast<u64*>(rounds[off / 136].block)[17] = off == 0 ? 1 : 0;  // reset + padding
         for (int round = 0; round < 24; round++) {
-            if (t < 5) Cc[t] = A[t] ^ A[t + 5] ^ A[t + 10] ^ A[t + 15] ^ A[t + 20];
-            __syncthreads();
-            if (t < 25) {
-                const int x = t % 5, y = t / 5;
-                const u64 d = Cc[(x + 4) % 5] ^ rol64(Cc[(x + 1) % 5], 1);
-                Bm[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(A[t] ^ d, c_keccak_rot[t]);
-            }
-            __syncthreads();
-            if (t < 25) {
-                const int x = t % 5, y = t / 5;
-                u64 v = Bm[t] ^ (~Bm[(x + 1) % 5 + 5 * y] & Bm[(x + 2) % 5 + 5 * y]);
-                if (t == 0) v ^= c_keccak_rc[round];
-                A[t] = v;
-            }
-            __syncthreads();
+            // theta: column parity (the four other lanes of the column), D from the neighbouring columns' parities
+            const u64 c = a ^ __shfl(a, (t + 5) % 25) ^ __shfl(a, (t + 10) % 25) ^ __shfl(a, (t + 15) % 25) ^ __shfl(a, (t + 20) % 25);
+            const u64 d = __shfl(c, (x + 4) % 5) ^ rol64(__shfl(c, (x + 1) % 5), 1);
+            const u64 ap = a ^ d;
+            // rho + pi: lane (x, y) takes the rotated lane it receives
+            const u64 bm = rol64(__shfl(ap, src_pi), rot_pi);
+            // chi + iota
+            const u64 b1 = __shfl(bm, (x + 1) % 5 + 5 * y), b2 = __shfl(bm, (x + 2) % 5 + 5 * y);
+            a = bm ^ (~b1 & b2);
+            if (t == 0) a ^= c_keccak_rc[round];
         }
-        if (rounds && t < 25) reinterpret_cast<u64*>(rounds[off / 136].state_after)[t] = A[t];
+        if (rounds && t < 25) reinterpret_cast<u64*>(rounds[off / 136].state_after)[t] = a;
         if (last) break;
     }
-    if (t < 32) out[t] = (uint8_t)(A[t >> 3] >> (8 * (t & 7)));
+    // the first 32 bytes of the state: lanes 0..3
+    const u64 w = __shfl(a, (t >> 3) & 3);
+    if (t < 32) out[t] = (uint8_t)(w >> (8 * (t & 7)));
 }
 
 }  // namespace zkw

@@ -191,7 +191,7 @@ extern "C" int zkw_linear_keccak256(zkw_ctx* ctx, const zkw_log_query* messages,
     uint8_t* d_out = nullptr;
     ZKW_TRY(ctx->in("lk_q", messages, n, &d_q));
     ZKW_TRY(ctx->out("lk_out", hash_out, 32, &d_out));
-    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out, (zkw_keccak_round_record*)nullptr, (const u64*)nullptr, (const u64*)nullptr); }
+    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out, (zkw_keccak_round_record*)nullptr, (const u64*)nullptr, (const u64*)nullptr, false); }
     ZKW_TRY(launch_check("k_linear_keccak256"));
     ZKW_TRY(ctx->finish_out(hash_out, d_out, 32));
     return ctx->sync_if_host();
@@ -944,7 +944,9 @@ extern "C" int zkw_linear_hasher_synthesize_batch(zkw_ctx* ctx, const zkw_log_qu
     ZKW_TRY(ctx->scratch_t<uint8_t>("lh_hash", 32 * n_queues, &d_hash));
     ZKW_TRY(ctx->upload("lh_moff", moff, &d_moff));
     ZKW_TRY(ctx->upload("lh_roff", roff, &d_roff));
-    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3((unsigned)n_queues), dim3(64), 0, ctx->stream, d_q, (size_t)0, d_hash, d_rounds, d_moff, d_roff); }
+    { Prof _p(ctx, "k_linear_blocks"); hipLaunchKernelGGL(k_linear_blocks, dim3(blocks_for(roff[n_queues] * 18, 256)), dim3(256), 0, ctx->stream, d_q, d_moff, d_roff, (u32)n_queues, d_rounds); }
+    ZKW_TRY(launch_check("k_linear_blocks"));
+    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3((unsigned)n_queues), dim3(64), 0, ctx->stream, d_q, (size_t)0, d_hash, d_rounds, d_moff, d_roff, true); }
     ZKW_TRY(launch_check("k_linear_keccak256"));
     std::vector<zkw_linear_hasher_instance> recv(n_queues);
     std::vector<uint8_t> hashes(32 * n_queues);
