@@ -16,6 +16,7 @@
 #include "../../include/zkw_code_decommitter_circuit_spec.h"
 #include "../../include/zkw_keccak_circuit_spec.h"
 #include "../../include/zkw_linear_hasher_circuit_spec.h"
+#include "../../include/zkw_storage_application_circuit_spec.h"
 #include "../../include/zkw_types.h"
 #include "ram_circuit_kernels.cuh"  // CheckResult, flag_bad
 
@@ -28,15 +29,23 @@ NL_DEFINE_SPEC(h_sc, SC);
 NL_DEFINE_SPEC(h_dc, DC);
 NL_DEFINE_SPEC(h_kc, KC);
 NL_DEFINE_SPEC(h_lh, LH);
+NL_DEFINE_SPEC(h_sa, SA);
 static inline const nl_spec* nl_host_spec(int circuit_type) {
     switch (circuit_type) {
         case 6: return &h_sc_spec;
         case 3: return &h_dc_spec;
         case 5: return &h_kc_spec;
         case 13: return &h_lh_spec;
+        case 10: return &h_sa_spec;
         default: return nullptr;
     }
 }
+
+// cycles of a trace of `capacity` units of the circuit's own counting (LinearHasher: messages; StorageApplication: tree queries)
+static inline uint32_t nl_cycles_of(int circuit_type, uint32_t capacity) {
+    return circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(capacity) : circuit_type == 10 ? capacity * SA_CYCLES_PER_WALK : capacity;
+}
+static inline bool nl_is_netlist(int circuit_type) { return nl_host_spec(circuit_type) != nullptr; }
 
 // ---- what the kernels get: the spec with DEVICE pointers plus tables derived from it on the host
 struct NlHistEntry { u32 step, r0, r1, key0, lookup_rows; };  // rows [r0, r1) of the lookup rows of cycle step `step` hold this table

@@ -408,4 +408,121 @@ static __global__ void k_sap_instances(const SapBlock* __restrict__ blk) {
     w.num_items = hi - lo;
 }
 
+// ------------------------------------------------------------------------------------------------ synthesis inputs (type 10)
+// What zkw_storage_application_synthesize needs of a query after the builder's scratch is gone: the leaf before and after it.
+struct SapItem { u64 read_index, write_index; u32 read_value[8], written_value[8]; u32 rw, _pad; };
+static __global__ __launch_bounds__(64) void k_sap_items(SapJob job, SapItem* __restrict__ items) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= job.n) return;
+    const zkw_log_query* q = job.queries + i;
+    SapItem& it = items[i];
+    it.read_index = job.init_index[i];
+    it.write_index = job.new_index[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { it.read_value[k] = q->read_value[k]; it.written_value[k] = q->written_value[k]; }
+    it.rw = q->rw_flag != 0;
+    it._pad = 0;
+}
+
+// The inputs of the netlist engine (include/zkw_storage_application_circuit_spec.h: cycle = one Blake2s compression of a Merkle
+// walk, 257 cycles per walk; a read is one walk, a write two — storage_application.rs:141-153) for the instances of a block:
+// header bits, free elements (leaf message / sibling, the walk's key << 1), the state (hash 32, key 33) before every cycle.
+struct SapWalkJob {
+    const SapItem* items;     // block-wide
+    const u32* keys;          // [n][8]
+    const u32* paths;         // [n][256][8]
+    u64 first_item, num_items;
+    uint8_t* hdr_bits;        // [cycles]
+    uint8_t* free_elems;      // [cycles][97]
+    uint8_t* state_before;    // [cycles + 1][65]
+};
+constexpr u32 SAP_WALK_CYCLES = 257, SAP_WALK_STATE = 65, SAP_WALK_FREE = 97, SAP_WALK_MAX = 1024;
+
+// bits [o, o + 8) of the 256-bit little-endian number kw (bits outside [0, 256) are zero); o >= -8
+__device__ __forceinline__ u32 sap_key_bits(const u32* __restrict__ kw, int o) {
+    u32 r = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const int i = o + b;
+        if (i >= 0 && i < 256) r |= ((kw[i >> 5] >> (i & 31)) & 1u) << b;
+    }
+    return r;
+}
+
+static __global__ __launch_bounds__(256) void k_sap_walk_prepare(const SapWalkJob* __restrict__ jobs, u32 capacity) {
+    __shared__ u32 s_item[SAP_WALK_MAX];
+    __shared__ uint8_t s_phase[SAP_WALK_MAX];
+    __shared__ u32 s_nw;
+    const SapWalkJob j = jobs[blockIdx.x];
+    const u32 t = threadIdx.x, cycles = capacity * SAP_WALK_CYCLES;
+    if (t == 0) {
+        u32 nw = 0;
+        for (u64 k = 0; k < j.num_items && nw < capacity; k++) {
+            const u64 i = j.first_item + k;
+            s_item[nw] = (u32)i; s_phase[nw++] = 0;
+            if (j.items[i].rw && nw < capacity) { s_item[nw] = (u32)i; s_phase[nw++] = 1; }
+        }
+        s_nw = nw;
+    }
+    __syncthreads();
+    const u32 nw = s_nw;
+    // the hash chains: one lane per walk, the running hash AFTER cycle c goes to state_before[c + 1]
+    for (u32 w = t; w < nw; w += blockDim.x) {
+        const SapItem& it = j.items[s_item[w]];
+        const u32* kw = j.keys + 8 * (u64)s_item[w];
+        u32 cur[8];
+        if (s_phase[w]) sap_leaf_hash(it.write_index, it.written_value, cur); else sap_leaf_hash(it.read_index, it.read_value, cur);
+        uint8_t* st = j.state_before + ((size_t)w * SAP_WALK_CYCLES + 1) * SAP_WALK_STATE;
+        sap_bytes32(st, cur);
+        for (int L = 0; L < 256; L++) {
+            const u32* sib = j.paths + ((u64)s_item[w] * 256 + L) * 8;
+            u32 s[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = sib[k];
+            if ((kw[L >> 5] >> (L & 31)) & 1) sap_node_hash(s, cur, o); else sap_node_hash(cur, s, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) cur[k] = o[k];
+            st += SAP_WALK_STATE;
+            sap_bytes32(st, cur);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // everything else, a byte per thread and step: header bits, free elements, the key part of the states, the hash of the
+    // padding cycles (= the last walk's root) and of the state before cycle 0 (zero)
+    const u32 active = nw * SAP_WALK_CYCLES;
+    for (u32 c = t; c < cycles; c += blockDim.x) j.hdr_bits[c] = c >= active ? 2 : (c % SAP_WALK_CYCLES == 0 ? 1 : 0);
+    for (size_t e = t; e < (size_t)cycles * SAP_WALK_FREE; e += blockDim.x) {
+        const u32 c = (u32)(e / SAP_WALK_FREE), f = (u32)(e % SAP_WALK_FREE);
+        uint8_t v = 0;
+        if (c < active) {
+            const u32 w = c / SAP_WALK_CYCLES, i = c % SAP_WALK_CYCLES;
+            const SapItem& it = j.items[s_item[w]];
+            if (i == 0) {
+                if (f < 64) {  // index_be (8) || value_be (32) || zeros
+                    const u64 idx = s_phase[w] ? it.write_index : it.read_index;
+                    const u32* val = s_phase[w] ? it.written_value : it.read_value;
+                    if (f < 8) v = (uint8_t)(idx >> (8 * (7 - f)));
+                    else if (f < 40) { const u32 b = 31 - (f - 8); v = (uint8_t)(val[b >> 2] >> (8 * (b & 3))); }
+                } else v = (uint8_t)sap_key_bits(j.keys + 8 * (u64)s_item[w], 8 * (int)(f - 64) - 1);  // the key << 1, 33 bytes
+            } else if (f >= 32 && f < 64) {
+                const u32 x = j.paths[((u64)s_item[w] * 256 + (i - 1)) * 8 + ((f - 32) >> 2)];
+                v = (uint8_t)(x >> (8 * (f & 3)));
+            }
+        }
+        j.free_elems[e] = v;
+    }
+    for (size_t e = t; e < (size_t)(cycles + 1) * 33; e += blockDim.x) {  // key part: (key << 1) >> i before cycle i of a walk, i >= 1
+        const u32 c = (u32)(e / 33), k = (u32)(e % 33);
+        uint8_t v = 0;
+        if (c < active && c % SAP_WALK_CYCLES) v = (uint8_t)sap_key_bits(j.keys + 8 * (u64)s_item[c / SAP_WALK_CYCLES], (int)(c % SAP_WALK_CYCLES) + 8 * (int)k - 1);
+        j.state_before[(size_t)c * SAP_WALK_STATE + 32 + k] = v;
+    }
+    for (size_t e = t; e < (size_t)(cycles + 1 - active) * 32; e += blockDim.x) {  // hash part outside the walks
+        const u32 c = (u32)(e / 32), k = (u32)(e % 32);
+        if (c == 0) j.state_before[k] = 0;  // (the state before cycle 0)
+        else j.state_before[(size_t)(active + c) * SAP_WALK_STATE + k] = active ? j.state_before[(size_t)active * SAP_WALK_STATE + k] : 0;
+    }
+}
+
 }  // namespace zkw

@@ -4,6 +4,7 @@
 #include "zkw_ctx.h"
 #include "closed_forms_host.h"
 #include "decommitter_kernels.cuh"
+#include <functional>
 #include "precompile_kernels.cuh"
 #include "storage_application_kernels.cuh"
 #include "netlist_kernels.cuh"
@@ -389,8 +390,11 @@ struct zkw_storage_application_witness {
     u32 *keys = nullptr, *paths = nullptr, *roots = nullptr;
     u64* leaf_indexes = nullptr;
     zkw_storage_application_instance* instances = nullptr;
+    SapItem* items = nullptr;  // the leaf before / after every query: what synthesis needs once the builder's scratch is gone
+    u64* cf_pi = nullptr;      // compact forms [n_instances][18] then public inputs [n_instances][4] (a20), on first synthesis
+    u32 capacity = 0;
     void release() {
-        void* ptrs[] = {keys, paths, roots, leaf_indexes, instances};
+        void* ptrs[] = {keys, paths, roots, leaf_indexes, instances, items, cf_pi};
         for (void* p : ptrs)
             if (p) dev_free(p);
     }
@@ -413,6 +417,8 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
     alloc((void**)&w->paths, n * 256 * 32);
     alloc((void**)&w->roots, n * 32);
     alloc((void**)&w->leaf_indexes, n * 8);
+    alloc((void**)&w->items, n * sizeof(SapItem));
+    w->capacity = capacity;
     auto bail = [&](int rc) { w->release(); delete w; return rc; };
     if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed: %s", hipGetErrorString(e)));
     int rc = ZKW_OK;
@@ -461,6 +467,8 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
         TRY(launch_check("k_sap_keys"));
         { Prof _p(ctx, "k_sap_scan"); hipLaunchKernelGGL(k_sap_scan, dim3(1), dim3(1024), 0, ctx->stream, job); }
         TRY(launch_check("k_sap_scan"));
+        { Prof _p(ctx, "k_sap_items"); hipLaunchKernelGGL(k_sap_items, dim3(g64), dim3(64), 0, ctx->stream, job, w->items); }
+        TRY(launch_check("k_sap_items"));
         { Prof _p(ctx, "k_sap_pairs"); hipLaunchKernelGGL(k_sap_pairs, dim3(g64), dim3(64), 0, ctx->stream, job); }
         TRY(launch_check("k_sap_pairs"));
         { Prof _p(ctx, "k_sap_leaves"); hipLaunchKernelGGL(k_sap_leaves, dim3(g64), dim3(64), 0, ctx->stream, job); }
@@ -749,8 +757,10 @@ int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsign
     return launch_check("k_nl_hist");
 }
 
-// synthesis of instances of one netlist circuit from the block's round records (`sha_like`: zkw_sha256_round_record, else keccak)
-int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_rounds, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
+// synthesis of instances of one netlist circuit: `prepare` turns the builder's records into the engine's inputs (header bits, free
+// elements, the state before every cycle) at the pointers of the jobs it is handed; `capacity` is in cycles
+using NlPrepare = std::function<int(std::vector<NlPrepJob>&)>;
+int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
     const NlCached* nc = nullptr;
     ZKW_TRY(nl_get(ctx, circuit_type, &nc));
     const nl_spec& S = nc->host.s;
@@ -774,9 +784,7 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
     std::vector<NlJob> jobs(ni);
     const size_t bnd = NL_BOUNDARY_ROW(&S, capacity);
     for (size_t k = 0; k < ni; k++) {
-        const size_t rec_bytes = sha_like ? sizeof(zkw_sha256_round_record) : sizeof(zkw_keccak_round_record);
-        prep[k] = inst[k].fresh ? NlPrepJob{static_cast<const char*>(d_rounds) + inst[k].first_round * rec_bytes, 0, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n, S.state}
-                                : NlPrepJob{d_rounds, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n, S.state};
+        prep[k] = NlPrepJob{nullptr, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n, S.state};
         // The fill writes the lookup cells of every row above the boundary and the general-purpose cells of the header / gate rows;
         // everything else is zero. A slot whose previous tenant was the same layout (circuit, capacity, rows) already has those
         // zeros: nothing to clear (the multiplicity column is rewritten over the tables' rows). Otherwise: clear it.
@@ -791,22 +799,36 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
             HIP_TRY(hipMemsetAsync(tr + (size_t)S.mult_col * n_rows, 0, n_rows * sizeof(u64), ctx->stream));
         }
     }
-    NlPrepJob* d_prep = nullptr;
     NlJob* d_jobs = nullptr;
-    ZKW_TRY(ctx->upload("nl_prep", prep, &d_prep));
     ZKW_TRY(ctx->upload("nl_jobs", jobs, &d_jobs));
     const unsigned nj = (unsigned)ni;
-    if (sha_like) { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_sha, dim3(capacity + 1, nj), dim3(128), 0, ctx->stream, d_prep, capacity); }
-    else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
-    ZKW_TRY(launch_check("k_nl_prepare"));
+    ZKW_TRY(prepare(prep));
+    static_assert(SA_W == LH_W && SA_R == LH_R, "StorageApplication shares the fill instantiation of the LinearHasher geometry");
     switch (circuit_type) {
         case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
         case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
         case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;  // 13 and 10: 3 x 26
     }
     { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
     return launch_check("k_nl_finish");
+}
+
+// ... from the block's round records (`sha_like`: zkw_sha256_round_record, else zkw_keccak_round_record)
+int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_rounds, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
+    return nl_synthesize_with(ctx, circuit_type, [&](std::vector<NlPrepJob>& prep) {
+        const size_t rec_bytes = sha_like ? sizeof(zkw_sha256_round_record) : sizeof(zkw_keccak_round_record);
+        for (size_t k = 0; k < prep.size(); k++) {
+            if (inst[k].fresh) { prep[k].rounds = static_cast<const char*>(d_rounds) + inst[k].first_round * rec_bytes; prep[k].first_round = 0; }
+            else prep[k].rounds = d_rounds;
+        }
+        NlPrepJob* d_prep = nullptr;
+        ZKW_TRY(ctx->upload("nl_prep", prep, &d_prep));
+        const unsigned nj = (unsigned)prep.size();
+        if (sha_like) { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_sha, dim3(capacity + 1, nj), dim3(128), 0, ctx->stream, d_prep, capacity); }
+        else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
+        return launch_check("k_nl_prepare");
+    }, inst, capacity, n_rows);
 }
 
 int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u32 capacity, uint64_t* n_violations, uint64_t* first_bad) {
@@ -911,6 +933,42 @@ extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trac
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
         return fail(ZKW_ERR_INVALID, "zkw_code_decommitter_check_satisfied: bad argument");
     return nl_check(ctx, 3, t, slot, capacity, n_violations, first_bad);
+}
+
+// ------------------------------------------------------------------------------------------------ StorageApplication synthesis
+// ZkSyncBaseLayerCircuit::synthesis for StorageApplication (type 10): the Merkle walks of the instance's tree queries as Blake2s
+// compressions on 60 + 3 x 26 columns, Xor8 / And8 / ByteSplit<1..4, 7> (base_layer/storage_apply.rs:28-39,124-140). A walk is 257
+// cycles (leaf hash + 256 levels); capacity = cycles_per_storage_application walks (a read is one walk, a write two).
+extern "C" int zkw_storage_application_synthesize(zkw_ctx* ctx, zkw_storage_application_witness* w, size_t first_instance, size_t n_instances,
+                                                  zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_storage_application_synthesize: bad argument");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (t->n_cols < SA_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the StorageApplication circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, SA_COLS);
+    if (w->capacity > SAP_WALK_MAX) return fail(ZKW_ERR_INVALID, "capacity %u: at most %u walks per instance", w->capacity, SAP_WALK_MAX);
+    if (n_instances == 0) return ZKW_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!w->cf_pi) ZKW_TRY(closed_form_public_inputs<CfStorageApplication>(ctx, w->instances, w->n_instances, &w->cf_pi));
+    std::vector<zkw_storage_application_instance> rec(n_instances);
+    ZKW_TRY(ctx->read_small(rec.data(), w->instances + first_instance, n_instances * sizeof rec[0]));
+    std::vector<NlInstance> inst(n_instances);
+    for (size_t k = 0; k < n_instances; k++)
+        inst[k] = NlInstance{rec[k].first_item, (u32)rec[k].num_items, w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k), t, (first_slot + k) % t->n_slots, true};
+    const u32 capacity = w->capacity;
+    return nl_synthesize_with(ctx, 10, [&](std::vector<NlPrepJob>& prep) {
+        std::vector<SapWalkJob> jobs(prep.size());
+        for (size_t k = 0; k < prep.size(); k++)
+            jobs[k] = SapWalkJob{w->items, w->keys, w->paths, w->n ? prep[k].first_round : 0, w->n ? prep[k].n_active : 0, prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
+        SapWalkJob* d_jobs = nullptr;
+        ZKW_TRY(ctx->upload("sap_walk_jobs", jobs, &d_jobs));
+        { Prof _p(ctx, "k_sap_walk_prepare"); hipLaunchKernelGGL(k_sap_walk_prepare, dim3((unsigned)jobs.size()), dim3(256), 0, ctx->stream, d_jobs, capacity); }
+        return launch_check("k_sap_walk_prepare");
+    }, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows);
+}
+extern "C" int zkw_storage_application_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_storage_application_check_satisfied: bad argument");
+    return nl_check(ctx, 10, t, slot, capacity * SA_CYCLES_PER_WALK, n_violations, first_bad);
 }
 
 // LinearHasher (type 13): the Keccak-f netlist over the sponge of the serialized L2 -> L1 messages (compute_linear_keccak256,

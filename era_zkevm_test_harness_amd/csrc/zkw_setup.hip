@@ -62,9 +62,9 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
         case 9: out->num_columns = SS_COLS; out->rows_per_cycle = SS_ROWS_PER_CYCLE; out->region_stride = SS_REGION_STRIDE(capacity); boundary = SS_BOUNDARY_ROW(capacity); min_rows = SS_MIN_ROWS(capacity); pi_off = SS_ROWOFF_PI; break;
         case 11: case 12: out->num_columns = ES_COLS; out->rows_per_cycle = ES_ROWS_PER_CYCLE; out->region_stride = ES_REGION_STRIDE(capacity); boundary = ES_BOUNDARY_ROW(capacity); min_rows = ES_MIN_ROWS(capacity); pi_off = ES_ROWOFF_PI; break;
         // the netlist circuits ("zkw trace v4") are cycle-major: region_stride = 0, cycle i starts at row i * rows_per_cycle
-        case 3: case 5: case 6: case 13: {
+        case 3: case 5: case 6: case 10: case 13: {
             const nl_spec* sp = nl_host_spec(circuit_type);
-            const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(capacity) : capacity;
+            const uint32_t cycles = nl_cycles_of(circuit_type, capacity);
             out->num_columns = sp->cols; out->rows_per_cycle = sp->rows_per_cycle; boundary = NL_BOUNDARY_ROW(sp, cycles);
             min_rows = NL_USED_ROWS(sp, cycles); pi_off = 2 * NL_BND_ROWS(sp);
             out->total_table_rows = sp->total_table_rows;
@@ -106,7 +106,7 @@ extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, 
         for (uint64_t k = 0; bnd + k < lay.rows_used; k++) out[bnd + k] = (uint8_t)(rpc + k);
         return ZKW_OK;
     }
-    const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
+    const uint32_t cycles = nl_cycles_of(circuit_type, cap);
     const uint64_t rpc = lay.rows_per_cycle;
     const nl_spec* sp = nl_host_spec(circuit_type);
     std::vector<uint8_t> one(rpc);  // every cycle has the same selectors
@@ -147,7 +147,7 @@ bool link_spec_of(uint8_t t, LinkSpec* o) {
 
 extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t* sigma, uint32_t* n_columns) {
     LinkSpec sp;
-    const bool netlist = circuit_type == 3 || circuit_type == 5 || circuit_type == 6 || circuit_type == 13;
+    const bool netlist = nl_is_netlist(circuit_type);
     if (netlist) sp = {(int)nl_host_spec(circuit_type)->mult_col, 0, 0, 0, 0, nullptr};  // all but the multiplicity column
     else if (!link_spec_of(circuit_type, &sp))
         return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: circuit type %u has no layout in this library", (unsigned)circuit_type);
@@ -177,7 +177,7 @@ extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacit
         // the netlist circuits: every operand cell of a lookup / gate is a copy of the cell that produced it (the references of
         // the spec, resolved exactly as the checkers do: k_kc_check_rows, k_sc_check_cycle); constants and free witness bytes
         // are under no copy constraint
-        const uint32_t cycles = circuit_type == 13 ? ZKW_LINEAR_HASHER_CYCLES(cap) : cap;
+        const uint32_t cycles = nl_cycles_of(circuit_type, cap);
         const nl_spec* ns = nl_host_spec(circuit_type);
         const uint64_t nb = NL_BOUNDARY_ROW(ns, cycles), brows = NL_BND_ROWS(ns);
         // the cell a reference names, seen from step st of cycle c (nl_home of netlist_kernels.cuh as coordinates); false: a constant

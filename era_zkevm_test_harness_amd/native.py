@@ -144,6 +144,8 @@ SYMBOLS = [
     ("zkw_storage_application_witness_device_ptr", _vp, [_vp, _int]),
     ("zkw_storage_application_witness_get", _int, [_vp, _int, _vp, _sz]),
     ("zkw_storage_application_witness_free", None, [_vp]),
+    ("zkw_storage_application_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_storage_application_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_precompile_build", _int, [_vp, _int, _vp, _vp, _sz, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_precompile_build_with_tails", _int, [_vp, _int, _vp, _vp, _sz, _vp, _sz, C.c_uint32, _vp, _vp, _vp]),
     ("zkw_precompile_witness_num_instances", _sz, [_vp]),
@@ -1217,6 +1219,27 @@ def _ctx_check_if_satisfied_code_decommitter(self, trace, slot, capacity):
 
 
 Context.synthesize_code_decommitter = _ctx_synthesize_code_decommitter
+
+SA_COLS = 139  # 60 + 3 x 26 + 1 (include/zkw_storage_application_circuit_spec.h)
+SA_CYCLES_PER_WALK = 257
+
+
+def _ctx_synthesize_storage_application(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+    """ZkSyncBaseLayerCircuit::StorageApplication synthesis ("zkw trace v4": the Merkle walks of the instance's tree queries as
+    Blake2s compressions on 60 + 3 x 26 columns) for instances of a StorageApplicationWitness (the trace needs SA_COLS columns)."""
+    n = witness.num_instances - first_instance if n_instances is None else n_instances
+    _check(load().zkw_storage_application_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+
+def _ctx_check_if_satisfied_storage_application(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_storage_application_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+Context.synthesize_storage_application = _ctx_synthesize_storage_application
+Context.check_if_satisfied_storage_application = _ctx_check_if_satisfied_storage_application
 Context.check_if_satisfied_code_decommitter = _ctx_check_if_satisfied_code_decommitter
 Context.synthesize_sha256_round_function = _ctx_synthesize_sha256_round_function
 Context.check_if_satisfied_sha256_round_function = _ctx_check_if_satisfied_sha256_round_function
@@ -1660,7 +1683,7 @@ class Block:
     CHECKERS = {8: "zkw_ram_check_satisfied", 2: "zkw_decommit_sorter_check_satisfied", 4: "zkw_log_demux_check_satisfied",
                 9: "zkw_storage_sorter_check_satisfied", 11: "zkw_events_sorter_check_satisfied", 12: "zkw_events_sorter_check_satisfied",
                 5: "zkw_keccak_round_check_satisfied", 13: "zkw_linear_hasher_check_satisfied", 6: "zkw_sha256_round_check_satisfied",
-                3: "zkw_code_decommitter_check_satisfied"}
+                3: "zkw_code_decommitter_check_satisfied", 10: "zkw_storage_application_check_satisfied"}
 
     def check_satisfied(self, circuit_type, trace_handle, slot):
         """check_if_satisfied (src/tests/mod.rs:130-259) on a slot handed to a synthesize callback: (n_violations, first_bad)"""

@@ -584,6 +584,21 @@ int zkw_code_decommitter_synthesize(zkw_ctx *ctx, zkw_decommitter_witness *w, si
 int zkw_code_decommitter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                                          uint64_t *n_violations, uint64_t *first_bad);
 
+/* ---- StorageApplication circuit (type 10) ----------------------------------------------------------------
+   ZkSyncBaseLayerCircuit::synthesis for the storage application (wrapper circuit_definitions/src/circuit_definitions/
+   base_layer/storage_apply.rs:28-39: 60 + 3 x 26 columns; :124-140: Xor8, And8, ByteSplit<1, 2, 3, 4, 7> = 132 352 table rows =
+   vk_10.json's total_tables_len; 2^20 rows, capacity 33 tree queries). Trace "zkw trace v4",
+   include/zkw_storage_application_circuit_spec.h: the Merkle walks of the instance's tree queries — a read is one walk, a write
+   two (old leaf, new leaf), src/witness/individual_circuits/storage_application.rs:141-153 — as Blake2s-256 compressions on
+   bytes, one cycle per compression, SA_CYCLES_PER_WALK = 257 cycles per walk (leaf hash, 256 levels; the key is shifted
+   through the cycle state and its low bit picks the sibling's side), idle cycles beyond the instance's walks;
+   122 rows per cycle = 33 walks in 2^20 rows. w: the witness of zkw_storage_application_build (its capacity). The public
+   input is the instance's closed-form commitment (a20). n_rows >= 2^18 (the tables' 132 352 rows). */
+int zkw_storage_application_synthesize(zkw_ctx *ctx, zkw_storage_application_witness *w, size_t first_instance,
+                                       size_t n_instances, zkw_trace *t, size_t first_slot);
+int zkw_storage_application_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
+                                            uint64_t *n_violations, uint64_t *first_bad);
+
 /* ---- LinearHasher circuit (type 13) ---------------------------------------------------------------------
    ZkSyncBaseLayerCircuit::synthesis for the L1-messages hasher (wrapper base_layer/linear_hasher.rs:28-138, witness
    compute_linear_keccak256 data_hasher_and_merklizer.rs:8-67): the Keccak-f netlist of the type-5 trace over the sponge that

@@ -15,11 +15,13 @@
 #include "../include/zkw_code_decommitter_circuit_spec.h"
 #include "../include/zkw_keccak_circuit_spec.h"
 #include "../include/zkw_linear_hasher_circuit_spec.h"
+#include "../include/zkw_storage_application_circuit_spec.h"
 
 NL_DEFINE_SPEC(sc, SC);
 NL_DEFINE_SPEC(dc, DC);
 NL_DEFINE_SPEC(kc, KC);
 NL_DEFINE_SPEC(lh, LH);
+NL_DEFINE_SPEC(sa, SA);
 
 const nl_spec *orc_nl_spec(int circuit_type) {
     switch (circuit_type) {
@@ -27,6 +29,7 @@ const nl_spec *orc_nl_spec(int circuit_type) {
         case 3: return &dc_spec;
         case 5: return &kc_spec;
         case 13: return &lh_spec;
+        case 10: return &sa_spec;
         default: return NULL;
     }
 }
@@ -413,4 +416,70 @@ void orc_nl_slots_per_cycle(int circuit_type, uint32_t *out) {
     *out = 0;
     if (!sp) return;
     for (uint32_t s = 0; s < sp->steps_per_cycle; s++) *out += sp->step_types[sp->cycle[s].type].n_ops;
+}
+
+/* ---- StorageApplication (type 10): the Merkle walks of an instance's tree queries as cycles of the Blake2s netlist
+   (tools/gen_storage_application_circuit.py). A read is one walk, a write two — the old leaf's path, then the new leaf's
+   (src/witness/individual_circuits/storage_application.rs:141-153, 216-247); a walk = leaf hash (tree/mod.rs:322-329) + 256
+   node hashes (:394-402) with the sibling on the side the key's bit names (:187-217). items: the instance's queries; keys /
+   paths / read_indexes: their rows of orc_storage_application_build's outputs; next_enumeration_index: before the instance
+   (a first write takes the next one, tree/mod.rs:305-313). capacity in walks. */
+void orc_blake2s256(const uint8_t *msg, size_t len, uint8_t out[32]);
+int orc_storage_application_synthesize(const zkw_log_query *items, size_t n_items, const uint8_t *keys, const uint8_t *paths,
+                                       const uint64_t *read_indexes, uint64_t next_enumeration_index, uint32_t capacity,
+                                       const uint64_t pi[4], size_t n_rows, uint64_t *trace) {
+    const uint32_t cycles = capacity * SA_CYCLES_PER_WALK;
+    uint8_t *hdr = calloc(cycles, 1), *fr = calloc((size_t)cycles * SA_FREE_PER_CYCLE + 1, 1), *st = calloc((size_t)(cycles + 1) * SA_STATE, 1);
+    uint32_t c = 0;
+    int rc = 0;
+    for (size_t i = 0; i < n_items && rc == 0; i++) {
+        const zkw_log_query *q = &items[i];
+        const uint8_t *key = keys + 32 * i;
+        uint64_t write_index = read_indexes[i];
+        if (q->rw_flag && write_index == 0) write_index = next_enumeration_index++;
+        for (int phase = 0; phase < (q->rw_flag ? 2 : 1); phase++) {
+            if (c + SA_CYCLES_PER_WALK > cycles) { rc = -10; break; } /* more walks than the capacity */
+            const uint64_t index = phase ? write_index : read_indexes[i];
+            const uint32_t *val = phase ? q->written_value : q->read_value;
+            uint8_t msg[64] = {0}, cur[32], key33[33] = {0};
+            for (int b = 0; b < 8; b++) msg[b] = (uint8_t)(index >> (8 * (7 - b)));
+            for (int b = 0; b < 32; b++) msg[8 + b] = (uint8_t)(val[(31 - b) / 4] >> (8 * ((31 - b) % 4))); /* big-endian U256 */
+            for (int b = 0; b < 257; b++) /* key << 1 */
+                if (b && ((key[(b - 1) / 8] >> ((b - 1) % 8)) & 1)) key33[b / 8] |= (uint8_t)(1u << (b % 8));
+            /* the leaf cycle */
+            hdr[c] = 1;
+            memcpy(fr + (size_t)c * SA_FREE_PER_CYCLE + SA_FREE_X, msg, 32);
+            memcpy(fr + (size_t)c * SA_FREE_PER_CYCLE + SA_FREE_Y, msg + 32, 32);
+            memcpy(fr + (size_t)c * SA_FREE_PER_CYCLE + SA_FREE_KEY, key33, 33);
+            orc_blake2s256(msg, 40, cur);
+            for (int level = 0; level <= 256; level++) {
+                /* state after cycle c: the running hash, the key shifted once more */
+                uint8_t *nx = st + (size_t)(c + 1) * SA_STATE;
+                memcpy(nx, cur, 32);
+                for (int b = 0; b < 32; b++) key33[b] = (uint8_t)((key33[b] >> 1) | (key33[b + 1] << 7));
+                key33[32] >>= 1;
+                memcpy(nx + 32, key33, 33);
+                c++;
+                if (level == 256) break;
+                const uint8_t *sib = paths + ((size_t)i * 256 + level) * 32;
+                const int right = (key[level / 8] >> (level % 8)) & 1;
+                uint8_t buf[64];
+                memcpy(buf, right ? sib : cur, 32);
+                memcpy(buf + 32, right ? cur : sib, 32);
+                orc_blake2s256(buf, 64, cur);
+                hdr[c] = 0;
+                memcpy(fr + (size_t)c * SA_FREE_PER_CYCLE + SA_FREE_Y, sib, 32);
+            }
+        }
+    }
+    for (; c < cycles; c++) { /* padding cycles carry the hash; the key is zero by now */
+        hdr[c] = 2;
+        memcpy(st + (size_t)(c + 1) * SA_STATE, st + (size_t)c * SA_STATE, SA_STATE);
+    }
+    if (rc == 0) rc = orc_nl_synthesize(&sa_spec, cycles, hdr, fr, st, pi, n_rows, trace);
+    free(hdr); free(fr); free(st);
+    return rc;
+}
+uint64_t orc_storage_application_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
+    return orc_nl_check(&sa_spec, trace, capacity * SA_CYCLES_PER_WALK, n_rows, first_bad);
 }

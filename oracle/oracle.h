@@ -242,7 +242,7 @@ int64_t orc_precompile_build_ex(int kind, const zkw_log_query *requests, const u
                                 zkw_keccak_round_record *keccak_rounds);
 /* ---- the netlist circuits ("zkw trace v4", include/zkw_netlist.h), netlist_circuit.c: one fill, one checker, four specs */
 #include "../include/zkw_netlist.h"
-const nl_spec *orc_nl_spec(int circuit_type); /* 6, 3, 5, 13 */
+const nl_spec *orc_nl_spec(int circuit_type); /* 6, 3, 5, 13, 10 */
 int orc_nl_synthesize(const nl_spec *sp, uint32_t capacity, const uint8_t *hdr_bits, const uint8_t *free_elems, const uint8_t *state_before,
                       const uint64_t pi[4], size_t n_rows, uint64_t *trace);
 uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
@@ -264,6 +264,10 @@ void orc_decommitter_set_sha256_rounds(zkw_sha256_round_record *r);
 int orc_code_decommitter_round_synthesize(const uint8_t state_in[32], const zkw_sha256_round_record *rounds, uint32_t n_active,
                                           uint32_t capacity, const uint64_t pi[4], size_t n_rows, uint64_t *trace);
 uint64_t orc_code_decommitter_round_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+int orc_storage_application_synthesize(const zkw_log_query *items, size_t n_items, const uint8_t *keys, const uint8_t *paths,
+                                       const uint64_t *read_indexes, uint64_t next_enumeration_index, uint32_t capacity,
+                                       const uint64_t pi[4], size_t n_rows, uint64_t *trace);
+uint64_t orc_storage_application_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 size_t orc_linear_hasher_rounds(const zkw_log_query *q, size_t n, zkw_keccak_round_record *records);
 
 /* ---- callstack (a3 / a6), see callstack.c */

@@ -676,10 +676,10 @@ def nl_slots_per_cycle(circuit_type):
 
 
 def __getattr__(name):  # SC_COLS, KC_ROWS_PER_CYCLE, ...: read from the compiled specs, not restated here
-    m = re.fullmatch(r"(SC|DC|KC|LH)_(COLS|ROWS_PER_CYCLE)", name)
+    m = re.fullmatch(r"(SC|DC|KC|LH|SA)_(COLS|ROWS_PER_CYCLE)", name)
     if not m:
         raise AttributeError(name)
-    g = nl_geometry({"SC": 6, "DC": 3, "KC": 5, "LH": 13}[m.group(1)])
+    g = nl_geometry({"SC": 6, "DC": 3, "KC": 5, "LH": 13, "SA": 10}[m.group(1)])
     return g["cols"] if m.group(2) == "COLS" else g["rows_per_cycle"]
 
 
@@ -879,6 +879,42 @@ def storage_application_build(tree, queries, query_tails, capacity):
         raise RuntimeError(f"orc_storage_application_build failed: {rc}")
     o["instances"] = o["instances"][:rc]
     return o
+
+
+SA_CYCLES_PER_WALK = 257
+
+
+def storage_application_synthesize(build_out, queries, instance_index, capacity, n_rows, public_input=None):
+    """Fill the StorageApplication trace ("zkw trace v4": Blake2s Merkle walks, tools/gen_storage_application_circuit.py) of one
+    instance from the outputs of storage_application_build: one walk per read, two per write, idle cycles up to `capacity` walks."""
+    inst = build_out["instances"][instance_index]
+    first, n = int(inst["first_item"]), int(inst["num_items"])
+    q = np.ascontiguousarray(np.asarray(queries, dtype=LOG_QUERY)[first:first + n])
+    keys = np.ascontiguousarray(build_out["derived_keys"][first:first + n])
+    paths = np.ascontiguousarray(build_out["merkle_paths"][first:first + n])
+    idx = np.ascontiguousarray(build_out["leaf_indexes"][first:first + n])
+    ctr = inst["initial_next_enumeration_counter"] if inst["start_flag"] else inst["hidden_fsm_input"]["next_enumeration_counter"]
+    next_index = int(ctr[0]) | (int(ctr[1]) << 32)
+    pi = np.ascontiguousarray(public_input if public_input is not None else
+                              closed_form_public_inputs(10, build_out["instances"])[1][instance_index], dtype=np.uint64)
+    trace = np.zeros((nl_geometry(10)["cols"], n_rows), np.uint64)
+    f = lib().orc_storage_application_synthesize
+    f.restype = C.c_int
+    rc = f(_p(q) if n else None, C.c_size_t(n), _p(keys) if n else None, _p(paths) if n else None, _p(idx) if n else None,
+           C.c_uint64(next_index), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_storage_application_synthesize failed: {rc}")
+    return trace
+
+
+def storage_application_check(trace, capacity):
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_storage_application_check
+    f.restype = C.c_uint64
+    bad = f(_p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value
+    return bad, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
 DS_COLS = 149

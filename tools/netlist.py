@@ -74,6 +74,11 @@ def keccak_tables():
            [Table(f"BYTESPLIT_{k}", FN_BYTESPLIT, k, 1, 8, 2) for k in (1, 2, 3, 4)]
 
 
+def storage_tables():
+    """storage_apply.rs:124-140: the Keccak set + ByteSplit<7> = 132 352 rows (`total_tables_len` of vk_10.json)"""
+    return keccak_tables() + [Table("BYTESPLIT_7", FN_BYTESPLIT, 7, 1, 8, 2)]
+
+
 class Val:
     """a value produced inside a step: output `slot` of lookup `item`, NEW cell `slot` of gate `item`, or hint `item`"""
     __slots__ = ("kind", "item", "slot", "index")
