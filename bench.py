@@ -248,6 +248,18 @@ def hash_circuits_gpu(local_rank, blk):
                                      "queue is serial, ~4.5 ms whatever the batch",
                                 single_queue_ms_per_call=timed(1, lambda: ctx.synthesize_linear_hasher(queues[0], states[:1], 774, t, 0))["ms_per_call"])
     t.free()
+    # StorageApplication (type 10): Blake2s Merkle walks, 33 tree queries (8 481 cycles) per instance
+    sq, _existing = synthetic.storage_application_trace(200, seed=4, write_fraction=0.6)
+    stails = ctx.queue_push_chain_log(ctx.encode_log_queries(sq))[1]
+    tree, answers = synthetic.storage_tree_for(sq, seed=1)
+    idx, paths = answers(sq)
+    w = ctx.decompose_into_storage_application_witnesses(sq, stails, idx, paths, tree.root, tree.next_enumeration_index, 33)
+    n = min(8, w.num_instances)
+    t = native.Trace(ctx, n_rows, n, n_cols=native.SA_COLS)
+    out["storage_application"] = dict(timed(n, lambda: ctx.synthesize_storage_application(w, t, 0, n, 0)), capacity=33, columns=native.SA_COLS,
+                                      trace_bytes=native.SA_COLS * n_rows * 8, cycles_per_instance=33 * native.SA_CYCLES_PER_WALK)
+    t.free()
+    w.free()
     ctx.close()
     return out
 
@@ -261,11 +273,21 @@ def full_block_cpu(blk, threads):
     from oracle import block as ob, pyoracle
 
     pyoracle.build()
+    # untimed, like the GPU leg's first block: the deduplicated storage queries, for the tree that holds the pre-block state
+    # (the same leaves as synthetic.storage_tree_for(dedup, seed=1), in the oracle's tree)
+    dedup = ob.create_artifacts_after_vm(blk)["witnesses"]["storage_sorter"]["result_q"]
+    tree = pyoracle.Tree()
+    rng = np.random.default_rng(1)
+    for _ in range(10):
+        tree.insert_leaf(rng.bytes(32), rng.bytes(32))
+    for q in dedup:
+        if q["read_value"].any():
+            tree.insert_leaf(pyoracle.derive_final_address(q), b"".join(int(x).to_bytes(4, "big") for x in q["read_value"][::-1]))
     timings = {}
     t0 = time.perf_counter()
-    a = ob.create_artifacts_after_vm(blk, timings=timings)
+    a = ob.create_artifacts_after_vm(blk, storage_tree=tree, timings=timings)
     t1 = time.perf_counter()
-    jobs = [(ct, i) for ct in ob.EMISSION_ORDER for i in range(a["witnesses"][ob.SYNTH[ct][0]]["instances"].size)]
+    jobs = [(ct, i) for ct in ob.EMISSION_ORDER if ob.SYNTH[ct][0] in a["witnesses"] for i in range(a["witnesses"][ob.SYNTH[ct][0]]["instances"].size)]
 
     def synth(job):
         ct, i = job
@@ -282,8 +304,8 @@ def full_block_cpu(blk, threads):
             "wall_concurrent_ms": (conc_s + (t2 - t1)) * 1e3,
             "kind": "port", "instances_synthesized": len(jobs), "instances_in_block": 17,
             "builders_s": {k: round(v, 3) for k, v in timings.items()},
-            "sample": "the same block: builders sequential on 1 thread (reference order), %d instances synthesized on %d threads; "
-                      "no StorageApplication on the CPU side (its tree walk is host work on both sides)" % (len(jobs), threads)}
+            "sample": "the same block: builders sequential on 1 thread (reference order, incl. the storage application over the "
+                      "oracle's tree), %d instances synthesized on %d threads" % (len(jobs), threads)}
 
 
 def main():

@@ -140,6 +140,7 @@ def create_artifacts_after_vm(block, capacities=None, storage_tree=None, timings
     if storage_tree is not None:
         sap = timed("storage_application", o.storage_application_build, storage_tree, sto["result_q"],
                     sto["result_new_tails"], cap[STORAGE_APPLICATION])
+        sap["queries"] = sto["result_q"]  # the instances' tree queries (a read = one Merkle walk, a write = two)
         art["storage_application"] = sap
         pis[STORAGE_APPLICATION] = o.closed_form_public_inputs(STORAGE_APPLICATION, sap["instances"])[1]
     recursion = {t: o.recursion_queue(t, p) for t, p in pis.items()}
@@ -151,21 +152,28 @@ def _linear_hasher_synthesize(w, i, capacity, n_rows):
     return o.linear_hasher_synthesize(w["messages"], w["instances"]["queue_state"][0], capacity, n_rows)[0]
 
 
-SYNTH = {LOG_DEMUXER: ("log_demuxer", o.log_demux_synthesize), RAM_PERMUTATION: ("ram_permutation", o.ram_synthesize),
+def _storage_application_synthesize(w, i, capacity, n_rows):
+    return o.storage_application_synthesize(w, w["queries"], i, capacity, n_rows)
+
+
+SYNTH = {STORAGE_APPLICATION: ("storage_application", _storage_application_synthesize), LOG_DEMUXER: ("log_demuxer", o.log_demux_synthesize), RAM_PERMUTATION: ("ram_permutation", o.ram_synthesize),
          DECOMMITS_SORTER: ("decommits_sorter", o.decommit_sorter_synthesize), STORAGE_SORTER: ("storage_sorter", o.storage_sorter_synthesize),
          EVENTS_SORTER: ("events_sorter", o.events_sorter_synthesize), L1_MESSAGES_SORTER: ("l1_messages_sorter", o.events_sorter_synthesize),
          CODE_DECOMMITTER: ("code_decommitter", o.code_decommitter_synthesize), KECCAK256: ("keccak256", o.keccak_round_synthesize), SHA256: ("sha256", o.sha256_round_synthesize), L1_MESSAGES_HASHER: ("l1_messages_hasher", _linear_hasher_synthesize)}
-# oracle.rs:975-984 demuxer, :1039-1049 RAM, then CircuitMaker order :1494-1732 (the types that have a synthesis here)
-EMISSION_ORDER = (LOG_DEMUXER, RAM_PERMUTATION, DECOMMITS_SORTER, CODE_DECOMMITTER, KECCAK256, SHA256, STORAGE_SORTER, EVENTS_SORTER, L1_MESSAGES_SORTER,
+# oracle.rs:975-984 demuxer, :1039-1049 RAM, :1115-1130 storage application (when the block has a storage tree), then CircuitMaker
+# order :1494-1732 (the types that have a synthesis here)
+EMISSION_ORDER = (LOG_DEMUXER, RAM_PERMUTATION, STORAGE_APPLICATION, DECOMMITS_SORTER, CODE_DECOMMITTER, KECCAK256, SHA256, STORAGE_SORTER, EVENTS_SORTER, L1_MESSAGES_SORTER,
                   L1_MESSAGES_HASHER)
 
 
 def synthesize_all(artifacts, n_rows, on_trace=None):
-    """ZkSyncBaseLayerCircuit::synthesis of every instance of the ten synthesized types in emission order; returns the
+    """ZkSyncBaseLayerCircuit::synthesis of every instance of the eleven synthesized types in emission order; returns the
     number of instances. on_trace(circuit_type, instance, trace) is called with each filled trace."""
     done = 0
     for ctype in EMISSION_ORDER:
         key, fn = SYNTH[ctype]
+        if key not in artifacts["witnesses"]:
+            continue  # (no storage tree: no storage application)
         w = artifacts["witnesses"][key]
         for i in range(w["instances"].size):
             t = fn(w, i, artifacts["capacities"][ctype], n_rows)

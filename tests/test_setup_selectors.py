@@ -16,7 +16,7 @@ def _tables(ctype):
         return {1: (3, lambda a, b, c: [a ^ b ^ c]), 2: (3, lambda e, f, g: [(e & f) ^ (~e & g & 15)]),
                 3: (3, lambda a, b, c: [(a & b) ^ (a & c) ^ (b & c)]), 4: sp(1), 5: sp(2)}
     bs = lambda k: (1, lambda a: [a & ((1 << k) - 1), a >> k])  # noqa: E731
-    return {1: (2, lambda a, b: [a ^ b]), 2: (2, lambda a, b: [a & b]), 3: bs(1), 4: bs(2), 5: bs(3), 6: bs(4)}  # Xor8, And8, ByteSplit<1..4>
+    return {1: (2, lambda a, b: [a ^ b]), 2: (2, lambda a, b: [a & b]), 3: bs(1), 4: bs(2), 5: bs(3), 6: bs(4), 7: bs(7)}  # Xor8, And8, ByteSplit<1..4> (+ <7>: type 10)
 
 
 def _netlist_cases(oracle):
@@ -32,6 +32,10 @@ def _netlist_cases(oracle):
     out.append((3, 7, oracle.code_decommitter_synthesize(a["witnesses"]["code_decommitter"], 1, 7, N_ROWS)) + geo(3))
     q = synthetic.mixed_log_queue(36, seed=8)[:7]
     out.append((13, 20, oracle.linear_hasher_synthesize(q, np.zeros(1, oracle.QUEUE_STATE4), 20, N_ROWS)[0]) + geo(13))
+    from sap_case import storage_application_case
+    sq, tails, tree, _idx, _paths = storage_application_case(oracle, 5, seed=9)
+    sap = oracle.storage_application_build(tree, sq, tails, 3)
+    out.append((10, 3, oracle.storage_application_synthesize(sap, sq, 1, 3, N_ROWS)) + geo(10))
     return out
 
 
@@ -43,8 +47,8 @@ def test_netlist_selectors_name_the_tables_of_their_rows(oracle):
         body = trace[:col0 + width * lpr]
         assert not body[:, sel == nv.ROW_PADDING].any(), ctype
         hdr = sel == nv.ROW_HEADER
-        cycles = nv.linear_hasher_cycles(cap) if ctype == 13 else cap
-        steps = {3: 3, 6: 3, 5: 26, 13: 26}[ctype]  # every step of a cycle starts with a header row (SHA-256: a compression in three steps)
+        cycles = nv.linear_hasher_cycles(cap) if ctype == 13 else cap * nv.SA_CYCLES_PER_WALK if ctype == 10 else cap
+        steps = {3: 3, 6: 3, 5: 26, 13: 26, 10: 1}[ctype]  # every step of a cycle starts with a header row (SHA-256: a compression in three steps)
         assert int(hdr.sum()) == cycles * steps
         assert not body[col0:, hdr].any()
         lookups = (sel < nv.ROW_HEADER) & ((sel & 0x3F) != 0)

@@ -54,14 +54,14 @@ def test_sigma_is_the_link_structure(oracle):
 
 
 def test_sigma_of_the_netlist_circuits(oracle):
-    """types 5, 13, 6, 3: the classes come from the netlists' operand references — traces satisfy sigma, a bumped cell of a
+    """types 5, 13, 6, 3, 10: the classes come from the netlists' operand references — traces satisfy sigma, a bumped cell of a
     cycle is a copy violation (kind 2) or a broken relation (kind 1 / 7) for the oracle's checker, a free witness byte is in
     no cycle"""
     from tests.test_setup_selectors import _netlist_cases
 
     rng = np.random.default_rng(2)
     checks = {5: oracle.keccak_round_check, 13: lambda t, c: oracle.linear_hasher_check(t, oracle.linear_hasher_cycles(c)),
-              6: oracle.sha256_round_check, 3: oracle.code_decommitter_check}
+              6: oracle.sha256_round_check, 3: oracle.code_decommitter_check, 10: oracle.storage_application_check}
     n_rows = 1 << 18
     for ctype, cap, trace, col0, width, lpr in _netlist_cases(oracle):
         sigma = nv.setup_copy_permutation(ctype, cap, n_rows)

@@ -35,3 +35,19 @@ ctx.synthesize_linear_hasher_batch(queues, st, 774, t8, 0); ctx.synchronize()
 ctx.profile_reset()
 t0 = time.perf_counter(); ctx.synthesize_linear_hasher_batch(queues, st, 774, t8, 0); ctx.synchronize(); dt = time.perf_counter() - t0
 print("linear hasher, 8 queues per call", f"{dt*1e3:.2f} ms = {8/dt:.0f} circuits/s", {k: round(v[0], 3) for k, v in ctx.profile().items()})
+# StorageApplication (type 10): 8 instances of 33 tree queries each (Blake2s Merkle walks, 8 481 cycles per instance)
+ctx.profile_enable(False)
+sq, _existing = synthetic.storage_application_trace(200, seed=4, write_fraction=0.6)
+stails = ctx.queue_push_chain_log(ctx.encode_log_queries(sq))[1]
+tree, answers = synthetic.storage_tree_for(sq, seed=1)
+idx, paths = answers(sq)
+w = ctx.decompose_into_storage_application_witnesses(sq, stails, idx, paths, tree.root, tree.next_enumeration_index, 33)
+n = min(8, w.num_instances)
+t = native.Trace(ctx, n_rows, n, n_cols=native.SA_COLS)
+ctx.synthesize_storage_application(w, t, 0, n, 0); ctx.synchronize()
+ctx.profile_enable(True); ctx.profile_reset()
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter(); ctx.synthesize_storage_application(w, t, 0, n, 0); ctx.synchronize(); best = min(best, time.perf_counter() - t0)
+print("storage application", f"{n} instances {best*1e3:.2f} ms = {n/best:.0f} circuits/s", {k: round(v[0] / 3, 3) for k, v in ctx.profile().items()})
+assert all(ctx.check_if_satisfied_storage_application(t, i, 33)[0] == 0 for i in range(n))
