@@ -449,79 +449,96 @@ __device__ __forceinline__ u32 sap_key_bits(const u32* __restrict__ kw, int o) {
     return r;
 }
 
-static __global__ __launch_bounds__(256) void k_sap_walk_prepare(const SapWalkJob* __restrict__ jobs, u32 capacity) {
+// the walks of an instance, in order: (item, 0 = the path of the leaf as read / 1 = of the leaf as written)
+__device__ __forceinline__ u32 sap_walk_list(const SapWalkJob& j, u32 capacity, u32* item, uint8_t* phase) {
+    u32 nw = 0;
+    for (u64 k = 0; k < j.num_items && nw < capacity; k++) {
+        const u64 i = j.first_item + k;
+        item[nw] = (u32)i; phase[nw++] = 0;
+        if (j.items[i].rw && nw < capacity) { item[nw] = (u32)i; phase[nw++] = 1; }
+    }
+    return nw;
+}
+
+// 1. the hash chains: one lane per walk (257 dependent Blake2s compressions), the running hash AFTER cycle c goes to
+//    state_before[c + 1]. grid = (instances), 64 lanes per workgroup walk the instance's <= capacity walks.
+static __global__ __launch_bounds__(64) void k_sap_walk_chains(const SapWalkJob* __restrict__ jobs, u32 capacity) {
     __shared__ u32 s_item[SAP_WALK_MAX];
     __shared__ uint8_t s_phase[SAP_WALK_MAX];
     __shared__ u32 s_nw;
     const SapWalkJob j = jobs[blockIdx.x];
-    const u32 t = threadIdx.x, cycles = capacity * SAP_WALK_CYCLES;
-    if (t == 0) {
-        u32 nw = 0;
-        for (u64 k = 0; k < j.num_items && nw < capacity; k++) {
-            const u64 i = j.first_item + k;
-            s_item[nw] = (u32)i; s_phase[nw++] = 0;
-            if (j.items[i].rw && nw < capacity) { s_item[nw] = (u32)i; s_phase[nw++] = 1; }
-        }
-        s_nw = nw;
-    }
+    if (threadIdx.x == 0) s_nw = sap_walk_list(j, capacity, s_item, s_phase);
     __syncthreads();
-    const u32 nw = s_nw;
-    // the hash chains: one lane per walk, the running hash AFTER cycle c goes to state_before[c + 1]
-    for (u32 w = t; w < nw; w += blockDim.x) {
+    for (u32 w = threadIdx.x; w < s_nw; w += blockDim.x) {
         const SapItem& it = j.items[s_item[w]];
         const u32* kw = j.keys + 8 * (u64)s_item[w];
-        u32 cur[8];
+        u32 key[8], cur[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) key[k] = kw[k];
         if (s_phase[w]) sap_leaf_hash(it.write_index, it.written_value, cur); else sap_leaf_hash(it.read_index, it.read_value, cur);
         uint8_t* st = j.state_before + ((size_t)w * SAP_WALK_CYCLES + 1) * SAP_WALK_STATE;
         sap_bytes32(st, cur);
-        for (int L = 0; L < 256; L++) {
-            const u32* sib = j.paths + ((u64)s_item[w] * 256 + L) * 8;
+        const u32* sib = j.paths + (u64)s_item[w] * 256 * 8;
+        for (int L = 0; L < 256; L++, sib += 8) {
             u32 s[8], o[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) s[k] = sib[k];
-            if ((kw[L >> 5] >> (L & 31)) & 1) sap_node_hash(s, cur, o); else sap_node_hash(cur, s, o);
+            if ((key[L >> 5] >> (L & 31)) & 1) sap_node_hash(s, cur, o); else sap_node_hash(cur, s, o);
 #pragma unroll
             for (int k = 0; k < 8; k++) cur[k] = o[k];
             st += SAP_WALK_STATE;
             sap_bytes32(st, cur);
         }
     }
-    __threadfence_block();
+}
+
+// 2. everything else, a cycle per thread: the header bit, the free elements, the key part of the state before the cycle, and —
+//    outside the walks — its hash part (the last walk's root in the padding cycles, zero before cycle 0).
+//    grid = (ceil((cycles + 1) / 256), instances)
+static __global__ __launch_bounds__(256) void k_sap_walk_cycles(const SapWalkJob* __restrict__ jobs, u32 capacity) {
+    __shared__ u32 s_item[SAP_WALK_MAX];
+    __shared__ uint8_t s_phase[SAP_WALK_MAX];
+    __shared__ u32 s_nw;
+    const SapWalkJob j = jobs[blockIdx.y];
+    if (threadIdx.x == 0) s_nw = sap_walk_list(j, capacity, s_item, s_phase);
     __syncthreads();
-    // everything else, a byte per thread and step: header bits, free elements, the key part of the states, the hash of the
-    // padding cycles (= the last walk's root) and of the state before cycle 0 (zero)
-    const u32 active = nw * SAP_WALK_CYCLES;
-    for (u32 c = t; c < cycles; c += blockDim.x) j.hdr_bits[c] = c >= active ? 2 : (c % SAP_WALK_CYCLES == 0 ? 1 : 0);
-    for (size_t e = t; e < (size_t)cycles * SAP_WALK_FREE; e += blockDim.x) {
-        const u32 c = (u32)(e / SAP_WALK_FREE), f = (u32)(e % SAP_WALK_FREE);
-        uint8_t v = 0;
-        if (c < active) {
-            const u32 w = c / SAP_WALK_CYCLES, i = c % SAP_WALK_CYCLES;
-            const SapItem& it = j.items[s_item[w]];
-            if (i == 0) {
-                if (f < 64) {  // index_be (8) || value_be (32) || zeros
-                    const u64 idx = s_phase[w] ? it.write_index : it.read_index;
-                    const u32* val = s_phase[w] ? it.written_value : it.read_value;
-                    if (f < 8) v = (uint8_t)(idx >> (8 * (7 - f)));
-                    else if (f < 40) { const u32 b = 31 - (f - 8); v = (uint8_t)(val[b >> 2] >> (8 * (b & 3))); }
-                } else v = (uint8_t)sap_key_bits(j.keys + 8 * (u64)s_item[w], 8 * (int)(f - 64) - 1);  // the key << 1, 33 bytes
-            } else if (f >= 32 && f < 64) {
-                const u32 x = j.paths[((u64)s_item[w] * 256 + (i - 1)) * 8 + ((f - 32) >> 2)];
-                v = (uint8_t)(x >> (8 * (f & 3)));
-            }
+    const u32 cycles = capacity * SAP_WALK_CYCLES, active = s_nw * SAP_WALK_CYCLES;
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > cycles) return;
+    uint8_t* st = j.state_before + (size_t)c * SAP_WALK_STATE;
+    const u32 w = c / SAP_WALK_CYCLES, i = c % SAP_WALK_CYCLES;
+    const bool in_walk = c < active;
+    u32 key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (in_walk) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) key[k] = j.keys[8 * (u64)s_item[w] + k];
+    }
+    // key part of the state: (key << 1) >> i before cycle i >= 1 of a walk, zero before a leaf cycle and in the padding
+    for (u32 k = 0; k < 33; k++) st[32 + k] = (in_walk && i) ? (uint8_t)sap_key_bits(key, (int)i + 8 * (int)k - 1) : 0;
+    if (c >= active || c == 0) {  // hash part outside the walks (the chains write [1, active])
+        if (c > active || c == 0) {
+            const uint8_t* root = j.state_before + (size_t)active * SAP_WALK_STATE;
+            for (u32 k = 0; k < 32; k++) st[k] = (c && active) ? root[k] : 0;
         }
-        j.free_elems[e] = v;
     }
-    for (size_t e = t; e < (size_t)(cycles + 1) * 33; e += blockDim.x) {  // key part: (key << 1) >> i before cycle i of a walk, i >= 1
-        const u32 c = (u32)(e / 33), k = (u32)(e % 33);
-        uint8_t v = 0;
-        if (c < active && c % SAP_WALK_CYCLES) v = (uint8_t)sap_key_bits(j.keys + 8 * (u64)s_item[c / SAP_WALK_CYCLES], (int)(c % SAP_WALK_CYCLES) + 8 * (int)k - 1);
-        j.state_before[(size_t)c * SAP_WALK_STATE + 32 + k] = v;
-    }
-    for (size_t e = t; e < (size_t)(cycles + 1 - active) * 32; e += blockDim.x) {  // hash part outside the walks
-        const u32 c = (u32)(e / 32), k = (u32)(e % 32);
-        if (c == 0) j.state_before[k] = 0;  // (the state before cycle 0)
-        else j.state_before[(size_t)(active + c) * SAP_WALK_STATE + k] = active ? j.state_before[(size_t)active * SAP_WALK_STATE + k] : 0;
+    if (c == cycles) return;
+    j.hdr_bits[c] = in_walk ? (i == 0 ? 1 : 0) : 2;
+    uint8_t* fr = j.free_elems + (size_t)c * SAP_WALK_FREE;
+    if (!in_walk) {
+        for (u32 f = 0; f < SAP_WALK_FREE; f++) fr[f] = 0;
+    } else if (i == 0) {  // the leaf cycle: index_be (8) || value_be (32) || zeros, then the key << 1 (33 bytes)
+        const SapItem& it = j.items[s_item[w]];
+        const u64 idx = s_phase[w] ? it.write_index : it.read_index;
+        const u32* val = s_phase[w] ? it.written_value : it.read_value;
+        for (u32 f = 0; f < 8; f++) fr[f] = (uint8_t)(idx >> (8 * (7 - f)));
+        for (u32 f = 8; f < 40; f++) { const u32 b = 31 - (f - 8); fr[f] = (uint8_t)(val[b >> 2] >> (8 * (b & 3))); }
+        for (u32 f = 40; f < 64; f++) fr[f] = 0;
+        for (u32 k = 0; k < 33; k++) fr[64 + k] = (uint8_t)sap_key_bits(key, 8 * (int)k - 1);
+    } else {  // a level cycle: the sibling
+        const u32* sib = j.paths + ((u64)s_item[w] * 256 + (i - 1)) * 8;
+        for (u32 f = 0; f < 32; f++) fr[f] = 0;
+        for (u32 k = 0; k < 8; k++) { const u32 x = sib[k]; for (u32 b = 0; b < 4; b++) fr[32 + 4 * k + b] = (uint8_t)(x >> (8 * b)); }
+        for (u32 f = 64; f < SAP_WALK_FREE; f++) fr[f] = 0;
     }
 }
 

@@ -961,8 +961,10 @@ extern "C" int zkw_storage_application_synthesize(zkw_ctx* ctx, zkw_storage_appl
             jobs[k] = SapWalkJob{w->items, w->keys, w->paths, w->n ? prep[k].first_round : 0, w->n ? prep[k].n_active : 0, prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
         SapWalkJob* d_jobs = nullptr;
         ZKW_TRY(ctx->upload("sap_walk_jobs", jobs, &d_jobs));
-        { Prof _p(ctx, "k_sap_walk_prepare"); hipLaunchKernelGGL(k_sap_walk_prepare, dim3((unsigned)jobs.size()), dim3(256), 0, ctx->stream, d_jobs, capacity); }
-        return launch_check("k_sap_walk_prepare");
+        { Prof _p(ctx, "k_sap_walk_chains"); hipLaunchKernelGGL(k_sap_walk_chains, dim3((unsigned)jobs.size()), dim3(64), 0, ctx->stream, d_jobs, capacity); }
+        ZKW_TRY(launch_check("k_sap_walk_chains"));
+        { Prof _p(ctx, "k_sap_walk_cycles"); hipLaunchKernelGGL(k_sap_walk_cycles, dim3((capacity * SAP_WALK_CYCLES + 256) / 256, (unsigned)jobs.size()), dim3(256), 0, ctx->stream, d_jobs, capacity); }
+        return launch_check("k_sap_walk_cycles");
     }, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows);
 }
 extern "C" int zkw_storage_application_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
