@@ -69,7 +69,24 @@ struct NlDev {
     u32 vsize;                   // bytes of a wave's value array
     u32 fill_waves;              // waves per workgroup of k_nl_fill (8 or 16)
     u32 lds_bytes, lds_bytes16;  // dynamic LDS of k_nl_fill with 8 / 16 waves per workgroup
+    // the lane-per-cycle path (k_nl_walk + k_nl_expand, circuits with thousands of short cycles): a resolved instruction stream
+    // per step type (operands as (kind, index) with the value's LDS slot already looked up: slots are re-used once a value is dead),
+    // where a step's state comes from, and what pass 2 needs to know about a row of a cycle
+    const u32* prog;             // NL_I_* words
+    const u32* prog0;            // [step type]
+    const uint16_t* out_src;     // [step type][state]: NL_SRC_* encoded
+    const struct NlRowMeta* rowmeta;  // [rows_per_cycle]
+    u32 max_slots, walk_lds;     // LDS of k_nl_walk = (max_slots + 3 * state) * 64
 };
+struct NlRowMeta { u32 key_base; uint16_t lookup_rows; uint8_t rowend, flags /* 1: general cells written, 2: lookup row */, keyfmt /* n_in | in_bits << 4 */, _pad[3]; };
+// operand sources of the instruction stream: kind << 13 | index
+enum { NL_SRC_VAL = 0, NL_SRC_HDR = 1, NL_SRC_PREV = 2, NL_SRC_CYC = 3, NL_SRC_FREE = 4, NL_SRC_RC = 5, NL_SRC_IMM = 6 };
+// instructions: LOOKUP w0 = 1 | fn << 4 | param << 8 | n_in << 12 | n_out << 14, w1 = src0 | src1 << 16, w2 = src2 | dst0 << 16,
+//   w3 = dst1 | dst2 << 16, w4 = row << 16 | first column;  HINT w0 = 2 | lo_a << 4 | n_a << 8 | lo_b << 12 | n_b << 16,
+//   w1 = src_a | src_b << 16, w2 = dst;  GATE w0 = 3 | n_known << 4 | n_new << 12 | mask_last << 20 | new_step << 24, w1 = constant,
+//   w2 = row << 16 | first column, w3 = shift of the first NEW cell, then n_known x (src | code << 16), n_new x dst;
+//   LATE w0 = 4, w1 = src, w2 = row << 16 | column (a gate's late cell, written once its producer has run);  END 0. dst 0xFFFF: not kept
+enum { NL_I_END = 0, NL_I_LOOKUP = 1, NL_I_HINT = 2, NL_I_GATE = 3, NL_I_LATE = 4 };
 struct NlJob {
     const uint8_t* hdr_bits;      // [capacity]: bit 0 reset, bit 1 idle
     const uint8_t* free_elems;    // [capacity][free_per_cycle]
@@ -387,6 +404,184 @@ static __global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __re
             for (u32 k = 0; k < 256 / LW; k++)
                 if (lane + k * LW < STATE) val[V.prev + lane + k * LW] = nx[k];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ lane-per-cycle fill
+// For circuits with thousands of short cycles (SHA-256 family, StorageApplication) the level walk of k_nl_fill — a wave per
+// cycle, ~15 items per level, an LDS round trip per level — is latency-bound. Here a LANE owns a cycle: the 64 lanes of a wave
+// run the same resolved instruction stream on 64 cycles, no level structure, no cross-lane traffic; values live in LDS as
+// [slot][lane] (64 consecutive bytes per access: conflict-free), slots re-used once a value is dead. The cells of 64 cycles
+// cannot be stored coalesced from that shape (a trace is cycle-major: lane <-> cycle is a stride of rows_per_cycle rows), so pass 1
+// writes them as BYTES into a scratch tile [column][row of the cycle][64 cycles] (coalesced, an eighth of the trace), and pass 2
+// (k_nl_expand) transposes 64 rows x 64 cycles of a column through LDS and stores u64 cells lane <-> row, 512 contiguous bytes
+// per cycle — plus the 16-bit keys of the lookups in the layout k_nl_hist reads.
+__device__ __forceinline__ u32 nl_walk_get(u32 src, const uint8_t* __restrict__ vals, const uint8_t* __restrict__ prev, const uint8_t* __restrict__ cyc,
+                                           const uint8_t* __restrict__ fr, const uint8_t* rc, u32 h0, u32 h1, u32 h2, u32 h3, u32 lane) {
+    const u32 kind = src >> 13, idx = src & 0x1FFF;  // uniform across the wave: scalar branches
+    switch (kind) {
+        case NL_SRC_VAL: return vals[idx * 64 + lane];
+        case NL_SRC_HDR: return idx == 0 ? h0 : idx == 1 ? h1 : idx == 2 ? h2 : h3;
+        case NL_SRC_PREV: return prev[idx * 64 + lane];
+        case NL_SRC_CYC: return cyc[idx * 64 + lane];
+        case NL_SRC_FREE: return fr[idx];
+        case NL_SRC_RC: return rc[idx];
+        default: return idx;
+    }
+}
+
+template <int W, int R>
+static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity,
+                                                       uint8_t* __restrict__ scratch, size_t scratch_per_job) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const NlDev& D = *devp;
+    const nl_spec& S = D.s;
+    const NlJob job = jobs[blockIdx.y];
+    const u32 lane = threadIdx.x, tile = blockIdx.x;
+    const u32 STATE = S.state, RPC = S.rows_per_cycle, STEPS = S.steps_per_cycle, FPC = S.free_per_cycle, G = S.g;
+    const u32 c = min(tile * 64 + lane, capacity - 1);  // (the lanes beyond the last cycle walk it again; pass 2 ignores them)
+    uint8_t* const vals = lds;
+    uint8_t* prev = lds + (size_t)D.max_slots * 64;
+    uint8_t* next = prev + STATE * 64;
+    uint8_t* const cyc = next + STATE * 64;
+    uint8_t* const sc = scratch + blockIdx.y * scratch_per_job + (size_t)tile * ((size_t)S.mult_col * RPC * 64) + lane;
+#define NL_SC(col, row) sc[((size_t)(col) * RPC + (row)) * 64]
+    const u32 bits = job.hdr_bits[c], h0 = bits & 1, h1 = (bits >> 1) & 1;
+    const u32 h2 = (u32)(uint8_t)(S.masks[0] + S.masks[1] * (int)h0), h3 = (u32)(uint8_t)(S.masks[2] + S.masks[3] * (int)h1);
+    for (u32 k = 0; k < STATE; k++) {
+        const uint8_t x = job.state_before[(size_t)c * STATE + k];
+        cyc[k * 64 + lane] = x;
+        prev[k * 64 + lane] = x;
+    }
+    const u32* const prog = D.prog;
+    u32 free_at = 0;
+    for (u32 s = 0; s < STEPS; s++) {
+        const nl_cycle_step cs = S.cycle[s];
+        const u32 type = cs.type, row0 = cs.row0;
+        const uint8_t* const fr = job.free_elems + (size_t)c * FPC + free_at;
+        free_at += S.step_types[type].n_free;
+        NL_SC(0, row0) = (uint8_t)h0; NL_SC(1, row0) = (uint8_t)h1; NL_SC(2, row0) = (uint8_t)h2; NL_SC(3, row0) = (uint8_t)h3;
+        u32 pc = D.prog0[type];
+        for (;;) {
+            const u32 w0 = prog[pc];
+            const u32 opc = w0 & 15;
+            if (opc == NL_I_END) break;
+            if (opc == NL_I_LOOKUP) {
+                const u32 w1 = prog[pc + 1], w2 = prog[pc + 2], w3 = prog[pc + 3], w4 = prog[pc + 4];
+                pc += 5;
+                const u32 fn = (w0 >> 4) & 15, param = (w0 >> 8) & 15, n_in = (w0 >> 12) & 3, n_out = (w0 >> 14) & 3;
+                const u32 a0 = nl_walk_get(w1 & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
+                const u32 a1 = n_in > 1 ? nl_walk_get(w1 >> 16, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane) : 0u;
+                const u32 a2 = n_in > 2 ? nl_walk_get(w2 & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane) : 0u;
+                u32 o0, o1, o2;
+                nl_eval_sel(fn, param, a0, a1, a2, o0, o1, o2);
+                const u32 row = row0 + (w4 >> 16), col = w4 & 0xFFFF;
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    const int jj = k - (int)n_in;
+                    const u32 vin = k == 0 ? a0 : k == 1 ? a1 : a2;
+                    const u32 vout = jj == 0 ? o0 : jj == 1 ? o1 : o2;
+                    NL_SC(col + k, row) = (uint8_t)(jj < 0 ? vin : (jj < (int)n_out ? vout : 0u));
+                }
+                const u32 d0 = w2 >> 16, d1 = w3 & 0xFFFF, d2 = w3 >> 16;
+                if (d0 != 0xFFFF) vals[d0 * 64 + lane] = (uint8_t)o0;
+                if (d1 != 0xFFFF) vals[d1 * 64 + lane] = (uint8_t)o1;
+                if (d2 != 0xFFFF) vals[d2 * 64 + lane] = (uint8_t)o2;
+            } else if (opc == NL_I_HINT) {
+                const u32 w1 = prog[pc + 1], w2 = prog[pc + 2];
+                pc += 3;
+                const u32 a = nl_walk_get(w1 & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
+                const u32 b = nl_walk_get(w1 >> 16, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
+                const u32 lo_a = (w0 >> 4) & 15, n_a = (w0 >> 8) & 15, lo_b = (w0 >> 12) & 15, n_b = (w0 >> 16) & 15;
+                if ((w2 & 0xFFFF) != 0xFFFF) vals[(w2 & 0xFFFF) * 64 + lane] = (uint8_t)(((a >> lo_a) & ((1u << n_a) - 1)) | (((b >> lo_b) & ((1u << n_b) - 1)) << n_a));
+            } else if (opc == NL_I_GATE) {
+                const u32 n_known = (w0 >> 4) & 255, n_new = (w0 >> 12) & 255, mask_last = (w0 >> 20) & 1, new_step = w0 >> 24;
+                const u32 constant = prog[pc + 1], w2 = prog[pc + 2], sh0 = prog[pc + 3];
+                pc += 4;
+                const u32 row = row0 + (w2 >> 16), col = w2 & 0xFFFF;
+                long long sum = constant;
+                for (u32 i = 0; i < n_known; i++) {
+                    const u32 t = prog[pc + i], code = t >> 16;
+                    if (code & NL_TERM_LATE) continue;  // in the constraint, not in the evaluation: an NL_I_LATE writes the cell
+                    const long long x = (long long)nl_walk_get(t & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
+                    NL_SC(col + i, row) = (uint8_t)x;
+                    sum += (code & 0x80) ? -(x << (code & 0x7F)) : (x << (code & 0x7F));
+                }
+                pc += n_known;
+                for (u32 i = 0; i < n_new; i++) {
+                    u64 x = (u64)sum >> (sh0 + i * new_step);
+                    if (i + 1 < n_new || mask_last) x &= (1ull << new_step) - 1;
+                    const u32 d = prog[pc + i] & 0xFFFF;
+                    NL_SC(col + n_known + i, row) = (uint8_t)x;
+                    if (d != 0xFFFF) vals[d * 64 + lane] = (uint8_t)x;
+                }
+                pc += n_new;
+            } else {  // NL_I_LATE
+                const u32 w1 = prog[pc + 1], w2 = prog[pc + 2];
+                pc += 3;
+                NL_SC(w2 & 0xFFFF, row0 + (w2 >> 16)) = (uint8_t)nl_walk_get(w1 & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
+            }
+        }
+        // the state this step leaves: the next step's PREV bank
+        const uint16_t* const so = D.out_src + (size_t)type * STATE;
+        for (u32 k = 0; k < STATE; k++) next[k * 64 + lane] = (uint8_t)nl_walk_get(so[k], vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
+        uint8_t* const tmp = prev; prev = next; next = tmp;
+    }
+#undef NL_SC
+}
+
+// pass 2. grid (units, tiles of 64 cycles, instances), one wave per unit: unit < G * row_blocks: a general-purpose column x 64
+// rows of the cycle; the others: a lookup slot (W columns + its keys) x 64 rows. 64 x 64 bytes of the scratch tile per column
+// through LDS (row pitch 68 bytes: lanes read one byte each at distinct banks), then per cycle one 512-byte store per column.
+template <int W, int R>
+static __global__ __launch_bounds__(64) void k_nl_expand(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows,
+                                                         const uint8_t* __restrict__ scratch, size_t scratch_per_job) {
+    __shared__ __attribute__((aligned(16))) uint8_t tileb[W][64 * 68];
+    const NlDev& D = *devp;
+    const nl_spec& S = D.s;
+    const NlJob job = jobs[blockIdx.z];
+    const u32 lane = threadIdx.x, tile = blockIdx.y, RPC = S.rows_per_cycle, G = S.g;
+    const u32 row_blocks = (RPC + 63) / 64;
+    const bool general = blockIdx.x < G * row_blocks;
+    const u32 u = general ? blockIdx.x : blockIdx.x - G * row_blocks;
+    const u32 rb = u % row_blocks, which = u / row_blocks;      // which: the column / the lookup slot
+    const u32 col0 = general ? which : G + W * which, ncols = general ? 1 : W;
+    const u32 r = rb * 64 + lane;                                // row of the cycle this lane stores
+    const bool row_ok = r < RPC;
+    const NlRowMeta rm = D.rowmeta[row_ok ? r : 0];
+    if (general) {  // nothing of this column in these rows: leave (uniform)
+        bool any = row_ok && (rm.flags & 1);
+        if (!__any(any)) return;
+    }
+    const uint8_t* const sc = scratch + blockIdx.z * scratch_per_job + (size_t)tile * ((size_t)S.mult_col * RPC * 64);
+    const u32 rows_here = min(64u, RPC - rb * 64);
+    for (u32 cc = 0; cc < ncols; cc++) {
+        const u32* const src = reinterpret_cast<const u32*>(sc + ((size_t)(col0 + cc) * RPC + rb * 64) * 64);
+        for (u32 d = lane; d < rows_here * 16; d += 64) *reinterpret_cast<u32*>(&tileb[cc][(d >> 4) * 68 + (d & 15) * 4]) = src[d];
+    }
+    __syncthreads();
+    const u32 cyc0 = tile * 64, ncyc = min(64u, capacity - cyc0);
+    u64* const trace = job.trace;
+    if (general) {
+        const bool write = row_ok && (rm.flags & 1), used = which < rm.rowend;
+        if (!write) return;
+        for (u32 k = 0; k < ncyc; k++)
+            trace[(size_t)col0 * n_rows + (size_t)(cyc0 + k) * RPC + r] = used ? (u64)tileb[0][lane * 68 + k] : 0ull;
+        return;
+    }
+    if (!row_ok) return;
+    const bool lk = (rm.flags & 2) != 0;
+    const u32 n_in = rm.keyfmt & 15, in_bits = rm.keyfmt >> 4;
+    uint16_t* const keys = job.keys + rm.key_base + (size_t)which * rm.lookup_rows;
+    for (u32 k = 0; k < ncyc; k++) {
+        const size_t row = (size_t)(cyc0 + k) * RPC + r;
+        u32 a[W];
+#pragma unroll
+        for (int cc = 0; cc < W; cc++) {
+            a[cc] = lk ? tileb[cc][lane * 68 + k] : 0u;
+            trace[(size_t)(col0 + cc) * n_rows + row] = a[cc];
+        }
+        if (lk) keys[(size_t)(cyc0 + k) * D.keys_per_cycle] = (uint16_t)(a[0] | (n_in > 1 ? a[1] << in_bits : 0u) | (n_in > 2 ? a[2] << (2 * in_bits) : 0u));
     }
 }
 

@@ -4,6 +4,7 @@
 #include "zkw_ctx.h"
 #include "closed_forms_host.h"
 #include "decommitter_kernels.cuh"
+#include <array>
 #include <functional>
 #include "precompile_kernels.cuh"
 #include "storage_application_kernels.cuh"
@@ -723,6 +724,141 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
     d.lds_bytes16 = NlLds(*hs, V.size, d.n_pk_terms, 16).total;
     d.fill_waves = d.lds_bytes16 <= 160 * 1024 ? 16 : 8;
     if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d: %u terms packed into %u, LDS %u bytes for %u waves\n", circuit_type, hs->n_terms, d.n_pk_terms, d.fill_waves == 16 ? d.lds_bytes16 : d.lds_bytes, d.fill_waves);
+    // ---- the lane-per-cycle path: instruction stream with LDS slots (linear scan over the evaluation order), state sources,
+    // per-row metadata of a cycle
+    {
+        auto enc_src = [&](u32 ref, const std::vector<uint16_t>& slot_of) -> uint16_t {
+            if (ref < NL_REF_HDR) return (uint16_t)(NL_SRC_VAL << 13 | slot_of[ref]);
+            if (ref < NL_REF_PREV) return (uint16_t)(NL_SRC_HDR << 13 | (ref - NL_REF_HDR));
+            if (ref < NL_REF_CYC) return (uint16_t)(NL_SRC_PREV << 13 | (ref - NL_REF_PREV));
+            if (ref < NL_REF_FREE) return (uint16_t)(NL_SRC_CYC << 13 | (ref - NL_REF_CYC));
+            if (ref < NL_REF_RC) return (uint16_t)(NL_SRC_FREE << 13 | (ref - NL_REF_FREE));
+            if (ref < NL_REF_CONST) return (uint16_t)(NL_SRC_RC << 13 | (ref - NL_REF_RC));
+            return (uint16_t)(NL_SRC_IMM << 13 | (ref - NL_REF_CONST));
+        };
+        std::vector<u32> prog, prog0(hs->n_step_types);
+        std::vector<uint16_t> out_src((size_t)hs->n_step_types * hs->state);
+        u32 max_slots = 1;
+        for (u32 k = 0; k < hs->n_step_types; k++) {
+            const nl_step_type& T = hs->step_types[k];
+            const u32 n_items = hs->level_start[T.level0 + T.n_levels];
+            // the items in evaluation order as (reads, writes); a fused hint is a hint followed by its lookup
+            struct Item { int kind; u32 idx; };  // 0 lookup slot, 1 gate, 2 hint
+            std::vector<Item> items;
+            for (u32 e = 0; e < n_items; e++) {
+                const u32 it = hs->order[T.order0 + e];
+                if (it >= NL_ORDER_HINT) items.push_back({2, it - NL_ORDER_HINT});
+                else if (it >= NL_ORDER_GATE) items.push_back({1, it - NL_ORDER_GATE});
+                else if (it >= NL_ORDER_FUSED) { items.push_back({2, it - NL_ORDER_FUSED}); items.push_back({0, hs->hints[T.hint0 + (it - NL_ORDER_FUSED)].fused_slot}); }
+                else items.push_back({0, it});
+            }
+            const long END = (long)items.size();
+            std::vector<long> last_use(T.n_values, -1);
+            auto use = [&](u32 ref, long at) { if (ref < NL_REF_HDR && at > last_use[ref]) last_use[ref] = at; };
+            for (long i = 0; i < END; i++) {
+                const Item& it = items[i];
+                if (it.kind == 0) {
+                    const nl_op& op = hs->ops[T.op0 + it.idx];
+                    const nl_table& tb = hs->tables[op.table - 1];
+                    for (u32 a = 0; a < tb.n_in; a++) use(op.in[a], i);
+                } else if (it.kind == 1) {
+                    const nl_gate& g = hs->gates[T.gate0 + it.idx];
+                    const nl_term* tm = hs->terms + T.term0 + g.first_term;
+                    for (u32 a = 0; a < g.n_known; a++) use(tm[a].ref, (tm[a].code & NL_TERM_LATE) ? END : i);
+                } else {
+                    const nl_hint& h = hs->hints[T.hint0 + it.idx];
+                    use(h.ref_a, i); use(h.ref_b, i);
+                }
+            }
+            for (u32 e = 0; e < hs->state; e++) use(hs->out[(size_t)k * hs->state + e], END);
+            // linear scan: a value's slot is free again after the item that reads it last
+            std::vector<uint16_t> slot_of(T.n_values, 0xFFFF);
+            std::vector<uint16_t> free_slots;
+            std::vector<std::vector<u32>> dies_at(END + 1);
+            u32 next_slot = 0;
+            auto define = [&](u32 v, long at) -> uint16_t {
+                if (last_use[v] < 0) return 0xFFFF;  // never read: not kept
+                uint16_t sl;
+                if (!free_slots.empty()) { sl = free_slots.back(); free_slots.pop_back(); } else sl = (uint16_t)next_slot++;
+                slot_of[v] = sl;
+                if (last_use[v] < END) dies_at[last_use[v]].push_back(v);
+                (void)at;
+                return sl;
+            };
+            prog0[k] = (u32)prog.size();
+            std::vector<std::array<u32, 3>> late;  // (src ref, row, col) of the gates' late cells
+            for (long i = 0; i < END; i++) {
+                const Item& it = items[i];
+                if (it.kind == 0) {
+                    const nl_op& op = hs->ops[T.op0 + it.idx];
+                    const nl_table& tb = hs->tables[op.table - 1];
+                    uint16_t src[3] = {(uint16_t)(NL_SRC_IMM << 13), (uint16_t)(NL_SRC_IMM << 13), (uint16_t)(NL_SRC_IMM << 13)};
+                    for (u32 a = 0; a < tb.n_in; a++) src[a] = enc_src(op.in[a], slot_of);
+                    for (u32 v : dies_at[i]) free_slots.push_back(slot_of[v]);  // read first, then written: an output may take an input's slot
+                    uint16_t dst[3] = {0xFFFF, 0xFFFF, 0xFFFF};
+                    if (op.out != 0xFFFF)
+                        for (u32 o = 0; o < tb.n_out; o++) dst[o] = define(op.out + o, i);
+                    prog.push_back(NL_I_LOOKUP | tb.fn << 4 | tb.param << 8 | tb.n_in << 12 | tb.n_out << 14);
+                    prog.push_back(src[0] | (u32)src[1] << 16);
+                    prog.push_back(src[2] | (u32)dst[0] << 16);
+                    prog.push_back(dst[1] | (u32)dst[2] << 16);
+                    prog.push_back((1 + it.idx / hs->r) << 16 | (hs->g + hs->w * (it.idx % hs->r)));
+                } else if (it.kind == 1) {
+                    const nl_gate& g = hs->gates[T.gate0 + it.idx];
+                    const nl_term* tm = hs->terms + T.term0 + g.first_term;
+                    bool has_late = false;
+                    std::vector<u32> words;
+                    for (u32 a = 0; a < g.n_known; a++) {
+                        words.push_back(enc_src(tm[a].ref, slot_of) | (u32)(tm[a].code & 0x1FF) << 16);
+                        if (tm[a].code & NL_TERM_LATE) { has_late = true; late.push_back({tm[a].ref, g.row, (u32)g.col + a}); }
+                    }
+                    for (u32 v : dies_at[i]) free_slots.push_back(slot_of[v]);
+                    const u32 sh0 = g.n_new ? (tm[g.n_known].code & 0x7F) : 0, step = g.n_new > 1 ? (tm[g.n_known + 1].code & 0x7F) - sh0 : 8;
+                    prog.push_back(NL_I_GATE | (u32)g.n_known << 4 | (u32)g.n_new << 12 | (has_late ? 1u : 0u) << 20 | step << 24);
+                    prog.push_back(g.constant);
+                    prog.push_back((u32)g.row << 16 | g.col);
+                    prog.push_back(sh0);
+                    prog.insert(prog.end(), words.begin(), words.end());
+                    for (u32 a = 0; a < g.n_new; a++) prog.push_back(define(tm[g.n_known + a].ref, i));
+                } else {
+                    const nl_hint& h = hs->hints[T.hint0 + it.idx];
+                    const uint16_t sa = enc_src(h.ref_a, slot_of), sb = enc_src(h.ref_b, slot_of);
+                    for (u32 v : dies_at[i]) free_slots.push_back(slot_of[v]);
+                    prog.push_back(NL_I_HINT | (u32)h.lo_a << 4 | (u32)h.n_a << 8 | (u32)h.lo_b << 12 | (u32)h.n_b << 16);
+                    prog.push_back(sa | (u32)sb << 16);
+                    prog.push_back(define(h.value, i));
+                }
+            }
+            for (auto& lc : late) { prog.push_back(NL_I_LATE); prog.push_back(enc_src(lc[0], slot_of)); prog.push_back(lc[1] << 16 | lc[2]); }
+            prog.push_back(NL_I_END);
+            for (u32 e = 0; e < hs->state; e++) out_src[(size_t)k * hs->state + e] = enc_src(hs->out[(size_t)k * hs->state + e], slot_of);
+            max_slots = std::max(max_slots, next_slot);
+            if (next_slot >= (1u << 13)) return fail(ZKW_ERR_INVALID, "netlist circuit %d: %u live values", circuit_type, next_slot);
+        }
+        std::vector<NlRowMeta> rowmeta(hs->rows_per_cycle);
+        for (u32 st = 0; st < hs->steps_per_cycle; st++) {
+            const nl_step_type& T = hs->step_types[hs->cycle[st].type];
+            for (u32 r = 0; r < T.rows; r++) {
+                NlRowMeta& m = rowmeta[hs->cycle[st].row0 + r];
+                memset(&m, 0, sizeof m);
+                m.rowend = (uint8_t)hs->gate_row_end[T.rowend0 + r];
+                m.flags = (uint8_t)((r <= T.gate_rows ? 1 : 0) | (r >= 1 && r <= T.lookup_rows ? 2 : 0));
+                m.lookup_rows = (uint16_t)T.lookup_rows;
+                if (m.flags & 2) {
+                    const nl_table& tb = hs->tables[hs->ops[T.op0 + (r - 1) * hs->r].table - 1];
+                    m.keyfmt = (uint8_t)(tb.n_in | tb.in_bits << 4);
+                    m.key_base = key0[st] + (r - 1);
+                }
+            }
+        }
+        ZKW_TRY(nl_to_device(prog.data(), prog.size(), &d.prog));
+        ZKW_TRY(nl_to_device(prog0.data(), prog0.size(), &d.prog0));
+        ZKW_TRY(nl_to_device(out_src.data(), out_src.size(), &d.out_src));
+        ZKW_TRY(nl_to_device(rowmeta.data(), rowmeta.size(), &d.rowmeta));
+        d.max_slots = max_slots;
+        d.walk_lds = (max_slots + 3 * hs->state) * 64;
+        if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d, lane-per-cycle path: %zu program words, %u LDS slots, %u bytes of LDS per wave\n", circuit_type, prog.size(), max_slots, d.walk_lds);
+    }
     const NlDev* dd = nullptr;
     ZKW_TRY(nl_to_device(&d, 1, &dd));
     c.host = d;
@@ -748,8 +884,34 @@ int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsi
     { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R, WAVES>), dim3(blocks, nj), dim3(64 * WAVES), lds, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
     return launch_check("k_nl_fill");
 }
+// the lane-per-cycle path (k_nl_walk + k_nl_expand): for traces of at least 1 024 cycles whose live values fit the LDS
+template <int W, int R>
+int nl_launch_fill_lanes(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
+    static bool attr_set[16] = {};
+    if (!attr_set[ctx->device & 15]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_walk<W, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[ctx->device & 15] = true;
+    }
+    const nl_spec& S = nc->host.s;
+    const unsigned tiles = (capacity + 63) / 64, row_blocks = (S.rows_per_cycle + 63) / 64;
+    const size_t per_job = ((size_t)tiles * S.mult_col * S.rows_per_cycle * 64 + 255) & ~(size_t)255;
+    uint8_t* d_bytes = nullptr;
+    ZKW_TRY(ctx->scratch_t<uint8_t>("nl_bytes", per_job * nj, &d_bytes));
+    { Prof _p(ctx, "k_nl_walk"); hipLaunchKernelGGL((k_nl_walk<W, R>), dim3(tiles, nj), dim3(64), nc->host.walk_lds, ctx->stream, nc->dev, d_jobs, capacity, d_bytes, per_job); }
+    ZKW_TRY(launch_check("k_nl_walk"));
+    { Prof _p(ctx, "k_nl_expand"); hipLaunchKernelGGL((k_nl_expand<W, R>), dim3((S.g + R) * row_blocks, tiles, nj), dim3(64), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows, d_bytes, per_job); }
+    return launch_check("k_nl_expand");
+}
+
 template <int W, int R>
 int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
+    static const int lanes_mode = [] { const char* e = getenv("ZKW_NL_LANES"); return e ? atoi(e) : -1; }();  // 0 / 1 force a path (measurement)
+    const bool lanes = lanes_mode >= 0 ? lanes_mode != 0 : (capacity >= 1024 && nc->host.walk_lds <= 160 * 1024);
+    if (lanes && nc->host.walk_lds <= 160 * 1024) {
+        ZKW_TRY((nl_launch_fill_lanes<W, R>(ctx, nc, d_jobs, nj, capacity, n_rows)));
+        { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+        return launch_check("k_nl_hist");
+    }
     // (a call with few cycles keeps 8 waves per workgroup: twice the workgroups, so that every CU has one)
     if (nc->host.fill_waves == 16 && (size_t)((capacity + 15) / 16) * nj >= 128) ZKW_TRY((nl_launch_fill_w<W, R, 16>(ctx, nc, d_jobs, nj, capacity, n_rows)));
     else ZKW_TRY((nl_launch_fill_w<W, R, 8>(ctx, nc, d_jobs, nj, capacity, n_rows)));
