@@ -76,7 +76,7 @@ struct NlDev {
     const u32* prog0;            // [step type]
     const uint16_t* out_src;     // [step type][state]: NL_SRC_* encoded
     const struct NlRowMeta* rowmeta;  // [rows_per_cycle]
-    u32 max_slots, walk_lds;     // LDS of k_nl_walk = (max_slots + 3 * state) * 64
+    u32 max_slots, walk_lds;     // LDS of k_nl_walk = (max_slots + 3 * state + max_free) * 64
 };
 struct NlRowMeta { u32 key_base; uint16_t lookup_rows; uint8_t rowend, flags /* 1: general cells written, 2: lookup row */, keyfmt /* n_in | in_bits << 4 */, _pad[3]; };
 // operand sources of the instruction stream: kind << 13 | index
@@ -416,23 +416,36 @@ static __global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __re
 // writes them as BYTES into a scratch tile [column][row of the cycle][64 cycles] (coalesced, an eighth of the trace), and pass 2
 // (k_nl_expand) transposes 64 rows x 64 cycles of a column through LDS and stores u64 cells lane <-> row, 512 contiguous bytes
 // per cycle — plus the 16-bit keys of the lookups in the layout k_nl_hist reads.
-__device__ __forceinline__ u32 nl_walk_get(u32 src, const uint8_t* __restrict__ vals, const uint8_t* __restrict__ prev, const uint8_t* __restrict__ cyc,
-                                           const uint8_t* __restrict__ fr, const uint8_t* rc, u32 h0, u32 h1, u32 h2, u32 h3, u32 lane) {
+// The instruction stream and the state sources are KERNEL ARGUMENTS (known global address space, uniform index: scalar loads,
+// which wait on lgkmcnt only). A vector load inside the item loop would make the wave wait for every outstanding global store
+// of the loop (gfx9 returns loads and stores through one in-order counter): measured 1.5 us per item with the pointers taken
+// from the NlDev struct (generic address space: flat loads).
+// (every LDS operand is an OFFSET into the kernel's one shared array: with pointers the compiler cannot tell the address space
+// and emits flat loads, which wait for every outstanding global store — measured: 1.5 us per item)
+#define NL_WALK_GET(src) nl_walk_get(lds, (src), o_vals, o_prev, o_cyc, o_fr, rc_lo, rc_hi, h0, h1, h2, h3, lane)
+__device__ __forceinline__ u32 nl_walk_get(const uint8_t* lds, u32 src, u32 o_vals, u32 o_prev, u32 o_cyc, u32 o_fr, u32 rc_lo, u32 rc_hi,
+                                           u32 h0, u32 h1, u32 h2, u32 h3, u32 lane) {
     const u32 kind = src >> 13, idx = src & 0x1FFF;  // uniform across the wave: scalar branches
     switch (kind) {
-        case NL_SRC_VAL: return vals[idx * 64 + lane];
+        case NL_SRC_VAL: return lds[o_vals + idx * 64 + lane];
         case NL_SRC_HDR: return idx == 0 ? h0 : idx == 1 ? h1 : idx == 2 ? h2 : h3;
-        case NL_SRC_PREV: return prev[idx * 64 + lane];
-        case NL_SRC_CYC: return cyc[idx * 64 + lane];
-        case NL_SRC_FREE: return fr[idx];
-        case NL_SRC_RC: return rc[idx];
+        case NL_SRC_PREV: return lds[o_prev + idx * 64 + lane];
+        case NL_SRC_CYC: return lds[o_cyc + idx * 64 + lane];
+        case NL_SRC_FREE: return lds[o_fr + idx * 64 + lane];
+        case NL_SRC_RC: return ((idx < 4 ? rc_lo : rc_hi) >> (8 * (idx & 3))) & 255u;
         default: return idx;
     }
 }
 
 template <int W, int R>
 static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity,
-                                                       uint8_t* __restrict__ scratch, size_t scratch_per_job) {
+                                                       uint8_t* __restrict__ scratch, size_t scratch_per_job, const u32* __restrict__ prog_g,
+                                                       const u32* __restrict__ prog0, const uint16_t* __restrict__ out_src_g) {
+    // the constant address space: never clobbered, so a uniform index is a scalar load whatever the loop stores
+    typedef const __attribute__((address_space(4))) u32* c_u32;
+    typedef const __attribute__((address_space(4))) uint16_t* c_u16;
+    const c_u32 prog = (c_u32)prog_g;
+    const c_u16 out_src = (c_u16)out_src_g;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
@@ -440,28 +453,44 @@ static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__
     const u32 lane = threadIdx.x, tile = blockIdx.x;
     const u32 STATE = S.state, RPC = S.rows_per_cycle, STEPS = S.steps_per_cycle, FPC = S.free_per_cycle, G = S.g;
     const u32 c = min(tile * 64 + lane, capacity - 1);  // (the lanes beyond the last cycle walk it again; pass 2 ignores them)
-    uint8_t* const vals = lds;
-    uint8_t* prev = lds + (size_t)D.max_slots * 64;
-    uint8_t* next = prev + STATE * 64;
-    uint8_t* const cyc = next + STATE * 64;
+    const u32 o_vals = 0, o_cyc = D.max_slots * 64 + 2 * STATE * 64, o_fr = o_cyc + STATE * 64;  // [slot][lane] | prev | next | cyc | free
+    u32 o_prev = D.max_slots * 64, o_next = o_prev + STATE * 64;
     uint8_t* const sc = scratch + blockIdx.y * scratch_per_job + (size_t)tile * ((size_t)S.mult_col * RPC * 64) + lane;
 #define NL_SC(col, row) sc[((size_t)(col) * RPC + (row)) * 64]
     const u32 bits = job.hdr_bits[c], h0 = bits & 1, h1 = (bits >> 1) & 1;
     const u32 h2 = (u32)(uint8_t)(S.masks[0] + S.masks[1] * (int)h0), h3 = (u32)(uint8_t)(S.masks[2] + S.masks[3] * (int)h1);
-    for (u32 k = 0; k < STATE; k++) {
-        const uint8_t x = job.state_before[(size_t)c * STATE + k];
-        cyc[k * 64 + lane] = x;
-        prev[k * 64 + lane] = x;
+    for (u32 k0 = 0; k0 < STATE; k0 += 16) {  // 16 independent loads in flight
+        uint8_t x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = k0 + k < STATE ? job.state_before[(size_t)c * STATE + k0 + k] : (uint8_t)0;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k0 + k < STATE) { lds[o_cyc + (k0 + k) * 64 + lane] = x[k]; lds[o_prev + (k0 + k) * 64 + lane] = x[k]; }
     }
-    const u32* const prog = D.prog;
     u32 free_at = 0;
     for (u32 s = 0; s < STEPS; s++) {
+        // (loaded through generic pointers of the spec struct, i.e. into vector registers: made scalars again, or everything derived
+        // from them — the program counter first of all — would count as divergent and be fetched with vector loads)
         const nl_cycle_step cs = S.cycle[s];
-        const u32 type = cs.type, row0 = cs.row0;
-        const uint8_t* const fr = job.free_elems + (size_t)c * FPC + free_at;
-        free_at += S.step_types[type].n_free;
+        const u32 type = (u32)__builtin_amdgcn_readfirstlane((int)cs.type), row0 = (u32)__builtin_amdgcn_readfirstlane((int)cs.row0);
+        const u32 n_free = (u32)__builtin_amdgcn_readfirstlane((int)S.step_types[type].n_free);
+        const uint8_t* const frg = job.free_elems + (size_t)c * FPC + free_at;
+        free_at += n_free;
+        for (u32 f0 = 0; f0 < n_free; f0 += 16) {  // 16 independent loads in flight (a lane's elements are consecutive bytes)
+            uint8_t x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = f0 + k < n_free ? frg[f0 + k] : (uint8_t)0;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (f0 + k < n_free) lds[o_fr + (f0 + k) * 64 + lane] = x[k];
+        }
+        u32 rc_lo, rc_hi;
+        __builtin_memcpy(&rc_lo, cs.rc, 4);
+        __builtin_memcpy(&rc_hi, cs.rc + 4, 4);
+        rc_lo = (u32)__builtin_amdgcn_readfirstlane((int)rc_lo);
+        rc_hi = (u32)__builtin_amdgcn_readfirstlane((int)rc_hi);
         NL_SC(0, row0) = (uint8_t)h0; NL_SC(1, row0) = (uint8_t)h1; NL_SC(2, row0) = (uint8_t)h2; NL_SC(3, row0) = (uint8_t)h3;
-        u32 pc = D.prog0[type];
+        u32 pc = (u32)__builtin_amdgcn_readfirstlane((int)prog0[type]);
         for (;;) {
             const u32 w0 = prog[pc];
             const u32 opc = w0 & 15;
@@ -470,9 +499,9 @@ static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__
                 const u32 w1 = prog[pc + 1], w2 = prog[pc + 2], w3 = prog[pc + 3], w4 = prog[pc + 4];
                 pc += 5;
                 const u32 fn = (w0 >> 4) & 15, param = (w0 >> 8) & 15, n_in = (w0 >> 12) & 3, n_out = (w0 >> 14) & 3;
-                const u32 a0 = nl_walk_get(w1 & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
-                const u32 a1 = n_in > 1 ? nl_walk_get(w1 >> 16, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane) : 0u;
-                const u32 a2 = n_in > 2 ? nl_walk_get(w2 & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane) : 0u;
+                const u32 a0 = NL_WALK_GET(w1 & 0xFFFF);
+                const u32 a1 = n_in > 1 ? NL_WALK_GET(w1 >> 16) : 0u;
+                const u32 a2 = n_in > 2 ? NL_WALK_GET(w2 & 0xFFFF) : 0u;
                 u32 o0, o1, o2;
                 nl_eval_sel(fn, param, a0, a1, a2, o0, o1, o2);
                 const u32 row = row0 + (w4 >> 16), col = w4 & 0xFFFF;
@@ -484,16 +513,16 @@ static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__
                     NL_SC(col + k, row) = (uint8_t)(jj < 0 ? vin : (jj < (int)n_out ? vout : 0u));
                 }
                 const u32 d0 = w2 >> 16, d1 = w3 & 0xFFFF, d2 = w3 >> 16;
-                if (d0 != 0xFFFF) vals[d0 * 64 + lane] = (uint8_t)o0;
-                if (d1 != 0xFFFF) vals[d1 * 64 + lane] = (uint8_t)o1;
-                if (d2 != 0xFFFF) vals[d2 * 64 + lane] = (uint8_t)o2;
+                if (d0 != 0xFFFF) lds[o_vals + d0 * 64 + lane] = (uint8_t)o0;
+                if (d1 != 0xFFFF) lds[o_vals + d1 * 64 + lane] = (uint8_t)o1;
+                if (d2 != 0xFFFF) lds[o_vals + d2 * 64 + lane] = (uint8_t)o2;
             } else if (opc == NL_I_HINT) {
                 const u32 w1 = prog[pc + 1], w2 = prog[pc + 2];
                 pc += 3;
-                const u32 a = nl_walk_get(w1 & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
-                const u32 b = nl_walk_get(w1 >> 16, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
+                const u32 a = NL_WALK_GET(w1 & 0xFFFF);
+                const u32 b = NL_WALK_GET(w1 >> 16);
                 const u32 lo_a = (w0 >> 4) & 15, n_a = (w0 >> 8) & 15, lo_b = (w0 >> 12) & 15, n_b = (w0 >> 16) & 15;
-                if ((w2 & 0xFFFF) != 0xFFFF) vals[(w2 & 0xFFFF) * 64 + lane] = (uint8_t)(((a >> lo_a) & ((1u << n_a) - 1)) | (((b >> lo_b) & ((1u << n_b) - 1)) << n_a));
+                if ((w2 & 0xFFFF) != 0xFFFF) lds[o_vals + (w2 & 0xFFFF) * 64 + lane] = (uint8_t)(((a >> lo_a) & ((1u << n_a) - 1)) | (((b >> lo_b) & ((1u << n_b) - 1)) << n_a));
             } else if (opc == NL_I_GATE) {
                 const u32 n_known = (w0 >> 4) & 255, n_new = (w0 >> 12) & 255, mask_last = (w0 >> 20) & 1, new_step = w0 >> 24;
                 const u32 constant = prog[pc + 1], w2 = prog[pc + 2], sh0 = prog[pc + 3];
@@ -503,7 +532,7 @@ static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__
                 for (u32 i = 0; i < n_known; i++) {
                     const u32 t = prog[pc + i], code = t >> 16;
                     if (code & NL_TERM_LATE) continue;  // in the constraint, not in the evaluation: an NL_I_LATE writes the cell
-                    const long long x = (long long)nl_walk_get(t & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
+                    const long long x = (long long)NL_WALK_GET(t & 0xFFFF);
                     NL_SC(col + i, row) = (uint8_t)x;
                     sum += (code & 0x80) ? -(x << (code & 0x7F)) : (x << (code & 0x7F));
                 }
@@ -513,19 +542,19 @@ static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__
                     if (i + 1 < n_new || mask_last) x &= (1ull << new_step) - 1;
                     const u32 d = prog[pc + i] & 0xFFFF;
                     NL_SC(col + n_known + i, row) = (uint8_t)x;
-                    if (d != 0xFFFF) vals[d * 64 + lane] = (uint8_t)x;
+                    if (d != 0xFFFF) lds[o_vals + d * 64 + lane] = (uint8_t)x;
                 }
                 pc += n_new;
             } else {  // NL_I_LATE
                 const u32 w1 = prog[pc + 1], w2 = prog[pc + 2];
                 pc += 3;
-                NL_SC(w2 & 0xFFFF, row0 + (w2 >> 16)) = (uint8_t)nl_walk_get(w1 & 0xFFFF, vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
+                NL_SC(w2 & 0xFFFF, row0 + (w2 >> 16)) = (uint8_t)NL_WALK_GET(w1 & 0xFFFF);
             }
         }
         // the state this step leaves: the next step's PREV bank
-        const uint16_t* const so = D.out_src + (size_t)type * STATE;
-        for (u32 k = 0; k < STATE; k++) next[k * 64 + lane] = (uint8_t)nl_walk_get(so[k], vals, prev, cyc, fr, cs.rc, h0, h1, h2, h3, lane);
-        uint8_t* const tmp = prev; prev = next; next = tmp;
+        const c_u16 so = out_src + (size_t)type * STATE;
+        for (u32 k = 0; k < STATE; k++) lds[o_next + k * 64 + lane] = (uint8_t)NL_WALK_GET(so[k]);
+        const u32 tmp = o_prev; o_prev = o_next; o_next = tmp;
     }
 #undef NL_SC
 }

@@ -319,6 +319,12 @@ extern "C" int zkw_set_chain_form(zkw_ctx* ctx, int lanes_per_state) {
     return ZKW_OK;
 }
 
+extern "C" int zkw_set_netlist_fill_form(zkw_ctx* ctx, int form) {
+    if (!ctx || (form != 0 && form != 1)) return fail(ZKW_ERR_INVALID, "netlist fill form must be 0 (a wave per cycle) or 1 (a lane per cycle)");
+    ctx->netlist_fill_form = form;
+    return ZKW_OK;
+}
+
 extern "C" int zkw_synchronize(zkw_ctx* ctx) {
     if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -82,6 +82,7 @@ struct zkw_ctx {
     std::atomic<bool> destroying{false};
     bool chain_service = false;  // queue chains go to the device's chain service (batched with other contexts' chains)
     int chain_form = 0;  // lanes per Poseidon2 state in the queue-chain kernel: 4 (quad), 16 (row), 0 = auto
+    int netlist_fill_form = 0;  // 0: a wave per cycle (k_nl_fill), 1: a lane per cycle (k_nl_walk + k_nl_expand)
     std::map<std::string, DevBuf> pool;  // named grow-only scratch
     std::map<std::string, HostStage> stages;
     // optional per-kernel timing with HIP events on the context's stream (zkw_profile_*)

@@ -851,12 +851,13 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
                 }
             }
         }
+        prog.resize(prog.size() + 256, NL_I_END);  // (the fetch window reads up to three chunks ahead)
         ZKW_TRY(nl_to_device(prog.data(), prog.size(), &d.prog));
         ZKW_TRY(nl_to_device(prog0.data(), prog0.size(), &d.prog0));
         ZKW_TRY(nl_to_device(out_src.data(), out_src.size(), &d.out_src));
         ZKW_TRY(nl_to_device(rowmeta.data(), rowmeta.size(), &d.rowmeta));
         d.max_slots = max_slots;
-        d.walk_lds = (max_slots + 3 * hs->state) * 64;
+        d.walk_lds = (max_slots + 3 * hs->state + hs->max_free) * 64;
         if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d, lane-per-cycle path: %zu program words, %u LDS slots, %u bytes of LDS per wave\n", circuit_type, prog.size(), max_slots, d.walk_lds);
     }
     const NlDev* dd = nullptr;
@@ -884,7 +885,7 @@ int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsi
     { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R, WAVES>), dim3(blocks, nj), dim3(64 * WAVES), lds, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
     return launch_check("k_nl_fill");
 }
-// the lane-per-cycle path (k_nl_walk + k_nl_expand): for traces of at least 1 024 cycles whose live values fit the LDS
+// the lane-per-cycle path (k_nl_walk + k_nl_expand), for netlists whose live values fit the LDS
 template <int W, int R>
 int nl_launch_fill_lanes(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
     static bool attr_set[16] = {};
@@ -897,7 +898,7 @@ int nl_launch_fill_lanes(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, 
     const size_t per_job = ((size_t)tiles * S.mult_col * S.rows_per_cycle * 64 + 255) & ~(size_t)255;
     uint8_t* d_bytes = nullptr;
     ZKW_TRY(ctx->scratch_t<uint8_t>("nl_bytes", per_job * nj, &d_bytes));
-    { Prof _p(ctx, "k_nl_walk"); hipLaunchKernelGGL((k_nl_walk<W, R>), dim3(tiles, nj), dim3(64), nc->host.walk_lds, ctx->stream, nc->dev, d_jobs, capacity, d_bytes, per_job); }
+    { Prof _p(ctx, "k_nl_walk"); hipLaunchKernelGGL((k_nl_walk<W, R>), dim3(tiles, nj), dim3(64), nc->host.walk_lds, ctx->stream, nc->dev, d_jobs, capacity, d_bytes, per_job, nc->host.prog, nc->host.prog0, nc->host.out_src); }
     ZKW_TRY(launch_check("k_nl_walk"));
     { Prof _p(ctx, "k_nl_expand"); hipLaunchKernelGGL((k_nl_expand<W, R>), dim3((S.g + R) * row_blocks, tiles, nj), dim3(64), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows, d_bytes, per_job); }
     return launch_check("k_nl_expand");
@@ -905,9 +906,10 @@ int nl_launch_fill_lanes(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, 
 
 template <int W, int R>
 int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
-    static const int lanes_mode = [] { const char* e = getenv("ZKW_NL_LANES"); return e ? atoi(e) : -1; }();  // 0 / 1 force a path (measurement)
-    const bool lanes = lanes_mode >= 0 ? lanes_mode != 0 : (capacity >= 1024 && nc->host.walk_lds <= 160 * 1024);
-    if (lanes && nc->host.walk_lds <= 160 * 1024) {
+    // the lane-per-cycle form is opt-in (zkw_set_netlist_fill_form, or ZKW_NL_LANES=1 for a whole process): bit-identical, measured
+    // SLOWER than the wave-per-cycle form on every circuit
+    static const int lanes_env = [] { const char* e = getenv("ZKW_NL_LANES"); return e ? atoi(e) : 0; }();
+    if ((lanes_env || ctx->netlist_fill_form == 1) && nc->host.walk_lds <= 160 * 1024) {
         ZKW_TRY((nl_launch_fill_lanes<W, R>(ctx, nc, d_jobs, nj, capacity, n_rows)));
         { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
         return launch_check("k_nl_hist");

@@ -34,6 +34,7 @@ SYMBOLS = [
     ("zkw_set_pointer_mode", _int, [_vp, _int]),
     ("zkw_synchronize", _int, [_vp]),
     ("zkw_set_chain_form", _int, [_vp, _int]),
+    ("zkw_set_netlist_fill_form", _int, [_vp, _int]),
     ("zkw_set_chain_service", _int, [_vp, _int]),
     ("zkw_buffer_alloc", _int, [_vp, _int, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("zkw_buffer_free", None, [_int, _vp]),
@@ -786,6 +787,10 @@ class Context:
 
     def set_chain_form(self, lanes_per_state):
         _check(load().zkw_set_chain_form(self.handle, lanes_per_state))
+
+    def set_netlist_fill_form(self, form):
+        """0: a wave per cycle (default), 1: a lane per cycle (zkw.h)"""
+        _check(load().zkw_set_netlist_fill_form(self.handle, form))
 
     def synchronize(self):
         _check(load().zkw_synchronize(self.handle))

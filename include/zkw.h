@@ -72,6 +72,11 @@ int zkw_synchronize(zkw_ctx *ctx);
    fewest instructions per permutation, for launches of tens of thousands of queues) or 0 = choose by the number of
    chains in the launch (default). Results are identical. */
 int zkw_set_chain_form(zkw_ctx *ctx, int lanes_per_state);
+/* tuning knob: how the netlist circuits (types 3, 5, 6, 10, 13) are filled. 0 (default): a wave owns a cycle and walks its
+   netlist level by level (k_nl_fill). 1: a lane owns a cycle — 64 cycles run one resolved instruction stream side by side,
+   cells go through a byte-sized scratch tile and a transposing pass (k_nl_walk + k_nl_expand). Results are identical; form 1
+   is the slower one on every circuit measured so far and is kept as a tested alternative. */
+int zkw_set_netlist_fill_form(zkw_ctx *ctx, int form);
 /* Opt this context into the device's chain service: its queue-chain jobs are no longer launched on its own stream but
    handed to a per-device worker that merges the jobs of ALL opted-in contexts arriving within a short window (0.4 - 4 ms)
    into ONE launch on a high-priority stream, and the call waits for that launch. For hosts that keep many contexts busy

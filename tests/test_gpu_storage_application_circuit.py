@@ -127,3 +127,33 @@ def test_production_geometry(ctx, oracle):
     assert np.array_equal(got, exp)
     t.free()
     w.free()
+
+
+def test_lane_per_cycle_fill_is_identical(ctx, oracle):
+    """zkw_set_netlist_fill_form(ctx, 1): the lane-per-cycle form of the netlist fill (k_nl_walk + k_nl_expand) gives the same cells
+    as the oracle for a StorageApplication and a Sha256RoundFunction instance, garbage in the slot before"""
+    from era_zkevm_test_harness_amd import native, synthetic
+
+    ctx.set_netlist_fill_form(1)
+    try:
+        q, w, o = _build(ctx, oracle, 7, 4, seed=31)
+        t = native.Trace(ctx, N_ROWS, 1, n_cols=native.SA_COLS)
+        garbage = np.full((native.SA_COLS, N_ROWS), 77, np.uint64)
+        ctx.synchronize()
+        assert _hip().hipMemcpy(t.device_ptr(0), garbage.ctypes.data, garbage.nbytes, 1) == 0
+        ctx.synthesize_storage_application(w, t, 1, 1, 0)
+        assert np.array_equal(t.get(0), oracle.storage_application_synthesize(o, q, 1, 4, N_ROWS))
+        assert ctx.check_if_satisfied_storage_application(t, 0, 4) == (0, (0, 0, 0))
+        t.free()
+        w.free()
+        req, mq = synthetic.precompile_trace(1, 9, seed=3, max_rounds=4)
+        tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+        mem_in = np.zeros(1, native.QUEUE_STATE12)
+        ws, os_ = ctx._precompile(1, req, tails, mq, 70, mem_in), oracle.precompile_build(1, req, tails, mq, 70, mem_in)
+        t = native.Trace(ctx, N_ROWS, 1, n_cols=native.SC_COLS)
+        ctx.synthesize_sha256_round_function(ws, t, 0, 1, 0)
+        assert np.array_equal(t.get(0), oracle.sha256_round_synthesize(os_, 0, 70, N_ROWS))
+        t.free()
+        ws.free()
+    finally:
+        ctx.set_netlist_fill_form(0)
