@@ -133,7 +133,8 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
         t3 = time.perf_counter()
         wall = parallel.max_over_ranks(t3 - t0, torch.device("cuda", local_rank))
         rep = {"wall_ms": wall * 1e3, "builders_ms": (t1 - t0) * 1e3, "synthesis_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3,
-               "instances_synthesized": n_synth, "instances_in_block": 17, "n_gpus": world, "instances": {str(t): B.num_instances(t) for t in range(2, 14)},
+               "instances_synthesized": n_synth, "instances_in_block": 3 + sum(B.num_instances(t) for t in range(2, 14)),  # + basic_test's 3 MainVM instances (need the VM)
+               "n_gpus": world, "instances": {str(t): B.num_instances(t) for t in range(2, 14)},
                "spans_ms": {name: round(e - s_, 2) for name, s_, e in B.timings() if name != "builders"},
                "memory_queue_items": B.memory_queue_length}
         B.free()
@@ -302,7 +303,8 @@ def full_block_cpu(blk, threads):
     return {"wall_ms": (t2 - t0) * 1e3, "builders_ms": (t1 - t0) * 1e3, "synthesis_ms": (t2 - t1) * 1e3, "cores": threads,
             "builders_sequential_ms": (t1 - t0) * 1e3, "builders_concurrent_ms": conc_s * 1e3,
             "wall_concurrent_ms": (conc_s + (t2 - t1)) * 1e3,
-            "kind": "port", "instances_synthesized": len(jobs), "instances_in_block": 17,
+            "kind": "port", "instances_synthesized": len(jobs),
+            "instances_in_block": 3 + sum(w_["instances"].size for w_ in a["witnesses"].values()),  # + 3 MainVM
             "builders_s": {k: round(v, 3) for k, v in timings.items()},
             "sample": "the same block: builders sequential on 1 thread (reference order, incl. the storage application over the "
                       "oracle's tree), %d instances synthesized on %d threads" % (len(jobs), threads)}

@@ -91,6 +91,8 @@ struct SapJob {
     u64* chunk_end;                // [n + 1] exclusive end of instance c
     u32* jstar;                    // [256][n]
     u32 *A0, *A1, *C0, *C1;        // [n][8] ping-pong: current-tree / pre-state ancestor hashes
+    u32 *R0, *R1;                  // [n][8] ping-pong: ancestors of the leaf AS READ over the current siblings (the first walk of a write)
+    u32* walk_hashes;              // [n][2][257][8] kept for synthesis: level 0 = the leaf hash; [0] the leaf as read, [1] as written
     u32* roots;                    // [n][8] root after query i
     u32* violations;
     u64* meta;                     // [0] number of instances, [1] next enumeration index after the block
@@ -205,30 +207,43 @@ static __global__ __launch_bounds__(64) void k_sap_leaves(SapJob job) {
         for (int k = 0; k < 8; k++) a[k] = c[k];
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) { job.A0[8 * i + k] = a[k]; job.C0[8 * i + k] = c[k]; }
+    for (int k = 0; k < 8; k++) {
+        job.A0[8 * i + k] = a[k]; job.C0[8 * i + k] = c[k]; job.R0[8 * i + k] = c[k];
+        job.walk_hashes[((i * 2 + 0) * 257) * 8 + k] = c[k];
+        job.walk_hashes[((i * 2 + 1) * 257) * 8 + k] = a[k];
+    }
 }
 
 // one level of every path: A(i, L + 1), C(i, L + 1) from level L (see the header comment)
 __device__ __forceinline__ void sap_level_step(const SapJob& job, int L, u64 i) {
     const u32 *Ac = (L & 1) ? job.A1 : job.A0, *Cc = (L & 1) ? job.C1 : job.C0;
     u32 *An = (L & 1) ? job.A0 : job.A1, *Cn = (L & 1) ? job.C0 : job.C1;
+    const u32* Rc = (L & 1) ? job.R1 : job.R0;
+    u32* Rn = (L & 1) ? job.R0 : job.R1;
     const u32 js = job.jstar[(u64)L * job.n + i];
     const u32* ip = job.init_paths + ((u64)i * 256 + L) * 8;
-    u32 init_sib[8], sib[8], a[8], c[8], o[8];
+    u32 init_sib[8], sib[8], a[8], c[8], r[8], o[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         init_sib[k] = ip[k];
         sib[k] = js == SAP_NONE ? init_sib[k] : Ac[8 * (u64)js + k];
         a[k] = Ac[8 * i + k];
         c[k] = Cc[8 * i + k];
+        r[k] = Rc[8 * i + k];
     }
     u32* op = job.paths + ((u64)i * 256 + L) * 8;
 #pragma unroll
     for (int k = 0; k < 8; k++) op[k] = sib[k];
     const bool right = (job.keys[8 * i + (L >> 5)] >> (L & 31)) & 1;  // is_right_side_node, tree/mod.rs:147-155
     if (right) sap_node_hash(sib, a, o); else sap_node_hash(a, sib, o);
+    u32* const wh = job.walk_hashes + ((i * 2) * 257 + (u64)(L + 1)) * 8;
 #pragma unroll
-    for (int k = 0; k < 8; k++) An[8 * i + k] = o[k];
+    for (int k = 0; k < 8; k++) { An[8 * i + k] = o[k]; wh[257 * 8 + k] = o[k]; }
+    if (job.queries[i].rw_flag) {  // the walk of the leaf as read over the same siblings; a read has one walk only (a == r)
+        if (right) sap_node_hash(sib, r, o); else sap_node_hash(r, sib, o);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { Rn[8 * i + k] = o[k]; wh[k] = o[k]; }
     if (right) sap_node_hash(init_sib, c, o); else sap_node_hash(c, init_sib, o);
 #pragma unroll
     for (int k = 0; k < 8; k++) Cn[8 * i + k] = o[k];
@@ -431,6 +446,7 @@ struct SapWalkJob {
     const SapItem* items;     // block-wide
     const u32* keys;          // [n][8]
     const u32* paths;         // [n][256][8]
+    const u32* walk_hashes;   // [n][2][257][8]: the running hash after every cycle of a query's walks (the builder's level walk)
     u64 first_item, num_items;
     uint8_t* hdr_bits;        // [cycles]
     uint8_t* free_elems;      // [cycles][97]
@@ -460,41 +476,9 @@ __device__ __forceinline__ u32 sap_walk_list(const SapWalkJob& j, u32 capacity, 
     return nw;
 }
 
-// 1. the hash chains: one lane per walk (257 dependent Blake2s compressions), the running hash AFTER cycle c goes to
-//    state_before[c + 1]. grid = (instances), 64 lanes per workgroup walk the instance's <= capacity walks.
-static __global__ __launch_bounds__(64) void k_sap_walk_chains(const SapWalkJob* __restrict__ jobs, u32 capacity) {
-    __shared__ u32 s_item[SAP_WALK_MAX];
-    __shared__ uint8_t s_phase[SAP_WALK_MAX];
-    __shared__ u32 s_nw;
-    const SapWalkJob j = jobs[blockIdx.x];
-    if (threadIdx.x == 0) s_nw = sap_walk_list(j, capacity, s_item, s_phase);
-    __syncthreads();
-    for (u32 w = threadIdx.x; w < s_nw; w += blockDim.x) {
-        const SapItem& it = j.items[s_item[w]];
-        const u32* kw = j.keys + 8 * (u64)s_item[w];
-        u32 key[8], cur[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) key[k] = kw[k];
-        if (s_phase[w]) sap_leaf_hash(it.write_index, it.written_value, cur); else sap_leaf_hash(it.read_index, it.read_value, cur);
-        uint8_t* st = j.state_before + ((size_t)w * SAP_WALK_CYCLES + 1) * SAP_WALK_STATE;
-        sap_bytes32(st, cur);
-        const u32* sib = j.paths + (u64)s_item[w] * 256 * 8;
-        for (int L = 0; L < 256; L++, sib += 8) {
-            u32 s[8], o[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) s[k] = sib[k];
-            if ((key[L >> 5] >> (L & 31)) & 1) sap_node_hash(s, cur, o); else sap_node_hash(cur, s, o);
-#pragma unroll
-            for (int k = 0; k < 8; k++) cur[k] = o[k];
-            st += SAP_WALK_STATE;
-            sap_bytes32(st, cur);
-        }
-    }
-}
-
-// 2. everything else, a cycle per thread: the header bit, the free elements, the key part of the state before the cycle, and —
-//    outside the walks — its hash part (the last walk's root in the padding cycles, zero before cycle 0).
-//    grid = (ceil((cycles + 1) / 256), instances)
+// A cycle per thread: the header bit, the free elements and the state before the cycle — the key part, and the running hash, which
+// the builder's level walk left behind for every level of every walk (walk_hashes: no hashing here; the padding cycles carry the last
+// walk's root, the state before cycle 0 is zero). grid = (ceil((cycles + 1) / 256), instances)
 static __global__ __launch_bounds__(256) void k_sap_walk_cycles(const SapWalkJob* __restrict__ jobs, u32 capacity) {
     __shared__ u32 s_item[SAP_WALK_MAX];
     __shared__ uint8_t s_phase[SAP_WALK_MAX];
@@ -515,10 +499,14 @@ static __global__ __launch_bounds__(256) void k_sap_walk_cycles(const SapWalkJob
     }
     // key part of the state: (key << 1) >> i before cycle i >= 1 of a walk, zero before a leaf cycle and in the padding
     for (u32 k = 0; k < 33; k++) st[32 + k] = (in_walk && i) ? (uint8_t)sap_key_bits(key, (int)i + 8 * (int)k - 1) : 0;
-    if (c >= active || c == 0) {  // hash part outside the walks (the chains write [1, active])
-        if (c > active || c == 0) {
-            const uint8_t* root = j.state_before + (size_t)active * SAP_WALK_STATE;
-            for (u32 k = 0; k < 32; k++) st[k] = (c && active) ? root[k] : 0;
+    {   // hash part: what the previous cycle left = level (i - 1) of this walk, the previous walk's root before a leaf cycle
+        const u32 cp = c == 0 ? 0 : min(c, active) - 1;  // the cycle whose result this is
+        const u32 wp = cp / SAP_WALK_CYCLES, ip = cp % SAP_WALK_CYCLES;
+        const bool zero = c == 0 || active == 0;
+        const u32* h = j.walk_hashes + (((u64)s_item[zero ? 0 : wp] * 2 + (zero ? 0 : s_phase[wp])) * 257 + ip) * 8;
+        for (u32 k = 0; k < 8; k++) {
+            const u32 x = zero ? 0u : h[k];
+            for (u32 b = 0; b < 4; b++) st[4 * k + b] = (uint8_t)(x >> (8 * b));
         }
     }
     if (c == cycles) return;

@@ -392,10 +392,11 @@ struct zkw_storage_application_witness {
     u64* leaf_indexes = nullptr;
     zkw_storage_application_instance* instances = nullptr;
     SapItem* items = nullptr;  // the leaf before / after every query: what synthesis needs once the builder's scratch is gone
+    u32* walk_hashes = nullptr;  // [n][2][257][8]: the running hashes of every query's walks (level 0 = the leaf hash), for synthesis
     u64* cf_pi = nullptr;      // compact forms [n_instances][18] then public inputs [n_instances][4] (a20), on first synthesis
     u32 capacity = 0;
     void release() {
-        void* ptrs[] = {keys, paths, roots, leaf_indexes, instances, items, cf_pi};
+        void* ptrs[] = {keys, paths, roots, leaf_indexes, instances, items, walk_hashes, cf_pi};
         for (void* p : ptrs)
             if (p) dev_free(p);
     }
@@ -419,6 +420,7 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
     alloc((void**)&w->roots, n * 32);
     alloc((void**)&w->leaf_indexes, n * 8);
     alloc((void**)&w->items, n * sizeof(SapItem));
+    alloc((void**)&w->walk_hashes, n * 2 * 257 * 32);
     w->capacity = capacity;
     auto bail = [&](int rc) { w->release(); delete w; return rc; };
     if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed: %s", hipGetErrorString(e)));
@@ -438,7 +440,7 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
         TRY(ctx->in("sap_ip", init_merkle_paths, n * 256 * 32, &d_ip));
     }
     job.init_paths = reinterpret_cast<const u32*>(d_ip);
-    job.keys = w->keys; job.paths = w->paths; job.roots = w->roots;
+    job.keys = w->keys; job.paths = w->paths; job.roots = w->roots; job.walk_hashes = w->walk_hashes;
     TRY(ctx->scratch_t<u64>("sap_newidx", n + 1, &job.new_index));
     TRY(ctx->scratch_t<u32>("sap_prevw", n + 1, &job.prev_write));
     TRY(ctx->scratch_t<u32>("sap_chunk", n + 1, &job.chunk_of));
@@ -449,6 +451,8 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
     TRY(ctx->scratch_t<u32>("sap_A1", (n + 1) * 8, &job.A1));
     TRY(ctx->scratch_t<u32>("sap_C0", (n + 1) * 8, &job.C0));
     TRY(ctx->scratch_t<u32>("sap_C1", (n + 1) * 8, &job.C1));
+    TRY(ctx->scratch_t<u32>("sap_R0", (n + 1) * 8, &job.R0));
+    TRY(ctx->scratch_t<u32>("sap_R1", (n + 1) * 8, &job.R1));
     TRY(ctx->scratch_t<u32>("sap_viol", 1, &d_viol));
     TRY(ctx->scratch_t<u64>("sap_meta", 2, &d_meta));
     TRY(ctx->scratch_t<u64>("sap_snap", (n + 1) * 25, &d_snap));
@@ -1122,11 +1126,9 @@ extern "C" int zkw_storage_application_synthesize(zkw_ctx* ctx, zkw_storage_appl
     return nl_synthesize_with(ctx, 10, [&](std::vector<NlPrepJob>& prep) {
         std::vector<SapWalkJob> jobs(prep.size());
         for (size_t k = 0; k < prep.size(); k++)
-            jobs[k] = SapWalkJob{w->items, w->keys, w->paths, w->n ? prep[k].first_round : 0, w->n ? prep[k].n_active : 0, prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
+            jobs[k] = SapWalkJob{w->items, w->keys, w->paths, w->walk_hashes, w->n ? prep[k].first_round : 0, w->n ? prep[k].n_active : 0, prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
         SapWalkJob* d_jobs = nullptr;
         ZKW_TRY(ctx->upload("sap_walk_jobs", jobs, &d_jobs));
-        { Prof _p(ctx, "k_sap_walk_chains"); hipLaunchKernelGGL(k_sap_walk_chains, dim3((unsigned)jobs.size()), dim3(64), 0, ctx->stream, d_jobs, capacity); }
-        ZKW_TRY(launch_check("k_sap_walk_chains"));
         { Prof _p(ctx, "k_sap_walk_cycles"); hipLaunchKernelGGL(k_sap_walk_cycles, dim3((capacity * SAP_WALK_CYCLES + 256) / 256, (unsigned)jobs.size()), dim3(256), 0, ctx->stream, d_jobs, capacity); }
         return launch_check("k_sap_walk_cycles");
     }, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows);

@@ -410,9 +410,9 @@ def block_production(seed=1):
     instance of every type, two of ECRecover and StorageApplication; the three MainVM instances need the VM) with every
     builder at its PRODUCTION capacity (circuit_sequencer_api/src/geometry_config.rs:5-20): a memory queue of exactly
     136 714 queries, 117 500 decommit requests over ~2 800 SHA-256 rounds of bytecode, a log queue of ~58 000 records
-    (storage over 60 slots, events, L1 messages, keccak256 / sha256 / ecrecover calls)."""
+    (storage over 30 slots: two StorageApplication instances of 33 tree queries, as in basic_test, events, L1 messages, keccak256 / sha256 / ecrecover calls)."""
     return block_after_vm(seed=seed, total_memory=136714, n_bytecodes=400, n_decommits=117500, n_storage=35000,
-                          n_storage_cells=60, n_events=11000, n_l1_messages=700, n_precompile_calls=(60, 700, 14))
+                          n_storage_cells=30, n_events=11000, n_l1_messages=700, n_precompile_calls=(60, 700, 14))
 
 
 class StorageTree:
