@@ -4,6 +4,7 @@
 // The reference walks the sorted requests sequentially carrying counters; here every per-chunk snapshot is
 // expressed through prefix counts of the `is_fresh` flag, so chunks are filled independently.
 #pragma once
+#include "scan_kernels.cuh"
 #include "log_kernels.cuh"
 
 namespace zkw {
@@ -43,67 +44,46 @@ static __global__ __launch_bounds__(256) void k_decommit_gather_encode(const zkw
     for (int k = 0; k < 4; k++) o[k] = make_ulonglong2(e[2 * k], e[2 * k + 1]);
 }
 
-// one workgroup: inclusive prefix count of is_fresh over the sorted requests, index of the latest fresh
-// request at or before each position, the reference's ordering self-check (:99-114), and the compaction
-// of the fresh requests (= the deduplicated queue, :121-140)
-static __global__ __launch_bounds__(1024) void k_decommit_dedup(const zkw_decommit_query* __restrict__ sorted_q,
-                                                         const u64* __restrict__ sorted_enc, size_t n,
-                                                         u32* __restrict__ fresh_count /* [n] inclusive */,
-                                                         u32* __restrict__ last_fresh /* [n] */,
-                                                         zkw_decommit_query* __restrict__ dedup_q,
-                                                         u64* __restrict__ dedup_enc, u32* __restrict__ totals /* [2]: n_dedup, violations */) {
-    __shared__ u32 sh_cnt[16], sh_last[16];
-    __shared__ u32 carry_cnt, carry_last, viol;
-    if (threadIdx.x == 0) { carry_cnt = 0; carry_last = 0; viol = 0; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (size_t base = 0; base < n; base += 1024) {
-        const size_t i = base + threadIdx.x;
-        const bool live = i < n;
-        bool fresh = false;
-        if (live) {
-            const zkw_decommit_query* d = sorted_q + i;
-            fresh = d->is_fresh != 0;
-            if (i > 0) {
-                const zkw_decommit_query* p = d - 1;
-                bool same = true;
-                for (int k = 0; k < 8; k++) same &= d->hash[k] == p->hash[k];
-                if (same && (d->memory_page != p->memory_page || !(d->timestamp > p->timestamp))) atomicAdd(&viol, 1u);
-            }
-        }
-        const unsigned long long bal = __ballot(fresh);
-        const u32 below = __popcll(bal & ((2ull << lane) - 1));  // inclusive within the wave
-        // latest fresh index within the wave at or before this lane (0xFFFFFFFF = none)
-        const unsigned long long mine = bal & ((2ull << lane) - 1);
-        const u32 wl = mine ? (u32)(base + wave * 64 + (63 - __clzll(mine))) : 0xFFFFFFFFu;
-        if (lane == 63) { sh_cnt[wave] = below; }
-        if (lane == 63) { sh_last[wave] = wl; }
-        __syncthreads();
-        u32 cnt = carry_cnt + below, lf = wl;
-        u32 prev_last = carry_last;
-        for (int w = 0; w < wave; w++) { cnt += sh_cnt[w]; if (sh_last[w] != 0xFFFFFFFFu) prev_last = sh_last[w]; }
-        if (lf == 0xFFFFFFFFu) lf = prev_last;
-        if (live) {
-            fresh_count[i] = cnt;
-            last_fresh[i] = lf;
-            if (fresh) {
-                const size_t dst = cnt - 1;
-                const uint4* s = reinterpret_cast<const uint4*>(sorted_q + i);
-                uint4* d = reinterpret_cast<uint4*>(dedup_q + dst);
-                d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
-                const ulonglong2* se = reinterpret_cast<const ulonglong2*>(sorted_enc + 8 * i);
-                ulonglong2* de = reinterpret_cast<ulonglong2*>(dedup_enc + 8 * dst);
-                de[0] = se[0]; de[1] = se[1]; de[2] = se[2]; de[3] = se[3];
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) {
-            carry_cnt = cnt;
-            carry_last = lf;
-        }
-        __syncthreads();
+// is_fresh of a sorted request: the flag of flag_prefix (scan_kernels.cuh)
+struct DecommitFreshFlag {
+    const zkw_decommit_query* sorted_q;
+    __device__ u32 operator()(size_t i) const { return sorted_q[i].is_fresh ? 1u : 0u; }
+};
+
+// every request on its own, given the tiled prefix count of is_fresh (prefix[k] = fresh among [0, k)): the inclusive count, the
+// reference's ordering self-check (:99-114), the compaction of the fresh requests (= the deduplicated queue, :121-140) and the
+// position of every fresh request (fresh_pos[k] = index of the k-th). totals[1] is zeroed by the caller.
+static __global__ __launch_bounds__(256) void k_decommit_dedup(const zkw_decommit_query* __restrict__ sorted_q, const u64* __restrict__ sorted_enc, size_t n,
+                                                        const u32* __restrict__ prefix, u32* __restrict__ fresh_count /* [n] inclusive */,
+                                                        u32* __restrict__ fresh_pos /* [n] */, zkw_decommit_query* __restrict__ dedup_q,
+                                                        u64* __restrict__ dedup_enc, u32* __restrict__ totals /* [2]: n_dedup, violations */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const zkw_decommit_query* d = sorted_q + i;
+    if (i > 0) {
+        const zkw_decommit_query* p = d - 1;
+        bool same = true;
+        for (int k = 0; k < 8; k++) same &= d->hash[k] == p->hash[k];
+        if (same && (d->memory_page != p->memory_page || !(d->timestamp > p->timestamp))) atomicAdd(&totals[1], 1u);
     }
-    if (threadIdx.x == 0) { totals[0] = carry_cnt; totals[1] = viol; }
+    const u32 cnt = prefix[i + 1];
+    fresh_count[i] = cnt;
+    if (i + 1 == n) totals[0] = cnt;
+    if (cnt != prefix[i]) {  // fresh
+        const size_t dst = cnt - 1;
+        fresh_pos[dst] = (u32)i;
+        const uint4* s = reinterpret_cast<const uint4*>(sorted_q + i);
+        uint4* o = reinterpret_cast<uint4*>(dedup_q + dst);
+        o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+        const ulonglong2* se = reinterpret_cast<const ulonglong2*>(sorted_enc + 8 * i);
+        ulonglong2* de = reinterpret_cast<ulonglong2*>(dedup_enc + 8 * dst);
+        de[0] = se[0]; de[1] = se[1]; de[2] = se[2]; de[3] = se[3];
+    }
+}
+// last_fresh[i] = index of the latest fresh request at or before i (0 when there is none yet)
+static __global__ __launch_bounds__(256) void k_decommit_last_fresh(const u32* __restrict__ fresh_count, const u32* __restrict__ fresh_pos, size_t n, u32* __restrict__ last_fresh) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) last_fresh[i] = fresh_count[i] ? fresh_pos[fresh_count[i] - 1] : 0u;
 }
 
 struct DecommitBlock {

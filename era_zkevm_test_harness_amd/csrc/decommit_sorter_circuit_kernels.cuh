@@ -12,6 +12,7 @@
 // (one prefix array), and the number of pushes before a cycle is max(f - 1, 0) because a group is pushed when the
 // next one opens. The cells of a row are scattered through the generated DS_FILL_<row> lists.
 #pragma once
+#include "scan_kernels.cuh"
 #include "decommit_kernels.cuh"
 #include "ram_circuit_kernels.cuh"
 
@@ -453,30 +454,11 @@ static __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob
     for (int col = 0; col < DS_G + DS_L; col++) TR(col, rPI) = col < 4 ? job.public_input[col] : 0;
 }
 
-// fresh_prefix[k] = fresh requests among sorted[0, k), k = 0..n. One workgroup, tiles of 1024.
-static __global__ __launch_bounds__(1024) void k_ds_fresh_prefix(const zkw_decommit_query* __restrict__ sorted_q, size_t n, u32* __restrict__ prefix) {
-    __shared__ u32 s[1024];
-    __shared__ u32 carry;
-    const int t = threadIdx.x;
-    if (t == 0) { carry = 0; prefix[0] = 0; }
-    __syncthreads();
-    for (size_t base = 0; base < n; base += 1024) {
-        const size_t i = base + t;
-        const u32 f = i < n ? (sorted_q[i].is_fresh ? 1u : 0u) : 0u;
-        s[t] = f;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const u32 v = t >= off ? s[t - off] : 0;
-            __syncthreads();
-            s[t] += v;
-            __syncthreads();
-        }
-        if (i < n) prefix[i + 1] = carry + s[t];
-        __syncthreads();
-        if (t == 0) carry += s[1023];
-        __syncthreads();
-    }
-}
+// fresh_prefix[k] = fresh requests among sorted[0, k), k = 0..n: the flag of flag_prefix (scan_kernels.cuh)
+struct DsFreshFlag {
+    const zkw_decommit_query* sorted_q;
+    __device__ u32 operator()(size_t i) const { return sorted_q[i].is_fresh ? 1u : 0u; }
+};
 
 #undef TR
 }  // namespace zkw

@@ -5,6 +5,7 @@
 // "kept" (forward event not followed by its rollback) is a local predicate on neighbours, the result queue
 // is the compaction of the kept items, and the number of pushes a chunk has made is a prefix count.
 #pragma once
+#include "scan_kernels.cuh"
 #include "log_kernels.cuh"
 
 namespace zkw {
@@ -54,69 +55,56 @@ __device__ __forceinline__ bool same_words(const u32* a, const u32* b, int n) {
     return eq;
 }
 
-// one workgroup: kept flags + inclusive prefix count, the reference's asserts (:344-356, :512-533), and the
-// compaction of the kept items into normalised result records (:541-553) with their encodings
-static __global__ __launch_bounds__(1024) void k_events_dedup(const zkw_log_query* __restrict__ sorted_q, size_t n,
-                                                       u32* __restrict__ kept_count /* [n] inclusive */,
-                                                       zkw_log_query* __restrict__ result_q, u64* __restrict__ result_enc,
-                                                       u32* __restrict__ totals /* [2]: n_result, violations */) {
-    __shared__ u32 sh_cnt[16];
-    __shared__ u32 carry, viol;
-    if (threadIdx.x == 0) { carry = 0; viol = 0; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (size_t base = 0; base < n; base += 1024) {
-        const size_t i = base + threadIdx.x;
-        const bool live = i < n;
-        bool kept = false;
-        zkw_log_query me;
-        if (live) {
-            load_log(sorted_q + i, me);
-            bool bad = me.shard_id != 0;
-            if (i == 0) {
-                bad |= me.rollback != 0;
-            } else {
-                const zkw_log_query* p = sorted_q + i - 1;
-                bad |= me.rw_flag == 0;
-                if (p->timestamp == me.timestamp) {
-                    bad |= me.rollback == 0 || p->rollback != 0 || p->rw_flag == 0 ||
-                           p->tx_number_in_block != me.tx_number_in_block || p->is_service != me.is_service ||
-                           !same_words(p->address, me.address, 5) || !same_words(p->key, me.key, 8) ||
-                           !same_words(p->written_value, me.written_value, 8);
-                } else {
-                    bad |= me.rollback != 0;
-                }
-            }
-            if (bad) atomicAdd(&viol, 1u);
-            kept = !me.rollback && (i + 1 == n || sorted_q[i + 1].timestamp != me.timestamp);
+// kept = a forward record that no rollback follows (:541-553): the flag of flag_prefix (scan_kernels.cuh)
+struct EventsKeptFlag {
+    const zkw_log_query* sorted_q;
+    size_t n;
+    __device__ u32 operator()(size_t i) const { return (!sorted_q[i].rollback && (i + 1 == n || sorted_q[i + 1].timestamp != sorted_q[i].timestamp)) ? 1u : 0u; }
+};
+
+// every record on its own, given the tiled prefix count of the kept flags (prefix[k] = kept among [0, k)): the reference's asserts
+// (:344-356, :512-533), the inclusive count, and the compaction of the kept items into normalised result records (:541-553) with
+// their encodings. totals[1] (violations) is zeroed by the caller; the last record's thread writes totals[0] = n_result.
+static __global__ __launch_bounds__(256) void k_events_dedup(const zkw_log_query* __restrict__ sorted_q, size_t n, const u32* __restrict__ prefix,
+                                                      u32* __restrict__ kept_count /* [n] inclusive */,
+                                                      zkw_log_query* __restrict__ result_q, u64* __restrict__ result_enc,
+                                                      u32* __restrict__ totals /* [2]: n_result, violations */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    zkw_log_query me;
+    load_log(sorted_q + i, me);
+    bool bad = me.shard_id != 0;
+    if (i == 0) {
+        bad |= me.rollback != 0;
+    } else {
+        const zkw_log_query* p = sorted_q + i - 1;
+        bad |= me.rw_flag == 0;
+        if (p->timestamp == me.timestamp) {
+            bad |= me.rollback == 0 || p->rollback != 0 || p->rw_flag == 0 ||
+                   p->tx_number_in_block != me.tx_number_in_block || p->is_service != me.is_service ||
+                   !same_words(p->address, me.address, 5) || !same_words(p->key, me.key, 8) ||
+                   !same_words(p->written_value, me.written_value, 8);
+        } else {
+            bad |= me.rollback != 0;
         }
-        const unsigned long long bal = __ballot(kept);
-        const u32 below = __popcll(bal & ((2ull << lane) - 1));
-        if (lane == 63) sh_cnt[wave] = below;
-        __syncthreads();
-        u32 cnt = carry + below;
-        for (int w = 0; w < wave; w++) cnt += sh_cnt[w];
-        if (live) {
-            kept_count[i] = cnt;
-            if (kept) {
-                zkw_log_query r;
-                memset(&r, 0, sizeof r);
-                r.tx_number_in_block = me.tx_number_in_block;
-                r.shard_id = me.shard_id;
-                for (int k = 0; k < 5; k++) r.address[k] = me.address[k];
-                for (int k = 0; k < 8; k++) { r.key[k] = me.key[k]; r.written_value[k] = me.written_value[k]; }
-                r.is_service = me.is_service;
-                store_log(result_q + (cnt - 1), r);
-                u64 e[20];
-                encode_log_query(r, false, 0, e);
-                store_enc20(result_enc + 20 * (size_t)(cnt - 1), e);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = cnt;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) { totals[0] = carry; totals[1] = viol; }
+    if (bad) atomicAdd(&totals[1], 1u);
+    const u32 cnt = prefix[i + 1];
+    kept_count[i] = cnt;
+    if (i + 1 == n) totals[0] = cnt;
+    if (cnt != prefix[i]) {  // kept
+        zkw_log_query r;
+        memset(&r, 0, sizeof r);
+        r.tx_number_in_block = me.tx_number_in_block;
+        r.shard_id = me.shard_id;
+        for (int k = 0; k < 5; k++) r.address[k] = me.address[k];
+        for (int k = 0; k < 8; k++) { r.key[k] = me.key[k]; r.written_value[k] = me.written_value[k]; }
+        r.is_service = me.is_service;
+        store_log(result_q + (cnt - 1), r);
+        u64 e[20];
+        encode_log_query(r, false, 0, e);
+        store_enc20(result_enc + 20 * (size_t)(cnt - 1), e);
+    }
 }
 
 struct EventsBlock {

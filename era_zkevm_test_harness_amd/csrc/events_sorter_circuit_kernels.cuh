@@ -11,6 +11,7 @@
 // operation of the 4-wide log queue is three dependent permutations (lib.rs:179-221): one lane runs all three and
 // writes the three Poseidon2 rows. Cells of the general rows are scattered through the generated ES_FILL_<row> lists.
 #pragma once
+#include "scan_kernels.cuh"
 #include "decommit_sorter_circuit_kernels.cuh"
 #include "log_kernels.cuh"
 #include "../../include/zkw_events_sorter_circuit_spec.h"
@@ -402,31 +403,12 @@ static __global__ __launch_bounds__(64) void k_es_fill_boundary(const EsSynthJob
 }
 
 // kept_prefix[k] = #{ j < k : record j is a forward record whose successor has another timestamp }, k = 0..n
-// (a record without a successor is never counted: it is flushed at the very end). One workgroup, tiles of 1024.
-static __global__ __launch_bounds__(1024) void k_es_kept_prefix(const zkw_log_query* __restrict__ sorted_q, size_t n, u32* __restrict__ prefix) {
-    __shared__ u32 s[1024];
-    __shared__ u32 carry;
-    const int t = threadIdx.x;
-    if (t == 0) { carry = 0; prefix[0] = 0; }
-    __syncthreads();
-    for (size_t base = 0; base < n; base += 1024) {
-        const size_t j = base + t;
-        u32 f = 0;
-        if (j + 1 < n) f = (!sorted_q[j].rollback && sorted_q[j + 1].timestamp != sorted_q[j].timestamp) ? 1u : 0u;
-        s[t] = f;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const u32 v = t >= off ? s[t - off] : 0;
-            __syncthreads();
-            s[t] += v;
-            __syncthreads();
-        }
-        if (j < n) prefix[j + 1] = carry + s[t];
-        __syncthreads();
-        if (t == 0) carry += s[1023];
-        __syncthreads();
-    }
-}
+// (a record without a successor is never counted: it is flushed at the very end): the flag of flag_prefix (scan_kernels.cuh)
+struct EsKeptFlag {
+    const zkw_log_query* sorted_q;
+    size_t n;
+    __device__ u32 operator()(size_t j) const { return (j + 1 < n && !sorted_q[j].rollback && sorted_q[j + 1].timestamp != sorted_q[j].timestamp) ? 1u : 0u; }
+};
 
 #undef TR
 }  // namespace zkw

@@ -1,0 +1,76 @@
+// scan_kernels.cuh — tiled prefix count of a per-item flag: prefix[k] = #{ i < k : flag(i) }, k = 0..n. Three launches (per-tile
+// inclusive counts with wave ballots, an exclusive scan of the tile totals, the tile offsets added), any n; replaces the
+// single-workgroup loops the synthesis of the sorter circuits used for their compaction indices.
+#pragma once
+#include "zkw_ctx.h"
+
+namespace zkw {
+
+constexpr int FLAG_PREFIX_TILE = 1024;
+
+template <class Flag>
+static __global__ __launch_bounds__(FLAG_PREFIX_TILE) void k_flag_prefix_tiles(Flag flag, size_t n, u32* __restrict__ prefix, u32* __restrict__ tile_sums) {
+    __shared__ u32 s_wave[FLAG_PREFIX_TILE / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t i = (size_t)blockIdx.x * FLAG_PREFIX_TILE + t;
+    const bool f = i < n && flag(i) != 0;
+    const unsigned long long bal = __ballot(f);
+    const u32 incl = __popcll(bal & ((2ull << lane) - 1));
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    u32 before = 0;
+    for (int w = 0; w < wave; w++) before += s_wave[w];
+    if (i < n) prefix[i + 1] = before + incl;
+    if (t == FLAG_PREFIX_TILE - 1) tile_sums[blockIdx.x] = before + incl;
+    if (i == 0) prefix[0] = 0;
+}
+
+// exclusive scan of the tile totals in place: one workgroup, n_tiles = n / 1024 elements
+static __global__ __launch_bounds__(1024) void k_flag_prefix_offsets(u32* __restrict__ tile_sums, u32 n_tiles) {
+    __shared__ u32 s[1024];
+    __shared__ u32 carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < n_tiles; base += 1024) {
+        const u32 i = base + t;
+        const u32 v = i < n_tiles ? tile_sums[i] : 0;
+        s[t] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const u32 x = t >= off ? s[t - off] : 0;
+            __syncthreads();
+            s[t] += x;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_sums[i] = carry + s[t] - v;
+        __syncthreads();
+        if (t == 0) carry += s[1023];
+        __syncthreads();
+    }
+}
+
+static __global__ __launch_bounds__(256) void k_flag_prefix_apply(u32* __restrict__ prefix, const u32* __restrict__ tile_offsets, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) prefix[i + 1] += tile_offsets[i / FLAG_PREFIX_TILE];
+}
+
+// d_prefix: [n + 1] on the device; stream-ordered on the context's stream
+template <class Flag>
+static int flag_prefix(zkw_ctx* ctx, const char* name, Flag flag, size_t n, u32* d_prefix) {
+    if (n == 0) return hipMemsetAsync(d_prefix, 0, sizeof(u32), ctx->stream) == hipSuccess ? ZKW_OK : fail(ZKW_ERR_HIP, "memset failed");
+    const unsigned n_tiles = (unsigned)((n + FLAG_PREFIX_TILE - 1) / FLAG_PREFIX_TILE);
+    u32* d_tiles = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("flag_prefix_tiles", n_tiles, &d_tiles));
+    { Prof _p(ctx, name); hipLaunchKernelGGL((k_flag_prefix_tiles<Flag>), dim3(n_tiles), dim3(FLAG_PREFIX_TILE), 0, ctx->stream, flag, n, d_prefix, d_tiles); }
+    ZKW_TRY(launch_check(name));
+    if (n_tiles > 1) {
+        hipLaunchKernelGGL(k_flag_prefix_offsets, dim3(1), dim3(1024), 0, ctx->stream, d_tiles, n_tiles);
+        ZKW_TRY(launch_check("k_flag_prefix_offsets"));
+        hipLaunchKernelGGL(k_flag_prefix_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_prefix, d_tiles, n);
+        ZKW_TRY(launch_check("k_flag_prefix_apply"));
+    }
+    return ZKW_OK;
+}
+
+}  // namespace zkw

@@ -73,8 +73,15 @@ static int decommit_prepare(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_dec
     ZKW_TRY(ctx->scratch_t<u32>("dec_fresh", n, &fresh_count));
     ZKW_TRY(ctx->scratch_t<u32>("dec_lastf", n, &last_fresh));
     ZKW_TRY(ctx->scratch_t<u32>("dec_totals", 2, &totals));
-    { Prof _p(ctx, "k_decommit_dedup"); hipLaunchKernelGGL(k_decommit_dedup, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, w->sorted_enc, n, fresh_count, last_fresh, w->dedup_q, w->dedup_enc, totals); }
+    u32 *fresh_prefix = nullptr, *fresh_pos = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("dec_fresh_prefix", n + 1, &fresh_prefix));
+    ZKW_TRY(ctx->scratch_t<u32>("dec_fresh_pos", n, &fresh_pos));
+    HIP_TRY(hipMemsetAsync(totals, 0, 2 * sizeof(u32), ctx->stream));
+    ZKW_TRY(flag_prefix(ctx, "k_decommit_fresh_prefix", DecommitFreshFlag{w->sorted_q}, n, fresh_prefix));
+    { Prof _p(ctx, "k_decommit_dedup"); hipLaunchKernelGGL(k_decommit_dedup, dim3(grid), dim3(256), 0, ctx->stream, w->sorted_q, w->sorted_enc, n, fresh_prefix, fresh_count, fresh_pos, w->dedup_q, w->dedup_enc, totals); }
     ZKW_TRY(launch_check("k_decommit_dedup"));
+    { Prof _p(ctx, "k_decommit_last_fresh"); hipLaunchKernelGGL(k_decommit_last_fresh, dim3(grid), dim3(256), 0, ctx->stream, fresh_count, fresh_pos, n, last_fresh); }
+    ZKW_TRY(launch_check("k_decommit_last_fresh"));
     u32 h_totals[2] = {0, 0};
     ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
     if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "decommit requests with the same hash disagree on page or are not "
@@ -298,7 +305,11 @@ static int events_run(zkw_ctx* ctx, zkw_events_witness* w, const zkw_log_query* 
     ZKW_TRY(launch_check("k_log_gather_encode"));
     ZKW_TRY(ctx->scratch_t<u32>("evt_kept", n, &kept));
     ZKW_TRY(ctx->scratch_t<u32>("evt_totals", 2, &totals));
-    { Prof _p(ctx, "k_events_dedup"); hipLaunchKernelGGL(k_events_dedup, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, kept, w->result_q, r_enc, totals); }
+    u32* kept_prefix = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("evt_kept_prefix", n + 1, &kept_prefix));
+    HIP_TRY(hipMemsetAsync(totals, 0, 2 * sizeof(u32), ctx->stream));
+    ZKW_TRY(flag_prefix(ctx, "k_events_kept_prefix", EventsKeptFlag{w->sorted_q, n}, n, kept_prefix));
+    { Prof _p(ctx, "k_events_dedup"); hipLaunchKernelGGL(k_events_dedup, dim3(grid), dim3(256), 0, ctx->stream, w->sorted_q, n, kept_prefix, kept, w->result_q, r_enc, totals); }
     ZKW_TRY(launch_check("k_events_dedup"));
     u32 h_totals[2] = {0, 0};
     ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
@@ -830,8 +841,7 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
     HIP_TRY(hipSetDevice(ctx->device));
     if (!w->fresh_prefix) {
         HIP_TRY(dev_malloc((void**)&w->fresh_prefix, (w->n + 2) * sizeof(u32)));
-        { Prof _p(ctx, "k_ds_fresh_prefix"); hipLaunchKernelGGL(k_ds_fresh_prefix, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, w->n, w->fresh_prefix); }
-        ZKW_TRY(launch_check("k_ds_fresh_prefix"));
+        ZKW_TRY(flag_prefix(ctx, "k_ds_fresh_prefix", DsFreshFlag{w->sorted_q}, w->n, w->fresh_prefix));
     }
     u32* d_hist = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("ds_hist", n_instances * 256, &d_hist));
@@ -896,8 +906,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
     HIP_TRY(hipSetDevice(ctx->device));
     if (!w->kept_prefix) {
         HIP_TRY(dev_malloc((void**)&w->kept_prefix, (n + 2) * sizeof(u32)));
-        { Prof _p(ctx, "k_es_kept_prefix"); hipLaunchKernelGGL(k_es_kept_prefix, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, w->kept_prefix); }
-        ZKW_TRY(launch_check("k_es_kept_prefix"));
+        ZKW_TRY(flag_prefix(ctx, "k_es_kept_prefix", EsKeptFlag{w->sorted_q, n}, n, w->kept_prefix));
     }
     u32* d_hist = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("es_hist", n_instances * 256, &d_hist));

@@ -93,3 +93,30 @@ def test_code_decommitter_random(ctx, oracle, seed):
     t.free()
     w.free()
     dec.free()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_storage_application_random(ctx, oracle, seed):
+    """type 10: random numbers of slots, read / write mixes and capacities (2 = one write per instance .. larger than the block):
+    every instance cut the reference's chunking rule makes, dirty slots, both checkers"""
+    from era_zkevm_test_harness_amd import native
+    from sap_case import storage_application_case
+
+    rng = np.random.default_rng(300 + seed)
+    n = int(rng.integers(1, 12))
+    q, tails, tree, idx, paths = storage_application_case(oracle, n, seed=400 + seed)
+    q["rw_flag"] = (rng.random(n) < rng.random()).astype(np.uint8)
+    ro = q["rw_flag"] == 0
+    q["written_value"][ro] = q["read_value"][ro]
+    capacity = int(rng.choice([2, 3, 5, 7]))  # 7 walks x 257 cycles x 122 rows < 2^18 rows
+    w = ctx.decompose_into_storage_application_witnesses(q, tails, idx, paths, tree.root, tree.next_enumeration_index, capacity)
+    o = oracle.storage_application_build(tree, q, tails, capacity)
+    assert w.num_instances == o["instances"].size
+    t = native.Trace(ctx, N_ROWS, 1, n_cols=native.SA_COLS)
+    for i in sorted({0, w.num_instances // 2, w.num_instances - 1}):
+        _dirty(ctx, t, native.SA_COLS)
+        ctx.synthesize_storage_application(w, t, i, 1, 0)
+        _compare(ctx, native, t, i, None, oracle.storage_application_synthesize(o, q, i, capacity, N_ROWS),
+                 ctx.check_if_satisfied_storage_application, oracle.storage_application_check, capacity)
+    t.free()
+    w.free()
