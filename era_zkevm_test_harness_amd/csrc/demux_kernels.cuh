@@ -5,6 +5,7 @@
 // chains run concurrently with the input queue's chain in one launch.
 #pragma once
 #include "events_kernels.cuh"
+#include "scan_kernels.cuh"
 
 namespace zkw {
 
@@ -23,84 +24,45 @@ __device__ __forceinline__ int demux_route(const zkw_log_query& q, const zkw_dem
     return -2;
 }
 
-// one workgroup, two sweeps: (1) totals per route -> queue offsets; (2) inclusive prefix counts per route,
-// scatter of the routed items and their encodings
-static __global__ __launch_bounds__(1024) void k_demux_route(const zkw_log_query* __restrict__ q, const u64* __restrict__ in_enc,
-                                                      size_t n, zkw_demux_params params,
-                                                      u32* __restrict__ route_count /* [6][n] inclusive */,
-                                                      zkw_log_query* __restrict__ out_q, u64* __restrict__ out_enc,
-                                                      u64* __restrict__ totals /* [8]: offsets[7], violations */) {
-    __shared__ u32 sh_cnt[6][16];
-    __shared__ u32 carry[6], base[7], viol;
-    if (threadIdx.x < 6) carry[threadIdx.x] = 0;
-    if (threadIdx.x == 0) viol = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int sweep = 0; sweep < 2; sweep++) {
-        for (size_t b0 = 0; b0 < n; b0 += 1024) {
-            const size_t i = b0 + threadIdx.x;
-            const bool live = i < n;
-            int r = -1;
-            if (live) {
-                zkw_log_query m;
-                m.aux_byte = q[i].aux_byte; m.shard_id = q[i].shard_id; m.rollback = q[i].rollback;
-                for (int k = 0; k < 5; k++) m.address[k] = q[i].address[k];
-                r = demux_route(m, params);
-                if (r == -2 && sweep == 0) atomicAdd(&viol, 1u);
-            }
-            u32 mine = 0, below[6];  // inclusive counts inside the wave, per route
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                const unsigned long long bal = __ballot(r == c);
-                below[c] = __popcll(bal & ((2ull << lane) - 1));
-                if (lane == 63) sh_cnt[c][wave] = below[c];
-                if (r == c) mine = below[c];
-            }
-            __syncthreads();
-            u32 cnt[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                u32 v = carry[c];
-                for (int w = 0; w < wave; w++) v += sh_cnt[c][w];
-                cnt[c] = v;  // exclusive of this wave
-            }
-            u32 tile_tot[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                u32 v = 0;
-                for (int w = 0; w < 16; w++) v += sh_cnt[c][w];
-                tile_tot[c] = v;
-            }
-            if (sweep == 1 && live) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) route_count[(size_t)c * n + i] = cnt[c] + below[c];
-            }
-            if (sweep == 1 && live && r >= 0) {
-                const size_t dst = base[r] + cnt[r] + mine - 1;
-                zkw_log_query m;
-                load_log(q + i, m);
-                store_log(out_q + dst, m);
-                const ulonglong2* se = reinterpret_cast<const ulonglong2*>(in_enc + 20 * i);
-                ulonglong2* de = reinterpret_cast<ulonglong2*>(out_enc + 20 * dst);
-#pragma unroll
-                for (int k = 0; k < 10; k++) de[k] = se[k];
-            }
-            __syncthreads();
-            if (threadIdx.x < 6) carry[threadIdx.x] += tile_tot[threadIdx.x];
-            __syncthreads();
-        }
-        if (sweep == 0) {
-            if (threadIdx.x == 0) {
-                base[0] = 0;
-                for (int c = 0; c < 6; c++) base[c + 1] = base[c] + carry[c];
-                for (int c = 0; c < 7; c++) totals[c] = base[c];
-                totals[7] = viol;
-            }
-            __syncthreads();
-            if (threadIdx.x < 6) carry[threadIdx.x] = 0;
-            __syncthreads();
-        }
+// the route of item i: the functor of route_prefix (scan_kernels.cuh); -2 (no circuit takes the log) counts as a violation below
+struct DemuxRoute {
+    const zkw_log_query* q;
+    zkw_demux_params params;
+    __device__ int operator()(size_t i) const {
+        zkw_log_query m;
+        m.aux_byte = q[i].aux_byte; m.shard_id = q[i].shard_id; m.rollback = q[i].rollback;
+        for (int k = 0; k < 5; k++) m.address[k] = q[i].address[k];
+        return demux_route(m, params);
     }
+};
+
+// queue offsets from the routes' totals (totals[7] = violations is zeroed by the caller and counted by k_demux_route)
+static __global__ void k_demux_offsets(const u32* __restrict__ route_count /* [6][n] inclusive */, size_t n, u64* __restrict__ totals /* [8] */) {
+    if (threadIdx.x || blockIdx.x) return;
+    u64 acc = 0;
+    for (int c = 0; c < 6; c++) { totals[c] = acc; acc += n ? route_count[(size_t)c * n + n - 1] : 0; }
+    totals[6] = acc;
+}
+
+// every item on its own, given the tiled inclusive counts per route: the scatter of the routed items and their encodings into
+// the six queues (stable: position = offset of the queue + items of the same route before it)
+static __global__ __launch_bounds__(256) void k_demux_route(const zkw_log_query* __restrict__ q, const u64* __restrict__ in_enc, size_t n,
+                                                     zkw_demux_params params, const u32* __restrict__ route_count /* [6][n] inclusive */,
+                                                     zkw_log_query* __restrict__ out_q, u64* __restrict__ out_enc,
+                                                     u64* __restrict__ totals /* [8]: offsets[7], violations */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = DemuxRoute{q, params}(i);
+    if (r == -2) atomicAdd(reinterpret_cast<unsigned long long*>(&totals[7]), 1ull);
+    if (r < 0) return;
+    const size_t dst = totals[r] + route_count[(size_t)r * n + i] - 1;
+    zkw_log_query m;
+    load_log(q + i, m);
+    store_log(out_q + dst, m);
+    const ulonglong2* se = reinterpret_cast<const ulonglong2*>(in_enc + 20 * i);
+    ulonglong2* de = reinterpret_cast<ulonglong2*>(out_enc + 20 * dst);
+#pragma unroll
+    for (int k = 0; k < 10; k++) de[k] = se[k];
 }
 
 struct DemuxBlock {

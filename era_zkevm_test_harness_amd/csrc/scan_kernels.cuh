@@ -73,4 +73,52 @@ static int flag_prefix(zkw_ctx* ctx, const char* name, Flag flag, size_t n, u32*
     return ZKW_OK;
 }
 
+// ---- K routes at once: route(i) in [-1, K); count[c][i] = #{ j <= i : route(j) == c } (inclusive), totals[c] = count[c][n - 1].
+// The same three launches with K counters side by side (the log demuxer's six stable compactions).
+template <int K, class Route>
+static __global__ __launch_bounds__(FLAG_PREFIX_TILE) void k_route_prefix_tiles(Route route, size_t n, u32* __restrict__ count /* [K][n] */, u32* __restrict__ tile_sums /* [K][n_tiles] */) {
+    __shared__ u32 s_wave[K][FLAG_PREFIX_TILE / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t i = (size_t)blockIdx.x * FLAG_PREFIX_TILE + t;
+    const int r = i < n ? route(i) : -1;
+    u32 incl[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        const unsigned long long bal = __ballot(r == c);
+        incl[c] = __popcll(bal & ((2ull << lane) - 1));
+        if (lane == 63) s_wave[c][wave] = incl[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        u32 before = 0;
+        for (int w = 0; w < wave; w++) before += s_wave[c][w];
+        if (i < n) count[(size_t)c * n + i] = before + incl[c];
+        if (t == FLAG_PREFIX_TILE - 1) tile_sums[(size_t)c * gridDim.x + blockIdx.x] = before + incl[c];
+    }
+}
+template <int K>
+static __global__ __launch_bounds__(256) void k_route_prefix_apply(u32* __restrict__ count, const u32* __restrict__ tile_offsets, size_t n, u32 n_tiles) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < K; c++) count[(size_t)c * n + i] += tile_offsets[(size_t)c * n_tiles + i / FLAG_PREFIX_TILE];
+}
+template <int K, class Route>
+static int route_prefix(zkw_ctx* ctx, const char* name, Route route, size_t n, u32* d_count /* [K][n] */) {
+    if (n == 0) return ZKW_OK;
+    const unsigned n_tiles = (unsigned)((n + FLAG_PREFIX_TILE - 1) / FLAG_PREFIX_TILE);
+    u32* d_tiles = nullptr;
+    ZKW_TRY(ctx->scratch_t<u32>("route_prefix_tiles", (size_t)K * n_tiles, &d_tiles));
+    { Prof _p(ctx, name); hipLaunchKernelGGL((k_route_prefix_tiles<K, Route>), dim3(n_tiles), dim3(FLAG_PREFIX_TILE), 0, ctx->stream, route, n, d_count, d_tiles); }
+    ZKW_TRY(launch_check(name));
+    if (n_tiles > 1) {
+        for (int c = 0; c < K; c++) hipLaunchKernelGGL(k_flag_prefix_offsets, dim3(1), dim3(1024), 0, ctx->stream, d_tiles + (size_t)c * n_tiles, n_tiles);
+        ZKW_TRY(launch_check("k_flag_prefix_offsets"));
+        hipLaunchKernelGGL((k_route_prefix_apply<K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_count, d_tiles, n, n_tiles);
+        ZKW_TRY(launch_check("k_route_prefix_apply"));
+    }
+    return ZKW_OK;
+}
+
 }  // namespace zkw

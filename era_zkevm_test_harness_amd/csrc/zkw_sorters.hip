@@ -481,7 +481,11 @@ static int demux_run(zkw_ctx* ctx, zkw_demux_witness* w, const zkw_log_query* d_
     { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, in_enc); }
     ZKW_TRY(launch_check("k_encode_log"));
     u32* route_count = w->route_count;
-    { Prof _p(ctx, "k_demux_route"); hipLaunchKernelGGL(k_demux_route, dim3(1), dim3(1024), 0, ctx->stream, d_q, in_enc, n, params, route_count, w->out_q, out_enc, w->d_offsets); }
+    HIP_TRY(hipMemsetAsync(w->d_offsets, 0, 8 * sizeof(u64), ctx->stream));
+    ZKW_TRY((route_prefix<6>(ctx, "k_demux_route_prefix", DemuxRoute{d_q, params}, n, route_count)));
+    hipLaunchKernelGGL(k_demux_offsets, dim3(1), dim3(64), 0, ctx->stream, route_count, n, w->d_offsets);
+    ZKW_TRY(launch_check("k_demux_offsets"));
+    { Prof _p(ctx, "k_demux_route"); hipLaunchKernelGGL(k_demux_route, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, in_enc, n, params, route_count, w->out_q, out_enc, w->d_offsets); }
     ZKW_TRY(launch_check("k_demux_route"));
     u64 h_tot[8];
     ZKW_TRY(ctx->read_small(h_tot, w->d_offsets, sizeof h_tot));
