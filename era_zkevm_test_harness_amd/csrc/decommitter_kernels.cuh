@@ -40,6 +40,11 @@ __device__ __forceinline__ void sha256_compress(u32 st[8], u32 w[16]) {
     st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
 }
 
+// what a round of a builder's walk does to the queues of its circuit (the queue section of the netlist circuits,
+// netlist_queue_kernels.cuh): the request it belongs to, the index of the first memory query it pushes, how many it pushes,
+// flags: 1 = the round pops its request, 2 = the last push is the digest write (sha256)
+struct RoundOps { u32 request, first_query, n_push, flags; };
+
 struct DecommitterJob {
     const zkw_decommit_query* requests;  // [n_requests]
     const u32* words;                    // [total_words][8] LE limbs
@@ -51,6 +56,7 @@ struct DecommitterJob {
     u32* violations;
     u64 n_requests;
     zkw_sha256_round_record* sha256_rounds;  // may be null: [total_rounds], the cycles of the CodeDecommitter circuit (type 3)
+    RoundOps* round_ops;                     // may be null: [total_rounds]
 };
 
 // one lane per request: SHA-256 over its bytecode (two big-endian words per block, padding in the last
@@ -95,6 +101,7 @@ static __global__ __launch_bounds__(64) void k_decommitter_sha(DecommitterJob jo
         u32* o = job.round_states + 8 * (r0 + r);
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = st[j];
+        if (job.round_ops) job.round_ops[r0 + r] = RoundOps{(u32)k, (u32)(w0 + 2 * r), 2 * r + 1 < nw ? 2u : 1u, r == 0 ? 1u : 0u};
     }
     bool ok = true;
     for (int j = 1; j < 8; j++) ok &= st[j] == q.hash[7 - j];

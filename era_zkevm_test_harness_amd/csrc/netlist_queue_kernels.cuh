@@ -1,0 +1,293 @@
+// netlist_queue_kernels.cuh — the QUEUE SECTION of the netlist circuits (format, reference citations: include/zkw_netlist_queue.h):
+// the request-queue pops and memory-queue pushes of Sha256RoundFunction (6) and CodeDecommitter (3) as Poseidon2 rows below the
+// hash netlist of a "zkw trace v4" trace, tied to it by copy constraints (value nibbles of the hashed words / of the digest).
+// Queue arithmetic: circuit_encodings/src/lib.rs:180-203, 391-429; encodings: memory_query.rs:24-118, log_query.rs:102-396,
+// decommittment_request.rs:9-74. Placement is this library's own.
+//
+// Fill (k_nlq_fill): a LANE owns one operation of one cycle (grid: cycles / 64 x operations x instances — a workgroup's lanes run the
+// same operation, so control flow is uniform); the section is region-major (consecutive cycles = consecutive rows), so every store of
+// a wave is one 512-byte row segment. The linked cells are read back from the netlist rows that k_nl_fill wrote earlier on the stream.
+#pragma once
+#include "../../include/zkw_netlist_queue.h"
+#include "netlist_kernels.cuh"
+
+namespace zkw {
+
+// what a round of the builder's walk did to the queues (written by k_precompile_walk / k_decommitter_sha): the request it belongs to,
+// the index of the first memory query it pushes, how many it pushes, flags: 1 = the round pops its request, 2 = it pushes one more
+// query than the reads (sha256: the digest write)
+struct NlqQueueIn { const void* items; const u64* states; u64 init[12]; u64 n_items; };
+struct NlqJob { const nlq_feed* feed; u64* trace; NlqQueueIn queues[NLQ_MAX_QUEUES]; };
+struct NlqFeedJob { const RoundOps* round_ops; u64 first_round; u32 n_active; nlq_feed* feed; };
+struct NlqFreeHome { uint16_t row, col; };  // the one cell of a cycle that holds FREE element i
+
+#define NLQ_TR(col, row) trace[(size_t)(col) * n_rows + (size_t)(row)]
+
+// feed of a cycle from the builder's per-round record (the oracle walks the rounds instead: orc_sha256_queue_feed)
+static __global__ __launch_bounds__(64) void k_nlq_feed(int circuit_type, const NlqFeedJob* __restrict__ jobs, u32 capacity, u32 n_ops) {
+    const NlqFeedJob j = jobs[blockIdx.y];
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= capacity) return;
+    nlq_feed* f = j.feed + (size_t)c * n_ops;
+    if (c >= j.n_active) {  // idle: everything disabled, the queues stay where the last active round left them
+        u32 nreq = 0, nq = 0;
+        if (j.n_active || j.first_round) {
+            const RoundOps ro = j.round_ops[j.first_round + j.n_active - 1];
+            nreq = ro.request + 1; nq = ro.first_query + ro.n_push;
+        }
+        f[0] = nlq_feed{0, nreq};
+        for (u32 k = 1; k < n_ops; k++) f[k] = nlq_feed{0, nq};
+        return;
+    }
+    const RoundOps ro = j.round_ops[j.first_round + c];
+    const u32 pop = ro.flags & 1;
+    f[0] = nlq_feed{pop, pop ? ro.request : ro.request + 1};
+    if (circuit_type == 6) {
+        f[1] = nlq_feed{1, ro.first_query};
+        f[2] = nlq_feed{1, ro.first_query + 1};
+        f[3] = nlq_feed{(ro.flags >> 1) & 1, ro.first_query + 2};
+    } else {
+        f[1] = nlq_feed{1, ro.first_query};
+        f[2] = nlq_feed{ro.n_push > 1 ? 1u : 0u, ro.first_query + 1};
+    }
+}
+
+struct NlqCellStore {  // cell k of a block whose first row (within the cycle's operations) is r0, for cycle c
+    u64* trace; size_t n_rows; size_t row00; u32 capacity, g;
+    __device__ __forceinline__ u64& at(u32 r0, u32 k) const {
+        const u32 r = k >= 2 * g ? 2 : k >= g ? 1 : 0;  // (blocks have at most 130 cells, g >= 60)
+        return trace[(size_t)(k - r * g) * n_rows + row00 + (size_t)(r0 + r) * capacity];
+    }
+};
+
+// the 130 variables of one flattened Poseidon2 gate (oracle/ram_circuit.c orc_poseidon2_flattened), stored as they are produced
+__device__ __forceinline__ void nlq_fill_p2(const NlqCellStore& st, u32 r0, u64 s[12]) {
+    u32 pos = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) st.at(r0, pos++) = gl::canon(s[k]);
+    p2::external(s);
+    int r = 0;
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+        p2::full_round(s, r);
+#pragma unroll
+        for (int j = 0; j < 12; j++) st.at(r0, pos + j) = gl::canon(s[j]);
+        pos += 12;
+    }
+    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
+        s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
+        st.at(r0, pos++) = gl::canon(s[0]);
+        p2::internal(s);
+    }
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+        p2::full_round(s, r);
+#pragma unroll
+        for (int j = 0; j < 12; j++) { s[j] = gl::canon(s[j]); st.at(r0, pos + j) = s[j]; }
+        pos += 12;
+    }
+}
+
+__device__ __forceinline__ u64 nlq_linked_value(const nl_spec& S, const NlqFreeHome* __restrict__ fh, const u64* __restrict__ trace, size_t n_rows, u32 capacity,
+                                                u32 c, const nlq_op& op, u32 cell) {
+    uint32_t next = 0;
+    const u32 ref = nlq_link_ref(&op, cell, &next);
+    if (next) return nl_home_cell(S, trace, n_rows, capacity, c + 1, 0, ref);
+    const NlqFreeHome h = fh[ref - NL_REF_FREE];
+    return NLQ_TR(h.col, (size_t)c * S.rows_per_cycle + h.row);
+}
+
+__device__ __forceinline__ void nlq_state_before(const NlqQueueIn& q, u32 w, u64 idx, u64 out[12]) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) out[k] = 0;
+    const u64* src = idx ? q.states + (idx - 1) * w : q.init;
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+        if ((u32)k < w) out[k] = src[k];
+}
+
+// enc element e of an operation from a cell reader
+template <class F>
+__device__ __forceinline__ u64 nlq_enc_value(u32 item, u32 e, F&& cell) {
+    const u32 n = nlq_enc_n_terms(item, e);
+    u64 acc = 0;
+    for (u32 i = 0; i < n; i++) {
+        const nlq_term tm = nlq_enc_term(item, e, i);
+        acc = gl::add(acc, gl::mul(gl::canon(cell(tm.cell)), 1ull << tm.shift));
+    }
+    return gl::canon(acc);
+}
+
+// grid (ceil(capacity / 64), n_ops, instances)
+static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, nlq_desc d, const NlqJob* __restrict__ jobs,
+                                                        u32 capacity, size_t n_rows) {
+    const nl_spec& S = devp->s;
+    const NlqJob& job = jobs[blockIdx.z];
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (c >= capacity) return;
+    u64* trace = job.trace;
+    const nlq_op op = d.ops[j];
+    const nlq_feed f = job.feed[(size_t)c * d.n_ops + j];
+    const NlqQueueIn& Q = job.queues[op.queue];
+    const u32 G = S.g, w = nlq_kind_width(op.kind), ncomp = nlq_item_comps(op.item), nenc = nlq_item_enc(op.item), r0 = nlq_op_row0(&d, G, j);
+    const NlqCellStore st{trace, n_rows, (size_t)NLQ_BASE(&S, capacity) + 1 + c, capacity, G};
+    const void* rec = f.en ? static_cast<const char*>(Q.items) + (size_t)f.idx * nlq_item_bytes(op.item) : nullptr;
+    // components (the cells are re-read for the encodings: they are this lane's own stores, L2-resident)
+    st.at(r0, 0) = f.en ? 1 : 0;
+    for (u32 k = 1; k < ncomp; k++)
+        st.at(r0, k) = nlq_comp_linked(&op, k) ? nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k) : nlq_item_component(op.item, rec, k);
+    for (u32 e = 0; e < nenc; e++)
+        st.at(r0, ncomp + e) = nlq_enc_value(op.item, e, [&](u32 cell) { return st.at(r0, cell); });
+    u64 old[12];
+    nlq_state_before(Q, w, f.idx, old);
+    u64 s[12];  // (the encodings are read back from the lane's own cells: no per-lane array with run-time indices, i.e. no scratch)
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = st.at(r0, ncomp + k);
+    if (op.kind != NLQ_POP4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[8 + k] = old[8 + k];
+        nlq_fill_p2(st, nlq_p2_row0(&d, G, j, 0), s);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[8 + k] = 0;
+        nlq_fill_p2(st, nlq_p2_row0(&d, G, j, 0), s);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = st.at(r0, ncomp + 8 + k);
+        nlq_fill_p2(st, nlq_p2_row0(&d, G, j, 1), s);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { s[k] = st.at(r0, ncomp + 16 + k); s[4 + k] = old[k]; }
+        nlq_fill_p2(st, nlq_p2_row0(&d, G, j, 2), s);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+        if ((u32)k < w) {
+            st.at(r0, ncomp + nenc + k) = old[k];
+            st.at(r0, ncomp + nenc + w + k) = f.en ? s[k] : old[k];
+        }
+    // QBND: the queue states before cycle 0 (written by the first operation on the queue) and after the last cycle (by the last)
+    const size_t q0 = NLQ_BASE(&S, capacity);
+    bool first = true, last = true;
+    for (u32 i = 0; i < d.n_ops; i++)
+        if (d.ops[i].queue == op.queue) { if (i < j) first = false; if (i > j) last = false; }
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+        if ((u32)k < w) {
+            if (c == 0 && first) NLQ_TR(nlq_bnd_col(&d, op.queue, 0, k), q0) = old[k];
+            if (c + 1 == capacity && last) NLQ_TR(nlq_bnd_col(&d, op.queue, 1, k), q0) = f.en ? s[k] : old[k];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ checker (codes of oracle/netlist_queue.c)
+__device__ __forceinline__ u64 nlq_cell_at(const nl_spec& S, const u64* __restrict__ trace, size_t n_rows, u32 capacity, u32 c, u32 r0, u32 k) {
+    return NLQ_TR(k % S.g, NLQ_ROW(&S, capacity, r0 + k / S.g, c));
+}
+__device__ u64 nlq_prev_new(const nl_spec& S, const nlq_desc& d, const u64* __restrict__ trace, size_t n_rows, u32 capacity, u32 c, u32 j, u32 queue, u32 k) {
+    for (;;) {
+        while (j > 0) {
+            j--;
+            if (d.ops[j].queue == queue) return nlq_cell_at(S, trace, n_rows, capacity, c, nlq_op_row0(&d, S.g, j), nlq_new0(&d.ops[j]) + k);
+        }
+        if (c == 0) return NLQ_TR(nlq_bnd_col(&d, queue, 0, k), NLQ_BASE(&S, capacity));
+        c--;
+        j = d.n_ops;
+    }
+}
+
+// grid (ceil(capacity / 64), n_ops): one lane per operation of a cycle; lane (0, 0, 0) also checks the QBND row
+static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, nlq_desc d, const u64* __restrict__ trace,
+                                                         u32 capacity, size_t n_rows, CheckResult* res) {
+    const nl_spec& S = devp->s;
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    const u32 G = S.g, p2rows = nlq_rows_for(NLQ_P2_CELLS, G);
+    const size_t q0 = NLQ_BASE(&S, capacity);
+    if (c == 0 && j == 0) {
+        for (u32 q = 0; q < d.n_queues; q++) {
+            bool ok = true;
+            for (u32 k = 0; k < d.width[q]; k++)
+                if (NLQ_TR(nlq_bnd_col(&d, q, 1, k), q0) != nlq_prev_new(S, d, trace, n_rows, capacity, capacity, 0, q, k)) ok = false;
+            if (!ok) flag_bad(res, 4, 0x100 + q, q0);
+        }
+        for (u32 col = nlq_bnd_cells(&d); col < G; col++)
+            if (NLQ_TR(col, q0)) { flag_bad(res, 6, col, q0); break; }
+    }
+    if (c >= capacity) return;
+    const nlq_op op = d.ops[j];
+    const u32 w = nlq_kind_width(op.kind), ncomp = nlq_item_comps(op.item), nenc = nlq_item_enc(op.item), r0 = nlq_op_row0(&d, G, j);
+    const u32 ncells = ncomp + nenc + 2 * w, erows = nlq_rows_for(ncells, G);
+    const u64 row_e = NLQ_ROW(&S, capacity, r0, c);
+    auto cell = [&](u32 k) { return nlq_cell_at(S, trace, n_rows, capacity, c, r0, k); };
+    const u64 en = cell(0);
+    if (en > 1) flag_bad(res, 3, j, row_e);
+    const size_t hdr_row = (size_t)c * S.rows_per_cycle;
+    if (op.en_rule == NLQ_EN_RESET && en != NLQ_TR(NL_HDR_RESET, hdr_row)) flag_bad(res, 3, 0x100 + j, row_e);
+    if (op.en_rule == NLQ_EN_ACTIVE && gl::canon(en) != gl::canon(gl::sub(1, gl::canon(NLQ_TR(NL_HDR_IDLE, hdr_row))))) flag_bad(res, 3, 0x100 + j, row_e);
+    bool ok = true;
+    for (u32 k = 1; k < ncomp; k++)
+        if (nlq_comp_linked(&op, k) && cell(k) != nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k)) ok = false;
+    if (!ok) flag_bad(res, 2, j, row_e);
+    u64 enc[20], old[12], nw[12];
+    for (u32 e = 0; e < nenc; e++) {
+        enc[e] = cell(ncomp + e);
+        if (nlq_enc_value(op.item, e, cell) != gl::canon(enc[e])) flag_bad(res, 7, 32 * j + e, row_e);
+    }
+    for (u32 k = 0; k < 12; k++) { old[k] = k < w ? cell(ncomp + nenc + k) : 0; nw[k] = k < w ? cell(ncomp + nenc + w + k) : 0; }
+    u64 out[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) out[k] = 0;
+    for (u32 p = 0; p < nlq_kind_perms(op.kind); p++) {
+        const u32 pr0 = nlq_p2_row0(&d, G, j, p);
+        const u64 row_p = NLQ_ROW(&S, capacity, pr0, c);
+        u64 want[12], s[12];
+        if (op.kind != NLQ_POP4) { for (int k = 0; k < 8; k++) want[k] = enc[k]; for (int k = 0; k < 4; k++) want[8 + k] = old[8 + k]; }
+        else if (p == 0) { for (int k = 0; k < 8; k++) want[k] = enc[k]; for (int k = 0; k < 4; k++) want[8 + k] = 0; }
+        else if (p == 1) { for (int k = 0; k < 8; k++) want[k] = enc[8 + k]; for (int k = 0; k < 4; k++) want[8 + k] = out[8 + k]; }
+        else { for (int k = 0; k < 4; k++) { want[k] = enc[16 + k]; want[4 + k] = old[k]; want[8 + k] = out[8 + k]; } }
+        ok = true;
+        for (u32 k = 0; k < 12; k++) {
+            s[k] = nlq_cell_at(S, trace, n_rows, capacity, c, pr0, k);
+            if (s[k] != want[k]) ok = false;
+            s[k] = gl::canon(s[k]);
+        }
+        if (!ok) flag_bad(res, 2, 0x1000 + 4 * j + p, row_p);
+        // the flattened-gate relation: recompute and compare every variable
+        ok = true;
+        u32 pos = 12;
+        p2::external(s);
+        int r = 0;
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+            p2::full_round(s, r);
+            for (int i = 0; i < 12; i++) ok &= nlq_cell_at(S, trace, n_rows, capacity, c, pr0, pos + i) == gl::canon(s[i]);
+            pos += 12;
+        }
+        for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
+            s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
+            ok &= nlq_cell_at(S, trace, n_rows, capacity, c, pr0, pos++) == gl::canon(s[0]);
+            p2::internal(s);
+        }
+        for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
+            p2::full_round(s, r);
+            for (int i = 0; i < 12; i++) ok &= nlq_cell_at(S, trace, n_rows, capacity, c, pr0, pos + i) == gl::canon(s[i]);
+            pos += 12;
+        }
+        if (!ok) flag_bad(res, 8, 4 * j + p, row_p);
+        for (u32 k = 0; k < 12; k++) out[k] = nlq_cell_at(S, trace, n_rows, capacity, c, pr0, NLQ_P2_CELLS - 12 + k);
+        for (u32 rr = 0; rr < p2rows; rr++)
+            for (u32 col = (rr + 1 == p2rows ? NLQ_P2_CELLS - rr * G : G); col < G; col++)
+                if (NLQ_TR(col, NLQ_ROW(&S, capacity, pr0 + rr, c))) { flag_bad(res, 6, col, NLQ_ROW(&S, capacity, pr0 + rr, c)); break; }
+    }
+    ok = true;
+    for (u32 k = 0; k < w; k++) {
+        const u64 o = gl::canon(old[k]);
+        const u64 want = gl::canon(gl::add(o, gl::mul(gl::canon(en), gl::canon(gl::sub(gl::canon(out[k]), o)))));
+        if (want != gl::canon(nw[k])) ok = false;
+    }
+    if (!ok) flag_bad(res, 7, 0x800 + j, row_e);
+    ok = true;
+    for (u32 k = 0; k < w; k++)
+        if (old[k] != nlq_prev_new(S, d, trace, n_rows, capacity, c, j, op.queue, k)) ok = false;
+    if (!ok) flag_bad(res, 2, 0x2000 + j, row_e);
+    for (u32 rr = 0; rr < erows; rr++)
+        for (u32 col = (rr + 1 == erows ? ncells - rr * G : G); col < G; col++)
+            if (NLQ_TR(col, NLQ_ROW(&S, capacity, r0 + rr, c))) { flag_bad(res, 6, col, NLQ_ROW(&S, capacity, r0 + rr, c)); break; }
+}
+#undef NLQ_TR
+
+}  // namespace zkw

@@ -104,6 +104,7 @@ struct PrecompileJob {
     u32 capacity;
     zkw_keccak_round_record* keccak_rounds;  // keccak256 only, may be null: one record per round in the global round order
     zkw_sha256_round_record* sha256_rounds;  // sha256 only, may be null
+    RoundOps* round_ops;                     // sha256 only, may be null: [total_rounds]
 };
 
 __device__ __forceinline__ void word_be_bytes(const u32* limbs, uint8_t out[32]) {  // U256::to_big_endian
@@ -159,6 +160,7 @@ static __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job
 #pragma unroll
                 for (int m = 0; m < 8; m++) rec[m] = (u64)__builtin_bswap32(w[2 * m]) | ((u64)__builtin_bswap32(w[2 * m + 1]) << 32);
             }
+            if (job.round_ops) job.round_ops[g0 + round] = RoundOps{(u32)r, (u32)(qpos - 2), is_last_round ? 3u : 2u, (round == 0 ? 1u : 0u) | (is_last_round ? 2u : 0u)};
             sha256_compress(sha, w);  // expands the schedule in place
             if (rec) {
                 rec[8] = (u64)(round == 0 ? 1u : 0u) | ((u64)sha[0] << 32);

@@ -9,6 +9,7 @@
 #include "precompile_kernels.cuh"
 #include "storage_application_kernels.cuh"
 #include "netlist_kernels.cuh"
+#include "netlist_queue_kernels.cuh"
 #include "sort.h"
 
 // ------------------------------------------------------------------------------------------------ code decommitter
@@ -22,8 +23,14 @@ struct zkw_decommitter_witness {
     zkw_sha256_round_record* sha256_rounds = nullptr;  // [total_rounds]: the cycles of the circuit
     u32 capacity = 0;
     u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
+    // the queues of the circuit's queue section (netlist_queue_kernels.cuh): the popped requests and the states of their queue, what
+    // every round does to the queues, the memory queue's state before the first write
+    zkw_decommit_query* requests = nullptr;
+    u64* dedup_tails = nullptr;
+    RoundOps* round_ops = nullptr;
+    zkw_queue_state12 mem_in{};
     void release() {
-        void* ptrs[] = {mem_q, mem_enc, mem_tails, round_states, instances, sha256_rounds, cf_pi};
+        void* ptrs[] = {mem_q, mem_enc, mem_tails, round_states, instances, sha256_rounds, cf_pi, requests, dedup_tails, round_ops};
         for (void* p : ptrs)
             if (p) dev_free(p);
     }
@@ -80,6 +87,10 @@ extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit
     alloc((void**)&w->mem_tails, w->total_words * 96);
     alloc((void**)&w->round_states, w->total_rounds * 32);
     alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
+    alloc((void**)&w->requests, n_requests * sizeof(zkw_decommit_query));
+    alloc((void**)&w->dedup_tails, n_requests * 96);
+    alloc((void**)&w->round_ops, w->total_rounds * sizeof(RoundOps));
+    w->mem_in = *mem_in;
     w->capacity = capacity;
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_decommitter_instance));
     auto bail = [&](int rc) { w->release(); delete w; return rc; };
@@ -97,7 +108,10 @@ extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit
     if (rc == ZKW_OK) rc = ctx->scratch_t<u32>("dcm_viol", 1, &d_viol);
     if (rc != ZKW_OK) return bail(rc);
     if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
-    DecommitterJob job{d_req, d_words, d_woff, d_roff, w->round_states, w->mem_q, w->mem_enc, d_viol, n_requests, w->sha256_rounds};
+    if (hipMemcpyAsync(w->requests, d_req, n_requests * sizeof(zkw_decommit_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(w->dedup_tails, d_dt, n_requests * 96, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+        return bail(fail(ZKW_ERR_HIP, "copy of the decommit requests failed"));
+    DecommitterJob job{d_req, d_words, d_woff, d_roff, w->round_states, w->mem_q, w->mem_enc, d_viol, n_requests, w->sha256_rounds, w->round_ops};
     { Prof _p(ctx, "k_decommitter_sha"); hipLaunchKernelGGL(k_decommitter_sha, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
     if ((rc = launch_check("k_decommitter_sha")) != ZKW_OK) return bail(rc);
     { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(w->total_words, 256)), dim3(256), 0, ctx->stream, job, (u64)w->total_words); }
@@ -231,8 +245,15 @@ struct zkw_precompile_witness {
     int kind = 0;
     u32 capacity = 0;
     u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
+    // sha256 only — the queues of the circuit's queue section (netlist_queue_kernels.cuh): the precompile calls and the states of their
+    // queue, the memory queries, what every round does to the queues, the memory queue's state before the first query
+    zkw_log_query* requests = nullptr;
+    u64* req_tails = nullptr;
+    zkw_mem_query* mem_q = nullptr;
+    RoundOps* round_ops = nullptr;
+    zkw_queue_state12 mem_in{};
     void release() {
-        void* ptrs[] = {mem_enc, mem_tails, instances, keccak_rounds, sha256_rounds, cf_pi};
+        void* ptrs[] = {mem_enc, mem_tails, instances, keccak_rounds, sha256_rounds, cf_pi, requests, req_tails, mem_q, round_ops};
         for (void* p : ptrs)
             if (p) dev_free(p);
     }
@@ -282,7 +303,14 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
     alloc((void**)&w->mem_tails, n_queries * 96);
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_precompile_instance));
     if (kind == ZKW_PRECOMPILE_KECCAK256) alloc((void**)&w->keccak_rounds, w->total_rounds * sizeof(zkw_keccak_round_record));
-    if (kind == ZKW_PRECOMPILE_SHA256) alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
+    if (kind == ZKW_PRECOMPILE_SHA256) {
+        alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
+        alloc((void**)&w->requests, n_requests * sizeof(zkw_log_query));
+        alloc((void**)&w->req_tails, n_requests * 32);
+        alloc((void**)&w->mem_q, n_queries * sizeof(zkw_mem_query));
+        alloc((void**)&w->round_ops, w->total_rounds * sizeof(RoundOps));
+    }
+    w->mem_in = *mem_in;
     auto bail = [&](int rc) { w->release(); delete w; return rc; };
     if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_precompile_build: hipMalloc failed: %s", hipGetErrorString(e)));
     int rc = ZKW_OK;
@@ -306,7 +334,12 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
                 if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
             }
         }
-        PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity, w->keccak_rounds, w->sha256_rounds};
+        if (kind == ZKW_PRECOMPILE_SHA256 &&
+            (hipMemcpyAsync(w->requests, d_req, n_requests * sizeof(zkw_log_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+             hipMemcpyAsync(w->req_tails, d_rt, n_requests * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+             (n_queries && hipMemcpyAsync(w->mem_q, d_mq, n_queries * sizeof(zkw_mem_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)))
+            return bail(fail(ZKW_ERR_HIP, "copy of the precompile calls failed"));
+        PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity, w->keccak_rounds, w->sha256_rounds, w->round_ops};
         { Prof _p(ctx, "k_precompile_walk"); hipLaunchKernelGGL(k_precompile_walk, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
         if ((rc = launch_check("k_precompile_walk")) != ZKW_OK) return bail(rc);
     }
@@ -586,7 +619,7 @@ extern "C" int zkw_precompile_closed_forms(zkw_ctx* ctx, zkw_precompile_witness*
 // four generated specs on the reference's geometry and table sets. The device copy of a spec (its arrays, the general-purpose cell
 // map, the key layout and the histogram plan) is built once per device and circuit and never freed.
 namespace {
-struct NlCached { NlDev host; NlDev* dev = nullptr; };
+struct NlCached { NlDev host; NlDev* dev = nullptr; const NlqFreeHome* free_home = nullptr; /* circuits with a queue section: the cell of every FREE element */ };
 std::mutex g_nl_mu;
 std::map<std::pair<int, int>, NlCached>& nl_cache() { static auto* m = new std::map<std::pair<int, int>, NlCached>(); return *m; }
 
@@ -864,6 +897,29 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
         d.walk_lds = (max_slots + 3 * hs->state + hs->max_free) * 64;
         if (getenv("ZKW_NL_VERBOSE")) fprintf(stderr, "[zkw] netlist circuit %d, lane-per-cycle path: %zu program words, %u LDS slots, %u bytes of LDS per wave\n", circuit_type, prog.size(), max_slots, d.walk_lds);
     }
+    if (nlq_desc_of(circuit_type)) {  // the one cell of a cycle that uses FREE element i (tools/netlist.py asserts there is exactly one)
+        std::vector<NlqFreeHome> fh(hs->free_per_cycle, NlqFreeHome{0xFFFF, 0xFFFF});
+        u32 off = 0;
+        for (u32 st = 0; st < hs->steps_per_cycle; st++) {
+            const nl_cycle_step& cs = hs->cycle[st];
+            const nl_step_type& T = hs->step_types[cs.type];
+            for (u32 j = 0; j < T.n_ops; j++) {
+                const nl_op& op = hs->ops[T.op0 + j];
+                if (op.out == 0xFFFF) continue;
+                for (u32 i = 0; i < hs->tables[op.table - 1].n_in; i++)
+                    if (op.in[i] >= NL_REF_FREE && op.in[i] < NL_REF_RC) fh[off + op.in[i] - NL_REF_FREE] = NlqFreeHome{(uint16_t)(cs.row0 + 1 + j / hs->r), (uint16_t)(hs->g + hs->w * (j % hs->r) + i)};
+            }
+            for (u32 gi = 0; gi < T.n_gates; gi++) {
+                const nl_gate& gt = hs->gates[T.gate0 + gi];
+                for (u32 i = 0; i < gt.n_known; i++) {
+                    const u32 ref = hs->terms[T.term0 + gt.first_term + i].ref;
+                    if (ref >= NL_REF_FREE && ref < NL_REF_RC) fh[off + ref - NL_REF_FREE] = NlqFreeHome{(uint16_t)(cs.row0 + gt.row), (uint16_t)(gt.col + i)};
+                }
+            }
+            off += T.n_free;
+        }
+        ZKW_TRY(nl_to_device(fh.data(), fh.size(), &c.free_home));
+    }
     const NlDev* dd = nullptr;
     ZKW_TRY(nl_to_device(&d, 1, &dd));
     c.host = d;
@@ -933,7 +989,7 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
     ZKW_TRY(nl_get(ctx, circuit_type, &nc));
     const nl_spec& S = nc->host.s;
     if ((nc->host.fill_waves == 16 ? nc->host.lds_bytes16 : nc->host.lds_bytes) > 160 * 1024) return fail(ZKW_ERR_INVALID, "netlist of circuit %d needs %u bytes of LDS", circuit_type, nc->host.lds_bytes);
-    const size_t used = NL_USED_ROWS(&S, capacity);
+    const size_t used = nlq_used_rows(&S, nlq_desc_of(circuit_type), capacity);  // netlist rows + the queue section where there is one
     if (used > n_rows || S.total_table_rows > n_rows)
         return fail(ZKW_ERR_INVALID, "capacity %u needs %zu rows (tables: %u), trace has %zu", capacity, used, S.total_table_rows, n_rows);
     const size_t ni = inst.size();
@@ -999,12 +1055,43 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
     }, inst, capacity, n_rows);
 }
 
+// the queue section of the instances nl_synthesize has just filled (include/zkw_netlist_queue.h): request-queue pops and memory-queue
+// pushes as Poseidon2 rows below the netlist, on the same stream (the fill reads the linked netlist cells back)
+struct NlqQueues { NlqQueueIn q[NLQ_MAX_QUEUES]; const RoundOps* round_ops; };
+int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
+    const nlq_desc* d = nlq_desc_of(circuit_type);
+    if (!d || inst.empty()) return ZKW_OK;
+    const NlCached* nc = nullptr;
+    ZKW_TRY(nl_get(ctx, circuit_type, &nc));
+    const size_t ni = inst.size(), feed_n = (size_t)capacity * d->n_ops;
+    nlq_feed* d_feed = nullptr;
+    ZKW_TRY(ctx->scratch_t<nlq_feed>("nlq_feed", ni * feed_n, &d_feed));
+    std::vector<NlqFeedJob> fj(ni);
+    std::vector<NlqJob> jobs(ni);
+    for (size_t k = 0; k < ni; k++) {
+        fj[k] = NlqFeedJob{Q.round_ops, inst[k].first_round, inst[k].n_active, d_feed + k * feed_n};
+        jobs[k].feed = fj[k].feed;
+        jobs[k].trace = inst[k].t->data + inst[k].slot * inst[k].t->slot_elems();  // (the slot keeps the tag nl_synthesize_with gave it)
+        for (u32 q = 0; q < NLQ_MAX_QUEUES; q++) jobs[k].queues[q] = Q.q[q];
+    }
+    NlqFeedJob* d_fj = nullptr;
+    NlqJob* d_jobs = nullptr;
+    ZKW_TRY(ctx->upload("nlq_feed_jobs", fj, &d_fj));
+    ZKW_TRY(ctx->upload("nlq_jobs", jobs, &d_jobs));
+    const unsigned cb = (capacity + 63) / 64;
+    { Prof _p(ctx, "k_nlq_feed"); hipLaunchKernelGGL(k_nlq_feed, dim3(cb, (unsigned)ni), dim3(64), 0, ctx->stream, circuit_type, d_fj, capacity, d->n_ops); }
+    ZKW_TRY(launch_check("k_nlq_feed"));
+    { Prof _p(ctx, "k_nlq_fill"); hipLaunchKernelGGL(k_nlq_fill, dim3(cb, d->n_ops, (unsigned)ni), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, *d, d_jobs, capacity, n_rows); }
+    return launch_check("k_nlq_fill");
+}
+
 int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u32 capacity, uint64_t* n_violations, uint64_t* first_bad) {
     const NlCached* nc = nullptr;
     ZKW_TRY(nl_get(ctx, circuit_type, &nc));
     const nl_spec& S = nc->host.s;
     if (t->n_cols < S.cols) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %u", t->n_cols, S.cols);
-    if (NL_USED_ROWS(&S, capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    const nlq_desc* qd = nlq_desc_of(circuit_type);
+    if (nlq_used_rows(&S, qd, capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     HIP_TRY(hipSetDevice(ctx->device));
     const u64* trace = t->data + slot * t->slot_elems();
     const size_t n_rows = t->n_rows;
@@ -1017,8 +1104,12 @@ int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u3
     HIP_TRY(hipMemsetAsync(d_hist, 0, S.total_table_rows * sizeof(u32), ctx->stream));
     { Prof _p(ctx, "k_nl_check_steps"); hipLaunchKernelGGL(k_nl_check_steps, dim3((nc->host.max_items + 255) / 256, capacity * S.steps_per_cycle), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
     ZKW_TRY(launch_check("k_nl_check_steps"));
-    { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
+    { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res, (u64)NL_USED_ROWS(&S, capacity), (u64)nlq_used_rows(&S, qd, capacity)); }
     ZKW_TRY(launch_check("k_nl_check_tail"));
+    if (qd) {
+        { Prof _p(ctx, "k_nlq_check"); hipLaunchKernelGGL(k_nlq_check, dim3((capacity + 63) / 64, qd->n_ops), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, *qd, trace, capacity, n_rows, d_res); }
+        ZKW_TRY(launch_check("k_nlq_check"));
+    }
     CheckResult res;
     ZKW_TRY(ctx->read_small(&res, d_res, sizeof res));
     *n_violations = res.violations;
@@ -1073,8 +1164,14 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
-    return nl_synthesize(ctx, 6, true, w->sha256_rounds, nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
-                         w->capacity, t->n_rows);
+    const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
+    ZKW_TRY(nl_synthesize(ctx, 6, true, w->sha256_rounds, inst, w->capacity, t->n_rows));
+    NlqQueues Q{};  // the precompile calls are popped (the head runs through the states their pushes left), the memory queries pushed
+    Q.q[0] = NlqQueueIn{w->requests, w->req_tails, {0}, w->n_requests};
+    Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->n_queries};
+    memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
+    Q.round_ops = w->round_ops;
+    return nlq_synthesize(ctx, 6, Q, inst, w->capacity, t->n_rows);
 }
 extern "C" int zkw_sha256_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
@@ -1094,8 +1191,14 @@ extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_wit
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!w->cf_pi) ZKW_TRY(closed_form_public_inputs<CfDecommitter>(ctx, w->instances, w->n_instances, &w->cf_pi));
-    return nl_synthesize(ctx, 3, true, w->sha256_rounds, nl_instances(first_instance, n_instances, w->capacity, true, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
-                         w->capacity, t->n_rows);
+    const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, w->capacity, true, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
+    ZKW_TRY(nl_synthesize(ctx, 3, true, w->sha256_rounds, inst, w->capacity, t->n_rows));
+    NlqQueues Q{};  // the decommit requests are popped, the code words written to memory
+    Q.q[0] = NlqQueueIn{w->requests, w->dedup_tails, {0}, w->n_requests};
+    Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->total_words};
+    memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
+    Q.round_ops = w->round_ops;
+    return nlq_synthesize(ctx, 3, Q, inst, w->capacity, t->n_rows);
 }
 extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)

@@ -7,6 +7,7 @@
 #include "log_demux_circuit_kernels.cuh"
 #include "storage_sorter_circuit_kernels.cuh"
 #include "netlist_kernels.cuh"
+#include "../../include/zkw_netlist_queue.h"
 
 extern "C" int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometry* out) {
     // {copy columns, lookup width, repetitions, max degree, capacity, big size hint}: vm_main.rs:29-44,
@@ -66,8 +67,10 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
             const nl_spec* sp = nl_host_spec(circuit_type);
             const uint32_t cycles = nl_cycles_of(circuit_type, capacity);
             out->num_columns = sp->cols; out->rows_per_cycle = sp->rows_per_cycle; boundary = NL_BOUNDARY_ROW(sp, cycles);
-            min_rows = NL_USED_ROWS(sp, cycles); pi_off = 2 * NL_BND_ROWS(sp);
+            const nlq_desc* qd = nlq_desc_of(circuit_type);
+            min_rows = nlq_used_rows(sp, qd, cycles); pi_off = 2 * NL_BND_ROWS(sp);
             out->total_table_rows = sp->total_table_rows;
+            if (qd) { out->queue_first_row = NLQ_BASE(sp, cycles); out->queue_rows_per_cycle = nlq_rows_per_cycle(qd, sp->g); }
             break;
         }
         default: return ZKW_OK;  // a known circuit type this library does not synthesize yet: synthesizable = 0
@@ -118,7 +121,14 @@ extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, 
             row[r] = (uint8_t)((r <= T.lookup_rows ? sp->ops[T.op0 + (r - 1) * sp->r].table : 0) | (sp->gate_row_end[T.rowend0 + r] ? ZKW_ROW_HAS_GATES : 0));
     }
     for (uint32_t c = 0; c < cycles; c++) memcpy(out + (uint64_t)c * rpc, one.data(), rpc);
-    for (uint64_t k = 0; (uint64_t)cycles * rpc + k < lay.rows_used; k++) out[(uint64_t)cycles * rpc + k] = (uint8_t)(ZKW_ROW_BOUNDARY + k);
+    for (uint64_t k = 0; (uint64_t)cycles * rpc + k < NL_USED_ROWS(sp, cycles); k++) out[(uint64_t)cycles * rpc + k] = (uint8_t)(ZKW_ROW_BOUNDARY + k);
+    if (const nlq_desc* qd = nlq_desc_of(circuit_type)) {  // the queue section: region-major below the PI row
+        out[NLQ_BASE(sp, cycles)] = ZKW_ROW_QUEUE_BOUNDARY;
+        for (uint32_t j = 0; j < qd->n_ops; j++) {
+            const uint32_t r0 = nlq_op_row0(qd, sp->g, j), erows = nlq_rows_for(nlq_enc_cells(&qd->ops[j]), sp->g), rows = nlq_op_rows(&qd->ops[j], sp->g);
+            for (uint32_t r = 0; r < rows; r++) memset(out + NLQ_ROW(sp, cycles, r0 + r, 0), r < erows ? ZKW_ROW_QUEUE_ENCODING : ZKW_ROW_QUEUE_POSEIDON2, cycles);
+        }
+    }
     return ZKW_OK;
 }
 
@@ -236,6 +246,76 @@ extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacit
         if (cycles)
             for (uint32_t k = 0; k < ns->state; k++)
                 if (home(cycles, 0, NL_REF_CYC + k, &hc, &hr)) unite((uint64_t)(k % ns->g), nb + brows + k / ns->g, hc, hr);
+        // the queue section (include/zkw_netlist_queue.h): a permutation's inputs are copies of the encoding / the old state / the
+        // previous permutation's capacity, `old` of the previous `new` on the queue, the linked value nibbles of their netlist cells
+        if (const nlq_desc* qd = nlq_desc_of(circuit_type)) {
+            const uint32_t G = ns->g;
+            const uint64_t q0 = NLQ_BASE(ns, cycles);
+            auto qc = [&](uint32_t c, uint32_t r0, uint32_t k, uint64_t* col, uint64_t* row) { *col = k % G; *row = NLQ_ROW(ns, cycles, r0 + k / G, c); };
+            auto free_home = [&](uint32_t fi, uint64_t* col, uint64_t* row_in_cycle) {  // the one cell that uses FREE element fi of the (single-step or first-step) cycle
+                uint32_t off = 0;
+                for (uint32_t st = 0; st < ns->steps_per_cycle; st++) {
+                    const nl_cycle_step& cs = ns->cycle[st];
+                    const nl_step_type& T = ns->step_types[cs.type];
+                    if (fi >= off && fi < off + T.n_free) {
+                        const uint32_t ref = NL_REF_FREE + (fi - off);
+                        for (uint32_t j = 0; j < T.n_ops; j++) {
+                            const nl_op& op = ns->ops[T.op0 + j];
+                            if (op.out == 0xFFFF) continue;
+                            for (uint32_t i = 0; i < ns->tables[op.table - 1].n_in; i++)
+                                if (op.in[i] == ref) { *col = ns->g + ns->w * (j % ns->r) + i; *row_in_cycle = cs.row0 + 1 + j / ns->r; return true; }
+                        }
+                        for (uint32_t gi = 0; gi < T.n_gates; gi++) {
+                            const nl_gate& g = ns->gates[T.gate0 + gi];
+                            for (uint32_t i = 0; i < g.n_known; i++)
+                                if (ns->terms[T.term0 + g.first_term + i].ref == ref) { *col = g.col + i; *row_in_cycle = cs.row0 + g.row; return true; }
+                        }
+                    }
+                    off += T.n_free;
+                }
+                return false;
+            };
+            std::vector<int> last_op(qd->n_queues, -1);  // per queue: the operation whose `new` is the current state (-1: QBND in)
+            std::vector<uint32_t> last_cyc(qd->n_queues, 0);
+            uint64_t ca, ra, cb, rb;
+            for (uint32_t c = 0; c < cycles; c++)
+                for (uint32_t j = 0; j < qd->n_ops; j++) {
+                    const nlq_op& op = qd->ops[j];
+                    const uint32_t w = nlq_kind_width(op.kind), r0 = nlq_op_row0(qd, G, j), e0 = nlq_enc0(&op), o0 = nlq_old0(&op);
+                    for (uint32_t k = 1; k < nlq_item_comps(op.item); k++) {
+                        if (!nlq_comp_linked(&op, k)) continue;
+                        uint32_t next = 0;
+                        const uint32_t ref = nlq_link_ref(&op, k, &next);
+                        qc(c, r0, k, &ca, &ra);
+                        if (next) { if (home(c + 1, 0, ref, &hc, &hr)) unite(ca, ra, hc, hr); }
+                        else if (free_home(ref - NL_REF_FREE, &cb, &rb)) unite(ca, ra, cb, (uint64_t)c * ns->rows_per_cycle + rb);
+                    }
+                    for (uint32_t p = 0; p < nlq_kind_perms(op.kind); p++) {
+                        const uint32_t pr0 = nlq_p2_row0(qd, G, j, p);
+                        for (uint32_t k = 0; k < 12; k++) {
+                            qc(c, pr0, k, &ca, &ra);
+                            if (op.kind != NLQ_POP4) { if (k < 8) qc(c, r0, e0 + k, &cb, &rb); else qc(c, r0, o0 + k, &cb, &rb); }
+                            else if (k >= 8) { if (p == 0) continue; qc(c, nlq_p2_row0(qd, G, j, p - 1), NLQ_P2_CELLS - 12 + k, &cb, &rb); }
+                            else if (p < 2) qc(c, r0, e0 + 8 * p + k, &cb, &rb);
+                            else if (k < 4) qc(c, r0, e0 + 16 + k, &cb, &rb);
+                            else qc(c, r0, o0 + (k - 4), &cb, &rb);
+                            unite(ca, ra, cb, rb);
+                        }
+                    }
+                    for (uint32_t k = 0; k < w; k++) {
+                        qc(c, r0, o0 + k, &ca, &ra);
+                        if (last_op[op.queue] < 0) { cb = nlq_bnd_col(qd, op.queue, 0, k); rb = q0; }
+                        else qc(last_cyc[op.queue], nlq_op_row0(qd, G, (uint32_t)last_op[op.queue]), nlq_new0(&qd->ops[last_op[op.queue]]) + k, &cb, &rb);
+                        unite(ca, ra, cb, rb);
+                    }
+                    last_op[op.queue] = (int)j; last_cyc[op.queue] = c;
+                }
+            for (uint32_t q = 0; q < qd->n_queues; q++)
+                for (uint32_t k = 0; k < qd->width[q] && last_op[q] >= 0; k++) {
+                    qc(last_cyc[q], nlq_op_row0(qd, G, (uint32_t)last_op[q]), nlq_new0(&qd->ops[last_op[q]]) + k, &cb, &rb);
+                    unite(nlq_bnd_col(qd, q, 1, k), q0, cb, rb);
+                }
+        }
     }
     for (int l = 0; l < sp.num_links; l++) {
         const rc_link k = sp.links[l];

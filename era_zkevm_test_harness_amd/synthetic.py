@@ -249,6 +249,32 @@ def callstack_trace(n_ops, seed=0, max_depth=40, final_unwind=True):
     return ops, e
 
 
+_SHA256_K = np.array([
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2], dtype=np.uint32)
+_SHA256_IV = np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32)
+
+
+def sha256_compress_many(states, blocks):
+    """FIPS 180-4 compression of N chaining states [N, 8] with N message blocks [N, 16] (big-endian words), vectorised over N"""
+    rotr = lambda x, n: (x >> np.uint32(n)) | (x << np.uint32(32 - n))  # noqa: E731
+    w = [blocks[:, t].astype(np.uint32) for t in range(16)]
+    for t in range(16, 64):
+        s0 = rotr(w[t - 15], 7) ^ rotr(w[t - 15], 18) ^ (w[t - 15] >> np.uint32(3))
+        s1 = rotr(w[t - 2], 17) ^ rotr(w[t - 2], 19) ^ (w[t - 2] >> np.uint32(10))
+        w.append(w[t - 16] + s0 + w[t - 7] + s1)
+    a, b, c, d, e, f, g, h = (states[:, k].astype(np.uint32) for k in range(8))
+    for t in range(64):
+        t1 = h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + _SHA256_K[t] + w[t]
+        t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c))
+        h, g, f, e, d, c, b, a = g, f, e, d + t1, c, b, a, t1 + t2
+    return states.astype(np.uint32) + np.stack([a, b, c, d, e, f, g, h], axis=1)
+
+
 def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
     """Requests of one precompile (0 keccak256, 1 sha256, 2 ecrecover) with the memory queries the VM would have
     made for them, in the order the reference flattens them (reads round by round, then the write(s))."""
@@ -258,6 +284,7 @@ def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
     req = random_log_queries(max(n_requests, 1), seed=seed + 1)[:n_requests]
     req["timestamp"] = np.sort(rng.integers(1, 1 << 30, n_requests).astype(np.uint32) * 2)
     qs = []
+    sha_shape = []  # sha256: (index of the request's first query, rounds)
 
     def query(ts, page, index, rw):
         m = np.zeros(1, MEM_QUERY)
@@ -275,6 +302,7 @@ def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
             rounds = int(rng.integers(1, max_rounds + 1))
             in_off = int(rng.integers(0, 1 << 16))
             key[0], key[1], key[6] = in_off, 2 * rounds, rounds
+            sha_shape.append((len(qs), rounds))
             for r in range(2 * rounds):
                 qs.append(query(ts, page_r, in_off + r, 0))
             qs.append(query(ts + 1, page_w, out_off, 1))
@@ -299,6 +327,16 @@ def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
             qs.append(query(ts + 1, page_w, out_off, 1))
         req["key"][k] = key
     mq = np.concatenate(qs) if qs else np.zeros(0, MEM_QUERY)
+    if kind == 1 and sha_shape:  # the word a sha256 call writes is the chaining state after its rounds (no padding: the caller pads)
+        first = np.array([a for a, _ in sha_shape])
+        rounds = np.array([b for _, b in sha_shape])
+        st = np.tile(_SHA256_IV, (first.size, 1))
+        with np.errstate(over="ignore"):
+            for r in range(int(rounds.max())):
+                live = np.nonzero(rounds > r)[0]
+                blocks = np.concatenate([mq["value"][first[live] + 2 * r][:, ::-1], mq["value"][first[live] + 2 * r + 1][:, ::-1]], axis=1)
+                st[live] = sha256_compress_many(st[live], blocks)
+        mq["value"][first + 2 * rounds] = st[:, ::-1]
     return req, mq
 
 

@@ -130,6 +130,12 @@ typedef struct zkw_circuit_layout {
     uint64_t trace_len;         /* 2^20 */
     uint32_t public_input_column[4];
     uint64_t public_input_row[4];
+    /* the queue section of a netlist circuit (types 6 and 3; include/zkw_netlist_queue.h): request-queue pops and memory-queue pushes
+       as Poseidon2 rows below the netlist. Row queue_first_row holds the queue states before / after the instance; row r of the
+       operations of cycle c is queue_first_row + 1 + r * cycles + c. 0 rows per cycle: the type has no section. */
+    uint64_t queue_first_row;
+    uint32_t queue_rows_per_cycle;
+    uint32_t _pad;
 } zkw_circuit_layout;
 int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_layout *out);
 /* Setup side, selectors: out[r] (host, n_rows bytes) says which gate set applies to row r of a trace of this library's
@@ -142,6 +148,9 @@ int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_l
 #define ZKW_ROW_HAS_GATES 0x40
 #define ZKW_ROW_HEADER 0x80
 #define ZKW_ROW_BOUNDARY 0xC0
+#define ZKW_ROW_QUEUE_BOUNDARY 0xE0 /* queue section: the queue states before / after the instance */
+#define ZKW_ROW_QUEUE_ENCODING 0xE1 /* queue section: an item's fields, its encoding (linear gates), old / new state (selection gates) */
+#define ZKW_ROW_QUEUE_POSEIDON2 0xE2 /* queue section: a (folded) flattened Poseidon2 gate */
 #define ZKW_ROW_PADDING 0xFF
 int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint8_t *out);
 /* Setup side, copy permutation of the ten synthesized types: sigma[c * n_rows + r] (host, *n_columns x n_rows words;

@@ -1,0 +1,206 @@
+/* zkw_netlist_queue.h — the QUEUE SECTION of a "zkw trace v4" netlist circuit: the request-queue pops and memory-queue pushes of a
+ * hash circuit as Poseidon2 rows inside its trace, tied to the hash netlist by copy constraints. What the reference's circuits do
+ * with their `requests_queue.pop_front(..)` / `memory_queue.push(..)` gadgets (era-zkevm_circuits, absent; the out-of-circuit mirror
+ * is src/witness/individual_circuits/sha256_round_function.rs:172-246 and decommit_code.rs:136-401), restated on the queue
+ * arithmetic the reference does hold: FullWidthQueueSimulator::push (circuit_encodings/src/lib.rs:391-429: absorb the 8-element
+ * encoding over the old tail, ONE permutation, the new tail is the whole state), QueueSimulator::push (lib.rs:180-203: hash of the
+ * 20-element encoding ++ old tail from a zero state, THREE permutations, the new tail is elements 0..3), the encodings of
+ * memory_query.rs:24-118 / log_query.rs:102-396 / decommittment_request.rs:9-74. Placement is this library's own (PARITY UNPINNED
+ * at the placement level, like the rest of v4). Shared by csrc/netlist_queue_kernels.cuh, the host side and oracle/netlist_queue.c.
+ *
+ * Rows. The section starts below the PI row: q0 = NL_USED_ROWS(spec, capacity). Row q0 = QBND: for every queue its state before
+ * cycle 0, then for every queue its state after the last cycle (general-purpose columns, back to back). Then the cycles'
+ * operations, REGION-major: row r of a cycle's operations (r < q_rows_per_cycle) of cycle c is row q0 + 1 + r * capacity + c, so
+ * that consecutive cycles are consecutive rows (coalesced stores of the lane-per-operation fill). Lookup columns of all section
+ * rows are zero and not counted in the multiplicity column (like the boundary rows).
+ *
+ * One operation = an ENC block, then 1 or 3 P2 blocks; a block of n cells folds over ceil(n / G) rows, cell k at (row k / G,
+ * column k % G). ENC block: [en | components | enc[8 or 20] | old[w] | new[w]], w = 12 or 4:
+ *   en boolean (by rule: free, == the cycle's `reset`, or == 1 - `idle`); components = the item's fields (some LINKED = copies of
+ *   netlist cells: the value nibbles of a memory word that is hashed / the digest that is written); enc_j = sum of component * 2^s
+ *   (nlq_enc_terms); old = the queue state before (copy of the previous operation's `new` on that queue, across cycles; QBND for
+ *   the first); new = old + en * (out - old).
+ * P2 block: the 130 variables of the flattened Poseidon2 gate (12 inputs, states after the full rounds, S-box outputs of the
+ * partial rounds — oracle/ram_circuit.c orc_poseidon2_flattened); inputs = enc / old by copy; out = its last 12 cells.
+ *   PUSH12 / POP12: in = enc[0..8] ++ old[8..12]; out[0..12].     POP4: in_0 = enc[0..8] ++ 0000, in_1 = enc[8..16] ++ out_0[8..12],
+ *   in_2 = enc[16..20] ++ old[0..4] ++ out_1[8..12]; out = out_2[0..4].
+ * NOT constrained here (placed): the FSM arithmetic between the request and the memory addresses (offsets, pages, timestamps,
+ * rounds left), ranges of the unlinked components.
+ */
+#ifndef ZKW_NETLIST_QUEUE_H
+#define ZKW_NETLIST_QUEUE_H
+#include "zkw_netlist.h"
+#include "zkw_types.h"
+
+#define NLQ_P2_CELLS 130
+#define NLQ_MAX_OPS 8
+#define NLQ_MAX_QUEUES 2
+#define NLQ_MAX_TERMS 14
+
+enum { NLQ_PUSH12 = 1, NLQ_POP12 = 2, NLQ_POP4 = 3 }; /* PUSH12 and POP12 are the same arithmetic on a tail / on a head */
+enum { NLQ_ITEM_MEM = 1, NLQ_ITEM_LOG = 2, NLQ_ITEM_DECOMMIT = 3 };
+enum { NLQ_EN_FREE = 0, NLQ_EN_RESET = 1, NLQ_EN_ACTIVE = 2 };
+/* links of a memory query's 64 value nibbles (little end first) to the SHA-256 netlist:
+   SHA_BLOCK + arg k: the cycle's message block, memory word k (U256::to_big_endian = block bytes 32k..32k+31; FREE element 2b + hi);
+   SHA_DIGEST: the chaining state after the cycle (limb j of the written U256 = H[7 - j]) */
+enum { NLQ_LINK_NONE = 0, NLQ_LINK_SHA_BLOCK = 1, NLQ_LINK_SHA_DIGEST = 2 };
+
+typedef struct nlq_op { uint8_t kind, item, queue, en_rule, link, link_arg; } nlq_op;
+typedef struct nlq_desc { uint32_t n_ops, n_queues; uint32_t width[NLQ_MAX_QUEUES]; nlq_op ops[NLQ_MAX_OPS]; } nlq_desc;
+typedef struct nlq_feed { uint32_t en; uint32_t idx; } nlq_feed; /* per (cycle, op): enabled?, index of the item (enabled) / of the queue's next item (disabled) */
+typedef struct nlq_term { uint16_t cell; uint16_t shift; } nlq_term;
+
+/* Sha256RoundFunction (6): pop the precompile call (first round of a request), read two words, write the digest (last round).
+   CodeDecommitter (3): pop the decommit request (first round of a bytecode), write two code words (the second one is missing in the
+   last round of a bytecode with an odd word count). */
+static const nlq_desc NLQ_DESC_SHA256 = {4, 2, {4, 12}, {
+    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 0},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 1},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_FREE, NLQ_LINK_SHA_DIGEST, 0}}};
+static const nlq_desc NLQ_DESC_CODE_DECOMMITTER = {3, 2, {12, 12}, {
+    {NLQ_POP12, NLQ_ITEM_DECOMMIT, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 0},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_FREE, NLQ_LINK_SHA_BLOCK, 1}}};
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define NLQ_HD __host__ __device__ static inline
+#else
+#define NLQ_HD static inline
+#endif
+
+/* host only: kernels take the descriptor by value */
+static inline const nlq_desc *nlq_desc_of(int circuit_type) {
+    return circuit_type == 6 ? &NLQ_DESC_SHA256 : circuit_type == 3 ? &NLQ_DESC_CODE_DECOMMITTER : (const nlq_desc *)0;
+}
+NLQ_HD uint32_t nlq_kind_width(uint32_t kind) { return kind == NLQ_POP4 ? 4u : 12u; }
+NLQ_HD uint32_t nlq_kind_perms(uint32_t kind) { return kind == NLQ_POP4 ? 3u : 1u; }
+/* component cells of an item, `en` (cell 0) included; encoding elements */
+NLQ_HD uint32_t nlq_item_comps(uint32_t item) { return item == NLQ_ITEM_MEM ? 70u : item == NLQ_ITEM_LOG ? 76u : 18u; }
+NLQ_HD uint32_t nlq_item_enc(uint32_t item) { return item == NLQ_ITEM_LOG ? 20u : 8u; }
+/* cells of the ENC block: [0, comps) | enc | old | new */
+NLQ_HD uint32_t nlq_enc0(const nlq_op *op) { return nlq_item_comps(op->item); }
+NLQ_HD uint32_t nlq_old0(const nlq_op *op) { return nlq_enc0(op) + nlq_item_enc(op->item); }
+NLQ_HD uint32_t nlq_new0(const nlq_op *op) { return nlq_old0(op) + nlq_kind_width(op->kind); }
+NLQ_HD uint32_t nlq_enc_cells(const nlq_op *op) { return nlq_new0(op) + nlq_kind_width(op->kind); }
+NLQ_HD uint32_t nlq_rows_for(uint32_t cells, uint32_t g) { return (cells + g - 1) / g; }
+NLQ_HD uint32_t nlq_op_rows(const nlq_op *op, uint32_t g) { return nlq_rows_for(nlq_enc_cells(op), g) + nlq_kind_perms(op->kind) * nlq_rows_for(NLQ_P2_CELLS, g); }
+/* first row (within a cycle's operations) of operation j / of its P2 block p */
+NLQ_HD uint32_t nlq_op_row0(const nlq_desc *d, uint32_t g, uint32_t j) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < j; i++) r += nlq_op_rows(&d->ops[i], g);
+    return r;
+}
+NLQ_HD uint32_t nlq_p2_row0(const nlq_desc *d, uint32_t g, uint32_t j, uint32_t p) {
+    return nlq_op_row0(d, g, j) + nlq_rows_for(nlq_enc_cells(&d->ops[j]), g) + p * nlq_rows_for(NLQ_P2_CELLS, g);
+}
+NLQ_HD uint32_t nlq_rows_per_cycle(const nlq_desc *d, uint32_t g) { return nlq_op_row0(d, g, d->n_ops); }
+#define NLQ_BASE(spec, capacity) NL_USED_ROWS(spec, capacity)
+/* trace row of row r of the operations of cycle c */
+#define NLQ_ROW(spec, capacity, r, c) (NLQ_BASE(spec, capacity) + 1 + (uint64_t)(r) * (capacity) + (c))
+NLQ_HD uint64_t nlq_used_rows(const nl_spec *sp, const nlq_desc *d, uint32_t capacity) {
+    return NL_USED_ROWS(sp, capacity) + (d ? 1 + (uint64_t)capacity * nlq_rows_per_cycle(d, sp->g) : 0);
+}
+/* the largest number of cycles whose netlist rows + queue section fit n_rows */
+NLQ_HD uint32_t nlq_max_capacity(const nl_spec *sp, const nlq_desc *d, uint64_t n_rows) {
+    const uint64_t fixed = 2 * NL_BND_ROWS(sp) + 1 + (d ? 1 : 0), per = sp->rows_per_cycle + (d ? nlq_rows_per_cycle(d, sp->g) : 0);
+    return n_rows > fixed ? (uint32_t)((n_rows - fixed) / per) : 0;
+}
+/* QBND row: column of element k of queue q's state before cycle 0 (out == 0) / after the last cycle (out == 1) */
+NLQ_HD uint32_t nlq_bnd_col(const nlq_desc *d, uint32_t q, uint32_t out, uint32_t k) {
+    uint32_t col = 0;
+    for (uint32_t o = 0; o < 2; o++)
+        for (uint32_t i = 0; i < d->n_queues; i++) {
+            if (o == out && i == q) return col + k;
+            col += d->width[i];
+        }
+    return col;
+}
+NLQ_HD uint32_t nlq_bnd_cells(const nlq_desc *d) { return nlq_bnd_col(d, d->n_queues, 1, 0); }
+
+/* ---- components. MEM: 1 timestamp, 2 page, 3 index, 4 rw, 5 value_is_pointer, 6 + t: value nibble t (little end first).
+   LOG: 1..8 read_value limbs, 9..16 written_value limbs, 17 timestamp, 18 tx_number, 19 aux_byte, 20 shard_id, 21 rw, 22 is_service,
+   23 rollback, 24 + b: key byte b (little end first), 56 + b: address byte b.   DECOMMIT: 1..8 hash limbs, 9..12 memory_page bytes,
+   13..16 timestamp bytes, 17 is_fresh. */
+#define NLQ_MEM_NIBBLE0 6
+NLQ_HD int nlq_comp_linked(const nlq_op *op, uint32_t cell) { return op->link != NLQ_LINK_NONE && cell >= NLQ_MEM_NIBBLE0 && cell < NLQ_MEM_NIBBLE0 + 64; }
+/* the netlist reference a linked cell copies, and the cycle it is seen from (*next: 1 = the state AFTER the cycle = CYC of cycle + 1) */
+NLQ_HD uint32_t nlq_link_ref(const nlq_op *op, uint32_t cell, uint32_t *next) {
+    const uint32_t t = cell - NLQ_MEM_NIBBLE0;
+    if (op->link == NLQ_LINK_SHA_DIGEST) { *next = 1; return NL_REF_CYC + 8 * (7 - t / 8) + t % 8; }
+    *next = 0;
+    return NL_REF_FREE + 2 * (32 * op->link_arg + 31 - t / 2) + (t & 1);
+}
+
+/* enc element j of an item = sum over its terms of cell * 2^shift (in the field): number of terms, term i (no arrays: the kernels
+   keep this in registers) */
+NLQ_HD uint32_t nlq_enc_n_terms(uint32_t item, uint32_t j) {
+    if (item == NLQ_ITEM_MEM) return j < 2 ? 1u : j == 2 ? 3u : j < 7 ? 14u : 8u;
+    if (item == NLQ_ITEM_LOG) return j <= 17 ? 4u : j == 18 ? 2u : 1u;
+    return j < 3 ? 4u : 1u;
+}
+NLQ_HD nlq_term nlq_enc_term(uint32_t item, uint32_t j, uint32_t i) {
+    nlq_term t;
+    uint32_t cell, shift = 0;
+    if (item == NLQ_ITEM_MEM) { /* memory_query.rs:60-110: timestamp | page | index + rw << 32 + is_ptr << 33 | limb w + three rider bytes of limbs 5..7 | limb 4 */
+        if (j < 2) cell = 1 + j;
+        else if (j == 2) { cell = 3 + i; shift = i ? 31 + i : 0; }
+        else if (i < 8) { cell = NLQ_MEM_NIBBLE0 + 8 * (j == 7 ? 4 : j - 3) + i; shift = 4 * i; }
+        else { const uint32_t ii = i - 8, byte = 20 + 3 * (j - 3) + ii / 2; cell = NLQ_MEM_NIBBLE0 + 2 * byte + (ii & 1); shift = 32 + 8 * (ii / 2) + 4 * (ii & 1); }
+    } else if (item == NLQ_ITEM_LOG) { /* log_query.rs:150-360: a limb + three bytes of key ++ address | tx_number, address[19], aux_byte, shard_id | rw + 2 * is_service | rollback */
+        if (j < 17) {
+            if (i == 0) cell = j < 16 ? 1 + j : 17;
+            else { const uint32_t x = 3 * j + (i - 1); cell = x < 32 ? 24 + x : 56 + (x - 32); shift = 32 + 8 * (i - 1); }
+        } else if (j == 17) { cell = i == 0 ? 18 : i == 1 ? 56 + 19 : i == 2 ? 19 : 20; shift = i ? 24 + 8 * i : 0; }
+        else if (j == 18) { cell = 21 + i; shift = i; }
+        else cell = 23;
+    } else { /* decommittment_request.rs:20-70: hash limb + three bytes of page / timestamp / is_fresh */
+        if (j < 3 && i) { cell = 9 + 3 * j + (i - 1); shift = 32 + 8 * (i - 1); }
+        else cell = 1 + j;
+    }
+    t.cell = (uint16_t)cell; t.shift = (uint16_t)shift;
+    return t;
+}
+/* component `cell` (>= 1) of an item record (zkw_mem_query / zkw_log_query / zkw_decommit_query); a null record is all zeros */
+NLQ_HD uint64_t nlq_item_component(uint32_t item, const void *rec, uint32_t cell) {
+    if (!rec) return 0;
+    if (item == NLQ_ITEM_MEM) {
+        const zkw_mem_query *q = (const zkw_mem_query *)rec;
+        switch (cell) {
+            case 1: return q->timestamp;
+            case 2: return q->page;
+            case 3: return q->index;
+            case 4: return q->rw_flag ? 1 : 0;
+            case 5: return q->value_is_pointer ? 1 : 0;
+            default: { const uint32_t t = cell - NLQ_MEM_NIBBLE0; return (q->value[t / 8] >> (4 * (t % 8))) & 15u; }
+        }
+    }
+    if (item == NLQ_ITEM_LOG) {
+        const zkw_log_query *q = (const zkw_log_query *)rec;
+        if (cell <= 8) return q->read_value[cell - 1];
+        if (cell <= 16) return q->written_value[cell - 9];
+        switch (cell) {
+            case 17: return q->timestamp;
+            case 18: return q->tx_number_in_block;
+            case 19: return q->aux_byte;
+            case 20: return q->shard_id;
+            case 21: return q->rw_flag ? 1 : 0;
+            case 22: return q->is_service ? 1 : 0;
+            case 23: return q->rollback ? 1 : 0;
+            default: break;
+        }
+        if (cell < 56) { const uint32_t b = cell - 24; return (q->key[b / 4] >> (8 * (b % 4))) & 255u; }
+        { const uint32_t b = cell - 56; return (q->address[b / 4] >> (8 * (b % 4))) & 255u; }
+    }
+    {
+        const zkw_decommit_query *q = (const zkw_decommit_query *)rec;
+        if (cell <= 8) return q->hash[cell - 1];
+        if (cell <= 12) return (q->memory_page >> (8 * (cell - 9))) & 255u;
+        if (cell <= 16) return (q->timestamp >> (8 * (cell - 13))) & 255u;
+        return q->is_fresh ? 1 : 0;
+    }
+}
+NLQ_HD uint32_t nlq_item_bytes(uint32_t item) {
+    return item == NLQ_ITEM_MEM ? (uint32_t)sizeof(zkw_mem_query) : item == NLQ_ITEM_LOG ? (uint32_t)sizeof(zkw_log_query) : (uint32_t)sizeof(zkw_decommit_query);
+}
+#endif /* ZKW_NETLIST_QUEUE_H */

@@ -16,6 +16,7 @@
 #include "../include/zkw_keccak_circuit_spec.h"
 #include "../include/zkw_linear_hasher_circuit_spec.h"
 #include "../include/zkw_storage_application_circuit_spec.h"
+#include "../include/zkw_netlist_queue.h"
 
 NL_DEFINE_SPEC(sc, SC);
 NL_DEFINE_SPEC(dc, DC);
@@ -82,11 +83,48 @@ static uint64_t home(const view *v, uint32_t c, uint32_t s, uint32_t ref) {
     }
 }
 
+uint64_t orc_nl_home(const nl_spec *sp, const uint64_t *trace, size_t n_rows, uint32_t capacity, uint32_t c, uint32_t s, uint32_t ref) {
+    const view v = {sp, trace, n_rows, capacity};
+    return home(&v, c, s, ref);
+}
+
+static int type_of_spec(const nl_spec *sp) {
+    static const int types[] = {6, 3, 5, 13, 10};
+    for (int i = 0; i < 5; i++)
+        if (orc_nl_spec(types[i]) == sp) return types[i];
+    return 0;
+}
+
 /* free elements of a cycle are laid out step after step */
 static uint32_t free_offset(const nl_spec *sp, uint32_t s) {
     uint32_t off = 0;
     for (uint32_t i = 0; i < s; i++) off += sp->step_types[sp->cycle[i].type].n_free;
     return off;
+}
+
+/* The one cell that holds FREE element `free_index` of a cycle (an element is used once: tools/netlist.py asserts it): its row within
+   the cycle and its column. Returns 0, or -1 when no item uses the element. */
+int orc_nl_free_home(const nl_spec *sp, uint32_t free_index, uint32_t *row_in_cycle, uint32_t *col) {
+    for (uint32_t s = 0; s < sp->steps_per_cycle; s++) {
+        const nl_cycle_step *cs = &sp->cycle[s];
+        const nl_step_type *T = &sp->step_types[cs->type];
+        const uint32_t off = free_offset(sp, s);
+        if (free_index < off || free_index >= off + T->n_free) continue;
+        const uint32_t ref = NL_REF_FREE + (free_index - off);
+        for (uint32_t j = 0; j < T->n_ops; j++) {
+            const nl_op *op = &sp->ops[T->op0 + j];
+            if (op->out == 0xFFFF) continue;
+            for (uint32_t i = 0; i < sp->tables[op->table - 1].n_in; i++)
+                if (op->in[i] == ref) { *row_in_cycle = cs->row0 + 1 + j / sp->r; *col = sp->g + sp->w * (j % sp->r) + i; return 0; }
+        }
+        for (uint32_t gi = 0; gi < T->n_gates; gi++) {
+            const nl_gate *g = &sp->gates[T->gate0 + gi];
+            const nl_term *tm = &sp->terms[T->term0 + g->first_term];
+            for (uint32_t i = 0; i < g->n_known; i++)
+                if (tm[i].ref == ref) { *row_in_cycle = cs->row0 + g->row; *col = g->col + i; return 0; }
+        }
+    }
+    return -1;
 }
 
 int orc_nl_synthesize(const nl_spec *sp, uint32_t capacity, const uint8_t *hdr_bits, const uint8_t *free_elems, const uint8_t *state_before,
@@ -206,7 +244,10 @@ static uint64_t fmul(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __in
 
 uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
     result res = {0, ~0ull};
-    if (!sp || n_rows < NL_USED_ROWS(sp, capacity)) { *first_bad = 0; return ~0ull; }
+    const int ctype = type_of_spec(sp);
+    const nlq_desc *qd = nlq_desc_of(ctype);
+    if (!sp || n_rows < nlq_used_rows(sp, qd, capacity)) { *first_bad = 0; return ~0ull; }
+    const size_t q_begin = NL_USED_ROWS(sp, capacity), q_end = nlq_used_rows(sp, qd, capacity); /* the queue section's rows (zkw_netlist_queue.h) */
     const view v = {sp, trace, n_rows, capacity};
     uint32_t *hist = calloc(sp->total_table_rows, sizeof(uint32_t));
     for (uint32_t c = 0; c < capacity; c++)
@@ -287,7 +328,7 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
         if (TR(sp->mult_col, row) != (row < sp->total_table_rows ? hist[row] : 0)) flag(&res, 5, 0, row);
         if (row < bnd) continue;
         const size_t off = row - bnd;
-        for (uint32_t col = 0; col < sp->mult_col; col++) {
+        for (uint32_t col = (row >= q_begin && row < q_end) ? sp->g : 0; col < sp->mult_col; col++) { /* (the section's general-purpose cells: orc_nlq_check) */
             int allowed = 0;
             if (off < 2 * brows) allowed = col < sp->g && (off % brows) * sp->g + col < sp->state;
             else if (off == 2 * brows) allowed = col < 4;
@@ -302,6 +343,11 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
             }
     }
     free(hist);
+    if (qd) {
+        uint64_t qfirst = ~0ull;
+        res.n += orc_nlq_check(ctype, trace, capacity, n_rows, &qfirst);
+        if (qfirst < res.first) res.first = qfirst;
+    }
     *first_bad = res.n ? res.first : 0;
     return res.n;
 }
@@ -327,8 +373,10 @@ static int sha_like(const nl_spec *sp, const uint8_t state_in[32], const zkw_sha
             memcpy(nx, nx - ST, ST);
         }
     }
-    const int rc = orc_nl_synthesize(sp, capacity, hdr, fr, st, pi, n_rows, trace);
+    int rc = orc_nl_synthesize(sp, capacity, hdr, fr, st, pi, n_rows, trace);
     free(hdr); free(fr); free(st);
+    /* the queue section the bare records imply; a caller that holds the block's queues writes the real one over it (orc_nlq_synthesize) */
+    if (rc == 0 && nlq_used_rows(sp, nlq_desc_of(type_of_spec(sp)), capacity) <= n_rows) rc = orc_nlq_standalone(type_of_spec(sp), rounds, n_active, capacity, n_rows, trace);
     return rc;
 }
 int orc_sha256_round_synthesize(const uint8_t state_in[32], const zkw_sha256_round_record *rounds, uint32_t n_active, uint32_t capacity,
@@ -482,4 +530,10 @@ int orc_storage_application_synthesize(const zkw_log_query *items, size_t n_item
 }
 uint64_t orc_storage_application_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad) {
     return orc_nl_check(&sa_spec, trace, capacity * SA_CYCLES_PER_WALK, n_rows, first_bad);
+}
+
+/* for the tests: {row within the cycle, column} of the cell that holds FREE element `free_index` */
+int orc_nl_free_home_of(int circuit_type, uint32_t free_index, uint32_t out[2]) {
+    const nl_spec *sp = orc_nl_spec(circuit_type);
+    return sp ? orc_nl_free_home(sp, free_index, &out[0], &out[1]) : -1;
 }

@@ -308,6 +308,21 @@ void orc_recursion_queue(uint64_t circuit_type, const uint64_t *pi, size_t n, co
 void orc_serialize_l1_message(const zkw_log_query *q, uint8_t out[88]);
 void orc_linear_keccak256(const zkw_log_query *q, size_t n, uint8_t hash_out[32]);
 
+/* ---- the queue section of the netlist circuits (netlist_queue.c; format: include/zkw_netlist_queue.h) */
+typedef struct orc_nlq_queue {
+    const void *items;      /* zkw_log_query / zkw_mem_query / zkw_decommit_query [n_items] */
+    const uint64_t *states; /* [n_items][width]: the queue state after item i (tail after the push / head after the pop) */
+    const uint64_t *init;   /* [width]: the state before item 0; NULL = zeros */
+    size_t n_items;
+} orc_nlq_queue;
+struct nlq_feed;
+int orc_nlq_synthesize(int circuit_type, uint32_t capacity, const struct nlq_feed *feed, const orc_nlq_queue *queues, size_t n_rows, uint64_t *trace);
+uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+int orc_nlq_standalone(int circuit_type, const zkw_sha256_round_record *rounds, uint32_t n_active, uint32_t capacity, size_t n_rows, uint64_t *trace);
+void orc_sha256_queue_feed(const zkw_sha256_round_record *rounds, size_t total_rounds, size_t first_round, uint32_t n_active, uint32_t capacity, struct nlq_feed *feed);
+void orc_code_decommitter_queue_feed(const zkw_sha256_round_record *rounds, size_t total_rounds, const uint64_t *word_offsets, size_t first_round,
+                                     uint32_t n_active, uint32_t capacity, struct nlq_feed *feed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -485,6 +485,7 @@ def decommitter_build(requests, dedup_tails, words, word_offsets, capacity, mem_
     if rc < 0:
         raise RuntimeError(f"orc_decommitter_build failed: {rc}")
     o["instances"] = o["instances"][:rc]
+    o.update(requests=requests, dedup_tails=dedup_tails.reshape(-1, 12), word_offsets=woff - woff[0], mem_in=mem_in)  # the queues (queue section)
     return o
 
 
@@ -630,6 +631,7 @@ def precompile_build(kind, requests, request_tails, mem_queries, capacity, mem_i
         o["sha256_rounds"] = sha_rounds[:int(o["instances"]["num_rounds"].sum()) if req.size else 0]
     if rounds is not None:  # one record per Keccak-f call, in the global round order
         o["keccak_rounds"] = rounds[:int(o["instances"]["num_rounds"].sum()) if req.size else 0]
+    o.update(requests=req, request_tails=rt.reshape(-1, 4), mem_queries=mq, mem_in=mem_in)  # the queues (queue section)
     return o
 
 
@@ -658,6 +660,60 @@ def nl_geometry(circuit_type):
     out = np.zeros(6, np.uint32)
     lib().orc_nl_geometry(C.c_int(circuit_type), _p(out))
     return dict(zip(("cols", "general", "width", "lookups_per_row", "table_rows", "rows_per_cycle"), (int(x) for x in out)))
+
+
+NLQ_FEED = np.dtype([("en", np.uint32), ("idx", np.uint32)])
+
+
+class _NlqQueue(C.Structure):
+    _fields_ = [("items", C.c_void_p), ("states", C.c_void_p), ("init", C.c_void_p), ("n_items", C.c_size_t)]
+
+
+def nlq_geometry(circuit_type, capacity):
+    """the queue section of a netlist circuit (include/zkw_netlist_queue.h): first row, rows per cycle, rows used by netlist + section,
+    operations per cycle, the largest capacity that fits 2^20 rows"""
+    out = np.zeros(8, np.uint64)
+    lib().orc_nlq_geometry(C.c_int(circuit_type), C.c_uint32(capacity), _p(out))
+    return dict(zip(("has", "first_row", "rows_per_cycle", "rows_used", "ops", "max_capacity", "queues"), (int(x) for x in out)))
+
+
+def nlq_cell(circuit_type, capacity, cycle, op, block=-1, region=0, k=0):
+    """(column, row) of a cell of the queue section: block -1 = the ENC block (region 0 components, 1 enc, 2 old, 3 new), block p = P2
+    block p; op == ops per cycle: the QBND row (k = column)"""
+    out = np.zeros(2, np.uint64)
+    f = lib().orc_nlq_cell
+    f.restype = C.c_int
+    assert f(C.c_int(circuit_type), C.c_uint32(capacity), C.c_uint32(cycle), C.c_uint32(op), C.c_int(block), C.c_int(region), C.c_uint32(k), _p(out)) == 0
+    return int(out[0]), int(out[1])
+
+
+def _nlq_overlay(circuit_type, trace, build_out, instance_index, capacity):
+    """write the instance's REAL queue section (the block's request / memory queues) over the one the bare records imply"""
+    inst = build_out["instances"][instance_index]
+    first, n = int(inst["first_round"]), int(inst["num_rounds"])
+    rounds = np.ascontiguousarray(build_out["sha256_rounds"])
+    g = nlq_geometry(circuit_type, capacity)
+    feed = np.zeros((capacity, g["ops"]), NLQ_FEED)
+    mem_in = np.ascontiguousarray(build_out["mem_in"], dtype=QUEUE_STATE12)
+    init_tail = np.ascontiguousarray(mem_in["tail"][0], dtype=np.uint64)
+    mt = np.ascontiguousarray(build_out["mem_tails"], dtype=np.uint64)
+    if circuit_type == 6:
+        lib().orc_sha256_queue_feed(_p(rounds), C.c_size_t(rounds.size), C.c_size_t(first), C.c_uint32(n), C.c_uint32(capacity), _p(feed))
+        items0, states0 = np.ascontiguousarray(build_out["requests"], dtype=LOG_QUERY), np.ascontiguousarray(build_out["request_tails"], dtype=np.uint64)
+        items1 = np.ascontiguousarray(build_out["mem_queries"], dtype=MEM_QUERY)
+    else:
+        woff = np.ascontiguousarray(build_out["word_offsets"], dtype=np.uint64)
+        lib().orc_code_decommitter_queue_feed(_p(rounds), C.c_size_t(rounds.size), _p(woff), C.c_size_t(first), C.c_uint32(n), C.c_uint32(capacity), _p(feed))
+        items0, states0 = np.ascontiguousarray(build_out["requests"], dtype=DECOMMIT_QUERY), np.ascontiguousarray(build_out["dedup_tails"], dtype=np.uint64)
+        items1 = np.ascontiguousarray(build_out["mem_q"], dtype=MEM_QUERY)
+    queues = (_NlqQueue * 2)(_NlqQueue(items0.ctypes.data, states0.ctypes.data, None, items0.size),
+                             _NlqQueue(items1.ctypes.data, mt.ctypes.data, init_tail.ctypes.data, items1.size))
+    f = lib().orc_nlq_synthesize
+    f.restype = C.c_int
+    rc = f(C.c_int(circuit_type), C.c_uint32(capacity), _p(feed), queues, C.c_size_t(trace.shape[1]), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_nlq_synthesize failed: {rc}")
+    return trace
 
 
 def nl_spec_state(circuit_type):
@@ -705,7 +761,8 @@ def sha256_round_synthesize(build_out, instance_index, capacity, n_rows, public_
     state_in = (np.ascontiguousarray(build_out["sha256_rounds"][first - 1]["state_after"]).view(np.uint8) if first
                 else np.zeros(32, np.uint8))
     pi = (public_input if public_input is not None else closed_form_public_inputs(6, build_out["instances"])[1][instance_index])
-    return sha256_round_synthesize_raw(state_in, build_out["sha256_rounds"][first:first + n], capacity, n_rows, pi)
+    trace = sha256_round_synthesize_raw(state_in, build_out["sha256_rounds"][first:first + n], capacity, n_rows, pi)
+    return _nlq_overlay(6, trace, build_out, instance_index, capacity) if "requests" in build_out else trace
 
 
 
@@ -725,7 +782,7 @@ def code_decommitter_synthesize(build_out, instance_index, capacity, n_rows, pub
     rc = f(_p(np.ascontiguousarray(state_in)), _p(recs) if n else None, C.c_uint32(n), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_code_decommitter_round_synthesize failed: {rc}")
-    return trace
+    return _nlq_overlay(3, trace, build_out, instance_index, capacity) if "dedup_tails" in build_out else trace
 
 
 def code_decommitter_check(trace, capacity):
