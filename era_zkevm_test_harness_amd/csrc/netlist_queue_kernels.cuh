@@ -42,7 +42,11 @@ static __global__ __launch_bounds__(64) void k_nlq_feed(int circuit_type, const 
     const RoundOps ro = j.round_ops[j.first_round + c];
     const u32 pop = ro.flags & 1;
     f[0] = nlq_feed{pop, pop ? ro.request : ro.request + 1};
-    if (circuit_type == 6) {
+    if (circuit_type == 5) {  // up to six reads, then the digest write
+        const u32 write = (ro.flags >> 1) & 1, n_reads = ro.n_push - write;
+        for (u32 k = 0; k < 6; k++) f[1 + k] = nlq_feed{k < n_reads ? 1u : 0u, ro.first_query + (k < n_reads ? k : n_reads)};
+        f[7] = nlq_feed{write, ro.first_query + n_reads};
+    } else if (circuit_type == 6) {
         f[1] = nlq_feed{1, ro.first_query};
         f[2] = nlq_feed{1, ro.first_query + 1};
         f[3] = nlq_feed{(ro.flags >> 1) & 1, ro.first_query + 2};
@@ -223,27 +227,25 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
     for (u32 k = 1; k < ncomp; k++)
         if (nlq_comp_linked(&op, k) && cell(k) != nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k)) ok = false;
     if (!ok) flag_bad(res, 2, j, row_e);
-    u64 enc[20], old[12], nw[12];
-    for (u32 e = 0; e < nenc; e++) {
-        enc[e] = cell(ncomp + e);
-        if (nlq_enc_value(op.item, e, cell) != gl::canon(enc[e])) flag_bad(res, 7, 32 * j + e, row_e);
-    }
-    for (u32 k = 0; k < 12; k++) { old[k] = k < w ? cell(ncomp + nenc + k) : 0; nw[k] = k < w ? cell(ncomp + nenc + w + k) : 0; }
-    u64 out[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) out[k] = 0;
-    for (u32 p = 0; p < nlq_kind_perms(op.kind); p++) {
+    // (no per-lane arrays with run-time indices — they would live in scratch memory: every value is read from its cell where it is used)
+    for (u32 e = 0; e < nenc; e++)
+        if (nlq_enc_value(op.item, e, cell) != gl::canon(cell(ncomp + e))) flag_bad(res, 7, 32 * j + e, row_e);
+    const u32 o0 = ncomp + nenc, n_perms = nlq_kind_perms(op.kind);
+    auto want_in = [&](u32 p, u32 k) -> u64 {  // what input k of permutation p copies
+        if (op.kind != NLQ_POP4) return k < 8 ? cell(ncomp + k) : cell(o0 + k);
+        if (k >= 8) return p == 0 ? 0 : nlq_cell_at(S, trace, n_rows, capacity, c, nlq_p2_row0(&d, G, j, p - 1), NLQ_P2_CELLS - 12 + k);
+        if (p < 2) return cell(ncomp + 8 * p + k);
+        return k < 4 ? cell(ncomp + 16 + k) : cell(o0 + (k - 4));
+    };
+    for (u32 p = 0; p < n_perms; p++) {
         const u32 pr0 = nlq_p2_row0(&d, G, j, p);
         const u64 row_p = NLQ_ROW(&S, capacity, pr0, c);
-        u64 want[12], s[12];
-        if (op.kind != NLQ_POP4) { for (int k = 0; k < 8; k++) want[k] = enc[k]; for (int k = 0; k < 4; k++) want[8 + k] = old[8 + k]; }
-        else if (p == 0) { for (int k = 0; k < 8; k++) want[k] = enc[k]; for (int k = 0; k < 4; k++) want[8 + k] = 0; }
-        else if (p == 1) { for (int k = 0; k < 8; k++) want[k] = enc[8 + k]; for (int k = 0; k < 4; k++) want[8 + k] = out[8 + k]; }
-        else { for (int k = 0; k < 4; k++) { want[k] = enc[16 + k]; want[4 + k] = old[k]; want[8 + k] = out[8 + k]; } }
+        u64 s[12];
         ok = true;
-        for (u32 k = 0; k < 12; k++) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
             s[k] = nlq_cell_at(S, trace, n_rows, capacity, c, pr0, k);
-            if (s[k] != want[k]) ok = false;
+            if (s[k] != want_in(p, k)) ok = false;
             s[k] = gl::canon(s[k]);
         }
         if (!ok) flag_bad(res, 2, 0x1000 + 4 * j + p, row_p);
@@ -254,6 +256,7 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
         int r = 0;
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
             p2::full_round(s, r);
+#pragma unroll
             for (int i = 0; i < 12; i++) ok &= nlq_cell_at(S, trace, n_rows, capacity, c, pr0, pos + i) == gl::canon(s[i]);
             pos += 12;
         }
@@ -264,25 +267,26 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
         }
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
             p2::full_round(s, r);
+#pragma unroll
             for (int i = 0; i < 12; i++) ok &= nlq_cell_at(S, trace, n_rows, capacity, c, pr0, pos + i) == gl::canon(s[i]);
             pos += 12;
         }
         if (!ok) flag_bad(res, 8, 4 * j + p, row_p);
-        for (u32 k = 0; k < 12; k++) out[k] = nlq_cell_at(S, trace, n_rows, capacity, c, pr0, NLQ_P2_CELLS - 12 + k);
         for (u32 rr = 0; rr < p2rows; rr++)
             for (u32 col = (rr + 1 == p2rows ? NLQ_P2_CELLS - rr * G : G); col < G; col++)
                 if (NLQ_TR(col, NLQ_ROW(&S, capacity, pr0 + rr, c))) { flag_bad(res, 6, col, NLQ_ROW(&S, capacity, pr0 + rr, c)); break; }
     }
+    const u32 out_r0 = nlq_p2_row0(&d, G, j, n_perms - 1);
     ok = true;
     for (u32 k = 0; k < w; k++) {
-        const u64 o = gl::canon(old[k]);
-        const u64 want = gl::canon(gl::add(o, gl::mul(gl::canon(en), gl::canon(gl::sub(gl::canon(out[k]), o)))));
-        if (want != gl::canon(nw[k])) ok = false;
+        const u64 o = gl::canon(cell(o0 + k)), out_k = gl::canon(nlq_cell_at(S, trace, n_rows, capacity, c, out_r0, NLQ_P2_CELLS - 12 + k));
+        const u64 want = gl::canon(gl::add(o, gl::mul(gl::canon(en), gl::canon(gl::sub(out_k, o)))));
+        if (want != gl::canon(cell(o0 + w + k))) ok = false;
     }
     if (!ok) flag_bad(res, 7, 0x800 + j, row_e);
     ok = true;
     for (u32 k = 0; k < w; k++)
-        if (old[k] != nlq_prev_new(S, d, trace, n_rows, capacity, c, j, op.queue, k)) ok = false;
+        if (cell(o0 + k) != nlq_prev_new(S, d, trace, n_rows, capacity, c, j, op.queue, k)) ok = false;
     if (!ok) flag_bad(res, 2, 0x2000 + j, row_e);
     for (u32 rr = 0; rr < erows; rr++)
         for (u32 col = (rr + 1 == erows ? ncells - rr * G : G); col < G; col++)

@@ -104,7 +104,7 @@ struct PrecompileJob {
     u32 capacity;
     zkw_keccak_round_record* keccak_rounds;  // keccak256 only, may be null: one record per round in the global round order
     zkw_sha256_round_record* sha256_rounds;  // sha256 only, may be null
-    RoundOps* round_ops;                     // sha256 only, may be null: [total_rounds]
+    RoundOps* round_ops;                     // keccak256 / sha256, may be null: [total_rounds]
 };
 
 __device__ __forceinline__ void word_be_bytes(const u32* limbs, uint8_t out[32]) {  // U256::to_big_endian
@@ -176,6 +176,7 @@ static __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job
             qpos += 6; reads += 4;
         } else {
             const bool paddings_round = needs_extra_padding_round && is_last_round;
+            const u64 qpos_before = qpos;
             for (int slot = 0; slot < ZKW_KECCAK_MEMORY_READS_PER_CYCLE; slot++) {
                 const u32 memory_index = abi.input_memory_offset / 32, unalignment = abi.input_memory_offset % 32;
                 const u32 at_most = 32 - unalignment;
@@ -194,6 +195,7 @@ static __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job
                 }
                 filled += meaningful;
             }
+            if (job.round_ops) job.round_ops[g0 + round] = RoundOps{(u32)r, (u32)qpos_before, (u32)(qpos - qpos_before) + (is_last_round ? 1u : 0u), (round == 0 ? 1u : 0u) | (is_last_round ? 2u : 0u)};
             // consume::<136>, padding applied to the copy
             u64 lanes[17];
 #pragma unroll

@@ -245,7 +245,7 @@ struct zkw_precompile_witness {
     int kind = 0;
     u32 capacity = 0;
     u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4], made by the first synthesis call
-    // sha256 only — the queues of the circuit's queue section (netlist_queue_kernels.cuh): the precompile calls and the states of their
+    // keccak256 / sha256 — the queues of the circuit's queue section (netlist_queue_kernels.cuh): the precompile calls and the states of their
     // queue, the memory queries, what every round does to the queues, the memory queue's state before the first query
     zkw_log_query* requests = nullptr;
     u64* req_tails = nullptr;
@@ -303,8 +303,8 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
     alloc((void**)&w->mem_tails, n_queries * 96);
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_precompile_instance));
     if (kind == ZKW_PRECOMPILE_KECCAK256) alloc((void**)&w->keccak_rounds, w->total_rounds * sizeof(zkw_keccak_round_record));
-    if (kind == ZKW_PRECOMPILE_SHA256) {
-        alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
+    if (kind == ZKW_PRECOMPILE_SHA256) alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
+    if (kind != ZKW_PRECOMPILE_ECRECOVER) {
         alloc((void**)&w->requests, n_requests * sizeof(zkw_log_query));
         alloc((void**)&w->req_tails, n_requests * 32);
         alloc((void**)&w->mem_q, n_queries * sizeof(zkw_mem_query));
@@ -334,7 +334,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
                 if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
             }
         }
-        if (kind == ZKW_PRECOMPILE_SHA256 &&
+        if (kind != ZKW_PRECOMPILE_ECRECOVER &&
             (hipMemcpyAsync(w->requests, d_req, n_requests * sizeof(zkw_log_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
              hipMemcpyAsync(w->req_tails, d_rt, n_requests * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
              (n_queries && hipMemcpyAsync(w->mem_q, d_mq, n_queries * sizeof(zkw_mem_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)))
@@ -1144,8 +1144,14 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     if (n_instances == 0) return ZKW_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));  // public inputs of the block's instances (a20), once
-    return nl_synthesize(ctx, 5, false, w->keccak_rounds, nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot),
-                         w->capacity, t->n_rows);
+    const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
+    ZKW_TRY(nl_synthesize(ctx, 5, false, w->keccak_rounds, inst, w->capacity, t->n_rows));
+    NlqQueues Q{};  // the precompile calls are popped, the memory queries (unaligned reads, the digest write) pushed
+    Q.q[0] = NlqQueueIn{w->requests, w->req_tails, {0}, w->n_requests};
+    Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->n_queries};
+    memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
+    Q.round_ops = w->round_ops;
+    return nlq_synthesize(ctx, 5, Q, inst, w->capacity, t->n_rows);
 }
 extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)

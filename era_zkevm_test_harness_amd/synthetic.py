@@ -275,6 +275,49 @@ def sha256_compress_many(states, blocks):
     return states.astype(np.uint32) + np.stack([a, b, c, d, e, f, g, h], axis=1)
 
 
+_KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B, 0x0000000080000001,
+              0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088, 0x0000000080008009, 0x000000008000000A,
+              0x000000008000808B, 0x800000000000008B, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+              0x000000000000800A, 0x800000008000000A, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+_KECCAK_ROT = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]  # [x][y]
+
+
+def keccak_f1600_many(a):
+    """Keccak-f[1600] on N states [N, 25] of uint64 lanes (lane x + 5y), vectorised over N"""
+    a = [a[:, i].copy() for i in range(25)]
+    rol = lambda v, n: v if n == 0 else (v << np.uint64(n)) | (v >> np.uint64(64 - n))  # noqa: E731
+    for rc in _KECCAK_RC:
+        c = [a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20] for x in range(5)]
+        d = [c[(x - 1) % 5] ^ rol(c[(x + 1) % 5], 1) for x in range(5)]
+        a = [a[i] ^ d[i % 5] for i in range(25)]
+        b = [None] * 25
+        for x in range(5):
+            for y in range(5):
+                b[y + 5 * ((2 * x + 3 * y) % 5)] = rol(a[x + 5 * y], _KECCAK_ROT[x][y])
+        a = [b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]) for y in range(5) for x in range(5)]
+        a[0] = a[0] ^ np.uint64(rc)
+    return np.stack(a, axis=1)
+
+
+def keccak256_many(messages):
+    """Keccak-256 (pad10*1 with the 0x01 domain byte, as the keccak256 precompile pads) of a list of byte strings -> [N, 32] uint8"""
+    n = len(messages)
+    rounds = np.array([len(m) // 136 + 1 for m in messages])
+    buf = np.zeros((n, int(rounds.max()) * 136), np.uint8)
+    for i, m in enumerate(messages):
+        buf[i, :len(m)] = np.frombuffer(m, np.uint8)
+        buf[i, len(m)] ^= 0x01
+        buf[i, rounds[i] * 136 - 1] ^= 0x80
+    st = np.zeros((n, 25), np.uint64)
+    for r in range(int(rounds.max())):
+        live = np.nonzero(rounds > r)[0]
+        blk = buf[live, 136 * r:136 * (r + 1)].copy().view("<u8")
+        cur = st[live]
+        cur[:, :17] ^= blk
+        st[live] = keccak_f1600_many(cur)
+    return np.ascontiguousarray(st[:, :4]).view(np.uint8).reshape(n, 32)
+
+
 def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
     """Requests of one precompile (0 keccak256, 1 sha256, 2 ecrecover) with the memory queries the VM would have
     made for them, in the order the reference flattens them (reads round by round, then the write(s))."""
@@ -285,6 +328,7 @@ def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
     req["timestamp"] = np.sort(rng.integers(1, 1 << 30, n_requests).astype(np.uint32) * 2)
     qs = []
     sha_shape = []  # sha256: (index of the request's first query, rounds)
+    keccak_shape = []  # keccak256: (index of the request's first query, reads, byte offset in the first word, length)
 
     def query(ts, page, index, rw):
         m = np.zeros(1, MEM_QUERY)
@@ -321,6 +365,7 @@ def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
             if rng.random() < 0.3:
                 in_off = in_off // 32 * 32 + int(rng.choice([0, 31]))
             key[0], key[1] = in_off, length
+            keccak_shape.append((len(qs), (in_off + length - 1) // 32 - in_off // 32 + 1 if length else 0, in_off % 32, length))
             if length:
                 for wi in range(in_off // 32, (in_off + length - 1) // 32 + 1):
                     qs.append(query(ts, page_r, wi, 0))
@@ -337,6 +382,14 @@ def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
                 blocks = np.concatenate([mq["value"][first[live] + 2 * r][:, ::-1], mq["value"][first[live] + 2 * r + 1][:, ::-1]], axis=1)
                 st[live] = sha256_compress_many(st[live], blocks)
         mq["value"][first + 2 * rounds] = st[:, ::-1]
+    if kind == 0 and keccak_shape:  # the word a keccak256 call writes is the Keccak-256 digest of the bytes it read (U256::from_big_endian)
+        msgs = []
+        for first, reads, skip, length in keccak_shape:
+            words = mq["value"][first:first + reads][:, ::-1].astype(">u4").tobytes()  # U256::to_big_endian of every word read
+            msgs.append(words[skip:skip + length])
+        dig = keccak256_many(msgs)
+        at = np.array([first + reads for first, reads, _, _ in keccak_shape])
+        mq["value"][at] = np.ascontiguousarray(dig[:, ::-1]).view("<u4")
     return req, mq
 
 

@@ -38,12 +38,13 @@
 #define NLQ_MAX_TERMS 14
 
 enum { NLQ_PUSH12 = 1, NLQ_POP12 = 2, NLQ_POP4 = 3 }; /* PUSH12 and POP12 are the same arithmetic on a tail / on a head */
-enum { NLQ_ITEM_MEM = 1, NLQ_ITEM_LOG = 2, NLQ_ITEM_DECOMMIT = 3 };
+enum { NLQ_ITEM_MEM = 1, NLQ_ITEM_LOG = 2, NLQ_ITEM_DECOMMIT = 3, NLQ_ITEM_MEM8 = 4 /* a memory query with its value as 32 bytes (the byte-valued netlists) */ };
 enum { NLQ_EN_FREE = 0, NLQ_EN_RESET = 1, NLQ_EN_ACTIVE = 2 };
 /* links of a memory query's 64 value nibbles (little end first) to the SHA-256 netlist:
    SHA_BLOCK + arg k: the cycle's message block, memory word k (U256::to_big_endian = block bytes 32k..32k+31; FREE element 2b + hi);
    SHA_DIGEST: the chaining state after the cycle (limb j of the written U256 = H[7 - j]) */
-enum { NLQ_LINK_NONE = 0, NLQ_LINK_SHA_BLOCK = 1, NLQ_LINK_SHA_DIGEST = 2 };
+enum { NLQ_LINK_NONE = 0, NLQ_LINK_SHA_BLOCK = 1, NLQ_LINK_SHA_DIGEST = 2,
+       NLQ_LINK_KECCAK_DIGEST = 3 /* MEM8: value byte x (little end first) = byte 31 - x of the sponge state after the cycle (the first four lanes, U256::from_big_endian) */ };
 
 typedef struct nlq_op { uint8_t kind, item, queue, en_rule, link, link_arg; } nlq_op;
 typedef struct nlq_desc { uint32_t n_ops, n_queues; uint32_t width[NLQ_MAX_QUEUES]; nlq_op ops[NLQ_MAX_OPS]; } nlq_desc;
@@ -63,6 +64,16 @@ static const nlq_desc NLQ_DESC_CODE_DECOMMITTER = {3, 2, {12, 12}, {
     {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 0},
     {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_FREE, NLQ_LINK_SHA_BLOCK, 1}}};
 
+/* Keccak256RoundFunction (5): pop the precompile call (first round of a request), up to MEMORY_READS_PER_CYCLE = 6 reads into the byte
+   buffer (keccak256_round_function.rs:232-290: unaligned, so which buffer bytes a word lands on is data — the reads are NOT linked to
+   the block), write the digest after a request's last round (linked). */
+static const nlq_desc NLQ_DESC_KECCAK256 = {8, 2, {4, 12}, {
+    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_KECCAK_DIGEST, 0}}};
+
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define NLQ_HD __host__ __device__ static inline
 #else
@@ -71,12 +82,12 @@ static const nlq_desc NLQ_DESC_CODE_DECOMMITTER = {3, 2, {12, 12}, {
 
 /* host only: kernels take the descriptor by value */
 static inline const nlq_desc *nlq_desc_of(int circuit_type) {
-    return circuit_type == 6 ? &NLQ_DESC_SHA256 : circuit_type == 3 ? &NLQ_DESC_CODE_DECOMMITTER : (const nlq_desc *)0;
+    return circuit_type == 6 ? &NLQ_DESC_SHA256 : circuit_type == 3 ? &NLQ_DESC_CODE_DECOMMITTER : circuit_type == 5 ? &NLQ_DESC_KECCAK256 : (const nlq_desc *)0;
 }
 NLQ_HD uint32_t nlq_kind_width(uint32_t kind) { return kind == NLQ_POP4 ? 4u : 12u; }
 NLQ_HD uint32_t nlq_kind_perms(uint32_t kind) { return kind == NLQ_POP4 ? 3u : 1u; }
 /* component cells of an item, `en` (cell 0) included; encoding elements */
-NLQ_HD uint32_t nlq_item_comps(uint32_t item) { return item == NLQ_ITEM_MEM ? 70u : item == NLQ_ITEM_LOG ? 76u : 18u; }
+NLQ_HD uint32_t nlq_item_comps(uint32_t item) { return item == NLQ_ITEM_MEM ? 70u : item == NLQ_ITEM_LOG ? 76u : item == NLQ_ITEM_MEM8 ? 38u : 18u; }
 NLQ_HD uint32_t nlq_item_enc(uint32_t item) { return item == NLQ_ITEM_LOG ? 20u : 8u; }
 /* cells of the ENC block: [0, comps) | enc | old | new */
 NLQ_HD uint32_t nlq_enc0(const nlq_op *op) { return nlq_item_comps(op->item); }
@@ -123,10 +134,13 @@ NLQ_HD uint32_t nlq_bnd_cells(const nlq_desc *d) { return nlq_bnd_col(d, d->n_qu
    23 rollback, 24 + b: key byte b (little end first), 56 + b: address byte b.   DECOMMIT: 1..8 hash limbs, 9..12 memory_page bytes,
    13..16 timestamp bytes, 17 is_fresh. */
 #define NLQ_MEM_NIBBLE0 6
-NLQ_HD int nlq_comp_linked(const nlq_op *op, uint32_t cell) { return op->link != NLQ_LINK_NONE && cell >= NLQ_MEM_NIBBLE0 && cell < NLQ_MEM_NIBBLE0 + 64; }
+NLQ_HD int nlq_comp_linked(const nlq_op *op, uint32_t cell) {
+    return op->link != NLQ_LINK_NONE && cell >= NLQ_MEM_NIBBLE0 && cell < NLQ_MEM_NIBBLE0 + (op->item == NLQ_ITEM_MEM8 ? 32u : 64u);
+}
 /* the netlist reference a linked cell copies, and the cycle it is seen from (*next: 1 = the state AFTER the cycle = CYC of cycle + 1) */
 NLQ_HD uint32_t nlq_link_ref(const nlq_op *op, uint32_t cell, uint32_t *next) {
     const uint32_t t = cell - NLQ_MEM_NIBBLE0;
+    if (op->link == NLQ_LINK_KECCAK_DIGEST) { *next = 1; return NL_REF_CYC + (31 - t); }
     if (op->link == NLQ_LINK_SHA_DIGEST) { *next = 1; return NL_REF_CYC + 8 * (7 - t / 8) + t % 8; }
     *next = 0;
     return NL_REF_FREE + 2 * (32 * op->link_arg + 31 - t / 2) + (t & 1);
@@ -136,6 +150,7 @@ NLQ_HD uint32_t nlq_link_ref(const nlq_op *op, uint32_t cell, uint32_t *next) {
    keep this in registers) */
 NLQ_HD uint32_t nlq_enc_n_terms(uint32_t item, uint32_t j) {
     if (item == NLQ_ITEM_MEM) return j < 2 ? 1u : j == 2 ? 3u : j < 7 ? 14u : 8u;
+    if (item == NLQ_ITEM_MEM8) return j < 2 ? 1u : j == 2 ? 3u : j < 7 ? 7u : 4u;
     if (item == NLQ_ITEM_LOG) return j <= 17 ? 4u : j == 18 ? 2u : 1u;
     return j < 3 ? 4u : 1u;
 }
@@ -147,6 +162,11 @@ NLQ_HD nlq_term nlq_enc_term(uint32_t item, uint32_t j, uint32_t i) {
         else if (j == 2) { cell = 3 + i; shift = i ? 31 + i : 0; }
         else if (i < 8) { cell = NLQ_MEM_NIBBLE0 + 8 * (j == 7 ? 4 : j - 3) + i; shift = 4 * i; }
         else { const uint32_t ii = i - 8, byte = 20 + 3 * (j - 3) + ii / 2; cell = NLQ_MEM_NIBBLE0 + 2 * byte + (ii & 1); shift = 32 + 8 * (ii / 2) + 4 * (ii & 1); }
+    } else if (item == NLQ_ITEM_MEM8) { /* the same encoding over value BYTES: 6 + x = value byte x, little end first */
+        if (j < 2) cell = 1 + j;
+        else if (j == 2) { cell = 3 + i; shift = i ? 31 + i : 0; }
+        else if (i < 4) { cell = NLQ_MEM_NIBBLE0 + 4 * (j == 7 ? 4 : j - 3) + i; shift = 8 * i; }
+        else { cell = NLQ_MEM_NIBBLE0 + 20 + 3 * (j - 3) + (i - 4); shift = 32 + 8 * (i - 4); }
     } else if (item == NLQ_ITEM_LOG) { /* log_query.rs:150-360: a limb + three bytes of key ++ address | tx_number, address[19], aux_byte, shard_id | rw + 2 * is_service | rollback */
         if (j < 17) {
             if (i == 0) cell = j < 16 ? 1 + j : 17;
@@ -175,6 +195,17 @@ NLQ_HD uint64_t nlq_item_component(uint32_t item, const void *rec, uint32_t cell
             default: { const uint32_t t = cell - NLQ_MEM_NIBBLE0; return (q->value[t / 8] >> (4 * (t % 8))) & 15u; }
         }
     }
+    if (item == NLQ_ITEM_MEM8) {
+        const zkw_mem_query *q = (const zkw_mem_query *)rec;
+        switch (cell) {
+            case 1: return q->timestamp;
+            case 2: return q->page;
+            case 3: return q->index;
+            case 4: return q->rw_flag ? 1 : 0;
+            case 5: return q->value_is_pointer ? 1 : 0;
+            default: { const uint32_t t = cell - NLQ_MEM_NIBBLE0; return (q->value[t / 4] >> (8 * (t % 4))) & 255u; }
+        }
+    }
     if (item == NLQ_ITEM_LOG) {
         const zkw_log_query *q = (const zkw_log_query *)rec;
         if (cell <= 8) return q->read_value[cell - 1];
@@ -201,6 +232,6 @@ NLQ_HD uint64_t nlq_item_component(uint32_t item, const void *rec, uint32_t cell
     }
 }
 NLQ_HD uint32_t nlq_item_bytes(uint32_t item) {
-    return item == NLQ_ITEM_MEM ? (uint32_t)sizeof(zkw_mem_query) : item == NLQ_ITEM_LOG ? (uint32_t)sizeof(zkw_log_query) : (uint32_t)sizeof(zkw_decommit_query);
+    return item == NLQ_ITEM_MEM || item == NLQ_ITEM_MEM8 ? (uint32_t)sizeof(zkw_mem_query) : item == NLQ_ITEM_LOG ? (uint32_t)sizeof(zkw_log_query) : (uint32_t)sizeof(zkw_decommit_query);
 }
 #endif /* ZKW_NETLIST_QUEUE_H */

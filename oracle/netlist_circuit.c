@@ -406,8 +406,9 @@ static int keccak_like(const nl_spec *sp, const uint8_t state_in[200], const zkw
             memcpy(nx, nx - 200, 200);
         }
     }
-    const int rc = orc_nl_synthesize(sp, capacity, hdr, fr, st, pi, n_rows, trace);
+    int rc = orc_nl_synthesize(sp, capacity, hdr, fr, st, pi, n_rows, trace);
     free(hdr); free(fr); free(st);
+    if (rc == 0 && nlq_used_rows(sp, nlq_desc_of(type_of_spec(sp)), capacity) <= n_rows) rc = orc_nlq_standalone_keccak(type_of_spec(sp), rounds, n_active, capacity, n_rows, trace);
     return rc;
 }
 int orc_keccak_round_synthesize(const uint8_t state_in[200], const zkw_keccak_round_record *rounds, uint32_t n_active, uint32_t capacity,

@@ -346,3 +346,72 @@ int orc_nlq_cell(int circuit_type, uint32_t capacity, uint32_t c, uint32_t j, in
     out[1] = NLQ_ROW(sp, capacity, r0 + k / sp->g, c);
     return 0;
 }
+
+/* Keccak256RoundFunction: per round up to ZKW_KECCAK_MEMORY_READS_PER_CYCLE unaligned reads into the 192-byte buffer — a word is read
+   when it has meaningful bytes left and the buffer has room for them (keccak256_round_function.rs:232-290) — and the digest write
+   after a request's last round (:366-380). The rounds of all requests in their global order; feed: [capacity][8]. */
+void orc_keccak_queue_feed(const zkw_log_query *requests, size_t n_req, size_t first_round, uint32_t n_active, uint32_t capacity, nlq_feed *feed) {
+    size_t g = 0, q = 0, popped = 0;
+    for (size_t r = 0; r < n_req && g < first_round + n_active; r++) {
+        uint32_t off = requests[r].key[0], len = requests[r].key[1], filled = 0;
+        const size_t rounds = (len + 135) / 136 + (len % 136 == 0 ? 1 : 0);
+        for (size_t round = 0; round < rounds && g < first_round + n_active; round++, g++) {
+            nlq_feed *f = g >= first_round ? feed + (g - first_round) * 8 : NULL;
+            if (f) f[0] = (nlq_feed){round == 0, (uint32_t)popped}; /* (a later round: the call is popped already, `popped` is the next one) */
+            if (round == 0) popped++;
+            uint32_t n_reads = 0;
+            for (int slot = 0; slot < ZKW_KECCAK_MEMORY_READS_PER_CYCLE; slot++) {
+                const uint32_t at_most = 32 - off % 32, meaningful = len >= at_most ? at_most : len;
+                if (meaningful == 0 || filled + meaningful > ZKW_KECCAK_PRECOMPILE_BUFFER_SIZE) continue;
+                off += meaningful; len -= meaningful; filled += meaningful;
+                n_reads++;
+            }
+            filled = filled < 136 ? 0 : filled - 136;
+            const int last = round + 1 == rounds;
+            for (uint32_t k = 0; k < 6 && f; k++) f[1 + k] = (nlq_feed){k < n_reads, (uint32_t)(q + (k < n_reads ? k : n_reads))};
+            q += n_reads;
+            if (f) f[7] = (nlq_feed){(uint32_t)last, (uint32_t)q};
+            if (last) q++;
+        }
+    }
+    for (uint32_t c = n_active; c < capacity; c++) {
+        nlq_feed *f = feed + (size_t)c * 8;
+        f[0] = (nlq_feed){0, (uint32_t)popped};
+        for (int k = 1; k < 8; k++) f[k] = (nlq_feed){0, (uint32_t)q};
+    }
+}
+
+/* the section that bare Keccak round records imply: an all-zero request per `reset` round, no reads (their alignment is not in the
+   records), a write of the digest after a request's last round */
+int orc_nlq_standalone_keccak(int circuit_type, const zkw_keccak_round_record *rounds, uint32_t n_active, uint32_t capacity, size_t n_rows, uint64_t *trace) {
+    const nlq_desc *d = nlq_desc_of(circuit_type);
+    if (!d) return 0;
+    size_t n_req = 0, n_q = 0;
+    zkw_mem_query *mq = calloc((size_t)n_active + 1, sizeof *mq);
+    nlq_feed *feed = calloc((size_t)capacity * d->n_ops + 1, sizeof *feed);
+    for (uint32_t c = 0; c < capacity; c++) {
+        nlq_feed *f = feed + (size_t)c * d->n_ops;
+        const int active = c < n_active, pop = active && rounds[c].reset, last = active && (c + 1 == n_active || rounds[c + 1].reset);
+        f[0] = (nlq_feed){(uint32_t)pop, (uint32_t)n_req};
+        if (pop) n_req++;
+        if (!pop) f[0].idx = (uint32_t)n_req;
+        for (uint32_t k = 1; k + 1 < d->n_ops; k++) f[k] = (nlq_feed){0, (uint32_t)n_q};
+        f[d->n_ops - 1] = (nlq_feed){(uint32_t)last, (uint32_t)n_q};
+        if (last) {
+            zkw_mem_query *w = &mq[n_q++];
+            w->rw_flag = 1;
+            for (int b = 0; b < 32; b++) w->value[(31 - b) / 4] |= (uint32_t)rounds[c].state_after[b] << (8 * ((31 - b) % 4));
+        }
+    }
+    uint64_t *menc = calloc(n_q * 8 + 1, 8), *mtails = calloc(n_q * 12 + 1, 8), zero12[12] = {0};
+    orc_encode_memory_queries(mq, n_q, menc);
+    orc_queue_push_chain_full(menc, n_q, zero12, mtails);
+    zkw_log_query *req = calloc(n_req + 1, sizeof *req);
+    uint64_t *renc = calloc(n_req * 20 + 1, 8), *rstates = calloc(n_req * 4 + 1, 8);
+    orc_encode_log_queries(req, n_req, NULL, renc);
+    orc_queue_push_chain_log(renc, n_req, zero12, NULL, rstates);
+    const orc_nlq_queue queues[2] = {{req, rstates, NULL, n_req}, {mq, mtails, NULL, n_q}};
+    const int rc = orc_nlq_synthesize(circuit_type, capacity, feed, queues, n_rows, trace);
+    free(mq); free(feed); free(menc); free(mtails); free(req); free(renc); free(rstates);
+    return rc;
+}

@@ -319,6 +319,8 @@ struct nlq_feed;
 int orc_nlq_synthesize(int circuit_type, uint32_t capacity, const struct nlq_feed *feed, const orc_nlq_queue *queues, size_t n_rows, uint64_t *trace);
 uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 int orc_nlq_standalone(int circuit_type, const zkw_sha256_round_record *rounds, uint32_t n_active, uint32_t capacity, size_t n_rows, uint64_t *trace);
+int orc_nlq_standalone_keccak(int circuit_type, const zkw_keccak_round_record *rounds, uint32_t n_active, uint32_t capacity, size_t n_rows, uint64_t *trace);
+void orc_keccak_queue_feed(const zkw_log_query *requests, size_t n_req, size_t first_round, uint32_t n_active, uint32_t capacity, struct nlq_feed *feed);
 void orc_sha256_queue_feed(const zkw_sha256_round_record *rounds, size_t total_rounds, size_t first_round, uint32_t n_active, uint32_t capacity, struct nlq_feed *feed);
 void orc_code_decommitter_queue_feed(const zkw_sha256_round_record *rounds, size_t total_rounds, const uint64_t *word_offsets, size_t first_round,
                                      uint32_t n_active, uint32_t capacity, struct nlq_feed *feed);

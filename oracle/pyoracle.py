@@ -652,7 +652,7 @@ def keccak_round_synthesize(build_out, instance_index, capacity, n_rows, public_
     rc = f(_p(state_in), _p(recs) if n else None, C.c_uint32(n), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_keccak_round_synthesize failed: {rc}")
-    return trace
+    return _nlq_overlay(5, trace, build_out, instance_index, capacity) if "requests" in build_out else trace
 
 
 def nl_geometry(circuit_type):
@@ -691,13 +691,18 @@ def _nlq_overlay(circuit_type, trace, build_out, instance_index, capacity):
     """write the instance's REAL queue section (the block's request / memory queues) over the one the bare records imply"""
     inst = build_out["instances"][instance_index]
     first, n = int(inst["first_round"]), int(inst["num_rounds"])
-    rounds = np.ascontiguousarray(build_out["sha256_rounds"])
+    rounds = np.ascontiguousarray(build_out["sha256_rounds"]) if circuit_type != 5 else None
     g = nlq_geometry(circuit_type, capacity)
     feed = np.zeros((capacity, g["ops"]), NLQ_FEED)
     mem_in = np.ascontiguousarray(build_out["mem_in"], dtype=QUEUE_STATE12)
     init_tail = np.ascontiguousarray(mem_in["tail"][0], dtype=np.uint64)
     mt = np.ascontiguousarray(build_out["mem_tails"], dtype=np.uint64)
-    if circuit_type == 6:
+    if circuit_type == 5:
+        req = np.ascontiguousarray(build_out["requests"], dtype=LOG_QUERY)
+        lib().orc_keccak_queue_feed(_p(req), C.c_size_t(req.size), C.c_size_t(first), C.c_uint32(n), C.c_uint32(capacity), _p(feed))
+        items0, states0 = req, np.ascontiguousarray(build_out["request_tails"], dtype=np.uint64)
+        items1 = np.ascontiguousarray(build_out["mem_queries"], dtype=MEM_QUERY)
+    elif circuit_type == 6:
         lib().orc_sha256_queue_feed(_p(rounds), C.c_size_t(rounds.size), C.c_size_t(first), C.c_uint32(n), C.c_uint32(capacity), _p(feed))
         items0, states0 = np.ascontiguousarray(build_out["requests"], dtype=LOG_QUERY), np.ascontiguousarray(build_out["request_tails"], dtype=np.uint64)
         items1 = np.ascontiguousarray(build_out["mem_queries"], dtype=MEM_QUERY)

@@ -67,8 +67,9 @@ def test_traces_match_oracle_and_tamper_parity(ctx, oracle, ct):
     if oracle.nlq_geometry(ct, cap)["has"]:  # the queue section: flags, linked nibbles, encodings, states, Poseidon2 variables, QBND, unused
         qg = oracle.nlq_geometry(ct, cap)
         qc = lambda *a, **k: oracle.nlq_cell(ct, cap, *a, **k)  # noqa: E731
-        cells += [qc(2, 1), qc(2, 0), qc(3, 3), qc(2, 1, -1, 0, 16), qc(2, 2, -1, 0, 1), qc(3, 1, -1, 1, 4), qc(3, 1, -1, 2, 9), qc(3, 2, -1, 3, 2),
-                  qc(3, 1, 0, 0, 3), qc(3, 1, 0, 0, 70), qc(3, 3, 0, 0, 129), qc(2, 0, -1, 0, 5), qc(2, 0, 1, 0, 40), qc(4, 0, 2, 0, 6), qc(4, 0, -1, 3, 1),
+        last = qg["ops"] - 1  # the digest write
+        cells += [qc(2, 1), qc(2, 0), qc(3, last), qc(2, 1, -1, 0, 16), qc(2, last, -1, 0, 20), qc(2, 2, -1, 0, 1), qc(3, 1, -1, 1, 4), qc(3, 1, -1, 2, 9), qc(3, 2, -1, 3, 2),
+                  qc(3, 1, 0, 0, 3), qc(3, 1, 0, 0, 70), qc(3, last, 0, 0, 129), qc(2, 0, -1, 0, 5), qc(2, 0, 1, 0, 40), qc(4, 0, 2, 0, 6), qc(4, 0, -1, 3, 1),
                   qc(0, qg["ops"], k=1), qc(0, qg["ops"], k=4 + 12 + 1), qc(0, qg["ops"], k=G - 1), (G - 1, qc(2, 1)[1]), (G + 2, qc(2, 1)[1]),
                   (int(rng.integers(0, G)), qg["rows_used"] + 2)]
         cells += [(int(rng.integers(0, G)), int(rng.integers(qg["first_row"], qg["rows_used"]))) for _ in range(10)]
