@@ -121,7 +121,7 @@ __device__ __forceinline__ u64 nlq_enc_value(u32 item, u32 e, F&& cell) {
 }
 
 // grid (ceil(capacity / 64), n_ops, instances)
-static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, nlq_desc d, const NlqJob* __restrict__ jobs,
+static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, const NlqFreeHome* __restrict__ lh, nlq_desc d, const NlqJob* __restrict__ jobs,
                                                         u32 capacity, size_t n_rows) {
     const nl_spec& S = devp->s;
     const NlqJob& job = jobs[blockIdx.z];
@@ -136,8 +136,11 @@ static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict_
     const void* rec = f.en ? static_cast<const char*>(Q.items) + (size_t)f.idx * nlq_item_bytes(op.item) : nullptr;
     // components (the cells are re-read for the encodings: they are this lane's own stores, L2-resident)
     st.at(r0, 0) = f.en ? 1 : 0;
-    for (u32 k = 1; k < ncomp; k++)
-        st.at(r0, k) = nlq_comp_linked(&op, k) ? nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k) : nlq_item_component(op.item, rec, k);
+    for (u32 k = 1; k < ncomp; k++) {
+        if (!nlq_comp_linked(&op, k)) { st.at(r0, k) = nlq_item_component(op.item, rec, k); continue; }
+        const NlqFreeHome h = lh[j * 64 + (k - NLQ_MEM_NIBBLE0)];  // (the source cell inside this cycle, where the host could resolve it)
+        st.at(r0, k) = h.row != 0xFFFF ? NLQ_TR(h.col, (size_t)c * S.rows_per_cycle + h.row) : nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k);
+    }
     for (u32 e = 0; e < nenc; e++)
         st.at(r0, ncomp + e) = nlq_enc_value(op.item, e, [&](u32 cell) { return st.at(r0, cell); });
     u64 old[12];

@@ -619,7 +619,8 @@ extern "C" int zkw_precompile_closed_forms(zkw_ctx* ctx, zkw_precompile_witness*
 // four generated specs on the reference's geometry and table sets. The device copy of a spec (its arrays, the general-purpose cell
 // map, the key layout and the histogram plan) is built once per device and circuit and never freed.
 namespace {
-struct NlCached { NlDev host; NlDev* dev = nullptr; const NlqFreeHome* free_home = nullptr; /* circuits with a queue section: the cell of every FREE element */ };
+struct NlCached { NlDev host; NlDev* dev = nullptr; const NlqFreeHome* free_home = nullptr; /* circuits with a queue section: the cell of every FREE element */
+                  const NlqFreeHome* link_home = nullptr; /* [operation][64]: the cell (within the cycle) a linked value cell copies, for the fill */ };
 std::mutex g_nl_mu;
 std::map<std::pair<int, int>, NlCached>& nl_cache() { static auto* m = new std::map<std::pair<int, int>, NlCached>(); return *m; }
 
@@ -919,6 +920,26 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
             off += T.n_free;
         }
         ZKW_TRY(nl_to_device(fh.data(), fh.size(), &c.free_home));
+        // the fill's shortcut: where a linked value cell's source sits inside ITS OWN cycle (a FREE element's cell; a state element
+        // after the cycle = the value the last step leaves); 0xFFFF = resolve it the long way (nl_home_cell), as the checker always does
+        const nlq_desc* qd = nlq_desc_of(circuit_type);
+        std::vector<NlqFreeHome> lh((size_t)NLQ_MAX_OPS * 64, NlqFreeHome{0xFFFF, 0xFFFF});
+        const nl_cycle_step& ls = hs->cycle[hs->steps_per_cycle - 1];
+        const nl_step_type& LT = hs->step_types[ls.type];
+        for (u32 j = 0; j < qd->n_ops; j++)
+            for (u32 cell = NLQ_MEM_NIBBLE0; cell < NLQ_MEM_NIBBLE0 + 64; cell++) {
+                if (!nlq_comp_linked(&qd->ops[j], cell)) continue;
+                uint32_t next = 0;
+                const u32 ref = nlq_link_ref(&qd->ops[j], cell, &next);
+                NlqFreeHome& o = lh[(size_t)j * 64 + (cell - NLQ_MEM_NIBBLE0)];
+                if (!next) { o = fh[ref - NL_REF_FREE]; continue; }
+                const u32 r2 = hs->out[(size_t)ls.type * hs->state + (ref - NL_REF_CYC)];
+                if (r2 >= NL_REF_HDR) continue;
+                const nl_home h = hs->homes[LT.home0 + r2];
+                if (h.kind == 1) { const nl_gate& gt = hs->gates[LT.gate0 + h.item]; o = NlqFreeHome{(uint16_t)(ls.row0 + gt.row), (uint16_t)(gt.col + h.cell)}; }
+                else o = NlqFreeHome{(uint16_t)(ls.row0 + 1 + h.item / hs->r), (uint16_t)(hs->g + hs->w * (h.item % hs->r) + h.cell)};
+            }
+        ZKW_TRY(nl_to_device(lh.data(), lh.size(), &c.link_home));
     }
     const NlDev* dd = nullptr;
     ZKW_TRY(nl_to_device(&d, 1, &dd));
@@ -1081,7 +1102,7 @@ int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std
     const unsigned cb = (capacity + 63) / 64;
     { Prof _p(ctx, "k_nlq_feed"); hipLaunchKernelGGL(k_nlq_feed, dim3(cb, (unsigned)ni), dim3(64), 0, ctx->stream, circuit_type, d_fj, capacity, d->n_ops); }
     ZKW_TRY(launch_check("k_nlq_feed"));
-    { Prof _p(ctx, "k_nlq_fill"); hipLaunchKernelGGL(k_nlq_fill, dim3(cb, d->n_ops, (unsigned)ni), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, *d, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_nlq_fill"); hipLaunchKernelGGL(k_nlq_fill, dim3(cb, d->n_ops, (unsigned)ni), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, nc->link_home, *d, d_jobs, capacity, n_rows); }
     return launch_check("k_nlq_fill");
 }
 

@@ -555,14 +555,17 @@ int zkw_callstack_simulate(zkw_ctx *ctx, const uint8_t *is_push, size_t n_ops, c
                            uint64_t *round_states, uint32_t *entry_index);
 
 /* ---- Keccak256RoundFunction circuit (type 5) ----------------------------------------------------------------
-   ZkSyncBaseLayerCircuit::synthesis for the keccak256 round function (wrapper geometry: circuit_definitions/src/
-   circuit_definitions/base_layer/keccak256_round_function.rs:28-39,52-142: 86 copy columns, width-3 lookups x 14 per row
-   with one table id per row, 2^20 rows, capacity 293). Trace "zkw trace v3", include/zkw_keccak_circuit_spec.h: 137 columns
-   (zkw_trace_create_with_columns(.., 137, ..)), a netlist of byte lookups (XOR8, ANDN8, ROT<1..7>) stating, per cycle,
-   out = idle ? prev : Keccak-f[1600]((reset ? 0 : prev) ^ block); cycles = the instance's rounds (ZKW_PRC_KECCAK_ROUNDS),
-   idle up to the capacity the witness was built with. n_rows >= 65 536 (one multiplicity column per 2^16-row table).
-   The check re-derives every relation from the cells: table membership, copy constraints, headers, boundary rows,
-   multiplicities. w must be a keccak256 witness (zkw_precompile_build(ctx, ZKW_PRECOMPILE_KECCAK256, ..)). */
+   ZkSyncBaseLayerCircuit::synthesis for the keccak256 round function on the wrapper's geometry and table set (circuit_definitions/src/
+   circuit_definitions/base_layer/keccak256_round_function.rs:28-39,120-140: 86 copy columns, width-3 lookups x 14 per row with one
+   table id per row, Xor8 / And8 / ByteSplit<1..4> = 132 096 table rows = vk_5.json's total_tables_len, ONE multiplicity column; 2^20
+   rows, capacity 293). Trace "zkw trace v4" (include/zkw_netlist.h, include/zkw_keccak_circuit_spec.h): 129 columns
+   (zkw_trace_create_with_columns(.., 129, ..)), per cycle a netlist stating out = idle ? prev : Keccak-f[1600]((reset ? 0 : prev) ^
+   block); cycles = the instance's rounds (ZKW_PRC_KECCAK_ROUNDS), idle up to the capacity the witness was built with. Below the PI row:
+   the QUEUE SECTION (include/zkw_netlist_queue.h) — per cycle the pop of the precompile call, up to six memory reads and the digest
+   write as Poseidon2 rows, the queues chained through the trace, the written value's bytes copies of the sponge state. n_rows >=
+   max(262 144, zkw_circuit_layout_of(5, capacity).rows_used). The check re-derives every relation from the cells: table membership,
+   copy constraints, gates, headers, boundary rows, multiplicities, the section's encodings / permutations / selections / chains.
+   w must be a keccak256 witness (zkw_precompile_build(ctx, ZKW_PRECOMPILE_KECCAK256, ..)) whose write queries hold the digests. */
 /* compact closed-form inputs [n_instances][18] and public inputs [n_instances][4] of a precompile witness (any kind), DEVICE
    pointers valid until the witness is freed; computed on ctx's stream at the first call and kept with the witness (the
    type-5 synthesis writes them into the PI rows). Either out pointer may be NULL. */
@@ -573,26 +576,31 @@ int zkw_keccak_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t sl
                                      uint64_t *n_violations, uint64_t *first_bad);
 
 /* ---- Sha256RoundFunction circuit (type 6) ------------------------------------------------------------------
-   ZkSyncBaseLayerCircuit::synthesis for the sha256 round function (wrapper geometry: circuit_definitions/src/
-   circuit_definitions/base_layer/sha256_round_function.rs:28-39,52-134; 2^20 rows, capacity 2206). Trace "zkw trace v3",
-   include/zkw_sha256_circuit_spec.h: 138 columns, one netlist per cycle of 6552 byte lookups (XOR8, ANDN8, AND8, ROT<1..7>)
-   and 184 32-bit ADD gates in the general-purpose columns of the same rows, stating out = idle ? prev :
-   sha256_compress(reset ? IV : prev, block); 469 rows per cycle (up to 2235 cycles in 2^20 rows). Cycles = the instance's
-   rounds (ZKW_PRC_SHA256_ROUNDS), idle up to the witness's capacity; n_rows >= 65 536. w must be a sha256 witness.
-   Context scratch per instance of the call (kept by the context for the next call): 21 MB of multiplicity histogram slices
-   and 2 bytes per lookup of keys (29 MB at capacity 2206); the same holds for the type-5 / 13 / 3 calls. */
+   ZkSyncBaseLayerCircuit::synthesis for the sha256 round function on the wrapper's geometry and table set (circuit_definitions/src/
+   circuit_definitions/base_layer/sha256_round_function.rs:28-39,121-134: 116 copy columns, width-4 lookups x 9 per row, TriXor4 / Ch4 /
+   Maj4 / Split4BitChunk<1,2> = 12 320 table rows = vk_6.json's total_tables_len; 2^20 rows, capacity 2206). Trace "zkw trace v4",
+   include/zkw_sha256_circuit_spec.h: 153 columns, per cycle a netlist on 4-bit chunks stating out = idle ? prev :
+   sha256_compress(reset ? IV : prev, block); cycles = the instance's rounds (ZKW_PRC_SHA256_ROUNDS), idle up to the witness's
+   capacity. Below the PI row the QUEUE SECTION (include/zkw_netlist_queue.h): per cycle the pop of the precompile call (first round of
+   a request), the two memory reads whose value nibbles are copies of the block's message nibbles, the write of the digest (last
+   round; value nibbles = copies of the state after the cycle) as Poseidon2 rows. A write query that does not hold the digest makes
+   the trace unsatisfied. n_rows >= zkw_circuit_layout_of(6, capacity).rows_used. w must be a sha256 witness.
+   Context scratch per instance of the call (kept by the context for the next call): multiplicity histogram slices and 2 bytes per
+   lookup of keys; the same holds for the type-5 / 13 / 3 / 10 calls. */
 int zkw_sha256_round_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t first_instance, size_t n_instances,
                                 zkw_trace *t, size_t first_slot);
 int zkw_sha256_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                                      uint64_t *n_violations, uint64_t *first_bad);
 
 /* ---- CodeDecommitter circuit (type 3) ----------------------------------------------------------------------
-   ZkSyncBaseLayerCircuit::synthesis for the code decommitter (wrapper geometry: circuit_definitions/src/circuit_definitions/
-   base_layer/code_decommitter.rs:28-39: 2^20 rows, capacity 2845 SHA-256 rounds). Trace "zkw trace v3",
-   include/zkw_code_decommitter_circuit_spec.h: the SHA-256 netlist of the type-6 trace at 18 lookups per row (150 columns,
-   366 rows per cycle: up to 2864 cycles in 2^20 rows); one cycle per round of the unpacked bytecodes (ZKW_DCM_SHA256_ROUNDS:
-   block as hashed incl. the final padding, reset at a bytecode's first round, state after), idle beyond the instance's
-   rounds. w: the witness of zkw_decommitter_build. n_rows >= 65 536. */
+   ZkSyncBaseLayerCircuit::synthesis for the code decommitter on the wrapper's geometry (circuit_definitions/src/circuit_definitions/
+   base_layer/code_decommitter.rs:28-39,121-134: 108 copy columns, width-4 lookups x 11 per row, the SHA-256 table set = 12 320 rows;
+   2^20 rows, capacity 2845 SHA-256 rounds). Trace "zkw trace v4", include/zkw_code_decommitter_circuit_spec.h: the SHA-256 netlist of
+   the type-6 trace at this geometry (153 columns); one cycle per round of the unpacked bytecodes (ZKW_DCM_SHA256_ROUNDS: block as
+   hashed incl. the final padding, reset at a bytecode's first round, state after), idle beyond the instance's rounds; below the PI row
+   the QUEUE SECTION (include/zkw_netlist_queue.h): per cycle the pop of the decommit request (a bytecode's first round) and the memory
+   writes of the round's two code words (one in a bytecode's last round), value nibbles = copies of the block's message nibbles.
+   w: the witness of zkw_decommitter_build. n_rows >= zkw_circuit_layout_of(3, capacity).rows_used. */
 int zkw_code_decommitter_synthesize(zkw_ctx *ctx, zkw_decommitter_witness *w, size_t first_instance, size_t n_instances,
                                     zkw_trace *t, size_t first_slot);
 int zkw_code_decommitter_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
