@@ -18,7 +18,7 @@ namespace zkw {
 // query than the reads (sha256: the digest write)
 struct NlqQueueIn { const void* items; const u64* states; u64 init[12]; u64 n_items; };
 struct NlqJob { const nlq_feed* feed; u64* trace; NlqQueueIn queues[NLQ_MAX_QUEUES]; };
-struct NlqFeedJob { const RoundOps* round_ops; u64 first_round; u32 n_active; nlq_feed* feed; };
+struct NlqFeedJob { const RoundOps* round_ops; u64 first_round; u32 n_active; nlq_feed* feed; u64 n_items; /* L1MessagesHasher: messages of the queue */ };
 struct NlqFreeHome { uint16_t row, col; };  // the one cell of a cycle that holds FREE element i
 
 #define NLQ_TR(col, row) trace[(size_t)(col) * n_rows + (size_t)(row)]
@@ -29,6 +29,13 @@ static __global__ __launch_bounds__(64) void k_nlq_feed(int circuit_type, const 
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= capacity) return;
     nlq_feed* f = j.feed + (size_t)c * n_ops;
+    if (circuit_type == 13) {  // message m is popped in the cycle that absorbs its first byte (at most two per cycle)
+        u64 m0 = NLQ_LH_FIRST(c), m1 = NLQ_LH_FIRST(c + 1);
+        if (m0 > j.n_items) m0 = j.n_items;
+        if (m1 > j.n_items) m1 = j.n_items;
+        for (u32 k = 0; k < 2; k++) f[k] = m0 + k < m1 ? nlq_feed{1, (u32)(m0 + k)} : nlq_feed{0, (u32)m1};
+        return;
+    }
     if (c >= j.n_active) {  // idle: everything disabled, the queues stay where the last active round left them
         u32 nreq = 0, nq = 0;
         if (j.n_active || j.first_round) {

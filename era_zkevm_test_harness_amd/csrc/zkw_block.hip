@@ -852,8 +852,11 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
                 case T_SHA: rc = zkw_sha256_round_synthesize(c, B->pre[1], first, cnt, ring, 0); break;
                 case T_HSH: {  // one instance over the net L2 -> L1 messages (the L1 sorter's result queue)
                     zkw_linear_hasher_instance rec;
-                    rc = zkw_linear_hasher_synthesize(c, static_cast<const zkw_log_query*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_RESULT_QUERIES)),
-                                                      zkw_events_witness_num_results(B->l1), &B->linear_hasher.queue_state, B->cap[T_HSH], ring, 0, &rec, nullptr);
+                    // (the result queue's states are the events sorter's: the pops of the trace's queue section run through them)
+                    const uint64_t lh_off[2] = {0, zkw_events_witness_num_results(B->l1)};
+                    rc = zkw_linear_hasher_synthesize_batch_with_tails(c, static_cast<const zkw_log_query*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_RESULT_QUERIES)), lh_off, 1,
+                                                                       &B->linear_hasher.queue_state, static_cast<const uint64_t*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_RESULT_NEW_TAILS)),
+                                                                       B->cap[T_HSH], ring, 0, &rec, nullptr);
                     break;
                 }
             }

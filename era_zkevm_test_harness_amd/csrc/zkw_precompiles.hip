@@ -1079,7 +1079,8 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
 // the queue section of the instances nl_synthesize has just filled (include/zkw_netlist_queue.h): request-queue pops and memory-queue
 // pushes as Poseidon2 rows below the netlist, on the same stream (the fill reads the linked netlist cells back)
 struct NlqQueues { NlqQueueIn q[NLQ_MAX_QUEUES]; const RoundOps* round_ops; };
-int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
+int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows,
+                   const std::vector<NlqQueues>* per_instance = nullptr /* independent queues per instance (L1MessagesHasher) */) {
     const nlq_desc* d = nlq_desc_of(circuit_type);
     if (!d || inst.empty()) return ZKW_OK;
     const NlCached* nc = nullptr;
@@ -1090,10 +1091,11 @@ int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std
     std::vector<NlqFeedJob> fj(ni);
     std::vector<NlqJob> jobs(ni);
     for (size_t k = 0; k < ni; k++) {
-        fj[k] = NlqFeedJob{Q.round_ops, inst[k].first_round, inst[k].n_active, d_feed + k * feed_n};
+        const NlqQueues& QK = per_instance ? (*per_instance)[k] : Q;
+        fj[k] = NlqFeedJob{QK.round_ops, inst[k].first_round, inst[k].n_active, d_feed + k * feed_n, QK.q[0].n_items};
         jobs[k].feed = fj[k].feed;
         jobs[k].trace = inst[k].t->data + inst[k].slot * inst[k].t->slot_elems();  // (the slot keeps the tag nl_synthesize_with gave it)
-        for (u32 q = 0; q < NLQ_MAX_QUEUES; q++) jobs[k].queues[q] = Q.q[q];
+        for (u32 q = 0; q < NLQ_MAX_QUEUES; q++) jobs[k].queues[q] = QK.q[q];
     }
     NlqFeedJob* d_fj = nullptr;
     NlqJob* d_jobs = nullptr;
@@ -1271,8 +1273,11 @@ extern "C" int zkw_storage_application_check_satisfied(zkw_ctx* ctx, const zkw_t
 
 // LinearHasher (type 13): the Keccak-f netlist over the sponge of the serialized L2 -> L1 messages (compute_linear_keccak256,
 // data_hasher_and_merklizer.rs:8-67; wrapper base_layer/linear_hasher.rs:28-138). One instance per block.
-extern "C" int zkw_linear_hasher_synthesize_batch(zkw_ctx* ctx, const zkw_log_query* messages, const uint64_t* message_offsets, size_t n_queues,
-                                                  const zkw_queue_state4* queue_states, uint32_t capacity, zkw_trace* t, size_t first_slot,
+// message_tails: [total][4], the state of a queue after each of its messages was pushed (what the events sorter keeps as
+// ZKW_EVT_RESULT_NEW_TAILS) — the heads the circuit's pops run through; NULL: hashed here from queue_states[b].head (one serial
+// Poseidon2 chain per queue)
+extern "C" int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx* ctx, const zkw_log_query* messages, const uint64_t* message_offsets, size_t n_queues,
+                                                  const zkw_queue_state4* queue_states, const uint64_t* message_tails, uint32_t capacity, zkw_trace* t, size_t first_slot,
                                                   zkw_linear_hasher_instance* records_out, uint64_t* public_inputs_out) {
     if (!ctx || !t || !message_offsets || !queue_states || !records_out || t->ctx->device != ctx->device || capacity == 0)
         return fail(ZKW_ERR_INVALID, "zkw_linear_hasher_synthesize_batch: bad argument");
@@ -1329,9 +1334,41 @@ extern "C" int zkw_linear_hasher_synthesize_batch(zkw_ctx* ctx, const zkw_log_qu
     std::vector<NlInstance> inst(n_queues);
     for (size_t b = 0; b < n_queues; b++) inst[b] = NlInstance{roff[b], (u32)(roff[b + 1] - roff[b]), d_pi + 4 * b, t, first_slot + b, true};
     ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows));
+    {   // the queue section: every message is popped (Poseidon2 rows below the netlist, include/zkw_netlist_queue.h)
+        const u64* d_tails = nullptr;
+        if (total && message_tails) ZKW_TRY(ctx->in("lh_tails", message_tails, total * 4, &d_tails));
+        else if (total) {
+            u64 *d_enc = nullptr, *d_new = nullptr, *d_heads = nullptr;
+            ZKW_TRY(ctx->scratch_t<u64>("lh_enc", total * 20, &d_enc));
+            ZKW_TRY(ctx->scratch_t<u64>("lh_new_tails", total * 4, &d_new));
+            std::vector<u64> heads(4 * n_queues);
+            for (size_t b = 0; b < n_queues; b++) memcpy(&heads[4 * b], queue_states[b].head, 32);
+            ZKW_TRY(ctx->upload("lh_heads", heads, &d_heads));
+            { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, d_q, total, (const u32*)nullptr, d_enc); }
+            ZKW_TRY(launch_check("k_encode_log"));
+            std::vector<LogChainJob> chains;
+            for (size_t b = 0; b < n_queues; b++)
+                if (moff[b + 1] > moff[b]) chains.push_back(LogChainJob{d_enc + 20 * moff[b], nullptr, nullptr, d_new + 4 * moff[b], d_heads + 4 * b, moff[b + 1] - moff[b]});
+            ZKW_TRY(dev_log_chains(ctx, d_enc, total, chains));
+            d_tails = d_new;
+        }
+        std::vector<NlqQueues> per(n_queues);
+        for (size_t b = 0; b < n_queues; b++) {
+            per[b] = NlqQueues{};
+            per[b].q[0] = NlqQueueIn{d_q ? d_q + moff[b] : nullptr, d_tails ? d_tails + 4 * moff[b] : nullptr, {0}, moff[b + 1] - moff[b]};
+            memcpy(per[b].q[0].init, queue_states[b].head, 32);
+        }
+        ZKW_TRY(nlq_synthesize(ctx, 13, per[0], inst, cycles, n_rows, &per));
+    }
     memcpy(records_out, recv.data(), n_queues * sizeof recv[0]);
     if (public_inputs_out) ZKW_TRY(ctx->read_small(public_inputs_out, d_pi, 32 * n_queues));
     return ZKW_OK;
+}
+
+extern "C" int zkw_linear_hasher_synthesize_batch(zkw_ctx* ctx, const zkw_log_query* messages, const uint64_t* message_offsets, size_t n_queues,
+                                                  const zkw_queue_state4* queue_states, uint32_t capacity, zkw_trace* t, size_t first_slot,
+                                                  zkw_linear_hasher_instance* records_out, uint64_t* public_inputs_out) {
+    return zkw_linear_hasher_synthesize_batch_with_tails(ctx, messages, message_offsets, n_queues, queue_states, nullptr, capacity, t, first_slot, records_out, public_inputs_out);
 }
 
 extern "C" int zkw_linear_hasher_synthesize(zkw_ctx* ctx, const zkw_log_query* messages, size_t n, const zkw_queue_state4* queue_state,

@@ -137,6 +137,7 @@ SYMBOLS = [
     ("zkw_sha256_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_linear_hasher_synthesize", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
     ("zkw_linear_hasher_synthesize_batch", _int, [_vp, _vp, _vp, _sz, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
+    ("zkw_linear_hasher_synthesize_batch_with_tails", _int, [_vp, _vp, _vp, _sz, _vp, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
     ("zkw_linear_hasher_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),

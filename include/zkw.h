@@ -639,6 +639,13 @@ int zkw_linear_hasher_synthesize(zkw_ctx *ctx, const zkw_log_query *messages, si
 int zkw_linear_hasher_synthesize_batch(zkw_ctx *ctx, const zkw_log_query *messages, const uint64_t *message_offsets, size_t n_queues,
                                        const zkw_queue_state4 *queue_states, uint32_t capacity, zkw_trace *t, size_t first_slot,
                                        zkw_linear_hasher_instance *records_out, uint64_t *public_inputs_out);
+/* The same with the queues' states given: message_tails [total][4] = the state of a queue after each of its messages was pushed (the
+   events sorter's ZKW_EVT_RESULT_NEW_TAILS) — the heads the circuit's pops run through in the trace's queue section
+   (include/zkw_netlist_queue.h: every message is popped as three Poseidon2 permutations below the netlist, the head chained from
+   queue_states[b].head). NULL: hashed here, one serial Poseidon2 chain per queue (what zkw_linear_hasher_synthesize[_batch] do). */
+int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx *ctx, const zkw_log_query *messages, const uint64_t *message_offsets, size_t n_queues,
+                                                  const zkw_queue_state4 *queue_states, const uint64_t *message_tails, uint32_t capacity, zkw_trace *t,
+                                                  size_t first_slot, zkw_linear_hasher_instance *records_out, uint64_t *public_inputs_out);
 
 /* ---- public inputs and the recursion queue (a20) ---------------------------------------------------- */
 /* commit_variable_length_encodable_item as driven by simulate_public_input_value_from_witness

@@ -74,6 +74,15 @@ static const nlq_desc NLQ_DESC_KECCAK256 = {8, 2, {4, 12}, {
     {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0},
     {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_KECCAK_DIGEST, 0}}};
 
+/* L1MessagesHasher (13): the circuit pops EVERY message of the queue and hashes its 88-byte serialisation (linear_hasher in the absent
+   crate; out of circuit data_hasher_and_merklizer.rs:8-67). A message is popped in the cycle that absorbs its first byte — cycle
+   floor(88 m / 136), at most two per cycle. Which block bytes a message lands on depends on the cycle (period 11), so the popped
+   fields are NOT linked to the block (placed). One queue. */
+static const nlq_desc NLQ_DESC_LINEAR_HASHER = {2, 1, {4, 0}, {
+    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_FREE, NLQ_LINK_NONE, 0}, {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_FREE, NLQ_LINK_NONE, 0}}};
+/* messages whose first byte is absorbed by cycle c: [nlq_lh_first(c), nlq_lh_first(c + 1)) */
+#define NLQ_LH_FIRST(c) (((uint64_t)(c) * 136 + 87) / 88)
+
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define NLQ_HD __host__ __device__ static inline
 #else
@@ -82,7 +91,8 @@ static const nlq_desc NLQ_DESC_KECCAK256 = {8, 2, {4, 12}, {
 
 /* host only: kernels take the descriptor by value */
 static inline const nlq_desc *nlq_desc_of(int circuit_type) {
-    return circuit_type == 6 ? &NLQ_DESC_SHA256 : circuit_type == 3 ? &NLQ_DESC_CODE_DECOMMITTER : circuit_type == 5 ? &NLQ_DESC_KECCAK256 : (const nlq_desc *)0;
+    return circuit_type == 6 ? &NLQ_DESC_SHA256 : circuit_type == 3 ? &NLQ_DESC_CODE_DECOMMITTER : circuit_type == 5 ? &NLQ_DESC_KECCAK256 :
+           circuit_type == 13 ? &NLQ_DESC_LINEAR_HASHER : (const nlq_desc *)0;
 }
 NLQ_HD uint32_t nlq_kind_width(uint32_t kind) { return kind == NLQ_POP4 ? 4u : 12u; }
 NLQ_HD uint32_t nlq_kind_perms(uint32_t kind) { return kind == NLQ_POP4 ? 3u : 1u; }

@@ -386,6 +386,7 @@ void orc_keccak_queue_feed(const zkw_log_query *requests, size_t n_req, size_t f
 int orc_nlq_standalone_keccak(int circuit_type, const zkw_keccak_round_record *rounds, uint32_t n_active, uint32_t capacity, size_t n_rows, uint64_t *trace) {
     const nlq_desc *d = nlq_desc_of(circuit_type);
     if (!d) return 0;
+    if (circuit_type == 13) return orc_linear_hasher_queue_section(NULL, 0, NULL, capacity, n_rows, trace); /* bare records: no message is known, nothing is popped */
     size_t n_req = 0, n_q = 0;
     zkw_mem_query *mq = calloc((size_t)n_active + 1, sizeof *mq);
     nlq_feed *feed = calloc((size_t)capacity * d->n_ops + 1, sizeof *feed);
@@ -413,5 +414,31 @@ int orc_nlq_standalone_keccak(int circuit_type, const zkw_keccak_round_record *r
     const orc_nlq_queue queues[2] = {{req, rstates, NULL, n_req}, {mq, mtails, NULL, n_q}};
     const int rc = orc_nlq_synthesize(circuit_type, capacity, feed, queues, n_rows, trace);
     free(mq); free(feed); free(menc); free(mtails); free(req); free(renc); free(rstates);
+    return rc;
+}
+
+/* L1MessagesHasher: message m of the n is popped in the cycle that absorbs its first byte; feed: [cycles][2] */
+void orc_linear_hasher_queue_feed(size_t n_messages, uint32_t cycles, nlq_feed *feed) {
+    for (uint32_t c = 0; c < cycles; c++) {
+        uint64_t m0 = NLQ_LH_FIRST(c), m1 = NLQ_LH_FIRST(c + 1);
+        if (m0 > n_messages) m0 = n_messages;
+        if (m1 > n_messages) m1 = n_messages;
+        for (uint32_t k = 0; k < 2; k++) {
+            const int en = m0 + k < m1;
+            feed[(size_t)c * 2 + k] = (nlq_feed){(uint32_t)en, (uint32_t)(en ? m0 + k : m1)};
+        }
+    }
+}
+/* the section of a LinearHasher trace: `messages` popped from a queue whose head is `head` (NULL: zeros, the empty queue's state) */
+int orc_linear_hasher_queue_section(const zkw_log_query *messages, size_t n, const uint64_t *head, uint32_t cycles, size_t n_rows, uint64_t *trace) {
+    uint64_t *enc = calloc(n * 20 + 1, 8), *states = calloc(n * 4 + 1, 8), zero[4] = {0};
+    if (!head) head = zero;
+    nlq_feed *feed = calloc((size_t)cycles * 2 + 1, sizeof *feed);
+    orc_encode_log_queries(messages, n, NULL, enc);
+    orc_queue_push_chain_log(enc, n, head, NULL, states);
+    orc_linear_hasher_queue_feed(n, cycles, feed);
+    const orc_nlq_queue queues[2] = {{messages, states, head, n}, {NULL, NULL, NULL, 0}};
+    const int rc = orc_nlq_synthesize(13, cycles, feed, queues, n_rows, trace);
+    free(enc); free(states); free(feed);
     return rc;
 }

@@ -321,6 +321,8 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
 int orc_nlq_standalone(int circuit_type, const zkw_sha256_round_record *rounds, uint32_t n_active, uint32_t capacity, size_t n_rows, uint64_t *trace);
 int orc_nlq_standalone_keccak(int circuit_type, const zkw_keccak_round_record *rounds, uint32_t n_active, uint32_t capacity, size_t n_rows, uint64_t *trace);
 void orc_keccak_queue_feed(const zkw_log_query *requests, size_t n_req, size_t first_round, uint32_t n_active, uint32_t capacity, struct nlq_feed *feed);
+void orc_linear_hasher_queue_feed(size_t n_messages, uint32_t cycles, struct nlq_feed *feed);
+int orc_linear_hasher_queue_section(const zkw_log_query *messages, size_t n, const uint64_t *head, uint32_t cycles, size_t n_rows, uint64_t *trace);
 void orc_sha256_queue_feed(const zkw_sha256_round_record *rounds, size_t total_rounds, size_t first_round, uint32_t n_active, uint32_t capacity, struct nlq_feed *feed);
 void orc_code_decommitter_queue_feed(const zkw_sha256_round_record *rounds, size_t total_rounds, const uint64_t *word_offsets, size_t first_round,
                                      uint32_t n_active, uint32_t capacity, struct nlq_feed *feed);

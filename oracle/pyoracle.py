@@ -836,6 +836,12 @@ def linear_hasher_synthesize(messages, queue_state, capacity, n_rows):
     rc = g(_p(np.zeros(200, np.uint8)), _p(recs), C.c_uint32(n), C.c_uint32(cycles), _p(pi), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_linear_hasher_round_synthesize failed: {rc}")
+    h = lib().orc_linear_hasher_queue_section  # the pops of the messages as Poseidon2 rows (the queue section)
+    h.restype = C.c_int
+    head = np.ascontiguousarray(inst["queue_state"]["head"][0], dtype=np.uint64)
+    rc = h(_p(q) if q.size else None, C.c_size_t(q.size), _p(head), C.c_uint32(cycles), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_linear_hasher_queue_section failed: {rc}")
     return trace, inst, pi
 
 

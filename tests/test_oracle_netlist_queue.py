@@ -33,8 +33,9 @@ def test_section_geometry_keeps_the_reference_capacity(oracle):
         assert g["has"] == 1 and g["rows_per_cycle"] == rows and g["queues"] == 2
         assert g["max_capacity"] >= REFERENCE_CAPACITY[ct], (ct, g)
         assert g["rows_used"] == g["first_row"] + 1 + 10 * rows
-    for ct in (13, 10):
-        assert oracle.nlq_geometry(ct, 10)["has"] == 0
+    g = oracle.nlq_geometry(13, 501)  # L1MessagesHasher: 774 messages = 501 cycles, two pops per cycle
+    assert g["has"] == 1 and g["rows_per_cycle"] == 16 and g["queues"] == 1 and g["max_capacity"] >= 501
+    assert oracle.nlq_geometry(10, 10)["has"] == 0
 
 
 def _case(oracle, ct, cap):
@@ -125,3 +126,30 @@ def test_section_tampering_is_caught(oracle, ct):
         assert n > 0
         n_section = sum(1 for _ in [0] if first[2] >= g["first_row"] or n >= 2)
         assert n_section == 1
+
+
+def test_linear_hasher_pops_every_message(oracle):
+    """type 13: every message of the queue is popped in the cycle that absorbs its first byte; the head runs from the queue's head to
+    the state after the last push; tampering with a popped field, a permutation variable or the chain is caught"""
+    cap = 20
+    cycles = oracle.linear_hasher_cycles(cap)
+    q = synthetic.mixed_log_queue(60, seed=8)[:13]
+    qs = np.zeros(1, oracle.QUEUE_STATE4)
+    qs["head"][0] = [5, 6, 7, 8]  # a queue that something was popped from before
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(q), qs["head"][0])[1]
+    t, inst, pi = oracle.linear_hasher_synthesize(q, qs, cap, 1 << 18)
+    assert oracle.linear_hasher_check(t, cycles) == (0, (0, 0, 0))
+    g = oracle.nlq_geometry(13, cycles)
+    assert t[:4, g["first_row"]].tolist() == [5, 6, 7, 8] and t[4:8, g["first_row"]].tolist() == np.asarray(tails[-1]).tolist()
+    popped = [(c, j) for c in range(cycles) for j in range(2) if t[oracle.nlq_cell(13, cycles, c, j)]]
+    assert len(popped) == q.size and popped[:5] == [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)]  # first bytes 0, 88 | 176, 264 | 352 ...
+    enc = oracle.encode_log_queries(q)
+    for m, (c, j) in enumerate(popped):
+        assert [int(t[oracle.nlq_cell(13, cycles, c, j, -1, 1, k)]) for k in range(20)] == enc[m].tolist()
+    for (col, row), kinds in ((oracle.nlq_cell(13, cycles, 1, 0, -1, 0, 30), (7,)), (oracle.nlq_cell(13, cycles, 1, 0, 2, 0, 50), (8,)),
+                              (oracle.nlq_cell(13, cycles, 2, 0, -1, 2, 1), (2,)), (oracle.nlq_cell(13, cycles, 3, 1), (3, 7)),
+                              (oracle.nlq_cell(13, cycles, 0, 2, k=5), (4,))):
+        bad = t.copy()
+        bad[col, row] += 1
+        n, first = oracle.linear_hasher_check(bad, cycles)
+        assert n > 0 and first[0] in kinds, ((col, row), n, first)

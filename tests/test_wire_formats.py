@@ -35,9 +35,9 @@ def test_layouts_against_reference_hints(tmp_path):
         lay = native.circuit_layout(t)
         assert lay["fits"] and int(lay["region_stride"]) == 0 and int(lay["rows_used"]) + int(lay["nop_rows"]) == 1 << 20
         assert int(lay["rows_used"]) == table[t][2] <= (1 << 20)
-        # the PI row closes the netlist part; types 6, 3 and 5 carry their queue section (Poseidon2 rows of the pops / pushes) below it
-        q_rows = 1 + int(lay["capacity"]) * int(lay["queue_rows_per_cycle"]) if int(lay["queue_rows_per_cycle"]) else 0
-        assert (int(lay["queue_rows_per_cycle"]) > 0) == (t in (6, 3, 5))
+        # the PI row closes the netlist part; types 6, 3, 5 and 13 carry their queue section (Poseidon2 rows of the pops / pushes) below it
+        q_rows = int(lay["rows_used"]) - int(lay["queue_first_row"]) if int(lay["queue_rows_per_cycle"]) else 0
+        assert (int(lay["queue_rows_per_cycle"]) > 0) == (t in (6, 3, 5, 13))
         assert wire.finalization_hint_of_layout(t)["public_inputs"][0][1] == int(lay["rows_used"]) - q_rows - 1
     for t in sorted(synth - {3, 5, 6, 10, 13}):
         name, ref_rows, ours = table[t]
