@@ -243,10 +243,12 @@ def hash_circuits_gpu(local_rank, blk):
     queues = [synthetic.mixed_log_queue(4000, seed=3 + k)[:700] for k in range(8)]
     t = native.Trace(ctx, n_rows, 8, n_cols=native.LH_COLS)
     states = np.zeros(8, native.QUEUE_STATE4)
-    out["linear_hasher"] = dict(timed(8, lambda: ctx.synthesize_linear_hasher_batch(queues, states, 774, t, 0)), capacity=774,
+    qtails = [ctx.queue_push_chain_log(ctx.encode_log_queries(q))[1] for q in queues]  # the queues' states: the sorter that builds a queue holds them
+    out["linear_hasher"] = dict(timed(8, lambda: ctx.synthesize_linear_hasher_batch(queues, states, 774, t, 0, tails=qtails)), capacity=774,
                                 columns=native.LH_COLS, trace_bytes=native.LH_COLS * n_rows * 8,
-                                note="the L1-messages queues of 8 blocks per call (zkw_linear_hasher_synthesize_batch); the sponge of a "
-                                     "queue is serial, ~4.5 ms whatever the batch",
+                                note="the L1-messages queues of 8 blocks per call (zkw_linear_hasher_synthesize_batch_with_tails: the queues' "
+                                     "states come from the sorter that built them, as in zkw_block_synthesize); the sponge of a "
+                                     "queue is serial, ~4.5 ms whatever the batch; single_queue_ms_per_call hashes the queue's states inside the call",
                                 single_queue_ms_per_call=timed(1, lambda: ctx.synthesize_linear_hasher(queues[0], states[:1], 774, t, 0))["ms_per_call"])
     t.free()
     # StorageApplication (type 10): Blake2s Merkle walks, 33 tree queries (8 481 cycles) per instance

@@ -4,9 +4,9 @@
 // Queue arithmetic: circuit_encodings/src/lib.rs:180-203, 391-429; encodings: memory_query.rs:24-118, log_query.rs:102-396,
 // decommittment_request.rs:9-74. Placement is this library's own.
 //
-// Fill (k_nlq_fill): a LANE owns one operation of one cycle (grid: cycles / 64 x operations x instances — a workgroup's lanes run the
-// same operation, so control flow is uniform); the section is region-major (consecutive cycles = consecutive rows), so every store of
-// a wave is one 512-byte row segment. The linked cells are read back from the netlist rows that k_nl_fill wrote earlier on the stream.
+// Fill (k_nlq_fill): a ROW of 16 lanes owns one operation of one cycle and runs its permutations cooperatively (p2::Coop); the four
+// rows of a wave take four consecutive cycles of the same operation (uniform control flow); the section is region-major (consecutive
+// cycles = consecutive rows). The linked cells are read back from the netlist rows that k_nl_fill wrote earlier on the stream.
 #pragma once
 #include "../../include/zkw_netlist_queue.h"
 #include "netlist_kernels.cuh"
@@ -71,32 +71,6 @@ struct NlqCellStore {  // cell k of a block whose first row (within the cycle's 
     }
 };
 
-// the 130 variables of one flattened Poseidon2 gate (oracle/ram_circuit.c orc_poseidon2_flattened), stored as they are produced
-__device__ __forceinline__ void nlq_fill_p2(const NlqCellStore& st, u32 r0, u64 s[12]) {
-    u32 pos = 0;
-#pragma unroll
-    for (int k = 0; k < 12; k++) st.at(r0, pos++) = gl::canon(s[k]);
-    p2::external(s);
-    int r = 0;
-    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
-        p2::full_round(s, r);
-#pragma unroll
-        for (int j = 0; j < 12; j++) st.at(r0, pos + j) = gl::canon(s[j]);
-        pos += 12;
-    }
-    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
-        s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
-        st.at(r0, pos++) = gl::canon(s[0]);
-        p2::internal(s);
-    }
-    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) {
-        p2::full_round(s, r);
-#pragma unroll
-        for (int j = 0; j < 12; j++) { s[j] = gl::canon(s[j]); st.at(r0, pos + j) = s[j]; }
-        pos += 12;
-    }
-}
-
 __device__ __forceinline__ u64 nlq_linked_value(const nl_spec& S, const NlqFreeHome* __restrict__ fh, const u64* __restrict__ trace, size_t n_rows, u32 capacity,
                                                 u32 c, const nlq_op& op, u32 cell) {
     uint32_t next = 0;
@@ -104,15 +78,6 @@ __device__ __forceinline__ u64 nlq_linked_value(const nl_spec& S, const NlqFreeH
     if (next) return nl_home_cell(S, trace, n_rows, capacity, c + 1, 0, ref);
     const NlqFreeHome h = fh[ref - NL_REF_FREE];
     return NLQ_TR(h.col, (size_t)c * S.rows_per_cycle + h.row);
-}
-
-__device__ __forceinline__ void nlq_state_before(const NlqQueueIn& q, u32 w, u64 idx, u64 out[12]) {
-#pragma unroll
-    for (int k = 0; k < 12; k++) out[k] = 0;
-    const u64* src = idx ? q.states + (idx - 1) * w : q.init;
-#pragma unroll
-    for (int k = 0; k < 12; k++)
-        if ((u32)k < w) out[k] = src[k];
 }
 
 // enc element e of an operation from a cell reader
@@ -127,66 +92,105 @@ __device__ __forceinline__ u64 nlq_enc_value(u32 item, u32 e, F&& cell) {
     return gl::canon(acc);
 }
 
-// grid (ceil(capacity / 64), n_ops, instances)
+// One flattened Poseidon2 gate by the 16 lanes of a row (p2::Coop, the form of the queue-chain kernels: lane g holds element g, the
+// linear layers cross lanes by DPP): every lane stores its element after each full round, lane 0 the S-box output of each partial
+// round — the 130 variables in the order of orc_poseidon2_flattened. x: this lane's input (0 in lanes 12..15); returns its output.
+template <class Put>
+__device__ __forceinline__ u64 nlq_coop_p2(const p2::Coop& co, u64 x, u32 g, Put&& put) {
+    if (co.active) put(g, gl::canon(x));
+    x = co.external(x);
+#pragma unroll
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
+        x = co.external(p2::pow7_sched(p2::add_rc_sched(x, co.rc_full[k])));
+        if (co.active) put(12 * (k + 1) + g, gl::canon(x));
+    }
+    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
+        const u64 rc = p2::c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];
+        const u64 sx = p2::pow7_sched(p2::add_rc_sched(x, rc));
+        if (co.first) put(12 * (P2_HALF_FULL_ROUNDS + 1) + k, gl::canon(sx));
+        x = co.internal(co.first ? sx : x);
+    }
+#pragma unroll
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
+        x = co.external(p2::pow7_sched(p2::add_rc_sched(x, co.rc_full[P2_HALF_FULL_ROUNDS + k])));
+        if (co.active) put(12 * (P2_HALF_FULL_ROUNDS + 1) + P2_PARTIAL_ROUNDS + 12 * k + g, gl::canon(x));
+    }
+    return gl::canon(x);
+}
+
+// grid (ceil(capacity / 4), n_ops, instances), 64 lanes: a ROW of 16 lanes owns one operation of one cycle, the four rows of a wave
+// four consecutive cycles of the same operation (uniform control flow; a store instruction writes 32-byte segments of <= 16 columns).
+// Lane g computes what it needs itself — its cells of the ENC block (stride 16), the encoding elements its permutation inputs take —
+// from the item record / the linked netlist cells; only the permutation crosses lanes. (The first version gave an operation to a LANE:
+// its three dependent lane-serial permutations of ~65 us each were the whole kernel time.)
 static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, const NlqFreeHome* __restrict__ lh, nlq_desc d, const NlqJob* __restrict__ jobs,
                                                         u32 capacity, size_t n_rows) {
     const nl_spec& S = devp->s;
     const NlqJob& job = jobs[blockIdx.z];
-    const u32 c = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
-    if (c >= capacity) return;
+    const u32 g = threadIdx.x & 15, c_raw = blockIdx.x * 4 + (threadIdx.x >> 4), j = blockIdx.y;
+    const bool valid = c_raw < capacity;
+    const u32 c = valid ? c_raw : capacity - 1;  // a row beyond the capacity recomputes the last cycle and stores nothing (DPP wants whole rows)
     u64* trace = job.trace;
+    p2::Coop co;
+    co.init((int)g);
     const nlq_op op = d.ops[j];
     const nlq_feed f = job.feed[(size_t)c * d.n_ops + j];
     const NlqQueueIn& Q = job.queues[op.queue];
     const u32 G = S.g, w = nlq_kind_width(op.kind), ncomp = nlq_item_comps(op.item), nenc = nlq_item_enc(op.item), r0 = nlq_op_row0(&d, G, j);
     const NlqCellStore st{trace, n_rows, (size_t)NLQ_BASE(&S, capacity) + 1 + c, capacity, G};
     const void* rec = f.en ? static_cast<const char*>(Q.items) + (size_t)f.idx * nlq_item_bytes(op.item) : nullptr;
-    // components (the cells are re-read for the encodings: they are this lane's own stores, L2-resident)
-    st.at(r0, 0) = f.en ? 1 : 0;
-    for (u32 k = 1; k < ncomp; k++) {
-        if (!nlq_comp_linked(&op, k)) { st.at(r0, k) = nlq_item_component(op.item, rec, k); continue; }
-        const NlqFreeHome h = lh[j * 64 + (k - NLQ_MEM_NIBBLE0)];  // (the source cell inside this cycle, where the host could resolve it)
-        st.at(r0, k) = h.row != 0xFFFF ? NLQ_TR(h.col, (size_t)c * S.rows_per_cycle + h.row) : nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k);
-    }
-    for (u32 e = 0; e < nenc; e++)
-        st.at(r0, ncomp + e) = nlq_enc_value(op.item, e, [&](u32 cell) { return st.at(r0, cell); });
-    u64 old[12];
-    nlq_state_before(Q, w, f.idx, old);
-    u64 s[12];  // (the encodings are read back from the lane's own cells: no per-lane array with run-time indices, i.e. no scratch)
+    // the linked cells of the operation (64 nibbles / 32 bytes of a memory word's value) are fetched once, four independent loads per
+    // lane, and staged in LDS: the encodings read every one of them, and a dependent table + cell load per term was the kernel's time
+    __shared__ u64 sh_link[4][64];
+    u64* my_link = sh_link[threadIdx.x >> 4];
+    if (op.link != NLQ_LINK_NONE) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = st.at(r0, ncomp + k);
-    if (op.kind != NLQ_POP4) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) s[8 + k] = old[8 + k];
-        nlq_fill_p2(st, nlq_p2_row0(&d, G, j, 0), s);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) s[8 + k] = 0;
-        nlq_fill_p2(st, nlq_p2_row0(&d, G, j, 0), s);
-#pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = st.at(r0, ncomp + 8 + k);
-        nlq_fill_p2(st, nlq_p2_row0(&d, G, j, 1), s);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { s[k] = st.at(r0, ncomp + 16 + k); s[4 + k] = old[k]; }
-        nlq_fill_p2(st, nlq_p2_row0(&d, G, j, 2), s);
-    }
-#pragma unroll
-    for (int k = 0; k < 12; k++)
-        if ((u32)k < w) {
-            st.at(r0, ncomp + nenc + k) = old[k];
-            st.at(r0, ncomp + nenc + w + k) = f.en ? s[k] : old[k];
+        for (u32 q = 0; q < 4; q++) {
+            const u32 k = NLQ_MEM_NIBBLE0 + g + 16 * q;
+            if (!nlq_comp_linked(&op, k)) continue;
+            const NlqFreeHome h = lh[j * 64 + (k - NLQ_MEM_NIBBLE0)];  // (the source cell inside this cycle, where the host could resolve it)
+            my_link[k - NLQ_MEM_NIBBLE0] = h.row != 0xFFFF ? NLQ_TR(h.col, (size_t)c * S.rows_per_cycle + h.row) : nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k);
         }
+    }
+    __syncthreads();
+    auto comp = [&](u32 k) -> u64 {  // cell k >= 1 of the ENC block: a field of the item, or the netlist cell it copies
+        return nlq_comp_linked(&op, k) ? my_link[k - NLQ_MEM_NIBBLE0] : nlq_item_component(op.item, rec, k);
+    };
+    auto enc_val = [&](u32 e) -> u64 { return e < nenc ? nlq_enc_value(op.item, e, comp) : 0; };
+    for (u32 k = g; k < ncomp; k += 16) {
+        const u64 v = k ? comp(k) : (u64)(f.en ? 1 : 0);
+        if (valid) st.at(r0, k) = v;
+    }
+    const u64 e_lo = enc_val(g), e_hi = enc_val(16 + g);  // enc[g], enc[16 + g]
+    if (valid && g < nenc) st.at(r0, ncomp + g) = e_lo;
+    if (valid && 16 + g < nenc) st.at(r0, ncomp + 16 + g) = e_hi;
+    const u64* src = f.idx ? Q.states + (f.idx - 1) * w : Q.init;
+    const u64 old = g < w ? src[g] : 0;
+    auto put_at = [&](u32 pr0) { return [&st, pr0, valid](u32 k, u64 v) { if (valid) st.at(pr0, k) = v; }; };
+    u64 out;
+    if (op.kind != NLQ_POP4) {  // enc[0..8] ++ old[8..12]
+        out = nlq_coop_p2(co, g < 8 ? e_lo : g < 12 ? old : 0, g, put_at(nlq_p2_row0(&d, G, j, 0)));
+    } else {  // enc[0..8] ++ 0000 | enc[8..16] ++ capacity | enc[16..20] ++ old[0..4] ++ capacity
+        out = nlq_coop_p2(co, g < 8 ? e_lo : 0, g, put_at(nlq_p2_row0(&d, G, j, 0)));
+        const u64 e_mid = enc_val(8 + g);
+        out = nlq_coop_p2(co, g < 8 ? e_mid : g < 12 ? out : 0, g, put_at(nlq_p2_row0(&d, G, j, 1)));
+        const u64 old_up = (u64)__shfl((unsigned long long)old, (int)((threadIdx.x & 48) | ((g - 4) & 15)), 64);  // lane 4 + k takes old[k]
+        out = nlq_coop_p2(co, g < 4 ? e_hi : g < 8 ? old_up : g < 12 ? out : 0, g, put_at(nlq_p2_row0(&d, G, j, 2)));
+    }
+    const u64 nw = f.en ? out : old;
+    if (valid && g < w) {
+        st.at(r0, ncomp + nenc + g) = old;
+        st.at(r0, ncomp + nenc + w + g) = nw;
+    }
     // QBND: the queue states before cycle 0 (written by the first operation on the queue) and after the last cycle (by the last)
     const size_t q0 = NLQ_BASE(&S, capacity);
     bool first = true, last = true;
     for (u32 i = 0; i < d.n_ops; i++)
         if (d.ops[i].queue == op.queue) { if (i < j) first = false; if (i > j) last = false; }
-#pragma unroll
-    for (int k = 0; k < 12; k++)
-        if ((u32)k < w) {
-            if (c == 0 && first) NLQ_TR(nlq_bnd_col(&d, op.queue, 0, k), q0) = old[k];
-            if (c + 1 == capacity && last) NLQ_TR(nlq_bnd_col(&d, op.queue, 1, k), q0) = f.en ? s[k] : old[k];
-        }
+    if (valid && g < w) {
+        if (c == 0 && first) NLQ_TR(nlq_bnd_col(&d, op.queue, 0, g), q0) = old;
+        if (c + 1 == capacity && last) NLQ_TR(nlq_bnd_col(&d, op.queue, 1, g), q0) = nw;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ checker (codes of oracle/netlist_queue.c)

@@ -1104,7 +1104,7 @@ int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std
     const unsigned cb = (capacity + 63) / 64;
     { Prof _p(ctx, "k_nlq_feed"); hipLaunchKernelGGL(k_nlq_feed, dim3(cb, (unsigned)ni), dim3(64), 0, ctx->stream, circuit_type, d_fj, capacity, d->n_ops); }
     ZKW_TRY(launch_check("k_nlq_feed"));
-    { Prof _p(ctx, "k_nlq_fill"); hipLaunchKernelGGL(k_nlq_fill, dim3(cb, d->n_ops, (unsigned)ni), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, nc->link_home, *d, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_nlq_fill"); hipLaunchKernelGGL(k_nlq_fill, dim3((capacity + 3) / 4, d->n_ops, (unsigned)ni), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, nc->link_home, *d, d_jobs, capacity, n_rows); }
     return launch_check("k_nlq_fill");
 }
 

@@ -1175,8 +1175,10 @@ def _ctx_synthesize_linear_hasher(self, messages, queue_state, capacity, trace, 
     return rec, pi
 
 
-def _ctx_synthesize_linear_hasher_batch(self, queues, queue_states, capacity, trace, first_slot=0):
-    """zkw_linear_hasher_synthesize_batch: the L1-messages queues of several blocks in one call (queue b -> slot first_slot + b).
+def _ctx_synthesize_linear_hasher_batch(self, queues, queue_states, capacity, trace, first_slot=0, tails=None):
+    """zkw_linear_hasher_synthesize_batch[_with_tails]: the L1-messages queues of several blocks in one call (queue b -> slot
+    first_slot + b). tails: per queue the states [n, 4] after each message's push (what the sorter that built the queue holds; the
+    pops of the trace's queue section run through them) — None: hashed inside the call, one serial chain per queue.
     Returns (records, public inputs [n, 4])."""
     qs = [np.ascontiguousarray(q, dtype=LOG_QUERY) for q in queues]
     off = np.zeros(len(qs) + 1, np.uint64)
@@ -1185,6 +1187,12 @@ def _ctx_synthesize_linear_hasher_batch(self, queues, queue_states, capacity, tr
     st = np.ascontiguousarray(queue_states, dtype=QUEUE_STATE4).reshape(len(qs))
     rec = np.zeros(len(qs), LINEAR_HASHER_INSTANCE)
     pi = np.zeros((len(qs), 4), np.uint64)
+    if tails is not None:
+        ft = (np.concatenate([np.ascontiguousarray(t_, dtype=np.uint64).reshape(-1, 4) for t_ in tails]) if flat.size else np.zeros((0, 4), np.uint64))
+        assert ft.shape[0] == flat.size
+        _check(load().zkw_linear_hasher_synthesize_batch_with_tails(self.handle, _np_ptr(flat) if flat.size else None, _np_ptr(off), len(qs), _np_ptr(st),
+                                                                    _np_ptr(ft) if flat.size else None, capacity, trace.handle, first_slot, _np_ptr(rec), _np_ptr(pi)))
+        return rec, pi
     _check(load().zkw_linear_hasher_synthesize_batch(self.handle, _np_ptr(flat) if flat.size else None, _np_ptr(off), len(qs), _np_ptr(st),
                                                      capacity, trace.handle, first_slot, _np_ptr(rec), _np_ptr(pi)))
     return rec, pi

@@ -124,6 +124,18 @@ def test_linear_hasher_batch_equals_single_calls(ctx, oracle):
         assert ctx.check_if_satisfied_linear_hasher(t, 1 + k, cap) == (0, (0, 0, 0))
     with pytest.raises(native.ZkwError):
         ctx.synthesize_linear_hasher_batch(queues, states, cap, t, 2)  # one slot short
+    # the queues' states handed in (zkw_linear_hasher_synthesize_batch_with_tails, what zkw_block_synthesize does): the same traces;
+    # a non-empty queue head is where the pops of the queue section start; wrong states are a broken chain, which the checker reports
+    states["head"][2] = [9, 8, 7, 6]
+    tails = [oracle.queue_push_chain_log(oracle.encode_log_queries(q), states["head"][k])[1] for k, q in enumerate(queues)]
+    ctx.synthesize_linear_hasher_batch(queues, states, cap, t, 1, tails=tails)
+    for k, q in enumerate(queues):
+        exp, _orec, _opi = oracle.linear_hasher_synthesize(q, states[k:k + 1], cap, N_ROWS)
+        assert np.array_equal(t.get(1 + k), exp), k
+    bad = [x.copy() for x in tails]
+    bad[0][3, 1] += 1
+    ctx.synthesize_linear_hasher_batch(queues, states, cap, t, 1, tails=bad)
+    assert ctx.check_if_satisfied_linear_hasher(t, 1, cap)[0] > 0 and ctx.check_if_satisfied_linear_hasher(t, 2, cap)[0] == 0
     t.free()
 
 

