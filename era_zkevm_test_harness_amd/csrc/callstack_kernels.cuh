@@ -11,6 +11,7 @@
 // a stable sort of the pushes by depth + binary searches, then one launch per depth level (4 permutations per
 // node), then a gather per operation.
 #pragma once
+#include "scan_kernels.cuh"
 #include "../../include/zkw_types.h"
 #include "poseidon2.cuh"
 
@@ -46,44 +47,27 @@ static __global__ __launch_bounds__(64) void k_encode_callstack(const zkw_callst
     for (int k = 0; k < 32; k++) enc[32 * i + k] = o[k];
 }
 
-// meta[0] = number of pushes, meta[1] = maximum depth, meta[2] = error (1: pop from the empty stack)
-// One workgroup of 1024 lanes walks the operations in tiles, carrying (depth, push count) across tiles.
-static __global__ __launch_bounds__(1024) void k_stack_depth(const uint8_t* __restrict__ is_push, size_t n, u32* __restrict__ depth_after,
-                                                      u32* __restrict__ push_rank, u32* __restrict__ meta) {
-    __shared__ int s_d[1024];
-    __shared__ u32 s_p[1024];
-    __shared__ int carry_d;
-    __shared__ u32 carry_p, max_d, err;
-    const int t = threadIdx.x;
-    if (t == 0) { carry_d = 0; carry_p = 0; max_d = 0; err = 0; }
-    __syncthreads();
-    for (size_t base = 0; base < n; base += 1024) {
-        const size_t i = base + t;
-        const int push = i < n ? (is_push[i] ? 1 : 0) : 0;
-        const int delta = i < n ? (push ? 1 : -1) : 0;
-        s_d[t] = delta;
-        s_p[t] = (u32)push;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-            const int vd = t >= off ? s_d[t - off] : 0;
-            const u32 vp = t >= off ? s_p[t - off] : 0;
-            __syncthreads();
-            s_d[t] += vd;
-            s_p[t] += vp;
-            __syncthreads();
-        }
-        if (i < n) {
-            const int d = carry_d + s_d[t];
-            if (d < 0) atomicOr(&err, 1u);
-            depth_after[i] = (u32)d;
-            push_rank[i] = carry_p + s_p[t] - (u32)push;  // pushes strictly before i
-            if (d > 0) atomicMax(&max_d, (u32)d);
-        }
-        __syncthreads();
-        if (t == 0) { carry_d += s_d[1023]; carry_p += s_p[1023]; }
-        __syncthreads();
+// The depth after every operation and the number of pushes before it are two prefix sums over the operations (+1 / -1 per push / pop,
+// 1 per push): sum_prefix<2> (scan_kernels.cuh, tiled: any number of operations), then one lane per operation.
+struct StackDelta {
+    const uint8_t* is_push;
+    __device__ void operator()(size_t i, u64 v[2]) const {
+        const bool push = is_push[i] != 0;
+        v[0] = push ? 1ull : ~0ull;  // -1 in wrap-around arithmetic
+        v[1] = push ? 1ull : 0ull;
     }
-    if (t == 0) { meta[0] = carry_p; meta[1] = max_d; meta[2] = err; }
+};
+// meta[0] = number of pushes, meta[1] = maximum depth, meta[2] = error (1: pop from the empty stack); meta zeroed by the caller
+static __global__ __launch_bounds__(256) void k_stack_depth(const uint8_t* __restrict__ is_push, size_t n, const u64* __restrict__ prefix /* [2][n + 1] */,
+                                                            u32* __restrict__ depth_after, u32* __restrict__ push_rank, u32* __restrict__ meta) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) meta[0] = (u32)prefix[(n + 1) + n];
+    if (i >= n) return;
+    const long long d = (long long)prefix[i] + (is_push[i] ? 1 : -1);
+    if (d < 0) atomicOr(&meta[2], 1u);
+    depth_after[i] = (u32)d;
+    push_rank[i] = (u32)prefix[(n + 1) + i];  // pushes strictly before i
+    if (d > 0) atomicMax(&meta[1], (u32)d);
 }
 
 static __global__ __launch_bounds__(256) void k_stack_push_keys(const uint8_t* __restrict__ is_push, size_t n, const u32* __restrict__ depth_after,

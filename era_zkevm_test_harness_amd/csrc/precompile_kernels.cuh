@@ -13,6 +13,7 @@
 // snapshots and queue states into the instance record (k_precompile_instances).
 #pragma once
 #include "decommitter_kernels.cuh"
+#include "scan_kernels.cuh"
 
 namespace zkw {
 
@@ -45,47 +46,17 @@ __device__ __forceinline__ void precompile_request_shape(int kind, const zkw_log
     }
 }
 
-// offsets[0..3][n+1]: exclusive prefix sums of rounds, queries, reads. meta[0..3] = totals, meta[3] = error
-// (a request without rounds). One workgroup walks the requests in tiles of 1024.
-static __global__ __launch_bounds__(1024) void k_precompile_counts(int kind, const zkw_log_query* __restrict__ requests, size_t n,
-                                                            u64* __restrict__ round_off, u64* __restrict__ query_off,
-                                                            u64* __restrict__ read_off, u64* __restrict__ meta) {
-    __shared__ u64 s[3][1024];
-    __shared__ u64 carry[3];
-    __shared__ u32 err;
-    const int t = threadIdx.x;
-    if (t == 0) { carry[0] = carry[1] = carry[2] = 0; err = 0; }
-    __syncthreads();
-    for (size_t base = 0; base < n; base += 1024) {
-        const size_t i = base + t;
-        u64 v[3] = {0, 0, 0};
-        if (i < n) {
-            precompile_request_shape(kind, requests[i], v[0], v[1], v[2]);
-            if (v[0] == 0 || v[0] > (1ull << 32)) atomicOr(&err, 1u);
-        }
-        for (int c = 0; c < 3; c++) s[c][t] = v[c];
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            u64 a[3];
-            for (int c = 0; c < 3; c++) a[c] = t >= off ? s[c][t - off] : 0;
-            __syncthreads();
-            for (int c = 0; c < 3; c++) s[c][t] += a[c];
-            __syncthreads();
-        }
-        if (i < n) {
-            round_off[i] = carry[0] + s[0][t] - v[0];
-            query_off[i] = carry[1] + s[1][t] - v[1];
-            read_off[i] = carry[2] + s[2][t] - v[2];
-        }
-        __syncthreads();
-        if (t == 0) for (int c = 0; c < 3; c++) carry[c] += s[c][1023];
-        __syncthreads();
+// rounds / queries / reads of request i, for the tiled prefix sums (sum_prefix<3>, scan_kernels.cuh) that place every request in the
+// global round / query / read sequences; *err |= 1 for a request without rounds
+struct PrecompileShape {
+    int kind;
+    const zkw_log_query* requests;
+    u32* err;
+    __device__ void operator()(size_t i, u64 v[3]) const {
+        precompile_request_shape(kind, requests[i], v[0], v[1], v[2]);
+        if (v[0] == 0 || v[0] > (1ull << 32)) atomicOr(err, 1u);
     }
-    if (t == 0) {
-        round_off[n] = carry[0]; query_off[n] = carry[1]; read_off[n] = carry[2];
-        meta[0] = carry[0]; meta[1] = carry[1]; meta[2] = carry[2]; meta[3] = err;
-    }
-}
+};
 
 // the internal part of the FSM at an instance boundary + how far the global sequences have advanced
 struct PrecompileSnap {

@@ -1507,7 +1507,12 @@ extern "C" int zkw_callstack_simulate(zkw_ctx* ctx, const uint8_t* is_push, size
     ZKW_TRY(ctx->scratch_t<u32>("st_node", n_ops, &d_node));
     ZKW_TRY(ctx->scratch_t<u64>("st_rounds", n_ops * 48, &d_rounds));
     ZKW_TRY(ctx->scratch("st_tmp", tmp_bytes + 256, &tmp));
-    { Prof _p(ctx, "k_stack_depth"); hipLaunchKernelGGL(k_stack_depth, dim3(1), dim3(1024), 0, ctx->stream, d_ops, n_ops, d_depth, d_rank, d_meta); }
+    u64 *d_prefix = nullptr, *d_totals = nullptr;
+    ZKW_TRY(ctx->scratch_t<u64>("st_prefix", 2 * (n_ops + 1), &d_prefix));
+    ZKW_TRY(ctx->scratch_t<u64>("st_totals", 2, &d_totals));
+    HIP_TRY(hipMemsetAsync(d_meta, 0, 4 * sizeof(u32), ctx->stream));
+    ZKW_TRY((sum_prefix<2>(ctx, "k_stack_prefix", StackDelta{d_ops}, n_ops, d_prefix, d_totals)));
+    { Prof _p(ctx, "k_stack_depth"); hipLaunchKernelGGL(k_stack_depth, dim3(blocks_for(n_ops, 256)), dim3(256), 0, ctx->stream, d_ops, n_ops, d_prefix, d_depth, d_rank, d_meta); }
     ZKW_TRY(launch_check("k_stack_depth"));
     u32 meta[3];
     ZKW_TRY(ctx->read_small(meta, d_meta, sizeof meta));

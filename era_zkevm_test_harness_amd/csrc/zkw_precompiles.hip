@@ -277,12 +277,12 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
         ZKW_TRY(ctx->in("pc_req", requests, n_requests, &d_req));
         ZKW_TRY(ctx->in("pc_rt", request_tails, n_requests * 4, &d_rt));
         if (n_queries) ZKW_TRY(ctx->in("pc_mq", mem_queries, n_queries, &d_mq));
-        ZKW_TRY(ctx->scratch_t<u64>("pc_roff", n_requests + 1, &d_roff));
-        ZKW_TRY(ctx->scratch_t<u64>("pc_qoff", n_requests + 1, &d_qoff));
-        ZKW_TRY(ctx->scratch_t<u64>("pc_rdoff", n_requests + 1, &d_rdoff));
+        u64* d_off = nullptr;  // [3][n_requests + 1]: exclusive prefix sums of rounds, queries, reads (totals at [n_requests])
+        ZKW_TRY(ctx->scratch_t<u64>("pc_off", 3 * (n_requests + 1), &d_off));
+        d_roff = d_off; d_qoff = d_off + (n_requests + 1); d_rdoff = d_off + 2 * (n_requests + 1);
         ZKW_TRY(ctx->scratch_t<u64>("pc_meta", 4, &d_meta));
-        { Prof _p(ctx, "k_precompile_counts"); hipLaunchKernelGGL(k_precompile_counts, dim3(1), dim3(1024), 0, ctx->stream, kind, d_req, n_requests, d_roff, d_qoff, d_rdoff, d_meta); }
-        ZKW_TRY(launch_check("k_precompile_counts"));
+        HIP_TRY(hipMemsetAsync(d_meta, 0, 4 * sizeof(u64), ctx->stream));
+        ZKW_TRY((sum_prefix<3>(ctx, "k_precompile_counts", PrecompileShape{kind, d_req, reinterpret_cast<u32*>(d_meta + 3)}, n_requests, d_off, d_meta)));
         ZKW_TRY(ctx->read_small(meta, d_meta, sizeof meta));
         if (meta[3]) return fail(ZKW_ERR_INVALID, "a precompile request without rounds (the first round carries `new_request`)");
         if (meta[1] != n_queries)

@@ -488,7 +488,7 @@ def test_callstack_pop_from_empty(ctx):
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
-@pytest.mark.parametrize("n_req,capacity", [(0, 5), (1, 1), (40, 3), (40, 7), (300, 293), (300, 100000)])
+@pytest.mark.parametrize("n_req,capacity", [(0, 5), (1, 1), (40, 3), (40, 7), (300, 293), (300, 100000), (2500, 400)])  # (2500 requests: three tiles of the prefix sums)
 def test_precompile_builders(ctx, oracle, kind, n_req, capacity):
     from era_zkevm_test_harness_amd import native
 
