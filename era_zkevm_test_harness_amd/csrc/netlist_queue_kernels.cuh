@@ -71,13 +71,15 @@ struct NlqCellStore {  // cell k of a block whose first row (within the cycle's 
     }
 };
 
+// the netlist cell a linked component copies; has = false when the cell has no link in this cycle
 __device__ __forceinline__ u64 nlq_linked_value(const nl_spec& S, const NlqFreeHome* __restrict__ fh, const u64* __restrict__ trace, size_t n_rows, u32 capacity,
-                                                u32 c, const nlq_op& op, u32 cell) {
-    uint32_t next = 0;
-    const u32 ref = nlq_link_ref(&op, cell, &next);
-    if (next) return nl_home_cell(S, trace, n_rows, capacity, c + 1, 0, ref);
+                                                u32 c, const nlq_op& op, u32 cell, bool& has) {
+    uint32_t cyc = 0, ref = 0;
+    has = nlq_link_target(&op, c, capacity, cell, &cyc, &ref) != 0;
+    if (!has) return 0;
+    if (ref >= NL_REF_CYC && ref < NL_REF_FREE) return nl_home_cell(S, trace, n_rows, capacity, cyc, 0, ref);
     const NlqFreeHome h = fh[ref - NL_REF_FREE];
-    return NLQ_TR(h.col, (size_t)c * S.rows_per_cycle + h.row);
+    return NLQ_TR(h.col, (size_t)cyc * S.rows_per_cycle + h.row);
 }
 
 // enc element e of an operation from a cell reader
@@ -141,20 +143,24 @@ static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict_
     const void* rec = f.en ? static_cast<const char*>(Q.items) + (size_t)f.idx * nlq_item_bytes(op.item) : nullptr;
     // the linked cells of the operation (64 nibbles / 32 bytes of a memory word's value) are fetched once, four independent loads per
     // lane, and staged in LDS: the encodings read every one of them, and a dependent table + cell load per term was the kernel's time
-    __shared__ u64 sh_link[4][64];
+    __shared__ u64 sh_link[4][80];  // by cell index (the linkable cells of every item lie below 80)
     u64* my_link = sh_link[threadIdx.x >> 4];
     if (op.link != NLQ_LINK_NONE) {
 #pragma unroll
-        for (u32 q = 0; q < 4; q++) {
-            const u32 k = NLQ_MEM_NIBBLE0 + g + 16 * q;
-            if (!nlq_comp_linked(&op, k)) continue;
-            const NlqFreeHome h = lh[j * 64 + (k - NLQ_MEM_NIBBLE0)];  // (the source cell inside this cycle, where the host could resolve it)
-            my_link[k - NLQ_MEM_NIBBLE0] = h.row != 0xFFFF ? NLQ_TR(h.col, (size_t)c * S.rows_per_cycle + h.row) : nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k);
+        for (u32 q = 0; q < 5; q++) {
+            const u32 k = g + 16 * q;
+            if (k == 0 || k >= ncomp || !nlq_comp_linked(&op, k)) continue;
+            // (the source cell inside this cycle, where the host could resolve it: the links that do not depend on the cycle)
+            const NlqFreeHome h = k >= NLQ_MEM_NIBBLE0 && k < NLQ_MEM_NIBBLE0 + 64 ? lh[j * 64 + (k - NLQ_MEM_NIBBLE0)] : NlqFreeHome{0xFFFF, 0xFFFF};
+            if (h.row != 0xFFFF) { my_link[k] = NLQ_TR(h.col, (size_t)c * S.rows_per_cycle + h.row); continue; }
+            bool has = false;
+            const u64 v = nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k, has);
+            my_link[k] = has ? v : nlq_item_component(op.item, rec, k);  // no link in this cycle: the item's own field
         }
     }
     __syncthreads();
     auto comp = [&](u32 k) -> u64 {  // cell k >= 1 of the ENC block: a field of the item, or the netlist cell it copies
-        return nlq_comp_linked(&op, k) ? my_link[k - NLQ_MEM_NIBBLE0] : nlq_item_component(op.item, rec, k);
+        return nlq_comp_linked(&op, k) ? my_link[k] : nlq_item_component(op.item, rec, k);
     };
     auto enc_val = [&](u32 e) -> u64 { return e < nenc ? nlq_enc_value(op.item, e, comp) : 0; };
     for (u32 k = g; k < ncomp; k += 16) {
@@ -239,7 +245,11 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
     if (op.en_rule == NLQ_EN_ACTIVE && gl::canon(en) != gl::canon(gl::sub(1, gl::canon(NLQ_TR(NL_HDR_IDLE, hdr_row))))) flag_bad(res, 3, 0x100 + j, row_e);
     bool ok = true;
     for (u32 k = 1; k < ncomp; k++)
-        if (nlq_comp_linked(&op, k) && cell(k) != nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k)) ok = false;
+    {
+        bool has = false;
+        const u64 v = nlq_linked_value(S, fh, trace, n_rows, capacity, c, op, k, has);
+        if (has && cell(k) != v) ok = false;
+    }
     if (!ok) flag_bad(res, 2, j, row_e);
     // (no per-lane arrays with run-time indices — they would live in scratch memory: every value is read from its cell where it is used)
     for (u32 e = 0; e < nenc; e++)

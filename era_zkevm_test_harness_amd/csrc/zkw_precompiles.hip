@@ -928,7 +928,7 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
         const nl_step_type& LT = hs->step_types[ls.type];
         for (u32 j = 0; j < qd->n_ops; j++)
             for (u32 cell = NLQ_MEM_NIBBLE0; cell < NLQ_MEM_NIBBLE0 + 64; cell++) {
-                if (!nlq_comp_linked(&qd->ops[j], cell)) continue;
+                if (!nlq_comp_linked(&qd->ops[j], cell) || qd->ops[j].link == NLQ_LINK_LH_MESSAGE) continue;  // (links that depend on the cycle: the long way)
                 uint32_t next = 0;
                 const u32 ref = nlq_link_ref(&qd->ops[j], cell, &next);
                 NlqFreeHome& o = lh[(size_t)j * 64 + (cell - NLQ_MEM_NIBBLE0)];

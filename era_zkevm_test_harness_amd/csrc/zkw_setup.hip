@@ -283,12 +283,11 @@ extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacit
                     const nlq_op& op = qd->ops[j];
                     const uint32_t w = nlq_kind_width(op.kind), r0 = nlq_op_row0(qd, G, j), e0 = nlq_enc0(&op), o0 = nlq_old0(&op);
                     for (uint32_t k = 1; k < nlq_item_comps(op.item); k++) {
-                        if (!nlq_comp_linked(&op, k)) continue;
-                        uint32_t next = 0;
-                        const uint32_t ref = nlq_link_ref(&op, k, &next);
+                        uint32_t cyc = 0, ref = 0;
+                        if (!nlq_link_target(&op, c, cycles, k, &cyc, &ref)) continue;
                         qc(c, r0, k, &ca, &ra);
-                        if (next) { if (home(c + 1, 0, ref, &hc, &hr)) unite(ca, ra, hc, hr); }
-                        else if (free_home(ref - NL_REF_FREE, &cb, &rb)) unite(ca, ra, cb, (uint64_t)c * ns->rows_per_cycle + rb);
+                        if (ref >= NL_REF_CYC && ref < NL_REF_FREE) { if (home(cyc, 0, ref, &hc, &hr)) unite(ca, ra, hc, hr); }
+                        else if (free_home(ref - NL_REF_FREE, &cb, &rb)) unite(ca, ra, cb, (uint64_t)cyc * ns->rows_per_cycle + rb);
                     }
                     for (uint32_t p = 0; p < nlq_kind_perms(op.kind); p++) {
                         const uint32_t pr0 = nlq_p2_row0(qd, G, j, p);

@@ -44,7 +44,12 @@ enum { NLQ_EN_FREE = 0, NLQ_EN_RESET = 1, NLQ_EN_ACTIVE = 2 };
    SHA_BLOCK + arg k: the cycle's message block, memory word k (U256::to_big_endian = block bytes 32k..32k+31; FREE element 2b + hi);
    SHA_DIGEST: the chaining state after the cycle (limb j of the written U256 = H[7 - j]) */
 enum { NLQ_LINK_NONE = 0, NLQ_LINK_SHA_BLOCK = 1, NLQ_LINK_SHA_DIGEST = 2,
-       NLQ_LINK_KECCAK_DIGEST = 3 /* MEM8: value byte x (little end first) = byte 31 - x of the sponge state after the cycle (the first four lanes, U256::from_big_endian) */ };
+       NLQ_LINK_KECCAK_DIGEST = 3 /* MEM8: value byte x (little end first) = byte 31 - x of the sponge state after the cycle (the first four lanes, U256::from_big_endian) */,
+       NLQ_LINK_LH_MESSAGE = 4 /* LOG: the byte-valued fields of a popped L2 -> L1 message are copies of the bytes the sponge absorbs: byte k of the
+          88-byte serialisation (log_query.rs:503-534: shard | is_service | tx_number | address | key | written_value, big end first) of message
+          m is byte 88 m + k of the hashed stream = FREE element (88 m + k) % 136 of cycle (88 m + k) / 136 — the cycle the message is popped in
+          or the next one. Linked: shard_id, is_service, the 20 address bytes, the 32 key bytes (the fields that ARE bytes in the encoding);
+          tx_number and written_value are limbs there: placed. */ };
 
 typedef struct nlq_op { uint8_t kind, item, queue, en_rule, link, link_arg; } nlq_op;
 typedef struct nlq_desc { uint32_t n_ops, n_queues; uint32_t width[NLQ_MAX_QUEUES]; nlq_op ops[NLQ_MAX_OPS]; } nlq_desc;
@@ -76,10 +81,10 @@ static const nlq_desc NLQ_DESC_KECCAK256 = {8, 2, {4, 12}, {
 
 /* L1MessagesHasher (13): the circuit pops EVERY message of the queue and hashes its 88-byte serialisation (linear_hasher in the absent
    crate; out of circuit data_hasher_and_merklizer.rs:8-67). A message is popped in the cycle that absorbs its first byte — cycle
-   floor(88 m / 136), at most two per cycle. Which block bytes a message lands on depends on the cycle (period 11), so the popped
-   fields are NOT linked to the block (placed). One queue. */
+   floor(88 m / 136), at most two per cycle. Which block bytes a message lands on depends on the cycle (period 11): the links of its
+   byte-valued fields (NLQ_LINK_LH_MESSAGE; link_arg = the slot 0 / 1 of the cycle) are a function of the cycle. One queue. */
 static const nlq_desc NLQ_DESC_LINEAR_HASHER = {2, 1, {4, 0}, {
-    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_FREE, NLQ_LINK_NONE, 0}, {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_FREE, NLQ_LINK_NONE, 0}}};
+    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 0}, {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 1}}};
 /* messages whose first byte is absorbed by cycle c: [nlq_lh_first(c), nlq_lh_first(c + 1)) */
 #define NLQ_LH_FIRST(c) (((uint64_t)(c) * 136 + 87) / 88)
 
@@ -144,16 +149,47 @@ NLQ_HD uint32_t nlq_bnd_cells(const nlq_desc *d) { return nlq_bnd_col(d, d->n_qu
    23 rollback, 24 + b: key byte b (little end first), 56 + b: address byte b.   DECOMMIT: 1..8 hash limbs, 9..12 memory_page bytes,
    13..16 timestamp bytes, 17 is_fresh. */
 #define NLQ_MEM_NIBBLE0 6
-NLQ_HD int nlq_comp_linked(const nlq_op *op, uint32_t cell) {
-    return op->link != NLQ_LINK_NONE && cell >= NLQ_MEM_NIBBLE0 && cell < NLQ_MEM_NIBBLE0 + (op->item == NLQ_ITEM_MEM8 ? 32u : 64u);
+/* byte of the 88-byte serialisation that a field cell of a LOG item holds, or -1 */
+NLQ_HD int nlq_lh_byte_of_cell(uint32_t cell) {
+    if (cell == 20) return 0;                                     /* shard_id */
+    if (cell == 22) return 1;                                     /* is_service as a byte */
+    if (cell >= 56 && cell < 76) return 4 + (19 - (int)(cell - 56)); /* address, big end first */
+    if (cell >= 24 && cell < 56) return 24 + (31 - (int)(cell - 24)); /* key, big end first */
+    return -1;
 }
-/* the netlist reference a linked cell copies, and the cycle it is seen from (*next: 1 = the state AFTER the cycle = CYC of cycle + 1) */
+/* can this cell be a copy of a netlist cell (whether it is may depend on the cycle: nlq_link_target) */
+NLQ_HD int nlq_comp_linked(const nlq_op *op, uint32_t cell) {
+    if (op->link == NLQ_LINK_NONE) return 0;
+    if (op->link == NLQ_LINK_LH_MESSAGE) return nlq_lh_byte_of_cell(cell) >= 0;
+    return cell >= NLQ_MEM_NIBBLE0 && cell < NLQ_MEM_NIBBLE0 + (op->item == NLQ_ITEM_MEM8 ? 32u : 64u);
+}
+/* the netlist reference a linked cell copies, and the cycle it is seen from (*next: 1 = the state AFTER the cycle = CYC of cycle + 1);
+   the links that do not depend on the cycle */
 NLQ_HD uint32_t nlq_link_ref(const nlq_op *op, uint32_t cell, uint32_t *next) {
     const uint32_t t = cell - NLQ_MEM_NIBBLE0;
     if (op->link == NLQ_LINK_KECCAK_DIGEST) { *next = 1; return NL_REF_CYC + (31 - t); }
     if (op->link == NLQ_LINK_SHA_DIGEST) { *next = 1; return NL_REF_CYC + 8 * (7 - t / 8) + t % 8; }
     *next = 0;
     return NL_REF_FREE + 2 * (32 * op->link_arg + 31 - t / 2) + (t & 1);
+}
+/* The link of `cell` of an operation of cycle c, if it has one there: the netlist reference and the cycle it is resolved in (a CYC
+   reference of cycle c + 1 = the state after c; a FREE reference = that cycle's element). Returns 0 when the cell is free in this cycle
+   (L1MessagesHasher: the slot holds no message by the 88 / 136 pattern, or the byte lies beyond the last cycle). */
+NLQ_HD int nlq_link_target(const nlq_op *op, uint32_t c, uint32_t capacity, uint32_t cell, uint32_t *cycle, uint32_t *ref) {
+    if (!nlq_comp_linked(op, cell)) return 0;
+    if (op->link == NLQ_LINK_LH_MESSAGE) {
+        const uint64_t m = NLQ_LH_FIRST(c) + op->link_arg;
+        if (m >= NLQ_LH_FIRST(c + 1)) return 0;
+        const uint64_t pos = 88 * m + (uint64_t)nlq_lh_byte_of_cell(cell);
+        if (pos / 136 >= capacity) return 0;
+        *cycle = (uint32_t)(pos / 136);
+        *ref = NL_REF_FREE + (uint32_t)(pos % 136);
+        return 1;
+    }
+    uint32_t next = 0;
+    *ref = nlq_link_ref(op, cell, &next);
+    *cycle = c + next;
+    return 1;
 }
 
 /* enc element j of an item = sum over its terms of cell * 2^shift (in the field): number of terms, term i (no arrays: the kernels

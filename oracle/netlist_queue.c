@@ -23,14 +23,15 @@ static uint64_t fmul_pow2(uint64_t x, uint32_t shift) { return orc_gl_mul(x % P,
 /* cell k of a block whose first row (within the cycle's operations) is r0 */
 #define QCELL(r0, k) TR((k) % G, NLQ_ROW(sp, capacity, (r0) + (k) / G, c))
 
-/* the netlist cell a linked component copies */
-static uint64_t linked_value(const nl_spec *sp, const uint64_t *trace, size_t n_rows, uint32_t capacity, uint32_t c, const nlq_op *op, uint32_t cell) {
-    uint32_t next = 0;
-    const uint32_t ref = nlq_link_ref(op, cell, &next);
-    if (next) return orc_nl_home(sp, trace, n_rows, capacity, c + 1, 0, ref);
+/* the netlist cell a linked component copies; *has = 0 when the cell has no link in this cycle */
+static uint64_t linked_value(const nl_spec *sp, const uint64_t *trace, size_t n_rows, uint32_t capacity, uint32_t c, const nlq_op *op, uint32_t cell, int *has) {
+    uint32_t cyc = 0, ref = 0;
+    *has = nlq_link_target(op, c, capacity, cell, &cyc, &ref);
+    if (!*has) return 0;
+    if (ref >= NL_REF_CYC && ref < NL_REF_FREE) return orc_nl_home(sp, trace, n_rows, capacity, cyc, 0, ref);
     uint32_t row = 0, col = 0;
-    if (orc_nl_free_home(sp, ref - NL_REF_FREE, &row, &col)) return 0;
-    return TR(col, (size_t)c * sp->rows_per_cycle + row);
+    if (orc_nl_free_home(sp, ref - NL_REF_FREE, &row, &col)) { *has = 0; return 0; }
+    return TR(col, (size_t)cyc * sp->rows_per_cycle + row);
 }
 
 static void state_before(const orc_nlq_queue *q, uint32_t width, uint64_t idx, uint64_t out[12]) {
@@ -57,8 +58,11 @@ int orc_nlq_synthesize(int circuit_type, uint32_t capacity, const nlq_feed *feed
             const void *rec = f.en ? (const char *)Q->items + (size_t)f.idx * nlq_item_bytes(op->item) : NULL;
             uint64_t cells[128], old[12], out[12];
             cells[0] = f.en ? 1 : 0;
-            for (uint32_t k = 1; k < ncomp; k++)
-                cells[k] = nlq_comp_linked(op, k) ? linked_value(sp, trace, n_rows, capacity, c, op, k) : nlq_item_component(op->item, rec, k);
+            for (uint32_t k = 1; k < ncomp; k++) {
+                int has = 0;
+                const uint64_t v = linked_value(sp, trace, n_rows, capacity, c, op, k, &has);
+                cells[k] = has ? v : nlq_item_component(op->item, rec, k);
+            }
             for (uint32_t e = 0; e < nenc; e++) {
                 uint64_t acc = 0;
                 for (uint32_t i = 0; i < nlq_enc_n_terms(op->item, e); i++) {
@@ -149,7 +153,11 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
             /* linked components */
             int ok = 1;
             for (uint32_t k = 1; k < ncomp; k++)
-                if (nlq_comp_linked(op, k) && cells[k] != linked_value(sp, trace, n_rows, capacity, c, op, k)) ok = 0;
+            {
+                int has = 0;
+                const uint64_t v = linked_value(sp, trace, n_rows, capacity, c, op, k, &has);
+                if (has && cells[k] != v) ok = 0;
+            }
             if (!ok) flag(&res, 2, j, row_e);
             /* encodings */
             for (uint32_t e = 0; e < nenc; e++) {

@@ -146,10 +146,25 @@ def test_linear_hasher_pops_every_message(oracle):
     enc = oracle.encode_log_queries(q)
     for m, (c, j) in enumerate(popped):
         assert [int(t[oracle.nlq_cell(13, cycles, c, j, -1, 1, k)]) for k in range(20)] == enc[m].tolist()
-    for (col, row), kinds in ((oracle.nlq_cell(13, cycles, 1, 0, -1, 0, 30), (7,)), (oracle.nlq_cell(13, cycles, 1, 0, 2, 0, 50), (8,)),
+    for (col, row), kinds in ((oracle.nlq_cell(13, cycles, 1, 0, -1, 0, 30), (2,)), (oracle.nlq_cell(13, cycles, 1, 0, -1, 0, 10), (7,)), (oracle.nlq_cell(13, cycles, 1, 0, 2, 0, 50), (8,)),
                               (oracle.nlq_cell(13, cycles, 2, 0, -1, 2, 1), (2,)), (oracle.nlq_cell(13, cycles, 3, 1), (3, 7)),
                               (oracle.nlq_cell(13, cycles, 0, 2, k=5), (4,))):
         bad = t.copy()
         bad[col, row] += 1
         n, first = oracle.linear_hasher_check(bad, cycles)
         assert n > 0 and first[0] in kinds, ((col, row), n, first)
+    # (cell 30 is a key byte: a COPY of the block byte the sponge absorbs; cell 10 a written_value limb: only its encoding notices.)
+    # The other way round — a hashed block byte of message 2 (cycle 1: bytes 40..127 of the block hold message 2 = stream bytes 176..263):
+    import ctypes as C
+
+    lib = oracle.lib()
+    lib.orc_nl_free_home_of.restype = C.c_int
+    rpc = oracle.nl_geometry(13)["rows_per_cycle"]
+    # (free element, linked): byte 0 of cycle 1 is stream byte 136 = key byte 48 - 24 of message 1, popped in cycle 0: a link across cycles
+    for free_index, linked in ((40, True), (41, True), (42, False), (43, False), (44, True), (70, True), (100, False), (135, True), (0, True), (39, False)):
+        row_col = np.zeros(2, np.uint32)
+        assert lib.orc_nl_free_home_of(C.c_int(13), C.c_uint32(free_index), C.c_void_p(row_col.ctypes.data)) == 0
+        bad = t.copy()
+        bad[int(row_col[1]), rpc + int(row_col[0])] ^= 1
+        n, _first = oracle.linear_hasher_check(bad, cycles)
+        assert n == (3 if linked else 2), (free_index, n)  # two violations in the netlist (the XOR lookup, its consumer) + the link
