@@ -143,11 +143,11 @@ static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict_
     const void* rec = f.en ? static_cast<const char*>(Q.items) + (size_t)f.idx * nlq_item_bytes(op.item) : nullptr;
     // the linked cells of the operation (64 nibbles / 32 bytes of a memory word's value) are fetched once, four independent loads per
     // lane, and staged in LDS: the encodings read every one of them, and a dependent table + cell load per term was the kernel's time
-    __shared__ u64 sh_link[4][80];  // by cell index (the linkable cells of every item lie below 80)
+    __shared__ u64 sh_link[4][112];  // by cell index (the linkable cells of every item lie below 112)
     u64* my_link = sh_link[threadIdx.x >> 4];
     if (op.link != NLQ_LINK_NONE) {
 #pragma unroll
-        for (u32 q = 0; q < 5; q++) {
+        for (u32 q = 0; q < 7; q++) {
             const u32 k = g + 16 * q;
             if (k == 0 || k >= ncomp || !nlq_comp_linked(&op, k)) continue;
             // (the source cell inside this cycle, where the host could resolve it: the links that do not depend on the cycle)
@@ -159,8 +159,16 @@ static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict_
         }
     }
     __syncthreads();
-    auto comp = [&](u32 k) -> u64 {  // cell k >= 1 of the ENC block: a field of the item, or the netlist cell it copies
-        return nlq_comp_linked(&op, k) ? my_link[k] : nlq_item_component(op.item, rec, k);
+    auto comp0 = [&](u32 k) -> u64 { return nlq_comp_linked(&op, k) ? my_link[k] : nlq_item_component(op.item, rec, k); };
+    auto comp = [&](u32 k) -> u64 {  // cell k >= 1 of the ENC block: a field of the item, the netlist cell it copies, or the recomposition of byte cells
+        const int r = nlq_aux_of_cell(op.item, k);
+        if (r < 0) return comp0(k);
+        u64 acc = 0;
+        for (u32 i = 0; i < nlq_aux_n_terms(op.item, (u32)r); i++) {
+            const nlq_term tm = nlq_aux_term(op.item, (u32)r, i);
+            acc = gl::add(acc, gl::mul(gl::canon(comp0(tm.cell)), 1ull << tm.shift));
+        }
+        return gl::canon(acc);
     };
     auto enc_val = [&](u32 e) -> u64 { return e < nenc ? nlq_enc_value(op.item, e, comp) : 0; };
     for (u32 k = g; k < ncomp; k += 16) {
@@ -254,6 +262,14 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
     // (no per-lane arrays with run-time indices — they would live in scratch memory: every value is read from its cell where it is used)
     for (u32 e = 0; e < nenc; e++)
         if (nlq_enc_value(op.item, e, cell) != gl::canon(cell(ncomp + e))) flag_bad(res, 7, 32 * j + e, row_e);
+    for (u32 r = 0; r < nlq_aux_n(op.item); r++) {  // recomposition gates (a limb = its bytes)
+        u64 acc = 0;
+        for (u32 i = 0; i < nlq_aux_n_terms(op.item, r); i++) {
+            const nlq_term tm = nlq_aux_term(op.item, r, i);
+            acc = gl::add(acc, gl::mul(gl::canon(cell(tm.cell)), 1ull << tm.shift));
+        }
+        if (gl::canon(acc) != gl::canon(cell(nlq_aux_result(op.item, r)))) flag_bad(res, 7, 0x400 + 16 * j + r, row_e);
+    }
     const u32 o0 = ncomp + nenc, n_perms = nlq_kind_perms(op.kind);
     auto want_in = [&](u32 p, u32 k) -> u64 {  // what input k of permutation p copies
         if (op.kind != NLQ_POP4) return k < 8 ? cell(ncomp + k) : cell(o0 + k);

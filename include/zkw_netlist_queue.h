@@ -38,7 +38,8 @@
 #define NLQ_MAX_TERMS 14
 
 enum { NLQ_PUSH12 = 1, NLQ_POP12 = 2, NLQ_POP4 = 3 }; /* PUSH12 and POP12 are the same arithmetic on a tail / on a head */
-enum { NLQ_ITEM_MEM = 1, NLQ_ITEM_LOG = 2, NLQ_ITEM_DECOMMIT = 3, NLQ_ITEM_MEM8 = 4 /* a memory query with its value as 32 bytes (the byte-valued netlists) */ };
+enum { NLQ_ITEM_MEM = 1, NLQ_ITEM_LOG = 2, NLQ_ITEM_DECOMMIT = 3, NLQ_ITEM_MEM8 = 4 /* a memory query with its value as 32 bytes (the byte-valued netlists) */,
+       NLQ_ITEM_LOGB = 5 /* a log query that also holds written_value and tx_number as BYTES, tied to the limbs by recomposition gates (nlq_aux_*) */ };
 enum { NLQ_EN_FREE = 0, NLQ_EN_RESET = 1, NLQ_EN_ACTIVE = 2 };
 /* links of a memory query's 64 value nibbles (little end first) to the SHA-256 netlist:
    SHA_BLOCK + arg k: the cycle's message block, memory word k (U256::to_big_endian = block bytes 32k..32k+31; FREE element 2b + hi);
@@ -48,8 +49,8 @@ enum { NLQ_LINK_NONE = 0, NLQ_LINK_SHA_BLOCK = 1, NLQ_LINK_SHA_DIGEST = 2,
        NLQ_LINK_LH_MESSAGE = 4 /* LOG: the byte-valued fields of a popped L2 -> L1 message are copies of the bytes the sponge absorbs: byte k of the
           88-byte serialisation (log_query.rs:503-534: shard | is_service | tx_number | address | key | written_value, big end first) of message
           m is byte 88 m + k of the hashed stream = FREE element (88 m + k) % 136 of cycle (88 m + k) / 136 — the cycle the message is popped in
-          or the next one. Linked: shard_id, is_service, the 20 address bytes, the 32 key bytes (the fields that ARE bytes in the encoding);
-          tx_number and written_value are limbs there: placed. */ };
+          or the next one. All 88 bytes are linked: shard_id, is_service, the address and key bytes (bytes in the encoding anyway) and the
+          tx_number / written_value bytes of NLQ_ITEM_LOGB (the encoding takes their limbs: nlq_aux_* recompose them). */ };
 
 typedef struct nlq_op { uint8_t kind, item, queue, en_rule, link, link_arg; } nlq_op;
 typedef struct nlq_desc { uint32_t n_ops, n_queues; uint32_t width[NLQ_MAX_QUEUES]; nlq_op ops[NLQ_MAX_OPS]; } nlq_desc;
@@ -84,7 +85,7 @@ static const nlq_desc NLQ_DESC_KECCAK256 = {8, 2, {4, 12}, {
    floor(88 m / 136), at most two per cycle. Which block bytes a message lands on depends on the cycle (period 11): the links of its
    byte-valued fields (NLQ_LINK_LH_MESSAGE; link_arg = the slot 0 / 1 of the cycle) are a function of the cycle. One queue. */
 static const nlq_desc NLQ_DESC_LINEAR_HASHER = {2, 1, {4, 0}, {
-    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 0}, {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 1}}};
+    {NLQ_POP4, NLQ_ITEM_LOGB, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 0}, {NLQ_POP4, NLQ_ITEM_LOGB, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 1}}};
 /* messages whose first byte is absorbed by cycle c: [nlq_lh_first(c), nlq_lh_first(c + 1)) */
 #define NLQ_LH_FIRST(c) (((uint64_t)(c) * 136 + 87) / 88)
 
@@ -102,8 +103,8 @@ static inline const nlq_desc *nlq_desc_of(int circuit_type) {
 NLQ_HD uint32_t nlq_kind_width(uint32_t kind) { return kind == NLQ_POP4 ? 4u : 12u; }
 NLQ_HD uint32_t nlq_kind_perms(uint32_t kind) { return kind == NLQ_POP4 ? 3u : 1u; }
 /* component cells of an item, `en` (cell 0) included; encoding elements */
-NLQ_HD uint32_t nlq_item_comps(uint32_t item) { return item == NLQ_ITEM_MEM ? 70u : item == NLQ_ITEM_LOG ? 76u : item == NLQ_ITEM_MEM8 ? 38u : 18u; }
-NLQ_HD uint32_t nlq_item_enc(uint32_t item) { return item == NLQ_ITEM_LOG ? 20u : 8u; }
+NLQ_HD uint32_t nlq_item_comps(uint32_t item) { return item == NLQ_ITEM_MEM ? 70u : item == NLQ_ITEM_LOG ? 76u : item == NLQ_ITEM_LOGB ? 110u : item == NLQ_ITEM_MEM8 ? 38u : 18u; }
+NLQ_HD uint32_t nlq_item_enc(uint32_t item) { return item == NLQ_ITEM_LOG || item == NLQ_ITEM_LOGB ? 20u : 8u; }
 /* cells of the ENC block: [0, comps) | enc | old | new */
 NLQ_HD uint32_t nlq_enc0(const nlq_op *op) { return nlq_item_comps(op->item); }
 NLQ_HD uint32_t nlq_old0(const nlq_op *op) { return nlq_enc0(op) + nlq_item_enc(op->item); }
@@ -155,6 +156,9 @@ NLQ_HD int nlq_lh_byte_of_cell(uint32_t cell) {
     if (cell == 22) return 1;                                     /* is_service as a byte */
     if (cell >= 56 && cell < 76) return 4 + (19 - (int)(cell - 56)); /* address, big end first */
     if (cell >= 24 && cell < 56) return 24 + (31 - (int)(cell - 24)); /* key, big end first */
+    if (cell >= 76 && cell < 108) return 56 + (31 - (int)(cell - 76)); /* written_value (LOGB), big end first */
+    if (cell == 108) return 3;                                     /* tx_number (LOGB): big end first */
+    if (cell == 109) return 2;
     return -1;
 }
 /* can this cell be a copy of a netlist cell (whether it is may depend on the cycle: nlq_link_target) */
@@ -197,7 +201,7 @@ NLQ_HD int nlq_link_target(const nlq_op *op, uint32_t c, uint32_t capacity, uint
 NLQ_HD uint32_t nlq_enc_n_terms(uint32_t item, uint32_t j) {
     if (item == NLQ_ITEM_MEM) return j < 2 ? 1u : j == 2 ? 3u : j < 7 ? 14u : 8u;
     if (item == NLQ_ITEM_MEM8) return j < 2 ? 1u : j == 2 ? 3u : j < 7 ? 7u : 4u;
-    if (item == NLQ_ITEM_LOG) return j <= 17 ? 4u : j == 18 ? 2u : 1u;
+    if (item == NLQ_ITEM_LOG || item == NLQ_ITEM_LOGB) return j <= 17 ? 4u : j == 18 ? 2u : 1u;
     return j < 3 ? 4u : 1u;
 }
 NLQ_HD nlq_term nlq_enc_term(uint32_t item, uint32_t j, uint32_t i) {
@@ -213,7 +217,7 @@ NLQ_HD nlq_term nlq_enc_term(uint32_t item, uint32_t j, uint32_t i) {
         else if (j == 2) { cell = 3 + i; shift = i ? 31 + i : 0; }
         else if (i < 4) { cell = NLQ_MEM_NIBBLE0 + 4 * (j == 7 ? 4 : j - 3) + i; shift = 8 * i; }
         else { cell = NLQ_MEM_NIBBLE0 + 20 + 3 * (j - 3) + (i - 4); shift = 32 + 8 * (i - 4); }
-    } else if (item == NLQ_ITEM_LOG) { /* log_query.rs:150-360: a limb + three bytes of key ++ address | tx_number, address[19], aux_byte, shard_id | rw + 2 * is_service | rollback */
+    } else if (item == NLQ_ITEM_LOG || item == NLQ_ITEM_LOGB) { /* log_query.rs:150-360: a limb + three bytes of key ++ address | tx_number, address[19], aux_byte, shard_id | rw + 2 * is_service | rollback */
         if (j < 17) {
             if (i == 0) cell = j < 16 ? 1 + j : 17;
             else { const uint32_t x = 3 * j + (i - 1); cell = x < 32 ? 24 + x : 56 + (x - 32); shift = 32 + 8 * (i - 1); }
@@ -227,6 +231,25 @@ NLQ_HD nlq_term nlq_enc_term(uint32_t item, uint32_t j, uint32_t i) {
     t.cell = (uint16_t)cell; t.shift = (uint16_t)shift;
     return t;
 }
+/* recomposition gates of an item (NLQ_ITEM_LOGB): relation r says cell nlq_aux_result = sum over its terms of cell * 2^shift.
+   r < 8: written_value limb r = its four bytes (cells 76 + 4 r ..); r = 8: tx_number = its two bytes (cells 108, 109) */
+NLQ_HD uint32_t nlq_aux_n(uint32_t item) { return item == NLQ_ITEM_LOGB ? 9u : 0u; }
+NLQ_HD uint32_t nlq_aux_result(uint32_t item, uint32_t r) { (void)item; return r < 8 ? 9u + r : 18u; }
+/* the gate whose result `cell` is, or -1 (the fill computes such a cell from the gate's terms: in a disabled operation the byte cells
+   may be copies of padding bytes, and the limb must still be their recomposition) */
+NLQ_HD int nlq_aux_of_cell(uint32_t item, uint32_t cell) {
+    if (item != NLQ_ITEM_LOGB) return -1;
+    return cell >= 9 && cell <= 16 ? (int)(cell - 9) : cell == 18 ? 8 : -1;
+}
+NLQ_HD uint32_t nlq_aux_n_terms(uint32_t item, uint32_t r) { (void)item; return r < 8 ? 4u : 2u; }
+NLQ_HD nlq_term nlq_aux_term(uint32_t item, uint32_t r, uint32_t i) {
+    nlq_term t;
+    (void)item;
+    t.cell = (uint16_t)(r < 8 ? 76 + 4 * r + i : 108 + i);
+    t.shift = (uint16_t)(8 * i);
+    return t;
+}
+
 /* component `cell` (>= 1) of an item record (zkw_mem_query / zkw_log_query / zkw_decommit_query); a null record is all zeros */
 NLQ_HD uint64_t nlq_item_component(uint32_t item, const void *rec, uint32_t cell) {
     if (!rec) return 0;
@@ -252,8 +275,12 @@ NLQ_HD uint64_t nlq_item_component(uint32_t item, const void *rec, uint32_t cell
             default: { const uint32_t t = cell - NLQ_MEM_NIBBLE0; return (q->value[t / 4] >> (8 * (t % 4))) & 255u; }
         }
     }
-    if (item == NLQ_ITEM_LOG) {
+    if (item == NLQ_ITEM_LOG || item == NLQ_ITEM_LOGB) {
         const zkw_log_query *q = (const zkw_log_query *)rec;
+        if (cell >= 76) { /* LOGB: written_value bytes (little end first), tx_number bytes */
+            if (cell < 108) { const uint32_t b = cell - 76; return (q->written_value[b / 4] >> (8 * (b % 4))) & 255u; }
+            return ((uint32_t)q->tx_number_in_block >> (8 * (cell - 108))) & 255u;
+        }
         if (cell <= 8) return q->read_value[cell - 1];
         if (cell <= 16) return q->written_value[cell - 9];
         switch (cell) {
@@ -278,6 +305,6 @@ NLQ_HD uint64_t nlq_item_component(uint32_t item, const void *rec, uint32_t cell
     }
 }
 NLQ_HD uint32_t nlq_item_bytes(uint32_t item) {
-    return item == NLQ_ITEM_MEM || item == NLQ_ITEM_MEM8 ? (uint32_t)sizeof(zkw_mem_query) : item == NLQ_ITEM_LOG ? (uint32_t)sizeof(zkw_log_query) : (uint32_t)sizeof(zkw_decommit_query);
+    return item == NLQ_ITEM_MEM || item == NLQ_ITEM_MEM8 ? (uint32_t)sizeof(zkw_mem_query) : item == NLQ_ITEM_LOG || item == NLQ_ITEM_LOGB ? (uint32_t)sizeof(zkw_log_query) : (uint32_t)sizeof(zkw_decommit_query);
 }
 #endif /* ZKW_NETLIST_QUEUE_H */

@@ -56,12 +56,20 @@ int orc_nlq_synthesize(int circuit_type, uint32_t capacity, const nlq_feed *feed
             const uint32_t w = nlq_kind_width(op->kind), ncomp = nlq_item_comps(op->item), nenc = nlq_item_enc(op->item), r0 = nlq_op_row0(d, G, j);
             if (f.en && f.idx >= Q->n_items) return -2;
             const void *rec = f.en ? (const char *)Q->items + (size_t)f.idx * nlq_item_bytes(op->item) : NULL;
-            uint64_t cells[128], old[12], out[12];
+            uint64_t cells[160], old[12], out[12];
             cells[0] = f.en ? 1 : 0;
             for (uint32_t k = 1; k < ncomp; k++) {
                 int has = 0;
                 const uint64_t v = linked_value(sp, trace, n_rows, capacity, c, op, k, &has);
                 cells[k] = has ? v : nlq_item_component(op->item, rec, k);
+            }
+            for (uint32_t r = 0; r < nlq_aux_n(op->item); r++) { /* a limb is the recomposition of its byte cells */
+                uint64_t acc = 0;
+                for (uint32_t i = 0; i < nlq_aux_n_terms(op->item, r); i++) {
+                    const nlq_term tm = nlq_aux_term(op->item, r, i);
+                    acc = orc_gl_add(acc, fmul_pow2(cells[tm.cell], tm.shift));
+                }
+                cells[nlq_aux_result(op->item, r)] = acc;
             }
             for (uint32_t e = 0; e < nenc; e++) {
                 uint64_t acc = 0;
@@ -142,7 +150,7 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
             const uint32_t w = nlq_kind_width(op->kind), ncomp = nlq_item_comps(op->item), nenc = nlq_item_enc(op->item), r0 = nlq_op_row0(d, G, j);
             const uint32_t ncells = ncomp + nenc + 2 * w, erows = nlq_rows_for(ncells, G);
             const uint64_t row_e = NLQ_ROW(sp, capacity, r0, c);
-            uint64_t cells[128];
+            uint64_t cells[160];
             for (uint32_t k = 0; k < ncells; k++) cells[k] = QCELL(r0, k);
             const uint64_t en = cells[0];
             /* flag */
@@ -167,6 +175,15 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
                     acc = orc_gl_add(acc, fmul_pow2(cells[tm.cell], tm.shift));
                 }
                 if (acc != cells[ncomp + e] % P) flag(&res, 7, 32 * j + e, row_e);
+            }
+            /* recomposition gates (a limb = its bytes) */
+            for (uint32_t r = 0; r < nlq_aux_n(op->item); r++) {
+                uint64_t acc = 0;
+                for (uint32_t i = 0; i < nlq_aux_n_terms(op->item, r); i++) {
+                    const nlq_term tm = nlq_aux_term(op->item, r, i);
+                    acc = orc_gl_add(acc, fmul_pow2(cells[tm.cell], tm.shift));
+                }
+                if (acc != cells[nlq_aux_result(op->item, r)] % P) flag(&res, 7, 0x400 + 16 * j + r, row_e);
             }
             /* permutations */
             const uint64_t *enc = cells + ncomp, *old = cells + ncomp + nenc, *nw = old + w;

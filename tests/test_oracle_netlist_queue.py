@@ -34,7 +34,7 @@ def test_section_geometry_keeps_the_reference_capacity(oracle):
         assert g["max_capacity"] >= REFERENCE_CAPACITY[ct], (ct, g)
         assert g["rows_used"] == g["first_row"] + 1 + 10 * rows
     g = oracle.nlq_geometry(13, 501)  # L1MessagesHasher: 774 messages = 501 cycles, two pops per cycle
-    assert g["has"] == 1 and g["rows_per_cycle"] == 16 and g["queues"] == 1 and g["max_capacity"] >= 501
+    assert g["has"] == 1 and g["rows_per_cycle"] == 18 and g["queues"] == 1 and g["max_capacity"] >= 501
     assert oracle.nlq_geometry(10, 10)["has"] == 0
 
 
@@ -153,7 +153,7 @@ def test_linear_hasher_pops_every_message(oracle):
         bad[col, row] += 1
         n, first = oracle.linear_hasher_check(bad, cycles)
         assert n > 0 and first[0] in kinds, ((col, row), n, first)
-    # (cell 30 is a key byte: a COPY of the block byte the sponge absorbs; cell 10 a written_value limb: only its encoding notices.)
+    # (cell 30 is a key byte: a COPY of the block byte the sponge absorbs; cell 10 a written_value limb: its recomposition gate and its encoding notice.)
     # The other way round — a hashed block byte of message 2 (cycle 1: bytes 40..127 of the block hold message 2 = stream bytes 176..263):
     import ctypes as C
 
@@ -161,7 +161,7 @@ def test_linear_hasher_pops_every_message(oracle):
     lib.orc_nl_free_home_of.restype = C.c_int
     rpc = oracle.nl_geometry(13)["rows_per_cycle"]
     # (free element, linked): byte 0 of cycle 1 is stream byte 136 = key byte 48 - 24 of message 1, popped in cycle 0: a link across cycles
-    for free_index, linked in ((40, True), (41, True), (42, False), (43, False), (44, True), (70, True), (100, False), (135, True), (0, True), (39, False)):
+    for free_index, linked in ((40, True), (41, True), (42, True), (43, True), (44, True), (70, True), (100, True), (135, True), (0, True), (39, True)):  # all 88 bytes of a message
         row_col = np.zeros(2, np.uint32)
         assert lib.orc_nl_free_home_of(C.c_int(13), C.c_uint32(free_index), C.c_void_p(row_col.ctypes.data)) == 0
         bad = t.copy()
