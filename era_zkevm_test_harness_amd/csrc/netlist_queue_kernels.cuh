@@ -224,7 +224,7 @@ __device__ u64 nlq_prev_new(const nl_spec& S, const nlq_desc& d, const u64* __re
 }
 
 // grid (ceil(capacity / 64), n_ops): one lane per operation of a cycle; lane (0, 0, 0) also checks the QBND row
-static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, nlq_desc d, const u64* __restrict__ trace,
+static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, nlq_desc d, nlq_rels rels, const u64* __restrict__ trace,
                                                          u32 capacity, size_t n_rows, CheckResult* res) {
     const nl_spec& S = devp->s;
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
@@ -241,6 +241,15 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
             if (NLQ_TR(col, q0)) { flag_bad(res, 6, col, q0); break; }
     }
     if (c >= capacity) return;
+    if (j == 0)  // the relations between the operations of the cycle (include/zkw_netlist_queue.h nlq_rel)
+        for (u32 i = 0; i < rels.n; i++) {
+            const nlq_rel r = rels.r[i];
+            const u64 en = gl::canon(nlq_cell_at(S, trace, n_rows, capacity, c, nlq_op_row0(&d, G, r.gate), 0));
+            const u64 b = gl::canon(nlq_cell_at(S, trace, n_rows, capacity, c, nlq_op_row0(&d, G, r.op_b), r.cell_b));
+            const u64 a = r.op_a == NLQ_REL_CONST ? 0 : gl::canon(nlq_cell_at(S, trace, n_rows, capacity, c, nlq_op_row0(&d, G, r.op_a), r.cell_a));
+            const u64 diff = gl::canon(gl::sub(gl::canon(gl::sub(b, a)), (u64)r.add));
+            if (gl::canon(gl::mul(en, diff)) != 0) flag_bad(res, 7, 0x1000 + i, NLQ_ROW(&S, capacity, nlq_op_row0(&d, G, r.gate), c));
+        }
     const nlq_op op = d.ops[j];
     const u32 w = nlq_kind_width(op.kind), ncomp = nlq_item_comps(op.item), nenc = nlq_item_enc(op.item), r0 = nlq_op_row0(&d, G, j);
     const u32 ncells = ncomp + nenc + 2 * w, erows = nlq_rows_for(ncells, G);

@@ -1130,7 +1130,7 @@ int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u3
     { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res, (u64)NL_USED_ROWS(&S, capacity), (u64)nlq_used_rows(&S, qd, capacity)); }
     ZKW_TRY(launch_check("k_nl_check_tail"));
     if (qd) {
-        { Prof _p(ctx, "k_nlq_check"); hipLaunchKernelGGL(k_nlq_check, dim3((capacity + 63) / 64, qd->n_ops), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, *qd, trace, capacity, n_rows, d_res); }
+        { Prof _p(ctx, "k_nlq_check"); hipLaunchKernelGGL(k_nlq_check, dim3((capacity + 63) / 64, qd->n_ops), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, *qd, *nlq_rels_of(circuit_type), trace, capacity, n_rows, d_res); }
         ZKW_TRY(launch_check("k_nlq_check"));
     }
     CheckResult res;

@@ -223,6 +223,16 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
                 for (uint32_t col = (r + 1 == erows ? ncells - r * G : G); col < G; col++)
                     if (TR(col, NLQ_ROW(sp, capacity, r0 + r, c))) { flag(&res, 6, col, NLQ_ROW(sp, capacity, r0 + r, c)); break; }
         }
+    /* relations between the operations of a cycle (kind 7, index 0x1000 + relation, at the gate operation's ENC row) */
+    const nlq_rels *rels = nlq_rels_of(circuit_type);
+    for (uint32_t c = 0; c < capacity; c++)
+        for (uint32_t i = 0; i < rels->n; i++) {
+            const nlq_rel *r = &rels->r[i];
+            const uint64_t en = QCELL(nlq_op_row0(d, G, r->gate), 0) % P, b = QCELL(nlq_op_row0(d, G, r->op_b), r->cell_b) % P;
+            const uint64_t a = r->op_a == NLQ_REL_CONST ? 0 : QCELL(nlq_op_row0(d, G, r->op_a), r->cell_a) % P;
+            const uint64_t diff = orc_gl_sub(orc_gl_sub(b, a), (uint64_t)r->add);
+            if (orc_gl_mul(en, diff) != 0) flag(&res, 7, 0x1000 + i, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->gate), c));
+        }
     /* QBND */
     for (uint32_t q = 0; q < d->n_queues; q++) {
         int ok = 1;
@@ -307,12 +317,14 @@ int orc_nlq_standalone(int circuit_type, const zkw_sha256_round_record *rounds, 
             if (!sha && k == 1 && last) break; /* the padding half-block of a bytecode is not a code word */
             zkw_mem_query *q = &mq[n_q++];
             q->rw_flag = sha ? 0 : 1;
+            q->index = (uint32_t)(n_req ? woff[n_req] - woff[n_req - 1] : 0); /* the word's number within its request: consecutive words */
             for (int b = 0; b < 32; b++) q->value[(31 - b) / 4] |= (uint32_t)rounds[r].block[32 * k + b] << (8 * ((31 - b) % 4)); /* U256::from_big_endian */
             if (n_req) woff[n_req]++;
         }
         if (sha && last) {
             zkw_mem_query *q = &mq[n_q++];
             q->rw_flag = 1;
+            q->timestamp = 1; /* one tick after the reads */
             for (int j = 0; j < 8; j++) q->value[j] = rounds[r].state_after[7 - j];
         }
     }

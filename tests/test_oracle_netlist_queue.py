@@ -103,12 +103,34 @@ def test_section_tampering_is_caught(oracle, ct):
         "qbnd_unused": (cell(0, g["ops"], k=G - 1), (6,)),
         "unused": ((G - 1, cell(2, 1, -1, 0, 0)[1]), (6,)),
         "section_lookup_col": ((G + 2, cell(2, 1)[1]), (6,)),
+        # the FSM arithmetic visible inside a cycle (nlq_rel): word index / page of a pushed query against its neighbour's. The encoding
+        # notices too (kind 7 either way); what only the relation sees is a CONSISTENT change — see below
+        "index": (cell(2, 2, -1, 0, 3), (7,)), "rw": (cell(2, 1, -1, 0, 4), (7,)),
     }
     for name, ((col, row), kinds) in cases.items():
         bad = t.copy()
         bad[col, row] += 1
         n, first = check(bad, cap)
         assert n > 0 and first[0] in kinds, (name, (col, row), n, first)
+    # a query that is self-consistent (fields + encoding + permutation + chain recomputed by the oracle's own fill) but not the
+    # NEIGHBOUR of the one before it: only the relations between the operations of a cycle object
+    if ct in (6, 3):
+        bo = dict(o)
+        key = "mem_queries" if ct == 6 else "mem_q"
+        mq = bo[key].copy()
+        victim = 4 if ct == 6 else 3   # a second word of some round
+        mq["index"][victim] += 5
+        bo[key] = mq
+        enc = oracle.encode_memory_queries(mq)
+        init = np.asarray(bo["mem_in"]["tail"][0], dtype=np.uint64)
+        bo["mem_tails"] = oracle.queue_push_chain_full(enc, init)
+        for i in range(bo["instances"].size):
+            n, first = check(synth(bo, i, cap, N_ROWS), cap)
+            if n:
+                assert first[0] == 7 and first[1] >= 0x1000, first
+                break
+        else:
+            raise AssertionError("the shifted word index went unnoticed")
     if ct == 5:
         return
     # a message nibble of the hash netlist that a memory word's value copies: the link notices (kind 2 in the section's rows)
