@@ -228,8 +228,12 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
     for (uint32_t c = 0; c < capacity; c++)
         for (uint32_t i = 0; i < rels->n; i++) {
             const nlq_rel *r = &rels->r[i];
-            const uint64_t en = QCELL(nlq_op_row0(d, G, r->gate), 0) % P, b = QCELL(nlq_op_row0(d, G, r->op_b), r->cell_b) % P;
-            const uint64_t a = r->op_a == NLQ_REL_CONST ? 0 : QCELL(nlq_op_row0(d, G, r->op_a), r->cell_a) % P;
+            if (r->prev && c == 0) continue;
+            uint64_t en = QCELL(nlq_op_row0(d, G, r->gate), 0) % P;
+            if (r->gate2 != NLQ_REL_CONST) en = orc_gl_sub(en, QCELL(nlq_op_row0(d, G, r->gate2), 0) % P);
+            const uint64_t b = QCELL(nlq_op_row0(d, G, r->op_b), r->cell_b) % P;
+            const uint32_t ca = r->prev ? c - 1 : c;
+            const uint64_t a = r->op_a == NLQ_REL_CONST ? 0 : TR(r->cell_a % G, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->op_a) + r->cell_a / G, ca)) % P;
             const uint64_t diff = orc_gl_sub(orc_gl_sub(b, a), (uint64_t)r->add);
             if (orc_gl_mul(en, diff) != 0) flag(&res, 7, 0x1000 + i, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->gate), c));
         }

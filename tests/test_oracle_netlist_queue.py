@@ -131,6 +131,21 @@ def test_section_tampering_is_caught(oracle, ct):
                 break
         else:
             raise AssertionError("the shifted word index went unnoticed")
+    # ... and BOTH words of a later round of a request moved together (consecutive among themselves): only the relation that carries the
+    # word offset from round to round objects (nlq_rel.prev)
+    if ct == 6:
+        resets = o["sha256_rounds"]["reset"]
+        r = int(np.flatnonzero(resets == 0)[0])
+        fq = 2 * r + int(np.count_nonzero(resets[:r + 1])) - 1
+        bo = dict(o)
+        mq = bo["mem_queries"].copy()
+        mq["index"][fq:fq + 2] += 5
+        bo["mem_queries"] = mq
+        bo["mem_tails"] = oracle.queue_push_chain_full(oracle.encode_memory_queries(mq), np.asarray(bo["mem_in"]["tail"][0], dtype=np.uint64))
+        inst = int(np.searchsorted(np.cumsum(bo["instances"]["num_rounds"]), r, side="right"))
+        n, first = check(synth(bo, inst, cap, N_ROWS), cap)
+        first_in_instance = r == int(bo["instances"]["first_round"][inst])
+        assert (n == 0) if first_in_instance else (n > 0 and first[0] == 7 and first[1] >= 0x1000 + 11), (n, first)
     if ct == 5:
         return
     # a message nibble of the hash netlist that a memory word's value copies: the link notices (kind 2 in the section's rows)
