@@ -100,37 +100,41 @@ static const nlq_desc NLQ_DESC_LINEAR_HASHER = {2, 1, {4, 0}, {
    en(gate) * (cell_b of op_b - cell_a of op_a - add) = 0; op_a = NLQ_REL_CONST: en(gate) * (cell_b of op_b - add) = 0.
    prev = 1: cell_a is taken from the PREVIOUS cycle (no relation at cycle 0: an instance's first cycle continues from the FSM input,
    which is placed) and the factor is en(gate) - en(gate2): "this round reads and does not start a request" — the word offset carried
-   from round to round. (Rounds left and the call's ABI against a request's first address stay placed.) Memory-query cells: 1 timestamp, 2 page, 3 index, 4 rw, 5 value_is_pointer; log-query cell 17: timestamp. */
+   from round to round. span = n > 1: the operand is the little-endian recomposition of n byte cells cell_a .. cell_a + n - 1 (a limb of
+   the popped call's ABI: key bytes 0..3 = input offset, 16..19 = page to read — precompile_abi_in_log; a decommit request's page /
+   timestamp bytes) — a request's FIRST address against the call. (Rounds left stay placed.) Memory-query cells: 1 timestamp, 2 page, 3 index, 4 rw, 5 value_is_pointer; log-query cell 17: timestamp. */
 #define NLQ_REL_CONST 0xFF
-typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; uint8_t prev, gate2; } nlq_rel;
+typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; uint8_t prev, gate2, span; } nlq_rel;
 #define NLQ_MAX_RELS 40
 /* Sha256RoundFunction: the reads are reads of consecutive words of one page at the call's timestamp, the write is a write one tick
    later (sha256_round_function.rs:204-246: timestamp_to_use_for_read / _write); nothing is a pointer */
 #define NLQ_RELS_SHA256 { \
-    {NLQ_REL_CONST, 0, 1, 4, 1, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 2, 4, 2, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 3, 4, 3, 1, 0, 0xFF}, \
-    {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 3, 5, 3, 0, 0, 0xFF}, \
-    {1, 3, 2, 3, 2, 1, 0, 0xFF}, {1, 2, 2, 2, 2, 0, 0, 0xFF}, {1, 1, 2, 1, 2, 0, 0, 0xFF}, {1, 1, 3, 1, 3, 1, 0, 0xFF}, {0, 17, 1, 1, 0, 0, 0, 0xFF}, \
-    {2, 3, 1, 3, 1, 1, 1, 0}, {2, 2, 1, 2, 1, 0, 1, 0}, {2, 1, 1, 1, 1, 0, 1, 0}}
+    {NLQ_REL_CONST, 0, 1, 4, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 4, 2, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 3, 4, 3, 1, 0, 0xFF, 1}, \
+    {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 3, 5, 3, 0, 0, 0xFF, 1}, \
+    {1, 3, 2, 3, 2, 1, 0, 0xFF, 1}, {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {1, 1, 3, 1, 3, 1, 0, 0xFF, 1}, {0, 17, 1, 1, 0, 0, 0, 0xFF, 1}, \
+    {2, 3, 1, 3, 1, 1, 1, 0, 1}, {2, 2, 1, 2, 1, 0, 1, 0, 1}, {2, 1, 1, 1, 1, 0, 1, 0, 1}, \
+    {0, 24, 1, 3, 0, 0, 0, 0xFF, 4}, {0, 40, 1, 2, 0, 0, 0, 0xFF, 4}}
 /* CodeDecommitter: the code words are written (not pointers) to consecutive words of one page at one timestamp (decommit_code.rs:47-78) */
 #define NLQ_RELS_CODE_DECOMMITTER { \
-    {NLQ_REL_CONST, 0, 1, 4, 1, 1, 0, 0xFF}, {NLQ_REL_CONST, 0, 2, 4, 2, 1, 0, 0xFF}, {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF}, \
-    {1, 3, 2, 3, 2, 1, 0, 0xFF}, {1, 2, 2, 2, 2, 0, 0, 0xFF}, {1, 1, 2, 1, 2, 0, 0, 0xFF}, \
-    {2, 3, 1, 3, 1, 1, 1, 0}, {2, 2, 1, 2, 1, 0, 1, 0}, {2, 1, 1, 1, 1, 0, 1, 0}}
+    {NLQ_REL_CONST, 0, 1, 4, 1, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 4, 2, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF, 1}, \
+    {1, 3, 2, 3, 2, 1, 0, 0xFF, 1}, {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, \
+    {2, 3, 1, 3, 1, 1, 1, 0, 1}, {2, 2, 1, 2, 1, 0, 1, 0, 1}, {2, 1, 1, 1, 1, 0, 1, 0, 1}, \
+    {0, 9, 1, 2, 0, 0, 0, 0xFF, 4}, {0, 13, 1, 1, 0, 0, 0, 0xFF, 4}, {NLQ_REL_CONST, 0, 1, 3, 0, 0, 0, 0xFF, 1}}
 /* Keccak256RoundFunction: up to six reads of consecutive words of one page at one timestamp (a round may read nothing, so neither the
    call's timestamp nor the write's is tied to a read's inside one cycle) */
 #define NLQ_RELS_KECCAK256 { \
-    {NLQ_REL_CONST, 0, 1, 4, 1, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 2, 4, 2, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 3, 4, 3, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 4, 4, 4, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 5, 4, 5, 0, 0, 0xFF}, \
-    {NLQ_REL_CONST, 0, 6, 4, 6, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 7, 4, 7, 1, 0, 0xFF}, \
-    {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 3, 5, 3, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 4, 5, 4, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 5, 5, 5, 0, 0, 0xFF}, \
-    {NLQ_REL_CONST, 0, 6, 5, 6, 0, 0, 0xFF}, {NLQ_REL_CONST, 0, 7, 5, 7, 0, 0, 0xFF}, \
-    {1, 3, 2, 3, 2, 1, 0, 0xFF}, {2, 3, 3, 3, 3, 1, 0, 0xFF}, {3, 3, 4, 3, 4, 1, 0, 0xFF}, {4, 3, 5, 3, 5, 1, 0, 0xFF}, {5, 3, 6, 3, 6, 1, 0, 0xFF}, \
-    {1, 2, 2, 2, 2, 0, 0, 0xFF}, {2, 2, 3, 2, 3, 0, 0, 0xFF}, {3, 2, 4, 2, 4, 0, 0, 0xFF}, {4, 2, 5, 2, 5, 0, 0, 0xFF}, {5, 2, 6, 2, 6, 0, 0, 0xFF}, \
-    {1, 1, 2, 1, 2, 0, 0, 0xFF}, {2, 1, 3, 1, 3, 0, 0, 0xFF}, {3, 1, 4, 1, 4, 0, 0, 0xFF}, {4, 1, 5, 1, 5, 0, 0, 0xFF}, {5, 1, 6, 1, 6, 0, 0, 0xFF}}
+    {NLQ_REL_CONST, 0, 1, 4, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 4, 2, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 3, 4, 3, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 4, 4, 4, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 5, 4, 5, 0, 0, 0xFF, 1}, \
+    {NLQ_REL_CONST, 0, 6, 4, 6, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 7, 4, 7, 1, 0, 0xFF, 1}, \
+    {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 3, 5, 3, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 4, 5, 4, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 5, 5, 5, 0, 0, 0xFF, 1}, \
+    {NLQ_REL_CONST, 0, 6, 5, 6, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 7, 5, 7, 0, 0, 0xFF, 1}, \
+    {1, 3, 2, 3, 2, 1, 0, 0xFF, 1}, {2, 3, 3, 3, 3, 1, 0, 0xFF, 1}, {3, 3, 4, 3, 4, 1, 0, 0xFF, 1}, {4, 3, 5, 3, 5, 1, 0, 0xFF, 1}, {5, 3, 6, 3, 6, 1, 0, 0xFF, 1}, \
+    {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {2, 2, 3, 2, 3, 0, 0, 0xFF, 1}, {3, 2, 4, 2, 4, 0, 0, 0xFF, 1}, {4, 2, 5, 2, 5, 0, 0, 0xFF, 1}, {5, 2, 6, 2, 6, 0, 0, 0xFF, 1}, \
+    {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {2, 1, 3, 1, 3, 0, 0, 0xFF, 1}, {3, 1, 4, 1, 4, 0, 0, 0xFF, 1}, {4, 1, 5, 1, 5, 0, 0, 0xFF, 1}, {5, 1, 6, 1, 6, 0, 0, 0xFF, 1}}
 typedef struct nlq_rels { uint32_t n; nlq_rel r[NLQ_MAX_RELS]; } nlq_rels;
-static const nlq_rels NLQ_RELS_OF_SHA256 = {14, NLQ_RELS_SHA256};
-static const nlq_rels NLQ_RELS_OF_CODE_DECOMMITTER = {10, NLQ_RELS_CODE_DECOMMITTER};
+static const nlq_rels NLQ_RELS_OF_SHA256 = {16, NLQ_RELS_SHA256};
+static const nlq_rels NLQ_RELS_OF_CODE_DECOMMITTER = {13, NLQ_RELS_CODE_DECOMMITTER};
 static const nlq_rels NLQ_RELS_OF_KECCAK256 = {29, NLQ_RELS_KECCAK256};
-static const nlq_rels NLQ_RELS_NONE = {0, {{0, 0, 0, 0, 0, 0, 0, 0}}};
+static const nlq_rels NLQ_RELS_NONE = {0, {{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
 static inline const nlq_rels *nlq_rels_of(int circuit_type) {
     return circuit_type == 6 ? &NLQ_RELS_OF_SHA256 : circuit_type == 3 ? &NLQ_RELS_OF_CODE_DECOMMITTER : circuit_type == 5 ? &NLQ_RELS_OF_KECCAK256 : &NLQ_RELS_NONE;
 }

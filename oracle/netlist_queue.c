@@ -233,7 +233,11 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
             if (r->gate2 != NLQ_REL_CONST) en = orc_gl_sub(en, QCELL(nlq_op_row0(d, G, r->gate2), 0) % P);
             const uint64_t b = QCELL(nlq_op_row0(d, G, r->op_b), r->cell_b) % P;
             const uint32_t ca = r->prev ? c - 1 : c;
-            const uint64_t a = r->op_a == NLQ_REL_CONST ? 0 : TR(r->cell_a % G, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->op_a) + r->cell_a / G, ca)) % P;
+            uint64_t a = 0;
+            for (uint32_t k = 0; r->op_a != NLQ_REL_CONST && k < (r->span ? r->span : 1u); k++) { /* (span: little-endian recomposition of byte cells) */
+                const uint32_t cell = r->cell_a + k;
+                a = orc_gl_add(a, fmul_pow2(TR(cell % G, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->op_a) + cell / G, ca)), 8 * k));
+            }
             const uint64_t diff = orc_gl_sub(orc_gl_sub(b, a), (uint64_t)r->add);
             if (orc_gl_mul(en, diff) != 0) flag(&res, 7, 0x1000 + i, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->gate), c));
         }
