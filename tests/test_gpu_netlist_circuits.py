@@ -199,3 +199,56 @@ def test_code_decommitter_over_a_block(ctx, oracle):
     t.free()
     w.free()
     dec.free()
+
+
+@pytest.mark.parametrize("ct", [3, 13])
+def test_queue_section_tamper_parity_decommitter_and_linear_hasher(ctx, oracle, ct):
+    """the two checkers agree (violation count and smallest code) on tampered cells of the queue section of types 3 and 13 — the
+    full-width pop, the recomposition gates and cycle-dependent links of the L1 messages, the relations between operations — and on a
+    tampered hashed cell of the netlist, which the links must notice"""
+    import ctypes
+
+    from era_zkevm_test_harness_amd import native
+
+    rng = np.random.default_rng(100 + ct)
+    if ct == 3:
+        from oracle import block as ob
+
+        b = synthetic.block_after_vm(seed=2)
+        cap = cycles = 7
+        o = ob.create_artifacts_after_vm(b, {ob.CODE_DECOMMITTER: cap})["witnesses"]["code_decommitter"]
+        base = oracle.code_decommitter_synthesize(o, 1, cap, N_ROWS)
+        check, ocheck, cols = ctx.check_if_satisfied_code_decommitter, oracle.code_decommitter_check, native.DC_COLS
+        ocap = cap
+    else:
+        cap = 20
+        cycles = oracle.linear_hasher_cycles(cap)
+        q = synthetic.mixed_log_queue(60, seed=8)[:13]
+        base, _rec, _pi = oracle.linear_hasher_synthesize(q, np.zeros(1, native.QUEUE_STATE4), cap, N_ROWS)
+        check, ocheck, cols = ctx.check_if_satisfied_linear_hasher, oracle.linear_hasher_check, native.LH_COLS
+        ocap = cycles
+    assert ocheck(base, ocap) == (0, (0, 0, 0))
+    qg = oracle.nlq_geometry(ct, cycles)
+    G = oracle.nl_geometry(ct)["general"]
+    rpc = oracle.nl_geometry(ct)["rows_per_cycle"]
+    qc = lambda *a, **k: oracle.nlq_cell(ct, cycles, *a, **k)  # noqa: E731
+    cells = [qc(2, 0), qc(2, 1), qc(1, 0, -1, 0, 3), qc(1, 0, -1, 0, 10), qc(1, 1, -1, 0, 30), qc(2, 0, -1, 1, 2), qc(2, 0, -1, 2, 1), qc(2, 0, -1, 3, 0),
+             qc(2, 0, 0, 0, 5), qc(2, 0, 0, 0, 77), qc(3, 1, 0, 0, 129), qc(0, qg["ops"], k=1), qc(0, qg["ops"], k=G - 1), (G - 1, qc(2, 0)[1]), (G + 1, qc(2, 1)[1])]
+    if ct == 13:
+        cells += [qc(1, 0, -1, 0, 80), qc(1, 1, -1, 0, 108), qc(1, 0, -1, 0, 18), qc(1, 0, 2, 0, 40)]  # a written_value byte, a tx byte, tx_number, the third permutation
+    cells += [(int(rng.integers(0, G)), int(rng.integers(qg["first_row"], qg["rows_used"]))) for _ in range(20)]
+    cells += [(int(rng.integers(0, cols - 1)), int(rng.integers(rpc, 3 * rpc))) for _ in range(8)]  # the netlist of cycles 1-2: hashed cells among them
+    t = native.Trace(ctx, N_ROWS, 1, n_cols=cols)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    n_flagged = 0
+    for col, row in cells:
+        bad = base.copy()
+        bad[col, row] += 1
+        ctx.synchronize()
+        assert hip.hipMemcpy(t.device_ptr(0), bad.ctypes.data, bad.nbytes, 1) == 0
+        got, want = check(t, 0, cap), ocheck(bad, ocap)
+        assert got == want, ((col, row), got, want)
+        n_flagged += got[0] > 0
+    assert n_flagged >= len(cells) - 8
+    t.free()
