@@ -113,7 +113,8 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 3, 5, 3, 0, 0, 0xFF, 1}, \
     {1, 3, 2, 3, 2, 1, 0, 0xFF, 1}, {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {1, 1, 3, 1, 3, 1, 0, 0xFF, 1}, {0, 17, 1, 1, 0, 0, 0, 0xFF, 1}, \
     {2, 3, 1, 3, 1, 1, 1, 0, 1}, {2, 2, 1, 2, 1, 0, 1, 0, 1}, {2, 1, 1, 1, 1, 0, 1, 0, 1}, \
-    {0, 24, 1, 3, 0, 0, 0, 0xFF, 4}, {0, 40, 1, 2, 0, 0, 0, 0xFF, 4}}
+    {0, 24, 1, 3, 0, 0, 0, 0xFF, 4}, {0, 40, 1, 2, 0, 0, 0, 0xFF, 4}, \
+    {3, 0, 0, 0, 1, 0, 1, 0xFF, 1} /* a round that reads pops a call exactly when the round before wrote a digest: ties the write's free `en` to `reset` */}
 /* CodeDecommitter: the code words are written (not pointers) to consecutive words of one page at one timestamp (decommit_code.rs:47-78) */
 #define NLQ_RELS_CODE_DECOMMITTER { \
     {NLQ_REL_CONST, 0, 1, 4, 1, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 4, 2, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF, 1}, \
@@ -131,7 +132,7 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {2, 2, 3, 2, 3, 0, 0, 0xFF, 1}, {3, 2, 4, 2, 4, 0, 0, 0xFF, 1}, {4, 2, 5, 2, 5, 0, 0, 0xFF, 1}, {5, 2, 6, 2, 6, 0, 0, 0xFF, 1}, \
     {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {2, 1, 3, 1, 3, 0, 0, 0xFF, 1}, {3, 1, 4, 1, 4, 0, 0, 0xFF, 1}, {4, 1, 5, 1, 5, 0, 0, 0xFF, 1}, {5, 1, 6, 1, 6, 0, 0, 0xFF, 1}}
 typedef struct nlq_rels { uint32_t n; nlq_rel r[NLQ_MAX_RELS]; } nlq_rels;
-static const nlq_rels NLQ_RELS_OF_SHA256 = {16, NLQ_RELS_SHA256};
+static const nlq_rels NLQ_RELS_OF_SHA256 = {17, NLQ_RELS_SHA256};
 static const nlq_rels NLQ_RELS_OF_CODE_DECOMMITTER = {13, NLQ_RELS_CODE_DECOMMITTER};
 static const nlq_rels NLQ_RELS_OF_KECCAK256 = {29, NLQ_RELS_KECCAK256};
 static const nlq_rels NLQ_RELS_NONE = {0, {{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
