@@ -55,126 +55,95 @@ __device__ __forceinline__ bool same_cell_dev(const zkw_log_query* a, const zkw_
     return a->shard_id == b->shard_id && same_words(a->address, b->address, 5) && same_words(a->key, b->key, 8);
 }
 
-// block-wide inclusive scans over one 1024-item tile (16 waves), with a carry from the previous tiles
-__device__ __forceinline__ int tile_scan_add(int v, int* sh, int carry) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
-    if (lane == 63) sh[wave] = v;
-    __syncthreads();
-    int pre = carry;
-    for (int w = 0; w < wave; w++) pre += sh[w];
-    __syncthreads();
-    return v + pre;
-}
-__device__ __forceinline__ u32 tile_scan_max(u32 v, u32* sh, u32 carry) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { u32 o = __shfl_up(v, d, 64); if (lane >= d) v = v > o ? v : o; }
-    if (lane == 63) sh[wave] = v;
-    __syncthreads();
-    u32 pre = carry;
-    for (int w = 0; w < wave; w++) pre = pre > sh[w] ? pre : sh[w];
-    __syncthreads();
-    return v > pre ? v : pre;
-}
-
 __device__ __forceinline__ void cell_current_value(const zkw_log_query& m, u32 out[8]) {
     // forward write -> written value; rollback -> the value before the write; read -> the value read
     const bool fwd_write = m.rw_flag && !m.rollback;
     for (int k = 0; k < 8; k++) out[k] = fwd_write ? m.written_value[k] : m.read_value[k];
 }
 
-static __global__ __launch_bounds__(1024) void k_storage_cells(const zkw_log_query* __restrict__ sorted_q, size_t n, StorageScan sc,
-                                                        zkw_log_query* __restrict__ result_q, u64* __restrict__ result_enc,
-                                                        u32* __restrict__ totals /* [2]: n_result, violations */) {
-    __shared__ int sh_i[16];
-    __shared__ u32 sh_u[16];
-    __shared__ int carry_d;
-    __shared__ u32 carry_s, carry_r, carry_e, viol;
-    if (threadIdx.x == 0) { carry_d = 0; carry_s = 0; carry_r = 0; carry_e = 0; viol = 0; }
-    __syncthreads();
-    // sweep 1: D and S
-    for (size_t b0 = 0; b0 < n; b0 += 1024) {
-        const size_t i = b0 + threadIdx.x;
-        const bool live = i < n;
-        int delta = 0;
-        u32 start = 0;
-        if (live) {
-            const zkw_log_query* m = sorted_q + i;
-            delta = m->rw_flag ? (m->rollback ? -1 : 1) : 0;
-            const bool is_start = i == 0 || !same_cell_dev(m, m - 1);
-            start = is_start ? (u32)i : 0;
-            if (is_start && m->rw_flag && m->rollback) atomicAdd(&viol, 1u);  // sort_storage_access.rs:91 / storage_sort_dedup.rs:342
-            if (m->shard_id != 0) atomicAdd(&viol, 1u);
-        }
-        const int d = tile_scan_add(delta, sh_i, carry_d);
-        const u32 s = tile_scan_max(start, sh_u, carry_s);
-        if (live) { sc.D[i] = d; sc.S[i] = s; }
-        __syncthreads();
-        if (threadIdx.x == 1023) { carry_d = d; carry_s = s; }
-        __syncthreads();
+// ---- the per-cell registers and the deduplicated queue (sort_storage_access.rs:64-253) as TILED prefix passes (scan_kernels.cuh) —
+// the first version was one workgroup sweeping the queue three times. D = inclusive sum of the depth deltas (sum_prefix), S = first item
+// of an item's cell (flag_prefix over the cell starts numbers the cells, the starts scatter their index), R = reads seen at depth 0,
+// E = emitting cells (flag_prefix each), then one lane per item emits.
+struct StoDelta {
+    const zkw_log_query* q;
+    __device__ void operator()(size_t i, u64 v[1]) const { v[0] = q[i].rw_flag ? (q[i].rollback ? ~0ull : 1ull) : 0ull; }
+};
+struct StoIsStart {
+    const zkw_log_query* q;
+    __device__ u32 operator()(size_t i) const { return (i == 0 || !same_cell_dev(q + i, q + i - 1)) ? 1u : 0u; }
+};
+static __global__ __launch_bounds__(256) void k_storage_first(const u32* __restrict__ start_prefix, size_t n, u32* __restrict__ first) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && start_prefix[i + 1] != start_prefix[i]) first[start_prefix[i + 1] - 1] = (u32)i;
+}
+static __global__ __launch_bounds__(256) void k_storage_ds(const zkw_log_query* __restrict__ sorted_q, size_t n, const u64* __restrict__ delta_prefix,
+                                                           const u32* __restrict__ start_prefix, const u32* __restrict__ first, StorageScan sc, u32* __restrict__ viol) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const zkw_log_query* m = sorted_q + i;
+    const int delta = m->rw_flag ? (m->rollback ? -1 : 1) : 0;
+    sc.D[i] = (int)(long long)delta_prefix[i] + delta;
+    sc.S[i] = first[start_prefix[i + 1] - 1];
+    const bool is_start = start_prefix[i + 1] != start_prefix[i];
+    if (is_start && m->rw_flag && m->rollback) atomicAdd(viol, 1u);  // sort_storage_access.rs:91 / storage_sort_dedup.rs:342
+    if (m->shard_id != 0) atomicAdd(viol, 1u);
+}
+struct StoReadAtZero {  // a read at depth zero; a negative depth = a rollback without a pending write (changes_stack.pop().unwrap())
+    const zkw_log_query* q;
+    StorageScan sc;
+    u32* viol;
+    __device__ u32 operator()(size_t i) const {
+        const u32 s = sc.S[i];
+        const int depth = sc.D[i] - (s ? sc.D[s - 1] : 0);
+        if (depth < 0) atomicAdd(viol, 1u);
+        return (!q[i].rw_flag && depth == 0) ? 1u : 0u;
     }
-    // sweep 2: R (reads at depth zero)
-    for (size_t b0 = 0; b0 < n; b0 += 1024) {
-        const size_t i = b0 + threadIdx.x;
-        const bool live = i < n;
-        int flag = 0;
-        if (live) {
-            const u32 s = sc.S[i];
-            const int depth = sc.D[i] - (s ? sc.D[s - 1] : 0);
-            if (depth < 0) atomicAdd(&viol, 1u);  // a rollback without a pending write (changes_stack.pop().unwrap())
-            flag = (!sorted_q[i].rw_flag && depth == 0) ? 1 : 0;
-        }
-        const int r = tile_scan_add(flag, sh_i, (int)carry_r);
-        if (live) sc.R[i] = (u32)r;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_r = (u32)r;
-        __syncthreads();
-    }
-    // sweep 3: E and the compaction of the deduplicated queries (sort_storage_access.rs:205-253)
-    for (size_t b0 = 0; b0 < n; b0 += 1024) {
-        const size_t i = b0 + threadIdx.x;
-        const bool live = i < n;
-        int emits = 0;
-        zkw_log_query me;
-        u32 s = 0;
-        int depth = 0;
-        if (live) {
-            load_log(sorted_q + i, me);
-            s = sc.S[i];
-            depth = sc.D[i] - (s ? sc.D[s - 1] : 0);
-            const bool has = sc.R[i] - (s ? sc.R[s - 1] : 0) > 0;
-            const bool cell_last = i + 1 == n || sc.S[i + 1] != s;
-            emits = (cell_last && (depth > 0 || has)) ? 1 : 0;
-        }
-        const int e = tile_scan_add(emits, sh_i, (int)carry_e);
-        if (live) {
-            sc.E[i] = (u32)e;
-            if (emits) {
-                u32 cur[8];
-                cell_current_value(me, cur);
-                const zkw_log_query* first = sorted_q + s;
-                bool eq = true;
-                for (int k = 0; k < 8; k++) eq &= cur[k] == first->read_value[k];
-                if (depth == 0 && !eq) atomicAdd(&viol, 1u);  // sort_storage_access.rs:198-203
-                zkw_log_query r;
-                memset(&r, 0, sizeof r);
-                r.shard_id = me.shard_id;
-                for (int k = 0; k < 5; k++) r.address[k] = me.address[k];
-                for (int k = 0; k < 8; k++) { r.key[k] = me.key[k]; r.read_value[k] = first->read_value[k]; r.written_value[k] = cur[k]; }
-                r.rw_flag = eq ? 0 : 1;
-                store_log(result_q + (e - 1), r);
-                u64 enc[20];
-                encode_log_query(r, false, 0, enc);
-                store_enc20(result_enc + 20 * (size_t)(e - 1), enc);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_e = (u32)e;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { totals[0] = carry_e; totals[1] = viol; }
+};
+__device__ __forceinline__ bool storage_emits(const StorageScan& sc, const u32* __restrict__ read_prefix, size_t n, size_t i, u32& s, int& depth) {
+    s = sc.S[i];
+    depth = sc.D[i] - (s ? sc.D[s - 1] : 0);
+    const bool has = read_prefix[i + 1] - read_prefix[s] > 0;  // (inclusive counts: R[i] - R[s - 1])
+    const bool cell_last = i + 1 == n || sc.S[i + 1] != s;
+    return cell_last && (depth > 0 || has);
+}
+struct StoEmits {
+    StorageScan sc;
+    const u32* read_prefix;
+    size_t n;
+    __device__ u32 operator()(size_t i) const { u32 s; int depth; return storage_emits(sc, read_prefix, n, i, s, depth) ? 1u : 0u; }
+};
+static __global__ __launch_bounds__(256) void k_storage_emit(const zkw_log_query* __restrict__ sorted_q, size_t n, StorageScan sc, const u32* __restrict__ read_prefix,
+                                                             const u32* __restrict__ emit_prefix, zkw_log_query* __restrict__ result_q, u64* __restrict__ result_enc,
+                                                             u32* __restrict__ totals /* [2]: n_result, violations (accumulated by the passes before) */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) totals[0] = emit_prefix[n];
+    if (i >= n) return;
+    sc.R[i] = read_prefix[i + 1];
+    const u32 e = emit_prefix[i + 1];
+    sc.E[i] = e;
+    if (e == emit_prefix[i]) return;
+    u32 s;
+    int depth;
+    (void)storage_emits(sc, read_prefix, n, i, s, depth);
+    zkw_log_query me;
+    load_log(sorted_q + i, me);
+    u32 cur[8];
+    cell_current_value(me, cur);
+    const zkw_log_query* first = sorted_q + s;
+    bool eq = true;
+    for (int k = 0; k < 8; k++) eq &= cur[k] == first->read_value[k];
+    if (depth == 0 && !eq) atomicAdd(&totals[1], 1u);  // sort_storage_access.rs:198-203
+    zkw_log_query r;
+    memset(&r, 0, sizeof r);
+    r.shard_id = me.shard_id;
+    for (int k = 0; k < 5; k++) r.address[k] = me.address[k];
+    for (int k = 0; k < 8; k++) { r.key[k] = me.key[k]; r.read_value[k] = first->read_value[k]; r.written_value[k] = cur[k]; }
+    r.rw_flag = eq ? 0 : 1;
+    store_log(result_q + (e - 1), r);
+    u64 enc[20];
+    encode_log_query(r, false, 0, enc);
+    store_enc20(result_enc + 20 * (size_t)(e - 1), enc);
 }
 
 struct StorageBlock {

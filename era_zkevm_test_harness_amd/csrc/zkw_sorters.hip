@@ -629,7 +629,7 @@ struct zkw_storage_witness {
     u64* lhs_enc = nullptr;    // [n][20]: unsorted with extended timestamp (permutation argument only)
     u64* tails_all = nullptr;  // [5n][4]
     u64 *challenges = nullptr, *lhs_z = nullptr, *rhs_z = nullptr;
-    u32* scans = nullptr;  // [4][n]: D, S, R, E of k_storage_cells (kept for synthesis)
+    u32* scans = nullptr;  // [4][n]: D, S, R, E of the per-cell prefix passes (k_storage_ds / k_storage_emit; kept for synthesis)
     zkw_storage_sorter_instance* instances = nullptr;
     u64* cf_pi = nullptr;  // compact forms [ni][18] | public inputs [ni][4]
     void release() {
@@ -690,8 +690,27 @@ static int storage_run(zkw_ctx* ctx, zkw_storage_witness* w, const zkw_log_query
     sc.R = w->scans + 2 * n;
     sc.E = w->scans + 3 * n;
     ZKW_TRY(ctx->scratch_t<u32>("sto_totals", 2, &totals));
-    { Prof _p(ctx, "k_storage_cells"); hipLaunchKernelGGL(k_storage_cells, dim3(1), dim3(1024), 0, ctx->stream, w->sorted_q, n, sc, w->result_q, r_enc, totals); }
-    ZKW_TRY(launch_check("k_storage_cells"));
+    {   // tiled prefix passes (storage_kernels.cuh): depth deltas, cell starts, reads at depth zero, emitting cells
+        u64 *d_dpfx = nullptr, *d_dtot = nullptr;
+        u32 *d_spfx = nullptr, *d_rpfx = nullptr, *d_epfx = nullptr, *d_first = nullptr;
+        ZKW_TRY(ctx->scratch_t<u64>("sto_dpfx", n + 1, &d_dpfx));
+        ZKW_TRY(ctx->scratch_t<u64>("sto_dtot", 1, &d_dtot));
+        ZKW_TRY(ctx->scratch_t<u32>("sto_spfx", n + 1, &d_spfx));
+        ZKW_TRY(ctx->scratch_t<u32>("sto_rpfx", n + 1, &d_rpfx));
+        ZKW_TRY(ctx->scratch_t<u32>("sto_epfx", n + 1, &d_epfx));
+        ZKW_TRY(ctx->scratch_t<u32>("sto_first", n, &d_first));
+        HIP_TRY(hipMemsetAsync(totals, 0, 2 * sizeof(u32), ctx->stream));
+        ZKW_TRY((sum_prefix<1>(ctx, "k_storage_depth_prefix", StoDelta{w->sorted_q}, n, d_dpfx, d_dtot)));
+        ZKW_TRY(flag_prefix(ctx, "k_storage_start_prefix", StoIsStart{w->sorted_q}, n, d_spfx));
+        { Prof _p(ctx, "k_storage_first"); hipLaunchKernelGGL(k_storage_first, dim3(grid), dim3(256), 0, ctx->stream, d_spfx, n, d_first); }
+        ZKW_TRY(launch_check("k_storage_first"));
+        { Prof _p(ctx, "k_storage_ds"); hipLaunchKernelGGL(k_storage_ds, dim3(grid), dim3(256), 0, ctx->stream, w->sorted_q, n, d_dpfx, d_spfx, d_first, sc, totals + 1); }
+        ZKW_TRY(launch_check("k_storage_ds"));
+        ZKW_TRY(flag_prefix(ctx, "k_storage_read_prefix", StoReadAtZero{w->sorted_q, sc, totals + 1}, n, d_rpfx));
+        ZKW_TRY(flag_prefix(ctx, "k_storage_emit_prefix", StoEmits{sc, d_rpfx, n}, n, d_epfx));
+        { Prof _p(ctx, "k_storage_emit"); hipLaunchKernelGGL(k_storage_emit, dim3(grid), dim3(256), 0, ctx->stream, w->sorted_q, n, sc, d_rpfx, d_epfx, w->result_q, r_enc, totals); }
+        ZKW_TRY(launch_check("k_storage_emit"));
+    }
     u32 h_totals[2] = {0, 0};
     ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
     if (h_totals[1]) return fail(ZKW_ERR_CHECK_FAILED, "storage log is not a consistent history (%u violations of the asserts at "
