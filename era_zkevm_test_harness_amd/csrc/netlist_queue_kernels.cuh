@@ -245,14 +245,14 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
         for (u32 i = 0; i < rels.n; i++) {
             const nlq_rel r = rels.r[i];
             if (r.prev && c == 0) continue;
-            u64 en = gl::canon(nlq_cell_at(S, trace, n_rows, capacity, c, nlq_op_row0(&d, G, r.gate), 0));
+            u64 en = r.gate == NLQ_REL_ACTIVE ? gl::canon(gl::sub(1, gl::canon(NLQ_TR(NL_HDR_IDLE, (size_t)c * S.rows_per_cycle)))) : gl::canon(nlq_cell_at(S, trace, n_rows, capacity, c, nlq_op_row0(&d, G, r.gate), 0));
             if (r.gate2 != NLQ_REL_CONST) en = gl::canon(gl::sub(en, gl::canon(nlq_cell_at(S, trace, n_rows, capacity, c, nlq_op_row0(&d, G, r.gate2), 0))));
             const u64 b = gl::canon(nlq_cell_at(S, trace, n_rows, capacity, c, nlq_op_row0(&d, G, r.op_b), r.cell_b));
             u64 a = 0;
             for (u32 k = 0; r.op_a != NLQ_REL_CONST && k < (r.span ? r.span : 1u); k++)  // (span: little-endian recomposition of byte cells)
                 a = gl::canon(gl::add(a, gl::mul(gl::canon(nlq_cell_at(S, trace, n_rows, capacity, r.prev ? c - 1 : c, nlq_op_row0(&d, G, r.op_a), r.cell_a + k)), 1ull << (8 * k))));
-            const u64 diff = gl::canon(gl::sub(gl::canon(gl::sub(b, a)), (u64)r.add));
-            if (gl::canon(gl::mul(en, diff)) != 0) flag_bad(res, 7, 0x1000 + i, NLQ_ROW(&S, capacity, nlq_op_row0(&d, G, r.gate), c));
+            const u64 diff = gl::canon(gl::sub(gl::canon(r.prev == 3 ? gl::add(b, a) : gl::sub(b, a)), (u64)r.add));
+            if (gl::canon(gl::mul(en, diff)) != 0) flag_bad(res, 7, 0x1000 + i, NLQ_ROW(&S, capacity, nlq_op_row0(&d, G, r.gate == NLQ_REL_ACTIVE ? r.op_b : r.gate), c));
         }
     const nlq_op op = d.ops[j];
     const u32 w = nlq_kind_width(op.kind), ncomp = nlq_item_comps(op.item), nenc = nlq_item_enc(op.item), r0 = nlq_op_row0(&d, G, j);

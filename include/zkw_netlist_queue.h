@@ -98,12 +98,13 @@ static const nlq_desc NLQ_DESC_LINEAR_HASHER = {2, 1, {4, 0}, {
 
 /* RELATIONS between the fields of a cycle's operations — the part of the circuits' FSM arithmetic that is visible inside one cycle:
    en(gate) * (cell_b of op_b - cell_a of op_a - add) = 0; op_a = NLQ_REL_CONST: en(gate) * (cell_b of op_b - add) = 0.
-   prev = 1: cell_a is taken from the PREVIOUS cycle (no relation at cycle 0: an instance's first cycle continues from the FSM input,
+   prev = 1 (3: and NEGATED: b + a - add): cell_a is taken from the PREVIOUS cycle (no relation at cycle 0: an instance's first cycle continues from the FSM input,
    which is placed) and the factor is en(gate) - en(gate2): "this round reads and does not start a request" — the word offset carried
    from round to round. span = n > 1: the operand is the little-endian recomposition of n byte cells cell_a .. cell_a + n - 1 (a limb of
    the popped call's ABI: key bytes 0..3 = input offset, 16..19 = page to read — precompile_abi_in_log; a decommit request's page /
    timestamp bytes) — a request's FIRST address against the call. (Rounds left stay placed.) Memory-query cells: 1 timestamp, 2 page, 3 index, 4 rw, 5 value_is_pointer; log-query cell 17: timestamp. */
 #define NLQ_REL_CONST 0xFF
+#define NLQ_REL_ACTIVE 0xFE /* as a gate: the factor is 1 - idle of the cycle's netlist header (circuits without an always-on operation) */
 typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; uint8_t prev, gate2, span; } nlq_rel;
 #define NLQ_MAX_RELS 40
 /* Sha256RoundFunction: the reads are reads of consecutive words of one page at the call's timestamp, the write is a write one tick
@@ -120,7 +121,8 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {NLQ_REL_CONST, 0, 1, 4, 1, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 4, 2, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF, 1}, \
     {1, 3, 2, 3, 2, 1, 0, 0xFF, 1}, {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, \
     {2, 3, 1, 3, 1, 1, 1, 0, 1}, {2, 2, 1, 2, 1, 0, 1, 0, 1}, {2, 1, 1, 1, 1, 0, 1, 0, 1}, \
-    {0, 9, 1, 2, 0, 0, 0, 0xFF, 4}, {0, 13, 1, 1, 0, 0, 0, 0xFF, 4}, {NLQ_REL_CONST, 0, 1, 3, 0, 0, 0, 0xFF, 1}}
+    {0, 9, 1, 2, 0, 0, 0, 0xFF, 4}, {0, 13, 1, 1, 0, 0, 0, 0xFF, 4}, {NLQ_REL_CONST, 0, 1, 3, 0, 0, 0, 0xFF, 1}, \
+    {2, 0, 0, 0, 1, 1, 3, 0xFF, 1} /* a round pops a request exactly when the round before wrote only one word (a bytecode's last round): en_pop + en_word1(prev) = 1 */}
 /* Keccak256RoundFunction: up to six reads of consecutive words of one page at one timestamp (a round may read nothing, so neither the
    call's timestamp nor the write's is tied to a read's inside one cycle) */
 #define NLQ_RELS_KECCAK256 { \
@@ -130,11 +132,12 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {NLQ_REL_CONST, 0, 6, 5, 6, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 7, 5, 7, 0, 0, 0xFF, 1}, \
     {1, 3, 2, 3, 2, 1, 0, 0xFF, 1}, {2, 3, 3, 3, 3, 1, 0, 0xFF, 1}, {3, 3, 4, 3, 4, 1, 0, 0xFF, 1}, {4, 3, 5, 3, 5, 1, 0, 0xFF, 1}, {5, 3, 6, 3, 6, 1, 0, 0xFF, 1}, \
     {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {2, 2, 3, 2, 3, 0, 0, 0xFF, 1}, {3, 2, 4, 2, 4, 0, 0, 0xFF, 1}, {4, 2, 5, 2, 5, 0, 0, 0xFF, 1}, {5, 2, 6, 2, 6, 0, 0, 0xFF, 1}, \
-    {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {2, 1, 3, 1, 3, 0, 0, 0xFF, 1}, {3, 1, 4, 1, 4, 0, 0, 0xFF, 1}, {4, 1, 5, 1, 5, 0, 0, 0xFF, 1}, {5, 1, 6, 1, 6, 0, 0, 0xFF, 1}}
+    {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {2, 1, 3, 1, 3, 0, 0, 0xFF, 1}, {3, 1, 4, 1, 4, 0, 0, 0xFF, 1}, {4, 1, 5, 1, 5, 0, 0, 0xFF, 1}, {5, 1, 6, 1, 6, 0, 0, 0xFF, 1}, \
+    {7, 0, 0, 0, NLQ_REL_ACTIVE, 0, 1, 0xFF, 1} /* an active round pops a call exactly when the round before wrote a digest */}
 typedef struct nlq_rels { uint32_t n; nlq_rel r[NLQ_MAX_RELS]; } nlq_rels;
 static const nlq_rels NLQ_RELS_OF_SHA256 = {17, NLQ_RELS_SHA256};
-static const nlq_rels NLQ_RELS_OF_CODE_DECOMMITTER = {13, NLQ_RELS_CODE_DECOMMITTER};
-static const nlq_rels NLQ_RELS_OF_KECCAK256 = {29, NLQ_RELS_KECCAK256};
+static const nlq_rels NLQ_RELS_OF_CODE_DECOMMITTER = {14, NLQ_RELS_CODE_DECOMMITTER};
+static const nlq_rels NLQ_RELS_OF_KECCAK256 = {30, NLQ_RELS_KECCAK256};
 static const nlq_rels NLQ_RELS_NONE = {0, {{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
 static inline const nlq_rels *nlq_rels_of(int circuit_type) {
     return circuit_type == 6 ? &NLQ_RELS_OF_SHA256 : circuit_type == 3 ? &NLQ_RELS_OF_CODE_DECOMMITTER : circuit_type == 5 ? &NLQ_RELS_OF_KECCAK256 : &NLQ_RELS_NONE;

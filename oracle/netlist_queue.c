@@ -229,7 +229,7 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
         for (uint32_t i = 0; i < rels->n; i++) {
             const nlq_rel *r = &rels->r[i];
             if (r->prev && c == 0) continue;
-            uint64_t en = QCELL(nlq_op_row0(d, G, r->gate), 0) % P;
+            uint64_t en = r->gate == NLQ_REL_ACTIVE ? orc_gl_sub(1, TR(NL_HDR_IDLE, (size_t)c * sp->rows_per_cycle) % P) : QCELL(nlq_op_row0(d, G, r->gate), 0) % P;
             if (r->gate2 != NLQ_REL_CONST) en = orc_gl_sub(en, QCELL(nlq_op_row0(d, G, r->gate2), 0) % P);
             const uint64_t b = QCELL(nlq_op_row0(d, G, r->op_b), r->cell_b) % P;
             const uint32_t ca = r->prev ? c - 1 : c;
@@ -238,8 +238,8 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
                 const uint32_t cell = r->cell_a + k;
                 a = orc_gl_add(a, fmul_pow2(TR(cell % G, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->op_a) + cell / G, ca)), 8 * k));
             }
-            const uint64_t diff = orc_gl_sub(orc_gl_sub(b, a), (uint64_t)r->add);
-            if (orc_gl_mul(en, diff) != 0) flag(&res, 7, 0x1000 + i, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->gate), c));
+            const uint64_t diff = orc_gl_sub(r->prev == 3 ? orc_gl_add(b, a) : orc_gl_sub(b, a), (uint64_t)r->add);
+            if (orc_gl_mul(en, diff) != 0) flag(&res, 7, 0x1000 + i, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->gate == NLQ_REL_ACTIVE ? r->op_b : r->gate), c));
         }
     /* QBND */
     for (uint32_t q = 0; q < d->n_queues; q++) {
