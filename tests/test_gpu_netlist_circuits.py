@@ -252,3 +252,38 @@ def test_queue_section_tamper_parity_decommitter_and_linear_hasher(ctx, oracle, 
         n_flagged += got[0] > 0
     assert n_flagged >= len(cells) - 8
     t.free()
+
+
+def test_production_geometry_decommitter_and_linear_hasher(ctx, oracle):
+    """2^20 rows at the reference capacities (2845 SHA-256 rounds / 774 messages) with the queue sections: synthesized and checked on the GPU"""
+    from era_zkevm_test_harness_amd import native
+
+    n_rows = 1 << 20
+    for ct in (3, 13):
+        lay = native.circuit_layout(ct)
+        assert int(lay["fits"]) == 1 and int(lay["queue_rows_per_cycle"]) > 0 and int(lay["rows_used"]) <= n_rows
+    # CodeDecommitter: the bytecodes of a synthetic block at capacity 2845
+    b = synthetic.block_after_vm(seed=2)
+    cap = int(native.circuit_geometry(3)["capacity"])
+    dec = ctx.compute_decommitts_sorter_circuit_snapshots(b["decommit_queries"], 5)
+    dq, dt = dec.get(native.DEC_DEDUP_QUERIES), dec.get(native.DEC_DEDUP_TAILS)
+    codes = [b["bytecodes"][h.tobytes()] for h in dq["hash"]]
+    woff = np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]).astype(np.uint64)
+    w = ctx.compute_decommitter_circuit_snapshots(dq, dt, np.concatenate(codes), woff, cap, np.zeros(1, native.QUEUE_STATE12))
+    t = native.Trace(ctx, n_rows, 1, n_cols=native.DC_COLS)
+    ctx.synthesize_code_decommitter(w, t, 0, 1, 0)
+    assert ctx.check_if_satisfied_code_decommitter(t, 0, cap) == (0, (0, 0, 0))
+    t.free(); w.free(); dec.free()
+    # L1MessagesHasher: a full queue of 774 messages, the queue's states handed in
+    cap = int(native.circuit_geometry(13)["capacity"])
+    q = synthetic.mixed_log_queue(4 * cap + 100, seed=5)[:cap]
+    assert q.size == cap
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(q))[1]
+    t = native.Trace(ctx, n_rows, 1, n_cols=native.LH_COLS)
+    rec, _pi = ctx.synthesize_linear_hasher_batch([q], np.zeros(1, native.QUEUE_STATE4), cap, t, 0, tails=[tails])
+    assert rec["keccak256_hash"][0].tobytes() == oracle.linear_keccak256(q)
+    assert ctx.check_if_satisfied_linear_hasher(t, 0, cap) == (0, (0, 0, 0))
+    lay = native.circuit_layout(13)
+    qb = t.get(0, 0, 8)[:, int(lay["queue_first_row"])]  # QBND: the head before (zeros) | after = the state after the last push
+    assert qb[:4].tolist() == [0, 0, 0, 0] and qb[4:8].tolist() == np.asarray(tails[-1]).tolist()
+    t.free()
