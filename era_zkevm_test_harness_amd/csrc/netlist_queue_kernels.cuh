@@ -196,6 +196,15 @@ static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict_
         st.at(r0, ncomp + nenc + g) = old;
         st.at(r0, ncomp + nenc + w + g) = nw;
     }
+    if (g < op.extra) {  // registers: a limb of the request the cycle is working on (the last one operation 0 popped)
+        const nlq_feed f0 = job.feed[(size_t)c * d.n_ops];
+        const NlqQueueIn& Q0 = job.queues[d.ops[0].queue];
+        const long long cur = (long long)f0.idx - (f0.en ? 0 : 1);
+        const void* rec0 = cur >= 0 && (u64)cur < Q0.n_items ? static_cast<const char*>(Q0.items) + (size_t)cur * nlq_item_bytes(d.ops[0].item) : nullptr;
+        u64 v = 0;
+        for (u32 i = 0; i < 4; i++) v |= nlq_item_component(d.ops[0].item, rec0, op.reg_cell[g] + i) << (8 * i);
+        if (valid) st.at(r0, ncomp + nenc + 2 * w + g) = v;
+    }
     // QBND: the queue states before cycle 0 (written by the first operation on the queue) and after the last cycle (by the last)
     const size_t q0 = NLQ_BASE(&S, capacity);
     bool first = true, last = true;
@@ -256,7 +265,7 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
         }
     const nlq_op op = d.ops[j];
     const u32 w = nlq_kind_width(op.kind), ncomp = nlq_item_comps(op.item), nenc = nlq_item_enc(op.item), r0 = nlq_op_row0(&d, G, j);
-    const u32 ncells = ncomp + nenc + 2 * w, erows = nlq_rows_for(ncells, G);
+    const u32 ncells = nlq_enc_cells(&op), erows = nlq_rows_for(ncells, G);
     const u64 row_e = NLQ_ROW(&S, capacity, r0, c);
     auto cell = [&](u32 k) { return nlq_cell_at(S, trace, n_rows, capacity, c, r0, k); };
     const u64 en = cell(0);

@@ -53,7 +53,9 @@ enum { NLQ_LINK_NONE = 0, NLQ_LINK_SHA_BLOCK = 1, NLQ_LINK_SHA_DIGEST = 2,
           or the next one. All 88 bytes are linked: shard_id, is_service, the address and key bytes (bytes in the encoding anyway) and the
           tx_number / written_value bytes of NLQ_ITEM_LOGB (the encoding takes their limbs: nlq_aux_* recompose them). */ };
 
-typedef struct nlq_op { uint8_t kind, item, queue, en_rule, link, link_arg; } nlq_op;
+typedef struct nlq_op { uint8_t kind, item, queue, en_rule, link, link_arg;
+                         uint8_t extra, reg_cell[2]; /* REGISTER cells after `new`: register r holds the limb (four byte cells from reg_cell[r]) of the
+                            request the cycle is working on (the item operation 0 popped last) — FSM state carried by relations (nlq_rel) */ } nlq_op;
 typedef struct nlq_desc { uint32_t n_ops, n_queues; uint32_t width[NLQ_MAX_QUEUES]; nlq_op ops[NLQ_MAX_OPS]; } nlq_desc;
 typedef struct nlq_feed { uint32_t en; uint32_t idx; } nlq_feed; /* per (cycle, op): enabled?, index of the item (enabled) / of the queue's next item (disabled) */
 typedef struct nlq_term { uint16_t cell; uint16_t shift; } nlq_term;
@@ -62,31 +64,31 @@ typedef struct nlq_term { uint16_t cell; uint16_t shift; } nlq_term;
    CodeDecommitter (3): pop the decommit request (first round of a bytecode), write two code words (the second one is missing in the
    last round of a bytecode with an odd word count). */
 static const nlq_desc NLQ_DESC_SHA256 = {4, 2, {4, 12}, {
-    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0},
-    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 0},
-    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 1},
-    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_FREE, NLQ_LINK_SHA_DIGEST, 0}}};
+    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 1, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_FREE, NLQ_LINK_SHA_DIGEST, 0, 2, {24 + 20, 24 + 8}}}}; /* registers: the ABI's page to write (key bytes 20..23), output offset (8..11) */
 static const nlq_desc NLQ_DESC_CODE_DECOMMITTER = {3, 2, {12, 12}, {
-    {NLQ_POP12, NLQ_ITEM_DECOMMIT, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0},
-    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 0},
-    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_FREE, NLQ_LINK_SHA_BLOCK, 1}}};
+    {NLQ_POP12, NLQ_ITEM_DECOMMIT, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_FREE, NLQ_LINK_SHA_BLOCK, 1, 0, {0, 0}}}};
 
 /* Keccak256RoundFunction (5): pop the precompile call (first round of a request), up to MEMORY_READS_PER_CYCLE = 6 reads into the byte
    buffer (keccak256_round_function.rs:232-290: unaligned, so which buffer bytes a word lands on is data — the reads are NOT linked to
    the block), write the digest after a request's last round (linked). */
 static const nlq_desc NLQ_DESC_KECCAK256 = {8, 2, {4, 12}, {
-    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0},
-    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0},
-    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0},
-    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0},
-    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_KECCAK_DIGEST, 0}}};
+    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_KECCAK_DIGEST, 0, 0, {0, 0}}}};
 
 /* L1MessagesHasher (13): the circuit pops EVERY message of the queue and hashes its 88-byte serialisation (linear_hasher in the absent
    crate; out of circuit data_hasher_and_merklizer.rs:8-67). A message is popped in the cycle that absorbs its first byte — cycle
    floor(88 m / 136), at most two per cycle. Which block bytes a message lands on depends on the cycle (period 11): the links of its
    byte-valued fields (NLQ_LINK_LH_MESSAGE; link_arg = the slot 0 / 1 of the cycle) are a function of the cycle. One queue. */
 static const nlq_desc NLQ_DESC_LINEAR_HASHER = {2, 1, {4, 0}, {
-    {NLQ_POP4, NLQ_ITEM_LOGB, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 0}, {NLQ_POP4, NLQ_ITEM_LOGB, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 1}}};
+    {NLQ_POP4, NLQ_ITEM_LOGB, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 0, 0, {0, 0}}, {NLQ_POP4, NLQ_ITEM_LOGB, 0, NLQ_EN_FREE, NLQ_LINK_LH_MESSAGE, 1, 0, {0, 0}}}};
 /* messages whose first byte is absorbed by cycle c: [nlq_lh_first(c), nlq_lh_first(c + 1)) */
 #define NLQ_LH_FIRST(c) (((uint64_t)(c) * 136 + 87) / 88)
 
@@ -115,7 +117,10 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {1, 3, 2, 3, 2, 1, 0, 0xFF, 1}, {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {1, 1, 3, 1, 3, 1, 0, 0xFF, 1}, {0, 17, 1, 1, 0, 0, 0, 0xFF, 1}, \
     {2, 3, 1, 3, 1, 1, 1, 0, 1}, {2, 2, 1, 2, 1, 0, 1, 0, 1}, {2, 1, 1, 1, 1, 0, 1, 0, 1}, \
     {0, 24, 1, 3, 0, 0, 0, 0xFF, 4}, {0, 40, 1, 2, 0, 0, 0, 0xFF, 4}, \
-    {3, 0, 0, 0, 1, 0, 1, 0xFF, 1} /* a round that reads pops a call exactly when the round before wrote a digest: ties the write's free `en` to `reset` */}
+    {3, 0, 0, 0, 1, 0, 1, 0xFF, 1} /* a round that reads pops a call exactly when the round before wrote a digest: ties the write's free `en` to `reset` */, \
+    {0, 44, 3, 102, 0, 0, 0, 0xFF, 4}, {0, 32, 3, 103, 0, 0, 0, 0xFF, 4} /* a pop loads the registers (cells 102, 103 of the write: page / offset to write) from the call's ABI */, \
+    {3, 102, 3, 102, 1, 0, 1, 0, 1}, {3, 103, 3, 103, 1, 0, 1, 0, 1} /* a round that continues a request keeps them */, \
+    {3, 102, 3, 2, 3, 0, 0, 0xFF, 1}, {3, 103, 3, 3, 3, 0, 0, 0xFF, 1} /* the digest is written where the call said */}
 /* CodeDecommitter: the code words are written (not pointers) to consecutive words of one page at one timestamp (decommit_code.rs:47-78) */
 #define NLQ_RELS_CODE_DECOMMITTER { \
     {NLQ_REL_CONST, 0, 1, 4, 1, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 4, 2, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF, 1}, \
@@ -135,7 +140,7 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {2, 1, 3, 1, 3, 0, 0, 0xFF, 1}, {3, 1, 4, 1, 4, 0, 0, 0xFF, 1}, {4, 1, 5, 1, 5, 0, 0, 0xFF, 1}, {5, 1, 6, 1, 6, 0, 0, 0xFF, 1}, \
     {7, 0, 0, 0, NLQ_REL_ACTIVE, 0, 1, 0xFF, 1} /* an active round pops a call exactly when the round before wrote a digest */}
 typedef struct nlq_rels { uint32_t n; nlq_rel r[NLQ_MAX_RELS]; } nlq_rels;
-static const nlq_rels NLQ_RELS_OF_SHA256 = {17, NLQ_RELS_SHA256};
+static const nlq_rels NLQ_RELS_OF_SHA256 = {23, NLQ_RELS_SHA256};
 static const nlq_rels NLQ_RELS_OF_CODE_DECOMMITTER = {14, NLQ_RELS_CODE_DECOMMITTER};
 static const nlq_rels NLQ_RELS_OF_KECCAK256 = {30, NLQ_RELS_KECCAK256};
 static const nlq_rels NLQ_RELS_NONE = {0, {{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
@@ -157,7 +162,8 @@ NLQ_HD uint32_t nlq_item_enc(uint32_t item) { return item == NLQ_ITEM_LOG || ite
 NLQ_HD uint32_t nlq_enc0(const nlq_op *op) { return nlq_item_comps(op->item); }
 NLQ_HD uint32_t nlq_old0(const nlq_op *op) { return nlq_enc0(op) + nlq_item_enc(op->item); }
 NLQ_HD uint32_t nlq_new0(const nlq_op *op) { return nlq_old0(op) + nlq_kind_width(op->kind); }
-NLQ_HD uint32_t nlq_enc_cells(const nlq_op *op) { return nlq_new0(op) + nlq_kind_width(op->kind); }
+NLQ_HD uint32_t nlq_reg0(const nlq_op *op) { return nlq_new0(op) + nlq_kind_width(op->kind); }
+NLQ_HD uint32_t nlq_enc_cells(const nlq_op *op) { return nlq_reg0(op) + op->extra; }
 NLQ_HD uint32_t nlq_rows_for(uint32_t cells, uint32_t g) { return (cells + g - 1) / g; }
 NLQ_HD uint32_t nlq_op_rows(const nlq_op *op, uint32_t g) { return nlq_rows_for(nlq_enc_cells(op), g) + nlq_kind_perms(op->kind) * nlq_rows_for(NLQ_P2_CELLS, g); }
 /* first row (within a cycle's operations) of operation j / of its P2 block p */

@@ -96,7 +96,16 @@ int orc_nlq_synthesize(int circuit_type, uint32_t capacity, const nlq_feed *feed
                 cells[ncomp + nenc + k] = old[k];
                 cells[ncomp + nenc + w + k] = f.en ? out[k] : old[k];
             }
-            for (uint32_t k = 0; k < ncomp + nenc + 2 * w; k++) QCELL(r0, k) = cells[k];
+            for (uint32_t r = 0; r < op->extra; r++) { /* registers: a limb of the request the cycle is working on (the last one operation 0 popped) */
+                const nlq_feed f0 = feed[(size_t)c * d->n_ops];
+                const orc_nlq_queue *Q0 = &queues[d->ops[0].queue];
+                const int64_t cur = (int64_t)f0.idx - (f0.en ? 0 : 1);
+                const void *rec0 = cur >= 0 && (uint64_t)cur < Q0->n_items ? (const char *)Q0->items + (size_t)cur * nlq_item_bytes(d->ops[0].item) : NULL;
+                uint64_t v = 0;
+                for (uint32_t i = 0; i < 4; i++) v |= nlq_item_component(d->ops[0].item, rec0, op->reg_cell[r] + i) << (8 * i);
+                cells[ncomp + nenc + 2 * w + r] = v;
+            }
+            for (uint32_t k = 0; k < nlq_enc_cells(op); k++) QCELL(r0, k) = cells[k];
         }
     /* QBND: the queue states before cycle 0 and after the last cycle */
     for (uint32_t q = 0; q < d->n_queues; q++) {
@@ -148,7 +157,7 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
         for (uint32_t j = 0; j < d->n_ops; j++) {
             const nlq_op *op = &d->ops[j];
             const uint32_t w = nlq_kind_width(op->kind), ncomp = nlq_item_comps(op->item), nenc = nlq_item_enc(op->item), r0 = nlq_op_row0(d, G, j);
-            const uint32_t ncells = ncomp + nenc + 2 * w, erows = nlq_rows_for(ncells, G);
+            const uint32_t ncells = nlq_enc_cells(op), erows = nlq_rows_for(ncells, G);
             const uint64_t row_e = NLQ_ROW(sp, capacity, r0, c);
             uint64_t cells[160];
             for (uint32_t k = 0; k < ncells; k++) cells[k] = QCELL(r0, k);

@@ -146,6 +146,21 @@ def test_section_tampering_is_caught(oracle, ct):
         n, first = check(synth(bo, inst, cap, N_ROWS), cap)
         first_in_instance = r == int(bo["instances"]["first_round"][inst])
         assert (n == 0) if first_in_instance else (n > 0 and first[0] == 7 and first[1] >= 0x1000 + 11), (n, first)
+    # ... and a digest written to another page than the call's ABI names (self-consistent again): only the registers that carry the ABI's
+    # page / offset to write from the pop to the request's last round object
+    if ct == 6:
+        resets = o["sha256_rounds"]["reset"]
+        last = int(np.flatnonzero(resets)[1]) - 1                       # the last round of the first request
+        wq = 2 * last + int(np.count_nonzero(resets[:last + 1])) - 1 + 2  # its write query
+        assert o["mem_queries"]["rw_flag"][wq] == 1
+        bo = dict(o)
+        mq = bo["mem_queries"].copy()
+        mq["page"][wq] += 1
+        bo["mem_queries"] = mq
+        bo["mem_tails"] = oracle.queue_push_chain_full(oracle.encode_memory_queries(mq), np.asarray(bo["mem_in"]["tail"][0], dtype=np.uint64))
+        inst = int(np.searchsorted(np.cumsum(bo["instances"]["num_rounds"]), last, side="right"))
+        n, first = check(synth(bo, inst, cap, N_ROWS), cap)
+        assert n == 1 and first[0] == 7 and first[1] == 0x1000 + 21, (n, first)
     if ct == 5:
         return
     # a message nibble of the hash netlist that a memory word's value copies: the link notices (kind 2 in the section's rows)
