@@ -81,7 +81,7 @@ static const nlq_desc NLQ_DESC_KECCAK256 = {8, 2, {4, 12}, {
     {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}},
     {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}},
     {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}},
-    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_KECCAK_DIGEST, 0, 0, {0, 0}}}};
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_KECCAK_DIGEST, 0, 2, {24 + 20, 24 + 8}}}}; /* registers: the ABI's page to write, output offset */
 
 /* L1MessagesHasher (13): the circuit pops EVERY message of the queue and hashes its 88-byte serialisation (linear_hasher in the absent
    crate; out of circuit data_hasher_and_merklizer.rs:8-67). A message is popped in the cycle that absorbs its first byte — cycle
@@ -138,11 +138,13 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {1, 3, 2, 3, 2, 1, 0, 0xFF, 1}, {2, 3, 3, 3, 3, 1, 0, 0xFF, 1}, {3, 3, 4, 3, 4, 1, 0, 0xFF, 1}, {4, 3, 5, 3, 5, 1, 0, 0xFF, 1}, {5, 3, 6, 3, 6, 1, 0, 0xFF, 1}, \
     {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {2, 2, 3, 2, 3, 0, 0, 0xFF, 1}, {3, 2, 4, 2, 4, 0, 0, 0xFF, 1}, {4, 2, 5, 2, 5, 0, 0, 0xFF, 1}, {5, 2, 6, 2, 6, 0, 0, 0xFF, 1}, \
     {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {2, 1, 3, 1, 3, 0, 0, 0xFF, 1}, {3, 1, 4, 1, 4, 0, 0, 0xFF, 1}, {4, 1, 5, 1, 5, 0, 0, 0xFF, 1}, {5, 1, 6, 1, 6, 0, 0, 0xFF, 1}, \
-    {7, 0, 0, 0, NLQ_REL_ACTIVE, 0, 1, 0xFF, 1} /* an active round pops a call exactly when the round before wrote a digest */}
+    {7, 0, 0, 0, NLQ_REL_ACTIVE, 0, 1, 0xFF, 1} /* an active round pops a call exactly when the round before wrote a digest */, \
+    {0, 44, 7, 70, 0, 0, 0, 0xFF, 4}, {0, 32, 7, 71, 0, 0, 0, 0xFF, 4}, {7, 70, 7, 70, NLQ_REL_ACTIVE, 0, 1, 0, 1}, {7, 71, 7, 71, NLQ_REL_ACTIVE, 0, 1, 0, 1}, \
+    {7, 70, 7, 2, 7, 0, 0, 0xFF, 1}, {7, 71, 7, 3, 7, 0, 0, 0xFF, 1} /* the registers (cells 70, 71 of the write): loaded by a pop, kept by a round that continues a request, the digest is written there */}
 typedef struct nlq_rels { uint32_t n; nlq_rel r[NLQ_MAX_RELS]; } nlq_rels;
 static const nlq_rels NLQ_RELS_OF_SHA256 = {23, NLQ_RELS_SHA256};
 static const nlq_rels NLQ_RELS_OF_CODE_DECOMMITTER = {14, NLQ_RELS_CODE_DECOMMITTER};
-static const nlq_rels NLQ_RELS_OF_KECCAK256 = {30, NLQ_RELS_KECCAK256};
+static const nlq_rels NLQ_RELS_OF_KECCAK256 = {36, NLQ_RELS_KECCAK256};
 static const nlq_rels NLQ_RELS_NONE = {0, {{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
 static inline const nlq_rels *nlq_rels_of(int circuit_type) {
     return circuit_type == 6 ? &NLQ_RELS_OF_SHA256 : circuit_type == 3 ? &NLQ_RELS_OF_CODE_DECOMMITTER : circuit_type == 5 ? &NLQ_RELS_OF_KECCAK256 : &NLQ_RELS_NONE;
