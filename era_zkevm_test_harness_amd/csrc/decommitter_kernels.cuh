@@ -42,7 +42,7 @@ __device__ __forceinline__ void sha256_compress(u32 st[8], u32 w[16]) {
 
 // what a round of a builder's walk does to the queues of its circuit (the queue section of the netlist circuits,
 // netlist_queue_kernels.cuh): the request it belongs to, the index of the first memory query it pushes, how many it pushes,
-// flags: 1 = the round pops its request, 2 = the last push is the digest write (sha256)
+// flags: 1 = the round pops its request, 2 = the last push is the digest write (sha256); bits 8.. = rounds left after this one (sha256)
 struct RoundOps { u32 request, first_query, n_push, flags; };
 
 struct DecommitterJob {

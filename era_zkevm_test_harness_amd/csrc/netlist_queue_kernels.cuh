@@ -56,7 +56,7 @@ static __global__ __launch_bounds__(64) void k_nlq_feed(int circuit_type, const 
     } else if (circuit_type == 6) {
         f[1] = nlq_feed{1, ro.first_query};
         f[2] = nlq_feed{1, ro.first_query + 1};
-        f[3] = nlq_feed{(ro.flags >> 1) & 1, ro.first_query + 2};
+        f[3] = nlq_feed{(ro.flags >> 1) & 1, ro.first_query + 2, ro.flags >> 8};  // aux: rounds left after this one
     } else {
         f[1] = nlq_feed{1, ro.first_query};
         f[2] = nlq_feed{ro.n_push > 1 ? 1u : 0u, ro.first_query + 1};
@@ -202,7 +202,8 @@ static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict_
         const long long cur = (long long)f0.idx - (f0.en ? 0 : 1);
         const void* rec0 = cur >= 0 && (u64)cur < Q0.n_items ? static_cast<const char*>(Q0.items) + (size_t)cur * nlq_item_bytes(d.ops[0].item) : nullptr;
         u64 v = 0;
-        for (u32 i = 0; i < 4; i++) v |= nlq_item_component(d.ops[0].item, rec0, op.reg_cell[g] + i) << (8 * i);
+        if (g >= 2) v = f.aux;  // a counter the feed supplies
+        else for (u32 i = 0; i < 4; i++) v |= nlq_item_component(d.ops[0].item, rec0, op.reg_cell[g] + i) << (8 * i);
         if (valid) st.at(r0, ncomp + nenc + 2 * w + g) = v;
     }
     // QBND: the queue states before cycle 0 (written by the first operation on the queue) and after the last cycle (by the last)
@@ -260,7 +261,7 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
             u64 a = 0;
             for (u32 k = 0; r.op_a != NLQ_REL_CONST && k < (r.span ? r.span : 1u); k++)  // (span: little-endian recomposition of byte cells)
                 a = gl::canon(gl::add(a, gl::mul(gl::canon(nlq_cell_at(S, trace, n_rows, capacity, r.prev ? c - 1 : c, nlq_op_row0(&d, G, r.op_a), r.cell_a + k)), 1ull << (8 * k))));
-            const u64 diff = gl::canon(gl::sub(gl::canon(r.prev == 3 ? gl::add(b, a) : gl::sub(b, a)), (u64)r.add));
+            const u64 diff = gl::canon(gl::sub(gl::canon(r.prev == 3 ? gl::add(b, a) : gl::sub(b, a)), r.add >= 0 ? (u64)r.add : gl::P - (u64)(-r.add)));
             if (gl::canon(gl::mul(en, diff)) != 0) flag_bad(res, 7, 0x1000 + i, NLQ_ROW(&S, capacity, nlq_op_row0(&d, G, r.gate == NLQ_REL_ACTIVE ? r.op_b : r.gate), c));
         }
     const nlq_op op = d.ops[j];

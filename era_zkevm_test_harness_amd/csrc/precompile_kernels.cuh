@@ -131,7 +131,7 @@ static __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job
 #pragma unroll
                 for (int m = 0; m < 8; m++) rec[m] = (u64)__builtin_bswap32(w[2 * m]) | ((u64)__builtin_bswap32(w[2 * m + 1]) << 32);
             }
-            if (job.round_ops) job.round_ops[g0 + round] = RoundOps{(u32)r, (u32)(qpos - 2), is_last_round ? 3u : 2u, (round == 0 ? 1u : 0u) | (is_last_round ? 2u : 0u)};
+            if (job.round_ops) job.round_ops[g0 + round] = RoundOps{(u32)r, (u32)(qpos - 2), is_last_round ? 3u : 2u, (round == 0 ? 1u : 0u) | (is_last_round ? 2u : 0u) | ((u32)(rounds_left - 1) << 8)};  // (bits 8..: rounds left after this one)
             sha256_compress(sha, w);  // expands the schedule in place
             if (rec) {
                 rec[8] = (u64)(round == 0 ? 1u : 0u) | ((u64)sha[0] << 32);

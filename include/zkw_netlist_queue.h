@@ -57,7 +57,7 @@ typedef struct nlq_op { uint8_t kind, item, queue, en_rule, link, link_arg;
                          uint8_t extra, reg_cell[2]; /* REGISTER cells after `new`: register r holds the limb (four byte cells from reg_cell[r]) of the
                             request the cycle is working on (the item operation 0 popped last) — FSM state carried by relations (nlq_rel) */ } nlq_op;
 typedef struct nlq_desc { uint32_t n_ops, n_queues; uint32_t width[NLQ_MAX_QUEUES]; nlq_op ops[NLQ_MAX_OPS]; } nlq_desc;
-typedef struct nlq_feed { uint32_t en; uint32_t idx; } nlq_feed; /* per (cycle, op): enabled?, index of the item (enabled) / of the queue's next item (disabled) */
+typedef struct nlq_feed { uint32_t en; uint32_t idx; uint32_t aux; } nlq_feed; /* per (cycle, op): enabled?, index of the item (enabled) / of the queue's next item (disabled); aux: the value of the operation's registers beyond the first two (SHA-256: rounds left) */
 typedef struct nlq_term { uint16_t cell; uint16_t shift; } nlq_term;
 
 /* Sha256RoundFunction (6): pop the precompile call (first round of a request), read two words, write the digest (last round).
@@ -67,7 +67,7 @@ static const nlq_desc NLQ_DESC_SHA256 = {4, 2, {4, 12}, {
     {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0, 0, {0, 0}},
     {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 0, 0, {0, 0}},
     {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 1, 0, {0, 0}},
-    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_FREE, NLQ_LINK_SHA_DIGEST, 0, 2, {24 + 20, 24 + 8}}}}; /* registers: the ABI's page to write (key bytes 20..23), output offset (8..11) */
+    {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_FREE, NLQ_LINK_SHA_DIGEST, 0, 3, {24 + 20, 24 + 8}}}}; /* registers: the ABI's page to write (key bytes 20..23), output offset (8..11); rounds left after this one (nlq_feed.aux) */
 static const nlq_desc NLQ_DESC_CODE_DECOMMITTER = {3, 2, {12, 12}, {
     {NLQ_POP12, NLQ_ITEM_DECOMMIT, 0, NLQ_EN_RESET, NLQ_LINK_NONE, 0, 0, {0, 0}},
     {NLQ_PUSH12, NLQ_ITEM_MEM, 1, NLQ_EN_ACTIVE, NLQ_LINK_SHA_BLOCK, 0, 0, {0, 0}},
@@ -120,7 +120,8 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {3, 0, 0, 0, 1, 0, 1, 0xFF, 1} /* a round that reads pops a call exactly when the round before wrote a digest: ties the write's free `en` to `reset` */, \
     {0, 44, 3, 102, 0, 0, 0, 0xFF, 4}, {0, 32, 3, 103, 0, 0, 0, 0xFF, 4} /* a pop loads the registers (cells 102, 103 of the write: page / offset to write) from the call's ABI */, \
     {3, 102, 3, 102, 1, 0, 1, 0, 1}, {3, 103, 3, 103, 1, 0, 1, 0, 1} /* a round that continues a request keeps them */, \
-    {3, 102, 3, 2, 3, 0, 0, 0xFF, 1}, {3, 103, 3, 3, 3, 0, 0, 0xFF, 1} /* the digest is written where the call said */}
+    {3, 102, 3, 2, 3, 0, 0, 0xFF, 1}, {3, 103, 3, 3, 3, 0, 0, 0xFF, 1} /* the digest is written where the call said */, \
+    {0, 48, 3, 104, 0, -1, 0, 0xFF, 4}, {3, 104, 3, 104, 1, -1, 1, 0, 1}, {NLQ_REL_CONST, 0, 3, 104, 3, 0, 0, 0xFF, 1} /* rounds left (cell 104): a pop loads the ABI's round count (key bytes 24..27) - 1, a continuing round counts down, the digest is written at zero */}
 /* CodeDecommitter: the code words are written (not pointers) to consecutive words of one page at one timestamp (decommit_code.rs:47-78) */
 #define NLQ_RELS_CODE_DECOMMITTER { \
     {NLQ_REL_CONST, 0, 1, 4, 1, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 4, 2, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF, 1}, \
@@ -142,7 +143,7 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {0, 44, 7, 70, 0, 0, 0, 0xFF, 4}, {0, 32, 7, 71, 0, 0, 0, 0xFF, 4}, {7, 70, 7, 70, NLQ_REL_ACTIVE, 0, 1, 0, 1}, {7, 71, 7, 71, NLQ_REL_ACTIVE, 0, 1, 0, 1}, \
     {7, 70, 7, 2, 7, 0, 0, 0xFF, 1}, {7, 71, 7, 3, 7, 0, 0, 0xFF, 1} /* the registers (cells 70, 71 of the write): loaded by a pop, kept by a round that continues a request, the digest is written there */}
 typedef struct nlq_rels { uint32_t n; nlq_rel r[NLQ_MAX_RELS]; } nlq_rels;
-static const nlq_rels NLQ_RELS_OF_SHA256 = {23, NLQ_RELS_SHA256};
+static const nlq_rels NLQ_RELS_OF_SHA256 = {26, NLQ_RELS_SHA256};
 static const nlq_rels NLQ_RELS_OF_CODE_DECOMMITTER = {14, NLQ_RELS_CODE_DECOMMITTER};
 static const nlq_rels NLQ_RELS_OF_KECCAK256 = {36, NLQ_RELS_KECCAK256};
 static const nlq_rels NLQ_RELS_NONE = {0, {{0, 0, 0, 0, 0, 0, 0, 0, 0}}};

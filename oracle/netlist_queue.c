@@ -10,6 +10,7 @@
 #include <string.h>
 #include "oracle.h"
 #include "../include/zkw_netlist_queue.h"
+#pragma GCC diagnostic ignored "-Wmissing-field-initializers" /* (nlq_feed){en, idx}: aux = 0 */
 
 #define P ZKW_GOLDILOCKS_P
 #define TR(c, r) trace[(size_t)(c) * n_rows + (size_t)(r)]
@@ -102,7 +103,8 @@ int orc_nlq_synthesize(int circuit_type, uint32_t capacity, const nlq_feed *feed
                 const int64_t cur = (int64_t)f0.idx - (f0.en ? 0 : 1);
                 const void *rec0 = cur >= 0 && (uint64_t)cur < Q0->n_items ? (const char *)Q0->items + (size_t)cur * nlq_item_bytes(d->ops[0].item) : NULL;
                 uint64_t v = 0;
-                for (uint32_t i = 0; i < 4; i++) v |= nlq_item_component(d->ops[0].item, rec0, op->reg_cell[r] + i) << (8 * i);
+                if (r >= 2) v = f.aux; /* a counter the feed supplies */
+                else for (uint32_t i = 0; i < 4; i++) v |= nlq_item_component(d->ops[0].item, rec0, op->reg_cell[r] + i) << (8 * i);
                 cells[ncomp + nenc + 2 * w + r] = v;
             }
             for (uint32_t k = 0; k < nlq_enc_cells(op); k++) QCELL(r0, k) = cells[k];
@@ -247,7 +249,7 @@ uint64_t orc_nlq_check(int circuit_type, const uint64_t *trace, uint32_t capacit
                 const uint32_t cell = r->cell_a + k;
                 a = orc_gl_add(a, fmul_pow2(TR(cell % G, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->op_a) + cell / G, ca)), 8 * k));
             }
-            const uint64_t diff = orc_gl_sub(r->prev == 3 ? orc_gl_add(b, a) : orc_gl_sub(b, a), (uint64_t)r->add);
+            const uint64_t diff = orc_gl_sub(r->prev == 3 ? orc_gl_add(b, a) : orc_gl_sub(b, a), r->add >= 0 ? (uint64_t)r->add : P - (uint64_t)(-r->add));
             if (orc_gl_mul(en, diff) != 0) flag(&res, 7, 0x1000 + i, NLQ_ROW(sp, capacity, nlq_op_row0(d, G, r->gate == NLQ_REL_ACTIVE ? r->op_b : r->gate), c));
         }
     /* QBND */
@@ -286,7 +288,9 @@ void orc_sha256_queue_feed(const zkw_sha256_round_record *rounds, size_t total_r
         f[1] = (nlq_feed){1, (uint32_t)q};
         f[2] = (nlq_feed){1, (uint32_t)q + 1};
         q += 2;
-        f[3] = (nlq_feed){(uint32_t)last, (uint32_t)q};
+        size_t end = r + 1; /* the request's rounds end before the next reset */
+        while (end < total_rounds && !rounds[end].reset) end++;
+        f[3] = (nlq_feed){(uint32_t)last, (uint32_t)q, (uint32_t)(end - r - 1)};
         if (last) q++;
     }
 }
@@ -352,6 +356,10 @@ int orc_nlq_standalone(int circuit_type, const zkw_sha256_round_record *rounds, 
     uint64_t *rstates = NULL;
     if (sha) {
         req = calloc(n_req + 1, sizeof(zkw_log_query));
+        for (size_t k = 0, r = 0; r < n_active; r++) { /* a call's ABI names its number of rounds (key limb 6) */
+            if (rounds[r].reset) k++;
+            if (k) ((zkw_log_query *)req)[k - 1].key[6]++;
+        }
         uint64_t *renc = calloc(n_req * 20 + 1, 8);
         rstates = calloc(n_req * 4 + 1, 8);
         orc_encode_log_queries(req, n_req, NULL, renc);

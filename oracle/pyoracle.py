@@ -662,7 +662,7 @@ def nl_geometry(circuit_type):
     return dict(zip(("cols", "general", "width", "lookups_per_row", "table_rows", "rows_per_cycle"), (int(x) for x in out)))
 
 
-NLQ_FEED = np.dtype([("en", np.uint32), ("idx", np.uint32)])
+NLQ_FEED = np.dtype([("en", np.uint32), ("idx", np.uint32), ("aux", np.uint32)])
 
 
 class _NlqQueue(C.Structure):
