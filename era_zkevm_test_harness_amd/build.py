@@ -16,6 +16,8 @@ SOURCES = ["zkw_api.hip", "zkw_sorters.hip", "zkw_precompiles.hip", "zkw_setup.h
            "sort.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+if os.environ.get("ZKW_PROBE_BUILD"):  # measurement knobs that produce invalid traces (ZKW_NL_PROBE); never in the default library
+    FLAGS.append("-DZKW_PROBE_BUILD")
 
 
 def _deps():

@@ -915,20 +915,33 @@ extern "C" int zkw_blocks_gather_closed_form_inputs(zkw_block* const* blocks, si
                                                     size_t max_per_block, uint64_t* out) {
     if (!comm || (n_blocks && !blocks) || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || max_per_block == 0) return ZKW_ERR_INVALID;
     const size_t words = 1 + 24 * max_per_block;
+    // A failure that only this rank can see (a block that was not built, a block with too many instances) must not keep the
+    // rank out of the collective — the others would wait for it forever. The block's record travels with an error sentinel
+    // in its count word instead; the failing rank AND the root return the error after the gather.
+    const uint64_t BAD = ~0ull;
+    int local_rc = ZKW_OK;
     std::vector<uint32_t> owner(n_blocks);
     std::vector<uint64_t> mine;
     for (size_t k = 0; k < n_blocks; k++) {
         owner[k] = (uint32_t)zkw_blocks_owner(k, world);
         if ((int)owner[k] != rank) continue;
-        zkw_block* B = blocks[k];
-        if (!B) return ZKW_ERR_INVALID;
-        std::vector<uint8_t> types;
-        std::vector<uint32_t> index, one;
-        int rc = shard_plan(B, 1, &types, &index, &one);
-        if (rc != ZKW_OK) return rc;
-        if (types.size() > max_per_block) { g_block_error = "zkw_blocks_gather_closed_form_inputs: block has more instances than max_per_block"; return ZKW_ERR_INVALID; }
         const size_t base = mine.size();
         mine.resize(base + words, 0);
+        zkw_block* B = blocks[k];
+        std::vector<uint8_t> types;
+        std::vector<uint32_t> index, one;
+        int rc = B ? shard_plan(B, 1, &types, &index, &one) : ZKW_ERR_INVALID;
+        if (rc == ZKW_OK && types.size() > max_per_block) {
+            g_block_error = "zkw_blocks_gather_closed_form_inputs: block has more instances than max_per_block";
+            rc = ZKW_ERR_INVALID;
+        } else if (!B) {
+            g_block_error = "zkw_blocks_gather_closed_form_inputs: a block this rank owns is NULL";
+        }
+        if (rc != ZKW_OK) {
+            mine[base] = BAD;
+            if (local_rc == ZKW_OK) local_rc = rc;
+            continue;
+        }
         mine[base] = types.size();
         for (size_t i = 0; i < types.size(); i++) {
             const PerType& p = B->per[types[i]];
@@ -939,6 +952,18 @@ extern "C" int zkw_blocks_gather_closed_form_inputs(zkw_block* const* blocks, si
             std::copy(p.pi.begin() + 4 * index[i], p.pi.begin() + 4 * (index[i] + 1), r + 20);
         }
     }
-    if (rank == root && n_blocks && !out) return ZKW_ERR_INVALID;
-    return zkw_gather_records(comm, owner.data(), n_blocks, mine.data(), words * 8, root, out);
+    std::vector<uint64_t> sink;  // a root without an output array still takes part, then reports the bad argument
+    const bool no_out = rank == root && n_blocks && !out;
+    if (no_out) sink.resize(n_blocks * words);
+    int rc = zkw_gather_records(comm, owner.data(), n_blocks, mine.data(), words * 8, root, no_out ? sink.data() : out);
+    if (rc != ZKW_OK) return rc;
+    if (local_rc != ZKW_OK) return local_rc;
+    if (no_out) return ZKW_ERR_INVALID;
+    if (rank == root)
+        for (size_t k = 0; k < n_blocks; k++)
+            if (out[k * words] == BAD) {
+                g_block_error = "zkw_blocks_gather_closed_form_inputs: the owner of block " + std::to_string(k) + " (rank " + std::to_string(owner[k]) + ") reported a failure";
+                return ZKW_ERR_INVALID;
+            }
+    return ZKW_OK;
 }

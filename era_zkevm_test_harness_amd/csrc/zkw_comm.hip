@@ -9,15 +9,19 @@
 //   * RCCL  — device pointers, enqueued on the context's stream, xGMI inside a node. Resolved with dlopen when a
 //             communicator of more than one rank is created: libzkw does not link against it, a single-GPU host never
 //             loads it, and a failure to find it is an error code, not a load failure.
-//   * TCP   — a full mesh of loopback / LAN sockets (rank j connects to every i < j at port + i). Host pointers when
-//             the communicator has no context, device pointers staged through pinned host memory when it has one. It
-//             exists so that the collective's logic (unequal counts, empty ranks, root != 0, rank order) is exercised by
-//             multi-process tests on machines without GPUs, and as the transport of last resort where RCCL cannot start.
+//   * TCP   — a full mesh of sockets on ONE host (every rank binds and connects on the same `address`, 127.0.0.1 unless
+//             told otherwise: rank j connects to every i < j at port + i). Host pointers when the communicator has no
+//             context, device pointers staged through host memory when it has one. It exists so that the collective's
+//             logic (unequal counts, empty ranks, root != 0, rank order) is exercised by multi-process tests on machines
+//             without GPUs, and as the transport of last resort where RCCL cannot start. The hello carries a job id
+//             (ZKW_COMM_JOB_ID, 64 bits, 0 when unset) next to the rank: a process of another job that reaches the port
+//             is turned away. It is a test / fallback transport for one trusted host, not an authenticated channel.
 #include <arpa/inet.h>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <rccl/rccl.h>
 #include <sys/socket.h>
 #include <unistd.h>
@@ -149,6 +153,7 @@ struct TcpTransport : Transport {
         const char* c = static_cast<const char*>(p);
         while (n) {
             ssize_t k = ::send(f, c, n, MSG_NOSIGNAL);
+            if (k < 0 && (errno == EINTR || errno == EAGAIN || errno == EWOULDBLOCK)) continue;
             if (k <= 0) return -1;
             c += k;
             n -= (size_t)k;
@@ -159,6 +164,7 @@ struct TcpTransport : Transport {
         char* c = static_cast<char*>(p);
         while (n) {
             ssize_t k = ::recv(f, c, n, 0);
+            if (k < 0 && (errno == EINTR || errno == EAGAIN || errno == EWOULDBLOCK)) continue;
             if (k <= 0) return -1;
             c += k;
             n -= (size_t)k;
@@ -220,14 +226,14 @@ extern "C" int zkw_comm_unique_id(uint8_t id[ZKW_COMM_ID_BYTES]) {
     return ZKW_OK;
 }
 
-extern "C" int zkw_comm_init(zkw_ctx* ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, zkw_comm** out) {
-    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return zkw_fail(ZKW_ERR_INVALID, "zkw_comm_init: bad argument");
+static int comm_init(zkw_ctx* ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, bool force_rccl, zkw_comm** out) {
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || ((world > 1 || force_rccl) && !id)) return zkw_fail(ZKW_ERR_INVALID, "zkw_comm_init: bad argument");
     if (hipSetDevice(zkw_ctx_device(ctx)) != hipSuccess) return zkw_fail(ZKW_ERR_HIP, "zkw_comm_init: hipSetDevice failed");
     zkw_comm* c = new zkw_comm();
     c->ctx = ctx;
     c->rank = rank;
     c->world = world;
-    if (world == 1) {  // a single rank needs no transport at all
+    if (world == 1 && !force_rccl) {  // a single rank needs no transport at all
         LocalTransport* t = new LocalTransport();
         t->stream = static_cast<hipStream_t>(zkw_ctx_stream(ctx));
         t->device = true;
@@ -248,6 +254,31 @@ extern "C" int zkw_comm_init(zkw_ctx* ctx, const uint8_t id[ZKW_COMM_ID_BYTES], 
     return ZKW_OK;
 }
 
+extern "C" int zkw_comm_init(zkw_ctx* ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, zkw_comm** out) {
+    return comm_init(ctx, id, rank, world, false, out);
+}
+
+// The RCCL transport whatever the world size: with world == 1 this is ncclCommInitRank over one rank, so that the dlopen,
+// the symbol table, the stream ordering and the error paths of the transport run on a single-GPU host (tests).
+extern "C" int zkw_comm_init_rccl(zkw_ctx* ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, zkw_comm** out) {
+    return comm_init(ctx, id, rank, world, true, out);
+}
+
+// One grouped send + receive of `bytes` from this rank to `peer` and back from it through the communicator's transport table
+// (peer == own rank: a send to self matched by a receive from self inside one group, which RCCL supports). src / dst as in
+// zkw_gather_closed_form_inputs (device pointers; host pointers on a context-less TCP communicator; they must not overlap).
+// Enqueued on the stream (zkw_comm_synchronize). The local transport has no peers and refuses.
+extern "C" int zkw_comm_exchange(zkw_comm* c, const void* src, void* dst, size_t bytes, int peer) {
+    if (!c || !src || !dst || bytes == 0 || peer < 0 || peer >= c->world) return zkw_fail(ZKW_ERR_INVALID, "zkw_comm_exchange: bad argument");
+    if (c->ctx && hipSetDevice(zkw_ctx_device(c->ctx)) != hipSuccess) return zkw_fail(ZKW_ERR_HIP, "hipSetDevice failed");
+    Transport& t = *c->tp;
+    int rc = t.begin();
+    if (rc != ZKW_OK) return rc;
+    if ((rc = t.send(src, bytes, peer)) != ZKW_OK) return rc;
+    if ((rc = t.recv(dst, bytes, peer)) != ZKW_OK) return rc;
+    return t.end();
+}
+
 extern "C" int zkw_comm_init_tcp(zkw_ctx* ctx, const char* address, int port, int rank, int world, int timeout_ms, zkw_comm** out) {
     if (!out || !address || world < 1 || rank < 0 || rank >= world || port <= 0 || port + world > 65535) return zkw_fail(ZKW_ERR_INVALID, "zkw_comm_init_tcp: bad argument");
     if (ctx && hipSetDevice(zkw_ctx_device(ctx)) != hipSuccess) return zkw_fail(ZKW_ERR_HIP, "zkw_comm_init_tcp: hipSetDevice failed");
@@ -255,7 +286,13 @@ extern "C" int zkw_comm_init_tcp(zkw_ctx* ctx, const char* address, int port, in
     t->fd.assign((size_t)world, -1);
     t->device = ctx != nullptr;
     if (ctx) t->stream = static_cast<hipStream_t>(zkw_ctx_stream(ctx));
-    auto fail_with = [&](const char* what) { delete t; return zkw_fail(ZKW_ERR_HIP, "zkw_comm_init_tcp (rank %d): %s: %s", rank, what, strerror(errno)); };
+    auto fail_with = [&](const char* what) {
+        const int err = errno;  // before the cleanup's close() calls can change it
+        delete t;
+        return zkw_fail(ZKW_ERR_HIP, "zkw_comm_init_tcp (rank %d): %s: %s", rank, what, strerror(err));
+    };
+    struct Hello { uint64_t job; int32_t rank; int32_t world; } hello{0, rank, world};
+    if (const char* j = getenv("ZKW_COMM_JOB_ID")) hello.job = strtoull(j, nullptr, 0);
     sockaddr_in sa{};
     sa.sin_family = AF_INET;
     if (inet_pton(AF_INET, address, &sa.sin_addr) != 1) { delete t; return zkw_fail(ZKW_ERR_INVALID, "zkw_comm_init_tcp: '%s' is not an IPv4 address", address); }
@@ -277,8 +314,7 @@ extern "C" int zkw_comm_init_tcp(zkw_ctx* ctx, const char* address, int port, in
             sa.sin_port = htons((uint16_t)(port + peer));
             if (connect(f, reinterpret_cast<sockaddr*>(&sa), sizeof sa) == 0) {
                 setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-                const int32_t me = rank;
-                if (TcpTransport::write_all(f, &me, sizeof me) != 0) { close(f); if (lfd >= 0) close(lfd); return fail_with("hello"); }
+                if (TcpTransport::write_all(f, &hello, sizeof hello) != 0) { close(f); if (lfd >= 0) close(lfd); return fail_with("hello"); }
                 t->fd[peer] = f;
                 break;
             }
@@ -287,18 +323,33 @@ extern "C" int zkw_comm_init_tcp(zkw_ctx* ctx, const char* address, int port, in
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
     }
-    for (int k = rank + 1; k < world; k++) {
-        timeval tv{};
-        const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
-        tv.tv_sec = left > 0 ? left / 1000 : 0;
-        tv.tv_usec = left > 0 ? (left % 1000) * 1000 : 1000;
-        setsockopt(lfd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    // accept() and the hello are bounded by poll() on the descriptors: a receive timeout set on the listening socket would
+    // be inherited by every accepted data socket and fail a later gather whose peer is still computing
+    auto wait_readable = [&](int f) {
+        for (;;) {
+            const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+            if (left <= 0) { errno = ETIMEDOUT; return false; }
+            pollfd pf{f, POLLIN, 0};
+            const int k = poll(&pf, 1, (int)std::min<long long>(left, 1000));
+            if (k > 0) return true;
+            if (k < 0 && errno != EINTR) return false;
+        }
+    };
+    for (int k = rank + 1; k < world;) {
+        if (!wait_readable(lfd)) { close(lfd); return fail_with("accept (timed out)"); }
         int f = accept(lfd, nullptr, nullptr);
-        if (f < 0) { close(lfd); return fail_with("accept (timed out)"); }
+        if (f < 0) {
+            if (errno == EINTR || errno == EAGAIN || errno == ECONNABORTED) continue;
+            close(lfd);
+            return fail_with("accept");
+        }
         setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-        int32_t who = -1;
-        if (TcpTransport::read_all(f, &who, sizeof who) != 0 || who <= rank || who >= world || t->fd[who] >= 0) { close(f); close(lfd); delete t; return zkw_fail(ZKW_ERR_HIP, "zkw_comm_init_tcp: bad hello"); }
-        t->fd[who] = f;
+        Hello h{};
+        if (!wait_readable(f) || TcpTransport::read_all(f, &h, sizeof h) != 0) { close(f); close(lfd); return fail_with("hello (timed out)"); }
+        if (h.job != hello.job) { close(f); continue; }  // a process of another job: not one of ours, keep waiting
+        if (h.world != world || h.rank <= rank || h.rank >= world || t->fd[h.rank] >= 0) { close(f); close(lfd); delete t; return zkw_fail(ZKW_ERR_HIP, "zkw_comm_init_tcp: bad hello (rank %d of %d)", h.rank, h.world); }
+        t->fd[h.rank] = f;
+        k++;
     }
     if (lfd >= 0) close(lfd);
     zkw_comm* c = new zkw_comm();

@@ -958,7 +958,13 @@ int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsi
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ctx->device & 15] = true;
     }
-    static const u32 probe = [] { const char* e = getenv("ZKW_NL_PROBE"); return e ? (u32)atoi(e) : 0u; }();  // measurement only: 1 = no level walk, 2 = no streaming
+#ifdef ZKW_PROBE_BUILD  // measurement builds only (ZKW_PROBE_BUILD=1 python -m era_zkevm_test_harness_amd.build --force): 1 = no level walk, 2 = no
+                        // streaming — the traces are then INVALID, so the knob does not exist in the library that ships
+    static const u32 probe = [] { const char* e = getenv("ZKW_NL_PROBE"); return e ? (u32)atoi(e) : 0u; }();
+    if (probe) fprintf(stderr, "libzkw: ZKW_NL_PROBE=%u — k_nl_fill skips work, the traces are invalid\n", probe);
+#else
+    const u32 probe = 0;
+#endif
     // as many workgroups as the LDS lets a CU hold: the write phase is a stream of stores and wants waves in flight
     const unsigned lds = WAVES == 16 ? nc->host.lds_bytes16 : nc->host.lds_bytes;
     const unsigned per_cu = std::max<unsigned>(1, std::min<unsigned>(4, (160u * 1024u) / std::max<unsigned>(1, lds)));

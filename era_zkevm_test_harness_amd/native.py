@@ -175,6 +175,8 @@ SYMBOLS = [
     ("zkw_comm_unique_id", _int, [_vp]),
     ("zkw_comm_init", _int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
     ("zkw_comm_init_tcp", _int, [_vp, C.c_char_p, _int, _int, _int, _int, C.POINTER(_vp)]),
+    ("zkw_comm_init_rccl", _int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
+    ("zkw_comm_exchange", _int, [_vp, _vp, _vp, C.c_size_t, _int]),
     ("zkw_comm_destroy", None, [_vp]),
     ("zkw_comm_synchronize", _int, [_vp]),
     ("zkw_gather_records", _int, [_vp, _vp, _sz, _vp, _sz, _int, _vp]),
@@ -1847,6 +1849,20 @@ class Comm:
         _check(load().zkw_comm_init_tcp(ctx.handle if ctx is not None else None, address.encode(), port, rank, world, timeout_ms, C.byref(self.handle)))
         self.ctx, self.rank, self.world = ctx, rank, world
         return self
+
+    @classmethod
+    def rccl(cls, ctx, rank=0, world=1, unique_id=None):
+        """zkw_comm_init_rccl: the RCCL transport whatever the world size (world == 1: ncclCommInitRank over one rank)"""
+        self = cls.__new__(cls)
+        self.handle = C.c_void_p(None)
+        idbuf = np.frombuffer(unique_id if unique_id is not None else cls.unique_id(), np.uint8).copy()
+        _check(load().zkw_comm_init_rccl(ctx.handle, _np_ptr(idbuf), rank, world, C.byref(self.handle)))
+        self.ctx, self.rank, self.world = ctx, rank, world
+        return self
+
+    def exchange(self, src_ptr, dst_ptr, nbytes, peer):
+        """zkw_comm_exchange: grouped send to + receive from `peer` (device pointers; enqueued on the stream)"""
+        _check(load().zkw_comm_exchange(self.handle, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), nbytes, peer))
 
     def synchronize(self):
         _check(load().zkw_comm_synchronize(self.handle))

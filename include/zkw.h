@@ -731,7 +731,12 @@ void zkw_trace_free(zkw_trace *t);
 size_t zkw_trace_num_rows(const zkw_trace *t);
 size_t zkw_trace_num_cols(const zkw_trace *t); /* default 149 = 133 copy-permutation + 15 lookup + 1 multiplicity */
 size_t zkw_trace_num_slots(const zkw_trace *t);
-/* device address of slot's column 0; column c starts at + c * n_rows */
+/* device address of slot's column 0; column c starts at + c * n_rows.
+   CONTRACT: the library remembers which layout a slot last held (a netlist synthesis into a slot that still holds the same
+   circuit / capacity / row count skips clearing it); taking this pointer FORGETS that — the caller may write through it — so
+   the next synthesis into the slot clears it again. A pointer kept from an earlier call must therefore not be written
+   through after a later synthesis into the slot: take the pointer again (or read with zkw_trace_get, which keeps the slot's
+   state). Reading through a kept pointer is always fine. */
 const uint64_t *zkw_trace_device_ptr(const zkw_trace *t, size_t slot);
 /* copy columns [first_col, first_col + n_cols) of a slot out (host, or device in ZKW_PTR_DEVICE mode) */
 int zkw_trace_get(const zkw_trace *t, size_t slot, uint32_t first_col, uint32_t n_cols, uint64_t *dst);
@@ -825,7 +830,17 @@ typedef struct zkw_comm zkw_comm;
 int zkw_comm_unique_id(uint8_t id[ZKW_COMM_ID_BYTES]);
 /* collective over all ranks (ncclCommInitRank); world == 1 needs no id and no RCCL. Work runs on ctx's stream. */
 int zkw_comm_init(zkw_ctx *ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, zkw_comm **out);
-/* the same communicator over a full mesh of TCP sockets: rank j connects to every rank i < j at address:(port + i).
+/* the RCCL transport whatever the world size (world == 1: ncclCommInitRank over one rank; `id` is required): what lets a
+   single-GPU host run the transport's dlopen, symbol table, stream ordering and error paths (tests/test_gpu_comm_rccl.py) */
+int zkw_comm_init_rccl(zkw_ctx *ctx, const uint8_t id[ZKW_COMM_ID_BYTES], int rank, int world, zkw_comm **out);
+/* one grouped send of src[bytes] to `peer` + receive of dst[bytes] from it through the communicator's transport (peer may be
+   the own rank on RCCL: a send to self matched by a receive from self). Pointers as in zkw_gather_closed_form_inputs, not
+   overlapping. Enqueued on the stream (zkw_comm_synchronize). */
+int zkw_comm_exchange(zkw_comm *c, const void *src, void *dst, size_t bytes, int peer);
+/* the same communicator over a full mesh of TCP sockets on ONE host: every rank binds and connects on `address`
+   (use 127.0.0.1), rank j connects to every rank i < j at address:(port + i); the hello carries the 64-bit job id of the
+   environment variable ZKW_COMM_JOB_ID (0 when unset) and connections of another job are turned away. A test / fallback
+   transport for one trusted host, not an authenticated channel.
    ctx == NULL: a host-memory communicator (records / recv of zkw_gather_closed_form_inputs are HOST pointers; needs no GPU);
    ctx != NULL: device pointers, staged through host memory. timeout_ms <= 0: 30 s. Collective over all ranks. */
 int zkw_comm_init_tcp(zkw_ctx *ctx, const char *address, int port, int rank, int world, int timeout_ms, zkw_comm **out);

@@ -96,6 +96,74 @@ def test_gather_over_tcp_between_processes(world, root, types):
         assert len(set(got[0][3])) == world  # LPT uses every rank
 
 
+def _late_rank_main(rank, world, port, delay_s, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import time
+        from era_zkevm_test_harness_amd import native as nv
+
+        if rank == 1:
+            time.sleep(delay_s[0])  # connects late: the root's accept() has used up most of its init timeout by then
+        comm = nv.Comm.tcp(None, "127.0.0.1", port, rank, world, 3000)
+        if rank == 1:
+            time.sleep(delay_s[1])  # ... and needs longer than what was left of it to finish its shard
+        owner = np.array([0, 1, 1], np.uint32)
+        rec = _records(np.array([8, 9, 9], np.uint8))
+        out = comm.gather_records(owner, rec[owner == rank], 0)
+        comm.destroy()
+        q.put((rank, None if out is None else out.tolist()))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "error: " + traceback.format_exc()))
+
+
+def test_gather_waits_for_a_slow_peer():
+    """a receive timeout on the listening socket was inherited by the accepted data sockets, so a peer that
+    connected late and then computed for longer than the leftover init time failed the root's gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port_block(2)
+    procs = [ctx.Process(target=_late_rank_main, args=(r, 2, port, (2.0, 2.5), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert got[1] is None
+    assert np.array_equal(np.array(got[0], np.uint64).reshape(-1, 24), _records(np.array([8, 9, 9], np.uint8)))
+
+
+def _job_rank_main(rank, port, job, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["ZKW_COMM_JOB_ID"] = job
+        from era_zkevm_test_harness_amd import native as nv
+
+        try:
+            comm = nv.Comm.tcp(None, "127.0.0.1", port, rank, 2, 1500)
+            comm.destroy()
+            q.put((rank, "connected"))
+        except nv.ZkwError as e:
+            q.put((rank, "refused: " + str(e)))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "error: " + traceback.format_exc()))
+
+
+def test_tcp_hello_turns_away_another_job():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port_block(2)
+    procs = [ctx.Process(target=_job_rank_main, args=(r, port, "0x1234" if r == 0 else "0x9999", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert got[0].startswith("refused") and "timed out" in got[0], got  # rank 0 never saw a rank of ITS job
+
+
 def test_tcp_comm_rejects_bad_arguments():
     from era_zkevm_test_harness_amd import native as nv
 

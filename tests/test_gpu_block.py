@@ -305,7 +305,7 @@ def test_blocks_run_sharded_and_gather_two_ranks_over_tcp(ctx):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    res, err = {}, []
+    res, err, failed = {}, [], {}
 
     def rank_main(rank):
         try:
@@ -314,6 +314,16 @@ def test_blocks_run_sharded_and_gather_two_ranks_over_tcp(ctx):
             mine = nv.Block.run_sharded(0, bs, rank, 2, caps)
             assert [m is not None for m in mine] == [k % 2 == rank for k in range(5)]
             res[rank] = nv.Block.gather_sharded(mine, comm, rank, 2, root=1, max_per_block=256)
+            # a failure only ONE rank can see (rank 0 hands over a block it did not build) must stay collective: rank 0 still
+            # takes part with an error record, both it and the root come back with an error instead of the root waiting forever
+            broken = [None if (rank == 0 and k == 2) else m for k, m in enumerate(mine)]
+            try:
+                nv.Block.gather_sharded(broken, comm, rank, 2, root=1, max_per_block=256)
+                failed[rank] = None
+            except nv.ZkwError as e:
+                failed[rank] = str(e)
+            again = nv.Block.gather_sharded(mine, comm, rank, 2, root=1, max_per_block=256)  # the communicator is still in step
+            assert (again is None) if rank == 0 else all(np.array_equal(a, b) for a, b in zip(again, res[rank]))
             comm.destroy()
             for m in mine:
                 if m is not None:
@@ -329,6 +339,7 @@ def test_blocks_run_sharded_and_gather_two_ranks_over_tcp(ctx):
         t.join(300)
     assert not err, err
     assert res[0] is None and len(res[1]) == 5
+    assert failed[0] and "NULL" in failed[0] and failed[1] and "block 2" in failed[1], failed
     comm1 = nv.Comm(ctx, 0, 1)
     for b, got in zip(bs, res[1]):
         one = nv.Block(0, b, caps)

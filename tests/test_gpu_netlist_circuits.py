@@ -287,3 +287,29 @@ def test_production_geometry_decommitter_and_linear_hasher(ctx, oracle):
     qb = t.get(0, 0, 8)[:, int(lay["queue_first_row"])]  # QBND: the head before (zeros) | after = the state after the last push
     assert qb[:4].tolist() == [0, 0, 0, 0] and qb[4:8].tolist() == np.asarray(tails[-1]).tolist()
     t.free()
+
+
+@pytest.mark.parametrize("ct", [5, 6])
+def test_slot_reuse_keeps_no_stale_cells(ctx, oracle, ct):
+    """a slot whose layout tag matches is NOT cleared (zkw_precompiles.hip, nl_synthesize_with) — the path the block ring
+    and bench.py take. Every instance of a queue is synthesized INTO THE SAME SLOT one after the other without the slot's pointer
+    being taken in between (taking it resets the tag), a full instance followed by the partial last one and then by instance 0 again,
+    from two different request queues: each time the slot must equal the oracle's trace of that instance cell for cell."""
+    from era_zkevm_test_harness_amd import native
+
+    kind, cols, synth, check, osynth, ocheck, cap = CIRCUITS[ct]
+    cols = getattr(native, cols)
+    t = native.Trace(ctx, N_ROWS, 1, n_cols=cols)
+    wa, oa = _precompile(ctx, oracle, kind, 9, cap, seed=3)
+    wb, ob = _precompile(ctx, oracle, kind, 5, cap, seed=21, max_rounds=2)
+    assert wa.num_instances >= 3 and wb.num_instances >= 2
+    order = [(wa, oa, 0), (wa, oa, wa.num_instances - 1), (wb, ob, wb.num_instances - 1), (wb, ob, 0), (wa, oa, 1), (wa, oa, wa.num_instances - 1)]
+    for w, o, i in order:
+        getattr(ctx, synth)(w, t, i, 1, 0)  # instance i into slot 0; t.get() copies through the library (no zkw_trace_device_ptr)
+        exp = getattr(oracle, osynth)(o, i, cap, N_ROWS)
+        got = t.get(0)
+        assert np.array_equal(got, exp), (i, np.argwhere(got != exp)[:4])
+        assert getattr(ctx, check)(t, 0, cap) == (0, (0, 0, 0))
+    t.free()
+    wa.free()
+    wb.free()
