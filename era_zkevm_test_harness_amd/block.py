@@ -111,19 +111,16 @@ def synthesize_and_check(ctx, artifacts, n_rows):
     """ZkSyncBaseLayerCircuit::synthesis + check_if_satisfied for every instance of the six circuit types libzkw
     synthesizes; returns {circuit type: number of instances}, raises on the first unsatisfied trace."""
     w, cap = artifacts["witnesses"], artifacts["capacities"]
-    plan = ((RAM_PERMUTATION, w["ram_permutation"], ctx.synthesize_ram, ctx.check_if_satisfied_ram, None),
-            (DECOMMITS_SORTER, w["decommits_sorter"], ctx.synthesize_decommit_sorter, ctx.check_if_satisfied_decommit_sorter, None),
-            (LOG_DEMUXER, w["log_demuxer"], ctx.synthesize_log_demux, ctx.check_if_satisfied_log_demux, 151),
-            (STORAGE_SORTER, w["storage_sorter"], ctx.synthesize_storage_sorter, ctx.check_if_satisfied_storage_sorter, None),
-            (EVENTS_SORTER, w["events_sorter"], ctx.synthesize_events_sorter, ctx.check_if_satisfied_events_sorter, None),
-            (L1_MESSAGES_SORTER, w["l1_messages_sorter"], ctx.synthesize_events_sorter, ctx.check_if_satisfied_events_sorter, None))
+    # through the type-dispatching entry points (zkw_synthesize / zkw_check_satisfied = the reference's enum methods)
+    plan = ((RAM_PERMUTATION, w["ram_permutation"], None), (DECOMMITS_SORTER, w["decommits_sorter"], None), (LOG_DEMUXER, w["log_demuxer"], 151),
+            (STORAGE_SORTER, w["storage_sorter"], None), (EVENTS_SORTER, w["events_sorter"], None), (L1_MESSAGES_SORTER, w["l1_messages_sorter"], None))
     done = {}
-    for ctype, wit, synth, check, n_cols in plan:
+    for ctype, wit, n_cols in plan:
         n_inst = wit.num_instances
         t = nv.Trace(ctx, n_rows, 1, n_cols=n_cols)
         for i in range(n_inst):
-            synth(wit, t, i, 1, 0)
-            bad, first = check(t, 0, cap[ctype])
+            ctx.synthesize(ctype, wit, t, i, 1, 0)
+            bad, first = ctx.check_if_satisfied(ctype, t, 0, cap[ctype])
             if bad:
                 t.free()
                 raise AssertionError(f"circuit type {ctype}, instance {i}: {bad} violations, first {first}")

@@ -170,6 +170,8 @@ SYMBOLS = [
     ("zkw_trace_get", _int, [_vp, _sz, _u32, _u32, _vp]),
     ("zkw_ram_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
     ("zkw_ram_check_satisfied", _int, [_vp, _vp, _sz, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("zkw_synthesize", _int, [_vp, C.c_uint8, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_check_satisfied", _int, [_vp, C.c_uint8, _vp, _sz, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("zkw_vm_slice_instances", _int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("zkw_shard_lpt", _int, [_vp, _sz, _int, _vp]),
     ("zkw_comm_unique_id", _int, [_vp]),
@@ -916,6 +918,19 @@ class Context:
         fills trace slots (first_slot + k) % n_slots with instances first_instance + k."""
         n = witness.num_instances - first_instance if n_instances is None else n_instances
         _check(load().zkw_ram_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+    def synthesize(self, circuit_type, witness, trace, first_instance=0, n_instances=1, first_slot=0):
+        """zkw_synthesize: ZkSyncBaseLayerCircuit::synthesis as ONE entry point over the circuit types (base_layer/mod.rs:286-323);
+        `witness` = the witness object of the type (its .handle is passed) or a raw handle"""
+        h = getattr(witness, "handle", witness)
+        _check(load().zkw_synthesize(self.handle, circuit_type, h, first_instance, n_instances, trace.handle, first_slot))
+
+    def check_if_satisfied(self, circuit_type, trace, slot, capacity):
+        """zkw_check_satisfied: (violations, (kind, index, row) of the first) for a slot holding `circuit_type`"""
+        bad, first = C.c_uint64(0), C.c_uint64(0)
+        _check(load().zkw_check_satisfied(self.handle, circuit_type, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+        v = first.value
+        return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
     def check_if_satisfied_ram(self, trace, slot, capacity):
         """check_if_satisfied (src/tests/mod.rs:130-259): (violations, (kind, index, row) of the first)."""
@@ -1696,18 +1711,13 @@ class Block:
         assert n.value == total
         return out if rank == root else None
 
-    CHECKERS = {8: "zkw_ram_check_satisfied", 2: "zkw_decommit_sorter_check_satisfied", 4: "zkw_log_demux_check_satisfied",
-                9: "zkw_storage_sorter_check_satisfied", 11: "zkw_events_sorter_check_satisfied", 12: "zkw_events_sorter_check_satisfied",
-                5: "zkw_keccak_round_check_satisfied", 13: "zkw_linear_hasher_check_satisfied", 6: "zkw_sha256_round_check_satisfied",
-                3: "zkw_code_decommitter_check_satisfied", 10: "zkw_storage_application_check_satisfied"}
-
     def check_satisfied(self, circuit_type, trace_handle, slot):
-        """check_if_satisfied (src/tests/mod.rs:130-259) on a slot handed to a synthesize callback: (n_violations, first_bad)"""
+        """check_if_satisfied (src/tests/mod.rs:130-259) on a slot handed to a synthesize callback, through the type-dispatching
+        entry point zkw_check_satisfied: (n_violations, first_bad)"""
         lib = load()
         bad, first = C.c_uint64(0), C.c_uint64(0)
         cap = self.capacities[circuit_type]
-        _check(getattr(lib, self.CHECKERS[circuit_type])(lib.zkw_block_context(self.handle, circuit_type), trace_handle, slot,
-                                                         cap, C.byref(bad), C.byref(first)))
+        _check(lib.zkw_check_satisfied(lib.zkw_block_context(self.handle, circuit_type), circuit_type, trace_handle, slot, cap, C.byref(bad), C.byref(first)))
         return bad.value, first.value
 
     def free(self):

@@ -755,6 +755,48 @@ int zkw_ram_synthesize(zkw_ctx *ctx, const zkw_ram_witness *w, size_t first_inst
 int zkw_ram_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                             uint64_t *n_violations, uint64_t *first_bad);
 
+/* ---- type-dispatching synthesis (8b) ------------------------------------------------------------------------------ */
+/* BaseLayerCircuitType numbering (ZkSyncBaseLayerCircuit::numeric_circuit_type, base_layer/mod.rs:442-476) */
+enum {
+    ZKW_CIRCUIT_MAIN_VM = 1,
+    ZKW_CIRCUIT_CODE_DECOMMITTMENTS_SORTER = 2,
+    ZKW_CIRCUIT_CODE_DECOMMITTER = 3,
+    ZKW_CIRCUIT_LOG_DEMUXER = 4,
+    ZKW_CIRCUIT_KECCAK256_ROUND_FUNCTION = 5,
+    ZKW_CIRCUIT_SHA256_ROUND_FUNCTION = 6,
+    ZKW_CIRCUIT_ECRECOVER = 7,
+    ZKW_CIRCUIT_RAM_PERMUTATION = 8,
+    ZKW_CIRCUIT_STORAGE_SORTER = 9,
+    ZKW_CIRCUIT_STORAGE_APPLICATION = 10,
+    ZKW_CIRCUIT_EVENTS_SORTER = 11,
+    ZKW_CIRCUIT_L1_MESSAGES_SORTER = 12,
+    ZKW_CIRCUIT_L1_MESSAGES_HASHER = 13
+};
+/* the "witness" of the L1MessagesHasher for zkw_synthesize: its instances are whole queues (one instance per queue,
+   data_hasher_and_merklizer.rs:34-60), the arguments of zkw_linear_hasher_synthesize_batch_with_tails as one record */
+typedef struct zkw_linear_hasher_witness {
+    const zkw_log_query *messages;        /* all queues back to back (host or device per the pointer mode) */
+    const uint64_t *message_offsets;      /* [n_queues + 1] (host) */
+    size_t n_queues;
+    const zkw_queue_state4 *queue_states; /* [n_queues] (host) */
+    const uint64_t *message_tails;        /* [total][4] or NULL (see zkw_linear_hasher_synthesize_batch_with_tails) */
+    uint32_t capacity;                    /* messages per instance */
+    zkw_linear_hasher_instance *records_out; /* [n_queues] or NULL */
+    uint64_t *public_inputs_out;             /* [n_queues][4] or NULL */
+} zkw_linear_hasher_witness;
+/* ZkSyncBaseLayerCircuit::synthesis (base_layer/mod.rs:286-323: one `match` over the enum's variants): instances
+   [first_instance, first_instance + n_instances) of `witness` into slots first_slot.. of `t`. `witness` is the witness handle
+   of the type: 2 zkw_decommit_witness, 3 zkw_decommitter_witness, 4 zkw_demux_witness, 5 / 6 / 7 zkw_precompile_witness (of that
+   kind), 8 zkw_ram_witness, 9 zkw_storage_witness, 10 zkw_storage_application_witness, 11 / 12 zkw_events_witness, 13
+   zkw_linear_hasher_witness* (a record of pointers, above) — exactly what zkw_block_witness(b, type) returns for 2..12. The
+   trace must have the type's column count (zkw_circuit_layout_of). Type 1 (MainVM) has no synthesis here: ZKW_ERR_INVALID. */
+int zkw_synthesize(zkw_ctx *ctx, uint8_t circuit_type, const void *witness, size_t first_instance, size_t n_instances, zkw_trace *t,
+                   size_t first_slot);
+/* check_if_satisfied of base_test_circuit (src/tests/mod.rs:130-259) for a slot that holds an instance of `circuit_type` at
+   `capacity` (type 13: messages): n_violations / first_bad as the per-type checkers report them. */
+int zkw_check_satisfied(zkw_ctx *ctx, uint8_t circuit_type, const zkw_trace *t, size_t slot, uint32_t capacity, uint64_t *n_violations,
+                        uint64_t *first_bad);
+
 /* ---- MainVM instance slicing (a19) ------------------------------------------------------------------------------ */
 /* The loop of src/witness/oracle.rs:1229-1469 (`vm_snapshots.windows(2)`): every window [at_cycle_k, at_cycle_{k+1}) of
    the VM's snapshots becomes one MainVM instance whose VmWitnessOracle FIFOs are the elements of eight cycle-stamped

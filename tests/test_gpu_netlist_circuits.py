@@ -301,7 +301,7 @@ def test_slot_reuse_keeps_no_stale_cells(ctx, oracle, ct):
     cols = getattr(native, cols)
     t = native.Trace(ctx, N_ROWS, 1, n_cols=cols)
     wa, oa = _precompile(ctx, oracle, kind, 9, cap, seed=3)
-    wb, ob = _precompile(ctx, oracle, kind, 5, cap, seed=21, max_rounds=2)
+    wb, ob = _precompile(ctx, oracle, kind, 10, cap, seed=21, max_rounds=3)
     assert wa.num_instances >= 3 and wb.num_instances >= 2
     order = [(wa, oa, 0), (wa, oa, wa.num_instances - 1), (wb, ob, wb.num_instances - 1), (wb, ob, 0), (wa, oa, 1), (wa, oa, wa.num_instances - 1)]
     for w, o, i in order:
@@ -313,3 +313,49 @@ def test_slot_reuse_keeps_no_stale_cells(ctx, oracle, ct):
     t.free()
     wa.free()
     wb.free()
+
+
+def test_type_dispatching_entry_points(ctx, oracle):
+    """zkw_synthesize / zkw_check_satisfied (the reference's `match` in ZkSyncBaseLayerCircuit::synthesis, base_layer/mod.rs:286-323):
+    the same cells and verdicts as the per-type functions for the netlist types incl. the L1MessagesHasher's record-of-pointers
+    witness; MainVM and unknown types are refused"""
+    import ctypes as C
+
+    from era_zkevm_test_harness_amd import native
+
+    for ct in (5, 6):
+        kind, cols, synth, check, osynth, ocheck, cap = CIRCUITS[ct]
+        w, o = _precompile(ctx, oracle, kind, 6, cap)
+        t = native.Trace(ctx, N_ROWS, 2, n_cols=getattr(native, cols))
+        ctx.synthesize(ct, w, t, 1, 2, 0)
+        for k in range(2):
+            assert np.array_equal(t.get(k), getattr(oracle, osynth)(o, 1 + k, cap, N_ROWS))
+            assert ctx.check_if_satisfied(ct, t, k, cap) == (0, (0, 0, 0))
+        with pytest.raises(native.ZkwError):
+            ctx.synthesize(1, w, t, 0, 1, 0)
+        with pytest.raises(native.ZkwError):
+            ctx.synthesize(14, w, t, 0, 1, 0)
+        t.free()
+        w.free()
+    # type 13: instance k = queue k of a zkw_linear_hasher_witness
+    cap, sizes = 20, (7, 0, 13)
+    queues = [synthetic.random_log_queries(max(n, 1), seed=60 + k)[:n] for k, n in enumerate(sizes)]
+    flat = np.concatenate(queues)
+    off = np.array([0, 7, 7, 20], np.uint64)
+    states = np.zeros(3, native.QUEUE_STATE4)
+
+    class LHW(C.Structure):
+        _fields_ = [("messages", C.c_void_p), ("message_offsets", C.c_void_p), ("n_queues", C.c_size_t), ("queue_states", C.c_void_p),
+                    ("message_tails", C.c_void_p), ("capacity", C.c_uint32), ("records_out", C.c_void_p), ("public_inputs_out", C.c_void_p)]
+
+    pis = np.zeros((3, 4), np.uint64)
+    lw = LHW(flat.ctypes.data, off.ctypes.data, 3, states.ctypes.data, None, cap, None, pis.ctypes.data)
+    t = native.Trace(ctx, N_ROWS, 2, n_cols=native.LH_COLS)
+    ctx.synthesize(13, C.addressof(lw), t, 1, 2, 0)  # queues 1 and 2 -> slots 0 and 1
+    for k in range(2):
+        exp, _rec, opi = oracle.linear_hasher_synthesize(queues[1 + k], states[1 + k:2 + k], cap, N_ROWS)
+        assert np.array_equal(t.get(k), exp) and np.array_equal(pis[1 + k], opi)
+        assert ctx.check_if_satisfied(13, t, k, cap) == (0, (0, 0, 0))
+    with pytest.raises(native.ZkwError):
+        ctx.synthesize(13, C.addressof(lw), t, 2, 2, 0)  # queue 3 of 3
+    t.free()
