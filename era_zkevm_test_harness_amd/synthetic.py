@@ -353,10 +353,34 @@ def precompile_trace(kind, n_requests, seed=0, max_rounds=5):
         elif kind == 2:
             in_off = int(rng.integers(0, 1 << 16))
             key[0], key[1], key[3] = in_off, 4, 2
-            for r in range(4):
-                qs.append(query(ts, page_r, in_off + r, 0))
-            for r in range(2):
-                qs.append(query(ts + 1, page_w, out_off + r, 1))
+            # hash, v, r, s as the caller laid them out; the precompile writes (1, address) or (0, 0): real signatures, and the failures the
+            # VM's precompile has (zk_evm_abstractions ecrecover: r / s out of range, x^3 + 7 not a square)
+            from . import secp256k1 as ec
+
+            h = int.from_bytes(rng.bytes(32), "big")
+            sk, kk = int.from_bytes(rng.bytes(32), "big") % (ec.N - 1) + 1, int.from_bytes(rng.bytes(32), "big") % (ec.N - 1) + 1
+            v, r_, s_ = ec.sign(h, sk, kk)
+            mode = int(rng.integers(0, 10))
+            if mode == 0:
+                r_ = ec.N + int(rng.integers(0, 1000))
+            elif mode == 1:
+                s_ = 0
+            elif mode == 2:
+                r_ = int(rng.integers(1, 1 << 62))
+                while ec.lift_x(r_, 0) is not None:
+                    r_ += 1
+            elif mode == 3:
+                v = 1 - v  # the other root: another key, still a success
+            ok, addr = ec.ecrecover(h, v, r_, s_)
+            assert mode in (0, 1, 2) or ok == 1
+            for k_, val in enumerate((h, v, r_, s_)):
+                m = query(ts, page_r, in_off + k_, 0)
+                m["value"] = np.frombuffer(int(val).to_bytes(32, "little"), "<u4")
+                qs.append(m)
+            for k_, val in enumerate((ok, addr)):
+                m = query(ts + 1, page_w, out_off + k_, 1)
+                m["value"] = np.frombuffer(int(val).to_bytes(32, "little"), "<u4")
+                qs.append(m)
         else:
             # lengths around the interesting edges: empty, one byte short of / exactly / one past whole blocks
             choices = [0, 1, 31, 32, 33, 135, 136, 137, 271, 272, 273, 136 * max_rounds]

@@ -1,0 +1,722 @@
+/* zkw_ecrecover.h — the EC SECTION of the ECRecover circuit (type 7): record types of the generated spec
+ * (include/zkw_ecrecover_ec_spec.h, format and statement: tools/gen_ecrecover_circuit.py), secp256k1 / Goldilocks helpers, the
+ * evaluation of a cycle's value tape, and the relation every item states over its cells. Plain C that also compiles as HIP device
+ * code; shared by the kernels (csrc/ecrecover_kernels.cuh), the host side and the test oracle (oracle/ecrecover_circuit.c) the way
+ * include/zkw_netlist.h shares nl_table_eval. The independent restatement of these semantics is the Python evaluator of the
+ * generator (tests compare tapes); the reference's circuit body (ecrecover_function_entry_point, era-zkevm_circuits) is absent
+ * from /root/reference, so the placement is this library's own — geometry and tables are base_layer/ecrecover.rs:30-41,138-176.
+ *
+ * Rows of cycle c: EC_FIRST_ROW + c * EC_ROWS_PER_CYCLE + run.row0 + instance * type.n_rows + row; a row = 80 general-purpose
+ * cells + 16 lookup slots of width 3 of ONE table. Items (32-bit words, w0 = kind | row << 4 | col << 16 | aux << 24):
+ *   LIN    aux = known cells; n_new; const lo, hi; known x {ref, coef (i32)}; new x {tape index, shift | width << 8}
+ *   SEL    refs b, x, y; out tape index                      cells [b, x, y, o]
+ *   FMA    aux = 1: d is NEW; refs a, b, c; d (tape index / ref)  cells [a, b, c, d]
+ *   MUL    aux = modulus (0 P, 1 N); refs a0, b0, r0 (limb i = ref + i); q tape0, carry tape0   cells a 0.., b 16.., q 32.., r 48.., c 64..78
+ *   HINT   aux = kind; arguments (no cells)
+ *   LOOKUP row, col = slot; aux = inputs; table (| EC_ROWTAB_PER_INSTANCE); in0, in1; out tape0   cells [in.., out..] at 80 + 3 slot
+ * References: kind << 28 | payload — 0 TAPE t, 1 PREV k (state element k of the previous segment), 2 GLOB k, 3 GLOBJ (base | stride << 16:
+ * global base + stride * instance), 4 CONST v, 5 BIG (idx << 4 | limb), 6 IN k (input byte), 0xFFFFFFFF none. */
+#ifndef ZKW_ECRECOVER_H
+#define ZKW_ECRECOVER_H
+#include <stdint.h>
+#include <stddef.h>
+#include "zkw_ecrecover_ec_spec.h"
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define EC_HD __host__ __device__ static inline
+#else
+#define EC_HD static inline
+#endif
+
+enum { EC_I_LIN = 1, EC_I_SEL = 2, EC_I_FMA = 3, EC_I_MUL = 4, EC_I_HINT = 5, EC_I_LOOKUP = 6 };
+enum { EC_H_MULSUB = 1, EC_H_DIV = 2, EC_H_SQRT = 3, EC_H_ISZERO = 4, EC_H_GE = 5 };
+enum { EC_K_TAPE = 0, EC_K_PREV = 1, EC_K_GLOB = 2, EC_K_GLOBJ = 3, EC_K_CONST = 4, EC_K_BIG = 5, EC_K_IN = 6 };
+#define EC_NONE 0xFFFFFFFFu
+#define EC_GL_P 0xFFFFFFFF00000001ull
+#define EC_STATE 32
+#define EC_FIXED_WORDS (256 * 256 * 2) /* the 256 FixedBaseMul tables: [8 C + i][byte] -> {x word i, y word i} */
+
+typedef struct ec_seg_type { uint32_t n_rows, n_tape, item0, n_items, index0, cell0, home0, out0, rowtab0; } ec_seg_type;
+typedef struct ec_run { uint32_t type, count, row0, tape0; } ec_run;
+typedef struct ec_spec {
+    const ec_seg_type *types;
+    const ec_run *runs;
+    const uint32_t *items, *item_index, *cells, *homes, *outs;
+    const uint16_t *rowtab;
+    const uint32_t *globs, *bigs;
+    const uint16_t *in_home;
+    const uint32_t *key_byte;
+    const uint32_t *fixed; /* EC_FIXED_WORDS, built by ec_build_fixed_tables */
+} ec_spec;
+
+#define EC_DEFINE_SPEC(name)                                                                                            \
+    static const ec_seg_type name##_types[] = EC_TYPES_INIT;                                                            \
+    static const ec_run name##_runs[] = EC_RUNS_INIT;                                                                   \
+    static const uint32_t name##_items[] = EC_ITEMS_INIT;                                                               \
+    static const uint32_t name##_item_index[] = EC_ITEM_INDEX_INIT;                                                     \
+    static const uint32_t name##_cells[] = EC_CELLS_INIT;                                                               \
+    static const uint32_t name##_homes[] = EC_HOME_INIT;                                                                \
+    static const uint32_t name##_outs[] = EC_OUT_INIT;                                                                  \
+    static const uint16_t name##_rowtab[] = EC_ROWTAB_INIT;                                                             \
+    static const uint32_t name##_globs[] = EC_GLOB_INIT;                                                                \
+    static const uint32_t name##_bigs[] = EC_BIG_INIT;                                                                  \
+    static const uint16_t name##_in_home[] = EC_IN_HOME_INIT;                                                           \
+    static const uint32_t name##_key_byte[] = EC_KEY_BYTE_INIT
+
+/* ---- Goldilocks (canonical inputs and outputs) ------------------------------------------------------------------------ */
+EC_HD uint64_t ec_gl_add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    if (s < a || s >= EC_GL_P) s -= EC_GL_P;
+    return s;
+}
+EC_HD uint64_t ec_gl_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (EC_GL_P - b); }
+EC_HD uint64_t ec_gl_mul(uint64_t a, uint64_t b) {
+    const uint64_t a0 = (uint32_t)a, a1 = a >> 32, b0 = (uint32_t)b, b1 = b >> 32;
+    const uint64_t p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+    const uint64_t mid = (p00 >> 32) + (uint32_t)p01 + (uint32_t)p10;
+    const uint64_t lo = (uint32_t)p00 | (mid << 32);
+    const uint64_t hi = p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+    /* x = hi_hi 2^96 + hi_lo 2^64 + lo, 2^64 = 2^32 - 1, 2^96 = -1 */
+    const uint64_t hi_hi = hi >> 32, hi_lo = (uint32_t)hi;
+    uint64_t t = lo - hi_hi;
+    if (lo < hi_hi) t -= 0xFFFFFFFFull; /* + p */
+    const uint64_t u = hi_lo * 0xFFFFFFFFull;
+    uint64_t r = t + u;
+    if (r < t) r += 0xFFFFFFFFull;
+    if (r >= EC_GL_P) r -= EC_GL_P;
+    return r;
+}
+EC_HD uint64_t ec_gl_inv(uint64_t a) { /* a^(p - 2); 0 -> 0 */
+    uint64_t r = 1, b = a;
+    uint64_t e = EC_GL_P - 2;
+    while (e) {
+        if (e & 1) r = ec_gl_mul(r, b);
+        b = ec_gl_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+EC_HD uint64_t ec_gl_from_i64(int64_t v) { return v >= 0 ? (uint64_t)v % EC_GL_P : EC_GL_P - ((uint64_t)(-v) % EC_GL_P); }
+
+/* ---- 256-bit arithmetic modulo m = 2^256 - c (the secp256k1 base and scalar fields), 32-bit words little end first ------ */
+typedef struct ec_u256 { uint32_t w[8]; } ec_u256;
+typedef struct ec_mod { uint32_t m[8]; uint32_t c[5]; uint32_t nc; } ec_mod;
+
+EC_HD ec_mod ec_modulus(uint32_t which) { /* 0: P = 2^256 - 2^32 - 977, 1: N */
+    ec_mod M;
+    if (which == 0) {
+        const uint32_t m[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (int i = 0; i < 8; i++) M.m[i] = m[i];
+        M.c[0] = 977; M.c[1] = 1; M.c[2] = M.c[3] = M.c[4] = 0;
+        M.nc = 2;
+    } else {
+        const uint32_t m[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        const uint32_t c[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 0x1u};
+        for (int i = 0; i < 8; i++) M.m[i] = m[i];
+        for (int i = 0; i < 5; i++) M.c[i] = c[i];
+        M.nc = 5;
+    }
+    return M;
+}
+EC_HD int ec_cmp8(const uint32_t *a, const uint32_t *b) {
+    for (int i = 7; i >= 0; i--)
+        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    return 0;
+}
+EC_HD void ec_sub8(uint32_t *a, const uint32_t *b) { /* a -= b */
+    uint64_t br = 0;
+    for (int i = 0; i < 8; i++) {
+        const uint64_t d = (uint64_t)a[i] - b[i] - br;
+        a[i] = (uint32_t)d;
+        br = (d >> 32) & 1;
+    }
+}
+/* out[na + nb] = a * b */
+EC_HD void ec_mul_words(const uint32_t *a, int na, const uint32_t *b, int nb, uint32_t *out) {
+    for (int i = 0; i < na + nb; i++) out[i] = 0;
+    for (int i = 0; i < na; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < nb; j++) {
+            const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
+            out[i + j] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        out[i + nb] = (uint32_t)carry;
+    }
+}
+/* x (n <= 20 words) mod m */
+EC_HD ec_u256 ec_reduce(const uint32_t *x, int n, const ec_mod *M) {
+    uint32_t cur[24], nxt[24];
+    int len = n;
+    for (int i = 0; i < 24; i++) cur[i] = i < n ? x[i] : 0;
+    while (len > 8) { /* x = hi 2^256 + lo = hi c + lo */
+        int top = len;
+        while (top > 8 && cur[top - 1] == 0) top--;
+        if (top <= 8) break;
+        const int nh = top - 8;
+        ec_mul_words(cur + 8, nh, M->c, (int)M->nc, nxt);
+        int nl = nh + (int)M->nc;
+        if (nl < 9) { for (int i = nl; i < 9; i++) nxt[i] = 0; nl = 9; }
+        else nxt[nl++] = 0;
+        uint64_t carry = 0;
+        for (int i = 0; i < nl; i++) {
+            const uint64_t t = (uint64_t)nxt[i] + (i < 8 ? cur[i] : 0) + carry;
+            nxt[i] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        for (int i = 0; i < 24; i++) cur[i] = i < nl ? nxt[i] : 0;
+        len = nl;
+    }
+    ec_u256 r;
+    for (int i = 0; i < 8; i++) r.w[i] = cur[i];
+    while (ec_cmp8(r.w, M->m) >= 0) ec_sub8(r.w, M->m);
+    return r;
+}
+EC_HD ec_u256 ec_mulmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) {
+    uint32_t t[16];
+    ec_mul_words(a->w, 8, b->w, 8, t);
+    return ec_reduce(t, 16, M);
+}
+EC_HD ec_u256 ec_submod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) { /* a, b < m */
+    ec_u256 r = *a;
+    if (ec_cmp8(a->w, b->w) >= 0) { ec_sub8(r.w, b->w); return r; }
+    uint64_t carry = 0; /* a + m - b */
+    for (int i = 0; i < 8; i++) {
+        const uint64_t t = (uint64_t)a->w[i] + M->m[i] + carry;
+        r.w[i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    ec_sub8(r.w, b->w);
+    return r;
+}
+EC_HD ec_u256 ec_addmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) {
+    uint32_t t[9];
+    uint64_t carry = 0;
+    for (int i = 0; i < 8; i++) {
+        const uint64_t s = (uint64_t)a->w[i] + b->w[i] + carry;
+        t[i] = (uint32_t)s;
+        carry = s >> 32;
+    }
+    t[8] = (uint32_t)carry;
+    return ec_reduce(t, 9, M);
+}
+EC_HD int ec_is_zero8(const ec_u256 *a) {
+    uint32_t o = 0;
+    for (int i = 0; i < 8; i++) o |= a->w[i];
+    return o == 0;
+}
+/* a^e mod m, e = m - 2 (inverse) or (p + 1) / 4 (square root): exponent given as 8 words */
+EC_HD ec_u256 ec_powmod(const ec_u256 *a, const uint32_t *e, const ec_mod *M) {
+    ec_u256 r;
+    for (int i = 0; i < 8; i++) r.w[i] = i == 0;
+    int started = 0;
+    for (int bit = 255; bit >= 0; bit--) {
+        if (started) r = ec_mulmod(&r, &r, M);
+        if ((e[bit >> 5] >> (bit & 31)) & 1) {
+            if (started) r = ec_mulmod(&r, a, M);
+            else { r = *a; started = 1; }
+        }
+    }
+    return r;
+}
+EC_HD ec_u256 ec_invmod(const ec_u256 *a, const ec_mod *M) {
+    uint32_t e[8];
+    for (int i = 0; i < 8; i++) e[i] = M->m[i];
+    e[0] -= 2; /* (both moduli end in ...2F / ...41: no borrow) */
+    return ec_powmod(a, e, M);
+}
+/* a vector of 16 (possibly lazy: up to 2^24 each) limbs as an integer of 9 words */
+EC_HD void ec_from_limbs16(const uint64_t *l, uint32_t out[9]) {
+    uint64_t acc = 0;
+    for (int i = 0; i < 9; i++) out[i] = 0;
+    for (int k = 0; k < 16; k += 2) {
+        acc += l[k] + (l[k + 1] << 16);
+        out[k / 2] = (uint32_t)acc;
+        acc >>= 32;
+    }
+    out[8] = (uint32_t)acc;
+}
+EC_HD void ec_to_limbs16(const ec_u256 *a, uint64_t *l) {
+    for (int k = 0; k < 16; k++) l[k] = (a->w[k / 2] >> (16 * (k & 1))) & 0xFFFFu;
+}
+
+/* ---- reading references ------------------------------------------------------------------------------------------------- */
+typedef struct ec_eval_ctx {
+    const ec_spec *S;
+    uint64_t *tape;          /* the cycle's tape */
+    const uint8_t *in;       /* 128 input bytes */
+    uint32_t base, prev_base, prev_type, inst;
+} ec_eval_ctx;
+
+/* absolute tape index a reference names, or EC_NONE for the kinds that are not tape values */
+EC_HD uint32_t ec_ref_tape(const ec_spec *S, uint32_t ref, uint32_t base, uint32_t prev_base, uint32_t prev_type, uint32_t inst) {
+    const uint32_t kind = ref >> 28, a = ref & 0x0FFFFFFFu;
+    switch (kind) {
+        case EC_K_TAPE: return base + a;
+        case EC_K_PREV: return prev_base + S->outs[S->types[prev_type].out0 + a];
+        case EC_K_GLOB: return S->globs[a];
+        case EC_K_GLOBJ: return S->globs[(a & 0xFFFFu) + (uint32_t)((int32_t)(int8_t)(a >> 16) * (int32_t)inst)];
+        default: return EC_NONE;
+    }
+}
+EC_HD uint64_t ec_ref_const(const ec_spec *S, uint32_t ref, const uint8_t *in) {
+    const uint32_t kind = ref >> 28, a = ref & 0x0FFFFFFFu;
+    if (kind == EC_K_CONST) return a;
+    if (kind == EC_K_BIG) return S->bigs[(a >> 4) * 16 + (a & 15)];
+    return in[a]; /* EC_K_IN */
+}
+EC_HD uint64_t ec_get(const ec_eval_ctx *E, uint32_t ref) {
+    const uint32_t t = ec_ref_tape(E->S, ref, E->base, E->prev_base, E->prev_type, E->inst);
+    return t != EC_NONE ? E->tape[t] : ec_ref_const(E->S, ref, E->in);
+}
+EC_HD void ec_get_vec(const ec_eval_ctx *E, uint32_t ref0, uint64_t *out) {
+    for (uint32_t i = 0; i < 16; i++) out[i] = ec_get(E, ref0 + i);
+}
+EC_HD uint32_t ec_item_words(const uint32_t *w) {
+    const uint32_t kind = w[0] & 15, aux = w[0] >> 24;
+    switch (kind) {
+        case EC_I_LIN: return 4 + 2 * aux + 2 * w[1];
+        case EC_I_SEL: case EC_I_FMA: case EC_I_LOOKUP: return 5;
+        case EC_I_MUL: return 6;
+        default: return aux == EC_H_MULSUB ? 7 : aux == EC_H_DIV ? 5 : aux == EC_H_SQRT ? 4 : aux == EC_H_ISZERO ? 3 : 4;
+    }
+}
+
+/* q (16 limbs, the top one up to 24 bits) and the 15 carries (+ 2^31) of a MUL row; returns 0 when a * b + 8 m - r is not a
+   non-negative multiple of m (no witness) */
+EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r, uint32_t which, uint64_t *q, uint64_t *c) {
+    const ec_mod M = ec_modulus(which);
+    uint32_t A[9], B[9], R[9], T[20], U[20];
+    ec_from_limbs16(a, A);
+    ec_from_limbs16(b, B);
+    ec_from_limbs16(r, R);
+    ec_mul_words(A, 9, B, 9, T); /* 18 words */
+    T[18] = T[19] = 0;
+    uint64_t carry = 0; /* + 8 m */
+    for (int i = 0; i < 20; i++) {
+        uint64_t add = 0;
+        if (i < 9) add = i < 8 ? (((uint64_t)M.m[i] << 3) & 0xFFFFFFFFull) | (i ? M.m[i - 1] >> 29 : 0) : (uint64_t)(M.m[7] >> 29);
+        const uint64_t t = (uint64_t)T[i] + add + carry;
+        T[i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    uint64_t br = 0; /* - r */
+    for (int i = 0; i < 20; i++) {
+        const uint64_t d = (uint64_t)T[i] - (i < 9 ? R[i] : 0) - br;
+        T[i] = (uint32_t)d;
+        br = (d >> 32) & 1;
+    }
+    if (br) return 0;
+    /* Q = T / m exactly, m = 2^256 - c: Q <- ceil((T + Q c) / 2^256) from Q = T >> 256 */
+    uint32_t Q[12], Qc[20];
+    for (int i = 0; i < 12; i++) Q[i] = T[8 + i];
+    for (int it = 0; it < 4; it++) {
+        ec_mul_words(Q, 12, M.c, (int)M.nc, Qc); /* 12 + nc words */
+        for (int i = 12 + (int)M.nc; i < 20; i++) Qc[i] = 0;
+        uint64_t cy = 0;
+        for (int i = 0; i < 20; i++) {
+            const uint64_t t = (uint64_t)T[i] + Qc[i] + (i < 8 ? 0xFFFFFFFFull : 0) + cy;
+            U[i] = (uint32_t)t;
+            cy = t >> 32;
+        }
+        for (int i = 0; i < 12; i++) Q[i] = U[8 + i];
+    }
+    if (Q[8] >> 8 || Q[9] || Q[10] || Q[11]) return 0; /* q < 2^264 */
+    ec_mul_words(Q, 12, M.m, 8, U);
+    for (int i = 0; i < 20; i++)
+        if (U[i] != T[i]) return 0;
+    for (int k = 0; k < 15; k++) q[k] = (Q[k / 2] >> (16 * (k & 1))) & 0xFFFFu;
+    q[15] = (Q[7] >> 16) | ((uint64_t)Q[8] << 16);
+    /* carries of the 32-bit positions */
+    int64_t cin = 0;
+    for (int k = 0; k < 16; k++) {
+        int64_t d = 0;
+        for (int half = 0; half < 2; half++) {
+            const int t = 2 * k + half;
+            int64_t s = 0;
+            for (int i = 0; i < 16; i++) {
+                const int j = t - i;
+                if (j < 0 || j > 15) continue;
+                const int64_t mj = (int64_t)((M.m[j / 2] >> (16 * (j & 1))) & 0xFFFFu);
+                s += (int64_t)a[i] * (int64_t)b[j] - ((int64_t)q[i] - (i == 0 ? EC_KMUL : 0)) * mj;
+            }
+            if (t < 16) s -= (int64_t)r[t];
+            d += half ? s * 65536 : s;
+        }
+        const int64_t tot = d + cin;
+        if (tot & 0xFFFFFFFFll) return 0;
+        cin = tot >> 32;
+        if (k < 15) {
+            if (cin <= -(1ll << 31) || cin >= (1ll << 31)) return 0;
+            c[k] = (uint64_t)(cin + (1ll << 31));
+        } else if (cin != 0) return 0;
+    }
+    return 1;
+}
+
+/* evaluates the items of one segment instance onto the tape; returns 0, or 1 + the item's index when the inputs have no witness
+   (a division by zero in the incomplete addition, a broken assertion) */
+EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
+    const ec_spec *S = E->S;
+    const ec_seg_type *T = &S->types[type];
+    const uint32_t *w = S->items + T->item0;
+    uint64_t *tape = E->tape + E->base;
+    for (uint32_t n = 0; n < T->n_items; n++, w += ec_item_words(w)) {
+        const uint32_t kind = w[0] & 15, aux = w[0] >> 24;
+        if (kind == EC_I_LIN) {
+            const uint32_t nk = aux, nn = w[1];
+            const uint32_t *kn = w + 4, *nw = w + 4 + 2 * nk;
+            if (nn == 1 && nw[1] == 0) { /* one NEW cell = the whole sum, in the field (it may be "negative") */
+                uint64_t acc = ec_gl_from_i64((int64_t)((uint64_t)w[2] | ((uint64_t)w[3] << 32)));
+                for (uint32_t i = 0; i < nk; i++) {
+                    const uint64_t v = ec_get(E, kn[2 * i]);
+                    acc = ec_gl_add(acc, ec_gl_mul(v, ec_gl_from_i64((int32_t)kn[2 * i + 1])));
+                }
+                tape[nw[0]] = acc;
+                continue;
+            }
+            int64_t s = (int64_t)((uint64_t)w[2] | ((uint64_t)w[3] << 32));
+            for (uint32_t i = 0; i < nk; i++) s += (int64_t)ec_get(E, kn[2 * i]) * (int64_t)(int32_t)kn[2 * i + 1];
+            if (nn == 0) { if (s != 0) return 1 + (int)n; continue; }
+            if (s < 0) return 1 + (int)n;
+            for (uint32_t i = 0; i < nn; i++) {
+                const uint32_t sh = nw[2 * i + 1] & 0xFF, wd = nw[2 * i + 1] >> 8;
+                uint64_t x = (uint64_t)s >> sh;
+                if (wd) x &= (1ull << wd) - 1;
+                tape[nw[2 * i]] = x;
+            }
+        } else if (kind == EC_I_SEL) {
+            tape[w[4]] = ec_get(E, w[1]) ? ec_get(E, w[2]) : ec_get(E, w[3]);
+        } else if (kind == EC_I_FMA) {
+            const uint64_t v = ec_gl_add(ec_gl_mul(ec_get(E, w[1]) % EC_GL_P, ec_get(E, w[2]) % EC_GL_P), ec_get(E, w[3]) % EC_GL_P);
+            if (aux) tape[w[4]] = v;
+            else if (v != ec_get(E, w[4]) % EC_GL_P) return 1 + (int)n;
+        } else if (kind == EC_I_MUL) {
+            uint64_t a[16], b[16], r[16];
+            ec_get_vec(E, w[1], a);
+            ec_get_vec(E, w[2], b);
+            ec_get_vec(E, w[3], r);
+            if (!ec_mul_witness(a, b, r, aux, tape + w[4], tape + w[5])) return 1 + (int)n;
+        } else if (kind == EC_I_LOOKUP) {
+            const uint64_t a = ec_get(E, w[2]);
+            if ((w[1] & 0xFF) == EC_T_XOR8) {
+                const uint64_t b = ec_get(E, w[3]);
+                if (a > 255 || b > 255) return 1 + (int)n;
+                tape[w[4]] = a ^ b;
+            } else {
+                if (a > 255) return 1 + (int)n;
+                const uint32_t tb = (w[1] & 0xFF) - EC_T_FIXED0 + 8 * E->inst;
+                tape[w[4]] = S->fixed[((size_t)tb * 256 + a) * 2];
+                tape[w[4] + 1] = S->fixed[((size_t)tb * 256 + a) * 2 + 1];
+            }
+        } else { /* hints */
+            uint64_t va[16], vb[16];
+            if (aux == EC_H_MULSUB || aux == EC_H_DIV) {
+                const ec_mod M = ec_modulus(w[1]);
+                uint32_t A[9], B[9];
+                ec_get_vec(E, w[2], va);
+                ec_get_vec(E, w[3], vb);
+                ec_from_limbs16(va, A);
+                ec_from_limbs16(vb, B);
+                const ec_u256 a = ec_reduce(A, 9, &M), b = ec_reduce(B, 9, &M);
+                ec_u256 res;
+                if (aux == EC_H_DIV) {
+                    if (ec_is_zero8(&b)) return 1 + (int)n;
+                    const ec_u256 bi = ec_invmod(&b, &M);
+                    res = ec_mulmod(&a, &bi, &M);
+                    ec_to_limbs16(&res, tape + w[4]);
+                } else {
+                    res = ec_mulmod(&a, &b, &M);
+                    for (int o = 4; o <= 5; o++)
+                        if (w[o] != EC_NONE) {
+                            uint32_t C[9];
+                            ec_get_vec(E, w[o], va);
+                            ec_from_limbs16(va, C);
+                            const ec_u256 cc = ec_reduce(C, 9, &M);
+                            res = ec_submod(&res, &cc, &M);
+                        }
+                    ec_to_limbs16(&res, tape + w[6]);
+                }
+            } else if (aux == EC_H_SQRT) {
+                const ec_mod M = ec_modulus(0);
+                uint32_t A[9];
+                ec_get_vec(E, w[1], va);
+                ec_from_limbs16(va, A);
+                const ec_u256 t = ec_reduce(A, 9, &M);
+                const uint32_t e[8] = {0xBFFFFF0Cu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x3FFFFFFFu}; /* (p + 1) / 4 */
+                ec_u256 y = ec_powmod(&t, e, &M);
+                ec_u256 y2 = ec_mulmod(&y, &y, &M);
+                uint64_t e_nr = 0;
+                if (ec_cmp8(y2.w, t.w) != 0) { /* no root: a root of -t proves it (p = 3 mod 4) */
+                    e_nr = 1;
+                    ec_u256 zero;
+                    for (int i = 0; i < 8; i++) zero.w[i] = 0;
+                    const ec_u256 nt = ec_submod(&zero, &t, &M);
+                    y = ec_powmod(&nt, e, &M);
+                } else if ((y.w[0] & 1) != (ec_get(E, w[2]) & 1)) {
+                    ec_u256 zero;
+                    for (int i = 0; i < 8; i++) zero.w[i] = 0;
+                    y = ec_submod(&zero, &y, &M);
+                }
+                ec_to_limbs16(&y, tape + w[3]);
+                tape[w[3] + 16] = e_nr;
+            } else if (aux == EC_H_ISZERO) {
+                const uint64_t x = ec_get(E, w[1]) % EC_GL_P;
+                tape[w[2]] = x ? ec_gl_inv(x) : 0;
+                tape[w[2] + 1] = x ? 0 : 1;
+            } else { /* EC_H_GE: a >= the constant */
+                ec_get_vec(E, w[1], va);
+                int ge = 1;
+                for (int i = 15; i >= 0; i--) {
+                    const uint64_t cst = S->bigs[w[2] * 16 + (uint32_t)i];
+                    if (va[i] != cst) { ge = va[i] > cst; break; }
+                }
+                tape[w[3]] = (uint64_t)ge;
+            }
+        }
+    }
+    return 0;
+}
+
+/* the whole cycle: tape[EC_TAPE_PER_CYCLE] from the 128 input bytes. Returns 0, or (run << 24 | instance << 12 | 1 + item) of the
+   first item without a witness */
+EC_HD uint32_t ec_eval_cycle(const ec_spec *S, const uint8_t *in, uint64_t *tape) {
+    ec_eval_ctx E;
+    E.S = S; E.tape = tape; E.in = in;
+    E.prev_base = 0; E.prev_type = 0;
+    for (uint32_t r = 0; r < EC_NUM_RUNS; r++) {
+        const ec_run *R = &S->runs[r];
+        const ec_seg_type *T = &S->types[R->type];
+        for (uint32_t j = 0; j < R->count; j++) {
+            E.base = R->tape0 + j * T->n_tape;
+            E.inst = j;
+            const int bad = ec_eval_segment(&E, R->type);
+            if (bad) return (r << 24) | (j << 12) | (uint32_t)bad;
+            E.prev_base = E.base;
+            E.prev_type = R->type;
+        }
+    }
+    return 0;
+}
+
+/* ---- layout -------------------------------------------------------------------------------------------------------------- */
+/* segment instance that holds row `r` (< EC_ROWS_PER_CYCLE) of a cycle */
+EC_HD void ec_locate_row(const ec_spec *S, uint32_t r, uint32_t *run, uint32_t *inst, uint32_t *row) {
+    uint32_t k = 0;
+    while (k + 1 < EC_NUM_RUNS && S->runs[k + 1].row0 <= r) k++;
+    const uint32_t nr = S->types[S->runs[k].type].n_rows;
+    *run = k;
+    *inst = (r - S->runs[k].row0) / nr;
+    *row = (r - S->runs[k].row0) % nr;
+}
+/* the (run, instance) before (run, inst); run 0 has none */
+EC_HD void ec_prev_segment(const ec_spec *S, uint32_t run, uint32_t inst, uint32_t *prun, uint32_t *pinst) {
+    if (inst) { *prun = run; *pinst = inst - 1; }
+    else { *prun = run ? run - 1 : 0; *pinst = run ? S->runs[run - 1].count - 1 : 0; }
+}
+/* value of a cell reference seen from segment (run, inst) of a cycle with this tape */
+EC_HD uint64_t ec_cell_value(const ec_spec *S, const uint64_t *tape, const uint8_t *in, uint32_t run, uint32_t inst, uint32_t ref) {
+    if (ref == EC_NONE) return 0;
+    uint32_t prun, pinst;
+    ec_prev_segment(S, run, inst, &prun, &pinst);
+    const uint32_t base = S->runs[run].tape0 + inst * S->types[S->runs[run].type].n_tape;
+    const uint32_t pbase = S->runs[prun].tape0 + pinst * S->types[S->runs[prun].type].n_tape;
+    const uint32_t t = ec_ref_tape(S, ref, base, pbase, S->runs[prun].type, inst);
+    return t != EC_NONE ? tape[t] : ec_ref_const(S, ref, in);
+}
+/* row (within the cycle) and column of the HOME cell of absolute tape index t */
+EC_HD void ec_home_of_tape(const ec_spec *S, uint32_t t, uint32_t *row, uint32_t *col) {
+    uint32_t k = 0;
+    while (k + 1 < EC_NUM_RUNS && S->runs[k + 1].tape0 <= t) k++;
+    const ec_seg_type *T = &S->types[S->runs[k].type];
+    const uint32_t inst = (t - S->runs[k].tape0) / T->n_tape, idx = (t - S->runs[k].tape0) % T->n_tape;
+    const uint32_t h = S->homes[T->home0 + idx];
+    *row = S->runs[k].row0 + inst * T->n_rows + (h >> 8);
+    *col = h & 0xFF;
+}
+/* table id of a row of segment (run, inst), 0 = the row has no lookups */
+EC_HD uint32_t ec_row_table(const ec_spec *S, uint32_t run, uint32_t inst, uint32_t row) {
+    const uint32_t t = S->rowtab[S->types[S->runs[run].type].rowtab0 + row];
+    return (t & EC_ROWTAB_PER_INSTANCE) ? (t & 0x7FFFu) + 8 * inst : t;
+}
+/* stacked-table row (= row of the multiplicity column) a lookup of table id `tb` with these inputs hits: Xor8 at 0, And8 at 65 536,
+   FixedBaseMul<i, C> (id 3 + 8 C + i) at 131 072 + 256 (id - 3) */
+EC_HD uint32_t ec_table_key(uint32_t tb, uint64_t a, uint64_t b) {
+    return tb == EC_T_XOR8 ? (uint32_t)(a | (b << 8)) : 131072u + 256u * (tb - EC_T_FIXED0) + (uint32_t)a;
+}
+
+/* ---- the relations, from cells alone. `cell(col)` reads the item's row; returns 0 when the relation holds ------------------ */
+typedef struct ec_row_view { const uint64_t *trace; size_t n_rows, row; } ec_row_view;
+EC_HD uint64_t ec_rv(const ec_row_view *v, uint32_t col) { return v->trace[(size_t)col * v->n_rows + v->row]; }
+EC_HD int ec_canon(uint64_t x) { return x < EC_GL_P; }
+
+EC_HD int ec_check_item(const ec_spec *S, const uint32_t *w, const ec_row_view *v, uint32_t inst) {
+    const uint32_t kind = w[0] & 15, aux = w[0] >> 24, col = (w[0] >> 16) & 0xFF;
+    if (kind == EC_I_LIN) {
+        const uint32_t nk = aux, nn = w[1];
+        uint64_t acc = ec_gl_from_i64((int64_t)((uint64_t)w[2] | ((uint64_t)w[3] << 32)));
+        for (uint32_t i = 0; i < nk; i++) {
+            const uint64_t x = ec_rv(v, col + i);
+            if (!ec_canon(x)) return 1;
+            acc = ec_gl_add(acc, ec_gl_mul(x, ec_gl_from_i64((int32_t)w[4 + 2 * i + 1])));
+        }
+        for (uint32_t i = 0; i < nn; i++) {
+            const uint64_t x = ec_rv(v, col + nk + i);
+            if (!ec_canon(x)) return 1;
+            acc = ec_gl_sub(acc, ec_gl_mul(x, 1ull << (w[4 + 2 * nk + 2 * i + 1] & 0xFF)));
+        }
+        return acc != 0;
+    }
+    if (kind == EC_I_SEL) {
+        const uint64_t b = ec_rv(v, col), x = ec_rv(v, col + 1), y = ec_rv(v, col + 2), o = ec_rv(v, col + 3);
+        if (!ec_canon(b) || !ec_canon(x) || !ec_canon(y) || !ec_canon(o)) return 1;
+        return ec_gl_sub(ec_gl_add(ec_gl_mul(b, ec_gl_sub(x, y)), y), o) != 0;
+    }
+    if (kind == EC_I_FMA) {
+        const uint64_t a = ec_rv(v, col), b = ec_rv(v, col + 1), c = ec_rv(v, col + 2), d = ec_rv(v, col + 3);
+        if (!ec_canon(a) || !ec_canon(b) || !ec_canon(c) || !ec_canon(d)) return 1;
+        return ec_gl_add(ec_gl_mul(a, b), c) != d;
+    }
+    if (kind == EC_I_MUL) {
+        const ec_mod M = ec_modulus(aux);
+        uint64_t cin = 0; /* carry c_{k-1} - 2^31, in the field */
+        for (int c = 0; c < 80; c++)
+            if (!ec_canon(ec_rv(v, (uint32_t)c))) return 1;
+        for (int k = 0; k < 16; k++) {
+            uint64_t d = 0;
+            for (int half = 0; half < 2; half++) {
+                const int t = 2 * k + half;
+                uint64_t s = 0;
+                for (int i = 0; i < 16; i++) {
+                    const int j = t - i;
+                    if (j < 0 || j > 15) continue;
+                    const uint64_t mj = (M.m[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
+                    s = ec_gl_add(s, ec_gl_mul(ec_rv(v, (uint32_t)i), ec_rv(v, 16u + (uint32_t)j)));
+                    const uint64_t qi = i == 0 ? ec_gl_sub(ec_rv(v, 32), EC_KMUL) : ec_rv(v, 32u + (uint32_t)i);
+                    s = ec_gl_sub(s, ec_gl_mul(qi, mj));
+                }
+                if (t < 16) s = ec_gl_sub(s, ec_rv(v, 48u + (uint32_t)t));
+                d = ec_gl_add(d, half ? ec_gl_mul(s, 65536) : s);
+            }
+            const uint64_t cout = k < 15 ? ec_gl_sub(ec_rv(v, 64u + (uint32_t)k), 1ull << 31) : 0;
+            if (ec_gl_add(d, cin) != ec_gl_mul(cout, 1ull << 32)) return 1;
+            cin = cout;
+        }
+        return ec_rv(v, 79) != 0;
+    }
+    if (kind == EC_I_LOOKUP) {
+        const uint32_t c0 = EC_G + EC_W * col;
+        const uint64_t a = ec_rv(v, c0), b = ec_rv(v, c0 + 1), c = ec_rv(v, c0 + 2);
+        if ((w[1] & 0xFF) == EC_T_XOR8) return a > 255 || b > 255 || c != (a ^ b);
+        const uint32_t tb = (w[1] & 0xFF) - EC_T_FIXED0 + 8 * inst;
+        return a > 255 || b != S->fixed[((size_t)tb * 256 + a) * 2] || c != S->fixed[((size_t)tb * 256 + a) * 2 + 1];
+    }
+    return 0; /* hints state nothing */
+}
+
+/* ---- the 256 FixedBaseMul tables (host): word i of x and of y of byte * 2^(8 C) * G, (0, 0) for byte 0 ---------------------- */
+typedef struct ec_jac { ec_u256 x, y, z; } ec_jac; /* z == 0: infinity */
+EC_HD ec_jac ec_jac_double(const ec_jac *p, const ec_mod *M) {
+    if (ec_is_zero8(&p->z)) return *p;
+    ec_jac r;
+    const ec_u256 a = ec_mulmod(&p->x, &p->x, M), b = ec_mulmod(&p->y, &p->y, M), c = ec_mulmod(&b, &b, M);
+    ec_u256 t = ec_addmod(&p->x, &b, M);
+    t = ec_mulmod(&t, &t, M);
+    t = ec_submod(&t, &a, M);
+    t = ec_submod(&t, &c, M);
+    const ec_u256 d = ec_addmod(&t, &t, M);
+    ec_u256 e = ec_addmod(&a, &a, M);
+    e = ec_addmod(&e, &a, M);
+    const ec_u256 f = ec_mulmod(&e, &e, M);
+    ec_u256 d2 = ec_addmod(&d, &d, M);
+    r.x = ec_submod(&f, &d2, M);
+    ec_u256 c8 = ec_addmod(&c, &c, M);
+    c8 = ec_addmod(&c8, &c8, M);
+    c8 = ec_addmod(&c8, &c8, M);
+    ec_u256 dx = ec_submod(&d, &r.x, M);
+    dx = ec_mulmod(&e, &dx, M);
+    r.y = ec_submod(&dx, &c8, M);
+    const ec_u256 yz = ec_mulmod(&p->y, &p->z, M);
+    r.z = ec_addmod(&yz, &yz, M);
+    return r;
+}
+EC_HD ec_jac ec_jac_add(const ec_jac *p, const ec_jac *q, const ec_mod *M) {
+    if (ec_is_zero8(&p->z)) return *q;
+    if (ec_is_zero8(&q->z)) return *p;
+    const ec_u256 z1z1 = ec_mulmod(&p->z, &p->z, M), z2z2 = ec_mulmod(&q->z, &q->z, M);
+    const ec_u256 u1 = ec_mulmod(&p->x, &z2z2, M), u2 = ec_mulmod(&q->x, &z1z1, M);
+    ec_u256 s1 = ec_mulmod(&p->y, &q->z, M);
+    s1 = ec_mulmod(&s1, &z2z2, M);
+    ec_u256 s2 = ec_mulmod(&q->y, &p->z, M);
+    s2 = ec_mulmod(&s2, &z1z1, M);
+    const ec_u256 h = ec_submod(&u2, &u1, M), rr = ec_submod(&s2, &s1, M);
+    if (ec_is_zero8(&h)) {
+        if (ec_is_zero8(&rr)) return ec_jac_double(p, M);
+        ec_jac inf = *p;
+        for (int i = 0; i < 8; i++) inf.z.w[i] = 0;
+        return inf;
+    }
+    const ec_u256 h2 = ec_mulmod(&h, &h, M), h3 = ec_mulmod(&h2, &h, M), u1h2 = ec_mulmod(&u1, &h2, M);
+    ec_jac r;
+    ec_u256 t = ec_mulmod(&rr, &rr, M);
+    t = ec_submod(&t, &h3, M);
+    t = ec_submod(&t, &u1h2, M);
+    r.x = ec_submod(&t, &u1h2, M);
+    ec_u256 v = ec_submod(&u1h2, &r.x, M);
+    v = ec_mulmod(&rr, &v, M);
+    const ec_u256 s1h3 = ec_mulmod(&s1, &h3, M);
+    r.y = ec_submod(&v, &s1h3, M);
+    const ec_u256 zz = ec_mulmod(&p->z, &q->z, M);
+    r.z = ec_mulmod(&zz, &h, M);
+    return r;
+}
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <stdlib.h>
+/* out[EC_FIXED_WORDS]; boojum's create_fixed_base_mul_table<i, C> (gadgets/tables/fixed_base_mul_table, absent crate; the contents
+   are the public curve: row `byte` of table (i, C) = 32-bit word i of the affine x and y of byte * 2^(8 C) * G) */
+static inline void ec_build_fixed_tables(uint32_t *out) {
+    const ec_mod M = ec_modulus(0);
+    ec_jac *pts = (ec_jac *)malloc(sizeof(ec_jac) * 32 * 256);
+    ec_u256 *pre = (ec_u256 *)malloc(sizeof(ec_u256) * 32 * 256);
+    ec_jac base;
+    const uint32_t gx[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu, 0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
+    const uint32_t gy[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u, 0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
+    for (int i = 0; i < 8; i++) { base.x.w[i] = gx[i]; base.y.w[i] = gy[i]; base.z.w[i] = i == 0; }
+    for (int C = 0; C < 32; C++) {
+        ec_jac cur = base;
+        for (int i = 0; i < 8; i++) cur.z.w[i] = 0; /* infinity */
+        for (int b = 0; b < 256; b++) {
+            pts[C * 256 + b] = cur;
+            cur = ec_jac_add(&cur, &base, &M);
+        }
+        for (int d = 0; d < 8; d++) base = ec_jac_double(&base, &M);
+    }
+    /* one inversion for all z (Montgomery's trick), infinity skipped */
+    ec_u256 acc;
+    for (int i = 0; i < 8; i++) acc.w[i] = i == 0;
+    for (int k = 0; k < 32 * 256; k++) {
+        pre[k] = acc;
+        if (!ec_is_zero8(&pts[k].z)) acc = ec_mulmod(&acc, &pts[k].z, &M);
+    }
+    ec_u256 inv = ec_invmod(&acc, &M);
+    for (int k = 32 * 256 - 1; k >= 0; k--) {
+        const int C = k / 256, b = k % 256;
+        ec_u256 x, y;
+        for (int i = 0; i < 8; i++) x.w[i] = y.w[i] = 0;
+        if (!ec_is_zero8(&pts[k].z)) {
+            const ec_u256 zi = ec_mulmod(&inv, &pre[k], &M);
+            inv = ec_mulmod(&inv, &pts[k].z, &M);
+            const ec_u256 zi2 = ec_mulmod(&zi, &zi, &M), zi3 = ec_mulmod(&zi2, &zi, &M);
+            x = ec_mulmod(&pts[k].x, &zi2, &M);
+            y = ec_mulmod(&pts[k].y, &zi3, &M);
+        }
+        for (int i = 0; i < 8; i++) {
+            out[((size_t)(8 * C + i) * 256 + (size_t)b) * 2] = x.w[i];
+            out[((size_t)(8 * C + i) * 256 + (size_t)b) * 2 + 1] = y.w[i];
+        }
+    }
+    free(pts);
+    free(pre);
+}
+#endif
+#endif /* ZKW_ECRECOVER_H */

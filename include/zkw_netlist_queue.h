@@ -51,7 +51,12 @@ enum { NLQ_LINK_NONE = 0, NLQ_LINK_SHA_BLOCK = 1, NLQ_LINK_SHA_DIGEST = 2,
           88-byte serialisation (log_query.rs:503-534: shard | is_service | tx_number | address | key | written_value, big end first) of message
           m is byte 88 m + k of the hashed stream = FREE element (88 m + k) % 136 of cycle (88 m + k) / 136 — the cycle the message is popped in
           or the next one. All 88 bytes are linked: shard_id, is_service, the address and key bytes (bytes in the encoding anyway) and the
-          tx_number / written_value bytes of NLQ_ITEM_LOGB (the encoding takes their limbs: nlq_aux_* recompose them). */ };
+          tx_number / written_value bytes of NLQ_ITEM_LOGB (the encoding takes their limbs: nlq_aux_* recompose them). */,
+       NLQ_LINK_EC_OK = 5 /* MEM8, ECRecover's first write (the success marker, src/witness/individual_circuits/ecrecover.rs:160-178): value byte 0 =
+          state byte EK_STATE_OK after the cycle (`ok`, carried there by the netlist's select step), the other bytes = a state byte that is
+          the constant zero */ };
+#define NLQ_EK_STATE_OK 32   /* = EK_STATE_OK of include/zkw_ecrecover_circuit_spec.h */
+#define NLQ_EK_STATE_ZERO 40 /* a state byte of the ECRecover netlist that is the constant 0 */
 
 typedef struct nlq_op { uint8_t kind, item, queue, en_rule, link, link_arg;
                          uint8_t extra, reg_cell[2]; /* REGISTER cells after `new`: register r holds the limb (four byte cells from reg_cell[r]) of the
@@ -82,6 +87,18 @@ static const nlq_desc NLQ_DESC_KECCAK256 = {8, 2, {4, 12}, {
     {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}},
     {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_NONE, 0, 0, {0, 0}},
     {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_FREE, NLQ_LINK_KECCAK_DIGEST, 0, 2, {24 + 20, 24 + 8}}}}; /* registers: the ABI's page to write, output offset */
+
+/* ECRecover (7): every cycle is one request (ecrecover.rs:143-178): pop the call, read hash / v / r / s (four consecutive words), write
+   the success marker and the address. The reads' value bytes are the inputs of the EC section (include/zkw_ecrecover.h): that copy
+   constraint is stated and checked on the EC side (the input bytes' home cells), so the operations carry no link here; the writes are
+   linked to the netlist's state after the cycle (the masked address digest[12..32] as the Keccak256RoundFunction links its digest, `ok`
+   in state byte 32). */
+static const nlq_desc NLQ_DESC_ECRECOVER = {7, 2, {4, 12}, {
+    {NLQ_POP4, NLQ_ITEM_LOG, 0, NLQ_EN_ACTIVE, NLQ_LINK_NONE, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_ACTIVE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_ACTIVE, NLQ_LINK_NONE, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_ACTIVE, NLQ_LINK_NONE, 0, 0, {0, 0}}, {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_ACTIVE, NLQ_LINK_NONE, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_ACTIVE, NLQ_LINK_EC_OK, 0, 0, {0, 0}},
+    {NLQ_PUSH12, NLQ_ITEM_MEM8, 1, NLQ_EN_ACTIVE, NLQ_LINK_KECCAK_DIGEST, 0, 0, {0, 0}}}};
 
 /* L1MessagesHasher (13): the circuit pops EVERY message of the queue and hashes its 88-byte serialisation (linear_hasher in the absent
    crate; out of circuit data_hasher_and_merklizer.rs:8-67). A message is popped in the cycle that absorbs its first byte — cycle
@@ -142,19 +159,34 @@ typedef struct nlq_rel { uint8_t op_a, cell_a, op_b, cell_b, gate; int8_t add; u
     {7, 0, 0, 0, NLQ_REL_ACTIVE, 0, 1, 0xFF, 1} /* an active round pops a call exactly when the round before wrote a digest */, \
     {0, 44, 7, 70, 0, 0, 0, 0xFF, 4}, {0, 32, 7, 71, 0, 0, 0, 0xFF, 4}, {7, 70, 7, 70, NLQ_REL_ACTIVE, 0, 1, 0, 1}, {7, 71, 7, 71, NLQ_REL_ACTIVE, 0, 1, 0, 1}, \
     {7, 70, 7, 2, 7, 0, 0, 0xFF, 1}, {7, 71, 7, 3, 7, 0, 0, 0xFF, 1} /* the registers (cells 70, 71 of the write): loaded by a pop, kept by a round that continues a request, the digest is written there */}
+/* ECRecover: four reads of consecutive words of the call's page to read from its input offset at its timestamp, two writes of
+   consecutive words of its page to write from its output offset one tick later (ecrecover.rs:143-178; zk_evm's precompile); all in ONE
+   cycle, so the whole address arithmetic of a request is relations between the cycle's operations */
+#define NLQ_RELS_ECRECOVER { \
+    {NLQ_REL_CONST, 0, 1, 4, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 4, 2, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 3, 4, 3, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 4, 4, 4, 0, 0, 0xFF, 1}, \
+    {NLQ_REL_CONST, 0, 5, 4, 5, 1, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 6, 4, 6, 1, 0, 0xFF, 1}, \
+    {NLQ_REL_CONST, 0, 1, 5, 1, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 2, 5, 2, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 3, 5, 3, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 4, 5, 4, 0, 0, 0xFF, 1}, \
+    {NLQ_REL_CONST, 0, 5, 5, 5, 0, 0, 0xFF, 1}, {NLQ_REL_CONST, 0, 6, 5, 6, 0, 0, 0xFF, 1}, \
+    {1, 3, 2, 3, 2, 1, 0, 0xFF, 1}, {2, 3, 3, 3, 3, 1, 0, 0xFF, 1}, {3, 3, 4, 3, 4, 1, 0, 0xFF, 1}, {5, 3, 6, 3, 6, 1, 0, 0xFF, 1}, \
+    {1, 2, 2, 2, 2, 0, 0, 0xFF, 1}, {2, 2, 3, 2, 3, 0, 0, 0xFF, 1}, {3, 2, 4, 2, 4, 0, 0, 0xFF, 1}, {5, 2, 6, 2, 6, 0, 0, 0xFF, 1}, \
+    {1, 1, 2, 1, 2, 0, 0, 0xFF, 1}, {2, 1, 3, 1, 3, 0, 0, 0xFF, 1}, {3, 1, 4, 1, 4, 0, 0, 0xFF, 1}, {5, 1, 6, 1, 6, 0, 0, 0xFF, 1}, \
+    {1, 1, 5, 1, 5, 1, 0, 0xFF, 1}, {0, 17, 1, 1, 0, 0, 0, 0xFF, 1}, \
+    {0, 24, 1, 3, 0, 0, 0, 0xFF, 4}, {0, 40, 1, 2, 0, 0, 0, 0xFF, 4}, {0, 32, 5, 3, 0, 0, 0, 0xFF, 4}, {0, 44, 5, 2, 0, 0, 0, 0xFF, 4}}
 typedef struct nlq_rels { uint32_t n; nlq_rel r[NLQ_MAX_RELS]; } nlq_rels;
+static const nlq_rels NLQ_RELS_OF_ECRECOVER = {30, NLQ_RELS_ECRECOVER};
 static const nlq_rels NLQ_RELS_OF_SHA256 = {26, NLQ_RELS_SHA256};
 static const nlq_rels NLQ_RELS_OF_CODE_DECOMMITTER = {14, NLQ_RELS_CODE_DECOMMITTER};
 static const nlq_rels NLQ_RELS_OF_KECCAK256 = {36, NLQ_RELS_KECCAK256};
 static const nlq_rels NLQ_RELS_NONE = {0, {{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
 static inline const nlq_rels *nlq_rels_of(int circuit_type) {
-    return circuit_type == 6 ? &NLQ_RELS_OF_SHA256 : circuit_type == 3 ? &NLQ_RELS_OF_CODE_DECOMMITTER : circuit_type == 5 ? &NLQ_RELS_OF_KECCAK256 : &NLQ_RELS_NONE;
+    return circuit_type == 6 ? &NLQ_RELS_OF_SHA256 : circuit_type == 3 ? &NLQ_RELS_OF_CODE_DECOMMITTER : circuit_type == 5 ? &NLQ_RELS_OF_KECCAK256 :
+           circuit_type == 7 ? &NLQ_RELS_OF_ECRECOVER : &NLQ_RELS_NONE;
 }
 
 /* host only: kernels take the descriptor by value */
 static inline const nlq_desc *nlq_desc_of(int circuit_type) {
     return circuit_type == 6 ? &NLQ_DESC_SHA256 : circuit_type == 3 ? &NLQ_DESC_CODE_DECOMMITTER : circuit_type == 5 ? &NLQ_DESC_KECCAK256 :
-           circuit_type == 13 ? &NLQ_DESC_LINEAR_HASHER : (const nlq_desc *)0;
+           circuit_type == 13 ? &NLQ_DESC_LINEAR_HASHER : circuit_type == 7 ? &NLQ_DESC_ECRECOVER : (const nlq_desc *)0;
 }
 NLQ_HD uint32_t nlq_kind_width(uint32_t kind) { return kind == NLQ_POP4 ? 4u : 12u; }
 NLQ_HD uint32_t nlq_kind_perms(uint32_t kind) { return kind == NLQ_POP4 ? 3u : 1u; }
@@ -229,6 +261,7 @@ NLQ_HD int nlq_comp_linked(const nlq_op *op, uint32_t cell) {
 NLQ_HD uint32_t nlq_link_ref(const nlq_op *op, uint32_t cell, uint32_t *next) {
     const uint32_t t = cell - NLQ_MEM_NIBBLE0;
     if (op->link == NLQ_LINK_KECCAK_DIGEST) { *next = 1; return NL_REF_CYC + (31 - t); }
+    if (op->link == NLQ_LINK_EC_OK) { *next = 1; return NL_REF_CYC + (t == 0 ? NLQ_EK_STATE_OK : NLQ_EK_STATE_ZERO); }
     if (op->link == NLQ_LINK_SHA_DIGEST) { *next = 1; return NL_REF_CYC + 8 * (7 - t / 8) + t % 8; }
     *next = 0;
     return NL_REF_FREE + 2 * (32 * op->link_arg + 31 - t / 2) + (t & 1);

@@ -16,6 +16,7 @@
 #include "../include/zkw_keccak_circuit_spec.h"
 #include "../include/zkw_linear_hasher_circuit_spec.h"
 #include "../include/zkw_storage_application_circuit_spec.h"
+#include "../include/zkw_ecrecover_circuit_spec.h"
 #include "../include/zkw_netlist_queue.h"
 
 NL_DEFINE_SPEC(sc, SC);
@@ -23,6 +24,7 @@ NL_DEFINE_SPEC(dc, DC);
 NL_DEFINE_SPEC(kc, KC);
 NL_DEFINE_SPEC(lh, LH);
 NL_DEFINE_SPEC(sa, SA);
+NL_DEFINE_SPEC(ek, EK); /* ECRecover (7): the Keccak-f netlist over the public key; its EC section: ecrecover_circuit.c */
 
 const nl_spec *orc_nl_spec(int circuit_type) {
     switch (circuit_type) {
@@ -31,6 +33,7 @@ const nl_spec *orc_nl_spec(int circuit_type) {
         case 5: return &kc_spec;
         case 13: return &lh_spec;
         case 10: return &sa_spec;
+        case 7: return &ek_spec;
         default: return NULL;
     }
 }
@@ -89,8 +92,8 @@ uint64_t orc_nl_home(const nl_spec *sp, const uint64_t *trace, size_t n_rows, ui
 }
 
 static int type_of_spec(const nl_spec *sp) {
-    static const int types[] = {6, 3, 5, 13, 10};
-    for (int i = 0; i < 5; i++)
+    static const int types[] = {6, 3, 5, 13, 10, 7};
+    for (int i = 0; i < 6; i++)
         if (orc_nl_spec(types[i]) == sp) return types[i];
     return 0;
 }
@@ -323,10 +326,18 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
                         if (TR(col, base + r)) { flag(&res, 6, col, base + r); break; }
             }
         }
+    size_t e_begin = 0, e_end = 0; /* ECRecover: the EC section below the queue section has its own checker (it adds its lookups to hist) */
+    if (ctype == 7) {
+        uint64_t efirst = ~0ull;
+        e_begin = orc_ec_first_row(capacity); e_end = orc_ec_used_rows(capacity);
+        if (e_end > n_rows) { free(hist); *first_bad = 0; return ~0ull; }
+        res.n += orc_ec_check(trace, capacity, n_rows, hist, &efirst);
+        if (efirst && efirst < res.first) res.first = efirst;
+    }
     const size_t bnd = NL_BOUNDARY_ROW(sp, capacity), brows = NL_BND_ROWS(sp);
     for (size_t row = 0; row < n_rows; row++) {
         if (TR(sp->mult_col, row) != (row < sp->total_table_rows ? hist[row] : 0)) flag(&res, 5, 0, row);
-        if (row < bnd) continue;
+        if (row < bnd || (row >= e_begin && row < e_end)) continue;
         const size_t off = row - bnd;
         for (uint32_t col = (row >= q_begin && row < q_end) ? sp->g : 0; col < sp->mult_col; col++) { /* (the section's general-purpose cells: orc_nlq_check) */
             int allowed = 0;

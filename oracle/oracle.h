@@ -309,6 +309,22 @@ void orc_serialize_l1_message(const zkw_log_query *q, uint8_t out[88]);
 void orc_linear_keccak256(const zkw_log_query *q, size_t n, uint8_t hash_out[32]);
 
 /* ---- the queue section of the netlist circuits (netlist_queue.c; format: include/zkw_netlist_queue.h) */
+/* ---- ECRecover circuit (type 7), ecrecover_circuit.c ---- */
+struct ec_spec;
+const struct ec_spec *orc_ec_spec(void);
+uint64_t orc_ec_first_row(uint32_t capacity);
+uint64_t orc_ec_used_rows(uint32_t capacity);
+void orc_ec_geometry(uint32_t capacity, uint64_t out[8]);
+uint32_t orc_ec_eval_cycle(const uint8_t in[128], uint64_t *tape);
+void orc_ec_outputs(const uint64_t *tape, uint8_t out[66]);
+int orc_ec_cell(int what, uint32_t k, uint32_t out[2]);
+int orc_ecrecover_synthesize(const uint8_t *inputs, uint32_t n_active, uint32_t capacity, const uint64_t pi[4], size_t n_rows, uint64_t *trace);
+uint64_t orc_ec_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint32_t *hist, uint64_t *first_bad);
+uint64_t orc_ecrecover_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
+struct nlq_feed;
+void orc_ecrecover_queue_feed(size_t first_round, uint32_t n_active, uint32_t capacity, struct nlq_feed *feed);
+int orc_nl_free_home(const nl_spec *sp, uint32_t free_index, uint32_t *row_in_cycle, uint32_t *col);
+
 typedef struct orc_nlq_queue {
     const void *items;      /* zkw_log_query / zkw_mem_query / zkw_decommit_query [n_items] */
     const uint64_t *states; /* [n_items][width]: the queue state after item i (tail after the push / head after the pop) */

@@ -721,6 +721,102 @@ def _nlq_overlay(circuit_type, trace, build_out, instance_index, capacity):
     return trace
 
 
+# ---- ECRecover circuit (type 7): oracle/ecrecover_circuit.c ------------------------------------------------------------------
+def ec_geometry(capacity):
+    """the EC section of an ECRecover trace: first row, rows per cycle, rows used by the whole trace, tape values per cycle"""
+    out = np.zeros(8, np.uint64)
+    lib().orc_ec_geometry(C.c_uint32(capacity), _p(out))
+    return dict(zip(("first_row", "rows_per_cycle", "rows_used", "tape_per_cycle", "types", "runs"), (int(x) for x in out)))
+
+
+def ec_inputs(h, v, r, s):
+    """the 128 input bytes of a cycle: value bytes (little end first) of the reads hash, v, r, s (256-bit integers)"""
+    return np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in (h, v, r, s)), np.uint8).copy()
+
+
+def ec_eval_cycle(inputs):
+    """the value tape of one cycle (include/zkw_ecrecover.h ec_eval_cycle); raises when the inputs have no witness"""
+    inp = np.ascontiguousarray(inputs, dtype=np.uint8)
+    assert inp.size == 128
+    tape = np.zeros(ec_geometry(1)["tape_per_cycle"], np.uint64)
+    f = lib().orc_ec_eval_cycle
+    f.restype = C.c_uint32
+    rc = f(_p(inp), _p(tape))
+    if rc:
+        raise RuntimeError(f"ec_eval_cycle: no witness (run {rc >> 24}, instance {(rc >> 12) & 0xFFF}, item {(rc & 0xFFF) - 1})")
+    return tape
+
+
+def ec_outputs(tape):
+    """(ok, mask, the 64 key bytes Q.x || Q.y big end first) of an evaluated tape"""
+    out = np.zeros(66, np.uint8)
+    lib().orc_ec_outputs(_p(np.ascontiguousarray(tape, dtype=np.uint64)), _p(out))
+    return int(out[0]), int(out[1]), out[2:].tobytes()
+
+
+def ec_cell(capacity, cycle, what, k):
+    """(column, trace row) of a cell of the EC section: what = "glob" (home of global k), "in" (home of input byte k), "key" (home of key
+    byte k), "mul" (column 0 of the k-th MUL row of the first double-and-add segment)"""
+    out = np.zeros(2, np.uint32)
+    f = lib().orc_ec_cell
+    f.restype = C.c_int
+    assert f(C.c_int({"glob": 0, "in": 1, "key": 2, "mul": 3}[what]), C.c_uint32(k), _p(out)) == 0
+    g = ec_geometry(capacity)
+    return int(out[1]), g["first_row"] + cycle * g["rows_per_cycle"] + int(out[0])
+
+
+def ecrecover_inputs_of(build_out, instance_index, capacity):
+    """[capacity][128]: the value bytes of the four reads of every cycle of an instance (zeros for the idle cycles)"""
+    inst = build_out["instances"][instance_index]
+    first, n = int(inst["first_round"]), int(inst["num_rounds"])
+    mq = build_out["mem_queries"]
+    inp = np.zeros((capacity, 128), np.uint8)
+    for c in range(n):
+        q = mq[6 * (first + c):6 * (first + c) + 4]
+        inp[c] = np.ascontiguousarray(q["value"]).view(np.uint8).reshape(-1)  # limb 0 first, little endian = value byte x
+    return inp
+
+
+def ecrecover_synthesize(build_out, instance_index, capacity, n_rows, public_input=None):
+    """Fill the ECRecover trace of one instance from the outputs of precompile_build(2, ...): the Keccak-f netlist over the recovered keys,
+    the queue section, the EC section"""
+    inst = build_out["instances"][instance_index]
+    first, n = int(inst["first_round"]), int(inst["num_rounds"])
+    inp = ecrecover_inputs_of(build_out, instance_index, capacity)
+    pi = np.ascontiguousarray(public_input if public_input is not None else
+                              closed_form_public_inputs(7, build_out["instances"])[1][instance_index], dtype=np.uint64)
+    trace = np.zeros((nl_geometry(7)["cols"], n_rows), np.uint64)
+    f = lib().orc_ecrecover_synthesize
+    f.restype = C.c_int
+    rc = f(_p(inp), C.c_uint32(n), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_ecrecover_synthesize failed: {rc}")
+    feed = np.zeros((capacity, 7), NLQ_FEED)
+    lib().orc_ecrecover_queue_feed(C.c_size_t(first), C.c_uint32(n), C.c_uint32(capacity), _p(feed))
+    req = np.ascontiguousarray(build_out["requests"], dtype=LOG_QUERY)
+    states0 = np.ascontiguousarray(build_out["request_tails"], dtype=np.uint64)
+    mq = np.ascontiguousarray(build_out["mem_queries"], dtype=MEM_QUERY)
+    mt = np.ascontiguousarray(build_out["mem_tails"], dtype=np.uint64)
+    init_tail = np.ascontiguousarray(np.ascontiguousarray(build_out["mem_in"], dtype=QUEUE_STATE12)["tail"][0], dtype=np.uint64)
+    queues = (_NlqQueue * 2)(_NlqQueue(req.ctypes.data, states0.ctypes.data, None, req.size), _NlqQueue(mq.ctypes.data, mt.ctypes.data, init_tail.ctypes.data, mq.size))
+    g = lib().orc_nlq_synthesize
+    g.restype = C.c_int
+    rc = g(C.c_int(7), C.c_uint32(capacity), _p(feed), queues, C.c_size_t(n_rows), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_nlq_synthesize failed: {rc}")
+    return trace
+
+
+def ecrecover_check(trace, capacity):
+    t = np.ascontiguousarray(trace, dtype=np.uint64)
+    first = C.c_uint64(0)
+    f = lib().orc_ecrecover_check
+    f.restype = C.c_uint64
+    bad = f(_p(t), C.c_uint32(capacity), C.c_size_t(t.shape[1]), C.byref(first))
+    v = first.value
+    return int(bad), (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
 def nl_spec_state(circuit_type):
     """elements of a netlist circuit's cycle state (what the boundary rows hold): 256 for the SHA-256 circuits (the chaining value's 64
     nibbles, then zeros: the steps of a compression pass more between them), 200 bytes for the Keccak circuits"""

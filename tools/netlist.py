@@ -61,7 +61,7 @@ class Table:
         if f == FN_SPLIT4:
             lo, hi = a[0] & ((1 << k) - 1), a[0] >> k
             return [lo, hi, (lo << (4 - k)) | hi]
-        raise ValueError(f)
+        raise ValueError(f)  # (FIXEDBASE tables of the ECRecover circuit have field-element outputs: never used by a byte netlist)
 
 
 def sha_tables():
