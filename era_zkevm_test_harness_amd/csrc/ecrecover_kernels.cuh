@@ -1,0 +1,203 @@
+// ecrecover_kernels.cuh — the EC SECTION of the ECRecover circuit (type 7) on the GPU: secp256k1 arithmetic over field-element-valued
+// rows below the Keccak-f netlist and the queue section of the trace. Geometry and tables are the reference wrapper's
+// (circuit_definitions/src/circuit_definitions/base_layer/ecrecover.rs:30-41,138-176); the circuit body is in the absent crate
+// era-zkevm_circuits, so the placement is this library's own: format and statement in tools/gen_ecrecover_circuit.py, item semantics in
+// include/zkw_ecrecover.h (shared with the test oracle the way nl_table_eval is).
+//
+// Fill, three kernels on the context's stream:
+//   k_ec_inputs   the value bytes of the cycle's four reads;
+//   k_ec_tape     one LANE per cycle (= request) evaluates the cycle's value tape: the items in program order — the double-and-add
+//                 chain is serial in its 288 segments, and its quotients lambda = dy / dx are modular inversions;
+//   k_ec_prepare  the tape's outputs -> the inputs of the byte netlist (the 64 key bytes, the mask, ok as FREE elements; the state the
+//                 netlist will have after the cycle = the masked address: one Keccak-f per cycle here, for the boundary rows);
+//   k_ec_stream   one lane per ROW: every cell of the row is a reference into the tape (or a constant): 128 coalesced stores per wave and
+//                 column; rows that hold lookups add their 16 slots to the multiplicity column.
+// Check: k_ec_check_items (one lane per item instance: the relation from the cells alone), k_ec_check_rows (one lane per row: copies
+// against the home cells / constants / the read queries' value bytes, empty cells, the lookups' multiplicities), k_ec_check_links (the
+// netlist's FREE elements against the key bytes / mask / ok).
+#pragma once
+#include "../../include/zkw_ecrecover_circuit_spec.h"
+#include "../../include/zkw_ecrecover.h"
+#include "netlist_queue_kernels.cuh"
+
+namespace zkw {
+
+EC_DEFINE_SPEC(h_ecs);
+
+struct EcJob {
+    const zkw_mem_query* mem_q;   // the witness's memory queries (6 per request: hash, v, r, s read; ok, address written)
+    u64 first_request;            // of the instance
+    u32 n_active;                 // requests of the instance; cycles beyond are idle (zero inputs)
+    uint8_t* inputs;              // [capacity][128]: the value bytes of the four reads of every cycle (k_ec_inputs)
+    u64* tape;                    // [capacity][EC_TAPE_PER_CYCLE]
+    u64* trace;                   // the slot
+    uint8_t* hdr_bits;            // the netlist's inputs (NlPrepJob): [capacity]
+    uint8_t* free_elems;          // [capacity][EK_FREE_PER_CYCLE]
+    uint8_t* state_before;        // [capacity + 1][200]
+};
+
+// grid (cycles, jobs) x 128: input byte k of cycle c = value byte k % 32 (little end first) of read k / 32; zeros for an idle cycle
+static __global__ __launch_bounds__(128) void k_ec_inputs(const EcJob* __restrict__ jobs) {
+    const EcJob j = jobs[blockIdx.y];
+    const u32 c = blockIdx.x, k = threadIdx.x;
+    u32 v = 0;
+    if (c < j.n_active) v = (j.mem_q[6 * (j.first_request + c) + k / 32].value[(k % 32) / 4] >> (8 * (k % 4))) & 0xFF;
+    j.inputs[(size_t)c * 128 + k] = (uint8_t)v;
+}
+
+// grid (cycles / EC_TAPE_LANES, jobs): a lane per cycle; the workspace of the 256-bit arithmetic (every array with run-time indices) is
+// a slice of LDS per lane. status: atomicMax of 1 + (job << 16 | cycle) for a cycle whose inputs have no witness
+constexpr int EC_TAPE_LANES = 64;
+static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_tape(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status) {
+    __shared__ ec_ws s_ws[EC_TAPE_LANES];
+    const EcJob j = jobs[blockIdx.y];
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= capacity) return;
+    const ec_spec S = *Sp;
+    if (ec_eval_cycle(&S, j.inputs + (size_t)c * 128, j.tape + (size_t)c * EC_TAPE_PER_CYCLE, &s_ws[threadIdx.x])) atomicMax(status, 1u + (blockIdx.y << 16 | c));
+}
+
+// grid (cycles / 64, jobs): the netlist's inputs of a cycle from its tape
+static __global__ __launch_bounds__(64) void k_ec_prepare(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity) {
+    const EcJob j = jobs[blockIdx.y];
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > capacity) return;
+    if (c == 0)
+        for (int k = 0; k < 200; k++) j.state_before[k] = 0;
+    if (c == capacity) return;
+    const ec_spec& S = *Sp;
+    const u64* tape = j.tape + (size_t)c * EC_TAPE_PER_CYCLE;
+    const u64 ok = tape[S.globs[EC_GL_OK]], mask = tape[S.globs[EC_GL_MASK]];
+    uint8_t* f = j.free_elems + (size_t)c * EK_FREE_PER_CYCLE;
+    u64 st[25];
+    for (int k = 0; k < 25; k++) st[k] = 0;
+    const u32 post0 = S.runs[EC_NUM_RUNS - 1].tape0;
+    for (int k = 0; k < 64; k++) {
+        const u64 b = tape[post0 + S.key_byte[k]];
+        f[k] = (uint8_t)b;
+        st[k / 8] |= b << (8 * (k % 8));
+    }
+    f[EK_FREE_MASK] = (uint8_t)mask;
+    f[EK_FREE_OK] = (uint8_t)ok;
+    j.hdr_bits[c] = c < j.n_active ? 0 : 2;  // idle: the queue operations of the cycle are disabled
+    st[8] ^= 0x01;                           // Keccak padding of a 64-byte message: byte 64 = 0x01, byte 135 = 0x80
+    st[16] ^= 0x80ull << 56;
+    keccak_f1600(st);
+    uint8_t* nx = j.state_before + (size_t)(c + 1) * 200;
+    for (int k = 0; k < 200; k++) nx[k] = 0;
+    for (int k = 12; k < 32; k++) nx[k] = (uint8_t)(st[k / 8] >> (8 * (k % 8))) & (uint8_t)mask;
+    nx[EK_STATE_OK] = (uint8_t)ok;
+}
+
+#define EC_TR(col, row) trace[(size_t)(col) * n_rows + (size_t)(row)]
+
+// grid (rows of a cycle / 64, cycles, jobs): a lane per row
+static __global__ __launch_bounds__(64) void k_ec_stream(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, u32 mult_col) {
+    const EcJob j = jobs[blockIdx.z];
+    const u32 c = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= EC_ROWS_PER_CYCLE) return;
+    const ec_spec& S = *Sp;
+    u64* trace = j.trace;
+    const uint8_t* in = j.inputs + (size_t)c * 128;  // (only the PRE segment's rows name input bytes)
+    u32 run, inst, row;
+    ec_locate_row(&S, r, &run, &inst, &row);
+    const ec_seg_type& T = S.types[S.runs[run].type];
+    u32 prun, pinst;
+    ec_prev_segment(&S, run, inst, &prun, &pinst);
+    const u32 base = S.runs[run].tape0 + inst * T.n_tape, pbase = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape, ptype = S.runs[prun].type;
+    const u64* tape = j.tape + (size_t)c * EC_TAPE_PER_CYCLE;
+    const uint32_t* cells = S.cells + T.cell0 + (size_t)row * EC_ROW_CELLS;
+    const size_t tr = first_row + (size_t)c * EC_ROWS_PER_CYCLE + r;
+    const u32 tb = ec_row_table(&S, run, inst, row);
+    u64 key_a = 0;
+#pragma unroll 4
+    for (u32 col = 0; col < EC_ROW_CELLS; col++) {
+        const u32 ref = cells[col];
+        u64 v = 0;
+        if (ref != EC_NONE) {
+            const u32 t = ec_ref_tape(&S, ref, base, pbase, ptype, inst);
+            v = t != EC_NONE ? tape[t] : ec_ref_const(&S, ref, in);
+        }
+        EC_TR(col, tr) = v;
+        if (tb && col >= EC_G) {  // the row's lookups: slot = (col - 80) / 3, inputs are its first two cells
+            const u32 k = (col - EC_G) % EC_W;
+            if (k == 0) key_a = v;
+            else if (k == 1) atomicAdd(reinterpret_cast<unsigned long long*>(&EC_TR(mult_col, ec_table_key(tb, key_a, v))), 1ull);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ checker
+// grid (items / 256, segment instances of a cycle, cycles): one lane per item instance
+static __global__ __launch_bounds__(256) void k_ec_check_items(const ec_spec* __restrict__ Sp, const u64* __restrict__ trace, u32 capacity, size_t n_rows, size_t first_row,
+                                                               CheckResult* res) {
+    const ec_spec S = *Sp;
+    u32 seg = blockIdx.y, run = 0;
+    while (seg >= S.runs[run].count) { seg -= S.runs[run].count; run++; }
+    const ec_seg_type& T = S.types[S.runs[run].type];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T.n_items) return;
+    const uint32_t* w = S.items + T.item0 + S.item_index[T.index0 + i];
+    const size_t seg0 = first_row + (size_t)blockIdx.z * EC_ROWS_PER_CYCLE + S.runs[run].row0 + (size_t)seg * T.n_rows;
+    const ec_row_view v = {trace, n_rows, seg0 + ((w[0] >> 4) & 0xFFF)};
+    if (ec_check_item(&S, w, &v, seg)) flag_bad(res, (w[0] & 15) == EC_I_LOOKUP ? 1 : 7, i, v.row);
+}
+
+// grid (rows of a cycle / 64, cycles): one lane per row — copies, empty cells, the multiplicities of the row's lookups
+static __global__ __launch_bounds__(64) void k_ec_check_rows(const ec_spec* __restrict__ Sp, const NlDev* __restrict__ devp, nlq_desc qd, const u64* __restrict__ trace, u32 capacity,
+                                                             size_t n_rows, size_t first_row, u32* __restrict__ hist, CheckResult* res) {
+    const u32 c = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= EC_ROWS_PER_CYCLE) return;
+    const ec_spec& S = *Sp;
+    const nl_spec& N = devp->s;
+    u32 run, inst, row;
+    ec_locate_row(&S, r, &run, &inst, &row);
+    const ec_seg_type& T = S.types[S.runs[run].type];
+    u32 prun, pinst;
+    ec_prev_segment(&S, run, inst, &prun, &pinst);
+    const u32 base = S.runs[run].tape0 + inst * T.n_tape, pbase = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape, ptype = S.runs[prun].type;
+    const uint32_t* cells = S.cells + T.cell0 + (size_t)row * EC_ROW_CELLS;
+    const size_t cyc0 = first_row + (size_t)c * EC_ROWS_PER_CYCLE, tr = cyc0 + r;
+    for (u32 col = 0; col < EC_ROW_CELLS; col++) {
+        const u32 ref = cells[col];
+        const u64 x = EC_TR(col, tr);
+        if (ref == EC_NONE) { if (x) flag_bad(res, 6, col, tr); continue; }
+        const u32 t = ec_ref_tape(&S, ref, base, pbase, ptype, inst);
+        if (t != EC_NONE) {
+            u32 hr, hc;
+            ec_home_of_tape(&S, t, &hr, &hc);
+            if (x != EC_TR(hc, cyc0 + hr)) flag_bad(res, 2, col, tr);
+        } else if ((ref >> 28) == EC_K_IN) {
+            const u32 k = ref & 0xFFFF, h = S.in_home[k];
+            if (run == 0 && row == (h >> 8) && col == (h & 0xFF)) {  // the home: a copy of value byte k % 32 of read k / 32 (queue section)
+                const u32 op = 1 + k / 32, cell = NLQ_MEM_NIBBLE0 + k % 32;
+                const size_t qrow = NLQ_ROW(&N, capacity, nlq_op_row0(&qd, N.g, op) + cell / N.g, c);
+                if (x != EC_TR(cell % N.g, qrow)) flag_bad(res, 2, 0x1000 + k, tr);
+            } else if (x != EC_TR(h & 0xFF, cyc0 + (h >> 8))) flag_bad(res, 2, col, tr);
+        } else if (x != ec_ref_const(&S, ref, nullptr)) flag_bad(res, 2, col, tr);
+    }
+    const u32 tb = ec_row_table(&S, run, inst, row);
+    if (tb)
+        for (u32 slot = 0; slot < EC_R; slot++) {
+            const u64 a = EC_TR(EC_G + EC_W * slot, tr), b = EC_TR(EC_G + EC_W * slot + 1, tr);
+            if (a < 256 && (tb != EC_T_XOR8 || b < 256)) atomicAdd(&hist[ec_table_key(tb, a, b)], 1u);  // (a bad key: flagged by its item)
+        }
+}
+
+// grid (cycles): lane k = FREE element k of the cycle's netlist against the EC value it copies (key byte / mask / ok)
+static __global__ __launch_bounds__(128) void k_ec_check_links(const ec_spec* __restrict__ Sp, const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ free_home,
+                                                               const u64* __restrict__ trace, size_t n_rows, size_t first_row, CheckResult* res) {
+    const u32 c = blockIdx.x, k = threadIdx.x;
+    if (k >= EK_FREE_PER_CYCLE) return;
+    const ec_spec& S = *Sp;
+    const NlqFreeHome fh = free_home[k];
+    if (fh.row == 0xFFFF) return;
+    const u32 t = k < 64 ? S.runs[EC_NUM_RUNS - 1].tape0 + S.key_byte[k] : S.globs[k == EK_FREE_MASK ? EC_GL_MASK : EC_GL_OK];
+    u32 hr, hc;
+    ec_home_of_tape(&S, t, &hr, &hc);
+    const size_t nrow = (size_t)c * devp->s.rows_per_cycle + fh.row;
+    if (EC_TR(fh.col, nrow) != EC_TR(hc, first_row + (size_t)c * EC_ROWS_PER_CYCLE + hr)) flag_bad(res, 2, 0x2000 + k, nrow);
+}
+#undef EC_TR
+
+}  // namespace zkw

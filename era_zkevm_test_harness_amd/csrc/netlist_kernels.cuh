@@ -17,6 +17,7 @@
 #include "../../include/zkw_keccak_circuit_spec.h"
 #include "../../include/zkw_linear_hasher_circuit_spec.h"
 #include "../../include/zkw_storage_application_circuit_spec.h"
+#include "../../include/zkw_ecrecover_circuit_spec.h"
 #include "../../include/zkw_types.h"
 #include "ram_circuit_kernels.cuh"  // CheckResult, flag_bad
 
@@ -30,6 +31,7 @@ NL_DEFINE_SPEC(h_dc, DC);
 NL_DEFINE_SPEC(h_kc, KC);
 NL_DEFINE_SPEC(h_lh, LH);
 NL_DEFINE_SPEC(h_sa, SA);
+NL_DEFINE_SPEC(h_ek, EK);  // ECRecover (7): Keccak-f over the recovered public key; its EC section: ecrecover_kernels.cuh
 static inline const nl_spec* nl_host_spec(int circuit_type) {
     switch (circuit_type) {
         case 6: return &h_sc_spec;
@@ -37,6 +39,7 @@ static inline const nl_spec* nl_host_spec(int circuit_type) {
         case 5: return &h_kc_spec;
         case 13: return &h_lh_spec;
         case 10: return &h_sa_spec;
+        case 7: return &h_ek_spec;
         default: return nullptr;
     }
 }
@@ -128,7 +131,7 @@ struct NlLds {
         tab = take(s.n_tables * sizeof(nl_table));
         types = take(s.n_step_types * sizeof(nl_step_type));
         cyc = take(s.steps_per_cycle * sizeof(nl_cycle_step));
-        op_table = take(s.n_ops);
+        op_table = take(s.n_ops * 2);  // (16-bit: the ECRecover table set has 262 tables)
         op_in = take(s.n_ops * 6);
         op_out = take(s.n_ops * 2);
         gates = take(s.n_gates * sizeof(NlLdsGate));
@@ -180,7 +183,7 @@ static __global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __re
     nl_table* const s_tab = reinterpret_cast<nl_table*>(lds + L.tab);
     nl_step_type* const s_types = reinterpret_cast<nl_step_type*>(lds + L.types);
     nl_cycle_step* const s_cyc = reinterpret_cast<nl_cycle_step*>(lds + L.cyc);
-    uint8_t* const s_op_table = lds + L.op_table;
+    uint16_t* const s_op_table = reinterpret_cast<uint16_t*>(lds + L.op_table);
     uint16_t* const s_op_in = reinterpret_cast<uint16_t*>(lds + L.op_in);  // [3][n_ops]
     uint16_t* const s_op_out = reinterpret_cast<uint16_t*>(lds + L.op_out);
     NlLdsGate* const s_gates = reinterpret_cast<NlLdsGate*>(lds + L.gates);
@@ -197,7 +200,7 @@ static __global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __re
     for (u32 i = t; i < S.steps_per_cycle; i += NL_FILL_THREADS) s_cyc[i] = S.cycle[i];
     for (u32 i = t; i < S.n_ops; i += NL_FILL_THREADS) {
         const nl_op op = S.ops[i];
-        s_op_table[i] = (uint8_t)op.table;
+        s_op_table[i] = op.table;
         for (int k = 0; k < 3; k++) s_op_in[k * S.n_ops + i] = V.dense(op.in[k]);
         s_op_out[i] = op.out;
     }
@@ -856,14 +859,15 @@ static __global__ __launch_bounds__(256) void k_nl_check_steps(const NlDev* __re
 }
 
 static __global__ __launch_bounds__(256) void k_nl_check_tail(const NlDev* __restrict__ devp, const u64* __restrict__ trace, u32 capacity, size_t n_rows,
-                                                       const u32* __restrict__ hist, CheckResult* res, u64 q_begin, u64 q_end) {
-    // rows [q_begin, q_end): the queue section (netlist_queue_kernels.cuh checks its general-purpose cells; its lookup cells are zero)
+                                                       const u32* __restrict__ hist, CheckResult* res, u64 q_begin, u64 q_end, u64 e_begin, u64 e_end) {
+    // rows [q_begin, q_end): the queue section (netlist_queue_kernels.cuh checks its general-purpose cells; its lookup cells are zero);
+    // rows [e_begin, e_end): the EC section of the ECRecover circuit (ecrecover_kernels.cuh checks every cell of it)
     const nl_spec& S = devp->s;
     const size_t bnd = NL_BOUNDARY_ROW(&S, capacity), brows = NL_BND_ROWS(&S);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += stride) {
         if (NL_TR(S.mult_col, row) != (row < S.total_table_rows ? (u64)hist[row] : 0)) flag_bad(res, 5, 0, row);
-        if (row < bnd) continue;
+        if (row < bnd || (row >= e_begin && row < e_end)) continue;
         const size_t off = row - bnd;
         for (u32 col = (row >= q_begin && row < q_end) ? S.g : 0; col < S.mult_col; col++) {
             bool allowed = false;

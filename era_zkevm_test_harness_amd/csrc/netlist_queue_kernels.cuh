@@ -49,7 +49,9 @@ static __global__ __launch_bounds__(64) void k_nlq_feed(int circuit_type, const 
     const RoundOps ro = j.round_ops[j.first_round + c];
     const u32 pop = ro.flags & 1;
     f[0] = nlq_feed{pop, pop ? ro.request : ro.request + 1};
-    if (circuit_type == 5) {  // up to six reads, then the digest write
+    if (circuit_type == 7) {  // one request per cycle: four reads, two writes
+        for (u32 k = 0; k < 6; k++) f[1 + k] = nlq_feed{1, ro.first_query + k};
+    } else if (circuit_type == 5) {  // up to six reads, then the digest write
         const u32 write = (ro.flags >> 1) & 1, n_reads = ro.n_push - write;
         for (u32 k = 0; k < 6; k++) f[1 + k] = nlq_feed{k < n_reads ? 1u : 0u, ro.first_query + (k < n_reads ? k : n_reads)};
         f[7] = nlq_feed{write, ro.first_query + n_reads};

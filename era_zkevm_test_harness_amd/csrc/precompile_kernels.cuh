@@ -75,7 +75,7 @@ struct PrecompileJob {
     u32 capacity;
     zkw_keccak_round_record* keccak_rounds;  // keccak256 only, may be null: one record per round in the global round order
     zkw_sha256_round_record* sha256_rounds;  // sha256 only, may be null
-    RoundOps* round_ops;                     // keccak256 / sha256, may be null: [total_rounds]
+    RoundOps* round_ops;                     // may be null: [total_rounds]
 };
 
 __device__ __forceinline__ void word_be_bytes(const u32* limbs, uint8_t out[32]) {  // U256::to_big_endian
@@ -144,6 +144,7 @@ static __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job
         } else if (kind == ZKW_PRECOMPILE_ECRECOVER) {
             for (int k = 0; k < 4; k++) bad |= job.mem_q[qpos + k].rw_flag;
             for (int k = 4; k < 6; k++) bad |= !job.mem_q[qpos + k].rw_flag;
+            if (job.round_ops) job.round_ops[g0 + round] = RoundOps{(u32)r, (u32)qpos, 6u, 1u};  // the request's one round pops it and pushes its six queries
             qpos += 6; reads += 4;
         } else {
             const bool paddings_round = needs_extra_padding_round && is_last_round;

@@ -3,6 +3,8 @@
 // which `match`es over the enum's thirteen variants, and of `base_test_circuit`'s `check_if_satisfied` (src/tests/mod.rs:130-259).
 // Host code written against include/zkw.h only: one `switch` over BaseLayerCircuitType in front of the per-type functions, so that
 // a host holds ONE function pointer per operation, like the reference's enum method. No kernels.
+#include <vector>
+
 #include "../../include/zkw.h"
 #include "zkw_internal.h"
 
@@ -25,11 +27,17 @@ extern "C" int zkw_synthesize(zkw_ctx* ctx, uint8_t circuit_type, const void* wi
             // one instance per queue (data_hasher_and_merklizer.rs:34-60): "instance k" of the witness is its k-th queue
             const zkw_linear_hasher_witness* lw = static_cast<const zkw_linear_hasher_witness*>(witness);
             if (first_instance + n_instances > lw->n_queues || !lw->message_offsets) return zkw_fail(ZKW_ERR_INVALID, "zkw_synthesize: L1MessagesHasher queues [%zu, %zu) of %zu", first_instance, first_instance + n_instances, lw->n_queues);
-            return zkw_linear_hasher_synthesize_batch_with_tails(ctx, lw->messages, lw->message_offsets + first_instance, n_instances, lw->queue_states + first_instance,
-                                                                 lw->message_tails, lw->capacity, t, first_slot, lw->records_out ? lw->records_out + first_instance : nullptr,
+            // the batch entry point wants offsets that start at 0 and a records array: rebase the window [first_instance, + n_instances)
+            std::vector<uint64_t> off(n_instances + 1);
+            const uint64_t base = lw->message_offsets[first_instance];
+            for (size_t k = 0; k <= n_instances; k++) off[k] = lw->message_offsets[first_instance + k] - base;
+            std::vector<zkw_linear_hasher_instance> scratch_records(lw->records_out ? 0 : n_instances);
+            return zkw_linear_hasher_synthesize_batch_with_tails(ctx, lw->messages ? lw->messages + base : nullptr, off.data(), n_instances, lw->queue_states + first_instance,
+                                                                 lw->message_tails ? lw->message_tails + 4 * base : nullptr, lw->capacity, t, first_slot,
+                                                                 lw->records_out ? lw->records_out + first_instance : scratch_records.data(),
                                                                  lw->public_inputs_out ? lw->public_inputs_out + 4 * first_instance : nullptr);
         }
-        case ZKW_CIRCUIT_ECRECOVER: return zkw_fail(ZKW_ERR_INVALID, "zkw_synthesize: ECRecover (type 7) is not synthesized yet");
+        case ZKW_CIRCUIT_ECRECOVER: return zkw_ecrecover_synthesize(ctx, static_cast<zkw_precompile_witness*>(w), first_instance, n_instances, t, first_slot);
         case ZKW_CIRCUIT_MAIN_VM: return zkw_fail(ZKW_ERR_INVALID, "zkw_synthesize: MainVM (type 1) has no synthesis in this library (it needs the VM; DESIGN.md)");
         default: return zkw_fail(ZKW_ERR_INVALID, "zkw_synthesize: unknown circuit type %u", circuit_type);
     }
@@ -43,7 +51,7 @@ extern "C" int zkw_check_satisfied(zkw_ctx* ctx, uint8_t circuit_type, const zkw
         case ZKW_CIRCUIT_LOG_DEMUXER: return zkw_log_demux_check_satisfied(ctx, t, slot, capacity, n_violations, first_bad);
         case ZKW_CIRCUIT_KECCAK256_ROUND_FUNCTION: return zkw_keccak_round_check_satisfied(ctx, t, slot, capacity, n_violations, first_bad);
         case ZKW_CIRCUIT_SHA256_ROUND_FUNCTION: return zkw_sha256_round_check_satisfied(ctx, t, slot, capacity, n_violations, first_bad);
-        case ZKW_CIRCUIT_ECRECOVER: return zkw_fail(ZKW_ERR_INVALID, "zkw_check_satisfied: ECRecover (type 7) is not synthesized yet");
+        case ZKW_CIRCUIT_ECRECOVER: return zkw_ecrecover_check_satisfied(ctx, t, slot, capacity, n_violations, first_bad);
         case ZKW_CIRCUIT_RAM_PERMUTATION: return zkw_ram_check_satisfied(ctx, t, slot, capacity, n_violations, first_bad);
         case ZKW_CIRCUIT_STORAGE_SORTER: return zkw_storage_sorter_check_satisfied(ctx, t, slot, capacity, n_violations, first_bad);
         case ZKW_CIRCUIT_STORAGE_APPLICATION: return zkw_storage_application_check_satisfied(ctx, t, slot, capacity, n_violations, first_bad);

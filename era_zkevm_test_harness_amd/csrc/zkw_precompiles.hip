@@ -10,6 +10,7 @@
 #include "storage_application_kernels.cuh"
 #include "netlist_kernels.cuh"
 #include "netlist_queue_kernels.cuh"
+#include "ecrecover_kernels.cuh"
 #include "sort.h"
 
 // ------------------------------------------------------------------------------------------------ code decommitter
@@ -304,12 +305,10 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
     alloc((void**)&w->instances, w->n_instances * sizeof(zkw_precompile_instance));
     if (kind == ZKW_PRECOMPILE_KECCAK256) alloc((void**)&w->keccak_rounds, w->total_rounds * sizeof(zkw_keccak_round_record));
     if (kind == ZKW_PRECOMPILE_SHA256) alloc((void**)&w->sha256_rounds, w->total_rounds * sizeof(zkw_sha256_round_record));
-    if (kind != ZKW_PRECOMPILE_ECRECOVER) {
-        alloc((void**)&w->requests, n_requests * sizeof(zkw_log_query));
-        alloc((void**)&w->req_tails, n_requests * 32);
-        alloc((void**)&w->mem_q, n_queries * sizeof(zkw_mem_query));
-        alloc((void**)&w->round_ops, w->total_rounds * sizeof(RoundOps));
-    }
+    alloc((void**)&w->requests, n_requests * sizeof(zkw_log_query));  // (the queue sections of the three circuits)
+    alloc((void**)&w->req_tails, n_requests * 32);
+    alloc((void**)&w->mem_q, n_queries * sizeof(zkw_mem_query));
+    alloc((void**)&w->round_ops, w->total_rounds * sizeof(RoundOps));
     w->mem_in = *mem_in;
     auto bail = [&](int rc) { w->release(); delete w; return rc; };
     if (e != hipSuccess) return bail(fail(ZKW_ERR_OOM, "zkw_precompile_build: hipMalloc failed: %s", hipGetErrorString(e)));
@@ -334,8 +333,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
                 if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
             }
         }
-        if (kind != ZKW_PRECOMPILE_ECRECOVER &&
-            (hipMemcpyAsync(w->requests, d_req, n_requests * sizeof(zkw_log_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        if ((hipMemcpyAsync(w->requests, d_req, n_requests * sizeof(zkw_log_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
              hipMemcpyAsync(w->req_tails, d_rt, n_requests * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
              (n_queries && hipMemcpyAsync(w->mem_q, d_mq, n_queries * sizeof(zkw_mem_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)))
             return bail(fail(ZKW_ERR_HIP, "copy of the precompile calls failed"));
@@ -702,7 +700,9 @@ int nl_get(zkw_ctx* ctx, int circuit_type, const NlCached** out) {
     }
     first[hs->n_tables] = (u32)entries.size();
     std::vector<u32> slices(hs->n_tables, 1);
-    for (int left = 64 - (int)hs->n_tables; left > 0; left--) {  // the next slice goes to the table with the most lookups per slice
+    int in_use = 0;  // a table no lookup of the netlist uses (ECRecover's FixedBaseMul tables: its EC section counts those) gets no slice
+    for (u32 tb = 0; tb < hs->n_tables; tb++) { slices[tb] = weight[tb] ? 1 : 0; in_use += weight[tb] ? 1 : 0; }
+    for (int left = 64 - in_use; left > 0; left--) {  // the next slice goes to the table with the most lookups per slice
         u32 best = 0;
         for (u32 tb = 1; tb < hs->n_tables; tb++)
             if (weight[tb] * slices[best] > weight[best] * slices[tb]) best = tb;
@@ -1059,6 +1059,7 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
         case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
         case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
         case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
+        case 7: ZKW_TRY((nl_launch_fill<EK_W, EK_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
         default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;  // 13 and 10: 3 x 26
     }
     { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
@@ -1114,6 +1115,44 @@ int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std
     return launch_check("k_nlq_fill");
 }
 
+// ---- the EC section of the ECRecover circuit (ecrecover_kernels.cuh): the spec on the device, once per device
+struct EcCached { ec_spec host; const ec_spec* dev = nullptr; u32 segments_per_cycle = 0; };
+std::map<int, EcCached>& ec_cache() { static auto* m = new std::map<int, EcCached>(); return *m; }
+size_t ec_first_row(u32 capacity) { return nlq_used_rows(nl_host_spec(7), nlq_desc_of(7), capacity); }
+size_t ec_used_rows(u32 capacity) { return ec_first_row(capacity) + (size_t)capacity * EC_ROWS_PER_CYCLE; }
+int ec_get(zkw_ctx* ctx, const EcCached** out) {
+    std::lock_guard<std::mutex> g(g_nl_mu);
+    EcCached& c = ec_cache()[ctx->device];
+    if (c.dev) { *out = &c; return ZKW_OK; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    static const std::vector<uint32_t>* fixed = [] {  // the 256 FixedBaseMul tables (8 192 curve points), built once per process
+        auto* v = new std::vector<uint32_t>(EC_FIXED_WORDS);
+        ec_build_fixed_tables(v->data());
+        return v;
+    }();
+    ec_spec d;
+    ZKW_TRY(nl_to_device(h_ecs_types, EC_NUM_TYPES, &d.types));
+    ZKW_TRY(nl_to_device(h_ecs_runs, EC_NUM_RUNS, &d.runs));
+    ZKW_TRY(nl_to_device(h_ecs_items, EC_NUM_ITEM_WORDS, &d.items));
+    ZKW_TRY(nl_to_device(h_ecs_item_index, EC_NUM_ITEMS, &d.item_index));
+    ZKW_TRY(nl_to_device(h_ecs_cells, EC_NUM_CELLS, &d.cells));
+    ZKW_TRY(nl_to_device(h_ecs_homes, EC_NUM_HOMES, &d.homes));
+    ZKW_TRY(nl_to_device(h_ecs_outs, (size_t)EC_NUM_TYPES * EC_STATE, &d.outs));
+    ZKW_TRY(nl_to_device(h_ecs_rowtab, EC_NUM_ROWTAB, &d.rowtab));
+    ZKW_TRY(nl_to_device(h_ecs_globs, EC_GL_COUNT, &d.globs));
+    ZKW_TRY(nl_to_device(h_ecs_bigs, (size_t)EC_NUM_BIGS * 16, &d.bigs));
+    ZKW_TRY(nl_to_device(h_ecs_in_home, 128, &d.in_home));
+    ZKW_TRY(nl_to_device(h_ecs_key_byte, 64, &d.key_byte));
+    ZKW_TRY(nl_to_device(fixed->data(), fixed->size(), &d.fixed));
+    const ec_spec* dd = nullptr;
+    ZKW_TRY(nl_to_device(&d, 1, &dd));
+    c.host = ec_spec{h_ecs_types, h_ecs_runs, h_ecs_items, h_ecs_item_index, h_ecs_cells, h_ecs_homes, h_ecs_outs, h_ecs_rowtab, h_ecs_globs, h_ecs_bigs, h_ecs_in_home, h_ecs_key_byte, fixed->data()};
+    for (u32 r = 0; r < EC_NUM_RUNS; r++) c.segments_per_cycle += h_ecs_runs[r].count;
+    c.dev = dd;
+    *out = &c;
+    return ZKW_OK;
+}
+
 int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u32 capacity, uint64_t* n_violations, uint64_t* first_bad) {
     const NlCached* nc = nullptr;
     ZKW_TRY(nl_get(ctx, circuit_type, &nc));
@@ -1133,7 +1172,20 @@ int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u3
     HIP_TRY(hipMemsetAsync(d_hist, 0, S.total_table_rows * sizeof(u32), ctx->stream));
     { Prof _p(ctx, "k_nl_check_steps"); hipLaunchKernelGGL(k_nl_check_steps, dim3((nc->host.max_items + 255) / 256, capacity * S.steps_per_cycle), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
     ZKW_TRY(launch_check("k_nl_check_steps"));
-    { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res, (u64)NL_USED_ROWS(&S, capacity), (u64)nlq_used_rows(&S, qd, capacity)); }
+    u64 e_begin = 0, e_end = 0;
+    if (circuit_type == 7) {  // the EC section below the queue section: its own checker, which adds its lookups to the histogram first
+        const EcCached* ec = nullptr;
+        ZKW_TRY(ec_get(ctx, &ec));
+        e_begin = ec_first_row(capacity); e_end = ec_used_rows(capacity);
+        if (e_end > n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+        { Prof _p(ctx, "k_ec_check_items"); hipLaunchKernelGGL(k_ec_check_items, dim3((EC_MAX_ITEMS + 255) / 256, ec->segments_per_cycle, capacity), dim3(256), 0, ctx->stream, ec->dev, trace, capacity, n_rows, (size_t)e_begin, d_res); }
+        ZKW_TRY(launch_check("k_ec_check_items"));
+        { Prof _p(ctx, "k_ec_check_rows"); hipLaunchKernelGGL(k_ec_check_rows, dim3((EC_ROWS_PER_CYCLE + 63) / 64, capacity), dim3(64), 0, ctx->stream, ec->dev, nc->dev, *qd, trace, capacity, n_rows, (size_t)e_begin, d_hist, d_res); }
+        ZKW_TRY(launch_check("k_ec_check_rows"));
+        { Prof _p(ctx, "k_ec_check_links"); hipLaunchKernelGGL(k_ec_check_links, dim3(capacity), dim3(128), 0, ctx->stream, ec->dev, nc->dev, nc->free_home, trace, n_rows, (size_t)e_begin, d_res); }
+        ZKW_TRY(launch_check("k_ec_check_links"));
+    }
+    { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res, (u64)NL_USED_ROWS(&S, capacity), (u64)nlq_used_rows(&S, qd, capacity), e_begin, e_end); }
     ZKW_TRY(launch_check("k_nl_check_tail"));
     if (qd) {
         { Prof _p(ctx, "k_nlq_check"); hipLaunchKernelGGL(k_nlq_check, dim3((capacity + 63) / 64, qd->n_ops), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, *qd, *nlq_rels_of(circuit_type), trace, capacity, n_rows, d_res); }
@@ -1186,6 +1238,67 @@ extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
         return fail(ZKW_ERR_INVALID, "zkw_keccak_round_check_satisfied: bad argument");
     return nl_check(ctx, 5, t, slot, capacity, n_violations, first_bad);
+}
+
+// ZkSyncBaseLayerCircuit::synthesis for ECRecover (type 7): 80 + 3 x 16 columns, Xor8 / And8 / 8 x 32 FixedBaseMul / ByteSplit<1..4> =
+// 197 632 table rows (base_layer/ecrecover.rs:30-41,138-176). One cycle per request (ecrecover.rs:143-178: four reads, two writes):
+// the EC section recovers the key from the read values, the netlist hashes it, the queue section pops the call and pushes the queries.
+extern "C" int zkw_ecrecover_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances, zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_ecrecover_synthesize: bad argument");
+    if (w->kind != ZKW_PRECOMPILE_ECRECOVER) return fail(ZKW_ERR_INVALID, "zkw_ecrecover_synthesize: not an ecrecover witness");
+    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
+    if (t->n_cols < EK_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the ECRecover circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, EK_COLS);
+    if (n_instances == 0) return ZKW_OK;
+    const u32 capacity = w->capacity;
+    const size_t n_rows = t->n_rows;
+    if (ec_used_rows(capacity) > n_rows) return fail(ZKW_ERR_INVALID, "capacity %u needs %zu rows, trace has %zu", capacity, ec_used_rows(capacity), n_rows);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
+    const EcCached* ec = nullptr;
+    ZKW_TRY(ec_get(ctx, &ec));
+    const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
+    const size_t ni = inst.size();
+    u64* d_tape = nullptr;
+    u32* d_status = nullptr;
+    uint8_t* d_inputs = nullptr;
+    ZKW_TRY(ctx->scratch_t<u64>("ec_tape", ni * capacity * (size_t)EC_TAPE_PER_CYCLE, &d_tape));
+    ZKW_TRY(ctx->scratch_t<uint8_t>("ec_inputs", ni * capacity * (size_t)128, &d_inputs));
+    ZKW_TRY(ctx->scratch_t<u32>("ec_status", 1, &d_status));
+    HIP_TRY(hipMemsetAsync(d_status, 0, 4, ctx->stream));
+    std::vector<EcJob> jobs(ni);
+    EcJob* d_jobs = nullptr;
+    const unsigned cb = (capacity + 1 + 63) / 64, nj = (unsigned)ni;
+    // the netlist's inputs come from the EC tapes: evaluate them inside the engine's `prepare` step
+    ZKW_TRY(nl_synthesize_with(ctx, 7, [&](std::vector<NlPrepJob>& prep) {
+        for (size_t k = 0; k < ni; k++)
+            jobs[k] = EcJob{w->mem_q, inst[k].first_round, inst[k].n_active, d_inputs + k * capacity * (size_t)128, d_tape + k * capacity * (size_t)EC_TAPE_PER_CYCLE,
+                            inst[k].t->data + inst[k].slot * inst[k].t->slot_elems(), prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
+        ZKW_TRY(ctx->upload("ec_jobs", jobs, &d_jobs));
+        { Prof _p(ctx, "k_ec_inputs"); hipLaunchKernelGGL(k_ec_inputs, dim3(capacity, nj), dim3(128), 0, ctx->stream, d_jobs); }
+        ZKW_TRY(launch_check("k_ec_inputs"));
+        { Prof _p(ctx, "k_ec_tape"); hipLaunchKernelGGL(k_ec_tape, dim3((capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj), dim3(EC_TAPE_LANES), 0, ctx->stream, ec->dev, d_jobs, capacity, d_status); }
+        ZKW_TRY(launch_check("k_ec_tape"));
+        { Prof _p(ctx, "k_ec_prepare"); hipLaunchKernelGGL(k_ec_prepare, dim3(cb, nj), dim3(64), 0, ctx->stream, ec->dev, d_jobs, capacity); }
+        return launch_check("k_ec_prepare");
+    }, inst, capacity, n_rows));
+    u32 status = 0;
+    ZKW_TRY(ctx->read_small(&status, d_status, 4));
+    if (status) return fail(ZKW_ERR_CHECK_FAILED, "zkw_ecrecover_synthesize: request %llu has no witness (the accumulator of the incomplete addition met x1 == x2)",
+                            (unsigned long long)(inst[(status - 1) >> 16].first_round + ((status - 1) & 0xFFFF)));
+    NlqQueues Q{};
+    Q.q[0] = NlqQueueIn{w->requests, w->req_tails, {0}, w->n_requests};
+    Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->n_queries};
+    memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
+    Q.round_ops = w->round_ops;
+    ZKW_TRY(nlq_synthesize(ctx, 7, Q, inst, capacity, n_rows));
+    { Prof _p(ctx, "k_ec_stream"); hipLaunchKernelGGL(k_ec_stream, dim3((EC_ROWS_PER_CYCLE + 63) / 64, capacity, nj), dim3(64), 0, ctx->stream, ec->dev, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL); }
+    return launch_check("k_ec_stream");
+}
+extern "C" int zkw_ecrecover_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
+    if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
+        return fail(ZKW_ERR_INVALID, "zkw_ecrecover_check_satisfied: bad argument");
+    return nl_check(ctx, 7, t, slot, capacity, n_violations, first_bad);
 }
 
 // ZkSyncBaseLayerCircuit::synthesis for Sha256RoundFunction (type 6): 116 + 4 x 9 columns, TriXor4 / Ch4 / Maj4 / Split4BitChunk<1, 2>

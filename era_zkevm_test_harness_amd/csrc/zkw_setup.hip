@@ -8,6 +8,7 @@
 #include "storage_sorter_circuit_kernels.cuh"
 #include "netlist_kernels.cuh"
 #include "../../include/zkw_netlist_queue.h"
+#include "../../include/zkw_ecrecover.h"
 
 extern "C" int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometry* out) {
     // {copy columns, lookup width, repetitions, max degree, capacity, big size hint}: vm_main.rs:29-44,
@@ -63,7 +64,7 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
         case 9: out->num_columns = SS_COLS; out->rows_per_cycle = SS_ROWS_PER_CYCLE; out->region_stride = SS_REGION_STRIDE(capacity); boundary = SS_BOUNDARY_ROW(capacity); min_rows = SS_MIN_ROWS(capacity); pi_off = SS_ROWOFF_PI; break;
         case 11: case 12: out->num_columns = ES_COLS; out->rows_per_cycle = ES_ROWS_PER_CYCLE; out->region_stride = ES_REGION_STRIDE(capacity); boundary = ES_BOUNDARY_ROW(capacity); min_rows = ES_MIN_ROWS(capacity); pi_off = ES_ROWOFF_PI; break;
         // the netlist circuits ("zkw trace v4") are cycle-major: region_stride = 0, cycle i starts at row i * rows_per_cycle
-        case 3: case 5: case 6: case 10: case 13: {
+        case 3: case 5: case 6: case 7: case 10: case 13: {
             const nl_spec* sp = nl_host_spec(circuit_type);
             const uint32_t cycles = nl_cycles_of(circuit_type, capacity);
             out->num_columns = sp->cols; out->rows_per_cycle = sp->rows_per_cycle; boundary = NL_BOUNDARY_ROW(sp, cycles);
@@ -71,6 +72,12 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
             min_rows = nlq_used_rows(sp, qd, cycles); pi_off = 2 * NL_BND_ROWS(sp);
             out->total_table_rows = sp->total_table_rows;
             if (qd) { out->queue_first_row = NLQ_BASE(sp, cycles); out->queue_rows_per_cycle = nlq_rows_per_cycle(qd, sp->g); }
+            if (circuit_type == 7) {  // the EC section below the queue section, cycle-major (include/zkw_ecrecover.h)
+                out->ec_first_row = min_rows;
+                out->ec_rows_per_cycle = EC_ROWS_PER_CYCLE;
+                min_rows += (uint64_t)cycles * EC_ROWS_PER_CYCLE;
+                if (min_rows < sp->total_table_rows) min_rows = sp->total_table_rows;  // the multiplicity column has a row per table row (197 632 > 7 cycles' rows)
+            }
             break;
         }
         default: return ZKW_OK;  // a known circuit type this library does not synthesize yet: synthesizable = 0
@@ -118,10 +125,31 @@ extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, 
         uint8_t* row = one.data() + sp->cycle[st].row0;
         row[0] = ZKW_ROW_HEADER;
         for (uint32_t r = 1; r < T.rows; r++)
-            row[r] = (uint8_t)((r <= T.lookup_rows ? sp->ops[T.op0 + (r - 1) * sp->r].table : 0) | (sp->gate_row_end[T.rowend0 + r] ? ZKW_ROW_HAS_GATES : 0));
+        {
+            uint32_t tb = r <= T.lookup_rows ? sp->ops[T.op0 + (r - 1) * sp->r].table : 0;
+            if (tb > 2 && sp->n_tables > 0x3F) tb -= 256;  // ECRecover's 262 tables: its netlist uses Xor8 (1), And8 (2) and ByteSplit<k> (259..262 -> 3..6)
+            row[r] = (uint8_t)(tb | (sp->gate_row_end[T.rowend0 + r] ? ZKW_ROW_HAS_GATES : 0));
+        }
     }
     for (uint32_t c = 0; c < cycles; c++) memcpy(out + (uint64_t)c * rpc, one.data(), rpc);
     for (uint64_t k = 0; (uint64_t)cycles * rpc + k < NL_USED_ROWS(sp, cycles); k++) out[(uint64_t)cycles * rpc + k] = (uint8_t)(ZKW_ROW_BOUNDARY + k);
+    if (circuit_type == 7) {  // the EC section: per row the table of its lookup slots / whether it is a MUL row / has gates
+        EC_DEFINE_SPEC(ecs);
+        std::vector<uint8_t> cyc(EC_ROWS_PER_CYCLE, ZKW_ROW_EC_GATES);
+        for (uint32_t r = 0; r < EC_NUM_RUNS; r++) {
+            const ec_seg_type& T = ecs_types[ecs_runs[r].type];
+            std::vector<uint8_t> seg(T.n_rows, ZKW_ROW_EC_GATES);
+            for (uint32_t row = 0; row < T.n_rows; row++) {
+                const uint32_t tb = ecs_rowtab[T.rowtab0 + row];
+                if (tb) seg[row] = (tb & 0x7FFF) == EC_T_XOR8 ? ZKW_ROW_EC_XOR8 : ZKW_ROW_EC_FIXED_BASE;
+            }
+            const uint32_t* w = ecs_items + T.item0;
+            for (uint32_t i = 0; i < T.n_items; i++, w += ec_item_words(w))
+                if ((w[0] & 15) == EC_I_MUL) seg[(w[0] >> 4) & 0xFFF] |= ZKW_ROW_EC_MUL;
+            for (uint32_t j = 0; j < ecs_runs[r].count; j++) memcpy(cyc.data() + ecs_runs[r].row0 + (size_t)j * T.n_rows, seg.data(), T.n_rows);
+        }
+        for (uint32_t c = 0; c < cycles; c++) memcpy(out + lay.ec_first_row + (uint64_t)c * EC_ROWS_PER_CYCLE, cyc.data(), EC_ROWS_PER_CYCLE);
+    }
     if (const nlq_desc* qd = nlq_desc_of(circuit_type)) {  // the queue section: region-major below the PI row
         out[NLQ_BASE(sp, cycles)] = ZKW_ROW_QUEUE_BOUNDARY;
         for (uint32_t j = 0; j < qd->n_ops; j++) {

@@ -140,6 +140,8 @@ SYMBOLS = [
     ("zkw_linear_hasher_synthesize_batch_with_tails", _int, [_vp, _vp, _vp, _sz, _vp, _vp, C.c_uint32, _vp, _sz, _vp, _vp]),
     ("zkw_linear_hasher_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
+    ("zkw_ecrecover_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_ecrecover_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
     ("zkw_storage_application_witness_bytes", _sz, [_vp, _int]),
@@ -1092,7 +1094,7 @@ CIRCUIT_GEOMETRY = np.dtype(
 CIRCUIT_LAYOUT = np.dtype(
     [("synthesizable", "<u4"), ("fits", "<u4"), ("capacity", "<u4"), ("num_columns", "<u4"), ("rows_per_cycle", "<u4"), ("total_table_rows", "<u4"),
      ("region_stride", "<u8"), ("rows_used", "<u8"), ("nop_rows", "<u8"), ("trace_len", "<u8"), ("public_input_column", "<u4", (4,)),
-     ("public_input_row", "<u8", (4,)), ("queue_first_row", "<u8"), ("queue_rows_per_cycle", "<u4"), ("_pad", "<u4")])
+     ("public_input_row", "<u8", (4,)), ("queue_first_row", "<u8"), ("queue_rows_per_cycle", "<u4"), ("ec_rows_per_cycle", "<u4"), ("ec_first_row", "<u8")])
 
 
 def circuit_layout(circuit_type: int, capacity: int = 0):
@@ -1171,6 +1173,23 @@ def _ctx_synthesize_keccak_round_function(self, witness, trace, first_instance=0
 def _ctx_check_if_satisfied_keccak_round_function(self, trace, slot, capacity):
     bad, first = C.c_uint64(0), C.c_uint64(0)
     _check(load().zkw_keccak_round_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
+    v = first.value
+    return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
+
+
+EK_COLS = 129  # 80 + 3 x 16 + 1 (include/zkw_ecrecover_circuit_spec.h)
+
+
+def _ctx_synthesize_ecrecover(self, witness, trace, first_instance=0, n_instances=None, first_slot=0):
+    """ZkSyncBaseLayerCircuit::ECRecover synthesis for instances of an ecrecover PrecompileWitness (the trace needs EK_COLS columns and
+    at least 197 632 rows: the stacked tables)"""
+    n = witness.num_instances - first_instance if n_instances is None else n_instances
+    _check(load().zkw_ecrecover_synthesize(self.handle, witness.handle, first_instance, n, trace.handle, first_slot))
+
+
+def _ctx_check_if_satisfied_ecrecover(self, trace, slot, capacity):
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_ecrecover_check_satisfied(self.handle, trace.handle, slot, capacity, C.byref(bad), C.byref(first)))
     v = first.value
     return bad.value, (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
@@ -1293,6 +1312,8 @@ def _ctx_check_if_satisfied_linear_hasher(self, trace, slot, capacity):
 Context.check_if_satisfied_linear_hasher = _ctx_check_if_satisfied_linear_hasher
 Context.check_copy_permutation = _ctx_check_copy_permutation
 Context.synthesize_linear_hasher = _ctx_synthesize_linear_hasher
+Context.synthesize_ecrecover = _ctx_synthesize_ecrecover
+Context.check_if_satisfied_ecrecover = _ctx_check_if_satisfied_ecrecover
 Context.synthesize_linear_hasher_batch = _ctx_synthesize_linear_hasher_batch
 Context.synthesize_keccak_round_function = _ctx_synthesize_keccak_round_function
 Context.check_if_satisfied_keccak_round_function = _ctx_check_if_satisfied_keccak_round_function

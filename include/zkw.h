@@ -135,7 +135,9 @@ typedef struct zkw_circuit_layout {
        operations of cycle c is queue_first_row + 1 + r * cycles + c. 0 rows per cycle: the type has no section. */
     uint64_t queue_first_row;
     uint32_t queue_rows_per_cycle;
-    uint32_t _pad;
+    /* the EC section of the ECRecover circuit (type 7; include/zkw_ecrecover.h): row r of cycle c is ec_first_row + c * ec_rows_per_cycle + r */
+    uint32_t ec_rows_per_cycle;
+    uint64_t ec_first_row;
 } zkw_circuit_layout;
 int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_layout *out);
 /* Setup side, selectors: out[r] (host, n_rows bytes) says which gate set applies to row r of a trace of this library's
@@ -151,6 +153,10 @@ int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_l
 #define ZKW_ROW_QUEUE_BOUNDARY 0xE0 /* queue section: the queue states before / after the instance */
 #define ZKW_ROW_QUEUE_ENCODING 0xE1 /* queue section: an item's fields, its encoding (linear gates), old / new state (selection gates) */
 #define ZKW_ROW_QUEUE_POSEIDON2 0xE2 /* queue section: a (folded) flattened Poseidon2 gate */
+#define ZKW_ROW_EC_GATES 0xF0      /* EC section of the ECRecover circuit: LIN / SEL / FMA gates in the general-purpose columns, no lookups */
+#define ZKW_ROW_EC_XOR8 0xF1       /* ... its 16 lookup slots are Xor8 (byte range checks) */
+#define ZKW_ROW_EC_FIXED_BASE 0xF2 /* ... its lookup slots are a FixedBaseMul table (which one: the row's segment instance) */
+#define ZKW_ROW_EC_MUL 0x04        /* | on an EC row: the general-purpose columns are ONE non-native multiplication gate */
 #define ZKW_ROW_PADDING 0xFF
 int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint8_t *out);
 /* Setup side, copy permutation of the ten synthesized types: sigma[c * n_rows + r] (host, *n_columns x n_rows words;
@@ -574,6 +580,24 @@ int zkw_keccak_round_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t 
                                 zkw_trace *t, size_t first_slot);
 int zkw_keccak_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity,
                                      uint64_t *n_violations, uint64_t *first_bad);
+
+/* ---- ECRecover circuit (type 7) ----------------------------------------------------------------------------
+   ZkSyncBaseLayerCircuit::synthesis for the ecrecover precompile on the wrapper's geometry and table set (circuit_definitions/src/
+   circuit_definitions/base_layer/ecrecover.rs:30-41: 80 copy columns, width-3 lookups x 16 per row; :138-176: Xor8, And8, the 8 x 32
+   FixedBaseMulTable<i, C>, ByteSplit<1..4> = 197 632 table rows = vk_7.json's total_tables_len; 2^20 rows, capacity 7 requests). One
+   cycle per request (src/witness/individual_circuits/ecrecover.rs:143-178: 4 reads, 2 writes). Trace = three parts
+   (tools/gen_ecrecover_circuit.py): the Keccak-f netlist over the recovered public key ("zkw trace v4",
+   include/zkw_ecrecover_circuit_spec.h), the queue section (pop of the call, four reads, two writes: include/zkw_netlist_queue.h) and the
+   EC SECTION (include/zkw_ecrecover.h, zkw_ecrecover_ec_spec.h): secp256k1 over 16-bit limbs in field-element-valued rows — r / s range
+   flags, the square root of x^3 + 7, u1 = h / r and u2 = s / r, 256 double-and-add steps over the bits of u2, 32 table additions over
+   the bytes of u1 (FixedBaseMul lookups), normalisation; the read values are the section's inputs, the written values the netlist's
+   masked digest and the success flag, all by copy constraints. A request whose accumulator meets x1 == x2 in the (incomplete, affine)
+   addition has no witness: ZKW_ERR_CHECK_FAILED. w must be an ecrecover witness. n_rows >= zkw_circuit_layout_of(7, capacity).rows_used
+   (>= 197 632: the tables). Context scratch: 4 MB of value tape per request of the call. */
+int zkw_ecrecover_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t first_instance, size_t n_instances, zkw_trace *t,
+                             size_t first_slot);
+int zkw_ecrecover_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity, uint64_t *n_violations,
+                                  uint64_t *first_bad);
 
 /* ---- Sha256RoundFunction circuit (type 6) ------------------------------------------------------------------
    ZkSyncBaseLayerCircuit::synthesis for the sha256 round function on the wrapper's geometry and table set (circuit_definitions/src/

@@ -98,24 +98,29 @@ EC_HD uint64_t ec_gl_inv(uint64_t a) { /* a^(p - 2); 0 -> 0 */
 }
 EC_HD uint64_t ec_gl_from_i64(int64_t v) { return v >= 0 ? (uint64_t)v % EC_GL_P : EC_GL_P - ((uint64_t)(-v) % EC_GL_P); }
 
-/* ---- 256-bit arithmetic modulo m = 2^256 - c (the secp256k1 base and scalar fields), 32-bit words little end first ------ */
+/* ---- 256-bit arithmetic modulo m = 2^256 - c (the secp256k1 base and scalar fields), 32-bit words little end first ------
+   Every array with run-time indices lives in a caller-provided WORKSPACE (`ec_ws`: the stack on a CPU, a slice of LDS in the
+   kernels — per-lane arrays with run-time indices would otherwise become scratch memory, which every HSA queue that ran the kernel
+   keeps for every wave slot of the chip: tests/test_kernel_resources.py); 256-bit values (`ec_u256`) are indexed by constants only. */
 typedef struct ec_u256 { uint32_t w[8]; } ec_u256;
-typedef struct ec_mod { uint32_t m[8]; uint32_t c[5]; uint32_t nc; } ec_mod;
+typedef struct ec_mod { const uint32_t *m, *c, *inv_e; uint32_t nc; } ec_mod;
+typedef struct ec_ws {
+    uint32_t cur[24], nxt[24], prod[18], A[9], B[9], R[9], T[20], U[20], Q[12], Qc[20];
+    uint64_t va[16], vb[16], vc[16];
+} ec_ws;
+
+static const uint32_t EC_P_M[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+static const uint32_t EC_P_C[5] = {977u, 1u, 0u, 0u, 0u};
+static const uint32_t EC_P_INV_E[8] = {0xFFFFFC2Du, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; /* p - 2 */
+static const uint32_t EC_P_SQRT_E[8] = {0xBFFFFF0Cu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x3FFFFFFFu}; /* (p + 1) / 4 */
+static const uint32_t EC_N_M[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+static const uint32_t EC_N_C[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 0x1u};
+static const uint32_t EC_N_INV_E[8] = {0xD036413Fu, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; /* n - 2 */
 
 EC_HD ec_mod ec_modulus(uint32_t which) { /* 0: P = 2^256 - 2^32 - 977, 1: N */
     ec_mod M;
-    if (which == 0) {
-        const uint32_t m[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        for (int i = 0; i < 8; i++) M.m[i] = m[i];
-        M.c[0] = 977; M.c[1] = 1; M.c[2] = M.c[3] = M.c[4] = 0;
-        M.nc = 2;
-    } else {
-        const uint32_t m[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        const uint32_t c[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 0x1u};
-        for (int i = 0; i < 8; i++) M.m[i] = m[i];
-        for (int i = 0; i < 5; i++) M.c[i] = c[i];
-        M.nc = 5;
-    }
+    if (which == 0) { M.m = EC_P_M; M.c = EC_P_C; M.inv_e = EC_P_INV_E; M.nc = 2; }
+    else { M.m = EC_N_M; M.c = EC_N_C; M.inv_e = EC_N_INV_E; M.nc = 5; }
     return M;
 }
 EC_HD int ec_cmp8(const uint32_t *a, const uint32_t *b) {
@@ -136,17 +141,18 @@ EC_HD void ec_mul_words(const uint32_t *a, int na, const uint32_t *b, int nb, ui
     for (int i = 0; i < na + nb; i++) out[i] = 0;
     for (int i = 0; i < na; i++) {
         uint64_t carry = 0;
+        const uint64_t ai = a[i];
         for (int j = 0; j < nb; j++) {
-            const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
+            const uint64_t t = ai * b[j] + out[i + j] + carry;
             out[i + j] = (uint32_t)t;
             carry = t >> 32;
         }
         out[i + nb] = (uint32_t)carry;
     }
 }
-/* x (n <= 20 words) mod m */
-EC_HD ec_u256 ec_reduce(const uint32_t *x, int n, const ec_mod *M) {
-    uint32_t cur[24], nxt[24];
+/* x (n <= 20 words, not W->cur / W->nxt) mod m */
+EC_HD ec_u256 ec_reduce(const uint32_t *x, int n, const ec_mod *M, ec_ws *W) {
+    uint32_t *cur = W->cur, *nxt = W->nxt;
     int len = n;
     for (int i = 0; i < 24; i++) cur[i] = i < n ? x[i] : 0;
     while (len > 8) { /* x = hi 2^256 + lo = hi c + lo */
@@ -168,14 +174,24 @@ EC_HD ec_u256 ec_reduce(const uint32_t *x, int n, const ec_mod *M) {
         len = nl;
     }
     ec_u256 r;
-    for (int i = 0; i < 8; i++) r.w[i] = cur[i];
+    r.w[0] = cur[0]; r.w[1] = cur[1]; r.w[2] = cur[2]; r.w[3] = cur[3]; r.w[4] = cur[4]; r.w[5] = cur[5]; r.w[6] = cur[6]; r.w[7] = cur[7];
     while (ec_cmp8(r.w, M->m) >= 0) ec_sub8(r.w, M->m);
     return r;
 }
-EC_HD ec_u256 ec_mulmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) {
-    uint32_t t[16];
-    ec_mul_words(a->w, 8, b->w, 8, t);
-    return ec_reduce(t, 16, M);
+EC_HD ec_u256 ec_mulmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M, ec_ws *W) {
+    uint32_t *t = W->prod;
+    for (int i = 0; i < 16; i++) t[i] = 0;
+    for (int i = 0; i < 8; i++) { /* (constant trip counts: a and b stay in registers) */
+        uint64_t carry = 0;
+        const uint64_t ai = a->w[i];
+        for (int j = 0; j < 8; j++) {
+            const uint64_t v = ai * b->w[j] + t[i + j] + carry;
+            t[i + j] = (uint32_t)v;
+            carry = v >> 32;
+        }
+        t[i + 8] = (uint32_t)carry;
+    }
+    return ec_reduce(t, 16, M, W);
 }
 EC_HD ec_u256 ec_submod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) { /* a, b < m */
     ec_u256 r = *a;
@@ -189,8 +205,8 @@ EC_HD ec_u256 ec_submod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) { /
     ec_sub8(r.w, b->w);
     return r;
 }
-EC_HD ec_u256 ec_addmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) {
-    uint32_t t[9];
+EC_HD ec_u256 ec_addmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M, ec_ws *W) {
+    uint32_t *t = W->prod;
     uint64_t carry = 0;
     for (int i = 0; i < 8; i++) {
         const uint64_t s = (uint64_t)a->w[i] + b->w[i] + carry;
@@ -198,37 +214,38 @@ EC_HD ec_u256 ec_addmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) {
         carry = s >> 32;
     }
     t[8] = (uint32_t)carry;
-    return ec_reduce(t, 9, M);
+    return ec_reduce(t, 9, M, W);
 }
 EC_HD int ec_is_zero8(const ec_u256 *a) {
     uint32_t o = 0;
     for (int i = 0; i < 8; i++) o |= a->w[i];
     return o == 0;
 }
-/* a^e mod m, e = m - 2 (inverse) or (p + 1) / 4 (square root): exponent given as 8 words */
-EC_HD ec_u256 ec_powmod(const ec_u256 *a, const uint32_t *e, const ec_mod *M) {
-    ec_u256 r;
-    for (int i = 0; i < 8; i++) r.w[i] = i == 0;
+EC_HD ec_u256 ec_zero256(void) {
+    ec_u256 z;
+    for (int i = 0; i < 8; i++) z.w[i] = 0;
+    return z;
+}
+/* a^e mod m, e = 8 words in constant memory (m - 2: the inverse; (p + 1) / 4: the square root) */
+EC_HD ec_u256 ec_powmod(const ec_u256 *a, const uint32_t *e, const ec_mod *M, ec_ws *W) {
+    ec_u256 r = *a;
     int started = 0;
-    for (int bit = 255; bit >= 0; bit--) {
-        if (started) r = ec_mulmod(&r, &r, M);
-        if ((e[bit >> 5] >> (bit & 31)) & 1) {
-            if (started) r = ec_mulmod(&r, a, M);
-            else { r = *a; started = 1; }
+    for (int wi = 7; wi >= 0; wi--) {
+        const uint32_t word = e[wi];
+        for (int bit = 31; bit >= 0; bit--) {
+            if (started) r = ec_mulmod(&r, &r, M, W);
+            if ((word >> bit) & 1) {
+                if (started) r = ec_mulmod(&r, a, M, W);
+                started = 1; /* (the first set bit: r = a already) */
+            }
         }
     }
     return r;
 }
-EC_HD ec_u256 ec_invmod(const ec_u256 *a, const ec_mod *M) {
-    uint32_t e[8];
-    for (int i = 0; i < 8; i++) e[i] = M->m[i];
-    e[0] -= 2; /* (both moduli end in ...2F / ...41: no borrow) */
-    return ec_powmod(a, e, M);
-}
+EC_HD ec_u256 ec_invmod(const ec_u256 *a, const ec_mod *M, ec_ws *W) { return ec_powmod(a, M->inv_e, M, W); }
 /* a vector of 16 (possibly lazy: up to 2^24 each) limbs as an integer of 9 words */
-EC_HD void ec_from_limbs16(const uint64_t *l, uint32_t out[9]) {
+EC_HD void ec_from_limbs16(const uint64_t *l, uint32_t *out) {
     uint64_t acc = 0;
-    for (int i = 0; i < 9; i++) out[i] = 0;
     for (int k = 0; k < 16; k += 2) {
         acc += l[k] + (l[k + 1] << 16);
         out[k / 2] = (uint32_t)acc;
@@ -237,7 +254,10 @@ EC_HD void ec_from_limbs16(const uint64_t *l, uint32_t out[9]) {
     out[8] = (uint32_t)acc;
 }
 EC_HD void ec_to_limbs16(const ec_u256 *a, uint64_t *l) {
-    for (int k = 0; k < 16; k++) l[k] = (a->w[k / 2] >> (16 * (k & 1))) & 0xFFFFu;
+    l[0] = a->w[0] & 0xFFFFu; l[1] = a->w[0] >> 16; l[2] = a->w[1] & 0xFFFFu; l[3] = a->w[1] >> 16;
+    l[4] = a->w[2] & 0xFFFFu; l[5] = a->w[2] >> 16; l[6] = a->w[3] & 0xFFFFu; l[7] = a->w[3] >> 16;
+    l[8] = a->w[4] & 0xFFFFu; l[9] = a->w[4] >> 16; l[10] = a->w[5] & 0xFFFFu; l[11] = a->w[5] >> 16;
+    l[12] = a->w[6] & 0xFFFFu; l[13] = a->w[6] >> 16; l[14] = a->w[7] & 0xFFFFu; l[15] = a->w[7] >> 16;
 }
 
 /* ---- reading references ------------------------------------------------------------------------------------------------- */
@@ -245,6 +265,7 @@ typedef struct ec_eval_ctx {
     const ec_spec *S;
     uint64_t *tape;          /* the cycle's tape */
     const uint8_t *in;       /* 128 input bytes */
+    ec_ws *W;
     uint32_t base, prev_base, prev_type, inst;
 } ec_eval_ctx;
 
@@ -282,11 +303,11 @@ EC_HD uint32_t ec_item_words(const uint32_t *w) {
     }
 }
 
-/* q (16 limbs, the top one up to 24 bits) and the 15 carries (+ 2^31) of a MUL row; returns 0 when a * b + 8 m - r is not a
-   non-negative multiple of m (no witness) */
-EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r, uint32_t which, uint64_t *q, uint64_t *c) {
+/* q (16 limbs, the top one up to 24 bits) and the 15 carries (+ 2^31) of a MUL row; a, b, r: limb vectors (W->va / vb / vc or any
+   memory); returns 0 when a * b + 8 m - r is not a non-negative multiple of m (no witness) */
+EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r, uint32_t which, uint64_t *q, uint64_t *c, ec_ws *W) {
     const ec_mod M = ec_modulus(which);
-    uint32_t A[9], B[9], R[9], T[20], U[20];
+    uint32_t *A = W->A, *B = W->B, *R = W->R, *T = W->T, *U = W->U, *Q = W->Q, *Qc = W->Qc;
     ec_from_limbs16(a, A);
     ec_from_limbs16(b, B);
     ec_from_limbs16(r, R);
@@ -308,7 +329,6 @@ EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r
     }
     if (br) return 0;
     /* Q = T / m exactly, m = 2^256 - c: Q <- ceil((T + Q c) / 2^256) from Q = T >> 256 */
-    uint32_t Q[12], Qc[20];
     for (int i = 0; i < 12; i++) Q[i] = T[8 + i];
     for (int it = 0; it < 4; it++) {
         ec_mul_words(Q, 12, M.c, (int)M.nc, Qc); /* 12 + nc words */
@@ -354,6 +374,13 @@ EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r
     return 1;
 }
 
+/* the limb vector a reference names, reduced mod m */
+EC_HD ec_u256 ec_get_reduced(const ec_eval_ctx *E, uint32_t ref0, const ec_mod *M) {
+    ec_get_vec(E, ref0, E->W->va);
+    ec_from_limbs16(E->W->va, E->W->A);
+    return ec_reduce(E->W->A, 9, M, E->W);
+}
+
 /* evaluates the items of one segment instance onto the tape; returns 0, or 1 + the item's index when the inputs have no witness
    (a division by zero in the incomplete addition, a broken assertion) */
 EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
@@ -361,6 +388,7 @@ EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
     const ec_seg_type *T = &S->types[type];
     const uint32_t *w = S->items + T->item0;
     uint64_t *tape = E->tape + E->base;
+    ec_ws *W = E->W;
     for (uint32_t n = 0; n < T->n_items; n++, w += ec_item_words(w)) {
         const uint32_t kind = w[0] & 15, aux = w[0] >> 24;
         if (kind == EC_I_LIN) {
@@ -392,11 +420,10 @@ EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
             if (aux) tape[w[4]] = v;
             else if (v != ec_get(E, w[4]) % EC_GL_P) return 1 + (int)n;
         } else if (kind == EC_I_MUL) {
-            uint64_t a[16], b[16], r[16];
-            ec_get_vec(E, w[1], a);
-            ec_get_vec(E, w[2], b);
-            ec_get_vec(E, w[3], r);
-            if (!ec_mul_witness(a, b, r, aux, tape + w[4], tape + w[5])) return 1 + (int)n;
+            ec_get_vec(E, w[1], W->va);
+            ec_get_vec(E, w[2], W->vb);
+            ec_get_vec(E, w[3], W->vc);
+            if (!ec_mul_witness(W->va, W->vb, W->vc, aux, tape + w[4], tape + w[5], W)) return 1 + (int)n;
         } else if (kind == EC_I_LOOKUP) {
             const uint64_t a = ec_get(E, w[2]);
             if ((w[1] & 0xFF) == EC_T_XOR8) {
@@ -409,70 +436,47 @@ EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
                 tape[w[4]] = S->fixed[((size_t)tb * 256 + a) * 2];
                 tape[w[4] + 1] = S->fixed[((size_t)tb * 256 + a) * 2 + 1];
             }
-        } else { /* hints */
-            uint64_t va[16], vb[16];
-            if (aux == EC_H_MULSUB || aux == EC_H_DIV) {
-                const ec_mod M = ec_modulus(w[1]);
-                uint32_t A[9], B[9];
-                ec_get_vec(E, w[2], va);
-                ec_get_vec(E, w[3], vb);
-                ec_from_limbs16(va, A);
-                ec_from_limbs16(vb, B);
-                const ec_u256 a = ec_reduce(A, 9, &M), b = ec_reduce(B, 9, &M);
-                ec_u256 res;
-                if (aux == EC_H_DIV) {
-                    if (ec_is_zero8(&b)) return 1 + (int)n;
-                    const ec_u256 bi = ec_invmod(&b, &M);
-                    res = ec_mulmod(&a, &bi, &M);
-                    ec_to_limbs16(&res, tape + w[4]);
-                } else {
-                    res = ec_mulmod(&a, &b, &M);
-                    for (int o = 4; o <= 5; o++)
-                        if (w[o] != EC_NONE) {
-                            uint32_t C[9];
-                            ec_get_vec(E, w[o], va);
-                            ec_from_limbs16(va, C);
-                            const ec_u256 cc = ec_reduce(C, 9, &M);
-                            res = ec_submod(&res, &cc, &M);
-                        }
-                    ec_to_limbs16(&res, tape + w[6]);
-                }
-            } else if (aux == EC_H_SQRT) {
-                const ec_mod M = ec_modulus(0);
-                uint32_t A[9];
-                ec_get_vec(E, w[1], va);
-                ec_from_limbs16(va, A);
-                const ec_u256 t = ec_reduce(A, 9, &M);
-                const uint32_t e[8] = {0xBFFFFF0Cu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x3FFFFFFFu}; /* (p + 1) / 4 */
-                ec_u256 y = ec_powmod(&t, e, &M);
-                ec_u256 y2 = ec_mulmod(&y, &y, &M);
-                uint64_t e_nr = 0;
-                if (ec_cmp8(y2.w, t.w) != 0) { /* no root: a root of -t proves it (p = 3 mod 4) */
-                    e_nr = 1;
-                    ec_u256 zero;
-                    for (int i = 0; i < 8; i++) zero.w[i] = 0;
-                    const ec_u256 nt = ec_submod(&zero, &t, &M);
-                    y = ec_powmod(&nt, e, &M);
-                } else if ((y.w[0] & 1) != (ec_get(E, w[2]) & 1)) {
-                    ec_u256 zero;
-                    for (int i = 0; i < 8; i++) zero.w[i] = 0;
-                    y = ec_submod(&zero, &y, &M);
-                }
-                ec_to_limbs16(&y, tape + w[3]);
-                tape[w[3] + 16] = e_nr;
-            } else if (aux == EC_H_ISZERO) {
-                const uint64_t x = ec_get(E, w[1]) % EC_GL_P;
-                tape[w[2]] = x ? ec_gl_inv(x) : 0;
-                tape[w[2] + 1] = x ? 0 : 1;
-            } else { /* EC_H_GE: a >= the constant */
-                ec_get_vec(E, w[1], va);
-                int ge = 1;
-                for (int i = 15; i >= 0; i--) {
-                    const uint64_t cst = S->bigs[w[2] * 16 + (uint32_t)i];
-                    if (va[i] != cst) { ge = va[i] > cst; break; }
-                }
-                tape[w[3]] = (uint64_t)ge;
+        } else if (aux == EC_H_MULSUB || aux == EC_H_DIV) {
+            const ec_mod M = ec_modulus(w[1]);
+            const ec_u256 a = ec_get_reduced(E, w[2], &M), b = ec_get_reduced(E, w[3], &M);
+            ec_u256 res;
+            if (aux == EC_H_DIV) {
+                if (ec_is_zero8(&b)) return 1 + (int)n;
+                const ec_u256 bi = ec_invmod(&b, &M, W);
+                res = ec_mulmod(&a, &bi, &M, W);
+                ec_to_limbs16(&res, tape + w[4]);
+            } else {
+                res = ec_mulmod(&a, &b, &M, W);
+                if (w[4] != EC_NONE) { const ec_u256 cc = ec_get_reduced(E, w[4], &M); res = ec_submod(&res, &cc, &M); }
+                if (w[5] != EC_NONE) { const ec_u256 dd = ec_get_reduced(E, w[5], &M); res = ec_submod(&res, &dd, &M); }
+                ec_to_limbs16(&res, tape + w[6]);
             }
+        } else if (aux == EC_H_SQRT) {
+            const ec_mod M = ec_modulus(0);
+            const ec_u256 t = ec_get_reduced(E, w[1], &M);
+            ec_u256 y = ec_powmod(&t, EC_P_SQRT_E, &M, W);
+            const ec_u256 y2 = ec_mulmod(&y, &y, &M, W), zero = ec_zero256();
+            uint64_t e_nr = 0;
+            if (ec_cmp8(y2.w, t.w) != 0) { /* no root: a root of -t proves it (p = 3 mod 4) */
+                e_nr = 1;
+                const ec_u256 nt = ec_submod(&zero, &t, &M);
+                y = ec_powmod(&nt, EC_P_SQRT_E, &M, W);
+            } else if ((y.w[0] & 1) != (ec_get(E, w[2]) & 1)) {
+                y = ec_submod(&zero, &y, &M);
+            }
+            ec_to_limbs16(&y, tape + w[3]);
+            tape[w[3] + 16] = e_nr;
+        } else if (aux == EC_H_ISZERO) {
+            const uint64_t x = ec_get(E, w[1]) % EC_GL_P;
+            tape[w[2]] = x ? ec_gl_inv(x) : 0;
+            tape[w[2] + 1] = x ? 0 : 1;
+        } else { /* EC_H_GE: a >= the constant */
+            int ge = 1;
+            for (int i = 15; i >= 0; i--) {
+                const uint64_t av = ec_get(E, w[1] + (uint32_t)i), cst = S->bigs[w[2] * 16 + (uint32_t)i];
+                if (av != cst) { ge = av > cst; break; }
+            }
+            tape[w[3]] = (uint64_t)ge;
         }
     }
     return 0;
@@ -480,9 +484,9 @@ EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
 
 /* the whole cycle: tape[EC_TAPE_PER_CYCLE] from the 128 input bytes. Returns 0, or (run << 24 | instance << 12 | 1 + item) of the
    first item without a witness */
-EC_HD uint32_t ec_eval_cycle(const ec_spec *S, const uint8_t *in, uint64_t *tape) {
+EC_HD uint32_t ec_eval_cycle(const ec_spec *S, const uint8_t *in, uint64_t *tape, ec_ws *W) {
     ec_eval_ctx E;
-    E.S = S; E.tape = tape; E.in = in;
+    E.S = S; E.tape = tape; E.in = in; E.W = W;
     E.prev_base = 0; E.prev_type = 0;
     for (uint32_t r = 0; r < EC_NUM_RUNS; r++) {
         const ec_run *R = &S->runs[r];
@@ -616,66 +620,66 @@ EC_HD int ec_check_item(const ec_spec *S, const uint32_t *w, const ec_row_view *
 
 /* ---- the 256 FixedBaseMul tables (host): word i of x and of y of byte * 2^(8 C) * G, (0, 0) for byte 0 ---------------------- */
 typedef struct ec_jac { ec_u256 x, y, z; } ec_jac; /* z == 0: infinity */
-EC_HD ec_jac ec_jac_double(const ec_jac *p, const ec_mod *M) {
+EC_HD ec_jac ec_jac_double(const ec_jac *p, const ec_mod *M, ec_ws *W) {
     if (ec_is_zero8(&p->z)) return *p;
     ec_jac r;
-    const ec_u256 a = ec_mulmod(&p->x, &p->x, M), b = ec_mulmod(&p->y, &p->y, M), c = ec_mulmod(&b, &b, M);
-    ec_u256 t = ec_addmod(&p->x, &b, M);
-    t = ec_mulmod(&t, &t, M);
+    const ec_u256 a = ec_mulmod(&p->x, &p->x, M, W), b = ec_mulmod(&p->y, &p->y, M, W), c = ec_mulmod(&b, &b, M, W);
+    ec_u256 t = ec_addmod(&p->x, &b, M, W);
+    t = ec_mulmod(&t, &t, M, W);
     t = ec_submod(&t, &a, M);
     t = ec_submod(&t, &c, M);
-    const ec_u256 d = ec_addmod(&t, &t, M);
-    ec_u256 e = ec_addmod(&a, &a, M);
-    e = ec_addmod(&e, &a, M);
-    const ec_u256 f = ec_mulmod(&e, &e, M);
-    ec_u256 d2 = ec_addmod(&d, &d, M);
+    const ec_u256 d = ec_addmod(&t, &t, M, W);
+    ec_u256 e = ec_addmod(&a, &a, M, W);
+    e = ec_addmod(&e, &a, M, W);
+    const ec_u256 f = ec_mulmod(&e, &e, M, W);
+    ec_u256 d2 = ec_addmod(&d, &d, M, W);
     r.x = ec_submod(&f, &d2, M);
-    ec_u256 c8 = ec_addmod(&c, &c, M);
-    c8 = ec_addmod(&c8, &c8, M);
-    c8 = ec_addmod(&c8, &c8, M);
+    ec_u256 c8 = ec_addmod(&c, &c, M, W);
+    c8 = ec_addmod(&c8, &c8, M, W);
+    c8 = ec_addmod(&c8, &c8, M, W);
     ec_u256 dx = ec_submod(&d, &r.x, M);
-    dx = ec_mulmod(&e, &dx, M);
+    dx = ec_mulmod(&e, &dx, M, W);
     r.y = ec_submod(&dx, &c8, M);
-    const ec_u256 yz = ec_mulmod(&p->y, &p->z, M);
-    r.z = ec_addmod(&yz, &yz, M);
+    const ec_u256 yz = ec_mulmod(&p->y, &p->z, M, W);
+    r.z = ec_addmod(&yz, &yz, M, W);
     return r;
 }
-EC_HD ec_jac ec_jac_add(const ec_jac *p, const ec_jac *q, const ec_mod *M) {
+EC_HD ec_jac ec_jac_add(const ec_jac *p, const ec_jac *q, const ec_mod *M, ec_ws *W) {
     if (ec_is_zero8(&p->z)) return *q;
     if (ec_is_zero8(&q->z)) return *p;
-    const ec_u256 z1z1 = ec_mulmod(&p->z, &p->z, M), z2z2 = ec_mulmod(&q->z, &q->z, M);
-    const ec_u256 u1 = ec_mulmod(&p->x, &z2z2, M), u2 = ec_mulmod(&q->x, &z1z1, M);
-    ec_u256 s1 = ec_mulmod(&p->y, &q->z, M);
-    s1 = ec_mulmod(&s1, &z2z2, M);
-    ec_u256 s2 = ec_mulmod(&q->y, &p->z, M);
-    s2 = ec_mulmod(&s2, &z1z1, M);
+    const ec_u256 z1z1 = ec_mulmod(&p->z, &p->z, M, W), z2z2 = ec_mulmod(&q->z, &q->z, M, W);
+    const ec_u256 u1 = ec_mulmod(&p->x, &z2z2, M, W), u2 = ec_mulmod(&q->x, &z1z1, M, W);
+    ec_u256 s1 = ec_mulmod(&p->y, &q->z, M, W);
+    s1 = ec_mulmod(&s1, &z2z2, M, W);
+    ec_u256 s2 = ec_mulmod(&q->y, &p->z, M, W);
+    s2 = ec_mulmod(&s2, &z1z1, M, W);
     const ec_u256 h = ec_submod(&u2, &u1, M), rr = ec_submod(&s2, &s1, M);
     if (ec_is_zero8(&h)) {
-        if (ec_is_zero8(&rr)) return ec_jac_double(p, M);
+        if (ec_is_zero8(&rr)) return ec_jac_double(p, M, W);
         ec_jac inf = *p;
         for (int i = 0; i < 8; i++) inf.z.w[i] = 0;
         return inf;
     }
-    const ec_u256 h2 = ec_mulmod(&h, &h, M), h3 = ec_mulmod(&h2, &h, M), u1h2 = ec_mulmod(&u1, &h2, M);
+    const ec_u256 h2 = ec_mulmod(&h, &h, M, W), h3 = ec_mulmod(&h2, &h, M, W), u1h2 = ec_mulmod(&u1, &h2, M, W);
     ec_jac r;
-    ec_u256 t = ec_mulmod(&rr, &rr, M);
+    ec_u256 t = ec_mulmod(&rr, &rr, M, W);
     t = ec_submod(&t, &h3, M);
     t = ec_submod(&t, &u1h2, M);
     r.x = ec_submod(&t, &u1h2, M);
     ec_u256 v = ec_submod(&u1h2, &r.x, M);
-    v = ec_mulmod(&rr, &v, M);
-    const ec_u256 s1h3 = ec_mulmod(&s1, &h3, M);
+    v = ec_mulmod(&rr, &v, M, W);
+    const ec_u256 s1h3 = ec_mulmod(&s1, &h3, M, W);
     r.y = ec_submod(&v, &s1h3, M);
-    const ec_u256 zz = ec_mulmod(&p->z, &q->z, M);
-    r.z = ec_mulmod(&zz, &h, M);
+    const ec_u256 zz = ec_mulmod(&p->z, &q->z, M, W);
+    r.z = ec_mulmod(&zz, &h, M, W);
     return r;
 }
-#if !defined(__HIP_DEVICE_COMPILE__)
 #include <stdlib.h>
 /* out[EC_FIXED_WORDS]; boojum's create_fixed_base_mul_table<i, C> (gadgets/tables/fixed_base_mul_table, absent crate; the contents
    are the public curve: row `byte` of table (i, C) = 32-bit word i of the affine x and y of byte * 2^(8 C) * G) */
 static inline void ec_build_fixed_tables(uint32_t *out) {
     const ec_mod M = ec_modulus(0);
+    ec_ws ws;
     ec_jac *pts = (ec_jac *)malloc(sizeof(ec_jac) * 32 * 256);
     ec_u256 *pre = (ec_u256 *)malloc(sizeof(ec_u256) * 32 * 256);
     ec_jac base;
@@ -687,28 +691,28 @@ static inline void ec_build_fixed_tables(uint32_t *out) {
         for (int i = 0; i < 8; i++) cur.z.w[i] = 0; /* infinity */
         for (int b = 0; b < 256; b++) {
             pts[C * 256 + b] = cur;
-            cur = ec_jac_add(&cur, &base, &M);
+            cur = ec_jac_add(&cur, &base, &M, &ws);
         }
-        for (int d = 0; d < 8; d++) base = ec_jac_double(&base, &M);
+        for (int d = 0; d < 8; d++) base = ec_jac_double(&base, &M, &ws);
     }
     /* one inversion for all z (Montgomery's trick), infinity skipped */
     ec_u256 acc;
     for (int i = 0; i < 8; i++) acc.w[i] = i == 0;
     for (int k = 0; k < 32 * 256; k++) {
         pre[k] = acc;
-        if (!ec_is_zero8(&pts[k].z)) acc = ec_mulmod(&acc, &pts[k].z, &M);
+        if (!ec_is_zero8(&pts[k].z)) acc = ec_mulmod(&acc, &pts[k].z, &M, &ws);
     }
-    ec_u256 inv = ec_invmod(&acc, &M);
+    ec_u256 inv = ec_invmod(&acc, &M, &ws);
     for (int k = 32 * 256 - 1; k >= 0; k--) {
         const int C = k / 256, b = k % 256;
         ec_u256 x, y;
         for (int i = 0; i < 8; i++) x.w[i] = y.w[i] = 0;
         if (!ec_is_zero8(&pts[k].z)) {
-            const ec_u256 zi = ec_mulmod(&inv, &pre[k], &M);
-            inv = ec_mulmod(&inv, &pts[k].z, &M);
-            const ec_u256 zi2 = ec_mulmod(&zi, &zi, &M), zi3 = ec_mulmod(&zi2, &zi, &M);
-            x = ec_mulmod(&pts[k].x, &zi2, &M);
-            y = ec_mulmod(&pts[k].y, &zi3, &M);
+            const ec_u256 zi = ec_mulmod(&inv, &pre[k], &M, &ws);
+            inv = ec_mulmod(&inv, &pts[k].z, &M, &ws);
+            const ec_u256 zi2 = ec_mulmod(&zi, &zi, &M, &ws), zi3 = ec_mulmod(&zi2, &zi, &M, &ws);
+            x = ec_mulmod(&pts[k].x, &zi2, &M, &ws);
+            y = ec_mulmod(&pts[k].y, &zi3, &M, &ws);
         }
         for (int i = 0; i < 8; i++) {
             out[((size_t)(8 * C + i) * 256 + (size_t)b) * 2] = x.w[i];
@@ -718,5 +722,4 @@ static inline void ec_build_fixed_tables(uint32_t *out) {
     free(pts);
     free(pre);
 }
-#endif
 #endif /* ZKW_ECRECOVER_H */

@@ -44,7 +44,7 @@ void orc_ec_geometry(uint32_t capacity, uint64_t out[8]) {
     out[0] = orc_ec_first_row(capacity); out[1] = EC_ROWS_PER_CYCLE; out[2] = orc_ec_used_rows(capacity); out[3] = EC_TAPE_PER_CYCLE;
     out[4] = EC_NUM_TYPES; out[5] = EC_NUM_RUNS;
 }
-uint32_t orc_ec_eval_cycle(const uint8_t in[128], uint64_t *tape) { return ec_eval_cycle(orc_ec_spec(), in, tape); }
+uint32_t orc_ec_eval_cycle(const uint8_t in[128], uint64_t *tape) { ec_ws ws; return ec_eval_cycle(orc_ec_spec(), in, tape, &ws); }
 /* (ok, mask, the 64 key bytes as the netlist hashes them) of an evaluated tape */
 void orc_ec_outputs(const uint64_t *tape, uint8_t out[66]) {
     const ec_spec *S = orc_ec_spec();
@@ -81,7 +81,8 @@ int orc_ecrecover_synthesize(const uint8_t *inputs, uint32_t n_active, uint32_t 
     int rc = 0;
     for (uint32_t c = 0; c < capacity && rc == 0; c++) {
         uint64_t *tape = tapes + (size_t)c * EC_TAPE_PER_CYCLE;
-        if (ec_eval_cycle(S, inputs + (size_t)c * 128, tape)) { rc = -2 - (int)c; break; }
+        ec_ws ws;
+        if (ec_eval_cycle(S, inputs + (size_t)c * 128, tape, &ws)) { rc = -2 - (int)c; break; }
         uint8_t o[66], dig[32];
         orc_ec_outputs(tape, o);
         uint8_t *f = fr + (size_t)c * EK_FREE_PER_CYCLE;

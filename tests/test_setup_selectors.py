@@ -82,6 +82,30 @@ def test_queue_circuit_selectors(oracle):
         t = oracle.ram_synthesize(w, i, cap, 1 << 15)
         assert not t[:148, sel == nv.ROW_PADDING].any() and t[:148, sel == 0].any()
     with pytest.raises(nv.ZkwError):
-        nv.setup_row_selectors(7)       # ECRecover: no layout
+        nv.setup_row_selectors(1)       # MainVM: no layout
     with pytest.raises(nv.ZkwError):
         nv.setup_row_selectors(8, 136714, 1 << 19)  # does not fit
+
+
+def test_ecrecover_selectors(oracle):
+    """type 7: the Keccak-f netlist rows, the queue section, then the EC section — per row its lookup table kind and whether the
+    general-purpose columns are ONE non-native multiplication gate; an oracle trace is zero wherever the selector says padding"""
+    cap = 2
+    n_rows = 1 << 18
+    lay = nv.circuit_layout(7, cap)
+    g = oracle.ec_geometry(cap)
+    assert int(lay["ec_first_row"]) == g["first_row"] and int(lay["rows_used"]) == max(g["rows_used"], 197632)
+    sel = nv.setup_row_selectors(7, cap, n_rows)
+    ec = sel[g["first_row"]:g["rows_used"]].reshape(cap, g["rows_per_cycle"])
+    assert (ec[0] == ec[1]).all() and not (ec == nv.ROW_PADDING).any()
+    kinds = ec[0] & 0xF3
+    assert set(np.unique(kinds)) == {0xF0, 0xF1, 0xF2}
+    n_mul = int(((ec[0] & 0x04) != 0).sum())
+    assert n_mul == 7 * 256 + 3 * 32 + 3 + 6  # MUL rows: double-and-add, table additions, the last addition, the pre-segment (x^2, x^3, y^2, 1 / r, u2, u1)
+    assert int((kinds == 0xF2).sum()) == 8 * 32  # one FixedBaseMul table per row: 8 words x 32 bytes of u1
+    req, mq = synthetic.precompile_trace(2, 3, seed=4)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    b = oracle.precompile_build(2, req, tails, mq, cap, np.zeros(1, nv.QUEUE_STATE12))
+    t = oracle.ecrecover_synthesize(b, 0, cap, n_rows)
+    assert not t[:128, sel == nv.ROW_PADDING].any()
+    assert not t[80:128, g["first_row"]:g["rows_used"]][:, ec.reshape(-1) == 0xF0].any()  # rows without lookups: zero lookup cells
