@@ -57,6 +57,118 @@ static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_tape(const ec_spec*
     if (ec_eval_cycle(&S, j.inputs + (size_t)c * 128, j.tape + (size_t)c * EC_TAPE_PER_CYCLE, &s_ws[threadIdx.x])) atomicMax(status, 1u + (blockIdx.y << 16 | c));
 }
 
+// ---- the fast form of the tape: the accumulator's trajectory first, then every segment on its own lane ------------------------------
+// The serial kernel above spends its time in ~550 modular inversions per cycle (every quotient lambda of the affine additions), one after
+// the other, because segment k needs the accumulator segment k - 1 leaves. The trajectory does not need the quotients: k_ec_chain runs
+// the PRE segment, then the same double-and-add / table additions in JACOBIAN coordinates (no inversion), converts all 288 points with
+// ONE inversion (Montgomery's trick) and writes them where the segments' `out` states live on the tape; with every segment's input
+// state in place, k_ec_segments evaluates the 289 remaining segments of every cycle side by side (their own out cells are rewritten with
+// the same values). Same tape, bit for bit.
+struct EcChainScratch { ec_jac* pts; ec_u256* pre; };  // [cycles of the call][EC_CHAIN_POINTS]
+constexpr u32 EC_CHAIN_POINTS = 288;                    // 256 double-and-add steps + 32 table additions
+
+__device__ __forceinline__ ec_u256 ec_load_limbs(const u64* __restrict__ tape, const uint32_t* __restrict__ idx) {
+    ec_u256 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.w[i] = (u32)tape[idx[2 * i]] | ((u32)tape[idx[2 * i + 1]] << 16);
+    return r;
+}
+
+// grid (cycles / EC_TAPE_LANES, jobs): a lane per cycle
+static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_chain(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
+    __shared__ ec_ws s_ws[EC_TAPE_LANES];
+    const EcJob j = jobs[blockIdx.y];
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= capacity) return;
+    const ec_spec S = *Sp;
+    ec_ws* W = &s_ws[threadIdx.x];
+    u64* tape = j.tape + (size_t)c * EC_TAPE_PER_CYCLE;
+    ec_eval_ctx E;
+    E.S = &S; E.tape = tape; E.in = j.inputs + (size_t)c * 128; E.W = W;
+    E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
+    if (const int bad = ec_eval_segment(&E, S.runs[0].type)) { atomicMax(status, 1u + (blockIdx.y << 16 | c)); (void)bad; return; }
+    const ec_mod M = ec_modulus(0);
+    const size_t slot = (size_t)blockIdx.y * capacity + c;
+    ec_jac* pts = sc.pts + slot * EC_CHAIN_POINTS;
+    ec_u256* pre = sc.pre + slot * EC_CHAIN_POINTS;
+    const ec_u256 rx = ec_load_limbs(tape, S.globs + EC_GL_RX), ry = ec_load_limbs(tape, S.globs + EC_GL_RY);
+    ec_u256 one = ec_zero256(), ax, ay, az;
+    one.w[0] = 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        ax.w[i] = S.bigs[EC_BIG_OX * 16 + 2 * i] | (S.bigs[EC_BIG_OX * 16 + 2 * i + 1] << 16);
+        ay.w[i] = S.bigs[EC_BIG_OY * 16 + 2 * i] | (S.bigs[EC_BIG_OY * 16 + 2 * i + 1] << 16);
+    }
+    az = one;
+    for (u32 k = 0; k < 256; k++) {
+        ec_jdbl(&ax, &ay, &az, &M);
+        if (tape[S.globs[EC_GL_BITS + 255 - k]]) ec_jmadd(&ax, &ay, &az, &rx, &ry, &M);
+        pts[k].x = ax; pts[k].y = ay; pts[k].z = az;
+    }
+    for (u32 C = 0; C < 32; C++) {
+        const u32 b = (u32)tape[S.globs[EC_GL_U1 + C]];
+        if (b) {  // minus byte * 2^(8C) * G: the table point with its y negated
+            ec_u256 tx, ty;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                tx.w[i] = S.fixed[((size_t)(8 * C + i) * 256 + b) * 2];
+                ty.w[i] = S.fixed[((size_t)(8 * C + i) * 256 + b) * 2 + 1];
+            }
+            const ec_u256 zero = ec_zero256();
+            const ec_u256 nty = ec_submod(&zero, &ty, &M);
+            ec_jmadd(&ax, &ay, &az, &tx, &nty, &M);
+        }
+        pts[256 + C].x = ax; pts[256 + C].y = ay; pts[256 + C].z = az;
+    }
+    // all 288 points to affine with one inversion; a point at infinity has no affine form (and the circuit no witness)
+    ec_u256 run = one;
+    for (u32 k = 0; k < EC_CHAIN_POINTS; k++) {
+        pre[k] = run;
+        const ec_u256 z = pts[k].z;
+        if (ec_is_zero8(&z)) { atomicMax(status, 1u + (blockIdx.y << 16 | c)); return; }
+        run = ec_mulmod(&run, &z, &M, W);
+    }
+    ec_u256 inv = ec_invmod(&run, &M, W);
+    for (int k = (int)EC_CHAIN_POINTS - 1; k >= 0; k--) {
+        const ec_u256 px = pts[k].x, py = pts[k].y, pz = pts[k].z, pk = pre[k];
+        const ec_u256 zi = ec_mulmod(&inv, &pk, &M, W);
+        inv = ec_mulmod(&inv, &pz, &M, W);
+        const ec_u256 zi2 = ec_mulmod(&zi, &zi, &M, W), zi3 = ec_mulmod(&zi2, &zi, &M, W);
+        const ec_u256 x = ec_mulmod(&px, &zi2, &M, W), y = ec_mulmod(&py, &zi3, &M, W);
+        const u32 run_i = k < 256 ? 1u : 2u, inst = k < 256 ? (u32)k : (u32)k - 256u;
+        const ec_seg_type& T = S.types[S.runs[run_i].type];
+        u64* seg = tape + S.runs[run_i].tape0 + inst * T.n_tape;
+        const uint32_t* outs = S.outs + T.out0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            seg[outs[2 * i]] = x.w[i] & 0xFFFFu; seg[outs[2 * i + 1]] = x.w[i] >> 16;
+            seg[outs[16 + 2 * i]] = y.w[i] & 0xFFFFu; seg[outs[16 + 2 * i + 1]] = y.w[i] >> 16;
+        }
+    }
+}
+
+// grid (segments after PRE = 289, lanes' chunks of the call's cycles): lane = one cycle of the call (job-major), block = one segment,
+// so that a wave runs ONE item list
+static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_segments(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, u32* status) {
+    __shared__ ec_ws s_ws[EC_TAPE_LANES];
+    const u32 lane = blockIdx.y * blockDim.x + threadIdx.x;
+    if (lane >= n_cycles) return;
+    const u32 job = lane / capacity, c = lane % capacity;
+    const EcJob j = jobs[job];
+    const ec_spec S = *Sp;
+    u32 seg = blockIdx.x, run = 1;
+    while (seg >= S.runs[run].count) { seg -= S.runs[run].count; run++; }
+    u32 prun, pinst;
+    ec_prev_segment(&S, run, seg, &prun, &pinst);
+    ec_eval_ctx E;
+    E.S = &S; E.tape = j.tape + (size_t)c * EC_TAPE_PER_CYCLE; E.in = j.inputs + (size_t)c * 128; E.W = &s_ws[threadIdx.x];
+    E.base = S.runs[run].tape0 + seg * S.types[S.runs[run].type].n_tape;
+    E.prev_base = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape;
+    E.prev_type = S.runs[prun].type;
+    E.inst = seg;
+    if (ec_eval_segment(&E, S.runs[run].type)) atomicMax(status, 1u + (job << 16 | c));
+}
+
 // grid (cycles / 64, jobs): the netlist's inputs of a cycle from its tape
 static __global__ __launch_bounds__(64) void k_ec_prepare(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity) {
     const EcJob j = jobs[blockIdx.y];

@@ -780,9 +780,9 @@ extern "C" int zkw_block_timings(const zkw_block* B, char* names, size_t names_b
 namespace {
 // emission order of the synthesized types: the builders that hand their circuits to the callback themselves — log demuxer
 // (oracle.rs:975-984), RAM permutation (:1039-1049), storage application (:1115-1130) —, then CircuitMaker order (:1494-1732:
-// decommits sorter, code decommitter, keccak, sha256, [ecrecover], storage sorter, events sorter, L1-messages sorter,
+// decommits sorter, code decommitter, keccak, sha256, ecrecover, storage sorter, events sorter, L1-messages sorter,
 // L1-messages hasher)
-const int kOrder[11] = {T_DMX, T_RAM, T_SAP, T_DEC, T_DCM, T_KEC, T_SHA, T_STO, T_EVT, T_L1, T_HSH};
+const int kOrder[12] = {T_DMX, T_RAM, T_SAP, T_DEC, T_DCM, T_KEC, T_SHA, T_ECR, T_STO, T_EVT, T_L1, T_HSH};
 // the block's synthesizable instances in emission order and their LPT owners
 int shard_plan(const zkw_block* B, int world, std::vector<uint8_t>* types, std::vector<uint32_t>* index, std::vector<uint32_t>* owner) {
     for (int t : kOrder)
@@ -840,16 +840,9 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
             size_t cnt = 1;
             while (cnt < ring_slots && first + cnt < ni && owned(t, first + cnt)) cnt++;
             switch (t) {
-                case T_DMX: rc = zkw_log_demux_synthesize(c, B->dmx, first, cnt, ring, 0); break;
-                case T_RAM: rc = zkw_ram_synthesize(c, B->ram, first, cnt, ring, 0); break;
-                case T_DEC: rc = zkw_decommit_sorter_synthesize(c, B->dec, first, cnt, ring, 0); break;
-                case T_STO: rc = zkw_storage_sorter_synthesize(c, B->sto, first, cnt, ring, 0); break;
-                case T_EVT: rc = zkw_events_sorter_synthesize(c, B->evt, first, cnt, ring, 0); break;
-                case T_L1: rc = zkw_events_sorter_synthesize(c, B->l1, first, cnt, ring, 0); break;
-                case T_SAP: rc = zkw_storage_application_synthesize(c, B->sap, first, cnt, ring, 0); break;
-                case T_DCM: rc = zkw_code_decommitter_synthesize(c, B->dcm, first, cnt, ring, 0); break;
-                case T_KEC: rc = zkw_keccak_round_synthesize(c, B->pre[0], first, cnt, ring, 0); break;
-                case T_SHA: rc = zkw_sha256_round_synthesize(c, B->pre[1], first, cnt, ring, 0); break;
+                default:  // one entry point for every witness-handle type (ZkSyncBaseLayerCircuit::synthesis, base_layer/mod.rs:286-323)
+                    rc = zkw_synthesize(c, (uint8_t)t, zkw_block_witness(B, (uint8_t)t), first, cnt, ring, 0);
+                    break;
                 case T_HSH: {  // one instance over the net L2 -> L1 messages (the L1 sorter's result queue)
                     zkw_linear_hasher_instance rec;
                     // (the result queue's states are the events sorter's: the pops of the trace's queue section run through them)

@@ -1277,8 +1277,21 @@ extern "C" int zkw_ecrecover_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w,
         ZKW_TRY(ctx->upload("ec_jobs", jobs, &d_jobs));
         { Prof _p(ctx, "k_ec_inputs"); hipLaunchKernelGGL(k_ec_inputs, dim3(capacity, nj), dim3(128), 0, ctx->stream, d_jobs); }
         ZKW_TRY(launch_check("k_ec_inputs"));
-        { Prof _p(ctx, "k_ec_tape"); hipLaunchKernelGGL(k_ec_tape, dim3((capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj), dim3(EC_TAPE_LANES), 0, ctx->stream, ec->dev, d_jobs, capacity, d_status); }
-        ZKW_TRY(launch_check("k_ec_tape"));
+        // the serial form (one lane walks a whole cycle, an inversion per quotient) is kept for cross-checks: ZKW_EC_SERIAL=1, same tape
+        static const bool serial = [] { const char* e = getenv("ZKW_EC_SERIAL"); return e && atoi(e) != 0; }();
+        if (serial) {
+            { Prof _p(ctx, "k_ec_tape"); hipLaunchKernelGGL(k_ec_tape, dim3((capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj), dim3(EC_TAPE_LANES), 0, ctx->stream, ec->dev, d_jobs, capacity, d_status); }
+            ZKW_TRY(launch_check("k_ec_tape"));
+        } else {
+            EcChainScratch sc{};
+            ZKW_TRY(ctx->scratch_t<ec_jac>("ec_chain_pts", ni * capacity * (size_t)EC_CHAIN_POINTS, &sc.pts));
+            ZKW_TRY(ctx->scratch_t<ec_u256>("ec_chain_pre", ni * capacity * (size_t)EC_CHAIN_POINTS, &sc.pre));
+            { Prof _p(ctx, "k_ec_chain"); hipLaunchKernelGGL(k_ec_chain, dim3((capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj), dim3(EC_TAPE_LANES), 0, ctx->stream, ec->dev, d_jobs, capacity, d_status, sc); }
+            ZKW_TRY(launch_check("k_ec_chain"));
+            const u32 n_cycles = (u32)(ni * capacity);
+            { Prof _p(ctx, "k_ec_segments"); hipLaunchKernelGGL(k_ec_segments, dim3(ec->segments_per_cycle - 1, (n_cycles + EC_TAPE_LANES - 1) / EC_TAPE_LANES), dim3(EC_TAPE_LANES), 0, ctx->stream, ec->dev, d_jobs, capacity, n_cycles, d_status); }
+            ZKW_TRY(launch_check("k_ec_segments"));
+        }
         { Prof _p(ctx, "k_ec_prepare"); hipLaunchKernelGGL(k_ec_prepare, dim3(cb, nj), dim3(64), 0, ctx->stream, ec->dev, d_jobs, capacity); }
         return launch_check("k_ec_prepare");
     }, inst, capacity, n_rows));

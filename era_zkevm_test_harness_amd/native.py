@@ -1725,7 +1725,7 @@ class Block:
     def gather_closed_form_inputs(self, comm, rank=0, world=1, root=0):
         """the multi-GPU path's one collective: records [n][24] = [circuit type, instance, compact form (18), public input (4)]
         in emission order on the root, None elsewhere"""
-        total = sum(self.num_instances(t) for t in (4, 8, 10, 2, 3, 5, 6, 9, 11, 12, 13))  # the synthesized types, zkw_block.hip kOrder
+        total = sum(self.num_instances(t) for t in (4, 8, 10, 2, 3, 5, 6, 7, 9, 11, 12, 13))  # the synthesized types, zkw_block.hip kOrder
         out = np.zeros((total, 24), np.uint64)
         n = C.c_size_t(0)
         _check(load().zkw_block_gather_closed_form_inputs(self.handle, comm.handle, rank, world, root, _np_ptr(out), total, C.byref(n)))

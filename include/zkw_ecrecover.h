@@ -23,9 +23,16 @@
 #include "zkw_ecrecover_ec_spec.h"
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
-#define EC_HD __host__ __device__ static inline
+#define EC_HD __host__ __device__ __forceinline__ static
 #else
 #define EC_HD static inline
+#endif
+/* loops over the words of a 256-bit value are unrolled, so that such a value lives in registers on the GPU (a loop the compiler keeps
+   rolled indexes the value at run time, which puts it in scratch memory: tests/test_kernel_resources.py) */
+#if defined(__HIPCC__) || defined(__clang__)
+#define EC_UNROLL _Pragma("unroll")
+#else
+#define EC_UNROLL _Pragma("GCC unroll 16")
 #endif
 
 enum { EC_I_LIN = 1, EC_I_SEL = 2, EC_I_FMA = 3, EC_I_MUL = 4, EC_I_HINT = 5, EC_I_LOOKUP = 6 };
@@ -123,14 +130,19 @@ EC_HD ec_mod ec_modulus(uint32_t which) { /* 0: P = 2^256 - 2^32 - 977, 1: N */
     else { M.m = EC_N_M; M.c = EC_N_C; M.inv_e = EC_N_INV_E; M.nc = 5; }
     return M;
 }
-EC_HD int ec_cmp8(const uint32_t *a, const uint32_t *b) {
-    for (int i = 7; i >= 0; i--)
-        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
-    return 0;
+EC_HD int ec_cmp8(const uint32_t *a, const uint32_t *b) { /* branch-free: the borrow of a - b and whether any word differs */
+    uint64_t br = 0;
+    uint32_t diff = 0;
+    EC_UNROLL for (int i = 0; i < 8; i++) {
+        const uint64_t d = (uint64_t)a[i] - b[i] - br;
+        br = (d >> 32) & 1;
+        diff |= a[i] ^ b[i];
+    }
+    return br ? -1 : diff ? 1 : 0;
 }
 EC_HD void ec_sub8(uint32_t *a, const uint32_t *b) { /* a -= b */
     uint64_t br = 0;
-    for (int i = 0; i < 8; i++) {
+    EC_UNROLL for (int i = 0; i < 8; i++) {
         const uint64_t d = (uint64_t)a[i] - b[i] - br;
         a[i] = (uint32_t)d;
         br = (d >> 32) & 1;
@@ -178,26 +190,87 @@ EC_HD ec_u256 ec_reduce(const uint32_t *x, int n, const ec_mod *M, ec_ws *W) {
     while (ec_cmp8(r.w, M->m) >= 0) ec_sub8(r.w, M->m);
     return r;
 }
+/* ---- the multiplication the inversions and the curve arithmetic spend their time in: constant shapes only, so that on the GPU every
+   word lives in a register (the generic ec_reduce above walks arrays of run-time length in the workspace).
+   x = hi 2^256 + lo = hi c + lo, folded a fixed number of times:  P (c = 2^32 + 977): 16 -> 11 -> 9 -> 9 words;
+   N (c of 129 bits): 16 -> 14 -> 10 -> 9 -> 9 words; then at most two subtractions of m. */
+/* acc[0 .. NA) += h[0 .. NH) * c[0 .. NC) (NA >= NH + NC; no carry out of acc by the callers' bounds) */
+#define EC_FOLD_MAC(acc, NA, h, NH, c, NC)                                        \
+    EC_UNROLL for (int i_ = 0; i_ < (NH); i_++) {                                 \
+        uint64_t cy_ = 0;                                                         \
+        const uint64_t hi_ = (h)[i_];                                             \
+        EC_UNROLL for (int j_ = 0; j_ < (NC); j_++) {                             \
+            const uint64_t v_ = hi_ * (c)[j_] + (acc)[i_ + j_] + cy_;             \
+            (acc)[i_ + j_] = (uint32_t)v_;                                        \
+            cy_ = v_ >> 32;                                                       \
+        }                                                                         \
+        EC_UNROLL for (int k_ = i_ + (NC); k_ < (NA); k_++) {                     \
+            const uint64_t v_ = (uint64_t)(acc)[k_] + cy_;                        \
+            (acc)[k_] = (uint32_t)v_;                                             \
+            cy_ = v_ >> 32;                                                       \
+        }                                                                         \
+    }
+EC_HD ec_u256 ec_finish8(const uint32_t *x9, const uint32_t *m) { /* x9 < 2^256 + small: the last fold's 9 words, word 8 is 0 or 1 */
+    ec_u256 r;
+    EC_UNROLL for (int i = 0; i < 8; i++) r.w[i] = x9[i];
+    uint32_t top = x9[8];
+    for (int rep = 0; rep < 3; rep++) {
+        if (!top && ec_cmp8(r.w, m) < 0) break;
+        uint64_t br = 0;
+        EC_UNROLL for (int i = 0; i < 8; i++) {
+            const uint64_t d = (uint64_t)r.w[i] - m[i] - br;
+            r.w[i] = (uint32_t)d;
+            br = (d >> 32) & 1;
+        }
+        top -= (uint32_t)br;
+    }
+    return r;
+}
+EC_HD ec_u256 ec_reduce16_p(const uint32_t *t) {
+    const uint32_t c[2] = {977u, 1u};
+    uint32_t a1[11], a2[9], a3[9];
+    EC_UNROLL for (int i = 0; i < 11; i++) a1[i] = i < 8 ? t[i] : 0;
+    EC_FOLD_MAC(a1, 11, t + 8, 8, c, 2)
+    EC_UNROLL for (int i = 0; i < 9; i++) a2[i] = i < 8 ? a1[i] : 0;
+    EC_FOLD_MAC(a2, 9, a1 + 8, 3, c, 2)
+    EC_UNROLL for (int i = 0; i < 9; i++) a3[i] = i < 8 ? a2[i] : 0;
+    EC_FOLD_MAC(a3, 9, a2 + 8, 1, c, 2)
+    return ec_finish8(a3, EC_P_M);
+}
+EC_HD ec_u256 ec_reduce16_n(const uint32_t *t) {
+    const uint32_t c[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 0x1u};
+    uint32_t a1[14], a2[11], a3[9], a4[9];
+    EC_UNROLL for (int i = 0; i < 14; i++) a1[i] = i < 8 ? t[i] : 0;
+    EC_FOLD_MAC(a1, 14, t + 8, 8, c, 5)   /* < 2^385: 13 words, word 13 stays 0 */
+    EC_UNROLL for (int i = 0; i < 11; i++) a2[i] = i < 8 ? a1[i] : 0;
+    EC_FOLD_MAC(a2, 11, a1 + 8, 5, c, 5)  /* hi < 2^129 (5 words; word 13 of a1 is 0): < 2^259 */
+    EC_UNROLL for (int i = 0; i < 9; i++) a3[i] = i < 8 ? a2[i] : 0;
+    EC_FOLD_MAC(a3, 9, a2 + 8, 1, c, 5)   /* hi < 8 */
+    EC_UNROLL for (int i = 0; i < 9; i++) a4[i] = i < 8 ? a3[i] : 0;
+    EC_FOLD_MAC(a4, 9, a3 + 8, 1, c, 5)   /* hi <= 1 */
+    return ec_finish8(a4, EC_N_M);
+}
 EC_HD ec_u256 ec_mulmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M, ec_ws *W) {
-    uint32_t *t = W->prod;
-    for (int i = 0; i < 16; i++) t[i] = 0;
-    for (int i = 0; i < 8; i++) { /* (constant trip counts: a and b stay in registers) */
+    (void)W;
+    uint32_t t[16];
+    EC_UNROLL for (int i = 0; i < 16; i++) t[i] = 0;
+    EC_UNROLL for (int i = 0; i < 8; i++) {
         uint64_t carry = 0;
         const uint64_t ai = a->w[i];
-        for (int j = 0; j < 8; j++) {
+        EC_UNROLL for (int j = 0; j < 8; j++) {
             const uint64_t v = ai * b->w[j] + t[i + j] + carry;
             t[i + j] = (uint32_t)v;
             carry = v >> 32;
         }
         t[i + 8] = (uint32_t)carry;
     }
-    return ec_reduce(t, 16, M, W);
+    return M->nc == 2 ? ec_reduce16_p(t) : ec_reduce16_n(t);
 }
 EC_HD ec_u256 ec_submod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) { /* a, b < m */
     ec_u256 r = *a;
     if (ec_cmp8(a->w, b->w) >= 0) { ec_sub8(r.w, b->w); return r; }
     uint64_t carry = 0; /* a + m - b */
-    for (int i = 0; i < 8; i++) {
+    EC_UNROLL for (int i = 0; i < 8; i++) {
         const uint64_t t = (uint64_t)a->w[i] + M->m[i] + carry;
         r.w[i] = (uint32_t)t;
         carry = t >> 32;
@@ -205,25 +278,26 @@ EC_HD ec_u256 ec_submod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M) { /
     ec_sub8(r.w, b->w);
     return r;
 }
-EC_HD ec_u256 ec_addmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M, ec_ws *W) {
-    uint32_t *t = W->prod;
+EC_HD ec_u256 ec_addmod(const ec_u256 *a, const ec_u256 *b, const ec_mod *M, ec_ws *W) { /* a, b < m */
+    (void)W;
+    ec_u256 r;
     uint64_t carry = 0;
-    for (int i = 0; i < 8; i++) {
+    EC_UNROLL for (int i = 0; i < 8; i++) {
         const uint64_t s = (uint64_t)a->w[i] + b->w[i] + carry;
-        t[i] = (uint32_t)s;
+        r.w[i] = (uint32_t)s;
         carry = s >> 32;
     }
-    t[8] = (uint32_t)carry;
-    return ec_reduce(t, 9, M, W);
+    if (carry || ec_cmp8(r.w, M->m) >= 0) ec_sub8(r.w, M->m); /* (a borrow out of the top cancels the carry) */
+    return r;
 }
 EC_HD int ec_is_zero8(const ec_u256 *a) {
     uint32_t o = 0;
-    for (int i = 0; i < 8; i++) o |= a->w[i];
+    EC_UNROLL for (int i = 0; i < 8; i++) o |= a->w[i];
     return o == 0;
 }
 EC_HD ec_u256 ec_zero256(void) {
     ec_u256 z;
-    for (int i = 0; i < 8; i++) z.w[i] = 0;
+    EC_UNROLL for (int i = 0; i < 8; i++) z.w[i] = 0;
     return z;
 }
 /* a^e mod m, e = 8 words in constant memory (m - 2: the inverse; (p + 1) / 4: the square root) */
@@ -246,7 +320,7 @@ EC_HD ec_u256 ec_invmod(const ec_u256 *a, const ec_mod *M, ec_ws *W) { return ec
 /* a vector of 16 (possibly lazy: up to 2^24 each) limbs as an integer of 9 words */
 EC_HD void ec_from_limbs16(const uint64_t *l, uint32_t *out) {
     uint64_t acc = 0;
-    for (int k = 0; k < 16; k += 2) {
+    EC_UNROLL for (int k = 0; k < 16; k += 2) {
         acc += l[k] + (l[k + 1] << 16);
         out[k / 2] = (uint32_t)acc;
         acc >>= 32;
@@ -616,6 +690,45 @@ EC_HD int ec_check_item(const ec_spec *S, const uint32_t *w, const ec_row_view *
         return a > 255 || b != S->fixed[((size_t)tb * 256 + a) * 2] || c != S->fixed[((size_t)tb * 256 + a) * 2 + 1];
     }
     return 0; /* hints state nothing */
+}
+
+/* ---- Jacobian arithmetic without case distinctions (the kernels' accumulator chain): in place on three 256-bit values; a degenerate
+   input (the point at infinity, equal x in the addition) leaves z == 0, which the caller checks once at the end -------------------- */
+EC_HD void ec_jdbl(ec_u256 *X, ec_u256 *Y, ec_u256 *Z, const ec_mod *M) { /* a = 0: 7 multiplications */
+    const ec_u256 a = ec_mulmod(X, X, M, 0), b = ec_mulmod(Y, Y, M, 0), c = ec_mulmod(&b, &b, M, 0);
+    ec_u256 t = ec_addmod(X, &b, M, 0);
+    t = ec_mulmod(&t, &t, M, 0);
+    t = ec_submod(&t, &a, M);
+    t = ec_submod(&t, &c, M);
+    const ec_u256 d = ec_addmod(&t, &t, M, 0);
+    ec_u256 e = ec_addmod(&a, &a, M, 0);
+    e = ec_addmod(&e, &a, M, 0);
+    const ec_u256 f = ec_mulmod(&e, &e, M, 0), d2 = ec_addmod(&d, &d, M, 0);
+    const ec_u256 yz = ec_mulmod(Y, Z, M, 0);
+    *X = ec_submod(&f, &d2, M);
+    ec_u256 c8 = ec_addmod(&c, &c, M, 0);
+    c8 = ec_addmod(&c8, &c8, M, 0);
+    c8 = ec_addmod(&c8, &c8, M, 0);
+    ec_u256 dx = ec_submod(&d, X, M);
+    dx = ec_mulmod(&e, &dx, M, 0);
+    *Y = ec_submod(&dx, &c8, M);
+    *Z = ec_addmod(&yz, &yz, M, 0);
+}
+EC_HD void ec_jmadd(ec_u256 *X, ec_u256 *Y, ec_u256 *Z, const ec_u256 *x2, const ec_u256 *y2, const ec_mod *M) { /* + the affine (x2, y2): 11 */
+    const ec_u256 zz = ec_mulmod(Z, Z, M, 0), zzz = ec_mulmod(&zz, Z, M, 0);
+    const ec_u256 u2 = ec_mulmod(x2, &zz, M, 0), s2 = ec_mulmod(y2, &zzz, M, 0);
+    const ec_u256 h = ec_submod(&u2, X, M), r = ec_submod(&s2, Y, M);
+    const ec_u256 h2 = ec_mulmod(&h, &h, M, 0), h3 = ec_mulmod(&h2, &h, M, 0), xh2 = ec_mulmod(X, &h2, M, 0);
+    ec_u256 t = ec_mulmod(&r, &r, M, 0);
+    t = ec_submod(&t, &h3, M);
+    t = ec_submod(&t, &xh2, M);
+    const ec_u256 x3 = ec_submod(&t, &xh2, M);
+    ec_u256 v = ec_submod(&xh2, &x3, M);
+    v = ec_mulmod(&r, &v, M, 0);
+    const ec_u256 yh3 = ec_mulmod(Y, &h3, M, 0);
+    *Z = ec_mulmod(Z, &h, M, 0);
+    *X = x3;
+    *Y = ec_submod(&v, &yh3, M);
 }
 
 /* ---- the 256 FixedBaseMul tables (host): word i of x and of y of byte * 2^(8 C) * G, (0, 0) for byte 0 ---------------------- */

@@ -159,15 +159,15 @@ def _storage_application_synthesize(w, i, capacity, n_rows):
 SYNTH = {STORAGE_APPLICATION: ("storage_application", _storage_application_synthesize), LOG_DEMUXER: ("log_demuxer", o.log_demux_synthesize), RAM_PERMUTATION: ("ram_permutation", o.ram_synthesize),
          DECOMMITS_SORTER: ("decommits_sorter", o.decommit_sorter_synthesize), STORAGE_SORTER: ("storage_sorter", o.storage_sorter_synthesize),
          EVENTS_SORTER: ("events_sorter", o.events_sorter_synthesize), L1_MESSAGES_SORTER: ("l1_messages_sorter", o.events_sorter_synthesize),
-         CODE_DECOMMITTER: ("code_decommitter", o.code_decommitter_synthesize), KECCAK256: ("keccak256", o.keccak_round_synthesize), SHA256: ("sha256", o.sha256_round_synthesize), L1_MESSAGES_HASHER: ("l1_messages_hasher", _linear_hasher_synthesize)}
+         CODE_DECOMMITTER: ("code_decommitter", o.code_decommitter_synthesize), KECCAK256: ("keccak256", o.keccak_round_synthesize), SHA256: ("sha256", o.sha256_round_synthesize), ECRECOVER: ("ecrecover", o.ecrecover_synthesize), L1_MESSAGES_HASHER: ("l1_messages_hasher", _linear_hasher_synthesize)}
 # oracle.rs:975-984 demuxer, :1039-1049 RAM, :1115-1130 storage application (when the block has a storage tree), then CircuitMaker
 # order :1494-1732 (the types that have a synthesis here)
-EMISSION_ORDER = (LOG_DEMUXER, RAM_PERMUTATION, STORAGE_APPLICATION, DECOMMITS_SORTER, CODE_DECOMMITTER, KECCAK256, SHA256, STORAGE_SORTER, EVENTS_SORTER, L1_MESSAGES_SORTER,
+EMISSION_ORDER = (LOG_DEMUXER, RAM_PERMUTATION, STORAGE_APPLICATION, DECOMMITS_SORTER, CODE_DECOMMITTER, KECCAK256, SHA256, ECRECOVER, STORAGE_SORTER, EVENTS_SORTER, L1_MESSAGES_SORTER,
                   L1_MESSAGES_HASHER)
 
 
 def synthesize_all(artifacts, n_rows, on_trace=None):
-    """ZkSyncBaseLayerCircuit::synthesis of every instance of the eleven synthesized types in emission order; returns the
+    """ZkSyncBaseLayerCircuit::synthesis of every instance of the twelve synthesized types in emission order; returns the
     number of instances. on_trace(circuit_type, instance, trace) is called with each filled trace."""
     done = 0
     for ctype in EMISSION_ORDER:

@@ -170,7 +170,7 @@ def test_block_sequencer_matches_builder_by_builder(ctx, oracle, seed):
         seen.append((ctype, inst))
 
     n = B.synthesize(1 << 18, ring_slots=3, callback=on_circuit)
-    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.STORAGE_APPLICATION, blk.DECOMMITS_SORTER, blk.CODE_DECOMMITTER, blk.KECCAK256, blk.SHA256, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER,
+    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.STORAGE_APPLICATION, blk.DECOMMITS_SORTER, blk.CODE_DECOMMITTER, blk.KECCAK256, blk.SHA256, blk.ECRECOVER, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER,
              blk.L1_MESSAGES_HASHER]
     assert seen == [(t, i) for t in order for i in range(B.num_instances(t))] and n == len(seen) > 12
     spans = {name for name, _, _ in B.timings()}
@@ -201,7 +201,7 @@ def test_block_sharded_synthesis_and_gather(ctx):
     caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
             blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
     B = nv.Block(0, b, caps)
-    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.DECOMMITS_SORTER, blk.CODE_DECOMMITTER, blk.KECCAK256, blk.SHA256, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER,
+    order = [blk.LOG_DEMUXER, blk.RAM_PERMUTATION, blk.DECOMMITS_SORTER, blk.CODE_DECOMMITTER, blk.KECCAK256, blk.SHA256, blk.ECRECOVER, blk.STORAGE_SORTER, blk.EVENTS_SORTER, blk.L1_MESSAGES_SORTER,
              blk.L1_MESSAGES_HASHER]
     full = [(t, i) for t in order for i in range(B.num_instances(t))]
     owner = nv.shard_lpt([t for t, _ in full], 3)

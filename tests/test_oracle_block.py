@@ -24,7 +24,7 @@ def test_oracle_block_threads_queues_and_satisfies_circuits(oracle):
     checks = {ob.LOG_DEMUXER: oracle.log_demux_check, ob.RAM_PERMUTATION: oracle.ram_check, ob.DECOMMITS_SORTER: oracle.decommit_sorter_check,
               ob.STORAGE_SORTER: oracle.storage_sorter_check, ob.EVENTS_SORTER: oracle.events_sorter_check,
               ob.L1_MESSAGES_SORTER: oracle.events_sorter_check, ob.KECCAK256: oracle.keccak_round_check, ob.SHA256: oracle.sha256_round_check,
-              ob.CODE_DECOMMITTER: oracle.code_decommitter_check,
+              ob.CODE_DECOMMITTER: oracle.code_decommitter_check, ob.ECRECOVER: oracle.ecrecover_check,
               ob.L1_MESSAGES_HASHER: lambda t, cap: oracle.linear_hasher_check(t, oracle.linear_hasher_cycles(cap))}
     seen = []
 
