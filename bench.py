@@ -199,33 +199,52 @@ def full_blocks_batched(local_rank, blk, K=48, rounds=3, rank=0, world=1, comm=N
 
 
 def hash_circuits_gpu(local_rank, blk):
-    """Synthesis rates of the netlist circuits (DESIGN.md 3.17-3.18) at the reference's geometry — 2^20 rows, capacities of
-    geometry_config.rs — on synthetic precompile calls / the block's bytecodes: instances per second of 8 (4, 1) traces per
-    call, memset of the slots included. Not part of `value`."""
+    """Synthesis rates of the netlist circuits (DESIGN.md 3.17-3.19) at the reference's geometry — 2^20 rows, capacities of
+    geometry_config.rs — on synthetic precompile calls / the block's bytecodes, 8 (4) traces per call. Two rates per circuit:
+    `circuits_per_s` with the slots re-used (a slot that already holds the circuit's layout keeps its zeros: the call writes
+    `write_bytes_per_circuit`, NOT `trace_bytes`) and `cold` with the slots' layout forgotten before every call (every cell of the slot
+    is written: cleared or filled). `written_GBps` = circuits_per_s x write_bytes_per_circuit, the figure to hold against the HBM peak.
+    Not part of `value`."""
     ctx = native.Context(local_rank)
     n_rows = 1 << 20
     out = {}
 
-    def timed(n, fn, reps=3):
-        best = None
-        for _ in range(reps):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            fn()
-            ctx.synchronize()
-            dt = time.perf_counter() - t0
-            best = dt if best is None or dt < best else best
-        return {"circuits_per_s": n / best, "ms_per_call": best * 1e3, "instances_per_call": n}
+    def timed(n, fn, reps=3, trace=None, ctype=None, cap=0):
+        def run(cold):
+            best = None
+            for _ in range(reps):
+                if cold and trace is not None:
+                    for k in range(n):
+                        trace.device_ptr(k)  # taking the pointer forgets the slot's layout: the next call clears it
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                ctx.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+            return best
+        best = run(False)
+        rep = {"circuits_per_s": n / best, "ms_per_call": best * 1e3, "instances_per_call": n}
+        if ctype is not None:
+            warm_b, cold_b = native.circuit_fill_bytes(ctype, cap, n_rows)
+            c = run(True)
+            rep.update(write_bytes_per_circuit=warm_b, written_GBps=n / best * warm_b / 1e9, frac_of_hbm_peak_on_bytes_written=n / best * warm_b / 8e12,
+                       cold={"circuits_per_s": n / c, "ms_per_call": c * 1e3, "write_bytes_per_circuit": cold_b, "written_GBps": n / c * cold_b / 1e9})
+        return rep
 
     mem_in = np.zeros(1, native.QUEUE_STATE12)
-    for name, kind, n_req, cap, cols, synth in (("keccak256_round_function", 0, 1400, 293, native.KC_COLS, ctx.synthesize_keccak_round_function),
-                                                ("sha256_round_function", 1, 6000, 2206, native.SC_COLS, ctx.synthesize_sha256_round_function)):
+    for name, kind, n_req, cap, cols, synth, ctype in (("keccak256_round_function", 0, 1400, 293, native.KC_COLS, ctx.synthesize_keccak_round_function, 5),
+                                                       ("sha256_round_function", 1, 6000, 2206, native.SC_COLS, ctx.synthesize_sha256_round_function, 6),
+                                                       ("ecrecover", 2, 7 * 8, 7, native.EK_COLS, ctx.synthesize_ecrecover, 7)):
         req, mq = synthetic.precompile_trace(kind, n_req, seed=5, max_rounds=6)
         tails = ctx.queue_push_chain_log(ctx.encode_log_queries(req))[1]
         w = ctx._precompile(kind, req, tails, mq, cap, mem_in)
         n = min(8, w.num_instances)
         t = native.Trace(ctx, n_rows, n, n_cols=cols)
-        out[name] = dict(timed(n, lambda: synth(w, t, 0, n, 0)), capacity=cap, columns=cols, trace_bytes=cols * n_rows * 8)
+        out[name] = dict(timed(n, lambda: synth(w, t, 0, n, 0), trace=t, ctype=ctype, cap=cap), capacity=cap, columns=cols, trace_bytes=cols * n_rows * 8)
+        if ctype == 7:
+            out[name]["note"] = ("7 requests per instance (geometry_config.rs): the accumulator chain of a request is serial (k_ec_chain, ~17 ms per call whatever "
+                                 "the batch), the other kernels scale with it: 32 instances per call run at ~1 000 circuits/s (tools/probe_ecrecover_synth.py)")
         t.free()
         w.free()
     dec = ctx.compute_decommitts_sorter_circuit_snapshots(blk["decommit_queries"], 117500)
@@ -235,7 +254,7 @@ def hash_circuits_gpu(local_rank, blk):
     w = ctx.compute_decommitter_circuit_snapshots(dq, dt_, np.concatenate(codes), woff, 2845, mem_in)
     n = min(4, w.num_instances)
     t = native.Trace(ctx, n_rows, n, n_cols=native.DC_COLS)
-    out["code_decommitter"] = dict(timed(n, lambda: ctx.synthesize_code_decommitter(w, t, 0, n, 0)), capacity=2845, columns=native.DC_COLS,
+    out["code_decommitter"] = dict(timed(n, lambda: ctx.synthesize_code_decommitter(w, t, 0, n, 0), trace=t, ctype=3, cap=2845), capacity=2845, columns=native.DC_COLS,
                                    trace_bytes=native.DC_COLS * n_rows * 8)
     t.free()
     w.free()
@@ -244,7 +263,7 @@ def hash_circuits_gpu(local_rank, blk):
     t = native.Trace(ctx, n_rows, 8, n_cols=native.LH_COLS)
     states = np.zeros(8, native.QUEUE_STATE4)
     qtails = [ctx.queue_push_chain_log(ctx.encode_log_queries(q))[1] for q in queues]  # the queues' states: the sorter that builds a queue holds them
-    out["linear_hasher"] = dict(timed(8, lambda: ctx.synthesize_linear_hasher_batch(queues, states, 774, t, 0, tails=qtails)), capacity=774,
+    out["linear_hasher"] = dict(timed(8, lambda: ctx.synthesize_linear_hasher_batch(queues, states, 774, t, 0, tails=qtails), trace=t, ctype=13, cap=774), capacity=774,
                                 columns=native.LH_COLS, trace_bytes=native.LH_COLS * n_rows * 8,
                                 note="the L1-messages queues of 8 blocks per call (zkw_linear_hasher_synthesize_batch_with_tails: the queues' "
                                      "states come from the sorter that built them, as in zkw_block_synthesize); the sponge of a "
@@ -259,7 +278,7 @@ def hash_circuits_gpu(local_rank, blk):
     w = ctx.decompose_into_storage_application_witnesses(sq, stails, idx, paths, tree.root, tree.next_enumeration_index, 33)
     n = min(8, w.num_instances)
     t = native.Trace(ctx, n_rows, n, n_cols=native.SA_COLS)
-    out["storage_application"] = dict(timed(n, lambda: ctx.synthesize_storage_application(w, t, 0, n, 0)), capacity=33, columns=native.SA_COLS,
+    out["storage_application"] = dict(timed(n, lambda: ctx.synthesize_storage_application(w, t, 0, n, 0), trace=t, ctype=10, cap=33), capacity=33, columns=native.SA_COLS,
                                       trace_bytes=native.SA_COLS * n_rows * 8, cycles_per_instance=33 * native.SA_CYCLES_PER_WALK)
     t.free()
     w.free()
@@ -328,6 +347,7 @@ def main():
                          "P = 1 is the plain sequential step)")
     ap.add_argument("--stagger-ms", type=float, default=-1.0, help="start offset between pipelines (default 500 ms)")
     ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--no-h2d", action="store_true", help="skip the inputs-from-host leg (2 extra steps with a concurrent pinned H2D feed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hash-circuits", action="store_true", help="skip the synthesis-rate leg of the netlist circuits")
     ap.add_argument("--no-full-block", action="store_true", help="skip the full-block wall-time leg")
@@ -523,6 +543,56 @@ def main():
             prof[k] = (a[0] + ms, a[1] + cnt)
         c.profile_enable(False)
 
+    # ---- inputs arriving from host memory. The throughput leg's queries are resident in HBM; a host hands them over
+    # from its own memory (external_calls::run's witness vectors). A true double buffer of the step's inputs needs twice their HBM
+    # (2 x 95 GB next to the batch), so this leg measures the two things that decide whether the transfer matters: the pinned
+    # host -> device rate of this box, and the step time while a copy stream moves one step's worth of input bytes per step (1 GiB chunks
+    # from a pinned buffer into two alternating staging buffers) next to the unchanged compute. The consumed queries stay the resident ones.
+    h2d = None
+    if world == 1 and not args.no_h2d:
+        try:
+            chunk = 1 << 30
+            host = torch.empty(chunk, dtype=torch.uint8, pin_memory=True)
+            host.random_(0, 256)
+            stage = [torch.empty(chunk, dtype=torch.uint8, device=dev) for _ in range(2)]
+            cstream = torch.cuda.Stream(device=dev)
+            step_bytes = B * n * q_item
+
+            def feed(total_bytes, done):
+                torch.cuda.set_device(local_rank)
+                t_a = time.perf_counter()
+                with torch.cuda.stream(cstream):
+                    for k in range(-(-total_bytes // chunk)):
+                        stage[k % 2].copy_(host, non_blocking=True)
+                        if k % 8 == 7:
+                            cstream.synchronize()  # (bounds the queue of pending copies)
+                cstream.synchronize()
+                done.append(time.perf_counter() - t_a)
+
+            alone = []
+            feed(16 * chunk, alone)
+            rate_alone = 16 * chunk / alone[0] / 1e9
+            done = []
+            th = threading.Thread(target=feed, args=(2 * step_bytes, done))
+            torch.cuda.synchronize()
+            t_h = time.perf_counter()
+            th.start()
+            run_steps(2, stagger_s)
+            torch.cuda.synchronize()
+            dt_h = time.perf_counter() - t_h
+            th.join()
+            h2d = {"pinned_h2d_GBps_alone": rate_alone, "input_bytes_per_step": step_bytes,
+                   "ms_per_step_with_concurrent_feed": dt_h / 2 * 1e3, "feed_ms_per_step": done[0] / 2 * 1e3,
+                   "pinned_h2d_GBps_during_compute": 2 * step_bytes / done[0] / 1e9,
+                   "circuits_per_s_with_concurrent_feed": 2 * n_inst_local / dt_h,
+                   "transfer_hidden": done[0] <= dt_h,
+                   "note": "2 steps of the same work while a copy stream moves one step's input bytes per step from pinned host memory into two "
+                           "alternating 1 GiB staging buffers; the queries the kernels consume stay the resident ones (a full double buffer of the "
+                           "inputs needs 2 x their HBM)"}
+            del host, stage
+        except Exception as e:  # noqa: BLE001 — a box without enough pinned memory: report, do not fail the bench
+            h2d = {"error": repr(e)}
+
     if rank == 0:
         assert gathered.shape[0] == n_inst_local * world
         circuits = n_inst_local * world * args.steps
@@ -562,6 +632,38 @@ def main():
             profiled_items = 2 * t["blocks"] * n if kernel.startswith("k_chain") else None
             scale = (launches_items / profiled_items) if profiled_items else 1.0
             return k["traffic_bytes_per_launch"] * scale
+
+        def valu_roofline():
+            """The bound that matters for this step: VALU issue. 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave-instruction
+            = 6.14e11 wave-instructions/s. Instruction counts per unit of work: SQ_INSTS_VALU of the committed PMC pass
+            (profiles/rNN/valu.json: rocprofv3 --pmc SQ_INSTS_VALU at the benchmarked batch) when there is one, else the ISA counts of
+            DESIGN.md 7.4 (507 wave-instructions per queue item in the quad chain, 228 per lane-permutation of k_ram_fill_poseidon)."""
+            peak = 256 * 4 * 2.4e9 / 4
+            per_unit = {"k_chain_full_q4": 507.0, "k_chain_full": 1480.0, "k_ram_fill_poseidon": 2 * 228.0 * n}  # per item / per instance
+            src = "ISA instruction counts (DESIGN.md 7.4)"
+            path = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "valu.json") for r_ in ("r06", "r05", "r04")) if os.path.exists(p_)), None)
+            if path is not None:
+                v = json.load(open(path))
+                per_unit.update({k.replace("zkw::", ""): x["wave_insts_per_unit"] for k, x in v["kernels"].items()})
+                src = "SQ_INSTS_VALU, " + os.path.relpath(path, ROOT)
+            units = {"k_chain_full_q4": 2 * items * P, "k_chain_full": 2 * items * P}  # queue items per step (all pipelines)
+            per_kernel, total = {}, 0.0
+            for k, (kms, kcnt) in prof.items():
+                base_name = k.split("<")[0]
+                if base_name not in per_unit or not kcnt:
+                    continue
+                u = units.get(base_name, n_inst_local)  # the fills: instances per step
+                insts = per_unit[base_name] * u
+                if base_name == "k_ram_fill_poseidon" and "<" in k:
+                    insts /= 2  # two template instances share the per-instance count
+                total += insts
+                a = insts / (kms / args.steps * 1e-3)
+                per_kernel[k] = {"wave_insts_per_step": insts, "ms_per_step": kms / args.steps, "achieved": a, "frac": a / peak}
+            floor_ms = total / peak * 1e3
+            return {"bound": "valu", "peak": peak, "unit": "wave-instructions/s", "source": src, "per_kernel": per_kernel,
+                    "step": {"wave_insts": total, "floor_ms": floor_ms, "ms_per_step": dt / args.steps * 1e3, "frac": floor_ms / (dt / args.steps * 1e3),
+                             "note": "kernels with a counted instruction volume only (the chains and the Poseidon2 rows: ~90 % of the step's VALU work); "
+                                     "frac = the step's VALU-issue floor over its wall time"}}
 
         name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / max(cnt, 1)
@@ -603,6 +705,8 @@ def main():
                          "note": "k_chain_full is a serial Poseidon2 chain per queue: latency/VALU-bound, permutations/s is "
                                  "its meaningful rate; with P pipelines its launches overlap the other pipelines' synthesis, "
                                  "so per-kernel times sum to more than the wall time"},
+            "roofline_valu": valu_roofline(),
+            "inputs_from_host": h2d,
             "synthesis": {"trace_bytes_per_circuit": 149 * n_rows * 8, "kernels_ms_per_step": synth_ms / args.steps,
                           "achieved_GBps": synth_gbs, "frac_of_hbm_peak": synth_gbs / HBM_PEAK_GBS if synth_gbs else None,
                           "per_kernel": hbm_kernels},

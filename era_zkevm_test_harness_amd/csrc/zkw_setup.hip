@@ -94,6 +94,34 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
     return ZKW_OK;
 }
 
+// Bytes a synthesis call writes into one slot (algorithmic: the cells the fill kernels store, 8 bytes each) — what the measured rates
+// of bench.py's `hash_circuits` leg are divided into. `warm`: the slot already holds this layout (its zeros are kept, the netlist
+// engine's slot tag); `cold`: any other slot — every cell of the slot's columns is written once (cleared or filled).
+extern "C" int zkw_circuit_fill_bytes(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t* warm, uint64_t* cold) {
+    zkw_circuit_layout lay;
+    ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
+    if (!lay.synthesizable || !warm || !cold) return fail(ZKW_ERR_INVALID, "zkw_circuit_fill_bytes: bad argument");
+    *cold = (uint64_t)lay.num_columns * n_rows * 8;
+    if (lay.region_stride) { *warm = *cold; return ZKW_OK; }  // the queue circuits write every cell of the slot, every time
+    const nl_spec* sp = nl_host_spec(circuit_type);
+    const uint32_t cycles = nl_cycles_of(circuit_type, lay.capacity);
+    uint64_t per_cycle = 0;
+    for (uint32_t st = 0; st < sp->steps_per_cycle; st++) {
+        const nl_step_type& T = sp->step_types[sp->cycle[st].type];
+        per_cycle += (uint64_t)T.lookup_rows * sp->w * sp->r;
+        for (uint32_t r = 0; r < T.rows; r++) per_cycle += sp->gate_row_end[T.rowend0 + r];
+    }
+    uint64_t cells = per_cycle * cycles + 2ull * sp->state + 4 + sp->total_table_rows;
+    if (const nlq_desc* qd = nlq_desc_of(circuit_type)) {
+        uint64_t q = 0;
+        for (uint32_t j = 0; j < qd->n_ops; j++) q += nlq_enc_cells(&qd->ops[j]) + (uint64_t)nlq_kind_perms(qd->ops[j].kind) * NLQ_P2_CELLS;
+        cells += q * cycles + nlq_bnd_cells(qd);
+    }
+    if (circuit_type == 7) cells += (uint64_t)cycles * EC_ROWS_PER_CYCLE * EC_ROW_CELLS;
+    *warm = cells * 8;
+    return ZKW_OK;
+}
+
 // Setup side, selectors: which gate set applies to each row of a trace of this library's layout — what the
 // reference's setup keeps in its constant columns (gate selectors, the lookup table id of a row). Host arithmetic over the specs.
 //   queue circuits (2, 4, 8, 9, 11, 12; "zkw trace v2", region-major): selector = row type of the spec (0 .. NUM_ROW_TYPES - 1:

@@ -62,6 +62,7 @@ SYMBOLS = [
     ("zkw_version", C.c_char_p, []),
     ("zkw_circuit_geometry_of", _int, [C.c_uint8, _vp]),
     ("zkw_circuit_layout_of", _int, [C.c_uint8, _u32, _vp]),
+    ("zkw_circuit_fill_bytes", _int, [C.c_uint8, _u32, _sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("zkw_profile_enable", _int, [_vp, _int]),
     ("zkw_profile_reset", _int, [_vp]),
     ("zkw_profile_get", _int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -1095,6 +1096,13 @@ CIRCUIT_LAYOUT = np.dtype(
     [("synthesizable", "<u4"), ("fits", "<u4"), ("capacity", "<u4"), ("num_columns", "<u4"), ("rows_per_cycle", "<u4"), ("total_table_rows", "<u4"),
      ("region_stride", "<u8"), ("rows_used", "<u8"), ("nop_rows", "<u8"), ("trace_len", "<u8"), ("public_input_column", "<u4", (4,)),
      ("public_input_row", "<u8", (4,)), ("queue_first_row", "<u8"), ("queue_rows_per_cycle", "<u4"), ("ec_rows_per_cycle", "<u4"), ("ec_first_row", "<u8")])
+
+
+def circuit_fill_bytes(circuit_type: int, capacity: int = 0, n_rows: int = 1 << 20):
+    """zkw_circuit_fill_bytes: (warm, cold) bytes one synthesis call writes into one slot"""
+    warm, cold = C.c_uint64(0), C.c_uint64(0)
+    _check(load().zkw_circuit_fill_bytes(circuit_type, capacity, n_rows, C.byref(warm), C.byref(cold)))
+    return warm.value, cold.value
 
 
 def circuit_layout(circuit_type: int, capacity: int = 0):

@@ -147,6 +147,10 @@ int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_l
    ZKW_ROW_HAS_GATES where ADD gates sit in the general-purpose columns, ZKW_ROW_HEADER for a cycle's first row, boundary rows
    ZKW_ROW_BOUNDARY + k. ZKW_ROW_PADDING: the row holds nothing (all cells zero). capacity 0 = the type's default.
    No GPU needed. Copy-permutation (sigma) columns are not produced yet. */
+/* bytes one synthesis call writes into one slot (the cells its fill kernels store x 8): *warm when the slot already holds this layout
+   (a netlist circuit keeps the slot's zeros: see zkw_trace_device_ptr), *cold for any other slot (every cell of the slot's columns).
+   The queue circuits write every cell every time (warm == cold). What measured circuits/s are multiplied by to get bytes/s. */
+int zkw_circuit_fill_bytes(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t *warm, uint64_t *cold);
 #define ZKW_ROW_HAS_GATES 0x40
 #define ZKW_ROW_HEADER 0x80
 #define ZKW_ROW_BOUNDARY 0xC0

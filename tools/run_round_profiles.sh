@@ -10,16 +10,16 @@ OUT=$(cd "$OUT" && pwd)
 export TMPDIR=/tmp
 # 1. the default bench (throughput leg + full-block leg + CPU legs), without a profiler
 timeout -s KILL 1200 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-timeout -s KILL 900 python bench.py --pipelines 1 --no-cpu-baseline --no-full-block > "$OUT/bench_sequential.json" 2> "$OUT/bench_sequential.err"
+timeout -s KILL 900 python bench.py --pipelines 1 --no-cpu-baseline --no-full-block --no-h2d > "$OUT/bench_sequential.json" 2> "$OUT/bench_sequential.err"
 # 2. the same command under rocprofv3 --kernel-trace --stats
 cd /tmp && rm -rf /tmp/prof_stats && timeout -s KILL 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- \
     python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_default_under_rocprofv3.json" 2> "$OUT/rocprof_stats.err"
 cp "$(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1)" "$OUT/bench_default_kernel_stats.csv"
 # 3. HBM counters AT THE BENCHMARKED BATCH, one pass each (never combined with other trace domains): one timed step of the
 #    sequential form (counter collection serialises the dispatches anyway)
-for C in FETCH_SIZE WRITE_SIZE; do
+for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_BUSY_CYCLES; do
     rm -rf /tmp/prof_pmc && timeout -s KILL 1500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_pmc -- \
-        python "$ROOT/bench.py" --pipelines 1 --steps 1 --warmup 0 --no-cpu-baseline --no-full-block > "$OUT/bench_pmc_$C.json" 2> "$OUT/rocprof_pmc_$C.err"
+        python "$ROOT/bench.py" --pipelines 1 --steps 1 --warmup 0 --no-cpu-baseline --no-full-block --no-h2d > "$OUT/bench_pmc_$C.json" 2> "$OUT/rocprof_pmc_$C.err"
     python3 - "$(ls /tmp/prof_pmc/*/*counter_collection.csv | head -1)" "$OUT/bench_pmc_$C.summary.csv" <<'PY'
 import collections, csv, sys
 tot, disp = collections.defaultdict(float), collections.defaultdict(set)
@@ -40,6 +40,8 @@ for P in ds es ld ss; do
     echo "== tools/probe_${P}_synth.py" >> "$OUT/synthesis_probes.txt"
     timeout -s KILL 300 python tools/probe_${P}_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
 done
+echo "== tools/probe_ecrecover_synth.py (ECRecover, 7 requests per instance, 2^20 rows; 8 and 32 instances per call)" >> "$OUT/synthesis_probes.txt"
+timeout -s KILL 300 python tools/probe_ecrecover_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
 echo "== tools/probe_netlist_perf.py (Keccak256RoundFunction 293 / Sha256RoundFunction 2206 cycles, 2^20 rows, 8 instances; L1MessagesHasher)" >> "$OUT/synthesis_probes.txt"
 timeout -s KILL 300 python tools/probe_netlist_perf.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
 rm -rf /tmp/pk_nl && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk_nl -- python tools/probe_netlist_perf.py > /dev/null 2>&1
