@@ -68,8 +68,8 @@ int main(int argc, char **argv) {
     TRY(zkw_trace_create(ctx, n_rows, 1, &t));
     for (size_t i = 0; i < n_inst; i++) {
         uint64_t bad = 0, first = 0;
-        TRY(zkw_ram_synthesize(ctx, w, i, 1, t, 0));
-        TRY(zkw_ram_check_satisfied(ctx, t, 0, capacity, &bad, &first));
+        TRY(zkw_synthesize(ctx, ZKW_CIRCUIT_RAM_PERMUTATION, w, i, 1, t, 0)); /* ZkSyncBaseLayerCircuit::synthesis: one entry point over the circuit types */
+        TRY(zkw_check_satisfied(ctx, ZKW_CIRCUIT_RAM_PERMUTATION, t, 0, capacity, &bad, &first));
         printf("  instance %zu: items [%llu, +%llu) start %u completion %u  public input %016llx..  %s\n", i,
                (unsigned long long)inst[i].first_item, (unsigned long long)inst[i].num_items, inst[i].start_flag,
                inst[i].completion_flag, (unsigned long long)pi[4 * i], bad ? "NOT SATISFIED" : "satisfied");
