@@ -620,9 +620,9 @@ def main():
         }
         def pmc_traffic(kernel, launches_items):
             """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate
-            runs at the benchmarked batch, gfx950 FETCH correction applied: profiles/r03/traffic.json, or round 2's; counters cannot be read
+            runs at the benchmarked batch, gfx950 FETCH correction applied: the newest profiles/rNN/traffic.json; counters cannot be read
             inside this process). Scaled by items per launch when this run's launch differs from the profiled one."""
-            path = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "traffic.json") for r_ in ("r03", "r02")) if os.path.exists(p_)), None)
+            path = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "traffic.json") for r_ in ("r04", "r03", "r02")) if os.path.exists(p_)), None)
             if path is None:
                 return None
             t = json.load(open(path))
@@ -700,7 +700,7 @@ def main():
                        "pipelines_per_gpu": P, "pipeline_stagger_ms": stagger_s * 1e3, "gather": gather_backend},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(name, 2 * items),
-                         "traffic_unit": "bytes per launch (PMC, profiles/r03/traffic.json)", "algorithmic_bytes_per_launch": ab,
+                         "traffic_unit": "bytes per launch (PMC, newest profiles/rNN/traffic.json)", "algorithmic_bytes_per_launch": ab,
                          "avg_launch_ms": avg_ms,
                          "note": "k_chain_full is a serial Poseidon2 chain per queue: latency/VALU-bound, permutations/s is "
                                  "its meaningful rate; with P pipelines its launches overlap the other pipelines' synthesis, "
