@@ -96,31 +96,9 @@ __device__ __forceinline__ u64 nlq_enc_value(u32 item, u32 e, F&& cell) {
     return gl::canon(acc);
 }
 
-// One flattened Poseidon2 gate by the 16 lanes of a row (p2::Coop, the form of the queue-chain kernels: lane g holds element g, the
-// linear layers cross lanes by DPP): every lane stores its element after each full round, lane 0 the S-box output of each partial
-// round — the 130 variables in the order of orc_poseidon2_flattened. x: this lane's input (0 in lanes 12..15); returns its output.
+// the flattened Poseidon2 gate of the queue rows: p2::coop_flattened (poseidon2.cuh)
 template <class Put>
-__device__ __forceinline__ u64 nlq_coop_p2(const p2::Coop& co, u64 x, u32 g, Put&& put) {
-    if (co.active) put(g, gl::canon(x));
-    x = co.external(x);
-#pragma unroll
-    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
-        x = co.external(p2::pow7_sched(p2::add_rc_sched(x, co.rc_full[k])));
-        if (co.active) put(12 * (k + 1) + g, gl::canon(x));
-    }
-    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
-        const u64 rc = p2::c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];
-        const u64 sx = p2::pow7_sched(p2::add_rc_sched(x, rc));
-        if (co.first) put(12 * (P2_HALF_FULL_ROUNDS + 1) + k, gl::canon(sx));
-        x = co.internal(co.first ? sx : x);
-    }
-#pragma unroll
-    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
-        x = co.external(p2::pow7_sched(p2::add_rc_sched(x, co.rc_full[P2_HALF_FULL_ROUNDS + k])));
-        if (co.active) put(12 * (P2_HALF_FULL_ROUNDS + 1) + P2_PARTIAL_ROUNDS + 12 * k + g, gl::canon(x));
-    }
-    return gl::canon(x);
-}
+__device__ __forceinline__ u64 nlq_coop_p2(const p2::Coop& co, u64 x, u32 g, Put&& put) { return p2::coop_flattened(co, x, g, put); }
 
 // grid (ceil(capacity / 4), n_ops, instances), 64 lanes: a ROW of 16 lanes owns one operation of one cycle, the four rows of a wave
 // four consecutive cycles of the same operation (uniform control flow; a store instruction writes 32-byte segments of <= 16 columns).

@@ -290,6 +290,33 @@ struct Coop {
     }
 };
 
+// One flattened Poseidon2 gate by the 16 lanes of a row (Coop, the form of the queue-chain kernels: lane g holds element g, the
+// linear layers cross lanes by DPP): every lane stores its element after each full round, lane 0 the S-box output of each partial
+// round — the 130 variables in the order of orc_poseidon2_flattened. x: this lane's input (0 in lanes 12..15); returns its output.
+template <class Put>
+__device__ __forceinline__ u64 coop_flattened(const Coop& co, u64 x, u32 g, Put&& put) {
+    if (co.active) put(g, gl::canon(x));
+    x = co.external(x);
+#pragma unroll
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
+        x = co.external(pow7_sched(add_rc_sched(x, co.rc_full[k])));
+        if (co.active) put(12 * (k + 1) + g, gl::canon(x));
+    }
+    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
+        const u64 rc = c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];
+        const u64 sx = pow7_sched(add_rc_sched(x, rc));
+        if (co.first) put(12 * (P2_HALF_FULL_ROUNDS + 1) + k, gl::canon(sx));
+        x = co.internal(co.first ? sx : x);
+    }
+#pragma unroll
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
+        x = co.external(pow7_sched(add_rc_sched(x, co.rc_full[P2_HALF_FULL_ROUNDS + k])));
+        if (co.active) put(12 * (P2_HALF_FULL_ROUNDS + 1) + P2_PARTIAL_ROUNDS + 12 * k + g, gl::canon(x));
+    }
+    return gl::canon(x);
+}
+
+
 // ---------------------------------------------------------------- one state per QUAD (4 lanes)
 // Lane j of the quad holds elements {j, 4+j, 8+j} (column j of the three 4-element blocks), 16 states per
 // wave. The 4x4 block products cross lanes with quad_perm DPP only; the sum over blocks and most of the

@@ -15,6 +15,8 @@
 #include "../../include/zkw_decommit_sorter_circuit_spec.h"
 #include "../../include/zkw_events_sorter_circuit_spec.h"
 #include "ram_kernels.cuh"
+#include "public_input_kernels.cuh"
+#include "closed_form_kernels.cuh"
 
 namespace zkw {
 
@@ -33,7 +35,9 @@ struct SynthJob {
     u64* trace;             // [RC_COLS][n_rows]
     u32* hist;              // [256] lookup-value histogram of this trace (zeroed before the fills)
     u32* nd_tiles;          // [ceil(capacity/256)] exclusive prefix of nondeterministic writes per 256-cycle tile
-    const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ram_commitments)
+    const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ram_commitments): not written into the trace (the
+                              // closed-form section derives the PI row), kept for callers that compare
+    const zkw_ram_instance* first_inst;  // the block's first instance (its observable input is every instance's: postprocessing/mod.rs:358-364)
 };
 
 constexpr int ROW_SLOTS[RC_NUM_ROW_TYPES] = RC_ROW_NUM_SLOTS_INIT;
@@ -507,10 +511,13 @@ static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __
     }
 }
 
-// runs after k_ram_fill_tail (same stream): the three boundary rows
-static __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const SynthJob job = jobs[blockIdx.x];
-    if (threadIdx.x != 0) return;
+static __constant__ rc_link c_links[RC_NUM_LINKS] = RC_LINKS_INIT;
+static __constant__ uint8_t c_is_poseidon[RC_NUM_ROW_TYPES] = RC_ROW_IS_POSEIDON_INIT;
+static __constant__ rc_cf_const c_cf_consts[RC_CF_NUM_CONSTS] = RC_CF_CONSTS_INIT;
+static __constant__ rc_cf_free c_cf_free[RC_CF_NUM_FREE] = RC_CF_FREE_INIT;
+
+// the register rows BND_IN / BND_OUT (one lane)
+__device__ __forceinline__ void ram_fill_register_rows(const SynthJob& job, u32 capacity, size_t n_rows) {
     const u64* lhs_z_all = job.lhs_z;
     const u64* rhs_z_all = job.rhs_z;
     const size_t n_total = job.n_block;
@@ -563,7 +570,53 @@ static __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob*
     TR(RC_BND_OUT_cnt, bout) = TR(RC_C_cnt, (size_t)RC_ROW_C * RC_REGION_STRIDE(capacity) + capacity - 1);
     TR(RC_BND_OUT_completion, bout) = in->completion_flag ? 1 : 0;
     TR(RC_BND_OUT_w_end, bout) = inv_or_zero(len_out); TR(RC_BND_OUT_z_end, bout) = len_out == 0;
-    for (int k = 0; k < 4; k++) TR(RC_PI_pi0 + k, bin - RC_ROWOFF_BND_IN + RC_ROWOFF_PI) = job.public_input[k];
+}
+
+// a value row of the closed-form section: the bytes of limbs 5..7 into the lookup cells (and the multiplicity column: +1 for the byte,
+// -1 for the zero the cell held); VIN also the encoding elements es3..es6 of the limbs (memory_query.rs:60-110)
+__device__ __forceinline__ void ram_value_row(u64* trace, size_t n_rows, size_t row, int v0, int b0, int e3) {
+    zkw_mem_query q;
+    memset(&q, 0, sizeof q);
+    for (int k = 0; k < 8; k++) q.value[k] = (u32)TR(v0 + k, row);
+    for (int l = 5; l < 8; l++)
+        for (int k = 0; k < 4; k++) {
+            const u64 b = (q.value[l] >> (8 * k)) & 0xFF;
+            TR(b0 + 4 * (l - 5) + k, row) = b;
+            TR(RC_MULT_COL, b) += 1;
+            TR(RC_MULT_COL, 0) -= 1;
+        }
+    if (e3 < 0) return;
+    u64 e[8];
+    encode_mem_query(q, e);
+    for (int k = 0; k < 4; k++) TR(e3 + k, row) = e[3 + k];
+}
+
+// runs after k_ram_fill_tail (same stream): the register rows, then the closed-form section (closed_form_kernels.cuh) down to the PI row
+static __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const SynthJob job = jobs[blockIdx.x];
+    __shared__ u64 sh_oi[RAM_INPUT_ENC_LEN], sh_fi[RAM_FSM_ENC_LEN], sh_fo[RAM_FSM_ENC_LEN], sh_flags[2];
+    if (threadIdx.x == 0) ram_fill_register_rows(job, capacity, n_rows);
+    if (threadIdx.x == 1) {
+        int m = put_queue12(job.first_inst->unsorted_queue_initial_state, sh_oi);
+        m += put_queue12(job.first_inst->sorted_queue_initial_state, sh_oi + m);
+        sh_oi[m] = job.first_inst->non_deterministic_bootloader_memory_snapshot_length;
+    }
+    if (threadIdx.x == 2) ram_encode_fsm(job.inst->hidden_fsm_input, sh_fi);
+    if (threadIdx.x == 3) {
+        ram_encode_fsm(job.inst->hidden_fsm_output, sh_fo);
+        sh_flags[0] = job.inst->start_flag ? 1 : 0;
+        sh_flags[1] = job.inst->completion_flag ? 1 : 0;
+    }
+    __syncthreads();
+    const CfSpec S = {RC_CF_FIRST_ROW_TYPE, RC_CF_NUM_ROWS, RC_NUM_LINKS, RC_CF_NUM_CONSTS, RC_CF_NUM_FREE, RC_ROWS_PER_CYCLE, RC_ROW_PI,
+                      c_links, c_is_poseidon, c_cf_consts, c_cf_free};
+    const CfSources src = {sh_oi, sh_fi, sh_fo, sh_flags, nullptr};
+    u64* trace = job.trace;
+    cf_fill_wave(S, trace, n_rows, (size_t)RC_BOUNDARY_ROW(capacity), src, [&](int rt, size_t row) {
+        if (threadIdx.x != 0) return;
+        if (rt == RC_ROW_VIN) ram_value_row(trace, n_rows, row, RC_VIN_VIN_v0, RC_VIN_VIN_v5_b0, RC_VIN_VIN_e3);
+        if (rt == RC_ROW_VOUT) ram_value_row(trace, n_rows, row, RC_VOUT_VOUT_v0, RC_VOUT_VOUT_v5_b0, -1);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -573,8 +626,6 @@ static __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob*
 static __constant__ rc_term c_terms[RC_NUM_TERMS] = RC_TERMS_INIT;
 static __constant__ rc_constraint c_cons[RC_NUM_CONSTRAINTS] = RC_CONSTRAINTS_INIT;
 static __constant__ uint16_t c_row_first[RC_NUM_ROW_TYPES + 1] = RC_ROW_FIRST_CONSTRAINT_INIT;
-static __constant__ uint8_t c_is_poseidon[RC_NUM_ROW_TYPES] = RC_ROW_IS_POSEIDON_INIT;
-static __constant__ rc_link c_links[RC_NUM_LINKS] = RC_LINKS_INIT;
 static __constant__ rc_term c_ds_terms[DS_NUM_TERMS] = DS_TERMS_INIT;
 static __constant__ rc_constraint c_ds_cons[DS_NUM_CONSTRAINTS] = DS_CONSTRAINTS_INIT;
 static __constant__ uint16_t c_ds_row_first[DS_NUM_ROW_TYPES + 1] = DS_ROW_FIRST_CONSTRAINT_INIT;

@@ -1370,6 +1370,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
         j.hist = d_hist + 256 * k;
         j.nd_tiles = d_nd + (size_t)n_tiles * k;
         j.public_input = w->public_inputs + 4 * idx;
+        j.first_inst = w->instances + w->inst_offsets[b];
     }
     SynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("synth_jobs", jobs, &d_jobs));

@@ -1,9 +1,22 @@
 """Host-side helpers for RAMPermutation synthesis (zkw trace v2, include/zkw_ram_circuit_spec.h)."""
 import numpy as np
 
+import os
+import re
+
 ROWS_PER_CYCLE = 6
 N_COLS = 149
-N_BOUNDARY_ROWS = 3
+N_BOUNDARY_ROWS = 40  # BND_IN, BND_OUT, PI + the closed-form section (sponges of the closed-form input, selections, challenges)
+
+
+def spec_macros(header="zkw_ram_circuit_spec.h", prefix="RC"):
+    """the integer macros of a generated spec header ({name without prefix: value}): row offsets (ROWOFF_*), cells (<ROW>_<var>) ..."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", header)
+    out = {}
+    with open(path) as f:
+        for m in re.finditer(rf"^#define {prefix}_(\w+) (\d+)\b", f.read(), re.M):
+            out[m.group(1)] = int(m.group(2))
+    return out
 
 
 REGION_ALIGN = 64
@@ -15,7 +28,7 @@ def region_stride(capacity: int) -> int:
 
 
 def boundary_row(capacity: int) -> int:
-    """RC_BOUNDARY_ROW: first of the three boundary rows (BND_IN, BND_OUT, PI)."""
+    """RC_BOUNDARY_ROW: first of the boundary rows (BND_IN, BND_OUT, PI, then the closed-form section)."""
     return ROWS_PER_CYCLE * region_stride(capacity)
 
 

@@ -1,0 +1,91 @@
+/* TEST INFRASTRUCTURE — CPU restatement, never linked into the product (see oracle.h).
+ *
+ * The CLOSED-FORM SECTION of a queue circuit's trace (tools/gen_ram_circuit.py, class ClosedForm): what the reference's circuits derive
+ * inside the trace — the Fiat-Shamir challenges (produce_fs_challenges, src/witness/utils.rs:498-550), the commitments of the closed-form
+ * input and the public input (commit_variable_length_encodable_item / ClosedFormInputCompactForm::from_full_form, utils.rs:269-306), the
+ * start-flag selection of the initial state (W/ram_permutation.rs:355-384) — as boundary rows: flattened Poseidon2 rows chained into
+ * overwrite-mode sponges, selection rows, copies. One generic walk over the generated tables (links of kind 5, constant cells, FREE
+ * cells), sequential and obvious; shares no code with the checker (circuit_check.c). */
+#include <string.h>
+#include "oracle.h"
+#include "../include/zkw_ram_circuit_spec.h"
+
+#define CELL(col, row) trace[(size_t)(col) * n_rows + (row)]
+
+typedef struct {
+    int first, n, n_links, n_consts, n_free, rows_per_cycle, pi_row_type;
+    const rc_link *links;
+    const uint8_t *is_poseidon;
+    const rc_cf_const *consts;
+    const rc_cf_free *frees;
+} orc_cf_spec;
+typedef void (*orc_cf_hook)(void *user, int row_type, uint64_t *trace, size_t n_rows, size_t row);
+
+/* src[k]: the encoding FREE cells of source k are taken from (0 observable input, 1 hidden FSM input, 2 hidden FSM output, 3 flags,
+   4 observable output); bnd = first boundary row of the trace */
+static void cf_fill(const orc_cf_spec *S, uint64_t *trace, size_t n_rows, size_t bnd, const uint64_t *const src[5], orc_cf_hook hook, void *user) {
+#define ROW_OF(rt) (bnd + (size_t)((rt) - S->rows_per_cycle))
+    for (int r = S->first; r <= S->first + S->n; r++) {
+        const int rt = r < S->first + S->n ? r : S->pi_row_type; /* last: the public-input row takes its copies */
+        const size_t row = ROW_OF(rt);
+        for (int l = 0; l < S->n_links; l++)
+            if (S->links[l].kind == 5 && S->links[l].row_a == rt) CELL(S->links[l].col_a, row) = CELL(S->links[l].col_b, ROW_OF(S->links[l].row_b));
+        if (rt == S->pi_row_type) break;
+        for (int k = 0; k < S->n_consts; k++)
+            if (S->consts[k].row == rt) CELL(S->consts[k].col, row) = S->consts[k].value;
+        for (int k = 0; k < S->n_free; k++)
+            if (S->frees[k].row == rt) CELL(S->frees[k].col, row) = src[S->frees[k].src][S->frees[k].idx];
+        if (hook) hook(user, rt, trace, n_rows, row);
+        if (S->is_poseidon[rt]) {
+            uint64_t in[12], slots[130];
+            for (int k = 0; k < 12; k++) in[k] = CELL(k, row);
+            orc_poseidon2_flattened(in, slots);
+            for (int k = 0; k < 130; k++) CELL(k, row) = slots[k];
+        }
+    }
+#undef ROW_OF
+}
+
+/* ---- RAMPermutation (type 8) ---- */
+static const rc_link RC_LINKS[] = RC_LINKS_INIT;
+static const uint8_t RC_IS_POSEIDON[] = RC_ROW_IS_POSEIDON_INIT;
+static const rc_cf_const RC_CONSTS[] = RC_CF_CONSTS_INIT;
+static const rc_cf_free RC_FREES[] = RC_CF_FREE_INIT;
+static const orc_cf_spec CF_RC = {RC_CF_FIRST_ROW_TYPE, RC_CF_NUM_ROWS, RC_NUM_LINKS, RC_CF_NUM_CONSTS, RC_CF_NUM_FREE, RC_ROWS_PER_CYCLE, RC_ROW_PI,
+                                  RC_LINKS, RC_IS_POSEIDON, RC_CONSTS, RC_FREES};
+
+/* the value rows: bytes of limbs 5..7 into the lookup cells (and the multiplicity column: +1 for the byte, -1 for the zero the cell held);
+   VIN also the encoding elements es3..es6 of the limbs (memory_query.rs:60-110) */
+static void ram_value_row(uint64_t *trace, size_t n_rows, size_t row, int v0, int b0, int e3) {
+    uint64_t v[8];
+    for (int k = 0; k < 8; k++) v[k] = CELL(v0 + k, row);
+    for (int l = 5; l < 8; l++)
+        for (int k = 0; k < 4; k++) {
+            const uint64_t b = (v[l] >> (8 * k)) & 0xFF;
+            CELL(b0 + 4 * (l - 5) + k, row) = b;
+            CELL(RC_MULT_COL, b) += 1;
+            CELL(RC_MULT_COL, 0) -= 1;
+        }
+    if (e3 < 0) return;
+    zkw_mem_query q;
+    memset(&q, 0, sizeof q);
+    for (int k = 0; k < 8; k++) q.value[k] = (uint32_t)v[k];
+    uint64_t e[8];
+    orc_encode_memory_query(&q, e);
+    for (int k = 0; k < 4; k++) CELL(e3 + k, row) = e[3 + k];
+}
+static void ram_hook(void *user, int rt, uint64_t *trace, size_t n_rows, size_t row) {
+    (void)user;
+    if (rt == RC_ROW_VIN) ram_value_row(trace, n_rows, row, RC_VIN_VIN_v0, RC_VIN_VIN_v5_b0, RC_VIN_VIN_e3);
+    if (rt == RC_ROW_VOUT) ram_value_row(trace, n_rows, row, RC_VOUT_VOUT_v0, RC_VOUT_VOUT_v5_b0, -1);
+}
+
+/* the closed-form section and the PI row of a synthesized RAM trace (after orc_ram_synthesize). `first` = the block's first instance */
+void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_instance *in, uint32_t capacity, size_t n_rows, uint64_t *trace) {
+    uint64_t oi[ORC_RAM_INPUT_ENC_LEN], fi[ORC_RAM_FSM_ENC_LEN], fo[ORC_RAM_FSM_ENC_LEN], flags[2] = {in->start_flag ? 1u : 0u, in->completion_flag ? 1u : 0u};
+    orc_ram_encode_observable_input(first, oi);
+    orc_ram_encode_fsm(&in->hidden_fsm_input, fi);
+    orc_ram_encode_fsm(&in->hidden_fsm_output, fo);
+    const uint64_t *src[5] = {oi, fi, fo, flags, NULL};
+    cf_fill(&CF_RC, trace, n_rows, (size_t)RC_BOUNDARY_ROW(capacity), src, ram_hook, NULL);
+}

@@ -100,15 +100,6 @@ void orc_recursion_queue(uint64_t circuit_type, const uint64_t *pi, size_t n, co
     orc_queue_push_chain_full(enc, n, tail_in, tails);
 }
 
-/* the PI row of a synthesized RAM trace ("zkw trace v1", include/zkw_ram_circuit_spec.h) */
-void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_instance *in, uint32_t capacity,
-                               size_t n_rows, uint64_t *trace) {
-    uint64_t compact[18], pi[4];
-    orc_ram_public_input(first, in, compact, pi);
-    const size_t row = (size_t)RC_BOUNDARY_ROW(capacity) + RC_ROWOFF_PI;
-    for (int k = 0; k < 4; k++) trace[(size_t)(RC_PI_pi0 + k) * n_rows + row] = pi[k];
-}
-
 /* ---- CodeDecommittmentsSorter (type 2): encodings in the order of the reference's struct literals
    (sort_decommit_requests.rs:402-414; DecommitQuery = {code_hash, page, is_first, timestamp}) */
 size_t orc_ds_encode_fsm(const zkw_decommit_sorter_fsm *f, uint64_t out[ORC_DS_FSM_ENC_LEN]) {

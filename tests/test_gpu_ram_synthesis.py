@@ -81,7 +81,7 @@ def test_gpu_checker_rejects_tampering(ctx, oracle):
     assert ctx.check_if_satisfied_ram(t, 0, capacity)[0] == 0
     host = t.get(0)
     rng = np.random.default_rng(2)
-    used = np.argwhere(host[:148, :boundary_row(capacity) + 2] != 0)
+    used = np.argwhere(host[:148, :boundary_row(capacity) + 40] != 0)
     kinds = set()
     base = native.load().zkw_trace_device_ptr(t.handle, 0)
     for _ in range(25):
@@ -99,6 +99,17 @@ def test_gpu_checker_rejects_tampering(ctx, oracle):
         _hip_copy(addr, old)
     assert ctx.check_if_satisfied_ram(t, 0, capacity)[0] == 0
     assert len(kinds) >= 2
+    # the closed-form section: challenges, start-flag selection, commitments, public input (what the reference derives in-circuit)
+    from closed_form_case import ram_closed_form_tampers
+    for name, c, r in ram_closed_form_tampers(capacity):
+        addr = base + (int(c) * n_rows + int(r)) * 8
+        new = np.array([(int(host[c, r]) + 1) % P], np.uint64)
+        _hip_copy(addr, new)
+        bad, first = ctx.check_if_satisfied_ram(t, 0, capacity)
+        obad, ofirst = oracle.ram_check(_with(host, c, r, new[0]), capacity)
+        assert bad > 0 and bad == obad and first[0] == ofirst[0], (name, bad, first, obad, ofirst)
+        _hip_copy(addr, np.array([host[c, r]], np.uint64))
+    assert ctx.check_if_satisfied_ram(t, 0, capacity)[0] == 0
     # multiplicity and padding
     for (c, r) in ((148, 3), (7, n_rows - 1)):
         addr = base + (c * n_rows + r) * 8

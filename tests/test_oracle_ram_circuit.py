@@ -3,10 +3,11 @@ constraint / copy link / lookup of the spec, and tampering is detected (the refe
 `check_if_satisfied` on every emitted circuit, src/tests/mod.rs:130-259)."""
 import numpy as np
 
-from era_zkevm_test_harness_amd.ram_circuit import boundary_row
+from era_zkevm_test_harness_amd.ram_circuit import boundary_row, spec_macros
 import pytest
 
 from era_zkevm_test_harness_amd import synthetic
+from closed_form_case import ram_closed_form_tampers
 
 P = 0xFFFFFFFF00000001
 
@@ -68,7 +69,7 @@ def test_tampering_is_detected(oracle):
     assert oracle.ram_check(t, capacity)[0] == 0
     rng = np.random.default_rng(1)
     kinds = set()
-    used = [(c, r) for c in range(148) for r in range(boundary_row(capacity) + 2) if t[c, r] != 0]
+    used = [(c, r) for c in range(148) for r in range(boundary_row(capacity) + 40) if t[c, r] != 0]
     for _ in range(60):
         c, r = used[rng.integers(len(used))]
         t2 = t.copy()
@@ -84,6 +85,29 @@ def test_tampering_is_detected(oracle):
     assert oracle.ram_check(t2, capacity)[0] > 0
     t2 = t.copy(); t2[5, n_rows - 1] = 7
     assert oracle.ram_check(t2, capacity)[0] > 0
+
+
+def test_closed_form_section(oracle):
+    """What the reference's circuit computes in-trace, this trace states: the PI row is the commitment of the compact form of the
+    closed-form input (utils.rs:269-306), the challenges of BND_IN come out of the sponge over the observable input's tails and lengths
+    (utils.rs:498-550), BND_IN is start ? observable input : hidden FSM input. Instance 0 starts the block, instance 1 continues it."""
+    capacity, n_rows = 64, 1024
+    o = _build(oracle, 150, capacity)
+    M = spec_macros()
+    _, pis = oracle.ram_public_inputs(o["instances"])
+    for idx in (0, 1, 2):
+        t = oracle.ram_synthesize(o, idx, capacity, n_rows)
+        assert oracle.ram_check(t, capacity)[0] == 0
+        b = boundary_row(capacity)
+        assert np.array_equal(t[M["PI_pi0"]:M["PI_pi0"] + 4, b + M["ROWOFF_PI"]], pis[idx])
+        assert int(t[M["SEL0_start"], b + M["ROWOFF_SEL0"]]) == (1 if idx == 0 else 0)
+        ch = o["challenges"].reshape(2, 9)
+        for rep in range(2):
+            assert np.array_equal(t[M["CH3_CH3_o0"]:M["CH3_CH3_o0"] + 8, b + M[f"ROWOFF_CH{3 + rep}"]], ch[rep, 1:])
+        for name, c, r in ram_closed_form_tampers(capacity):
+            t2 = t.copy()
+            t2[c, r] = (int(t2[c, r]) + 1) % P
+            assert oracle.ram_check(t2, capacity)[0] > 0, (idx, name)
 
 
 def test_invalid_memory_is_rejected(oracle):

@@ -73,10 +73,11 @@ def test_queue_circuit_selectors(oracle):
     sel = nv.setup_row_selectors(8, cap, 1 << 15)
     lay = nv.circuit_layout(8, cap)
     stride = int(lay["region_stride"])
-    assert stride == 1024 and int((sel != nv.ROW_PADDING).sum()) == 6 * cap + 3
+    n_bnd = int(lay["rows_used"]) - 6 * stride  # BND_IN, BND_OUT, PI and the closed-form section (sponges, selections)
+    assert stride == 1024 and n_bnd == 40 and int((sel != nv.ROW_PADDING).sum()) == 6 * cap + n_bnd
     for r in range(6):
         assert (sel[r * stride:r * stride + cap] == r).all() and (sel[r * stride + cap:(r + 1) * stride] == nv.ROW_PADDING).all()
-    assert sel[6 * stride:6 * stride + 3].tolist() == [6, 7, 8]
+    assert sel[6 * stride:6 * stride + n_bnd].tolist() == list(range(6, 6 + n_bnd))
     w = oracle.ram_build_instances(synthetic.ram_trace(3 * cap - 17, seed=5), cap, 0)
     for i in (0, 2):  # a full instance and the ragged last one
         t = oracle.ram_synthesize(w, i, cap, 1 << 15)

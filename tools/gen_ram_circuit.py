@@ -71,6 +71,96 @@ class Row:
         self.c([(1, [flag, a]), (-1, [flag, b]), (1, [b]), (-1, [out])], f"{out} = {flag} ? {a} : {b}")
 
 
+# ---------------- the closed-form section: what the reference's circuits derive INSIDE the trace and this layout used to place -------
+# (round 4). Boundary rows, shared by the queue-circuit generators:
+#   * SPONGE rows: one flattened Poseidon2 gate per permutation of an overwrite-mode sponge from the zero state with the length in the
+#     last capacity word (commit_variable_length_encodable_item / produce_fs_challenges, src/witness/utils.rs:498-550, 269-306): row j
+#     absorbs words 8j .. 8j+7 (zero padded) over the capacity the row before left; the first four outputs of the last row are the
+#     commitment. A word is a copy of a boundary cell, or FREE (the row's own cell is its home: a struct the trace has no registers for).
+#   * links between boundary rows are emitted as kind 5 (cell == cell of another boundary row).
+P2_OUT0 = 118  # slots of a flattened Poseidon2 row: 12 inputs, 4 x 12 full-round states, 22 partial S-box outputs, 3 x 12, 12 outputs
+
+
+def p2_boundary_row(name):
+    r = Row(name, False)
+    for k in range(12):
+        r.slot(f"{name}_i{k}")
+    for rr in range(4):
+        for k in range(12):
+            r.slot(f"{name}_f{rr}_{k}")
+    for rr in range(22):
+        r.slot(f"{name}_p{rr}")
+    for rr in range(3):
+        for k in range(12):
+            r.slot(f"{name}_f{4 + rr}_{k}")
+    for k in range(12):
+        r.slot(f"{name}_o{k}")
+    assert len(r.slots) == 130 and r.slot(f"{name}_o0") == P2_OUT0
+    return r
+
+
+class ClosedForm:
+    """collects the section's rows and its (row, var) == (row, var) copy constraints; resolve() turns them into kind-5 links"""
+
+    SRC_OBS_IN, SRC_FSM_IN, SRC_FSM_OUT, SRC_FLAG, SRC_OBS_OUT = 0, 1, 2, 3, 4  # where a fill takes a FREE cell from: word idx of that encoding
+
+    def __init__(self):
+        self.rows, self.copies, self.p2_names, self.free, self.consts = [], [], [], [], []
+
+    def free_cell(self, row, var, src, idx):
+        self.free.append((row, var, src, idx))
+
+    def copy(self, row_a, var_a, row_b, var_b):
+        self.copies.append((row_a, var_a, row_b, var_b))
+
+    def sponge(self, prefix, words, squeeze=0, free_src=None):
+        """words: list of None (FREE) | (row, var) (copy) | ("const", v). Returns the rows; word w lives at (rows[w // 8], f"{name}_i{w % 8}").
+        squeeze: extra permutations after the absorption (each takes the whole state of the row before)."""
+        n = len(words)
+        rows = []
+        for j in range((n + 7) // 8 + squeeze):
+            name = f"{prefix}{j}"
+            r = p2_boundary_row(name)
+            self.p2_names.append(name)
+            absorbing = j < (n + 7) // 8
+            for k in range(12):
+                cell = f"{name}_i{k}"
+                if absorbing and k < 8:
+                    w = words[8 * j + k] if 8 * j + k < n else ("const", 0)
+                    if w is None:
+                        self.free_cell(r, cell, free_src, 8 * j + k)
+                        continue
+                    if w[0] == "const":
+                        r.c([(1, [cell]), (-w[1], [])], f"{cell} = {w[1]}")
+                        self.consts.append((r, cell, w[1]))
+                    else:
+                        self.copy(r, cell, w[0], w[1])
+                elif j == 0:
+                    v = n if k == 11 else 0  # the zero state with the length in the last element (specialize_for_len)
+                    r.c([(1, [cell]), (-v, [])], f"{cell} = {v}")
+                    self.consts.append((r, cell, v))
+                else:
+                    self.copy(r, cell, rows[-1], f"{rows[-1].name}_o{k}")
+            rows.append(r)
+        self.rows += rows
+        return rows
+
+    def word_cell(self, rows, w):
+        return rows[w // 8], f"{rows[w // 8].name}_i{w % 8}"
+
+    def resolve(self, all_rows):
+        out = []
+        for ra, va, rb, vb in self.copies:
+            out.append((5, all_rows.index(ra), ra.slot(va), all_rows.index(rb), rb.slot(vb), 0))
+        return out
+
+    def tables(self, all_rows, section_rows):
+        """what a fill needs next to the links: the section's row types in order, the cells that are constants, the FREE cells"""
+        return {"first": all_rows.index(section_rows[0]), "n": len(section_rows),
+                "consts": [(all_rows.index(r), r.slot(v), val) for r, v, val in self.consts],
+                "free": [(all_rows.index(r), r.slot(v), src, idx) for r, v, src, idx in self.free]}
+
+
 def build():
     PU, PS = Row("PU"), Row("PS")
     A, B, Cc, D = Row("A"), Row("B"), Row("C"), Row("D")
@@ -217,7 +307,102 @@ def build():
     for k in range(4):
         PI.slot(f"pi{k}")
 
-    rows = [PU, PS, A, B, Cc, D, BIN, BOUT, PI]
+    # ---------------- closed-form section (see ClosedForm): challenges, input / output commitments, start-flag selection
+    cf = ClosedForm()
+    q25 = lambda q: [f"{q}h{k}" for k in range(12)] + [f"tail_{q[0]}{k}" for k in range(12)] + [f"len_{q[0]}"]  # noqa: E731  head, tail, length
+    # observable input (RamPermutationInputData, the block's FIRST instance's: postprocessing/mod.rs:358-364): FREE words
+    OI = cf.sponge("OI", [None] * 51, free_src=ClosedForm.SRC_OBS_IN)
+    oi = lambda w: cf.word_cell(OI, w)  # noqa: E731
+    # hidden FSM input (RamPermutationFSMInputOutput, W/ram_permutation.rs:385-406): FREE words, tied to the registers by the selection rows
+    FI = cf.sponge("FI", [None] * 69, free_src=ClosedForm.SRC_FSM_IN)
+    fi = lambda w: cf.word_cell(FI, w)  # noqa: E731
+    # value limbs of the previous value: the registers hold its ENCODING elements (memory_query.rs:60-110), the closed form its eight limbs
+    def value_row(name):
+        r = Row(name, False)
+        for k in range(8):
+            r.slot(f"{name}_v{k}")
+        b = {l: [f"{name}_v{l}_b{k}" for k in range(4)] for l in (5, 6, 7)}
+        for l in (5, 6, 7):
+            for x in b[l]:
+                r.lookup(x)
+            r.c([(1, [f"{name}_v{l}"])] + [(-(1 << (8 * k)), [b[l][k]]) for k in range(4)], f"v{l} = sum bytes")
+        pk = ((3, 0, b[5][0], b[5][1], b[5][2]), (4, 1, b[5][3], b[6][0], b[6][1]), (5, 2, b[6][2], b[6][3], b[7][0]), (6, 3, b[7][1], b[7][2], b[7][3]))
+        for e, l, x0, x1, x2 in pk:
+            r.c([(1, [f"{name}_e{e}"]), (-1, [f"{name}_v{l}"]), (-(1 << 32), [x0]), (-(1 << 40), [x1]), (-(1 << 48), [x2])], f"es{e} of the limbs")
+        return r
+    VIN, VOUT = value_row("VIN"), value_row("VOUT")
+    for k in range(8):
+        cf.copy(VIN, f"VIN_v{k}", *fi(4 + 25 + 25 + 3 + 2 + k))
+    for e in (3, 4, 5, 6):
+        cf.copy(VOUT, f"VOUT_e{e}", BOUT, f"es{e}")
+    for k in range(8):
+        if k != 4:
+            cf.free_cell(VOUT, f"VOUT_v{k}", ClosedForm.SRC_FSM_OUT, 59 + k)
+    # hidden FSM output: the registers after the last cycle
+    fo_words = ([(BOUT, f"lhs{r}") for r in range(2)] + [(BOUT, f"rhs{r}") for r in range(2)] + [(BOUT, v) for v in q25("u")] + [(BOUT, v) for v in q25("s")] +
+                [(BOUT, "ts"), (BOUT, "idx"), (BOUT, "page"), (BOUT, "idx"), (BOUT, "page")] +
+                [(VOUT, f"VOUT_v{k}") if k != 4 else (BOUT, "v4") for k in range(8)] + [(BOUT, "ptr"), (BOUT, "cnt")])
+    assert len(fo_words) == 69
+    FO = cf.sponge("FO", fo_words)
+    cf.copy(VOUT, "VOUT_v4", BOUT, "v4")
+    # start-flag selection (utils.rs:269-306 `start_flag`-conditional state; W/ram_permutation.rs:355-365): register at cycle -1 =
+    # start ? the observable input's queue state (accumulators ONE, previous key / value / counter ZERO) : the hidden FSM input
+    S0, S1 = Row("SEL0", False), Row("SEL1", False)
+    S0.boolean("start")
+    cf.free_cell(S0, "start", ClosedForm.SRC_FLAG, 0)
+    S1.slot("start1")
+    cf.copy(S1, "start1", S0, "start")
+    n_sel = [0]
+
+    def select3(obs_cell, fi_cell, target):
+        row, st = (S0, "start") if len(S0.slots) + 3 <= G else (S1, "start1")
+        a, b, t = (f"s{n_sel[0]}_{x}" for x in "abt")
+        n_sel[0] += 1
+        row.c([(1, [t]), (-1, [st, a]), (-1, [b]), (1, [st, b])], f"{target[1]} = start ? observable input : hidden FSM input")
+        cf.copy(row, a, *obs_cell)
+        cf.copy(row, b, *fi_cell)
+        cf.copy(row, t, *target)
+
+    def select2(init, fi_cell, target):
+        b, t = (f"s{n_sel[0]}_{x}" for x in "bt")
+        n_sel[0] += 1
+        S1.c([(1, [t]), (-init, ["start1"]), (-1, [b]), (1, ["start1", b])], f"{target[1]} = start ? {init} : hidden FSM input")
+        cf.copy(S1, b, *fi_cell)
+        cf.copy(S1, t, *target)
+
+    for qi, q in enumerate(("u", "s")):
+        regs_q = [(BIN, f"{q}h{k}") for k in range(12)] + [(BOUT, f"tail_{q}{k}") for k in range(12)] + [(BIN, f"len_{q}")]
+        for k in range(25):
+            select3(oi(25 * qi + k), fi(4 + 25 * qi + k), regs_q[k])
+    for r in range(2):
+        select2(1, fi(r), (BIN, f"lhs{r}"))
+        select2(1, fi(2 + r), (BIN, f"rhs{r}"))
+    for k, v in enumerate(("ts", "idx", "page")):
+        select2(0, fi(54 + k), (BIN, v))
+    for k, v in enumerate(("idx", "page")):  # previous_full_key repeats (index, page)
+        select2(0, fi(57 + k), (BIN, v))
+    for e in (3, 4, 5, 6):
+        select2(0, (VIN, f"VIN_e{e}"), (BIN, f"es{e}"))
+    select2(0, fi(59 + 4), (BIN, "v4"))
+    select2(0, fi(67), (BIN, "ptr"))
+    select2(0, fi(68), (BIN, "cnt"))
+    # Fiat-Shamir challenges of the permutation argument (produce_fs_challenges, utils.rs:498-550, called with the observable input's
+    # queue tails and lengths, W/ram_permutation.rs:80-90): 26 words -> 4 absorbing permutations, 8 challenges, one more permutation, 8 more
+    fs_words = [oi(12 + k) for k in range(12)] + [oi(24)] + [oi(25 + 12 + k) for k in range(12)] + [oi(49)]
+    CH = cf.sponge("CH", fs_words, squeeze=1)
+    for r in range(2):
+        for k in range(1, 9):
+            cf.copy(BIN, f"g.c{r}_{k}", CH[3 + r], f"{CH[3 + r].name}_o{k - 1}")
+    # compact form and the public input (ClosedFormInputCompactForm::from_full_form + commit: utils.rs:294-303)
+    last = lambda rows_: rows_[-1]  # noqa: E731
+    cp_words = ([(S0, "start"), (BOUT, "completion")] + [(last(OI), f"{last(OI).name}_o{k}") for k in range(4)] + [("const", 0)] * 4 +
+                [(last(FI), f"{last(FI).name}_o{k}") for k in range(4)] + [(last(FO), f"{last(FO).name}_o{k}") for k in range(4)])
+    CP = cf.sponge("CP", cp_words)
+    for k in range(4):
+        cf.copy(PI, f"pi{k}", last(CP), f"{last(CP).name}_o{k}")
+    cf_rows = OI + FI + [VIN, VOUT] + FO + [S0, S1] + CH + CP
+
+    rows = [PU, PS, A, B, Cc, D, BIN, BOUT, PI] + cf_rows
 
     # ---------------- copy links
     # every occurrence of a variable is linked to its "home": the first row (in `rows` order) that holds
@@ -247,13 +432,16 @@ def build():
                     links.append((0, ri, col, home[v][0], home[v][1], 0))
             elif r is BOUT and v in regs:
                 links.append((3, ri, col, home[v][0], home[v][1], 0))
+    links += cf.resolve(rows)
+    build.poseidon_rows = ("PU", "PS") + tuple(cf.p2_names)
+    build.cf_tables = cf.tables(rows, cf_rows)
     return rows, links, regs
 
 
 def emit(rows, links, path, prefix="RC", guard="ZKW_RAM_CIRCUIT_SPEC_H",
          title=("/* GENERATED by tools/gen_ram_circuit.py — do not edit. Layout contract of the RAMPermutation trace",
                 " * emitted by zkw_ram_synthesize (\"zkw trace v2\"). See the generator's docstring and DESIGN.md. */"),
-         poseidon_rows=("PU", "PS"), shared_types=False):
+         poseidon_rows=("PU", "PS"), shared_types=False, cf_tables=None):
     """Writes the spec header. `prefix` replaces RC in every macro so that several circuits can coexist; the
     rc_term / rc_constraint / rc_link types are declared by the RAM header only (shared_types=True skips them)."""
     out = []
@@ -322,6 +510,17 @@ def emit(rows, links, path, prefix="RC", guard="ZKW_RAM_CIRCUIT_SPEC_H",
     w("   kind 2: b = BND_IN (one row per instance); kind 3: a = BND_OUT, b at the LAST cycle */")
     if not shared_types:
         out.append("typedef struct { uint8_t kind, row_a, col_a, row_b, col_b, bin_col; } rc_link;")
+    if cf_tables is not None:
+        w("/* the closed-form section (boundary rows below PI; tools/gen_ram_circuit.py ClosedForm): row types [first, first + n) in fill order;")
+        w("   a fill walks them: copies by the kind-5 links whose row_a is the row, the constant cells, the FREE cells (src 0 observable input /")
+        w("   1 hidden FSM input / 2 hidden FSM output / 3 flag / 4 observable output, word idx), then the permutation of a Poseidon2 row */")
+        w(f"#define RC_CF_FIRST_ROW_TYPE {cf_tables['first']}\n#define RC_CF_NUM_ROWS {cf_tables['n']}")
+        if not shared_types:
+            out.append("typedef struct { uint8_t row, col; uint64_t value; } rc_cf_const;")
+            out.append("typedef struct { uint8_t row, col, src; uint16_t idx; } rc_cf_free;")
+        w(f"#define RC_CF_NUM_CONSTS {len(cf_tables['consts'])}\n#define RC_CF_NUM_FREE {len(cf_tables['free'])}")
+        w("#define RC_CF_CONSTS_INIT {" + ", ".join(f"{{{a}, {b}, {c}ULL}}" for a, b, c in cf_tables["consts"]) + "}")
+        w("#define RC_CF_FREE_INIT {" + ", ".join(f"{{{a}, {b}, {c}, {d}}}" for a, b, c, d in cf_tables["free"]) + "}")
     w(f"#define RC_NUM_LINKS {len(links)}")
     w("#define RC_LINKS_INIT { \\")
     for k in links:
@@ -337,7 +536,7 @@ if __name__ == "__main__":
     rows, links, regs = build()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "include", "zkw_ram_circuit_spec.h")
-    nt, nc = emit(rows, links, path)
+    nt, nc = emit(rows, links, path, poseidon_rows=build.poseidon_rows, cf_tables=build.cf_tables)
     for r in rows:
         print(f"{r.name:8s} slots {len(r.slots):3d} lookups {len(r.lookups):2d} constraints {len(r.constraints)}")
     print(f"{nt} terms, {nc} constraints, {len(links)} links -> {path}")
