@@ -14,12 +14,24 @@
 namespace zkw {
 
 struct CfSpec {
-    int first, n, n_links, n_consts, n_free, rows_per_cycle, pi_row;
+    int first, n, n_links, n_consts, n_free, n_products, rows_per_cycle, pi_row;
     const rc_link* links;
     const uint8_t* is_poseidon;
     const rc_cf_const* consts;
     const rc_cf_free* frees;
+    const rc_cf_product* products;
 };
+
+// the section's tables of a spec header in constant memory, and the members a checker spec struct (SpecRam ...) exposes them through
+#define ZKW_CF_TABLES(PFX, pfx)                                                                                          \
+    static __constant__ rc_cf_const c_##pfx##_cf_consts[PFX##_CF_NUM_CONSTS] = PFX##_CF_CONSTS_INIT;                     \
+    static __constant__ rc_cf_free c_##pfx##_cf_free[PFX##_CF_NUM_FREE] = PFX##_CF_FREE_INIT;                            \
+    static __constant__ rc_cf_product c_##pfx##_cf_products[PFX##_CF_NUM_PRODUCTS ? PFX##_CF_NUM_PRODUCTS : 1] = PFX##_CF_PRODUCTS_INIT;
+#define ZKW_CF_SPEC_MEMBERS(PFX, pfx)                                                                                    \
+    __device__ static CfSpec cf_spec() {                                                                                 \
+        return CfSpec{PFX##_CF_FIRST_ROW_TYPE, PFX##_CF_NUM_ROWS, PFX##_NUM_LINKS, PFX##_CF_NUM_CONSTS, PFX##_CF_NUM_FREE, PFX##_CF_NUM_PRODUCTS, \
+                      PFX##_ROWS_PER_CYCLE, PFX##_ROW_PI, links(), is_poseidon(), c_##pfx##_cf_consts, c_##pfx##_cf_free, c_##pfx##_cf_products}; \
+    }
 
 struct CfSources {  // LDS pointers; picked by a select chain (an array indexed at run time would live in scratch memory)
     const u64 *obs_in, *fsm_in, *fsm_out, *flags, *obs_out;
@@ -48,6 +60,8 @@ __device__ __forceinline__ void cf_fill_wave(const CfSpec& S, u64* __restrict__ 
         for (int k = (int)lane; k < S.n_free; k += 64)
             if (S.frees[k].row == rt) CF_CELL(S.frees[k].col, row) = src.pick(S.frees[k].src)[S.frees[k].idx];
         __syncthreads();
+        for (int k = (int)lane; k < S.n_products; k += 64)  // a product's factors are cells the row copied
+            if (S.products[k].row == rt) CF_CELL(S.products[k].col, row) = gl::canon(gl::mul(CF_CELL(S.products[k].col_a, row), CF_CELL(S.products[k].col_b, row)));
         hook(rt, row);
         __syncthreads();
         if (S.is_poseidon[rt]) {  // uniform
@@ -58,6 +72,14 @@ __device__ __forceinline__ void cf_fill_wave(const CfSpec& S, u64* __restrict__ 
         __syncthreads();
     }
 #undef CF_CELL
+}
+
+// a lookup cell of a section row takes a byte: the multiplicity column counted a zero there (the tail kernels count every lookup cell below
+// the cycles as zero). One lane.
+__device__ __forceinline__ void cf_put_byte(u64* trace, size_t n_rows, int mult_col, int col, size_t row, u64 b) {
+    trace[(size_t)col * n_rows + row] = b;
+    trace[(size_t)mult_col * n_rows + b] += 1;
+    trace[(size_t)mult_col * n_rows] -= 1;
 }
 
 }  // namespace zkw

@@ -32,7 +32,8 @@ struct DsSynthJob {
     u32 rq_len_in;
     u64* trace;
     u32* hist;  // [256]
-    const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ds_commitments)
+    const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ds_commitments): not written, the closed-form section derives it
+    const zkw_decommit_sorter_instance* first_inst;  // the block's first instance (the shared observable input)
 };
 
 struct DsVars {
@@ -379,9 +380,7 @@ static __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* _
 }
 
 // runs after everything else (same stream): BND_IN, BND_OUT, the flush permutation PF, PI
-static __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const DsSynthJob& job = jobs[blockIdx.x];
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void ds_fill_register_rows(const DsSynthJob& job, u32 capacity, size_t n_rows) {
     u64* trace = job.trace;
     const zkw_decommit_sorter_instance* in = job.inst;
     const size_t rs = DS_REGION_STRIDE(capacity), bnd = (size_t)DS_BOUNDARY_ROW(capacity);
@@ -450,8 +449,45 @@ static __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob
         DS_FILL_BND_OUT(DS_XC, DS_XP, DS_XG, DS_XC)
         for (int col = DS_NSLOTS_BND_OUT; col < DS_G + DS_L; col++) TR(col, row) = 0;
     }
-    const size_t rPI = bnd + DS_ROWOFF_PI;
-    for (int col = 0; col < DS_G + DS_L; col++) TR(col, rPI) = col < 4 ? job.public_input[col] : 0;
+}
+
+// runs after everything else (same stream): BND_IN, BND_OUT, the flush permutation PF (one lane), then the closed-form section
+// (closed_form_kernels.cuh) down to the PI row
+static __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const DsSynthJob& job = jobs[blockIdx.x];
+    __shared__ u64 sh_oi[50], sh_oo[25], sh_fi[DS_FSM_ENC_LEN], sh_fo[DS_FSM_ENC_LEN], sh_flags[2];
+    if (threadIdx.x == 0) ds_fill_register_rows(job, capacity, n_rows);
+    if (threadIdx.x == 1) {
+        put_queue12(job.first_inst->initial_queue_state, sh_oi);
+        put_queue12(job.first_inst->sorted_queue_initial_state, sh_oi + 25);
+        put_queue12(job.inst->final_queue_state, sh_oo);
+    }
+    if (threadIdx.x == 2) ds_encode_fsm(job.inst->hidden_fsm_input, sh_fi);
+    if (threadIdx.x == 3) {
+        ds_encode_fsm(job.inst->hidden_fsm_output, sh_fo);
+        sh_flags[0] = job.inst->start_flag ? 1 : 0;
+        sh_flags[1] = job.inst->completion_flag ? 1 : 0;
+    }
+    __syncthreads();
+    const CfSources src = {sh_oi, sh_fi, sh_fo, sh_flags, sh_oo};
+    u64* trace = job.trace;
+    cf_fill_wave(SpecDecommitSorter::cf_spec(), trace, n_rows, (size_t)DS_BOUNDARY_ROW(capacity), src, [&](int rt, size_t row) {
+        if (threadIdx.x != 0 || rt != DS_ROW_GIN) return;
+        // the encoding of the open group's first request from the FSM words the row copied (decommit query encoding, decommit_kernels.cuh)
+        zkw_decommit_query g;
+        memset(&g, 0, sizeof g);
+        for (int k = 0; k < 8; k++) g.hash[k] = (u32)TR(DS_GIN_gh0 + k, row);
+        g.memory_page = (u32)TR(DS_GIN_gpage, row);
+        g.timestamp = (u32)TR(DS_GIN_gfts, row);
+        g.is_fresh = 1;
+        for (int k = 0; k < 4; k++) {
+            cf_put_byte(trace, n_rows, DS_MULT_COL, DS_GIN_gpage_b0 + k, row, (g.memory_page >> (8 * k)) & 0xFF);
+            cf_put_byte(trace, n_rows, DS_MULT_COL, DS_GIN_gfts_b0 + k, row, (g.timestamp >> (8 * k)) & 0xFF);
+        }
+        u64 e[8];
+        encode_decommit_query(g, e);
+        for (int k = 0; k < 3; k++) TR(DS_GIN_gge0 + k, row) = e[k];
+    });
 }
 
 // fresh_prefix[k] = fresh requests among sorted[0, k), k = 0..n: the flag of flag_prefix (scan_kernels.cuh)

@@ -513,8 +513,7 @@ static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __
 
 static __constant__ rc_link c_links[RC_NUM_LINKS] = RC_LINKS_INIT;
 static __constant__ uint8_t c_is_poseidon[RC_NUM_ROW_TYPES] = RC_ROW_IS_POSEIDON_INIT;
-static __constant__ rc_cf_const c_cf_consts[RC_CF_NUM_CONSTS] = RC_CF_CONSTS_INIT;
-static __constant__ rc_cf_free c_cf_free[RC_CF_NUM_FREE] = RC_CF_FREE_INIT;
+ZKW_CF_TABLES(RC, rc)
 
 // the register rows BND_IN / BND_OUT (one lane)
 __device__ __forceinline__ void ram_fill_register_rows(const SynthJob& job, u32 capacity, size_t n_rows) {
@@ -581,9 +580,7 @@ __device__ __forceinline__ void ram_value_row(u64* trace, size_t n_rows, size_t 
     for (int l = 5; l < 8; l++)
         for (int k = 0; k < 4; k++) {
             const u64 b = (q.value[l] >> (8 * k)) & 0xFF;
-            TR(b0 + 4 * (l - 5) + k, row) = b;
-            TR(RC_MULT_COL, b) += 1;
-            TR(RC_MULT_COL, 0) -= 1;
+            cf_put_byte(trace, n_rows, RC_MULT_COL, b0 + 4 * (l - 5) + k, row, b);
         }
     if (e3 < 0) return;
     u64 e[8];
@@ -608,8 +605,8 @@ static __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob*
         sh_flags[1] = job.inst->completion_flag ? 1 : 0;
     }
     __syncthreads();
-    const CfSpec S = {RC_CF_FIRST_ROW_TYPE, RC_CF_NUM_ROWS, RC_NUM_LINKS, RC_CF_NUM_CONSTS, RC_CF_NUM_FREE, RC_ROWS_PER_CYCLE, RC_ROW_PI,
-                      c_links, c_is_poseidon, c_cf_consts, c_cf_free};
+    const CfSpec S = {RC_CF_FIRST_ROW_TYPE, RC_CF_NUM_ROWS, RC_NUM_LINKS, RC_CF_NUM_CONSTS, RC_CF_NUM_FREE, RC_CF_NUM_PRODUCTS, RC_ROWS_PER_CYCLE, RC_ROW_PI,
+                      c_links, c_is_poseidon, c_rc_cf_consts, c_rc_cf_free, c_rc_cf_products};
     const CfSources src = {sh_oi, sh_fi, sh_fo, sh_flags, nullptr};
     u64* trace = job.trace;
     cf_fill_wave(S, trace, n_rows, (size_t)RC_BOUNDARY_ROW(capacity), src, [&](int rt, size_t row) {
@@ -641,6 +638,7 @@ struct SpecRam {  // RAMPermutation, circuit type 8
     __device__ static const uint8_t* is_poseidon() { return c_is_poseidon; }
     __device__ static const rc_link* links() { return c_links; }
 };
+ZKW_CF_TABLES(DS, ds)
 struct SpecDecommitSorter {  // CodeDecommittmentsSorter, circuit type 2
     static constexpr int G = DS_G, L = DS_L, ROWS_PER_CYCLE = DS_ROWS_PER_CYCLE, NUM_ROW_TYPES = DS_NUM_ROW_TYPES, NUM_LINKS = DS_NUM_LINKS;
     static constexpr int OFF_BIN = DS_ROWOFF_BND_IN, OFF_BOUT = DS_ROWOFF_BND_OUT;
@@ -649,6 +647,7 @@ struct SpecDecommitSorter {  // CodeDecommittmentsSorter, circuit type 2
     __device__ static const uint16_t* row_first() { return c_ds_row_first; }
     __device__ static const uint8_t* is_poseidon() { return c_ds_is_poseidon; }
     __device__ static const rc_link* links() { return c_ds_links; }
+    ZKW_CF_SPEC_MEMBERS(DS, ds)
 };
 static __constant__ rc_term c_es_terms[ES_NUM_TERMS] = ES_TERMS_INIT;
 static __constant__ rc_constraint c_es_cons[ES_NUM_CONSTRAINTS] = ES_CONSTRAINTS_INIT;

@@ -886,6 +886,7 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
         j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
         j.hist = d_hist + 256 * k;
         j.public_input = w->public_inputs + 4 * (first_instance + k);
+        j.first_inst = w->instances;  // one block per witness
     }
     DsSynthJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("ds_jobs", jobs, &d_jobs));

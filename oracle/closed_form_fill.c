@@ -9,16 +9,28 @@
 #include <string.h>
 #include "oracle.h"
 #include "../include/zkw_ram_circuit_spec.h"
+#include "../include/zkw_decommit_sorter_circuit_spec.h"
 
 #define CELL(col, row) trace[(size_t)(col) * n_rows + (row)]
 
 typedef struct {
-    int first, n, n_links, n_consts, n_free, rows_per_cycle, pi_row_type;
+    int first, n, n_links, n_consts, n_free, n_products, rows_per_cycle, pi_row_type;
     const rc_link *links;
     const uint8_t *is_poseidon;
     const rc_cf_const *consts;
     const rc_cf_free *frees;
+    const rc_cf_product *products;
 } orc_cf_spec;
+/* the tables of the spec header with prefix PFX as an orc_cf_spec named CF_<PFX> */
+#define CF_SPEC(PFX)                                                                                                                  \
+    static const rc_link PFX##_links_[] = PFX##_LINKS_INIT;                                                                           \
+    static const uint8_t PFX##_is_poseidon_[] = PFX##_ROW_IS_POSEIDON_INIT;                                                           \
+    static const rc_cf_const PFX##_consts_[] = PFX##_CF_CONSTS_INIT;                                                                  \
+    static const rc_cf_free PFX##_frees_[] = PFX##_CF_FREE_INIT;                                                                      \
+    static const rc_cf_product PFX##_products_[] = PFX##_CF_PRODUCTS_INIT;                                                            \
+    static const orc_cf_spec CF_##PFX = {PFX##_CF_FIRST_ROW_TYPE, PFX##_CF_NUM_ROWS, PFX##_NUM_LINKS, PFX##_CF_NUM_CONSTS, PFX##_CF_NUM_FREE, \
+                                         PFX##_CF_NUM_PRODUCTS, PFX##_ROWS_PER_CYCLE, PFX##_ROW_PI, PFX##_links_, PFX##_is_poseidon_,   \
+                                         PFX##_consts_, PFX##_frees_, PFX##_products_}
 typedef void (*orc_cf_hook)(void *user, int row_type, uint64_t *trace, size_t n_rows, size_t row);
 
 /* src[k]: the encoding FREE cells of source k are taken from (0 observable input, 1 hidden FSM input, 2 hidden FSM output, 3 flags,
@@ -35,6 +47,8 @@ static void cf_fill(const orc_cf_spec *S, uint64_t *trace, size_t n_rows, size_t
             if (S->consts[k].row == rt) CELL(S->consts[k].col, row) = S->consts[k].value;
         for (int k = 0; k < S->n_free; k++)
             if (S->frees[k].row == rt) CELL(S->frees[k].col, row) = src[S->frees[k].src][S->frees[k].idx];
+        for (int k = 0; k < S->n_products; k++)
+            if (S->products[k].row == rt) CELL(S->products[k].col, row) = orc_gl_mul(CELL(S->products[k].col_a, row), CELL(S->products[k].col_b, row));
         if (hook) hook(user, rt, trace, n_rows, row);
         if (S->is_poseidon[rt]) {
             uint64_t in[12], slots[130];
@@ -47,12 +61,7 @@ static void cf_fill(const orc_cf_spec *S, uint64_t *trace, size_t n_rows, size_t
 }
 
 /* ---- RAMPermutation (type 8) ---- */
-static const rc_link RC_LINKS[] = RC_LINKS_INIT;
-static const uint8_t RC_IS_POSEIDON[] = RC_ROW_IS_POSEIDON_INIT;
-static const rc_cf_const RC_CONSTS[] = RC_CF_CONSTS_INIT;
-static const rc_cf_free RC_FREES[] = RC_CF_FREE_INIT;
-static const orc_cf_spec CF_RC = {RC_CF_FIRST_ROW_TYPE, RC_CF_NUM_ROWS, RC_NUM_LINKS, RC_CF_NUM_CONSTS, RC_CF_NUM_FREE, RC_ROWS_PER_CYCLE, RC_ROW_PI,
-                                  RC_LINKS, RC_IS_POSEIDON, RC_CONSTS, RC_FREES};
+CF_SPEC(RC);
 
 /* the value rows: bytes of limbs 5..7 into the lookup cells (and the multiplicity column: +1 for the byte, -1 for the zero the cell held);
    VIN also the encoding elements es3..es6 of the limbs (memory_query.rs:60-110) */
@@ -88,4 +97,45 @@ void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_inst
     orc_ram_encode_fsm(&in->hidden_fsm_output, fo);
     const uint64_t *src[5] = {oi, fi, fo, flags, NULL};
     cf_fill(&CF_RC, trace, n_rows, (size_t)RC_BOUNDARY_ROW(capacity), src, ram_hook, NULL);
+}
+
+/* a lookup cell of a section row takes a byte: the multiplicity column counted a zero there (the register fills count every cell of the
+   lookup columns before the section is filled) */
+static void put_byte(uint64_t *trace, size_t n_rows, int mult_col, int col, size_t row, uint64_t b) {
+    CELL(col, row) = b;
+    CELL(mult_col, b) += 1;
+    CELL(mult_col, 0) -= 1;
+}
+
+/* ---- CodeDecommittmentsSorter (type 2) ---- */
+CF_SPEC(DS);
+/* GIN: the encoding of the open group's first request (previous_record.hash, page, first_encountered_timestamp, fresh) from the FSM words the
+   row copied (decommit query encoding, oracle.c orc_encode_decommit_queries) */
+static void ds_hook(void *user, int rt, uint64_t *trace, size_t n_rows, size_t row) {
+    (void)user;
+    if (rt != DS_ROW_GIN) return;
+    zkw_decommit_query g;
+    memset(&g, 0, sizeof g);
+    for (int k = 0; k < 8; k++) g.hash[k] = (uint32_t)CELL(DS_GIN_gh0 + k, row);
+    g.memory_page = (uint32_t)CELL(DS_GIN_gpage, row);
+    g.timestamp = (uint32_t)CELL(DS_GIN_gfts, row);
+    g.is_fresh = 1;
+    for (int k = 0; k < 4; k++) {
+        put_byte(trace, n_rows, DS_MULT_COL, DS_GIN_gpage_b0 + k, row, (g.memory_page >> (8 * k)) & 0xFF);
+        put_byte(trace, n_rows, DS_MULT_COL, DS_GIN_gfts_b0 + k, row, (g.timestamp >> (8 * k)) & 0xFF);
+    }
+    uint64_t e[8];
+    orc_encode_decommit_queries(&g, 1, e);
+    for (int k = 0; k < 3; k++) CELL(DS_GIN_gge0 + k, row) = e[k];
+}
+void orc_ds_fill_closed_form(const zkw_decommit_sorter_instance *first, const zkw_decommit_sorter_instance *in, uint32_t capacity, size_t n_rows,
+                             uint64_t *trace) {
+    uint64_t oi[50], oo[25], fi[ORC_DS_FSM_ENC_LEN], fo[ORC_DS_FSM_ENC_LEN], flags[2] = {in->start_flag ? 1u : 0u, in->completion_flag ? 1u : 0u};
+    orc_put_queue12(&first->initial_queue_state, oi);
+    orc_put_queue12(&first->sorted_queue_initial_state, oi + 25);
+    orc_put_queue12(&in->final_queue_state, oo);
+    orc_ds_encode_fsm(&in->hidden_fsm_input, fi);
+    orc_ds_encode_fsm(&in->hidden_fsm_output, fo);
+    const uint64_t *src[5] = {oi, fi, fo, flags, oo};
+    cf_fill(&CF_DS, trace, n_rows, (size_t)DS_BOUNDARY_ROW(capacity), src, ds_hook, NULL);
 }

@@ -218,8 +218,7 @@ int orc_decommit_sorter_synthesize(const zkw_decommit_sorter_instance *inst, con
         if (cur.completion && !cur.z_end) return -6;
     }
 
-    if (public_input) /* the commitment of the closed-form input (orc_ds_public_inputs), placed like in the RAM trace */
-        for (int k = 0; k < 4; k++) CELL(DS_PI_pi0 + k, bnd + DS_ROWOFF_PI) = public_input[k];
+    (void)public_input; /* the PI row is derived by the closed-form section (orc_ds_fill_closed_form, closed_form_fill.c), which runs next */
 
     /* multiplicities of the 8-bit range-check table: every cell of the lookup columns, padding included */
     for (int t = 0; t < 256; t++) CELL(DS_MULT_COL, t) = 0;

@@ -296,6 +296,10 @@ void orc_ram_public_input(const zkw_ram_instance *first, const zkw_ram_instance 
 void orc_ram_public_inputs(const zkw_ram_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);
 void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_instance *in, uint32_t capacity,
                                size_t n_rows, uint64_t *trace);
+/* the closed-form sections of the other queue circuits (closed_form_fill.c): after orc_*_synthesize; `first` = the block's first instance */
+size_t orc_put_queue12(const zkw_queue_state12 *q, uint64_t *o);
+void orc_ds_fill_closed_form(const zkw_decommit_sorter_instance *first, const zkw_decommit_sorter_instance *in, uint32_t capacity,
+                             size_t n_rows, uint64_t *trace);
 #define ORC_DS_FSM_ENC_LEN 100
 size_t orc_ds_encode_fsm(const zkw_decommit_sorter_fsm *f, uint64_t out[ORC_DS_FSM_ENC_LEN]);
 void orc_ds_public_inputs(const zkw_decommit_sorter_instance *inst, size_t n, uint64_t *compact, uint64_t *pi);

@@ -35,7 +35,7 @@ void orc_commit_var_length(const uint64_t *enc, size_t n, uint64_t out[4]) {
     memcpy(out, s, 32);
 }
 
-static size_t put_queue12(const zkw_queue_state12 *q, uint64_t *o) {
+size_t orc_put_queue12(const zkw_queue_state12 *q, uint64_t *o) {
     memcpy(o, q->head, 96);
     memcpy(o + 12, q->tail, 96);
     o[24] = q->length;
@@ -45,8 +45,8 @@ static size_t put_queue12(const zkw_queue_state12 *q, uint64_t *o) {
 /* RamPermutationInputData: unsorted_queue_initial_state, sorted_queue_initial_state, snapshot length */
 size_t orc_ram_encode_observable_input(const zkw_ram_instance *in, uint64_t out[ORC_RAM_INPUT_ENC_LEN]) {
     size_t m = 0;
-    m += put_queue12(&in->unsorted_queue_initial_state, out + m);
-    m += put_queue12(&in->sorted_queue_initial_state, out + m);
+    m += orc_put_queue12(&in->unsorted_queue_initial_state, out + m);
+    m += orc_put_queue12(&in->sorted_queue_initial_state, out + m);
     out[m++] = in->non_deterministic_bootloader_memory_snapshot_length;
     return m;
 }
@@ -56,8 +56,8 @@ size_t orc_ram_encode_fsm(const zkw_ram_fsm *f, uint64_t out[ORC_RAM_FSM_ENC_LEN
     size_t m = 0;
     for (int r = 0; r < 2; r++) out[m++] = f->lhs_accumulator[r];
     for (int r = 0; r < 2; r++) out[m++] = f->rhs_accumulator[r];
-    m += put_queue12(&f->current_unsorted_queue_state, out + m);
-    m += put_queue12(&f->current_sorted_queue_state, out + m);
+    m += orc_put_queue12(&f->current_unsorted_queue_state, out + m);
+    m += orc_put_queue12(&f->current_sorted_queue_state, out + m);
     for (int k = 0; k < 3; k++) out[m++] = f->previous_sorting_key[k];
     for (int k = 0; k < 2; k++) out[m++] = f->previous_full_key[k];
     for (int k = 0; k < 8; k++) out[m++] = f->previous_value[k];
@@ -104,9 +104,9 @@ void orc_recursion_queue(uint64_t circuit_type, const uint64_t *pi, size_t n, co
    (sort_decommit_requests.rs:402-414; DecommitQuery = {code_hash, page, is_first, timestamp}) */
 size_t orc_ds_encode_fsm(const zkw_decommit_sorter_fsm *f, uint64_t out[ORC_DS_FSM_ENC_LEN]) {
     size_t m = 0;
-    m += put_queue12(&f->initial_queue_state, out + m);
-    m += put_queue12(&f->sorted_queue_state, out + m);
-    m += put_queue12(&f->final_queue_state, out + m);
+    m += orc_put_queue12(&f->initial_queue_state, out + m);
+    m += orc_put_queue12(&f->sorted_queue_state, out + m);
+    m += orc_put_queue12(&f->final_queue_state, out + m);
     for (int r = 0; r < 2; r++) out[m++] = f->lhs_accumulator[r];
     for (int r = 0; r < 2; r++) out[m++] = f->rhs_accumulator[r];
     for (int k = 0; k < 9; k++) out[m++] = f->previous_packed_key[k];
@@ -126,10 +126,10 @@ void orc_ds_public_inputs(const zkw_decommit_sorter_instance *inst, size_t n, ui
         uint64_t *cf = compact + 18 * i;
         cf[0] = inst[i].start_flag ? 1 : 0;
         cf[1] = inst[i].completion_flag ? 1 : 0;
-        size_t m = put_queue12(&first->initial_queue_state, buf);
-        m += put_queue12(&first->sorted_queue_initial_state, buf + m);
+        size_t m = orc_put_queue12(&first->initial_queue_state, buf);
+        m += orc_put_queue12(&first->sorted_queue_initial_state, buf + m);
         orc_commit_var_length(buf, m, cf + 2);
-        m = put_queue12(&inst[i].final_queue_state, buf);
+        m = orc_put_queue12(&inst[i].final_queue_state, buf);
         orc_commit_var_length(buf, m, cf + 6);
         m = orc_ds_encode_fsm(&inst[i].hidden_fsm_input, buf);
         orc_commit_var_length(buf, m, cf + 10);
@@ -276,8 +276,8 @@ static size_t dcm_fsm(const zkw_decommitter_fsm *f, uint64_t *o) {
     o[m++] = f->state_get_from_queue ? 1 : 0;
     o[m++] = f->state_decommit ? 1 : 0;
     o[m++] = f->finished ? 1 : 0;
-    m += put_queue12(&f->decommittment_requests_queue_state, o + m);
-    m += put_queue12(&f->memory_queue_state, o + m);
+    m += orc_put_queue12(&f->decommittment_requests_queue_state, o + m);
+    m += orc_put_queue12(&f->memory_queue_state, o + m);
     return m;
 }
 /* {Keccak256,Sha256}RoundFunctionFSMInputOutput { internal_fsm, log_queue_state, memory_queue_state };
@@ -314,7 +314,7 @@ static size_t pre_fsm(int kind, const zkw_precompile_fsm *f, uint64_t *o) {
         o[m++] = f->num_rounds;
     }
     m += put_queue4(&f->log_queue_state, o + m);
-    m += put_queue12(&f->memory_queue_state, o + m);
+    m += orc_put_queue12(&f->memory_queue_state, o + m);
     return m;
 }
 /* StorageApplicationFSMInputOutput { current_root_hash, next_enumeration_counter, current_storage_application_log_state,
@@ -341,9 +341,9 @@ int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_
                 if (w[i].start_flag) first = i;
                 start = w[i].start_flag; completion = w[i].completion_flag;
                 /* CodeDecommitterInputData { memory_queue_initial_state, sorted_requests_queue_initial_state } */
-                n_in = put_queue12(&w[first].memory_queue_initial_state, in);
-                n_in += put_queue12(&w[first].sorted_requests_queue_initial_state, in + n_in);
-                n_out = put_queue12(&w[i].memory_queue_final_state, out);
+                n_in = orc_put_queue12(&w[first].memory_queue_initial_state, in);
+                n_in += orc_put_queue12(&w[first].sorted_requests_queue_initial_state, in + n_in);
+                n_out = orc_put_queue12(&w[i].memory_queue_final_state, out);
                 n_fi = dcm_fsm(&w[i].hidden_fsm_input, fi);
                 n_fo = dcm_fsm(&w[i].hidden_fsm_output, fo);
                 break;
@@ -355,8 +355,8 @@ int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_
                 start = w[i].start_flag; completion = w[i].completion_flag;
                 /* PrecompileFunctionInputData { initial_log_queue_state, initial_memory_queue_state } */
                 n_in = put_queue4(&w[first].initial_log_queue_state, in);
-                n_in += put_queue12(&w[first].initial_memory_queue_state, in + n_in);
-                n_out = put_queue12(&w[i].final_memory_state, out);
+                n_in += orc_put_queue12(&w[first].initial_memory_queue_state, in + n_in);
+                n_out = orc_put_queue12(&w[i].final_memory_state, out);
                 n_fi = pre_fsm(kind, &w[i].hidden_fsm_input, fi);
                 n_fo = pre_fsm(kind, &w[i].hidden_fsm_output, fo);
                 break;

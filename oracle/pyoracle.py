@@ -1091,12 +1091,12 @@ def decommit_sorter_synthesize(build_out, instance_index, capacity, n_rows):
     inst = o["instances"][instance_index:instance_index + 1]
     f = lib().orc_decommit_sorter_synthesize
     f.restype = C.c_int
-    _, pis = decommit_sorter_public_inputs(o["instances"])
-    pi = np.ascontiguousarray(pis[instance_index])
     rc = f(_p(inst), _p(o["sorted_q"]), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), None, C.c_uint32(0),
-           _p(pi), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+           None, C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_decommit_sorter_synthesize failed: {rc}")
+    first = o["instances"][0:1]  # one block: its first instance carries the shared observable input
+    lib().orc_ds_fill_closed_form(_p(first), _p(inst), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     return trace
 
 

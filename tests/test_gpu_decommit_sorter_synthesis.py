@@ -71,7 +71,7 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
     assert ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)[0] == 0
     host = t.get(0)
     rng = np.random.default_rng(2)
-    used = np.argwhere(host[:148, :7 * 128 + 3] != 0)
+    used = np.argwhere(host[:148, :7 * 128 + 53] != 0)
     base = native.load().zkw_trace_device_ptr(t.handle, 0)
     import ctypes as C
 
@@ -85,5 +85,18 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
         hip.hipMemcpy(C.c_void_p(addr), new.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
         assert ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)[0] > 0, (c, r)
         hip.hipMemcpy(C.c_void_p(addr), old.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
+    assert ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)[0] == 0
+    # the closed-form section: challenges, start-flag selection, commitments, public input — same verdict as the oracle's checker
+    from closed_form_case import decommit_sorter_tampers
+    for name, c, r in decommit_sorter_tampers(capacity):
+        addr = base + (int(c) * n_rows + int(r)) * 8
+        new = np.array([(int(host[c, r]) + 1) % P], np.uint64)
+        hip.hipMemcpy(C.c_void_p(addr), new.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
+        bad, first = ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)
+        h2 = host.copy()
+        h2[c, r] = new[0]
+        obad, ofirst = oracle.decommit_sorter_check(h2, capacity)
+        assert bad > 0 and bad == obad and first[0] == ofirst[0], (name, bad, first, obad, ofirst)
+        hip.hipMemcpy(C.c_void_p(addr), np.array([host[c, r]], np.uint64).ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
     assert ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)[0] == 0
     t.free()

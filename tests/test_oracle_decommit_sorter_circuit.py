@@ -57,12 +57,38 @@ def test_checker_notices_tampering(oracle):
     t = oracle.decommit_sorter_synthesize(o, 0, capacity, n_rows)
     assert oracle.decommit_sorter_check(t, capacity)[0] == 0
     rng = np.random.default_rng(1)
-    used = [(c, r) for c in range(148) for r in range(_bnd(capacity) + 3) if t[c, r] != 0]
+    used = [(c, r) for c in range(148) for r in range(_bnd(capacity) + 53) if t[c, r] != 0]
     for _ in range(40):
         c, r = used[rng.integers(len(used))]
         t2 = t.copy()
         t2[c, r] = (int(t2[c, r]) + 1) % P
         assert oracle.decommit_sorter_check(t2, capacity)[0] > 0, (c, r)
+
+
+def test_closed_form_section(oracle):
+    """the PI row is derived in-trace (sponges over the closed-form input -> compact form -> commitment) and equals the builder's public
+    input; the challenges of BND_IN are the challenge sponge's outputs; tampering with any of it is caught"""
+    from closed_form_case import decommit_sorter_tampers
+    from era_zkevm_test_harness_amd.ram_circuit import spec_macros
+
+    M = spec_macros("zkw_decommit_sorter_circuit_spec.h", "DS")
+    capacity, n_rows = 64, 1024
+    o = oracle.decommit_sorter_build(synthetic.decommit_trace(150, 9, seed=4), capacity)
+    _, pis = oracle.decommit_sorter_public_inputs(o["instances"])
+    b = _bnd(capacity)
+    assert o["instances"].size == 3
+    for idx in range(3):
+        t = oracle.decommit_sorter_synthesize(o, idx, capacity, n_rows)
+        assert oracle.decommit_sorter_check(t, capacity)[0] == 0
+        assert np.array_equal(t[M["PI_pi0"]:M["PI_pi0"] + 4, b + M["ROWOFF_PI"]], pis[idx])
+        assert int(t[M["SEL0_flag"], b + M["ROWOFF_SEL0"]]) == (1 if idx == 0 else 0)
+        ch = o["challenges"].reshape(2, 9)
+        for rep in range(2):
+            assert np.array_equal(t[M["CH3_CH3_o0"]:M["CH3_CH3_o0"] + 8, b + M[f"ROWOFF_CH{3 + rep}"]], ch[rep, 1:])
+        for name, c, r in decommit_sorter_tampers(capacity):
+            t2 = t.copy()
+            t2[c, r] = (int(t2[c, r]) + 1) % P
+            assert oracle.decommit_sorter_check(t2, capacity)[0] > 0, (idx, name)
 
 
 def test_unsorted_or_mislabelled_input_is_rejected(oracle):

@@ -178,7 +178,84 @@ def build():
     for k in range(4):
         PI.slot(f"pi{k}")
 
-    rows = [PU, PS, PR, A, B, Cc, D, BIN, BOUT, PF, PI]
+    # ---------------- closed-form section (gen_ram_circuit.ClosedForm): what the reference's circuit derives in-trace
+    cf = dsl.ClosedForm()
+    SRC = dsl.ClosedForm
+    # observable input (CodeDecommittmentsDeduplicatorInputData: initial_queue_state, sorted_queue_initial_state), the block's first instance's
+    OI = cf.sponge("OI", [None] * 50, free_src=SRC.SRC_OBS_IN)
+    oi = lambda w: cf.word_cell(OI, w)  # noqa: E731
+    # hidden FSM input (CodeDecommittmentsDeduplicatorFSMInputOutput, sort_decommit_requests.rs:396-411): queue states 0 / 25 / 50,
+    # lhs 75, rhs 77, previous_packed_key 79 (timestamp, hash words), previous_record 88 (hash 8, page, is_fresh, timestamp), first_encountered_timestamp 99
+    FI = cf.sponge("FI", [None] * 100, free_src=SRC.SRC_FSM_IN)
+    fi = lambda w: cf.word_cell(FI, w)  # noqa: E731
+    # the open group's first request as the registers hold it — the ENCODING of (previous_record.hash, page, first_encountered_timestamp,
+    # fresh) (decommit query encoding: hash words 0..2 carry the page / timestamp bytes and the fresh flag) — from the FSM's words
+    GIN = Row("GIN", False)
+    for k in range(8):
+        GIN.slot(f"gh{k}")
+        cf.copy(GIN, f"gh{k}", *fi(88 + k))
+    GIN.slot("gpage"), GIN.slot("gfts")
+    cf.copy(GIN, "gpage", *fi(96))
+    cf.copy(GIN, "gfts", *fi(99))
+    pb = GIN.bytes_of("gpage", "gpage")
+    tb = GIN.bytes_of("gfts", "gfts")
+    GIN.c([(1, ["gge0"]), (-1, ["gh0"]), (-(1 << 32), [pb[0]]), (-(1 << 40), [pb[1]]), (-(1 << 48), [pb[2]])], "ge0 of the open group")
+    GIN.c([(1, ["gge1"]), (-1, ["gh1"]), (-(1 << 32), [pb[3]]), (-(1 << 40), [tb[0]]), (-(1 << 48), [tb[1]])], "ge1")
+    GIN.c([(1, ["gge2"]), (-1, ["gh2"]), (-(1 << 32), [tb[2]]), (-(1 << 40), [tb[3]]), (-(1 << 48), [])], "ge2 (fresh)")
+    cf.rows.append(GIN)
+    # start-flag selection: registers at cycle -1 = start ? (observable input's queues, the empty result queue, accumulators ONE, no
+    # previous key, no open group) : hidden FSM input
+    SEL = dsl.Selections(cf, "SEL")
+    for qi, q in enumerate(("u", "s")):
+        for k in range(12):
+            SEL.sel3(oi(25 * qi + k), fi(25 * qi + k), (BIN, f"{q}h{k}"))
+            SEL.sel3(oi(25 * qi + 12 + k), fi(25 * qi + 12 + k), (BOUT, f"tail_{q}{k}"))
+        SEL.sel3(oi(25 * qi + 24), fi(25 * qi + 24), (BIN, f"len_{q}"))
+    for k in range(12):
+        SEL.sel2(0, fi(50 + 12 + k), (BIN, f"rh{k}"))  # the deduplicated queue starts empty (the reference's callers hand in a fresh simulator)
+    SEL.sel2(0, fi(74), (BIN, "len_r"))
+    for r in range(2):
+        SEL.sel2(1, fi(75 + r), (BIN, f"lhs{r}"))
+        SEL.sel2(1, fi(77 + r), (BIN, f"rhs{r}"))
+    key_regs = ["ts", "h0", "h1", "h2", "es3", "es4", "es5", "es6", "es7"]  # previous_packed_key: timestamp, then the hash words
+    for k, v in enumerate(key_regs):
+        SEL.sel2(0, fi(79 + k), (BIN, v))
+    SEL.sel2(0, fi(96), (BIN, "page"))
+    SEL.not_flag((BIN, "gvalid"))
+    for k in range(8):
+        SEL.sel2(0, (GIN, f"gge{k}" if k < 3 else f"gh{k}"), (BIN, f"ge{k}"))
+    # hidden FSM output: the registers after the last cycle (the deduplicated queue WITHOUT the open group's request unless the instance
+    # completes: final_rh / final_len_r, the builder's snapshot rule sort_decommit_requests.rs:150-158)
+    q25 = lambda q: [(BOUT, f"{q}h{k}") for k in range(12)] + [(BOUT, f"tail_{q}{k}") for k in range(12)] + [(BOUT, f"len_{q}")]  # noqa: E731
+    fo_words = (q25("u") + q25("s") + [("const", 0)] * 12 + [(BOUT, f"final_rh{k}") for k in range(12)] + [(BOUT, "final_len_r")] +
+                [(BOUT, f"lhs{r}") for r in range(2)] + [(BOUT, f"rhs{r}") for r in range(2)] + [(BOUT, v) for v in key_regs] +
+                [(BOUT, v) for v in key_regs[1:]] + [(BOUT, "page"), None, (BOUT, "ts"), None])  # is_fresh / first_encountered_timestamp: only committed
+    assert len(fo_words) == 100
+    FO = cf.sponge("FO", fo_words, free_src=SRC.SRC_FSM_OUT)
+    # observable output (final_queue_state): completion ? the deduplicated queue after the flush : the placeholder (zeros), :340-372
+    OSEL = dsl.Selections(cf, "OSEL", flag_cell=(BOUT, "completion"))
+    oo_words = [("const", 0)] * 12 + [OSEL.gate((BOUT, f"final_rh{k}")) for k in range(12)] + [OSEL.gate((BOUT, "final_len_r"))]
+    cf.rows += OSEL.rows
+    OO = cf.sponge("OO", oo_words)
+    # Fiat-Shamir challenges over the observable input's queue tails and lengths (sort_decommit_requests.rs:205-215)
+    fs_words = [oi(12 + k) for k in range(12)] + [oi(24)] + [oi(25 + 12 + k) for k in range(12)] + [oi(49)]
+    CH = cf.sponge("CH", fs_words, squeeze=1)
+    for r in range(2):
+        for k in range(1, 9):
+            cf.copy(BIN, f"g.c{r}_{k}", CH[3 + r], f"{CH[3 + r].name}_o{k - 1}")
+    last = lambda rows_: rows_[-1]  # noqa: E731
+    cp_words = [SEL.flag(), (BOUT, "completion")]
+    for sp in (OI, OO, FI, FO):
+        cp_words += [(last(sp), f"{last(sp).name}_o{k}") for k in range(4)]
+    CP = cf.sponge("CP", cp_words)
+    for k in range(4):
+        cf.copy(PI, f"pi{k}", last(CP), f"{last(CP).name}_o{k}")
+    # fill order: a row's copies come from rows before it (or from the register rows)
+    pos = cf.rows.index(GIN) + 1
+    cf.rows[pos:pos] = SEL.rows
+    build.cf = cf
+
+    rows = [PU, PS, PR, A, B, Cc, D, BIN, BOUT, PF, PI] + cf.rows
     # the previous request's key is simply the previous cycle's cells (a padding cycle holds zeros, which is also what
     # the builder hands over after a partial last chunk, sort_decommit_requests.rs:174-181)
     return rows, regs
@@ -214,7 +291,7 @@ def links_of(rows, regs):
                 links.append((3, ri, col, home[v][0], home[v][1], 0))
             elif v.startswith("x."):
                 links.append((4, ri, col, rows.index(BOUT), BOUT.slot(v[2:]), 0))
-    return links
+    return links + build.cf.resolve(rows)
 
 
 if __name__ == "__main__":
@@ -226,7 +303,8 @@ if __name__ == "__main__":
                       title=("/* GENERATED by tools/gen_decommit_sorter_circuit.py — do not edit. Layout contract of the",
                              " * CodeDecommittmentsSorter trace emitted by zkw_decommit_sorter_synthesize (\"zkw trace v2\"). */",
                              "#include \"zkw_ram_circuit_spec.h\" /* rc_term, rc_constraint, rc_link */"),
-                      poseidon_rows=("PU", "PS", "PR", "PF"), shared_types=True)
+                      poseidon_rows=("PU", "PS", "PR", "PF") + tuple(build.cf.p2_names), shared_types=True,
+                      cf_tables=build.cf.tables(rows, build.cf.rows))
     # scatter lists for the oracle's fill: one struct field per distinct variable, one X-entry per cell
     names = []
     for r in rows:

@@ -105,7 +105,7 @@ class ClosedForm:
     SRC_OBS_IN, SRC_FSM_IN, SRC_FSM_OUT, SRC_FLAG, SRC_OBS_OUT = 0, 1, 2, 3, 4  # where a fill takes a FREE cell from: word idx of that encoding
 
     def __init__(self):
-        self.rows, self.copies, self.p2_names, self.free, self.consts = [], [], [], [], []
+        self.rows, self.copies, self.p2_names, self.free, self.consts, self.products = [], [], [], [], [], []
 
     def free_cell(self, row, var, src, idx):
         self.free.append((row, var, src, idx))
@@ -158,7 +158,71 @@ class ClosedForm:
         """what a fill needs next to the links: the section's row types in order, the cells that are constants, the FREE cells"""
         return {"first": all_rows.index(section_rows[0]), "n": len(section_rows),
                 "consts": [(all_rows.index(r), r.slot(v), val) for r, v, val in self.consts],
-                "free": [(all_rows.index(r), r.slot(v), src, idx) for r, v, src, idx in self.free]}
+                "free": [(all_rows.index(r), r.slot(v), src, idx) for r, v, src, idx in self.free],
+                "products": [(all_rows.index(r), r.slot(t), r.slot(a), r.slot(b)) for r, t, a, b in self.products]}
+
+
+class Selections:
+    """Rows of flag-conditional selections, opened as they fill up (each holds its own copy of the flag). The flag is the instance's
+    start flag (FREE boolean in the first row: the closed form's word, fill source SRC_FLAG idx 0) or a boolean cell that exists already
+    (completion in BND_OUT). Every selected value is a fresh cell tied to its target by a copy."""
+
+    def __init__(self, cf, prefix, flag_cell=None):
+        self.cf, self.prefix, self.flag_cell, self.rows, self.n = cf, prefix, flag_cell, [], 0
+
+    def _row(self, need):
+        if self.rows and len(self.rows[-1].slots) + need <= G:
+            return self.rows[-1]
+        r = Row(f"{self.prefix}{len(self.rows)}", False)
+        if self.flag_cell is None and not self.rows:
+            r.boolean("flag")
+            self.cf.free_cell(r, "flag", ClosedForm.SRC_FLAG, 0)
+        else:
+            r.slot("flag")
+            self.cf.copy(r, "flag", *(self.flag_cell or (self.rows[0], "flag")))
+        self.rows.append(r)
+        return r
+
+    def flag(self):
+        """(row, var) of the flag's first cell"""
+        return (self._row(0), "flag")
+
+    def _names(self, letters):
+        self.n += 1
+        return [f"s{self.n - 1}_{x}" for x in letters]
+
+    def sel3(self, a_cell, b_cell, target, why=""):
+        """target = flag ? a : b"""
+        row = self._row(3)
+        a, b, t = self._names("abt")
+        row.c([(1, [t]), (-1, ["flag", a]), (-1, [b]), (1, ["flag", b])], why or f"{target[1]} = flag ? {a_cell[1]} : {b_cell[1]}")
+        self.cf.copy(row, a, *a_cell)
+        self.cf.copy(row, b, *b_cell)
+        self.cf.copy(row, t, *target)
+
+    def sel2(self, init, b_cell, target, why=""):
+        """target = flag ? init (a constant) : b"""
+        row = self._row(2)
+        b, t = self._names("bt")
+        row.c([(1, [t]), (-init, ["flag"]), (-1, [b]), (1, ["flag", b])], why or f"{target[1]} = flag ? {init} : {b_cell[1]}")
+        self.cf.copy(row, b, *b_cell)
+        self.cf.copy(row, t, *target)
+
+    def gate(self, b_cell, why=""):
+        """a fresh cell = flag ? b : 0; returns it (a sponge word copies it)"""
+        row = self._row(2)
+        b, t = self._names("bt")
+        row.c([(1, [t]), (-1, ["flag", b])], why or f"flag ? {b_cell[1]} : 0")
+        self.cf.copy(row, b, *b_cell)
+        self.cf.products.append((row, t, "flag", b))  # nothing to copy it from: a fill computes it
+        return (row, t)
+
+    def not_flag(self, target, why=""):
+        """target = 1 - flag"""
+        row = self._row(1)
+        (t,) = self._names("t")
+        row.c([(1, [t]), (1, ["flag"]), (-1, [])], why or f"{target[1]} = 1 - flag")
+        self.cf.copy(row, t, *target)
 
 
 def build():
@@ -518,9 +582,13 @@ def emit(rows, links, path, prefix="RC", guard="ZKW_RAM_CIRCUIT_SPEC_H",
         if not shared_types:
             out.append("typedef struct { uint8_t row, col; uint64_t value; } rc_cf_const;")
             out.append("typedef struct { uint8_t row, col, src; uint16_t idx; } rc_cf_free;")
+            out.append("typedef struct { uint8_t row, col, col_a, col_b; } rc_cf_product; /* cell = cell a * cell b of the same row, computed by a fill after the row's copies */")
         w(f"#define RC_CF_NUM_CONSTS {len(cf_tables['consts'])}\n#define RC_CF_NUM_FREE {len(cf_tables['free'])}")
         w("#define RC_CF_CONSTS_INIT {" + ", ".join(f"{{{a}, {b}, {c}ULL}}" for a, b, c in cf_tables["consts"]) + "}")
         w("#define RC_CF_FREE_INIT {" + ", ".join(f"{{{a}, {b}, {c}, {d}}}" for a, b, c, d in cf_tables["free"]) + "}")
+        prods = cf_tables.get("products", [])
+        w(f"#define RC_CF_NUM_PRODUCTS {len(prods)}")
+        w("#define RC_CF_PRODUCTS_INIT {" + ", ".join(f"{{{a}, {b}, {c}, {d}}}" for a, b, c, d in prods) + ("}" if prods else "{0, 0, 0, 0}}") + "  /* (one zero entry when there are none) */")
     w(f"#define RC_NUM_LINKS {len(links)}")
     w("#define RC_LINKS_INIT { \\")
     for k in links:
