@@ -74,6 +74,28 @@ __device__ __forceinline__ void cf_fill_wave(const CfSpec& S, u64* __restrict__ 
 #undef CF_CELL
 }
 
+// the section of a circuit whose closed form has a record encoder Cf (public_input_kernels.cuh: CfEventsSorter ...; S = its checker spec):
+// lanes 1..3 stage the encodings of the records in LDS, then the walk. The caller's lane 0 may write the register rows before calling
+// (the barrier in here orders them). Called by every lane of a 64-lane block.
+template <class Cf, class S, class Hook>
+__device__ __forceinline__ void cf_section_from_records(const typename Cf::Inst* first, const typename Cf::Inst* inst, u64* trace, size_t n_rows, size_t bnd,
+                                                        Hook&& hook) {
+    __shared__ u64 sh_oi[Cf::MAXLEN], sh_oo[Cf::MAXLEN], sh_fi[Cf::MAXLEN], sh_fo[Cf::MAXLEN], sh_flags[2];
+    if (threadIdx.x == 1) {
+        Cf::input(*first, sh_oi);
+        Cf::output(*inst, sh_oo);
+    }
+    if (threadIdx.x == 2) Cf::fsm(Cf::fsm_in(*inst), sh_fi);
+    if (threadIdx.x == 3) {
+        Cf::fsm(Cf::fsm_out(*inst), sh_fo);
+        sh_flags[0] = inst->start_flag ? 1 : 0;
+        sh_flags[1] = inst->completion_flag ? 1 : 0;
+    }
+    __syncthreads();
+    const CfSources src = {sh_oi, sh_fi, sh_fo, sh_flags, sh_oo};
+    cf_fill_wave(S::cf_spec(), trace, n_rows, bnd, src, hook);
+}
+
 // a lookup cell of a section row takes a byte: the multiplicity column counted a zero there (the tail kernels count every lookup cell below
 // the cycles as zero). One lane.
 __device__ __forceinline__ void cf_put_byte(u64* trace, size_t n_rows, int mult_col, int col, size_t row, u64 b) {

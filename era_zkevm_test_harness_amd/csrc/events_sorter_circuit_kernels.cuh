@@ -30,7 +30,8 @@ struct EsSynthJob {
     u64 n_block;
     u64 rq_tail_in[4];                         // result queue before the block
     u32 rq_len_in;
-    const u64* public_input;  // [4]: commitment of the compact closed-form input
+    const u64* public_input;  // [4]: commitment of the compact closed-form input (not written: the closed-form section derives the PI row)
+    const zkw_events_sorter_instance* first_inst;  // the block's first instance (the shared observable input)
     u64* trace;
     u32* hist;
 };
@@ -338,9 +339,7 @@ static __global__ __launch_bounds__(256) void k_es_fill_tail(const EsSynthJob* _
 }
 
 // BND_IN, BND_OUT, the flush permutations F1..F3, PI (runs last on the stream: reads the last cycle's rows)
-static __global__ __launch_bounds__(64) void k_es_fill_boundary(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const EsSynthJob& job = jobs[blockIdx.x];
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void es_fill_register_rows(const EsSynthJob& job, u32 capacity, size_t n_rows) {
     u64* trace = job.trace;
     const zkw_events_sorter_instance* in = job.inst;
     const size_t rs = ES_REGION_STRIDE(capacity), bnd = (size_t)ES_BOUNDARY_ROW(capacity);
@@ -398,8 +397,14 @@ static __global__ __launch_bounds__(64) void k_es_fill_boundary(const EsSynthJob
         ES_FILL_BND_OUT(ES_XC, ES_XPB, ES_XG, ES_XC)
         for (int col = ES_NSLOTS_BND_OUT; col < ES_G + ES_L; col++) TR(col, row) = 0;
     }
-    const size_t rPI = bnd + ES_ROWOFF_PI;
-    for (int col = 0; col < ES_G + ES_L; col++) TR(col, rPI) = col < 4 ? job.public_input[col] : 0;
+}
+
+// BND_IN, BND_OUT, the flush permutations F1..F3 (one lane), then the closed-form section down to the PI row (runs last on the stream: reads
+// the last cycle's rows)
+static __global__ __launch_bounds__(64) void k_es_fill_boundary(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const EsSynthJob& job = jobs[blockIdx.x];
+    if (threadIdx.x == 0) es_fill_register_rows(job, capacity, n_rows);
+    cf_section_from_records<CfEventsSorter, SpecEventsSorter>(job.first_inst, job.inst, job.trace, n_rows, (size_t)ES_BOUNDARY_ROW(capacity), [](int, size_t) {});
 }
 
 // kept_prefix[k] = #{ j < k : record j is a forward record whose successor has another timestamp }, k = 0..n

@@ -22,6 +22,7 @@ static __constant__ rc_constraint c_ld_cons[LD_NUM_CONSTRAINTS] = LD_CONSTRAINTS
 static __constant__ uint16_t c_ld_row_first[LD_NUM_ROW_TYPES + 1] = LD_ROW_FIRST_CONSTRAINT_INIT;
 static __constant__ uint8_t c_ld_is_poseidon[LD_NUM_ROW_TYPES] = LD_ROW_IS_POSEIDON_INIT;
 static __constant__ rc_link c_ld_links[LD_NUM_LINKS] = LD_LINKS_INIT;
+ZKW_CF_TABLES(LD, ld)
 struct SpecLogDemux {  // LogDemuxer, circuit type 4
     static constexpr int G = LD_G, L = LD_L, ROWS_PER_CYCLE = LD_ROWS_PER_CYCLE, NUM_ROW_TYPES = LD_NUM_ROW_TYPES, NUM_LINKS = LD_NUM_LINKS;
     static constexpr int OFF_BIN = LD_ROWOFF_BND_IN, OFF_BOUT = LD_ROWOFF_BND_OUT;
@@ -30,6 +31,7 @@ struct SpecLogDemux {  // LogDemuxer, circuit type 4
     __device__ static const uint16_t* row_first() { return c_ld_row_first; }
     __device__ static const uint8_t* is_poseidon() { return c_ld_is_poseidon; }
     __device__ static const rc_link* links() { return c_ld_links; }
+    ZKW_CF_SPEC_MEMBERS(LD, ld)
 };
 
 struct LdSynthJob {
@@ -40,7 +42,8 @@ struct LdSynthJob {
     const u32* route_count;    // [6][n] inclusive prefix counts per route
     u64 offsets[7];
     u64 n_block;
-    const u64* public_input;  // [4]: commitment of the compact closed-form input
+    const u64* public_input;  // [4]: commitment of the compact closed-form input (not written: the closed-form section derives the PI row)
+    const zkw_log_demux_instance* first_inst;  // the block's first instance (the shared observable input)
     u64* trace;
     u32* hist;
 };
@@ -249,9 +252,7 @@ static __global__ __launch_bounds__(256) void k_ld_fill_tail(const LdSynthJob* _
 }
 
 // BND_IN, BND_OUT, PI (runs last on the stream: reads the last cycle's row Q)
-static __global__ __launch_bounds__(64) void k_ld_fill_boundary(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const LdSynthJob& job = jobs[blockIdx.x];
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void ld_fill_register_rows(const LdSynthJob& job, u32 capacity, size_t n_rows) {
     u64* trace = job.trace;
     const zkw_log_demux_instance* in = job.inst;
     const size_t rs = LD_REGION_STRIDE(capacity), bnd = (size_t)LD_BOUNDARY_ROW(capacity);
@@ -288,8 +289,13 @@ static __global__ __launch_bounds__(64) void k_ld_fill_boundary(const LdSynthJob
         LD_FILL_BND_OUT(LD_XC, LD_XPB, LD_XG, LD_XC)
         for (int col = LD_NSLOTS_BND_OUT; col < LD_G + LD_L; col++) TR(col, row) = 0;
     }
-    const size_t rPI = bnd + LD_ROWOFF_PI;
-    for (int col = 0; col < LD_G + LD_L; col++) TR(col, rPI) = col < 4 ? job.public_input[col] : 0;
+}
+
+// the register rows (one lane), then the closed-form section down to the PI row (runs last on the stream: reads the last cycle's rows)
+static __global__ __launch_bounds__(64) void k_ld_fill_boundary(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const LdSynthJob& job = jobs[blockIdx.x];
+    if (threadIdx.x == 0) ld_fill_register_rows(job, capacity, n_rows);
+    cf_section_from_records<CfLogDemux, SpecLogDemux>(job.first_inst, job.inst, job.trace, n_rows, (size_t)LD_BOUNDARY_ROW(capacity), [](int, size_t) {});
 }
 
 #undef TR

@@ -654,6 +654,7 @@ static __constant__ rc_constraint c_es_cons[ES_NUM_CONSTRAINTS] = ES_CONSTRAINTS
 static __constant__ uint16_t c_es_row_first[ES_NUM_ROW_TYPES + 1] = ES_ROW_FIRST_CONSTRAINT_INIT;
 static __constant__ uint8_t c_es_is_poseidon[ES_NUM_ROW_TYPES] = ES_ROW_IS_POSEIDON_INIT;
 static __constant__ rc_link c_es_links[ES_NUM_LINKS] = ES_LINKS_INIT;
+ZKW_CF_TABLES(ES, es)
 struct SpecEventsSorter {  // EventsSorter / L1MessagesSorter, circuit types 11 and 12
     static constexpr int G = ES_G, L = ES_L, ROWS_PER_CYCLE = ES_ROWS_PER_CYCLE, NUM_ROW_TYPES = ES_NUM_ROW_TYPES, NUM_LINKS = ES_NUM_LINKS;
     static constexpr int OFF_BIN = ES_ROWOFF_BND_IN, OFF_BOUT = ES_ROWOFF_BND_OUT;
@@ -662,6 +663,7 @@ struct SpecEventsSorter {  // EventsSorter / L1MessagesSorter, circuit types 11 
     __device__ static const uint16_t* row_first() { return c_es_row_first; }
     __device__ static const uint8_t* is_poseidon() { return c_es_is_poseidon; }
     __device__ static const rc_link* links() { return c_es_links; }
+    ZKW_CF_SPEC_MEMBERS(ES, es)
 };
 
 struct CheckResult {

@@ -23,6 +23,7 @@ static __constant__ rc_constraint c_ss_cons[SS_NUM_CONSTRAINTS] = SS_CONSTRAINTS
 static __constant__ uint16_t c_ss_row_first[SS_NUM_ROW_TYPES + 1] = SS_ROW_FIRST_CONSTRAINT_INIT;
 static __constant__ uint8_t c_ss_is_poseidon[SS_NUM_ROW_TYPES] = SS_ROW_IS_POSEIDON_INIT;
 static __constant__ rc_link c_ss_links[SS_NUM_LINKS] = SS_LINKS_INIT;
+ZKW_CF_TABLES(SS, ss)
 struct SpecStorageSorter {  // StorageSorter, circuit type 9
     static constexpr int G = SS_G, L = SS_L, ROWS_PER_CYCLE = SS_ROWS_PER_CYCLE, NUM_ROW_TYPES = SS_NUM_ROW_TYPES, NUM_LINKS = SS_NUM_LINKS;
     static constexpr int OFF_BIN = SS_ROWOFF_BND_IN, OFF_BOUT = SS_ROWOFF_BND_OUT;
@@ -31,6 +32,7 @@ struct SpecStorageSorter {  // StorageSorter, circuit type 9
     __device__ static const uint16_t* row_first() { return c_ss_row_first; }
     __device__ static const uint8_t* is_poseidon() { return c_ss_is_poseidon; }
     __device__ static const rc_link* links() { return c_ss_links; }
+    ZKW_CF_SPEC_MEMBERS(SS, ss)
 };
 
 struct SsSynthJob {
@@ -42,7 +44,8 @@ struct SsSynthJob {
     const u64 *lhs_z, *rhs_z;                          // [2][n]
     StorageScan sc;                                    // D, S, R, E over the sorted records
     u64 n_block;
-    const u64* public_input;  // [4]: commitment of the compact closed-form input
+    const u64* public_input;  // [4]: commitment of the compact closed-form input (not written: the closed-form section derives the PI row)
+    const zkw_storage_sorter_instance* first_inst;  // the block's first instance (the shared observable input)
     u64* trace;
     u32* hist;
 };
@@ -429,9 +432,7 @@ static __global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* _
 }
 
 // BND_IN, BND_OUT, the flush permutations F1..F3, PI (runs last on the stream: reads the last cycle's rows)
-static __global__ __launch_bounds__(64) void k_ss_fill_boundary(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const SsSynthJob& job = jobs[blockIdx.x];
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void ss_fill_register_rows(const SsSynthJob& job, u32 capacity, size_t n_rows) {
     u64* trace = job.trace;
     const zkw_storage_sorter_instance* in = job.inst;
     const size_t rs = SS_REGION_STRIDE(capacity), bnd = (size_t)SS_BOUNDARY_ROW(capacity);
@@ -510,8 +511,13 @@ static __global__ __launch_bounds__(64) void k_ss_fill_boundary(const SsSynthJob
         SS_FILL_BND_OUT(SS_XC, SS_XPB, SS_XG, SS_XC)
         for (int col = SS_NSLOTS_BND_OUT; col < SS_G + SS_L; col++) TR(col, row) = 0;
     }
-    const size_t rPI = bnd + SS_ROWOFF_PI;
-    for (int col = 0; col < SS_G + SS_L; col++) TR(col, rPI) = col < 4 ? job.public_input[col] : 0;
+}
+
+// the register rows (one lane), then the closed-form section down to the PI row (runs last on the stream: reads the last cycle's rows)
+static __global__ __launch_bounds__(64) void k_ss_fill_boundary(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const SsSynthJob& job = jobs[blockIdx.x];
+    if (threadIdx.x == 0) ss_fill_register_rows(job, capacity, n_rows);
+    cf_section_from_records<CfStorageSorter, SpecStorageSorter>(job.first_inst, job.inst, job.trace, n_rows, (size_t)SS_BOUNDARY_ROW(capacity), [](int, size_t) {});
 }
 
 #undef TR

@@ -378,9 +378,16 @@ extern "C" int zkw_events_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, siz
             inst.hidden_fsm_input.lhs_accumulator[r] = inst.hidden_fsm_input.rhs_accumulator[r] = 1;
             inst.hidden_fsm_output.lhs_accumulator[r] = inst.hidden_fsm_output.rhs_accumulator[r] = 1;
         }
-        if (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemset(w->challenges, 0, 42 * 8) != hipSuccess)
+        // the circuit derives its challenges whatever the queue holds (the trace's closed-form section does): those of two empty queues
+        u64* d_zero = nullptr;
+        rc = ctx->scratch_t<u64>("empty_queue_tail", 4, &d_zero);
+        if (rc == ZKW_OK && (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
+                             hipMemsetAsync(d_zero, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess))
             rc = fail(ZKW_ERR_HIP, "copy failed");
+        if (rc == ZKW_OK) {
+            std::vector<FsJob> fs(1, FsJob{d_zero, d_zero, 0u, 0u, w->challenges});
+            rc = dev_fs(ctx, fs, 4, 21);
+        }
     } else {
         const zkw_log_query* d_q = nullptr;
         rc = ctx->in("evt_q", q, n, &d_q);
@@ -772,9 +779,16 @@ extern "C" int zkw_storage_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, si
         inst.start_flag = inst.completion_flag = 1;
         for (int r = 0; r < 2; r++) inst.hidden_fsm_output.lhs_accumulator[r] = inst.hidden_fsm_output.rhs_accumulator[r] = 1;
         inst.hidden_fsm_output.cycle_idx = 4;
-        if (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemset(w->challenges, 0, 42 * 8) != hipSuccess)
+        // the circuit derives its challenges whatever the queue holds (the trace's closed-form section does): those of two empty queues
+        u64* d_zero = nullptr;
+        rc = ctx->scratch_t<u64>("empty_queue_tail", 4, &d_zero);
+        if (rc == ZKW_OK && (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
+                             hipMemsetAsync(d_zero, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess))
             rc = fail(ZKW_ERR_HIP, "copy failed");
+        if (rc == ZKW_OK) {
+            std::vector<FsJob> fs(1, FsJob{d_zero, d_zero, 0u, 0u, w->challenges});
+            rc = dev_fs(ctx, fs, 4, 21);
+        }
     } else {
         const zkw_log_query* d_q = nullptr;
         rc = ctx->in("sto_q", q, n, &d_q);
@@ -952,6 +966,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
         memcpy(j.rq_tail_in, w->result_in.tail, 32);
         j.rq_len_in = w->result_in.length;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
+        j.first_inst = w->instances;  // one block per witness
         j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
         j.hist = d_hist + 256 * k;
     }
@@ -1016,6 +1031,7 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
         for (int c = 0; c < 7; c++) j.offsets[c] = w->offsets[c];
         j.n_block = n;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
+        j.first_inst = w->instances;  // one block per witness
         j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
         j.hist = d_hist + 256 * k;
     }
@@ -1076,6 +1092,7 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
         j.sc.D = reinterpret_cast<int*>(w->scans); j.sc.S = w->scans + n; j.sc.R = w->scans + 2 * n; j.sc.E = w->scans + 3 * n;
         j.n_block = n;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
+        j.first_inst = w->instances;  // one block per witness
         j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
         j.hist = d_hist + 256 * k;
     }

@@ -10,6 +10,9 @@
 #include "oracle.h"
 #include "../include/zkw_ram_circuit_spec.h"
 #include "../include/zkw_decommit_sorter_circuit_spec.h"
+#include "../include/zkw_events_sorter_circuit_spec.h"
+#include "../include/zkw_log_demux_circuit_spec.h"
+#include "../include/zkw_storage_sorter_circuit_spec.h"
 
 #define CELL(col, row) trace[(size_t)(col) * n_rows + (row)]
 
@@ -138,4 +141,46 @@ void orc_ds_fill_closed_form(const zkw_decommit_sorter_instance *first, const zk
     orc_ds_encode_fsm(&in->hidden_fsm_output, fo);
     const uint64_t *src[5] = {oi, fi, fo, flags, oo};
     cf_fill(&CF_DS, trace, n_rows, (size_t)DS_BOUNDARY_ROW(capacity), src, ds_hook, NULL);
+}
+
+/* ---- EventsSorter / L1MessagesSorter (types 11 / 12) ---- */
+CF_SPEC(ES);
+void orc_es_fill_closed_form(const zkw_events_sorter_instance *first, const zkw_events_sorter_instance *in, uint32_t capacity, size_t n_rows,
+                             uint64_t *trace) {
+    uint64_t oi[18], oo[9], fi[80], fo[80], flags[2] = {in->start_flag ? 1u : 0u, in->completion_flag ? 1u : 0u};
+    orc_put_queue4(&first->initial_log_queue_state, oi);
+    orc_put_queue4(&first->intermediate_sorted_queue_state, oi + 9);
+    orc_put_queue4(&in->final_queue_state, oo);
+    orc_es_fsm(&in->hidden_fsm_input, fi);
+    orc_es_fsm(&in->hidden_fsm_output, fo);
+    const uint64_t *src[5] = {oi, fi, fo, flags, oo};
+    cf_fill(&CF_ES, trace, n_rows, (size_t)ES_BOUNDARY_ROW(capacity), src, NULL, NULL);
+}
+
+/* ---- LogDemuxer (type 4) ---- */
+CF_SPEC(LD);
+void orc_ld_fill_closed_form(const zkw_log_demux_instance *first, const zkw_log_demux_instance *in, uint32_t capacity, size_t n_rows, uint64_t *trace) {
+    uint64_t oi[9], oo[64], fi[64], fo[64], flags[2] = {in->start_flag ? 1u : 0u, in->completion_flag ? 1u : 0u};
+    orc_put_queue4(&first->initial_log_queue_state, oi);
+    size_t m = 0;
+    for (int c = 0; c < ZKW_DEMUX_NUM_QUEUES; c++) m += orc_put_queue4(&in->output_queue_state[c], oo + m);
+    orc_ld_fsm(&in->hidden_fsm_input, fi);
+    orc_ld_fsm(&in->hidden_fsm_output, fo);
+    const uint64_t *src[5] = {oi, fi, fo, flags, oo};
+    cf_fill(&CF_LD, trace, n_rows, (size_t)LD_BOUNDARY_ROW(capacity), src, NULL, NULL);
+}
+
+/* ---- StorageSorter (type 9) ---- */
+CF_SPEC(SS);
+void orc_ss_fill_closed_form(const zkw_storage_sorter_instance *first, const zkw_storage_sorter_instance *in, uint32_t capacity, size_t n_rows,
+                             uint64_t *trace) {
+    uint64_t oi[19], oo[9], fi[80], fo[80], flags[2] = {in->start_flag ? 1u : 0u, in->completion_flag ? 1u : 0u};
+    oi[0] = first->shard_id_to_process;
+    orc_put_queue4(&first->unsorted_log_queue_state, oi + 1);
+    orc_put_queue4(&first->intermediate_sorted_queue_state, oi + 10);
+    orc_put_queue4(&in->final_sorted_queue_state, oo);
+    orc_ss_fsm(&in->hidden_fsm_input, fi);
+    orc_ss_fsm(&in->hidden_fsm_output, fo);
+    const uint64_t *src[5] = {oi, fi, fo, flags, oo};
+    cf_fill(&CF_SS, trace, n_rows, (size_t)SS_BOUNDARY_ROW(capacity), src, NULL, NULL);
 }

@@ -245,8 +245,7 @@ int orc_events_sorter_synthesize(const zkw_events_sorter_instance *inst, const z
         if (cur.completion && !cur.z_end) return -7;
     }
 
-    if (public_input)
-        for (int k = 0; k < 4; k++) CELL(ES_PI_pi0 + k, bnd + ES_ROWOFF_PI) = public_input[k];
+    (void)public_input; /* the PI row is derived by the closed-form section (orc_es_fill_closed_form, closed_form_fill.c), which runs next */
     for (int t = 0; t < 256; t++) CELL(ES_MULT_COL, t) = 0;
     for (int c = ES_G; c < ES_G + ES_L; c++)
         for (size_t r = 0; r < n_rows; r++) {

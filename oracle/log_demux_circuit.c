@@ -160,8 +160,7 @@ int orc_log_demux_synthesize(const zkw_log_demux_instance *inst, const uint64_t 
         if (cur.completion && !cur.z_end) return -7;
     }
 
-    if (public_input)
-        for (int k = 0; k < 4; k++) CELL(LD_PI_pi0 + k, bnd + LD_ROWOFF_PI) = public_input[k];
+    (void)public_input; /* the PI row is derived by the closed-form section (orc_ld_fill_closed_form, closed_form_fill.c), which runs next */
     for (int t = 0; t < 256; t++) CELL(LD_MULT_COL, t) = 0;
     for (int c = LD_G; c < LD_G + LD_L; c++)
         for (size_t r = 0; r < n_rows; r++) {

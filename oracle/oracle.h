@@ -298,6 +298,16 @@ void orc_ram_fill_public_input(const zkw_ram_instance *first, const zkw_ram_inst
                                size_t n_rows, uint64_t *trace);
 /* the closed-form sections of the other queue circuits (closed_form_fill.c): after orc_*_synthesize; `first` = the block's first instance */
 size_t orc_put_queue12(const zkw_queue_state12 *q, uint64_t *o);
+size_t orc_put_queue4(const zkw_queue_state4 *q, uint64_t *o);
+size_t orc_es_fsm(const zkw_events_sorter_fsm *f, uint64_t *o); /* 68 words */
+size_t orc_ss_fsm(const zkw_storage_sorter_fsm *f, uint64_t *o); /* 77 words */
+size_t orc_ld_fsm(const zkw_log_demux_fsm *f, uint64_t *o);      /* 63 words */
+void orc_ld_fill_closed_form(const zkw_log_demux_instance *first, const zkw_log_demux_instance *in, uint32_t capacity, size_t n_rows,
+                             uint64_t *trace);
+void orc_ss_fill_closed_form(const zkw_storage_sorter_instance *first, const zkw_storage_sorter_instance *in, uint32_t capacity,
+                             size_t n_rows, uint64_t *trace);
+void orc_es_fill_closed_form(const zkw_events_sorter_instance *first, const zkw_events_sorter_instance *in, uint32_t capacity,
+                             size_t n_rows, uint64_t *trace);
 void orc_ds_fill_closed_form(const zkw_decommit_sorter_instance *first, const zkw_decommit_sorter_instance *in, uint32_t capacity,
                              size_t n_rows, uint64_t *trace);
 #define ORC_DS_FSM_ENC_LEN 100

@@ -143,7 +143,7 @@ void orc_ds_public_inputs(const zkw_decommit_sorter_instance *inst, size_t n, ui
    order = the struct declarations as mirrored by include/zkw_types.h (the reference's struct literals: log_demux.rs:
    283-301, storage_sort_dedup.rs:577-612, events_sort_dedup.rs:426-455); LogQuery in the declaration order of the
    in-circuit struct (absent crate). PARITY UNPINNED like the types above. */
-static size_t put_queue4(const zkw_queue_state4 *q, uint64_t *o) {
+size_t orc_put_queue4(const zkw_queue_state4 *q, uint64_t *o) {
     memcpy(o, q->head, 32);
     memcpy(o + 4, q->tail, 32);
     o[8] = q->length;
@@ -175,9 +175,9 @@ static void compact_and_pi(int start, int completion, const uint64_t *in, size_t
     orc_commit_var_length(cf, 18, pi);
 }
 
-static size_t ld_fsm(const zkw_log_demux_fsm *f, uint64_t *o) {
-    size_t m = put_queue4(&f->initial_log_queue_state, o);
-    for (int c = 0; c < ZKW_DEMUX_NUM_QUEUES; c++) m += put_queue4(&f->queue_state[c], o + m);
+size_t orc_ld_fsm(const zkw_log_demux_fsm *f, uint64_t *o) {
+    size_t m = orc_put_queue4(&f->initial_log_queue_state, o);
+    for (int c = 0; c < ZKW_DEMUX_NUM_QUEUES; c++) m += orc_put_queue4(&f->queue_state[c], o + m);
     return m;
 }
 void orc_log_demux_public_inputs(const zkw_log_demux_instance *inst, size_t n, uint64_t *compact, uint64_t *pi) {
@@ -185,21 +185,21 @@ void orc_log_demux_public_inputs(const zkw_log_demux_instance *inst, size_t n, u
     uint64_t in[16], out[64], fi[64], fo[64];
     for (size_t i = 0; i < n; i++) {
         if (inst[i].start_flag) first = inst + i;
-        const size_t n_in = put_queue4(&first->initial_log_queue_state, in);
+        const size_t n_in = orc_put_queue4(&first->initial_log_queue_state, in);
         size_t n_out = 0;
-        for (int c = 0; c < ZKW_DEMUX_NUM_QUEUES; c++) n_out += put_queue4(&inst[i].output_queue_state[c], out + n_out);
-        const size_t n_fi = ld_fsm(&inst[i].hidden_fsm_input, fi), n_fo = ld_fsm(&inst[i].hidden_fsm_output, fo);
+        for (int c = 0; c < ZKW_DEMUX_NUM_QUEUES; c++) n_out += orc_put_queue4(&inst[i].output_queue_state[c], out + n_out);
+        const size_t n_fi = orc_ld_fsm(&inst[i].hidden_fsm_input, fi), n_fo = orc_ld_fsm(&inst[i].hidden_fsm_output, fo);
         compact_and_pi(inst[i].start_flag, inst[i].completion_flag, in, n_in, out, n_out, fi, n_fi, fo, n_fo, compact + 18 * i, pi + 4 * i);
     }
 }
 
-static size_t es_fsm(const zkw_events_sorter_fsm *f, uint64_t *o) {
+size_t orc_es_fsm(const zkw_events_sorter_fsm *f, uint64_t *o) {
     size_t m = 0;
     for (int r = 0; r < 2; r++) o[m++] = f->lhs_accumulator[r];
     for (int r = 0; r < 2; r++) o[m++] = f->rhs_accumulator[r];
-    m += put_queue4(&f->initial_unsorted_queue_state, o + m);
-    m += put_queue4(&f->intermediate_sorted_queue_state, o + m);
-    m += put_queue4(&f->final_result_queue_state, o + m);
+    m += orc_put_queue4(&f->initial_unsorted_queue_state, o + m);
+    m += orc_put_queue4(&f->intermediate_sorted_queue_state, o + m);
+    m += orc_put_queue4(&f->final_result_queue_state, o + m);
     o[m++] = f->previous_key;
     return m + put_log_query(&f->previous_item, o + m);
 }
@@ -208,21 +208,21 @@ void orc_events_sorter_public_inputs(const zkw_events_sorter_instance *inst, siz
     uint64_t in[32], out[16], fi[80], fo[80];
     for (size_t i = 0; i < n; i++) {
         if (inst[i].start_flag) first = inst + i;
-        size_t n_in = put_queue4(&first->initial_log_queue_state, in);
-        n_in += put_queue4(&first->intermediate_sorted_queue_state, in + n_in);
-        const size_t n_out = put_queue4(&inst[i].final_queue_state, out);
-        const size_t n_fi = es_fsm(&inst[i].hidden_fsm_input, fi), n_fo = es_fsm(&inst[i].hidden_fsm_output, fo);
+        size_t n_in = orc_put_queue4(&first->initial_log_queue_state, in);
+        n_in += orc_put_queue4(&first->intermediate_sorted_queue_state, in + n_in);
+        const size_t n_out = orc_put_queue4(&inst[i].final_queue_state, out);
+        const size_t n_fi = orc_es_fsm(&inst[i].hidden_fsm_input, fi), n_fo = orc_es_fsm(&inst[i].hidden_fsm_output, fo);
         compact_and_pi(inst[i].start_flag, inst[i].completion_flag, in, n_in, out, n_out, fi, n_fi, fo, n_fo, compact + 18 * i, pi + 4 * i);
     }
 }
 
-static size_t ss_fsm(const zkw_storage_sorter_fsm *f, uint64_t *o) {
+size_t orc_ss_fsm(const zkw_storage_sorter_fsm *f, uint64_t *o) {
     size_t m = 0;
     for (int r = 0; r < 2; r++) o[m++] = f->lhs_accumulator[r];
     for (int r = 0; r < 2; r++) o[m++] = f->rhs_accumulator[r];
-    m += put_queue4(&f->current_unsorted_queue_state, o + m);
-    m += put_queue4(&f->current_intermediate_sorted_queue_state, o + m);
-    m += put_queue4(&f->current_final_sorted_queue_state, o + m);
+    m += orc_put_queue4(&f->current_unsorted_queue_state, o + m);
+    m += orc_put_queue4(&f->current_intermediate_sorted_queue_state, o + m);
+    m += orc_put_queue4(&f->current_final_sorted_queue_state, o + m);
     o[m++] = f->cycle_idx;
     for (int k = 0; k < ZKW_STORAGE_PACKED_KEY_LENGTH; k++) o[m++] = f->previous_packed_key[k];
     for (int k = 0; k < 8; k++) o[m++] = f->previous_key[k];
@@ -240,10 +240,10 @@ void orc_storage_sorter_public_inputs(const zkw_storage_sorter_instance *inst, s
     for (size_t i = 0; i < n; i++) {
         if (inst[i].start_flag) first = inst + i;
         in[0] = first->shard_id_to_process;
-        size_t n_in = 1 + put_queue4(&first->unsorted_log_queue_state, in + 1);
-        n_in += put_queue4(&first->intermediate_sorted_queue_state, in + n_in);
-        const size_t n_out = put_queue4(&inst[i].final_sorted_queue_state, out);
-        const size_t n_fi = ss_fsm(&inst[i].hidden_fsm_input, fi), n_fo = ss_fsm(&inst[i].hidden_fsm_output, fo);
+        size_t n_in = 1 + orc_put_queue4(&first->unsorted_log_queue_state, in + 1);
+        n_in += orc_put_queue4(&first->intermediate_sorted_queue_state, in + n_in);
+        const size_t n_out = orc_put_queue4(&inst[i].final_sorted_queue_state, out);
+        const size_t n_fi = orc_ss_fsm(&inst[i].hidden_fsm_input, fi), n_fo = orc_ss_fsm(&inst[i].hidden_fsm_output, fo);
         compact_and_pi(inst[i].start_flag, inst[i].completion_flag, in, n_in, out, n_out, fi, n_fi, fo, n_fo, compact + 18 * i, pi + 4 * i);
     }
 }
@@ -313,7 +313,7 @@ static size_t pre_fsm(int kind, const zkw_precompile_fsm *f, uint64_t *o) {
         o[m++] = f->output_offset;
         o[m++] = f->num_rounds;
     }
-    m += put_queue4(&f->log_queue_state, o + m);
+    m += orc_put_queue4(&f->log_queue_state, o + m);
     m += orc_put_queue12(&f->memory_queue_state, o + m);
     return m;
 }
@@ -322,7 +322,7 @@ static size_t pre_fsm(int kind, const zkw_precompile_fsm *f, uint64_t *o) {
 static size_t sap_fsm(const zkw_storage_application_fsm *f, uint64_t *o) {
     size_t m = put_bytes(f->current_root_hash, 32, o);
     m += put_u32s(f->next_enumeration_counter, 2, o + m);
-    m += put_queue4(&f->current_storage_application_log_state, o + m);
+    m += orc_put_queue4(&f->current_storage_application_log_state, o + m);
     m += put_bytes(f->current_diffs_keccak_accumulator_state, 200, o + m);
     return m;
 }
@@ -354,7 +354,7 @@ int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_
                 if (w[i].start_flag) first = i;
                 start = w[i].start_flag; completion = w[i].completion_flag;
                 /* PrecompileFunctionInputData { initial_log_queue_state, initial_memory_queue_state } */
-                n_in = put_queue4(&w[first].initial_log_queue_state, in);
+                n_in = orc_put_queue4(&w[first].initial_log_queue_state, in);
                 n_in += orc_put_queue12(&w[first].initial_memory_queue_state, in + n_in);
                 n_out = orc_put_queue12(&w[i].final_memory_state, out);
                 n_fi = pre_fsm(kind, &w[i].hidden_fsm_input, fi);
@@ -370,7 +370,7 @@ int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_
                 in[0] = w[first].shard;
                 n_in = 1 + put_bytes(w[first].initial_root_hash, 32, in + 1);
                 n_in += put_u32s(w[first].initial_next_enumeration_counter, 2, in + n_in);
-                n_in += put_queue4(&w[first].storage_application_log_state, in + n_in);
+                n_in += orc_put_queue4(&w[first].storage_application_log_state, in + n_in);
                 /* StorageApplicationOutputData { new_root_hash, new_next_enumeration_counter, state_diffs_keccak256_hash } */
                 n_out = put_bytes(w[i].new_root_hash, 32, out);
                 n_out += put_u32s(w[i].new_next_enumeration_counter, 2, out + n_out);
@@ -382,7 +382,7 @@ int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_
             case 13: {
                 const zkw_linear_hasher_instance *w = (const zkw_linear_hasher_instance *)instances;
                 start = w[i].start_flag; completion = w[i].completion_flag;
-                n_in = put_queue4(&w[i].queue_state, in);      /* LinearHasherInputData { queue_state } */
+                n_in = orc_put_queue4(&w[i].queue_state, in);      /* LinearHasherInputData { queue_state } */
                 n_out = put_bytes(w[i].keccak256_hash, 32, out); /* LinearHasherOutputData { keccak256_hash } */
                 break;                                          /* hidden FSM = (): nothing absorbed */
             }

@@ -1129,11 +1129,12 @@ def events_sorter_synthesize(build_out, instance_index, capacity, n_rows):
     inst = o["instances"][instance_index:instance_index + 1]
     f = lib().orc_events_sorter_synthesize
     f.restype = C.c_int
-    pi = events_sorter_public_inputs(o["instances"])[1][instance_index:instance_index + 1].copy()
     rc = f(_p(inst), _p(o["sorted_q"]), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), None, C.c_uint32(0),
-           _p(pi), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+           None, C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_events_sorter_synthesize failed: {rc}")
+    first = o["instances"][0:1]  # one block: its first instance carries the shared observable input
+    lib().orc_es_fill_closed_form(_p(first), _p(inst), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     return trace
 
 
@@ -1158,10 +1159,11 @@ def log_demux_synthesize(build_out, instance_index, capacity, n_rows):
     enc = o["in_enc"] if o["in_enc"].size else np.zeros((1, 20), np.uint64)
     f = lib().orc_log_demux_synthesize
     f.restype = C.c_int
-    pi = log_demux_public_inputs(o["instances"])[1][instance_index:instance_index + 1].copy()
-    rc = f(_p(inst), _p(enc), _p(pi), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
+    rc = f(_p(inst), _p(enc), None, C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_log_demux_synthesize failed: {rc}")
+    first = o["instances"][0:1]  # one block: its first instance carries the shared observable input
+    lib().orc_ld_fill_closed_form(_p(first), _p(inst), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     return trace
 
 
@@ -1185,11 +1187,12 @@ def storage_sorter_synthesize(build_out, instance_index, capacity, n_rows):
     inst = o["instances"][instance_index:instance_index + 1]
     f = lib().orc_storage_sorter_synthesize
     f.restype = C.c_int
-    pi = storage_sorter_public_inputs(o["instances"])[1][instance_index:instance_index + 1].copy()
-    rc = f(_p(inst), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), _p(pi), C.c_uint32(capacity), C.c_size_t(n_rows),
+    rc = f(_p(inst), _p(o["unsorted_enc"]), _p(o["sorted_enc"]), _p(o["challenges"]), None, C.c_uint32(capacity), C.c_size_t(n_rows),
            _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_storage_sorter_synthesize failed: {rc}")
+    first = o["instances"][0:1]  # one block: its first instance carries the shared observable input
+    lib().orc_ss_fill_closed_form(_p(first), _p(inst), C.c_uint32(capacity), C.c_size_t(n_rows), _p(trace))
     return trace
 
 

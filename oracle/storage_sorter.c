@@ -56,6 +56,10 @@ int64_t orc_storage_sorter_build(const zkw_log_query *q, size_t n, uint32_t capa
         w->start_flag = w->completion_flag = 1;
         for (int r = 0; r < 2; r++) w->hidden_fsm_output.lhs_accumulator[r] = w->hidden_fsm_output.rhs_accumulator[r] = 1;
         w->hidden_fsm_output.cycle_idx = 4; /* the reference's hack, :45 */
+        { /* the circuit derives its challenges whatever the queue holds (the trace's closed-form section does): those of two empty queues */
+            const uint64_t z4[4] = {0};
+            orc_fs_challenges(z4, 0, z4, 0, 4, 21, challenges);
+        }
         return 1;
     }
     const uint64_t zero4[4] = {0};

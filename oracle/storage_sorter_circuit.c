@@ -302,8 +302,7 @@ int orc_storage_sorter_synthesize(const zkw_storage_sorter_instance *inst, const
         if (cur.completion && (pr.lhs[0] != pr.rhs[0] || pr.lhs[1] != pr.rhs[1])) return -11;
     }
 
-    if (public_input)
-        for (int k = 0; k < 4; k++) CELL(SS_PI_pi0 + k, bnd + SS_ROWOFF_PI) = public_input[k];
+    (void)public_input; /* the PI row is derived by the closed-form section (orc_ss_fill_closed_form, closed_form_fill.c), which runs next */
     for (int t = 0; t < 256; t++) CELL(SS_MULT_COL, t) = 0;
     for (int c = SS_G; c < SS_G + SS_L; c++)
         for (size_t r = 0; r < n_rows; r++) {

@@ -82,7 +82,7 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
     assert ctx.check_if_satisfied_log_demux(t, 0, capacity)[0] == 0
     host = t.get(0)
     rng = np.random.default_rng(2)
-    used = np.argwhere(host[:150, :12 * 64 + 2] != 0)  # not the (unconstrained) PI row
+    used = np.argwhere(host[:150, :12 * 64 + 33] != 0)
     base = native.load().zkw_trace_device_ptr(t.handle, 0)
     hip = C.CDLL("libamdhip64.so")
     for _ in range(25):
@@ -95,6 +95,10 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
         assert ctx.check_if_satisfied_log_demux(t, 0, capacity)[0] > 0, (c, r)
         hip.hipMemcpy(C.c_void_p(addr), old.ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
     assert ctx.check_if_satisfied_log_demux(t, 0, capacity)[0] == 0
+    # the closed-form section: challenges, start-flag selection, commitments, public input — same verdict as the oracle's checker
+    from closed_form_case import gpu_tamper_parity, log_demux_tampers
+    gpu_tamper_parity(base, n_rows, host, lambda: ctx.check_if_satisfied_log_demux(t, 0, capacity), lambda h: oracle.log_demux_check(h, capacity),
+                      log_demux_tampers(capacity))
     t.free()
 
 

@@ -53,7 +53,7 @@ def test_checker_notices_tampering(oracle):
     t = oracle.events_sorter_synthesize(o, 0, capacity, n_rows)
     assert oracle.events_sorter_check(t, capacity)[0] == 0
     rng = np.random.default_rng(1)
-    used = [(c, r) for c in range(138) for r in range(_bnd(capacity) + 5) if t[c, r] != 0]
+    used = [(c, r) for c in range(138) for r in range(_bnd(capacity) + 40) if t[c, r] != 0]
     for _ in range(40):
         c, r = used[rng.integers(len(used))]
         t2 = t.copy()
@@ -71,3 +71,16 @@ def test_empty_queue_dummy_instance(oracle):
     bout = t[:, _bnd(16) + 1]
     fo = o["instances"][0]["hidden_fsm_output"]
     assert [int(bout[names[k]]) for k in ("lhs0", "lhs1", "rhs0", "rhs1")] == [1, 1, 1, 1] == [int(x) for x in fo["lhs_accumulator"]] + [int(x) for x in fo["rhs_accumulator"]]
+
+
+def test_closed_form_section(oracle):
+    """challenges, start-flag selection, commitments and the PI row are derived in-trace (gen_ram_circuit.ClosedForm)"""
+    from closed_form_case import check_section, events_sorter_tampers
+
+    capacity, n_rows = 32, 2048
+    o = oracle.events_sorter_build(synthetic.events_trace(60, 0.3, seed=6), capacity)
+    n = o["instances"].size
+    assert n >= 3
+    check_section(lambda i: oracle.events_sorter_synthesize(o, i, capacity, n_rows), lambda t: oracle.events_sorter_check(t, capacity),
+                  oracle.events_sorter_public_inputs(o["instances"])[1], "zkw_events_sorter_circuit_spec.h", "ES", 22, capacity, n,
+                  events_sorter_tampers(capacity), challenges=o["challenges"].reshape(2, 21))

@@ -63,7 +63,7 @@ def test_checker_notices_tampering(oracle):
     t = oracle.log_demux_synthesize(o, 0, capacity, n_rows)
     assert oracle.log_demux_check(t, capacity)[0] == 0
     rng = np.random.default_rng(1)
-    used = [(c, r) for c in range(150) for r in range(_bnd(capacity) + 2) if t[c, r] != 0]  # the PI row is unconstrained
+    used = [(c, r) for c in range(150) for r in range(_bnd(capacity) + 33) if t[c, r] != 0]
     for _ in range(40):
         c, r = used[rng.integers(len(used))]
         t2 = t.copy()
@@ -101,3 +101,16 @@ def test_public_input_row_and_compact_forms(oracle):
     assert len({tuple(p) for p in pi.tolist()}) == n_inst
     t = oracle.log_demux_synthesize(o, 1, capacity, n_rows)
     assert t[:4, _bnd(capacity) + 2].tolist() == pi[1].tolist()
+
+
+def test_closed_form_section(oracle):
+    """start-flag selection, commitments and the PI row are derived in-trace (gen_ram_circuit.ClosedForm); no challenges in this circuit"""
+    from closed_form_case import check_section, log_demux_tampers
+
+    capacity, n_rows = 64, 2048
+    o = oracle.log_demux_build(synthetic.mixed_log_queue(170, seed=6), capacity)
+    n = o["instances"].size
+    assert n == 3
+    check_section(lambda i: oracle.log_demux_synthesize(o, i, capacity, n_rows), lambda t: oracle.log_demux_check(t, capacity),
+                  oracle.log_demux_public_inputs(o["instances"])[1], "zkw_log_demux_circuit_spec.h", "LD", 12, capacity, n,
+                  log_demux_tampers(capacity))

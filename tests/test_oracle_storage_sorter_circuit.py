@@ -72,7 +72,7 @@ def test_checker_notices_tampering(oracle):
     t = oracle.storage_sorter_synthesize(o, 0, capacity, n_rows)
     assert oracle.storage_sorter_check(t, capacity)[0] == 0
     rng = np.random.default_rng(1)
-    used = [(c, r) for c in range(148) for r in range(_bnd(capacity) + 5) if t[c, r] != 0]  # the PI row is unconstrained
+    used = [(c, r) for c in range(148) for r in range(_bnd(capacity) + 43) if t[c, r] != 0]
     for _ in range(40):
         c, r = used[rng.integers(len(used))]
         t2 = t.copy()
@@ -103,3 +103,16 @@ def test_empty_queue_dummy_instance(oracle):
     bout = t[:, _bnd(16) + 1]
     fo = o["instances"][0]["hidden_fsm_output"]
     assert [int(bout[names[k]]) for k in ("lhs0", "lhs1", "rhs0", "rhs1")] == [1, 1, 1, 1] == [int(x) for x in fo["lhs_accumulator"]] + [int(x) for x in fo["rhs_accumulator"]]
+
+
+def test_closed_form_section(oracle):
+    """challenges, start-flag selection, commitments and the PI row are derived in-trace (gen_ram_circuit.ClosedForm)"""
+    from closed_form_case import check_section, storage_sorter_tampers
+
+    capacity, n_rows = 32, 2048
+    o = oracle.storage_sorter_build(synthetic.storage_trace(90, 7, seed=6), capacity)
+    n = o["instances"].size
+    assert n == 3
+    check_section(lambda i: oracle.storage_sorter_synthesize(o, i, capacity, n_rows), lambda t: oracle.storage_sorter_check(t, capacity),
+                  oracle.storage_sorter_public_inputs(o["instances"])[1], "zkw_storage_sorter_circuit_spec.h", "SS", 22, capacity, n,
+                  storage_sorter_tampers(capacity), challenges=o["challenges"].reshape(2, 21))

@@ -200,7 +200,65 @@ def build():
     for k in range(4):
         PI.slot(f"pi{k}")
 
-    rows = U + S + R + [A] + N + [T, V, W, Q, BIN, BOUT] + F + [PI]
+    # ---------------- closed-form section (gen_ram_circuit.ClosedForm): what the reference's circuit derives in-trace
+    cf = dsl.ClosedForm()
+    SRC = dsl.ClosedForm
+    # observable input (EventsDeduplicatorInputData: initial_log_queue_state, intermediate_sorted_queue_state; head 4, tail 4, length)
+    OI = cf.sponge("OI", [None] * 18, free_src=SRC.SRC_OBS_IN)
+    oi = lambda w: cf.word_cell(OI, w)  # noqa: E731
+    # hidden FSM input (EventsDeduplicatorFSMInputOutput, events_sort_dedup.rs:426-455): lhs 0, rhs 2, unsorted queue 4, sorted queue 13,
+    # result queue 22, previous_key 31, previous_item 32 (LogQuery: address 5, key 8, read 8, written 8, rw, aux, rollback, service, shard, tx, timestamp)
+    FI = cf.sponge("FI", [None] * 68, free_src=SRC.SRC_FSM_IN)
+    fi = lambda w: cf.word_cell(FI, w)  # noqa: E731
+    SEL = dsl.Selections(cf, "SEL")
+    for qi, q in enumerate(("u", "s")):
+        for k in range(4):
+            SEL.sel3(oi(9 * qi + k), fi(4 + 9 * qi + k), (BIN, f"{q}h{k}"))
+            SEL.sel3(oi(9 * qi + 4 + k), fi(4 + 9 * qi + 4 + k), (BOUT, f"tail_{q}{k}"))
+        SEL.sel3(oi(9 * qi + 8), fi(4 + 9 * qi + 8), (BIN, f"len_{q}"))
+    for k in range(4):
+        SEL.sel2(0, fi(22 + 4 + k), (BIN, f"rh{k}"))  # the result queue starts empty (the reference's callers hand in a fresh simulator)
+    SEL.sel2(0, fi(30), (BIN, "len_r"))
+    for r in range(2):
+        SEL.sel2(1, fi(r), (BIN, f"lhs{r}"))
+        SEL.sel2(1, fi(2 + r), (BIN, f"rhs{r}"))
+    SEL.sel2(0, fi(31), (BIN, "kts"))
+    SEL.sel2(0, fi(32 + 31), (BIN, "krb"))
+    SEL.not_flag((BIN, "valid"))
+    # ne (the previous record's normalised encoding, what a later cycle pushes): zero at the start; for a continuing instance the FSM's
+    # previous_item is only committed — its 52 key / address bytes re-encoded in-trace would take nine more rows
+    for k in range(20):
+        SEL.zero_if_flag((BIN, f"ne{k}"))
+    # hidden FSM output: the registers after the last cycle
+    OSEL = dsl.Selections(cf, "OSEL", flag_cell=(BOUT, "completion"))
+    fo_key = OSEL.free_unless_flag((BOUT, "kts"), SRC.SRC_FSM_OUT, 31)  # a completing instance hands over placeholders (:174-181 of the sorter builders)
+    fo_rb = OSEL.free_unless_flag((BOUT, "krb"), SRC.SRC_FSM_OUT, 32 + 31)
+    q9 = lambda h, q: [(BOUT, f"{h}{k}") for k in range(4)] + [(BOUT, f"tail_{q}{k}") for k in range(4)] + [(BOUT, f"len_{q}")]  # noqa: E731
+    fo_words = ([(BOUT, f"lhs{r}") for r in range(2)] + [(BOUT, f"rhs{r}") for r in range(2)] + q9("uh", "u") + q9("sh", "s") +
+                [("const", 0)] * 4 + [(BOUT, f"final_rh{k}") for k in range(4)] + [(BOUT, "final_len_r")] + [fo_key] + [None] * 31 + [fo_rb] + [None] * 4)
+    assert len(fo_words) == 68
+    FO = cf.sponge("FO", fo_words, free_src=SRC.SRC_FSM_OUT)
+    # observable output (final_queue_state): completion ? the result queue after the flush : the placeholder (zeros)
+    oo_words = [("const", 0)] * 4 + [OSEL.gate((BOUT, f"final_rh{k}")) for k in range(4)] + [OSEL.gate((BOUT, "final_len_r"))]
+    pos = cf.rows.index(FO[0])
+    cf.rows[pos:pos] = OSEL.rows
+    OO = cf.sponge("OO", oo_words)
+    # Fiat-Shamir challenges over the observable input's queue tails and lengths (events_sort_dedup.rs:104-116): 10 words, 40 challenges
+    fs_words = [oi(4 + k) for k in range(4)] + [oi(8)] + [oi(9 + 4 + k) for k in range(4)] + [oi(17)]
+    CH = cf.sponge("CH", fs_words, squeeze=4)
+    dsl.challenge_links(cf, BIN, CH, 2, 20)
+    last = lambda rows_: rows_[-1]  # noqa: E731
+    cp_words = [SEL.flag(), (BOUT, "completion")]
+    for sp in (OI, OO, FI, FO):
+        cp_words += [(last(sp), f"{last(sp).name}_o{k}") for k in range(4)]
+    CP = cf.sponge("CP", cp_words)
+    for k in range(4):
+        cf.copy(PI, f"pi{k}", last(CP), f"{last(CP).name}_o{k}")
+    pos = cf.rows.index(last(FI)) + 1
+    cf.rows[pos:pos] = SEL.rows  # fill order: a row's copies come from rows before it (or from the register rows)
+    build.cf = cf
+
+    rows = U + S + R + [A] + N + [T, V, W, Q, BIN, BOUT] + F + [PI] + cf.rows
     return rows, regs
 
 
@@ -243,7 +301,7 @@ def links_of(rows, regs):
                 links.append((4, ri, col, rows.index(BOUT), BOUT.slot(v[2:]), 0))
             elif v.startswith("y."):
                 links.append((5, ri, col, bhome[v[2:]][0], bhome[v[2:]][1], 0))
-    return links
+    return links + build.cf.resolve(rows)
 
 
 def emit_scatter(rows, path, prefix):
@@ -281,7 +339,8 @@ if __name__ == "__main__":
                       title=("/* GENERATED by tools/gen_events_sorter_circuit.py — do not edit. Layout contract of the EventsSorter /",
                              " * L1MessagesSorter trace emitted by zkw_events_sorter_synthesize (\"zkw trace v2\"). */",
                              "#include \"zkw_ram_circuit_spec.h\" /* rc_term, rc_constraint, rc_link */"),
-                      poseidon_rows=("U1", "U2", "U3", "S1", "S2", "S3", "R1", "R2", "R3", "F1", "F2", "F3"), shared_types=True)
+                      poseidon_rows=("U1", "U2", "U3", "S1", "S2", "S3", "R1", "R2", "R3", "F1", "F2", "F3") + tuple(build.cf.p2_names),
+                      shared_types=True, cf_tables=build.cf.tables(rows, build.cf.rows))
     emit_scatter(rows, path, "ES")
     for r in rows:
         print(f"{r.name:8s} slots {len(r.slots):3d} lookups {len(r.lookups):2d} constraints {len(r.constraints)}")

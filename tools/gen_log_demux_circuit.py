@@ -100,7 +100,47 @@ def build():
     for k in range(4):
         PI.slot(f"pi{k}")
 
-    rows = I + Pp + X + [R, Q, BIN, BOUT, PI]
+    # ---------------- closed-form section (gen_ram_circuit.ClosedForm): what the reference's circuit derives in-trace
+    cf = dsl.ClosedForm()
+    SRC = dsl.ClosedForm
+    OI = cf.sponge("OI", [None] * 9, free_src=SRC.SRC_OBS_IN)  # LogDemuxerInputData: initial_log_queue_state (head 4, tail 4, length)
+    oi = lambda w: cf.word_cell(OI, w)  # noqa: E731
+    # hidden FSM input (LogDemuxerFSMInputOutput, log_demux.rs:283-301): the input queue, then the six output queues
+    FI = cf.sponge("FI", [None] * 63, free_src=SRC.SRC_FSM_IN)
+    fi = lambda w: cf.word_cell(FI, w)  # noqa: E731
+    SEL = dsl.Selections(cf, "SEL")
+    for k in range(4):
+        SEL.sel3(oi(k), fi(k), (BIN, f"ih{k}"))
+        SEL.sel3(oi(4 + k), fi(4 + k), (BOUT, f"tail_i{k}"))
+    SEL.sel3(oi(8), fi(8), (BIN, "len_i"))
+    for c, q in enumerate(QUEUES):  # the output queues start empty (log_demux.rs:110-168)
+        for k in range(4):
+            SEL.sel2(0, fi(9 + 9 * c + 4 + k), (BIN, f"qt_{q}{k}"))
+        SEL.sel2(0, fi(9 + 9 * c + 8), (BIN, f"ql_{q}"))
+    # hidden FSM output: the registers after the last cycle
+    fo_words = [(BOUT, f"ih{k}") for k in range(4)] + [(BOUT, f"tail_i{k}") for k in range(4)] + [(BOUT, "len_i")]
+    for q in QUEUES:
+        fo_words += [("const", 0)] * 4 + [(BOUT, f"qt_{q}{k}") for k in range(4)] + [(BOUT, f"ql_{q}")]
+    FO = cf.sponge("FO", fo_words)
+    # observable output (the six queues): completion ? the registers : the placeholder (zeros)
+    OSEL = dsl.Selections(cf, "OSEL", flag_cell=(BOUT, "completion"))
+    oo_words = []
+    for q in QUEUES:
+        oo_words += [("const", 0)] * 4 + [OSEL.gate((BOUT, f"qt_{q}{k}")) for k in range(4)] + [OSEL.gate((BOUT, f"ql_{q}"))]
+    cf.rows += OSEL.rows
+    OO = cf.sponge("OO", oo_words)
+    last = lambda rows_: rows_[-1]  # noqa: E731
+    cp_words = [SEL.flag(), (BOUT, "completion")]
+    for sp in (OI, OO, FI, FO):
+        cp_words += [(last(sp), f"{last(sp).name}_o{k}") for k in range(4)]
+    CP = cf.sponge("CP", cp_words)
+    for k in range(4):
+        cf.copy(PI, f"pi{k}", last(CP), f"{last(CP).name}_o{k}")
+    pos = cf.rows.index(last(FI)) + 1
+    cf.rows[pos:pos] = SEL.rows  # fill order: a row's copies come from rows before it (or from the register rows)
+    esg.build.cf = cf  # links_of appends the section's copies
+
+    rows = I + Pp + X + [R, Q, BIN, BOUT, PI] + cf.rows
     return rows, regs
 
 
@@ -113,7 +153,8 @@ if __name__ == "__main__":
                       title=("/* GENERATED by tools/gen_log_demux_circuit.py — do not edit. Layout contract of the LogDemuxer trace",
                              " * emitted by zkw_log_demux_synthesize (\"zkw trace v2\"). */",
                              "#include \"zkw_ram_circuit_spec.h\" /* rc_term, rc_constraint, rc_link */"),
-                      poseidon_rows=("I1", "I2", "I3", "P1", "P2", "P3"), shared_types=True)
+                      poseidon_rows=("I1", "I2", "I3", "P1", "P2", "P3") + tuple(esg.build.cf.p2_names), shared_types=True,
+                      cf_tables=esg.build.cf.tables(rows, esg.build.cf.rows))
     esg.emit_scatter(rows, path, "LD")
     for r in rows:
         print(f"{r.name:8s} slots {len(r.slots):3d} lookups {len(r.lookups):2d} constraints {len(r.constraints)}")

@@ -217,12 +217,40 @@ class Selections:
         self.cf.products.append((row, t, "flag", b))  # nothing to copy it from: a fill computes it
         return (row, t)
 
+    def zero_if_flag(self, target, why=""):
+        """flag => target = 0 (nothing is said when the flag is clear)"""
+        row = self._row(1)
+        (t,) = self._names("t")
+        row.c([(1, ["flag", t])], why or f"flag => {target[1]} = 0")
+        self.cf.copy(row, t, *target)
+
+    def free_unless_flag(self, b_cell, src, idx, why=""):
+        """a fresh FREE cell w (word idx of fill source src) with flag = 0 => w = b; returns it (a sponge word copies it). With the
+        completion flag: a word of the hidden FSM output is the register unless the instance completes (nobody consumes that output, and the
+        reference's builders put placeholders there)"""
+        row = self._row(2)
+        b, w = self._names("bw")
+        row.c([(1, [w]), (-1, [b]), (-1, ["flag", w]), (1, ["flag", b])], why or f"(1 - flag) * (word - {b_cell[1]}) = 0")
+        self.cf.copy(row, b, *b_cell)
+        self.cf.free_cell(row, w, src, idx)
+        return (row, w)
+
     def not_flag(self, target, why=""):
         """target = 1 - flag"""
         row = self._row(1)
         (t,) = self._names("t")
         row.c([(1, [t]), (1, ["flag"]), (-1, [])], why or f"{target[1]} = 1 - flag")
         self.cf.copy(row, t, *target)
+
+
+def challenge_links(cf, BIN, CH, n_absorb, per_rep):
+    """BND_IN's g.c{rep}_{k} (k = 1..per_rep; challenge 0 is the constant ONE) are the squeezed words in order: eight per permutation,
+    the first eight from the state the last absorption left (produce_fs_challenges, utils.rs:520-548)"""
+    for rep in range(2):
+        for k in range(1, per_rep + 1):
+            j = per_rep * rep + k - 1
+            row = CH[n_absorb - 1 + j // 8]
+            cf.copy(BIN, f"g.c{rep}_{k}", row, f"{row.name}_o{j % 8}")
 
 
 def build():

@@ -239,7 +239,74 @@ def build():
     for k in range(4):
         PI.slot(f"pi{k}")
 
-    rows = U + S + R + [A] + X + [K, C1, C2, Q, BIN, BOUT] + F + [PI]
+    # ---------------- closed-form section (gen_ram_circuit.ClosedForm): what the reference's circuit derives in-trace
+    cf = dsl.ClosedForm()
+    SRC = dsl.ClosedForm
+    # observable input (StorageDeduplicatorInputData: shard_id_to_process, unsorted_log_queue_state, intermediate_sorted_queue_state)
+    OI = cf.sponge("OI", [None] * 19, free_src=SRC.SRC_OBS_IN)
+    oi = lambda w: cf.word_cell(OI, w)  # noqa: E731
+    # hidden FSM input (StorageDeduplicatorFSMInputOutput, storage_sort_dedup.rs:577-612): lhs 0, rhs 2, unsorted 4, sorted 13, result 22,
+    # cycle_idx 31, previous_packed_key 32 (13), previous_key 45 (8), previous_address 53 (5), previous_timestamp 58, has 59, base 60, current 68, depth 76
+    FI = cf.sponge("FI", [None] * 77, free_src=SRC.SRC_FSM_IN)
+    fi = lambda w: cf.word_cell(FI, w)  # noqa: E731
+    SEL = dsl.Selections(cf, "SEL")
+    for qi, q in enumerate(("u", "s")):
+        for k in range(4):
+            SEL.sel3(oi(1 + 9 * qi + k), fi(4 + 9 * qi + k), (BIN, f"{q}h{k}"))
+            SEL.sel3(oi(1 + 9 * qi + 4 + k), fi(4 + 9 * qi + 4 + k), (BOUT, f"tail_{q}{k}"))
+        SEL.sel3(oi(1 + 9 * qi + 8), fi(4 + 9 * qi + 8), (BIN, f"len_{q}"))
+    for k in range(4):
+        SEL.sel2(0, fi(22 + 4 + k), (BIN, f"rh{k}"))  # the result queue starts empty
+    SEL.sel2(0, fi(30), (BIN, "len_r"))
+    for r in range(2):
+        SEL.sel2(1, fi(r), (BIN, f"lhs{r}"))
+        SEL.sel2(1, fi(2 + r), (BIN, f"rhs{r}"))
+    SEL.sel2(0, oi(0), (BIN, "ksh"))  # the open cell's shard is the instance's shard once a cell is open
+    SEL.sel2(0, fi(58), (BIN, "kts"))
+    SEL.not_flag((BIN, "valid"))
+    SEL.sel2(0, fi(76), (BIN, "depth"))
+    SEL.sel2(0, fi(59), (BIN, "has"))
+    for k in range(8):
+        SEL.sel2(0, fi(60 + k), (BIN, f"base{k}"))
+        SEL.sel2(0, fi(68 + k), (BIN, f"cur{k}"))
+    # kc (the open cell's key as 3-byte chunks of the packed key's 52 bytes): zero at the start; for a continuing instance the FSM's
+    # previous_packed_key is only committed — re-chunking its bytes in-trace would take five more rows
+    for k in range(18):
+        SEL.zero_if_flag((BIN, kc[k]))
+    cf.copy(BIN, "cidx", *fi(31))  # cycle_idx is carried whatever the start flag says (storage_sort_dedup.rs:597)
+    # hidden FSM output: the registers after the last cycle; the words the builders replace by placeholders when the instance completes
+    # (nobody consumes them) are the registers unless completion
+    OSEL = dsl.Selections(cf, "OSEL", flag_cell=(BOUT, "completion"))
+    q9 = lambda h, q: [(BOUT, f"{h}{k}") for k in range(4)] + [(BOUT, f"tail_{q}{k}") for k in range(4)] + [(BOUT, f"len_{q}")]  # noqa: E731
+    unless = lambda reg, w: OSEL.free_unless_flag((BOUT, reg), SRC.SRC_FSM_OUT, w)  # noqa: E731
+    fo_words = ([(BOUT, f"lhs{r}") for r in range(2)] + [(BOUT, f"rhs{r}") for r in range(2)] + q9("uh", "u") + q9("sh", "s") +
+                [("const", 0)] * 4 + [(BOUT, f"final_rh{k}") for k in range(4)] + [(BOUT, "final_len_r")] + [unless("cidx", 31)] +
+                [None] * 26 + [unless("kts", 58), unless("has", 59)] + [unless(f"base{k}", 60 + k) for k in range(8)] +
+                [unless(f"cur{k}", 68 + k) for k in range(8)] + [unless("depth", 76)])
+    assert len(fo_words) == 77
+    cf.rows += OSEL.rows
+    FO = cf.sponge("FO", fo_words, free_src=SRC.SRC_FSM_OUT)
+    # observable output (final_sorted_queue_state): completion ? the result queue after the flush : the placeholder (zeros)
+    OS2 = dsl.Selections(cf, "OGATE", flag_cell=(BOUT, "completion"))
+    oo_words = [("const", 0)] * 4 + [OS2.gate((BOUT, f"final_rh{k}")) for k in range(4)] + [OS2.gate((BOUT, "final_len_r"))]
+    cf.rows += OS2.rows
+    OO = cf.sponge("OO", oo_words)
+    # Fiat-Shamir challenges over the observable input's queue tails and lengths (storage_sort_dedup.rs:120-130): 10 words, 40 challenges
+    fs_words = [oi(1 + 4 + k) for k in range(4)] + [oi(9)] + [oi(10 + 4 + k) for k in range(4)] + [oi(18)]
+    CH = cf.sponge("CH", fs_words, squeeze=4)
+    dsl.challenge_links(cf, BIN, CH, 2, 20)
+    last = lambda rows_: rows_[-1]  # noqa: E731
+    cp_words = [SEL.flag(), (BOUT, "completion")]
+    for sp in (OI, OO, FI, FO):
+        cp_words += [(last(sp), f"{last(sp).name}_o{k}") for k in range(4)]
+    CP = cf.sponge("CP", cp_words)
+    for k in range(4):
+        cf.copy(PI, f"pi{k}", last(CP), f"{last(CP).name}_o{k}")
+    pos = cf.rows.index(last(FI)) + 1
+    cf.rows[pos:pos] = SEL.rows  # fill order: a row's copies come from rows before it (or from the register rows)
+    esg.build.cf = cf  # links_of appends the section's copies
+
+    rows = U + S + R + [A] + X + [K, C1, C2, Q, BIN, BOUT] + F + [PI] + cf.rows
     return rows, regs
 
 
@@ -252,7 +319,8 @@ if __name__ == "__main__":
                       title=("/* GENERATED by tools/gen_storage_sorter_circuit.py — do not edit. Layout contract of the StorageSorter trace",
                              " * emitted by zkw_storage_sorter_synthesize (\"zkw trace v2\"). */",
                              "#include \"zkw_ram_circuit_spec.h\" /* rc_term, rc_constraint, rc_link */"),
-                      poseidon_rows=("U1", "U2", "U3", "S1", "S2", "S3", "R1", "R2", "R3", "F1", "F2", "F3"), shared_types=True)
+                      poseidon_rows=("U1", "U2", "U3", "S1", "S2", "S3", "R1", "R2", "R3", "F1", "F2", "F3") + tuple(esg.build.cf.p2_names),
+                      shared_types=True, cf_tables=esg.build.cf.tables(rows, esg.build.cf.rows))
     esg.emit_scatter(rows, path, "SS")
     for r in rows:
         print(f"{r.name:8s} slots {len(r.slots):3d} lookups {len(r.lookups):2d} constraints {len(r.constraints)}")
