@@ -30,16 +30,19 @@ def test_layouts_against_reference_hints(tmp_path):
     assert {t: ref[t]["name"] for t in ref} == wire.CIRCUIT_NAMES
     table = wire.rows_used_table(ref)
     synth = {t for t, (_, _, ours) in table.items() if ours is not None}
-    assert synth == {2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13}
-    for t in (3, 5, 6, 10, 13):  # the netlist circuits: cycle-major, their own column counts
+    assert synth == {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13}
+    for t in (3, 5, 6, 7, 10, 13):  # the netlist circuits: cycle-major, their own column counts
         lay = native.circuit_layout(t)
         assert lay["fits"] and int(lay["region_stride"]) == 0 and int(lay["rows_used"]) + int(lay["nop_rows"]) == 1 << 20
         assert int(lay["rows_used"]) == table[t][2] <= (1 << 20)
         # the PI row closes the netlist part; types 6, 3, 5 and 13 carry their queue section (Poseidon2 rows of the pops / pushes) below it
-        q_rows = int(lay["rows_used"]) - int(lay["queue_first_row"]) if int(lay["queue_rows_per_cycle"]) else 0
-        assert (int(lay["queue_rows_per_cycle"]) > 0) == (t in (6, 3, 5, 13))
-        assert wire.finalization_hint_of_layout(t)["public_inputs"][0][1] == int(lay["rows_used"]) - q_rows - 1
-    for t in sorted(synth - {3, 5, 6, 10, 13}):
+        # (type 7 also its EC section below that, and its lookup tables are longer than its gates: rows_used = 197 632 table rows)
+        assert (int(lay["queue_rows_per_cycle"]) > 0) == (t in (6, 3, 5, 13, 7))
+        pi_row = int(lay["queue_first_row"]) - 1 if int(lay["queue_rows_per_cycle"]) else int(lay["rows_used"]) - 1
+        assert wire.finalization_hint_of_layout(t)["public_inputs"][0][1] == pi_row
+        if t == 7:
+            assert int(lay["ec_first_row"]) + int(lay["capacity"]) * int(lay["ec_rows_per_cycle"]) <= int(lay["rows_used"]) == int(lay["total_table_rows"])
+    for t in sorted(synth - {3, 5, 6, 7, 10, 13}):
         name, ref_rows, ours = table[t]
         lay = native.circuit_layout(t)
         geo = native.circuit_geometry(t)
@@ -56,6 +59,6 @@ def test_layouts_against_reference_hints(tmp_path):
         path = os.path.join(tmp_path, os.path.basename(wire.base_layer_paths(str(tmp_path), t)[1]))
         wire.dump(path, t, hint)
         assert wire.load(path) == (t, hint)
-    assert not native.circuit_layout(1)["synthesizable"] and not native.circuit_layout(7)["synthesizable"]
+    assert not native.circuit_layout(1)["synthesizable"]
     with pytest.raises(native.ZkwError):
         native.circuit_layout(14)
