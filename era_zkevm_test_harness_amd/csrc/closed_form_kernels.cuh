@@ -4,18 +4,21 @@
 // start-flag selection of the initial state (W/ram_permutation.rs:355-384) — as boundary rows: flattened Poseidon2 rows chained into
 // overwrite-mode sponges, selection rows, copies (tools/gen_ram_circuit.py, class ClosedForm).
 //
-// A few dozen rows per trace, strictly sequential (every sponge row takes the row before): one wave per trace walks the generated tables
-// row type by row type — the lanes share a row's copies / constants / FREE cells, 16 of them its permutation (p2::coop_flattened) — in the
-// boundary kernel of the circuit, after the fills the copies read. Nothing here is bandwidth: ~40 rows x 148 cells against a 2^20-row trace.
+// A few dozen rows per trace, strictly sequential (every sponge row takes the row before): one 256-lane block per trace walks the generated SCHEDULE
+// step by step (rows of one dependency level: the lanes share their copies / constants / FREE cells, every 16-lane DPP row runs one of their
+// permutations, p2::coop_flattened) — in the boundary kernel of the circuit, after the fills the copies read. Nothing here is bandwidth: ~40 rows x 148 cells against a 2^20-row trace.
 #pragma once
 #include "../../include/zkw_ram_circuit_spec.h"
 #include "poseidon2.cuh"
 
 namespace zkw {
 
+constexpr int CF_MAX_STEPS = 24, CF_MAX_STEP_ROWS = 64, CF_MAX_COPIES = 1024, CF_MAX_CONSTS = 128, CF_MAX_FREE = 256, CF_MAX_PRODUCTS = 64;  // LDS copies of the tables
 struct CfSpec {
-    int first, n, n_links, n_consts, n_free, n_products, rows_per_cycle, pi_row;
-    const rc_link* links;
+    int n_steps, rows_per_cycle, n_step_rows, n_copies, n_consts, n_free, n_products;
+    const rc_cf_step* steps;      // the parallel schedule of the spec header: rows grouped by dependency level, tables sorted by step
+    const uint8_t* step_rows;
+    const rc_cf_copy* copies;
     const uint8_t* is_poseidon;
     const rc_cf_const* consts;
     const rc_cf_free* frees;
@@ -24,76 +27,122 @@ struct CfSpec {
 
 // the section's tables of a spec header in constant memory, and the members a checker spec struct (SpecRam ...) exposes them through
 #define ZKW_CF_TABLES(PFX, pfx)                                                                                          \
+    static __constant__ rc_cf_step c_##pfx##_cf_steps[PFX##_CF_NUM_STEPS] = PFX##_CF_STEPS_INIT;                         \
+    static __constant__ uint8_t c_##pfx##_cf_step_rows[PFX##_CF_NUM_STEP_ROWS] = PFX##_CF_STEP_ROWS_INIT;                \
+    static __constant__ rc_cf_copy c_##pfx##_cf_copies[PFX##_CF_NUM_COPIES] = PFX##_CF_COPIES_INIT;                      \
     static __constant__ rc_cf_const c_##pfx##_cf_consts[PFX##_CF_NUM_CONSTS] = PFX##_CF_CONSTS_INIT;                     \
     static __constant__ rc_cf_free c_##pfx##_cf_free[PFX##_CF_NUM_FREE] = PFX##_CF_FREE_INIT;                            \
-    static __constant__ rc_cf_product c_##pfx##_cf_products[PFX##_CF_NUM_PRODUCTS ? PFX##_CF_NUM_PRODUCTS : 1] = PFX##_CF_PRODUCTS_INIT;
-#define ZKW_CF_SPEC_MEMBERS(PFX, pfx)                                                                                    \
-    __device__ static CfSpec cf_spec() {                                                                                 \
-        return CfSpec{PFX##_CF_FIRST_ROW_TYPE, PFX##_CF_NUM_ROWS, PFX##_NUM_LINKS, PFX##_CF_NUM_CONSTS, PFX##_CF_NUM_FREE, PFX##_CF_NUM_PRODUCTS, \
-                      PFX##_ROWS_PER_CYCLE, PFX##_ROW_PI, links(), is_poseidon(), c_##pfx##_cf_consts, c_##pfx##_cf_free, c_##pfx##_cf_products}; \
-    }
+    static __constant__ rc_cf_product c_##pfx##_cf_products[PFX##_CF_NUM_PRODUCTS ? PFX##_CF_NUM_PRODUCTS : 1] = PFX##_CF_PRODUCTS_INIT;       \
+    static_assert(PFX##_CF_NUM_STEPS <= CF_MAX_STEPS && PFX##_CF_NUM_STEP_ROWS <= CF_MAX_STEP_ROWS && PFX##_CF_NUM_COPIES <= CF_MAX_COPIES && \
+                  PFX##_CF_NUM_CONSTS <= CF_MAX_CONSTS && PFX##_CF_NUM_FREE <= CF_MAX_FREE && PFX##_CF_NUM_PRODUCTS <= CF_MAX_PRODUCTS, "closed-form tables outgrew their LDS copies");
+#define ZKW_CF_SPEC(PFX, pfx, is_poseidon_table)                                                                         \
+    CfSpec{PFX##_CF_NUM_STEPS, PFX##_ROWS_PER_CYCLE, PFX##_CF_NUM_STEP_ROWS, PFX##_CF_NUM_COPIES, PFX##_CF_NUM_CONSTS, PFX##_CF_NUM_FREE, PFX##_CF_NUM_PRODUCTS, c_##pfx##_cf_steps, c_##pfx##_cf_step_rows, c_##pfx##_cf_copies, is_poseidon_table, \
+           c_##pfx##_cf_consts, c_##pfx##_cf_free, c_##pfx##_cf_products}
+#define ZKW_CF_SPEC_MEMBERS(PFX, pfx) \
+    __device__ static CfSpec cf_spec() { return ZKW_CF_SPEC(PFX, pfx, is_poseidon()); }
 
 struct CfSources {  // LDS pointers; picked by a select chain (an array indexed at run time would live in scratch memory)
     const u64 *obs_in, *fsm_in, *fsm_out, *flags, *obs_out;
     __device__ __forceinline__ const u64* pick(int k) const { return k == 0 ? obs_in : k == 1 ? fsm_in : k == 2 ? fsm_out : k == 3 ? flags : obs_out; }
 };
 
-// src[k]: where the FREE cells of source k come from (0 observable input, 1 hidden FSM input, 2 hidden FSM output, 3 flags, 4 observable
-// output: encodings staged in LDS by the caller); bnd = first boundary row. hook(row_type, row) runs between a row's copies and its
-// permutation (all lanes call it). Called by every lane of a 64-lane block; the rows it copies from must be visible (barrier before).
+constexpr int CF_THREADS = 256;  // 16 DPP rows: up to 16 permutations of a step side by side
+
+// The walk, by a CF_THREADS-lane block. src: where the FREE cells come from (encodings staged in LDS by the caller: 0 observable input,
+// 1 hidden FSM input, 2 hidden FSM output, 3 flags, 4 observable output); bnd = first boundary row. hook(row_type, row) runs between a
+// row's copies / products and its permutation (all lanes call it, for every row of the step). The register rows the section copies from
+// must be written and visible (barrier before). A step = rows that depend only on earlier steps: their copies / constants / FREE cells
+// are shared by all lanes, their permutations run one per 16-lane DPP row (p2::coop_flattened) — the sponges of the observable input,
+// the FSM input and output and the challenges advance side by side, so a section costs its longest chain (12 - 19 steps), not its rows.
 template <class Hook>
-__device__ __forceinline__ void cf_fill_wave(const CfSpec& S, u64* __restrict__ trace, size_t n_rows, size_t bnd, const CfSources& src, Hook&& hook) {
+__device__ __forceinline__ void cf_fill_block(const CfSpec& S, u64* __restrict__ trace, size_t n_rows, size_t bnd, const CfSources& src, Hook&& hook) {
 #define CF_CELL(col, row) trace[(size_t)(col) * n_rows + (row)]
-    const u32 lane = threadIdx.x, g = lane & 15;
+#define CF_ROW(rt) (bnd + (size_t)((rt) - S.rows_per_cycle))
+    const u32 t = threadIdx.x, g = t & 15, grp = t >> 4;
+    // the tables in LDS: every step reads them with per-lane indices (from constant memory that is a vector load per read, in the
+    // dependent chain of every step)
+    __shared__ rc_cf_step sh_steps[CF_MAX_STEPS];
+    __shared__ uint8_t sh_step_rows[CF_MAX_STEP_ROWS];
+    __shared__ rc_cf_copy sh_copies[CF_MAX_COPIES];
+    __shared__ rc_cf_const sh_consts[CF_MAX_CONSTS];
+    __shared__ rc_cf_free sh_free[CF_MAX_FREE];
+    __shared__ rc_cf_product sh_products[CF_MAX_PRODUCTS];
+    for (int k = (int)t; k < S.n_steps; k += CF_THREADS) sh_steps[k] = S.steps[k];
+    for (int k = (int)t; k < S.n_step_rows; k += CF_THREADS) sh_step_rows[k] = S.step_rows[k];
+    for (int k = (int)t; k < S.n_copies; k += CF_THREADS) sh_copies[k] = S.copies[k];
+    for (int k = (int)t; k < S.n_consts; k += CF_THREADS) sh_consts[k] = S.consts[k];
+    for (int k = (int)t; k < S.n_free; k += CF_THREADS) sh_free[k] = S.frees[k];
+    for (int k = (int)t; k < S.n_products; k += CF_THREADS) sh_products[k] = S.products[k];
+    __syncthreads();
     p2::Coop co;
     co.init((int)g);
-    for (int r = S.first; r <= S.first + S.n; r++) {
-        const int rt = r < S.first + S.n ? r : S.pi_row;  // last: the public-input row takes its copies
-        const size_t row = bnd + (size_t)(rt - S.rows_per_cycle);
-        for (int l = (int)lane; l < S.n_links; l += 64) {
-            const rc_link k = S.links[l];
-            if (k.kind == 5 && k.row_a == rt) CF_CELL(k.col_a, row) = CF_CELL(k.col_b, bnd + (size_t)(k.row_b - S.rows_per_cycle));
+    for (int st = 0; st < S.n_steps; st++) {
+        const rc_cf_step s = sh_steps[st];
+        // the cells a step initialises are independent: all loads first, then the stores
+        u64 cv[CF_MAX_COPIES / CF_THREADS];
+#pragma unroll
+        for (int r = 0; r < CF_MAX_COPIES / CF_THREADS; r++) {
+            const int k = (int)t + r * CF_THREADS;
+            if (k < s.n_copies) { const rc_cf_copy c = sh_copies[s.copy0 + k]; cv[r] = CF_CELL(c.col_b, CF_ROW(c.row_b)); }
         }
-        if (rt == S.pi_row) break;
-        for (int k = (int)lane; k < S.n_consts; k += 64)
-            if (S.consts[k].row == rt) CF_CELL(S.consts[k].col, row) = S.consts[k].value;
-        for (int k = (int)lane; k < S.n_free; k += 64)
-            if (S.frees[k].row == rt) CF_CELL(S.frees[k].col, row) = src.pick(S.frees[k].src)[S.frees[k].idx];
+        for (int k = (int)t; k < s.n_consts; k += CF_THREADS) {
+            const rc_cf_const c = sh_consts[s.const0 + k];
+            CF_CELL(c.col, CF_ROW(c.row)) = c.value;
+        }
+        for (int k = (int)t; k < s.n_free; k += CF_THREADS) {
+            const rc_cf_free f = sh_free[s.free0 + k];
+            CF_CELL(f.col, CF_ROW(f.row)) = src.pick(f.src)[f.idx];
+        }
+#pragma unroll
+        for (int r = 0; r < CF_MAX_COPIES / CF_THREADS; r++) {
+            const int k = (int)t + r * CF_THREADS;
+            if (k < s.n_copies) { const rc_cf_copy c = sh_copies[s.copy0 + k]; CF_CELL(c.col_a, CF_ROW(c.row_a)) = cv[r]; }
+        }
         __syncthreads();
-        for (int k = (int)lane; k < S.n_products; k += 64)  // a product's factors are cells the row copied
-            if (S.products[k].row == rt) CF_CELL(S.products[k].col, row) = gl::canon(gl::mul(CF_CELL(S.products[k].col_a, row), CF_CELL(S.products[k].col_b, row)));
-        hook(rt, row);
+        for (int k = (int)t; k < s.n_prods; k += CF_THREADS) {  // a product's factors are cells the row copied
+            const rc_cf_product p = sh_products[s.prod0 + k];
+            const size_t row = CF_ROW(p.row);
+            CF_CELL(p.col, row) = gl::canon(gl::mul(CF_CELL(p.col_a, row), CF_CELL(p.col_b, row)));
+        }
+        for (int k = 0; k < s.n_rows; k++) {
+            const int rt = sh_step_rows[s.row0 + k];
+            hook(rt, CF_ROW(rt));
+        }
         __syncthreads();
-        if (S.is_poseidon[rt]) {  // uniform
-            const u64 x = g < 12 ? CF_CELL(g, row) : 0;
-            const bool writer = lane < 16;  // the other three rows of the wave run the same permutation and store nothing
-            p2::coop_flattened(co, x, g, [&](u32 slot, u64 v) { if (writer) CF_CELL(slot, row) = v; });
+        for (int k0 = 0; k0 < s.n_rows; k0 += CF_THREADS / 16) {  // uniform trip count; a group without a Poseidon2 row runs the permutation on zeros and stores nothing
+            const int k = k0 + (int)grp;
+            const int rt = k < s.n_rows ? sh_step_rows[s.row0 + k] : -1;
+            const bool p2row = rt >= 0 && S.is_poseidon[rt];
+            const size_t row = p2row ? CF_ROW(rt) : bnd;
+            const u64 x = p2row && g < 12 ? CF_CELL(g, row) : 0;
+            p2::coop_flattened(co, x, g, [&](u32 slot, u64 v) { if (p2row) CF_CELL(slot, row) = v; });
         }
         __syncthreads();
     }
+#undef CF_ROW
 #undef CF_CELL
 }
 
 // the section of a circuit whose closed form has a record encoder Cf (public_input_kernels.cuh: CfEventsSorter ...; S = its checker spec):
-// lanes 1..3 stage the encodings of the records in LDS, then the walk. The caller's lane 0 may write the register rows before calling
-// (the barrier in here orders them). Called by every lane of a 64-lane block.
+// one lane of waves 1..3 each stages encodings of the records in LDS, then the walk. The caller's lane 0 may write the register rows
+// before calling (the barrier in here orders them). Called by every lane of a CF_THREADS-lane block.
 template <class Cf, class S, class Hook>
 __device__ __forceinline__ void cf_section_from_records(const typename Cf::Inst* first, const typename Cf::Inst* inst, u64* trace, size_t n_rows, size_t bnd,
                                                         Hook&& hook) {
     __shared__ u64 sh_oi[Cf::MAXLEN], sh_oo[Cf::MAXLEN], sh_fi[Cf::MAXLEN], sh_fo[Cf::MAXLEN], sh_flags[2];
-    if (threadIdx.x == 1) {
+    if (threadIdx.x == 64) {  // (one lane of each of the other three waves: the encoders run side by side)
         Cf::input(*first, sh_oi);
         Cf::output(*inst, sh_oo);
     }
-    if (threadIdx.x == 2) Cf::fsm(Cf::fsm_in(*inst), sh_fi);
-    if (threadIdx.x == 3) {
+    if (threadIdx.x == 128) Cf::fsm(Cf::fsm_in(*inst), sh_fi);
+    if (threadIdx.x == 192) {
         Cf::fsm(Cf::fsm_out(*inst), sh_fo);
         sh_flags[0] = inst->start_flag ? 1 : 0;
         sh_flags[1] = inst->completion_flag ? 1 : 0;
     }
     __syncthreads();
     const CfSources src = {sh_oi, sh_fi, sh_fo, sh_flags, sh_oo};
-    cf_fill_wave(S::cf_spec(), trace, n_rows, bnd, src, hook);
+    cf_fill_block(S::cf_spec(), trace, n_rows, bnd, src, hook);
 }
 
 // a lookup cell of a section row takes a byte: the multiplicity column counted a zero there (the tail kernels count every lookup cell below

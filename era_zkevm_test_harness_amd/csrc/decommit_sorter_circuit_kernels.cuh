@@ -200,6 +200,10 @@ static __global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob
     } else if (i < rs) {
         zero_gap_row(trace, n_rows, (size_t)ROW * rs + i);
     }
+    if (WHICH == 1 && blockIdx.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells (GIN: bytes of the FSM input's page and first-encountered timestamp)
+        hist_bytes(sh_hist, job.inst->hidden_fsm_input.previous_record.memory_page);
+        hist_bytes(sh_hist, job.inst->hidden_fsm_input.first_encountered_timestamp);
+    }
     hist_flush(sh_hist, job.hist);
 }
 
@@ -354,12 +358,23 @@ static __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __
 }
 
 // the zero padding below the boundary rows and the multiplicity column (see k_ram_fill_tail)
-static __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const DsSynthJob& job = jobs[blockIdx.y];
+constexpr int DS_BOUNDARY_ROWS = (DS_NUM_ROW_TYPES - DS_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
+__device__ __forceinline__ void ds_boundary_block(const DsSynthJob& job, u32 capacity, size_t n_rows);
+static __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+    // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
+    // dependent permutations that the other blocks' stores hide), then (DS_G + DS_L + 1) * TAIL_CHUNKS blocks per trace
+    if (blockIdx.x < n_jobs) {
+        __builtin_amdgcn_s_setprio(3);
+        ds_boundary_block(jobs[blockIdx.x], capacity, n_rows);
+        return;
+    }
+    constexpr u32 PER_JOB = (DS_G + DS_L + 1) * TAIL_CHUNKS;
+    const u32 bid = (blockIdx.x - n_jobs) % PER_JOB;
+    const DsSynthJob& job = jobs[(blockIdx.x - n_jobs) / PER_JOB];
     u64* trace = job.trace;
-    const int col = blockIdx.x / TAIL_CHUNKS, ch = blockIdx.x % TAIL_CHUNKS;
+    const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < DS_G + DS_L) {
-        const size_t bnd = (size_t)DS_BOUNDARY_ROW(capacity);
+        const size_t bnd = (size_t)DS_BOUNDARY_ROW(capacity) + DS_BOUNDARY_ROWS;
         const size_t n_pairs = (n_rows - bnd) / 2;
         const size_t per = (n_pairs + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_pairs ? lo + per : n_pairs;
         ulonglong2* c2 = reinterpret_cast<ulonglong2*>(trace + (size_t)col * n_rows + bnd);
@@ -373,7 +388,7 @@ static __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* _
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];
-            if (r == 0) v += (u64)DS_L * n_rows - (u64)DS_LOOKUPS_PER_CYCLE * capacity;
+            if (r == 0) v += (u64)DS_L * n_rows - (u64)DS_LOOKUPS_PER_CYCLE * capacity - 8;  // (8: GIN's byte cells, counted in job.hist by k_ds_fill_poseidon<1>)
         }
         mlt[r] = v;
     }
@@ -453,17 +468,23 @@ __device__ __forceinline__ void ds_fill_register_rows(const DsSynthJob& job, u32
 
 // runs after everything else (same stream): BND_IN, BND_OUT, the flush permutation PF (one lane), then the closed-form section
 // (closed_form_kernels.cuh) down to the PI row
-static __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const DsSynthJob& job = jobs[blockIdx.x];
+// (the extra block of k_ds_fill_tail, whose other blocks zero the rows BELOW the boundary rows: the boundary rows' cells are zeroed here first)
+__device__ __forceinline__ void ds_boundary_block(const DsSynthJob& job, u32 capacity, size_t n_rows) {
+    {
+        u64* trace = job.trace;
+        const size_t bnd = (size_t)DS_BOUNDARY_ROW(capacity);
+        for (int k = threadIdx.x; k < (DS_G + DS_L) * DS_BOUNDARY_ROWS; k += CF_THREADS) TR(k / DS_BOUNDARY_ROWS, bnd + k % DS_BOUNDARY_ROWS) = 0;
+    }
+    __syncthreads();
     __shared__ u64 sh_oi[50], sh_oo[25], sh_fi[DS_FSM_ENC_LEN], sh_fo[DS_FSM_ENC_LEN], sh_flags[2];
     if (threadIdx.x == 0) ds_fill_register_rows(job, capacity, n_rows);
-    if (threadIdx.x == 1) {
+    if (threadIdx.x == 64) {  // (one lane of each of the other three waves: the encoders run side by side)
         put_queue12(job.first_inst->initial_queue_state, sh_oi);
         put_queue12(job.first_inst->sorted_queue_initial_state, sh_oi + 25);
         put_queue12(job.inst->final_queue_state, sh_oo);
     }
-    if (threadIdx.x == 2) ds_encode_fsm(job.inst->hidden_fsm_input, sh_fi);
-    if (threadIdx.x == 3) {
+    if (threadIdx.x == 128) ds_encode_fsm(job.inst->hidden_fsm_input, sh_fi);
+    if (threadIdx.x == 192) {
         ds_encode_fsm(job.inst->hidden_fsm_output, sh_fo);
         sh_flags[0] = job.inst->start_flag ? 1 : 0;
         sh_flags[1] = job.inst->completion_flag ? 1 : 0;
@@ -471,7 +492,7 @@ static __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob
     __syncthreads();
     const CfSources src = {sh_oi, sh_fi, sh_fo, sh_flags, sh_oo};
     u64* trace = job.trace;
-    cf_fill_wave(SpecDecommitSorter::cf_spec(), trace, n_rows, (size_t)DS_BOUNDARY_ROW(capacity), src, [&](int rt, size_t row) {
+    cf_fill_block(SpecDecommitSorter::cf_spec(), trace, n_rows, (size_t)DS_BOUNDARY_ROW(capacity), src, [&](int rt, size_t row) {
         if (threadIdx.x != 0 || rt != DS_ROW_GIN) return;
         // the encoding of the open group's first request from the FSM words the row copied (decommit query encoding, decommit_kernels.cuh)
         zkw_decommit_query g;
@@ -481,8 +502,8 @@ static __global__ __launch_bounds__(64) void k_ds_fill_boundary(const DsSynthJob
         g.timestamp = (u32)TR(DS_GIN_gfts, row);
         g.is_fresh = 1;
         for (int k = 0; k < 4; k++) {
-            cf_put_byte(trace, n_rows, DS_MULT_COL, DS_GIN_gpage_b0 + k, row, (g.memory_page >> (8 * k)) & 0xFF);
-            cf_put_byte(trace, n_rows, DS_MULT_COL, DS_GIN_gfts_b0 + k, row, (g.timestamp >> (8 * k)) & 0xFF);
+            TR(DS_GIN_gpage_b0 + k, row) = (g.memory_page >> (8 * k)) & 0xFF;  // (counted in the histogram by k_ds_fill_poseidon<1>)
+            TR(DS_GIN_gfts_b0 + k, row) = (g.timestamp >> (8 * k)) & 0xFF;
         }
         u64 e[8];
         encode_decommit_query(g, e);

@@ -439,6 +439,8 @@ static __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __res
     } else if (i < RC_REGION_STRIDE(capacity)) {
         zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_C * RC_REGION_STRIDE(capacity) + i);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0)  // the closed-form section's lookup cells (VIN / VOUT: bytes of limbs 5..7 of the previous value)
+        for (int l = 5; l < 8; l++) { hist_bytes(sh_hist, job.inst->hidden_fsm_input.previous_value[l]); hist_bytes(sh_hist, job.inst->hidden_fsm_output.previous_value[l]); }
     hist_flush(sh_hist, job.hist);
 }
 
@@ -485,13 +487,26 @@ static __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __res
 // runs at 3.9 TB/s, this at 5.6, tools/ubench_fill.hip). The last TAIL_CHUNKS blocks of a job do the multiplicity
 // column. grid.y = job.
 constexpr int TAIL_CHUNKS = 8;
-static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const SynthJob job = jobs[blockIdx.y];
+constexpr int RC_BOUNDARY_ROWS = RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE;  // register rows, PI, the closed-form section
+constexpr int RC_CF_LOOKUP_CELLS = 24;                                   // VIN / VOUT byte cells (counted in job.hist by k_ram_fill_C)
+static_assert(RC_BOUNDARY_ROWS % 2 == 0, "the tail's 16-byte stores start below the boundary rows");
+__device__ __forceinline__ void ram_boundary_block(const SynthJob& job, u32 capacity, size_t n_rows);
+static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+    // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
+    // dependent permutations that the other blocks' stores hide), then (RC_G + RC_L + 1) * TAIL_CHUNKS blocks per trace
+    if (blockIdx.x < n_jobs) {
+        __builtin_amdgcn_s_setprio(3);
+        ram_boundary_block(jobs[blockIdx.x], capacity, n_rows);
+        return;
+    }
+    constexpr u32 PER_JOB = (RC_G + RC_L + 1) * TAIL_CHUNKS;
+    const u32 bid = (blockIdx.x - n_jobs) % PER_JOB;
+    const SynthJob& job = jobs[(blockIdx.x - n_jobs) / PER_JOB];
     u64* trace = job.trace;
-    const int col = blockIdx.x / TAIL_CHUNKS, ch = blockIdx.x % TAIL_CHUNKS;
+    const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < RC_G + RC_L) {
-        const size_t bnd = (size_t)RC_BOUNDARY_ROW(capacity);  // a multiple of 64 rows: 16-byte aligned
-        const size_t n_pairs = (n_rows - bnd) / 2;             // n_rows is even (power of two)
+        const size_t bnd = (size_t)RC_BOUNDARY_ROW(capacity) + RC_BOUNDARY_ROWS;  // a multiple of 2 rows: 16-byte aligned
+        const size_t n_pairs = (n_rows - bnd) / 2;                               // n_rows is even (power of two)
         const size_t per = (n_pairs + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_pairs ? lo + per : n_pairs;
         ulonglong2* c2 = reinterpret_cast<ulonglong2*>(trace + (size_t)col * n_rows + bnd);
         const ulonglong2 z = make_ulonglong2(0, 0);
@@ -505,7 +520,7 @@ static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];
-            if (r == 0) v += (u64)RC_L * n_rows - (u64)LOOKUPS_PER_CYCLE * capacity;
+            if (r == 0) v += (u64)RC_L * n_rows - (u64)LOOKUPS_PER_CYCLE * capacity - RC_CF_LOOKUP_CELLS;
         }
         m[r] = v;
     }
@@ -571,8 +586,7 @@ __device__ __forceinline__ void ram_fill_register_rows(const SynthJob& job, u32 
     TR(RC_BND_OUT_w_end, bout) = inv_or_zero(len_out); TR(RC_BND_OUT_z_end, bout) = len_out == 0;
 }
 
-// a value row of the closed-form section: the bytes of limbs 5..7 into the lookup cells (and the multiplicity column: +1 for the byte,
-// -1 for the zero the cell held); VIN also the encoding elements es3..es6 of the limbs (memory_query.rs:60-110)
+// a value row of the closed-form section: the bytes of limbs 5..7 into the lookup cells; VIN also the encoding elements es3..es6 of the limbs (memory_query.rs:60-110)
 __device__ __forceinline__ void ram_value_row(u64* trace, size_t n_rows, size_t row, int v0, int b0, int e3) {
     zkw_mem_query q;
     memset(&q, 0, sizeof q);
@@ -580,7 +594,7 @@ __device__ __forceinline__ void ram_value_row(u64* trace, size_t n_rows, size_t 
     for (int l = 5; l < 8; l++)
         for (int k = 0; k < 4; k++) {
             const u64 b = (q.value[l] >> (8 * k)) & 0xFF;
-            cf_put_byte(trace, n_rows, RC_MULT_COL, b0 + 4 * (l - 5) + k, row, b);
+            TR(b0 + 4 * (l - 5) + k, row) = b;  // (counted in the histogram by k_ram_fill_C)
         }
     if (e3 < 0) return;
     u64 e[8];
@@ -588,28 +602,33 @@ __device__ __forceinline__ void ram_value_row(u64* trace, size_t n_rows, size_t 
     for (int k = 0; k < 4; k++) TR(e3 + k, row) = e[3 + k];
 }
 
-// runs after k_ram_fill_tail (same stream): the register rows, then the closed-form section (closed_form_kernels.cuh) down to the PI row
-static __global__ __launch_bounds__(64) void k_ram_fill_boundary(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const SynthJob job = jobs[blockIdx.x];
+// the extra block of k_ram_fill_tail (its other blocks zero the rows BELOW the boundary rows): the boundary rows' cells zeroed, the
+// register rows, then the closed-form section (closed_form_kernels.cuh) down to the PI row. Reads the last cycle's row C (an earlier kernel).
+__device__ __forceinline__ void ram_boundary_block(const SynthJob& job, u32 capacity, size_t n_rows) {
+    {
+        u64* trace = job.trace;
+        const size_t bnd = (size_t)RC_BOUNDARY_ROW(capacity);
+        for (int k = threadIdx.x; k < (RC_G + RC_L) * RC_BOUNDARY_ROWS; k += CF_THREADS) TR(k / RC_BOUNDARY_ROWS, bnd + k % RC_BOUNDARY_ROWS) = 0;
+    }
+    __syncthreads();
     __shared__ u64 sh_oi[RAM_INPUT_ENC_LEN], sh_fi[RAM_FSM_ENC_LEN], sh_fo[RAM_FSM_ENC_LEN], sh_flags[2];
     if (threadIdx.x == 0) ram_fill_register_rows(job, capacity, n_rows);
-    if (threadIdx.x == 1) {
+    if (threadIdx.x == 64) {  // (one lane of each of the other three waves: the encoders run side by side)
         int m = put_queue12(job.first_inst->unsorted_queue_initial_state, sh_oi);
         m += put_queue12(job.first_inst->sorted_queue_initial_state, sh_oi + m);
         sh_oi[m] = job.first_inst->non_deterministic_bootloader_memory_snapshot_length;
     }
-    if (threadIdx.x == 2) ram_encode_fsm(job.inst->hidden_fsm_input, sh_fi);
-    if (threadIdx.x == 3) {
+    if (threadIdx.x == 128) ram_encode_fsm(job.inst->hidden_fsm_input, sh_fi);
+    if (threadIdx.x == 192) {
         ram_encode_fsm(job.inst->hidden_fsm_output, sh_fo);
         sh_flags[0] = job.inst->start_flag ? 1 : 0;
         sh_flags[1] = job.inst->completion_flag ? 1 : 0;
     }
     __syncthreads();
-    const CfSpec S = {RC_CF_FIRST_ROW_TYPE, RC_CF_NUM_ROWS, RC_NUM_LINKS, RC_CF_NUM_CONSTS, RC_CF_NUM_FREE, RC_CF_NUM_PRODUCTS, RC_ROWS_PER_CYCLE, RC_ROW_PI,
-                      c_links, c_is_poseidon, c_rc_cf_consts, c_rc_cf_free, c_rc_cf_products};
+    const CfSpec S = ZKW_CF_SPEC(RC, rc, c_is_poseidon);
     const CfSources src = {sh_oi, sh_fi, sh_fo, sh_flags, nullptr};
     u64* trace = job.trace;
-    cf_fill_wave(S, trace, n_rows, (size_t)RC_BOUNDARY_ROW(capacity), src, [&](int rt, size_t row) {
+    cf_fill_block(S, trace, n_rows, (size_t)RC_BOUNDARY_ROW(capacity), src, [&](int rt, size_t row) {
         if (threadIdx.x != 0) return;
         if (rt == RC_ROW_VIN) ram_value_row(trace, n_rows, row, RC_VIN_VIN_v0, RC_VIN_VIN_v5_b0, RC_VIN_VIN_e3);
         if (rt == RC_ROW_VOUT) ram_value_row(trace, n_rows, row, RC_VOUT_VOUT_v0, RC_VOUT_VOUT_v5_b0, -1);

@@ -406,12 +406,23 @@ static __global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __
     hist_flush(sh_hist, job.hist);
 }
 
-static __global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const SsSynthJob& job = jobs[blockIdx.y];
+constexpr int SS_BOUNDARY_ROWS = (SS_NUM_ROW_TYPES - SS_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
+__device__ __forceinline__ void ss_boundary_block(const SsSynthJob& job, u32 capacity, size_t n_rows);
+static __global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+    // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
+    // dependent permutations that the other blocks' stores hide), then (SS_G + SS_L + 1) * TAIL_CHUNKS blocks per trace
+    if (blockIdx.x < n_jobs) {
+        __builtin_amdgcn_s_setprio(3);
+        ss_boundary_block(jobs[blockIdx.x], capacity, n_rows);
+        return;
+    }
+    constexpr u32 PER_JOB = (SS_G + SS_L + 1) * TAIL_CHUNKS;
+    const u32 bid = (blockIdx.x - n_jobs) % PER_JOB;
+    const SsSynthJob& job = jobs[(blockIdx.x - n_jobs) / PER_JOB];
     u64* trace = job.trace;
-    const int col = blockIdx.x / TAIL_CHUNKS, ch = blockIdx.x % TAIL_CHUNKS;
+    const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < SS_G + SS_L) {
-        const size_t bnd = (size_t)SS_BOUNDARY_ROW(capacity);
+        const size_t bnd = (size_t)SS_BOUNDARY_ROW(capacity) + SS_BOUNDARY_ROWS;
         const size_t n_pairs = (n_rows - bnd) / 2;
         const size_t per = (n_pairs + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_pairs ? lo + per : n_pairs;
         ulonglong2* c2 = reinterpret_cast<ulonglong2*>(trace + (size_t)col * n_rows + bnd);
@@ -514,8 +525,14 @@ __device__ __forceinline__ void ss_fill_register_rows(const SsSynthJob& job, u32
 }
 
 // the register rows (one lane), then the closed-form section down to the PI row (runs last on the stream: reads the last cycle's rows)
-static __global__ __launch_bounds__(64) void k_ss_fill_boundary(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const SsSynthJob& job = jobs[blockIdx.x];
+// (the extra block of k_ss_fill_tail, whose other blocks zero the rows BELOW the boundary rows: the boundary rows' cells are zeroed here first)
+__device__ __forceinline__ void ss_boundary_block(const SsSynthJob& job, u32 capacity, size_t n_rows) {
+    {
+        u64* trace = job.trace;
+        const size_t bnd = (size_t)SS_BOUNDARY_ROW(capacity);
+        for (int k = threadIdx.x; k < (SS_G + SS_L) * SS_BOUNDARY_ROWS; k += CF_THREADS) TR(k / SS_BOUNDARY_ROWS, bnd + k % SS_BOUNDARY_ROWS) = 0;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) ss_fill_register_rows(job, capacity, n_rows);
     cf_section_from_records<CfStorageSorter, SpecStorageSorter>(job.first_inst, job.inst, job.trace, n_rows, (size_t)SS_BOUNDARY_ROW(capacity), [](int, size_t) {});
 }

@@ -1392,10 +1392,9 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     ZKW_TRY(launch_check("k_ram_fill_C"));
     { Prof _p(ctx, "k_ram_fill_D"); hipLaunchKernelGGL(k_ram_fill_D, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_D"));
-    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3((RC_G + RC_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    // (+ 1: the block that fills the boundary rows and the closed-form section, hidden behind the zero fill)
+    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(nj * ((RC_G + RC_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_tail"));
-    { Prof _p(ctx, "k_ram_fill_boundary"); hipLaunchKernelGGL(k_ram_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ram_fill_boundary"));
     return ctx->sync_if_host();
 }
 

@@ -921,10 +921,8 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
     ZKW_TRY(launch_check("k_ds_fill_row<C>"));
     { Prof _p(ctx, "k_ds_fill_row_D"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_D>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_row<D>"));
-    { Prof _p(ctx, "k_ds_fill_tail"); hipLaunchKernelGGL(k_ds_fill_tail, dim3((DS_G + DS_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_tail"); hipLaunchKernelGGL(k_ds_fill_tail, dim3(nj * ((DS_G + DS_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_tail"));
-    { Prof _p(ctx, "k_ds_fill_boundary"); hipLaunchKernelGGL(k_ds_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ds_fill_boundary"));
     return ctx->sync_if_host();
 }
 
@@ -986,10 +984,8 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
     ES_LAUNCH_ROW(A) ES_LAUNCH_ROW(N0) ES_LAUNCH_ROW(N1) ES_LAUNCH_ROW(N2) ES_LAUNCH_ROW(N3) ES_LAUNCH_ROW(N4) ES_LAUNCH_ROW(N5)
     ES_LAUNCH_ROW(N6) ES_LAUNCH_ROW(N7) ES_LAUNCH_ROW(T) ES_LAUNCH_ROW(V) ES_LAUNCH_ROW(W) ES_LAUNCH_ROW(Q)
 #undef ES_LAUNCH_ROW
-    { Prof _p(ctx, "k_es_fill_tail"); hipLaunchKernelGGL(k_es_fill_tail, dim3((ES_G + ES_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_es_fill_tail"); hipLaunchKernelGGL(k_es_fill_tail, dim3(nj * ((ES_G + ES_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_es_fill_tail"));
-    { Prof _p(ctx, "k_es_fill_boundary"); hipLaunchKernelGGL(k_es_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_es_fill_boundary"));
     return ctx->sync_if_host();
 }
 
@@ -1048,10 +1044,8 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
     ZKW_TRY(launch_check("k_ld_fill_row<" #R ">"));
     LD_LAUNCH_ROW(X0) LD_LAUNCH_ROW(X1) LD_LAUNCH_ROW(X2) LD_LAUNCH_ROW(X3) LD_LAUNCH_ROW(R) LD_LAUNCH_ROW(Q)
 #undef LD_LAUNCH_ROW
-    { Prof _p(ctx, "k_ld_fill_tail"); hipLaunchKernelGGL(k_ld_fill_tail, dim3((LD_G + LD_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ld_fill_tail"); hipLaunchKernelGGL(k_ld_fill_tail, dim3(nj * ((LD_G + LD_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ld_fill_tail"));
-    { Prof _p(ctx, "k_ld_fill_boundary"); hipLaunchKernelGGL(k_ld_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ld_fill_boundary"));
     return ctx->sync_if_host();
 }
 
@@ -1112,10 +1106,8 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
     SS_LAUNCH_ROW(A) SS_LAUNCH_ROW(X0) SS_LAUNCH_ROW(X1) SS_LAUNCH_ROW(X2) SS_LAUNCH_ROW(X3) SS_LAUNCH_ROW(X4) SS_LAUNCH_ROW(X5)
     SS_LAUNCH_ROW(X6) SS_LAUNCH_ROW(X7) SS_LAUNCH_ROW(K) SS_LAUNCH_ROW(C1) SS_LAUNCH_ROW(C2) SS_LAUNCH_ROW(Q)
 #undef SS_LAUNCH_ROW
-    { Prof _p(ctx, "k_ss_fill_tail"); hipLaunchKernelGGL(k_ss_fill_tail, dim3((SS_G + SS_L + 1) * TAIL_CHUNKS, nj), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ss_fill_tail"); hipLaunchKernelGGL(k_ss_fill_tail, dim3(nj * ((SS_G + SS_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ss_fill_tail"));
-    { Prof _p(ctx, "k_ss_fill_boundary"); hipLaunchKernelGGL(k_ss_fill_boundary, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
-    ZKW_TRY(launch_check("k_ss_fill_boundary"));
     return ctx->sync_if_host();
 }
 

@@ -155,11 +155,38 @@ class ClosedForm:
         return out
 
     def tables(self, all_rows, section_rows):
-        """what a fill needs next to the links: the section's row types in order, the cells that are constants, the FREE cells"""
+        """what a fill needs next to the links: the section's row types in order, the cells that are constants, the FREE cells, the product
+        cells — and a SCHEDULE for a parallel fill: rows grouped into steps by dependency level (a row's copies come from rows of earlier
+        steps or from the register rows), every table sorted by step with the steps' index ranges. The PI row is the last step."""
+        idx = {id(r): k for k, r in enumerate(all_rows)}
+        pi = next(r for r in all_rows if r.name == "PI")
+        sect = {id(r) for r in section_rows}
+        level = {}
+        for r in section_rows:  # section_rows is a valid sequential order: sources come first
+            lv = 0
+            for ra, _, rb, _ in self.copies:
+                if ra is r and id(rb) in sect:
+                    assert id(rb) in level, f"{r.name} copies from {rb.name}, which is filled later"
+                    lv = max(lv, level[id(rb)] + 1)
+            level[id(r)] = lv
+        n_levels = max(level.values()) + 1
+        level[id(pi)] = n_levels
+        steps = [[r for r in section_rows if level[id(r)] == lv] for lv in range(n_levels)] + [[pi]]
+        step_of = {id(r): k for k, rows_ in enumerate(steps) for r in rows_}
+        copies = sorted(((step_of[id(ra)], idx[id(ra)], ra.slot(va), idx[id(rb)], rb.slot(vb)) for ra, va, rb, vb in self.copies if id(ra) in step_of))
+        consts = sorted((step_of[id(r)], idx[id(r)], r.slot(v), val) for r, v, val in self.consts)
+        free = sorted((step_of[id(r)], idx[id(r)], r.slot(v), src, i) for r, v, src, i in self.free)
+        prods = sorted((step_of[id(r)], idx[id(r)], r.slot(t), r.slot(a), r.slot(b)) for r, t, a, b in self.products)
+
+        def ranges(tab):
+            return [(sum(1 for e in tab if e[0] < k), sum(1 for e in tab if e[0] == k)) for k in range(len(steps))]
+
+        step_rows = [idx[id(r)] for rows_ in steps for r in rows_]
+        row0 = [sum(len(x) for x in steps[:k]) for k in range(len(steps))]
+        sched = [(row0[k], len(steps[k])) + ranges(copies)[k] + ranges(consts)[k] + ranges(free)[k] + ranges(prods)[k] for k in range(len(steps))]
         return {"first": all_rows.index(section_rows[0]), "n": len(section_rows),
-                "consts": [(all_rows.index(r), r.slot(v), val) for r, v, val in self.consts],
-                "free": [(all_rows.index(r), r.slot(v), src, idx) for r, v, src, idx in self.free],
-                "products": [(all_rows.index(r), r.slot(t), r.slot(a), r.slot(b)) for r, t, a, b in self.products]}
+                "consts": [e[1:] for e in consts], "free": [e[1:] for e in free], "products": [e[1:] for e in prods],
+                "copies": [e[1:] for e in copies], "steps": sched, "step_rows": step_rows}
 
 
 class Selections:
@@ -611,12 +638,22 @@ def emit(rows, links, path, prefix="RC", guard="ZKW_RAM_CIRCUIT_SPEC_H",
             out.append("typedef struct { uint8_t row, col; uint64_t value; } rc_cf_const;")
             out.append("typedef struct { uint8_t row, col, src; uint16_t idx; } rc_cf_free;")
             out.append("typedef struct { uint8_t row, col, col_a, col_b; } rc_cf_product; /* cell = cell a * cell b of the same row, computed by a fill after the row's copies */")
+            out.append("typedef struct { uint8_t row_a, col_a, row_b, col_b; } rc_cf_copy;   /* the kind-5 links whose row_a is a section row or the PI row */")
+            out.append("/* a step of the parallel fill schedule: rows whose copies come from earlier steps (or the register rows); index ranges into the")
+            out.append("   step-sorted tables: STEP_ROWS, COPIES, CONSTS, FREE, PRODUCTS */")
+            out.append("typedef struct { uint16_t row0, n_rows, copy0, n_copies, const0, n_consts, free0, n_free, prod0, n_prods; } rc_cf_step;")
         w(f"#define RC_CF_NUM_CONSTS {len(cf_tables['consts'])}\n#define RC_CF_NUM_FREE {len(cf_tables['free'])}")
         w("#define RC_CF_CONSTS_INIT {" + ", ".join(f"{{{a}, {b}, {c}ULL}}" for a, b, c in cf_tables["consts"]) + "}")
         w("#define RC_CF_FREE_INIT {" + ", ".join(f"{{{a}, {b}, {c}, {d}}}" for a, b, c, d in cf_tables["free"]) + "}")
         prods = cf_tables.get("products", [])
         w(f"#define RC_CF_NUM_PRODUCTS {len(prods)}")
         w("#define RC_CF_PRODUCTS_INIT {" + ", ".join(f"{{{a}, {b}, {c}, {d}}}" for a, b, c, d in prods) + ("}" if prods else "{0, 0, 0, 0}}") + "  /* (one zero entry when there are none) */")
+        w(f"#define RC_CF_NUM_COPIES {len(cf_tables['copies'])}")
+        w("#define RC_CF_COPIES_INIT {" + ", ".join(f"{{{a}, {b}, {c}, {d}}}" for a, b, c, d in cf_tables["copies"]) + "}")
+        w(f"#define RC_CF_NUM_STEPS {len(cf_tables['steps'])}")
+        w("#define RC_CF_STEPS_INIT {" + ", ".join("{" + ", ".join(map(str, e)) + "}" for e in cf_tables["steps"]) + "}")
+        w(f"#define RC_CF_NUM_STEP_ROWS {len(cf_tables['step_rows'])}")
+        w("#define RC_CF_STEP_ROWS_INIT {" + ", ".join(map(str, cf_tables["step_rows"])) + "}")
     w(f"#define RC_NUM_LINKS {len(links)}")
     w("#define RC_LINKS_INIT { \\")
     for k in links:
