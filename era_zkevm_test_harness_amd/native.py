@@ -44,6 +44,13 @@ SYMBOLS = [
     ("zkw_block_linear_hasher_instance", _int, [_vp, _vp]),
     ("zkw_setup_copy_permutation", _int, [C.c_uint8, C.c_uint32, _sz, _vp, _vp]),
     ("zkw_check_copy_permutation", _int, [_vp, _vp, _sz, _vp, C.c_uint32, _vp, _vp]),
+    ("zkw_ntt", _int, [_vp, _vp, _vp, _u32, _sz, _int]),
+    ("zkw_lde", _int, [_vp, _vp, _u32, _sz, _u32, _vp]),
+    ("zkw_merkle_tree_words", _sz, [_sz, _u32]),
+    ("zkw_merkle_tree_with_cap", _int, [_vp, _vp, _sz, _sz, _sz, _u32, _vp, _vp]),
+    ("zkw_setup_num_columns", _int, [C.c_uint8, _vp]),
+    ("zkw_setup_columns", _int, [_vp, C.c_uint8, _u32, _u32, _vp]),
+    ("zkw_setup_commit", _int, [_vp, C.c_uint8, _u32, _u32, _u32, _u32, _vp]),
     ("zkw_setup_row_selectors", _int, [C.c_uint8, C.c_uint32, _sz, _vp]),
     ("zkw_vm_trace_build", _int, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(_vp)]),
     ("zkw_vm_trace_count", _sz, [_vp, _int]),
@@ -1006,6 +1013,53 @@ class Context:
         buf = np.concatenate([enc.reshape(-1), np.zeros(1, np.uint64)])
         _check(load().zkw_commit_encodings(self.handle, _np_ptr(buf), enc.shape[0], enc.shape[1], _np_ptr(out)))
         return out
+
+    # ---- the setup side as field elements (include/zkw.h: NTT, LDE, Merkle tree with a cap)
+    def ntt(self, values, inverse=False) -> np.ndarray:
+        """zkw_ntt over the last axis of [n_cols][2^k] (natural order in and out)"""
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        v2 = v.reshape(-1, v.shape[-1])
+        log_n = int(v2.shape[1]).bit_length() - 1
+        assert 1 << log_n == v2.shape[1]
+        out = np.zeros_like(v2)
+        _check(load().zkw_ntt(self.handle, _np_ptr(v2), _np_ptr(out), C.c_uint32(log_n), C.c_size_t(v2.shape[0]), C.c_int(1 if inverse else 0)))
+        return out.reshape(v.shape)
+
+    def lde(self, values, lde_factor=2) -> np.ndarray:
+        """zkw_lde: [n_cols][n] values on the domain -> [lde_factor][n_cols][n] on the cosets 7 * w_(lde n)^c * <w_n>"""
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        assert v.ndim == 2
+        log_n = int(v.shape[1]).bit_length() - 1
+        out = np.zeros((lde_factor,) + v.shape, np.uint64)
+        _check(load().zkw_lde(self.handle, _np_ptr(v), C.c_uint32(log_n), C.c_size_t(v.shape[0]), C.c_uint32(lde_factor), _np_ptr(out)))
+        return out
+
+    def merkle_tree_with_cap(self, leaf_cols, cap_size=16, want_tree=False):
+        """zkw_merkle_tree_with_cap: leaf_cols [n_sets][n_cols][n] -> cap [cap_size][4] (and every level, leaves first, [nodes][4])"""
+        v = np.ascontiguousarray(leaf_cols, dtype=np.uint64)
+        assert v.ndim == 3
+        n_sets, n_cols, n = v.shape
+        cap = np.zeros((cap_size, 4), np.uint64)
+        lib = load()
+        tree = np.zeros((lib.zkw_merkle_tree_words(C.c_size_t(n_sets * n), C.c_uint32(cap_size)) // 4, 4), np.uint64) if want_tree else None
+        _check(lib.zkw_merkle_tree_with_cap(self.handle, _np_ptr(v), C.c_size_t(n_sets), C.c_size_t(n_cols), C.c_size_t(n), C.c_uint32(cap_size),
+                                            _np_ptr(cap), _np_ptr(tree) if want_tree else None))
+        return (cap, tree) if want_tree else cap
+
+    def setup_columns(self, circuit_type, capacity, log_n) -> np.ndarray:
+        """zkw_setup_columns: the sigma columns as field elements, then the selector column: [n_columns][2^log_n]"""
+        nc = C.c_uint32(0)
+        _check(load().zkw_setup_num_columns(C.c_uint8(circuit_type), C.byref(nc)))
+        out = np.zeros((nc.value, 1 << log_n), np.uint64)
+        _check(load().zkw_setup_columns(self.handle, C.c_uint8(circuit_type), C.c_uint32(capacity), C.c_uint32(log_n), _np_ptr(out)))
+        return out
+
+    def setup_commit(self, circuit_type, capacity, log_n, lde_factor=2, cap_size=16) -> np.ndarray:
+        """zkw_setup_commit: setup columns -> monomial form -> LDE -> Merkle tree -> cap [cap_size][4], all on the device"""
+        cap = np.zeros((cap_size, 4), np.uint64)
+        _check(load().zkw_setup_commit(self.handle, C.c_uint8(circuit_type), C.c_uint32(capacity), C.c_uint32(log_n), C.c_uint32(lde_factor),
+                                       C.c_uint32(cap_size), _np_ptr(cap)))
+        return cap
 
     def closed_form_public_inputs(self, circuit_type, instances):
         """zkw_closed_form_public_inputs: compact closed-form inputs [n][18] and public inputs [n][4] of the instance

@@ -174,6 +174,35 @@ int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacity, size_t n
 int zkw_check_copy_permutation(zkw_ctx *ctx, const zkw_trace *t, size_t slot, const uint64_t *sigma, uint32_t n_columns,
                                uint64_t *n_violations, uint64_t *first_bad);
 
+/* ---- Setup side as field elements: NTT, low-degree extension, Merkle tree with a cap ------------------------------------
+   What the reference does between a synthesized circuit and its verification key (src/prover_utils.rs:48-197
+   create_base_layer_setup_data: SetupBaseStorage -> SetupStorage in monomial form and as an LDE of factor fri_lde_factor ->
+   MerkleTreeWithCap over the LDE (cap 16) -> VerificationKey.setup_merkle_tree_cap; bodies in boojum, absent). Pinned by the
+   reference's data: leaf = overwrite-mode Poseidon2 sponge over a position's values (eight at a time, zero padded), node =
+   permutation of (left || right || 0000), ONE binary tree over all LDE positions cut at the cap: every Merkle path of the
+   committed proofs and setup_merkle_tree_cap of the vks reproduce (tests/golden/reference_merkle_paths_kat.json). The domain:
+   multiplicative generator 7, w_(2^32) = 7^((p-1)/2^32) = 0x185629dcda58878c (boojum's constant). NOT pinned (bodies absent):
+   which point a leaf index stands for — here leaf c * n + i is the point 7 * w_(lde n)^c * w_n^i, natural order — and the coset
+   representatives of the sigma polynomials (here k_j = 7^j). Pointers follow the context's pointer mode; arrays are column-major
+   like the traces ([column][position]). log_n <= 20.
+   zkw_ntt: out[c][k] = sum_j in[c][j] w_n^(jk) (inverse: w^-1 and 1/n), natural order both sides, out may be in.
+   zkw_lde: values of n_cols polynomials on the domain -> out[coset][column][i], lde_factor cosets (a power of two <= 8).
+   zkw_merkle_tree_with_cap: leaf_cols[set][column][i] (leaf index = set * n + i) -> cap[cap_size][4]; tree (optional, NULL to skip):
+     every level, leaves first, zkw_merkle_tree_words(n_sets * n, cap_size) words — the cap is its last level.
+   zkw_setup_num_columns / zkw_setup_columns: the setup columns of one of this library's layouts as field elements
+     ([n_columns][2^log_n]): the sigma columns of zkw_setup_copy_permutation (cell (c', r') as k_c' * w^r'), then the selector
+     column of zkw_setup_row_selectors. zkw_setup_commit: those columns -> monomial form -> LDE -> tree -> cap[cap_size][4]
+     (host pointer in host mode), all on the device. */
+int zkw_ntt(zkw_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t log_n, size_t n_cols, int inverse);
+int zkw_lde(zkw_ctx *ctx, const uint64_t *values, uint32_t log_n, size_t n_cols, uint32_t lde_factor, uint64_t *out);
+size_t zkw_merkle_tree_words(size_t n_leaves, uint32_t cap_size);
+int zkw_merkle_tree_with_cap(zkw_ctx *ctx, const uint64_t *leaf_cols, size_t n_sets, size_t n_cols, size_t n, uint32_t cap_size,
+                             uint64_t *cap, uint64_t *tree);
+int zkw_setup_num_columns(uint8_t circuit_type, uint32_t *n_columns);
+int zkw_setup_columns(zkw_ctx *ctx, uint8_t circuit_type, uint32_t capacity, uint32_t log_n, uint64_t *columns);
+int zkw_setup_commit(zkw_ctx *ctx, uint8_t circuit_type, uint32_t capacity, uint32_t log_n, uint32_t lde_factor, uint32_t cap_size,
+                     uint64_t *cap);
+
 /* ---- per-kernel timing -------------------------------------------------------------------------- */
 /* When enabled, every kernel launch (and library sort) of this context is bracketed by HIP events
    recorded on the context's stream; totals are keyed by kernel name ("k_chain_full", "k_gp_local",

@@ -364,4 +364,12 @@ void orc_code_decommitter_queue_feed(const zkw_sha256_round_record *rounds, size
 int orc_vm_slice_instances(const zkw_vm_tracer_streams *s, zkw_vm_instance *out, uint32_t *read_index, uint32_t *write_index,
                            uint64_t *n_reads, uint64_t *n_writes);
 
+/* ---- the setup side as field elements (commit.c): NTT, LDE, Merkle tree with a cap */
+uint64_t orc_root_of_unity(uint32_t log_n);
+void orc_gl_powers(uint64_t base, size_t n, uint64_t *out);
+void orc_ntt(uint64_t *x, uint32_t log_n, int inverse);
+void orc_lde(const uint64_t *values, uint32_t log_n, size_t n_cols, uint32_t lde_factor, uint64_t *out);
+uint64_t orc_poly_eval(const uint64_t *coeffs, size_t n, uint64_t x);
+void orc_merkle_tree_with_cap(const uint64_t *leaf_cols, size_t n_sets, size_t n_cols, size_t n, uint32_t cap_size, uint64_t *tree);
+
 #endif

@@ -1316,3 +1316,52 @@ def vm_slice_instances(tracer):
     if rc != 0:
         raise RuntimeError(f"orc_vm_slice_instances failed: {rc}")
     return inst, ri[:nr.value], wi[:nw.value]
+
+
+# ---- the setup side as field elements (commit.c)
+def root_of_unity(log_n):
+    f = lib().orc_root_of_unity
+    f.restype = C.c_uint64
+    return int(f(C.c_uint32(log_n)))
+
+
+def gl_powers(base, n):
+    out = np.zeros(n, np.uint64)
+    lib().orc_gl_powers(C.c_uint64(base), C.c_size_t(n), _p(out))
+    return out
+
+
+def ntt(values, inverse=False):
+    """orc_ntt over the last axis (natural order in and out)"""
+    v = np.ascontiguousarray(values, dtype=np.uint64).copy()
+    v2 = v.reshape(-1, v.shape[-1])
+    log_n = int(v2.shape[1]).bit_length() - 1
+    for r in range(v2.shape[0]):
+        row = np.ascontiguousarray(v2[r])
+        lib().orc_ntt(_p(row), C.c_uint32(log_n), C.c_int(1 if inverse else 0))
+        v2[r] = row
+    return v
+
+
+def lde(values, lde_factor=2):
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    log_n = int(v.shape[1]).bit_length() - 1
+    out = np.zeros((lde_factor,) + v.shape, np.uint64)
+    lib().orc_lde(_p(v), C.c_uint32(log_n), C.c_size_t(v.shape[0]), C.c_uint32(lde_factor), _p(out))
+    return out
+
+
+def poly_eval(coeffs, x):
+    c = np.ascontiguousarray(coeffs, dtype=np.uint64)
+    f = lib().orc_poly_eval
+    f.restype = C.c_uint64
+    return int(f(_p(c), C.c_size_t(c.size), C.c_uint64(x)))
+
+
+def merkle_tree_with_cap(leaf_cols, cap_size=16):
+    """every level, leaves first: [nodes][4]; the cap is the last cap_size nodes"""
+    v = np.ascontiguousarray(leaf_cols, dtype=np.uint64)
+    n_sets, n_cols, n = v.shape
+    tree = np.zeros((2 * n_sets * n - cap_size, 4), np.uint64)
+    lib().orc_merkle_tree_with_cap(_p(v), C.c_size_t(n_sets), C.c_size_t(n_cols), C.c_size_t(n), C.c_uint32(cap_size), _p(tree))
+    return tree
