@@ -44,6 +44,21 @@ echo "== tools/probe_ecrecover_synth.py (ECRecover, 7 requests per instance, 2^2
 timeout -s KILL 300 python tools/probe_ecrecover_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
 echo "== tools/probe_netlist_perf.py (Keccak256RoundFunction 293 / Sha256RoundFunction 2206 cycles, 2^20 rows, 8 instances; L1MessagesHasher)" >> "$OUT/synthesis_probes.txt"
 timeout -s KILL 300 python tools/probe_netlist_perf.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
+echo "== tools/probe_setup_commit.py (setup side as field elements: NTT / LDE / Merkle tree of 131 columns x 2^20, zkw_setup_commit of three layouts)" >> "$OUT/synthesis_probes.txt"
+timeout -s KILL 300 python tools/probe_setup_commit.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
+rm -rf /tmp/pk_sc && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk_sc -- python tools/probe_setup_commit.py > /dev/null 2>&1
+cp "$(ls /tmp/pk_sc/*/*kernel_stats.csv | head -1)" "$OUT/setup_commit_kernel_stats.csv"
+rm -rf /tmp/pk_sv && timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pk_sv -- python tools/probe_setup_commit.py > /dev/null 2>&1
+python3 - "$(ls /tmp/pk_sv/*/*counter_collection.csv | head -1)" > "$OUT/setup_commit_valu.txt" <<'PY'
+import collections, csv, sys
+tot, disp = collections.defaultdict(float), collections.defaultdict(set)
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    tot[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+print("SQ_INSTS_VALU (wave-instructions) per dispatch; 131 columns x 2^20 points per NTT pass, 2^21 leaves x 17 permutations for k_merkle_leaves")
+for k in sorted(tot, key=lambda k: -tot[k])[:8]:
+    print(f"{k} {len(disp[k])} dispatches {tot[k] / len(disp[k]):.4g} per dispatch")
+PY
 rm -rf /tmp/pk_nl && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk_nl -- python tools/probe_netlist_perf.py > /dev/null 2>&1
 cp "$(ls /tmp/pk_nl/*/*kernel_stats.csv | head -1)" "$OUT/netlist_kernel_stats.csv"
 # 5b. HBM counters of the netlist probe (separate passes per counter): bytes per dispatch of 8 instances
