@@ -213,8 +213,6 @@ bool link_spec_of(uint8_t t, LinkSpec* o) {
 
 extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t* sigma, uint32_t* n_columns) {
     LinkSpec sp;
-    if (circuit_type == ZKW_CIRCUIT_ECRECOVER)  // its Keccak-f and queue sections are netlist cells, the EC section's references (include/zkw_ecrecover.h) are not folded in yet
-        return fail(ZKW_ERR_INVALID, "zkw_setup_copy_permutation: the ECRecover circuit's EC section has no copy classes in this library yet");
     const bool netlist = nl_is_netlist(circuit_type);
     if (netlist) sp = {(int)nl_host_spec(circuit_type)->mult_col, 0, 0, 0, 0, nullptr};  // all but the multiplicity column
     else if (!link_spec_of(circuit_type, &sp))
@@ -372,6 +370,46 @@ extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacit
                     qc(last_cyc[q], nlq_op_row0(qd, G, (uint32_t)last_op[q]), nlq_new0(&qd->ops[last_op[q]]) + k, &cb, &rb);
                     unite(nlq_bnd_col(qd, q, 1, k), q0, cb, rb);
                 }
+            // ECRecover's EC section (include/zkw_ecrecover.h): every cell with a tape reference is a copy of the value's home cell; an input
+            // byte's home is a copy of the read query's value byte in the queue section, its other occurrences of that home; the netlist's
+            // FREE elements (key bytes, mask, ok) are copies of EC home cells — the relations k_ec_check_rows / k_ec_check_links walk
+            if (circuit_type == ZKW_CIRCUIT_ECRECOVER) {
+                EC_DEFINE_SPEC(ecs);
+                const ec_spec S = {ecs_types, ecs_runs, ecs_items, ecs_item_index, ecs_cells, ecs_homes, ecs_outs, ecs_rowtab, ecs_globs, ecs_bigs, ecs_in_home, ecs_key_byte, nullptr};
+                for (uint32_t c = 0; c < cycles; c++) {
+                    const uint64_t cyc0 = lay.ec_first_row + (uint64_t)c * EC_ROWS_PER_CYCLE;
+                    for (uint32_t r = 0; r < EC_ROWS_PER_CYCLE; r++) {
+                        uint32_t run, inst, row, prun, pinst, hr2, hc2;
+                        ec_locate_row(&S, r, &run, &inst, &row);
+                        const ec_seg_type& T = S.types[S.runs[run].type];
+                        ec_prev_segment(&S, run, inst, &prun, &pinst);
+                        const uint32_t base = S.runs[run].tape0 + inst * T.n_tape, pbase = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape;
+                        const uint32_t* cells = S.cells + T.cell0 + (size_t)row * EC_ROW_CELLS;
+                        for (uint32_t col = 0; col < EC_ROW_CELLS; col++) {
+                            const uint32_t ref = cells[col];
+                            if (ref == EC_NONE) continue;
+                            const uint32_t t = ec_ref_tape(&S, ref, base, pbase, S.runs[prun].type, inst);
+                            if (t != EC_NONE) {
+                                ec_home_of_tape(&S, t, &hr2, &hc2);
+                                unite(col, cyc0 + r, hc2, cyc0 + hr2);
+                            } else if ((ref >> 28) == EC_K_IN) {
+                                const uint32_t k = ref & 0xFFFF, h = S.in_home[k];
+                                if (run == 0 && row == (h >> 8) && col == (h & 0xFF)) {
+                                    const uint32_t op = 1 + k / 32, cell = NLQ_MEM_NIBBLE0 + k % 32;
+                                    unite(col, cyc0 + r, cell % G, NLQ_ROW(ns, cycles, nlq_op_row0(qd, G, op) + cell / G, c));
+                                } else unite(col, cyc0 + r, h & 0xFF, cyc0 + (h >> 8));
+                            }
+                        }
+                    }
+                    for (uint32_t k = 0; k < EK_FREE_PER_CYCLE; k++) {
+                        if (!free_home(k, &cb, &rb)) continue;
+                        const uint32_t t = k < 64 ? S.runs[EC_NUM_RUNS - 1].tape0 + S.key_byte[k] : S.globs[k == EK_FREE_MASK ? EC_GL_MASK : EC_GL_OK];
+                        uint32_t hr2, hc2;
+                        ec_home_of_tape(&S, t, &hr2, &hc2);
+                        unite(cb, (uint64_t)c * ns->rows_per_cycle + rb, hc2, cyc0 + hr2);
+                    }
+                }
+            }
         }
     }
     for (int l = 0; l < sp.num_links; l++) {

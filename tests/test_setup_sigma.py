@@ -83,8 +83,46 @@ def test_sigma_of_the_netlist_circuits(oracle):
             assert n > 0 and first[0] in (1, 2, 7), (ctype, int(cell), first)
 
 
+def test_sigma_of_the_ecrecover_circuit(oracle):
+    """type 7: Keccak-f netlist + queue section + the EC section (cells with a tape reference are copies of the value's home cell, an input
+    byte's home of the read query's value byte, the netlist's key / mask / ok elements of EC home cells): the oracle's trace satisfies
+    sigma, a bumped cell of a cycle is caught by the oracle's checker, cells of all three parts are in cycles"""
+    cap, n_rows = 2, 1 << 18
+    req, mq = synthetic.precompile_trace(2, 3, seed=4)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    b = oracle.precompile_build(2, req, tails, mq, cap, np.zeros(1, nv.QUEUE_STATE12))
+    t = oracle.ecrecover_synthesize(b, 0, cap, n_rows)
+    assert oracle.ecrecover_check(t, cap)[0] == 0
+    sigma = nv.setup_copy_permutation(7, cap, n_rows)
+    G = sigma.shape[0]
+    assert G == 128
+    flat = sigma.reshape(-1)
+    ident = np.arange(flat.size, dtype=np.uint64)
+    assert np.array_equal(np.sort(flat), ident)
+    body = t[:G].reshape(-1)
+    assert np.array_equal(body, body[flat])
+    moved = np.flatnonzero(flat != ident)
+    g = oracle.ec_geometry(cap)
+    rows = moved % n_rows
+    lay = nv.circuit_layout(7, cap)
+    in_ec = (rows >= g["first_row"]) & (rows < g["first_row"] + cap * g["rows_per_cycle"])
+    in_queue = (rows >= int(lay["queue_first_row"])) & (rows < g["first_row"])
+    assert in_ec.sum() > 100000 and in_queue.sum() > 500 and (~in_ec & ~in_queue).sum() > 10000
+    rng = np.random.default_rng(3)
+    for cell in np.concatenate([rng.choice(moved[in_ec], 6, replace=False), rng.choice(moved[in_queue], 2, replace=False)]):
+        bad = t.copy()
+        bad[int(cell) // n_rows, int(cell) % n_rows] += 1
+        bb = bad[:G].reshape(-1)
+        assert not np.array_equal(bb, bb[flat])
+        assert oracle.ecrecover_check(bad, cap)[0] > 0, int(cell)
+    # an EC-section cell that holds a value and is in no cycle: a constant or a value used once (its own home); sigma fixes it
+    ec_cells = np.flatnonzero((flat == ident) & (body != 0))
+    ec_cells = ec_cells[(ec_cells % n_rows >= g["first_row"]) & (ec_cells % n_rows < g["first_row"] + cap * g["rows_per_cycle"])]
+    assert ec_cells.size > 0
+
+
 def test_sigma_rejects_what_it_cannot_describe():
     with pytest.raises(nv.ZkwError):
-        nv.setup_copy_permutation(7, 0, 1 << 20)   # ECRecover: no layout
+        nv.setup_copy_permutation(1, 0, 1 << 20)   # MainVM: no layout
     with pytest.raises(nv.ZkwError):
         nv.setup_copy_permutation(8, 136714, 1 << 19)
