@@ -4,14 +4,15 @@ import numpy as np
 sys.path.insert(0, '.')
 from era_zkevm_test_harness_amd import native, synthetic
 ctx = native.Context(0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8  # instances per synthesis call (8 = the bench's hash_circuits leg)
 n_rows = 1 << 20
 mem_in = np.zeros(1, native.QUEUE_STATE12)
-for name, kind, n_req, cap, cols, synth in (("keccak", 0, 1400, 293, native.KC_COLS, ctx.synthesize_keccak_round_function),
-                                            ("sha256", 1, 6000, 2206, native.SC_COLS, ctx.synthesize_sha256_round_function)):
+for name, kind, n_req, cap, cols, synth in (("keccak", 0, 1400 * N // 8, 293, native.KC_COLS, ctx.synthesize_keccak_round_function),
+                                            ("sha256", 1, 6000 * N // 8, 2206, native.SC_COLS, ctx.synthesize_sha256_round_function)):
     req, mq = synthetic.precompile_trace(kind, n_req, seed=5, max_rounds=6)
     tails = ctx.queue_push_chain_log(ctx.encode_log_queries(req))[1]
     w = ctx._precompile(kind, req, tails, mq, cap, mem_in)
-    n = min(8, w.num_instances)
+    n = min(N, w.num_instances)
     t = native.Trace(ctx, n_rows, n, n_cols=cols)
     synth(w, t, 0, n, 0); ctx.synchronize()
     ctx.profile_enable(True); ctx.profile_reset()
@@ -22,6 +23,8 @@ for name, kind, n_req, cap, cols, synth in (("keccak", 0, 1400, 293, native.KC_C
     print(name, f"{n} instances {best*1e3:.2f} ms = {n/best:.0f} circuits/s", {k: round(v[0] / 3, 3) for k, v in prof.items()})
     ctx.profile_enable(False)
     t.free(); w.free()
+if N != 8:
+    sys.exit(0)
 q = synthetic.mixed_log_queue(4000, seed=3)[:700]
 t = native.Trace(ctx, n_rows, 1, n_cols=native.LH_COLS)
 ctx.synthesize_linear_hasher(q, np.zeros(1, native.QUEUE_STATE4), 774, t, 0); ctx.synchronize()
