@@ -13,9 +13,10 @@
 
 namespace zkw {
 
-constexpr int CF_MAX_STEPS = 24, CF_MAX_STEP_ROWS = 64, CF_MAX_COPIES = 1024, CF_MAX_CONSTS = 128, CF_MAX_FREE = 256, CF_MAX_PRODUCTS = 64;  // LDS copies of the tables
+constexpr int CF_MAX_STEPS = 24, CF_MAX_STEP_ROWS = 96, CF_MAX_COPIES = 1536, CF_MAX_CONSTS = 192, CF_MAX_FREE = 256, CF_MAX_PRODUCTS = 64, CF_MAX_BYTES = 64,
+              CF_MAX_LINEARS = 96, CF_MAX_LIN_TERMS = 256;  // LDS copies of the tables
 struct CfSpec {
-    int n_steps, rows_per_cycle, n_step_rows, n_copies, n_consts, n_free, n_products;
+    int n_steps, rows_per_cycle, n_step_rows, n_copies, n_consts, n_free, n_products, n_bytes, n_linears, n_lin_terms;
     const rc_cf_step* steps;      // the parallel schedule of the spec header: rows grouped by dependency level, tables sorted by step
     const uint8_t* step_rows;
     const rc_cf_copy* copies;
@@ -23,6 +24,9 @@ struct CfSpec {
     const rc_cf_const* consts;
     const rc_cf_free* frees;
     const rc_cf_product* products;
+    const rc_cf_bytes* bytes;          // lookup cells = the bytes of a limb cell of the row (their multiplicities: the circuit's fill kernels count them from the records)
+    const rc_cf_linear* linears;       // cell = constant + sum coef * cell of the row
+    const rc_cf_lin_term* lin_terms;
 };
 
 // the section's tables of a spec header in constant memory, and the members a checker spec struct (SpecRam ...) exposes them through
@@ -33,11 +37,17 @@ struct CfSpec {
     static __constant__ rc_cf_const c_##pfx##_cf_consts[PFX##_CF_NUM_CONSTS] = PFX##_CF_CONSTS_INIT;                     \
     static __constant__ rc_cf_free c_##pfx##_cf_free[PFX##_CF_NUM_FREE] = PFX##_CF_FREE_INIT;                            \
     static __constant__ rc_cf_product c_##pfx##_cf_products[PFX##_CF_NUM_PRODUCTS ? PFX##_CF_NUM_PRODUCTS : 1] = PFX##_CF_PRODUCTS_INIT;       \
+    static __constant__ rc_cf_bytes c_##pfx##_cf_bytes[PFX##_CF_NUM_BYTES ? PFX##_CF_NUM_BYTES : 1] = PFX##_CF_BYTES_INIT;                     \
+    static __constant__ rc_cf_linear c_##pfx##_cf_linears[PFX##_CF_NUM_LINEARS ? PFX##_CF_NUM_LINEARS : 1] = PFX##_CF_LINEARS_INIT;            \
+    static __constant__ rc_cf_lin_term c_##pfx##_cf_lin_terms[PFX##_CF_NUM_LIN_TERMS ? PFX##_CF_NUM_LIN_TERMS : 1] = PFX##_CF_LIN_TERMS_INIT;  \
     static_assert(PFX##_CF_NUM_STEPS <= CF_MAX_STEPS && PFX##_CF_NUM_STEP_ROWS <= CF_MAX_STEP_ROWS && PFX##_CF_NUM_COPIES <= CF_MAX_COPIES && \
-                  PFX##_CF_NUM_CONSTS <= CF_MAX_CONSTS && PFX##_CF_NUM_FREE <= CF_MAX_FREE && PFX##_CF_NUM_PRODUCTS <= CF_MAX_PRODUCTS, "closed-form tables outgrew their LDS copies");
+                  PFX##_CF_NUM_CONSTS <= CF_MAX_CONSTS && PFX##_CF_NUM_FREE <= CF_MAX_FREE && PFX##_CF_NUM_PRODUCTS <= CF_MAX_PRODUCTS &&     \
+                  PFX##_CF_NUM_BYTES <= CF_MAX_BYTES && PFX##_CF_NUM_LINEARS <= CF_MAX_LINEARS && PFX##_CF_NUM_LIN_TERMS <= CF_MAX_LIN_TERMS, \
+                  "closed-form tables outgrew their LDS copies");
 #define ZKW_CF_SPEC(PFX, pfx, is_poseidon_table)                                                                         \
-    CfSpec{PFX##_CF_NUM_STEPS, PFX##_ROWS_PER_CYCLE, PFX##_CF_NUM_STEP_ROWS, PFX##_CF_NUM_COPIES, PFX##_CF_NUM_CONSTS, PFX##_CF_NUM_FREE, PFX##_CF_NUM_PRODUCTS, c_##pfx##_cf_steps, c_##pfx##_cf_step_rows, c_##pfx##_cf_copies, is_poseidon_table, \
-           c_##pfx##_cf_consts, c_##pfx##_cf_free, c_##pfx##_cf_products}
+    CfSpec{PFX##_CF_NUM_STEPS, PFX##_ROWS_PER_CYCLE, PFX##_CF_NUM_STEP_ROWS, PFX##_CF_NUM_COPIES, PFX##_CF_NUM_CONSTS, PFX##_CF_NUM_FREE, PFX##_CF_NUM_PRODUCTS, \
+           PFX##_CF_NUM_BYTES, PFX##_CF_NUM_LINEARS, PFX##_CF_NUM_LIN_TERMS, c_##pfx##_cf_steps, c_##pfx##_cf_step_rows, c_##pfx##_cf_copies, is_poseidon_table, \
+           c_##pfx##_cf_consts, c_##pfx##_cf_free, c_##pfx##_cf_products, c_##pfx##_cf_bytes, c_##pfx##_cf_linears, c_##pfx##_cf_lin_terms}
 #define ZKW_CF_SPEC_MEMBERS(PFX, pfx) \
     __device__ static CfSpec cf_spec() { return ZKW_CF_SPEC(PFX, pfx, is_poseidon()); }
 
@@ -67,19 +77,25 @@ __device__ __forceinline__ void cf_fill_block(const CfSpec& S, u64* __restrict__
     __shared__ rc_cf_const sh_consts[CF_MAX_CONSTS];
     __shared__ rc_cf_free sh_free[CF_MAX_FREE];
     __shared__ rc_cf_product sh_products[CF_MAX_PRODUCTS];
+    __shared__ rc_cf_bytes sh_bytes[CF_MAX_BYTES];
+    __shared__ rc_cf_linear sh_linears[CF_MAX_LINEARS];
+    __shared__ rc_cf_lin_term sh_lin_terms[CF_MAX_LIN_TERMS];
     for (int k = (int)t; k < S.n_steps; k += CF_THREADS) sh_steps[k] = S.steps[k];
     for (int k = (int)t; k < S.n_step_rows; k += CF_THREADS) sh_step_rows[k] = S.step_rows[k];
     for (int k = (int)t; k < S.n_copies; k += CF_THREADS) sh_copies[k] = S.copies[k];
     for (int k = (int)t; k < S.n_consts; k += CF_THREADS) sh_consts[k] = S.consts[k];
     for (int k = (int)t; k < S.n_free; k += CF_THREADS) sh_free[k] = S.frees[k];
     for (int k = (int)t; k < S.n_products; k += CF_THREADS) sh_products[k] = S.products[k];
+    for (int k = (int)t; k < S.n_bytes; k += CF_THREADS) sh_bytes[k] = S.bytes[k];
+    for (int k = (int)t; k < S.n_linears; k += CF_THREADS) sh_linears[k] = S.linears[k];
+    for (int k = (int)t; k < S.n_lin_terms; k += CF_THREADS) sh_lin_terms[k] = S.lin_terms[k];
     __syncthreads();
     p2::Coop co;
     co.init((int)g);
     for (int st = 0; st < S.n_steps; st++) {
         const rc_cf_step s = sh_steps[st];
         // the cells a step initialises are independent: all loads first, then the stores
-        u64 cv[CF_MAX_COPIES / CF_THREADS];
+        u64 cv[CF_MAX_COPIES / CF_THREADS];  // (unrolled: registers)
 #pragma unroll
         for (int r = 0; r < CF_MAX_COPIES / CF_THREADS; r++) {
             const int k = (int)t + r * CF_THREADS;
@@ -99,6 +115,24 @@ __device__ __forceinline__ void cf_fill_block(const CfSpec& S, u64* __restrict__
             if (k < s.n_copies) { const rc_cf_copy c = sh_copies[s.copy0 + k]; CF_CELL(c.col_a, CF_ROW(c.row_a)) = cv[r]; }
         }
         __syncthreads();
+        if (s.n_bytes) {  // (uniform) the bytes of limb cells the rows copied: one lane per byte
+            for (int k = (int)t; k < 4 * s.n_bytes; k += CF_THREADS) {
+                const rc_cf_bytes b = sh_bytes[s.byte0 + (k >> 2)];
+                const size_t row = CF_ROW(b.row);
+                CF_CELL(b.col_b0 + (k & 3), row) = (CF_CELL(b.col_limb, row) >> (8 * (k & 3))) & 0xFF;
+            }
+            __syncthreads();
+        }
+        for (int k = (int)t; k < s.n_lins; k += CF_THREADS) {  // linear combinations of the row's cells (copied cells, bytes)
+            const rc_cf_linear l = sh_linears[s.lin0 + k];
+            const size_t row = CF_ROW(l.row);
+            u64 acc = l.constant;
+            for (int j = 0; j < l.n_terms; j++) {
+                const rc_cf_lin_term tm = sh_lin_terms[l.term0 + j];
+                acc = gl::add(acc, gl::mul(tm.coef, CF_CELL(tm.col, row)));
+            }
+            CF_CELL(l.col, row) = gl::canon(acc);
+        }
         for (int k = (int)t; k < s.n_prods; k += CF_THREADS) {  // a product's factors are cells the row copied
             const rc_cf_product p = sh_products[s.prod0 + k];
             const size_t row = CF_ROW(p.row);

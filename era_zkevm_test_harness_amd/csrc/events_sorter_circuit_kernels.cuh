@@ -310,6 +310,12 @@ static __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __
     } else if (i < rs) {
         zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, ES_G + ES_L);
     }
+    if (ROW == ES_ROW_A && blockIdx.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells: the key / address bytes of the FSM records' previous_item (bridge rows NIB* / NOB*)
+        const zkw_log_query& a = job.inst->hidden_fsm_input.previous_item;
+        const zkw_log_query& b = job.inst->hidden_fsm_output.previous_item;
+        for (int k = 0; k < 8; k++) { hist_bytes(sh_hist, a.key[k]); hist_bytes(sh_hist, b.key[k]); }
+        for (int k = 0; k < 5; k++) { hist_bytes(sh_hist, a.address[k]); hist_bytes(sh_hist, b.address[k]); }
+    }
     hist_flush(sh_hist, job.hist);
 }
 
@@ -343,7 +349,7 @@ static __global__ __launch_bounds__(256) void k_es_fill_tail(const EsSynthJob* _
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];
-            if (r == 0) v += (u64)ES_L * n_rows - (u64)ES_LOOKUPS_PER_CYCLE * capacity;
+            if (r == 0) v += (u64)ES_L * n_rows - (u64)ES_LOOKUPS_PER_CYCLE * capacity - 4 * ES_CF_NUM_BYTES;  // (the section's byte cells: counted in job.hist by k_es_fill_row<A>)
         }
         mlt[r] = v;
     }

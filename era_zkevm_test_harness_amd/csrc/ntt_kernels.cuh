@@ -148,12 +148,16 @@ static __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass2(NttArgs A) {
 static __global__ __launch_bounds__(256) void k_merkle_leaves(const u64* __restrict__ cols, size_t n_cols, size_t stride, size_t n, u64* __restrict__ digests) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u64 s[12];
+    u64 s[12], nx[8];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) nx[k] = (size_t)k < n_cols ? cols[(size_t)k * stride + i] : 0;
     for (size_t c0 = 0; c0 < n_cols; c0 += 8) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = c0 + k < n_cols ? cols[(c0 + k) * stride + i] : 0;
+        for (int k = 0; k < 8; k++) s[k] = nx[k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) nx[k] = c0 + 8 + k < n_cols ? cols[(c0 + 8 + k) * stride + i] : 0;  // the next chunk's loads fly during the permutation
         p2::permute(s);
     }
 #pragma unroll

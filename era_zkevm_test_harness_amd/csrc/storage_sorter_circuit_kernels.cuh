@@ -403,6 +403,11 @@ static __global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __
     } else if (i < rs) {
         zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, SS_G + SS_L);
     }
+    if (ROW == SS_ROW_A && blockIdx.x == 0 && threadIdx.x == 0)  // the closed-form section's lookup cells: the bytes of the FSM records' previous_packed_key (bridge rows KIB* / KOB*)
+        for (int k = 0; k < ZKW_STORAGE_PACKED_KEY_LENGTH; k++) {
+            hist_bytes(sh_hist, job.inst->hidden_fsm_input.previous_packed_key[k]);
+            hist_bytes(sh_hist, job.inst->hidden_fsm_output.previous_packed_key[k]);
+        }
     hist_flush(sh_hist, job.hist);
 }
 
@@ -436,7 +441,7 @@ static __global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* _
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];
-            if (r == 0) v += (u64)SS_L * n_rows - (u64)SS_LOOKUPS_PER_CYCLE * capacity;
+            if (r == 0) v += (u64)SS_L * n_rows - (u64)SS_LOOKUPS_PER_CYCLE * capacity - 4 * SS_CF_NUM_BYTES;  // (the section's byte cells: counted in job.hist by k_ss_fill_row<A>)
         }
         mlt[r] = v;
     }

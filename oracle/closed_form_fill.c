@@ -17,12 +17,15 @@
 #define CELL(col, row) trace[(size_t)(col) * n_rows + (row)]
 
 typedef struct {
-    int first, n, n_links, n_consts, n_free, n_products, rows_per_cycle, pi_row_type;
+    int first, n, n_links, n_consts, n_free, n_products, rows_per_cycle, pi_row_type, n_bytes, n_linears, mult_col;
     const rc_link *links;
     const uint8_t *is_poseidon;
     const rc_cf_const *consts;
     const rc_cf_free *frees;
     const rc_cf_product *products;
+    const rc_cf_bytes *bytes;       /* lookup cells = the bytes of a limb cell of the row (the multiplicity column follows: +1 byte, -1 zero) */
+    const rc_cf_linear *linears;    /* cell = constant + sum coef * cell of the row */
+    const rc_cf_lin_term *lin_terms;
 } orc_cf_spec;
 /* the tables of the spec header with prefix PFX as an orc_cf_spec named CF_<PFX> */
 #define CF_SPEC(PFX)                                                                                                                  \
@@ -31,9 +34,13 @@ typedef struct {
     static const rc_cf_const PFX##_consts_[] = PFX##_CF_CONSTS_INIT;                                                                  \
     static const rc_cf_free PFX##_frees_[] = PFX##_CF_FREE_INIT;                                                                      \
     static const rc_cf_product PFX##_products_[] = PFX##_CF_PRODUCTS_INIT;                                                            \
+    static const rc_cf_bytes PFX##_bytes_[] = PFX##_CF_BYTES_INIT;                                                                    \
+    static const rc_cf_linear PFX##_linears_[] = PFX##_CF_LINEARS_INIT;                                                               \
+    static const rc_cf_lin_term PFX##_lin_terms_[] = PFX##_CF_LIN_TERMS_INIT;                                                         \
     static const orc_cf_spec CF_##PFX = {PFX##_CF_FIRST_ROW_TYPE, PFX##_CF_NUM_ROWS, PFX##_NUM_LINKS, PFX##_CF_NUM_CONSTS, PFX##_CF_NUM_FREE, \
-                                         PFX##_CF_NUM_PRODUCTS, PFX##_ROWS_PER_CYCLE, PFX##_ROW_PI, PFX##_links_, PFX##_is_poseidon_,   \
-                                         PFX##_consts_, PFX##_frees_, PFX##_products_}
+                                         PFX##_CF_NUM_PRODUCTS, PFX##_ROWS_PER_CYCLE, PFX##_ROW_PI, PFX##_CF_NUM_BYTES, PFX##_CF_NUM_LINEARS,  \
+                                         PFX##_MULT_COL, PFX##_links_, PFX##_is_poseidon_, PFX##_consts_, PFX##_frees_, PFX##_products_, \
+                                         PFX##_bytes_, PFX##_linears_, PFX##_lin_terms_}
 typedef void (*orc_cf_hook)(void *user, int row_type, uint64_t *trace, size_t n_rows, size_t row);
 
 /* src[k]: the encoding FREE cells of source k are taken from (0 observable input, 1 hidden FSM input, 2 hidden FSM output, 3 flags,
@@ -50,6 +57,25 @@ static void cf_fill(const orc_cf_spec *S, uint64_t *trace, size_t n_rows, size_t
             if (S->consts[k].row == rt) CELL(S->consts[k].col, row) = S->consts[k].value;
         for (int k = 0; k < S->n_free; k++)
             if (S->frees[k].row == rt) CELL(S->frees[k].col, row) = src[S->frees[k].src][S->frees[k].idx];
+        for (int k = 0; k < S->n_bytes; k++)
+            if (S->bytes[k].row == rt) {
+                const uint32_t limb = (uint32_t)CELL(S->bytes[k].col_limb, row);
+                for (int b = 0; b < 4; b++) {
+                    const uint64_t v = (limb >> (8 * b)) & 0xFF;
+                    CELL(S->bytes[k].col_b0 + b, row) = v;
+                    CELL(S->mult_col, v) += 1;
+                    CELL(S->mult_col, 0) -= 1;
+                }
+            }
+        for (int k = 0; k < S->n_linears; k++)
+            if (S->linears[k].row == rt) {
+                uint64_t acc = S->linears[k].constant;
+                for (int t = 0; t < S->linears[k].n_terms; t++) {
+                    const rc_cf_lin_term *tm = &S->lin_terms[S->linears[k].term0 + t];
+                    acc = orc_gl_add(acc, orc_gl_mul(tm->coef, CELL(tm->col, row)));
+                }
+                CELL(S->linears[k].col, row) = acc;
+            }
         for (int k = 0; k < S->n_products; k++)
             if (S->products[k].row == rt) CELL(S->products[k].col, row) = orc_gl_mul(CELL(S->products[k].col_a, row), CELL(S->products[k].col_b, row));
         if (hook) hook(user, rt, trace, n_rows, row);

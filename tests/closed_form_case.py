@@ -50,13 +50,19 @@ def decommit_sorter_tampers(capacity):
 
 def events_sorter_tampers(capacity):
     return section_tampers("zkw_events_sorter_circuit_spec.h", "ES", 22, capacity,
-                           extra=(("previous record's encoding at the start", "BND_IN_valid", "BND_IN"), ("handed-over previous key", "BND_OUT_kts", "BND_OUT")))
+                           extra=(("previous-record flag", "BND_IN_valid", "BND_IN"), ("handed-over previous key", "BND_OUT_kts", "BND_OUT"),
+                                  ("previous record's normalised encoding (register)", "BND_IN_ne3", "BND_IN"), ("its re-derivation from the FSM input", "NIE_NI_ne9", "NIE"),
+                                  ("a key byte of the FSM input's previous_item", "NIB1_NI_w7_b2", "NIB1"), ("a limb of the handed-over previous_item", "NOB0_NO_w5", "NOB0"),
+                                  ("the handed-over record's encoding", "NOE_NO_ne17", "NOE")))
 
 
 def storage_sorter_tampers(capacity):
     return section_tampers("zkw_storage_sorter_circuit_spec.h", "SS", 22, capacity,
                            extra=(("open-cell flag", "BND_IN_valid", "BND_IN"), ("handed-over depth", "BND_OUT_depth", "BND_OUT"),
-                                  ("cycle index", "BND_IN_cidx", "BND_IN")))
+                                  ("cycle index", "BND_IN_cidx", "BND_IN"), ("open cell's key chunk (register)", "BND_IN_kc4", "BND_IN"),
+                                  ("its re-derivation from the FSM input", "KIE_KI_kc9", "KIE"), ("a byte of the FSM input's packed key", "KIB1_KI_p5_b1", "KIB1"),
+                                  ("a limb of the handed-over packed key", "KOB0_KO_p2", "KOB0"), ("the handed-over key's chunk", "KOE_KO_kc17", "KOE"),
+                                  ("previous_key word of the FSM input", "FI5_FI5_i6", "FI5")))
 
 
 def log_demux_tampers(capacity):

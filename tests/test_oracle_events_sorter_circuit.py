@@ -53,7 +53,7 @@ def test_checker_notices_tampering(oracle):
     t = oracle.events_sorter_synthesize(o, 0, capacity, n_rows)
     assert oracle.events_sorter_check(t, capacity)[0] == 0
     rng = np.random.default_rng(1)
-    used = [(c, r) for c in range(138) for r in range(_bnd(capacity) + 40) if t[c, r] != 0]
+    used = [(c, r) for c in range(138) for r in range(_bnd(capacity) + 56) if t[c, r] != 0]
     for _ in range(40):
         c, r = used[rng.integers(len(used))]
         t2 = t.copy()

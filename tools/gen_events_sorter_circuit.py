@@ -225,23 +225,30 @@ def build():
     SEL.sel2(0, fi(31), (BIN, "kts"))
     SEL.sel2(0, fi(32 + 31), (BIN, "krb"))
     SEL.not_flag((BIN, "valid"))
-    # ne (the previous record's normalised encoding, what a later cycle pushes): zero at the start; for a continuing instance the FSM's
-    # previous_item is only committed — its 52 key / address bytes re-encoded in-trace would take nine more rows
+    # ne (the previous record's normalised encoding, what a later cycle pushes) = start ? 0 : the encoding re-derived in-trace from the
+    # FSM input's previous_item (eight bridge rows)
+    NI_rows, NEI, _ = normalised_encoding_rows(cf, "NI", lambda r, v, w: cf.copy(r, v, *fi(32 + w)))
+    cf.rows += NI_rows
     for k in range(20):
-        SEL.zero_if_flag((BIN, f"ne{k}"))
+        SEL.sel2(0, (NEI, f"NI_ne{k}"), (BIN, f"ne{k}"))
     # hidden FSM output: the registers after the last cycle
     OSEL = dsl.Selections(cf, "OSEL", flag_cell=(BOUT, "completion"))
     fo_key = OSEL.free_unless_flag((BOUT, "kts"), SRC.SRC_FSM_OUT, 31)  # a completing instance hands over placeholders (:174-181 of the sorter builders)
     fo_rb = OSEL.free_unless_flag((BOUT, "krb"), SRC.SRC_FSM_OUT, 32 + 31)
+    # the handed-over previous_item: its normalised encoding, re-derived from the words the FSM-output sponge absorbs, is the register ne
+    # unless the instance completes (eight more bridge rows; the words are FREE cells there, the sponge copies them)
+    NO_rows, NEO, fo_item = normalised_encoding_rows(cf, "NO", lambda r, v, w: cf.free_cell(r, v, SRC.SRC_FSM_OUT, 32 + 32 + w - 32))
+    for k in range(20):
+        OSEL.eq_unless_flag((NEO, f"NO_ne{k}"), (BOUT, f"ne{k}"))
     q9 = lambda h, q: [(BOUT, f"{h}{k}") for k in range(4)] + [(BOUT, f"tail_{q}{k}") for k in range(4)] + [(BOUT, f"len_{q}")]  # noqa: E731
     fo_words = ([(BOUT, f"lhs{r}") for r in range(2)] + [(BOUT, f"rhs{r}") for r in range(2)] + q9("uh", "u") + q9("sh", "s") +
-                [("const", 0)] * 4 + [(BOUT, f"final_rh{k}") for k in range(4)] + [(BOUT, "final_len_r")] + [fo_key] + [None] * 31 + [fo_rb] + [None] * 4)
+                [("const", 0)] * 4 + [(BOUT, f"final_rh{k}") for k in range(4)] + [(BOUT, "final_len_r")] + [fo_key] + [fo_item.get(w) if w != 31 else fo_rb for w in range(36)])
     assert len(fo_words) == 68
     FO = cf.sponge("FO", fo_words, free_src=SRC.SRC_FSM_OUT)
     # observable output (final_queue_state): completion ? the result queue after the flush : the placeholder (zeros)
     oo_words = [("const", 0)] * 4 + [OSEL.gate((BOUT, f"final_rh{k}")) for k in range(4)] + [OSEL.gate((BOUT, "final_len_r"))]
     pos = cf.rows.index(FO[0])
-    cf.rows[pos:pos] = OSEL.rows
+    cf.rows[pos:pos] = NO_rows + OSEL.rows
     OO = cf.sponge("OO", oo_words)
     # Fiat-Shamir challenges over the observable input's queue tails and lengths (events_sort_dedup.rs:104-116): 10 words, 40 challenges
     fs_words = [oi(4 + k) for k in range(4)] + [oi(8)] + [oi(9 + 4 + k) for k in range(4)] + [oi(17)]
@@ -254,12 +261,50 @@ def build():
     CP = cf.sponge("CP", cp_words)
     for k in range(4):
         cf.copy(PI, f"pi{k}", last(CP), f"{last(CP).name}_o{k}")
-    pos = cf.rows.index(last(FI)) + 1
+    pos = cf.rows.index(NEI) + 1
     cf.rows[pos:pos] = SEL.rows  # fill order: a row's copies come from rows before it (or from the register rows)
     build.cf = cf
 
     rows = U + S + R + [A] + N + [T, V, W, Q, BIN, BOUT] + F + [PI] + cf.rows
     return rows, regs
+
+
+# previous_item (LogQuery) words inside the FSM encoding: address 0..4, key 5..12, read_value 13..20, written_value 21..28, rw 29, aux 30,
+# rollback 31, is_service 32, shard 33, tx_number 34, timestamp 35
+def normalised_encoding_rows(cf, prefix, bind):
+    """The NORMALISED encoding of a log record (read value, timestamp, aux byte, rw and rollback flags cleared: events_sort_dedup.rs:541-553;
+    encoding log_query.rs:102-396) from its FSM words: seven rows split the 8 key and 5 address limbs into the 52 bytes that ride as the
+    3-byte tails of the encoding's words (two limbs per row: the geometry has 8 lookups), one row recomposes ne0..ne19.
+    bind(row, var, w): ties the cell to word w of previous_item (a copy of the FSM-input sponge's cell, or a FREE cell the FSM-output
+    sponge copies). Returns (rows, NE row, {w: (row, var)})."""
+    cells, rows, tb = {}, [], []
+    limb_words = list(range(5, 13)) + list(range(0, 5))  # tail bytes: key bytes, then address bytes
+    for j in range(7):
+        r = Row(f"{prefix}B{j}", False)
+        for w in limb_words[2 * j:2 * j + 2]:
+            v = f"{prefix}_w{w}"
+            r.slot(v)
+            bind(r, v, w)
+            cells[w] = (r, v)
+            tb += [(r, b) for b in cf.bytes_of(r, v, v)]
+        rows.append(r)
+    NE = Row(f"{prefix}E", False)
+    for i, (r, b) in enumerate(tb):
+        NE.slot(f"tb{i}")
+        cf.copy(NE, f"tb{i}", r, b)
+    for w in list(range(21, 29)) + [32, 33, 34]:
+        v = f"{prefix}_w{w}"
+        NE.slot(v)
+        bind(NE, v, w)
+        cells[w] = (NE, v)
+    for k in range(17):
+        base = [(1, f"{prefix}_w{21 + k - 8}")] if 8 <= k < 16 else []
+        cf.linear(NE, f"{prefix}_ne{k}", base + [(1 << 32, f"tb{3 * k}"), (1 << 40, f"tb{3 * k + 1}"), (1 << 48, f"tb{3 * k + 2}")], why=f"normalised encoding word {k}")
+    cf.linear(NE, f"{prefix}_ne17", [(1, f"{prefix}_w34"), (1 << 32, "tb51"), (1 << 48, f"{prefix}_w33")], why="ne17 = tx + address byte 19 << 32 + shard << 48 (aux cleared)")
+    cf.linear(NE, f"{prefix}_ne18", [(2, f"{prefix}_w32")], why="ne18 = 2 * is_service (rw cleared)")
+    cf.linear(NE, f"{prefix}_ne19", [], why="ne19 = 0 (rollback cleared)")
+    rows.append(NE)
+    return rows, NE, cells
 
 
 def links_of(rows, regs):

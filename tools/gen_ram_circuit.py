@@ -106,12 +106,24 @@ class ClosedForm:
 
     def __init__(self):
         self.rows, self.copies, self.p2_names, self.free, self.consts, self.products = [], [], [], [], [], []
+        self.byte_cells, self.linears = [], []
 
     def free_cell(self, row, var, src, idx):
         self.free.append((row, var, src, idx))
 
     def copy(self, row_a, var_a, row_b, var_b):
         self.copies.append((row_a, var_a, row_b, var_b))
+
+    def bytes_of(self, row, limb, tag):
+        """the four bytes of a 32-bit limb cell as lookup cells of the same row (limb = sum bytes * 2^8k), computed by a fill; returns their names"""
+        bs = row.bytes_of(limb, tag)
+        self.byte_cells.append((row, limb, bs[0]))
+        return bs
+
+    def linear(self, row, var, terms, const=0, why=""):
+        """var = const + sum coef * cell over cells of the same row, computed by a fill (terms: [(coef, var)])"""
+        row.c([(1, [var])] + [(-c, [v]) for c, v in terms] + ([(-const, [])] if const else []), why or f"{var} = linear combination")
+        self.linears.append((row, var, [(c % P, v) for c, v in terms], const % P))
 
     def sponge(self, prefix, words, squeeze=0, free_src=None):
         """words: list of None (FREE) | (row, var) (copy) | ("const", v). Returns the rows; word w lives at (rows[w // 8], f"{name}_i{w % 8}").
@@ -177,16 +189,24 @@ class ClosedForm:
         consts = sorted((step_of[id(r)], idx[id(r)], r.slot(v), val) for r, v, val in self.consts)
         free = sorted((step_of[id(r)], idx[id(r)], r.slot(v), src, i) for r, v, src, i in self.free)
         prods = sorted((step_of[id(r)], idx[id(r)], r.slot(t), r.slot(a), r.slot(b)) for r, t, a, b in self.products)
+        byts = sorted((step_of[id(r)], idx[id(r)], r.slot(limb), r.slot(b0)) for r, limb, b0 in self.byte_cells)
+        lins = sorted(((step_of[id(r)], idx[id(r)], r.slot(v), [(c, r.slot(x)) for c, x in terms], const) for r, v, terms, const in self.linears), key=lambda e: e[:3])
+        lin_terms, lin_entries = [], []
+        for st, ri, col, terms, const in lins:
+            lin_entries.append((st, ri, col, len(lin_terms), len(terms), const))
+            lin_terms += [(c_, coef) for coef, c_ in terms]
 
         def ranges(tab):
             return [(sum(1 for e in tab if e[0] < k), sum(1 for e in tab if e[0] == k)) for k in range(len(steps))]
 
         step_rows = [idx[id(r)] for rows_ in steps for r in rows_]
         row0 = [sum(len(x) for x in steps[:k]) for k in range(len(steps))]
-        sched = [(row0[k], len(steps[k])) + ranges(copies)[k] + ranges(consts)[k] + ranges(free)[k] + ranges(prods)[k] for k in range(len(steps))]
+        sched = [(row0[k], len(steps[k])) + ranges(copies)[k] + ranges(consts)[k] + ranges(free)[k] + ranges(prods)[k] + ranges(byts)[k] + ranges(lin_entries)[k]
+                 for k in range(len(steps))]
         return {"first": all_rows.index(section_rows[0]), "n": len(section_rows),
                 "consts": [e[1:] for e in consts], "free": [e[1:] for e in free], "products": [e[1:] for e in prods],
-                "copies": [e[1:] for e in copies], "steps": sched, "step_rows": step_rows}
+                "copies": [e[1:] for e in copies], "steps": sched, "step_rows": step_rows,
+                "bytes": [e[1:] for e in byts], "linears": [e[1:] for e in lin_entries], "lin_terms": lin_terms}
 
 
 class Selections:
@@ -261,6 +281,14 @@ class Selections:
         self.cf.copy(row, b, *b_cell)
         self.cf.free_cell(row, w, src, idx)
         return (row, w)
+
+    def eq_unless_flag(self, a_cell, b_cell, why=""):
+        """flag = 0 => a = b (copies of both)"""
+        row = self._row(2)
+        a, b = self._names("ab")
+        row.c([(1, [a]), (-1, [b]), (-1, ["flag", a]), (1, ["flag", b])], why or f"(1 - flag) * ({a_cell[1]} - {b_cell[1]}) = 0")
+        self.cf.copy(row, a, *a_cell)
+        self.cf.copy(row, b, *b_cell)
 
     def not_flag(self, target, why=""):
         """target = 1 - flag"""
@@ -640,14 +668,23 @@ def emit(rows, links, path, prefix="RC", guard="ZKW_RAM_CIRCUIT_SPEC_H",
             out.append("typedef struct { uint8_t row, col, col_a, col_b; } rc_cf_product; /* cell = cell a * cell b of the same row, computed by a fill after the row's copies */")
             out.append("typedef struct { uint8_t row_a, col_a, row_b, col_b; } rc_cf_copy;   /* the kind-5 links whose row_a is a section row or the PI row */")
             out.append("/* a step of the parallel fill schedule: rows whose copies come from earlier steps (or the register rows); index ranges into the")
-            out.append("   step-sorted tables: STEP_ROWS, COPIES, CONSTS, FREE, PRODUCTS */")
-            out.append("typedef struct { uint16_t row0, n_rows, copy0, n_copies, const0, n_consts, free0, n_free, prod0, n_prods; } rc_cf_step;")
+            out.append("   step-sorted tables: STEP_ROWS, COPIES, CONSTS, FREE, PRODUCTS, and the computed cells of the")
+            out.append("   step-sorted tables BYTES (lookup cells b0..b0+3 = the bytes of a limb cell of the row) and LINEARS (cell = constant + sum coef * cell of the row: terms in LIN_TERMS) */")
+            out.append("typedef struct { uint16_t row0, n_rows, copy0, n_copies, const0, n_consts, free0, n_free, prod0, n_prods, byte0, n_bytes, lin0, n_lins; } rc_cf_step;")
+            out.append("typedef struct { uint8_t row, col_limb, col_b0, _pad; } rc_cf_bytes;")
+            out.append("typedef struct { uint8_t row, col; uint16_t term0, n_terms; uint64_t constant; } rc_cf_linear;")
+            out.append("typedef struct { uint64_t coef; uint8_t col; } rc_cf_lin_term;")
         w(f"#define RC_CF_NUM_CONSTS {len(cf_tables['consts'])}\n#define RC_CF_NUM_FREE {len(cf_tables['free'])}")
         w("#define RC_CF_CONSTS_INIT {" + ", ".join(f"{{{a}, {b}, {c}ULL}}" for a, b, c in cf_tables["consts"]) + "}")
         w("#define RC_CF_FREE_INIT {" + ", ".join(f"{{{a}, {b}, {c}, {d}}}" for a, b, c, d in cf_tables["free"]) + "}")
         prods = cf_tables.get("products", [])
         w(f"#define RC_CF_NUM_PRODUCTS {len(prods)}")
         w("#define RC_CF_PRODUCTS_INIT {" + ", ".join(f"{{{a}, {b}, {c}, {d}}}" for a, b, c, d in prods) + ("}" if prods else "{0, 0, 0, 0}}") + "  /* (one zero entry when there are none) */")
+        for name, key, fmt in (("BYTES", "bytes", lambda e: f"{{{e[0]}, {e[1]}, {e[2]}, 0}}"), ("LINEARS", "linears", lambda e: f"{{{e[0]}, {e[1]}, {e[2]}, {e[3]}, {e[4]}ULL}}"),
+                               ("LIN_TERMS", "lin_terms", lambda e: f"{{{e[1]}ULL, {e[0]}}}")):
+            tab = cf_tables.get(key, [])
+            w(f"#define RC_CF_NUM_{name} {len(tab)}")
+            w(f"#define RC_CF_{name}_INIT {{" + (", ".join(fmt(e) for e in tab) if tab else "{0}") + "}  /* (one zero entry when there are none) */")
         w(f"#define RC_CF_NUM_COPIES {len(cf_tables['copies'])}")
         w("#define RC_CF_COPIES_INIT {" + ", ".join(f"{{{a}, {b}, {c}, {d}}}" for a, b, c, d in cf_tables["copies"]) + "}")
         w(f"#define RC_CF_NUM_STEPS {len(cf_tables['steps'])}")

@@ -269,22 +269,30 @@ def build():
     for k in range(8):
         SEL.sel2(0, fi(60 + k), (BIN, f"base{k}"))
         SEL.sel2(0, fi(68 + k), (BIN, f"cur{k}"))
-    # kc (the open cell's key as 3-byte chunks of the packed key's 52 bytes): zero at the start; for a continuing instance the FSM's
-    # previous_packed_key is only committed — re-chunking its bytes in-trace would take five more rows
+    # kc (the open cell's key as 3-byte chunks of the packed key's 52 bytes) = start ? 0 : re-chunked in-trace from the FSM input's
+    # previous_packed_key (five bridge rows); previous_key / previous_address repeat the packed key's limbs
+    KI_rows, KIE, _ = packed_key_rows(cf, "KI", lambda r, v, j: cf.copy(r, v, *fi(32 + j)))
+    cf.rows += KI_rows
     for k in range(18):
-        SEL.zero_if_flag((BIN, kc[k]))
+        SEL.sel2(0, (KIE, f"KI_kc{k}"), (BIN, kc[k]))
+    for j in range(13):
+        cf.copy(*fi(45 + j), *fi(32 + j))
     cf.copy(BIN, "cidx", *fi(31))  # cycle_idx is carried whatever the start flag says (storage_sort_dedup.rs:597)
     # hidden FSM output: the registers after the last cycle; the words the builders replace by placeholders when the instance completes
     # (nobody consumes them) are the registers unless completion
     OSEL = dsl.Selections(cf, "OSEL", flag_cell=(BOUT, "completion"))
     q9 = lambda h, q: [(BOUT, f"{h}{k}") for k in range(4)] + [(BOUT, f"tail_{q}{k}") for k in range(4)] + [(BOUT, f"len_{q}")]  # noqa: E731
     unless = lambda reg, w: OSEL.free_unless_flag((BOUT, reg), SRC.SRC_FSM_OUT, w)  # noqa: E731
+    # the handed-over packed key: its chunks, re-derived from the words the FSM-output sponge absorbs, are the registers kc unless the instance completes
+    KO_rows, KOE, ko = packed_key_rows(cf, "KO", lambda r, v, j: cf.free_cell(r, v, SRC.SRC_FSM_OUT, 32 + j))
+    for k in range(18):
+        OSEL.eq_unless_flag((KOE, f"KO_kc{k}"), (BOUT, kc[k]))
     fo_words = ([(BOUT, f"lhs{r}") for r in range(2)] + [(BOUT, f"rhs{r}") for r in range(2)] + q9("uh", "u") + q9("sh", "s") +
                 [("const", 0)] * 4 + [(BOUT, f"final_rh{k}") for k in range(4)] + [(BOUT, "final_len_r")] + [unless("cidx", 31)] +
-                [None] * 26 + [unless("kts", 58), unless("has", 59)] + [unless(f"base{k}", 60 + k) for k in range(8)] +
+                ko + ko + [unless("kts", 58), unless("has", 59)] + [unless(f"base{k}", 60 + k) for k in range(8)] +
                 [unless(f"cur{k}", 68 + k) for k in range(8)] + [unless("depth", 76)])
     assert len(fo_words) == 77
-    cf.rows += OSEL.rows
+    cf.rows += KO_rows + OSEL.rows
     FO = cf.sponge("FO", fo_words, free_src=SRC.SRC_FSM_OUT)
     # observable output (final_sorted_queue_state): completion ? the result queue after the flush : the placeholder (zeros)
     OS2 = dsl.Selections(cf, "OGATE", flag_cell=(BOUT, "completion"))
@@ -302,12 +310,38 @@ def build():
     CP = cf.sponge("CP", cp_words)
     for k in range(4):
         cf.copy(PI, f"pi{k}", last(CP), f"{last(CP).name}_o{k}")
-    pos = cf.rows.index(last(FI)) + 1
+    pos = cf.rows.index(KIE) + 1
     cf.rows[pos:pos] = SEL.rows  # fill order: a row's copies come from rows before it (or from the register rows)
     esg.build.cf = cf  # links_of appends the section's copies
 
     rows = U + S + R + [A] + X + [K, C1, C2, Q, BIN, BOUT] + F + [PI] + cf.rows
     return rows, regs
+
+
+def packed_key_rows(cf, prefix, bind):
+    """The open cell's key as the registers hold it — eighteen 3-byte chunks kc0..kc17 of the 52 little-endian bytes of previous_packed_key
+    (key limbs, then address limbs: comparison_key, log_query.rs:82-92) — from the FSM's thirteen words: four rows split the limbs into bytes
+    (16 lookups per row), one row recomposes the chunks. bind(row, var, j): ties the cell to previous_packed_key[j] (a copy of the FSM-input
+    sponge's cell, or a FREE cell the FSM-output sponge copies). Returns (rows, KE row, [(row, var) of limb j])."""
+    rows, tb, limbs = [], [], []
+    for j0 in range(0, 13, 4):
+        r = Row(f"{prefix}B{j0 // 4}", False)
+        for j in range(j0, min(j0 + 4, 13)):
+            v = f"{prefix}_p{j}"
+            r.slot(v)
+            bind(r, v, j)
+            limbs.append((r, v))
+            tb += [(r, b) for b in cf.bytes_of(r, v, v)]
+        rows.append(r)
+    KE = Row(f"{prefix}E", False)
+    for i, (r, b) in enumerate(tb):
+        KE.slot(f"kb{i}")
+        cf.copy(KE, f"kb{i}", r, b)
+    for k in range(17):
+        cf.linear(KE, f"{prefix}_kc{k}", [(1, f"kb{3 * k}"), (1 << 8, f"kb{3 * k + 1}"), (1 << 16, f"kb{3 * k + 2}")], why=f"key chunk {k}")
+    cf.linear(KE, f"{prefix}_kc17", [(1, "kb51")], why="key chunk 17 = the last byte")
+    rows.append(KE)
+    return rows, KE, limbs
 
 
 if __name__ == "__main__":
