@@ -200,9 +200,11 @@ static __global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob
     } else if (i < rs) {
         zero_gap_row(trace, n_rows, (size_t)ROW * rs + i);
     }
-    if (WHICH == 1 && blockIdx.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells (GIN: bytes of the FSM input's page and first-encountered timestamp)
+    if (WHICH == 1 && blockIdx.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells (GIN / GOUT: bytes of the FSM records' page and first-encountered timestamp)
         hist_bytes(sh_hist, job.inst->hidden_fsm_input.previous_record.memory_page);
         hist_bytes(sh_hist, job.inst->hidden_fsm_input.first_encountered_timestamp);
+        hist_bytes(sh_hist, job.inst->hidden_fsm_output.previous_record.memory_page);  // GOUT: the handed-over group's page and first timestamp
+        hist_bytes(sh_hist, job.inst->hidden_fsm_output.first_encountered_timestamp);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -388,7 +390,7 @@ static __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* _
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];
-            if (r == 0) v += (u64)DS_L * n_rows - (u64)DS_LOOKUPS_PER_CYCLE * capacity - 8;  // (8: GIN's byte cells, counted in job.hist by k_ds_fill_poseidon<1>)
+            if (r == 0) v += (u64)DS_L * n_rows - (u64)DS_LOOKUPS_PER_CYCLE * capacity - 8 - 4 * DS_CF_NUM_BYTES;  // (GIN's 8 byte cells and GOUT's, counted in job.hist by k_ds_fill_poseidon<1>)
         }
         mlt[r] = v;
     }

@@ -45,7 +45,8 @@ def section_tampers(header, prefix, rows_per_cycle, capacity, extra=(), challeng
 def decommit_sorter_tampers(capacity):
     return section_tampers("zkw_decommit_sorter_circuit_spec.h", "DS", 7, capacity,
                            extra=(("page byte of the open group", "GIN_gpage_b0", "GIN"), ("open group's encoding", "GIN_gge2", "GIN"),
-                                  ("open-group flag", "BND_IN_gvalid", "BND_IN")))
+                                  ("open-group flag", "BND_IN_gvalid", "BND_IN"), ("handed-over first-encountered timestamp", "GOUT_gof", "GOUT"),
+                                  ("handed-over group's encoding", "GOUT_goge1", "GOUT")))
 
 
 def events_sorter_tampers(capacity):

@@ -71,7 +71,7 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
     assert ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)[0] == 0
     host = t.get(0)
     rng = np.random.default_rng(2)
-    used = np.argwhere(host[:148, :7 * 128 + 53] != 0)
+    used = np.argwhere(host[:148, :7 * 128 + 54] != 0)
     base = native.load().zkw_trace_device_ptr(t.handle, 0)
     import ctypes as C
 

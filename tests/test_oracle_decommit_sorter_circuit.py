@@ -57,7 +57,7 @@ def test_checker_notices_tampering(oracle):
     t = oracle.decommit_sorter_synthesize(o, 0, capacity, n_rows)
     assert oracle.decommit_sorter_check(t, capacity)[0] == 0
     rng = np.random.default_rng(1)
-    used = [(c, r) for c in range(148) for r in range(_bnd(capacity) + 53) if t[c, r] != 0]
+    used = [(c, r) for c in range(148) for r in range(_bnd(capacity) + 54) if t[c, r] != 0]
     for _ in range(40):
         c, r = used[rng.integers(len(used))]
         t2 = t.copy()

@@ -231,9 +231,29 @@ def build():
                 [(BOUT, f"lhs{r}") for r in range(2)] + [(BOUT, f"rhs{r}") for r in range(2)] + [(BOUT, v) for v in key_regs] +
                 [(BOUT, v) for v in key_regs[1:]] + [(BOUT, "page"), None, (BOUT, "ts"), None])  # is_fresh / first_encountered_timestamp: only committed
     assert len(fo_words) == 100
+    # the handed-over open group: its encoding re-derived from the FSM output's words (hash = the key registers, page, first_encountered_timestamp,
+    # fresh) is the register ge unless the instance completes (the builders hand over placeholders then, :174-181)
+    GOUT = Row("GOUT", False)
+    for v in ("gop", "gof", "goh0", "goh1", "goh2"):
+        GOUT.slot(v)
+    cf.copy(GOUT, "gop", BOUT, "page")
+    cf.free_cell(GOUT, "gof", SRC.SRC_FSM_OUT, 99)
+    for k in range(3):
+        cf.copy(GOUT, f"goh{k}", BOUT, f"h{k}")
+    opb = cf.bytes_of(GOUT, "gop", "gop")
+    otb = cf.bytes_of(GOUT, "gof", "gof")
+    cf.linear(GOUT, "goge0", [(1, "goh0"), (1 << 32, opb[0]), (1 << 40, opb[1]), (1 << 48, opb[2])], why="ge0 of the handed-over group")
+    cf.linear(GOUT, "goge1", [(1, "goh1"), (1 << 32, opb[3]), (1 << 40, otb[0]), (1 << 48, otb[1])], why="ge1")
+    cf.linear(GOUT, "goge2", [(1, "goh2"), (1 << 32, otb[2]), (1 << 40, otb[3])], const=1 << 48, why="ge2 (fresh)")
+    cf.rows.append(GOUT)
+    fo_words[99] = (GOUT, "gof")
+    OSEL = dsl.Selections(cf, "OSEL", flag_cell=(BOUT, "completion"))
+    for k in range(3):
+        OSEL.eq_unless_flag((GOUT, f"goge{k}"), (BOUT, f"ge{k}"))
+    for k in range(3, 8):
+        OSEL.eq_unless_flag((BOUT, f"es{k}"), (BOUT, f"ge{k}"))
     FO = cf.sponge("FO", fo_words, free_src=SRC.SRC_FSM_OUT)
     # observable output (final_queue_state): completion ? the deduplicated queue after the flush : the placeholder (zeros), :340-372
-    OSEL = dsl.Selections(cf, "OSEL", flag_cell=(BOUT, "completion"))
     oo_words = [("const", 0)] * 12 + [OSEL.gate((BOUT, f"final_rh{k}")) for k in range(12)] + [OSEL.gate((BOUT, "final_len_r"))]
     cf.rows += OSEL.rows
     OO = cf.sponge("OO", oo_words)
