@@ -198,6 +198,48 @@ def full_blocks_batched(local_rank, blk, K=48, rounds=3, rank=0, world=1, comm=N
     return best
 
 
+
+def setup_commit_gpu(local_rank):
+    """The setup side as field elements (create_base_layer_setup_data, src/prover_utils.rs:48-197) at production size:
+    131 columns x 2^20 rows (the events sorter's setup columns' shape), LDE x 2, Merkle tree with cap 16, on device-resident columns.
+    Per-kernel times from the library's own events; NTT passes as GB/s over their read + write, leaf hashing as permutations/s. Not part
+    of `value`."""
+    import ctypes as C_
+    ctx = native.Context(local_rank)
+    ctx.set_pointer_mode(native.PTR_DEVICE)
+    lib = native.load()
+    log_n, n_cols, lde = 20, 131, 2
+    n = 1 << log_n
+    g = torch.Generator(device="cuda").manual_seed(1)
+    vals = torch.randint(0, 2**62, (n_cols, n), dtype=torch.int64, device="cuda", generator=g)
+    ext = torch.empty((lde, n_cols, n), dtype=torch.int64, device="cuda")
+    cap = torch.empty((16, 4), dtype=torch.int64, device="cuda")
+
+    def run():
+        native._check(lib.zkw_lde(ctx.handle, vals.data_ptr(), log_n, n_cols, lde, ext.data_ptr()))
+        native._check(lib.zkw_merkle_tree_with_cap(ctx.handle, ext.data_ptr(), lde, n_cols, n, 16, cap.data_ptr(), None))
+    run(); ctx.synchronize()
+    ctx.profile_enable(True); ctx.profile_reset()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    prof = {k: (v[0] / reps, v[1] // reps) for k, v in ctx.profile().items()}
+    ctx.profile_enable(False)
+    arr = n_cols * n * 8
+    out = {"columns": n_cols, "log_n": log_n, "lde_factor": lde, "cap_size": 16, "ms_per_commit": dt * 1e3,
+           "kernels_ms": {k: ms for k, (ms, c) in prof.items()},
+           "ntt_pass_GBps_read_plus_write": {k: c * 2 * arr / ms / 1e6 for k, (ms, c) in prof.items() if k.startswith("k_ntt")},
+           "leaf_permutations_per_s": lde * n * ((n_cols + 7) // 8) / (prof["k_merkle_leaves"][0] * 1e-3) if "k_merkle_leaves" in prof else None,
+           "note": "NTT passes are VALU-bound (5 multiplications + 10 additions of a 64-bit prime field per point and pass on 32-bit ALUs: "
+                   "0.86 of VALU issue peak by SQ_INSTS_VALU, profiles/r04/setup_commit_valu.txt), not HBM-bound"}
+    del vals, ext, cap
+    ctx.close()
+    torch.cuda.empty_cache()
+    return out
+
 def hash_circuits_gpu(local_rank, blk):
     """Synthesis rates of the netlist circuits at the reference's geometry — 2^20 rows, capacities of
     geometry_config.rs — on synthetic precompile calls / the block's bytecodes, 8 (4) traces per call. Two rates per circuit:
@@ -732,6 +774,10 @@ def main():
                 torch.cuda.empty_cache()
                 native.trim_caches()
                 out["hash_circuits"] = hash_circuits_gpu(local_rank, blk_inputs)
+                try:
+                    out["setup_commit"] = setup_commit_gpu(local_rank)
+                except Exception as e:  # a side leg: never the reason the contract's line is missing
+                    out["setup_commit"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(base, args.cpu_sample)
             if full_block is not None:
