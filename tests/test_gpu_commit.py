@@ -117,3 +117,25 @@ def test_setup_commit_at_production_size(ctx, oracle):
     gamma, w = oracle.root_of_unity(log_n + 1), oracle.root_of_unity(log_n)
     for c, i in ((0, 3), (1, 99999)):
         assert oracle.poly_eval(coeffs, 7 * pow(gamma, c, P) * pow(w, i, P) % P) == int(ext[c, -1, i])
+
+
+def test_setup_commit_of_every_synthesized_type(ctx, oracle):
+    """all twelve layouts commit (2^18 rows, reduced capacities): twelve different caps; ECRecover's (the newest copy classes: its EC section)
+    equals the oracle's pipeline over the device's columns, and its columns are sigma as field elements + the selector column"""
+    log_n = 18
+    caps = {2: 1000, 3: 300, 4: 1000, 5: 50, 6: 300, 7: 2, 8: 1000, 9: 1000, 10: 4, 11: 1000, 12: 1000, 13: 100}
+    commits = {t: ctx.setup_commit(t, c, log_n) for t, c in caps.items()}
+    assert all(v.shape == (16, 4) and int(v.max()) < P for v in commits.values())
+    distinct = {tuple(v.reshape(-1)) for t, v in commits.items() if t != 12}   # (11 and 12 share one layout)
+    assert len(distinct) == 11 and np.array_equal(commits[11], commits[12])
+    cols = ctx.setup_columns(7, 2, log_n)
+    sigma = native.setup_copy_permutation(7, 2, 1 << log_n)
+    assert cols.shape[0] == sigma.shape[0] + 1
+    om = oracle.gl_powers(oracle.root_of_unity(log_n), 1 << log_n)
+    rng = np.random.default_rng(7)
+    for cell in rng.integers(0, sigma.size, 200):
+        c, r = divmod(int(cell), 1 << log_n)
+        t = int(sigma[c, r])
+        assert int(cols[c, r]) == pow(7, t >> log_n, P) * int(om[t & ((1 << log_n) - 1)]) % P
+    want = oracle.merkle_tree_with_cap(oracle.lde(cols, 2), 16)
+    assert np.array_equal(commits[7], want[-16:])
