@@ -192,15 +192,21 @@ extern "C" int zkw_merkle_tree_with_cap(zkw_ctx* ctx, const uint64_t* leaf_cols,
 // w^row', coset representatives k_j = 7^j), then ONE selector column (zkw_setup_row_selectors: the byte as a field element).
 extern "C" int zkw_setup_num_columns(uint8_t circuit_type, uint32_t* n_columns) {
     if (!n_columns) return fail(ZKW_ERR_INVALID, "zkw_setup_num_columns: null argument");
-    uint32_t g = 0;
+    uint32_t g = 0, tc = 0;
     ZKW_TRY(zkw_setup_copy_permutation(circuit_type, 0, 0, nullptr, &g));
-    *n_columns = g + 1;
+    ZKW_TRY(zkw_setup_lookup_tables(circuit_type, 0, nullptr, &tc));
+    *n_columns = g + 1 + tc;
     return ZKW_OK;
 }
 
 static int setup_columns_device(zkw_ctx* ctx, uint8_t circuit_type, uint32_t capacity, uint32_t log_n, u64* d_cols, uint32_t n_setup_cols) {
     const size_t n = (size_t)1 << log_n;
-    const uint32_t G = n_setup_cols - 1;
+    uint32_t tc = 0;
+    ZKW_TRY(zkw_setup_lookup_tables(circuit_type, 0, nullptr, &tc));
+    const uint32_t G = n_setup_cols - 1 - tc;
+    std::vector<uint64_t> tables((size_t)tc * n);
+    ZKW_TRY(zkw_setup_lookup_tables(circuit_type, n, tables.data(), &tc));
+    HIP_TRY(hipMemcpyAsync(d_cols + (size_t)(G + 1) * n, tables.data(), tables.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     std::vector<uint64_t> sigma((size_t)G * n);
     uint32_t g2 = 0;
     ZKW_TRY(zkw_setup_copy_permutation(circuit_type, capacity, n, sigma.data(), &g2));

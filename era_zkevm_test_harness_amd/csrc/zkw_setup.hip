@@ -468,3 +468,42 @@ extern "C" int zkw_check_copy_permutation(zkw_ctx* ctx, const zkw_trace* t, size
     return ZKW_OK;
 }
 
+// Setup side, the lookup tables as columns: what the reference's setup keeps as table polynomials (add_tables of the wrappers, e.g.
+// base_layer/sha256_round_function.rs:116-150; boojum's create_*_table, absent). Row t of the stacked table = row t of the multiplicity
+// column: the table's cells (inputs, then outputs: `width` columns) and a table-id column (index in the circuit's table list + 1; 0 = no
+// table row). Queue circuits: the one 8-bit range table (width 1). Netlist circuits: their table list; ECRecover's FixedBaseMul<i, C>
+// tables come from ec_build_fixed_tables. cols = NULL only reports *n_columns (= width + 1).
+extern "C" int zkw_setup_lookup_tables(uint8_t circuit_type, size_t n_rows, uint64_t* cols, uint32_t* n_columns) {
+    if (!n_columns) return fail(ZKW_ERR_INVALID, "zkw_setup_lookup_tables: null argument");
+    const nl_spec* ns = nl_host_spec(circuit_type);
+    LinkSpec sp;
+    if (!ns && !link_spec_of(circuit_type, &sp)) return fail(ZKW_ERR_INVALID, "zkw_setup_lookup_tables: circuit type %u has no layout in this library", (unsigned)circuit_type);
+    const uint32_t width = ns ? ns->w : 1;
+    *n_columns = width + 1;
+    if (!cols) return ZKW_OK;
+    const size_t total = ns ? ns->total_table_rows : 256;
+    if (total > n_rows) return fail(ZKW_ERR_INVALID, "zkw_setup_lookup_tables: %zu table rows need more than %zu rows", total, n_rows);
+    memset(cols, 0, (size_t)(width + 1) * n_rows * sizeof(uint64_t));
+    if (!ns) {
+        for (size_t r = 0; r < 256; r++) { cols[r] = r; cols[n_rows + r] = 1; }
+        return ZKW_OK;
+    }
+    std::vector<uint32_t> fixed;
+    for (uint32_t k = 0; k < ns->n_tables; k++) {
+        const nl_table& t = ns->tables[k];
+        if (t.fn > NL_FN_SPLIT4 && fixed.empty()) { fixed.resize(EC_FIXED_WORDS); ec_build_fixed_tables(fixed.data()); }  // (fn 8: FixedBaseMul, param = 8 C + i)
+        for (uint32_t key = 0; key < t.rows; key++) {
+            uint32_t a[3] = {0, 0, 0}, o[3] = {0, 0, 0};
+            for (uint32_t i = 0; i < t.n_in; i++) a[i] = (key >> (t.in_bits * i)) & ((1u << t.in_bits) - 1);
+            if (t.fn <= NL_FN_SPLIT4) nl_table_eval(t.fn, t.param, a, o);
+            else { o[0] = fixed[((size_t)t.param * 256 + key) * 2]; o[1] = fixed[((size_t)t.param * 256 + key) * 2 + 1]; }
+            const size_t row = (size_t)t.offset + key;
+            uint32_t c = 0;
+            for (uint32_t i = 0; i < t.n_in; i++) cols[(size_t)c++ * n_rows + row] = a[i];
+            for (uint32_t i = 0; i < t.n_out && c < width; i++) cols[(size_t)c++ * n_rows + row] = o[i];
+            cols[(size_t)width * n_rows + row] = k + 1;
+        }
+    }
+    return ZKW_OK;
+}
+

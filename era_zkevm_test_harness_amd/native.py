@@ -48,6 +48,7 @@ SYMBOLS = [
     ("zkw_lde", _int, [_vp, _vp, _u32, _sz, _u32, _vp]),
     ("zkw_merkle_tree_words", _sz, [_sz, _u32]),
     ("zkw_merkle_tree_with_cap", _int, [_vp, _vp, _sz, _sz, _sz, _u32, _vp, _vp]),
+    ("zkw_setup_lookup_tables", _int, [C.c_uint8, _sz, _vp, _vp]),
     ("zkw_setup_num_columns", _int, [C.c_uint8, _vp]),
     ("zkw_setup_columns", _int, [_vp, C.c_uint8, _u32, _u32, _vp]),
     ("zkw_setup_commit", _int, [_vp, C.c_uint8, _u32, _u32, _u32, _u32, _vp]),
@@ -1822,6 +1823,15 @@ def setup_row_selectors(circuit_type, capacity=0, n_rows=1 << 20):
     """zkw_setup_row_selectors: the selector (row type / lookup table id) of every row of this library's layout; no GPU needed"""
     out = np.zeros(n_rows, np.uint8)
     _check(load().zkw_setup_row_selectors(circuit_type, capacity, n_rows, _np_ptr(out)))
+    return out
+
+
+def setup_lookup_tables(circuit_type, n_rows):
+    """zkw_setup_lookup_tables: [width + 1][n_rows]: the stacked lookup table's cells, then the table-id column; no GPU needed"""
+    nc = C.c_uint32(0)
+    _check(load().zkw_setup_lookup_tables(circuit_type, 0, None, C.byref(nc)))
+    out = np.zeros((nc.value, n_rows), np.uint64)
+    _check(load().zkw_setup_lookup_tables(circuit_type, n_rows, _np_ptr(out), C.byref(nc)))
     return out
 
 

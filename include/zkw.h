@@ -190,14 +190,18 @@ int zkw_check_copy_permutation(zkw_ctx *ctx, const zkw_trace *t, size_t slot, co
    zkw_merkle_tree_with_cap: leaf_cols[set][column][i] (leaf index = set * n + i) -> cap[cap_size][4]; tree (optional, NULL to skip):
      every level, leaves first, zkw_merkle_tree_words(n_sets * n, cap_size) words — the cap is its last level.
    zkw_setup_num_columns / zkw_setup_columns: the setup columns of one of this library's layouts as field elements
-     ([n_columns][2^log_n]): the sigma columns of zkw_setup_copy_permutation (cell (c', r') as k_c' * w^r'), then the selector
-     column of zkw_setup_row_selectors. zkw_setup_commit: those columns -> monomial form -> LDE -> tree -> cap[cap_size][4]
+     ([n_columns][2^log_n]): the sigma columns of zkw_setup_copy_permutation (cell (c', r') as k_c' * w^r'), the selector
+     column of zkw_setup_row_selectors, then the lookup-table columns of zkw_setup_lookup_tables. zkw_setup_commit: those columns -> monomial form -> LDE -> tree -> cap[cap_size][4]
      (host pointer in host mode), all on the device. */
 int zkw_ntt(zkw_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t log_n, size_t n_cols, int inverse);
 int zkw_lde(zkw_ctx *ctx, const uint64_t *values, uint32_t log_n, size_t n_cols, uint32_t lde_factor, uint64_t *out);
 size_t zkw_merkle_tree_words(size_t n_leaves, uint32_t cap_size);
 int zkw_merkle_tree_with_cap(zkw_ctx *ctx, const uint64_t *leaf_cols, size_t n_sets, size_t n_cols, size_t n, uint32_t cap_size,
                              uint64_t *cap, uint64_t *tree);
+/* the lookup tables of a layout as columns (host; what the wrappers' add_tables put into the setup): cols[c][t] for row t of the stacked table
+   (= row t of the multiplicity column): the table's cells (inputs, then outputs: width columns), then a table-id column (1-based index in the
+   circuit's table list, 0 = not a table row). Queue circuits: the 8-bit range table (width 1). cols = NULL only reports *n_columns. */
+int zkw_setup_lookup_tables(uint8_t circuit_type, size_t n_rows, uint64_t *cols, uint32_t *n_columns);
 int zkw_setup_num_columns(uint8_t circuit_type, uint32_t *n_columns);
 int zkw_setup_columns(zkw_ctx *ctx, uint8_t circuit_type, uint32_t capacity, uint32_t log_n, uint64_t *columns);
 int zkw_setup_commit(zkw_ctx *ctx, uint8_t circuit_type, uint32_t capacity, uint32_t log_n, uint32_t lde_factor, uint32_t cap_size,

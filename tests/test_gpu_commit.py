@@ -69,14 +69,16 @@ def test_merkle_tree_matches_oracle(ctx, oracle, n_sets, n_cols, n, cap):
 
 
 def test_setup_commit_of_a_layout(ctx, oracle):
-    """RAMPermutation at capacity 300 in 2^12 rows: the columns are sigma as field elements + the selector column; the cap of the device
+    """RAMPermutation at capacity 300 in 2^12 rows: the columns are sigma as field elements, the selector column, the lookup-table columns; the cap of the device
     pipeline == the oracle's pipeline on the same columns; a leaf of the tree opens to that cap; a different capacity commits differently"""
     ctype, cap, log_n = 8, 300, 12
     n = 1 << log_n
     cols = ctx.setup_columns(ctype, cap, log_n)
     sigma = native.setup_copy_permutation(ctype, cap, n)
     sel = native.setup_row_selectors(ctype, cap, n)
-    assert cols.shape == (sigma.shape[0] + 1, n) and np.array_equal(cols[-1], sel.astype(np.uint64))
+    tab = native.setup_lookup_tables(ctype, n)
+    G = sigma.shape[0]
+    assert cols.shape == (G + 1 + tab.shape[0], n) and np.array_equal(cols[G], sel.astype(np.uint64)) and np.array_equal(cols[G + 1:], tab)
     w = oracle.root_of_unity(log_n)
     om = oracle.gl_powers(w, n)
     for c, r in ((0, 0), (5, 17), (130, 2000), (132, n - 1)):
@@ -91,7 +93,7 @@ def test_setup_commit_of_a_layout(ctx, oracle):
 
 
 def test_setup_commit_at_production_size(ctx, oracle):
-    """EventsSorter at its production capacity, 2^20 rows, LDE x 2, cap 16 (131 columns): the device cap equals a tree built from the device's
+    """EventsSorter at its production capacity, 2^20 rows, LDE x 2, cap 16 (133 columns): the device cap equals a tree built from the device's
     LDE columns, and sampled leaves open to it by the reference's path rule with the oracle's hashes"""
     ctype, log_n = 11, 20
     n = 1 << log_n
@@ -112,7 +114,7 @@ def test_setup_commit_at_production_size(ctx, oracle):
             width //= 2
             idx >>= 1
         assert np.array_equal(cur, commit[idx])
-    # spot-check the extension of the selector column against Horner evaluation
+    # spot-check the extension of the last column (the table ids) against Horner evaluation
     coeffs = ctx.ntt(cols[-1:], inverse=True)[0]
     gamma, w = oracle.root_of_unity(log_n + 1), oracle.root_of_unity(log_n)
     for c, i in ((0, 3), (1, 99999)):
@@ -130,7 +132,7 @@ def test_setup_commit_of_every_synthesized_type(ctx, oracle):
     assert len(distinct) == 11 and np.array_equal(commits[11], commits[12])
     cols = ctx.setup_columns(7, 2, log_n)
     sigma = native.setup_copy_permutation(7, 2, 1 << log_n)
-    assert cols.shape[0] == sigma.shape[0] + 1
+    assert cols.shape[0] == sigma.shape[0] + 1 + 4 and np.array_equal(cols[sigma.shape[0] + 1:], native.setup_lookup_tables(7, 1 << log_n))
     om = oracle.gl_powers(oracle.root_of_unity(log_n), 1 << log_n)
     rng = np.random.default_rng(7)
     for cell in rng.integers(0, sigma.size, 200):

@@ -110,3 +110,48 @@ def test_ecrecover_selectors(oracle):
     t = oracle.ecrecover_synthesize(b, 0, cap, n_rows)
     assert not t[:128, sel == nv.ROW_PADDING].any()
     assert not t[80:128, g["first_row"]:g["rows_used"]][:, ec.reshape(-1) == 0xF0].any()  # rows without lookups: zero lookup cells
+
+
+def test_lookup_tables_as_columns(oracle):
+    """zkw_setup_lookup_tables: the stacked table a layout's multiplicity column counts, as columns. Every table row obeys the table's
+    function (restated above from the reference's table set), every table has all its keys, the row count is the layout's, and every
+    lookup tuple of an oracle trace is a row of the table its selector names."""
+    for ctype, cap, trace, col0, width, lpr in _netlist_cases(oracle):
+        tab = nv.setup_lookup_tables(ctype, N_ROWS)
+        assert tab.shape == (width + 1, N_ROWS)
+        ids = tab[width].astype(np.int64)
+        lay = nv.circuit_layout(ctype, cap)
+        assert int((ids != 0).sum()) == int(lay["total_table_rows"]) and not tab[:, ids == 0].any()
+        fns = _tables(ctype)
+        key = lambda cells: sum(c.astype(np.uint64) << np.uint64(16 * i) for i, c in enumerate(cells))  # noqa: E731
+        sel = nv.setup_row_selectors(ctype, cap, N_ROWS)
+        for t, (n_in, fn) in fns.items():
+            rows = np.flatnonzero(ids == t)
+            if rows.size == 0:
+                continue  # (ByteSplit<7> is type 10's only)
+            cells = [tab[k, rows].astype(np.int64) for k in range(width)]
+            outs = fn(*cells[:n_in])
+            for k, o in enumerate(outs):
+                assert np.array_equal(cells[n_in + k], o), (ctype, t, k)
+            bits = 4 if ctype in (3, 6) else 8
+            assert rows.size == 1 << (bits * n_in) and np.unique(key(cells[:n_in])).size == rows.size  # every key once
+            # the trace's lookups of this table
+            lrows = np.flatnonzero((sel < nv.ROW_HEADER) & ((sel & 0x3F) == t))
+            if lrows.size:
+                table_keys = key([tab[k, rows] for k in range(width)])
+                for slot in range(lpr):
+                    got = key([trace[col0 + width * slot + k, lrows] for k in range(width)])
+                    assert np.isin(got, table_keys).all(), (ctype, t, slot)
+    # the queue circuits: the 8-bit range table
+    tab = nv.setup_lookup_tables(8, 1024)
+    assert tab.shape == (2, 1024) and np.array_equal(tab[0, :256], np.arange(256, dtype=np.uint64)) and (tab[1, :256] == 1).all() and not tab[:, 256:].any()
+    # ECRecover: Xor8, And8, the 256 FixedBaseMul<i, C> tables (row b = word i of x and y of b * 2^(8 C) * G), ByteSplit<1..4>
+    from era_zkevm_test_harness_amd import secp256k1 as ec
+    tab = nv.setup_lookup_tables(7, 1 << 18)
+    ids = tab[3].astype(np.int64)
+    assert int((ids != 0).sum()) == 197632 and set(np.unique(ids)) == set(range(0, 263))
+    for i, c, b in ((0, 0, 1), (7, 0, 2), (3, 5, 200), (1, 31, 255)):
+        row = 131072 + 256 * (8 * c + i) + b
+        x, y = ec.mul(b << (8 * c), ec.G)
+        assert int(ids[row]) == 3 + 8 * c + i and [int(tab[k, row]) for k in range(3)] == [b, (x >> (32 * i)) & 0xFFFFFFFF, (y >> (32 * i)) & 0xFFFFFFFF]
+    assert [int(tab[k, 131072]) for k in range(3)] == [0, 0, 0]  # byte 0: the point at infinity as (0, 0)
