@@ -82,5 +82,5 @@ done
 (cd tools && for b in probe_hw_queues2; do [ -x ./$b ] && { echo "== $b (default environment)"; timeout -s KILL 120 ./$b; echo "== $b (GPU_MAX_HW_QUEUES=8)"; GPU_MAX_HW_QUEUES=8 timeout -s KILL 120 ./$b; }; done) > "$OUT/hw_queue_probes.txt" 2>&1
 # 7. K production-capacity blocks in flight at once (zkw_blocks_run + chain service), builders + synthesis + release
 for K in 1 16 48 96; do timeout -s KILL 600 python tools/probe_block_concurrency.py $K 3 2>&1 | grep "^K=" | tail -1; done > "$OUT/blocks_in_flight.txt"
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/gpu_tests_tail.txt"
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > "$OUT/gpu_tests_tail.txt"
 ls -la "$OUT"
