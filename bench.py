@@ -658,7 +658,9 @@ def main():
             "k_ram_fill_B": 148 * cell + wit * 96,
             "k_ram_fill_C": 148 * cell + wit * 96,
             "k_ram_fill_D": 148 * cell + 48 * cell,           # reads the queue tails back from the Poseidon2 rows
-            "k_ram_fill_tail": per_launch_inst * 8 * (148 * (n_rows - 6 * stride) + n_rows),
+            # the multiplicity column; the zero padding below the boundary rows is written only into a slot that held another layout
+            # (slot layout tag): never inside the timed region, whose ring slots were filled by the warm-up step
+            "k_ram_fill_tail": per_launch_inst * 8 * n_rows,
         }
         def pmc_traffic(kernel, launches_items):
             """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate
@@ -717,7 +719,7 @@ def main():
                 gbs = alg_bytes[k] / (kms / kcnt * 1e-3) / 1e9
                 hbm_kernels[k] = {"achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": kms / kcnt}
         synth_ms = sum(v[0] for k, v in prof.items() if k.startswith("k_ram_fill") or k.startswith("k_ram_nd"))
-        synth_gbs = (149 * n_rows * 8 * n_inst_local * args.steps) / (synth_ms * 1e-3) / 1e9 if synth_ms else None
+        synth_gbs = (native.circuit_fill_bytes(8, CAPACITY, n_rows)[0] * n_inst_local * args.steps) / (synth_ms * 1e-3) / 1e9 if synth_ms else None  # bytes actually written (slot reuse)
         chain_ms, chain_cnt = prof.get("k_chain_full", prof.get("k_chain_full_q4", (0.0, 1)))
         free_after, total_mem = torch.cuda.mem_get_info(dev)
         out = {
@@ -739,7 +741,11 @@ def main():
                        "trace_layout": "zkw trace v2 (own gate placement, same geometry as the reference wrapper; not interoperable "
                                        "with the reference's vk_8 / finalization_hint_8: DESIGN.md section 4)",
                        "blocks_per_gpu": B, "queries_per_block": n, "parallelism": f"instances sharded x{world}",
-                       "pipelines_per_gpu": P, "pipeline_stagger_ms": stagger_s * 1e3, "gather": gather_backend},
+                       "pipelines_per_gpu": P, "pipeline_stagger_ms": stagger_s * 1e3, "gather": gather_backend,
+                       "trace_slots": "ring of 16 slots; a slot that already holds this layout keeps its zero padding rows (layout tag): "
+                                      "write_bytes_per_circuit of trace_bytes_per_circuit are written per synthesis",
+                       "write_bytes_per_circuit": native.circuit_fill_bytes(8, CAPACITY, n_rows)[0],
+                       "trace_bytes_per_circuit": native.circuit_fill_bytes(8, CAPACITY, n_rows)[1]},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(name, 2 * items),
                          "traffic_unit": "bytes per launch (PMC, newest profiles/rNN/traffic.json)", "algorithmic_bytes_per_launch": ab,

@@ -34,6 +34,7 @@ struct DsSynthJob {
     u32* hist;  // [256]
     const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ds_commitments): not written, the closed-form section derives it
     const zkw_decommit_sorter_instance* first_inst;  // the block's first instance (the shared observable input)
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
 };
 
 struct DsVars {
@@ -376,6 +377,7 @@ static __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* _
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < DS_G + DS_L) {
+        if (job.tail_clean) return;
         const size_t bnd = (size_t)DS_BOUNDARY_ROW(capacity) + DS_BOUNDARY_ROWS;
         const size_t n_pairs = (n_rows - bnd) / 2;
         const size_t per = (n_pairs + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_pairs ? lo + per : n_pairs;

@@ -34,6 +34,7 @@ struct EsSynthJob {
     const zkw_events_sorter_instance* first_inst;  // the block's first instance (the shared observable input)
     u64* trace;
     u32* hist;
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
 };
 
 struct EsVars {
@@ -335,6 +336,7 @@ static __global__ __launch_bounds__(256) void k_es_fill_tail(const EsSynthJob* _
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < ES_G + ES_L) {
+        if (job.tail_clean) return;
         const size_t bnd = (size_t)ES_BOUNDARY_ROW(capacity) + ES_BOUNDARY_ROWS;
         const size_t n_pairs = (n_rows - bnd) / 2;
         const size_t per = (n_pairs + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_pairs ? lo + per : n_pairs;

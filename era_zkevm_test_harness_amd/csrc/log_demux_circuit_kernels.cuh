@@ -46,6 +46,7 @@ struct LdSynthJob {
     const zkw_log_demux_instance* first_inst;  // the block's first instance (the shared observable input)
     u64* trace;
     u32* hist;
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
 };
 
 struct LdVars {
@@ -242,6 +243,7 @@ static __global__ __launch_bounds__(256) void k_ld_fill_tail(const LdSynthJob* _
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < LD_G + LD_L) {
+        if (job.tail_clean) return;
         const size_t bnd = (size_t)LD_BOUNDARY_ROW(capacity) + LD_BOUNDARY_ROWS;
         const size_t n_pairs = (n_rows - bnd) / 2;
         const size_t per = (n_pairs + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_pairs ? lo + per : n_pairs;

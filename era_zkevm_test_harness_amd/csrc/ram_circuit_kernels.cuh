@@ -38,6 +38,7 @@ struct SynthJob {
     const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ram_commitments): not written into the trace (the
                               // closed-form section derives the PI row), kept for callers that compare
     const zkw_ram_instance* first_inst;  // the block's first instance (its observable input is every instance's: postprocessing/mod.rs:358-364)
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
 };
 
 constexpr int ROW_SLOTS[RC_NUM_ROW_TYPES] = RC_ROW_NUM_SLOTS_INIT;
@@ -444,9 +445,18 @@ static __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __res
     hist_flush(sh_hist, job.hist);
 }
 
-static __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const SynthJob job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+// 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each — the register rows and the closed-form section, a chain of a
+// dozen dependent permutations (ram_boundary_block below) — dispatched first and at raised priority so that the row-D blocks' work hides
+// it (it reads the last cycle's row C, an earlier kernel; nothing of row D); then n_tiles blocks of 256 cycles per trace.
+__device__ __forceinline__ void ram_boundary_block(const SynthJob& job, u32 capacity, size_t n_rows);
+static __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__ jobs, u32 n_jobs, u32 n_tiles, u32 capacity, size_t n_rows) {
+    if (blockIdx.x < n_jobs) {
+        __builtin_amdgcn_s_setprio(3);
+        ram_boundary_block(jobs[blockIdx.x], capacity, n_rows);
+        return;
+    }
+    const SynthJob& job = jobs[(blockIdx.x - n_jobs) / n_tiles];
+    const u32 i = ((blockIdx.x - n_jobs) % n_tiles) * blockDim.x + threadIdx.x;
     const size_t rs = RC_REGION_STRIDE(capacity);
     if (i >= capacity) {
         if (i < rs) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_D * rs + i);
@@ -490,21 +500,15 @@ constexpr int TAIL_CHUNKS = 8;
 constexpr int RC_BOUNDARY_ROWS = RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE;  // register rows, PI, the closed-form section
 constexpr int RC_CF_LOOKUP_CELLS = 24;                                   // VIN / VOUT byte cells (counted in job.hist by k_ram_fill_C)
 static_assert(RC_BOUNDARY_ROWS % 2 == 0, "the tail's 16-byte stores start below the boundary rows");
-__device__ __forceinline__ void ram_boundary_block(const SynthJob& job, u32 capacity, size_t n_rows);
-static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
-    // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
-    // dependent permutations that the other blocks' stores hide), then (RC_G + RC_L + 1) * TAIL_CHUNKS blocks per trace
-    if (blockIdx.x < n_jobs) {
-        __builtin_amdgcn_s_setprio(3);
-        ram_boundary_block(jobs[blockIdx.x], capacity, n_rows);
-        return;
-    }
+static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    // 1-D grid: (RC_G + RC_L + 1) * TAIL_CHUNKS blocks per trace (the boundary rows above the zero padding are k_ram_fill_D's first blocks)
     constexpr u32 PER_JOB = (RC_G + RC_L + 1) * TAIL_CHUNKS;
-    const u32 bid = (blockIdx.x - n_jobs) % PER_JOB;
-    const SynthJob& job = jobs[(blockIdx.x - n_jobs) / PER_JOB];
+    const u32 bid = blockIdx.x % PER_JOB;
+    const SynthJob& job = jobs[blockIdx.x / PER_JOB];
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < RC_G + RC_L) {
+        if (job.tail_clean) return;
         const size_t bnd = (size_t)RC_BOUNDARY_ROW(capacity) + RC_BOUNDARY_ROWS;  // a multiple of 2 rows: 16-byte aligned
         const size_t n_pairs = (n_rows - bnd) / 2;                               // n_rows is even (power of two)
         const size_t per = (n_pairs + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_pairs ? lo + per : n_pairs;
@@ -602,7 +606,7 @@ __device__ __forceinline__ void ram_value_row(u64* trace, size_t n_rows, size_t 
     for (int k = 0; k < 4; k++) TR(e3 + k, row) = e[3 + k];
 }
 
-// the extra block of k_ram_fill_tail (its other blocks zero the rows BELOW the boundary rows): the boundary rows' cells zeroed, the
+// the first blocks of k_ram_fill_D (the tail kernel zeroes the rows BELOW the boundary rows): the boundary rows' cells zeroed, the
 // register rows, then the closed-form section (closed_form_kernels.cuh) down to the PI row. Reads the last cycle's row C (an earlier kernel).
 __device__ __forceinline__ void ram_boundary_block(const SynthJob& job, u32 capacity, size_t n_rows) {
     {

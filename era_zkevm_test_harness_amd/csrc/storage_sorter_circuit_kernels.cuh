@@ -48,6 +48,7 @@ struct SsSynthJob {
     const zkw_storage_sorter_instance* first_inst;  // the block's first instance (the shared observable input)
     u64* trace;
     u32* hist;
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
 };
 
 struct SsVars {
@@ -427,6 +428,7 @@ static __global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* _
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < SS_G + SS_L) {
+        if (job.tail_clean) return;
         const size_t bnd = (size_t)SS_BOUNDARY_ROW(capacity) + SS_BOUNDARY_ROWS;
         const size_t n_pairs = (n_rows - bnd) / 2;
         const size_t per = (n_pairs + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_pairs ? lo + per : n_pairs;

@@ -1366,7 +1366,12 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
         j.lhs_z = w->zbuf_l + 2 * (lo - z_base);
         j.rhs_z = w->zbuf_r + 2 * (lo - z_base);
         j.n_block = nb;
-        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
+        {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
+            const uint64_t tag = ((uint64_t)ZKW_CIRCUIT_RAM_PERMUTATION << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
+            const size_t slot = (first_slot + k) % t->n_slots;
+            j.tail_clean = t->tag_of(slot) == tag;
+            j.trace = t->slot_for_write(slot, tag);
+        }
         j.hist = d_hist + 256 * k;
         j.nd_tiles = d_nd + (size_t)n_tiles * k;
         j.public_input = w->public_inputs + 4 * idx;
@@ -1390,10 +1395,9 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     ZKW_TRY(launch_check("k_ram_fill_B"));
     { Prof _p(ctx, "k_ram_fill_C"); hipLaunchKernelGGL(k_ram_fill_C, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_C"));
-    { Prof _p(ctx, "k_ram_fill_D"); hipLaunchKernelGGL(k_ram_fill_D, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_D"); hipLaunchKernelGGL(k_ram_fill_D, dim3(nj * (n_tiles + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, n_tiles, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_D"));
-    // (+ 1: the block that fills the boundary rows and the closed-form section, hidden behind the zero fill)
-    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(nj * ((RC_G + RC_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(nj * ((RC_G + RC_L + 1) * TAIL_CHUNKS)), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_tail"));
     return ctx->sync_if_host();
 }

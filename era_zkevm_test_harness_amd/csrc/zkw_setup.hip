@@ -102,7 +102,11 @@ extern "C" int zkw_circuit_fill_bytes(uint8_t circuit_type, uint32_t capacity, s
     ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
     if (!lay.synthesizable || !warm || !cold) return fail(ZKW_ERR_INVALID, "zkw_circuit_fill_bytes: bad argument");
     *cold = (uint64_t)lay.num_columns * n_rows * 8;
-    if (lay.region_stride) { *warm = *cold; return ZKW_OK; }  // the queue circuits write every cell of the slot, every time
+    if (lay.region_stride) {  // the queue circuits: every cell down to the boundary rows and the multiplicity column, every time; the zero padding below only when the slot held another layout
+        const uint64_t rows = (lay.rows_used + 1) & ~1ull;
+        *warm = ((uint64_t)(lay.num_columns - 1) * rows + n_rows) * 8;
+        return ZKW_OK;
+    }
     const nl_spec* sp = nl_host_spec(circuit_type);
     const uint32_t cycles = nl_cycles_of(circuit_type, lay.capacity);
     uint64_t per_cycle = 0;

@@ -897,7 +897,12 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
         j.n_block = w->n;
         memcpy(j.rq_tail_in, w->dedup_in.tail, 96);
         j.rq_len_in = w->dedup_in.length;
-        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
+        {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
+            const uint64_t tag = ((uint64_t)2 << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
+            const size_t slot = (first_slot + k) % t->n_slots;
+            j.tail_clean = t->tag_of(slot) == tag;
+            j.trace = t->slot_for_write(slot, tag);
+        }
         j.hist = d_hist + 256 * k;
         j.public_input = w->public_inputs + 4 * (first_instance + k);
         j.first_inst = w->instances;  // one block per witness
@@ -965,7 +970,12 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
         j.rq_len_in = w->result_in.length;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
         j.first_inst = w->instances;  // one block per witness
-        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
+        {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
+            const uint64_t tag = ((uint64_t)11 << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
+            const size_t slot = (first_slot + k) % t->n_slots;
+            j.tail_clean = t->tag_of(slot) == tag;
+            j.trace = t->slot_for_write(slot, tag);
+        }
         j.hist = d_hist + 256 * k;
     }
     EsSynthJob* d_jobs = nullptr;
@@ -1028,7 +1038,12 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
         j.n_block = n;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
         j.first_inst = w->instances;  // one block per witness
-        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
+        {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
+            const uint64_t tag = ((uint64_t)4 << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
+            const size_t slot = (first_slot + k) % t->n_slots;
+            j.tail_clean = t->tag_of(slot) == tag;
+            j.trace = t->slot_for_write(slot, tag);
+        }
         j.hist = d_hist + 256 * k;
     }
     LdSynthJob* d_jobs = nullptr;
@@ -1087,7 +1102,12 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
         j.n_block = n;
         j.public_input = w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k);
         j.first_inst = w->instances;  // one block per witness
-        j.trace = t->slot_for_write((first_slot + k) % t->n_slots, 0);
+        {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
+            const uint64_t tag = ((uint64_t)9 << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
+            const size_t slot = (first_slot + k) % t->n_slots;
+            j.tail_clean = t->tag_of(slot) == tag;
+            j.trace = t->slot_for_write(slot, tag);
+        }
         j.hist = d_hist + 256 * k;
     }
     SsSynthJob* d_jobs = nullptr;

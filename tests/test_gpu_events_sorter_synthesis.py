@@ -118,3 +118,20 @@ def test_empty_queue_dummy_instance(ctx, oracle):
     assert np.array_equal(t.get(0)[:139], oracle.events_sorter_synthesize(o, 0, 16, 2048))
     assert ctx.check_if_satisfied_events_sorter(t, 0, 16)[0] == 0
     t.free()
+
+
+def test_slot_reuse_keeps_the_padding_rows(ctx, oracle):
+    """as tests/test_gpu_ram_synthesis.py::test_slot_reuse_keeps_the_padding_rows, for the events sorter's tail kernel"""
+    from era_zkevm_test_harness_amd import native
+
+    n_rows = 4096
+    q = synthetic.events_trace(150, 0.3, seed=5)
+    t = native.Trace(ctx, n_rows, 1)
+    for capacity in (64, 32, 64):
+        w = ctx.compute_events_dedup_and_sort(q, capacity)
+        o = oracle.events_sorter_build(q, capacity)
+        for idx in range(o["instances"].size):
+            ctx.synthesize_events_sorter(w, t, idx, 1, 0)
+            assert np.array_equal(t.get(0)[:139], oracle.events_sorter_synthesize(o, idx, capacity, n_rows)), (capacity, idx)
+        w.free()
+    t.free()

@@ -229,3 +229,23 @@ def test_witness_outlives_later_builds_in_host_pointer_mode(ctx, oracle):
     assert np.array_equal(w1.get(native.RAM_UNSORTED_ENC), o1["unsorted_enc"])
     assert np.array_equal(w1.get(native.RAM_RHS_Z).reshape(2, -1), o1["rhs_z"])
     t.free(); w1.free(); w2.free()
+
+
+def test_slot_reuse_keeps_the_padding_rows(ctx, oracle):
+    """a slot whose previous tenant had the same layout keeps its zero padding rows (the tail kernel skips them): instance after instance
+    into ONE slot without touching the device pointer, a ragged last instance after full ones, then another capacity (the tag no longer
+    matches: everything is cleared), then back — every trace equals the oracle's cell for cell"""
+    from era_zkevm_test_harness_amd import native
+
+    n_rows = 2048
+    q = _trace(700, seed=9)
+    t = native.Trace(ctx, n_rows, 1)
+    for capacity in (256, 128, 256):
+        w = ctx.compute_ram_circuit_snapshots(q, capacity, 2)
+        o = oracle.ram_build_instances(q, capacity, 2)
+        assert w.num_instances >= 3
+        for idx in range(w.num_instances):  # the last one is ragged
+            ctx.synthesize_ram(w, t, idx, 1, 0)
+            assert np.array_equal(t.get(0), oracle.ram_synthesize(o, idx, capacity, n_rows)), (capacity, idx)
+        w.free()
+    t.free()
