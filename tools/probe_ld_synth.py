@@ -27,8 +27,8 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 prof = ctx.profile()
-bytes_per_inst = 151 * n_rows * 8
-print(f"synthesis: {dt*1e3:.2f} ms per {n_inst} instances = {n_inst/dt:.0f} circuits/s, {n_inst*bytes_per_inst/dt/1e12:.2f} TB/s")
+bytes_per_inst = native.circuit_fill_bytes(4, capacity, n_rows)[0]  # bytes a synthesis writes into a slot that already holds this layout (slot layout tags)
+print(f"synthesis: {dt*1e3:.2f} ms per {n_inst} instances = {n_inst/dt:.0f} circuits/s, {n_inst*bytes_per_inst/dt/1e12:.2f} TB/s of bytes written")
 for k, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
     print(f"  {k:24s} {ms/reps:8.3f} ms per pass ({cnt//reps} launches)")
 bad, first = ctx.check_if_satisfied_log_demux(t, 1, capacity)
