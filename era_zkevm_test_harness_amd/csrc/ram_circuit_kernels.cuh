@@ -38,7 +38,9 @@ struct SynthJob {
     const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ram_commitments): not written into the trace (the
                               // closed-form section derives the PI row), kept for callers that compare
     const zkw_ram_instance* first_inst;  // the block's first instance (its observable input is every instance's: postprocessing/mod.rs:358-364)
-    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): every cell that is zero in EVERY trace of the layout — the padding
+                     // rows below the boundary rows, the gap rows of the regions, the unused columns of each row type, rows >= 256 of the multiplicity column —
+                     // is still zero: the kernels skip those stores
 };
 
 constexpr int ROW_SLOTS[RC_NUM_ROW_TYPES] = RC_ROW_NUM_SLOTS_INIT;
@@ -165,15 +167,15 @@ static __global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob*
             put_bytes(trace, n_rows, row, RC_PU_v1_b0, q.value[1]);
             hist_bytes(sh_hist, q.index); hist_bytes(sh_hist, q.value[0]); hist_bytes(sh_hist, q.value[1]);
         } else {
-            for (int c = 130; c < RC_G; c++) TR(c, row) = 0;
+            if (!job.tail_clean) for (int c = 130; c < RC_G; c++) TR(c, row) = 0;
             put_bytes(trace, n_rows, row, RC_PS_ts_b0, q.timestamp);
             put_bytes(trace, n_rows, row, RC_PS_page_b0, q.page);
             put_bytes(trace, n_rows, row, RC_PS_v4_b0, q.value[4]);
             hist_bytes(sh_hist, q.timestamp); hist_bytes(sh_hist, q.page); hist_bytes(sh_hist, q.value[4]);
         }
-        for (int c = RC_G + 12; c < RC_G + RC_L; c++) TR(c, row) = 0;
+        if (!job.tail_clean) for (int c = RC_G + 12; c < RC_G + RC_L; c++) TR(c, row) = 0;
     } else if (i < RC_REGION_STRIDE(capacity)) {
-        zero_gap_row(job.trace, n_rows, (size_t)(SIDE == 0 ? RC_ROW_PU : RC_ROW_PS) * RC_REGION_STRIDE(capacity) + i);
+        if (!job.tail_clean) zero_gap_row(job.trace, n_rows, (size_t)(SIDE == 0 ? RC_ROW_PU : RC_ROW_PS) * RC_REGION_STRIDE(capacity) + i);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -273,10 +275,12 @@ static __global__ __launch_bounds__(256) void k_ram_fill_A(const SynthJob* __res
         put_bytes(trace, n_rows, row, RC_A_v5_b0, c.q.value[5]);
         hist_bytes(sh_hist, c.q.value[2]); hist_bytes(sh_hist, c.q.value[3]); hist_bytes(sh_hist, c.q.value[5]);
         constexpr int NA = ROW_SLOTS[RC_ROW_A];  // general slots used by row type A
-        for (int col = NA; col < RC_G; col++) TR(col, row) = 0;
-        for (int col = RC_G + 12; col < RC_G + RC_L; col++) TR(col, row) = 0;
+        if (!job.tail_clean) {
+            for (int col = NA; col < RC_G; col++) TR(col, row) = 0;
+            for (int col = RC_G + 12; col < RC_G + RC_L; col++) TR(col, row) = 0;
+        }
     } else if (i < RC_REGION_STRIDE(capacity)) {
-        zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_A * RC_REGION_STRIDE(capacity) + i);
+        if (!job.tail_clean) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_A * RC_REGION_STRIDE(capacity) + i);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -303,10 +307,12 @@ static __global__ __launch_bounds__(256) void k_ram_fill_B(const SynthJob* __res
         TR(RC_B_ts, row) = c.q.timestamp; TR(RC_B_P_ts, row) = c.pq.timestamp;
         hist_bytes(sh_hist, c.q.value[6]); hist_bytes(sh_hist, c.q.value[7]); hist_bytes(sh_hist, d0);
         constexpr int NB = ROW_SLOTS[RC_ROW_B];
-        for (int col = NB; col < RC_G; col++) TR(col, row) = 0;
-        for (int col = RC_G + 12; col < RC_G + RC_L; col++) TR(col, row) = 0;
+        if (!job.tail_clean) {
+            for (int col = NB; col < RC_G; col++) TR(col, row) = 0;
+            for (int col = RC_G + 12; col < RC_G + RC_L; col++) TR(col, row) = 0;
+        }
     } else if (i < RC_REGION_STRIDE(capacity)) {
-        zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_B * RC_REGION_STRIDE(capacity) + i);
+        if (!job.tail_clean) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_B * RC_REGION_STRIDE(capacity) + i);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -435,10 +441,12 @@ static __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __res
         const u64 p_cnt = (u64)in->hidden_fsm_input.num_nondeterministic_writes + job.nd_tiles[blockIdx.x] + before;
         TR(RC_C_P_cnt, row) = p_cnt; TR(RC_C_cnt, row) = p_cnt + (nd ? 1 : 0);
         constexpr int NC = ROW_SLOTS[RC_ROW_C];
-        for (int col = NC; col < RC_G; col++) TR(col, row) = 0;
-        for (int col = RC_G + 8; col < RC_G + RC_L; col++) TR(col, row) = 0;
+        if (!job.tail_clean) {
+            for (int col = NC; col < RC_G; col++) TR(col, row) = 0;
+            for (int col = RC_G + 8; col < RC_G + RC_L; col++) TR(col, row) = 0;
+        }
     } else if (i < RC_REGION_STRIDE(capacity)) {
-        zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_C * RC_REGION_STRIDE(capacity) + i);
+        if (!job.tail_clean) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_C * RC_REGION_STRIDE(capacity) + i);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)  // the closed-form section's lookup cells (VIN / VOUT: bytes of limbs 5..7 of the previous value)
         for (int l = 5; l < 8; l++) { hist_bytes(sh_hist, job.inst->hidden_fsm_input.previous_value[l]); hist_bytes(sh_hist, job.inst->hidden_fsm_output.previous_value[l]); }
@@ -459,7 +467,7 @@ static __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __res
     const u32 i = ((blockIdx.x - n_jobs) % n_tiles) * blockDim.x + threadIdx.x;
     const size_t rs = RC_REGION_STRIDE(capacity);
     if (i >= capacity) {
-        if (i < rs) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_D * rs + i);
+        if (i < rs && !job.tail_clean) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_D * rs + i);
         return;
     }
     u64* trace = job.trace;
@@ -488,7 +496,7 @@ static __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __res
         TR(RC_D_so0 + o, row) = so; TR(RC_D_P_sh0 + o, row) = b; TR(RC_D_sh0 + o, row) = can_pop ? so : b;
     }
     constexpr int ND = ROW_SLOTS[RC_ROW_D];
-    for (int col = ND; col < RC_G + RC_L; col++) TR(col, row) = 0;
+    if (!job.tail_clean) for (int col = ND; col < RC_G + RC_L; col++) TR(col, row) = 0;
 }
 
 // the zero padding from the first boundary row down (all general + lookup columns) and the multiplicity column.
@@ -520,7 +528,7 @@ static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __
     // multiplicities: histogram of the used lookup cells + every unused lookup cell counts as value 0
     u64* m = trace + (size_t)RC_MULT_COL * n_rows;
     const size_t per = (n_rows + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_rows ? lo + per : n_rows;
-    for (size_t r = lo + threadIdx.x; r < hi; r += 256) {
+    for (size_t r = lo + threadIdx.x; r < (job.tail_clean && hi > 256 ? (lo < 256 ? 256 : lo) : hi); r += 256) {  // (a clean slot: rows >= 256 of the column are still zero)
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];

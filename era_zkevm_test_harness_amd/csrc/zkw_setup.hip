@@ -105,6 +105,12 @@ extern "C" int zkw_circuit_fill_bytes(uint8_t circuit_type, uint32_t capacity, s
     if (lay.region_stride) {  // the queue circuits: every cell down to the boundary rows and the multiplicity column, every time; the zero padding below only when the slot held another layout
         const uint64_t rows = (lay.rows_used + 1) & ~1ull;
         *warm = ((uint64_t)(lay.num_columns - 1) * rows + n_rows) * 8;
+        if (circuit_type == ZKW_CIRCUIT_RAM_PERMUTATION) {  // its fills also skip the cells that are zero in every trace: unused columns of a row type, gap rows, multiplicity rows >= 256
+            static const int slots[] = RC_ROW_NUM_SLOTS_INIT, looks[] = RC_ROW_NUM_LOOKUPS_INIT;
+            uint64_t per_cycle = 0;
+            for (int r = 0; r < RC_ROWS_PER_CYCLE; r++) per_cycle += (uint64_t)slots[r] + looks[r];
+            *warm = (per_cycle * lay.capacity + (uint64_t)(lay.num_columns - 1) * (rows - (uint64_t)lay.rows_per_cycle * lay.region_stride) + 256) * 8;
+        }
         return ZKW_OK;
     }
     const nl_spec* sp = nl_host_spec(circuit_type);
