@@ -902,18 +902,77 @@ static int ram_alloc(zkw_ram_witness* w, size_t n_blocks) {
     return ZKW_OK;
 }
 
-__global__ void k_block_ids(const u64* __restrict__ offsets, int n_blocks, size_t n, u32* __restrict__ ids) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int lo = 0, hi = n_blocks;  // largest b with offsets[b] <= i
+// the block a query position belongs to: largest b with offsets[b] <= i
+__device__ __forceinline__ u32 block_of_position(const u64* __restrict__ offsets, int n_blocks, size_t i) {
+    int lo = 0, hi = n_blocks;
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (offsets[mid] <= i) lo = mid; else hi = mid;
     }
-    ids[i] = (u32)lo;
+    return (u32)lo;
 }
 
-// the sorting permutation for all blocks at once (see sort.hip)
+// Widths of the sort key's fields in this batch: max timestamp / page / index, so that the radix sort only walks
+// the bits that are in use.
+__global__ void k_ram_key_ranges(const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ maxima) {
+    u32 t = 0, p = 0, x = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        t = max(t, q[i].timestamp);
+        p = max(p, q[i].page);
+        x = max(x, q[i].index);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        t = max(t, (u32)__shfl_xor((int)t, o));
+        p = max(p, (u32)__shfl_xor((int)p, o));
+        x = max(x, (u32)__shfl_xor((int)x, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(maxima + 0, t);
+        atomicMax(maxima + 1, p);
+        atomicMax(maxima + 2, x);
+    }
+}
+
+// (block, page, index, timestamp) packed into one word, most significant first
+__global__ void k_ram_packed_keys(const zkw_mem_query* __restrict__ q, size_t n, const u64* __restrict__ offsets,
+                                  int n_blocks, unsigned bits_p, unsigned bits_i, unsigned bits_t,
+                                  u64* __restrict__ key, u32* __restrict__ iota) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 k = n_blocks > 1 ? block_of_position(offsets, n_blocks, i) : 0;
+    k = (k << bits_p) | q[i].page;
+    k = (k << bits_i) | q[i].index;
+    k = (k << bits_t) | q[i].timestamp;
+    key[i] = k;
+    iota[i] = (u32)i;
+}
+
+// (block, page, index) of the items in their current order `perm`, packed into one word
+__global__ void k_ram_packed_cells(const u64* __restrict__ cell, const u32* __restrict__ perm, size_t n,
+                                   const u64* __restrict__ offsets, int n_blocks, unsigned bits_p, unsigned bits_i,
+                                   u64* __restrict__ key) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 src = perm[i];
+    const u64 c = cell[src];
+    u64 k = n_blocks > 1 ? block_of_position(offsets, n_blocks, src) : 0;
+    k = (k << bits_p) | (c >> 32);
+    k = (k << bits_i) | (c & 0xFFFFFFFFu);
+    key[i] = k;
+}
+
+__global__ void k_block_ids(const u64* __restrict__ offsets, int n_blocks, size_t n, u32* __restrict__ ids) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ids[i] = block_of_position(offsets, n_blocks, i);
+}
+
+static unsigned bits_in_use(u32 x) { return x ? 32u - (unsigned)__builtin_clz(x) : 0u; }
+
+// The sorting permutation for all blocks at once: order (block, page, index, timestamp), W/ram_permutation.rs:48-53
+// per block. The key is as wide as this batch makes it, and the sort takes the cheapest of three routes:
+//   one   - all four fields fit 64 bits: one radix sort of the packed word over the bits in use;
+//   two   - they do not, but (block, page, index) do: timestamps first, then the packed cell word (stable);
+//   three - full-width pages and indices in a multi-block batch: timestamp, cell, block id, each stable.
 // `work_a` / `work_b`: two device areas of 32 bytes per query that nothing else uses until the sort is over (the
 // builder passes the capacity-word arrays, which the chains fill afterwards); the radix temporary falls back to
 // the context scratch when it does not fit (tiny batches: its histograms dominate).
@@ -933,31 +992,62 @@ static int ram_sort(zkw_ctx* ctx, const zkw_mem_query* d_q, size_t total, const 
     if (tmp_off + tmp_bytes <= total * 32) tmp = static_cast<char*>(work_b) + tmp_off;
     else ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
     const unsigned grid = blocks_for(total, 256);
+
+    void* d_max_v = nullptr;
+    ZKW_TRY(ctx->scratch("sort_max", 256, &d_max_v));
+    u32* d_max = static_cast<u32*>(d_max_v);
+    HIP_TRY(hipMemsetAsync(d_max, 0, 16, ctx->stream));
+    { Prof _p(ctx, "k_ram_key_ranges");
+      const unsigned g = grid < 4096 ? grid : 4096;
+      hipLaunchKernelGGL(k_ram_key_ranges, dim3(g), dim3(256), 0, ctx->stream, d_q, total, d_max); }
+    ZKW_TRY(launch_check("k_ram_key_ranges"));
+    u32 maxima[4];
+    ZKW_TRY(ctx->read_small(maxima, d_max, 16));
+    const unsigned bits_t = bits_in_use(maxima[0]), bits_p = bits_in_use(maxima[1]), bits_i = bits_in_use(maxima[2]);
+    unsigned bits_b = 0;
+    while ((1ull << bits_b) < n_blocks) bits_b++;
+    u64* d_off = nullptr;
+    if (n_blocks > 1) ZKW_TRY(ctx->upload("sort_off", offsets, &d_off));
+
+    if (bits_b + bits_p + bits_i + bits_t <= 64) {
+        const unsigned bits = bits_b + bits_p + bits_i + bits_t;
+        { Prof _p(ctx, "k_ram_packed_keys");
+          hipLaunchKernelGGL(k_ram_packed_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, total, d_off, (int)n_blocks,
+                             bits_p, bits_i, bits_t, k64a, v0); }
+        ZKW_TRY(launch_check("k_ram_packed_keys"));
+        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, v0, v1, total, bits ? bits : 1, ctx->stream)); }
+        *perm_out = v1;
+        return ZKW_OK;
+    }
+
     { Prof _p(ctx, "k_ram_sort_keys"); hipLaunchKernelGGL(k_ram_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, total, ts, cell, v0,
                        (const u64*)nullptr, 0); }
     ZKW_TRY(launch_check("k_ram_sort_keys"));
     // pass 1: timestamp
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, ts, k32, v0, v1, total, 32, ctx->stream)); }
+    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, ts, k32, v0, v1, total, bits_t ? bits_t : 1, ctx->stream)); }
+    if (bits_b + bits_p + bits_i <= 64) {
+        // pass 2: (block, page, index) of the ts-sorted items
+        const unsigned bits = bits_b + bits_p + bits_i;
+        { Prof _p(ctx, "k_ram_packed_cells");
+          hipLaunchKernelGGL(k_ram_packed_cells, dim3(grid), dim3(256), 0, ctx->stream, cell, v1, total, d_off, (int)n_blocks,
+                             bits_p, bits_i, k64a); }
+        ZKW_TRY(launch_check("k_ram_packed_cells"));
+        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, v1, v0, total, bits ? bits : 1, ctx->stream)); }
+        *perm_out = v0;
+        return ZKW_OK;
+    }
     // pass 2: cell of the ts-sorted items
     { Prof _p(ctx, "k_gather_u64_by_u32"); hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, cell, v1, total, k64a); }
     ZKW_TRY(launch_check("k_gather_u64_by_u32"));
     { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, v1, v0, total, 64, ctx->stream)); }
-    u32* perm = v0;
-    if (n_blocks > 1) {
-        // pass 3: block id, so that each block's items end up contiguous again
-        u64* d_off = nullptr;
-        ZKW_TRY(ctx->upload("sort_off", offsets, &d_off));
-        unsigned bits = 1;
-        while ((1ull << bits) < n_blocks) bits++;
-        { Prof _p(ctx, "k_block_ids"); hipLaunchKernelGGL(k_block_ids, dim3(grid), dim3(256), 0, ctx->stream, d_off, (int)n_blocks, total, ts); }
-        ZKW_TRY(launch_check("k_block_ids"));
-        // ts[] now holds block ids in ORIGINAL order; gather them through the current permutation
-        { Prof _p(ctx, "k_gather_u32_by_u32"); hipLaunchKernelGGL(k_gather_u32_by_u32, dim3(grid), dim3(256), 0, ctx->stream, ts, v0, total, k32); }
-        ZKW_TRY(launch_check("k_gather_u32_by_u32"));
-        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, k32, ts, v0, v1, total, bits, ctx->stream)); }
-        perm = v1;
-    }
-    *perm_out = perm;
+    // pass 3: block id, so that each block's items end up contiguous again (only multi-block batches get here)
+    { Prof _p(ctx, "k_block_ids"); hipLaunchKernelGGL(k_block_ids, dim3(grid), dim3(256), 0, ctx->stream, d_off, (int)n_blocks, total, ts); }
+    ZKW_TRY(launch_check("k_block_ids"));
+    // ts[] now holds block ids in ORIGINAL order; gather them through the current permutation
+    { Prof _p(ctx, "k_gather_u32_by_u32"); hipLaunchKernelGGL(k_gather_u32_by_u32, dim3(grid), dim3(256), 0, ctx->stream, ts, v0, total, k32); }
+    ZKW_TRY(launch_check("k_gather_u32_by_u32"));
+    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, k32, ts, v0, v1, total, bits_b, ctx->stream)); }
+    *perm_out = v1;
     return ZKW_OK;
 }
 

@@ -210,6 +210,44 @@ def test_ram_builder_batch_of_blocks(ctx, oracle):
     w.free()
 
 
+@pytest.mark.parametrize("route,pages,indices,ts_start,n_blocks", [
+    ("one", 64, 256, 1, 3),                 # every field narrow: a single packed sort
+    ("one", 1, 1, 0, 1),                    # one cell, one block: a key of (almost) no bits
+    ("two", 2**32 - 9, 2**16, 2**31, 3),    # 2 + 32 + 16 + 32 bits: timestamps first, then the packed cell word
+    ("three", 2**32 - 9, 2**32, 2**31, 3),  # 2 + 32 + 32 bits of cell alone: timestamp, cell, block id
+    ("two", 2**32 - 9, 2**32, 2**31, 1),    # one block: full-width cell word, no block pass
+])
+def test_ram_sort_routes_by_key_width(ctx, oracle, route, pages, indices, ts_start, n_blocks):
+    """The sort packs (block, page, index, timestamp) into as few radix passes as the batch's key widths allow; each
+    route has to give the reference's stable order (W/ram_permutation.rs:48-53), including (cell, ts) ties."""
+    from era_zkevm_test_harness_amd import native
+
+    lens = [1500, 1, 2200][:n_blocks]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    blocks = []
+    for i, ln in enumerate(lens):
+        b = synthetic.ram_trace(ln, seed=900 + i, pages=pages, indices=indices, first_page=8 if pages > 1 else 0,
+                                ts_start=ts_start)
+        if pages > 64:  # wide keys are sparse: fold most of them onto a few cells so that ties and runs exist
+            fold = np.arange(ln) % 3 != 0
+            b["page"][fold] = b["page"][0]
+            b["index"][fold] = b["index"][fold] % 5
+        b["timestamp"] = ts_start + (b["timestamp"] - ts_start) // 4
+        blocks.append(b)
+    q = np.concatenate(blocks)
+    w = ctx.compute_ram_circuit_snapshots(q, 512, list(range(n_blocks)), block_offsets=offs)
+    sq, inst = w.get(native.RAM_SORTED_QUERIES), w.get(native.RAM_INSTANCES)
+    i0 = 0
+    for b, ln in enumerate(lens):
+        lo = int(offs[b])
+        o = oracle.ram_build_instances(q[lo:lo + ln], 512, b)
+        assert np.array_equal(sq[lo:lo + ln], o["sorted_q"]), (route, b)
+        k = o["instances"].size
+        assert inst[i0:i0 + k].tobytes() == o["instances"].tobytes(), (route, b)
+        i0 += k
+    w.free()
+
+
 def test_full_size_properties(ctx):
     """Production capacity (136 714 queries, BASELINE config geometry): size-independent properties."""
     from era_zkevm_test_harness_amd import native
