@@ -489,18 +489,22 @@ def main():
     def pipeline_pass(p):
         """witness generation + synthesis of sub-batch p (blocks p*Bp .. (p+1)*Bp) on pipeline p's stream"""
         c, w, ring = ctxs[p], ws[p], rings[p]
+        span = [p, time.perf_counter()]  # host clock of the pass: start | builders done | synthesis turn taken | synthesis done | end
         with torch.cuda.stream(streams[p]):
             c.compute_ram_circuit_snapshots((q.data_ptr() + p * Bp * n * q_item, Bp * n), CAPACITY, 0, block_offsets=offs, witness=w)
             if P > 1 and synth_turns:
                 # synthesis phases take turns: a pipeline fills at full speed while the others are in their chain pass,
                 # instead of two synthesis phases slowing each other down (DESIGN.md 3.2)
                 streams[p].synchronize()
+                span.append(time.perf_counter())
                 synth_lock.acquire()
+                span.append(time.perf_counter())
             try:
                 for first in range(0, n_inst_p, ring_p):  # synthesis: every instance -> a full 2^20-row trace
                     c.synthesize_ram(w, ring, first, min(ring_p, n_inst_p - first), 0)
                 if P > 1 and synth_turns:
                     streams[p].synchronize()
+                    span.append(time.perf_counter())
             finally:
                 if P > 1 and synth_turns:
                     synth_lock.release()
@@ -512,11 +516,14 @@ def main():
             rec[lo:hi, :18] = cp
             rec[lo:hi, 18:] = pp
             streams[p].synchronize()
+        span.append(time.perf_counter())
+        pass_spans.append(span)
 
     from concurrent.futures import ThreadPoolExecutor
     import threading
     pool = ThreadPoolExecutor(P)
     synth_lock = threading.Lock()
+    pass_spans = []
     synth_turns = os.environ.get("ZKW_SYNTH_TURNS", "1") != "0"
 
     def pipeline_run(p, passes, delay_s):
@@ -573,11 +580,13 @@ def main():
         c.profile_reset()
     parallel.barrier()
     torch.cuda.synchronize()
+    pass_spans.clear()
     t0 = time.perf_counter()
     gathered = run_steps(args.steps, stagger_s)
     torch.cuda.synchronize()
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    timed_spans = [[s_[0]] + [round((x - t0) * 1e3, 1) for x in s_[1:]] for s_ in sorted(pass_spans, key=lambda s_: s_[1])]
     prof = {}
     for c in ctxs:  # kernel time per name, summed over the pipelines (HIP events on each pipeline's own stream)
         for k, (ms, cnt) in c.profile().items():
@@ -645,7 +654,16 @@ def main():
         per_launch_inst = min(ring_p, n_inst_p)
         stride = (CAPACITY + 63) // 64 * 64            # rows per region incl. the alignment gap (zkw trace v2)
         cell = 8 * stride * per_launch_inst            # one column of one region, all instances of a launch
+        cell_used = 8 * CAPACITY * per_launch_inst     # the rows of it a warm slot gets (the alignment gap keeps its zeros)
         wit = per_launch_inst * n                      # witness items read by a launch
+        # cells a region's fill stores per cycle: the slots its row type uses + its lookup cells (generated spec); the cells that are zero
+        # in every trace stay untouched in a slot that already holds the layout (slot layout tag)
+        with open(os.path.join(ROOT, "include", "zkw_ram_circuit_spec.h")) as f_:
+            spec_txt = f_.read()
+        def spec_list(name):
+            import re
+            return [int(x) for x in re.search(r"#define %s \{([^}]*)\}" % name, spec_txt).group(1).split(",")]
+        used = [a_ + b_ for a_, b_ in zip(spec_list("RC_ROW_NUM_SLOTS_INIT"), spec_list("RC_ROW_NUM_LOOKUPS_INIT"))][:6]  # PU PS A B C D
         alg_bytes = {
             "k_chain_full": 2 * items * (48 + 32),            # per chain item: the 48-byte query in, 4 capacity words out
             "k_chain_full_q4": 2 * items * (48 + 32),
@@ -653,11 +671,11 @@ def main():
             "k_gp_apply": 2 * items * 32,
             "k_encode_mem": items * (48 + 64),
             "k_gather_encode": items * (48 + 4 + 48),
-            "k_ram_fill_poseidon": 148 * cell + wit * (48 + 32),        # one Poseidon2 region per launch
-            "k_ram_fill_A": 148 * cell + wit * (48 + 48 + 32),
-            "k_ram_fill_B": 148 * cell + wit * 96,
-            "k_ram_fill_C": 148 * cell + wit * 96,
-            "k_ram_fill_D": 148 * cell + 48 * cell,           # reads the queue tails back from the Poseidon2 rows
+            "k_ram_fill_poseidon": (used[0] + used[1]) / 2 * cell_used + wit * (48 + 32),  # one Poseidon2 region per launch
+            "k_ram_fill_A": used[2] * cell_used + wit * (48 + 48 + 32),
+            "k_ram_fill_B": used[3] * cell_used + wit * 96,
+            "k_ram_fill_C": used[4] * cell_used + wit * 96,
+            "k_ram_fill_D": used[5] * cell_used + 48 * cell_used,  # reads the queue tails back from the Poseidon2 rows
             # the multiplicity column; the zero padding below the boundary rows is written only into a slot that held another layout
             # (slot layout tag): never inside the timed region, whose ring slots were filled by the warm-up step
             "k_ram_fill_tail": per_launch_inst * 8 * n_rows,
@@ -761,6 +779,9 @@ def main():
             "hbm_used_GB": (total_mem - free_after) / 1e9,
             "poseidon2_perm_per_s": 2 * items * chain_cnt / (chain_ms * 1e-3) if chain_ms else None,  # inside the chain launches
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+            # host clock of every pipeline pass of the timed region, ms since its start: [pipeline, start, builders done, synthesis turn taken,
+            # synthesis done, end] (P = 1: [pipeline, start, end]) - where the step's wall time goes between the two pipelines
+            "pass_spans_ms": timed_spans,
         }
         if full_block is not None:
             out["full_block"] = full_block

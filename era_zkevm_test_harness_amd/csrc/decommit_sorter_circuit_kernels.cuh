@@ -34,7 +34,7 @@ struct DsSynthJob {
     u32* hist;  // [256]
     const u64* public_input;  // [4] commitment of the instance's closed-form input (k_ds_commitments): not written, the closed-form section derives it
     const zkw_decommit_sorter_instance* first_inst;  // the block's first instance (the shared observable input)
-    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): every cell that is zero in EVERY trace of the layout (the padding rows, the gap rows of a region, the columns a row type does not use, multiplicity rows >= 256) is still zero: the fills skip those stores
 };
 
 struct DsVars {
@@ -194,12 +194,12 @@ static __global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob
                 put_bytes(trace, n_rows, row, DS_PS_h3_b0 + 4 * (k - 3), c.q.hash[k]);
                 hist_bytes(sh_hist, c.q.hash[k]);
             }
-            for (int col = DS_G + 16; col < DS_G + DS_L; col++) TR(col, row) = 0;
+            if (!job.tail_clean) for (int col = DS_G + 16; col < DS_G + DS_L; col++) TR(col, row) = 0;
         } else {
-            for (int col = DS_G; col < DS_G + DS_L; col++) TR(col, row) = 0;
+            if (!job.tail_clean) for (int col = DS_G; col < DS_G + DS_L; col++) TR(col, row) = 0;
         }
     } else if (i < rs) {
-        zero_gap_row(trace, n_rows, (size_t)ROW * rs + i);
+        if (!job.tail_clean) zero_gap_row(trace, n_rows, (size_t)ROW * rs + i);
     }
     if (WHICH == 1 && blockIdx.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells (GIN / GOUT: bytes of the FSM records' page and first-encountered timestamp)
         hist_bytes(sh_hist, job.inst->hidden_fsm_input.previous_record.memory_page);
@@ -351,11 +351,11 @@ static __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __
         if (ROW == DS_ROW_D) { DS_FILL_D(DS_XC, DS_XP, DS_XG, DS_XC) }
         constexpr int NS = ROW == DS_ROW_A ? DS_NSLOTS_A : (ROW == DS_ROW_B ? DS_NSLOTS_B : (ROW == DS_ROW_C ? DS_NSLOTS_C : DS_NSLOTS_D));
         constexpr int NL = ROW == DS_ROW_A ? DS_NLOOK_A : (ROW == DS_ROW_B ? DS_NLOOK_B : (ROW == DS_ROW_C ? DS_NLOOK_C : DS_NLOOK_D));
-        for (int col = NS; col < DS_G; col++) TR(col, row) = 0;
-        for (int col = DS_G + NL; col < DS_G + DS_L; col++) TR(col, row) = 0;
+        if (!job.tail_clean) for (int col = NS; col < DS_G; col++) TR(col, row) = 0;
+        if (!job.tail_clean) for (int col = DS_G + NL; col < DS_G + DS_L; col++) TR(col, row) = 0;
         for (int col = DS_G; col < DS_G + NL; col++) atomicAdd(&sh_hist[(u32)TR(col, row) & 0xFF], 1u);
     } else if (i < rs) {
-        zero_gap_row(trace, n_rows, (size_t)ROW * rs + i);
+        if (!job.tail_clean) zero_gap_row(trace, n_rows, (size_t)ROW * rs + i);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -388,7 +388,7 @@ static __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* _
     }
     u64* mlt = trace + (size_t)DS_MULT_COL * n_rows;
     const size_t per = (n_rows + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_rows ? lo + per : n_rows;
-    for (size_t r = lo + threadIdx.x; r < hi; r += 256) {
+    for (size_t r = lo + threadIdx.x; r < (job.tail_clean && hi > 256 ? (lo < 256 ? 256 : lo) : hi); r += 256) {  // (a clean slot: rows >= 256 of the column are still zero)
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];

@@ -34,7 +34,7 @@ struct EsSynthJob {
     const zkw_events_sorter_instance* first_inst;  // the block's first instance (the shared observable input)
     u64* trace;
     u32* hist;
-    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): every cell that is zero in EVERY trace of the layout (the padding rows, the gap rows of a region, the columns a row type does not use, multiplicity rows >= 256) is still zero: the fills skip those stores
 };
 
 struct EsVars {
@@ -174,10 +174,10 @@ static __global__ __launch_bounds__(64) void k_es_fill_queue(const EsSynthJob* _
             for (int k = 0; k < 4; k++) old[k] = ph[k];
         }
         es_queue_op(trace, n_rows, (size_t)R1 * rs + i, (size_t)(R1 + 1) * rs + i, (size_t)(R1 + 2) * rs + i, enc, old, out4);
-        for (int r = 0; r < 3; r++)
+        if (!job.tail_clean) for (int r = 0; r < 3; r++)
             for (int col = ES_G; col < ES_G + ES_L; col++) TR(col, (size_t)(R1 + r) * rs + i) = 0;
     } else if (i < rs) {
-        for (int r = 0; r < 3; r++) zero_gap_row_n(trace, n_rows, (size_t)(R1 + r) * rs + i, ES_G + ES_L);
+        if (!job.tail_clean) for (int r = 0; r < 3; r++) zero_gap_row_n(trace, n_rows, (size_t)(R1 + r) * rs + i, ES_G + ES_L);
     }
 }
 
@@ -305,11 +305,11 @@ static __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __
                                ES_NSLOTS_N5, ES_NSLOTS_N6, ES_NSLOTS_N7, ES_NSLOTS_T, ES_NSLOTS_V, ES_NSLOTS_W, ES_NSLOTS_Q};
         constexpr int NLK[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, ES_NLOOK_A, ES_NLOOK_N0, ES_NLOOK_N1, ES_NLOOK_N2, ES_NLOOK_N3, ES_NLOOK_N4,
                                ES_NLOOK_N5, ES_NLOOK_N6, ES_NLOOK_N7, ES_NLOOK_T, ES_NLOOK_V, ES_NLOOK_W, ES_NLOOK_Q};
-        for (int col = NSL[ROW]; col < ES_G; col++) TR(col, row) = 0;
-        for (int col = ES_G + NLK[ROW]; col < ES_G + ES_L; col++) TR(col, row) = 0;
+        if (!job.tail_clean) for (int col = NSL[ROW]; col < ES_G; col++) TR(col, row) = 0;
+        if (!job.tail_clean) for (int col = ES_G + NLK[ROW]; col < ES_G + ES_L; col++) TR(col, row) = 0;
         for (int col = ES_G; col < ES_G + NLK[ROW]; col++) atomicAdd(&sh_hist[(u32)TR(col, row) & 0xFF], 1u);
     } else if (i < rs) {
-        zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, ES_G + ES_L);
+        if (!job.tail_clean) zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, ES_G + ES_L);
     }
     if (ROW == ES_ROW_A && blockIdx.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells: the key / address bytes of the FSM records' previous_item (bridge rows NIB* / NOB*)
         const zkw_log_query& a = job.inst->hidden_fsm_input.previous_item;
@@ -347,7 +347,7 @@ static __global__ __launch_bounds__(256) void k_es_fill_tail(const EsSynthJob* _
     }
     u64* mlt = trace + (size_t)ES_MULT_COL * n_rows;
     const size_t per = (n_rows + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_rows ? lo + per : n_rows;
-    for (size_t r = lo + threadIdx.x; r < hi; r += 256) {
+    for (size_t r = lo + threadIdx.x; r < (job.tail_clean && hi > 256 ? (lo < 256 ? 256 : lo) : hi); r += 256) {  // (a clean slot: rows >= 256 of the column are still zero)
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];

@@ -46,7 +46,7 @@ struct LdSynthJob {
     const zkw_log_demux_instance* first_inst;  // the block's first instance (the shared observable input)
     u64* trace;
     u32* hist;
-    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): every cell that is zero in EVERY trace of the layout (the padding rows, the gap rows of a region, the columns a row type does not use, multiplicity rows >= 256) is still zero: the fills skip those stores
 };
 
 struct LdVars {
@@ -121,10 +121,10 @@ static __global__ __launch_bounds__(64) void k_ld_fill_queue(const LdSynthJob* _
                 if (r == q) ld_queue_tail(job, c, q, old);
         }
         es_queue_op(trace, n_rows, (size_t)R1 * rs + i, (size_t)(R1 + 1) * rs + i, (size_t)(R1 + 2) * rs + i, enc, old, out4);
-        for (int r = 0; r < 3; r++)
+        if (!job.tail_clean) for (int r = 0; r < 3; r++)
             for (int col = 130; col < LD_G + LD_L; col++) TR(col, (size_t)(R1 + r) * rs + i) = 0;
     } else if (i < rs) {
-        for (int r = 0; r < 3; r++) zero_gap_row_n(trace, n_rows, (size_t)(R1 + r) * rs + i, LD_G + LD_L);
+        if (!job.tail_clean) for (int r = 0; r < 3; r++) zero_gap_row_n(trace, n_rows, (size_t)(R1 + r) * rs + i, LD_G + LD_L);
     }
 }
 
@@ -218,11 +218,11 @@ static __global__ __launch_bounds__(256) void k_ld_fill_row(const LdSynthJob* __
 #undef LD_ROWCASE
         constexpr int NSL[] = {0, 0, 0, 0, 0, 0, LD_NSLOTS_X0, LD_NSLOTS_X1, LD_NSLOTS_X2, LD_NSLOTS_X3, LD_NSLOTS_R, LD_NSLOTS_Q};
         constexpr int NLK[] = {0, 0, 0, 0, 0, 0, LD_NLOOK_X0, LD_NLOOK_X1, LD_NLOOK_X2, LD_NLOOK_X3, LD_NLOOK_R, LD_NLOOK_Q};
-        for (int col = NSL[ROW]; col < LD_G; col++) TR(col, row) = 0;
-        for (int col = LD_G + NLK[ROW]; col < LD_G + LD_L; col++) TR(col, row) = 0;
+        if (!job.tail_clean) for (int col = NSL[ROW]; col < LD_G; col++) TR(col, row) = 0;
+        if (!job.tail_clean) for (int col = LD_G + NLK[ROW]; col < LD_G + LD_L; col++) TR(col, row) = 0;
         for (int col = LD_G; col < LD_G + NLK[ROW]; col++) atomicAdd(&sh_hist[(u32)TR(col, row) & 0xFF], 1u);
     } else if (i < rs) {
-        zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, LD_G + LD_L);
+        if (!job.tail_clean) zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, LD_G + LD_L);
     }
     hist_flush(sh_hist, job.hist);
 }
@@ -254,7 +254,7 @@ static __global__ __launch_bounds__(256) void k_ld_fill_tail(const LdSynthJob* _
     }
     u64* mlt = trace + (size_t)LD_MULT_COL * n_rows;
     const size_t per = (n_rows + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_rows ? lo + per : n_rows;
-    for (size_t r = lo + threadIdx.x; r < hi; r += 256) {
+    for (size_t r = lo + threadIdx.x; r < (job.tail_clean && hi > 256 ? (lo < 256 ? 256 : lo) : hi); r += 256) {  // (a clean slot: rows >= 256 of the column are still zero)
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];

@@ -1,7 +1,8 @@
 // sort.hip — ordering step of the sorter circuits (K7). Replaces rayon `par_sort_by` at
 // src/witness/individual_circuits/ram_permutation.rs:48-53.
 //
-// Stable LSD composition of device-wide radix sorts (rocPRIM): timestamp (32 bit), then cell =
+// Device-wide radix sorts (rocPRIM) of the keys ram_sort (zkw_api.hip) packs: one sort of (block, page, index, timestamp) when the
+// batch fits them into 64 bits, else a stable LSD composition: timestamp (32 bit), then cell =
 // page<<32|index (64 bit), then block id (only as many bits as there are blocks). Stability of each
 // pass makes the result identical to the reference's stable comparison sort by (page, index, ts).
 // This is a plain library primitive (like a library GEMM); the kernels that are specific to this

@@ -48,7 +48,7 @@ struct SsSynthJob {
     const zkw_storage_sorter_instance* first_inst;  // the block's first instance (the shared observable input)
     u64* trace;
     u32* hist;
-    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): the padding rows below the boundary rows are still zero, the tail kernel skips them
+    u32 tail_clean;  // the slot already holds this layout (same circuit, capacity, rows): every cell that is zero in EVERY trace of the layout (the padding rows, the gap rows of a region, the columns a row type does not use, multiplicity rows >= 256) is still zero: the fills skip those stores
 };
 
 struct SsVars {
@@ -191,10 +191,10 @@ static __global__ __launch_bounds__(64) void k_ss_fill_queue(const SsSynthJob* _
             ss_prev_head(job, c, WHICH, old);
         }
         es_queue_op(trace, n_rows, (size_t)R1 * rs + i, (size_t)(R1 + 1) * rs + i, (size_t)(R1 + 2) * rs + i, enc, old, out4);
-        for (int r = 0; r < 3; r++)
+        if (!job.tail_clean) for (int r = 0; r < 3; r++)
             for (int col = 130; col < SS_G + SS_L; col++) TR(col, (size_t)(R1 + r) * rs + i) = 0;
     } else if (i < rs) {
-        for (int r = 0; r < 3; r++) zero_gap_row_n(trace, n_rows, (size_t)(R1 + r) * rs + i, SS_G + SS_L);
+        if (!job.tail_clean) for (int r = 0; r < 3; r++) zero_gap_row_n(trace, n_rows, (size_t)(R1 + r) * rs + i, SS_G + SS_L);
     }
 }
 
@@ -398,11 +398,11 @@ static __global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __
                                SS_NSLOTS_X5, SS_NSLOTS_X6, SS_NSLOTS_X7, SS_NSLOTS_K, SS_NSLOTS_C1, SS_NSLOTS_C2, SS_NSLOTS_Q};
         constexpr int NLK[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, SS_NLOOK_A, SS_NLOOK_X0, SS_NLOOK_X1, SS_NLOOK_X2, SS_NLOOK_X3, SS_NLOOK_X4,
                                SS_NLOOK_X5, SS_NLOOK_X6, SS_NLOOK_X7, SS_NLOOK_K, SS_NLOOK_C1, SS_NLOOK_C2, SS_NLOOK_Q};
-        for (int col = NSL[ROW]; col < SS_G; col++) TR(col, row) = 0;
-        for (int col = SS_G + NLK[ROW]; col < SS_G + SS_L; col++) TR(col, row) = 0;
+        if (!job.tail_clean) for (int col = NSL[ROW]; col < SS_G; col++) TR(col, row) = 0;
+        if (!job.tail_clean) for (int col = SS_G + NLK[ROW]; col < SS_G + SS_L; col++) TR(col, row) = 0;
         for (int col = SS_G; col < SS_G + NLK[ROW]; col++) atomicAdd(&sh_hist[(u32)TR(col, row) & 0xFF], 1u);
     } else if (i < rs) {
-        zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, SS_G + SS_L);
+        if (!job.tail_clean) zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, SS_G + SS_L);
     }
     if (ROW == SS_ROW_A && blockIdx.x == 0 && threadIdx.x == 0)  // the closed-form section's lookup cells: the bytes of the FSM records' previous_packed_key (bridge rows KIB* / KOB*)
         for (int k = 0; k < ZKW_STORAGE_PACKED_KEY_LENGTH; k++) {
@@ -439,7 +439,7 @@ static __global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* _
     }
     u64* mlt = trace + (size_t)SS_MULT_COL * n_rows;
     const size_t per = (n_rows + TAIL_CHUNKS - 1) / TAIL_CHUNKS, lo = ch * per, hi = lo + per < n_rows ? lo + per : n_rows;
-    for (size_t r = lo + threadIdx.x; r < hi; r += 256) {
+    for (size_t r = lo + threadIdx.x; r < (job.tail_clean && hi > 256 ? (lo < 256 ? 256 : lo) : hi); r += 256) {  // (a clean slot: rows >= 256 of the column are still zero)
         u64 v = 0;
         if (r < 256) {
             v = job.hist[r];

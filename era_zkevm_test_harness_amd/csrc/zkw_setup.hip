@@ -102,15 +102,26 @@ extern "C" int zkw_circuit_fill_bytes(uint8_t circuit_type, uint32_t capacity, s
     ZKW_TRY(zkw_circuit_layout_of(circuit_type, capacity, &lay));
     if (!lay.synthesizable || !warm || !cold) return fail(ZKW_ERR_INVALID, "zkw_circuit_fill_bytes: bad argument");
     *cold = (uint64_t)lay.num_columns * n_rows * 8;
-    if (lay.region_stride) {  // the queue circuits: every cell down to the boundary rows and the multiplicity column, every time; the zero padding below only when the slot held another layout
-        const uint64_t rows = (lay.rows_used + 1) & ~1ull;
-        *warm = ((uint64_t)(lay.num_columns - 1) * rows + n_rows) * 8;
-        if (circuit_type == ZKW_CIRCUIT_RAM_PERMUTATION) {  // its fills also skip the cells that are zero in every trace: unused columns of a row type, gap rows, multiplicity rows >= 256
-            static const int slots[] = RC_ROW_NUM_SLOTS_INIT, looks[] = RC_ROW_NUM_LOOKUPS_INIT;
-            uint64_t per_cycle = 0;
-            for (int r = 0; r < RC_ROWS_PER_CYCLE; r++) per_cycle += (uint64_t)slots[r] + looks[r];
-            *warm = (per_cycle * lay.capacity + (uint64_t)(lay.num_columns - 1) * (rows - (uint64_t)lay.rows_per_cycle * lay.region_stride) + 256) * 8;
+    if (lay.region_stride) {
+        // the queue circuits: a slot that already holds the layout gets the cells a row type uses (its slots + its lookup cells, per cycle),
+        // every cell of the boundary rows and the 256 multiplicity rows; the cells that are zero in every trace — unused columns of a row
+        // type, the gap rows of a region, the padding below the boundary rows, multiplicity rows >= 256 — keep their zeros
+        static const int rc_s[] = RC_ROW_NUM_SLOTS_INIT, rc_l[] = RC_ROW_NUM_LOOKUPS_INIT, ds_s[] = DS_ROW_NUM_SLOTS_INIT, ds_l[] = DS_ROW_NUM_LOOKUPS_INIT,
+                         es_s[] = ES_ROW_NUM_SLOTS_INIT, es_l[] = ES_ROW_NUM_LOOKUPS_INIT, ld_s[] = LD_ROW_NUM_SLOTS_INIT, ld_l[] = LD_ROW_NUM_LOOKUPS_INIT,
+                         ss_s[] = SS_ROW_NUM_SLOTS_INIT, ss_l[] = SS_ROW_NUM_LOOKUPS_INIT;
+        const int *slots = nullptr, *looks = nullptr;
+        switch (circuit_type) {
+            case ZKW_CIRCUIT_RAM_PERMUTATION: slots = rc_s; looks = rc_l; break;
+            case ZKW_CIRCUIT_CODE_DECOMMITTMENTS_SORTER: slots = ds_s; looks = ds_l; break;
+            case ZKW_CIRCUIT_LOG_DEMUXER: slots = ld_s; looks = ld_l; break;
+            case ZKW_CIRCUIT_STORAGE_SORTER: slots = ss_s; looks = ss_l; break;
+            case ZKW_CIRCUIT_EVENTS_SORTER: case ZKW_CIRCUIT_L1_MESSAGES_SORTER: slots = es_s; looks = es_l; break;
+            default: return fail(ZKW_ERR_INVALID, "zkw_circuit_fill_bytes: circuit type %u has no region-major spec", (unsigned)circuit_type);
         }
+        const uint64_t rows = (lay.rows_used + 1) & ~1ull;
+        uint64_t per_cycle = 0;
+        for (uint32_t r = 0; r < lay.rows_per_cycle; r++) per_cycle += (uint64_t)slots[r] + looks[r];
+        *warm = (per_cycle * lay.capacity + (uint64_t)(lay.num_columns - 1) * (rows - (uint64_t)lay.rows_per_cycle * lay.region_stride) + 256) * 8;
         return ZKW_OK;
     }
     const nl_spec* sp = nl_host_spec(circuit_type);

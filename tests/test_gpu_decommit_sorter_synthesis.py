@@ -100,3 +100,22 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
         hip.hipMemcpy(C.c_void_p(addr), np.array([host[c, r]], np.uint64).ctypes.data_as(C.c_void_p), C.c_size_t(8), 1)
     assert ctx.check_if_satisfied_decommit_sorter(t, 0, capacity)[0] == 0
     t.free()
+
+
+def test_slot_reuse_keeps_the_zero_cells(ctx, oracle):
+    """A slot that already holds this layout keeps every cell that is zero in all of its traces (padding rows, region gaps, the columns a row
+    type does not use, multiplicity rows >= 256): consecutive instances — full ones, then a ragged last one — and a change of capacity
+    (another layout: everything is rewritten) into ONE slot, each compared cell for cell."""
+    from era_zkevm_test_harness_amd import native
+
+    n_rows = 2048
+    q = synthetic.decommit_trace(300, 40, seed=6)
+    t = native.Trace(ctx, n_rows, 1)
+    for capacity in (128, 64, 128):
+        w = ctx.compute_decommitts_sorter_circuit_snapshots(q, capacity)
+        o = oracle.decommit_sorter_build(q, capacity)
+        for idx in range(o["instances"].size):
+            ctx.synthesize_decommit_sorter(w, t, idx, 1, 0)
+            assert np.array_equal(t.get(0), oracle.decommit_sorter_synthesize(o, idx, capacity, n_rows)), (capacity, idx)
+        w.free()
+    t.free()

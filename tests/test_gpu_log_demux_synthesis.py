@@ -113,3 +113,20 @@ def test_compact_forms_and_public_inputs(ctx, oracle):
     assert o["instances"].size >= 3
     assert np.array_equal(w.get(nv.DMX_COMPACT_FORMS), compact)
     assert np.array_equal(w.get(nv.DMX_PUBLIC_INPUTS), pi)
+
+
+def test_slot_reuse_keeps_the_zero_cells(ctx, oracle):
+    """as tests/test_gpu_decommit_sorter_synthesis.py::test_slot_reuse_keeps_the_zero_cells, for the log demultiplexer"""
+    from era_zkevm_test_harness_amd import native
+
+    n_rows = 2048
+    q = synthetic.mixed_log_queue(200, seed=8)
+    t = native.Trace(ctx, n_rows, 1, n_cols=LD_COLS)
+    for capacity in (70, 32, 70):
+        w = ctx.compute_logs_demux(q, capacity)
+        o = oracle.log_demux_build(q, capacity)
+        for idx in range(o["instances"].size):
+            ctx.synthesize_log_demux(w, t, idx, 1, 0)
+            assert np.array_equal(t.get(0), oracle.log_demux_synthesize(o, idx, capacity, n_rows)), (capacity, idx)
+        w.free()
+    t.free()

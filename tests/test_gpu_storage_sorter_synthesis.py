@@ -117,3 +117,20 @@ def test_empty_queue_dummy_instance(ctx, oracle):
     assert np.array_equal(t.get(0)[:149], oracle.storage_sorter_synthesize(o, 0, 16, 2048))
     assert ctx.check_if_satisfied_storage_sorter(t, 0, 16)[0] == 0
     t.free()
+
+
+def test_slot_reuse_keeps_the_zero_cells(ctx, oracle):
+    """as tests/test_gpu_decommit_sorter_synthesis.py::test_slot_reuse_keeps_the_zero_cells, for the storage sorter"""
+    from era_zkevm_test_harness_amd import native
+
+    n_rows = 2048
+    q = synthetic.storage_trace(150, 40, seed=8)
+    t = native.Trace(ctx, n_rows, 1)
+    for capacity in (50, 32, 50):
+        w = ctx.compute_storage_dedup_and_sort(q, capacity)
+        o = oracle.storage_sorter_build(q, capacity)
+        for idx in range(o["instances"].size):
+            ctx.synthesize_storage_sorter(w, t, idx, 1, 0)
+            assert np.array_equal(t.get(0), oracle.storage_sorter_synthesize(o, idx, capacity, n_rows)), (capacity, idx)
+        w.free()
+    t.free()

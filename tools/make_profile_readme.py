@@ -1,6 +1,7 @@
 """Regenerates profiles/<round>/README.md and traffic.json from the CSV / JSON / text files next to them (numbers are never
 typed by hand). Usage: python tools/make_profile_readme.py r02"""
 import csv
+import re
 import json
 import os
 import sys
@@ -32,8 +33,15 @@ W, F = pmc("bench_pmc_WRITE_SIZE.summary.csv"), pmc("bench_pmc_FETCH_SIZE.summar
 B = pmc_run["config"]["blocks_per_gpu"]
 n = pmc_run["config"]["queries_per_block"]
 stride, n_rows, inst = (n + 63) // 64 * 64, 1 << 20, 16
-alg_w = {k: 148 * stride * 8 * inst for k in ("zkw::k_ram_fill_poseidon<0>", "zkw::k_ram_fill_poseidon<1>", "zkw::k_ram_fill_A",
-                                              "zkw::k_ram_fill_B", "zkw::k_ram_fill_C", "zkw::k_ram_fill_D")}
+# cells a region's fill stores per cycle in a slot that already holds the layout (all but the first launches of a ring slot): the slots
+# its row type uses + its lookup cells, from the generated spec; the cells that are zero in every trace are not rewritten
+_spec = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "zkw_ram_circuit_spec.h")).read()
+def _spec_list(name):
+    return [int(x) for x in re.search(r"#define %s \{([^}]*)\}" % name, _spec).group(1).split(",")]
+_used = [a + b for a, b in zip(_spec_list("RC_ROW_NUM_SLOTS_INIT"), _spec_list("RC_ROW_NUM_LOOKUPS_INIT"))]
+alg_w = {"zkw::k_ram_fill_poseidon<0>": _used[0], "zkw::k_ram_fill_poseidon<1>": _used[1], "zkw::k_ram_fill_A": _used[2],
+         "zkw::k_ram_fill_B": _used[3], "zkw::k_ram_fill_C": _used[4], "zkw::k_ram_fill_D": _used[5]}
+alg_w = {k: v * n * 8 * inst for k, v in alg_w.items()}
 alg_w["zkw::k_ram_fill_tail"] = n_rows * 8 * inst  # the multiplicity column; the zero padding below the boundary rows is only written into a slot that held another layout (slot layout tags)
 chain = next((k for k in W if k.startswith("zkw::k_chain_full")), None)
 alg_r = {}
