@@ -141,3 +141,17 @@ def test_setup_commit_of_every_synthesized_type(ctx, oracle):
         assert int(cols[c, r]) == pow(7, t >> log_n, P) * int(om[t & ((1 << log_n) - 1)]) % P
     want = oracle.merkle_tree_with_cap(oracle.lde(cols, 2), 16)
     assert np.array_equal(commits[7], want[-16:])
+
+
+def test_verification_key_of_a_layout(ctx, tmp_path):
+    """the key of the EventsSorter layout in the reference's vk_N.json shape: the cap is zkw_setup_commit's at 2^20 rows / LDE x 2 / cap 16, the
+    file round-trips through the reference's enum-keyed JSON, and the geometry fields repeat the wrapper's"""
+    from era_zkevm_test_harness_amd import wire
+
+    vk = wire.verification_key_of_layout(ctx, 11)
+    assert np.array_equal(np.array(vk["setup_merkle_tree_cap"], np.uint64), ctx.setup_commit(11, 0, 20))
+    fp = vk["fixed_parameters"]
+    assert fp["domain_size"] == 1 << 20 and fp["fri_lde_factor"] == 2 and fp["cap_size"] == 16 and fp["total_tables_len"] == 256
+    path = tmp_path / "vk_11.json"
+    wire.dump(path, 11, vk)
+    assert wire.load(path) == (11, vk)

@@ -62,3 +62,34 @@ def test_layouts_against_reference_hints(tmp_path):
     assert not native.circuit_layout(1)["synthesizable"]
     with pytest.raises(native.ZkwError):
         native.circuit_layout(14)
+
+
+def test_verification_key_of_a_layout_has_the_reference_shape():
+    """wire.verification_key_payload: the key of this library's RAMPermutation layout next to the reference's vk_8.json (a fixture copy of
+    setup/base_layer/vk_8.json): same fields, same geometry / lookup parameters / domain / table length / cap size; the PI cells are the
+    layout's, the selector description is this library's single row-type column"""
+    import numpy as np
+
+    from era_zkevm_test_harness_amd import native, wire
+
+    ref_type, ref = wire.load(os.path.join(GOLD, "reference_setup", "vk_8.json"))
+    assert ref_type == 8
+    cap = np.arange(64, dtype=np.uint64).reshape(16, 4)
+    vk = wire.verification_key_payload(8, cap)
+    assert list(vk) == list(ref) and list(vk["fixed_parameters"]) == list(ref["fixed_parameters"])
+    fp, rp = vk["fixed_parameters"], ref["fixed_parameters"]
+    for k in ("lookup_parameters", "domain_size", "total_tables_len", "fri_lde_factor", "cap_size", "quotient_degree"):
+        assert fp[k] == rp[k], k
+    for k in ("num_columns_under_copy_permutation", "num_witness_columns", "max_allowed_constraint_degree"):
+        assert fp["parameters"][k] == rp["parameters"][k], k
+    lay = native.circuit_layout(8)
+    assert fp["public_inputs_locations"] == [[int(c), int(r)] for c, r in zip(lay["public_input_column"], lay["public_input_row"])]
+    assert fp["parameters"]["num_constant_columns"] == 1 and list(fp["selectors_placement"]) == ["RowTypeColumn"]
+    assert vk["setup_merkle_tree_cap"] == cap.tolist()
+    assert wire.loads(wire.dumps(8, vk)) == (8, vk)
+    for t in (2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13):
+        assert wire.verification_key_payload(t, cap)["fixed_parameters"]["parameters"]["num_columns_under_copy_permutation"] == native.circuit_geometry(t)["num_columns_under_copy_permutation"]
+    with pytest.raises(ValueError):
+        wire.verification_key_payload(1, cap)  # MainVM has no layout here
+    with pytest.raises(ValueError):
+        wire.verification_key_payload(8, cap[:3])
