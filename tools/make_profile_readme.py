@@ -165,7 +165,7 @@ for name, title in (("full_block_probe.txt", "One production-capacity block (too
                     ("netlist_kc_kernel_stats.csv", "rocprofv3 --kernel-trace --stats of tools/probe_kc_synth.py (Keccak256RoundFunction, 3 x 8 instances + the builder)"),
                     ("netlist_sc_kernel_stats.csv", "rocprofv3 --kernel-trace --stats of tools/probe_sc_synth.py (Sha256RoundFunction, 3 x 8 instances + the builder)"),
                     ("netlist_kernel_stats.csv", "rocprofv3 --kernel-trace --stats of tools/probe_netlist_perf.py (netlist circuits at production geometry: Keccak256RoundFunction and Sha256RoundFunction 4 x 8 instances, L1MessagesHasher 2 x 1 + 2 x 8 queues, + the builders)"),
-                    ("netlist_pmc.txt", "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes) of the netlist probe: HBM bytes per dispatch (k_nl_fill: 8 instances per dispatch, mixed over the circuits)"),
+                    ("netlist_pmc.txt", "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE / SQ_INSTS_VALU / SQ_INSTS_LDS / SQ_INSTS_VMEM_WR (separate passes) of the netlist probe: HBM bytes and wave-instructions per dispatch (k_nl_fill: 8 instances per dispatch, mixed over the circuits)"),
                     ("netlist_fill_split.txt", "Where the netlist fill's time went (builds with one phase compiled out) and the steps of moving the multiplicity counting out of it"),
                     ("gpu_tests_tail.txt", "pytest tests -m gpu on the same box")):
     path = os.path.join(D, name)

@@ -63,7 +63,7 @@ rm -rf /tmp/pk_nl && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --outp
 cp "$(ls /tmp/pk_nl/*/*kernel_stats.csv | head -1)" "$OUT/netlist_kernel_stats.csv"
 # 5b. HBM counters of the netlist probe (separate passes per counter): bytes per dispatch of 8 instances
 : > "$OUT/netlist_pmc.txt"
-for C in WRITE_SIZE FETCH_SIZE; do
+for C in WRITE_SIZE FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR; do
     rm -rf /tmp/pn && timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pn -- python tools/probe_netlist_perf.py > /dev/null 2>&1
     python3 - "$(ls /tmp/pn/*/*counter_collection.csv | head -1)" $C >> "$OUT/netlist_pmc.txt" <<'PY'
 import collections, csv, sys
@@ -74,7 +74,10 @@ for r in csv.DictReader(open(sys.argv[1])):
 # the counters are in KiB; FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section: the same corrections as traffic.json)
 scale = 1024 * (2 if sys.argv[2] == "FETCH_SIZE" else 1)
 for k in sorted(tot, key=lambda k: -tot[k])[:8]:
-    print(f"{sys.argv[2]}{' x2' if scale > 1024 else ''} {k} {len(disp[k])} dispatches {tot[k] / len(disp[k]) * scale / 1e9:.3g} GB per dispatch")
+    if sys.argv[2].startswith("SQ_"):  # instruction counts (wave-instructions), all XCDs
+        print(f"{sys.argv[2]} {k} {len(disp[k])} dispatches {tot[k] / len(disp[k]):.4g} wave-instructions per dispatch")
+    else:
+        print(f"{sys.argv[2]}{' x2' if scale > 1024 else ''} {k} {len(disp[k])} dispatches {tot[k] / len(disp[k]) * scale / 1e9:.3g} GB per dispatch")
 PY
 done
 # 6. the hardware probes behind DESIGN.md 3.2
