@@ -676,9 +676,9 @@ def main():
             "k_ram_fill_B": used[3] * cell_used + wit * 96,
             "k_ram_fill_C": used[4] * cell_used + wit * 96,
             "k_ram_fill_D": used[5] * cell_used + 48 * cell_used,  # reads the queue tails back from the Poseidon2 rows
-            # the multiplicity column; the zero padding below the boundary rows is written only into a slot that held another layout
+            # rows 0..255 of the multiplicity column; its other rows and the zero padding below the boundary rows are written only into a slot that held another layout
             # (slot layout tag): never inside the timed region, whose ring slots were filled by the warm-up step
-            "k_ram_fill_tail": per_launch_inst * 8 * n_rows,
+            "k_ram_fill_tail": per_launch_inst * 8 * 256,
         }
         def pmc_traffic(kernel, launches_items):
             """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate

@@ -42,7 +42,12 @@ _used = [a + b for a, b in zip(_spec_list("RC_ROW_NUM_SLOTS_INIT"), _spec_list("
 alg_w = {"zkw::k_ram_fill_poseidon<0>": _used[0], "zkw::k_ram_fill_poseidon<1>": _used[1], "zkw::k_ram_fill_A": _used[2],
          "zkw::k_ram_fill_B": _used[3], "zkw::k_ram_fill_C": _used[4], "zkw::k_ram_fill_D": _used[5]}
 alg_w = {k: v * n * 8 * inst for k, v in alg_w.items()}
-alg_w["zkw::k_ram_fill_tail"] = n_rows * 8 * inst  # the multiplicity column; the zero padding below the boundary rows is only written into a slot that held another layout (slot layout tags)
+# rows 0..255 of the multiplicity column; its other rows and the zero padding below the boundary rows are only written into a slot that held
+# another layout (slot layout tags): in this run that is the FIRST launch (16 fresh slots), averaged in over the run's launches
+_tail_warm = 256 * 8 * inst
+_tail_cold = ((148 * (n_rows - (6 * stride + 40)) + n_rows) * 8) * inst
+_tail_n = W.get("zkw::k_ram_fill_tail", (1, 0))[0] or 1
+alg_w["zkw::k_ram_fill_tail"] = (_tail_warm * (_tail_n - 1) + _tail_cold) / _tail_n
 chain = next((k for k in W if k.startswith("zkw::k_chain_full")), None)
 alg_r = {}
 if chain:
