@@ -148,8 +148,9 @@ int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_l
    ZKW_ROW_BOUNDARY + k. ZKW_ROW_PADDING: the row holds nothing (all cells zero). capacity 0 = the type's default.
    No GPU needed. Copy-permutation (sigma) columns are not produced yet. */
 /* bytes one synthesis call writes into one slot (the cells its fill kernels store x 8): *warm when the slot already holds this layout
-   (a netlist circuit keeps the slot's zeros: see zkw_trace_device_ptr), *cold for any other slot (every cell of the slot's columns).
-   The queue circuits write every cell every time (warm == cold). What measured circuits/s are multiplied by to get bytes/s. */
+   (same circuit, capacity and row count: the slot keeps every cell that is zero in all traces of the layout — padding rows, the columns
+   a row type does not use, region gaps, multiplicity rows >= 256; see zkw_trace_device_ptr for what resets the tag), *cold for any other
+   slot (every cell of the slot's columns). What measured circuits/s are multiplied by to get bytes/s. */
 int zkw_circuit_fill_bytes(uint8_t circuit_type, uint32_t capacity, size_t n_rows, uint64_t *warm, uint64_t *cold);
 #define ZKW_ROW_HAS_GATES 0x40
 #define ZKW_ROW_HEADER 0x80
@@ -793,9 +794,10 @@ size_t zkw_trace_num_rows(const zkw_trace *t);
 size_t zkw_trace_num_cols(const zkw_trace *t); /* default 149 = 133 copy-permutation + 15 lookup + 1 multiplicity */
 size_t zkw_trace_num_slots(const zkw_trace *t);
 /* device address of slot's column 0; column c starts at + c * n_rows.
-   CONTRACT: the library remembers which layout a slot last held (a netlist synthesis into a slot that still holds the same
-   circuit / capacity / row count skips clearing it); taking this pointer FORGETS that — the caller may write through it — so
-   the next synthesis into the slot clears it again. A pointer kept from an earlier call must therefore not be written
+   CONTRACT: the library remembers which layout a slot last held (a synthesis of any circuit type into a slot that still holds the
+   same circuit / capacity / row count stores only the cells that can differ between traces of that layout and relies on the rest
+   still being zero); taking this pointer FORGETS that — the caller may write through it — so
+   the next synthesis into the slot writes every cell again. A pointer kept from an earlier call must therefore not be written
    through after a later synthesis into the slot: take the pointer again (or read with zkw_trace_get, which keeps the slot's
    state). Reading through a kept pointer is always fine. */
 const uint64_t *zkw_trace_device_ptr(const zkw_trace *t, size_t slot);
