@@ -486,13 +486,21 @@ def main():
     lib = native.load()
     q_item = q.element_size() * q.shape[2]  # 48 bytes per query
 
-    def pipeline_pass(p):
+    def pipeline_pass(p, last=False):
         """witness generation + synthesis of sub-batch p (blocks p*Bp .. (p+1)*Bp) on pipeline p's stream"""
         c, w, ring = ctxs[p], ws[p], rings[p]
         span = [p, time.perf_counter()]  # host clock of the pass: start | builders done | synthesis turn taken | synthesis done | end
         with torch.cuda.stream(streams[p]):
             c.compute_ram_circuit_snapshots((q.data_ptr() + p * Bp * n * q_item, Bp * n), CAPACITY, 0, block_offsets=offs, witness=w)
-            if P > 1 and synth_turns:
+            if phased:
+                # two pipelines in lockstep (DESIGN.md 3.2): a phase = one pipeline's builders next to the other's synthesis; the next phase
+                # starts when both are done. Two chain passes never overlap (1 804 chain waves on 1 024 SIMDs: two on one SIMD take turns
+                # and both chains stretch from 2.0 to 3.3 s), two synthesis phases never overlap either.
+                streams[p].synchronize()
+                span.append(time.perf_counter())
+                phase_barrier.wait()
+                span.append(time.perf_counter())
+            elif P > 1 and synth_turns:
                 # synthesis phases take turns: a pipeline fills at full speed while the others are in their chain pass,
                 # instead of two synthesis phases slowing each other down (DESIGN.md 3.2)
                 streams[p].synchronize()
@@ -502,11 +510,13 @@ def main():
             try:
                 for first in range(0, n_inst_p, ring_p):  # synthesis: every instance -> a full 2^20-row trace
                     c.synthesize_ram(w, ring, first, min(ring_p, n_inst_p - first), 0)
-                if P > 1 and synth_turns:
+                if P > 1 and (synth_turns or phased):
                     streams[p].synchronize()
                     span.append(time.perf_counter())
+                if phased and not (last and p == P - 1):
+                    phase_barrier.wait()  # (the last synthesis of the last pipeline has nothing next to it)
             finally:
-                if P > 1 and synth_turns:
+                if P > 1 and synth_turns and not phased:
                     synth_lock.release()
             lo, hi = p * n_inst_p, (p + 1) * n_inst_p
             cp, pp = compact[lo:hi], pis[lo:hi]
@@ -525,13 +535,22 @@ def main():
     synth_lock = threading.Lock()
     pass_spans = []
     synth_turns = os.environ.get("ZKW_SYNTH_TURNS", "1") != "0"
+    phased = P == 2 and os.environ.get("ZKW_PHASED", "0") != "0"  # experiment: with one chain workgroup per CU the turn-taking default does as well
+    phase_barrier = threading.Barrier(2)
 
     def pipeline_run(p, passes, delay_s):
         torch.cuda.set_device(local_rank)
-        if delay_s > 0:
-            time.sleep(delay_s)
-        for _ in range(passes):
-            pipeline_pass(p)
+        try:
+            if phased:
+                if p == 1:
+                    phase_barrier.wait()  # phase 0 is pipeline 0's builders alone
+            elif delay_s > 0:
+                time.sleep(delay_s)
+            for k in range(passes):
+                pipeline_pass(p, last=k == passes - 1)
+        except BaseException:
+            phase_barrier.abort()  # the other pipeline must not wait for a phase that will not come
+            raise
 
     recv_all = torch.empty((n_inst_local * world, inst_bytes), dtype=torch.uint8, device=dev) if rank == 0 else None
 
@@ -759,7 +778,9 @@ def main():
                        "trace_layout": "zkw trace v2 (own gate placement, same geometry as the reference wrapper; not interoperable "
                                        "with the reference's vk_8 / finalization_hint_8: DESIGN.md section 4)",
                        "blocks_per_gpu": B, "queries_per_block": n, "parallelism": f"instances sharded x{world}",
-                       "pipelines_per_gpu": P, "pipeline_stagger_ms": stagger_s * 1e3, "gather": gather_backend,
+                       "pipelines_per_gpu": P, "pipeline_stagger_ms": 0.0 if phased else stagger_s * 1e3,
+                       "pipeline_schedule": ("lockstep: a phase = one pipeline's builders next to the other's synthesis, the next phase starts when both are done" if phased else
+                                             "synthesis phases take turns" if P > 1 and synth_turns else "free-running" if P > 1 else "one pipeline"), "gather": gather_backend,
                        "trace_slots": "ring of 16 slots; a slot that already holds this layout keeps its zero padding rows (layout tag): "
                                       "write_bytes_per_circuit of trace_bytes_per_circuit are written per synthesis",
                        "write_bytes_per_circuit": native.circuit_fill_bytes(8, CAPACITY, n_rows)[0],

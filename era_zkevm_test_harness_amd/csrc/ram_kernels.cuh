@@ -166,10 +166,15 @@ static __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __rest
 
 // Quad form: 16 chains per wave (p2::Coop4). Lane j of a quad loads enc[j], enc[4+j] and stores tails[j],
 // tails[4+j], tails[8+j]: 32 contiguous bytes per quad per access.
-static __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict__ jobs, int n_jobs) {
+// WAVES = 1: one wave per workgroup (placed wherever a wave slot is free). WAVES = 4 (`k_chain_full_q4x4`): the four waves of a
+// workgroup go to the four SIMDs of ONE CU, and the launch asks for more than half of a CU's LDS (unused) so that a CU takes one such
+// workgroup: every chain wave of a launch of <= 16 384 chains has a SIMD without another chain wave on it, whatever else (the
+// other pipeline's fills) occupies the chip when the launch arrives — see dev_chains.
+template <int WAVES>
+static __device__ __forceinline__ void chain_full_q4_body(const ChainJob* __restrict__ jobs, int n_jobs) {
     __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
     const int lane = threadIdx.x & 63, j = lane & 3;
-    const int chain = blockIdx.x * 16 + (lane >> 2);
+    const int chain = blockIdx.x * (16 * WAVES) + (threadIdx.x >> 2);
     p2::Coop4 co;
     co.init(j);
     ChainJob job;
@@ -234,6 +239,8 @@ static __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __r
     }
     flush();
 }
+static __global__ __launch_bounds__(64) void k_chain_full_q4(const ChainJob* __restrict__ jobs, int n_jobs) { chain_full_q4_body<1>(jobs, n_jobs); }
+static __global__ __launch_bounds__(256) void k_chain_full_q4x4(const ChainJob* __restrict__ jobs, int n_jobs) { chain_full_q4_body<4>(jobs, n_jobs); }
 
 // Pair form: 32 chains per wave (p2::Coop2). Lane j of a pair holds elements 4c + 2j, 4c + 2j + 1: it loads / stores 16
 // contiguous bytes per block of four. Half the waves of the quad form for the same queues and ~half its wave-instructions per

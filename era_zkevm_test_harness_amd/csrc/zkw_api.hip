@@ -364,6 +364,25 @@ extern "C" int zkw_profile_names(zkw_ctx* ctx, char* buf, size_t buf_bytes) {
     return ZKW_OK;
 }
 
+// The quad chain kernel's launch. Up to 16 384 chains (= 256 CUs x 4 SIMDs x 16 chains per wave) go out as 4-wave workgroups with an
+// LDS request of more than half a CU's 160 KB: one workgroup per CU, its waves on the CU's four SIMDs — no two chain waves of the launch
+// share a SIMD even when the launch arrives on a chip that another stream's fill kernels keep full (one-wave workgroups then land
+// wherever a slot is free, some SIMDs get two or three chain waves, and the pass takes 1.5x or 2x as long: the slowest chain sets it).
+// A second such launch cannot start on a CU that still holds the first one's workgroup, so overlapping chain passes queue up instead of
+// doubling up. ZKW_CHAIN_WG4=0 restores one-wave workgroups.
+static int launch_chain_q4(hipStream_t st, const ChainJob* d_jobs, int n_jobs) {
+    static const bool wg4 = [] { const char* e = getenv("ZKW_CHAIN_WG4"); return !(e && e[0] == '0'); }();
+    static const unsigned lds = 84 * 1024;
+    if (wg4 && n_jobs > 64 && n_jobs <= 256 * 64) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_full_q4x4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HIP_TRY(attr);
+        hipLaunchKernelGGL(k_chain_full_q4x4, dim3((n_jobs + 63) / 64), dim3(256), lds, st, d_jobs, n_jobs);
+    } else {
+        hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
+    }
+    return ZKW_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ chain service
 // Many contexts, few launches. A queue chain is serial — microseconds per item on ONE wave — and a launch of n chains costs
 // what its longest chain costs as long as every wave has a SIMD to itself (4 096 chains in the row form). When many blocks
@@ -478,7 +497,7 @@ struct ChainService {
                 const int nf = (int)b->full.size(), nl = (int)b->log.size();
                 if (rc == ZKW_OK && nl) hipLaunchKernelGGL(k_chain_log, dim3((nl + 3) / 4), dim3(64), 0, st_log, reinterpret_cast<const LogChainJob*>(dp + off_log), nl);
                 if (rc == ZKW_OK && nf) {
-                    if (nf >= 4096) hipLaunchKernelGGL(k_chain_full_q4, dim3((nf + 15) / 16), dim3(64), 0, st, reinterpret_cast<const ChainJob*>(dp), nf);
+                    if (nf >= 4096) (void)launch_chain_q4(st, reinterpret_cast<const ChainJob*>(dp), nf);
                     else hipLaunchKernelGGL(k_chain_full, dim3((nf + 3) / 4), dim3(64), 0, st, reinterpret_cast<const ChainJob*>(dp), nf);
                 }
                 fail_hip(hipGetLastError(), "chain launch");
@@ -582,7 +601,7 @@ int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     {
         Prof _p(ctx, name);
         if (form == 16) hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
-        else if (form == 4) hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
+        else if (form == 4) ZKW_TRY(launch_chain_q4(st, d_jobs, n_jobs));
         else if (form == 2) hipLaunchKernelGGL(k_chain_full_p2, dim3((n_jobs + 31) / 32), dim3(64), 0, st, d_jobs, n_jobs);
         else hipLaunchKernelGGL(k_chain_full_lane, dim3((n_jobs + 63) / 64), dim3(64), 0, st, d_jobs, n_jobs);
         if (ctx->chain_stream) {  // the profiling events live on the context's stream: bring the kernel's end onto it first
