@@ -122,7 +122,7 @@ if fb:
         w(f"* batched full-block leg: **{bt['blocks_per_s']:.1f} blocks/s** with {bt['blocks']} blocks in flight (builders {bt['builders_ms']:.0f} ms, "
           f"synthesis of {bt['instances_synthesized']} instances {bt['synthesis_ms']:.0f} ms, release {bt['release_ms']:.0f} ms).")
     if bench.get("hash_circuits"):
-        w("* netlist circuits at the reference geometry (2^20 rows; circuits/s incl. the memset of the slots): " + ", ".join(
+        w("* netlist circuits at the reference geometry (2^20 rows; circuits/s into slots that already hold the layout; cold rates in the JSON): " + ", ".join(
             f"{k} {v['circuits_per_s']:.0f} (capacity {v['capacity']})" for k, v in bench["hash_circuits"].items()) + ".")
     w("* spans of the builders (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in sorted(fb["spans_ms"].items(), key=lambda kv: -kv[1])[:8]) + ".")
 cb = bench.get("cpu_baseline")
