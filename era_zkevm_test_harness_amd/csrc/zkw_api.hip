@@ -374,8 +374,13 @@ static int launch_chain_q4(hipStream_t st, const ChainJob* d_jobs, int n_jobs) {
     static const bool wg4 = [] { const char* e = getenv("ZKW_CHAIN_WG4"); return !(e && e[0] == '0'); }();
     static const unsigned lds = 84 * 1024;
     if (wg4 && n_jobs > 64 && n_jobs <= 256 * 64) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_full_q4x4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        HIP_TRY(attr);
+        static std::atomic<bool> allowed[64];  // per device: a kernel's LDS limit is raised on the device that runs it
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !allowed[dev].load()) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_full_q4x4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) allowed[dev].store(true);
+        }
         hipLaunchKernelGGL(k_chain_full_q4x4, dim3((n_jobs + 63) / 64), dim3(256), lds, st, d_jobs, n_jobs);
     } else {
         hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
