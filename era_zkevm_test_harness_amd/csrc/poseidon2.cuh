@@ -133,6 +133,7 @@ constexpr int QP_ROT1 = 1 | (2 << 2) | (3 << 4) | (0 << 6);  // lane j reads lan
 constexpr int QP_ROT2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);
 constexpr int QP_ROT3 = 3 | (0 << 2) | (1 << 4) | (2 << 6);
 constexpr int QP_SWAP1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);
+constexpr int QP_BCAST0 = 0;                                   // every lane of a quad reads its lane 0
 constexpr int ROW_ROR4 = 0x124, ROW_ROR8 = 0x128, ROW_ROR12 = 0x12C;
 
 template <int CTRL>
@@ -168,10 +169,12 @@ struct Coop {
     u32 rsh, hi_mask;                      // 32 - shift (mod 32) and all-ones unless shift == 0: the word x * 2^shift spills
     bool active;                           // g < 12
     bool first;                            // g == 0
+    bool second;                           // g == 1: lane 0's helper in the partial rounds' S-box (pow7_pair)
 
     __device__ __forceinline__ void init(int g) {
         active = g < 12;
         first = g == 0;
+        second = g == 1;
 #pragma unroll
         for (int k = 0; k < 2 * P2_HALF_FULL_ROUNDS; k++) {
             int round = k < P2_HALF_FULL_ROUNDS ? k : k + P2_PARTIAL_ROUNDS;
@@ -280,13 +283,24 @@ struct Coop {
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) x = external(pow7_sched(add_rc_sched(x, rc_full[k])));
         for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
             u64 rc = c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];  // wave-uniform -> scalar load
-            u64 sx = pow7_sched(add_rc_sched(x, rc));
+            u64 sx = pow7_pair(add_rc_sched(x, rc));
             x = internal(first ? sx : x);
         }
 #pragma unroll
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++)
             x = external(pow7_sched(add_rc_sched(x, rc_full[P2_HALF_FULL_ROUNDS + k])));
         return x;
+    }
+
+    // The ONE S-box of a partial round (element 0) on two lanes of the row's first quad: after the square, lane 0 multiplies on to the cube
+    // while lane 1 squares again, and lane 0 takes the fourth power across the quad — three multiplications deep instead of four (a lone
+    // wave's time is its instruction count). Only lane 0's result means anything; the other lanes' is discarded by the caller.
+    __device__ __forceinline__ u64 pow7_pair(u64 t) const {
+        const u64 t0 = dpp64<QP_BCAST0>(t);            // lanes 0..3 of a quad: lane 0's element
+        const u64 x2 = gl::mul_sched(t0, t0);
+        const u64 b = second ? x2 : t0;
+        const u64 y = gl::mul_sched(x2, b);            // lane 0: x^3, lane 1: x^4
+        return gl::mul_sched(y, dpp64<QP_SWAP1>(y));   // lane 0: x^3 * x^4
     }
 };
 
