@@ -318,7 +318,7 @@ __device__ __forceinline__ u64 coop_flattened(const Coop& co, u64 x, u32 g, Put&
     }
     for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
         const u64 rc = c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];
-        const u64 sx = pow7_sched(add_rc_sched(x, rc));
+        const u64 sx = co.pow7_pair(add_rc_sched(x, rc));  // (lane 0's value is the S-box output; the other lanes' is not used)
         if (co.first) put(12 * (P2_HALF_FULL_ROUNDS + 1) + k, gl::canon(sx));
         x = co.internal(co.first ? sx : x);
     }
