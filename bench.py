@@ -381,7 +381,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=0,
                     help="independent memory queues per GPU per step (0 = size the batch to the free HBM)")
     ap.add_argument("--queries", type=int, default=CAPACITY)
-    ap.add_argument("--ring", type=int, default=16, help="trace buffers (1.25 GB each) in the output ring, all pipelines together")
+    ap.add_argument("--ring", type=int, default=20, help="trace buffers (1.25 GB each) in the output ring, all pipelines together (20: a synthesis phase of 10 instances per launch is as long as the other pipeline's builder phase, DESIGN.md 3.2)")
     ap.add_argument("--pipelines", type=int, default=int(os.environ.get("ZKW_PIPELINES", "2")),
                     help="the step's blocks are split into P sub-batches that run as independent pipelines (own context, HIP "
                          "stream, host thread), started a fraction of a chain pass apart so that one pipeline's synthesis "
@@ -781,7 +781,8 @@ def main():
                        "pipelines_per_gpu": P, "pipeline_stagger_ms": 0.0 if phased else stagger_s * 1e3,
                        "pipeline_schedule": ("lockstep: a phase = one pipeline's builders next to the other's synthesis, the next phase starts when both are done" if phased else
                                              "synthesis phases take turns" if P > 1 and synth_turns else "free-running" if P > 1 else "one pipeline"), "gather": gather_backend,
-                       "trace_slots": "ring of 16 slots; a slot that already holds this layout keeps its zero padding rows (layout tag): "
+                       "ring_slots": args.ring, "instances_per_synthesis_launch": per_launch_inst,
+                       "trace_slots": f"ring of {args.ring} slots; a slot that already holds this layout keeps every cell that is zero in all of its traces (layout tag): "
                                       "write_bytes_per_circuit of trace_bytes_per_circuit are written per synthesis",
                        "write_bytes_per_circuit": native.circuit_fill_bytes(8, CAPACITY, n_rows)[0],
                        "trace_bytes_per_circuit": native.circuit_fill_bytes(8, CAPACITY, n_rows)[1]},

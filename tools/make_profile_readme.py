@@ -28,11 +28,11 @@ seq = last_json("bench_sequential.json")
 pmc_run = last_json("bench_pmc_WRITE_SIZE.json")
 W, F = pmc("bench_pmc_WRITE_SIZE.summary.csv"), pmc("bench_pmc_FETCH_SIZE.summary.csv")
 
-# algorithmic bytes per launch at the benchmarked batch (sequential form: one builder launch over all blocks, 16 instances
-# per synthesis launch), DESIGN.md 3.1
+# algorithmic bytes per launch at the benchmarked batch (sequential form: one builder launch over all blocks, `instances_per_synthesis_launch`
+# instances per synthesis launch), DESIGN.md 3.1
 B = pmc_run["config"]["blocks_per_gpu"]
 n = pmc_run["config"]["queries_per_block"]
-stride, n_rows, inst = (n + 63) // 64 * 64, 1 << 20, 16
+stride, n_rows, inst = (n + 63) // 64 * 64, 1 << 20, pmc_run["config"].get("instances_per_synthesis_launch", 16)
 # cells a region's fill stores per cycle in a slot that already holds the layout (all but the first launches of a ring slot): the slots
 # its row type uses + its lookup cells, from the generated spec; the cells that are zero in every trace are not rewritten
 _spec = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "zkw_ram_circuit_spec.h")).read()
