@@ -57,6 +57,22 @@ def test_queue_chain_forms_agree(ctx, oracle, form):
             assert np.array_equal(got[lo:lo + ln], oracle.queue_push_chain_full(enc[lo:lo + ln], tins[k])), k
 
 
+def test_queue_chain_thousands_of_queues_take_the_quad_form(ctx, oracle):
+    """4 100 short queues in one call: dev_chains picks the quad form by itself (>= 4 096 chains) and launches it as 4-wave workgroups,
+    one per CU (launch_chain_q4: the path of the throughput benchmark); the last workgroup is partly empty. Every queue against the oracle."""
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 4, 4100).tolist()
+    lens[17], lens[4099] = 9, 3
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    enc = synthetic.random_field_elements(277, (int(offsets[-1]), 8))
+    tins = synthetic.random_field_elements(278, (len(lens), 12))
+    got = ctx.queue_push_chain_full_batch(enc, offsets, tins)
+    for k in list(range(0, 4100, 37)) + [17, 4095, 4096, 4099]:
+        lo, ln = int(offsets[k]), lens[k]
+        if ln:
+            assert np.array_equal(got[lo:lo + ln], oracle.queue_push_chain_full(enc[lo:lo + ln], tins[k])), k
+
+
 @pytest.mark.parametrize("form", [1, 2, 4])
 def test_ram_builder_chain_forms(ctx, oracle, form):
     """the RAM builder's chain path (queries encoded on the fly, the sorted side through the permutation, capacity words +
