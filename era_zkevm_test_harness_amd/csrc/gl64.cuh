@@ -201,6 +201,22 @@ GL_HD u64 pow(u64 a, u64 e) {
     return r;
 }
 
-GL_HD u64 inv(u64 a) { return pow(a, P - 2); }
+// a^(p - 2) by an addition chain: p - 2 = (2^31 - 1) * 2^33 + (2^32 - 1), and with e_k = a^(2^k - 1): e_2k = e_k^(2^k) * e_k,
+// e_(k+1) = e_k^2 * a — 64 squarings + 9 multiplications (square-and-multiply over the 63 one-bits of p - 2: 64 + 63)
+GL_HD u64 sqr_n(u64 a, int n) {
+    for (int i = 0; i < n; i++) a = sqr(a);
+    return a;
+}
+GL_HD u64 inv(u64 a) {
+    const u64 e2 = mul(sqr(a), a);
+    const u64 e3 = mul(sqr(e2), a);
+    const u64 e6 = mul(sqr_n(e3, 3), e3);
+    const u64 e12 = mul(sqr_n(e6, 6), e6);
+    const u64 e24 = mul(sqr_n(e12, 12), e12);
+    const u64 e30 = mul(sqr_n(e24, 6), e6);
+    const u64 e31 = mul(sqr(e30), a);
+    const u64 e32 = mul(sqr(e31), a);
+    return mul(sqr_n(e31, 33), e32);
+}
 
 }  // namespace gl
