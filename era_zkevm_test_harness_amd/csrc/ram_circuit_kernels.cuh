@@ -457,46 +457,69 @@ static __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __res
 // dozen dependent permutations (ram_boundary_block below) — dispatched first and at raised priority so that the row-D blocks' work hides
 // it (it reads the last cycle's row C, an earlier kernel; nothing of row D); then n_tiles blocks of 256 cycles per trace.
 __device__ __forceinline__ void ram_boundary_block(const SynthJob& job, u32 capacity, size_t n_rows);
+constexpr int RC_D_TILES = 4;  // tiles of 256 cycles per row-D block
 static __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__ jobs, u32 n_jobs, u32 n_tiles, u32 capacity, size_t n_rows) {
     if (blockIdx.x < n_jobs) {
         __builtin_amdgcn_s_setprio(3);
         ram_boundary_block(jobs[blockIdx.x], capacity, n_rows);
         return;
     }
+    // a row-D block covers RC_D_TILES consecutive tiles of 256 cycles, a lane one cycle of each: the row's one expensive witness is the inverse of
+    // the queue length, and the lane's RC_D_TILES inverses come from ONE field inversion (Montgomery's trick: 3 (K - 1) multiplications more)
     const SynthJob& job = jobs[(blockIdx.x - n_jobs) / n_tiles];
-    const u32 i = ((blockIdx.x - n_jobs) % n_tiles) * blockDim.x + threadIdx.x;
+    const u32 i0 = ((blockIdx.x - n_jobs) % n_tiles) * (RC_D_TILES * 256) + threadIdx.x;
     const size_t rs = RC_REGION_STRIDE(capacity);
-    if (i >= capacity) {
-        if (i < rs && !job.tail_clean) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_D * rs + i);
-        return;
-    }
     u64* trace = job.trace;
     const zkw_ram_instance* in = job.inst;
-    const size_t m = in->num_items, row = (size_t)RC_ROW_D * rs + i;
-    const size_t rPU = (size_t)RC_ROW_PU * rs + i, rPS = (size_t)RC_ROW_PS * rs + i;
+    const size_t m = in->num_items;
     const RegsIn ri = regs_in(in);
-    const bool can_pop = i < m;
-    const u64 p_len = (u64)ri.len - (i < m ? i : m);
-    const u64 w_len = inv_or_zero(p_len), z_len = p_len == 0;
-    TR(RC_D_P_len_u, row) = p_len; TR(RC_D_w_lu, row) = w_len; TR(RC_D_z_lu, row) = z_len;
-    TR(RC_D_P_len_s, row) = p_len; TR(RC_D_w_ls, row) = w_len; TR(RC_D_z_ls, row) = z_len;
-    TR(RC_D_can_pop, row) = can_pop ? 1 : 0;
-    TR(RC_D_len_u, row) = p_len - (can_pop ? 1 : 0); TR(RC_D_len_s, row) = p_len - (can_pop ? 1 : 0);
-    // The Poseidon2 rows (written earlier on this stream by k_ram_fill_poseidon) hold the queue tails: the output of
-    // a popped cycle IS the tail after that item. The head entering cycle i is the output of the last popped cycle
-    // before it (the FSM input for i = 0).
-    const size_t p = i - 1 < m ? i - 1 : m - 1, rPUp = (size_t)RC_ROW_PU * rs + p, rPSp = (size_t)RC_ROW_PS * rs + p;
+    u64 len[RC_D_TILES], pre[RC_D_TILES], w[RC_D_TILES];
+    u64 acc = 1;
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
-        const u64 uo = TR(RC_PU_uo0 + k, rPU);
-        const u64 so = TR(RC_PS_so0 + k, rPS);
-        const u64 a = i == 0 ? ri.uh[k] : TR(RC_PU_uo0 + k, rPUp), b = i == 0 ? ri.sh[k] : TR(RC_PS_so0 + k, rPSp);
-        const int o = 3 * k;
-        TR(RC_D_uo0 + o, row) = uo; TR(RC_D_P_uh0 + o, row) = a; TR(RC_D_uh0 + o, row) = can_pop ? uo : a;
-        TR(RC_D_so0 + o, row) = so; TR(RC_D_P_sh0 + o, row) = b; TR(RC_D_sh0 + o, row) = can_pop ? so : b;
+    for (int k = 0; k < RC_D_TILES; k++) {
+        const u32 i = i0 + 256 * k;
+        len[k] = (u64)ri.len - (i < m ? i : m);
+        pre[k] = acc;                                  // product of the lengths before this one (zero lengths count as 1)
+        acc = gl::mul(acc, len[k] ? len[k] : 1);
     }
-    constexpr int ND = ROW_SLOTS[RC_ROW_D];
-    if (!job.tail_clean) for (int col = ND; col < RC_G + RC_L; col++) TR(col, row) = 0;
+    acc = gl::inv(acc);
+#pragma unroll
+    for (int k = RC_D_TILES - 1; k >= 0; k--) {
+        w[k] = len[k] ? gl::canon(gl::mul(acc, pre[k])) : 0;
+        acc = gl::mul(acc, len[k] ? len[k] : 1);
+    }
+#pragma unroll
+    for (int k = 0; k < RC_D_TILES; k++) {
+        const u32 i = i0 + 256 * k;
+        if (i >= capacity) {
+            if (i < rs && !job.tail_clean) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_D * rs + i);
+            continue;
+        }
+        const size_t row = (size_t)RC_ROW_D * rs + i;
+        const size_t rPU = (size_t)RC_ROW_PU * rs + i, rPS = (size_t)RC_ROW_PS * rs + i;
+        const bool can_pop = i < m;
+        const u64 p_len = len[k];
+        const u64 w_len = w[k], z_len = p_len == 0;
+        TR(RC_D_P_len_u, row) = p_len; TR(RC_D_w_lu, row) = w_len; TR(RC_D_z_lu, row) = z_len;
+        TR(RC_D_P_len_s, row) = p_len; TR(RC_D_w_ls, row) = w_len; TR(RC_D_z_ls, row) = z_len;
+        TR(RC_D_can_pop, row) = can_pop ? 1 : 0;
+        TR(RC_D_len_u, row) = p_len - (can_pop ? 1 : 0); TR(RC_D_len_s, row) = p_len - (can_pop ? 1 : 0);
+        // The Poseidon2 rows (written earlier on this stream by k_ram_fill_poseidon) hold the queue tails: the output of
+        // a popped cycle IS the tail after that item. The head entering cycle i is the output of the last popped cycle
+        // before it (the FSM input for i = 0).
+        const size_t p = i - 1 < m ? i - 1 : m - 1, rPUp = (size_t)RC_ROW_PU * rs + p, rPSp = (size_t)RC_ROW_PS * rs + p;
+#pragma unroll
+        for (int e = 0; e < 12; e++) {
+            const u64 uo = TR(RC_PU_uo0 + e, rPU);
+            const u64 so = TR(RC_PS_so0 + e, rPS);
+            const u64 a = i == 0 ? ri.uh[e] : TR(RC_PU_uo0 + e, rPUp), b = i == 0 ? ri.sh[e] : TR(RC_PS_so0 + e, rPSp);
+            const int o = 3 * e;
+            TR(RC_D_uo0 + o, row) = uo; TR(RC_D_P_uh0 + o, row) = a; TR(RC_D_uh0 + o, row) = can_pop ? uo : a;
+            TR(RC_D_so0 + o, row) = so; TR(RC_D_P_sh0 + o, row) = b; TR(RC_D_sh0 + o, row) = can_pop ? so : b;
+        }
+        constexpr int ND = ROW_SLOTS[RC_ROW_D];
+        if (!job.tail_clean) for (int col = ND; col < RC_G + RC_L; col++) TR(col, row) = 0;
+    }
 }
 
 // the zero padding from the first boundary row down (all general + lookup columns) and the multiplicity column.

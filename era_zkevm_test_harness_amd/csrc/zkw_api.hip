@@ -1509,7 +1509,8 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     ZKW_TRY(launch_check("k_ram_fill_B"));
     { Prof _p(ctx, "k_ram_fill_C"); hipLaunchKernelGGL(k_ram_fill_C, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_C"));
-    { Prof _p(ctx, "k_ram_fill_D"); hipLaunchKernelGGL(k_ram_fill_D, dim3(nj * (n_tiles + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, n_tiles, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_D"); const unsigned d_tiles = (unsigned)((rstride + RC_D_TILES * 256 - 1) / (RC_D_TILES * 256));  // row D: RC_D_TILES tiles per block (they share one inversion per lane)
+      hipLaunchKernelGGL(k_ram_fill_D, dim3(nj * (d_tiles + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, d_tiles, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_D"));
     { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(nj * ((RC_G + RC_L + 1) * TAIL_CHUNKS)), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_tail"));
