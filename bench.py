@@ -373,6 +373,72 @@ def full_block_cpu(blk, threads):
                       "oracle's tree), %d instances synthesized on %d threads" % (len(jobs), threads)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks of this same command line (one process per GPU,
+    torch.distributed.run with a 127.0.0.1 rendezvous on a free port), let rank 0 print the JSON line on the inherited stdout,
+    return the job's exit code. Fails loudly when the node has fewer than N GPUs: N ranks on fewer devices would be a different
+    measurement (one process per GPU)."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    if not args.launcher_self_test:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} but this node has {have} GPU(s): refusing to run {n} ranks on fewer devices", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_self_test(args):
+    """The N-rank plumbing of this file without a GPU (tests/test_bench_launcher.py): rendezvous from the torchrun variables over
+    gloo, barrier + max-over-ranks timing, the per-instance closed-form records (176 B each, deterministic in rank and index)
+    gathered to rank 0 in rank order through torch.distributed AND through libzkw's zkw_gather_closed_form_inputs over its TCP
+    transport (the RCCL branch's code path minus the transport). No circuit is built: the line says so and carries no rate."""
+    rank, _local_rank, world = parallel.init_from_env(backend="gloo")
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    inst_local, words = 5, 22
+    rec = (np.arange(inst_local * words, dtype=np.uint64).reshape(inst_local, words) + np.uint64(1000 * rank)) * np.uint64(0x9E3779B97F4A7C15)
+    counts = [inst_local] * world
+    comm = native.Comm.tcp(None, "127.0.0.1", int(os.environ["MASTER_PORT"]) + 1, rank, world, 30000) if world > 1 else None
+    recv = np.zeros((inst_local * world, words), np.uint64) if rank == 0 else None
+    parallel.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = parallel.gather_records(torch.from_numpy(rec.view(np.uint8).reshape(inst_local, -1).copy()), counts, dst=0)
+        if comm is not None:
+            cnt = np.array(counts, np.uint64)
+            native._check(native.load().zkw_gather_closed_form_inputs(comm.handle, rec.ctypes.data, cnt.ctypes.data, words * 8, 0,
+                                                                      recv.ctypes.data if rank == 0 else None))
+            comm.synchronize()
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, "cpu")
+    if rank == 0:
+        exp = np.concatenate([(np.arange(inst_local * words, dtype=np.uint64).reshape(inst_local, words) + np.uint64(1000 * r)) * np.uint64(0x9E3779B97F4A7C15)
+                              for r in range(world)])
+        got = out.numpy().reshape(-1).view(np.uint64).reshape(-1, words)
+        ok = bool(np.array_equal(got, exp)) and (comm is None or bool(np.array_equal(recv, exp)))
+        print(json.dumps({"metric": "LAUNCHER SELF-TEST (no circuit work, not a measurement)", "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "records_gathered": int(got.shape[0]),
+                          "records_match": ok, "config": {"workload": "none", "gather": "torch.distributed (gloo) + libzkw zkw_gather_closed_form_inputs (TCP)"}}),
+              flush=True)
+    if comm is not None:
+        comm.destroy()
+    parallel.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -393,10 +459,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hash-circuits", action="store_true", help="skip the synthesis-rate leg of the netlist circuits")
     ap.add_argument("--no-full-block", action="store_true", help="skip the full-block wall-time leg")
+    ap.add_argument("--launcher-self-test", action="store_true",
+                    help="CPU only, no circuit work: the N ranks exchange synthetic closed-form records over gloo and over the C ABI's "
+                         "TCP transport and rank 0 prints a line marked as a self-test (tests/test_bench_launcher.py)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))  # `python bench.py --gpus N` on its own: one process per GPU, this process only waits for them
+    if args.launcher_self_test:
+        return launcher_self_test(args)
+
     rank, local_rank, world = parallel.init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: start the ranks with torchrun --nproc-per-node {args.gpus}, or let bench.py do it (unset WORLD_SIZE)"
+    assert torch.cuda.device_count() > local_rank, f"rank {rank}: no GPU {local_rank} (torch sees {torch.cuda.device_count()})"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     n = args.queries
@@ -604,7 +679,9 @@ def main():
     gathered = run_steps(args.steps, stagger_s)
     torch.cuda.synchronize()
     parallel.barrier()
-    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    dt_rank = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt_rank, dev)
+    dt_ranks = parallel.all_ranks(dt_rank, dev)
     timed_spans = [[s_[0]] + [round((x - t0) * 1e3, 1) for x in s_[1:]] for s_ in sorted(pass_spans, key=lambda s_: s_[1])]
     prof = {}
     for c in ctxs:  # kernel time per name, summed over the pipelines (HIP events on each pipeline's own stream)
@@ -767,6 +844,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "per_rank_circuits_per_s": [n_inst_local * args.steps / d_ for d_ in dt_ranks],  # each rank's own clock over the same timed region
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -84,6 +84,16 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def all_ranks(value: float, device):
+    """every rank's value, in rank order (e.g. the per-rank wall time of the timed region)"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def min_over_ranks(value: int, device) -> int:
     """Agree on a common integer (the smallest proposal), e.g. the batch size every rank can hold."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -1,0 +1,262 @@
+"""BASELINE shapes against the ORACLE (not against the device's own checker): every synthesized circuit type at the reference's
+capacity (geometry_config.rs:5-20) in a 2^20-row trace (base_layer/mod.rs:17 — TRACE_LEN_LOG_2_FOR_CALCULATION... the size hint of
+every base-layer circuit), one FULL and one RAGGED instance each, through the C ABI and compared with the oracle's trace cell for
+cell; the builders' outputs at the same sizes (instance records, chains, grand products, public inputs) byte for byte.
+
+  type  circuit                       capacity
+   8    RAMPermutation                136 714      (the configuration bench.py's headline is quoted on)
+   2    CodeDecommittmentsSorter      117 500
+   4    LogDemuxer                     58 750
+   9    StorageSorter                  46 921
+  11/12 Events / L1Messages sorter     31 287
+   3    CodeDecommitter                 2 845
+   6    Sha256RoundFunction             2 206
+  13    L1MessagesHasher                  774
+   5    Keccak256RoundFunction            293
+  10    StorageApplication                 33
+   7    ECRecover                           7
+
+The oracle needs 2-10 s per 2^20-row instance on one core; the whole file runs in a few minutes."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+N_ROWS = 1 << 20
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from era_zkevm_test_harness_amd import native
+
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def _same(got, exp, what):
+    if got.shape != exp.shape:
+        raise AssertionError(f"{what}: shape {got.shape} vs {exp.shape}")
+    if not np.array_equal(got, exp):
+        bad = np.argwhere(got != exp)
+        raise AssertionError(f"{what}: {len(bad)} cells differ, first (col, row) = {bad[:6].tolist()}")
+
+
+def _geometry(native, ct, capacity):
+    assert int(native.circuit_geometry(ct)["capacity"]) == capacity
+
+
+def test_ram_permutation_136714(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    capacity = 136714
+    _geometry(nv, 8, capacity)
+    q = synthetic.ram_trace(capacity + 20000, seed=11)
+    w = ctx.compute_ram_circuit_snapshots(q, capacity, 0)
+    o = oracle.ram_build_instances(q, capacity, 0)
+    assert w.num_instances == 2 and o["instances"].size == 2
+    # a10 at the BASELINE size: the builder's outputs
+    assert w.get(nv.RAM_INSTANCES).tobytes() == o["instances"].tobytes()
+    _same(w.get(nv.RAM_SORTED_QUERIES), o["sorted_q"], "sorted queries")
+    _same(w.get(nv.RAM_UNSORTED_TAILS), o["unsorted_tails"], "unsorted tails")
+    _same(w.get(nv.RAM_SORTED_TAILS), o["sorted_tails"], "sorted tails")
+    _same(w.get(nv.RAM_LHS_Z).reshape(2, -1), o["lhs_z"], "lhs z")
+    _same(w.get(nv.RAM_RHS_Z).reshape(2, -1), o["rhs_z"], "rhs z")
+    _same(w.get(nv.RAM_PUBLIC_INPUTS), oracle.ram_public_inputs(o["instances"])[1], "public inputs")
+    t = nv.Trace(ctx, N_ROWS, 2)
+    ctx.synthesize_ram(w, t)
+    for idx in range(2):  # 0: full, 1: ragged (20 000 of 136 714)
+        _same(t.get(idx), oracle.ram_synthesize(o, idx, capacity, N_ROWS), f"RAM instance {idx}")
+    t.free()
+    w.free()
+
+
+def test_decommit_sorter_117500(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    capacity = 117500
+    _geometry(nv, 2, capacity)
+    q = synthetic.decommit_trace(capacity + 5000, 3000, seed=9)
+    w = ctx.compute_decommitts_sorter_circuit_snapshots(q, capacity)
+    o = oracle.decommit_sorter_build(q, capacity)
+    assert w.get(nv.DEC_INSTANCES).tobytes() == o["instances"].tobytes() and o["instances"].size == 2
+    _same(w.get(nv.DEC_SORTED_TAILS), o["sorted_tails"], "sorted tails")
+    _same(w.get(nv.DEC_DEDUP_TAILS), o["dedup_tails"], "dedup tails")
+    _same(w.get(nv.DEC_LHS_Z).reshape(2, -1), o["lhs_z"], "lhs z")
+    _same(w.get(nv.DEC_PUBLIC_INPUTS), oracle.decommit_sorter_public_inputs(o["instances"])[1], "public inputs")
+    t = nv.Trace(ctx, N_ROWS, 2)
+    ctx.synthesize_decommit_sorter(w, t)
+    for idx in range(2):
+        _same(t.get(idx), oracle.decommit_sorter_synthesize(o, idx, capacity, N_ROWS), f"decommit sorter instance {idx}")
+    t.free()
+    w.free()
+
+
+def test_log_demuxer_58750(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    capacity = 58750
+    _geometry(nv, 4, capacity)
+    q = synthetic.mixed_log_queue(70000, seed=9)
+    w = ctx.compute_logs_demux(q, capacity)
+    o = oracle.log_demux_build(q, capacity)
+    assert w.get(nv.DMX_INSTANCES).tobytes() == o["instances"].tobytes() and o["instances"].size == 2
+    _same(w.get(nv.DMX_IN_NEW_TAILS), o["in_new_tails"], "input tails")
+    _same(w.get(nv.DMX_OUT_NEW_TAILS), o["out_new_tails"], "output tails")
+    _same(w.get(nv.DMX_PUBLIC_INPUTS), oracle.log_demux_public_inputs(o["instances"])[1], "public inputs")
+    t = nv.Trace(ctx, N_ROWS, 2, n_cols=nv.LD_COLS)
+    ctx.synthesize_log_demux(w, t)
+    for idx in range(2):
+        _same(t.get(idx), oracle.log_demux_synthesize(o, idx, capacity, N_ROWS), f"log demuxer instance {idx}")
+    t.free()
+    w.free()
+
+
+def test_storage_sorter_46921(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    capacity = 46921
+    _geometry(nv, 9, capacity)
+    q = synthetic.storage_trace(60000, 9000, seed=9)
+    w = ctx.compute_storage_dedup_and_sort(q, capacity)
+    o = oracle.storage_sorter_build(q, capacity)
+    assert w.get(nv.STO_INSTANCES).tobytes() == o["instances"].tobytes() and o["instances"].size == 2
+    _same(w.get(nv.STO_SORTED_NEW_TAILS), o["sorted_new_tails"], "sorted tails")
+    _same(w.get(nv.STO_RESULT_NEW_TAILS), o["result_new_tails"], "result tails")
+    _same(w.get(nv.STO_LHS_Z).reshape(2, -1), o["lhs_z"], "lhs z")
+    _same(w.get(nv.STO_PUBLIC_INPUTS), oracle.storage_sorter_public_inputs(o["instances"])[1], "public inputs")
+    t = nv.Trace(ctx, N_ROWS, 2)
+    ctx.synthesize_storage_sorter(w, t)
+    for idx in range(2):
+        _same(t.get(idx), oracle.storage_sorter_synthesize(o, idx, capacity, N_ROWS), f"storage sorter instance {idx}")
+    t.free()
+    w.free()
+
+
+def test_events_sorter_31287(ctx, oracle):
+    """types 11 and 12 are one circuit body over two queues (events_sort_dedup.rs); the same capacity"""
+    from era_zkevm_test_harness_amd import native as nv
+
+    capacity = 31287
+    _geometry(nv, 11, capacity)
+    _geometry(nv, 12, capacity)
+    q = synthetic.events_trace(30000, 0.2, seed=9)
+    assert capacity < q.size < 2 * capacity
+    w = ctx.compute_events_dedup_and_sort(q, capacity)
+    o = oracle.events_sorter_build(q, capacity)
+    assert w.get(nv.EVT_INSTANCES).tobytes() == o["instances"].tobytes() and o["instances"].size == 2
+    _same(w.get(nv.EVT_PUBLIC_INPUTS), oracle.events_sorter_public_inputs(o["instances"])[1], "public inputs")
+    t = nv.Trace(ctx, N_ROWS, 2)
+    ctx.synthesize_events_sorter(w, t)
+    for idx in range(2):
+        _same(t.get(idx)[:139], oracle.events_sorter_synthesize(o, idx, capacity, N_ROWS), f"events sorter instance {idx}")
+    t.free()
+    w.free()
+
+
+@pytest.mark.parametrize("ct,kind,n_req,max_rounds", [(5, 0, 300, 2), (6, 1, 1700, 3)])
+def test_keccak_293_and_sha256_2206(ctx, oracle, ct, kind, n_req, max_rounds):
+    from era_zkevm_test_harness_amd import native as nv
+
+    cols, synth, osynth = {5: (nv.KC_COLS, ctx.synthesize_keccak_round_function, oracle.keccak_round_synthesize),
+                           6: (nv.SC_COLS, ctx.synthesize_sha256_round_function, oracle.sha256_round_synthesize)}[ct]
+    capacity = {5: 293, 6: 2206}[ct]
+    _geometry(nv, ct, capacity)
+    req, mq = synthetic.precompile_trace(kind, n_req, seed=11, max_rounds=max_rounds)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    mem_in = np.zeros(1, nv.QUEUE_STATE12)
+    w = ctx._precompile(kind, req, tails, mq, capacity, mem_in)
+    o = oracle.precompile_build(kind, req, tails, mq, capacity, mem_in)
+    ni = w.num_instances
+    assert ni == o["instances"].size and ni >= 2
+    assert w.get(nv.PRC_INSTANCES).tobytes() == o["instances"].tobytes()
+    last = int(o["instances"][ni - 1]["num_items"]) if "num_items" in o["instances"].dtype.names else None
+    t = nv.Trace(ctx, N_ROWS, 2, n_cols=cols)
+    synth(w, t, 0, 1, 0)
+    synth(w, t, ni - 1, 1, 1)
+    _same(t.get(0), osynth(o, 0, capacity, N_ROWS), f"type {ct} instance 0 (full)")
+    _same(t.get(1), osynth(o, ni - 1, capacity, N_ROWS), f"type {ct} instance {ni - 1} (last, {last} items)")
+    t.free()
+    w.free()
+
+
+def test_code_decommitter_2845(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    capacity = 2845
+    _geometry(nv, 3, capacity)
+    b = synthetic.block_after_vm(seed=2)
+    dec = ctx.compute_decommitts_sorter_circuit_snapshots(b["decommit_queries"], 5)
+    dq, dt = dec.get(nv.DEC_DEDUP_QUERIES), dec.get(nv.DEC_DEDUP_TAILS)
+    codes = [b["bytecodes"][h.tobytes()] for h in dq["hash"]]
+    woff = np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]).astype(np.uint64)
+    mem_in = np.zeros(1, nv.QUEUE_STATE12)
+    w = ctx.compute_decommitter_circuit_snapshots(dq, dt, np.concatenate(codes), woff, capacity, mem_in)
+    o = oracle.decommitter_build(dq, dt, np.concatenate(codes), woff, capacity, mem_in)
+    ni = w.num_instances
+    assert ni == o["instances"].size
+    assert w.get(nv.DCM_INSTANCES).tobytes() == o["instances"].tobytes()
+    t = nv.Trace(ctx, N_ROWS, 1, n_cols=nv.DC_COLS)
+    for idx in sorted({0, ni - 1}):  # the block's bytecodes: the last instance is the ragged one
+        ctx.synthesize_code_decommitter(w, t, idx, 1, 0)
+        _same(t.get(0), oracle.code_decommitter_synthesize(o, idx, capacity, N_ROWS), f"code decommitter instance {idx}")
+    t.free()
+    w.free()
+    dec.free()
+
+
+def test_l1_messages_hasher_774(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    capacity = 774
+    _geometry(nv, 13, capacity)
+    src = synthetic.mixed_log_queue(4 * capacity + 100, seed=5)
+    queues = [src[:capacity], src[capacity:capacity + 301]]  # a full queue and a ragged one
+    states = np.zeros(2, nv.QUEUE_STATE4)
+    t = nv.Trace(ctx, N_ROWS, 2, n_cols=nv.LH_COLS)
+    rec, pi = ctx.synthesize_linear_hasher_batch(queues, states, capacity, t, 0)
+    for k, q in enumerate(queues):
+        exp, orec, opi = oracle.linear_hasher_synthesize(q, states[k:k + 1], capacity, N_ROWS)
+        _same(t.get(k), exp, f"L1 messages hasher queue {k}")
+        assert rec[k:k + 1].tobytes() == orec.tobytes() and np.array_equal(pi[k], opi)
+    t.free()
+
+
+def test_storage_application_33(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+    from sap_case import storage_application_case
+
+    capacity = 33
+    _geometry(nv, 10, capacity)
+    q, tails, tree, idx, paths = storage_application_case(oracle, 60, seed=77)
+    w = ctx.decompose_into_storage_application_witnesses(q, tails, idx, paths, tree.root, tree.next_enumeration_index, capacity)
+    o = oracle.storage_application_build(tree, q, tails, capacity)
+    ni = w.num_instances
+    assert ni == o["instances"].size and ni >= 2
+    assert w.get(nv.SAP_INSTANCES).tobytes() == o["instances"].tobytes()
+    t = nv.Trace(ctx, N_ROWS, 1, n_cols=nv.SA_COLS)
+    for i in (0, ni - 1):
+        ctx.synthesize_storage_application(w, t, i, 1, 0)
+        _same(t.get(0), oracle.storage_application_synthesize(o, q, i, capacity, N_ROWS), f"storage application instance {i}")
+    t.free()
+    w.free()
+
+
+def test_ecrecover_7(ctx, oracle):
+    from era_zkevm_test_harness_amd import native as nv
+
+    capacity = 7
+    _geometry(nv, 7, capacity)
+    req, mq = synthetic.precompile_trace(2, 10, seed=11)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    mem_in = np.zeros(1, nv.QUEUE_STATE12)
+    w = ctx._precompile(2, req, tails, mq, capacity, mem_in)
+    o = oracle.precompile_build(2, req, tails, mq, capacity, mem_in)
+    assert w.num_instances == 2 and w.get(nv.PRC_INSTANCES).tobytes() == o["instances"].tobytes()
+    t = nv.Trace(ctx, N_ROWS, 2, n_cols=nv.EK_COLS)
+    ctx.synthesize_ecrecover(w, t, 0, 2, 0)
+    for i in range(2):  # 7 requests, then 3
+        _same(t.get(i), oracle.ecrecover_synthesize(o, i, capacity, N_ROWS), f"ECRecover instance {i}")
+    t.free()
+    w.free()
