@@ -129,6 +129,48 @@ __device__ __forceinline__ u64 mul_sched(u64 a, u64 b) {
 }
 #endif
 
+#if defined(__HIPCC__)
+// a * b mod p priced by the MEASURED issue cost of each instruction class on gfx950 (tools/ubench_valu_ceiling.hip, profiles/r05:
+// per wave-instruction and SIMD a 32-bit VALU op costs 2.2 cycles, v_mad_u64_u32 4.1, an add / subtract that writes or reads a carry 4.2,
+// a 64-bit add or compare ~4) rather than by instruction count. For kernels that keep a SIMD full (the trace fills: 4-8 waves per SIMD)
+// cycles are what a multiplication costs; the compiler's form is 21 instructions = 68.7 cycles (six v_mov to pair a half with a zero
+// register, four 64-bit adds, two 64-bit compares), this one 14 instructions = ~51:
+//   four independent 32 x 32 products, the cross terms added inside the multiplier (carry cm, worth 2^96 = -1), three adds-with-carry
+//   for the exact words w1..w3, w2 * (2^32 - 1) + (w1:w0) in one more v_mad_u64_u32 (carry c1, worth 2^64 = EPS), w3 and cm taken off
+//   by one borrow chain (borrow b1, worth -EPS), and ONE 64-bit add of (c1 - b1) * EPS built by three v_cndmask from the two flags
+//   (both set: the wrap and the borrow cancel). Carries live in SGPR pairs, the flag algebra runs on the scalar unit.
+// One asm statement per instruction: the compiler still schedules and interleaves independent multiplications. Weak in, weak out.
+__device__ __forceinline__ u64 mul_cyc(u64 a, u64 b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return 0;  // device-only
+#else
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p, q, h, x, cm, c1, cw, cw2, bw, b1f, dead;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(dead) : "v"(a0), "v"(b0));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(q), "=s"(dead) : "v"(a0), "v"(b1));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(h), "=s"(dead) : "v"(a1), "v"(b1));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(q), "=s"(cm) : "v"(a1), "v"(b0), "v"(q));
+    const u32 p0 = (u32)p, p1 = (u32)(p >> 32), q0 = (u32)q, q1 = (u32)(q >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
+    u32 w1, w2, w3, y0, y1, dlo, dhi;
+    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(w1), "=s"(cw) : "v"(p1), "v"(q0));
+    asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(w2), "=s"(cw2) : "v"(h0), "v"(q1), "s"(cw));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(w3), "=s"(dead) : "v"(h1), "s"(cw2));  // h1 <= 2^32 - 2: no carry out
+    const u64 lo = ((u64)w1 << 32) | p0;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(x), "=s"(c1) : "v"(w2), "v"(lo));
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+    asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(y0), "=s"(bw) : "v"(x0), "v"(w3), "s"(cm));
+    asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(y1), "=s"(b1f) : "v"(x1), "s"(bw));
+    const u64 mp = c1 & ~b1f, mn = b1f & ~c1;  // +EPS / -EPS (scalar unit)
+    asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(dhi) : "s"(mn));
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(dlo) : "s"(mn));
+    asm("v_cndmask_b32_e64 %0, %1, -1, %2" : "=v"(dlo) : "v"(dlo), "s"(mp));
+    u64 d = ((u64)dhi << 32) | dlo;  // -EPS = (1, 0xFFFFFFFF) mod 2^64
+    asm("" : "+v"(d));               // one register pair, one v_lshl_add_u64 (the optimizer otherwise adds the halves one by one)
+    return (((u64)y1 << 32) | y0) + d;
+#endif
+}
+#endif
+
 GL_HD u64 mul(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GL_MUL_SCHEDULED_EVERYWHERE)
     // measured (bench.py): the hand-scheduled form only pays where a wave runs ONE dependent S-box chain (the row-form

@@ -1378,6 +1378,8 @@ extern "C" int zkw_trace_create_with_columns(zkw_ctx* ctx, size_t n_rows, size_t
     t->n_rows = n_rows;
     t->n_cols = n_cols;
     t->n_slots = n_slots;
+    t->slot_tag.reset(new std::atomic<uint64_t>[n_slots]);
+    for (size_t k = 0; k < n_slots; k++) t->slot_tag[k].store(0, std::memory_order_relaxed);
     hipError_t e = dev_malloc((void**)&t->data, t->slot_elems() * n_slots * sizeof(u64));
     if (e != hipSuccess) {
         delete t;
@@ -1462,6 +1464,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     ZKW_TRY(ctx->scratch_t<u32>("synth_hist", n_instances * 256, &d_hist));
     ZKW_TRY(ctx->scratch_t<u32>("synth_nd", n_instances * n_tiles, &d_nd));
     HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    SlotClaims claims(t);
     std::vector<SynthJob> jobs(n_instances);
     size_t b = b_first;
     for (size_t k = 0; k < n_instances; k++) {
@@ -1483,8 +1486,9 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
         {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
             const uint64_t tag = ((uint64_t)ZKW_CIRCUIT_RAM_PERMUTATION << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
             const size_t slot = (first_slot + k) % t->n_slots;
-            j.tail_clean = t->tag_of(slot) == tag;
-            j.trace = t->slot_for_write(slot, tag);
+            bool clean = false;
+            j.trace = claims.claim(slot, tag, &clean);
+            j.tail_clean = clean;
         }
         j.hist = d_hist + 256 * k;
         j.nd_tiles = d_nd + (size_t)n_tiles * k;
@@ -1514,7 +1518,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     ZKW_TRY(launch_check("k_ram_fill_D"));
     { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(nj * ((RC_G + RC_L + 1) * TAIL_CHUNKS)), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_tail"));
-    return ctx->sync_if_host();
+    return claims.commit_if(ctx->sync_if_host());
 }
 
 

@@ -271,16 +271,43 @@ struct zkw_trace {
     size_t n_rows = 0, n_cols = RC_COLS, n_slots = 0;
     u64* data = nullptr;
     size_t slot_elems() const { return n_cols * n_rows; }
-    // What a slot held last, for the netlist circuits (which then only rewrite the cells their fill writes: everything else is
-    // still zero from the same layout's previous tenant). 0 = unknown; every other writer and zkw_trace_device_ptr reset it.
-    mutable std::vector<uint64_t> slot_tag;
+    // What a slot held last (0 = unknown): a synthesis into a slot whose tag is its own layout only rewrites the cells its fill writes,
+    // everything else is still zero from the same layout's previous tenant. Every other writer and zkw_trace_device_ptr reset the tag.
+    // Sized at creation (zkw_trace_create_with_columns), relaxed atomics: a consumer thread may take a slot's pointer while a
+    // producer synthesizes into another slot of the same trace.
+    std::unique_ptr<std::atomic<uint64_t>[]> slot_tag;
     u64* slot_for_write(size_t slot, uint64_t tag) const {
-        if (slot_tag.size() != n_slots) slot_tag.assign(n_slots, 0);
-        slot_tag[slot] = tag;
+        slot_tag[slot].store(tag, std::memory_order_relaxed);
         return data + slot * slot_elems();
     }
-    uint64_t tag_of(size_t slot) const { return slot_tag.size() == n_slots ? slot_tag[slot] : 0; }
+    uint64_t tag_of(size_t slot) const { return slot_tag[slot].load(std::memory_order_relaxed); }
 };
+
+// The slots one synthesis call writes. claim() reads a slot's tag and RESETS it; commit() — after the call's last launch has been
+// enqueued — writes the new tags. A call that fails in between (upload, scratch, a launch) leaves its slots tagged "unknown", so the
+// next synthesis into them is a cold one (the tag used to be set while the job list was built, and a failed call left a
+// slot of the previous tenant's data under the new layout's tag).
+struct SlotClaims {
+    struct Claim { const zkw_trace* t; size_t slot; uint64_t tag; };
+    const zkw_trace* t;
+    std::vector<Claim> pending;
+    explicit SlotClaims(const zkw_trace* tr = nullptr) : t(tr) {}
+    u64* claim(size_t slot, uint64_t tag, bool* clean) { return claim(t, slot, tag, clean); }
+    u64* claim(const zkw_trace* tr, size_t slot, uint64_t tag, bool* clean) {
+        *clean = tr->tag_of(slot) == tag;
+        pending.push_back(Claim{tr, slot, tag});
+        return tr->slot_for_write(slot, 0);
+    }
+    void commit() {
+        for (auto& p : pending) p.t->slot_for_write(p.slot, p.tag);
+        pending.clear();
+    }
+    int commit_if(int rc) {
+        if (rc == ZKW_OK) commit();
+        return rc;
+    }
+};
+
 
 // device-level steps (zkw_api.hip): every builder's queue chains, challenges and grand products go through these
 int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc);

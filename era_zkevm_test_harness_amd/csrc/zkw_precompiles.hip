@@ -1033,6 +1033,7 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
     ZKW_TRY(ctx->scratch_t<u32>("nl_hist", ni * hist_n, &d_hist));
     std::vector<NlPrepJob> prep(ni);
     std::vector<NlJob> jobs(ni);
+    SlotClaims claims;  // the slots' layout tags are written after the last launch: a failed call leaves them "unknown" (zkw_ctx.h)
     const size_t bnd = NL_BOUNDARY_ROW(&S, capacity);
     for (size_t k = 0; k < ni; k++) {
         prep[k] = NlPrepJob{nullptr, inst[k].first_round, inst[k].n_active, d_hdr + k * hdr_n, d_free + k * free_n, d_state + k * state_n, S.state};
@@ -1040,8 +1041,8 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
         // everything else is zero. A slot whose previous tenant was the same layout (circuit, capacity, rows) already has those
         // zeros: nothing to clear (the multiplicity column is rewritten over the tables' rows). Otherwise: clear it.
         const uint64_t tag = ((uint64_t)circuit_type << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
-        const bool clean = inst[k].t->tag_of(inst[k].slot) == tag;
-        u64* tr = inst[k].t->slot_for_write(inst[k].slot, tag);
+        bool clean = false;
+        u64* tr = claims.claim(inst[k].t, inst[k].slot, tag, &clean);
         jobs[k] = NlJob{prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before, inst[k].public_input, tr, d_keys + k * keys_n, d_hist + k * hist_n};
         if (!clean) {
             HIP_TRY(hipMemsetAsync(tr, 0, (size_t)S.g * n_rows * sizeof(u64), ctx->stream));  // general-purpose columns
@@ -1063,7 +1064,7 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
         default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;  // 13 and 10: 3 x 26
     }
     { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
-    return launch_check("k_nl_finish");
+    return claims.commit_if(launch_check("k_nl_finish"));
 }
 
 // ... from the block's round records (`sha_like`: zkw_sha256_round_record, else zkw_keccak_round_record)

@@ -883,6 +883,7 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
     u32* d_hist = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("ds_hist", n_instances * 256, &d_hist));
     HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    SlotClaims claims(t);
     std::vector<DsSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         DsSynthJob& j = jobs[k];
@@ -900,8 +901,9 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
         {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
             const uint64_t tag = ((uint64_t)2 << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
             const size_t slot = (first_slot + k) % t->n_slots;
-            j.tail_clean = t->tag_of(slot) == tag;
-            j.trace = t->slot_for_write(slot, tag);
+            bool clean = false;
+            j.trace = claims.claim(slot, tag, &clean);
+            j.tail_clean = clean;
         }
         j.hist = d_hist + 256 * k;
         j.public_input = w->public_inputs + 4 * (first_instance + k);
@@ -928,7 +930,7 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
     ZKW_TRY(launch_check("k_ds_fill_row<D>"));
     { Prof _p(ctx, "k_ds_fill_tail"); hipLaunchKernelGGL(k_ds_fill_tail, dim3(nj * ((DS_G + DS_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_tail"));
-    return ctx->sync_if_host();
+    return claims.commit_if(ctx->sync_if_host());
 }
 
 // ------------------------------------------------------------------------------------------------ events / L1 messages sorter synthesis (a21, types 11 / 12)
@@ -955,6 +957,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
     const size_t m = n ? n : 1;
     u64 *u_enc = w->enc_all, *s_enc = w->enc_all + 20 * m;
     u64 *u_new = w->tails_all + 4 * m, *s_new = w->tails_all + 12 * m, *r_new = w->tails_all + 16 * m;
+    SlotClaims claims(t);
     std::vector<EsSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         EsSynthJob& j = jobs[k];
@@ -973,8 +976,9 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
         {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
             const uint64_t tag = ((uint64_t)11 << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
             const size_t slot = (first_slot + k) % t->n_slots;
-            j.tail_clean = t->tag_of(slot) == tag;
-            j.trace = t->slot_for_write(slot, tag);
+            bool clean = false;
+            j.trace = claims.claim(slot, tag, &clean);
+            j.tail_clean = clean;
         }
         j.hist = d_hist + 256 * k;
     }
@@ -996,7 +1000,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
 #undef ES_LAUNCH_ROW
     { Prof _p(ctx, "k_es_fill_tail"); hipLaunchKernelGGL(k_es_fill_tail, dim3(nj * ((ES_G + ES_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_es_fill_tail"));
-    return ctx->sync_if_host();
+    return claims.commit_if(ctx->sync_if_host());
 }
 
 extern "C" int zkw_events_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
@@ -1026,6 +1030,7 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
     u32* d_hist = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("ld_hist", n_instances * 256, &d_hist));
     HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    SlotClaims claims(t);
     std::vector<LdSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         LdSynthJob& j = jobs[k];
@@ -1041,8 +1046,9 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
         {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
             const uint64_t tag = ((uint64_t)4 << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
             const size_t slot = (first_slot + k) % t->n_slots;
-            j.tail_clean = t->tag_of(slot) == tag;
-            j.trace = t->slot_for_write(slot, tag);
+            bool clean = false;
+            j.trace = claims.claim(slot, tag, &clean);
+            j.tail_clean = clean;
         }
         j.hist = d_hist + 256 * k;
     }
@@ -1061,7 +1067,7 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
 #undef LD_LAUNCH_ROW
     { Prof _p(ctx, "k_ld_fill_tail"); hipLaunchKernelGGL(k_ld_fill_tail, dim3(nj * ((LD_G + LD_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ld_fill_tail"));
-    return ctx->sync_if_host();
+    return claims.commit_if(ctx->sync_if_host());
 }
 
 extern "C" int zkw_log_demux_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,
@@ -1090,6 +1096,7 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
     u32* d_hist = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("ss_hist", n_instances * 256, &d_hist));
     HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    SlotClaims claims(t);
     std::vector<SsSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
         SsSynthJob& j = jobs[k];
@@ -1105,8 +1112,9 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
         {   // a slot whose previous tenant was this layout keeps its zero padding rows (zkw_ctx.h slot_tag; every other writer resets the tag)
             const uint64_t tag = ((uint64_t)9 << 56) ^ ((uint64_t)capacity << 24) ^ (uint64_t)n_rows ^ 0x5A00000000000000ull;
             const size_t slot = (first_slot + k) % t->n_slots;
-            j.tail_clean = t->tag_of(slot) == tag;
-            j.trace = t->slot_for_write(slot, tag);
+            bool clean = false;
+            j.trace = claims.claim(slot, tag, &clean);
+            j.tail_clean = clean;
         }
         j.hist = d_hist + 256 * k;
     }
@@ -1128,7 +1136,7 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
 #undef SS_LAUNCH_ROW
     { Prof _p(ctx, "k_ss_fill_tail"); hipLaunchKernelGGL(k_ss_fill_tail, dim3(nj * ((SS_G + SS_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ss_fill_tail"));
-    return ctx->sync_if_host();
+    return claims.commit_if(ctx->sync_if_host());
 }
 
 extern "C" int zkw_storage_sorter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity,

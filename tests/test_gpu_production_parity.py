@@ -105,7 +105,7 @@ def test_log_demuxer_58750(ctx, oracle):
     _same(w.get(nv.DMX_IN_NEW_TAILS), o["in_new_tails"], "input tails")
     _same(w.get(nv.DMX_OUT_NEW_TAILS), o["out_new_tails"], "output tails")
     _same(w.get(nv.DMX_PUBLIC_INPUTS), oracle.log_demux_public_inputs(o["instances"])[1], "public inputs")
-    t = nv.Trace(ctx, N_ROWS, 2, n_cols=nv.LD_COLS)
+    t = nv.Trace(ctx, N_ROWS, 2, n_cols=151)
     ctx.synthesize_log_demux(w, t)
     for idx in range(2):
         _same(t.get(idx), oracle.log_demux_synthesize(o, idx, capacity, N_ROWS), f"log demuxer instance {idx}")
