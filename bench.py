@@ -459,6 +459,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hash-circuits", action="store_true", help="skip the synthesis-rate leg of the netlist circuits")
     ap.add_argument("--no-full-block", action="store_true", help="skip the full-block wall-time leg")
+    ap.add_argument("--no-validate", action="store_true", help="skip the oracle comparison of one ring slot per pipeline after the timed region")
     ap.add_argument("--launcher-self-test", action="store_true",
                     help="CPU only, no circuit work: the N ranks exchange synthetic closed-form records over gloo and over the C ABI's "
                          "TCP transport and rank 0 prints a line marked as a self-test (tests/test_bench_launcher.py)")
@@ -740,6 +741,33 @@ def main():
         except Exception as e:  # noqa: BLE001 — a box without enough pinned memory: report, do not fail the bench
             h2d = {"error": repr(e)}
 
+    # ---- the timed region's own output against the oracle: one ring slot of every pipeline, as the last pass left it, is
+    # compared cell for cell with the CPU restatement's trace of the same block (untimed; the oracle is the checker here, never the product)
+    validation = None
+    if rank == 0 and not args.no_validate:
+        from oracle import pyoracle
+
+        pyoracle.build()
+        checked = []
+        last_first = (n_inst_p - 1) // ring_p * ring_p  # the last synthesis launch of a pass wrote instances last_first.. into slots 0..
+        for p in range(P):
+            slot = (n_inst_p - 1 - last_first) if p == 0 else 0  # pipeline 0: the pass's very last instance; the others: the launch's first
+            inst = last_first + slot
+            blk = p * Bp + inst // inst_per_block
+            streams[p].synchronize()
+            qh = q[blk].cpu().numpy().reshape(-1).view(native.MEM_QUERY)
+            o = pyoracle.ram_build_instances(qh, CAPACITY, 0)
+            exp = pyoracle.ram_synthesize(o, inst % inst_per_block, CAPACITY, n_rows)
+            got = rings[p].get(slot)
+            n_diff = int(np.count_nonzero(got != exp))
+            pi_ok = bool(np.array_equal(pis[p * n_inst_p + inst].cpu().numpy().view(np.uint64), pyoracle.ram_public_inputs(o["instances"])[1][inst % inst_per_block]))
+            checked.append({"pipeline": p, "block": int(blk), "instance": int(inst), "ring_slot": int(slot), "cells": int(got.size), "cells_differing": n_diff, "public_input_equal": pi_ok})
+            del got, exp
+        validation = {"checker": "oracle/liboracle.so (orc_ram_build_instances + orc_ram_synthesize)", "slots": checked,
+                      "ok": all(c["cells_differing"] == 0 and c["public_input_equal"] for c in checked)}
+        if not validation["ok"]:
+            print(f"[bench] VALIDATION FAILED: {checked}", file=sys.stderr)
+
     if rank == 0:
         assert gathered.shape[0] == n_inst_local * world
         circuits = n_inst_local * world * args.steps
@@ -792,20 +820,28 @@ def main():
             return k["traffic_bytes_per_launch"] * scale
 
         def valu_roofline():
-            """The bound that matters for this step: VALU issue. 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave-instruction
-            = 6.14e11 wave-instructions/s. Instruction counts per unit of work: SQ_INSTS_VALU of the committed PMC pass
-            (profiles/rNN/valu.json: rocprofv3 --pmc SQ_INSTS_VALU at the benchmarked batch) when there is one, else the ISA counts of
-            DESIGN.md 7.4 (507 wave-instructions per queue item in the quad chain, 228 per lane-permutation of k_ram_fill_poseidon)."""
-            peak = 256 * 4 * 2.4e9 / 4
+            """The bound that matters for this step: VALU issue, against a MEASURED ceiling. tools/ubench_valu_ceiling.hip
+            (profiles/rNN/valu_ceiling.json) gives the chip's wave-instructions/s per instruction class at 1-8 waves per SIMD: full-rate ops
+            (32-bit add / sub / logic / mov) 1.1e12, half-rate ops (v_mad_u64_u32, shifts, carries, 64-bit ops, DPP, v_cndmask on SGPR masks)
+            6.0e11 — and the rate of the two instruction MIXES the Goldilocks kernels are made of, run with no memory traffic at the best
+            occupancy: Poseidon2 one state per quad (the chain kernels' code) and one state per lane (the fills' code), 6.7-6.8e11. A kernel's
+            ceiling is the rate of its own mix; the step's floor is the sum of its kernels' instruction volumes over their ceilings.
+            Instruction counts per unit of work: SQ_INSTS_VALU of the committed PMC pass (profiles/rNN/valu.json, rocprofv3 --pmc
+            SQ_INSTS_VALU at the benchmarked batch) when there is one, else the ISA counts of DESIGN.md."""
+            cpath = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "valu_ceiling.json") for r_ in ("r06", "r05")) if os.path.exists(p_)), None)
+            if cpath is None:
+                return None
+            ceil_ = json.load(open(cpath))["summary"]
+            mix = ceil_["goldilocks_mix_wave_insts_per_s"]
             per_unit = {"k_chain_full_q4": 507.0, "k_chain_full": 1480.0, "k_ram_fill_poseidon": 2 * 228.0 * n}  # per item / per instance
-            src = "ISA instruction counts (DESIGN.md 7.4)"
+            src = "ISA instruction counts (DESIGN.md)"
             path = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "valu.json") for r_ in ("r06", "r05", "r04")) if os.path.exists(p_)), None)
             if path is not None:
                 v = json.load(open(path))
                 per_unit.update({k.replace("zkw::", ""): x["wave_insts_per_unit"] for k, x in v["kernels"].items()})
                 src = "SQ_INSTS_VALU, " + os.path.relpath(path, ROOT)
             units = {"k_chain_full_q4": 2 * items * P, "k_chain_full": 2 * items * P}  # queue items per step (all pipelines)
-            per_kernel, total = {}, 0.0
+            per_kernel, total, floor_s = {}, 0.0, 0.0
             for k, (kms, kcnt) in prof.items():
                 base_name = k.split("<")[0]
                 if base_name not in per_unit or not kcnt:
@@ -814,14 +850,26 @@ def main():
                 insts = per_unit[base_name] * u
                 if base_name == "k_ram_fill_poseidon" and "<" in k:
                     insts /= 2  # two template instances share the per-instance count
+                ceiling = mix["p2_quad_form"] if base_name.startswith("k_chain") else mix["p2_lane_form"]
                 total += insts
+                floor_s += insts / ceiling
                 a = insts / (kms / args.steps * 1e-3)
-                per_kernel[k] = {"wave_insts_per_step": insts, "ms_per_step": kms / args.steps, "achieved": a, "frac": a / peak}
-            floor_ms = total / peak * 1e3
-            return {"bound": "valu", "peak": peak, "unit": "wave-instructions/s", "source": src, "per_kernel": per_kernel,
+                per_kernel[k] = {"wave_insts_per_step": insts, "ms_per_step": kms / args.steps, "achieved": a, "ceiling": ceiling, "frac": a / ceiling,
+                                 "mix": "Poseidon2, one state per quad" if base_name.startswith("k_chain") else "Poseidon2 / field arithmetic, one state per lane"}
+                if base_name.startswith("k_chain"):
+                    # the chain launch runs ONE wave per SIMD by design (a serial chain per quad): what that occupancy allows for this code
+                    waves = -(-2 * items // 16)
+                    alone = ceil_["one_wave_per_simd"]["p2_quad_form_perm_per_s"] * min(1.0, waves / 1024.0)
+                    per_kernel[k]["perm_per_s_inside_launches"] = 2 * items * kcnt / (kms * 1e-3)
+                    per_kernel[k]["perm_per_s_one_wave_per_simd_alone"] = alone
+                    per_kernel[k]["frac_of_one_wave_per_simd"] = per_kernel[k]["perm_per_s_inside_launches"] / alone
+            floor_ms = floor_s * 1e3
+            return {"bound": "valu", "peak_measured": {"full_rate": ceil_["full_rate_wave_insts_per_s"], "half_rate": ceil_["half_rate_wave_insts_per_s"], "goldilocks_mix": mix},
+                    "peak": mix["p2_lane_form"], "unit": "wave-instructions/s", "ceiling_source": os.path.relpath(cpath, ROOT), "source": src, "per_kernel": per_kernel,
                     "step": {"wave_insts": total, "floor_ms": floor_ms, "ms_per_step": dt / args.steps * 1e3, "frac": floor_ms / (dt / args.steps * 1e3),
-                             "note": "kernels with a counted instruction volume only (the chains and the Poseidon2 rows: ~90 % of the step's VALU work); "
-                                     "frac = the step's VALU-issue floor over its wall time"}}
+                             "note": "kernels with a counted instruction volume only (the chains, the Poseidon2 rows and rows A-D: ~95 % of the step's VALU work); "
+                                     "frac = the step's VALU-issue floor at the measured ceiling of each kernel's instruction mix over its wall time. With P pipelines a "
+                                     "kernel overlaps the other pipeline's kernels, so a per-kernel frac is its share of a SIMD it does not have to itself"}}
 
         name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / max(cnt, 1)
@@ -882,6 +930,7 @@ def main():
             # host clock of every pipeline pass of the timed region, ms since its start: [pipeline, start, builders done, synthesis turn taken,
             # synthesis done, end] (P = 1: [pipeline, start, end]) - where the step's wall time goes between the two pipelines
             "pass_spans_ms": timed_spans,
+            "validation": validation,
         }
         if full_block is not None:
             out["full_block"] = full_block
