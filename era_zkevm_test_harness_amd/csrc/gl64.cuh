@@ -42,6 +42,22 @@ GL_HD u64 add(u64 a, u64 b) {
 #endif
 }
 
+// a + c (mod p) for a CANONICAL c (a round constant): the sum wraps at most once, and after a wrap it is below c < p, so adding EPS cannot
+// wrap again — four instructions instead of the nine of the general add. Weak a in, weak out.
+GL_HD u64 add_canon(u64 a, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long s;
+    const bool w = __builtin_uaddll_overflow(a, c, &s);
+    u32 f = w ? 1u : 0u;
+    u64 r, dead;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(dead) : "v"(f), "v"((u64)s));  // + EPS after a wrap
+    return r;
+#else
+    u64 s = a + c;
+    return s < a ? s + EPS : s;
+#endif
+}
+
 // a - b (mod p)
 GL_HD u64 sub(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -171,7 +187,11 @@ __device__ __forceinline__ u64 mul_cyc(u64 a, u64 b) {
 }
 #endif
 
-GL_HD u64 mul(u64 a, u64 b) {
+// a * b mod p, the compiler-scheduled form: four chained v_mad_u64_u32 + reduce128, 21 instructions that the compiler interleaves with
+// whatever else the lane has to do. For LATENCY-bound code — the serial queue chains, one wave per SIMD (p2::Coop4 / Coop2): with the
+// 14-instruction form below k_chain_full_q4 was 11 % slower (4.91 -> 5.45 s per step, profiles/r05/README.md), its carry chains through
+// SGPR pairs stall a lone wave. Weak in, weak out.
+GL_HD u64 mul_lat(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GL_MUL_SCHEDULED_EVERYWHERE)
     // measured (bench.py): the hand-scheduled form only pays where a wave runs ONE dependent S-box chain (the row-form
     // queue chains, p2::Coop: 9.99 -> 7.44 us per permutation with the other hand-scheduled pieces). Kernels with several
@@ -196,6 +216,17 @@ GL_HD u64 mul(u64 a, u64 b) {
 #endif
 }
 
+// a * b mod p. On the device: the 14-instruction form (mul_cyc) — every kernel that keeps its SIMDs full is bound by VALU issue cycles,
+// and nearly every instruction of a multiplication is a half-rate one (profiles/r05/valu_ceiling.json), so fewer instructions is the
+// lever: k_ram_fill_poseidon 2.75 -> 2.31 s per step, row C 0.49 -> 0.31 s. GL_MUL_COMPILER_FORM restores the old default (A/B builds).
+GL_HD u64 mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_MUL_COMPILER_FORM)
+    return mul_cyc(a, b);
+#else
+    return mul_lat(a, b);
+#endif
+}
+
 GL_HD u64 sqr(u64 a) { return mul(a, a); }
 
 // a*b + c
@@ -207,6 +238,12 @@ GL_HD u64 pow7(u64 x) {
     u64 x3 = mul(x2, x);
     u64 x4 = sqr(x2);
     return mul(x3, x4);
+}
+GL_HD u64 pow7_lat(u64 x) {  // for the latency-bound chain forms (see mul_lat)
+    u64 x2 = mul_lat(x, x);
+    u64 x3 = mul_lat(x2, x);
+    u64 x4 = mul_lat(x2, x2);
+    return mul_lat(x3, x4);
 }
 
 // x * 2^s for 0 <= s < 32

@@ -12,6 +12,7 @@
 // memset. Multiplicities are a pass of their own over 16-bit keys the fill leaves behind (k_nl_hist: a table's bins in LDS).
 #pragma once
 #include "../../include/zkw_netlist.h"
+#include "netlist_eval.cuh"
 #include "../../include/zkw_sha256_circuit_spec.h"
 #include "../../include/zkw_code_decommitter_circuit_spec.h"
 #include "../../include/zkw_keccak_circuit_spec.h"

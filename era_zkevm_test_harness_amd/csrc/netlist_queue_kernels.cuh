@@ -304,7 +304,7 @@ static __global__ __launch_bounds__(64) void k_nlq_check(const NlDev* __restrict
             pos += 12;
         }
         for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
-            s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
+            s[0] = gl::pow7(gl::add_canon(s[0], p2::rc_at(12 * r)));
             ok &= nlq_cell_at(S, trace, n_rows, capacity, c, pr0, pos++) == gl::canon(s[0]);
             p2::internal(s);
         }

@@ -76,8 +76,68 @@ GL_HD void m4w(const u64 x[4], Wide t[4]) {
     t[0] = wadd(t3, t5); t[1] = t5; t[2] = wadd(t2, t4); t[3] = t4;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- the linear layers of the lane form on the device, written against the measured issue cost of gfx950 (profiles/r05/valu_ceiling.json:
+// nearly every integer instruction that is not a plain 32-bit add / logic op costs the same ~4 cycles, so the count decides). Both layers are
+// sums of a few field elements with small coefficients, so they are done on the two 32-bit WORD PLANES of the state separately — a plane's
+// sums stay below 2^40 in a 64-bit accumulator, with no carry between the planes to track — and every sum is one instruction:
+// v_mad_u64_u32 (32-bit word x small coefficient + 64-bit accumulator) or v_lshl_add_u64 ((acc << k) + acc). An output L + 2^32 H is then
+// brought back to 64 bits with 2^64 = EPS in five instructions (wp_reduce). Against the Wide (lo64 + hi32) form above — three instructions
+// per addition, a 64-bit compare for every carry: external layer ~250 -> ~160 instructions, internal layer ~190 -> ~110.
+__device__ __forceinline__ u64 mad_acc(u32 a, u32 k, u64 acc) {  // a * k + acc, no overflow by construction
+    u64 r, dead;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(dead) : "v"(a), "s"(k), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ u64 mad_acc1(u32 a, u64 acc) {  // a + acc
+    u64 r, dead;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(r), "=s"(dead) : "v"(a), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ u64 mad_acc2(u32 a, u64 acc) {  // 2 a + acc
+    u64 r, dead;
+    asm("v_mad_u64_u32 %0, %1, %2, 2, %3" : "=v"(r), "=s"(dead) : "v"(a), "v"(acc));
+    return r;
+}
+// L + 2^32 H mod p for L, H < 2^63 (weak out): the high word of L takes the low word of H (carry c, worth 2^64 = EPS), the high word of H and c
+// go in as (Hhi + c) * EPS through the multiplier (carry c2; after that wrap the value is below 2^63, so adding EPS once more cannot wrap)
+__device__ __forceinline__ u64 wp_reduce(u64 L, u64 H) {
+    const u32 l0 = (u32)L, l1 = (u32)(L >> 32), h0 = (u32)H, h1 = (u32)(H >> 32);
+    u32 n1, k, f;
+    u64 c, c2, dead, r;
+    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(n1), "=s"(c) : "v"(l1), "v"(h0));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(k), "=s"(dead) : "v"(h1), "s"(c));
+    const u64 x = ((u64)n1 << 32) | l0;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(c2) : "v"(k), "v"(x));
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(f) : "s"(c2));
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(dead) : "v"(f), "v"(r));  // + EPS after a wrap
+    return r;
+}
+// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] of one word plane of a block by the Poseidon2 addition chain: 8 instructions (+ one zero extension each for t0, t1)
+__device__ __forceinline__ void m4_plane(u32 a0, u32 a1, u32 a2, u32 a3, u64 y[4]) {
+    const u64 t0 = mad_acc1(a0, (u64)a1), t1 = mad_acc1(a2, (u64)a3);
+    const u64 t2 = mad_acc2(a1, t1), t3 = mad_acc2(a3, t0);
+    const u64 t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;  // v_lshl_add_u64
+    y[0] = t3 + t5; y[1] = t5; y[2] = t2 + t4; y[3] = t4;
+}
+#endif
+
 // external layer circ(2*M4, M4, M4): every output is < 64 * 2^64 before its single reduction
 GL_HD void external(u64 s[12]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(P2_LINEAR_WIDE)
+    u64 L[12], H[12];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        m4_plane((u32)s[4 * b], (u32)s[4 * b + 1], (u32)s[4 * b + 2], (u32)s[4 * b + 3], L + 4 * b);
+        m4_plane((u32)(s[4 * b] >> 32), (u32)(s[4 * b + 1] >> 32), (u32)(s[4 * b + 2] >> 32), (u32)(s[4 * b + 3] >> 32), H + 4 * b);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // a plane's entries are < 16 * 2^32, the sums below < 64 * 2^32
+        const u64 cl = L[i] + L[4 + i] + L[8 + i], ch = H[i] + H[4 + i] + H[8 + i];
+#pragma unroll
+        for (int b = 0; b < 3; b++) s[4 * b + i] = wp_reduce(L[4 * b + i] + cl, H[4 * b + i] + ch);
+    }
+#else
     Wide t[12];
     m4w(s, t); m4w(s + 4, t + 4); m4w(s + 8, t + 8);
 #pragma unroll
@@ -85,37 +145,69 @@ GL_HD void external(u64 s[12]) {
         Wide col = wadd(wadd(t[i], t[4 + i]), t[8 + i]);
         s[i] = wreduce(wadd(t[i], col)); s[4 + i] = wreduce(wadd(t[4 + i], col)); s[8 + i] = wreduce(wadd(t[8 + i], col));
     }
+#endif
 }
 
 // internal layer: y_i = x_i * 2^shift_i + sum_j x_j
 GL_HD void internal(u64 s[12]) {
+    constexpr u32 SH[12] = P2_INTERNAL_DIAG_SHIFTS_INIT;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(P2_LINEAR_WIDE)
+    u64 sl = (u64)(u32)s[0], sh = s[0] >> 32;  // the planes' sums: < 12 * 2^32
+#pragma unroll
+    for (int i = 1; i < 12; i++) { sl = mad_acc1((u32)s[i], sl); sh = mad_acc1((u32)(s[i] >> 32), sh); }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {  // word * 2^shift + the plane's sum: < 2^47
+        const u64 l = SH[i] ? mad_acc((u32)s[i], 1u << SH[i], sl) : mad_acc1((u32)s[i], sl);
+        const u64 h = SH[i] ? mad_acc((u32)(s[i] >> 32), 1u << SH[i], sh) : mad_acc1((u32)(s[i] >> 32), sh);
+        s[i] = wp_reduce(l, h);
+    }
+#else
     Wide sum = wide(s[0]);
 #pragma unroll
     for (int i = 1; i < 12; i++) sum = wadd(sum, wide(s[i]));
-    constexpr u32 SH[12] = P2_INTERNAL_DIAG_SHIFTS_INIT;
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = wreduce(wadd(SH[i] ? wshl(wide(s[i]), SH[i]) : wide(s[i]), sum));
+#endif
 }
 
+// LAT: the S-boxes through gl::mul_lat (the compiler-scheduled multiplication) instead of the 14-instruction form. For the few one-lane
+// sponges whose loops stay rolled (commitments, challenges): there the carry flags of the short form's SGPR pairs spill (48 B of scratch
+// per lane, which tests/test_kernel_resources.py forbids), and their time does not matter.
+#ifndef P2_SBOX_GROUP
+#define P2_SBOX_GROUP 3
+#endif
+template <bool LAT = false>
 GL_HD void full_round(u64 s[12], int r) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl::pow7(gl::add(s[i], rc_at(12 * r + i)));
+    for (int i = 0; i < 12; i++) {
+        s[i] = LAT ? gl::pow7_lat(gl::add_canon(s[i], rc_at(12 * r + i))) : gl::pow7(gl::add_canon(s[i], rc_at(12 * r + i)));
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the twelve S-boxes of a round are independent and the scheduler would interleave them all: every multiplication in flight
+        // holds three carry flags in SGPR pairs, twelve of them exhaust the 102 SGPRs, the spills go to VGPRs and the fills drop to 3
+        // waves per SIMD. A scheduling barrier after every P2_SBOX_GROUP S-boxes keeps that many in flight (the waves of a full SIMD
+        // supply the rest of the parallelism).
+        if (!LAT && (i + 1) % P2_SBOX_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
     external(s);
 }
 
+template <bool LAT = false>
 GL_HD void partial_round(u64 s[12], int r) {
-    s[0] = gl::pow7(gl::add(s[0], rc_at(12 * r)));
+    s[0] = LAT ? gl::pow7_lat(gl::add_canon(s[0], rc_at(12 * r))) : gl::pow7(gl::add_canon(s[0], rc_at(12 * r)));
     internal(s);
 }
 
 // weak in, weak out
+template <bool LAT = false>
 GL_HD void permute(u64 s[12]) {
     external(s);
     int r = 0;
-    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) full_round(s, r);
-    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) partial_round(s, r);
-    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) full_round(s, r);
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) full_round<LAT>(s, r);
+    for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) partial_round<LAT>(s, r);
+    for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++, r++) full_round<LAT>(s, r);
 }
+GL_HD void permute_lat(u64 s[12]) { permute<true>(s); }
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------- one state per 16-lane row
@@ -402,7 +494,7 @@ struct Coop4 {
 #pragma unroll
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) x[c] = gl::pow7(gl::add(x[c], rc_full[k][c]));
+            for (int c = 0; c < 3; c++) x[c] = gl::pow7_lat(gl::add_canon(x[c], rc_full[k][c]));
             external(x);
         }
         for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
@@ -412,17 +504,17 @@ struct Coop4 {
             // the gaps the compiler's schedule leaves, and the opaque asm blocks only cost)
             // the round's one S-box on two lanes of the quad, as in the row form (Coop::pow7_pair): lane 0 goes on to the cube while
             // lane 1 squares again — three multiplications per partial round instead of four for the whole wave
-            const u64 t0 = dpp64<QP_BCAST0>(gl::add(x[0], rc));
-            const u64 x2 = gl::mul(t0, t0);
-            const u64 y = gl::mul(x2, second ? x2 : t0);
-            const u64 sx = gl::mul(y, dpp64<QP_SWAP1>(y));
+            const u64 t0 = dpp64<QP_BCAST0>(gl::add_canon(x[0], rc));
+            const u64 x2 = gl::mul_lat(t0, t0);
+            const u64 y = gl::mul_lat(x2, second ? x2 : t0);
+            const u64 sx = gl::mul_lat(y, dpp64<QP_SWAP1>(y));
             x[0] = first ? sx : x[0];
             internal(x);
         }
 #pragma unroll
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) x[c] = gl::pow7(gl::add(x[c], rc_full[P2_HALF_FULL_ROUNDS + k][c]));
+            for (int c = 0; c < 3; c++) x[c] = gl::pow7_lat(gl::add_canon(x[c], rc_full[P2_HALF_FULL_ROUNDS + k][c]));
             external(x);
         }
     }
@@ -496,19 +588,19 @@ struct Coop2 {
 #pragma unroll
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) x[i] = gl::pow7(gl::add(x[i], rc_full[k][i]));
+            for (int i = 0; i < 6; i++) x[i] = gl::pow7_lat(gl::add(x[i], rc_full[k][i]));
             external(x);
         }
         for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
             const u64 rc = c_rc[12 * (P2_HALF_FULL_ROUNDS + k)];
-            const u64 sx = gl::pow7(gl::add(x[0], rc));
+            const u64 sx = gl::pow7_lat(gl::add(x[0], rc));
             x[0] = first ? sx : x[0];
             internal(x);
         }
 #pragma unroll
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) x[i] = gl::pow7(gl::add(x[i], rc_full[P2_HALF_FULL_ROUNDS + k][i]));
+            for (int i = 0; i < 6; i++) x[i] = gl::pow7_lat(gl::add(x[i], rc_full[P2_HALF_FULL_ROUNDS + k][i]));
             external(x);
         }
     }

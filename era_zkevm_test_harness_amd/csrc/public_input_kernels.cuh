@@ -29,11 +29,11 @@ __device__ inline void commit_var_length(const u64* enc, int n, u64 out[4]) {
     int i = 0;
     for (; i + 8 <= n; i += 8) {
         for (int k = 0; k < 8; k++) s[k] = enc[i + k];
-        p2::permute(s);
+        p2::permute_lat(s);  // rolled one-lane sponge: see p2::permute<LAT>
     }
     if (i < n) {
         for (int k = 0; k < 8; k++) s[k] = (i + k < n) ? enc[i + k] : 0;
-        p2::permute(s);
+        p2::permute_lat(s);  // rolled one-lane sponge: see p2::permute<LAT>
     }
     for (int k = 0; k < 4; k++) out[k] = gl::canon(s[k]);
 }

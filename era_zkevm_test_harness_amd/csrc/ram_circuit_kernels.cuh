@@ -112,7 +112,7 @@ __device__ __forceinline__ void fill_flattened_poseidon(u64* trace, size_t n_row
         pos += 12;
     }
     for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
-        s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
+        s[0] = gl::pow7(gl::add_canon(s[0], p2::rc_at(12 * r)));
         TR(pos++, row) = gl::canon(s[0]);
         p2::internal(s);
     }
@@ -782,7 +782,7 @@ static __global__ __launch_bounds__(64) void k_check_rows(const u64* __restrict_
             pos += 12;
         }
         for (int k = 0; k < P2_PARTIAL_ROUNDS; k++, r++) {
-            s[0] = gl::pow7(gl::add(s[0], p2::rc_at(12 * r)));
+            s[0] = gl::pow7(gl::add_canon(s[0], p2::rc_at(12 * r)));
             ok &= gl::canon(s[0]) == CELLV(pos);
             pos++;
             p2::internal(s);

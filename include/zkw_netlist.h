@@ -2,7 +2,7 @@
  * (Sha256RoundFunction 6, CodeDecommitter 3, Keccak256RoundFunction 5, L1MessagesHasher 13) are emitted in. The format and the
  * reference geometry / table sets it reproduces are described in tools/netlist.py; the per-circuit specs are the generated
  * include/zkw_*_circuit_spec.h. Shared by the HIP kernels (csrc/netlist_kernels.cuh), the host side (setup: selectors, copy
- * permutation) and the test oracle (oracle/netlist_circuit.c). Plain C.
+ * permutation) and the test oracle (oracle/netlist_circuit.c): record types and layout macros only, no semantics. Plain C.
  *
  * Trace of an instance with `capacity` cycles, column-major u64[cols][n_rows]:
  *   columns [0, G)                 general-purpose (copy-permutation) columns: step headers, gates, boundary rows
@@ -70,32 +70,8 @@ typedef struct nl_spec {
 #define NL_PI_ROW(spec, capacity) (NL_BOUNDARY_ROW(spec, capacity) + 2 * NL_BND_ROWS(spec))
 #define NL_USED_ROWS(spec, capacity) (NL_PI_ROW(spec, capacity) + 1)
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
-#define NL_HD __host__ __device__ static inline
-#else
-#define NL_HD static inline
-#endif
-
-/* out[0..n_out) of a table for inputs a[0..n_in) (contents of boojum's create_*_table) */
-NL_HD void nl_table_eval(uint32_t fn, uint32_t k, const uint32_t a[3], uint32_t out[3]) {
-    out[0] = out[1] = out[2] = 0;
-    switch (fn) {
-        case NL_FN_XOR8: out[0] = a[0] ^ a[1]; break;
-        case NL_FN_AND8: out[0] = a[0] & a[1]; break;
-        case NL_FN_BYTESPLIT: out[0] = a[0] & ((1u << k) - 1); out[1] = a[0] >> k; break;
-        case NL_FN_TRIXOR4: out[0] = a[0] ^ a[1] ^ a[2]; break;
-        case NL_FN_CH4: out[0] = (a[0] & a[1]) ^ (~a[0] & a[2] & 15u); break;
-        case NL_FN_MAJ4: out[0] = (a[0] & a[1]) ^ (a[0] & a[2]) ^ (a[1] & a[2]); break;
-        case NL_FN_SPLIT4: out[0] = a[0] & ((1u << k) - 1); out[1] = a[0] >> k; out[2] = (out[0] << (4 - k)) | out[1]; break;
-        default: break;
-    }
-}
-/* row of the stacked table (= of the multiplicity column) that a lookup with these inputs hits */
-NL_HD uint32_t nl_table_key(const nl_table *t, const uint32_t a[3]) {
-    uint32_t k = 0;
-    for (uint32_t i = 0; i < t->n_in; i++) k |= a[i] << (t->in_bits * i);
-    return t->offset + k;
-}
+/* What a table computes (boojum's create_*_table contents) is NOT in this header: the library's evaluator is
+ * era_zkevm_test_harness_amd/csrc/netlist_eval.cuh, the test oracle enumerates the tables' rows itself (oracle/netlist_tables.c). */
 
 /* a spec struct from the generated macros of one circuit: NL_DEFINE_SPEC(sc, SC) defines `static const nl_spec sc_spec` */
 #define NL_DEFINE_SPEC(name, P)                                                                                                   \

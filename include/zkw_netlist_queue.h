@@ -109,7 +109,7 @@ static const nlq_desc NLQ_DESC_LINEAR_HASHER = {2, 1, {4, 0}, {
 /* messages whose first byte is absorbed by cycle c: [nlq_lh_first(c), nlq_lh_first(c + 1)) */
 #define NLQ_LH_FIRST(c) (((uint64_t)(c) * 136 + 87) / 88)
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NLQ_HD __host__ __device__ static inline
 #else
 #define NLQ_HD static inline

@@ -8,27 +8,35 @@
  * results — recovered addresses against public secp256k1 / Ethereum vectors (tests/test_oracle_ecrecover_circuit.py).
  *
  * A trace = the EK byte netlist (one Keccak-f per cycle over the public key; oracle/netlist_circuit.c), the queue section (pop, 4
- * reads, 2 writes; oracle/netlist_queue.c) and the EC section, whose item semantics are include/zkw_ecrecover.h (shared with the
- * kernels the way nl_table_eval is; their independent restatement is the generator's Python evaluator).
+ * reads, 2 writes; oracle/netlist_queue.c) and the EC section, evaluated and checked by oracle/ecrecover_eval.c — the oracle's own
+ * code over the spec's FORMAT (include/zkw_ecrecover_layout.h); the library's evaluator (include/zkw_ecrecover.h) is not compiled here.
  */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
 #include "../include/zkw_ecrecover_circuit_spec.h"
 #include "../include/zkw_netlist_queue.h"
-#include "../include/zkw_ecrecover.h"
+#include "../include/zkw_ecrecover_layout.h"
+
+/* oracle/ecrecover_eval.c */
+void orc_ec_build_fixed_own(uint32_t *out);
+uint32_t orc_ec_eval_cycle_own(const ec_spec *S, const uint8_t *in, uint64_t *tape);
+int orc_ec_check_item_own(const ec_spec *S, const uint32_t *w, const uint64_t *trace, size_t n_rows, size_t row, uint32_t inst);
 
 EC_DEFINE_SPEC(ecs);
 static uint32_t *g_fixed = NULL;
 static ec_spec g_spec;
 
+static pthread_once_t g_spec_once = PTHREAD_ONCE_INIT;
+static void spec_init(void) { /* once per process, whichever thread comes first (the FixedBaseMul tables take a moment) */
+    g_fixed = malloc(sizeof(uint32_t) * EC_FIXED_WORDS);
+    orc_ec_build_fixed_own(g_fixed);
+    const ec_spec s = {ecs_types, ecs_runs, ecs_items, ecs_item_index, ecs_cells, ecs_homes, ecs_outs, ecs_rowtab, ecs_globs, ecs_bigs, ecs_in_home, ecs_key_byte, g_fixed};
+    g_spec = s;
+}
 const ec_spec *orc_ec_spec(void) {
-    if (!g_fixed) {
-        g_fixed = malloc(sizeof(uint32_t) * EC_FIXED_WORDS);
-        ec_build_fixed_tables(g_fixed);
-        const ec_spec s = {ecs_types, ecs_runs, ecs_items, ecs_item_index, ecs_cells, ecs_homes, ecs_outs, ecs_rowtab, ecs_globs, ecs_bigs, ecs_in_home, ecs_key_byte, g_fixed};
-        g_spec = s;
-    }
+    pthread_once(&g_spec_once, spec_init);
     return &g_spec;
 }
 
@@ -44,7 +52,7 @@ void orc_ec_geometry(uint32_t capacity, uint64_t out[8]) {
     out[0] = orc_ec_first_row(capacity); out[1] = EC_ROWS_PER_CYCLE; out[2] = orc_ec_used_rows(capacity); out[3] = EC_TAPE_PER_CYCLE;
     out[4] = EC_NUM_TYPES; out[5] = EC_NUM_RUNS;
 }
-uint32_t orc_ec_eval_cycle(const uint8_t in[128], uint64_t *tape) { ec_ws ws; return ec_eval_cycle(orc_ec_spec(), in, tape, &ws); }
+uint32_t orc_ec_eval_cycle(const uint8_t in[128], uint64_t *tape) { return orc_ec_eval_cycle_own(orc_ec_spec(), in, tape); }
 /* (ok, mask, the 64 key bytes as the netlist hashes them) of an evaluated tape */
 void orc_ec_outputs(const uint64_t *tape, uint8_t out[66]) {
     const ec_spec *S = orc_ec_spec();
@@ -81,8 +89,7 @@ int orc_ecrecover_synthesize(const uint8_t *inputs, uint32_t n_active, uint32_t 
     int rc = 0;
     for (uint32_t c = 0; c < capacity && rc == 0; c++) {
         uint64_t *tape = tapes + (size_t)c * EC_TAPE_PER_CYCLE;
-        ec_ws ws;
-        if (ec_eval_cycle(S, inputs + (size_t)c * 128, tape, &ws)) { rc = -2 - (int)c; break; }
+        if (orc_ec_eval_cycle_own(S, inputs + (size_t)c * 128, tape)) { rc = -2 - (int)c; break; }
         uint8_t o[66], dig[32];
         orc_ec_outputs(tape, o);
         uint8_t *f = fr + (size_t)c * EK_FREE_PER_CYCLE;
@@ -144,8 +151,8 @@ uint64_t orc_ec_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, u
                 const size_t seg0 = cyc0 + S->runs[r].row0 + (size_t)j * T->n_rows;
                 const uint32_t *w = S->items + T->item0;
                 for (uint32_t i = 0; i < T->n_items; i++, w += ec_item_words(w)) {
-                    const ec_row_view v = {trace, n_rows, seg0 + ((w[0] >> 4) & 0xFFF)};
-                    if (ec_check_item(S, w, &v, j)) flag(&n, &first, (w[0] & 15) == EC_I_LOOKUP ? 1 : 7, i, v.row);
+                    const size_t irow = seg0 + ((w[0] >> 4) & 0xFFF);
+                    if (orc_ec_check_item_own(S, w, trace, n_rows, irow, j)) flag(&n, &first, (w[0] & 15) == EC_I_LOOKUP ? 1 : 7, i, irow);
                 }
                 uint32_t prun, pinst;
                 ec_prev_segment(S, r, j, &prun, &pinst);

@@ -167,12 +167,12 @@ int orc_nl_synthesize(const nl_spec *sp, uint32_t capacity, const uint8_t *hdr_b
                     const uint32_t col = sp->g + sp->w * (it % sp->r);
                     uint32_t a[3] = {0, 0, 0}, o[3];
                     for (uint32_t i = 0; i < t->n_in; i++) a[i] = REF(op->in[i]);
-                    nl_table_eval(t->fn, t->param, a, o);
+                    orc_nl_lookup(t, a, o);
                     for (uint32_t i = 0; i < t->n_in; i++) TR(col + i, row) = a[i];
                     for (uint32_t i = 0; i < t->n_out; i++) TR(col + t->n_in + i, row) = o[i];
                     if (op->out != 0xFFFF) {
                         for (uint32_t i = 0; i < t->n_out; i++) val[op->out + i] = (uint8_t)o[i];
-                        hist[nl_table_key(t, a)]++;
+                        hist[orc_nl_multiplicity_row(t, a)]++;
                     }
                 } else if (it < NL_ORDER_HINT) {
                     const nl_gate *g = &sp->gates[T->gate0 + (it - NL_ORDER_GATE)];
@@ -283,7 +283,7 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
                     a[i] = (uint32_t)x;
                 }
                 if (ok) {
-                    nl_table_eval(t->fn, t->param, a, o);
+                    orc_nl_lookup(t, a, o);
                     for (uint32_t i = 0; i < t->n_out; i++) ok &= TR(col + t->n_in + i, row) == o[i];
                     for (uint32_t i = t->n_in + t->n_out; i < sp->w; i++) ok &= TR(col + i, row) == 0;
                 }
@@ -299,7 +299,7 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
                     if (a[i] != home(&v, c, s, ref)) copies = 0;
                 }
                 if (!copies) flag(&res, 2, slot, row);
-                hist[nl_table_key(t, a)]++; /* padding lookups hit entry 0 of their table like any other */
+                hist[orc_nl_multiplicity_row(t, a)]++; /* padding lookups hit entry 0 of their table like any other */
             }
             /* gates */
             for (uint32_t gi = 0; gi < T->n_gates; gi++) {

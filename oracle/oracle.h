@@ -243,6 +243,9 @@ int64_t orc_precompile_build_ex(int kind, const zkw_log_query *requests, const u
 /* ---- the netlist circuits ("zkw trace v4", include/zkw_netlist.h), netlist_circuit.c: one fill, one checker, four specs */
 #include "../include/zkw_netlist.h"
 const nl_spec *orc_nl_spec(int circuit_type); /* 6, 3, 5, 13, 10 */
+/* netlist_tables.c: the tables' contents enumerated by the oracle itself (no code shared with the library's evaluator) */
+void orc_nl_lookup(const nl_table *t, const uint32_t a[3], uint32_t out[3]);
+uint32_t orc_nl_multiplicity_row(const nl_table *t, const uint32_t a[3]);
 int orc_nl_synthesize(const nl_spec *sp, uint32_t capacity, const uint8_t *hdr_bits, const uint8_t *free_elems, const uint8_t *state_before,
                       const uint64_t pi[4], size_t n_rows, uint64_t *trace);
 uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);

@@ -735,7 +735,7 @@ def ec_inputs(h, v, r, s):
 
 
 def ec_eval_cycle(inputs):
-    """the value tape of one cycle (include/zkw_ecrecover.h ec_eval_cycle); raises when the inputs have no witness"""
+    """the value tape of one cycle (oracle/ecrecover_eval.c: the oracle's own evaluator); raises when the inputs have no witness"""
     inp = np.ascontiguousarray(inputs, dtype=np.uint8)
     assert inp.size == 128
     tape = np.zeros(ec_geometry(1)["tape_per_cycle"], np.uint64)

@@ -7,12 +7,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "gl64.cuh"
+#include "poseidon2.cuh"
 using gl::u32;
 using gl::u64;
 
 template <int V> __device__ __forceinline__ u64 mulv(u64 a, u64 b);
-template <> __device__ __forceinline__ u64 mulv<0>(u64 a, u64 b) { return gl::mul(a, b); }
+template <> __device__ __forceinline__ u64 mulv<0>(u64 a, u64 b) { return gl::mul_lat(a, b); }
 template <> __device__ __forceinline__ u64 mulv<1>(u64 a, u64 b) { return gl::mul_sched(a, b); }
 template <> __device__ __forceinline__ u64 mulv<2>(u64 a, u64 b) { return gl::mul_cyc(a, b); }
 
@@ -37,8 +37,29 @@ template <int V>
 __global__ void k_check(const u64* a, const u64* b, size_t n, unsigned long long* n_bad, u64* first) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u64 r = gl::canon(mulv<V>(a[i], b[i])), e = gl::canon(gl::mul(a[i], b[i]));
+    u64 r = gl::canon(mulv<V>(a[i], b[i])), e = gl::canon(gl::mul_lat(a[i], b[i]));
     if (r != e && atomicAdd(n_bad, 1ull) == 0) { first[0] = a[i]; first[1] = b[i]; first[2] = r; first[3] = e; }
+}
+
+__global__ void k_perm(u64* st, size_t n) {  // the lane form as the trace fills run it
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s[12];
+    for (int k = 0; k < 12; k++) s[k] = st[12 * i + k];
+    p2::permute(s);
+    for (int k = 0; k < 12; k++) st[12 * i + k] = gl::canon(s[k]);
+}
+__global__ void k_perm_q4(u64* st, size_t n) {  // the quad form (the chain kernels): lane j of a quad holds elements j, 4 + j, 8 + j
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t i = t / 4;
+    int j = (int)(t & 3);
+    p2::Coop4 co;
+    co.init(j);
+    u64 x[3];
+    const bool live = i < n;
+    for (int c = 0; c < 3; c++) x[c] = live ? st[12 * i + 4 * c + j] : 0;
+    co.permute(x);
+    if (live) for (int c = 0; c < 3; c++) st[12 * i + 4 * c + j] = gl::canon(x[c]);
 }
 
 static u64 sm(u64& s) { u64 z = (s += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
@@ -68,6 +89,35 @@ template <int V> int check(const char* name) {
     fprintf(stderr, "\n");
     hipFree(da); hipFree(db); hipFree(df); hipFree(dn);
     return bad != 0;
+}
+
+static int check_perm() {
+    // device forms against the HOST form of the same header (the Wide lo64 + hi32 linear layers, __int128 products)
+    const size_t n = 1 << 14;
+    std::vector<u64> st(12 * n), ref;
+    u64 s = 99;
+    const u64 edge[6] = {0, 1, gl::P - 1, gl::P, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFF00000000ull};
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 12; k++) {
+            u64 v = sm(s);
+            if (i < 64) v = edge[(i + k * (i / 6 + 1)) % 6];           // states of edge values only
+            else if (i % 5 == 0 && k % 3 == 0) v |= 0xFFFFFFFF00000000ull;  // (weak inputs: the layers must take any u64)
+            st[12 * i + k] = v;
+        }
+    ref = st;
+    for (size_t i = 0; i < n; i++) { p2::permute(&ref[12 * i]); for (int k = 0; k < 12; k++) ref[12 * i + k] = gl::canon(ref[12 * i + k]); }
+    int bad_total = 0;
+    for (int form = 0; form < 2; form++) {
+        u64* d; hipMalloc(&d, st.size() * 8); hipMemcpy(d, st.data(), st.size() * 8, hipMemcpyHostToDevice);
+        if (form == 0) hipLaunchKernelGGL(k_perm, dim3((unsigned)(n / 64)), dim3(64), 0, 0, d, n);
+        else hipLaunchKernelGGL(k_perm_q4, dim3((unsigned)(4 * n / 64)), dim3(64), 0, 0, d, n);
+        std::vector<u64> got(st.size()); hipMemcpy(got.data(), d, st.size() * 8, hipMemcpyDeviceToHost); hipFree(d);
+        size_t bad = 0;
+        for (size_t i = 0; i < st.size(); i++) bad += got[i] != ref[i];
+        fprintf(stderr, "check permutation (%s form, %zu states): %zu words differ from the host form\n", form ? "quad" : "lane", n, bad);
+        bad_total |= bad != 0;
+    }
+    return bad_total;
 }
 
 template <int V> void timeit(const char* name, u64* out, int n_cu, bool last) {
@@ -100,7 +150,7 @@ template <int V> void timeit(const char* name, u64* out, int n_cu, bool last) {
 int main() {
     int n_cu = 0;
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0);
-    int bad = check<1>("mul_sched") | check<2>("mul_cyc");
+    int bad = check<1>("mul_sched") | check<2>("mul_cyc") | check_perm();
     u64* out; hipMalloc(&out, (size_t)n_cu * 8 * 256 * 8);
     printf("{\"checks_failed\": %d, \"variants\": [\n", bad);
     timeit<0>("gl::mul (compiler form, 21 wave-instructions)", out, n_cu, false);

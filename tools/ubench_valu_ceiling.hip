@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_glmul(u64* out, u64 seed, int iters) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) m[i] = gl::mul(m[i], m[(i + 1) & 3]);
+            for (int i = 0; i < 4; i++) m[i] = gl::mul_lat(m[i], m[(i + 1) & 3]);
         }
     }
     u64 s = m[0] ^ m[1] ^ m[2] ^ m[3];
