@@ -459,6 +459,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hash-circuits", action="store_true", help="skip the synthesis-rate leg of the netlist circuits")
     ap.add_argument("--no-full-block", action="store_true", help="skip the full-block wall-time leg")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the sensitivity legs (cold slots, per-block address patterns, wide sort keys: 2 steps each)")
     ap.add_argument("--no-validate", action="store_true", help="skip the oracle comparison of one ring slot per pipeline after the timed region")
     ap.add_argument("--launcher-self-test", action="store_true",
                     help="CPU only, no circuit work: the N ranks exchange synthetic closed-form records over gloo and over the C ABI's "
@@ -585,6 +586,9 @@ def main():
                 span.append(time.perf_counter())
             try:
                 for first in range(0, n_inst_p, ring_p):  # synthesis: every instance -> a full 2^20-row trace
+                    if cold_slots[0]:  # sensitivity leg: the consumer took every slot's pointer, the layout tags are forgotten, every cell is written
+                        for k_ in range(min(ring_p, n_inst_p - first)):
+                            ring.device_ptr(k_)
                     c.synthesize_ram(w, ring, first, min(ring_p, n_inst_p - first), 0)
                 if P > 1 and (synth_turns or phased):
                     streams[p].synchronize()
@@ -611,6 +615,7 @@ def main():
     synth_lock = threading.Lock()
     pass_spans = []
     synth_turns = os.environ.get("ZKW_SYNTH_TURNS", "1") != "0"
+    cold_slots = [False]
     phased = P == 2 and os.environ.get("ZKW_PHASED", "0") != "0"  # experiment: with one chain workgroup per CU the turn-taking default does as well
     phase_barrier = threading.Barrier(2)
 
@@ -768,6 +773,44 @@ def main():
         if not validation["ok"]:
             print(f"[bench] VALIDATION FAILED: {checked}", file=sys.stderr)
 
+    # ---- how much the headline depends on three things the synthetic workload is kind about; `value` is unchanged.
+    sensitivity = None
+    if world == 1 and not args.no_sensitivity:
+        def timed_steps(k):
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            run_steps(k, stagger_s)
+            torch.cuda.synchronize()
+            return k * n_inst_local / (time.perf_counter() - t_)
+        sensitivity = {"steps_per_leg": 2}
+        try:
+            sensitivity["baseline_2_steps_circuits_per_s"] = timed_steps(2)  # the unchanged workload over 2 steps: what the legs compare with
+            # (1) cold slots: the prover took every slot's pointer (zkw_trace_device_ptr), so a synthesis writes all 1 250 MB of a trace
+            #     instead of the 578 MB that differ between two traces of the layout
+            cold_slots[0] = True
+            sensitivity["cold_slots_circuits_per_s"] = timed_steps(2)
+            cold_slots[0] = False
+            run_steps(1, stagger_s)  # (re-warm the ring)
+            # (2) every block its own address pattern: page ^= m_b, index ^= n_b (bijections, the trace stays a valid memory): 14 142 distinct
+            #     sort permutations instead of one base trace's
+            g2 = torch.Generator(device="cpu").manual_seed(77 + rank)
+            pm = torch.randint(0, 64, (B, 1), generator=g2, dtype=torch.int32).to(dev)
+            im = torch.randint(0, 256, (B, 1), generator=g2, dtype=torch.int32).to(dev)
+            q[:, :, 1] ^= pm
+            q[:, :, 2] ^= im
+            sensitivity["per_block_address_patterns_circuits_per_s"] = timed_steps(2)
+            # (3) wide keys: pages over 20 bits, indices over 16, timestamps over 32 (odd multipliers mod 2^k are bijections, the timestamp
+            #     shift keeps the order): block + page + index + timestamp no longer fit one 64-bit key, the sort takes route two
+            q[:, :, 1] = (q[:, :, 1] * 0x9E375) & 0xFFFFF
+            q[:, :, 2] = (q[:, :, 2] * 0x9E37) & 0xFFFF
+            q[:, :, 0] <<= 14  # 136 714 << 14 < 2^32 (the int32 tensor holds the same 32 bits)
+            sensitivity["wide_keys_20_16_32_circuits_per_s"] = timed_steps(2)
+            sensitivity["note"] = ("2 timed steps each after the timed region (so each figure carries the pipelines' start-up, which `value` over "
+                                   f"{args.steps} steps amortises: compare with per-leg baseline below); legs are cumulative in the order listed: (3) runs on (2)'s inputs")
+        except Exception as e:  # noqa: BLE001 — a side leg
+            sensitivity["error"] = repr(e)
+            cold_slots[0] = False
+
     if rank == 0:
         assert gathered.shape[0] == n_inst_local * world
         circuits = n_inst_local * world * args.steps
@@ -921,6 +964,7 @@ def main():
                                  "so per-kernel times sum to more than the wall time"},
             "roofline_valu": valu_roofline(),
             "inputs_from_host": h2d,
+            "sensitivity": sensitivity,
             "synthesis": {"trace_bytes_per_circuit": 149 * n_rows * 8, "kernels_ms_per_step": synth_ms / args.steps,
                           "achieved_GBps": synth_gbs, "frac_of_hbm_peak": synth_gbs / HBM_PEAK_GBS if synth_gbs else None,
                           "per_kernel": hbm_kernels},
