@@ -277,17 +277,21 @@ def hash_circuits_gpu(local_rank, blk):
     mem_in = np.zeros(1, native.QUEUE_STATE12)
     for name, kind, n_req, cap, cols, synth, ctype in (("keccak256_round_function", 0, 1400, 293, native.KC_COLS, ctx.synthesize_keccak_round_function, 5),
                                                        ("sha256_round_function", 1, 6000, 2206, native.SC_COLS, ctx.synthesize_sha256_round_function, 6),
-                                                       ("ecrecover", 2, 7 * 8, 7, native.EK_COLS, ctx.synthesize_ecrecover, 7)):
+                                                       ("ecrecover", 2, 7 * 32, 7, native.EK_COLS, ctx.synthesize_ecrecover, 7)):
         req, mq = synthetic.precompile_trace(kind, n_req, seed=5, max_rounds=6)
         tails = ctx.queue_push_chain_log(ctx.encode_log_queries(req))[1]
         w = ctx._precompile(kind, req, tails, mq, cap, mem_in)
         n = min(8, w.num_instances)
         t = native.Trace(ctx, n_rows, n, n_cols=cols)
         out[name] = dict(timed(n, lambda: synth(w, t, 0, n, 0), trace=t, ctype=ctype, cap=cap), capacity=cap, columns=cols, trace_bytes=cols * n_rows * 8)
-        if ctype == 7:
-            out[name]["note"] = ("7 requests per instance (geometry_config.rs): the accumulator chain of a request is serial (k_ec_chain, ~17 ms per call whatever "
-                                 "the batch), the other kernels scale with it: 32 instances per call run at ~1 000 circuits/s (tools/probe_ecrecover_synth.py)")
         t.free()
+        if ctype == 7:  # the accumulator chain of a request is serial (one lane, ~13 ms per call whatever the batch): a second figure at 32 instances per call
+            n32 = min(32, w.num_instances)
+            t = native.Trace(ctx, n_rows, n32, n_cols=cols)
+            out[name]["at_32_instances_per_call"] = timed(n32, lambda: synth(w, t, 0, n32, 0))
+            out[name]["note"] = ("7 requests per instance (geometry_config.rs): the accumulator chain of a request is serial (k_ec_chain: one lane per request, ~13 ms per "
+                                 "call whatever the batch — PRE segment 4.5, 256 double-and-add steps 7, batch inversion 2: profiles/r05/README.md), the other kernels scale with the batch")
+            t.free()
         w.free()
     dec = ctx.compute_decommitts_sorter_circuit_snapshots(blk["decommit_queries"], 117500)
     dq, dt_ = dec.get(native.DEC_DEDUP_QUERIES), dec.get(native.DEC_DEDUP_TAILS)

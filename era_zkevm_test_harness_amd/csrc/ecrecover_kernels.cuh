@@ -57,6 +57,144 @@ static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_tape(const ec_spec*
     if (ec_eval_cycle(&S, j.inputs + (size_t)c * 128, j.tape + (size_t)c * EC_TAPE_PER_CYCLE, &s_ws[threadIdx.x])) atomicMax(status, 1u + (blockIdx.y << 16 | c));
 }
 
+// ---- the base field of secp256k1 for the accumulator chain: OUTLINED multiplication ------------------------------------------------
+// The chain below is ~6 500 multiplications mod p = 2^256 - 2^32 - 977 on ONE lane per request. With ec_mulmod inlined everywhere
+// (include/zkw_ecrecover.h: forced, because its operands travel as pointers) k_ec_chain was 62 000 instructions of straight-line code,
+// 22 000 of them register moves, far beyond the instruction cache: 17 ms per call whatever the batch (ECRecover at 0.003 of
+// HBM). Here the multiplication is ONE function of ~260 instructions that every call site CALLS: operands and result by value (eight
+// VGPRs each, no stack, no scratch), product scanning (a column at a time: one v_mad_u64_u32 + one add-with-carry per partial product
+// into a 96-bit accumulator), the fold hi * (2^32 + 977) + lo word by word through the same multiplier, one conditional subtraction.
+// Canonical in, canonical out, like ec_mulmod.
+namespace ecf {
+__device__ __forceinline__ void mac(u64& acc, u32& ext, u32 a, u32 b) {  // (ext : acc) += a * b
+    u64 c, dead;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(c) : "v"(a), "v"(b));
+    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %2" : "+v"(ext), "=s"(dead) : "s"(c));
+}
+__device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 acc) {  // a * b + acc (no overflow by construction)
+    u64 r, dead;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(dead) : "v"(a), "v"(b), "v"(acc));
+    return r;
+}
+// x (8 words) + carry-in chain helpers are written with 64-bit sums: the compiler keeps the carries in the adds
+__device__ __forceinline__ ec_u256 cond_sub_p(const u32* r, u32 top) {  // r + top * 2^256 < 2 p  ->  mod p
+    // r >= p  <=>  r + (2^32 + 977) carries out of 256 bits
+    u32 u[8];
+    u64 c = (u64)r[0] + 977u;
+    u[0] = (u32)c; c >>= 32;
+    c += (u64)r[1] + 1u;
+    u[1] = (u32)c; c >>= 32;
+#pragma unroll
+    for (int i = 2; i < 8; i++) { c += r[i]; u[i] = (u32)c; c >>= 32; }
+    const bool ge = top != 0 || c != 0;
+    ec_u256 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.w[i] = ge ? u[i] : r[i];
+    return o;
+}
+__device__ __attribute__((noinline)) ec_u256 mul(ec_u256 a, ec_u256 b) {
+    // product scanning: one 96-bit accumulator walks the columns. (A form with one accumulator per column — eight independent chains in
+    // flight — was measured too: 15.0 instead of 13.0 ms per call; a lone wave issues a v_mad_u64_u32 every ~8 cycles whether it depends
+    // on the previous one or not (profiles/r05/valu_ceiling.json, one wave per SIMD), so the extra moves of that form only cost.)
+    u32 t[16];
+    u64 acc = 0;
+    u32 ext = 0;
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (k - i >= 0 && k - i < 8) mac(acc, ext, a.w[i], b.w[k - i]);
+        t[k] = (u32)acc;
+        acc = (acc >> 32) | ((u64)ext << 32);
+        ext = 0;
+    }
+    t[15] = (u32)acc;
+    // fold: lo + hi * 977 + (hi << 32); word j: lo_j + 977 hi_j + hi_(j-1) + carry  (< 2^42 + 2^33: one 64-bit accumulator)
+    u32 r[8];
+    u64 cy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        cy = mad32(t[8 + j], 977u, cy);
+        cy = mad32(t[j], 1u, cy);
+        if (j) cy = mad32(t[8 + j - 1], 1u, cy);
+        r[j] = (u32)cy;
+        cy >>= 32;
+    }
+    const u64 R = cy + t[15];  // what is left above 2^256: < 2^33 + 2^11
+    // second fold: R * (2^32 + 977) onto the low words (R * 977 < 2^45; R << 32 spans words 1..2)
+    u64 c2 = (u64)r[0] + (R & 0xFFFFFFFFull) * 977u;
+    r[0] = (u32)c2; c2 >>= 32;
+    c2 += (u64)r[1] + (R >> 32) * 977u + (R & 0xFFFFFFFFull);
+    r[1] = (u32)c2; c2 >>= 32;
+    c2 += (u64)r[2] + (R >> 32);
+    r[2] = (u32)c2; c2 >>= 32;
+#pragma unroll
+    for (int i = 3; i < 8; i++) { c2 += r[i]; r[i] = (u32)c2; c2 >>= 32; }
+    return cond_sub_p(r, (u32)c2);  // (a wrap leaves a tiny low part: one subtraction of p settles either case)
+}
+__device__ __attribute__((noinline)) ec_u256 add(ec_u256 a, ec_u256 b) {  // a, b < p
+    u32 r[8];
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (u64)a.w[i] + b.w[i]; r[i] = (u32)c; c >>= 32; }
+    return cond_sub_p(r, (u32)c);
+}
+__device__ __attribute__((noinline)) ec_u256 sub(ec_u256 a, ec_u256 b) {  // a, b < p
+    u32 r[8];
+    long long c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (long long)a.w[i] - (long long)b.w[i]; r[i] = (u32)c; c >>= 32; }
+    if (c == 0) { ec_u256 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.w[i] = r[i];
+        return o; }
+    // borrowed: + p = - (2^32 + 977) mod 2^256
+    ec_u256 o;
+    long long d = (long long)r[0] - 977;
+    o.w[0] = (u32)d; d >>= 32;
+    d += (long long)r[1] - 1;
+    o.w[1] = (u32)d; d >>= 32;
+#pragma unroll
+    for (int i = 2; i < 8; i++) { d += r[i]; o.w[i] = (u32)d; d >>= 32; }
+    return o;
+}
+// Jacobian doubling (a = 0, 7 multiplications) and mixed addition (11), the formulas of ec_jdbl / ec_jmadd (include/zkw_ecrecover.h)
+__device__ __forceinline__ void jdbl(ec_u256& X, ec_u256& Y, ec_u256& Z) {
+    const ec_u256 a = mul(X, X), b = mul(Y, Y), c = mul(b, b);
+    ec_u256 t = add(X, b);
+    t = mul(t, t);
+    t = sub(t, a);
+    t = sub(t, c);
+    const ec_u256 d = add(t, t);
+    ec_u256 e = add(a, a);
+    e = add(e, a);
+    const ec_u256 f = mul(e, e), d2 = add(d, d), yz = mul(Y, Z);
+    X = sub(f, d2);
+    ec_u256 c8 = add(c, c);
+    c8 = add(c8, c8);
+    c8 = add(c8, c8);
+    ec_u256 dx = sub(d, X);
+    dx = mul(e, dx);
+    Y = sub(dx, c8);
+    Z = add(yz, yz);
+}
+__device__ __forceinline__ void jmadd(ec_u256& X, ec_u256& Y, ec_u256& Z, const ec_u256& x2, const ec_u256& y2) {
+    const ec_u256 zz = mul(Z, Z), zzz = mul(zz, Z), u2 = mul(x2, zz), s2 = mul(y2, zzz);
+    const ec_u256 h = sub(u2, X), r = sub(s2, Y);
+    const ec_u256 h2 = mul(h, h), h3 = mul(h2, h), xh2 = mul(X, h2);
+    ec_u256 t = mul(r, r);
+    t = sub(t, h3);
+    t = sub(t, xh2);
+    const ec_u256 x3 = sub(t, xh2);
+    ec_u256 v = sub(xh2, x3);
+    v = mul(r, v);
+    const ec_u256 yh3 = mul(Y, h3);
+    Z = mul(Z, h);
+    X = x3;
+    Y = sub(v, yh3);
+}
+}  // namespace ecf
+
 // ---- the fast form of the tape: the accumulator's trajectory first, then every segment on its own lane ------------------------------
 // The serial kernel above spends its time in ~550 modular inversions per cycle (every quotient lambda of the affine additions), one after
 // the other, because segment k needs the accumulator segment k - 1 leaves. The trajectory does not need the quotients: k_ec_chain runs
@@ -101,8 +239,8 @@ static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_chain(const ec_spec
     }
     az = one;
     for (u32 k = 0; k < 256; k++) {
-        ec_jdbl(&ax, &ay, &az, &M);
-        if (tape[S.globs[EC_GL_BITS + 255 - k]]) ec_jmadd(&ax, &ay, &az, &rx, &ry, &M);
+        ecf::jdbl(ax, ay, az);
+        if (tape[S.globs[EC_GL_BITS + 255 - k]]) ecf::jmadd(ax, ay, az, rx, ry);
         pts[k].x = ax; pts[k].y = ay; pts[k].z = az;
     }
     for (u32 C = 0; C < 32; C++) {
@@ -114,9 +252,8 @@ static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_chain(const ec_spec
                 tx.w[i] = S.fixed[((size_t)(8 * C + i) * 256 + b) * 2];
                 ty.w[i] = S.fixed[((size_t)(8 * C + i) * 256 + b) * 2 + 1];
             }
-            const ec_u256 zero = ec_zero256();
-            const ec_u256 nty = ec_submod(&zero, &ty, &M);
-            ec_jmadd(&ax, &ay, &az, &tx, &nty, &M);
+            const ec_u256 nty = ecf::sub(ec_zero256(), ty);
+            ecf::jmadd(ax, ay, az, tx, nty);
         }
         pts[256 + C].x = ax; pts[256 + C].y = ay; pts[256 + C].z = az;
     }
@@ -126,15 +263,15 @@ static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_chain(const ec_spec
         pre[k] = run;
         const ec_u256 z = pts[k].z;
         if (ec_is_zero8(&z)) { atomicMax(status, 1u + (blockIdx.y << 16 | c)); return; }
-        run = ec_mulmod(&run, &z, &M, W);
+        run = ecf::mul(run, z);
     }
-    ec_u256 inv = ec_invmod(&run, &M, W);
+    ec_u256 inv = ec_invmod(&run, &M, W);  // binary extended Euclid (include/zkw_ecrecover.h)
     for (int k = (int)EC_CHAIN_POINTS - 1; k >= 0; k--) {
         const ec_u256 px = pts[k].x, py = pts[k].y, pz = pts[k].z, pk = pre[k];
-        const ec_u256 zi = ec_mulmod(&inv, &pk, &M, W);
-        inv = ec_mulmod(&inv, &pz, &M, W);
-        const ec_u256 zi2 = ec_mulmod(&zi, &zi, &M, W), zi3 = ec_mulmod(&zi2, &zi, &M, W);
-        const ec_u256 x = ec_mulmod(&px, &zi2, &M, W), y = ec_mulmod(&py, &zi3, &M, W);
+        const ec_u256 zi = ecf::mul(inv, pk);
+        inv = ecf::mul(inv, pz);
+        const ec_u256 zi2 = ecf::mul(zi, zi), zi3 = ecf::mul(zi2, zi);
+        const ec_u256 x = ecf::mul(px, zi2), y = ecf::mul(py, zi3);
         const u32 run_i = k < 256 ? 1u : 2u, inst = k < 256 ? (u32)k : (u32)k - 256u;
         const ec_seg_type& T = S.types[S.runs[run_i].type];
         u64* seg = tape + S.runs[run_i].tape0 + inst * T.n_tape;

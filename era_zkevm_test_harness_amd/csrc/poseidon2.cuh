@@ -429,6 +429,11 @@ __device__ __forceinline__ u64 coop_flattened(const Coop& co, u64 x, u32 g, Put&
 // internal layer stay inside the lane, and the three elements of a lane give the in-order wave three
 // independent S-box chains to interleave. ~8.1k instructions per permutation step for 16 states, against
 // ~5.9k for 4 states in the row-of-16 form above.
+#if defined(P2_Q4_FULL_CYC)
+#define Q4_FULL_POW7 gl::pow7
+#else
+#define Q4_FULL_POW7 gl::pow7_lat
+#endif
 struct Coop4 {
     u64 rc_full[2 * P2_HALF_FULL_ROUNDS][3];
     u32 ka, kb, kd;
@@ -494,7 +499,7 @@ struct Coop4 {
 #pragma unroll
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) x[c] = gl::pow7_lat(gl::add_canon(x[c], rc_full[k][c]));
+            for (int c = 0; c < 3; c++) x[c] = Q4_FULL_POW7(gl::add_canon(x[c], rc_full[k][c]));
             external(x);
         }
         for (int k = 0; k < P2_PARTIAL_ROUNDS; k++) {
@@ -514,7 +519,7 @@ struct Coop4 {
 #pragma unroll
         for (int k = 0; k < P2_HALF_FULL_ROUNDS; k++) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) x[c] = gl::pow7_lat(gl::add_canon(x[c], rc_full[P2_HALF_FULL_ROUNDS + k][c]));
+            for (int c = 0; c < 3; c++) x[c] = Q4_FULL_POW7(gl::add_canon(x[c], rc_full[P2_HALF_FULL_ROUNDS + k][c]));
             external(x);
         }
     }

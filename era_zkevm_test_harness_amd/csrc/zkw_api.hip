@@ -416,8 +416,14 @@ struct ChainService {
     std::vector<std::thread> workers;
     bool stop = false;
 
+    // ZKW_CHAIN_WORKERS (default 4): launches in flight at once — a worker stays with its batch until the batch's longest chain is done;
+    // ZKW_CHAIN_WINDOW_US (default 400 / 4000): silence that closes a batch / its maximal age
+    int n_workers = 4;
+    long quiet_us = 400, max_us = 4000;
     explicit ChainService(int dev) : device(dev) {
-        for (int i = 0; i < 4; i++) workers.emplace_back([this] { run(); });
+        if (const char* e = getenv("ZKW_CHAIN_WORKERS")) n_workers = std::max(1, std::min(32, atoi(e)));
+        if (const char* e = getenv("ZKW_CHAIN_WINDOW_US")) { quiet_us = std::max(50L, atol(e)); max_us = 10 * quiet_us; }
+        for (int i = 0; i < n_workers; i++) workers.emplace_back([this] { run(); });
     }
     ~ChainService() {
         { std::lock_guard<std::mutex> g(mu); stop = true; }
@@ -464,7 +470,7 @@ struct ChainService {
                 for (;;) {
                     const auto now = std::chrono::steady_clock::now();
                     if (!open) break;  // another worker took it
-                    if (now - last_arrival >= std::chrono::microseconds(400) || now - open_since >= std::chrono::milliseconds(4)) break;
+                    if (now - last_arrival >= std::chrono::microseconds(quiet_us) || now - open_since >= std::chrono::microseconds(max_us)) break;
                     cv_work.wait_for(lk, std::chrono::microseconds(200));
                     if (stop) break;
                 }
