@@ -372,19 +372,27 @@ extern "C" int zkw_profile_names(zkw_ctx* ctx, char* buf, size_t buf_bytes) {
 // doubling up. ZKW_CHAIN_WG4=0 restores one-wave workgroups.
 static int launch_chain_q4(hipStream_t st, const ChainJob* d_jobs, int n_jobs) {
     static const bool wg4 = [] { const char* e = getenv("ZKW_CHAIN_WG4"); return !(e && e[0] == '0'); }();
-    static const unsigned lds = 84 * 1024;
     if (wg4 && n_jobs > 64 && n_jobs <= 256 * 64) {
-        static std::atomic<bool> allowed[64];  // per device: a kernel's LDS limit is raised on the device that runs it
+        // per device: 0 not tried, > 0 the LDS request that was granted (more than half a CU's LDS, from the device's own figure), -1 refused:
+        // a device or partition mode without that much LDS per workgroup runs the one-wave form, which is correct everywhere
+        static std::atomic<int> lds_of[64];
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
-        if (dev < 0 || dev >= 64 || !allowed[dev].load()) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_full_q4x4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (dev >= 0 && dev < 64) allowed[dev].store(true);
+        int lds = dev >= 0 && dev < 64 ? lds_of[dev].load() : 0;
+        if (lds == 0) {
+            int per_cu = 0;
+            if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || per_cu <= 0) per_cu = 160 * 1024;
+            const int want = (per_cu / 2 + 4096) & ~1023;  // 84 KB of 160: one such workgroup per CU
+            lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_full_q4x4), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess ? want : -1;
+            if (lds < 0) (void)hipGetLastError();
+            if (dev >= 0 && dev < 64) lds_of[dev].store(lds);
         }
-        hipLaunchKernelGGL(k_chain_full_q4x4, dim3((n_jobs + 63) / 64), dim3(256), lds, st, d_jobs, n_jobs);
-    } else {
-        hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
+        if (lds > 0) {
+            hipLaunchKernelGGL(k_chain_full_q4x4, dim3((n_jobs + 63) / 64), dim3(256), (size_t)lds, st, d_jobs, n_jobs);
+            return ZKW_OK;
+        }
     }
+    hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
     return ZKW_OK;
 }
 
@@ -508,7 +516,7 @@ struct ChainService {
                 const int nf = (int)b->full.size(), nl = (int)b->log.size();
                 if (rc == ZKW_OK && nl) hipLaunchKernelGGL(k_chain_log, dim3((nl + 3) / 4), dim3(64), 0, st_log, reinterpret_cast<const LogChainJob*>(dp + off_log), nl);
                 if (rc == ZKW_OK && nf) {
-                    if (nf >= 4096) (void)launch_chain_q4(st, reinterpret_cast<const ChainJob*>(dp), nf);
+                    if (nf >= 4096) { const int lrc = launch_chain_q4(st, reinterpret_cast<const ChainJob*>(dp), nf); if (lrc != ZKW_OK && rc == ZKW_OK) { rc = lrc; err = "chain launch (quad form)"; } }
                     else hipLaunchKernelGGL(k_chain_full, dim3((nf + 3) / 4), dim3(64), 0, st, reinterpret_cast<const ChainJob*>(dp), nf);
                 }
                 fail_hip(hipGetLastError(), "chain launch");

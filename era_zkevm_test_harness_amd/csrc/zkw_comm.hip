@@ -315,6 +315,19 @@ extern "C" int zkw_comm_init_tcp(zkw_ctx* ctx, const char* address, int port, in
             if (connect(f, reinterpret_cast<sockaddr*>(&sa), sizeof sa) == 0) {
                 setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
                 if (TcpTransport::write_all(f, &hello, sizeof hello) != 0) { close(f); if (lfd >= 0) close(lfd); return fail_with("hello"); }
+                // the listener answers one byte: 1 = taken, 0 = turned away (another job id / a bad rank). A listener that is not one of this
+                // job's (or that closes the socket) is an error HERE, not at the first collective
+                unsigned char ack = 0;
+                bool got = false;
+                for (;;) {
+                    const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+                    if (left <= 0) { errno = ETIMEDOUT; break; }
+                    pollfd pf{f, POLLIN, 0};
+                    const int k = poll(&pf, 1, (int)std::min<long long>(left, 1000));
+                    if (k > 0) { const ssize_t n = recv(f, &ack, 1, 0); if (n == 1) got = true; else if (n == 0) errno = ECONNRESET; break; }
+                    if (k < 0 && errno != EINTR) break;
+                }
+                if (!got || ack != 1) { if (got) errno = ECONNREFUSED; close(f); if (lfd >= 0) close(lfd); return fail_with(got ? "hello turned away by the listener (job id or rank mismatch)" : "hello acknowledgement"); }
                 t->fd[peer] = f;
                 break;
             }
@@ -345,9 +358,21 @@ extern "C" int zkw_comm_init_tcp(zkw_ctx* ctx, const char* address, int port, in
         }
         setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
         Hello h{};
-        if (!wait_readable(f) || TcpTransport::read_all(f, &h, sizeof h) != 0) { close(f); close(lfd); return fail_with("hello (timed out)"); }
-        if (h.job != hello.job) { close(f); continue; }  // a process of another job: not one of ours, keep waiting
-        if (h.world != world || h.rank <= rank || h.rank >= world || t->fd[h.rank] >= 0) { close(f); close(lfd); delete t; return zkw_fail(ZKW_ERR_HIP, "zkw_comm_init_tcp: bad hello (rank %d of %d)", h.rank, h.world); }
+        {   // the WHOLE hello under the deadline: a peer that sends part of it must not hang the init past timeout_ms
+            size_t have = 0;
+            bool ok = true;
+            while (have < sizeof h) {
+                if (!wait_readable(f)) { ok = false; break; }
+                const ssize_t n = recv(f, reinterpret_cast<char*>(&h) + have, sizeof h - have, 0);
+                if (n > 0) have += (size_t)n;
+                else if (n == 0 || (errno != EINTR && errno != EAGAIN)) { ok = false; if (n == 0) errno = ECONNRESET; break; }
+            }
+            if (!ok) { close(f); close(lfd); return fail_with("hello (timed out or cut short)"); }
+        }
+        const unsigned char no = 0, yes = 1;
+        if (h.job != hello.job) { (void)!write(f, &no, 1); close(f); continue; }  // a process of another job: told so, keep waiting for ours
+        if (h.world != world || h.rank <= rank || h.rank >= world || t->fd[h.rank] >= 0) { (void)!write(f, &no, 1); close(f); close(lfd); delete t; return zkw_fail(ZKW_ERR_HIP, "zkw_comm_init_tcp: bad hello (rank %d of %d)", h.rank, h.world); }
+        if (TcpTransport::write_all(f, &yes, 1) != 0) { close(f); close(lfd); return fail_with("hello acknowledgement"); }
         t->fd[h.rank] = f;
         k++;
     }

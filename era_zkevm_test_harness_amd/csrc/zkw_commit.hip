@@ -234,7 +234,7 @@ static int setup_columns_device(zkw_ctx* ctx, uint8_t circuit_type, uint32_t cap
 
 extern "C" int zkw_setup_columns(zkw_ctx* ctx, uint8_t circuit_type, uint32_t capacity, uint32_t log_n, uint64_t* columns) {
     uint32_t nc = 0;
-    if (!ctx || !columns || log_n > 24) return fail(ZKW_ERR_INVALID, "zkw_setup_columns: bad argument");
+    if (!ctx || !columns || log_n > 20) return fail(ZKW_ERR_INVALID, "zkw_setup_columns: bad argument (log_n <= 20: the twiddle tables of k_powers hold 1024 x 1024 exponents)");
     ZKW_TRY(zkw_setup_num_columns(circuit_type, &nc));
     HIP_TRY(hipSetDevice(ctx->device));
     u64* d_cols = nullptr;

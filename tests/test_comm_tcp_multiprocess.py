@@ -162,6 +162,8 @@ def test_tcp_hello_turns_away_another_job():
     for p in procs:
         p.join(30)
     assert got[0].startswith("refused") and "timed out" in got[0], got  # rank 0 never saw a rank of ITS job
+    # ... and the connector learns it at init (it used to store the descriptor as connected and fail at the first collective)
+    assert got[1].startswith("refused") and "turned away" in got[1], got
 
 
 def test_tcp_comm_rejects_bad_arguments():
