@@ -149,53 +149,82 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     return best, blk
 
 
-def full_blocks_batched(local_rank, blk, K=48, rounds=3, rank=0, world=1, comm=None):
-    """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once (one host thread per block; the chain
-    service merges every block's Poseidon2 queue chains into a few shared launches, so K blocks cost about two chain passes
-    instead of K), then every synthesizable instance of every block into its trace, then the blocks released. With N GPUs the
-    K x N blocks are sharded over the ranks by zkw_blocks_run_sharded (round-robin, nothing replicated) and every block's
-    closed-form records are gathered to rank 0 (zkw_blocks_gather_closed_form_inputs): the mode that scales. The first round
-    fills the library's buffer caches (untimed); the best of the others is reported."""
-    from concurrent.futures import ThreadPoolExecutor
+def full_blocks_batched(local_rank, blk, K=96, rounds=4, rank=0, world=1, comm=None):
+    """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once (zkw_blocks_run: one host thread per block; the
+    chain service merges every block's Poseidon2 queue chains into shared launches, so K blocks cost about two chain passes instead of K),
+    every synthesizable instance of every block into its trace (zkw_blocks_synthesize: the ECRecover instances of all blocks in joint calls,
+    the other types block by block on the library's threads), the blocks released. On one GPU the batches are PIPELINED: the builders of
+    batch k + 1 run (on a host thread) next to the synthesis of batch k; the figure is blocks of the timed batches over their wall time, the
+    first batch (which fills the library's buffer caches) untimed. With N GPUs the K x N blocks are sharded over the ranks by
+    zkw_blocks_run_sharded (round-robin, nothing replicated) and every block's closed-form records are gathered to rank 0
+    (zkw_blocks_gather_closed_form_inputs), batch after batch."""
+    import threading
 
-    # K = 48: with 96 blocks in flight (27 blocks/s, tools/probe_block_concurrency.py) rocprofv3's own interception crashes in
-    # hipMemcpyAsync under ~500 host threads; the bench must stay profilable
+    # ZKW_BATCHED_BLOCKS: 48 for runs under rocprofv3 (its interception crashes in hipMemcpyAsync under ~500 host threads: tools/run_round_profiles.sh)
     K = int(os.environ.get("ZKW_BATCHED_BLOCKS", K))
     distinct = [blk] + [synthetic.block_production(seed=2 + k) for k in range(3)]
     blocks = [distinct[(k // world) % len(distinct)] for k in range(K * world)]
     dev = torch.device("cuda", local_rank)
-    best = None
-    for r in range(rounds):
-        parallel.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if world == 1:
-            bs = native.Block.run_many(local_rank, blocks)
-        else:
-            bs = native.Block.run_sharded(local_rank, blocks, rank, world)
-        mine = [b for b in bs if b is not None]
+
+    def build():
+        return native.Block.run_many(local_rank, blocks) if world == 1 else native.Block.run_sharded(local_rank, blocks, rank, world)
+
+    def finish(bs, rep):
         t1 = time.perf_counter()
-        with ThreadPoolExecutor(8) as ex:  # the blocks' synthesis calls side by side (they are short kernels and host waits)
-            n = sum(ex.map(lambda b: b.synthesize(1 << 20, ring_slots=1), mine))
+        mine = [b for b in bs if b is not None]
+        rep["instances"] += native.Block.synthesize_many(mine, 1 << 20, ring_slots=1)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        n_records = None
         if world > 1 and comm is not None:
             got = native.Block.gather_sharded(bs, comm, rank, world, root=0)
-            n_records = sum(len(g) for g in got) if got is not None else None
+            rep["records"] = (rep["records"] or 0) + (sum(len(g) for g in got) if got is not None else 0)
         t3 = time.perf_counter()
         for b in mine:
             b.free()
         t4 = time.perf_counter()
-        wall = parallel.max_over_ranks(t4 - t0, dev)
-        n_all = int(parallel.sum_over_ranks(n, dev)) if world > 1 else n
-        rep = {"blocks": K * world, "blocks_per_gpu": K, "n_gpus": world, "blocks_per_s": K * world / wall, "blocks_per_s_this_rank": len(mine) / (t4 - t0),
-               "synthesized_circuits_per_s": n_all / wall, "wall_ms": wall * 1e3, "builders_ms": (t1 - t0) * 1e3, "synthesis_ms": (t2 - t1) * 1e3,
-               "gather_ms": (t3 - t2) * 1e3, "release_ms": (t4 - t3) * 1e3, "instances_synthesized": n_all, "records_gathered": n_records,
-               "sharding": "one GPU" if world == 1 else "zkw_blocks_run_sharded (round-robin over ranks) + zkw_blocks_gather_closed_form_inputs"}
-        if r and (best is None or rep["wall_ms"] < best["wall_ms"]):
-            best = rep
-    return best
+        rep["synthesis_ms"].append((t2 - t1) * 1e3); rep["gather_ms"].append((t3 - t2) * 1e3); rep["release_ms"].append((t4 - t3) * 1e3)
+
+    warm = build()
+    finish(warm, {"instances": 0, "records": None, "synthesis_ms": [], "gather_ms": [], "release_ms": []})  # fills the caches
+    rep = {"instances": 0, "records": None, "synthesis_ms": [], "gather_ms": [], "release_ms": [], "builders_ms": []}
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if world == 1:
+        tb = time.perf_counter()
+        cur = build()
+        rep["builders_ms"].append((time.perf_counter() - tb) * 1e3)
+        for r in range(1, rounds):
+            box = []
+
+            def builder():
+                torch.cuda.set_device(local_rank)
+                t_ = time.perf_counter()
+                box.append(build())
+                rep["builders_ms"].append((time.perf_counter() - t_) * 1e3)
+            th = threading.Thread(target=builder)
+            th.start()
+            finish(cur, rep)
+            th.join()
+            cur = box[0]
+        finish(cur, rep)
+    else:
+        for r in range(rounds):
+            tb = time.perf_counter()
+            cur = build()
+            rep["builders_ms"].append((time.perf_counter() - tb) * 1e3)
+            finish(cur, rep)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    n_all = int(parallel.sum_over_ranks(rep["instances"], dev)) if world > 1 else rep["instances"]
+    r3 = lambda v: [round(x, 1) for x in v]  # noqa: E731
+    return {"blocks": K * world * rounds, "blocks_per_gpu_in_flight": K, "batches": rounds, "n_gpus": world, "blocks_per_s": K * world * rounds / wall,
+            "synthesized_circuits_per_s": n_all / wall, "wall_ms": wall * 1e3, "builders_ms_per_batch": r3(rep["builders_ms"]),
+            "synthesis_ms_per_batch": r3(rep["synthesis_ms"]), "gather_ms_per_batch": r3(rep["gather_ms"]), "release_ms_per_batch": r3(rep["release_ms"]),
+            "instances_synthesized": n_all, "records_gathered": rep["records"],
+            "schedule": "pipelined: builders of batch k + 1 next to the synthesis of batch k" if world == 1 else "batch after batch",
+            "sharding": "one GPU" if world == 1 else "zkw_blocks_run_sharded (round-robin over ranks) + zkw_blocks_gather_closed_form_inputs"}
 
 
 

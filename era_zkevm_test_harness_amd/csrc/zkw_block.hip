@@ -19,7 +19,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <future>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -799,8 +801,13 @@ extern "C" int zkw_block_synthesize(zkw_block* B, size_t n_rows, size_t ring_slo
     return zkw_block_synthesize_sharded(B, n_rows, ring_slots, 0, 1, cb, user, n_done);
 }
 
+static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type);
 extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb,
                                             void* user, size_t* n_done) {
+    return block_synthesize_impl(B, n_rows, ring_slots, rank, world, cb, user, n_done, -1);
+}
+// skip_type: a circuit type whose instances somebody else synthesizes (zkw_blocks_synthesize: ECRecover of all blocks in joint calls)
+static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type) {
     if (!B || n_rows == 0 || ring_slots == 0 || world < 1 || rank < 0 || rank >= world) return ZKW_ERR_INVALID;
     std::vector<uint8_t> plan_types;
     std::vector<uint32_t> plan_index, plan_owner;
@@ -830,6 +837,7 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
     const double a = B->ms_now();
     size_t done = 0;
     for (int t : kOrder) {
+        if (t == skip_type) continue;
         const size_t ni = zkw_block_num_instances(B, (uint8_t)t);
         zkw_ctx* c = zkw_block_context(B, (uint8_t)t);
         zkw_trace* ring = B->ring;
@@ -869,6 +877,88 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
     B->span("synthesis", a);
     if (n_done) *n_done = done;
     return ZKW_OK;
+}
+
+// ---- K blocks: every instance of every block. Two things differ from K calls of zkw_block_synthesize: (1) the ECRecover instances of ALL
+// blocks go through joint calls (zkw_ecrecover_synthesize_multi, at most `ec_chunk` instances each, a ring of their own): the accumulator
+// chain of a request is one lane and ~13 ms per call whatever the batch, so 48 blocks' calls one after the other were 0.6 of the 0.75 s
+// their synthesis took; (2) the other types run block by block on up to 8 host threads of the library (each block on its own ring of
+// `ring_slots` slots and its own contexts), next to the ECRecover thread. cb may be called from several threads at once; a slot is the
+// callee's until it returns (external_calls::run's circuit_callback, per block in the reference's emission order except that ECRecover
+// instances arrive on their own).
+extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, size_t n_rows, size_t ring_slots, size_t ec_chunk, zkw_blocks_circuit_fn cb,
+                                     void* user, size_t* n_done) {
+    if (!blocks || n_blocks == 0 || n_rows == 0 || ring_slots == 0) return ZKW_ERR_INVALID;
+    for (size_t k = 0; k < n_blocks; k++)
+        if (!blocks[k] || blocks[k]->device != blocks[0]->device) return ZKW_ERR_INVALID;
+    if (ec_chunk == 0) ec_chunk = 32;
+    std::atomic<size_t> done{0};
+    std::atomic<int> first_rc{ZKW_OK};
+    auto note = [&](int rc) { int ok = ZKW_OK; if (rc != ZKW_OK) first_rc.compare_exchange_strong(ok, rc); };
+    struct Fwd { size_t block; zkw_blocks_circuit_fn cb; void* user; };
+    auto fwd = [](void* u, uint8_t type, size_t inst, const zkw_trace* tr, size_t slot, const uint64_t* pi) -> int {
+        const Fwd* f = static_cast<const Fwd*>(u);
+        return f->cb ? f->cb(f->user, f->block, type, inst, tr, slot, pi) : 0;
+    };
+    // (1) ECRecover of all blocks
+    std::thread ec_thread([&] {
+        if (hipSetDevice(blocks[0]->device) != hipSuccess) { note(ZKW_ERR_HIP); return; }
+        size_t most = 0, total = 0;
+        for (size_t k = 0; k < n_blocks; k++) { const size_t n = zkw_block_num_instances(blocks[k], T_ECR); most = std::max(most, n); total += n; }
+        if (total == 0) return;
+        // a context of its own: the blocks' precompile contexts are busy with their Keccak / SHA-256 / decommitter instances on the other threads
+        zkw_ctx* c = zkw_create(blocks[0]->device);
+        if (!c) { note(ZKW_ERR_NO_DEVICE); return; }
+        int rc = ZKW_OK;
+        const size_t slots = std::max(most, std::min(ec_chunk, total));
+        zkw_trace* ring = nullptr;
+        rc = zkw_trace_create_with_columns(c, n_rows, 129 /* 80 + 3 x 16 + 1 columns: include/zkw_ecrecover_circuit_spec.h EK_COLS */, slots, &ring);
+        if (rc != ZKW_OK) { note(rc); zkw_destroy(c); return; }
+        for (size_t b0 = 0; b0 < n_blocks && first_rc.load() == ZKW_OK;) {
+            std::vector<zkw_precompile_witness*> ws;
+            std::vector<size_t> owner;
+            size_t cnt = 0, b1 = b0;
+            while (b1 < n_blocks && cnt + zkw_block_num_instances(blocks[b1], T_ECR) <= slots) {
+                ws.push_back(static_cast<zkw_precompile_witness*>(zkw_block_witness(blocks[b1], T_ECR)));
+                cnt += zkw_block_num_instances(blocks[b1], T_ECR);
+                b1++;
+            }
+            rc = zkw_ecrecover_synthesize_multi(c, ws.data(), ws.size(), ring, 0);
+            if (rc == ZKW_OK) rc = zkw_synchronize(c);
+            if (rc != ZKW_OK) { note(rc); break; }
+            size_t slot = 0;
+            for (size_t b = b0; b < b1 && first_rc.load() == ZKW_OK; b++) {
+                const size_t ni = zkw_block_num_instances(blocks[b], T_ECR);
+                for (size_t i = 0; i < ni; i++, slot++) {
+                    if (cb && cb(user, b, (uint8_t)T_ECR, i, ring, slot, blocks[b]->per[T_ECR].pi.data() + 4 * i) != 0) { note(ZKW_ERR_CHECK_FAILED); break; }
+                    done++;
+                }
+            }
+            b0 = b1;
+        }
+        zkw_trace_free(ring);
+        zkw_destroy(c);
+    });
+    // (2) everything else, block by block on a few threads
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    const size_t n_threads = std::min<size_t>(8, n_blocks);
+    for (size_t th = 0; th < n_threads; th++)
+        pool.emplace_back([&] {
+            for (;;) {
+                const size_t b = next.fetch_add(1);
+                if (b >= n_blocks || first_rc.load() != ZKW_OK) return;
+                Fwd f{b, cb, user};
+                size_t n = 0;
+                const int rc = block_synthesize_impl(blocks[b], n_rows, ring_slots, 0, 1, fwd, &f, &n, T_ECR);
+                done += n;
+                if (rc != ZKW_OK) note(rc);
+            }
+        });
+    for (auto& t : pool) t.join();
+    ec_thread.join();
+    if (n_done) *n_done = done.load();
+    return first_rc.load();
 }
 
 // ---- multi-GPU: every rank has run the builders (they are deterministic and bounded by one serial chain, so replicating

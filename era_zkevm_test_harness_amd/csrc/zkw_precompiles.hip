@@ -599,8 +599,13 @@ extern "C" void zkw_storage_application_witness_free(zkw_storage_application_wit
     ctx_release(owner);
 }
 
+// (work_ctx: whose stream and scratch do the work — the witness's own context, or the private one of a joint call over many witnesses)
+static int precompile_closed_forms_with(zkw_ctx* ctx, zkw_precompile_witness* w, const uint64_t** compact, const uint64_t** public_inputs);
 extern "C" int zkw_precompile_closed_forms(zkw_ctx* ctx, zkw_precompile_witness* w, const uint64_t** compact, const uint64_t** public_inputs) {
     if (!ctx || !w || w->ctx != ctx) return fail(ZKW_ERR_INVALID, "zkw_precompile_closed_forms: bad argument");
+    return precompile_closed_forms_with(ctx, w, compact, public_inputs);
+}
+static int precompile_closed_forms_with(zkw_ctx* ctx, zkw_precompile_witness* w, const uint64_t** compact, const uint64_t** public_inputs) {
     HIP_TRY(hipSetDevice(ctx->device));
     if (!w->cf_pi) {
         if (w->kind == ZKW_PRECOMPILE_KECCAK256) ZKW_TRY(closed_form_public_inputs<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>>(ctx, w->instances, w->n_instances, &w->cf_pi));
@@ -1244,21 +1249,39 @@ extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t
 // ZkSyncBaseLayerCircuit::synthesis for ECRecover (type 7): 80 + 3 x 16 columns, Xor8 / And8 / 8 x 32 FixedBaseMul / ByteSplit<1..4> =
 // 197 632 table rows (base_layer/ecrecover.rs:30-41,138-176). One cycle per request (ecrecover.rs:143-178: four reads, two writes):
 // the EC section recovers the key from the read values, the netlist hashes it, the queue section pops the call and pushes the queries.
-extern "C" int zkw_ecrecover_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances, zkw_trace* t, size_t first_slot) {
-    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_ecrecover_synthesize: bad argument");
-    if (w->kind != ZKW_PRECOMPILE_ECRECOVER) return fail(ZKW_ERR_INVALID, "zkw_ecrecover_synthesize: not an ecrecover witness");
-    if (first_instance + n_instances > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
-    if (n_instances > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", n_instances, t->n_slots);
-    if (t->n_cols < EK_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the ECRecover circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, EK_COLS);
-    if (n_instances == 0) return ZKW_OK;
-    const u32 capacity = w->capacity;
+// The instances [first[k], first[k] + count[k]) of witness ws[k], k = 0 .. n_ws - 1, into consecutive slots from first_slot — ONE launch of
+// every EC kernel over all of them. The accumulator chain of a request is one lane and ~13 ms whatever the batch (k_ec_chain), so the
+// instances of MANY blocks in one call cost what one block's cost (zkw_blocks_synthesize); the queue sections are per witness (their queues are).
+// The witnesses may belong to other contexts of the same device: their builders must have finished (zkw_block_run returns after them).
+static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const* ws, const size_t* first, const size_t* count, size_t n_ws, zkw_trace* t, size_t first_slot) {
+    if (n_ws == 0) return ZKW_OK;
+    const u32 capacity = ws[0]->capacity;
     const size_t n_rows = t->n_rows;
+    size_t total = 0;
+    for (size_t k = 0; k < n_ws; k++) {
+        zkw_precompile_witness* w = ws[k];
+        if (!w || w->kind != ZKW_PRECOMPILE_ECRECOVER) return fail(ZKW_ERR_INVALID, "zkw_ecrecover_synthesize: not an ecrecover witness");
+        if (w->ctx->device != ctx->device || w->capacity != capacity) return fail(ZKW_ERR_INVALID, "zkw_ecrecover_synthesize: witnesses of another device or capacity");
+        if (first[k] + count[k] > w->n_instances) return fail(ZKW_ERR_INVALID, "instance range out of bounds");
+        total += count[k];
+    }
+    if (total > t->n_slots) return fail(ZKW_ERR_INVALID, "more instances (%zu) than trace slots (%zu)", total, t->n_slots);
+    if (t->n_cols < EK_COLS) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the ECRecover circuit needs %d (zkw_trace_create_with_columns)", t->n_cols, EK_COLS);
+    if (total == 0) return ZKW_OK;
     if (ec_used_rows(capacity) > n_rows) return fail(ZKW_ERR_INVALID, "capacity %u needs %zu rows, trace has %zu", capacity, ec_used_rows(capacity), n_rows);
     HIP_TRY(hipSetDevice(ctx->device));
-    ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
     const EcCached* ec = nullptr;
     ZKW_TRY(ec_get(ctx, &ec));
-    const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
+    std::vector<NlInstance> inst;
+    std::vector<size_t> w_of, start_of(n_ws + 1, 0);  // instance -> witness; witness -> its first instance of the call
+    for (size_t k = 0; k < n_ws; k++) {
+        zkw_precompile_witness* w = ws[k];
+        ZKW_TRY(precompile_closed_forms_with(ctx, w, nullptr, nullptr));  // on THIS call's context: the witness's own may be busy on another thread
+        const std::vector<NlInstance> one = nl_instances(first[k], count[k], capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot + inst.size());
+        inst.insert(inst.end(), one.begin(), one.end());
+        w_of.insert(w_of.end(), one.size(), k);
+        start_of[k + 1] = inst.size();
+    }
     const size_t ni = inst.size();
     u64* d_tape = nullptr;
     u32* d_status = nullptr;
@@ -1273,7 +1296,7 @@ extern "C" int zkw_ecrecover_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w,
     // the netlist's inputs come from the EC tapes: evaluate them inside the engine's `prepare` step
     ZKW_TRY(nl_synthesize_with(ctx, 7, [&](std::vector<NlPrepJob>& prep) {
         for (size_t k = 0; k < ni; k++)
-            jobs[k] = EcJob{w->mem_q, inst[k].first_round, inst[k].n_active, d_inputs + k * capacity * (size_t)128, d_tape + k * capacity * (size_t)EC_TAPE_PER_CYCLE,
+            jobs[k] = EcJob{ws[w_of[k]]->mem_q, inst[k].first_round, inst[k].n_active, d_inputs + k * capacity * (size_t)128, d_tape + k * capacity * (size_t)EC_TAPE_PER_CYCLE,
                             inst[k].t->data + inst[k].slot * inst[k].t->slot_elems(), prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
         ZKW_TRY(ctx->upload("ec_jobs", jobs, &d_jobs));
         { Prof _p(ctx, "k_ec_inputs"); hipLaunchKernelGGL(k_ec_inputs, dim3(capacity, nj), dim3(128), 0, ctx->stream, d_jobs); }
@@ -1298,16 +1321,36 @@ extern "C" int zkw_ecrecover_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w,
     }, inst, capacity, n_rows));
     u32 status = 0;
     ZKW_TRY(ctx->read_small(&status, d_status, 4));
-    if (status) return fail(ZKW_ERR_CHECK_FAILED, "zkw_ecrecover_synthesize: request %llu has no witness (the accumulator of the incomplete addition met x1 == x2)",
-                            (unsigned long long)(inst[(status - 1) >> 16].first_round + ((status - 1) & 0xFFFF)));
-    NlqQueues Q{};
-    Q.q[0] = NlqQueueIn{w->requests, w->req_tails, {0}, w->n_requests};
-    Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->n_queries};
-    memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
-    Q.round_ops = w->round_ops;
-    ZKW_TRY(nlq_synthesize(ctx, 7, Q, inst, capacity, n_rows));
+    if (status) return fail(ZKW_ERR_CHECK_FAILED, "zkw_ecrecover_synthesize: request %llu (instance %u of the call) has no witness (the accumulator of the incomplete addition met x1 == x2)",
+                            (unsigned long long)(inst[(status - 1) >> 16].first_round + ((status - 1) & 0xFFFF)), (unsigned)((status - 1) >> 16));
+    for (size_t k = 0; k < n_ws; k++) {  // the queue sections: per witness (its request and memory queues)
+        if (start_of[k + 1] == start_of[k]) continue;
+        zkw_precompile_witness* w = ws[k];
+        NlqQueues Q{};
+        Q.q[0] = NlqQueueIn{w->requests, w->req_tails, {0}, w->n_requests};
+        Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->n_queries};
+        memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
+        Q.round_ops = w->round_ops;
+        const std::vector<NlInstance> sub(inst.begin() + start_of[k], inst.begin() + start_of[k + 1]);
+        ZKW_TRY(nlq_synthesize(ctx, 7, Q, sub, capacity, n_rows));
+    }
     { Prof _p(ctx, "k_ec_stream"); hipLaunchKernelGGL(k_ec_stream, dim3((EC_ROWS_PER_CYCLE + 63) / 64, capacity, nj), dim3(64), 0, ctx->stream, ec->dev, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL); }
     return launch_check("k_ec_stream");
+}
+
+extern "C" int zkw_ecrecover_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances, zkw_trace* t, size_t first_slot) {
+    if (!ctx || !w || !t || w->ctx != ctx || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_ecrecover_synthesize: bad argument");
+    return ecrecover_synthesize_many(ctx, &w, &first_instance, &n_instances, 1, t, first_slot);
+}
+// every instance of every witness (one per block), in order, into slots first_slot ..: see ecrecover_synthesize_many
+extern "C" int zkw_ecrecover_synthesize_multi(zkw_ctx* ctx, zkw_precompile_witness* const* witnesses, size_t n_witnesses, zkw_trace* t, size_t first_slot) {
+    if (!ctx || !t || (n_witnesses && !witnesses) || t->ctx->device != ctx->device) return fail(ZKW_ERR_INVALID, "zkw_ecrecover_synthesize_multi: bad argument");
+    std::vector<size_t> first(n_witnesses, 0), count(n_witnesses, 0);
+    for (size_t k = 0; k < n_witnesses; k++) {
+        if (!witnesses[k]) return fail(ZKW_ERR_INVALID, "zkw_ecrecover_synthesize_multi: null witness");
+        count[k] = witnesses[k]->n_instances;
+    }
+    return ecrecover_synthesize_many(ctx, witnesses, first.data(), count.data(), n_witnesses, t, first_slot);
 }
 extern "C" int zkw_ecrecover_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)

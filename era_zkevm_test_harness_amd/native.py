@@ -150,6 +150,7 @@ SYMBOLS = [
     ("zkw_linear_hasher_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_keccak_round_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_ecrecover_synthesize", _int, [_vp, _vp, _sz, _sz, _vp, _sz]),
+    ("zkw_ecrecover_synthesize_multi", _int, [_vp, _vp, _sz, _vp, _sz]),
     ("zkw_ecrecover_check_satisfied", _int, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     ("zkw_storage_application_build", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     ("zkw_storage_application_witness_num_instances", _sz, [_vp]),
@@ -216,6 +217,7 @@ SYMBOLS = [
     ("zkw_block_timings", _int, [_vp, C.c_char_p, _sz, _vp, _vp, _sz, C.POINTER(_sz)]),
     ("zkw_block_synthesize", _int, [_vp, _sz, _sz, _vp, _vp, C.POINTER(_sz)]),
     ("zkw_block_synthesize_sharded", _int, [_vp, _sz, _sz, _int, _int, _vp, _vp, C.POINTER(_sz)]),
+    ("zkw_blocks_synthesize", _int, [_vp, _sz, _sz, _sz, _sz, _vp, _vp, C.POINTER(_sz)]),
     ("zkw_block_gather_closed_form_inputs", _int, [_vp, _vp, _int, _int, _int, _vp, _sz, C.POINTER(_sz)]),
 ]
 
@@ -1542,6 +1544,7 @@ class VmTrace:
 # ---- one block (zkw_block_run): the post-VM half of create_artifacts_from_tracer inside the library ------------------
 STORAGE_TREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
 CIRCUIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint8, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64))
+BLOCKS_CIRCUIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_uint8, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64))
 
 
 class BlockInputs(C.Structure):
@@ -1780,6 +1783,33 @@ class Block:
         cb = CIRCUIT_FN(_cb)
         n = C.c_size_t(0)
         rc = load().zkw_block_synthesize_sharded(self.handle, n_rows, ring_slots, rank, world, C.cast(cb, C.c_void_p), None, C.byref(n))
+        if err:
+            raise err[0]
+        _check(rc)
+        return n.value
+
+    @staticmethod
+    def synthesize_many(blocks, n_rows, ring_slots=1, ec_chunk=32, callback=None):
+        """zkw_blocks_synthesize: every instance of every block (None entries skipped); the ECRecover instances of all blocks in joint
+        calls of at most ec_chunk instances. callback(block_index, circuit_type, instance, trace_handle, slot, public_input[4]) may be
+        called from several library threads. Returns the number of instances synthesized."""
+        mine = [b for b in blocks if b is not None]
+        if not mine:
+            return 0
+        err = []
+
+        def _cb(_user, blk, ctype, inst, trace, slot, pi):
+            try:
+                if callback is not None:
+                    callback(int(blk), int(ctype), int(inst), trace, int(slot), [int(pi[i]) for i in range(4)])
+                return 0
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                return 1
+        cb = BLOCKS_CIRCUIT_FN(_cb) if callback is not None else None
+        ptrs = (C.c_void_p * len(mine))(*[b.handle for b in mine])
+        n = C.c_size_t(0)
+        rc = load().zkw_blocks_synthesize(ptrs, len(mine), n_rows, ring_slots, ec_chunk, C.cast(cb, C.c_void_p) if cb is not None else None, None, C.byref(n))
         if err:
             raise err[0]
         _check(rc)

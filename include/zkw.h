@@ -634,6 +634,10 @@ int zkw_keccak_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t sl
    (>= 197 632: the tables). Context scratch: 4 MB of value tape per request of the call. */
 int zkw_ecrecover_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t first_instance, size_t n_instances, zkw_trace *t,
                              size_t first_slot);
+/* Every instance of every witness (e.g. one ECRecover witness per block), in order, into slots first_slot ..: ONE launch of every EC
+   kernel over all of them. The witnesses may belong to other contexts of ctx's device; their builders must have finished. */
+int zkw_ecrecover_synthesize_multi(zkw_ctx *ctx, zkw_precompile_witness *const *witnesses, size_t n_witnesses, zkw_trace *t,
+                                   size_t first_slot);
 int zkw_ecrecover_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t slot, uint32_t capacity, uint64_t *n_violations,
                                   uint64_t *first_bad);
 
@@ -1076,6 +1080,16 @@ int zkw_block_synthesize(zkw_block *b, size_t n_rows, size_t ring_slots, zkw_cir
    only the instances zkw_shard_lpt gives it (the plan covers the block's synthesizable instances in emission order). */
 int zkw_block_synthesize_sharded(zkw_block *b, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb,
                                  void *user, size_t *n_done);
+/* K blocks at once (after zkw_blocks_run): every synthesizable instance of every block. Differs from K calls of zkw_block_synthesize in
+   two ways: the ECRecover instances of ALL blocks are synthesized in joint calls (zkw_ecrecover_synthesize_multi: at most ec_chunk
+   instances each, 0 = 32, into a ring of their own) — a request's accumulator chain costs ~13 ms per call whatever the batch —, and the
+   other types run block by block on up to eight threads of the library, each block on its own ring of ring_slots slots. cb (may be NULL)
+   is called from those threads, possibly concurrently, with the block's index; per block the order is the reference's emission order
+   except that ECRecover instances arrive on their own. */
+typedef int (*zkw_blocks_circuit_fn)(void *user, size_t block, uint8_t circuit_type, size_t instance, const zkw_trace *trace, size_t slot,
+                                     const uint64_t public_input[4]);
+int zkw_blocks_synthesize(zkw_block *const *blocks, size_t n_blocks, size_t n_rows, size_t ring_slots, size_t ec_chunk,
+                          zkw_blocks_circuit_fn cb, void *user, size_t *n_done);
 /* The one collective of the multi-GPU path: per owned instance the record [circuit_type, instance, compact closed-form
    input (18), public input (4)] (24 words) is gathered to `root` over `comm` (RCCL), which receives them in emission
    order in out[n_records][24] (host) for the recursion-queue replay (postprocessing/mod.rs:396-402). Collective. */

@@ -290,6 +290,50 @@ def test_blocks_run_many_at_once(ctx, oracle):
         m.free()
 
 
+def test_blocks_synthesize_many_equals_block_by_block(ctx):
+    """zkw_blocks_synthesize (the ECRecover instances of all blocks in joint calls, the other types block by block on the library's
+    threads): every trace it hands out is the trace zkw_block_synthesize hands out for the same (block, type, instance) — compared by a
+    digest of all cells — and satisfies its circuit; a chunk smaller than the total splits the joint calls"""
+    import hashlib
+    import threading
+
+    from era_zkevm_test_harness_amd import block as blk, native as nv
+
+    caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
+    bs = [synthetic.block_after_vm(seed=40 + k, n_vm_memory=1200 + 300 * k, n_storage=50 + 20 * k) for k in range(4)]
+    many = nv.Block.run_many(0, bs, caps)
+    n_rows = 1 << 18
+    lib = nv.load()
+
+    def digest(trace, slot, ctype):
+        # the circuit's own columns (a ring is as wide as the widest type: the columns beyond a type's width belong to nobody)
+        cols, rows = int(nv.circuit_layout(ctype)["num_columns"]), lib.zkw_trace_num_rows(trace)
+        a = np.zeros((cols, rows), np.uint64)
+        nv._check(lib.zkw_trace_get(trace, slot, 0, cols, a.ctypes.data))
+        return hashlib.sha256(a.tobytes()).hexdigest()
+
+    ref = {}
+    for bi, m in enumerate(many):
+        m.synthesize(n_rows, ring_slots=2, callback=lambda t, i, tr, s, pi, bi=bi: ref.__setitem__((bi, t, i), (digest(tr, s, t), tuple(pi))))
+    got, bad, lock = {}, [], threading.Lock()
+
+    def cb(bi, t, i, tr, s, pi):
+        d, v = digest(tr, s, t), many[bi].check_satisfied(t, tr, s)[0]
+        with lock:
+            got[(bi, t, i)] = (d, tuple(pi))
+            bad.append(v)
+    for chunk in (32, 3):  # 3 < the blocks' ECRecover instances together: several joint calls
+        got.clear()
+        n = nv.Block.synthesize_many(many, n_rows, ring_slots=2, ec_chunk=chunk, callback=cb)
+        assert n == len(ref) == len(got), (chunk, n, len(ref), len(got))
+        assert got == ref, [k for k in ref if got.get(k) != ref[k]][:5]
+    assert not any(bad)
+    assert sum(1 for k in ref if k[1] == 7) >= 4  # ECRecover instances of several blocks went through the joint calls
+    for m in many:
+        m.free()
+
+
 def test_blocks_run_sharded_and_gather_two_ranks_over_tcp(ctx):
     """zkw_blocks_run_sharded + zkw_blocks_gather_closed_form_inputs with world = 2 on one GPU: two host threads are the two
     ranks (the socket transport of zkw_comm between them), each builds only its round-robin share of five blocks, and the root

@@ -119,8 +119,13 @@ if fb:
       f"{fb['speedup_vs_cpu']:.2f}x.")
     if fb.get("batched"):
         bt = fb["batched"]
-        w(f"* batched full-block leg: **{bt['blocks_per_s']:.1f} blocks/s** with {bt['blocks']} blocks in flight (builders {bt['builders_ms']:.0f} ms, "
-          f"synthesis of {bt['instances_synthesized']} instances {bt['synthesis_ms']:.0f} ms, release {bt['release_ms']:.0f} ms).")
+        if "builders_ms_per_batch" in bt:
+            w(f"* batched full-block leg: **{bt['blocks_per_s']:.1f} blocks/s** = {bt['synthesized_circuits_per_s']:.0f} circuits/s over {bt['batches']} batches of "
+              f"{bt['blocks_per_gpu_in_flight']} blocks in flight ({bt['schedule']}): builders {bt['builders_ms_per_batch']} ms, synthesis {bt['synthesis_ms_per_batch']} ms, "
+              f"release {bt['release_ms_per_batch']} ms per batch.")
+        else:
+            w(f"* batched full-block leg: **{bt['blocks_per_s']:.1f} blocks/s** with {bt['blocks']} blocks in flight (builders {bt['builders_ms']:.0f} ms, "
+              f"synthesis of {bt['instances_synthesized']} instances {bt['synthesis_ms']:.0f} ms, release {bt['release_ms']:.0f} ms).")
     if bench.get("hash_circuits"):
         w("* netlist circuits at the reference geometry (2^20 rows; circuits/s into slots that already hold the layout; cold rates in the JSON): " + ", ".join(
             f"{k} {v['circuits_per_s']:.0f} (capacity {v['capacity']})" for k, v in bench["hash_circuits"].items()) + ".")

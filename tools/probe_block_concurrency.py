@@ -15,8 +15,7 @@ for r in range(reps):
     t0 = time.perf_counter()
     bs = nv.Block.run_many(0, blocks)
     t1 = time.perf_counter()
-    with ThreadPoolExecutor(8) as ex:
-        n = sum(ex.map(lambda b: b.synthesize(1 << 20, ring_slots=1), bs))
+    n = nv.Block.synthesize_many(bs, 1 << 20, ring_slots=1)
     t2 = time.perf_counter()
     spans = {}
     for name, s, e in bs[0].timings():

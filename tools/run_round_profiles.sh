@@ -9,17 +9,17 @@ mkdir -p "$OUT"
 OUT=$(cd "$OUT" && pwd)
 export TMPDIR=/tmp
 # 1. the default bench (throughput leg + full-block leg + CPU legs), without a profiler
-timeout -s KILL 1200 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-timeout -s KILL 900 python bench.py --pipelines 1 --no-cpu-baseline --no-full-block --no-h2d > "$OUT/bench_sequential.json" 2> "$OUT/bench_sequential.err"
+timeout -s KILL 1500 python bench.py --steps 20 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+timeout -s KILL 900 python bench.py --pipelines 1 --no-cpu-baseline --no-full-block --no-h2d --no-sensitivity > "$OUT/bench_sequential.json" 2> "$OUT/bench_sequential.err"
 # 2. the same command under rocprofv3 --kernel-trace --stats
 cd /tmp && rm -rf /tmp/prof_stats && timeout -s KILL 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- \
-    python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_default_under_rocprofv3.json" 2> "$OUT/rocprof_stats.err"
+    env ZKW_BATCHED_BLOCKS=48 python "$ROOT/bench.py" --no-cpu-baseline --no-sensitivity > "$OUT/bench_default_under_rocprofv3.json" 2> "$OUT/rocprof_stats.err"
 cp "$(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1)" "$OUT/bench_default_kernel_stats.csv"
 # 3. HBM counters AT THE BENCHMARKED BATCH, one pass each (never combined with other trace domains): one timed step of the
 #    sequential form (counter collection serialises the dispatches anyway)
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_BUSY_CYCLES; do
     rm -rf /tmp/prof_pmc && timeout -s KILL 1500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_pmc -- \
-        python "$ROOT/bench.py" --pipelines 1 --steps 1 --warmup 0 --no-cpu-baseline --no-full-block --no-h2d > "$OUT/bench_pmc_$C.json" 2> "$OUT/rocprof_pmc_$C.err"
+        python "$ROOT/bench.py" --pipelines 1 --steps 1 --warmup 0 --no-cpu-baseline --no-full-block --no-h2d --no-sensitivity --no-validate > "$OUT/bench_pmc_$C.json" 2> "$OUT/rocprof_pmc_$C.err"
     python3 - "$(ls /tmp/prof_pmc/*/*counter_collection.csv | head -1)" "$OUT/bench_pmc_$C.summary.csv" <<'PY'
 import collections, csv, sys
 tot, disp = collections.defaultdict(float), collections.defaultdict(set)
