@@ -149,17 +149,16 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     return best, blk
 
 
-def full_blocks_batched(local_rank, blk, K=96, rounds=4, rank=0, world=1, comm=None):
+def full_blocks_batched(local_rank, blk, K=96, rounds=3, rank=0, world=1, comm=None):
     """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once (zkw_blocks_run: one host thread per block; the
     chain service merges every block's Poseidon2 queue chains into shared launches, so K blocks cost about two chain passes instead of K),
     every synthesizable instance of every block into its trace (zkw_blocks_synthesize: the ECRecover instances of all blocks in joint calls,
-    the other types block by block on the library's threads), the blocks released. On one GPU the batches are PIPELINED: the builders of
-    batch k + 1 run (on a host thread) next to the synthesis of batch k; the figure is blocks of the timed batches over their wall time, the
+    the other types block by block on the library's threads), the blocks released; batch after batch (the builders of batch k + 1 next to
+    the synthesis of batch k were measured: 20.7 / 26.6 blocks/s at 48 / 96 in flight against 24.9 / 29.6 one after the other — the
+    synthesis starves next to the chains' high-priority streams). The figure is the blocks of the timed batches over their wall time, the
     first batch (which fills the library's buffer caches) untimed. With N GPUs the K x N blocks are sharded over the ranks by
     zkw_blocks_run_sharded (round-robin, nothing replicated) and every block's closed-form records are gathered to rank 0
     (zkw_blocks_gather_closed_form_inputs), batch after batch."""
-    import threading
-
     # ZKW_BATCHED_BLOCKS: 48 for runs under rocprofv3 (its interception crashes in hipMemcpyAsync under ~500 host threads: tools/run_round_profiles.sh)
     K = int(os.environ.get("ZKW_BATCHED_BLOCKS", K))
     distinct = [blk] + [synthetic.block_production(seed=2 + k) for k in range(3)]
@@ -190,30 +189,11 @@ def full_blocks_batched(local_rank, blk, K=96, rounds=4, rank=0, world=1, comm=N
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if world == 1:
+    for r in range(rounds):
         tb = time.perf_counter()
         cur = build()
         rep["builders_ms"].append((time.perf_counter() - tb) * 1e3)
-        for r in range(1, rounds):
-            box = []
-
-            def builder():
-                torch.cuda.set_device(local_rank)
-                t_ = time.perf_counter()
-                box.append(build())
-                rep["builders_ms"].append((time.perf_counter() - t_) * 1e3)
-            th = threading.Thread(target=builder)
-            th.start()
-            finish(cur, rep)
-            th.join()
-            cur = box[0]
         finish(cur, rep)
-    else:
-        for r in range(rounds):
-            tb = time.perf_counter()
-            cur = build()
-            rep["builders_ms"].append((time.perf_counter() - tb) * 1e3)
-            finish(cur, rep)
     torch.cuda.synchronize()
     parallel.barrier()
     wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
@@ -223,7 +203,7 @@ def full_blocks_batched(local_rank, blk, K=96, rounds=4, rank=0, world=1, comm=N
             "synthesized_circuits_per_s": n_all / wall, "wall_ms": wall * 1e3, "builders_ms_per_batch": r3(rep["builders_ms"]),
             "synthesis_ms_per_batch": r3(rep["synthesis_ms"]), "gather_ms_per_batch": r3(rep["gather_ms"]), "release_ms_per_batch": r3(rep["release_ms"]),
             "instances_synthesized": n_all, "records_gathered": rep["records"],
-            "schedule": "pipelined: builders of batch k + 1 next to the synthesis of batch k" if world == 1 else "batch after batch",
+            "schedule": "batch after batch: builders (zkw_blocks_run), synthesis (zkw_blocks_synthesize), release",
             "sharding": "one GPU" if world == 1 else "zkw_blocks_run_sharded (round-robin over ranks) + zkw_blocks_gather_closed_form_inputs"}
 
 

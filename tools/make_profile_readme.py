@@ -121,7 +121,7 @@ if fb:
         bt = fb["batched"]
         if "builders_ms_per_batch" in bt:
             w(f"* batched full-block leg: **{bt['blocks_per_s']:.1f} blocks/s** = {bt['synthesized_circuits_per_s']:.0f} circuits/s over {bt['batches']} batches of "
-              f"{bt['blocks_per_gpu_in_flight']} blocks in flight ({bt['schedule']}): builders {bt['builders_ms_per_batch']} ms, synthesis {bt['synthesis_ms_per_batch']} ms, "
+              f"{bt['blocks_per_gpu_in_flight']} blocks in flight (batch after batch): builders {bt['builders_ms_per_batch']} ms, synthesis {bt['synthesis_ms_per_batch']} ms, "
               f"release {bt['release_ms_per_batch']} ms per batch.")
         else:
             w(f"* batched full-block leg: **{bt['blocks_per_s']:.1f} blocks/s** with {bt['blocks']} blocks in flight (builders {bt['builders_ms']:.0f} ms, "
