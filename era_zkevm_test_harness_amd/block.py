@@ -132,5 +132,5 @@ def synthesize_and_check(ctx, artifacts, n_rows):
 
 def _pi_row(ctype, capacity):
     rows_per_cycle, off = {RAM_PERMUTATION: (6, 2), DECOMMITS_SORTER: (7, 3), LOG_DEMUXER: (12, 2), STORAGE_SORTER: (22, 5),
-                           EVENTS_SORTER: (22, 5), L1_MESSAGES_SORTER: (22, 5)}[ctype]
+                           EVENTS_SORTER: (13, 5), L1_MESSAGES_SORTER: (13, 5)}[ctype]
     return rows_per_cycle * ((capacity + 63) // 64 * 64) + off

@@ -174,8 +174,10 @@ static __global__ __launch_bounds__(64) void k_es_fill_queue(const EsSynthJob* _
             for (int k = 0; k < 4; k++) old[k] = ph[k];
         }
         es_queue_op(trace, n_rows, (size_t)R1 * rs + i, (size_t)(R1 + 1) * rs + i, (size_t)(R1 + 2) * rs + i, enc, old, out4);
-        if (!job.tail_clean) for (int r = 0; r < 3; r++)
-            for (int col = ES_G; col < ES_G + ES_L; col++) TR(col, (size_t)(R1 + r) * rs + i) = 0;
+        // (the rows' lookup cells — range checks of the record's bytes — are written by k_es_fill_row<NTV>, which runs after this kernel;
+        //  only the cells no lookup uses are cleared here: row R3 holds 6 of 8)
+        if (!job.tail_clean && WHICH == 2)
+            for (int col = ES_G + ES_NLOOK_R3; col < ES_G + ES_L; col++) TR(col, (size_t)(R1 + 2) * rs + i) = 0;
     } else if (i < rs) {
         if (!job.tail_clean) for (int r = 0; r < 3; r++) zero_gap_row_n(trace, n_rows, (size_t)(R1 + r) * rs + i, ES_G + ES_L);
     }
@@ -239,7 +241,7 @@ static __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __
                 else { cur.lc1 = lc; cur.rc1 = rc; cur.nl1 = nl; cur.nr1 = nr; prev.lhs1 = pl; prev.rhs1 = pr; cur.lhs1 = can_pop ? nl : pl; cur.rhs1 = can_pop ? nr : pr; }
             }
         }
-        if (ROW >= ES_ROW_N0 && ROW <= ES_ROW_N7) {
+        if (ROW == ES_ROW_NTV) {  // the relations that split the sorted record's encoding (the former rows N0..N7, T, V)
             const u32 rv[8] = {(u32)es[0], (u32)es[1], (u32)es[2], (u32)es[3], (u32)es[4], (u32)es[5], (u32)es[6], (u32)es[7]};
             const u32 kb[8] = {(u32)(es[0] >> 32), (u32)(es[1] >> 32), (u32)(es[2] >> 32), (u32)(es[3] >> 32), (u32)(es[4] >> 32),
                                (u32)(es[5] >> 32), (u32)(es[6] >> 32), (u32)(es[7] >> 32)};
@@ -248,13 +250,18 @@ static __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __
             ES_BYTES4(cur, rv4, rv[4]); ES_BYTES4(cur, rv5, rv[5]); ES_BYTES4(cur, rv6, rv[6]); ES_BYTES4(cur, rv7, rv[7]);
             ES_BYTES3(cur, kb0, kb[0]); ES_BYTES3(cur, kb1, kb[1]); ES_BYTES3(cur, kb2, kb[2]); ES_BYTES3(cur, kb3, kb[3]);
             ES_BYTES3(cur, kb4, kb[4]); ES_BYTES3(cur, kb5, kb[5]); ES_BYTES3(cur, kb6, kb[6]); ES_BYTES3(cur, kb7, kb[7]);
-        }
-        if (ROW == ES_ROW_T) { ES_BYTES4(cur, ts, ts); ES_BYTES3(cur, a16, (u32)(es[16] >> 32)); }
-        if (ROW == ES_ROW_V) {
+            ES_BYTES4(cur, ts, ts); ES_BYTES3(cur, a16, (u32)(es[16] >> 32));
             cur.tx = (u32)es[17];
             ES_BYTES4(cur, tx, (u32)es[17]);
             cur.a19 = (es[17] >> 32) & 0xFF; cur.aux = (es[17] >> 40) & 0xFF; cur.shard = (es[17] >> 48) & 0xFF;
             cur.rw = es[18] & 1; cur.sv = (es[18] >> 1) & 1;
+            // the 70 bytes are range-checked in the lookup columns of the nine Poseidon2 rows (eight per row: the flattened gate leaves
+            // them free); this kernel runs after the queue kernels and owns those cells
+#define ES_LOOKROW(R) { const size_t row = (size_t)ES_ROW_##R * rs + i; ES_LOOK_##R(ES_XL) }
+#define ES_XL(col, v) { TR(col, row) = cur.v; atomicAdd(&sh_hist[(u32)cur.v & 0xFF], 1u); }
+            ES_LOOKROW(U1) ES_LOOKROW(U2) ES_LOOKROW(U3) ES_LOOKROW(S1) ES_LOOKROW(S2) ES_LOOKROW(S3) ES_LOOKROW(R1) ES_LOOKROW(R2) ES_LOOKROW(R3)
+#undef ES_XL
+#undef ES_LOOKROW
         }
         if (ROW == ES_ROW_W) {
             const u64 t = (u64)ts - (u64)c.p_kts;  // wraps below zero
@@ -298,13 +305,11 @@ static __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __
             ES_SET20(prev, ne, pne); ES_SET20(cur, ne, one);
         }
 #define ES_ROWCASE(R) if (ROW == ES_ROW_##R) { ES_FILL_##R(ES_XC, ES_XP, ES_XG, ES_XC) }
-        ES_ROWCASE(A) ES_ROWCASE(N0) ES_ROWCASE(N1) ES_ROWCASE(N2) ES_ROWCASE(N3) ES_ROWCASE(N4) ES_ROWCASE(N5) ES_ROWCASE(N6) ES_ROWCASE(N7)
-        ES_ROWCASE(T) ES_ROWCASE(V) ES_ROWCASE(W) ES_ROWCASE(Q)
+        ES_ROWCASE(A) ES_ROWCASE(NTV) ES_ROWCASE(W) ES_ROWCASE(Q)
 #undef ES_ROWCASE
-        constexpr int NSL[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, ES_NSLOTS_A, ES_NSLOTS_N0, ES_NSLOTS_N1, ES_NSLOTS_N2, ES_NSLOTS_N3, ES_NSLOTS_N4,
-                               ES_NSLOTS_N5, ES_NSLOTS_N6, ES_NSLOTS_N7, ES_NSLOTS_T, ES_NSLOTS_V, ES_NSLOTS_W, ES_NSLOTS_Q};
-        constexpr int NLK[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, ES_NLOOK_A, ES_NLOOK_N0, ES_NLOOK_N1, ES_NLOOK_N2, ES_NLOOK_N3, ES_NLOOK_N4,
-                               ES_NLOOK_N5, ES_NLOOK_N6, ES_NLOOK_N7, ES_NLOOK_T, ES_NLOOK_V, ES_NLOOK_W, ES_NLOOK_Q};
+        constexpr int NSL[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, ES_NSLOTS_A, ES_NSLOTS_NTV, ES_NSLOTS_W, ES_NSLOTS_Q};
+        constexpr int NLK[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, ES_NLOOK_A, ES_NLOOK_NTV, ES_NLOOK_W, ES_NLOOK_Q};
+        static_assert(ES_ROW_Q == 12 && ES_ROW_A == 9, "row order of the generated spec");
         if (!job.tail_clean) for (int col = NSL[ROW]; col < ES_G; col++) TR(col, row) = 0;
         if (!job.tail_clean) for (int col = ES_G + NLK[ROW]; col < ES_G + ES_L; col++) TR(col, row) = 0;
         for (int col = ES_G; col < ES_G + NLK[ROW]; col++) atomicAdd(&sh_hist[(u32)TR(col, row) & 0xFF], 1u);

@@ -995,8 +995,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
     ZKW_TRY(launch_check("k_es_fill_queue<2>"));
 #define ES_LAUNCH_ROW(R) { Prof _p(ctx, "k_es_fill_row"); hipLaunchKernelGGL((k_es_fill_row<ES_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
     ZKW_TRY(launch_check("k_es_fill_row<" #R ">"));
-    ES_LAUNCH_ROW(A) ES_LAUNCH_ROW(N0) ES_LAUNCH_ROW(N1) ES_LAUNCH_ROW(N2) ES_LAUNCH_ROW(N3) ES_LAUNCH_ROW(N4) ES_LAUNCH_ROW(N5)
-    ES_LAUNCH_ROW(N6) ES_LAUNCH_ROW(N7) ES_LAUNCH_ROW(T) ES_LAUNCH_ROW(V) ES_LAUNCH_ROW(W) ES_LAUNCH_ROW(Q)
+    ES_LAUNCH_ROW(A) ES_LAUNCH_ROW(NTV) ES_LAUNCH_ROW(W) ES_LAUNCH_ROW(Q)  // NTV after the queue kernels: it writes the range checks into their rows' lookup columns
 #undef ES_LAUNCH_ROW
     { Prof _p(ctx, "k_es_fill_tail"); hipLaunchKernelGGL(k_es_fill_tail, dim3(nj * ((ES_G + ES_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_es_fill_tail"));

@@ -211,15 +211,14 @@ int orc_events_sorter_synthesize(const zkw_events_sorter_instance *inst, const z
             for (int k = 0; k < 20; k++) on[k] = can_pop ? cn[k] : pn[k];
             SET20(cur, ne, on);
         }
-        /* scatter (the Poseidon rows' gate cells are in place; they have no lookup cells in use) */
+        /* scatter (the Poseidon rows' gate cells are in place; their lookup columns carry the range checks of the record's 70 bytes,
+           whose relations are row NTV's: tools/gen_events_sorter_circuit.py) */
 #define ROWAT(R) const size_t row = (size_t)(R) * rs + i;
         { ROWAT(ES_ROW_A) ES_FILL_A(XC, XP, XG, XC) }
-        { ROWAT(ES_ROW_N0) ES_FILL_N0(XC, XP, XG, XC) } { ROWAT(ES_ROW_N1) ES_FILL_N1(XC, XP, XG, XC) }
-        { ROWAT(ES_ROW_N2) ES_FILL_N2(XC, XP, XG, XC) } { ROWAT(ES_ROW_N3) ES_FILL_N3(XC, XP, XG, XC) }
-        { ROWAT(ES_ROW_N4) ES_FILL_N4(XC, XP, XG, XC) } { ROWAT(ES_ROW_N5) ES_FILL_N5(XC, XP, XG, XC) }
-        { ROWAT(ES_ROW_N6) ES_FILL_N6(XC, XP, XG, XC) } { ROWAT(ES_ROW_N7) ES_FILL_N7(XC, XP, XG, XC) }
-        { ROWAT(ES_ROW_T) ES_FILL_T(XC, XP, XG, XC) }
-        { ROWAT(ES_ROW_V) ES_FILL_V(XC, XP, XG, XC) }
+        { ROWAT(ES_ROW_NTV) ES_FILL_NTV(XC, XP, XG, XC) }
+        { ROWAT(ES_ROW_U1) ES_LOOK_U1(XC) } { ROWAT(ES_ROW_U2) ES_LOOK_U2(XC) } { ROWAT(ES_ROW_U3) ES_LOOK_U3(XC) }
+        { ROWAT(ES_ROW_S1) ES_LOOK_S1(XC) } { ROWAT(ES_ROW_S2) ES_LOOK_S2(XC) } { ROWAT(ES_ROW_S3) ES_LOOK_S3(XC) }
+        { ROWAT(ES_ROW_R1) ES_LOOK_R1(XC) } { ROWAT(ES_ROW_R2) ES_LOOK_R2(XC) } { ROWAT(ES_ROW_R3) ES_LOOK_R3(XC) }
         { ROWAT(ES_ROW_W) ES_FILL_W(XC, XP, XG, XC) }
         { ROWAT(ES_ROW_Q) ES_FILL_Q(XC, XP, XG, XC) }
         prev = cur;

@@ -50,7 +50,7 @@ def decommit_sorter_tampers(capacity):
 
 
 def events_sorter_tampers(capacity):
-    return section_tampers("zkw_events_sorter_circuit_spec.h", "ES", 22, capacity,
+    return section_tampers("zkw_events_sorter_circuit_spec.h", "ES", 13, capacity,
                            extra=(("previous-record flag", "BND_IN_valid", "BND_IN"), ("handed-over previous key", "BND_OUT_kts", "BND_OUT"),
                                   ("previous record's normalised encoding (register)", "BND_IN_ne3", "BND_IN"), ("its re-derivation from the FSM input", "NIE_NI_ne9", "NIE"),
                                   ("a key byte of the FSM input's previous_item", "NIB1_NI_w7_b2", "NIB1"), ("a limb of the handed-over previous_item", "NOB0_NO_w5", "NOB0"),

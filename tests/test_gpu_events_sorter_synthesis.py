@@ -72,7 +72,7 @@ def test_gpu_checker_flags_tampering(ctx, oracle):
     assert ctx.check_if_satisfied_events_sorter(t, 0, capacity)[0] == 0
     host = t.get(0)
     rng = np.random.default_rng(2)
-    used = np.argwhere(host[:138, :22 * 64 + 56] != 0)
+    used = np.argwhere(host[:138, :13 * 64 + 56] != 0)
     base = native.load().zkw_trace_device_ptr(t.handle, 0)
     hip = C.CDLL("libamdhip64.so")
     for _ in range(25):

@@ -9,7 +9,7 @@ import pytest
 from era_zkevm_test_harness_amd import synthetic
 
 P = 0xFFFFFFFF00000001
-ROWS_PER_CYCLE = 22
+ROWS_PER_CYCLE = 13
 
 
 def _bnd(capacity):
@@ -82,5 +82,5 @@ def test_closed_form_section(oracle):
     n = o["instances"].size
     assert n >= 3
     check_section(lambda i: oracle.events_sorter_synthesize(o, i, capacity, n_rows), lambda t: oracle.events_sorter_check(t, capacity),
-                  oracle.events_sorter_public_inputs(o["instances"])[1], "zkw_events_sorter_circuit_spec.h", "ES", 22, capacity, n,
+                  oracle.events_sorter_public_inputs(o["instances"])[1], "zkw_events_sorter_circuit_spec.h", "ES", 13, capacity, n,
                   events_sorter_tampers(capacity), challenges=o["challenges"].reshape(2, 21))

@@ -7,7 +7,12 @@ Geometry of the reference wrapper (circuit_definitions/.../base_layer/events_sor
 src/witness/individual_circuits/events_sort_dedup.rs:16-580. The circuit body lives in the absent crate
 era-zkevm_circuits, so gate placement is OUR design ("parity unpinned" at the trace-layout level).
 
-Statement, per cycle (21 rows, region-major): pop the unsorted and the sorted log queue in lock step — a 4-wide queue
+Rows per cycle: 13 (round 5; 22 before — the reference's own placement uses 590 817 rows for 31 287 cycles = 18.9 per cycle, ours was
+looser). The ten sparse rows N0-N7, T, V (seven range-checked bytes and three linear relations each) are ONE row NTV now: its 123 cells
+are the relations' operands, and the 70 bytes are range-checked in the lookup columns of the nine Poseidon2 rows (8 per row), which
+the flattened gate leaves unused; NTV holds copies of them.
+
+Statement, per cycle (region-major): pop the unsorted and the sorted log queue in lock step — a 4-wide queue
 hashes enc(20) || tail(4) in three permutations (circuit_encodings/src/lib.rs:179-221): rows U1-U3, S1-S3 —, multiply
 both grand-product accumulators (A, W = 20), split the sorted record's encoding far enough to (i) read timestamp and
 rollback flag and (ii) rebuild the encoding of its *normalised* form — read value, timestamp, aux byte, rw and
@@ -60,8 +65,16 @@ def build():
     S = [Row("S1"), Row("S2"), Row("S3")]
     R = [Row("R1"), Row("R2"), Row("R3")]
     A = Row("A")
-    N = [Row(f"N{k}") for k in range(8)]
-    T, V, W, Q = Row("T"), Row("V"), Row("W"), Row("Q")
+    NTV = Row("NTV")
+    N = [NTV] * 8   # (the relations of the former rows N0..N7, T, V all live in NTV)
+    T, V, W, Q = NTV, NTV, Row("W"), Row("Q")
+    p2_rows = U + S + R
+    byte_home = []  # the range checks ride in the Poseidon2 rows' lookup columns, eight per row
+
+    def range_checked(b):
+        prow = p2_rows[len(byte_home) // dsl.L]
+        prow.lookup(b)
+        byte_home.append(b)
     BIN, BOUT, PI = Row("BND_IN", False), Row("BND_OUT", False), Row("PI", False)
     F = [Row("F1", False), Row("F2", False), Row("F3", False)]
 
@@ -97,7 +110,7 @@ def build():
         lo = [f"rv{k}_b{j}" for j in range(4)]
         hi = [f"kb{k}_b{j}" for j in range(3)]
         for b in lo + hi:
-            row.lookup(b)
+            range_checked(b)
         row.c([(1, [f"rv{k}"])] + [(-(1 << (8 * j)), [lo[j]]) for j in range(4)], f"rv{k} = sum bytes")
         row.c([(1, [es[k]]), (-1, [f"rv{k}"])] + [(-(1 << (32 + 8 * j)), [hi[j]]) for j in range(3)], f"es{k} = rv{k} + key bytes")
         row.c([(1, [cn[k]]), (-1, [es[k]]), (1, [f"rv{k}"])], f"cn{k} = es{k} without the read value")
@@ -106,7 +119,7 @@ def build():
     tb = [f"ts_b{j}" for j in range(4)]
     ab = [f"a16_b{j}" for j in range(3)]
     for b in tb + ab:
-        T.lookup(b)
+        range_checked(b)
     T.c([(1, ["ts"])] + [(-(1 << (8 * j)), [tb[j]]) for j in range(4)], "ts = sum bytes")
     T.c([(1, [es[16]]), (-1, ["ts"])] + [(-(1 << (32 + 8 * j)), [ab[j]]) for j in range(3)], "es16 = ts + address bytes")
     T.c([(1, [cn[16]]), (-1, [es[16]]), (1, ["ts"])], "cn16 = es16 without the timestamp")
@@ -116,7 +129,7 @@ def build():
     # ---------------- row V: es17 = tx number + address byte 19 << 32 + aux byte << 40 + shard << 48; flags
     xb = [f"tx_b{j}" for j in range(4)]
     for b in xb + ["a19", "aux", "shard"]:
-        V.lookup(b)
+        range_checked(b)
     V.c([(1, ["tx"])] + [(-(1 << (8 * j)), [xb[j]]) for j in range(4)], "tx = sum bytes")
     V.c([(1, [es[17]]), (-1, ["tx"]), (-(1 << 32), ["a19"]), (-(1 << 40), ["aux"]), (-(1 << 48), ["shard"])], "es17")
     V.c([(1, [cn[17]]), (-1, [es[17]]), (1 << 40, ["aux"])], "cn17 = es17 without the aux byte")
@@ -265,7 +278,8 @@ def build():
     cf.rows[pos:pos] = SEL.rows  # fill order: a row's copies come from rows before it (or from the register rows)
     build.cf = cf
 
-    rows = U + S + R + [A] + N + [T, V, W, Q, BIN, BOUT] + F + [PI] + cf.rows
+    assert len(byte_home) == 70 and len(NTV.slots) <= dsl.G, (len(byte_home), len(NTV.slots))
+    rows = U + S + R + [A, NTV, W, Q, BIN, BOUT] + F + [PI] + cf.rows
     return rows, regs
 
 
@@ -370,6 +384,8 @@ def emit_scatter(rows, path, prefix):
             base = v.split(".", 1)[1] if kind != "XC" else v
             ent.append(f"{kind}({r.slot(v)}, {base})")
         lines.append(f"#define {prefix}_FILL_{r.name}(XC, XP, XG, XX) " + " ".join(ent))
+        if r.lookups:  # the row's lookup cells alone (the Poseidon2 rows: their 130 gate cells are written by the permutation itself)
+            lines.append(f"#define {prefix}_LOOK_{r.name}(XC) " + " ".join(f"XC({r.slot(v)}, {v})" for v in r.lookups))
     txt = open(path).read()
     txt = txt.replace("\n#endif\n", "\n" + "\n".join(lines) + "\n#endif\n")
     open(path, "w").write(txt)
