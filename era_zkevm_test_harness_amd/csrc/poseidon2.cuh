@@ -429,6 +429,11 @@ __device__ __forceinline__ u64 coop_flattened(const Coop& co, u64 x, u32 g, Put&
 // internal layer stay inside the lane, and the three elements of a lane give the in-order wave three
 // independent S-box chains to interleave. ~8.1k instructions per permutation step for 16 states, against
 // ~5.9k for 4 states in the row-of-16 form above.
+#if defined(P2_Q4_PARTIAL_SCHED)
+#define Q4_PARTIAL_MUL gl::mul_sched
+#else
+#define Q4_PARTIAL_MUL gl::mul_lat
+#endif
 #if defined(P2_Q4_FULL_CYC)
 #define Q4_FULL_POW7 gl::pow7
 #else
@@ -510,9 +515,9 @@ struct Coop4 {
             // the round's one S-box on two lanes of the quad, as in the row form (Coop::pow7_pair): lane 0 goes on to the cube while
             // lane 1 squares again — three multiplications per partial round instead of four for the whole wave
             const u64 t0 = dpp64<QP_BCAST0>(gl::add_canon(x[0], rc));
-            const u64 x2 = gl::mul_lat(t0, t0);
-            const u64 y = gl::mul_lat(x2, second ? x2 : t0);
-            const u64 sx = gl::mul_lat(y, dpp64<QP_SWAP1>(y));
+            const u64 x2 = Q4_PARTIAL_MUL(t0, t0);
+            const u64 y = Q4_PARTIAL_MUL(x2, second ? x2 : t0);
+            const u64 sx = Q4_PARTIAL_MUL(y, dpp64<QP_SWAP1>(y));
             x[0] = first ? sx : x[0];
             internal(x);
         }

@@ -80,6 +80,16 @@ for k in sorted(tot, key=lambda k: -tot[k])[:8]:
         print(f"{sys.argv[2]}{' x2' if scale > 1024 else ''} {k} {len(disp[k])} dispatches {tot[k] / len(disp[k]) * scale / 1e9:.3g} GB per dispatch")
 PY
 done
+# 5c. the VALU ceiling: instruction classes at 1-8 waves per SIMD, the Goldilocks mixes counted by SQ_INSTS_VALU (class
+#     indices 32 gl::mul, 33 lane-form Poseidon2, 34 quad-form Poseidon2 of tools/ubench_valu_ceiling.hip), the multiplication variants
+if [ -x tools/ubench_valu_ceiling ]; then
+    timeout -s KILL 600 tools/ubench_valu_ceiling > "$OUT/valu_ceiling_raw.json" 2> /dev/null
+    for m in 32 33 34; do
+        rm -rf /tmp/pvc_$m && (cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pvc_$m -- "$ROOT/tools/ubench_valu_ceiling" $m > /dev/null 2>&1)
+        cp "$(ls /tmp/pvc_$m/*/*counter_collection.csv | head -1)" "$OUT/valu_ceiling_pmc_$m.csv"
+    done
+fi
+[ -x tools/ubench_glmul ] && timeout -s KILL 300 tools/ubench_glmul > "$OUT/glmul_variants.json" 2> "$OUT/glmul_variants_checks.txt"
 # 6. the hardware probes behind DESIGN.md 3.2
 (cd tools && for b in probe_wave_placement probe_clock_regime ubench_perm; do [ -x ./$b ] && { echo "== $b"; timeout -s KILL 300 ./$b; }; done) > "$OUT/hardware_probes.txt" 2>&1
 (cd tools && for b in probe_hw_queues2; do [ -x ./$b ] && { echo "== $b (default environment)"; timeout -s KILL 120 ./$b; echo "== $b (GPU_MAX_HW_QUEUES=8)"; GPU_MAX_HW_QUEUES=8 timeout -s KILL 120 ./$b; }; done) > "$OUT/hw_queue_probes.txt" 2>&1

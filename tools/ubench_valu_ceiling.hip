@@ -10,7 +10,8 @@
 //   (4) p2::permute               Poseidon2, one state per lane           (the mix of k_ram_fill_poseidon)
 //   (5) p2::Coop4::permute        Poseidon2, one state per quad of lanes  (the mix of k_chain_full_q4)
 // with no memory traffic inside the timed loop. Modes 0-2 have a known instruction count (asm volatile, REP per iteration);
-// modes 3-5 are counted by `rocprofv3 --pmc SQ_INSTS_VALU` on this same binary (tools/run_round_profiles.sh valu_ceiling).
+// the last three classes (indices 32-34) are counted by `rocprofv3 --pmc SQ_INSTS_VALU` on this same binary (tools/run_round_profiles.sh step 5c,
+// tools/make_valu_ceiling.py).
 //
 // Occupancy is pinned: a launch is 256 CUs x W workgroups of 256 threads (one wave per SIMD each) and every workgroup asks for
 // 160 KiB / W of LDS, so at most W fit on a CU and all 256 x W are resident at once when the dispatcher spreads them evenly
