@@ -865,7 +865,7 @@ def main():
             """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate
             runs at the benchmarked batch, gfx950 FETCH correction applied: the newest profiles/rNN/traffic.json; counters cannot be read
             inside this process). Scaled by items per launch when this run's launch differs from the profiled one."""
-            path = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "traffic.json") for r_ in ("r04", "r03", "r02")) if os.path.exists(p_)), None)
+            path = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "traffic.json") for r_ in ("r06", "r05", "r04", "r03", "r02")) if os.path.exists(p_)), None)
             if path is None:
                 return None
             t = json.load(open(path))
