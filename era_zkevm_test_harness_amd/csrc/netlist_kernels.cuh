@@ -860,9 +860,10 @@ static __global__ __launch_bounds__(256) void k_nl_check_steps(const NlDev* __re
 }
 
 static __global__ __launch_bounds__(256) void k_nl_check_tail(const NlDev* __restrict__ devp, const u64* __restrict__ trace, u32 capacity, size_t n_rows,
-                                                       const u32* __restrict__ hist, CheckResult* res, u64 q_begin, u64 q_end, u64 e_begin, u64 e_end) {
+                                                       const u32* __restrict__ hist, CheckResult* res, u64 q_begin, u64 q_end, u64 e_begin, u64 e_end, u64 c_begin, u64 c_end) {
     // rows [q_begin, q_end): the queue section (netlist_queue_kernels.cuh checks its general-purpose cells; its lookup cells are zero);
-    // rows [e_begin, e_end): the EC section of the ECRecover circuit (ecrecover_kernels.cuh checks every cell of it)
+    // rows [e_begin, e_end): the EC section of the ECRecover circuit (ecrecover_kernels.cuh checks every cell of it);
+    // rows [c_begin, c_end): the closed-form section (netlist_closed_form_kernels.cuh: its general-purpose cells; lookup cells zero)
     const nl_spec& S = devp->s;
     const size_t bnd = NL_BOUNDARY_ROW(&S, capacity), brows = NL_BND_ROWS(&S);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -870,7 +871,7 @@ static __global__ __launch_bounds__(256) void k_nl_check_tail(const NlDev* __res
         if (NL_TR(S.mult_col, row) != (row < S.total_table_rows ? (u64)hist[row] : 0)) flag_bad(res, 5, 0, row);
         if (row < bnd || (row >= e_begin && row < e_end)) continue;
         const size_t off = row - bnd;
-        for (u32 col = (row >= q_begin && row < q_end) ? S.g : 0; col < S.mult_col; col++) {
+        for (u32 col = ((row >= q_begin && row < q_end) || (row >= c_begin && row < c_end)) ? S.g : 0; col < S.mult_col; col++) {
             bool allowed = false;
             if (off < 2 * brows) allowed = col < S.g && (off % brows) * S.g + col < S.state;
             else if (off == 2 * brows) allowed = col < 4;

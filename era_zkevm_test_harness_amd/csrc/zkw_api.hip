@@ -215,6 +215,12 @@ static void ctx_destroy_now(zkw_ctx* ctx) {
     if (ctx->pinned_rb) pin_free(ctx->pinned_rb);
     if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
     if (ctx->chain_ev_b) (void)hipEventDestroy(ctx->chain_ev_b);
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+        (void)hipEventDestroy(ctx->side_ev_fork);
+        (void)hipEventDestroy(ctx->side_ev_join);
+    }
     if (ctx->own_stream) {
         (void)hipStreamSynchronize(ctx->own_stream);
         stream_pool().release(ctx->own_stream);

@@ -76,6 +76,27 @@ struct zkw_ctx {
     int ptr_mode = ZKW_PTR_HOST;
     hipStream_t chain_stream = nullptr;  // optional second stream for the queue-chain kernels (zkw_set_chain_stream)
     hipEvent_t chain_ev_a = nullptr, chain_ev_b = nullptr;
+    // a lazily created side stream for work that depends on nothing the main stream is about to write (the closed-form sponges of the
+    // netlist circuits): fork = it waits for everything queued on `stream` so far, join = `stream` waits for it
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_ev_fork = nullptr, side_ev_join = nullptr;
+    int side_fork(hipStream_t* out) {
+        if (!side_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&side_ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&side_ev_join, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(side_ev_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(side_stream, side_ev_fork, 0));
+        *out = side_stream;
+        return ZKW_OK;
+    }
+    int side_join() {
+        if (!side_stream) return ZKW_OK;
+        HIP_TRY(hipEventRecord(side_ev_join, side_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, side_ev_join, 0));
+        return ZKW_OK;
+    }
     // witnesses and traces created from this context keep it alive: zkw_destroy defers while any is outstanding
     std::atomic<long> children{0};
     std::atomic<bool> destroy_requested{false};

@@ -10,6 +10,7 @@
 #include "storage_application_kernels.cuh"
 #include "netlist_kernels.cuh"
 #include "netlist_queue_kernels.cuh"
+#include "netlist_closed_form_kernels.cuh"
 #include "ecrecover_kernels.cuh"
 #include "sort.h"
 
@@ -1016,12 +1017,14 @@ int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsign
 // synthesis of instances of one netlist circuit: `prepare` turns the builder's records into the engine's inputs (header bits, free
 // elements, the state before every cycle) at the pointers of the jobs it is handed; `capacity` is in cycles
 using NlPrepare = std::function<int(std::vector<NlPrepJob>&)>;
-int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
+using NlAfterClear = std::function<int()>;  // runs once the slots are claimed and cleared, before the fills (the closed-form sponges start here, on a side stream)
+int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows,
+                       const NlAfterClear& after_clear = {}) {
     const NlCached* nc = nullptr;
     ZKW_TRY(nl_get(ctx, circuit_type, &nc));
     const nl_spec& S = nc->host.s;
     if ((nc->host.fill_waves == 16 ? nc->host.lds_bytes16 : nc->host.lds_bytes) > 160 * 1024) return fail(ZKW_ERR_INVALID, "netlist of circuit %d needs %u bytes of LDS", circuit_type, nc->host.lds_bytes);
-    const size_t used = nlq_used_rows(&S, nlq_desc_of(circuit_type), capacity);  // netlist rows + the queue section where there is one
+    const size_t used = nlcf_used_rows(circuit_type, &S, capacity);  // netlist rows + the queue, EC and closed-form sections
     if (used > n_rows || S.total_table_rows > n_rows)
         return fail(ZKW_ERR_INVALID, "capacity %u needs %zu rows (tables: %u), trace has %zu", capacity, used, S.total_table_rows, n_rows);
     const size_t ni = inst.size();
@@ -1059,6 +1062,7 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
     NlJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("nl_jobs", jobs, &d_jobs));
     const unsigned nj = (unsigned)ni;
+    if (after_clear) ZKW_TRY(after_clear());
     ZKW_TRY(prepare(prep));
     static_assert(SA_W == LH_W && SA_R == LH_R, "StorageApplication shares the fill instantiation of the LinearHasher geometry");
     switch (circuit_type) {
@@ -1073,7 +1077,8 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
 }
 
 // ... from the block's round records (`sha_like`: zkw_sha256_round_record, else zkw_keccak_round_record)
-int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_rounds, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows) {
+int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_rounds, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows,
+                  const NlAfterClear& after_clear = {}) {
     return nl_synthesize_with(ctx, circuit_type, [&](std::vector<NlPrepJob>& prep) {
         const size_t rec_bytes = sha_like ? sizeof(zkw_sha256_round_record) : sizeof(zkw_keccak_round_record);
         for (size_t k = 0; k < prep.size(); k++) {
@@ -1086,7 +1091,7 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
         if (sha_like) { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_sha, dim3(capacity + 1, nj), dim3(128), 0, ctx->stream, d_prep, capacity); }
         else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
         return launch_check("k_nl_prepare");
-    }, inst, capacity, n_rows);
+    }, inst, capacity, n_rows, after_clear);
 }
 
 // the queue section of the instances nl_synthesize has just filled (include/zkw_netlist_queue.h): request-queue pops and memory-queue
@@ -1119,6 +1124,44 @@ int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std
     ZKW_TRY(launch_check("k_nlq_feed"));
     { Prof _p(ctx, "k_nlq_fill"); hipLaunchKernelGGL(k_nlq_fill, dim3((capacity + 3) / 4, d->n_ops, (unsigned)ni), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, nc->link_home, *d, d_jobs, capacity, n_rows); }
     return launch_check("k_nlq_fill");
+}
+
+// ---- the closed-form section (include/zkw_netlist_closed_form.h; netlist_closed_form_kernels.cuh) of the instances first_index + k of a
+// witness's records (d_inst) in the slots of inst[k]. nlcf_begin: flags, words, the four sponges and the compact form, on the context's
+// side stream — it reads only the records, so it runs next to the netlist fill; call it once the slots are cleared (NlAfterClear).
+// nlcf_end: joins, then the tie cells (copies of the registers the fills have written by then) on the main stream.
+struct NlcfCall { NlcfJob* d_jobs = nullptr; size_t n = 0; };
+template <class T>
+int nlcf_begin(zkw_ctx* ctx, int circuit_type, const typename T::Inst* d_inst, size_t first_index, const std::vector<NlInstance>& inst, u32 cycles, size_t n_rows,
+               NlcfCall* call, const char* jobs_name = "nlcf_jobs") {
+    const nlcf_desc* d = nlcf_desc_of(circuit_type);
+    const nl_spec* S = nl_host_spec(circuit_type);
+    if (!d || !S) return fail(ZKW_ERR_INVALID, "circuit type %d has no closed-form section", circuit_type);
+    if (nlcf_used_rows(circuit_type, S, cycles) > n_rows) return fail(ZKW_ERR_INVALID, "the closed-form section does not fit the trace");
+    static_assert(sizeof(u64) * 4 * T::MAXLEN <= 60 * 1024, "the encodings are staged in LDS");
+    std::vector<NlcfJob> jobs(inst.size());
+    for (size_t k = 0; k < inst.size(); k++) jobs[k] = NlcfJob{inst[k].t->data + inst[k].slot * inst[k].t->slot_elems(), (u64)(first_index + k)};
+    ZKW_TRY(ctx->upload(jobs_name, jobs, &call->d_jobs));
+    call->n = jobs.size();
+    if (jobs.empty()) return ZKW_OK;
+    hipStream_t side = nullptr;
+    ZKW_TRY(ctx->side_fork(&side));
+    hipLaunchKernelGGL((k_nlcf_sponges<T>), dim3((unsigned)jobs.size()), dim3(256), 0, side, *d, d_inst, call->d_jobs, S->g, n_rows, (u64)nlcf_first_row(circuit_type, S, cycles));
+    return launch_check("k_nlcf_sponges");
+}
+int nlcf_end(zkw_ctx* ctx, int circuit_type, const NlcfCall& call, u32 cycles, size_t n_rows) {
+    if (call.n == 0) return ZKW_OK;
+    const nlcf_desc* d = nlcf_desc_of(circuit_type);
+    const NlCached* nc = nullptr;
+    ZKW_TRY(nl_get(ctx, circuit_type, &nc));
+    ZKW_TRY(ctx->side_join());
+    const u32 cells = nlcf_header_cells(d) - nlcf_group_cell0(d, 0);
+    if (cells == 0) return ZKW_OK;
+    const nlq_desc* qd = nlq_desc_of(circuit_type);
+    const nlq_desc none{};
+    { Prof _p(ctx, "k_nlcf_ties"); hipLaunchKernelGGL(k_nlcf_ties, dim3((cells + 255) / 256, (unsigned)call.n), dim3(256), 0, ctx->stream, *d, qd ? *qd : none, nc->dev, call.d_jobs, cycles, n_rows,
+                                                    (u64)nlcf_first_row(circuit_type, &nc->host.s, cycles)); }
+    return launch_check("k_nlcf_ties");
 }
 
 // ---- the EC section of the ECRecover circuit (ecrecover_kernels.cuh): the spec on the device, once per device
@@ -1165,7 +1208,7 @@ int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u3
     const nl_spec& S = nc->host.s;
     if (t->n_cols < S.cols) return fail(ZKW_ERR_INVALID, "trace has %zu columns, the circuit needs %u", t->n_cols, S.cols);
     const nlq_desc* qd = nlq_desc_of(circuit_type);
-    if (nlq_used_rows(&S, qd, capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
+    if (nlcf_used_rows(circuit_type, &S, capacity) > t->n_rows) return fail(ZKW_ERR_INVALID, "capacity does not fit the trace");
     HIP_TRY(hipSetDevice(ctx->device));
     const u64* trace = t->data + slot * t->slot_elems();
     const size_t n_rows = t->n_rows;
@@ -1191,8 +1234,18 @@ int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u3
         { Prof _p(ctx, "k_ec_check_links"); hipLaunchKernelGGL(k_ec_check_links, dim3(capacity), dim3(128), 0, ctx->stream, ec->dev, nc->dev, nc->free_home, trace, n_rows, (size_t)e_begin, d_res); }
         ZKW_TRY(launch_check("k_ec_check_links"));
     }
-    { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res, (u64)NL_USED_ROWS(&S, capacity), (u64)nlq_used_rows(&S, qd, capacity), e_begin, e_end); }
+    { Prof _p(ctx, "k_nl_check_tail"); hipLaunchKernelGGL(k_nl_check_tail, dim3(1024), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res, (u64)NL_USED_ROWS(&S, capacity), (u64)nlq_used_rows(&S, qd, capacity), e_begin, e_end,
+                                                        (u64)nlcf_first_row(circuit_type, &S, capacity), (u64)nlcf_used_rows(circuit_type, &S, capacity)); }
     ZKW_TRY(launch_check("k_nl_check_tail"));
+    if (const nlcf_desc* cd = nlcf_desc_of(circuit_type)) {  // the closed-form section: its own checker (its lookup cells: the tail kernel)
+        u32 ties = 0;
+        for (u32 gi = 0; gi < cd->n_groups; gi++) ties += cd->g[gi].count;
+        const u32 tie_blocks = (ties + 255) / 256, perm_blocks = (nlcf_n_perms(cd) + 15) / 16;
+        const nlq_desc none{};
+        { Prof _p(ctx, "k_nlcf_check"); hipLaunchKernelGGL(k_nlcf_check, dim3(tie_blocks + perm_blocks + 1), dim3(256), 0, ctx->stream, *cd, qd ? *qd : none, nc->dev, trace, capacity, n_rows,
+                                                         (u64)nlcf_first_row(circuit_type, &S, capacity), tie_blocks, perm_blocks, d_res); }
+        ZKW_TRY(launch_check("k_nlcf_check"));
+    }
     if (qd) {
         { Prof _p(ctx, "k_nlq_check"); hipLaunchKernelGGL(k_nlq_check, dim3((capacity + 63) / 64, qd->n_ops), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, *qd, *nlq_rels_of(circuit_type), trace, capacity, n_rows, d_res); }
         ZKW_TRY(launch_check("k_nlq_check"));
@@ -1232,13 +1285,17 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));  // public inputs of the block's instances (a20), once
     const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
-    ZKW_TRY(nl_synthesize(ctx, 5, false, w->keccak_rounds, inst, w->capacity, t->n_rows));
+    NlcfCall cf;  // the closed-form section: sponges next to the fills, the ties after them
+    ZKW_TRY(nl_synthesize(ctx, 5, false, w->keccak_rounds, inst, w->capacity, t->n_rows, [&] {
+        return nlcf_begin<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>>(ctx, 5, w->instances, first_instance, inst, w->capacity, t->n_rows, &cf);
+    }));
     NlqQueues Q{};  // the precompile calls are popped, the memory queries (unaligned reads, the digest write) pushed
     Q.q[0] = NlqQueueIn{w->requests, w->req_tails, {0}, w->n_requests};
     Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->n_queries};
     memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
     Q.round_ops = w->round_ops;
-    return nlq_synthesize(ctx, 5, Q, inst, w->capacity, t->n_rows);
+    ZKW_TRY(nlq_synthesize(ctx, 5, Q, inst, w->capacity, t->n_rows));
+    return nlcf_end(ctx, 5, cf, w->capacity, t->n_rows);
 }
 extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
@@ -1333,6 +1390,11 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
         Q.round_ops = w->round_ops;
         const std::vector<NlInstance> sub(inst.begin() + start_of[k], inst.begin() + start_of[k + 1]);
         ZKW_TRY(nlq_synthesize(ctx, 7, Q, sub, capacity, n_rows));
+        NlcfCall cf;  // the closed-form section (a 34-word FSM: eight dependent permutations; the side stream buys nothing here)
+        char name[32];
+        snprintf(name, sizeof name, "nlcf_jobs_%zu", k % 64);
+        ZKW_TRY((nlcf_begin<CfPrecompile<ZKW_PRECOMPILE_ECRECOVER>>(ctx, 7, w->instances, first[k], sub, capacity, n_rows, &cf, name)));
+        ZKW_TRY(nlcf_end(ctx, 7, cf, capacity, n_rows));
     }
     { Prof _p(ctx, "k_ec_stream"); hipLaunchKernelGGL(k_ec_stream, dim3((EC_ROWS_PER_CYCLE + 63) / 64, capacity, nj), dim3(64), 0, ctx->stream, ec->dev, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL); }
     return launch_check("k_ec_stream");
@@ -1370,13 +1432,17 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     HIP_TRY(hipSetDevice(ctx->device));
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
     const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
-    ZKW_TRY(nl_synthesize(ctx, 6, true, w->sha256_rounds, inst, w->capacity, t->n_rows));
+    NlcfCall cf;
+    ZKW_TRY(nl_synthesize(ctx, 6, true, w->sha256_rounds, inst, w->capacity, t->n_rows, [&] {
+        return nlcf_begin<CfPrecompile<ZKW_PRECOMPILE_SHA256>>(ctx, 6, w->instances, first_instance, inst, w->capacity, t->n_rows, &cf);
+    }));
     NlqQueues Q{};  // the precompile calls are popped (the head runs through the states their pushes left), the memory queries pushed
     Q.q[0] = NlqQueueIn{w->requests, w->req_tails, {0}, w->n_requests};
     Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->n_queries};
     memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
     Q.round_ops = w->round_ops;
-    return nlq_synthesize(ctx, 6, Q, inst, w->capacity, t->n_rows);
+    ZKW_TRY(nlq_synthesize(ctx, 6, Q, inst, w->capacity, t->n_rows));
+    return nlcf_end(ctx, 6, cf, w->capacity, t->n_rows);
 }
 extern "C" int zkw_sha256_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
@@ -1397,13 +1463,17 @@ extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_wit
     HIP_TRY(hipSetDevice(ctx->device));
     if (!w->cf_pi) ZKW_TRY(closed_form_public_inputs<CfDecommitter>(ctx, w->instances, w->n_instances, &w->cf_pi));
     const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, w->capacity, true, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
-    ZKW_TRY(nl_synthesize(ctx, 3, true, w->sha256_rounds, inst, w->capacity, t->n_rows));
+    NlcfCall cf;
+    ZKW_TRY(nl_synthesize(ctx, 3, true, w->sha256_rounds, inst, w->capacity, t->n_rows, [&] {
+        return nlcf_begin<CfDecommitter>(ctx, 3, w->instances, first_instance, inst, w->capacity, t->n_rows, &cf);
+    }));
     NlqQueues Q{};  // the decommit requests are popped, the code words written to memory
     Q.q[0] = NlqQueueIn{w->requests, w->dedup_tails, {0}, w->n_requests};
     Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->total_words};
     memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
     Q.round_ops = w->round_ops;
-    return nlq_synthesize(ctx, 3, Q, inst, w->capacity, t->n_rows);
+    ZKW_TRY(nlq_synthesize(ctx, 3, Q, inst, w->capacity, t->n_rows));
+    return nlcf_end(ctx, 3, cf, w->capacity, t->n_rows);
 }
 extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
@@ -1431,7 +1501,8 @@ extern "C" int zkw_storage_application_synthesize(zkw_ctx* ctx, zkw_storage_appl
     for (size_t k = 0; k < n_instances; k++)
         inst[k] = NlInstance{rec[k].first_item, (u32)rec[k].num_items, w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k), t, (first_slot + k) % t->n_slots, true};
     const u32 capacity = w->capacity;
-    return nl_synthesize_with(ctx, 10, [&](std::vector<NlPrepJob>& prep) {
+    NlcfCall cf;
+    ZKW_TRY(nl_synthesize_with(ctx, 10, [&](std::vector<NlPrepJob>& prep) {
         std::vector<SapWalkJob> jobs(prep.size());
         for (size_t k = 0; k < prep.size(); k++)
             jobs[k] = SapWalkJob{w->items, w->keys, w->paths, w->walk_hashes, w->n ? prep[k].first_round : 0, w->n ? prep[k].n_active : 0, prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
@@ -1439,7 +1510,10 @@ extern "C" int zkw_storage_application_synthesize(zkw_ctx* ctx, zkw_storage_appl
         ZKW_TRY(ctx->upload("sap_walk_jobs", jobs, &d_jobs));
         { Prof _p(ctx, "k_sap_walk_cycles"); hipLaunchKernelGGL(k_sap_walk_cycles, dim3((capacity * SAP_WALK_CYCLES + 256) / 256, (unsigned)jobs.size()), dim3(256), 0, ctx->stream, d_jobs, capacity); }
         return launch_check("k_sap_walk_cycles");
-    }, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows);
+    }, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows, [&] {
+        return nlcf_begin<CfStorageApplication>(ctx, 10, w->instances, first_instance, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows, &cf);
+    }));
+    return nlcf_end(ctx, 10, cf, capacity * SA_CYCLES_PER_WALK, t->n_rows);
 }
 extern "C" int zkw_storage_application_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
@@ -1509,7 +1583,8 @@ extern "C" int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx* ctx, const
     ZKW_TRY(launch_check("k_commit_encodings"));
     std::vector<NlInstance> inst(n_queues);
     for (size_t b = 0; b < n_queues; b++) inst[b] = NlInstance{roff[b], (u32)(roff[b + 1] - roff[b]), d_pi + 4 * b, t, first_slot + b, true};
-    ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows));
+    NlcfCall cf;
+    ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows, [&] { return nlcf_begin<CfLinearHasher>(ctx, 13, d_rec, 0, inst, cycles, n_rows, &cf); }));
     {   // the queue section: every message is popped (Poseidon2 rows below the netlist, include/zkw_netlist_queue.h)
         const u64* d_tails = nullptr;
         if (total && message_tails) ZKW_TRY(ctx->in("lh_tails", message_tails, total * 4, &d_tails));
@@ -1536,6 +1611,7 @@ extern "C" int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx* ctx, const
         }
         ZKW_TRY(nlq_synthesize(ctx, 13, per[0], inst, cycles, n_rows, &per));
     }
+    ZKW_TRY(nlcf_end(ctx, 13, cf, cycles, n_rows));
     memcpy(records_out, recv.data(), n_queues * sizeof recv[0]);
     if (public_inputs_out) ZKW_TRY(ctx->read_small(public_inputs_out, d_pi, 32 * n_queues));
     return ZKW_OK;

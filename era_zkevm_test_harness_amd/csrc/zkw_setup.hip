@@ -7,7 +7,7 @@
 #include "log_demux_circuit_kernels.cuh"
 #include "storage_sorter_circuit_kernels.cuh"
 #include "netlist_kernels.cuh"
-#include "../../include/zkw_netlist_queue.h"
+#include "../../include/zkw_netlist_closed_form.h"
 #include "../../include/zkw_ecrecover.h"
 
 extern "C" int zkw_circuit_geometry_of(uint8_t circuit_type, zkw_circuit_geometry* out) {
@@ -76,8 +76,14 @@ extern "C" int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zk
                 out->ec_first_row = min_rows;
                 out->ec_rows_per_cycle = EC_ROWS_PER_CYCLE;
                 min_rows += (uint64_t)cycles * EC_ROWS_PER_CYCLE;
-                if (min_rows < sp->total_table_rows) min_rows = sp->total_table_rows;  // the multiplicity column has a row per table row (197 632 > 7 cycles' rows)
             }
+            if (const nlcf_desc* cd = nlcf_desc_of(circuit_type)) {  // the closed-form section: the last rows in use
+                out->closed_form_first_row = min_rows;
+                out->closed_form_rows = nlcf_rows(cd, sp->g);
+                out->closed_form_header_rows = nlcf_header_rows(cd, sp->g);
+                min_rows += out->closed_form_rows;
+            }
+            if (circuit_type == 7 && min_rows < sp->total_table_rows) min_rows = sp->total_table_rows;  // the multiplicity column has a row per table row (197 632 > 7 cycles' rows)
             break;
         }
         default: return ZKW_OK;  // a known circuit type this library does not synthesize yet: synthesizable = 0
@@ -139,6 +145,7 @@ extern "C" int zkw_circuit_fill_bytes(uint8_t circuit_type, uint32_t capacity, s
         cells += q * cycles + nlq_bnd_cells(qd);
     }
     if (circuit_type == 7) cells += (uint64_t)cycles * EC_ROWS_PER_CYCLE * EC_ROW_CELLS;
+    if (const nlcf_desc* cd = nlcf_desc_of(circuit_type)) cells += nlcf_header_cells(cd) + (uint64_t)nlcf_n_perms(cd) * NLQ_P2_CELLS;
     *warm = cells * 8;
     return ZKW_OK;
 }
@@ -205,6 +212,10 @@ extern "C" int zkw_setup_row_selectors(uint8_t circuit_type, uint32_t capacity, 
             const uint32_t r0 = nlq_op_row0(qd, sp->g, j), erows = nlq_rows_for(nlq_enc_cells(&qd->ops[j]), sp->g), rows = nlq_op_rows(&qd->ops[j], sp->g);
             for (uint32_t r = 0; r < rows; r++) memset(out + NLQ_ROW(sp, cycles, r0 + r, 0), r < erows ? ZKW_ROW_QUEUE_ENCODING : ZKW_ROW_QUEUE_POSEIDON2, cycles);
         }
+    }
+    if (lay.closed_form_rows) {
+        memset(out + lay.closed_form_first_row, ZKW_ROW_CLOSED_FORM_WORDS, lay.closed_form_header_rows);
+        memset(out + lay.closed_form_first_row + lay.closed_form_header_rows, ZKW_ROW_CLOSED_FORM_POSEIDON2, lay.closed_form_rows - lay.closed_form_header_rows);
     }
     return ZKW_OK;
 }
@@ -432,6 +443,53 @@ extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacit
                 }
             }
         }
+    }
+    if (netlist) {
+        // the closed-form section (include/zkw_netlist_closed_form.h): a tie's a / b cells are copies of words, its digits of the registers;
+        // a permutation's inputs are copies of words / of the permutation before; the PI row's cells of the last permutation's outputs
+        const uint32_t cycles = nl_cycles_of(circuit_type, cap);
+        const nl_spec* ns = nl_host_spec(circuit_type);
+        const nlcf_desc* cd = nlcf_desc_of(circuit_type);
+        const nlq_desc* qd = nlq_desc_of(circuit_type);
+        const uint32_t G = ns->g;
+        const uint64_t c0 = nlcf_first_row(circuit_type, ns, cycles), nb = NL_BOUNDARY_ROW(ns, cycles), brows = NL_BND_ROWS(ns);
+        auto hcell = [&](uint32_t k, uint64_t* col, uint64_t* row) { *col = k % G; *row = c0 + k / G; };
+        auto pcell = [&](uint32_t perm, uint32_t v, uint64_t* col, uint64_t* row) { *col = v % G; *row = c0 + nlcf_perm_row0(cd, G, perm) + v / G; };
+        uint64_t ca, ra, cb, rb;
+        for (uint32_t gi = 0; cd && gi < cd->n_groups; gi++) {
+            const nlcf_group& gr = cd->g[gi];
+            for (uint32_t j = 0; j < gr.count; j++) {
+                const uint32_t c = nlcf_tie_cell0(cd, gi, j);
+                const int32_t wa = nlcf_tie_word(&gr, gr.a_word0, j), wb = nlcf_tie_word(&gr, gr.b_word0, j);
+                if (wa >= 0) { hcell(c, &ca, &ra); hcell(nlcf_word_cell(cd, nlcf_a_part(&gr), (uint32_t)wa), &cb, &rb); unite(ca, ra, cb, rb); }
+                if (wb >= 0) { hcell(c + 1, &ca, &ra); hcell(nlcf_word_cell(cd, nlcf_b_part(&gr), (uint32_t)wb), &cb, &rb); unite(ca, ra, cb, rb); }
+                for (uint32_t t = 0; t < gr.n_cells; t++) {
+                    hcell(c + 2 + t, &ca, &ra);
+                    if (gr.reg_kind == NLCF_REG_QUEUE_BEFORE || gr.reg_kind == NLCF_REG_QUEUE_AFTER) { cb = nlq_bnd_col(qd, gr.queue, gr.reg_kind == NLCF_REG_QUEUE_AFTER, gr.reg0 + j); rb = NLQ_BASE(ns, cycles); }
+                    else { const uint32_t e = (gr.reg0 + j) * gr.n_cells + t; cb = e % G; rb = nb + (gr.reg_kind == NLCF_REG_STATE_OUT ? brows : 0) + e / G; }
+                    unite(ca, ra, cb, rb);
+                }
+            }
+        }
+        const uint32_t cp0 = cd ? nlcf_perm0(cd, 4) : 0;
+        for (uint32_t perm = 0; cd && perm < nlcf_n_perms(cd); perm++) {
+            uint32_t part = 4, q = perm - cp0, n = NLCF_CP_WORDS;
+            if (perm < cp0) { part = 0; while (perm >= nlcf_perm0(cd, part + 1)) part++; q = perm - nlcf_perm0(cd, part); n = cd->n[part]; }
+            for (uint32_t v = 0; v < 12; v++) {
+                pcell(perm, v, &ca, &ra);
+                if (v >= 8) { if (!q) continue; pcell(perm - 1, 118 + v, &cb, &rb); }
+                else {
+                    const uint32_t w = 8 * q + v;
+                    if (w >= n) continue;
+                    if (part < 4) hcell(nlcf_word_cell(cd, part, w), &cb, &rb);
+                    else if (w < 2) hcell(w, &cb, &rb);
+                    else { const uint32_t cpart = (w - 2) / 4; if (!cd->n[cpart]) continue; pcell(nlcf_perm0(cd, cpart + 1) - 1, 118 + (w - 2) % 4, &cb, &rb); }
+                }
+                unite(ca, ra, cb, rb);
+            }
+        }
+        if (cd)
+            for (uint32_t k = 0; k < 4; k++) { pcell(nlcf_n_perms(cd) - 1, 118 + k, &cb, &rb); unite(k, NL_PI_ROW(ns, cycles), cb, rb); }
     }
     for (int l = 0; l < sp.num_links; l++) {
         const rc_link k = sp.links[l];

@@ -1152,7 +1152,8 @@ CIRCUIT_GEOMETRY = np.dtype(
 CIRCUIT_LAYOUT = np.dtype(
     [("synthesizable", "<u4"), ("fits", "<u4"), ("capacity", "<u4"), ("num_columns", "<u4"), ("rows_per_cycle", "<u4"), ("total_table_rows", "<u4"),
      ("region_stride", "<u8"), ("rows_used", "<u8"), ("nop_rows", "<u8"), ("trace_len", "<u8"), ("public_input_column", "<u4", (4,)),
-     ("public_input_row", "<u8", (4,)), ("queue_first_row", "<u8"), ("queue_rows_per_cycle", "<u4"), ("ec_rows_per_cycle", "<u4"), ("ec_first_row", "<u8")])
+     ("public_input_row", "<u8", (4,)), ("queue_first_row", "<u8"), ("queue_rows_per_cycle", "<u4"), ("ec_rows_per_cycle", "<u4"), ("ec_first_row", "<u8"),
+     ("closed_form_first_row", "<u8"), ("closed_form_rows", "<u4"), ("closed_form_header_rows", "<u4")])
 
 
 def circuit_fill_bytes(circuit_type: int, capacity: int = 0, n_rows: int = 1 << 20):

@@ -138,6 +138,12 @@ typedef struct zkw_circuit_layout {
     /* the EC section of the ECRecover circuit (type 7; include/zkw_ecrecover.h): row r of cycle c is ec_first_row + c * ec_rows_per_cycle + r */
     uint32_t ec_rows_per_cycle;
     uint64_t ec_first_row;
+    /* the closed-form section of a netlist circuit (types 3, 5, 6, 7, 10, 13; include/zkw_netlist_closed_form.h): flags, the words of the
+       closed-form input, their ties to the trace's registers, then the flattened Poseidon2 rows of the commitments, the compact form and
+       the public input — closed_form_rows rows from closed_form_first_row, the last of rows_used */
+    uint64_t closed_form_first_row;
+    uint32_t closed_form_rows;
+    uint32_t closed_form_header_rows; /* rows of flags / words / ties; the rest are Poseidon2 rows */
 } zkw_circuit_layout;
 int zkw_circuit_layout_of(uint8_t circuit_type, uint32_t capacity, zkw_circuit_layout *out);
 /* Setup side, selectors: out[r] (host, n_rows bytes) says which gate set applies to row r of a trace of this library's
@@ -158,6 +164,8 @@ int zkw_circuit_fill_bytes(uint8_t circuit_type, uint32_t capacity, size_t n_row
 #define ZKW_ROW_QUEUE_BOUNDARY 0xE0 /* queue section: the queue states before / after the instance */
 #define ZKW_ROW_QUEUE_ENCODING 0xE1 /* queue section: an item's fields, its encoding (linear gates), old / new state (selection gates) */
 #define ZKW_ROW_QUEUE_POSEIDON2 0xE2 /* queue section: a (folded) flattened Poseidon2 gate */
+#define ZKW_ROW_CLOSED_FORM_WORDS 0xE4 /* closed-form section: flags, words, ties (selection / recomposition gates) */
+#define ZKW_ROW_CLOSED_FORM_POSEIDON2 0xE5 /* closed-form section: a (folded) flattened Poseidon2 gate of a commitment sponge */
 #define ZKW_ROW_EC_GATES 0xF0      /* EC section of the ECRecover circuit: LIN / SEL / FMA gates in the general-purpose columns, no lookups */
 #define ZKW_ROW_EC_XOR8 0xF1       /* ... its 16 lookup slots are Xor8 (byte range checks) */
 #define ZKW_ROW_EC_FIXED_BASE 0xF2 /* ... its lookup slots are a FixedBaseMul table (which one: the row's segment instance) */

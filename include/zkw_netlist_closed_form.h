@@ -1,0 +1,155 @@
+/* zkw_netlist_closed_form.h — the CLOSED-FORM SECTION of a "zkw trace v4" netlist circuit (types 3, 5, 6, 7, 10, 13): what the
+ * reference's circuits derive in-circuit around their round function — the commitments of the observable input / output and of the
+ * hidden FSM input / output, the compact form and the public input (ClosedFormInputCompactForm::from_full_form +
+ * commit_variable_length_encodable_item, src/witness/utils.rs:269-306), and the start-flag selection of the state the first cycle
+ * continues from (`state = start_flag ? fresh : hidden_fsm_input`, mirrored out of circuit by
+ * src/witness/individual_circuits/sha256_round_function.rs:172-201, keccak256_round_function.rs:214-231, decommit_code.rs:172-199,
+ * ecrecover.rs:120-141) — as rows of the trace, the way docs/KERNELS.md 3.20 does it for the six queue circuits. Until round 5 the
+ * PI row of these traces was PLACED: any public input passed the checkers.
+ *
+ * Layout only (record types, cell positions, the tie tables); the arithmetic is csrc/netlist_closed_form_kernels.cuh on the device and
+ * oracle/netlist_closed_form.c in the test oracle. Placement is this library's own (the gadget bodies are in the absent
+ * era-zkevm_circuits crate): PARITY UNPINNED at the placement level, like the rest of v4.
+ *
+ * Rows. The section starts at row c0 = nlcf_first_row(): below the queue section (below the EC section for ECRecover), general-purpose
+ * columns only (cell k of a block at row k / G, column k % G; lookup cells zero, not counted in the multiplicity column).
+ *   HEADER block: [start | completion | OI words | OO words | FI words | FO words | tie cells]. A word is one element of the flat
+ *     encodings the commitments absorb (oracle/public_input.c, csrc/public_input_kernels.cuh: field order of the reference's struct
+ *     literals), FREE unless a tie binds it. start / completion boolean.
+ *   TIE cells [a | b | r_0 .. r_{n-1}] bind a word to a REGISTER of the trace (a QBND cell of the queue section: the state of a queue
+ *     before cycle 0 / after the last cycle; or state elements of the netlist's BND_IN / BND_OUT rows, n digits of `bits` bits):
+ *     r_t = copy of the register cell, R = sum r_t << (bits t);
+ *       IN:         a = copy of OI word (or the constant 0), b = copy of FI word;  R = b + start (a - b)
+ *       IN_ALWAYS:  a = copy of OI word;                                           R = a         (circuits without a hidden FSM)
+ *       OUT:        a = copy of FO word;                                           R = a
+ *       OUT_LIVE:   a = copy of FO word;                                           (1 - completion) (R - a) = 0   (the hash state: an instance
+ *                   that ends its block early leaves the state of an EMPTY round in the FSM output — keccak256_round_function.rs:376-394,
+ *                   sha256_round_function.rs:262-279 —, where this library's idle cycles carry the last digest; nothing consumes that output)
+ *       OO:         a = copy of OO word, b = copy of the FO word of the register;  R = b, a = completion b   (b absent: R = a = completion R)
+ *   P2 blocks (the 130 variables of the flattened Poseidon2 gate, ceil(130 / G) rows each): the four sponges in overwrite mode from
+ *     the state (0, .., 0, n) — permutation p absorbs words 8p .. 8p + 7 (copies; constants 0 beyond n) over the capacity the
+ *     permutation before left (copies) —, then the three permutations over the 18 words of the compact form [start, completion,
+ *     c(OI), c(OO), c(FI), c(FO)] (copies of the sponges' last outputs 0..3; the constant 0 for an empty encoding). The PI row's four
+ *     cells are copies of the last permutation's outputs 0..3.
+ * What stays only committed (FREE words): everything the ties below do not name — the flags, timestamps and call parameters of the
+ * internal FSMs, Keccak's byte buffer, the queue LENGTHS and the far ends of the queues (tail of a popped queue, head of the memory
+ * queue), all of StorageApplication's words.
+ */
+#ifndef ZKW_NETLIST_CLOSED_FORM_H
+#define ZKW_NETLIST_CLOSED_FORM_H
+#include "zkw_netlist_queue.h"
+#include "zkw_ecrecover_ec_spec.h"
+
+enum { NLCF_OI = 0, NLCF_OO = 1, NLCF_FI = 2, NLCF_FO = 3 };
+enum { NLCF_IN = 1, NLCF_IN_ALWAYS = 2, NLCF_OUT = 3, NLCF_OUT_OO = 4, NLCF_OUT_LIVE = 5 };
+enum { NLCF_REG_QUEUE_BEFORE = 0, NLCF_REG_QUEUE_AFTER = 1, NLCF_REG_STATE_IN = 2, NLCF_REG_STATE_OUT = 3 };
+#define NLCF_MAX_GROUPS 10
+#define NLCF_CP_WORDS 18
+#define NLCF_CP_PERMS 3
+
+/* a run of `count` ties: tie j binds register reg0 + j (QUEUE: element of the queue state; STATE: elements (reg0 + j) * n_cells ..)
+   to words a_word0 + j / b_word0 + j (lanes_xy: the FSM holds Keccak's bytes as [x][y][8], the netlist as lane x + 5 y) */
+typedef struct nlcf_group { uint8_t kind, reg_kind, queue, n_cells, bits, lanes_xy; uint16_t count, reg0; int16_t a_word0, b_word0; } nlcf_group;
+typedef struct nlcf_desc { uint16_t n[4]; uint16_t n_groups; nlcf_group g[NLCF_MAX_GROUPS]; } nlcf_desc;
+
+/* Sha256RoundFunction (6). OI = PrecompileFunctionInputData {log queue: head 0..3, tail 4..7, length 8; memory queue: head 9..20, tail
+   21..32, length 33}; OO = the final memory queue state (head 0..11, tail 12..23, length 24); FSM = 3 flags, sha256_inner_state 3..10,
+   2 timestamps, 5 call parameters, log queue 18..26, memory queue 27..51. The netlist's state = the chaining value as 8 x 8 nibbles. */
+static const nlcf_desc NLCF_DESC_SHA256 = {{34, 25, 52, 52}, 7, {
+    {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, 18}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 21, 39},
+    {NLCF_IN, NLCF_REG_STATE_IN, 0, 8, 4, 0, 8, 0, -1, 3},
+    {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 18, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 39, -1},
+    {NLCF_OUT_LIVE, NLCF_REG_STATE_OUT, 0, 8, 4, 0, 8, 0, 3, -1},
+    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 39}}};
+/* CodeDecommitter (3). OI = CodeDecommitterInputData {memory queue 0..24, sorted requests queue 25..49}; OO = the final memory queue
+   state; FSM = sha256_inner_state 0..7, hash_to_compare_against 8..15, 5 counters, 3 flags, requests queue 24..48, memory queue 49..73.
+   Queue 0 of the section = the requests (popped: head), queue 1 = the memory queue (pushed: tail). */
+static const nlcf_desc NLCF_DESC_CODE_DECOMMITTER = {{50, 25, 74, 74}, 7, {
+    {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 12, 0, 25, 24}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 12, 61},
+    {NLCF_IN, NLCF_REG_STATE_IN, 0, 8, 4, 0, 8, 0, -1, 0},
+    {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 12, 0, 24, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 61, -1},
+    {NLCF_OUT_LIVE, NLCF_REG_STATE_OUT, 0, 8, 4, 0, 8, 0, 0, -1},
+    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 61}}};
+/* Keccak256RoundFunction (5). OI / OO as type 6; FSM = 4 flags, keccak_internal_state 4..203 ([x][y][8] bytes), 2 timestamps, 6 call
+   parameters, the byte buffer 212..403 and its fill 404, log queue 405..413, memory queue 414..438. The netlist's state = the sponge
+   state as 200 bytes, lane x + 5 y. */
+static const nlcf_desc NLCF_DESC_KECCAK256 = {{34, 25, 439, 439}, 7, {
+    {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, 405}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 21, 426},
+    {NLCF_IN, NLCF_REG_STATE_IN, 0, 1, 8, 1, 200, 0, -1, 4},
+    {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 405, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 426, -1},
+    {NLCF_OUT_LIVE, NLCF_REG_STATE_OUT, 0, 1, 8, 1, 200, 0, 4, -1},
+    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 426}}};
+/* ECRecover (7). OI / OO as type 6; FSM = EcrecoverCircuitFSMInputOutput {log queue 0..8, memory queue 9..33} (ecrecover.rs:226-233): a
+   cycle is a whole request, the netlist carries nothing between cycles. */
+static const nlcf_desc NLCF_DESC_ECRECOVER = {{34, 25, 34, 34}, 5, {
+    {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, 0}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 21, 21},
+    {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 0, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 21, -1},
+    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 21}}};
+/* L1MessagesHasher (13). OI = LinearHasherInputData {queue_state: head 0..3, tail 4..7, length 8}, OO = LinearHasherOutputData
+   {keccak256_hash: 32 bytes}, no hidden FSM (one instance per block: data_hasher_and_merklizer.rs:34-60). The pops start at the
+   queue's head; the digest is the first 32 bytes of the sponge state after the last cycle. (That the pops END at the queue's tail —
+   every message is hashed — is not tied: the entry points take the queue state from the caller, and callers pass states without a tail.) */
+static const nlcf_desc NLCF_DESC_LINEAR_HASHER = {{9, 32, 0, 0}, 2, {
+    {NLCF_IN_ALWAYS, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, -1},
+    {NLCF_OUT_OO, NLCF_REG_STATE_OUT, 0, 1, 8, 0, 32, 0, 0, -1}}};
+/* StorageApplication (10). OI = {shard, initial_root_hash 32 bytes, enumeration counter 2, log queue 9} = 44, OO = {new_root_hash 32,
+   counter 2, state_diffs_keccak256_hash 32} = 66, FSM = {root hash 32, counter 2, log queue 9, Keccak accumulator 200} = 243
+   (storage_application.rs:286-336). The trace holds the Blake2s walks only (no queue side, docs/KERNELS.md 3.17): no ties — the words are
+   committed, the commitments and the public input derived in-trace. */
+static const nlcf_desc NLCF_DESC_STORAGE_APPLICATION = {{44, 66, 243, 243}, 0, {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+
+static inline const nlcf_desc *nlcf_desc_of(int circuit_type) {
+    return circuit_type == 6 ? &NLCF_DESC_SHA256 : circuit_type == 3 ? &NLCF_DESC_CODE_DECOMMITTER : circuit_type == 5 ? &NLCF_DESC_KECCAK256 :
+           circuit_type == 7 ? &NLCF_DESC_ECRECOVER : circuit_type == 13 ? &NLCF_DESC_LINEAR_HASHER :
+           circuit_type == 10 ? &NLCF_DESC_STORAGE_APPLICATION : (const nlcf_desc *)0;
+}
+
+/* ---- cells of the HEADER block */
+#define NLCF_CELL_START 0u
+#define NLCF_CELL_COMPLETION 1u
+NLQ_HD uint32_t nlcf_word_cell(const nlcf_desc *d, uint32_t part, uint32_t k) {
+    uint32_t c = 2;
+    for (uint32_t p = 0; p < part; p++) c += d->n[p];
+    return c + k;
+}
+NLQ_HD uint32_t nlcf_group_cell0(const nlcf_desc *d, uint32_t gi) {
+    uint32_t c = nlcf_word_cell(d, 4, 0);
+    for (uint32_t i = 0; i < gi; i++) c += (uint32_t)d->g[i].count * (2u + d->g[i].n_cells);
+    return c;
+}
+NLQ_HD uint32_t nlcf_header_cells(const nlcf_desc *d) { return nlcf_group_cell0(d, d->n_groups); }
+/* tie j of group gi: its first cell; the word index of its `a` / `b` side (-1: none) */
+NLQ_HD uint32_t nlcf_tie_cell0(const nlcf_desc *d, uint32_t gi, uint32_t j) { return nlcf_group_cell0(d, gi) + j * (2u + d->g[gi].n_cells); }
+NLQ_HD int32_t nlcf_tie_word(const nlcf_group *g, int32_t word0, uint32_t j) {
+    if (word0 < 0) return -1;
+    if (!g->lanes_xy) return word0 + (int32_t)j;
+    const uint32_t lane = j / 8, x = lane % 5, y = lane / 5; /* netlist byte j of lane x + 5 y = FSM byte [x][y][j % 8] */
+    return word0 + (int32_t)(8 * (5 * x + y) + j % 8);
+}
+/* which part the words of a tie's sides belong to */
+NLQ_HD uint32_t nlcf_a_part(const nlcf_group *g) { return g->kind == NLCF_OUT || g->kind == NLCF_OUT_LIVE ? NLCF_FO : g->kind == NLCF_OUT_OO ? NLCF_OO : NLCF_OI; }
+NLQ_HD uint32_t nlcf_b_part(const nlcf_group *g) { return g->kind == NLCF_OUT_OO ? NLCF_FO : NLCF_FI; }
+
+/* ---- P2 blocks: sponge of part p = perms [nlcf_perm0(p), nlcf_perm0(p + 1)), then the compact form's three */
+NLQ_HD uint32_t nlcf_part_perms(const nlcf_desc *d, uint32_t part) { return (d->n[part] + 7u) / 8u; }
+NLQ_HD uint32_t nlcf_perm0(const nlcf_desc *d, uint32_t part) {
+    uint32_t c = 0;
+    for (uint32_t p = 0; p < part && p < 4; p++) c += nlcf_part_perms(d, p);
+    return c;
+}
+NLQ_HD uint32_t nlcf_n_perms(const nlcf_desc *d) { return nlcf_perm0(d, 4) + NLCF_CP_PERMS; }
+NLQ_HD uint32_t nlcf_header_rows(const nlcf_desc *d, uint32_t g) { return nlq_rows_for(nlcf_header_cells(d), g); }
+NLQ_HD uint32_t nlcf_rows(const nlcf_desc *d, uint32_t g) { return nlcf_header_rows(d, g) + nlcf_n_perms(d) * nlq_rows_for(NLQ_P2_CELLS, g); }
+/* row (relative to the section's first row) of P2 block `perm` */
+NLQ_HD uint32_t nlcf_perm_row0(const nlcf_desc *d, uint32_t g, uint32_t perm) { return nlcf_header_rows(d, g) + perm * nlq_rows_for(NLQ_P2_CELLS, g); }
+
+/* ---- where the section is (host only: kernels take the first row and the descriptor by value) */
+static inline uint64_t nlcf_first_row(int circuit_type, const nl_spec *sp, uint32_t cycles) {
+    return nlq_used_rows(sp, nlq_desc_of(circuit_type), cycles) + (circuit_type == 7 ? (uint64_t)cycles * EC_ROWS_PER_CYCLE : 0);
+}
+/* rows a trace of `cycles` cycles uses: netlist + queue section (+ EC section) + closed-form section */
+static inline uint64_t nlcf_used_rows(int circuit_type, const nl_spec *sp, uint32_t cycles) {
+    const nlcf_desc *d = nlcf_desc_of(circuit_type);
+    return nlcf_first_row(circuit_type, sp, cycles) + (d ? nlcf_rows(d, sp->g) : 0);
+}
+#endif /* ZKW_NETLIST_CLOSED_FORM_H */

@@ -17,7 +17,7 @@
 #include "../include/zkw_linear_hasher_circuit_spec.h"
 #include "../include/zkw_storage_application_circuit_spec.h"
 #include "../include/zkw_ecrecover_circuit_spec.h"
-#include "../include/zkw_netlist_queue.h"
+#include "../include/zkw_netlist_closed_form.h"
 
 NL_DEFINE_SPEC(sc, SC);
 NL_DEFINE_SPEC(dc, DC);
@@ -249,8 +249,9 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
     result res = {0, ~0ull};
     const int ctype = type_of_spec(sp);
     const nlq_desc *qd = nlq_desc_of(ctype);
-    if (!sp || n_rows < nlq_used_rows(sp, qd, capacity)) { *first_bad = 0; return ~0ull; }
+    if (!sp || n_rows < nlcf_used_rows(ctype, sp, capacity)) { *first_bad = 0; return ~0ull; }
     const size_t q_begin = NL_USED_ROWS(sp, capacity), q_end = nlq_used_rows(sp, qd, capacity); /* the queue section's rows (zkw_netlist_queue.h) */
+    const size_t c_begin = nlcf_first_row(ctype, sp, capacity), c_end = nlcf_used_rows(ctype, sp, capacity); /* the closed-form section's (zkw_netlist_closed_form.h) */
     const view v = {sp, trace, n_rows, capacity};
     uint32_t *hist = calloc(sp->total_table_rows, sizeof(uint32_t));
     for (uint32_t c = 0; c < capacity; c++)
@@ -339,7 +340,7 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
         if (TR(sp->mult_col, row) != (row < sp->total_table_rows ? hist[row] : 0)) flag(&res, 5, 0, row);
         if (row < bnd || (row >= e_begin && row < e_end)) continue;
         const size_t off = row - bnd;
-        for (uint32_t col = (row >= q_begin && row < q_end) ? sp->g : 0; col < sp->mult_col; col++) { /* (the section's general-purpose cells: orc_nlq_check) */
+        for (uint32_t col = ((row >= q_begin && row < q_end) || (row >= c_begin && row < c_end)) ? sp->g : 0; col < sp->mult_col; col++) { /* (the sections' general-purpose cells: orc_nlq_check, orc_nlcf_check) */
             int allowed = 0;
             if (off < 2 * brows) allowed = col < sp->g && (off % brows) * sp->g + col < sp->state;
             else if (off == 2 * brows) allowed = col < 4;
@@ -358,6 +359,12 @@ uint64_t orc_nl_check(const nl_spec *sp, const uint64_t *trace, uint32_t capacit
         uint64_t qfirst = ~0ull;
         res.n += orc_nlq_check(ctype, trace, capacity, n_rows, &qfirst);
         if (qfirst < res.first) res.first = qfirst;
+    }
+    if (nlcf_desc_of(ctype)) {
+        uint64_t cfirst = ~0ull;
+        const uint64_t nc = orc_nlcf_check(ctype, trace, capacity, n_rows, &cfirst);
+        res.n += nc;
+        if (nc && cfirst < res.first) res.first = cfirst;
     }
     *first_bad = res.n ? res.first : 0;
     return res.n;
@@ -388,6 +395,7 @@ static int sha_like(const nl_spec *sp, const uint8_t state_in[32], const zkw_sha
     free(hdr); free(fr); free(st);
     /* the queue section the bare records imply; a caller that holds the block's queues writes the real one over it (orc_nlq_synthesize) */
     if (rc == 0 && nlq_used_rows(sp, nlq_desc_of(type_of_spec(sp)), capacity) <= n_rows) rc = orc_nlq_standalone(type_of_spec(sp), rounds, n_active, capacity, n_rows, trace);
+    if (rc == 0 && nlcf_used_rows(type_of_spec(sp), sp, capacity) <= n_rows) rc = orc_nlcf_standalone(type_of_spec(sp), capacity, n_rows, trace); /* (replaces `pi`) */
     return rc;
 }
 int orc_sha256_round_synthesize(const uint8_t state_in[32], const zkw_sha256_round_record *rounds, uint32_t n_active, uint32_t capacity,
@@ -420,6 +428,7 @@ static int keccak_like(const nl_spec *sp, const uint8_t state_in[200], const zkw
     int rc = orc_nl_synthesize(sp, capacity, hdr, fr, st, pi, n_rows, trace);
     free(hdr); free(fr); free(st);
     if (rc == 0 && nlq_used_rows(sp, nlq_desc_of(type_of_spec(sp)), capacity) <= n_rows) rc = orc_nlq_standalone_keccak(type_of_spec(sp), rounds, n_active, capacity, n_rows, trace);
+    if (rc == 0 && nlcf_used_rows(type_of_spec(sp), sp, capacity) <= n_rows) rc = orc_nlcf_standalone(type_of_spec(sp), capacity, n_rows, trace); /* (replaces `pi`) */
     return rc;
 }
 int orc_keccak_round_synthesize(const uint8_t state_in[200], const zkw_keccak_round_record *rounds, uint32_t n_active, uint32_t capacity,

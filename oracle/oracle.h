@@ -209,6 +209,13 @@ void orc_storage_sorter_public_inputs(const zkw_storage_sorter_instance *inst, s
 /* closed-form commitments of the circuits 3, 5, 6, 7, 10, 13 (instances: the type's zkw_*_instance records); -1 = unknown type */
 #define ORC_CF_MAX_FSM_LEN 448
 int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_t n, uint64_t *compact, uint64_t *pi);
+int orc_cf_encode(int circuit_type, const void *instances, size_t i, uint64_t *w /* 4 x ORC_CF_MAX_FSM_LEN */, size_t n[4], int flags[2]);
+/* the closed-form section of the netlist circuits (netlist_closed_form.c; include/zkw_netlist_closed_form.h) */
+int orc_nlcf_fill(int circuit_type, const void *instances, size_t i, uint32_t cycles, size_t n_rows, uint64_t *trace);
+int orc_nlcf_standalone(int circuit_type, uint32_t cycles, size_t n_rows, uint64_t *trace);
+uint64_t orc_nlcf_check(int circuit_type, const uint64_t *trace, uint32_t cycles, size_t n_rows, uint64_t *first_bad);
+void orc_nlcf_geometry(int circuit_type, uint32_t cycles, uint64_t out[9]);
+int orc_nlcf_cell(int circuit_type, uint32_t cycles, int what, uint32_t k, uint64_t out[2]);
 uint64_t orc_log_demux_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 /* storage_sorter_circuit.c: StorageSorter synthesis (circuit type 9) */
 int orc_storage_sorter_synthesize(const zkw_storage_sorter_instance *inst, const uint64_t *unsorted_enc, const uint64_t *sorted_enc,

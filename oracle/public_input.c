@@ -327,69 +327,81 @@ static size_t sap_fsm(const zkw_storage_application_fsm *f, uint64_t *o) {
     return m;
 }
 
-int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_t n, uint64_t *compact, uint64_t *pi) {
-    uint64_t in[64], out[80];
-    uint64_t *fi = malloc(2 * ORC_CF_MAX_FSM_LEN * sizeof(uint64_t)), *fo = fi + ORC_CF_MAX_FSM_LEN;
-    int rc = 0;
-    size_t first = 0;
-    for (size_t i = 0; i < n && rc == 0; i++) {
-        size_t n_in = 0, n_out = 0, n_fi = 0, n_fo = 0;
-        int start = 0, completion = 0;
-        switch (circuit_type) {
-            case 3: {
-                const zkw_decommitter_instance *w = (const zkw_decommitter_instance *)instances;
-                if (w[i].start_flag) first = i;
-                start = w[i].start_flag; completion = w[i].completion_flag;
-                /* CodeDecommitterInputData { memory_queue_initial_state, sorted_requests_queue_initial_state } */
-                n_in = orc_put_queue12(&w[first].memory_queue_initial_state, in);
-                n_in += orc_put_queue12(&w[first].sorted_requests_queue_initial_state, in + n_in);
-                n_out = orc_put_queue12(&w[i].memory_queue_final_state, out);
-                n_fi = dcm_fsm(&w[i].hidden_fsm_input, fi);
-                n_fo = dcm_fsm(&w[i].hidden_fsm_output, fo);
-                break;
-            }
-            case 5: case 6: case 7: {
-                const zkw_precompile_instance *w = (const zkw_precompile_instance *)instances;
-                const int kind = circuit_type - 5; /* ZKW_PRECOMPILE_KECCAK256 .. ZKW_PRECOMPILE_ECRECOVER */
-                if (w[i].start_flag) first = i;
-                start = w[i].start_flag; completion = w[i].completion_flag;
-                /* PrecompileFunctionInputData { initial_log_queue_state, initial_memory_queue_state } */
-                n_in = orc_put_queue4(&w[first].initial_log_queue_state, in);
-                n_in += orc_put_queue12(&w[first].initial_memory_queue_state, in + n_in);
-                n_out = orc_put_queue12(&w[i].final_memory_state, out);
-                n_fi = pre_fsm(kind, &w[i].hidden_fsm_input, fi);
-                n_fo = pre_fsm(kind, &w[i].hidden_fsm_output, fo);
-                break;
-            }
-            case 10: {
-                const zkw_storage_application_instance *w = (const zkw_storage_application_instance *)instances;
-                if (w[i].start_flag) first = i;
-                start = w[i].start_flag; completion = w[i].completion_flag;
-                /* StorageApplicationInputData { shard, initial_root_hash, initial_next_enumeration_counter,
-                   storage_application_log_state } */
-                in[0] = w[first].shard;
-                n_in = 1 + put_bytes(w[first].initial_root_hash, 32, in + 1);
-                n_in += put_u32s(w[first].initial_next_enumeration_counter, 2, in + n_in);
-                n_in += orc_put_queue4(&w[first].storage_application_log_state, in + n_in);
-                /* StorageApplicationOutputData { new_root_hash, new_next_enumeration_counter, state_diffs_keccak256_hash } */
-                n_out = put_bytes(w[i].new_root_hash, 32, out);
-                n_out += put_u32s(w[i].new_next_enumeration_counter, 2, out + n_out);
-                n_out += put_bytes(w[i].state_diffs_keccak256_hash, 32, out + n_out);
-                n_fi = sap_fsm(&w[i].hidden_fsm_input, fi);
-                n_fo = sap_fsm(&w[i].hidden_fsm_output, fo);
-                break;
-            }
-            case 13: {
-                const zkw_linear_hasher_instance *w = (const zkw_linear_hasher_instance *)instances;
-                start = w[i].start_flag; completion = w[i].completion_flag;
-                n_in = orc_put_queue4(&w[i].queue_state, in);      /* LinearHasherInputData { queue_state } */
-                n_out = put_bytes(w[i].keccak256_hash, 32, out); /* LinearHasherOutputData { keccak256_hash } */
-                break;                                          /* hidden FSM = (): nothing absorbed */
-            }
-            default: rc = -1; break;
+/* the four flat encodings of instance i (w: 4 slices of ORC_CF_MAX_FSM_LEN words: observable input — of the block's FIRST instance,
+   postprocessing/mod.rs:358-364 —, observable output, hidden FSM input, hidden FSM output), their lengths, {start, completion} */
+int orc_cf_encode(int circuit_type, const void *instances, size_t i, uint64_t *w, size_t n[4], int flags[2]) {
+    uint64_t *in = w, *out = w + ORC_CF_MAX_FSM_LEN, *fi = w + 2 * ORC_CF_MAX_FSM_LEN, *fo = w + 3 * ORC_CF_MAX_FSM_LEN;
+    size_t n_in = 0, n_out = 0, n_fi = 0, n_fo = 0, first = i;
+    int start = 0, completion = 0;
+    switch (circuit_type) {
+        case 3: {
+            const zkw_decommitter_instance *w_ = (const zkw_decommitter_instance *)instances;
+            while (first > 0 && !w_[first].start_flag) first--;
+            start = w_[i].start_flag; completion = w_[i].completion_flag;
+            /* CodeDecommitterInputData { memory_queue_initial_state, sorted_requests_queue_initial_state } */
+            n_in = orc_put_queue12(&w_[first].memory_queue_initial_state, in);
+            n_in += orc_put_queue12(&w_[first].sorted_requests_queue_initial_state, in + n_in);
+            n_out = orc_put_queue12(&w_[i].memory_queue_final_state, out);
+            n_fi = dcm_fsm(&w_[i].hidden_fsm_input, fi);
+            n_fo = dcm_fsm(&w_[i].hidden_fsm_output, fo);
+            break;
         }
-        if (rc == 0) compact_and_pi(start, completion, in, n_in, out, n_out, fi, n_fi, fo, n_fo, compact + 18 * i, pi + 4 * i);
+        case 5: case 6: case 7: {
+            const zkw_precompile_instance *w_ = (const zkw_precompile_instance *)instances;
+            const int kind = circuit_type - 5; /* ZKW_PRECOMPILE_KECCAK256 .. ZKW_PRECOMPILE_ECRECOVER */
+            while (first > 0 && !w_[first].start_flag) first--;
+            start = w_[i].start_flag; completion = w_[i].completion_flag;
+            /* PrecompileFunctionInputData { initial_log_queue_state, initial_memory_queue_state } */
+            n_in = orc_put_queue4(&w_[first].initial_log_queue_state, in);
+            n_in += orc_put_queue12(&w_[first].initial_memory_queue_state, in + n_in);
+            n_out = orc_put_queue12(&w_[i].final_memory_state, out);
+            n_fi = pre_fsm(kind, &w_[i].hidden_fsm_input, fi);
+            n_fo = pre_fsm(kind, &w_[i].hidden_fsm_output, fo);
+            break;
+        }
+        case 10: {
+            const zkw_storage_application_instance *w_ = (const zkw_storage_application_instance *)instances;
+            while (first > 0 && !w_[first].start_flag) first--;
+            start = w_[i].start_flag; completion = w_[i].completion_flag;
+            /* StorageApplicationInputData { shard, initial_root_hash, initial_next_enumeration_counter,
+               storage_application_log_state } */
+            in[0] = w_[first].shard;
+            n_in = 1 + put_bytes(w_[first].initial_root_hash, 32, in + 1);
+            n_in += put_u32s(w_[first].initial_next_enumeration_counter, 2, in + n_in);
+            n_in += orc_put_queue4(&w_[first].storage_application_log_state, in + n_in);
+            /* StorageApplicationOutputData { new_root_hash, new_next_enumeration_counter, state_diffs_keccak256_hash } */
+            n_out = put_bytes(w_[i].new_root_hash, 32, out);
+            n_out += put_u32s(w_[i].new_next_enumeration_counter, 2, out + n_out);
+            n_out += put_bytes(w_[i].state_diffs_keccak256_hash, 32, out + n_out);
+            n_fi = sap_fsm(&w_[i].hidden_fsm_input, fi);
+            n_fo = sap_fsm(&w_[i].hidden_fsm_output, fo);
+            break;
+        }
+        case 13: {
+            const zkw_linear_hasher_instance *w_ = (const zkw_linear_hasher_instance *)instances;
+            start = w_[i].start_flag; completion = w_[i].completion_flag;
+            n_in = orc_put_queue4(&w_[i].queue_state, in);      /* LinearHasherInputData { queue_state } */
+            n_out = put_bytes(w_[i].keccak256_hash, 32, out); /* LinearHasherOutputData { keccak256_hash } */
+            break;                                          /* hidden FSM = (): nothing absorbed */
+        }
+        default: return -1;
     }
-    free(fi);
+    n[0] = n_in; n[1] = n_out; n[2] = n_fi; n[3] = n_fo;
+    flags[0] = start ? 1 : 0; flags[1] = completion ? 1 : 0;
+    return 0;
+}
+
+int orc_closed_form_public_inputs(int circuit_type, const void *instances, size_t n, uint64_t *compact, uint64_t *pi) {
+    uint64_t *w = malloc(4 * ORC_CF_MAX_FSM_LEN * sizeof(uint64_t));
+    int rc = 0;
+    for (size_t i = 0; i < n && rc == 0; i++) {
+        size_t m[4];
+        int flags[2];
+        rc = orc_cf_encode(circuit_type, instances, i, w, m, flags);
+        if (rc == 0)
+            compact_and_pi(flags[0], flags[1], w, m[0], w + ORC_CF_MAX_FSM_LEN, m[1], w + 2 * ORC_CF_MAX_FSM_LEN, m[2], w + 3 * ORC_CF_MAX_FSM_LEN, m[3],
+                           compact + 18 * i, pi + 4 * i);
+    }
+    free(w);
     return rc;
 }

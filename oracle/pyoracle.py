@@ -652,7 +652,9 @@ def keccak_round_synthesize(build_out, instance_index, capacity, n_rows, public_
     rc = f(_p(state_in), _p(recs) if n else None, C.c_uint32(n), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_keccak_round_synthesize failed: {rc}")
-    return _nlq_overlay(5, trace, build_out, instance_index, capacity) if "requests" in build_out else trace
+    if "requests" not in build_out:
+        return trace  # (the sections the bare records imply: orc_nlq_standalone_keccak, orc_nlcf_standalone)
+    return _nlcf_overlay(5, _nlq_overlay(5, trace, build_out, instance_index, capacity), build_out["instances"], instance_index, capacity, PRECOMPILE_INSTANCE)
 
 
 def nl_geometry(circuit_type):
@@ -685,6 +687,51 @@ def nlq_cell(circuit_type, capacity, cycle, op, block=-1, region=0, k=0):
     f.restype = C.c_int
     assert f(C.c_int(circuit_type), C.c_uint32(capacity), C.c_uint32(cycle), C.c_uint32(op), C.c_int(block), C.c_int(region), C.c_uint32(k), _p(out)) == 0
     return int(out[0]), int(out[1])
+
+
+def nlcf_geometry(circuit_type, cycles):
+    """the closed-form section of a netlist circuit (include/zkw_netlist_closed_form.h): first row, rows, rows used by the whole trace,
+    header cells, permutations, words of the observable input / output and the hidden FSM input / output"""
+    out = np.zeros(9, np.uint64)
+    lib().orc_nlcf_geometry(C.c_int(circuit_type), C.c_uint32(cycles), _p(out))
+    return dict(zip(("first_row", "rows", "rows_used", "header_cells", "perms", "n_oi", "n_oo", "n_fi", "n_fo"), (int(x) for x in out)))
+
+
+def nlcf_cell(circuit_type, cycles, what, k=0, group=None, tie=0):
+    """(column, row) of a cell of the closed-form section: what = "flag" (k = 0 start, 1 completion), "oi" / "oo" / "fi" / "fo" word k,
+    "p2" (k = 130 * permutation + variable), "tie" (cell k of tie `tie` of group `group`: 0 a, 1 b, 2.. register digits), "pi" """
+    code = {"flag": 0, "oi": 1, "oo": 2, "fi": 3, "fo": 4, "p2": 5, "tie": 6, "pi": 7}[what]
+    if what == "tie":
+        k = (group << 28) | (tie << 16) | k
+    out = np.zeros(2, np.uint64)
+    f = lib().orc_nlcf_cell
+    f.restype = C.c_int
+    rc = f(C.c_int(circuit_type), C.c_uint32(cycles), C.c_int(code), C.c_uint32(k), _p(out))
+    assert rc == 0, rc
+    return int(out[0]), int(out[1])
+
+
+def _nlcf_overlay(circuit_type, trace, instances, instance_index, cycles, dtype):
+    """write the instance's closed-form section (words of its record, commitments, compact form; the PI row becomes the last
+    permutation's output) below the other sections"""
+    inst = np.ascontiguousarray(instances, dtype=dtype)
+    f = lib().orc_nlcf_fill
+    f.restype = C.c_int
+    rc = f(C.c_int(circuit_type), _p(inst), C.c_size_t(instance_index), C.c_uint32(cycles), C.c_size_t(trace.shape[1]), _p(trace))
+    if rc != 0:
+        raise RuntimeError(f"orc_nlcf_fill failed: {rc}")
+    return trace
+
+
+def nlq_check(circuit_type, trace, capacity):
+    """orc_nlq_check: the queue section's own checker alone (the whole-trace checkers add the netlist's and the closed-form section's)"""
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    first_bad = C.c_uint64(0)
+    f = lib().orc_nlq_check
+    f.restype = C.c_uint64
+    bad = f(C.c_int(circuit_type), _p(trace), C.c_uint32(capacity), C.c_size_t(trace.shape[1]), C.byref(first_bad))
+    v = first_bad.value if bad else 0
+    return int(bad), (v >> 56, (v >> 32) & 0xFFFFFF, v & 0xFFFFFFFF)
 
 
 def _nlq_overlay(circuit_type, trace, build_out, instance_index, capacity):
@@ -804,7 +851,7 @@ def ecrecover_synthesize(build_out, instance_index, capacity, n_rows, public_inp
     rc = g(C.c_int(7), C.c_uint32(capacity), _p(feed), queues, C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_nlq_synthesize failed: {rc}")
-    return trace
+    return _nlcf_overlay(7, trace, build_out["instances"], instance_index, capacity, PRECOMPILE_INSTANCE)
 
 
 def ecrecover_check(trace, capacity):
@@ -863,7 +910,9 @@ def sha256_round_synthesize(build_out, instance_index, capacity, n_rows, public_
                 else np.zeros(32, np.uint8))
     pi = (public_input if public_input is not None else closed_form_public_inputs(6, build_out["instances"])[1][instance_index])
     trace = sha256_round_synthesize_raw(state_in, build_out["sha256_rounds"][first:first + n], capacity, n_rows, pi)
-    return _nlq_overlay(6, trace, build_out, instance_index, capacity) if "requests" in build_out else trace
+    if "requests" not in build_out:
+        return trace
+    return _nlcf_overlay(6, _nlq_overlay(6, trace, build_out, instance_index, capacity), build_out["instances"], instance_index, capacity, PRECOMPILE_INSTANCE)
 
 
 
@@ -883,7 +932,9 @@ def code_decommitter_synthesize(build_out, instance_index, capacity, n_rows, pub
     rc = f(_p(np.ascontiguousarray(state_in)), _p(recs) if n else None, C.c_uint32(n), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_code_decommitter_round_synthesize failed: {rc}")
-    return _nlq_overlay(3, trace, build_out, instance_index, capacity) if "dedup_tails" in build_out else trace
+    if "dedup_tails" not in build_out:
+        return trace
+    return _nlcf_overlay(3, _nlq_overlay(3, trace, build_out, instance_index, capacity), build_out["instances"], instance_index, capacity, DECOMMITTER_INSTANCE)
 
 
 def code_decommitter_check(trace, capacity):
@@ -938,7 +989,7 @@ def linear_hasher_synthesize(messages, queue_state, capacity, n_rows):
     rc = h(_p(q) if q.size else None, C.c_size_t(q.size), _p(head), C.c_uint32(cycles), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_linear_hasher_queue_section failed: {rc}")
-    return trace, inst, pi
+    return _nlcf_overlay(13, trace, inst, 0, cycles, LINEAR_HASHER_INSTANCE), inst, pi
 
 
 def linear_hasher_check(trace, cycles):
@@ -1068,7 +1119,7 @@ def storage_application_synthesize(build_out, queries, instance_index, capacity,
            C.c_uint64(next_index), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
     if rc != 0:
         raise RuntimeError(f"orc_storage_application_synthesize failed: {rc}")
-    return trace
+    return _nlcf_overlay(10, trace, build_out["instances"], instance_index, capacity * SA_CYCLES_PER_WALK, STORAGE_APPLICATION_INSTANCE)
 
 
 def storage_application_check(trace, capacity):

@@ -1,6 +1,7 @@
 """Regenerates tests/golden/netlist_trace_digests.json: SHA-256 digests of small oracle-synthesized traces of the netlist
-circuits (types 5, 13, 6, 3; "zkw trace v4") on fixed seeds, public-input cells zeroed. Types 5, 6, 3 and 13 include their queue section
-(Poseidon2 rows of the pops / pushes, include/zkw_netlist_queue.h), so the digests also pin the permutation and the encodings.
+circuits (types 5, 13, 6, 3; "zkw trace v4") on fixed seeds. Types 5, 6, 3 and 13 include their queue section (Poseidon2 rows of the
+pops / pushes, include/zkw_netlist_queue.h) and — since round 5 — their closed-form section (include/zkw_netlist_closed_form.h: the words of the
+instance record, the commitment sponges, the public input they yield), so the digests also pin the permutation and the encodings.
 Run from the repository root:  python tests/golden/make_netlist_digests.py"""
 import hashlib
 import json

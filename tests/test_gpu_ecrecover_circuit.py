@@ -71,6 +71,8 @@ def test_traces_match_oracle_and_tamper_parity(ctx, oracle):
     qg = oracle.nlq_geometry(7, cap)
     cells += [(int(rng.integers(0, 80)), int(rng.integers(qg["first_row"], qg["rows_used"]))) for _ in range(8)]  # the queue section
     cells += [oracle.nlq_cell(7, cap, 0, 3, -1, 0, 6 + 2), oracle.nlq_cell(7, cap, 1, 5, -1, 0, 6), oracle.nlq_cell(7, cap, 0, 6, -1, 0, 6 + 19)]  # a read byte, ok, an address byte
+    from nlcf_cells import closed_form_cells
+    cells += closed_form_cells(oracle, 7, cap, rng)  # the closed-form section below the EC section
     hip = ctypes.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     n_flagged = 0

@@ -73,6 +73,8 @@ def test_traces_match_oracle_and_tamper_parity(ctx, oracle, ct):
                   qc(0, qg["ops"], k=1), qc(0, qg["ops"], k=4 + 12 + 1), qc(0, qg["ops"], k=G - 1), (G - 1, qc(2, 1)[1]), (G + 2, qc(2, 1)[1]),
                   (int(rng.integers(0, G)), qg["rows_used"] + 2)]
         cells += [(int(rng.integers(0, G)), int(rng.integers(qg["first_row"], qg["rows_used"]))) for _ in range(10)]
+    from nlcf_cells import closed_form_cells
+    cells += closed_form_cells(oracle, ct, cap, rng)  # the closed-form section: flags, words, ties, sponges, the PI row
     import ctypes
 
     hip = ctypes.CDLL("libamdhip64.so")
@@ -87,7 +89,7 @@ def test_traces_match_oracle_and_tamper_parity(ctx, oracle, ct):
         want = getattr(oracle, ocheck)(bad, cap)
         assert got == want, ((col, row), got, want)
         n_flagged += got[0] > 0
-    assert n_flagged >= len(cells) - 2  # (a PI cell is free; everything else is constrained)
+    assert n_flagged >= len(cells) - 2  # (nearly everything is constrained — since round 5 the PI row too)
     t.free()
     w.free()
 
@@ -238,6 +240,8 @@ def test_queue_section_tamper_parity_decommitter_and_linear_hasher(ctx, oracle, 
         cells += [qc(1, 0, -1, 0, 80), qc(1, 1, -1, 0, 108), qc(1, 0, -1, 0, 18), qc(1, 0, 2, 0, 40)]  # a written_value byte, a tx byte, tx_number, the third permutation
     cells += [(int(rng.integers(0, G)), int(rng.integers(qg["first_row"], qg["rows_used"]))) for _ in range(20)]
     cells += [(int(rng.integers(0, cols - 1)), int(rng.integers(rpc, 3 * rpc))) for _ in range(8)]  # the netlist of cycles 1-2: hashed cells among them
+    from nlcf_cells import closed_form_cells
+    cells += closed_form_cells(oracle, ct, cycles, rng)
     t = native.Trace(ctx, N_ROWS, 1, n_cols=cols)
     hip = ctypes.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]

@@ -46,7 +46,7 @@ def test_traces_match_oracle(ctx, oracle, n, capacity):
     lay = native.circuit_layout(10, capacity)
     g = oracle.nl_geometry(10)
     assert int(lay["num_columns"]) == native.SA_COLS == g["cols"] and int(lay["total_table_rows"]) == g["table_rows"] == 132352
-    assert int(lay["rows_per_cycle"]) == g["rows_per_cycle"] and int(lay["rows_used"]) == capacity * WALK * g["rows_per_cycle"] + 2 * 2 + 1
+    assert int(lay["rows_per_cycle"]) == g["rows_per_cycle"] and int(lay["rows_used"]) == capacity * WALK * g["rows_per_cycle"] + 2 * 2 + 1 + oracle.nlcf_geometry(10, capacity * WALK)["rows"]
     t = native.Trace(ctx, N_ROWS, ni, n_cols=native.SA_COLS)
     garbage = np.full((native.SA_COLS, N_ROWS), 0x1234567, np.uint64)  # the slot's previous tenant
     ctx.synchronize()
@@ -82,6 +82,8 @@ def test_tamper_parity(ctx, oracle):
     cells += [(cols - 1, int(rng.integers(0, g["table_rows"]))) for _ in range(4)] + [(cols - 1, g["table_rows"] + 5)]  # multiplicities
     cells += [(int(rng.integers(0, G)), used + k) for k in range(0, 2 * 2 + 3)]                             # boundary rows, PI, below
     cells += [(0, rpc), (1, rpc), (2, rpc), (3, 2 * rpc), (0, WALK * rpc), (2, WALK * rpc)]                 # reset / idle / masks of level and leaf cycles
+    from nlcf_cells import closed_form_cells
+    cells += closed_form_cells(oracle, 10, capacity * WALK, rng)  # the closed-form section: words, commitment sponges, the PI row
     hip = _hip()
     n_flagged = 0
     for col, row in cells:

@@ -5,7 +5,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALLOWED = re.compile(r"^(zkw_types\.h|zkw_poseidon2_params\.h|zkw_[a-z0-9_]+_spec\.h|zkw_netlist\.h|zkw_netlist_queue\.h|zkw_ecrecover_layout\.h)$")
+ALLOWED = re.compile(r"^(zkw_types\.h|zkw_poseidon2_params\.h|zkw_[a-z0-9_]+_spec\.h|zkw_netlist\.h|zkw_netlist_queue\.h|zkw_netlist_closed_form\.h|zkw_ecrecover_layout\.h)$")
 
 
 def _includes(path):
@@ -27,7 +27,7 @@ def test_oracle_includes_only_format_and_table_headers():
             seen.add(base)
     assert "zkw_ecrecover_layout.h" in seen and "zkw_netlist.h" in seen
     # and the shared headers themselves include nothing that carries semantics
-    for base in ("zkw_netlist.h", "zkw_ecrecover_layout.h", "zkw_netlist_queue.h"):
+    for base in ("zkw_netlist.h", "zkw_ecrecover_layout.h", "zkw_netlist_queue.h", "zkw_netlist_closed_form.h"):
         for inc in _includes(os.path.join(ROOT, "include", base)):
             assert ALLOWED.match(os.path.basename(inc)), (base, inc)
 

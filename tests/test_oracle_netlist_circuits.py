@@ -159,8 +159,9 @@ def test_trace_satisfies_and_tampering_is_caught(oracle, specs, ct):
     assert int(t[g["cols"] - 1].sum()) == cap * sum(len(spec.step_types[k].slots) for k, _ in spec.cycle)  # every lookup counted once
     assert not t[g["cols"] - 1, g["table_rows"]:].any()
     cells = _cells(spec, cap)
-    cells["below"] = (cells["below"][0], oracle.nlq_geometry(ct, cap)["rows_used"] + 3)  # below the queue section, where there is one
-    want = {"lookup_out": 1, "lookup_in": 1, "reset": 3, "mask0": 2, "hdr_lookup": 6, "mult": 5, "bnd_out": 4, "below": 6, "hdr_general": 6,
+    cells["below"] = (cells["below"][0], oracle.nlcf_geometry(ct, cap)["rows_used"] + 3)  # below the queue and closed-form sections
+    # (a state element after the last cycle: the closed-form section's tie to the FSM-output word objects first, kind 2, then the boundary rule, kind 4)
+    want = {"lookup_out": 1, "lookup_in": 1, "reset": 3, "mask0": 2, "hdr_lookup": 6, "mult": 5, "bnd_out": 2, "below": 6, "hdr_general": 6,
             "gate_known": 2, "gate_new": 2, "gate_unused": 6}
     for name, (col, row) in cells.items():
         bad = t.copy()

@@ -1,0 +1,159 @@
+"""The closed-form section of the netlist circuits (include/zkw_netlist_closed_form.h; oracle/netlist_closed_form.c): what the reference's
+circuits derive around their round function — commitments of the closed-form input, the compact form, the public input
+(src/witness/utils.rs:269-306), the start-flag selection of the state the first cycle continues from — is derived in the trace:
+tampering with the PI row, a flag, a word of the FSM / observable encodings, a register or a permutation variable is caught."""
+import numpy as np
+import pytest
+
+from era_zkevm_test_harness_amd import synthetic
+
+N_ROWS = 1 << 18
+
+
+def _precompile_case(oracle, kind, cap):
+    req, mq = synthetic.precompile_trace(kind, 9, seed=3, max_rounds=4)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    w = oracle.precompile_build(kind, req, tails, mq, cap, np.zeros(1, oracle.QUEUE_STATE12))
+    synth = {0: oracle.keccak_round_synthesize, 1: oracle.sha256_round_synthesize}[kind]
+    check = {0: oracle.keccak_round_check, 1: oracle.sha256_round_check}[kind]
+    return w, synth, check
+
+
+def _case(oracle, ct):
+    """(witness dict, synth(w, i) -> trace, check(trace), cycles)"""
+    if ct in (5, 6):
+        cap = 6 if ct == 5 else 7
+        w, synth, check = _precompile_case(oracle, ct - 5, cap)
+        return w, (lambda i: synth(w, i, cap, N_ROWS)), (lambda t: check(t, cap)), cap
+    if ct == 3:
+        from oracle import block as ob
+        a = ob.create_artifacts_after_vm(synthetic.block_after_vm(seed=2), {ob.CODE_DECOMMITTER: 7})
+        w = a["witnesses"]["code_decommitter"]
+        return w, (lambda i: oracle.code_decommitter_synthesize(w, i, 7, N_ROWS)), (lambda t: oracle.code_decommitter_check(t, 7)), 7
+    raise AssertionError(ct)
+
+
+@pytest.mark.parametrize("ct", [6, 3, 5])
+def test_instances_satisfy_and_the_public_input_is_the_reference_commitment(oracle, ct):
+    w, synth, check, cycles = _case(oracle, ct)
+    n = w["instances"].size
+    assert n >= 3  # a first, a middle and a last instance: start / completion flags in all combinations that occur
+    compact, pis = oracle.closed_form_public_inputs(ct, w["instances"])
+    g = oracle.nlcf_geometry(ct, cycles)
+    assert g["rows"] > 0 and g["rows_used"] == g["first_row"] + g["rows"]
+    for i in range(n):
+        t = synth(i)
+        assert check(t) == (0, (0, 0, 0)), i
+        col, row = oracle.nlcf_cell(ct, cycles, "pi", 0)
+        assert t[:4, row].tolist() == pis[i].tolist()  # the in-trace sponges yield utils.rs:269-306's value
+        assert int(t[oracle.nlcf_cell(ct, cycles, "flag", 0)]) == int(w["instances"]["start_flag"][i])
+        assert int(t[oracle.nlcf_cell(ct, cycles, "flag", 1)]) == int(w["instances"]["completion_flag"][i])
+        # the compact form's 18 words are the inputs of the last three permutations
+        cp0 = g["perms"] - 3
+        words = [int(t[oracle.nlcf_cell(ct, cycles, "p2", 130 * (cp0 + k // 8) + k % 8)]) for k in range(18)]
+        assert words == compact[i].tolist()
+        assert not t[:, g["rows_used"]:].any() or g["rows_used"] < int(oracle.nl_geometry(ct)["table_rows"])
+
+
+@pytest.mark.parametrize("ct", [6, 3, 5])
+def test_tampering_is_caught(oracle, ct):
+    w, synth, check, cycles = _case(oracle, ct)
+    g = oracle.nlcf_geometry(ct, cycles)
+    mid, last = 1, w["instances"].size - 1
+    t_mid, t_last = synth(mid), synth(last)
+    assert check(t_mid)[0] == 0 and check(t_last)[0] == 0
+    cell = lambda *a, **k: oracle.nlcf_cell(ct, cycles, *a, **k)  # noqa: E731
+    # (cell, the violation kinds that may be reported first)
+    cases = {
+        "pi": (cell("pi", 2), (4,)), "start": (cell("flag", 0), (2, 3, 7)), "completion": (cell("flag", 1), (2, 3, 7)),
+        "oi_word": (cell("oi", 3), (2,)), "oo_word": (cell("oo", 20), (2,)),
+        "fi_flag_word": (cell("fi", 1 if ct != 3 else 21), (2,)),     # a word no tie names: only its sponge copy objects
+        "fi_state_word": (cell("fi", 5 if ct != 3 else 2), (2,)),     # the hash state: the tie's copy objects first
+        "fo_word": (cell("fo", g["n_fo"] - 2), (2,)),
+        "tie_a": (cell("tie", 0, group=0, tie=1), (2,)), "tie_digit": (cell("tie", 2, group=2, tie=0), (2,)),
+        "p2_in": (cell("p2", 130 * 1 + 3), (2,)), "p2_mid": (cell("p2", 130 * 2 + 60), (8,)), "p2_out": (cell("p2", 130 * 0 + 127), (2, 8)),
+        "cp_out": (cell("p2", 130 * (g["perms"] - 1) + 119), (4, 8)),
+        "header_unused": ((oracle.nl_geometry(ct)["general"] - 1, g["first_row"] + -(-g["header_cells"] // oracle.nl_geometry(ct)["general"]) - 1), (6,)),
+        "section_lookup_col": ((oracle.nl_geometry(ct)["general"] + 1, g["first_row"] + 2), (6,)),
+    }
+    if g["header_cells"] % oracle.nl_geometry(ct)["general"] == 0:
+        del cases["header_unused"]
+    for name, ((col, row), kinds) in cases.items():
+        bad = t_mid.copy()
+        bad[col, row] += 1
+        n, first = check(bad)
+        assert n > 0 and first[0] in kinds, (name, (col, row), n, first)
+    # registers the section is tied to: the queue states of the queue section, the hash state of the boundary rows
+    q = oracle.nlq_geometry(ct, cycles)
+    for name, (col, row) in {"qbnd_before": (1, q["first_row"]), "bnd_in": (2, cycles * oracle.nl_geometry(ct)["rows_per_cycle"])}.items():
+        bad = t_mid.copy()
+        bad[col, row] += 1
+        n, first = check(bad)
+        assert n > 0 and first[0] == 2, (name, n, first)
+    # a CONSISTENT forgery of a word — the word, its sponge and everything downstream recomputed — moves the public input: the words
+    # are bound by the PI row (the aggregation layer holds the public input), and a tied word by its register too
+    for what, k in (("fi", 1 if ct != 3 else 21), ("oi", 8)):
+        inst = w["instances"].copy()
+        forged = dict(w)
+        if what == "fi":
+            name = "read_words_for_round" if ct != 3 else "state_get_from_queue"
+            inst["hidden_fsm_input"][name][mid] ^= 1
+        else:
+            q0 = "initial_log_queue_state" if ct != 3 else "memory_queue_initial_state"
+            inst[q0]["length"][0] += 1
+        forged["instances"] = inst
+        if ct == 3:
+            t2 = oracle.code_decommitter_synthesize(forged, mid, 7, N_ROWS)
+        else:
+            t2 = (oracle.keccak_round_synthesize if ct == 5 else oracle.sha256_round_synthesize)(forged, mid, cycles, N_ROWS)
+        assert check(t2)[0] == 0  # self-consistent ...
+        col, row = cell("pi", 0)
+        assert t2[:4, row].tolist() != t_mid[:4, row].tolist()  # ... under another public input
+    # a forged TIED word (the memory queue's tail in the FSM input) is not even self-consistent: the register disagrees
+    inst = w["instances"].copy()
+    inst["hidden_fsm_input"]["memory_queue_state"]["tail"][mid][3] += 1
+    forged = dict(w)
+    forged["instances"] = inst
+    t2 = (oracle.code_decommitter_synthesize(forged, mid, 7, N_ROWS) if ct == 3 else
+          (oracle.keccak_round_synthesize if ct == 5 else oracle.sha256_round_synthesize)(forged, mid, cycles, N_ROWS))
+    n, first = check(t2)
+    assert n == 1 and first[0] == 7
+    # the last instance: completion gates the observable output (the final memory queue state) and frees the hash state of the FSM output
+    oo_tail = cell("oo", 12 + 5)
+    bad = t_last.copy()
+    bad[oo_tail] += 1
+    assert check(bad)[0] > 0
+    assert int(t_last[cell("flag", 1)]) == 1 and int(t_mid[cell("flag", 1)]) == 0
+    assert not any(int(t_mid[cell("oo", k)]) for k in range(g["n_oo"]))  # not the last instance: the placeholder output
+
+
+def test_linear_hasher_and_storage_application_sections(oracle):
+    """type 13 (no hidden FSM: the queue's head and the digest are tied to the observable input / output) and type 10 (no ties: words
+    committed, commitments and public input derived)"""
+    q = synthetic.mixed_log_queue(36, seed=8)[:7]
+    qs = np.zeros(1, oracle.QUEUE_STATE4)
+    qs["head"][0] = [5, 6, 7, 8]
+    t, inst, pi = oracle.linear_hasher_synthesize(q, qs, 20, N_ROWS)
+    cycles = oracle.linear_hasher_cycles(20)
+    assert oracle.linear_hasher_check(t, cycles) == (0, (0, 0, 0))
+    assert t[:4, oracle.nlcf_cell(13, cycles, "pi", 0)[1]].tolist() == np.asarray(pi).tolist()
+    for name, (col, row), kinds in (("pi", oracle.nlcf_cell(13, cycles, "pi", 1), (4,)), ("head word", oracle.nlcf_cell(13, cycles, "oi", 2), (2,)),
+                                    ("digest word", oracle.nlcf_cell(13, cycles, "oo", 31), (2,)), ("tail word (free)", oracle.nlcf_cell(13, cycles, "oi", 6), (2,)),
+                                    ("digest byte in the netlist", (3, cycles * oracle.nl_geometry(13)["rows_per_cycle"] + -(-200 // oracle.nl_geometry(13)["general"])), (2, 4))):
+        bad = t.copy()
+        bad[col, row] += 1
+        n, first = oracle.linear_hasher_check(bad, cycles)
+        assert n > 0 and first[0] in kinds, (name, n, first)
+    from sap_case import storage_application_case
+    sq, tails, tree, _idx, _paths = storage_application_case(oracle, 5, seed=9)
+    sap = oracle.storage_application_build(tree, sq, tails, 3)
+    _c, pis = oracle.closed_form_public_inputs(10, sap["instances"])
+    for i in range(sap["instances"].size):
+        t = oracle.storage_application_synthesize(sap, sq, i, 3, N_ROWS)
+        assert oracle.storage_application_check(t, 3) == (0, (0, 0, 0))
+        cyc = 3 * oracle.SA_CYCLES_PER_WALK
+        assert t[:4, oracle.nlcf_cell(10, cyc, "pi", 0)[1]].tolist() == pis[i].tolist()
+        for what, k in (("pi", 0), ("fi", 40), ("oo", 65), ("p2", 130 * 7 + 100)):
+            bad = t.copy()
+            bad[oracle.nlcf_cell(10, cyc, what, k)] += 1
+            assert oracle.storage_application_check(bad, 3)[0] > 0, (i, what)

@@ -99,7 +99,7 @@ def test_section_tampering_is_caught(oracle, ct):
         "old": (cell(3, 1, -1, 2, 9), (2,)), "new": (cell(3, 1, -1, 3, 2), (2,)),
         "p2_in": (cell(3, 1, 0, 0, 3), (2,)), "p2_mid": (cell(3, 1, 0, 0, 70), (8,)), "p2_out": (cell(3, 1, 0, 0, 129), (7,)),
         "pop_comp": (cell(2, 0, -1, 0, 5), (7,)), "pop_p2": (cell(2, 0, 0 if ct == 3 else 1, 0, 40), (8,)),
-        "qbnd_in": (cell(0, g["ops"], k=1), (2,)), "qbnd_out": (cell(0, g["ops"], k=w0 + 12 + 1), (4,)),
+        "qbnd_in": (cell(0, g["ops"], k=1), (2,)), "qbnd_out": (cell(0, g["ops"], k=w0 + 12 + 1), (2, 4)),
         "qbnd_unused": (cell(0, g["ops"], k=G - 1), (6,)),
         "unused": ((G - 1, cell(2, 1, -1, 0, 0)[1]), (6,)),
         "section_lookup_col": ((G + 2, cell(2, 1)[1]), (6,)),
@@ -125,8 +125,10 @@ def test_section_tampering_is_caught(oracle, ct):
         init = np.asarray(bo["mem_in"]["tail"][0], dtype=np.uint64)
         bo["mem_tails"] = oracle.queue_push_chain_full(enc, init)
         for i in range(bo["instances"].size):
-            n, first = check(synth(bo, i, cap, N_ROWS), cap)
-            if n:
+            forged = synth(bo, i, cap, N_ROWS)
+            n, first = oracle.nlq_check(ct, forged, cap)  # (the section's own checker: the instance records were not re-made, so the
+            if n:                                         # closed-form section objects as well — the memory queue's tail is committed there)
+                assert check(forged, cap)[0] >= n
                 assert first[0] == 7 and first[1] >= 0x1000, first
                 break
         else:
@@ -143,7 +145,7 @@ def test_section_tampering_is_caught(oracle, ct):
         bo["mem_queries"] = mq
         bo["mem_tails"] = oracle.queue_push_chain_full(oracle.encode_memory_queries(mq), np.asarray(bo["mem_in"]["tail"][0], dtype=np.uint64))
         inst = int(np.searchsorted(np.cumsum(bo["instances"]["num_rounds"]), r, side="right"))
-        n, first = check(synth(bo, inst, cap, N_ROWS), cap)
+        n, first = oracle.nlq_check(ct, synth(bo, inst, cap, N_ROWS), cap)
         first_in_instance = r == int(bo["instances"]["first_round"][inst])
         assert (n == 0) if first_in_instance else (n > 0 and first[0] == 7 and first[1] >= 0x1000 + 11), (n, first)
     # ... and a digest written to another page than the call's ABI names (self-consistent again): only the registers that carry the ABI's
@@ -159,7 +161,7 @@ def test_section_tampering_is_caught(oracle, ct):
         bo["mem_queries"] = mq
         bo["mem_tails"] = oracle.queue_push_chain_full(oracle.encode_memory_queries(mq), np.asarray(bo["mem_in"]["tail"][0], dtype=np.uint64))
         inst = int(np.searchsorted(np.cumsum(bo["instances"]["num_rounds"]), last, side="right"))
-        n, first = check(synth(bo, inst, cap, N_ROWS), cap)
+        n, first = oracle.nlq_check(ct, synth(bo, inst, cap, N_ROWS), cap)
         assert n == 1 and first[0] == 7 and first[1] == 0x1000 + 21, (n, first)
     if ct == 5:
         return

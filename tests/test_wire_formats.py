@@ -38,7 +38,10 @@ def test_layouts_against_reference_hints(tmp_path):
         # the PI row closes the netlist part; types 6, 3, 5 and 13 carry their queue section (Poseidon2 rows of the pops / pushes) below it
         # (type 7 also its EC section below that, and its lookup tables are longer than its gates: rows_used = 197 632 table rows)
         assert (int(lay["queue_rows_per_cycle"]) > 0) == (t in (6, 3, 5, 13, 7))
-        pi_row = int(lay["queue_first_row"]) - 1 if int(lay["queue_rows_per_cycle"]) else int(lay["rows_used"]) - 1
+        # the closed-form section (flags, words, ties, commitment sponges: docs/KERNELS.md 3.22) closes every one of them
+        assert int(lay["closed_form_rows"]) > int(lay["closed_form_header_rows"]) > 0
+        assert int(lay["closed_form_first_row"]) + int(lay["closed_form_rows"]) == int(lay["rows_used"]) or t == 7
+        pi_row = int(lay["queue_first_row"]) - 1 if int(lay["queue_rows_per_cycle"]) else int(lay["closed_form_first_row"]) - 1
         assert wire.finalization_hint_of_layout(t)["public_inputs"][0][1] == pi_row
         if t == 7:
             assert int(lay["ec_first_row"]) + int(lay["capacity"]) * int(lay["ec_rows_per_cycle"]) <= int(lay["rows_used"]) == int(lay["total_table_rows"])

@@ -13,7 +13,7 @@ timeout -s KILL 1500 python bench.py --steps 20 > "$OUT/bench_default.json" 2> "
 timeout -s KILL 900 python bench.py --pipelines 1 --no-cpu-baseline --no-full-block --no-h2d --no-sensitivity > "$OUT/bench_sequential.json" 2> "$OUT/bench_sequential.err"
 # 2. the same command under rocprofv3 --kernel-trace --stats
 cd /tmp && rm -rf /tmp/prof_stats && timeout -s KILL 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- \
-    env ZKW_BATCHED_BLOCKS=48 python "$ROOT/bench.py" --no-cpu-baseline --no-sensitivity > "$OUT/bench_default_under_rocprofv3.json" 2> "$OUT/rocprof_stats.err"
+    env ZKW_BATCHED_BLOCKS=16 python "$ROOT/bench.py" --no-cpu-baseline --no-sensitivity > "$OUT/bench_default_under_rocprofv3.json" 2> "$OUT/rocprof_stats.err"
 cp "$(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1)" "$OUT/bench_default_kernel_stats.csv"
 # 3. HBM counters AT THE BENCHMARKED BATCH, one pass each (never combined with other trace domains): one timed step of the
 #    sequential form (counter collection serialises the dispatches anyway)
