@@ -55,8 +55,15 @@ static __global__ __launch_bounds__(256) void k_nlcf_sponges(nlcf_desc d, const 
         const u64 v = k < 2 ? sh_flags[k] : k < w1 ? sh_w[0][k - 2] : k < w2 ? sh_w[1][k - w1] : k < w3 ? sh_w[2][k - w2] : sh_w[3][k - w3];
         NLCF_H(k) = v;
     }
-    // the sponges: row p of wave 0 = part p, a uniform number of rounds (a row that has run out permutes zeros and stores nothing)
+    // the sponges: row p of wave 0 = part p, a uniform number of rounds (a row that has run out permutes zeros and stores nothing).
+    // A permutation's 130 stores go to (slot % G, row0 + slot / G): the division by the run-time G is a multiplication by its reciprocal
+    // (exact for slot < 2^16), the block's first row is computed once per permutation — the chain is latency, every instruction of it counts
     const u32 g = lane & 15, part = lane >> 4;
+    const u32 g_inv = (u32)((0x100000000ull + G - 1) / G), p2_rows = nlq_rows_for(NLQ_P2_CELLS, G), hdr_rows = nlcf_header_rows(&d, G);
+    auto store_p2 = [&](u64* base /* (column 0, first row of the block) */, u32 slot, u64 v) {
+        const u32 r = (u32)(((u64)slot * g_inv) >> 32), c = slot - r * G;
+        base[(size_t)c * n_rows + r] = v;
+    };
     p2::Coop co;
     co.init((int)g);
     if (wave == 0) {
@@ -64,12 +71,13 @@ static __global__ __launch_bounds__(256) void k_nlcf_sponges(nlcf_desc d, const 
         u32 most = 0;
         for (u32 p = 0; p < 4; p++) most = max(most, (u32)((d.n[p] + 7) / 8));
         u64 out = g == 11 ? (u64)n : 0;  // overwrite mode from (0, .., 0, n): apply_length_specialization
-        for (u32 q = 0; q < most; q++) {
+        u64* base = trace + c0 + hdr_rows + (size_t)perm0 * p2_rows;
+        for (u32 q = 0; q < most; q++, base += p2_rows) {
             const bool on = q < perms;
             u64 x = 0;
             if (on && g < 8) x = 8 * q + g < n ? sh_w[part][8 * q + g] : 0;
             else if (on && g < 12) x = out;
-            const u64 y = p2::coop_flattened(co, x, g, [&](u32 slot, u64 v) { if (on) NLCF_P(perm0 + q, slot) = v; });
+            const u64 y = p2::coop_flattened(co, x, g, [&](u32 slot, u64 v) { if (on) store_p2(base, slot, v); });
             if (on) out = y;
         }
         if (g < 4) sh_c[part][g] = n ? out : 0;  // an empty encoding commits to zero
@@ -77,14 +85,14 @@ static __global__ __launch_bounds__(256) void k_nlcf_sponges(nlcf_desc d, const 
     __syncthreads();
     if (wave == 0) {  // the compact form [start, completion, c(OI), c(OO), c(FI), c(FO)] -> the public input (row 0 of the wave)
         const bool on = part == 0;
-        const u32 cp0 = nlcf_perm0(&d, 4);
+        u64* base = trace + c0 + hdr_rows + (size_t)nlcf_perm0(&d, 4) * p2_rows;
         u64 out = g == 11 ? (u64)NLCF_CP_WORDS : 0;
-        for (u32 q = 0; q < NLCF_CP_PERMS; q++) {
+        for (u32 q = 0; q < NLCF_CP_PERMS; q++, base += p2_rows) {
             const u32 k = 8 * q + g;
             u64 x = 0;
             if (on && g < 8) x = k >= NLCF_CP_WORDS ? 0 : k < 2 ? sh_flags[k] : sh_c[(k - 2) / 4][(k - 2) % 4];
             else if (on && g < 12) x = out;
-            const u64 y = p2::coop_flattened(co, x, g, [&](u32 slot, u64 v) { if (on) NLCF_P(cp0 + q, slot) = v; });
+            const u64 y = p2::coop_flattened(co, x, g, [&](u32 slot, u64 v) { if (on) store_p2(base, slot, v); });
             out = y;
         }
     }

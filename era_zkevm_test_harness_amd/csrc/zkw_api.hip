@@ -499,6 +499,10 @@ struct ChainService {
             int rc = ZKW_OK;
             std::string err;
             auto fail_hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == ZKW_OK) { rc = ZKW_ERR_HIP; err = std::string(what) + ": " + hipGetErrorString(e); } };
+            static const bool log_batches = getenv("ZKW_CHAIN_LOG") != nullptr;  // debugging aid: one line per batch (when it left, what it carries)
+            const auto t_launch = std::chrono::steady_clock::now();
+            size_t longest = 0;
+            if (log_batches) for (const ChainJob& j : b->full) longest = std::max(longest, (size_t)j.n);
             const size_t bytes = b->full.size() * sizeof(ChainJob) + b->log.size() * sizeof(LogChainJob) + 256;
             if (!st || !st_log) { rc = ZKW_ERR_HIP; err = "chain service: no stream"; }
             if (rc == ZKW_OK && cap < bytes) {  // grow-only; the outgrown pair goes back to the allocation cache (no hipFree stall)
@@ -544,6 +548,12 @@ struct ChainService {
                 b->done[0] = b->done[1] = true;
             }
             cv_done.notify_all();
+            if (log_batches) {
+                static const auto t_zero = std::chrono::steady_clock::now();
+                const auto us = [&](std::chrono::steady_clock::time_point t) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(t - t_zero).count(); };
+                fprintf(stderr, "[zkw chain] batch of %d waiters: %zu full-width chains (longest %zu items), %zu log chains; left at %ld us, done at %ld us\n", b->waiters, b->full.size(), longest,
+                        b->log.size(), us(t_launch), us(std::chrono::steady_clock::now()));
+            }
         }
         if (pin) pin_free(pin);
         if (dev) dev_free(dev);

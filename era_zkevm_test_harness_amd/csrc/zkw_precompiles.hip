@@ -997,19 +997,22 @@ int nl_launch_fill_lanes(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, 
     return launch_check("k_nl_expand");
 }
 
+using NlAfterFill = std::function<int()>;  // runs once the fill kernel is queued, before the histogram / finish / queue-section kernels (the closed-form sponges fork here)
 template <int W, int R>
-int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
+int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows, const NlAfterFill& after_fill) {
     // the lane-per-cycle form is opt-in (zkw_set_netlist_fill_form, or ZKW_NL_LANES=1 for a whole process): bit-identical, measured
     // SLOWER than the wave-per-cycle form on every circuit
     static const int lanes_env = [] { const char* e = getenv("ZKW_NL_LANES"); return e ? atoi(e) : 0; }();
     if ((lanes_env || ctx->netlist_fill_form == 1) && nc->host.walk_lds <= 160 * 1024) {
         ZKW_TRY((nl_launch_fill_lanes<W, R>(ctx, nc, d_jobs, nj, capacity, n_rows)));
+        if (after_fill) ZKW_TRY(after_fill());
         { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
         return launch_check("k_nl_hist");
     }
     // (a call with few cycles keeps 8 waves per workgroup: twice the workgroups, so that every CU has one)
     if (nc->host.fill_waves == 16 && (size_t)((capacity + 15) / 16) * nj >= 128) ZKW_TRY((nl_launch_fill_w<W, R, 16>(ctx, nc, d_jobs, nj, capacity, n_rows)));
     else ZKW_TRY((nl_launch_fill_w<W, R, 8>(ctx, nc, d_jobs, nj, capacity, n_rows)));
+    if (after_fill) ZKW_TRY(after_fill());
     { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
     return launch_check("k_nl_hist");
 }
@@ -1017,9 +1020,8 @@ int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsign
 // synthesis of instances of one netlist circuit: `prepare` turns the builder's records into the engine's inputs (header bits, free
 // elements, the state before every cycle) at the pointers of the jobs it is handed; `capacity` is in cycles
 using NlPrepare = std::function<int(std::vector<NlPrepJob>&)>;
-using NlAfterClear = std::function<int()>;  // runs once the slots are claimed and cleared, before the fills (the closed-form sponges start here, on a side stream)
 int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows,
-                       const NlAfterClear& after_clear = {}) {
+                       const NlAfterFill& after_fill = {}) {
     const NlCached* nc = nullptr;
     ZKW_TRY(nl_get(ctx, circuit_type, &nc));
     const nl_spec& S = nc->host.s;
@@ -1062,15 +1064,14 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
     NlJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("nl_jobs", jobs, &d_jobs));
     const unsigned nj = (unsigned)ni;
-    if (after_clear) ZKW_TRY(after_clear());
     ZKW_TRY(prepare(prep));
     static_assert(SA_W == LH_W && SA_R == LH_R, "StorageApplication shares the fill instantiation of the LinearHasher geometry");
     switch (circuit_type) {
-        case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        case 7: ZKW_TRY((nl_launch_fill<EK_W, EK_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;
-        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows))); break;  // 13 and 10: 3 x 26
+        case 6: ZKW_TRY((nl_launch_fill<SC_W, SC_R>(ctx, nc, d_jobs, nj, capacity, n_rows, after_fill))); break;
+        case 3: ZKW_TRY((nl_launch_fill<DC_W, DC_R>(ctx, nc, d_jobs, nj, capacity, n_rows, after_fill))); break;
+        case 5: ZKW_TRY((nl_launch_fill<KC_W, KC_R>(ctx, nc, d_jobs, nj, capacity, n_rows, after_fill))); break;
+        case 7: ZKW_TRY((nl_launch_fill<EK_W, EK_R>(ctx, nc, d_jobs, nj, capacity, n_rows, after_fill))); break;
+        default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows, after_fill))); break;  // 13 and 10: 3 x 26
     }
     { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
     return claims.commit_if(launch_check("k_nl_finish"));
@@ -1078,7 +1079,7 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
 
 // ... from the block's round records (`sha_like`: zkw_sha256_round_record, else zkw_keccak_round_record)
 int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_rounds, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows,
-                  const NlAfterClear& after_clear = {}) {
+                  const NlAfterFill& after_fill = {}) {
     return nl_synthesize_with(ctx, circuit_type, [&](std::vector<NlPrepJob>& prep) {
         const size_t rec_bytes = sha_like ? sizeof(zkw_sha256_round_record) : sizeof(zkw_keccak_round_record);
         for (size_t k = 0; k < prep.size(); k++) {
@@ -1091,7 +1092,7 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
         if (sha_like) { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_sha, dim3(capacity + 1, nj), dim3(128), 0, ctx->stream, d_prep, capacity); }
         else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
         return launch_check("k_nl_prepare");
-    }, inst, capacity, n_rows, after_clear);
+    }, inst, capacity, n_rows, after_fill);
 }
 
 // the queue section of the instances nl_synthesize has just filled (include/zkw_netlist_queue.h): request-queue pops and memory-queue
@@ -1128,9 +1129,13 @@ int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std
 
 // ---- the closed-form section (include/zkw_netlist_closed_form.h; netlist_closed_form_kernels.cuh) of the instances first_index + k of a
 // witness's records (d_inst) in the slots of inst[k]. nlcf_begin: flags, words, the four sponges and the compact form, on the context's
-// side stream — it reads only the records, so it runs next to the netlist fill; call it once the slots are cleared (NlAfterClear).
-// nlcf_end: joins, then the tie cells (copies of the registers the fills have written by then) on the main stream.
-struct NlcfCall { NlcfJob* d_jobs = nullptr; size_t n = 0; };
+// side stream — a chain of up to 58 dependent permutations in ONE wave per instance (0.1 - 0.6 ms of latency, no work). It reads only the
+// records; WHEN it runs was measured (8 instances per call, tools/probe_netlist_perf.py): on the main stream Keccak 2.08 -> 2.67 ms, SHA-256
+// 3.01 -> 3.13; on the side stream from the start of the call, NEXT TO k_nl_fill, Keccak 2.26 but SHA-256 3.35 — the fill is a persistent grid
+// that fills every CU's registers, a CU that holds a sponge wave first cannot take its fill workgroup until the sponge is done, and that
+// workgroup's whole share ends late; so the fork is AFTER the fill kernel (NlAfterFill): the sponges run next to the histogram, finish and
+// queue-section kernels, which leave room. nlcf_end: joins, then the tie cells (copies of the registers the fills have written) on the main stream.
+struct NlcfCall { NlcfJob* d_jobs = nullptr; size_t n = 0; bool forked = false; };
 template <class T>
 int nlcf_begin(zkw_ctx* ctx, int circuit_type, const typename T::Inst* d_inst, size_t first_index, const std::vector<NlInstance>& inst, u32 cycles, size_t n_rows,
                NlcfCall* call, const char* jobs_name = "nlcf_jobs") {
@@ -1146,6 +1151,7 @@ int nlcf_begin(zkw_ctx* ctx, int circuit_type, const typename T::Inst* d_inst, s
     if (jobs.empty()) return ZKW_OK;
     hipStream_t side = nullptr;
     ZKW_TRY(ctx->side_fork(&side));
+    call->forked = true;
     hipLaunchKernelGGL((k_nlcf_sponges<T>), dim3((unsigned)jobs.size()), dim3(256), 0, side, *d, d_inst, call->d_jobs, S->g, n_rows, (u64)nlcf_first_row(circuit_type, S, cycles));
     return launch_check("k_nlcf_sponges");
 }
@@ -1154,7 +1160,7 @@ int nlcf_end(zkw_ctx* ctx, int circuit_type, const NlcfCall& call, u32 cycles, s
     const nlcf_desc* d = nlcf_desc_of(circuit_type);
     const NlCached* nc = nullptr;
     ZKW_TRY(nl_get(ctx, circuit_type, &nc));
-    ZKW_TRY(ctx->side_join());
+    if (call.forked) ZKW_TRY(ctx->side_join());
     const u32 cells = nlcf_header_cells(d) - nlcf_group_cell0(d, 0);
     if (cells == 0) return ZKW_OK;
     const nlq_desc* qd = nlq_desc_of(circuit_type);
