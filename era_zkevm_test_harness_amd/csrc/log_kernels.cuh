@@ -104,9 +104,10 @@ struct LogChainJob {
     u64 n;
 };
 
-static __global__ __launch_bounds__(64) void k_chain_log(const LogChainJob* __restrict__ jobs, int n_jobs) {
+template <int WAVES>  // 4: `k_chain_log_x4`, one workgroup per CU, a wave per SIMD (ram_kernels.cuh, k_chain_full_x4)
+static __device__ __forceinline__ void chain_log_body(const LogChainJob* __restrict__ jobs, int n_jobs) {
     const int lane = threadIdx.x & 63, g = lane & 15;
-    const int chain = blockIdx.x * 4 + (lane >> 4);
+    const int chain = (blockIdx.x * WAVES + (int)(threadIdx.x >> 6)) * 4 + (lane >> 4);
     p2::Coop co;
     co.init(g);
     LogChainJob job;
@@ -135,5 +136,7 @@ static __global__ __launch_bounds__(64) void k_chain_log(const LogChainJob* __re
         }
     }
 }
+static __global__ __launch_bounds__(64) void k_chain_log(const LogChainJob* __restrict__ jobs, int n_jobs) { chain_log_body<1>(jobs, n_jobs); }
+static __global__ __launch_bounds__(256) void k_chain_log_x4(const LogChainJob* __restrict__ jobs, int n_jobs) { chain_log_body<4>(jobs, n_jobs); }
 
 }  // namespace zkw

@@ -101,10 +101,15 @@ struct ChainOut {
     u64* marks;
 };
 
-static __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ jobs, int n_jobs) {
+// WAVES = 1: one wave per workgroup. WAVES = 4 (`k_chain_full_x4`, the chain service's launches): the four waves of a workgroup go to
+// the four SIMDs of ONE CU and the launch asks for more than half of a CU's LDS (unused), so that no two chain waves — of this launch or
+// of another chain launch that runs next to it — share a SIMD (as `k_chain_full_q4x4` below; measured with 96 blocks in flight: three
+// concurrent one-wave launches ran 1.4 - 1.5 x as long as alone).
+template <int WAVES>
+static __device__ __forceinline__ void chain_full_body(const ChainJob* __restrict__ jobs, int n_jobs) {
     __builtin_amdgcn_s_setprio(3);  // a serial chain is latency-bound: its wave issues before the fill waves sharing the SIMD
     const int lane = threadIdx.x & 63, g = lane & 15;
-    const int chain = blockIdx.x * 4 + (lane >> 4);
+    const int chain = (blockIdx.x * WAVES + (int)(threadIdx.x >> 6)) * 4 + (lane >> 4);
     p2::Coop co;
     co.init(g);
     ChainJob job;
@@ -163,6 +168,8 @@ static __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __rest
     }
     flush();
 }
+static __global__ __launch_bounds__(64) void k_chain_full(const ChainJob* __restrict__ jobs, int n_jobs) { chain_full_body<1>(jobs, n_jobs); }
+static __global__ __launch_bounds__(256) void k_chain_full_x4(const ChainJob* __restrict__ jobs, int n_jobs) { chain_full_body<4>(jobs, n_jobs); }
 
 // Quad form: 16 chains per wave (p2::Coop4). Lane j of a quad loads enc[j], enc[4+j] and stores tails[j],
 // tails[4+j], tails[8+j]: 32 contiguous bytes per quad per access.

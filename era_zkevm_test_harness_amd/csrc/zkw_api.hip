@@ -376,23 +376,27 @@ extern "C" int zkw_profile_names(zkw_ctx* ctx, char* buf, size_t buf_bytes) {
 // wherever a slot is free, some SIMDs get two or three chain waves, and the pass takes 1.5x or 2x as long: the slowest chain sets it).
 // A second such launch cannot start on a CU that still holds the first one's workgroup, so overlapping chain passes queue up instead of
 // doubling up. ZKW_CHAIN_WG4=0 restores one-wave workgroups.
+// the LDS request that lets a CU take ONE 4-wave workgroup of `func` (more than half of the CU's LDS, from the device's own figure); -1 when
+// the device refuses it: a device or partition mode without that much LDS per workgroup runs the one-wave form, which is correct everywhere
+static int one_workgroup_per_cu_lds(const void* func, int slot /* 0 .. 3: which kernel */) {
+    static std::atomic<int> lds_of[4][64];  // per kernel and device: 0 not tried, > 0 granted, -1 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    int lds = lds_of[slot][dev].load();
+    if (lds == 0) {
+        int per_cu = 0;
+        if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || per_cu <= 0) per_cu = 160 * 1024;
+        const int want = (per_cu / 2 + 4096) & ~1023;  // 84 KB of 160: one such workgroup per CU
+        lds = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess ? want : -1;
+        if (lds < 0) (void)hipGetLastError();
+        lds_of[slot][dev].store(lds);
+    }
+    return lds;
+}
 static int launch_chain_q4(hipStream_t st, const ChainJob* d_jobs, int n_jobs) {
     static const bool wg4 = [] { const char* e = getenv("ZKW_CHAIN_WG4"); return !(e && e[0] == '0'); }();
     if (wg4 && n_jobs > 64 && n_jobs <= 256 * 64) {
-        // per device: 0 not tried, > 0 the LDS request that was granted (more than half a CU's LDS, from the device's own figure), -1 refused:
-        // a device or partition mode without that much LDS per workgroup runs the one-wave form, which is correct everywhere
-        static std::atomic<int> lds_of[64];
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        int lds = dev >= 0 && dev < 64 ? lds_of[dev].load() : 0;
-        if (lds == 0) {
-            int per_cu = 0;
-            if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || per_cu <= 0) per_cu = 160 * 1024;
-            const int want = (per_cu / 2 + 4096) & ~1023;  // 84 KB of 160: one such workgroup per CU
-            lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_full_q4x4), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess ? want : -1;
-            if (lds < 0) (void)hipGetLastError();
-            if (dev >= 0 && dev < 64) lds_of[dev].store(lds);
-        }
+        const int lds = one_workgroup_per_cu_lds(reinterpret_cast<const void*>(&k_chain_full_q4x4), 0);
         if (lds > 0) {
             hipLaunchKernelGGL(k_chain_full_q4x4, dim3((n_jobs + 63) / 64), dim3(256), (size_t)lds, st, d_jobs, n_jobs);
             return ZKW_OK;
@@ -400,6 +404,20 @@ static int launch_chain_q4(hipStream_t st, const ChainJob* d_jobs, int n_jobs) {
     }
     hipLaunchKernelGGL(k_chain_full_q4, dim3((n_jobs + 15) / 16), dim3(64), 0, st, d_jobs, n_jobs);
     return ZKW_OK;
+}
+// the row forms as the chain service launches them: 16 chains per 4-wave workgroup, one workgroup per CU (up to 4 096 chains), so that the
+// waves of launches that run side by side — a memory-queue stage next to a decommit stage next to a log-queue stage — never share a SIMD
+static void launch_chain_full_rows(hipStream_t st, const ChainJob* d_jobs, int n_jobs) {
+    static const bool wg4 = [] { const char* e = getenv("ZKW_CHAIN_WG4"); return !(e && e[0] == '0'); }();
+    const int lds = wg4 && n_jobs > 4 && n_jobs <= 256 * 16 ? one_workgroup_per_cu_lds(reinterpret_cast<const void*>(&k_chain_full_x4), 1) : -1;
+    if (lds > 0) hipLaunchKernelGGL(k_chain_full_x4, dim3((n_jobs + 15) / 16), dim3(256), (size_t)lds, st, d_jobs, n_jobs);
+    else hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
+}
+static void launch_chain_log_rows(hipStream_t st, const LogChainJob* d_jobs, int n_jobs) {
+    static const bool wg4 = [] { const char* e = getenv("ZKW_CHAIN_WG4"); return !(e && e[0] == '0'); }();
+    const int lds = wg4 && n_jobs > 4 && n_jobs <= 256 * 16 ? one_workgroup_per_cu_lds(reinterpret_cast<const void*>(&k_chain_log_x4), 2) : -1;
+    if (lds > 0) hipLaunchKernelGGL(k_chain_log_x4, dim3((n_jobs + 15) / 16), dim3(256), (size_t)lds, st, d_jobs, n_jobs);
+    else hipLaunchKernelGGL(k_chain_log, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
 }
 
 // ------------------------------------------------------------------------------------------------ chain service
@@ -421,25 +439,33 @@ struct ChainService {
         bool done[2] = {false, false};  // [0] full-width chains, [1] log-queue chains
         int rc = ZKW_OK;
         std::string err;
+        int key = 0;
+        std::chrono::steady_clock::time_point open_since, last_arrival;
     };
     int device = 0;
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
-    std::shared_ptr<Batch> open;   // the batch that still accepts jobs
-    std::chrono::steady_clock::time_point open_since, last_arrival;
+    // the batches that still accept jobs, by KEY: 0 = whatever arrives (contexts without a tag), else one stage of one builder branch
+    // (zkw_ctx::next_chain_key) — the jobs of that stage of ALL blocks in flight, which are equally long, travel in one launch
+    std::map<int, std::shared_ptr<Batch>> open;
+    int expected = 0;  // blocks in flight under zkw_blocks_run: a keyed batch with that many submitters leaves at once
     std::vector<std::thread> workers;
     bool stop = false;
 
-    // ZKW_CHAIN_WORKERS (default 4): launches in flight at once — a worker stays with its batch until the batch's longest chain is done
-    // (8 / 12 / 16 workers measured 12.0 / 9.8 / 8.3 blocks/s against 17-18 with 4: more concurrent one-wave kernels than hardware queues);
-    // ZKW_CHAIN_WINDOW_US (default 4000, the maximal age of a batch is ten times that): the silence that closes a batch. 48 blocks' builder
-    // threads reach a chain stage within a few milliseconds of each other: with the 400 us of rounds 2-4 their jobs went out in ~35 launches
-    // per 48 blocks, each as long as its longest chain; with 4 ms the stages travel together: builders of 48 blocks 1.95-2.04 -> 1.6 s
-    int n_workers = 4;
-    long quiet_us = 4000, max_us = 40000;
+    // ZKW_CHAIN_WORKERS (default 8): launches in flight at once — a worker stays with its batch until the batch's longest chain is done; each has ONE
+    // high-priority stream (8 = the high-priority hardware queues under GPU_MAX_HW_QUEUES=8: two streams per worker, or more workers,
+    // put two long launches on one queue — 12.0 / 9.8 / 8.3 blocks/s with 8 / 12 / 16 two-stream workers in round 5's first half).
+    // ZKW_CHAIN_WINDOW_US (default 4000, the maximal age of a batch is ten times that): the silence that closes a batch. Round 5, second
+    // half (ZKW_CHAIN_LOG=1 at 96 blocks in flight): the first few blocks to reach a stage left in four small batches, took the four
+    // workers for the 1.1 s of a memory-queue chain, and the other ~90 blocks' chains waited for a worker — three rounds of 1.1 s for work
+    // that fits one. Hence the keys and `expected`: a keyed batch waits for ALL blocks in flight (or ZKW_CHAIN_LONG_WINDOW_US of silence,
+    // default 100 ms: a block may skip a stage or fail), so a stage is ONE launch.
+    int n_workers = 8;
+    long quiet_us = 4000, max_us = 40000, quiet_long_us = 100000;
     explicit ChainService(int dev) : device(dev) {
         if (const char* e = getenv("ZKW_CHAIN_WORKERS")) n_workers = std::max(1, std::min(32, atoi(e)));
         if (const char* e = getenv("ZKW_CHAIN_WINDOW_US")) { quiet_us = std::max(50L, atol(e)); max_us = 10 * quiet_us; }
+        if (const char* e = getenv("ZKW_CHAIN_LONG_WINDOW_US")) quiet_long_us = std::max(50L, atol(e));
         for (int i = 0; i < n_workers; i++) workers.emplace_back([this] { run(); });
     }
     ~ChainService() {
@@ -447,16 +473,30 @@ struct ChainService {
         cv_work.notify_all();
         for (auto& t : workers) t.join();
     }
-    int submit(const std::vector<ChainJob>* full, const std::vector<LogChainJob>* log, std::string* err) {
+    void expect(int delta) {
+        { std::lock_guard<std::mutex> g(mu); expected = std::max(0, expected + delta); }
+        cv_work.notify_all();
+    }
+    // (under the lock) may this batch leave?
+    bool ready(const Batch& b, std::chrono::steady_clock::time_point now) const {
+        if (b.key != 0 && expected > 1) {
+            if (b.waiters >= expected) return true;
+            return now - b.last_arrival >= std::chrono::microseconds(quiet_long_us) || now - b.open_since >= std::chrono::microseconds(10 * quiet_long_us);
+        }
+        return now - b.last_arrival >= std::chrono::microseconds(quiet_us) || now - b.open_since >= std::chrono::microseconds(max_us);
+    }
+    int submit(const std::vector<ChainJob>* full, const std::vector<LogChainJob>* log, std::string* err, int key) {
         std::shared_ptr<Batch> b;
         {
             std::unique_lock<std::mutex> lk(mu);
-            if (!open) { open = std::make_shared<Batch>(); open_since = std::chrono::steady_clock::now(); }
-            b = open;
+            std::shared_ptr<Batch>& slot = open[key];
+            const auto now = std::chrono::steady_clock::now();
+            if (!slot) { slot = std::make_shared<Batch>(); slot->key = key; slot->open_since = now; }
+            b = slot;
             if (full) b->full.insert(b->full.end(), full->begin(), full->end());
             if (log) b->log.insert(b->log.end(), log->begin(), log->end());
             b->waiters++;
-            last_arrival = std::chrono::steady_clock::now();
+            b->last_arrival = now;
             cv_work.notify_one();
             const int kind = full ? 0 : 1;
             cv_done.wait(lk, [&] { return b->done[kind]; });
@@ -469,11 +509,10 @@ struct ChainService {
     }
     void run() {
         (void)hipSetDevice(device);
-        hipStream_t st = nullptr, st_log = nullptr;  // the two kinds of chains of a batch run side by side, not one after the other
+        hipStream_t st = nullptr, st_log = nullptr;  // st_log: only for a batch that carries both kinds (unkeyed jobs): they run side by side
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) st = nullptr;
-        if (hipStreamCreateWithPriority(&st_log, hipStreamNonBlocking, hi) != hipSuccess) st_log = nullptr;
         void* pin = nullptr;
         void* dev = nullptr;
         size_t cap = 0;
@@ -481,20 +520,17 @@ struct ChainService {
             std::shared_ptr<Batch> b;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return stop || open; });
-                if (stop) break;
-                // batching window: launch when nothing has arrived for 400 us, or 4 ms after the first job
                 for (;;) {
-                    const auto now = std::chrono::steady_clock::now();
-                    if (!open) break;  // another worker took it
-                    if (now - last_arrival >= std::chrono::microseconds(quiet_us) || now - open_since >= std::chrono::microseconds(max_us)) break;
-                    cv_work.wait_for(lk, std::chrono::microseconds(200));
                     if (stop) break;
+                    const auto now = std::chrono::steady_clock::now();
+                    auto best = open.end();  // the ready batch that has been open longest
+                    for (auto it = open.begin(); it != open.end(); ++it)
+                        if (it->second && ready(*it->second, now) && (best == open.end() || it->second->open_since < best->second->open_since)) best = it;
+                    if (best != open.end()) { b = best->second; open.erase(best); break; }
+                    if (open.empty()) cv_work.wait(lk, [&] { return stop || !open.empty(); });
+                    else cv_work.wait_for(lk, std::chrono::microseconds(200));
                 }
                 if (stop) break;
-                if (!open) continue;
-                b = open;
-                open.reset();
             }
             int rc = ZKW_OK;
             std::string err;
@@ -504,7 +540,10 @@ struct ChainService {
             size_t longest = 0;
             if (log_batches) for (const ChainJob& j : b->full) longest = std::max(longest, (size_t)j.n);
             const size_t bytes = b->full.size() * sizeof(ChainJob) + b->log.size() * sizeof(LogChainJob) + 256;
-            if (!st || !st_log) { rc = ZKW_ERR_HIP; err = "chain service: no stream"; }
+            const bool mixed = !b->full.empty() && !b->log.empty();
+            if (mixed && !st_log && hipStreamCreateWithPriority(&st_log, hipStreamNonBlocking, hi) != hipSuccess) st_log = nullptr;
+            hipStream_t sl = mixed ? st_log : st;  // the log-queue chains' stream
+            if (!st || !sl) { rc = ZKW_ERR_HIP; err = "chain service: no stream"; }
             if (rc == ZKW_OK && cap < bytes) {  // grow-only; the outgrown pair goes back to the allocation cache (no hipFree stall)
                 const size_t want = bytes * 2;
                 void *np = nullptr, *nd = nullptr;
@@ -527,13 +566,13 @@ struct ChainService {
                 fail_hip(hipMemcpyAsync(dp, hp, off_log + b->log.size() * sizeof(LogChainJob), hipMemcpyHostToDevice, st), "job upload");
                 fail_hip(hipStreamSynchronize(st), "job upload");
                 const int nf = (int)b->full.size(), nl = (int)b->log.size();
-                if (rc == ZKW_OK && nl) hipLaunchKernelGGL(k_chain_log, dim3((nl + 3) / 4), dim3(64), 0, st_log, reinterpret_cast<const LogChainJob*>(dp + off_log), nl);
+                if (rc == ZKW_OK && nl) launch_chain_log_rows(sl, reinterpret_cast<const LogChainJob*>(dp + off_log), nl);
                 if (rc == ZKW_OK && nf) {
                     if (nf >= 4096) { const int lrc = launch_chain_q4(st, reinterpret_cast<const ChainJob*>(dp), nf); if (lrc != ZKW_OK && rc == ZKW_OK) { rc = lrc; err = "chain launch (quad form)"; } }
-                    else hipLaunchKernelGGL(k_chain_full, dim3((nf + 3) / 4), dim3(64), 0, st, reinterpret_cast<const ChainJob*>(dp), nf);
+                    else launch_chain_full_rows(st, reinterpret_cast<const ChainJob*>(dp), nf);
                 }
                 fail_hip(hipGetLastError(), "chain launch");
-                fail_hip(hipStreamSynchronize(st_log), "chain batch (log queues)");
+                fail_hip(hipStreamSynchronize(sl), "chain batch (log queues)");
                 {
                     std::lock_guard<std::mutex> g(mu);
                     if (rc != ZKW_OK) { b->rc = rc; b->err = err; }
@@ -576,6 +615,19 @@ static ChainService* chain_service_of(int device) {
     return p;
 }
 
+// zkw_blocks_run tells the device's service how many blocks are in flight (delta = +K before, -K after)
+extern "C" int zkw_chain_service_expect(int device_id, int delta) {
+    if (device_id < 0) return fail(ZKW_ERR_INVALID, "zkw_chain_service_expect: bad device");
+    chain_service_of(device_id)->expect(delta);
+    return ZKW_OK;
+}
+extern "C" int zkw_set_chain_tag(zkw_ctx* ctx, int tag) {
+    if (!ctx || tag < 0 || tag > 1000) return fail(ZKW_ERR_INVALID, "zkw_set_chain_tag: bad argument");
+    ctx->chain_tag = tag;
+    ctx->chain_seq = 0;
+    return ZKW_OK;
+}
+
 extern "C" int zkw_set_chain_service(zkw_ctx* ctx, int on) {
     if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
     ctx->chain_service = on != 0;
@@ -584,11 +636,11 @@ extern "C" int zkw_set_chain_service(zkw_ctx* ctx, int on) {
 }
 
 // hand the chains of one builder call over to the service and wait for them
-static int chain_service_run(zkw_ctx* ctx, const std::vector<ChainJob>* full, const std::vector<LogChainJob>* log, const char* name) {
+static int chain_service_run(zkw_ctx* ctx, const std::vector<ChainJob>* full, const std::vector<LogChainJob>* log, const char* name, int key) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // the jobs' inputs are produced on this context's stream
     const auto t0 = std::chrono::steady_clock::now();
     std::string err;
-    const int rc = chain_service_of(ctx->device)->submit(full, log, &err);
+    const int rc = chain_service_of(ctx->device)->submit(full, log, &err, key);
     if (ctx->profiling) {  // wall time spent waiting for the shared launch (no HIP events: it runs on the service's stream)
         auto& t = ctx->prof_totals[std::string(name) + "(service)"];
         t.first += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -613,8 +665,9 @@ int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) {
 // issues a VALU instruction every ~2 cycles (measured 3.7 us per permutation step, flat from 1 to 4096
 // concurrent chains), so throughput comes from giving each wave its own SIMD: up to 1024 waves.
 int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
+    const int key = ctx->chain_service ? ctx->next_chain_key() : 0;  // (counted even when there is nothing to hash: equal stages of all blocks keep equal keys)
     if (jobs.empty()) return ZKW_OK;
-    if (ctx->chain_service) return chain_service_run(ctx, &jobs, nullptr, "k_chain_full");
+    if (ctx->chain_service) return chain_service_run(ctx, &jobs, nullptr, "k_chain_full", key);
     ChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("chain_jobs", jobs, &d_jobs));
     int n_jobs = (int)jobs.size();
@@ -822,13 +875,14 @@ extern "C" int zkw_encode_decommit_queries(zkw_ctx* ctx, const zkw_decommit_quer
 
 // device-level: rounds 1-2 of every item in parallel, then one serial permutation per item and queue
 int dev_log_chains(zkw_ctx* ctx, const u64* d_enc, size_t total, std::vector<LogChainJob>& jobs) {
+    const int key = ctx->chain_service ? ctx->next_chain_key() : 0;
     if (total == 0 || jobs.empty()) return ZKW_OK;
     u64* d_pre = nullptr;
     ZKW_TRY(ctx->scratch_t<u64>("log_pre", total * 4, &d_pre));
     { Prof _p(ctx, "k_log_prehash"); hipLaunchKernelGGL(k_log_prehash, dim3(blocks_for(total, 128)), dim3(128), 0, ctx->stream, d_enc, total, d_pre); }
     ZKW_TRY(launch_check("k_log_prehash"));
     for (auto& j : jobs) j.pre = d_pre + (j.enc - d_enc) / 20 * 4;
-    if (ctx->chain_service) return chain_service_run(ctx, nullptr, &jobs, "k_chain_log");
+    if (ctx->chain_service) return chain_service_run(ctx, nullptr, &jobs, "k_chain_log", key);
     LogChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("log_chain_jobs", jobs, &d_jobs));
     const int n_jobs = (int)jobs.size();

@@ -296,6 +296,7 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
         if (!B->ctx[i]) return from_rc(ZKW_ERR_NO_DEVICE);
         ST_ZKW(zkw_set_pointer_mode(B->ctx[i], ZKW_PTR_DEVICE));
         if (B->use_chain_service) ST_ZKW(zkw_set_chain_service(B->ctx[i], 1));
+        ST_ZKW(zkw_set_chain_tag(B->ctx[i], i + 1));  // the chain service batches equal stages of equal branches of all blocks in flight
         if (getenv("ZKW_BLOCK_PROFILE")) ST_ZKW(zkw_profile_enable(B->ctx[i], 1));
     }
     for (int i = 0; i < N_XFER; i++) {
@@ -602,6 +603,8 @@ extern "C" int zkw_blocks_run(int device_id, const zkw_block_inputs* const* inpu
     std::vector<zkw_block*> blocks(n_blocks, nullptr);
     std::vector<std::future<Status>> futs;
     const Clock::time_point t0 = Clock::now();
+    (void)zkw_chain_service_expect(device_id, (int)n_blocks);  // a stage of all these blocks is one launch (zkw_api.hip, ChainService)
+    struct Unexpect { int dev, n; ~Unexpect() { (void)zkw_chain_service_expect(dev, -n); } } unexpect{device_id, (int)n_blocks};
     for (size_t k = 0; k < n_blocks; k++) {
         zkw_block* B = new zkw_block();
         B->device = device_id;

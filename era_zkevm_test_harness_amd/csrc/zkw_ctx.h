@@ -102,6 +102,10 @@ struct zkw_ctx {
     std::atomic<bool> destroy_requested{false};
     std::atomic<bool> destroying{false};
     bool chain_service = false;  // queue chains go to the device's chain service (batched with other contexts' chains)
+    // which stage of which builder branch a chain submission is (zkw_block sets the tag of a branch's context; the sequence number counts
+    // the context's submissions): with many blocks in flight the service batches EQUAL stages of all blocks into one launch (zkw_api.hip)
+    int chain_tag = 0, chain_seq = 0;
+    int next_chain_key() { return chain_tag ? chain_tag * 4096 + (chain_seq++ & 4095) : 0; }
     int chain_form = 0;  // lanes per Poseidon2 state in the queue-chain kernel: 4 (quad), 16 (row), 0 = auto
     int netlist_fill_form = 0;  // 0: a wave per cycle (k_nl_fill), 1: a lane per cycle (k_nl_walk + k_nl_expand)
     std::map<std::string, DevBuf> pool;  // named grow-only scratch
@@ -285,6 +289,7 @@ static inline int zero_netlist_slot(zkw_ctx* ctx, u64* trace, size_t n_rows, siz
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 void ctx_retain(zkw_ctx* ctx);
+
 void ctx_release(zkw_ctx* ctx);
 
 struct zkw_trace {

@@ -36,6 +36,8 @@ SYMBOLS = [
     ("zkw_set_chain_form", _int, [_vp, _int]),
     ("zkw_set_netlist_fill_form", _int, [_vp, _int]),
     ("zkw_set_chain_service", _int, [_vp, _int]),
+    ("zkw_set_chain_tag", _int, [_vp, _int]),
+    ("zkw_chain_service_expect", _int, [_int, _int]),
     ("zkw_buffer_alloc", _int, [_vp, _int, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("zkw_buffer_free", None, [_int, _vp]),
     ("zkw_stream_acquire", _int, [_vp, C.POINTER(C.c_void_p)]),

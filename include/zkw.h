@@ -82,6 +82,14 @@ int zkw_set_netlist_fill_form(zkw_ctx *ctx, int form);
    into ONE launch on a high-priority stream, and the call waits for that launch. For hosts that keep many contexts busy
    at once (zkw_blocks_run): K concurrent builders cost one chain pass instead of K serialised ones. Results are identical. */
 int zkw_set_chain_service(zkw_ctx *ctx, int on);
+/* Stages. A host that runs the SAME graph of builders for many blocks at once (zkw_blocks_run) gives every branch of the graph a
+   tag (> 0) on its context: the n-th chain submission of the contexts tagged t is stage (t, n), and the service batches a stage of
+   all blocks into ONE launch — its chains are equally long, so the launch costs what one costs. zkw_chain_service_expect(+K) says
+   how many blocks are in flight on the device: a stage with K submitters leaves at once, otherwise after 100 ms of silence (a block
+   may skip a stage); (-K) when they are done. Without a tag or an expectation the service batches by arrival time as before.
+   Measured at 96 production-capacity blocks in flight: DESIGN.md, review table item 4. */
+int zkw_set_chain_tag(zkw_ctx *ctx, int tag);
+int zkw_chain_service_expect(int device_id, int delta);
 /* Buffers and streams from the library's caches (see "memory" above), for hosts that build graphs of contexts the way
    zkw_block_run does. pinned_host = 0: device memory on ctx's device, 1: pinned host memory. Contents are unspecified.
    zkw_stream_release synchronises the stream. */

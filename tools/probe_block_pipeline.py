@@ -1,5 +1,5 @@
-"""Whole blocks per second with the builders of batch k + 1 running next to the synthesis of batch k (two host threads, each driving
-zkw_blocks_run / zkw_block_synthesize): usage probe_block_pipeline.py K [batches]"""
+"""Whole blocks per second with the builders of batch k + 1 running next to the synthesis of batch k (two host threads, one driving
+zkw_blocks_run, one zkw_blocks_synthesize): usage probe_block_pipeline.py K [batches]"""
 import sys, time, threading
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, '.')
@@ -11,14 +11,12 @@ base = [synthetic.block_production(seed=1 + k) for k in range(4)]
 blocks = [base[k % 4] for k in range(K)]
 warm = nv.Block(0, base[0]); warm.synthesize(1 << 20, ring_slots=1); warm.free()
 bs = nv.Block.run_many(0, blocks)  # fills the caches
-with ThreadPoolExecutor(8) as ex:
-    list(ex.map(lambda b: b.synthesize(1 << 20, ring_slots=1), bs))
+nv.Block.synthesize_many(bs, 1 << 20, ring_slots=1)
 for b in bs: b.free()
 
 def synth(bs, out):
     t = time.perf_counter()
-    with ThreadPoolExecutor(8) as ex:
-        out.append(sum(ex.map(lambda b: b.synthesize(1 << 20, ring_slots=1), bs)))
+    out.append(nv.Block.synthesize_many(bs, 1 << 20, ring_slots=1))  # zkw_blocks_synthesize: ECRecover of all blocks in joint calls, the other types on library threads
     for b in bs: b.free()
     out.append(time.perf_counter() - t)
 
