@@ -521,19 +521,17 @@ def main():
     n = args.queries
     B = args.blocks
     P = max(1, args.pipelines)
-    full_block = blk_inputs = hash_circuits = None
+    full_block = blk_inputs = hash_circuits = setup_commit = None
     comm_ctx = native.Context(local_rank)
     comm = make_comm(comm_ctx, rank, world)
     gather_backend = "libzkw zkw_gather_closed_form_inputs (RCCL)" if comm is not None else "torch.distributed (RCCL)"
-    if not args.no_full_block:  # before the batch takes the HBM; its buffers are released again. N > 1: every rank runs the
-        # (deterministic, chain-bound) builders, synthesizes its LPT share of the block's instances, one gather to rank 0
+    if not args.no_full_block and os.environ.get("ZKW_FULL_BLOCK_FIRST"):
+        # experiment: the full-block legs BEFORE the timed region, as rounds 2-5 had them. They leave the process in one of two
+        # states (round 5, six default runs: 2 896 - 3 039 circuits/s four times, 2 516 - 2 586 twice — every HBM- or latency-bound kernel of
+        # the step 30 - 100 % slower, k_ram_fill_tail 12 -> 70 ms): hundreds of streams and the chain service's high-priority queues stay mapped
+        # and the hardware scheduler time-slices them. The timed region now runs FIRST, in a process that has created nothing else.
         full_block, blk_inputs = full_block_gpu(local_rank, rank=rank, world=world, comm=comm)
         native.trim_caches()  # the batch below is sized by the free HBM
-        torch.cuda.empty_cache()
-    if os.environ.get("ZKW_HASH_CIRCUITS_FIRST") and blk_inputs is not None:
-        # experiment: the hash-circuit leg BEFORE the timed region, to see what it leaves behind
-        hash_circuits = hash_circuits_gpu(local_rank, blk_inputs)
-        native.trim_caches()
         torch.cuda.empty_cache()
     if B <= 0:
         free, _total = torch.cuda.mem_get_info(dev)
@@ -854,6 +852,31 @@ def main():
             sensitivity["error"] = repr(e)
             cold_slots[0] = False
 
+    free_after, total_mem = torch.cuda.mem_get_info(dev)  # (HBM in use by the batch: read before it is released)
+    batch_released = False
+    if not args.no_full_block and full_block is None:
+        # ---- the full-block legs, AFTER the timed region and with the batch released (every rank: N > 1 runs the deterministic, chain-bound
+        # builders on every rank, synthesizes its LPT share of the block's instances, one gather to rank 0)
+        for w_ in ws:
+            w_.free()
+        for r_ in rings:
+            r_.free()
+        del q, records, compact, pis
+        torch.cuda.empty_cache()
+        native.trim_caches()
+        batch_released = True
+        if rank == 0 and not args.no_hash_circuits:  # the hash-circuit rates before the full-block legs, for the same reason the timed region is first
+            hash_circuits = hash_circuits_gpu(local_rank, synthetic.block_production(seed=1))
+            try:
+                setup_commit = setup_commit_gpu(local_rank)
+            except Exception as e:  # noqa: BLE001 — a side leg: never the reason the contract's line is missing
+                setup_commit = {"error": repr(e)}
+            native.trim_caches()
+            torch.cuda.empty_cache()
+        full_block, blk_inputs = full_block_gpu(local_rank, rank=rank, world=world, comm=comm)
+        native.trim_caches()
+        torch.cuda.empty_cache()
+
     if rank == 0:
         assert gathered.shape[0] == n_inst_local * world
         circuits = n_inst_local * world * args.steps
@@ -969,7 +992,6 @@ def main():
         synth_ms = sum(v[0] for k, v in prof.items() if k.startswith("k_ram_fill") or k.startswith("k_ram_nd"))
         synth_gbs = (native.circuit_fill_bytes(8, CAPACITY, n_rows)[0] * n_inst_local * args.steps) / (synth_ms * 1e-3) / 1e9 if synth_ms else None  # bytes actually written (slot reuse)
         chain_ms, chain_cnt = prof.get("k_chain_full", prof.get("k_chain_full_q4", (0.0, 1)))
-        free_after, total_mem = torch.cuda.mem_get_info(dev)
         out = {
             "metric": "base-layer circuits/sec (2^20 rows); full-block synth wall-time 1/8 GPU",
             "value": circuits / dt,
@@ -1023,19 +1045,22 @@ def main():
             out["full_block"] = full_block
             if hash_circuits is not None:
                 out["hash_circuits"] = hash_circuits
+                if setup_commit is not None:
+                    out["setup_commit"] = setup_commit
             elif not args.no_hash_circuits:
                 # AFTER the timed region and with the batch released. Round 2 measured an 11 % loss of the throughput leg when this
                 # leg ran first (1604 against 1800 circuits/s): the leg's context and streams shifted the round-robin assignment of
                 # the pipelines' streams to hardware queues, and two pipelines on one queue do not overlap — the mechanism fixed at
                 # the pipelines' stream creation above (alternating priorities). With that fix the order no longer matters:
                 # ZKW_HASH_CIRCUITS_FIRST=1 gives 1761 against 1797 circuits/s (3-step runs, round 3, gpurun_out/r03l)
-                for w_ in ws:
-                    w_.free()
-                for r_ in rings:
-                    r_.free()
-                del q, records, compact, pis
-                torch.cuda.empty_cache()
-                native.trim_caches()
+                if not batch_released:
+                    for w_ in ws:
+                        w_.free()
+                    for r_ in rings:
+                        r_.free()
+                    del q, records, compact, pis
+                    torch.cuda.empty_cache()
+                    native.trim_caches()
                 out["hash_circuits"] = hash_circuits_gpu(local_rank, blk_inputs)
                 try:
                     out["setup_commit"] = setup_commit_gpu(local_rank)
