@@ -300,35 +300,43 @@ def hash_circuits_gpu(local_rank, blk):
             out[name]["at_32_instances_per_call"] = timed(n32, lambda: synth(w, t, 0, n32, 0))
             out[name]["note"] = ("7 requests per instance (geometry_config.rs): the accumulator chain of a request is serial (k_ec_chain: one lane per request, ~13 ms per "
                                  "call whatever the batch — PRE segment 4.5, 256 double-and-add steps 7, batch inversion 2: profiles/r05/README.md), the other kernels scale with the batch")
-            # ... and that chain is four waves: a SECOND call in flight (another context = another stream, its own witness and slots) runs its
-            # chain under the first call's segment / stream kernels. Two host threads, 4 calls of 32 instances each.
+            # ... and that chain is a handful of waves (one lane per request, issued at s_setprio 3): MORE CALLS IN FLIGHT (a context = a stream,
+            # its own witness and slots, one host thread each) run their chains under the other calls' segment / stream kernels.
             from concurrent.futures import ThreadPoolExecutor
-            ctx2 = native.Context(local_rank)
-            w2 = ctx2._precompile(kind, req, ctx2.queue_push_chain_log(ctx2.encode_log_queries(req))[1], mq, cap, mem_in)
-            t2 = native.Trace(ctx2, n_rows, n32, n_cols=cols)
-            ctx2.synthesize_ecrecover(w2, t2, 0, n32, 0)  # (slots claimed, kernels loaded)
-            ctx2.synchronize()
+            extra = []
+            for _k in range(3):
+                c_ = native.Context(local_rank)
+                w_ = c_._precompile(kind, req, c_.queue_push_chain_log(c_.encode_log_queries(req))[1], mq, cap, mem_in)
+                t_ = native.Trace(c_, n_rows, n32, n_cols=cols)
+                c_.synthesize_ecrecover(w_, t_, 0, n32, 0)  # (slots claimed, kernels loaded)
+                c_.synchronize()
+                extra.append((c_, w_, t_))
+            lanes = [(ctx, w, t)] + extra
 
-            def calls(c_, w_, t_, reps_=4):
+            def calls(c_, w_, t_, reps_=6):
                 for _ in range(reps_):
                     c_.synthesize_ecrecover(w_, t_, 0, n32, 0)
                 c_.synchronize()
 
-            best2 = None
-            with ThreadPoolExecutor(2) as ex:
-                for _ in range(3):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    fs = [ex.submit(calls, ctx, w, t), ex.submit(calls, ctx2, w2, t2)]
-                    for f in fs:
-                        f.result()
-                    dt = time.perf_counter() - t0
-                    best2 = dt if best2 is None or dt < best2 else best2
-            out[name]["two_calls_in_flight"] = {"circuits_per_s": 2 * 4 * n32 / best2, "instances_per_call": n32, "calls": 8, "ms": best2 * 1e3,
-                                                "note": "two contexts, one host thread each, 4 calls of 32 instances per thread: a call's serial chain (4 waves) hides under the other call's kernels"}
-            t2.free()
-            w2.free()
-            ctx2.close()
+            in_flight = {}
+            for nt in (2, 4):
+                best_ = None
+                with ThreadPoolExecutor(nt) as ex:
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for f in [ex.submit(calls, *lanes[k]) for k in range(nt)]:
+                            f.result()
+                        dt = time.perf_counter() - t0
+                        best_ = dt if best_ is None or dt < best_ else best_
+                in_flight[str(nt)] = {"circuits_per_s": nt * 6 * n32 / best_, "ms": best_ * 1e3}
+            out[name]["calls_in_flight"] = dict(in_flight, instances_per_call=n32, calls_per_thread=6,
+                                                note="N contexts, one host thread each, 6 calls of 32 instances per thread: a call's serial chains hide under the other calls' kernels")
+            out[name]["two_calls_in_flight"] = in_flight["2"]
+            for c_, w_, t_ in extra:
+                t_.free()
+                w_.free()
+                c_.close()
             t.free()
         w.free()
     dec = ctx.compute_decommitts_sorter_circuit_snapshots(blk["decommit_queries"], 117500)

@@ -214,6 +214,8 @@ __device__ __forceinline__ ec_u256 ec_load_limbs(const u64* __restrict__ tape, c
 
 // grid (cycles / EC_TAPE_LANES, jobs): a lane per cycle
 static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_chain(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
+    __builtin_amdgcn_s_setprio(3);  // a request's accumulator chain is one lane and 13 ms of dependent instructions: its wave issues before whatever
+                                    // shares the SIMD (another call's segment / stream kernels when two calls are in flight)
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
     const EcJob j = jobs[blockIdx.y];
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
