@@ -355,6 +355,9 @@ def hash_circuits_gpu(local_rank, blk):
     t = native.Trace(ctx, n_rows, 8, n_cols=native.LH_COLS)
     states = np.zeros(8, native.QUEUE_STATE4)
     qtails = [ctx.queue_push_chain_log(ctx.encode_log_queries(q))[1] for q in queues]  # the queues' states: the sorter that builds a queue holds them
+    for k_, qt_ in enumerate(qtails):  # (a queue state names its tail: the circuit's closed-form section ties the last pop to it)
+        states["tail"][k_] = qt_[-1]
+        states["length"][k_] = len(queues[k_])
     out["linear_hasher"] = dict(timed(8, lambda: ctx.synthesize_linear_hasher_batch(queues, states, 774, t, 0, tails=qtails), trace=t, ctype=13, cap=774), capacity=774,
                                 columns=native.LH_COLS, trace_bytes=native.LH_COLS * n_rows * 8,
                                 note="the L1-messages queues of 8 blocks per call (zkw_linear_hasher_synthesize_batch_with_tails: the queues' "

@@ -32,8 +32,8 @@
  *     c(OI), c(OO), c(FI), c(FO)] (copies of the sponges' last outputs 0..3; the constant 0 for an empty encoding). The PI row's four
  *     cells are copies of the last permutation's outputs 0..3.
  * What stays only committed (FREE words): everything the ties below do not name — the flags, timestamps and call parameters of the
- * internal FSMs, Keccak's byte buffer, the queue LENGTHS and the far ends of the queues (tail of a popped queue, head of the memory
- * queue), all of StorageApplication's words.
+ * internal FSMs, Keccak's byte buffer, the queue LENGTHS and the far ends of the queues (tail of a popped queue — but for the
+ * L1MessagesHasher, whose pops must reach it —, head of the memory queue), all of StorageApplication's words.
  */
 #ifndef ZKW_NETLIST_CLOSED_FORM_H
 #define ZKW_NETLIST_CLOSED_FORM_H
@@ -87,10 +87,11 @@ static const nlcf_desc NLCF_DESC_ECRECOVER = {{34, 25, 34, 34}, 5, {
     {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 21}}};
 /* L1MessagesHasher (13). OI = LinearHasherInputData {queue_state: head 0..3, tail 4..7, length 8}, OO = LinearHasherOutputData
    {keccak256_hash: 32 bytes}, no hidden FSM (one instance per block: data_hasher_and_merklizer.rs:34-60). The pops start at the
-   queue's head; the digest is the first 32 bytes of the sponge state after the last cycle. (That the pops END at the queue's tail —
-   every message is hashed — is not tied: the entry points take the queue state from the caller, and callers pass states without a tail.) */
-static const nlcf_desc NLCF_DESC_LINEAR_HASHER = {{9, 32, 0, 0}, 2, {
-    {NLCF_IN_ALWAYS, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, -1},
+   queue's head and END AT ITS TAIL — every message of the queue is hashed, none left out (the reference's circuit pops until the queue
+   is empty and the queue's consistency check compares head and tail then); the digest is the first 32 bytes of the sponge state after
+   the last cycle. A caller's queue_state must be the queue's: tail = the state after its last push (head, when it is empty). */
+static const nlcf_desc NLCF_DESC_LINEAR_HASHER = {{9, 32, 0, 0}, 3, {
+    {NLCF_IN_ALWAYS, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, -1}, {NLCF_IN_ALWAYS, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 4, -1},
     {NLCF_OUT_OO, NLCF_REG_STATE_OUT, 0, 1, 8, 0, 32, 0, 0, -1}}};
 /* StorageApplication (10). OI = {shard, initial_root_hash 32 bytes, enumeration counter 2, log queue 9} = 44, OO = {new_root_hash 32,
    counter 2, state_diffs_keccak256_hash 32} = 66, FSM = {root hash 32, counter 2, log queue 9, Keccak accumulator 200} = 243

@@ -962,6 +962,18 @@ def linear_hasher_cycles(capacity):
     return capacity * 88 // 136 + 1
 
 
+def linear_hasher_queue_state(messages, head=None):
+    """the QueueState4 of a queue that holds exactly `messages` pushed over `head` (zeros): tail = the state after the last push (= head
+    when there is none), length = their number — what the circuit's closed-form section ties its pops to"""
+    q = np.ascontiguousarray(messages, dtype=LOG_QUERY)
+    st = np.zeros(1, QUEUE_STATE4)
+    h = np.zeros(4, np.uint64) if head is None else np.asarray(head, dtype=np.uint64)
+    st["head"][0] = h
+    st["tail"][0] = queue_push_chain_log(encode_log_queries(q), h)[1][-1] if q.size else h
+    st["length"] = q.size
+    return st
+
+
 def linear_hasher_synthesize(messages, queue_state, capacity, n_rows):
     """LinearHasher (type 13): (trace, instance record, public input) for the net L2 -> L1 messages of a block"""
     q = np.ascontiguousarray(messages, dtype=LOG_QUERY)

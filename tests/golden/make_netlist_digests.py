@@ -38,7 +38,7 @@ def cases():
     for i in range(w["instances"].size):
         out[f"code_decommitter/capacity7/instance{i}"] = digest(o.code_decommitter_synthesize(w, i, 7, N_ROWS, public_input=ZERO_PI))
     q = synthetic.mixed_log_queue(36, seed=8)[:7]
-    tr, inst, pi = o.linear_hasher_synthesize(q, np.zeros(1, o.QUEUE_STATE4), 20, N_ROWS)
+    tr, inst, pi = o.linear_hasher_synthesize(q, o.linear_hasher_queue_state(q), 20, N_ROWS)
     g = o.nl_geometry(13)
     tr[:4, o.linear_hasher_cycles(20) * g["rows_per_cycle"] + 2 * -(-200 // g["general"])] = 0  # the Poseidon2-dependent public input
     out["linear_hasher/capacity20/7messages"] = digest(tr)

@@ -14,7 +14,7 @@ def closed_form_cells(oracle, ct, cycles, rng, n_random=10):
              cc("p2", 130 * (perms - 1) + 119), cc("p2", 130 * (perms - 1) + 90)]
     if g["n_fi"]:
         cells += [cc("fi", 1), cc("fi", g["n_fi"] // 2), cc("fo", g["n_fo"] - 2), cc("fo", 0)]
-    n_groups = {6: 7, 3: 7, 5: 7, 7: 5, 13: 2, 10: 0}[ct]
+    n_groups = {6: 7, 3: 7, 5: 7, 7: 5, 13: 3, 10: 0}[ct]
     for gi in range(n_groups):
         cells += [cc("tie", 0, group=gi, tie=1), cc("tie", 1, group=gi, tie=0), cc("tie", 2, group=gi, tie=2)]
     header_rows = -(-g["header_cells"] // G)

@@ -99,7 +99,7 @@ def test_linear_hasher_matches_oracle(ctx, oracle):
 
     for n, cap in ((0, 4), (7, 20), (20, 20)):
         q = synthetic.random_log_queries(max(n, 1), seed=n + 1)[:n]
-        qs = np.zeros(1, native.QUEUE_STATE4)
+        qs = oracle.linear_hasher_queue_state(q)  # the queue's own state: the closed-form section ties the pops to its head AND its tail
         t = native.Trace(ctx, N_ROWS, 1, n_cols=native.LH_COLS)
         rec, pi = ctx.synthesize_linear_hasher(q, qs, cap, t, 0)
         exp, orec, opi = oracle.linear_hasher_synthesize(q, qs, cap, N_ROWS)
@@ -115,8 +115,7 @@ def test_linear_hasher_batch_equals_single_calls(ctx, oracle):
 
     cap, sizes = 20, (7, 0, 20, 1, 13)
     queues = [synthetic.random_log_queries(max(n, 1), seed=40 + k)[:n] for k, n in enumerate(sizes)]
-    states = np.zeros(len(sizes), native.QUEUE_STATE4)
-    states["length"] = np.arange(len(sizes))  # distinguishable records
+    states = np.concatenate([oracle.linear_hasher_queue_state(q) for q in queues])
     t = native.Trace(ctx, N_ROWS, len(sizes) + 1, n_cols=native.LH_COLS)
     rec, pi = ctx.synthesize_linear_hasher_batch(queues, states, cap, t, 1)
     for k, q in enumerate(queues):
@@ -128,7 +127,7 @@ def test_linear_hasher_batch_equals_single_calls(ctx, oracle):
         ctx.synthesize_linear_hasher_batch(queues, states, cap, t, 2)  # one slot short
     # the queues' states handed in (zkw_linear_hasher_synthesize_batch_with_tails, what zkw_block_synthesize does): the same traces;
     # a non-empty queue head is where the pops of the queue section start; wrong states are a broken chain, which the checker reports
-    states["head"][2] = [9, 8, 7, 6]
+    states[2:3] = oracle.linear_hasher_queue_state(queues[2], [9, 8, 7, 6])
     tails = [oracle.queue_push_chain_log(oracle.encode_log_queries(q), states["head"][k])[1] for k, q in enumerate(queues)]
     ctx.synthesize_linear_hasher_batch(queues, states, cap, t, 1, tails=tails)
     for k, q in enumerate(queues):
@@ -226,7 +225,7 @@ def test_queue_section_tamper_parity_decommitter_and_linear_hasher(ctx, oracle, 
         cap = 20
         cycles = oracle.linear_hasher_cycles(cap)
         q = synthetic.mixed_log_queue(60, seed=8)[:13]
-        base, _rec, _pi = oracle.linear_hasher_synthesize(q, np.zeros(1, native.QUEUE_STATE4), cap, N_ROWS)
+        base, _rec, _pi = oracle.linear_hasher_synthesize(q, oracle.linear_hasher_queue_state(q), cap, N_ROWS)
         check, ocheck, cols = ctx.check_if_satisfied_linear_hasher, oracle.linear_hasher_check, native.LH_COLS
         ocap = cycles
     assert ocheck(base, ocap) == (0, (0, 0, 0))
@@ -284,7 +283,7 @@ def test_production_geometry_decommitter_and_linear_hasher(ctx, oracle):
     assert q.size == cap
     tails = oracle.queue_push_chain_log(oracle.encode_log_queries(q))[1]
     t = native.Trace(ctx, n_rows, 1, n_cols=native.LH_COLS)
-    rec, _pi = ctx.synthesize_linear_hasher_batch([q], np.zeros(1, native.QUEUE_STATE4), cap, t, 0, tails=[tails])
+    rec, _pi = ctx.synthesize_linear_hasher_batch([q], oracle.linear_hasher_queue_state(q), cap, t, 0, tails=[tails])
     assert rec["keccak256_hash"][0].tobytes() == oracle.linear_keccak256(q)
     assert ctx.check_if_satisfied_linear_hasher(t, 0, cap) == (0, (0, 0, 0))
     lay = native.circuit_layout(13)
@@ -346,7 +345,7 @@ def test_type_dispatching_entry_points(ctx, oracle):
     queues = [synthetic.random_log_queries(max(n, 1), seed=60 + k)[:n] for k, n in enumerate(sizes)]
     flat = np.concatenate(queues)
     off = np.array([0, 7, 7, 20], np.uint64)
-    states = np.zeros(3, native.QUEUE_STATE4)
+    states = np.concatenate([oracle.linear_hasher_queue_state(q) for q in queues])
 
     class LHW(C.Structure):
         _fields_ = [("messages", C.c_void_p), ("message_offsets", C.c_void_p), ("n_queues", C.c_size_t), ("queue_states", C.c_void_p),

@@ -213,7 +213,7 @@ def test_l1_messages_hasher_774(ctx, oracle):
     _geometry(nv, 13, capacity)
     src = synthetic.mixed_log_queue(4 * capacity + 100, seed=5)
     queues = [src[:capacity], src[capacity:capacity + 301]]  # a full queue and a ragged one
-    states = np.zeros(2, nv.QUEUE_STATE4)
+    states = np.concatenate([oracle.linear_hasher_queue_state(q) for q in queues])
     t = nv.Trace(ctx, N_ROWS, 2, n_cols=nv.LH_COLS)
     rec, pi = ctx.synthesize_linear_hasher_batch(queues, states, capacity, t, 0)
     for k, q in enumerate(queues):

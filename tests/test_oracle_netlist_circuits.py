@@ -218,7 +218,7 @@ def test_keccak_round_records_are_the_sponge(oracle):
 def test_linear_hasher_circuit(oracle, n, cap):
     """type 13: one instance over the block's net L2 -> L1 messages; BND_OUT's first 32 bytes = the pubdata hash"""
     q = synthetic.random_log_queries(max(n, 1), seed=n + 1)[:n]
-    t, inst, pi = oracle.linear_hasher_synthesize(q, np.zeros(1, oracle.QUEUE_STATE4), cap, N_ROWS)
+    t, inst, pi = oracle.linear_hasher_synthesize(q, oracle.linear_hasher_queue_state(q), cap, N_ROWS)
     cycles = oracle.linear_hasher_cycles(cap)
     assert oracle.linear_hasher_check(t, cycles) == (0, (0, 0, 0))
     g = oracle.nl_geometry(13)

@@ -131,14 +131,13 @@ def test_linear_hasher_and_storage_application_sections(oracle):
     """type 13 (no hidden FSM: the queue's head and the digest are tied to the observable input / output) and type 10 (no ties: words
     committed, commitments and public input derived)"""
     q = synthetic.mixed_log_queue(36, seed=8)[:7]
-    qs = np.zeros(1, oracle.QUEUE_STATE4)
-    qs["head"][0] = [5, 6, 7, 8]
+    qs = oracle.linear_hasher_queue_state(q, [5, 6, 7, 8])
     t, inst, pi = oracle.linear_hasher_synthesize(q, qs, 20, N_ROWS)
     cycles = oracle.linear_hasher_cycles(20)
     assert oracle.linear_hasher_check(t, cycles) == (0, (0, 0, 0))
     assert t[:4, oracle.nlcf_cell(13, cycles, "pi", 0)[1]].tolist() == np.asarray(pi).tolist()
     for name, (col, row), kinds in (("pi", oracle.nlcf_cell(13, cycles, "pi", 1), (4,)), ("head word", oracle.nlcf_cell(13, cycles, "oi", 2), (2,)),
-                                    ("digest word", oracle.nlcf_cell(13, cycles, "oo", 31), (2,)), ("tail word (free)", oracle.nlcf_cell(13, cycles, "oi", 6), (2,)),
+                                    ("digest word", oracle.nlcf_cell(13, cycles, "oo", 31), (2,)), ("tail word", oracle.nlcf_cell(13, cycles, "oi", 6), (2,)),
                                     ("digest byte in the netlist", (3, cycles * oracle.nl_geometry(13)["rows_per_cycle"] + -(-200 // oracle.nl_geometry(13)["general"])), (2, 4))):
         bad = t.copy()
         bad[col, row] += 1

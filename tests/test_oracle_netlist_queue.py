@@ -188,8 +188,7 @@ def test_linear_hasher_pops_every_message(oracle):
     cap = 20
     cycles = oracle.linear_hasher_cycles(cap)
     q = synthetic.mixed_log_queue(60, seed=8)[:13]
-    qs = np.zeros(1, oracle.QUEUE_STATE4)
-    qs["head"][0] = [5, 6, 7, 8]  # a queue that something was popped from before
+    qs = oracle.linear_hasher_queue_state(q, [5, 6, 7, 8])  # a queue that something was popped from before
     tails = oracle.queue_push_chain_log(oracle.encode_log_queries(q), qs["head"][0])[1]
     t, inst, pi = oracle.linear_hasher_synthesize(q, qs, cap, 1 << 18)
     assert oracle.linear_hasher_check(t, cycles) == (0, (0, 0, 0))
@@ -202,7 +201,7 @@ def test_linear_hasher_pops_every_message(oracle):
         assert [int(t[oracle.nlq_cell(13, cycles, c, j, -1, 1, k)]) for k in range(20)] == enc[m].tolist()
     for (col, row), kinds in ((oracle.nlq_cell(13, cycles, 1, 0, -1, 0, 30), (2,)), (oracle.nlq_cell(13, cycles, 1, 0, -1, 0, 10), (7,)), (oracle.nlq_cell(13, cycles, 1, 0, 2, 0, 50), (8,)),
                               (oracle.nlq_cell(13, cycles, 2, 0, -1, 2, 1), (2,)), (oracle.nlq_cell(13, cycles, 3, 1), (3, 7)),
-                              (oracle.nlq_cell(13, cycles, 0, 2, k=5), (4,))):
+                              (oracle.nlq_cell(13, cycles, 0, 2, k=5), (2, 4))):  # (QBND's head after the last pop: the closed-form section's tie to the queue's tail objects first)
         bad = t.copy()
         bad[col, row] += 1
         n, first = oracle.linear_hasher_check(bad, cycles)

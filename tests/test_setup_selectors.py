@@ -31,7 +31,7 @@ def _netlist_cases(oracle):
     a = ob.create_artifacts_after_vm(synthetic.block_after_vm(seed=2), {ob.CODE_DECOMMITTER: 7})
     out.append((3, 7, oracle.code_decommitter_synthesize(a["witnesses"]["code_decommitter"], 1, 7, N_ROWS)) + geo(3))
     q = synthetic.mixed_log_queue(36, seed=8)[:7]
-    out.append((13, 20, oracle.linear_hasher_synthesize(q, np.zeros(1, oracle.QUEUE_STATE4), 20, N_ROWS)[0]) + geo(13))
+    out.append((13, 20, oracle.linear_hasher_synthesize(q, oracle.linear_hasher_queue_state(q), 20, N_ROWS)[0]) + geo(13))
     from sap_case import storage_application_case
     sq, tails, tree, _idx, _paths = storage_application_case(oracle, 5, seed=9)
     sap = oracle.storage_application_build(tree, sq, tails, 3)

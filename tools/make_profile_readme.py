@@ -128,7 +128,10 @@ if fb:
               f"synthesis of {bt['instances_synthesized']} instances {bt['synthesis_ms']:.0f} ms, release {bt['release_ms']:.0f} ms).")
     if bench.get("hash_circuits"):
         w("* netlist circuits at the reference geometry (2^20 rows; circuits/s into slots that already hold the layout; cold rates in the JSON): " + ", ".join(
-            f"{k} {v['circuits_per_s']:.0f} (capacity {v['capacity']})" for k, v in bench["hash_circuits"].items()) + ".")
+            f"{k} {v['circuits_per_s']:.0f} (capacity {v['capacity']})" for k, v in bench["hash_circuits"].items()) + "."
+          + ("".join(f" ECRecover at 32 instances per call: {e['at_32_instances_per_call']['circuits_per_s']:.0f}"
+                     + (", with " + ", ".join(f"{n_} calls in flight {x['circuits_per_s']:.0f}" for n_, x in e["calls_in_flight"].items() if isinstance(x, dict)) if e.get("calls_in_flight") else "") + "."
+                     for e in [bench["hash_circuits"].get("ecrecover", {})] if e.get("at_32_instances_per_call"))))
     w("* spans of the builders (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in sorted(fb["spans_ms"].items(), key=lambda kv: -kv[1])[:8]) + ".")
 cb = bench.get("cpu_baseline")
 if cb:
