@@ -112,13 +112,19 @@ __device__ __forceinline__ u64 nlcf_reg(const nlcf_desc& d, const nlq_desc& qd, 
                                         const nlcf_group& gr, u32 j, u32 t) {
     if (gr.reg_kind == NLCF_REG_QUEUE_BEFORE || gr.reg_kind == NLCF_REG_QUEUE_AFTER)
         return NLCF_TR(nlq_bnd_col(&qd, gr.queue, gr.reg_kind == NLCF_REG_QUEUE_AFTER, gr.reg0 + j), NLQ_BASE(&S, cycles));
+    if (gr.reg_kind == NLCF_REG_OP_FIRST || gr.reg_kind == NLCF_REG_OP_LAST) {  // the GATED kinds: digit 0 the operation's cell, 1 / 2 the gates' enables
+        const u32 op = t == 0 ? gr.queue : t == 1 ? gr.gate : gr.gate2, cell = t == 0 ? gr.reg0 : 0;
+        const u32 c = gr.reg_kind == NLCF_REG_OP_LAST ? cycles - 1 : 0;
+        if (op == NLCF_GATE_ACTIVE) return NLCF_TR(NL_HDR_IDLE, (size_t)c * S.rows_per_cycle);  // the cycle's idle bit
+        return NLCF_TR(cell % S.g, NLQ_ROW(&S, cycles, nlq_op_row0(&qd, S.g, op) + cell / S.g, c));
+    }
     const u32 e = (gr.reg0 + j) * gr.n_cells + t;
     return NLCF_TR(e % S.g, NL_BOUNDARY_ROW(&S, cycles) + (gr.reg_kind == NLCF_REG_STATE_OUT ? NL_BND_ROWS(&S) : 0) + e / S.g);
 }
 // the word a tie's a (side 0) / b (side 1) cell copies, read from the header block; no word: the constant 0
 __device__ __forceinline__ u64 nlcf_side(const nlcf_desc& d, const u64* __restrict__ trace, size_t n_rows, u64 c0, u32 G, const nlcf_group& gr, u32 j, int side) {
     const int32_t w = nlcf_tie_word(&gr, side ? gr.b_word0 : gr.a_word0, j);
-    if (w < 0) return 0;
+    if (w < 0) return side ? 0 : gr.a_const;
     const u32 k = nlcf_word_cell(&d, side ? nlcf_b_part(&gr) : nlcf_a_part(&gr), (u32)w);
     return NLCF_H(k);
 }
@@ -175,20 +181,34 @@ static __global__ __launch_bounds__(256) void k_nlcf_check(nlcf_desc d, nlq_desc
         const u64 start = NLCF_H(NLCF_CELL_START), completion = NLCF_H(NLCF_CELL_COMPLETION);
         if (a != nlcf_side(d, trace, n_rows, c0, G, gr, i, 0)) flag_bad(res, 2, c, c0 + c / G);
         if (b != nlcf_side(d, trace, n_rows, c0, G, gr, i, 1)) flag_bad(res, 2, c + 1, c0 + (c + 1) / G);
-        u64 R = 0;
+        u64 R = 0, dig[3] = {0, 0, 0};
         for (u32 k = gr.n_cells; k-- > 0;) {
             const u64 x = NLCF_H(c + 2 + k);
             if (x != nlcf_reg(d, qd, S, trace, n_rows, cycles, gr, i, k)) flag_bad(res, 2, c + 2 + k, c0 + (c + 2 + k) / G);
             R = gl::add(gr.n_cells > 1 ? gl::mul(R, 1ull << gr.bits) : 0, x);
+            if (k < 3) dig[k] = x;
         }
         R = gl::canon(R);
         const u64 am = gl::canon(a), bm = gl::canon(b);
         const bool has_b = gr.b_word0 >= 0;
+        const u64 addf = gr.add >= 0 ? (u64)gr.add : gl::P - (u64)(-gr.add);
         bool ok;
         switch (gr.kind) {
             case NLCF_IN: ok = R == gl::canon(gl::add(bm, gl::mul(start, gl::sub(am, bm)))); break;
             case NLCF_OUT_LIVE: ok = completion == 1 || R == am; break;
             case NLCF_OUT_OO: ok = has_b ? (R == bm && am == gl::canon(gl::mul(completion, bm))) : (R == am && am == gl::canon(gl::mul(completion, R))); break;
+            case NLCF_IN_GATED: {  // (g1 - g2) (r - (b + start (a - b)) - add) = 0
+                const u64 g1 = gr.gate == NLCF_GATE_ACTIVE ? gl::sub(1, dig[1]) : dig[1];
+                const u64 gate = gl::sub(g1, gr.n_cells > 2 ? dig[2] : 0), sel = gl::add(bm, gl::mul(start, gl::sub(am, bm)));
+                ok = gl::canon(gl::mul(gate, gl::sub(gl::sub(dig[0], sel), addf))) == 0;
+                break;
+            }
+            case NLCF_OUT_GATED: {  // (1 - completion) (g1 - g2) (a -/+ r - add) = 0
+                const u64 lhs = gr.negate ? gl::add(am, dig[0]) : gl::sub(am, dig[0]);
+                const u64 gate = gr.n_cells < 2 ? 1 : gl::sub(dig[1], gr.n_cells > 2 ? dig[2] : 0);
+                ok = gl::canon(gl::mul(gl::mul(gl::sub(1, completion), gate), gl::sub(lhs, addf))) == 0;
+                break;
+            }
             default: ok = R == am; break;
         }
         if (!ok) flag_bad(res, 7, c, c0 + c / G);

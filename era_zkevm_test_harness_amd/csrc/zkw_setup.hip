@@ -466,7 +466,12 @@ extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacit
                 for (uint32_t t = 0; t < gr.n_cells; t++) {
                     hcell(c + 2 + t, &ca, &ra);
                     if (gr.reg_kind == NLCF_REG_QUEUE_BEFORE || gr.reg_kind == NLCF_REG_QUEUE_AFTER) { cb = nlq_bnd_col(qd, gr.queue, gr.reg_kind == NLCF_REG_QUEUE_AFTER, gr.reg0 + j); rb = NLQ_BASE(ns, cycles); }
-                    else { const uint32_t e = (gr.reg0 + j) * gr.n_cells + t; cb = e % G; rb = nb + (gr.reg_kind == NLCF_REG_STATE_OUT ? brows : 0) + e / G; }
+                    else if (gr.reg_kind == NLCF_REG_OP_FIRST || gr.reg_kind == NLCF_REG_OP_LAST) {  // a cell / an enable of an operation of the queue section in cycle 0 / the last cycle
+                        const uint32_t op = t == 0 ? gr.queue : t == 1 ? gr.gate : gr.gate2, cell = t == 0 ? gr.reg0 : 0;
+                        const uint32_t cyc = gr.reg_kind == NLCF_REG_OP_LAST ? cycles - 1 : 0;
+                        if (op == NLCF_GATE_ACTIVE) { cb = NL_HDR_IDLE; rb = (uint64_t)cyc * ns->rows_per_cycle; }  // the cycle's idle bit
+                        else { cb = cell % G; rb = NLQ_ROW(ns, cycles, nlq_op_row0(qd, G, op) + cell / G, cyc); }
+                    } else { const uint32_t e = (gr.reg0 + j) * gr.n_cells + t; cb = e % G; rb = nb + (gr.reg_kind == NLCF_REG_STATE_OUT ? brows : 0) + e / G; }
                     unite(ca, ra, cb, rb);
                 }
             }

@@ -26,6 +26,15 @@
  *                   that ends its block early leaves the state of an EMPTY round in the FSM output — keccak256_round_function.rs:376-394,
  *                   sha256_round_function.rs:262-279 —, where this library's idle cycles carry the last digest; nothing consumes that output)
  *       OO:         a = copy of OO word, b = copy of the FO word of the register;  R = b, a = completion b   (b absent: R = a = completion R)
+ *     The GATED kinds tie the FSM words that the relations of the queue section (zkw_netlist_queue.h, nlq_rel with prev = 1) carry from
+ *     cycle to cycle — the word offset / page / timestamp of the next read, the page / offset to write, the rounds left, "the round before
+ *     wrote a digest" — at the two ends of an instance, where those relations have no neighbour cycle. Cells [a | b | r | g1 | g2]:
+ *     r, g1, g2 = copies of a cell of an operation and of the enables of two operations (g2 may be absent) in cycle 0 / the last cycle;
+ *       IN_GATED:   a = copy of OI word or the constant a_const, b = copy of FI word;  (g1 - g2) (r - (b + start (a - b)) - add) = 0
+ *                   — the relation of cycle c >= 1 with the FSM input in the place of cycle c - 1
+ *       OUT_GATED:  a = copy of FO word;                                  (1 - completion) (g1 - g2) (a -/+ r - add) = 0   (no gate cells: 1)
+ *                   — what the next instance continues from is what this one's last cycle holds (a non-final instance has no idle cycle)
+ *     A gate NLCF_GATE_ACTIVE stands for 1 - idle of the cycle's netlist header (its digit copies the idle cell).
  *   P2 blocks (the 130 variables of the flattened Poseidon2 gate, ceil(130 / G) rows each): the four sponges in overwrite mode from
  *     the state (0, .., 0, n) — permutation p absorbs words 8p .. 8p + 7 (copies; constants 0 beyond n) over the capacity the
  *     permutation before left (copies) —, then the three permutations over the 18 words of the compact form [start, completion,
@@ -41,44 +50,89 @@
 #include "zkw_ecrecover_ec_spec.h"
 
 enum { NLCF_OI = 0, NLCF_OO = 1, NLCF_FI = 2, NLCF_FO = 3 };
-enum { NLCF_IN = 1, NLCF_IN_ALWAYS = 2, NLCF_OUT = 3, NLCF_OUT_OO = 4, NLCF_OUT_LIVE = 5 };
-enum { NLCF_REG_QUEUE_BEFORE = 0, NLCF_REG_QUEUE_AFTER = 1, NLCF_REG_STATE_IN = 2, NLCF_REG_STATE_OUT = 3 };
-#define NLCF_MAX_GROUPS 10
+enum { NLCF_IN = 1, NLCF_IN_ALWAYS = 2, NLCF_OUT = 3, NLCF_OUT_OO = 4, NLCF_OUT_LIVE = 5, NLCF_IN_GATED = 6, NLCF_OUT_GATED = 7 };
+enum { NLCF_REG_QUEUE_BEFORE = 0, NLCF_REG_QUEUE_AFTER = 1, NLCF_REG_STATE_IN = 2, NLCF_REG_STATE_OUT = 3,
+       NLCF_REG_OP_FIRST = 4 /* a cell of an operation of the queue section in cycle 0 */, NLCF_REG_OP_LAST = 5 /* ... in the last cycle */ };
+#define NLCF_MAX_GROUPS 24
+#define NLCF_NO_GATE 0xFF
+#define NLCF_GATE_ACTIVE 0xFE /* as a gate: 1 - idle of the cycle's netlist header (the digit is a copy of the idle cell) */
 #define NLCF_CP_WORDS 18
 #define NLCF_CP_PERMS 3
 
 /* a run of `count` ties: tie j binds register reg0 + j (QUEUE: element of the queue state; STATE: elements (reg0 + j) * n_cells ..)
    to words a_word0 + j / b_word0 + j (lanes_xy: the FSM holds Keccak's bytes as [x][y][8], the netlist as lane x + 5 y) */
-typedef struct nlcf_group { uint8_t kind, reg_kind, queue, n_cells, bits, lanes_xy; uint16_t count, reg0; int16_t a_word0, b_word0; } nlcf_group;
+typedef struct nlcf_group { uint8_t kind, reg_kind, queue, n_cells, bits, lanes_xy; uint16_t count, reg0; int16_t a_word0, b_word0;
+                            /* the GATED kinds (count = 1; queue = the operation, reg0 = its cell): */ int8_t add; uint8_t a_const, gate, gate2, negate; } nlcf_group;
 typedef struct nlcf_desc { uint16_t n[4]; uint16_t n_groups; nlcf_group g[NLCF_MAX_GROUPS]; } nlcf_desc;
 
+#if defined(__GNUC__)
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wmissing-field-initializers" /* the ungated kinds leave {add, a_const, gate, gate2, negate} zero */
+#endif
 /* Sha256RoundFunction (6). OI = PrecompileFunctionInputData {log queue: head 0..3, tail 4..7, length 8; memory queue: head 9..20, tail
    21..32, length 33}; OO = the final memory queue state (head 0..11, tail 12..23, length 24); FSM = 3 flags, sha256_inner_state 3..10,
    2 timestamps, 5 call parameters, log queue 18..26, memory queue 27..51. The netlist's state = the chaining value as 8 x 8 nibbles. */
-static const nlcf_desc NLCF_DESC_SHA256 = {{34, 25, 52, 52}, 7, {
+/* ... and the internal FSM's address arithmetic at the two ends of an instance (operations of NLQ_DESC_SHA256: 0 pop, 1 / 2 reads, 3 digest
+   write with its registers 102 page to write, 103 offset to write, 104 rounds left; memory-query cells 1 timestamp, 2 page, 3 index). FSM
+   words: 0 read_precompile_call, 1 read_words_for_round, 11 timestamp_to_use_for_read, 13 input_page, 14 input_offset = the next word to
+   read, 15 output_page, 16 output_offset, 17 num_rounds = rounds left (sha256_round_function.rs:204-246,302-316). */
+static const nlcf_desc NLCF_DESC_SHA256 = {{34, 25, 52, 52}, 22, {
     {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, 18}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 21, 39},
     {NLCF_IN, NLCF_REG_STATE_IN, 0, 8, 4, 0, 8, 0, -1, 3},
     {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 18, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 39, -1},
     {NLCF_OUT_LIVE, NLCF_REG_STATE_OUT, 0, 8, 4, 0, 8, 0, 3, -1},
-    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 39}}};
+    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 39},
+    /* cycle 0 continues a request (it reads and does not pop): the first read is the next word of the FSM's page at its timestamp, the registers are the FSM's */
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 1, 3, 0, 0, 1, 3, -1, 14, 0, 0, 1, 0, 0}, {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 1, 3, 0, 0, 1, 2, -1, 13, 0, 0, 1, 0, 0},
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 1, 3, 0, 0, 1, 1, -1, 11, 0, 0, 1, 0, 0},
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 3, 3, 0, 0, 1, 102, -1, 15, 0, 0, 1, 0, 0}, {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 3, 3, 0, 0, 1, 103, -1, 16, 0, 0, 1, 0, 0},
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 3, 3, 0, 0, 1, 104, -1, 17, -1, 0, 1, 0, 0},
+    /* an active cycle 0 pops a call exactly when the FSM says so (a first instance: always) */
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 0, 2, 0, 0, 1, 0, -1, 0, 0, 1, 1, NLCF_NO_GATE, 0},
+    /* the FSM output of a non-final instance is what its last cycle holds */
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 1, 0, 0, 1, 3, 14, -1, 1, 0, 0, 0, 0}, {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 1, 0, 0, 1, 2, 13, -1, 0, 0, 0, 0, 0},
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 1, 0, 0, 1, 1, 11, -1, 0, 0, 0, 0, 0},
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 102, 15, -1, 0, 0, 0, 0, 0}, {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 103, 16, -1, 0, 0, 0, 0, 0},
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 104, 17, -1, 0, 0, 0, 0, 0},
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0} /* read_precompile_call = the last cycle wrote a digest */,
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 0, 1, -1, 1, 0, 0, 0, 1} /* read_words_for_round = 1 - that */}};
 /* CodeDecommitter (3). OI = CodeDecommitterInputData {memory queue 0..24, sorted requests queue 25..49}; OO = the final memory queue
    state; FSM = sha256_inner_state 0..7, hash_to_compare_against 8..15, 5 counters, 3 flags, requests queue 24..48, memory queue 49..73.
    Queue 0 of the section = the requests (popped: head), queue 1 = the memory queue (pushed: tail). */
-static const nlcf_desc NLCF_DESC_CODE_DECOMMITTER = {{50, 25, 74, 74}, 7, {
+/* ... FSM words 16 current_index = the next word to write, 17 current_page, 18 timestamp, 21 state_get_from_queue, 22 state_decommit
+   (decommit_code.rs:228-350); operations of NLQ_DESC_CODE_DECOMMITTER: 0 pop, 1 first word (every active cycle), 2 second word (absent in a
+   bytecode's last round). */
+static const nlcf_desc NLCF_DESC_CODE_DECOMMITTER = {{50, 25, 74, 74}, 18, {
     {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 12, 0, 25, 24}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 12, 61},
     {NLCF_IN, NLCF_REG_STATE_IN, 0, 8, 4, 0, 8, 0, -1, 0},
     {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 12, 0, 24, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 61, -1},
     {NLCF_OUT_LIVE, NLCF_REG_STATE_OUT, 0, 8, 4, 0, 8, 0, 0, -1},
-    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 61}}};
+    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 61},
+    /* cycle 0 continues a bytecode: its first word goes where the FSM says; it pops a request exactly when the FSM says so */
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 1, 3, 0, 0, 1, 3, -1, 16, 0, 0, 1, 0, 0}, {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 1, 3, 0, 0, 1, 2, -1, 17, 0, 0, 1, 0, 0},
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 1, 3, 0, 0, 1, 1, -1, 18, 0, 0, 1, 0, 0},
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 0, 2, 0, 0, 1, 0, -1, 21, 0, 1, 1, NLCF_NO_GATE, 0},
+    /* a non-final instance leaves: the index after the last word written (the second word when the last cycle has one), page, timestamp, the state */
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 2, 0, 0, 1, 3, 16, -1, 1, 0, 2, NLCF_NO_GATE, 0}, {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 1, 3, 0, 0, 1, 3, 16, -1, 1, 0, 1, 2, 0},
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 1, 1, 0, 0, 1, 2, 17, -1, 0, 0, 0, 0, 0}, {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 1, 1, 0, 0, 1, 1, 18, -1, 0, 0, 0, 0, 0},
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 1, 0, 0, 1, 0, 21, -1, 1, 0, 0, 0, 1} /* state_get_from_queue = 1 - "the last cycle wrote a second word" */,
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 1, 0, 0, 1, 0, 22, -1, 0, 0, 0, 0, 0} /* state_decommit = that */}};
 /* Keccak256RoundFunction (5). OI / OO as type 6; FSM = 4 flags, keccak_internal_state 4..203 ([x][y][8] bytes), 2 timestamps, 6 call
    parameters, the byte buffer 212..403 and its fill 404, log queue 405..413, memory queue 414..438. The netlist's state = the sponge
    state as 200 bytes, lane x + 5 y. */
-static const nlcf_desc NLCF_DESC_KECCAK256 = {{34, 25, 439, 439}, 7, {
+/* ... FSM words 0 read_precompile_call, 209 output_page, 210 output_offset (keccak256_round_function.rs:420-441); operations of
+   NLQ_DESC_KECCAK256: 0 pop, 1..6 unaligned reads, 7 digest write with its registers 70 page to write, 71 offset to write. (The byte
+   offset / length of the input and the byte buffer have no register in the queue section: committed only.) */
+static const nlcf_desc NLCF_DESC_KECCAK256 = {{34, 25, 439, 439}, 13, {
     {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, 405}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 21, 426},
     {NLCF_IN, NLCF_REG_STATE_IN, 0, 1, 8, 1, 200, 0, -1, 4},
     {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 405, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 426, -1},
     {NLCF_OUT_LIVE, NLCF_REG_STATE_OUT, 0, 1, 8, 1, 200, 0, 4, -1},
-    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 426}}};
+    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 426},
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 7, 3, 0, 0, 1, 70, -1, 209, 0, 0, NLCF_GATE_ACTIVE, 0, 0}, {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 7, 3, 0, 0, 1, 71, -1, 210, 0, 0, NLCF_GATE_ACTIVE, 0, 0},
+    {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 0, 2, 0, 0, 1, 0, -1, 0, 0, 1, NLCF_GATE_ACTIVE, NLCF_NO_GATE, 0},
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 7, 1, 0, 0, 1, 70, 209, -1, 0, 0, 0, 0, 0}, {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 7, 1, 0, 0, 1, 71, 210, -1, 0, 0, 0, 0, 0},
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 7, 1, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0} /* read_precompile_call = the last cycle wrote a digest */}};
 /* ECRecover (7). OI / OO as type 6; FSM = EcrecoverCircuitFSMInputOutput {log queue 0..8, memory queue 9..33} (ecrecover.rs:226-233): a
    cycle is a whole request, the netlist carries nothing between cycles. */
 static const nlcf_desc NLCF_DESC_ECRECOVER = {{34, 25, 34, 34}, 5, {
@@ -98,6 +152,10 @@ static const nlcf_desc NLCF_DESC_LINEAR_HASHER = {{9, 32, 0, 0}, 3, {
    (storage_application.rs:286-336). The trace holds the Blake2s walks only (no queue side, docs/KERNELS.md 3.17): no ties — the words are
    committed, the commitments and the public input derived in-trace. */
 static const nlcf_desc NLCF_DESC_STORAGE_APPLICATION = {{44, 66, 243, 243}, 0, {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+
+#if defined(__GNUC__)
+#pragma GCC diagnostic pop
+#endif
 
 static inline const nlcf_desc *nlcf_desc_of(int circuit_type) {
     return circuit_type == 6 ? &NLCF_DESC_SHA256 : circuit_type == 3 ? &NLCF_DESC_CODE_DECOMMITTER : circuit_type == 5 ? &NLCF_DESC_KECCAK256 :
@@ -128,7 +186,7 @@ NLQ_HD int32_t nlcf_tie_word(const nlcf_group *g, int32_t word0, uint32_t j) {
     return word0 + (int32_t)(8 * (5 * x + y) + j % 8);
 }
 /* which part the words of a tie's sides belong to */
-NLQ_HD uint32_t nlcf_a_part(const nlcf_group *g) { return g->kind == NLCF_OUT || g->kind == NLCF_OUT_LIVE ? NLCF_FO : g->kind == NLCF_OUT_OO ? NLCF_OO : NLCF_OI; }
+NLQ_HD uint32_t nlcf_a_part(const nlcf_group *g) { return g->kind == NLCF_OUT || g->kind == NLCF_OUT_LIVE || g->kind == NLCF_OUT_GATED ? NLCF_FO : g->kind == NLCF_OUT_OO ? NLCF_OO : NLCF_OI; }
 NLQ_HD uint32_t nlcf_b_part(const nlcf_group *g) { return g->kind == NLCF_OUT_OO ? NLCF_FO : NLCF_FI; }
 
 /* ---- P2 blocks: sponge of part p = perms [nlcf_perm0(p), nlcf_perm0(p + 1)), then the compact form's three */

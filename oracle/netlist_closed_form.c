@@ -35,11 +35,17 @@ static uint64_t *pcell(const geom *g, uint64_t *trace, uint32_t perm, uint32_t v
     return &trace[(size_t)(v % g->G) * g->n_rows + g->c0 + nlcf_perm_row0(g->d, g->G, perm) + v / g->G];
 }
 static size_t prow(const geom *g, uint32_t perm, uint32_t v) { return g->c0 + nlcf_perm_row0(g->d, g->G, perm) + v / g->G; }
-/* digit t of the register tie j of a group binds */
+/* digit t of the register tie j of a group binds (the GATED kinds: digit 0 the operation's cell, 1 / 2 the enables of the gate operations) */
 static uint64_t *reg_cell(const geom *g, uint64_t *trace, const nlcf_group *gr, uint32_t j, uint32_t t) {
     const nl_spec *sp = g->sp;
     if (gr->reg_kind == NLCF_REG_QUEUE_BEFORE || gr->reg_kind == NLCF_REG_QUEUE_AFTER)
         return &trace[(size_t)nlq_bnd_col(g->qd, gr->queue, gr->reg_kind == NLCF_REG_QUEUE_AFTER, gr->reg0 + j) * g->n_rows + NLQ_BASE(sp, g->cycles)];
+    if (gr->reg_kind == NLCF_REG_OP_FIRST || gr->reg_kind == NLCF_REG_OP_LAST) {
+        const uint32_t op = t == 0 ? gr->queue : t == 1 ? gr->gate : gr->gate2, cell = t == 0 ? gr->reg0 : 0;
+        const uint32_t c = gr->reg_kind == NLCF_REG_OP_LAST ? g->cycles - 1 : 0;
+        if (op == NLCF_GATE_ACTIVE) return &trace[(size_t)NL_HDR_IDLE * g->n_rows + (size_t)c * sp->rows_per_cycle]; /* the cycle's idle bit */
+        return &trace[(size_t)(cell % g->G) * g->n_rows + NLQ_ROW(sp, g->cycles, nlq_op_row0(g->qd, g->G, op) + cell / g->G, c)];
+    }
     const uint32_t e = (gr->reg0 + j) * gr->n_cells + t;
     const size_t row = NL_BOUNDARY_ROW(sp, g->cycles) + (gr->reg_kind == NLCF_REG_STATE_OUT ? NL_BND_ROWS(sp) : 0) + e / g->G;
     return &trace[(size_t)(e % g->G) * g->n_rows + row];
@@ -95,7 +101,7 @@ static int fill_words(int circuit_type, uint32_t cycles, size_t n_rows, uint64_t
         for (uint32_t j = 0; j < gr->count; j++) {
             const uint32_t c = nlcf_tie_cell0(d, gi, j);
             const int32_t wa = nlcf_tie_word(gr, gr->a_word0, j), wb = nlcf_tie_word(gr, gr->b_word0, j);
-            const uint64_t a = wa >= 0 ? w[nlcf_a_part(gr)][wa] : 0, b = wb >= 0 ? w[nlcf_b_part(gr)][wb] : 0;
+            const uint64_t a = wa >= 0 ? w[nlcf_a_part(gr)][wa] : gr->a_const, b = wb >= 0 ? w[nlcf_b_part(gr)][wb] : 0;
             *hcell(&g, trace, c) = a;
             *hcell(&g, trace, c + 1) = b;
             for (uint32_t t = 0; t < gr->n_cells; t++) *hcell(&g, trace, c + 2 + t) = *reg_cell(&g, trace, gr, j, t); /* copies of what the other sections hold */
@@ -145,6 +151,15 @@ int orc_nlcf_standalone(int circuit_type, uint32_t cycles, size_t n_rows, uint64
         for (uint32_t j = 0; j < gr->count; j++) {
             const uint64_t R = recompose(&g, trace, gr, j, NULL);
             const int32_t wa = nlcf_tie_word(gr, gr->a_word0, j), wb = nlcf_tie_word(gr, gr->b_word0, j);
+            if (gr->kind == NLCF_IN_GATED) { /* start = 0: the FSM word the relation wants (register - add) */
+                if (wb >= 0) w[NLCF_FI][wb] = orc_gl_sub(*reg_cell(&g, trace, gr, j, 0) % P, gr->add >= 0 ? (uint64_t)gr->add : P - (uint64_t)(-gr->add));
+                continue;
+            }
+            if (gr->kind == NLCF_OUT_GATED) { /* completion = 0: the FSM word the relation wants */
+                const uint64_t r = *reg_cell(&g, trace, gr, j, 0) % P, addf = gr->add >= 0 ? (uint64_t)gr->add : P - (uint64_t)(-gr->add);
+                w[NLCF_FO][wa] = gr->negate ? orc_gl_sub(addf, r) : orc_gl_add(r, addf);
+                continue;
+            }
             if (gr->kind == NLCF_IN && wb >= 0) w[NLCF_FI][wb] = R;
             else if (gr->kind == NLCF_IN_ALWAYS || gr->kind == NLCF_OUT || gr->kind == NLCF_OUT_LIVE) w[nlcf_a_part(gr)][wa] = R;
             else if (gr->kind == NLCF_OUT_OO && wb < 0) w[NLCF_OO][wa] = R; /* (with an FSM: completion = 0, the word stays zero) */
@@ -180,7 +195,7 @@ uint64_t orc_nlcf_check(int circuit_type, const uint64_t *trace, uint32_t cycles
             const uint32_t c = nlcf_tie_cell0(d, gi, j);
             const int32_t wa = nlcf_tie_word(gr, gr->a_word0, j), wb = nlcf_tie_word(gr, gr->b_word0, j);
             const uint64_t a = *hcell(&g, tr, c), b = *hcell(&g, tr, c + 1);
-            if (a != (wa >= 0 ? *hcell(&g, tr, nlcf_word_cell(d, nlcf_a_part(gr), (uint32_t)wa)) : 0)) flag(&res, 2, c, hrow(&g, c));
+            if (a != (wa >= 0 ? *hcell(&g, tr, nlcf_word_cell(d, nlcf_a_part(gr), (uint32_t)wa)) : gr->a_const)) flag(&res, 2, c, hrow(&g, c));
             if (b != (wb >= 0 ? *hcell(&g, tr, nlcf_word_cell(d, nlcf_b_part(gr), (uint32_t)wb)) : 0)) flag(&res, 2, c + 1, hrow(&g, c + 1));
             uint64_t digits[16];
             for (uint32_t t = 0; t < gr->n_cells; t++) {
@@ -188,8 +203,22 @@ uint64_t orc_nlcf_check(int circuit_type, const uint64_t *trace, uint32_t cycles
                 if (digits[t] != *reg_cell(&g, tr, gr, j, t)) flag(&res, 2, c + 2 + t, hrow(&g, c + 2 + t));
             }
             const uint64_t R = recompose(&g, trace, gr, j, digits), am = a % P, bm = b % P;
+            const uint64_t addf = gr->add >= 0 ? (uint64_t)gr->add : P - (uint64_t)(-gr->add);
             int ok;
             switch (gr->kind) {
+                case NLCF_IN_GATED: { /* (g1 - g2) (r - (b + start (a - b)) - add) = 0 */
+                    const uint64_t g1 = gr->gate == NLCF_GATE_ACTIVE ? orc_gl_sub(1, digits[1] % P) : digits[1] % P;
+                    const uint64_t gate = orc_gl_sub(g1, gr->n_cells > 2 ? digits[2] % P : 0);
+                    const uint64_t sel = orc_gl_add(bm, orc_gl_mul(start % P, orc_gl_sub(am, bm)));
+                    ok = orc_gl_mul(gate, orc_gl_sub(orc_gl_sub(digits[0] % P, sel), addf)) == 0;
+                    break;
+                }
+                case NLCF_OUT_GATED: { /* (1 - completion) (g1 - g2) (a -/+ r - add) = 0 */
+                    const uint64_t r = digits[0] % P, lhs = gr->negate ? orc_gl_add(am, r) : orc_gl_sub(am, r);
+                    const uint64_t gate = gr->n_cells < 2 ? 1 : orc_gl_sub(digits[1] % P, gr->n_cells > 2 ? digits[2] % P : 0);
+                    ok = orc_gl_mul(orc_gl_mul(orc_gl_sub(1, completion % P), gate), orc_gl_sub(lhs, addf)) == 0;
+                    break;
+                }
                 case NLCF_IN: ok = R == orc_gl_add(bm, orc_gl_mul(start % P, orc_gl_sub(am, bm))); break;
                 case NLCF_OUT_LIVE: ok = completion == 1 || R == am; break;
                 case NLCF_OUT_OO: ok = wb >= 0 ? (R == bm && am == orc_gl_mul(completion % P, bm)) : (R == am && am == orc_gl_mul(completion % P, R)); break;
@@ -237,7 +266,7 @@ void orc_nlcf_geometry(int circuit_type, uint32_t cycles, uint64_t out[9]) {
     for (int p = 0; p < 4; p++) out[5 + p] = d->n[p];
 }
 /* (column, row) of a cell: what = 0 header cell k (0 start, 1 completion); 1..4 word k of OI / OO / FI / FO; 5 variable k % 130 of P2
-   block k / 130; 6 cell `k & 0xFFFF` of tie `k >> 16 & 0xFFF` of group `k >> 28`; 7 PI cell k */
+   block k / 130; 6 cell `k & 0x3FFF` of tie `k >> 14 & 0xFFF` of group `k >> 26`; 7 PI cell k */
 int orc_nlcf_cell(int circuit_type, uint32_t cycles, int what, uint32_t k, uint64_t out[2]) {
     geom g;
     if (geom_of(circuit_type, cycles, (size_t)1 << 40, &g)) return -1;
@@ -249,7 +278,7 @@ int orc_nlcf_cell(int circuit_type, uint32_t cycles, int what, uint32_t k, uint6
         out[0] = (k % 130) % g.G; out[1] = prow(&g, k / 130, k % 130);
         return 0;
     } else if (what == 6) {
-        const uint32_t gi = k >> 28, j = (k >> 16) & 0xFFF, c = k & 0xFFFF;
+        const uint32_t gi = k >> 26, j = (k >> 14) & 0xFFF, c = k & 0x3FFF;
         if (gi >= g.d->n_groups || j >= g.d->g[gi].count || c >= 2u + g.d->g[gi].n_cells) return -2;
         cell = nlcf_tie_cell0(g.d, gi, j) + c;
     } else if (what == 7) { out[0] = k; out[1] = NL_PI_ROW(g.sp, cycles); return 0; }

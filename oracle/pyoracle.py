@@ -702,7 +702,8 @@ def nlcf_cell(circuit_type, cycles, what, k=0, group=None, tie=0):
     "p2" (k = 130 * permutation + variable), "tie" (cell k of tie `tie` of group `group`: 0 a, 1 b, 2.. register digits), "pi" """
     code = {"flag": 0, "oi": 1, "oo": 2, "fi": 3, "fo": 4, "p2": 5, "tie": 6, "pi": 7}[what]
     if what == "tie":
-        k = (group << 28) | (tie << 16) | k
+        assert group < 64 and tie < 4096 and k < 16384
+        k = (group << 26) | (tie << 14) | k
     out = np.zeros(2, np.uint64)
     f = lib().orc_nlcf_cell
     f.restype = C.c_int

@@ -3,6 +3,17 @@ every part, tie cells, permutation inputs / middles / outputs of a commitment sp
 of the section, its lookup columns, random cells of its rows."""
 
 
+def _cell_or_none(oracle, ct, cycles, group, tie, k):
+    import ctypes as C
+    import numpy as np
+
+    out = np.zeros(2, np.uint64)
+    f = oracle.lib().orc_nlcf_cell
+    f.restype = C.c_int
+    rc = f(C.c_int(ct), C.c_uint32(cycles), C.c_int(6), C.c_uint32((group << 26) | (tie << 14) | k), C.c_void_p(out.ctypes.data))
+    return (int(out[0]), int(out[1])) if rc == 0 else None
+
+
 def closed_form_cells(oracle, ct, cycles, rng, n_random=10):
     g = oracle.nlcf_geometry(ct, cycles)
     geo = oracle.nl_geometry(ct)
@@ -14,9 +25,13 @@ def closed_form_cells(oracle, ct, cycles, rng, n_random=10):
              cc("p2", 130 * (perms - 1) + 119), cc("p2", 130 * (perms - 1) + 90)]
     if g["n_fi"]:
         cells += [cc("fi", 1), cc("fi", g["n_fi"] // 2), cc("fo", g["n_fo"] - 2), cc("fo", 0)]
-    n_groups = {6: 7, 3: 7, 5: 7, 7: 5, 13: 3, 10: 0}[ct]
-    for gi in range(n_groups):
-        cells += [cc("tie", 0, group=gi, tie=1), cc("tie", 1, group=gi, tie=0), cc("tie", 2, group=gi, tie=2)]
+    gi = 0
+    while gi < 64:  # every group: a / b cells of a tie, a register digit of another (group shapes differ: probe the layout)
+        got = [_cell_or_none(oracle, ct, cycles, gi, tie, k) for tie, k in ((0, 0), (0, 1), (0, 2), (1, 0), (2, 2), (0, 3))]
+        if got[0] is None:
+            break
+        cells += [x for x in got if x is not None]
+        gi += 1
     header_rows = -(-g["header_cells"] // G)
     if g["header_cells"] % G:
         cells.append((G - 1, g["first_row"] + header_rows - 1))  # an unused cell of the header block's last row

@@ -96,7 +96,7 @@ def test_tampering_is_caught(oracle, ct):
         inst = w["instances"].copy()
         forged = dict(w)
         if what == "fi":
-            name = "read_words_for_round" if ct != 3 else "state_get_from_queue"
+            name = "read_words_for_round" if ct != 3 else "length_in_bits"  # (words no tie names on the input side)
             inst["hidden_fsm_input"][name][mid] ^= 1
         else:
             q0 = "initial_log_queue_state" if ct != 3 else "memory_queue_initial_state"
@@ -156,3 +156,89 @@ def test_linear_hasher_and_storage_application_sections(oracle):
             bad = t.copy()
             bad[oracle.nlcf_cell(10, cyc, what, k)] += 1
             assert oracle.storage_application_check(bad, 3)[0] > 0, (i, what)
+
+
+def test_sha256_fsm_words_are_tied_at_both_ends_of_an_instance(oracle):
+    """type 6: the internal FSM's address arithmetic (next word to read, page, timestamp, page / offset to write, rounds left, "the round
+    before wrote a digest") is tied to the first cycle's operations on the input side and to the last cycle's on the output side: a forged
+    word with everything downstream recomputed — which only moved the public input before — is now caught by its register (kind 7)"""
+    cap = 3
+    req, mq = synthetic.precompile_trace(1, 9, seed=3, max_rounds=4)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    w = oracle.precompile_build(1, req, tails, mq, cap, np.zeros(1, oracle.QUEUE_STATE12))
+    n = w["instances"].size
+    assert n >= 5
+    base = [oracle.sha256_round_synthesize(w, i, cap, N_ROWS) for i in range(n)]
+    assert all(oracle.sha256_round_check(t, cap)[0] == 0 for t in base)
+    # an instance whose first cycle CONTINUES a request (reads, does not pop), and one whose first cycle pops
+    pops0 = [int(t[oracle.nlq_cell(6, cap, 0, 0)]) for t in base]
+    cont = next(i for i in range(1, n - 1) if pops0[i] == 0)
+    fresh = next(i for i in range(1, n - 1) if pops0[i] == 1)
+
+    def forged(i, side, field, delta):
+        inst = w["instances"].copy()
+        inst[side][field][i] = inst[side][field][i] ^ 1 if delta is None else inst[side][field][i] + delta
+        f = dict(w)
+        f["instances"] = inst
+        return oracle.sha256_round_check(oracle.sha256_round_synthesize(f, i, cap, N_ROWS), cap)
+
+    for field in ("input_offset", "input_page", "timestamp_to_use_for_read", "output_page", "output_offset", "num_rounds"):
+        nb, first = forged(cont, "hidden_fsm_input", field, 1)
+        assert nb == 1 and first[0] == 7, (field, nb, first)            # the register of cycle 0 disagrees
+        nb, first = forged(fresh, "hidden_fsm_input", field, 1)
+        assert nb == 0, (field, nb, first)                              # a cycle 0 that pops loads them from the call: the FSM's are dead
+        nb, first = forged(cont, "hidden_fsm_output", field, 1)
+        assert nb == 1 and first[0] == 7, (field, nb, first)            # the last cycle disagrees
+    for i in (cont, fresh):
+        nb, first = forged(i, "hidden_fsm_input", "read_precompile_call", None)  # flipped
+        assert nb == 1 and first[0] == 7, (i, nb, first)                # pop <=> the FSM says "read a call"
+    nb, first = forged(n - 1, "hidden_fsm_output", "num_rounds", 1)
+    assert nb == 0                                                      # the last instance: completion frees the FSM output
+
+
+def test_decommitter_and_keccak_fsm_words_are_tied_at_both_ends(oracle):
+    """types 3 and 5: the FSM words the queue section's relations carry — the decommitter's next word index / page / timestamp and its
+    "get a request" state, Keccak's page / offset to write and "read a call" — against the first and the last cycle of an instance"""
+    from oracle import block as ob
+    a = ob.create_artifacts_after_vm(synthetic.block_after_vm(seed=2), {ob.CODE_DECOMMITTER: 2})
+    w = a["witnesses"]["code_decommitter"]
+    n = w["instances"].size
+    synth = lambda f, i: oracle.code_decommitter_synthesize(f, i, 2, N_ROWS)  # noqa: E731
+    check = lambda t: oracle.code_decommitter_check(t, 2)  # noqa: E731
+    pops0 = [int(synth(w, i)[oracle.nlq_cell(3, 2, 0, 0)]) for i in range(n)]
+    cont = next(i for i in range(1, n - 1) if pops0[i] == 0)
+
+    def forged(w_, synth_, check_, i, side, field, flip=False):
+        inst = w_["instances"].copy()
+        inst[side][field][i] = inst[side][field][i] ^ 1 if flip else inst[side][field][i] + 1
+        f = dict(w_)
+        f["instances"] = inst
+        return check_(synth_(f, i))
+
+    for field in ("current_index", "current_page", "timestamp"):
+        for side in ("hidden_fsm_input", "hidden_fsm_output"):
+            nb, first = forged(w, synth, check, cont, side, field)
+            assert nb == 1 and first[0] == 7, (field, side, nb, first)
+    for side in ("hidden_fsm_input", "hidden_fsm_output"):
+        nb, first = forged(w, synth, check, cont, side, "state_get_from_queue", flip=True)
+        assert nb == 1 and first[0] == 7, (side, nb, first)
+    nb, _ = forged(w, synth, check, n - 1, "hidden_fsm_output", "current_index")
+    assert nb == 0  # the last instance: completion frees the FSM output
+
+    req, mq = synthetic.precompile_trace(0, 9, seed=3, max_rounds=4)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    k = oracle.precompile_build(0, req, tails, mq, 2, np.zeros(1, oracle.QUEUE_STATE12))
+    ksynth = lambda f, i: oracle.keccak_round_synthesize(f, i, 2, N_ROWS)  # noqa: E731
+    kcheck = lambda t: oracle.keccak_round_check(t, 2)  # noqa: E731
+    kn = k["instances"].size
+    kpops0 = [int(ksynth(k, i)[oracle.nlq_cell(5, 2, 0, 0)]) for i in range(kn)]
+    kcont = next(i for i in range(1, kn - 1) if kpops0[i] == 0)
+    for field in ("output_page", "output_offset"):
+        for side in ("hidden_fsm_input", "hidden_fsm_output"):
+            nb, first = forged(k, ksynth, kcheck, kcont, side, field)
+            assert nb == 1 and first[0] == 7, (field, side, nb, first)
+    for side in ("hidden_fsm_input", "hidden_fsm_output"):
+        nb, first = forged(k, ksynth, kcheck, kcont, side, "read_precompile_call", flip=True)
+        assert nb == 1 and first[0] == 7, (side, nb, first)
+    nb, _ = forged(k, ksynth, kcheck, kcont, "hidden_fsm_input", "input_offset")
+    assert nb == 0  # Keccak's byte offset has no register in the queue section: committed (it moves the public input), not tied
