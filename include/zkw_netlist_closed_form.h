@@ -40,8 +40,9 @@
  *     permutation before left (copies) —, then the three permutations over the 18 words of the compact form [start, completion,
  *     c(OI), c(OO), c(FI), c(FO)] (copies of the sponges' last outputs 0..3; the constant 0 for an empty encoding). The PI row's four
  *     cells are copies of the last permutation's outputs 0..3.
- * What stays only committed (FREE words): everything the ties below do not name — the flags, timestamps and call parameters of the
- * internal FSMs, Keccak's byte buffer, the queue LENGTHS and the far ends of the queues (tail of a popped queue — but for the
+ * What stays only committed (FREE words): everything the ties below do not name — the `completed` / `padding_round` flags and the
+ * write timestamp of the internal FSMs, Keccak's byte offset / length / buffer and the decommitter's round count and length (no registers
+ * for them in the queue section), the queue LENGTHS and the far ends of the queues (tail of a popped queue — but for the
  * L1MessagesHasher, whose pops must reach it —, head of the memory queue), all of StorageApplication's words.
  */
 #ifndef ZKW_NETLIST_CLOSED_FORM_H
