@@ -945,7 +945,8 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
     // (2) everything else, block by block on a few threads
     std::atomic<size_t> next{0};
     std::vector<std::thread> pool;
-    const size_t n_threads = std::min<size_t>(8, n_blocks);
+    static const size_t max_threads = [] { const char* e = getenv("ZKW_SYNTH_THREADS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 ? v : 8); }();
+    const size_t n_threads = std::min<size_t>(max_threads, n_blocks);
     for (size_t th = 0; th < n_threads; th++)
         pool.emplace_back([&] {
             for (;;) {
