@@ -108,8 +108,12 @@ __device__ __forceinline__ bool nlcf_tie_at(const nlcf_desc& d, u32 i, NlcfTieAt
     }
     return false;
 }
-__device__ __forceinline__ u64 nlcf_reg(const nlcf_desc& d, const nlq_desc& qd, const nl_spec& S, const u64* __restrict__ trace, size_t n_rows, u32 cycles,
+__device__ __forceinline__ u64 nlcf_reg(const nlcf_desc& d, const nlq_desc& qd, const nl_spec& S, const u64* __restrict__ trace, size_t n_rows, u32 cycles, u64 c0,
                                         const nlcf_group& gr, u32 j, u32 t) {
+    if (gr.reg_kind == NLCF_REG_FO_WORD) {  // a word of the FSM output: the header block's own cell
+        const u32 G = S.g, k = nlcf_word_cell(&d, NLCF_FO, gr.reg0 + j);
+        return NLCF_H(k);
+    }
     if (gr.reg_kind == NLCF_REG_QUEUE_BEFORE || gr.reg_kind == NLCF_REG_QUEUE_AFTER)
         return NLCF_TR(nlq_bnd_col(&qd, gr.queue, gr.reg_kind == NLCF_REG_QUEUE_AFTER, gr.reg0 + j), NLQ_BASE(&S, cycles));
     if (gr.reg_kind == NLCF_REG_OP_FIRST || gr.reg_kind == NLCF_REG_OP_LAST) {  // the GATED kinds: digit 0 the operation's cell, 1 / 2 the gates' enables
@@ -139,7 +143,7 @@ static __global__ __launch_bounds__(256) void k_nlcf_ties(nlcf_desc d, nlq_desc 
     if (!nlcf_tie_at(d, blockIdx.x * blockDim.x + threadIdx.x, &at)) return;
     const nlcf_group& gr = d.g[at.gi];
     const u32 k = nlcf_tie_cell0(&d, at.gi, at.j) + at.c;
-    NLCF_H(k) = at.c < 2 ? nlcf_side(d, trace, n_rows, c0, G, gr, at.j, (int)at.c) : nlcf_reg(d, qd, S, trace, n_rows, cycles, gr, at.j, at.c - 2);
+    NLCF_H(k) = at.c < 2 ? nlcf_side(d, trace, n_rows, c0, G, gr, at.j, (int)at.c) : nlcf_reg(d, qd, S, trace, n_rows, cycles, c0, gr, at.j, at.c - 2);
 }
 
 // the value input v of P2 block `perm` copies (oracle: perm_source)
@@ -184,7 +188,7 @@ static __global__ __launch_bounds__(256) void k_nlcf_check(nlcf_desc d, nlq_desc
         u64 R = 0, dig[3] = {0, 0, 0};
         for (u32 k = gr.n_cells; k-- > 0;) {
             const u64 x = NLCF_H(c + 2 + k);
-            if (x != nlcf_reg(d, qd, S, trace, n_rows, cycles, gr, i, k)) flag_bad(res, 2, c + 2 + k, c0 + (c + 2 + k) / G);
+            if (x != nlcf_reg(d, qd, S, trace, n_rows, cycles, c0, gr, i, k)) flag_bad(res, 2, c + 2 + k, c0 + (c + 2 + k) / G);
             R = gl::add(gr.n_cells > 1 ? gl::mul(R, 1ull << gr.bits) : 0, x);
             if (k < 3) dig[k] = x;
         }
@@ -196,6 +200,7 @@ static __global__ __launch_bounds__(256) void k_nlcf_check(nlcf_desc d, nlq_desc
         switch (gr.kind) {
             case NLCF_IN: ok = R == gl::canon(gl::add(bm, gl::mul(start, gl::sub(am, bm)))); break;
             case NLCF_OUT_LIVE: ok = completion == 1 || R == am; break;
+            case NLCF_DONE: ok = gl::canon(gl::mul(completion, gl::sub(R, am))) == 0; break;
             case NLCF_OUT_OO: ok = has_b ? (R == bm && am == gl::canon(gl::mul(completion, bm))) : (R == am && am == gl::canon(gl::mul(completion, R))); break;
             case NLCF_IN_GATED: {  // (g1 - g2) (r - (b + start (a - b)) - add) = 0
                 const u64 g1 = gr.gate == NLCF_GATE_ACTIVE ? gl::sub(1, dig[1]) : dig[1];

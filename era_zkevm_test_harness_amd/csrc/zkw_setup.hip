@@ -465,7 +465,8 @@ extern "C" int zkw_setup_copy_permutation(uint8_t circuit_type, uint32_t capacit
                 if (wb >= 0) { hcell(c + 1, &ca, &ra); hcell(nlcf_word_cell(cd, nlcf_b_part(&gr), (uint32_t)wb), &cb, &rb); unite(ca, ra, cb, rb); }
                 for (uint32_t t = 0; t < gr.n_cells; t++) {
                     hcell(c + 2 + t, &ca, &ra);
-                    if (gr.reg_kind == NLCF_REG_QUEUE_BEFORE || gr.reg_kind == NLCF_REG_QUEUE_AFTER) { cb = nlq_bnd_col(qd, gr.queue, gr.reg_kind == NLCF_REG_QUEUE_AFTER, gr.reg0 + j); rb = NLQ_BASE(ns, cycles); }
+                    if (gr.reg_kind == NLCF_REG_FO_WORD) hcell(nlcf_word_cell(cd, NLCF_FO, gr.reg0 + j), &cb, &rb);  // a word of the FSM output: a cell of the header block
+                    else if (gr.reg_kind == NLCF_REG_QUEUE_BEFORE || gr.reg_kind == NLCF_REG_QUEUE_AFTER) { cb = nlq_bnd_col(qd, gr.queue, gr.reg_kind == NLCF_REG_QUEUE_AFTER, gr.reg0 + j); rb = NLQ_BASE(ns, cycles); }
                     else if (gr.reg_kind == NLCF_REG_OP_FIRST || gr.reg_kind == NLCF_REG_OP_LAST) {  // a cell / an enable of an operation of the queue section in cycle 0 / the last cycle
                         const uint32_t op = t == 0 ? gr.queue : t == 1 ? gr.gate : gr.gate2, cell = t == 0 ? gr.reg0 : 0;
                         const uint32_t cyc = gr.reg_kind == NLCF_REG_OP_LAST ? cycles - 1 : 0;

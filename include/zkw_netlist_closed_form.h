@@ -26,6 +26,10 @@
  *                   that ends its block early leaves the state of an EMPTY round in the FSM output — keccak256_round_function.rs:376-394,
  *                   sha256_round_function.rs:262-279 —, where this library's idle cycles carry the last digest; nothing consumes that output)
  *       OO:         a = copy of OO word, b = copy of the FO word of the register;  R = b, a = completion b   (b absent: R = a = completion R)
+ *       DONE:       a = copy of FO word;                                           completion (R - a) = 0   (the popped queue's head after the
+ *                   last pop of the LAST instance is its tail: every request of the block was served)
+ *     The register of an IN tie may also be a word of the FSM OUTPUT (NLCF_REG_FO_WORD): the far end of a queue — the tail of the popped
+ *     queue, the head of the memory queue — never moves, FO word = start ? OI word : FI word.
  *     The GATED kinds tie the FSM words that the relations of the queue section (zkw_netlist_queue.h, nlq_rel with prev = 1) carry from
  *     cycle to cycle — the word offset / page / timestamp of the next read, the page / offset to write, the rounds left, "the round before
  *     wrote a digest" — at the two ends of an instance, where those relations have no neighbour cycle. Cells [a | b | r | g1 | g2]:
@@ -42,8 +46,7 @@
  *     cells are copies of the last permutation's outputs 0..3.
  * What stays only committed (FREE words): everything the ties below do not name — the `completed` / `padding_round` flags and the
  * write timestamp of the internal FSMs, Keccak's byte offset / length / buffer and the decommitter's round count and length (no registers
- * for them in the queue section), the queue LENGTHS and the far ends of the queues (tail of a popped queue — but for the
- * L1MessagesHasher, whose pops must reach it —, head of the memory queue), all of StorageApplication's words.
+ * for them in the queue section), the queue LENGTHS, all of StorageApplication's words.
  */
 #ifndef ZKW_NETLIST_CLOSED_FORM_H
 #define ZKW_NETLIST_CLOSED_FORM_H
@@ -51,10 +54,11 @@
 #include "zkw_ecrecover_ec_spec.h"
 
 enum { NLCF_OI = 0, NLCF_OO = 1, NLCF_FI = 2, NLCF_FO = 3 };
-enum { NLCF_IN = 1, NLCF_IN_ALWAYS = 2, NLCF_OUT = 3, NLCF_OUT_OO = 4, NLCF_OUT_LIVE = 5, NLCF_IN_GATED = 6, NLCF_OUT_GATED = 7 };
+enum { NLCF_IN = 1, NLCF_IN_ALWAYS = 2, NLCF_OUT = 3, NLCF_OUT_OO = 4, NLCF_OUT_LIVE = 5, NLCF_IN_GATED = 6, NLCF_OUT_GATED = 7, NLCF_DONE = 8 };
 enum { NLCF_REG_QUEUE_BEFORE = 0, NLCF_REG_QUEUE_AFTER = 1, NLCF_REG_STATE_IN = 2, NLCF_REG_STATE_OUT = 3,
-       NLCF_REG_OP_FIRST = 4 /* a cell of an operation of the queue section in cycle 0 */, NLCF_REG_OP_LAST = 5 /* ... in the last cycle */ };
-#define NLCF_MAX_GROUPS 24
+       NLCF_REG_OP_FIRST = 4 /* a cell of an operation of the queue section in cycle 0 */, NLCF_REG_OP_LAST = 5 /* ... in the last cycle */,
+       NLCF_REG_FO_WORD = 6 /* a word of the FSM output (the header block's own cell): what an instance hands on unchanged */ };
+#define NLCF_MAX_GROUPS 32
 #define NLCF_NO_GATE 0xFF
 #define NLCF_GATE_ACTIVE 0xFE /* as a gate: 1 - idle of the cycle's netlist header (the digit is a copy of the idle cell) */
 #define NLCF_CP_WORDS 18
@@ -77,7 +81,7 @@ typedef struct nlcf_desc { uint16_t n[4]; uint16_t n_groups; nlcf_group g[NLCF_M
    write with its registers 102 page to write, 103 offset to write, 104 rounds left; memory-query cells 1 timestamp, 2 page, 3 index). FSM
    words: 0 read_precompile_call, 1 read_words_for_round, 11 timestamp_to_use_for_read, 13 input_page, 14 input_offset = the next word to
    read, 15 output_page, 16 output_offset, 17 num_rounds = rounds left (sha256_round_function.rs:204-246,302-316). */
-static const nlcf_desc NLCF_DESC_SHA256 = {{34, 25, 52, 52}, 22, {
+static const nlcf_desc NLCF_DESC_SHA256 = {{34, 25, 52, 52}, 25, {
     {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, 18}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 21, 39},
     {NLCF_IN, NLCF_REG_STATE_IN, 0, 8, 4, 0, 8, 0, -1, 3},
     {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 18, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 39, -1},
@@ -96,14 +100,16 @@ static const nlcf_desc NLCF_DESC_SHA256 = {{34, 25, 52, 52}, 22, {
     {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 102, 15, -1, 0, 0, 0, 0, 0}, {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 103, 16, -1, 0, 0, 0, 0, 0},
     {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 104, 17, -1, 0, 0, 0, 0, 0},
     {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0} /* read_precompile_call = the last cycle wrote a digest */,
-    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 0, 1, -1, 1, 0, 0, 0, 1} /* read_words_for_round = 1 - that */}};
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 3, 1, 0, 0, 1, 0, 1, -1, 1, 0, 0, 0, 1} /* read_words_for_round = 1 - that */,
+    /* the far ends never move; the last instance leaves the popped queue empty */
+    {NLCF_IN, NLCF_REG_FO_WORD, 0, 1, 0, 0, 4, 22, 4, 22}, {NLCF_IN, NLCF_REG_FO_WORD, 0, 1, 0, 0, 12, 27, 9, 27}, {NLCF_DONE, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 22, -1}}};
 /* CodeDecommitter (3). OI = CodeDecommitterInputData {memory queue 0..24, sorted requests queue 25..49}; OO = the final memory queue
    state; FSM = sha256_inner_state 0..7, hash_to_compare_against 8..15, 5 counters, 3 flags, requests queue 24..48, memory queue 49..73.
    Queue 0 of the section = the requests (popped: head), queue 1 = the memory queue (pushed: tail). */
 /* ... FSM words 16 current_index = the next word to write, 17 current_page, 18 timestamp, 21 state_get_from_queue, 22 state_decommit
    (decommit_code.rs:228-350); operations of NLQ_DESC_CODE_DECOMMITTER: 0 pop, 1 first word (every active cycle), 2 second word (absent in a
    bytecode's last round). */
-static const nlcf_desc NLCF_DESC_CODE_DECOMMITTER = {{50, 25, 74, 74}, 18, {
+static const nlcf_desc NLCF_DESC_CODE_DECOMMITTER = {{50, 25, 74, 74}, 21, {
     {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 12, 0, 25, 24}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 12, 61},
     {NLCF_IN, NLCF_REG_STATE_IN, 0, 8, 4, 0, 8, 0, -1, 0},
     {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 12, 0, 24, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 61, -1},
@@ -117,14 +123,16 @@ static const nlcf_desc NLCF_DESC_CODE_DECOMMITTER = {{50, 25, 74, 74}, 18, {
     {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 2, 0, 0, 1, 3, 16, -1, 1, 0, 2, NLCF_NO_GATE, 0}, {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 1, 3, 0, 0, 1, 3, 16, -1, 1, 0, 1, 2, 0},
     {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 1, 1, 0, 0, 1, 2, 17, -1, 0, 0, 0, 0, 0}, {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 1, 1, 0, 0, 1, 1, 18, -1, 0, 0, 0, 0, 0},
     {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 1, 0, 0, 1, 0, 21, -1, 1, 0, 0, 0, 1} /* state_get_from_queue = 1 - "the last cycle wrote a second word" */,
-    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 1, 0, 0, 1, 0, 22, -1, 0, 0, 0, 0, 0} /* state_decommit = that */}};
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 2, 1, 0, 0, 1, 0, 22, -1, 0, 0, 0, 0, 0} /* state_decommit = that */,
+    /* the far ends never move; the last instance leaves the popped queue empty */
+    {NLCF_IN, NLCF_REG_FO_WORD, 0, 1, 0, 0, 12, 36, 37, 36}, {NLCF_IN, NLCF_REG_FO_WORD, 0, 1, 0, 0, 12, 49, 0, 49}, {NLCF_DONE, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 12, 0, 36, -1}}};
 /* Keccak256RoundFunction (5). OI / OO as type 6; FSM = 4 flags, keccak_internal_state 4..203 ([x][y][8] bytes), 2 timestamps, 6 call
    parameters, the byte buffer 212..403 and its fill 404, log queue 405..413, memory queue 414..438. The netlist's state = the sponge
    state as 200 bytes, lane x + 5 y. */
 /* ... FSM words 0 read_precompile_call, 209 output_page, 210 output_offset (keccak256_round_function.rs:420-441); operations of
    NLQ_DESC_KECCAK256: 0 pop, 1..6 unaligned reads, 7 digest write with its registers 70 page to write, 71 offset to write. (The byte
    offset / length of the input and the byte buffer have no register in the queue section: committed only.) */
-static const nlcf_desc NLCF_DESC_KECCAK256 = {{34, 25, 439, 439}, 13, {
+static const nlcf_desc NLCF_DESC_KECCAK256 = {{34, 25, 439, 439}, 16, {
     {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, 405}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 21, 426},
     {NLCF_IN, NLCF_REG_STATE_IN, 0, 1, 8, 1, 200, 0, -1, 4},
     {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 405, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 426, -1},
@@ -133,13 +141,17 @@ static const nlcf_desc NLCF_DESC_KECCAK256 = {{34, 25, 439, 439}, 13, {
     {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 7, 3, 0, 0, 1, 70, -1, 209, 0, 0, NLCF_GATE_ACTIVE, 0, 0}, {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 7, 3, 0, 0, 1, 71, -1, 210, 0, 0, NLCF_GATE_ACTIVE, 0, 0},
     {NLCF_IN_GATED, NLCF_REG_OP_FIRST, 0, 2, 0, 0, 1, 0, -1, 0, 0, 1, NLCF_GATE_ACTIVE, NLCF_NO_GATE, 0},
     {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 7, 1, 0, 0, 1, 70, 209, -1, 0, 0, 0, 0, 0}, {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 7, 1, 0, 0, 1, 71, 210, -1, 0, 0, 0, 0, 0},
-    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 7, 1, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0} /* read_precompile_call = the last cycle wrote a digest */}};
+    {NLCF_OUT_GATED, NLCF_REG_OP_LAST, 7, 1, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0} /* read_precompile_call = the last cycle wrote a digest */,
+    /* the far ends never move; the last instance leaves the popped queue empty */
+    {NLCF_IN, NLCF_REG_FO_WORD, 0, 1, 0, 0, 4, 409, 4, 409}, {NLCF_IN, NLCF_REG_FO_WORD, 0, 1, 0, 0, 12, 414, 9, 414}, {NLCF_DONE, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 409, -1}}};
 /* ECRecover (7). OI / OO as type 6; FSM = EcrecoverCircuitFSMInputOutput {log queue 0..8, memory queue 9..33} (ecrecover.rs:226-233): a
    cycle is a whole request, the netlist carries nothing between cycles. */
-static const nlcf_desc NLCF_DESC_ECRECOVER = {{34, 25, 34, 34}, 5, {
+static const nlcf_desc NLCF_DESC_ECRECOVER = {{34, 25, 34, 34}, 8, {
     {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 0, 1, 0, 0, 4, 0, 0, 0}, {NLCF_IN, NLCF_REG_QUEUE_BEFORE, 1, 1, 0, 0, 12, 0, 21, 21},
     {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 0, -1}, {NLCF_OUT, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 21, -1},
-    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 21}}};
+    {NLCF_OUT_OO, NLCF_REG_QUEUE_AFTER, 1, 1, 0, 0, 12, 0, 12, 21},
+    /* the far ends never move; the last instance leaves the popped queue empty */
+    {NLCF_IN, NLCF_REG_FO_WORD, 0, 1, 0, 0, 4, 4, 4, 4}, {NLCF_IN, NLCF_REG_FO_WORD, 0, 1, 0, 0, 12, 9, 9, 9}, {NLCF_DONE, NLCF_REG_QUEUE_AFTER, 0, 1, 0, 0, 4, 0, 4, -1}}};
 /* L1MessagesHasher (13). OI = LinearHasherInputData {queue_state: head 0..3, tail 4..7, length 8}, OO = LinearHasherOutputData
    {keccak256_hash: 32 bytes}, no hidden FSM (one instance per block: data_hasher_and_merklizer.rs:34-60). The pops start at the
    queue's head and END AT ITS TAIL — every message of the queue is hashed, none left out (the reference's circuit pops until the queue
@@ -187,7 +199,7 @@ NLQ_HD int32_t nlcf_tie_word(const nlcf_group *g, int32_t word0, uint32_t j) {
     return word0 + (int32_t)(8 * (5 * x + y) + j % 8);
 }
 /* which part the words of a tie's sides belong to */
-NLQ_HD uint32_t nlcf_a_part(const nlcf_group *g) { return g->kind == NLCF_OUT || g->kind == NLCF_OUT_LIVE || g->kind == NLCF_OUT_GATED ? NLCF_FO : g->kind == NLCF_OUT_OO ? NLCF_OO : NLCF_OI; }
+NLQ_HD uint32_t nlcf_a_part(const nlcf_group *g) { return g->kind == NLCF_OUT || g->kind == NLCF_OUT_LIVE || g->kind == NLCF_OUT_GATED || g->kind == NLCF_DONE ? NLCF_FO : g->kind == NLCF_OUT_OO ? NLCF_OO : NLCF_OI; }
 NLQ_HD uint32_t nlcf_b_part(const nlcf_group *g) { return g->kind == NLCF_OUT_OO ? NLCF_FO : NLCF_FI; }
 
 /* ---- P2 blocks: sponge of part p = perms [nlcf_perm0(p), nlcf_perm0(p + 1)), then the compact form's three */

@@ -46,6 +46,7 @@ static uint64_t *reg_cell(const geom *g, uint64_t *trace, const nlcf_group *gr, 
         if (op == NLCF_GATE_ACTIVE) return &trace[(size_t)NL_HDR_IDLE * g->n_rows + (size_t)c * sp->rows_per_cycle]; /* the cycle's idle bit */
         return &trace[(size_t)(cell % g->G) * g->n_rows + NLQ_ROW(sp, g->cycles, nlq_op_row0(g->qd, g->G, op) + cell / g->G, c)];
     }
+    if (gr->reg_kind == NLCF_REG_FO_WORD) return hcell(g, trace, nlcf_word_cell(g->d, NLCF_FO, gr->reg0 + j)); /* the header block's own cell */
     const uint32_t e = (gr->reg0 + j) * gr->n_cells + t;
     const size_t row = NL_BOUNDARY_ROW(sp, g->cycles) + (gr->reg_kind == NLCF_REG_STATE_OUT ? NL_BND_ROWS(sp) : 0) + e / g->G;
     return &trace[(size_t)(e % g->G) * g->n_rows + row];
@@ -160,10 +161,17 @@ int orc_nlcf_standalone(int circuit_type, uint32_t cycles, size_t n_rows, uint64
                 w[NLCF_FO][wa] = gr->negate ? orc_gl_sub(addf, r) : orc_gl_add(r, addf);
                 continue;
             }
+            if (gr->kind == NLCF_DONE) continue; /* (completion = 0 in the standalone form) */
+            if (gr->kind == NLCF_IN && gr->reg_kind == NLCF_REG_FO_WORD) continue; /* second pass below: the FO words are being made here */
             if (gr->kind == NLCF_IN && wb >= 0) w[NLCF_FI][wb] = R;
             else if (gr->kind == NLCF_IN_ALWAYS || gr->kind == NLCF_OUT || gr->kind == NLCF_OUT_LIVE) w[nlcf_a_part(gr)][wa] = R;
             else if (gr->kind == NLCF_OUT_OO && wb < 0) w[NLCF_OO][wa] = R; /* (with an FSM: completion = 0, the word stays zero) */
         }
+    }
+    for (uint32_t gi = 0; gi < d->n_groups; gi++) { /* words an instance hands on unchanged: FI := what the FO pass above made */
+        const nlcf_group *gr = &d->g[gi];
+        if (gr->kind != NLCF_IN || gr->reg_kind != NLCF_REG_FO_WORD) continue;
+        for (uint32_t j = 0; j < gr->count; j++) w[NLCF_FI][gr->b_word0 + j] = w[NLCF_FO][gr->reg0 + j];
     }
     const size_t n[4] = {d->n[0], d->n[1], d->n[2], d->n[3]};
     const int rc = fill_words(circuit_type, cycles, n_rows, trace, flags, w, n);
@@ -221,6 +229,7 @@ uint64_t orc_nlcf_check(int circuit_type, const uint64_t *trace, uint32_t cycles
                 }
                 case NLCF_IN: ok = R == orc_gl_add(bm, orc_gl_mul(start % P, orc_gl_sub(am, bm))); break;
                 case NLCF_OUT_LIVE: ok = completion == 1 || R == am; break;
+                case NLCF_DONE: ok = orc_gl_mul(completion % P, orc_gl_sub(R, am)) == 0; break;
                 case NLCF_OUT_OO: ok = wb >= 0 ? (R == bm && am == orc_gl_mul(completion % P, bm)) : (R == am && am == orc_gl_mul(completion % P, R)); break;
                 default: ok = R == am; break;
             }

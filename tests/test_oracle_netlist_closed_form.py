@@ -242,3 +242,41 @@ def test_decommitter_and_keccak_fsm_words_are_tied_at_both_ends(oracle):
         assert nb == 1 and first[0] == 7, (side, nb, first)
     nb, _ = forged(k, ksynth, kcheck, kcont, "hidden_fsm_input", "input_offset")
     assert nb == 0  # Keccak's byte offset has no register in the queue section: committed (it moves the public input), not tied
+
+
+def test_far_ends_of_the_queues_and_the_empty_queue_at_completion(oracle):
+    """The tail of the popped queue and the head of the memory queue never move (FSM output word = start ? observable word : FSM input
+    word), and the last instance leaves the popped queue empty (its head after the last pop = its tail): a forged far end, or a block
+    declared complete while requests remain, is caught"""
+    cap = 3
+    req, mq = synthetic.precompile_trace(1, 9, seed=3, max_rounds=4)
+    tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+    w = oracle.precompile_build(1, req, tails, mq, cap, np.zeros(1, oracle.QUEUE_STATE12))
+    mid = 2
+
+    def check_forged(mutate):
+        inst = w["instances"].copy()
+        mutate(inst)
+        f = dict(w)
+        f["instances"] = inst
+        return oracle.sha256_round_check(oracle.sha256_round_synthesize(f, mid, cap, N_ROWS), cap)
+
+    def fo_tail(inst):
+        inst["hidden_fsm_output"]["log_queue_state"]["tail"][mid][1] += 1
+
+    def fo_mem_head(inst):
+        inst["hidden_fsm_output"]["memory_queue_state"]["head"][mid][7] += 1
+
+    def fi_tail(inst):
+        inst["hidden_fsm_input"]["log_queue_state"]["tail"][mid][2] += 1
+
+    for m in (fo_tail, fo_mem_head, fi_tail):
+        nb, first = check_forged(m)
+        assert nb == 1 and first[0] == 7, (m.__name__, nb, first)
+
+    def complete_early(inst):  # "this was the block's last instance" while calls remain in the queue
+        inst["completion_flag"][mid] = 1
+        inst["final_memory_state"][mid] = inst["hidden_fsm_output"]["memory_queue_state"][mid]
+
+    nb, first = check_forged(complete_early)
+    assert nb >= 1 and first[0] == 7, (nb, first)  # the head after the last pop is not the queue's tail
