@@ -451,6 +451,8 @@ struct SapWalkJob {
     uint8_t* hdr_bits;        // [cycles]
     uint8_t* free_elems;      // [cycles][97]
     uint8_t* state_before;    // [cycles + 1][65]
+    const uint8_t* idle_root; // [32]: the root an instance WITHOUT walks carries in its idle cycles (its FSM output's current_root_hash: the
+                              // closed-form section ties the root an instance hands on to the state after its last cycle); unused when it has walks
 };
 constexpr u32 SAP_WALK_CYCLES = 257, SAP_WALK_STATE = 65, SAP_WALK_FREE = 97, SAP_WALK_MAX = 1024;
 
@@ -506,7 +508,7 @@ static __global__ __launch_bounds__(256) void k_sap_walk_cycles(const SapWalkJob
         const u32* h = j.walk_hashes + (((u64)s_item[zero ? 0 : wp] * 2 + (zero ? 0 : s_phase[wp])) * 257 + ip) * 8;
         for (u32 k = 0; k < 8; k++) {
             const u32 x = zero ? 0u : h[k];
-            for (u32 b = 0; b < 4; b++) st[4 * k + b] = (uint8_t)(x >> (8 * b));
+            for (u32 b = 0; b < 4; b++) st[4 * k + b] = active == 0 && j.idle_root ? j.idle_root[4 * k + b] : (uint8_t)(x >> (8 * b));
         }
     }
     if (c == cycles) return;

@@ -1511,7 +1511,9 @@ extern "C" int zkw_storage_application_synthesize(zkw_ctx* ctx, zkw_storage_appl
     ZKW_TRY(nl_synthesize_with(ctx, 10, [&](std::vector<NlPrepJob>& prep) {
         std::vector<SapWalkJob> jobs(prep.size());
         for (size_t k = 0; k < prep.size(); k++)
-            jobs[k] = SapWalkJob{w->items, w->keys, w->paths, w->walk_hashes, w->n ? prep[k].first_round : 0, w->n ? prep[k].n_active : 0, prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
+            jobs[k] = SapWalkJob{w->items, w->keys, w->paths, w->walk_hashes, w->n ? prep[k].first_round : 0, w->n ? prep[k].n_active : 0, prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before,
+                                 reinterpret_cast<const uint8_t*>(w->instances + first_instance + k) + offsetof(zkw_storage_application_instance, hidden_fsm_output) +
+                                     offsetof(zkw_storage_application_fsm, current_root_hash)};
         SapWalkJob* d_jobs = nullptr;
         ZKW_TRY(ctx->upload("sap_walk_jobs", jobs, &d_jobs));
         { Prof _p(ctx, "k_sap_walk_cycles"); hipLaunchKernelGGL(k_sap_walk_cycles, dim3((capacity * SAP_WALK_CYCLES + 256) / 256, (unsigned)jobs.size()), dim3(256), 0, ctx->stream, d_jobs, capacity); }

@@ -162,9 +162,11 @@ static const nlcf_desc NLCF_DESC_LINEAR_HASHER = {{9, 32, 0, 0}, 3, {
     {NLCF_OUT_OO, NLCF_REG_STATE_OUT, 0, 1, 8, 0, 32, 0, 0, -1}}};
 /* StorageApplication (10). OI = {shard, initial_root_hash 32 bytes, enumeration counter 2, log queue 9} = 44, OO = {new_root_hash 32,
    counter 2, state_diffs_keccak256_hash 32} = 66, FSM = {root hash 32, counter 2, log queue 9, Keccak accumulator 200} = 243
-   (storage_application.rs:286-336). The trace holds the Blake2s walks only (no queue side, docs/KERNELS.md 3.17): no ties — the words are
-   committed, the commitments and the public input derived in-trace. */
-static const nlcf_desc NLCF_DESC_STORAGE_APPLICATION = {{44, 66, 243, 243}, 0, {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+   (storage_application.rs:286-336). The trace holds the Blake2s walks only (no queue side, docs/KERNELS.md 3.17): the ROOT an instance
+   hands on is the running hash after its last cycle (the root its last walk computed; an instance without walks carries its root through
+   its idle cycles), and the block's new_root_hash is that of the last instance; the other words are committed, not tied. */
+static const nlcf_desc NLCF_DESC_STORAGE_APPLICATION = {{44, 66, 243, 243}, 2, {
+    {NLCF_OUT, NLCF_REG_STATE_OUT, 0, 1, 8, 0, 32, 0, 0, -1}, {NLCF_OUT_OO, NLCF_REG_STATE_OUT, 0, 1, 8, 0, 32, 0, 0, 0}}};
 
 #if defined(__GNUC__)
 #pragma GCC diagnostic pop

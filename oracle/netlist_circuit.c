@@ -496,11 +496,13 @@ void orc_nl_slots_per_cycle(int circuit_type, uint32_t *out) {
 void orc_blake2s256(const uint8_t *msg, size_t len, uint8_t out[32]);
 int orc_storage_application_synthesize(const zkw_log_query *items, size_t n_items, const uint8_t *keys, const uint8_t *paths,
                                        const uint64_t *read_indexes, uint64_t next_enumeration_index, uint32_t capacity,
-                                       const uint64_t pi[4], size_t n_rows, uint64_t *trace) {
+                                       const uint64_t pi[4], size_t n_rows, uint64_t *trace, const uint8_t *idle_root /* [32] or NULL: what an instance
+                                       without walks carries (its current root: the closed-form section ties the root handed on to the last state) */) {
     const uint32_t cycles = capacity * SA_CYCLES_PER_WALK;
     uint8_t *hdr = calloc(cycles, 1), *fr = calloc((size_t)cycles * SA_FREE_PER_CYCLE + 1, 1), *st = calloc((size_t)(cycles + 1) * SA_STATE, 1);
     uint32_t c = 0;
     int rc = 0;
+    if (n_items == 0 && idle_root) memcpy(st, idle_root, 32);
     for (size_t i = 0; i < n_items && rc == 0; i++) {
         const zkw_log_query *q = &items[i];
         const uint8_t *key = keys + 32 * i;

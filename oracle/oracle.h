@@ -276,7 +276,7 @@ int orc_code_decommitter_round_synthesize(const uint8_t state_in[32], const zkw_
 uint64_t orc_code_decommitter_round_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 int orc_storage_application_synthesize(const zkw_log_query *items, size_t n_items, const uint8_t *keys, const uint8_t *paths,
                                        const uint64_t *read_indexes, uint64_t next_enumeration_index, uint32_t capacity,
-                                       const uint64_t pi[4], size_t n_rows, uint64_t *trace);
+                                       const uint64_t pi[4], size_t n_rows, uint64_t *trace, const uint8_t *idle_root);
 uint64_t orc_storage_application_check(const uint64_t *trace, uint32_t capacity, size_t n_rows, uint64_t *first_bad);
 size_t orc_linear_hasher_rounds(const zkw_log_query *q, size_t n, zkw_keccak_round_record *records);
 

@@ -1129,7 +1129,8 @@ def storage_application_synthesize(build_out, queries, instance_index, capacity,
     f = lib().orc_storage_application_synthesize
     f.restype = C.c_int
     rc = f(_p(q) if n else None, C.c_size_t(n), _p(keys) if n else None, _p(paths) if n else None, _p(idx) if n else None,
-           C.c_uint64(next_index), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace))
+           C.c_uint64(next_index), C.c_uint32(capacity), _p(pi), C.c_size_t(n_rows), _p(trace),
+           _p(np.ascontiguousarray(inst["hidden_fsm_output"]["current_root_hash"], dtype=np.uint8)))  # (an instance without walks carries its root)
     if rc != 0:
         raise RuntimeError(f"orc_storage_application_synthesize failed: {rc}")
     return _nlcf_overlay(10, trace, build_out["instances"], instance_index, capacity * SA_CYCLES_PER_WALK, STORAGE_APPLICATION_INSTANCE)

@@ -280,3 +280,30 @@ def test_far_ends_of_the_queues_and_the_empty_queue_at_completion(oracle):
 
     nb, first = check_forged(complete_early)
     assert nb >= 1 and first[0] == 7, (nb, first)  # the head after the last pop is not the queue's tail
+
+
+def test_storage_application_root_is_the_last_walks_root(oracle):
+    """type 10: the root an instance hands on (FSM output) and the block's new_root_hash (observable output of the last instance) are the
+    running hash after the instance's last cycle — the root its last walk computed; an instance without walks carries its root through
+    its idle cycles"""
+    from sap_case import storage_application_case
+    sq, tails, tree, _idx, _paths = storage_application_case(oracle, 7, seed=9)
+    sap = oracle.storage_application_build(tree, sq, tails, 3)
+    n = sap["instances"].size
+    assert n >= 3
+    for i, field in ((1, ("hidden_fsm_output", "current_root_hash")), (n - 1, ("new_root_hash",))):
+        inst = sap["instances"].copy()
+        rec = inst[field[0]] if len(field) == 1 else inst[field[0]][field[1]]
+        rec[i][5] ^= 1
+        f = dict(sap)
+        f["instances"] = inst
+        nb, first = oracle.storage_application_check(oracle.storage_application_synthesize(f, sq, i, 3, N_ROWS), 3)
+        # (everything downstream recomputed: only the ties object — the FSM-output root is named by two of them: "the state is this root" and
+        # "the block's new root is this root when the instance completes")
+        assert nb == (2 if len(field) == 2 else 1) and first[0] == 7, (field, nb, first)
+    empty_q, empty_t, tree0, _i, _p = storage_application_case(oracle, 0, seed=9)
+    e = oracle.storage_application_build(tree0, empty_q, empty_t, 3)
+    assert e["instances"].size == 1 and int(e["instances"]["num_items"][0]) == 0
+    t = oracle.storage_application_synthesize(e, empty_q, 0, 3, N_ROWS)
+    assert oracle.storage_application_check(t, 3) == (0, (0, 0, 0))
+    assert e["instances"]["new_root_hash"][0].any()  # the dummy instance hands the initial root on: it rides in the idle cycles' state

@@ -128,7 +128,7 @@ def test_tampering_is_caught(oracle, case, spec):
     grow, gcol = st.gate_pos[gi]
     nk = len(st.gates[gi][0])
     cells = {"lookup_out": ((G + 2, base + 1), 1), "lookup_in_range": ((G, base + 1), 1), "reset": ((0, base), 2),  # (the 255 * reset gate copies the bit: the copy (2) is reported before the header (3)) "mask0": ((2, base), 3),
-             "hdr_lookup": ((G + 1, base), 6), "mult": ((g["cols"] - 1, 7), 5), "bnd_out": ((3, 5 * WALK * rpc + 2), 4),
+             "hdr_lookup": ((G + 1, base), 6), "mult": ((g["cols"] - 1, 7), 5), "bnd_out": ((3, 5 * WALK * rpc + 2), 2),  # (a root byte after the last cycle: the closed-form tie to the FSM output objects first, kind 2, then the boundary rule, 4)
              "below": ((G // 2, oracle.nlcf_geometry(10, 5 * WALK)["rows_used"] + 3), 6), "gate_known": ((gcol, base + grow), 2), "gate_digit": ((gcol + nk, base + grow), 2)}
     for name, ((col, row), kind) in cells.items():
         bad = t.copy()
