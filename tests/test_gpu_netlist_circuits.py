@@ -362,3 +362,67 @@ def test_type_dispatching_entry_points(ctx, oracle):
     with pytest.raises(native.ZkwError):
         ctx.synthesize(13, C.addressof(lw), t, 2, 2, 0)  # queue 3 of 3
     t.free()
+
+
+def test_forged_fsm_words_get_the_oracles_verdict(ctx, oracle):
+    """the closed-form section's gated ties (docs/KERNELS.md 3.22): an FSM word forged in the instance record with the whole section recomputed
+    (the oracle's fill) is ONE violation of kind 7 on the oracle — the GPU checker must say the same about the same trace (types 6, 3, 5, 10)"""
+    import ctypes
+
+    from era_zkevm_test_harness_amd import native
+    from oracle import block as ob
+    from sap_case import storage_application_case
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+    def verdicts(cols, check, ocheck, trace, cap, ocap=None):
+        t = native.Trace(ctx, N_ROWS, 1, n_cols=cols)
+        ctx.synchronize()
+        assert hip.hipMemcpy(t.device_ptr(0), trace.ctypes.data, trace.nbytes, 1) == 0
+        got, want = check(t, 0, cap), ocheck(trace, cap if ocap is None else ocap)
+        t.free()
+        return got, want
+
+    def forge(w, i, path, flip=False):
+        inst = w["instances"].copy()
+        rec = inst
+        for p in path[:-1]:
+            rec = rec[p]
+        rec[path[-1]][i] = rec[path[-1]][i] ^ 1 if flip else rec[path[-1]][i] + 1
+        f = dict(w)
+        f["instances"] = inst
+        return f
+
+    for kind, ct, cap, cols, synth, check, ocheck, fields in (
+            (1, 6, 3, native.SC_COLS, oracle.sha256_round_synthesize, ctx.check_if_satisfied_sha256_round_function, oracle.sha256_round_check,
+             [("hidden_fsm_input", "input_offset"), ("hidden_fsm_output", "num_rounds"), ("hidden_fsm_input", "output_page")]),
+            (0, 5, 2, native.KC_COLS, oracle.keccak_round_synthesize, ctx.check_if_satisfied_keccak_round_function, oracle.keccak_round_check,
+             [("hidden_fsm_input", "output_offset"), ("hidden_fsm_output", "output_page")])):
+        req, mq = synthetic.precompile_trace(kind, 9, seed=3, max_rounds=4)
+        tails = oracle.queue_push_chain_log(oracle.encode_log_queries(req))[1]
+        w = oracle.precompile_build(kind, req, tails, mq, cap, np.zeros(1, native.QUEUE_STATE12))
+        n = w["instances"].size
+        cont = next(i for i in range(1, n - 1) if int(synth(w, i, cap, N_ROWS)[oracle.nlq_cell(ct, cap, 0, 0)]) == 0)
+        for path in fields:
+            got, want = verdicts(cols, check, ocheck, synth(forge(w, cont, path), cont, cap, N_ROWS), cap)
+            assert want[0] == 1 and want[1][0] == 7 and got == want, (ct, path, got, want)
+        got, want = verdicts(cols, check, ocheck, synth(forge(w, cont, ("hidden_fsm_output", "log_queue_state", "tail"), flip=False), cont, cap, N_ROWS), cap)
+        assert want[0] >= 1 and got == want, (ct, "far end", got, want)
+    a = ob.create_artifacts_after_vm(synthetic.block_after_vm(seed=2), {ob.CODE_DECOMMITTER: 2})
+    w = a["witnesses"]["code_decommitter"]
+    n = w["instances"].size
+    cont = next(i for i in range(1, n - 1) if int(oracle.code_decommitter_synthesize(w, i, 2, N_ROWS)[oracle.nlq_cell(3, 2, 0, 0)]) == 0)
+    for path in (("hidden_fsm_input", "current_index"), ("hidden_fsm_output", "timestamp")):
+        got, want = verdicts(native.DC_COLS, ctx.check_if_satisfied_code_decommitter, oracle.code_decommitter_check,
+                             oracle.code_decommitter_synthesize(forge(w, cont, path), cont, 2, N_ROWS), 2)
+        assert want[0] == 1 and want[1][0] == 7 and got == want, (3, path, got, want)
+    sq, stails, tree, _idx, _paths = storage_application_case(oracle, 7, seed=9)
+    sap = oracle.storage_application_build(tree, sq, stails, 3)
+    inst = sap["instances"].copy()
+    inst["hidden_fsm_output"]["current_root_hash"][1][5] ^= 1
+    f = dict(sap)
+    f["instances"] = inst
+    got, want = verdicts(native.SA_COLS, ctx.check_if_satisfied_storage_application, oracle.storage_application_check,
+                         oracle.storage_application_synthesize(f, sq, 1, 3, N_ROWS), 3)
+    assert want[0] == 2 and want[1][0] == 7 and got == want, (10, got, want)
