@@ -507,6 +507,22 @@ struct ChainService {
             return rc;
         }
     }
+    // a context that has nothing to hand over for stage `key` (no chains there, or chains short enough to run on its own stream): it still counts
+    // as one of the `expected` submitters, or the blocks that do have chains would wait out the long window (measured: 100 ms per block in the
+    // decommit sorter's prepare stage, where three of four synthetic blocks took the short path)
+    void skip(int key) {
+        if (key == 0) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (expected <= 1) return;
+            std::shared_ptr<Batch>& slot = open[key];
+            const auto now = std::chrono::steady_clock::now();
+            if (!slot) { slot = std::make_shared<Batch>(); slot->key = key; slot->open_since = now; }
+            slot->waiters++;
+            slot->last_arrival = now;
+        }
+        cv_work.notify_one();
+    }
     void run() {
         (void)hipSetDevice(device);
         hipStream_t st = nullptr, st_log = nullptr;  // st_log: only for a batch that carries both kinds (unkeyed jobs): they run side by side
@@ -544,7 +560,8 @@ struct ChainService {
             if (mixed && !st_log && hipStreamCreateWithPriority(&st_log, hipStreamNonBlocking, hi) != hipSuccess) st_log = nullptr;
             hipStream_t sl = mixed ? st_log : st;  // the log-queue chains' stream
             if (!st || !sl) { rc = ZKW_ERR_HIP; err = "chain service: no stream"; }
-            if (rc == ZKW_OK && cap < bytes) {  // grow-only; the outgrown pair goes back to the allocation cache (no hipFree stall)
+            const bool nothing = b->full.empty() && b->log.empty();  // every submitter of the stage skipped it
+            if (rc == ZKW_OK && !nothing && cap < bytes) {  // grow-only; the outgrown pair goes back to the allocation cache (no hipFree stall)
                 const size_t want = bytes * 2;
                 void *np = nullptr, *nd = nullptr;
                 fail_hip(pin_malloc(&np, want), "hipHostMalloc");
@@ -557,7 +574,7 @@ struct ChainService {
                     pin_free(np);
                 }
             }
-            if (rc == ZKW_OK) {
+            if (rc == ZKW_OK && !nothing) {
                 char* hp = static_cast<char*>(pin);
                 char* dp = static_cast<char*>(dev);
                 const size_t off_log = (b->full.size() * sizeof(ChainJob) + 127) & ~(size_t)127;
@@ -666,13 +683,14 @@ int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) {
 // concurrent chains), so throughput comes from giving each wave its own SIMD: up to 1024 waves.
 int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
     const int key = ctx->chain_service ? ctx->next_chain_key() : 0;  // (counted even when there is nothing to hash: equal stages of all blocks keep equal keys)
-    if (jobs.empty()) return ZKW_OK;
+    if (jobs.empty()) { if (ctx->chain_service) chain_service_of(ctx->device)->skip(key); return ZKW_OK; }
     // the service is for chains whose LATENCY matters (a launch costs what its longest chain costs): a handful of items per chain — the
     // recursion queues of a block, eleven chains of a few records — is cheaper on the context's own stream than a rendezvous with every
     // other block in flight (measured at 96 blocks: that last stage waited 0.2 - 0.3 s for the slowest block)
     u64 longest = 0;
     for (const ChainJob& j : jobs) longest = std::max<u64>(longest, j.n);
     if (ctx->chain_service && longest > 64) return chain_service_run(ctx, &jobs, nullptr, "k_chain_full", key);
+    if (ctx->chain_service) chain_service_of(ctx->device)->skip(key);
     ChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("chain_jobs", jobs, &d_jobs));
     int n_jobs = (int)jobs.size();
@@ -881,7 +899,7 @@ extern "C" int zkw_encode_decommit_queries(zkw_ctx* ctx, const zkw_decommit_quer
 // device-level: rounds 1-2 of every item in parallel, then one serial permutation per item and queue
 int dev_log_chains(zkw_ctx* ctx, const u64* d_enc, size_t total, std::vector<LogChainJob>& jobs) {
     const int key = ctx->chain_service ? ctx->next_chain_key() : 0;
-    if (total == 0 || jobs.empty()) return ZKW_OK;
+    if (total == 0 || jobs.empty()) { if (ctx->chain_service) chain_service_of(ctx->device)->skip(key); return ZKW_OK; }
     u64* d_pre = nullptr;
     ZKW_TRY(ctx->scratch_t<u64>("log_pre", total * 4, &d_pre));
     { Prof _p(ctx, "k_log_prehash"); hipLaunchKernelGGL(k_log_prehash, dim3(blocks_for(total, 128)), dim3(128), 0, ctx->stream, d_enc, total, d_pre); }

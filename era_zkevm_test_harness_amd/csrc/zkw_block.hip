@@ -319,11 +319,12 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
     std::vector<zkw_decommit_query> dedup;
     {
         Timed t(B, "decommit_sorter.prepare");
-        ST_TRY(B->upload(X_MAIN, &d_dq, in->decommit_queries, in->n_decommit_queries));
-        ST_ZKW(zkw_decommit_sorter_prepare(B->ctx[C_DEC], d_dq, in->n_decommit_queries, B->cap[T_DEC], nullptr, &B->dec));
+        { Timed t1(B, "decommit_sorter.prepare.upload"); ST_TRY(B->upload(X_MAIN, &d_dq, in->decommit_queries, in->n_decommit_queries)); }
+        { Timed t2(B, "decommit_sorter.prepare.kernels"); ST_ZKW(zkw_decommit_sorter_prepare(B->ctx[C_DEC], d_dq, in->n_decommit_queries, B->cap[T_DEC], nullptr, &B->dec)); }
         dedup.resize(zkw_decommit_witness_num_dedup(B->dec));
+        { Timed t3(B, "decommit_sorter.prepare.readback");
         ST_TRY(B->xf[X_MAIN].d2h(dedup.data(), zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_QUERIES),
-                         dedup.size() * sizeof(zkw_decommit_query)));
+                         dedup.size() * sizeof(zkw_decommit_query))); }
     }
     auto f_dec = std::async(std::launch::async, dec_finish_branch, B);  // its three chains run next to everything below
 
