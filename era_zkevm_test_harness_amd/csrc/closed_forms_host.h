@@ -9,7 +9,7 @@ template <class T>
 static int closed_form_public_inputs(zkw_ctx* ctx, const typename T::Inst* d_inst, size_t ni, u64** cf_pi) {
     if (!*cf_pi) HIP_TRY(dev_malloc((void**)cf_pi, ni * (COMPACT_FORM_LEN + 4) * sizeof(u64)));
     u64 *compact = *cf_pi, *pis = *cf_pi + COMPACT_FORM_LEN * ni;
-    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3(blocks_for(4 * ni, CfLanes<T>::value)), dim3(CfLanes<T>::value), 0, ctx->stream, d_inst, ni, compact); }
+    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3((unsigned)ni), dim3(64), 0, ctx->stream, d_inst, ni, compact); }
     ZKW_TRY(launch_check("k_closed_form_commitments"));
     { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, compact, ni, (u32)COMPACT_FORM_LEN, pis); }
     return launch_check("k_commit_encodings");
@@ -24,7 +24,7 @@ static int closed_form_from_records(zkw_ctx* ctx, const void* instances, size_t 
     u64 *d_cf = nullptr, *d_pi = nullptr;
     ZKW_TRY(ctx->out("cf_compact", reinterpret_cast<u64*>(compact), n * COMPACT_FORM_LEN, &d_cf));
     ZKW_TRY(ctx->out("cf_pi", reinterpret_cast<u64*>(public_inputs), n * 4, &d_pi));
-    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3(blocks_for(4 * n, CfLanes<T>::value)), dim3(CfLanes<T>::value), 0, ctx->stream, d_inst, n, d_cf); }
+    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3((unsigned)n), dim3(64), 0, ctx->stream, d_inst, n, d_cf); }
     ZKW_TRY(launch_check("k_closed_form_commitments"));
     { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, d_cf, n, (u32)COMPACT_FORM_LEN, d_pi); }
     ZKW_TRY(launch_check("k_commit_encodings"));

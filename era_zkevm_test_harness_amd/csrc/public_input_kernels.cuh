@@ -356,39 +356,55 @@ struct CfLinearHasher {
     __device__ static NoFsm fsm_out(const Inst&) { return NoFsm{}; }
 };
 
-// lanes per workgroup: the encoding buffers are slices of LDS (64 KB per workgroup), so the long encodings run narrower
+// One wave per instance: DPP row p (16 lanes) = part p of the closed form (observable input, observable output, FSM input, FSM output).
+// Lane 0 of a row runs the part's encoder into its LDS slice (a run-time-indexed per-lane array would live in scratch memory, DESIGN.md
+// 3.14), then the row absorbs the words eight at a time through the cooperative permutation (p2::Coop: a lane per state element, linear
+// layers by DPP) — commit_variable_length_encodable_item: overwrite mode from (0, .., 0, n), the last chunk zero padded, the first four
+// state words. Round 5: was one LANE per part running the lane-serial permutation — 55 dependent permutations of ~13 us for a Keccak FSM,
+// 0.73 ms per launch on ONE wave, and with 96 blocks in flight these single-wave kernels are what the hardware queues spend their time
+// on (docs/KERNELS.md 3.14); the row form is ~3 x shorter.
 template <class T> struct CfLanes { static constexpr int value = 64; };
-template <> struct CfLanes<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>> { static constexpr int value = 16; };
-template <> struct CfLanes<CfStorageApplication> { static constexpr int value = 32; };
-
 template <class T>
-static __global__ __launch_bounds__(CfLanes<T>::value) void k_closed_form_commitments(const typename T::Inst* __restrict__ inst, size_t n,
-                                                                               u64* __restrict__ compact) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t i = t >> 2;
-    const int part = (int)(t & 3);
+static __global__ __launch_bounds__(64) void k_closed_form_commitments(const typename T::Inst* __restrict__ inst, size_t n, u64* __restrict__ compact) {
+    const size_t i = blockIdx.x;
     if (i >= n) return;
+    __shared__ u64 sh_buf[4][T::MAXLEN];
+    __shared__ int sh_m[4];
+    const u32 lane = threadIdx.x & 63, g = lane & 15, part = lane >> 4;
     u64* cf = compact + COMPACT_FORM_LEN * i;
-    // in LDS, one slice per lane: a run-time-indexed per-lane array would live in scratch memory
-    __shared__ u64 sh_buf[CfLanes<T>::value * T::MAXLEN];
-    u64* buf = sh_buf + threadIdx.x * T::MAXLEN;
-    u64 c[4];
-    int m;
-    if (part == 0) {  // the observable input is the one of the block's first instance (postprocessing/mod.rs:358-364)
-        size_t j = i;
-        while (j > 0 && !inst[j].start_flag) j--;
-        m = T::input(inst[j], buf);
-    } else if (part == 1) {
-        cf[0] = inst[i].start_flag ? 1 : 0;
-        cf[1] = inst[i].completion_flag ? 1 : 0;
-        m = T::output(inst[i], buf);
-    } else {
-        m = T::fsm(part == 2 ? T::fsm_in(inst[i]) : T::fsm_out(inst[i]), buf);
+    if (g == 0) {
+        int m;
+        if (part == 0) {  // the observable input is the one of the block's first instance (postprocessing/mod.rs:358-364)
+            size_t j = i;
+            while (j > 0 && !inst[j].start_flag) j--;
+            m = T::input(inst[j], sh_buf[0]);
+        } else if (part == 1) {
+            cf[0] = inst[i].start_flag ? 1 : 0;
+            cf[1] = inst[i].completion_flag ? 1 : 0;
+            m = T::output(inst[i], sh_buf[1]);
+        } else {
+            m = T::fsm(part == 2 ? T::fsm_in(inst[i]) : T::fsm_out(inst[i]), sh_buf[part]);
+        }
+        if (m > T::MAXLEN) __builtin_trap();  // an encoder outgrew its slice: fail loudly instead of hashing a neighbour's words
+        sh_m[part] = m;
     }
-    if (m > T::MAXLEN) __builtin_trap();  // an encoder outgrew its slice: fail loudly instead of hashing a neighbour's words
-    commit_var_length(buf, m, c);
+    __syncthreads();
+    const u32 m = (u32)sh_m[part];
+    u32 most = 0;
+    for (int p = 0; p < 4; p++) most = max(most, ((u32)sh_m[p] + 7) / 8);
+    p2::Coop co;
+    co.init((int)g);
+    u64 x = g == 11 ? (u64)m : 0;  // apply_length_specialization
+    const u32 perms = (m + 7) / 8;
+    for (u32 q = 0; q < most; q++) {  // a uniform trip count: the DPP steps are wave-wide; a row that has run out keeps its state
+        const bool on = q < perms;
+        u64 in = x;
+        if (g < 8) in = 8 * q + g < m ? sh_buf[part][8 * q + g] : 0;  // AbsorptionModeOverwrite
+        const u64 y = co.permute(on ? in : 0);
+        if (on) x = y;
+    }
     const int at = part == 0 ? 2 : (part == 1 ? 6 : (part == 2 ? 10 : 14));
-    for (int k = 0; k < 4; k++) cf[at + k] = c[k];
+    if (g < 4) cf[at + g] = gl::canon(x);  // (an empty encoding: no permutation, the zero state's first words)
 }
 
 static __global__ __launch_bounds__(64) void k_encode_recursion(u64 circuit_type, const u64* __restrict__ pi, size_t n,

@@ -1582,9 +1582,8 @@ extern "C" int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx* ctx, const
     ZKW_TRY(ctx->scratch_t<u64>("lh_cf", COMPACT_FORM_LEN * n_queues, &d_cf));
     ZKW_TRY(ctx->scratch_t<u64>("lh_pi", 4 * n_queues, &d_pi));
     {
-        constexpr int lanes = CfLanes<CfLinearHasher>::value;
         Prof _p(ctx, "k_closed_form_commitments");
-        hipLaunchKernelGGL((k_closed_form_commitments<CfLinearHasher>), dim3(blocks_for(4 * n_queues, lanes)), dim3(lanes), 0, ctx->stream, d_rec, n_queues, d_cf);
+        hipLaunchKernelGGL((k_closed_form_commitments<CfLinearHasher>), dim3((unsigned)n_queues), dim3(64), 0, ctx->stream, d_rec, n_queues, d_cf);
     }
     ZKW_TRY(launch_check("k_closed_form_commitments"));
     { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n_queues, 64)), dim3(64), 0, ctx->stream, d_cf, n_queues, (u32)COMPACT_FORM_LEN, d_pi); }
