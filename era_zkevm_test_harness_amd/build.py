@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libzkw.so")
 SOURCES = ["zkw_api.hip", "zkw_sorters.hip", "zkw_precompiles.hip", "zkw_setup.hip", "zkw_block.hip", "zkw_recursion.hip", "zkw_comm.hip", "zkw_vm_trace.hip",
-           "zkw_dispatch.hip", "zkw_commit.hip", "sort.hip"]
+           "zkw_dispatch.hip", "zkw_commit.hip", "zkw_batch.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("ZKW_PROBE_BUILD"):  # measurement knobs that produce invalid traces (ZKW_NL_PROBE); never in the default library

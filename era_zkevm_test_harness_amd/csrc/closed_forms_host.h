@@ -9,9 +9,9 @@ template <class T>
 static int closed_form_public_inputs(zkw_ctx* ctx, const typename T::Inst* d_inst, size_t ni, u64** cf_pi) {
     if (!*cf_pi) HIP_TRY(dev_malloc((void**)cf_pi, ni * (COMPACT_FORM_LEN + 4) * sizeof(u64)));
     u64 *compact = *cf_pi, *pis = *cf_pi + COMPACT_FORM_LEN * ni;
-    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3((unsigned)ni), dim3(64), 0, ctx->stream, d_inst, ni, compact); }
+    { Prof _p(ctx, "k_closed_form_commitments"); ZKW_LAUNCH_T(ctx, (k_closed_form_commitments<T>), "k_closed_form_commitments", (unsigned)ni, 64, d_inst, ni, compact); }
     ZKW_TRY(launch_check("k_closed_form_commitments"));
-    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, compact, ni, (u32)COMPACT_FORM_LEN, pis); }
+    { Prof _p(ctx, "k_commit_encodings"); ZKW_LAUNCH(ctx, k_commit_encodings, blocks_for(ni, 64), 64, compact, ni, (u32)COMPACT_FORM_LEN, pis); }
     return launch_check("k_commit_encodings");
 }
 
@@ -24,9 +24,9 @@ static int closed_form_from_records(zkw_ctx* ctx, const void* instances, size_t 
     u64 *d_cf = nullptr, *d_pi = nullptr;
     ZKW_TRY(ctx->out("cf_compact", reinterpret_cast<u64*>(compact), n * COMPACT_FORM_LEN, &d_cf));
     ZKW_TRY(ctx->out("cf_pi", reinterpret_cast<u64*>(public_inputs), n * 4, &d_pi));
-    { Prof _p(ctx, "k_closed_form_commitments"); hipLaunchKernelGGL((k_closed_form_commitments<T>), dim3((unsigned)n), dim3(64), 0, ctx->stream, d_inst, n, d_cf); }
+    { Prof _p(ctx, "k_closed_form_commitments"); ZKW_LAUNCH_T(ctx, (k_closed_form_commitments<T>), "k_closed_form_commitments", (unsigned)n, 64, d_inst, n, d_cf); }
     ZKW_TRY(launch_check("k_closed_form_commitments"));
-    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, d_cf, n, (u32)COMPACT_FORM_LEN, d_pi); }
+    { Prof _p(ctx, "k_commit_encodings"); ZKW_LAUNCH(ctx, k_commit_encodings, blocks_for(n, 64), 64, d_cf, n, (u32)COMPACT_FORM_LEN, d_pi); }
     ZKW_TRY(launch_check("k_commit_encodings"));
     ZKW_TRY(ctx->finish_out(reinterpret_cast<u64*>(compact), d_cf, n * COMPACT_FORM_LEN));
     ZKW_TRY(ctx->finish_out(reinterpret_cast<u64*>(public_inputs), d_pi, n * 4));

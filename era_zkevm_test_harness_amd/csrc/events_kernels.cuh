@@ -10,9 +10,9 @@
 
 namespace zkw {
 
-static __global__ void k_events_sort_keys(const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ key,
+static __device__ void k_events_sort_keys(const VB& vb, const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ key,
                                    u32* __restrict__ iota) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     key[i] = ((u64)q[i].timestamp << 1) | (q[i].rollback ? 1 : 0);  // rollback sorts after its forward twin
     iota[i] = (u32)i;
@@ -36,10 +36,10 @@ __device__ __forceinline__ void store_enc20(u64* dst, const u64 e[20]) {
     for (int k = 0; k < 10; k++) o[k] = make_ulonglong2(e[2 * k], e[2 * k + 1]);
 }
 
-static __global__ __launch_bounds__(256) void k_log_gather_encode(const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
+static __device__ void k_log_gather_encode(const VB& vb, const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
                                                            size_t n, zkw_log_query* __restrict__ sorted_q,
                                                            u64* __restrict__ sorted_enc) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     zkw_log_query m;
     load_log(q + perm[i], m);
@@ -65,11 +65,11 @@ struct EventsKeptFlag {
 // every record on its own, given the tiled prefix count of the kept flags (prefix[k] = kept among [0, k)): the reference's asserts
 // (:344-356, :512-533), the inclusive count, and the compaction of the kept items into normalised result records (:541-553) with
 // their encodings. totals[1] (violations) is zeroed by the caller; the last record's thread writes totals[0] = n_result.
-static __global__ __launch_bounds__(256) void k_events_dedup(const zkw_log_query* __restrict__ sorted_q, size_t n, const u32* __restrict__ prefix,
+static __device__ void k_events_dedup(const VB& vb, const zkw_log_query* __restrict__ sorted_q, size_t n, const u32* __restrict__ prefix,
                                                       u32* __restrict__ kept_count /* [n] inclusive */,
                                                       zkw_log_query* __restrict__ result_q, u64* __restrict__ result_enc,
                                                       u32* __restrict__ totals /* [2]: n_result, violations */) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     zkw_log_query me;
     load_log(sorted_q + i, me);
@@ -127,10 +127,10 @@ __device__ __forceinline__ void qs4(zkw_queue_state4& s, const u64* head, const 
     s._pad = 0;
 }
 
-static __global__ void k_events_instances(const EventsBlock* __restrict__ blk) {
+static __device__ void k_events_instances(const VB& vb, const EventsBlock* __restrict__ blk) {
     const EventsBlock& b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
-    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;
     if (idx >= n_inst) return;
     zkw_events_sorter_instance& w = b.instances[idx];  // filled in place: a local copy would live in scratch memory
     memset(&w, 0, sizeof w);

@@ -87,8 +87,8 @@ __device__ __forceinline__ void word_be_bytes(const u32* limbs, uint8_t out[32])
 }
 
 // one lane per request
-static __global__ __launch_bounds__(64) void k_precompile_walk(PrecompileJob job) {
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_precompile_walk(const VB& vb, PrecompileJob job) {
+    const u64 r = (u64)vb.x * blockDim.x + threadIdx.x;
     if (r >= job.n_requests) return;
     const zkw_log_query request = job.requests[r];
     PrecompileAbi abi = precompile_abi_in_log(request);
@@ -267,9 +267,9 @@ struct PrecompileBlock {
     u32 capacity;
 };
 
-static __global__ void k_precompile_instances(const PrecompileBlock* __restrict__ blk) {
+static __device__ void k_precompile_instances(const VB& vb, const PrecompileBlock* __restrict__ blk) {
     const PrecompileBlock& b = *blk;
-    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;
     if (idx >= b.n_instances) return;
     const u64* req_final = b.n_requests ? b.req_tails + 4 * (b.n_requests - 1) : nullptr;
     auto queues = [&](zkw_precompile_fsm& f, u64 popped, u64 queries_done) {

@@ -33,10 +33,10 @@ __device__ __forceinline__ void encode_mem_query(const zkw_mem_query& q, u64 out
     out[7] = v[4];
 }
 
-static __global__ __launch_bounds__(256) void k_encode_mem(const zkw_mem_query* __restrict__ q, size_t n,
+static __device__ void k_encode_mem(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n,
                                                     u64* __restrict__ enc) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)vb.nx * blockDim.x;
     for (; i < n; i += stride) {
         const uint4* src = reinterpret_cast<const uint4*>(q + i);
         uint4 w0 = src[0], w1 = src[1], w2 = src[2];
@@ -432,8 +432,8 @@ struct FsJob {
 // No per-lane arrays with run-time indices: they would live in scratch memory, and every HSA queue that ever ran the
 // kernel keeps scratch-per-lane x every wave slot of the chip (117 MB for 224 B per lane) out of the runtime's 4 GB
 // scratch aperture; with 32 hardware queues in use that exhausted it (HSA_STATUS_ERROR_OUT_OF_RESOURCES).
-static __global__ void k_fs_challenges(const FsJob* __restrict__ jobs, int n_jobs, int state_w, int n_chal) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_fs_challenges(const VB& vb, const FsJob* __restrict__ jobs, int n_jobs, int state_w, int n_chal) {
+    int j = vb.x * blockDim.x + threadIdx.x;
     if (j >= n_jobs) return;
     const FsJob job = jobs[j];
     const int m = 2 * state_w + 2;
@@ -503,12 +503,12 @@ __device__ __forceinline__ u64 wave_scan_mul(u64 v, int lane) {
 }
 
 template <int W, int REPS>
-static __global__ __launch_bounds__(GP_BLOCK) void k_gp_local(const GpSeg* __restrict__ segs,
+static __device__ void k_gp_local(const VB& vb, const GpSeg* __restrict__ segs,
                                                        const GpTile* __restrict__ tiles,
                                                        u64* __restrict__ tile_aggr /* [n_tiles_total][REPS] */) {
     __shared__ u64 sh_ch[REPS][W + 1];
     __shared__ u64 sh_wave[REPS][GP_BLOCK / 64];
-    const GpTile t = tiles[blockIdx.x];
+    const GpTile t = tiles[vb.x];
     const GpSeg seg = segs[t.seg];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < REPS * (W + 1); k += GP_BLOCK) sh_ch[k / (W + 1)][k % (W + 1)] = seg.chal[k];
@@ -560,14 +560,14 @@ static __global__ __launch_bounds__(GP_BLOCK) void k_gp_local(const GpSeg* __res
     }
     if (tid == 0) {
 #pragma unroll
-        for (int r = 0; r < REPS; r++) tile_aggr[(u64)blockIdx.x * REPS + r] = carry[r];
+        for (int r = 0; r < REPS; r++) tile_aggr[(u64)vb.x * REPS + r] = carry[r];
     }
 }
 
 // exclusive scan of the tile aggregates inside each segment: one lane per (segment, repetition)
 template <int REPS>
-static __global__ void k_gp_tiles(const GpSeg* __restrict__ segs, int n_segs, u64* __restrict__ tile_aggr) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_gp_tiles(const VB& vb, const GpSeg* __restrict__ segs, int n_segs, u64* __restrict__ tile_aggr) {
+    int j = vb.x * blockDim.x + threadIdx.x;
     if (j >= n_segs * REPS) return;
     const GpSeg seg = segs[j / REPS];
     const int r = j % REPS;
@@ -581,15 +581,15 @@ static __global__ void k_gp_tiles(const GpSeg* __restrict__ segs, int n_segs, u6
 }
 
 template <int REPS>
-static __global__ __launch_bounds__(GP_BLOCK) void k_gp_apply(const GpSeg* __restrict__ segs,
+static __device__ void k_gp_apply(const VB& vb, const GpSeg* __restrict__ segs,
                                                        const GpTile* __restrict__ tiles,
                                                        const u64* __restrict__ tile_prefix) {
-    const GpTile t = tiles[blockIdx.x];
+    const GpTile t = tiles[vb.x];
     const GpSeg seg = segs[t.seg];
     const u64 base = (u64)t.tile * GP_TILE;
 #pragma unroll
     for (int r = 0; r < REPS; r++) {
-        const u64 pre = tile_prefix[(u64)blockIdx.x * REPS + r];
+        const u64 pre = tile_prefix[(u64)vb.x * REPS + r];
         u64* z = seg.z + (u64)r * seg.n;
         for (int slab = 0; slab < GP_SLABS; slab++) {
             const u64 row = base + (u64)slab * GP_BLOCK + threadIdx.x;
@@ -601,10 +601,10 @@ static __global__ __launch_bounds__(GP_BLOCK) void k_gp_apply(const GpSeg* __res
 // ------------------------------------------------------------------------------------------------
 // K7 support: sort keys and the gather that applies the sorting permutation.
 // Sorting order (W/ram_permutation.rs:50-53): (page, index) then timestamp, stable.
-static __global__ void k_ram_sort_keys(const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ ts,
+static __device__ void k_ram_sort_keys(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ ts,
                                 u64* __restrict__ cell, u32* __restrict__ iota, const u64* __restrict__ seg_off,
                                 int n_segs) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     ts[i] = q[i].timestamp;
     cell[i] = ((u64)q[i].page << 32) | q[i].index;
@@ -612,25 +612,25 @@ static __global__ void k_ram_sort_keys(const zkw_mem_query* __restrict__ q, size
     (void)seg_off; (void)n_segs;
 }
 
-static __global__ void k_gather_u32_by_u32(const u32* __restrict__ src, const u32* __restrict__ idx, size_t n,
+static __device__ void k_gather_u32_by_u32(const VB& vb, const u32* __restrict__ src, const u32* __restrict__ idx, size_t n,
                                     u32* __restrict__ dst) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
 }
 
-static __global__ void k_gather_u64_by_u32(const u64* __restrict__ src, const u32* __restrict__ idx, size_t n,
+static __device__ void k_gather_u64_by_u32(const VB& vb, const u64* __restrict__ src, const u32* __restrict__ idx, size_t n,
                                     u64* __restrict__ dst) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
 }
 
 // sorted_q[i] = q[perm[i]] and its encoding in the same pass (the sorted side never needs the
 // un-encoded query again except for the FSM snapshots, which read sorted_q).
-static __global__ __launch_bounds__(256) void k_gather_encode(const zkw_mem_query* __restrict__ q,
+static __device__ void k_gather_encode(const VB& vb, const zkw_mem_query* __restrict__ q,
                                                        const u32* __restrict__ perm, size_t n,
                                                        zkw_mem_query* __restrict__ sorted_q,
                                                        u64* __restrict__ sorted_enc) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4* src = reinterpret_cast<const uint4*>(q + perm[i]);
     uint4 w0 = src[0], w1 = src[1], w2 = src[2];
@@ -670,11 +670,11 @@ __device__ __forceinline__ void copy12(u64* dst, const u64* src) {
 }
 
 // pass 1: count nondeterministic writes per chunk (rw && ts == 0 && page == BOOTLOADER_HEAP_PAGE)
-static __global__ __launch_bounds__(256) void k_ram_count_nondet(const RamBlock* __restrict__ blocks) {
-    const RamBlock b = blocks[blockIdx.y];
+static __device__ void k_ram_count_nondet(const VB& vb, const RamBlock* __restrict__ blocks) {
+    const RamBlock b = blocks[vb.y];
     const u64 n_inst = (b.n + b.capacity - 1) / b.capacity;
     __shared__ u32 sh[4];
-    for (u64 inst = blockIdx.x; inst < n_inst; inst += gridDim.x) {
+    for (u64 inst = vb.x; inst < n_inst; inst += vb.nx) {
         const u64 lo = inst * b.capacity, hi = lo + b.capacity < b.n ? lo + b.capacity : b.n;
         u32 cnt = 0;
         for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
@@ -690,10 +690,10 @@ static __global__ __launch_bounds__(256) void k_ram_count_nondet(const RamBlock*
 }
 
 // pass 2: one lane per instance
-static __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
-    const RamBlock b = blocks[blockIdx.y];
+static __device__ void k_ram_instances(const VB& vb, const RamBlock* __restrict__ blocks) {
+    const RamBlock b = blocks[vb.y];
     const u64 n_inst = (b.n + b.capacity - 1) / b.capacity;
-    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;
     if (idx >= n_inst) return;
     const u64 n = b.n, lo = idx * b.capacity, hi = lo + b.capacity < n ? lo + b.capacity : n;
     zkw_ram_instance& w = b.instances[idx];  // filled in place: a local copy would live in scratch memory
@@ -749,10 +749,10 @@ static __global__ void k_ram_instances(const RamBlock* __restrict__ blocks) {
 // ------------------------------------------------------------------------------------------------
 // Full tails on demand: tails[i] = permute(enc[i] || caps[i-1]) (zero capacity at the first item of a queue).
 // One item per lane; offsets[] are the queue boundaries inside the batch.
-static __global__ __launch_bounds__(64) void k_tails_expand(const u64* __restrict__ enc, const u64* __restrict__ caps,
+static __device__ void k_tails_expand(const VB& vb, const u64* __restrict__ enc, const u64* __restrict__ caps,
                                                      const u64* __restrict__ offsets, int n_queues, size_t n,
                                                      u64* __restrict__ tails) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int lo = 0, hi = n_queues;  // largest b with offsets[b] <= i
     while (hi - lo > 1) {

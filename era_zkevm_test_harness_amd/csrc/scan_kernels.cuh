@@ -9,10 +9,10 @@ namespace zkw {
 constexpr int FLAG_PREFIX_TILE = 1024;
 
 template <class Flag>
-static __global__ __launch_bounds__(FLAG_PREFIX_TILE) void k_flag_prefix_tiles(Flag flag, size_t n, u32* __restrict__ prefix, u32* __restrict__ tile_sums) {
+static __device__ void k_flag_prefix_tiles(const VB& vb, Flag flag, size_t n, u32* __restrict__ prefix, u32* __restrict__ tile_sums) {
     __shared__ u32 s_wave[FLAG_PREFIX_TILE / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const size_t i = (size_t)blockIdx.x * FLAG_PREFIX_TILE + t;
+    const size_t i = (size_t)vb.x * FLAG_PREFIX_TILE + t;
     const bool f = i < n && flag(i) != 0;
     const unsigned long long bal = __ballot(f);
     const u32 incl = __popcll(bal & ((2ull << lane) - 1));
@@ -21,12 +21,12 @@ static __global__ __launch_bounds__(FLAG_PREFIX_TILE) void k_flag_prefix_tiles(F
     u32 before = 0;
     for (int w = 0; w < wave; w++) before += s_wave[w];
     if (i < n) prefix[i + 1] = before + incl;
-    if (t == FLAG_PREFIX_TILE - 1) tile_sums[blockIdx.x] = before + incl;
+    if (t == FLAG_PREFIX_TILE - 1) tile_sums[vb.x] = before + incl;
     if (i == 0) prefix[0] = 0;
 }
 
 // exclusive scan of the tile totals in place: one workgroup, n_tiles = n / 1024 elements
-static __global__ __launch_bounds__(1024) void k_flag_prefix_offsets(u32* __restrict__ tile_sums, u32 n_tiles) {
+static __device__ void k_flag_prefix_offsets(const VB& vb, u32* __restrict__ tile_sums, u32 n_tiles) {
     __shared__ u32 s[1024];
     __shared__ u32 carry;
     const int t = threadIdx.x;
@@ -50,24 +50,24 @@ static __global__ __launch_bounds__(1024) void k_flag_prefix_offsets(u32* __rest
     }
 }
 
-static __global__ __launch_bounds__(256) void k_flag_prefix_apply(u32* __restrict__ prefix, const u32* __restrict__ tile_offsets, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_flag_prefix_apply(const VB& vb, u32* __restrict__ prefix, const u32* __restrict__ tile_offsets, size_t n) {
+    const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n) prefix[i + 1] += tile_offsets[i / FLAG_PREFIX_TILE];
 }
 
 // d_prefix: [n + 1] on the device; stream-ordered on the context's stream
 template <class Flag>
 static int flag_prefix(zkw_ctx* ctx, const char* name, Flag flag, size_t n, u32* d_prefix) {
-    if (n == 0) return hipMemsetAsync(d_prefix, 0, sizeof(u32), ctx->stream) == hipSuccess ? ZKW_OK : fail(ZKW_ERR_HIP, "memset failed");
+    if (n == 0) return ctx->memset_async(d_prefix, 0, sizeof(u32)) == hipSuccess ? ZKW_OK : fail(ZKW_ERR_HIP, "memset failed");
     const unsigned n_tiles = (unsigned)((n + FLAG_PREFIX_TILE - 1) / FLAG_PREFIX_TILE);
     u32* d_tiles = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("flag_prefix_tiles", n_tiles, &d_tiles));
-    { Prof _p(ctx, name); hipLaunchKernelGGL((k_flag_prefix_tiles<Flag>), dim3(n_tiles), dim3(FLAG_PREFIX_TILE), 0, ctx->stream, flag, n, d_prefix, d_tiles); }
+    { Prof _p(ctx, name); ZKW_LAUNCH_T(ctx, (k_flag_prefix_tiles<Flag>), "k_flag_prefix_tiles", n_tiles, FLAG_PREFIX_TILE, flag, n, d_prefix, d_tiles); }
     ZKW_TRY(launch_check(name));
     if (n_tiles > 1) {
-        hipLaunchKernelGGL(k_flag_prefix_offsets, dim3(1), dim3(1024), 0, ctx->stream, d_tiles, n_tiles);
+        ZKW_LAUNCH(ctx, k_flag_prefix_offsets, 1, 1024, d_tiles, n_tiles);
         ZKW_TRY(launch_check("k_flag_prefix_offsets"));
-        hipLaunchKernelGGL(k_flag_prefix_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_prefix, d_tiles, n);
+        ZKW_LAUNCH(ctx, k_flag_prefix_apply, (unsigned)((n + 255) / 256), 256, d_prefix, d_tiles, n);
         ZKW_TRY(launch_check("k_flag_prefix_apply"));
     }
     return ZKW_OK;
@@ -76,10 +76,10 @@ static int flag_prefix(zkw_ctx* ctx, const char* name, Flag flag, size_t n, u32*
 // ---- K routes at once: route(i) in [-1, K); count[c][i] = #{ j <= i : route(j) == c } (inclusive), totals[c] = count[c][n - 1].
 // The same three launches with K counters side by side (the log demuxer's six stable compactions).
 template <int K, class Route>
-static __global__ __launch_bounds__(FLAG_PREFIX_TILE) void k_route_prefix_tiles(Route route, size_t n, u32* __restrict__ count /* [K][n] */, u32* __restrict__ tile_sums /* [K][n_tiles] */) {
+static __device__ void k_route_prefix_tiles(const VB& vb, Route route, size_t n, u32* __restrict__ count /* [K][n] */, u32* __restrict__ tile_sums /* [K][n_tiles] */) {
     __shared__ u32 s_wave[K][FLAG_PREFIX_TILE / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const size_t i = (size_t)blockIdx.x * FLAG_PREFIX_TILE + t;
+    const size_t i = (size_t)vb.x * FLAG_PREFIX_TILE + t;
     const int r = i < n ? route(i) : -1;
     u32 incl[K];
 #pragma unroll
@@ -94,12 +94,12 @@ static __global__ __launch_bounds__(FLAG_PREFIX_TILE) void k_route_prefix_tiles(
         u32 before = 0;
         for (int w = 0; w < wave; w++) before += s_wave[c][w];
         if (i < n) count[(size_t)c * n + i] = before + incl[c];
-        if (t == FLAG_PREFIX_TILE - 1) tile_sums[(size_t)c * gridDim.x + blockIdx.x] = before + incl[c];
+        if (t == FLAG_PREFIX_TILE - 1) tile_sums[(size_t)c * vb.nx + vb.x] = before + incl[c];
     }
 }
 template <int K>
-static __global__ __launch_bounds__(256) void k_route_prefix_apply(u32* __restrict__ count, const u32* __restrict__ tile_offsets, size_t n, u32 n_tiles) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_route_prefix_apply(const VB& vb, u32* __restrict__ count, const u32* __restrict__ tile_offsets, size_t n, u32 n_tiles) {
+    const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
 #pragma unroll
     for (int c = 0; c < K; c++) count[(size_t)c * n + i] += tile_offsets[(size_t)c * n_tiles + i / FLAG_PREFIX_TILE];
@@ -110,12 +110,12 @@ static int route_prefix(zkw_ctx* ctx, const char* name, Route route, size_t n, u
     const unsigned n_tiles = (unsigned)((n + FLAG_PREFIX_TILE - 1) / FLAG_PREFIX_TILE);
     u32* d_tiles = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("route_prefix_tiles", (size_t)K * n_tiles, &d_tiles));
-    { Prof _p(ctx, name); hipLaunchKernelGGL((k_route_prefix_tiles<K, Route>), dim3(n_tiles), dim3(FLAG_PREFIX_TILE), 0, ctx->stream, route, n, d_count, d_tiles); }
+    { Prof _p(ctx, name); ZKW_LAUNCH_T(ctx, (k_route_prefix_tiles<K, Route>), "k_route_prefix_tiles", n_tiles, FLAG_PREFIX_TILE, route, n, d_count, d_tiles); }
     ZKW_TRY(launch_check(name));
     if (n_tiles > 1) {
-        for (int c = 0; c < K; c++) hipLaunchKernelGGL(k_flag_prefix_offsets, dim3(1), dim3(1024), 0, ctx->stream, d_tiles + (size_t)c * n_tiles, n_tiles);
+        for (int c = 0; c < K; c++) ZKW_LAUNCH(ctx, k_flag_prefix_offsets, 1, 1024, d_tiles + (size_t)c * n_tiles, n_tiles);
         ZKW_TRY(launch_check("k_flag_prefix_offsets"));
-        hipLaunchKernelGGL((k_route_prefix_apply<K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_count, d_tiles, n, n_tiles);
+        ZKW_LAUNCH_T(ctx, (k_route_prefix_apply<K>), "k_route_prefix_apply", (unsigned)((n + 255) / 256), 256, d_count, d_tiles, n, n_tiles);
         ZKW_TRY(launch_check("k_route_prefix_apply"));
     }
     return ZKW_OK;
@@ -125,10 +125,10 @@ static int route_prefix(zkw_ctx* ctx, const char* name, Route route, size_t n, u
 // totals[c] = the sum over all items. val(i, v) fills v[0..K). The same three launches; replaces the single-workgroup sweeps of
 // k_precompile_counts (rounds / queries / reads per request) and k_stack_depth (depth, push rank).
 template <int K, class Val>
-static __global__ __launch_bounds__(FLAG_PREFIX_TILE) void k_sum_prefix_tiles(Val val, size_t n, u64* __restrict__ out /* [K][n + 1] */, u64* __restrict__ tile_sums /* [K][n_tiles] */) {
+static __device__ void k_sum_prefix_tiles(const VB& vb, Val val, size_t n, u64* __restrict__ out /* [K][n + 1] */, u64* __restrict__ tile_sums /* [K][n_tiles] */) {
     __shared__ u64 s_wave[K][FLAG_PREFIX_TILE / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const size_t i = (size_t)blockIdx.x * FLAG_PREFIX_TILE + t;
+    const size_t i = (size_t)vb.x * FLAG_PREFIX_TILE + t;
     u64 v[K], incl[K];
 #pragma unroll
     for (int c = 0; c < K; c++) v[c] = 0;
@@ -150,11 +150,11 @@ static __global__ __launch_bounds__(FLAG_PREFIX_TILE) void k_sum_prefix_tiles(Va
         u64 before = 0;
         for (int w = 0; w < wave; w++) before += s_wave[c][w];
         if (i < n) out[(size_t)c * (n + 1) + i] = before + incl[c] - v[c];
-        if (t == FLAG_PREFIX_TILE - 1) tile_sums[(size_t)c * gridDim.x + blockIdx.x] = before + incl[c];
+        if (t == FLAG_PREFIX_TILE - 1) tile_sums[(size_t)c * vb.nx + vb.x] = before + incl[c];
     }
 }
 // exclusive scan of one sum's tile totals in place (one workgroup), its grand total to *total and to out_last (= out[c][n])
-static __global__ __launch_bounds__(1024) void k_sum_prefix_offsets(u64* __restrict__ tile_sums, u32 n_tiles, u64* __restrict__ total, u64* __restrict__ out_last) {
+static __device__ void k_sum_prefix_offsets(const VB& vb, u64* __restrict__ tile_sums, u32 n_tiles, u64* __restrict__ total, u64* __restrict__ out_last) {
     __shared__ u64 s[1024];
     __shared__ u64 carry;
     const int t = threadIdx.x;
@@ -179,8 +179,8 @@ static __global__ __launch_bounds__(1024) void k_sum_prefix_offsets(u64* __restr
     if (t == 0) { *total = carry; *out_last = carry; }
 }
 template <int K>
-static __global__ __launch_bounds__(256) void k_sum_prefix_apply(u64* __restrict__ out, const u64* __restrict__ tile_offsets, size_t n, u32 n_tiles) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_sum_prefix_apply(const VB& vb, u64* __restrict__ out, const u64* __restrict__ tile_offsets, size_t n, u32 n_tiles) {
+    const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
 #pragma unroll
     for (int c = 0; c < K; c++) out[(size_t)c * (n + 1) + i] += tile_offsets[(size_t)c * n_tiles + i / FLAG_PREFIX_TILE];
@@ -192,13 +192,13 @@ static int sum_prefix(zkw_ctx* ctx, const char* name, Val val, size_t n, u64* d_
     u64* d_tiles = nullptr;
     ZKW_TRY(ctx->scratch_t<u64>("sum_prefix_tiles", (size_t)K * (n_tiles ? n_tiles : 1), &d_tiles));
     if (n) {
-        { Prof _p(ctx, name); hipLaunchKernelGGL((k_sum_prefix_tiles<K, Val>), dim3(n_tiles), dim3(FLAG_PREFIX_TILE), 0, ctx->stream, val, n, d_out, d_tiles); }
+        { Prof _p(ctx, name); ZKW_LAUNCH_T(ctx, (k_sum_prefix_tiles<K, Val>), "k_sum_prefix_tiles", n_tiles, FLAG_PREFIX_TILE, val, n, d_out, d_tiles); }
         ZKW_TRY(launch_check(name));
     }
-    for (int c = 0; c < K; c++) hipLaunchKernelGGL(k_sum_prefix_offsets, dim3(1), dim3(1024), 0, ctx->stream, d_tiles + (size_t)c * n_tiles, n_tiles, d_totals + c, d_out + (size_t)c * (n + 1) + n);
+    for (int c = 0; c < K; c++) ZKW_LAUNCH(ctx, k_sum_prefix_offsets, 1, 1024, d_tiles + (size_t)c * n_tiles, n_tiles, d_totals + c, d_out + (size_t)c * (n + 1) + n);
     ZKW_TRY(launch_check("k_sum_prefix_offsets"));
     if (n_tiles > 1) {
-        hipLaunchKernelGGL((k_sum_prefix_apply<K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_out, d_tiles, n, n_tiles);
+        ZKW_LAUNCH_T(ctx, (k_sum_prefix_apply<K>), "k_sum_prefix_apply", (unsigned)((n + 255) / 256), 256, d_out, d_tiles, n, n_tiles);
         ZKW_TRY(launch_check("k_sum_prefix_apply"));
     }
     return ZKW_OK;

@@ -102,8 +102,8 @@ struct SapJob {
 };
 
 // derive_final_address: Blake2s-256(0^12 || address BE (20) || key BE (32))
-static __global__ __launch_bounds__(64) void k_sap_keys(SapJob job) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_sap_keys(const VB& vb, SapJob job) {
+    const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     const zkw_log_query* q = job.queries + i;
     u32 m[16], k[8];
@@ -119,7 +119,7 @@ static __global__ __launch_bounds__(64) void k_sap_keys(SapJob job) {
 
 // One workgroup. Flags are staged in LDS tile by tile; lane 0 runs the two sequential rules (instance cuts,
 // storage_application.rs:143-165; enumeration of first writes, tree/mod.rs:305-313), all lanes write the results.
-static __global__ __launch_bounds__(1024) void k_sap_scan(SapJob job) {
+static __device__ void k_sap_scan(const VB& vb, SapJob job) {
     __shared__ uint8_t s_rw[1024], s_first[1024];
     __shared__ u32 s_chunk[1024], s_prev[1024], s_enum[1024];
     __shared__ u32 total, chunk, first_writes, prev;
@@ -165,16 +165,16 @@ static __global__ __launch_bounds__(1024) void k_sap_scan(SapJob job) {
 // j*(i, L): the latest write j < i whose key first differs from key_i (from the top) at bit L. One wave per block,
 // lane = i; j is uniform across the wave so key_j is a broadcast load. The per-lane level table lives in LDS as
 // [level][lane] (bank = lane, conflict free).
-static __global__ __launch_bounds__(64) void k_sap_pairs(SapJob job) {
+static __device__ void k_sap_pairs(const VB& vb, SapJob job) {
     __shared__ u32 tab[256 * 64];
     const int lane = threadIdx.x;
-    const u64 i = (u64)blockIdx.x * 64 + lane;
+    const u64 i = (u64)vb.x * 64 + lane;
     for (int L = 0; L < 256; L++) tab[L * 64 + lane] = SAP_NONE;
     u32 ki[8];
     const bool live = i < job.n;
 #pragma unroll
     for (int w = 0; w < 8; w++) ki[w] = live ? job.keys[8 * i + w] : 0;
-    const u64 last = (u64)blockIdx.x * 64 + 63 < job.n ? (u64)blockIdx.x * 64 + 63 : job.n - 1;
+    const u64 last = (u64)vb.x * 64 + 63 < job.n ? (u64)vb.x * 64 + 63 : job.n - 1;
     bool dup = false;
     for (u64 j = 0; j < last; j++) {
         if (!job.queries[j].rw_flag) continue;  // uniform
@@ -195,8 +195,8 @@ static __global__ __launch_bounds__(64) void k_sap_pairs(SapJob job) {
 }
 
 // level 0: the leaf after the query (current tree) and the leaf before the block (pre-state check)
-static __global__ __launch_bounds__(64) void k_sap_leaves(SapJob job) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_sap_leaves(const VB& vb, SapJob job) {
+    const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     const zkw_log_query* q = job.queries + i;
     u32 a[8], c[8];
@@ -250,8 +250,8 @@ __device__ __forceinline__ void sap_level_step(const SapJob& job, int L, u64 i) 
 }
 
 // Level-synchronous launches: for blocks with more storage queries than one workgroup walks (n > SAP_PERSISTENT_MAX)
-static __global__ __launch_bounds__(64) void k_sap_level(SapJob job, int L) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_sap_level(const VB& vb, SapJob job, int L) {
+    const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i < job.n) sap_level_step(job, L, i);
 }
 
@@ -261,7 +261,7 @@ static __global__ __launch_bounds__(64) void k_sap_level(SapJob job, int L) {
 // is a chain of 256 dependent Blake2s pairs either way.
 constexpr int SAP_PERSISTENT_THREADS = 256;
 constexpr u64 SAP_PERSISTENT_MAX = 4 * SAP_PERSISTENT_THREADS;
-static __global__ __launch_bounds__(SAP_PERSISTENT_THREADS) void k_sap_levels(SapJob job) {
+static __device__ void k_sap_levels(const VB& vb, SapJob job) {
     for (int L = 0; L < 256; L++) {
         for (u64 i = threadIdx.x; i < job.n; i += SAP_PERSISTENT_THREADS) sap_level_step(job, L, i);
         __threadfence();
@@ -270,8 +270,8 @@ static __global__ __launch_bounds__(SAP_PERSISTENT_THREADS) void k_sap_levels(Sa
 }
 
 // after level 255 (A0 / C0 hold the roots): root after every query + the reference's inclusion asserts
-static __global__ __launch_bounds__(64) void k_sap_roots(SapJob job) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_sap_roots(const VB& vb, SapJob job) {
+    const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     bool bad = false;
     for (int k = 0; k < 8; k++) bad |= job.C0[8 * i + k] != job.initial_root[k];  // the given pre-state proof
@@ -305,7 +305,7 @@ __device__ __forceinline__ u32 sap_diff_byte(const SapJob& job, u64 i, int pos) 
 }
 
 // one wave: the running Keccak-256 over the writes' state diffs (two rate blocks each, :253-260)
-static __global__ __launch_bounds__(64) void k_sap_keccak(SapJob job, SapKeccakOut out) {
+static __device__ void k_sap_keccak(const VB& vb, SapJob job, SapKeccakOut out) {
     __shared__ u64 A[25], Bm[25], Cc[5];
     const int t = threadIdx.x;
     if (t < 25) A[t] = 0;
@@ -370,9 +370,9 @@ __device__ __forceinline__ void sap_bytes32(uint8_t* dst, const u32* words) {
         for (int b = 0; b < 4; b++) dst[4 * k + b] = (uint8_t)(words[k] >> (8 * b));
 }
 
-static __global__ void k_sap_instances(const SapBlock* __restrict__ blk) {
+static __device__ void k_sap_instances(const VB& vb, const SapBlock* __restrict__ blk) {
     const SapBlock b = *blk;
-    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 c = (u64)vb.x * blockDim.x + threadIdx.x;
     if (c >= b.n_instances) return;
     const u64 n = b.job.n;
     const u64* tail_final = n ? b.query_tails + 4 * (n - 1) : nullptr;
@@ -426,8 +426,8 @@ static __global__ void k_sap_instances(const SapBlock* __restrict__ blk) {
 // ------------------------------------------------------------------------------------------------ synthesis inputs (type 10)
 // What zkw_storage_application_synthesize needs of a query after the builder's scratch is gone: the leaf before and after it.
 struct SapItem { u64 read_index, write_index; u32 read_value[8], written_value[8]; u32 rw, _pad; };
-static __global__ __launch_bounds__(64) void k_sap_items(SapJob job, SapItem* __restrict__ items) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_sap_items(const VB& vb, SapJob job, SapItem* __restrict__ items) {
+    const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     const zkw_log_query* q = job.queries + i;
     SapItem& it = items[i];

@@ -14,11 +14,11 @@ typedef uint64_t u64;
 constexpr int VM_TILE = 4096;  // memory-stream items per workgroup of the read/write partition
 
 // reads per tile
-static __global__ __launch_bounds__(256) void k_vm_rw_tile_counts(const zkw_mem_query* __restrict__ q, u64 n, u32* __restrict__ tile_reads) {
+static __device__ void k_vm_rw_tile_counts(const VB& vb, const zkw_mem_query* __restrict__ q, u64 n, u32* __restrict__ tile_reads) {
     __shared__ u32 s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    const u64 base = (u64)blockIdx.x * VM_TILE;
+    const u64 base = (u64)vb.x * VM_TILE;
     u32 c = 0;
     for (int k = threadIdx.x; k < VM_TILE; k += 256) {
         const u64 i = base + k;
@@ -27,11 +27,11 @@ static __global__ __launch_bounds__(256) void k_vm_rw_tile_counts(const zkw_mem_
     for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
     if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, c);
     __syncthreads();
-    if (threadIdx.x == 0) tile_reads[blockIdx.x] = s_cnt;
+    if (threadIdx.x == 0) tile_reads[vb.x] = s_cnt;
 }
 
 // exclusive scan of the tile counts (one workgroup: a block has at most a few thousand tiles)
-static __global__ __launch_bounds__(1024) void k_vm_rw_scan_tiles(u32* __restrict__ tile_reads, u32 n_tiles, u64* __restrict__ total_reads) {
+static __device__ void k_vm_rw_scan_tiles(const VB& vb, u32* __restrict__ tile_reads, u32 n_tiles, u64* __restrict__ total_reads) {
     __shared__ u32 s_wave[16];
     __shared__ u32 s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -57,10 +57,10 @@ static __global__ __launch_bounds__(1024) void k_vm_rw_scan_tiles(u32* __restric
 }
 
 // stable partition: read_prefix[i] = reads among [0, i); index arrays of the reads / writes in order
-static __global__ __launch_bounds__(256) void k_vm_rw_scatter(const zkw_mem_query* __restrict__ q, u64 n, const u32* __restrict__ tile_offsets,
+static __device__ void k_vm_rw_scatter(const VB& vb, const zkw_mem_query* __restrict__ q, u64 n, const u32* __restrict__ tile_offsets,
                                                        u32* __restrict__ read_prefix, u32* __restrict__ read_index, u32* __restrict__ write_index) {
     __shared__ u32 s_wave[4];
-    const u64 base = (u64)blockIdx.x * VM_TILE + (u64)threadIdx.x * 16;  // 16 consecutive items per thread
+    const u64 base = (u64)vb.x * VM_TILE + (u64)threadIdx.x * 16;  // 16 consecutive items per thread
     u32 flags = 0, c = 0;
     for (int k = 0; k < 16; k++) {
         const u64 i = base + k;
@@ -73,7 +73,7 @@ static __global__ __launch_bounds__(256) void k_vm_rw_scatter(const zkw_mem_quer
     }
     if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = x;
     __syncthreads();
-    u32 r = tile_offsets[blockIdx.x] + x - c;
+    u32 r = tile_offsets[vb.x] + x - c;
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) r += s_wave[w];
     for (int k = 0; k < 16; k++) {
         const u64 i = base + k;
@@ -144,10 +144,10 @@ __device__ void vm_aux_at(const zkw_vm_tracer_streams& s, u32 at_cycle, bool fin
     }  // the last instance with an empty history: StorageLogDetailedState::default() as is (:1443-1447)
 }
 
-static __global__ __launch_bounds__(64) void k_vm_slice(VmSliceJob job) {
+static __device__ void k_vm_slice(const VB& vb, VmSliceJob job) {
     const zkw_vm_tracer_streams& s = job.s;
     const u64 n_inst = s.n_snapshots - 1;
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= n_inst) return;
     zkw_vm_instance& v = job.out[i];  // filled in place: a local copy would live in scratch memory
     memset(&v, 0, sizeof v);

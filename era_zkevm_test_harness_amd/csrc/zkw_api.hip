@@ -9,7 +9,7 @@
 #include "closed_forms_host.h"
 #include "callstack_kernels.cuh"
 #include "vm_kernels.cuh"
-#include "sort.h"
+#include "radix_sort.cuh"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string g_last_error;
@@ -333,8 +333,35 @@ extern "C" int zkw_set_netlist_fill_form(zkw_ctx* ctx, int form) {
 
 extern "C" int zkw_synchronize(zkw_ctx* ctx) {
     if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
+    if (ctx->batched()) return zkw_batch_sync(ctx->batch);  // parks the calling fiber until what it queued has run
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ZKW_OK;
+}
+
+// A context of a block that runs inside a batch (zkw_batch.h): no stream of its own — what it launches travels on the batch's stream,
+// merged with the other blocks' launches. zkw_ctx_leave_batch hands it over to ordinary use (synthesis, getters) on that stream.
+zkw_ctx* zkw_ctx_create_in_batch(int device_id, zkw_batch* b) {
+    zkw_ctx* ctx = new zkw_ctx();
+    ctx->device = device_id;
+    ctx->batch = b;
+    ctx->stream = zkw_batch_stream(b);
+    ctx->ptr_mode = ZKW_PTR_DEVICE;
+    return ctx;
+}
+void* zkw_device_shared_stream(int device_id) {
+    static std::mutex mu;
+    static std::map<int, hipStream_t>& m = *new std::map<int, hipStream_t>();
+    std::lock_guard<std::mutex> g(mu);
+    auto it = m.find(device_id);
+    if (it != m.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    m[device_id] = s;
+    return s;
+}
+void zkw_ctx_leave_batch(zkw_ctx* ctx, void* stream) {
+    ctx->batch = nullptr;
+    ctx->stream = static_cast<hipStream_t>(stream);
 }
 
 extern "C" int zkw_profile_enable(zkw_ctx* ctx, int on) {
@@ -418,6 +445,16 @@ static void launch_chain_log_rows(hipStream_t st, const LogChainJob* d_jobs, int
     const int lds = wg4 && n_jobs > 4 && n_jobs <= 256 * 16 ? one_workgroup_per_cu_lds(reinterpret_cast<const void*>(&k_chain_log_x4), 2) : -1;
     if (lds > 0) hipLaunchKernelGGL(k_chain_log_x4, dim3((n_jobs + 15) / 16), dim3(256), (size_t)lds, st, d_jobs, n_jobs);
     else hipLaunchKernelGGL(k_chain_log, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
+}
+
+int zkw_launch_chain_full(hipStream_t st, const ChainJob* d_jobs, int n_jobs) {
+    if (n_jobs >= 4096) return launch_chain_q4(st, d_jobs, n_jobs);
+    launch_chain_full_rows(st, d_jobs, n_jobs);
+    return ZKW_OK;
+}
+int zkw_launch_chain_log(hipStream_t st, const LogChainJob* d_jobs, int n_jobs) {
+    launch_chain_log_rows(st, d_jobs, n_jobs);
+    return ZKW_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ chain service
@@ -674,7 +711,7 @@ int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) {
     if (n == 0) return ZKW_OK;
     unsigned grid = blocks_for(n, 256);
     if (grid > 256 * 16) grid = 256 * 16;
-    { Prof _p(ctx, "k_encode_mem"); hipLaunchKernelGGL(k_encode_mem, dim3(grid), dim3(256), 0, ctx->stream, q, n, enc); }
+    { Prof _p(ctx, "k_encode_mem"); ZKW_LAUNCH(ctx, k_encode_mem, grid, 256, q, n, enc); }
     return launch_check("k_encode_mem");
 }
 
@@ -682,6 +719,7 @@ int dev_encode(zkw_ctx* ctx, const zkw_mem_query* q, size_t n, u64* enc) {
 // issues a VALU instruction every ~2 cycles (measured 3.7 us per permutation step, flat from 1 to 4096
 // concurrent chains), so throughput comes from giving each wave its own SIMD: up to 1024 waves.
 int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs) {
+    if (ctx->batched()) return jobs.empty() ? ZKW_OK : zkw_batch_chains(ctx->batch, jobs.data(), jobs.size(), nullptr, 0);  // one launch per stage of all blocks
     const int key = ctx->chain_service ? ctx->next_chain_key() : 0;  // (counted even when there is nothing to hash: equal stages of all blocks keep equal keys)
     if (jobs.empty()) { if (ctx->chain_service) chain_service_of(ctx->device)->skip(key); return ZKW_OK; }
     // the service is for chains whose LATENCY matters (a launch costs what its longest chain costs): a handful of items per chain — the
@@ -731,19 +769,18 @@ int dev_fs(zkw_ctx* ctx, const std::vector<FsJob>& jobs, int state_w, int n_chal
     FsJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("fs_jobs", jobs, &d_jobs));
     int n = (int)jobs.size();
-    { Prof _p(ctx, "k_fs_challenges"); hipLaunchKernelGGL(k_fs_challenges, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, n, state_w, n_chal); }
+    { Prof _p(ctx, "k_fs_challenges"); ZKW_LAUNCH(ctx, k_fs_challenges, (n + 63) / 64, 64, d_jobs, n, state_w, n_chal); }
     return launch_check("k_fs_challenges");
 }
 
 template <int W, int REPS>
 static int gp_launch(zkw_ctx* ctx, const GpSeg* d_segs, int n_segs, const GpTile* d_tiles, unsigned n_tiles,
                      u64* d_aggr) {
-    { Prof _p(ctx, "k_gp_local"); hipLaunchKernelGGL((k_gp_local<W, REPS>), dim3(n_tiles), dim3(GP_BLOCK), 0, ctx->stream, d_segs, d_tiles, d_aggr); }
+    { Prof _p(ctx, "k_gp_local"); ZKW_LAUNCH_T(ctx, (k_gp_local<W, REPS>), "k_gp_local", n_tiles, GP_BLOCK, d_segs, d_tiles, d_aggr); }
     ZKW_TRY(launch_check("k_gp_local"));
-    { Prof _p(ctx, "k_gp_tiles"); hipLaunchKernelGGL((k_gp_tiles<REPS>), dim3((n_segs * REPS + 63) / 64), dim3(64), 0, ctx->stream, d_segs, n_segs,
-                       d_aggr); }
+    { Prof _p(ctx, "k_gp_tiles"); ZKW_LAUNCH_T(ctx, (k_gp_tiles<REPS>), "k_gp_tiles", (n_segs * REPS + 63) / 64, 64, d_segs, n_segs, d_aggr); }
     ZKW_TRY(launch_check("k_gp_tiles"));
-    { Prof _p(ctx, "k_gp_apply"); hipLaunchKernelGGL((k_gp_apply<REPS>), dim3(n_tiles), dim3(GP_BLOCK), 0, ctx->stream, d_segs, d_tiles, d_aggr); }
+    { Prof _p(ctx, "k_gp_apply"); ZKW_LAUNCH_T(ctx, (k_gp_apply<REPS>), "k_gp_apply", n_tiles, GP_BLOCK, d_segs, d_tiles, d_aggr); }
     return launch_check("k_gp_apply");
 }
 
@@ -876,7 +913,7 @@ extern "C" int zkw_encode_log_queries(zkw_ctx* ctx, const zkw_log_query* q, size
     ZKW_TRY(ctx->in("lenc_q", q, n, &d_q));
     if (ext_ts) ZKW_TRY(ctx->in("lenc_ts", ext_ts, n, &d_e));
     ZKW_TRY(ctx->out("lenc_out", enc, n * 20, &d_enc));
-    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, n, d_e, d_enc); }
+    { Prof _p(ctx, "k_encode_log"); ZKW_LAUNCH(ctx, k_encode_log, blocks_for(n, 256), 256, d_q, n, d_e, d_enc); }
     ZKW_TRY(launch_check("k_encode_log"));
     ZKW_TRY(ctx->finish_out(enc, d_enc, n * 20));
     return ctx->sync_if_host();
@@ -890,7 +927,7 @@ extern "C" int zkw_encode_decommit_queries(zkw_ctx* ctx, const zkw_decommit_quer
     u64* d_enc = nullptr;
     ZKW_TRY(ctx->in("denc_q", q, n, &d_q));
     ZKW_TRY(ctx->out("denc_out", enc, n * 8, &d_enc));
-    { Prof _p(ctx, "k_encode_decommit"); hipLaunchKernelGGL(k_encode_decommit, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, n, d_enc); }
+    { Prof _p(ctx, "k_encode_decommit"); ZKW_LAUNCH(ctx, k_encode_decommit, blocks_for(n, 256), 256, d_q, n, d_enc); }
     ZKW_TRY(launch_check("k_encode_decommit"));
     ZKW_TRY(ctx->finish_out(enc, d_enc, n * 8));
     return ctx->sync_if_host();
@@ -898,13 +935,14 @@ extern "C" int zkw_encode_decommit_queries(zkw_ctx* ctx, const zkw_decommit_quer
 
 // device-level: rounds 1-2 of every item in parallel, then one serial permutation per item and queue
 int dev_log_chains(zkw_ctx* ctx, const u64* d_enc, size_t total, std::vector<LogChainJob>& jobs) {
-    const int key = ctx->chain_service ? ctx->next_chain_key() : 0;
-    if (total == 0 || jobs.empty()) { if (ctx->chain_service) chain_service_of(ctx->device)->skip(key); return ZKW_OK; }
+    const int key = ctx->chain_service && !ctx->batched() ? ctx->next_chain_key() : 0;
+    if (total == 0 || jobs.empty()) { if (ctx->chain_service && !ctx->batched()) chain_service_of(ctx->device)->skip(key); return ZKW_OK; }
     u64* d_pre = nullptr;
     ZKW_TRY(ctx->scratch_t<u64>("log_pre", total * 4, &d_pre));
-    { Prof _p(ctx, "k_log_prehash"); hipLaunchKernelGGL(k_log_prehash, dim3(blocks_for(total, 128)), dim3(128), 0, ctx->stream, d_enc, total, d_pre); }
+    { Prof _p(ctx, "k_log_prehash"); ZKW_LAUNCH(ctx, k_log_prehash, blocks_for(total, 128), 128, d_enc, total, d_pre); }
     ZKW_TRY(launch_check("k_log_prehash"));
     for (auto& j : jobs) j.pre = d_pre + (j.enc - d_enc) / 20 * 4;
+    if (ctx->batched()) return zkw_batch_chains(ctx->batch, nullptr, 0, jobs.data(), jobs.size());
     if (ctx->chain_service) return chain_service_run(ctx, nullptr, &jobs, "k_chain_log", key);
     LogChainJob* d_jobs = nullptr;
     ZKW_TRY(ctx->upload("log_chain_jobs", jobs, &d_jobs));
@@ -1048,9 +1086,9 @@ __device__ __forceinline__ u32 block_of_position(const u64* __restrict__ offsets
 
 // Widths of the sort key's fields in this batch: max timestamp / page / index, so that the radix sort only walks
 // the bits that are in use.
-__global__ void k_ram_key_ranges(const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ maxima) {
+static __device__ void k_ram_key_ranges(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ maxima) {
     u32 t = 0, p = 0, x = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)vb.x * blockDim.x + threadIdx.x; i < n; i += (size_t)vb.nx * blockDim.x) {
         t = max(t, q[i].timestamp);
         p = max(p, q[i].page);
         x = max(x, q[i].index);
@@ -1068,10 +1106,10 @@ __global__ void k_ram_key_ranges(const zkw_mem_query* __restrict__ q, size_t n, 
 }
 
 // (block, page, index, timestamp) packed into one word, most significant first
-__global__ void k_ram_packed_keys(const zkw_mem_query* __restrict__ q, size_t n, const u64* __restrict__ offsets,
+static __device__ void k_ram_packed_keys(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n, const u64* __restrict__ offsets,
                                   int n_blocks, unsigned bits_p, unsigned bits_i, unsigned bits_t,
                                   u64* __restrict__ key, u32* __restrict__ iota) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 k = n_blocks > 1 ? block_of_position(offsets, n_blocks, i) : 0;
     k = (k << bits_p) | q[i].page;
@@ -1082,10 +1120,10 @@ __global__ void k_ram_packed_keys(const zkw_mem_query* __restrict__ q, size_t n,
 }
 
 // (block, page, index) of the items in their current order `perm`, packed into one word
-__global__ void k_ram_packed_cells(const u64* __restrict__ cell, const u32* __restrict__ perm, size_t n,
+static __device__ void k_ram_packed_cells(const VB& vb, const u64* __restrict__ cell, const u32* __restrict__ perm, size_t n,
                                    const u64* __restrict__ offsets, int n_blocks, unsigned bits_p, unsigned bits_i,
                                    u64* __restrict__ key) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u32 src = perm[i];
     const u64 c = cell[src];
@@ -1095,8 +1133,8 @@ __global__ void k_ram_packed_cells(const u64* __restrict__ cell, const u32* __re
     key[i] = k;
 }
 
-__global__ void k_block_ids(const u64* __restrict__ offsets, int n_blocks, size_t n, u32* __restrict__ ids) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_block_ids(const VB& vb, const u64* __restrict__ offsets, int n_blocks, size_t n, u32* __restrict__ ids) {
+    size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n) ids[i] = block_of_position(offsets, n_blocks, i);
 }
 
@@ -1130,10 +1168,10 @@ static int ram_sort(zkw_ctx* ctx, const zkw_mem_query* d_q, size_t total, const 
     void* d_max_v = nullptr;
     ZKW_TRY(ctx->scratch("sort_max", 256, &d_max_v));
     u32* d_max = static_cast<u32*>(d_max_v);
-    HIP_TRY(hipMemsetAsync(d_max, 0, 16, ctx->stream));
+    HIP_TRY(ctx->memset_async(d_max, 0, 16));
     { Prof _p(ctx, "k_ram_key_ranges");
       const unsigned g = grid < 4096 ? grid : 4096;
-      hipLaunchKernelGGL(k_ram_key_ranges, dim3(g), dim3(256), 0, ctx->stream, d_q, total, d_max); }
+      ZKW_LAUNCH(ctx, k_ram_key_ranges, g, 256, d_q, total, d_max); }
     ZKW_TRY(launch_check("k_ram_key_ranges"));
     u32 maxima[4];
     ZKW_TRY(ctx->read_small(maxima, d_max, 16));
@@ -1146,41 +1184,38 @@ static int ram_sort(zkw_ctx* ctx, const zkw_mem_query* d_q, size_t total, const 
     if (bits_b + bits_p + bits_i + bits_t <= 64) {
         const unsigned bits = bits_b + bits_p + bits_i + bits_t;
         { Prof _p(ctx, "k_ram_packed_keys");
-          hipLaunchKernelGGL(k_ram_packed_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, total, d_off, (int)n_blocks,
-                             bits_p, bits_i, bits_t, k64a, v0); }
+          ZKW_LAUNCH(ctx, k_ram_packed_keys, grid, 256, d_q, total, d_off, (int)n_blocks, bits_p, bits_i, bits_t, k64a, v0); }
         ZKW_TRY(launch_check("k_ram_packed_keys"));
-        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, v0, v1, total, bits ? bits : 1, ctx->stream)); }
+        { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u64>(ctx, tmp, tmp_bytes, k64a, k64b, v0, v1, total, bits ? bits : 1)); }
         *perm_out = v1;
         return ZKW_OK;
     }
 
-    { Prof _p(ctx, "k_ram_sort_keys"); hipLaunchKernelGGL(k_ram_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, total, ts, cell, v0,
-                       (const u64*)nullptr, 0); }
+    { Prof _p(ctx, "k_ram_sort_keys"); ZKW_LAUNCH(ctx, k_ram_sort_keys, grid, 256, d_q, total, ts, cell, v0, (const u64*)nullptr, 0); }
     ZKW_TRY(launch_check("k_ram_sort_keys"));
     // pass 1: timestamp
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, ts, k32, v0, v1, total, bits_t ? bits_t : 1, ctx->stream)); }
+    { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u32>(ctx, tmp, tmp_bytes, ts, k32, v0, v1, total, bits_t ? bits_t : 1)); }
     if (bits_b + bits_p + bits_i <= 64) {
         // pass 2: (block, page, index) of the ts-sorted items
         const unsigned bits = bits_b + bits_p + bits_i;
         { Prof _p(ctx, "k_ram_packed_cells");
-          hipLaunchKernelGGL(k_ram_packed_cells, dim3(grid), dim3(256), 0, ctx->stream, cell, v1, total, d_off, (int)n_blocks,
-                             bits_p, bits_i, k64a); }
+          ZKW_LAUNCH(ctx, k_ram_packed_cells, grid, 256, cell, v1, total, d_off, (int)n_blocks, bits_p, bits_i, k64a); }
         ZKW_TRY(launch_check("k_ram_packed_cells"));
-        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, v1, v0, total, bits ? bits : 1, ctx->stream)); }
+        { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u64>(ctx, tmp, tmp_bytes, k64a, k64b, v1, v0, total, bits ? bits : 1)); }
         *perm_out = v0;
         return ZKW_OK;
     }
     // pass 2: cell of the ts-sorted items
-    { Prof _p(ctx, "k_gather_u64_by_u32"); hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, cell, v1, total, k64a); }
+    { Prof _p(ctx, "k_gather_u64_by_u32"); ZKW_LAUNCH(ctx, k_gather_u64_by_u32, grid, 256, cell, v1, total, k64a); }
     ZKW_TRY(launch_check("k_gather_u64_by_u32"));
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, v1, v0, total, 64, ctx->stream)); }
+    { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u64>(ctx, tmp, tmp_bytes, k64a, k64b, v1, v0, total, 64)); }
     // pass 3: block id, so that each block's items end up contiguous again (only multi-block batches get here)
-    { Prof _p(ctx, "k_block_ids"); hipLaunchKernelGGL(k_block_ids, dim3(grid), dim3(256), 0, ctx->stream, d_off, (int)n_blocks, total, ts); }
+    { Prof _p(ctx, "k_block_ids"); ZKW_LAUNCH(ctx, k_block_ids, grid, 256, d_off, (int)n_blocks, total, ts); }
     ZKW_TRY(launch_check("k_block_ids"));
     // ts[] now holds block ids in ORIGINAL order; gather them through the current permutation
-    { Prof _p(ctx, "k_gather_u32_by_u32"); hipLaunchKernelGGL(k_gather_u32_by_u32, dim3(grid), dim3(256), 0, ctx->stream, ts, v0, total, k32); }
+    { Prof _p(ctx, "k_gather_u32_by_u32"); ZKW_LAUNCH(ctx, k_gather_u32_by_u32, grid, 256, ts, v0, total, k32); }
     ZKW_TRY(launch_check("k_gather_u32_by_u32"));
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, k32, ts, v0, v1, total, bits_b, ctx->stream)); }
+    { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u32>(ctx, tmp, tmp_bytes, k32, ts, v0, v1, total, bits_b)); }
     *perm_out = v1;
     return ZKW_OK;
 }
@@ -1205,7 +1240,7 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
         w->unsorted_q = d_q;
     } else {  // d_q is the context's staging copy, which the next call overwrites
         if (!w->owned_q) HIP_TRY(dev_malloc((void**)&w->owned_q, (total + 1) * sizeof(zkw_mem_query)));
-        HIP_TRY(hipMemcpyAsync(w->owned_q, d_q, total * sizeof(zkw_mem_query), hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx->copy_async(w->owned_q, d_q, total * sizeof(zkw_mem_query), hipMemcpyDeviceToDevice));
         w->unsorted_q = w->owned_q;
     }
     // K7 (sorted side)
@@ -1215,7 +1250,7 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
     w->enc_valid = false;
     w->sorted_valid = false;
     // the permutation lives in the sort's scratch (the capacity-word arrays the chains are about to fill): keep a copy
-    HIP_TRY(hipMemcpyAsync(w->perm, perm, total * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx->copy_async(w->perm, perm, total * sizeof(u32), hipMemcpyDeviceToDevice));
     // K2: 2 chains per block, all in one launch
     std::vector<ChainJob> chains;
     chains.reserve(2 * n_blocks);
@@ -1264,17 +1299,17 @@ static int ram_run(zkw_ctx* ctx, zkw_ram_witness* w, const zkw_mem_query* d_q, c
         RamBlock* d_blocks = nullptr;
         ZKW_TRY(ctx->upload("ram_blocks", blocks, &d_blocks));
         const unsigned gx = (unsigned)(max_inst < 64 ? max_inst : 64), gy = (unsigned)(b1 - b0);
-        { Prof _p(ctx, "k_ram_count_nondet"); hipLaunchKernelGGL(k_ram_count_nondet, dim3(gx, gy), dim3(256), 0, ctx->stream, d_blocks); }
+        { Prof _p(ctx, "k_ram_count_nondet"); ZKW_LAUNCH_2D(ctx, k_ram_count_nondet, gx, gy, 256, d_blocks); }
         ZKW_TRY(launch_check("k_ram_count_nondet"));
-        { Prof _p(ctx, "k_ram_instances"); hipLaunchKernelGGL(k_ram_instances, dim3(blocks_for(max_inst, 64), gy), dim3(64), 0, ctx->stream, d_blocks); }
+        { Prof _p(ctx, "k_ram_instances"); ZKW_LAUNCH_2D(ctx, k_ram_instances, blocks_for(max_inst, 64), gy, 64, d_blocks); }
         ZKW_TRY(launch_check("k_ram_instances"));
         b0 = b1;
     }
     // a20: compact forms and public inputs of every instance (postprocessing/mod.rs:353-369)
     const size_t ni = w->n_instances;
-    { Prof _p(ctx, "k_ram_commitments"); hipLaunchKernelGGL(k_ram_commitments, dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, w->instances, ni, w->compact_forms); }
+    { Prof _p(ctx, "k_ram_commitments"); ZKW_LAUNCH(ctx, k_ram_commitments, blocks_for(4 * ni, 64), 64, w->instances, ni, w->compact_forms); }
     ZKW_TRY(launch_check("k_ram_commitments"));
-    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, w->compact_forms, ni, (u32)COMPACT_FORM_LEN, w->public_inputs); }
+    { Prof _p(ctx, "k_commit_encodings"); ZKW_LAUNCH(ctx, k_commit_encodings, blocks_for(ni, 64), 64, w->compact_forms, ni, (u32)COMPACT_FORM_LEN, w->public_inputs); }
     return launch_check("k_commit_encodings");
 }
 
@@ -1350,7 +1385,7 @@ static int ram_sorted_queries(const zkw_ram_witness* cw) {
     const size_t t = w->total;
     if (!w->sorted_q && dev_malloc((void**)&w->sorted_q, (t + 1) * sizeof(zkw_mem_query)) != hipSuccess)
         return fail(ZKW_ERR_OOM, "no room for the sorted queries (%zu bytes): read ZKW_RAM_SORTED_QUERIES from a smaller batch", t * sizeof(zkw_mem_query));
-    { Prof _p(ctx, "k_gather_encode"); hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(t, 256)), dim3(256), 0, ctx->stream, w->unsorted_q, w->perm, t, w->sorted_q, (u64*)nullptr); }
+    { Prof _p(ctx, "k_gather_encode"); ZKW_LAUNCH(ctx, k_gather_encode, blocks_for(t, 256), 256, w->unsorted_q, w->perm, t, w->sorted_q, (u64*)nullptr); }
     ZKW_TRY(launch_check("k_gather_encode"));
     w->sorted_valid = true;
     return ZKW_OK;
@@ -1406,9 +1441,9 @@ static int ram_full_tails(const zkw_ram_witness* cw) {
     u64* d_off = nullptr;
     ZKW_TRY(ctx->upload("tails_off", w->offsets, &d_off));
     const int nq = (int)(w->offsets.size() - 1);
-    { Prof _p(ctx, "k_tails_expand"); hipLaunchKernelGGL(k_tails_expand, dim3(blocks_for(t, 64)), dim3(64), 0, ctx->stream, w->unsorted_enc, w->unsorted_caps, d_off, nq, t, w->unsorted_tails); }
+    { Prof _p(ctx, "k_tails_expand"); ZKW_LAUNCH(ctx, k_tails_expand, blocks_for(t, 64), 64, w->unsorted_enc, w->unsorted_caps, d_off, nq, t, w->unsorted_tails); }
     ZKW_TRY(launch_check("k_tails_expand"));
-    { Prof _p(ctx, "k_tails_expand"); hipLaunchKernelGGL(k_tails_expand, dim3(blocks_for(t, 64)), dim3(64), 0, ctx->stream, w->sorted_enc, w->sorted_caps, d_off, nq, t, w->sorted_tails); }
+    { Prof _p(ctx, "k_tails_expand"); ZKW_LAUNCH(ctx, k_tails_expand, blocks_for(t, 64), 64, w->sorted_enc, w->sorted_caps, d_off, nq, t, w->sorted_tails); }
     ZKW_TRY(launch_check("k_tails_expand"));
     w->tails_valid = true;
     return ZKW_OK;
@@ -1461,9 +1496,7 @@ extern "C" int zkw_ram_witness_get(const zkw_ram_witness* w, int what, void* dst
     if (dst_bytes < bytes) return fail(ZKW_ERR_INVALID, "zkw_ram_witness_get: need %zu bytes, got %zu", bytes, dst_bytes);
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes,
-                           ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                           ctx->stream));
+    HIP_TRY(ctx->copy_async(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return ctx->sync_if_host();
 }
 
@@ -1528,8 +1561,7 @@ extern "C" int zkw_trace_get(const zkw_trace* t, size_t slot, uint32_t first_col
     zkw_ctx* ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const u64* src = t->data + slot * t->slot_elems() + (size_t)first_col * t->n_rows;
-    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n_cols * t->n_rows * sizeof(u64),
-                           ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx->copy_async(dst, src, (size_t)n_cols * t->n_rows * sizeof(u64), ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return ctx->sync_if_host();
 }
 
@@ -1565,7 +1597,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     {   // the fills read the sorted queue contiguously: gather the touched blocks once per call
         const size_t cnt = w->offsets[b_end] - z_base;
         Prof _p(ctx, "k_gather_encode");
-        hipLaunchKernelGGL(k_gather_encode, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, w->unsorted_q, w->perm + z_base, cnt, w->sq_win, (u64*)nullptr);
+        ZKW_LAUNCH(ctx, k_gather_encode, blocks_for(cnt, 256), 256, w->unsorted_q, w->perm + z_base, cnt, w->sq_win, (u64*)nullptr);
     }
     ZKW_TRY(launch_check("k_gather_encode"));
     const u32 rstride = (u32)RC_REGION_STRIDE(capacity);  // rows per region incl. the alignment gap
@@ -1573,7 +1605,7 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     u32 *d_hist = nullptr, *d_nd = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("synth_hist", n_instances * 256, &d_hist));
     ZKW_TRY(ctx->scratch_t<u32>("synth_nd", n_instances * n_tiles, &d_nd));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx->memset_async(d_hist, 0, n_instances * 256 * sizeof(u32)));
     SlotClaims claims(t);
     std::vector<SynthJob> jobs(n_instances);
     size_t b = b_first;
@@ -1676,7 +1708,7 @@ extern "C" int zkw_commit_encodings(zkw_ctx* ctx, const uint64_t* enc, size_t n_
     u64* d_out = nullptr;
     ZKW_TRY(ctx->in("ce_enc", enc, n_items * item_len + 1, &d_enc));
     ZKW_TRY(ctx->out("ce_out", out, n_items * 4, &d_out));
-    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, d_enc, n_items, item_len, d_out); }
+    { Prof _p(ctx, "k_commit_encodings"); ZKW_LAUNCH(ctx, k_commit_encodings, blocks_for(n_items, 64), 64, d_enc, n_items, item_len, d_out); }
     ZKW_TRY(launch_check("k_commit_encodings"));
     ZKW_TRY(ctx->finish_out(out, d_out, n_items * 4));
     return ctx->sync_if_host();
@@ -1691,7 +1723,7 @@ extern "C" int zkw_encode_recursion_requests(zkw_ctx* ctx, uint64_t circuit_type
     u64* d_enc = nullptr;
     ZKW_TRY(ctx->in("rr_pi", public_inputs, n * 4, &d_pi));
     ZKW_TRY(ctx->out("rr_enc", enc, n * 8, &d_enc));
-    { Prof _p(ctx, "k_encode_recursion"); hipLaunchKernelGGL(k_encode_recursion, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, circuit_type, d_pi, n, d_enc); }
+    { Prof _p(ctx, "k_encode_recursion"); ZKW_LAUNCH(ctx, k_encode_recursion, blocks_for(n, 64), 64, circuit_type, d_pi, n, d_enc); }
     ZKW_TRY(launch_check("k_encode_recursion"));
     ZKW_TRY(ctx->finish_out(enc, d_enc, n * 8));
     return ctx->sync_if_host();
@@ -1743,7 +1775,7 @@ extern "C" int zkw_callstack_simulate(zkw_ctx* ctx, const uint8_t* is_push, size
     u64 *d_prefix = nullptr, *d_totals = nullptr;
     ZKW_TRY(ctx->scratch_t<u64>("st_prefix", 2 * (n_ops + 1), &d_prefix));
     ZKW_TRY(ctx->scratch_t<u64>("st_totals", 2, &d_totals));
-    HIP_TRY(hipMemsetAsync(d_meta, 0, 4 * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx->memset_async(d_meta, 0, 4 * sizeof(u32)));
     ZKW_TRY((sum_prefix<2>(ctx, "k_stack_prefix", StackDelta{d_ops}, n_ops, d_prefix, d_totals)));
     { Prof _p(ctx, "k_stack_depth"); hipLaunchKernelGGL(k_stack_depth, dim3(blocks_for(n_ops, 256)), dim3(256), 0, ctx->stream, d_ops, n_ops, d_prefix, d_depth, d_rank, d_meta); }
     ZKW_TRY(launch_check("k_stack_depth"));
@@ -1758,7 +1790,7 @@ extern "C" int zkw_callstack_simulate(zkw_ctx* ctx, const uint8_t* is_push, size
         ZKW_TRY(launch_check("k_stack_push_keys"));
         unsigned bits = 1;
         while ((1ull << bits) <= max_depth) bits++;
-        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, d_pd, d_sd, d_pid, d_sid, n_push, bits, ctx->stream)); }
+        { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u32>(ctx, tmp, tmp_bytes, d_pd, d_sd, d_pid, d_sid, n_push, bits)); }
     }
     { Prof _p(ctx, "k_stack_links"); hipLaunchKernelGGL(k_stack_links, dim3(grid), dim3(256), 0, ctx->stream, d_ops, n_ops, d_depth, d_rank, d_sd, d_sid, d_meta, d_parent, d_node); }
     ZKW_TRY(launch_check("k_stack_links"));
@@ -1823,15 +1855,15 @@ extern "C" int zkw_vm_slice_instances(zkw_ctx* ctx, const zkw_vm_tracer_streams*
         ZKW_TRY(ctx->out("vm_ri", memory_read_index, n_mem, &d_ri));
         ZKW_TRY(ctx->out("vm_wi", memory_write_index, n_mem, &d_wi));
     }
-    { Prof _p(ctx, "k_vm_rw_tile_counts"); hipLaunchKernelGGL(k_vm_rw_tile_counts, dim3(n_tiles), dim3(256), 0, ctx->stream, job.s.vm_memory_queries, (u64)n_mem, d_tiles); }
+    { Prof _p(ctx, "k_vm_rw_tile_counts"); ZKW_LAUNCH(ctx, k_vm_rw_tile_counts, n_tiles, 256, job.s.vm_memory_queries, (u64)n_mem, d_tiles); }
     ZKW_TRY(launch_check("k_vm_rw_tile_counts"));
-    { Prof _p(ctx, "k_vm_rw_scan_tiles"); hipLaunchKernelGGL(k_vm_rw_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, d_tiles, n_tiles, d_total); }
+    { Prof _p(ctx, "k_vm_rw_scan_tiles"); ZKW_LAUNCH(ctx, k_vm_rw_scan_tiles, 1, 1024, d_tiles, n_tiles, d_total); }
     ZKW_TRY(launch_check("k_vm_rw_scan_tiles"));
-    { Prof _p(ctx, "k_vm_rw_scatter"); hipLaunchKernelGGL(k_vm_rw_scatter, dim3(n_tiles), dim3(256), 0, ctx->stream, job.s.vm_memory_queries, (u64)n_mem, d_tiles, d_prefix, d_ri, d_wi); }
+    { Prof _p(ctx, "k_vm_rw_scatter"); ZKW_LAUNCH(ctx, k_vm_rw_scatter, n_tiles, 256, job.s.vm_memory_queries, (u64)n_mem, d_tiles, d_prefix, d_ri, d_wi); }
     ZKW_TRY(launch_check("k_vm_rw_scatter"));
     job.read_prefix = d_prefix;
     ZKW_TRY(ctx->out("vm_inst", instances, n_inst, &job.out));
-    { Prof _p(ctx, "k_vm_slice"); hipLaunchKernelGGL(k_vm_slice, dim3(blocks_for(n_inst, 64)), dim3(64), 0, ctx->stream, job); }
+    { Prof _p(ctx, "k_vm_slice"); ZKW_LAUNCH(ctx, k_vm_slice, blocks_for(n_inst, 64), 64, job); }
     ZKW_TRY(launch_check("k_vm_slice"));
     ZKW_TRY(ctx->finish_out(instances, job.out, n_inst));
     if (memory_read_index) {

@@ -28,6 +28,8 @@
 #include <vector>
 
 #include "../../include/zkw.h"
+#include "zkw_batch.h"     // K blocks as fibers of one thread (zkw_blocks_run)
+#include "zkw_internal.h"  // a context inside a batch
 
 namespace {
 
@@ -80,6 +82,7 @@ struct PerType {
 enum { X_MAIN = 0, X_LOG, X_STO, X_EVT, X_L1, X_RAM, X_DEC, N_XFER };
 struct Xfer {
     zkw_ctx* c = nullptr;  // any context of the block: names the device for the library's buffer / stream caches
+    zkw_batch* batch = nullptr;  // the block runs as fibers of a batch: copies are queued with it (small) or go straight onto its stream (large)
     hipStream_t st = nullptr;
     void* pin = nullptr;
     size_t cap = 0;
@@ -96,6 +99,10 @@ struct Xfer {
     }
     Status d2h(void* dst, const void* src, size_t bytes) {
         if (!bytes) return Status();
+        if (batch) {
+            zkw_batch_copy_d2h(batch, dst, src, bytes);
+            return from_rc(zkw_batch_sync(batch));
+        }
         ST_TRY(reserve(bytes));
         ST_HIP(hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, st));
         ST_HIP(hipStreamSynchronize(st));
@@ -104,6 +111,13 @@ struct Xfer {
     }
     Status h2d(void* dst, const void* src, size_t bytes) {
         if (!bytes) return Status();
+        if (batch) {
+            // small: captured into the batch's upload arena and copied on the device; large (a block's queues): straight onto the batch's
+            // stream — the destination is a fresh buffer nothing queued before touches, and everything queued after this call runs after it
+            if (bytes <= ((size_t)64 << 10)) zkw_batch_copy_h2d(batch, dst, src, bytes);
+            else ST_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, zkw_batch_stream(batch)));
+            return Status();
+        }
         ST_TRY(reserve(bytes));
         memcpy(pin, src, bytes);
         ST_HIP(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, st));
@@ -112,6 +126,7 @@ struct Xfer {
     }
     void destroy() {
         if (st) zkw_stream_release(c, st);
+        st = nullptr;
         if (pin) zkw_buffer_free(1, pin);
         for (void* q : retired) zkw_buffer_free(1, q);
     }
@@ -121,6 +136,8 @@ struct Xfer {
 
 struct zkw_block {
     int device = 0;
+    zkw_batch* batch = nullptr;  // set while the block's builders run as fibers of zkw_blocks_run's batch
+    bool from_batch = false;     // its contexts have no stream of their own: they sit on the device's shared stream between calls
     zkw_ctx* ctx[N_CTX] = {};
     Xfer xf[N_XFER];
     uint32_t cap[14] = {};
@@ -191,6 +208,33 @@ struct Timed {
     ~Timed() { b->span(name, a); }
 };
 
+// A branch of the builder graph: a host thread (zkw_block_run) or — the block being one of a batch — a fiber of the batch's thread.
+struct Branch {
+    std::future<Status> fut;
+    std::shared_ptr<Status> st;
+    zkw_batch* batch = nullptr;
+    int fiber = -1;
+    Status get() {
+        if (!batch) return fut.get();
+        if (fiber < 0) return Status{ZKW_ERR_OOM, "zkw_batch: a builder branch could not be started"};
+        (void)zkw_batch_join(batch, fiber);
+        return *st;
+    }
+};
+template <class F>
+Branch start_branch(zkw_block* B, F f) {
+    Branch b;
+    if (B->batch) {
+        b.batch = B->batch;
+        b.st = std::make_shared<Status>();
+        std::shared_ptr<Status> st = b.st;
+        b.fiber = zkw_batch_spawn(B->batch, [st, f]() { *st = f(); return st->rc; });  // (what the caller has queued so far runs first)
+    } else {
+        b.fut = std::async(std::launch::async, f);
+    }
+    return b;
+}
+
 // ---- branch: log demuxer, then the three sorters (each on its own thread) --------------------------------------
 Status storage_branch(zkw_block* B, const zkw_block_inputs* in, const zkw_log_query* d_q, size_t n) {
     ST_HIP(hipSetDevice(B->device));
@@ -259,9 +303,11 @@ Status log_branch(zkw_block* B, const zkw_block_inputs* in) {
     const zkw_log_query* d_out = static_cast<const zkw_log_query*>(zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_OUT_QUERIES));
     auto q = [&](int k) { return d_out + B->dmx_off[k]; };
     auto nq = [&](int k) { return (size_t)(B->dmx_off[k + 1] - B->dmx_off[k]); };
-    auto f_sto = std::async(std::launch::async, storage_branch, B, in, q(0), nq(0));
-    auto f_evt = std::async(std::launch::async, events_branch, B, 0, q(1), nq(1));
-    auto f_l1 = std::async(std::launch::async, events_branch, B, 1, q(2), nq(2));
+    const zkw_log_query *q0 = q(0), *q1 = q(1), *q2 = q(2);
+    const size_t n0 = nq(0), n1 = nq(1), n2 = nq(2);
+    auto f_sto = start_branch(B, [=] { return storage_branch(B, in, q0, n0); });
+    auto f_evt = start_branch(B, [=] { return events_branch(B, 0, q1, n1); });
+    auto f_l1 = start_branch(B, [=] { return events_branch(B, 1, q2, n2); });
     Status s0 = f_sto.get(), s1 = f_evt.get(), s2 = f_l1.get();
     if (!s0.ok()) return s0;
     if (!s1.ok()) return s1;
@@ -292,6 +338,10 @@ std::string key32(const uint32_t* h) { return std::string(reinterpret_cast<const
 Status run(zkw_block* B, const zkw_block_inputs* in) {
     ST_HIP(hipSetDevice(B->device));
     for (int i = 0; i < N_CTX; i++) {
+        if (B->batch) {  // no stream, no chain service: what the context launches travels with the batch (device pointers)
+            B->ctx[i] = zkw_ctx_create_in_batch(B->device, B->batch);
+            continue;
+        }
         B->ctx[i] = zkw_create(B->device);
         if (!B->ctx[i]) return from_rc(ZKW_ERR_NO_DEVICE);
         ST_ZKW(zkw_set_pointer_mode(B->ctx[i], ZKW_PTR_DEVICE));
@@ -302,6 +352,8 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
     for (int i = 0; i < N_XFER; i++) {
         void* st = nullptr;
         B->xf[i].c = B->ctx[0];
+        B->xf[i].batch = B->batch;
+        if (B->batch) continue;
         ST_ZKW(zkw_stream_acquire(B->ctx[0], &st));
         B->xf[i].st = static_cast<hipStream_t>(st);
         ST_TRY(B->xf[i].reserve(i == X_MAIN || i == X_LOG ? (size_t)8 << 20 : (size_t)1 << 20));
@@ -312,7 +364,7 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
         B->cap[t] = in->capacities[t] ? in->capacities[t] : g.capacity;
     }
     // the log branch does not depend on anything else: start it first
-    auto f_log = std::async(std::launch::async, log_branch, B, in);
+    auto f_log = start_branch(B, [=] { return log_branch(B, in); });
 
     // 1. decommit sorter, contents only: the deduplicated requests fix which code words enter the memory queue
     zkw_decommit_query* d_dq = nullptr;
@@ -326,7 +378,7 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
         ST_TRY(B->xf[X_MAIN].d2h(dedup.data(), zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_QUERIES),
                          dedup.size() * sizeof(zkw_decommit_query))); }
     }
-    auto f_dec = std::async(std::launch::async, dec_finish_branch, B);  // its three chains run next to everything below
+    auto f_dec = start_branch(B, [=] { return dec_finish_branch(B); });  // its three chains run next to everything below
 
     // 2. the whole memory queue: VM | code words in the order of the deduplicated queue | keccak256 | sha256 | ecrecover
     std::vector<uint32_t> words;
@@ -373,7 +425,8 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
         ST_ZKW(zkw_decommitter_memory_queries(B->ctx[C_PRE], d_dedup, dedup.size(), d_words, woff.data(), B->d_all_mem + B->mem_off[1]));
         ST_ZKW(zkw_synchronize(B->ctx[C_PRE]));
     }
-    auto f_ram = std::async(std::launch::async, ram_branch, B, in, &d_tails);
+    const uint64_t** pp_tails = &d_tails;
+    auto f_ram = start_branch(B, [=] { return ram_branch(B, in, pp_tails); });
 
     Status s_ram = f_ram.get(), s_dec = f_dec.get(), s_log = f_log.get();
     ST_TRY(s_ram);
@@ -591,9 +644,13 @@ extern "C" int zkw_block_run(int device_id, const zkw_block_inputs* in, zkw_bloc
 
 extern "C" const char* zkw_block_last_error(void) { return g_block_error.c_str(); }
 
-// K blocks at once: one host thread per block runs the same dependency graph, every context opted into the device's chain
-// service, so that the blocks' queue chains — the only long-running work — share a few launches (csrc/zkw_api.hip, "chain
-// service") instead of queueing behind each other on HIP's hardware queues. Throughput of whole blocks, not latency of one.
+// K blocks at once. The blocks' builder graphs run as FIBERS of the calling thread (zkw_batch.h): no thread and no stream per block; a
+// context of a block launches nothing itself, and whenever no fiber can go on the launches they left travel merged — one launch per kernel
+// and stage over all K blocks, the queue chains of a stage as one chain launch on a high-priority stream. The builder code is
+// zkw_block_run's, the kernels' bodies are the same (zkw_launch.h), so every block's results are what zkw_block_run gives for it alone.
+// Throughput of whole blocks, not latency of one. (ZKW_BLOCKS_THREADS=1: round 5's schedule — a host thread per block and branch, the
+// chain service batching the chains — kept as the baseline profiles/r06 compares against.)
+static int blocks_run_threads(int device_id, const zkw_block_inputs* const* inputs, size_t n_blocks, zkw_block** out);
 extern "C" int zkw_blocks_run(int device_id, const zkw_block_inputs* const* inputs, size_t n_blocks, zkw_block** out) {
     if (!inputs || !out || n_blocks == 0) return ZKW_ERR_INVALID;
     for (size_t k = 0; k < n_blocks; k++) {
@@ -601,6 +658,50 @@ extern "C" int zkw_blocks_run(int device_id, const zkw_block_inputs* const* inpu
         if (!inputs_valid(in)) return ZKW_ERR_INVALID;
         out[k] = nullptr;
     }
+    static const bool threads = [] { const char* e = getenv("ZKW_BLOCKS_THREADS"); return e && e[0] == '1'; }();
+    if (threads) return blocks_run_threads(device_id, inputs, n_blocks, out);
+    if (hipSetDevice(device_id) != hipSuccess) return ZKW_ERR_HIP;
+    zkw_batch* batch = zkw_batch_create(device_id);
+    if (!batch) { g_block_error = zkw_last_error(); return ZKW_ERR_HIP; }
+    std::vector<zkw_block*> blocks(n_blocks, nullptr);
+    std::vector<std::function<int()>> roots;
+    const Clock::time_point t0 = Clock::now();
+    for (size_t k = 0; k < n_blocks; k++) {
+        zkw_block* B = new zkw_block();
+        B->device = device_id;
+        B->t0 = t0;
+        B->batch = batch;
+        B->use_chain_service = false;
+        blocks[k] = B;
+        const zkw_block_inputs* in = inputs[k];
+        roots.push_back([B, in]() -> int {
+            Timed t(B, "builders");
+            Status s = run(B, in);
+            if (!s.ok()) (void)zkw_fail(s.rc, "%s", s.msg.c_str());
+            return s.rc;
+        });
+    }
+    const int rc = zkw_batch_run(batch, roots);
+    // the contexts leave the batch: ordinary contexts on the device's shared stream from here on (synthesis moves them to its workers' streams)
+    void* shared = zkw_device_shared_stream(device_id);
+    for (zkw_block* B : blocks) {
+        B->batch = nullptr;
+        B->from_batch = true;
+        for (int i = 0; i < N_XFER; i++) B->xf[i].batch = nullptr;
+        for (int i = 0; i < N_CTX; i++)
+            if (B->ctx[i]) zkw_ctx_leave_batch(B->ctx[i], shared);
+    }
+    if (rc != ZKW_OK) g_block_error = zkw_last_error();
+    zkw_batch_destroy(batch);  // (waits for the batch's streams; its arenas go back to the allocation cache)
+    if (rc != ZKW_OK || !shared) {
+        for (zkw_block* B : blocks) zkw_block_free(B);
+        return rc != ZKW_OK ? rc : ZKW_ERR_HIP;
+    }
+    for (size_t k = 0; k < n_blocks; k++) out[k] = blocks[k];
+    return ZKW_OK;
+}
+
+static int blocks_run_threads(int device_id, const zkw_block_inputs* const* inputs, size_t n_blocks, zkw_block** out) {
     std::vector<zkw_block*> blocks(n_blocks, nullptr);
     std::vector<std::future<Status>> futs;
     const Clock::time_point t0 = Clock::now();
@@ -805,13 +906,17 @@ extern "C" int zkw_block_synthesize(zkw_block* B, size_t n_rows, size_t ring_slo
     return zkw_block_synthesize_sharded(B, n_rows, ring_slots, 0, 1, cb, user, n_done);
 }
 
-static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type);
+static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type,
+                                 zkw_trace* callers_ring);
 extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb,
                                             void* user, size_t* n_done) {
-    return block_synthesize_impl(B, n_rows, ring_slots, rank, world, cb, user, n_done, -1);
+    return block_synthesize_impl(B, n_rows, ring_slots, rank, world, cb, user, n_done, -1, nullptr);
 }
-// skip_type: a circuit type whose instances somebody else synthesizes (zkw_blocks_synthesize: ECRecover of all blocks in joint calls)
-static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type) {
+// skip_type: a circuit type whose instances somebody else synthesizes (zkw_blocks_synthesize: ECRecover of all blocks in joint calls);
+// callers_ring: a ring of `ring_slots` slots of 153 columns the caller owns (zkw_blocks_synthesize: one per worker, not one per block —
+// at 1.28 GB a slot, a ring per block capped the blocks in flight at ~150), else the block's own, created on first use
+static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type,
+                                 zkw_trace* callers_ring) {
     if (!B || n_rows == 0 || ring_slots == 0 || world < 1 || rank < 0 || rank >= world) return ZKW_ERR_INVALID;
     std::vector<uint8_t> plan_types;
     std::vector<uint32_t> plan_index, plan_owner;
@@ -828,12 +933,12 @@ static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots,
     }
     auto owned = [&](int t, size_t inst) { return inst < owner_of[t].size() && owner_of[t][inst] == rank; };
     if (hipSetDevice(B->device) != hipSuccess) return ZKW_ERR_HIP;
-    if (B->ring && (B->ring_rows != n_rows || B->ring_slots != ring_slots)) {
+    if (!callers_ring && B->ring && (B->ring_rows != n_rows || B->ring_slots != ring_slots)) {
         zkw_trace_free(B->ring);
         B->ring = nullptr;
     }
     int rc = ZKW_OK;
-    if (!B->ring) {
+    if (!callers_ring && !B->ring) {
         if ((rc = zkw_trace_create_with_columns(B->ctx[C_RAM], n_rows, 153, ring_slots, &B->ring)) != ZKW_OK) return rc;
         B->ring_rows = n_rows;
         B->ring_slots = ring_slots;
@@ -844,7 +949,7 @@ static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots,
         if (t == skip_type) continue;
         const size_t ni = zkw_block_num_instances(B, (uint8_t)t);
         zkw_ctx* c = zkw_block_context(B, (uint8_t)t);
-        zkw_trace* ring = B->ring;
+        zkw_trace* ring = callers_ring ? callers_ring : B->ring;
 
         for (size_t first = 0; first < ni;) {
             // a maximal run of consecutive instances this rank owns (world == 1: all of them), at most one ring
@@ -943,22 +1048,37 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
         zkw_trace_free(ring);
         zkw_destroy(c);
     });
-    // (2) everything else, block by block on a few threads
+    // (2) everything else, block by block on a few threads; a worker has ONE ring and ONE stream for all the blocks it takes
     std::atomic<size_t> next{0};
     std::vector<std::thread> pool;
     static const size_t max_threads = [] { const char* e = getenv("ZKW_SYNTH_THREADS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 ? v : 8); }();
     const size_t n_threads = std::min<size_t>(max_threads, n_blocks);
     for (size_t th = 0; th < n_threads; th++)
         pool.emplace_back([&] {
+            if (hipSetDevice(blocks[0]->device) != hipSuccess) { note(ZKW_ERR_HIP); return; }
+            zkw_ctx* wc = zkw_create(blocks[0]->device);
+            if (!wc) { note(ZKW_ERR_NO_DEVICE); return; }
+            zkw_trace* ring = nullptr;
+            int rc = zkw_trace_create_with_columns(wc, n_rows, 153, ring_slots, &ring);
+            void* shared = zkw_device_shared_stream(blocks[0]->device);
+            if (rc != ZKW_OK || !shared) { note(rc != ZKW_OK ? rc : ZKW_ERR_HIP); if (ring) zkw_trace_free(ring); zkw_destroy(wc); return; }
             for (;;) {
                 const size_t b = next.fetch_add(1);
-                if (b >= n_blocks || first_rc.load() != ZKW_OK) return;
+                if (b >= n_blocks || first_rc.load() != ZKW_OK) break;
+                zkw_block* B = blocks[b];
                 Fwd f{b, cb, user};
                 size_t n = 0;
-                const int rc = block_synthesize_impl(blocks[b], n_rows, ring_slots, 0, 1, fwd, &f, &n, T_ECR);
+                // a block built by a batch has no streams of its own: its contexts work on this worker's stream meanwhile
+                if (B->from_batch)
+                    for (int i = 0; i < N_CTX && rc == ZKW_OK; i++) rc = zkw_set_stream(B->ctx[i], zkw_ctx_stream(wc));
+                if (rc == ZKW_OK) rc = block_synthesize_impl(B, n_rows, ring_slots, 0, 1, fwd, &f, &n, T_ECR, ring);
+                if (B->from_batch)
+                    for (int i = 0; i < N_CTX; i++) { const int r2 = zkw_set_stream(B->ctx[i], shared); if (rc == ZKW_OK) rc = r2; }
                 done += n;
-                if (rc != ZKW_OK) note(rc);
+                if (rc != ZKW_OK) { note(rc); break; }
             }
+            zkw_trace_free(ring);
+            zkw_destroy(wc);
         });
     for (auto& t : pool) t.join();
     ec_thread.join();

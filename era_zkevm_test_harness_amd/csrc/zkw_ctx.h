@@ -24,6 +24,7 @@
 
 #include "../../include/zkw.h"
 #include "zkw_internal.h"
+#include "zkw_batch.h"
 #include "ram_kernels.cuh"
 #include "log_kernels.cuh"
 #include "../../include/zkw_ram_circuit_spec.h"  // RC_COLS: the default width of a trace
@@ -74,6 +75,28 @@ struct zkw_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int ptr_mode = ZKW_PTR_HOST;
+    // a context of a block that runs inside a batch (zkw_blocks_run, zkw_batch.h): launches, memsets, copies and waits on `stream` are
+    // queued with the batch / park the calling fiber instead of reaching HIP; `stream` is then the batch's stream (not owned)
+    zkw_batch* batch = nullptr;
+    bool batched() const { return batch && zkw_batch_in_fiber(batch); }
+    hipError_t memset_async(void* p, int value, size_t bytes) {
+        if (batched()) { zkw_batch_memset(batch, p, value, bytes); return hipSuccess; }
+        return hipMemsetAsync(p, value, bytes, stream);
+    }
+    hipError_t copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+        if (batched()) {
+            if (kind == hipMemcpyDeviceToDevice) zkw_batch_copy_d2d(batch, dst, src, bytes);
+            else if (kind == hipMemcpyHostToDevice) zkw_batch_copy_h2d(batch, dst, src, bytes);
+            else if (kind == hipMemcpyDeviceToHost) zkw_batch_copy_d2h(batch, dst, src, bytes);
+            else return hipErrorInvalidValue;
+            return hipSuccess;
+        }
+        return hipMemcpyAsync(dst, src, bytes, kind, stream);
+    }
+    hipError_t sync_stream() {
+        if (batched()) return zkw_batch_sync(batch) == ZKW_OK ? hipSuccess : hipErrorUnknown;
+        return hipStreamSynchronize(stream);
+    }
     hipStream_t chain_stream = nullptr;  // optional second stream for the queue-chain kernels (zkw_set_chain_stream)
     hipEvent_t chain_ev_a = nullptr, chain_ev_b = nullptr;
     // a lazily created side stream for work that depends on nothing the main stream is about to write (the closed-form sponges of the
@@ -166,6 +189,10 @@ struct zkw_ctx {
     // runtime before return)
     template <class T>
     int upload(const char* name, const std::vector<T>& h, T** out) {
+        if (batched()) {  // the batch's upload arena: captured now, on the device before anything queued after this call runs
+            *out = static_cast<T*>(zkw_batch_upload(batch, h.data(), h.size() * sizeof(T), alignof(T) > 16 ? alignof(T) : 16));
+            return *out ? ZKW_OK : ZKW_ERR_OOM;
+        }
         ZKW_TRY(scratch_t<T>(name, h.size() ? h.size() : 1, out));
         if (h.empty()) return ZKW_OK;
         const size_t bytes = h.size() * sizeof(T);
@@ -197,7 +224,7 @@ struct zkw_ctx {
         }
         T* d = nullptr;
         ZKW_TRY(scratch_t<T>(name, count, &d));
-        HIP_TRY(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIP_TRY(copy_async(d, src, count * sizeof(T), hipMemcpyHostToDevice));
         *out = d;
         return ZKW_OK;
     }
@@ -213,11 +240,11 @@ struct zkw_ctx {
     template <class T>
     int finish_out(T* dst, const T* dev, size_t count) {
         if (ptr_mode == ZKW_PTR_DEVICE || count == 0) return ZKW_OK;
-        HIP_TRY(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(copy_async(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost));
         return ZKW_OK;
     }
     int sync_if_host() {
-        if (ptr_mode == ZKW_PTR_HOST) HIP_TRY(hipStreamSynchronize(stream));
+        if (ptr_mode == ZKW_PTR_HOST) HIP_TRY(sync_stream());
         return ZKW_OK;
     }
     // Small device -> host readback (counts, violation flags) THROUGH PINNED MEMORY, then a sync of this stream only.
@@ -226,6 +253,10 @@ struct zkw_ctx {
     void* pinned_rb = nullptr;
     size_t pinned_rb_cap = 0;
     int read_small(void* dst, const void* src, size_t bytes) {
+        if (batched()) {  // one gather + one copy for all the blocks of the batch that read something back at this point
+            zkw_batch_copy_d2h(batch, dst, src, bytes);
+            return zkw_batch_sync(batch);
+        }
         if (pinned_rb_cap < bytes) {
             if (pinned_rb) retired_host.push_back(pinned_rb);
             pinned_rb = nullptr;
@@ -249,7 +280,7 @@ struct Prof {
     zkw_ctx* c;
     hipEvent_t b = nullptr;
     Prof(zkw_ctx* ctx, const char* name) : c(ctx) {
-        if (!c->profiling) return;
+        if (!c->profiling || c->batched()) return;
         hipEvent_t a = c->prof_event();
         b = c->prof_event();
         (void)hipEventRecord(a, c->stream);
@@ -265,6 +296,29 @@ static inline int launch_check(const char* what) {
     if (e != hipSuccess) return fail(ZKW_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
     return ZKW_OK;
 }
+
+// Launch of a kernel BODY (zkw_launch.h) with a grid of gx x gy workgroups of BS threads: on the context's stream, or — a context of a
+// batch — left with the batch to travel with the other blocks' launches of the same kernel. Arguments convert to the body's parameter types.
+template <auto Body, int BS>
+struct Launcher {
+    using S = LaunchSig<decltype(Body)>;
+    template <class... A>
+    static int go(zkw_ctx* ctx, const char* name, unsigned gx, unsigned gy, const A&... a) {
+        if (gx == 0 || gy == 0) return ZKW_OK;
+        if (ctx->batched()) {
+            typename S::T t;
+            S::pack(t, a...);
+            zkw_batch_launch(ctx->batch, S::template desc<Body, BS>(name), gx, gy, &t);
+            return ZKW_OK;
+        }
+        S::template single<Body, BS>(ctx->stream, gx, gy, a...);  // (timed by the caller's Prof, if any)
+        return launch_check(name);
+    }
+};
+#define ZKW_LAUNCH(ctx, kernel, gx, bs, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, #kernel, (unsigned)(gx), 1u, __VA_ARGS__)))
+#define ZKW_LAUNCH_2D(ctx, kernel, gx, gy, bs, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, #kernel, (unsigned)(gx), (unsigned)(gy), __VA_ARGS__)))
+// the same for a template kernel (the name has commas): ZKW_LAUNCH_T(ctx, (k_foo<A, B>), "k_foo", ...)
+#define ZKW_LAUNCH_T(ctx, kernel, name, gx, bs, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, name, (unsigned)(gx), 1u, __VA_ARGS__)))
 
 // rows [0, width) of blockIdx.y's column of a column-major strip
 static __global__ __launch_bounds__(256) void k_zero_strip(u64* __restrict__ base, size_t pitch, size_t width) {
@@ -289,6 +343,8 @@ static inline int zero_netlist_slot(zkw_ctx* ctx, u64* trace, size_t n_rows, siz
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 void ctx_retain(zkw_ctx* ctx);
+zkw_ctx* zkw_ctx_create_in_batch(int device_id, zkw_batch* b);
+void zkw_ctx_leave_batch(zkw_ctx* ctx, void* stream);
 
 void ctx_release(zkw_ctx* ctx);
 
@@ -341,3 +397,6 @@ int dev_chains(zkw_ctx* ctx, const std::vector<ChainJob>& jobs);
 int dev_fs(zkw_ctx* ctx, const std::vector<FsJob>& jobs, int state_w, int n_chal);
 int dev_grand_products(zkw_ctx* ctx, std::vector<GpSeg>& segs, int width, int n_reps);
 int dev_log_chains(zkw_ctx* ctx, const u64* d_enc, size_t total, std::vector<LogChainJob>& jobs);
+// the chain launches as the chain service and the batch make them (row forms up to 4 096 chains, the quad form above)
+int zkw_launch_chain_full(hipStream_t st, const ChainJob* d_jobs, int n_jobs);
+int zkw_launch_chain_log(hipStream_t st, const LogChainJob* d_jobs, int n_jobs);

@@ -12,7 +12,7 @@
 #include "netlist_queue_kernels.cuh"
 #include "netlist_closed_form_kernels.cuh"
 #include "ecrecover_kernels.cuh"
-#include "sort.h"
+#include "radix_sort.cuh"
 
 // ------------------------------------------------------------------------------------------------ code decommitter
 struct zkw_decommitter_witness {
@@ -56,7 +56,7 @@ extern "C" int zkw_decommitter_memory_queries(zkw_ctx* ctx, const zkw_decommit_q
     ZKW_TRY(ctx->out("dcm_mq_out", out, total, &d_out));
     DecommitterJob job{d_req, d_words, d_woff, nullptr, nullptr, d_out, nullptr, nullptr, n_requests, nullptr};
     if (total) {
-        { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, job, (u64)total); }
+        { Prof _p(ctx, "k_decommitter_mem_queries"); ZKW_LAUNCH(ctx, k_decommitter_mem_queries, blocks_for(total, 256), 256, job, (u64)total); }
         ZKW_TRY(launch_check("k_decommitter_mem_queries"));
     }
     ZKW_TRY(ctx->finish_out(out, d_out, total));
@@ -109,21 +109,20 @@ extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit
     if (rc == ZKW_OK) rc = ctx->upload("dcm_roff", roff, &d_roff);
     if (rc == ZKW_OK) rc = ctx->scratch_t<u32>("dcm_viol", 1, &d_viol);
     if (rc != ZKW_OK) return bail(rc);
-    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
-    if (hipMemcpyAsync(w->requests, d_req, n_requests * sizeof(zkw_decommit_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(w->dedup_tails, d_dt, n_requests * 96, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+    if (ctx->memset_async(d_viol, 0, 4) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
+    if (ctx->copy_async(w->requests, d_req, n_requests * sizeof(zkw_decommit_query), hipMemcpyDeviceToDevice) != hipSuccess ||
+        ctx->copy_async(w->dedup_tails, d_dt, n_requests * 96, hipMemcpyDeviceToDevice) != hipSuccess)
         return bail(fail(ZKW_ERR_HIP, "copy of the decommit requests failed"));
     DecommitterJob job{d_req, d_words, d_woff, d_roff, w->round_states, w->mem_q, w->mem_enc, d_viol, n_requests, w->sha256_rounds, w->round_ops};
-    { Prof _p(ctx, "k_decommitter_sha"); hipLaunchKernelGGL(k_decommitter_sha, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
+    { Prof _p(ctx, "k_decommitter_sha"); ZKW_LAUNCH(ctx, k_decommitter_sha, blocks_for(n_requests, 64), 64, job); }
     if ((rc = launch_check("k_decommitter_sha")) != ZKW_OK) return bail(rc);
-    { Prof _p(ctx, "k_decommitter_mem_queries"); hipLaunchKernelGGL(k_decommitter_mem_queries, dim3(blocks_for(w->total_words, 256)), dim3(256), 0, ctx->stream, job, (u64)w->total_words); }
+    { Prof _p(ctx, "k_decommitter_mem_queries"); ZKW_LAUNCH(ctx, k_decommitter_mem_queries, blocks_for(w->total_words, 256), 256, job, (u64)w->total_words); }
     if ((rc = launch_check("k_decommitter_mem_queries")) != ZKW_OK) return bail(rc);
     zkw_queue_state12* d_min = nullptr;
     std::vector<zkw_queue_state12> minv(1, *mem_in);
     if ((rc = ctx->upload("dcm_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
     if (given_mem_tails) {  // the caller has already hashed the memory queue this slice belongs to (zkw_block_run)
-        if (hipMemcpyAsync(w->mem_tails, given_mem_tails, w->total_words * 96,
-                           ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        if (ctx->copy_async(w->mem_tails, given_mem_tails, w->total_words * 96, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(ZKW_ERR_HIP, "copy of the given memory-queue states failed"));
     } else {
         std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, w->total_words});
@@ -140,7 +139,7 @@ extern "C" int zkw_decommitter_build_with_tails(zkw_ctx* ctx, const zkw_decommit
     blk[0].capacity = capacity;
     DecommitterBlock* d_blk = nullptr;
     if ((rc = ctx->upload("dcm_block", blk, &d_blk)) != ZKW_OK) return bail(rc);
-    { Prof _p(ctx, "k_decommitter_instances"); hipLaunchKernelGGL(k_decommitter_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    { Prof _p(ctx, "k_decommitter_instances"); ZKW_LAUNCH(ctx, k_decommitter_instances, blocks_for(w->n_instances, 64), 64, d_blk); }
     if ((rc = launch_check("k_decommitter_instances")) != ZKW_OK) return bail(rc);
     u32 viol = 0;
     if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
@@ -188,13 +187,13 @@ extern "C" int zkw_decommitter_witness_get(const zkw_decommitter_witness* w, int
     if (bytes == 0) return ZKW_OK;
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx->copy_async(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return ctx->sync_if_host();
 }
 extern "C" void zkw_decommitter_witness_free(zkw_decommitter_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)w->ctx->sync_stream();
     w->release();
     zkw_ctx* owner = w->ctx;
     delete w;
@@ -209,7 +208,7 @@ extern "C" int zkw_linear_keccak256(zkw_ctx* ctx, const zkw_log_query* messages,
     uint8_t* d_out = nullptr;
     ZKW_TRY(ctx->in("lk_q", messages, n, &d_q));
     ZKW_TRY(ctx->out("lk_out", hash_out, 32, &d_out));
-    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3(1), dim3(64), 0, ctx->stream, d_q, n, d_out, (zkw_keccak_round_record*)nullptr, (const u64*)nullptr, (const u64*)nullptr, false); }
+    { Prof _p(ctx, "k_linear_keccak256"); ZKW_LAUNCH(ctx, k_linear_keccak256, 1, 64, d_q, n, d_out, (zkw_keccak_round_record*)nullptr, (const u64*)nullptr, (const u64*)nullptr, false); }
     ZKW_TRY(launch_check("k_linear_keccak256"));
     ZKW_TRY(ctx->finish_out(hash_out, d_out, 32));
     return ctx->sync_if_host();
@@ -283,7 +282,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
         ZKW_TRY(ctx->scratch_t<u64>("pc_off", 3 * (n_requests + 1), &d_off));
         d_roff = d_off; d_qoff = d_off + (n_requests + 1); d_rdoff = d_off + 2 * (n_requests + 1);
         ZKW_TRY(ctx->scratch_t<u64>("pc_meta", 4, &d_meta));
-        HIP_TRY(hipMemsetAsync(d_meta, 0, 4 * sizeof(u64), ctx->stream));
+        HIP_TRY(ctx->memset_async(d_meta, 0, 4 * sizeof(u64)));
         ZKW_TRY((sum_prefix<3>(ctx, "k_precompile_counts", PrecompileShape{kind, d_req, reinterpret_cast<u32*>(d_meta + 3)}, n_requests, d_off, d_meta)));
         ZKW_TRY(ctx->read_small(meta, d_meta, sizeof meta));
         if (meta[3]) return fail(ZKW_ERR_INVALID, "a precompile request without rounds (the first round carries `new_request`)");
@@ -317,7 +316,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
     PrecompileSnap* d_snaps = nullptr;
     u32* d_viol = nullptr;
     if ((rc = ctx->scratch_t<u32>("pc_viol", 1, &d_viol)) != ZKW_OK) return bail(rc);
-    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
+    if (ctx->memset_async(d_viol, 0, 4) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
     if (n_requests) {
         if ((rc = ctx->scratch_t<PrecompileSnap>("pc_snaps", w->n_instances, &d_snaps)) != ZKW_OK) return bail(rc);
         if (n_queries) {
@@ -326,20 +325,19 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
             std::vector<zkw_queue_state12> minv(1, *mem_in);
             if ((rc = ctx->upload("pc_mem_in", minv, &d_min)) != ZKW_OK) return bail(rc);
             if (given_mem_tails) {  // already hashed by the caller as part of the whole memory queue (zkw_block_run)
-                if (hipMemcpyAsync(w->mem_tails, given_mem_tails, n_queries * 96,
-                                   ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                if (ctx->copy_async(w->mem_tails, given_mem_tails, n_queries * 96, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess)
                     return bail(fail(ZKW_ERR_HIP, "copy of the given memory-queue states failed"));
             } else {
                 std::vector<ChainJob> chains(1, ChainJob{w->mem_enc, w->mem_tails, d_min->tail, n_queries});
                 if ((rc = dev_chains(ctx, chains)) != ZKW_OK) return bail(rc);
             }
         }
-        if ((hipMemcpyAsync(w->requests, d_req, n_requests * sizeof(zkw_log_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-             hipMemcpyAsync(w->req_tails, d_rt, n_requests * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-             (n_queries && hipMemcpyAsync(w->mem_q, d_mq, n_queries * sizeof(zkw_mem_query), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)))
+        if ((ctx->copy_async(w->requests, d_req, n_requests * sizeof(zkw_log_query), hipMemcpyDeviceToDevice) != hipSuccess ||
+             ctx->copy_async(w->req_tails, d_rt, n_requests * 32, hipMemcpyDeviceToDevice) != hipSuccess ||
+             (n_queries && ctx->copy_async(w->mem_q, d_mq, n_queries * sizeof(zkw_mem_query), hipMemcpyDeviceToDevice) != hipSuccess)))
             return bail(fail(ZKW_ERR_HIP, "copy of the precompile calls failed"));
         PrecompileJob job{kind, d_req, d_mq, d_roff, d_qoff, d_rdoff, d_snaps, d_viol, n_requests, w->total_rounds, capacity, w->keccak_rounds, w->sha256_rounds, w->round_ops};
-        { Prof _p(ctx, "k_precompile_walk"); hipLaunchKernelGGL(k_precompile_walk, dim3(blocks_for(n_requests, 64)), dim3(64), 0, ctx->stream, job); }
+        { Prof _p(ctx, "k_precompile_walk"); ZKW_LAUNCH(ctx, k_precompile_walk, blocks_for(n_requests, 64), 64, job); }
         if ((rc = launch_check("k_precompile_walk")) != ZKW_OK) return bail(rc);
     }
     std::vector<PrecompileBlock> blk(1);
@@ -355,7 +353,7 @@ extern "C" int zkw_precompile_build_with_tails(zkw_ctx* ctx, int kind, const zkw
     blk[0].capacity = capacity;
     PrecompileBlock* d_blk = nullptr;
     if ((rc = ctx->upload("pc_block", blk, &d_blk)) != ZKW_OK) return bail(rc);
-    { Prof _p(ctx, "k_precompile_instances"); hipLaunchKernelGGL(k_precompile_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    { Prof _p(ctx, "k_precompile_instances"); ZKW_LAUNCH(ctx, k_precompile_instances, blocks_for(w->n_instances, 64), 64, d_blk); }
     if ((rc = launch_check("k_precompile_instances")) != ZKW_OK) return bail(rc);
     u32 viol = 0;
     if (ctx->read_small(&viol, d_viol, 4) != ZKW_OK)
@@ -403,13 +401,13 @@ extern "C" int zkw_precompile_witness_get(const zkw_precompile_witness* w, int w
     if (bytes == 0) return ZKW_OK;
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx->copy_async(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return ctx->sync_if_host();
 }
 extern "C" void zkw_precompile_witness_free(zkw_precompile_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)w->ctx->sync_stream();
     w->release();
     zkw_ctx* owner = w->ctx;
     delete w;
@@ -496,35 +494,35 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
     job.next_enumeration_index = initial_next_enumeration_index;
     memcpy(job.initial_root, initial_root, 32);
     job.capacity = capacity;
-    if (hipMemsetAsync(d_viol, 0, 4, ctx->stream) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
+    if (ctx->memset_async(d_viol, 0, 4) != hipSuccess) return bail(fail(ZKW_ERR_HIP, "memset failed"));
     u64 meta[2] = {1, initial_next_enumeration_index};
     if (n) {
         const unsigned g64 = blocks_for(n, 64);
-        { Prof _p(ctx, "k_sap_keys"); hipLaunchKernelGGL(k_sap_keys, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        { Prof _p(ctx, "k_sap_keys"); ZKW_LAUNCH(ctx, k_sap_keys, g64, 64, job); }
         TRY(launch_check("k_sap_keys"));
-        { Prof _p(ctx, "k_sap_scan"); hipLaunchKernelGGL(k_sap_scan, dim3(1), dim3(1024), 0, ctx->stream, job); }
+        { Prof _p(ctx, "k_sap_scan"); ZKW_LAUNCH(ctx, k_sap_scan, 1, 1024, job); }
         TRY(launch_check("k_sap_scan"));
-        { Prof _p(ctx, "k_sap_items"); hipLaunchKernelGGL(k_sap_items, dim3(g64), dim3(64), 0, ctx->stream, job, w->items); }
+        { Prof _p(ctx, "k_sap_items"); ZKW_LAUNCH(ctx, k_sap_items, g64, 64, job, w->items); }
         TRY(launch_check("k_sap_items"));
-        { Prof _p(ctx, "k_sap_pairs"); hipLaunchKernelGGL(k_sap_pairs, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        { Prof _p(ctx, "k_sap_pairs"); ZKW_LAUNCH(ctx, k_sap_pairs, g64, 64, job); }
         TRY(launch_check("k_sap_pairs"));
-        { Prof _p(ctx, "k_sap_leaves"); hipLaunchKernelGGL(k_sap_leaves, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        { Prof _p(ctx, "k_sap_leaves"); ZKW_LAUNCH(ctx, k_sap_leaves, g64, 64, job); }
         TRY(launch_check("k_sap_leaves"));
         static_assert(ZKW_STORAGE_TREE_DEPTH == 256, "k_sap_levels walks 256 levels");
         if (n <= SAP_PERSISTENT_MAX) {
             Prof _p(ctx, "k_sap_levels");
-            hipLaunchKernelGGL(k_sap_levels, dim3(1), dim3(SAP_PERSISTENT_THREADS), 0, ctx->stream, job);
+            ZKW_LAUNCH(ctx, k_sap_levels, 1, SAP_PERSISTENT_THREADS, job);
         } else {
             for (int L = 0; L < ZKW_STORAGE_TREE_DEPTH && rc == ZKW_OK; L++) {
                 Prof _p(ctx, "k_sap_level");
-                hipLaunchKernelGGL(k_sap_level, dim3(g64), dim3(64), 0, ctx->stream, job, L);
+                ZKW_LAUNCH(ctx, k_sap_level, g64, 64, job, L);
             }
         }
         TRY(launch_check("k_sap_level"));
-        { Prof _p(ctx, "k_sap_roots"); hipLaunchKernelGGL(k_sap_roots, dim3(g64), dim3(64), 0, ctx->stream, job); }
+        { Prof _p(ctx, "k_sap_roots"); ZKW_LAUNCH(ctx, k_sap_roots, g64, 64, job); }
         TRY(launch_check("k_sap_roots"));
         if (rc != ZKW_OK) return bail(rc);
-        if (hipMemcpyAsync(w->leaf_indexes, job.init_index, n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        if (ctx->copy_async(w->leaf_indexes, job.init_index, n * 8, hipMemcpyDeviceToDevice) != hipSuccess ||
             ctx->read_small(meta, d_meta, sizeof meta) != ZKW_OK)
             return bail(fail(ZKW_ERR_HIP, "readback failed"));
     }
@@ -532,7 +530,7 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
     if (dev_malloc((void**)&w->instances, w->n_instances * sizeof(zkw_storage_application_instance) + 64) != hipSuccess)
         return bail(fail(ZKW_ERR_OOM, "zkw_storage_application_build: hipMalloc failed"));
     SapKeccakOut ko{d_snap, d_hash};
-    { Prof _p(ctx, "k_sap_keccak"); hipLaunchKernelGGL(k_sap_keccak, dim3(1), dim3(64), 0, ctx->stream, job, ko); }
+    { Prof _p(ctx, "k_sap_keccak"); ZKW_LAUNCH(ctx, k_sap_keccak, 1, 64, job, ko); }
     TRY(launch_check("k_sap_keccak"));
     std::vector<SapBlock> blk(1);
     blk[0].job = job;
@@ -544,7 +542,7 @@ extern "C" int zkw_storage_application_build(zkw_ctx* ctx, const zkw_log_query* 
     SapBlock* d_blk = nullptr;
     TRY(ctx->upload("sap_block", blk, &d_blk));
     if (rc != ZKW_OK) return bail(rc);
-    { Prof _p(ctx, "k_sap_instances"); hipLaunchKernelGGL(k_sap_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    { Prof _p(ctx, "k_sap_instances"); ZKW_LAUNCH(ctx, k_sap_instances, blocks_for(w->n_instances, 64), 64, d_blk); }
     TRY(launch_check("k_sap_instances"));
     if (rc != ZKW_OK) return bail(rc);
     u32 viol = 0;
@@ -587,13 +585,13 @@ extern "C" int zkw_storage_application_witness_get(const zkw_storage_application
     if (bytes == 0) return ZKW_OK;
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx->copy_async(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return ctx->sync_if_host();
 }
 extern "C" void zkw_storage_application_witness_free(zkw_storage_application_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)w->ctx->sync_stream();
     w->release();
     zkw_ctx* owner = w->ctx;
     delete w;
@@ -1055,10 +1053,10 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
         u64* tr = claims.claim(inst[k].t, inst[k].slot, tag, &clean);
         jobs[k] = NlJob{prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before, inst[k].public_input, tr, d_keys + k * keys_n, d_hist + k * hist_n};
         if (!clean) {
-            HIP_TRY(hipMemsetAsync(tr, 0, (size_t)S.g * n_rows * sizeof(u64), ctx->stream));  // general-purpose columns
+            HIP_TRY(ctx->memset_async(tr, 0, (size_t)S.g * n_rows * sizeof(u64)));  // general-purpose columns
             hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - bnd + 255) / 256), S.mult_col - S.g), dim3(256), 0, ctx->stream, tr + (size_t)S.g * n_rows + bnd, n_rows, n_rows - bnd);
             ZKW_TRY(launch_check("k_zero_strip"));
-            HIP_TRY(hipMemsetAsync(tr + (size_t)S.mult_col * n_rows, 0, n_rows * sizeof(u64), ctx->stream));
+            HIP_TRY(ctx->memset_async(tr + (size_t)S.mult_col * n_rows, 0, n_rows * sizeof(u64)));
         }
     }
     NlJob* d_jobs = nullptr;
@@ -1223,8 +1221,8 @@ int nl_check(zkw_ctx* ctx, int circuit_type, const zkw_trace* t, size_t slot, u3
     ZKW_TRY(ctx->scratch_t<CheckResult>("check_res", 1, &d_res));
     ZKW_TRY(ctx->scratch_t<u32>("nl_check_hist", S.total_table_rows, &d_hist));
     CheckResult init{0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(d_res, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, S.total_table_rows * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx->copy_async(d_res, &init, sizeof init, hipMemcpyHostToDevice));
+    HIP_TRY(ctx->memset_async(d_hist, 0, S.total_table_rows * sizeof(u32)));
     { Prof _p(ctx, "k_nl_check_steps"); hipLaunchKernelGGL(k_nl_check_steps, dim3((nc->host.max_items + 255) / 256, capacity * S.steps_per_cycle), dim3(256), 0, ctx->stream, nc->dev, trace, capacity, n_rows, d_hist, d_res); }
     ZKW_TRY(launch_check("k_nl_check_steps"));
     u64 e_begin = 0, e_end = 0;
@@ -1352,7 +1350,7 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
     ZKW_TRY(ctx->scratch_t<u64>("ec_tape", ni * capacity * (size_t)EC_TAPE_PER_CYCLE, &d_tape));
     ZKW_TRY(ctx->scratch_t<uint8_t>("ec_inputs", ni * capacity * (size_t)128, &d_inputs));
     ZKW_TRY(ctx->scratch_t<u32>("ec_status", 1, &d_status));
-    HIP_TRY(hipMemsetAsync(d_status, 0, 4, ctx->stream));
+    HIP_TRY(ctx->memset_async(d_status, 0, 4));
     std::vector<EcJob> jobs(ni);
     EcJob* d_jobs = nullptr;
     const unsigned cb = (capacity + 1 + 63) / 64, nj = (unsigned)ni;
@@ -1563,9 +1561,9 @@ extern "C" int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx* ctx, const
     ZKW_TRY(ctx->scratch_t<uint8_t>("lh_hash", 32 * n_queues, &d_hash));
     ZKW_TRY(ctx->upload("lh_moff", moff, &d_moff));
     ZKW_TRY(ctx->upload("lh_roff", roff, &d_roff));
-    { Prof _p(ctx, "k_linear_blocks"); hipLaunchKernelGGL(k_linear_blocks, dim3(blocks_for(roff[n_queues] * 18, 256)), dim3(256), 0, ctx->stream, d_q, d_moff, d_roff, (u32)n_queues, d_rounds); }
+    { Prof _p(ctx, "k_linear_blocks"); ZKW_LAUNCH(ctx, k_linear_blocks, blocks_for(roff[n_queues] * 18, 256), 256, d_q, d_moff, d_roff, (u32)n_queues, d_rounds); }
     ZKW_TRY(launch_check("k_linear_blocks"));
-    { Prof _p(ctx, "k_linear_keccak256"); hipLaunchKernelGGL(k_linear_keccak256, dim3((unsigned)n_queues), dim3(64), 0, ctx->stream, d_q, (size_t)0, d_hash, d_rounds, d_moff, d_roff, true); }
+    { Prof _p(ctx, "k_linear_keccak256"); ZKW_LAUNCH(ctx, k_linear_keccak256, (unsigned)n_queues, 64, d_q, (size_t)0, d_hash, d_rounds, d_moff, d_roff, true); }
     ZKW_TRY(launch_check("k_linear_keccak256"));
     std::vector<zkw_linear_hasher_instance> recv(n_queues);
     std::vector<uint8_t> hashes(32 * n_queues);
@@ -1583,10 +1581,10 @@ extern "C" int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx* ctx, const
     ZKW_TRY(ctx->scratch_t<u64>("lh_pi", 4 * n_queues, &d_pi));
     {
         Prof _p(ctx, "k_closed_form_commitments");
-        hipLaunchKernelGGL((k_closed_form_commitments<CfLinearHasher>), dim3((unsigned)n_queues), dim3(64), 0, ctx->stream, d_rec, n_queues, d_cf);
+        ZKW_LAUNCH_T(ctx, (k_closed_form_commitments<CfLinearHasher>), "k_closed_form_commitments", (unsigned)n_queues, 64, d_rec, n_queues, d_cf);
     }
     ZKW_TRY(launch_check("k_closed_form_commitments"));
-    { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(n_queues, 64)), dim3(64), 0, ctx->stream, d_cf, n_queues, (u32)COMPACT_FORM_LEN, d_pi); }
+    { Prof _p(ctx, "k_commit_encodings"); ZKW_LAUNCH(ctx, k_commit_encodings, blocks_for(n_queues, 64), 64, d_cf, n_queues, (u32)COMPACT_FORM_LEN, d_pi); }
     ZKW_TRY(launch_check("k_commit_encodings"));
     std::vector<NlInstance> inst(n_queues);
     for (size_t b = 0; b < n_queues; b++) inst[b] = NlInstance{roff[b], (u32)(roff[b + 1] - roff[b]), d_pi + 4 * b, t, first_slot + b, true};
@@ -1602,7 +1600,7 @@ extern "C" int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx* ctx, const
             std::vector<u64> heads(4 * n_queues);
             for (size_t b = 0; b < n_queues; b++) memcpy(&heads[4 * b], queue_states[b].head, 32);
             ZKW_TRY(ctx->upload("lh_heads", heads, &d_heads));
-            { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(blocks_for(total, 256)), dim3(256), 0, ctx->stream, d_q, total, (const u32*)nullptr, d_enc); }
+            { Prof _p(ctx, "k_encode_log"); ZKW_LAUNCH(ctx, k_encode_log, blocks_for(total, 256), 256, d_q, total, (const u32*)nullptr, d_enc); }
             ZKW_TRY(launch_check("k_encode_log"));
             std::vector<LogChainJob> chains;
             for (size_t b = 0; b < n_queues; b++)

@@ -11,7 +11,7 @@
 #include "events_sorter_circuit_kernels.cuh"
 #include "log_demux_circuit_kernels.cuh"
 #include "storage_sorter_circuit_kernels.cuh"
-#include "sort.h"
+#include "radix_sort.cuh"
 
 // ------------------------------------------------------------------------------------------------ decommit sorter
 struct zkw_decommit_witness {
@@ -40,7 +40,7 @@ static int decommit_prepare(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_dec
     const size_t n = w->n;
     const unsigned grid = blocks_for(n, 256);
     // unsorted side
-    { Prof _p(ctx, "k_encode_decommit"); hipLaunchKernelGGL(k_encode_decommit, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, w->unsorted_enc); }
+    { Prof _p(ctx, "k_encode_decommit"); ZKW_LAUNCH(ctx, k_encode_decommit, grid, 256, d_q, n, w->unsorted_enc); }
     ZKW_TRY(launch_check("k_encode_decommit"));
     // sort: timestamp, then the hash from its least to its most significant 64 bits (stable LSD)
     u32 *ts = nullptr, *k32 = nullptr, *v0 = nullptr, *v1 = nullptr;
@@ -56,17 +56,17 @@ static int decommit_prepare(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_dec
     ZKW_TRY(ctx->scratch_t<u64>("sort_k64a", n, &k64a));
     ZKW_TRY(ctx->scratch_t<u64>("sort_k64b", n, &k64b));
     ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
-    { Prof _p(ctx, "k_decommit_sort_keys"); hipLaunchKernelGGL(k_decommit_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, ts, hk[0], hk[1], hk[2], hk[3], v0); }
+    { Prof _p(ctx, "k_decommit_sort_keys"); ZKW_LAUNCH(ctx, k_decommit_sort_keys, grid, 256, d_q, n, ts, hk[0], hk[1], hk[2], hk[3], v0); }
     ZKW_TRY(launch_check("k_decommit_sort_keys"));
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, ts, k32, v0, v1, n, 32, ctx->stream)); }
+    { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u32>(ctx, tmp, tmp_bytes, ts, k32, v0, v1, n, 32)); }
     u32 *cur = v1, *nxt = v0;
     for (int k = 0; k < 4; k++) {
-        { Prof _p(ctx, "k_gather_u64_by_u32"); hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, hk[k], cur, n, k64a); }
+        { Prof _p(ctx, "k_gather_u64_by_u32"); ZKW_LAUNCH(ctx, k_gather_u64_by_u32, grid, 256, hk[k], cur, n, k64a); }
         ZKW_TRY(launch_check("k_gather_u64_by_u32"));
-        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, cur, nxt, n, 64, ctx->stream)); }
+        { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u64>(ctx, tmp, tmp_bytes, k64a, k64b, cur, nxt, n, 64)); }
         u32* t = cur; cur = nxt; nxt = t;
     }
-    { Prof _p(ctx, "k_decommit_gather_encode"); hipLaunchKernelGGL(k_decommit_gather_encode, dim3(grid), dim3(256), 0, ctx->stream, d_q, cur, n, w->sorted_q, w->sorted_enc); }
+    { Prof _p(ctx, "k_decommit_gather_encode"); ZKW_LAUNCH(ctx, k_decommit_gather_encode, grid, 256, d_q, cur, n, w->sorted_q, w->sorted_enc); }
     ZKW_TRY(launch_check("k_decommit_gather_encode"));
     // deduplicated queue = the fresh requests in sorted order
     u32 *fresh_count = nullptr, *last_fresh = nullptr, *totals = nullptr;
@@ -76,11 +76,11 @@ static int decommit_prepare(zkw_ctx* ctx, zkw_decommit_witness* w, const zkw_dec
     u32 *fresh_prefix = nullptr, *fresh_pos = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("dec_fresh_prefix", n + 1, &fresh_prefix));
     ZKW_TRY(ctx->scratch_t<u32>("dec_fresh_pos", n, &fresh_pos));
-    HIP_TRY(hipMemsetAsync(totals, 0, 2 * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx->memset_async(totals, 0, 2 * sizeof(u32)));
     ZKW_TRY(flag_prefix(ctx, "k_decommit_fresh_prefix", DecommitFreshFlag{w->sorted_q}, n, fresh_prefix));
-    { Prof _p(ctx, "k_decommit_dedup"); hipLaunchKernelGGL(k_decommit_dedup, dim3(grid), dim3(256), 0, ctx->stream, w->sorted_q, w->sorted_enc, n, fresh_prefix, fresh_count, fresh_pos, w->dedup_q, w->dedup_enc, totals); }
+    { Prof _p(ctx, "k_decommit_dedup"); ZKW_LAUNCH(ctx, k_decommit_dedup, grid, 256, w->sorted_q, w->sorted_enc, n, fresh_prefix, fresh_count, fresh_pos, w->dedup_q, w->dedup_enc, totals); }
     ZKW_TRY(launch_check("k_decommit_dedup"));
-    { Prof _p(ctx, "k_decommit_last_fresh"); hipLaunchKernelGGL(k_decommit_last_fresh, dim3(grid), dim3(256), 0, ctx->stream, fresh_count, fresh_pos, n, last_fresh); }
+    { Prof _p(ctx, "k_decommit_last_fresh"); ZKW_LAUNCH(ctx, k_decommit_last_fresh, grid, 256, fresh_count, fresh_pos, n, last_fresh); }
     ZKW_TRY(launch_check("k_decommit_last_fresh"));
     u32 h_totals[2] = {0, 0};
     ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
@@ -117,7 +117,7 @@ static int decommit_finish(zkw_ctx* ctx, zkw_decommit_witness* w) {
                            fresh_count, last_fresh, w->instances, dedup_in, n, w->capacity};
     DecommitBlock* d_blk = nullptr;
     ZKW_TRY(ctx->upload("dec_block", blk, &d_blk));
-    { Prof _p(ctx, "k_decommit_instances"); hipLaunchKernelGGL(k_decommit_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    { Prof _p(ctx, "k_decommit_instances"); ZKW_LAUNCH(ctx, k_decommit_instances, blocks_for(w->n_instances, 64), 64, d_blk); }
     return launch_check("k_decommit_instances");
 }
 
@@ -172,10 +172,10 @@ extern "C" int zkw_decommit_sorter_finish(zkw_ctx* ctx, zkw_decommit_witness* w)
     int rc = decommit_finish(ctx, w);
     if (rc == ZKW_OK) {  // a20: compact forms and public inputs (postprocessing/mod.rs:353-369)
         const size_t ni = w->n_instances;
-        { Prof _p(ctx, "k_ds_commitments"); hipLaunchKernelGGL(k_ds_commitments, dim3(blocks_for(4 * ni, 64)), dim3(64), 0, ctx->stream, w->instances, ni, w->compact_forms); }
+        { Prof _p(ctx, "k_ds_commitments"); ZKW_LAUNCH(ctx, k_ds_commitments, blocks_for(4 * ni, 64), 64, w->instances, ni, w->compact_forms); }
         rc = launch_check("k_ds_commitments");
         if (rc == ZKW_OK) {
-            { Prof _p(ctx, "k_commit_encodings"); hipLaunchKernelGGL(k_commit_encodings, dim3(blocks_for(ni, 64)), dim3(64), 0, ctx->stream, w->compact_forms, ni, (u32)COMPACT_FORM_LEN, w->public_inputs); }
+            { Prof _p(ctx, "k_commit_encodings"); ZKW_LAUNCH(ctx, k_commit_encodings, blocks_for(ni, 64), 64, w->compact_forms, ni, (u32)COMPACT_FORM_LEN, w->public_inputs); }
             rc = launch_check("k_commit_encodings");
         }
     }
@@ -248,13 +248,13 @@ extern "C" int zkw_decommit_witness_get(const zkw_decommit_witness* w, int what,
     if (bytes == 0) return ZKW_OK;
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx->copy_async(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return ctx->sync_if_host();
 }
 extern "C" void zkw_decommit_witness_free(zkw_decommit_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)w->ctx->sync_stream();
     w->release();
     zkw_ctx* owner = w->ctx;
     delete w;
@@ -286,7 +286,7 @@ static int events_run(zkw_ctx* ctx, zkw_events_witness* w, const zkw_log_query* 
     const unsigned grid = blocks_for(n, 256);
     u64 *u_enc = w->enc_all, *s_enc = w->enc_all + 20 * n, *r_enc = w->enc_all + 40 * n;
     u64 *u_old = w->tails_all, *u_new = u_old + 4 * n, *s_old = u_new + 4 * n, *s_new = s_old + 4 * n, *r_new = s_new + 4 * n;
-    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, u_enc); }
+    { Prof _p(ctx, "k_encode_log"); ZKW_LAUNCH(ctx, k_encode_log, grid, 256, d_q, n, (const u32*)nullptr, u_enc); }
     ZKW_TRY(launch_check("k_encode_log"));
     // stable sort by (timestamp, rollback): 33-bit key
     u64 *key = nullptr, *key_out = nullptr;
@@ -298,18 +298,18 @@ static int events_run(zkw_ctx* ctx, zkw_events_witness* w, const zkw_log_query* 
     ZKW_TRY(ctx->scratch_t<u32>("sort_v0", n, &v0));
     ZKW_TRY(ctx->scratch_t<u32>("sort_v1", n, &v1));
     ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
-    { Prof _p(ctx, "k_events_sort_keys"); hipLaunchKernelGGL(k_events_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, key, v0); }
+    { Prof _p(ctx, "k_events_sort_keys"); ZKW_LAUNCH(ctx, k_events_sort_keys, grid, 256, d_q, n, key, v0); }
     ZKW_TRY(launch_check("k_events_sort_keys"));
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, key, key_out, v0, v1, n, 33, ctx->stream)); }
-    { Prof _p(ctx, "k_log_gather_encode"); hipLaunchKernelGGL(k_log_gather_encode, dim3(grid), dim3(256), 0, ctx->stream, d_q, v1, n, w->sorted_q, s_enc); }
+    { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u64>(ctx, tmp, tmp_bytes, key, key_out, v0, v1, n, 33)); }
+    { Prof _p(ctx, "k_log_gather_encode"); ZKW_LAUNCH(ctx, k_log_gather_encode, grid, 256, d_q, v1, n, w->sorted_q, s_enc); }
     ZKW_TRY(launch_check("k_log_gather_encode"));
     ZKW_TRY(ctx->scratch_t<u32>("evt_kept", n, &kept));
     ZKW_TRY(ctx->scratch_t<u32>("evt_totals", 2, &totals));
     u32* kept_prefix = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("evt_kept_prefix", n + 1, &kept_prefix));
-    HIP_TRY(hipMemsetAsync(totals, 0, 2 * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx->memset_async(totals, 0, 2 * sizeof(u32)));
     ZKW_TRY(flag_prefix(ctx, "k_events_kept_prefix", EventsKeptFlag{w->sorted_q, n}, n, kept_prefix));
-    { Prof _p(ctx, "k_events_dedup"); hipLaunchKernelGGL(k_events_dedup, dim3(grid), dim3(256), 0, ctx->stream, w->sorted_q, n, kept_prefix, kept, w->result_q, r_enc, totals); }
+    { Prof _p(ctx, "k_events_dedup"); ZKW_LAUNCH(ctx, k_events_dedup, grid, 256, w->sorted_q, n, kept_prefix, kept, w->result_q, r_enc, totals); }
     ZKW_TRY(launch_check("k_events_dedup"));
     u32 h_totals[2] = {0, 0};
     ZKW_TRY(ctx->read_small(h_totals, totals, sizeof h_totals));
@@ -335,7 +335,7 @@ static int events_run(zkw_ctx* ctx, zkw_events_witness* w, const zkw_log_query* 
     blk[0] = EventsBlock{w->sorted_q, u_new, s_new, r_new, w->lhs_z, w->rhs_z, kept, w->instances, result_in, n, w->capacity};
     EventsBlock* d_blk = nullptr;
     ZKW_TRY(ctx->upload("evt_block", blk, &d_blk));
-    { Prof _p(ctx, "k_events_instances"); hipLaunchKernelGGL(k_events_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    { Prof _p(ctx, "k_events_instances"); ZKW_LAUNCH(ctx, k_events_instances, blocks_for(w->n_instances, 64), 64, d_blk); }
     return launch_check("k_events_instances");
 }
 
@@ -382,7 +382,7 @@ extern "C" int zkw_events_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, siz
         u64* d_zero = nullptr;
         rc = ctx->scratch_t<u64>("empty_queue_tail", 4, &d_zero);
         if (rc == ZKW_OK && (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
-                             hipMemsetAsync(d_zero, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess))
+                             ctx->memset_async(d_zero, 0, 4 * sizeof(u64)) != hipSuccess))
             rc = fail(ZKW_ERR_HIP, "copy failed");
         if (rc == ZKW_OK) {
             std::vector<FsJob> fs(1, FsJob{d_zero, d_zero, 0u, 0u, w->challenges});
@@ -447,13 +447,13 @@ extern "C" int zkw_events_witness_get(const zkw_events_witness* w, int what, voi
     if (bytes == 0) return ZKW_OK;
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx->copy_async(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return ctx->sync_if_host();
 }
 extern "C" void zkw_events_witness_free(zkw_events_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)w->ctx->sync_stream();
     w->release();
     zkw_ctx* owner = w->ctx;
     delete w;
@@ -485,14 +485,14 @@ static int demux_run(zkw_ctx* ctx, zkw_demux_witness* w, const zkw_log_query* d_
     const size_t n = w->n;
     u64 *in_enc = w->enc_all, *out_enc = w->enc_all + 20 * n;
     u64 *in_old = w->tails_all, *in_new = in_old + 4 * n, *out_old = in_new + 4 * n, *out_new = out_old + 4 * n;
-    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, in_enc); }
+    { Prof _p(ctx, "k_encode_log"); ZKW_LAUNCH(ctx, k_encode_log, blocks_for(n, 256), 256, d_q, n, (const u32*)nullptr, in_enc); }
     ZKW_TRY(launch_check("k_encode_log"));
     u32* route_count = w->route_count;
-    HIP_TRY(hipMemsetAsync(w->d_offsets, 0, 8 * sizeof(u64), ctx->stream));
+    HIP_TRY(ctx->memset_async(w->d_offsets, 0, 8 * sizeof(u64)));
     ZKW_TRY((route_prefix<6>(ctx, "k_demux_route_prefix", DemuxRoute{d_q, params}, n, route_count)));
-    hipLaunchKernelGGL(k_demux_offsets, dim3(1), dim3(64), 0, ctx->stream, route_count, n, w->d_offsets);
+    ZKW_LAUNCH(ctx, k_demux_offsets, 1, 64, route_count, n, w->d_offsets);
     ZKW_TRY(launch_check("k_demux_offsets"));
-    { Prof _p(ctx, "k_demux_route"); hipLaunchKernelGGL(k_demux_route, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_q, in_enc, n, params, route_count, w->out_q, out_enc, w->d_offsets); }
+    { Prof _p(ctx, "k_demux_route"); ZKW_LAUNCH(ctx, k_demux_route, blocks_for(n, 256), 256, d_q, in_enc, n, params, route_count, w->out_q, out_enc, w->d_offsets); }
     ZKW_TRY(launch_check("k_demux_route"));
     u64 h_tot[8];
     ZKW_TRY(ctx->read_small(h_tot, w->d_offsets, sizeof h_tot));
@@ -517,7 +517,7 @@ static int demux_run(zkw_ctx* ctx, zkw_demux_witness* w, const zkw_log_query* d_
     blk[0].capacity = w->capacity;
     DemuxBlock* d_blk = nullptr;
     ZKW_TRY(ctx->upload("dmx_block", blk, &d_blk));
-    { Prof _p(ctx, "k_demux_instances"); hipLaunchKernelGGL(k_demux_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    { Prof _p(ctx, "k_demux_instances"); ZKW_LAUNCH(ctx, k_demux_instances, blocks_for(w->n_instances, 64), 64, d_blk); }
     return launch_check("k_demux_instances");
 }
 
@@ -612,13 +612,13 @@ extern "C" int zkw_demux_witness_get(const zkw_demux_witness* w, int what, void*
     if (bytes == 0) return ZKW_OK;
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx->copy_async(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return ctx->sync_if_host();
 }
 extern "C" void zkw_demux_witness_free(zkw_demux_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)w->ctx->sync_stream();
     w->release();
     zkw_ctx* owner = w->ctx;
     delete w;
@@ -668,26 +668,26 @@ static int storage_run(zkw_ctx* ctx, zkw_storage_witness* w, const zkw_log_query
     ZKW_TRY(ctx->scratch("sort_tmp", tmp_bytes + 256, &tmp));
     u32* iota = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("ssort_iota", n, &iota));
-    { Prof _p(ctx, "k_storage_sort_keys"); hipLaunchKernelGGL(k_storage_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], a2, iota); }
+    { Prof _p(ctx, "k_storage_sort_keys"); ZKW_LAUNCH(ctx, k_storage_sort_keys, grid, 256, d_q, n, kk[0], kk[1], kk[2], kk[3], kk[4], kk[5], a2, iota); }
     ZKW_TRY(launch_check("k_storage_sort_keys"));
     // plain and extended encodings of the unsorted side
-    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, (const u32*)nullptr, u_enc); }
+    { Prof _p(ctx, "k_encode_log"); ZKW_LAUNCH(ctx, k_encode_log, grid, 256, d_q, n, (const u32*)nullptr, u_enc); }
     ZKW_TRY(launch_check("k_encode_log"));
-    { Prof _p(ctx, "k_encode_log"); hipLaunchKernelGGL(k_encode_log, dim3(grid), dim3(256), 0, ctx->stream, d_q, n, (const u32*)iota, w->lhs_enc); }
+    { Prof _p(ctx, "k_encode_log"); ZKW_LAUNCH(ctx, k_encode_log, grid, 256, d_q, n, (const u32*)iota, w->lhs_enc); }
     ZKW_TRY(launch_check("k_encode_log"));
-    HIP_TRY(hipMemcpyAsync(v0, iota, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx->copy_async(v0, iota, n * sizeof(u32), hipMemcpyDeviceToDevice));
     u32 *cur = v0, *nxt = v1;
     for (int k = 0; k < 6; k++) {
-        { Prof _p(ctx, "k_gather_u64_by_u32"); hipLaunchKernelGGL(k_gather_u64_by_u32, dim3(grid), dim3(256), 0, ctx->stream, kk[k], cur, n, k64a); }
+        { Prof _p(ctx, "k_gather_u64_by_u32"); ZKW_LAUNCH(ctx, k_gather_u64_by_u32, grid, 256, kk[k], cur, n, k64a); }
         ZKW_TRY(launch_check("k_gather_u64_by_u32"));
-        { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u64(tmp, tmp_bytes, k64a, k64b, cur, nxt, n, 64, ctx->stream)); }
+        { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u64>(ctx, tmp, tmp_bytes, k64a, k64b, cur, nxt, n, 64)); }
         u32* t = cur; cur = nxt; nxt = t;
     }
-    { Prof _p(ctx, "k_gather_u32_by_u32"); hipLaunchKernelGGL(k_gather_u32_by_u32, dim3(grid), dim3(256), 0, ctx->stream, a2, cur, n, k32a); }
+    { Prof _p(ctx, "k_gather_u32_by_u32"); ZKW_LAUNCH(ctx, k_gather_u32_by_u32, grid, 256, a2, cur, n, k32a); }
     ZKW_TRY(launch_check("k_gather_u32_by_u32"));
-    { Prof _p(ctx, "radix_sort"); HIP_TRY(radix_sort_pairs_u32(tmp, tmp_bytes, k32a, k32b, cur, nxt, n, 32, ctx->stream)); }
+    { Prof _p(ctx, "radix_sort"); ZKW_TRY(radix_sort_pairs<u32>(ctx, tmp, tmp_bytes, k32a, k32b, cur, nxt, n, 32)); }
     { u32* t = cur; cur = nxt; nxt = t; }
-    { Prof _p(ctx, "k_storage_gather_encode"); hipLaunchKernelGGL(k_storage_gather_encode, dim3(grid), dim3(256), 0, ctx->stream, d_q, cur, n, w->sorted_q, w->sorted_ext, s_enc); }
+    { Prof _p(ctx, "k_storage_gather_encode"); ZKW_LAUNCH(ctx, k_storage_gather_encode, grid, 256, d_q, cur, n, w->sorted_q, w->sorted_ext, s_enc); }
     ZKW_TRY(launch_check("k_storage_gather_encode"));
     // per-cell registers and the deduplicated queue
     StorageScan sc;
@@ -706,16 +706,16 @@ static int storage_run(zkw_ctx* ctx, zkw_storage_witness* w, const zkw_log_query
         ZKW_TRY(ctx->scratch_t<u32>("sto_rpfx", n + 1, &d_rpfx));
         ZKW_TRY(ctx->scratch_t<u32>("sto_epfx", n + 1, &d_epfx));
         ZKW_TRY(ctx->scratch_t<u32>("sto_first", n, &d_first));
-        HIP_TRY(hipMemsetAsync(totals, 0, 2 * sizeof(u32), ctx->stream));
+        HIP_TRY(ctx->memset_async(totals, 0, 2 * sizeof(u32)));
         ZKW_TRY((sum_prefix<1>(ctx, "k_storage_depth_prefix", StoDelta{w->sorted_q}, n, d_dpfx, d_dtot)));
         ZKW_TRY(flag_prefix(ctx, "k_storage_start_prefix", StoIsStart{w->sorted_q}, n, d_spfx));
-        { Prof _p(ctx, "k_storage_first"); hipLaunchKernelGGL(k_storage_first, dim3(grid), dim3(256), 0, ctx->stream, d_spfx, n, d_first); }
+        { Prof _p(ctx, "k_storage_first"); ZKW_LAUNCH(ctx, k_storage_first, grid, 256, d_spfx, n, d_first); }
         ZKW_TRY(launch_check("k_storage_first"));
-        { Prof _p(ctx, "k_storage_ds"); hipLaunchKernelGGL(k_storage_ds, dim3(grid), dim3(256), 0, ctx->stream, w->sorted_q, n, d_dpfx, d_spfx, d_first, sc, totals + 1); }
+        { Prof _p(ctx, "k_storage_ds"); ZKW_LAUNCH(ctx, k_storage_ds, grid, 256, w->sorted_q, n, d_dpfx, d_spfx, d_first, sc, totals + 1); }
         ZKW_TRY(launch_check("k_storage_ds"));
         ZKW_TRY(flag_prefix(ctx, "k_storage_read_prefix", StoReadAtZero{w->sorted_q, sc, totals + 1}, n, d_rpfx));
         ZKW_TRY(flag_prefix(ctx, "k_storage_emit_prefix", StoEmits{sc, d_rpfx, n}, n, d_epfx));
-        { Prof _p(ctx, "k_storage_emit"); hipLaunchKernelGGL(k_storage_emit, dim3(grid), dim3(256), 0, ctx->stream, w->sorted_q, n, sc, d_rpfx, d_epfx, w->result_q, r_enc, totals); }
+        { Prof _p(ctx, "k_storage_emit"); ZKW_LAUNCH(ctx, k_storage_emit, grid, 256, w->sorted_q, n, sc, d_rpfx, d_epfx, w->result_q, r_enc, totals); }
         ZKW_TRY(launch_check("k_storage_emit"));
     }
     u32 h_totals[2] = {0, 0};
@@ -739,7 +739,7 @@ static int storage_run(zkw_ctx* ctx, zkw_storage_witness* w, const zkw_log_query
     blk[0] = StorageBlock{w->sorted_q, w->sorted_ext, u_new, s_new, r_new, w->lhs_z, w->rhs_z, sc, w->instances, n, w->capacity};
     StorageBlock* d_blk = nullptr;
     ZKW_TRY(ctx->upload("sto_block", blk, &d_blk));
-    { Prof _p(ctx, "k_storage_instances"); hipLaunchKernelGGL(k_storage_instances, dim3(blocks_for(w->n_instances, 64)), dim3(64), 0, ctx->stream, d_blk); }
+    { Prof _p(ctx, "k_storage_instances"); ZKW_LAUNCH(ctx, k_storage_instances, blocks_for(w->n_instances, 64), 64, d_blk); }
     return launch_check("k_storage_instances");
 }
 
@@ -783,7 +783,7 @@ extern "C" int zkw_storage_sorter_build(zkw_ctx* ctx, const zkw_log_query* q, si
         u64* d_zero = nullptr;
         rc = ctx->scratch_t<u64>("empty_queue_tail", 4, &d_zero);
         if (rc == ZKW_OK && (hipMemcpy(w->instances, &inst, sizeof inst, hipMemcpyHostToDevice) != hipSuccess ||
-                             hipMemsetAsync(d_zero, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess))
+                             ctx->memset_async(d_zero, 0, 4 * sizeof(u64)) != hipSuccess))
             rc = fail(ZKW_ERR_HIP, "copy failed");
         if (rc == ZKW_OK) {
             std::vector<FsJob> fs(1, FsJob{d_zero, d_zero, 0u, 0u, w->challenges});
@@ -849,13 +849,13 @@ extern "C" int zkw_storage_witness_get(const zkw_storage_witness* w, int what, v
     if (bytes == 0) return ZKW_OK;
     zkw_ctx* ctx = w->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx->copy_async(dst, src, bytes, ctx->ptr_mode == ZKW_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return ctx->sync_if_host();
 }
 extern "C" void zkw_storage_witness_free(zkw_storage_witness* w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
-    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)w->ctx->sync_stream();
     w->release();
     zkw_ctx* owner = w->ctx;
     delete w;
@@ -882,7 +882,7 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
     }
     u32* d_hist = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("ds_hist", n_instances * 256, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx->memset_async(d_hist, 0, n_instances * 256 * sizeof(u32)));
     SlotClaims claims(t);
     std::vector<DsSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
@@ -953,7 +953,7 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
     }
     u32* d_hist = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("es_hist", n_instances * 256, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx->memset_async(d_hist, 0, n_instances * 256 * sizeof(u32)));
     const size_t m = n ? n : 1;
     u64 *u_enc = w->enc_all, *s_enc = w->enc_all + 20 * m;
     u64 *u_new = w->tails_all + 4 * m, *s_new = w->tails_all + 12 * m, *r_new = w->tails_all + 16 * m;
@@ -1028,7 +1028,7 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
     HIP_TRY(hipSetDevice(ctx->device));
     u32* d_hist = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("ld_hist", n_instances * 256, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx->memset_async(d_hist, 0, n_instances * 256 * sizeof(u32)));
     SlotClaims claims(t);
     std::vector<LdSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
@@ -1094,7 +1094,7 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
     HIP_TRY(hipSetDevice(ctx->device));
     u32* d_hist = nullptr;
     ZKW_TRY(ctx->scratch_t<u32>("ss_hist", n_instances * 256, &d_hist));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, n_instances * 256 * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx->memset_async(d_hist, 0, n_instances * 256 * sizeof(u32)));
     SlotClaims claims(t);
     std::vector<SsSynthJob> jobs(n_instances);
     for (size_t k = 0; k < n_instances; k++) {
