@@ -156,6 +156,9 @@ static StreamPool& stream_pool() {
     return *p;
 }
 
+hipError_t zkw_pool_stream_acquire(hipStream_t* s) { return stream_pool().acquire(s); }
+void zkw_pool_stream_release(hipStream_t s) { stream_pool().release(s); }
+
 extern "C" void zkw_trim_caches(void) {
     alloc_cache().trim();
     stream_pool().trim();
@@ -215,9 +218,11 @@ static void ctx_destroy_now(zkw_ctx* ctx) {
     if (ctx->pinned_rb) pin_free(ctx->pinned_rb);
     if (ctx->chain_ev_a) (void)hipEventDestroy(ctx->chain_ev_a);
     if (ctx->chain_ev_b) (void)hipEventDestroy(ctx->chain_ev_b);
-    if (ctx->side_stream) {
+    if (ctx->side_stream) {  // a fork nobody joined
         (void)hipStreamSynchronize(ctx->side_stream);
-        (void)hipStreamDestroy(ctx->side_stream);
+        stream_pool().release(ctx->side_stream);
+    }
+    if (ctx->side_ev_fork) {
         (void)hipEventDestroy(ctx->side_ev_fork);
         (void)hipEventDestroy(ctx->side_ev_join);
     }
@@ -334,7 +339,7 @@ extern "C" int zkw_set_netlist_fill_form(zkw_ctx* ctx, int form) {
 extern "C" int zkw_synchronize(zkw_ctx* ctx) {
     if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
     if (ctx->batched()) return zkw_batch_sync(ctx->batch);  // parks the calling fiber until what it queued has run
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx->sync_stream());  // (and whatever a failed call left on the side stream)
     return ZKW_OK;
 }
 
@@ -347,6 +352,44 @@ zkw_ctx* zkw_ctx_create_in_batch(int device_id, zkw_batch* b) {
     ctx->stream = zkw_batch_stream(b);
     ctx->ptr_mode = ZKW_PTR_DEVICE;
     return ctx;
+}
+// (diagnostics, ZKW_BLOCK_MEM_LOG) bytes of a context's named scratch; device bytes handed out / idle in the allocation cache
+size_t zkw_ctx_scratch_bytes(const zkw_ctx* ctx) {
+    size_t b = 0;
+    for (auto& kv : ctx->pool) b += kv.second.cap;
+    for (void* q : ctx->retired_dev) { (void)q; }
+    return b;
+}
+// Scratch a context has acquired since `mark` (a set of names, zkw_ctx_scratch_mark) goes back to the allocation cache: the synthesis of
+// a block's instances leaves ~100 MB of windows in the block's contexts that nothing reads again. The stream must be idle.
+void zkw_ctx_scratch_mark(const zkw_ctx* ctx, std::vector<std::string>* names) {
+    names->clear();
+    for (auto& kv : ctx->pool) names->push_back(kv.first);
+}
+void zkw_ctx_scratch_release_since(zkw_ctx* ctx, const std::vector<std::string>& names) {
+    for (auto it = ctx->pool.begin(); it != ctx->pool.end();) {
+        if (std::find(names.begin(), names.end(), it->first) == names.end()) {
+            if (it->second.p) dev_free(it->second.p);
+            it = ctx->pool.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+void zkw_cache_stats(size_t* live_bytes, size_t* idle_bytes) {
+    AllocCache& c = alloc_cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    size_t l = 0, i = 0;
+    for (auto& kv : c.live[0]) l += kv.second.second;
+    for (int d = 0; d < AllocCache::MAX_DEV; d++)
+        for (auto& kv : c.idle[0][d]) i += kv.first * kv.second.size();
+    *live_bytes = l;
+    *idle_bytes = i;
+}
+int zkw_copy_device(zkw_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return fail(ZKW_ERR_INVALID, "null context");
+    if (bytes) HIP_TRY(ctx->copy_async(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return ZKW_OK;
 }
 void* zkw_device_shared_stream(int device_id) {
     static std::mutex mu;

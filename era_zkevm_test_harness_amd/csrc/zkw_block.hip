@@ -196,6 +196,15 @@ struct zkw_block {
         if (count) ST_TRY(xf[lane].h2d(*p, host, count * sizeof(T)));
         return Status();
     }
+    // one of the block's input queues: copied to the device, or borrowed when the host has left it there (zkw_block_inputs::queues_on_device)
+    template <class T>
+    Status queue_in(int lane, const T** p, const T* src, size_t count, bool on_device) {
+        if (on_device && count) { *p = src; return Status(); }
+        T* d = nullptr;
+        ST_TRY(upload(lane, &d, src, count));
+        *p = d;
+        return Status();
+    }
 };
 
 namespace {
@@ -292,10 +301,10 @@ Status events_branch(zkw_block* B, int which, const zkw_log_query* d_q, size_t n
 
 Status log_branch(zkw_block* B, const zkw_block_inputs* in) {
     ST_HIP(hipSetDevice(B->device));
-    zkw_log_query* d_logs = nullptr;
+    const zkw_log_query* d_logs = nullptr;
     {
         Timed t(B, "log_demuxer");
-        ST_TRY(B->upload(X_LOG, &d_logs, in->log_queries, in->n_log_queries));
+        ST_TRY(B->queue_in(X_LOG, &d_logs, in->log_queries, in->n_log_queries, in->queues_on_device != 0));
         ST_ZKW(zkw_log_demux_build(B->ctx[C_DMX], d_logs, in->n_log_queries, B->cap[T_DMX], nullptr, &B->dmx));
         ST_ZKW(zkw_synchronize(B->ctx[C_DMX]));
         ST_TRY(B->xf[X_LOG].d2h(B->dmx_off, zkw_demux_witness_device_ptr(B->dmx, ZKW_DMX_OUT_OFFSETS), sizeof B->dmx_off));
@@ -367,11 +376,11 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
     auto f_log = start_branch(B, [=] { return log_branch(B, in); });
 
     // 1. decommit sorter, contents only: the deduplicated requests fix which code words enter the memory queue
-    zkw_decommit_query* d_dq = nullptr;
+    const zkw_decommit_query* d_dq = nullptr;
     std::vector<zkw_decommit_query> dedup;
     {
         Timed t(B, "decommit_sorter.prepare");
-        { Timed t1(B, "decommit_sorter.prepare.upload"); ST_TRY(B->upload(X_MAIN, &d_dq, in->decommit_queries, in->n_decommit_queries)); }
+        { Timed t1(B, "decommit_sorter.prepare.upload"); ST_TRY(B->queue_in(X_MAIN, &d_dq, in->decommit_queries, in->n_decommit_queries, in->queues_on_device != 0)); }
         { Timed t2(B, "decommit_sorter.prepare.kernels"); ST_ZKW(zkw_decommit_sorter_prepare(B->ctx[C_DEC], d_dq, in->n_decommit_queries, B->cap[T_DEC], nullptr, &B->dec)); }
         dedup.resize(zkw_decommit_witness_num_dedup(B->dec));
         { Timed t3(B, "decommit_sorter.prepare.readback");
@@ -413,12 +422,15 @@ Status run(zkw_block* B, const zkw_block_inputs* in) {
             return s;
         }
         ST_TRY(B->alloc(&B->d_all_mem, B->n_mem));
-        if (in->n_vm_memory_queries)
-            ST_TRY(B->xf[X_MAIN].h2d(B->d_all_mem, in->vm_memory_queries, in->n_vm_memory_queries * sizeof(zkw_mem_query)));
-        for (int k = 0; k < 3; k++)
-            if (in->n_precompile_memory_queries[k])
-                ST_TRY(B->xf[X_MAIN].h2d(B->d_all_mem + B->mem_off[2 + k], in->precompile_memory_queries[k],
-                                 in->n_precompile_memory_queries[k] * sizeof(zkw_mem_query)));
+        // the parts the host supplies: host -> device, or (queues_on_device) device -> device on the precompile context's stream, which
+        // zkw_decommitter_memory_queries below continues on and the zkw_synchronize after it waits for
+        auto part_in = [&](zkw_mem_query* dst, const zkw_mem_query* src, size_t n) -> Status {
+            if (!n) return Status();
+            if (in->queues_on_device) return from_rc(zkw_copy_device(B->ctx[C_PRE], dst, src, n * sizeof(zkw_mem_query)));
+            return B->xf[X_MAIN].h2d(dst, src, n * sizeof(zkw_mem_query));
+        };
+        ST_TRY(part_in(B->d_all_mem, in->vm_memory_queries, in->n_vm_memory_queries));
+        for (int k = 0; k < 3; k++) ST_TRY(part_in(B->d_all_mem + B->mem_off[2 + k], in->precompile_memory_queries[k], in->n_precompile_memory_queries[k]));
         ST_TRY(B->upload(X_MAIN, &d_words, words.data(), words.size()));
         const zkw_decommit_query* d_dedup = static_cast<const zkw_decommit_query*>(zkw_decommit_witness_device_ptr(B->dec, ZKW_DEC_DEDUP_QUERIES));
         // on the precompile context: the decommit context is busy hashing
@@ -692,6 +704,20 @@ extern "C" int zkw_blocks_run(int device_id, const zkw_block_inputs* const* inpu
             if (B->ctx[i]) zkw_ctx_leave_batch(B->ctx[i], shared);
     }
     if (rc != ZKW_OK) g_block_error = zkw_last_error();
+    if (getenv("ZKW_BLOCK_MEM_LOG")) {
+        size_t scratch = 0, owned = 0, live = 0, idle = 0;
+        static const char* cn[N_CTX] = {"dec", "ram", "dmx", "sto", "evt", "l1", "pre"};
+        size_t per_ctx[N_CTX] = {};
+        for (zkw_block* B : blocks)
+            for (int i = 0; i < N_CTX; i++)
+                if (B->ctx[i]) { per_ctx[i] += zkw_ctx_scratch_bytes(B->ctx[i]); scratch += zkw_ctx_scratch_bytes(B->ctx[i]); }
+        (void)owned;
+        zkw_cache_stats(&live, &idle);
+        fprintf(stderr, "[zkw blocks] %zu blocks: %.1f MB of device buffers per block handed out by the cache (%.1f GB; %.1f GB idle in the cache), of which context scratch %.1f MB per block:",
+                n_blocks, live / 1e6 / n_blocks, live / 1e9, idle / 1e9, scratch / 1e6 / n_blocks);
+        for (int i = 0; i < N_CTX; i++) fprintf(stderr, " %s %.1f", cn[i], per_ctx[i] / 1e6 / n_blocks);
+        fprintf(stderr, "\n");
+    }
     zkw_batch_destroy(batch);  // (waits for the batch's streams; its arenas go back to the allocation cache)
     if (rc != ZKW_OK || !shared) {
         for (zkw_block* B : blocks) zkw_block_free(B);
@@ -777,6 +803,29 @@ extern "C" void zkw_block_free(zkw_block* B) {
     for (int i = 0; i < N_CTX; i++)
         if (B->ctx[i]) zkw_destroy(B->ctx[i]);
     delete B;
+}
+
+// K blocks released on a few threads of the library (a block's release is ~300 buffers going back to the allocation cache and seven
+// contexts torn down: ~1.2 ms of host time, which at 512 blocks per batch was 0.65 s of every 5.5 s cycle)
+extern "C" void zkw_blocks_free(zkw_block* const* blocks, size_t n_blocks) {
+    if (!blocks || n_blocks == 0) return;
+    static const size_t max_threads = [] { const char* e = getenv("ZKW_FREE_THREADS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 ? v : 8); }();
+    const size_t n_threads = std::min<size_t>(max_threads, (n_blocks + 15) / 16);
+    if (n_threads <= 1) {
+        for (size_t k = 0; k < n_blocks; k++) zkw_block_free(blocks[k]);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (size_t th = 0; th < n_threads; th++)
+        pool.emplace_back([&] {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= n_blocks) return;
+                zkw_block_free(blocks[k]);
+            }
+        });
+    for (auto& t : pool) t.join();
 }
 
 extern "C" void* zkw_block_witness(const zkw_block* B, uint8_t t) {
@@ -907,7 +956,7 @@ extern "C" int zkw_block_synthesize(zkw_block* B, size_t n_rows, size_t ring_slo
 }
 
 static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type,
-                                 zkw_trace* callers_ring);
+                                 zkw_trace* callers_ring, int only_type = -1);
 extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb,
                                             void* user, size_t* n_done) {
     return block_synthesize_impl(B, n_rows, ring_slots, rank, world, cb, user, n_done, -1, nullptr);
@@ -916,7 +965,7 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
 // callers_ring: a ring of `ring_slots` slots of 153 columns the caller owns (zkw_blocks_synthesize: one per worker, not one per block —
 // at 1.28 GB a slot, a ring per block capped the blocks in flight at ~150), else the block's own, created on first use
 static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type,
-                                 zkw_trace* callers_ring) {
+                                 zkw_trace* callers_ring, int only_type) {
     if (!B || n_rows == 0 || ring_slots == 0 || world < 1 || rank < 0 || rank >= world) return ZKW_ERR_INVALID;
     std::vector<uint8_t> plan_types;
     std::vector<uint32_t> plan_index, plan_owner;
@@ -946,7 +995,7 @@ static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots,
     const double a = B->ms_now();
     size_t done = 0;
     for (int t : kOrder) {
-        if (t == skip_type) continue;
+        if (t == skip_type || (only_type >= 0 && t != only_type)) continue;
         const size_t ni = zkw_block_num_instances(B, (uint8_t)t);
         zkw_ctx* c = zkw_block_context(B, (uint8_t)t);
         zkw_trace* ring = callers_ring ? callers_ring : B->ring;
@@ -1048,13 +1097,15 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
         zkw_trace_free(ring);
         zkw_destroy(c);
     });
-    // (2) everything else, block by block on a few threads; a worker has ONE ring and ONE stream for all the blocks it takes
-    std::atomic<size_t> next{0};
+    // (2) everything else on a few threads. A worker has ONE ring and ONE stream, owns every n_threads-th block, and goes through its blocks
+    // TYPE BY TYPE: the LogDemuxer instances of all its blocks, then their RAMPermutation instances, ... — a ring slot then holds the same
+    // layout call after call, so a fill only rewrites the cells it owns (zkw_trace::slot_tag): no zeroing pass over the ~1 GB of general
+    // columns of a netlist circuit, about half the bytes of a queue circuit. Block by block, every call into a slot was a cold one.
     std::vector<std::thread> pool;
     static const size_t max_threads = [] { const char* e = getenv("ZKW_SYNTH_THREADS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 ? v : 8); }();
     const size_t n_threads = std::min<size_t>(max_threads, n_blocks);
     for (size_t th = 0; th < n_threads; th++)
-        pool.emplace_back([&] {
+        pool.emplace_back([&, th] {
             if (hipSetDevice(blocks[0]->device) != hipSuccess) { note(ZKW_ERR_HIP); return; }
             zkw_ctx* wc = zkw_create(blocks[0]->device);
             if (!wc) { note(ZKW_ERR_NO_DEVICE); return; }
@@ -1062,26 +1113,51 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
             int rc = zkw_trace_create_with_columns(wc, n_rows, 153, ring_slots, &ring);
             void* shared = zkw_device_shared_stream(blocks[0]->device);
             if (rc != ZKW_OK || !shared) { note(rc != ZKW_OK ? rc : ZKW_ERR_HIP); if (ring) zkw_trace_free(ring); zkw_destroy(wc); return; }
-            for (;;) {
-                const size_t b = next.fetch_add(1);
-                if (b >= n_blocks || first_rc.load() != ZKW_OK) break;
-                zkw_block* B = blocks[b];
-                Fwd f{b, cb, user};
-                size_t n = 0;
-                // a block built by a batch has no streams of its own: its contexts work on this worker's stream meanwhile
+            std::vector<size_t> mine;
+            for (size_t b = th; b < n_blocks; b += n_threads) mine.push_back(b);
+            // a block built by a batch has no streams of its own: its contexts work on this worker's stream meanwhile. What the synthesis adds to
+            // the contexts' scratch (windows, gathers: ~100 MB per block) is released when the block's last type is done.
+            std::vector<std::vector<std::string>> marks(mine.size() * N_CTX);
+            for (size_t k = 0; k < mine.size() && rc == ZKW_OK; k++) {
+                zkw_block* B = blocks[mine[k]];
+                for (int i = 0; i < N_CTX; i++) zkw_ctx_scratch_mark(B->ctx[i], &marks[k * N_CTX + i]);
                 if (B->from_batch)
                     for (int i = 0; i < N_CTX && rc == ZKW_OK; i++) rc = zkw_set_stream(B->ctx[i], zkw_ctx_stream(wc));
-                if (rc == ZKW_OK) rc = block_synthesize_impl(B, n_rows, ring_slots, 0, 1, fwd, &f, &n, T_ECR, ring);
+            }
+            for (int t : kOrder) {
+                if (t == T_ECR) continue;
+                for (size_t k = 0; k < mine.size() && rc == ZKW_OK && first_rc.load() == ZKW_OK; k++) {
+                    Fwd f{mine[k], cb, user};
+                    size_t n = 0;
+                    rc = block_synthesize_impl(blocks[mine[k]], n_rows, ring_slots, 0, 1, fwd, &f, &n, T_ECR, ring, t);
+                    done += n;
+                }
+            }
+            for (size_t k = 0; k < mine.size(); k++) {
+                zkw_block* B = blocks[mine[k]];
+                for (int i = 0; i < N_CTX; i++)
+                    if (zkw_synchronize(B->ctx[i]) == ZKW_OK) zkw_ctx_scratch_release_since(B->ctx[i], marks[k * N_CTX + i]);
                 if (B->from_batch)
                     for (int i = 0; i < N_CTX; i++) { const int r2 = zkw_set_stream(B->ctx[i], shared); if (rc == ZKW_OK) rc = r2; }
-                done += n;
-                if (rc != ZKW_OK) { note(rc); break; }
             }
+            if (rc != ZKW_OK) note(rc);
             zkw_trace_free(ring);
             zkw_destroy(wc);
         });
     for (auto& t : pool) t.join();
     ec_thread.join();
+    if (getenv("ZKW_BLOCK_MEM_LOG")) {
+        size_t scratch = 0, live = 0, idle = 0, per_ctx[N_CTX] = {};
+        static const char* cn[N_CTX] = {"dec", "ram", "dmx", "sto", "evt", "l1", "pre"};
+        for (size_t k = 0; k < n_blocks; k++)
+            for (int i = 0; i < N_CTX; i++)
+                if (blocks[k]->ctx[i]) { per_ctx[i] += zkw_ctx_scratch_bytes(blocks[k]->ctx[i]); scratch += zkw_ctx_scratch_bytes(blocks[k]->ctx[i]); }
+        zkw_cache_stats(&live, &idle);
+        fprintf(stderr, "[zkw blocks] after the synthesis of %zu blocks: %.1f GB of device buffers handed out (%.1f GB idle in the cache), context scratch %.1f MB per block:", n_blocks, live / 1e9,
+                idle / 1e9, scratch / 1e6 / n_blocks);
+        for (int i = 0; i < N_CTX; i++) fprintf(stderr, " %s %.1f", cn[i], per_ctx[i] / 1e6 / n_blocks);
+        fprintf(stderr, "\n");
+    }
     if (n_done) *n_done = done.load();
     return first_rc.load();
 }

@@ -41,6 +41,9 @@ template <class T> static inline hipError_t dev_malloc(T** p, size_t bytes) { re
 static inline void dev_free(void* p) { zkw_cache_release(0, p); }
 static inline hipError_t pin_malloc(void** p, size_t bytes) { return zkw_cache_alloc(1, p, bytes); }
 static inline void pin_free(void* p) { zkw_cache_release(1, p); }
+// the library's stream pool (zkw_api.hip): streams are never destroyed while pooled; a released stream must be idle or ordered by events
+hipError_t zkw_pool_stream_acquire(hipStream_t* s);
+void zkw_pool_stream_release(hipStream_t s);
 
 #define HIP_TRY(expr)                                                                               \
     do {                                                                                            \
@@ -95,20 +98,23 @@ struct zkw_ctx {
     }
     hipError_t sync_stream() {
         if (batched()) return zkw_batch_sync(batch) == ZKW_OK ? hipSuccess : hipErrorUnknown;
+        if (side_stream && side_join() != ZKW_OK) return hipErrorUnknown;  // a fork left open by a failed call
         return hipStreamSynchronize(stream);
     }
     hipStream_t chain_stream = nullptr;  // optional second stream for the queue-chain kernels (zkw_set_chain_stream)
     hipEvent_t chain_ev_a = nullptr, chain_ev_b = nullptr;
-    // a lazily created side stream for work that depends on nothing the main stream is about to write (the closed-form sponges of the
-    // netlist circuits): fork = it waits for everything queued on `stream` so far, join = `stream` waits for it
+    // a side stream for work that depends on nothing the main stream is about to write (the closed-form sponges of the netlist circuits):
+    // fork = it waits for everything queued on `stream` so far, join = `stream` waits for it. Borrowed from the library's stream pool for the
+    // time between the two (round 6; it used to be created per context and destroyed with it: two streams per block in flight, and
+    // hipStreamDestroy waits for the whole device). A fork that was never joined — a failure in between — is joined by sync_stream().
     hipStream_t side_stream = nullptr;
     hipEvent_t side_ev_fork = nullptr, side_ev_join = nullptr;
     int side_fork(hipStream_t* out) {
-        if (!side_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+        if (!side_ev_fork) {
             HIP_TRY(hipEventCreateWithFlags(&side_ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&side_ev_join, hipEventDisableTiming));
         }
+        if (!side_stream) HIP_TRY(zkw_pool_stream_acquire(&side_stream));
         HIP_TRY(hipEventRecord(side_ev_fork, stream));
         HIP_TRY(hipStreamWaitEvent(side_stream, side_ev_fork, 0));
         *out = side_stream;
@@ -116,8 +122,13 @@ struct zkw_ctx {
     }
     int side_join() {
         if (!side_stream) return ZKW_OK;
-        HIP_TRY(hipEventRecord(side_ev_join, side_stream));
-        HIP_TRY(hipStreamWaitEvent(stream, side_ev_join, 0));
+        hipStream_t s = side_stream;
+        side_stream = nullptr;
+        const hipError_t e1 = hipEventRecord(side_ev_join, s);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(stream, side_ev_join, 0) : e1;
+        if (e2 != hipSuccess) (void)hipStreamSynchronize(s);  // the stream goes back to the pool idle either way
+        zkw_pool_stream_release(s);
+        HIP_TRY(e2);
         return ZKW_OK;
     }
     // witnesses and traces created from this context keep it alive: zkw_destroy defers while any is outstanding

@@ -204,6 +204,7 @@ SYMBOLS = [
     ("zkw_blocks_gather_closed_form_inputs", _int, [_vp, _sz, _vp, _int, _int, _int, _sz, _vp]),
     ("zkw_block_last_error", C.c_char_p, []),
     ("zkw_block_free", None, [_vp]),
+    ("zkw_blocks_free", None, [_vp, _sz]),
     ("zkw_block_witness", _vp, [_vp, C.c_uint8]),
     ("zkw_block_context", _vp, [_vp, C.c_uint8]),
     ("zkw_block_num_instances", _sz, [_vp, C.c_uint8]),
@@ -1561,7 +1562,7 @@ class BlockInputs(C.Structure):
                 ("num_non_deterministic_heap_queries", C.c_uint32),
                 ("storage_tree", STORAGE_TREE_FN), ("storage_tree_user", C.c_void_p),
                 ("storage_initial_root", C.c_uint8 * 32), ("storage_initial_next_enumeration_index", C.c_uint64),
-                ("capacities", C.c_uint32 * 14), ("vm_tracer", C.c_void_p)]
+                ("capacities", C.c_uint32 * 14), ("vm_tracer", C.c_void_p), ("queues_on_device", C.c_uint32)]
 
 
 class Block:
@@ -1574,21 +1575,51 @@ class Block:
                        6: "zkw_precompile_witness", 7: "zkw_precompile_witness", 8: "zkw_ram_witness", 9: "zkw_storage_witness",
                        10: "zkw_storage_application_witness", 11: "zkw_events_witness", 12: "zkw_events_witness"}
 
+    @staticmethod
+    def queues_to_device(block, device_id=0):
+        """The block dict with its four queues (VM memory queries, decommit requests, log queries, the precompiles' memory queries) copied
+        to the device ONCE, as a VM running next to the library would leave them: Block(..) of the result passes device pointers
+        (zkw_block_inputs.queues_on_device) and the builders read them in place. The host arrays stay in the dict for callers that
+        want them."""
+        import torch
+
+        def up(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(torch.device("cuda", device_id))
+            return (t, a.size)
+
+        d = dict(block)
+        d["_device_queues"] = {"vm": up(block["vm_memory_queries"], MEM_QUERY), "dq": up(block["decommit_queries"], DECOMMIT_QUERY),
+                               "lq": up(block["log_queries"], LOG_QUERY),
+                               "pm": [up(block["precompile_memory_queries"][k], MEM_QUERY) for k in range(3)]}
+        torch.cuda.synchronize(device_id)
+        return d
+
     def __init__(self, device_id, block, capacities=None, storage_tree=None, storage_initial_root=None,
                  storage_next_enumeration_index=0, num_non_deterministic_heap_queries=0, vm_tracer=None, _run=True):
         lib = load()
         inp = BlockInputs()
         keep = []
         self._inp = inp
+        dev_q = block.get("_device_queues")
 
-        def arr(a, dtype):
+        class _Dev:  # a queue that lives on the device: what the input struct needs of it
+            def __init__(self, pair):
+                self.tensor, self.size = pair
+                self.ctypes = type("p", (), {"data": self.tensor.data_ptr() if self.size else None})
+
+        def arr(a, dtype, dev=None):
+            if dev is not None:
+                keep.append(dev[0])
+                return _Dev(dev)
             a = np.ascontiguousarray(a, dtype=dtype)
             keep.append(a)
             return a
 
-        vm = arr(block["vm_memory_queries"], MEM_QUERY)
+        inp.queues_on_device = 1 if dev_q else 0
+        vm = arr(block["vm_memory_queries"], MEM_QUERY, dev_q and dev_q["vm"])
         inp.vm_memory_queries, inp.n_vm_memory_queries = vm.ctypes.data, vm.size
-        dq = arr(block["decommit_queries"], DECOMMIT_QUERY)
+        dq = arr(block["decommit_queries"], DECOMMIT_QUERY, dev_q and dev_q["dq"])
         inp.decommit_queries, inp.n_decommit_queries = dq.ctypes.data, dq.size
         hashes = list(block["bytecodes"].keys())
         codes = [np.ascontiguousarray(block["bytecodes"][h], dtype=np.uint32).reshape(-1, 8) for h in hashes]
@@ -1596,10 +1627,10 @@ class Block:
         ww = arr(np.concatenate(codes) if codes else np.zeros((0, 8), np.uint32), np.uint32)
         wo = arr(np.concatenate([[0], np.cumsum([c.shape[0] for c in codes])]), np.uint64)
         inp.bytecode_hashes, inp.bytecode_words, inp.bytecode_word_offsets, inp.n_bytecodes = hh.ctypes.data, ww.ctypes.data, wo.ctypes.data, len(hashes)
-        lq = arr(block["log_queries"], LOG_QUERY)
+        lq = arr(block["log_queries"], LOG_QUERY, dev_q and dev_q["lq"])
         inp.log_queries, inp.n_log_queries = lq.ctypes.data, lq.size
         for k in range(3):
-            mq = arr(block["precompile_memory_queries"][k], MEM_QUERY)
+            mq = arr(block["precompile_memory_queries"][k], MEM_QUERY, dev_q and dev_q["pm"][k])
             inp.precompile_memory_queries[k] = mq.ctypes.data if mq.size else None
             inp.n_precompile_memory_queries[k] = mq.size
         inp.num_non_deterministic_heap_queries = num_non_deterministic_heap_queries
@@ -1624,7 +1655,7 @@ class Block:
             inp.storage_initial_next_enumeration_index = storage_next_enumeration_index
         if vm_tracer is not None:  # the tracer's cycle-stamped vectors: MainVM instance records come back with the block
             t = dict(vm_tracer)
-            t.setdefault("vm_memory_queries", vm)              # ignored by the block (it uses its own memory queue / states)
+            t.setdefault("vm_memory_queries", np.ascontiguousarray(block["vm_memory_queries"], dtype=MEM_QUERY))  # ignored by the block (it uses its own memory queue / states)
             t.setdefault("memory_queue_tails", np.zeros((vm.size, 12), np.uint64))
             t.setdefault("decommit_queue_tails", np.zeros((dq.size, 12), np.uint64))
             self._vm_struct = _vm_streams_struct(t, keep)
@@ -1656,6 +1687,31 @@ class Block:
             raise ZkwError(rc, (lib.zkw_block_last_error() or b"").decode() or lib.zkw_last_error().decode())
         for o, h in zip(objs, outs):
             o.handle = C.c_void_p(h)
+        return objs
+
+    @staticmethod
+    def prepare_many(device_id, blocks, capacities=None):
+        """The input structs of `blocks` built once (a service that receives its blocks as arrays does this as they arrive): the list
+        run_prepared takes, any number of times."""
+        return [Block(device_id, b, capacities, _run=False) for b in blocks]
+
+    @staticmethod
+    def run_prepared(device_id, templates):
+        """zkw_blocks_run over inputs prepared by prepare_many: nothing but the call. Returns new Block objects (the templates stay
+        reusable; they share the input arrays)."""
+        import copy
+
+        lib = load()
+        ptrs = (C.c_void_p * len(templates))(*[C.addressof(o._inp) for o in templates])
+        outs = (C.c_void_p * len(templates))()
+        rc = lib.zkw_blocks_run(device_id, ptrs, len(templates), outs)
+        if rc != OK:
+            raise ZkwError(rc, (lib.zkw_block_last_error() or b"").decode() or lib.zkw_last_error().decode())
+        objs = []
+        for t, h in zip(templates, outs):
+            o = copy.copy(t)
+            o.handle = C.c_void_p(h)
+            objs.append(o)
         return objs
 
     @staticmethod
@@ -1841,6 +1897,17 @@ class Block:
         if self.handle:
             load().zkw_block_free(self.handle)
             self.handle = C.c_void_p(None)
+
+    @staticmethod
+    def free_many(blocks):
+        """zkw_blocks_free: the blocks released on a few threads of the library"""
+        live = [b for b in blocks if b is not None and b.handle]
+        if not live:
+            return
+        hs = (C.c_void_p * len(live))(*[b.handle for b in live])
+        load().zkw_blocks_free(hs, len(live))
+        for b in live:
+            b.handle = C.c_void_p(None)
 
     def __del__(self):
         try:

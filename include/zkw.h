@@ -1029,13 +1029,18 @@ typedef struct zkw_block_inputs {
        n_decommit_states must equal n_decommit_queries: the block supplies vm_memory_queries, memory_queue_tails and
        decommit_queue_tails itself, from the states it has just hashed (the fields of the same name are ignored). */
     const zkw_vm_tracer_streams *vm_tracer;
+    /* nonzero: the four QUEUES — vm_memory_queries, decommit_queries, log_queries, precompile_memory_queries[] — are DEVICE pointers
+       (a VM that runs next to the library leaves them in HBM); they are read, never written, and must stay valid until the block is
+       freed. The bytecodes and vm_tracer stay HOST pointers. 0 (the default): everything is host memory. */
+    uint32_t queues_on_device;
 } zkw_block_inputs;
-/* All pointers in `in` are HOST pointers. Blocks until every builder has finished. */
+/* All pointers in `in` are HOST pointers (but see queues_on_device). Blocks until every builder has finished. */
 int zkw_block_run(int device_id, const zkw_block_inputs *in, zkw_block **out);
-/* n_blocks independent blocks at once (a witness-generation service's batch): the same graph per block, one host thread
-   each, all queue chains of all blocks merged into a few launches by the device's chain service (zkw_set_chain_service):
-   K blocks cost about one block's chain pass while SIMDs and memory last. out[k] receives block k; on failure every block
-   is released and out[] is all NULL. */
+/* n_blocks independent blocks at once (a witness-generation service's batch): the same graph per block, but no host thread and no
+   stream per block — the blocks' builder branches run as fibers of the calling thread, and the launches they make of the same kernel
+   leave as ONE launch over a job table, a stage's queue chains as one chain launch (csrc/zkw_batch.h): K blocks cost about one block's
+   chain pass while SIMDs and memory last (~0.3 GB of HBM per production-capacity block). Each block's results are what zkw_block_run
+   gives for it alone. out[k] receives block k; on failure every block is released and out[] is all NULL. */
 int zkw_blocks_run(int device_id, const zkw_block_inputs *const *inputs, size_t n_blocks, zkw_block **out);
 /* The same on one rank of a multi-GPU job, the BLOCKS sharded (the mode that scales: nothing is replicated): rank r builds the
    blocks k with zkw_blocks_owner(k, world) == r (round-robin) and leaves out[k] = NULL for the others. Every rank passes the same
@@ -1052,6 +1057,8 @@ int zkw_blocks_gather_closed_form_inputs(zkw_block *const *blocks, size_t n_bloc
    is not the caller's) */
 const char *zkw_block_last_error(void);
 void zkw_block_free(zkw_block *b);
+/* n_blocks blocks released on a few threads of the library (NULL entries are skipped); what zkw_block_free does for each. */
+void zkw_blocks_free(zkw_block *const *blocks, size_t n_blocks);
 /* witness of one circuit type, to be cast to its zkw_*_witness type (2 zkw_decommit_witness, 3 zkw_decommitter_witness,
    4 zkw_demux_witness, 5/6/7 zkw_precompile_witness, 8 zkw_ram_witness, 9 zkw_storage_witness, 10
    zkw_storage_application_witness, 11/12 zkw_events_witness); NULL for the others. The handles belong to the block and

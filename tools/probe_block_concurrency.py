@@ -1,5 +1,5 @@
-"""K production-capacity blocks in flight at once through zkw_blocks_run (one host thread per block, every queue chain of
-every block merged into a few launches by the chain service): throughput of whole blocks. Usage: probe_block_concurrency.py K [reps]"""
+"""K production-capacity blocks in flight at once through zkw_blocks_run (the blocks' builders as fibers of one thread, their launches
+merged per kernel and stage: csrc/zkw_batch.h): throughput of whole blocks. Usage: probe_block_concurrency.py K [reps]"""
 import sys, time
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
@@ -15,6 +15,8 @@ for r in range(reps):
     t0 = time.perf_counter()
     bs = nv.Block.run_many(0, blocks)
     t1 = time.perf_counter()
+    import torch
+    free_b, total_b = torch.cuda.mem_get_info(0)
     n = nv.Block.synthesize_many(bs, 1 << 20, ring_slots=1)
     t2 = time.perf_counter()
     spans = {}
@@ -23,4 +25,4 @@ for r in range(reps):
     for b in bs: b.free()
     t3 = time.perf_counter()
     print(f"K={K:3d} round {r}: builders {1e3*(t1-t0):.0f} ms, synthesis of {n} instances {1e3*(t2-t1):.0f} ms, free {1e3*(t3-t2):.0f} ms -> "
-          f"{K/(t2-t0):.2f} blocks/s, {n/(t2-t0):.1f} synthesized circuits/s; block 0 spans: ram {spans.get('ram_permutation')}, dec {spans.get('decommit_sorter.finish')}, dmx {spans.get('log_demuxer')}")
+          f"{K/(t2-t0):.2f} blocks/s, {n/(t2-t0):.1f} synthesized circuits/s; block 0 spans: ram {spans.get('ram_permutation')}, dec {spans.get('decommit_sorter.finish')}, dmx {spans.get('log_demuxer')}; HBM in use after the builders {(total_b - free_b) / 2**30:.1f} GiB")
