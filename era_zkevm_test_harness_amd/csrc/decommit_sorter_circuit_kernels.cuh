@@ -154,12 +154,12 @@ __device__ __forceinline__ void ds_prev_result_queue(const DsSynthJob& job, cons
 // ------------------------------------------------------------------------------------------------
 // Poseidon2 rows: WHICH 0 = PU (pop unsorted), 1 = PS (pop sorted), 2 = PR (push into the deduplicated queue)
 template <int WHICH>
-static __global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ds_fill_poseidon(const VB& vb, const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     for (int t = threadIdx.x; t < 256; t += blockDim.x) sh_hist[t] = 0;
     __syncthreads();
-    const DsSynthJob& job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const DsSynthJob& job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = DS_REGION_STRIDE(capacity);
     constexpr int ROW = WHICH == 0 ? DS_ROW_PU : (WHICH == 1 ? DS_ROW_PS : DS_ROW_PR);
     u64* trace = job.trace;
@@ -201,7 +201,7 @@ static __global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob
     } else if (i < rs) {
         if (!job.tail_clean) zero_gap_row(trace, n_rows, (size_t)ROW * rs + i);
     }
-    if (WHICH == 1 && blockIdx.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells (GIN / GOUT: bytes of the FSM records' page and first-encountered timestamp)
+    if (WHICH == 1 && vb.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells (GIN / GOUT: bytes of the FSM records' page and first-encountered timestamp)
         hist_bytes(sh_hist, job.inst->hidden_fsm_input.previous_record.memory_page);
         hist_bytes(sh_hist, job.inst->hidden_fsm_input.first_encountered_timestamp);
         hist_bytes(sh_hist, job.inst->hidden_fsm_output.previous_record.memory_page);  // GOUT: the handed-over group's page and first timestamp
@@ -217,12 +217,12 @@ static __global__ __launch_bounds__(64) void k_ds_fill_poseidon(const DsSynthJob
 #define DS_XG(col, v) TR(col, row) = glob.v;
 
 template <int ROW>
-static __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ds_fill_row(const VB& vb, const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
-    const DsSynthJob& job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const DsSynthJob& job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = DS_REGION_STRIDE(capacity);
     u64* trace = job.trace;
     if (i < capacity) {
@@ -363,17 +363,17 @@ static __global__ __launch_bounds__(256) void k_ds_fill_row(const DsSynthJob* __
 // the zero padding below the boundary rows and the multiplicity column (see k_ram_fill_tail)
 constexpr int DS_BOUNDARY_ROWS = (DS_NUM_ROW_TYPES - DS_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
 __device__ __forceinline__ void ds_boundary_block(const DsSynthJob& job, u32 capacity, size_t n_rows);
-static __global__ __launch_bounds__(256) void k_ds_fill_tail(const DsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ds_fill_tail(const VB& vb, const DsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
     // dependent permutations that the other blocks' stores hide), then (DS_G + DS_L + 1) * TAIL_CHUNKS blocks per trace
-    if (blockIdx.x < n_jobs) {
+    if (vb.x < n_jobs) {
         __builtin_amdgcn_s_setprio(3);
-        ds_boundary_block(jobs[blockIdx.x], capacity, n_rows);
+        ds_boundary_block(jobs[vb.x], capacity, n_rows);
         return;
     }
     constexpr u32 PER_JOB = (DS_G + DS_L + 1) * TAIL_CHUNKS;
-    const u32 bid = (blockIdx.x - n_jobs) % PER_JOB;
-    const DsSynthJob& job = jobs[(blockIdx.x - n_jobs) / PER_JOB];
+    const u32 bid = (vb.x - n_jobs) % PER_JOB;
+    const DsSynthJob& job = jobs[(vb.x - n_jobs) / PER_JOB];
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < DS_G + DS_L) {

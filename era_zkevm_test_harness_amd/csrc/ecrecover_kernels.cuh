@@ -37,9 +37,9 @@ struct EcJob {
 };
 
 // grid (cycles, jobs) x 128: input byte k of cycle c = value byte k % 32 (little end first) of read k / 32; zeros for an idle cycle
-static __global__ __launch_bounds__(128) void k_ec_inputs(const EcJob* __restrict__ jobs) {
-    const EcJob j = jobs[blockIdx.y];
-    const u32 c = blockIdx.x, k = threadIdx.x;
+static __device__ void k_ec_inputs(const VB& vb, const EcJob* __restrict__ jobs) {
+    const EcJob j = jobs[vb.y];
+    const u32 c = vb.x, k = threadIdx.x;
     u32 v = 0;
     if (c < j.n_active) v = (j.mem_q[6 * (j.first_request + c) + k / 32].value[(k % 32) / 4] >> (8 * (k % 4))) & 0xFF;
     j.inputs[(size_t)c * 128 + k] = (uint8_t)v;
@@ -48,13 +48,13 @@ static __global__ __launch_bounds__(128) void k_ec_inputs(const EcJob* __restric
 // grid (cycles / EC_TAPE_LANES, jobs): a lane per cycle; the workspace of the 256-bit arithmetic (every array with run-time indices) is
 // a slice of LDS per lane. status: atomicMax of 1 + (job << 16 | cycle) for a cycle whose inputs have no witness
 constexpr int EC_TAPE_LANES = 64;
-static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_tape(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status) {
+static __device__ void k_ec_tape(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status) {
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
-    const EcJob j = jobs[blockIdx.y];
-    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    const EcJob j = jobs[vb.y];
+    const u32 c = vb.x * blockDim.x + threadIdx.x;
     if (c >= capacity) return;
     const ec_spec S = *Sp;
-    if (ec_eval_cycle(&S, j.inputs + (size_t)c * 128, j.tape + (size_t)c * EC_TAPE_PER_CYCLE, &s_ws[threadIdx.x])) atomicMax(status, 1u + (blockIdx.y << 16 | c));
+    if (ec_eval_cycle(&S, j.inputs + (size_t)c * 128, j.tape + (size_t)c * EC_TAPE_PER_CYCLE, &s_ws[threadIdx.x])) atomicMax(status, 1u + (vb.y << 16 | c));
 }
 
 // ---- the base field of secp256k1 for the accumulator chain: OUTLINED multiplication ------------------------------------------------
@@ -213,12 +213,12 @@ __device__ __forceinline__ ec_u256 ec_load_limbs(const u64* __restrict__ tape, c
 }
 
 // grid (cycles / EC_TAPE_LANES, jobs): a lane per cycle
-static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_chain(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
+static __device__ void k_ec_chain(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
     __builtin_amdgcn_s_setprio(3);  // a request's accumulator chain is one lane and 13 ms of dependent instructions: its wave issues before whatever
                                     // shares the SIMD (another call's segment / stream kernels when two calls are in flight)
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
-    const EcJob j = jobs[blockIdx.y];
-    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    const EcJob j = jobs[vb.y];
+    const u32 c = vb.x * blockDim.x + threadIdx.x;
     if (c >= capacity) return;
     const ec_spec S = *Sp;
     ec_ws* W = &s_ws[threadIdx.x];
@@ -226,9 +226,9 @@ static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_chain(const ec_spec
     ec_eval_ctx E;
     E.S = &S; E.tape = tape; E.in = j.inputs + (size_t)c * 128; E.W = W;
     E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
-    if (const int bad = ec_eval_segment(&E, S.runs[0].type)) { atomicMax(status, 1u + (blockIdx.y << 16 | c)); (void)bad; return; }
+    if (const int bad = ec_eval_segment(&E, S.runs[0].type)) { atomicMax(status, 1u + (vb.y << 16 | c)); (void)bad; return; }
     const ec_mod M = ec_modulus(0);
-    const size_t slot = (size_t)blockIdx.y * capacity + c;
+    const size_t slot = (size_t)vb.y * capacity + c;
     ec_jac* pts = sc.pts + slot * EC_CHAIN_POINTS;
     ec_u256* pre = sc.pre + slot * EC_CHAIN_POINTS;
     const ec_u256 rx = ec_load_limbs(tape, S.globs + EC_GL_RX), ry = ec_load_limbs(tape, S.globs + EC_GL_RY);
@@ -264,7 +264,7 @@ static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_chain(const ec_spec
     for (u32 k = 0; k < EC_CHAIN_POINTS; k++) {
         pre[k] = run;
         const ec_u256 z = pts[k].z;
-        if (ec_is_zero8(&z)) { atomicMax(status, 1u + (blockIdx.y << 16 | c)); return; }
+        if (ec_is_zero8(&z)) { atomicMax(status, 1u + (vb.y << 16 | c)); return; }
         run = ecf::mul(run, z);
     }
     ec_u256 inv = ec_invmod(&run, &M, W);  // binary extended Euclid (include/zkw_ecrecover.h)
@@ -288,14 +288,14 @@ static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_chain(const ec_spec
 
 // grid (segments after PRE = 289, lanes' chunks of the call's cycles): lane = one cycle of the call (job-major), block = one segment,
 // so that a wave runs ONE item list
-static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_segments(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, u32* status) {
+static __device__ void k_ec_segments(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, u32* status) {
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
-    const u32 lane = blockIdx.y * blockDim.x + threadIdx.x;
+    const u32 lane = vb.y * blockDim.x + threadIdx.x;
     if (lane >= n_cycles) return;
     const u32 job = lane / capacity, c = lane % capacity;
     const EcJob j = jobs[job];
     const ec_spec S = *Sp;
-    u32 seg = blockIdx.x, run = 1;
+    u32 seg = vb.x, run = 1;
     while (seg >= S.runs[run].count) { seg -= S.runs[run].count; run++; }
     u32 prun, pinst;
     ec_prev_segment(&S, run, seg, &prun, &pinst);
@@ -309,9 +309,9 @@ static __global__ __launch_bounds__(EC_TAPE_LANES) void k_ec_segments(const ec_s
 }
 
 // grid (cycles / 64, jobs): the netlist's inputs of a cycle from its tape
-static __global__ __launch_bounds__(64) void k_ec_prepare(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity) {
-    const EcJob j = jobs[blockIdx.y];
-    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_ec_prepare(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity) {
+    const EcJob j = jobs[vb.y];
+    const u32 c = vb.x * blockDim.x + threadIdx.x;
     if (c > capacity) return;
     if (c == 0)
         for (int k = 0; k < 200; k++) j.state_before[k] = 0;
@@ -343,9 +343,9 @@ static __global__ __launch_bounds__(64) void k_ec_prepare(const ec_spec* __restr
 #define EC_TR(col, row) trace[(size_t)(col) * n_rows + (size_t)(row)]
 
 // grid (rows of a cycle / 64, cycles, jobs): a lane per row
-static __global__ __launch_bounds__(64) void k_ec_stream(const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, u32 mult_col) {
-    const EcJob j = jobs[blockIdx.z];
-    const u32 c = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_ec_stream(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, u32 mult_col) {
+    const EcJob j = jobs[vb.z];
+    const u32 c = vb.y, r = vb.x * blockDim.x + threadIdx.x;
     if (r >= EC_ROWS_PER_CYCLE) return;
     const ec_spec& S = *Sp;
     u64* trace = j.trace;

@@ -149,9 +149,9 @@ __device__ __forceinline__ void es_queue_op(u64* trace, size_t n_rows, size_t r1
 
 // WHICH 0 = unsorted pop (U1..U3), 1 = sorted pop (S1..S3), 2 = result push (R1..R3)
 template <int WHICH>
-static __global__ __launch_bounds__(64) void k_es_fill_queue(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const EsSynthJob& job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_es_fill_queue(const VB& vb, const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const EsSynthJob& job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = ES_REGION_STRIDE(capacity);
     constexpr int R1 = WHICH == 0 ? ES_ROW_U1 : (WHICH == 1 ? ES_ROW_S1 : ES_ROW_R1);
     u64* trace = job.trace;
@@ -188,12 +188,12 @@ static __global__ __launch_bounds__(64) void k_es_fill_queue(const EsSynthJob* _
 #define ES_XG(col, v) TR(col, row) = glob.v;
 
 template <int ROW>
-static __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_es_fill_row(const VB& vb, const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
-    const EsSynthJob& job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const EsSynthJob& job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = ES_REGION_STRIDE(capacity);
     u64* trace = job.trace;
     if (i < capacity) {
@@ -316,7 +316,7 @@ static __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __
     } else if (i < rs) {
         if (!job.tail_clean) zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, ES_G + ES_L);
     }
-    if (ROW == ES_ROW_A && blockIdx.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells: the key / address bytes of the FSM records' previous_item (bridge rows NIB* / NOB*)
+    if (ROW == ES_ROW_A && vb.x == 0 && threadIdx.x == 0) {  // the closed-form section's lookup cells: the key / address bytes of the FSM records' previous_item (bridge rows NIB* / NOB*)
         const zkw_log_query& a = job.inst->hidden_fsm_input.previous_item;
         const zkw_log_query& b = job.inst->hidden_fsm_output.previous_item;
         for (int k = 0; k < 8; k++) { hist_bytes(sh_hist, a.key[k]); hist_bytes(sh_hist, b.key[k]); }
@@ -327,17 +327,17 @@ static __global__ __launch_bounds__(256) void k_es_fill_row(const EsSynthJob* __
 
 constexpr int ES_BOUNDARY_ROWS = (ES_NUM_ROW_TYPES - ES_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
 __device__ __forceinline__ void es_boundary_block(const EsSynthJob& job, u32 capacity, size_t n_rows);
-static __global__ __launch_bounds__(256) void k_es_fill_tail(const EsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_es_fill_tail(const VB& vb, const EsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
     // dependent permutations that the other blocks' stores hide), then (ES_G + ES_L + 1) * TAIL_CHUNKS blocks per trace
-    if (blockIdx.x < n_jobs) {
+    if (vb.x < n_jobs) {
         __builtin_amdgcn_s_setprio(3);
-        es_boundary_block(jobs[blockIdx.x], capacity, n_rows);
+        es_boundary_block(jobs[vb.x], capacity, n_rows);
         return;
     }
     constexpr u32 PER_JOB = (ES_G + ES_L + 1) * TAIL_CHUNKS;
-    const u32 bid = (blockIdx.x - n_jobs) % PER_JOB;
-    const EsSynthJob& job = jobs[(blockIdx.x - n_jobs) / PER_JOB];
+    const u32 bid = (vb.x - n_jobs) % PER_JOB;
+    const EsSynthJob& job = jobs[(vb.x - n_jobs) / PER_JOB];
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < ES_G + ES_L) {

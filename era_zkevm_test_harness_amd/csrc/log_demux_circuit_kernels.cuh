@@ -98,9 +98,9 @@ __device__ __forceinline__ int ld_route(const LdSynthJob& job, const LdCycle& c)
 
 // WHICH 0 = pop of the input queue (I1..I3), 1 = the conditional push (P1..P3)
 template <int WHICH>
-static __global__ __launch_bounds__(64) void k_ld_fill_queue(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const LdSynthJob& job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_ld_fill_queue(const VB& vb, const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const LdSynthJob& job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = LD_REGION_STRIDE(capacity);
     constexpr int R1 = WHICH == 0 ? LD_ROW_I1 : LD_ROW_P1;
     u64* trace = job.trace;
@@ -140,12 +140,12 @@ static __global__ __launch_bounds__(64) void k_ld_fill_queue(const LdSynthJob* _
 #define LD_QUEUES(M) M(st, 0) M(ev, 1) M(l1, 2) M(kc, 3) M(sh, 4) M(ec, 5)
 
 template <int ROW>
-static __global__ __launch_bounds__(256) void k_ld_fill_row(const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ld_fill_row(const VB& vb, const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
-    const LdSynthJob& job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const LdSynthJob& job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = LD_REGION_STRIDE(capacity);
     u64* trace = job.trace;
     if (i < capacity) {
@@ -229,17 +229,17 @@ static __global__ __launch_bounds__(256) void k_ld_fill_row(const LdSynthJob* __
 
 constexpr int LD_BOUNDARY_ROWS = (LD_NUM_ROW_TYPES - LD_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
 __device__ __forceinline__ void ld_boundary_block(const LdSynthJob& job, u32 capacity, size_t n_rows);
-static __global__ __launch_bounds__(256) void k_ld_fill_tail(const LdSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ld_fill_tail(const VB& vb, const LdSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
     // dependent permutations that the other blocks' stores hide), then (LD_G + LD_L + 1) * TAIL_CHUNKS blocks per trace
-    if (blockIdx.x < n_jobs) {
+    if (vb.x < n_jobs) {
         __builtin_amdgcn_s_setprio(3);
-        ld_boundary_block(jobs[blockIdx.x], capacity, n_rows);
+        ld_boundary_block(jobs[vb.x], capacity, n_rows);
         return;
     }
     constexpr u32 PER_JOB = (LD_G + LD_L + 1) * TAIL_CHUNKS;
-    const u32 bid = (blockIdx.x - n_jobs) % PER_JOB;
-    const LdSynthJob& job = jobs[(blockIdx.x - n_jobs) / PER_JOB];
+    const u32 bid = (vb.x - n_jobs) % PER_JOB;
+    const LdSynthJob& job = jobs[(vb.x - n_jobs) / PER_JOB];
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < LD_G + LD_L) {

@@ -27,9 +27,9 @@ struct NlcfJob { u64* trace; u64 index; };  // the slot; the instance's index in
 #define NLCF_P(perm, v) NLCF_TR((v) % G, c0 + nlcf_perm_row0(&d, G, (perm)) + (v) / G)
 
 template <class T>
-static __global__ __launch_bounds__(256) void k_nlcf_sponges(nlcf_desc d, const typename T::Inst* __restrict__ inst, const NlcfJob* __restrict__ jobs, u32 G,
+static __device__ void k_nlcf_sponges(const VB& vb, nlcf_desc d, const typename T::Inst* __restrict__ inst, const NlcfJob* __restrict__ jobs, u32 G,
                                                              size_t n_rows, u64 c0) {
-    const NlcfJob job = jobs[blockIdx.x];
+    const NlcfJob job = jobs[vb.x];
     u64* __restrict__ trace = job.trace;
     __shared__ u64 sh_w[4][T::MAXLEN];
     __shared__ u64 sh_c[4][4];
@@ -134,13 +134,13 @@ __device__ __forceinline__ u64 nlcf_side(const nlcf_desc& d, const u64* __restri
 }
 
 // grid (tie cells / 256, instances)
-static __global__ __launch_bounds__(256) void k_nlcf_ties(nlcf_desc d, nlq_desc qd, const NlDev* __restrict__ devp, const NlcfJob* __restrict__ jobs, u32 cycles,
+static __device__ void k_nlcf_ties(const VB& vb, nlcf_desc d, nlq_desc qd, const NlDev* __restrict__ devp, const NlcfJob* __restrict__ jobs, u32 cycles,
                                                           size_t n_rows, u64 c0) {
     const nl_spec& S = devp->s;
     const u32 G = S.g;
-    u64* __restrict__ trace = jobs[blockIdx.y].trace;
+    u64* __restrict__ trace = jobs[vb.y].trace;
     NlcfTieAt at;
-    if (!nlcf_tie_at(d, blockIdx.x * blockDim.x + threadIdx.x, &at)) return;
+    if (!nlcf_tie_at(d, vb.x * blockDim.x + threadIdx.x, &at)) return;
     const nlcf_group& gr = d.g[at.gi];
     const u32 k = nlcf_tie_cell0(&d, at.gi, at.j) + at.c;
     NLCF_H(k) = at.c < 2 ? nlcf_side(d, trace, n_rows, c0, G, gr, at.j, (int)at.c) : nlcf_reg(d, qd, S, trace, n_rows, cycles, c0, gr, at.j, at.c - 2);

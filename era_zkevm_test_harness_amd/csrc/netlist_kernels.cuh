@@ -170,13 +170,13 @@ __device__ __forceinline__ void nl_eval_sel(u32 fn, u32 k, u32 a0, u32 a1, u32 a
 // 3.35 ms per 8 SHA-256 instances. The walk is bound by the latency of its dependent LDS reads, which two waves per SIMD hide
 // from each other and one wave per SIMD does not; CPW below is what is left of that experiment.)
 template <int W, int R, int WAVES>
-static __global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
+static __device__ void k_nl_fill(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
     constexpr int CPW = 1, NL_FILL_WAVES = WAVES, NL_FILL_THREADS = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr u32 LW = 64 / CPW;                             // lanes that share a cycle
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
-    const NlJob job = jobs[blockIdx.y];
+    const NlJob job = jobs[vb.y];
     const int t = threadIdx.x, wv = t >> 6;
     const u32 lane = (u32)(t & 63) % LW, sub = (u32)(t & 63) / LW;
     const NlV V(S);
@@ -242,7 +242,7 @@ static __global__ __launch_bounds__(64 * WAVES) void k_nl_fill(const NlDev* __re
     const u32* const g_key0 = D.step_key0;
     const u32* const g_pk0 = D.pk0;
     const u32 keys_per_cycle = D.keys_per_cycle;
-    for (u32 c0 = (blockIdx.x * (NL_FILL_WAVES / CPW) + wv) * CPW; c0 < capacity; c0 += gridDim.x * NL_FILL_WAVES) {
+    for (u32 c0 = (vb.x * (NL_FILL_WAVES / CPW) + wv) * CPW; c0 < capacity; c0 += vb.nx * NL_FILL_WAVES) {
         NL_WAVE_SYNC();  // the previous cycle's write phase has read everything it needs
         const bool live = c0 + sub < capacity;         // (the last pair of a trace may have one cycle only: its half walks along, stores nothing)
         const u32 c = live ? c0 + sub : c0;
@@ -442,7 +442,7 @@ __device__ __forceinline__ u32 nl_walk_get(const uint8_t* lds, u32 src, u32 o_va
 }
 
 template <int W, int R>
-static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity,
+static __device__ void k_nl_walk(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity,
                                                        uint8_t* __restrict__ scratch, size_t scratch_per_job, const u32* __restrict__ prog_g,
                                                        const u32* __restrict__ prog0, const uint16_t* __restrict__ out_src_g) {
     // the constant address space: never clobbered, so a uniform index is a scalar load whatever the loop stores
@@ -453,13 +453,13 @@ static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
-    const NlJob job = jobs[blockIdx.y];
-    const u32 lane = threadIdx.x, tile = blockIdx.x;
+    const NlJob job = jobs[vb.y];
+    const u32 lane = threadIdx.x, tile = vb.x;
     const u32 STATE = S.state, RPC = S.rows_per_cycle, STEPS = S.steps_per_cycle, FPC = S.free_per_cycle, G = S.g;
     const u32 c = min(tile * 64 + lane, capacity - 1);  // (the lanes beyond the last cycle walk it again; pass 2 ignores them)
     const u32 o_vals = 0, o_cyc = D.max_slots * 64 + 2 * STATE * 64, o_fr = o_cyc + STATE * 64;  // [slot][lane] | prev | next | cyc | free
     u32 o_prev = D.max_slots * 64, o_next = o_prev + STATE * 64;
-    uint8_t* const sc = scratch + blockIdx.y * scratch_per_job + (size_t)tile * ((size_t)S.mult_col * RPC * 64) + lane;
+    uint8_t* const sc = scratch + vb.y * scratch_per_job + (size_t)tile * ((size_t)S.mult_col * RPC * 64) + lane;
 #define NL_SC(col, row) sc[((size_t)(col) * RPC + (row)) * 64]
     const u32 bits = job.hdr_bits[c], h0 = bits & 1, h1 = (bits >> 1) & 1;
     const u32 h2 = (u32)(uint8_t)(S.masks[0] + S.masks[1] * (int)h0), h3 = (u32)(uint8_t)(S.masks[2] + S.masks[3] * (int)h1);
@@ -567,16 +567,16 @@ static __global__ __launch_bounds__(64) void k_nl_walk(const NlDev* __restrict__
 // rows of the cycle; the others: a lookup slot (W columns + its keys) x 64 rows. 64 x 64 bytes of the scratch tile per column
 // through LDS (row pitch 68 bytes: lanes read one byte each at distinct banks), then per cycle one 512-byte store per column.
 template <int W, int R>
-static __global__ __launch_bounds__(64) void k_nl_expand(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows,
+static __device__ void k_nl_expand(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows,
                                                          const uint8_t* __restrict__ scratch, size_t scratch_per_job) {
     __shared__ __attribute__((aligned(16))) uint8_t tileb[W][64 * 68];
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
-    const NlJob job = jobs[blockIdx.z];
-    const u32 lane = threadIdx.x, tile = blockIdx.y, RPC = S.rows_per_cycle, G = S.g;
+    const NlJob job = jobs[vb.z];
+    const u32 lane = threadIdx.x, tile = vb.y, RPC = S.rows_per_cycle, G = S.g;
     const u32 row_blocks = (RPC + 63) / 64;
-    const bool general = blockIdx.x < G * row_blocks;
-    const u32 u = general ? blockIdx.x : blockIdx.x - G * row_blocks;
+    const bool general = vb.x < G * row_blocks;
+    const u32 u = general ? vb.x : vb.x - G * row_blocks;
     const u32 rb = u % row_blocks, which = u / row_blocks;      // which: the column / the lookup slot
     const u32 col0 = general ? which : G + W * which, ncols = general ? 1 : W;
     const u32 r = rb * 64 + lane;                                // row of the cycle this lane stores
@@ -586,7 +586,7 @@ static __global__ __launch_bounds__(64) void k_nl_expand(const NlDev* __restrict
         bool any = row_ok && (rm.flags & 1);
         if (!__any(any)) return;
     }
-    const uint8_t* const sc = scratch + blockIdx.z * scratch_per_job + (size_t)tile * ((size_t)S.mult_col * RPC * 64);
+    const uint8_t* const sc = scratch + vb.z * scratch_per_job + (size_t)tile * ((size_t)S.mult_col * RPC * 64);
     const u32 rows_here = min(64u, RPC - rb * 64);
     for (u32 cc = 0; cc < ncols; cc++) {
         const u32* const src = reinterpret_cast<const u32*>(sc + ((size_t)(col0 + cc) * RPC + rb * 64) * 64);
@@ -624,16 +624,16 @@ static __global__ __launch_bounds__(64) void k_nl_expand(const NlDev* __restrict
 constexpr int NL_HIST_THREADS = 1024;
 constexpr int NL_HIST_HALF = 32768;
 template <int R>
-static __global__ __launch_bounds__(NL_HIST_THREADS) void k_nl_hist(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_nl_hist(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
-    const NlJob job = jobs[blockIdx.z];
-    const u32 half = blockIdx.y, t = threadIdx.x;
+    const NlJob job = jobs[vb.z];
+    const u32 half = vb.y, t = threadIdx.x;
     u32 tb = 0;
-    while (D.hist_slice0[tb + 1] <= blockIdx.x) tb++;
+    while (D.hist_slice0[tb + 1] <= vb.x) tb++;
     const nl_table T = S.tables[tb];
     if (half * NL_HIST_HALF >= T.rows) return;
-    const u32 split = blockIdx.x - D.hist_slice0[tb], n_splits = D.hist_slice0[tb + 1] - D.hist_slice0[tb];
+    const u32 split = vb.x - D.hist_slice0[tb], n_splits = D.hist_slice0[tb + 1] - D.hist_slice0[tb];
     __shared__ u32 s_bins[NL_HIST_HALF];
     const u32 nbins = T.rows < NL_HIST_HALF ? T.rows : NL_HIST_HALF;
     for (u32 i = t; i < nbins; i += NL_HIST_THREADS) s_bins[i] = 0;
@@ -689,16 +689,16 @@ static __global__ __launch_bounds__(NL_HIST_THREADS) void k_nl_hist(const NlDev*
             if (key[b] != 0xFFFFFFFFu && key[b] / NL_HIST_HALF == half) atomicAdd(&s_bins[key[b] % NL_HIST_HALF], 1u);
     }
     __syncthreads();
-    u32* const out = job.hist + ((size_t)blockIdx.x * 2 + half) * NL_HIST_HALF;
+    u32* const out = job.hist + ((size_t)vb.x * 2 + half) * NL_HIST_HALF;
     for (u32 i = t; i < nbins; i += NL_HIST_THREADS) out[i] = s_bins[i];
 }
 
 // the multiplicity column (sum of a table's slices), boundary rows (BND_IN, BND_OUT) and the public input row
-static __global__ __launch_bounds__(256) void k_nl_finish(const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_nl_finish(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
-    const NlJob job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const NlJob job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     if (i < S.total_table_rows) {
         u32 tb = 0;
         while (tb + 1 < S.n_tables && S.tables[tb + 1].offset <= i) tb++;
@@ -718,10 +718,10 @@ static __global__ __launch_bounds__(256) void k_nl_finish(const NlDev* __restric
 
 // ---- round records -> the engine's inputs. SHA-like: 64-byte blocks, state 8 words as 64 nibbles; Keccak-like: 136 / 200 bytes
 struct NlPrepJob { const void* rounds; u64 first_round; u32 n_active; uint8_t* hdr_bits; uint8_t* free_elems; uint8_t* state_before; u32 state; /* elements of a cycle state (SHA-256: 64 nibbles of the chaining value, then zeros) */ };
-static __global__ __launch_bounds__(128) void k_nl_prepare_sha(const NlPrepJob* __restrict__ jobs, u32 capacity) {
-    const NlPrepJob j = jobs[blockIdx.y];
+static __device__ void k_nl_prepare_sha(const VB& vb, const NlPrepJob* __restrict__ jobs, u32 capacity) {
+    const NlPrepJob j = jobs[vb.y];
     const zkw_sha256_round_record* rounds = static_cast<const zkw_sha256_round_record*>(j.rounds);
-    const u32 c = blockIdx.x, t = threadIdx.x;  // c in [0, capacity]: the state BEFORE cycle c
+    const u32 c = vb.x, t = threadIdx.x;  // c in [0, capacity]: the state BEFORE cycle c
     const u64 idx = j.first_round + (c < j.n_active ? c : j.n_active);  // records before the cycle
     for (u32 k = t; k < j.state; k += 128)
         j.state_before[(size_t)c * j.state + k] = (idx && k < 64) ? (uint8_t)((rounds[idx - 1].state_after[k >> 3] >> (4 * (k & 7))) & 15) : 0;
@@ -731,10 +731,10 @@ static __global__ __launch_bounds__(128) void k_nl_prepare_sha(const NlPrepJob* 
     j.free_elems[(size_t)c * 128 + t] = (uint8_t)((t & 1) ? b >> 4 : b & 15);
     if (t == 0) j.hdr_bits[c] = active ? (rounds[j.first_round + c].reset ? 1 : 0) : 2;
 }
-static __global__ __launch_bounds__(256) void k_nl_prepare_keccak(const NlPrepJob* __restrict__ jobs, u32 capacity) {
-    const NlPrepJob j = jobs[blockIdx.y];
+static __device__ void k_nl_prepare_keccak(const VB& vb, const NlPrepJob* __restrict__ jobs, u32 capacity) {
+    const NlPrepJob j = jobs[vb.y];
     const zkw_keccak_round_record* rounds = static_cast<const zkw_keccak_round_record*>(j.rounds);
-    const u32 c = blockIdx.x, t = threadIdx.x;
+    const u32 c = vb.x, t = threadIdx.x;
     const u64 idx = j.first_round + (c < j.n_active ? c : j.n_active);
     if (t < 200) j.state_before[(size_t)c * 200 + t] = idx ? rounds[idx - 1].state_after[t] : 0;
     if (c == capacity) return;

@@ -24,9 +24,9 @@ struct NlqFreeHome { uint16_t row, col; };  // the one cell of a cycle that hold
 #define NLQ_TR(col, row) trace[(size_t)(col) * n_rows + (size_t)(row)]
 
 // feed of a cycle from the builder's per-round record (the oracle walks the rounds instead: orc_sha256_queue_feed)
-static __global__ __launch_bounds__(64) void k_nlq_feed(int circuit_type, const NlqFeedJob* __restrict__ jobs, u32 capacity, u32 n_ops) {
-    const NlqFeedJob j = jobs[blockIdx.y];
-    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_nlq_feed(const VB& vb, int circuit_type, const NlqFeedJob* __restrict__ jobs, u32 capacity, u32 n_ops) {
+    const NlqFeedJob j = jobs[vb.y];
+    const u32 c = vb.x * blockDim.x + threadIdx.x;
     if (c >= capacity) return;
     nlq_feed* f = j.feed + (size_t)c * n_ops;
     if (circuit_type == 13) {  // message m is popped in the cycle that absorbs its first byte (at most two per cycle)
@@ -105,11 +105,11 @@ __device__ __forceinline__ u64 nlq_coop_p2(const p2::Coop& co, u64 x, u32 g, Put
 // Lane g computes what it needs itself — its cells of the ENC block (stride 16), the encoding elements its permutation inputs take —
 // from the item record / the linked netlist cells; only the permutation crosses lanes. (The first version gave an operation to a LANE:
 // its three dependent lane-serial permutations of ~65 us each were the whole kernel time.)
-static __global__ __launch_bounds__(64) void k_nlq_fill(const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, const NlqFreeHome* __restrict__ lh, nlq_desc d, const NlqJob* __restrict__ jobs,
+static __device__ void k_nlq_fill(const VB& vb, const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, const NlqFreeHome* __restrict__ lh, nlq_desc d, const NlqJob* __restrict__ jobs,
                                                         u32 capacity, size_t n_rows) {
     const nl_spec& S = devp->s;
-    const NlqJob& job = jobs[blockIdx.z];
-    const u32 g = threadIdx.x & 15, c_raw = blockIdx.x * 4 + (threadIdx.x >> 4), j = blockIdx.y;
+    const NlqJob& job = jobs[vb.z];
+    const u32 g = threadIdx.x & 15, c_raw = vb.x * 4 + (threadIdx.x >> 4), j = vb.y;
     const bool valid = c_raw < capacity;
     const u32 c = valid ? c_raw : capacity - 1;  // a row beyond the capacity recomputes the last cycle and stores nothing (DPP wants whole rows)
     u64* trace = job.trace;

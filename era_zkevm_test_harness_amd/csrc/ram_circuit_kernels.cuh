@@ -128,13 +128,13 @@ __device__ __forceinline__ void fill_flattened_poseidon(u64* trace, size_t n_row
 // Poseidon2 rows (regions PU and PS): one lane per cycle runs the permutation and stores all 130
 // flattened-gate variables as it goes. SIDE 0 = unsorted queue, 1 = sorted queue.
 template <int SIDE>
-static __global__ __launch_bounds__(64) void k_ram_fill_poseidon(const SynthJob* __restrict__ jobs, u32 capacity,
+static __device__ void k_ram_fill_poseidon(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity,
                                                           size_t n_rows) {
     __shared__ u32 sh_hist[256];
     for (int t = threadIdx.x; t < 256; t += blockDim.x) sh_hist[t] = 0;
     __syncthreads();
-    const SynthJob job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const SynthJob job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     if (i < capacity) {
         u64* trace = job.trace;
         const zkw_ram_instance* in = job.inst;
@@ -230,12 +230,12 @@ __device__ __forceinline__ u64 acc_before(const u64* z, size_t first, size_t m, 
     return i == 0 ? fsm_in : z[first + (i - 1 < m ? i - 1 : m - 1)];
 }
 
-static __global__ __launch_bounds__(256) void k_ram_fill_A(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ram_fill_A(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
-    const SynthJob job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const SynthJob job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const u64* lhs_z_all = job.lhs_z;
     const u64* rhs_z_all = job.rhs_z;
     const size_t n_total = job.n_block;
@@ -285,12 +285,12 @@ static __global__ __launch_bounds__(256) void k_ram_fill_A(const SynthJob* __res
     hist_flush(sh_hist, job.hist);
 }
 
-static __global__ __launch_bounds__(256) void k_ram_fill_B(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ram_fill_B(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
-    const SynthJob job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const SynthJob job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     if (i < capacity) {
         u64* trace = job.trace;
         const size_t row = (size_t)RC_ROW_B * RC_REGION_STRIDE(capacity) + i;
@@ -323,10 +323,10 @@ __device__ __forceinline__ bool nd_flag(bool can_pop, const zkw_mem_query& q) {
 }
 
 // per 256-cycle tile: number of nondeterministic writes; then an exclusive scan per instance
-static __global__ __launch_bounds__(256) void k_ram_nd_tiles(const SynthJob* __restrict__ jobs, u32 capacity) {
+static __device__ void k_ram_nd_tiles(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity) {
     __shared__ u32 sh[4];
-    const SynthJob job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const SynthJob job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const zkw_ram_instance* in = job.inst;
     bool f = false;
     if (i < capacity && i < in->num_items) {
@@ -337,11 +337,11 @@ static __global__ __launch_bounds__(256) void k_ram_nd_tiles(const SynthJob* __r
     u32 cnt = __popcll(__ballot(f));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) job.nd_tiles[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) job.nd_tiles[vb.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-static __global__ __launch_bounds__(64) void k_ram_nd_scan(const SynthJob* __restrict__ jobs, int n_jobs, u32 n_tiles) {
+static __device__ void k_ram_nd_scan(const VB& vb, const SynthJob* __restrict__ jobs, int n_jobs, u32 n_tiles) {
     // one wave per job: exclusive prefix over the tile counts, 64 tiles at a time
-    u32* t = jobs[blockIdx.x].nd_tiles;
+    u32* t = jobs[vb.x].nd_tiles;
     const int lane = threadIdx.x;
     u32 acc = 0;
     for (u32 base = 0; base < n_tiles; base += 64) {
@@ -357,13 +357,13 @@ static __global__ __launch_bounds__(64) void k_ram_nd_scan(const SynthJob* __res
     }
 }
 
-static __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ram_fill_C(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     __shared__ u32 sh_wave[4];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
-    const SynthJob job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const SynthJob job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const bool live = i < capacity;
     CycleCtx c;
     c.can_pop = false;
@@ -438,7 +438,7 @@ static __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __res
         TR(RC_C_zz_a, row) = zz_a; TR(RC_C_all_zero, row) = all_zero; TR(RC_C_rw, row) = rw;
         TR(RC_C_ts, row) = c.q.timestamp; TR(RC_C_w_ts, row) = w[12]; TR(RC_C_z_ts, row) = x[12] == 0;
         TR(RC_C_w_heap, row) = w[13]; TR(RC_C_z_heap, row) = x[13] == 0; TR(RC_C_nd, row) = nd ? 1 : 0;
-        const u64 p_cnt = (u64)in->hidden_fsm_input.num_nondeterministic_writes + job.nd_tiles[blockIdx.x] + before;
+        const u64 p_cnt = (u64)in->hidden_fsm_input.num_nondeterministic_writes + job.nd_tiles[vb.x] + before;
         TR(RC_C_P_cnt, row) = p_cnt; TR(RC_C_cnt, row) = p_cnt + (nd ? 1 : 0);
         constexpr int NC = ROW_SLOTS[RC_ROW_C];
         if (!job.tail_clean) {
@@ -448,7 +448,7 @@ static __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __res
     } else if (i < RC_REGION_STRIDE(capacity)) {
         if (!job.tail_clean) zero_gap_row(job.trace, n_rows, (size_t)RC_ROW_C * RC_REGION_STRIDE(capacity) + i);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)  // the closed-form section's lookup cells (VIN / VOUT: bytes of limbs 5..7 of the previous value)
+    if (vb.x == 0 && threadIdx.x == 0)  // the closed-form section's lookup cells (VIN / VOUT: bytes of limbs 5..7 of the previous value)
         for (int l = 5; l < 8; l++) { hist_bytes(sh_hist, job.inst->hidden_fsm_input.previous_value[l]); hist_bytes(sh_hist, job.inst->hidden_fsm_output.previous_value[l]); }
     hist_flush(sh_hist, job.hist);
 }
@@ -458,16 +458,16 @@ static __global__ __launch_bounds__(256) void k_ram_fill_C(const SynthJob* __res
 // it (it reads the last cycle's row C, an earlier kernel; nothing of row D); then n_tiles blocks of 256 cycles per trace.
 __device__ __forceinline__ void ram_boundary_block(const SynthJob& job, u32 capacity, size_t n_rows);
 constexpr int RC_D_TILES = 4;  // tiles of 256 cycles per row-D block
-static __global__ __launch_bounds__(256) void k_ram_fill_D(const SynthJob* __restrict__ jobs, u32 n_jobs, u32 n_tiles, u32 capacity, size_t n_rows) {
-    if (blockIdx.x < n_jobs) {
+static __device__ void k_ram_fill_D(const VB& vb, const SynthJob* __restrict__ jobs, u32 n_jobs, u32 n_tiles, u32 capacity, size_t n_rows) {
+    if (vb.x < n_jobs) {
         __builtin_amdgcn_s_setprio(3);
-        ram_boundary_block(jobs[blockIdx.x], capacity, n_rows);
+        ram_boundary_block(jobs[vb.x], capacity, n_rows);
         return;
     }
     // a row-D block covers RC_D_TILES consecutive tiles of 256 cycles, a lane one cycle of each: the row's one expensive witness is the inverse of
     // the queue length, and the lane's RC_D_TILES inverses come from ONE field inversion (Montgomery's trick: 3 (K - 1) multiplications more)
-    const SynthJob& job = jobs[(blockIdx.x - n_jobs) / n_tiles];
-    const u32 i0 = ((blockIdx.x - n_jobs) % n_tiles) * (RC_D_TILES * 256) + threadIdx.x;
+    const SynthJob& job = jobs[(vb.x - n_jobs) / n_tiles];
+    const u32 i0 = ((vb.x - n_jobs) % n_tiles) * (RC_D_TILES * 256) + threadIdx.x;
     const size_t rs = RC_REGION_STRIDE(capacity);
     u64* trace = job.trace;
     const zkw_ram_instance* in = job.inst;
@@ -531,11 +531,11 @@ constexpr int TAIL_CHUNKS = 8;
 constexpr int RC_BOUNDARY_ROWS = RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE;  // register rows, PI, the closed-form section
 constexpr int RC_CF_LOOKUP_CELLS = 24;                                   // VIN / VOUT byte cells (counted in job.hist by k_ram_fill_C)
 static_assert(RC_BOUNDARY_ROWS % 2 == 0, "the tail's 16-byte stores start below the boundary rows");
-static __global__ __launch_bounds__(256) void k_ram_fill_tail(const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ram_fill_tail(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: (RC_G + RC_L + 1) * TAIL_CHUNKS blocks per trace (the boundary rows above the zero padding are k_ram_fill_D's first blocks)
     constexpr u32 PER_JOB = (RC_G + RC_L + 1) * TAIL_CHUNKS;
-    const u32 bid = blockIdx.x % PER_JOB;
-    const SynthJob& job = jobs[blockIdx.x / PER_JOB];
+    const u32 bid = vb.x % PER_JOB;
+    const SynthJob& job = jobs[vb.x / PER_JOB];
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < RC_G + RC_L) {

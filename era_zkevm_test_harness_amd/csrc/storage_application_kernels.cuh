@@ -481,15 +481,15 @@ __device__ __forceinline__ u32 sap_walk_list(const SapWalkJob& j, u32 capacity, 
 // A cycle per thread: the header bit, the free elements and the state before the cycle — the key part, and the running hash, which
 // the builder's level walk left behind for every level of every walk (walk_hashes: no hashing here; the padding cycles carry the last
 // walk's root, the state before cycle 0 is zero). grid = (ceil((cycles + 1) / 256), instances)
-static __global__ __launch_bounds__(256) void k_sap_walk_cycles(const SapWalkJob* __restrict__ jobs, u32 capacity) {
+static __device__ void k_sap_walk_cycles(const VB& vb, const SapWalkJob* __restrict__ jobs, u32 capacity) {
     __shared__ u32 s_item[SAP_WALK_MAX];
     __shared__ uint8_t s_phase[SAP_WALK_MAX];
     __shared__ u32 s_nw;
-    const SapWalkJob j = jobs[blockIdx.y];
+    const SapWalkJob j = jobs[vb.y];
     if (threadIdx.x == 0) s_nw = sap_walk_list(j, capacity, s_item, s_phase);
     __syncthreads();
     const u32 cycles = capacity * SAP_WALK_CYCLES, active = s_nw * SAP_WALK_CYCLES;
-    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 c = vb.x * blockDim.x + threadIdx.x;
     if (c > cycles) return;
     uint8_t* st = j.state_before + (size_t)c * SAP_WALK_STATE;
     const u32 w = c / SAP_WALK_CYCLES, i = c % SAP_WALK_CYCLES;

@@ -164,9 +164,9 @@ __device__ __forceinline__ bool ss_same_key(const u64 cv[18], const SsKeys& p) {
 
 // WHICH 0 = unsorted pop (U1..U3), 1 = sorted pop (S1..S3), 2 = result push (R1..R3)
 template <int WHICH>
-static __global__ __launch_bounds__(64) void k_ss_fill_queue(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
-    const SsSynthJob& job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ void k_ss_fill_queue(const VB& vb, const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+    const SsSynthJob& job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = SS_REGION_STRIDE(capacity);
     constexpr int R1 = WHICH == 0 ? SS_ROW_U1 : (WHICH == 1 ? SS_ROW_S1 : SS_ROW_R1);
     u64* trace = job.trace;
@@ -232,12 +232,12 @@ static __global__ __launch_bounds__(64) void k_ss_fill_queue(const SsSynthJob* _
     v.wq0 = _w[0]; v.wq1 = _w[1]; v.wq2 = _w[2]; v.wq3 = _w[3]; v.wq4 = _w[4]; v.wq5 = _w[5]; v.wq6 = _w[6]; v.wq7 = _w[7]; v.w_d = _w[8]; } while (0)
 
 template <int ROW>
-static __global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ss_fill_row(const VB& vb, const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
-    const SsSynthJob& job = jobs[blockIdx.y];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const SsSynthJob& job = jobs[vb.y];
+    const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = SS_REGION_STRIDE(capacity);
     u64* trace = job.trace;
     if (i < capacity) {
@@ -404,7 +404,7 @@ static __global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __
     } else if (i < rs) {
         if (!job.tail_clean) zero_gap_row_n(trace, n_rows, (size_t)ROW * rs + i, SS_G + SS_L);
     }
-    if (ROW == SS_ROW_A && blockIdx.x == 0 && threadIdx.x == 0)  // the closed-form section's lookup cells: the bytes of the FSM records' previous_packed_key (bridge rows KIB* / KOB*)
+    if (ROW == SS_ROW_A && vb.x == 0 && threadIdx.x == 0)  // the closed-form section's lookup cells: the bytes of the FSM records' previous_packed_key (bridge rows KIB* / KOB*)
         for (int k = 0; k < ZKW_STORAGE_PACKED_KEY_LENGTH; k++) {
             hist_bytes(sh_hist, job.inst->hidden_fsm_input.previous_packed_key[k]);
             hist_bytes(sh_hist, job.inst->hidden_fsm_output.previous_packed_key[k]);
@@ -414,17 +414,17 @@ static __global__ __launch_bounds__(256) void k_ss_fill_row(const SsSynthJob* __
 
 constexpr int SS_BOUNDARY_ROWS = (SS_NUM_ROW_TYPES - SS_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
 __device__ __forceinline__ void ss_boundary_block(const SsSynthJob& job, u32 capacity, size_t n_rows);
-static __global__ __launch_bounds__(256) void k_ss_fill_tail(const SsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+static __device__ void k_ss_fill_tail(const VB& vb, const SsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
     // dependent permutations that the other blocks' stores hide), then (SS_G + SS_L + 1) * TAIL_CHUNKS blocks per trace
-    if (blockIdx.x < n_jobs) {
+    if (vb.x < n_jobs) {
         __builtin_amdgcn_s_setprio(3);
-        ss_boundary_block(jobs[blockIdx.x], capacity, n_rows);
+        ss_boundary_block(jobs[vb.x], capacity, n_rows);
         return;
     }
     constexpr u32 PER_JOB = (SS_G + SS_L + 1) * TAIL_CHUNKS;
-    const u32 bid = (blockIdx.x - n_jobs) % PER_JOB;
-    const SsSynthJob& job = jobs[(blockIdx.x - n_jobs) / PER_JOB];
+    const u32 bid = (vb.x - n_jobs) % PER_JOB;
+    const SsSynthJob& job = jobs[(vb.x - n_jobs) / PER_JOB];
     u64* trace = job.trace;
     const int col = bid / TAIL_CHUNKS, ch = bid % TAIL_CHUNKS;
     if (col < SS_G + SS_L) {

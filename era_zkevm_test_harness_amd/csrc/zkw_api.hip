@@ -402,6 +402,17 @@ void* zkw_device_shared_stream(int device_id) {
     m[device_id] = s;
     return s;
 }
+// an existing context joins a batch for the time its block's instances are synthesized as one of the batch's fibers (its stream must be idle)
+void zkw_ctx_enter_batch(zkw_ctx* ctx, zkw_batch* b) {
+    ctx->batch = b;
+    ctx->stream = zkw_batch_stream(b);
+}
+// only the membership, not the stream: around a host callback that may use the context (a fiber must not park inside foreign frames)
+zkw_batch* zkw_ctx_swap_batch(zkw_ctx* ctx, zkw_batch* b) {
+    zkw_batch* old = ctx->batch;
+    ctx->batch = b;
+    return old;
+}
 void zkw_ctx_leave_batch(zkw_ctx* ctx, void* stream) {
     ctx->batch = nullptr;
     ctx->stream = static_cast<hipStream_t>(stream);
@@ -1684,24 +1695,24 @@ extern "C" int zkw_ram_synthesize(zkw_ctx* ctx, const zkw_ram_witness* w, size_t
     ZKW_TRY(ctx->upload("synth_jobs", jobs, &d_jobs));
     const unsigned nj = (unsigned)n_instances;
     const dim3 g64((rstride + 63) / 64, nj), g256(n_tiles, nj);
-    { Prof _p(ctx, "k_ram_nd_tiles"); hipLaunchKernelGGL(k_ram_nd_tiles, g256, dim3(256), 0, ctx->stream, d_jobs, capacity); }
+    { Prof _p(ctx, "k_ram_nd_tiles"); ZKW_LAUNCH_D(ctx, (k_ram_nd_tiles), "k_ram_nd_tiles", g256, 256, 0, d_jobs, capacity); }
     ZKW_TRY(launch_check("k_ram_nd_tiles"));
-    { Prof _p(ctx, "k_ram_nd_scan"); hipLaunchKernelGGL(k_ram_nd_scan, dim3(nj), dim3(64), 0, ctx->stream, d_jobs, (int)nj, n_tiles); }
+    { Prof _p(ctx, "k_ram_nd_scan"); ZKW_LAUNCH(ctx, k_ram_nd_scan, nj, 64, d_jobs, (int)nj, n_tiles); }
     ZKW_TRY(launch_check("k_ram_nd_scan"));
-    { Prof _p(ctx, "k_ram_fill_poseidon"); hipLaunchKernelGGL((k_ram_fill_poseidon<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_poseidon"); ZKW_LAUNCH_D(ctx, (k_ram_fill_poseidon<0>), "k_ram_fill_poseidon", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_poseidon<0>"));
-    { Prof _p(ctx, "k_ram_fill_poseidon"); hipLaunchKernelGGL((k_ram_fill_poseidon<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_poseidon"); ZKW_LAUNCH_D(ctx, (k_ram_fill_poseidon<1>), "k_ram_fill_poseidon", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_poseidon<1>"));
-    { Prof _p(ctx, "k_ram_fill_A"); hipLaunchKernelGGL(k_ram_fill_A, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_A"); ZKW_LAUNCH_D(ctx, (k_ram_fill_A), "k_ram_fill_A", g256, 256, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_A"));
-    { Prof _p(ctx, "k_ram_fill_B"); hipLaunchKernelGGL(k_ram_fill_B, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_B"); ZKW_LAUNCH_D(ctx, (k_ram_fill_B), "k_ram_fill_B", g256, 256, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_B"));
-    { Prof _p(ctx, "k_ram_fill_C"); hipLaunchKernelGGL(k_ram_fill_C, g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_C"); ZKW_LAUNCH_D(ctx, (k_ram_fill_C), "k_ram_fill_C", g256, 256, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_C"));
     { Prof _p(ctx, "k_ram_fill_D"); const unsigned d_tiles = (unsigned)((rstride + RC_D_TILES * 256 - 1) / (RC_D_TILES * 256));  // row D: RC_D_TILES tiles per block (they share one inversion per lane)
-      hipLaunchKernelGGL(k_ram_fill_D, dim3(nj * (d_tiles + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, d_tiles, capacity, n_rows); }
+      ZKW_LAUNCH(ctx, k_ram_fill_D, nj * (d_tiles + 1), 256, d_jobs, nj, d_tiles, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_D"));
-    { Prof _p(ctx, "k_ram_fill_tail"); hipLaunchKernelGGL(k_ram_fill_tail, dim3(nj * ((RC_G + RC_L + 1) * TAIL_CHUNKS)), dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ram_fill_tail"); ZKW_LAUNCH(ctx, k_ram_fill_tail, nj * ((RC_G + RC_L + 1) * TAIL_CHUNKS), 256, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ram_fill_tail"));
     return claims.commit_if(ctx->sync_if_host());
 }

@@ -36,7 +36,8 @@ hipStream_t zkw_batch_stream(zkw_batch* b);  // the in-order stream every merged
 bool zkw_batch_in_fiber(const zkw_batch* b);
 int zkw_batch_spawn(zkw_batch* b, std::function<int()> fn);  // fiber id
 int zkw_batch_join(zkw_batch* b, int fiber);                 // parks until that fiber has returned; its return code
-void zkw_batch_launch(zkw_batch* b, const zkw::BatchKernel* k, unsigned gx, unsigned gy, const void* tup);
+// (lds_bytes: dynamic LDS of the launch; launches merge when kernel AND lds_bytes agree)
+void zkw_batch_launch(zkw_batch* b, const zkw::BatchKernel* k, dim3 grid, size_t lds_bytes, const void* tup);
 // `bytes` of host memory captured NOW into the batch's upload arena; the device address is valid until the batch is destroyed and holds
 // the bytes for every launch queued after this call
 void* zkw_batch_upload(zkw_batch* b, const void* host, size_t bytes, size_t align);

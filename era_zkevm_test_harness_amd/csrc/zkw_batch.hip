@@ -59,10 +59,11 @@ struct Arena {
         size_t cap = 0, used = 0, moved = 0;  // [moved, used) has not crossed the bus yet
     };
     std::vector<Chunk> chunks;
+    size_t cur = 0;  // the chunk allocations come from; the ones before it are full, the ones after it empty (kept from earlier runs)
     int alloc(size_t bytes, size_t align, char** host, char** dev) {
         if (align < 16) align = 16;
-        if (!chunks.empty()) {
-            Chunk& c = chunks.back();
+        for (; cur < chunks.size(); cur++) {
+            Chunk& c = chunks[cur];
             const size_t at = (c.used + align - 1) & ~(align - 1);
             if (at + bytes <= c.cap) {
                 *host = c.host + at;
@@ -82,7 +83,12 @@ struct Arena {
         c.host = static_cast<char*>(h);
         c.dev = static_cast<char*>(d);
         chunks.push_back(c);
+        cur = chunks.size() - 1;
         return alloc(bytes, align, host, dev);
+    }
+    void reset() {  // between runs of a batch: nothing in flight refers to the arena any more
+        for (Chunk& c : chunks) c.used = c.moved = 0;
+        cur = 0;
     }
     void release() {
         for (Chunk& c : chunks) {
@@ -96,7 +102,7 @@ struct Arena {
 struct Op {
     enum Kind : uint8_t { LAUNCH, CHAIN } kind;
     const BatchKernel* k;
-    unsigned gx, gy;
+    unsigned gx, gy, gz, lds;
     size_t blob;  // LAUNCH: offset of the packed arguments in the fiber's blob; CHAIN: index into the fiber's chain list
 };
 struct ChainReq {
@@ -227,9 +233,10 @@ bool zkw_batch::flush() {
     n_flushes++;
     struct Merged {
         const BatchKernel* k;
+        unsigned lds = 0;
         std::vector<std::pair<Fiber*, const Op*>> jobs;
         char* d_table = nullptr;
-        unsigned *d_prefix = nullptr, *d_gx = nullptr;
+        unsigned *d_prefix = nullptr, *d_gxy = nullptr;
         unsigned total = 0;
     };
     struct ChainGroup {
@@ -259,11 +266,12 @@ bool zkw_batch::flush() {
             }
             Merged* m = nullptr;
             for (Merged& x : R.merged)
-                if (x.k == op.k) { m = &x; break; }
+                if (x.k == op.k && x.lds == op.lds) { m = &x; break; }
             if (!m) {
                 R.merged.push_back(Merged());
                 m = &R.merged.back();
                 m->k = op.k;
+                m->lds = op.lds;
             }
             m->jobs.emplace_back(f, &op);
         }
@@ -271,25 +279,26 @@ bool zkw_batch::flush() {
         for (Merged& m : R.merged) {
             const size_t n = m.jobs.size(), stride = m.k->tup_bytes;
             char *h_table = nullptr, *d_table = nullptr, *h_pre = nullptr, *d_pre = nullptr;
-            if (up.alloc(n * stride, m.k->tup_align, &h_table, &d_table) != ZKW_OK || up.alloc((2 * n + 1) * sizeof(unsigned), 16, &h_pre, &d_pre) != ZKW_OK) {
+            if (up.alloc(n * stride, m.k->tup_align, &h_table, &d_table) != ZKW_OK || up.alloc((3 * n + 1) * sizeof(unsigned), 16, &h_pre, &d_pre) != ZKW_OK) {
                 if (flush_rc == ZKW_OK) { flush_rc = ZKW_ERR_OOM; flush_err = zkw_last_error(); }
                 continue;
             }
             unsigned* pre = reinterpret_cast<unsigned*>(h_pre);
-            unsigned* gx = pre + n + 1;
+            unsigned* gxy = pre + n + 1;
             unsigned long long acc = 0;
             for (size_t j = 0; j < n; j++) {
                 const Op* op = m.jobs[j].second;
                 memcpy(h_table + j * stride, m.jobs[j].first->blob.data() + op->blob, stride);
                 pre[j] = (unsigned)acc;
-                gx[j] = op->gx;
-                acc += (unsigned long long)op->gx * op->gy;
+                gxy[2 * j] = op->gx;
+                gxy[2 * j + 1] = op->gy;
+                acc += (unsigned long long)op->gx * op->gy * op->gz;
             }
             pre[n] = (unsigned)acc;
             if (acc >= (1ull << 31) && flush_rc == ZKW_OK) { flush_rc = ZKW_ERR_INVALID; flush_err = std::string("zkw_batch: merged grid of ") + m.k->name + " is too large"; }
             m.d_table = d_table;
             m.d_prefix = reinterpret_cast<unsigned*>(d_pre);
-            m.d_gx = m.d_prefix + n + 1;
+            m.d_gxy = m.d_prefix + n + 1;
             m.total = (unsigned)acc;
         }
         ChainGroup& c = R.chain;
@@ -320,8 +329,8 @@ bool zkw_batch::flush() {
         for (Merged& m : R.merged) {
             if (m.total == 0) continue;
             int n = (int)m.jobs.size();
-            void* args[] = {&m.d_table, &m.d_prefix, &m.d_gx, &n};
-            fail_flush(hipLaunchKernel(m.k->multi_fn, dim3(m.total), dim3(m.k->bs), args, 0, main), m.k->name);
+            void* args[] = {&m.d_table, &m.d_prefix, &m.d_gxy, &n};
+            fail_flush(hipLaunchKernel(m.k->multi_fn, dim3(m.total), dim3(m.k->bs), args, m.lds, main), m.k->name);
             n_launches++;
             n_jobs += m.jobs.size();
         }
@@ -376,6 +385,8 @@ int zkw_batch::run(const std::vector<std::function<int()>>& roots) {
     if (hipSetDevice(device) != hipSuccess) return fail(ZKW_ERR_HIP, "hipSetDevice failed");
     zkw_batch* outer = tl_batch;
     tl_batch = this;
+    n_flushes = n_launches = n_jobs = n_chain_launches = n_switches = 0;
+    flush_host_ms = wait_ms = 0;
     for (auto& r : roots)
         if (make_fiber(this, r) < 0) { tl_batch = outer; return fail(ZKW_ERR_OOM, "zkw_batch: no stack for a fiber"); }
     int first_rc = ZKW_OK;
@@ -446,6 +457,10 @@ int zkw_batch::run(const std::vector<std::function<int()>>& roots) {
     for (hipStream_t s : chain_streams) (void)hipStreamSynchronize(s);
     for (hipEvent_t e : used_events) free_events.push_back(e);
     used_events.clear();
+    up.reset();
+    down.reset();
+    flush_rc = ZKW_OK;
+    flush_err.clear();
     if (getenv("ZKW_BATCH_LOG"))
         fprintf(stderr, "[zkw batch] %zu fibers, %zu flushes, %zu merged launches carrying %zu jobs, %zu chain launches, %zu switches; host %.1f ms in flushes, %.1f ms waiting\n",
                 fibers.size(), n_flushes, n_launches, n_jobs, n_chain_launches, n_switches, flush_host_ms, wait_ms);
@@ -523,12 +538,12 @@ int zkw_batch_join(zkw_batch* b, int fiber) {
     return ZKW_OK;
 }
 
-void zkw_batch_launch(zkw_batch* b, const BatchKernel* k, unsigned gx, unsigned gy, const void* tup) {
+void zkw_batch_launch(zkw_batch* b, const BatchKernel* k, dim3 grid, size_t lds_bytes, const void* tup) {
     Fiber* f = b->cur;
     const size_t at = (f->blob.size() + 15) & ~(size_t)15;
     f->blob.resize(at + k->tup_bytes);
     memcpy(f->blob.data() + at, tup, k->tup_bytes);
-    f->ops.push_back(Op{Op::LAUNCH, k, gx, gy, at});
+    f->ops.push_back(Op{Op::LAUNCH, k, grid.x, grid.y, grid.z, (unsigned)lds_bytes, at});
 }
 
 void* zkw_batch_upload(zkw_batch* b, const void* host, size_t bytes, size_t align) {
@@ -543,7 +558,7 @@ void zkw_batch_memset(zkw_batch* b, void* dev, int value, size_t bytes) {
     using S = LaunchSig<decltype(&k_batch_fill)>;
     S::T t;
     S::pack(t, dev, value, bytes);
-    zkw_batch_launch(b, S::desc<&k_batch_fill, 256>("k_batch_fill"), byte_grid(bytes), 1, &t);
+    zkw_batch_launch(b, S::desc<&k_batch_fill, 256>("k_batch_fill"), dim3(byte_grid(bytes)), 0, &t);
 }
 
 void zkw_batch_copy_d2d(zkw_batch* b, void* dst, const void* src, size_t bytes) {
@@ -551,7 +566,7 @@ void zkw_batch_copy_d2d(zkw_batch* b, void* dst, const void* src, size_t bytes) 
     using S = LaunchSig<decltype(&k_batch_copy)>;
     S::T t;
     S::pack(t, dst, src, bytes);
-    zkw_batch_launch(b, S::desc<&k_batch_copy, 256>("k_batch_copy"), byte_grid(bytes), 1, &t);
+    zkw_batch_launch(b, S::desc<&k_batch_copy, 256>("k_batch_copy"), dim3(byte_grid(bytes)), 0, &t);
 }
 
 void zkw_batch_copy_h2d(zkw_batch* b, void* dst, const void* host, size_t bytes) {
@@ -586,7 +601,7 @@ int zkw_batch_chains(zkw_batch* b, const ChainJob* full, size_t n_full, const Lo
         ChainReq& c = f->chains.back();
         if (n_full) c.full.assign(full, full + n_full);
         if (n_log) c.log.assign(log, log + n_log);
-        f->ops.push_back(Op{Op::CHAIN, nullptr, 0, 0, f->chains.size() - 1});
+        f->ops.push_back(Op{Op::CHAIN, nullptr, 0, 0, 0, 0, f->chains.size() - 1});
     }
     return zkw_batch_sync(b);
 }

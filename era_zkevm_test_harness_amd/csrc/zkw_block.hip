@@ -956,7 +956,7 @@ extern "C" int zkw_block_synthesize(zkw_block* B, size_t n_rows, size_t ring_slo
 }
 
 static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type,
-                                 zkw_trace* callers_ring, int only_type = -1);
+                                 zkw_trace* callers_ring, int only_type = -1, size_t slot0 = 0);
 extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb,
                                             void* user, size_t* n_done) {
     return block_synthesize_impl(B, n_rows, ring_slots, rank, world, cb, user, n_done, -1, nullptr);
@@ -965,7 +965,7 @@ extern "C" int zkw_block_synthesize_sharded(zkw_block* B, size_t n_rows, size_t 
 // callers_ring: a ring of `ring_slots` slots of 153 columns the caller owns (zkw_blocks_synthesize: one per worker, not one per block —
 // at 1.28 GB a slot, a ring per block capped the blocks in flight at ~150), else the block's own, created on first use
 static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb, void* user, size_t* n_done, int skip_type,
-                                 zkw_trace* callers_ring, int only_type) {
+                                 zkw_trace* callers_ring, int only_type, size_t slot0) {
     if (!B || n_rows == 0 || ring_slots == 0 || world < 1 || rank < 0 || rank >= world) return ZKW_ERR_INVALID;
     std::vector<uint8_t> plan_types;
     std::vector<uint32_t> plan_index, plan_owner;
@@ -1007,7 +1007,7 @@ static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots,
             while (cnt < ring_slots && first + cnt < ni && owned(t, first + cnt)) cnt++;
             switch (t) {
                 default:  // one entry point for every witness-handle type (ZkSyncBaseLayerCircuit::synthesis, base_layer/mod.rs:286-323)
-                    rc = zkw_synthesize(c, (uint8_t)t, zkw_block_witness(B, (uint8_t)t), first, cnt, ring, 0);
+                    rc = zkw_synthesize(c, (uint8_t)t, zkw_block_witness(B, (uint8_t)t), first, cnt, ring, slot0);
                     break;
                 case T_HSH: {  // one instance over the net L2 -> L1 messages (the L1 sorter's result queue)
                     zkw_linear_hasher_instance rec;
@@ -1015,7 +1015,7 @@ static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots,
                     const uint64_t lh_off[2] = {0, zkw_events_witness_num_results(B->l1)};
                     rc = zkw_linear_hasher_synthesize_batch_with_tails(c, static_cast<const zkw_log_query*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_RESULT_QUERIES)), lh_off, 1,
                                                                        &B->linear_hasher.queue_state, static_cast<const uint64_t*>(zkw_events_witness_device_ptr(B->l1, ZKW_EVT_RESULT_NEW_TAILS)),
-                                                                       B->cap[T_HSH], ring, 0, &rec, nullptr);
+                                                                       B->cap[T_HSH], ring, slot0, &rec, nullptr);
                     break;
                 }
             }
@@ -1025,7 +1025,13 @@ static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots,
             for (size_t k = 0; k < cnt; k++) {
                 if (cb) {
                     const uint64_t* pi = B->per[t].pi.data() + 4 * (first + k);
-                    if (cb(user, (uint8_t)t, first + k, ring, k, pi) != 0) return ZKW_ERR_CHECK_FAILED;
+                    // the callee may use the block's contexts (a check, a read): while it runs they are ordinary contexts on the batch's stream —
+                    // a fiber must not park inside the caller's frames (everything this fiber queued has run: the synchronise above)
+                    zkw_batch* held[N_CTX];
+                    for (int i = 0; i < N_CTX; i++) held[i] = zkw_ctx_swap_batch(B->ctx[i], nullptr);
+                    const int crc = cb(user, (uint8_t)t, first + k, ring, slot0 + k, pi);
+                    for (int i = 0; i < N_CTX; i++) (void)zkw_ctx_swap_batch(B->ctx[i], held[i]);
+                    if (crc != 0) return ZKW_ERR_CHECK_FAILED;
                 }
                 done++;
             }
@@ -1097,50 +1103,79 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
         zkw_trace_free(ring);
         zkw_destroy(c);
     });
-    // (2) everything else on a few threads. A worker has ONE ring and ONE stream, owns every n_threads-th block, and goes through its blocks
-    // TYPE BY TYPE: the LogDemuxer instances of all its blocks, then their RAMPermutation instances, ... — a ring slot then holds the same
-    // layout call after call, so a fill only rewrites the cells it owns (zkw_trace::slot_tag): no zeroing pass over the ~1 GB of general
-    // columns of a netlist circuit, about half the bytes of a queue circuit. Block by block, every call into a slot was a cold one.
+    // (2) everything else: a few workers, each with a contiguous share of the blocks, a ring of G x ring_slots slots and a batch (zkw_batch.h)
+    // of G fibers. Fiber s owns slot(s) s of the ring and every G-th block of the worker's share, and goes through them TYPE BY TYPE — the
+    // LogDemuxer instances of its blocks, then their RAMPermutation instances, ... — running the code zkw_block_synthesize runs. The G fibers
+    // move in step, so (a) the fills of a type leave as ONE launch per kernel over G instances instead of one small launch per block (a
+    // Keccak instance is 293 waves; the serial sponges — 3 - 4.5 ms of one wave for the L1-messages hasher — cost their latency once per G
+    // blocks), and (b) a slot holds the same layout call after call, so a fill only rewrites the cells it owns (zkw_trace::slot_tag): no
+    // zeroing pass over the ~1 GB of general columns of a netlist circuit, about half the bytes of a queue circuit. Round 5 ran the blocks one
+    // by one on eight threads with a ring per BLOCK (1.28 GB a slot: ~150 blocks in flight at most, every call into a slot a cold one).
+    // ZKW_SYNTH_THREADS workers (default 3: while one worker's fibers wait for a serial kernel the others' fills have the chip),
+    // ZKW_SYNTH_GROUP fibers per worker (default 16). cb is called on the workers' threads, one call at a time per worker.
     std::vector<std::thread> pool;
-    static const size_t max_threads = [] { const char* e = getenv("ZKW_SYNTH_THREADS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 ? v : 8); }();
-    const size_t n_threads = std::min<size_t>(max_threads, n_blocks);
+    static const size_t max_threads = [] { const char* e = getenv("ZKW_SYNTH_THREADS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 ? v : 3); }();
+    static const size_t group_size = [] { const char* e = getenv("ZKW_SYNTH_GROUP"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 256 ? v : 16); }();
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(max_threads, (n_blocks + group_size - 1) / group_size));
     for (size_t th = 0; th < n_threads; th++)
         pool.emplace_back([&, th] {
+            const size_t b0 = n_blocks * th / n_threads, b1 = n_blocks * (th + 1) / n_threads;
+            if (b0 == b1) return;
+            const size_t G = std::min(group_size, b1 - b0);
             if (hipSetDevice(blocks[0]->device) != hipSuccess) { note(ZKW_ERR_HIP); return; }
             zkw_ctx* wc = zkw_create(blocks[0]->device);
             if (!wc) { note(ZKW_ERR_NO_DEVICE); return; }
             zkw_trace* ring = nullptr;
-            int rc = zkw_trace_create_with_columns(wc, n_rows, 153, ring_slots, &ring);
+            int rc = zkw_trace_create_with_columns(wc, n_rows, 153, G * ring_slots, &ring);
             void* shared = zkw_device_shared_stream(blocks[0]->device);
-            if (rc != ZKW_OK || !shared) { note(rc != ZKW_OK ? rc : ZKW_ERR_HIP); if (ring) zkw_trace_free(ring); zkw_destroy(wc); return; }
-            std::vector<size_t> mine;
-            for (size_t b = th; b < n_blocks; b += n_threads) mine.push_back(b);
-            // a block built by a batch has no streams of its own: its contexts work on this worker's stream meanwhile. What the synthesis adds to
-            // the contexts' scratch (windows, gathers: ~100 MB per block) is released when the block's last type is done.
-            std::vector<std::vector<std::string>> marks(mine.size() * N_CTX);
-            for (size_t k = 0; k < mine.size() && rc == ZKW_OK; k++) {
-                zkw_block* B = blocks[mine[k]];
-                for (int i = 0; i < N_CTX; i++) zkw_ctx_scratch_mark(B->ctx[i], &marks[k * N_CTX + i]);
-                if (B->from_batch)
-                    for (int i = 0; i < N_CTX && rc == ZKW_OK; i++) rc = zkw_set_stream(B->ctx[i], zkw_ctx_stream(wc));
+            zkw_batch* batch = rc == ZKW_OK ? zkw_batch_create(blocks[0]->device) : nullptr;
+            if (rc != ZKW_OK || !shared || !batch) {
+                note(rc != ZKW_OK ? rc : ZKW_ERR_HIP);
+                if (batch) zkw_batch_destroy(batch);
+                if (ring) zkw_trace_free(ring);
+                zkw_destroy(wc);
+                return;
             }
-            for (int t : kOrder) {
-                if (t == T_ECR) continue;
-                for (size_t k = 0; k < mine.size() && rc == ZKW_OK && first_rc.load() == ZKW_OK; k++) {
-                    Fwd f{mine[k], cb, user};
-                    size_t n = 0;
-                    rc = block_synthesize_impl(blocks[mine[k]], n_rows, ring_slots, 0, 1, fwd, &f, &n, T_ECR, ring, t);
-                    done += n;
+            std::vector<std::vector<std::string>> marks((b1 - b0) * N_CTX);
+            std::vector<size_t> counts(b1 - b0, 0);
+            for (size_t b = b0; b < b1; b++)
+                for (int i = 0; i < N_CTX; i++) {
+                    zkw_ctx_scratch_mark(blocks[b]->ctx[i], &marks[(b - b0) * N_CTX + i]);
+                    (void)zkw_synchronize(blocks[b]->ctx[i]);  // (idle already: the builders are done)
+                    zkw_ctx_enter_batch(blocks[b]->ctx[i], batch);
                 }
-            }
-            for (size_t k = 0; k < mine.size(); k++) {
-                zkw_block* B = blocks[mine[k]];
-                for (int i = 0; i < N_CTX; i++)
-                    if (zkw_synchronize(B->ctx[i]) == ZKW_OK) zkw_ctx_scratch_release_since(B->ctx[i], marks[k * N_CTX + i]);
-                if (B->from_batch)
-                    for (int i = 0; i < N_CTX; i++) { const int r2 = zkw_set_stream(B->ctx[i], shared); if (rc == ZKW_OK) rc = r2; }
+            std::vector<std::function<int()>> roots;
+            for (size_t s = 0; s < G; s++)
+                roots.push_back([&, s]() -> int {
+                    for (int t : kOrder) {
+                        if (t == T_ECR) continue;
+                        for (size_t b = b0 + s; b < b1; b += G) {
+                            if (first_rc.load() != ZKW_OK) return ZKW_OK;
+                            Fwd f{b, cb, user};
+                            size_t n = 0;
+                            const int r = block_synthesize_impl(blocks[b], n_rows, ring_slots, 0, 1, fwd, &f, &n, T_ECR, ring, t, s * ring_slots);
+                            counts[b - b0] += n;
+                            if (r != ZKW_OK) return r;
+                            if (t == T_HSH)  // the block's last type: what its synthesis added to the contexts' scratch (~100 MB) goes back now
+                                for (int i = 0; i < N_CTX; i++) zkw_ctx_scratch_release_since(blocks[b]->ctx[i], marks[(b - b0) * N_CTX + i]);
+                        }
+                    }
+                    return ZKW_OK;
+                });
+            rc = zkw_batch_run(batch, roots);
+            for (size_t b = b0; b < b1; b++) {
+                zkw_block* B = blocks[b];
+                for (int i = 0; i < N_CTX; i++) {
+                    // what the synthesis added to the contexts' scratch (windows, gathers: ~100 MB per block) goes back right away; a block
+                    // built by a batch has no stream of its own and returns to the device's shared one, any other to its own
+                    zkw_ctx_leave_batch(B->ctx[i], shared);
+                    if (!B->from_batch) (void)zkw_set_stream(B->ctx[i], ZKW_STREAM_OWN);
+                    zkw_ctx_scratch_release_since(B->ctx[i], marks[(b - b0) * N_CTX + i]);
+                }
+                done += counts[b - b0];
             }
             if (rc != ZKW_OK) note(rc);
+            zkw_batch_destroy(batch);
             zkw_trace_free(ring);
             zkw_destroy(wc);
         });

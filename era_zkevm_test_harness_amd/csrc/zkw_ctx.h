@@ -314,27 +314,35 @@ template <auto Body, int BS>
 struct Launcher {
     using S = LaunchSig<decltype(Body)>;
     template <class... A>
-    static int go(zkw_ctx* ctx, const char* name, unsigned gx, unsigned gy, const A&... a) {
-        if (gx == 0 || gy == 0) return ZKW_OK;
+    static int go(zkw_ctx* ctx, const char* name, dim3 grid, size_t lds_bytes, const A&... a) {
+        if (grid.x == 0 || grid.y == 0 || grid.z == 0) return ZKW_OK;
         if (ctx->batched()) {
             typename S::T t;
             S::pack(t, a...);
-            zkw_batch_launch(ctx->batch, S::template desc<Body, BS>(name), gx, gy, &t);
+            zkw_batch_launch(ctx->batch, S::template desc<Body, BS>(name), grid, lds_bytes, &t);
             return ZKW_OK;
         }
-        S::template single<Body, BS>(ctx->stream, gx, gy, a...);  // (timed by the caller's Prof, if any)
+        S::template single<Body, BS>(ctx->stream, grid, lds_bytes, a...);  // (timed by the caller's Prof, if any)
         return launch_check(name);
     }
+    // more than the default 64 KB of dynamic LDS for both launch forms of the kernel (once per device is enough; cheap to repeat)
+    static int allow_dynamic_lds(int bytes) {
+        HIP_TRY(hipFuncSetAttribute(S::template single_fn<Body, BS>(), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIP_TRY(hipFuncSetAttribute(S::template desc<Body, BS>("")->multi_fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        return ZKW_OK;
+    }
 };
-#define ZKW_LAUNCH(ctx, kernel, gx, bs, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, #kernel, (unsigned)(gx), 1u, __VA_ARGS__)))
-#define ZKW_LAUNCH_2D(ctx, kernel, gx, gy, bs, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, #kernel, (unsigned)(gx), (unsigned)(gy), __VA_ARGS__)))
+#define ZKW_LAUNCH(ctx, kernel, gx, bs, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, #kernel, dim3((unsigned)(gx)), 0, __VA_ARGS__)))
+#define ZKW_LAUNCH_2D(ctx, kernel, gx, gy, bs, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, #kernel, dim3((unsigned)(gx), (unsigned)(gy)), 0, __VA_ARGS__)))
 // the same for a template kernel (the name has commas): ZKW_LAUNCH_T(ctx, (k_foo<A, B>), "k_foo", ...)
-#define ZKW_LAUNCH_T(ctx, kernel, name, gx, bs, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, name, (unsigned)(gx), 1u, __VA_ARGS__)))
+#define ZKW_LAUNCH_T(ctx, kernel, name, gx, bs, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, name, dim3((unsigned)(gx)), 0, __VA_ARGS__)))
+// the general form: any dim3 grid, dynamic LDS
+#define ZKW_LAUNCH_D(ctx, kernel, name, grid, bs, lds, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, name, grid, lds, __VA_ARGS__)))
 
 // rows [0, width) of blockIdx.y's column of a column-major strip
-static __global__ __launch_bounds__(256) void k_zero_strip(u64* __restrict__ base, size_t pitch, size_t width) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < width) base[(size_t)blockIdx.y * pitch + i] = 0;
+static __device__ void k_zero_strip(const VB& vb, u64* __restrict__ base, size_t pitch, size_t width) {
+    const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
+    if (i < width) base[(size_t)vb.y * pitch + i] = 0;
 }
 // Zeroes what the fill of a "zkw trace v3" netlist circuit does NOT write itself: the general-purpose columns [0, g) (the
 // fill then overwrites its header / gate cells), the lookup columns [g, g + lookup_cols) below the last cycle only (the fill
@@ -343,7 +351,7 @@ static __global__ __launch_bounds__(256) void k_zero_strip(u64* __restrict__ bas
 static inline int zero_netlist_slot(zkw_ctx* ctx, u64* trace, size_t n_rows, size_t g, size_t lookup_cols, size_t n_cols, size_t used_rows) {
     HIP_TRY(hipMemsetAsync(trace, 0, g * n_rows * sizeof(u64), ctx->stream));
     if (used_rows < n_rows) {  // (hipMemset2DAsync ran this strip at 0.8 TB/s: 0.2 ms per Keccak slot)
-        hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - used_rows + 255) / 256), (unsigned)lookup_cols), dim3(256), 0, ctx->stream,
+        ZKW_LAUNCH_2D(ctx, k_zero_strip, (unsigned)((n_rows - used_rows + 255) / 256), (unsigned)lookup_cols, 256,
                            trace + g * n_rows + used_rows, n_rows, n_rows - used_rows);
         ZKW_TRY(launch_check("k_zero_strip"));
     }

@@ -13,6 +13,8 @@ void zkw_ctx_release(zkw_ctx* ctx);
 // a context that belongs to a batch of blocks (zkw_batch.h): created without a stream, handed over to ordinary use afterwards
 struct zkw_batch;
 zkw_ctx* zkw_ctx_create_in_batch(int device_id, zkw_batch* b);
+void zkw_ctx_enter_batch(zkw_ctx* ctx, zkw_batch* b);
+zkw_batch* zkw_ctx_swap_batch(zkw_ctx* ctx, zkw_batch* b);
 void zkw_ctx_leave_batch(zkw_ctx* ctx, void* stream);
 void* zkw_device_shared_stream(int device_id);  // one stream per device for contexts that have none of their own (never destroyed)
 int zkw_copy_device(zkw_ctx* ctx, void* dst, const void* src, size_t bytes);  // device -> device, ordered on the context's stream (or queued with its batch)

@@ -21,7 +21,7 @@
 namespace zkw {
 
 struct VB {
-    unsigned x, y, nx, ny;  // this workgroup's position in its job's grid, and that grid
+    unsigned x, y, z, nx, ny, nz;  // this workgroup's position in its job's grid, and that grid
 };
 
 // a plain aggregate of the body's arguments (host and device lay it out alike: one compiler)
@@ -42,18 +42,18 @@ template <auto Body, class H, class... R, class... U> __device__ __forceinline__
 }
 
 template <auto Body, int BS, class... A> __global__ __launch_bounds__(BS) void k_single(A... a) {
-    Body(VB{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}, a...);
+    Body(VB{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z}, a...);
 }
-// prefix[j] <= blockIdx.x < prefix[j + 1]: job j; gx[j] = the job's grid in x (its y extent follows from the prefix)
+// prefix[j] <= blockIdx.x < prefix[j + 1]: job j; gxy[2 j], gxy[2 j + 1] = the job's grid in x and y (its z extent follows from the prefix)
 template <auto Body, int BS, class... A> __global__ __launch_bounds__(BS) void k_multi(const Tup<A...>* __restrict__ jobs, const unsigned* __restrict__ prefix,
-                                                                                      const unsigned* __restrict__ gx, int n_jobs) {
+                                                                                      const unsigned* __restrict__ gxy, int n_jobs) {
     int lo = 0, hi = n_jobs;
     while (hi - lo > 1) {
         const int m = (lo + hi) >> 1;
         if (prefix[m] <= blockIdx.x) lo = m; else hi = m;
     }
-    const unsigned local = blockIdx.x - prefix[lo], total = prefix[lo + 1] - prefix[lo], nx = gx[lo];
-    tup_apply<Body>(VB{local % nx, local / nx, nx, total / nx}, jobs[lo]);
+    const unsigned local = blockIdx.x - prefix[lo], total = prefix[lo + 1] - prefix[lo], nx = gxy[2 * lo], ny = gxy[2 * lo + 1];
+    tup_apply<Body>(VB{local % nx, (local / nx) % ny, local / (nx * ny), nx, ny, total / (nx * ny)}, jobs[lo]);
 }
 
 // what the batch needs to know about a kernel to merge its launches
@@ -66,11 +66,13 @@ struct BatchKernel {
 template <class F> struct LaunchSig;
 template <class... A> struct LaunchSig<void (*)(const VB&, A...)> {
     using T = Tup<A...>;
-    template <auto Body, int BS> static void single(hipStream_t st, unsigned gx, unsigned gy, A... a) {
-        hipLaunchKernelGGL((k_single<Body, BS, A...>), dim3(gx, gy), dim3(BS), 0, st, a...);
+    template <auto Body, int BS> static void single(hipStream_t st, dim3 grid, size_t lds_bytes, A... a) {
+        hipLaunchKernelGGL((k_single<Body, BS, A...>), grid, dim3(BS), lds_bytes, st, a...);
     }
+    template <auto Body, int BS> static const void* single_fn() { return reinterpret_cast<const void*>(&k_single<Body, BS, A...>); }
     template <auto Body, int BS> static const BatchKernel* desc(const char* name) {
-        static const BatchKernel k{reinterpret_cast<const void*>(&k_multi<Body, BS, A...>), (unsigned)BS, (unsigned)sizeof(T), (unsigned)alignof(T), name};
+        static BatchKernel k{reinterpret_cast<const void*>(&k_multi<Body, BS, A...>), (unsigned)BS, (unsigned)sizeof(T), (unsigned)alignof(T), name};
+        if (name && name[0] && !k.name[0]) k.name = name;
         return &k;
     }
     static void pack(T& t, const A&... a) { tup_pack(t, a...); }

@@ -959,7 +959,7 @@ template <int W, int R, int WAVES>
 int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
     static bool attr_set[16] = {};
     if (!attr_set[ctx->device & 15]) {  // more than the default 64 KB of dynamic LDS
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_fill<W, R, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZKW_TRY((Launcher<&k_nl_fill<W, R, WAVES>, 64 * WAVES>::allow_dynamic_lds(160 * 1024)));
         attr_set[ctx->device & 15] = true;
     }
 #ifdef ZKW_PROBE_BUILD  // measurement builds only (ZKW_PROBE_BUILD=1 python -m era_zkevm_test_harness_amd.build --force): 1 = no level walk, 2 = no
@@ -973,7 +973,7 @@ int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsi
     const unsigned lds = WAVES == 16 ? nc->host.lds_bytes16 : nc->host.lds_bytes;
     const unsigned per_cu = std::max<unsigned>(1, std::min<unsigned>(4, (160u * 1024u) / std::max<unsigned>(1, lds)));
     const unsigned blocks = std::min<unsigned>((capacity + WAVES - 1) / WAVES, std::max<unsigned>(1, 256 * per_cu / nj));
-    { Prof _p(ctx, "k_nl_fill"); hipLaunchKernelGGL((k_nl_fill<W, R, WAVES>), dim3(blocks, nj), dim3(64 * WAVES), lds, ctx->stream, nc->dev, d_jobs, capacity, n_rows, probe); }
+    { Prof _p(ctx, "k_nl_fill"); ZKW_LAUNCH_D(ctx, (k_nl_fill<W, R, WAVES>), "k_nl_fill", dim3(blocks, nj), 64 * WAVES, lds, nc->dev, d_jobs, capacity, n_rows, probe); }
     return launch_check("k_nl_fill");
 }
 // the lane-per-cycle path (k_nl_walk + k_nl_expand), for netlists whose live values fit the LDS
@@ -981,7 +981,7 @@ template <int W, int R>
 int nl_launch_fill_lanes(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
     static bool attr_set[16] = {};
     if (!attr_set[ctx->device & 15]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nl_walk<W, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZKW_TRY((Launcher<&k_nl_walk<W, R>, 64>::allow_dynamic_lds(160 * 1024)));
         attr_set[ctx->device & 15] = true;
     }
     const nl_spec& S = nc->host.s;
@@ -989,9 +989,9 @@ int nl_launch_fill_lanes(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, 
     const size_t per_job = ((size_t)tiles * S.mult_col * S.rows_per_cycle * 64 + 255) & ~(size_t)255;
     uint8_t* d_bytes = nullptr;
     ZKW_TRY(ctx->scratch_t<uint8_t>("nl_bytes", per_job * nj, &d_bytes));
-    { Prof _p(ctx, "k_nl_walk"); hipLaunchKernelGGL((k_nl_walk<W, R>), dim3(tiles, nj), dim3(64), nc->host.walk_lds, ctx->stream, nc->dev, d_jobs, capacity, d_bytes, per_job, nc->host.prog, nc->host.prog0, nc->host.out_src); }
+    { Prof _p(ctx, "k_nl_walk"); ZKW_LAUNCH_D(ctx, (k_nl_walk<W, R>), "k_nl_walk", dim3(tiles, nj), 64, nc->host.walk_lds, nc->dev, d_jobs, capacity, d_bytes, per_job, nc->host.prog, nc->host.prog0, nc->host.out_src); }
     ZKW_TRY(launch_check("k_nl_walk"));
-    { Prof _p(ctx, "k_nl_expand"); hipLaunchKernelGGL((k_nl_expand<W, R>), dim3((S.g + R) * row_blocks, tiles, nj), dim3(64), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows, d_bytes, per_job); }
+    { Prof _p(ctx, "k_nl_expand"); ZKW_LAUNCH_D(ctx, (k_nl_expand<W, R>), "k_nl_expand", dim3((S.g + R) * row_blocks, tiles, nj), 64, 0, nc->dev, d_jobs, capacity, n_rows, d_bytes, per_job); }
     return launch_check("k_nl_expand");
 }
 
@@ -1004,14 +1004,14 @@ int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsign
     if ((lanes_env || ctx->netlist_fill_form == 1) && nc->host.walk_lds <= 160 * 1024) {
         ZKW_TRY((nl_launch_fill_lanes<W, R>(ctx, nc, d_jobs, nj, capacity, n_rows)));
         if (after_fill) ZKW_TRY(after_fill());
-        { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+        { Prof _p(ctx, "k_nl_hist"); ZKW_LAUNCH_D(ctx, (k_nl_hist<R>), "k_nl_hist", dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), NL_HIST_THREADS, 0, nc->dev, d_jobs, capacity, n_rows); }
         return launch_check("k_nl_hist");
     }
     // (a call with few cycles keeps 8 waves per workgroup: twice the workgroups, so that every CU has one)
     if (nc->host.fill_waves == 16 && (size_t)((capacity + 15) / 16) * nj >= 128) ZKW_TRY((nl_launch_fill_w<W, R, 16>(ctx, nc, d_jobs, nj, capacity, n_rows)));
     else ZKW_TRY((nl_launch_fill_w<W, R, 8>(ctx, nc, d_jobs, nj, capacity, n_rows)));
     if (after_fill) ZKW_TRY(after_fill());
-    { Prof _p(ctx, "k_nl_hist"); hipLaunchKernelGGL((k_nl_hist<R>), dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), dim3(NL_HIST_THREADS), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_nl_hist"); ZKW_LAUNCH_D(ctx, (k_nl_hist<R>), "k_nl_hist", dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), NL_HIST_THREADS, 0, nc->dev, d_jobs, capacity, n_rows); }
     return launch_check("k_nl_hist");
 }
 
@@ -1054,7 +1054,7 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
         jobs[k] = NlJob{prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before, inst[k].public_input, tr, d_keys + k * keys_n, d_hist + k * hist_n};
         if (!clean) {
             HIP_TRY(ctx->memset_async(tr, 0, (size_t)S.g * n_rows * sizeof(u64)));  // general-purpose columns
-            hipLaunchKernelGGL(k_zero_strip, dim3((unsigned)((n_rows - bnd + 255) / 256), S.mult_col - S.g), dim3(256), 0, ctx->stream, tr + (size_t)S.g * n_rows + bnd, n_rows, n_rows - bnd);
+            ZKW_LAUNCH_2D(ctx, k_zero_strip, (unsigned)((n_rows - bnd + 255) / 256), S.mult_col - S.g, 256, tr + (size_t)S.g * n_rows + bnd, n_rows, n_rows - bnd);
             ZKW_TRY(launch_check("k_zero_strip"));
             HIP_TRY(ctx->memset_async(tr + (size_t)S.mult_col * n_rows, 0, n_rows * sizeof(u64)));
         }
@@ -1071,7 +1071,7 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
         case 7: ZKW_TRY((nl_launch_fill<EK_W, EK_R>(ctx, nc, d_jobs, nj, capacity, n_rows, after_fill))); break;
         default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows, after_fill))); break;  // 13 and 10: 3 x 26
     }
-    { Prof _p(ctx, "k_nl_finish"); hipLaunchKernelGGL(k_nl_finish, dim3((std::max(S.state, S.total_table_rows) + 255) / 256, nj), dim3(256), 0, ctx->stream, nc->dev, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_nl_finish"); ZKW_LAUNCH_2D(ctx, k_nl_finish, (std::max(S.state, S.total_table_rows) + 255) / 256, nj, 256, nc->dev, d_jobs, capacity, n_rows); }
     return claims.commit_if(launch_check("k_nl_finish"));
 }
 
@@ -1087,8 +1087,8 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
         NlPrepJob* d_prep = nullptr;
         ZKW_TRY(ctx->upload("nl_prep", prep, &d_prep));
         const unsigned nj = (unsigned)prep.size();
-        if (sha_like) { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_sha, dim3(capacity + 1, nj), dim3(128), 0, ctx->stream, d_prep, capacity); }
-        else { Prof _p(ctx, "k_nl_prepare"); hipLaunchKernelGGL(k_nl_prepare_keccak, dim3(capacity + 1, nj), dim3(256), 0, ctx->stream, d_prep, capacity); }
+        if (sha_like) { Prof _p(ctx, "k_nl_prepare"); ZKW_LAUNCH_2D(ctx, k_nl_prepare_sha, capacity + 1, nj, 128, d_prep, capacity); }
+        else { Prof _p(ctx, "k_nl_prepare"); ZKW_LAUNCH_2D(ctx, k_nl_prepare_keccak, capacity + 1, nj, 256, d_prep, capacity); }
         return launch_check("k_nl_prepare");
     }, inst, capacity, n_rows, after_fill);
 }
@@ -1119,9 +1119,9 @@ int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std
     ZKW_TRY(ctx->upload("nlq_feed_jobs", fj, &d_fj));
     ZKW_TRY(ctx->upload("nlq_jobs", jobs, &d_jobs));
     const unsigned cb = (capacity + 63) / 64;
-    { Prof _p(ctx, "k_nlq_feed"); hipLaunchKernelGGL(k_nlq_feed, dim3(cb, (unsigned)ni), dim3(64), 0, ctx->stream, circuit_type, d_fj, capacity, d->n_ops); }
+    { Prof _p(ctx, "k_nlq_feed"); ZKW_LAUNCH_2D(ctx, k_nlq_feed, cb, (unsigned)ni, 64, circuit_type, d_fj, capacity, d->n_ops); }
     ZKW_TRY(launch_check("k_nlq_feed"));
-    { Prof _p(ctx, "k_nlq_fill"); hipLaunchKernelGGL(k_nlq_fill, dim3((capacity + 3) / 4, d->n_ops, (unsigned)ni), dim3(64), 0, ctx->stream, nc->dev, nc->free_home, nc->link_home, *d, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_nlq_fill"); ZKW_LAUNCH_D(ctx, (k_nlq_fill), "k_nlq_fill", dim3((capacity + 3) / 4, d->n_ops, (unsigned)ni), 64, 0, nc->dev, nc->free_home, nc->link_home, *d, d_jobs, capacity, n_rows); }
     return launch_check("k_nlq_fill");
 }
 
@@ -1147,10 +1147,14 @@ int nlcf_begin(zkw_ctx* ctx, int circuit_type, const typename T::Inst* d_inst, s
     ZKW_TRY(ctx->upload(jobs_name, jobs, &call->d_jobs));
     call->n = jobs.size();
     if (jobs.empty()) return ZKW_OK;
+    if (ctx->batched()) {  // a context of a batch has one stream: the sponges of all the group's blocks travel as one launch, behind the fills
+        ZKW_LAUNCH_D(ctx, (k_nlcf_sponges<T>), "k_nlcf_sponges", dim3((unsigned)jobs.size()), 256, 0, *d, d_inst, (const NlcfJob*)call->d_jobs, S->g, n_rows, (u64)nlcf_first_row(circuit_type, S, cycles));
+        return ZKW_OK;
+    }
     hipStream_t side = nullptr;
     ZKW_TRY(ctx->side_fork(&side));
     call->forked = true;
-    hipLaunchKernelGGL((k_nlcf_sponges<T>), dim3((unsigned)jobs.size()), dim3(256), 0, side, *d, d_inst, call->d_jobs, S->g, n_rows, (u64)nlcf_first_row(circuit_type, S, cycles));
+    Launcher<&k_nlcf_sponges<T>, 256>::S::template single<&k_nlcf_sponges<T>, 256>(side, dim3((unsigned)jobs.size()), 0, *d, d_inst, call->d_jobs, S->g, n_rows, (u64)nlcf_first_row(circuit_type, S, cycles));
     return launch_check("k_nlcf_sponges");
 }
 int nlcf_end(zkw_ctx* ctx, int circuit_type, const NlcfCall& call, u32 cycles, size_t n_rows) {
@@ -1163,8 +1167,7 @@ int nlcf_end(zkw_ctx* ctx, int circuit_type, const NlcfCall& call, u32 cycles, s
     if (cells == 0) return ZKW_OK;
     const nlq_desc* qd = nlq_desc_of(circuit_type);
     const nlq_desc none{};
-    { Prof _p(ctx, "k_nlcf_ties"); hipLaunchKernelGGL(k_nlcf_ties, dim3((cells + 255) / 256, (unsigned)call.n), dim3(256), 0, ctx->stream, *d, qd ? *qd : none, nc->dev, call.d_jobs, cycles, n_rows,
-                                                    (u64)nlcf_first_row(circuit_type, &nc->host.s, cycles)); }
+    { Prof _p(ctx, "k_nlcf_ties"); ZKW_LAUNCH_2D(ctx, k_nlcf_ties, (cells + 255) / 256, (unsigned)call.n, 256, *d, qd ? *qd : none, nc->dev, call.d_jobs, cycles, n_rows, (u64)nlcf_first_row(circuit_type, &nc->host.s, cycles)); }
     return launch_check("k_nlcf_ties");
 }
 
@@ -1360,24 +1363,24 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
             jobs[k] = EcJob{ws[w_of[k]]->mem_q, inst[k].first_round, inst[k].n_active, d_inputs + k * capacity * (size_t)128, d_tape + k * capacity * (size_t)EC_TAPE_PER_CYCLE,
                             inst[k].t->data + inst[k].slot * inst[k].t->slot_elems(), prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
         ZKW_TRY(ctx->upload("ec_jobs", jobs, &d_jobs));
-        { Prof _p(ctx, "k_ec_inputs"); hipLaunchKernelGGL(k_ec_inputs, dim3(capacity, nj), dim3(128), 0, ctx->stream, d_jobs); }
+        { Prof _p(ctx, "k_ec_inputs"); ZKW_LAUNCH_2D(ctx, k_ec_inputs, capacity, nj, 128, d_jobs); }
         ZKW_TRY(launch_check("k_ec_inputs"));
         // the serial form (one lane walks a whole cycle, an inversion per quotient) is kept for cross-checks: ZKW_EC_SERIAL=1, same tape
         static const bool serial = [] { const char* e = getenv("ZKW_EC_SERIAL"); return e && atoi(e) != 0; }();
         if (serial) {
-            { Prof _p(ctx, "k_ec_tape"); hipLaunchKernelGGL(k_ec_tape, dim3((capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj), dim3(EC_TAPE_LANES), 0, ctx->stream, ec->dev, d_jobs, capacity, d_status); }
+            { Prof _p(ctx, "k_ec_tape"); ZKW_LAUNCH_2D(ctx, k_ec_tape, (capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj, EC_TAPE_LANES, ec->dev, d_jobs, capacity, d_status); }
             ZKW_TRY(launch_check("k_ec_tape"));
         } else {
             EcChainScratch sc{};
             ZKW_TRY(ctx->scratch_t<ec_jac>("ec_chain_pts", ni * capacity * (size_t)EC_CHAIN_POINTS, &sc.pts));
             ZKW_TRY(ctx->scratch_t<ec_u256>("ec_chain_pre", ni * capacity * (size_t)EC_CHAIN_POINTS, &sc.pre));
-            { Prof _p(ctx, "k_ec_chain"); hipLaunchKernelGGL(k_ec_chain, dim3((capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj), dim3(EC_TAPE_LANES), 0, ctx->stream, ec->dev, d_jobs, capacity, d_status, sc); }
+            { Prof _p(ctx, "k_ec_chain"); ZKW_LAUNCH_2D(ctx, k_ec_chain, (capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj, EC_TAPE_LANES, ec->dev, d_jobs, capacity, d_status, sc); }
             ZKW_TRY(launch_check("k_ec_chain"));
             const u32 n_cycles = (u32)(ni * capacity);
-            { Prof _p(ctx, "k_ec_segments"); hipLaunchKernelGGL(k_ec_segments, dim3(ec->segments_per_cycle - 1, (n_cycles + EC_TAPE_LANES - 1) / EC_TAPE_LANES), dim3(EC_TAPE_LANES), 0, ctx->stream, ec->dev, d_jobs, capacity, n_cycles, d_status); }
+            { Prof _p(ctx, "k_ec_segments"); ZKW_LAUNCH_2D(ctx, k_ec_segments, ec->segments_per_cycle - 1, (n_cycles + EC_TAPE_LANES - 1) / EC_TAPE_LANES, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, d_status); }
             ZKW_TRY(launch_check("k_ec_segments"));
         }
-        { Prof _p(ctx, "k_ec_prepare"); hipLaunchKernelGGL(k_ec_prepare, dim3(cb, nj), dim3(64), 0, ctx->stream, ec->dev, d_jobs, capacity); }
+        { Prof _p(ctx, "k_ec_prepare"); ZKW_LAUNCH_2D(ctx, k_ec_prepare, cb, nj, 64, ec->dev, d_jobs, capacity); }
         return launch_check("k_ec_prepare");
     }, inst, capacity, n_rows));
     u32 status = 0;
@@ -1400,7 +1403,7 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
         ZKW_TRY((nlcf_begin<CfPrecompile<ZKW_PRECOMPILE_ECRECOVER>>(ctx, 7, w->instances, first[k], sub, capacity, n_rows, &cf, name)));
         ZKW_TRY(nlcf_end(ctx, 7, cf, capacity, n_rows));
     }
-    { Prof _p(ctx, "k_ec_stream"); hipLaunchKernelGGL(k_ec_stream, dim3((EC_ROWS_PER_CYCLE + 63) / 64, capacity, nj), dim3(64), 0, ctx->stream, ec->dev, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL); }
+    { Prof _p(ctx, "k_ec_stream"); ZKW_LAUNCH_D(ctx, (k_ec_stream), "k_ec_stream", dim3((EC_ROWS_PER_CYCLE + 63) / 64, capacity, nj), 64, 0, ec->dev, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL); }
     return launch_check("k_ec_stream");
 }
 
@@ -1514,7 +1517,7 @@ extern "C" int zkw_storage_application_synthesize(zkw_ctx* ctx, zkw_storage_appl
                                      offsetof(zkw_storage_application_fsm, current_root_hash)};
         SapWalkJob* d_jobs = nullptr;
         ZKW_TRY(ctx->upload("sap_walk_jobs", jobs, &d_jobs));
-        { Prof _p(ctx, "k_sap_walk_cycles"); hipLaunchKernelGGL(k_sap_walk_cycles, dim3((capacity * SAP_WALK_CYCLES + 256) / 256, (unsigned)jobs.size()), dim3(256), 0, ctx->stream, d_jobs, capacity); }
+        { Prof _p(ctx, "k_sap_walk_cycles"); ZKW_LAUNCH_2D(ctx, k_sap_walk_cycles, (capacity * SAP_WALK_CYCLES + 256) / 256, (unsigned)jobs.size(), 256, d_jobs, capacity); }
         return launch_check("k_sap_walk_cycles");
     }, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows, [&] {
         return nlcf_begin<CfStorageApplication>(ctx, 10, w->instances, first_instance, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows, &cf);

@@ -914,21 +914,21 @@ extern "C" int zkw_decommit_sorter_synthesize(zkw_ctx* ctx, const zkw_decommit_w
     const unsigned nj = (unsigned)n_instances;
     const u32 rstride = (u32)DS_REGION_STRIDE(capacity);
     const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
-    { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_poseidon"); ZKW_LAUNCH_D(ctx, (k_ds_fill_poseidon<0>), "k_ds_fill_poseidon", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_poseidon<0>"));
-    { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_poseidon"); ZKW_LAUNCH_D(ctx, (k_ds_fill_poseidon<1>), "k_ds_fill_poseidon", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_poseidon<1>"));
-    { Prof _p(ctx, "k_ds_fill_poseidon"); hipLaunchKernelGGL((k_ds_fill_poseidon<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_poseidon"); ZKW_LAUNCH_D(ctx, (k_ds_fill_poseidon<2>), "k_ds_fill_poseidon", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_poseidon<2>"));
-    { Prof _p(ctx, "k_ds_fill_row_A"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_A>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_row_A"); ZKW_LAUNCH_D(ctx, (k_ds_fill_row<DS_ROW_A>), "k_ds_fill_row", g256, 256, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_row<A>"));
-    { Prof _p(ctx, "k_ds_fill_row_B"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_B>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_row_B"); ZKW_LAUNCH_D(ctx, (k_ds_fill_row<DS_ROW_B>), "k_ds_fill_row", g256, 256, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_row<B>"));
-    { Prof _p(ctx, "k_ds_fill_row_C"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_C>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_row_C"); ZKW_LAUNCH_D(ctx, (k_ds_fill_row<DS_ROW_C>), "k_ds_fill_row", g256, 256, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_row<C>"));
-    { Prof _p(ctx, "k_ds_fill_row_D"); hipLaunchKernelGGL((k_ds_fill_row<DS_ROW_D>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_row_D"); ZKW_LAUNCH_D(ctx, (k_ds_fill_row<DS_ROW_D>), "k_ds_fill_row", g256, 256, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_row<D>"));
-    { Prof _p(ctx, "k_ds_fill_tail"); hipLaunchKernelGGL(k_ds_fill_tail, dim3(nj * ((DS_G + DS_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
+    { Prof _p(ctx, "k_ds_fill_tail"); ZKW_LAUNCH(ctx, k_ds_fill_tail, nj * ((DS_G + DS_L + 1) * TAIL_CHUNKS + 1), 256, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ds_fill_tail"));
     return claims.commit_if(ctx->sync_if_host());
 }
@@ -987,17 +987,17 @@ extern "C" int zkw_events_sorter_synthesize(zkw_ctx* ctx, const zkw_events_witne
     const unsigned nj = (unsigned)n_instances;
     const u32 rstride = (u32)ES_REGION_STRIDE(capacity);
     const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
-    { Prof _p(ctx, "k_es_fill_queue"); hipLaunchKernelGGL((k_es_fill_queue<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_es_fill_queue"); ZKW_LAUNCH_D(ctx, (k_es_fill_queue<0>), "k_es_fill_queue", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_es_fill_queue<0>"));
-    { Prof _p(ctx, "k_es_fill_queue"); hipLaunchKernelGGL((k_es_fill_queue<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_es_fill_queue"); ZKW_LAUNCH_D(ctx, (k_es_fill_queue<1>), "k_es_fill_queue", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_es_fill_queue<1>"));
-    { Prof _p(ctx, "k_es_fill_queue"); hipLaunchKernelGGL((k_es_fill_queue<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_es_fill_queue"); ZKW_LAUNCH_D(ctx, (k_es_fill_queue<2>), "k_es_fill_queue", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_es_fill_queue<2>"));
-#define ES_LAUNCH_ROW(R) { Prof _p(ctx, "k_es_fill_row"); hipLaunchKernelGGL((k_es_fill_row<ES_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
+#define ES_LAUNCH_ROW(R) { Prof _p(ctx, "k_es_fill_row"); ZKW_LAUNCH_D(ctx, (k_es_fill_row<ES_ROW_##R>), "k_es_fill_row", g256, 256, 0, d_jobs, capacity, n_rows); } \
     ZKW_TRY(launch_check("k_es_fill_row<" #R ">"));
     ES_LAUNCH_ROW(A) ES_LAUNCH_ROW(NTV) ES_LAUNCH_ROW(W) ES_LAUNCH_ROW(Q)  // NTV after the queue kernels: it writes the range checks into their rows' lookup columns
 #undef ES_LAUNCH_ROW
-    { Prof _p(ctx, "k_es_fill_tail"); hipLaunchKernelGGL(k_es_fill_tail, dim3(nj * ((ES_G + ES_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
+    { Prof _p(ctx, "k_es_fill_tail"); ZKW_LAUNCH(ctx, k_es_fill_tail, nj * ((ES_G + ES_L + 1) * TAIL_CHUNKS + 1), 256, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_es_fill_tail"));
     return claims.commit_if(ctx->sync_if_host());
 }
@@ -1056,15 +1056,15 @@ extern "C" int zkw_log_demux_synthesize(zkw_ctx* ctx, const zkw_demux_witness* w
     const unsigned nj = (unsigned)n_instances;
     const u32 rstride = (u32)LD_REGION_STRIDE(capacity);
     const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
-    { Prof _p(ctx, "k_ld_fill_queue"); hipLaunchKernelGGL((k_ld_fill_queue<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ld_fill_queue"); ZKW_LAUNCH_D(ctx, (k_ld_fill_queue<0>), "k_ld_fill_queue", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ld_fill_queue<0>"));
-    { Prof _p(ctx, "k_ld_fill_queue"); hipLaunchKernelGGL((k_ld_fill_queue<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ld_fill_queue"); ZKW_LAUNCH_D(ctx, (k_ld_fill_queue<1>), "k_ld_fill_queue", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ld_fill_queue<1>"));
-#define LD_LAUNCH_ROW(R) { Prof _p(ctx, "k_ld_fill_row"); hipLaunchKernelGGL((k_ld_fill_row<LD_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
+#define LD_LAUNCH_ROW(R) { Prof _p(ctx, "k_ld_fill_row"); ZKW_LAUNCH_D(ctx, (k_ld_fill_row<LD_ROW_##R>), "k_ld_fill_row", g256, 256, 0, d_jobs, capacity, n_rows); } \
     ZKW_TRY(launch_check("k_ld_fill_row<" #R ">"));
     LD_LAUNCH_ROW(X0) LD_LAUNCH_ROW(X1) LD_LAUNCH_ROW(X2) LD_LAUNCH_ROW(X3) LD_LAUNCH_ROW(R) LD_LAUNCH_ROW(Q)
 #undef LD_LAUNCH_ROW
-    { Prof _p(ctx, "k_ld_fill_tail"); hipLaunchKernelGGL(k_ld_fill_tail, dim3(nj * ((LD_G + LD_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
+    { Prof _p(ctx, "k_ld_fill_tail"); ZKW_LAUNCH(ctx, k_ld_fill_tail, nj * ((LD_G + LD_L + 1) * TAIL_CHUNKS + 1), 256, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ld_fill_tail"));
     return claims.commit_if(ctx->sync_if_host());
 }
@@ -1122,18 +1122,18 @@ extern "C" int zkw_storage_sorter_synthesize(zkw_ctx* ctx, const zkw_storage_wit
     const unsigned nj = (unsigned)n_instances;
     const u32 rstride = (u32)SS_REGION_STRIDE(capacity);
     const dim3 g64((rstride + 63) / 64, nj), g256((rstride + 255) / 256, nj);
-    { Prof _p(ctx, "k_ss_fill_queue"); hipLaunchKernelGGL((k_ss_fill_queue<0>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ss_fill_queue"); ZKW_LAUNCH_D(ctx, (k_ss_fill_queue<0>), "k_ss_fill_queue", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ss_fill_queue<0>"));
-    { Prof _p(ctx, "k_ss_fill_queue"); hipLaunchKernelGGL((k_ss_fill_queue<1>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ss_fill_queue"); ZKW_LAUNCH_D(ctx, (k_ss_fill_queue<1>), "k_ss_fill_queue", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ss_fill_queue<1>"));
-    { Prof _p(ctx, "k_ss_fill_queue"); hipLaunchKernelGGL((k_ss_fill_queue<2>), g64, dim3(64), 0, ctx->stream, d_jobs, capacity, n_rows); }
+    { Prof _p(ctx, "k_ss_fill_queue"); ZKW_LAUNCH_D(ctx, (k_ss_fill_queue<2>), "k_ss_fill_queue", g64, 64, 0, d_jobs, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ss_fill_queue<2>"));
-#define SS_LAUNCH_ROW(R) { Prof _p(ctx, "k_ss_fill_row"); hipLaunchKernelGGL((k_ss_fill_row<SS_ROW_##R>), g256, dim3(256), 0, ctx->stream, d_jobs, capacity, n_rows); } \
+#define SS_LAUNCH_ROW(R) { Prof _p(ctx, "k_ss_fill_row"); ZKW_LAUNCH_D(ctx, (k_ss_fill_row<SS_ROW_##R>), "k_ss_fill_row", g256, 256, 0, d_jobs, capacity, n_rows); } \
     ZKW_TRY(launch_check("k_ss_fill_row<" #R ">"));
     SS_LAUNCH_ROW(A) SS_LAUNCH_ROW(X0) SS_LAUNCH_ROW(X1) SS_LAUNCH_ROW(X2) SS_LAUNCH_ROW(X3) SS_LAUNCH_ROW(X4) SS_LAUNCH_ROW(X5)
     SS_LAUNCH_ROW(X6) SS_LAUNCH_ROW(X7) SS_LAUNCH_ROW(K) SS_LAUNCH_ROW(C1) SS_LAUNCH_ROW(C2) SS_LAUNCH_ROW(Q)
 #undef SS_LAUNCH_ROW
-    { Prof _p(ctx, "k_ss_fill_tail"); hipLaunchKernelGGL(k_ss_fill_tail, dim3(nj * ((SS_G + SS_L + 1) * TAIL_CHUNKS + 1)), dim3(256), 0, ctx->stream, d_jobs, nj, capacity, n_rows); }
+    { Prof _p(ctx, "k_ss_fill_tail"); ZKW_LAUNCH(ctx, k_ss_fill_tail, nj * ((SS_G + SS_L + 1) * TAIL_CHUNKS + 1), 256, d_jobs, nj, capacity, n_rows); }
     ZKW_TRY(launch_check("k_ss_fill_tail"));
     return claims.commit_if(ctx->sync_if_host());
 }

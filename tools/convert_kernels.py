@@ -10,7 +10,11 @@ KERNEL_FILES = ["ram_kernels.cuh", "log_kernels.cuh", "scan_kernels.cuh", "decom
                 "storage_kernels.cuh", "decommitter_kernels.cuh", "precompile_kernels.cuh", "storage_application_kernels.cuh",
                 "closed_form_kernels.cuh", "public_input_kernels.cuh", "vm_kernels.cuh", "zkw_api.hip"]
 LAUNCH_FILES = ["zkw_api.hip", "zkw_sorters.hip", "zkw_precompiles.hip", "scan_kernels.cuh", "closed_forms_host.h"]
-KEEP_GLOBAL = re.compile(r"k_chain_|k_sap_walk_cycles|k_check_|k_ram_fill|k_ram_hist")
+KEEP_GLOBAL = re.compile(r"k_chain_|check")
+# second pass of round 6: the synthesis kernels too (zkw_blocks_synthesize runs groups of blocks as fibers: one fill launch per type and group)
+SYNTH_KERNEL_FILES = ["ram_circuit_kernels.cuh", "decommit_sorter_circuit_kernels.cuh", "events_sorter_circuit_kernels.cuh", "log_demux_circuit_kernels.cuh",
+                      "storage_sorter_circuit_kernels.cuh", "netlist_kernels.cuh", "netlist_queue_kernels.cuh", "netlist_closed_form_kernels.cuh",
+                      "ecrecover_kernels.cuh", "storage_application_kernels.cuh", "zkw_ctx.h"]
 
 DEF = re.compile(r"(?:static )?__global__ (?:__launch_bounds__\(([^)]*)\) )?void (k_\w+)\(")
 
@@ -48,7 +52,7 @@ def convert_defs(path, bounds):
                     break
             k += 1
         body = s[j:k + 1]
-        body = body.replace("blockIdx.x", "vb.x").replace("gridDim.x", "vb.nx").replace("blockIdx.y", "vb.y").replace("gridDim.y", "vb.ny")
+        body = body.replace("blockIdx.x", "vb.x").replace("gridDim.x", "vb.nx").replace("blockIdx.y", "vb.y").replace("gridDim.y", "vb.ny").replace("blockIdx.z", "vb.z").replace("gridDim.z", "vb.nz")
         params = s[m.end():params_end]
         head = "static __device__ void %s(const VB& vb%s" % (name, ", " + params if params.strip() else "")
         out.append(head + s[params_end:j] + body)
@@ -103,6 +107,12 @@ def convert_launches(path, bounds, report):
         mctx = re.match(r"^(.*)->stream$", stream)
         g = re.match(r"^dim3\((.*)\)$", grid)
         b = re.match(r"^dim3\((.*)\)$", block)
+        if mctx and b and len(split_top(b.group(1))) == 1 and not (g and shm == "0" and len(split_top(g.group(1))) <= 2):
+            # the general form: any dim3 grid expression, dynamic LDS
+            out.append(s[pos:m.start()])
+            out.append("ZKW_LAUNCH_D(%s, (%s), \"%s\", %s, %s, %s, %s)" % (mctx.group(1), base, name, grid, b.group(1), shm, ", ".join(a[5:])))
+            pos = i + 1
+            continue
         if not (mctx and g and b and shm == "0"):
             report.append("%s: manual: %s" % (os.path.basename(path), inner[:120].replace("\n", " ")))
             continue
@@ -130,10 +140,10 @@ def convert_launches(path, bounds, report):
 
 def main():
     bounds, report = {}, []
-    for f in KERNEL_FILES:
+    for f in KERNEL_FILES + SYNTH_KERNEL_FILES:
         convert_defs(os.path.join(CSRC, f), bounds)
     # kernels converted in an earlier run of this script (definitions no longer match DEF)
-    for f in KERNEL_FILES:
+    for f in KERNEL_FILES + SYNTH_KERNEL_FILES:
         for m in re.finditer(r"static __device__ void (k_\w+)\(const VB& vb", open(os.path.join(CSRC, f)).read()):
             bounds.setdefault(m.group(1), None)
     for f in LAUNCH_FILES:
