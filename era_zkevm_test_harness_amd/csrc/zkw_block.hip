@@ -1043,6 +1043,25 @@ static int block_synthesize_impl(zkw_block* B, size_t n_rows, size_t ring_slots,
     return ZKW_OK;
 }
 
+// high-priority streams for the ECRecover threads: kept for the life of the process (hipStreamDestroy waits for the whole device)
+static std::mutex g_prio_mu;
+static std::unordered_map<int, std::vector<hipStream_t>>& g_prio_idle = *new std::unordered_map<int, std::vector<hipStream_t>>();  // by device
+static hipStream_t priority_stream_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> g(g_prio_mu);
+        std::vector<hipStream_t>& idle = g_prio_idle[device];
+        if (!idle.empty()) { hipStream_t s = idle.back(); idle.pop_back(); return s; }
+    }
+    int lo = 0, hi = 0;
+    hipStream_t s = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
+    return s;
+}
+static void priority_stream_release(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> g(g_prio_mu);
+    g_prio_idle[device].push_back(s);
+}
+
 // ---- K blocks: every instance of every block. Two things differ from K calls of zkw_block_synthesize: (1) the ECRecover instances of ALL
 // blocks go through joint calls (zkw_ecrecover_synthesize_multi, at most `ec_chunk` instances each, a ring of their own): the accumulator
 // chain of a request is one lane and ~13 ms per call whatever the batch, so 48 blocks' calls one after the other were 0.6 of the 0.75 s
@@ -1055,54 +1074,77 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
     if (!blocks || n_blocks == 0 || n_rows == 0 || ring_slots == 0) return ZKW_ERR_INVALID;
     for (size_t k = 0; k < n_blocks; k++)
         if (!blocks[k] || blocks[k]->device != blocks[0]->device) return ZKW_ERR_INVALID;
-    if (ec_chunk == 0) ec_chunk = 32;
+    // the ring of the joint ECRecover calls is ec_chunk slots of 129 columns (1.08 GB each at 2^20 rows): 16 by default, at most 64
+    if (ec_chunk == 0) ec_chunk = 16;
+    if (ec_chunk > 64) ec_chunk = 64;
     std::atomic<size_t> done{0};
     std::atomic<int> first_rc{ZKW_OK};
+    const Clock::time_point t_start = Clock::now();
+    static const bool synth_log = getenv("ZKW_SYNTH_LOG") != nullptr;  // one line per thread: when it was done
+    auto log_done = [&](const char* who, size_t idx) {
+        if (synth_log) fprintf(stderr, "[zkw synth] %s %zu done at %.0f ms\n", who, idx, std::chrono::duration<double, std::milli>(Clock::now() - t_start).count());
+    };
     auto note = [&](int rc) { int ok = ZKW_OK; if (rc != ZKW_OK) first_rc.compare_exchange_strong(ok, rc); };
     struct Fwd { size_t block; zkw_blocks_circuit_fn cb; void* user; };
     auto fwd = [](void* u, uint8_t type, size_t inst, const zkw_trace* tr, size_t slot, const uint64_t* pi) -> int {
         const Fwd* f = static_cast<const Fwd*>(u);
         return f->cb ? f->cb(f->user, f->block, type, inst, tr, slot, pi) : 0;
     };
-    // (1) ECRecover of all blocks
-    std::thread ec_thread([&] {
-        if (hipSetDevice(blocks[0]->device) != hipSuccess) { note(ZKW_ERR_HIP); return; }
-        size_t most = 0, total = 0;
-        for (size_t k = 0; k < n_blocks; k++) { const size_t n = zkw_block_num_instances(blocks[k], T_ECR); most = std::max(most, n); total += n; }
-        if (total == 0) return;
-        // a context of its own: the blocks' precompile contexts are busy with their Keccak / SHA-256 / decommitter instances on the other threads
-        zkw_ctx* c = zkw_create(blocks[0]->device);
-        if (!c) { note(ZKW_ERR_NO_DEVICE); return; }
-        int rc = ZKW_OK;
-        const size_t slots = std::max(most, std::min(ec_chunk, total));
-        zkw_trace* ring = nullptr;
-        rc = zkw_trace_create_with_columns(c, n_rows, 129 /* 80 + 3 x 16 + 1 columns: include/zkw_ecrecover_circuit_spec.h EK_COLS */, slots, &ring);
-        if (rc != ZKW_OK) { note(rc); zkw_destroy(c); return; }
-        for (size_t b0 = 0; b0 < n_blocks && first_rc.load() == ZKW_OK;) {
-            std::vector<zkw_precompile_witness*> ws;
-            std::vector<size_t> owner;
-            size_t cnt = 0, b1 = b0;
-            while (b1 < n_blocks && cnt + zkw_block_num_instances(blocks[b1], T_ECR) <= slots) {
-                ws.push_back(static_cast<zkw_precompile_witness*>(zkw_block_witness(blocks[b1], T_ECR)));
-                cnt += zkw_block_num_instances(blocks[b1], T_ECR);
-                b1++;
-            }
-            rc = zkw_ecrecover_synthesize_multi(c, ws.data(), ws.size(), ring, 0);
-            if (rc == ZKW_OK) rc = zkw_synchronize(c);
-            if (rc != ZKW_OK) { note(rc); break; }
-            size_t slot = 0;
-            for (size_t b = b0; b < b1 && first_rc.load() == ZKW_OK; b++) {
-                const size_t ni = zkw_block_num_instances(blocks[b], T_ECR);
-                for (size_t i = 0; i < ni; i++, slot++) {
-                    if (cb && cb(user, b, (uint8_t)T_ECR, i, ring, slot, blocks[b]->per[T_ECR].pi.data() + 4 * i) != 0) { note(ZKW_ERR_CHECK_FAILED); break; }
-                    done++;
+    // (1) ECRecover of all blocks: joint calls of up to ec_chunk instances, on ZKW_EC_THREADS threads (default 2), each with a ring and a context of
+    // its own on a HIGH-PRIORITY stream. A call is latency — the accumulator chain of a request is one lane, ~13 ms whatever the batch, the
+    // segment evaluator's dependent loads another ~9 ms — and next to the other types' fills a single thread on an ordinary stream was the
+    // long pole of the whole synthesis (its kernels queued behind the fills: 2.2 - 3.1 s for the 1 024 instances of 512 blocks, the workers done
+    // after 1.6 - 1.9 s); priority streams have hardware queues of their own, and two calls in flight hide each other's serial kernels.
+    static const size_t ec_threads_max = [] { const char* e = getenv("ZKW_EC_THREADS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 8 ? v : 2); }();
+    size_t ec_most = 0, ec_total = 0;
+    for (size_t k = 0; k < n_blocks; k++) { const size_t n = zkw_block_num_instances(blocks[k], T_ECR); ec_most = std::max(ec_most, n); ec_total += n; }
+    const size_t ec_slots = std::max(ec_most, std::min(ec_chunk, ec_total));
+    const size_t n_ec_threads = ec_total == 0 ? 0 : std::max<size_t>(1, std::min(ec_threads_max, (ec_total + ec_slots - 1) / ec_slots));
+    std::mutex ec_mu;
+    size_t ec_cursor = 0;
+    std::vector<std::thread> ec_pool;
+    for (size_t et = 0; et < n_ec_threads; et++)
+        ec_pool.emplace_back([&, et] {
+            if (hipSetDevice(blocks[0]->device) != hipSuccess) { note(ZKW_ERR_HIP); return; }
+            // a context of its own: the blocks' precompile contexts are busy with their Keccak / SHA-256 / decommitter instances on the other threads
+            zkw_ctx* c = zkw_create(blocks[0]->device);
+            if (!c) { note(ZKW_ERR_NO_DEVICE); return; }
+            hipStream_t hp = priority_stream_acquire(blocks[0]->device);
+            int rc = hp ? zkw_set_stream(c, hp) : ZKW_OK;  // (no priority stream: the context's own)
+            zkw_trace* ring = nullptr;
+            if (rc == ZKW_OK) rc = zkw_trace_create_with_columns(c, n_rows, 129 /* 80 + 3 x 16 + 1 columns: include/zkw_ecrecover_circuit_spec.h EK_COLS */, ec_slots, &ring);
+            while (rc == ZKW_OK && first_rc.load() == ZKW_OK) {
+                std::vector<zkw_precompile_witness*> ws;
+                size_t cnt = 0, b0, b1;
+                {
+                    std::lock_guard<std::mutex> g(ec_mu);
+                    b0 = b1 = ec_cursor;
+                    while (b1 < n_blocks && cnt + zkw_block_num_instances(blocks[b1], T_ECR) <= ec_slots) {
+                        ws.push_back(static_cast<zkw_precompile_witness*>(zkw_block_witness(blocks[b1], T_ECR)));
+                        cnt += zkw_block_num_instances(blocks[b1], T_ECR);
+                        b1++;
+                    }
+                    ec_cursor = b1;
+                }
+                if (b0 == b1) break;
+                rc = zkw_ecrecover_synthesize_multi(c, ws.data(), ws.size(), ring, 0);
+                if (rc == ZKW_OK) rc = zkw_synchronize(c);
+                if (rc != ZKW_OK) break;
+                size_t slot = 0;
+                for (size_t b = b0; b < b1 && first_rc.load() == ZKW_OK; b++) {
+                    const size_t ni = zkw_block_num_instances(blocks[b], T_ECR);
+                    for (size_t i = 0; i < ni; i++, slot++) {
+                        if (cb && cb(user, b, (uint8_t)T_ECR, i, ring, slot, blocks[b]->per[T_ECR].pi.data() + 4 * i) != 0) { note(ZKW_ERR_CHECK_FAILED); break; }
+                        done++;
+                    }
                 }
             }
-            b0 = b1;
-        }
-        zkw_trace_free(ring);
-        zkw_destroy(c);
-    });
+            if (rc != ZKW_OK) note(rc);
+            log_done("ecrecover thread", et);
+            if (ring) zkw_trace_free(ring);
+            if (hp) { (void)zkw_set_stream(c, ZKW_STREAM_OWN); priority_stream_release(blocks[0]->device, hp); }
+            zkw_destroy(c);
+        });
     // (2) everything else: a few workers, each with a contiguous share of the blocks, a ring of G x ring_slots slots and a batch (zkw_batch.h)
     // of G fibers. Fiber s owns slot(s) s of the ring and every G-th block of the worker's share, and goes through them TYPE BY TYPE — the
     // LogDemuxer instances of its blocks, then their RAMPermutation instances, ... — running the code zkw_block_synthesize runs. The G fibers
@@ -1111,7 +1153,7 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
     // blocks), and (b) a slot holds the same layout call after call, so a fill only rewrites the cells it owns (zkw_trace::slot_tag): no
     // zeroing pass over the ~1 GB of general columns of a netlist circuit, about half the bytes of a queue circuit. Round 5 ran the blocks one
     // by one on eight threads with a ring per BLOCK (1.28 GB a slot: ~150 blocks in flight at most, every call into a slot a cold one).
-    // ZKW_SYNTH_THREADS workers (default 3: while one worker's fibers wait for a serial kernel the others' fills have the chip),
+    // ZKW_SYNTH_THREADS workers (default 3: while one worker's fibers wait for a serial kernel the others' fills have the chip; 2 and 4 measured about the same),
     // ZKW_SYNTH_GROUP fibers per worker (default 16). cb is called on the workers' threads, one call at a time per worker.
     std::vector<std::thread> pool;
     static const size_t max_threads = [] { const char* e = getenv("ZKW_SYNTH_THREADS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 ? v : 3); }();
@@ -1136,11 +1178,9 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
                 zkw_destroy(wc);
                 return;
             }
-            std::vector<std::vector<std::string>> marks((b1 - b0) * N_CTX);
             std::vector<size_t> counts(b1 - b0, 0);
             for (size_t b = b0; b < b1; b++)
                 for (int i = 0; i < N_CTX; i++) {
-                    zkw_ctx_scratch_mark(blocks[b]->ctx[i], &marks[(b - b0) * N_CTX + i]);
                     (void)zkw_synchronize(blocks[b]->ctx[i]);  // (idle already: the builders are done)
                     zkw_ctx_enter_batch(blocks[b]->ctx[i], batch);
                 }
@@ -1153,11 +1193,15 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
                             if (first_rc.load() != ZKW_OK) return ZKW_OK;
                             Fwd f{b, cb, user};
                             size_t n = 0;
+                            // what the synthesis of a type adds to its context's scratch (windows, gathers: up to ~50 MB) goes back as soon as
+                            // its instances are done: kept until the block's release it was 100 MB x every block of the batch
+                            zkw_ctx* c = zkw_block_context(blocks[b], (uint8_t)t);
+                            std::vector<std::string> mark;
+                            zkw_ctx_scratch_mark(c, &mark);
                             const int r = block_synthesize_impl(blocks[b], n_rows, ring_slots, 0, 1, fwd, &f, &n, T_ECR, ring, t, s * ring_slots);
                             counts[b - b0] += n;
                             if (r != ZKW_OK) return r;
-                            if (t == T_HSH)  // the block's last type: what its synthesis added to the contexts' scratch (~100 MB) goes back now
-                                for (int i = 0; i < N_CTX; i++) zkw_ctx_scratch_release_since(blocks[b]->ctx[i], marks[(b - b0) * N_CTX + i]);
+                            zkw_ctx_scratch_release_since(c, mark);
                         }
                     }
                     return ZKW_OK;
@@ -1166,21 +1210,20 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
             for (size_t b = b0; b < b1; b++) {
                 zkw_block* B = blocks[b];
                 for (int i = 0; i < N_CTX; i++) {
-                    // what the synthesis added to the contexts' scratch (windows, gathers: ~100 MB per block) goes back right away; a block
-                    // built by a batch has no stream of its own and returns to the device's shared one, any other to its own
+                    // a block built by a batch has no stream of its own and returns to the device's shared one, any other to its own
                     zkw_ctx_leave_batch(B->ctx[i], shared);
                     if (!B->from_batch) (void)zkw_set_stream(B->ctx[i], ZKW_STREAM_OWN);
-                    zkw_ctx_scratch_release_since(B->ctx[i], marks[(b - b0) * N_CTX + i]);
                 }
                 done += counts[b - b0];
             }
             if (rc != ZKW_OK) note(rc);
+            log_done("worker", th);
             zkw_batch_destroy(batch);
             zkw_trace_free(ring);
             zkw_destroy(wc);
         });
     for (auto& t : pool) t.join();
-    ec_thread.join();
+    for (auto& t : ec_pool) t.join();
     if (getenv("ZKW_BLOCK_MEM_LOG")) {
         size_t scratch = 0, live = 0, idle = 0, per_ctx[N_CTX] = {};
         static const char* cn[N_CTX] = {"dec", "ram", "dmx", "sto", "evt", "l1", "pre"};

@@ -1848,7 +1848,7 @@ class Block:
         return n.value
 
     @staticmethod
-    def synthesize_many(blocks, n_rows, ring_slots=1, ec_chunk=32, callback=None):
+    def synthesize_many(blocks, n_rows, ring_slots=1, ec_chunk=0, callback=None):
         """zkw_blocks_synthesize: every instance of every block (None entries skipped); the ECRecover instances of all blocks in joint
         calls of at most ec_chunk instances. callback(block_index, circuit_type, instance, trace_handle, slot, public_input[4]) may be
         called from several library threads. Returns the number of instances synthesized."""

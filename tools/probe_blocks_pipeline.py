@@ -25,7 +25,7 @@ def build():
 
 def synth(bs):
     t = time.perf_counter()
-    n = nv.Block.synthesize_many(bs, 1 << 20, ring_slots=1)
+    n = nv.Block.synthesize_many(bs, 1 << 20, ring_slots=1, ec_chunk=int(os.environ.get("EC_CHUNK", "0")))
     return n, time.perf_counter() - t
 
 
@@ -40,11 +40,20 @@ print(f"warm-up: builders {tb*1e3:.0f} ms, synthesis {ts*1e3:.0f} ms, release {t
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 total = 0
-if mode == "seq":
+if mode in ("seq", "seqbg"):
+    bg = None
     for r in range(batches):
-        bs, tb = build(); n, ts = synth(bs); tf = free(bs); total += n
+        bs, tb = build()
+        if bg is not None: bg.join()
+        n, ts = synth(bs); total += n
+        if mode == "seqbg":   # the release of a batch under the builders of the next one (host work both)
+            tf = 0.0
+            bg = threading.Thread(target=free, args=(bs,)); bg.start()
+        else:
+            tf = free(bs)
         fr, tot = torch.cuda.mem_get_info(0)
         print(f"K={K} batch {r}: builders {tb*1e3:.0f} ms, synthesis of {n} instances {ts*1e3:.0f} ms, release {tf*1e3:.0f} ms; HBM in use {(tot-fr)/2**30:.0f} GiB", flush=True)
+    if bg is not None: bg.join()
 else:
     res = {}
     def t_build(): res["b"] = build()
