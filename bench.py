@@ -141,6 +141,8 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
         if best is None or rep["wall_ms"] < best["wall_ms"]:
             best = rep
     best["batched"] = full_blocks_batched(local_rank, blk, rank=rank, world=world, comm=comm)
+    best["scaling_note"] = ("`batched` is the leg that scales with N (whole blocks sharded over the ranks, nothing replicated); the single block above "
+                            "does not: its builders are one serial chain replicated on every rank, only its ~35 ms of synthesis are shared")
     best["note"] = ("one block on %d GPU(s): builders = zkw_block_run (every builder of the post-VM half of "
                     "create_artifacts_from_tracer; replicated on every rank: they are bounded by the block's longest serial "
                     "Poseidon2 queue chain, memory queue = %d items x ~10.3 us, which more GPUs cannot shorten); synthesis = this "
@@ -149,24 +151,26 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     return best, blk
 
 
-def full_blocks_batched(local_rank, blk, K=96, rounds=3, rank=0, world=1, comm=None):
-    """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once (zkw_blocks_run: one host thread per block; the
-    chain service merges every block's Poseidon2 queue chains into shared launches, so K blocks cost about two chain passes instead of K),
-    every synthesizable instance of every block into its trace (zkw_blocks_synthesize: the ECRecover instances of all blocks in joint calls,
-    the other types block by block on the library's threads), the blocks released; batch after batch (the builders of batch k + 1 next to
-    the synthesis of batch k were measured: 20.7 / 26.6 blocks/s at 48 / 96 in flight against 24.9 / 29.6 one after the other — the
-    synthesis starves next to the chains' high-priority streams). The figure is the blocks of the timed batches over their wall time, the
-    first batch (which fills the library's buffer caches) untimed. With N GPUs the K x N blocks are sharded over the ranks by
-    zkw_blocks_run_sharded (round-robin, nothing replicated) and every block's closed-form records are gathered to rank 0
-    (zkw_blocks_gather_closed_form_inputs), batch after batch."""
-    # ZKW_BATCHED_BLOCKS: 48 for runs under rocprofv3 (its interception crashes in hipMemcpyAsync under ~500 host threads: tools/run_round_profiles.sh)
+def full_blocks_batched(local_rank, blk, K=512, rounds=3, rank=0, world=1, comm=None):
+    """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once. zkw_blocks_run runs the blocks' builder graphs
+    as fibers of ONE host thread and merges their launches per kernel and stage (csrc/zkw_batch.h: no thread and no stream per block);
+    zkw_blocks_synthesize synthesizes every instance of every block — groups of slot-owning fibers going through their blocks type by type,
+    the ECRecover instances of all blocks in joint calls on two priority streams —; zkw_blocks_free releases the batch. Batch after batch
+    (the builders of batch k + 1 under the synthesis of batch k were measured: the chains' priority waves slow the fills by 70 %, and two
+    batches of 256 do not beat one of 512). The figure is the blocks of the timed batches over their wall time; the first batch (which
+    fills the library's buffer caches) is untimed. The blocks' four queues are resident in HBM when the clock starts
+    (zkw_block_inputs.queues_on_device: the contract's "inputs already resident"); `host_inputs` repeats one batch with host arrays.
+    With N GPUs the K x N blocks are sharded over the ranks by zkw_blocks_run_sharded (round-robin, nothing replicated) and every block's
+    closed-form records are gathered to rank 0 (zkw_blocks_gather_closed_form_inputs), batch after batch."""
     K = int(os.environ.get("ZKW_BATCHED_BLOCKS", K))
-    distinct = [blk] + [synthetic.block_production(seed=2 + k) for k in range(3)]
-    blocks = [distinct[(k // world) % len(distinct)] for k in range(K * world)]
+    distinct_host = [blk] + [synthetic.block_production(seed=2 + k) for k in range(3)]
+    distinct = [native.Block.queues_to_device(b, local_rank) for b in distinct_host]
+    pick = lambda pool: [pool[(k // world) % len(pool)] for k in range(K * world)]  # noqa: E731
+    templates = native.Block.prepare_many(local_rank, pick(distinct))  # the input structs, once: a service builds them as its blocks arrive
     dev = torch.device("cuda", local_rank)
 
-    def build():
-        return native.Block.run_many(local_rank, blocks) if world == 1 else native.Block.run_sharded(local_rank, blocks, rank, world)
+    def build(tpl):
+        return native.Block.run_prepared(local_rank, tpl) if world == 1 else native.Block.run_sharded_prepared(local_rank, tpl, rank, world)
 
     def finish(bs, rep):
         t1 = time.perf_counter()
@@ -178,33 +182,50 @@ def full_blocks_batched(local_rank, blk, K=96, rounds=3, rank=0, world=1, comm=N
             got = native.Block.gather_sharded(bs, comm, rank, world, root=0)
             rep["records"] = (rep["records"] or 0) + (sum(len(g) for g in got) if got is not None else 0)
         t3 = time.perf_counter()
-        for b in mine:
-            b.free()
+        native.Block.free_many(mine)
         t4 = time.perf_counter()
         rep["synthesis_ms"].append((t2 - t1) * 1e3); rep["gather_ms"].append((t3 - t2) * 1e3); rep["release_ms"].append((t4 - t3) * 1e3)
 
-    warm = build()
-    finish(warm, {"instances": 0, "records": None, "synthesis_ms": [], "gather_ms": [], "release_ms": []})  # fills the caches
-    rep = {"instances": 0, "records": None, "synthesis_ms": [], "gather_ms": [], "release_ms": [], "builders_ms": []}
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for r in range(rounds):
-        tb = time.perf_counter()
-        cur = build()
-        rep["builders_ms"].append((time.perf_counter() - tb) * 1e3)
-        finish(cur, rep)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-    n_all = int(parallel.sum_over_ranks(rep["instances"], dev)) if world > 1 else rep["instances"]
+    def timed(tpl, n_rounds):
+        rep = {"instances": 0, "records": None, "synthesis_ms": [], "gather_ms": [], "release_ms": [], "builders_ms": []}
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _r in range(n_rounds):
+            tb = time.perf_counter()
+            cur = build(tpl)
+            rep["builders_ms"].append((time.perf_counter() - tb) * 1e3)
+            finish(cur, rep)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+        rep["wall"] = wall
+        rep["n_all"] = int(parallel.sum_over_ranks(rep["instances"], dev)) if world > 1 else rep["instances"]
+        return rep
+
+    finish(build(templates), {"instances": 0, "records": None, "synthesis_ms": [], "gather_ms": [], "release_ms": []})  # fills the caches
+    rep = timed(templates, rounds)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
     r3 = lambda v: [round(x, 1) for x in v]  # noqa: E731
-    return {"blocks": K * world * rounds, "blocks_per_gpu_in_flight": K, "batches": rounds, "n_gpus": world, "blocks_per_s": K * world * rounds / wall,
-            "synthesized_circuits_per_s": n_all / wall, "wall_ms": wall * 1e3, "builders_ms_per_batch": r3(rep["builders_ms"]),
-            "synthesis_ms_per_batch": r3(rep["synthesis_ms"]), "gather_ms_per_batch": r3(rep["gather_ms"]), "release_ms_per_batch": r3(rep["release_ms"]),
-            "instances_synthesized": n_all, "records_gathered": rep["records"],
-            "schedule": "batch after batch: builders (zkw_blocks_run), synthesis (zkw_blocks_synthesize), release",
-            "sharding": "one GPU" if world == 1 else "zkw_blocks_run_sharded (round-robin over ranks) + zkw_blocks_gather_closed_form_inputs"}
+    out = {"blocks": K * world * rounds, "blocks_per_gpu_in_flight": K, "batches": rounds, "n_gpus": world, "blocks_per_s": K * world * rounds / rep["wall"],
+           "per_rank_blocks_per_s": K * rounds / rep["wall"], "synthesized_circuits_per_s": rep["n_all"] / rep["wall"], "wall_ms": rep["wall"] * 1e3,
+           "builders_ms_per_batch": r3(rep["builders_ms"]), "synthesis_ms_per_batch": r3(rep["synthesis_ms"]), "gather_ms_per_batch": r3(rep["gather_ms"]),
+           "release_ms_per_batch": r3(rep["release_ms"]), "instances_synthesized": rep["n_all"], "records_gathered": rep["records"],
+           "inputs": "the blocks' four queues resident in HBM (zkw_block_inputs.queues_on_device); bytecodes and input structs on the host",
+           "host_threads_per_block": 0, "streams_per_block": 0,
+           "schedule": "batch after batch: builders (zkw_blocks_run: fibers of one thread, launches merged per kernel and stage), synthesis (zkw_blocks_synthesize: "
+                       "slot-owning fibers type by type, ECRecover in joint calls), release (zkw_blocks_free)",
+           "sharding": "one GPU" if world == 1 else "zkw_blocks_run_sharded (round-robin over ranks) + zkw_blocks_gather_closed_form_inputs",
+           "rccl_ranks": world if (world > 1 and comm is not None) else 0}
+    try:  # the same with the queues in host memory (PCIe inside the builders): one batch
+        del templates
+        host_tpl = native.Block.prepare_many(local_rank, pick(distinct_host))
+        h = timed(host_tpl, 1)
+        out["host_inputs"] = {"blocks_per_s": K * world / h["wall"], "builders_ms": round(h["builders_ms"][0], 1), "synthesis_ms": round(h["synthesis_ms"][0], 1),
+                              "note": "the four queues of every block as host arrays (~20 MB per block over PCIe inside zkw_blocks_run)"}
+    except Exception as e:  # noqa: BLE001 - a side figure
+        out["host_inputs"] = {"error": repr(e)}
+    return out
 
 
 
@@ -513,6 +534,7 @@ def main():
     ap.add_argument("--no-hash-circuits", action="store_true", help="skip the synthesis-rate leg of the netlist circuits")
     ap.add_argument("--no-full-block", action="store_true", help="skip the full-block wall-time leg")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the sensitivity legs (cold slots, per-block address patterns, wide sort keys: 3 steps each)")
+    ap.add_argument("--cold-steps", type=int, default=0, help="timed steps of the cold-slots figure `value_cold_slots` (0 = as many as --steps)")
     ap.add_argument("--no-validate", action="store_true", help="skip the oracle comparison of one ring slot per pipeline after the timed region")
     ap.add_argument("--launcher-self-test", action="store_true",
                     help="CPU only, no circuit work: the N ranks exchange synthetic closed-form records over gloo and over the C ABI's "
@@ -838,9 +860,11 @@ def main():
             run_steps(1, stagger_s)  # (the validation and host-feed legs left the pipelines idle: one untimed step first)
             sensitivity["baseline_circuits_per_s"] = timed_steps(3)  # the unchanged workload over the same 3 steps: what the legs compare with
             # (1) cold slots: the prover took every slot's pointer (zkw_trace_device_ptr), so a synthesis writes all 1 250 MB of a trace
-            #     instead of the 578 MB that differ between two traces of the layout
+            #     instead of the 578 MB that differ between two traces of the layout. Over as many steps as `value`
             cold_slots[0] = True
-            sensitivity["cold_slots_circuits_per_s"] = timed_steps(3)
+            run_steps(1, stagger_s)
+            sensitivity["cold_slots_steps"] = args.cold_steps if args.cold_steps > 0 else args.steps
+            sensitivity["cold_slots_circuits_per_s"] = timed_steps(sensitivity["cold_slots_steps"])
             cold_slots[0] = False
             run_steps(1, stagger_s)  # (re-warm the ring)
             # (2) every block its own address pattern: page ^= m_b, index ^= n_b (bijections, the trace stays a valid memory): 14 142 distinct
@@ -1006,6 +1030,10 @@ def main():
         out = {
             "metric": "base-layer circuits/sec (2^20 rows); full-block synth wall-time 1/8 GPU",
             "value": circuits / dt,
+            # the same workload when the consumer has taken every slot's pointer before each synthesis (all 1 250 MB of a trace written instead of
+            # the 578 MB a slot that still holds the layout needs): the figure a prover that scribbles on its slots would see
+            "value_cold_slots": (sensitivity or {}).get("cold_slots_circuits_per_s"),
+            "value_cold_slots_steps": (sensitivity or {}).get("cold_slots_steps"),
             "unit": "circuits/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -1034,6 +1062,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(name, 2 * items),
                          "traffic_unit": "bytes per launch (PMC, newest profiles/rNN/traffic.json)", "algorithmic_bytes_per_launch": ab,
+                         "bytes_basis": "SURVEY 8(d) algorithmic bytes of the kernel: 48 B query read + 32 B capacity words written per queue item (nothing else moves)",
                          "avg_launch_ms": avg_ms,
                          "note": "k_chain_full is a serial Poseidon2 chain per queue: latency/VALU-bound, permutations/s is "
                                  "its meaningful rate; with P pipelines its launches overlap the other pipelines' synthesis, "
@@ -1043,6 +1072,10 @@ def main():
             "sensitivity": sensitivity,
             "synthesis": {"trace_bytes_per_circuit": 149 * n_rows * 8, "kernels_ms_per_step": synth_ms / args.steps,
                           "achieved_GBps": synth_gbs, "frac_of_hbm_peak": synth_gbs / HBM_PEAK_GBS if synth_gbs else None,
+                          "bytes_basis": "written: write_bytes_per_circuit (a slot that holds the layout keeps the cells that are zero in every trace)",
+                          "achieved_GBps_on_trace_bytes": (synth_gbs * 149 * n_rows * 8 / native.circuit_fill_bytes(8, CAPACITY, n_rows)[0]) if synth_gbs else None,
+                          "frac_of_hbm_peak_on_trace_bytes": (synth_gbs * 149 * n_rows * 8 / native.circuit_fill_bytes(8, CAPACITY, n_rows)[0] / HBM_PEAK_GBS) if synth_gbs else None,
+                          "bytes_basis_trace": "SURVEY 8(d): 149 x 2^20 x 8 B per circuit, what a cold slot gets; the kernels' time is the warm slots'",
                           "per_kernel": hbm_kernels},
             "hbm_used_GB": (total_mem - free_after) / 1e9,
             "poseidon2_perm_per_s": 2 * items * chain_cnt / (chain_ms * 1e-3) if chain_ms else None,  # inside the chain launches

@@ -10,7 +10,7 @@
 namespace zkw {
 
 // sort keys: timestamp and the four 64-bit halves of the hash (least significant first)
-static __device__ void k_decommit_sort_keys(const VB& vb, const zkw_decommit_query* __restrict__ q, size_t n, u32* __restrict__ ts,
+static __device__ __forceinline__ void k_decommit_sort_keys(const VB& vb, const zkw_decommit_query* __restrict__ q, size_t n, u32* __restrict__ ts,
                                      u64* __restrict__ h0, u64* __restrict__ h1, u64* __restrict__ h2,
                                      u64* __restrict__ h3, u32* __restrict__ iota) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
@@ -24,7 +24,7 @@ static __device__ void k_decommit_sort_keys(const VB& vb, const zkw_decommit_que
     iota[i] = (u32)i;
 }
 
-static __device__ void k_decommit_gather_encode(const VB& vb, const zkw_decommit_query* __restrict__ q,
+static __device__ __forceinline__ void k_decommit_gather_encode(const VB& vb, const zkw_decommit_query* __restrict__ q,
                                                                 const u32* __restrict__ perm, size_t n,
                                                                 zkw_decommit_query* __restrict__ sorted_q,
                                                                 u64* __restrict__ sorted_enc) {
@@ -53,7 +53,7 @@ struct DecommitFreshFlag {
 // every request on its own, given the tiled prefix count of is_fresh (prefix[k] = fresh among [0, k)): the inclusive count, the
 // reference's ordering self-check (:99-114), the compaction of the fresh requests (= the deduplicated queue, :121-140) and the
 // position of every fresh request (fresh_pos[k] = index of the k-th). totals[1] is zeroed by the caller.
-static __device__ void k_decommit_dedup(const VB& vb, const zkw_decommit_query* __restrict__ sorted_q, const u64* __restrict__ sorted_enc, size_t n,
+static __device__ __forceinline__ void k_decommit_dedup(const VB& vb, const zkw_decommit_query* __restrict__ sorted_q, const u64* __restrict__ sorted_enc, size_t n,
                                                         const u32* __restrict__ prefix, u32* __restrict__ fresh_count /* [n] inclusive */,
                                                         u32* __restrict__ fresh_pos /* [n] */, zkw_decommit_query* __restrict__ dedup_q,
                                                         u64* __restrict__ dedup_enc, u32* __restrict__ totals /* [2]: n_dedup, violations */) {
@@ -81,7 +81,7 @@ static __device__ void k_decommit_dedup(const VB& vb, const zkw_decommit_query* 
     }
 }
 // last_fresh[i] = index of the latest fresh request at or before i (0 when there is none yet)
-static __device__ void k_decommit_last_fresh(const VB& vb, const u32* __restrict__ fresh_count, const u32* __restrict__ fresh_pos, size_t n, u32* __restrict__ last_fresh) {
+static __device__ __forceinline__ void k_decommit_last_fresh(const VB& vb, const u32* __restrict__ fresh_count, const u32* __restrict__ fresh_pos, size_t n, u32* __restrict__ last_fresh) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n) last_fresh[i] = fresh_count[i] ? fresh_pos[fresh_count[i] - 1] : 0u;
 }
@@ -112,7 +112,7 @@ __device__ __forceinline__ void dedup_state_at(const DecommitBlock& b, u32 cnt, 
     qs12(s, b.dedup_in.head, cnt ? b.dedup_tails + 12 * (size_t)(cnt - 1) : b.dedup_in.tail, b.dedup_in.length + cnt);
 }
 
-static __device__ void k_decommit_instances(const VB& vb, const DecommitBlock* __restrict__ blk) {
+static __device__ __forceinline__ void k_decommit_instances(const VB& vb, const DecommitBlock* __restrict__ blk) {
     const DecommitBlock& b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;

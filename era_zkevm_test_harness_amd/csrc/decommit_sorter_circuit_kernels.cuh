@@ -154,7 +154,7 @@ __device__ __forceinline__ void ds_prev_result_queue(const DsSynthJob& job, cons
 // ------------------------------------------------------------------------------------------------
 // Poseidon2 rows: WHICH 0 = PU (pop unsorted), 1 = PS (pop sorted), 2 = PR (push into the deduplicated queue)
 template <int WHICH>
-static __device__ void k_ds_fill_poseidon(const VB& vb, const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ds_fill_poseidon(const VB& vb, const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     for (int t = threadIdx.x; t < 256; t += blockDim.x) sh_hist[t] = 0;
     __syncthreads();
@@ -217,7 +217,7 @@ static __device__ void k_ds_fill_poseidon(const VB& vb, const DsSynthJob* __rest
 #define DS_XG(col, v) TR(col, row) = glob.v;
 
 template <int ROW>
-static __device__ void k_ds_fill_row(const VB& vb, const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ds_fill_row(const VB& vb, const DsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -363,7 +363,7 @@ static __device__ void k_ds_fill_row(const VB& vb, const DsSynthJob* __restrict_
 // the zero padding below the boundary rows and the multiplicity column (see k_ram_fill_tail)
 constexpr int DS_BOUNDARY_ROWS = (DS_NUM_ROW_TYPES - DS_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
 __device__ __forceinline__ void ds_boundary_block(const DsSynthJob& job, u32 capacity, size_t n_rows);
-static __device__ void k_ds_fill_tail(const VB& vb, const DsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ds_fill_tail(const VB& vb, const DsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
     // dependent permutations that the other blocks' stores hide), then (DS_G + DS_L + 1) * TAIL_CHUNKS blocks per trace
     if (vb.x < n_jobs) {

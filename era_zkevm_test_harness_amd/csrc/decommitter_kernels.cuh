@@ -61,7 +61,7 @@ struct DecommitterJob {
 
 // one lane per request: SHA-256 over its bytecode (two big-endian words per block, padding in the last
 // block, decommit_code.rs:286-320), every round's state kept; digest compared with the request's hash
-static __device__ void k_decommitter_sha(const VB& vb, DecommitterJob job) {
+static __device__ __forceinline__ void k_decommitter_sha(const VB& vb, DecommitterJob job) {
     const u64 k = (u64)vb.x * blockDim.x + threadIdx.x;
     if (k >= job.n_requests) return;
     const zkw_decommit_query q = job.requests[k];
@@ -109,7 +109,7 @@ static __device__ void k_decommitter_sha(const VB& vb, DecommitterJob job) {
 }
 
 // one lane per code word: the memory write it becomes (decommit_code.rs:47-78) and its encoding
-static __device__ void k_decommitter_mem_queries(const VB& vb, DecommitterJob job, u64 total_words) {
+static __device__ __forceinline__ void k_decommitter_mem_queries(const VB& vb, DecommitterJob job, u64 total_words) {
     const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= total_words) return;
     u64 lo = 0, hi = job.n_requests;  // largest k with word_offsets[k] <= i
@@ -147,7 +147,7 @@ struct DecommitterBlock {
     u32 capacity;
 };
 
-static __device__ void k_decommitter_instances(const VB& vb, const DecommitterBlock* __restrict__ blk) {
+static __device__ __forceinline__ void k_decommitter_instances(const VB& vb, const DecommitterBlock* __restrict__ blk) {
     const DecommitterBlock& b = *blk;
     const u64 n_inst = (b.total_rounds + b.capacity - 1) / b.capacity, nreq = b.job.n_requests;
     const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;
@@ -273,7 +273,7 @@ __device__ __forceinline__ u64 l1_block_lane(const zkw_log_query* q, size_t len,
 // The absorbed blocks of all queues of a batch, in parallel: thread = (block, word w < 18) -> rounds[block].block words (w = 17:
 // the reset flag). The serial sponge then only loads them — building a block's bytes from the 88-byte serialisations inside the
 // sponge loop (eight dependent message loads and a division per byte) took more of its time than the permutation.
-static __device__ void k_linear_blocks(const VB& vb, const zkw_log_query* __restrict__ q, const u64* __restrict__ msg_off,
+static __device__ __forceinline__ void k_linear_blocks(const VB& vb, const zkw_log_query* __restrict__ q, const u64* __restrict__ msg_off,
                                                                const u64* __restrict__ round_off, u32 n_queues, zkw_keccak_round_record* __restrict__ rounds) {
     const u64 i = (u64)vb.x * blockDim.x + threadIdx.x, total = round_off[n_queues] * 18;
     if (i >= total) return;
@@ -293,7 +293,7 @@ static __device__ void k_linear_blocks(const VB& vb, const zkw_log_query* __rest
 // Batch form: workgroup b hashes the messages [msg_off[b], msg_off[b + 1]) into out + 32 b, its round records start at
 // rounds + round_off[b] (msg_off == nullptr: one queue of n messages). The queues of a batch run side by side — the chain of
 // one queue stays serial.
-static __device__ void k_linear_keccak256(const VB& vb, const zkw_log_query* __restrict__ q, size_t n, uint8_t* __restrict__ out,
+static __device__ __forceinline__ void k_linear_keccak256(const VB& vb, const zkw_log_query* __restrict__ q, size_t n, uint8_t* __restrict__ out,
                                                          zkw_keccak_round_record* __restrict__ rounds,
                                                          const u64* __restrict__ msg_off, const u64* __restrict__ round_off, bool blocks_ready) {
     const int t = threadIdx.x;

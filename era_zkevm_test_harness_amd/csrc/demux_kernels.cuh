@@ -37,7 +37,7 @@ struct DemuxRoute {
 };
 
 // queue offsets from the routes' totals (totals[7] = violations is zeroed by the caller and counted by k_demux_route)
-static __device__ void k_demux_offsets(const VB& vb, const u32* __restrict__ route_count /* [6][n] inclusive */, size_t n, u64* __restrict__ totals /* [8] */) {
+static __device__ __forceinline__ void k_demux_offsets(const VB& vb, const u32* __restrict__ route_count /* [6][n] inclusive */, size_t n, u64* __restrict__ totals /* [8] */) {
     if (threadIdx.x || vb.x) return;
     u64 acc = 0;
     for (int c = 0; c < 6; c++) { totals[c] = acc; acc += n ? route_count[(size_t)c * n + n - 1] : 0; }
@@ -46,7 +46,7 @@ static __device__ void k_demux_offsets(const VB& vb, const u32* __restrict__ rou
 
 // every item on its own, given the tiled inclusive counts per route: the scatter of the routed items and their encodings into
 // the six queues (stable: position = offset of the queue + items of the same route before it)
-static __device__ void k_demux_route(const VB& vb, const zkw_log_query* __restrict__ q, const u64* __restrict__ in_enc, size_t n,
+static __device__ __forceinline__ void k_demux_route(const VB& vb, const zkw_log_query* __restrict__ q, const u64* __restrict__ in_enc, size_t n,
                                                      zkw_demux_params params, const u32* __restrict__ route_count /* [6][n] inclusive */,
                                                      zkw_log_query* __restrict__ out_q, u64* __restrict__ out_enc,
                                                      u64* __restrict__ totals /* [8]: offsets[7], violations */) {
@@ -75,7 +75,7 @@ struct DemuxBlock {
     u32 capacity;
 };
 
-static __device__ void k_demux_instances(const VB& vb, const DemuxBlock* __restrict__ blk) {
+static __device__ __forceinline__ void k_demux_instances(const VB& vb, const DemuxBlock* __restrict__ blk) {
     const DemuxBlock b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;

@@ -37,7 +37,7 @@ struct EcJob {
 };
 
 // grid (cycles, jobs) x 128: input byte k of cycle c = value byte k % 32 (little end first) of read k / 32; zeros for an idle cycle
-static __device__ void k_ec_inputs(const VB& vb, const EcJob* __restrict__ jobs) {
+static __device__ __forceinline__ void k_ec_inputs(const VB& vb, const EcJob* __restrict__ jobs) {
     const EcJob j = jobs[vb.y];
     const u32 c = vb.x, k = threadIdx.x;
     u32 v = 0;
@@ -48,7 +48,7 @@ static __device__ void k_ec_inputs(const VB& vb, const EcJob* __restrict__ jobs)
 // grid (cycles / EC_TAPE_LANES, jobs): a lane per cycle; the workspace of the 256-bit arithmetic (every array with run-time indices) is
 // a slice of LDS per lane. status: atomicMax of 1 + (job << 16 | cycle) for a cycle whose inputs have no witness
 constexpr int EC_TAPE_LANES = 64;
-static __device__ void k_ec_tape(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status) {
+static __device__ __forceinline__ void k_ec_tape(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status) {
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
     const EcJob j = jobs[vb.y];
     const u32 c = vb.x * blockDim.x + threadIdx.x;
@@ -213,7 +213,7 @@ __device__ __forceinline__ ec_u256 ec_load_limbs(const u64* __restrict__ tape, c
 }
 
 // grid (cycles / EC_TAPE_LANES, jobs): a lane per cycle
-static __device__ void k_ec_chain(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
+static __device__ __forceinline__ void k_ec_chain(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
     __builtin_amdgcn_s_setprio(3);  // a request's accumulator chain is one lane and 13 ms of dependent instructions: its wave issues before whatever
                                     // shares the SIMD (another call's segment / stream kernels when two calls are in flight)
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
@@ -288,7 +288,7 @@ static __device__ void k_ec_chain(const VB& vb, const ec_spec* __restrict__ Sp, 
 
 // grid (segments after PRE = 289, lanes' chunks of the call's cycles): lane = one cycle of the call (job-major), block = one segment,
 // so that a wave runs ONE item list
-static __device__ void k_ec_segments(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, u32* status) {
+static __device__ __forceinline__ void k_ec_segments(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, u32* status) {
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
     const u32 lane = vb.y * blockDim.x + threadIdx.x;
     if (lane >= n_cycles) return;
@@ -309,7 +309,7 @@ static __device__ void k_ec_segments(const VB& vb, const ec_spec* __restrict__ S
 }
 
 // grid (cycles / 64, jobs): the netlist's inputs of a cycle from its tape
-static __device__ void k_ec_prepare(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity) {
+static __device__ __forceinline__ void k_ec_prepare(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity) {
     const EcJob j = jobs[vb.y];
     const u32 c = vb.x * blockDim.x + threadIdx.x;
     if (c > capacity) return;
@@ -343,7 +343,7 @@ static __device__ void k_ec_prepare(const VB& vb, const ec_spec* __restrict__ Sp
 #define EC_TR(col, row) trace[(size_t)(col) * n_rows + (size_t)(row)]
 
 // grid (rows of a cycle / 64, cycles, jobs): a lane per row
-static __device__ void k_ec_stream(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, u32 mult_col) {
+static __device__ __forceinline__ void k_ec_stream(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, u32 mult_col) {
     const EcJob j = jobs[vb.z];
     const u32 c = vb.y, r = vb.x * blockDim.x + threadIdx.x;
     if (r >= EC_ROWS_PER_CYCLE) return;

@@ -10,7 +10,7 @@
 
 namespace zkw {
 
-static __device__ void k_events_sort_keys(const VB& vb, const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ key,
+static __device__ __forceinline__ void k_events_sort_keys(const VB& vb, const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ key,
                                    u32* __restrict__ iota) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -36,7 +36,7 @@ __device__ __forceinline__ void store_enc20(u64* dst, const u64 e[20]) {
     for (int k = 0; k < 10; k++) o[k] = make_ulonglong2(e[2 * k], e[2 * k + 1]);
 }
 
-static __device__ void k_log_gather_encode(const VB& vb, const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
+static __device__ __forceinline__ void k_log_gather_encode(const VB& vb, const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
                                                            size_t n, zkw_log_query* __restrict__ sorted_q,
                                                            u64* __restrict__ sorted_enc) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
@@ -65,7 +65,7 @@ struct EventsKeptFlag {
 // every record on its own, given the tiled prefix count of the kept flags (prefix[k] = kept among [0, k)): the reference's asserts
 // (:344-356, :512-533), the inclusive count, and the compaction of the kept items into normalised result records (:541-553) with
 // their encodings. totals[1] (violations) is zeroed by the caller; the last record's thread writes totals[0] = n_result.
-static __device__ void k_events_dedup(const VB& vb, const zkw_log_query* __restrict__ sorted_q, size_t n, const u32* __restrict__ prefix,
+static __device__ __forceinline__ void k_events_dedup(const VB& vb, const zkw_log_query* __restrict__ sorted_q, size_t n, const u32* __restrict__ prefix,
                                                       u32* __restrict__ kept_count /* [n] inclusive */,
                                                       zkw_log_query* __restrict__ result_q, u64* __restrict__ result_enc,
                                                       u32* __restrict__ totals /* [2]: n_result, violations */) {
@@ -127,7 +127,7 @@ __device__ __forceinline__ void qs4(zkw_queue_state4& s, const u64* head, const 
     s._pad = 0;
 }
 
-static __device__ void k_events_instances(const VB& vb, const EventsBlock* __restrict__ blk) {
+static __device__ __forceinline__ void k_events_instances(const VB& vb, const EventsBlock* __restrict__ blk) {
     const EventsBlock& b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;

@@ -149,7 +149,7 @@ __device__ __forceinline__ void es_queue_op(u64* trace, size_t n_rows, size_t r1
 
 // WHICH 0 = unsorted pop (U1..U3), 1 = sorted pop (S1..S3), 2 = result push (R1..R3)
 template <int WHICH>
-static __device__ void k_es_fill_queue(const VB& vb, const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_es_fill_queue(const VB& vb, const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const EsSynthJob& job = jobs[vb.y];
     const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = ES_REGION_STRIDE(capacity);
@@ -188,7 +188,7 @@ static __device__ void k_es_fill_queue(const VB& vb, const EsSynthJob* __restric
 #define ES_XG(col, v) TR(col, row) = glob.v;
 
 template <int ROW>
-static __device__ void k_es_fill_row(const VB& vb, const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_es_fill_row(const VB& vb, const EsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -327,7 +327,7 @@ static __device__ void k_es_fill_row(const VB& vb, const EsSynthJob* __restrict_
 
 constexpr int ES_BOUNDARY_ROWS = (ES_NUM_ROW_TYPES - ES_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
 __device__ __forceinline__ void es_boundary_block(const EsSynthJob& job, u32 capacity, size_t n_rows);
-static __device__ void k_es_fill_tail(const VB& vb, const EsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_es_fill_tail(const VB& vb, const EsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
     // dependent permutations that the other blocks' stores hide), then (ES_G + ES_L + 1) * TAIL_CHUNKS blocks per trace
     if (vb.x < n_jobs) {

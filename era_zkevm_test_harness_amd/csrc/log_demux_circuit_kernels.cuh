@@ -98,7 +98,7 @@ __device__ __forceinline__ int ld_route(const LdSynthJob& job, const LdCycle& c)
 
 // WHICH 0 = pop of the input queue (I1..I3), 1 = the conditional push (P1..P3)
 template <int WHICH>
-static __device__ void k_ld_fill_queue(const VB& vb, const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ld_fill_queue(const VB& vb, const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const LdSynthJob& job = jobs[vb.y];
     const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = LD_REGION_STRIDE(capacity);
@@ -140,7 +140,7 @@ static __device__ void k_ld_fill_queue(const VB& vb, const LdSynthJob* __restric
 #define LD_QUEUES(M) M(st, 0) M(ev, 1) M(l1, 2) M(kc, 3) M(sh, 4) M(ec, 5)
 
 template <int ROW>
-static __device__ void k_ld_fill_row(const VB& vb, const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ld_fill_row(const VB& vb, const LdSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -229,7 +229,7 @@ static __device__ void k_ld_fill_row(const VB& vb, const LdSynthJob* __restrict_
 
 constexpr int LD_BOUNDARY_ROWS = (LD_NUM_ROW_TYPES - LD_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
 __device__ __forceinline__ void ld_boundary_block(const LdSynthJob& job, u32 capacity, size_t n_rows);
-static __device__ void k_ld_fill_tail(const VB& vb, const LdSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ld_fill_tail(const VB& vb, const LdSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
     // dependent permutations that the other blocks' stores hide), then (LD_G + LD_L + 1) * TAIL_CHUNKS blocks per trace
     if (vb.x < n_jobs) {

@@ -32,7 +32,7 @@ __device__ __forceinline__ void encode_log_query(const zkw_log_query& q, bool ha
     static_assert(ZKW_EXTENDED_TIMESTAMP_ENCODING_ELEMENT == 19, "extended timestamp rides in element 19");
 }
 
-static __device__ void k_encode_log(const VB& vb, const zkw_log_query* __restrict__ q, size_t n,
+static __device__ __forceinline__ void k_encode_log(const VB& vb, const zkw_log_query* __restrict__ q, size_t n,
                                                     const u32* __restrict__ ext_ts, u64* __restrict__ enc) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -57,7 +57,7 @@ __device__ __forceinline__ void encode_decommit_query(const zkw_decommit_query& 
     for (int k = 3; k < 8; k++) out[k] = d.hash[k];
 }
 
-static __device__ void k_encode_decommit(const VB& vb, const zkw_decommit_query* __restrict__ q, size_t n,
+static __device__ __forceinline__ void k_encode_decommit(const VB& vb, const zkw_decommit_query* __restrict__ q, size_t n,
                                                          u64* __restrict__ enc) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -77,7 +77,7 @@ static __device__ void k_encode_decommit(const VB& vb, const zkw_decommit_query*
 // started from the zero state. Only the THIRD round sees the previous tail, so rounds 1-2 of every item
 // are computed in parallel (k_log_prehash: one item per lane, keeps the 4 capacity words) and the serial
 // chain is one permutation per item (k_chain_log, one chain per 16-lane DPP row).
-static __device__ void k_log_prehash(const VB& vb, const u64* __restrict__ enc /* [n][20] */, size_t n,
+static __device__ __forceinline__ void k_log_prehash(const VB& vb, const u64* __restrict__ enc /* [n][20] */, size_t n,
                                                      u64* __restrict__ pre /* [n][4] */) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -27,7 +27,7 @@ struct NlcfJob { u64* trace; u64 index; };  // the slot; the instance's index in
 #define NLCF_P(perm, v) NLCF_TR((v) % G, c0 + nlcf_perm_row0(&d, G, (perm)) + (v) / G)
 
 template <class T>
-static __device__ void k_nlcf_sponges(const VB& vb, nlcf_desc d, const typename T::Inst* __restrict__ inst, const NlcfJob* __restrict__ jobs, u32 G,
+static __device__ __forceinline__ void k_nlcf_sponges(const VB& vb, const nlcf_desc& d, const typename T::Inst* __restrict__ inst, const NlcfJob* __restrict__ jobs, u32 G,
                                                              size_t n_rows, u64 c0) {
     const NlcfJob job = jobs[vb.x];
     u64* __restrict__ trace = job.trace;
@@ -134,7 +134,7 @@ __device__ __forceinline__ u64 nlcf_side(const nlcf_desc& d, const u64* __restri
 }
 
 // grid (tie cells / 256, instances)
-static __device__ void k_nlcf_ties(const VB& vb, nlcf_desc d, nlq_desc qd, const NlDev* __restrict__ devp, const NlcfJob* __restrict__ jobs, u32 cycles,
+static __device__ __forceinline__ void k_nlcf_ties(const VB& vb, const nlcf_desc& d, const nlq_desc& qd, const NlDev* __restrict__ devp, const NlcfJob* __restrict__ jobs, u32 cycles,
                                                           size_t n_rows, u64 c0) {
     const nl_spec& S = devp->s;
     const u32 G = S.g;

@@ -170,7 +170,7 @@ __device__ __forceinline__ void nl_eval_sel(u32 fn, u32 k, u32 a0, u32 a1, u32 a
 // 3.35 ms per 8 SHA-256 instances. The walk is bound by the latency of its dependent LDS reads, which two waves per SIMD hide
 // from each other and one wave per SIMD does not; CPW below is what is left of that experiment.)
 template <int W, int R, int WAVES>
-static __device__ void k_nl_fill(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
+static __device__ __forceinline__ void k_nl_fill(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows, u32 probe) {
     constexpr int CPW = 1, NL_FILL_WAVES = WAVES, NL_FILL_THREADS = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr u32 LW = 64 / CPW;                             // lanes that share a cycle
@@ -442,7 +442,7 @@ __device__ __forceinline__ u32 nl_walk_get(const uint8_t* lds, u32 src, u32 o_va
 }
 
 template <int W, int R>
-static __device__ void k_nl_walk(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity,
+static __device__ __forceinline__ void k_nl_walk(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity,
                                                        uint8_t* __restrict__ scratch, size_t scratch_per_job, const u32* __restrict__ prog_g,
                                                        const u32* __restrict__ prog0, const uint16_t* __restrict__ out_src_g) {
     // the constant address space: never clobbered, so a uniform index is a scalar load whatever the loop stores
@@ -567,7 +567,7 @@ static __device__ void k_nl_walk(const VB& vb, const NlDev* __restrict__ devp, c
 // rows of the cycle; the others: a lookup slot (W columns + its keys) x 64 rows. 64 x 64 bytes of the scratch tile per column
 // through LDS (row pitch 68 bytes: lanes read one byte each at distinct banks), then per cycle one 512-byte store per column.
 template <int W, int R>
-static __device__ void k_nl_expand(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows,
+static __device__ __forceinline__ void k_nl_expand(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows,
                                                          const uint8_t* __restrict__ scratch, size_t scratch_per_job) {
     __shared__ __attribute__((aligned(16))) uint8_t tileb[W][64 * 68];
     const NlDev& D = *devp;
@@ -624,7 +624,7 @@ static __device__ void k_nl_expand(const VB& vb, const NlDev* __restrict__ devp,
 constexpr int NL_HIST_THREADS = 1024;
 constexpr int NL_HIST_HALF = 32768;
 template <int R>
-static __device__ void k_nl_hist(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_nl_hist(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
     const NlJob job = jobs[vb.z];
@@ -694,7 +694,7 @@ static __device__ void k_nl_hist(const VB& vb, const NlDev* __restrict__ devp, c
 }
 
 // the multiplicity column (sum of a table's slices), boundary rows (BND_IN, BND_OUT) and the public input row
-static __device__ void k_nl_finish(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_nl_finish(const VB& vb, const NlDev* __restrict__ devp, const NlJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const NlDev& D = *devp;
     const nl_spec& S = D.s;
     const NlJob job = jobs[vb.y];
@@ -718,7 +718,7 @@ static __device__ void k_nl_finish(const VB& vb, const NlDev* __restrict__ devp,
 
 // ---- round records -> the engine's inputs. SHA-like: 64-byte blocks, state 8 words as 64 nibbles; Keccak-like: 136 / 200 bytes
 struct NlPrepJob { const void* rounds; u64 first_round; u32 n_active; uint8_t* hdr_bits; uint8_t* free_elems; uint8_t* state_before; u32 state; /* elements of a cycle state (SHA-256: 64 nibbles of the chaining value, then zeros) */ };
-static __device__ void k_nl_prepare_sha(const VB& vb, const NlPrepJob* __restrict__ jobs, u32 capacity) {
+static __device__ __forceinline__ void k_nl_prepare_sha(const VB& vb, const NlPrepJob* __restrict__ jobs, u32 capacity) {
     const NlPrepJob j = jobs[vb.y];
     const zkw_sha256_round_record* rounds = static_cast<const zkw_sha256_round_record*>(j.rounds);
     const u32 c = vb.x, t = threadIdx.x;  // c in [0, capacity]: the state BEFORE cycle c
@@ -731,7 +731,7 @@ static __device__ void k_nl_prepare_sha(const VB& vb, const NlPrepJob* __restric
     j.free_elems[(size_t)c * 128 + t] = (uint8_t)((t & 1) ? b >> 4 : b & 15);
     if (t == 0) j.hdr_bits[c] = active ? (rounds[j.first_round + c].reset ? 1 : 0) : 2;
 }
-static __device__ void k_nl_prepare_keccak(const VB& vb, const NlPrepJob* __restrict__ jobs, u32 capacity) {
+static __device__ __forceinline__ void k_nl_prepare_keccak(const VB& vb, const NlPrepJob* __restrict__ jobs, u32 capacity) {
     const NlPrepJob j = jobs[vb.y];
     const zkw_keccak_round_record* rounds = static_cast<const zkw_keccak_round_record*>(j.rounds);
     const u32 c = vb.x, t = threadIdx.x;

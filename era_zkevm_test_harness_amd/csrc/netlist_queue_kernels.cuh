@@ -24,7 +24,7 @@ struct NlqFreeHome { uint16_t row, col; };  // the one cell of a cycle that hold
 #define NLQ_TR(col, row) trace[(size_t)(col) * n_rows + (size_t)(row)]
 
 // feed of a cycle from the builder's per-round record (the oracle walks the rounds instead: orc_sha256_queue_feed)
-static __device__ void k_nlq_feed(const VB& vb, int circuit_type, const NlqFeedJob* __restrict__ jobs, u32 capacity, u32 n_ops) {
+static __device__ __forceinline__ void k_nlq_feed(const VB& vb, int circuit_type, const NlqFeedJob* __restrict__ jobs, u32 capacity, u32 n_ops) {
     const NlqFeedJob j = jobs[vb.y];
     const u32 c = vb.x * blockDim.x + threadIdx.x;
     if (c >= capacity) return;
@@ -105,7 +105,7 @@ __device__ __forceinline__ u64 nlq_coop_p2(const p2::Coop& co, u64 x, u32 g, Put
 // Lane g computes what it needs itself — its cells of the ENC block (stride 16), the encoding elements its permutation inputs take —
 // from the item record / the linked netlist cells; only the permutation crosses lanes. (The first version gave an operation to a LANE:
 // its three dependent lane-serial permutations of ~65 us each were the whole kernel time.)
-static __device__ void k_nlq_fill(const VB& vb, const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, const NlqFreeHome* __restrict__ lh, nlq_desc d, const NlqJob* __restrict__ jobs,
+static __device__ __forceinline__ void k_nlq_fill(const VB& vb, const NlDev* __restrict__ devp, const NlqFreeHome* __restrict__ fh, const NlqFreeHome* __restrict__ lh, const nlq_desc& d, const NlqJob* __restrict__ jobs,
                                                         u32 capacity, size_t n_rows) {
     const nl_spec& S = devp->s;
     const NlqJob& job = jobs[vb.z];

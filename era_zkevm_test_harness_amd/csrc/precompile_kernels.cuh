@@ -87,7 +87,7 @@ __device__ __forceinline__ void word_be_bytes(const u32* limbs, uint8_t out[32])
 }
 
 // one lane per request
-static __device__ void k_precompile_walk(const VB& vb, PrecompileJob job) {
+static __device__ __forceinline__ void k_precompile_walk(const VB& vb, PrecompileJob job) {
     const u64 r = (u64)vb.x * blockDim.x + threadIdx.x;
     if (r >= job.n_requests) return;
     const zkw_log_query request = job.requests[r];
@@ -267,7 +267,7 @@ struct PrecompileBlock {
     u32 capacity;
 };
 
-static __device__ void k_precompile_instances(const VB& vb, const PrecompileBlock* __restrict__ blk) {
+static __device__ __forceinline__ void k_precompile_instances(const VB& vb, const PrecompileBlock* __restrict__ blk) {
     const PrecompileBlock& b = *blk;
     const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;
     if (idx >= b.n_instances) return;

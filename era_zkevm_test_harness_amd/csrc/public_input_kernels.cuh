@@ -38,7 +38,7 @@ __device__ inline void commit_var_length(const u64* enc, int n, u64 out[4]) {
     for (int k = 0; k < 4; k++) out[k] = gl::canon(s[k]);
 }
 
-static __device__ void k_commit_encodings(const VB& vb, const u64* __restrict__ enc, size_t n_items, u32 item_len,
+static __device__ __forceinline__ void k_commit_encodings(const VB& vb, const u64* __restrict__ enc, size_t n_items, u32 item_len,
                                                          u64* __restrict__ out) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
@@ -69,7 +69,7 @@ __device__ inline int ram_encode_fsm(const zkw_ram_fsm& f, u64* o) {
 
 // lane = 4 * instance + part; part 0: observable input of the block's FIRST instance, 1: flags + empty output,
 // 2: hidden FSM input, 3: hidden FSM output
-static __device__ void k_ram_commitments(const VB& vb, const zkw_ram_instance* __restrict__ inst, size_t n,
+static __device__ __forceinline__ void k_ram_commitments(const VB& vb, const zkw_ram_instance* __restrict__ inst, size_t n,
                                                         u64* __restrict__ compact) {
     const size_t t = (size_t)vb.x * blockDim.x + threadIdx.x;
     const size_t i = t >> 2;
@@ -116,7 +116,7 @@ __device__ inline int ds_encode_fsm(const zkw_decommit_sorter_fsm& f, u64* o) {
     o[m++] = f.first_encountered_timestamp;
     return m;
 }
-static __device__ void k_ds_commitments(const VB& vb, const zkw_decommit_sorter_instance* __restrict__ inst, size_t n,
+static __device__ __forceinline__ void k_ds_commitments(const VB& vb, const zkw_decommit_sorter_instance* __restrict__ inst, size_t n,
                                                        u64* __restrict__ compact) {
     const size_t t = (size_t)vb.x * blockDim.x + threadIdx.x;
     const size_t i = t >> 2;
@@ -365,7 +365,7 @@ struct CfLinearHasher {
 // on (docs/KERNELS.md 3.14); the row form is ~3 x shorter.
 template <class T> struct CfLanes { static constexpr int value = 64; };
 template <class T>
-static __device__ void k_closed_form_commitments(const VB& vb, const typename T::Inst* __restrict__ inst, size_t n, u64* __restrict__ compact) {
+static __device__ __forceinline__ void k_closed_form_commitments(const VB& vb, const typename T::Inst* __restrict__ inst, size_t n, u64* __restrict__ compact) {
     const size_t i = vb.x;
     if (i >= n) return;
     __shared__ u64 sh_buf[4][T::MAXLEN];
@@ -407,7 +407,7 @@ static __device__ void k_closed_form_commitments(const VB& vb, const typename T:
     if (g < 4) cf[at + g] = gl::canon(x);  // (an empty encoding: no permutation, the zero state's first words)
 }
 
-static __device__ void k_encode_recursion(const VB& vb, u64 circuit_type, const u64* __restrict__ pi, size_t n,
+static __device__ __forceinline__ void k_encode_recursion(const VB& vb, u64 circuit_type, const u64* __restrict__ pi, size_t n,
                                                          u64* __restrict__ enc) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

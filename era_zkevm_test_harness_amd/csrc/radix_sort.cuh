@@ -23,7 +23,7 @@ template <class K>
 static __device__ __forceinline__ unsigned rs_digit(K key, unsigned shift, unsigned mask) { return (unsigned)(key >> shift) & mask; }
 
 template <class K>
-static __device__ void k_rs_hist(const VB& vb, const K* __restrict__ keys, size_t n, unsigned shift, unsigned mask, u32* __restrict__ hist, u32 n_tiles) {
+static __device__ __forceinline__ void k_rs_hist(const VB& vb, const K* __restrict__ keys, size_t n, unsigned shift, unsigned mask, u32* __restrict__ hist, u32 n_tiles) {
     __shared__ u32 cnt[256];
     const int t = threadIdx.x;
     cnt[t] = 0;
@@ -39,7 +39,7 @@ static __device__ void k_rs_hist(const VB& vb, const K* __restrict__ keys, size_
 }
 
 // in place: hist[i] <- exclusive prefix inside its chunk; chunk_tot[c] <- the chunk's total. 1024 threads x 16 entries.
-static __device__ void k_rs_scan_a(const VB& vb, u32* __restrict__ hist, size_t n_entries, u32* __restrict__ chunk_tot) {
+static __device__ __forceinline__ void k_rs_scan_a(const VB& vb, u32* __restrict__ hist, size_t n_entries, u32* __restrict__ chunk_tot) {
     __shared__ u32 s_wave[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t base = (size_t)vb.x * RS_CHUNK + (size_t)t * 16;
@@ -69,7 +69,7 @@ static __device__ void k_rs_scan_a(const VB& vb, u32* __restrict__ hist, size_t 
 }
 
 // exclusive scan of the chunk totals in place (one workgroup of 1024, any count)
-static __device__ void k_rs_scan_b(const VB& vb, u32* __restrict__ chunk_tot, u32 n_chunks) {
+static __device__ __forceinline__ void k_rs_scan_b(const VB& vb, u32* __restrict__ chunk_tot, u32 n_chunks) {
     __shared__ u32 s_wave[16];
     __shared__ u32 carry;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -96,14 +96,22 @@ static __device__ void k_rs_scan_b(const VB& vb, u32* __restrict__ chunk_tot, u3
 }
 
 template <class K>
-static __device__ void k_rs_scatter(const VB& vb, const K* __restrict__ kin, const u32* __restrict__ vin, size_t n, unsigned shift, unsigned mask,
+static __device__ __forceinline__ void k_rs_scatter(const VB& vb, const K* __restrict__ kin, const u32* __restrict__ vin, size_t n, unsigned shift, unsigned mask,
                                     const u32* __restrict__ hist, const u32* __restrict__ chunk_off, u32 n_tiles, K* __restrict__ kout, u32* __restrict__ vout) {
-    __shared__ u32 wcnt[RS_WAVES][256];  // phase A: a wave's digit counts; phase B: the next free place of (wave, digit)
+    // The tile is sorted by digit in LDS first and written out in that order: a digit's keys of the tile are then consecutive lanes'
+    // consecutive addresses. Writing every pair straight to its place (the first form of this kernel) ran a pass over random digits at
+    // 0.8 TB/s — 8- and 4-byte stores scattered over 256 runs per tile — against 3.9 TB/s when all digits were equal.
+    __shared__ K s_key[RS_TILE];
+    __shared__ u32 s_val[RS_TILE];
+    __shared__ u32 wcnt[RS_WAVES][256];  // phase A: a wave's digit counts; phase B: the next free place (in the tile) of (wave, digit)
+    __shared__ u32 s_first[256];         // where digit d's run starts in the sorted tile
+    __shared__ u32 s_gbase[256];         // global place of the run's first pair minus s_first[d]
+    __shared__ u32 s_wsum[RS_WAVES];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
     for (int w = 0; w < RS_WAVES; w++) wcnt[w][t] = 0;
     __syncthreads();
-    const size_t base = (size_t)vb.x * RS_TILE + (size_t)wave * (RS_ROUNDS * 64) + lane;
+    const size_t tile0 = (size_t)vb.x * RS_TILE, base = tile0 + (size_t)wave * (RS_ROUNDS * 64) + lane;
     K key[RS_ROUNDS];
     unsigned long long same[RS_ROUNDS];  // the lanes of this wave whose key of the round has the same digit
 #pragma unroll
@@ -124,15 +132,26 @@ static __device__ void k_rs_scatter(const VB& vb, const K* __restrict__ kin, con
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {  // digit t: where each wave's keys of that digit start
-        const size_t e = (size_t)t * n_tiles + vb.x;
-        u32 at = hist[e] + chunk_off[e / RS_CHUNK];
+    {  // digit t: its run in the sorted tile (exclusive scan of the tile's digit counts), where each wave's keys of it go, where the run goes globally
+        u32 c[RS_WAVES], total = 0;
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; w++) {
-            const u32 c = wcnt[w][t];
-            wcnt[w][t] = at;
-            at += c;
+        for (int w = 0; w < RS_WAVES; w++) { c[w] = wcnt[w][t]; total += c[w]; }
+        u32 incl = total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 y = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += y;
         }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        u32 first = incl - total;
+        for (int w = 0; w < wave; w++) first += s_wsum[w];
+        s_first[t] = first;
+        const size_t e = (size_t)t * n_tiles + vb.x;
+        s_gbase[t] = hist[e] + chunk_off[e / RS_CHUNK] - first;
+        u32 at = first;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) { wcnt[w][t] = at; at += c[w]; }
     }
     __syncthreads();
 #pragma unroll
@@ -142,12 +161,21 @@ static __device__ void k_rs_scatter(const VB& vb, const K* __restrict__ kin, con
         if (m) {
             const unsigned d = rs_digit(key[r], shift, mask);
             const u32 at = wcnt[wave][d] + (u32)__popcll(m & ((1ull << lane) - 1));
-            kout[at] = key[r];
-            vout[at] = vin[i];
+            s_key[at] = key[r];
+            s_val[at] = vin[i];
         }
         __builtin_amdgcn_wave_barrier();
         if (m && (m & ((1ull << lane) - 1)) == 0) wcnt[wave][rs_digit(key[r], shift, mask)] += (u32)__popcll(m);
         __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    const u32 in_tile = (u32)(n - tile0 < (size_t)RS_TILE ? n - tile0 : (size_t)RS_TILE);
+#pragma unroll 4
+    for (u32 p = t; p < in_tile; p += 256) {
+        const K k = s_key[p];
+        const u32 at = s_gbase[rs_digit(k, shift, mask)] + p;
+        kout[at] = k;
+        vout[at] = s_val[p];
     }
 }
 

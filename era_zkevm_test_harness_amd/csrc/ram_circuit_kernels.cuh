@@ -128,7 +128,7 @@ __device__ __forceinline__ void fill_flattened_poseidon(u64* trace, size_t n_row
 // Poseidon2 rows (regions PU and PS): one lane per cycle runs the permutation and stores all 130
 // flattened-gate variables as it goes. SIDE 0 = unsorted queue, 1 = sorted queue.
 template <int SIDE>
-static __device__ void k_ram_fill_poseidon(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity,
+static __device__ __forceinline__ void k_ram_fill_poseidon(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity,
                                                           size_t n_rows) {
     __shared__ u32 sh_hist[256];
     for (int t = threadIdx.x; t < 256; t += blockDim.x) sh_hist[t] = 0;
@@ -230,7 +230,7 @@ __device__ __forceinline__ u64 acc_before(const u64* z, size_t first, size_t m, 
     return i == 0 ? fsm_in : z[first + (i - 1 < m ? i - 1 : m - 1)];
 }
 
-static __device__ void k_ram_fill_A(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ram_fill_A(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -285,7 +285,7 @@ static __device__ void k_ram_fill_A(const VB& vb, const SynthJob* __restrict__ j
     hist_flush(sh_hist, job.hist);
 }
 
-static __device__ void k_ram_fill_B(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ram_fill_B(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -323,7 +323,7 @@ __device__ __forceinline__ bool nd_flag(bool can_pop, const zkw_mem_query& q) {
 }
 
 // per 256-cycle tile: number of nondeterministic writes; then an exclusive scan per instance
-static __device__ void k_ram_nd_tiles(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity) {
+static __device__ __forceinline__ void k_ram_nd_tiles(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity) {
     __shared__ u32 sh[4];
     const SynthJob job = jobs[vb.y];
     const u32 i = vb.x * blockDim.x + threadIdx.x;
@@ -339,7 +339,7 @@ static __device__ void k_ram_nd_tiles(const VB& vb, const SynthJob* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) job.nd_tiles[vb.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-static __device__ void k_ram_nd_scan(const VB& vb, const SynthJob* __restrict__ jobs, int n_jobs, u32 n_tiles) {
+static __device__ __forceinline__ void k_ram_nd_scan(const VB& vb, const SynthJob* __restrict__ jobs, int n_jobs, u32 n_tiles) {
     // one wave per job: exclusive prefix over the tile counts, 64 tiles at a time
     u32* t = jobs[vb.x].nd_tiles;
     const int lane = threadIdx.x;
@@ -357,7 +357,7 @@ static __device__ void k_ram_nd_scan(const VB& vb, const SynthJob* __restrict__ 
     }
 }
 
-static __device__ void k_ram_fill_C(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ram_fill_C(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     __shared__ u32 sh_wave[4];
     sh_hist[threadIdx.x] = 0;
@@ -458,7 +458,7 @@ static __device__ void k_ram_fill_C(const VB& vb, const SynthJob* __restrict__ j
 // it (it reads the last cycle's row C, an earlier kernel; nothing of row D); then n_tiles blocks of 256 cycles per trace.
 __device__ __forceinline__ void ram_boundary_block(const SynthJob& job, u32 capacity, size_t n_rows);
 constexpr int RC_D_TILES = 4;  // tiles of 256 cycles per row-D block
-static __device__ void k_ram_fill_D(const VB& vb, const SynthJob* __restrict__ jobs, u32 n_jobs, u32 n_tiles, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ram_fill_D(const VB& vb, const SynthJob* __restrict__ jobs, u32 n_jobs, u32 n_tiles, u32 capacity, size_t n_rows) {
     if (vb.x < n_jobs) {
         __builtin_amdgcn_s_setprio(3);
         ram_boundary_block(jobs[vb.x], capacity, n_rows);
@@ -531,7 +531,7 @@ constexpr int TAIL_CHUNKS = 8;
 constexpr int RC_BOUNDARY_ROWS = RC_NUM_ROW_TYPES - RC_ROWS_PER_CYCLE;  // register rows, PI, the closed-form section
 constexpr int RC_CF_LOOKUP_CELLS = 24;                                   // VIN / VOUT byte cells (counted in job.hist by k_ram_fill_C)
 static_assert(RC_BOUNDARY_ROWS % 2 == 0, "the tail's 16-byte stores start below the boundary rows");
-static __device__ void k_ram_fill_tail(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ram_fill_tail(const VB& vb, const SynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: (RC_G + RC_L + 1) * TAIL_CHUNKS blocks per trace (the boundary rows above the zero padding are k_ram_fill_D's first blocks)
     constexpr u32 PER_JOB = (RC_G + RC_L + 1) * TAIL_CHUNKS;
     const u32 bid = vb.x % PER_JOB;

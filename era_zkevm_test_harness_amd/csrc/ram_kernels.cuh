@@ -33,7 +33,7 @@ __device__ __forceinline__ void encode_mem_query(const zkw_mem_query& q, u64 out
     out[7] = v[4];
 }
 
-static __device__ void k_encode_mem(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n,
+static __device__ __forceinline__ void k_encode_mem(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n,
                                                     u64* __restrict__ enc) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)vb.nx * blockDim.x;
@@ -432,7 +432,7 @@ struct FsJob {
 // No per-lane arrays with run-time indices: they would live in scratch memory, and every HSA queue that ever ran the
 // kernel keeps scratch-per-lane x every wave slot of the chip (117 MB for 224 B per lane) out of the runtime's 4 GB
 // scratch aperture; with 32 hardware queues in use that exhausted it (HSA_STATUS_ERROR_OUT_OF_RESOURCES).
-static __device__ void k_fs_challenges(const VB& vb, const FsJob* __restrict__ jobs, int n_jobs, int state_w, int n_chal) {
+static __device__ __forceinline__ void k_fs_challenges(const VB& vb, const FsJob* __restrict__ jobs, int n_jobs, int state_w, int n_chal) {
     int j = vb.x * blockDim.x + threadIdx.x;
     if (j >= n_jobs) return;
     const FsJob job = jobs[j];
@@ -503,7 +503,7 @@ __device__ __forceinline__ u64 wave_scan_mul(u64 v, int lane) {
 }
 
 template <int W, int REPS>
-static __device__ void k_gp_local(const VB& vb, const GpSeg* __restrict__ segs,
+static __device__ __forceinline__ void k_gp_local(const VB& vb, const GpSeg* __restrict__ segs,
                                                        const GpTile* __restrict__ tiles,
                                                        u64* __restrict__ tile_aggr /* [n_tiles_total][REPS] */) {
     __shared__ u64 sh_ch[REPS][W + 1];
@@ -566,7 +566,7 @@ static __device__ void k_gp_local(const VB& vb, const GpSeg* __restrict__ segs,
 
 // exclusive scan of the tile aggregates inside each segment: one lane per (segment, repetition)
 template <int REPS>
-static __device__ void k_gp_tiles(const VB& vb, const GpSeg* __restrict__ segs, int n_segs, u64* __restrict__ tile_aggr) {
+static __device__ __forceinline__ void k_gp_tiles(const VB& vb, const GpSeg* __restrict__ segs, int n_segs, u64* __restrict__ tile_aggr) {
     int j = vb.x * blockDim.x + threadIdx.x;
     if (j >= n_segs * REPS) return;
     const GpSeg seg = segs[j / REPS];
@@ -581,7 +581,7 @@ static __device__ void k_gp_tiles(const VB& vb, const GpSeg* __restrict__ segs, 
 }
 
 template <int REPS>
-static __device__ void k_gp_apply(const VB& vb, const GpSeg* __restrict__ segs,
+static __device__ __forceinline__ void k_gp_apply(const VB& vb, const GpSeg* __restrict__ segs,
                                                        const GpTile* __restrict__ tiles,
                                                        const u64* __restrict__ tile_prefix) {
     const GpTile t = tiles[vb.x];
@@ -601,7 +601,7 @@ static __device__ void k_gp_apply(const VB& vb, const GpSeg* __restrict__ segs,
 // ------------------------------------------------------------------------------------------------
 // K7 support: sort keys and the gather that applies the sorting permutation.
 // Sorting order (W/ram_permutation.rs:50-53): (page, index) then timestamp, stable.
-static __device__ void k_ram_sort_keys(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ ts,
+static __device__ __forceinline__ void k_ram_sort_keys(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ ts,
                                 u64* __restrict__ cell, u32* __restrict__ iota, const u64* __restrict__ seg_off,
                                 int n_segs) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
@@ -612,13 +612,13 @@ static __device__ void k_ram_sort_keys(const VB& vb, const zkw_mem_query* __rest
     (void)seg_off; (void)n_segs;
 }
 
-static __device__ void k_gather_u32_by_u32(const VB& vb, const u32* __restrict__ src, const u32* __restrict__ idx, size_t n,
+static __device__ __forceinline__ void k_gather_u32_by_u32(const VB& vb, const u32* __restrict__ src, const u32* __restrict__ idx, size_t n,
                                     u32* __restrict__ dst) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
 }
 
-static __device__ void k_gather_u64_by_u32(const VB& vb, const u64* __restrict__ src, const u32* __restrict__ idx, size_t n,
+static __device__ __forceinline__ void k_gather_u64_by_u32(const VB& vb, const u64* __restrict__ src, const u32* __restrict__ idx, size_t n,
                                     u64* __restrict__ dst) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
@@ -626,7 +626,7 @@ static __device__ void k_gather_u64_by_u32(const VB& vb, const u64* __restrict__
 
 // sorted_q[i] = q[perm[i]] and its encoding in the same pass (the sorted side never needs the
 // un-encoded query again except for the FSM snapshots, which read sorted_q).
-static __device__ void k_gather_encode(const VB& vb, const zkw_mem_query* __restrict__ q,
+static __device__ __forceinline__ void k_gather_encode(const VB& vb, const zkw_mem_query* __restrict__ q,
                                                        const u32* __restrict__ perm, size_t n,
                                                        zkw_mem_query* __restrict__ sorted_q,
                                                        u64* __restrict__ sorted_enc) {
@@ -670,7 +670,7 @@ __device__ __forceinline__ void copy12(u64* dst, const u64* src) {
 }
 
 // pass 1: count nondeterministic writes per chunk (rw && ts == 0 && page == BOOTLOADER_HEAP_PAGE)
-static __device__ void k_ram_count_nondet(const VB& vb, const RamBlock* __restrict__ blocks) {
+static __device__ __forceinline__ void k_ram_count_nondet(const VB& vb, const RamBlock* __restrict__ blocks) {
     const RamBlock b = blocks[vb.y];
     const u64 n_inst = (b.n + b.capacity - 1) / b.capacity;
     __shared__ u32 sh[4];
@@ -690,7 +690,7 @@ static __device__ void k_ram_count_nondet(const VB& vb, const RamBlock* __restri
 }
 
 // pass 2: one lane per instance
-static __device__ void k_ram_instances(const VB& vb, const RamBlock* __restrict__ blocks) {
+static __device__ __forceinline__ void k_ram_instances(const VB& vb, const RamBlock* __restrict__ blocks) {
     const RamBlock b = blocks[vb.y];
     const u64 n_inst = (b.n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;
@@ -749,7 +749,7 @@ static __device__ void k_ram_instances(const VB& vb, const RamBlock* __restrict_
 // ------------------------------------------------------------------------------------------------
 // Full tails on demand: tails[i] = permute(enc[i] || caps[i-1]) (zero capacity at the first item of a queue).
 // One item per lane; offsets[] are the queue boundaries inside the batch.
-static __device__ void k_tails_expand(const VB& vb, const u64* __restrict__ enc, const u64* __restrict__ caps,
+static __device__ __forceinline__ void k_tails_expand(const VB& vb, const u64* __restrict__ enc, const u64* __restrict__ caps,
                                                      const u64* __restrict__ offsets, int n_queues, size_t n,
                                                      u64* __restrict__ tails) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;

@@ -9,7 +9,7 @@ namespace zkw {
 constexpr int FLAG_PREFIX_TILE = 1024;
 
 template <class Flag>
-static __device__ void k_flag_prefix_tiles(const VB& vb, Flag flag, size_t n, u32* __restrict__ prefix, u32* __restrict__ tile_sums) {
+static __device__ __forceinline__ void k_flag_prefix_tiles(const VB& vb, Flag flag, size_t n, u32* __restrict__ prefix, u32* __restrict__ tile_sums) {
     __shared__ u32 s_wave[FLAG_PREFIX_TILE / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t i = (size_t)vb.x * FLAG_PREFIX_TILE + t;
@@ -26,7 +26,7 @@ static __device__ void k_flag_prefix_tiles(const VB& vb, Flag flag, size_t n, u3
 }
 
 // exclusive scan of the tile totals in place: one workgroup, n_tiles = n / 1024 elements
-static __device__ void k_flag_prefix_offsets(const VB& vb, u32* __restrict__ tile_sums, u32 n_tiles) {
+static __device__ __forceinline__ void k_flag_prefix_offsets(const VB& vb, u32* __restrict__ tile_sums, u32 n_tiles) {
     __shared__ u32 s[1024];
     __shared__ u32 carry;
     const int t = threadIdx.x;
@@ -50,7 +50,7 @@ static __device__ void k_flag_prefix_offsets(const VB& vb, u32* __restrict__ til
     }
 }
 
-static __device__ void k_flag_prefix_apply(const VB& vb, u32* __restrict__ prefix, const u32* __restrict__ tile_offsets, size_t n) {
+static __device__ __forceinline__ void k_flag_prefix_apply(const VB& vb, u32* __restrict__ prefix, const u32* __restrict__ tile_offsets, size_t n) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n) prefix[i + 1] += tile_offsets[i / FLAG_PREFIX_TILE];
 }
@@ -76,7 +76,7 @@ static int flag_prefix(zkw_ctx* ctx, const char* name, Flag flag, size_t n, u32*
 // ---- K routes at once: route(i) in [-1, K); count[c][i] = #{ j <= i : route(j) == c } (inclusive), totals[c] = count[c][n - 1].
 // The same three launches with K counters side by side (the log demuxer's six stable compactions).
 template <int K, class Route>
-static __device__ void k_route_prefix_tiles(const VB& vb, Route route, size_t n, u32* __restrict__ count /* [K][n] */, u32* __restrict__ tile_sums /* [K][n_tiles] */) {
+static __device__ __forceinline__ void k_route_prefix_tiles(const VB& vb, Route route, size_t n, u32* __restrict__ count /* [K][n] */, u32* __restrict__ tile_sums /* [K][n_tiles] */) {
     __shared__ u32 s_wave[K][FLAG_PREFIX_TILE / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t i = (size_t)vb.x * FLAG_PREFIX_TILE + t;
@@ -98,7 +98,7 @@ static __device__ void k_route_prefix_tiles(const VB& vb, Route route, size_t n,
     }
 }
 template <int K>
-static __device__ void k_route_prefix_apply(const VB& vb, u32* __restrict__ count, const u32* __restrict__ tile_offsets, size_t n, u32 n_tiles) {
+static __device__ __forceinline__ void k_route_prefix_apply(const VB& vb, u32* __restrict__ count, const u32* __restrict__ tile_offsets, size_t n, u32 n_tiles) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
 #pragma unroll
@@ -125,7 +125,7 @@ static int route_prefix(zkw_ctx* ctx, const char* name, Route route, size_t n, u
 // totals[c] = the sum over all items. val(i, v) fills v[0..K). The same three launches; replaces the single-workgroup sweeps of
 // k_precompile_counts (rounds / queries / reads per request) and k_stack_depth (depth, push rank).
 template <int K, class Val>
-static __device__ void k_sum_prefix_tiles(const VB& vb, Val val, size_t n, u64* __restrict__ out /* [K][n + 1] */, u64* __restrict__ tile_sums /* [K][n_tiles] */) {
+static __device__ __forceinline__ void k_sum_prefix_tiles(const VB& vb, Val val, size_t n, u64* __restrict__ out /* [K][n + 1] */, u64* __restrict__ tile_sums /* [K][n_tiles] */) {
     __shared__ u64 s_wave[K][FLAG_PREFIX_TILE / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t i = (size_t)vb.x * FLAG_PREFIX_TILE + t;
@@ -154,7 +154,7 @@ static __device__ void k_sum_prefix_tiles(const VB& vb, Val val, size_t n, u64* 
     }
 }
 // exclusive scan of one sum's tile totals in place (one workgroup), its grand total to *total and to out_last (= out[c][n])
-static __device__ void k_sum_prefix_offsets(const VB& vb, u64* __restrict__ tile_sums, u32 n_tiles, u64* __restrict__ total, u64* __restrict__ out_last) {
+static __device__ __forceinline__ void k_sum_prefix_offsets(const VB& vb, u64* __restrict__ tile_sums, u32 n_tiles, u64* __restrict__ total, u64* __restrict__ out_last) {
     __shared__ u64 s[1024];
     __shared__ u64 carry;
     const int t = threadIdx.x;
@@ -179,7 +179,7 @@ static __device__ void k_sum_prefix_offsets(const VB& vb, u64* __restrict__ tile
     if (t == 0) { *total = carry; *out_last = carry; }
 }
 template <int K>
-static __device__ void k_sum_prefix_apply(const VB& vb, u64* __restrict__ out, const u64* __restrict__ tile_offsets, size_t n, u32 n_tiles) {
+static __device__ __forceinline__ void k_sum_prefix_apply(const VB& vb, u64* __restrict__ out, const u64* __restrict__ tile_offsets, size_t n, u32 n_tiles) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
 #pragma unroll

@@ -102,7 +102,7 @@ struct SapJob {
 };
 
 // derive_final_address: Blake2s-256(0^12 || address BE (20) || key BE (32))
-static __device__ void k_sap_keys(const VB& vb, SapJob job) {
+static __device__ __forceinline__ void k_sap_keys(const VB& vb, SapJob job) {
     const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     const zkw_log_query* q = job.queries + i;
@@ -119,7 +119,7 @@ static __device__ void k_sap_keys(const VB& vb, SapJob job) {
 
 // One workgroup. Flags are staged in LDS tile by tile; lane 0 runs the two sequential rules (instance cuts,
 // storage_application.rs:143-165; enumeration of first writes, tree/mod.rs:305-313), all lanes write the results.
-static __device__ void k_sap_scan(const VB& vb, SapJob job) {
+static __device__ __forceinline__ void k_sap_scan(const VB& vb, SapJob job) {
     __shared__ uint8_t s_rw[1024], s_first[1024];
     __shared__ u32 s_chunk[1024], s_prev[1024], s_enum[1024];
     __shared__ u32 total, chunk, first_writes, prev;
@@ -165,7 +165,7 @@ static __device__ void k_sap_scan(const VB& vb, SapJob job) {
 // j*(i, L): the latest write j < i whose key first differs from key_i (from the top) at bit L. One wave per block,
 // lane = i; j is uniform across the wave so key_j is a broadcast load. The per-lane level table lives in LDS as
 // [level][lane] (bank = lane, conflict free).
-static __device__ void k_sap_pairs(const VB& vb, SapJob job) {
+static __device__ __forceinline__ void k_sap_pairs(const VB& vb, SapJob job) {
     __shared__ u32 tab[256 * 64];
     const int lane = threadIdx.x;
     const u64 i = (u64)vb.x * 64 + lane;
@@ -195,7 +195,7 @@ static __device__ void k_sap_pairs(const VB& vb, SapJob job) {
 }
 
 // level 0: the leaf after the query (current tree) and the leaf before the block (pre-state check)
-static __device__ void k_sap_leaves(const VB& vb, SapJob job) {
+static __device__ __forceinline__ void k_sap_leaves(const VB& vb, SapJob job) {
     const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     const zkw_log_query* q = job.queries + i;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void sap_level_step(const SapJob& job, int L, u64 i) 
 }
 
 // Level-synchronous launches: for blocks with more storage queries than one workgroup walks (n > SAP_PERSISTENT_MAX)
-static __device__ void k_sap_level(const VB& vb, SapJob job, int L) {
+static __device__ __forceinline__ void k_sap_level(const VB& vb, SapJob job, int L) {
     const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i < job.n) sap_level_step(job, L, i);
 }
@@ -261,7 +261,7 @@ static __device__ void k_sap_level(const VB& vb, SapJob job, int L) {
 // is a chain of 256 dependent Blake2s pairs either way.
 constexpr int SAP_PERSISTENT_THREADS = 256;
 constexpr u64 SAP_PERSISTENT_MAX = 4 * SAP_PERSISTENT_THREADS;
-static __device__ void k_sap_levels(const VB& vb, SapJob job) {
+static __device__ __forceinline__ void k_sap_levels(const VB& vb, SapJob job) {
     for (int L = 0; L < 256; L++) {
         for (u64 i = threadIdx.x; i < job.n; i += SAP_PERSISTENT_THREADS) sap_level_step(job, L, i);
         __threadfence();
@@ -270,7 +270,7 @@ static __device__ void k_sap_levels(const VB& vb, SapJob job) {
 }
 
 // after level 255 (A0 / C0 hold the roots): root after every query + the reference's inclusion asserts
-static __device__ void k_sap_roots(const VB& vb, SapJob job) {
+static __device__ __forceinline__ void k_sap_roots(const VB& vb, SapJob job) {
     const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     bool bad = false;
@@ -305,7 +305,7 @@ __device__ __forceinline__ u32 sap_diff_byte(const SapJob& job, u64 i, int pos) 
 }
 
 // one wave: the running Keccak-256 over the writes' state diffs (two rate blocks each, :253-260)
-static __device__ void k_sap_keccak(const VB& vb, SapJob job, SapKeccakOut out) {
+static __device__ __forceinline__ void k_sap_keccak(const VB& vb, SapJob job, SapKeccakOut out) {
     __shared__ u64 A[25], Bm[25], Cc[5];
     const int t = threadIdx.x;
     if (t < 25) A[t] = 0;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void sap_bytes32(uint8_t* dst, const u32* words) {
         for (int b = 0; b < 4; b++) dst[4 * k + b] = (uint8_t)(words[k] >> (8 * b));
 }
 
-static __device__ void k_sap_instances(const VB& vb, const SapBlock* __restrict__ blk) {
+static __device__ __forceinline__ void k_sap_instances(const VB& vb, const SapBlock* __restrict__ blk) {
     const SapBlock b = *blk;
     const u64 c = (u64)vb.x * blockDim.x + threadIdx.x;
     if (c >= b.n_instances) return;
@@ -426,7 +426,7 @@ static __device__ void k_sap_instances(const VB& vb, const SapBlock* __restrict_
 // ------------------------------------------------------------------------------------------------ synthesis inputs (type 10)
 // What zkw_storage_application_synthesize needs of a query after the builder's scratch is gone: the leaf before and after it.
 struct SapItem { u64 read_index, write_index; u32 read_value[8], written_value[8]; u32 rw, _pad; };
-static __device__ void k_sap_items(const VB& vb, SapJob job, SapItem* __restrict__ items) {
+static __device__ __forceinline__ void k_sap_items(const VB& vb, SapJob job, SapItem* __restrict__ items) {
     const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     const zkw_log_query* q = job.queries + i;
@@ -481,7 +481,7 @@ __device__ __forceinline__ u32 sap_walk_list(const SapWalkJob& j, u32 capacity, 
 // A cycle per thread: the header bit, the free elements and the state before the cycle — the key part, and the running hash, which
 // the builder's level walk left behind for every level of every walk (walk_hashes: no hashing here; the padding cycles carry the last
 // walk's root, the state before cycle 0 is zero). grid = (ceil((cycles + 1) / 256), instances)
-static __device__ void k_sap_walk_cycles(const VB& vb, const SapWalkJob* __restrict__ jobs, u32 capacity) {
+static __device__ __forceinline__ void k_sap_walk_cycles(const VB& vb, const SapWalkJob* __restrict__ jobs, u32 capacity) {
     __shared__ u32 s_item[SAP_WALK_MAX];
     __shared__ uint8_t s_phase[SAP_WALK_MAX];
     __shared__ u32 s_nw;

@@ -12,7 +12,7 @@
 
 namespace zkw {
 
-static __device__ void k_storage_sort_keys(const VB& vb, const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ k0, u64* __restrict__ k1,
+static __device__ __forceinline__ void k_storage_sort_keys(const VB& vb, const zkw_log_query* __restrict__ q, size_t n, u64* __restrict__ k0, u64* __restrict__ k1,
                                     u64* __restrict__ k2, u64* __restrict__ k3, u64* __restrict__ a0, u64* __restrict__ a1,
                                     u32* __restrict__ a2, u32* __restrict__ iota) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
@@ -29,7 +29,7 @@ static __device__ void k_storage_sort_keys(const VB& vb, const zkw_log_query* __
 }
 
 // sorted_q[i] = q[perm[i]], encoded with extended_timestamp = perm[i] (its position in the unsorted queue)
-static __device__ void k_storage_gather_encode(const VB& vb, const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
+static __device__ __forceinline__ void k_storage_gather_encode(const VB& vb, const zkw_log_query* __restrict__ q, const u32* __restrict__ perm,
                                                                size_t n, zkw_log_query* __restrict__ sorted_q,
                                                                u32* __restrict__ sorted_ext, u64* __restrict__ sorted_enc) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
@@ -73,11 +73,11 @@ struct StoIsStart {
     const zkw_log_query* q;
     __device__ u32 operator()(size_t i) const { return (i == 0 || !same_cell_dev(q + i, q + i - 1)) ? 1u : 0u; }
 };
-static __device__ void k_storage_first(const VB& vb, const u32* __restrict__ start_prefix, size_t n, u32* __restrict__ first) {
+static __device__ __forceinline__ void k_storage_first(const VB& vb, const u32* __restrict__ start_prefix, size_t n, u32* __restrict__ first) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n && start_prefix[i + 1] != start_prefix[i]) first[start_prefix[i + 1] - 1] = (u32)i;
 }
-static __device__ void k_storage_ds(const VB& vb, const zkw_log_query* __restrict__ sorted_q, size_t n, const u64* __restrict__ delta_prefix,
+static __device__ __forceinline__ void k_storage_ds(const VB& vb, const zkw_log_query* __restrict__ sorted_q, size_t n, const u64* __restrict__ delta_prefix,
                                                            const u32* __restrict__ start_prefix, const u32* __restrict__ first, StorageScan sc, u32* __restrict__ viol) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -113,7 +113,7 @@ struct StoEmits {
     size_t n;
     __device__ u32 operator()(size_t i) const { u32 s; int depth; return storage_emits(sc, read_prefix, n, i, s, depth) ? 1u : 0u; }
 };
-static __device__ void k_storage_emit(const VB& vb, const zkw_log_query* __restrict__ sorted_q, size_t n, StorageScan sc, const u32* __restrict__ read_prefix,
+static __device__ __forceinline__ void k_storage_emit(const VB& vb, const zkw_log_query* __restrict__ sorted_q, size_t n, StorageScan sc, const u32* __restrict__ read_prefix,
                                                              const u32* __restrict__ emit_prefix, zkw_log_query* __restrict__ result_q, u64* __restrict__ result_enc,
                                                              u32* __restrict__ totals /* [2]: n_result, violations (accumulated by the passes before) */) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
@@ -160,7 +160,7 @@ struct StorageBlock {
     u32 capacity;
 };
 
-static __device__ void k_storage_instances(const VB& vb, const StorageBlock* __restrict__ blk) {
+static __device__ __forceinline__ void k_storage_instances(const VB& vb, const StorageBlock* __restrict__ blk) {
     const StorageBlock b = *blk;
     const u64 n = b.n, n_inst = (n + b.capacity - 1) / b.capacity;
     const u64 idx = (u64)vb.x * blockDim.x + threadIdx.x;

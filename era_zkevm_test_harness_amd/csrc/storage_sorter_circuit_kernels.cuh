@@ -164,7 +164,7 @@ __device__ __forceinline__ bool ss_same_key(const u64 cv[18], const SsKeys& p) {
 
 // WHICH 0 = unsorted pop (U1..U3), 1 = sorted pop (S1..S3), 2 = result push (R1..R3)
 template <int WHICH>
-static __device__ void k_ss_fill_queue(const VB& vb, const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ss_fill_queue(const VB& vb, const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     const SsSynthJob& job = jobs[vb.y];
     const u32 i = vb.x * blockDim.x + threadIdx.x;
     const size_t rs = SS_REGION_STRIDE(capacity);
@@ -232,7 +232,7 @@ static __device__ void k_ss_fill_queue(const VB& vb, const SsSynthJob* __restric
     v.wq0 = _w[0]; v.wq1 = _w[1]; v.wq2 = _w[2]; v.wq3 = _w[3]; v.wq4 = _w[4]; v.wq5 = _w[5]; v.wq6 = _w[6]; v.wq7 = _w[7]; v.w_d = _w[8]; } while (0)
 
 template <int ROW>
-static __device__ void k_ss_fill_row(const VB& vb, const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ss_fill_row(const VB& vb, const SsSynthJob* __restrict__ jobs, u32 capacity, size_t n_rows) {
     __shared__ u32 sh_hist[256];
     sh_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -414,7 +414,7 @@ static __device__ void k_ss_fill_row(const VB& vb, const SsSynthJob* __restrict_
 
 constexpr int SS_BOUNDARY_ROWS = (SS_NUM_ROW_TYPES - SS_ROWS_PER_CYCLE + 1) & ~1;  // register rows, PI, flush rows, the closed-form section (rounded up to even: 16-byte stores below)
 __device__ __forceinline__ void ss_boundary_block(const SsSynthJob& job, u32 capacity, size_t n_rows);
-static __device__ void k_ss_fill_tail(const VB& vb, const SsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
+static __device__ __forceinline__ void k_ss_fill_tail(const VB& vb, const SsSynthJob* __restrict__ jobs, u32 n_jobs, u32 capacity, size_t n_rows) {
     // 1-D grid: the first n_jobs blocks fill the boundary rows of one trace each (dispatched first and at raised priority: a chain of a dozen
     // dependent permutations that the other blocks' stores hide), then (SS_G + SS_L + 1) * TAIL_CHUNKS blocks per trace
     if (vb.x < n_jobs) {

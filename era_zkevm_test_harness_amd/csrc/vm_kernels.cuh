@@ -14,7 +14,7 @@ typedef uint64_t u64;
 constexpr int VM_TILE = 4096;  // memory-stream items per workgroup of the read/write partition
 
 // reads per tile
-static __device__ void k_vm_rw_tile_counts(const VB& vb, const zkw_mem_query* __restrict__ q, u64 n, u32* __restrict__ tile_reads) {
+static __device__ __forceinline__ void k_vm_rw_tile_counts(const VB& vb, const zkw_mem_query* __restrict__ q, u64 n, u32* __restrict__ tile_reads) {
     __shared__ u32 s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
@@ -31,7 +31,7 @@ static __device__ void k_vm_rw_tile_counts(const VB& vb, const zkw_mem_query* __
 }
 
 // exclusive scan of the tile counts (one workgroup: a block has at most a few thousand tiles)
-static __device__ void k_vm_rw_scan_tiles(const VB& vb, u32* __restrict__ tile_reads, u32 n_tiles, u64* __restrict__ total_reads) {
+static __device__ __forceinline__ void k_vm_rw_scan_tiles(const VB& vb, u32* __restrict__ tile_reads, u32 n_tiles, u64* __restrict__ total_reads) {
     __shared__ u32 s_wave[16];
     __shared__ u32 s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -57,7 +57,7 @@ static __device__ void k_vm_rw_scan_tiles(const VB& vb, u32* __restrict__ tile_r
 }
 
 // stable partition: read_prefix[i] = reads among [0, i); index arrays of the reads / writes in order
-static __device__ void k_vm_rw_scatter(const VB& vb, const zkw_mem_query* __restrict__ q, u64 n, const u32* __restrict__ tile_offsets,
+static __device__ __forceinline__ void k_vm_rw_scatter(const VB& vb, const zkw_mem_query* __restrict__ q, u64 n, const u32* __restrict__ tile_offsets,
                                                        u32* __restrict__ read_prefix, u32* __restrict__ read_index, u32* __restrict__ write_index) {
     __shared__ u32 s_wave[4];
     const u64 base = (u64)vb.x * VM_TILE + (u64)threadIdx.x * 16;  // 16 consecutive items per thread
@@ -144,7 +144,7 @@ __device__ void vm_aux_at(const zkw_vm_tracer_streams& s, u32 at_cycle, bool fin
     }  // the last instance with an empty history: StorageLogDetailedState::default() as is (:1443-1447)
 }
 
-static __device__ void k_vm_slice(const VB& vb, VmSliceJob job) {
+static __device__ __forceinline__ void k_vm_slice(const VB& vb, VmSliceJob job) {
     const zkw_vm_tracer_streams& s = job.s;
     const u64 n_inst = s.n_snapshots - 1;
     const u64 i = (u64)vb.x * blockDim.x + threadIdx.x;

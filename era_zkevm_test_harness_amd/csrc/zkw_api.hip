@@ -1140,7 +1140,7 @@ __device__ __forceinline__ u32 block_of_position(const u64* __restrict__ offsets
 
 // Widths of the sort key's fields in this batch: max timestamp / page / index, so that the radix sort only walks
 // the bits that are in use.
-static __device__ void k_ram_key_ranges(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ maxima) {
+static __device__ __forceinline__ void k_ram_key_ranges(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n, u32* __restrict__ maxima) {
     u32 t = 0, p = 0, x = 0;
     for (size_t i = (size_t)vb.x * blockDim.x + threadIdx.x; i < n; i += (size_t)vb.nx * blockDim.x) {
         t = max(t, q[i].timestamp);
@@ -1160,7 +1160,7 @@ static __device__ void k_ram_key_ranges(const VB& vb, const zkw_mem_query* __res
 }
 
 // (block, page, index, timestamp) packed into one word, most significant first
-static __device__ void k_ram_packed_keys(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n, const u64* __restrict__ offsets,
+static __device__ __forceinline__ void k_ram_packed_keys(const VB& vb, const zkw_mem_query* __restrict__ q, size_t n, const u64* __restrict__ offsets,
                                   int n_blocks, unsigned bits_p, unsigned bits_i, unsigned bits_t,
                                   u64* __restrict__ key, u32* __restrict__ iota) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
@@ -1174,7 +1174,7 @@ static __device__ void k_ram_packed_keys(const VB& vb, const zkw_mem_query* __re
 }
 
 // (block, page, index) of the items in their current order `perm`, packed into one word
-static __device__ void k_ram_packed_cells(const VB& vb, const u64* __restrict__ cell, const u32* __restrict__ perm, size_t n,
+static __device__ __forceinline__ void k_ram_packed_cells(const VB& vb, const u64* __restrict__ cell, const u32* __restrict__ perm, size_t n,
                                    const u64* __restrict__ offsets, int n_blocks, unsigned bits_p, unsigned bits_i,
                                    u64* __restrict__ key) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
@@ -1187,7 +1187,7 @@ static __device__ void k_ram_packed_cells(const VB& vb, const u64* __restrict__ 
     key[i] = k;
 }
 
-static __device__ void k_block_ids(const VB& vb, const u64* __restrict__ offsets, int n_blocks, size_t n, u32* __restrict__ ids) {
+static __device__ __forceinline__ void k_block_ids(const VB& vb, const u64* __restrict__ offsets, int n_blocks, size_t n, u32* __restrict__ ids) {
     size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < n) ids[i] = block_of_position(offsets, n_blocks, i);
 }

@@ -13,7 +13,7 @@ namespace {
 using Clock = std::chrono::steady_clock;
 
 // ---- the two kernels of the batch itself -------------------------------------------------------------------------------------------
-static __device__ void k_batch_fill(const VB& vb, void* dst, int value, size_t bytes) {
+static __device__ __forceinline__ void k_batch_fill(const VB& vb, void* dst, int value, size_t bytes) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x, stride = (size_t)vb.nx * blockDim.x;
     unsigned char* d = static_cast<unsigned char*>(dst);
     const unsigned char v = (unsigned char)value;
@@ -26,7 +26,7 @@ static __device__ void k_batch_fill(const VB& vb, void* dst, int value, size_t b
         for (size_t k = i; k < bytes; k += stride) d[k] = v;
     }
 }
-static __device__ void k_batch_copy(const VB& vb, void* dst, const void* src, size_t bytes) {
+static __device__ __forceinline__ void k_batch_copy(const VB& vb, void* dst, const void* src, size_t bytes) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x, stride = (size_t)vb.nx * blockDim.x;
     unsigned char* d = static_cast<unsigned char*>(dst);
     const unsigned char* s = static_cast<const unsigned char*>(src);

@@ -340,7 +340,7 @@ struct Launcher {
 #define ZKW_LAUNCH_D(ctx, kernel, name, grid, bs, lds, ...) ZKW_TRY((Launcher<&kernel, bs>::go(ctx, name, grid, lds, __VA_ARGS__)))
 
 // rows [0, width) of blockIdx.y's column of a column-major strip
-static __device__ void k_zero_strip(const VB& vb, u64* __restrict__ base, size_t pitch, size_t width) {
+static __device__ __forceinline__ void k_zero_strip(const VB& vb, u64* __restrict__ base, size_t pitch, size_t width) {
     const size_t i = (size_t)vb.x * blockDim.x + threadIdx.x;
     if (i < width) base[(size_t)vb.y * pitch + i] = 0;
 }

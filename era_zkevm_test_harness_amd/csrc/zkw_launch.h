@@ -16,6 +16,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 #include <utility>
 
 namespace zkw {
@@ -53,7 +54,10 @@ template <auto Body, int BS, class... A> __global__ __launch_bounds__(BS) void k
         if (prefix[m] <= blockIdx.x) lo = m; else hi = m;
     }
     const unsigned local = blockIdx.x - prefix[lo], total = prefix[lo + 1] - prefix[lo], nx = gxy[2 * lo], ny = gxy[2 * lo + 1];
-    tup_apply<Body>(VB{local % nx, (local / nx) % ny, local / (nx * ny), nx, ny, total / (nx * ny)}, jobs[lo]);
+    // (the divisions run on the vector unit; the results are wave-uniform and belong in scalar registers — a 1024-thread kernel has 64
+    // vector registers per lane and none to spare for six copies of a constant)
+    auto uni = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    tup_apply<Body>(VB{uni(local % nx), uni((local / nx) % ny), uni(local / (nx * ny)), nx, ny, uni(total / (nx * ny))}, jobs[uni((unsigned)lo)]);
 }
 
 // what the batch needs to know about a kernel to merge its launches
@@ -63,19 +67,23 @@ struct BatchKernel {
     const char* name;
 };
 
+// A body may take a large descriptor as `const D&`: as a launch of its own the reference binds to the kernel argument, as a job of a merged
+// launch to the job table in global memory — by value it would be copied into scratch there (it is indexed dynamically). The argument tuple
+// holds the decayed types.
 template <class F> struct LaunchSig;
-template <class... A> struct LaunchSig<void (*)(const VB&, A...)> {
-    using T = Tup<A...>;
-    template <auto Body, int BS> static void single(hipStream_t st, dim3 grid, size_t lds_bytes, A... a) {
-        hipLaunchKernelGGL((k_single<Body, BS, A...>), grid, dim3(BS), lds_bytes, st, a...);
+template <class... P> struct LaunchSig<void (*)(const VB&, P...)> {
+    template <class X> using Dec = typename std::remove_cv<typename std::remove_reference<X>::type>::type;
+    using T = Tup<Dec<P>...>;
+    template <auto Body, int BS> static void single(hipStream_t st, dim3 grid, size_t lds_bytes, const Dec<P>&... a) {
+        hipLaunchKernelGGL((k_single<Body, BS, Dec<P>...>), grid, dim3(BS), lds_bytes, st, a...);
     }
-    template <auto Body, int BS> static const void* single_fn() { return reinterpret_cast<const void*>(&k_single<Body, BS, A...>); }
+    template <auto Body, int BS> static const void* single_fn() { return reinterpret_cast<const void*>(&k_single<Body, BS, Dec<P>...>); }
     template <auto Body, int BS> static const BatchKernel* desc(const char* name) {
-        static BatchKernel k{reinterpret_cast<const void*>(&k_multi<Body, BS, A...>), (unsigned)BS, (unsigned)sizeof(T), (unsigned)alignof(T), name};
+        static BatchKernel k{reinterpret_cast<const void*>(&k_multi<Body, BS, Dec<P>...>), (unsigned)BS, (unsigned)sizeof(T), (unsigned)alignof(T), name};
         if (name && name[0] && !k.name[0]) k.name = name;
         return &k;
     }
-    static void pack(T& t, const A&... a) { tup_pack(t, a...); }
+    static void pack(T& t, const Dec<P>&... a) { tup_pack(t, a...); }
 };
 
 }  // namespace zkw

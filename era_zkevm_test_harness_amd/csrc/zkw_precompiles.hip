@@ -957,9 +957,12 @@ struct NlInstance { u64 first_round; u32 n_active; const u64* public_input; cons
 
 template <int W, int R, int WAVES>
 int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsigned nj, u32 capacity, size_t n_rows) {
+    using L = Launcher<&k_nl_fill<W, R, WAVES>, 64 * WAVES>;
     static bool attr_set[16] = {};
     if (!attr_set[ctx->device & 15]) {  // more than the default 64 KB of dynamic LDS
-        ZKW_TRY((Launcher<&k_nl_fill<W, R, WAVES>, 64 * WAVES>::allow_dynamic_lds(160 * 1024)));
+        // (the 16-wave form is a launch of its own only: as a job of a merged launch its 64 registers per lane do not hold the job lookup too)
+        if constexpr (WAVES == 16) HIP_TRY(hipFuncSetAttribute(L::S::template single_fn<&k_nl_fill<W, R, WAVES>, 64 * WAVES>(), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        else ZKW_TRY(L::allow_dynamic_lds(160 * 1024));
         attr_set[ctx->device & 15] = true;
     }
 #ifdef ZKW_PROBE_BUILD  // measurement builds only (ZKW_PROBE_BUILD=1 python -m era_zkevm_test_harness_amd.build --force): 1 = no level walk, 2 = no
@@ -973,7 +976,13 @@ int nl_launch_fill_w(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsi
     const unsigned lds = WAVES == 16 ? nc->host.lds_bytes16 : nc->host.lds_bytes;
     const unsigned per_cu = std::max<unsigned>(1, std::min<unsigned>(4, (160u * 1024u) / std::max<unsigned>(1, lds)));
     const unsigned blocks = std::min<unsigned>((capacity + WAVES - 1) / WAVES, std::max<unsigned>(1, 256 * per_cu / nj));
-    { Prof _p(ctx, "k_nl_fill"); ZKW_LAUNCH_D(ctx, (k_nl_fill<W, R, WAVES>), "k_nl_fill", dim3(blocks, nj), 64 * WAVES, lds, nc->dev, d_jobs, capacity, n_rows, probe); }
+    if constexpr (WAVES == 16) {
+        Prof _p(ctx, "k_nl_fill");
+        L::S::template single<&k_nl_fill<W, R, WAVES>, 64 * WAVES>(ctx->stream, dim3(blocks, nj), lds, nc->dev, d_jobs, capacity, n_rows, probe);
+    } else {
+        Prof _p(ctx, "k_nl_fill");
+        ZKW_LAUNCH_D(ctx, (k_nl_fill<W, R, WAVES>), "k_nl_fill", dim3(blocks, nj), 64 * WAVES, lds, nc->dev, d_jobs, capacity, n_rows, probe);
+    }
     return launch_check("k_nl_fill");
 }
 // the lane-per-cycle path (k_nl_walk + k_nl_expand), for netlists whose live values fit the LDS
@@ -1008,7 +1017,7 @@ int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsign
         return launch_check("k_nl_hist");
     }
     // (a call with few cycles keeps 8 waves per workgroup: twice the workgroups, so that every CU has one)
-    if (nc->host.fill_waves == 16 && (size_t)((capacity + 15) / 16) * nj >= 128) ZKW_TRY((nl_launch_fill_w<W, R, 16>(ctx, nc, d_jobs, nj, capacity, n_rows)));
+    if (nc->host.fill_waves == 16 && (size_t)((capacity + 15) / 16) * nj >= 128 && !ctx->batched()) ZKW_TRY((nl_launch_fill_w<W, R, 16>(ctx, nc, d_jobs, nj, capacity, n_rows)));
     else ZKW_TRY((nl_launch_fill_w<W, R, 8>(ctx, nc, d_jobs, nj, capacity, n_rows)));
     if (after_fill) ZKW_TRY(after_fill());
     { Prof _p(ctx, "k_nl_hist"); ZKW_LAUNCH_D(ctx, (k_nl_hist<R>), "k_nl_hist", dim3(nc->host.n_hist_slices, nc->host.s.total_table_rows > NL_HIST_HALF ? 2 : 1, nj), NL_HIST_THREADS, 0, nc->dev, d_jobs, capacity, n_rows); }

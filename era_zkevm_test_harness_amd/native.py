@@ -1715,6 +1715,27 @@ class Block:
         return objs
 
     @staticmethod
+    def run_sharded_prepared(device_id, templates, rank, world):
+        """zkw_blocks_run_sharded over inputs prepared by prepare_many: a Block for every owned index, None elsewhere"""
+        import copy
+
+        lib = load()
+        ptrs = (C.c_void_p * len(templates))(*[C.addressof(o._inp) for o in templates])
+        outs = (C.c_void_p * len(templates))()
+        rc = lib.zkw_blocks_run_sharded(device_id, ptrs, len(templates), rank, world, outs)
+        if rc != OK:
+            raise ZkwError(rc, (lib.zkw_block_last_error() or b"").decode() or lib.zkw_last_error().decode())
+        res = []
+        for t, h in zip(templates, outs):
+            if h is None:
+                res.append(None)
+            else:
+                o = copy.copy(t)
+                o.handle = C.c_void_p(h)
+                res.append(o)
+        return res
+
+    @staticmethod
     def run_sharded(device_id, blocks, rank, world, capacities=None):
         """zkw_blocks_run_sharded: every rank passes the same list of blocks; rank r builds the blocks k with k % world == r.
         Returns a list with a Block for every owned index and None elsewhere."""

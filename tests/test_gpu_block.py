@@ -290,6 +290,70 @@ def test_blocks_run_many_at_once(ctx, oracle):
         m.free()
 
 
+def test_blocks_run_512_in_flight_heterogeneous(ctx):
+    """zkw_blocks_run with 512 blocks in flight (fibers of one host thread, launches merged per kernel and stage: csrc/zkw_batch.h), the
+    blocks of EIGHT different shapes interleaved — among them blocks with no events, no L1 messages, no storage accesses, no precompile
+    calls (builders that take their early exits while the other blocks' equal stages go on: ADVICE r5, the chain service's stage keys) —
+    half of the shapes with their queues resident on the device (zkw_block_inputs.queues_on_device): every block's records equal what
+    zkw_block_run gives for its shape alone, and every instance zkw_blocks_synthesize hands out satisfies its circuit."""
+    import threading
+
+    from era_zkevm_test_harness_amd import block as blk, native as nv
+
+    caps = {blk.DECOMMITS_SORTER: 5, blk.CODE_DECOMMITTER: 7, blk.LOG_DEMUXER: 64, blk.KECCAK256: 3, blk.SHA256: 4, blk.ECRECOVER: 2,
+            blk.RAM_PERMUTATION: 1000, blk.STORAGE_SORTER: 40, blk.EVENTS_SORTER: 16, blk.L1_MESSAGES_SORTER: 9, blk.L1_MESSAGES_HASHER: 48}
+    shapes = [synthetic.block_after_vm(seed=60, n_vm_memory=900, n_storage=50),
+              synthetic.block_after_vm(seed=61, n_vm_memory=1400, n_storage=70, n_events=0),
+              synthetic.block_after_vm(seed=62, n_vm_memory=700, n_storage=40, n_l1_messages=0),
+              synthetic.block_after_vm(seed=63, n_vm_memory=1100, n_storage=0, n_storage_cells=1),
+              synthetic.block_after_vm(seed=64, n_vm_memory=800, n_storage=30, n_precompile_calls=(0, 0, 0)),
+              synthetic.block_after_vm(seed=65, n_vm_memory=1000, n_storage=20, n_events=0, n_l1_messages=0),
+              synthetic.block_after_vm(seed=66, n_vm_memory=1300, n_storage=90, n_decommits=40, n_bytecodes=9),
+              synthetic.block_after_vm(seed=67, n_vm_memory=600, n_storage=10, n_events=3, n_l1_messages=1, n_precompile_calls=(1, 0, 2))]
+    whats = ((blk.RAM_PERMUTATION, nv.RAM_INSTANCES), (blk.DECOMMITS_SORTER, nv.DEC_INSTANCES), (blk.LOG_DEMUXER, nv.DMX_INSTANCES),
+             (blk.STORAGE_SORTER, nv.STO_INSTANCES), (blk.EVENTS_SORTER, nv.EVT_INSTANCES), (blk.L1_MESSAGES_SORTER, nv.EVT_INSTANCES),
+             (blk.CODE_DECOMMITTER, nv.DCM_INSTANCES), (blk.KECCAK256, nv.PRC_INSTANCES), (blk.SHA256, nv.PRC_INSTANCES), (blk.ECRECOVER, nv.PRC_INSTANCES))
+
+    def record(b):
+        r = {"mem": b.memory_queue_state().tobytes()}
+        for t, w in whats:
+            a = b.witness_get(t, w, np.uint8)
+            r[(t, w)] = None if a is None else a.tobytes()
+        for t in range(2, 14):
+            pi = b.public_inputs(t)
+            r[("pi", t)] = None if pi is None else pi.tobytes()
+            rq = b.recursion_queue(t)
+            r[("rq", t)] = None if rq is None or rq[1] is None else rq[1].tobytes()
+        return r
+
+    ref = []
+    for sh in shapes:
+        one = nv.Block(0, sh, caps)
+        ref.append(record(one))
+        one.free()
+    inputs = [nv.Block.queues_to_device(sh) if k % 2 else sh for k, sh in enumerate(shapes)]
+    K = 512
+    templates = nv.Block.prepare_many(0, [inputs[k % len(inputs)] for k in range(K)], caps)
+    many = nv.Block.run_prepared(0, templates)
+    assert len(many) == K
+    for k, m in enumerate(many):
+        got, exp = record(m), ref[k % len(shapes)]
+        assert got.keys() == exp.keys()
+        for key in exp:
+            assert got[key] == exp[key], (k, key)
+    # every instance of the first 64 blocks (eight of each shape) through zkw_blocks_synthesize, checked as it is handed out
+    bad, lock = [], threading.Lock()
+
+    def cb(bi, t, i, tr, s, pi):
+        v = many[bi].check_satisfied(t, tr, s)[0]
+        with lock:
+            bad.append((bi, t, i, v))
+
+    n = nv.Block.synthesize_many(many[:64], 1 << 18, ring_slots=1, callback=cb)
+    assert n == len(bad) and n >= 64 * 9 and not any(v for *_x, v in bad), [x for x in bad if x[3]][:5]
+    nv.Block.free_many(many)
+
+
 def test_blocks_synthesize_many_equals_block_by_block(ctx):
     """zkw_blocks_synthesize (the ECRecover instances of all blocks in joint calls, the other types block by block on the library's
     threads): every trace it hands out is the trace zkw_block_synthesize hands out for the same (block, type, instance) — compared by a

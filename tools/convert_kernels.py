@@ -54,7 +54,7 @@ def convert_defs(path, bounds):
         body = s[j:k + 1]
         body = body.replace("blockIdx.x", "vb.x").replace("gridDim.x", "vb.nx").replace("blockIdx.y", "vb.y").replace("gridDim.y", "vb.ny").replace("blockIdx.z", "vb.z").replace("gridDim.z", "vb.nz")
         params = s[m.end():params_end]
-        head = "static __device__ void %s(const VB& vb%s" % (name, ", " + params if params.strip() else "")
+        head = "static __device__ __forceinline__ void %s(const VB& vb%s" % (name, ", " + params if params.strip() else "")
         out.append(head + s[params_end:j] + body)
         pos = k + 1
     out.append(s[pos:])
@@ -144,7 +144,7 @@ def main():
         convert_defs(os.path.join(CSRC, f), bounds)
     # kernels converted in an earlier run of this script (definitions no longer match DEF)
     for f in KERNEL_FILES + SYNTH_KERNEL_FILES:
-        for m in re.finditer(r"static __device__ void (k_\w+)\(const VB& vb", open(os.path.join(CSRC, f)).read()):
+        for m in re.finditer(r"static __device__ (?:__forceinline__ )?void (k_\w+)\(const VB& vb", open(os.path.join(CSRC, f)).read()):
             bounds.setdefault(m.group(1), None)
     for f in LAUNCH_FILES:
         convert_launches(os.path.join(CSRC, f), bounds, report)
