@@ -502,9 +502,19 @@ def launcher_self_test(args):
                               for r in range(world)])
         got = out.numpy().reshape(-1).view(np.uint64).reshape(-1, words)
         ok = bool(np.array_equal(got, exp)) and (comm is None or bool(np.array_equal(recv, exp)))
-        print(json.dumps({"metric": "LAUNCHER SELF-TEST (no circuit work, not a measurement)", "value": None, "n_gpus": world, "steps": args.steps,
+        # the block-sharded leg's plan and record format (full_block.batched at N > 1): block k belongs to rank zkw_blocks_owner(k, N), its
+        # closed-form records travel as ONE fixed-size record of 1 + 24 x max_per_block words through zkw_gather_records
+        lib = native.load()
+        n_blocks, max_per_block = 2 * world + 1, 3
+        owners = [int(lib.zkw_blocks_owner(k, world)) for k in range(n_blocks)]
+        print(json.dumps({"metric": "LAUNCHER SELF-TEST (no circuit work, not a measurement)", "value": None, "value_cold_slots": None, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "records_gathered": int(got.shape[0]),
-                          "records_match": ok, "config": {"workload": "none", "gather": "torch.distributed (gloo) + libzkw zkw_gather_closed_form_inputs (TCP)"}}),
+                          "records_match": ok, "config": {"workload": "none", "gather": "torch.distributed (gloo) + libzkw zkw_gather_closed_form_inputs (TCP)"},
+                          "roofline": {"bytes_basis": None}, "synthesis": {"bytes_basis": None, "frac_of_hbm_peak_on_trace_bytes": None},
+                          "full_block": {"batched": {"sharding": "zkw_blocks_run_sharded (round-robin over ranks) + zkw_blocks_gather_closed_form_inputs",
+                                                     "n_gpus": world, "rccl_ranks": 0, "blocks_per_s": None, "per_rank_blocks_per_s": None,
+                                                     "block_owners": owners, "record_words": 1 + 24 * max_per_block},
+                                         "scaling_note": "the single block does not scale with N (replicated builders); `batched` does"}}),
               flush=True)
     if comm is not None:
         comm.destroy()

@@ -4,6 +4,7 @@
 library is written next to this file (in-tree: it travels to the GPU box with the repo snapshot and is
 git-ignored).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -29,28 +30,51 @@ def _deps():
     return out
 
 
+def _digest(src):
+    """What an object file depends on: the unit, every header it can include, the compiler and its flags. Objects are keyed on this CONTENT
+    hash (round 6; rounds 1-5 compared modification times, and an object that travelled in a snapshot with a newer mtime than an edited
+    header would have gone unnoticed)."""
+    h = hashlib.sha256()
+    h.update(" ".join([HIPCC, *FLAGS]).encode())
+    for path in [os.path.join(CSRC, src)] + sorted(_deps()):
+        h.update(os.path.relpath(path, HERE).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    hdr_mtime = max(os.path.getmtime(p) for p in _deps())
     objs, rebuilt = [], False
     procs = []
+    known = {src.replace(".hip", ".o") for src in SOURCES} | {src.replace(".hip", ".sha256") for src in SOURCES}
+    for stray in os.listdir(OBJ):  # nothing but this list's objects is ever linked or kept (a foreign or stale object tree is not trusted)
+        if stray not in known:
+            os.remove(os.path.join(OBJ, stray))
     for src in SOURCES:
-        sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src.replace(".hip", ".o"))
+        hp = os.path.join(OBJ, src.replace(".hip", ".sha256"))
         objs.append(op)
-        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_mtime):
-            cmd = [HIPCC, *FLAGS, "-c", sp, "-o", op]
+        want = _digest(src)
+        have = open(hp).read().strip() if os.path.exists(hp) else None
+        if force or not os.path.exists(op) or have != want:
+            if os.path.exists(hp):
+                os.remove(hp)
+            cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            procs.append((src, hp, want, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
             rebuilt = True
-    for src, p in procs:
+    for src, hp, want, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        with open(hp, "w") as f:
+            f.write(want)
         if verbose and out.strip():
             print(out)
-    if rebuilt or not os.path.exists(LIB):
+    # the library is relinked whenever an object was rebuilt, it is missing, or it is older than an object
+    if rebuilt or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:

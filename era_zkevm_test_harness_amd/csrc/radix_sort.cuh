@@ -5,7 +5,8 @@
 //
 // Written as kernel BODIES (zkw_launch.h): inside zkw_blocks_run the K blocks' sorts of a stage travel as one launch per kernel and pass.
 //
-// A pass over n pairs, tile = 4 waves x 16 rounds x 64 keys = 4 096 keys, wave w of a tile owns the keys [1024 w, 1024 (w + 1)) of it:
+// A pass over n pairs, tile = 4 waves x 8 rounds x 64 keys = 2 048 keys (30 KB of LDS: five workgroups per CU; 16 rounds — two workgroups per
+// CU — ran the scatter of 1.9 G pairs at 1.8 TB/s), wave w of a tile owns the keys [512 w, 512 (w + 1)) of it:
 //   k_rs_hist     per tile: 256 digit counts (LDS atomics) -> hist[digit][tile]
 //   k_rs_scan_a   exclusive scan of hist (digit-major) in chunks of 16 384 entries, chunk totals aside
 //   k_rs_scan_b   exclusive scan of the chunk totals (one workgroup)
@@ -17,7 +18,7 @@
 
 namespace zkw {
 
-constexpr int RS_ROUNDS = 16, RS_WAVES = 4, RS_TILE = RS_WAVES * RS_ROUNDS * 64, RS_CHUNK = 16384;
+constexpr int RS_ROUNDS = 8, RS_WAVES = 4, RS_TILE = RS_WAVES * RS_ROUNDS * 64, RS_CHUNK = 16384;
 
 template <class K>
 static __device__ __forceinline__ unsigned rs_digit(K key, unsigned shift, unsigned mask) { return (unsigned)(key >> shift) & mask; }
@@ -113,12 +114,18 @@ static __device__ __forceinline__ void k_rs_scatter(const VB& vb, const K* __res
     __syncthreads();
     const size_t tile0 = (size_t)vb.x * RS_TILE, base = tile0 + (size_t)wave * (RS_ROUNDS * 64) + lane;
     K key[RS_ROUNDS];
+    u32 val[RS_ROUNDS];
     unsigned long long same[RS_ROUNDS];  // the lanes of this wave whose key of the round has the same digit
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {  // every load of the tile in flight before the first ballot
+        const size_t i = base + (size_t)r * 64;
+        key[r] = i < n ? kin[i] : (K)0;
+        val[r] = i < n ? vin[i] : 0u;
+    }
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const size_t i = base + (size_t)r * 64;
         const bool ok = i < n;
-        key[r] = ok ? kin[i] : (K)0;
         const unsigned d = rs_digit(key[r], shift, mask);
         unsigned long long m = __ballot(ok);
 #pragma unroll
@@ -156,13 +163,12 @@ static __device__ __forceinline__ void k_rs_scatter(const VB& vb, const K* __res
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
-        const size_t i = base + (size_t)r * 64;
         const unsigned long long m = same[r];
         if (m) {
             const unsigned d = rs_digit(key[r], shift, mask);
             const u32 at = wcnt[wave][d] + (u32)__popcll(m & ((1ull << lane) - 1));
             s_key[at] = key[r];
-            s_val[at] = vin[i];
+            s_val[at] = val[r];
         }
         __builtin_amdgcn_wave_barrier();
         if (m && (m & ((1ull << lane) - 1)) == 0) wcnt[wave][rs_digit(key[r], shift, mask)] += (u32)__popcll(m);

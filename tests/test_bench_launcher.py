@@ -26,6 +26,13 @@ def test_gpus_2_starts_two_ranks_and_gathers():
     assert out["records_gathered"] == 2 * 5 and out["records_match"] is True
     assert "SELF-TEST" in out["metric"] and out["value"] is None  # can never be read as a measurement
     assert "starting 2 ranks" in r.stderr
+    # the fields VERDICT r5 item 5 asks of the line: the cold-slot figure next to `value`, the byte bases, and a block leg that leads with the
+    # sharded blocks (round-robin owners, ranks in the collective)
+    assert "value_cold_slots" in out and "bytes_basis" in out["roofline"] and "bytes_basis" in out["synthesis"]
+    b = out["full_block"]["batched"]
+    assert b["n_gpus"] == 2 and "zkw_blocks_run_sharded" in b["sharding"] and "rccl_ranks" in b and "per_rank_blocks_per_s" in b
+    assert b["block_owners"] == [0, 1, 0, 1, 0] and b["record_words"] == 73
+    assert "does not scale" in out["full_block"]["scaling_note"]
 
 
 def test_refuses_more_ranks_than_gpus():
