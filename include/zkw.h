@@ -364,7 +364,13 @@ typedef struct zkw_events_witness zkw_events_witness;
    events_sort_dedup.rs:16-580 — used twice by the reference (events and L2->L1 messages, oracle.rs:1069-1088).
    q: the demuxed log queue in queue order (n == 0 yields the reference's single dummy instance);
    result_in (host, NULL = empty): state of the result queue the net events are appended to.
-   ZKW_ERR_CHECK_FAILED when one of the reference's asserts on the queue's shape fails. */
+   PRECONDITION (a deliberate difference from the reference): the queue must be WELL-FORMED — per timestamp at most
+   one forward record, optionally followed, somewhere later in the queue, by its own rollback twin (same timestamp and payload,
+   rollback = 1). The reference's comparator (events_sort_dedup.rs:81-90) is not a strict weak order on other queues, so its result
+   there depends on the sorting algorithm; this library sorts stably by (timestamp, rollback) — which is what the reference's
+   comparator does on well-formed queues — and REJECTS everything else with ZKW_ERR_CHECK_FAILED (the number of violations in
+   zkw_last_error()) instead of reproducing an order nobody specified. ZKW_ERR_CHECK_FAILED also when one of the reference's own
+   asserts on the queue's shape fails (events_sort_dedup.rs:344-356, 512-533). */
 int zkw_events_sorter_build(zkw_ctx *ctx, const zkw_log_query *q, size_t n, uint32_t capacity,
                             const zkw_queue_state4 *result_in, zkw_events_witness **out);
 enum {
