@@ -389,6 +389,10 @@ int zkw_batch::run(const std::vector<std::function<int()>>& roots) {
     flush_host_ms = wait_ms = 0;
     for (auto& r : roots)
         if (make_fiber(this, r) < 0) { tl_batch = outer; return fail(ZKW_ERR_OOM, "zkw_batch: no stack for a fiber"); }
+    static const int verbose = [] { const char* e = getenv("ZKW_BATCH_LOG"); return e ? atoi(e) : 0; }();  // 2: one line per flush
+    const auto t_run = Clock::now();
+    auto ms_since = [&](Clock::time_point t) { return std::chrono::duration<double, std::milli>(Clock::now() - t).count(); };
+    auto t_sweep = Clock::now();
     int first_rc = ZKW_OK;
     std::string first_err;
     auto note = [&](int rc, const std::string& e) { if (rc != ZKW_OK && first_rc == ZKW_OK) { first_rc = rc; first_err = e; } };
@@ -415,7 +419,11 @@ int zkw_batch::run(const std::vector<std::function<int()>>& roots) {
         if (live == 0) break;
         if (ran) continue;  // a sweep may have made joiners ready
         // 2. nobody can run: send what they left
+        const double host_ms = ms_since(t_sweep);
+        const size_t l0 = n_launches, c0 = n_chain_launches;
+        const auto t_fl = Clock::now();
         flush();
+        const double fl_ms = ms_since(t_fl);
         // 3. wait until some parked fiber has everything it waits for
         const auto tw = Clock::now();
         bool woke = false;
@@ -450,6 +458,13 @@ int zkw_batch::run(const std::vector<std::function<int()>>& roots) {
             if (spins > 64) usleep(spins > 1024 ? 200 : 20);
         }
         wait_ms += std::chrono::duration<double, std::milli>(Clock::now() - tw).count();
+        if (verbose >= 2) {
+            size_t woken = 0;
+            for (auto& fp : fibers) woken += fp->state == Fiber::READY;
+            fprintf(stderr, "[zkw batch] t=%8.1f ms: fibers ran %.1f ms, flush %.1f ms (%zu merged launches, %zu chain launches), waited %.1f ms, %zu fibers woken\n", ms_since(t_run), host_ms, fl_ms,
+                    n_launches - l0, n_chain_launches - c0, ms_since(tw), woken);
+        }
+        t_sweep = Clock::now();
     }
     tl_batch = outer;
     if (flush_rc != ZKW_OK && first_rc == ZKW_OK) { first_rc = flush_rc; first_err = flush_err; }

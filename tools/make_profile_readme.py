@@ -6,6 +6,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import short  # k_single / k_multi forms of a kernel body by the name the kernel had before round 6
+
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 D = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", ROUND)
 
@@ -22,6 +25,8 @@ def pmc(name):
 
 
 rows = list(csv.DictReader(open(os.path.join(D, "bench_default_kernel_stats.csv"))))
+for r in rows:
+    r["Name"] = short(r["Name"])
 bench = last_json("bench_default.json")
 under = last_json("bench_default_under_rocprofv3.json")
 seq = last_json("bench_sequential.json")
@@ -172,7 +177,11 @@ if valu:
     w("\nPeak issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave-instruction = 6.14e11 wave-instructions/s; bench.py's `roofline_valu` divides.")
 for name, title in (("full_block_probe.txt", "One production-capacity block (tools/probe_block.py, ZKW_BLOCK_PROFILE=1: per-kernel HIP-event times of every branch's context, then the spans)"),
                     ("synthesis_probes.txt", "Synthesis of the other circuit types at production geometry (tools/probe_{ds,es,ld,ss}_synth.py, 16 instances per pass; tools/probe_netlist_perf.py)"),
-                    ("blocks_in_flight.txt", "K production-capacity blocks in flight at once (tools/probe_block_concurrency.py K 3: zkw_blocks_run + chain service; last of 3 rounds)"),
+                    ("blocks_in_flight.txt", "K production-capacity blocks in flight at once (tools/probe_blocks_pipeline.py K 3 seq device: zkw_blocks_run + zkw_blocks_synthesize + zkw_blocks_free, batch after batch; the summary line of 3 batches)"),
+                    ("blocks_kernel_stats.csv", "rocprofv3 --kernel-trace --stats of the block leg alone (tools/probe_blocks_pipeline.py 512 2 seq device: warm-up batch + 2 batches of 512 blocks; ` [merged]` = the k_multi form)"),
+                    ("builders_timeline_512.txt", "The builders of 512 blocks, one line per flush of the batch (ZKW_BATCH_LOG=2 tools/probe_blocks_builders_trace.py 512; second run)"),
+                    ("order_of_legs.txt", "The order of the legs (ZKW_FULL_BLOCK_FIRST=1 against the default), 10 timed steps each on the same box"),
+                    ("rocprof_stats_runs.txt", "Did rocprofv3 --kernel-trace --stats run through the whole bench, 512 blocks in flight in the batched leg included?"),
                     ("hardware_probes.txt", "Hardware probes behind DESIGN.md 3.2 (tools/probe_wave_placement, probe_clock_regime, ubench_perm)"),
                     ("hw_queue_probes.txt", "Concurrent long kernels per priority class against GPU_MAX_HW_QUEUES (tools/probe_hw_queues2, DESIGN.md 3.14)"),
                     ("netlist_kc_kernel_stats.csv", "rocprofv3 --kernel-trace --stats of tools/probe_kc_synth.py (Keccak256RoundFunction, 3 x 8 instances + the builder)"),
@@ -187,7 +196,10 @@ for name, title in (("full_block_probe.txt", "One production-capacity block (too
         w("```")
         txt = open(path).read().rstrip().splitlines()
         if name.endswith("_kernel_stats.csv"):
-            txt = [l[:170] for l in txt[:12]]
+            hdr, body = txt[0], txt[1:26 if name.startswith("blocks") else 12]
+            txt = [hdr] + ['"%s",%s' % (short(l.split('",')[0].lstrip('"')), l.split('",', 1)[1][:60]) if '",' in l else l[:170] for l in body]
+        if name == "builders_timeline_512.txt":
+            txt = txt[-80:]
         if name == "full_block_probe.txt":  # keep the last repetition's kernel table and the spans
             keep = [l for l in txt if not l.startswith("[zkw_block]")]
             tab = [l for l in txt if l.startswith("[zkw_block]")]
