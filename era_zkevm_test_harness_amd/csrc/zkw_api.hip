@@ -495,7 +495,7 @@ static void launch_chain_full_rows(hipStream_t st, const ChainJob* d_jobs, int n
     else hipLaunchKernelGGL(k_chain_full, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
 }
 static void launch_chain_log_rows(hipStream_t st, const LogChainJob* d_jobs, int n_jobs) {
-    static const bool wg4 = [] { const char* e = getenv("ZKW_CHAIN_WG4"); return !(e && e[0] == '0'); }();
+    static const bool wg4 = [] { const char* e = getenv("ZKW_CHAIN_WG4"); const char* l = getenv("ZKW_CHAIN_LOG_WG4"); return !(e && e[0] == '0') && !(l && l[0] == '0'); }();
     const int lds = wg4 && n_jobs > 4 && n_jobs <= 256 * 16 ? one_workgroup_per_cu_lds(reinterpret_cast<const void*>(&k_chain_log_x4), 2) : -1;
     if (lds > 0) hipLaunchKernelGGL(k_chain_log_x4, dim3((n_jobs + 15) / 16), dim3(256), (size_t)lds, st, d_jobs, n_jobs);
     else hipLaunchKernelGGL(k_chain_log, dim3((n_jobs + 3) / 4), dim3(64), 0, st, d_jobs, n_jobs);
@@ -507,7 +507,10 @@ int zkw_launch_chain_full(hipStream_t st, const ChainJob* d_jobs, int n_jobs) {
     return ZKW_OK;
 }
 int zkw_launch_chain_log(hipStream_t st, const LogChainJob* d_jobs, int n_jobs) {
-    launch_chain_log_rows(st, d_jobs, n_jobs);
+    // more than 4 096 log-queue chains (the three sorters' stages of 512 blocks arrive together: 4 608): several launches of the form that
+    // takes a CU per 16 chains, rather than one launch of one-wave workgroups that settle on the SIMDs of other stages' chains (the jobs are
+    // sorted by length: the first launch holds the long ones, the others are gone in milliseconds)
+    for (int at = 0; at < n_jobs; at += 4096) launch_chain_log_rows(st, d_jobs + at, std::min(4096, n_jobs - at));
     return ZKW_OK;
 }
 

@@ -302,6 +302,12 @@ bool zkw_batch::flush() {
             m.total = (unsigned)acc;
         }
         ChainGroup& c = R.chain;
+        // Longest chains first: a workgroup of the row form holds 16 chains and lives as long as its longest one. In the order the blocks
+        // submitted them — a demuxer's 58 750-item input queue next to its six output queues of 35 000 ... 0 items — every workgroup of a
+        // stage holds a long chain and the stage keeps all its CUs for its whole length (512 blocks' demuxers: 224 CUs for 0.4 s, and the
+        // memory-queue chains that arrive 0.1 s later wait for them). Sorted, the long chains share workgroups and the others leave early.
+        std::stable_sort(c.full.begin(), c.full.end(), [](const ChainJob& a, const ChainJob& b) { return a.n > b.n; });
+        std::stable_sort(c.log.begin(), c.log.end(), [](const LogChainJob& a, const LogChainJob& b) { return a.n > b.n; });
         if (!c.full.empty()) {
             char *h = nullptr, *d = nullptr;
             if (up.alloc(c.full.size() * sizeof(ChainJob), alignof(ChainJob), &h, &d) == ZKW_OK) {
