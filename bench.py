@@ -151,43 +151,51 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     return best, blk
 
 
-def full_blocks_batched(local_rank, blk, K=512, rounds=3, rank=0, world=1, comm=None):
-    """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once. zkw_blocks_run runs the blocks' builder graphs
-    as fibers of ONE host thread and merges their launches per kernel and stage (csrc/zkw_batch.h: no thread and no stream per block);
+def full_blocks_batched(local_rank, blk, K=512, rounds=10, rank=0, world=1, comm=None):
+    """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once — two batches of K / 2, the builders of one under the
+    synthesis of the other. zkw_blocks_run runs a batch's builder graphs as fibers of ONE host thread and merges their launches per kernel and
+    stage (csrc/zkw_batch.h: no thread and no stream per block; the chains of a stage as one launch, longest chains first);
     zkw_blocks_synthesize synthesizes every instance of every block — groups of slot-owning fibers going through their blocks type by type,
-    the ECRecover instances of all blocks in joint calls on two priority streams —; zkw_blocks_free releases the batch. Batch after batch
-    (the builders of batch k + 1 under the synthesis of batch k were measured: the chains' priority waves slow the fills by 70 %, and two
-    batches of 256 do not beat one of 512). The figure is the blocks of the timed batches over their wall time; the first batch (which
-    fills the library's buffer caches) is untimed. The blocks' four queues are resident in HBM when the clock starts
+    the ECRecover instances of all blocks in joint calls on two priority streams —; zkw_blocks_free releases the batch, on a third thread.
+    The figure is the blocks of the timed batches over their wall time, start-up (the first batch's builders have nothing to hide under) and
+    drain included; a first batch, which fills the library's buffer caches, is untimed. `batch_after_batch` is the same work as ONE batch of K
+    at a time (builders, synthesis, release in turn). The blocks' four queues are resident in HBM when the clock starts
     (zkw_block_inputs.queues_on_device: the contract's "inputs already resident"); `host_inputs` repeats one batch with host arrays.
-    With N GPUs the K x N blocks are sharded over the ranks by zkw_blocks_run_sharded (round-robin, nothing replicated) and every block's
-    closed-form records are gathered to rank 0 (zkw_blocks_gather_closed_form_inputs), batch after batch."""
+    With N GPUs the blocks of every batch are sharded over the ranks by zkw_blocks_run_sharded (round-robin, nothing replicated) and every
+    block's closed-form records are gathered to rank 0 (zkw_blocks_gather_closed_form_inputs), batch after batch."""
+    import threading
+
     K = int(os.environ.get("ZKW_BATCHED_BLOCKS", K))
+    Kb = max(1, K // 2)  # blocks per batch and GPU in the overlapped schedule
     distinct_host = [blk] + [synthetic.block_production(seed=2 + k) for k in range(3)]
     distinct = [native.Block.queues_to_device(b, local_rank) for b in distinct_host]
-    pick = lambda pool: [pool[(k // world) % len(pool)] for k in range(K * world)]  # noqa: E731
-    templates = native.Block.prepare_many(local_rank, pick(distinct))  # the input structs, once: a service builds them as its blocks arrive
+    pick = lambda pool, n: [pool[(k // world) % len(pool)] for k in range(n * world)]  # noqa: E731
     dev = torch.device("cuda", local_rank)
 
     def build(tpl):
         return native.Block.run_prepared(local_rank, tpl) if world == 1 else native.Block.run_sharded_prepared(local_rank, tpl, rank, world)
 
-    def finish(bs, rep):
+    def synth(bs, rep):
         t1 = time.perf_counter()
         mine = [b for b in bs if b is not None]
         rep["instances"] += native.Block.synthesize_many(mine, 1 << 20, ring_slots=1)
-        torch.cuda.synchronize()
         t2 = time.perf_counter()
         if world > 1 and comm is not None:
             got = native.Block.gather_sharded(bs, comm, rank, world, root=0)
             rep["records"] = (rep["records"] or 0) + (sum(len(g) for g in got) if got is not None else 0)
-        t3 = time.perf_counter()
-        native.Block.free_many(mine)
-        t4 = time.perf_counter()
-        rep["synthesis_ms"].append((t2 - t1) * 1e3); rep["gather_ms"].append((t3 - t2) * 1e3); rep["release_ms"].append((t4 - t3) * 1e3)
+        rep["synthesis_ms"].append((t2 - t1) * 1e3); rep["gather_ms"].append((time.perf_counter() - t2) * 1e3)
+        return mine
 
-    def timed(tpl, n_rounds):
-        rep = {"instances": 0, "records": None, "synthesis_ms": [], "gather_ms": [], "release_ms": [], "builders_ms": []}
+    def release(mine, rep):
+        t = time.perf_counter()
+        native.Block.free_many(mine)
+        rep["release_ms"].append((time.perf_counter() - t) * 1e3)
+
+    def new_rep():
+        return {"instances": 0, "records": None, "synthesis_ms": [], "gather_ms": [], "release_ms": [], "builders_ms": []}
+
+    def in_turn(tpl, n_rounds):
+        rep = new_rep()
         parallel.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -195,36 +203,78 @@ def full_blocks_batched(local_rank, blk, K=512, rounds=3, rank=0, world=1, comm=
             tb = time.perf_counter()
             cur = build(tpl)
             rep["builders_ms"].append((time.perf_counter() - tb) * 1e3)
-            finish(cur, rep)
+            release(synth(cur, rep), rep)
         torch.cuda.synchronize()
         parallel.barrier()
-        wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-        rep["wall"] = wall
+        rep["wall"] = parallel.max_over_ranks(time.perf_counter() - t0, dev)
         rep["n_all"] = int(parallel.sum_over_ranks(rep["instances"], dev)) if world > 1 else rep["instances"]
         return rep
 
-    finish(build(templates), {"instances": 0, "records": None, "synthesis_ms": [], "gather_ms": [], "release_ms": []})  # fills the caches
-    rep = timed(templates, rounds)
+    def overlapped(tpl, n_rounds):
+        rep = new_rep()
+        box = {}
+
+        def t_build():
+            tb = time.perf_counter()
+            box["next"] = build(tpl)
+            rep["builders_ms"].append((time.perf_counter() - tb) * 1e3)
+
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t_build()
+        cur, old = box.pop("next"), None
+        for r in range(n_rounds):
+            th = []
+            if r + 1 < n_rounds:
+                th.append(threading.Thread(target=t_build))
+            if old is not None:
+                th.append(threading.Thread(target=release, args=(old, rep)))
+            for t in th:
+                t.start()
+            old = synth(cur, rep)  # (this thread: the collective of the N > 1 leg stays on the thread that owns the process group)
+            for t in th:
+                t.join()
+            cur = box.pop("next", None)
+        release(old, rep)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        rep["wall"] = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+        rep["n_all"] = int(parallel.sum_over_ranks(rep["instances"], dev)) if world > 1 else rep["instances"]
+        return rep
+
+    tpl_half = native.Block.prepare_many(local_rank, pick(distinct, Kb))  # the input structs, once: a service builds them as its blocks arrive
+    in_turn(tpl_half, 1)  # fills the caches
+    ov = overlapped(tpl_half, rounds)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     r3 = lambda v: [round(x, 1) for x in v]  # noqa: E731
-    out = {"blocks": K * world * rounds, "blocks_per_gpu_in_flight": K, "batches": rounds, "n_gpus": world, "blocks_per_s": K * world * rounds / rep["wall"],
-           "per_rank_blocks_per_s": K * rounds / rep["wall"], "synthesized_circuits_per_s": rep["n_all"] / rep["wall"], "wall_ms": rep["wall"] * 1e3,
-           "builders_ms_per_batch": r3(rep["builders_ms"]), "synthesis_ms_per_batch": r3(rep["synthesis_ms"]), "gather_ms_per_batch": r3(rep["gather_ms"]),
-           "release_ms_per_batch": r3(rep["release_ms"]), "instances_synthesized": rep["n_all"], "records_gathered": rep["records"],
+    out = {"blocks": Kb * world * rounds, "blocks_per_gpu_in_flight": 2 * Kb, "blocks_per_batch_and_gpu": Kb, "batches": rounds, "n_gpus": world,
+           "blocks_per_s": Kb * world * rounds / ov["wall"], "per_rank_blocks_per_s": Kb * rounds / ov["wall"],
+           "synthesized_circuits_per_s": ov["n_all"] / ov["wall"], "wall_ms": ov["wall"] * 1e3,
+           "builders_ms_per_batch": r3(ov["builders_ms"]), "synthesis_ms_per_batch": r3(ov["synthesis_ms"]), "gather_ms_per_batch": r3(ov["gather_ms"]),
+           "release_ms_per_batch": r3(ov["release_ms"]), "instances_synthesized": ov["n_all"], "records_gathered": ov["records"],
            "inputs": "the blocks' four queues resident in HBM (zkw_block_inputs.queues_on_device); bytecodes and input structs on the host",
            "host_threads_per_block": 0, "streams_per_block": 0,
-           "schedule": "batch after batch: builders (zkw_blocks_run: fibers of one thread, launches merged per kernel and stage), synthesis (zkw_blocks_synthesize: "
-                       "slot-owning fibers type by type, ECRecover in joint calls), release (zkw_blocks_free)",
+           "schedule": "two batches in flight: the builders of batch k + 1 (zkw_blocks_run: fibers of one thread, launches merged per kernel and stage) under the "
+                       "synthesis of batch k (zkw_blocks_synthesize: slot-owning fibers type by type, ECRecover in joint calls), the release of batch k - 1 "
+                       "(zkw_blocks_free) on a third thread; start-up and drain inside the timed region",
            "sharding": "one GPU" if world == 1 else "zkw_blocks_run_sharded (round-robin over ranks) + zkw_blocks_gather_closed_form_inputs",
-           "rccl_ranks": world if (world > 1 and comm is not None) else 0}
-    try:  # the same with the queues in host memory (PCIe inside the builders): one batch
-        del templates
-        host_tpl = native.Block.prepare_many(local_rank, pick(distinct_host))
-        h = timed(host_tpl, 1)
-        out["host_inputs"] = {"blocks_per_s": K * world / h["wall"], "builders_ms": round(h["builders_ms"][0], 1), "synthesis_ms": round(h["synthesis_ms"][0], 1),
-                              "note": "the four queues of every block as host arrays (~20 MB per block over PCIe inside zkw_blocks_run)"}
-    except Exception as e:  # noqa: BLE001 - a side figure
-        out["host_inputs"] = {"error": repr(e)}
+           "rccl_ranks": world if (world > 1 and comm is not None) else 0, "hbm_in_use_GB": (total_b - free_b) / 1e9}
+    del tpl_half
+    try:  # one batch of K at a time
+        tpl_full = native.Block.prepare_many(local_rank, pick(distinct, 2 * Kb))
+        it = in_turn(tpl_full, 2)
+        out["batch_after_batch"] = {"blocks_per_gpu_in_flight": 2 * Kb, "batches": 2, "blocks_per_s": 2 * Kb * world * 2 / it["wall"],
+                                    "builders_ms_per_batch": r3(it["builders_ms"]), "synthesis_ms_per_batch": r3(it["synthesis_ms"]),
+                                    "release_ms_per_batch": r3(it["release_ms"])}
+        del tpl_full
+        # the same with the queues in host memory (PCIe inside the builders): one batch
+        host_tpl = native.Block.prepare_many(local_rank, pick(distinct_host, 2 * Kb))
+        h = in_turn(host_tpl, 1)
+        out["host_inputs"] = {"blocks_per_s": 2 * Kb * world / h["wall"], "builders_ms": round(h["builders_ms"][0], 1), "synthesis_ms": round(h["synthesis_ms"][0], 1),
+                              "note": "one batch of %d at a time, the four queues of every block as host arrays (~20 MB per block over PCIe inside zkw_blocks_run)" % (2 * Kb)}
+    except Exception as e:  # noqa: BLE001 - side figures
+        out["side_legs_error"] = repr(e)
     return out
 
 
