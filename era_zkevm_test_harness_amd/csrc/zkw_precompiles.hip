@@ -1027,8 +1027,11 @@ int nl_launch_fill(zkw_ctx* ctx, const NlCached* nc, const NlJob* d_jobs, unsign
 // synthesis of instances of one netlist circuit: `prepare` turns the builder's records into the engine's inputs (header bits, free
 // elements, the state before every cycle) at the pointers of the jobs it is handed; `capacity` is in cycles
 using NlPrepare = std::function<int(std::vector<NlPrepJob>&)>;
+// `hold`: the caller has more launches to make into the same slots (the queue, EC and closed-form sections): the slots' layout tags are handed to
+// it uncommitted and it commits them after ITS last launch (committed here, a failure in those later launches left a slot tagged with
+// a layout whose lower sections were never written)
 int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows,
-                       const NlAfterFill& after_fill = {}) {
+                       const NlAfterFill& after_fill = {}, SlotClaims* hold = nullptr) {
     const NlCached* nc = nullptr;
     ZKW_TRY(nl_get(ctx, circuit_type, &nc));
     const nl_spec& S = nc->host.s;
@@ -1081,12 +1084,17 @@ int nl_synthesize_with(zkw_ctx* ctx, int circuit_type, const NlPrepare& prepare,
         default: ZKW_TRY((nl_launch_fill<LH_W, LH_R>(ctx, nc, d_jobs, nj, capacity, n_rows, after_fill))); break;  // 13 and 10: 3 x 26
     }
     { Prof _p(ctx, "k_nl_finish"); ZKW_LAUNCH_2D(ctx, k_nl_finish, (std::max(S.state, S.total_table_rows) + 255) / 256, nj, 256, nc->dev, d_jobs, capacity, n_rows); }
-    return claims.commit_if(launch_check("k_nl_finish"));
+    const int rc = launch_check("k_nl_finish");
+    if (rc == ZKW_OK && hold) {
+        hold->pending.insert(hold->pending.end(), claims.pending.begin(), claims.pending.end());
+        return ZKW_OK;
+    }
+    return claims.commit_if(rc);
 }
 
 // ... from the block's round records (`sha_like`: zkw_sha256_round_record, else zkw_keccak_round_record)
 int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_rounds, const std::vector<NlInstance>& inst, u32 capacity, size_t n_rows,
-                  const NlAfterFill& after_fill = {}) {
+                  const NlAfterFill& after_fill = {}, SlotClaims* hold = nullptr) {
     return nl_synthesize_with(ctx, circuit_type, [&](std::vector<NlPrepJob>& prep) {
         const size_t rec_bytes = sha_like ? sizeof(zkw_sha256_round_record) : sizeof(zkw_keccak_round_record);
         for (size_t k = 0; k < prep.size(); k++) {
@@ -1099,7 +1107,7 @@ int nl_synthesize(zkw_ctx* ctx, int circuit_type, bool sha_like, const void* d_r
         if (sha_like) { Prof _p(ctx, "k_nl_prepare"); ZKW_LAUNCH_2D(ctx, k_nl_prepare_sha, capacity + 1, nj, 128, d_prep, capacity); }
         else { Prof _p(ctx, "k_nl_prepare"); ZKW_LAUNCH_2D(ctx, k_nl_prepare_keccak, capacity + 1, nj, 256, d_prep, capacity); }
         return launch_check("k_nl_prepare");
-    }, inst, capacity, n_rows, after_fill);
+    }, inst, capacity, n_rows, after_fill, hold);
 }
 
 // the queue section of the instances nl_synthesize has just filled (include/zkw_netlist_queue.h): request-queue pops and memory-queue
@@ -1302,16 +1310,17 @@ extern "C" int zkw_keccak_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));  // public inputs of the block's instances (a20), once
     const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
     NlcfCall cf;  // the closed-form section: sponges next to the fills, the ties after them
+    SlotClaims claims;  // the slots' tags: committed after the closed-form section's last launch
     ZKW_TRY(nl_synthesize(ctx, 5, false, w->keccak_rounds, inst, w->capacity, t->n_rows, [&] {
         return nlcf_begin<CfPrecompile<ZKW_PRECOMPILE_KECCAK256>>(ctx, 5, w->instances, first_instance, inst, w->capacity, t->n_rows, &cf);
-    }));
+    }, &claims));
     NlqQueues Q{};  // the precompile calls are popped, the memory queries (unaligned reads, the digest write) pushed
     Q.q[0] = NlqQueueIn{w->requests, w->req_tails, {0}, w->n_requests};
     Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->n_queries};
     memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
     Q.round_ops = w->round_ops;
     ZKW_TRY(nlq_synthesize(ctx, 5, Q, inst, w->capacity, t->n_rows));
-    return nlcf_end(ctx, 5, cf, w->capacity, t->n_rows);
+    return claims.commit_if(nlcf_end(ctx, 5, cf, w->capacity, t->n_rows));
 }
 extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
@@ -1367,6 +1376,7 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
     EcJob* d_jobs = nullptr;
     const unsigned cb = (capacity + 1 + 63) / 64, nj = (unsigned)ni;
     // the netlist's inputs come from the EC tapes: evaluate them inside the engine's `prepare` step
+    SlotClaims claims;  // the slots' tags: committed after the EC section's stream kernel, the call's last launch
     ZKW_TRY(nl_synthesize_with(ctx, 7, [&](std::vector<NlPrepJob>& prep) {
         for (size_t k = 0; k < ni; k++)
             jobs[k] = EcJob{ws[w_of[k]]->mem_q, inst[k].first_round, inst[k].n_active, d_inputs + k * capacity * (size_t)128, d_tape + k * capacity * (size_t)EC_TAPE_PER_CYCLE,
@@ -1391,7 +1401,7 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
         }
         { Prof _p(ctx, "k_ec_prepare"); ZKW_LAUNCH_2D(ctx, k_ec_prepare, cb, nj, 64, ec->dev, d_jobs, capacity); }
         return launch_check("k_ec_prepare");
-    }, inst, capacity, n_rows));
+    }, inst, capacity, n_rows, {}, &claims));
     u32 status = 0;
     ZKW_TRY(ctx->read_small(&status, d_status, 4));
     if (status) return fail(ZKW_ERR_CHECK_FAILED, "zkw_ecrecover_synthesize: request %llu (instance %u of the call) has no witness (the accumulator of the incomplete addition met x1 == x2)",
@@ -1413,7 +1423,7 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
         ZKW_TRY(nlcf_end(ctx, 7, cf, capacity, n_rows));
     }
     { Prof _p(ctx, "k_ec_stream"); ZKW_LAUNCH_D(ctx, (k_ec_stream), "k_ec_stream", dim3((EC_ROWS_PER_CYCLE + 63) / 64, capacity, nj), 64, 0, ec->dev, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL); }
-    return launch_check("k_ec_stream");
+    return claims.commit_if(launch_check("k_ec_stream"));
 }
 
 extern "C" int zkw_ecrecover_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances, zkw_trace* t, size_t first_slot) {
@@ -1449,16 +1459,17 @@ extern "C" int zkw_sha256_round_synthesize(zkw_ctx* ctx, zkw_precompile_witness*
     ZKW_TRY(zkw_precompile_closed_forms(ctx, w, nullptr, nullptr));
     const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, w->capacity, w->n_requests != 0, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
     NlcfCall cf;
+    SlotClaims claims;  // the slots' tags: committed after the closed-form section's last launch
     ZKW_TRY(nl_synthesize(ctx, 6, true, w->sha256_rounds, inst, w->capacity, t->n_rows, [&] {
         return nlcf_begin<CfPrecompile<ZKW_PRECOMPILE_SHA256>>(ctx, 6, w->instances, first_instance, inst, w->capacity, t->n_rows, &cf);
-    }));
+    }, &claims));
     NlqQueues Q{};  // the precompile calls are popped (the head runs through the states their pushes left), the memory queries pushed
     Q.q[0] = NlqQueueIn{w->requests, w->req_tails, {0}, w->n_requests};
     Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->n_queries};
     memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
     Q.round_ops = w->round_ops;
     ZKW_TRY(nlq_synthesize(ctx, 6, Q, inst, w->capacity, t->n_rows));
-    return nlcf_end(ctx, 6, cf, w->capacity, t->n_rows);
+    return claims.commit_if(nlcf_end(ctx, 6, cf, w->capacity, t->n_rows));
 }
 extern "C" int zkw_sha256_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
@@ -1480,16 +1491,17 @@ extern "C" int zkw_code_decommitter_synthesize(zkw_ctx* ctx, zkw_decommitter_wit
     if (!w->cf_pi) ZKW_TRY(closed_form_public_inputs<CfDecommitter>(ctx, w->instances, w->n_instances, &w->cf_pi));
     const std::vector<NlInstance> inst = nl_instances(first_instance, n_instances, w->capacity, true, w->total_rounds, w->cf_pi, w->n_instances, t, first_slot);
     NlcfCall cf;
+    SlotClaims claims;  // the slots' tags: committed after the closed-form section's last launch
     ZKW_TRY(nl_synthesize(ctx, 3, true, w->sha256_rounds, inst, w->capacity, t->n_rows, [&] {
         return nlcf_begin<CfDecommitter>(ctx, 3, w->instances, first_instance, inst, w->capacity, t->n_rows, &cf);
-    }));
+    }, &claims));
     NlqQueues Q{};  // the decommit requests are popped, the code words written to memory
     Q.q[0] = NlqQueueIn{w->requests, w->dedup_tails, {0}, w->n_requests};
     Q.q[1] = NlqQueueIn{w->mem_q, w->mem_tails, {0}, w->total_words};
     memcpy(Q.q[1].init, w->mem_in.tail, sizeof w->mem_in.tail);
     Q.round_ops = w->round_ops;
     ZKW_TRY(nlq_synthesize(ctx, 3, Q, inst, w->capacity, t->n_rows));
-    return nlcf_end(ctx, 3, cf, w->capacity, t->n_rows);
+    return claims.commit_if(nlcf_end(ctx, 3, cf, w->capacity, t->n_rows));
 }
 extern "C" int zkw_code_decommitter_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
@@ -1518,6 +1530,7 @@ extern "C" int zkw_storage_application_synthesize(zkw_ctx* ctx, zkw_storage_appl
         inst[k] = NlInstance{rec[k].first_item, (u32)rec[k].num_items, w->cf_pi + COMPACT_FORM_LEN * w->n_instances + 4 * (first_instance + k), t, (first_slot + k) % t->n_slots, true};
     const u32 capacity = w->capacity;
     NlcfCall cf;
+    SlotClaims claims;  // the slots' tags: committed after the closed-form section's last launch
     ZKW_TRY(nl_synthesize_with(ctx, 10, [&](std::vector<NlPrepJob>& prep) {
         std::vector<SapWalkJob> jobs(prep.size());
         for (size_t k = 0; k < prep.size(); k++)
@@ -1530,8 +1543,8 @@ extern "C" int zkw_storage_application_synthesize(zkw_ctx* ctx, zkw_storage_appl
         return launch_check("k_sap_walk_cycles");
     }, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows, [&] {
         return nlcf_begin<CfStorageApplication>(ctx, 10, w->instances, first_instance, inst, capacity * SA_CYCLES_PER_WALK, t->n_rows, &cf);
-    }));
-    return nlcf_end(ctx, 10, cf, capacity * SA_CYCLES_PER_WALK, t->n_rows);
+    }, &claims));
+    return claims.commit_if(nlcf_end(ctx, 10, cf, capacity * SA_CYCLES_PER_WALK, t->n_rows));
 }
 extern "C" int zkw_storage_application_check_satisfied(zkw_ctx* ctx, const zkw_trace* t, size_t slot, uint32_t capacity, uint64_t* n_violations, uint64_t* first_bad) {
     if (!ctx || !t || t->ctx->device != ctx->device || slot >= t->n_slots || !n_violations || capacity == 0)
@@ -1601,7 +1614,8 @@ extern "C" int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx* ctx, const
     std::vector<NlInstance> inst(n_queues);
     for (size_t b = 0; b < n_queues; b++) inst[b] = NlInstance{roff[b], (u32)(roff[b + 1] - roff[b]), d_pi + 4 * b, t, first_slot + b, true};
     NlcfCall cf;
-    ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows, [&] { return nlcf_begin<CfLinearHasher>(ctx, 13, d_rec, 0, inst, cycles, n_rows, &cf); }));
+    SlotClaims claims;  // the slots' tags: committed after the closed-form section's last launch
+    ZKW_TRY(nl_synthesize(ctx, 13, false, d_rounds, inst, cycles, n_rows, [&] { return nlcf_begin<CfLinearHasher>(ctx, 13, d_rec, 0, inst, cycles, n_rows, &cf); }, &claims));
     {   // the queue section: every message is popped (Poseidon2 rows below the netlist, include/zkw_netlist_queue.h)
         const u64* d_tails = nullptr;
         if (total && message_tails) ZKW_TRY(ctx->in("lh_tails", message_tails, total * 4, &d_tails));
@@ -1628,7 +1642,7 @@ extern "C" int zkw_linear_hasher_synthesize_batch_with_tails(zkw_ctx* ctx, const
         }
         ZKW_TRY(nlq_synthesize(ctx, 13, per[0], inst, cycles, n_rows, &per));
     }
-    ZKW_TRY(nlcf_end(ctx, 13, cf, cycles, n_rows));
+    ZKW_TRY(claims.commit_if(nlcf_end(ctx, 13, cf, cycles, n_rows)));
     memcpy(records_out, recv.data(), n_queues * sizeof recv[0]);
     if (public_inputs_out) ZKW_TRY(ctx->read_small(public_inputs_out, d_pi, 32 * n_queues));
     return ZKW_OK;

@@ -46,7 +46,10 @@
  *     cells are copies of the last permutation's outputs 0..3.
  * What stays only committed (FREE words): everything the ties below do not name — the `completed` / `padding_round` flags and the
  * write timestamp of the internal FSMs, Keccak's byte offset / length / buffer and the decommitter's round count and length (no registers
- * for them in the queue section), the queue LENGTHS, all of StorageApplication's words.
+ * for them in the queue section), the queue LENGTHS, StorageApplication's words other than the OUTGOING root (NLCF_DESC_STORAGE_APPLICATION
+ * below ties the FSM output's current_root_hash / the observable output's new_root_hash to the state after the instance's last cycle; the root an
+ * instance STARTS from — the FSM input's / the observable input's initial_root_hash — is not tied: the trace has no register the first walk is
+ * compared with (the queue side type 10 lacks), so the chain of roots between instances is carried by the commitments only — a known gap).
  */
 #ifndef ZKW_NETLIST_CLOSED_FORM_H
 #define ZKW_NETLIST_CLOSED_FORM_H
