@@ -151,15 +151,14 @@ def full_block_gpu(local_rank, reps=3, rank=0, world=1, comm=None):
     return best, blk
 
 
-def full_blocks_batched(local_rank, blk, K=512, rounds=10, rank=0, world=1, comm=None):
-    """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once — two batches of K / 2, the builders of one under the
-    synthesis of the other. zkw_blocks_run runs a batch's builder graphs as fibers of ONE host thread and merges their launches per kernel and
-    stage (csrc/zkw_batch.h: no thread and no stream per block; the chains of a stage as one launch, longest chains first);
-    zkw_blocks_synthesize synthesizes every instance of every block — groups of slot-owning fibers going through their blocks type by type,
-    the ECRecover instances of all blocks in joint calls on two priority streams —; zkw_blocks_free releases the batch, on a third thread.
-    The figure is the blocks of the timed batches over their wall time, start-up (the first batch's builders have nothing to hide under) and
-    drain included; a first batch, which fills the library's buffer caches, is untimed. `batch_after_batch` is the same work as ONE batch of K
-    at a time (builders, synthesis, release in turn). The blocks' four queues are resident in HBM when the clock starts
+def full_blocks_batched(local_rank, blk, K=512, rounds=3, rank=0, world=1, comm=None):
+    """Throughput of WHOLE blocks: K production-capacity blocks PER GPU in flight at once, batch after batch. zkw_blocks_run runs a batch's
+    builder graphs as fibers of ONE host thread and merges their launches per kernel and stage (csrc/zkw_batch.h: no thread and no stream per
+    block; the chains of a stage as one launch, longest chains first); zkw_blocks_synthesize synthesizes every instance of every block — groups
+    of slot-owning fibers going through their blocks type by type, the ECRecover instances of all blocks in joint calls on two priority
+    streams —; zkw_blocks_free releases the batch. The figure is the blocks of the timed batches over their wall time; a first batch, which fills
+    the library's buffer caches, is untimed. `two_batches_in_flight` is the same work as two batches of K / 2 with the builders of one under
+    the synthesis of the other. The blocks' four queues are resident in HBM when the clock starts
     (zkw_block_inputs.queues_on_device: the contract's "inputs already resident"); `host_inputs` repeats one batch with host arrays.
     With N GPUs the blocks of every batch are sharded over the ranks by zkw_blocks_run_sharded (round-robin, nothing replicated) and every
     block's closed-form records are gathered to rank 0 (zkw_blocks_gather_closed_form_inputs), batch after batch."""
@@ -243,36 +242,39 @@ def full_blocks_batched(local_rank, blk, K=512, rounds=10, rank=0, world=1, comm
         rep["n_all"] = int(parallel.sum_over_ranks(rep["instances"], dev)) if world > 1 else rep["instances"]
         return rep
 
-    tpl_half = native.Block.prepare_many(local_rank, pick(distinct, Kb))  # the input structs, once: a service builds them as its blocks arrive
-    in_turn(tpl_half, 1)  # fills the caches
-    ov = overlapped(tpl_half, rounds)
+    # the input structs, once: a service builds them as its blocks arrive
+    tpl_full = native.Block.prepare_many(local_rank, pick(distinct, 2 * Kb))
+    in_turn(tpl_full, 1)  # fills the caches
+    it = in_turn(tpl_full, rounds)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     r3 = lambda v: [round(x, 1) for x in v]  # noqa: E731
-    out = {"blocks": Kb * world * rounds, "blocks_per_gpu_in_flight": 2 * Kb, "blocks_per_batch_and_gpu": Kb, "batches": rounds, "n_gpus": world,
-           "blocks_per_s": Kb * world * rounds / ov["wall"], "per_rank_blocks_per_s": Kb * rounds / ov["wall"],
-           "synthesized_circuits_per_s": ov["n_all"] / ov["wall"], "wall_ms": ov["wall"] * 1e3,
-           "builders_ms_per_batch": r3(ov["builders_ms"]), "synthesis_ms_per_batch": r3(ov["synthesis_ms"]), "gather_ms_per_batch": r3(ov["gather_ms"]),
-           "release_ms_per_batch": r3(ov["release_ms"]), "instances_synthesized": ov["n_all"], "records_gathered": ov["records"],
+    out = {"blocks": 2 * Kb * world * rounds, "blocks_per_gpu_in_flight": 2 * Kb, "batches": rounds, "n_gpus": world,
+           "blocks_per_s": 2 * Kb * world * rounds / it["wall"], "per_rank_blocks_per_s": 2 * Kb * rounds / it["wall"],
+           "synthesized_circuits_per_s": it["n_all"] / it["wall"], "wall_ms": it["wall"] * 1e3,
+           "builders_ms_per_batch": r3(it["builders_ms"]), "synthesis_ms_per_batch": r3(it["synthesis_ms"]), "gather_ms_per_batch": r3(it["gather_ms"]),
+           "release_ms_per_batch": r3(it["release_ms"]), "instances_synthesized": it["n_all"], "records_gathered": it["records"],
            "inputs": "the blocks' four queues resident in HBM (zkw_block_inputs.queues_on_device); bytecodes and input structs on the host",
            "host_threads_per_block": 0, "streams_per_block": 0,
-           "schedule": "two batches in flight: the builders of batch k + 1 (zkw_blocks_run: fibers of one thread, launches merged per kernel and stage) under the "
-                       "synthesis of batch k (zkw_blocks_synthesize: slot-owning fibers type by type, ECRecover in joint calls), the release of batch k - 1 "
-                       "(zkw_blocks_free) on a third thread; start-up and drain inside the timed region",
+           "schedule": "batch after batch: builders (zkw_blocks_run: fibers of one thread, launches merged per kernel and stage, a stage's chains as one launch, longest "
+                       "first), synthesis (zkw_blocks_synthesize: slot-owning fibers type by type, ECRecover in joint calls on priority streams), release (zkw_blocks_free)",
            "sharding": "one GPU" if world == 1 else "zkw_blocks_run_sharded (round-robin over ranks) + zkw_blocks_gather_closed_form_inputs",
            "rccl_ranks": world if (world > 1 and comm is not None) else 0, "hbm_in_use_GB": (total_b - free_b) / 1e9}
-    del tpl_half
-    try:  # one batch of K at a time
-        tpl_full = native.Block.prepare_many(local_rank, pick(distinct, 2 * Kb))
-        it = in_turn(tpl_full, 2)
-        out["batch_after_batch"] = {"blocks_per_gpu_in_flight": 2 * Kb, "batches": 2, "blocks_per_s": 2 * Kb * world * 2 / it["wall"],
-                                    "builders_ms_per_batch": r3(it["builders_ms"]), "synthesis_ms_per_batch": r3(it["synthesis_ms"]),
-                                    "release_ms_per_batch": r3(it["release_ms"])}
-        del tpl_full
+    try:
         # the same with the queues in host memory (PCIe inside the builders): one batch
         host_tpl = native.Block.prepare_many(local_rank, pick(distinct_host, 2 * Kb))
         h = in_turn(host_tpl, 1)
         out["host_inputs"] = {"blocks_per_s": 2 * Kb * world / h["wall"], "builders_ms": round(h["builders_ms"][0], 1), "synthesis_ms": round(h["synthesis_ms"][0], 1),
-                              "note": "one batch of %d at a time, the four queues of every block as host arrays (~20 MB per block over PCIe inside zkw_blocks_run)" % (2 * Kb)}
+                              "note": "one batch, the four queues of every block as host arrays (~20 MB per block over PCIe inside zkw_blocks_run)"}
+        del host_tpl, tpl_full
+        # two batches of K / 2 in flight: the builders of batch k + 1 under the synthesis of batch k, the release of batch k - 1 on a third thread.
+        # Faster on average and less even (round 6, eight runs of 8 batches: 113 - 150 blocks/s against 136 - 138 for one batch of K at a time —
+        # the chains' priority waves and the fills share SIMDs, and a step is as long as the slower of the two): reported next to the headline figure
+        tpl_half = native.Block.prepare_many(local_rank, pick(distinct, Kb))
+        ov = overlapped(tpl_half, 8)
+        out["two_batches_in_flight"] = {"blocks_per_batch_and_gpu": Kb, "batches": 8, "blocks_per_s": Kb * world * 8 / ov["wall"],
+                                        "builders_ms_per_batch": r3(ov["builders_ms"]), "synthesis_ms_per_batch": r3(ov["synthesis_ms"]),
+                                        "release_ms_per_batch": r3(ov["release_ms"]),
+                                        "note": "start-up (the first batch's builders have nothing to hide under) and drain inside the timed region"}
     except Exception as e:  # noqa: BLE001 - side figures
         out["side_legs_error"] = repr(e)
     return out

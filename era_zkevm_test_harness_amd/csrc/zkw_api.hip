@@ -71,6 +71,11 @@ struct AllocCache {
         hipError_t e = raw_alloc(host, p, cls);
         if (e != hipSuccess) {
             (void)hipGetLastError();
+            // the device (or the pinned pool) is full of buffers the cache holds idle: give them all back and try once more. Every hipFree
+            // waits for the device, so this costs seconds when thousands of buffers are cached — worth a line when it happens
+            static std::atomic<int> n_trims{0};
+            if (n_trims.fetch_add(1) < 8)
+                fprintf(stderr, "[zkw] out of %s memory at a request of %zu bytes: the allocation cache is emptied and the request retried (expect a stall)\n", host ? "pinned host" : "device", cls);
             trim();
             e = raw_alloc(host, p, cls);
         }
