@@ -1109,12 +1109,16 @@ int zkw_block_synthesize(zkw_block *b, size_t n_rows, size_t ring_slots, zkw_cir
    only the instances zkw_shard_lpt gives it (the plan covers the block's synthesizable instances in emission order). */
 int zkw_block_synthesize_sharded(zkw_block *b, size_t n_rows, size_t ring_slots, int rank, int world, zkw_circuit_fn cb,
                                  void *user, size_t *n_done);
-/* K blocks at once (after zkw_blocks_run): every synthesizable instance of every block. Differs from K calls of zkw_block_synthesize in
-   two ways: the ECRecover instances of ALL blocks are synthesized in joint calls (zkw_ecrecover_synthesize_multi: at most ec_chunk
-   instances each, 0 = 32, into a ring of their own) — a request's accumulator chain costs ~13 ms per call whatever the batch —, and the
-   other types run block by block on up to eight threads of the library, each block on its own ring of ring_slots slots. cb (may be NULL)
-   is called from those threads, possibly concurrently, with the block's index; per block the order is the reference's emission order
-   except that ECRecover instances arrive on their own. */
+/* K blocks at once (after zkw_blocks_run): every synthesizable instance of every block, each trace cell for cell what zkw_block_synthesize
+   hands out for the same (block, type, instance). How it differs from K calls of zkw_block_synthesize: (1) the ECRecover instances of ALL blocks
+   are synthesized in joint calls (zkw_ecrecover_synthesize_multi: at most ec_chunk instances each, 0 = 16, at most 64) on two threads of the
+   library with rings and priority streams of their own — a request's accumulator chain costs ~13 ms per call whatever the batch; (2) the other
+   types run on a few workers (ZKW_SYNTH_THREADS, default 3), each with ONE ring of 16 x ring_slots slots (a ring belongs to a worker, not to a
+   block: 1.28 GB a slot) and a contiguous share of the blocks: 16 fibers of the worker's thread own a slot each and go through their blocks TYPE BY
+   TYPE, in step, so that a type's fills leave as one launch per kernel over 16 instances and a slot keeps its layout from call to call
+   (csrc/zkw_batch.h). cb (may be NULL) is called from the workers' threads, possibly concurrently (one call at a time per worker), with the
+   block's index; the slot is the callee's until it returns; per block the types arrive in the reference's emission order except that ECRecover
+   instances arrive on their own, and between blocks the order is by type first. */
 typedef int (*zkw_blocks_circuit_fn)(void *user, size_t block, uint8_t circuit_type, size_t instance, const zkw_trace *trace, size_t slot,
                                      const uint64_t public_input[4]);
 int zkw_blocks_synthesize(zkw_block *const *blocks, size_t n_blocks, size_t n_rows, size_t ring_slots, size_t ec_chunk,
