@@ -394,7 +394,13 @@ int zkw_batch::run(const std::vector<std::function<int()>>& roots) {
     n_flushes = n_launches = n_jobs = n_chain_launches = n_switches = 0;
     flush_host_ms = wait_ms = 0;
     for (auto& r : roots)
-        if (make_fiber(this, r) < 0) { tl_batch = outer; return fail(ZKW_ERR_OOM, "zkw_batch: no stack for a fiber"); }
+        if (make_fiber(this, r) < 0) {
+            for (auto& f : fibers)
+                if (f->stack) munmap(f->stack, f->stack_bytes);
+            fibers.clear();  // (none of them has run)
+            tl_batch = outer;
+            return fail(ZKW_ERR_OOM, "zkw_batch: no stack for a fiber");
+        }
     static const int verbose = [] { const char* e = getenv("ZKW_BATCH_LOG"); return e ? atoi(e) : 0; }();  // 2: one line per flush
     const auto t_run = Clock::now();
     auto ms_since = [&](Clock::time_point t) { return std::chrono::duration<double, std::milli>(Clock::now() - t).count(); };

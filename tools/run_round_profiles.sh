@@ -10,7 +10,9 @@ OUT=$(cd "$OUT" && pwd)
 export TMPDIR=/tmp
 export ZKW_ROOT="$ROOT"
 # 1. the default bench (throughput leg + full-block leg + CPU legs), without a profiler
+S0=$(date +%s)
 timeout -s KILL 1800 python bench.py --steps 20 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+echo "python bench.py --steps 20: $(( $(date +%s) - S0 )) s of wall time" > "$OUT/bench_wall_time.txt"
 timeout -s KILL 900 python bench.py --pipelines 1 --no-cpu-baseline --no-full-block --no-h2d --no-sensitivity > "$OUT/bench_sequential.json" 2> "$OUT/bench_sequential.err"
 # 2. the same command under rocprofv3 --kernel-trace --stats, the batched full-block leg with its 512 blocks in flight included (round 5: that leg
 #    died inside the HIP runtime under the profiler with ~500 host threads; round 6 has one thread per batch)
@@ -112,6 +114,8 @@ fi
 # 7. K production-capacity blocks in flight at once (zkw_blocks_run + zkw_blocks_synthesize + zkw_blocks_free), batch after batch; the builders'
 #    timeline of 512 blocks (one line per flush of the batch); round 5's schedule (a thread per block, the chain service) on the same box
 for K in 1 64 128 256 512; do timeout -s KILL 600 python tools/probe_blocks_pipeline.py $K 3 seq device 2>&1 | grep "^K=" | tail -1; done > "$OUT/blocks_in_flight.txt"
+echo "two batches in flight (the builders of one under the synthesis of the other), 6 batches:" >> "$OUT/blocks_in_flight.txt"
+timeout -s KILL 600 python tools/probe_blocks_pipeline.py 256 6 overlap device 2>&1 | grep "^K=" | tail -1 >> "$OUT/blocks_in_flight.txt"
 echo "round 5's schedule (ZKW_BLOCKS_THREADS=1: a host thread per block and branch, chains through the chain service), 96 in flight:" >> "$OUT/blocks_in_flight.txt"
 ZKW_BLOCKS_THREADS=1 timeout -s KILL 600 python tools/probe_blocks_pipeline.py 96 3 seq host 2>&1 | grep "^K=" | tail -1 >> "$OUT/blocks_in_flight.txt"
 ZKW_BATCH_LOG=2 timeout -s KILL 300 python tools/probe_blocks_builders_trace.py 512 2>&1 | grep -E "zkw batch|builders of" > "$OUT/builders_timeline_512.txt"
