@@ -222,6 +222,7 @@ int make_fiber(zkw_batch* b, std::function<int()> fn) {
 
 }  // namespace
 
+static bool ensure_chain_streams(zkw_batch* b);
 // One flush: every pending launch of every fiber, position by position. Returns whether anything was sent.
 bool zkw_batch::flush() {
     const auto t0 = Clock::now();
@@ -349,6 +350,7 @@ bool zkw_batch::flush() {
             fail_flush(hipEventRecord(before, main), "hipEventRecord");
             for (int kind = 0; kind < 2 && flush_rc == ZKW_OK; kind++) {
                 if (kind == 0 ? !c.d_full : !c.d_log) continue;
+                if (!ensure_chain_streams(this)) { fail_flush(hipErrorOutOfMemory, "hipStreamCreateWithPriority"); break; }
                 hipStream_t st = chain_streams[next_chain_stream++ % chain_streams.size()];
                 fail_flush(hipStreamWaitEvent(st, before, 0), "hipStreamWaitEvent");
                 int rc = kind == 0 ? zkw_launch_chain_full(st, c.d_full, (int)c.full.size()) : zkw_launch_chain_log(st, c.d_log, (int)c.log.size());
@@ -505,27 +507,35 @@ zkw_batch* zkw_batch_create(int device) {
     zkw_batch* b = new zkw_batch();
     b->device = device;
     BatchStreams& S = batch_streams(device);
-    static const int n_chain = [] { const char* e = getenv("ZKW_BATCH_CHAIN_STREAMS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 32 ? v : 8; }();
     {
         std::lock_guard<std::mutex> g(S.mu);
         if (!S.idle_main.empty()) { b->main = S.idle_main.back(); S.idle_main.pop_back(); }
-        while ((int)b->chain_streams.size() < n_chain && !S.idle_chain.empty()) { b->chain_streams.push_back(S.idle_chain.back()); S.idle_chain.pop_back(); }
     }
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    bool ok = true;
-    if (!b->main) ok = hipStreamCreateWithFlags(&b->main, hipStreamNonBlocking) == hipSuccess;
-    while (ok && (int)b->chain_streams.size() < n_chain) {
-        hipStream_t s = nullptr;
-        ok = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) == hipSuccess;
-        if (ok) b->chain_streams.push_back(s);
-    }
-    if (!ok) {
+    if (!b->main && hipStreamCreateWithFlags(&b->main, hipStreamNonBlocking) != hipSuccess) {
         fail(ZKW_ERR_HIP, "zkw_batch: hipStreamCreate failed");
         zkw_batch_destroy(b);
         return nullptr;
     }
-    return b;
+    return b;  // (the chain streams are borrowed when the first chain launch needs them: a batch that synthesizes has none)
+}
+
+// the batch's high-priority streams for queue chains, borrowed from the device's pool on first use
+static bool ensure_chain_streams(zkw_batch* b) {
+    if (!b->chain_streams.empty()) return true;
+    static const int n_chain = [] { const char* e = getenv("ZKW_BATCH_CHAIN_STREAMS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 32 ? v : 8; }();
+    BatchStreams& S = batch_streams(b->device);
+    {
+        std::lock_guard<std::mutex> g(S.mu);
+        while ((int)b->chain_streams.size() < n_chain && !S.idle_chain.empty()) { b->chain_streams.push_back(S.idle_chain.back()); S.idle_chain.pop_back(); }
+    }
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    while ((int)b->chain_streams.size() < n_chain) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) break;
+        b->chain_streams.push_back(s);
+    }
+    return !b->chain_streams.empty();
 }
 
 void zkw_batch_destroy(zkw_batch* b) {

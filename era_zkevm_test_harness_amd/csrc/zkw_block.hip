@@ -1171,6 +1171,7 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
             int rc = zkw_trace_create_with_columns(wc, n_rows, 153, G * ring_slots, &ring);
             void* shared = zkw_device_shared_stream(blocks[0]->device);
             zkw_batch* batch = rc == ZKW_OK ? zkw_batch_create(blocks[0]->device) : nullptr;
+            log_done("worker's ring and batch ready:", th);
             if (rc != ZKW_OK || !shared || !batch) {
                 note(rc != ZKW_OK ? rc : ZKW_ERR_HIP);
                 if (batch) zkw_batch_destroy(batch);

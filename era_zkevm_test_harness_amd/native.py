@@ -1905,13 +1905,17 @@ class Block:
         assert n.value == total
         return out if rank == root else None
 
-    def check_satisfied(self, circuit_type, trace_handle, slot):
+    def check_satisfied(self, circuit_type, trace_handle, slot, ctx=None):
         """check_if_satisfied (src/tests/mod.rs:130-259) on a slot handed to a synthesize callback, through the type-dispatching
-        entry point zkw_check_satisfied: (n_violations, first_bad)"""
+        entry point zkw_check_satisfied: (n_violations, first_bad). `ctx`: the Context the check runs on — REQUIRED inside a callback of
+        synthesize_many (one per calling thread): the block's own contexts are busy there (a block's ECRecover instances arrive from another
+        thread than its other types, and both would use the block's precompile context). Default: the block's context of that type, which is
+        fine for Block.synthesize (one thread, one instance at a time)."""
         lib = load()
         bad, first = C.c_uint64(0), C.c_uint64(0)
         cap = self.capacities[circuit_type]
-        _check(lib.zkw_check_satisfied(lib.zkw_block_context(self.handle, circuit_type), circuit_type, trace_handle, slot, cap, C.byref(bad), C.byref(first)))
+        h = ctx.handle if ctx is not None else lib.zkw_block_context(self.handle, circuit_type)
+        _check(lib.zkw_check_satisfied(h, circuit_type, trace_handle, slot, cap, C.byref(bad), C.byref(first)))
         return bad.value, first.value
 
     def free(self):

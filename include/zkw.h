@@ -1118,7 +1118,10 @@ int zkw_block_synthesize_sharded(zkw_block *b, size_t n_rows, size_t ring_slots,
    TYPE, in step, so that a type's fills leave as one launch per kernel over 16 instances and a slot keeps its layout from call to call
    (csrc/zkw_batch.h). cb (may be NULL) is called from the workers' threads, possibly concurrently (one call at a time per worker), with the
    block's index; the slot is the callee's until it returns; per block the types arrive in the reference's emission order except that ECRecover
-   instances arrive on their own, and between blocks the order is by type first. */
+   instances arrive on their own, and between blocks the order is by type first. The callee must NOT use the blocks' contexts
+   (zkw_block_context): they are at work on the blocks' other instances — a block's ECRecover instances arrive from another thread than its
+   Keccak / SHA-256 / decommitter instances, which share the block's precompile context. A check (zkw_check_satisfied) or a read
+   (zkw_trace_get) inside cb takes a context of the calling thread's own. */
 typedef int (*zkw_blocks_circuit_fn)(void *user, size_t block, uint8_t circuit_type, size_t instance, const zkw_trace *trace, size_t slot,
                                      const uint64_t public_input[4]);
 int zkw_blocks_synthesize(zkw_block *const *blocks, size_t n_blocks, size_t n_rows, size_t ring_slots, size_t ec_chunk,

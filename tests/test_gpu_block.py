@@ -342,15 +342,21 @@ def test_blocks_run_512_in_flight_heterogeneous(ctx):
         for key in exp:
             assert got[key] == exp[key], (k, key)
     # every instance of the first 64 blocks (eight of each shape) through zkw_blocks_synthesize, checked as it is handed out
-    bad, lock = [], threading.Lock()
+    bad, lock, local, checkers = [], threading.Lock(), threading.local(), []
 
     def cb(bi, t, i, tr, s, pi):
-        v = many[bi].check_satisfied(t, tr, s)[0]
+        if not hasattr(local, "ctx"):  # a checker context per calling thread: the blocks' own contexts are busy (include/zkw.h, zkw_blocks_synthesize)
+            local.ctx = nv.Context(0)
+            with lock:
+                checkers.append(local.ctx)
+        v = many[bi].check_satisfied(t, tr, s, ctx=local.ctx)[0]
         with lock:
             bad.append((bi, t, i, v))
 
     n = nv.Block.synthesize_many(many[:64], 1 << 18, ring_slots=1, callback=cb)
     assert n == len(bad) and n >= 64 * 9 and not any(v for *_x, v in bad), [x for x in bad if x[3]][:5]
+    for c in checkers:
+        c.close()
     nv.Block.free_many(many)
 
 
@@ -380,10 +386,14 @@ def test_blocks_synthesize_many_equals_block_by_block(ctx):
     ref = {}
     for bi, m in enumerate(many):
         m.synthesize(n_rows, ring_slots=2, callback=lambda t, i, tr, s, pi, bi=bi: ref.__setitem__((bi, t, i), (digest(tr, s, t), tuple(pi))))
-    got, bad, lock = {}, [], threading.Lock()
+    got, bad, lock, local, checkers = {}, [], threading.Lock(), threading.local(), []
 
     def cb(bi, t, i, tr, s, pi):
-        d, v = digest(tr, s, t), many[bi].check_satisfied(t, tr, s)[0]
+        if not hasattr(local, "ctx"):  # a checker context per calling thread: the blocks' own contexts are busy (include/zkw.h, zkw_blocks_synthesize)
+            local.ctx = nv.Context(0)
+            with lock:
+                checkers.append(local.ctx)
+        d, v = digest(tr, s, t), many[bi].check_satisfied(t, tr, s, ctx=local.ctx)[0]
         with lock:
             got[(bi, t, i)] = (d, tuple(pi))
             bad.append(v)
