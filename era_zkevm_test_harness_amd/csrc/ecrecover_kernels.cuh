@@ -29,12 +29,15 @@ struct EcJob {
     u64 first_request;            // of the instance
     u32 n_active;                 // requests of the instance; cycles beyond are idle (zero inputs)
     uint8_t* inputs;              // [capacity][128]: the value bytes of the four reads of every cycle (k_ec_inputs)
-    u64* tape;                    // [capacity][EC_TAPE_PER_CYCLE]
+    u64* tape;                    // [EC_TAPE_PER_CYCLE][ec_tape_stride(capacity)]: value t of cycle c at tape[t * stride + c]
     u64* trace;                   // the slot
     uint8_t* hdr_bits;            // the netlist's inputs (NlPrepJob): [capacity]
     uint8_t* free_elems;          // [capacity][EK_FREE_PER_CYCLE]
     uint8_t* state_before;        // [capacity + 1][200]
 };
+// the cycles of an instance are interleaved on its tape: the lanes of a wave are cycles (k_ec_chain, k_ec_segments), or rows x cycles
+// (k_ec_stream), and value t of the instance's cycles shares one cache line (capacity 7: 56 of 64 bytes) instead of seven 4 MB apart
+__host__ __device__ __forceinline__ u32 ec_tape_stride(u32 capacity) { return (capacity + 7u) & ~7u; }
 
 // grid (cycles, jobs) x 128: input byte k of cycle c = value byte k % 32 (little end first) of read k / 32; zeros for an idle cycle
 static __device__ __forceinline__ void k_ec_inputs(const VB& vb, const EcJob* __restrict__ jobs) {
@@ -54,7 +57,7 @@ static __device__ __forceinline__ void k_ec_tape(const VB& vb, const ec_spec* __
     const u32 c = vb.x * blockDim.x + threadIdx.x;
     if (c >= capacity) return;
     const ec_spec S = *Sp;
-    if (ec_eval_cycle(&S, j.inputs + (size_t)c * 128, j.tape + (size_t)c * EC_TAPE_PER_CYCLE, &s_ws[threadIdx.x])) atomicMax(status, 1u + (vb.y << 16 | c));
+    if (ec_eval_cycle_strided(&S, j.inputs + (size_t)c * 128, j.tape + c, ec_tape_stride(capacity), &s_ws[threadIdx.x])) atomicMax(status, 1u + (vb.y << 16 | c));
 }
 
 // ---- the base field of secp256k1 for the accumulator chain: OUTLINED multiplication ------------------------------------------------
@@ -197,41 +200,54 @@ __device__ __forceinline__ void jmadd(ec_u256& X, ec_u256& Y, ec_u256& Z, const 
 
 // ---- the fast form of the tape: the accumulator's trajectory first, then every segment on its own lane ------------------------------
 // The serial kernel above spends its time in ~550 modular inversions per cycle (every quotient lambda of the affine additions), one after
-// the other, because segment k needs the accumulator segment k - 1 leaves. The trajectory does not need the quotients: k_ec_chain runs
-// the PRE segment, then the same double-and-add / table additions in JACOBIAN coordinates (no inversion), converts all 288 points with
-// ONE inversion (Montgomery's trick) and writes them where the segments' `out` states live on the tape; with every segment's input
-// state in place, k_ec_segments evaluates the 289 remaining segments of every cycle side by side (their own out cells are rewritten with
-// the same values). Same tape, bit for bit.
-struct EcChainScratch { ec_jac* pts; ec_u256* pre; };  // [cycles of the call][EC_CHAIN_POINTS]
-constexpr u32 EC_CHAIN_POINTS = 288;                    // 256 double-and-add steps + 32 table additions
+// the other, because segment k needs the accumulator segment k - 1 leaves. The trajectory does not need the quotients:
+//   k_ec_chain    a lane per cycle: the MAIN items of the PRE segment (what the globals — R, the bits of u2, the bytes of u1 — need: 262 of
+//                 its 1 445 items, tools/gen_ecrecover_circuit.py split_pre), then the same double-and-add / table additions in JACOBIAN
+//                 coordinates (no inversion): 288 points;
+//   k_ec_affine   a lane per (cycle, point): the point to affine with an inversion of its own (288 x cycles lanes side by side cost what
+//                 one costs; the serial Montgomery batch of round 5 was 2 ms of the chain's lane) onto the tape, where the segments'
+//                 `out` states live;
+//   k_ec_segments with every segment's input state in place, the 289 remaining segments of every cycle and the other parts of PRE side
+//                 by side (their own out cells are rewritten with the same values).
+// Same tape, bit for bit (tests/test_ec_library_evaluator_host.py walks the library's evaluator in this order on the host).
+struct EcChainScratch { ec_jac* pts; };  // [cycles of the call][EC_CHAIN_POINTS]
+constexpr u32 EC_CHAIN_POINTS = 288;     // 256 double-and-add steps + 32 table additions
+constexpr u32 EC_PRE_PART_ITEMS[EC_PRE_PARTS] = EC_PRE_PART_ITEMS_INIT;
 
-__device__ __forceinline__ ec_u256 ec_load_limbs(const u64* __restrict__ tape, const uint32_t* __restrict__ idx) {
+__device__ __forceinline__ ec_u256 ec_load_limbs(const u64* __restrict__ tape, size_t ts, const uint32_t* __restrict__ idx) {
     ec_u256 r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.w[i] = (u32)tape[idx[2 * i]] | ((u32)tape[idx[2 * i + 1]] << 16);
+    for (int i = 0; i < 8; i++) r.w[i] = (u32)tape[idx[2 * i] * ts] | ((u32)tape[idx[2 * i + 1] * ts] << 16);
     return r;
 }
 
 // grid (cycles / EC_TAPE_LANES, jobs): a lane per cycle
 static __device__ __forceinline__ void k_ec_chain(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
-    __builtin_amdgcn_s_setprio(3);  // a request's accumulator chain is one lane and 13 ms of dependent instructions: its wave issues before whatever
-                                    // shares the SIMD (another call's segment / stream kernels when two calls are in flight)
+    __builtin_amdgcn_s_setprio(3);  // a request's accumulator chain is one lane and milliseconds of dependent instructions: its wave issues before
+                                    // whatever shares the SIMD (another call's segment / stream kernels when two calls are in flight)
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
     const EcJob j = jobs[vb.y];
     const u32 c = vb.x * blockDim.x + threadIdx.x;
     if (c >= capacity) return;
     const ec_spec S = *Sp;
     ec_ws* W = &s_ws[threadIdx.x];
-    u64* tape = j.tape + (size_t)c * EC_TAPE_PER_CYCLE;
+    const size_t ts = ec_tape_stride(capacity);
+    u64* tape = j.tape + c;
     ec_eval_ctx E;
-    E.S = &S; E.tape = tape; E.in = j.inputs + (size_t)c * 128; E.W = W;
+    E.S = &S; E.tape = tape; E.ts = (u32)ts; E.in = j.inputs + (size_t)c * 128; E.W = W;
     E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
-    if (const int bad = ec_eval_segment(&E, S.runs[0].type)) { atomicMax(status, 1u + (vb.y << 16 | c)); (void)bad; return; }
-    const ec_mod M = ec_modulus(0);
+    if (const int bad = ec_eval_items(&E, S.runs[0].type, 0, EC_PRE_PART_ITEMS[0])) { atomicMax(status, 1u + (vb.y << 16 | c)); (void)bad; return; }
     const size_t slot = (size_t)vb.y * capacity + c;
     ec_jac* pts = sc.pts + slot * EC_CHAIN_POINTS;
-    ec_u256* pre = sc.pre + slot * EC_CHAIN_POINTS;
-    const ec_u256 rx = ec_load_limbs(tape, S.globs + EC_GL_RX), ry = ec_load_limbs(tape, S.globs + EC_GL_RY);
+    const ec_u256 rx = ec_load_limbs(tape, ts, S.globs + EC_GL_RX), ry = ec_load_limbs(tape, ts, S.globs + EC_GL_RY);
+    u32 bits[8];  // of u2, bit 255 - k = step k: loaded once (a load per step would be two dependent ones inside the serial loop)
+#pragma unroll
+    for (int wd = 0; wd < 8; wd++) {
+        u32 v = 0;
+#pragma unroll
+        for (int b = 0; b < 32; b++) v |= (u32)(tape[S.globs[EC_GL_BITS + 32 * wd + b] * ts] & 1) << b;
+        bits[wd] = v;
+    }
     ec_u256 one = ec_zero256(), ax, ay, az;
     one.w[0] = 1;
 #pragma unroll
@@ -240,13 +256,21 @@ static __device__ __forceinline__ void k_ec_chain(const VB& vb, const ec_spec* _
         ay.w[i] = S.bigs[EC_BIG_OY * 16 + 2 * i] | (S.bigs[EC_BIG_OY * 16 + 2 * i + 1] << 16);
     }
     az = one;
-    for (u32 k = 0; k < 256; k++) {
-        ecf::jdbl(ax, ay, az);
-        if (tape[S.globs[EC_GL_BITS + 255 - k]]) ecf::jmadd(ax, ay, az, rx, ry);
-        pts[k].x = ax; pts[k].y = ay; pts[k].z = az;
+#pragma unroll 1
+    for (int wd = 7; wd >= 0; wd--) {
+        const u32 word = bits[7];  // (the word of this pass: the array is rotated below so that every index is a constant)
+#pragma unroll 1
+        for (int b = 31; b >= 0; b--) {
+            const u32 k = 255u - (32u * (u32)wd + (u32)b);
+            ecf::jdbl(ax, ay, az);
+            if ((word >> b) & 1) ecf::jmadd(ax, ay, az, rx, ry);
+            pts[k].x = ax; pts[k].y = ay; pts[k].z = az;
+        }
+#pragma unroll
+        for (int i = 7; i > 0; i--) bits[i] = bits[i - 1];
     }
     for (u32 C = 0; C < 32; C++) {
-        const u32 b = (u32)tape[S.globs[EC_GL_U1 + C]];
+        const u32 b = (u32)tape[S.globs[EC_GL_U1 + C] * ts];
         if (b) {  // minus byte * 2^(8C) * G: the table point with its y negated
             ec_u256 tx, ty;
 #pragma unroll
@@ -259,48 +283,62 @@ static __device__ __forceinline__ void k_ec_chain(const VB& vb, const ec_spec* _
         }
         pts[256 + C].x = ax; pts[256 + C].y = ay; pts[256 + C].z = az;
     }
-    // all 288 points to affine with one inversion; a point at infinity has no affine form (and the circuit no witness)
-    ec_u256 run = one;
-    for (u32 k = 0; k < EC_CHAIN_POINTS; k++) {
-        pre[k] = run;
-        const ec_u256 z = pts[k].z;
-        if (ec_is_zero8(&z)) { atomicMax(status, 1u + (vb.y << 16 | c)); return; }
-        run = ecf::mul(run, z);
-    }
-    ec_u256 inv = ec_invmod(&run, &M, W);  // binary extended Euclid (include/zkw_ecrecover.h)
-    for (int k = (int)EC_CHAIN_POINTS - 1; k >= 0; k--) {
-        const ec_u256 px = pts[k].x, py = pts[k].y, pz = pts[k].z, pk = pre[k];
-        const ec_u256 zi = ecf::mul(inv, pk);
-        inv = ecf::mul(inv, pz);
-        const ec_u256 zi2 = ecf::mul(zi, zi), zi3 = ecf::mul(zi2, zi);
-        const ec_u256 x = ecf::mul(px, zi2), y = ecf::mul(py, zi3);
-        const u32 run_i = k < 256 ? 1u : 2u, inst = k < 256 ? (u32)k : (u32)k - 256u;
-        const ec_seg_type& T = S.types[S.runs[run_i].type];
-        u64* seg = tape + S.runs[run_i].tape0 + inst * T.n_tape;
-        const uint32_t* outs = S.outs + T.out0;
+}
+
+// grid (points x cycles of the call / 64): a lane per (cycle, point) — the point to affine, onto the tape where the `out` state of its
+// segment lives. A point at infinity has no affine form (and the circuit no witness)
+static __device__ __forceinline__ void k_ec_affine(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, u32* status, EcChainScratch sc) {
+    const u32 lane = vb.x * blockDim.x + threadIdx.x;
+    if (lane >= n_cycles * EC_CHAIN_POINTS) return;
+    const u32 cyc = lane / EC_CHAIN_POINTS, k = lane % EC_CHAIN_POINTS;
+    const u32 job = cyc / capacity, c = cyc % capacity;
+    const ec_spec& S = *Sp;
+    const ec_jac P = sc.pts[(size_t)cyc * EC_CHAIN_POINTS + k];
+    if (ec_is_zero8(&P.z)) { atomicMax(status, 1u + (job << 16 | c)); return; }
+    const ec_mod M = ec_modulus(0);
+    const ec_u256 zi = ec_invmod(&P.z, &M, nullptr);  // binary extended Euclid, registers only (include/zkw_ecrecover.h)
+    const ec_u256 zi2 = ecf::mul(zi, zi), zi3 = ecf::mul(zi2, zi);
+    const ec_u256 x = ecf::mul(P.x, zi2), y = ecf::mul(P.y, zi3);
+    const u32 run_i = k < 256 ? 1u : 2u, inst = k < 256 ? k : k - 256u;
+    const ec_seg_type& T = S.types[S.runs[run_i].type];
+    const size_t ts = ec_tape_stride(capacity);
+    u64* seg = jobs[job].tape + c + (size_t)(S.runs[run_i].tape0 + inst * T.n_tape) * ts;
+    const uint32_t* outs = S.outs + T.out0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            seg[outs[2 * i]] = x.w[i] & 0xFFFFu; seg[outs[2 * i + 1]] = x.w[i] >> 16;
-            seg[outs[16 + 2 * i]] = y.w[i] & 0xFFFFu; seg[outs[16 + 2 * i + 1]] = y.w[i] >> 16;
-        }
+    for (int i = 0; i < 8; i++) {
+        seg[outs[2 * i] * ts] = x.w[i] & 0xFFFFu; seg[outs[2 * i + 1] * ts] = x.w[i] >> 16;
+        seg[outs[16 + 2 * i] * ts] = y.w[i] & 0xFFFFu; seg[outs[16 + 2 * i + 1] * ts] = y.w[i] >> 16;
     }
 }
 
-// grid (segments after PRE = 289, lanes' chunks of the call's cycles): lane = one cycle of the call (job-major), block = one segment,
-// so that a wave runs ONE item list
-static __device__ __forceinline__ void k_ec_segments(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, u32* status) {
+// grid (segments after PRE = 289, then PRE's parts after MAIN; lanes' chunks of the call's cycles): lane = one cycle of the call (job-major),
+// block = one segment (or one part of PRE), so that a wave runs ONE item list. The workspace is 476 bytes a lane: five workgroups on a CU,
+// the 290 x (cycles / 64) workgroups of a 32-instance call all resident at once (they are latency-bound: dependent loads of the item walk)
+static __device__ __forceinline__ void k_ec_segments(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, u32 n_segments, u32* status) {
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
     const u32 lane = vb.y * blockDim.x + threadIdx.x;
     if (lane >= n_cycles) return;
     const u32 job = lane / capacity, c = lane % capacity;
     const EcJob j = jobs[job];
     const ec_spec S = *Sp;
+    ec_eval_ctx E;
+    E.S = &S; E.tape = j.tape + c; E.ts = ec_tape_stride(capacity); E.in = j.inputs + (size_t)c * 128; E.W = &s_ws[threadIdx.x];
+    if (vb.x >= n_segments) {  // a part of PRE after MAIN
+        const u32 part = vb.x - n_segments + 1;
+        u32 first = 0, count = 0;
+#pragma unroll
+        for (u32 p = 0; p < EC_PRE_PARTS; p++) {
+            if (p < part) first += EC_PRE_PART_ITEMS[p];
+            if (p == part) count = EC_PRE_PART_ITEMS[p];
+        }
+        E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
+        if (ec_eval_items(&E, S.runs[0].type, first, count)) atomicMax(status, 1u + (job << 16 | c));
+        return;
+    }
     u32 seg = vb.x, run = 1;
     while (seg >= S.runs[run].count) { seg -= S.runs[run].count; run++; }
     u32 prun, pinst;
     ec_prev_segment(&S, run, seg, &prun, &pinst);
-    ec_eval_ctx E;
-    E.S = &S; E.tape = j.tape + (size_t)c * EC_TAPE_PER_CYCLE; E.in = j.inputs + (size_t)c * 128; E.W = &s_ws[threadIdx.x];
     E.base = S.runs[run].tape0 + seg * S.types[S.runs[run].type].n_tape;
     E.prev_base = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape;
     E.prev_type = S.runs[prun].type;
@@ -317,14 +355,15 @@ static __device__ __forceinline__ void k_ec_prepare(const VB& vb, const ec_spec*
         for (int k = 0; k < 200; k++) j.state_before[k] = 0;
     if (c == capacity) return;
     const ec_spec& S = *Sp;
-    const u64* tape = j.tape + (size_t)c * EC_TAPE_PER_CYCLE;
-    const u64 ok = tape[S.globs[EC_GL_OK]], mask = tape[S.globs[EC_GL_MASK]];
+    const size_t ts = ec_tape_stride(capacity);
+    const u64* tape = j.tape + c;
+    const u64 ok = tape[S.globs[EC_GL_OK] * ts], mask = tape[S.globs[EC_GL_MASK] * ts];
     uint8_t* f = j.free_elems + (size_t)c * EK_FREE_PER_CYCLE;
     u64 st[25];
     for (int k = 0; k < 25; k++) st[k] = 0;
     const u32 post0 = S.runs[EC_NUM_RUNS - 1].tape0;
     for (int k = 0; k < 64; k++) {
-        const u64 b = tape[post0 + S.key_byte[k]];
+        const u64 b = tape[(post0 + S.key_byte[k]) * ts];
         f[k] = (uint8_t)b;
         st[k / 8] |= b << (8 * (k % 8));
     }
@@ -342,40 +381,82 @@ static __device__ __forceinline__ void k_ec_prepare(const VB& vb, const ec_spec*
 
 #define EC_TR(col, row) trace[(size_t)(col) * n_rows + (size_t)(row)]
 
-// grid (rows of a cycle / 64, cycles, jobs): a lane per row
-static __device__ __forceinline__ void k_ec_stream(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, u32 mult_col) {
+// ---- the rows: every cell of a row is a reference (into the cycle's tape, an input byte) or a constant. The references are RESOLVED once
+// per device (zkw_precompiles.hip ec_get: segment instance, previous segment, instance-dependent globals all folded in), so the kernel
+// does no decoding: entry = kind << 30 | payload — 0 a constant (empty cells: 0), 1 a tape value of the cycle, 2 an input byte.
+struct EcStreamDev {
+    const u32* refs;            // [EC_ROW_CELLS][EC_ROWS_PER_CYCLE]
+    const uint16_t* row_table;  // [EC_ROWS_PER_CYCLE]: the table the row's 16 slots look up (0: none)
+    const uint16_t* xor_index;  // [EC_ROWS_PER_CYCLE]: the row's place among the cycle's Xor8 rows (the others: 0xFFFF)
+    u32 n_xor_rows;
+};
+// grid (rows of a cycle / 64, cycles / 8, jobs) x 512: a lane per (row, cycle), the cycle fastest — eight neighbouring lanes read value t of
+// eight cycles from one line of the interleaved tape, and a wave stores eight rows of each of its cycles (64 contiguous bytes per cycle).
+// Multiplicities: the Xor8 lookups (16 per row on most rows: 27 M of a 32-instance call) leave 16-bit keys behind for k_ec_hist — as
+// global atomics on the multiplicity column they were 1.7 of the kernel's 3.8 ms; the FixedBaseMul lookups (8 per FIX segment) stay atomics.
+constexpr int EC_STREAM_ROWS = 64, EC_STREAM_THREADS = 8 * EC_STREAM_ROWS;
+static __device__ __forceinline__ void k_ec_stream(const VB& vb, EcStreamDev sd, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, u32 mult_col, uint16_t* __restrict__ keybuf) {
     const EcJob j = jobs[vb.z];
-    const u32 c = vb.y, r = vb.x * blockDim.x + threadIdx.x;
-    if (r >= EC_ROWS_PER_CYCLE) return;
-    const ec_spec& S = *Sp;
+    const u32 c = vb.y * 8 + (threadIdx.x & 7), r = vb.x * EC_STREAM_ROWS + (threadIdx.x >> 3);
+    if (r >= EC_ROWS_PER_CYCLE || c >= capacity) return;
     u64* trace = j.trace;
     const uint8_t* in = j.inputs + (size_t)c * 128;  // (only the PRE segment's rows name input bytes)
-    u32 run, inst, row;
-    ec_locate_row(&S, r, &run, &inst, &row);
-    const ec_seg_type& T = S.types[S.runs[run].type];
-    u32 prun, pinst;
-    ec_prev_segment(&S, run, inst, &prun, &pinst);
-    const u32 base = S.runs[run].tape0 + inst * T.n_tape, pbase = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape, ptype = S.runs[prun].type;
-    const u64* tape = j.tape + (size_t)c * EC_TAPE_PER_CYCLE;
-    const uint32_t* cells = S.cells + T.cell0 + (size_t)row * EC_ROW_CELLS;
+    const size_t ts = ec_tape_stride(capacity);
+    const u64* tape = j.tape + c;
+    const u32* refs = sd.refs + r;
     const size_t tr = first_row + (size_t)c * EC_ROWS_PER_CYCLE + r;
-    const u32 tb = ec_row_table(&S, run, inst, row);
-    u64 key_a = 0;
-#pragma unroll 4
-    for (u32 col = 0; col < EC_ROW_CELLS; col++) {
-        const u32 ref = cells[col];
-        u64 v = 0;
-        if (ref != EC_NONE) {
-            const u32 t = ec_ref_tape(&S, ref, base, pbase, ptype, inst);
-            v = t != EC_NONE ? tape[t] : ec_ref_const(&S, ref, in);
-        }
-        EC_TR(col, tr) = v;
-        if (tb && col >= EC_G) {  // the row's lookups: slot = (col - 80) / 3, inputs are its first two cells
-            const u32 k = (col - EC_G) % EC_W;
-            if (k == 0) key_a = v;
-            else if (k == 1) atomicAdd(reinterpret_cast<unsigned long long*>(&EC_TR(mult_col, ec_table_key(tb, key_a, v))), 1ull);
+    auto value = [&](u32 col) -> u64 {
+        const u32 e = refs[(size_t)col * EC_ROWS_PER_CYCLE], a = e & 0x3FFFFFFFu;
+        return (e >> 30) == 0 ? (u64)a : (e >> 30) == 1 ? tape[a * ts] : (u64)in[a];
+    };
+#pragma unroll 8
+    for (u32 col = 0; col < EC_G; col++) EC_TR(col, tr) = value(col);
+    const u32 tb = sd.row_table[r];
+    u32 keys[EC_R / 2];
+#pragma unroll
+    for (u32 slot = 0; slot < EC_R; slot++) {  // the row's lookups: the inputs of a slot are its first two cells
+        const u32 col = EC_G + EC_W * slot;
+        const u64 a = value(col), b = value(col + 1), o = value(col + 2);
+        EC_TR(col, tr) = a;
+        EC_TR(col + 1, tr) = b;
+        EC_TR(col + 2, tr) = o;
+        const u32 key = (u32)a | ((u32)b << 8);
+        if (slot & 1) keys[slot / 2] |= key << 16;
+        else keys[slot / 2] = key;
+        if (tb > EC_T_XOR8) atomicAdd(reinterpret_cast<unsigned long long*>(&EC_TR(mult_col, ec_table_key(tb, a, b))), 1ull);
+    }
+    if (tb == EC_T_XOR8) {
+        uint4* dst = reinterpret_cast<uint4*>(keybuf + (((size_t)vb.z * capacity + c) * sd.n_xor_rows + sd.xor_index[r]) * EC_R);
+        dst[0] = make_uint4(keys[0], keys[1], keys[2], keys[3]);
+        dst[1] = make_uint4(keys[4], keys[5], keys[6], keys[7]);
+    }
+}
+
+// grid (2 halves of the Xor8 table, jobs) x 1024: an instance's Xor8 keys (k_ec_stream) counted in LDS, the half's 32 768 bins added onto the
+// instance's multiplicity column — this workgroup's rows of it and nobody else's at that time (the netlist's own multiplicities are
+// there already: k_nl_finish, earlier on the stream)
+constexpr int EC_HIST_THREADS = 1024, EC_HIST_HALF = 32768;
+static __device__ __forceinline__ void k_ec_hist(const VB& vb, const EcJob* __restrict__ jobs, u32 capacity, u32 n_xor_rows, size_t n_rows, u32 mult_col, const uint16_t* __restrict__ keybuf) {
+    __shared__ u32 s_bins[EC_HIST_HALF];
+    const u32 half = vb.x, t = threadIdx.x;
+    for (u32 i = t; i < EC_HIST_HALF; i += EC_HIST_THREADS) s_bins[i] = 0;
+    __syncthreads();
+    const size_t per_job = (size_t)capacity * n_xor_rows * EC_R;  // a multiple of 16 keys
+    const uint4* keys = reinterpret_cast<const uint4*>(keybuf + (size_t)vb.y * per_job);
+    for (size_t i = t; i < per_job / 8; i += EC_HIST_THREADS) {
+        const uint4 v = keys[i];
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
+            if ((lo >> 15) == half) atomicAdd(&s_bins[lo & 32767u], 1u);
+            if ((hi >> 15) == half) atomicAdd(&s_bins[hi & 32767u], 1u);
         }
     }
+    __syncthreads();
+    u64* trace = jobs[vb.y].trace;
+    for (u32 i = t; i < EC_HIST_HALF; i += EC_HIST_THREADS)
+        if (const u32 n = s_bins[i]) EC_TR(mult_col, (size_t)half * EC_HIST_HALF + i) += n;  // (Xor8 sits at row 0 of the stacked tables: ec_table_key)
 }
 
 // ------------------------------------------------------------------------------------------------ checker

@@ -1189,7 +1189,7 @@ int nlcf_end(zkw_ctx* ctx, int circuit_type, const NlcfCall& call, u32 cycles, s
 }
 
 // ---- the EC section of the ECRecover circuit (ecrecover_kernels.cuh): the spec on the device, once per device
-struct EcCached { ec_spec host; const ec_spec* dev = nullptr; u32 segments_per_cycle = 0; };
+struct EcCached { ec_spec host; const ec_spec* dev = nullptr; u32 segments_per_cycle = 0; EcStreamDev stream{}; };
 std::map<int, EcCached>& ec_cache() { static auto* m = new std::map<int, EcCached>(); return *m; }
 size_t ec_first_row(u32 capacity) { return nlq_used_rows(nl_host_spec(7), nlq_desc_of(7), capacity); }
 size_t ec_used_rows(u32 capacity) { return ec_first_row(capacity) + (size_t)capacity * EC_ROWS_PER_CYCLE; }
@@ -1221,6 +1221,39 @@ int ec_get(zkw_ctx* ctx, const EcCached** out) {
     ZKW_TRY(nl_to_device(&d, 1, &dd));
     c.host = ec_spec{h_ecs_types, h_ecs_runs, h_ecs_items, h_ecs_item_index, h_ecs_cells, h_ecs_homes, h_ecs_outs, h_ecs_rowtab, h_ecs_globs, h_ecs_bigs, h_ecs_in_home, h_ecs_key_byte, fixed->data()};
     for (u32 r = 0; r < EC_NUM_RUNS; r++) c.segments_per_cycle += h_ecs_runs[r].count;
+    {   // the rows of a cycle with every reference resolved (k_ec_stream): kind << 30 | payload, column-major
+        std::vector<u32> refs((size_t)EC_ROW_CELLS * EC_ROWS_PER_CYCLE);
+        std::vector<uint16_t> row_table(EC_ROWS_PER_CYCLE), xor_index(EC_ROWS_PER_CYCLE, 0xFFFF);
+        u32 n_xor = 0;
+        for (u32 r = 0; r < EC_ROWS_PER_CYCLE; r++) {
+            u32 run, inst, row, prun, pinst;
+            ec_locate_row(&c.host, r, &run, &inst, &row);
+            ec_prev_segment(&c.host, run, inst, &prun, &pinst);
+            const ec_seg_type& T = h_ecs_types[h_ecs_runs[run].type];
+            const u32 base = h_ecs_runs[run].tape0 + inst * T.n_tape, pbase = h_ecs_runs[prun].tape0 + pinst * h_ecs_types[h_ecs_runs[prun].type].n_tape;
+            for (u32 col = 0; col < EC_ROW_CELLS; col++) {
+                const u32 ref = h_ecs_cells[T.cell0 + (size_t)row * EC_ROW_CELLS + col];
+                u32 e = 0;  // an empty cell: the constant 0
+                if (ref != EC_NONE) {
+                    const u32 t = ec_ref_tape(&c.host, ref, base, pbase, h_ecs_runs[prun].type, inst);
+                    if (t != EC_NONE) e = 1u << 30 | t;
+                    else if ((ref >> 28) == EC_K_IN) e = 2u << 30 | (ref & 0x0FFFFFFFu);
+                    else {
+                        const uint64_t v = ec_ref_const(&c.host, ref, nullptr);
+                        if (v >> 30) return fail(ZKW_ERR_INVALID, "ECRecover spec: a constant cell of %llu does not fit the resolved row table", (unsigned long long)v);
+                        e = (u32)v;
+                    }
+                }
+                refs[(size_t)col * EC_ROWS_PER_CYCLE + r] = e;
+            }
+            row_table[r] = (uint16_t)ec_row_table(&c.host, run, inst, row);
+            if (row_table[r] == EC_T_XOR8) xor_index[r] = (uint16_t)n_xor++;
+        }
+        ZKW_TRY(nl_to_device(refs.data(), refs.size(), &c.stream.refs));
+        ZKW_TRY(nl_to_device(row_table.data(), row_table.size(), &c.stream.row_table));
+        ZKW_TRY(nl_to_device(xor_index.data(), xor_index.size(), &c.stream.xor_index));
+        c.stream.n_xor_rows = n_xor;
+    }
     c.dev = dd;
     *out = &c;
     return ZKW_OK;
@@ -1368,7 +1401,8 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
     u64* d_tape = nullptr;
     u32* d_status = nullptr;
     uint8_t* d_inputs = nullptr;
-    ZKW_TRY(ctx->scratch_t<u64>("ec_tape", ni * capacity * (size_t)EC_TAPE_PER_CYCLE, &d_tape));
+    const size_t tape_per_instance = (size_t)EC_TAPE_PER_CYCLE * ec_tape_stride(capacity);  // the cycles of an instance interleaved (ecrecover_kernels.cuh)
+    ZKW_TRY(ctx->scratch_t<u64>("ec_tape", ni * tape_per_instance, &d_tape));
     ZKW_TRY(ctx->scratch_t<uint8_t>("ec_inputs", ni * capacity * (size_t)128, &d_inputs));
     ZKW_TRY(ctx->scratch_t<u32>("ec_status", 1, &d_status));
     HIP_TRY(ctx->memset_async(d_status, 0, 4));
@@ -1379,7 +1413,7 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
     SlotClaims claims;  // the slots' tags: committed after the EC section's stream kernel, the call's last launch
     ZKW_TRY(nl_synthesize_with(ctx, 7, [&](std::vector<NlPrepJob>& prep) {
         for (size_t k = 0; k < ni; k++)
-            jobs[k] = EcJob{ws[w_of[k]]->mem_q, inst[k].first_round, inst[k].n_active, d_inputs + k * capacity * (size_t)128, d_tape + k * capacity * (size_t)EC_TAPE_PER_CYCLE,
+            jobs[k] = EcJob{ws[w_of[k]]->mem_q, inst[k].first_round, inst[k].n_active, d_inputs + k * capacity * (size_t)128, d_tape + k * tape_per_instance,
                             inst[k].t->data + inst[k].slot * inst[k].t->slot_elems(), prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
         ZKW_TRY(ctx->upload("ec_jobs", jobs, &d_jobs));
         { Prof _p(ctx, "k_ec_inputs"); ZKW_LAUNCH_2D(ctx, k_ec_inputs, capacity, nj, 128, d_jobs); }
@@ -1392,11 +1426,12 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
         } else {
             EcChainScratch sc{};
             ZKW_TRY(ctx->scratch_t<ec_jac>("ec_chain_pts", ni * capacity * (size_t)EC_CHAIN_POINTS, &sc.pts));
-            ZKW_TRY(ctx->scratch_t<ec_u256>("ec_chain_pre", ni * capacity * (size_t)EC_CHAIN_POINTS, &sc.pre));
             { Prof _p(ctx, "k_ec_chain"); ZKW_LAUNCH_2D(ctx, k_ec_chain, (capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj, EC_TAPE_LANES, ec->dev, d_jobs, capacity, d_status, sc); }
             ZKW_TRY(launch_check("k_ec_chain"));
-            const u32 n_cycles = (u32)(ni * capacity);
-            { Prof _p(ctx, "k_ec_segments"); ZKW_LAUNCH_2D(ctx, k_ec_segments, ec->segments_per_cycle - 1, (n_cycles + EC_TAPE_LANES - 1) / EC_TAPE_LANES, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, d_status); }
+            const u32 n_cycles = (u32)(ni * capacity), n_segments = ec->segments_per_cycle - 1;
+            { Prof _p(ctx, "k_ec_affine"); ZKW_LAUNCH(ctx, k_ec_affine, ((size_t)n_cycles * EC_CHAIN_POINTS + 63) / 64, 64, ec->dev, d_jobs, capacity, n_cycles, d_status, sc); }
+            ZKW_TRY(launch_check("k_ec_affine"));
+            { Prof _p(ctx, "k_ec_segments"); ZKW_LAUNCH_2D(ctx, k_ec_segments, n_segments + EC_PRE_PARTS - 1, (n_cycles + EC_TAPE_LANES - 1) / EC_TAPE_LANES, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, n_segments, d_status); }
             ZKW_TRY(launch_check("k_ec_segments"));
         }
         { Prof _p(ctx, "k_ec_prepare"); ZKW_LAUNCH_2D(ctx, k_ec_prepare, cb, nj, 64, ec->dev, d_jobs, capacity); }
@@ -1422,8 +1457,12 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
         ZKW_TRY((nlcf_begin<CfPrecompile<ZKW_PRECOMPILE_ECRECOVER>>(ctx, 7, w->instances, first[k], sub, capacity, n_rows, &cf, name)));
         ZKW_TRY(nlcf_end(ctx, 7, cf, capacity, n_rows));
     }
-    { Prof _p(ctx, "k_ec_stream"); ZKW_LAUNCH_D(ctx, (k_ec_stream), "k_ec_stream", dim3((EC_ROWS_PER_CYCLE + 63) / 64, capacity, nj), 64, 0, ec->dev, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL); }
-    return claims.commit_if(launch_check("k_ec_stream"));
+    uint16_t* d_keys = nullptr;  // the Xor8 lookups' keys: [instance][cycle][Xor8 row of the cycle][16]
+    ZKW_TRY(ctx->scratch_t<uint16_t>("ec_xor_keys", ni * capacity * (size_t)ec->stream.n_xor_rows * EC_R, &d_keys));
+    { Prof _p(ctx, "k_ec_stream"); ZKW_LAUNCH_D(ctx, (k_ec_stream), "k_ec_stream", dim3((EC_ROWS_PER_CYCLE + EC_STREAM_ROWS - 1) / EC_STREAM_ROWS, (capacity + 7) / 8, nj), EC_STREAM_THREADS, 0, ec->stream, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL, d_keys); }
+    ZKW_TRY(launch_check("k_ec_stream"));
+    { Prof _p(ctx, "k_ec_hist"); ZKW_LAUNCH_2D(ctx, k_ec_hist, 2, nj, EC_HIST_THREADS, d_jobs, capacity, ec->stream.n_xor_rows, n_rows, (u32)EK_MULT_COL, d_keys); }
+    return claims.commit_if(launch_check("k_ec_hist"));
 }
 
 extern "C" int zkw_ecrecover_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances, zkw_trace* t, size_t first_slot) {

@@ -69,8 +69,11 @@ EC_HD uint64_t ec_gl_from_i64(int64_t v) { return v >= 0 ? (uint64_t)v % EC_GL_P
 typedef struct ec_u256 { uint32_t w[8]; } ec_u256;
 typedef struct ec_mod { const uint32_t *m, *c, *inv_e; uint32_t nc; } ec_mod;
 typedef struct ec_ws {
-    uint32_t cur[24], nxt[24], prod[18], A[9], B[9], R[9], T[20], U[20], Q[12], Qc[20];
-    uint64_t va[16], vb[16], vc[16];
+    uint32_t va[16], vb[16], vc[16]; /* the limb vectors of a MUL row / of a hint's operand: lazy limbs, < 2^32 (ec_get_vec) */
+    uint32_t A[9], B[9];             /* two of them as integers */
+    uint32_t big[52];                /* ec_mul_witness: T[20] | Q[12] | Qc[20]; ec_reduce: cur[24] | nxt[24] */
+    uint32_t pad;                    /* 119 words = 476 bytes: an odd word stride between the lanes' slices of LDS, and five 64-lane
+                                        workgroups of k_ec_segments on a CU (30.5 KB each) instead of two (the struct was 1 044 bytes) */
 } ec_ws;
 
 static const uint32_t EC_P_M[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -119,9 +122,9 @@ EC_HD void ec_mul_words(const uint32_t *a, int na, const uint32_t *b, int nb, ui
         out[i + nb] = (uint32_t)carry;
     }
 }
-/* x (n <= 20 words, not W->cur / W->nxt) mod m */
+/* x (n <= 20 words, not inside W->big) mod m */
 EC_HD ec_u256 ec_reduce(const uint32_t *x, int n, const ec_mod *M, ec_ws *W) {
-    uint32_t *cur = W->cur, *nxt = W->nxt;
+    uint32_t *cur = W->big, *nxt = W->big + 24;
     int len = n;
     for (int i = 0; i < 24; i++) cur[i] = i < n ? x[i] : 0;
     while (len > 8) { /* x = hi 2^256 + lo = hi c + lo */
@@ -329,26 +332,28 @@ EC_HD ec_u256 ec_invmod(const ec_u256 *a, const ec_mod *M, ec_ws *W) {
     return r;
 }
 /* a vector of 16 (possibly lazy: up to 2^24 each) limbs as an integer of 9 words */
-EC_HD void ec_from_limbs16(const uint64_t *l, uint32_t *out) {
+EC_HD void ec_from_limbs16(const uint32_t *l, uint32_t *out) {
     uint64_t acc = 0;
     EC_UNROLL for (int k = 0; k < 16; k += 2) {
-        acc += l[k] + (l[k + 1] << 16);
+        acc += (uint64_t)l[k] + ((uint64_t)l[k + 1] << 16);
         out[k / 2] = (uint32_t)acc;
         acc >>= 32;
     }
     out[8] = (uint32_t)acc;
 }
-EC_HD void ec_to_limbs16(const ec_u256 *a, uint64_t *l) {
-    l[0] = a->w[0] & 0xFFFFu; l[1] = a->w[0] >> 16; l[2] = a->w[1] & 0xFFFFu; l[3] = a->w[1] >> 16;
-    l[4] = a->w[2] & 0xFFFFu; l[5] = a->w[2] >> 16; l[6] = a->w[3] & 0xFFFFu; l[7] = a->w[3] >> 16;
-    l[8] = a->w[4] & 0xFFFFu; l[9] = a->w[4] >> 16; l[10] = a->w[5] & 0xFFFFu; l[11] = a->w[5] >> 16;
-    l[12] = a->w[6] & 0xFFFFu; l[13] = a->w[6] >> 16; l[14] = a->w[7] & 0xFFFFu; l[15] = a->w[7] >> 16;
+EC_HD void ec_to_limbs16(const ec_u256 *a, uint64_t *l, size_t ts) { /* limb k at l[k * ts] */
+    EC_UNROLL for (int k = 0; k < 8; k++) {
+        l[(size_t)(2 * k) * ts] = a->w[k] & 0xFFFFu;
+        l[(size_t)(2 * k + 1) * ts] = a->w[k] >> 16;
+    }
 }
 
 /* ---- reading references ------------------------------------------------------------------------------------------------- */
 typedef struct ec_eval_ctx {
     const ec_spec *S;
-    uint64_t *tape;          /* the cycle's tape */
+    uint64_t *tape;          /* the cycle's tape: value t at tape[t * ts] */
+    uint32_t ts;             /* 1: a tape of its own; the kernels interleave the cycles of an instance (ts = the capacity rounded up to 8:
+                                the lanes of a wave are cycles, and value t of neighbouring cycles shares a cache line) */
     const uint8_t *in;       /* 128 input bytes */
     ec_ws *W;
     uint32_t base, prev_base, prev_type, inst;
@@ -356,19 +361,26 @@ typedef struct ec_eval_ctx {
 
 EC_HD uint64_t ec_get(const ec_eval_ctx *E, uint32_t ref) {
     const uint32_t t = ec_ref_tape(E->S, ref, E->base, E->prev_base, E->prev_type, E->inst);
-    return t != EC_NONE ? E->tape[t] : ec_ref_const(E->S, ref, E->in);
+    return t != EC_NONE ? E->tape[(size_t)t * E->ts] : ec_ref_const(E->S, ref, E->in);
 }
-EC_HD void ec_get_vec(const ec_eval_ctx *E, uint32_t ref0, uint64_t *out) {
-    for (uint32_t i = 0; i < 16; i++) out[i] = ec_get(E, ref0 + i);
+/* the 16 limbs a reference names; returns nonzero when one of them does not fit 32 bits (no limb vector of a satisfiable cycle does:
+   canonical limbs are 16 bits, lazy sums of a few of them with the limbs of 4 m stay below 2^24) */
+EC_HD uint32_t ec_get_vec(const ec_eval_ctx *E, uint32_t ref0, uint32_t *out) {
+    uint64_t hi = 0;
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint64_t v = ec_get(E, ref0 + i);
+        out[i] = (uint32_t)v;
+        hi |= v >> 32;
+    }
+    return hi != 0;
 }
-/* q (16 limbs, the top one up to 24 bits) and the 15 carries (+ 2^31) of a MUL row; a, b, r: limb vectors (W->va / vb / vc or any
-   memory); returns 0 when a * b + 8 m - r is not a non-negative multiple of m (no witness) */
-EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r, uint32_t which, uint64_t *q, uint64_t *c, ec_ws *W) {
+/* q (16 limbs, the top one up to 24 bits) and the 15 carries (+ 2^31) of a MUL row (element k at [k * ts]); a, b, r: limb vectors (W->va /
+   vb / vc or any memory); returns 0 when a * b + 8 m - r is not a non-negative multiple of m (no witness) */
+EC_HD int ec_mul_witness(const uint32_t *a, const uint32_t *b, const uint32_t *r, uint32_t which, uint64_t *q, uint64_t *c, size_t ts, ec_ws *W) {
     const ec_mod M = ec_modulus(which);
-    uint32_t *A = W->A, *B = W->B, *R = W->R, *T = W->T, *U = W->U, *Q = W->Q, *Qc = W->Qc;
+    uint32_t *A = W->A, *B = W->B, *T = W->big, *Q = W->big + 20, *Qc = W->big + 32;
     ec_from_limbs16(a, A);
     ec_from_limbs16(b, B);
-    ec_from_limbs16(r, R);
     ec_mul_words(A, 9, B, 9, T); /* 18 words */
     T[18] = T[19] = 0;
     uint64_t carry = 0; /* + 8 m */
@@ -379,14 +391,20 @@ EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r
         T[i] = (uint32_t)t;
         carry = t >> 32;
     }
-    uint64_t br = 0; /* - r */
+    uint64_t br = 0, racc = 0; /* - r: its nine words come off the limbs as they are needed */
     for (int i = 0; i < 20; i++) {
-        const uint64_t d = (uint64_t)T[i] - (i < 9 ? R[i] : 0) - br;
+        uint64_t rw = 0;
+        if (i < 8) {
+            racc += (uint64_t)r[2 * i] + ((uint64_t)r[2 * i + 1] << 16);
+            rw = (uint32_t)racc;
+            racc >>= 32;
+        } else if (i == 8) rw = (uint32_t)racc;
+        const uint64_t d = (uint64_t)T[i] - rw - br;
         T[i] = (uint32_t)d;
         br = (d >> 32) & 1;
     }
     if (br) return 0;
-    /* Q = T / m exactly, m = 2^256 - c: Q <- ceil((T + Q c) / 2^256) from Q = T >> 256 */
+    /* Q = T / m exactly, m = 2^256 - c: Q <- ceil((T + Q c) / 2^256) from Q = T >> 256 (the sum's low eight words only carry) */
     for (int i = 0; i < 12; i++) Q[i] = T[8 + i];
     for (int it = 0; it < 4; it++) {
         ec_mul_words(Q, 12, M.c, (int)M.nc, Qc); /* 12 + nc words */
@@ -394,17 +412,16 @@ EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r
         uint64_t cy = 0;
         for (int i = 0; i < 20; i++) {
             const uint64_t t = (uint64_t)T[i] + Qc[i] + (i < 8 ? 0xFFFFFFFFull : 0) + cy;
-            U[i] = (uint32_t)t;
+            if (i >= 8) Q[i - 8] = (uint32_t)t;
             cy = t >> 32;
         }
-        for (int i = 0; i < 12; i++) Q[i] = U[8 + i];
     }
     if (Q[8] >> 8 || Q[9] || Q[10] || Q[11]) return 0; /* q < 2^264 */
-    ec_mul_words(Q, 12, M.m, 8, U);
+    ec_mul_words(Q, 12, M.m, 8, Qc);
     for (int i = 0; i < 20; i++)
-        if (U[i] != T[i]) return 0;
-    for (int k = 0; k < 15; k++) q[k] = (Q[k / 2] >> (16 * (k & 1))) & 0xFFFFu;
-    q[15] = (Q[7] >> 16) | ((uint64_t)Q[8] << 16);
+        if (Qc[i] != T[i]) return 0;
+    for (int k = 0; k < 15; k++) q[(size_t)k * ts] = (Q[k / 2] >> (16 * (k & 1))) & 0xFFFFu;
+    q[(size_t)15 * ts] = (Q[7] >> 16) | ((uint64_t)Q[8] << 16);
     /* carries of the 32-bit positions */
     int64_t cin = 0;
     for (int k = 0; k < 16; k++) {
@@ -416,7 +433,7 @@ EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r
                 const int j = t - i;
                 if (j < 0 || j > 15) continue;
                 const int64_t mj = (int64_t)((M.m[j / 2] >> (16 * (j & 1))) & 0xFFFFu);
-                s += (int64_t)a[i] * (int64_t)b[j] - ((int64_t)q[i] - (i == 0 ? EC_KMUL : 0)) * mj;
+                s += (int64_t)a[i] * (int64_t)b[j] - ((int64_t)q[(size_t)i * ts] - (i == 0 ? EC_KMUL : 0)) * mj;
             }
             if (t < 16) s -= (int64_t)r[t];
             d += half ? s * 65536 : s;
@@ -426,28 +443,32 @@ EC_HD int ec_mul_witness(const uint64_t *a, const uint64_t *b, const uint64_t *r
         cin = tot >> 32;
         if (k < 15) {
             if (cin <= -(1ll << 31) || cin >= (1ll << 31)) return 0;
-            c[k] = (uint64_t)(cin + (1ll << 31));
+            c[(size_t)k * ts] = (uint64_t)(cin + (1ll << 31));
         } else if (cin != 0) return 0;
     }
     return 1;
 }
 
 /* the limb vector a reference names, reduced mod m */
-EC_HD ec_u256 ec_get_reduced(const ec_eval_ctx *E, uint32_t ref0, const ec_mod *M) {
-    ec_get_vec(E, ref0, E->W->va);
+EC_HD ec_u256 ec_get_reduced(const ec_eval_ctx *E, uint32_t ref0, const ec_mod *M, uint32_t *wide) {
+    *wide |= ec_get_vec(E, ref0, E->W->va);
     ec_from_limbs16(E->W->va, E->W->A);
     return ec_reduce(E->W->A, 9, M, E->W);
 }
 
 /* evaluates the items of one segment instance onto the tape; returns 0, or 1 + the item's index when the inputs have no witness
    (a division by zero in the incomplete addition, a broken assertion) */
-EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
+EC_HD int ec_eval_items(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t count);
+EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) { return ec_eval_items(E, type, 0, E->S->types[type].n_items); }
+/* items [first, first + count) of the segment type, in order (the whole segment, or one of PRE's parts: EC_PRE_PART_ITEMS_INIT) */
+EC_HD int ec_eval_items(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t count) {
     const ec_spec *S = E->S;
     const ec_seg_type *T = &S->types[type];
-    const uint32_t *w = S->items + T->item0;
-    uint64_t *tape = E->tape + E->base;
+    const uint32_t *w = S->items + T->item0 + S->item_index[T->index0 + first];
+    const size_t ts = E->ts;
+    uint64_t *tape = E->tape + (size_t)E->base * ts; /* value k of this segment at tape[k * ts] */
     ec_ws *W = E->W;
-    for (uint32_t n = 0; n < T->n_items; n++, w += ec_item_words(w)) {
+    for (uint32_t n = first; n < first + count; n++, w += ec_item_words(w)) {
         const uint32_t kind = w[0] & 15, aux = w[0] >> 24;
         if (kind == EC_I_LIN) {
             const uint32_t nk = aux, nn = w[1];
@@ -458,7 +479,7 @@ EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
                     const uint64_t v = ec_get(E, kn[2 * i]);
                     acc = ec_gl_add(acc, ec_gl_mul(v, ec_gl_from_i64((int32_t)kn[2 * i + 1])));
                 }
-                tape[nw[0]] = acc;
+                tape[(size_t)(nw[0]) * ts] = acc;
                 continue;
             }
             int64_t s = (int64_t)((uint64_t)w[2] | ((uint64_t)w[3] << 32));
@@ -469,49 +490,52 @@ EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
                 const uint32_t sh = nw[2 * i + 1] & 0xFF, wd = nw[2 * i + 1] >> 8;
                 uint64_t x = (uint64_t)s >> sh;
                 if (wd) x &= (1ull << wd) - 1;
-                tape[nw[2 * i]] = x;
+                tape[(size_t)(nw[2 * i]) * ts] = x;
             }
         } else if (kind == EC_I_SEL) {
-            tape[w[4]] = ec_get(E, w[1]) ? ec_get(E, w[2]) : ec_get(E, w[3]);
+            tape[(size_t)(w[4]) * ts] = ec_get(E, w[1]) ? ec_get(E, w[2]) : ec_get(E, w[3]);
         } else if (kind == EC_I_FMA) {
             const uint64_t v = ec_gl_add(ec_gl_mul(ec_get(E, w[1]) % EC_GL_P, ec_get(E, w[2]) % EC_GL_P), ec_get(E, w[3]) % EC_GL_P);
-            if (aux) tape[w[4]] = v;
+            if (aux) tape[(size_t)(w[4]) * ts] = v;
             else if (v != ec_get(E, w[4]) % EC_GL_P) return 1 + (int)n;
         } else if (kind == EC_I_MUL) {
-            ec_get_vec(E, w[1], W->va);
-            ec_get_vec(E, w[2], W->vb);
-            ec_get_vec(E, w[3], W->vc);
-            if (!ec_mul_witness(W->va, W->vb, W->vc, aux, tape + w[4], tape + w[5], W)) return 1 + (int)n;
+            if (ec_get_vec(E, w[1], W->va) | ec_get_vec(E, w[2], W->vb) | ec_get_vec(E, w[3], W->vc)) return 1 + (int)n;
+            if (!ec_mul_witness(W->va, W->vb, W->vc, aux, tape + (size_t)w[4] * ts, tape + (size_t)w[5] * ts, ts, W)) return 1 + (int)n;
         } else if (kind == EC_I_LOOKUP) {
             const uint64_t a = ec_get(E, w[2]);
             if ((w[1] & 0xFF) == EC_T_XOR8) {
                 const uint64_t b = ec_get(E, w[3]);
                 if (a > 255 || b > 255) return 1 + (int)n;
-                tape[w[4]] = a ^ b;
+                tape[(size_t)(w[4]) * ts] = a ^ b;
             } else {
                 if (a > 255) return 1 + (int)n;
                 const uint32_t tb = (w[1] & 0xFF) - EC_T_FIXED0 + 8 * E->inst;
-                tape[w[4]] = S->fixed[((size_t)tb * 256 + a) * 2];
-                tape[w[4] + 1] = S->fixed[((size_t)tb * 256 + a) * 2 + 1];
+                tape[(size_t)(w[4]) * ts] = S->fixed[((size_t)tb * 256 + a) * 2];
+                tape[(size_t)(w[4] + 1) * ts] = S->fixed[((size_t)tb * 256 + a) * 2 + 1];
             }
         } else if (aux == EC_H_MULSUB || aux == EC_H_DIV) {
             const ec_mod M = ec_modulus(w[1]);
-            const ec_u256 a = ec_get_reduced(E, w[2], &M), b = ec_get_reduced(E, w[3], &M);
+            uint32_t wide = 0;
+            const ec_u256 a = ec_get_reduced(E, w[2], &M, &wide), b = ec_get_reduced(E, w[3], &M, &wide);
+            if (wide) return 1 + (int)n;
             ec_u256 res;
             if (aux == EC_H_DIV) {
                 if (ec_is_zero8(&b)) return 1 + (int)n;
                 const ec_u256 bi = ec_invmod(&b, &M, W);
                 res = ec_mulmod(&a, &bi, &M, W);
-                ec_to_limbs16(&res, tape + w[4]);
+                ec_to_limbs16(&res, tape + (size_t)w[4] * ts, ts);
             } else {
                 res = ec_mulmod(&a, &b, &M, W);
-                if (w[4] != EC_NONE) { const ec_u256 cc = ec_get_reduced(E, w[4], &M); res = ec_submod(&res, &cc, &M); }
-                if (w[5] != EC_NONE) { const ec_u256 dd = ec_get_reduced(E, w[5], &M); res = ec_submod(&res, &dd, &M); }
-                ec_to_limbs16(&res, tape + w[6]);
+                if (w[4] != EC_NONE) { const ec_u256 cc = ec_get_reduced(E, w[4], &M, &wide); res = ec_submod(&res, &cc, &M); }
+                if (w[5] != EC_NONE) { const ec_u256 dd = ec_get_reduced(E, w[5], &M, &wide); res = ec_submod(&res, &dd, &M); }
+                if (wide) return 1 + (int)n;
+                ec_to_limbs16(&res, tape + (size_t)w[6] * ts, ts);
             }
         } else if (aux == EC_H_SQRT) {
             const ec_mod M = ec_modulus(0);
-            const ec_u256 t = ec_get_reduced(E, w[1], &M);
+            uint32_t wide = 0;
+            const ec_u256 t = ec_get_reduced(E, w[1], &M, &wide);
+            if (wide) return 1 + (int)n;
             ec_u256 y = ec_powmod(&t, EC_P_SQRT_E, &M, W);
             const ec_u256 y2 = ec_mulmod(&y, &y, &M, W), zero = ec_zero256();
             uint64_t e_nr = 0;
@@ -522,19 +546,19 @@ EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
             } else if ((y.w[0] & 1) != (ec_get(E, w[2]) & 1)) {
                 y = ec_submod(&zero, &y, &M);
             }
-            ec_to_limbs16(&y, tape + w[3]);
-            tape[w[3] + 16] = e_nr;
+            ec_to_limbs16(&y, tape + (size_t)w[3] * ts, ts);
+            tape[(size_t)(w[3] + 16) * ts] = e_nr;
         } else if (aux == EC_H_ISZERO) {
             const uint64_t x = ec_get(E, w[1]) % EC_GL_P;
-            tape[w[2]] = x ? ec_gl_inv(x) : 0;
-            tape[w[2] + 1] = x ? 0 : 1;
+            tape[(size_t)(w[2]) * ts] = x ? ec_gl_inv(x) : 0;
+            tape[(size_t)(w[2] + 1) * ts] = x ? 0 : 1;
         } else { /* EC_H_GE: a >= the constant */
             int ge = 1;
             for (int i = 15; i >= 0; i--) {
                 const uint64_t av = ec_get(E, w[1] + (uint32_t)i), cst = S->bigs[w[2] * 16 + (uint32_t)i];
                 if (av != cst) { ge = av > cst; break; }
             }
-            tape[w[3]] = (uint64_t)ge;
+            tape[(size_t)(w[3]) * ts] = (uint64_t)ge;
         }
     }
     return 0;
@@ -542,9 +566,9 @@ EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) {
 
 /* the whole cycle: tape[EC_TAPE_PER_CYCLE] from the 128 input bytes. Returns 0, or (run << 24 | instance << 12 | 1 + item) of the
    first item without a witness */
-EC_HD uint32_t ec_eval_cycle(const ec_spec *S, const uint8_t *in, uint64_t *tape, ec_ws *W) {
+EC_HD uint32_t ec_eval_cycle_strided(const ec_spec *S, const uint8_t *in, uint64_t *tape, uint32_t ts, ec_ws *W) {
     ec_eval_ctx E;
-    E.S = S; E.tape = tape; E.in = in; E.W = W;
+    E.S = S; E.tape = tape; E.ts = ts; E.in = in; E.W = W;
     E.prev_base = 0; E.prev_type = 0;
     for (uint32_t r = 0; r < EC_NUM_RUNS; r++) {
         const ec_run *R = &S->runs[r];
@@ -560,6 +584,7 @@ EC_HD uint32_t ec_eval_cycle(const ec_spec *S, const uint8_t *in, uint64_t *tape
     }
     return 0;
 }
+EC_HD uint32_t ec_eval_cycle(const ec_spec *S, const uint8_t *in, uint64_t *tape, ec_ws *W) { return ec_eval_cycle_strided(S, in, tape, 1, W); }
 
 /* ---- the relations, from cells alone. `cell(col)` reads the item's row; returns 0 when the relation holds ------------------ */
 typedef struct ec_row_view { const uint64_t *trace; size_t n_rows, row; } ec_row_view;

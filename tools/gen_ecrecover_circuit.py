@@ -483,7 +483,84 @@ def build_pre():
     s.globs = [v.a for v in xs + ys + bits + u1b + [ok, mask]]
     assert len(s.globs) == GL_COUNT
     s.finish()
+    s.parts = split_pre(s)
     return s
+
+
+def item_reads_writes(it):
+    """(tape indices of the item's own segment it reads, tape indices it writes)"""
+    k = it["k"]
+    if k == I_LIN:
+        rd, wr = [r for r, _c in it["known"]], it["outs"]
+    elif k == I_SEL:
+        rd, wr = [it["b"], it["x"], it["y"]], [it["out"]]
+    elif k == I_FMA:
+        rd, wr = [it["a"], it["b"], it["c"]] + ([] if it["new"] else [it["d"]]), ([it["d"]] if it["new"] else [])
+    elif k == I_MUL:
+        rd, wr = list(it["a"]) + list(it["b"]) + list(it["r"]), list(it["q"]) + list(it["c"])
+    elif k == I_HINT:
+        rd = [r for key in ("a", "b", "c", "d") for r in (it.get(key) or [])]
+        wr = it["outs"]
+    else:
+        rd, wr = it["ins"], it["outs"]
+    return {r.a for r in rd if r.kind == K_TAPE}, {r.a for r in wr}
+
+
+def split_pre(s, parts=2):
+    """PRE's items in the order MAIN, REST 0, REST 1, ...: MAIN = what the cycle's globals and the accumulator's start need (the
+    ancestors of `globs` and `out`): the accumulator chain of a request waits for exactly these. The REST (range checks, byte
+    decompositions, MUL rows, assertions: most of the segment) is evaluated beside the other segments, in `parts` lists that share no
+    tape value they write — every list keeps the segment's order, so an item still follows what it reads. Cells, homes and tape indices
+    are untouched (they were fixed by finish()); only the order the evaluator walks the items in changes. Returns the part sizes."""
+    rw = [item_reads_writes(it) for it in s.items]
+    needed = set(s.globs) | {r.a for r in s.out}
+    main = [False] * len(s.items)
+    for i in range(len(s.items) - 1, -1, -1):
+        if rw[i][1] & needed:
+            main[i] = True
+            needed |= rw[i][0]
+    rest = [i for i in range(len(s.items)) if not main[i]]
+    # components of the rest: items joined by a tape value one of them writes and another reads
+    parent = {i: i for i in rest}
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    writer = {}
+    for i in rest:
+        for t in rw[i][1]:
+            writer[t] = i
+    for i in rest:
+        for t in rw[i][0]:
+            if t in writer and writer[t] != i:
+                parent[find(i)] = find(writer[t])
+    comps = {}
+    for i in rest:
+        comps.setdefault(find(i), []).append(i)
+    cost = lambda i: 12 if s.items[i]["k"] in (I_MUL, I_HINT) else 1  # noqa: E731  (a MUL row / a hint weighs about a dozen small items)
+    bins = [[] for _ in range(parts)]
+    load = [0] * parts
+    for c in sorted(comps.values(), key=lambda c: -sum(cost(i) for i in c)):
+        b = load.index(min(load))
+        bins[b] += c
+        load[b] += sum(cost(i) for i in c)
+    order = [i for i in range(len(s.items)) if main[i]]
+    sizes = [len(order)]
+    for b in bins:
+        order += sorted(b)
+        sizes.append(len(b))
+    # an item still follows what it reads
+    pos, seen = {i: n for n, i in enumerate(order)}, {}
+    for i in order:
+        for t in rw[i][0]:
+            assert t in seen and pos[seen[t]] < pos[i], (s.name, "an item would run before what it reads", i)
+        for t in rw[i][1]:
+            seen[t] = i
+    s.items = [s.items[i] for i in order]
+    return sizes
 
 
 def glob_vec(base):
@@ -927,6 +1004,8 @@ def emit_ec(spec, path):
     for name, idx in BIGS.items():
         w(f"#define EC_BIG_{name} {idx}")
     w(f"#define EC_GL_RX {GL_RX}\n#define EC_GL_RY {GL_RY}\n#define EC_GL_BITS {GL_BITS}\n#define EC_GL_U1 {GL_U1}\n#define EC_GL_OK {GL_OK}\n#define EC_GL_MASK {GL_MASK}\n#define EC_GL_COUNT {GL_COUNT}")
+    w("/* PRE's items come as MAIN (what the globals and the accumulator's start need), then the rest in lists that share no tape value they write */")
+    w(f"#define EC_PRE_PARTS {len(pre.parts)}\n#define EC_PRE_PART_ITEMS_INIT {{" + ", ".join(str(x) for x in pre.parts) + "}")
     w(f"#define EC_T_XOR8 {T_XOR8}\n#define EC_T_FIXED0 {T_FIXED0}\n#define EC_ROWTAB_PER_INSTANCE {ROWTAB_PER_INSTANCE}")
     w("/* segment types {rows, tape values, item0 (words), items, index0, cell0, home0, out0, rowtab0} */")
     w("#define EC_TYPES_INIT {" + ", ".join("{" + ", ".join(str(x) for x in t) + "}" for t in types) + "}")
