@@ -201,18 +201,25 @@ __device__ __forceinline__ void jmadd(ec_u256& X, ec_u256& Y, ec_u256& Z, const 
 // ---- the fast form of the tape: the accumulator's trajectory first, then every segment on its own lane ------------------------------
 // The serial kernel above spends its time in ~550 modular inversions per cycle (every quotient lambda of the affine additions), one after
 // the other, because segment k needs the accumulator segment k - 1 leaves. The trajectory does not need the quotients:
-//   k_ec_chain    a lane per cycle: the MAIN items of the PRE segment (what the globals — R, the bits of u2, the bytes of u1 — need: 262 of
-//                 its 1 445 items, tools/gen_ecrecover_circuit.py split_pre), then the same double-and-add / table additions in JACOBIAN
-//                 coordinates (no inversion): 288 points;
+//   k_ec_chain    a wave per cycle: the MAIN items of the PRE segment (what the globals — R, the bits of u2, the bytes of u1 — need: 262 of
+//                 its 1 445 items, tools/gen_ecrecover_circuit.py split_segment), then the same double-and-add / table additions in
+//                 JACOBIAN coordinates (no inversion): 288 points;
 //   k_ec_affine   a lane per (cycle, point): the point to affine with an inversion of its own (288 x cycles lanes side by side cost what
 //                 one costs; the serial Montgomery batch of round 5 was 2 ms of the chain's lane) onto the tape, where the segments'
 //                 `out` states live;
-//   k_ec_segments with every segment's input state in place, the 289 remaining segments of every cycle and the other parts of PRE side
-//                 by side (their own out cells are rewritten with the same values).
+//   k_ec_segments with every segment's input state in place, three launches over item lists (tools/gen_ecrecover_circuit.py split_segment):
+//                 the MAIN items of the 289 other segments of every cycle side by side (the hints and what lies between them; their
+//                 own out cells are rewritten with the same values); the MUL rows of every segment with what else they need; then
+//                 the LEAVES — range checks, byte decompositions, assertions: nine tenths of a segment — in lists of ~190 items that
+//                 write no common value, a lane each (1 400 lists per cycle). The walk of an item list is ~3 us an item on a wave
+//                 whatever its lanes, so the rate is set by the waves in flight: the first two launches hold the 256-bit workspace in
+//                 LDS (476 bytes a lane: five waves on a CU), the leaves need neither it nor the registers of the 256-bit arithmetic
+//                 (k_ec_leaves). Whole segments as lists were 3.1 ms at best and 4.1 ms for 32 instances.
 // Same tape, bit for bit (tests/test_ec_library_evaluator_host.py walks the library's evaluator in this order on the host).
 struct EcChainScratch { ec_jac* pts; };  // [cycles of the call][EC_CHAIN_POINTS]
 constexpr u32 EC_CHAIN_POINTS = 288;     // 256 double-and-add steps + 32 table additions
-constexpr u32 EC_PRE_PART_ITEMS[EC_PRE_PARTS] = EC_PRE_PART_ITEMS_INIT;
+constexpr u32 EC_PART_ITEMS[EC_NUM_TYPES][EC_MAX_PARTS] = EC_PART_ITEMS_INIT;
+struct EcTask { u32 run, inst, first, count; };  // items [first, first + count) of segment (run, inst)
 
 __device__ __forceinline__ ec_u256 ec_load_limbs(const u64* __restrict__ tape, size_t ts, const uint32_t* __restrict__ idx) {
     ec_u256 r;
@@ -221,22 +228,29 @@ __device__ __forceinline__ ec_u256 ec_load_limbs(const u64* __restrict__ tape, s
     return r;
 }
 
-// grid (cycles / EC_TAPE_LANES, jobs): a lane per cycle
+// grid (cycles, jobs) x 64: a WAVE per cycle, its first lane at work, and a SIMD per wave. The chain is bound by the SIMD's issue rate, not
+// by latency: a wave instruction costs its 4 (v_mad_u64_u32: 16) cycles whatever the number of active lanes — ~2 100 cycles per
+// multiplication mod p, 3.1 ms for the 256 steps — so two chain waves on one SIMD take twice as long, and lanes that share a wave run the
+// mixed addition at every step (one of seven bits of u2 is set 99 % of the time) instead of on half of them. Measured (32 instances, per
+// wave): 4.75 ms alone on a SIMD; one-wave workgroups land two or three to a SIMD wherever the dispatcher likes (4.7 .. 9 ms, the launch
+// takes the slowest); four-wave workgroups with a CU to themselves (an LDS request of more than half a CU) are NOT spread over the CU's
+// four SIMDs reliably (4.8 / 9.5 / 14 ms: four, two, one SIMD). What does hold: a wave that owns the SIMD's whole register file — the two
+// moves below make the kernel's footprint 256 + 256 registers — shares the SIMD with nobody, whoever else is running.
+constexpr int EC_CHAIN_WAVES = 1;
 static __device__ __forceinline__ void k_ec_chain(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
-    __builtin_amdgcn_s_setprio(3);  // a request's accumulator chain is one lane and milliseconds of dependent instructions: its wave issues before
-                                    // whatever shares the SIMD (another call's segment / stream kernels when two calls are in flight)
-    __shared__ ec_ws s_ws[EC_TAPE_LANES];
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");  // (the whole register file of the SIMD: see above)
+    __shared__ ec_ws s_ws[EC_CHAIN_WAVES];
     const EcJob j = jobs[vb.y];
-    const u32 c = vb.x * blockDim.x + threadIdx.x;
-    if (c >= capacity) return;
+    const u32 c = vb.x * EC_CHAIN_WAVES + (threadIdx.x >> 6);
+    if (c >= capacity || (threadIdx.x & 63)) return;
     const ec_spec S = *Sp;
-    ec_ws* W = &s_ws[threadIdx.x];
+    ec_ws* W = &s_ws[threadIdx.x >> 6];
     const size_t ts = ec_tape_stride(capacity);
     u64* tape = j.tape + c;
     ec_eval_ctx E;
     E.S = &S; E.tape = tape; E.ts = (u32)ts; E.in = j.inputs + (size_t)c * 128; E.W = W;
     E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
-    if (const int bad = ec_eval_items(&E, S.runs[0].type, 0, EC_PRE_PART_ITEMS[0])) { atomicMax(status, 1u + (vb.y << 16 | c)); (void)bad; return; }
+    if (const int bad = ec_eval_items(&E, S.runs[0].type, 0, EC_PART_ITEMS[0][0])) { atomicMax(status, 1u + (vb.y << 16 | c)); (void)bad; return; }
     const size_t slot = (size_t)vb.y * capacity + c;
     ec_jac* pts = sc.pts + slot * EC_CHAIN_POINTS;
     const ec_u256 rx = ec_load_limbs(tape, ts, S.globs + EC_GL_RX), ry = ec_load_limbs(tape, ts, S.globs + EC_GL_RY);
@@ -311,39 +325,43 @@ static __device__ __forceinline__ void k_ec_affine(const VB& vb, const ec_spec* 
     }
 }
 
-// grid (segments after PRE = 289, then PRE's parts after MAIN; lanes' chunks of the call's cycles): lane = one cycle of the call (job-major),
-// block = one segment (or one part of PRE), so that a wave runs ONE item list. The workspace is 476 bytes a lane: five workgroups on a CU,
-// the 290 x (cycles / 64) workgroups of a 32-instance call all resident at once (they are latency-bound: dependent loads of the item walk)
-static __device__ __forceinline__ void k_ec_segments(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, u32 n_segments, u32* status) {
+// grid (tasks, lanes' chunks of the call's cycles): lane = one cycle of the call (job-major), block = one task — a part of the items of one
+// segment — so that a wave runs ONE item list. The workspace is 476 bytes a lane: five workgroups on a CU
+static __device__ __forceinline__ void k_ec_segments(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, const EcTask* __restrict__ tasks, u32* status) {
     __shared__ ec_ws s_ws[EC_TAPE_LANES];
     const u32 lane = vb.y * blockDim.x + threadIdx.x;
     if (lane >= n_cycles) return;
     const u32 job = lane / capacity, c = lane % capacity;
     const EcJob j = jobs[job];
     const ec_spec S = *Sp;
+    const EcTask T = tasks[vb.x];
+    u32 prun, pinst;
+    ec_prev_segment(&S, T.run, T.inst, &prun, &pinst);
     ec_eval_ctx E;
     E.S = &S; E.tape = j.tape + c; E.ts = ec_tape_stride(capacity); E.in = j.inputs + (size_t)c * 128; E.W = &s_ws[threadIdx.x];
-    if (vb.x >= n_segments) {  // a part of PRE after MAIN
-        const u32 part = vb.x - n_segments + 1;
-        u32 first = 0, count = 0;
-#pragma unroll
-        for (u32 p = 0; p < EC_PRE_PARTS; p++) {
-            if (p < part) first += EC_PRE_PART_ITEMS[p];
-            if (p == part) count = EC_PRE_PART_ITEMS[p];
-        }
-        E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
-        if (ec_eval_items(&E, S.runs[0].type, first, count)) atomicMax(status, 1u + (job << 16 | c));
-        return;
-    }
-    u32 seg = vb.x, run = 1;
-    while (seg >= S.runs[run].count) { seg -= S.runs[run].count; run++; }
-    u32 prun, pinst;
-    ec_prev_segment(&S, run, seg, &prun, &pinst);
-    E.base = S.runs[run].tape0 + seg * S.types[S.runs[run].type].n_tape;
+    E.base = S.runs[T.run].tape0 + T.inst * S.types[S.runs[T.run].type].n_tape;
     E.prev_base = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape;
     E.prev_type = S.runs[prun].type;
-    E.inst = seg;
-    if (ec_eval_segment(&E, S.runs[run].type)) atomicMax(status, 1u + (job << 16 | c));
+    E.inst = T.inst;
+    if (ec_eval_items(&E, S.runs[T.run].type, T.first, T.count)) atomicMax(status, 1u + (job << 16 | c));
+}
+// the same over lists of small items only (a segment's LEAVES): no workspace, a quarter of the registers
+static __device__ __forceinline__ void k_ec_leaves(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32 n_cycles, const EcTask* __restrict__ tasks, u32* status) {
+    const u32 lane = vb.y * blockDim.x + threadIdx.x;
+    if (lane >= n_cycles) return;
+    const u32 job = lane / capacity, c = lane % capacity;
+    const EcJob j = jobs[job];
+    const ec_spec S = *Sp;
+    const EcTask T = tasks[vb.x];
+    u32 prun, pinst;
+    ec_prev_segment(&S, T.run, T.inst, &prun, &pinst);
+    ec_eval_ctx E;
+    E.S = &S; E.tape = j.tape + c; E.ts = ec_tape_stride(capacity); E.in = j.inputs + (size_t)c * 128; E.W = nullptr;
+    E.base = S.runs[T.run].tape0 + T.inst * S.types[S.runs[T.run].type].n_tape;
+    E.prev_base = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape;
+    E.prev_type = S.runs[prun].type;
+    E.inst = T.inst;
+    if (ec_eval_items_of(&E, S.runs[T.run].type, T.first, T.count, 1)) atomicMax(status, 1u + (job << 16 | c));
 }
 
 // grid (cycles / 64, jobs): the netlist's inputs of a cycle from its tape

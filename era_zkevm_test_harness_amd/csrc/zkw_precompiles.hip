@@ -1189,7 +1189,7 @@ int nlcf_end(zkw_ctx* ctx, int circuit_type, const NlcfCall& call, u32 cycles, s
 }
 
 // ---- the EC section of the ECRecover circuit (ecrecover_kernels.cuh): the spec on the device, once per device
-struct EcCached { ec_spec host; const ec_spec* dev = nullptr; u32 segments_per_cycle = 0; EcStreamDev stream{}; };
+struct EcCached { ec_spec host; const ec_spec* dev = nullptr; u32 segments_per_cycle = 0; EcStreamDev stream{}; const EcTask* tasks_main = nullptr; const EcTask* tasks_muls = nullptr; const EcTask* tasks_leaves = nullptr; u32 n_main = 0, n_muls = 0, n_leaves = 0; };
 std::map<int, EcCached>& ec_cache() { static auto* m = new std::map<int, EcCached>(); return *m; }
 size_t ec_first_row(u32 capacity) { return nlq_used_rows(nl_host_spec(7), nlq_desc_of(7), capacity); }
 size_t ec_used_rows(u32 capacity) { return ec_first_row(capacity) + (size_t)capacity * EC_ROWS_PER_CYCLE; }
@@ -1253,6 +1253,25 @@ int ec_get(zkw_ctx* ctx, const EcCached** out) {
         ZKW_TRY(nl_to_device(row_table.data(), row_table.size(), &c.stream.row_table));
         ZKW_TRY(nl_to_device(xor_index.data(), xor_index.size(), &c.stream.xor_index));
         c.stream.n_xor_rows = n_xor;
+    }
+    {   // the item lists of k_ec_segments / k_ec_leaves: MAIN of the segments after PRE (PRE's is the chain kernel's), MULS, LEAVES
+        std::vector<EcTask> mains, muls, leaves;
+        for (u32 r = 0; r < EC_NUM_RUNS; r++)
+            for (u32 inst = 0; inst < h_ecs_runs[r].count; inst++) {
+                u32 first = 0;
+                for (u32 p = 0; p < EC_MAX_PARTS; p++) {
+                    const u32 n = EC_PART_ITEMS[h_ecs_runs[r].type][p];
+                    if (n && !(r == 0 && p == 0)) (p == 0 ? mains : p == 1 ? muls : leaves).push_back(EcTask{r, inst, first, n});
+                    first += n;
+                }
+                if (first != h_ecs_types[h_ecs_runs[r].type].n_items) return fail(ZKW_ERR_INVALID, "ECRecover spec: the parts of segment type %u do not add up", h_ecs_runs[r].type);
+            }
+        ZKW_TRY(nl_to_device(mains.data(), mains.size(), &c.tasks_main));
+        ZKW_TRY(nl_to_device(muls.data(), muls.size(), &c.tasks_muls));
+        ZKW_TRY(nl_to_device(leaves.data(), leaves.size(), &c.tasks_leaves));
+        c.n_main = (u32)mains.size();
+        c.n_muls = (u32)muls.size();
+        c.n_leaves = (u32)leaves.size();
     }
     c.dev = dd;
     *out = &c;
@@ -1426,13 +1445,18 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
         } else {
             EcChainScratch sc{};
             ZKW_TRY(ctx->scratch_t<ec_jac>("ec_chain_pts", ni * capacity * (size_t)EC_CHAIN_POINTS, &sc.pts));
-            { Prof _p(ctx, "k_ec_chain"); ZKW_LAUNCH_2D(ctx, k_ec_chain, (capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj, EC_TAPE_LANES, ec->dev, d_jobs, capacity, d_status, sc); }
+            { Prof _p(ctx, "k_ec_chain"); ZKW_LAUNCH_2D(ctx, k_ec_chain, (capacity + EC_CHAIN_WAVES - 1) / EC_CHAIN_WAVES, nj, EC_CHAIN_WAVES * 64, ec->dev, d_jobs, capacity, d_status, sc); }
             ZKW_TRY(launch_check("k_ec_chain"));
-            const u32 n_cycles = (u32)(ni * capacity), n_segments = ec->segments_per_cycle - 1;
+            const u32 n_cycles = (u32)(ni * capacity);
             { Prof _p(ctx, "k_ec_affine"); ZKW_LAUNCH(ctx, k_ec_affine, ((size_t)n_cycles * EC_CHAIN_POINTS + 63) / 64, 64, ec->dev, d_jobs, capacity, n_cycles, d_status, sc); }
             ZKW_TRY(launch_check("k_ec_affine"));
-            { Prof _p(ctx, "k_ec_segments"); ZKW_LAUNCH_2D(ctx, k_ec_segments, n_segments + EC_PRE_PARTS - 1, (n_cycles + EC_TAPE_LANES - 1) / EC_TAPE_LANES, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, n_segments, d_status); }
+            const unsigned chunks = (n_cycles + EC_TAPE_LANES - 1) / EC_TAPE_LANES;
+            { Prof _p(ctx, "k_ec_segments_main"); ZKW_LAUNCH_2D(ctx, k_ec_segments, ec->n_main, chunks, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, ec->tasks_main, d_status); }
             ZKW_TRY(launch_check("k_ec_segments"));
+            { Prof _p(ctx, "k_ec_segments_muls"); ZKW_LAUNCH_2D(ctx, k_ec_segments, ec->n_muls, chunks, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, ec->tasks_muls, d_status); }
+            ZKW_TRY(launch_check("k_ec_segments"));
+            { Prof _p(ctx, "k_ec_leaves"); ZKW_LAUNCH_2D(ctx, k_ec_leaves, ec->n_leaves, chunks, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, ec->tasks_leaves, d_status); }
+            ZKW_TRY(launch_check("k_ec_leaves"));
         }
         { Prof _p(ctx, "k_ec_prepare"); ZKW_LAUNCH_2D(ctx, k_ec_prepare, cb, nj, 64, ec->dev, d_jobs, capacity); }
         return launch_check("k_ec_prepare");

@@ -458,10 +458,13 @@ EC_HD ec_u256 ec_get_reduced(const ec_eval_ctx *E, uint32_t ref0, const ec_mod *
 
 /* evaluates the items of one segment instance onto the tape; returns 0, or 1 + the item's index when the inputs have no witness
    (a division by zero in the incomplete addition, a broken assertion) */
-EC_HD int ec_eval_items(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t count);
+EC_HD int ec_eval_items_of(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t count, const int small_only);
+EC_HD int ec_eval_items(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t count) { return ec_eval_items_of(E, type, first, count, 0); }
 EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) { return ec_eval_items(E, type, 0, E->S->types[type].n_items); }
-/* items [first, first + count) of the segment type, in order (the whole segment, or one of PRE's parts: EC_PRE_PART_ITEMS_INIT) */
-EC_HD int ec_eval_items(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t count) {
+/* items [first, first + count) of the segment type, in order (the whole segment, or one of its parts: EC_PART_ITEMS_INIT). small_only (a
+   constant at every call site: the branch folds): the list holds no MUL row and no hint — a segment's LEAVES — so E->W is not used (nor
+   the registers of the 256-bit arithmetic); such an item in the list is reported as one without a witness */
+EC_HD int ec_eval_items_of(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t count, const int small_only) {
     const ec_spec *S = E->S;
     const ec_seg_type *T = &S->types[type];
     const uint32_t *w = S->items + T->item0 + S->item_index[T->index0 + first];
@@ -498,6 +501,8 @@ EC_HD int ec_eval_items(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t 
             const uint64_t v = ec_gl_add(ec_gl_mul(ec_get(E, w[1]) % EC_GL_P, ec_get(E, w[2]) % EC_GL_P), ec_get(E, w[3]) % EC_GL_P);
             if (aux) tape[(size_t)(w[4]) * ts] = v;
             else if (v != ec_get(E, w[4]) % EC_GL_P) return 1 + (int)n;
+        } else if (small_only && (kind == EC_I_MUL || kind == EC_I_HINT)) {
+            return 1 + (int)n;
         } else if (kind == EC_I_MUL) {
             if (ec_get_vec(E, w[1], W->va) | ec_get_vec(E, w[2], W->vb) | ec_get_vec(E, w[3], W->vc)) return 1 + (int)n;
             if (!ec_mul_witness(W->va, W->vb, W->vc, aux, tape + (size_t)w[4] * ts, tape + (size_t)w[5] * ts, ts, W)) return 1 + (int)n;
@@ -513,6 +518,8 @@ EC_HD int ec_eval_items(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t 
                 tape[(size_t)(w[4]) * ts] = S->fixed[((size_t)tb * 256 + a) * 2];
                 tape[(size_t)(w[4] + 1) * ts] = S->fixed[((size_t)tb * 256 + a) * 2 + 1];
             }
+        } else if (small_only) {
+            return 1 + (int)n;
         } else if (aux == EC_H_MULSUB || aux == EC_H_DIV) {
             const ec_mod M = ec_modulus(w[1]);
             uint32_t wide = 0;

@@ -107,14 +107,31 @@ DECOMMITTER_INSTANCE = np.dtype(
      ("num_rounds", "<u8"), ("first_request", "<u8"), ("num_requests", "<u8"), ("first_word", "<u8"), ("num_words", "<u8")])
 
 
+def _sources_digest():
+    """sha256 over everything liboracle.so is made of: oracle/*.c, *.h, the Makefile and the shared format headers in include/ (the generated
+    circuit specs among them — a spec regenerated by tools/gen_*.py must rebuild the checker too; file times do not survive a snapshot)"""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    files = [os.path.join(_HERE, f) for f in sorted(os.listdir(_HERE)) if f.endswith((".c", ".h")) or f == "Makefile"]
+    files += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force=False):
-    """Compile liboracle.so with gcc (building the checker is not using it)."""
+    """Compile liboracle.so with gcc (building the checker is not using it). Keyed on the content of its sources."""
     if os.environ.get("ZKW_ORACLE_LIB"):
         return _LIB_PATH
-    if force or not os.path.exists(_LIB_PATH) or any(
-            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in os.listdir(_HERE) if f.endswith((".c", ".h"))):
+    stamp, want = _LIB_PATH + ".sha256", _sources_digest()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if force or not os.path.exists(_LIB_PATH) or have != want:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
     return _LIB_PATH
 
 

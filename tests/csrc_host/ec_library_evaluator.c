@@ -20,36 +20,36 @@ static ec_spec spec(void) {
 uint32_t lib_ec_tape_per_cycle(void) { return EC_TAPE_PER_CYCLE; }
 uint32_t lib_ec_ws_bytes(void) { return (uint32_t)sizeof(ec_ws); }
 
-/* order 0: ec_eval_cycle. order 1: PRE main; runs 1.. in order; PRE's other parts, last first. `ts`: the stride between consecutive values
+/* order 0: ec_eval_cycle. order 1: the MAIN part of every segment in program order, the MULS parts, then the lists of LEAVES (as small items only), last first. `ts`: the stride between consecutive values
    of the tape (the kernels interleave the cycles of an instance: value t at tape[t * ts]). Returns 0 or the evaluator's failure code */
 uint32_t lib_ec_eval_cycle(const uint8_t *in, uint64_t *tape, int order, uint32_t ts) {
     const ec_spec S = spec();
     ec_ws W;
     memset(&W, 0xA5, sizeof W);
     if (order == 0) return ec_eval_cycle_strided(&S, in, tape, ts, &W);
-    static const uint32_t parts[EC_PRE_PARTS] = EC_PRE_PART_ITEMS_INIT;
+    static const uint32_t parts[EC_NUM_TYPES][EC_MAX_PARTS] = EC_PART_ITEMS_INIT;
     ec_eval_ctx E;
     E.S = &S; E.tape = tape; E.ts = ts; E.in = in; E.W = &W;
-    E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
-    int bad = ec_eval_items(&E, S.runs[0].type, 0, parts[0]);
-    if (bad) return (uint32_t)bad;
-    for (uint32_t r = 1; r < EC_NUM_RUNS; r++)
-        for (uint32_t j = 0; j < S.runs[r].count; j++) {
-            uint32_t prun, pinst;
-            ec_prev_segment(&S, r, j, &prun, &pinst);
-            E.base = S.runs[r].tape0 + j * S.types[S.runs[r].type].n_tape;
-            E.prev_base = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape;
-            E.prev_type = S.runs[prun].type;
-            E.inst = j;
-            bad = ec_eval_segment(&E, S.runs[r].type);
-            if (bad) return (r << 24) | (j << 12) | (uint32_t)bad;
+    for (int phase = 0; phase < 3; phase++) /* the MAIN parts in program order, the MULS parts, then the lists of LEAVES, last first */
+        for (uint32_t rr = 0; rr < EC_NUM_RUNS; rr++) {
+            const uint32_t r = phase == 2 ? EC_NUM_RUNS - 1 - rr : rr, type = S.runs[r].type;
+            for (uint32_t jj = 0; jj < S.runs[r].count; jj++) {
+                const uint32_t j = phase == 2 ? S.runs[r].count - 1 - jj : jj;
+                uint32_t prun, pinst;
+                ec_prev_segment(&S, r, j, &prun, &pinst);
+                E.base = S.runs[r].tape0 + j * S.types[type].n_tape;
+                E.prev_base = S.runs[prun].tape0 + pinst * S.types[S.runs[prun].type].n_tape;
+                E.prev_type = S.runs[prun].type;
+                E.inst = j;
+                for (int pp = 0; pp < EC_MAX_PARTS; pp++) {
+                    const int p = phase == 2 ? EC_MAX_PARTS - 1 - pp : pp;
+                    if ((p < 2 ? p : 2) != phase || parts[type][p] == 0) continue;
+                    uint32_t first = 0;
+                    for (int k = 0; k < p; k++) first += parts[type][k];
+                    const int bad = ec_eval_items_of(&E, type, first, parts[type][p], phase == 2);
+                    if (bad) return (r << 24) | (j << 12) | (uint32_t)bad;
+                }
+            }
         }
-    E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
-    for (int p = EC_PRE_PARTS - 1; p >= 1; p--) { /* (the parts are independent of each other) */
-        uint32_t first = 0;
-        for (int k = 0; k < p; k++) first += parts[k];
-        bad = ec_eval_items(&E, S.runs[0].type, first, parts[p]);
-        if (bad) return (uint32_t)bad;
-    }
     return 0;
 }

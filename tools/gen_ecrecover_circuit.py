@@ -483,7 +483,7 @@ def build_pre():
     s.globs = [v.a for v in xs + ys + bits + u1b + [ok, mask]]
     assert len(s.globs) == GL_COUNT
     s.finish()
-    s.parts = split_pre(s)
+    s.parts = split_segment(s)
     return s
 
 
@@ -506,21 +506,39 @@ def item_reads_writes(it):
     return {r.a for r in rd if r.kind == K_TAPE}, {r.a for r in wr}
 
 
-def split_pre(s, parts=2):
-    """PRE's items in the order MAIN, REST 0, REST 1, ...: MAIN = what the cycle's globals and the accumulator's start need (the
-    ancestors of `globs` and `out`): the accumulator chain of a request waits for exactly these. The REST (range checks, byte
-    decompositions, MUL rows, assertions: most of the segment) is evaluated beside the other segments, in `parts` lists that share no
-    tape value they write — every list keeps the segment's order, so an item still follows what it reads. Cells, homes and tape indices
-    are untouched (they were fixed by finish()); only the order the evaluator walks the items in changes. Returns the part sizes."""
+PART_ITEMS = 200  # items a list of a segment's LEAVES should hold
+
+
+def split_segment(s):
+    """the segment's items in the order MAIN, MULS, LEAVES 0, LEAVES 1, ...:
+      MAIN    the ancestors of what later segments read — the state the segment leaves (`out`) and, for PRE, the cycle's globals: the hints
+              and the limb-wise sums between them, a tenth of the items. PRE's MAIN is what the accumulator chain of a request waits for;
+              the MAINs of the other segments are one launch (every segment's input state is known from the chain);
+      MULS    the MUL rows (quotient and carries of a 256-bit product: the one item kind besides the hints that needs the 256-bit
+              workspace) and what they still need beyond MAIN (the lazy sums on their r side);
+      LEAVES  everything else — byte decompositions, range-check lookups, assertions: nine tenths of a segment, small items only — in
+              lists that share no tape value they write, a lane each.
+    Every list keeps the segment's order, so an item still follows what it reads. Cells, homes and tape indices are untouched (they were
+    fixed by finish()); only the order the evaluator walks the items in changes. Returns the sizes [MAIN, MULS, LEAVES...]."""
     rw = [item_reads_writes(it) for it in s.items]
+    n = len(s.items)
     needed = set(s.globs) | {r.a for r in s.out}
-    main = [False] * len(s.items)
-    for i in range(len(s.items) - 1, -1, -1):
+    main = [False] * n
+    for i in range(n - 1, -1, -1):
         if rw[i][1] & needed:
             main[i] = True
             needed |= rw[i][0]
-    rest = [i for i in range(len(s.items)) if not main[i]]
-    # components of the rest: items joined by a tape value one of them writes and another reads
+    heavy = lambda i: s.items[i]["k"] in (I_MUL, I_HINT)  # noqa: E731
+    muls, needed = [False] * n, set()
+    for i in range(n - 1, -1, -1):
+        if main[i]:
+            continue
+        if heavy(i) or (rw[i][1] & needed):
+            muls[i] = True
+            needed |= rw[i][0]
+    rest = [i for i in range(n) if not main[i] and not muls[i]]
+    assert not any(heavy(i) for i in rest)
+    # components of the leaves: items joined by a tape value one of them writes and another reads
     parent = {i: i for i in rest}
 
     def find(x):
@@ -540,20 +558,20 @@ def split_pre(s, parts=2):
     comps = {}
     for i in rest:
         comps.setdefault(find(i), []).append(i)
-    cost = lambda i: 12 if s.items[i]["k"] in (I_MUL, I_HINT) else 1  # noqa: E731  (a MUL row / a hint weighs about a dozen small items)
+    parts = max(1, round(len(rest) / PART_ITEMS))
     bins = [[] for _ in range(parts)]
-    load = [0] * parts
-    for c in sorted(comps.values(), key=lambda c: -sum(cost(i) for i in c)):
-        b = load.index(min(load))
+    for c in sorted(comps.values(), key=lambda c: -len(c)):
+        b = min(range(parts), key=lambda k: len(bins[k]))
         bins[b] += c
-        load[b] += sum(cost(i) for i in c)
-    order = [i for i in range(len(s.items)) if main[i]]
+    order = [i for i in range(n) if main[i]]
     sizes = [len(order)]
+    order += [i for i in range(n) if muls[i]]
+    sizes.append(len(order) - sizes[0])
     for b in bins:
         order += sorted(b)
         sizes.append(len(b))
     # an item still follows what it reads
-    pos, seen = {i: n for n, i in enumerate(order)}, {}
+    pos, seen = {i: k for k, i in enumerate(order)}, {}
     for i in order:
         for t in rw[i][0]:
             assert t in seen and pos[seen[t]] < pos[i], (s.name, "an item would run before what it reads", i)
@@ -579,6 +597,7 @@ def build_daa():
     bit = Ref(K_GLOBJ, GL_BITS + 255, -1)  # instance j takes bit 255 - j
     s.out = [s.sel(bit, x4[k], x3[k]) for k in range(16)] + [s.sel(bit, y4[k], y3[k]) for k in range(16)]
     s.finish()
+    s.parts = split_segment(s)
     return s
 
 
@@ -604,6 +623,7 @@ def build_fix():
     s.mul_checked(MOD_P, lam, dxx, s.lazy([(y3, 1), (y1, 1)]))
     s.out = [s.sel(z, x1[k], x3[k]) for k in range(16)] + [s.sel(z, y1[k], y3[k]) for k in range(16)]
     s.finish()
+    s.parts = split_segment(s)
     return s
 
 
@@ -616,6 +636,7 @@ def build_post():
     # (check_vec16 inside add_points made them): find them again as the NEW cells of the byte decompositions of qx / qy
     s.out = qx + qy
     s.finish()
+    s.parts = split_segment(s)
     return s
 
 
@@ -1004,8 +1025,9 @@ def emit_ec(spec, path):
     for name, idx in BIGS.items():
         w(f"#define EC_BIG_{name} {idx}")
     w(f"#define EC_GL_RX {GL_RX}\n#define EC_GL_RY {GL_RY}\n#define EC_GL_BITS {GL_BITS}\n#define EC_GL_U1 {GL_U1}\n#define EC_GL_OK {GL_OK}\n#define EC_GL_MASK {GL_MASK}\n#define EC_GL_COUNT {GL_COUNT}")
-    w("/* PRE's items come as MAIN (what the globals and the accumulator's start need), then the rest in lists that share no tape value they write */")
-    w(f"#define EC_PRE_PARTS {len(pre.parts)}\n#define EC_PRE_PART_ITEMS_INIT {{" + ", ".join(str(x) for x in pre.parts) + "}")
+    w("/* a segment type's items come as MAIN (what the state it leaves — PRE: and the globals — needs), MULS (the MUL rows and what else they need), then the leaves in lists that share no tape value they write: items per part */")
+    mp = max(len(st.parts) for st in spec.types)
+    w(f"#define EC_MAX_PARTS {mp}\n#define EC_PART_ITEMS_INIT {{" + ", ".join("{" + ", ".join(str(x) for x in st.parts + [0] * (mp - len(st.parts))) + "}" for st in spec.types) + "}")
     w(f"#define EC_T_XOR8 {T_XOR8}\n#define EC_T_FIXED0 {T_FIXED0}\n#define EC_ROWTAB_PER_INSTANCE {ROWTAB_PER_INSTANCE}")
     w("/* segment types {rows, tape values, item0 (words), items, index0, cell0, home0, out0, rowtab0} */")
     w("#define EC_TYPES_INIT {" + ", ".join("{" + ", ".join(str(x) for x in t) + "}" for t in types) + "}")
