@@ -19,6 +19,7 @@
 #include "../../include/zkw_ecrecover_circuit_spec.h"
 #include "../../include/zkw_ecrecover.h"
 #include "netlist_queue_kernels.cuh"
+#include "ec_field.cuh"
 
 namespace zkw {
 
@@ -60,143 +61,6 @@ static __device__ __forceinline__ void k_ec_tape(const VB& vb, const ec_spec* __
     if (ec_eval_cycle_strided(&S, j.inputs + (size_t)c * 128, j.tape + c, ec_tape_stride(capacity), &s_ws[threadIdx.x])) atomicMax(status, 1u + (vb.y << 16 | c));
 }
 
-// ---- the base field of secp256k1 for the accumulator chain: OUTLINED multiplication ------------------------------------------------
-// The chain below is ~6 500 multiplications mod p = 2^256 - 2^32 - 977 on ONE lane per request. With ec_mulmod inlined everywhere
-// (include/zkw_ecrecover.h: forced, because its operands travel as pointers) k_ec_chain was 62 000 instructions of straight-line code,
-// 22 000 of them register moves, far beyond the instruction cache: 17 ms per call whatever the batch (ECRecover at 0.003 of
-// HBM). Here the multiplication is ONE function of ~260 instructions that every call site CALLS: operands and result by value (eight
-// VGPRs each, no stack, no scratch), product scanning (a column at a time: one v_mad_u64_u32 + one add-with-carry per partial product
-// into a 96-bit accumulator), the fold hi * (2^32 + 977) + lo word by word through the same multiplier, one conditional subtraction.
-// Canonical in, canonical out, like ec_mulmod.
-namespace ecf {
-__device__ __forceinline__ void mac(u64& acc, u32& ext, u32 a, u32 b) {  // (ext : acc) += a * b
-    u64 c, dead;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(c) : "v"(a), "v"(b));
-    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %2" : "+v"(ext), "=s"(dead) : "s"(c));
-}
-__device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 acc) {  // a * b + acc (no overflow by construction)
-    u64 r, dead;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(dead) : "v"(a), "v"(b), "v"(acc));
-    return r;
-}
-// x (8 words) + carry-in chain helpers are written with 64-bit sums: the compiler keeps the carries in the adds
-__device__ __forceinline__ ec_u256 cond_sub_p(const u32* r, u32 top) {  // r + top * 2^256 < 2 p  ->  mod p
-    // r >= p  <=>  r + (2^32 + 977) carries out of 256 bits
-    u32 u[8];
-    u64 c = (u64)r[0] + 977u;
-    u[0] = (u32)c; c >>= 32;
-    c += (u64)r[1] + 1u;
-    u[1] = (u32)c; c >>= 32;
-#pragma unroll
-    for (int i = 2; i < 8; i++) { c += r[i]; u[i] = (u32)c; c >>= 32; }
-    const bool ge = top != 0 || c != 0;
-    ec_u256 o;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o.w[i] = ge ? u[i] : r[i];
-    return o;
-}
-__device__ __attribute__((noinline)) ec_u256 mul(ec_u256 a, ec_u256 b) {
-    // product scanning: one 96-bit accumulator walks the columns. (A form with one accumulator per column — eight independent chains in
-    // flight — was measured too: 15.0 instead of 13.0 ms per call; a lone wave issues a v_mad_u64_u32 every ~8 cycles whether it depends
-    // on the previous one or not (profiles/r05/valu_ceiling.json, one wave per SIMD), so the extra moves of that form only cost.)
-    u32 t[16];
-    u64 acc = 0;
-    u32 ext = 0;
-#pragma unroll
-    for (int k = 0; k < 15; k++) {
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (k - i >= 0 && k - i < 8) mac(acc, ext, a.w[i], b.w[k - i]);
-        t[k] = (u32)acc;
-        acc = (acc >> 32) | ((u64)ext << 32);
-        ext = 0;
-    }
-    t[15] = (u32)acc;
-    // fold: lo + hi * 977 + (hi << 32); word j: lo_j + 977 hi_j + hi_(j-1) + carry  (< 2^42 + 2^33: one 64-bit accumulator)
-    u32 r[8];
-    u64 cy = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        cy = mad32(t[8 + j], 977u, cy);
-        cy = mad32(t[j], 1u, cy);
-        if (j) cy = mad32(t[8 + j - 1], 1u, cy);
-        r[j] = (u32)cy;
-        cy >>= 32;
-    }
-    const u64 R = cy + t[15];  // what is left above 2^256: < 2^33 + 2^11
-    // second fold: R * (2^32 + 977) onto the low words (R * 977 < 2^45; R << 32 spans words 1..2)
-    u64 c2 = (u64)r[0] + (R & 0xFFFFFFFFull) * 977u;
-    r[0] = (u32)c2; c2 >>= 32;
-    c2 += (u64)r[1] + (R >> 32) * 977u + (R & 0xFFFFFFFFull);
-    r[1] = (u32)c2; c2 >>= 32;
-    c2 += (u64)r[2] + (R >> 32);
-    r[2] = (u32)c2; c2 >>= 32;
-#pragma unroll
-    for (int i = 3; i < 8; i++) { c2 += r[i]; r[i] = (u32)c2; c2 >>= 32; }
-    return cond_sub_p(r, (u32)c2);  // (a wrap leaves a tiny low part: one subtraction of p settles either case)
-}
-__device__ __attribute__((noinline)) ec_u256 add(ec_u256 a, ec_u256 b) {  // a, b < p
-    u32 r[8];
-    u64 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { c += (u64)a.w[i] + b.w[i]; r[i] = (u32)c; c >>= 32; }
-    return cond_sub_p(r, (u32)c);
-}
-__device__ __attribute__((noinline)) ec_u256 sub(ec_u256 a, ec_u256 b) {  // a, b < p
-    u32 r[8];
-    long long c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { c += (long long)a.w[i] - (long long)b.w[i]; r[i] = (u32)c; c >>= 32; }
-    if (c == 0) { ec_u256 o;
-#pragma unroll
-        for (int i = 0; i < 8; i++) o.w[i] = r[i];
-        return o; }
-    // borrowed: + p = - (2^32 + 977) mod 2^256
-    ec_u256 o;
-    long long d = (long long)r[0] - 977;
-    o.w[0] = (u32)d; d >>= 32;
-    d += (long long)r[1] - 1;
-    o.w[1] = (u32)d; d >>= 32;
-#pragma unroll
-    for (int i = 2; i < 8; i++) { d += r[i]; o.w[i] = (u32)d; d >>= 32; }
-    return o;
-}
-// Jacobian doubling (a = 0, 7 multiplications) and mixed addition (11), the formulas of ec_jdbl / ec_jmadd (include/zkw_ecrecover.h)
-__device__ __forceinline__ void jdbl(ec_u256& X, ec_u256& Y, ec_u256& Z) {
-    const ec_u256 a = mul(X, X), b = mul(Y, Y), c = mul(b, b);
-    ec_u256 t = add(X, b);
-    t = mul(t, t);
-    t = sub(t, a);
-    t = sub(t, c);
-    const ec_u256 d = add(t, t);
-    ec_u256 e = add(a, a);
-    e = add(e, a);
-    const ec_u256 f = mul(e, e), d2 = add(d, d), yz = mul(Y, Z);
-    X = sub(f, d2);
-    ec_u256 c8 = add(c, c);
-    c8 = add(c8, c8);
-    c8 = add(c8, c8);
-    ec_u256 dx = sub(d, X);
-    dx = mul(e, dx);
-    Y = sub(dx, c8);
-    Z = add(yz, yz);
-}
-__device__ __forceinline__ void jmadd(ec_u256& X, ec_u256& Y, ec_u256& Z, const ec_u256& x2, const ec_u256& y2) {
-    const ec_u256 zz = mul(Z, Z), zzz = mul(zz, Z), u2 = mul(x2, zz), s2 = mul(y2, zzz);
-    const ec_u256 h = sub(u2, X), r = sub(s2, Y);
-    const ec_u256 h2 = mul(h, h), h3 = mul(h2, h), xh2 = mul(X, h2);
-    ec_u256 t = mul(r, r);
-    t = sub(t, h3);
-    t = sub(t, xh2);
-    const ec_u256 x3 = sub(t, xh2);
-    ec_u256 v = sub(xh2, x3);
-    v = mul(r, v);
-    const ec_u256 yh3 = mul(Y, h3);
-    Z = mul(Z, h);
-    X = x3;
-    Y = sub(v, yh3);
-}
-}  // namespace ecf
 
 // ---- the fast form of the tape: the accumulator's trajectory first, then every segment on its own lane ------------------------------
 // The serial kernel above spends its time in ~550 modular inversions per cycle (every quotient lambda of the affine additions), one after
@@ -221,39 +85,44 @@ constexpr u32 EC_CHAIN_POINTS = 288;     // 256 double-and-add steps + 32 table 
 constexpr u32 EC_PART_ITEMS[EC_NUM_TYPES][EC_MAX_PARTS] = EC_PART_ITEMS_INIT;
 struct EcTask { u32 run, inst, first, count; };  // items [first, first + count) of segment (run, inst)
 
-__device__ __forceinline__ ec_u256 ec_load_limbs(const u64* __restrict__ tape, size_t ts, const uint32_t* __restrict__ idx) {
-    ec_u256 r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.w[i] = (u32)tape[idx[2 * i] * ts] | ((u32)tape[idx[2 * i + 1] * ts] << 16);
-    return r;
-}
-
-// grid (cycles, jobs) x 64: a WAVE per cycle, its first lane at work, and a SIMD per wave. The chain is bound by the SIMD's issue rate, not
-// by latency: a wave instruction costs its 4 (v_mad_u64_u32: 16) cycles whatever the number of active lanes — ~2 100 cycles per
-// multiplication mod p, 3.1 ms for the 256 steps — so two chain waves on one SIMD take twice as long, and lanes that share a wave run the
-// mixed addition at every step (one of seven bits of u2 is set 99 % of the time) instead of on half of them. Measured (32 instances, per
-// wave): 4.75 ms alone on a SIMD; one-wave workgroups land two or three to a SIMD wherever the dispatcher likes (4.7 .. 9 ms, the launch
-// takes the slowest); four-wave workgroups with a CU to themselves (an LDS request of more than half a CU) are NOT spread over the CU's
-// four SIMDs reliably (4.8 / 9.5 / 14 ms: four, two, one SIMD). What does hold: a wave that owns the SIMD's whole register file — the two
-// moves below make the kernel's footprint 256 + 256 registers — shares the SIMD with nobody, whoever else is running.
-constexpr int EC_CHAIN_WAVES = 1;
+// grid (cycles, jobs) x 64: a WAVE per cycle and a SIMD per wave. The chain is bound by the SIMD's issue rate, not by latency: a wave
+// instruction costs its 4 (v_mad_u64_u32: 16) cycles whatever the number of active lanes. So
+//  - the 256-bit arithmetic runs with a LIMB PER LANE (ec_field.cuh ecl: 8 multiply-adds on 16 lanes per product instead of 64 on one,
+//    words moved by DPP row shifts, carries settled by a lookahead over the lanes' ballot): ~600 cycles per multiplication mod p instead
+//    of ~2 100 with a value in one lane (the double-and-add loop was 3.1 ms of a 4.75 ms wave);
+//  - a request has a wave of its own: lanes that shared a wave ran the mixed addition at every step (one of seven bits of u2 is set 99 % of
+//    the time) instead of on half of them;
+//  - the wave owns its SIMD: two chain waves on one SIMD take twice as long, and neither one-wave workgroups (they land two or three to a
+//    SIMD wherever the dispatcher likes: 4.7 .. 9 ms per wave, the launch takes the slowest) nor four-wave workgroups with a CU to
+//    themselves (an LDS request of more than half a CU: NOT spread over the CU's four SIMDs reliably — 4.8 / 9.5 / 14 ms) give that. What
+//    does: a wave that holds the SIMD's whole register file — the two moves below make the kernel's footprint 256 + 256 registers —
+//    shares the SIMD with nobody, whoever else is running.
+// The MAIN items of PRE (an item interpreter, one value per lane) run on lane 0 first.
 static __device__ __forceinline__ void k_ec_chain(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
     asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");  // (the whole register file of the SIMD: see above)
-    __shared__ ec_ws s_ws[EC_CHAIN_WAVES];
+    __shared__ ec_ws s_ws;
     const EcJob j = jobs[vb.y];
-    const u32 c = vb.x * EC_CHAIN_WAVES + (threadIdx.x >> 6);
-    if (c >= capacity || (threadIdx.x & 63)) return;
+    const u32 c = vb.x, lane = threadIdx.x;
+    if (c >= capacity || lane >= 16) return;  // (ecl: lanes 0 .. 15 of the wave)
     const ec_spec S = *Sp;
-    ec_ws* W = &s_ws[threadIdx.x >> 6];
     const size_t ts = ec_tape_stride(capacity);
     u64* tape = j.tape + c;
-    ec_eval_ctx E;
-    E.S = &S; E.tape = tape; E.ts = (u32)ts; E.in = j.inputs + (size_t)c * 128; E.W = W;
-    E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
-    if (const int bad = ec_eval_items(&E, S.runs[0].type, 0, EC_PART_ITEMS[0][0])) { atomicMax(status, 1u + (vb.y << 16 | c)); (void)bad; return; }
+    u32 bad = 0;
+    if (lane == 0) {
+        ec_eval_ctx E;
+        E.S = &S; E.tape = tape; E.ts = (u32)ts; E.in = j.inputs + (size_t)c * 128; E.W = &s_ws;
+        E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
+        bad = ec_eval_items(&E, S.runs[0].type, 0, EC_PART_ITEMS[0][0]) != 0;
+        if (bad) atomicMax(status, 1u + (vb.y << 16 | c));
+    }
+    __threadfence_block();  // (lane 0's tape values are read by the wave's other lanes below)
+    if (__builtin_amdgcn_readlane(bad, 0)) return;
     const size_t slot = (size_t)vb.y * capacity + c;
     ec_jac* pts = sc.pts + slot * EC_CHAIN_POINTS;
-    const ec_u256 rx = ec_load_limbs(tape, ts, S.globs + EC_GL_RX), ry = ec_load_limbs(tape, ts, S.globs + EC_GL_RY);
+    const bool live = lane < 8;  // a value: limb i in lane i, zero in lanes 8 .. 15
+    const u32 li = lane & 7;
+    auto limb_of = [&](const uint32_t* idx) -> u32 { return live ? ((u32)tape[idx[2 * li] * ts] | ((u32)tape[idx[2 * li + 1] * ts] << 16)) : 0u; };
+    const u32 rx = limb_of(S.globs + EC_GL_RX), ry = limb_of(S.globs + EC_GL_RY);
     u32 bits[8];  // of u2, bit 255 - k = step k: loaded once (a load per step would be two dependent ones inside the serial loop)
 #pragma unroll
     for (int wd = 0; wd < 8; wd++) {
@@ -262,40 +131,29 @@ static __device__ __forceinline__ void k_ec_chain(const VB& vb, const ec_spec* _
         for (int b = 0; b < 32; b++) v |= (u32)(tape[S.globs[EC_GL_BITS + 32 * wd + b] * ts] & 1) << b;
         bits[wd] = v;
     }
-    ec_u256 one = ec_zero256(), ax, ay, az;
-    one.w[0] = 1;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        ax.w[i] = S.bigs[EC_BIG_OX * 16 + 2 * i] | (S.bigs[EC_BIG_OX * 16 + 2 * i + 1] << 16);
-        ay.w[i] = S.bigs[EC_BIG_OY * 16 + 2 * i] | (S.bigs[EC_BIG_OY * 16 + 2 * i + 1] << 16);
-    }
-    az = one;
+    u32 ax = live ? (S.bigs[EC_BIG_OX * 16 + 2 * li] | (S.bigs[EC_BIG_OX * 16 + 2 * li + 1] << 16)) : 0u;
+    u32 ay = live ? (S.bigs[EC_BIG_OY * 16 + 2 * li] | (S.bigs[EC_BIG_OY * 16 + 2 * li + 1] << 16)) : 0u;
+    u32 az = lane == 0 ? 1u : 0u;
 #pragma unroll 1
     for (int wd = 7; wd >= 0; wd--) {
-        const u32 word = bits[7];  // (the word of this pass: the array is rotated below so that every index is a constant)
+        const u32 word = (u32)__builtin_amdgcn_readfirstlane(bits[7]);  // (the word of this pass: the array is rotated below so that every index is a constant)
 #pragma unroll 1
         for (int b = 31; b >= 0; b--) {
             const u32 k = 255u - (32u * (u32)wd + (u32)b);
-            ecf::jdbl(ax, ay, az);
-            if ((word >> b) & 1) ecf::jmadd(ax, ay, az, rx, ry);
-            pts[k].x = ax; pts[k].y = ay; pts[k].z = az;
+            ecl::jdbl(ax, ay, az);
+            if ((word >> b) & 1) ecl::jmadd(ax, ay, az, rx, ry);
+            if (live) { pts[k].x.w[li] = ax; pts[k].y.w[li] = ay; pts[k].z.w[li] = az; }
         }
 #pragma unroll
         for (int i = 7; i > 0; i--) bits[i] = bits[i - 1];
     }
     for (u32 C = 0; C < 32; C++) {
-        const u32 b = (u32)tape[S.globs[EC_GL_U1 + C] * ts];
+        const u32 b = (u32)__builtin_amdgcn_readfirstlane((u32)tape[S.globs[EC_GL_U1 + C] * ts]);
         if (b) {  // minus byte * 2^(8C) * G: the table point with its y negated
-            ec_u256 tx, ty;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                tx.w[i] = S.fixed[((size_t)(8 * C + i) * 256 + b) * 2];
-                ty.w[i] = S.fixed[((size_t)(8 * C + i) * 256 + b) * 2 + 1];
-            }
-            const ec_u256 nty = ecf::sub(ec_zero256(), ty);
-            ecf::jmadd(ax, ay, az, tx, nty);
+            const u32 tx = live ? S.fixed[((size_t)(8 * C + li) * 256 + b) * 2] : 0u, ty = live ? S.fixed[((size_t)(8 * C + li) * 256 + b) * 2 + 1] : 0u;
+            ecl::jmadd(ax, ay, az, tx, ecl::sub(0u, ty));
         }
-        pts[256 + C].x = ax; pts[256 + C].y = ay; pts[256 + C].z = az;
+        if (live) { pts[256 + C].x.w[li] = ax; pts[256 + C].y.w[li] = ay; pts[256 + C].z.w[li] = az; }
     }
 }
 

@@ -1445,7 +1445,7 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
         } else {
             EcChainScratch sc{};
             ZKW_TRY(ctx->scratch_t<ec_jac>("ec_chain_pts", ni * capacity * (size_t)EC_CHAIN_POINTS, &sc.pts));
-            { Prof _p(ctx, "k_ec_chain"); ZKW_LAUNCH_2D(ctx, k_ec_chain, (capacity + EC_CHAIN_WAVES - 1) / EC_CHAIN_WAVES, nj, EC_CHAIN_WAVES * 64, ec->dev, d_jobs, capacity, d_status, sc); }
+            { Prof _p(ctx, "k_ec_chain"); ZKW_LAUNCH_2D(ctx, k_ec_chain, capacity, nj, 64, ec->dev, d_jobs, capacity, d_status, sc); }
             ZKW_TRY(launch_check("k_ec_chain"));
             const u32 n_cycles = (u32)(ni * capacity);
             { Prof _p(ctx, "k_ec_affine"); ZKW_LAUNCH(ctx, k_ec_affine, ((size_t)n_cycles * EC_CHAIN_POINTS + 63) / 64, 64, ec->dev, d_jobs, capacity, n_cycles, d_status, sc); }
