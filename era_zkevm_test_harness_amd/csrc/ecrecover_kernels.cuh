@@ -237,9 +237,14 @@ static __device__ __forceinline__ void k_ec_prepare(const VB& vb, const ec_spec*
     uint8_t* f = j.free_elems + (size_t)c * EK_FREE_PER_CYCLE;
     u64 st[25];
     for (int k = 0; k < 25; k++) st[k] = 0;
+    // the key bytes Q.x || Q.y, big end first, off the 16-bit limbs of the state POST leaves (its MAIN items: the byte cells themselves are
+    // among POST's leaves, which may still be on their way on the side stream)
     const u32 post0 = S.runs[EC_NUM_RUNS - 1].tape0;
-    for (int k = 0; k < 64; k++) {
-        const u64 b = tape[(post0 + S.key_byte[k]) * ts];
+    const uint32_t* post_out = S.outs + S.types[S.runs[EC_NUM_RUNS - 1].type].out0;
+#pragma unroll
+    for (int k = 0; k < 64; k++) {  // (unrolled: st[] stays in registers)
+        const int jb = k < 32 ? 31 - k : 63 - k;  // byte of the coordinate, little end first
+        const u64 b = (tape[(post0 + post_out[(k < 32 ? 0 : 16) + jb / 2]) * ts] >> (8 * (jb & 1))) & 0xFF;
         f[k] = (uint8_t)b;
         st[k / 8] |= b << (8 * (k % 8));
     }
@@ -265,13 +270,17 @@ struct EcStreamDev {
     const uint16_t* row_table;  // [EC_ROWS_PER_CYCLE]: the table the row's 16 slots look up (0: none)
     const uint16_t* xor_index;  // [EC_ROWS_PER_CYCLE]: the row's place among the cycle's Xor8 rows (the others: 0xFFFF)
     u32 n_xor_rows;
+    const u32* fix_rows;        // the cycle's rows that look up a FixedBaseMul table: row | table << 16
+    u32 n_fix_rows;
 };
 // grid (rows of a cycle / 64, cycles / 8, jobs) x 512: a lane per (row, cycle), the cycle fastest — eight neighbouring lanes read value t of
 // eight cycles from one line of the interleaved tape, and a wave stores eight rows of each of its cycles (64 contiguous bytes per cycle).
 // Multiplicities: the Xor8 lookups (16 per row on most rows: 27 M of a 32-instance call) leave 16-bit keys behind for k_ec_hist — as
-// global atomics on the multiplicity column they were 1.7 of the kernel's 3.8 ms; the FixedBaseMul lookups (8 per FIX segment) stay atomics.
+// global atomics on the multiplicity column they were 1.7 of the kernel's 3.8 ms; the FixedBaseMul lookups (8 rows per FIX segment) are
+// counted by k_ec_hist too, from the cells this kernel writes: the kernel itself never touches the multiplicity column, so it may run
+// beside the netlist's finish kernel, which stores that column.
 constexpr int EC_STREAM_ROWS = 64, EC_STREAM_THREADS = 8 * EC_STREAM_ROWS;
-static __device__ __forceinline__ void k_ec_stream(const VB& vb, EcStreamDev sd, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, u32 mult_col, uint16_t* __restrict__ keybuf) {
+static __device__ __forceinline__ void k_ec_stream(const VB& vb, EcStreamDev sd, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, uint16_t* __restrict__ keybuf) {
     const EcJob j = jobs[vb.z];
     const u32 c = vb.y * 8 + (threadIdx.x & 7), r = vb.x * EC_STREAM_ROWS + (threadIdx.x >> 3);
     if (r >= EC_ROWS_PER_CYCLE || c >= capacity) return;
@@ -299,7 +308,6 @@ static __device__ __forceinline__ void k_ec_stream(const VB& vb, EcStreamDev sd,
         const u32 key = (u32)a | ((u32)b << 8);
         if (slot & 1) keys[slot / 2] |= key << 16;
         else keys[slot / 2] = key;
-        if (tb > EC_T_XOR8) atomicAdd(reinterpret_cast<unsigned long long*>(&EC_TR(mult_col, ec_table_key(tb, a, b))), 1ull);
     }
     if (tb == EC_T_XOR8) {
         uint4* dst = reinterpret_cast<uint4*>(keybuf + (((size_t)vb.z * capacity + c) * sd.n_xor_rows + sd.xor_index[r]) * EC_R);
@@ -310,11 +318,19 @@ static __device__ __forceinline__ void k_ec_stream(const VB& vb, EcStreamDev sd,
 
 // grid (2 halves of the Xor8 table, jobs) x 1024: an instance's Xor8 keys (k_ec_stream) counted in LDS, the half's 32 768 bins added onto the
 // instance's multiplicity column — this workgroup's rows of it and nobody else's at that time (the netlist's own multiplicities are
-// there already: k_nl_finish, earlier on the stream)
+// there already: k_nl_finish, earlier on the stream). The second workgroup also counts the FixedBaseMul lookups, from the rows' cells
+// (16 slots a row: the byte's, and 15 padding slots that look up entry 0): a few thousand atomics on rows of the column nobody else adds to.
 constexpr int EC_HIST_THREADS = 1024, EC_HIST_HALF = 32768;
-static __device__ __forceinline__ void k_ec_hist(const VB& vb, const EcJob* __restrict__ jobs, u32 capacity, u32 n_xor_rows, size_t n_rows, u32 mult_col, const uint16_t* __restrict__ keybuf) {
+static __device__ __forceinline__ void k_ec_hist(const VB& vb, EcStreamDev sd, const EcJob* __restrict__ jobs, u32 capacity, size_t n_rows, size_t first_row, u32 mult_col, const uint16_t* __restrict__ keybuf) {
     __shared__ u32 s_bins[EC_HIST_HALF];
-    const u32 half = vb.x, t = threadIdx.x;
+    const u32 half = vb.x, t = threadIdx.x, n_xor_rows = sd.n_xor_rows;
+    u64* trace = jobs[vb.y].trace;
+    if (half == 1)
+        for (u32 i = t; i < capacity * sd.n_fix_rows * EC_R; i += EC_HIST_THREADS) {
+            const u32 slot = i % EC_R, fr = sd.fix_rows[(i / EC_R) % sd.n_fix_rows], c = i / (EC_R * sd.n_fix_rows);
+            const size_t tr = first_row + (size_t)c * EC_ROWS_PER_CYCLE + (fr & 0xFFFFu);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&EC_TR(mult_col, ec_table_key(fr >> 16, EC_TR(EC_G + EC_W * slot, tr), EC_TR(EC_G + EC_W * slot + 1, tr)))), 1ull);
+        }
     for (u32 i = t; i < EC_HIST_HALF; i += EC_HIST_THREADS) s_bins[i] = 0;
     __syncthreads();
     const size_t per_job = (size_t)capacity * n_xor_rows * EC_R;  // a multiple of 16 keys
@@ -330,7 +346,6 @@ static __device__ __forceinline__ void k_ec_hist(const VB& vb, const EcJob* __re
         }
     }
     __syncthreads();
-    u64* trace = jobs[vb.y].trace;
     for (u32 i = t; i < EC_HIST_HALF; i += EC_HIST_THREADS)
         if (const u32 n = s_bins[i]) EC_TR(mult_col, (size_t)half * EC_HIST_HALF + i) += n;  // (Xor8 sits at row 0 of the stacked tables: ec_table_key)
 }

@@ -1153,7 +1153,7 @@ int nlq_synthesize(zkw_ctx* ctx, int circuit_type, const NlqQueues& Q, const std
 struct NlcfCall { NlcfJob* d_jobs = nullptr; size_t n = 0; bool forked = false; };
 template <class T>
 int nlcf_begin(zkw_ctx* ctx, int circuit_type, const typename T::Inst* d_inst, size_t first_index, const std::vector<NlInstance>& inst, u32 cycles, size_t n_rows,
-               NlcfCall* call, const char* jobs_name = "nlcf_jobs") {
+               NlcfCall* call, const char* jobs_name = "nlcf_jobs", bool on_main_stream = false) {
     const nlcf_desc* d = nlcf_desc_of(circuit_type);
     const nl_spec* S = nl_host_spec(circuit_type);
     if (!d || !S) return fail(ZKW_ERR_INVALID, "circuit type %d has no closed-form section", circuit_type);
@@ -1164,7 +1164,8 @@ int nlcf_begin(zkw_ctx* ctx, int circuit_type, const typename T::Inst* d_inst, s
     ZKW_TRY(ctx->upload(jobs_name, jobs, &call->d_jobs));
     call->n = jobs.size();
     if (jobs.empty()) return ZKW_OK;
-    if (ctx->batched()) {  // a context of a batch has one stream: the sponges of all the group's blocks travel as one launch, behind the fills
+    if (ctx->batched() || on_main_stream) {  // a context of a batch has one stream: the sponges of all the group's blocks travel as one launch, behind the fills
+                                             // (on_main_stream: the caller's own fork is open — ECRecover's EC section)
         ZKW_LAUNCH_D(ctx, (k_nlcf_sponges<T>), "k_nlcf_sponges", dim3((unsigned)jobs.size()), 256, 0, *d, d_inst, (const NlcfJob*)call->d_jobs, S->g, n_rows, (u64)nlcf_first_row(circuit_type, S, cycles));
         return ZKW_OK;
     }
@@ -1224,6 +1225,7 @@ int ec_get(zkw_ctx* ctx, const EcCached** out) {
     {   // the rows of a cycle with every reference resolved (k_ec_stream): kind << 30 | payload, column-major
         std::vector<u32> refs((size_t)EC_ROW_CELLS * EC_ROWS_PER_CYCLE);
         std::vector<uint16_t> row_table(EC_ROWS_PER_CYCLE), xor_index(EC_ROWS_PER_CYCLE, 0xFFFF);
+        std::vector<u32> fix_rows;
         u32 n_xor = 0;
         for (u32 r = 0; r < EC_ROWS_PER_CYCLE; r++) {
             u32 run, inst, row, prun, pinst;
@@ -1248,11 +1250,14 @@ int ec_get(zkw_ctx* ctx, const EcCached** out) {
             }
             row_table[r] = (uint16_t)ec_row_table(&c.host, run, inst, row);
             if (row_table[r] == EC_T_XOR8) xor_index[r] = (uint16_t)n_xor++;
+            else if (row_table[r]) fix_rows.push_back(r | (u32)row_table[r] << 16);
         }
         ZKW_TRY(nl_to_device(refs.data(), refs.size(), &c.stream.refs));
         ZKW_TRY(nl_to_device(row_table.data(), row_table.size(), &c.stream.row_table));
         ZKW_TRY(nl_to_device(xor_index.data(), xor_index.size(), &c.stream.xor_index));
         c.stream.n_xor_rows = n_xor;
+        ZKW_TRY(nl_to_device(fix_rows.data(), fix_rows.size(), &c.stream.fix_rows));
+        c.stream.n_fix_rows = (u32)fix_rows.size();
     }
     {   // the item lists of k_ec_segments / k_ec_leaves: MAIN of the segments after PRE (PRE's is the chain kernel's), MULS, LEAVES
         std::vector<EcTask> mains, muls, leaves;
@@ -1428,17 +1433,23 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
     std::vector<EcJob> jobs(ni);
     EcJob* d_jobs = nullptr;
     const unsigned cb = (capacity + 1 + 63) / 64, nj = (unsigned)ni;
+    // the serial form (one lane walks a whole cycle, an inversion per quotient) is kept for cross-checks: ZKW_EC_SERIAL=1, same tape
+    static const bool serial = [] { const char* e = getenv("ZKW_EC_SERIAL"); return e && atoi(e) != 0; }();
+    const u32 n_cycles = (u32)(ni * capacity);
+    const unsigned chunks = (n_cycles + EC_TAPE_LANES - 1) / EC_TAPE_LANES;
+    const dim3 stream_grid((EC_ROWS_PER_CYCLE + EC_STREAM_ROWS - 1) / EC_STREAM_ROWS, (capacity + 7) / 8, nj);
+    uint16_t* d_keys = nullptr;  // the Xor8 lookups' keys: [instance][cycle][Xor8 row of the cycle][16]
+    ZKW_TRY(ctx->scratch_t<uint16_t>("ec_xor_keys", ni * capacity * (size_t)ec->stream.n_xor_rows * EC_R, &d_keys));
+    bool forked = false;
     // the netlist's inputs come from the EC tapes: evaluate them inside the engine's `prepare` step
-    SlotClaims claims;  // the slots' tags: committed after the EC section's stream kernel, the call's last launch
-    ZKW_TRY(nl_synthesize_with(ctx, 7, [&](std::vector<NlPrepJob>& prep) {
+    SlotClaims claims;  // the slots' tags: committed after the call's last launch
+    ZKW_TRY(nl_synthesize_with(ctx, 7, [&](std::vector<NlPrepJob>& prep) -> int {
         for (size_t k = 0; k < ni; k++)
             jobs[k] = EcJob{ws[w_of[k]]->mem_q, inst[k].first_round, inst[k].n_active, d_inputs + k * capacity * (size_t)128, d_tape + k * tape_per_instance,
                             inst[k].t->data + inst[k].slot * inst[k].t->slot_elems(), prep[k].hdr_bits, prep[k].free_elems, prep[k].state_before};
         ZKW_TRY(ctx->upload("ec_jobs", jobs, &d_jobs));
         { Prof _p(ctx, "k_ec_inputs"); ZKW_LAUNCH_2D(ctx, k_ec_inputs, capacity, nj, 128, d_jobs); }
         ZKW_TRY(launch_check("k_ec_inputs"));
-        // the serial form (one lane walks a whole cycle, an inversion per quotient) is kept for cross-checks: ZKW_EC_SERIAL=1, same tape
-        static const bool serial = [] { const char* e = getenv("ZKW_EC_SERIAL"); return e && atoi(e) != 0; }();
         if (serial) {
             { Prof _p(ctx, "k_ec_tape"); ZKW_LAUNCH_2D(ctx, k_ec_tape, (capacity + EC_TAPE_LANES - 1) / EC_TAPE_LANES, nj, EC_TAPE_LANES, ec->dev, d_jobs, capacity, d_status); }
             ZKW_TRY(launch_check("k_ec_tape"));
@@ -1447,24 +1458,35 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
             ZKW_TRY(ctx->scratch_t<ec_jac>("ec_chain_pts", ni * capacity * (size_t)EC_CHAIN_POINTS, &sc.pts));
             { Prof _p(ctx, "k_ec_chain"); ZKW_LAUNCH_2D(ctx, k_ec_chain, capacity, nj, 64, ec->dev, d_jobs, capacity, d_status, sc); }
             ZKW_TRY(launch_check("k_ec_chain"));
-            const u32 n_cycles = (u32)(ni * capacity);
             { Prof _p(ctx, "k_ec_affine"); ZKW_LAUNCH(ctx, k_ec_affine, ((size_t)n_cycles * EC_CHAIN_POINTS + 63) / 64, 64, ec->dev, d_jobs, capacity, n_cycles, d_status, sc); }
             ZKW_TRY(launch_check("k_ec_affine"));
-            const unsigned chunks = (n_cycles + EC_TAPE_LANES - 1) / EC_TAPE_LANES;
             { Prof _p(ctx, "k_ec_segments_main"); ZKW_LAUNCH_2D(ctx, k_ec_segments, ec->n_main, chunks, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, ec->tasks_main, d_status); }
             ZKW_TRY(launch_check("k_ec_segments"));
-            { Prof _p(ctx, "k_ec_segments_muls"); ZKW_LAUNCH_2D(ctx, k_ec_segments, ec->n_muls, chunks, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, ec->tasks_muls, d_status); }
-            ZKW_TRY(launch_check("k_ec_segments"));
-            { Prof _p(ctx, "k_ec_leaves"); ZKW_LAUNCH_2D(ctx, k_ec_leaves, ec->n_leaves, chunks, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, ec->tasks_leaves, d_status); }
-            ZKW_TRY(launch_check("k_ec_leaves"));
         }
+        // the netlist's inputs need the globals (PRE's MAIN: the chain kernel) and the state POST leaves (its MAIN) only
         { Prof _p(ctx, "k_ec_prepare"); ZKW_LAUNCH_2D(ctx, k_ec_prepare, cb, nj, 64, ec->dev, d_jobs, capacity); }
-        return launch_check("k_ec_prepare");
+        ZKW_TRY(launch_check("k_ec_prepare"));
+        if (!serial) {
+            // the rest of the EC section — MUL rows, leaves, the rows themselves — beside the netlist's fill, histogram and queue section:
+            // on the side stream (a context of a batch has one stream: behind the fills there)
+            hipStream_t st = ctx->stream;
+            if (!ctx->batched()) { ZKW_TRY(ctx->side_fork(&st)); forked = true; }
+            if (forked) {
+                Launcher<&k_ec_segments, EC_TAPE_LANES>::S::template single<&k_ec_segments, EC_TAPE_LANES>(st, dim3(ec->n_muls, chunks), 0, ec->dev, (const EcJob*)d_jobs, capacity, n_cycles, ec->tasks_muls, d_status);
+                ZKW_TRY(launch_check("k_ec_segments"));
+                Launcher<&k_ec_leaves, EC_TAPE_LANES>::S::template single<&k_ec_leaves, EC_TAPE_LANES>(st, dim3(ec->n_leaves, chunks), 0, ec->dev, (const EcJob*)d_jobs, capacity, n_cycles, ec->tasks_leaves, d_status);
+                ZKW_TRY(launch_check("k_ec_leaves"));
+                Launcher<&k_ec_stream, EC_STREAM_THREADS>::S::template single<&k_ec_stream, EC_STREAM_THREADS>(st, stream_grid, 0, ec->stream, (const EcJob*)d_jobs, capacity, n_rows, ec_first_row(capacity), d_keys);
+                ZKW_TRY(launch_check("k_ec_stream"));
+            } else {
+                { Prof _p(ctx, "k_ec_segments_muls"); ZKW_LAUNCH_2D(ctx, k_ec_segments, ec->n_muls, chunks, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, ec->tasks_muls, d_status); }
+                ZKW_TRY(launch_check("k_ec_segments"));
+                { Prof _p(ctx, "k_ec_leaves"); ZKW_LAUNCH_2D(ctx, k_ec_leaves, ec->n_leaves, chunks, EC_TAPE_LANES, ec->dev, d_jobs, capacity, n_cycles, ec->tasks_leaves, d_status); }
+                ZKW_TRY(launch_check("k_ec_leaves"));
+            }
+        }
+        return ZKW_OK;
     }, inst, capacity, n_rows, {}, &claims));
-    u32 status = 0;
-    ZKW_TRY(ctx->read_small(&status, d_status, 4));
-    if (status) return fail(ZKW_ERR_CHECK_FAILED, "zkw_ecrecover_synthesize: request %llu (instance %u of the call) has no witness (the accumulator of the incomplete addition met x1 == x2)",
-                            (unsigned long long)(inst[(status - 1) >> 16].first_round + ((status - 1) & 0xFFFF)), (unsigned)((status - 1) >> 16));
     for (size_t k = 0; k < n_ws; k++) {  // the queue sections: per witness (its request and memory queues)
         if (start_of[k + 1] == start_of[k]) continue;
         zkw_precompile_witness* w = ws[k];
@@ -1475,18 +1497,22 @@ static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const
         Q.round_ops = w->round_ops;
         const std::vector<NlInstance> sub(inst.begin() + start_of[k], inst.begin() + start_of[k + 1]);
         ZKW_TRY(nlq_synthesize(ctx, 7, Q, sub, capacity, n_rows));
-        NlcfCall cf;  // the closed-form section (a 34-word FSM: eight dependent permutations; the side stream buys nothing here)
+        NlcfCall cf;  // the closed-form section (a 34-word FSM: eight dependent permutations) on the main stream: the side stream is the EC section's
         char name[32];
         snprintf(name, sizeof name, "nlcf_jobs_%zu", k % 64);
-        ZKW_TRY((nlcf_begin<CfPrecompile<ZKW_PRECOMPILE_ECRECOVER>>(ctx, 7, w->instances, first[k], sub, capacity, n_rows, &cf, name)));
+        ZKW_TRY((nlcf_begin<CfPrecompile<ZKW_PRECOMPILE_ECRECOVER>>(ctx, 7, w->instances, first[k], sub, capacity, n_rows, &cf, name, true)));
         ZKW_TRY(nlcf_end(ctx, 7, cf, capacity, n_rows));
     }
-    uint16_t* d_keys = nullptr;  // the Xor8 lookups' keys: [instance][cycle][Xor8 row of the cycle][16]
-    ZKW_TRY(ctx->scratch_t<uint16_t>("ec_xor_keys", ni * capacity * (size_t)ec->stream.n_xor_rows * EC_R, &d_keys));
-    { Prof _p(ctx, "k_ec_stream"); ZKW_LAUNCH_D(ctx, (k_ec_stream), "k_ec_stream", dim3((EC_ROWS_PER_CYCLE + EC_STREAM_ROWS - 1) / EC_STREAM_ROWS, (capacity + 7) / 8, nj), EC_STREAM_THREADS, 0, ec->stream, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL, d_keys); }
-    ZKW_TRY(launch_check("k_ec_stream"));
-    { Prof _p(ctx, "k_ec_hist"); ZKW_LAUNCH_2D(ctx, k_ec_hist, 2, nj, EC_HIST_THREADS, d_jobs, capacity, ec->stream.n_xor_rows, n_rows, (u32)EK_MULT_COL, d_keys); }
-    return claims.commit_if(launch_check("k_ec_hist"));
+    if (forked) ZKW_TRY(ctx->side_join());
+    else { Prof _p(ctx, "k_ec_stream"); ZKW_LAUNCH_D(ctx, (k_ec_stream), "k_ec_stream", stream_grid, EC_STREAM_THREADS, 0, ec->stream, d_jobs, capacity, n_rows, ec_first_row(capacity), d_keys); }
+    // the Xor8 multiplicities onto the column the netlist's finish kernel has written
+    { Prof _p(ctx, "k_ec_hist"); ZKW_LAUNCH_2D(ctx, k_ec_hist, 2, nj, EC_HIST_THREADS, ec->stream, d_jobs, capacity, n_rows, ec_first_row(capacity), (u32)EK_MULT_COL, d_keys); }
+    ZKW_TRY(launch_check("k_ec_hist"));
+    u32 status = 0;
+    ZKW_TRY(ctx->read_small(&status, d_status, 4));
+    if (status) return fail(ZKW_ERR_CHECK_FAILED, "zkw_ecrecover_synthesize: request %llu (instance %u of the call) has no witness (the accumulator of the incomplete addition met x1 == x2)",
+                            (unsigned long long)(inst[(status - 1) >> 16].first_round + ((status - 1) & 0xFFFF)), (unsigned)((status - 1) >> 16));
+    return claims.commit_if(ZKW_OK);
 }
 
 extern "C" int zkw_ecrecover_synthesize(zkw_ctx* ctx, zkw_precompile_witness* w, size_t first_instance, size_t n_instances, zkw_trace* t, size_t first_slot) {

@@ -78,7 +78,7 @@ int main() {
     vals.push_back(from_words({0, 0, 0, 0, 1}));
     uint64_t st = 0x9E3779B97F4A7C15ull;
     auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
-    for (int k = 0; k < 40; k++) {
+    for (int k = 0; k < 160; k++) {
         ec_u256 v;
         for (int i = 0; i < 8; i++) v.w[i] = rnd();
         if (k % 4 == 1) for (int i = 2; i < 7; i++) v.w[i] = 0xFFFFFFFFu;  // runs of ones: carries ripple
