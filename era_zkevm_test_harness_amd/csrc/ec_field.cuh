@@ -272,5 +272,23 @@ __device__ __forceinline__ void jmadd(u32& X, u32& Y, u32& Z, u32 x2, u32 y2) {
     X = x3;
     Y = sub(v, yh3);
 }
+// a^((p + 1) / 4): the square root of a quadratic residue (p = 3 mod 4). Square-and-multiply over the constant exponent: uniform control flow
+__device__ __forceinline__ u32 pow_sqrt(u32 a) {
+    u32 r = a;
+    bool started = false;
+#pragma unroll 1
+    for (int wi = 7; wi >= 0; wi--) {
+        const u32 word = EC_P_SQRT_E[wi];
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; bit--) {
+            if (started) r = mul(r, r);
+            if ((word >> bit) & 1) {
+                if (started) r = mul(r, a);
+                started = true;  // (the first set bit: r = a already)
+            }
+        }
+    }
+    return r;
+}
 }  // namespace ecl
 }  // namespace zkw

@@ -107,20 +107,55 @@ static __device__ __forceinline__ void k_ec_chain(const VB& vb, const ec_spec* _
     const ec_spec S = *Sp;
     const size_t ts = ec_tape_stride(capacity);
     u64* tape = j.tape + c;
+    // PRE's MAIN items: an item walk on lane 0, but for the square root y = t^((p + 1) / 4) (EC_H_SQRT of include/zkw_ecrecover.h: ~500
+    // multiplications) in between, which the wave computes with a limb per lane
+    __shared__ u32 s_sqrt[10];  // t (8 words), the parity bit asked for, the tape index of the hint's 17 values
+    ec_eval_ctx E;
+    E.S = &S; E.tape = tape; E.ts = (u32)ts; E.in = j.inputs + (size_t)c * 128; E.W = &s_ws;
+    E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
     u32 bad = 0;
     if (lane == 0) {
-        ec_eval_ctx E;
-        E.S = &S; E.tape = tape; E.ts = (u32)ts; E.in = j.inputs + (size_t)c * 128; E.W = &s_ws;
-        E.base = S.runs[0].tape0; E.prev_base = 0; E.prev_type = 0; E.inst = 0;
-        bad = ec_eval_items(&E, S.runs[0].type, 0, EC_PART_ITEMS[0][0]) != 0;
+        bad = ec_eval_items(&E, S.runs[0].type, 0, EC_PRE_SQRT_ITEM) != 0;
+        if (!bad) {
+            const ec_seg_type& T0 = S.types[S.runs[0].type];
+            const uint32_t* w = S.items + T0.item0 + S.item_index[T0.index0 + EC_PRE_SQRT_ITEM];
+            const ec_mod M = ec_modulus(0);
+            uint32_t wide = 0;
+            const ec_u256 t = ec_get_reduced(&E, w[1], &M, &wide);
+            bad = wide != 0 || (w[0] & 15) != EC_I_HINT || (w[0] >> 24) != EC_H_SQRT;
+#pragma unroll
+            for (int i = 0; i < 8; i++) s_sqrt[i] = t.w[i];
+            s_sqrt[8] = (u32)ec_get(&E, w[2]) & 1u;
+            s_sqrt[9] = w[3];
+        }
         if (bad) atomicMax(status, 1u + (vb.y << 16 | c));
     }
-    __threadfence_block();  // (lane 0's tape values are read by the wave's other lanes below)
+    __threadfence_block();  // (lane 0's values are read by the wave's other lanes below)
+    if (__builtin_amdgcn_readlane(bad, 0)) return;
+    const bool live = lane < 8;  // a value: limb i in lane i, zero in lanes 8 .. 15
+    const u32 li = lane & 7;
+    {
+        const u32 t = live ? s_sqrt[li] : 0u;
+        u32 y = ecl::pow_sqrt(t), e_nr = 0;
+        if (__builtin_amdgcn_ballot_w64(ecl::mul(y, y) != t) & 0xFFull) {  // no root: a root of -t proves it (p = 3 mod 4)
+            e_nr = 1;
+            y = ecl::pow_sqrt(ecl::sub(0u, t));
+        } else if (((u32)__builtin_amdgcn_readlane(y, 0) & 1u) != s_sqrt[8]) {
+            y = ecl::sub(0u, y);
+        }
+        u64* out = tape + (size_t)(E.base + s_sqrt[9]) * ts;
+        if (live) { out[(size_t)(2 * li) * ts] = y & 0xFFFFu; out[(size_t)(2 * li + 1) * ts] = y >> 16; }
+        if (lane == 0) out[(size_t)16 * ts] = e_nr;
+    }
+    __threadfence_block();
+    if (lane == 0) {
+        bad = ec_eval_items(&E, S.runs[0].type, EC_PRE_SQRT_ITEM + 1, EC_PART_ITEMS[0][0] - EC_PRE_SQRT_ITEM - 1) != 0;
+        if (bad) atomicMax(status, 1u + (vb.y << 16 | c));
+    }
+    __threadfence_block();
     if (__builtin_amdgcn_readlane(bad, 0)) return;
     const size_t slot = (size_t)vb.y * capacity + c;
     ec_jac* pts = sc.pts + slot * EC_CHAIN_POINTS;
-    const bool live = lane < 8;  // a value: limb i in lane i, zero in lanes 8 .. 15
-    const u32 li = lane & 7;
     auto limb_of = [&](const uint32_t* idx) -> u32 { return live ? ((u32)tape[idx[2 * li] * ts] | ((u32)tape[idx[2 * li + 1] * ts] << 16)) : 0u; };
     const u32 rx = limb_of(S.globs + EC_GL_RX), ry = limb_of(S.globs + EC_GL_RY);
     u32 bits[8];  // of u2, bit 255 - k = step k: loaded once (a load per step would be two dependent ones inside the serial loop)

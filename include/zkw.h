@@ -653,7 +653,10 @@ int zkw_keccak_round_check_satisfied(zkw_ctx *ctx, const zkw_trace *t, size_t sl
    the bytes of u1 (FixedBaseMul lookups), normalisation; the read values are the section's inputs, the written values the netlist's
    masked digest and the success flag, all by copy constraints. A request whose accumulator meets x1 == x2 in the (incomplete, affine)
    addition has no witness: ZKW_ERR_CHECK_FAILED. w must be an ecrecover witness. n_rows >= zkw_circuit_layout_of(7, capacity).rows_used
-   (>= 197 632: the tables). Context scratch: 4 MB of value tape per request of the call. */
+   (>= 197 632: the tables). Context scratch: 4 MB of value tape per request of the call (the cycles of an instance interleaved: capacity
+   rounded up to 8 tapes per instance), 27 KB of Jacobian points per request, 240 KB of lookup keys per request. The call uses the
+   context's side stream (the EC section's rows are written beside the netlist's fill) and returns with both streams' work queued and the
+   status read: the slots are the caller's when it returns. */
 int zkw_ecrecover_synthesize(zkw_ctx *ctx, zkw_precompile_witness *w, size_t first_instance, size_t n_instances, zkw_trace *t,
                              size_t first_slot);
 /* Every instance of every witness (e.g. one ECRecover witness per block), in order, into slots first_slot ..: ONE launch of every EC
@@ -1112,7 +1115,7 @@ int zkw_block_synthesize_sharded(zkw_block *b, size_t n_rows, size_t ring_slots,
 /* K blocks at once (after zkw_blocks_run): every synthesizable instance of every block, each trace cell for cell what zkw_block_synthesize
    hands out for the same (block, type, instance). How it differs from K calls of zkw_block_synthesize: (1) the ECRecover instances of ALL blocks
    are synthesized in joint calls (zkw_ecrecover_synthesize_multi: at most ec_chunk instances each, 0 = 16, at most 64) on two threads of the
-   library with rings and priority streams of their own — a request's accumulator chain costs ~13 ms per call whatever the batch; (2) the other
+   library with rings and priority streams of their own — a request's accumulator chain costs ~3.5 ms per call whatever the batch (round 5: 13 ms); (2) the other
    types run on a few workers (ZKW_SYNTH_THREADS, default 3), each with ONE ring of 16 x ring_slots slots (a ring belongs to a worker, not to a
    block: 1.28 GB a slot) and a contiguous share of the blocks: 16 fibers of the worker's thread own a slot each and go through their blocks TYPE BY
    TYPE, in step, so that a type's fills leave as one launch per kernel over 16 instances and a slot keeps its layout from call to call

@@ -341,7 +341,7 @@ EC_HD void ec_from_limbs16(const uint32_t *l, uint32_t *out) {
     }
     out[8] = (uint32_t)acc;
 }
-EC_HD void ec_to_limbs16(const ec_u256 *a, uint64_t *l, size_t ts) { /* limb k at l[k * ts] */
+EC_HD void ec_to_limbs16(const ec_u256 *a, ec_tp l, size_t ts) { /* limb k at l[k * ts] */
     EC_UNROLL for (int k = 0; k < 8; k++) {
         l[(size_t)(2 * k) * ts] = a->w[k] & 0xFFFFu;
         l[(size_t)(2 * k + 1) * ts] = a->w[k] >> 16;
@@ -361,7 +361,7 @@ typedef struct ec_eval_ctx {
 
 EC_HD uint64_t ec_get(const ec_eval_ctx *E, uint32_t ref) {
     const uint32_t t = ec_ref_tape(E->S, ref, E->base, E->prev_base, E->prev_type, E->inst);
-    return t != EC_NONE ? E->tape[(size_t)t * E->ts] : ec_ref_const(E->S, ref, E->in);
+    return t != EC_NONE ? ((ec_ctp)E->tape)[(size_t)t * E->ts] : ec_ref_const(E->S, ref, E->in);
 }
 /* the 16 limbs a reference names; returns nonzero when one of them does not fit 32 bits (no limb vector of a satisfiable cycle does:
    canonical limbs are 16 bits, lazy sums of a few of them with the limbs of 4 m stay below 2^24) */
@@ -376,7 +376,7 @@ EC_HD uint32_t ec_get_vec(const ec_eval_ctx *E, uint32_t ref0, uint32_t *out) {
 }
 /* q (16 limbs, the top one up to 24 bits) and the 15 carries (+ 2^31) of a MUL row (element k at [k * ts]); a, b, r: limb vectors (W->va /
    vb / vc or any memory); returns 0 when a * b + 8 m - r is not a non-negative multiple of m (no witness) */
-EC_HD int ec_mul_witness(const uint32_t *a, const uint32_t *b, const uint32_t *r, uint32_t which, uint64_t *q, uint64_t *c, size_t ts, ec_ws *W) {
+EC_HD int ec_mul_witness(const uint32_t *a, const uint32_t *b, const uint32_t *r, uint32_t which, ec_tp q, ec_tp c, size_t ts, ec_ws *W) {
     const ec_mod M = ec_modulus(which);
     uint32_t *A = W->A, *B = W->B, *T = W->big, *Q = W->big + 20, *Qc = W->big + 32;
     ec_from_limbs16(a, A);
@@ -464,18 +464,24 @@ EC_HD int ec_eval_segment(ec_eval_ctx *E, uint32_t type) { return ec_eval_items(
 /* items [first, first + count) of the segment type, in order (the whole segment, or one of its parts: EC_PART_ITEMS_INIT). small_only (a
    constant at every call site: the branch folds): the list holds no MUL row and no hint — a segment's LEAVES — so E->W is not used (nor
    the registers of the 256-bit arithmetic); such an item in the list is reported as one without a witness */
-EC_HD int ec_eval_items_of(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32_t count, const int small_only) {
+EC_HD int ec_eval_items_of(ec_eval_ctx *E_in, uint32_t type, uint32_t first, uint32_t count, const int small_only) {
+    /* every lane of a wave walks the SAME list (its lanes are cycles): the position in the list and what a reference decodes through are
+       uniform, and saying so (EC_UNIFORM) lets the item words and the spec's tables come by scalar loads; only tape values and input bytes
+       are per lane */
+    ec_eval_ctx U = *E_in, *E = &U;
+    U.base = EC_UNIFORM(U.base); U.prev_base = EC_UNIFORM(U.prev_base); U.prev_type = EC_UNIFORM(U.prev_type); U.inst = EC_UNIFORM(U.inst); U.ts = EC_UNIFORM(U.ts);
+    type = EC_UNIFORM(type); first = EC_UNIFORM(first); count = EC_UNIFORM(count);
     const ec_spec *S = E->S;
-    const ec_seg_type *T = &S->types[type];
-    const uint32_t *w = S->items + T->item0 + S->item_index[T->index0 + first];
+    const ec_ctype T = (ec_ctype)S->types + type;
+    ec_cw w = (ec_cw)S->items + EC_UNIFORM(T->item0 + ((ec_cw)S->item_index)[T->index0 + first]);
     const size_t ts = E->ts;
-    uint64_t *tape = E->tape + (size_t)E->base * ts; /* value k of this segment at tape[k * ts] */
+    ec_tp tape = (ec_tp)E->tape + (size_t)E->base * ts; /* value k of this segment at tape[k * ts] */
     ec_ws *W = E->W;
-    for (uint32_t n = first; n < first + count; n++, w += ec_item_words(w)) {
+    for (uint32_t n = first; n < first + count; n++, w += ec_item_words_of(w[0], w[1])) {
         const uint32_t kind = w[0] & 15, aux = w[0] >> 24;
         if (kind == EC_I_LIN) {
             const uint32_t nk = aux, nn = w[1];
-            const uint32_t *kn = w + 4, *nw = w + 4 + 2 * nk;
+            ec_cw kn = w + 4, nw = w + 4 + 2 * nk;
             if (nn == 1 && nw[1] == 0) { /* one NEW cell = the whole sum, in the field (it may be "negative") */
                 uint64_t acc = ec_gl_from_i64((int64_t)((uint64_t)w[2] | ((uint64_t)w[3] << 32)));
                 for (uint32_t i = 0; i < nk; i++) {
@@ -515,8 +521,8 @@ EC_HD int ec_eval_items_of(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32
             } else {
                 if (a > 255) return 1 + (int)n;
                 const uint32_t tb = (w[1] & 0xFF) - EC_T_FIXED0 + 8 * E->inst;
-                tape[(size_t)(w[4]) * ts] = S->fixed[((size_t)tb * 256 + a) * 2];
-                tape[(size_t)(w[4] + 1) * ts] = S->fixed[((size_t)tb * 256 + a) * 2 + 1];
+                tape[(size_t)(w[4]) * ts] = ((ec_cw)S->fixed)[((size_t)tb * 256 + a) * 2];
+                tape[(size_t)(w[4] + 1) * ts] = ((ec_cw)S->fixed)[((size_t)tb * 256 + a) * 2 + 1];
             }
         } else if (small_only) {
             return 1 + (int)n;
@@ -562,7 +568,7 @@ EC_HD int ec_eval_items_of(ec_eval_ctx *E, uint32_t type, uint32_t first, uint32
         } else { /* EC_H_GE: a >= the constant */
             int ge = 1;
             for (int i = 15; i >= 0; i--) {
-                const uint64_t av = ec_get(E, w[1] + (uint32_t)i), cst = S->bigs[w[2] * 16 + (uint32_t)i];
+                const uint64_t av = ec_get(E, w[1] + (uint32_t)i), cst = ((ec_cw)S->bigs)[w[2] * 16 + (uint32_t)i];
                 if (av != cst) { ge = av > cst; break; }
             }
             tape[(size_t)(w[3]) * ts] = (uint64_t)ge;

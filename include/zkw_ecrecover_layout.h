@@ -26,6 +26,23 @@
 #define EC_HD static inline
 #endif
 
+/* The spec's arrays through the CONSTANT address space and a tape through the GLOBAL one on the device: a generic pointer makes every access
+   a flat load (85 of them in the item walk of a segment's leaves, each a round trip of its own), while a constant-space load at a uniform
+   index — the item words, the tables a reference decodes through: the same for all lanes of a wave — is a scalar load. Plain pointers on a host. */
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) uint32_t *ec_cw;
+typedef const __attribute__((address_space(4))) uint16_t *ec_ch;
+typedef __attribute__((address_space(1))) uint64_t *ec_tp;
+typedef const __attribute__((address_space(1))) uint64_t *ec_ctp;
+#define EC_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x))) /* a value every lane of the wave holds alike: into a scalar register */
+#else
+#define EC_UNIFORM(x) ((uint32_t)(x))
+typedef const uint32_t *ec_cw;
+typedef const uint16_t *ec_ch;
+typedef uint64_t *ec_tp;
+typedef const uint64_t *ec_ctp;
+#endif
+
 enum { EC_I_LIN = 1, EC_I_SEL = 2, EC_I_FMA = 3, EC_I_MUL = 4, EC_I_HINT = 5, EC_I_LOOKUP = 6 };
 enum { EC_H_MULSUB = 1, EC_H_DIV = 2, EC_H_SQRT = 3, EC_H_ISZERO = 4, EC_H_GE = 5 };
 enum { EC_K_TAPE = 0, EC_K_PREV = 1, EC_K_GLOB = 2, EC_K_GLOBJ = 3, EC_K_CONST = 4, EC_K_BIG = 5, EC_K_IN = 6 };
@@ -47,6 +64,12 @@ typedef struct ec_spec {
     const uint32_t *fixed; /* EC_FIXED_WORDS, the 256 FixedBaseMul tables, built by the includer */
 } ec_spec;
 
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) ec_seg_type *ec_ctype;
+#else
+typedef const ec_seg_type *ec_ctype;
+#endif
+
 #define EC_DEFINE_SPEC(name)                                                                                            \
     static const ec_seg_type name##_types[] = EC_TYPES_INIT;                                                            \
     static const ec_run name##_runs[] = EC_RUNS_INIT;                                                                   \
@@ -66,17 +89,26 @@ EC_HD uint32_t ec_ref_tape(const ec_spec *S, uint32_t ref, uint32_t base, uint32
     const uint32_t kind = ref >> 28, a = ref & 0x0FFFFFFFu;
     switch (kind) {
         case EC_K_TAPE: return base + a;
-        case EC_K_PREV: return prev_base + S->outs[S->types[prev_type].out0 + a];
-        case EC_K_GLOB: return S->globs[a];
-        case EC_K_GLOBJ: return S->globs[(a & 0xFFFFu) + (uint32_t)((int32_t)(int8_t)(a >> 16) * (int32_t)inst)];
+        case EC_K_PREV: return prev_base + ((ec_cw)S->outs)[((ec_ctype)S->types)[prev_type].out0 + a];
+        case EC_K_GLOB: return ((ec_cw)S->globs)[a];
+        case EC_K_GLOBJ: return ((ec_cw)S->globs)[(a & 0xFFFFu) + (uint32_t)((int32_t)(int8_t)(a >> 16) * (int32_t)inst)];
         default: return EC_NONE;
     }
 }
 EC_HD uint64_t ec_ref_const(const ec_spec *S, uint32_t ref, const uint8_t *in) {
     const uint32_t kind = ref >> 28, a = ref & 0x0FFFFFFFu;
     if (kind == EC_K_CONST) return a;
-    if (kind == EC_K_BIG) return S->bigs[(a >> 4) * 16 + (a & 15)];
+    if (kind == EC_K_BIG) return ((ec_cw)S->bigs)[(a >> 4) * 16 + (a & 15)];
     return in[a]; /* EC_K_IN */
+}
+EC_HD uint32_t ec_item_words_of(uint32_t w0, uint32_t w1) {
+    const uint32_t kind = w0 & 15, aux = w0 >> 24;
+    switch (kind) {
+        case EC_I_LIN: return 4 + 2 * aux + 2 * w1;
+        case EC_I_SEL: case EC_I_FMA: case EC_I_LOOKUP: return 5;
+        case EC_I_MUL: return 6;
+        default: return aux == EC_H_MULSUB ? 7 : aux == EC_H_DIV ? 5 : aux == EC_H_SQRT ? 4 : aux == EC_H_ISZERO ? 3 : 4;
+    }
 }
 EC_HD uint32_t ec_item_words(const uint32_t *w) {
     const uint32_t kind = w[0] & 15, aux = w[0] >> 24;

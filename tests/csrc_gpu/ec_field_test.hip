@@ -11,7 +11,7 @@
 
 using namespace zkw;
 
-struct Out { ec_u256 mul_l, add_l, sub_l, mul_f, add_f, sub_f, jd_l[3], jd_f[3], ja_l[3], ja_f[3]; };
+struct Out { ec_u256 mul_l, add_l, sub_l, mul_f, add_f, sub_f, jd_l[3], jd_f[3], ja_l[3], ja_f[3], sqrt_l; };
 
 __device__ ec_u256 gather(u32 v) {  // the limbs of a lane-form value, in lane 0
     ec_u256 r;
@@ -30,10 +30,11 @@ __global__ void k_test(const ec_u256* A, const ec_u256* B, Out* out, int n) {
         ecl::jdbl(X, Y, Z);
         u32 X2 = a, Y2 = b, Z2 = m;
         ecl::jmadd(X2, Y2, Z2, s, d);
+        const ec_u256 gq = gather(i % 37 == 0 ? ecl::pow_sqrt(a) : 0u);  // (a^((p + 1) / 4): ~500 multiplications, on a sample of the pairs)
         const ec_u256 gm = gather(m), gs = gather(s), gd = gather(d), gx = gather(X), gy = gather(Y), gz = gather(Z), hx = gather(X2), hy = gather(Y2), hz = gather(Z2);
         if (lane == 0) {
             Out& o = out[i];
-            o.mul_l = gm; o.add_l = gs; o.sub_l = gd;
+            o.mul_l = gm; o.add_l = gs; o.sub_l = gd; o.sqrt_l = gq;
             o.jd_l[0] = gx; o.jd_l[1] = gy; o.jd_l[2] = gz;
             o.ja_l[0] = hx; o.ja_l[1] = hy; o.ja_l[2] = hz;
             const ec_u256 fa = A[i], fb = B[i];
@@ -111,6 +112,10 @@ int main() {
                 else if (!eq(O[i].mul_l, m)) bad = "ecl::mul";
                 else if (!eq(O[i].add_l, s)) bad = "ecl::add";
                 else if (!eq(O[i].sub_l, d)) bad = "ecl::sub";
+                else if (i % 37 == 0) {
+                    const ec_u256 q = ec_powmod(&A[i], EC_P_SQRT_E, &M, &W);
+                    if (!eq(O[i].sqrt_l, q)) bad = "ecl::pow_sqrt";
+                }
             } else
                 for (int k = 0; k < 3 && !bad; k++) {
                     if (!eq(O[i].jd_l[k], O[i].jd_f[k])) bad = "jdbl";

@@ -1026,6 +1026,9 @@ def emit_ec(spec, path):
         w(f"#define EC_BIG_{name} {idx}")
     w(f"#define EC_GL_RX {GL_RX}\n#define EC_GL_RY {GL_RY}\n#define EC_GL_BITS {GL_BITS}\n#define EC_GL_U1 {GL_U1}\n#define EC_GL_OK {GL_OK}\n#define EC_GL_MASK {GL_MASK}\n#define EC_GL_COUNT {GL_COUNT}")
     w("/* a segment type's items come as MAIN (what the state it leaves — PRE: and the globals — needs), MULS (the MUL rows and what else they need), then the leaves in lists that share no tape value they write: items per part */")
+    sq = [i for i, it in enumerate(pre.items) if it["k"] == I_HINT and it["hint"] == H_SQRT]
+    assert len(sq) == 1 and sq[0] < pre.parts[0], "the square root is one item of PRE's MAIN part"
+    w(f"/* PRE's square-root hint (an item of its MAIN part): k_ec_chain evaluates it with a limb per lane between the items before and after it */\n#define EC_PRE_SQRT_ITEM {sq[0]}")
     mp = max(len(st.parts) for st in spec.types)
     w(f"#define EC_MAX_PARTS {mp}\n#define EC_PART_ITEMS_INIT {{" + ", ".join("{" + ", ".join(str(x) for x in st.parts + [0] * (mp - len(st.parts))) + "}" for st in spec.types) + "}")
     w(f"#define EC_T_XOR8 {T_XOR8}\n#define EC_T_FIXED0 {T_FIXED0}\n#define EC_ROWTAB_PER_INSTANCE {ROWTAB_PER_INSTANCE}")

@@ -177,6 +177,8 @@ if valu:
     w("\nPeak issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave-instruction = 6.14e11 wave-instructions/s; bench.py's `roofline_valu` divides.")
 for name, title in (("full_block_probe.txt", "One production-capacity block (tools/probe_block.py, ZKW_BLOCK_PROFILE=1: per-kernel HIP-event times of every branch's context, then the spans)"),
                     ("synthesis_probes.txt", "Synthesis of the other circuit types at production geometry (tools/probe_{ds,es,ld,ss}_synth.py, 16 instances per pass; tools/probe_netlist_perf.py)"),
+                    ("ecrecover_steps.txt", "ECRecover synthesis at 32 instances per call through round 6's steps (tools/probe_ecrecover_synth.py on the box after each step; per-kernel HIP-event times in ms; docs/KERNELS.md 3.19)"),
+                    ("ecrecover_kernel_stats.csv", "rocprofv3 --kernel-trace --stats of tools/probe_ecrecover_synth.py (ECRecover at production geometry: 4 calls of 8 and 4 calls of 32 instances + the builder and two checks)"),
                     ("blocks_in_flight.txt", "K production-capacity blocks in flight at once (tools/probe_blocks_pipeline.py K 3 seq device: zkw_blocks_run + zkw_blocks_synthesize + zkw_blocks_free, batch after batch; the summary line of 3 batches)"),
                     ("blocks_kernel_stats.csv", "rocprofv3 --kernel-trace --stats of the block leg alone (tools/probe_blocks_pipeline.py 512 2 seq device: warm-up batch + 2 batches of 512 blocks; ` [merged]` = the k_multi form)"),
                     ("builders_timeline_512.txt", "The builders of 512 blocks, one line per flush of the batch (ZKW_BATCH_LOG=2 tools/probe_blocks_builders_trace.py 512; second run)"),
@@ -196,7 +198,7 @@ for name, title in (("full_block_probe.txt", "One production-capacity block (too
         w("```")
         txt = open(path).read().rstrip().splitlines()
         if name.endswith("_kernel_stats.csv"):
-            hdr, body = txt[0], txt[1:26 if name.startswith("blocks") else 12]
+            hdr, body = txt[0], txt[1:26 if name.startswith("blocks") else 16 if name.startswith("ecrecover") else 12]
             txt = [hdr] + ['"%s",%s' % (short(l.split('",')[0].lstrip('"')), l.split('",', 1)[1][:60]) if '",' in l else l[:170] for l in body]
         if name == "builders_timeline_512.txt":
             txt = txt[-80:]
