@@ -367,12 +367,12 @@ def hash_circuits_gpu(local_rank, blk):
         t = native.Trace(ctx, n_rows, n, n_cols=cols)
         out[name] = dict(timed(n, lambda: synth(w, t, 0, n, 0), trace=t, ctype=ctype, cap=cap), capacity=cap, columns=cols, trace_bytes=cols * n_rows * 8)
         t.free()
-        if ctype == 7:  # the accumulator chain of a request is serial (a wave per request, ~3.6 ms per call whatever the batch): a second figure at 32 instances per call
+        if ctype == 7:  # the accumulator chain of a request is serial (a wave per request, ~2.5 ms per call whatever the batch): a second figure at 32 instances per call
             n32 = min(32, w.num_instances)
             t = native.Trace(ctx, n_rows, n32, n_cols=cols)
             out[name]["at_32_instances_per_call"] = timed(n32, lambda: synth(w, t, 0, n32, 0))
             out[name]["note"] = ("7 requests per instance (geometry_config.rs): the accumulator chain of a request is serial — k_ec_chain, a wave per request that owns its "
-                                 "SIMD, 256-bit arithmetic with a limb per lane: ~3.6 ms per call whatever the batch (round 5: one lane per request, 13 ms) —, the segments "
+                                 "SIMD, 256-bit arithmetic with a limb per lane: ~2.5 ms per call whatever the batch (round 5: one lane per request, 13 ms) —, the segments "
                                  "are item lists (MAIN / MULS / LEAVES) side by side, the EC rows stream beside the netlist's fill: docs/KERNELS.md 3.19, profiles/r06/README.md")
             # ... and that chain is a wave per request on a SIMD of its own: MORE CALLS IN FLIGHT (a context = a stream, its own witness and slots, one
             # host thread each) run their chains under the other calls' segment / stream kernels.

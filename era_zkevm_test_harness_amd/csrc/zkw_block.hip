@@ -1064,7 +1064,7 @@ static void priority_stream_release(int device, hipStream_t s) {
 
 // ---- K blocks: every instance of every block. Two things differ from K calls of zkw_block_synthesize: (1) the ECRecover instances of ALL
 // blocks go through joint calls (zkw_ecrecover_synthesize_multi, at most `ec_chunk` instances each, a ring of their own): the accumulator
-// chain of a request was one lane and ~13 ms per call whatever the batch (round 6: a wave, 3.5 ms), so 48 blocks' calls one after the other were 0.6 of the 0.75 s
+// chain of a request was one lane and ~13 ms per call whatever the batch (round 6: a wave, 2.5 ms), so 48 blocks' calls one after the other were 0.6 of the 0.75 s
 // their synthesis took; (2) the other types run block by block on up to 8 host threads of the library (each block on its own ring of
 // `ring_slots` slots and its own contexts), next to the ECRecover thread. cb may be called from several threads at once; a slot is the
 // callee's until it returns (external_calls::run's circuit_callback, per block in the reference's emission order except that ECRecover
@@ -1091,7 +1091,7 @@ extern "C" int zkw_blocks_synthesize(zkw_block* const* blocks, size_t n_blocks, 
         return f->cb ? f->cb(f->user, f->block, type, inst, tr, slot, pi) : 0;
     };
     // (1) ECRecover of all blocks: joint calls of up to ec_chunk instances, on ZKW_EC_THREADS threads (default 2), each with a ring and a context of
-    // its own on a HIGH-PRIORITY stream. A call is latency — the accumulator chain of a request is one wave, ~3.5 ms whatever the batch (13 ms when this was written), the
+    // its own on a HIGH-PRIORITY stream. A call is latency — the accumulator chain of a request is one wave, ~2.5 ms whatever the batch (13 ms when this was written), the
     // segment evaluator's dependent loads another ~9 ms — and next to the other types' fills a single thread on an ordinary stream was the
     // long pole of the whole synthesis (its kernels queued behind the fills: 2.2 - 3.1 s for the 1 024 instances of 512 blocks, the workers done
     // after 1.6 - 1.9 s); priority streams have hardware queues of their own, and two calls in flight hide each other's serial kernels.

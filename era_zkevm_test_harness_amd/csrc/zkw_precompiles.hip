@@ -1389,7 +1389,7 @@ extern "C" int zkw_keccak_round_check_satisfied(zkw_ctx* ctx, const zkw_trace* t
 // 197 632 table rows (base_layer/ecrecover.rs:30-41,138-176). One cycle per request (ecrecover.rs:143-178: four reads, two writes):
 // the EC section recovers the key from the read values, the netlist hashes it, the queue section pops the call and pushes the queries.
 // The instances [first[k], first[k] + count[k]) of witness ws[k], k = 0 .. n_ws - 1, into consecutive slots from first_slot — ONE launch of
-// every EC kernel over all of them. The accumulator chain of a request is one wave and ~3.5 ms whatever the batch (k_ec_chain; round 5: one lane, 13 ms), so the
+// every EC kernel over all of them. The accumulator chain of a request is one wave and ~2.5 ms whatever the batch (k_ec_chain; round 5: one lane, 13 ms), so the
 // instances of MANY blocks in one call cost what one block's cost (zkw_blocks_synthesize); the queue sections are per witness (their queues are).
 // The witnesses may belong to other contexts of the same device: their builders must have finished (zkw_block_run returns after them).
 static int ecrecover_synthesize_many(zkw_ctx* ctx, zkw_precompile_witness* const* ws, const size_t* first, const size_t* count, size_t n_ws, zkw_trace* t, size_t first_slot) {

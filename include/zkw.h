@@ -1115,7 +1115,7 @@ int zkw_block_synthesize_sharded(zkw_block *b, size_t n_rows, size_t ring_slots,
 /* K blocks at once (after zkw_blocks_run): every synthesizable instance of every block, each trace cell for cell what zkw_block_synthesize
    hands out for the same (block, type, instance). How it differs from K calls of zkw_block_synthesize: (1) the ECRecover instances of ALL blocks
    are synthesized in joint calls (zkw_ecrecover_synthesize_multi: at most ec_chunk instances each, 0 = 16, at most 64) on two threads of the
-   library with rings and priority streams of their own — a request's accumulator chain costs ~3.5 ms per call whatever the batch (round 5: 13 ms); (2) the other
+   library with rings and priority streams of their own — a request's accumulator chain costs ~2.5 ms per call whatever the batch (round 5: 13 ms); (2) the other
    types run on a few workers (ZKW_SYNTH_THREADS, default 3), each with ONE ring of 16 x ring_slots slots (a ring belongs to a worker, not to a
    block: 1.28 GB a slot) and a contiguous share of the blocks: 16 fibers of the worker's thread own a slot each and go through their blocks TYPE BY
    TYPE, in step, so that a type's fills leave as one launch per kernel over 16 instances and a slot keeps its layout from call to call
