@@ -366,11 +366,14 @@ EC_HD uint64_t ec_get(const ec_eval_ctx *E, uint32_t ref) {
 /* the 16 limbs a reference names; returns nonzero when one of them does not fit 32 bits (no limb vector of a satisfiable cycle does:
    canonical limbs are 16 bits, lazy sums of a few of them with the limbs of 4 m stay below 2^24) */
 EC_HD uint32_t ec_get_vec(const ec_eval_ctx *E, uint32_t ref0, uint32_t *out) {
-    uint64_t hi = 0;
-    for (uint32_t i = 0; i < 16; i++) {
-        const uint64_t v = ec_get(E, ref0 + i);
-        out[i] = (uint32_t)v;
-        hi |= v >> 32;
+    /* where the sixteen values live first, then the sixteen loads side by side (one after the other they were sixteen round trips) */
+    uint32_t t[16];
+    uint64_t v[16], hi = 0;
+    EC_UNROLL for (int i = 0; i < 16; i++) t[i] = ec_ref_tape(E->S, ref0 + (uint32_t)i, E->base, E->prev_base, E->prev_type, E->inst);
+    EC_UNROLL for (int i = 0; i < 16; i++) v[i] = t[i] != EC_NONE ? ((ec_ctp)E->tape)[(size_t)t[i] * E->ts] : ec_ref_const(E->S, ref0 + (uint32_t)i, E->in);
+    EC_UNROLL for (int i = 0; i < 16; i++) {
+        out[i] = (uint32_t)v[i];
+        hi |= v[i] >> 32;
     }
     return hi != 0;
 }
@@ -422,7 +425,9 @@ EC_HD int ec_mul_witness(const uint32_t *a, const uint32_t *b, const uint32_t *r
         if (Qc[i] != T[i]) return 0;
     for (int k = 0; k < 15; k++) q[(size_t)k * ts] = (Q[k / 2] >> (16 * (k & 1))) & 0xFFFFu;
     q[(size_t)15 * ts] = (Q[7] >> 16) | ((uint64_t)Q[8] << 16);
-    /* carries of the 32-bit positions */
+    /* carries of the 32-bit positions. The 512 products below take the limbs of q off the quotient's words and the limbs of m off the
+       workspace (Qc is free by now) — read back from the tape / through M.m they were 1 024 loads a MUL row, one after the other */
+    for (int j = 0; j < 16; j++) Qc[j] = (M.m[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
     int64_t cin = 0;
     for (int k = 0; k < 16; k++) {
         int64_t d = 0;
@@ -432,8 +437,9 @@ EC_HD int ec_mul_witness(const uint32_t *a, const uint32_t *b, const uint32_t *r
             for (int i = 0; i < 16; i++) {
                 const int j = t - i;
                 if (j < 0 || j > 15) continue;
-                const int64_t mj = (int64_t)((M.m[j / 2] >> (16 * (j & 1))) & 0xFFFFu);
-                s += (int64_t)a[i] * (int64_t)b[j] - ((int64_t)q[(size_t)i * ts] - (i == 0 ? EC_KMUL : 0)) * mj;
+                const int64_t mj = (int64_t)Qc[j];
+                const int64_t qi = i < 15 ? (int64_t)((Q[i / 2] >> (16 * (i & 1))) & 0xFFFFu) : (int64_t)((Q[7] >> 16) | ((uint64_t)Q[8] << 16));
+                s += (int64_t)a[i] * (int64_t)b[j] - (qi - (i == 0 ? EC_KMUL : 0)) * mj;
             }
             if (t < 16) s -= (int64_t)r[t];
             d += half ? s * 65536 : s;

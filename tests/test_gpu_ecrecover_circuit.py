@@ -151,3 +151,20 @@ def test_production_geometry(ctx, oracle):
     assert np.array_equal(t.get(2), exp)
     t.free()
     w.free()
+
+
+def test_capacity_beyond_eight_cycles_per_instance(ctx, oracle):
+    """capacity 9: the tape of an instance interleaves its cycles sixteen to a value (the stride is the capacity rounded up to 8) and the row
+    kernel takes two groups of eight cycles — trace == oracle cell for cell, a full instance and one with idle cycles"""
+    from era_zkevm_test_harness_amd import native
+
+    cap = 9
+    w, o = _build(ctx, oracle, 11, cap, seed=21)
+    assert w.num_instances == 2 == o["instances"].size
+    t = native.Trace(ctx, N_ROWS, 2, n_cols=native.EK_COLS)
+    ctx.synthesize_ecrecover(w, t, 0, 2, 0)
+    for i in range(2):
+        assert np.array_equal(t.get(i), oracle.ecrecover_synthesize(o, i, cap, N_ROWS)), i
+        assert ctx.check_if_satisfied_ecrecover(t, i, cap) == (0, (0, 0, 0))
+    t.free()
+    w.free()
