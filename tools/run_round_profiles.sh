@@ -56,6 +56,8 @@ for P in ds es ld ss; do
 done
 echo "== tools/probe_ecrecover_synth.py (ECRecover, 7 requests per instance, 2^20 rows; 8 and 32 instances per call)" >> "$OUT/synthesis_probes.txt"
 timeout -s KILL 300 python tools/probe_ecrecover_synth.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
+rm -rf /tmp/pk_ec && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk_ec -- python tools/probe_ecrecover_synth.py > /dev/null 2>&1
+f=$(ls /tmp/pk_ec/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" "$OUT/ecrecover_kernel_stats.csv"  # (k_ec_segments / k_ec_leaves / k_ec_stream run on the side stream: only the trace times them)
 echo "== tools/probe_netlist_perf.py (Keccak256RoundFunction 293 / Sha256RoundFunction 2206 cycles, 2^20 rows, 8 instances; L1MessagesHasher)" >> "$OUT/synthesis_probes.txt"
 timeout -s KILL 300 python tools/probe_netlist_perf.py 2>&1 | grep -v amdgpu.ids >> "$OUT/synthesis_probes.txt"
 echo "== tools/probe_setup_commit.py (setup side as field elements: NTT / LDE / Merkle tree of 131 columns x 2^20, zkw_setup_commit of three layouts)" >> "$OUT/synthesis_probes.txt"
