@@ -92,11 +92,13 @@ struct EcTask { u32 run, inst, first, count; };  // items [first, first + count)
 //    of ~2 100 with a value in one lane (the double-and-add loop was 3.1 ms of a 4.75 ms wave);
 //  - a request has a wave of its own: lanes that shared a wave ran the mixed addition at every step (one of seven bits of u2 is set 99 % of
 //    the time) instead of on half of them;
-//  - the wave owns its SIMD: two chain waves on one SIMD take twice as long, and neither one-wave workgroups (they land two or three to a
-//    SIMD wherever the dispatcher likes: 4.7 .. 9 ms per wave, the launch takes the slowest) nor four-wave workgroups with a CU to
-//    themselves (an LDS request of more than half a CU: NOT spread over the CU's four SIMDs reliably — 4.8 / 9.5 / 14 ms) give that. What
-//    does: a wave that holds the SIMD's whole register file — the two moves below make the kernel's footprint 256 + 256 registers —
-//    shares the SIMD with nobody, whoever else is running.
+//  - the wave owns its SIMD: two chain waves on one SIMD take twice as long (eight-wave workgroups, a value in one lane: waves 0-3 end at
+//    4.75 ms, waves 4-6, which share their SIMDs, at ~7). Per-wave end times of the other shapes (profiles/r06/ecrecover_steps.txt):
+//    one-wave workgroups 4.7 .. 9 ms (the launch takes the slowest), four-wave workgroups with a CU to themselves (an LDS request of more
+//    than half a CU) whole workgroups at 4.8 / 9.5 / 14 ms — as if their waves sat on four, two, one SIMD; an idle chip spreads one-wave
+//    workgroups one to a SIMD (tools/probe_wave_placement), behind other kernels of the stream it evidently does not. What gives every
+//    wave its SIMD: holding the SIMD's whole register file — the two moves below make the kernel's footprint 256 + 256 registers — so
+//    that nobody else's wave fits beside it, whoever else is running (4.5 .. 6.6 ms with a value in one lane).
 // The MAIN items of PRE (an item interpreter, one value per lane) run on lane 0 first.
 static __device__ __forceinline__ void k_ec_chain(const VB& vb, const ec_spec* __restrict__ Sp, const EcJob* __restrict__ jobs, u32 capacity, u32* status, EcChainScratch sc) {
     asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");  // (the whole register file of the SIMD: see above)
