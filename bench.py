@@ -359,7 +359,7 @@ def hash_circuits_gpu(local_rank, blk):
     mem_in = np.zeros(1, native.QUEUE_STATE12)
     for name, kind, n_req, cap, cols, synth, ctype in (("keccak256_round_function", 0, 1400, 293, native.KC_COLS, ctx.synthesize_keccak_round_function, 5),
                                                        ("sha256_round_function", 1, 6000, 2206, native.SC_COLS, ctx.synthesize_sha256_round_function, 6),
-                                                       ("ecrecover", 2, 7 * 32, 7, native.EK_COLS, ctx.synthesize_ecrecover, 7)):
+                                                       ("ecrecover", 2, 7 * 64, 7, native.EK_COLS, ctx.synthesize_ecrecover, 7)):
         req, mq = synthetic.precompile_trace(kind, n_req, seed=5, max_rounds=6)
         tails = ctx.queue_push_chain_log(ctx.encode_log_queries(req))[1]
         w = ctx._precompile(kind, req, tails, mq, cap, mem_in)
@@ -371,6 +371,10 @@ def hash_circuits_gpu(local_rank, blk):
             n32 = min(32, w.num_instances)
             t = native.Trace(ctx, n_rows, n32, n_cols=cols)
             out[name]["at_32_instances_per_call"] = timed(n32, lambda: synth(w, t, 0, n32, 0))
+            n64 = min(64, w.num_instances)
+            t64 = native.Trace(ctx, n_rows, n64, n_cols=cols)
+            out[name]["at_64_instances_per_call"] = timed(n64, lambda: synth(w, t64, 0, n64, 0))
+            t64.free()
             out[name]["note"] = ("7 requests per instance (geometry_config.rs): the accumulator chain of a request is serial — k_ec_chain, a wave per request that owns its "
                                  "SIMD, 256-bit arithmetic with a limb per lane: ~2.5 ms per call whatever the batch (round 5: one lane per request, 13 ms) —, the segments "
                                  "are item lists (MAIN / MULS / LEAVES) side by side, the EC rows stream beside the netlist's fill: docs/KERNELS.md 3.19, profiles/r06/README.md")

@@ -134,7 +134,7 @@ if fb:
     if bench.get("hash_circuits"):
         w("* netlist circuits at the reference geometry (2^20 rows; circuits/s into slots that already hold the layout; cold rates in the JSON): " + ", ".join(
             f"{k} {v['circuits_per_s']:.0f} (capacity {v['capacity']})" for k, v in bench["hash_circuits"].items()) + "."
-          + ("".join(f" ECRecover at 32 instances per call: {e['at_32_instances_per_call']['circuits_per_s']:.0f}"
+          + ("".join(f" ECRecover at 32 instances per call: {e['at_32_instances_per_call']['circuits_per_s']:.0f}" + (f", at 64: {e['at_64_instances_per_call']['circuits_per_s']:.0f}" if e.get("at_64_instances_per_call") else "")
                      + (", with " + ", ".join(f"{n_} calls in flight {x['circuits_per_s']:.0f}" for n_, x in e["calls_in_flight"].items() if isinstance(x, dict)) if e.get("calls_in_flight") else "") + "."
                      for e in [bench["hash_circuits"].get("ecrecover", {})] if e.get("at_32_instances_per_call"))))
     w("* spans of the builders (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in sorted(fb["spans_ms"].items(), key=lambda kv: -kv[1])[:8]) + ".")
