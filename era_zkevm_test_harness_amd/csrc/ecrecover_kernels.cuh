@@ -4,14 +4,20 @@
 // era-zkevm_circuits, so the placement is this library's own: format and statement in tools/gen_ecrecover_circuit.py, item semantics in
 // include/zkw_ecrecover.h (shared with the test oracle the way nl_table_eval is).
 //
-// Fill, three kernels on the context's stream:
-//   k_ec_inputs   the value bytes of the cycle's four reads;
-//   k_ec_tape     one LANE per cycle (= request) evaluates the cycle's value tape: the items in program order — the double-and-add
-//                 chain is serial in its 288 segments, and its quotients lambda = dy / dx are modular inversions;
-//   k_ec_prepare  the tape's outputs -> the inputs of the byte netlist (the 64 key bytes, the mask, ok as FREE elements; the state the
-//                 netlist will have after the cycle = the masked address: one Keccak-f per cycle here, for the boundary rows);
-//   k_ec_stream   one lane per ROW: every cell of the row is a reference into the tape (or a constant): 128 coalesced stores per wave and
-//                 column; rows that hold lookups add their 16 slots to the multiplicity column.
+// Fill (zkw_precompiles.hip ecrecover_synthesize_many; docs/KERNELS.md 3.19 "Round 6"):
+//   k_ec_inputs    the value bytes of the cycle's four reads;
+//   k_ec_chain     a WAVE per cycle (= request), a limb of a 256-bit value per lane: the MAIN items of the PRE segment, then the accumulator's
+//                  trajectory — 256 double-and-add steps, 32 table additions — in Jacobian coordinates;
+//   k_ec_affine    a lane per (cycle, point): the trajectory's points to affine onto the tape, where the segments' `out` states live;
+//   k_ec_segments  item lists side by side, a lane per cycle: the MAIN items of the 289 segments after PRE, then the MUL rows of every segment;
+//   k_ec_prepare   the tape's outputs -> the inputs of the byte netlist (the 64 key bytes, the mask, ok as FREE elements; the state the
+//                  netlist will have after the cycle = the masked address: one Keccak-f per cycle here, for the boundary rows);
+//   k_ec_leaves    the remaining items (range checks, byte decompositions, assertions) as lists of ~190, no 256-bit workspace;
+//   k_ec_stream    a lane per (row, cycle): every cell of a row is a resolved reference into the tape (or a constant); the Xor8 lookups
+//                  leave 16-bit keys behind;
+//   k_ec_hist      an instance's Xor8 keys counted in LDS and the FixedBaseMul lookups onto the multiplicity column.
+//   (k_ec_tape: the serial form — one lane walks a whole cycle in program order — behind ZKW_EC_SERIAL=1, same tape.)
+//   From k_ec_segments' second launch to k_ec_stream the kernels run on the context's side stream, beside the netlist's fill.
 // Check: k_ec_check_items (one lane per item instance: the relation from the cells alone), k_ec_check_rows (one lane per row: copies
 // against the home cells / constants / the read queries' value bytes, empty cells, the lookups' multiplicities), k_ec_check_links (the
 // netlist's FREE elements against the key bytes / mask / ok).
